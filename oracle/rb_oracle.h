@@ -1,0 +1,112 @@
+/*
+ * rb_oracle.h -- TEST INFRASTRUCTURE ONLY.  NOT PART OF THE PRODUCT.
+ *
+ * CPU restatement (plain C) of the alshai/rowbowt rb_align hot path, used only
+ * as the parity checker by tests/, __graft_entry__.smoke() and the
+ * `cpu_baseline` leg of bench.py.  Nothing under rowbowt_amd/ links, imports
+ * or calls this library.
+ *
+ * Parity status: PINNED.  The restatement reads the reference's own shipped
+ * sdsl-serialised fixtures (tests/data/small.fa.{rbwt,tsa,mab},
+ * tests/data/greedy_seeding/ref.fa.{rbwt,tsa}) and reproduces every golden
+ * value in the reference's tests/rb_tests.cpp (:47-58, :83-95, :115-120,
+ * :131-140, :147-173) -- see tests/test_oracle_golden.py.
+ * The real reference cannot be compiled here (sdsl-lite, pfbwt-f,
+ * faster-minuter submodules are empty directories), so there is no oracle/_ref.
+ *
+ * Every function cites the reference file:line it follows
+ * (paths relative to the reference tree).
+ */
+#ifndef RB_ORACLE_H
+#define RB_ORACLE_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_index orc_index;
+
+/* rowbowt_io.hpp:146-152 LoadRbwtFlag */
+enum { ORC_NONE = 0, ORC_SA = 1, ORC_MA = 2, ORC_DL = 4, ORC_FT = 8 };
+
+/* rowbowt_io.hpp:176-189 load_rowbowt: reads <prefix>.rbwt (+.tsa/.mab/.docs by flag).
+ * Returns NULL on failure (message on stderr). */
+orc_index *orc_load(const char *prefix, int flags);
+
+/* rle_string.hpp:44-97 + toehold_sa.hpp:27-35,105-155 restated at run granularity:
+ * build from a run-length BWT (heads[R], lens[R]) and, optionally, the raw
+ * .ssa/.esa "y" values (SA at run start / run end, one per BWT run; NULL = no toehold SA).
+ * B is the rle_string block factor (reference default 2). */
+orc_index *orc_build_from_runs(const uint8_t *heads, const uint64_t *lens, uint64_t R, uint64_t B,
+                               const uint64_t *ssa_y, const uint64_t *esa_y);
+
+/* attach a marker array given as inclusive SA-index runs + per-run marker lists
+ * (mk_off[nruns+1] offsets into mk_vals). */
+int orc_set_markers(orc_index *, const uint64_t *run_start, const uint64_t *run_end, uint64_t nruns,
+                    const uint64_t *mk_off, const uint64_t *mk_vals);
+/* attach a doc list (doclist.hpp:57-73): names are '\0'-joined, starts[ndocs]. */
+int orc_set_docs(orc_index *, const char *names_joined, const uint64_t *starts, uint64_t ndocs);
+
+void orc_free(orc_index *);
+
+uint64_t orc_n(const orc_index *);      /* rle_string::size() */
+uint64_t orc_r(const orc_index *);      /* rle_string::number_of_runs() */
+int orc_has_tsa(const orc_index *);
+int orc_has_markers(const orc_index *);
+void orc_get_f(const orc_index *, uint64_t f_out[256]); /* rowbowt.hpp:770-778 build_f */
+
+/* decoded views, for cross-checking the product's loader (host logic tests) */
+void orc_get_runs(const orc_index *, uint8_t *heads_out, uint64_t *lens_out);          /* R each */
+void orc_get_tsa(const orc_index *, uint64_t *pred_pos, uint64_t *samples_last, uint64_t *pred_to_run); /* r each */
+uint64_t orc_marker_nruns(const orc_index *);
+uint64_t orc_marker_nvals(const orc_index *);
+void orc_get_markers(const orc_index *, uint64_t *run_start, uint64_t *run_end, uint64_t *mk_off, uint64_t *mk_vals);
+
+/* primitives (for unit tests) */
+uint64_t orc_rank(const orc_index *, uint64_t i, uint8_t c);        /* rle_string.hpp:131-161 */
+uint64_t orc_select(const orc_index *, uint64_t i, uint8_t c);      /* rle_string.hpp:107-126 */
+uint8_t  orc_access(const orc_index *, uint64_t i);                 /* rle_string.hpp:99-102 */
+uint64_t orc_run_of_position(const orc_index *, uint64_t i);        /* rle_string.hpp:166-186 */
+uint64_t orc_phi(const orc_index *, uint64_t i);                    /* toehold_sa.hpp:56-72 */
+uint64_t orc_last_run_sample(const orc_index *);                    /* toehold_sa.hpp:97-99 */
+
+/* rowbowt.hpp:74-88 */
+void orc_LF(const orc_index *, uint64_t lo, uint64_t hi, uint8_t c, uint64_t *lo_out, uint64_t *hi_out);
+/* rowbowt.hpp:121-131 (no ftab: rb_align never loads one) */
+void orc_find_range(const orc_index *, const uint8_t *q, uint64_t m, uint64_t *lo, uint64_t *hi);
+/* rowbowt.hpp:169-184; without a toehold SA returns the default LFData ({1,0}, ssamp unspecified -> 0) */
+void orc_find_range_w_toehold(const orc_index *, const uint8_t *q, uint64_t m, uint64_t *lo, uint64_t *hi, uint64_t *ssamp);
+/* rowbowt.hpp:613-615 -> toehold_sa.hpp:37-49: writes min(occ,max_hits) values to out (caller sized); returns count */
+uint64_t orc_locs_at(const orc_index *, uint64_t lo, uint64_t hi, uint64_t k, uint64_t max_hits, uint64_t *out);
+/* rowbowt.hpp:282-285 -> MarkerArray::at_range; returns count; out may be NULL to count only */
+uint64_t orc_markers_at(const orc_index *, uint64_t lo, uint64_t hi, uint64_t *out);
+/* rowbowt.hpp:292-339; returns number of markers written to out (cap entries; out may be NULL = count).
+ * Returns lo/hi of the final range ({1,0} when cleared). */
+uint64_t orc_find_range_w_markers(const orc_index *, const uint8_t *q, uint64_t m, uint64_t wsize, uint64_t max_range,
+                                  uint64_t *lo, uint64_t *hi, uint64_t *out, uint64_t cap);
+/* rowbowt.hpp:222-256 get_seeds_greedy_w_sample + :664-685 locate_from_longest_seed.
+ * Writes locs to out (cap entries); returns count.  seed_* (may be NULL) get the chosen seed. */
+uint64_t orc_greedy_locate(const orc_index *, const uint8_t *q, uint64_t m, uint64_t min_length, uint64_t max_hits,
+                           uint64_t *out, uint64_t cap,
+                           uint64_t *seed_lo, uint64_t *seed_hi, uint64_t *seed_qs, uint64_t *seed_qe, uint64_t *seed_k);
+/* rowbowt.hpp:623-625 -> doclist.hpp:46-50.  Returns pointer to the doc name (owned by index), offset in *off. */
+const char *orc_resolve_offset(const orc_index *, uint64_t i, uint64_t *off);
+
+/* batched drivers (what rb_align's loop does per read, rb_align.cpp:95-145,176-178), used for
+ * parity at scale and as bench.py's cpu_baseline.  seqs = concatenated read bytes, off[N+1].
+ * nthreads<=1 : serial like rb_align.  */
+void orc_find_range_batch(const orc_index *, const uint8_t *seqs, const uint64_t *off, uint64_t N,
+                          uint64_t *lo, uint64_t *hi, int nthreads);
+void orc_find_range_w_toehold_batch(const orc_index *, const uint8_t *seqs, const uint64_t *off, uint64_t N,
+                                    uint64_t *lo, uint64_t *hi, uint64_t *ssamp, int nthreads);
+/* two-pass variable-length locate: loc_off[N+1] must already hold the exclusive scan of min(occ,max_hits) */
+void orc_locs_at_batch(const orc_index *, const uint64_t *lo, const uint64_t *hi, const uint64_t *k, uint64_t N,
+                       uint64_t max_hits, const uint64_t *loc_off, uint64_t *locs, int nthreads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,139 @@
+"""Oracle (reference-shaped C restatement) vs the naive explicit-text FM index, on the toy
+fixture (config 1 of BASELINE.json: 10k synthetic 100 bp reads) and on random small texts."""
+import os
+
+import numpy as np
+import pytest
+
+import naive
+import orc
+
+
+def sample_reads(text, n_reads, m, rng, sub_rate=0.1, spans=None):
+    """reads sampled from the text, 10% with one substitution."""
+    L = len(text)
+    reads = []
+    for _ in range(n_reads):
+        if spans:
+            a, b = spans[rng.integers(len(spans))]
+            s = int(rng.integers(a, b - m + 1))
+        else:
+            s = int(rng.integers(0, L - m))
+        r = bytearray(text[s:s + m].tobytes())
+        if rng.random() < sub_rate:
+            p = int(rng.integers(m))
+            r[p] = rng.choice([c for c in b"ACGT" if c != r[p]])
+        reads.append(bytes(r))
+    return reads
+
+
+@pytest.fixture(scope="module")
+def small_pair(data_dir):
+    o = orc.Oracle.load(os.path.join(data_dir, "small.fa"), orc.SA | orc.MA)
+    heads, lens = o.runs()
+    text = naive.invert_bwt(naive.expand_bwt(heads, lens))
+    fm = naive.NaiveFM(text)
+    yield o, fm, text
+    o.close()
+
+
+def test_small_text_layout(small_pair, data_dir):
+    # T = ref + A*10 + hap1 + A*10 + hap2 + A*10 + 0x01
+    _o, _fm, text = small_pair
+    fa = b"".join(open(os.path.join(data_dir, "small.fa"), "rb").read().split(b"\n")[1:])
+    assert len(fa) == 10000
+    t = text.tobytes()
+    assert len(t) == 30031 and t[-1] == 1
+    assert t[:10000] == fa and t[10000:10010] == b"A" * 10
+    hap1 = bytearray(t[10010:20010])
+    diffs = [i for i in range(10000) if hap1[i] != fa[i]]
+    assert diffs == [289, 1859, 2239, 3193, 3734, 4121, 4650, 5500, 9035]
+
+
+def test_bwt_matches_naive_sa(small_pair):
+    o, fm, text = small_pair
+    heads, lens = o.runs()
+    assert (naive.bwt_from_sa(text, fm.sa) == naive.expand_bwt(heads, lens)).all()
+
+
+def test_config1_10k_reads(small_pair):
+    o, fm, text = small_pair
+    rng = np.random.default_rng(20240231)
+    spans = [(0, 10000), (10010, 20010), (20020, 30020)]
+    reads = sample_reads(text, 10000, 100, rng, spans=spans)
+    seqs, off = orc.pack_reads(reads)
+    lo, hi = o.find_range_batch(seqs, off, nthreads=4)
+    lo2, hi2, k = o.find_range_w_toehold_batch(seqs, off, nthreads=4)
+    assert (lo == lo2).all() and (hi == hi2).all()
+    n_empty = 0
+    for i, q in enumerate(reads):
+        want = fm.find_range(q)
+        assert (int(lo[i]), int(hi[i])) == want
+        if want == (1, 0):
+            n_empty += 1
+            assert int(k[i]) == 0
+        else:
+            assert int(k[i]) == int(fm.sa[want[1]])  # toehold = SA[hi]
+    assert 500 < n_empty < 1500
+    loc_off, locs = o.locs_at_batch(lo, hi, k, nthreads=4)
+    for i in range(0, len(reads), 97):
+        assert locs[int(loc_off[i]):int(loc_off[i + 1])].tolist() == fm.locs(int(lo[i]), int(hi[i]))
+
+
+def test_primitives_vs_naive(small_pair):
+    o, fm, text = small_pair
+    heads, lens = o.runs()
+    bwt = naive.expand_bwt(heads, lens)
+    rng = np.random.default_rng(7)
+    for c in (1, 65, 67, 71, 84):
+        occ = np.concatenate(([0], np.cumsum(bwt == c)))
+        pos_c = np.flatnonzero(bwt == c)
+        for i in rng.integers(0, len(bwt) + 1, 200):
+            assert o.rank(int(i), c) == int(occ[i])
+        for j in rng.integers(0, len(pos_c), 100):
+            assert o.select(int(j), c) == int(pos_c[j])
+    run_id = np.repeat(np.arange(len(heads)), lens.astype(np.int64))
+    for i in rng.integers(0, len(bwt), 300):
+        assert o.access(int(i)) == int(bwt[i])
+        assert o.run_of_position(int(i)) == int(run_id[i])
+    # phi(SA[i]) == SA[i-1]
+    for i in rng.integers(1, len(bwt), 300):
+        assert o.phi(int(fm.sa[i])) == int(fm.sa[i - 1])
+    assert o.rank(5, 0x4E) == 0  # absent symbol
+
+
+@pytest.mark.parametrize("seed,n,sigma", [(1, 500, 2), (2, 2000, 4), (3, 3000, 3), (4, 1200, 4)])
+def test_random_texts_build_from_runs(seed, n, sigma):
+    """orc_build_from_runs (rle_string ctor + ToeholdSA build restated) on random repetitive texts."""
+    rng = np.random.default_rng(seed)
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)[:sigma]
+    base = alpha[rng.integers(0, sigma, n // 4)]
+    parts = []
+    for _ in range(4):
+        h = base.copy()
+        for p in rng.integers(0, len(h), 5):
+            h[p] = alpha[rng.integers(0, sigma)]
+        parts.append(h)
+    text = np.concatenate(parts + [np.array([1], dtype=np.uint8)])
+    fm = naive.NaiveFM(text)
+    bwt = naive.bwt_from_sa(text, fm.sa)
+    heads, lens, brk = naive.rle(bwt)
+    ssa, esa = naive.run_samples(fm.sa, brk, len(text))
+    for B in (1, 2, 3):
+        o = orc.Oracle.from_runs(heads, lens, ssa, esa, B=B)
+        assert o.n == len(text) and o.r == len(heads)
+        for _ in range(150):
+            m = int(rng.integers(1, 40))
+            s = int(rng.integers(0, len(text) - 1 - m))
+            q = bytearray(text[s:s + m].tobytes())
+            if rng.random() < 0.3:
+                q[int(rng.integers(m))] = int(alpha[rng.integers(0, sigma)])
+            q = bytes(q)
+            want = fm.find_range(q)
+            assert o.find_range(q) == want
+            lo, hi, k = o.find_range_w_toehold(q)
+            assert (lo, hi) == want
+            if want != (1, 0):
+                assert o.locs_at(lo, hi, k) == fm.locs(lo, hi)
+                assert o.locs_at(lo, hi, k, 3) == fm.locs(lo, hi)[:3]
+        o.close()
