@@ -1,0 +1,187 @@
+/*
+ * rbg.h -- C-ABI of the MI355X-native backward-search engine for rowbowt's rb_align hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.  Everything the
+ * reference computes on this path through rbwt::RowBowt<ri::rle_string_sd> is reachable here,
+ * batched over N reads.  Each entry point cites the reference interface it replaces
+ * (paths relative to the reference tree).  The C++17 header shim that keeps the reference's own
+ * signatures on top of this ABI is rowbowt_amd/include/rowbowt_gpu.hpp; the binding a reference
+ * maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - Ranges are inclusive [lo,hi]; the empty range is exactly {1,0} (rowbowt.hpp:77,85).
+ *  - All positions are uint64_t.  Reads are raw bytes, matched as-is (no upper-casing, no N
+ *    handling: rb_align.cpp:121 passes seq->seq.s straight to find_range).
+ *  - A batch of reads is `seqs` (concatenated bytes) + `off[N+1]` (byte offsets, off[0]=0).
+ *  - Return value: RBG_OK (0) or a negative RBG_E* code; rbg_strerror() names it.  The reference
+ *    itself prints to stderr and exit(1)s (rowbowt_io.hpp:166-169); the shim maps codes to that.
+ *  - There is NO CPU compute path.  Every query entry point runs HIP kernels on a gfx950 device
+ *    and fails with RBG_ENODEV when none is usable.
+ *  - *_dev entry points take DEVICE pointers and a hipStream_t (as void*), launch asynchronously
+ *    and neither allocate nor synchronise (graph-capturable).  The plain entry points take HOST
+ *    pointers, stage through HBM and block until the results are in the caller's buffers.
+ *  - Thread safety: an rbg_index is immutable after load; concurrent query calls on one index
+ *    are allowed (the reference calls const methods concurrently, rb_markers.cpp:321-326).
+ */
+#ifndef RBG_H
+#define RBG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RBG_ABI_VERSION 1
+
+typedef struct rbg_index rbg_index;
+
+/* rbwt::LoadRbwtFlag, rowbowt_io.hpp:146-152 (same values) */
+enum { RBG_LOAD_NONE = 0, RBG_LOAD_SA = 1, RBG_LOAD_MA = 2, RBG_LOAD_DL = 4, RBG_LOAD_FT = 8 };
+
+enum {
+    RBG_OK = 0,
+    RBG_EIO = -1,      /* file missing / unreadable (reference: "bad file", exit(1)) */
+    RBG_EFORMAT = -2,  /* not the sdsl layout the reference's files use */
+    RBG_ENODEV = -3,   /* no usable gfx950 device / HIP error */
+    RBG_EARG = -4,     /* bad argument */
+    RBG_ENOMEM = -5,
+    RBG_ENOTLOADED = -6 /* structure (toehold SA / markers / docs) was not loaded */
+};
+
+/* device = HIP device ordinal to hold the index replica, or RBG_DEVICE_NONE to parse and flatten
+ * on the host only (no queries possible; used to inspect the layout without a GPU). */
+#define RBG_DEVICE_NONE (-1)
+
+int rbg_abi_version(void);
+const char *rbg_strerror(int code);
+
+/* ---- loading ------------------------------------------------------------------------------ */
+
+/* rbwt::load_rowbowt<ri::rle_string_sd>(prefix, flag), rowbowt_io.hpp:176-189:
+ * reads <prefix>.rbwt always, .tsa if SA, .mab if MA, .docs if DL (suffixes :17-21) in the
+ * sdsl-serialised layout the reference writes (rle_string.hpp:248-275, toehold_sa.hpp:74-91),
+ * flattens to the HBM layout and uploads one replica to `device`.
+ * RBG_LOAD_FT is accepted and ignored (rb_align never sets it, rb_align.cpp:149-157). */
+int rbg_load(const char *prefix, int flags, int device, rbg_index **out);
+
+/* Construction from raw inputs, replacing rle_string(std::string fname, B) rle_string.hpp:44-97
+ * and ToeholdSA(n, r, ssa, esa) toehold_sa.hpp:27-35 at run granularity:
+ * heads[R]/lens[R] = run-length BWT (byte 0 must already be stored as 1, rle_string.hpp:59,62);
+ * ssa_y/esa_y = the second u64 of each (x,y) pair of <pre>.ssa / <pre>.esa, one per BWT run
+ * (toehold_sa.hpp:133-155), or both NULL for no toehold SA. */
+int rbg_build_from_runs(const uint8_t *heads, const uint64_t *lens, uint64_t R,
+                        const uint64_t *ssa_y, const uint64_t *esa_y, int device, rbg_index **out);
+
+/* MarkerArray contents (pfbwt-f marker_array.hpp, loaded at rowbowt_io.hpp:185):
+ * inclusive SA-index runs + mk_off[nruns+1] offsets into mk_vals. */
+int rbg_set_markers(rbg_index *, const uint64_t *run_start, const uint64_t *run_end, uint64_t nruns,
+                    const uint64_t *mk_off, const uint64_t *mk_vals);
+/* DocList contents, doclist.hpp:57-73: names '\0'-joined, starts[ndocs]. */
+int rbg_set_docs(rbg_index *, const char *names_joined, const uint64_t *starts, uint64_t ndocs);
+
+void rbg_free(rbg_index *);
+
+/* ---- introspection ------------------------------------------------------------------------ */
+
+typedef struct rbg_info_t {
+    uint64_t n;             /* rle_string::size() */
+    uint64_t r;             /* rle_string::number_of_runs() */
+    uint32_t sigma;         /* distinct BWT symbols */
+    uint32_t pos_bytes;     /* 4 or 8: width of positions in the HBM layout */
+    int32_t device;         /* HIP ordinal or RBG_DEVICE_NONE */
+    uint32_t has_tsa, has_markers, has_docs;
+    uint64_t hbm_bytes;     /* bytes of the device replica */
+    uint64_t marker_runs, marker_vals;
+    uint32_t rank_bucket_shift, phi_bucket_shift;
+    uint32_t reserved;
+} rbg_info_t;
+int rbg_info(const rbg_index *, rbg_info_t *out);
+
+/* RowBowt::get_f(), rowbowt.hpp:719 / build_f :770-778: 256 entries. */
+int rbg_get_f(const rbg_index *, uint64_t f_out[256]);
+/* ToeholdSA::get_last_run_sample(), toehold_sa.hpp:97-99 */
+int rbg_last_run_sample(const rbg_index *, uint64_t *out);
+
+/* Host copies of the flattened layout, for layout tests (no compute).  Each call returns the
+ * element count in *count and, if dst != NULL, copies min(*count, cap) uint64 values.
+ * which: */
+enum {
+    RBG_ARR_RUN_HEADS = 0,   /* R values (head byte of each BWT run) */
+    RBG_ARR_RUN_START = 1,   /* R+1 values (BWT position where each run starts; last = n) */
+    RBG_ARR_SAMPLES_LAST = 2,/* r values: ToeholdSA::samples_last_ (toehold_sa.hpp:158) */
+    RBG_ARR_PRED_POS = 3,    /* r values: set bits of ToeholdSA::pred_ (:157) */
+    RBG_ARR_PHI_BASE = 4,    /* r values: samples_last_[pred_to_run_[j]-1] (:70), 0 where run 0 */
+    RBG_ARR_MARKER_START = 5, RBG_ARR_MARKER_END = 6, RBG_ARR_MARKER_OFF = 7, RBG_ARR_MARKER_VALS = 8
+};
+int rbg_host_array(const rbg_index *, int which, uint64_t *dst, uint64_t cap, uint64_t *count);
+
+/* ---- queries, host buffers (drop-in) ------------------------------------------------------ */
+
+/* RowBowt::find_range(const std::string&), rowbowt.hpp:121-131, for N reads. */
+int rbg_find_range(rbg_index *, const uint8_t *seqs, const uint64_t *off, uint64_t N,
+                   uint64_t *lo, uint64_t *hi);
+/* RowBowt::count, rowbowt.hpp:266-269. */
+int rbg_count(rbg_index *, const uint8_t *seqs, const uint64_t *off, uint64_t N, uint64_t *count);
+/* RowBowt::find_range_w_toehold, rowbowt.hpp:169-184 (LFData.rn / .ssamp); a failed read gets
+ * {1,0}, ssamp=0 (LFData::clear :153-159).  RBG_ENOTLOADED without a toehold SA. */
+int rbg_find_range_w_toehold(rbg_index *, const uint8_t *seqs, const uint64_t *off, uint64_t N,
+                             uint64_t *lo, uint64_t *hi, uint64_t *ssamp);
+/* RowBowt::locs_at(range, k, max_hits, locs), rowbowt.hpp:613-615 -> ToeholdSA::locate_range
+ * toehold_sa.hpp:37-49, for N (range, toehold) triples.  loc_off[N+1] is written (exclusive scan
+ * of min(occ,max_hits)); *locs is malloc()ed by the library with loc_off[N] entries and must be
+ * released with rbg_free_buffer.  Per read the order is SA[hi], SA[hi-1], ... (phi chain). */
+int rbg_locs_at(rbg_index *, const uint64_t *lo, const uint64_t *hi, const uint64_t *k, uint64_t N,
+                uint64_t max_hits, uint64_t *loc_off, uint64_t **locs);
+/* RowBowt::markers_at(range_t, vec), rowbowt.hpp:282-285 -> MarkerArray::at_range. */
+int rbg_markers_at(rbg_index *, const uint64_t *lo, const uint64_t *hi, uint64_t N,
+                   uint64_t *mk_off, uint64_t **mk);
+/* RowBowt::find_range_w_markers(query, wsize, max_range), rowbowt.hpp:292-339: final range plus
+ * the windowed marker list (window results PREPENDED, :320,:333). */
+int rbg_find_range_w_markers(rbg_index *, const uint8_t *seqs, const uint64_t *off, uint64_t N,
+                             uint64_t wsize, uint64_t max_range,
+                             uint64_t *lo, uint64_t *hi, uint64_t *mk_off, uint64_t **mk);
+void rbg_free_buffer(void *);
+
+/* RowBowt::resolve_offset, rowbowt.hpp:623-625 -> DocList::doc_and_offset_at doclist.hpp:46-50.
+ * *name points into the index (valid until rbg_free). */
+int rbg_resolve_offset(const rbg_index *, uint64_t i, const char **name, uint64_t *offset);
+
+/* ---- queries, device-resident buffers (HBM in, HBM out; asynchronous on `stream`) ---------- */
+
+int rbg_find_range_dev(rbg_index *, const uint8_t *d_seqs, const uint64_t *d_off, uint64_t N,
+                       uint64_t *d_lo, uint64_t *d_hi, void *stream);
+int rbg_find_range_w_toehold_dev(rbg_index *, const uint8_t *d_seqs, const uint64_t *d_off, uint64_t N,
+                                 uint64_t *d_lo, uint64_t *d_hi, uint64_t *d_ssamp, void *stream);
+/* locate, two-phase because the output is ragged:
+ *  1. rbg_locate_plan_dev writes d_loc_off[N+1]; d_tmp/tmp_bytes is scratch (query the size with
+ *     rbg_locate_plan_tmp_bytes).  Read d_loc_off[N] to size d_locs.
+ *  2. rbg_locate_fill_dev walks the phi chains into d_locs. */
+size_t rbg_locate_plan_tmp_bytes(uint64_t N);
+int rbg_locate_plan_dev(rbg_index *, const uint64_t *d_lo, const uint64_t *d_hi, uint64_t N, uint64_t max_hits,
+                        uint64_t *d_loc_off, void *d_tmp, size_t tmp_bytes, void *stream);
+int rbg_locate_fill_dev(rbg_index *, const uint64_t *d_lo, const uint64_t *d_hi, const uint64_t *d_k, uint64_t N,
+                        uint64_t max_hits, const uint64_t *d_loc_off, uint64_t *d_locs, void *stream);
+/* markers, same two-phase shape */
+int rbg_markers_plan_dev(rbg_index *, const uint64_t *d_lo, const uint64_t *d_hi, uint64_t N,
+                         uint64_t *d_mk_off, void *d_tmp, size_t tmp_bytes, void *stream);
+int rbg_markers_fill_dev(rbg_index *, const uint64_t *d_lo, const uint64_t *d_hi, uint64_t N,
+                         const uint64_t *d_mk_off, uint64_t *d_mk, void *stream);
+
+/* ---- global counters (the values the 8-GPU run reduces over RCCL) -------------------------- */
+/* {reads processed, reads matched (non-empty range), sum of occ, sum of located positions}
+ * accumulated on the device by every query since load / the last reset. */
+int rbg_counters(rbg_index *, uint64_t out[4]);
+int rbg_counters_reset(rbg_index *);
+
+/* ---- tuning (never changes results) -------------------------------------------------------- */
+/* Process-wide defaults read when an index is built/loaded: BLOCK_THREADS (multiple of 64),
+ * RANK/PHI_BUCKET_SHIFT (-1 = automatic), POS_BYTES (0 = automatic, 4 or 8 to force a width). */
+enum { RBG_OPT_BLOCK_THREADS = 1, RBG_OPT_RANK_BUCKET_SHIFT = 2, RBG_OPT_PHI_BUCKET_SHIFT = 3, RBG_OPT_POS_BYTES = 4 };
+int rbg_set_default_option(int opt, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RBG_H */

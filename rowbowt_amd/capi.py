@@ -1,0 +1,260 @@
+"""ctypes binding of rowbowt_amd/librbg.so (the C-ABI of include/rbg.h).
+
+Names mirror the reference's operator API for this path: rbwt::load_rowbowt (rowbowt_io.hpp:176),
+rbwt::LoadRbwtFlag (:146-152) and rbwt::RowBowt<> methods find_range / find_range_w_toehold /
+locs_at / count / markers_at / find_range_w_markers / resolve_offset (rowbowt.hpp), batched.
+The library must be present: a missing or unloadable librbg.so is an error, never a fallback.
+"""
+import ctypes as C
+import enum
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "librbg.so")
+
+U64 = C.c_uint64
+VP = C.c_void_p
+MAXU = 2**64 - 1
+DEVICE_NONE = -1
+
+OPT_BLOCK_THREADS, OPT_RANK_BUCKET_SHIFT, OPT_PHI_BUCKET_SHIFT, OPT_POS_BYTES = 1, 2, 3, 4
+(ARR_RUN_HEADS, ARR_RUN_START, ARR_SAMPLES_LAST, ARR_PRED_POS, ARR_PHI_BASE,
+ ARR_MARKER_START, ARR_MARKER_END, ARR_MARKER_OFF, ARR_MARKER_VALS) = range(9)
+
+
+class LoadRbwtFlag(enum.IntFlag):
+    """rbwt::LoadRbwtFlag, rowbowt_io.hpp:146-152"""
+    NONE = 0
+    SA = 1
+    MA = 2
+    DL = 4
+    FT = 8
+
+
+class RbgError(RuntimeError):
+    def __init__(self, code, what):
+        self.code = code
+        super().__init__(f"{what}: {lib().rbg_strerror(code).decode()} ({code})")
+
+
+class Info(C.Structure):
+    _fields_ = [("n", U64), ("r", U64), ("sigma", C.c_uint32), ("pos_bytes", C.c_uint32), ("device", C.c_int32),
+                ("has_tsa", C.c_uint32), ("has_markers", C.c_uint32), ("has_docs", C.c_uint32),
+                ("hbm_bytes", U64), ("marker_runs", U64), ("marker_vals", U64),
+                ("rank_bucket_shift", C.c_uint32), ("phi_bucket_shift", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+# every symbol include/rbg.h declares: (name, restype, argtypes)
+_PROTOS = [
+    ("rbg_abi_version", C.c_int, []),
+    ("rbg_strerror", C.c_char_p, [C.c_int]),
+    ("rbg_load", C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(VP)]),
+    ("rbg_build_from_runs", C.c_int, [VP, VP, U64, VP, VP, C.c_int, C.POINTER(VP)]),
+    ("rbg_set_markers", C.c_int, [VP, VP, VP, U64, VP, VP]),
+    ("rbg_set_docs", C.c_int, [VP, C.c_char_p, VP, U64]),
+    ("rbg_free", None, [VP]),
+    ("rbg_info", C.c_int, [VP, C.POINTER(Info)]),
+    ("rbg_get_f", C.c_int, [VP, VP]),
+    ("rbg_last_run_sample", C.c_int, [VP, C.POINTER(U64)]),
+    ("rbg_host_array", C.c_int, [VP, C.c_int, VP, U64, C.POINTER(U64)]),
+    ("rbg_find_range", C.c_int, [VP, VP, VP, U64, VP, VP]),
+    ("rbg_count", C.c_int, [VP, VP, VP, U64, VP]),
+    ("rbg_find_range_w_toehold", C.c_int, [VP, VP, VP, U64, VP, VP, VP]),
+    ("rbg_locs_at", C.c_int, [VP, VP, VP, VP, U64, U64, VP, C.POINTER(VP)]),
+    ("rbg_markers_at", C.c_int, [VP, VP, VP, U64, VP, C.POINTER(VP)]),
+    ("rbg_find_range_w_markers", C.c_int, [VP, VP, VP, U64, U64, U64, VP, VP, VP, C.POINTER(VP)]),
+    ("rbg_free_buffer", None, [VP]),
+    ("rbg_resolve_offset", C.c_int, [VP, U64, C.POINTER(C.c_char_p), C.POINTER(U64)]),
+    ("rbg_find_range_dev", C.c_int, [VP, VP, VP, U64, VP, VP, VP]),
+    ("rbg_find_range_w_toehold_dev", C.c_int, [VP, VP, VP, U64, VP, VP, VP, VP]),
+    ("rbg_locate_plan_tmp_bytes", C.c_size_t, [U64]),
+    ("rbg_locate_plan_dev", C.c_int, [VP, VP, VP, U64, U64, VP, VP, C.c_size_t, VP]),
+    ("rbg_locate_fill_dev", C.c_int, [VP, VP, VP, VP, U64, U64, VP, VP, VP]),
+    ("rbg_markers_plan_dev", C.c_int, [VP, VP, VP, U64, VP, VP, C.c_size_t, VP]),
+    ("rbg_markers_fill_dev", C.c_int, [VP, VP, VP, U64, VP, VP, VP]),
+    ("rbg_counters", C.c_int, [VP, VP]),
+    ("rbg_counters_reset", C.c_int, [VP]),
+    ("rbg_set_default_option", C.c_int, [C.c_int, C.c_int64]),
+]
+EXPORTS = [p[0] for p in _PROTOS]
+
+_lib = None
+
+
+def lib():
+    """Load librbg.so.  Fails loudly if the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            raise ImportError(f"{_SO} is missing: build it with `make -C rowbowt_amd/csrc` "
+                              "(or __graft_entry__.build()); there is no CPU fallback")
+        L = C.CDLL(_SO)
+        for name, res, args in _PROTOS:
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RbgError(rc, what)
+
+
+def _p(a):
+    return a.ctypes.data_as(VP) if a is not None else None
+
+
+def _u64(a):
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+def pack_reads(reads):
+    """list of bytes -> (uint8 concat, uint64 offsets[N+1]): the batch layout of the C-ABI."""
+    off = np.zeros(len(reads) + 1, dtype=np.uint64)
+    if len(reads):
+        off[1:] = np.cumsum([len(r) for r in reads], dtype=np.uint64)
+    seqs = np.frombuffer(b"".join(reads), dtype=np.uint8).copy() if len(reads) else np.zeros(0, np.uint8)
+    return seqs, off
+
+
+def set_default_option(opt, value):
+    _check(lib().rbg_set_default_option(opt, value), "rbg_set_default_option")
+
+
+def _take(ptr, n):
+    """copy a library-malloc'ed uint64 buffer into numpy and release it"""
+    out = np.zeros(n, dtype=np.uint64)
+    if n:
+        C.memmove(out.ctypes.data, ptr.value, n * 8)
+    lib().rbg_free_buffer(ptr)
+    return out
+
+
+class RowBowt:
+    """rbwt::RowBowt<ri::rle_string_sd> (rowbowt.hpp:23-24), batched over N reads."""
+
+    def __init__(self, handle):
+        self.h = handle
+        self.L = lib()
+
+    def close(self):
+        if self.h:
+            self.L.rbg_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @classmethod
+    def from_runs(cls, heads, lens, ssa=None, esa=None, device=0):
+        heads = np.ascontiguousarray(heads, dtype=np.uint8)
+        lens = _u64(lens)
+        ssa = _u64(ssa) if ssa is not None else None
+        esa = _u64(esa) if esa is not None else None
+        h = VP()
+        _check(lib().rbg_build_from_runs(_p(heads), _p(lens), len(heads), _p(ssa), _p(esa), device, C.byref(h)),
+               "rbg_build_from_runs")
+        return cls(h)
+
+    def set_markers(self, run_start, run_end, mk_off, mk_vals):
+        a = [_u64(v) for v in (run_start, run_end, mk_off, mk_vals)]
+        _check(self.L.rbg_set_markers(self.h, _p(a[0]), _p(a[1]), len(a[0]), _p(a[2]), _p(a[3])), "rbg_set_markers")
+
+    def set_docs(self, names, starts):
+        joined = b"\0".join(n.encode() for n in names) + b"\0"
+        s = _u64(starts)
+        _check(self.L.rbg_set_docs(self.h, joined, _p(s), len(names)), "rbg_set_docs")
+
+    # ---- introspection
+    def info(self):
+        i = Info()
+        _check(self.L.rbg_info(self.h, C.byref(i)), "rbg_info")
+        return i
+
+    def get_f(self):
+        out = np.zeros(256, dtype=np.uint64)
+        _check(self.L.rbg_get_f(self.h, _p(out)), "rbg_get_f")
+        return out
+
+    def last_run_sample(self):
+        v = U64()
+        _check(self.L.rbg_last_run_sample(self.h, C.byref(v)), "rbg_last_run_sample")
+        return v.value
+
+    def host_array(self, which):
+        cnt = U64()
+        _check(self.L.rbg_host_array(self.h, which, None, 0, C.byref(cnt)), "rbg_host_array")
+        out = np.zeros(cnt.value, dtype=np.uint64)
+        _check(self.L.rbg_host_array(self.h, which, _p(out), cnt.value, C.byref(cnt)), "rbg_host_array")
+        return out
+
+    # ---- queries (host buffers)
+    def find_range(self, seqs, off):
+        N = len(off) - 1
+        lo, hi = np.zeros(N, np.uint64), np.zeros(N, np.uint64)
+        _check(self.L.rbg_find_range(self.h, _p(seqs), _p(off), N, _p(lo), _p(hi)), "rbg_find_range")
+        return lo, hi
+
+    def count(self, seqs, off):
+        N = len(off) - 1
+        cnt = np.zeros(N, np.uint64)
+        _check(self.L.rbg_count(self.h, _p(seqs), _p(off), N, _p(cnt)), "rbg_count")
+        return cnt
+
+    def find_range_w_toehold(self, seqs, off):
+        N = len(off) - 1
+        lo, hi, k = np.zeros(N, np.uint64), np.zeros(N, np.uint64), np.zeros(N, np.uint64)
+        _check(self.L.rbg_find_range_w_toehold(self.h, _p(seqs), _p(off), N, _p(lo), _p(hi), _p(k)),
+               "rbg_find_range_w_toehold")
+        return lo, hi, k
+
+    def locs_at(self, lo, hi, k, max_hits=MAXU):
+        lo, hi, k = _u64(lo), _u64(hi), _u64(k)
+        N = len(lo)
+        loc_off = np.zeros(N + 1, np.uint64)
+        ptr = VP()
+        _check(self.L.rbg_locs_at(self.h, _p(lo), _p(hi), _p(k), N, max_hits, _p(loc_off), C.byref(ptr)), "rbg_locs_at")
+        return loc_off, _take(ptr, int(loc_off[N]))
+
+    def markers_at(self, lo, hi):
+        lo, hi = _u64(lo), _u64(hi)
+        N = len(lo)
+        mk_off = np.zeros(N + 1, np.uint64)
+        ptr = VP()
+        _check(self.L.rbg_markers_at(self.h, _p(lo), _p(hi), N, _p(mk_off), C.byref(ptr)), "rbg_markers_at")
+        return mk_off, _take(ptr, int(mk_off[N]))
+
+    def find_range_w_markers(self, seqs, off, wsize, max_range=MAXU):
+        N = len(off) - 1
+        lo, hi, mk_off = np.zeros(N, np.uint64), np.zeros(N, np.uint64), np.zeros(N + 1, np.uint64)
+        ptr = VP()
+        _check(self.L.rbg_find_range_w_markers(self.h, _p(seqs), _p(off), N, wsize, max_range & MAXU,
+                                               _p(lo), _p(hi), _p(mk_off), C.byref(ptr)), "rbg_find_range_w_markers")
+        return lo, hi, mk_off, _take(ptr, int(mk_off[N]))
+
+    def resolve_offset(self, i):
+        name, off = C.c_char_p(), U64()
+        _check(self.L.rbg_resolve_offset(self.h, i, C.byref(name), C.byref(off)), "rbg_resolve_offset")
+        return name.value.decode(), off.value
+
+    def counters(self):
+        out = np.zeros(4, np.uint64)
+        _check(self.L.rbg_counters(self.h, _p(out)), "rbg_counters")
+        return out
+
+    def counters_reset(self):
+        _check(self.L.rbg_counters_reset(self.h), "rbg_counters_reset")
+
+
+def load_rowbowt(prefix, flag=LoadRbwtFlag.NONE, device=0):
+    """rbwt::load_rowbowt(prefix, flag), rowbowt_io.hpp:176-189"""
+    h = VP()
+    _check(lib().rbg_load(os.fsencode(prefix), int(flag), device, C.byref(h)), f"rbg_load({prefix})")
+    return RowBowt(h)

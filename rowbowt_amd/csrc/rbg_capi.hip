@@ -1,0 +1,674 @@
+// rbg_capi.hip -- the C-ABI of include/rbg.h: owns the host copy of the flat index and its
+// HBM replica, stages host batches, launches the kernels of rbg_kernels.hip.
+// There is deliberately no CPU compute path in this library.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/rbg.h"
+#include "rbg_dev.h"
+#include "rbg_host.hpp"
+
+using namespace rbg;
+
+struct rbg_index {
+    HostIndex host;
+    int device = RBG_DEVICE_NONE;
+    DevIndex dev{};
+    LaunchCfg cfg;
+    std::vector<void *> allocs;  // every device allocation of the replica
+    uint64_t hbm_bytes = 0;
+    std::mutex mu;               // guards marker/doc attachment only; queries are lock-free
+};
+
+namespace {
+
+std::atomic<int64_t> g_opt_block_threads{256};
+std::atomic<int64_t> g_opt_rank_shift{-1};
+std::atomic<int64_t> g_opt_phi_shift{-1};
+std::atomic<int64_t> g_opt_pos_bytes{0};
+
+#define HIP_TRY(expr)                                                                             \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            std::fprintf(stderr, "rbg: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return e_ == hipErrorOutOfMemory ? RBG_ENOMEM : RBG_ENODEV;                           \
+        }                                                                                         \
+    } while (0)
+
+// RAII: make `device` current for the scope of one API call
+struct DeviceScope {
+    int prev = -1;
+    bool changed = false;
+    int rc = RBG_OK;
+    explicit DeviceScope(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) { rc = RBG_ENODEV; return; }
+        if (prev != device) {
+            if (hipSetDevice(device) != hipSuccess) { rc = RBG_ENODEV; return; }
+            changed = true;
+        }
+    }
+    ~DeviceScope() { if (changed) (void)hipSetDevice(prev); }
+};
+
+// device scratch freed at scope exit
+struct DevBuf {
+    void *p = nullptr;
+    int alloc(size_t bytes) {
+        if (bytes == 0) bytes = 8;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) { p = nullptr; return e == hipErrorOutOfMemory ? RBG_ENOMEM : RBG_ENODEV; }
+        return RBG_OK;
+    }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    template <typename T> T *as() { return static_cast<T *>(p); }
+};
+
+int dev_upload(rbg_index *ix, const void *src, size_t bytes, const void **dst) {
+    void *p = nullptr;
+    const size_t alloc = bytes ? (bytes + 255) & ~size_t(255) : 256;
+    HIP_TRY(hipMalloc(&p, alloc));
+    ix->allocs.push_back(p);
+    ix->hbm_bytes += alloc;
+    if (bytes) HIP_TRY(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
+    *dst = p;
+    return RBG_OK;
+}
+
+template <typename P>
+int upload_tables(rbg_index *ix) {
+    HostIndex &h = ix->host;
+    std::vector<DevSym> syms(h.sigma);
+    for (uint32_t s = 0; s < h.sigma; ++s) {
+        const SymTable &t = h.sym[s];
+        std::vector<RunEnt<P>> ent(t.nruns + 1);
+        for (uint64_t k = 0; k <= t.nruns; ++k) {
+            ent[k].start = static_cast<P>(t.start[k]);
+            ent[k].cum = static_cast<P>(t.cum[k]);
+        }
+        int rc = dev_upload(ix, ent.data(), ent.size() * sizeof(RunEnt<P>), &syms[s].ent);
+        if (rc) return rc;
+        syms[s].samp = nullptr;
+        if (h.has_tsa) {
+            std::vector<P> samp(t.nruns);
+            for (uint64_t k = 0; k < t.nruns; ++k) samp[k] = static_cast<P>(t.samp[k]);
+            rc = dev_upload(ix, samp.data(), samp.size() * sizeof(P), &syms[s].samp);
+            if (rc) return rc;
+        }
+        const void *b = nullptr;
+        rc = dev_upload(ix, t.bucket.data(), t.bucket.size() * sizeof(uint32_t), &b);
+        if (rc) return rc;
+        syms[s].bucket = static_cast<const uint32_t *>(b);
+        syms[s].nruns = t.nruns;
+        syms[s].F = t.F;
+        syms[s].total = t.total;
+        syms[s].shift = t.shift;
+        syms[s].pad = 0;
+    }
+    const void *p = nullptr;
+    int rc = dev_upload(ix, syms.data(), syms.size() * sizeof(DevSym), &p);
+    if (rc) return rc;
+    ix->dev.syms = static_cast<const DevSym *>(p);
+    if (h.has_tsa) {
+        std::vector<PhiEnt<P>> pe(h.r);
+        for (uint64_t j = 0; j < h.r; ++j) {
+            pe[j].pos = static_cast<P>(h.pred_pos[j]);
+            pe[j].base = static_cast<P>(h.phi_base[j]);
+        }
+        rc = dev_upload(ix, pe.data(), pe.size() * sizeof(PhiEnt<P>), &ix->dev.phi_ent);
+        if (rc) return rc;
+        rc = dev_upload(ix, h.phi_bucket.data(), h.phi_bucket.size() * sizeof(uint32_t), &p);
+        if (rc) return rc;
+        ix->dev.phi_bucket = static_cast<const uint32_t *>(p);
+    }
+    return RBG_OK;
+}
+
+int upload_markers(rbg_index *ix) {
+    const RawMarkers &m = ix->host.ma;
+    const void *p = nullptr;
+    int rc;
+    if ((rc = dev_upload(ix, m.start.data(), m.start.size() * 8, &p))) return rc;
+    ix->dev.mk_start = static_cast<const uint64_t *>(p);
+    if ((rc = dev_upload(ix, m.end.data(), m.end.size() * 8, &p))) return rc;
+    ix->dev.mk_end = static_cast<const uint64_t *>(p);
+    if ((rc = dev_upload(ix, m.off.data(), m.off.size() * 8, &p))) return rc;
+    ix->dev.mk_off = static_cast<const uint64_t *>(p);
+    if ((rc = dev_upload(ix, m.vals.data(), m.vals.size() * 8, &p))) return rc;
+    ix->dev.mk_vals = static_cast<const uint64_t *>(p);
+    ix->dev.mk_nruns = m.start.size();
+    return RBG_OK;
+}
+
+int upload(rbg_index *ix) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ix->device < 0 || ix->device >= ndev) {
+        std::fprintf(stderr, "rbg: no usable HIP device %d (found %d); this library has no CPU path\n", ix->device, ndev);
+        return RBG_ENODEV;
+    }
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, ix->device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        std::fprintf(stderr, "rbg: device %d is %s; kernels are built for gfx950 (MI355X) only\n", ix->device, prop.gcnArchName);
+        return RBG_ENODEV;
+    }
+    DeviceScope scope(ix->device);
+    if (scope.rc) return scope.rc;
+    HostIndex &h = ix->host;
+    DevIndex &d = ix->dev;
+    d = DevIndex{};
+    d.n = h.n;
+    d.r = h.r;
+    d.sigma = h.sigma;
+    d.pos_bytes = h.pos_bytes;
+    d.has_tsa = h.has_tsa ? 1 : 0;
+    d.last_run_sample = h.last_run_sample;
+    d.phi_shift = h.phi_shift;
+    int rc = h.pos_bytes == 4 ? upload_tables<uint32_t>(ix) : upload_tables<uint64_t>(ix);
+    if (rc) return rc;
+    const void *p = nullptr;
+    if ((rc = dev_upload(ix, h.lut, 256, &p))) return rc;
+    d.lut = static_cast<const uint8_t *>(p);
+    const unsigned long long zero[4] = {0, 0, 0, 0};
+    if ((rc = dev_upload(ix, zero, sizeof(zero), &p))) return rc;
+    d.counters = const_cast<unsigned long long *>(static_cast<const unsigned long long *>(p));
+    if (h.has_ma && (rc = upload_markers(ix))) return rc;
+    ix->cfg.block_threads = static_cast<int>(g_opt_block_threads.load());
+    ix->cfg.max_blocks = prop.multiProcessorCount * 32;
+    return RBG_OK;
+}
+
+FlattenOptions current_options() {
+    FlattenOptions o;
+    o.rank_bucket_shift = static_cast<int>(g_opt_rank_shift.load());
+    o.phi_bucket_shift = static_cast<int>(g_opt_phi_shift.load());
+    o.force_pos_bytes = static_cast<int>(g_opt_pos_bytes.load());
+    return o;
+}
+
+int finish(rbg_index *ix, int device, rbg_index **out) {
+    ix->device = device;
+    if (device != RBG_DEVICE_NONE) {
+        int rc = upload(ix);
+        if (rc) { rbg_free(ix); return rc; }
+    }
+    *out = ix;
+    return RBG_OK;
+}
+
+bool queryable(const rbg_index *ix) { return ix && ix->device != RBG_DEVICE_NONE; }
+
+bool markers_valid(const uint64_t *s, const uint64_t *e, uint64_t nruns, const uint64_t *off) {
+    for (uint64_t j = 0; j < nruns; ++j) {
+        if (e[j] < s[j] || off[j] > off[j + 1]) return false;
+        if (j && s[j] <= e[j - 1]) return false;  // disjoint, ascending
+    }
+    return nruns == 0 || off[0] == 0;
+}
+
+// common staging for host read batches
+struct ReadBatch {
+    DevBuf seqs, off;
+    int stage(const uint8_t *h_seqs, const uint64_t *h_off, uint64_t N, hipStream_t st) {
+        const uint64_t total = N ? h_off[N] : 0;
+        int rc;
+        if ((rc = seqs.alloc(((total + 7) & ~uint64_t(7)) + 8))) return rc;
+        if ((rc = off.alloc((N + 1) * 8))) return rc;
+        if (total) HIP_TRY(hipMemcpyAsync(seqs.p, h_seqs, total, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(off.p, h_off, (N + 1) * 8, hipMemcpyHostToDevice, st));
+        return RBG_OK;
+    }
+};
+
+int check_offsets(const uint64_t *off, uint64_t N) {
+    if (N == 0) return RBG_OK;
+    if (!off || off[0] != 0) return RBG_EARG;
+    for (uint64_t i = 0; i < N; ++i)
+        if (off[i + 1] < off[i]) return RBG_EARG;
+    return RBG_OK;
+}
+
+// shared tail of the ragged-output host calls: d_off[N+1] is planned on the device; size, fill, copy back
+template <typename FillFn>
+int ragged_finish(uint64_t N, DevBuf &d_off, uint64_t *h_off, uint64_t **h_vals, hipStream_t st, FillFn fill) {
+    HIP_TRY(hipMemcpyAsync(h_off, d_off.p, (N + 1) * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const uint64_t total = h_off[N];
+    *h_vals = static_cast<uint64_t *>(std::malloc(total ? total * 8 : 8));
+    if (!*h_vals) return RBG_ENOMEM;
+    if (total == 0) return RBG_OK;
+    DevBuf d_vals;
+    int rc = d_vals.alloc(total * 8);
+    if (!rc) rc = fill(d_vals.as<uint64_t>());
+    if (!rc) {
+        hipError_t e = hipMemcpyAsync(*h_vals, d_vals.p, total * 8, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) rc = RBG_ENODEV;
+    }
+    if (rc) { std::free(*h_vals); *h_vals = nullptr; }
+    return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rbg_abi_version(void) { return RBG_ABI_VERSION; }
+
+const char *rbg_strerror(int code) {
+    switch (code) {
+        case RBG_OK: return "ok";
+        case RBG_EIO: return "file missing or unreadable";
+        case RBG_EFORMAT: return "not the sdsl layout written by the reference";
+        case RBG_ENODEV: return "no usable gfx950 device / HIP error (there is no CPU path)";
+        case RBG_EARG: return "bad argument";
+        case RBG_ENOMEM: return "out of memory";
+        case RBG_ENOTLOADED: return "required structure (toehold SA / markers / docs) not loaded";
+        default: return "unknown error";
+    }
+}
+
+int rbg_set_default_option(int opt, int64_t value) {
+    switch (opt) {
+        case RBG_OPT_BLOCK_THREADS:
+            if (value < 64 || value > 1024 || value % 64) return RBG_EARG;
+            g_opt_block_threads = value; return RBG_OK;
+        case RBG_OPT_RANK_BUCKET_SHIFT:
+            if (value < -1 || value > 62) return RBG_EARG;
+            g_opt_rank_shift = value; return RBG_OK;
+        case RBG_OPT_PHI_BUCKET_SHIFT:
+            if (value < -1 || value > 62) return RBG_EARG;
+            g_opt_phi_shift = value; return RBG_OK;
+        case RBG_OPT_POS_BYTES:
+            if (value != 0 && value != 4 && value != 8) return RBG_EARG;
+            g_opt_pos_bytes = value; return RBG_OK;
+        default: return RBG_EARG;
+    }
+}
+
+int rbg_load(const char *prefix, int flags, int device, rbg_index **out) {
+    if (!prefix || !out) return RBG_EARG;
+    *out = nullptr;
+    const std::string pre(prefix);
+    RawRle rle;
+    int rc = parse_rbwt(pre + ".rbwt", rle);  // rowbowt_io.hpp:17,179-182
+    if (rc) return rc;
+    RawTsa tsa;
+    const bool want_sa = flags & RBG_LOAD_SA;
+    if (want_sa && (rc = parse_tsa(pre + ".tsa", tsa))) return rc;  // :18,184
+    rbg_index *ix = new (std::nothrow) rbg_index();
+    if (!ix) return RBG_ENOMEM;
+    rc = flatten(rle, want_sa ? &tsa : nullptr, current_options(), ix->host);
+    if (rc) { delete ix; return rc; }
+    if (flags & RBG_LOAD_MA) {  // :19,185
+        rc = parse_mab(pre + ".mab", ix->host.ma);
+        if (!rc && !markers_valid(ix->host.ma.start.data(), ix->host.ma.end.data(), ix->host.ma.start.size(), ix->host.ma.off.data()))
+            rc = RBG_EFORMAT;
+        if (rc) { delete ix; return rc; }
+        ix->host.has_ma = true;
+    }
+    if (flags & RBG_LOAD_DL) {  // :20,186
+        rc = parse_docs(pre + ".docs", ix->host.dl);
+        if (rc) { delete ix; return rc; }
+        ix->host.has_dl = true;
+    }
+    return finish(ix, device, out);
+}
+
+int rbg_build_from_runs(const uint8_t *heads, const uint64_t *lens, uint64_t R, const uint64_t *ssa_y,
+                        const uint64_t *esa_y, int device, rbg_index **out) {
+    if (!heads || !lens || !out || R == 0 || (!!ssa_y != !!esa_y)) return RBG_EARG;
+    *out = nullptr;
+    RawRle rle;
+    rle.R = R;
+    rle.B = 2;
+    rle.heads.assign(heads, heads + R);
+    rle.lens.assign(lens, lens + R);
+    uint64_t n = 0;
+    for (uint64_t i = 0; i < R; ++i) {
+        if (i && heads[i] == heads[i - 1]) return RBG_EARG;  // runs must be maximal
+        n += lens[i];
+    }
+    rle.n = n;
+    RawTsa tsa;
+    if (ssa_y) tsa_from_samples(n, R, ssa_y, esa_y, tsa);
+    rbg_index *ix = new (std::nothrow) rbg_index();
+    if (!ix) return RBG_ENOMEM;
+    int rc = flatten(rle, ssa_y ? &tsa : nullptr, current_options(), ix->host);
+    if (rc) { delete ix; return rc; }
+    return finish(ix, device, out);
+}
+
+int rbg_set_markers(rbg_index *ix, const uint64_t *run_start, const uint64_t *run_end, uint64_t nruns,
+                    const uint64_t *mk_off, const uint64_t *mk_vals) {
+    if (!ix || !run_start || !run_end || !mk_off || (!mk_vals && mk_off[nruns])) return RBG_EARG;
+    if (!markers_valid(run_start, run_end, nruns, mk_off)) return RBG_EARG;
+    std::lock_guard<std::mutex> g(ix->mu);
+    if (ix->host.has_ma) return RBG_EARG;  // immutable once attached
+    RawMarkers &m = ix->host.ma;
+    m.start.assign(run_start, run_start + nruns);
+    m.end.assign(run_end, run_end + nruns);
+    m.off.assign(mk_off, mk_off + nruns + 1);
+    m.vals.assign(mk_vals, mk_vals + mk_off[nruns]);
+    ix->host.has_ma = true;
+    if (ix->device != RBG_DEVICE_NONE) {
+        DeviceScope scope(ix->device);
+        if (scope.rc) return scope.rc;
+        return upload_markers(ix);
+    }
+    return RBG_OK;
+}
+
+int rbg_set_docs(rbg_index *ix, const char *names_joined, const uint64_t *starts, uint64_t ndocs) {
+    if (!ix || !names_joined || !starts) return RBG_EARG;
+    std::lock_guard<std::mutex> g(ix->mu);
+    RawDocs &d = ix->host.dl;
+    d = RawDocs();
+    const char *p = names_joined;
+    for (uint64_t i = 0; i < ndocs; ++i) {
+        d.names.emplace_back(p);
+        p += d.names.back().size() + 1;
+        d.starts.push_back(starts[i]);
+    }
+    d.sorted = d.starts;
+    std::sort(d.sorted.begin(), d.sorted.end());
+    ix->host.has_dl = true;
+    return RBG_OK;
+}
+
+void rbg_free(rbg_index *ix) {
+    if (!ix) return;
+    if (ix->device != RBG_DEVICE_NONE && !ix->allocs.empty()) {
+        DeviceScope scope(ix->device);
+        for (void *p : ix->allocs) (void)hipFree(p);
+    }
+    delete ix;
+}
+
+void rbg_free_buffer(void *p) { std::free(p); }
+
+int rbg_info(const rbg_index *ix, rbg_info_t *out) {
+    if (!ix || !out) return RBG_EARG;
+    std::memset(out, 0, sizeof(*out));
+    out->n = ix->host.n;
+    out->r = ix->host.r;
+    out->sigma = ix->host.sigma;
+    out->pos_bytes = ix->host.pos_bytes;
+    out->device = ix->device;
+    out->has_tsa = ix->host.has_tsa;
+    out->has_markers = ix->host.has_ma;
+    out->has_docs = ix->host.has_dl;
+    out->hbm_bytes = ix->hbm_bytes;
+    out->marker_runs = ix->host.ma.start.size();
+    out->marker_vals = ix->host.ma.vals.size();
+    out->rank_bucket_shift = ix->host.sym.empty() ? 0 : ix->host.sym.back().shift;
+    out->phi_bucket_shift = ix->host.phi_shift;
+    return RBG_OK;
+}
+
+int rbg_get_f(const rbg_index *ix, uint64_t f_out[256]) {
+    if (!ix || !f_out) return RBG_EARG;
+    std::memcpy(f_out, ix->host.f, 256 * sizeof(uint64_t));
+    return RBG_OK;
+}
+
+int rbg_last_run_sample(const rbg_index *ix, uint64_t *out) {
+    if (!ix || !out) return RBG_EARG;
+    if (!ix->host.has_tsa) return RBG_ENOTLOADED;
+    *out = ix->host.last_run_sample;
+    return RBG_OK;
+}
+
+int rbg_host_array(const rbg_index *ix, int which, uint64_t *dst, uint64_t cap, uint64_t *count) {
+    if (!ix || !count) return RBG_EARG;
+    const HostIndex &h = ix->host;
+    const std::vector<uint64_t> *v = nullptr;
+    std::vector<uint64_t> tmp;
+    switch (which) {
+        case RBG_ARR_RUN_HEADS: tmp.assign(h.run_heads.begin(), h.run_heads.end()); v = &tmp; break;
+        case RBG_ARR_RUN_START: v = &h.run_start; break;
+        case RBG_ARR_SAMPLES_LAST: v = &h.samples_last; break;
+        case RBG_ARR_PRED_POS: v = &h.pred_pos; break;
+        case RBG_ARR_PHI_BASE: v = &h.phi_base; break;
+        case RBG_ARR_MARKER_START: v = &h.ma.start; break;
+        case RBG_ARR_MARKER_END: v = &h.ma.end; break;
+        case RBG_ARR_MARKER_OFF: v = &h.ma.off; break;
+        case RBG_ARR_MARKER_VALS: v = &h.ma.vals; break;
+        default: return RBG_EARG;
+    }
+    *count = v->size();
+    if (dst) std::memcpy(dst, v->data(), std::min<uint64_t>(cap, v->size()) * 8);
+    return RBG_OK;
+}
+
+int rbg_resolve_offset(const rbg_index *ix, uint64_t i, const char **name, uint64_t *offset) {
+    if (!ix || !name || !offset) return RBG_EARG;
+    if (!ix->host.has_dl || ix->host.dl.names.empty()) return RBG_ENOTLOADED;
+    const RawDocs &d = ix->host.dl;
+    // DocList::doc_bounds_rank, doclist.hpp:77-79: rank(min(i+1, size)) over a bit-vector whose
+    // size is the LAST start read + 1 (doclist.hpp:66)
+    const uint64_t size = d.starts.back() + 1;
+    const uint64_t q = i + 1 > size ? size : i + 1;
+    const uint64_t rank = std::lower_bound(d.sorted.begin(), d.sorted.end(), q) - d.sorted.begin();
+    if (rank == 0) return RBG_EARG;  // reference indexes doc_names_[-1] here
+    *offset = i - d.sorted[rank - 1];           // doclist.hpp:48
+    *name = d.names[rank - 1].c_str();          // doclist.hpp:49
+    return RBG_OK;
+}
+
+// ---- device-resident entry points ------------------------------------------------------------------
+
+int rbg_find_range_dev(rbg_index *ix, const uint8_t *d_seqs, const uint64_t *d_off, uint64_t N, uint64_t *d_lo,
+                       uint64_t *d_hi, void *stream) {
+    if (!queryable(ix)) return RBG_ENODEV;
+    if (N && (!d_seqs || !d_off || !d_lo || !d_hi)) return RBG_EARG;
+    if (reinterpret_cast<uintptr_t>(d_seqs) & 7) return RBG_EARG;  // reads are fetched as aligned 8-byte words
+    return launch_find_range(ix->dev, ix->cfg, d_seqs, d_off, N, d_lo, d_hi, nullptr, stream) ? RBG_ENODEV : RBG_OK;
+}
+
+int rbg_find_range_w_toehold_dev(rbg_index *ix, const uint8_t *d_seqs, const uint64_t *d_off, uint64_t N,
+                                 uint64_t *d_lo, uint64_t *d_hi, uint64_t *d_ssamp, void *stream) {
+    if (!queryable(ix)) return RBG_ENODEV;
+    if (!ix->host.has_tsa) return RBG_ENOTLOADED;
+    if (N && (!d_seqs || !d_off || !d_lo || !d_hi || !d_ssamp)) return RBG_EARG;
+    if (reinterpret_cast<uintptr_t>(d_seqs) & 7) return RBG_EARG;
+    return launch_find_range(ix->dev, ix->cfg, d_seqs, d_off, N, d_lo, d_hi, d_ssamp, stream) ? RBG_ENODEV : RBG_OK;
+}
+
+size_t rbg_locate_plan_tmp_bytes(uint64_t N) { return scan_tmp_bytes(N); }
+
+int rbg_locate_plan_dev(rbg_index *ix, const uint64_t *d_lo, const uint64_t *d_hi, uint64_t N, uint64_t max_hits,
+                        uint64_t *d_loc_off, void *d_tmp, size_t tmp_bytes, void *stream) {
+    if (!queryable(ix)) return RBG_ENODEV;
+    if (!ix->host.has_tsa) return RBG_ENOTLOADED;
+    if (!d_loc_off || (N && (!d_lo || !d_hi || !d_tmp))) return RBG_EARG;
+    return launch_locate_plan(ix->dev, ix->cfg, d_lo, d_hi, N, max_hits, d_loc_off, d_tmp, tmp_bytes, stream) ? RBG_ENODEV : RBG_OK;
+}
+
+int rbg_locate_fill_dev(rbg_index *ix, const uint64_t *d_lo, const uint64_t *d_hi, const uint64_t *d_k, uint64_t N,
+                        uint64_t max_hits, const uint64_t *d_loc_off, uint64_t *d_locs, void *stream) {
+    if (!queryable(ix)) return RBG_ENODEV;
+    if (!ix->host.has_tsa) return RBG_ENOTLOADED;
+    if (N && (!d_lo || !d_hi || !d_k || !d_loc_off || !d_locs)) return RBG_EARG;
+    return launch_locate_fill(ix->dev, ix->cfg, d_lo, d_hi, d_k, N, max_hits, d_loc_off, d_locs, stream) ? RBG_ENODEV : RBG_OK;
+}
+
+int rbg_markers_plan_dev(rbg_index *ix, const uint64_t *d_lo, const uint64_t *d_hi, uint64_t N, uint64_t *d_mk_off,
+                         void *d_tmp, size_t tmp_bytes, void *stream) {
+    if (!queryable(ix)) return RBG_ENODEV;
+    if (!ix->host.has_ma) return RBG_ENOTLOADED;
+    if (!d_mk_off || (N && (!d_lo || !d_hi || !d_tmp))) return RBG_EARG;
+    return launch_markers_plan(ix->dev, ix->cfg, d_lo, d_hi, N, d_mk_off, d_tmp, tmp_bytes, stream) ? RBG_ENODEV : RBG_OK;
+}
+
+int rbg_markers_fill_dev(rbg_index *ix, const uint64_t *d_lo, const uint64_t *d_hi, uint64_t N,
+                         const uint64_t *d_mk_off, uint64_t *d_mk, void *stream) {
+    if (!queryable(ix)) return RBG_ENODEV;
+    if (!ix->host.has_ma) return RBG_ENOTLOADED;
+    if (N && (!d_lo || !d_hi || !d_mk_off || !d_mk)) return RBG_EARG;
+    return launch_markers_fill(ix->dev, ix->cfg, d_lo, d_hi, N, d_mk_off, d_mk, stream) ? RBG_ENODEV : RBG_OK;
+}
+
+// ---- host-buffer entry points ----------------------------------------------------------------------
+
+static int find_range_host(rbg_index *ix, const uint8_t *seqs, const uint64_t *off, uint64_t N, uint64_t *lo,
+                           uint64_t *hi, uint64_t *ssamp, uint64_t *count) {
+    if (!queryable(ix)) return RBG_ENODEV;
+    if (N == 0) return RBG_OK;
+    if (!off || (!seqs && off[N])) return RBG_EARG;
+    int rc = check_offsets(off, N);
+    if (rc) return rc;
+    DeviceScope scope(ix->device);
+    if (scope.rc) return scope.rc;
+    hipStream_t st = hipStreamPerThread;
+    ReadBatch rb;
+    if ((rc = rb.stage(seqs, off, N, st))) return rc;
+    DevBuf dlo, dhi, dss, dcnt;
+    if ((rc = dlo.alloc(N * 8)) || (rc = dhi.alloc(N * 8))) return rc;
+    if (ssamp && (rc = dss.alloc(N * 8))) return rc;
+    if (launch_find_range(ix->dev, ix->cfg, rb.seqs.as<uint8_t>(), rb.off.as<uint64_t>(), N, dlo.as<uint64_t>(),
+                          dhi.as<uint64_t>(), ssamp ? dss.as<uint64_t>() : nullptr, st))
+        return RBG_ENODEV;
+    if (count) {
+        if ((rc = dcnt.alloc(N * 8))) return rc;
+        if (launch_count_from_ranges(dlo.as<uint64_t>(), dhi.as<uint64_t>(), N, dcnt.as<uint64_t>(), st)) return RBG_ENODEV;
+        HIP_TRY(hipMemcpyAsync(count, dcnt.p, N * 8, hipMemcpyDeviceToHost, st));
+    }
+    if (lo) HIP_TRY(hipMemcpyAsync(lo, dlo.p, N * 8, hipMemcpyDeviceToHost, st));
+    if (hi) HIP_TRY(hipMemcpyAsync(hi, dhi.p, N * 8, hipMemcpyDeviceToHost, st));
+    if (ssamp) HIP_TRY(hipMemcpyAsync(ssamp, dss.p, N * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return RBG_OK;
+}
+
+int rbg_find_range(rbg_index *ix, const uint8_t *seqs, const uint64_t *off, uint64_t N, uint64_t *lo, uint64_t *hi) {
+    if (N && (!lo || !hi)) return RBG_EARG;
+    return find_range_host(ix, seqs, off, N, lo, hi, nullptr, nullptr);
+}
+
+int rbg_count(rbg_index *ix, const uint8_t *seqs, const uint64_t *off, uint64_t N, uint64_t *count) {
+    if (N && !count) return RBG_EARG;
+    return find_range_host(ix, seqs, off, N, nullptr, nullptr, nullptr, count);
+}
+
+int rbg_find_range_w_toehold(rbg_index *ix, const uint8_t *seqs, const uint64_t *off, uint64_t N, uint64_t *lo,
+                             uint64_t *hi, uint64_t *ssamp) {
+    if (ix && !ix->host.has_tsa) return RBG_ENOTLOADED;
+    if (N && (!lo || !hi || !ssamp)) return RBG_EARG;
+    return find_range_host(ix, seqs, off, N, lo, hi, ssamp, nullptr);
+}
+
+int rbg_locs_at(rbg_index *ix, const uint64_t *lo, const uint64_t *hi, const uint64_t *k, uint64_t N,
+                uint64_t max_hits, uint64_t *loc_off, uint64_t **locs) {
+    if (!queryable(ix)) return RBG_ENODEV;
+    if (!ix->host.has_tsa) return RBG_ENOTLOADED;
+    if (!loc_off || !locs || (N && (!lo || !hi || !k))) return RBG_EARG;
+    *locs = nullptr;
+    DeviceScope scope(ix->device);
+    if (scope.rc) return scope.rc;
+    hipStream_t st = hipStreamPerThread;
+    DevBuf dlo, dhi, dk, doff, dtmp;
+    const size_t tmp_bytes = scan_tmp_bytes(N);
+    int rc;
+    if ((rc = dlo.alloc(N * 8)) || (rc = dhi.alloc(N * 8)) || (rc = dk.alloc(N * 8)) || (rc = doff.alloc((N + 1) * 8)) ||
+        (rc = dtmp.alloc(tmp_bytes)))
+        return rc;
+    if (N) {
+        HIP_TRY(hipMemcpyAsync(dlo.p, lo, N * 8, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(dhi.p, hi, N * 8, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(dk.p, k, N * 8, hipMemcpyHostToDevice, st));
+    }
+    if (launch_locate_plan(ix->dev, ix->cfg, dlo.as<uint64_t>(), dhi.as<uint64_t>(), N, max_hits, doff.as<uint64_t>(), dtmp.p, tmp_bytes, st))
+        return RBG_ENODEV;
+    return ragged_finish(N, doff, loc_off, locs, st, [&](uint64_t *d_vals) {
+        return launch_locate_fill(ix->dev, ix->cfg, dlo.as<uint64_t>(), dhi.as<uint64_t>(), dk.as<uint64_t>(), N, max_hits,
+                                  doff.as<uint64_t>(), d_vals, st) ? RBG_ENODEV : RBG_OK;
+    });
+}
+
+int rbg_markers_at(rbg_index *ix, const uint64_t *lo, const uint64_t *hi, uint64_t N, uint64_t *mk_off, uint64_t **mk) {
+    if (!queryable(ix)) return RBG_ENODEV;
+    if (!ix->host.has_ma) return RBG_ENOTLOADED;
+    if (!mk_off || !mk || (N && (!lo || !hi))) return RBG_EARG;
+    *mk = nullptr;
+    DeviceScope scope(ix->device);
+    if (scope.rc) return scope.rc;
+    hipStream_t st = hipStreamPerThread;
+    DevBuf dlo, dhi, doff, dtmp;
+    const size_t tmp_bytes = scan_tmp_bytes(N);
+    int rc;
+    if ((rc = dlo.alloc(N * 8)) || (rc = dhi.alloc(N * 8)) || (rc = doff.alloc((N + 1) * 8)) || (rc = dtmp.alloc(tmp_bytes)))
+        return rc;
+    if (N) {
+        HIP_TRY(hipMemcpyAsync(dlo.p, lo, N * 8, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(dhi.p, hi, N * 8, hipMemcpyHostToDevice, st));
+    }
+    if (launch_markers_plan(ix->dev, ix->cfg, dlo.as<uint64_t>(), dhi.as<uint64_t>(), N, doff.as<uint64_t>(), dtmp.p, tmp_bytes, st))
+        return RBG_ENODEV;
+    return ragged_finish(N, doff, mk_off, mk, st, [&](uint64_t *d_vals) {
+        return launch_markers_fill(ix->dev, ix->cfg, dlo.as<uint64_t>(), dhi.as<uint64_t>(), N, doff.as<uint64_t>(), d_vals, st)
+                   ? RBG_ENODEV : RBG_OK;
+    });
+}
+
+int rbg_find_range_w_markers(rbg_index *ix, const uint8_t *seqs, const uint64_t *off, uint64_t N, uint64_t wsize,
+                             uint64_t max_range, uint64_t *lo, uint64_t *hi, uint64_t *mk_off, uint64_t **mk) {
+    if (!queryable(ix)) return RBG_ENODEV;
+    if (!ix->host.has_ma) return RBG_ENOTLOADED;  // reference: "warning: no marker array found!", default LFData
+    if (!mk_off || !mk || wsize == 0 || (N && (!lo || !hi || !off))) return RBG_EARG;
+    *mk = nullptr;
+    int rc = check_offsets(off, N);
+    if (rc) return rc;
+    DeviceScope scope(ix->device);
+    if (scope.rc) return scope.rc;
+    hipStream_t st = hipStreamPerThread;
+    ReadBatch rb;
+    if ((rc = rb.stage(seqs, off, N, st))) return rc;
+    DevBuf dlo, dhi, doff, dtmp;
+    const size_t tmp_bytes = scan_tmp_bytes(N);
+    if ((rc = dlo.alloc(N * 8)) || (rc = dhi.alloc(N * 8)) || (rc = doff.alloc((N + 1) * 8)) || (rc = dtmp.alloc(tmp_bytes)))
+        return rc;
+    if (launch_find_range_markers_plan(ix->dev, ix->cfg, rb.seqs.as<uint8_t>(), rb.off.as<uint64_t>(), N, wsize, max_range,
+                                       dlo.as<uint64_t>(), dhi.as<uint64_t>(), doff.as<uint64_t>(), dtmp.p, tmp_bytes, st))
+        return RBG_ENODEV;
+    if (N) {
+        HIP_TRY(hipMemcpyAsync(lo, dlo.p, N * 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(hi, dhi.p, N * 8, hipMemcpyDeviceToHost, st));
+    }
+    return ragged_finish(N, doff, mk_off, mk, st, [&](uint64_t *d_vals) {
+        return launch_find_range_markers_fill(ix->dev, ix->cfg, rb.seqs.as<uint8_t>(), rb.off.as<uint64_t>(), N, wsize,
+                                              max_range, doff.as<uint64_t>(), d_vals, st) ? RBG_ENODEV : RBG_OK;
+    });
+}
+
+// ---- counters --------------------------------------------------------------------------------------
+
+int rbg_counters(rbg_index *ix, uint64_t out[4]) {
+    if (!queryable(ix)) return RBG_ENODEV;
+    if (!out) return RBG_EARG;
+    DeviceScope scope(ix->device);
+    if (scope.rc) return scope.rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, ix->dev.counters, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return RBG_OK;
+}
+
+int rbg_counters_reset(rbg_index *ix) {
+    if (!queryable(ix)) return RBG_ENODEV;
+    DeviceScope scope(ix->device);
+    if (scope.rc) return scope.rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemset(ix->dev.counters, 0, 4 * sizeof(uint64_t)));
+    return RBG_OK;
+}
+
+}  // extern "C"

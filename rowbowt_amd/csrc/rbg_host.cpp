@@ -1,0 +1,437 @@
+// rbg_host.cpp -- readers for the reference's sdsl-serialised index files + the flattener.
+// See rbg_host.hpp for the reference file:line each piece replaces.
+#include "rbg_host.hpp"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <numeric>
+#include <sstream>
+
+#include "../../include/rbg.h"
+
+namespace rbg {
+namespace {
+
+// ---- byte cursor over a whole file --------------------------------------------------------------
+class Cursor {
+   public:
+    bool open(const std::string &fname) {
+        std::ifstream ifs(fname, std::ios::binary | std::ios::ate);
+        if (!ifs.good()) return false;
+        std::streamsize sz = ifs.tellg();
+        ifs.seekg(0);
+        buf_.resize(static_cast<size_t>(sz));
+        if (sz > 0 && !ifs.read(reinterpret_cast<char *>(buf_.data()), sz)) return false;
+        return true;
+    }
+    template <typename T>
+    T get() {
+        T v{};
+        if (!take(sizeof(T))) return v;
+        std::memcpy(&v, buf_.data() + pos_ - sizeof(T), sizeof(T));
+        return v;
+    }
+    const uint8_t *span(size_t nbytes) { return take(nbytes) ? buf_.data() + pos_ - nbytes : nullptr; }
+    bool ok() const { return ok_; }
+    bool at_end() const { return ok_ && pos_ == buf_.size(); }
+    size_t remaining() const { return buf_.size() - pos_; }
+    void fail() { ok_ = false; }
+
+   private:
+    bool take(size_t n) {
+        if (!ok_ || n > buf_.size() - pos_) { ok_ = false; return false; }
+        pos_ += n;
+        return true;
+    }
+    std::vector<uint8_t> buf_;
+    size_t pos_ = 0;
+    bool ok_ = true;
+};
+
+// sdsl::int_vector<w> as the reference's files hold it: one u64 header whose low 56 bits are the
+// length in bits and whose top byte is the element width, then ceil(bits/64) words.
+struct PackedVec {
+    uint64_t bits = 0;
+    unsigned width = 1;
+    std::vector<uint64_t> words;
+    uint64_t size() const { return bits / width; }
+    uint64_t at(uint64_t i) const {
+        const uint64_t b = i * width;
+        const unsigned sh = b & 63;
+        uint64_t x = words[b >> 6] >> sh;
+        if (sh + width > 64) x |= words[(b >> 6) + 1] << (64 - sh);
+        return width == 64 ? x : x & ((uint64_t(1) << width) - 1);
+    }
+    bool bit(uint64_t i) const { return (words[i >> 6] >> (i & 63)) & 1; }
+};
+
+bool read_packed(Cursor &c, PackedVec &v, bool keep) {
+    const uint64_t h = c.get<uint64_t>();
+    v.bits = h & ((uint64_t(1) << 56) - 1);
+    v.width = static_cast<unsigned>(h >> 56);
+    if (!c.ok() || v.width == 0 || v.width > 64) { c.fail(); return false; }
+    const uint64_t nwords = (v.bits + 63) / 64;
+    if (nwords > c.remaining() / 8) { c.fail(); return false; }
+    const uint8_t *p = c.span(nwords * 8);
+    if (!p) return false;
+    if (keep) {
+        v.words.resize(nwords + 1);
+        std::memcpy(v.words.data(), p, nwords * 8);
+        v.words[nwords] = 0;
+    }
+    return true;
+}
+
+// sdsl::select_support_mcl<b>: arg_cnt, then (if non-zero) superblock vector, mini_or_long bit
+// vector and one vector per 4096-argument superblock.  Nothing in it is needed.
+void skip_select_support(Cursor &c) {
+    const uint64_t arg_cnt = c.get<uint64_t>();
+    if (!c.ok() || arg_cnt == 0) return;
+    PackedVec tmp;
+    read_packed(c, tmp, false);
+    read_packed(c, tmp, false);
+    const uint64_t sb = (arg_cnt + 4095) >> 12;
+    for (uint64_t i = 0; i < sb && c.ok(); ++i) read_packed(c, tmp, false);
+}
+
+// sdsl::sd_vector<> (Elias-Fano): size, wl, low, high, select_1, select_0.  Decoded to the
+// ascending list of set positions.
+bool read_sd_vector(Cursor &c, uint64_t &universe, std::vector<uint64_t> &ones) {
+    universe = c.get<uint64_t>();
+    const unsigned wl = c.get<uint8_t>();
+    PackedVec low, high;
+    if (!read_packed(c, low, true) || !read_packed(c, high, true)) return false;
+    skip_select_support(c);
+    skip_select_support(c);
+    if (!c.ok() || wl >= 64) { c.fail(); return false; }
+    const uint64_t m = low.size();
+    ones.clear();
+    ones.reserve(m);
+    const uint64_t nwords = (high.bits + 63) / 64;
+    for (uint64_t w = 0; w < nwords && ones.size() < m; ++w) {
+        uint64_t x = high.words[w];
+        if (w == nwords - 1 && (high.bits & 63)) x &= (uint64_t(1) << (high.bits & 63)) - 1;
+        while (x && ones.size() < m) {
+            const uint64_t p = w * 64 + static_cast<unsigned>(__builtin_ctzll(x));
+            const uint64_t k = ones.size();
+            ones.push_back(((p - k) << wl) | (wl ? low.at(k) : 0));
+            x &= x - 1;
+        }
+    }
+    if (ones.size() != m) { c.fail(); return false; }
+    for (uint64_t k = 1; k < m; ++k)
+        if (ones[k] <= ones[k - 1]) { c.fail(); return false; }
+    if (m && ones.back() >= universe) { c.fail(); return false; }
+    return true;
+}
+
+// ri::sparse_sd_vector::load (sparse_sd_vector.hpp:194-200): u, then the sd_vector unless u == 0.
+bool read_sparse(Cursor &c, uint64_t &u, std::vector<uint64_t> &ones) {
+    u = c.get<uint64_t>();
+    ones.clear();
+    if (!c.ok()) return false;
+    if (u == 0) return true;
+    uint64_t inner = 0;
+    if (!read_sd_vector(c, inner, ones)) return false;
+    if (inner != u) { c.fail(); return false; }
+    return true;
+}
+
+// sdsl::wt_huff<> -> the plain symbol sequence.  Each element is recovered with the wavelet
+// tree's own access walk (bit at the node, rank inside the node, descend) over a popcount
+// directory built here; the serialised rank/select supports are skipped.
+bool read_wt_huff(Cursor &c, std::vector<uint8_t> &seq) {
+    const uint64_t size = c.get<uint64_t>();
+    (void)c.get<uint64_t>();  // sigma
+    PackedVec bv, tmp;
+    if (!read_packed(c, bv, true)) return false;
+    read_packed(c, tmp, false);  // rank_support_v
+    skip_select_support(c);
+    skip_select_support(c);
+    const uint64_t n_nodes = c.get<uint64_t>();
+    if (!c.ok() || n_nodes == 0 || n_nodes > 0xFFFF) { c.fail(); return false; }
+    struct Node { uint64_t bv_pos, bv_pos_rank; uint16_t parent, child[2]; };
+    std::vector<Node> nodes(n_nodes);
+    for (auto &nd : nodes) {  // 22-byte packed records
+        nd.bv_pos = c.get<uint64_t>();
+        nd.bv_pos_rank = c.get<uint64_t>();
+        nd.parent = c.get<uint16_t>();
+        nd.child[0] = c.get<uint16_t>();
+        nd.child[1] = c.get<uint16_t>();
+    }
+    uint16_t c_to_leaf[256];
+    for (auto &x : c_to_leaf) x = c.get<uint16_t>();
+    c.span(256 * 8);  // path[256]
+    if (!c.ok()) return false;
+    std::vector<int> leaf_symbol(n_nodes, -1);
+    for (int s = 0; s < 256; ++s)
+        if (c_to_leaf[s] != 0xFFFF) {
+            if (c_to_leaf[s] >= n_nodes) { c.fail(); return false; }
+            leaf_symbol[c_to_leaf[s]] = s;
+        }
+    // popcount directory: ones before each 64-bit word
+    const uint64_t nwords = (bv.bits + 63) / 64;
+    std::vector<uint64_t> before(nwords + 1, 0);
+    for (uint64_t w = 0; w < nwords; ++w) before[w + 1] = before[w] + __builtin_popcountll(bv.words[w]);
+    auto rank1 = [&](uint64_t p) {  // ones in bv[0,p)
+        const uint64_t w = p >> 6;
+        const unsigned b = p & 63;
+        return before[w] + (b ? __builtin_popcountll(bv.words[w] & ((uint64_t(1) << b) - 1)) : 0);
+    };
+    seq.resize(size);
+    for (uint64_t i = 0; i < size; ++i) {
+        uint32_t v = 0;
+        uint64_t pos = i;
+        unsigned depth = 0;
+        while (leaf_symbol[v] < 0) {
+            const uint64_t p = nodes[v].bv_pos + pos;
+            if (p >= bv.bits || ++depth > 256) { c.fail(); return false; }
+            const uint64_t ones_in_node = rank1(p) - nodes[v].bv_pos_rank;
+            const int b = bv.bit(p);
+            pos = b ? ones_in_node : pos - ones_in_node;
+            v = nodes[v].child[b];
+            if (v >= n_nodes) { c.fail(); return false; }
+        }
+        seq[i] = static_cast<uint8_t>(leaf_symbol[v]);
+    }
+    return true;
+}
+
+}  // namespace
+
+// ---- .rbwt ---------------------------------------------------------------------------------------
+int parse_rbwt(const std::string &fname, RawRle &out) {
+    Cursor c;
+    if (!c.open(fname)) return RBG_EIO;
+    out = RawRle();
+    out.n = c.get<uint64_t>();
+    out.R = c.get<uint64_t>();
+    out.B = c.get<uint64_t>();
+    if (!c.ok() || out.n == 0 || out.R == 0 || out.B == 0 || out.R > out.n) return RBG_EFORMAT;
+    uint64_t runs_u = 0;
+    std::vector<uint64_t> block_ends;  // `runs`: last position of every B-th run (rle_string.hpp:68,78)
+    if (!read_sparse(c, runs_u, block_ends)) return RBG_EFORMAT;
+    std::vector<std::vector<uint64_t>> letter_ones(256);
+    std::vector<uint64_t> letter_size(256, 0);
+    for (int s = 0; s < 256; ++s)
+        if (!read_sparse(c, letter_size[s], letter_ones[s])) return RBG_EFORMAT;
+    if (!read_wt_huff(c, out.heads)) return RBG_EFORMAT;
+    if (!c.at_end() || out.heads.size() != out.R || runs_u != out.n) return RBG_EFORMAT;
+    // run lengths: the k-th run of symbol s has length ones[k] - ones[k-1] in s-only space
+    // (sparse_sd_vector::gapAt, sparse_sd_vector.hpp:150-154; used by rle_string::run_at :238-242)
+    out.lens.resize(out.R);
+    std::vector<uint64_t> next(256, 0);
+    uint64_t total = 0;
+    for (uint64_t i = 0; i < out.R; ++i) {
+        const uint8_t s = out.heads[i];
+        if (i && s == out.heads[i - 1]) return RBG_EFORMAT;
+        const uint64_t k = next[s]++;
+        if (k >= letter_ones[s].size()) return RBG_EFORMAT;
+        const uint64_t len = k ? letter_ones[s][k] - letter_ones[s][k - 1] : letter_ones[s][0] + 1;
+        out.lens[i] = len;
+        total += len;
+        // cross-check against the block-sampled `runs` vector
+        if (i % out.B == out.B - 1 && i != out.R - 1) {
+            const uint64_t blk = i / out.B;
+            if (blk >= block_ends.size() || block_ends[blk] != total - 1) return RBG_EFORMAT;
+        }
+    }
+    for (int s = 0; s < 256; ++s) {
+        if (next[s] != letter_ones[s].size()) return RBG_EFORMAT;
+        if (!letter_ones[s].empty() && letter_ones[s].back() + 1 != letter_size[s]) return RBG_EFORMAT;
+    }
+    if (total != out.n) return RBG_EFORMAT;
+    return RBG_OK;
+}
+
+// ---- .tsa ----------------------------------------------------------------------------------------
+int parse_tsa(const std::string &fname, RawTsa &out) {
+    Cursor c;
+    if (!c.open(fname)) return RBG_EIO;
+    out = RawTsa();
+    out.r = c.get<uint64_t>();  // r first, then n (toehold_sa.hpp:86-87)
+    out.n = c.get<uint64_t>();
+    uint64_t u = 0;
+    if (!read_sparse(c, u, out.pred_pos)) return RBG_EFORMAT;
+    PackedVec sl, p2r;
+    if (!read_packed(c, sl, true) || !read_packed(c, p2r, true)) return RBG_EFORMAT;
+    if (!c.at_end() || u != out.n || out.pred_pos.size() != out.r || sl.size() != out.r || p2r.size() != out.r)
+        return RBG_EFORMAT;
+    out.samples_last.resize(out.r);
+    out.pred_to_run.resize(out.r);
+    for (uint64_t i = 0; i < out.r; ++i) {
+        out.samples_last[i] = sl.at(i);
+        out.pred_to_run[i] = p2r.at(i);
+        if (out.samples_last[i] >= out.n || out.pred_to_run[i] >= out.r) return RBG_EFORMAT;
+    }
+    return RBG_OK;
+}
+
+// toehold_sa.hpp:133-155 (sample = y ? y-1 : n-1) and build_phi :105-131
+void tsa_from_samples(uint64_t n, uint64_t r, const uint64_t *ssa_y, const uint64_t *esa_y, RawTsa &out) {
+    out = RawTsa();
+    out.n = n;
+    out.r = r;
+    out.samples_last.resize(r);
+    std::vector<uint64_t> first(r), order(r);
+    for (uint64_t i = 0; i < r; ++i) {
+        first[i] = ssa_y[i] ? ssa_y[i] - 1 : n - 1;
+        out.samples_last[i] = esa_y[i] ? esa_y[i] - 1 : n - 1;
+    }
+    std::iota(order.begin(), order.end(), uint64_t(0));
+    std::sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) {
+        return first[a] != first[b] ? first[a] < first[b] : a < b;
+    });
+    out.pred_pos.resize(r);
+    out.pred_to_run.resize(r);
+    for (uint64_t j = 0; j < r; ++j) {
+        out.pred_pos[j] = first[order[j]];
+        out.pred_to_run[j] = order[j];
+    }
+}
+
+// ---- .mab ----------------------------------------------------------------------------------------
+int parse_mab(const std::string &fname, RawMarkers &out) {
+    Cursor c;
+    if (!c.open(fname)) return RBG_EIO;
+    out = RawMarkers();
+    uint64_t u0 = 0, u1 = 0, u2 = 0;
+    std::vector<uint64_t> firsts;
+    if (!read_sd_vector(c, u0, out.start) || !read_sd_vector(c, u1, out.end) || !read_sd_vector(c, u2, firsts))
+        return RBG_EFORMAT;
+    const uint64_t count = c.get<uint64_t>();
+    if (!c.ok() || count > c.remaining() / 8) return RBG_EFORMAT;
+    out.vals.resize(count);
+    const uint8_t *p = c.span(count * 8);
+    if (count) std::memcpy(out.vals.data(), p, count * 8);
+    out.wsize = c.get<int32_t>();
+    const uint64_t nruns = out.start.size();
+    if (!c.at_end() || out.end.size() != nruns || firsts.size() != nruns) return RBG_EFORMAT;
+    out.off.assign(firsts.begin(), firsts.end());
+    out.off.push_back(count);
+    for (uint64_t j = 0; j < nruns; ++j)
+        if (out.end[j] < out.start[j] || out.off[j] > out.off[j + 1]) return RBG_EFORMAT;
+    return RBG_OK;
+}
+
+// ---- .docs ---------------------------------------------------------------------------------------
+int parse_docs(const std::string &fname, RawDocs &out) {
+    std::ifstream ifs(fname);
+    if (!ifs.good()) return RBG_EIO;
+    out = RawDocs();
+    std::string name;
+    uint64_t pos = 0;
+    while (ifs >> name >> pos) {  // doclist.hpp:62
+        out.names.push_back(name);
+        out.starts.push_back(pos);
+    }
+    out.sorted = out.starts;
+    std::sort(out.sorted.begin(), out.sorted.end());
+    return RBG_OK;
+}
+
+// ---- flatten -------------------------------------------------------------------------------------
+namespace {
+uint32_t auto_shift(uint64_t n, uint64_t items) {
+    // largest shift with (n >> shift) >= items: about one item per bucket, never more buckets than 2x items
+    if (items == 0) items = 1;
+    uint32_t s = 0;
+    while (s < 63 && (n >> (s + 1)) >= items) ++s;
+    return s;
+}
+void build_buckets(const std::vector<uint64_t> &sorted_pos, uint64_t count, uint64_t n, uint32_t shift,
+                   std::vector<uint32_t> &bucket) {
+    const uint64_t nb = (n >> shift) + 2;
+    bucket.assign(nb, 0);
+    // bucket[b] = # positions < (b << shift)
+    uint64_t k = 0;
+    for (uint64_t b = 0; b < nb; ++b) {
+        const unsigned __int128 lim = static_cast<unsigned __int128>(b) << shift;
+        while (k < count && static_cast<unsigned __int128>(sorted_pos[k]) < lim) ++k;
+        bucket[b] = static_cast<uint32_t>(k);
+    }
+}
+}  // namespace
+
+int flatten(const RawRle &rle, const RawTsa *tsa, const FlattenOptions &opt, HostIndex &out) {
+    const uint64_t R = rle.R;
+    if (R == 0 || rle.heads.size() != R || rle.lens.size() != R) return RBG_EARG;
+    if (R >= 0xFFFFFFF0ull) return RBG_EARG;  // bucket words are 32-bit run ordinals
+    if (tsa && (tsa->r != R || tsa->samples_last.size() != R || tsa->pred_pos.size() != R || tsa->pred_to_run.size() != R))
+        return RBG_EFORMAT;
+    out = HostIndex();
+    out.r = R;
+    out.run_heads = rle.heads;
+    out.run_start.resize(R + 1);
+    uint64_t cnt[256] = {0}, nr[256] = {0};
+    uint64_t pos = 0;
+    for (uint64_t i = 0; i < R; ++i) {
+        if (rle.lens[i] == 0) return RBG_EARG;
+        out.run_start[i] = pos;
+        pos += rle.lens[i];
+        cnt[rle.heads[i]] += rle.lens[i];
+        nr[rle.heads[i]]++;
+    }
+    out.run_start[R] = pos;
+    out.n = pos;
+    if (tsa && tsa->n != out.n) return RBG_EFORMAT;
+    // F column (RowBowt::build_f, rowbowt.hpp:770-778) and slots
+    std::memset(out.lut, 0xFF, sizeof(out.lut));
+    uint64_t acc = 0;
+    for (int s = 0; s < 256; ++s) {
+        out.f[s] = acc;
+        acc += cnt[s];
+        if (cnt[s]) {
+            out.lut[s] = static_cast<uint8_t>(out.sym.size());
+            SymTable t;
+            t.byte = static_cast<uint8_t>(s);
+            t.nruns = nr[s];
+            t.total = cnt[s];
+            t.F = out.f[s];
+            t.start.reserve(nr[s] + 1);
+            t.cum.reserve(nr[s] + 1);
+            if (tsa) t.samp.reserve(nr[s]);
+            out.sym.push_back(std::move(t));
+        }
+    }
+    out.f[256] = acc;
+    out.sigma = static_cast<uint32_t>(out.sym.size());
+    if (out.sigma > 255) return RBG_EARG;  // slot 0xFF is the "absent" marker
+    out.pos_bytes = opt.force_pos_bytes ? opt.force_pos_bytes : (out.n < 0xFFFFFFFFull ? 4 : 8);
+    if (out.pos_bytes == 4 && out.n >= 0xFFFFFFFFull) return RBG_EARG;
+    std::vector<uint64_t> seen(out.sigma, 0);
+    for (uint64_t i = 0; i < R; ++i) {
+        const uint32_t slot = out.lut[rle.heads[i]];
+        SymTable &t = out.sym[slot];
+        t.start.push_back(out.run_start[i]);
+        t.cum.push_back(seen[slot]);
+        if (tsa) t.samp.push_back(tsa->samples_last[i]);
+        seen[slot] += rle.lens[i];
+    }
+    for (SymTable &t : out.sym) {
+        t.start.push_back(out.n);
+        t.cum.push_back(t.total);
+        t.shift = opt.rank_bucket_shift >= 0 ? static_cast<uint32_t>(opt.rank_bucket_shift) : auto_shift(out.n, t.nruns);
+        if (((out.n >> t.shift) + 2) > 0xFFFFFFF0ull) return RBG_EARG;
+        build_buckets(t.start, t.nruns, out.n, t.shift, t.bucket);
+    }
+    if (tsa) {
+        out.has_tsa = true;
+        out.samples_last = tsa->samples_last;
+        out.pred_pos = tsa->pred_pos;
+        out.phi_base.resize(R);
+        for (uint64_t j = 0; j < R; ++j) {
+            const uint64_t run = tsa->pred_to_run[j];
+            out.phi_base[j] = run ? tsa->samples_last[run - 1] : 0;  // toehold_sa.hpp:67-70
+            if (j && out.pred_pos[j] <= out.pred_pos[j - 1]) return RBG_EFORMAT;
+        }
+        out.last_run_sample = (tsa->samples_last[R - 1] + 1) % out.n;  // toehold_sa.hpp:97-99
+        out.phi_shift = opt.phi_bucket_shift >= 0 ? static_cast<uint32_t>(opt.phi_bucket_shift) : auto_shift(out.n, R);
+        build_buckets(out.pred_pos, R, out.n, out.phi_shift, out.phi_bucket);
+    }
+    return RBG_OK;
+}
+
+}  // namespace rbg

@@ -1,0 +1,96 @@
+// rbg_host.hpp -- host side of the engine: readers for the reference's on-disk files and the
+// flattener that produces the HBM layout.  Pure C++17, no HIP, no sdsl.
+//
+// What it replaces in the reference (paths relative to the reference tree):
+//   rle_string::load            include/rle_string.hpp:265-275
+//   sparse_sd_vector::load      include/sparse_sd_vector.hpp:194-200   (sdsl::sd_vector<> bytes)
+//   huff_string::load           include/huff_string.hpp:61-63          (sdsl::wt_huff<> bytes)
+//   ToeholdSA::load / build_phi include/toehold_sa.hpp:85-91, :105-131
+//   DocList::load               include/doclist.hpp:57-73
+//   MarkerArray::load           pfbwt-f marker_array.hpp (un-vendored; layout per SURVEY 8b-format)
+//   RowBowt::build_f            include/rowbowt.hpp:770-778
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace rbg {
+
+// ---- decoded contents of the reference's files -------------------------------------------------
+struct RawRle {          // ri::rle_string, as a plain run-length BWT
+    uint64_t n = 0, R = 0, B = 0;
+    std::vector<uint8_t> heads;   // R
+    std::vector<uint64_t> lens;   // R
+};
+struct RawTsa {          // ToeholdSA members, toehold_sa.hpp:157-161
+    uint64_t r = 0, n = 0;
+    std::vector<uint64_t> pred_pos;      // set bits of pred_, ascending
+    std::vector<uint64_t> samples_last;  // BWT-run order
+    std::vector<uint64_t> pred_to_run;   // text order
+};
+struct RawMarkers {
+    std::vector<uint64_t> start, end;  // inclusive SA-index runs, ascending
+    std::vector<uint64_t> off;         // nruns+1 offsets into vals
+    std::vector<uint64_t> vals;        // MarkerT values
+    int32_t wsize = 0;
+};
+struct RawDocs {
+    std::vector<std::string> names;    // file order
+    std::vector<uint64_t> starts;      // file order
+    std::vector<uint64_t> sorted;      // ascending (the bit-vector view)
+};
+
+int parse_rbwt(const std::string &fname, RawRle &out);
+int parse_tsa(const std::string &fname, RawTsa &out);
+int parse_mab(const std::string &fname, RawMarkers &out);
+int parse_docs(const std::string &fname, RawDocs &out);
+// raw .ssa/.esa y values -> RawTsa (toehold_sa.hpp:105-155)
+void tsa_from_samples(uint64_t n, uint64_t r, const uint64_t *ssa_y, const uint64_t *esa_y, RawTsa &out);
+
+// ---- the flat layout, host copy ------------------------------------------------------------------
+// One table per distinct BWT symbol ("slot").  Entry k describes the k-th run of that symbol:
+//   start[k] = BWT position where the run begins (ascending),
+//   cum[k]   = number of this symbol in BWT[0, start[k])   (cum[nruns] = total),
+//   samp[k]  = ToeholdSA::samples_last_ of that run (only with a toehold SA).
+// bucket[b] = number of runs with start < (b << shift): a direct-addressed first level so that a
+// predecessor search touches one bucket word pair and then a handful of adjacent entries.
+struct SymTable {
+    uint8_t byte = 0;
+    uint32_t shift = 0;
+    uint64_t nruns = 0, total = 0, F = 0;
+    std::vector<uint64_t> start, cum;  // nruns + 1 (sentinel: start = n, cum = total)
+    std::vector<uint64_t> samp;        // nruns or empty
+    std::vector<uint32_t> bucket;      // (n >> shift) + 2
+};
+
+struct HostIndex {
+    uint64_t n = 0, r = 0;
+    uint32_t sigma = 0;
+    uint32_t pos_bytes = 8;
+    uint8_t lut[256];        // byte -> slot, 0xFF = symbol absent from the BWT
+    uint64_t f[257];         // f[c] = # symbols < c  (RowBowt::f_, plus f[256] = n)
+    std::vector<SymTable> sym;
+    std::vector<uint8_t> run_heads;    // R
+    std::vector<uint64_t> run_start;   // R + 1
+    // toehold SA
+    bool has_tsa = false;
+    uint64_t last_run_sample = 0;      // toehold_sa.hpp:97-99
+    std::vector<uint64_t> samples_last, pred_pos, phi_base;
+    uint32_t phi_shift = 0;
+    std::vector<uint32_t> phi_bucket;  // (n >> phi_shift) + 2 : # pred_pos < (b << phi_shift)
+    bool has_ma = false;
+    RawMarkers ma;
+    bool has_dl = false;
+    RawDocs dl;
+};
+
+struct FlattenOptions {
+    int rank_bucket_shift = -1;  // <0: automatic (about one run per bucket)
+    int phi_bucket_shift = -1;
+    int force_pos_bytes = 0;     // 0: 4 when n fits, else 8
+};
+
+int flatten(const RawRle &rle, const RawTsa *tsa, const FlattenOptions &opt, HostIndex &out);
+
+}  // namespace rbg

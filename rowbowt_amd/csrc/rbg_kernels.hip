@@ -1,0 +1,422 @@
+// rbg_kernels.hip -- gfx950 (MI355X, wave64) kernels for the rb_align hot path.
+//
+//  K1/K2  k_find_range<P,TOEHOLD>  batched backward search, one lane walks one read.
+//         Replaces RowBowt::find_range (rowbowt.hpp:121-131) / find_range_w_toehold (:169-184),
+//         i.e. m x { RowBowt::LF :74-88 -> 2 x rle_string::rank rle_string.hpp:131-161 } and the
+//         toehold update of LF_w_loc (:555-573).
+//  K3     k_locate_fill<P>         phi chains, ToeholdSA::locate_range toehold_sa.hpp:37-49 / phi :56-72.
+//  K4     k_markers_*              MarkerArray::at_range behind RowBowt::markers_at rowbowt.hpp:282-285.
+//
+// Integer gather kernels: no MFMA (nothing here is a contraction).  The bound is HBM / fabric
+// transactions per LF step, so the layout (rbg_dev.h) makes one rank = one bucket word pair +
+// one short run of adjacent RunEnt records, and both ranks of a step are issued back to back.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include "rbg_dev.h"
+
+namespace rbg {
+namespace {
+
+constexpr int kWave = 64;
+
+// ---- rank over one symbol table -----------------------------------------------------------------
+// Returns # of the symbol in BWT[0,i)  ==  rle_string::rank(i,c) (rle_string.hpp:131-161), via
+// the identity  rank = cum[j] + min(i - start[j], len[j])  for the last run j with start[j] < i.
+// *pred = j (or -1), *inside = (i-1 lies inside run j), used by the toehold update.
+template <typename P>
+__device__ __forceinline__ uint64_t rank_sym(const DevSym &S, uint64_t i, int64_t *pred, bool *inside) {
+    const RunEnt<P> *__restrict__ ent = static_cast<const RunEnt<P> *>(S.ent);
+    const uint64_t b = i >> S.shift;
+    uint32_t a = S.bucket[b];
+    uint32_t z = S.bucket[b + 1];
+    // runs [0,a) start below the bucket (hence below i); runs [z,..) start at or above i's bucket end
+    while (z - a > 4) {
+        const uint32_t mid = a + ((z - a) >> 1);
+        if (static_cast<uint64_t>(ent[mid].start) < i) a = mid + 1; else z = mid;
+    }
+    while (a < z && static_cast<uint64_t>(ent[a].start) < i) ++a;
+    if (a == 0) { *pred = -1; *inside = false; return 0; }
+    const uint32_t j = a - 1;
+    const RunEnt<P> e = ent[j];
+    const RunEnt<P> e1 = ent[j + 1];
+    const uint64_t len = static_cast<uint64_t>(e1.cum) - static_cast<uint64_t>(e.cum);
+    const uint64_t d = i - static_cast<uint64_t>(e.start);
+    *pred = j;
+    *inside = d <= len;
+    return static_cast<uint64_t>(e.cum) + (d < len ? d : len);
+}
+
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+    return v;
+}
+
+// ---- K1 / K2 ------------------------------------------------------------------------------------
+template <typename P, bool TOEHOLD>
+__global__ __launch_bounds__(256) void k_find_range(const DevIndex ix, const uint8_t *__restrict__ seqs,
+                                                    const uint64_t *__restrict__ off, const uint64_t N,
+                                                    uint64_t *__restrict__ lo_out, uint64_t *__restrict__ hi_out,
+                                                    uint64_t *__restrict__ ss_out) {
+    __shared__ uint8_t s_lut[256];
+    __shared__ DevSym s_sym[kLdsSyms];
+    for (int t = threadIdx.x; t < 256; t += blockDim.x) s_lut[t] = ix.lut[t];
+    const int nlds = ix.sigma < static_cast<uint32_t>(kLdsSyms) ? static_cast<int>(ix.sigma) : kLdsSyms;
+    for (int t = threadIdx.x; t < nlds; t += blockDim.x) s_sym[t] = ix.syms[t];
+    __syncthreads();
+
+    const uint64_t *__restrict__ words = reinterpret_cast<const uint64_t *>(seqs);
+    unsigned long long c_reads = 0, c_matched = 0, c_occ = 0;
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < N; i += stride) {
+        const uint64_t beg = off[i];
+        uint64_t p = off[i + 1];
+        uint64_t lo = 0, hi = ix.n - 1;  // full_range(), rowbowt.hpp:115-118
+        uint64_t k = TOEHOLD ? ix.last_run_sample : 0;
+        uint64_t cur_wi = ~uint64_t(0), w = 0;
+        bool alive = true;
+        while (p > beg) {  // right-to-left over the read (rowbowt.hpp:127-129, :175-181)
+            --p;
+            const uint64_t wi = p >> 3;
+            if (wi != cur_wi) { w = words[wi]; cur_wi = wi; }
+            const uint32_t c = static_cast<uint32_t>(w >> ((p & 7) * 8)) & 0xFFu;
+            const uint32_t slot = s_lut[c];
+            if (slot == 0xFFu) { alive = false; break; }  // symbol absent: f_[c] >= f_[c+1], rowbowt.hpp:76
+            const DevSym S = slot < static_cast<uint32_t>(kLdsSyms) ? s_sym[slot] : ix.syms[slot];
+            int64_t pj, qj;
+            bool pin, qin;
+            const uint64_t c_before = rank_sym<P>(S, lo, &pj, &pin);       // rowbowt.hpp:79
+            const uint64_t c_upto = rank_sym<P>(S, hi + 1, &qj, &qin);     // rowbowt.hpp:83
+            const uint64_t c_inside = c_upto - c_before;
+            if (c_inside == 0) { alive = false; break; }                   // rowbowt.hpp:85
+            if (TOEHOLD) {
+                // LF_w_loc, rowbowt.hpp:559-566.  Run qj is the last run of c starting at or before
+                // hi: either it contains hi (bwt_[hi]==c -> k-1), or it ends before hi and its last
+                // position is select(rank(hi,c)-1,c), whose run-end sample is samples_last_[run].
+                if (qin) k = k - 1;
+                else k = static_cast<uint64_t>(static_cast<const P *>(S.samp)[qj]);
+            }
+            lo = S.F + c_before;           // rowbowt.hpp:86
+            hi = lo + c_inside - 1;        // rowbowt.hpp:87
+        }
+        if (!alive) { lo = 1; hi = 0; k = 0; }  // {1,0}; LFData::clear rowbowt.hpp:153-159
+        lo_out[i] = lo;
+        hi_out[i] = hi;
+        if (TOEHOLD) ss_out[i] = k;
+        c_reads += 1;
+        if (alive) { c_matched += 1; c_occ += hi - lo + 1; }
+    }
+    c_reads = wave_sum(c_reads);
+    c_matched = wave_sum(c_matched);
+    c_occ = wave_sum(c_occ);
+    if ((threadIdx.x & (kWave - 1)) == 0 && c_reads) {
+        atomicAdd(&ix.counters[0], c_reads);
+        if (c_matched) atomicAdd(&ix.counters[1], c_matched);
+        if (c_occ) atomicAdd(&ix.counters[2], c_occ);
+    }
+}
+
+// ---- K3: locate ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_occ(const uint64_t *__restrict__ lo, const uint64_t *__restrict__ hi,
+                                             const uint64_t N, const uint64_t max_hits, uint64_t *__restrict__ out) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < N; i += stride) {
+        uint64_t occ = hi[i] >= lo[i] ? hi[i] - lo[i] + 1 : 0;  // toehold_sa.hpp:38-39
+        if (occ > max_hits) occ = max_hits;
+        out[i + 1] = occ;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[0] = 0;
+}
+
+template <typename P>
+__device__ __forceinline__ uint64_t phi_step(const DevIndex &ix, uint64_t i) {
+    const PhiEnt<P> *__restrict__ ent = static_cast<const PhiEnt<P> *>(ix.phi_ent);
+    const uint64_t b = i >> ix.phi_shift;
+    uint32_t a = ix.phi_bucket[b];
+    uint32_t z = ix.phi_bucket[b + 1];
+    while (z - a > 4) {
+        const uint32_t mid = a + ((z - a) >> 1);
+        if (static_cast<uint64_t>(ent[mid].pos) < i) a = mid + 1; else z = mid;
+    }
+    while (a < z && static_cast<uint64_t>(ent[a].pos) < i) ++a;
+    // a == pred_.rank(i); circular predecessor (sparse_sd_vector.hpp:141-143)
+    const uint64_t jr = a ? a - 1 : ix.r - 1;
+    const PhiEnt<P> e = ent[jr];
+    const uint64_t j = e.pos;
+    const uint64_t delta = j < i ? i - j : i + 1;  // toehold_sa.hpp:65
+    uint64_t s = static_cast<uint64_t>(e.base) + delta;
+    if (s >= ix.n) s -= ix.n;  // (prev_sample + delta) % n_, both terms <= n
+    return s;
+}
+
+template <typename P>
+__global__ __launch_bounds__(256) void k_locate_fill(const DevIndex ix, const uint64_t *__restrict__ lo,
+                                                     const uint64_t *__restrict__ hi, const uint64_t *__restrict__ k,
+                                                     const uint64_t N, const uint64_t max_hits,
+                                                     const uint64_t *__restrict__ loc_off, uint64_t *__restrict__ locs) {
+    unsigned long long c_locs = 0;
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < N; i += stride) {
+        const uint64_t l = lo[i], h = hi[i];
+        uint64_t occ = h >= l ? h - l + 1 : 0;
+        if (occ > max_hits) occ = max_hits;
+        if (occ == 0) continue;
+        uint64_t *dst = locs + loc_off[i];
+        uint64_t k1 = k[i];
+        dst[0] = k1;
+        for (uint64_t t = 1; t < occ; ++t) {
+            k1 = phi_step<P>(ix, k1);
+            dst[t] = k1;
+        }
+        c_locs += occ;
+    }
+    c_locs = wave_sum(c_locs);
+    if ((threadIdx.x & (kWave - 1)) == 0 && c_locs) atomicAdd(&ix.counters[3], c_locs);
+}
+
+// ---- K4: markers --------------------------------------------------------------------------------
+// runs are disjoint, ascending inclusive SA-index intervals; at_range(lo,hi) = values of all runs
+// with start <= hi && end >= lo, in run order.
+__device__ __forceinline__ void marker_span(const DevIndex &ix, uint64_t lo, uint64_t hi, uint64_t *first, uint64_t *last) {
+    uint64_t a = 0, z = ix.mk_nruns;
+    while (a < z) { const uint64_t m = a + ((z - a) >> 1); if (ix.mk_end[m] < lo) a = m + 1; else z = m; }
+    *first = a;  // first run with end >= lo
+    a = 0; z = ix.mk_nruns;
+    while (a < z) { const uint64_t m = a + ((z - a) >> 1); if (ix.mk_start[m] <= hi) a = m + 1; else z = m; }
+    *last = a;   // one past the last run with start <= hi
+}
+
+__global__ __launch_bounds__(256) void k_markers_count(const DevIndex ix, const uint64_t *__restrict__ lo,
+                                                       const uint64_t *__restrict__ hi, const uint64_t N,
+                                                       uint64_t *__restrict__ out) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < N; i += stride) {
+        uint64_t cnt = 0;
+        if (hi[i] >= lo[i]) {
+            uint64_t f, l;
+            marker_span(ix, lo[i], hi[i], &f, &l);
+            if (l > f) cnt = ix.mk_off[l] - ix.mk_off[f];
+        }
+        out[i + 1] = cnt;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[0] = 0;
+}
+
+__global__ __launch_bounds__(256) void k_markers_fill(const DevIndex ix, const uint64_t *__restrict__ lo,
+                                                      const uint64_t *__restrict__ hi, const uint64_t N,
+                                                      const uint64_t *__restrict__ mk_off, uint64_t *__restrict__ mk) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < N; i += stride) {
+        if (hi[i] < lo[i]) continue;
+        uint64_t f, l;
+        marker_span(ix, lo[i], hi[i], &f, &l);
+        if (l <= f) continue;
+        const uint64_t src = ix.mk_off[f], cnt = ix.mk_off[l] - src;
+        uint64_t *dst = mk + mk_off[i];
+        for (uint64_t t = 0; t < cnt; ++t) dst[t] = ix.mk_vals[src + t];
+    }
+}
+
+
+// ---- find_range_w_markers (rowbowt.hpp:292-339) --------------------------------------------------
+// Backward search that queries the marker array at every window end (:315-323) and once more at
+// the end when (m-1) % wsize != 0 (:328-335).  Window results are PREPENDED in the reference
+// (:320,:333), so query q's markers land at  total - (c_0 + ... + c_q).
+// FILL=false: count pass (writes lo/hi and per-read totals to cnt_out[i+1]);
+// FILL=true : re-walks the read and writes the markers at mk_off[i].
+template <typename P, bool FILL>
+__global__ __launch_bounds__(256) void k_find_range_markers(const DevIndex ix, const uint8_t *__restrict__ seqs,
+                                                            const uint64_t *__restrict__ off, const uint64_t N,
+                                                            const uint64_t wsize, const uint64_t max_range,
+                                                            uint64_t *__restrict__ lo_out, uint64_t *__restrict__ hi_out,
+                                                            uint64_t *__restrict__ cnt_out,
+                                                            const uint64_t *__restrict__ mk_off, uint64_t *__restrict__ mk) {
+    __shared__ uint8_t s_lut[256];
+    __shared__ DevSym s_sym[kLdsSyms];
+    for (int t = threadIdx.x; t < 256; t += blockDim.x) s_lut[t] = ix.lut[t];
+    const int nlds = ix.sigma < static_cast<uint32_t>(kLdsSyms) ? static_cast<int>(ix.sigma) : kLdsSyms;
+    for (int t = threadIdx.x; t < nlds; t += blockDim.x) s_sym[t] = ix.syms[t];
+    __syncthreads();
+    const uint64_t *__restrict__ words = reinterpret_cast<const uint64_t *>(seqs);
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    if (!FILL && blockIdx.x == 0 && threadIdx.x == 0) cnt_out[0] = 0;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < N; i += stride) {
+        const uint64_t beg = off[i], end = off[i + 1], m = end - beg;
+        uint64_t total = 0;
+        uint64_t lo = 1, hi = 0;
+        bool alive = m >= wsize;  // rowbowt.hpp:299-302: shorter queries return the default LFData
+        if (alive) {
+            lo = 0; hi = ix.n - 1;
+            uint64_t window_ei = m, acc = 0;
+            const uint64_t want = FILL ? mk_off[i + 1] - mk_off[i] : 0;
+            uint64_t *dst = FILL ? mk + mk_off[i] : nullptr;
+            uint64_t cur_wi = ~uint64_t(0), w = 0;
+            for (uint64_t s = 0; s <= m; ++s) {
+                bool query;
+                if (s < m) {
+                    const uint64_t p = end - 1 - s;
+                    const uint64_t wi = p >> 3;
+                    if (wi != cur_wi) { w = words[wi]; cur_wi = wi; }
+                    const uint32_t c = static_cast<uint32_t>(w >> ((p & 7) * 8)) & 0xFFu;
+                    const uint32_t slot = s_lut[c];
+                    if (slot == 0xFFu) { alive = false; break; }
+                    const DevSym S = slot < static_cast<uint32_t>(kLdsSyms) ? s_sym[slot] : ix.syms[slot];
+                    int64_t pj; bool pin;
+                    const uint64_t c_before = rank_sym<P>(S, lo, &pj, &pin);
+                    const uint64_t c_inside = rank_sym<P>(S, hi + 1, &pj, &pin) - c_before;
+                    if (c_inside == 0) { alive = false; break; }
+                    lo = S.F + c_before;
+                    hi = lo + c_inside - 1;
+                    query = window_ei - (m - s) >= wsize;  // :315
+                    if (query) window_ei = m - s;          // :322
+                } else {
+                    query = (m - 1) % wsize != 0;          // :328
+                }
+                if (query && hi - lo + 1 <= max_range) {   // :318,:331
+                    uint64_t f, l;
+                    marker_span(ix, lo, hi, &f, &l);
+                    if (l > f) {
+                        const uint64_t src = ix.mk_off[f], cnt = ix.mk_off[l] - src;
+                        acc += cnt;
+                        if (FILL) {
+                            uint64_t *d = dst + (want - acc);
+                            for (uint64_t t = 0; t < cnt; ++t) d[t] = ix.mk_vals[src + t];
+                        }
+                    }
+                }
+            }
+            total = alive ? acc : 0;
+            if (!alive) { lo = 1; hi = 0; }  // lf.clear(), :311-313
+        }
+        if (!FILL) {
+            lo_out[i] = lo;
+            hi_out[i] = hi;
+            cnt_out[i + 1] = total;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_count(const uint64_t *__restrict__ lo, const uint64_t *__restrict__ hi,
+                                               const uint64_t N, uint64_t *__restrict__ out) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < N; i += stride)
+        out[i] = hi[i] >= lo[i] ? hi[i] - lo[i] + 1 : 0;  // RowBowt::count, rowbowt.hpp:266-269
+}
+
+int grid_for(const LaunchCfg &cfg, uint64_t N) {
+    const int bt = cfg.block_threads;
+    uint64_t blocks = (N + bt - 1) / bt;
+    const uint64_t cap = cfg.max_blocks > 0 ? static_cast<uint64_t>(cfg.max_blocks) : 256ull * 32;
+    if (blocks > cap) blocks = cap;
+    if (blocks == 0) blocks = 1;
+    return static_cast<int>(blocks);
+}
+
+}  // namespace
+
+int launch_find_range(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
+                      uint64_t *lo, uint64_t *hi, uint64_t *ssamp, void *stream) {
+    if (N == 0) return 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid(grid_for(cfg, N)), block(cfg.block_threads);
+    const bool toe = ssamp != nullptr;
+    if (ix.pos_bytes == 4) {
+        if (toe) hipLaunchKernelGGL((k_find_range<uint32_t, true>), grid, block, 0, st, ix, seqs, off, N, lo, hi, ssamp);
+        else hipLaunchKernelGGL((k_find_range<uint32_t, false>), grid, block, 0, st, ix, seqs, off, N, lo, hi, ssamp);
+    } else {
+        if (toe) hipLaunchKernelGGL((k_find_range<uint64_t, true>), grid, block, 0, st, ix, seqs, off, N, lo, hi, ssamp);
+        else hipLaunchKernelGGL((k_find_range<uint64_t, false>), grid, block, 0, st, ix, seqs, off, N, lo, hi, ssamp);
+    }
+    return static_cast<int>(hipGetLastError());
+}
+
+size_t scan_tmp_bytes(uint64_t N) {
+    size_t bytes = 0;
+    uint64_t *p = nullptr;
+    (void)hipcub::DeviceScan::InclusiveSum(nullptr, bytes, p, p, static_cast<int64_t>(N ? N : 1));
+    return bytes + 256;
+}
+
+static int scan_in_place(uint64_t *vals, uint64_t N, void *tmp, size_t tmp_bytes, hipStream_t st) {
+    if (N == 0) return 0;
+    size_t need = 0;
+    (void)hipcub::DeviceScan::InclusiveSum(nullptr, need, vals, vals, static_cast<int64_t>(N));
+    if (need > tmp_bytes) return static_cast<int>(hipErrorInvalidValue);
+    return static_cast<int>(hipcub::DeviceScan::InclusiveSum(tmp, need, vals, vals, static_cast<int64_t>(N), st));
+}
+
+int launch_locate_plan(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t *lo, const uint64_t *hi, uint64_t N,
+                       uint64_t max_hits, uint64_t *loc_off, void *tmp, size_t tmp_bytes, void *stream) {
+    (void)ix;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(k_occ, dim3(grid_for(cfg, N)), dim3(cfg.block_threads), 0, st, lo, hi, N, max_hits, loc_off);
+    int rc = static_cast<int>(hipGetLastError());
+    if (rc) return rc;
+    return scan_in_place(loc_off + 1, N, tmp, tmp_bytes, st);
+}
+
+int launch_locate_fill(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t *lo, const uint64_t *hi,
+                       const uint64_t *k, uint64_t N, uint64_t max_hits, const uint64_t *loc_off, uint64_t *locs,
+                       void *stream) {
+    if (N == 0) return 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid(grid_for(cfg, N)), block(cfg.block_threads);
+    if (ix.pos_bytes == 4) hipLaunchKernelGGL((k_locate_fill<uint32_t>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, locs);
+    else hipLaunchKernelGGL((k_locate_fill<uint64_t>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, locs);
+    return static_cast<int>(hipGetLastError());
+}
+
+int launch_markers_plan(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t *lo, const uint64_t *hi, uint64_t N,
+                        uint64_t *mk_off, void *tmp, size_t tmp_bytes, void *stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(k_markers_count, dim3(grid_for(cfg, N)), dim3(cfg.block_threads), 0, st, ix, lo, hi, N, mk_off);
+    int rc = static_cast<int>(hipGetLastError());
+    if (rc) return rc;
+    return scan_in_place(mk_off + 1, N, tmp, tmp_bytes, st);
+}
+
+int launch_markers_fill(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t *lo, const uint64_t *hi, uint64_t N,
+                        const uint64_t *mk_off, uint64_t *mk, void *stream) {
+    if (N == 0) return 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(k_markers_fill, dim3(grid_for(cfg, N)), dim3(cfg.block_threads), 0, st, ix, lo, hi, N, mk_off, mk);
+    return static_cast<int>(hipGetLastError());
+}
+
+
+int launch_find_range_markers_plan(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off,
+                                   uint64_t N, uint64_t wsize, uint64_t max_range, uint64_t *lo, uint64_t *hi,
+                                   uint64_t *mk_off, void *tmp, size_t tmp_bytes, void *stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid(grid_for(cfg, N)), block(cfg.block_threads);
+    if (ix.pos_bytes == 4)
+        hipLaunchKernelGGL((k_find_range_markers<uint32_t, false>), grid, block, 0, st, ix, seqs, off, N, wsize, max_range, lo, hi, mk_off, nullptr, nullptr);
+    else
+        hipLaunchKernelGGL((k_find_range_markers<uint64_t, false>), grid, block, 0, st, ix, seqs, off, N, wsize, max_range, lo, hi, mk_off, nullptr, nullptr);
+    int rc = static_cast<int>(hipGetLastError());
+    if (rc) return rc;
+    return scan_in_place(mk_off + 1, N, tmp, tmp_bytes, st);
+}
+
+int launch_find_range_markers_fill(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off,
+                                   uint64_t N, uint64_t wsize, uint64_t max_range, const uint64_t *mk_off, uint64_t *mk,
+                                   void *stream) {
+    if (N == 0) return 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid(grid_for(cfg, N)), block(cfg.block_threads);
+    if (ix.pos_bytes == 4)
+        hipLaunchKernelGGL((k_find_range_markers<uint32_t, true>), grid, block, 0, st, ix, seqs, off, N, wsize, max_range, nullptr, nullptr, nullptr, mk_off, mk);
+    else
+        hipLaunchKernelGGL((k_find_range_markers<uint64_t, true>), grid, block, 0, st, ix, seqs, off, N, wsize, max_range, nullptr, nullptr, nullptr, mk_off, mk);
+    return static_cast<int>(hipGetLastError());
+}
+
+int launch_count_from_ranges(const uint64_t *lo, const uint64_t *hi, uint64_t N, uint64_t *count, void *stream) {
+    if (N == 0) return 0;
+    LaunchCfg cfg;
+    hipLaunchKernelGGL(k_count, dim3(grid_for(cfg, N)), dim3(256), 0, static_cast<hipStream_t>(stream), lo, hi, N, count);
+    return static_cast<int>(hipGetLastError());
+}
+
+}  // namespace rbg

@@ -1,0 +1,129 @@
+"""CPU-only checks of the product's host side: the C-ABI library loads and exports every symbol
+include/rbg.h declares, the sdsl readers + flattener reproduce what the oracle's independent
+reader decodes, and query entry points refuse to run without a device (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import orc
+import rowbowt_amd as ra
+from rowbowt_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_exports_match_header():
+    hdr = open(os.path.join(ROOT, "include", "rbg.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(rbg_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(capi.EXPORTS)
+    L = ra.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.rbg_abi_version() == 1
+    assert b"CPU" in L.rbg_strerror(-3)
+
+
+@pytest.fixture(scope="module")
+def small_host(data_dir):
+    rb = ra.load_rowbowt(os.path.join(data_dir, "small.fa"), ra.LoadRbwtFlag.SA | ra.LoadRbwtFlag.MA, device=capi.DEVICE_NONE)
+    yield rb
+    rb.close()
+
+
+@pytest.fixture(scope="module")
+def small_orc(data_dir):
+    o = orc.Oracle.load(os.path.join(data_dir, "small.fa"), orc.SA | orc.MA)
+    yield o
+    o.close()
+
+
+def test_loader_matches_oracle_reader(small_host, small_orc):
+    i = small_host.info()
+    assert (i.n, i.r, i.sigma, i.pos_bytes, i.device) == (30031, 7573, 5, 4, -1)
+    assert i.has_tsa and i.has_markers and not i.has_docs
+    heads, lens = small_orc.runs()
+    assert (small_host.host_array(capi.ARR_RUN_HEADS) == heads).all()
+    starts = np.concatenate(([0], np.cumsum(lens))).astype(np.uint64)
+    assert (small_host.host_array(capi.ARR_RUN_START) == starts).all()
+    assert (small_host.get_f() == small_orc.f()).all()
+    pred_pos, samples_last, pred_to_run = small_orc.tsa()
+    assert (small_host.host_array(capi.ARR_PRED_POS) == pred_pos).all()
+    assert (small_host.host_array(capi.ARR_SAMPLES_LAST) == samples_last).all()
+    base = np.where(pred_to_run > 0, samples_last[np.maximum(pred_to_run.astype(np.int64) - 1, 0)], 0)
+    assert (small_host.host_array(capi.ARR_PHI_BASE) == base.astype(np.uint64)).all()
+    assert small_host.last_run_sample() == small_orc.last_run_sample()
+    s, e, o, v = small_orc.markers()
+    assert (small_host.host_array(capi.ARR_MARKER_START) == s).all()
+    assert (small_host.host_array(capi.ARR_MARKER_END) == e).all()
+    assert (small_host.host_array(capi.ARR_MARKER_OFF) == o).all()
+    assert (small_host.host_array(capi.ARR_MARKER_VALS) == v).all()
+    assert i.marker_runs == 190 and i.marker_vals == 190
+
+
+def test_greedy_seeding_fixture(data_dir):
+    rb = ra.load_rowbowt(os.path.join(data_dir, "greedy_seeding", "ref.fa"),
+                         ra.LoadRbwtFlag.SA | ra.LoadRbwtFlag.DL, device=capi.DEVICE_NONE)
+    i = rb.info()
+    assert (i.n, i.r) == (20047, 14949) and i.has_docs
+    assert rb.resolve_offset(1234) == ("greedy_seeding", 1234)
+    assert rb.resolve_offset(0) == ("greedy_seeding", 0)
+    rb.close()
+
+
+def test_resolve_offset_matches_oracle(small_host, small_orc):
+    names, starts = ["ref", "hap1", "hap2"], [0, 10010, 20020]
+    small_host.set_docs(names, starts)
+    small_orc.set_docs(names, starts)
+    for i in (0, 1, 9999, 10009, 10010, 10011, 20019, 20020, 25000, 30030):
+        assert small_host.resolve_offset(i) == small_orc.resolve_offset(i)
+
+
+def test_errors(tmp_path, data_dir):
+    with pytest.raises(ra.RbgError) as e:
+        ra.load_rowbowt(str(tmp_path / "nope"), device=capi.DEVICE_NONE)
+    assert e.value.code == -1  # RBG_EIO: reference prints "bad file" and exit(1)s
+    bad = tmp_path / "bad.rbwt"
+    raw = open(os.path.join(data_dir, "small.fa.rbwt"), "rb").read()
+    bad.write_bytes(raw[:-7])
+    with pytest.raises(ra.RbgError) as e:
+        ra.load_rowbowt(str(tmp_path / "bad"), device=capi.DEVICE_NONE)
+    assert e.value.code == -2
+    bad.write_bytes(raw + b"\0")
+    with pytest.raises(ra.RbgError) as e:
+        ra.load_rowbowt(str(tmp_path / "bad"), device=capi.DEVICE_NONE)
+    assert e.value.code == -2
+    # .tsa requested but absent
+    (tmp_path / "only.rbwt").write_bytes(raw)
+    with pytest.raises(ra.RbgError) as e:
+        ra.load_rowbowt(str(tmp_path / "only"), ra.LoadRbwtFlag.SA, device=capi.DEVICE_NONE)
+    assert e.value.code == -1
+
+
+def test_no_cpu_compute_path(small_host):
+    """Without a device the query entry points must refuse (RBG_ENODEV), not compute on the CPU."""
+    seqs, off = ra.pack_reads([b"ACGT"])
+    for fn in (lambda: small_host.find_range(seqs, off), lambda: small_host.count(seqs, off),
+               lambda: small_host.find_range_w_toehold(seqs, off),
+               lambda: small_host.locs_at([0], [1], [5]), lambda: small_host.markers_at([0], [1]),
+               lambda: small_host.find_range_w_markers(seqs, off, 2)):
+        with pytest.raises(ra.RbgError) as e:
+            fn()
+        assert e.value.code == -3
+
+
+def test_build_from_runs_layout():
+    heads = np.frombuffer(b"ACAG\x01T", dtype=np.uint8)
+    lens = np.array([3, 2, 1, 4, 1, 2], dtype=np.uint64)
+    rb = ra.RowBowt.from_runs(heads, lens, device=capi.DEVICE_NONE)
+    i = rb.info()
+    assert (i.n, i.r, i.sigma) == (13, 6, 5)
+    f = rb.get_f()
+    assert [int(f[c]) for c in (1, 65, 67, 71, 84)] == [0, 1, 5, 7, 11]
+    assert rb.host_array(capi.ARR_RUN_START).tolist() == [0, 3, 5, 6, 10, 11, 13]
+    rb.close()
+    with pytest.raises(ra.RbgError):  # non-maximal runs
+        ra.RowBowt.from_runs(np.frombuffer(b"AAC", dtype=np.uint8), np.array([1, 1, 1], np.uint64), device=capi.DEVICE_NONE)

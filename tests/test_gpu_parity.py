@@ -1,0 +1,242 @@
+"""Parity tests proper: the HIP path (through the C-ABI) against the oracle and the reference's
+golden values.  Bit-exact: everything on this path is unsigned 64-bit integer work.  Need an MI355X."""
+import os
+
+import numpy as np
+import pytest
+
+import golden_values as G
+import orc
+import rowbowt_amd as ra
+from rowbowt_amd import capi
+from synth import SynthIndex
+
+pytestmark = pytest.mark.gpu
+MAXU = G.MAXU
+ALL = ra.LoadRbwtFlag.SA | ra.LoadRbwtFlag.MA
+
+
+@pytest.fixture(scope="module")
+def small(data_dir):
+    rb = ra.load_rowbowt(os.path.join(data_dir, "small.fa"), ALL, device=0)
+    o = orc.Oracle.load(os.path.join(data_dir, "small.fa"), orc.SA | orc.MA)
+    yield rb, o
+    rb.close()
+    o.close()
+
+
+@pytest.fixture(scope="module")
+def simple_reads(data_dir):
+    return orc.read_fastx(os.path.join(data_dir, "simple_query.fq"))[1]
+
+
+@pytest.fixture(scope="module")
+def error_reads(data_dir):
+    return orc.read_fastx(os.path.join(data_dir, "error_query.fq"))[1]
+
+
+def split(off, vals):
+    return [vals[int(off[i]):int(off[i + 1])].tolist() for i in range(len(off) - 1)]
+
+
+# ---- the reference's own golden vectors, through the HIP path ------------------------------------
+def test_golden_count(small, simple_reads):
+    rb, _ = small
+    seqs, off = ra.pack_reads(simple_reads)
+    lo, hi = rb.find_range(seqs, off)
+    assert list(zip(lo.tolist(), hi.tolist())) == G.SIMPLE_RANGES  # rb_tests.cpp:115-120
+    assert rb.count(seqs, off).tolist() == [h - l + 1 for l, h in G.SIMPLE_RANGES]
+
+
+def test_golden_kmers(small):
+    rb, _ = small
+    qs = list(G.KMER_RANGES)
+    lo, hi = rb.find_range(*ra.pack_reads(qs))
+    assert list(zip(lo.tolist(), hi.tolist())) == [G.KMER_RANGES[q] for q in qs]  # rb_tests.cpp:147-173
+
+
+def test_golden_locate(small, simple_reads):
+    rb, _ = small
+    seqs, off = ra.pack_reads(simple_reads)
+    lo, hi, k = rb.find_range_w_toehold(seqs, off)
+    assert list(zip(lo.tolist(), hi.tolist())) == G.SIMPLE_RANGES
+    loc_off, locs = rb.locs_at(lo, hi, k, MAXU)
+    assert locs.tolist() == G.SIMPLE_ALL_LOCS  # rb_tests.cpp:47-58
+    assert split(loc_off, locs) == G.SIMPLE_LOCS_PER_READ
+
+
+def test_golden_markers(small, simple_reads):
+    rb, _ = small
+    seqs, off = ra.pack_reads(simple_reads)
+    lo, hi, mk_off, mk = rb.find_range_w_markers(seqs, off, 10, MAXU)  # rb_tests.cpp:126
+    assert list(zip(lo.tolist(), hi.tolist())) == G.SIMPLE_RANGES
+    for got, want in zip(split(mk_off, mk), G.SIMPLE_FIRST_MARKER):  # rb_tests.cpp:131-140
+        if want is None:
+            assert got == []
+        else:
+            assert (G.get_pos(got[0]), G.get_allele(got[0])) == want
+
+
+def test_error_reads(small, error_reads):
+    rb, o = small
+    seqs, off = ra.pack_reads(error_reads)
+    lo, hi, k = rb.find_range_w_toehold(seqs, off)
+    want = [o.find_range_w_toehold(q) for q in error_reads]
+    assert list(zip(lo.tolist(), hi.tolist(), k.tolist())) == want
+    assert want[0] == (1, 0, 0)
+
+
+# ---- config 1 of BASELINE.json: toy index, 10k synthetic 100 bp reads ---------------------------
+def test_config1_toy_10k(small):
+    import naive
+    from test_oracle_vs_naive import sample_reads
+    rb, o = small
+    heads, lens = o.runs()
+    text = naive.invert_bwt(naive.expand_bwt(heads, lens))
+    rng = np.random.default_rng(20240231)
+    reads = sample_reads(text, 10000, 100, rng, spans=[(0, 10000), (10010, 20010), (20020, 30020)])
+    seqs, off = ra.pack_reads(reads)
+    rb.counters_reset()
+    lo, hi, k = rb.find_range_w_toehold(seqs, off)
+    wlo, whi, wk = o.find_range_w_toehold_batch(seqs, off, nthreads=4)
+    assert (lo == wlo).all() and (hi == whi).all() and (k == wk).all()
+    lo2, hi2 = rb.find_range(seqs, off)
+    assert (lo2 == wlo).all() and (hi2 == whi).all()
+    loc_off, locs = rb.locs_at(lo, hi, k)
+    woff, wlocs = o.locs_at_batch(wlo, whi, wk, nthreads=4)
+    assert (loc_off == woff).all() and (locs == wlocs).all()
+    # counters: {reads, matched, sum occ, sum locs}; two find_range passes + one locate
+    occ = np.where(whi >= wlo, whi - wlo + 1, 0)
+    c = rb.counters()
+    assert c.tolist() == [20000, 2 * int((whi >= wlo).sum()), 2 * int(occ.sum()), int(occ.sum())]
+
+
+# ---- synthetic pangenomes: both position widths, several bucket shifts, ragged reads ------------
+@pytest.fixture(scope="module")
+def synth():
+    return SynthIndex(L=4000, H=8, n_sites=60, seed=11)
+
+
+@pytest.mark.parametrize("pos_bytes,rshift,pshift", [(0, -1, -1), (8, -1, -1), (4, 0, 0), (8, 3, 2), (4, 12, 12), (8, 40, 40)])
+def test_synth_all_paths(synth, pos_bytes, rshift, pshift):
+    S = synth
+    ra.set_default_option(capi.OPT_POS_BYTES, pos_bytes)
+    ra.set_default_option(capi.OPT_RANK_BUCKET_SHIFT, rshift)
+    ra.set_default_option(capi.OPT_PHI_BUCKET_SHIFT, pshift)
+    try:
+        rb = ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0)
+    finally:
+        for o_ in (capi.OPT_POS_BYTES, capi.OPT_RANK_BUCKET_SHIFT, capi.OPT_PHI_BUCKET_SHIFT):
+            ra.set_default_option(o_, 0 if o_ == capi.OPT_POS_BYTES else -1)
+    o = orc.Oracle.from_runs(S.heads, S.lens, S.ssa, S.esa)
+    assert rb.info().pos_bytes == (pos_bytes or 4)
+    reads = S.sample_reads(3000, 60, seed=5, sub_rate=0.15, ragged=True)
+    reads += [b"", b"A", b"N", b"ACGTN", b"acgt", bytes([1]), bytes([255]) * 3, bytes([0]), S.text[:500].tobytes()]
+    seqs, off = ra.pack_reads(reads)
+    lo, hi, k = rb.find_range_w_toehold(seqs, off)
+    wlo, whi, wk = o.find_range_w_toehold_batch(seqs, off)
+    assert (lo == wlo).all() and (hi == whi).all() and (k == wk).all()
+    # independent check against the explicit-text FM index too
+    for i in range(0, len(reads), 37):
+        assert (int(lo[i]), int(hi[i])) == S.fm.find_range(reads[i])
+    for max_hits in (MAXU, 1, 3, 0):
+        loc_off, locs = rb.locs_at(lo, hi, k, max_hits)
+        woff, wlocs = o.locs_at_batch(wlo, whi, wk, max_hits)
+        assert (loc_off == woff).all() and (locs == wlocs).all()
+    rb.close()
+    o.close()
+
+
+def test_synth_markers(synth):
+    S = synth
+    rb = ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0)
+    o = orc.Oracle.from_runs(S.heads, S.lens, S.ssa, S.esa)
+    ms, me, mo, mv = S.markers(wsize=10)
+    assert len(ms) > 50 and int(np.diff(mo).max()) >= 1
+    rb.set_markers(ms, me, mo, mv)
+    o.set_markers(ms, me, mo, mv)
+    reads = S.sample_reads(1500, 50, seed=9, sub_rate=0.1) + [b"ACGT", b""]
+    seqs, off = ra.pack_reads(reads)
+    lo, hi = rb.find_range(seqs, off)
+    mk_off, mk = rb.markers_at(lo, hi)  # rb_align -m (rb_align.cpp:138)
+    got = split(mk_off, mk)
+    n_nonempty = 0
+    for i, q in enumerate(reads):
+        want = o.markers_at(int(lo[i]), int(hi[i]))
+        assert got[i] == want
+        n_nonempty += bool(want)
+    assert n_nonempty > 100
+    for wsize, max_range in ((10, MAXU), (7, MAXU), (10, 4), (25, 1000), (50, MAXU), (51, MAXU)):
+        lo2, hi2, mk_off2, mk2 = rb.find_range_w_markers(seqs, off, wsize, max_range)
+        got2 = split(mk_off2, mk2)
+        for i, q in enumerate(reads):
+            (wl, wh), wm = o.find_range_w_markers(q, wsize, max_range)
+            assert (int(lo2[i]), int(hi2[i])) == (wl, wh)
+            assert got2[i] == wm
+    rb.close()
+    o.close()
+
+
+def test_device_resident_api(synth):
+    """HBM in / HBM out entry points on torch's current stream (what bench.py times)."""
+    import ctypes as C
+    import torch
+    S = synth
+    rb = ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0)
+    o = orc.Oracle.from_runs(S.heads, S.lens, S.ssa, S.esa)
+    reads = S.sample_reads(5000, 100, seed=3, sub_rate=0.1)
+    seqs, off = ra.pack_reads(reads)
+    N = len(reads)
+    dev = torch.device("cuda:0")
+    pad = (-len(seqs)) % 8
+    d_seqs = torch.from_numpy(np.concatenate([seqs, np.zeros(pad, np.uint8)])).to(dev)
+    d_off = torch.from_numpy(off.view(np.int64)).to(dev)
+    d_lo, d_hi, d_k = (torch.empty(N, dtype=torch.int64, device=dev) for _ in range(3))
+    st = torch.cuda.current_stream().cuda_stream
+    L = ra.lib()
+    assert L.rbg_find_range_w_toehold_dev(rb.h, d_seqs.data_ptr(), d_off.data_ptr(), N, d_lo.data_ptr(),
+                                          d_hi.data_ptr(), d_k.data_ptr(), st) == 0
+    d_loc_off = torch.empty(N + 1, dtype=torch.int64, device=dev)
+    tmp_bytes = L.rbg_locate_plan_tmp_bytes(N)
+    d_tmp = torch.empty(tmp_bytes, dtype=torch.uint8, device=dev)
+    assert L.rbg_locate_plan_dev(rb.h, d_lo.data_ptr(), d_hi.data_ptr(), N, MAXU, d_loc_off.data_ptr(),
+                                 d_tmp.data_ptr(), tmp_bytes, st) == 0
+    total = int(d_loc_off[-1].item())
+    d_locs = torch.empty(max(total, 1), dtype=torch.int64, device=dev)
+    assert L.rbg_locate_fill_dev(rb.h, d_lo.data_ptr(), d_hi.data_ptr(), d_k.data_ptr(), N, MAXU,
+                                 d_loc_off.data_ptr(), d_locs.data_ptr(), st) == 0
+    torch.cuda.synchronize()
+    wlo, whi, wk = o.find_range_w_toehold_batch(seqs, off, nthreads=4)
+    woff, wlocs = o.locs_at_batch(wlo, whi, wk, nthreads=4)
+    assert (d_lo.cpu().numpy().view(np.uint64) == wlo).all()
+    assert (d_hi.cpu().numpy().view(np.uint64) == whi).all()
+    assert (d_k.cpu().numpy().view(np.uint64) == wk).all()
+    assert (d_loc_off.cpu().numpy().view(np.uint64) == woff).all()
+    assert (d_locs.cpu().numpy().view(np.uint64)[:total] == wlocs).all()
+    # unaligned read buffer is rejected, not mis-read
+    assert L.rbg_find_range_dev(rb.h, d_seqs.data_ptr() + 1, d_off.data_ptr(), N, d_lo.data_ptr(), d_hi.data_ptr(), st) == -4
+    rb.close()
+    o.close()
+
+
+def test_size_independent_properties(synth):
+    """Properties that hold at any size (used again at BASELINE sizes by bench.py --check):
+    every located position really is an occurrence; occ == number of distinct locations;
+    count of a read == count of its range; appending context never widens a range."""
+    S = synth
+    rb = ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0)
+    reads = S.sample_reads(2000, 80, seed=21, sub_rate=0.0)
+    seqs, off = ra.pack_reads(reads)
+    lo, hi, k = rb.find_range_w_toehold(seqs, off)
+    assert (hi >= lo).all()
+    loc_off, locs = rb.locs_at(lo, hi, k)
+    tb = S.text.tobytes()
+    for i, q in enumerate(reads):
+        mine = locs[int(loc_off[i]):int(loc_off[i + 1])].tolist()
+        assert len(mine) == int(hi[i] - lo[i] + 1) == len(set(mine))
+        for p in mine:
+            assert tb[p:p + len(q)] == q
+    suff = [q[20:] for q in reads]
+    slo, shi = rb.find_range(*ra.pack_reads(suff))
+    assert ((shi - slo) >= (hi - lo)).all()
+    rb.close()
