@@ -1,0 +1,327 @@
+#!/usr/bin/env python3
+"""bench.py -- reads/s of the rb_align hot path (exact-match count + locate) on MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic reads already resident in HBM:
+    K2  rbg_find_range_w_toehold_dev   (RowBowt::find_range_w_toehold, rowbowt.hpp:169-184)
+    K3a rbg_locate_plan_dev            (occ + exclusive scan)
+    K3b rbg_locate_fill_dev            (RowBowt::locs_at -> ToeholdSA::locate_range, toehold_sa.hpp:37-49)
+which is BASELINE.json configs[2] ("1xMI355X count+locate: chr22-scale index, 10M reads"), the
+configuration the metric "reads/s (100 bp, count+locate)" is quoted on.  The count-only rate
+(configs[1], rbg_find_range_dev) is measured in the same run and reported beside it.
+
+The index is SYNTHETIC (no real data here): rowbowt_amd/tools/synth_pangenome.py builds a
+chr22-scale pangenome text (L x H), its suffix array (torch sorts on the GPU), and from that the
+run-length BWT + run-boundary SA samples that rbg_build_from_runs flattens into HBM.  Index
+construction, read synthesis, oracle construction and the CPU baseline are all OUTSIDE the timed
+region.  Multi-GPU: the index is replicated, reads are sharded (each rank its own batch: weak
+scaling), no data-path collective; one RCCL all-reduce carries the 4 global counters.
+
+Launch: python bench.py [--gpus N --steps K --warmup W]; for N>1 under torch.distributed.run.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+MAXU = 2**64 - 1
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step")
+    ap.add_argument("--read-len", type=int, default=100)
+    ap.add_argument("--L", type=int, default=40_000_000, help="base sequence length")
+    ap.add_argument("--H", type=int, default=50, help="haplotypes")
+    ap.add_argument("--site-rate", type=float, default=0.01)
+    ap.add_argument("--seed", type=int, default=20240229)
+    ap.add_argument("--max-hits", type=int, default=-1, help="-1 = 2^64-1 like rb_align.cpp:125")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check-reads", type=int, default=20000, help="reads compared bit-exactly with the oracle")
+    return ap.parse_args()
+
+
+def log(rank, *a):
+    if rank == 0:
+        print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+
+    import rowbowt_amd as ra
+    from rowbowt_amd.tools import synth_pangenome as sp
+
+    L = ra.lib()
+    m = args.read_len
+    max_hits = MAXU if args.max_hits < 0 else args.max_hits
+
+    # ---- synthesis (outside the timed region) --------------------------------------------------
+    t0 = time.time()
+    text, info = sp.make_text(args.L, args.H, args.site_rate, args.seed, dev)
+    sa = sp.suffix_array(text)
+    torch.cuda.synchronize()
+    t_sa = time.time() - t0
+    inp = sp.index_inputs(text, sa)
+    del sa
+    torch.cuda.empty_cache()
+    log(rank, f"synthetic pangenome: L={args.L} H={args.H} n={inp['n']} r={inp['r']} n/r={inp['n'] / inp['r']:.1f} "
+              f"(suffix array {t_sa:.1f}s)")
+    t0 = time.time()
+    rb = ra.RowBowt.from_runs(inp["heads"], inp["lens"], inp["ssa"], inp["esa"], device=local_rank)
+    ix = rb.info()
+    log(rank, f"index replica: {ix.hbm_bytes / 1e6:.1f} MB HBM, pos_bytes={ix.pos_bytes}, sigma={ix.sigma}, "
+              f"flatten+upload {time.time() - t0:.1f}s")
+
+    N = args.reads
+    reads, _ = sp.sample_reads(text, info, N, m, seed=args.seed + 2 + rank, sub_rate=0.1)
+    del text
+    torch.cuda.empty_cache()
+    d_seqs = reads.reshape(-1)
+    if d_seqs.numel() % 8:
+        d_seqs = torch.cat([d_seqs, torch.zeros(8 - d_seqs.numel() % 8, dtype=torch.uint8, device=dev)])
+    d_off = (torch.arange(N + 1, device=dev, dtype=torch.int64) * m)
+    d_lo, d_hi, d_k = (torch.empty(N, dtype=torch.int64, device=dev) for _ in range(3))
+    d_loc_off = torch.empty(N + 1, dtype=torch.int64, device=dev)
+    tmp_bytes = L.rbg_locate_plan_tmp_bytes(N)
+    d_tmp = torch.empty(tmp_bytes, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream()
+    st = stream.cuda_stream
+
+    def chk(rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed: {L.rbg_strerror(rc).decode()}")
+
+    def k_count():
+        chk(L.rbg_find_range_dev(rb.h, d_seqs.data_ptr(), d_off.data_ptr(), N, d_lo.data_ptr(), d_hi.data_ptr(), st), "find_range")
+
+    def k_toehold():
+        chk(L.rbg_find_range_w_toehold_dev(rb.h, d_seqs.data_ptr(), d_off.data_ptr(), N, d_lo.data_ptr(), d_hi.data_ptr(),
+                                           d_k.data_ptr(), st), "find_range_w_toehold")
+
+    def k_plan():
+        chk(L.rbg_locate_plan_dev(rb.h, d_lo.data_ptr(), d_hi.data_ptr(), N, max_hits, d_loc_off.data_ptr(),
+                                  d_tmp.data_ptr(), tmp_bytes, st), "locate_plan")
+
+    # size the ragged output once (same reads every step => same total)
+    k_toehold()
+    k_plan()
+    total_locs = int(d_loc_off[-1].item())
+    d_locs = torch.empty(max(total_locs, 1), dtype=torch.int64, device=dev)
+    n_matched = int((d_hi.view(torch.int64) >= d_lo.view(torch.int64)).sum().item())
+    log(rank, f"reads/GPU={N} x {m} bp, matched={n_matched}, sum occ={total_locs} (mean occ/matched read "
+              f"{total_locs / max(n_matched, 1):.1f})")
+
+    def k_fill():
+        chk(L.rbg_locate_fill_dev(rb.h, d_lo.data_ptr(), d_hi.data_ptr(), d_k.data_ptr(), N, max_hits,
+                                  d_loc_off.data_ptr(), d_locs.data_ptr(), st), "locate_fill")
+
+    def step():
+        k_toehold()
+        k_plan()
+        k_fill()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(fn, steps, events=None):
+        barrier()
+        t = time.perf_counter()
+        for s in range(steps):
+            fn(s) if events else fn()
+        barrier()
+        return time.perf_counter() - t
+
+    # ---- count+locate (headline) ---------------------------------------------------------------
+    for _ in range(args.warmup):
+        step()
+    K = args.steps
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(K)]
+
+    def step_ev(s):
+        ev[s][0].record(stream)
+        k_toehold()
+        ev[s][1].record(stream)
+        k_plan()
+        ev[s][2].record(stream)
+        k_fill()
+        ev[s][3].record(stream)
+
+    rb.counters_reset()
+    el = timed(step_ev, K, events=True)
+    counters = rb.counters().astype(np.int64)
+    ms_toe = float(np.mean([ev[s][0].elapsed_time(ev[s][1]) for s in range(K)]))
+    ms_plan = float(np.mean([ev[s][1].elapsed_time(ev[s][2]) for s in range(K)]))
+    ms_fill = float(np.mean([ev[s][2].elapsed_time(ev[s][3]) for s in range(K)]))
+
+    # ---- count-only (configs[1]) ---------------------------------------------------------------
+    for _ in range(max(1, args.warmup)):
+        k_count()
+    evc = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(K)]
+
+    def count_ev(s):
+        evc[s][0].record(stream)
+        k_count()
+        evc[s][1].record(stream)
+
+    el_count = timed(count_ev, K, events=True)
+    ms_count = float(np.mean([evc[s][0].elapsed_time(evc[s][1]) for s in range(K)]))
+
+    # max over ranks, counters over RCCL
+    t_el = torch.tensor([el, el_count], dtype=torch.float64, device=dev)
+    t_cnt = torch.from_numpy(counters).to(dev)
+    if world > 1:
+        dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t_cnt, op=dist.ReduceOp.SUM)  # the only collective: 4 x u64 global counters
+    el, el_count = float(t_el[0].item()), float(t_el[1].item())
+    g_counters = t_cnt.cpu().numpy().tolist()
+
+    out = None
+    if rank == 0:
+        total_reads = N * world * K
+        value = total_reads / el
+        # algorithmic bytes (SURVEY 8d / DESIGN.md): per read 57*m+24 for count+toehold, 24 per located occurrence
+        alg_toe = (57 * m + 24) * N
+        alg_fill = 24 * total_locs
+        alg_count = (49 * m + 16) * N
+        kernels = {
+            "k_find_range<toehold>": {"ms": ms_toe, "alg_bytes": alg_toe},
+            "k_locate_fill": {"ms": ms_fill, "alg_bytes": alg_fill},
+            "locate_plan(k_occ+scan)": {"ms": ms_plan, "alg_bytes": 24 * N},
+            "k_find_range<count>": {"ms": ms_count, "alg_bytes": alg_count},
+        }
+        dom = max(("k_find_range<toehold>", "k_locate_fill"), key=lambda k: kernels[k]["ms"])
+        ach = kernels[dom]["alg_bytes"] / (kernels[dom]["ms"] * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "reads/s (100 bp, count+locate)",
+            "value": value,
+            "unit": "reads/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": args.warmup,
+            "ms_per_step": el / K * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u64" if ix.pos_bytes == 8 else "u32/u64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"count+locate (find_range_w_toehold + locs_at, max_hits={'2^64-1' if max_hits == MAXU else max_hits}) on a "
+                            f"synthetic chr22-scale pangenome r-index, {N} x {m} bp reads per GPU per step (BASELINE.json configs[2])",
+                "index": {"L": args.L, "H": args.H, "n": int(inp["n"]), "r": int(inp["r"]), "site_rate": args.site_rate,
+                          "hbm_bytes": int(ix.hbm_bytes), "pos_bytes": int(ix.pos_bytes), "seed": args.seed},
+                "reads_per_gpu": N, "read_len": m, "substituted_fraction": 0.1,
+                "parallelism": f"index replicated x{world}, reads sharded, no data-path collective",
+            },
+            "count_only": {"value": N * world * K / el_count, "unit": "reads/s", "ms_per_step": el_count / K * 1e3,
+                           "workload": "BASELINE.json configs[1]: find_range only"},
+            "counters": {"reads": g_counters[0], "matched": g_counters[1], "sum_occ": g_counters[2], "sum_locs": g_counters[3],
+                         "reduced_over": "RCCL all_reduce" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic},
+            "kernels": {k: {"ms": v["ms"], "alg_GBps": v["alg_bytes"] / (v["ms"] * 1e-3) / 1e9} for k, v in kernels.items()},
+        }
+
+    # ---- parity sample + CPU baseline (rank 0, N=1 only; never part of the timed region) ------
+    if rank == 0 and not (args.no_cpu_baseline and args.check_reads == 0):
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import orc  # oracle: checker + cpu_baseline only
+
+        t0 = time.time()
+        o = orc.Oracle.from_runs(inp["heads"], inp["lens"], inp["ssa"], inp["esa"])
+        log(rank, f"oracle built in {time.time() - t0:.1f}s")
+        nchk = min(args.check_reads, N)
+        ncopy = min(N, max(nchk, 1 if args.no_cpu_baseline else 50000))
+        h_seqs = reads[:ncopy].cpu().numpy().reshape(-1)
+        if nchk:
+            h_off = (np.arange(nchk + 1, dtype=np.uint64) * m)
+            k_toehold()
+            k_plan()
+            k_fill()
+            torch.cuda.synchronize()
+            g_lo = d_lo[:nchk].cpu().numpy().view(np.uint64)
+            g_hi = d_hi[:nchk].cpu().numpy().view(np.uint64)
+            g_k = d_k[:nchk].cpu().numpy().view(np.uint64)
+            g_off = d_loc_off[:nchk + 1].cpu().numpy().view(np.uint64)
+            g_locs = d_locs[:int(g_off[-1])].cpu().numpy().view(np.uint64)
+            ncpu = min(os.cpu_count() or 1, 64)
+            wlo, whi, wk = o.find_range_w_toehold_batch(h_seqs, h_off, nthreads=ncpu)
+            woff, wlocs = o.locs_at_batch(wlo, whi, wk, max_hits, nthreads=ncpu)
+            ok = bool((g_lo == wlo).all() and (g_hi == whi).all() and (g_k == wk).all() and (g_off == woff).all()
+                      and (g_locs == wlocs).all())
+            out["parity"] = {"reads_checked": nchk, "locs_checked": int(woff[-1]), "bit_exact_vs_oracle": ok}
+            if not ok:
+                print(json.dumps(out))
+                raise SystemExit("PARITY FAILURE: HIP path disagrees with the oracle")
+        if world == 1 and not args.no_cpu_baseline:
+            # bounded sample, single thread like rb_align's serial loop (rb_align.cpp:176-178)
+            probe = min(200, N)
+            p_off = (np.arange(probe + 1, dtype=np.uint64) * m)
+            t0 = time.perf_counter()
+            plo, phi, pk = o.find_range_w_toehold_batch(h_seqs[:probe * m], p_off, nthreads=1)
+            o.locs_at_batch(plo, phi, pk, max_hits, nthreads=1)
+            per_read = (time.perf_counter() - t0) / probe
+            ns = int(max(probe, min(ncopy, args.cpu_seconds / max(per_read, 1e-9))))
+            s_off = (np.arange(ns + 1, dtype=np.uint64) * m)
+            t0 = time.perf_counter()
+            slo, shi, sk = o.find_range_w_toehold_batch(h_seqs[:ns * m], s_off, nthreads=1)
+            o.locs_at_batch(slo, shi, sk, max_hits, nthreads=1)
+            dt = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": ns / dt, "unit": "reads/s", "cores": 1, "kind": "port",
+                                   "sample": f"first {ns} reads of the same batch, count+locate, oracle/rb_oracle.c "
+                                             f"(CPU restatement of the reference algorithm), {dt:.1f}s",
+                                   "host": f"{os.cpu_count()} logical CPUs"}
+            # all cores, for scale only
+            ncpu = os.cpu_count() or 1
+            na = min(ncopy, ns * min(ncpu, 64))
+            a_off = (np.arange(na + 1, dtype=np.uint64) * m)
+            t0 = time.perf_counter()
+            alo, ahi, ak = o.find_range_w_toehold_batch(h_seqs[:na * m], a_off, nthreads=ncpu)
+            o.locs_at_batch(alo, ahi, ak, max_hits, nthreads=ncpu)
+            dta = time.perf_counter() - t0
+            out["cpu_baseline_all_cores"] = {"value": na / dta, "unit": "reads/s", "cores": ncpu, "kind": "port",
+                                             "sample": f"first {na} reads, OpenMP over reads, {dta:.1f}s"}
+        o.close()
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    rb.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -246,6 +246,9 @@ __global__ __launch_bounds__(256) void k_find_range_markers(const DevIndex ix, c
         uint64_t total = 0;
         uint64_t lo = 1, hi = 0;
         bool alive = m >= wsize;  // rowbowt.hpp:299-302: shorter queries return the default LFData
+        // fill pass: a read with nothing to emit (including every read that dies: lf.clear() drops
+        // what earlier windows collected) must not write at all
+        if (FILL && mk_off[i + 1] == mk_off[i]) continue;
         if (alive) {
             lo = 0; hi = ix.n - 1;
             uint64_t window_ei = m, acc = 0;
