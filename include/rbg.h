@@ -96,6 +96,8 @@ typedef struct rbg_info_t {
     uint64_t marker_runs, marker_vals;
     uint32_t rank_bucket_shift, phi_bucket_shift;
     uint32_t reserved;
+    /* first-level slot tables: totals and how many buckets overflow their 2 inline entries */
+    uint64_t rank_slots, rank_slots_overflow, phi_slots, phi_slots_overflow;
 } rbg_info_t;
 int rbg_info(const rbg_index *, rbg_info_t *out);
 

@@ -43,7 +43,8 @@ class Info(C.Structure):
     _fields_ = [("n", U64), ("r", U64), ("sigma", C.c_uint32), ("pos_bytes", C.c_uint32), ("device", C.c_int32),
                 ("has_tsa", C.c_uint32), ("has_markers", C.c_uint32), ("has_docs", C.c_uint32),
                 ("hbm_bytes", U64), ("marker_runs", U64), ("marker_vals", U64),
-                ("rank_bucket_shift", C.c_uint32), ("phi_bucket_shift", C.c_uint32), ("reserved", C.c_uint32)]
+                ("rank_bucket_shift", C.c_uint32), ("phi_bucket_shift", C.c_uint32), ("reserved", C.c_uint32),
+                ("rank_slots", U64), ("rank_slots_overflow", U64), ("phi_slots", U64), ("phi_slots_overflow", U64)]
 
 
 # every symbol include/rbg.h declares: (name, restype, argtypes)

@@ -26,6 +26,7 @@ struct rbg_index {
     LaunchCfg cfg;
     std::vector<void *> allocs;  // every device allocation of the replica
     uint64_t hbm_bytes = 0;
+    uint64_t rank_slots = 0, rank_slots_overflow = 0, phi_slots = 0, phi_slots_overflow = 0;
     std::mutex mu;               // guards marker/doc attachment only; queries are lock-free
 };
 
@@ -84,6 +85,59 @@ int dev_upload(rbg_index *ix, const void *src, size_t bytes, const void **dst) {
     return RBG_OK;
 }
 
+// RankSlot table of one symbol (rbg_dev.h): slot b describes bucket [b << shift, (b+1) << shift)
+template <typename P>
+void build_rank_slots(const SymTable &t, uint64_t n, std::vector<RankSlot<P>> &slots, uint64_t *overflow) {
+    const uint64_t nb = (n >> t.shift) + 2;
+    slots.resize(nb);
+    uint64_t k = 0;  // # runs with start < bucket begin
+    for (uint64_t b = 0; b < nb; ++b) {
+        const unsigned __int128 beg = static_cast<unsigned __int128>(b) << t.shift;
+        const unsigned __int128 end = static_cast<unsigned __int128>(b + 1) << t.shift;
+        while (k < t.nruns && static_cast<unsigned __int128>(t.start[k]) < beg) ++k;
+        uint64_t cnt = 0;
+        while (k + cnt < t.nruns && static_cast<unsigned __int128>(t.start[k + cnt]) < end) ++cnt;
+        RankSlot<P> &s = slots[b];
+        s.pstart = k ? static_cast<P>(t.start[k - 1]) : kSent<P>;
+        s.pcum = k ? static_cast<P>(t.cum[k - 1]) : P(0);
+        s.a = static_cast<P>(k);
+        // cum[] carries the sentinel cum[nruns] = total, so cum[k + x] is valid for x <= cnt
+        s.s0 = cnt >= 1 ? static_cast<P>(t.start[k]) : kSent<P>;
+        s.c0 = static_cast<P>(t.cum[k]);
+        if (cnt >= 2) { s.s1 = static_cast<P>(t.start[k + 1]); s.c1 = static_cast<P>(t.cum[k + 1]); }
+        else { s.s1 = kSent<P>; s.c1 = static_cast<P>(t.cum[std::min(k + 1, t.nruns)]); }
+        s.next_cum = static_cast<P>(t.cum[std::min(k + 2, t.nruns)]);
+        if (cnt == 0) { s.c1 = s.c0; s.next_cum = s.c0; }
+        if (cnt == 1) s.next_cum = s.c1;
+        if (cnt > 2) { s.s1 = kOvf<P>; ++*overflow; }
+    }
+}
+
+template <typename P>
+void build_phi_slots(const HostIndex &h, std::vector<PhiSlot<P>> &slots, uint64_t *overflow) {
+    const uint64_t nb = (h.n >> h.phi_shift) + 2;
+    slots.resize(nb);
+    uint64_t k = 0;
+    for (uint64_t b = 0; b < nb; ++b) {
+        const unsigned __int128 beg = static_cast<unsigned __int128>(b) << h.phi_shift;
+        const unsigned __int128 end = static_cast<unsigned __int128>(b + 1) << h.phi_shift;
+        while (k < h.r && static_cast<unsigned __int128>(h.pred_pos[k]) < beg) ++k;
+        uint64_t cnt = 0;
+        while (k + cnt < h.r && static_cast<unsigned __int128>(h.pred_pos[k + cnt]) < end) ++cnt;
+        PhiSlot<P> &s = slots[b];
+        const uint64_t pj = k ? k - 1 : h.r - 1;  // circular predecessor, sparse_sd_vector.hpp:141-143
+        s.ppos = static_cast<P>(h.pred_pos[pj]);
+        s.pbase = static_cast<P>(h.phi_base[pj]);
+        s.a = static_cast<P>(k);
+        s.pad = 0;
+        s.p0 = cnt >= 1 ? static_cast<P>(h.pred_pos[k]) : kSent<P>;
+        s.b0 = cnt >= 1 ? static_cast<P>(h.phi_base[k]) : P(0);
+        s.p1 = cnt >= 2 ? static_cast<P>(h.pred_pos[k + 1]) : kSent<P>;
+        s.b1 = cnt >= 2 ? static_cast<P>(h.phi_base[k + 1]) : P(0);
+        if (cnt > 2) { s.p1 = kOvf<P>; ++*overflow; }
+    }
+}
+
 template <typename P>
 int upload_tables(rbg_index *ix) {
     HostIndex &h = ix->host;
@@ -104,10 +158,13 @@ int upload_tables(rbg_index *ix) {
             rc = dev_upload(ix, samp.data(), samp.size() * sizeof(P), &syms[s].samp);
             if (rc) return rc;
         }
-        const void *b = nullptr;
-        rc = dev_upload(ix, t.bucket.data(), t.bucket.size() * sizeof(uint32_t), &b);
-        if (rc) return rc;
-        syms[s].bucket = static_cast<const uint32_t *>(b);
+        {
+            std::vector<RankSlot<P>> slots;
+            build_rank_slots<P>(t, h.n, slots, &ix->rank_slots_overflow);
+            ix->rank_slots += slots.size();
+            rc = dev_upload(ix, slots.data(), slots.size() * sizeof(RankSlot<P>), &syms[s].slots);
+            if (rc) return rc;
+        }
         syms[s].nruns = t.nruns;
         syms[s].F = t.F;
         syms[s].total = t.total;
@@ -119,16 +176,20 @@ int upload_tables(rbg_index *ix) {
     if (rc) return rc;
     ix->dev.syms = static_cast<const DevSym *>(p);
     if (h.has_tsa) {
-        std::vector<PhiEnt<P>> pe(h.r);
-        for (uint64_t j = 0; j < h.r; ++j) {
-            pe[j].pos = static_cast<P>(h.pred_pos[j]);
-            pe[j].base = static_cast<P>(h.phi_base[j]);
+        {
+            std::vector<PhiEnt<P>> pe(h.r);
+            for (uint64_t j = 0; j < h.r; ++j) {
+                pe[j].pos = static_cast<P>(h.pred_pos[j]);
+                pe[j].base = static_cast<P>(h.phi_base[j]);
+            }
+            rc = dev_upload(ix, pe.data(), pe.size() * sizeof(PhiEnt<P>), &ix->dev.phi_ent);
+            if (rc) return rc;
         }
-        rc = dev_upload(ix, pe.data(), pe.size() * sizeof(PhiEnt<P>), &ix->dev.phi_ent);
+        std::vector<PhiSlot<P>> slots;
+        build_phi_slots<P>(h, slots, &ix->phi_slots_overflow);
+        ix->phi_slots = slots.size();
+        rc = dev_upload(ix, slots.data(), slots.size() * sizeof(PhiSlot<P>), &ix->dev.phi_slots);
         if (rc) return rc;
-        rc = dev_upload(ix, h.phi_bucket.data(), h.phi_bucket.size() * sizeof(uint32_t), &p);
-        if (rc) return rc;
-        ix->dev.phi_bucket = static_cast<const uint32_t *>(p);
     }
     return RBG_OK;
 }
@@ -412,6 +473,10 @@ int rbg_info(const rbg_index *ix, rbg_info_t *out) {
     out->marker_vals = ix->host.ma.vals.size();
     out->rank_bucket_shift = ix->host.sym.empty() ? 0 : ix->host.sym.back().shift;
     out->phi_bucket_shift = ix->host.phi_shift;
+    out->rank_slots = ix->rank_slots;
+    out->rank_slots_overflow = ix->rank_slots_overflow;
+    out->phi_slots = ix->phi_slots;
+    out->phi_slots_overflow = ix->phi_slots_overflow;
     return RBG_OK;
 }
 

@@ -22,10 +22,38 @@ struct PhiEnt {
     P base;
 };
 
+// First level of every predecessor search, direct-addressed by (position >> shift): one record
+// per bucket of 2^shift BWT positions that already CONTAINS the answer in the common case, so a
+// rank is ONE aligned 8-word load instead of "bucket word -> entries" (two dependent gathers).
+//   prev      = last run of the symbol starting strictly before the bucket (start = kSent if none)
+//   e0, e1    = first two runs starting inside the bucket (start = kSent if absent)
+//   cum of an absent entry = cum of the run that would come next, so len(p) = next(p).cum - p.cum
+//   a         = ordinal (within the symbol's run list) of the first run starting inside the bucket
+//   e1.start == kOvf: more than two runs start in the bucket -> search ent[a .. next slot's a)
+template <typename P>
+struct alignas(8 * sizeof(P)) RankSlot {
+    P pstart, pcum;
+    P s0, c0;
+    P s1, c1;
+    P next_cum;
+    P a;
+};
+// same idea for phi's predecessor structure over text positions (payload = phi base)
+template <typename P>
+struct alignas(8 * sizeof(P)) PhiSlot {
+    P ppos, pbase;
+    P p0, b0;
+    P p1, b1;
+    P a;
+    P pad;
+};
+template <typename P> constexpr P kSent = static_cast<P>(~static_cast<P>(0));
+template <typename P> constexpr P kOvf = static_cast<P>(~static_cast<P>(0) - 1);
+
 struct DevSym {
-    const void *ent;         // RunEnt<P>[nruns + 1] (sentinel: start = n, cum = total)
-    const void *samp;        // P[nruns]: samples_last_ of each run (nullptr without toehold SA)
-    const uint32_t *bucket;  // (n >> shift) + 2 words: # runs with start < (b << shift)
+    const void *ent;    // RunEnt<P>[nruns + 1] (sentinel: start = n, cum = total): overflow buckets, samples
+    const void *samp;   // P[nruns]: samples_last_ of each run (nullptr without toehold SA)
+    const void *slots;  // RankSlot<P>[(n >> shift) + 2]
     uint64_t nruns;
     uint64_t F;      // RowBowt::f_[byte]
     uint64_t total;  // occurrences of the symbol
@@ -42,8 +70,8 @@ struct DevIndex {
     uint32_t sigma;
     uint32_t pos_bytes;
     // phi
-    const void *phi_ent;         // PhiEnt<P>[r]
-    const uint32_t *phi_bucket;  // (n >> phi_shift) + 2
+    const void *phi_ent;    // PhiEnt<P>[r]
+    const void *phi_slots;  // PhiSlot<P>[(n >> phi_shift) + 2]
     uint32_t phi_shift;
     uint32_t has_tsa;
     // markers

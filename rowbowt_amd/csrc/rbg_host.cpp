@@ -335,30 +335,18 @@ int parse_docs(const std::string &fname, RawDocs &out) {
 // ---- flatten -------------------------------------------------------------------------------------
 namespace {
 uint32_t auto_shift(uint64_t n, uint64_t items) {
-    // largest shift with (n >> shift) >= items: about one item per bucket, never more buckets than 2x items
+    // largest shift with (n >> shift) >= 2 * items: 0.25-0.5 items per slot, so that a slot's two
+    // inline entries almost always suffice (rbg_dev.h RankSlot / PhiSlot)
     if (items == 0) items = 1;
     uint32_t s = 0;
-    while (s < 63 && (n >> (s + 1)) >= items) ++s;
+    while (s < 63 && (n >> (s + 1)) >= 2 * items) ++s;
     return s;
-}
-void build_buckets(const std::vector<uint64_t> &sorted_pos, uint64_t count, uint64_t n, uint32_t shift,
-                   std::vector<uint32_t> &bucket) {
-    const uint64_t nb = (n >> shift) + 2;
-    bucket.assign(nb, 0);
-    // bucket[b] = # positions < (b << shift)
-    uint64_t k = 0;
-    for (uint64_t b = 0; b < nb; ++b) {
-        const unsigned __int128 lim = static_cast<unsigned __int128>(b) << shift;
-        while (k < count && static_cast<unsigned __int128>(sorted_pos[k]) < lim) ++k;
-        bucket[b] = static_cast<uint32_t>(k);
-    }
 }
 }  // namespace
 
 int flatten(const RawRle &rle, const RawTsa *tsa, const FlattenOptions &opt, HostIndex &out) {
     const uint64_t R = rle.R;
     if (R == 0 || rle.heads.size() != R || rle.lens.size() != R) return RBG_EARG;
-    if (R >= 0xFFFFFFF0ull) return RBG_EARG;  // bucket words are 32-bit run ordinals
     if (tsa && (tsa->r != R || tsa->samples_last.size() != R || tsa->pred_pos.size() != R || tsa->pred_to_run.size() != R))
         return RBG_EFORMAT;
     out = HostIndex();
@@ -399,8 +387,9 @@ int flatten(const RawRle &rle, const RawTsa *tsa, const FlattenOptions &opt, Hos
     out.f[256] = acc;
     out.sigma = static_cast<uint32_t>(out.sym.size());
     if (out.sigma > 255) return RBG_EARG;  // slot 0xFF is the "absent" marker
-    out.pos_bytes = opt.force_pos_bytes ? opt.force_pos_bytes : (out.n < 0xFFFFFFFFull ? 4 : 8);
-    if (out.pos_bytes == 4 && out.n >= 0xFFFFFFFFull) return RBG_EARG;
+    // 32-bit positions need n below the two reserved marker values (rbg_dev.h kSent / kOvf)
+    out.pos_bytes = opt.force_pos_bytes ? opt.force_pos_bytes : (out.n < 0xFFFFFFF0ull ? 4 : 8);
+    if (out.pos_bytes == 4 && out.n >= 0xFFFFFFF0ull) return RBG_EARG;
     std::vector<uint64_t> seen(out.sigma, 0);
     for (uint64_t i = 0; i < R; ++i) {
         const uint32_t slot = out.lut[rle.heads[i]];
@@ -414,8 +403,6 @@ int flatten(const RawRle &rle, const RawTsa *tsa, const FlattenOptions &opt, Hos
         t.start.push_back(out.n);
         t.cum.push_back(t.total);
         t.shift = opt.rank_bucket_shift >= 0 ? static_cast<uint32_t>(opt.rank_bucket_shift) : auto_shift(out.n, t.nruns);
-        if (((out.n >> t.shift) + 2) > 0xFFFFFFF0ull) return RBG_EARG;
-        build_buckets(t.start, t.nruns, out.n, t.shift, t.bucket);
     }
     if (tsa) {
         out.has_tsa = true;
@@ -429,7 +416,6 @@ int flatten(const RawRle &rle, const RawTsa *tsa, const FlattenOptions &opt, Hos
         }
         out.last_run_sample = (tsa->samples_last[R - 1] + 1) % out.n;  // toehold_sa.hpp:97-99
         out.phi_shift = opt.phi_bucket_shift >= 0 ? static_cast<uint32_t>(opt.phi_bucket_shift) : auto_shift(out.n, R);
-        build_buckets(out.pred_pos, R, out.n, out.phi_shift, out.phi_bucket);
     }
     return RBG_OK;
 }

@@ -53,15 +53,14 @@ void tsa_from_samples(uint64_t n, uint64_t r, const uint64_t *ssa_y, const uint6
 //   start[k] = BWT position where the run begins (ascending),
 //   cum[k]   = number of this symbol in BWT[0, start[k])   (cum[nruns] = total),
 //   samp[k]  = ToeholdSA::samples_last_ of that run (only with a toehold SA).
-// bucket[b] = number of runs with start < (b << shift): a direct-addressed first level so that a
-// predecessor search touches one bucket word pair and then a handful of adjacent entries.
+// The direct-addressed first level (one slot per 2^shift BWT positions, rbg_dev.h RankSlot) is
+// generated from start/cum at upload time; `shift` is chosen here.
 struct SymTable {
     uint8_t byte = 0;
     uint32_t shift = 0;
     uint64_t nruns = 0, total = 0, F = 0;
     std::vector<uint64_t> start, cum;  // nruns + 1 (sentinel: start = n, cum = total)
     std::vector<uint64_t> samp;        // nruns or empty
-    std::vector<uint32_t> bucket;      // (n >> shift) + 2
 };
 
 struct HostIndex {
@@ -78,7 +77,6 @@ struct HostIndex {
     uint64_t last_run_sample = 0;      // toehold_sa.hpp:97-99
     std::vector<uint64_t> samples_last, pred_pos, phi_base;
     uint32_t phi_shift = 0;
-    std::vector<uint32_t> phi_bucket;  // (n >> phi_shift) + 2 : # pred_pos < (b << phi_shift)
     bool has_ma = false;
     RawMarkers ma;
     bool has_dl = false;
@@ -86,7 +84,7 @@ struct HostIndex {
 };
 
 struct FlattenOptions {
-    int rank_bucket_shift = -1;  // <0: automatic (about one run per bucket)
+    int rank_bucket_shift = -1;  // <0: automatic (about one run per two buckets)
     int phi_bucket_shift = -1;
     int force_pos_bytes = 0;     // 0: 4 when n fits, else 8
 };

@@ -8,8 +8,9 @@
 //  K4     k_markers_*              MarkerArray::at_range behind RowBowt::markers_at rowbowt.hpp:282-285.
 //
 // Integer gather kernels: no MFMA (nothing here is a contraction).  The bound is HBM / fabric
-// transactions per LF step, so the layout (rbg_dev.h) makes one rank = one bucket word pair +
-// one short run of adjacent RunEnt records, and both ranks of a step are issued back to back.
+// transactions per LF step, so the layout (rbg_dev.h) makes one rank = ONE aligned 8-word slot
+// (direct-addressed by position >> shift) that already holds the predecessor run, and both ranks
+// of a step share that slot whenever lo and hi+1 fall in the same bucket.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
@@ -24,27 +25,56 @@ constexpr int kWave = 64;
 // Returns # of the symbol in BWT[0,i)  ==  rle_string::rank(i,c) (rle_string.hpp:131-161), via
 // the identity  rank = cum[j] + min(i - start[j], len[j])  for the last run j with start[j] < i.
 // *pred = j (or -1), *inside = (i-1 lies inside run j), used by the toehold update.
+// `sl` is the RankSlot of bucket b = i >> shift, already in registers: in the common case nothing
+// else is read.  Only a bucket with more than two run starts walks the run list ent[a..z).
 template <typename P>
-__device__ __forceinline__ uint64_t rank_sym(const DevSym &S, uint64_t i, int64_t *pred, bool *inside) {
-    const RunEnt<P> *__restrict__ ent = static_cast<const RunEnt<P> *>(S.ent);
-    const uint64_t b = i >> S.shift;
-    uint32_t a = S.bucket[b];
-    uint32_t z = S.bucket[b + 1];
-    // runs [0,a) start below the bucket (hence below i); runs [z,..) start at or above i's bucket end
-    while (z - a > 4) {
-        const uint32_t mid = a + ((z - a) >> 1);
-        if (static_cast<uint64_t>(ent[mid].start) < i) a = mid + 1; else z = mid;
+__device__ __forceinline__ uint64_t rank_in_slot(const DevSym &S, const RankSlot<P> &sl, uint64_t b, uint64_t i,
+                                                 int64_t *pred, bool *inside) {
+    uint64_t pstart = sl.pstart, pcum = sl.pcum, nx = sl.c0;
+    int64_t j = static_cast<int64_t>(sl.a) - 1;
+    if (sl.s1 == kOvf<P>) {
+        const RunEnt<P> *__restrict__ ent = static_cast<const RunEnt<P> *>(S.ent);
+        uint64_t a = sl.a;
+        uint64_t z = static_cast<const RankSlot<P> *>(S.slots)[b + 1].a;
+        while (z - a > 4) {
+            const uint64_t mid = a + ((z - a) >> 1);
+            if (static_cast<uint64_t>(ent[mid].start) < i) a = mid + 1; else z = mid;
+        }
+        while (a < z && static_cast<uint64_t>(ent[a].start) < i) ++a;
+        if (a == 0) { *pred = -1; *inside = false; return 0; }
+        const RunEnt<P> e = ent[a - 1];
+        pstart = e.start;
+        pcum = e.cum;
+        nx = ent[a].cum;
+        j = static_cast<int64_t>(a) - 1;
+    } else {
+        if (static_cast<uint64_t>(sl.s0) < i) {
+            pstart = sl.s0; pcum = sl.c0; nx = sl.c1; j += 1;
+            if (static_cast<uint64_t>(sl.s1) < i) { pstart = sl.s1; pcum = sl.c1; nx = sl.next_cum; j += 1; }
+        }
+        if (pstart == static_cast<uint64_t>(kSent<P>)) { *pred = -1; *inside = false; return 0; }
     }
-    while (a < z && static_cast<uint64_t>(ent[a].start) < i) ++a;
-    if (a == 0) { *pred = -1; *inside = false; return 0; }
-    const uint32_t j = a - 1;
-    const RunEnt<P> e = ent[j];
-    const RunEnt<P> e1 = ent[j + 1];
-    const uint64_t len = static_cast<uint64_t>(e1.cum) - static_cast<uint64_t>(e.cum);
-    const uint64_t d = i - static_cast<uint64_t>(e.start);
+    const uint64_t len = nx - pcum;
+    const uint64_t d = i - pstart;
     *pred = j;
     *inside = d <= len;
-    return static_cast<uint64_t>(e.cum) + (d < len ? d : len);
+    return pcum + (d < len ? d : len);
+}
+
+// both ranks of one LF step (rowbowt.hpp:79,83).  lo and hi+1 usually share a bucket late in the
+// search (the range has narrowed to a few dozen rows), so the step is one 8-word load.
+template <typename P>
+__device__ __forceinline__ void rank_pair(const DevSym &S, uint64_t lo, uint64_t hi1, uint64_t *c_before, uint64_t *c_upto,
+                                          int64_t *qj, bool *qin) {
+    const RankSlot<P> *__restrict__ slots = static_cast<const RankSlot<P> *>(S.slots);
+    const uint64_t bl = lo >> S.shift, bh = hi1 >> S.shift;
+    const RankSlot<P> sl = slots[bl];
+    RankSlot<P> sh = sl;
+    if (bh != bl) sh = slots[bh];
+    int64_t pj;
+    bool pin;
+    *c_before = rank_in_slot<P>(S, sl, bl, lo, &pj, &pin);
+    *c_upto = rank_in_slot<P>(S, sh, bh, hi1, qj, qin);
 }
 
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
@@ -84,10 +114,10 @@ __global__ __launch_bounds__(256) void k_find_range(const DevIndex ix, const uin
             const uint32_t slot = s_lut[c];
             if (slot == 0xFFu) { alive = false; break; }  // symbol absent: f_[c] >= f_[c+1], rowbowt.hpp:76
             const DevSym S = slot < static_cast<uint32_t>(kLdsSyms) ? s_sym[slot] : ix.syms[slot];
-            int64_t pj, qj;
-            bool pin, qin;
-            const uint64_t c_before = rank_sym<P>(S, lo, &pj, &pin);       // rowbowt.hpp:79
-            const uint64_t c_upto = rank_sym<P>(S, hi + 1, &qj, &qin);     // rowbowt.hpp:83
+            int64_t qj;
+            bool qin;
+            uint64_t c_before, c_upto;
+            rank_pair<P>(S, lo, hi + 1, &c_before, &c_upto, &qj, &qin);    // rowbowt.hpp:79,83
             const uint64_t c_inside = c_upto - c_before;
             if (c_inside == 0) { alive = false; break; }                   // rowbowt.hpp:85
             if (TOEHOLD) {
@@ -131,21 +161,32 @@ __global__ __launch_bounds__(256) void k_occ(const uint64_t *__restrict__ lo, co
 
 template <typename P>
 __device__ __forceinline__ uint64_t phi_step(const DevIndex &ix, uint64_t i) {
-    const PhiEnt<P> *__restrict__ ent = static_cast<const PhiEnt<P> *>(ix.phi_ent);
+    const PhiSlot<P> *__restrict__ slots = static_cast<const PhiSlot<P> *>(ix.phi_slots);
     const uint64_t b = i >> ix.phi_shift;
-    uint32_t a = ix.phi_bucket[b];
-    uint32_t z = ix.phi_bucket[b + 1];
-    while (z - a > 4) {
-        const uint32_t mid = a + ((z - a) >> 1);
-        if (static_cast<uint64_t>(ent[mid].pos) < i) a = mid + 1; else z = mid;
+    const PhiSlot<P> sl = slots[b];
+    uint64_t j, base;
+    if (sl.p1 == kOvf<P>) {
+        const PhiEnt<P> *__restrict__ ent = static_cast<const PhiEnt<P> *>(ix.phi_ent);
+        uint64_t a = sl.a, z = slots[b + 1].a;
+        while (z - a > 4) {
+            const uint64_t mid = a + ((z - a) >> 1);
+            if (static_cast<uint64_t>(ent[mid].pos) < i) a = mid + 1; else z = mid;
+        }
+        while (a < z && static_cast<uint64_t>(ent[a].pos) < i) ++a;
+        // a == pred_.rank(i); circular predecessor (sparse_sd_vector.hpp:141-143)
+        const PhiEnt<P> e = ent[a ? a - 1 : ix.r - 1];
+        j = e.pos;
+        base = e.base;
+    } else {
+        // the slot of bucket 0 carries the LAST record as its "previous" one (circular predecessor)
+        j = sl.ppos; base = sl.pbase;
+        if (static_cast<uint64_t>(sl.p0) < i) {
+            j = sl.p0; base = sl.b0;
+            if (static_cast<uint64_t>(sl.p1) < i) { j = sl.p1; base = sl.b1; }
+        }
     }
-    while (a < z && static_cast<uint64_t>(ent[a].pos) < i) ++a;
-    // a == pred_.rank(i); circular predecessor (sparse_sd_vector.hpp:141-143)
-    const uint64_t jr = a ? a - 1 : ix.r - 1;
-    const PhiEnt<P> e = ent[jr];
-    const uint64_t j = e.pos;
     const uint64_t delta = j < i ? i - j : i + 1;  // toehold_sa.hpp:65
-    uint64_t s = static_cast<uint64_t>(e.base) + delta;
+    uint64_t s = base + delta;
     if (s >= ix.n) s -= ix.n;  // (prev_sample + delta) % n_, both terms <= n
     return s;
 }
@@ -265,9 +306,10 @@ __global__ __launch_bounds__(256) void k_find_range_markers(const DevIndex ix, c
                     const uint32_t slot = s_lut[c];
                     if (slot == 0xFFu) { alive = false; break; }
                     const DevSym S = slot < static_cast<uint32_t>(kLdsSyms) ? s_sym[slot] : ix.syms[slot];
-                    int64_t pj; bool pin;
-                    const uint64_t c_before = rank_sym<P>(S, lo, &pj, &pin);
-                    const uint64_t c_inside = rank_sym<P>(S, hi + 1, &pj, &pin) - c_before;
+                    int64_t qj; bool qin;
+                    uint64_t c_before, c_upto;
+                    rank_pair<P>(S, lo, hi + 1, &c_before, &c_upto, &qj, &qin);
+                    const uint64_t c_inside = c_upto - c_before;
                     if (c_inside == 0) { alive = false; break; }
                     lo = S.F + c_before;
                     hi = lo + c_inside - 1;

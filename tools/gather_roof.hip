@@ -1,0 +1,66 @@
+// gather_roof.hip -- empirical random-gather ceiling of one MI355X, in the access shape of the
+// backward-search kernels: every lane follows its own dependent chain of aligned W-byte loads at
+// uniformly random offsets of a T-byte table (no reuse between lanes).  Reported as accesses/s and
+// as GB/s of W-byte payload; compare with the 8 TB/s streaming peak to see what "HBM roofline"
+// means for a latency/transaction-bound integer gather.  Not part of the library.
+// build: hipcc -O3 --offload-arch=gfx950 tools/gather_roof.hip -o tools/gather_roof
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+template <int W>  // bytes per access: 8, 16, 32, 64
+__global__ __launch_bounds__(256) void chase(const uint4 *__restrict__ tab, unsigned long long nslots, int steps,
+                                             unsigned long long *out) {
+    unsigned long long x = (blockIdx.x * 256ull + threadIdx.x) * 0x9E3779B97F4A7C15ull + 12345;
+    unsigned long long acc = 0;
+    for (int s = 0; s < steps; ++s) {
+        x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
+        const unsigned long long slot = x % nslots;
+        const uint4 *p = tab + slot * (W / 16 ? W / 16 : 1);
+        if (W == 8) { acc += reinterpret_cast<const unsigned long long *>(tab)[slot]; }
+        else {
+            uint4 v = p[0];
+            acc += v.x;
+            if (W >= 32) { uint4 w = p[1]; acc += w.y; }
+            if (W >= 64) { uint4 w2 = p[2], w3 = p[3]; acc += w2.z + w3.w; }
+        }
+        x += acc;  // next address depends on the loaded data: one outstanding access per lane
+    }
+    out[blockIdx.x * 256ull + threadIdx.x] = acc;
+}
+
+int main(int argc, char **argv) {
+    const double gib = argc > 1 ? atof(argv[1]) : 4.0;
+    const int steps = argc > 2 ? atoi(argv[2]) : 200;
+    const size_t bytes = (size_t)(gib * (1ull << 30));
+    uint4 *tab;
+    hipMalloc(&tab, bytes);
+    hipMemset(tab, 1, bytes);
+    int cus = 256;
+    const int blocks = cus * 8;  // 8 waves/SIMD resident
+    unsigned long long *out;
+    hipMalloc(&out, blocks * 256ull * 8);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    printf("table %.1f GiB, %d blocks x 256 lanes, %d dependent accesses per lane\n", gib, blocks, steps);
+    auto run = [&](int W) {
+        const unsigned long long nslots = bytes / (W < 16 ? 8 : W);
+        for (int rep = 0; rep < 2; ++rep) {
+            hipEventRecord(e0);
+            if (W == 8) hipLaunchKernelGGL(chase<8>, dim3(blocks), dim3(256), 0, 0, tab, nslots, steps, out);
+            if (W == 16) hipLaunchKernelGGL(chase<16>, dim3(blocks), dim3(256), 0, 0, tab, nslots, steps, out);
+            if (W == 32) hipLaunchKernelGGL(chase<32>, dim3(blocks), dim3(256), 0, 0, tab, nslots, steps, out);
+            if (W == 64) hipLaunchKernelGGL(chase<64>, dim3(blocks), dim3(256), 0, 0, tab, nslots, steps, out);
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+        }
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        const double acc = (double)blocks * 256 * steps;
+        printf("W=%2d B: %.2f ms  %.2f G accesses/s  payload %.1f GB/s  (64B-sector traffic %.1f GB/s)\n", W, ms,
+               acc / ms / 1e6, acc * W / ms / 1e6, acc * (W > 64 ? W : 64) / ms / 1e6);
+    };
+    for (int W : {8, 16, 32, 64}) run(W);
+    return 0;
+}

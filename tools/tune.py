@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Layout/launch sweep on the bench index (GPU box only): builds the synthetic pangenome once, then
+one index replica per (rank_shift, phi_shift, block) and times the three kernels."""
+import argparse, os, sys, time
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import rowbowt_amd as ra
+from rowbowt_amd import capi
+from rowbowt_amd.tools import synth_pangenome as sp
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--L", type=int, default=40_000_000)
+ap.add_argument("--H", type=int, default=50)
+ap.add_argument("--reads", type=int, default=10_000_000)
+ap.add_argument("--configs", default="-1:-1:256")
+args = ap.parse_args()
+dev = torch.device("cuda:0")
+text, info = sp.make_text(args.L, args.H, 0.01, 20240229, dev)
+sa = sp.suffix_array(text)
+inp = sp.index_inputs(text, sa)
+del sa
+N, m = args.reads, 100
+reads, _ = sp.sample_reads(text, info, N, m, seed=20240231, sub_rate=0.1)
+del text
+torch.cuda.empty_cache()
+d_seqs = reads.reshape(-1)
+d_off = torch.arange(N + 1, device=dev, dtype=torch.int64) * m
+d_lo, d_hi, d_k = (torch.empty(N, dtype=torch.int64, device=dev) for _ in range(3))
+d_loc_off = torch.empty(N + 1, dtype=torch.int64, device=dev)
+L = ra.lib()
+tmp_bytes = L.rbg_locate_plan_tmp_bytes(N)
+d_tmp = torch.empty(tmp_bytes, dtype=torch.uint8, device=dev)
+st = torch.cuda.current_stream().cuda_stream
+MAXU = 2**64 - 1
+d_locs = None
+print(f"n={inp['n']} r={inp['r']}", flush=True)
+for cfg in args.configs.split(","):
+    rs, ps, bt = (int(x) for x in cfg.split(":"))
+    ra.set_default_option(capi.OPT_RANK_BUCKET_SHIFT, rs)
+    ra.set_default_option(capi.OPT_PHI_BUCKET_SHIFT, ps)
+    ra.set_default_option(capi.OPT_BLOCK_THREADS, bt)
+    t0 = time.time()
+    rb = ra.RowBowt.from_runs(inp["heads"], inp["lens"], inp["ssa"], inp["esa"], device=0)
+    i = rb.info()
+    def t(fn, reps=3):
+        fn(); torch.cuda.synchronize()
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        e[0].record()
+        for _ in range(reps): fn()
+        e[1].record(); torch.cuda.synchronize()
+        return e[0].elapsed_time(e[1]) / reps
+    ms_c = t(lambda: L.rbg_find_range_dev(rb.h, d_seqs.data_ptr(), d_off.data_ptr(), N, d_lo.data_ptr(), d_hi.data_ptr(), st))
+    ms_t = t(lambda: L.rbg_find_range_w_toehold_dev(rb.h, d_seqs.data_ptr(), d_off.data_ptr(), N, d_lo.data_ptr(), d_hi.data_ptr(), d_k.data_ptr(), st))
+    L.rbg_locate_plan_dev(rb.h, d_lo.data_ptr(), d_hi.data_ptr(), N, MAXU, d_loc_off.data_ptr(), d_tmp.data_ptr(), tmp_bytes, st)
+    if d_locs is None:
+        d_locs = torch.empty(int(d_loc_off[-1].item()), dtype=torch.int64, device=dev)
+    ms_f = t(lambda: L.rbg_locate_fill_dev(rb.h, d_lo.data_ptr(), d_hi.data_ptr(), d_k.data_ptr(), N, MAXU, d_loc_off.data_ptr(), d_locs.data_ptr(), st))
+    print(f"cfg rank_shift={i.rank_bucket_shift}({rs}) phi_shift={i.phi_bucket_shift}({ps}) block={bt}: hbm={i.hbm_bytes/1e9:.2f}GB "
+          f"rank_ovf={i.rank_slots_overflow}/{i.rank_slots} phi_ovf={i.phi_slots_overflow}/{i.phi_slots}  "
+          f"count={ms_c:.2f}ms toehold={ms_t:.2f}ms fill={ms_f:.2f}ms  build={time.time()-t0:.1f}s", flush=True)
+    rb.close()
