@@ -101,8 +101,8 @@ def main():
     del text
     torch.cuda.empty_cache()
     d_seqs = reads.reshape(-1)
-    if d_seqs.numel() % 8:
-        d_seqs = torch.cat([d_seqs, torch.zeros(8 - d_seqs.numel() % 8, dtype=torch.uint8, device=dev)])
+    if d_seqs.numel() % 16:  # reads are fetched as aligned 16-byte chunks
+        d_seqs = torch.cat([d_seqs, torch.zeros(16 - d_seqs.numel() % 16, dtype=torch.uint8, device=dev)])
     d_off = (torch.arange(N + 1, device=dev, dtype=torch.int64) * m)
     d_lo, d_hi, d_k = (torch.empty(N, dtype=torch.int64, device=dev) for _ in range(3))
     d_loc_off = torch.empty(N + 1, dtype=torch.int64, device=dev)

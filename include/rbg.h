@@ -179,7 +179,7 @@ int rbg_counters_reset(rbg_index *);
 
 /* ---- tuning (never changes results) -------------------------------------------------------- */
 /* Process-wide defaults read when an index is built/loaded: BLOCK_THREADS (multiple of 64),
- * RANK/PHI_BUCKET_SHIFT (-1 = automatic), POS_BYTES (0 = automatic, 4 or 8 to force a width). */
+ * RANK/PHI_BUCKET_SHIFT (-1 = automatic, else 0..8), POS_BYTES (0 = automatic, 4 or 8 to force a width). */
 enum { RBG_OPT_BLOCK_THREADS = 1, RBG_OPT_RANK_BUCKET_SHIFT = 2, RBG_OPT_PHI_BUCKET_SHIFT = 3, RBG_OPT_POS_BYTES = 4 };
 int rbg_set_default_option(int opt, int64_t value);
 

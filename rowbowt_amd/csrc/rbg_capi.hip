@@ -85,56 +85,74 @@ int dev_upload(rbg_index *ix, const void *src, size_t bytes, const void **dst) {
     return RBG_OK;
 }
 
-// RankSlot table of one symbol (rbg_dev.h): slot b describes bucket [b << shift, (b+1) << shift)
+// RankSlot table of one symbol (rbg_dev.h): slot b answers rank(i, c) for i in [b << shift, (b+1) << shift)
 template <typename P>
-void build_rank_slots(const SymTable &t, uint64_t n, std::vector<RankSlot<P>> &slots, uint64_t *overflow) {
+void build_rank_slots(const SymTable &t, uint64_t n, std::vector<RankSlot<P>> &slots, std::vector<uint32_t> &ord,
+                      uint64_t *overflow) {
     const uint64_t nb = (n >> t.shift) + 2;
+    const uint64_t S = uint64_t(1) << t.shift;
     slots.resize(nb);
+    ord.resize(nb);
     uint64_t k = 0;  // # runs with start < bucket begin
     for (uint64_t b = 0; b < nb; ++b) {
-        const unsigned __int128 beg = static_cast<unsigned __int128>(b) << t.shift;
-        const unsigned __int128 end = static_cast<unsigned __int128>(b + 1) << t.shift;
-        while (k < t.nruns && static_cast<unsigned __int128>(t.start[k]) < beg) ++k;
+        const uint64_t B0 = b << t.shift;
+        while (k < t.nruns && t.start[k] < B0) ++k;
+        ord[b] = static_cast<uint32_t>(k);
+        uint64_t r0 = 0, ext = 0, prev_is_c = 0;
+        if (k > 0) {
+            const uint64_t ps = t.start[k - 1], pl = t.cum[k] - t.cum[k - 1];  // cum[] has the sentinel
+            r0 = t.cum[k - 1] + std::min(pl, B0 - ps);
+            if (ps + pl > B0) ext = std::min(S, ps + pl - B0);
+            prev_is_c = ps + pl >= B0 ? 1 : 0;
+        }
+        uint32_t run[5] = {0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu};
         uint64_t cnt = 0;
-        while (k + cnt < t.nruns && static_cast<unsigned __int128>(t.start[k + cnt]) < end) ++cnt;
+        while (k + cnt < t.nruns && t.start[k + cnt] < B0 + S) {
+            if (cnt < 5) {
+                const uint64_t off = t.start[k + cnt] - B0;
+                const uint64_t len = std::min(t.cum[k + cnt + 1] - t.cum[k + cnt], B0 + S - t.start[k + cnt]);
+                run[cnt] = static_cast<uint32_t>(off | ((len - 1) << 8));
+            }
+            ++cnt;
+        }
+        uint32_t code = static_cast<uint32_t>(cnt);
+        if (cnt > 5) { code = kSlotOvf; ++*overflow; }
         RankSlot<P> &s = slots[b];
-        s.pstart = k ? static_cast<P>(t.start[k - 1]) : kSent<P>;
-        s.pcum = k ? static_cast<P>(t.cum[k - 1]) : P(0);
-        s.a = static_cast<P>(k);
-        // cum[] carries the sentinel cum[nruns] = total, so cum[k + x] is valid for x <= cnt
-        s.s0 = cnt >= 1 ? static_cast<P>(t.start[k]) : kSent<P>;
-        s.c0 = static_cast<P>(t.cum[k]);
-        if (cnt >= 2) { s.s1 = static_cast<P>(t.start[k + 1]); s.c1 = static_cast<P>(t.cum[k + 1]); }
-        else { s.s1 = kSent<P>; s.c1 = static_cast<P>(t.cum[std::min(k + 1, t.nruns)]); }
-        s.next_cum = static_cast<P>(t.cum[std::min(k + 2, t.nruns)]);
-        if (cnt == 0) { s.c1 = s.c0; s.next_cum = s.c0; }
-        if (cnt == 1) s.next_cum = s.c1;
-        if (cnt > 2) { s.s1 = kOvf<P>; ++*overflow; }
+        s.r0 = static_cast<P>(r0);
+        s.w1 = static_cast<P>(static_cast<uint32_t>(ext) | (code << 9) | (static_cast<uint32_t>(prev_is_c) << 12) | (run[0] << 16));
+        s.w2 = static_cast<P>(run[1] | (run[2] << 16));
+        s.w3 = static_cast<P>(run[3] | (run[4] << 16));
     }
 }
 
 template <typename P>
-void build_phi_slots(const HostIndex &h, std::vector<PhiSlot<P>> &slots, uint64_t *overflow) {
+void build_phi_slots(const HostIndex &h, std::vector<PhiSlot<P>> &slots, std::vector<uint32_t> &ord, uint64_t *overflow) {
     const uint64_t nb = (h.n >> h.phi_shift) + 2;
+    const uint64_t S = uint64_t(1) << h.phi_shift;
     slots.resize(nb);
+    ord.resize(nb);
+    // D = base - pos (mod n); with no predecessor the reference uses the LAST record with
+    // delta = i + 1 (toehold_sa.hpp:59,65), i.e. pos = -1
+    auto D_of = [&](uint64_t j) { return (h.phi_base[j] + h.n - h.pred_pos[j]) % h.n; };
     uint64_t k = 0;
     for (uint64_t b = 0; b < nb; ++b) {
-        const unsigned __int128 beg = static_cast<unsigned __int128>(b) << h.phi_shift;
-        const unsigned __int128 end = static_cast<unsigned __int128>(b + 1) << h.phi_shift;
-        while (k < h.r && static_cast<unsigned __int128>(h.pred_pos[k]) < beg) ++k;
-        uint64_t cnt = 0;
-        while (k + cnt < h.r && static_cast<unsigned __int128>(h.pred_pos[k + cnt]) < end) ++cnt;
+        const uint64_t B0 = b << h.phi_shift;
+        while (k < h.r && h.pred_pos[k] < B0) ++k;
+        ord[b] = static_cast<uint32_t>(k);
         PhiSlot<P> &s = slots[b];
-        const uint64_t pj = k ? k - 1 : h.r - 1;  // circular predecessor, sparse_sd_vector.hpp:141-143
-        s.ppos = static_cast<P>(h.pred_pos[pj]);
-        s.pbase = static_cast<P>(h.phi_base[pj]);
-        s.a = static_cast<P>(k);
-        s.pad = 0;
-        s.p0 = cnt >= 1 ? static_cast<P>(h.pred_pos[k]) : kSent<P>;
-        s.b0 = cnt >= 1 ? static_cast<P>(h.phi_base[k]) : P(0);
-        s.p1 = cnt >= 2 ? static_cast<P>(h.pred_pos[k + 1]) : kSent<P>;
-        s.b1 = cnt >= 2 ? static_cast<P>(h.phi_base[k + 1]) : P(0);
-        if (cnt > 2) { s.p1 = kOvf<P>; ++*overflow; }
+        s.dprev = static_cast<P>(k ? D_of(k - 1) : (h.phi_base[h.r - 1] + 1) % h.n);
+        uint64_t cnt = 0;
+        uint32_t off[2] = {0xFFu, 0xFFu};
+        uint64_t d[2] = {0, 0};
+        while (k + cnt < h.r && h.pred_pos[k + cnt] < B0 + S) {
+            if (cnt < 2) { off[cnt] = static_cast<uint32_t>(h.pred_pos[k + cnt] - B0); d[cnt] = D_of(k + cnt); }
+            ++cnt;
+        }
+        uint32_t code = static_cast<uint32_t>(cnt);
+        if (cnt > 2) { code = kPhiOvf; ++*overflow; }
+        s.d0 = static_cast<P>(d[0]);
+        s.d1 = static_cast<P>(d[1]);
+        s.meta = static_cast<P>(off[0] | (off[1] << 8) | (code << 16));
     }
 }
 
@@ -160,10 +178,15 @@ int upload_tables(rbg_index *ix) {
         }
         {
             std::vector<RankSlot<P>> slots;
-            build_rank_slots<P>(t, h.n, slots, &ix->rank_slots_overflow);
+            std::vector<uint32_t> ord;
+            build_rank_slots<P>(t, h.n, slots, ord, &ix->rank_slots_overflow);
             ix->rank_slots += slots.size();
             rc = dev_upload(ix, slots.data(), slots.size() * sizeof(RankSlot<P>), &syms[s].slots);
             if (rc) return rc;
+            const void *po = nullptr;
+            rc = dev_upload(ix, ord.data(), ord.size() * sizeof(uint32_t), &po);
+            if (rc) return rc;
+            syms[s].ord = static_cast<const uint32_t *>(po);
         }
         syms[s].nruns = t.nruns;
         syms[s].F = t.F;
@@ -186,10 +209,14 @@ int upload_tables(rbg_index *ix) {
             if (rc) return rc;
         }
         std::vector<PhiSlot<P>> slots;
-        build_phi_slots<P>(h, slots, &ix->phi_slots_overflow);
+        std::vector<uint32_t> ord;
+        build_phi_slots<P>(h, slots, ord, &ix->phi_slots_overflow);
         ix->phi_slots = slots.size();
         rc = dev_upload(ix, slots.data(), slots.size() * sizeof(PhiSlot<P>), &ix->dev.phi_slots);
         if (rc) return rc;
+        rc = dev_upload(ix, ord.data(), ord.size() * sizeof(uint32_t), &p);
+        if (rc) return rc;
+        ix->dev.phi_ord = static_cast<const uint32_t *>(p);
     }
     return RBG_OK;
 }
@@ -282,7 +309,7 @@ struct ReadBatch {
     int stage(const uint8_t *h_seqs, const uint64_t *h_off, uint64_t N, hipStream_t st) {
         const uint64_t total = N ? h_off[N] : 0;
         int rc;
-        if ((rc = seqs.alloc(((total + 7) & ~uint64_t(7)) + 8))) return rc;
+        if ((rc = seqs.alloc(((total + 15) & ~uint64_t(15)) + 16))) return rc;
         if ((rc = off.alloc((N + 1) * 8))) return rc;
         if (total) HIP_TRY(hipMemcpyAsync(seqs.p, h_seqs, total, hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync(off.p, h_off, (N + 1) * 8, hipMemcpyHostToDevice, st));
@@ -344,10 +371,10 @@ int rbg_set_default_option(int opt, int64_t value) {
             if (value < 64 || value > 1024 || value % 64) return RBG_EARG;
             g_opt_block_threads = value; return RBG_OK;
         case RBG_OPT_RANK_BUCKET_SHIFT:
-            if (value < -1 || value > 62) return RBG_EARG;
+            if (value < -1 || value > 8) return RBG_EARG;  // slot offsets are 8-bit
             g_opt_rank_shift = value; return RBG_OK;
         case RBG_OPT_PHI_BUCKET_SHIFT:
-            if (value < -1 || value > 62) return RBG_EARG;
+            if (value < -1 || value > 8) return RBG_EARG;
             g_opt_phi_shift = value; return RBG_OK;
         case RBG_OPT_POS_BYTES:
             if (value != 0 && value != 4 && value != 8) return RBG_EARG;
@@ -536,7 +563,7 @@ int rbg_find_range_dev(rbg_index *ix, const uint8_t *d_seqs, const uint64_t *d_o
                        uint64_t *d_hi, void *stream) {
     if (!queryable(ix)) return RBG_ENODEV;
     if (N && (!d_seqs || !d_off || !d_lo || !d_hi)) return RBG_EARG;
-    if (reinterpret_cast<uintptr_t>(d_seqs) & 7) return RBG_EARG;  // reads are fetched as aligned 8-byte words
+    if (reinterpret_cast<uintptr_t>(d_seqs) & 15) return RBG_EARG;  // reads are fetched as aligned 16-byte chunks
     return launch_find_range(ix->dev, ix->cfg, d_seqs, d_off, N, d_lo, d_hi, nullptr, stream) ? RBG_ENODEV : RBG_OK;
 }
 
@@ -545,7 +572,7 @@ int rbg_find_range_w_toehold_dev(rbg_index *ix, const uint8_t *d_seqs, const uin
     if (!queryable(ix)) return RBG_ENODEV;
     if (!ix->host.has_tsa) return RBG_ENOTLOADED;
     if (N && (!d_seqs || !d_off || !d_lo || !d_hi || !d_ssamp)) return RBG_EARG;
-    if (reinterpret_cast<uintptr_t>(d_seqs) & 7) return RBG_EARG;
+    if (reinterpret_cast<uintptr_t>(d_seqs) & 15) return RBG_EARG;
     return launch_find_range(ix->dev, ix->cfg, d_seqs, d_off, N, d_lo, d_hi, d_ssamp, stream) ? RBG_ENODEV : RBG_OK;
 }
 

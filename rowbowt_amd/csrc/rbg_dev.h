@@ -22,38 +22,40 @@ struct PhiEnt {
     P base;
 };
 
-// First level of every predecessor search, direct-addressed by (position >> shift): one record
-// per bucket of 2^shift BWT positions that already CONTAINS the answer in the common case, so a
-// rank is ONE aligned 8-word load instead of "bucket word -> entries" (two dependent gathers).
-//   prev      = last run of the symbol starting strictly before the bucket (start = kSent if none)
-//   e0, e1    = first two runs starting inside the bucket (start = kSent if absent)
-//   cum of an absent entry = cum of the run that would come next, so len(p) = next(p).cum - p.cum
-//   a         = ordinal (within the symbol's run list) of the first run starting inside the bucket
-//   e1.start == kOvf: more than two runs start in the bucket -> search ent[a .. next slot's a)
+// First level of every rank: one record per bucket of 2^shift BWT positions (shift <= 8),
+// direct-addressed by (position >> shift), that ANSWERS rank(i, c) for every i in the bucket in
+// the common case.  Four words (16 bytes when positions are 32-bit), so one rank is one load
+// request: tools/gather_roof.hip shows the chip is bound by the number of gather requests, not by
+// their bytes (51 G/s at 16 B, 30 G/s at 32 B).
+//   r0  = rank(B0, c), B0 = bucket begin
+//   w1  = ext (bits 0-8: how many positions from B0 are covered by a run of c that began before
+//         B0) | cnt (bits 9-11: runs of c that START inside the bucket, 0..5; 7 = more than 5)
+//         | prev_is_c (bit 12: position B0-1 holds c) | run0 (bits 16-31)
+//   w2  = run1 | run2 << 16,   w3 = run3 | run4 << 16
+//   run = off (8 bits, start - B0) | (len - 1) << 8, len clipped to the bucket; absent = 0xFFFF
+//   rank(i) = r0 + min(o, ext) + sum_t clamp(o - off_t, 0, len_t),  o = i - B0
+// cnt == 7 falls back to the run list ent[ord[b] .. ord[b+1]).
 template <typename P>
-struct alignas(8 * sizeof(P)) RankSlot {
-    P pstart, pcum;
-    P s0, c0;
-    P s1, c1;
-    P next_cum;
-    P a;
+struct alignas(4 * sizeof(P)) RankSlot {
+    P r0, w1, w2, w3;
 };
-// same idea for phi's predecessor structure over text positions (payload = phi base)
+// phi's first level over text positions: phi(i) = (D + i) mod n where D = base - pos (mod n) of
+// the last sampled position strictly before i.  dprev is that D at the bucket begin; d0/d1 belong
+// to the first two sampled positions inside the bucket.
+//   meta = off0 (bits 0-7) | off1 (8-15) | cnt (16-17: 0..2; 3 = more than 2); absent off = 0xFF
 template <typename P>
-struct alignas(8 * sizeof(P)) PhiSlot {
-    P ppos, pbase;
-    P p0, b0;
-    P p1, b1;
-    P a;
-    P pad;
+struct alignas(4 * sizeof(P)) PhiSlot {
+    P dprev, d0, d1, meta;
 };
-template <typename P> constexpr P kSent = static_cast<P>(~static_cast<P>(0));
-template <typename P> constexpr P kOvf = static_cast<P>(~static_cast<P>(0) - 1);
+constexpr uint32_t kSlotOvf = 7;
+constexpr uint32_t kPhiOvf = 3;
+constexpr uint32_t kMaxSlotShift = 8;
 
 struct DevSym {
     const void *ent;    // RunEnt<P>[nruns + 1] (sentinel: start = n, cum = total): overflow buckets, samples
     const void *samp;   // P[nruns]: samples_last_ of each run (nullptr without toehold SA)
     const void *slots;  // RankSlot<P>[(n >> shift) + 2]
+    const uint32_t *ord;  // (n >> shift) + 2: # runs of the symbol starting before each bucket
     uint64_t nruns;
     uint64_t F;      // RowBowt::f_[byte]
     uint64_t total;  // occurrences of the symbol
@@ -72,6 +74,7 @@ struct DevIndex {
     // phi
     const void *phi_ent;    // PhiEnt<P>[r]
     const void *phi_slots;  // PhiSlot<P>[(n >> phi_shift) + 2]
+    const uint32_t *phi_ord;  // (n >> phi_shift) + 2: # sampled positions before each bucket
     uint32_t phi_shift;
     uint32_t has_tsa;
     // markers

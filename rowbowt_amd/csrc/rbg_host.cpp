@@ -334,12 +334,11 @@ int parse_docs(const std::string &fname, RawDocs &out) {
 
 // ---- flatten -------------------------------------------------------------------------------------
 namespace {
-uint32_t auto_shift(uint64_t n, uint64_t items) {
-    // largest shift with (n >> shift) >= 2 * items: 0.25-0.5 items per slot, so that a slot's two
-    // inline entries almost always suffice (rbg_dev.h RankSlot / PhiSlot)
+// largest shift <= 8 (slot offsets are 8-bit, rbg_dev.h) with at most `per_slot` items per bucket on average
+uint32_t auto_shift(uint64_t n, uint64_t items, double per_slot) {
     if (items == 0) items = 1;
     uint32_t s = 0;
-    while (s < 63 && (n >> (s + 1)) >= 2 * items) ++s;
+    while (s < 8 && static_cast<double>(items) * static_cast<double>(uint64_t(2) << s) <= per_slot * static_cast<double>(n)) ++s;
     return s;
 }
 }  // namespace
@@ -347,6 +346,7 @@ uint32_t auto_shift(uint64_t n, uint64_t items) {
 int flatten(const RawRle &rle, const RawTsa *tsa, const FlattenOptions &opt, HostIndex &out) {
     const uint64_t R = rle.R;
     if (R == 0 || rle.heads.size() != R || rle.lens.size() != R) return RBG_EARG;
+    if (R >= 0xFFFFFFF0ull) return RBG_EARG;  // run ordinals (DevSym::ord) are 32-bit
     if (tsa && (tsa->r != R || tsa->samples_last.size() != R || tsa->pred_pos.size() != R || tsa->pred_to_run.size() != R))
         return RBG_EFORMAT;
     out = HostIndex();
@@ -402,7 +402,8 @@ int flatten(const RawRle &rle, const RawTsa *tsa, const FlattenOptions &opt, Hos
     for (SymTable &t : out.sym) {
         t.start.push_back(out.n);
         t.cum.push_back(t.total);
-        t.shift = opt.rank_bucket_shift >= 0 ? static_cast<uint32_t>(opt.rank_bucket_shift) : auto_shift(out.n, t.nruns);
+        t.shift = opt.rank_bucket_shift >= 0 ? static_cast<uint32_t>(opt.rank_bucket_shift) : auto_shift(out.n, t.nruns, 1.5);
+        if (t.shift > 8) return RBG_EARG;
     }
     if (tsa) {
         out.has_tsa = true;
@@ -415,7 +416,8 @@ int flatten(const RawRle &rle, const RawTsa *tsa, const FlattenOptions &opt, Hos
             if (j && out.pred_pos[j] <= out.pred_pos[j - 1]) return RBG_EFORMAT;
         }
         out.last_run_sample = (tsa->samples_last[R - 1] + 1) % out.n;  // toehold_sa.hpp:97-99
-        out.phi_shift = opt.phi_bucket_shift >= 0 ? static_cast<uint32_t>(opt.phi_bucket_shift) : auto_shift(out.n, R);
+        out.phi_shift = opt.phi_bucket_shift >= 0 ? static_cast<uint32_t>(opt.phi_bucket_shift) : auto_shift(out.n, R, 0.75);
+        if (out.phi_shift > 8) return RBG_EARG;
     }
     return RBG_OK;
 }

@@ -8,9 +8,9 @@
 //  K4     k_markers_*              MarkerArray::at_range behind RowBowt::markers_at rowbowt.hpp:282-285.
 //
 // Integer gather kernels: no MFMA (nothing here is a contraction).  The bound is HBM / fabric
-// transactions per LF step, so the layout (rbg_dev.h) makes one rank = ONE aligned 8-word slot
-// (direct-addressed by position >> shift) that already holds the predecessor run, and both ranks
-// of a step share that slot whenever lo and hi+1 fall in the same bucket.
+// transactions per LF step, so the layout (rbg_dev.h) makes one rank = ONE aligned 4-word slot
+// (direct-addressed by position >> shift) that already answers the rank, and both ranks of a step
+// share that slot whenever lo and hi+1 fall in the same bucket.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
@@ -22,59 +22,92 @@ namespace {
 constexpr int kWave = 64;
 
 // ---- rank over one symbol table -----------------------------------------------------------------
-// Returns # of the symbol in BWT[0,i)  ==  rle_string::rank(i,c) (rle_string.hpp:131-161), via
-// the identity  rank = cum[j] + min(i - start[j], len[j])  for the last run j with start[j] < i.
-// *pred = j (or -1), *inside = (i-1 lies inside run j), used by the toehold update.
-// `sl` is the RankSlot of bucket b = i >> shift, already in registers: in the common case nothing
-// else is read.  Only a bucket with more than two run starts walks the run list ent[a..z).
+// Returns # of the symbol in BWT[0,i)  ==  rle_string::rank(i,c) (rle_string.hpp:131-161).
+// `sl` is the RankSlot of bucket b = i >> shift, already in registers (rbg_dev.h): nothing else is
+// read unless the bucket holds more than 5 run starts.
+// *nbefore = # runs of the symbol that start in [B0, i)  (-> ordinal of the predecessor run),
+// *inside  = position i-1 holds the symbol; both feed the toehold update.
+struct RankAux {
+    uint32_t nbefore;
+    bool inside;
+    bool ovf;
+    int64_t pred;  // valid when ovf
+};
+
 template <typename P>
 __device__ __forceinline__ uint64_t rank_in_slot(const DevSym &S, const RankSlot<P> &sl, uint64_t b, uint64_t i,
-                                                 int64_t *pred, bool *inside) {
-    uint64_t pstart = sl.pstart, pcum = sl.pcum, nx = sl.c0;
-    int64_t j = static_cast<int64_t>(sl.a) - 1;
-    if (sl.s1 == kOvf<P>) {
+                                                 RankAux *aux) {
+    const uint32_t w1 = static_cast<uint32_t>(sl.w1), w2 = static_cast<uint32_t>(sl.w2), w3 = static_cast<uint32_t>(sl.w3);
+    const uint32_t cnt = (w1 >> 9) & 7u;
+    if (cnt == kSlotOvf) {
         const RunEnt<P> *__restrict__ ent = static_cast<const RunEnt<P> *>(S.ent);
-        uint64_t a = sl.a;
-        uint64_t z = static_cast<const RankSlot<P> *>(S.slots)[b + 1].a;
+        uint64_t a = S.ord[b], z = S.ord[b + 1];
         while (z - a > 4) {
             const uint64_t mid = a + ((z - a) >> 1);
             if (static_cast<uint64_t>(ent[mid].start) < i) a = mid + 1; else z = mid;
         }
         while (a < z && static_cast<uint64_t>(ent[a].start) < i) ++a;
-        if (a == 0) { *pred = -1; *inside = false; return 0; }
+        aux->ovf = true;
+        aux->nbefore = 0;
+        if (a == 0) { aux->pred = -1; aux->inside = false; return 0; }
         const RunEnt<P> e = ent[a - 1];
-        pstart = e.start;
-        pcum = e.cum;
-        nx = ent[a].cum;
-        j = static_cast<int64_t>(a) - 1;
-    } else {
-        if (static_cast<uint64_t>(sl.s0) < i) {
-            pstart = sl.s0; pcum = sl.c0; nx = sl.c1; j += 1;
-            if (static_cast<uint64_t>(sl.s1) < i) { pstart = sl.s1; pcum = sl.c1; nx = sl.next_cum; j += 1; }
-        }
-        if (pstart == static_cast<uint64_t>(kSent<P>)) { *pred = -1; *inside = false; return 0; }
+        const uint64_t len = static_cast<uint64_t>(ent[a].cum) - static_cast<uint64_t>(e.cum);
+        const uint64_t d = i - static_cast<uint64_t>(e.start);
+        aux->pred = static_cast<int64_t>(a) - 1;
+        aux->inside = d <= len;
+        return static_cast<uint64_t>(e.cum) + (d < len ? d : len);
     }
-    const uint64_t len = nx - pcum;
-    const uint64_t d = i - pstart;
-    *pred = j;
-    *inside = d <= len;
-    return pcum + (d < len ? d : len);
+    const uint32_t o = static_cast<uint32_t>(i - (b << S.shift));
+    const uint32_t ext = w1 & 0x1FFu;
+    uint32_t add = o < ext ? o : ext;
+    bool in = o ? (o <= ext) : ((w1 >> 12) & 1u);
+    uint32_t nb = 0;
+#define RBG_RUN(field)                                            \
+    {                                                             \
+        const uint32_t run_ = (field);                            \
+        const uint32_t off_ = run_ & 0xFFu;                       \
+        const uint32_t len_ = ((run_ >> 8) & 0xFFu) + 1u;         \
+        if (o > off_) {                                           \
+            const uint32_t d_ = o - off_;                         \
+            add += d_ < len_ ? d_ : len_;                         \
+            in = in || d_ <= len_;                                \
+            ++nb;                                                 \
+        }                                                         \
+    }
+    RBG_RUN(w1 >> 16)
+    RBG_RUN(w2 & 0xFFFFu)
+    RBG_RUN(w2 >> 16)
+    RBG_RUN(w3 & 0xFFFFu)
+    RBG_RUN(w3 >> 16)
+#undef RBG_RUN
+    aux->ovf = false;
+    aux->nbefore = nb;
+    aux->inside = in;
+    return static_cast<uint64_t>(sl.r0) + add;
 }
 
 // both ranks of one LF step (rowbowt.hpp:79,83).  lo and hi+1 usually share a bucket late in the
-// search (the range has narrowed to a few dozen rows), so the step is one 8-word load.
+// search (the range has narrowed to a few dozen rows), so the step is ONE 4-word load.
 template <typename P>
 __device__ __forceinline__ void rank_pair(const DevSym &S, uint64_t lo, uint64_t hi1, uint64_t *c_before, uint64_t *c_upto,
-                                          int64_t *qj, bool *qin) {
+                                          uint64_t *bh_out, RankAux *qaux) {
     const RankSlot<P> *__restrict__ slots = static_cast<const RankSlot<P> *>(S.slots);
     const uint64_t bl = lo >> S.shift, bh = hi1 >> S.shift;
     const RankSlot<P> sl = slots[bl];
     RankSlot<P> sh = sl;
     if (bh != bl) sh = slots[bh];
-    int64_t pj;
-    bool pin;
-    *c_before = rank_in_slot<P>(S, sl, bl, lo, &pj, &pin);
-    *c_upto = rank_in_slot<P>(S, sh, bh, hi1, qj, qin);
+    RankAux paux;
+    *c_before = rank_in_slot<P>(S, sl, bl, lo, &paux);
+    *c_upto = rank_in_slot<P>(S, sh, bh, hi1, qaux);
+    *bh_out = bh;
+}
+
+// samples_last_ of the last run of the symbol that starts before i (LF_w_loc, rowbowt.hpp:563-566);
+// only taken when position i-1 does not hold the symbol, which is the rare case.
+template <typename P>
+__device__ __forceinline__ uint64_t pred_sample(const DevSym &S, uint64_t b, const RankAux &aux) {
+    const uint64_t j = aux.ovf ? static_cast<uint64_t>(aux.pred) : static_cast<uint64_t>(S.ord[b]) + aux.nbefore - 1;
+    return static_cast<uint64_t>(static_cast<const P *>(S.samp)[j]);
 }
 
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
@@ -96,7 +129,7 @@ __global__ __launch_bounds__(256) void k_find_range(const DevIndex ix, const uin
     for (int t = threadIdx.x; t < nlds; t += blockDim.x) s_sym[t] = ix.syms[t];
     __syncthreads();
 
-    const uint64_t *__restrict__ words = reinterpret_cast<const uint64_t *>(seqs);
+    const uint4 *__restrict__ chunks = reinterpret_cast<const uint4 *>(seqs);  // reads are fetched 16 bytes at a time
     unsigned long long c_reads = 0, c_matched = 0, c_occ = 0;
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
     for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < N; i += stride) {
@@ -104,28 +137,30 @@ __global__ __launch_bounds__(256) void k_find_range(const DevIndex ix, const uin
         uint64_t p = off[i + 1];
         uint64_t lo = 0, hi = ix.n - 1;  // full_range(), rowbowt.hpp:115-118
         uint64_t k = TOEHOLD ? ix.last_run_sample : 0;
-        uint64_t cur_wi = ~uint64_t(0), w = 0;
+        uint64_t cur_ci = ~uint64_t(0);
+        uint4 w = make_uint4(0, 0, 0, 0);
         bool alive = true;
         while (p > beg) {  // right-to-left over the read (rowbowt.hpp:127-129, :175-181)
             --p;
-            const uint64_t wi = p >> 3;
-            if (wi != cur_wi) { w = words[wi]; cur_wi = wi; }
-            const uint32_t c = static_cast<uint32_t>(w >> ((p & 7) * 8)) & 0xFFu;
+            const uint64_t ci = p >> 4;
+            if (ci != cur_ci) { w = chunks[ci]; cur_ci = ci; }
+            const uint32_t sel = static_cast<uint32_t>(p) & 15u;
+            const uint32_t word = sel < 8 ? (sel < 4 ? w.x : w.y) : (sel < 12 ? w.z : w.w);
+            const uint32_t c = (word >> ((sel & 3u) * 8)) & 0xFFu;
             const uint32_t slot = s_lut[c];
             if (slot == 0xFFu) { alive = false; break; }  // symbol absent: f_[c] >= f_[c+1], rowbowt.hpp:76
             const DevSym S = slot < static_cast<uint32_t>(kLdsSyms) ? s_sym[slot] : ix.syms[slot];
-            int64_t qj;
-            bool qin;
-            uint64_t c_before, c_upto;
-            rank_pair<P>(S, lo, hi + 1, &c_before, &c_upto, &qj, &qin);    // rowbowt.hpp:79,83
+            RankAux q;
+            uint64_t c_before, c_upto, bh;
+            rank_pair<P>(S, lo, hi + 1, &c_before, &c_upto, &bh, &q);      // rowbowt.hpp:79,83
             const uint64_t c_inside = c_upto - c_before;
             if (c_inside == 0) { alive = false; break; }                   // rowbowt.hpp:85
             if (TOEHOLD) {
-                // LF_w_loc, rowbowt.hpp:559-566.  Run qj is the last run of c starting at or before
-                // hi: either it contains hi (bwt_[hi]==c -> k-1), or it ends before hi and its last
-                // position is select(rank(hi,c)-1,c), whose run-end sample is samples_last_[run].
-                if (qin) k = k - 1;
-                else k = static_cast<uint64_t>(static_cast<const P *>(S.samp)[qj]);
+                // LF_w_loc, rowbowt.hpp:559-566.  Either hi holds c (bwt_[hi]==c -> k-1), or the last
+                // run of c starting before hi ends before hi and its last position is
+                // select(rank(hi,c)-1,c), whose run-end sample is samples_last_[run].
+                if (q.inside) k = k - 1;
+                else k = pred_sample<P>(S, bh, q);
             }
             lo = S.F + c_before;           // rowbowt.hpp:86
             hi = lo + c_inside - 1;        // rowbowt.hpp:87
@@ -164,10 +199,11 @@ __device__ __forceinline__ uint64_t phi_step(const DevIndex &ix, uint64_t i) {
     const PhiSlot<P> *__restrict__ slots = static_cast<const PhiSlot<P> *>(ix.phi_slots);
     const uint64_t b = i >> ix.phi_shift;
     const PhiSlot<P> sl = slots[b];
-    uint64_t j, base;
-    if (sl.p1 == kOvf<P>) {
+    const uint32_t meta = static_cast<uint32_t>(sl.meta);
+    uint64_t s;
+    if (((meta >> 16) & 3u) == kPhiOvf) {
         const PhiEnt<P> *__restrict__ ent = static_cast<const PhiEnt<P> *>(ix.phi_ent);
-        uint64_t a = sl.a, z = slots[b + 1].a;
+        uint64_t a = ix.phi_ord[b], z = ix.phi_ord[b + 1];
         while (z - a > 4) {
             const uint64_t mid = a + ((z - a) >> 1);
             if (static_cast<uint64_t>(ent[mid].pos) < i) a = mid + 1; else z = mid;
@@ -175,19 +211,17 @@ __device__ __forceinline__ uint64_t phi_step(const DevIndex &ix, uint64_t i) {
         while (a < z && static_cast<uint64_t>(ent[a].pos) < i) ++a;
         // a == pred_.rank(i); circular predecessor (sparse_sd_vector.hpp:141-143)
         const PhiEnt<P> e = ent[a ? a - 1 : ix.r - 1];
-        j = e.pos;
-        base = e.base;
+        const uint64_t j = e.pos;
+        const uint64_t delta = j < i ? i - j : i + 1;  // toehold_sa.hpp:65
+        s = static_cast<uint64_t>(e.base) + delta;
     } else {
-        // the slot of bucket 0 carries the LAST record as its "previous" one (circular predecessor)
-        j = sl.ppos; base = sl.pbase;
-        if (static_cast<uint64_t>(sl.p0) < i) {
-            j = sl.p0; base = sl.b0;
-            if (static_cast<uint64_t>(sl.p1) < i) { j = sl.p1; base = sl.b1; }
-        }
+        const uint32_t o = static_cast<uint32_t>(i - (b << ix.phi_shift));
+        uint64_t D = sl.dprev;
+        if (o > (meta & 0xFFu)) D = sl.d0;
+        if (o > ((meta >> 8) & 0xFFu)) D = sl.d1;
+        s = D + i;  // D = (base - pos) mod n of the predecessor: base + (i - pos)
     }
-    const uint64_t delta = j < i ? i - j : i + 1;  // toehold_sa.hpp:65
-    uint64_t s = base + delta;
-    if (s >= ix.n) s -= ix.n;  // (prev_sample + delta) % n_, both terms <= n
+    if (s >= ix.n) s -= ix.n;  // (prev_sample + delta) % n_ (toehold_sa.hpp:71); s < 2n
     return s;
 }
 
@@ -205,11 +239,19 @@ __global__ __launch_bounds__(256) void k_locate_fill(const DevIndex ix, const ui
         if (occ == 0) continue;
         uint64_t *dst = locs + loc_off[i];
         uint64_t k1 = k[i];
-        dst[0] = k1;
-        for (uint64_t t = 1; t < occ; ++t) {
-            k1 = phi_step<P>(ix, k1);
-            dst[t] = k1;
+        // stores are gather-class requests too: emit two locations per 16-byte store
+        uint64_t t = 0;
+        if ((reinterpret_cast<uintptr_t>(dst) & 15u) && occ) {  // peel one to reach 16-byte alignment
+            dst[0] = k1;
+            t = 1;
+            if (t < occ) k1 = phi_step<P>(ix, k1);
         }
+        for (; t + 1 < occ; t += 2) {
+            const uint64_t k2 = phi_step<P>(ix, k1);
+            *reinterpret_cast<ulonglong2 *>(dst + t) = make_ulonglong2(k1, k2);
+            if (t + 2 < occ) k1 = phi_step<P>(ix, k2);
+        }
+        if (t < occ) dst[t] = k1;
         c_locs += occ;
     }
     c_locs = wave_sum(c_locs);
@@ -306,9 +348,9 @@ __global__ __launch_bounds__(256) void k_find_range_markers(const DevIndex ix, c
                     const uint32_t slot = s_lut[c];
                     if (slot == 0xFFu) { alive = false; break; }
                     const DevSym S = slot < static_cast<uint32_t>(kLdsSyms) ? s_sym[slot] : ix.syms[slot];
-                    int64_t qj; bool qin;
-                    uint64_t c_before, c_upto;
-                    rank_pair<P>(S, lo, hi + 1, &c_before, &c_upto, &qj, &qin);
+                    RankAux q;
+                    uint64_t c_before, c_upto, bh;
+                    rank_pair<P>(S, lo, hi + 1, &c_before, &c_upto, &bh, &q);
                     const uint64_t c_inside = c_upto - c_before;
                     if (c_inside == 0) { alive = false; break; }
                     lo = S.F + c_before;

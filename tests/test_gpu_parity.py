@@ -117,7 +117,7 @@ def synth():
     return SynthIndex(L=4000, H=8, n_sites=60, seed=11)
 
 
-@pytest.mark.parametrize("pos_bytes,rshift,pshift", [(0, -1, -1), (8, -1, -1), (4, 0, 0), (8, 3, 2), (4, 12, 12), (8, 40, 40)])
+@pytest.mark.parametrize("pos_bytes,rshift,pshift", [(0, -1, -1), (8, -1, -1), (4, 0, 0), (8, 3, 2), (4, 8, 8), (8, 8, 7), (4, 5, 6)])
 def test_synth_all_paths(synth, pos_bytes, rshift, pshift):
     S = synth
     ra.set_default_option(capi.OPT_POS_BYTES, pos_bytes)
@@ -188,7 +188,7 @@ def test_device_resident_api(synth):
     seqs, off = ra.pack_reads(reads)
     N = len(reads)
     dev = torch.device("cuda:0")
-    pad = (-len(seqs)) % 8
+    pad = (-len(seqs)) % 16
     d_seqs = torch.from_numpy(np.concatenate([seqs, np.zeros(pad, np.uint8)])).to(dev)
     d_off = torch.from_numpy(off.view(np.int64)).to(dev)
     d_lo, d_hi, d_k = (torch.empty(N, dtype=torch.int64, device=dev) for _ in range(3))

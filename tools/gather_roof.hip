@@ -33,17 +33,18 @@ __global__ __launch_bounds__(256) void chase(const uint4 *__restrict__ tab, unsi
 int main(int argc, char **argv) {
     const double gib = argc > 1 ? atof(argv[1]) : 4.0;
     const int steps = argc > 2 ? atoi(argv[2]) : 200;
+    const int waves_per_simd = argc > 3 ? atoi(argv[3]) : 8;
     const size_t bytes = (size_t)(gib * (1ull << 30));
     uint4 *tab;
     hipMalloc(&tab, bytes);
     hipMemset(tab, 1, bytes);
     int cus = 256;
-    const int blocks = cus * 8;  // 8 waves/SIMD resident
+    const int blocks = cus * waves_per_simd;  // 256-lane blocks: one block per CU = 1 wave per SIMD
     unsigned long long *out;
     hipMalloc(&out, blocks * 256ull * 8);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    printf("table %.1f GiB, %d blocks x 256 lanes, %d dependent accesses per lane\n", gib, blocks, steps);
+    printf("table %.3f GiB, %d blocks x 256 lanes (%d waves/SIMD), %d dependent accesses per lane\n", gib, blocks, waves_per_simd, steps);
     auto run = [&](int W) {
         const unsigned long long nslots = bytes / (W < 16 ? 8 : W);
         for (int rep = 0; rep < 2; ++rep) {
