@@ -73,6 +73,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
 
     import rowbowt_amd as ra
+    from rowbowt_amd import shard
     from rowbowt_amd.tools import synth_pangenome as sp
 
     L = ra.lib()
@@ -96,7 +97,10 @@ def main():
     log(rank, f"index replica: {ix.hbm_bytes / 1e6:.1f} MB HBM, pos_bytes={ix.pos_bytes}, sigma={ix.sigma}, "
               f"flatten+upload {time.time() - t0:.1f}s")
 
-    N = args.reads
+    # weak scaling: the global batch is world x --reads; this rank owns the contiguous block
+    # shard_bounds() gives it and synthesises exactly those reads
+    gb, ge = shard.shard_bounds(args.reads * world, rank, world)
+    N = ge - gb
     reads, _ = sp.sample_reads(text, info, N, m, seed=args.seed + 2 + rank, sub_rate=0.1)
     del text
     torch.cuda.empty_cache()
@@ -194,12 +198,10 @@ def main():
 
     # max over ranks, counters over RCCL
     t_el = torch.tensor([el, el_count], dtype=torch.float64, device=dev)
-    t_cnt = torch.from_numpy(counters).to(dev)
     if world > 1:
         dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
-        dist.all_reduce(t_cnt, op=dist.ReduceOp.SUM)  # the only collective: 4 x u64 global counters
     el, el_count = float(t_el[0].item()), float(t_el[1].item())
-    g_counters = t_cnt.cpu().numpy().tolist()
+    g_counters = shard.reduce_counters(counters, device=dev)  # the only collective of the run: 4 x u64 over RCCL
 
     out = None
     if rank == 0:

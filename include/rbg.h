@@ -121,6 +121,10 @@ int rbg_host_array(const rbg_index *, int which, uint64_t *dst, uint64_t cap, ui
 
 /* ---- queries, host buffers (drop-in) ------------------------------------------------------ */
 
+/* RowBowt::LF(range_t, uint8_t c), rowbowt.hpp:74-88: one backward step for N (range, symbol)
+ * triples.  An input range outside [0,n) x [0,n) or an absent symbol yields {1,0}. */
+int rbg_lf(rbg_index *, const uint64_t *lo, const uint64_t *hi, const uint8_t *sym, uint64_t N,
+           uint64_t *lo_out, uint64_t *hi_out);
 /* RowBowt::find_range(const std::string&), rowbowt.hpp:121-131, for N reads. */
 int rbg_find_range(rbg_index *, const uint8_t *seqs, const uint64_t *off, uint64_t N,
                    uint64_t *lo, uint64_t *hi);

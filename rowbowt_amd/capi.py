@@ -60,6 +60,7 @@ _PROTOS = [
     ("rbg_get_f", C.c_int, [VP, VP]),
     ("rbg_last_run_sample", C.c_int, [VP, C.POINTER(U64)]),
     ("rbg_host_array", C.c_int, [VP, C.c_int, VP, U64, C.POINTER(U64)]),
+    ("rbg_lf", C.c_int, [VP, VP, VP, VP, U64, VP, VP]),
     ("rbg_find_range", C.c_int, [VP, VP, VP, U64, VP, VP]),
     ("rbg_count", C.c_int, [VP, VP, VP, U64, VP]),
     ("rbg_find_range_w_toehold", C.c_int, [VP, VP, VP, U64, VP, VP, VP]),
@@ -197,6 +198,15 @@ class RowBowt:
         return out
 
     # ---- queries (host buffers)
+    def LF(self, lo, hi, sym):
+        """RowBowt::LF(range_t, uint8_t), rowbowt.hpp:74-88, for N triples"""
+        lo, hi = _u64(lo), _u64(hi)
+        sym = np.ascontiguousarray(sym, dtype=np.uint8)
+        N = len(lo)
+        nlo, nhi = np.zeros(N, np.uint64), np.zeros(N, np.uint64)
+        _check(self.L.rbg_lf(self.h, _p(lo), _p(hi), _p(sym), N, _p(nlo), _p(nhi)), "rbg_lf")
+        return nlo, nhi
+
     def find_range(self, seqs, off):
         N = len(off) - 1
         lo, hi = np.zeros(N, np.uint64), np.zeros(N, np.uint64)

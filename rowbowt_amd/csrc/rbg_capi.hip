@@ -642,6 +642,29 @@ static int find_range_host(rbg_index *ix, const uint8_t *seqs, const uint64_t *o
     return RBG_OK;
 }
 
+int rbg_lf(rbg_index *ix, const uint64_t *lo, const uint64_t *hi, const uint8_t *sym, uint64_t N, uint64_t *lo_out,
+           uint64_t *hi_out) {
+    if (!queryable(ix)) return RBG_ENODEV;
+    if (N == 0) return RBG_OK;
+    if (!lo || !hi || !sym || !lo_out || !hi_out) return RBG_EARG;
+    DeviceScope scope(ix->device);
+    if (scope.rc) return scope.rc;
+    hipStream_t st = hipStreamPerThread;
+    DevBuf dlo, dhi, dsym, dlo2, dhi2;
+    int rc;
+    if ((rc = dlo.alloc(N * 8)) || (rc = dhi.alloc(N * 8)) || (rc = dsym.alloc(N)) || (rc = dlo2.alloc(N * 8)) || (rc = dhi2.alloc(N * 8)))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(dlo.p, lo, N * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dhi.p, hi, N * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dsym.p, sym, N, hipMemcpyHostToDevice, st));
+    if (launch_lf(ix->dev, ix->cfg, dlo.as<uint64_t>(), dhi.as<uint64_t>(), dsym.as<uint8_t>(), N, dlo2.as<uint64_t>(), dhi2.as<uint64_t>(), st))
+        return RBG_ENODEV;
+    HIP_TRY(hipMemcpyAsync(lo_out, dlo2.p, N * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(hi_out, dhi2.p, N * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return RBG_OK;
+}
+
 int rbg_find_range(rbg_index *ix, const uint8_t *seqs, const uint64_t *off, uint64_t N, uint64_t *lo, uint64_t *hi) {
     if (N && (!lo || !hi)) return RBG_EARG;
     return find_range_host(ix, seqs, off, N, lo, hi, nullptr, nullptr);

@@ -109,6 +109,8 @@ int launch_find_range_markers_plan(const DevIndex &ix, const LaunchCfg &cfg, con
 int launch_find_range_markers_fill(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off,
                                    uint64_t N, uint64_t wsize, uint64_t max_range, const uint64_t *mk_off, uint64_t *mk,
                                    void *stream);
+int launch_lf(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t *lo, const uint64_t *hi, const uint8_t *sym,
+              uint64_t N, uint64_t *lo_out, uint64_t *hi_out, void *stream);
 int launch_count_from_ranges(const uint64_t *lo, const uint64_t *hi, uint64_t N, uint64_t *count, void *stream);
 
 }  // namespace rbg

@@ -384,6 +384,29 @@ __global__ __launch_bounds__(256) void k_find_range_markers(const DevIndex ix, c
     }
 }
 
+// ---- single LF step for N (range, symbol) triples: RowBowt::LF(range_t, uint8_t), rowbowt.hpp:74-88
+template <typename P>
+__global__ __launch_bounds__(256) void k_lf(const DevIndex ix, const uint64_t *__restrict__ lo_in,
+                                            const uint64_t *__restrict__ hi_in, const uint8_t *__restrict__ sym,
+                                            const uint64_t N, uint64_t *__restrict__ lo_out, uint64_t *__restrict__ hi_out) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < N; i += stride) {
+        const uint64_t lo = lo_in[i], hi = hi_in[i];
+        const uint32_t slot = ix.lut[sym[i]];
+        uint64_t nlo = 1, nhi = 0;
+        // hi >= n is outside rle_string::rank's domain (assert(i<=n), rle_string.hpp:132): answer {1,0}
+        if (slot != 0xFFu && hi < ix.n && lo <= hi + 1) {
+            const DevSym S = ix.syms[slot];
+            RankAux q;
+            uint64_t c_before, c_upto, bh;
+            rank_pair<P>(S, lo, hi + 1, &c_before, &c_upto, &bh, &q);
+            if (c_upto > c_before) { nlo = S.F + c_before; nhi = nlo + (c_upto - c_before) - 1; }
+        }
+        lo_out[i] = nlo;
+        hi_out[i] = nhi;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_count(const uint64_t *__restrict__ lo, const uint64_t *__restrict__ hi,
                                                const uint64_t N, uint64_t *__restrict__ out) {
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
@@ -496,6 +519,16 @@ int launch_find_range_markers_fill(const DevIndex &ix, const LaunchCfg &cfg, con
         hipLaunchKernelGGL((k_find_range_markers<uint32_t, true>), grid, block, 0, st, ix, seqs, off, N, wsize, max_range, nullptr, nullptr, nullptr, mk_off, mk);
     else
         hipLaunchKernelGGL((k_find_range_markers<uint64_t, true>), grid, block, 0, st, ix, seqs, off, N, wsize, max_range, nullptr, nullptr, nullptr, mk_off, mk);
+    return static_cast<int>(hipGetLastError());
+}
+
+int launch_lf(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t *lo, const uint64_t *hi, const uint8_t *sym,
+              uint64_t N, uint64_t *lo_out, uint64_t *hi_out, void *stream) {
+    if (N == 0) return 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid(grid_for(cfg, N)), block(cfg.block_threads);
+    if (ix.pos_bytes == 4) hipLaunchKernelGGL((k_lf<uint32_t>), grid, block, 0, st, ix, lo, hi, sym, N, lo_out, hi_out);
+    else hipLaunchKernelGGL((k_lf<uint64_t>), grid, block, 0, st, ix, lo, hi, sym, N, lo_out, hi_out);
     return static_cast<int>(hipGetLastError());
 }
 

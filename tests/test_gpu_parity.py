@@ -177,6 +177,27 @@ def test_synth_markers(synth):
     o.close()
 
 
+def test_single_LF_steps(small, synth):
+    """RowBowt::LF (rowbowt.hpp:74-88) one step at a time, against the oracle's LF."""
+    rb, o = small
+    rng = np.random.default_rng(5)
+    n = 30031
+    lo = rng.integers(0, n, 4000).astype(np.uint64)
+    hi = np.minimum(lo + rng.integers(0, 200, 4000).astype(np.uint64), np.uint64(n - 1))
+    lo[:50] = 0
+    hi[:50] = n - 1
+    sym = rng.choice(np.frombuffer(b"ACGT\x01N", dtype=np.uint8), 4000)
+    nlo, nhi = rb.LF(lo, hi, sym)
+    for i in range(4000):
+        assert (int(nlo[i]), int(nhi[i])) == o.LF(int(lo[i]), int(hi[i]), int(sym[i]))
+    # chaining LF reproduces find_range (rowbowt.hpp:127-129)
+    q = b"TATCTCCGCGATCTCCAACT"
+    l, h = np.array([0], np.uint64), np.array([n - 1], np.uint64)
+    for c in reversed(q):
+        l, h = rb.LF(l, h, np.array([c], np.uint8))
+    assert (int(l[0]), int(h[0])) == (24279, 24280)
+
+
 def test_device_resident_api(synth):
     """HBM in / HBM out entry points on torch's current stream (what bench.py times)."""
     import ctypes as C
@@ -240,3 +261,64 @@ def test_size_independent_properties(synth):
     slo, shi = rb.find_range(*ra.pack_reads(suff))
     assert ((shi - slo) >= (hi - lo)).all()
     rb.close()
+
+
+# ---- the rb_align-compatible CLI: byte-exact stdout (reference src/rb_align.cpp:118-145) ---------
+def _run_cli(args):
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rowbowt_amd", "rb_align")
+    p = subprocess.run([exe] + args, capture_output=True, timeout=120)
+    return p.returncode, p.stdout.decode(), p.stderr.decode()
+
+
+def test_cli_count_stdout(data_dir, simple_reads):
+    rc, out, err = _run_cli([os.path.join(data_dir, "small.fa"), os.path.join(data_dir, "simple_query.fq")])
+    assert rc == 0, err
+    names = ["r1.ref", "r1.sample0.0", "r2.ref", "r2.sample0.0", "r3.ref", "r3.sample0.0"]
+    want = "".join(f"{n} ({lo},{hi}), count={hi - lo + 1}\n" for n, (lo, hi) in zip(names, G.SIMPLE_RANGES))
+    assert out == want
+    assert len(err.strip().splitlines()[-1].split()) == 2  # "<load_s> <query_s>", rb_align.cpp:192
+    # empty ranges print the unsigned wrap of 0-1+1 (rb_align.cpp:122)
+    rc, out, _ = _run_cli([os.path.join(data_dir, "small.fa"), os.path.join(data_dir, "error_query.fq")])
+    lines = out.splitlines()
+    assert rc == 0 and lines[0] == "r1.ref (1,0), count=0" and lines[2] == "r2.ref (27430,27432), count=3"
+
+
+def test_cli_locs_and_markers_stdout(data_dir, tmp_path, small, simple_reads):
+    import gzip
+    import shutil
+    rb, o = small
+    for suf in (".rbwt", ".tsa", ".mab"):
+        shutil.copy(os.path.join(data_dir, "small.fa" + suf), tmp_path / ("idx" + suf))
+    (tmp_path / "idx.docs").write_text("ref 0\nhap1 10010\nhap2 20020\n")  # no .docs is shipped
+    o.set_docs(["ref", "hap1", "hap2"], [0, 10010, 20020])
+    fq = tmp_path / "q.fq.gz"  # gz + true FASTQ syntax + descriptions after the name
+    with gzip.open(fq, "wt") as f:
+        for i, q in enumerate(simple_reads):
+            f.write(f"@read{i} some description\n{q.decode()}\n+\n{'~' * len(q)}\n")
+    rc, out, err = _run_cli(["-s", "-m", str(tmp_path / "idx"), str(fq)])
+    assert rc == 0, err
+    want = ""
+    for i, q in enumerate(simple_reads):
+        lo, hi, k = o.find_range_w_toehold(q)
+        want += f"read{i} ({lo},{hi}), count={hi - lo + 1}\n\tlocs: "
+        for l in o.locs_at(lo, hi, k):
+            name, off = o.resolve_offset(l)
+            want += f"{l}/{name}:{off} "
+        want += "\n\tmarkers: "
+        mk = o.markers_at(lo, hi)
+        if not mk:
+            want += "no markers (consider building the marker array with a larger window size)"
+        for m_ in mk:
+            want += f"{G.get_pos(m_)}/{G.get_allele(m_)} "
+        want += "\n"
+    assert out == want
+    assert "20306/hap2:286 286/ref:286" in out
+    # missing index -> "bad file", exit(1) (rowbowt_io.hpp:166-169)
+    rc, _, err = _run_cli([str(tmp_path / "nope"), str(fq)])
+    assert rc == 1 and "bad file" in err
+    # truncated quality string -> error like kseq's -2 (rb_align.cpp:183-185)
+    bad = tmp_path / "bad.fq"
+    bad.write_text("@r\nACGT\n+\n~~\n")
+    rc, _, err = _run_cli([str(tmp_path / "idx"), str(bad)])
+    assert rc == 1 and "truncated quality string" in err
