@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""PCIe-inclusive rate of the drop-in (host-pointer) entry points on the bench index: the number
+DESIGN.md quotes beside (never instead of) the HBM-resident `value`.  GPU box only."""
+import os, sys, time
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import rowbowt_amd as ra
+from rowbowt_amd.tools import synth_pangenome as sp
+
+dev = torch.device("cuda:0")
+text, info = sp.make_text(40_000_000, 50, 0.01, 20240229, dev)
+sa = sp.suffix_array(text)
+inp = sp.index_inputs(text, sa)
+del sa
+N, m = 10_000_000, 100
+reads, _ = sp.sample_reads(text, info, N, m, seed=20240231, sub_rate=0.1)
+seqs = reads.cpu().numpy().reshape(-1)
+off = (np.arange(N + 1, dtype=np.uint64) * m)
+del text, reads
+torch.cuda.empty_cache()
+rb = ra.RowBowt.from_runs(inp["heads"], inp["lens"], inp["ssa"], inp["esa"], device=0)
+for rep in range(2):
+    t0 = time.perf_counter(); lo, hi = rb.find_range(seqs, off); t1 = time.perf_counter()
+    lo, hi, k = rb.find_range_w_toehold(seqs, off); t2 = time.perf_counter()
+    loc_off, locs = rb.locs_at(lo, hi, k); t3 = time.perf_counter()
+print(f"host-pointer API, {N} x {m} bp reads (1.0 GB H2D), n={inp['n']} r={inp['r']}:")
+print(f"  rbg_find_range                      {t1 - t0:.3f} s  -> {N / (t1 - t0):.3e} reads/s")
+print(f"  rbg_find_range_w_toehold            {t2 - t1:.3f} s  -> {N / (t2 - t1):.3e} reads/s")
+print(f"  rbg_locs_at ({len(locs)} locations, {len(locs) * 8 / 1e9:.1f} GB D2H)  {t3 - t2:.3f} s")
+print(f"  count+locate end to end            {t3 - t1:.3f} s  -> {N / (t3 - t1):.3e} reads/s (PCIe + per-call hipMalloc inclusive)")
