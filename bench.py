@@ -69,8 +69,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+    use_dist = world > 1 or "RANK" in os.environ  # under torch.distributed.run: always go through RCCL
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
 
     import rowbowt_amd as ra
     from rowbowt_amd import shard
@@ -149,7 +152,7 @@ def main():
         k_fill()
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -198,7 +201,7 @@ def main():
 
     # max over ranks, counters over RCCL
     t_el = torch.tensor([el, el_count], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
     el, el_count = float(t_el[0].item()), float(t_el[1].item())
     g_counters = shard.reduce_counters(counters, device=dev)  # the only collective of the run: 4 x u64 over RCCL
@@ -243,14 +246,15 @@ def main():
                 "workload": f"count+locate (find_range_w_toehold + locs_at, max_hits={'2^64-1' if max_hits == MAXU else max_hits}) on a "
                             f"synthetic chr22-scale pangenome r-index, {N} x {m} bp reads per GPU per step (BASELINE.json configs[2])",
                 "index": {"L": args.L, "H": args.H, "n": int(inp["n"]), "r": int(inp["r"]), "site_rate": args.site_rate,
-                          "hbm_bytes": int(ix.hbm_bytes), "pos_bytes": int(ix.pos_bytes), "seed": args.seed},
+                          "hbm_bytes": int(ix.hbm_bytes), "pos_bytes": int(ix.pos_bytes), "seed": args.seed,
+                          "two_symbol_steps": bool(ix.two_step_symbols), "pair_runs": int(ix.pair_runs)},
                 "reads_per_gpu": N, "read_len": m, "substituted_fraction": 0.1,
                 "parallelism": f"index replicated x{world}, reads sharded, no data-path collective",
             },
             "count_only": {"value": N * world * K / el_count, "unit": "reads/s", "ms_per_step": el_count / K * 1e3,
                            "workload": "BASELINE.json configs[1]: find_range only"},
             "counters": {"reads": g_counters[0], "matched": g_counters[1], "sum_occ": g_counters[2], "sum_locs": g_counters[3],
-                         "reduced_over": "RCCL all_reduce" if world > 1 else "single GPU"},
+                         "reduced_over": f"RCCL all_reduce over {world} rank(s)" if use_dist else "single GPU (no process group)"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic},
             "kernels": {k: {"ms": v["ms"], "alg_GBps": v["alg_bytes"] / (v["ms"] * 1e-3) / 1e9} for k, v in kernels.items()},
@@ -320,7 +324,7 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     rb.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

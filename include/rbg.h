@@ -98,6 +98,8 @@ typedef struct rbg_info_t {
     uint32_t reserved;
     /* first-level slot tables: totals and how many buckets overflow their 2 inline entries */
     uint64_t rank_slots, rank_slots_overflow, phi_slots, phi_slots_overflow;
+    /* two-symbol LF steps: number of symbols with pair tables (0 = disabled), total pair-runs */
+    uint64_t two_step_symbols, pair_runs;
 } rbg_info_t;
 int rbg_info(const rbg_index *, rbg_info_t *out);
 
@@ -183,8 +185,10 @@ int rbg_counters_reset(rbg_index *);
 
 /* ---- tuning (never changes results) -------------------------------------------------------- */
 /* Process-wide defaults read when an index is built/loaded: BLOCK_THREADS (multiple of 64),
- * RANK/PHI_BUCKET_SHIFT (-1 = automatic, else 0..8), POS_BYTES (0 = automatic, 4 or 8 to force a width). */
-enum { RBG_OPT_BLOCK_THREADS = 1, RBG_OPT_RANK_BUCKET_SHIFT = 2, RBG_OPT_PHI_BUCKET_SHIFT = 3, RBG_OPT_POS_BYTES = 4 };
+ * RANK/PHI_BUCKET_SHIFT (-1 = automatic, else 0..8), POS_BYTES (0 = automatic, 4 or 8 to force a width),
+ * TWO_STEP (1 = build pair tables so the search consumes two symbols per gather; 0 = off). */
+enum { RBG_OPT_BLOCK_THREADS = 1, RBG_OPT_RANK_BUCKET_SHIFT = 2, RBG_OPT_PHI_BUCKET_SHIFT = 3, RBG_OPT_POS_BYTES = 4,
+       RBG_OPT_TWO_STEP = 5 };
 int rbg_set_default_option(int opt, int64_t value);
 
 #ifdef __cplusplus

@@ -36,6 +36,7 @@ std::atomic<int64_t> g_opt_block_threads{256};
 std::atomic<int64_t> g_opt_rank_shift{-1};
 std::atomic<int64_t> g_opt_phi_shift{-1};
 std::atomic<int64_t> g_opt_pos_bytes{0};
+std::atomic<int64_t> g_opt_two_step{1};
 
 #define HIP_TRY(expr)                                                                             \
     do {                                                                                          \
@@ -156,48 +157,71 @@ void build_phi_slots(const HostIndex &h, std::vector<PhiSlot<P>> &slots, std::ve
     }
 }
 
+// one symbol (or pair-symbol) table -> its device record
 template <typename P>
-int upload_tables(rbg_index *ix) {
-    HostIndex &h = ix->host;
-    std::vector<DevSym> syms(h.sigma);
-    for (uint32_t s = 0; s < h.sigma; ++s) {
-        const SymTable &t = h.sym[s];
+int upload_sym(rbg_index *ix, const SymTable &t, bool with_samples, DevSym &d) {
+    const HostIndex &h = ix->host;
+    {
         std::vector<RunEnt<P>> ent(t.nruns + 1);
         for (uint64_t k = 0; k <= t.nruns; ++k) {
             ent[k].start = static_cast<P>(t.start[k]);
             ent[k].cum = static_cast<P>(t.cum[k]);
         }
-        int rc = dev_upload(ix, ent.data(), ent.size() * sizeof(RunEnt<P>), &syms[s].ent);
+        int rc = dev_upload(ix, ent.data(), ent.size() * sizeof(RunEnt<P>), &d.ent);
         if (rc) return rc;
-        syms[s].samp = nullptr;
-        if (h.has_tsa) {
-            std::vector<P> samp(t.nruns);
-            for (uint64_t k = 0; k < t.nruns; ++k) samp[k] = static_cast<P>(t.samp[k]);
-            rc = dev_upload(ix, samp.data(), samp.size() * sizeof(P), &syms[s].samp);
-            if (rc) return rc;
-        }
-        {
-            std::vector<RankSlot<P>> slots;
-            std::vector<uint32_t> ord;
-            build_rank_slots<P>(t, h.n, slots, ord, &ix->rank_slots_overflow);
-            ix->rank_slots += slots.size();
-            rc = dev_upload(ix, slots.data(), slots.size() * sizeof(RankSlot<P>), &syms[s].slots);
-            if (rc) return rc;
-            const void *po = nullptr;
-            rc = dev_upload(ix, ord.data(), ord.size() * sizeof(uint32_t), &po);
-            if (rc) return rc;
-            syms[s].ord = static_cast<const uint32_t *>(po);
-        }
-        syms[s].nruns = t.nruns;
-        syms[s].F = t.F;
-        syms[s].total = t.total;
-        syms[s].shift = t.shift;
-        syms[s].pad = 0;
+    }
+    d.samp = nullptr;
+    if (with_samples) {
+        std::vector<P> samp(t.nruns);
+        for (uint64_t k = 0; k < t.nruns; ++k) samp[k] = static_cast<P>(t.samp[k]);
+        int rc = dev_upload(ix, samp.data(), samp.size() * sizeof(P), &d.samp);
+        if (rc) return rc;
+    }
+    std::vector<RankSlot<P>> slots;
+    std::vector<uint32_t> ord;
+    build_rank_slots<P>(t, h.n, slots, ord, &ix->rank_slots_overflow);
+    ix->rank_slots += slots.size();
+    int rc = dev_upload(ix, slots.data(), slots.size() * sizeof(RankSlot<P>), &d.slots);
+    if (rc) return rc;
+    const void *po = nullptr;
+    rc = dev_upload(ix, ord.data(), ord.size() * sizeof(uint32_t), &po);
+    if (rc) return rc;
+    d.ord = static_cast<const uint32_t *>(po);
+    d.nruns = t.nruns;
+    d.F = t.F;
+    d.total = t.total;
+    d.shift = t.shift;
+    d.pad = 0;
+    return RBG_OK;
+}
+
+template <typename P>
+int upload_tables(rbg_index *ix) {
+    HostIndex &h = ix->host;
+    std::vector<DevSym> syms(h.sigma);
+    for (uint32_t s = 0; s < h.sigma; ++s) {
+        int rc = upload_sym<P>(ix, h.sym[s], h.has_tsa, syms[s]);
+        if (rc) return rc;
     }
     const void *p = nullptr;
     int rc = dev_upload(ix, syms.data(), syms.size() * sizeof(DevSym), &p);
     if (rc) return rc;
     ix->dev.syms = static_cast<const DevSym *>(p);
+    ix->dev.nmajor = 0;
+    if (!h.pair.empty()) {
+        std::vector<DevSym> pairs(h.pair.size());
+        for (size_t i = 0; i < h.pair.size(); ++i) {
+            rc = upload_sym<P>(ix, h.pair[i], h.has_tsa, pairs[i]);
+            if (rc) return rc;
+        }
+        rc = dev_upload(ix, pairs.data(), pairs.size() * sizeof(DevSym), &p);
+        if (rc) return rc;
+        ix->dev.pairs = static_cast<const DevSym *>(p);
+        rc = dev_upload(ix, h.major_of, 256, &p);
+        if (rc) return rc;
+        ix->dev.lut2 = static_cast<const uint8_t *>(p);
+        ix->dev.nmajor = h.nmajor;
+    }
     if (h.has_tsa) {
         {
             std::vector<PhiEnt<P>> pe(h.r);
@@ -280,6 +304,7 @@ FlattenOptions current_options() {
     o.rank_bucket_shift = static_cast<int>(g_opt_rank_shift.load());
     o.phi_bucket_shift = static_cast<int>(g_opt_phi_shift.load());
     o.force_pos_bytes = static_cast<int>(g_opt_pos_bytes.load());
+    o.two_step = static_cast<int>(g_opt_two_step.load());
     return o;
 }
 
@@ -379,6 +404,9 @@ int rbg_set_default_option(int opt, int64_t value) {
         case RBG_OPT_POS_BYTES:
             if (value != 0 && value != 4 && value != 8) return RBG_EARG;
             g_opt_pos_bytes = value; return RBG_OK;
+        case RBG_OPT_TWO_STEP:
+            if (value != 0 && value != 1) return RBG_EARG;
+            g_opt_two_step = value; return RBG_OK;
         default: return RBG_EARG;
     }
 }
@@ -504,6 +532,8 @@ int rbg_info(const rbg_index *ix, rbg_info_t *out) {
     out->rank_slots_overflow = ix->rank_slots_overflow;
     out->phi_slots = ix->phi_slots;
     out->phi_slots_overflow = ix->phi_slots_overflow;
+    out->two_step_symbols = ix->host.pair.empty() ? 0 : ix->host.nmajor;
+    for (const SymTable &t : ix->host.pair) out->pair_runs += t.nruns;
     return RBG_OK;
 }
 

@@ -63,7 +63,8 @@ struct DevSym {
     uint32_t pad;
 };
 
-constexpr int kLdsSyms = 8;  // symbol tables staged in LDS per workgroup; rarer slots read from HBM
+constexpr int kLdsSyms = 8;
+constexpr int kMaxMajor = 4;  // symbol tables staged in LDS per workgroup; rarer slots read from HBM
 
 struct DevIndex {
     uint64_t n, r;
@@ -83,6 +84,13 @@ struct DevIndex {
     // {reads, matched, sum occ, sum locs}
     unsigned long long *counters;
     const uint8_t *lut;  // 256 bytes, device memory
+    // two-symbol steps: pairs[m1 * nmajor + m2] describes the pair symbol (c1,c2) with the same
+    // record shape as a single symbol (F = first row of the SA interval of "c1c2", samp = SA-2 at
+    // pair-run ends); lut2 maps a byte to its major index 0..nmajor-1 or 0xFF.  nmajor == 0: off.
+    const DevSym *pairs;
+    const uint8_t *lut2;
+    uint32_t nmajor;
+    uint32_t pad2;
 };
 
 struct LaunchCfg {

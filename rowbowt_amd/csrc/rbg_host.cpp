@@ -341,6 +341,92 @@ uint32_t auto_shift(uint64_t n, uint64_t items, double per_slot) {
     while (s < 8 && static_cast<double>(items) * static_cast<double>(uint64_t(2) << s) <= per_slot * static_cast<double>(n)) ++s;
     return s;
 }
+
+// Pair tables for two-symbol LF steps.  LF2([lo,hi], c1c2) = C2 + rank2(.., (c1,c2)) where
+// rank2 counts rows p with (bwt[LF(p)], bwt[p]) == (c1, c2) and C2 = F[c1] + rank(F[c2], c1) is the
+// first row of the SA interval of "c1c2"; composing it is exactly two RowBowt::LF calls
+// (rowbowt.hpp:74-88), and the toehold after the two LF_w_loc calls (rowbowt.hpp:555-573) is
+// k-2 when row hi carries the pair, else (SA - 2) at the end of the last pair-run before hi.
+// The pair-runs of (.,c2) are the c2-runs cut where LF of their rows crosses a BWT run boundary,
+// so one linear sweep per c2 enumerates them in row order; the SA value at a pair-run end is
+// known because either that row or its LF image ends a BWT run.
+int build_pairs(HostIndex &out, const RawTsa *tsa, const FlattenOptions &opt) {
+    std::memset(out.major_of, 0xFF, sizeof(out.major_of));
+    out.nmajor = 0;
+    out.pair.clear();
+    if (!opt.two_step || out.sigma < 2) return RBG_OK;
+    // the terminator: the smallest symbol, occurring once (rle_string.hpp:59,62 maps 0 -> 1).
+    // Without one the (k-1)-1 wrap argument of DESIGN.md 2b does not hold: keep single steps only.
+    const SymTable &first = out.sym[0];
+    if (first.total != 1) return RBG_OK;
+    std::vector<uint32_t> order;
+    for (uint32_t s = 1; s < out.sigma; ++s) order.push_back(s);
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+        return out.sym[a].total != out.sym[b].total ? out.sym[a].total > out.sym[b].total : a < b;
+    });
+    if (order.size() > 4) order.resize(4);
+    std::sort(order.begin(), order.end());
+    out.nmajor = static_cast<uint32_t>(order.size());
+    for (uint32_t m = 0; m < out.nmajor; ++m) {
+        out.major_byte[m] = out.sym[order[m]].byte;
+        out.major_of[out.sym[order[m]].byte] = static_cast<uint8_t>(m);
+    }
+    const uint32_t M = out.nmajor;
+    out.pair.assign(M * M, SymTable());
+    const uint64_t R = out.r;
+    for (uint32_t m2 = 0; m2 < M; ++m2) {
+        const SymTable &t2 = out.sym[order[m2]];
+        uint64_t g = 0;  // global BWT run containing the current LF image
+        std::vector<uint64_t> seen(M, 0);
+        for (uint64_t k = 0; k < t2.nruns; ++k) {
+            const uint64_t s = t2.start[k], len = t2.cum[k + 1] - t2.cum[k];
+            const uint64_t Q = t2.F + t2.cum[k];  // LF of row s (rowbowt.hpp:65-68)
+            uint64_t q = Q;
+            while (q < Q + len) {
+                while (out.run_start[g + 1] <= q) ++g;
+                const uint64_t qend = std::min(Q + len, out.run_start[g + 1]);
+                const uint8_t m1 = out.major_of[out.run_heads[g]];
+                if (m1 != 0xFF) {
+                    SymTable &pt = out.pair[m1 * M + m2];
+                    pt.start.push_back(s + (q - Q));
+                    pt.cum.push_back(seen[m1]);
+                    seen[m1] += qend - q;
+                    if (tsa) {
+                        // SA - 2 at the pair-run's last row p*: if LF(p*) ends BWT run g its
+                        // samples_last_ is SA[LF(p*)] - 1; otherwise p* ends the c2-run
+                        uint64_t v;
+                        if (qend == out.run_start[g + 1]) v = tsa->samples_last[g];
+                        else {
+                            if (t2.samp[k] == 0) return RBG_EFORMAT;  // would need c1 == terminator
+                            v = t2.samp[k] - 1;
+                        }
+                        pt.samp.push_back(v);
+                    }
+                }
+                q = qend;
+            }
+        }
+        for (uint32_t m1 = 0; m1 < M; ++m1) {
+            SymTable &pt = out.pair[m1 * M + m2];
+            const SymTable &t1 = out.sym[order[m1]];
+            pt.byte = t2.byte;
+            pt.nruns = pt.start.size();
+            pt.total = seen[m1];
+            pt.start.push_back(out.n);
+            pt.cum.push_back(pt.total);
+            // C2 = F[c1] + rank(F[c2], c1): rows of suffixes starting with c1 followed by a smaller symbol
+            const uint64_t i = t2.F;
+            const uint64_t kk = std::lower_bound(t1.start.begin(), t1.start.begin() + t1.nruns, i) - t1.start.begin();
+            uint64_t rk = 0;
+            if (kk > 0) rk = t1.cum[kk - 1] + std::min(i - t1.start[kk - 1], t1.cum[kk] - t1.cum[kk - 1]);
+            pt.F = t1.F + rk;
+            pt.shift = opt.rank_bucket_shift >= 0 ? static_cast<uint32_t>(opt.rank_bucket_shift) : auto_shift(out.n, pt.nruns, 1.5);
+            if (pt.nruns >= 0xFFFFFFF0ull) return RBG_EARG;
+        }
+    }
+    (void)R;
+    return RBG_OK;
+}
 }  // namespace
 
 int flatten(const RawRle &rle, const RawTsa *tsa, const FlattenOptions &opt, HostIndex &out) {
@@ -419,7 +505,7 @@ int flatten(const RawRle &rle, const RawTsa *tsa, const FlattenOptions &opt, Hos
         out.phi_shift = opt.phi_bucket_shift >= 0 ? static_cast<uint32_t>(opt.phi_bucket_shift) : auto_shift(out.n, R, 0.75);
         if (out.phi_shift > 8) return RBG_EARG;
     }
-    return RBG_OK;
+    return build_pairs(out, tsa, opt);
 }
 
 }  // namespace rbg

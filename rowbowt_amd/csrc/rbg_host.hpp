@@ -73,6 +73,14 @@ struct HostIndex {
     std::vector<uint8_t> run_heads;    // R
     std::vector<uint64_t> run_start;   // R + 1
     // toehold SA
+    // two-symbol steps: for the <= 4 most frequent non-terminator symbols ("major"),
+    // pair[m1 * nmajor + m2] is the table of the pair symbol (c1, c2) = (bwt[LF(p)], bwt[p]):
+    // runs of rows whose two preceding text characters are c1 c2.  Its F is the first row of the
+    // SA interval of "c1c2"; its samp[] holds SA - 2 at the end of each pair-run.
+    uint32_t nmajor = 0;
+    uint8_t major_byte[4] = {0, 0, 0, 0};
+    uint8_t major_of[256];             // byte -> 0..nmajor-1, 0xFF otherwise
+    std::vector<SymTable> pair;        // nmajor * nmajor, or empty (two-step disabled)
     bool has_tsa = false;
     uint64_t last_run_sample = 0;      // toehold_sa.hpp:97-99
     std::vector<uint64_t> samples_last, pred_pos, phi_base;
@@ -87,6 +95,7 @@ struct FlattenOptions {
     int rank_bucket_shift = -1;  // <0: automatic (about one run per two buckets)
     int phi_bucket_shift = -1;
     int force_pos_bytes = 0;     // 0: 4 when n fits, else 8
+    int two_step = 1;            // build the pair tables
 };
 
 int flatten(const RawRle &rle, const RawTsa *tsa, const FlattenOptions &opt, HostIndex &out);

@@ -117,19 +117,39 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 }
 
 // ---- K1 / K2 ------------------------------------------------------------------------------------
+// per-lane cursor over the read bytes, fetched as aligned 16-byte chunks while walking right to left
+struct ByteCursor {
+    const uint4 *__restrict__ chunks;
+    uint64_t cur_ci;
+    uint4 w;
+    __device__ __forceinline__ uint32_t at(uint64_t p) {
+        const uint64_t ci = p >> 4;
+        if (ci != cur_ci) { w = chunks[ci]; cur_ci = ci; }
+        const uint32_t sel = static_cast<uint32_t>(p) & 15u;
+        const uint32_t word = sel < 8 ? (sel < 4 ? w.x : w.y) : (sel < 12 ? w.z : w.w);
+        return (word >> ((sel & 3u) * 8)) & 0xFFu;
+    }
+};
+
 template <typename P, bool TOEHOLD>
 __global__ __launch_bounds__(256) void k_find_range(const DevIndex ix, const uint8_t *__restrict__ seqs,
                                                     const uint64_t *__restrict__ off, const uint64_t N,
                                                     uint64_t *__restrict__ lo_out, uint64_t *__restrict__ hi_out,
                                                     uint64_t *__restrict__ ss_out) {
     __shared__ uint8_t s_lut[256];
+    __shared__ uint8_t s_lut2[256];
     __shared__ DevSym s_sym[kLdsSyms];
-    for (int t = threadIdx.x; t < 256; t += blockDim.x) s_lut[t] = ix.lut[t];
+    __shared__ DevSym s_pair[kMaxMajor * kMaxMajor];
+    const uint32_t M = ix.nmajor;
+    for (int t = threadIdx.x; t < 256; t += blockDim.x) {
+        s_lut[t] = ix.lut[t];
+        s_lut2[t] = M ? ix.lut2[t] : 0xFFu;
+    }
     const int nlds = ix.sigma < static_cast<uint32_t>(kLdsSyms) ? static_cast<int>(ix.sigma) : kLdsSyms;
     for (int t = threadIdx.x; t < nlds; t += blockDim.x) s_sym[t] = ix.syms[t];
+    for (int t = threadIdx.x; t < static_cast<int>(M * M); t += blockDim.x) s_pair[t] = ix.pairs[t];
     __syncthreads();
 
-    const uint4 *__restrict__ chunks = reinterpret_cast<const uint4 *>(seqs);  // reads are fetched 16 bytes at a time
     unsigned long long c_reads = 0, c_matched = 0, c_occ = 0;
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
     for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < N; i += stride) {
@@ -137,16 +157,35 @@ __global__ __launch_bounds__(256) void k_find_range(const DevIndex ix, const uin
         uint64_t p = off[i + 1];
         uint64_t lo = 0, hi = ix.n - 1;  // full_range(), rowbowt.hpp:115-118
         uint64_t k = TOEHOLD ? ix.last_run_sample : 0;
-        uint64_t cur_ci = ~uint64_t(0);
-        uint4 w = make_uint4(0, 0, 0, 0);
+        ByteCursor rd{reinterpret_cast<const uint4 *>(seqs), ~uint64_t(0), make_uint4(0, 0, 0, 0)};
         bool alive = true;
         while (p > beg) {  // right-to-left over the read (rowbowt.hpp:127-129, :175-181)
             --p;
-            const uint64_t ci = p >> 4;
-            if (ci != cur_ci) { w = chunks[ci]; cur_ci = ci; }
-            const uint32_t sel = static_cast<uint32_t>(p) & 15u;
-            const uint32_t word = sel < 8 ? (sel < 4 ? w.x : w.y) : (sel < 12 ? w.z : w.w);
-            const uint32_t c = (word >> ((sel & 3u) * 8)) & 0xFFu;
+            const uint32_t c = rd.at(p);
+            // Two reference iterations in one gather when this symbol and the one to its left both
+            // have pair tables: LF(LF(range, c), c1) == F2[c1 c] + rank2(., (c1,c)); the toehold
+            // after the two LF_w_loc calls is k-2 if row hi carries the pair, else the pair-run
+            // sample.  An empty result is {1,0} whichever of the two steps emptied it.
+            const uint32_t m2 = s_lut2[c];
+            if (m2 != 0xFFu && p > beg) {
+                const uint32_t m1 = s_lut2[rd.at(p - 1)];
+                if (m1 != 0xFFu) {
+                    const DevSym S = s_pair[m1 * M + m2];
+                    RankAux q;
+                    uint64_t c_before, c_upto, bh;
+                    rank_pair<P>(S, lo, hi + 1, &c_before, &c_upto, &bh, &q);
+                    const uint64_t c_inside = c_upto - c_before;
+                    if (c_inside == 0) { alive = false; break; }
+                    if (TOEHOLD) {
+                        if (q.inside) k = k - 2;
+                        else k = pred_sample<P>(S, bh, q);
+                    }
+                    lo = S.F + c_before;
+                    hi = lo + c_inside - 1;
+                    --p;  // the left symbol is consumed too
+                    continue;
+                }
+            }
             const uint32_t slot = s_lut[c];
             if (slot == 0xFFu) { alive = false; break; }  // symbol absent: f_[c] >= f_[c+1], rowbowt.hpp:76
             const DevSym S = slot < static_cast<uint32_t>(kLdsSyms) ? s_sym[slot] : ix.syms[slot];

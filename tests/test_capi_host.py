@@ -64,6 +64,11 @@ def test_loader_matches_oracle_reader(small_host, small_orc):
     assert i.marker_runs == 190 and i.marker_vals == 190
 
 
+def test_two_step_tables_built(small_host):
+    i = small_host.info()
+    assert i.two_step_symbols == 4 and 0 < i.pair_runs <= 2 * i.r
+
+
 def test_greedy_seeding_fixture(data_dir):
     rb = ra.load_rowbowt(os.path.join(data_dir, "greedy_seeding", "ref.fa"),
                          ra.LoadRbwtFlag.SA | ra.LoadRbwtFlag.DL, device=capi.DEVICE_NONE)

@@ -117,21 +117,28 @@ def synth():
     return SynthIndex(L=4000, H=8, n_sites=60, seed=11)
 
 
-@pytest.mark.parametrize("pos_bytes,rshift,pshift", [(0, -1, -1), (8, -1, -1), (4, 0, 0), (8, 3, 2), (4, 8, 8), (8, 8, 7), (4, 5, 6)])
-def test_synth_all_paths(synth, pos_bytes, rshift, pshift):
+@pytest.mark.parametrize("pos_bytes,rshift,pshift,two_step",
+                         [(0, -1, -1, 1), (0, -1, -1, 0), (8, -1, -1, 1), (4, 0, 0, 1), (8, 3, 2, 0), (4, 8, 8, 1),
+                          (8, 8, 7, 1), (4, 5, 6, 0), (4, 2, 2, 1)])
+def test_synth_all_paths(synth, pos_bytes, rshift, pshift, two_step):
     S = synth
     ra.set_default_option(capi.OPT_POS_BYTES, pos_bytes)
     ra.set_default_option(capi.OPT_RANK_BUCKET_SHIFT, rshift)
     ra.set_default_option(capi.OPT_PHI_BUCKET_SHIFT, pshift)
+    ra.set_default_option(capi.OPT_TWO_STEP, two_step)
     try:
         rb = ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0)
     finally:
         for o_ in (capi.OPT_POS_BYTES, capi.OPT_RANK_BUCKET_SHIFT, capi.OPT_PHI_BUCKET_SHIFT):
             ra.set_default_option(o_, 0 if o_ == capi.OPT_POS_BYTES else -1)
+        ra.set_default_option(capi.OPT_TWO_STEP, 1)
     o = orc.Oracle.from_runs(S.heads, S.lens, S.ssa, S.esa)
     assert rb.info().pos_bytes == (pos_bytes or 4)
+    assert rb.info().two_step_symbols == (4 if two_step else 0)
     reads = S.sample_reads(3000, 60, seed=5, sub_rate=0.15, ragged=True)
-    reads += [b"", b"A", b"N", b"ACGTN", b"acgt", bytes([1]), bytes([255]) * 3, bytes([0]), S.text[:500].tobytes()]
+    reads += [b"", b"A", b"N", b"ACGTN", b"NACGT", b"ACNGT", b"AC", b"ACG", b"acgt", bytes([1]), bytes([255]) * 3, bytes([0]),
+              S.text[:500].tobytes(), S.text[:501].tobytes(), b"A" + bytes([1]), bytes([1]) + b"A",
+              S.text[-30:].tobytes(), S.text[-31:-1].tobytes(), S.text[-2:].tobytes()]
     seqs, off = ra.pack_reads(reads)
     lo, hi, k = rb.find_range_w_toehold(seqs, off)
     wlo, whi, wk = o.find_range_w_toehold_batch(seqs, off)
