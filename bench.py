@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check-reads", type=int, default=20000, help="reads compared bit-exactly with the oracle")
+    ap.add_argument("--property-reads", type=int, default=1_000_000,
+                    help="reads whose every reported location is checked against the text on the GPU (size-independent property)")
     return ap.parse_args()
 
 
@@ -105,7 +107,6 @@ def main():
     gb, ge = shard.shard_bounds(args.reads * world, rank, world)
     N = ge - gb
     reads, _ = sp.sample_reads(text, info, N, m, seed=args.seed + 2 + rank, sub_rate=0.1)
-    del text
     torch.cuda.empty_cache()
     d_seqs = reads.reshape(-1)
     if d_seqs.numel() % 16:  # reads are fetched as aligned 16-byte chunks
@@ -247,7 +248,7 @@ def main():
                             f"synthetic chr22-scale pangenome r-index, {N} x {m} bp reads per GPU per step (BASELINE.json configs[2])",
                 "index": {"L": args.L, "H": args.H, "n": int(inp["n"]), "r": int(inp["r"]), "site_rate": args.site_rate,
                           "hbm_bytes": int(ix.hbm_bytes), "pos_bytes": int(ix.pos_bytes), "seed": args.seed,
-                          "two_symbol_steps": bool(ix.two_step_symbols), "pair_runs": int(ix.pair_runs)},
+                          "symbols_per_gather": int(ix.kmer_steps), "pair_runs": int(ix.pair_runs), "triple_runs": int(ix.triple_runs)},
                 "reads_per_gpu": N, "read_len": m, "substituted_fraction": 0.1,
                 "parallelism": f"index replicated x{world}, reads sharded, no data-path collective",
             },
@@ -259,6 +260,37 @@ def main():
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic},
             "kernels": {k: {"ms": v["ms"], "alg_GBps": v["alg_bytes"] / (v["ms"] * 1e-3) / 1e9} for k, v in kernels.items()},
         }
+
+    # ---- full-size property check (outside the timed region): every location reported for the
+    # first --property-reads reads really is an occurrence, locations of a read are distinct and
+    # their number equals hi-lo+1; unmatched reads report {1,0}
+    if rank == 0 and args.property_reads > 0:
+        step()
+        torch.cuda.synchronize()
+        npr = min(args.property_reads, N)
+        offs = d_loc_off[:npr + 1]
+        nloc = int(offs[-1].item())
+        occ_t = offs[1:] - offs[:-1]
+        lo_t, hi_t = d_lo[:npr], d_hi[:npr]
+        ok_occ = bool((torch.where(hi_t >= lo_t, hi_t - lo_t + 1, torch.zeros_like(lo_t)) == occ_t).all().item())
+        ok_empty = bool(((hi_t >= lo_t) | ((lo_t == 1) & (hi_t == 0))).all().item())
+        ridx = torch.repeat_interleave(torch.arange(npr, device=dev), occ_t)
+        locs_t = d_locs[:nloc]
+        bad = torch.zeros(nloc, dtype=torch.bool, device=dev)
+        for j in range(m):
+            bad |= text[locs_t + j] != reads[ridx, j]
+        ok_match = not bool(bad.any().item())
+        key = ridx * (int(inp["n"]) + 1) + locs_t
+        ok_distinct = int(torch.unique(key).numel()) == nloc
+        out["properties_full_size"] = {"reads": npr, "locations": nloc, "every_location_is_an_occurrence": ok_match,
+                                       "locations_distinct": ok_distinct, "occ_equals_range_width": ok_occ,
+                                       "empty_is_{1,0}": ok_empty}
+        del ridx, locs_t, bad, key
+        if not (ok_match and ok_distinct and ok_occ and ok_empty):
+            print(json.dumps(out))
+            raise SystemExit("PROPERTY FAILURE at full size")
+    del text
+    torch.cuda.empty_cache()
 
     # ---- parity sample + CPU baseline (rank 0, N=1 only; never part of the timed region) ------
     if rank == 0 and not (args.no_cpu_baseline and args.check_reads == 0):

@@ -36,7 +36,7 @@ std::atomic<int64_t> g_opt_block_threads{256};
 std::atomic<int64_t> g_opt_rank_shift{-1};
 std::atomic<int64_t> g_opt_phi_shift{-1};
 std::atomic<int64_t> g_opt_pos_bytes{0};
-std::atomic<int64_t> g_opt_two_step{1};
+std::atomic<int64_t> g_opt_kmer_steps{3};
 
 #define HIP_TRY(expr)                                                                             \
     do {                                                                                          \
@@ -208,15 +208,26 @@ int upload_tables(rbg_index *ix) {
     if (rc) return rc;
     ix->dev.syms = static_cast<const DevSym *>(p);
     ix->dev.nmajor = 0;
+    ix->dev.kmer_steps = 1;
     if (!h.pair.empty()) {
-        std::vector<DevSym> pairs(h.pair.size());
-        for (size_t i = 0; i < h.pair.size(); ++i) {
-            rc = upload_sym<P>(ix, h.pair[i], h.has_tsa, pairs[i]);
-            if (rc) return rc;
+        auto upload_set = [&](const std::vector<SymTable> &tabs, const DevSym **dst) -> int {
+            std::vector<DevSym> recs(tabs.size());
+            for (size_t i = 0; i < tabs.size(); ++i) {
+                int r2 = upload_sym<P>(ix, tabs[i], h.has_tsa, recs[i]);
+                if (r2) return r2;
+            }
+            const void *pp = nullptr;
+            int r2 = dev_upload(ix, recs.data(), recs.size() * sizeof(DevSym), &pp);
+            if (r2) return r2;
+            *dst = static_cast<const DevSym *>(pp);
+            return RBG_OK;
+        };
+        if ((rc = upload_set(h.pair, &ix->dev.pairs))) return rc;
+        ix->dev.kmer_steps = 2;
+        if (!h.triple.empty()) {
+            if ((rc = upload_set(h.triple, &ix->dev.triples))) return rc;
+            ix->dev.kmer_steps = 3;
         }
-        rc = dev_upload(ix, pairs.data(), pairs.size() * sizeof(DevSym), &p);
-        if (rc) return rc;
-        ix->dev.pairs = static_cast<const DevSym *>(p);
         rc = dev_upload(ix, h.major_of, 256, &p);
         if (rc) return rc;
         ix->dev.lut2 = static_cast<const uint8_t *>(p);
@@ -304,7 +315,7 @@ FlattenOptions current_options() {
     o.rank_bucket_shift = static_cast<int>(g_opt_rank_shift.load());
     o.phi_bucket_shift = static_cast<int>(g_opt_phi_shift.load());
     o.force_pos_bytes = static_cast<int>(g_opt_pos_bytes.load());
-    o.two_step = static_cast<int>(g_opt_two_step.load());
+    o.kmer_steps = static_cast<int>(g_opt_kmer_steps.load());
     return o;
 }
 
@@ -404,9 +415,9 @@ int rbg_set_default_option(int opt, int64_t value) {
         case RBG_OPT_POS_BYTES:
             if (value != 0 && value != 4 && value != 8) return RBG_EARG;
             g_opt_pos_bytes = value; return RBG_OK;
-        case RBG_OPT_TWO_STEP:
-            if (value != 0 && value != 1) return RBG_EARG;
-            g_opt_two_step = value; return RBG_OK;
+        case RBG_OPT_KMER_STEPS:
+            if (value < 1 || value > 3) return RBG_EARG;
+            g_opt_kmer_steps = value; return RBG_OK;
         default: return RBG_EARG;
     }
 }
@@ -532,8 +543,10 @@ int rbg_info(const rbg_index *ix, rbg_info_t *out) {
     out->rank_slots_overflow = ix->rank_slots_overflow;
     out->phi_slots = ix->phi_slots;
     out->phi_slots_overflow = ix->phi_slots_overflow;
-    out->two_step_symbols = ix->host.pair.empty() ? 0 : ix->host.nmajor;
+    out->kmer_steps = ix->host.triple.empty() ? (ix->host.pair.empty() ? 1 : 2) : 3;
+    out->kmer_symbols = ix->host.pair.empty() ? 0 : ix->host.nmajor;
     for (const SymTable &t : ix->host.pair) out->pair_runs += t.nruns;
+    for (const SymTable &t : ix->host.triple) out->triple_runs += t.nruns;
     return RBG_OK;
 }
 

@@ -87,10 +87,11 @@ struct DevIndex {
     // two-symbol steps: pairs[m1 * nmajor + m2] describes the pair symbol (c1,c2) with the same
     // record shape as a single symbol (F = first row of the SA interval of "c1c2", samp = SA-2 at
     // pair-run ends); lut2 maps a byte to its major index 0..nmajor-1 or 0xFF.  nmajor == 0: off.
-    const DevSym *pairs;
+    const DevSym *pairs;    // nmajor^2
+    const DevSym *triples;  // nmajor^3 (kmer_steps == 3)
     const uint8_t *lut2;
     uint32_t nmajor;
-    uint32_t pad2;
+    uint32_t kmer_steps;    // 1, 2 or 3
 };
 
 struct LaunchCfg {

@@ -342,23 +342,125 @@ uint32_t auto_shift(uint64_t n, uint64_t items, double per_slot) {
     return s;
 }
 
-// Pair tables for two-symbol LF steps.  LF2([lo,hi], c1c2) = C2 + rank2(.., (c1,c2)) where
-// rank2 counts rows p with (bwt[LF(p)], bwt[p]) == (c1, c2) and C2 = F[c1] + rank(F[c2], c1) is the
-// first row of the SA interval of "c1c2"; composing it is exactly two RowBowt::LF calls
-// (rowbowt.hpp:74-88), and the toehold after the two LF_w_loc calls (rowbowt.hpp:555-573) is
-// k-2 when row hi carries the pair, else (SA - 2) at the end of the last pair-run before hi.
-// The pair-runs of (.,c2) are the c2-runs cut where LF of their rows crosses a BWT run boundary,
-// so one linear sweep per c2 enumerates them in row order; the SA value at a pair-run end is
-// known because either that row or its LF image ends a BWT run.
-int build_pairs(HostIndex &out, const RawTsa *tsa, const FlattenOptions &opt) {
+// Multi-symbol LF steps.  For the "major" symbols (the <= 4 most frequent non-terminator symbols)
+// a depth-d table T_d[x_{d-1} .. x_1 x_0] describes the rows p whose d preceding text characters
+// are x_{d-1} .. x_0, i.e. bwt[p] = x_0, bwt[LF(p)] = x_1, ...: runs of such rows (start, cum),
+// F = first row of the SA interval of the d-mer, samp = SA - d at the end of each run.  Then
+//   LF^d([lo,hi], d-mer) = F + rank_d(., d-mer)
+// is exactly d nested RowBowt::LF calls (rowbowt.hpp:74-88), and the toehold after d LF_w_loc
+// calls (rowbowt.hpp:555-573) is k-d when row hi carries the d-mer, else samp of the last run
+// starting before hi.
+//
+// T_{d+1} is composed from T_d: the rows with bwt = c are LF-mapped, run by run, onto a row-ordered
+// segmentation G_d of [0,n) by depth-d id; every overlap piece is one depth-(d+1) run.  The SA value
+// at a piece's last row is known: either its LF image ends a G_d segment (that segment's sample), or
+// the row ends the c-run (that run's samples_last_ minus d).
+struct Segmentation {          // row-ordered cover of [0,n): segment g = [start[g], start[g+1])
+    std::vector<uint64_t> start;  // + sentinel n
+    std::vector<uint32_t> id;     // depth-d table index, or kNoId
+    std::vector<uint64_t> samp;   // SA - d at the segment's last row (only with a toehold SA)
+};
+constexpr uint32_t kNoId = 0xFFFFFFFFu;
+
+int compose(const HostIndex &ix, const std::vector<uint32_t> &major_slot, const Segmentation &G, uint32_t depth,
+            uint32_t n_ids, const std::vector<SymTable> &prev, bool with_samples, const FlattenOptions &opt,
+            std::vector<SymTable> &out) {
+    const uint32_t M = static_cast<uint32_t>(major_slot.size());
+    out.assign(static_cast<size_t>(n_ids) * M, SymTable());
+    for (uint32_t m = 0; m < M; ++m) {
+        const SymTable &tc = ix.sym[major_slot[m]];
+        std::vector<uint64_t> seen(n_ids, 0);
+        uint64_t g = 0;
+        for (uint64_t k = 0; k < tc.nruns; ++k) {
+            const uint64_t s = tc.start[k], len = tc.cum[k + 1] - tc.cum[k];
+            const uint64_t Q = tc.F + tc.cum[k];  // LF of row s (rowbowt.hpp:65-68)
+            uint64_t q = Q;
+            while (q < Q + len) {
+                while (G.start[g + 1] <= q) ++g;
+                const uint64_t qend = std::min(Q + len, G.start[g + 1]);
+                const uint32_t id = G.id[g];
+                if (id != kNoId) {
+                    SymTable &t = out[static_cast<size_t>(id) * M + m];
+                    t.start.push_back(s + (q - Q));
+                    t.cum.push_back(seen[id]);
+                    seen[id] += qend - q;
+                    if (with_samples) {
+                        uint64_t v;
+                        if (qend == G.start[g + 1]) v = G.samp[g];
+                        else {
+                            if (tc.samp[k] < depth) return RBG_EFORMAT;  // would need the terminator inside the k-mer
+                            v = tc.samp[k] - depth;
+                        }
+                        t.samp.push_back(v);
+                    }
+                }
+                q = qend;
+            }
+        }
+        for (uint32_t id = 0; id < n_ids; ++id) {
+            SymTable &t = out[static_cast<size_t>(id) * M + m];
+            const SymTable &tp = prev[id];
+            t.byte = tc.byte;
+            t.nruns = t.start.size();
+            t.total = seen[id];
+            t.start.push_back(ix.n);
+            t.cum.push_back(t.total);
+            // F_{d+1}[id, c] = F_d[id] + rank_d(F[c], id): rows of the id-interval followed by a smaller symbol
+            const uint64_t i = tc.F;
+            const uint64_t kk = std::lower_bound(tp.start.begin(), tp.start.begin() + tp.nruns, i) - tp.start.begin();
+            uint64_t rk = 0;
+            if (kk > 0) rk = tp.cum[kk - 1] + std::min(i - tp.start[kk - 1], tp.cum[kk] - tp.cum[kk - 1]);
+            t.F = tp.F + rk;
+            t.shift = opt.rank_bucket_shift >= 0 ? static_cast<uint32_t>(opt.rank_bucket_shift) : auto_shift(ix.n, t.nruns, 1.5);
+            if (t.nruns >= 0xFFFFFFF0ull) return RBG_EARG;
+        }
+    }
+    return RBG_OK;
+}
+
+// row-ordered segmentation from a set of tables (their runs are disjoint); uncovered rows get kNoId
+void segmentation_of(const std::vector<SymTable> &tabs, uint64_t n, bool with_samples, Segmentation &G) {
+    struct Cur { uint64_t k; };
+    std::vector<Cur> cur(tabs.size(), Cur{0});
+    G.start.clear(); G.id.clear(); G.samp.clear();
+    uint64_t total = 0;
+    for (const SymTable &t : tabs) total += t.nruns;
+    G.start.reserve(2 * total + 2); G.id.reserve(2 * total + 2);
+    if (with_samples) G.samp.reserve(2 * total + 2);
+    uint64_t pos = 0;
+    while (true) {
+        // next run in row order (few tables: linear scan for the minimum start)
+        size_t best = tabs.size();
+        uint64_t best_start = n;
+        for (size_t i = 0; i < tabs.size(); ++i)
+            if (cur[i].k < tabs[i].nruns && tabs[i].start[cur[i].k] < best_start) { best = i; best_start = tabs[i].start[cur[i].k]; }
+        if (best == tabs.size()) break;
+        const SymTable &t = tabs[best];
+        const uint64_t k = cur[best].k++;
+        if (best_start > pos) {  // gap: rows whose context leaves the major alphabet
+            G.start.push_back(pos); G.id.push_back(kNoId);
+            if (with_samples) G.samp.push_back(0);
+        }
+        G.start.push_back(best_start); G.id.push_back(static_cast<uint32_t>(best));
+        if (with_samples) G.samp.push_back(t.samp[k]);
+        pos = best_start + (t.cum[k + 1] - t.cum[k]);
+    }
+    if (pos < n) {
+        G.start.push_back(pos); G.id.push_back(kNoId);
+        if (with_samples) G.samp.push_back(0);
+    }
+    G.start.push_back(n);
+}
+
+int build_kmer_tables(HostIndex &out, const RawTsa *tsa, const FlattenOptions &opt) {
     std::memset(out.major_of, 0xFF, sizeof(out.major_of));
     out.nmajor = 0;
     out.pair.clear();
-    if (!opt.two_step || out.sigma < 2) return RBG_OK;
+    out.triple.clear();
+    if (opt.kmer_steps < 2 || out.sigma < 2) return RBG_OK;
     // the terminator: the smallest symbol, occurring once (rle_string.hpp:59,62 maps 0 -> 1).
-    // Without one the (k-1)-1 wrap argument of DESIGN.md 2b does not hold: keep single steps only.
-    const SymTable &first = out.sym[0];
-    if (first.total != 1) return RBG_OK;
+    // Without one the wrap argument of DESIGN.md 2b does not hold: keep single steps only.
+    if (out.sym[0].total != 1) return RBG_OK;
     std::vector<uint32_t> order;
     for (uint32_t s = 1; s < out.sigma; ++s) order.push_back(s);
     std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
@@ -366,65 +468,30 @@ int build_pairs(HostIndex &out, const RawTsa *tsa, const FlattenOptions &opt) {
     });
     if (order.size() > 4) order.resize(4);
     std::sort(order.begin(), order.end());
-    out.nmajor = static_cast<uint32_t>(order.size());
-    for (uint32_t m = 0; m < out.nmajor; ++m) {
+    const uint32_t M = static_cast<uint32_t>(order.size());
+    out.nmajor = M;
+    for (uint32_t m = 0; m < M; ++m) {
         out.major_byte[m] = out.sym[order[m]].byte;
         out.major_of[out.sym[order[m]].byte] = static_cast<uint8_t>(m);
     }
-    const uint32_t M = out.nmajor;
-    out.pair.assign(M * M, SymTable());
-    const uint64_t R = out.r;
-    for (uint32_t m2 = 0; m2 < M; ++m2) {
-        const SymTable &t2 = out.sym[order[m2]];
-        uint64_t g = 0;  // global BWT run containing the current LF image
-        std::vector<uint64_t> seen(M, 0);
-        for (uint64_t k = 0; k < t2.nruns; ++k) {
-            const uint64_t s = t2.start[k], len = t2.cum[k + 1] - t2.cum[k];
-            const uint64_t Q = t2.F + t2.cum[k];  // LF of row s (rowbowt.hpp:65-68)
-            uint64_t q = Q;
-            while (q < Q + len) {
-                while (out.run_start[g + 1] <= q) ++g;
-                const uint64_t qend = std::min(Q + len, out.run_start[g + 1]);
-                const uint8_t m1 = out.major_of[out.run_heads[g]];
-                if (m1 != 0xFF) {
-                    SymTable &pt = out.pair[m1 * M + m2];
-                    pt.start.push_back(s + (q - Q));
-                    pt.cum.push_back(seen[m1]);
-                    seen[m1] += qend - q;
-                    if (tsa) {
-                        // SA - 2 at the pair-run's last row p*: if LF(p*) ends BWT run g its
-                        // samples_last_ is SA[LF(p*)] - 1; otherwise p* ends the c2-run
-                        uint64_t v;
-                        if (qend == out.run_start[g + 1]) v = tsa->samples_last[g];
-                        else {
-                            if (t2.samp[k] == 0) return RBG_EFORMAT;  // would need c1 == terminator
-                            v = t2.samp[k] - 1;
-                        }
-                        pt.samp.push_back(v);
-                    }
-                }
-                q = qend;
-            }
-        }
-        for (uint32_t m1 = 0; m1 < M; ++m1) {
-            SymTable &pt = out.pair[m1 * M + m2];
-            const SymTable &t1 = out.sym[order[m1]];
-            pt.byte = t2.byte;
-            pt.nruns = pt.start.size();
-            pt.total = seen[m1];
-            pt.start.push_back(out.n);
-            pt.cum.push_back(pt.total);
-            // C2 = F[c1] + rank(F[c2], c1): rows of suffixes starting with c1 followed by a smaller symbol
-            const uint64_t i = t2.F;
-            const uint64_t kk = std::lower_bound(t1.start.begin(), t1.start.begin() + t1.nruns, i) - t1.start.begin();
-            uint64_t rk = 0;
-            if (kk > 0) rk = t1.cum[kk - 1] + std::min(i - t1.start[kk - 1], t1.cum[kk] - t1.cum[kk - 1]);
-            pt.F = t1.F + rk;
-            pt.shift = opt.rank_bucket_shift >= 0 ? static_cast<uint32_t>(opt.rank_bucket_shift) : auto_shift(out.n, pt.nruns, 1.5);
-            if (pt.nruns >= 0xFFFFFFF0ull) return RBG_EARG;
-        }
+    // depth 1: the BWT runs themselves, id = major index of the head, sample = samples_last_ (SA - 1)
+    Segmentation G;
+    G.start = out.run_start;
+    G.id.resize(out.r);
+    for (uint64_t g = 0; g < out.r; ++g) {
+        const uint8_t m = out.major_of[out.run_heads[g]];
+        G.id[g] = m == 0xFF ? kNoId : m;
     }
-    (void)R;
+    if (tsa) G.samp = tsa->samples_last;
+    std::vector<SymTable> depth1(M);
+    for (uint32_t m = 0; m < M; ++m) depth1[m] = out.sym[order[m]];
+    int rc = compose(out, order, G, 1, M, depth1, tsa != nullptr, opt, out.pair);
+    if (rc) return rc;
+    if (opt.kmer_steps >= 3) {
+        segmentation_of(out.pair, out.n, tsa != nullptr, G);
+        rc = compose(out, order, G, 2, M * M, out.pair, tsa != nullptr, opt, out.triple);
+        if (rc) return rc;
+    }
     return RBG_OK;
 }
 }  // namespace
@@ -505,7 +572,7 @@ int flatten(const RawRle &rle, const RawTsa *tsa, const FlattenOptions &opt, Hos
         out.phi_shift = opt.phi_bucket_shift >= 0 ? static_cast<uint32_t>(opt.phi_bucket_shift) : auto_shift(out.n, R, 0.75);
         if (out.phi_shift > 8) return RBG_EARG;
     }
-    return build_pairs(out, tsa, opt);
+    return build_kmer_tables(out, tsa, opt);
 }
 
 }  // namespace rbg

@@ -73,14 +73,15 @@ struct HostIndex {
     std::vector<uint8_t> run_heads;    // R
     std::vector<uint64_t> run_start;   // R + 1
     // toehold SA
-    // two-symbol steps: for the <= 4 most frequent non-terminator symbols ("major"),
-    // pair[m1 * nmajor + m2] is the table of the pair symbol (c1, c2) = (bwt[LF(p)], bwt[p]):
-    // runs of rows whose two preceding text characters are c1 c2.  Its F is the first row of the
-    // SA interval of "c1c2"; its samp[] holds SA - 2 at the end of each pair-run.
+    // multi-symbol steps: for the <= 4 most frequent non-terminator symbols ("major"),
+    // pair[m1 * nmajor + m0] / triple[(m2 * nmajor + m1) * nmajor + m0] are the tables of the rows
+    // whose preceding text characters are x1 x0 / x2 x1 x0 (x0 = bwt[p] adjacent to the suffix).
+    // F is the first row of the SA interval of that k-mer; samp[] holds SA - k at each run end.
     uint32_t nmajor = 0;
     uint8_t major_byte[4] = {0, 0, 0, 0};
     uint8_t major_of[256];             // byte -> 0..nmajor-1, 0xFF otherwise
-    std::vector<SymTable> pair;        // nmajor * nmajor, or empty (two-step disabled)
+    std::vector<SymTable> pair;        // nmajor^2, or empty (multi-symbol steps disabled)
+    std::vector<SymTable> triple;      // nmajor^3, or empty
     bool has_tsa = false;
     uint64_t last_run_sample = 0;      // toehold_sa.hpp:97-99
     std::vector<uint64_t> samples_last, pred_pos, phi_base;
@@ -95,7 +96,7 @@ struct FlattenOptions {
     int rank_bucket_shift = -1;  // <0: automatic (about one run per two buckets)
     int phi_bucket_shift = -1;
     int force_pos_bytes = 0;     // 0: 4 when n fits, else 8
-    int two_step = 1;            // build the pair tables
+    int kmer_steps = 3;          // symbols consumed per gather: 1 (reference shape), 2 or 3
 };
 
 int flatten(const RawRle &rle, const RawTsa *tsa, const FlattenOptions &opt, HostIndex &out);

@@ -140,7 +140,9 @@ __global__ __launch_bounds__(256) void k_find_range(const DevIndex ix, const uin
     __shared__ uint8_t s_lut2[256];
     __shared__ DevSym s_sym[kLdsSyms];
     __shared__ DevSym s_pair[kMaxMajor * kMaxMajor];
+    __shared__ DevSym s_tri[kMaxMajor * kMaxMajor * kMaxMajor];
     const uint32_t M = ix.nmajor;
+    const bool use3 = ix.kmer_steps >= 3;
     for (int t = threadIdx.x; t < 256; t += blockDim.x) {
         s_lut[t] = ix.lut[t];
         s_lut2[t] = M ? ix.lut2[t] : 0xFFu;
@@ -148,6 +150,8 @@ __global__ __launch_bounds__(256) void k_find_range(const DevIndex ix, const uin
     const int nlds = ix.sigma < static_cast<uint32_t>(kLdsSyms) ? static_cast<int>(ix.sigma) : kLdsSyms;
     for (int t = threadIdx.x; t < nlds; t += blockDim.x) s_sym[t] = ix.syms[t];
     for (int t = threadIdx.x; t < static_cast<int>(M * M); t += blockDim.x) s_pair[t] = ix.pairs[t];
+    if (use3)
+        for (int t = threadIdx.x; t < static_cast<int>(M * M * M); t += blockDim.x) s_tri[t] = ix.triples[t];
     __syncthreads();
 
     unsigned long long c_reads = 0, c_matched = 0, c_occ = 0;
@@ -162,47 +166,41 @@ __global__ __launch_bounds__(256) void k_find_range(const DevIndex ix, const uin
         while (p > beg) {  // right-to-left over the read (rowbowt.hpp:127-129, :175-181)
             --p;
             const uint32_t c = rd.at(p);
-            // Two reference iterations in one gather when this symbol and the one to its left both
-            // have pair tables: LF(LF(range, c), c1) == F2[c1 c] + rank2(., (c1,c)); the toehold
-            // after the two LF_w_loc calls is k-2 if row hi carries the pair, else the pair-run
-            // sample.  An empty result is {1,0} whichever of the two steps emptied it.
-            const uint32_t m2 = s_lut2[c];
-            if (m2 != 0xFFu && p > beg) {
-                const uint32_t m1 = s_lut2[rd.at(p - 1)];
-                if (m1 != 0xFFu) {
-                    const DevSym S = s_pair[m1 * M + m2];
-                    RankAux q;
-                    uint64_t c_before, c_upto, bh;
-                    rank_pair<P>(S, lo, hi + 1, &c_before, &c_upto, &bh, &q);
-                    const uint64_t c_inside = c_upto - c_before;
-                    if (c_inside == 0) { alive = false; break; }
-                    if (TOEHOLD) {
-                        if (q.inside) k = k - 2;
-                        else k = pred_sample<P>(S, bh, q);
-                    }
-                    lo = S.F + c_before;
-                    hi = lo + c_inside - 1;
-                    --p;  // the left symbol is consumed too
-                    continue;
-                }
+            // Up to three reference iterations in one gather: when this symbol and its left
+            // neighbours all have k-mer tables, LF(LF(LF(range,x0),x1),x2) == F3[x2x1x0] + rank3(.),
+            // and the toehold after the nested LF_w_loc calls is k-adv if row hi carries the k-mer,
+            // else the k-mer run sample.  An empty result is {1,0} whichever of the
+            // nested steps emptied it.  Otherwise: one reference step (rowbowt.hpp:74-88, :555-573).
+            uint32_t adv = 1;
+            DevSym S;
+            const uint32_t m0 = s_lut2[c];
+            uint32_t m1 = 0xFFu;
+            if (m0 != 0xFFu && p > beg) m1 = s_lut2[rd.at(p - 1)];
+            if (m1 != 0xFFu) {
+                uint32_t m2 = 0xFFu;
+                if (use3 && p > beg + 1) m2 = s_lut2[rd.at(p - 2)];
+                if (m2 != 0xFFu) { S = s_tri[(m2 * M + m1) * M + m0]; adv = 3; }
+                else { S = s_pair[m1 * M + m0]; adv = 2; }
+            } else {
+                const uint32_t slot = s_lut[c];
+                if (slot == 0xFFu) { alive = false; break; }  // symbol absent: f_[c] >= f_[c+1], rowbowt.hpp:76
+                S = slot < static_cast<uint32_t>(kLdsSyms) ? s_sym[slot] : ix.syms[slot];
             }
-            const uint32_t slot = s_lut[c];
-            if (slot == 0xFFu) { alive = false; break; }  // symbol absent: f_[c] >= f_[c+1], rowbowt.hpp:76
-            const DevSym S = slot < static_cast<uint32_t>(kLdsSyms) ? s_sym[slot] : ix.syms[slot];
             RankAux q;
             uint64_t c_before, c_upto, bh;
             rank_pair<P>(S, lo, hi + 1, &c_before, &c_upto, &bh, &q);      // rowbowt.hpp:79,83
             const uint64_t c_inside = c_upto - c_before;
             if (c_inside == 0) { alive = false; break; }                   // rowbowt.hpp:85
             if (TOEHOLD) {
-                // LF_w_loc, rowbowt.hpp:559-566.  Either hi holds c (bwt_[hi]==c -> k-1), or the last
-                // run of c starting before hi ends before hi and its last position is
-                // select(rank(hi,c)-1,c), whose run-end sample is samples_last_[run].
-                if (q.inside) k = k - 1;
+                // LF_w_loc, rowbowt.hpp:559-566.  Either hi holds the symbol (bwt_[hi]==c -> k-1 per
+                // nested step), or the last run starting before hi ends before hi and its last row
+                // is select(rank(hi,c)-1,c), whose run-end sample is samples_last_[run] (resp. SA-adv).
+                if (q.inside) k = k - adv;
                 else k = pred_sample<P>(S, bh, q);
             }
             lo = S.F + c_before;           // rowbowt.hpp:86
             hi = lo + c_inside - 1;        // rowbowt.hpp:87
+            p -= adv - 1;                  // the left neighbours are consumed too
         }
         if (!alive) { lo = 1; hi = 0; k = 0; }  // {1,0}; LFData::clear rowbowt.hpp:153-159
         lo_out[i] = lo;
@@ -264,37 +262,75 @@ __device__ __forceinline__ uint64_t phi_step(const DevIndex &ix, uint64_t i) {
     return s;
 }
 
+// One lane walks one read's phi chain (toehold_sa.hpp:37-49); the chain is serial, the reads are
+// not.  The locations of a read are contiguous in `locs`, but a lane storing its own values would
+// make every store instruction touch 64 different lines, and stores are gather-class requests just
+// like the slot loads (tools/gather_roof.hip).  So values are staged per wave in LDS, kChunk steps
+// at a time, and flushed with 8 lanes writing one read's 64-byte segment: a store instruction then
+// touches ~8-12 lines instead of 64.
+constexpr int kChunk = 8;
+
+__device__ __forceinline__ void wave_lds_sync() {
+    // LDS operations of one wave execute in issue order; this only stops the compiler from moving
+    // the cross-lane reads above the writes (and vice versa)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <typename P>
 __global__ __launch_bounds__(256) void k_locate_fill(const DevIndex ix, const uint64_t *__restrict__ lo,
                                                      const uint64_t *__restrict__ hi, const uint64_t *__restrict__ k,
                                                      const uint64_t N, const uint64_t max_hits,
                                                      const uint64_t *__restrict__ loc_off, uint64_t *__restrict__ locs) {
+    __shared__ uint64_t s_val[4][kWave][kChunk + 1];  // +1: keeps the per-lane rows off the same banks
+    __shared__ uint64_t s_dst[4][kWave];
+    __shared__ uint64_t s_occ[4][kWave];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
     unsigned long long c_locs = 0;
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
-    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < N; i += stride) {
-        const uint64_t l = lo[i], h = hi[i];
-        uint64_t occ = h >= l ? h - l + 1 : 0;
-        if (occ > max_hits) occ = max_hits;
-        if (occ == 0) continue;
-        uint64_t *dst = locs + loc_off[i];
-        uint64_t k1 = k[i];
-        // stores are gather-class requests too: emit two locations per 16-byte store
-        uint64_t t = 0;
-        if ((reinterpret_cast<uintptr_t>(dst) & 15u) && occ) {  // peel one to reach 16-byte alignment
-            dst[0] = k1;
-            t = 1;
-            if (t < occ) k1 = phi_step<P>(ix, k1);
+    for (uint64_t base = static_cast<uint64_t>(blockIdx.x) * blockDim.x + wv * kWave; base < N; base += stride) {
+        const uint64_t i = base + lane;
+        uint64_t occ = 0, k1 = 0, dst = 0;
+        if (i < N) {
+            const uint64_t l = lo[i], h = hi[i];
+            occ = h >= l ? h - l + 1 : 0;  // toehold_sa.hpp:38-39
+            if (occ > max_hits) occ = max_hits;
+            k1 = k[i];
+            dst = loc_off[i];
         }
-        for (; t + 1 < occ; t += 2) {
-            const uint64_t k2 = phi_step<P>(ix, k1);
-            *reinterpret_cast<ulonglong2 *>(dst + t) = make_ulonglong2(k1, k2);
-            if (t + 2 < occ) k1 = phi_step<P>(ix, k2);
-        }
-        if (t < occ) dst[t] = k1;
+        s_dst[wv][lane] = dst;
+        s_occ[wv][lane] = occ;
         c_locs += occ;
+        uint64_t wmax = occ;
+#pragma unroll
+        for (int o = kWave / 2; o > 0; o >>= 1) {
+            const uint64_t other = __shfl_xor(wmax, o, kWave);
+            wmax = other > wmax ? other : wmax;
+        }
+        for (uint64_t t0 = 0; t0 < wmax; t0 += kChunk) {
+#pragma unroll
+            for (int e = 0; e < kChunk; ++e) {
+                const uint64_t t = t0 + e;
+                if (t < occ) {
+                    if (t) k1 = phi_step<P>(ix, k1);  // toehold_sa.hpp:44
+                    s_val[wv][lane][e] = k1;
+                }
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int pass = 0; pass < kChunk; ++pass) {
+                const int s = pass * (kWave / kChunk) + (lane >> 3);
+                const int e = lane & (kChunk - 1);
+                const uint64_t t = t0 + e;
+                if (t < s_occ[wv][s]) locs[s_dst[wv][s] + t] = s_val[wv][s][e];
+            }
+            wave_lds_sync();
+        }
+        wave_lds_sync();
     }
     c_locs = wave_sum(c_locs);
-    if ((threadIdx.x & (kWave - 1)) == 0 && c_locs) atomicAdd(&ix.counters[3], c_locs);
+    if (lane == 0 && c_locs) atomicAdd(&ix.counters[3], c_locs);
 }
 
 // ---- K4: markers --------------------------------------------------------------------------------

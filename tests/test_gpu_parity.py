@@ -117,24 +117,24 @@ def synth():
     return SynthIndex(L=4000, H=8, n_sites=60, seed=11)
 
 
-@pytest.mark.parametrize("pos_bytes,rshift,pshift,two_step",
-                         [(0, -1, -1, 1), (0, -1, -1, 0), (8, -1, -1, 1), (4, 0, 0, 1), (8, 3, 2, 0), (4, 8, 8, 1),
-                          (8, 8, 7, 1), (4, 5, 6, 0), (4, 2, 2, 1)])
-def test_synth_all_paths(synth, pos_bytes, rshift, pshift, two_step):
+@pytest.mark.parametrize("pos_bytes,rshift,pshift,ksteps",
+                         [(0, -1, -1, 3), (0, -1, -1, 2), (0, -1, -1, 1), (8, -1, -1, 3), (4, 0, 0, 2), (8, 3, 2, 1),
+                          (4, 8, 8, 3), (8, 8, 7, 2), (4, 5, 6, 1), (4, 2, 2, 3)])
+def test_synth_all_paths(synth, pos_bytes, rshift, pshift, ksteps):
     S = synth
     ra.set_default_option(capi.OPT_POS_BYTES, pos_bytes)
     ra.set_default_option(capi.OPT_RANK_BUCKET_SHIFT, rshift)
     ra.set_default_option(capi.OPT_PHI_BUCKET_SHIFT, pshift)
-    ra.set_default_option(capi.OPT_TWO_STEP, two_step)
+    ra.set_default_option(capi.OPT_KMER_STEPS, ksteps)
     try:
         rb = ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0)
     finally:
         for o_ in (capi.OPT_POS_BYTES, capi.OPT_RANK_BUCKET_SHIFT, capi.OPT_PHI_BUCKET_SHIFT):
             ra.set_default_option(o_, 0 if o_ == capi.OPT_POS_BYTES else -1)
-        ra.set_default_option(capi.OPT_TWO_STEP, 1)
+        ra.set_default_option(capi.OPT_KMER_STEPS, 3)
     o = orc.Oracle.from_runs(S.heads, S.lens, S.ssa, S.esa)
     assert rb.info().pos_bytes == (pos_bytes or 4)
-    assert rb.info().two_step_symbols == (4 if two_step else 0)
+    assert rb.info().kmer_steps == ksteps and rb.info().kmer_symbols == (4 if ksteps > 1 else 0)
     reads = S.sample_reads(3000, 60, seed=5, sub_rate=0.15, ragged=True)
     reads += [b"", b"A", b"N", b"ACGTN", b"NACGT", b"ACNGT", b"AC", b"ACG", b"acgt", bytes([1]), bytes([255]) * 3, bytes([0]),
               S.text[:500].tobytes(), S.text[:501].tobytes(), b"A" + bytes([1]), bytes([1]) + b"A",
@@ -329,3 +329,75 @@ def test_cli_locs_and_markers_stdout(data_dir, tmp_path, small, simple_reads):
     bad.write_text("@r\nACGT\n+\n~~\n")
     rc, _, err = _run_cli([str(tmp_path / "idx"), str(bad)])
     assert rc == 1 and "truncated quality string" in err
+
+
+# ---- mid-scale (n ~ 4e6) synthetic pangenome built with the bench's own generator on the GPU:
+# count, toehold, locate, markers (BASELINE configs 2, 3, 5 in miniature) against the oracle -----
+def test_midscale_pangenome_all_queries():
+    import torch
+    from rowbowt_amd.tools import synth_pangenome as sp
+    dev = torch.device("cuda:0")
+    text, info = sp.make_text(200_000, 20, 0.01, 77, dev)
+    sa = sp.suffix_array(text)
+    inp = sp.index_inputs(text, sa)
+    n, unit, H, L = info["n"], info["unit"], info["H"], info["L"]
+    rb = ra.RowBowt.from_runs(inp["heads"], inp["lens"], inp["ssa"], inp["esa"], device=0)
+    o = orc.Oracle.from_runs(inp["heads"], inp["lens"], inp["ssa"], inp["esa"])
+    assert rb.info().kmer_steps == 3 and rb.info().kmer_symbols == 4
+    # marker array like small.fa.mab: rows whose suffix starts within w bases before a variant site
+    w = 10
+    tcpu = text.cpu().numpy()
+    isa = np.empty(n, dtype=np.int64)
+    isa[sa.cpu().numpy()] = np.arange(n)
+    base = tcpu[:L]
+    site_pos = np.flatnonzero((tcpu[: H * unit].reshape(H, unit)[:, :L] != base[None, :]).any(axis=0))
+    tags = {}
+    for h in range(H):
+        hap = tcpu[h * unit:h * unit + L]
+        for s in site_pos:
+            allele = int(hap[s] != base[s])
+            for d in range(w):
+                p = s - d
+                if p >= 0:
+                    tags.setdefault(int(isa[h * unit + p]), set()).add(int(s) | (allele << 60))
+    rows = sorted(tags)
+    ms, me, mo, mv = [], [], [0], []
+    for r in rows:
+        vals = sorted(tags[r])
+        if ms and me[-1] == r - 1 and mv[mo[-2]:mo[-1]] == vals:
+            me[-1] = r
+        else:
+            ms.append(r); me.append(r); mv += vals; mo.append(len(mv))
+    rb.set_markers(ms, me, mo, mv)
+    o.set_markers(ms, me, mo, mv)
+    N, m = 200_000, 100
+    reads, _ = sp.sample_reads(text, info, N, m, seed=5, sub_rate=0.1)
+    seqs = reads.cpu().numpy().reshape(-1)
+    off = (np.arange(N + 1, dtype=np.uint64) * m)
+    rb.counters_reset()
+    lo, hi, k = rb.find_range_w_toehold(seqs, off)
+    wlo, whi, wk = o.find_range_w_toehold_batch(seqs, off, nthreads=8)
+    assert (lo == wlo).all() and (hi == whi).all() and (k == wk).all()
+    clo, chi = rb.find_range(seqs, off)
+    assert (clo == wlo).all() and (chi == whi).all()
+    loc_off, locs = rb.locs_at(lo, hi, k)
+    woff, wlocs = o.locs_at_batch(wlo, whi, wk, nthreads=8)
+    assert (loc_off == woff).all() and (locs == wlocs).all()
+    occ = np.where(whi >= wlo, whi - wlo + 1, 0)
+    assert rb.counters().tolist() == [2 * N, 2 * int((whi >= wlo).sum()), 2 * int(occ.sum()), int(occ.sum())]
+    mk_off, mk = rb.markers_at(lo, hi)
+    got = split(mk_off[:2001], mk)
+    hits = 0
+    for i in range(2000):
+        want = o.markers_at(int(lo[i]), int(hi[i]))
+        assert got[i] == want
+        hits += bool(want)
+    assert hits > 80  # ~ w * site_rate of the matched reads start within a marker window
+    sub = slice(0, 3000 * m)
+    lo2, hi2, mk_off2, mk2 = rb.find_range_w_markers(seqs[sub], off[:3001], 19, 1000)  # rb_markers defaults (rb_markers.cpp:29-30)
+    got2 = split(mk_off2, mk2)
+    for i in range(3000):
+        (wl, wh), wm = o.find_range_w_markers(reads[i].cpu().numpy().tobytes(), 19, 1000)
+        assert (int(lo2[i]), int(hi2[i])) == (wl, wh) and got2[i] == wm
+    rb.close()
+    o.close()
