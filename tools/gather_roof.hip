@@ -9,6 +9,33 @@
 #include <cstdlib>
 #include <vector>
 
+// variant: 16-byte accesses with a non-temporal hint, and two independent chains per lane
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+template <int MODE>  // 0: nt loads, 1: two chains per lane (plain loads), 2: two chains + nt
+__global__ __launch_bounds__(256) void chase16x(const uint4 *__restrict__ tab, unsigned long long nslots, int steps,
+                                                unsigned long long *out) {
+    unsigned long long x = (blockIdx.x * 256ull + threadIdx.x) * 0x9E3779B97F4A7C15ull + 12345;
+    unsigned long long y = x ^ 0xD1B54A32D192ED03ull;
+    unsigned long long acc = 0, acc2 = 0;
+    for (int s = 0; s < steps; ++s) {
+        x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
+        const uint4 *p = tab + x % nslots;
+        uint4 v;
+        if (MODE == 0 || MODE == 2) { u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p)); v = make_uint4(t.x, t.y, t.z, t.w); } else v = *p;
+        if (MODE >= 1) {
+            y ^= y >> 29; y *= 0xBF58476D1CE4E5B9ull; y ^= y >> 32;
+            const uint4 *p2 = tab + y % nslots;
+            uint4 v2;
+            if (MODE == 2) { u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p2)); v2 = make_uint4(t.x, t.y, t.z, t.w); } else v2 = *p2;
+            acc2 += v2.x;
+            y += acc2;
+        }
+        acc += v.x;
+        x += acc;
+    }
+    out[blockIdx.x * 256ull + threadIdx.x] = acc + acc2;
+}
+
 template <int W>  // bytes per access: 8, 16, 32, 64
 __global__ __launch_bounds__(256) void chase(const uint4 *__restrict__ tab, unsigned long long nslots, int steps,
                                              unsigned long long *out) {
@@ -63,5 +90,20 @@ int main(int argc, char **argv) {
                acc / ms / 1e6, acc * W / ms / 1e6, acc * (W > 64 ? W : 64) / ms / 1e6);
     };
     for (int W : {8, 16, 32, 64}) run(W);
+    for (int mode = 0; mode < 3; ++mode) {
+        const unsigned long long nslots = bytes / 16;
+        for (int rep = 0; rep < 2; ++rep) {
+            hipEventRecord(e0);
+            if (mode == 0) hipLaunchKernelGGL(chase16x<0>, dim3(blocks), dim3(256), 0, 0, tab, nslots, steps, out);
+            if (mode == 1) hipLaunchKernelGGL(chase16x<1>, dim3(blocks), dim3(256), 0, 0, tab, nslots, steps, out);
+            if (mode == 2) hipLaunchKernelGGL(chase16x<2>, dim3(blocks), dim3(256), 0, 0, tab, nslots, steps, out);
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+        }
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        const double acc = (double)blocks * 256 * steps * (mode >= 1 ? 2 : 1);
+        printf("16 B %s: %.2f ms  %.2f G accesses/s\n", mode == 0 ? "nt hint" : mode == 1 ? "two chains per lane" : "two chains + nt", ms, acc / ms / 1e6);
+    }
     return 0;
 }
