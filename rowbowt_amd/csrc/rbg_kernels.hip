@@ -21,6 +21,28 @@ namespace {
 
 constexpr int kWave = 64;
 
+// A slot is 4 words and must arrive as ONE request: left to itself the compiler fetches the word
+// that decides a branch first and the rest later (two gather requests instead of one; seen in the
+// ISA of k_locate_fill), so slots are loaded through a vector type.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+
+template <typename SlotT>
+__device__ __forceinline__ SlotT load_slot(const SlotT *p) {
+    SlotT s;
+    if constexpr (sizeof(SlotT) == 16) {
+        const u32x4 t = *reinterpret_cast<const u32x4 *>(p);
+        __builtin_memcpy(&s, &t, 16);
+    } else {
+        static_assert(sizeof(SlotT) == 32, "slot is 4 words of 4 or 8 bytes");
+        const u64x2 a = *reinterpret_cast<const u64x2 *>(p);
+        const u64x2 b = *(reinterpret_cast<const u64x2 *>(p) + 1);
+        __builtin_memcpy(&s, &a, 16);
+        __builtin_memcpy(reinterpret_cast<char *>(&s) + 16, &b, 16);
+    }
+    return s;
+}
+
 // ---- rank over one symbol table -----------------------------------------------------------------
 // Returns # of the symbol in BWT[0,i)  ==  rle_string::rank(i,c) (rle_string.hpp:131-161).
 // `sl` is the RankSlot of bucket b = i >> shift, already in registers (rbg_dev.h): nothing else is
@@ -93,9 +115,9 @@ __device__ __forceinline__ void rank_pair(const DevSym &S, uint64_t lo, uint64_t
                                           uint64_t *bh_out, RankAux *qaux) {
     const RankSlot<P> *__restrict__ slots = static_cast<const RankSlot<P> *>(S.slots);
     const uint64_t bl = lo >> S.shift, bh = hi1 >> S.shift;
-    const RankSlot<P> sl = slots[bl];
+    const RankSlot<P> sl = load_slot(slots + bl);
     RankSlot<P> sh = sl;
-    if (bh != bl) sh = slots[bh];
+    if (bh != bl) sh = load_slot(slots + bh);
     RankAux paux;
     *c_before = rank_in_slot<P>(S, sl, bl, lo, &paux);
     *c_upto = rank_in_slot<P>(S, sh, bh, hi1, qaux);
@@ -235,7 +257,7 @@ template <typename P>
 __device__ __forceinline__ uint64_t phi_step(const DevIndex &ix, uint64_t i) {
     const PhiSlot<P> *__restrict__ slots = static_cast<const PhiSlot<P> *>(ix.phi_slots);
     const uint64_t b = i >> ix.phi_shift;
-    const PhiSlot<P> sl = slots[b];
+    const PhiSlot<P> sl = load_slot(slots + b);
     const uint32_t meta = static_cast<uint32_t>(sl.meta);
     uint64_t s;
     if (((meta >> 16) & 3u) == kPhiOvf) {
@@ -268,7 +290,7 @@ __device__ __forceinline__ uint64_t phi_step(const DevIndex &ix, uint64_t i) {
 // like the slot loads (tools/gather_roof.hip).  So values are staged per wave in LDS, kChunk steps
 // at a time, and flushed with 8 lanes writing one read's 64-byte segment: a store instruction then
 // touches ~8-12 lines instead of 64.
-constexpr int kChunk = 8;
+constexpr int kChunk = 32;
 
 __device__ __forceinline__ void wave_lds_sync() {
     // LDS operations of one wave execute in issue order; this only stops the compiler from moving
@@ -319,11 +341,15 @@ __global__ __launch_bounds__(256) void k_locate_fill(const DevIndex ix, const ui
             }
             wave_lds_sync();
 #pragma unroll
-            for (int pass = 0; pass < kChunk; ++pass) {
-                const int s = pass * (kWave / kChunk) + (lane >> 3);
+            for (int pass = 0; pass < kChunk; ++pass) {  // kWave/kChunk reads per pass, kChunk lanes each
+                const int s = pass * (kWave / kChunk) + lane / kChunk;
                 const int e = lane & (kChunk - 1);
                 const uint64_t t = t0 + e;
+#ifdef RBG_ABLATE_STORES  /* timing experiment only: keep the values live, drop the stores */
+                if (t < s_occ[wv][s] && s_val[wv][s][e] == 0xFFFFFFFFFFFFFFFEull) locs[s_dst[wv][s] + t] = 1;
+#else
                 if (t < s_occ[wv][s]) locs[s_dst[wv][s] + t] = s_val[wv][s][e];
+#endif
             }
             wave_lds_sync();
         }
