@@ -151,6 +151,16 @@ int rbg_markers_at(rbg_index *, const uint64_t *lo, const uint64_t *hi, uint64_t
 int rbg_find_range_w_markers(rbg_index *, const uint8_t *seqs, const uint64_t *off, uint64_t N,
                              uint64_t wsize, uint64_t max_range,
                              uint64_t *lo, uint64_t *hi, uint64_t *mk_off, uint64_t **mk);
+/* Next-row f4 (greedy seeding).  RowBowt::get_seeds_greedy_w_sample(query, min_length),
+ * rowbowt.hpp:222-256, reduced by the choice locate_from_longest_seed makes (rowbowt.hpp:669-677):
+ * per read the FIRST seed of strictly greatest length, as LFData {rn, qstart, qend, ssamp}; a read
+ * with no seed of at least min_length gets rn={1,0}, qstart=qend=ssamp=0. */
+int rbg_greedy_longest_seed(rbg_index *, const uint8_t *seqs, const uint64_t *off, uint64_t N, uint64_t min_length,
+                            uint64_t *lo, uint64_t *hi, uint64_t *qstart, uint64_t *qend, uint64_t *ssamp);
+/* RowBowt::find_locs_greedy_seeding(s, min_length, max_hits), rowbowt.hpp:633-657 (== get_seeds +
+ * locate_from_longest_seed :664-685): locations of the longest seed, each minus the seed's qstart. */
+int rbg_find_locs_greedy_seeding(rbg_index *, const uint8_t *seqs, const uint64_t *off, uint64_t N, uint64_t min_length,
+                                 uint64_t max_hits, uint64_t *loc_off, uint64_t **locs);
 void rbg_free_buffer(void *);
 
 /* RowBowt::resolve_offset, rowbowt.hpp:623-625 -> DocList::doc_and_offset_at doclist.hpp:46-50.
@@ -172,6 +182,14 @@ int rbg_locate_plan_dev(rbg_index *, const uint64_t *d_lo, const uint64_t *d_hi,
                         uint64_t *d_loc_off, void *d_tmp, size_t tmp_bytes, void *stream);
 int rbg_locate_fill_dev(rbg_index *, const uint64_t *d_lo, const uint64_t *d_hi, const uint64_t *d_k, uint64_t N,
                         uint64_t max_hits, const uint64_t *d_loc_off, uint64_t *d_locs, void *stream);
+/* locate_fill with a per-read value subtracted from every location (d_sub nullable): the
+ * `locs[i] - best_range.qstart` of locate_from_longest_seed, rowbowt.hpp:681-683 */
+int rbg_locate_fill_offset_dev(rbg_index *, const uint64_t *d_lo, const uint64_t *d_hi, const uint64_t *d_k, uint64_t N,
+                               uint64_t max_hits, const uint64_t *d_loc_off, uint64_t *d_locs, const uint64_t *d_sub,
+                               void *stream);
+int rbg_greedy_longest_seed_dev(rbg_index *, const uint8_t *d_seqs, const uint64_t *d_off, uint64_t N, uint64_t min_length,
+                                uint64_t *d_lo, uint64_t *d_hi, uint64_t *d_qstart, uint64_t *d_qend, uint64_t *d_ssamp,
+                                void *stream);
 /* markers, same two-phase shape */
 int rbg_markers_plan_dev(rbg_index *, const uint64_t *d_lo, const uint64_t *d_hi, uint64_t N,
                          uint64_t *d_mk_off, void *d_tmp, size_t tmp_bytes, void *stream);

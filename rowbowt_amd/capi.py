@@ -68,6 +68,8 @@ _PROTOS = [
     ("rbg_locs_at", C.c_int, [VP, VP, VP, VP, U64, U64, VP, C.POINTER(VP)]),
     ("rbg_markers_at", C.c_int, [VP, VP, VP, U64, VP, C.POINTER(VP)]),
     ("rbg_find_range_w_markers", C.c_int, [VP, VP, VP, U64, U64, U64, VP, VP, VP, C.POINTER(VP)]),
+    ("rbg_greedy_longest_seed", C.c_int, [VP, VP, VP, U64, U64, VP, VP, VP, VP, VP]),
+    ("rbg_find_locs_greedy_seeding", C.c_int, [VP, VP, VP, U64, U64, U64, VP, C.POINTER(VP)]),
     ("rbg_free_buffer", None, [VP]),
     ("rbg_resolve_offset", C.c_int, [VP, U64, C.POINTER(C.c_char_p), C.POINTER(U64)]),
     ("rbg_find_range_dev", C.c_int, [VP, VP, VP, U64, VP, VP, VP]),
@@ -75,6 +77,8 @@ _PROTOS = [
     ("rbg_locate_plan_tmp_bytes", C.c_size_t, [U64]),
     ("rbg_locate_plan_dev", C.c_int, [VP, VP, VP, U64, U64, VP, VP, C.c_size_t, VP]),
     ("rbg_locate_fill_dev", C.c_int, [VP, VP, VP, VP, U64, U64, VP, VP, VP]),
+    ("rbg_locate_fill_offset_dev", C.c_int, [VP, VP, VP, VP, U64, U64, VP, VP, VP, VP]),
+    ("rbg_greedy_longest_seed_dev", C.c_int, [VP, VP, VP, U64, U64, VP, VP, VP, VP, VP, VP]),
     ("rbg_markers_plan_dev", C.c_int, [VP, VP, VP, U64, VP, VP, C.c_size_t, VP]),
     ("rbg_markers_fill_dev", C.c_int, [VP, VP, VP, U64, VP, VP, VP]),
     ("rbg_counters", C.c_int, [VP, VP]),
@@ -250,6 +254,23 @@ class RowBowt:
         _check(self.L.rbg_find_range_w_markers(self.h, _p(seqs), _p(off), N, wsize, max_range & MAXU,
                                                _p(lo), _p(hi), _p(mk_off), C.byref(ptr)), "rbg_find_range_w_markers")
         return lo, hi, mk_off, _take(ptr, int(mk_off[N]))
+
+    def greedy_longest_seed(self, seqs, off, min_length):
+        """get_seeds_greedy_w_sample (rowbowt.hpp:222-256) -> the seed locate_from_longest_seed picks (:669-677)"""
+        N = len(off) - 1
+        a = [np.zeros(N, np.uint64) for _ in range(5)]
+        _check(self.L.rbg_greedy_longest_seed(self.h, _p(seqs), _p(off), N, min_length, *[_p(x) for x in a]),
+               "rbg_greedy_longest_seed")
+        return a  # lo, hi, qstart, qend, ssamp
+
+    def find_locs_greedy_seeding(self, seqs, off, min_length, max_hits=MAXU):
+        """RowBowt::find_locs_greedy_seeding, rowbowt.hpp:633-657"""
+        N = len(off) - 1
+        loc_off = np.zeros(N + 1, np.uint64)
+        ptr = VP()
+        _check(self.L.rbg_find_locs_greedy_seeding(self.h, _p(seqs), _p(off), N, min_length, max_hits, _p(loc_off), C.byref(ptr)),
+               "rbg_find_locs_greedy_seeding")
+        return loc_off, _take(ptr, int(loc_off[N]))
 
     def resolve_offset(self, i):
         name, off = C.c_char_p(), U64()

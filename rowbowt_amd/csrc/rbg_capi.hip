@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -322,8 +323,12 @@ FlattenOptions current_options() {
 int finish(rbg_index *ix, int device, rbg_index **out) {
     ix->device = device;
     if (device != RBG_DEVICE_NONE) {
+        const auto t0 = std::chrono::steady_clock::now();
         int rc = upload(ix);
         if (rc) { rbg_free(ix); return rc; }
+        if (std::getenv("RBG_VERBOSE"))
+            std::fprintf(stderr, "rbg: slot tables + upload %.2f s (%.2f GB)\n",
+                         std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), ix->hbm_bytes / 1e9);
     }
     *out = ix;
     return RBG_OK;
@@ -634,7 +639,7 @@ int rbg_locate_fill_dev(rbg_index *ix, const uint64_t *d_lo, const uint64_t *d_h
     if (!queryable(ix)) return RBG_ENODEV;
     if (!ix->host.has_tsa) return RBG_ENOTLOADED;
     if (N && (!d_lo || !d_hi || !d_k || !d_loc_off || !d_locs)) return RBG_EARG;
-    return launch_locate_fill(ix->dev, ix->cfg, d_lo, d_hi, d_k, N, max_hits, d_loc_off, d_locs, stream) ? RBG_ENODEV : RBG_OK;
+    return launch_locate_fill(ix->dev, ix->cfg, d_lo, d_hi, d_k, N, max_hits, d_loc_off, d_locs, nullptr, stream) ? RBG_ENODEV : RBG_OK;
 }
 
 int rbg_markers_plan_dev(rbg_index *ix, const uint64_t *d_lo, const uint64_t *d_hi, uint64_t N, uint64_t *d_mk_off,
@@ -749,7 +754,7 @@ int rbg_locs_at(rbg_index *ix, const uint64_t *lo, const uint64_t *hi, const uin
         return RBG_ENODEV;
     return ragged_finish(N, doff, loc_off, locs, st, [&](uint64_t *d_vals) {
         return launch_locate_fill(ix->dev, ix->cfg, dlo.as<uint64_t>(), dhi.as<uint64_t>(), dk.as<uint64_t>(), N, max_hits,
-                                  doff.as<uint64_t>(), d_vals, st) ? RBG_ENODEV : RBG_OK;
+                                  doff.as<uint64_t>(), d_vals, nullptr, st) ? RBG_ENODEV : RBG_OK;
     });
 }
 
@@ -806,6 +811,77 @@ int rbg_find_range_w_markers(rbg_index *ix, const uint8_t *seqs, const uint64_t 
         return launch_find_range_markers_fill(ix->dev, ix->cfg, rb.seqs.as<uint8_t>(), rb.off.as<uint64_t>(), N, wsize,
                                               max_range, doff.as<uint64_t>(), d_vals, st) ? RBG_ENODEV : RBG_OK;
     });
+}
+
+// ---- greedy seeding (next-row f4) -----------------------------------------------------------------
+
+int rbg_greedy_longest_seed_dev(rbg_index *ix, const uint8_t *d_seqs, const uint64_t *d_off, uint64_t N, uint64_t min_length,
+                                uint64_t *d_lo, uint64_t *d_hi, uint64_t *d_qstart, uint64_t *d_qend, uint64_t *d_ssamp,
+                                void *stream) {
+    if (!queryable(ix)) return RBG_ENODEV;
+    if (!ix->host.has_tsa) return RBG_ENOTLOADED;
+    if (N && (!d_seqs || !d_off || !d_lo || !d_hi || !d_qstart || !d_qend || !d_ssamp)) return RBG_EARG;
+    if (reinterpret_cast<uintptr_t>(d_seqs) & 15) return RBG_EARG;
+    return launch_greedy_seed(ix->dev, ix->cfg, d_seqs, d_off, N, min_length, d_lo, d_hi, d_qstart, d_qend, d_ssamp, stream)
+               ? RBG_ENODEV : RBG_OK;
+}
+
+int rbg_locate_fill_offset_dev(rbg_index *ix, const uint64_t *d_lo, const uint64_t *d_hi, const uint64_t *d_k, uint64_t N,
+                               uint64_t max_hits, const uint64_t *d_loc_off, uint64_t *d_locs, const uint64_t *d_sub,
+                               void *stream) {
+    if (!queryable(ix)) return RBG_ENODEV;
+    if (!ix->host.has_tsa) return RBG_ENOTLOADED;
+    if (N && (!d_lo || !d_hi || !d_k || !d_loc_off || !d_locs)) return RBG_EARG;
+    return launch_locate_fill(ix->dev, ix->cfg, d_lo, d_hi, d_k, N, max_hits, d_loc_off, d_locs, d_sub, stream) ? RBG_ENODEV : RBG_OK;
+}
+
+static int greedy_host(rbg_index *ix, const uint8_t *seqs, const uint64_t *off, uint64_t N, uint64_t min_length,
+                       uint64_t *lo, uint64_t *hi, uint64_t *qs, uint64_t *qe, uint64_t *ss, bool locate, uint64_t max_hits,
+                       uint64_t *loc_off, uint64_t **locs) {
+    if (!queryable(ix)) return RBG_ENODEV;
+    if (!ix->host.has_tsa) return RBG_ENOTLOADED;
+    if (N && !off) return RBG_EARG;
+    int rc = check_offsets(off, N);
+    if (rc) return rc;
+    DeviceScope scope(ix->device);
+    if (scope.rc) return scope.rc;
+    hipStream_t st = hipStreamPerThread;
+    ReadBatch rb;
+    if ((rc = rb.stage(seqs, off, N, st))) return rc;
+    DevBuf d[5], doff, dtmp;
+    for (auto &b : d)
+        if ((rc = b.alloc(N * 8))) return rc;
+    if (launch_greedy_seed(ix->dev, ix->cfg, rb.seqs.as<uint8_t>(), rb.off.as<uint64_t>(), N, min_length, d[0].as<uint64_t>(),
+                           d[1].as<uint64_t>(), d[2].as<uint64_t>(), d[3].as<uint64_t>(), d[4].as<uint64_t>(), st))
+        return RBG_ENODEV;
+    uint64_t *outs[5] = {lo, hi, qs, qe, ss};
+    for (int a = 0; a < 5; ++a)
+        if (outs[a] && N) HIP_TRY(hipMemcpyAsync(outs[a], d[a].p, N * 8, hipMemcpyDeviceToHost, st));
+    if (!locate) {
+        HIP_TRY(hipStreamSynchronize(st));
+        return RBG_OK;
+    }
+    const size_t tmp_bytes = scan_tmp_bytes(N);
+    if ((rc = doff.alloc((N + 1) * 8)) || (rc = dtmp.alloc(tmp_bytes))) return rc;
+    if (launch_locate_plan(ix->dev, ix->cfg, d[0].as<uint64_t>(), d[1].as<uint64_t>(), N, max_hits, doff.as<uint64_t>(), dtmp.p, tmp_bytes, st))
+        return RBG_ENODEV;
+    return ragged_finish(N, doff, loc_off, locs, st, [&](uint64_t *d_vals) {
+        return launch_locate_fill(ix->dev, ix->cfg, d[0].as<uint64_t>(), d[1].as<uint64_t>(), d[4].as<uint64_t>(), N, max_hits,
+                                  doff.as<uint64_t>(), d_vals, d[2].as<uint64_t>(), st) ? RBG_ENODEV : RBG_OK;
+    });
+}
+
+int rbg_greedy_longest_seed(rbg_index *ix, const uint8_t *seqs, const uint64_t *off, uint64_t N, uint64_t min_length,
+                            uint64_t *lo, uint64_t *hi, uint64_t *qstart, uint64_t *qend, uint64_t *ssamp) {
+    if (N && (!lo || !hi || !qstart || !qend || !ssamp)) return RBG_EARG;
+    return greedy_host(ix, seqs, off, N, min_length, lo, hi, qstart, qend, ssamp, false, 0, nullptr, nullptr);
+}
+
+int rbg_find_locs_greedy_seeding(rbg_index *ix, const uint8_t *seqs, const uint64_t *off, uint64_t N, uint64_t min_length,
+                                 uint64_t max_hits, uint64_t *loc_off, uint64_t **locs) {
+    if (!loc_off || !locs) return RBG_EARG;
+    *locs = nullptr;
+    return greedy_host(ix, seqs, off, N, min_length, nullptr, nullptr, nullptr, nullptr, nullptr, true, max_hits, loc_off, locs);
 }
 
 // ---- counters --------------------------------------------------------------------------------------

@@ -3,6 +3,8 @@
 #include "rbg_host.hpp"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -496,7 +498,20 @@ int build_kmer_tables(HostIndex &out, const RawTsa *tsa, const FlattenOptions &o
 }
 }  // namespace
 
+namespace {
+struct StageTimer {
+    const char *what;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    explicit StageTimer(const char *w) : what(w) {}
+    ~StageTimer() {
+        if (std::getenv("RBG_VERBOSE"))
+            std::fprintf(stderr, "rbg: %s %.2f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    }
+};
+}  // namespace
+
 int flatten(const RawRle &rle, const RawTsa *tsa, const FlattenOptions &opt, HostIndex &out) {
+    StageTimer whole("flatten (incl. k-mer tables)");
     const uint64_t R = rle.R;
     if (R == 0 || rle.heads.size() != R || rle.lens.size() != R) return RBG_EARG;
     if (R >= 0xFFFFFFF0ull) return RBG_EARG;  // run ordinals (DevSym::ord) are 32-bit
@@ -572,6 +587,7 @@ int flatten(const RawRle &rle, const RawTsa *tsa, const FlattenOptions &opt, Hos
         out.phi_shift = opt.phi_bucket_shift >= 0 ? static_cast<uint32_t>(opt.phi_bucket_shift) : auto_shift(out.n, R, 0.75);
         if (out.phi_shift > 8) return RBG_EARG;
     }
+    StageTimer km("k-mer tables");
     return build_kmer_tables(out, tsa, opt);
 }
 

@@ -304,7 +304,8 @@ template <typename P>
 __global__ __launch_bounds__(256) void k_locate_fill(const DevIndex ix, const uint64_t *__restrict__ lo,
                                                      const uint64_t *__restrict__ hi, const uint64_t *__restrict__ k,
                                                      const uint64_t N, const uint64_t max_hits,
-                                                     const uint64_t *__restrict__ loc_off, uint64_t *__restrict__ locs) {
+                                                     const uint64_t *__restrict__ loc_off, uint64_t *__restrict__ locs,
+                                                     const uint64_t *__restrict__ sub) {
     __shared__ uint64_t s_val[4][kWave][kChunk + 1];  // +1: keeps the per-lane rows off the same banks
     __shared__ uint64_t s_dst[4][kWave];
     __shared__ uint64_t s_occ[4][kWave];
@@ -321,6 +322,7 @@ __global__ __launch_bounds__(256) void k_locate_fill(const DevIndex ix, const ui
             k1 = k[i];
             dst = loc_off[i];
         }
+        const uint64_t minus = (sub && i < N) ? sub[i] : 0;  // locate_from_longest_seed, rowbowt.hpp:681-683
         s_dst[wv][lane] = dst;
         s_occ[wv][lane] = occ;
         c_locs += occ;
@@ -336,7 +338,7 @@ __global__ __launch_bounds__(256) void k_locate_fill(const DevIndex ix, const ui
                 const uint64_t t = t0 + e;
                 if (t < occ) {
                     if (t) k1 = phi_step<P>(ix, k1);  // toehold_sa.hpp:44
-                    s_val[wv][lane][e] = k1;
+                    s_val[wv][lane][e] = k1 - minus;
                 }
             }
             wave_lds_sync();
@@ -485,6 +487,103 @@ __global__ __launch_bounds__(256) void k_find_range_markers(const DevIndex ix, c
     }
 }
 
+// ---- greedy seeding (next-row f4): RowBowt::get_seeds_greedy_w_sample (rowbowt.hpp:222-256)
+// reduced on the fly by locate_from_longest_seed's choice (rowbowt.hpp:669-677): per read, the
+// first seed of strictly greatest length.  Seeds are maximal exact matches found right to left;
+// the base that ends a seed is skipped.  A k-mer gather is attempted first; when it comes back
+// empty the symbol that actually ends the seed is found with single reference steps.
+template <typename P>
+__device__ __forceinline__ bool lf_w_loc(const DevSym &S, uint32_t adv, uint64_t &lo, uint64_t &hi, uint64_t &k) {
+    RankAux q;
+    uint64_t c_before, c_upto, bh;
+    rank_pair<P>(S, lo, hi + 1, &c_before, &c_upto, &bh, &q);
+    const uint64_t c_inside = c_upto - c_before;
+    if (c_inside == 0) return false;
+    if (q.inside) k = k - adv;
+    else k = pred_sample<P>(S, bh, q);
+    lo = S.F + c_before;
+    hi = lo + c_inside - 1;
+    return true;
+}
+
+template <typename P>
+__global__ __launch_bounds__(256) void k_greedy_seed(const DevIndex ix, const uint8_t *__restrict__ seqs,
+                                                     const uint64_t *__restrict__ off, const uint64_t N,
+                                                     const uint64_t min_length, uint64_t *__restrict__ lo_out,
+                                                     uint64_t *__restrict__ hi_out, uint64_t *__restrict__ qs_out,
+                                                     uint64_t *__restrict__ qe_out, uint64_t *__restrict__ ss_out) {
+    __shared__ uint8_t s_lut[256];
+    __shared__ uint8_t s_lut2[256];
+    __shared__ DevSym s_sym[kLdsSyms];
+    __shared__ DevSym s_pair[kMaxMajor * kMaxMajor];
+    __shared__ DevSym s_tri[kMaxMajor * kMaxMajor * kMaxMajor];
+    const uint32_t M = ix.nmajor;
+    const bool use3 = ix.kmer_steps >= 3;
+    for (int t = threadIdx.x; t < 256; t += blockDim.x) {
+        s_lut[t] = ix.lut[t];
+        s_lut2[t] = M ? ix.lut2[t] : 0xFFu;
+    }
+    const int nlds = ix.sigma < static_cast<uint32_t>(kLdsSyms) ? static_cast<int>(ix.sigma) : kLdsSyms;
+    for (int t = threadIdx.x; t < nlds; t += blockDim.x) s_sym[t] = ix.syms[t];
+    for (int t = threadIdx.x; t < static_cast<int>(M * M); t += blockDim.x) s_pair[t] = ix.pairs[t];
+    if (use3)
+        for (int t = threadIdx.x; t < static_cast<int>(M * M * M); t += blockDim.x) s_tri[t] = ix.triples[t];
+    __syncthreads();
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < N; i += stride) {
+        const uint64_t beg = off[i], m = off[i + 1] - beg;
+        const uint64_t first_k = ix.last_run_sample;  // rowbowt.hpp:230
+        uint64_t lo = 0, hi = ix.n - 1, plo = 0, phi = ix.n - 1;
+        uint64_t k = first_k, pk = ~uint64_t(0), ei = m;
+        uint64_t b_lo = 1, b_hi = 0, b_qs = 0, b_qe = 0, b_k = 0, b_len = 0;
+        ByteCursor rd{reinterpret_cast<const uint4 *>(seqs), ~uint64_t(0), make_uint4(0, 0, 0, 0)};
+        uint64_t j = m;  // next symbol to consume is q[j-1]
+        while (j > 0) {
+            const uint64_t p = beg + j - 1;
+            const uint32_t c = rd.at(p);
+            // k-mer attempt; success is identical to adv nested LF_w_loc calls
+            const uint32_t m0 = s_lut2[c];
+            uint32_t m1 = 0xFFu, adv = 0;
+            if (m0 != 0xFFu && j > 1) m1 = s_lut2[rd.at(p - 1)];
+            if (m1 != 0xFFu) {
+                uint32_t m2 = 0xFFu;
+                if (use3 && j > 2) m2 = s_lut2[rd.at(p - 2)];
+                const DevSym S = m2 != 0xFFu ? s_tri[(m2 * M + m1) * M + m0] : s_pair[m1 * M + m0];
+                const uint32_t want = m2 != 0xFFu ? 3u : 2u;
+                if (lf_w_loc<P>(S, want, lo, hi, k)) adv = want;
+            }
+            if (adv) {
+                plo = lo; phi = hi; pk = k;  // rowbowt.hpp:248-249
+                j -= adv;
+                continue;
+            }
+            // one reference step (rowbowt.hpp:235); an absent symbol is an empty range (:76)
+            const uint32_t slot = s_lut[c];
+            bool ok = false;
+            if (slot != 0xFFu) {
+                const DevSym S = slot < static_cast<uint32_t>(kLdsSyms) ? s_sym[slot] : ix.syms[slot];
+                ok = lf_w_loc<P>(S, 1u, lo, hi, k);
+            }
+            if (ok) {
+                plo = lo; phi = hi; pk = k;
+            } else {
+                // the seed covered q[j, ei)  (rowbowt.hpp:236-246; m-i == j here)
+                if (ei - j >= min_length && ei - j > b_len) { b_len = ei - j; b_lo = plo; b_hi = phi; b_qs = j; b_qe = ei; b_k = pk; }
+                k = first_k;
+                lo = 0; hi = ix.n - 1; plo = 0; phi = ix.n - 1;
+                ei = j - 1;  // skip the base that failed
+            }
+            j -= 1;
+        }
+        if (ei >= min_length && ei > b_len) { b_len = ei; b_lo = plo; b_hi = phi; b_qs = 0; b_qe = ei; b_k = pk; }  // :252-254
+        lo_out[i] = b_lo;
+        hi_out[i] = b_hi;
+        qs_out[i] = b_qs;
+        qe_out[i] = b_qe;
+        ss_out[i] = b_k;
+    }
+}
+
 // ---- single LF step for N (range, symbol) triples: RowBowt::LF(range_t, uint8_t), rowbowt.hpp:74-88
 template <typename P>
 __global__ __launch_bounds__(256) void k_lf(const DevIndex ix, const uint64_t *__restrict__ lo_in,
@@ -569,12 +668,12 @@ int launch_locate_plan(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t 
 
 int launch_locate_fill(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t *lo, const uint64_t *hi,
                        const uint64_t *k, uint64_t N, uint64_t max_hits, const uint64_t *loc_off, uint64_t *locs,
-                       void *stream) {
+                       const uint64_t *sub, void *stream) {
     if (N == 0) return 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid(grid_for(cfg, N)), block(cfg.block_threads);
-    if (ix.pos_bytes == 4) hipLaunchKernelGGL((k_locate_fill<uint32_t>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, locs);
-    else hipLaunchKernelGGL((k_locate_fill<uint64_t>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, locs);
+    if (ix.pos_bytes == 4) hipLaunchKernelGGL((k_locate_fill<uint32_t>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, locs, sub);
+    else hipLaunchKernelGGL((k_locate_fill<uint64_t>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, locs, sub);
     return static_cast<int>(hipGetLastError());
 }
 
@@ -620,6 +719,16 @@ int launch_find_range_markers_fill(const DevIndex &ix, const LaunchCfg &cfg, con
         hipLaunchKernelGGL((k_find_range_markers<uint32_t, true>), grid, block, 0, st, ix, seqs, off, N, wsize, max_range, nullptr, nullptr, nullptr, mk_off, mk);
     else
         hipLaunchKernelGGL((k_find_range_markers<uint64_t, true>), grid, block, 0, st, ix, seqs, off, N, wsize, max_range, nullptr, nullptr, nullptr, mk_off, mk);
+    return static_cast<int>(hipGetLastError());
+}
+
+int launch_greedy_seed(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
+                       uint64_t min_length, uint64_t *lo, uint64_t *hi, uint64_t *qs, uint64_t *qe, uint64_t *ss, void *stream) {
+    if (N == 0) return 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid(grid_for(cfg, N)), block(cfg.block_threads);
+    if (ix.pos_bytes == 4) hipLaunchKernelGGL((k_greedy_seed<uint32_t>), grid, block, 0, st, ix, seqs, off, N, min_length, lo, hi, qs, qe, ss);
+    else hipLaunchKernelGGL((k_greedy_seed<uint64_t>), grid, block, 0, st, ix, seqs, off, N, min_length, lo, hi, qs, qe, ss);
     return static_cast<int>(hipGetLastError());
 }
 

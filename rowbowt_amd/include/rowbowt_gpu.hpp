@@ -13,7 +13,8 @@
 // (rowbowt.hpp:171, :273, :294-297); a failed search is in-band {1,0}.  Anything the reference
 // would not survive (no GPU, HIP failure) also goes to stderr + exit(1).
 //
-// Not implemented here (out of scope of the rb_align path): ftab, greedy/lmem seeding.
+// Also offered (next-row f4): find_locs_greedy_seeding.  Not implemented here: ftab (result-neutral,
+// never loaded by rb_align), lmem seeding, the marker-seeding variants of rb_markers.
 #pragma once
 
 #include <cstdint>
@@ -194,6 +195,33 @@ class RowBowt {
                       "rbg_find_range_w_markers");
         lf.markers.assign(buf.p, buf.p + mk_off[1]);
         if (lf.rn.second >= lf.rn.first) { lf.qstart = 0; lf.qend = query.size(); }  // :336-337
+        return lf;
+    }
+
+    // rowbowt.hpp:633-662 (get_seeds_greedy_w_sample :222-256 + locate_from_longest_seed :664-685)
+    std::vector<uint64_t> &find_locs_greedy_seeding(std::string s, uint64_t min_length, uint64_t max_hits,
+                                                    std::vector<uint64_t> &locs) const {
+        locs.clear();
+        if (!has_tsa_) return locs;
+        const uint64_t off[2] = {0, s.size()};
+        uint64_t loc_off[2];
+        detail::LibBuf buf;
+        detail::check(rbg_find_locs_greedy_seeding(ix_.get(), reinterpret_cast<const uint8_t *>(s.data()), off, 1, min_length,
+                                                   max_hits, loc_off, &buf.p), "rbg_find_locs_greedy_seeding");
+        locs.assign(buf.p, buf.p + loc_off[1]);
+        return locs;
+    }
+    std::vector<uint64_t> find_locs_greedy_seeding(std::string s, uint64_t min_length, uint64_t max_hits) const {
+        std::vector<uint64_t> locs;
+        return find_locs_greedy_seeding(s, min_length, max_hits, locs);
+    }
+    // the seed locate_from_longest_seed would pick among get_seeds_greedy_w_sample(query, min_length)
+    LFData longest_greedy_seed(const std::string &query, uint64_t min_length) const {
+        LFData lf;
+        if (!has_tsa_) return lf;
+        const uint64_t off[2] = {0, query.size()};
+        detail::check(rbg_greedy_longest_seed(ix_.get(), reinterpret_cast<const uint8_t *>(query.data()), off, 1, min_length,
+                                              &lf.rn.first, &lf.rn.second, &lf.qstart, &lf.qend, &lf.ssamp), "rbg_greedy_longest_seed");
         return lf;
     }
 

@@ -213,11 +213,12 @@ class Oracle:
         return (a.value, b.value), out[:min(n, cap)].tolist()
 
     def greedy_locate(self, q, min_length, max_hits=MAXU):
-        cap = 4096
-        out = np.zeros(cap, dtype=np.uint64)
         s = [U64() for _ in range(5)]
-        n = self.L.orc_greedy_locate(self.h, q, len(q), min_length, max_hits, _p(out), cap, *s)
-        return out[:min(n, cap)].tolist(), tuple(v.value for v in s)
+        dummy = np.zeros(1, dtype=np.uint64)
+        n = self.L.orc_greedy_locate(self.h, q, len(q), min_length, max_hits, _p(dummy), 0, *s)  # count
+        out = np.zeros(max(n, 1), dtype=np.uint64)
+        n = self.L.orc_greedy_locate(self.h, q, len(q), min_length, max_hits, _p(out), max(n, 1), *s)
+        return out[:n].tolist(), tuple(v.value for v in s)
 
     def resolve_offset(self, i):
         off = U64()

@@ -401,3 +401,54 @@ def test_midscale_pangenome_all_queries():
         assert (int(lo2[i]), int(hi2[i])) == (wl, wh) and got2[i] == wm
     rb.close()
     o.close()
+
+
+# ---- next-row f4: greedy seeding (rowbowt.hpp:222-256, :633-685) ---------------------------------
+def test_greedy_seeding_golden(small, error_reads):
+    rb, o = small
+    seqs, off = ra.pack_reads(error_reads)
+    loc_off, locs = rb.find_locs_greedy_seeding(seqs, off, 10)  # rb_tests.cpp:73,80
+    got = split(loc_off, locs)
+    for g, want in zip(got, G.GREEDY_LOCS_PREFIX):  # rb_tests.cpp:83-95
+        if want is None:
+            assert g == []
+        else:
+            assert g[: len(want)] == want
+    for i, q in enumerate(error_reads):
+        assert got[i] == o.greedy_locate(q, 10)[0]
+
+
+@pytest.mark.parametrize("ksteps", [3, 1])
+def test_greedy_seeding_vs_oracle(synth, ksteps):
+    S = synth
+    ra.set_default_option(capi.OPT_KMER_STEPS, ksteps)
+    try:
+        rb = ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0)
+    finally:
+        ra.set_default_option(capi.OPT_KMER_STEPS, 3)
+    o = orc.Oracle.from_runs(S.heads, S.lens, S.ssa, S.esa)
+    rng = np.random.default_rng(17)
+    reads = []
+    for r in S.sample_reads(1500, 80, seed=33, sub_rate=0.0):
+        r = bytearray(r)
+        for _ in range(int(rng.integers(0, 4))):  # 0..3 substitutions -> several seeds per read
+            p = int(rng.integers(len(r)))
+            r[p] = int(rng.choice([c for c in b"ACGTN" if c != r[p]]))
+        reads.append(bytes(r))
+    reads += [b"", b"A", b"N", b"NNNN", b"ACGT" * 5, S.text[:64].tobytes()]
+    seqs, off = ra.pack_reads(reads)
+    for min_length, max_hits in ((10, MAXU), (1, MAXU), (0, MAXU), (25, 2), (81, MAXU)):
+        lo, hi, qs, qe, k = rb.greedy_longest_seed(seqs, off, min_length)
+        loc_off, locs = rb.find_locs_greedy_seeding(seqs, off, min_length, max_hits)
+        got = split(loc_off, locs)
+        nseeds = 0
+        for i, q in enumerate(reads):
+            wlocs, seed = o.greedy_locate(q, min_length, max_hits)
+            assert got[i] == wlocs, (i, min_length)
+            if wlocs or seed[1] >= seed[0] and seed[3] > seed[2]:
+                assert (int(lo[i]), int(hi[i]), int(qs[i]), int(qe[i]), int(k[i])) == seed
+                nseeds += 1
+        if min_length <= 25:
+            assert nseeds > 1000
+    rb.close()
+    o.close()
