@@ -183,6 +183,16 @@ __global__ __launch_bounds__(256) void k_find_range(const DevIndex ix, const uin
         uint64_t p = off[i + 1];
         uint64_t lo = 0, hi = ix.n - 1;  // full_range(), rowbowt.hpp:115-118
         uint64_t k = TOEHOLD ? ix.last_run_sample : 0;
+        // The toehold only flows forward through "k - adv" (row hi carries the symbol); a step that
+        // re-samples overwrites it.  While the range is still wide almost every step re-samples
+        // (bwt[hi] is a random symbol), so the two gathers of a re-sample (run ordinal, sample) are
+        // deferred until a later step or the end of the read actually needs the value.
+        bool pend = false;
+        const void *pend_samp = nullptr;
+        const uint32_t *pend_ord = nullptr;
+        uint64_t pend_b = 0;
+        int64_t pend_j = 0;  // ordinal offset (slot path) or absolute ordinal (overflow path)
+        bool pend_abs = false;
         ByteCursor rd{reinterpret_cast<const uint4 *>(seqs), ~uint64_t(0), make_uint4(0, 0, 0, 0)};
         bool alive = true;
         while (p > beg) {  // right-to-left over the read (rowbowt.hpp:127-129, :175-181)
@@ -217,12 +227,29 @@ __global__ __launch_bounds__(256) void k_find_range(const DevIndex ix, const uin
                 // LF_w_loc, rowbowt.hpp:559-566.  Either hi holds the symbol (bwt_[hi]==c -> k-1 per
                 // nested step), or the last run starting before hi ends before hi and its last row
                 // is select(rank(hi,c)-1,c), whose run-end sample is samples_last_[run] (resp. SA-adv).
-                if (q.inside) k = k - adv;
-                else k = pred_sample<P>(S, bh, q);
+                if (q.inside) {
+                    if (pend) {
+                        const uint64_t j = pend_abs ? static_cast<uint64_t>(pend_j) : static_cast<uint64_t>(pend_ord[pend_b]) + pend_j;
+                        k = static_cast<uint64_t>(static_cast<const P *>(pend_samp)[j]);
+                        pend = false;
+                    }
+                    k = k - adv;
+                } else {
+                    pend = true;
+                    pend_samp = S.samp;
+                    pend_ord = S.ord;
+                    pend_b = bh;
+                    pend_abs = q.ovf;
+                    pend_j = q.ovf ? q.pred : static_cast<int64_t>(q.nbefore) - 1;
+                }
             }
             lo = S.F + c_before;           // rowbowt.hpp:86
             hi = lo + c_inside - 1;        // rowbowt.hpp:87
             p -= adv - 1;                  // the left neighbours are consumed too
+        }
+        if (TOEHOLD && alive && pend) {
+            const uint64_t j = pend_abs ? static_cast<uint64_t>(pend_j) : static_cast<uint64_t>(pend_ord[pend_b]) + pend_j;
+            k = static_cast<uint64_t>(static_cast<const P *>(pend_samp)[j]);
         }
         if (!alive) { lo = 1; hi = 0; k = 0; }  // {1,0}; LFData::clear rowbowt.hpp:153-159
         lo_out[i] = lo;

@@ -133,3 +133,17 @@ def test_build_from_runs_layout():
     rb.close()
     with pytest.raises(ra.RbgError):  # non-maximal runs
         ra.RowBowt.from_runs(np.frombuffer(b"AAC", dtype=np.uint8), np.array([1, 1, 1], np.uint64), device=capi.DEVICE_NONE)
+
+
+def _compile_shim_test(tmp_path):
+    import subprocess
+    exe = tmp_path / "shim_goldens"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "rowbowt_amd", "include"),
+                           os.path.join(ROOT, "tests", "cpp", "shim_goldens.cpp"), "-o", str(exe),
+                           "-L", os.path.join(ROOT, "rowbowt_amd"), "-lrbg", "-Wl,-rpath," + os.path.join(ROOT, "rowbowt_amd")])
+    return exe
+
+
+def test_cpp_shim_compiles_against_reference_style_calls(tmp_path):
+    """rowbowt_gpu.hpp must accept the call shapes of the reference's tests (host compile only here)."""
+    assert _compile_shim_test(tmp_path).exists()

@@ -452,3 +452,17 @@ def test_greedy_seeding_vs_oracle(synth, ksteps):
             assert nseeds > 1000
     rb.close()
     o.close()
+
+
+def test_cpp_shim_reference_goldens(tmp_path, data_dir):
+    """The reference's own test assertions, issued through the C++ shim with the reference's signatures."""
+    import shutil
+    import subprocess
+    from test_capi_host import _compile_shim_test
+    exe = _compile_shim_test(tmp_path)
+    for suf in (".rbwt", ".tsa"):
+        shutil.copy(os.path.join(data_dir, "small.fa" + suf), tmp_path / ("idx" + suf))
+    (tmp_path / "idx.docs").write_text("ref 0\nhap1 10010\nhap2 20020\n")
+    p = subprocess.run([str(exe), data_dir, str(tmp_path / "idx")], capture_output=True, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    assert b"shim goldens ok" in p.stdout
