@@ -27,6 +27,8 @@ struct rbg_index {
     LaunchCfg cfg;
     std::vector<void *> allocs;  // every device allocation of the replica
     uint64_t hbm_bytes = 0;
+    void *arena = nullptr;       // one allocation holding every table of the replica
+    size_t arena_bytes = 0, arena_used = 0;
     uint64_t rank_slots = 0, rank_slots_overflow = 0, phi_slots = 0, phi_slots_overflow = 0;
     std::mutex mu;               // guards marker/doc attachment only; queries are lock-free
 };
@@ -76,15 +78,52 @@ struct DevBuf {
     template <typename T> T *as() { return static_cast<T *>(p); }
 };
 
+// The replica lives in ONE device allocation (the arena) that the tables are carved out of: a
+// thousand separate hipMallocs leave the tables scattered over physical memory, and the gather
+// rate of these kernels is sensitive to that.  Anything that does not fit the
+// pre-computed arena (markers attached later) gets its own allocation.
+constexpr size_t kArenaAlign = 64 * 1024;
+inline size_t arena_round(size_t bytes) { return ((bytes ? bytes : 1) + kArenaAlign - 1) & ~(kArenaAlign - 1); }
+
 int dev_upload(rbg_index *ix, const void *src, size_t bytes, const void **dst) {
     void *p = nullptr;
-    const size_t alloc = bytes ? (bytes + 255) & ~size_t(255) : 256;
-    HIP_TRY(hipMalloc(&p, alloc));
-    ix->allocs.push_back(p);
-    ix->hbm_bytes += alloc;
+    const size_t alloc = arena_round(bytes);
+    if (ix->arena && ix->arena_used + alloc <= ix->arena_bytes) {
+        p = static_cast<char *>(ix->arena) + ix->arena_used;
+        ix->arena_used += alloc;
+    } else {
+        HIP_TRY(hipMalloc(&p, alloc));
+        ix->allocs.push_back(p);
+        ix->hbm_bytes += alloc;
+    }
     if (bytes) HIP_TRY(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
     *dst = p;
     return RBG_OK;
+}
+
+template <typename P>
+size_t table_bytes(const SymTable &t, bool with_samples, uint64_t n) {
+    const uint64_t nb = (n >> t.shift) + 2;
+    return arena_round((t.nruns + 1) * sizeof(RunEnt<P>)) + (with_samples ? arena_round(t.nruns * sizeof(P)) : 0) +
+           arena_round(nb * sizeof(RankSlot<P>)) + arena_round(nb * sizeof(uint32_t));
+}
+
+template <typename P>
+size_t replica_bytes(const HostIndex &h) {
+    size_t total = 0;
+    for (const SymTable &t : h.sym) total += table_bytes<P>(t, h.has_tsa, h.n);
+    for (const SymTable &t : h.pair) total += table_bytes<P>(t, h.has_tsa, h.n);
+    for (const SymTable &t : h.triple) total += table_bytes<P>(t, h.has_tsa, h.n);
+    total += arena_round(h.sym.size() * sizeof(DevSym)) + arena_round(h.pair.size() * sizeof(DevSym)) +
+             arena_round(h.triple.size() * sizeof(DevSym)) + 3 * arena_round(256);
+    if (h.has_tsa) {
+        const uint64_t nb = (h.n >> h.phi_shift) + 2;
+        total += arena_round(h.r * sizeof(PhiEnt<P>)) + arena_round(nb * sizeof(PhiSlot<P>)) + arena_round(nb * sizeof(uint32_t));
+    }
+    if (h.has_ma)
+        total += arena_round(h.ma.start.size() * 8) + arena_round(h.ma.end.size() * 8) + arena_round(h.ma.off.size() * 8) +
+                 arena_round(h.ma.vals.size() * 8);
+    return total + 16 * kArenaAlign;
 }
 
 // RankSlot table of one symbol (rbg_dev.h): slot b answers rank(i, c) for i in [b << shift, (b+1) << shift)
@@ -297,6 +336,11 @@ int upload(rbg_index *ix) {
     d.has_tsa = h.has_tsa ? 1 : 0;
     d.last_run_sample = h.last_run_sample;
     d.phi_shift = h.phi_shift;
+    ix->arena_bytes = h.pos_bytes == 4 ? replica_bytes<uint32_t>(h) : replica_bytes<uint64_t>(h);
+    HIP_TRY(hipMalloc(&ix->arena, ix->arena_bytes));
+    ix->allocs.push_back(ix->arena);
+    ix->hbm_bytes += ix->arena_bytes;
+    ix->arena_used = 0;
     int rc = h.pos_bytes == 4 ? upload_tables<uint32_t>(ix) : upload_tables<uint64_t>(ix);
     if (rc) return rc;
     const void *p = nullptr;
