@@ -98,9 +98,9 @@ typedef struct rbg_info_t {
     uint32_t reserved;
     /* first-level slot tables: totals and how many buckets overflow their 2 inline entries */
     uint64_t rank_slots, rank_slots_overflow, phi_slots, phi_slots_overflow;
-    /* multi-symbol LF steps: symbols consumed per gather (1..3), size of the major alphabet that has
+    /* multi-symbol LF steps: symbols consumed per gather (1..4), size of the major alphabet that has
      * k-mer tables (0 = none), total runs of the 2-mer and 3-mer tables */
-    uint64_t kmer_steps, kmer_symbols, pair_runs, triple_runs;
+    uint64_t kmer_steps, kmer_symbols, pair_runs, triple_runs, quad_runs;
 } rbg_info_t;
 int rbg_info(const rbg_index *, rbg_info_t *out);
 
@@ -205,7 +205,7 @@ int rbg_counters_reset(rbg_index *);
 /* ---- tuning (never changes results) -------------------------------------------------------- */
 /* Process-wide defaults read when an index is built/loaded: BLOCK_THREADS (multiple of 64),
  * RANK/PHI_BUCKET_SHIFT (-1 = automatic, else 0..8), POS_BYTES (0 = automatic, 4 or 8 to force a width),
- * KMER_STEPS (1..3: symbols the backward search consumes per gather; 2 and 3 build the 2-mer / 3-mer
+ * KMER_STEPS (1..4: symbols the backward search consumes per gather; 2..4 build the k-mer
  * tables of DESIGN.md 2b; 1 keeps the reference's one-symbol steps only). */
 enum { RBG_OPT_BLOCK_THREADS = 1, RBG_OPT_RANK_BUCKET_SHIFT = 2, RBG_OPT_PHI_BUCKET_SHIFT = 3, RBG_OPT_POS_BYTES = 4,
        RBG_OPT_KMER_STEPS = 5 };

@@ -39,7 +39,7 @@ std::atomic<int64_t> g_opt_block_threads{256};
 std::atomic<int64_t> g_opt_rank_shift{-1};
 std::atomic<int64_t> g_opt_phi_shift{-1};
 std::atomic<int64_t> g_opt_pos_bytes{0};
-std::atomic<int64_t> g_opt_kmer_steps{3};
+std::atomic<int64_t> g_opt_kmer_steps{4};
 
 #define HIP_TRY(expr)                                                                             \
     do {                                                                                          \
@@ -114,8 +114,9 @@ size_t replica_bytes(const HostIndex &h) {
     for (const SymTable &t : h.sym) total += table_bytes<P>(t, h.has_tsa, h.n);
     for (const SymTable &t : h.pair) total += table_bytes<P>(t, h.has_tsa, h.n);
     for (const SymTable &t : h.triple) total += table_bytes<P>(t, h.has_tsa, h.n);
+    for (const SymTable &t : h.quad) total += table_bytes<P>(t, h.has_tsa, h.n);
     total += arena_round(h.sym.size() * sizeof(DevSym)) + arena_round(h.pair.size() * sizeof(DevSym)) +
-             arena_round(h.triple.size() * sizeof(DevSym)) + 3 * arena_round(256);
+             arena_round(h.triple.size() * sizeof(DevSym)) + arena_round(h.quad.size() * sizeof(DevSym)) + 3 * arena_round(256);
     if (h.has_tsa) {
         const uint64_t nb = (h.n >> h.phi_shift) + 2;
         total += arena_round(h.r * sizeof(PhiEnt<P>)) + arena_round(nb * sizeof(PhiSlot<P>)) + arena_round(nb * sizeof(uint32_t));
@@ -267,6 +268,10 @@ int upload_tables(rbg_index *ix) {
         if (!h.triple.empty()) {
             if ((rc = upload_set(h.triple, &ix->dev.triples))) return rc;
             ix->dev.kmer_steps = 3;
+        }
+        if (!h.quad.empty()) {
+            if ((rc = upload_set(h.quad, &ix->dev.quads))) return rc;
+            ix->dev.kmer_steps = 4;
         }
         rc = dev_upload(ix, h.major_of, 256, &p);
         if (rc) return rc;
@@ -465,7 +470,7 @@ int rbg_set_default_option(int opt, int64_t value) {
             if (value != 0 && value != 4 && value != 8) return RBG_EARG;
             g_opt_pos_bytes = value; return RBG_OK;
         case RBG_OPT_KMER_STEPS:
-            if (value < 1 || value > 3) return RBG_EARG;
+            if (value < 1 || value > 4) return RBG_EARG;
             g_opt_kmer_steps = value; return RBG_OK;
         default: return RBG_EARG;
     }
@@ -592,10 +597,11 @@ int rbg_info(const rbg_index *ix, rbg_info_t *out) {
     out->rank_slots_overflow = ix->rank_slots_overflow;
     out->phi_slots = ix->phi_slots;
     out->phi_slots_overflow = ix->phi_slots_overflow;
-    out->kmer_steps = ix->host.triple.empty() ? (ix->host.pair.empty() ? 1 : 2) : 3;
+    out->kmer_steps = !ix->host.quad.empty() ? 4 : !ix->host.triple.empty() ? 3 : !ix->host.pair.empty() ? 2 : 1;
     out->kmer_symbols = ix->host.pair.empty() ? 0 : ix->host.nmajor;
     for (const SymTable &t : ix->host.pair) out->pair_runs += t.nruns;
     for (const SymTable &t : ix->host.triple) out->triple_runs += t.nruns;
+    for (const SymTable &t : ix->host.quad) out->quad_runs += t.nruns;
     return RBG_OK;
 }
 

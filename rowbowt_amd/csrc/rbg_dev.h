@@ -88,10 +88,11 @@ struct DevIndex {
     // record shape as a single symbol (F = first row of the SA interval of "c1c2", samp = SA-2 at
     // pair-run ends); lut2 maps a byte to its major index 0..nmajor-1 or 0xFF.  nmajor == 0: off.
     const DevSym *pairs;    // nmajor^2
-    const DevSym *triples;  // nmajor^3 (kmer_steps == 3)
+    const DevSym *triples;  // nmajor^3 (kmer_steps >= 3)
+    const DevSym *quads;    // nmajor^4 (kmer_steps == 4)
     const uint8_t *lut2;
     uint32_t nmajor;
-    uint32_t kmer_steps;    // 1, 2 or 3
+    uint32_t kmer_steps;    // 1 .. 4
 };
 
 struct LaunchCfg {

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <fstream>
 #include <numeric>
+#include <queue>
 #include <sstream>
 
 #include "../../include/rbg.h"
@@ -422,30 +423,31 @@ int compose(const HostIndex &ix, const std::vector<uint32_t> &major_slot, const 
 
 // row-ordered segmentation from a set of tables (their runs are disjoint); uncovered rows get kNoId
 void segmentation_of(const std::vector<SymTable> &tabs, uint64_t n, bool with_samples, Segmentation &G) {
-    struct Cur { uint64_t k; };
-    std::vector<Cur> cur(tabs.size(), Cur{0});
     G.start.clear(); G.id.clear(); G.samp.clear();
     uint64_t total = 0;
     for (const SymTable &t : tabs) total += t.nruns;
     G.start.reserve(2 * total + 2); G.id.reserve(2 * total + 2);
     if (with_samples) G.samp.reserve(2 * total + 2);
+    // k-way merge of the tables' (already sorted) run lists by start row
+    using Item = std::pair<uint64_t, uint32_t>;  // (start, table)
+    std::priority_queue<Item, std::vector<Item>, std::greater<Item>> heap;
+    std::vector<uint64_t> cur(tabs.size(), 0);
+    for (size_t i = 0; i < tabs.size(); ++i)
+        if (tabs[i].nruns) heap.push(Item(tabs[i].start[0], static_cast<uint32_t>(i)));
     uint64_t pos = 0;
-    while (true) {
-        // next run in row order (few tables: linear scan for the minimum start)
-        size_t best = tabs.size();
-        uint64_t best_start = n;
-        for (size_t i = 0; i < tabs.size(); ++i)
-            if (cur[i].k < tabs[i].nruns && tabs[i].start[cur[i].k] < best_start) { best = i; best_start = tabs[i].start[cur[i].k]; }
-        if (best == tabs.size()) break;
-        const SymTable &t = tabs[best];
-        const uint64_t k = cur[best].k++;
-        if (best_start > pos) {  // gap: rows whose context leaves the major alphabet
+    while (!heap.empty()) {
+        const Item it = heap.top();
+        heap.pop();
+        const SymTable &t = tabs[it.second];
+        const uint64_t k = cur[it.second]++;
+        if (cur[it.second] < t.nruns) heap.push(Item(t.start[cur[it.second]], it.second));
+        if (it.first > pos) {  // gap: rows whose context leaves the major alphabet
             G.start.push_back(pos); G.id.push_back(kNoId);
             if (with_samples) G.samp.push_back(0);
         }
-        G.start.push_back(best_start); G.id.push_back(static_cast<uint32_t>(best));
+        G.start.push_back(it.first); G.id.push_back(it.second);
         if (with_samples) G.samp.push_back(t.samp[k]);
-        pos = best_start + (t.cum[k + 1] - t.cum[k]);
+        pos = it.first + (t.cum[k + 1] - t.cum[k]);
     }
     if (pos < n) {
         G.start.push_back(pos); G.id.push_back(kNoId);
@@ -459,6 +461,7 @@ int build_kmer_tables(HostIndex &out, const RawTsa *tsa, const FlattenOptions &o
     out.nmajor = 0;
     out.pair.clear();
     out.triple.clear();
+    out.quad.clear();
     if (opt.kmer_steps < 2 || out.sigma < 2) return RBG_OK;
     // the terminator: the smallest symbol, occurring once (rle_string.hpp:59,62 maps 0 -> 1).
     // Without one the wrap argument of DESIGN.md 2b does not hold: keep single steps only.
@@ -492,6 +495,11 @@ int build_kmer_tables(HostIndex &out, const RawTsa *tsa, const FlattenOptions &o
     if (opt.kmer_steps >= 3) {
         segmentation_of(out.pair, out.n, tsa != nullptr, G);
         rc = compose(out, order, G, 2, M * M, out.pair, tsa != nullptr, opt, out.triple);
+        if (rc) return rc;
+    }
+    if (opt.kmer_steps >= 4) {
+        segmentation_of(out.triple, out.n, tsa != nullptr, G);
+        rc = compose(out, order, G, 3, M * M * M, out.triple, tsa != nullptr, opt, out.quad);
         if (rc) return rc;
     }
     return RBG_OK;

@@ -82,6 +82,7 @@ struct HostIndex {
     uint8_t major_of[256];             // byte -> 0..nmajor-1, 0xFF otherwise
     std::vector<SymTable> pair;        // nmajor^2, or empty (multi-symbol steps disabled)
     std::vector<SymTable> triple;      // nmajor^3, or empty
+    std::vector<SymTable> quad;        // nmajor^4, or empty
     bool has_tsa = false;
     uint64_t last_run_sample = 0;      // toehold_sa.hpp:97-99
     std::vector<uint64_t> samples_last, pred_pos, phi_base;
@@ -96,7 +97,7 @@ struct FlattenOptions {
     int rank_bucket_shift = -1;  // <0: automatic (about one run per two buckets)
     int phi_bucket_shift = -1;
     int force_pos_bytes = 0;     // 0: 4 when n fits, else 8
-    int kmer_steps = 3;          // symbols consumed per gather: 1 (reference shape), 2 or 3
+    int kmer_steps = 4;          // symbols consumed per gather: 1 (reference shape) .. 4
 };
 
 int flatten(const RawRle &rle, const RawTsa *tsa, const FlattenOptions &opt, HostIndex &out);

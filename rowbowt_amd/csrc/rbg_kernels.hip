@@ -147,11 +147,37 @@ struct ByteCursor {
     __device__ __forceinline__ uint32_t at(uint64_t p) {
         const uint64_t ci = p >> 4;
         if (ci != cur_ci) { w = chunks[ci]; cur_ci = ci; }
+        // select + shift (indexing the vector by a run-time lane value makes the compiler spill it)
         const uint32_t sel = static_cast<uint32_t>(p) & 15u;
-        const uint32_t word = sel < 8 ? (sel < 4 ? w.x : w.y) : (sel < 12 ? w.z : w.w);
-        return (word >> ((sel & 3u) * 8)) & 0xFFu;
+        const uint64_t lo64 = (static_cast<uint64_t>(w.y) << 32) | w.x;
+        const uint64_t hi64 = (static_cast<uint64_t>(w.w) << 32) | w.z;
+        const uint64_t half = (sel & 8u) ? hi64 : lo64;
+        return static_cast<uint32_t>(half >> ((sel & 7u) * 8)) & 0xFFu;
     }
 };
+
+// LDS table of symbol / k-mer records: [singles | 2-mers | 3-mers | 4-mers]
+constexpr int kOff2 = kLdsSyms;
+constexpr int kOff3 = kOff2 + kMaxMajor * kMaxMajor;
+constexpr int kOff4 = kOff3 + kMaxMajor * kMaxMajor * kMaxMajor;
+constexpr int kTabMax = kOff4 + kMaxMajor * kMaxMajor * kMaxMajor * kMaxMajor;
+
+__device__ __forceinline__ void stage_tables(const DevIndex &ix, DevSym *s_tab, uint8_t *s_lut, uint8_t *s_lut2) {
+    const uint32_t M = ix.nmajor;
+    for (int t = threadIdx.x; t < 256; t += blockDim.x) {
+        s_lut[t] = ix.lut[t];
+        s_lut2[t] = M ? ix.lut2[t] : 0xFFu;
+    }
+    const int nlds = ix.sigma < static_cast<uint32_t>(kLdsSyms) ? static_cast<int>(ix.sigma) : kLdsSyms;
+    for (int t = threadIdx.x; t < nlds; t += blockDim.x) s_tab[t] = ix.syms[t];
+    if (ix.kmer_steps >= 2)
+        for (int t = threadIdx.x; t < static_cast<int>(M * M); t += blockDim.x) s_tab[kOff2 + t] = ix.pairs[t];
+    if (ix.kmer_steps >= 3)
+        for (int t = threadIdx.x; t < static_cast<int>(M * M * M); t += blockDim.x) s_tab[kOff3 + t] = ix.triples[t];
+    if (ix.kmer_steps >= 4)
+        for (int t = threadIdx.x; t < static_cast<int>(M * M * M * M); t += blockDim.x) s_tab[kOff4 + t] = ix.quads[t];
+    __syncthreads();
+}
 
 template <typename P, bool TOEHOLD>
 __global__ __launch_bounds__(256) void k_find_range(const DevIndex ix, const uint8_t *__restrict__ seqs,
@@ -160,21 +186,10 @@ __global__ __launch_bounds__(256) void k_find_range(const DevIndex ix, const uin
                                                     uint64_t *__restrict__ ss_out) {
     __shared__ uint8_t s_lut[256];
     __shared__ uint8_t s_lut2[256];
-    __shared__ DevSym s_sym[kLdsSyms];
-    __shared__ DevSym s_pair[kMaxMajor * kMaxMajor];
-    __shared__ DevSym s_tri[kMaxMajor * kMaxMajor * kMaxMajor];
+    __shared__ DevSym s_tab[kTabMax];
+    stage_tables(ix, s_tab, s_lut, s_lut2);
     const uint32_t M = ix.nmajor;
-    const bool use3 = ix.kmer_steps >= 3;
-    for (int t = threadIdx.x; t < 256; t += blockDim.x) {
-        s_lut[t] = ix.lut[t];
-        s_lut2[t] = M ? ix.lut2[t] : 0xFFu;
-    }
-    const int nlds = ix.sigma < static_cast<uint32_t>(kLdsSyms) ? static_cast<int>(ix.sigma) : kLdsSyms;
-    for (int t = threadIdx.x; t < nlds; t += blockDim.x) s_sym[t] = ix.syms[t];
-    for (int t = threadIdx.x; t < static_cast<int>(M * M); t += blockDim.x) s_pair[t] = ix.pairs[t];
-    if (use3)
-        for (int t = threadIdx.x; t < static_cast<int>(M * M * M); t += blockDim.x) s_tri[t] = ix.triples[t];
-    __syncthreads();
+    const uint32_t ksteps = ix.kmer_steps;
 
     unsigned long long c_reads = 0, c_matched = 0, c_occ = 0;
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
@@ -195,34 +210,13 @@ __global__ __launch_bounds__(256) void k_find_range(const DevIndex ix, const uin
         bool pend_abs = false;
         ByteCursor rd{reinterpret_cast<const uint4 *>(seqs), ~uint64_t(0), make_uint4(0, 0, 0, 0)};
         bool alive = true;
-        while (p > beg) {  // right-to-left over the read (rowbowt.hpp:127-129, :175-181)
-            --p;
-            const uint32_t c = rd.at(p);
-            // Up to three reference iterations in one gather: when this symbol and its left
-            // neighbours all have k-mer tables, LF(LF(LF(range,x0),x1),x2) == F3[x2x1x0] + rank3(.),
-            // and the toehold after the nested LF_w_loc calls is k-adv if row hi carries the k-mer,
-            // else the k-mer run sample (DESIGN.md 2b).  An empty result is {1,0} whichever of the
-            // nested steps emptied it.  Otherwise: one reference step (rowbowt.hpp:74-88, :555-573).
-            uint32_t adv = 1;
-            DevSym S;
-            const uint32_t m0 = s_lut2[c];
-            uint32_t m1 = 0xFFu;
-            if (m0 != 0xFFu && p > beg) m1 = s_lut2[rd.at(p - 1)];
-            if (m1 != 0xFFu) {
-                uint32_t m2 = 0xFFu;
-                if (use3 && p > beg + 1) m2 = s_lut2[rd.at(p - 2)];
-                if (m2 != 0xFFu) { S = s_tri[(m2 * M + m1) * M + m0]; adv = 3; }
-                else { S = s_pair[m1 * M + m0]; adv = 2; }
-            } else {
-                const uint32_t slot = s_lut[c];
-                if (slot == 0xFFu) { alive = false; break; }  // symbol absent: f_[c] >= f_[c+1], rowbowt.hpp:76
-                S = slot < static_cast<uint32_t>(kLdsSyms) ? s_sym[slot] : ix.syms[slot];
-            }
+        // one LF step (or several nested ones) through the record S; false = range emptied
+        auto step = [&](const DevSym &S, uint32_t adv) -> bool {
             RankAux q;
             uint64_t c_before, c_upto, bh;
             rank_pair<P>(S, lo, hi + 1, &c_before, &c_upto, &bh, &q);      // rowbowt.hpp:79,83
             const uint64_t c_inside = c_upto - c_before;
-            if (c_inside == 0) { alive = false; break; }                   // rowbowt.hpp:85
+            if (c_inside == 0) return false;                               // rowbowt.hpp:85
             if (TOEHOLD) {
                 // LF_w_loc, rowbowt.hpp:559-566.  Either hi holds the symbol (bwt_[hi]==c -> k-1 per
                 // nested step), or the last run starting before hi ends before hi and its last row
@@ -245,6 +239,49 @@ __global__ __launch_bounds__(256) void k_find_range(const DevIndex ix, const uin
             }
             lo = S.F + c_before;           // rowbowt.hpp:86
             hi = lo + c_inside - 1;        // rowbowt.hpp:87
+            return true;
+        };
+        while (p > beg) {  // right-to-left over the read (rowbowt.hpp:127-129, :175-181)
+            --p;
+            const uint32_t c = rd.at(p);
+            // Up to four reference iterations in one gather: when this symbol and its left
+            // neighbours all have k-mer tables, LF(LF(LF(range,x0),x1),x2) == F3[x2x1x0] + rank3(.),
+            // and the toehold after the nested LF_w_loc calls is k-adv if row hi carries the k-mer,
+            // else the k-mer run sample (DESIGN.md 2b).  An empty result is {1,0} whichever of the
+            // nested steps emptied it.  Otherwise: one reference step (rowbowt.hpp:74-88, :555-573).
+            uint32_t adv = 1, idx = 0;
+            const uint32_t m0 = s_lut2[c];
+            if (m0 != 0xFFu && ksteps >= 2 && p > beg) {
+                const uint32_t m1 = s_lut2[rd.at(p - 1)];
+                if (m1 != 0xFFu) {
+                    adv = 2;
+                    idx = kOff2 + m1 * M + m0;
+                    if (ksteps >= 3 && p > beg + 1) {
+                        const uint32_t m2 = s_lut2[rd.at(p - 2)];
+                        if (m2 != 0xFFu) {
+                            adv = 3;
+                            idx = kOff3 + (m2 * M + m1) * M + m0;
+                            if (ksteps >= 4 && p > beg + 2) {
+                                const uint32_t m3 = s_lut2[rd.at(p - 3)];
+                                if (m3 != 0xFFu) { adv = 4; idx = kOff4 + ((m3 * M + m2) * M + m1) * M + m0; }
+                            }
+                        }
+                    }
+                }
+            }
+            bool ok;
+            if (adv == 1) {
+                const uint32_t slot = s_lut[c];
+                if (slot == 0xFFu) { alive = false; break; }  // symbol absent: f_[c] >= f_[c+1], rowbowt.hpp:76
+                if (slot < static_cast<uint32_t>(kLdsSyms)) { const DevSym Sc = s_tab[slot]; ok = step(Sc, 1u); }
+                else ok = step(ix.syms[slot], 1u);  // rare symbols: record read from HBM field by field
+            } else {
+                // copy the 64-byte record with four wide LDS reads: reading it field by field makes
+                // every lane hit the same two banks (records are 16 dwords apart)
+                const DevSym Sc = s_tab[idx];
+                ok = step(Sc, adv);
+            }
+            if (!ok) { alive = false; break; }
             p -= adv - 1;                  // the left neighbours are consumed too
         }
         if (TOEHOLD && alive && pend) {

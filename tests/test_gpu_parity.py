@@ -118,8 +118,8 @@ def synth():
 
 
 @pytest.mark.parametrize("pos_bytes,rshift,pshift,ksteps",
-                         [(0, -1, -1, 3), (0, -1, -1, 2), (0, -1, -1, 1), (8, -1, -1, 3), (4, 0, 0, 2), (8, 3, 2, 1),
-                          (4, 8, 8, 3), (8, 8, 7, 2), (4, 5, 6, 1), (4, 2, 2, 3)])
+                         [(0, -1, -1, 4), (0, -1, -1, 3), (0, -1, -1, 2), (0, -1, -1, 1), (8, -1, -1, 4), (4, 0, 0, 2),
+                          (8, 3, 2, 1), (4, 8, 8, 3), (8, 8, 7, 4), (4, 5, 6, 1), (4, 2, 2, 4)])
 def test_synth_all_paths(synth, pos_bytes, rshift, pshift, ksteps):
     S = synth
     ra.set_default_option(capi.OPT_POS_BYTES, pos_bytes)
@@ -131,10 +131,11 @@ def test_synth_all_paths(synth, pos_bytes, rshift, pshift, ksteps):
     finally:
         for o_ in (capi.OPT_POS_BYTES, capi.OPT_RANK_BUCKET_SHIFT, capi.OPT_PHI_BUCKET_SHIFT):
             ra.set_default_option(o_, 0 if o_ == capi.OPT_POS_BYTES else -1)
-        ra.set_default_option(capi.OPT_KMER_STEPS, 3)
+        ra.set_default_option(capi.OPT_KMER_STEPS, 4)
     o = orc.Oracle.from_runs(S.heads, S.lens, S.ssa, S.esa)
     assert rb.info().pos_bytes == (pos_bytes or 4)
     assert rb.info().kmer_steps == ksteps and rb.info().kmer_symbols == (4 if ksteps > 1 else 0)
+    assert (rb.info().quad_runs > 0) == (ksteps == 4)
     reads = S.sample_reads(3000, 60, seed=5, sub_rate=0.15, ragged=True)
     reads += [b"", b"A", b"N", b"ACGTN", b"NACGT", b"ACNGT", b"AC", b"ACG", b"acgt", bytes([1]), bytes([255]) * 3, bytes([0]),
               S.text[:500].tobytes(), S.text[:501].tobytes(), b"A" + bytes([1]), bytes([1]) + b"A",
@@ -343,7 +344,7 @@ def test_midscale_pangenome_all_queries():
     n, unit, H, L = info["n"], info["unit"], info["H"], info["L"]
     rb = ra.RowBowt.from_runs(inp["heads"], inp["lens"], inp["ssa"], inp["esa"], device=0)
     o = orc.Oracle.from_runs(inp["heads"], inp["lens"], inp["ssa"], inp["esa"])
-    assert rb.info().kmer_steps == 3 and rb.info().kmer_symbols == 4
+    assert rb.info().kmer_steps == 4 and rb.info().kmer_symbols == 4
     # marker array like small.fa.mab: rows whose suffix starts within w bases before a variant site
     w = 10
     tcpu = text.cpu().numpy()
@@ -425,7 +426,7 @@ def test_greedy_seeding_vs_oracle(synth, ksteps):
     try:
         rb = ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0)
     finally:
-        ra.set_default_option(capi.OPT_KMER_STEPS, 3)
+        ra.set_default_option(capi.OPT_KMER_STEPS, 4)
     o = orc.Oracle.from_runs(S.heads, S.lens, S.ssa, S.esa)
     rng = np.random.default_rng(17)
     reads = []
