@@ -257,7 +257,9 @@ def main():
             "counters": {"reads": g_counters[0], "matched": g_counters[1], "sum_occ": g_counters[2], "sum_locs": g_counters[3],
                          "reduced_over": f"RCCL all_reduce over {world} rank(s)" if use_dist else "single GPU (no process group)"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic},
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                         "note": "achieved = algorithmic bytes of the reference's one-symbol-per-step algorithm (SURVEY 8d: 57m+24 per "
+                                 "read, 24 per located position) / kernel time; traffic = FETCH_SIZE+WRITE_SIZE of profiles/pmc_traffic.json"},
             "kernels": {k: {"ms": v["ms"], "alg_GBps": v["alg_bytes"] / (v["ms"] * 1e-3) / 1e9} for k, v in kernels.items()},
         }
 
