@@ -4,7 +4,8 @@
 One "step" = one pass of the hot path over one batch of synthetic reads already resident in HBM:
     K2  rbg_find_range_w_toehold_dev   (RowBowt::find_range_w_toehold, rowbowt.hpp:169-184)
     K3a rbg_locate_plan_dev            (occ + exclusive scan)
-    K3b rbg_locate_fill_dev            (RowBowt::locs_at -> ToeholdSA::locate_range, toehold_sa.hpp:37-49)
+    K3b rbg_locate_order_dev           (radix sort of the toeholds: chain order for locality; result-neutral)
+    K3c rbg_locate_fill_dev            (RowBowt::locs_at -> ToeholdSA::locate_range, toehold_sa.hpp:37-49)
 which is BASELINE.json configs[2] ("1xMI355X count+locate: chr22-scale index, 10M reads"), the
 configuration the metric "reads/s (100 bp, count+locate)" is quoted on.  The count-only rate
 (configs[1], rbg_find_range_dev) is measured in the same run and reported beside it.
@@ -143,13 +144,20 @@ def main():
     log(rank, f"reads/GPU={N} x {m} bp, matched={n_matched}, sum occ={total_locs} (mean occ/matched read "
               f"{total_locs / max(n_matched, 1):.1f})")
 
+    ws_bytes = L.rbg_locate_order_ws_bytes(N)
+    d_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+
+    def k_order():
+        chk(L.rbg_locate_order_dev(rb.h, d_k.data_ptr(), N, d_ws.data_ptr(), ws_bytes, st), "locate_order")
+
     def k_fill():
         chk(L.rbg_locate_fill_dev(rb.h, d_lo.data_ptr(), d_hi.data_ptr(), d_k.data_ptr(), N, max_hits,
-                                  d_loc_off.data_ptr(), d_locs.data_ptr(), st), "locate_fill")
+                                  d_loc_off.data_ptr(), d_locs.data_ptr(), d_ws.data_ptr(), st), "locate_fill")
 
     def step():
         k_toehold()
         k_plan()
+        k_order()
         k_fill()
 
     def barrier():
@@ -169,7 +177,7 @@ def main():
     for _ in range(args.warmup):
         step()
     K = args.steps
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(K)]
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(K)]
 
     def step_ev(s):
         ev[s][0].record(stream)
@@ -177,6 +185,8 @@ def main():
         ev[s][1].record(stream)
         k_plan()
         ev[s][2].record(stream)
+        k_order()
+        ev[s][4].record(stream)
         k_fill()
         ev[s][3].record(stream)
 
@@ -185,7 +195,8 @@ def main():
     counters = rb.counters().astype(np.int64)
     ms_toe = float(np.mean([ev[s][0].elapsed_time(ev[s][1]) for s in range(K)]))
     ms_plan = float(np.mean([ev[s][1].elapsed_time(ev[s][2]) for s in range(K)]))
-    ms_fill = float(np.mean([ev[s][2].elapsed_time(ev[s][3]) for s in range(K)]))
+    ms_order = float(np.mean([ev[s][2].elapsed_time(ev[s][4]) for s in range(K)]))
+    ms_fill = float(np.mean([ev[s][4].elapsed_time(ev[s][3]) for s in range(K)]))
 
     # ---- count-only (configs[1]) ---------------------------------------------------------------
     for _ in range(max(1, args.warmup)):
@@ -219,6 +230,7 @@ def main():
             "k_find_range<toehold>": {"ms": ms_toe, "alg_bytes": alg_toe},
             "k_locate_fill": {"ms": ms_fill, "alg_bytes": alg_fill},
             "locate_plan(k_occ+scan)": {"ms": ms_plan, "alg_bytes": 24 * N},
+            "locate_order(radix sort of toeholds)": {"ms": ms_order, "alg_bytes": 24 * N},
             "k_find_range<count>": {"ms": ms_count, "alg_bytes": alg_count},
         }
         dom = max(("k_find_range<toehold>", "k_locate_fill"), key=lambda k: kernels[k]["ms"])
@@ -307,9 +319,7 @@ def main():
         h_seqs = reads[:ncopy].cpu().numpy().reshape(-1)
         if nchk:
             h_off = (np.arange(nchk + 1, dtype=np.uint64) * m)
-            k_toehold()
-            k_plan()
-            k_fill()
+            step()
             torch.cuda.synchronize()
             g_lo = d_lo[:nchk].cpu().numpy().view(np.uint64)
             g_hi = d_hi[:nchk].cpu().numpy().view(np.uint64)

@@ -76,8 +76,10 @@ _PROTOS = [
     ("rbg_find_range_w_toehold_dev", C.c_int, [VP, VP, VP, U64, VP, VP, VP, VP]),
     ("rbg_locate_plan_tmp_bytes", C.c_size_t, [U64]),
     ("rbg_locate_plan_dev", C.c_int, [VP, VP, VP, U64, U64, VP, VP, C.c_size_t, VP]),
-    ("rbg_locate_fill_dev", C.c_int, [VP, VP, VP, VP, U64, U64, VP, VP, VP]),
-    ("rbg_locate_fill_offset_dev", C.c_int, [VP, VP, VP, VP, U64, U64, VP, VP, VP, VP]),
+    ("rbg_locate_order_ws_bytes", C.c_size_t, [U64]),
+    ("rbg_locate_order_dev", C.c_int, [VP, VP, U64, VP, C.c_size_t, VP]),
+    ("rbg_locate_fill_dev", C.c_int, [VP, VP, VP, VP, U64, U64, VP, VP, VP, VP]),
+    ("rbg_locate_fill_offset_dev", C.c_int, [VP, VP, VP, VP, U64, U64, VP, VP, VP, VP, VP]),
     ("rbg_greedy_longest_seed_dev", C.c_int, [VP, VP, VP, U64, U64, VP, VP, VP, VP, VP, VP]),
     ("rbg_markers_plan_dev", C.c_int, [VP, VP, VP, U64, VP, VP, C.c_size_t, VP]),
     ("rbg_markers_fill_dev", C.c_int, [VP, VP, VP, U64, VP, VP, VP]),

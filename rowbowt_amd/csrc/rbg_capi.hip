@@ -407,6 +407,18 @@ struct ReadBatch {
     }
 };
 
+// host-pointer locate paths: order the chains when the batch is big enough for the sort to pay
+int make_order(rbg_index *ix, const uint64_t *d_k, uint64_t N, DevBuf &ws, hipStream_t st, const void **order) {
+    *order = nullptr;
+    if (N < 4096 || N >= 0xFFFFFFFFull) return RBG_OK;
+    const size_t bytes = locate_order_ws_bytes(N);
+    int rc = ws.alloc(bytes);
+    if (rc) return rc;
+    if (launch_locate_order(ix->dev, ix->cfg, d_k, N, ws.p, bytes, st)) return RBG_ENODEV;
+    *order = ws.p;
+    return RBG_OK;
+}
+
 int check_offsets(const uint64_t *off, uint64_t N) {
     if (N == 0) return RBG_OK;
     if (!off || off[0] != 0) return RBG_EARG;
@@ -684,12 +696,22 @@ int rbg_locate_plan_dev(rbg_index *ix, const uint64_t *d_lo, const uint64_t *d_h
     return launch_locate_plan(ix->dev, ix->cfg, d_lo, d_hi, N, max_hits, d_loc_off, d_tmp, tmp_bytes, stream) ? RBG_ENODEV : RBG_OK;
 }
 
+size_t rbg_locate_order_ws_bytes(uint64_t N) { return locate_order_ws_bytes(N); }
+
+int rbg_locate_order_dev(rbg_index *ix, const uint64_t *d_k, uint64_t N, void *d_ws, size_t ws_bytes, void *stream) {
+    if (!queryable(ix)) return RBG_ENODEV;
+    if (!ix->host.has_tsa) return RBG_ENOTLOADED;
+    if (N && (!d_k || !d_ws)) return RBG_EARG;
+    if (N >= 0xFFFFFFFFull || ws_bytes < locate_order_ws_bytes(N) || (reinterpret_cast<uintptr_t>(d_ws) & 255)) return RBG_EARG;
+    return launch_locate_order(ix->dev, ix->cfg, d_k, N, d_ws, ws_bytes, stream) ? RBG_ENODEV : RBG_OK;
+}
+
 int rbg_locate_fill_dev(rbg_index *ix, const uint64_t *d_lo, const uint64_t *d_hi, const uint64_t *d_k, uint64_t N,
-                        uint64_t max_hits, const uint64_t *d_loc_off, uint64_t *d_locs, void *stream) {
+                        uint64_t max_hits, const uint64_t *d_loc_off, uint64_t *d_locs, const void *d_order, void *stream) {
     if (!queryable(ix)) return RBG_ENODEV;
     if (!ix->host.has_tsa) return RBG_ENOTLOADED;
     if (N && (!d_lo || !d_hi || !d_k || !d_loc_off || !d_locs)) return RBG_EARG;
-    return launch_locate_fill(ix->dev, ix->cfg, d_lo, d_hi, d_k, N, max_hits, d_loc_off, d_locs, nullptr, stream) ? RBG_ENODEV : RBG_OK;
+    return launch_locate_fill(ix->dev, ix->cfg, d_lo, d_hi, d_k, N, max_hits, d_loc_off, d_locs, nullptr, d_order, stream) ? RBG_ENODEV : RBG_OK;
 }
 
 int rbg_markers_plan_dev(rbg_index *ix, const uint64_t *d_lo, const uint64_t *d_hi, uint64_t N, uint64_t *d_mk_off,
@@ -802,9 +824,12 @@ int rbg_locs_at(rbg_index *ix, const uint64_t *lo, const uint64_t *hi, const uin
     }
     if (launch_locate_plan(ix->dev, ix->cfg, dlo.as<uint64_t>(), dhi.as<uint64_t>(), N, max_hits, doff.as<uint64_t>(), dtmp.p, tmp_bytes, st))
         return RBG_ENODEV;
+    DevBuf dord;
+    const void *order = nullptr;
+    if ((rc = make_order(ix, dk.as<uint64_t>(), N, dord, st, &order))) return rc;
     return ragged_finish(N, doff, loc_off, locs, st, [&](uint64_t *d_vals) {
         return launch_locate_fill(ix->dev, ix->cfg, dlo.as<uint64_t>(), dhi.as<uint64_t>(), dk.as<uint64_t>(), N, max_hits,
-                                  doff.as<uint64_t>(), d_vals, nullptr, st) ? RBG_ENODEV : RBG_OK;
+                                  doff.as<uint64_t>(), d_vals, nullptr, order, st) ? RBG_ENODEV : RBG_OK;
     });
 }
 
@@ -878,11 +903,11 @@ int rbg_greedy_longest_seed_dev(rbg_index *ix, const uint8_t *d_seqs, const uint
 
 int rbg_locate_fill_offset_dev(rbg_index *ix, const uint64_t *d_lo, const uint64_t *d_hi, const uint64_t *d_k, uint64_t N,
                                uint64_t max_hits, const uint64_t *d_loc_off, uint64_t *d_locs, const uint64_t *d_sub,
-                               void *stream) {
+                               const void *d_order, void *stream) {
     if (!queryable(ix)) return RBG_ENODEV;
     if (!ix->host.has_tsa) return RBG_ENOTLOADED;
     if (N && (!d_lo || !d_hi || !d_k || !d_loc_off || !d_locs)) return RBG_EARG;
-    return launch_locate_fill(ix->dev, ix->cfg, d_lo, d_hi, d_k, N, max_hits, d_loc_off, d_locs, d_sub, stream) ? RBG_ENODEV : RBG_OK;
+    return launch_locate_fill(ix->dev, ix->cfg, d_lo, d_hi, d_k, N, max_hits, d_loc_off, d_locs, d_sub, d_order, stream) ? RBG_ENODEV : RBG_OK;
 }
 
 static int greedy_host(rbg_index *ix, const uint8_t *seqs, const uint64_t *off, uint64_t N, uint64_t min_length,
@@ -915,9 +940,12 @@ static int greedy_host(rbg_index *ix, const uint8_t *seqs, const uint64_t *off, 
     if ((rc = doff.alloc((N + 1) * 8)) || (rc = dtmp.alloc(tmp_bytes))) return rc;
     if (launch_locate_plan(ix->dev, ix->cfg, d[0].as<uint64_t>(), d[1].as<uint64_t>(), N, max_hits, doff.as<uint64_t>(), dtmp.p, tmp_bytes, st))
         return RBG_ENODEV;
+    DevBuf dord;
+    const void *order = nullptr;
+    if ((rc = make_order(ix, d[4].as<uint64_t>(), N, dord, st, &order))) return rc;
     return ragged_finish(N, doff, loc_off, locs, st, [&](uint64_t *d_vals) {
         return launch_locate_fill(ix->dev, ix->cfg, d[0].as<uint64_t>(), d[1].as<uint64_t>(), d[4].as<uint64_t>(), N, max_hits,
-                                  doff.as<uint64_t>(), d_vals, d[2].as<uint64_t>(), st) ? RBG_ENODEV : RBG_OK;
+                                  doff.as<uint64_t>(), d_vals, d[2].as<uint64_t>(), order, st) ? RBG_ENODEV : RBG_OK;
     });
 }
 

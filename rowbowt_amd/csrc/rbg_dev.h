@@ -108,7 +108,11 @@ int launch_locate_plan(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t 
                        uint64_t max_hits, uint64_t *loc_off, void *tmp, size_t tmp_bytes, void *stream);
 int launch_locate_fill(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t *lo, const uint64_t *hi,
                        const uint64_t *k, uint64_t N, uint64_t max_hits, const uint64_t *loc_off, uint64_t *locs,
-                       const uint64_t *sub /*nullable: per-read value subtracted from every location*/, void *stream);
+                       const uint64_t *sub /*nullable: per-read value subtracted from every location*/,
+                       const void *order /*nullable: workspace filled by launch_locate_order*/, void *stream);
+size_t locate_order_ws_bytes(uint64_t N);
+int launch_locate_order(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t *k, uint64_t N, void *ws, size_t ws_bytes,
+                        void *stream);
 int launch_greedy_seed(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
                        uint64_t min_length, uint64_t *lo, uint64_t *hi, uint64_t *qs, uint64_t *qe, uint64_t *ss, void *stream);
 int launch_markers_plan(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t *lo, const uint64_t *hi, uint64_t N,

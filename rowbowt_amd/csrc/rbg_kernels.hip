@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256) void k_locate_fill(const DevIndex ix, const ui
                                                      const uint64_t *__restrict__ hi, const uint64_t *__restrict__ k,
                                                      const uint64_t N, const uint64_t max_hits,
                                                      const uint64_t *__restrict__ loc_off, uint64_t *__restrict__ locs,
-                                                     const uint64_t *__restrict__ sub) {
+                                                     const uint64_t *__restrict__ sub, const uint32_t *__restrict__ order) {
     __shared__ uint64_t s_val[4][kWave][kChunk + 1];  // +1: keeps the per-lane rows off the same banks
     __shared__ uint64_t s_dst[4][kWave];
     __shared__ uint64_t s_occ[4][kWave];
@@ -377,7 +377,12 @@ __global__ __launch_bounds__(256) void k_locate_fill(const DevIndex ix, const ui
     unsigned long long c_locs = 0;
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
     for (uint64_t base = static_cast<uint64_t>(blockIdx.x) * blockDim.x + wv * kWave; base < N; base += stride) {
-        const uint64_t i = base + lane;
+        // `order` (optional) lists the reads by toehold text position: neighbouring lanes then walk
+        // neighbouring phi slots (same DRAM rows / L2 lines) for the whole chain, because the chains of
+        // reads from nearby loci visit the haplotypes in the same order.  Results land at loc_off[i]
+        // whatever the processing order.
+        uint64_t i = base + lane;
+        if (order && i < N) i = order[i];
         uint64_t occ = 0, k1 = 0, dst = 0;
         if (i < N) {
             const uint64_t l = lo[i], h = hi[i];
@@ -705,6 +710,55 @@ int launch_find_range(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *s
     return static_cast<int>(hipGetLastError());
 }
 
+// ---- chain ordering for locate: permutation of the reads by toehold value (radix sort) ----------
+namespace {
+__global__ __launch_bounds__(256) void k_iota(uint32_t *__restrict__ v, const uint64_t N) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < N; i += stride) v[i] = static_cast<uint32_t>(i);
+}
+struct OrderWs {
+    size_t perm, iota, keys, sort, sort_bytes, total;
+};
+OrderWs order_layout(uint64_t N) {
+    auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
+    OrderWs w{};
+    w.perm = 0;
+    w.iota = up(w.perm + N * 4);
+    w.keys = up(w.iota + N * 4);
+    w.sort = up(w.keys + N * 8);
+    size_t bytes = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, static_cast<const uint64_t *>(nullptr), static_cast<uint64_t *>(nullptr),
+                                             static_cast<const uint32_t *>(nullptr), static_cast<uint32_t *>(nullptr),
+                                             static_cast<int64_t>(N ? N : 1), 0, 64);
+    w.sort_bytes = bytes;
+    w.total = up(w.sort + bytes) + 256;
+    return w;
+}
+}  // namespace
+
+size_t locate_order_ws_bytes(uint64_t N) { return order_layout(N).total; }
+
+int launch_locate_order(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t *k, uint64_t N, void *ws, size_t ws_bytes,
+                        void *stream) {
+    if (N == 0) return 0;
+    if (N >= 0xFFFFFFFFull) return static_cast<int>(hipErrorInvalidValue);  // permutation entries are 32-bit
+    const OrderWs w = order_layout(N);
+    if (ws_bytes < w.total || (reinterpret_cast<uintptr_t>(ws) & 255)) return static_cast<int>(hipErrorInvalidValue);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char *base = static_cast<char *>(ws);
+    uint32_t *perm = reinterpret_cast<uint32_t *>(base + w.perm);
+    uint32_t *iota = reinterpret_cast<uint32_t *>(base + w.iota);
+    uint64_t *keys = reinterpret_cast<uint64_t *>(base + w.keys);
+    hipLaunchKernelGGL(k_iota, dim3(grid_for(cfg, N)), dim3(256), 0, st, iota, N);
+    int rc = static_cast<int>(hipGetLastError());
+    if (rc) return rc;
+    int end_bit = 1;
+    while (end_bit < 64 && (ix.n >> end_bit)) ++end_bit;  // toeholds are text positions < n
+    size_t bytes = w.sort_bytes;
+    return static_cast<int>(hipcub::DeviceRadixSort::SortPairs(base + w.sort, bytes, k, keys, iota, perm, static_cast<int64_t>(N), 0,
+                                                               end_bit, st));
+}
+
 size_t scan_tmp_bytes(uint64_t N) {
     size_t bytes = 0;
     uint64_t *p = nullptr;
@@ -732,12 +786,12 @@ int launch_locate_plan(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t 
 
 int launch_locate_fill(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t *lo, const uint64_t *hi,
                        const uint64_t *k, uint64_t N, uint64_t max_hits, const uint64_t *loc_off, uint64_t *locs,
-                       const uint64_t *sub, void *stream) {
+                       const uint64_t *sub, const void *order, void *stream) {
     if (N == 0) return 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid(grid_for(cfg, N)), block(cfg.block_threads);
-    if (ix.pos_bytes == 4) hipLaunchKernelGGL((k_locate_fill<uint32_t>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, locs, sub);
-    else hipLaunchKernelGGL((k_locate_fill<uint64_t>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, locs, sub);
+    if (ix.pos_bytes == 4) hipLaunchKernelGGL((k_locate_fill<uint32_t>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, locs, sub, static_cast<const uint32_t *>(order));
+    else hipLaunchKernelGGL((k_locate_fill<uint64_t>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, locs, sub, static_cast<const uint32_t *>(order));
     return static_cast<int>(hipGetLastError());
 }
 

@@ -233,8 +233,17 @@ def test_device_resident_api(synth):
     total = int(d_loc_off[-1].item())
     d_locs = torch.empty(max(total, 1), dtype=torch.int64, device=dev)
     assert L.rbg_locate_fill_dev(rb.h, d_lo.data_ptr(), d_hi.data_ptr(), d_k.data_ptr(), N, MAXU,
-                                 d_loc_off.data_ptr(), d_locs.data_ptr(), st) == 0
+                                 d_loc_off.data_ptr(), d_locs.data_ptr(), None, st) == 0
+    # same walk with the chains ordered by toehold (locality only: identical output)
+    ws_bytes = L.rbg_locate_order_ws_bytes(N)
+    d_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    d_locs2 = torch.full_like(d_locs, -1)
+    assert L.rbg_locate_order_dev(rb.h, d_k.data_ptr(), N, d_ws.data_ptr(), ws_bytes, st) == 0
+    assert L.rbg_locate_fill_dev(rb.h, d_lo.data_ptr(), d_hi.data_ptr(), d_k.data_ptr(), N, MAXU,
+                                 d_loc_off.data_ptr(), d_locs2.data_ptr(), d_ws.data_ptr(), st) == 0
     torch.cuda.synchronize()
+    assert bool((d_locs[:total] == d_locs2[:total]).all().item())
+    assert L.rbg_locate_order_dev(rb.h, d_k.data_ptr(), N, d_ws.data_ptr(), ws_bytes - 1024, st) == -4  # workspace too small
     wlo, whi, wk = o.find_range_w_toehold_batch(seqs, off, nthreads=4)
     woff, wlocs = o.locs_at_batch(wlo, whi, wk, nthreads=4)
     assert (d_lo.cpu().numpy().view(np.uint64) == wlo).all()

@@ -59,8 +59,12 @@ for cfg in args.configs.split(","):
     L.rbg_locate_plan_dev(rb.h, d_lo.data_ptr(), d_hi.data_ptr(), N, MAXU, d_loc_off.data_ptr(), d_tmp.data_ptr(), tmp_bytes, st)
     if d_locs is None:
         d_locs = torch.empty(int(d_loc_off[-1].item()), dtype=torch.int64, device=dev)
-    ms_f = t(lambda: L.rbg_locate_fill_dev(rb.h, d_lo.data_ptr(), d_hi.data_ptr(), d_k.data_ptr(), N, MAXU, d_loc_off.data_ptr(), d_locs.data_ptr(), st))
+    ms_f0 = t(lambda: L.rbg_locate_fill_dev(rb.h, d_lo.data_ptr(), d_hi.data_ptr(), d_k.data_ptr(), N, MAXU, d_loc_off.data_ptr(), d_locs.data_ptr(), None, st))
+    wsb = L.rbg_locate_order_ws_bytes(N)
+    d_ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    ms_o = t(lambda: L.rbg_locate_order_dev(rb.h, d_k.data_ptr(), N, d_ws.data_ptr(), wsb, st))
+    ms_f = t(lambda: L.rbg_locate_fill_dev(rb.h, d_lo.data_ptr(), d_hi.data_ptr(), d_k.data_ptr(), N, MAXU, d_loc_off.data_ptr(), d_locs.data_ptr(), d_ws.data_ptr(), st))
     print(f"cfg kmer_steps={i.kmer_steps} pair_runs={i.pair_runs} triple_runs={i.triple_runs} quad_runs={i.quad_runs} rank_shift={i.rank_bucket_shift}({rs}) phi_shift={i.phi_bucket_shift}({ps}) block={bt}: hbm={i.hbm_bytes/1e9:.2f}GB "
           f"rank_ovf={i.rank_slots_overflow}/{i.rank_slots} phi_ovf={i.phi_slots_overflow}/{i.phi_slots}  "
-          f"count={ms_c:.2f}ms toehold={ms_t:.2f}ms fill={ms_f:.2f}ms  build={time.time()-t0:.1f}s", flush=True)
+          f"count={ms_c:.2f}ms toehold={ms_t:.2f}ms fill(unordered)={ms_f0:.2f}ms order={ms_o:.2f}ms fill={ms_f:.2f}ms  build={time.time()-t0:.1f}s", flush=True)
     rb.close()
