@@ -12,6 +12,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rbg.h"
@@ -198,36 +199,43 @@ void build_phi_slots(const HostIndex &h, std::vector<PhiSlot<P>> &slots, std::ve
     }
 }
 
-// one symbol (or pair-symbol) table -> its device record
+// one symbol (or k-mer) table -> its device record, in two halves so that the host-side array
+// building of many tables can run on worker threads while the uploads stay on the calling thread
 template <typename P>
-int upload_sym(rbg_index *ix, const SymTable &t, bool with_samples, DevSym &d) {
-    const HostIndex &h = ix->host;
-    {
-        std::vector<RunEnt<P>> ent(t.nruns + 1);
-        for (uint64_t k = 0; k <= t.nruns; ++k) {
-            ent[k].start = static_cast<P>(t.start[k]);
-            ent[k].cum = static_cast<P>(t.cum[k]);
-        }
-        int rc = dev_upload(ix, ent.data(), ent.size() * sizeof(RunEnt<P>), &d.ent);
-        if (rc) return rc;
-    }
-    d.samp = nullptr;
-    if (with_samples) {
-        std::vector<P> samp(t.nruns);
-        for (uint64_t k = 0; k < t.nruns; ++k) samp[k] = static_cast<P>(t.samp[k]);
-        int rc = dev_upload(ix, samp.data(), samp.size() * sizeof(P), &d.samp);
-        if (rc) return rc;
-    }
+struct PreparedSym {
+    std::vector<RunEnt<P>> ent;
+    std::vector<P> samp;
     std::vector<RankSlot<P>> slots;
     std::vector<uint32_t> ord;
-    build_rank_slots<P>(t, h.n, slots, ord, &ix->rank_slots_overflow);
-    ix->rank_slots += slots.size();
-    int rc = dev_upload(ix, slots.data(), slots.size() * sizeof(RankSlot<P>), &d.slots);
+    uint64_t overflow = 0;
+};
+
+template <typename P>
+void prepare_sym(const SymTable &t, bool with_samples, uint64_t n, PreparedSym<P> &p) {
+    p.ent.resize(t.nruns + 1);
+    for (uint64_t k = 0; k <= t.nruns; ++k) {
+        p.ent[k].start = static_cast<P>(t.start[k]);
+        p.ent[k].cum = static_cast<P>(t.cum[k]);
+    }
+    if (with_samples) {
+        p.samp.resize(t.nruns);
+        for (uint64_t k = 0; k < t.nruns; ++k) p.samp[k] = static_cast<P>(t.samp[k]);
+    }
+    build_rank_slots<P>(t, n, p.slots, p.ord, &p.overflow);
+}
+
+template <typename P>
+int commit_sym(rbg_index *ix, const SymTable &t, bool with_samples, PreparedSym<P> &p, DevSym &d) {
+    int rc = dev_upload(ix, p.ent.data(), p.ent.size() * sizeof(RunEnt<P>), &d.ent);
     if (rc) return rc;
+    d.samp = nullptr;
+    if (with_samples && (rc = dev_upload(ix, p.samp.data(), p.samp.size() * sizeof(P), &d.samp))) return rc;
+    if ((rc = dev_upload(ix, p.slots.data(), p.slots.size() * sizeof(RankSlot<P>), &d.slots))) return rc;
     const void *po = nullptr;
-    rc = dev_upload(ix, ord.data(), ord.size() * sizeof(uint32_t), &po);
-    if (rc) return rc;
+    if ((rc = dev_upload(ix, p.ord.data(), p.ord.size() * sizeof(uint32_t), &po))) return rc;
     d.ord = static_cast<const uint32_t *>(po);
+    ix->rank_slots += p.slots.size();
+    ix->rank_slots_overflow += p.overflow;
     d.nruns = t.nruns;
     d.F = t.F;
     d.total = t.total;
@@ -237,28 +245,45 @@ int upload_sym(rbg_index *ix, const SymTable &t, bool with_samples, DevSym &d) {
 }
 
 template <typename P>
+int upload_many(rbg_index *ix, const std::vector<SymTable> &tabs, bool with_samples, std::vector<DevSym> &recs) {
+    recs.resize(tabs.size());
+    const size_t T = std::max<size_t>(1, std::min<size_t>(16, std::thread::hardware_concurrency()));
+    for (size_t b = 0; b < tabs.size(); b += T) {
+        const size_t e = std::min(tabs.size(), b + T);
+        std::vector<PreparedSym<P>> prep(e - b);
+        std::vector<std::thread> workers;
+        for (size_t i = b + 1; i < e; ++i)
+            workers.emplace_back([&, i] { prepare_sym<P>(tabs[i], with_samples, ix->host.n, prep[i - b]); });
+        prepare_sym<P>(tabs[b], with_samples, ix->host.n, prep[0]);
+        for (auto &w : workers) w.join();
+        for (size_t i = b; i < e; ++i) {
+            int rc = commit_sym<P>(ix, tabs[i], with_samples, prep[i - b], recs[i]);
+            if (rc) return rc;
+            prep[i - b] = PreparedSym<P>();  // release before the next batch
+        }
+    }
+    return RBG_OK;
+}
+
+template <typename P>
 int upload_tables(rbg_index *ix) {
     HostIndex &h = ix->host;
-    std::vector<DevSym> syms(h.sigma);
-    for (uint32_t s = 0; s < h.sigma; ++s) {
-        int rc = upload_sym<P>(ix, h.sym[s], h.has_tsa, syms[s]);
-        if (rc) return rc;
-    }
+    std::vector<DevSym> syms;
+    int rc = upload_many<P>(ix, h.sym, h.has_tsa, syms);
+    if (rc) return rc;
     const void *p = nullptr;
-    int rc = dev_upload(ix, syms.data(), syms.size() * sizeof(DevSym), &p);
+    rc = dev_upload(ix, syms.data(), syms.size() * sizeof(DevSym), &p);
     if (rc) return rc;
     ix->dev.syms = static_cast<const DevSym *>(p);
     ix->dev.nmajor = 0;
     ix->dev.kmer_steps = 1;
     if (!h.pair.empty()) {
         auto upload_set = [&](const std::vector<SymTable> &tabs, const DevSym **dst) -> int {
-            std::vector<DevSym> recs(tabs.size());
-            for (size_t i = 0; i < tabs.size(); ++i) {
-                int r2 = upload_sym<P>(ix, tabs[i], h.has_tsa, recs[i]);
-                if (r2) return r2;
-            }
+            std::vector<DevSym> recs;
+            int r2 = upload_many<P>(ix, tabs, h.has_tsa, recs);
+            if (r2) return r2;
             const void *pp = nullptr;
-            int r2 = dev_upload(ix, recs.data(), recs.size() * sizeof(DevSym), &pp);
+            r2 = dev_upload(ix, recs.data(), recs.size() * sizeof(DevSym), &pp);
             if (r2) return r2;
             *dst = static_cast<const DevSym *>(pp);
             return RBG_OK;

@@ -11,6 +11,7 @@
 #include <numeric>
 #include <queue>
 #include <sstream>
+#include <thread>
 
 #include "../../include/rbg.h"
 
@@ -370,7 +371,9 @@ int compose(const HostIndex &ix, const std::vector<uint32_t> &major_slot, const 
             std::vector<SymTable> &out) {
     const uint32_t M = static_cast<uint32_t>(major_slot.size());
     out.assign(static_cast<size_t>(n_ids) * M, SymTable());
-    for (uint32_t m = 0; m < M; ++m) {
+    // one worker per symbol: worker m only touches the tables (id, m)
+    std::vector<int> rcs(M, RBG_OK);
+    auto work = [&](uint32_t m) {
         const SymTable &tc = ix.sym[major_slot[m]];
         std::vector<uint64_t> seen(n_ids, 0);
         uint64_t g = 0;
@@ -391,7 +394,7 @@ int compose(const HostIndex &ix, const std::vector<uint32_t> &major_slot, const 
                         uint64_t v;
                         if (qend == G.start[g + 1]) v = G.samp[g];
                         else {
-                            if (tc.samp[k] < depth) return RBG_EFORMAT;  // would need the terminator inside the k-mer
+                            if (tc.samp[k] < depth) { rcs[m] = RBG_EFORMAT; return; }  // would need the terminator inside the k-mer
                             v = tc.samp[k] - depth;
                         }
                         t.samp.push_back(v);
@@ -415,9 +418,15 @@ int compose(const HostIndex &ix, const std::vector<uint32_t> &major_slot, const 
             if (kk > 0) rk = tp.cum[kk - 1] + std::min(i - tp.start[kk - 1], tp.cum[kk] - tp.cum[kk - 1]);
             t.F = tp.F + rk;
             t.shift = opt.rank_bucket_shift >= 0 ? static_cast<uint32_t>(opt.rank_bucket_shift) : auto_shift(ix.n, t.nruns, 1.5);
-            if (t.nruns >= 0xFFFFFFF0ull) return RBG_EARG;
+            if (t.nruns >= 0xFFFFFFF0ull) { rcs[m] = RBG_EARG; return; }
         }
-    }
+    };
+    std::vector<std::thread> workers;
+    for (uint32_t m = 1; m < M; ++m) workers.emplace_back(work, m);
+    work(0);
+    for (auto &w : workers) w.join();
+    for (int rc : rcs)
+        if (rc) return rc;
     return RBG_OK;
 }
 

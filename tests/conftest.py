@@ -26,4 +26,12 @@ def _build_oracle():
     src = os.path.join(ROOT, "oracle", "rb_oracle.c")
     if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+    # the product library normally travels prebuilt (see __graft_entry__.build()); build it if a fresh
+    # checkout lacks it -- the tests never fall back to anything else
+    csrc = os.path.join(ROOT, "rowbowt_amd", "csrc")
+    lib = os.path.join(ROOT, "rowbowt_amd", "librbg.so")
+    cli = os.path.join(ROOT, "rowbowt_amd", "rb_align")
+    newest = max(os.path.getmtime(os.path.join(csrc, f)) for f in os.listdir(csrc) if f.endswith((".hip", ".cpp", ".h", ".hpp")))
+    if not os.path.exists(lib) or not os.path.exists(cli) or os.path.getmtime(lib) < newest:
+        subprocess.check_call(["make", "-C", csrc, "-j4"])
     yield

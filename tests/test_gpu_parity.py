@@ -331,6 +331,9 @@ def test_cli_locs_and_markers_stdout(data_dir, tmp_path, small, simple_reads):
         want += "\n"
     assert out == want
     assert "20306/hap2:286 286/ref:286" in out
+    # batching is invisible: one read per GPU batch gives the same bytes
+    rc, out1, _ = _run_cli(["-s", "-m", "--batch", "1", str(tmp_path / "idx"), str(fq)])
+    assert rc == 0 and out1 == want
     # missing index -> "bad file", exit(1) (rowbowt_io.hpp:166-169)
     rc, _, err = _run_cli([str(tmp_path / "nope"), str(fq)])
     assert rc == 1 and "bad file" in err
@@ -476,3 +479,25 @@ def test_cpp_shim_reference_goldens(tmp_path, data_dir):
     p = subprocess.run([str(exe), data_dir, str(tmp_path / "idx")], capture_output=True, timeout=300)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     assert b"shim goldens ok" in p.stdout
+
+
+def test_long_and_ragged_reads(synth):
+    """Reads far longer than the 100 bp of the bench (whole haplotypes, the whole text, longer than the
+    text), mixed with tiny ones in one batch."""
+    S = synth
+    rb = ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0)
+    o = orc.Oracle.from_runs(S.heads, S.lens, S.ssa, S.esa)
+    unit = S.L + S.pad
+    t = S.text.tobytes()
+    reads = [t[:S.L], t[unit:unit + S.L], t[3 * unit + 17:4 * unit - 33], t[:-1], t, t + b"A", t[5:3000] * 3, b"T", b"",
+             t[unit - 40:unit + 40], t[-200:-1], t[1:2 * unit]]
+    seqs, off = ra.pack_reads(reads)
+    lo, hi, k = rb.find_range_w_toehold(seqs, off)
+    wlo, whi, wk = o.find_range_w_toehold_batch(seqs, off)
+    assert (lo == wlo).all() and (hi == whi).all() and (k == wk).all()
+    assert int(hi[0]) >= int(lo[0]) and (int(lo[4]), int(hi[4])) != (1, 0) and (int(lo[5]), int(hi[5])) == (1, 0)
+    loc_off, locs = rb.locs_at(lo, hi, k)
+    woff, wlocs = o.locs_at_batch(wlo, whi, wk)
+    assert (loc_off == woff).all() and (locs == wlocs).all()
+    rb.close()
+    o.close()
