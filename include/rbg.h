@@ -213,9 +213,11 @@ int rbg_counters_reset(rbg_index *);
 /* Process-wide defaults read when an index is built/loaded: BLOCK_THREADS (multiple of 64),
  * RANK/PHI_BUCKET_SHIFT (-1 = automatic, else 0..8), POS_BYTES (0 = automatic, 4 or 8 to force a width),
  * KMER_STEPS (1..4: symbols the backward search consumes per gather; 2..4 build the k-mer
- * tables of DESIGN.md 2b; 1 keeps the reference's one-symbol steps only). */
+ * tables of DESIGN.md 2b; 1 keeps the reference's one-symbol steps only; the deepest levels are dropped
+ * automatically when the replica would not fit), HBM_BUDGET_MB (0 = three quarters of the free HBM:
+ * upper bound for the replica, deciding how many k-mer levels are kept). */
 enum { RBG_OPT_BLOCK_THREADS = 1, RBG_OPT_RANK_BUCKET_SHIFT = 2, RBG_OPT_PHI_BUCKET_SHIFT = 3, RBG_OPT_POS_BYTES = 4,
-       RBG_OPT_KMER_STEPS = 5 };
+       RBG_OPT_KMER_STEPS = 5, RBG_OPT_HBM_BUDGET_MB = 6 };
 int rbg_set_default_option(int opt, int64_t value);
 
 #ifdef __cplusplus

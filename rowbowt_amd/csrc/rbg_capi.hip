@@ -41,6 +41,7 @@ std::atomic<int64_t> g_opt_rank_shift{-1};
 std::atomic<int64_t> g_opt_phi_shift{-1};
 std::atomic<int64_t> g_opt_pos_bytes{0};
 std::atomic<int64_t> g_opt_kmer_steps{4};
+std::atomic<int64_t> g_opt_hbm_budget_mb{0};
 
 #define HIP_TRY(expr)                                                                             \
     do {                                                                                          \
@@ -366,7 +367,24 @@ int upload(rbg_index *ix) {
     d.has_tsa = h.has_tsa ? 1 : 0;
     d.last_run_sample = h.last_run_sample;
     d.phi_shift = h.phi_shift;
-    ix->arena_bytes = h.pos_bytes == 4 ? replica_bytes<uint32_t>(h) : replica_bytes<uint64_t>(h);
+    // The k-mer tables buy speed with memory: keep the deepest level that leaves a
+    // quarter of the free HBM (or RBG_OPT_HBM_BUDGET_MB) to the caller's read / result buffers.
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    const int64_t opt_mb = g_opt_hbm_budget_mb.load();
+    const size_t budget = opt_mb > 0 ? static_cast<size_t>(opt_mb) << 20 : free_b - free_b / 4;
+    auto need = [&] { return h.pos_bytes == 4 ? replica_bytes<uint32_t>(h) : replica_bytes<uint64_t>(h); };
+    while (need() > budget && !h.pair.empty()) {
+        std::vector<SymTable> &deepest = !h.quad.empty() ? h.quad : !h.triple.empty() ? h.triple : h.pair;
+        std::fprintf(stderr, "rbg: replica of %.1f GB exceeds the %.1f GB budget: dropping the %zu-table k-mer level\n",
+                     need() / 1e9, budget / 1e9, deepest.size());
+        std::vector<SymTable>().swap(deepest);
+    }
+    ix->arena_bytes = need();
+    if (ix->arena_bytes > free_b) {
+        std::fprintf(stderr, "rbg: index needs %.1f GB of HBM, %.1f GB free\n", ix->arena_bytes / 1e9, free_b / 1e9);
+        return RBG_ENOMEM;
+    }
     HIP_TRY(hipMalloc(&ix->arena, ix->arena_bytes));
     ix->allocs.push_back(ix->arena);
     ix->hbm_bytes += ix->arena_bytes;
@@ -506,6 +524,9 @@ int rbg_set_default_option(int opt, int64_t value) {
         case RBG_OPT_POS_BYTES:
             if (value != 0 && value != 4 && value != 8) return RBG_EARG;
             g_opt_pos_bytes = value; return RBG_OK;
+        case RBG_OPT_HBM_BUDGET_MB:
+            if (value < 0) return RBG_EARG;
+            g_opt_hbm_budget_mb = value; return RBG_OK;
         case RBG_OPT_KMER_STEPS:
             if (value < 1 || value > 4) return RBG_EARG;
             g_opt_kmer_steps = value; return RBG_OK;

@@ -501,3 +501,33 @@ def test_long_and_ragged_reads(synth):
     assert (loc_off == woff).all() and (locs == wlocs).all()
     rb.close()
     o.close()
+
+
+def test_hbm_budget_drops_kmer_levels(synth):
+    """A tight memory budget keeps fewer k-mer levels; answers do not change."""
+    S = synth
+    reads = S.sample_reads(500, 70, seed=2, sub_rate=0.1)
+    seqs, off = ra.pack_reads(reads)
+    o = orc.Oracle.from_runs(S.heads, S.lens, S.ssa, S.esa)
+    want = o.find_range_w_toehold_batch(seqs, off)
+    rb = ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0)
+    full = rb.info().hbm_bytes
+    assert rb.info().kmer_steps == 4
+    rb.close()
+    seen = set()
+    for frac in (0.7, 0.3, 0.08, 0.02):
+        ra.set_default_option(capi.OPT_HBM_BUDGET_MB, max(1, int(full * frac) >> 20))
+        try:
+            try:
+                rb = ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0)
+            except ra.RbgError as e:
+                assert e.code == -5  # RBG_ENOMEM: not even the single-symbol tables fit
+                continue
+        finally:
+            ra.set_default_option(capi.OPT_HBM_BUDGET_MB, 0)
+        seen.add(int(rb.info().kmer_steps))
+        got = rb.find_range_w_toehold(seqs, off)
+        assert all((g == w).all() for g, w in zip(got, want))
+        rb.close()
+    assert len(seen) >= 2 and min(seen) < 4
+    o.close()
