@@ -74,6 +74,12 @@ int rbg_load(const char *prefix, int flags, int device, rbg_index **out);
 int rbg_build_from_runs(const uint8_t *heads, const uint64_t *lens, uint64_t R,
                         const uint64_t *ssa_y, const uint64_t *esa_y, int device, rbg_index **out);
 
+/* Next-row f1: the same construction straight from rb_build's raw input files (rb_build.cpp:83-93):
+ * <pre>.bwt read as rle_string(fname) reads it (formatted extraction skips whitespace bytes,
+ * rle_string.hpp:58-62; byte 0 -> 1), <pre>.ssa / <pre>.esa as (x,y) u64 pairs (both or neither). */
+int rbg_build_from_files(const char *bwt_fname, const char *ssa_fname, const char *esa_fname, int device,
+                         rbg_index **out);
+
 /* MarkerArray contents (pfbwt-f marker_array.hpp, loaded at rowbowt_io.hpp:185):
  * inclusive SA-index runs + mk_off[nruns+1] offsets into mk_vals. */
 int rbg_set_markers(rbg_index *, const uint64_t *run_start, const uint64_t *run_end, uint64_t nruns,

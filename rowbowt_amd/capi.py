@@ -54,6 +54,7 @@ _PROTOS = [
     ("rbg_strerror", C.c_char_p, [C.c_int]),
     ("rbg_load", C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(VP)]),
     ("rbg_build_from_runs", C.c_int, [VP, VP, U64, VP, VP, C.c_int, C.POINTER(VP)]),
+    ("rbg_build_from_files", C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(VP)]),
     ("rbg_set_markers", C.c_int, [VP, VP, VP, U64, VP, VP]),
     ("rbg_set_docs", C.c_int, [VP, C.c_char_p, VP, U64]),
     ("rbg_free", None, [VP]),
@@ -170,6 +171,14 @@ class RowBowt:
         h = VP()
         _check(lib().rbg_build_from_runs(_p(heads), _p(lens), len(heads), _p(ssa), _p(esa), device, C.byref(h)),
                "rbg_build_from_runs")
+        return cls(h)
+
+    @classmethod
+    def from_files(cls, bwt, ssa=None, esa=None, device=0):
+        """rb_build's raw inputs (rb_build.cpp:83-93): <pre>.bwt, <pre>.ssa, <pre>.esa"""
+        h = VP()
+        _check(lib().rbg_build_from_files(os.fsencode(bwt), os.fsencode(ssa) if ssa else None,
+                                          os.fsencode(esa) if esa else None, device, C.byref(h)), "rbg_build_from_files")
         return cls(h)
 
     def set_markers(self, run_start, run_end, mk_off, mk_vals):

@@ -587,6 +587,30 @@ int rbg_build_from_runs(const uint8_t *heads, const uint64_t *lens, uint64_t R, 
     return finish(ix, device, out);
 }
 
+int rbg_build_from_files(const char *bwt_fname, const char *ssa_fname, const char *esa_fname, int device, rbg_index **out) {
+    if (!bwt_fname || !out || (!!ssa_fname != !!esa_fname)) return RBG_EARG;
+    *out = nullptr;
+    RawRle rle;
+    int rc = read_raw_bwt(bwt_fname, rle);
+    if (rc) return rc;
+    RawTsa tsa;
+    if (ssa_fname) {
+        std::vector<uint64_t> ssa, esa;
+        if ((rc = read_raw_samples(ssa_fname, ssa)) || (rc = read_raw_samples(esa_fname, esa))) return rc;
+        if (ssa.size() != rle.R || esa.size() != rle.R) return RBG_EFORMAT;  // one sample pair per BWT run
+        for (uint64_t i = 0; i < rle.R; ++i)
+            if (ssa[i] > rle.n || esa[i] > rle.n) return RBG_EFORMAT;
+        tsa_from_samples(rle.n, rle.R, ssa.data(), esa.data(), tsa);
+        for (uint64_t j = 1; j < rle.R; ++j)
+            if (tsa.pred_pos[j] == tsa.pred_pos[j - 1]) return RBG_EFORMAT;  // run-start samples must be distinct
+    }
+    rbg_index *ix = new (std::nothrow) rbg_index();
+    if (!ix) return RBG_ENOMEM;
+    rc = flatten(rle, ssa_fname ? &tsa : nullptr, current_options(), ix->host);
+    if (rc) { delete ix; return rc; }
+    return finish(ix, device, out);
+}
+
 int rbg_set_markers(rbg_index *ix, const uint64_t *run_start, const uint64_t *run_end, uint64_t nruns,
                     const uint64_t *mk_off, const uint64_t *mk_vals) {
     if (!ix || !run_start || !run_end || !mk_off || (!mk_vals && mk_off[nruns])) return RBG_EARG;

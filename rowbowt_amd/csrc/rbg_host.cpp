@@ -273,6 +273,53 @@ int parse_tsa(const std::string &fname, RawTsa &out) {
     return RBG_OK;
 }
 
+// rle_string(std::string fname, uint64_t B), rle_string.hpp:44-97, at byte level: formatted
+// extraction (`ifs >> c`) skips the whitespace bytes \t \n \v \f \r and space, every other byte is a
+// BWT symbol, byte 0 is stored as 1 (TERMINATOR)
+int read_raw_bwt(const std::string &fname, RawRle &out) {
+    std::ifstream ifs(fname, std::ios::binary);
+    if (!ifs.good()) return RBG_EIO;
+    out = RawRle();
+    out.B = 2;
+    std::vector<char> buf(1 << 20);
+    int last = -1;
+    uint64_t len = 0;
+    while (ifs) {
+        ifs.read(buf.data(), static_cast<std::streamsize>(buf.size()));
+        const std::streamsize got = ifs.gcount();
+        for (std::streamsize i = 0; i < got; ++i) {
+            unsigned char ch = static_cast<unsigned char>(buf[i]);
+            if (ch == ' ' || (ch >= 9 && ch <= 13)) continue;
+            if (ch == 0) ch = 1;
+            if (ch == last) { ++len; continue; }
+            if (last >= 0) { out.heads.push_back(static_cast<uint8_t>(last)); out.lens.push_back(len); }
+            last = ch;
+            len = 1;
+        }
+    }
+    if (last < 0) return RBG_EFORMAT;
+    out.heads.push_back(static_cast<uint8_t>(last));
+    out.lens.push_back(len);
+    out.R = out.heads.size();
+    out.n = 0;
+    for (uint64_t l : out.lens) out.n += l;
+    return RBG_OK;
+}
+
+// read_run_starts / read_run_ends, toehold_sa.hpp:133-155: (x, y) pairs, x ignored
+int read_raw_samples(const std::string &fname, std::vector<uint64_t> &y_out) {
+    std::ifstream ifs(fname, std::ios::binary | std::ios::ate);
+    if (!ifs.good()) return RBG_EIO;
+    const std::streamsize sz = ifs.tellg();
+    ifs.seekg(0);
+    const uint64_t pairs = static_cast<uint64_t>(sz) / 16;  // a trailing partial pair is dropped, as the reference's loop does
+    std::vector<uint64_t> raw(pairs * 2);
+    if (pairs && !ifs.read(reinterpret_cast<char *>(raw.data()), static_cast<std::streamsize>(pairs * 16))) return RBG_EIO;
+    y_out.resize(pairs);
+    for (uint64_t i = 0; i < pairs; ++i) y_out[i] = raw[2 * i + 1];
+    return RBG_OK;
+}
+
 // toehold_sa.hpp:133-155 (sample = y ? y-1 : n-1) and build_phi :105-131
 void tsa_from_samples(uint64_t n, uint64_t r, const uint64_t *ssa_y, const uint64_t *esa_y, RawTsa &out) {
     out = RawTsa();

@@ -45,6 +45,11 @@ int parse_rbwt(const std::string &fname, RawRle &out);
 int parse_tsa(const std::string &fname, RawTsa &out);
 int parse_mab(const std::string &fname, RawMarkers &out);
 int parse_docs(const std::string &fname, RawDocs &out);
+// raw build inputs of rb_build (rb_build.cpp:83-93): <pre>.bwt as rle_string(std::string fname, B) reads it
+// (rle_string.hpp:44-97: `ifs >> c` skips whitespace bytes, byte 0 becomes 1), <pre>.ssa / <pre>.esa as
+// (x, y) u64 pairs of which y is used (toehold_sa.hpp:133-155)
+int read_raw_bwt(const std::string &fname, RawRle &out);
+int read_raw_samples(const std::string &fname, std::vector<uint64_t> &y_out);
 // raw .ssa/.esa y values -> RawTsa (toehold_sa.hpp:105-155)
 void tsa_from_samples(uint64_t n, uint64_t r, const uint64_t *ssa_y, const uint64_t *esa_y, RawTsa &out);
 

@@ -147,3 +147,31 @@ def _compile_shim_test(tmp_path):
 def test_cpp_shim_compiles_against_reference_style_calls(tmp_path):
     """rowbowt_gpu.hpp must accept the call shapes of the reference's tests (host compile only here)."""
     assert _compile_shim_test(tmp_path).exists()
+
+
+def test_build_from_raw_files(tmp_path):
+    """rb_build's raw inputs: .bwt bytes (whitespace bytes skipped, 0 -> 1), .ssa/.esa (x,y) pairs."""
+    import naive
+    from synth import SynthIndex
+    S = SynthIndex(L=600, H=4, n_sites=12, seed=3)
+    bwt = naive.bwt_from_sa(S.text, S.fm.sa).copy()
+    raw = bytearray(bwt.tobytes().replace(b"\x01", b"\x00"))  # pfbwt writes the terminator as byte 0
+    raw[100:100] = b"\n \t"                                    # formatted extraction skips these
+    (tmp_path / "x.bwt").write_bytes(bytes(raw))
+    pairs = lambda y: np.stack([np.arange(len(y), dtype=np.uint64) * 7, y.astype(np.uint64)], axis=1).tobytes()
+    (tmp_path / "x.ssa").write_bytes(pairs(S.ssa))
+    (tmp_path / "x.esa").write_bytes(pairs(S.esa) + b"\x01\x02\x03")  # trailing partial pair is ignored
+    a = ra.RowBowt.from_files(str(tmp_path / "x.bwt"), str(tmp_path / "x.ssa"), str(tmp_path / "x.esa"), device=capi.DEVICE_NONE)
+    b = ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=capi.DEVICE_NONE)
+    for which in (capi.ARR_RUN_HEADS, capi.ARR_RUN_START, capi.ARR_SAMPLES_LAST, capi.ARR_PRED_POS, capi.ARR_PHI_BASE):
+        assert (a.host_array(which) == b.host_array(which)).all()
+    assert (a.get_f() == b.get_f()).all() and a.last_run_sample() == b.last_run_sample()
+    c = ra.RowBowt.from_files(str(tmp_path / "x.bwt"), device=capi.DEVICE_NONE)
+    assert c.info().r == a.info().r and not c.info().has_tsa
+    (tmp_path / "short.ssa").write_bytes(pairs(S.ssa[:-1]))
+    with pytest.raises(ra.RbgError) as e:
+        ra.RowBowt.from_files(str(tmp_path / "x.bwt"), str(tmp_path / "short.ssa"), str(tmp_path / "x.esa"), device=capi.DEVICE_NONE)
+    assert e.value.code == -2
+    with pytest.raises(ra.RbgError) as e:
+        ra.RowBowt.from_files(str(tmp_path / "missing.bwt"), device=capi.DEVICE_NONE)
+    assert e.value.code == -1
