@@ -107,7 +107,7 @@ template <typename P>
 size_t table_bytes(const SymTable &t, bool with_samples, uint64_t n) {
     const uint64_t nb = (n >> t.shift) + 2;
     return arena_round((t.nruns + 1) * sizeof(RunEnt<P>)) + (with_samples ? arena_round(t.nruns * sizeof(P)) : 0) +
-           arena_round(nb * sizeof(RankSlot<P>)) + arena_round(nb * sizeof(uint32_t));
+           arena_round(nb * sizeof(RankSlot)) + arena_round(nb * sizeof(uint32_t));
 }
 
 template <typename P>
@@ -131,7 +131,7 @@ size_t replica_bytes(const HostIndex &h) {
 
 // RankSlot table of one symbol (rbg_dev.h): slot b answers rank(i, c) for i in [b << shift, (b+1) << shift)
 template <typename P>
-void build_rank_slots(const SymTable &t, uint64_t n, std::vector<RankSlot<P>> &slots, std::vector<uint32_t> &ord,
+void build_rank_slots(const SymTable &t, uint64_t n, std::vector<RankSlot> &slots, std::vector<uint32_t> &ord,
                       uint64_t *overflow) {
     const uint64_t nb = (n >> t.shift) + 2;
     const uint64_t S = uint64_t(1) << t.shift;
@@ -149,10 +149,10 @@ void build_rank_slots(const SymTable &t, uint64_t n, std::vector<RankSlot<P>> &s
             if (ps + pl > B0) ext = std::min(S, ps + pl - B0);
             prev_is_c = ps + pl >= B0 ? 1 : 0;
         }
-        uint32_t run[5] = {0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu};
+        uint32_t run[kSlotRuns] = {0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu};
         uint64_t cnt = 0;
         while (k + cnt < t.nruns && t.start[k + cnt] < B0 + S) {
-            if (cnt < 5) {
+            if (cnt < static_cast<uint64_t>(kSlotRuns)) {
                 const uint64_t off = t.start[k + cnt] - B0;
                 const uint64_t len = std::min(t.cum[k + cnt + 1] - t.cum[k + cnt], B0 + S - t.start[k + cnt]);
                 run[cnt] = static_cast<uint32_t>(off | ((len - 1) << 8));
@@ -160,12 +160,12 @@ void build_rank_slots(const SymTable &t, uint64_t n, std::vector<RankSlot<P>> &s
             ++cnt;
         }
         uint32_t code = static_cast<uint32_t>(cnt);
-        if (cnt > 5) { code = kSlotOvf; ++*overflow; }
-        RankSlot<P> &s = slots[b];
-        s.r0 = static_cast<P>(r0);
-        s.w1 = static_cast<P>(static_cast<uint32_t>(ext) | (code << 9) | (static_cast<uint32_t>(prev_is_c) << 12) | (run[0] << 16));
-        s.w2 = static_cast<P>(run[1] | (run[2] << 16));
-        s.w3 = static_cast<P>(run[3] | (run[4] << 16));
+        if (cnt > static_cast<uint64_t>(kSlotRuns)) { code = kSlotOvf; ++*overflow; }
+        RankSlot &s = slots[b];
+        s.r0 = static_cast<uint32_t>(r0);
+        s.w1 = static_cast<uint32_t>(ext) | (code << 9) | (static_cast<uint32_t>(prev_is_c) << 12) | (run[0] << 16);
+        s.w2 = run[1] | (run[2] << 16);
+        s.w3 = run[3] | (static_cast<uint32_t>(r0 >> 32) << 16);  // flatten() guarantees n < 2^48
     }
 }
 
@@ -206,7 +206,7 @@ template <typename P>
 struct PreparedSym {
     std::vector<RunEnt<P>> ent;
     std::vector<P> samp;
-    std::vector<RankSlot<P>> slots;
+    std::vector<RankSlot> slots;
     std::vector<uint32_t> ord;
     uint64_t overflow = 0;
 };
@@ -231,7 +231,7 @@ int commit_sym(rbg_index *ix, const SymTable &t, bool with_samples, PreparedSym<
     if (rc) return rc;
     d.samp = nullptr;
     if (with_samples && (rc = dev_upload(ix, p.samp.data(), p.samp.size() * sizeof(P), &d.samp))) return rc;
-    if ((rc = dev_upload(ix, p.slots.data(), p.slots.size() * sizeof(RankSlot<P>), &d.slots))) return rc;
+    if ((rc = dev_upload(ix, p.slots.data(), p.slots.size() * sizeof(RankSlot), &d.slots))) return rc;
     const void *po = nullptr;
     if ((rc = dev_upload(ix, p.ord.data(), p.ord.size() * sizeof(uint32_t), &po))) return rc;
     d.ord = static_cast<const uint32_t *>(po);

@@ -24,21 +24,21 @@ struct PhiEnt {
 
 // First level of every rank: one record per bucket of 2^shift BWT positions (shift <= 8),
 // direct-addressed by (position >> shift), that ANSWERS rank(i, c) for every i in the bucket in
-// the common case.  Four words (16 bytes when positions are 32-bit), so one rank is one load
-// request: tools/gather_roof.hip shows the chip is bound by the number of gather requests, not by
-// their bytes (51 G/s at 16 B, 30 G/s at 32 B).
-//   r0  = rank(B0, c), B0 = bucket begin
+// the common case.  Four 32-bit words = 16 bytes whatever the position width (n < 2^48), so one
+// rank is one load request: tools/gather_roof.hip shows the chip is bound by the number of gather
+// requests, not by their bytes (51 G/s at 16 B, 30 G/s at 32 B).
+//   r0  = low 32 bits of rank(B0, c), B0 = bucket begin; bits 32-47 live in w3
 //   w1  = ext (bits 0-8: how many positions from B0 are covered by a run of c that began before
-//         B0) | cnt (bits 9-11: runs of c that START inside the bucket, 0..5; 7 = more than 5)
+//         B0) | cnt (bits 9-11: runs of c that START inside the bucket, 0..4; 7 = more than 4)
 //         | prev_is_c (bit 12: position B0-1 holds c) | run0 (bits 16-31)
-//   w2  = run1 | run2 << 16,   w3 = run3 | run4 << 16
+//   w2  = run1 | run2 << 16,   w3 = run3 | rank(B0,c)[47:32] << 16
 //   run = off (8 bits, start - B0) | (len - 1) << 8, len clipped to the bucket; absent = 0xFFFF
 //   rank(i) = r0 + min(o, ext) + sum_t clamp(o - off_t, 0, len_t),  o = i - B0
 // cnt == 7 falls back to the run list ent[ord[b] .. ord[b+1]).
-template <typename P>
-struct alignas(4 * sizeof(P)) RankSlot {
-    P r0, w1, w2, w3;
+struct alignas(16) RankSlot {
+    uint32_t r0, w1, w2, w3;
 };
+constexpr int kSlotRuns = 4;
 // phi's first level over text positions: phi(i) = (D + i) mod n where D = base - pos (mod n) of
 // the last sampled position strictly before i.  dprev is that D at the bucket begin; d0/d1 belong
 // to the first two sampled positions inside the bucket.
@@ -54,7 +54,7 @@ constexpr uint32_t kMaxSlotShift = 8;
 struct DevSym {
     const void *ent;    // RunEnt<P>[nruns + 1] (sentinel: start = n, cum = total): overflow buckets, samples
     const void *samp;   // P[nruns]: samples_last_ of each run (nullptr without toehold SA)
-    const void *slots;  // RankSlot<P>[(n >> shift) + 2]
+    const void *slots;  // RankSlot[(n >> shift) + 2]
     const uint32_t *ord;  // (n >> shift) + 2: # runs of the symbol starting before each bucket
     uint64_t nruns;
     uint64_t F;      // RowBowt::f_[byte]

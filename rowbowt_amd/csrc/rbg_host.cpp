@@ -579,6 +579,7 @@ int flatten(const RawRle &rle, const RawTsa *tsa, const FlattenOptions &opt, Hos
     const uint64_t R = rle.R;
     if (R == 0 || rle.heads.size() != R || rle.lens.size() != R) return RBG_EARG;
     if (R >= 0xFFFFFFF0ull) return RBG_EARG;  // run ordinals (DevSym::ord) are 32-bit
+    // (and, checked below once n is known: rank values must fit the 48 bits a RankSlot holds)
     if (tsa && (tsa->r != R || tsa->samples_last.size() != R || tsa->pred_pos.size() != R || tsa->pred_to_run.size() != R))
         return RBG_EFORMAT;
     out = HostIndex();
@@ -596,6 +597,7 @@ int flatten(const RawRle &rle, const RawTsa *tsa, const FlattenOptions &opt, Hos
     }
     out.run_start[R] = pos;
     out.n = pos;
+    if (out.n >> 48) return RBG_EARG;  // RankSlot carries 48-bit ranks (rbg_dev.h)
     if (tsa && tsa->n != out.n) return RBG_EFORMAT;
     // F column (RowBowt::build_f, rowbowt.hpp:770-778) and slots
     std::memset(out.lut, 0xFF, sizeof(out.lut));

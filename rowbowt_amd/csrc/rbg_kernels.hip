@@ -46,7 +46,7 @@ __device__ __forceinline__ SlotT load_slot(const SlotT *p) {
 // ---- rank over one symbol table -----------------------------------------------------------------
 // Returns # of the symbol in BWT[0,i)  ==  rle_string::rank(i,c) (rle_string.hpp:131-161).
 // `sl` is the RankSlot of bucket b = i >> shift, already in registers (rbg_dev.h): nothing else is
-// read unless the bucket holds more than 5 run starts.
+// read unless the bucket holds more than 4 run starts.
 // *nbefore = # runs of the symbol that start in [B0, i)  (-> ordinal of the predecessor run),
 // *inside  = position i-1 holds the symbol; both feed the toehold update.
 struct RankAux {
@@ -57,9 +57,9 @@ struct RankAux {
 };
 
 template <typename P>
-__device__ __forceinline__ uint64_t rank_in_slot(const DevSym &S, const RankSlot<P> &sl, uint64_t b, uint64_t i,
+__device__ __forceinline__ uint64_t rank_in_slot(const DevSym &S, const RankSlot &sl, uint64_t b, uint64_t i,
                                                  RankAux *aux) {
-    const uint32_t w1 = static_cast<uint32_t>(sl.w1), w2 = static_cast<uint32_t>(sl.w2), w3 = static_cast<uint32_t>(sl.w3);
+    const uint32_t w1 = sl.w1, w2 = sl.w2, w3 = sl.w3;
     const uint32_t cnt = (w1 >> 9) & 7u;
     if (cnt == kSlotOvf) {
         const RunEnt<P> *__restrict__ ent = static_cast<const RunEnt<P> *>(S.ent);
@@ -100,12 +100,11 @@ __device__ __forceinline__ uint64_t rank_in_slot(const DevSym &S, const RankSlot
     RBG_RUN(w2 & 0xFFFFu)
     RBG_RUN(w2 >> 16)
     RBG_RUN(w3 & 0xFFFFu)
-    RBG_RUN(w3 >> 16)
 #undef RBG_RUN
     aux->ovf = false;
     aux->nbefore = nb;
     aux->inside = in;
-    return static_cast<uint64_t>(sl.r0) + add;
+    return (static_cast<uint64_t>(sl.r0) | (static_cast<uint64_t>(w3 >> 16) << 32)) + add;
 }
 
 // both ranks of one LF step (rowbowt.hpp:79,83).  lo and hi+1 usually share a bucket late in the
@@ -113,10 +112,10 @@ __device__ __forceinline__ uint64_t rank_in_slot(const DevSym &S, const RankSlot
 template <typename P>
 __device__ __forceinline__ void rank_pair(const DevSym &S, uint64_t lo, uint64_t hi1, uint64_t *c_before, uint64_t *c_upto,
                                           uint64_t *bh_out, RankAux *qaux) {
-    const RankSlot<P> *__restrict__ slots = static_cast<const RankSlot<P> *>(S.slots);
+    const RankSlot *__restrict__ slots = static_cast<const RankSlot *>(S.slots);
     const uint64_t bl = lo >> S.shift, bh = hi1 >> S.shift;
-    const RankSlot<P> sl = load_slot(slots + bl);
-    RankSlot<P> sh = sl;
+    const RankSlot sl = load_slot(slots + bl);
+    RankSlot sh = sl;
     if (bh != bl) sh = load_slot(slots + bh);
     RankAux paux;
     *c_before = rank_in_slot<P>(S, sl, bl, lo, &paux);
