@@ -107,6 +107,8 @@ typedef struct rbg_info_t {
     /* multi-symbol LF steps: symbols consumed per gather (1..4), size of the major alphabet that has
      * k-mer tables (0 = none), total runs of the 2-mer and 3-mer tables */
     uint64_t kmer_steps, kmer_symbols, pair_runs, triple_runs, quad_runs;
+    /* ftab (RowBowt::build_ftab / search_ftab, rowbowt.hpp:726-758): word length of the device table, 0 = none */
+    uint64_t ftab_k;
 } rbg_info_t;
 int rbg_info(const rbg_index *, rbg_info_t *out);
 
@@ -221,9 +223,12 @@ int rbg_counters_reset(rbg_index *);
  * KMER_STEPS (1..4: symbols the backward search consumes per gather; 2..4 build the k-mer
  * tables of DESIGN.md 2b; 1 keeps the reference's one-symbol steps only; the deepest levels are dropped
  * automatically when the replica would not fit), HBM_BUDGET_MB (0 = three quarters of the free HBM:
- * upper bound for the replica, deciding how many k-mer levels are kept). */
+ * upper bound for the replica, deciding how many k-mer levels are kept), FTAB_K (-1 = automatic (12),
+ * 0 = no ftab, else the word length of the ftab built on the GPU at load time: the state after the
+ * last FTAB_K symbols of a read is one gather; result-neutral like the reference's ftab,
+ * rowbowt.hpp:124-125,726-758). */
 enum { RBG_OPT_BLOCK_THREADS = 1, RBG_OPT_RANK_BUCKET_SHIFT = 2, RBG_OPT_PHI_BUCKET_SHIFT = 3, RBG_OPT_POS_BYTES = 4,
-       RBG_OPT_KMER_STEPS = 5, RBG_OPT_HBM_BUDGET_MB = 6 };
+       RBG_OPT_KMER_STEPS = 5, RBG_OPT_HBM_BUDGET_MB = 6, RBG_OPT_FTAB_K = 7 };
 int rbg_set_default_option(int opt, int64_t value);
 
 #ifdef __cplusplus

@@ -42,6 +42,7 @@ std::atomic<int64_t> g_opt_phi_shift{-1};
 std::atomic<int64_t> g_opt_pos_bytes{0};
 std::atomic<int64_t> g_opt_kmer_steps{4};
 std::atomic<int64_t> g_opt_hbm_budget_mb{0};
+std::atomic<int64_t> g_opt_ftab_k{-1};
 
 #define HIP_TRY(expr)                                                                             \
     do {                                                                                          \
@@ -400,6 +401,33 @@ int upload(rbg_index *ix) {
     if (h.has_ma && (rc = upload_markers(ix))) return rc;
     ix->cfg.block_threads = static_cast<int>(g_opt_block_threads.load());
     ix->cfg.max_blocks = prop.multiProcessorCount * 32;
+    // ftab (next-row f3): built last, with the finished replica, by searching every word on the GPU
+    d.ftab = nullptr;
+    d.ftab_k = 0;
+    int64_t fk = g_opt_ftab_k.load();
+    if (fk < 0) {  // automatic: the longest word <= 12 with nmajor^k <= n/16 (4^12 words x 32 B = 537 MB)
+        fk = 0;
+        double w = 1;
+        while (d.nmajor >= 2 && fk < 12 && w * d.nmajor <= static_cast<double>(h.n) / 16) { w *= d.nmajor; ++fk; }
+    }
+    if (fk > 0 && d.nmajor >= 2) {
+        double words = 1;
+        for (int64_t t = 0; t < fk; ++t) words *= d.nmajor;
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        // the table plus the scratch of building it (word bytes, offsets, three result arrays)
+        if (words * (32.0 + fk + 40.0) < 0.5 * static_cast<double>(free_b) && words < 4.0e9) {
+            const uint64_t W = static_cast<uint64_t>(words);
+            void *tab = nullptr;
+            HIP_TRY(hipMalloc(&tab, W * 32));
+            ix->allocs.push_back(tab);
+            ix->hbm_bytes += W * 32;
+            if (launch_build_ftab(d, ix->cfg, static_cast<uint32_t>(fk), static_cast<unsigned long long *>(tab), nullptr)) return RBG_ENODEV;
+            d.ftab = static_cast<const unsigned long long *>(tab);
+            d.ftab_k = static_cast<uint32_t>(fk);
+            HIP_TRY(hipMemset(d.counters, 0, 4 * sizeof(uint64_t)));  // the build's own searches are not user queries
+        }
+    }
     return RBG_OK;
 }
 
@@ -524,6 +552,9 @@ int rbg_set_default_option(int opt, int64_t value) {
         case RBG_OPT_POS_BYTES:
             if (value != 0 && value != 4 && value != 8) return RBG_EARG;
             g_opt_pos_bytes = value; return RBG_OK;
+        case RBG_OPT_FTAB_K:
+            if (value < -1 || value > 16) return RBG_EARG;
+            g_opt_ftab_k = value; return RBG_OK;
         case RBG_OPT_HBM_BUDGET_MB:
             if (value < 0) return RBG_EARG;
             g_opt_hbm_budget_mb = value; return RBG_OK;
@@ -681,6 +712,7 @@ int rbg_info(const rbg_index *ix, rbg_info_t *out) {
     out->phi_slots_overflow = ix->phi_slots_overflow;
     out->kmer_steps = !ix->host.quad.empty() ? 4 : !ix->host.triple.empty() ? 3 : !ix->host.pair.empty() ? 2 : 1;
     out->kmer_symbols = ix->host.pair.empty() ? 0 : ix->host.nmajor;
+    out->ftab_k = ix->dev.ftab_k;
     for (const SymTable &t : ix->host.pair) out->pair_runs += t.nruns;
     for (const SymTable &t : ix->host.triple) out->triple_runs += t.nruns;
     for (const SymTable &t : ix->host.quad) out->quad_runs += t.nruns;

@@ -178,7 +178,7 @@ __device__ __forceinline__ void stage_tables(const DevIndex &ix, DevSym *s_tab, 
     __syncthreads();
 }
 
-template <typename P, bool TOEHOLD>
+template <typename P, bool TOEHOLD, bool USE_FTAB>
 __global__ __launch_bounds__(256) void k_find_range(const DevIndex ix, const uint8_t *__restrict__ seqs,
                                                     const uint64_t *__restrict__ off, const uint64_t N,
                                                     uint64_t *__restrict__ lo_out, uint64_t *__restrict__ hi_out,
@@ -209,6 +209,26 @@ __global__ __launch_bounds__(256) void k_find_range(const DevIndex ix, const uin
         bool pend_abs = false;
         ByteCursor rd{reinterpret_cast<const uint4 *>(seqs), ~uint64_t(0), make_uint4(0, 0, 0, 0)};
         bool alive = true;
+        // ftab (rowbowt.hpp:124-125, :745-758): while the range is still wide a step costs two slot
+        // gathers (lo and hi+1 fall in different buckets) plus toehold re-sampling; the state after the
+        // last ftab_k symbols is looked up with one gather instead.  Result-neutral: the table holds
+        // what this very kernel computes for that word.
+        if (USE_FTAB && ix.ftab_k && p - beg >= ix.ftab_k) {
+            uint64_t idx = 0, pw = 1;
+            bool all_major = true;
+            for (uint32_t t = 1; t <= ix.ftab_k; ++t) {  // right to left; leftmost symbol = most significant digit
+                const uint32_t mm = s_lut2[rd.at(p - t)];
+                all_major = all_major && mm != 0xFFu;
+                idx += (mm & 3u) * pw;
+                pw *= M;
+            }
+            if (all_major) {
+                const ulonglong4 e = *reinterpret_cast<const ulonglong4 *>(ix.ftab + 4 * idx);
+                lo = e.x; hi = e.y; k = e.z;
+                p -= ix.ftab_k;
+                if (hi < lo) { alive = false; p = beg; }
+            }
+        }
         // one LF step (or several nested ones) through the record S; false = range emptied
         auto step = [&](const DevSym &S, uint32_t adv) -> bool {
             RankAux q;
@@ -700,13 +720,79 @@ int launch_find_range(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *s
     const dim3 grid(grid_for(cfg, N)), block(cfg.block_threads);
     const bool toe = ssamp != nullptr;
     if (ix.pos_bytes == 4) {
-        if (toe) hipLaunchKernelGGL((k_find_range<uint32_t, true>), grid, block, 0, st, ix, seqs, off, N, lo, hi, ssamp);
-        else hipLaunchKernelGGL((k_find_range<uint32_t, false>), grid, block, 0, st, ix, seqs, off, N, lo, hi, ssamp);
+        if (toe) hipLaunchKernelGGL((k_find_range<uint32_t, true, true>), grid, block, 0, st, ix, seqs, off, N, lo, hi, ssamp);
+        else hipLaunchKernelGGL((k_find_range<uint32_t, false, true>), grid, block, 0, st, ix, seqs, off, N, lo, hi, ssamp);
     } else {
-        if (toe) hipLaunchKernelGGL((k_find_range<uint64_t, true>), grid, block, 0, st, ix, seqs, off, N, lo, hi, ssamp);
-        else hipLaunchKernelGGL((k_find_range<uint64_t, false>), grid, block, 0, st, ix, seqs, off, N, lo, hi, ssamp);
+        if (toe) hipLaunchKernelGGL((k_find_range<uint64_t, true, true>), grid, block, 0, st, ix, seqs, off, N, lo, hi, ssamp);
+        else hipLaunchKernelGGL((k_find_range<uint64_t, false, true>), grid, block, 0, st, ix, seqs, off, N, lo, hi, ssamp);
     }
     return static_cast<int>(hipGetLastError());
+}
+
+// ---- ftab construction: search every word of k major symbols with the step kernel itself ---------
+namespace {
+__global__ __launch_bounds__(256) void k_ftab_words(const DevIndex ix, const uint32_t k, const uint64_t W, uint8_t *__restrict__ seqs,
+                                                    uint64_t *__restrict__ off, const uint8_t *__restrict__ major_byte) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t w = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; w <= W; w += stride) {
+        off[w] = w * k;
+        if (w == W) break;
+        uint64_t x = w;
+        for (uint32_t t = k; t > 0; --t) {  // least significant digit = rightmost symbol
+            seqs[w * k + t - 1] = major_byte[x % ix.nmajor];
+            x /= ix.nmajor;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_ftab_pack(const uint64_t W, const uint64_t *__restrict__ lo, const uint64_t *__restrict__ hi,
+                                                   const uint64_t *__restrict__ ss, unsigned long long *__restrict__ tab) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t w = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; w < W; w += stride) {
+        tab[4 * w + 0] = lo[w];
+        tab[4 * w + 1] = hi[w];
+        tab[4 * w + 2] = ss ? ss[w] : 0;
+        tab[4 * w + 3] = 0;
+    }
+}
+}  // namespace
+
+int launch_build_ftab(const DevIndex &ix, const LaunchCfg &cfg, uint32_t k, unsigned long long *tab, void *stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    uint64_t W = 1;
+    for (uint32_t t = 0; t < k; ++t) W *= ix.nmajor;
+    uint8_t *seqs = nullptr, *mb = nullptr;
+    uint64_t *off = nullptr, *lo = nullptr, *hi = nullptr, *ss = nullptr;
+    hipError_t e = hipMalloc(&seqs, W * k + 64);
+    if (e == hipSuccess) e = hipMalloc(&off, (W + 1) * 8);
+    if (e == hipSuccess) e = hipMalloc(&lo, W * 8);
+    if (e == hipSuccess) e = hipMalloc(&hi, W * 8);
+    if (e == hipSuccess && ix.has_tsa) e = hipMalloc(&ss, W * 8);
+    if (e == hipSuccess) e = hipMalloc(&mb, 256);
+    if (e == hipSuccess) {
+        // major index -> byte, recovered from lut2 on the host side of the caller would need another
+        // argument; derive it here from the device lut2 with a tiny copy
+        uint8_t lut2[256], inv[256] = {0};
+        e = hipMemcpy(lut2, ix.lut2, 256, hipMemcpyDeviceToHost);
+        for (int b = 0; b < 256; ++b)
+            if (lut2[b] != 0xFF) inv[lut2[b]] = static_cast<uint8_t>(b);
+        if (e == hipSuccess) e = hipMemcpy(mb, inv, 256, hipMemcpyHostToDevice);
+    }
+    int rc = static_cast<int>(e);
+    if (!rc) {
+        DevIndex plain = ix;  // the words are searched WITHOUT a table
+        plain.ftab = nullptr;
+        plain.ftab_k = 0;
+        hipLaunchKernelGGL(k_ftab_words, dim3(grid_for(cfg, W + 1)), dim3(256), 0, st, plain, k, W, seqs, off, mb);
+        rc = static_cast<int>(hipGetLastError());
+        if (!rc) rc = launch_find_range(plain, cfg, seqs, off, W, lo, hi, ss, st);
+        if (!rc) {
+            hipLaunchKernelGGL(k_ftab_pack, dim3(grid_for(cfg, W)), dim3(256), 0, st, W, lo, hi, ss, tab);
+            rc = static_cast<int>(hipGetLastError());
+        }
+        if (!rc) rc = static_cast<int>(hipStreamSynchronize(st));
+    }
+    (void)hipFree(seqs); (void)hipFree(off); (void)hipFree(lo); (void)hipFree(hi); (void)hipFree(ss); (void)hipFree(mb);
+    return rc;
 }
 
 // ---- chain ordering for locate: permutation of the reads by toehold value (radix sort) ----------

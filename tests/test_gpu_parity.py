@@ -531,3 +531,30 @@ def test_hbm_budget_drops_kmer_levels(synth):
         rb.close()
     assert len(seen) >= 2 and min(seen) < 4
     o.close()
+
+
+@pytest.mark.parametrize("fk", [0, -1, 1, 3, 7])
+def test_ftab_is_result_neutral(synth, fk):
+    """The device ftab (rowbowt.hpp:124-125, :726-758) changes no answer, whatever its word length; reads
+    shorter than the word, reads with non-ACGT symbols inside the word, and absent words included."""
+    S = synth
+    ra.set_default_option(capi.OPT_FTAB_K, fk)
+    try:
+        rb = ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0)
+    finally:
+        ra.set_default_option(capi.OPT_FTAB_K, -1)
+    assert rb.info().ftab_k == (fk if fk >= 0 else 5)  # automatic: 4^k <= n/16 for n = 32 081
+    o = orc.Oracle.from_runs(S.heads, S.lens, S.ssa, S.esa)
+    reads = S.sample_reads(2000, 40, seed=8, sub_rate=0.3, ragged=True)
+    reads += [b"", b"A", b"AC", b"ACG", b"ACGTACG", b"ACGTACGN", b"NACGTACG", b"ACGNACGT", b"TTTTTTTTTTTT", bytes([1]) + b"ACGTACG",
+              S.text[:7].tobytes(), S.text[:8].tobytes(), S.text[-9:-1].tobytes(), S.text[-8:].tobytes()]
+    seqs, off = ra.pack_reads(reads)
+    rb.counters_reset()
+    lo, hi, k = rb.find_range_w_toehold(seqs, off)
+    wlo, whi, wk = o.find_range_w_toehold_batch(seqs, off)
+    assert (lo == wlo).all() and (hi == whi).all() and (k == wk).all()
+    clo, chi = rb.find_range(seqs, off)
+    assert (clo == wlo).all() and (chi == whi).all()
+    assert int(rb.counters()[0]) == 2 * len(reads)  # building the table left no trace in the counters
+    rb.close()
+    o.close()
