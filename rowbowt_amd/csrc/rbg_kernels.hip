@@ -713,20 +713,29 @@ int grid_for(const LaunchCfg &cfg, uint64_t N) {
 
 }  // namespace
 
-int launch_find_range(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
-                      uint64_t *lo, uint64_t *hi, uint64_t *ssamp, void *stream) {
+template <bool USE_FTAB>
+int launch_find_range_impl(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
+                           uint64_t *lo, uint64_t *hi, uint64_t *ssamp, void *stream) {
     if (N == 0) return 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid(grid_for(cfg, N)), block(cfg.block_threads);
     const bool toe = ssamp != nullptr;
     if (ix.pos_bytes == 4) {
-        if (toe) hipLaunchKernelGGL((k_find_range<uint32_t, true, true>), grid, block, 0, st, ix, seqs, off, N, lo, hi, ssamp);
-        else hipLaunchKernelGGL((k_find_range<uint32_t, false, true>), grid, block, 0, st, ix, seqs, off, N, lo, hi, ssamp);
+        if (toe) hipLaunchKernelGGL((k_find_range<uint32_t, true, USE_FTAB>), grid, block, 0, st, ix, seqs, off, N, lo, hi, ssamp);
+        else hipLaunchKernelGGL((k_find_range<uint32_t, false, USE_FTAB>), grid, block, 0, st, ix, seqs, off, N, lo, hi, ssamp);
     } else {
-        if (toe) hipLaunchKernelGGL((k_find_range<uint64_t, true, true>), grid, block, 0, st, ix, seqs, off, N, lo, hi, ssamp);
-        else hipLaunchKernelGGL((k_find_range<uint64_t, false, true>), grid, block, 0, st, ix, seqs, off, N, lo, hi, ssamp);
+        if (toe) hipLaunchKernelGGL((k_find_range<uint64_t, true, USE_FTAB>), grid, block, 0, st, ix, seqs, off, N, lo, hi, ssamp);
+        else hipLaunchKernelGGL((k_find_range<uint64_t, false, USE_FTAB>), grid, block, 0, st, ix, seqs, off, N, lo, hi, ssamp);
     }
     return static_cast<int>(hipGetLastError());
+}
+
+int launch_find_range(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
+                      uint64_t *lo, uint64_t *hi, uint64_t *ssamp, void *stream) {
+    // without a table the table-free instantiation runs (it is also the one that BUILDS the table,
+    // so profiles show that one-off launch under its own kernel name)
+    return ix.ftab_k ? launch_find_range_impl<true>(ix, cfg, seqs, off, N, lo, hi, ssamp, stream)
+                     : launch_find_range_impl<false>(ix, cfg, seqs, off, N, lo, hi, ssamp, stream);
 }
 
 // ---- ftab construction: search every word of k major symbols with the step kernel itself ---------

@@ -558,3 +558,42 @@ def test_ftab_is_result_neutral(synth, fk):
     assert int(rb.counters()[0]) == 2 * len(reads)  # building the table left no trace in the counters
     rb.close()
     o.close()
+
+
+def test_concurrent_queries_one_index(synth):
+    """The reference calls const query methods concurrently on one RowBowt (rb_markers.cpp:321-326);
+    concurrent host-pointer calls on one rbg_index must be independent (per-thread streams)."""
+    import threading
+    S = synth
+    rb = ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0)
+    o = orc.Oracle.from_runs(S.heads, S.lens, S.ssa, S.esa)
+    jobs = []
+    for t in range(6):
+        reads = S.sample_reads(3000 + 500 * t, 64, seed=100 + t, sub_rate=0.1, ragged=bool(t % 2))
+        seqs, off = ra.pack_reads(reads)
+        wlo, whi, wk = o.find_range_w_toehold_batch(seqs, off, nthreads=4)
+        woff, wlocs = o.locs_at_batch(wlo, whi, wk, nthreads=4)
+        jobs.append((seqs, off, wlo, whi, wk, woff, wlocs))
+    errors = []
+
+    def worker(job):
+        seqs, off, wlo, whi, wk, woff, wlocs = job
+        try:
+            for _ in range(5):
+                lo, hi, k = rb.find_range_w_toehold(seqs, off)
+                loc_off, locs = rb.locs_at(lo, hi, k)
+                clo, chi = rb.find_range(seqs, off)
+                if not ((lo == wlo).all() and (hi == whi).all() and (k == wk).all() and (loc_off == woff).all()
+                        and (locs == wlocs).all() and (clo == wlo).all() and (chi == whi).all()):
+                    errors.append("mismatch")
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(j,)) for j in jobs]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:3]
+    rb.close()
+    o.close()
