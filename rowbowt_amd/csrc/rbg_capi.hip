@@ -238,9 +238,7 @@ int commit_sym(rbg_index *ix, const SymTable &t, bool with_samples, PreparedSym<
     d.ord = static_cast<const uint32_t *>(po);
     ix->rank_slots += p.slots.size();
     ix->rank_slots_overflow += p.overflow;
-    d.nruns = t.nruns;
     d.F = t.F;
-    d.total = t.total;
     d.shift = t.shift;
     d.pad = 0;
     return RBG_OK;

@@ -51,14 +51,12 @@ constexpr uint32_t kSlotOvf = 7;
 constexpr uint32_t kPhiOvf = 3;
 constexpr uint32_t kMaxSlotShift = 8;
 
-struct DevSym {
-    const void *ent;    // RunEnt<P>[nruns + 1] (sentinel: start = n, cum = total): overflow buckets, samples
+struct DevSym {        // 48 bytes: 344 of them (symbols + 2/3/4-mers) are staged in LDS per workgroup
+    const void *ent;    // RunEnt<P>[nruns + 1] (sentinel: start = n, cum = total): overflow buckets
     const void *samp;   // P[nruns]: samples_last_ of each run (nullptr without toehold SA)
     const void *slots;  // RankSlot[(n >> shift) + 2]
     const uint32_t *ord;  // (n >> shift) + 2: # runs of the symbol starting before each bucket
-    uint64_t nruns;
-    uint64_t F;      // RowBowt::f_[byte]
-    uint64_t total;  // occurrences of the symbol
+    uint64_t F;      // RowBowt::f_[byte] (k-mer: first row of its SA interval)
     uint32_t shift;
     uint32_t pad;
 };

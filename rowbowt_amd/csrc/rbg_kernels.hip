@@ -179,7 +179,7 @@ __device__ __forceinline__ void stage_tables(const DevIndex &ix, DevSym *s_tab, 
 }
 
 template <typename P, bool TOEHOLD, bool USE_FTAB>
-__global__ __launch_bounds__(256) void k_find_range(const DevIndex ix, const uint8_t *__restrict__ seqs,
+__global__ __launch_bounds__(256, 8) void k_find_range(const DevIndex ix, const uint8_t *__restrict__ seqs,
                                                     const uint64_t *__restrict__ off, const uint64_t N,
                                                     uint64_t *__restrict__ lo_out, uint64_t *__restrict__ hi_out,
                                                     uint64_t *__restrict__ ss_out) {
