@@ -373,7 +373,7 @@ __device__ __forceinline__ uint64_t phi_step(const DevIndex &ix, uint64_t i) {
 // like the slot loads (tools/gather_roof.hip).  So values are staged per wave in LDS, kChunk steps
 // at a time, and flushed with 8 lanes writing one read's 64-byte segment: a store instruction then
 // touches ~8-12 lines instead of 64.
-constexpr int kChunk = 32;
+constexpr int kChunk = 16;
 
 __device__ __forceinline__ void wave_lds_sync() {
     // LDS operations of one wave execute in issue order; this only stops the compiler from moving
