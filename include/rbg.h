@@ -218,7 +218,7 @@ int rbg_counters(rbg_index *, uint64_t out[4]);
 int rbg_counters_reset(rbg_index *);
 
 /* ---- tuning (never changes results) -------------------------------------------------------- */
-/* Process-wide defaults read when an index is built/loaded: BLOCK_THREADS (multiple of 64),
+/* Process-wide defaults read when an index is built/loaded: BLOCK_THREADS (64, 128, 192 or 256),
  * RANK/PHI_BUCKET_SHIFT (-1 = automatic, else 0..8), POS_BYTES (0 = automatic, 4 or 8 to force a width),
  * KMER_STEPS (1..4: symbols the backward search consumes per gather; 2..4 build the k-mer
  * tables of DESIGN.md 2b; 1 keeps the reference's one-symbol steps only; the deepest levels are dropped

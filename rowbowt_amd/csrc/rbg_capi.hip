@@ -539,7 +539,7 @@ const char *rbg_strerror(int code) {
 int rbg_set_default_option(int opt, int64_t value) {
     switch (opt) {
         case RBG_OPT_BLOCK_THREADS:
-            if (value < 64 || value > 1024 || value % 64) return RBG_EARG;
+            if (value < 64 || value > 256 || value % 64) return RBG_EARG;  // kernels are built for <= 4 waves per workgroup
             g_opt_block_threads = value; return RBG_OK;
         case RBG_OPT_RANK_BUCKET_SHIFT:
             if (value < -1 || value > 8) return RBG_EARG;  // slot offsets are 8-bit
