@@ -850,9 +850,13 @@ int launch_locate_order(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t
     if (rc) return rc;
     int end_bit = 1;
     while (end_bit < 64 && (ix.n >> end_bit)) ++end_bit;  // toeholds are text positions < n
+    // the order only has to bring chains of nearby text positions together: the low bits (positions
+    // inside one 64-byte line of phi slots) need no sorting, which saves a radix pass
+    int begin_bit = static_cast<int>(ix.phi_shift) + 2;
+    if (end_bit - begin_bit < 8) begin_bit = 0;
     size_t bytes = w.sort_bytes;
-    return static_cast<int>(hipcub::DeviceRadixSort::SortPairs(base + w.sort, bytes, k, keys, iota, perm, static_cast<int64_t>(N), 0,
-                                                               end_bit, st));
+    return static_cast<int>(hipcub::DeviceRadixSort::SortPairs(base + w.sort, bytes, k, keys, iota, perm, static_cast<int64_t>(N),
+                                                               begin_bit, end_bit, st));
 }
 
 size_t scan_tmp_bytes(uint64_t N) {
