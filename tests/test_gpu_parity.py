@@ -442,7 +442,7 @@ def test_greedy_seeding_vs_oracle(synth, ksteps):
     o = orc.Oracle.from_runs(S.heads, S.lens, S.ssa, S.esa)
     rng = np.random.default_rng(17)
     reads = []
-    for r in S.sample_reads(1500, 80, seed=33, sub_rate=0.0):
+    for r in S.sample_reads(5000, 80, seed=33, sub_rate=0.0):  # > 4096: the host path orders the phi chains
         r = bytearray(r)
         for _ in range(int(rng.integers(0, 4))):  # 0..3 substitutions -> several seeds per read
             p = int(rng.integers(len(r)))
@@ -462,7 +462,7 @@ def test_greedy_seeding_vs_oracle(synth, ksteps):
                 assert (int(lo[i]), int(hi[i]), int(qs[i]), int(qe[i]), int(k[i])) == seed
                 nseeds += 1
         if min_length <= 25:
-            assert nseeds > 1000
+            assert nseeds > 3000
     rb.close()
     o.close()
 
