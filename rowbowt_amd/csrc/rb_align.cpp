@@ -13,10 +13,14 @@
 #include <getopt.h>
 #include <zlib.h>
 
+#include <algorithm>
+#include <cctype>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <future>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../include/rowbowt_gpu.hpp"
@@ -28,6 +32,7 @@ struct RbAlignArgs {  // rb_align.cpp:17-24
     int sam = 0, markers = 0;
     int device = 0;
     uint64_t batch = 1u << 20;
+    int threads = 8;  // output formatting workers
 };
 
 void print_help() {  // rb_align.cpp:26-35
@@ -38,6 +43,7 @@ void print_help() {  // rb_align.cpp:26-35
     fprintf(stderr, "    --sam/-s                         print locations\n");
     fprintf(stderr, "    --gpu <n>                        HIP device ordinal (default 0)\n");
     fprintf(stderr, "    --batch <n>                      reads per GPU batch (default 1048576)\n");
+    fprintf(stderr, "    --threads <n>                    output formatting threads (default 8)\n");
     fprintf(stderr, "    <input_prefix>                   index prefix\n");
     fprintf(stderr, "    <input_fastq>                    input fastq\n");
 }
@@ -49,6 +55,7 @@ RbAlignArgs parse_args(int argc, char **argv) {  // rb_align.cpp:37-84
                                            {"sam", no_argument, 0, 's'},
                                            {"gpu", required_argument, 0, 'g'},
                                            {"batch", required_argument, 0, 'b'},
+                                           {"threads", required_argument, 0, 't'},
                                            {0, 0, 0, 0}};
     int c, long_index = 0;
     while ((c = getopt_long(argc, argv, "o:smh", long_options, &long_index)) != -1) {
@@ -59,6 +66,7 @@ RbAlignArgs parse_args(int argc, char **argv) {  // rb_align.cpp:37-84
             case 'm': args.markers = 1; break;
             case 'g': args.device = atoi(optarg); break;
             case 'b': args.batch = strtoull(optarg, nullptr, 10); break;
+            case 't': args.threads = atoi(optarg); break;
             default: print_help(); exit(1);
         }
     }
@@ -73,103 +81,188 @@ RbAlignArgs parse_args(int argc, char **argv) {  // rb_align.cpp:37-84
     return args;
 }
 
-// FASTA/FASTQ reader with kseq_read's observable behaviour (kseq.h:178-219)
+// One batch of reads in the C-ABI's layout (names kept the same way)
+struct PackedBatch {
+    std::string names, seqs;
+    std::vector<uint64_t> name_off{0}, off{0};
+    size_t size() const { return off.size() - 1; }
+    void clear() { names.clear(); seqs.clear(); name_off.assign(1, 0); off.assign(1, 0); }
+};
+
+// FASTA/FASTQ reader with kseq_read's observable behaviour (kseq.h:178-219), block-buffered over
+// gzread and appending straight into a PackedBatch (no per-read strings)
 class FastxReader {
    public:
-    explicit FastxReader(gzFile fp) : fp_(fp) { buf_.resize(1 << 16); }
-    // 0 = record read, -1 = EOF, -2 = truncated quality string
-    int next(std::string &name, std::string &seq) {
-        name.clear();
-        seq.clear();
-        if (!have_header_) {
-            while (true) {
-                if (!getline()) return -1;
-                if (!line_.empty() && (line_[0] == '>' || line_[0] == '@')) break;
-            }
+    explicit FastxReader(gzFile fp) : fp_(fp), buf_(1 << 22) {}
+    // 0 = record appended, -1 = EOF, -2 = truncated quality string, -3 = stream error
+    int next(PackedBatch &b) {
+        int c;
+        if (last_char_ == 0) {  // jump to the next header character (kseq.h:183-187)
+            while ((c = getc()) >= 0 && c != '>' && c != '@') {}
+            if (c < 0) return c;
+            last_char_ = c;
         }
-        have_header_ = false;
-        const size_t ws = line_.find_first_of(" \t", 1);
-        name = line_.substr(1, ws == std::string::npos ? std::string::npos : ws - 1);
-        bool plus = false;
-        while (getline()) {
-            if (!line_.empty() && (line_[0] == '>' || line_[0] == '@')) { have_header_ = true; break; }
-            if (!line_.empty() && line_[0] == '+') { plus = true; break; }
-            for (char ch : line_)
-                if (static_cast<unsigned char>(ch) > 32) seq.push_back(ch);  // kseq keeps isgraph() bytes
+        // name = up to the first whitespace; rest of the line is the comment (kseq.h:189-190)
+        bool in_name = true, got_any = false;
+        while ((c = getc()) >= 0 && c != '\n') {
+            got_any = true;
+            if (in_name && !isspace(c)) b.names.push_back(static_cast<char>(c));
+            else in_name = false;
         }
-        if (!plus) return 0;
+        if (c < 0 && !got_any) return c == -3 ? -3 : -1;
+        b.name_off.push_back(b.names.size());
+        // sequence lines until a line starting with '>', '+' or '@' (kseq.h:195-199)
+        const size_t seq_begin = b.seqs.size();
+        while ((c = getc()) >= 0 && c != '>' && c != '+' && c != '@') {
+            if (c == '\n') continue;
+            b.seqs.push_back(static_cast<char>(c));
+            read_line_into(b.seqs, seq_begin);
+        }
+        last_char_ = (c == '>' || c == '@') ? c : 0;
+        const size_t seq_len = b.seqs.size() - seq_begin;
+        b.off.push_back(b.seqs.size());
+        if (c != '+') return c == -3 ? -3 : 0;  // FASTA
+        while ((c = getc()) >= 0 && c != '\n') {}  // rest of the '+' line
+        if (c < 0) return -2;                      // no quality string
         size_t qlen = 0;
-        while (qlen < seq.size()) {
-            if (!getline()) return -2;
-            qlen += line_.size();
-        }
-        if (qlen != seq.size()) return -2;
-        return 0;
+        qual_.clear();
+        do {  // kseq.h:212: at least one line, then until the quality is as long as the sequence
+            const size_t before = qual_.size();
+            if (!read_line_into(qual_, 0)) break;
+            qlen += qual_.size() - before;
+        } while (qlen < seq_len);
+        last_char_ = 0;
+        return qlen == seq_len ? 0 : -2;
     }
 
    private:
-    bool getline() {
-        line_.clear();
-        while (true) {
-            if (!gzgets(fp_, buf_.data(), static_cast<int>(buf_.size()))) return !line_.empty();
-            const size_t len = strlen(buf_.data());
-            line_.append(buf_.data(), len);
-            if (len && buf_[len - 1] == '\n') break;
+    int getc() {
+        if (begin_ >= end_) {
+            if (eof_) return -1;
+            const int got = gzread(fp_, buf_.data(), static_cast<unsigned>(buf_.size()));
+            if (got < 0) { eof_ = true; return -3; }
+            if (got == 0) { eof_ = true; return -1; }
+            begin_ = 0;
+            end_ = static_cast<size_t>(got);
         }
-        while (!line_.empty() && (line_.back() == '\n' || line_.back() == '\r')) line_.pop_back();
-        return true;
+        return static_cast<unsigned char>(buf_[begin_++]);
+    }
+    // ks_getuntil2(KS_SEP_LINE, append): rest of the current line without '\n'; a trailing '\r' is
+    // dropped when the string is longer than one byte (kseq.h:141).  false = nothing read at EOF.
+    bool read_line_into(std::string &str, size_t str_begin) {
+        bool got_any = false;
+        while (true) {
+            if (begin_ >= end_) {
+                const int c = getc();
+                if (c < 0) break;
+                --begin_;
+            }
+            const char *p = buf_.data() + begin_;
+            const char *nl = static_cast<const char *>(memchr(p, '\n', end_ - begin_));
+            const size_t take = nl ? static_cast<size_t>(nl - p) : end_ - begin_;
+            str.append(p, take);
+            got_any = true;
+            begin_ += take + (nl ? 1 : 0);
+            if (nl) break;
+        }
+        if (str.size() - str_begin > 1 && str.back() == '\r') str.pop_back();
+        return got_any;
     }
     gzFile fp_;
     std::vector<char> buf_;
-    std::string line_;
-    bool have_header_ = false;
+    size_t begin_ = 0, end_ = 0;
+    bool eof_ = false;
+    int last_char_ = 0;
+    std::string qual_;
 };
 
-// rb_report (rb_align.cpp:118-145) for a whole batch
-void report_batch(const rbwt::RowBowt<> &rb, const RbAlignArgs &args, const std::vector<std::string> &names,
-                  const std::vector<std::string> &seqs, std::string &out) {
-    using RB = rbwt::RowBowt<>;
-    const size_t N = seqs.size();
-    std::vector<RB::LFData> lfs;
-    std::vector<RB::range_t> ranges(N);
+inline void put_u64(std::string &out, uint64_t v) {
+    char tmp[24];
+    int n = 0;
+    do { tmp[n++] = static_cast<char>('0' + v % 10); v /= 10; } while (v);
+    while (n) out.push_back(tmp[--n]);
+}
+
+struct BatchResult {
+    std::vector<uint64_t> lo, hi, k, loc_off, mk_off;
+    uint64_t *locs = nullptr, *mk = nullptr;
+    ~BatchResult() { rbg_free_buffer(locs); rbg_free_buffer(mk); }
+};
+
+// rb_get_range + locs_at + markers_at (rb_align.cpp:95-145) for a whole batch, through the C-ABI
+void query_batch(const rbwt::RowBowt<> &rb, const RbAlignArgs &args, const PackedBatch &b, BatchResult &r) {
+    const uint64_t N = b.size();
+    const uint8_t *seqs = reinterpret_cast<const uint8_t *>(b.seqs.data());
+    rbg_index *ix = rb.handle();
+    r.lo.resize(N); r.hi.resize(N);
     if (args.sam) {  // rb_get_range(sa=true), rb_align.cpp:99-103
-        rb.find_range_w_toehold_batch(seqs, lfs);
-        for (size_t i = 0; i < N; ++i) ranges[i] = lfs[i].rn;
+        r.k.resize(N);
+        rbwt::detail::check(rbg_find_range_w_toehold(ix, seqs, b.off.data(), N, r.lo.data(), r.hi.data(), r.k.data()), "rbg_find_range_w_toehold");
+        r.loc_off.resize(N + 1);
+        rbwt::detail::check(rbg_locs_at(ix, r.lo.data(), r.hi.data(), r.k.data(), N, static_cast<uint64_t>(-1), r.loc_off.data(), &r.locs),
+                            "rbg_locs_at");  // rb_align.cpp:125
     } else {
-        rb.find_range_batch(seqs, ranges);
+        rbwt::detail::check(rbg_find_range(ix, seqs, b.off.data(), N, r.lo.data(), r.hi.data()), "rbg_find_range");
     }
-    std::vector<uint64_t> loc_off, locs, mk_off;
-    std::vector<MarkerT> mk;
-    if (args.sam) rb.locs_at_batch(lfs, static_cast<uint64_t>(-1), loc_off, locs);  // rb_align.cpp:125
-    if (args.markers) rb.markers_at_batch(ranges, mk_off, mk);                       // rb_align.cpp:138
-    char tmp[96];
-    for (size_t i = 0; i < N; ++i) {
-        out += names[i];
-        snprintf(tmp, sizeof(tmp), " (%llu,%llu), count=%llu\n", (unsigned long long)ranges[i].first,
-                 (unsigned long long)ranges[i].second, (unsigned long long)(ranges[i].second - ranges[i].first + 1));
-        out += tmp;
+    if (args.markers) {  // rb_align.cpp:138
+        r.mk_off.resize(N + 1);
+        rbwt::detail::check(rbg_markers_at(ix, r.lo.data(), r.hi.data(), N, r.mk_off.data(), &r.mk), "rbg_markers_at");
+    }
+}
+
+// the text of rb_report (rb_align.cpp:118-145) for reads [i0, i1)
+void format_range(const rbwt::RowBowt<> &rb, const RbAlignArgs &args, const PackedBatch &b, const BatchResult &r, size_t i0,
+                  size_t i1, std::string &out) {
+    for (size_t i = i0; i < i1; ++i) {
+        out.append(b.names, b.name_off[i], b.name_off[i + 1] - b.name_off[i]);
+        out += " (";
+        put_u64(out, r.lo[i]);
+        out.push_back(',');
+        put_u64(out, r.hi[i]);
+        out += "), count=";
+        put_u64(out, r.hi[i] - r.lo[i] + 1);  // unsigned wrap for the empty range, like the reference
+        out.push_back('\n');
         if (args.sam) {
             out += "\tlocs: ";
-            for (uint64_t t = loc_off[i]; t < loc_off[i + 1]; ++t) {
-                const auto x = rb.resolve_offset(locs[t]);
-                snprintf(tmp, sizeof(tmp), "%llu/", (unsigned long long)locs[t]);
-                out += tmp;
-                out += x.first;
-                snprintf(tmp, sizeof(tmp), ":%llu ", (unsigned long long)x.second);
-                out += tmp;
+            for (uint64_t t = r.loc_off[i]; t < r.loc_off[i + 1]; ++t) {
+                const char *name = nullptr;
+                uint64_t off = 0;
+                rbwt::detail::check(rbg_resolve_offset(rb.handle(), r.locs[t], &name, &off), "rbg_resolve_offset");
+                put_u64(out, r.locs[t]);
+                out.push_back('/');
+                out += name;
+                out.push_back(':');
+                put_u64(out, off);
+                out.push_back(' ');
             }
-            out += "\n";
+            out.push_back('\n');
         }
         if (args.markers) {
             out += "\tmarkers: ";
-            if (mk_off[i + 1] == mk_off[i]) out += "no markers (consider building the marker array with a larger window size)";
-            for (uint64_t t = mk_off[i]; t < mk_off[i + 1]; ++t) {
-                snprintf(tmp, sizeof(tmp), "%llu/%d ", (unsigned long long)get_pos(mk[t]), static_cast<int>(get_allele(mk[t])));
-                out += tmp;
+            if (r.mk_off[i + 1] == r.mk_off[i]) out += "no markers (consider building the marker array with a larger window size)";
+            for (uint64_t t = r.mk_off[i]; t < r.mk_off[i + 1]; ++t) {
+                put_u64(out, get_pos(r.mk[t]));
+                out.push_back('/');
+                put_u64(out, get_allele(r.mk[t]));
+                out.push_back(' ');
             }
-            out += "\n";
+            out.push_back('\n');
         }
     }
+}
+
+// query + format one batch; formatting is split over worker threads, pieces concatenated in order
+void report_batch(const rbwt::RowBowt<> &rb, const RbAlignArgs &args, const PackedBatch &b, std::vector<std::string> &pieces) {
+    BatchResult r;
+    query_batch(rb, args, b, r);
+    const size_t N = b.size();
+    const size_t T = std::max<size_t>(1, std::min<size_t>({static_cast<size_t>(args.threads), (N + 4095) / 4096, size_t(64)}));
+    pieces.assign(T, std::string());
+    std::vector<std::thread> workers;
+    for (size_t t = 1; t < T; ++t)
+        workers.emplace_back([&, t] { format_range(rb, args, b, r, N * t / T, N * (t + 1) / T, pieces[t]); });
+    format_range(rb, args, b, r, 0, N / T, pieces[0]);
+    for (auto &w : workers) w.join();
 }
 
 }  // namespace
@@ -198,23 +291,34 @@ int main(int argc, char **argv) {
     gzbuffer(fq_fp, 1 << 20);
     FastxReader reader(fq_fp);
     start = std::chrono::high_resolution_clock::now();
-    std::vector<std::string> names, seqs;
-    std::string name, seq, out;
+    // three overlapped stages: parse batch i+1 | query + format batch i | write batch i-1
     int err = 0;
-    while (true) {
-        names.clear();
-        seqs.clear();
-        while (names.size() < args.batch && (err = reader.next(name, seq)) == 0) {
-            names.push_back(name);
-            seqs.push_back(seq);
-        }
-        if (!names.empty()) {
-            out.clear();
-            report_batch(rb, args, names, seqs, out);
-            fwrite(out.data(), 1, out.size(), stdout);
-        }
-        if (err != 0) break;
+    auto parse = [&](PackedBatch &b) {
+        b.clear();
+        int e = 0;
+        while (b.size() < args.batch && (e = reader.next(b)) == 0) {}
+        return e;
+    };
+    PackedBatch cur, nxt;
+    err = parse(cur);
+    std::future<void> writer;
+    std::vector<std::string> pieces, writing;
+    while (cur.size() > 0) {
+        std::future<int> parser;
+        const bool more = err == 0;
+        if (more) parser = std::async(std::launch::async, parse, std::ref(nxt));
+        report_batch(rb, args, cur, pieces);
+        if (writer.valid()) writer.get();
+        writing.swap(pieces);
+        writer = std::async(std::launch::async, [&writing] {
+            for (const std::string &p : writing) fwrite(p.data(), 1, p.size(), stdout);
+        });
+        if (!more) break;
+        err = parser.get();
+        cur.clear();
+        std::swap(cur, nxt);
     }
+    if (writer.valid()) writer.get();
     fflush(stdout);
     stop = std::chrono::high_resolution_clock::now();
     const std::chrono::duration<double> total_query_time = stop - start;
