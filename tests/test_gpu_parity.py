@@ -597,3 +597,102 @@ def test_concurrent_queries_one_index(synth):
     assert not errors, errors[:3]
     rb.close()
     o.close()
+
+
+def _kseq_model(data: bytes):
+    """kseq_read (reference include/kseq.h:178-219) restated byte by byte, for the CLI parser test."""
+    recs, i, n, last = [], 0, len(data), 0
+    def getc():
+        nonlocal i
+        if i >= n:
+            return -1
+        i += 1
+        return data[i - 1]
+    def getline():  # ks_getuntil2(KS_SEP_LINE): rest of line, without '\n'
+        nonlocal i
+        if i >= n:
+            return None
+        j = data.find(b"\n", i)
+        if j < 0:
+            j = n
+        s = data[i:j]
+        i = min(j + 1, n)
+        return s
+    while True:
+        if last == 0:
+            c = getc()
+            while c >= 0 and c not in (62, 64):
+                c = getc()
+            if c < 0:
+                return recs, -1
+            last = c
+        # name up to whitespace, rest of the line = comment
+        j = i
+        while j < n and not chr(data[j]).isspace():
+            j += 1
+        if j == i and i >= n:
+            return recs, -1
+        name = data[i:j]
+        i = j
+        if i < n and data[i] != 10:
+            getline()
+        elif i < n:
+            i += 1
+        seq = b""
+        c = getc()
+        while c >= 0 and c not in (62, 43, 64):
+            if c != 10:
+                seq += bytes([c]) + (getline() or b"")
+                if len(seq) > 1 and seq.endswith(b"\r"):
+                    seq = seq[:-1]
+            c = getc()
+        last = c if c in (62, 64) else 0
+        if c != 43:
+            recs.append((name, seq))
+            if c < 0:
+                return recs, -1
+            continue
+        c = getc()
+        while c >= 0 and c != 10:
+            c = getc()
+        if c < 0:
+            recs.append((name, seq))
+            return recs, -2
+        qual = b""
+        while True:
+            l = getline()
+            if l is None:
+                break
+            qual += l
+            if len(qual) > 1 and qual.endswith(b"\r"):
+                qual = qual[:-1]
+            if len(qual) >= len(seq):
+                break
+        last = 0
+        recs.append((name, seq))
+        if len(qual) != len(seq):
+            return recs, -2
+
+
+def test_cli_parser_matches_kseq(data_dir, tmp_path, small):
+    rb, o = small
+    t = open(os.path.join(data_dir, "small.fa"), "rb").read().split(b"\n", 1)[1].replace(b"\n", b"")
+    s1, s2, s3 = t[100:160], t[500:530], t[900:1000]
+    blob = (b"junk before the first header\n>multi line\tcomment here\n" + s1[:20] + b"\n" + s1[20:45] + b"\n\n" + s1[45:] + b"\n"
+            b"@fq1 desc\r\n" + s2 + b"\r\n+\r\n" + b"I" * len(s2) + b"\r\n"
+            b">with space in seq\n" + s3[:10] + b" " + s3[10:] + b"\n"
+            b"@fq2\n" + s3[:50] + b"\n" + s3[50:] + b"\n+fq2\n" + b">" * 50 + b"\n" + b"@" * 50 + b"\n"
+            b">empty\n>last_no_newline\n" + s1)
+    fq = tmp_path / "weird.fx"
+    fq.write_bytes(blob)
+    recs, err = _kseq_model(blob)
+    assert err == -1 and [r[0] for r in recs] == [b"multi", b"fq1", b"with", b"fq2", b"empty", b"last_no_newline"]
+    assert recs[0][1] == s1 and recs[1][1] == s2 and recs[3][1] == s3 and recs[4][1] == b""
+    rc, out, errtxt = _run_cli([os.path.join(data_dir, "small.fa"), str(fq)])
+    assert rc == 0, errtxt
+    want = ""
+    for name, seq in recs:
+        lo, hi = o.find_range(seq)
+        want += f"{name.decode()} ({lo},{hi}), count={(hi - lo + 1) % 2**64}\n"
+    assert out == want
+    assert "(1,0), count=0" in out.splitlines()[2]  # the blank inside the sequence is kept, as kseq does
