@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check-reads", type=int, default=20000, help="reads compared bit-exactly with the oracle")
+    ap.add_argument("--markers", action="store_true",
+                    help="also run BASELINE.json configs[4] (rb_align -m: find_range + markers_at on a synthetic marker array "
+                         "over the same index), checked against the oracle on --check-reads reads")
     ap.add_argument("--two-stream", action="store_true",
                     help="also time the K steps as successive batches on two HIP streams (informational; off by default so "
                          "that a profile of the default command holds undisturbed per-kernel durations)")
@@ -96,6 +99,7 @@ def main():
     torch.cuda.synchronize()
     t_sa = time.time() - t0
     inp = sp.index_inputs(text, sa)
+    marker_arrays = sp.marker_array(text, info, sa, w=10) if args.markers else None
     del sa
     torch.cuda.empty_cache()
     log(rank, f"synthetic pangenome: L={args.L} H={args.H} n={inp['n']} r={inp['r']} n/r={inp['n'] / inp['r']:.1f} "
@@ -244,6 +248,36 @@ def main():
       same_out = bool((alt["locs"] == d_locs).all().item()) and bool((alt["loc_off"] == d_loc_off).all().item())
       del alt
 
+    # ---- markers path (BASELINE.json configs[4], rb_align -m: rb_align.cpp:133-143), optional ------
+    mk_block = None
+    if args.markers:
+        rb.set_markers(*marker_arrays)
+        d_mk_off = torch.empty(N + 1, dtype=torch.int64, device=dev)
+
+        def k_mplan():
+            chk(L.rbg_markers_plan_dev(rb.h, d_lo.data_ptr(), d_hi.data_ptr(), N, d_mk_off.data_ptr(), d_tmp.data_ptr(), tmp_bytes, st),
+                "markers_plan")
+
+        k_count()
+        k_mplan()
+        total_mk = int(d_mk_off[-1].item())
+        d_mk = torch.empty(max(total_mk, 1), dtype=torch.int64, device=dev)
+
+        def mstep():
+            k_count()
+            k_mplan()
+            chk(L.rbg_markers_fill_dev(rb.h, d_lo.data_ptr(), d_hi.data_ptr(), N, d_mk_off.data_ptr(), d_mk.data_ptr(), st), "markers_fill")
+
+        for _ in range(max(1, args.warmup)):
+            mstep()
+        el_mk = timed(mstep, K)
+        n_with = int(((d_mk_off[1:] - d_mk_off[:-1]) > 0).sum().item())
+        mk_block = {"value": N * K / el_mk, "unit": "reads/s (this rank)", "ms_per_step": el_mk / K * 1e3,
+                    "workload": "BASELINE.json configs[4] in rb_align -m form: find_range + markers_at(range), synthetic marker array "
+                                "(w=10 rows before every variant site, both alleles)",
+                    "marker_runs": int(len(marker_arrays[0])), "marker_values": int(len(marker_arrays[3])),
+                    "markers_reported": total_mk, "reads_with_markers": n_with}
+
     # max over ranks, counters over RCCL
     t_el = torch.tensor([el, el_count, el_pipe], dtype=torch.float64, device=dev)
     if use_dist:
@@ -301,6 +335,7 @@ def main():
                                      "identical_output": same_out,
                                      "workload": "the same K count+locate steps issued as successive batches on two HIP streams"}
                                     if args.two_stream else None),
+            "markers": mk_block,
             "count_only": {"value": N * world * K / el_count, "unit": "reads/s", "ms_per_step": el_count / K * 1e3,
                            "workload": "BASELINE.json configs[1]: find_range only"},
             "counters": {"reads": g_counters[0], "matched": g_counters[1], "sum_occ": g_counters[2], "sum_locs": g_counters[3],
@@ -375,6 +410,23 @@ def main():
             if not ok:
                 print(json.dumps(out))
                 raise SystemExit("PARITY FAILURE: HIP path disagrees with the oracle")
+        if args.markers and nchk:
+            o.set_markers(*marker_arrays)
+            mstep()
+            torch.cuda.synchronize()
+            m_lo = d_lo[:nchk].cpu().numpy().view(np.uint64)
+            m_hi = d_hi[:nchk].cpu().numpy().view(np.uint64)
+            m_off = d_mk_off[:nchk + 1].cpu().numpy().view(np.uint64)
+            m_val = d_mk[:int(m_off[-1])].cpu().numpy().view(np.uint64)
+            okm = True
+            for i in range(nchk):
+                if m_val[int(m_off[i]):int(m_off[i + 1])].tolist() != o.markers_at(int(m_lo[i]), int(m_hi[i])):
+                    okm = False
+                    break
+            out["markers"]["parity"] = {"reads_checked": nchk, "markers_checked": int(m_off[-1]), "bit_exact_vs_oracle": okm}
+            if not okm:
+                print(json.dumps(out))
+                raise SystemExit("PARITY FAILURE (markers): HIP path disagrees with the oracle")
         if world == 1 and not args.no_cpu_baseline:
             # bounded sample, single thread like rb_align's serial loop (rb_align.cpp:176-178)
             probe = min(200, N)

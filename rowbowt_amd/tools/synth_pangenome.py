@@ -149,3 +149,64 @@ def sample_reads(text, info, n_reads, m, seed, sub_rate=0.1):
         lut = torch.tensor(ACGT, dtype=torch.uint8, device=dev)
         reads[idx, p] = lut[(code + sh) % 4]
     return reads, start
+
+
+def marker_array(text, info, sa, w=10):
+    """Synthetic marker array shaped like the reference's small.fa.mab: for every variant
+    site and every haplotype, the SA rows whose suffix starts within `w` bases before the site carry
+    the marker  pos | allele << 60  (allele 0 = base sequence, 1 = alternative).  Consecutive rows with
+    the same single marker are merged into one run; rows holding several markers stay runs of their
+    own.  -> numpy (run_start, run_end, mk_off, mk_vals), uint64."""
+    dev = text.device
+    n, unit, H, L = info["n"], info["unit"], info["H"], info["L"]
+    base = text[:L]
+    haps = text[: H * unit].view(H, unit)[:, :L]
+    is_site = (haps != base[None, :]).any(dim=0)
+    sites = torch.nonzero(is_site).flatten()                       # [S]
+    allele = (haps[:, sites] != base[sites][None, :]).to(torch.int64)  # [H, S]
+    isa = torch.empty(n, dtype=torch.int32, device=dev)
+    isa[sa] = torch.arange(n, dtype=torch.int32, device=dev)
+    rows_l, vals_l = [], []
+    hoff = (torch.arange(H, device=dev, dtype=torch.int64) * unit)[:, None]
+    for d in range(w):
+        p = sites - d
+        ok = p >= 0
+        t = hoff + p[None, :]                                      # [H, S] text positions
+        r = isa[t.clamp(min=0)].to(torch.int64)
+        v = sites[None, :] | (allele << 60)
+        m = ok[None, :].expand_as(r)
+        rows_l.append(r[m])
+        vals_l.append(v[m])
+    rows = torch.cat(rows_l)
+    vals = torch.cat(vals_l)
+    del rows_l, vals_l, isa
+    # sort by (row, value) and drop exact duplicates
+    order = torch.argsort(vals, stable=True)
+    rows, vals = rows[order], vals[order]
+    order = torch.argsort(rows, stable=True)
+    rows, vals = rows[order], vals[order]
+    keep = torch.ones_like(rows, dtype=torch.bool)
+    keep[1:] = (rows[1:] != rows[:-1]) | (vals[1:] != vals[:-1])
+    rows, vals = rows[keep], vals[keep]
+    urows, counts = torch.unique_consecutive(rows, return_counts=True)
+    first = torch.cumsum(counts, 0) - counts                      # index of each row's first value
+    single = counts == 1
+    v0 = vals[first]
+    # a row continues the previous run iff both hold exactly one marker, the same one, and are adjacent
+    cont = torch.zeros_like(urows, dtype=torch.bool)
+    cont[1:] = single[1:] & single[:-1] & (urows[1:] == urows[:-1] + 1) & (v0[1:] == v0[:-1])
+    run_first = torch.nonzero(~cont).flatten()
+    run_start = urows[run_first]
+    run_last = torch.empty_like(run_first)
+    run_last[:-1] = run_first[1:] - 1
+    run_last[-1] = urows.numel() - 1
+    run_end = urows[run_last]
+    run_cnt = counts[run_first]
+    mk_off = torch.zeros(run_first.numel() + 1, dtype=torch.int64, device=dev)
+    mk_off[1:] = torch.cumsum(run_cnt, 0)
+    # values of a run = the values of its first row
+    src = torch.repeat_interleave(first[run_first], run_cnt) + (torch.arange(int(mk_off[-1].item()), device=dev) -
+                                                                 torch.repeat_interleave(mk_off[:-1], run_cnt))
+    mk_vals = vals[src]
+    u = lambda x: x.cpu().numpy().astype(np.uint64)
+    return u(run_start), u(run_end), u(mk_off), u(mk_vals)

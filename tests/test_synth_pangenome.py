@@ -39,3 +39,33 @@ def test_index_inputs_and_reads_through_oracle():
             assert o.locs_at(int(lo[i]), int(hi[i]), int(k[i])) == fm.locs(int(lo[i]), int(hi[i]))
     assert 250 < matched < 400
     o.close()
+
+
+def test_marker_array_builder_matches_loop_version():
+    """The vectorised marker-array synthesiser against a plain-loop construction (same rule as
+    tests/test_gpu_parity.py::test_midscale_pangenome_all_queries)."""
+    text, info = sp.make_text(1500, 5, 0.02, 11, "cpu")
+    sa = sp.suffix_array(text)
+    rs, re_, mo, mv = sp.marker_array(text, info, sa, w=6)
+    n, unit, H, L = info["n"], info["unit"], info["H"], info["L"]
+    t = text.numpy()
+    isa = np.empty(n, dtype=np.int64)
+    isa[sa.numpy()] = np.arange(n)
+    base = t[:L]
+    sites = np.flatnonzero((t[: H * unit].reshape(H, unit)[:, :L] != base[None, :]).any(axis=0))
+    tags = {}
+    for h in range(H):
+        for s in sites:
+            a = int(t[h * unit + s] != base[s])
+            for d in range(6):
+                if s - d >= 0:
+                    tags.setdefault(int(isa[h * unit + s - d]), set()).add(int(s) | (a << 60))
+    ws, we, wo, wv = [], [], [0], []
+    for r in sorted(tags):
+        vals = sorted(tags[r])
+        if ws and we[-1] == r - 1 and len(vals) == 1 and wv[wo[-2]:wo[-1]] == vals:
+            we[-1] = r
+        else:
+            ws.append(r); we.append(r); wv += vals; wo.append(len(wv))
+    assert rs.tolist() == ws and re_.tolist() == we and mo.tolist() == wo and mv.tolist() == wv
+    assert (rs[1:] > re_[:-1]).all()
