@@ -159,6 +159,23 @@ int rbg_markers_at(rbg_index *, const uint64_t *lo, const uint64_t *hi, uint64_t
 int rbg_find_range_w_markers(rbg_index *, const uint8_t *seqs, const uint64_t *off, uint64_t N,
                              uint64_t wsize, uint64_t max_range,
                              uint64_t *lo, uint64_t *hi, uint64_t *mk_off, uint64_t **mk);
+/* Next-row f4 (marker seeds).  RowBowt::get_markers_greedy_seeding(query, wsize, max_range, fn),
+ * rowbowt.hpp:406-482, in the form rb_markers runs it (no ftab: rb_markers.cpp:25,411-413): one
+ * record per call of the callback fn(range, (q.first, q.second), mbuf), in call order.  The
+ * markers are NOT sorted or deduplicated (the caller's out_fn does that, rb_markers.cpp:374-380).
+ * Works without a marker array too (every mbuf empty), like the reference (:273, :283). */
+typedef struct rbg_marker_seed {
+    uint64_t lo, hi;     /* range passed to fn (never empty in this variant) */
+    uint64_t qstart;     /* q.first */
+    uint64_t qend;       /* q.second + 1 (exclusive end; q.second itself wraps for an empty seed) */
+    uint64_t mk_begin;   /* this seed's mbuf = mk[mk_begin, mk_end) */
+    uint64_t mk_end;
+} rbg_marker_seed_t;
+/* seed_off[N+1] written; *seeds (seed_off[N] records) and *mk are malloc()ed by the library:
+ * release both with rbg_free_buffer. */
+int rbg_get_markers_greedy_seeding(rbg_index *, const uint8_t *seqs, const uint64_t *off, uint64_t N,
+                                   uint64_t wsize, uint64_t max_range,
+                                   uint64_t *seed_off, rbg_marker_seed_t **seeds, uint64_t **mk);
 /* Next-row f4 (greedy seeding).  RowBowt::get_seeds_greedy_w_sample(query, min_length),
  * rowbowt.hpp:222-256, reduced by the choice locate_from_longest_seed makes (rowbowt.hpp:669-677):
  * per read the FIRST seed of strictly greatest length, as LFData {rn, qstart, qend, ssamp}; a read
@@ -205,6 +222,14 @@ int rbg_locate_fill_offset_dev(rbg_index *, const uint64_t *d_lo, const uint64_t
 int rbg_greedy_longest_seed_dev(rbg_index *, const uint8_t *d_seqs, const uint64_t *d_off, uint64_t N, uint64_t min_length,
                                 uint64_t *d_lo, uint64_t *d_hi, uint64_t *d_qstart, uint64_t *d_qend, uint64_t *d_ssamp,
                                 void *stream);
+/* marker seeds, two-phase: plan writes the exclusive scans d_seed_off[N+1] (records per read) and
+ * d_mk_off[N+1] (markers per read); the caller sizes d_seeds / d_mk from their last entries. */
+int rbg_marker_seeds_plan_dev(rbg_index *, const uint8_t *d_seqs, const uint64_t *d_off, uint64_t N, uint64_t wsize,
+                              uint64_t max_range, uint64_t *d_seed_off, uint64_t *d_mk_off, void *d_tmp, size_t tmp_bytes,
+                              void *stream);
+int rbg_marker_seeds_fill_dev(rbg_index *, const uint8_t *d_seqs, const uint64_t *d_off, uint64_t N, uint64_t wsize,
+                              uint64_t max_range, const uint64_t *d_seed_off, const uint64_t *d_mk_off,
+                              rbg_marker_seed_t *d_seeds, uint64_t *d_mk, void *stream);
 /* markers, same two-phase shape */
 int rbg_markers_plan_dev(rbg_index *, const uint64_t *d_lo, const uint64_t *d_hi, uint64_t N,
                          uint64_t *d_mk_off, void *d_tmp, size_t tmp_bytes, void *stream);

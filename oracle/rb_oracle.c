@@ -519,6 +519,57 @@ uint64_t orc_find_range_w_markers(const orc_index *x, const uint8_t *q, uint64_t
     return total;
 }
 
+/* rowbowt.hpp:406-482 with ft_ == nullptr.  mbuf is appended to by every update_mbuf (markers_at
+ * does not clear, :271-285, :437-441) and cleared only after a failed seed was reported (:449). */
+uint64_t orc_markers_greedy_seeding(const orc_index *x, const uint8_t *q, uint64_t m, uint64_t wsize, uint64_t max_range,
+                                    uint64_t *seeds, uint64_t cap_seeds, uint64_t *mk_out, uint64_t cap_mk, uint64_t *nmk) {
+    const uint64_t fl = 0, fh = x->n - 1;          /* full_range(), :115-118 */
+    uint64_t l = fl, h = fh, pl = fl, ph = fh;     /* range, prev_range :427-428 */
+    uint64_t window_ei = m, seed_ei = m;           /* :434 */
+    uint64_t ns = 0, tot = 0, mb_begin = 0;        /* mbuf == markers [mb_begin, tot) */
+#define UPDATE_MBUF(L_, H_)                                                                \
+    do {                                                                                   \
+        if ((H_) - (L_) + 1 <= max_range) {                                                \
+            uint64_t c_ = orc_markers_at(x, (L_), (H_), NULL);                             \
+            if (c_ && mk_out && tot + c_ <= cap_mk) orc_markers_at(x, (L_), (H_), mk_out + tot); \
+            tot += c_;                                                                     \
+        }                                                                                  \
+    } while (0)
+#define EMIT(L_, H_, QS_, QE_)                                                             \
+    do {                                                                                   \
+        if (seeds && ns < cap_seeds) {                                                     \
+            uint64_t *d_ = seeds + 6 * ns;                                                 \
+            d_[0] = (L_); d_[1] = (H_); d_[2] = (QS_); d_[3] = (QE_); d_[4] = mb_begin; d_[5] = tot; \
+        }                                                                                  \
+        ++ns;                                                                              \
+    } while (0)
+    uint64_t i;
+    for (i = 0; i < m; ++i) {
+        orc_LF(x, l, h, q[m - i - 1], &l, &h);     /* :443 */
+        if (h < l) {                               /* :444 the seed fails */
+            if (seed_ei - (m - i) >= wsize) UPDATE_MBUF(pl, ph);   /* :445-447 */
+            EMIT(pl, ph, m - i, seed_ei);          /* :448 fn(prev_range, (m-i, seed_ei-1), mbuf) */
+            mb_begin = tot;                        /* :449 mbuf.clear() */
+            pl = fl; ph = fh;                      /* :450 */
+            seed_ei = m - i - 1;                   /* :452-453 */
+            window_ei = m - i - 1;
+            l = fl; h = fh;                        /* :466 */
+        } else {
+            if (window_ei - (m - i - 1) >= wsize) {    /* :469-472 */
+                UPDATE_MBUF(l, h);
+                window_ei = m - i - 1;
+            }
+            pl = l; ph = h;                        /* :473 */
+        }
+    }
+    if (h >= l && seed_ei - (m - i) >= wsize) UPDATE_MBUF(l, h);   /* :478-480 */
+    EMIT(l, h, m - i, seed_ei);                    /* :481 */
+#undef UPDATE_MBUF
+#undef EMIT
+    if (nmk) *nmk = tot;
+    return ns;
+}
+
 /* rowbowt.hpp:222-256 + :664-685 */
 uint64_t orc_greedy_locate(const orc_index *x, const uint8_t *q, uint64_t m, uint64_t min_length, uint64_t max_hits,
                            uint64_t *out, uint64_t cap,

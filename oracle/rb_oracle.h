@@ -92,6 +92,14 @@ uint64_t orc_find_range_w_markers(const orc_index *, const uint8_t *q, uint64_t 
 uint64_t orc_greedy_locate(const orc_index *, const uint8_t *q, uint64_t m, uint64_t min_length, uint64_t max_hits,
                            uint64_t *out, uint64_t cap,
                            uint64_t *seed_lo, uint64_t *seed_hi, uint64_t *seed_qs, uint64_t *seed_qe, uint64_t *seed_k);
+/* rowbowt.hpp:406-482 get_markers_greedy_seeding, the variant without an ftab (rb_markers' default,
+ * rb_markers.cpp:25,411-413).  One record per call of the callback `fn`, in call order:
+ * seeds[6*s..] = {range lo, range hi, q.first, q.second + 1 (= seed_ei, exclusive; q.second itself
+ * wraps when the seed is empty), first marker, one-past-last marker} (marker indices into mk_out,
+ * relative to this read).  Writes at most cap_seeds records / cap_mk markers; returns the number
+ * of records, *nmk = number of markers. */
+uint64_t orc_markers_greedy_seeding(const orc_index *, const uint8_t *q, uint64_t m, uint64_t wsize, uint64_t max_range,
+                                    uint64_t *seeds, uint64_t cap_seeds, uint64_t *mk_out, uint64_t cap_mk, uint64_t *nmk);
 /* rowbowt.hpp:623-625 -> doclist.hpp:46-50.  Returns pointer to the doc name (owned by index), offset in *off. */
 const char *orc_resolve_offset(const orc_index *, uint64_t i, uint64_t *off);
 

@@ -69,6 +69,7 @@ _PROTOS = [
     ("rbg_locs_at", C.c_int, [VP, VP, VP, VP, U64, U64, VP, C.POINTER(VP)]),
     ("rbg_markers_at", C.c_int, [VP, VP, VP, U64, VP, C.POINTER(VP)]),
     ("rbg_find_range_w_markers", C.c_int, [VP, VP, VP, U64, U64, U64, VP, VP, VP, C.POINTER(VP)]),
+    ("rbg_get_markers_greedy_seeding", C.c_int, [VP, VP, VP, U64, U64, U64, VP, C.POINTER(VP), C.POINTER(VP)]),
     ("rbg_greedy_longest_seed", C.c_int, [VP, VP, VP, U64, U64, VP, VP, VP, VP, VP]),
     ("rbg_find_locs_greedy_seeding", C.c_int, [VP, VP, VP, U64, U64, U64, VP, C.POINTER(VP)]),
     ("rbg_free_buffer", None, [VP]),
@@ -82,6 +83,8 @@ _PROTOS = [
     ("rbg_locate_fill_dev", C.c_int, [VP, VP, VP, VP, U64, U64, VP, VP, VP, VP]),
     ("rbg_locate_fill_offset_dev", C.c_int, [VP, VP, VP, VP, U64, U64, VP, VP, VP, VP, VP]),
     ("rbg_greedy_longest_seed_dev", C.c_int, [VP, VP, VP, U64, U64, VP, VP, VP, VP, VP, VP]),
+    ("rbg_marker_seeds_plan_dev", C.c_int, [VP, VP, VP, U64, U64, U64, VP, VP, VP, C.c_size_t, VP]),
+    ("rbg_marker_seeds_fill_dev", C.c_int, [VP, VP, VP, U64, U64, U64, VP, VP, VP, VP, VP]),
     ("rbg_markers_plan_dev", C.c_int, [VP, VP, VP, U64, VP, VP, C.c_size_t, VP]),
     ("rbg_markers_fill_dev", C.c_int, [VP, VP, VP, U64, VP, VP, VP]),
     ("rbg_counters", C.c_int, [VP, VP]),
@@ -265,6 +268,19 @@ class RowBowt:
         _check(self.L.rbg_find_range_w_markers(self.h, _p(seqs), _p(off), N, wsize, max_range & MAXU,
                                                _p(lo), _p(hi), _p(mk_off), C.byref(ptr)), "rbg_find_range_w_markers")
         return lo, hi, mk_off, _take(ptr, int(mk_off[N]))
+
+    def get_markers_greedy_seeding(self, seqs, off, wsize, max_range=MAXU):
+        """RowBowt::get_markers_greedy_seeding without ftab (rowbowt.hpp:406-482): -> seed_off[N+1],
+        seeds[S,6] = (lo, hi, qstart, qend, mk_begin, mk_end), mk"""
+        N = len(off) - 1
+        seed_off = np.zeros(N + 1, np.uint64)
+        ps, pm = VP(), VP()
+        _check(self.L.rbg_get_markers_greedy_seeding(self.h, _p(seqs), _p(off), N, wsize, max_range & MAXU, _p(seed_off),
+                                                     C.byref(ps), C.byref(pm)), "rbg_get_markers_greedy_seeding")
+        S = int(seed_off[N])
+        seeds = _take(ps, 6 * S).reshape(S, 6)
+        nmk = int(seeds[-1, 5]) if S else 0
+        return seed_off, seeds, _take(pm, nmk)
 
     def greedy_longest_seed(self, seqs, off, min_length):
         """get_seeds_greedy_w_sample (rowbowt.hpp:222-256) -> the seed locate_from_longest_seed picks (:669-677)"""

@@ -1,0 +1,117 @@
+// Host ingest shared by the command-line tools (next-row f2): a block-buffered FASTA/FASTQ reader
+// with kseq_read's observable behaviour (reference include/kseq.h:178-219), appending straight into
+// the C-ABI's packed batch layout.
+#pragma once
+#include <zlib.h>
+
+#include <cctype>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace rbg_cli {
+
+// One batch of reads in the C-ABI's layout (names kept the same way)
+struct PackedBatch {
+    std::string names, seqs;
+    std::vector<uint64_t> name_off{0}, off{0};
+    size_t size() const { return off.size() - 1; }
+    void clear() { names.clear(); seqs.clear(); name_off.assign(1, 0); off.assign(1, 0); }
+};
+
+// FASTA/FASTQ reader with kseq_read's observable behaviour (kseq.h:178-219), block-buffered over
+// gzread and appending straight into a PackedBatch (no per-read strings)
+class FastxReader {
+   public:
+    explicit FastxReader(gzFile fp) : fp_(fp), buf_(1 << 22) {}
+    // 0 = record appended, -1 = EOF, -2 = truncated quality string, -3 = stream error
+    int next(PackedBatch &b) {
+        int c;
+        if (last_char_ == 0) {  // jump to the next header character (kseq.h:183-187)
+            while ((c = getc()) >= 0 && c != '>' && c != '@') {}
+            if (c < 0) return c;
+            last_char_ = c;
+        }
+        // name = up to the first whitespace; rest of the line is the comment (kseq.h:189-190)
+        bool in_name = true, got_any = false;
+        while ((c = getc()) >= 0 && c != '\n') {
+            got_any = true;
+            if (in_name && !isspace(c)) b.names.push_back(static_cast<char>(c));
+            else in_name = false;
+        }
+        if (c < 0 && !got_any) return c == -3 ? -3 : -1;
+        b.name_off.push_back(b.names.size());
+        // sequence lines until a line starting with '>', '+' or '@' (kseq.h:195-199)
+        const size_t seq_begin = b.seqs.size();
+        while ((c = getc()) >= 0 && c != '>' && c != '+' && c != '@') {
+            if (c == '\n') continue;
+            b.seqs.push_back(static_cast<char>(c));
+            read_line_into(b.seqs, seq_begin);
+        }
+        last_char_ = (c == '>' || c == '@') ? c : 0;
+        const size_t seq_len = b.seqs.size() - seq_begin;
+        b.off.push_back(b.seqs.size());
+        if (c != '+') return c == -3 ? -3 : 0;  // FASTA
+        while ((c = getc()) >= 0 && c != '\n') {}  // rest of the '+' line
+        if (c < 0) return -2;                      // no quality string
+        size_t qlen = 0;
+        qual_.clear();
+        do {  // kseq.h:212: at least one line, then until the quality is as long as the sequence
+            const size_t before = qual_.size();
+            if (!read_line_into(qual_, 0)) break;
+            qlen += qual_.size() - before;
+        } while (qlen < seq_len);
+        last_char_ = 0;
+        return qlen == seq_len ? 0 : -2;
+    }
+
+   private:
+    int getc() {
+        if (begin_ >= end_) {
+            if (eof_) return -1;
+            const int got = gzread(fp_, buf_.data(), static_cast<unsigned>(buf_.size()));
+            if (got < 0) { eof_ = true; return -3; }
+            if (got == 0) { eof_ = true; return -1; }
+            begin_ = 0;
+            end_ = static_cast<size_t>(got);
+        }
+        return static_cast<unsigned char>(buf_[begin_++]);
+    }
+    // ks_getuntil2(KS_SEP_LINE, append): rest of the current line without '\n'; a trailing '\r' is
+    // dropped when the string is longer than one byte (kseq.h:141).  false = nothing read at EOF.
+    bool read_line_into(std::string &str, size_t str_begin) {
+        bool got_any = false;
+        while (true) {
+            if (begin_ >= end_) {
+                const int c = getc();
+                if (c < 0) break;
+                --begin_;
+            }
+            const char *p = buf_.data() + begin_;
+            const char *nl = static_cast<const char *>(memchr(p, '\n', end_ - begin_));
+            const size_t take = nl ? static_cast<size_t>(nl - p) : end_ - begin_;
+            str.append(p, take);
+            got_any = true;
+            begin_ += take + (nl ? 1 : 0);
+            if (nl) break;
+        }
+        if (str.size() - str_begin > 1 && str.back() == '\r') str.pop_back();
+        return got_any;
+    }
+    gzFile fp_;
+    std::vector<char> buf_;
+    size_t begin_ = 0, end_ = 0;
+    bool eof_ = false;
+    int last_char_ = 0;
+    std::string qual_;
+};
+
+inline void put_u64(std::string &out, uint64_t v) {
+    char tmp[24];
+    int n = 0;
+    do { tmp[n++] = static_cast<char>('0' + v % 10); v /= 10; } while (v);
+    while (n) out.push_back(tmp[--n]);
+}
+
+}  // namespace rbg_cli

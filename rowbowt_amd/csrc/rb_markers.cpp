@@ -1,0 +1,399 @@
+// rb_markers -- drop-in for the reference's marker genotyping tool
+//   rb_markers [--wsize N] [--max-range N] [--min-range N] [--heuristic ...] <index_prefix> <fastq>
+// (reference src/rb_markers.cpp) in its default seeding mode: get_markers_greedy_seeding without an
+// ftab on the read and on its reverse complement (rb_markers.cpp:396-413).  The per-read work of the
+// reference's thread pool (rb_markers.cpp:318-535) becomes one batched call into the MI355X engine
+// (rbg_get_markers_greedy_seeding, include/rbg.h) over 2N sequences; what the reference's callback
+// and worker do afterwards (sort/unique the markers, the seed filters, the text) runs on host
+// threads, in read order -- the order the reference produces with --threads 1.
+//
+// One stdout line per seed (rb_markers.cpp:253-262):
+//   "<name> <range_size> <+|-> <query_start> <query_len>" { " <seq>/<pos>/<allele>" | " ." } "\n"
+//
+// Not carried over (each exits 1 with a message, like the reference does for --overlap):
+//   --ftab/-f   the reference's ftab-seeded variant (rowbowt.hpp:430-433, :454-464) finds different
+//               seeds; only the default no-ftab path is built here
+//   --lmem      needs the ftab (rowbowt.hpp:346-349 exits 1 without it)
+//   --fbb/-x    other string type, other index file
+#include <getopt.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <future>
+#include <random>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../include/rowbowt_gpu.hpp"
+#include "fastx.hpp"
+
+namespace {
+
+using rbg_cli::FastxReader;
+using rbg_cli::PackedBatch;
+using rbg_cli::put_u64;
+
+struct RbMarkersArgs {  // rb_markers.cpp:22-40
+    std::string inpre, fastq_fname;
+    int ftab = 0, fbb = 0, overlap = 0, lmem = 0;
+    uint64_t wsize = 19, max_range = 1000, min_range = 0;
+    uint64_t threads = 1, max_tasks = 1024, read_len = 101, min_seed_len = 0;
+    int clear_conflicting = 0, clear_identical = 0, best_strand = 0, heuristic = 0;
+    int device = 0;
+    uint64_t batch = 1u << 19;
+};
+
+void print_help() {  // rb_markers.cpp:44-54
+    fprintf(stderr, "rb_markers\n");
+    fprintf(stderr, "Usage: rb_markers_only [options] <index_prefix> <input_fastq_name>\n");
+    fprintf(stderr, "    --wsize            <int>         window size for performing marker queries along read\n");
+    fprintf(stderr, "    --max-range        <int>         range-size upper threshold for performing marker queries\n");
+    fprintf(stderr, "    --min-range        <int>         range-size lower threshold for reporting markers\n");
+    fprintf(stderr, "    --threads          <int>         host threads formatting the output\n");
+    fprintf(stderr, "    --heuristic [--best-strand-only] [--min-seed-length <int>] [--read-len <int>]\n");
+    fprintf(stderr, "                [--clear-conflicting] [--clear-identical]\n");
+    fprintf(stderr, "    --gpu <n>                        HIP device ordinal (default 0)\n");
+    fprintf(stderr, "    --batch <n>                      reads per GPU batch (default 524288)\n");
+    fprintf(stderr, "    <input_prefix>                   index prefix\n");
+    fprintf(stderr, "    <input_fastq>                    input fastq\n");
+}
+
+RbMarkersArgs parse_args(int argc, char **argv) {  // rb_markers.cpp:56-134
+    static RbMarkersArgs args;
+    static struct option long_options[] = {{"wsize", required_argument, 0, 'w'},
+                                           {"max-range", required_argument, 0, 'r'},
+                                           {"min-range", required_argument, 0, 'm'},
+                                           {"threads", required_argument, 0, 't'},
+                                           {"max-tasks", required_argument, 0, 'u'},
+                                           {"read-len", required_argument, 0, 'l'},
+                                           {"fbb", no_argument, &args.fbb, 1},
+                                           {"ftab", no_argument, &args.ftab, 1},
+                                           {"overlap", no_argument, &args.overlap, 1},
+                                           {"lmem", no_argument, &args.lmem, 1},
+                                           {"heuristic", no_argument, &args.heuristic, 1},
+                                           {"best-strand-only", no_argument, &args.best_strand, 1},
+                                           {"min-seed-length", required_argument, 0, 'y'},
+                                           {"clear-conflicting", no_argument, &args.clear_conflicting, 1},
+                                           {"clear-identical", no_argument, &args.clear_identical, 1},
+                                           {"gpu", required_argument, 0, 'G'},
+                                           {"batch", required_argument, 0, 'B'},
+                                           {0, 0, 0, 0}};
+    int c, long_index = 0;
+    // "o:" is accepted by the reference's optstring but has no case: it ends in the default branch
+    while ((c = getopt_long(argc, argv, "o:w:r:hft:m:u:xl:y:", long_options, &long_index)) != -1) {
+        switch (c) {
+            case 0: break;
+            case 'y': args.min_seed_len = static_cast<uint64_t>(std::atol(optarg)); break;
+            case 'l': args.read_len = static_cast<uint64_t>(std::atol(optarg)); break;
+            case 't': args.threads = static_cast<uint64_t>(std::atol(optarg)); break;
+            case 'u': args.max_tasks = static_cast<uint64_t>(std::atol(optarg)); break;
+            case 'f': args.ftab = 1; break;
+            case 'r': args.max_range = static_cast<uint64_t>(std::atol(optarg)); break;
+            case 'm': args.min_range = static_cast<uint64_t>(std::atol(optarg)); break;
+            case 'w': args.wsize = static_cast<uint64_t>(std::atol(optarg)); break;
+            case 'h': print_help(); exit(0);
+            case 'x': args.fbb = 1; break;
+            case 'G': args.device = atoi(optarg); break;
+            case 'B': args.batch = strtoull(optarg, nullptr, 10); break;
+            default: print_help(); exit(1);
+        }
+    }
+    if (args.overlap) {  // rb_markers.cpp:121-124
+        fprintf(stderr, "overlapped seeds currently broken\n");
+        exit(1);
+    }
+    if (args.lmem) {  // without an ftab the reference stops at rowbowt.hpp:346-349
+        fprintf(stderr, "ftab must be enabled!\n");
+        exit(1);
+    }
+    if (args.ftab) {
+        fprintf(stderr, "rb_markers: the ftab-seeded variant (--ftab) is not built in this engine; run without it\n");
+        exit(1);
+    }
+    if (args.fbb) {
+        fprintf(stderr, "rb_markers: --fbb indexes are not supported by this engine\n");
+        exit(1);
+    }
+    if (argc - optind < 2) {
+        fprintf(stderr, "no argument provided\n");
+        exit(1);
+    }
+    args.inpre = argv[optind++];
+    args.fastq_fname = argv[optind++];
+    if (args.batch == 0) args.batch = 1;
+    if (args.threads == 0) args.threads = 1;
+    return args;
+}
+
+// seqtk's nt->ACGT table as rb_markers.cpp:139-156 carries it: A/C/G/T in either case keep their
+// base, 'N' and 'n' become 'A' (sic), every other byte becomes 'N'.
+struct NtTable {
+    uint8_t t[256];
+    NtTable() {
+        memset(t, 'N', sizeof t);
+        t['A'] = t['a'] = 'A';
+        t['C'] = t['c'] = 'C';
+        t['G'] = t['g'] = 'G';
+        t['T'] = t['t'] = 'T';
+        t['N'] = t['n'] = 'A';
+    }
+};
+const NtTable kNt;
+
+// complement of the five letters the table above can produce (comp_tab, rb_markers.cpp:159-168)
+inline char comp(char c) {
+    switch (c) {
+        case 'A': return 'T';
+        case 'C': return 'G';
+        case 'G': return 'C';
+        case 'T': return 'A';
+        default: return c;
+    }
+}
+
+bool marker_cmp(MarkerT a, MarkerT b) {  // rb_markers.cpp:228-236
+    if (get_seq(a) != get_seq(b)) return get_seq(a) < get_seq(b);
+    if (get_pos(a) != get_pos(b)) return get_pos(a) < get_pos(b);
+    return get_allele(a) < get_allele(b);
+}
+
+enum class Strand { FWD, REV };
+
+struct MarkerSeed {  // rb_markers.cpp:245-285
+    Strand strand = Strand::FWD;
+    uint64_t range_size = 0, query_start = 0, query_len = 0;
+    std::vector<MarkerT> markers;
+
+    // keeps only markers whose (seq,pos) no neighbour shares; assumes sorted (rb_markers.cpp:266-276).
+    // pm starts as marker 0, so a leading marker at seq 0 / pos 0 is dropped too, as in the reference.
+    void filter_identical_pos() {
+        if (markers.empty()) return;
+        std::vector<MarkerT> kept;
+        MarkerT pm = 0;
+        for (size_t i = 0; i < markers.size(); ++i) {
+            const MarkerT m = markers[i];
+            bool drop = get_seq(m) == get_seq(pm) && get_pos(m) == get_pos(pm);
+            if (!drop) {
+                pm = m;
+                drop = i + 1 < markers.size() && get_seq(markers[i + 1]) == get_seq(m) && get_pos(markers[i + 1]) == get_pos(m);
+            }
+            if (!drop) kept.push_back(m);
+        }
+        markers.swap(kept);
+    }
+    void clear_if_conflicting(uint64_t read_len) {  // rb_markers.cpp:279-284
+        if (markers.empty()) return;
+        if (get_seq(markers.back()) != get_seq(markers.front()) || get_pos(markers.back()) - get_pos(markers.front()) >= read_len)
+            markers.clear();
+    }
+};
+
+void print_seed(std::string &out, const char *name, size_t name_len, const MarkerSeed &ms) {  // print_buf, :253-262
+    out.append(name, name_len);
+    out.push_back(' ');
+    put_u64(out, ms.range_size);
+    out += ms.strand == Strand::FWD ? " + " : " - ";
+    put_u64(out, ms.query_start);
+    out.push_back(' ');
+    put_u64(out, ms.query_len);
+    if (!ms.markers.empty()) {
+        for (const MarkerT m : ms.markers) {
+            out.push_back(' ');
+            put_u64(out, get_seq(m));
+            out.push_back('/');
+            put_u64(out, get_pos(m));
+            out.push_back('/');
+            put_u64(out, get_allele(m));
+        }
+    } else {
+        out += " .";
+    }
+    out.push_back('\n');
+}
+
+struct BatchSeeds {
+    std::vector<uint64_t> seed_off;  // 2N+1: sequence 2i = read i forward, 2i+1 = its reverse complement
+    rbg_marker_seed_t *seeds = nullptr;
+    uint64_t *mk = nullptr;
+    ~BatchSeeds() { rbg_free_buffer(seeds); rbg_free_buffer(mk); }
+};
+
+// the reference's out_fn (rb_markers.cpp:365-382 / :439-464) for one callback record
+MarkerSeed make_seed(const RbMarkersArgs &args, const BatchSeeds &r, const rbg_marker_seed_t &s, Strand strand, uint64_t seq_len) {
+    MarkerSeed ms;
+    ms.strand = strand;
+    ms.range_size = s.hi - s.lo + 1;
+    ms.query_start = strand == Strand::REV ? seq_len - s.qstart - 1 : s.qstart;
+    ms.query_len = s.qend - s.qstart;  // q.second - q.first + 1
+    if (ms.range_size >= args.min_range && s.mk_end > s.mk_begin) {
+        ms.markers.assign(r.mk + s.mk_begin, r.mk + s.mk_end);
+        std::sort(ms.markers.begin(), ms.markers.end(), marker_cmp);
+        ms.markers.erase(std::unique(ms.markers.begin(), ms.markers.end()), ms.markers.end());
+    }
+    return ms;
+}
+
+// text for reads [i0, i1); first_fwd[i] is the heuristic worker's coin for read i
+void format_range(const RbMarkersArgs &args, const PackedBatch &b, const BatchSeeds &r, const std::vector<uint8_t> &first_fwd,
+                  size_t i0, size_t i1, std::string &out) {
+    std::vector<MarkerSeed> seeds;
+    for (size_t i = i0; i < i1; ++i) {
+        const char *name = b.names.data() + b.name_off[i];
+        const size_t name_len = b.name_off[i + 1] - b.name_off[i];
+        const uint64_t seq_len = b.off[i + 1] - b.off[i];
+        seeds.clear();
+        if (!args.heuristic) {  // worker, rb_markers.cpp:357-428: forward, then reverse complement
+            for (int st = 0; st < 2; ++st)
+                for (uint64_t s = r.seed_off[2 * i + st]; s < r.seed_off[2 * i + st + 1]; ++s)
+                    seeds.push_back(make_seed(args, r, r.seeds[s], st ? Strand::REV : Strand::FWD, seq_len));
+        } else {  // worker_heuristic, rb_markers.cpp:429-519
+            bool stop = false;
+            for (int pass = 0; pass < 2 && !stop; ++pass) {
+                const bool fwd = (pass == 0) == (first_fwd[i] != 0);
+                const int st = fwd ? 0 : 1;
+                for (uint64_t s = r.seed_off[2 * i + st]; s < r.seed_off[2 * i + st + 1]; ++s) {
+                    MarkerSeed ms = make_seed(args, r, r.seeds[s], fwd ? Strand::FWD : Strand::REV, seq_len);
+                    if (ms.query_len < args.min_seed_len) {  // :447 (before any marker work; same result)
+                        continue;
+                    }
+                    if (args.clear_conflicting) ms.clear_if_conflicting(args.read_len);
+                    if (args.clear_identical) ms.filter_identical_pos();
+                    // :460: not enough useful sequence left over (unsigned arithmetic as in the reference)
+                    if (args.best_strand && args.read_len - (ms.query_start + ms.query_len) < args.min_seed_len) stop = true;
+                    seeds.push_back(std::move(ms));
+                }
+                // `stop` is only looked at between the two strands (:499-502)
+            }
+            if (args.best_strand && !seeds.empty()) {  // keep_seeds_best_strand, :292-297, :308-314
+                auto best = std::max_element(seeds.begin(), seeds.end(),
+                                             [](const MarkerSeed &l, const MarkerSeed &r2) { return l.query_len < r2.query_len; });
+                const Strand keep = best->strand;
+                seeds.erase(std::remove_if(seeds.begin(), seeds.end(), [&](const MarkerSeed &ms) { return ms.strand != keep; }), seeds.end());
+            }
+            if (args.min_seed_len)  // keep_seeds_by_len, :299-303
+                seeds.erase(std::remove_if(seeds.begin(), seeds.end(), [&](const MarkerSeed &ms) { return ms.query_len < args.min_seed_len; }),
+                            seeds.end());
+        }
+        for (const MarkerSeed &ms : seeds) print_seed(out, name, name_len, ms);
+    }
+}
+
+// forward (through the nt table) and reverse-complement copies of every read, interleaved
+void make_strands(const PackedBatch &b, std::string &seqs, std::vector<uint64_t> &off) {
+    const size_t N = b.size();
+    seqs.resize(2 * b.seqs.size());
+    off.resize(2 * N + 1);
+    off[0] = 0;
+    for (size_t i = 0; i < N; ++i) {
+        const size_t beg = b.off[i], len = b.off[i + 1] - beg;
+        char *f = &seqs[2 * beg], *rc = f + len;
+        for (size_t t = 0; t < len; ++t) f[t] = static_cast<char>(kNt.t[static_cast<uint8_t>(b.seqs[beg + t])]);
+        for (size_t t = 0; t < len; ++t) rc[t] = comp(f[len - 1 - t]);  // revc_in_place, rb_markers.cpp:189-198
+        off[2 * i + 1] = 2 * beg + len;
+        off[2 * i + 2] = 2 * beg + 2 * len;
+    }
+}
+
+// std::mt19937 with its default seed, one bit per read, low bit first (RandomBoolGenerator, :210-225)
+struct RandomBoolGenerator {
+    bool get_bool() {
+        if (bit_count == 0) {
+            data = static_cast<uint32_t>(rng());
+            bit_count = 32;
+        }
+        const bool bit = data & 1;
+        data >>= 1;
+        bit_count--;
+        return bit;
+    }
+    std::mt19937 rng;
+    uint32_t data = 0;
+    int bit_count = 0;
+};
+
+void report_batch(const rbwt::RowBowt<> &rb, const RbMarkersArgs &args, const PackedBatch &b, RandomBoolGenerator &booler,
+                  std::vector<std::string> &pieces) {
+    const size_t N = b.size();
+    std::string seqs;
+    std::vector<uint64_t> off;
+    make_strands(b, seqs, off);
+    BatchSeeds r;
+    r.seed_off.resize(2 * N + 1);
+    rbwt::detail::check(rbg_get_markers_greedy_seeding(rb.handle(), reinterpret_cast<const uint8_t *>(seqs.data()), off.data(), 2 * N,
+                                                       args.wsize, args.max_range, r.seed_off.data(), &r.seeds, &r.mk),
+                        "rbg_get_markers_greedy_seeding");
+    std::vector<uint8_t> first_fwd(N, 1);
+    if (args.heuristic)
+        for (size_t i = 0; i < N; ++i) first_fwd[i] = booler.get_bool() ? 1 : 0;  // :483
+    const size_t T = std::max<size_t>(1, std::min<size_t>({static_cast<size_t>(args.threads), (N + 4095) / 4096, size_t(64)}));
+    pieces.assign(T, std::string());
+    std::vector<std::thread> workers;
+    for (size_t t = 1; t < T; ++t)
+        workers.emplace_back([&, t] { format_range(args, b, r, first_fwd, N * t / T, N * (t + 1) / T, pieces[t]); });
+    format_range(args, b, r, first_fwd, 0, N / T, pieces[0]);
+    for (auto &w : workers) w.join();
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+    const RbMarkersArgs args = parse_args(argc, argv);
+    auto start = std::chrono::high_resolution_clock::now();
+    std::cerr << "(rle_string_sd) loading rowbowt + markers" << std::endl;  // rb_markers.cpp:553-557
+    rbwt::RowBowt<> rb = rbwt::load_rowbowt<>(args.inpre, rbwt::LoadRbwtFlag::MA, args.device);  // :541-546
+    auto stop = std::chrono::high_resolution_clock::now();
+    std::chrono::duration<double> diff = stop - start;
+    std::cerr << "loading rowbowt + markers took: " << diff.count() << " seconds\n";
+
+    start = std::chrono::high_resolution_clock::now();
+    gzFile fq_fp = gzopen(args.fastq_fname.data(), "r");  // :568-572
+    if (fq_fp == NULL) {
+        fprintf(stderr, "invalid file\n");
+        exit(1);
+    }
+    gzbuffer(fq_fp, 1 << 20);
+    FastxReader reader(fq_fp);
+    RandomBoolGenerator booler;
+    int err = 0;
+    auto parse = [&](PackedBatch &b) {
+        b.clear();
+        int e = 0;
+        while (b.size() < args.batch && (e = reader.next(b)) == 0) {}
+        return e;
+    };
+    PackedBatch cur, nxt;
+    err = parse(cur);
+    std::future<void> writer;
+    std::vector<std::string> pieces, writing;
+    while (cur.size() > 0) {
+        std::future<int> parser;
+        const bool more = err == 0;
+        if (more) parser = std::async(std::launch::async, parse, std::ref(nxt));
+        report_batch(rb, args, cur, booler, pieces);
+        if (writer.valid()) writer.get();
+        writing.swap(pieces);
+        writer = std::async(std::launch::async, [&writing] {
+            for (const std::string &p : writing) fwrite(p.data(), 1, p.size(), stdout);
+        });
+        if (!more) break;
+        err = parser.get();
+        cur.clear();
+        std::swap(cur, nxt);
+    }
+    if (writer.valid()) writer.get();
+    fflush(stdout);
+    gzclose(fq_fp);
+    switch (err) {  // rb_markers.cpp:581-590
+        case -2: fprintf(stderr, "ERROR: truncated quality string\n"); exit(1);
+        case -3: fprintf(stderr, "ERROR: error reading stream\n"); exit(1);
+        default: break;
+    }
+    stop = std::chrono::high_resolution_clock::now();
+    diff = stop - start;
+    std::cerr << "counting markers took: " << diff.count() << " seconds" << std::endl;
+    return 0;
+}

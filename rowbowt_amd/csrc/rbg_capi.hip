@@ -988,6 +988,75 @@ int rbg_find_range_w_markers(rbg_index *ix, const uint8_t *seqs, const uint64_t 
     });
 }
 
+// ---- marker seeds (next-row f4): get_markers_greedy_seeding, rowbowt.hpp:406-482 ---------------------
+
+int rbg_marker_seeds_plan_dev(rbg_index *ix, const uint8_t *d_seqs, const uint64_t *d_off, uint64_t N, uint64_t wsize,
+                              uint64_t max_range, uint64_t *d_seed_off, uint64_t *d_mk_off, void *d_tmp, size_t tmp_bytes,
+                              void *stream) {
+    if (!queryable(ix)) return RBG_ENODEV;
+    if (!d_seed_off || !d_mk_off || (N && (!d_seqs || !d_off))) return RBG_EARG;
+    if (reinterpret_cast<uintptr_t>(d_seqs) & 15) return RBG_EARG;
+    if (tmp_bytes < scan_tmp_bytes(N) || (N && !d_tmp)) return RBG_EARG;
+    return launch_marker_seeds_plan(ix->dev, ix->cfg, d_seqs, d_off, N, wsize, max_range, d_seed_off, d_mk_off, d_tmp, tmp_bytes,
+                                    stream) ? RBG_ENODEV : RBG_OK;
+}
+
+int rbg_marker_seeds_fill_dev(rbg_index *ix, const uint8_t *d_seqs, const uint64_t *d_off, uint64_t N, uint64_t wsize,
+                              uint64_t max_range, const uint64_t *d_seed_off, const uint64_t *d_mk_off,
+                              rbg_marker_seed_t *d_seeds, uint64_t *d_mk, void *stream) {
+    if (!queryable(ix)) return RBG_ENODEV;
+    if (N && (!d_seqs || !d_off || !d_seed_off || !d_mk_off || !d_seeds)) return RBG_EARG;
+    if (reinterpret_cast<uintptr_t>(d_seqs) & 15) return RBG_EARG;
+    return launch_marker_seeds_fill(ix->dev, ix->cfg, d_seqs, d_off, N, wsize, max_range, d_seed_off, d_mk_off,
+                                    reinterpret_cast<uint64_t *>(d_seeds), d_mk, stream) ? RBG_ENODEV : RBG_OK;
+}
+
+int rbg_get_markers_greedy_seeding(rbg_index *ix, const uint8_t *seqs, const uint64_t *off, uint64_t N, uint64_t wsize,
+                                   uint64_t max_range, uint64_t *seed_off, rbg_marker_seed_t **seeds, uint64_t **mk) {
+    if (!queryable(ix)) return RBG_ENODEV;
+    if (!seed_off || !seeds || !mk || (N && !off)) return RBG_EARG;
+    *seeds = nullptr;
+    *mk = nullptr;
+    int rc = check_offsets(off, N);
+    if (rc) return rc;
+    DeviceScope scope(ix->device);
+    if (scope.rc) return scope.rc;
+    hipStream_t st = hipStreamPerThread;
+    ReadBatch rb;
+    if ((rc = rb.stage(seqs, off, N, st))) return rc;
+    DevBuf dsoff, dmoff, dtmp, dseeds, dmk;
+    const size_t tmp_bytes = scan_tmp_bytes(N);
+    if ((rc = dsoff.alloc((N + 1) * 8)) || (rc = dmoff.alloc((N + 1) * 8)) || (rc = dtmp.alloc(tmp_bytes))) return rc;
+    if (launch_marker_seeds_plan(ix->dev, ix->cfg, rb.seqs.as<uint8_t>(), rb.off.as<uint64_t>(), N, wsize, max_range,
+                                 dsoff.as<uint64_t>(), dmoff.as<uint64_t>(), dtmp.p, tmp_bytes, st))
+        return RBG_ENODEV;
+    uint64_t total_mk = 0;
+    HIP_TRY(hipMemcpyAsync(seed_off, dsoff.p, (N + 1) * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&total_mk, dmoff.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const uint64_t total_seeds = seed_off[N];
+    auto *h_seeds = static_cast<rbg_marker_seed_t *>(std::malloc(total_seeds ? total_seeds * sizeof(rbg_marker_seed_t) : 8));
+    auto *h_mk = static_cast<uint64_t *>(std::malloc(total_mk ? total_mk * 8 : 8));
+    if (!h_seeds || !h_mk) { std::free(h_seeds); std::free(h_mk); return RBG_ENOMEM; }
+    rc = RBG_OK;
+    if (total_seeds) {
+        if (!(rc = dseeds.alloc(total_seeds * sizeof(rbg_marker_seed_t))) && !(rc = dmk.alloc(total_mk ? total_mk * 8 : 8))) {
+            if (launch_marker_seeds_fill(ix->dev, ix->cfg, rb.seqs.as<uint8_t>(), rb.off.as<uint64_t>(), N, wsize, max_range,
+                                         dsoff.as<uint64_t>(), dmoff.as<uint64_t>(), dseeds.as<uint64_t>(), dmk.as<uint64_t>(), st))
+                rc = RBG_ENODEV;
+            hipError_t e = hipSuccess;
+            if (!rc) e = hipMemcpyAsync(h_seeds, dseeds.p, total_seeds * sizeof(rbg_marker_seed_t), hipMemcpyDeviceToHost, st);
+            if (!rc && e == hipSuccess && total_mk) e = hipMemcpyAsync(h_mk, dmk.p, total_mk * 8, hipMemcpyDeviceToHost, st);
+            if (!rc && e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) rc = RBG_ENODEV;
+        }
+    }
+    if (rc) { std::free(h_seeds); std::free(h_mk); return rc; }
+    *seeds = h_seeds;
+    *mk = h_mk;
+    return RBG_OK;
+}
+
 // ---- greedy seeding (next-row f4) -----------------------------------------------------------------
 
 int rbg_greedy_longest_seed_dev(rbg_index *ix, const uint8_t *d_seqs, const uint64_t *d_off, uint64_t N, uint64_t min_length,

@@ -674,6 +674,138 @@ __global__ __launch_bounds__(256) void k_greedy_seed(const DevIndex ix, const ui
     }
 }
 
+// ---- marker seeds (next-row f4): RowBowt::get_markers_greedy_seeding without an ftab
+// (rowbowt.hpp:406-482; rb_markers' default path, rb_markers.cpp:411-413).  One record per call of
+// the reference's callback: {range lo, range hi, q.first, seed_ei (= q.second + 1), first marker,
+// one past last marker}; the markers of a seed are what every window query along it appended to
+// mbuf (:437-441, :469-472), plus one more query when the seed ends or the read does (:445-447,
+// :478-480).  FILL=false counts records and markers per read; FILL=true re-walks and writes.
+// k-mer steps are used where no window query can fall inside them; a k-mer step that comes back
+// empty is retried symbol by symbol so the failing base is the reference's.
+template <typename P, bool FILL>
+__global__ __launch_bounds__(256) void k_marker_seeds(const DevIndex ix, const uint8_t *__restrict__ seqs,
+                                                      const uint64_t *__restrict__ off, const uint64_t N,
+                                                      const uint64_t wsize, const uint64_t max_range,
+                                                      uint64_t *__restrict__ seed_cnt, uint64_t *__restrict__ mk_cnt,
+                                                      const uint64_t *__restrict__ seed_off,
+                                                      const uint64_t *__restrict__ mk_off,
+                                                      uint64_t *__restrict__ seeds, uint64_t *__restrict__ mk) {
+    __shared__ uint8_t s_lut[256];
+    __shared__ uint8_t s_lut2[256];
+    __shared__ DevSym s_sym[kLdsSyms];
+    __shared__ DevSym s_pair[kMaxMajor * kMaxMajor];
+    __shared__ DevSym s_tri[kMaxMajor * kMaxMajor * kMaxMajor];
+    const uint32_t M = ix.nmajor;
+    const bool use3 = ix.kmer_steps >= 3;
+    for (int t = threadIdx.x; t < 256; t += blockDim.x) {
+        s_lut[t] = ix.lut[t];
+        s_lut2[t] = M ? ix.lut2[t] : 0xFFu;
+    }
+    const int nlds = ix.sigma < static_cast<uint32_t>(kLdsSyms) ? static_cast<int>(ix.sigma) : kLdsSyms;
+    for (int t = threadIdx.x; t < nlds; t += blockDim.x) s_sym[t] = ix.syms[t];
+    for (int t = threadIdx.x; t < static_cast<int>(M * M); t += blockDim.x) s_pair[t] = ix.pairs[t];
+    if (use3)
+        for (int t = threadIdx.x; t < static_cast<int>(M * M * M); t += blockDim.x) s_tri[t] = ix.triples[t];
+    __syncthreads();
+    if (!FILL && blockIdx.x == 0 && threadIdx.x == 0) { seed_cnt[0] = 0; mk_cnt[0] = 0; }
+    const bool have_ma = ix.mk_nruns != 0;
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < N; i += stride) {
+        const uint64_t beg = off[i], m = off[i + 1] - beg;
+        const uint64_t fhi = ix.n - 1;
+        uint64_t lo = 0, hi = fhi, plo = 0, phi = fhi;    // range, prev_range (:427-428)
+        uint64_t window_ei = m, seed_ei = m;              // :434
+        uint64_t ns = 0, tot = 0, mb_begin = 0;           // mbuf == markers [mb_begin, tot) of this read
+        uint64_t *srec = FILL ? seeds + 6 * seed_off[i] : nullptr;
+        const uint64_t mbase = FILL ? mk_off[i] : 0;
+        auto update_mbuf = [&](uint64_t l, uint64_t h) {  // :437-441
+            if (!have_ma || h - l + 1 > max_range) return;
+            uint64_t f, e;
+            marker_span(ix, l, h, &f, &e);
+            if (e <= f) return;
+            const uint64_t src = ix.mk_off[f], cnt = ix.mk_off[e] - src;
+            if (FILL) {
+                uint64_t *d = mk + mbase + tot;
+                for (uint64_t t = 0; t < cnt; ++t) d[t] = ix.mk_vals[src + t];
+            }
+            tot += cnt;
+        };
+        auto emit = [&](uint64_t l, uint64_t h, uint64_t qs, uint64_t qe) {  // fn(range, (qs, qe-1), mbuf)
+            if (FILL) {
+                uint64_t *d = srec + 6 * ns;
+                d[0] = l; d[1] = h; d[2] = qs; d[3] = qe; d[4] = mbase + mb_begin; d[5] = mbase + tot;
+            }
+            ++ns;
+        };
+        ByteCursor rd{reinterpret_cast<const uint4 *>(seqs), ~uint64_t(0), make_uint4(0, 0, 0, 0)};
+        uint64_t j = m;  // m - i of the reference; the next symbol consumed is q[j-1]
+        while (j > 0) {
+            const uint64_t p = beg + j - 1;
+            const uint32_t c = rd.at(p);
+            // symbols that may be consumed before the next window query fires (after the step that
+            // leaves j' with j' + wsize <= window_ei, :469)
+            uint64_t dist = j + wsize > window_ei ? j + wsize - window_ei : 1;
+            if (dist == 0) dist = 1;
+            const uint32_t m0 = s_lut2[c];
+            uint32_t m1 = 0xFFu, adv = 0;
+            if (m0 != 0xFFu && j > 1 && dist >= 2) m1 = s_lut2[rd.at(p - 1)];
+            if (m1 != 0xFFu) {
+                uint32_t m2 = 0xFFu;
+                if (use3 && j > 2 && dist >= 3) m2 = s_lut2[rd.at(p - 2)];
+                const DevSym S = m2 != 0xFFu ? s_tri[(m2 * M + m1) * M + m0] : s_pair[m1 * M + m0];
+                const uint32_t want = m2 != 0xFFu ? 3u : 2u;
+                RankAux q;
+                uint64_t c_before, c_upto, bh;
+                rank_pair<P>(S, lo, hi + 1, &c_before, &c_upto, &bh, &q);
+                if (c_upto > c_before) {
+                    lo = S.F + c_before;
+                    hi = lo + (c_upto - c_before) - 1;
+                    adv = want;
+                }
+            }
+            bool ok = adv != 0;
+            if (!ok) {
+                adv = 1;
+                const uint32_t slot = s_lut[c];
+                if (slot != 0xFFu) {
+                    const DevSym S = slot < static_cast<uint32_t>(kLdsSyms) ? s_sym[slot] : ix.syms[slot];
+                    RankAux q;
+                    uint64_t c_before, c_upto, bh;
+                    rank_pair<P>(S, lo, hi + 1, &c_before, &c_upto, &bh, &q);
+                    if (c_upto > c_before) {
+                        lo = S.F + c_before;
+                        hi = lo + (c_upto - c_before) - 1;
+                        ok = true;
+                    }
+                }
+            }
+            if (ok) {
+                j -= adv;
+                if (window_ei - j >= wsize) {             // :469-472 (m-i-1 == j after the step)
+                    update_mbuf(lo, hi);
+                    window_ei = j;
+                }
+                plo = lo; phi = hi;                       // :473
+            } else {
+                // the seed q[j, seed_ei) ends here; q[j-1] is skipped (:444-466)
+                if (seed_ei - j >= wsize) update_mbuf(plo, phi);
+                emit(plo, phi, j, seed_ei);
+                mb_begin = tot;
+                plo = 0; phi = fhi; lo = 0; hi = fhi;
+                j -= 1;
+                seed_ei = j;
+                window_ei = j;
+            }
+        }
+        if (hi >= lo && seed_ei >= wsize) update_mbuf(lo, hi);   // :478-480 (m-i == 0)
+        emit(lo, hi, 0, seed_ei);                                // :481
+        if (!FILL) {
+            seed_cnt[i + 1] = ns;
+            mk_cnt[i + 1] = tot;
+        }
+    }
+}
+
 // ---- single LF step for N (range, symbol) triples: RowBowt::LF(range_t, uint8_t), rowbowt.hpp:74-88
 template <typename P>
 __global__ __launch_bounds__(256) void k_lf(const DevIndex ix, const uint64_t *__restrict__ lo_in,
@@ -937,6 +1069,35 @@ int launch_find_range_markers_fill(const DevIndex &ix, const LaunchCfg &cfg, con
         hipLaunchKernelGGL((k_find_range_markers<uint32_t, true>), grid, block, 0, st, ix, seqs, off, N, wsize, max_range, nullptr, nullptr, nullptr, mk_off, mk);
     else
         hipLaunchKernelGGL((k_find_range_markers<uint64_t, true>), grid, block, 0, st, ix, seqs, off, N, wsize, max_range, nullptr, nullptr, nullptr, mk_off, mk);
+    return static_cast<int>(hipGetLastError());
+}
+
+int launch_marker_seeds_plan(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
+                             uint64_t wsize, uint64_t max_range, uint64_t *seed_off, uint64_t *mk_off, void *tmp,
+                             size_t tmp_bytes, void *stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid(grid_for(cfg, N)), block(cfg.block_threads);
+    if (ix.pos_bytes == 4)
+        hipLaunchKernelGGL((k_marker_seeds<uint32_t, false>), grid, block, 0, st, ix, seqs, off, N, wsize, max_range, seed_off, mk_off, nullptr, nullptr, nullptr, nullptr);
+    else
+        hipLaunchKernelGGL((k_marker_seeds<uint64_t, false>), grid, block, 0, st, ix, seqs, off, N, wsize, max_range, seed_off, mk_off, nullptr, nullptr, nullptr, nullptr);
+    int rc = static_cast<int>(hipGetLastError());
+    if (rc) return rc;
+    rc = scan_in_place(seed_off + 1, N, tmp, tmp_bytes, st);
+    if (rc) return rc;
+    return scan_in_place(mk_off + 1, N, tmp, tmp_bytes, st);
+}
+
+int launch_marker_seeds_fill(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
+                             uint64_t wsize, uint64_t max_range, const uint64_t *seed_off, const uint64_t *mk_off,
+                             uint64_t *seeds, uint64_t *mk, void *stream) {
+    if (N == 0) return 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid(grid_for(cfg, N)), block(cfg.block_threads);
+    if (ix.pos_bytes == 4)
+        hipLaunchKernelGGL((k_marker_seeds<uint32_t, true>), grid, block, 0, st, ix, seqs, off, N, wsize, max_range, nullptr, nullptr, seed_off, mk_off, seeds, mk);
+    else
+        hipLaunchKernelGGL((k_marker_seeds<uint64_t, true>), grid, block, 0, st, ix, seqs, off, N, wsize, max_range, nullptr, nullptr, seed_off, mk_off, seeds, mk);
     return static_cast<int>(hipGetLastError());
 }
 

@@ -32,6 +32,7 @@ def _build_oracle():
     lib = os.path.join(ROOT, "rowbowt_amd", "librbg.so")
     cli = os.path.join(ROOT, "rowbowt_amd", "rb_align")
     newest = max(os.path.getmtime(os.path.join(csrc, f)) for f in os.listdir(csrc) if f.endswith((".hip", ".cpp", ".h", ".hpp")))
-    if not os.path.exists(lib) or not os.path.exists(cli) or os.path.getmtime(lib) < newest:
+    cli2 = os.path.join(ROOT, "rowbowt_amd", "rb_markers")
+    if not os.path.exists(lib) or not os.path.exists(cli) or not os.path.exists(cli2) or os.path.getmtime(lib) < newest:
         subprocess.check_call(["make", "-C", csrc, "-j4"])
     yield

@@ -185,6 +185,61 @@ def test_synth_markers(synth):
     o.close()
 
 
+def _check_marker_seeds(rb, o, reads, wsize, max_range):
+    seqs, off = ra.pack_reads(reads)
+    seed_off, seeds, mk = rb.get_markers_greedy_seeding(seqs, off, wsize, max_range)
+    nseed = nmk = 0
+    for i, q in enumerate(reads):
+        want = o.markers_greedy_seeding(q, wsize, max_range)
+        got = seeds[int(seed_off[i]):int(seed_off[i + 1])]
+        assert len(got) == len(want), (i, q)
+        for g, (wl, wh, wqs, wqe, wm) in zip(got, want):
+            assert (int(g[0]), int(g[1]), int(g[2]), int(g[3])) == (wl, wh, wqs, wqe), (i, q)
+            assert mk[int(g[4]):int(g[5])].tolist() == wm, (i, q)
+            nmk += len(wm)
+        nseed += len(want)
+    return nseed, nmk
+
+
+def test_marker_seeds_small(small, simple_reads, error_reads):
+    """get_markers_greedy_seeding (rowbowt.hpp:406-482, no ftab) on the reference's fixture"""
+    rb, o = small
+    reads = simple_reads + error_reads + [b"", b"A", b"NNNN", b"ACGTNACGT", simple_reads[0] + b"N" + simple_reads[2]]
+    for wsize, max_range in ((19, 1000), (5, 1000), (1, MAXU), (0, 10), (10, 2), (21, 1000)):
+        nseed, _ = _check_marker_seeds(rb, o, reads, wsize, max_range)
+        assert nseed >= len(reads)
+
+
+def test_marker_seeds_synth(synth):
+    S = synth
+    rb = ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0)
+    o = orc.Oracle.from_runs(S.heads, S.lens, S.ssa, S.esa)
+    reads = S.sample_reads(1200, 60, seed=21, sub_rate=0.5) + [b"ACGT", b""]
+    # without a marker array every mbuf is empty, the seeds are the same (rowbowt.hpp:273,283)
+    nseed0, nmk0 = _check_marker_seeds(rb, o, reads, 10, MAXU)
+    assert nmk0 == 0 and nseed0 > len(reads)
+    ms, me, mo, mv = S.markers(wsize=10)
+    rb.set_markers(ms, me, mo, mv)
+    o.set_markers(ms, me, mo, mv)
+    tot = 0
+    for wsize, max_range in ((10, MAXU), (7, 1000), (19, 1000), (3, 6), (60, MAXU)):
+        nseed, nmk = _check_marker_seeds(rb, o, reads, wsize, max_range)
+        assert nseed == nseed0   # seeds do not depend on the windows
+        tot += nmk
+    assert tot > 1000
+    for ks in (1, 2, 3):
+        capi.set_default_option(capi.OPT_KMER_STEPS, ks)
+        try:
+            rb2 = ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0)
+            rb2.set_markers(ms, me, mo, mv)
+            _check_marker_seeds(rb2, o, reads[:400], 10, 1000)
+            rb2.close()
+        finally:
+            capi.set_default_option(capi.OPT_KMER_STEPS, 4)
+    rb.close()
+    o.close()
+
+
 def test_single_LF_steps(small, synth):
     """RowBowt::LF (rowbowt.hpp:74-88) one step at a time, against the oracle's LF."""
     rb, o = small
@@ -342,6 +397,67 @@ def test_cli_locs_and_markers_stdout(data_dir, tmp_path, small, simple_reads):
     bad.write_text("@r\nACGT\n+\n~~\n")
     rc, _, err = _run_cli([str(tmp_path / "idx"), str(bad)])
     assert rc == 1 and "truncated quality string" in err
+
+
+# ---- the rb_markers-compatible CLI (reference src/rb_markers.cpp, default seeding mode) ----------
+def _run_rb_markers(args):
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rowbowt_amd", "rb_markers")
+    p = subprocess.run([exe] + args, capture_output=True, timeout=120)
+    return p.returncode, p.stdout.decode(), p.stderr.decode()
+
+
+def test_cli_rb_markers_stdout(data_dir, tmp_path, small):
+    import rb_markers_model as RM
+    rb, o = small
+    idx = os.path.join(data_dir, "small.fa")
+    text = open(idx, "rb").read().split(b"\n", 1)[1].replace(b"\n", b"")
+    rng = np.random.default_rng(77)
+    recs = []
+    for fn in ("simple_query.fq", "error_query.fq"):
+        names, seqs = orc.read_fastx(os.path.join(data_dir, fn))
+        recs += list(zip(names, seqs))
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    for i in range(300):   # 101 bp reads from either strand, some with errors, lower case and Ns
+        p = int(rng.integers(0, len(text) - 101))
+        q = bytearray(text[p:p + 101])
+        if i % 2:
+            q = bytearray(bytes(q).translate(comp)[::-1])
+        for _ in range(int(rng.integers(0, 3))):
+            q[int(rng.integers(0, 101))] = b"ACGTN"[int(rng.integers(0, 5))]
+        if i % 7 == 0:
+            q = bytearray(bytes(q).lower())
+        recs.append((f"syn{i}".encode(), bytes(q)))
+    recs.append((b"short", b"ACG"))
+    recs.append((b"empty", b""))
+    fq = tmp_path / "reads.fq"
+    with open(fq, "wb") as f:
+        for name, seq in recs:
+            f.write(b"@" + name + b" x\n" + seq + b"\n+\n" + b"I" * len(seq) + b"\n")
+    rc, out, err = _run_rb_markers([idx, str(fq)])
+    assert rc == 0, err
+    want = RM.expected_stdout(o, recs)
+    assert out == want
+    assert " + 0 20 0/289/0\n" in out and out.count("\n") > 2 * len(recs) - 10
+    assert "loading rowbowt + markers took" in err and "counting markers took" in err
+    for args, kw in ((["--wsize", "10", "--max-range", "3", "--min-range", "2"], dict(wsize=10, max_range=3, min_range=2)),
+                     (["-w", "5", "--batch", "7", "--threads", "3"], dict(wsize=5)),
+                     (["--heuristic"], dict(heuristic=True)),
+                     (["--heuristic", "--best-strand-only", "--min-seed-length", "30", "--read-len", "101"],
+                      dict(heuristic=True, best_strand=True, min_seed_len=30, read_len=101)),
+                     (["--heuristic", "-y", "25", "--clear-conflicting", "--clear-identical", "-l", "50", "-w", "8"],
+                      dict(heuristic=True, min_seed_len=25, clear_conflicting=True, clear_identical=True, read_len=50, wsize=8))):
+        rc, out, err = _run_rb_markers(args + [idx, str(fq)])
+        assert rc == 0, err
+        assert out == RM.expected_stdout(o, recs, **kw), args
+    # modes the reference itself refuses or that need structures this engine does not build
+    for flag in ("--overlap", "--lmem", "--ftab", "--fbb"):
+        rc, _, err = _run_rb_markers([flag, idx, str(fq)])
+        assert rc == 1 and err
+    rc, _, err = _run_rb_markers([idx])
+    assert rc == 1 and "no argument provided" in err
+    rc, _, err = _run_rb_markers([str(tmp_path / "nope"), str(fq)])
+    assert rc == 1 and "bad file" in err
 
 
 # ---- mid-scale (n ~ 4e6) synthetic pangenome built with the bench's own generator on the GPU:

@@ -104,3 +104,51 @@ def test_greedy_seeding_fixture_loads(data_dir):
     locs = o.locs_at(lo, hi, k)
     assert len(locs) == hi - lo + 1
     o.close()
+
+
+def test_rb_markers_model_pieces():
+    """the pieces of the rb_markers model the CLI test leans on"""
+    import rb_markers_model as RM
+    rng = RM.MT19937()
+    assert [rng() for _ in range(2)] == [3499211612, 581869302]   # std::mt19937's first outputs, default seed
+    r = RM.MT19937()
+    for _ in range(9999):
+        r()
+    assert r() == 4123659995                                        # the C++ standard's 10000th value
+    assert RM.NT[ord("a")] == ord("A") and RM.NT[ord("N")] == ord("A") and RM.NT[ord("x")] == ord("N") and RM.NT[200] == ord("N")
+    assert b"ACGTN".translate(RM.COMP) == b"TGCAN"
+    mk = lambda seq, pos, al: (al << 60) | (seq << 48) | pos
+    ms = [mk(0, 5, 0), mk(0, 5, 1), mk(0, 9, 0), mk(1, 9, 1)]
+    assert RM.filter_identical_pos(ms) == [mk(0, 9, 0), mk(1, 9, 1)]
+    assert RM.filter_identical_pos([mk(0, 0, 1), mk(0, 3, 0)]) == [mk(0, 3, 0)]   # pm starts as marker 0
+    assert RM.clear_if_conflicting([mk(0, 5, 0), mk(0, 200, 0)], 101) == []
+    assert RM.clear_if_conflicting([mk(0, 5, 0), mk(0, 100, 0)], 101) == [mk(0, 5, 0), mk(0, 100, 0)]
+    assert RM.clear_if_conflicting([mk(0, 5, 0), mk(1, 6, 0)], 101) == []
+
+
+def test_oracle_marker_seeds_fixture(small_oracle=None):
+    """get_markers_greedy_seeding (rowbowt.hpp:406-482) on the shipped fixture: exact reads give one
+    seed over the whole read whose range is find_range's; its markers include markers_at's"""
+    import os
+    import orc
+    data = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+    o = orc.Oracle.load(os.path.join(data, "small.fa"), orc.SA | orc.MA)
+    names, seqs = orc.read_fastx(os.path.join(data, "simple_query.fq"))
+    for q in seqs:
+        seeds = o.markers_greedy_seeding(q, 19, 1000)
+        lo, hi = o.find_range(q)
+        assert len(seeds) == 1 and seeds[0][:4] == (lo, hi, 0, len(q))
+        assert set(o.markers_at(lo, hi)) <= set(seeds[0][4]) or hi - lo + 1 > 1000
+    # a read with one error: two seeds, right one first, the failing base skipped
+    names, seqs = orc.read_fastx(os.path.join(data, "error_query.fq"))
+    seeds = o.markers_greedy_seeding(seqs[0], 19, 1000)
+    assert [(s[2], s[3]) for s in seeds] == [(5, 20), (0, 4)]
+    # every seed is an exact match of its piece of the read and maximal to the left
+    for q in seqs:
+        for lo, hi, qs, qe, _ in o.markers_greedy_seeding(q, 5, 1000):
+            if qe > qs:
+                assert o.find_range(q[qs:qe]) == (lo, hi)
+                if qs > 0:
+                    l2, h2 = o.find_range(q[qs - 1:qe])
+                    assert h2 < l2
+    o.close()
