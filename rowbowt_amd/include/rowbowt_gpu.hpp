@@ -198,6 +198,24 @@ class RowBowt {
         return lf;
     }
 
+    // rowbowt.hpp:406-482, the variant without an ftab: fn(range, (q.first, q.second), mbuf) once per seed,
+    // right to left, exactly as the reference calls it (q.second = q.first - 1, wrapped, for an empty seed)
+    template <typename F>
+    void get_markers_greedy_seeding(const std::string query, uint64_t wsize, uint64_t max_range, F fn) const {
+        const uint64_t off[2] = {0, query.size()};
+        uint64_t seed_off[2];
+        rbg_marker_seed_t *seeds = nullptr;
+        detail::LibBuf mk;
+        detail::check(rbg_get_markers_greedy_seeding(ix_.get(), reinterpret_cast<const uint8_t *>(query.data()), off, 1, wsize,
+                                                     max_range, seed_off, &seeds, &mk.p), "rbg_get_markers_greedy_seeding");
+        std::unique_ptr<rbg_marker_seed_t, void (*)(void *)> hold(seeds, rbg_free_buffer);
+        for (uint64_t s = 0; s < seed_off[1]; ++s) {
+            const rbg_marker_seed_t &d = seeds[s];
+            fn(range_t(d.lo, d.hi), std::make_pair(static_cast<size_t>(d.qstart), static_cast<size_t>(d.qend - 1)),
+               std::vector<MarkerT>(mk.p + d.mk_begin, mk.p + d.mk_end));
+        }
+    }
+
     // rowbowt.hpp:633-662 (get_seeds_greedy_w_sample :222-256 + locate_from_longest_seed :664-685)
     std::vector<uint64_t> &find_locs_greedy_seeding(std::string s, uint64_t min_length, uint64_t max_hits,
                                                     std::vector<uint64_t> &locs) const {

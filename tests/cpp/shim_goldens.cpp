@@ -94,6 +94,25 @@ int main(int argc, char **argv) {
         if (g[i].empty()) { EXPECT_EQ(l.size(), 0u); continue; }
         for (size_t t = 0; t < g[i].size(); ++t) EXPECT_EQ(l[t], g[i][t]);
     }
+    // get_markers_greedy_seeding with the callback rb_markers passes (rowbowt.hpp:406-482): values from the oracle
+    {
+        std::vector<range_t> ranges;
+        std::vector<std::pair<size_t, size_t>> qs;
+        size_t nmk = 0;
+        auto fn = [&](range_t p, std::pair<size_t, size_t> q, std::vector<MarkerT> mbuf) { ranges.push_back(p); qs.push_back(q); nmk += mbuf.size(); };
+        rb.get_markers_greedy_seeding(simple[0], 19, 1000, fn);
+        EXPECT_EQ(ranges.size(), 1u);
+        EXPECT_EQ(ranges[0], want[0]);
+        EXPECT_EQ(qs[0], (std::pair<size_t, size_t>(0, 19)));
+        EXPECT_EQ(nmk, 2u);
+        ranges.clear(); qs.clear();
+        rb.get_markers_greedy_seeding(errq[0], 19, 1000, fn);
+        EXPECT_EQ(ranges.size(), 2u);
+        EXPECT_EQ(ranges[0], range_t(10661, 10663));
+        EXPECT_EQ(qs[0], (std::pair<size_t, size_t>(5, 19)));
+        EXPECT_EQ(ranges[1], range_t(24205, 24294));
+        EXPECT_EQ(qs[1], (std::pair<size_t, size_t>(0, 3)));
+    }
     // resolve_offset through a .docs file (rowbowt.hpp:623-625)
     RB rb2 = rbwt::load_rowbowt<>(argv[2], rbwt::LoadRbwtFlag::SA | rbwt::LoadRbwtFlag::DL);
     auto x = rb2.resolve_offset(20306);
