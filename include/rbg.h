@@ -80,6 +80,24 @@ int rbg_build_from_runs(const uint8_t *heads, const uint64_t *lens, uint64_t R,
 int rbg_build_from_files(const char *bwt_fname, const char *ssa_fname, const char *esa_fname, int device,
                          rbg_index **out);
 
+/* ---- next-row f1: native cache file and the rb_build outputs ----------------------------------
+ * "<prefix>.rbgpu" holds what the reference's .rbwt/.tsa/.mab/.docs hold, as flat little-endian
+ * arrays with a checksum (layout: rowbowt_amd/csrc/rbg_host.hpp); loading it needs no sdsl decoding.
+ * rbg_load() falls back to "<prefix>.rbgpu" when "<prefix>.rbwt" does not exist.
+ * rbg_convert_index: the reference's serialised files (rb_build's output, rowbowt_io.hpp:49-89) -> cache.
+ * rbg_convert_raw:   rb_build's raw inputs <pre>.bwt [+ .ssa/.esa] (rb_build.cpp:83-93; rle_string.hpp:44-97,
+ *                    toehold_sa.hpp:27-35,133-155), plus optionally an already serialised .mab and a
+ *                    .docs file -> cache.  (The raw .ma input is read by pfbwt-f's MarkerArray
+ *                    constructor, which is not vendored: not supported.)
+ * Both run on the host only.  rbg_load_cache: flags select the stored parts; asking for a part the
+ * file lacks is RBG_EIO, like a missing .tsa/.mab/.docs. */
+int rbg_convert_index(const char *prefix, int flags, const char *out_path);
+int rbg_convert_raw(const char *bwt_fname, const char *ssa_fname, const char *esa_fname, const char *mab_fname,
+                    const char *docs_fname, const char *out_path);
+int rbg_load_cache(const char *path, int flags, int device, rbg_index **out);
+/* RowBowt::build_ftab(k) + FTab::serialize (rowbowt.hpp:726-744, ftab.hpp:29-34): the reference's
+ * text .ftab ("<kmer> <lo> <hi>" per line, lexicographic), computed with the search kernel. 1 <= k <= 16. */
+int rbg_write_ftab(rbg_index *, uint64_t k, const char *path);
 /* MarkerArray contents (pfbwt-f marker_array.hpp, loaded at rowbowt_io.hpp:185):
  * inclusive SA-index runs + mk_off[nruns+1] offsets into mk_vals. */
 int rbg_set_markers(rbg_index *, const uint64_t *run_start, const uint64_t *run_end, uint64_t nruns,

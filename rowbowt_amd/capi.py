@@ -55,6 +55,10 @@ _PROTOS = [
     ("rbg_load", C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(VP)]),
     ("rbg_build_from_runs", C.c_int, [VP, VP, U64, VP, VP, C.c_int, C.POINTER(VP)]),
     ("rbg_build_from_files", C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(VP)]),
+    ("rbg_convert_index", C.c_int, [C.c_char_p, C.c_int, C.c_char_p]),
+    ("rbg_convert_raw", C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p]),
+    ("rbg_load_cache", C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(VP)]),
+    ("rbg_write_ftab", C.c_int, [VP, U64, C.c_char_p]),
     ("rbg_set_markers", C.c_int, [VP, VP, VP, U64, VP, VP]),
     ("rbg_set_docs", C.c_int, [VP, C.c_char_p, VP, U64]),
     ("rbg_free", None, [VP]),
@@ -134,6 +138,15 @@ def pack_reads(reads):
     return seqs, off
 
 
+def convert_index(prefix, flags, out_path):
+    _check(lib().rbg_convert_index(os.fsencode(prefix), int(flags), os.fsencode(out_path)), "rbg_convert_index")
+
+
+def convert_raw(bwt, ssa=None, esa=None, mab=None, docs=None, out_path=None):
+    e = lambda x: os.fsencode(x) if x else None
+    _check(lib().rbg_convert_raw(e(bwt), e(ssa), e(esa), e(mab), e(docs), e(out_path)), "rbg_convert_raw")
+
+
 def set_default_option(opt, value):
     _check(lib().rbg_set_default_option(opt, value), "rbg_set_default_option")
 
@@ -192,6 +205,17 @@ class RowBowt:
         joined = b"\0".join(n.encode() for n in names) + b"\0"
         s = _u64(starts)
         _check(self.L.rbg_set_docs(self.h, joined, _p(s), len(names)), "rbg_set_docs")
+
+    @classmethod
+    def from_cache(cls, path, flags=LoadRbwtFlag.NONE, device=0):
+        """native cache file written by convert_index / convert_raw / rb_build (include/rbg.h, next-row f1)"""
+        h = VP()
+        _check(lib().rbg_load_cache(os.fsencode(path), int(flags), device, C.byref(h)), "rbg_load_cache")
+        return cls(h)
+
+    def write_ftab(self, k, path):
+        """RowBowt::build_ftab(k) + FTab::serialize (rowbowt.hpp:726-744, ftab.hpp:29-34)"""
+        _check(self.L.rbg_write_ftab(self.h, k, os.fsencode(path)), "rbg_write_ftab")
 
     # ---- introspection
     def info(self):

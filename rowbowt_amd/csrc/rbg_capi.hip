@@ -517,6 +517,63 @@ int ragged_finish(uint64_t N, DevBuf &d_off, uint64_t *h_off, uint64_t **h_vals,
     return rc;
 }
 
+bool file_readable(const std::string &fname) {
+    FILE *f = std::fopen(fname.c_str(), "rb");
+    if (!f) return false;
+    std::fclose(f);
+    return true;
+}
+
+// the reference's serialised files -> decoded bundle (load_rowbowt, rowbowt_io.hpp:176-189)
+int bundle_from_index_files(const char *prefix, int flags, FlatBundle &b) {
+    const std::string pre(prefix);
+    int rc = parse_rbwt(pre + ".rbwt", b.rle);  // rowbowt_io.hpp:17,179-182
+    if (rc) return rc;
+    if (flags & RBG_LOAD_SA) {  // :18,184
+        if ((rc = parse_tsa(pre + ".tsa", b.tsa))) return rc;
+        b.has_tsa = true;
+    }
+    if (flags & RBG_LOAD_MA) {  // :19,185
+        if ((rc = parse_mab(pre + ".mab", b.ma))) return rc;
+        if (!markers_valid(b.ma.start.data(), b.ma.end.data(), b.ma.start.size(), b.ma.off.data())) return RBG_EFORMAT;
+        b.has_ma = true;
+    }
+    if (flags & RBG_LOAD_DL) {  // :20,186
+        if ((rc = parse_docs(pre + ".docs", b.dl))) return rc;
+        b.has_dl = true;
+    }
+    return RBG_OK;
+}
+
+// rb_build's raw inputs (rb_build.cpp:83-93) -> decoded bundle
+int bundle_from_raw_files(const char *bwt_fname, const char *ssa_fname, const char *esa_fname, FlatBundle &b) {
+    RawRle &rle = b.rle;
+    int rc = read_raw_bwt(bwt_fname, rle);
+    if (rc) return rc;
+    if (ssa_fname) {
+        std::vector<uint64_t> ssa, esa;
+        if ((rc = read_raw_samples(ssa_fname, ssa)) || (rc = read_raw_samples(esa_fname, esa))) return rc;
+        if (ssa.size() != rle.R || esa.size() != rle.R) return RBG_EFORMAT;  // one sample pair per BWT run
+        for (uint64_t i = 0; i < rle.R; ++i)
+            if (ssa[i] > rle.n || esa[i] > rle.n) return RBG_EFORMAT;
+        tsa_from_samples(rle.n, rle.R, ssa.data(), esa.data(), b.tsa);
+        for (uint64_t j = 1; j < rle.R; ++j)
+            if (b.tsa.pred_pos[j] == b.tsa.pred_pos[j - 1]) return RBG_EFORMAT;  // run-start samples must be distinct
+        b.has_tsa = true;
+    }
+    return RBG_OK;
+}
+
+int index_from_bundle(FlatBundle &b, int device, rbg_index **out) {
+    rbg_index *ix = new (std::nothrow) rbg_index();
+    if (!ix) return RBG_ENOMEM;
+    int rc = flatten(b.rle, b.has_tsa ? &b.tsa : nullptr, current_options(), ix->host);
+    if (rc) { delete ix; return rc; }
+    if (b.has_ma) { ix->host.ma = std::move(b.ma); ix->host.has_ma = true; }
+    if (b.has_dl) { ix->host.dl = std::move(b.dl); ix->host.has_dl = true; }
+    return finish(ix, device, out);
+}
+
 }  // namespace
 
 extern "C" {
@@ -566,30 +623,77 @@ int rbg_set_default_option(int opt, int64_t value) {
 int rbg_load(const char *prefix, int flags, int device, rbg_index **out) {
     if (!prefix || !out) return RBG_EARG;
     *out = nullptr;
-    const std::string pre(prefix);
-    RawRle rle;
-    int rc = parse_rbwt(pre + ".rbwt", rle);  // rowbowt_io.hpp:17,179-182
+    FlatBundle b;
+    int rc = bundle_from_index_files(prefix, flags, b);
+    // no .rbwt but a native cache next to where it would be: use that (rb_build of this engine writes it);
+    // a requested part the cache does not hold is still looked for in its own file (.docs is plain text
+    // that rb_build copies, rowbowt_io.hpp:73-80)
+    if (rc == RBG_EIO && !file_readable(std::string(prefix) + ".rbwt") && file_readable(std::string(prefix) + ".rbgpu")) {
+        const std::string pre(prefix);
+        FlatBundle c;
+        if ((rc = read_flat(pre + ".rbgpu", c))) return rc;
+        if ((flags & RBG_LOAD_SA) && !c.has_tsa) {
+            if ((rc = parse_tsa(pre + ".tsa", c.tsa))) return rc;
+            if (c.tsa.r != c.rle.R || c.tsa.n != c.rle.n) return RBG_EFORMAT;
+            c.has_tsa = true;
+        }
+        if ((flags & RBG_LOAD_MA) && !c.has_ma) {
+            if ((rc = parse_mab(pre + ".mab", c.ma))) return rc;
+            if (!markers_valid(c.ma.start.data(), c.ma.end.data(), c.ma.start.size(), c.ma.off.data())) return RBG_EFORMAT;
+            c.has_ma = true;
+        }
+        if ((flags & RBG_LOAD_DL) && !c.has_dl) {
+            if ((rc = parse_docs(pre + ".docs", c.dl))) return rc;
+            c.has_dl = true;
+        }
+        c.has_tsa = c.has_tsa && (flags & RBG_LOAD_SA);
+        c.has_ma = c.has_ma && (flags & RBG_LOAD_MA);
+        c.has_dl = c.has_dl && (flags & RBG_LOAD_DL);
+        return index_from_bundle(c, device, out);
+    }
     if (rc) return rc;
-    RawTsa tsa;
-    const bool want_sa = flags & RBG_LOAD_SA;
-    if (want_sa && (rc = parse_tsa(pre + ".tsa", tsa))) return rc;  // :18,184
-    rbg_index *ix = new (std::nothrow) rbg_index();
-    if (!ix) return RBG_ENOMEM;
-    rc = flatten(rle, want_sa ? &tsa : nullptr, current_options(), ix->host);
-    if (rc) { delete ix; return rc; }
-    if (flags & RBG_LOAD_MA) {  // :19,185
-        rc = parse_mab(pre + ".mab", ix->host.ma);
-        if (!rc && !markers_valid(ix->host.ma.start.data(), ix->host.ma.end.data(), ix->host.ma.start.size(), ix->host.ma.off.data()))
-            rc = RBG_EFORMAT;
-        if (rc) { delete ix; return rc; }
-        ix->host.has_ma = true;
+    return index_from_bundle(b, device, out);
+}
+
+int rbg_load_cache(const char *path, int flags, int device, rbg_index **out) {
+    if (!path || !out) return RBG_EARG;
+    *out = nullptr;
+    FlatBundle b;
+    int rc = read_flat(path, b);
+    if (rc) return rc;
+    // a part the caller asks for must be in the file, like a missing .tsa/.mab/.docs (rowbowt_io.hpp:166-169)
+    if (((flags & RBG_LOAD_SA) && !b.has_tsa) || ((flags & RBG_LOAD_MA) && !b.has_ma) || ((flags & RBG_LOAD_DL) && !b.has_dl))
+        return RBG_EIO;
+    b.has_tsa = b.has_tsa && (flags & RBG_LOAD_SA);
+    b.has_ma = b.has_ma && (flags & RBG_LOAD_MA);
+    b.has_dl = b.has_dl && (flags & RBG_LOAD_DL);
+    return index_from_bundle(b, device, out);
+}
+
+int rbg_convert_index(const char *prefix, int flags, const char *out_path) {
+    if (!prefix || !out_path) return RBG_EARG;
+    FlatBundle b;
+    int rc = bundle_from_index_files(prefix, flags, b);
+    if (rc) return rc;
+    return write_flat(out_path, b);
+}
+
+int rbg_convert_raw(const char *bwt_fname, const char *ssa_fname, const char *esa_fname, const char *mab_fname,
+                    const char *docs_fname, const char *out_path) {
+    if (!bwt_fname || !out_path || (!!ssa_fname != !!esa_fname)) return RBG_EARG;
+    FlatBundle b;
+    int rc = bundle_from_raw_files(bwt_fname, ssa_fname, esa_fname, b);
+    if (rc) return rc;
+    if (mab_fname) {
+        if ((rc = parse_mab(mab_fname, b.ma))) return rc;
+        if (!markers_valid(b.ma.start.data(), b.ma.end.data(), b.ma.start.size(), b.ma.off.data())) return RBG_EFORMAT;
+        b.has_ma = true;
     }
-    if (flags & RBG_LOAD_DL) {  // :20,186
-        rc = parse_docs(pre + ".docs", ix->host.dl);
-        if (rc) { delete ix; return rc; }
-        ix->host.has_dl = true;
+    if (docs_fname) {
+        if ((rc = parse_docs(docs_fname, b.dl))) return rc;
+        b.has_dl = true;
     }
-    return finish(ix, device, out);
+    return write_flat(out_path, b);
 }
 
 int rbg_build_from_runs(const uint8_t *heads, const uint64_t *lens, uint64_t R, const uint64_t *ssa_y,
@@ -619,25 +723,47 @@ int rbg_build_from_runs(const uint8_t *heads, const uint64_t *lens, uint64_t R, 
 int rbg_build_from_files(const char *bwt_fname, const char *ssa_fname, const char *esa_fname, int device, rbg_index **out) {
     if (!bwt_fname || !out || (!!ssa_fname != !!esa_fname)) return RBG_EARG;
     *out = nullptr;
-    RawRle rle;
-    int rc = read_raw_bwt(bwt_fname, rle);
+    FlatBundle b;
+    int rc = bundle_from_raw_files(bwt_fname, ssa_fname, esa_fname, b);
     if (rc) return rc;
-    RawTsa tsa;
-    if (ssa_fname) {
-        std::vector<uint64_t> ssa, esa;
-        if ((rc = read_raw_samples(ssa_fname, ssa)) || (rc = read_raw_samples(esa_fname, esa))) return rc;
-        if (ssa.size() != rle.R || esa.size() != rle.R) return RBG_EFORMAT;  // one sample pair per BWT run
-        for (uint64_t i = 0; i < rle.R; ++i)
-            if (ssa[i] > rle.n || esa[i] > rle.n) return RBG_EFORMAT;
-        tsa_from_samples(rle.n, rle.R, ssa.data(), esa.data(), tsa);
-        for (uint64_t j = 1; j < rle.R; ++j)
-            if (tsa.pred_pos[j] == tsa.pred_pos[j - 1]) return RBG_EFORMAT;  // run-start samples must be distinct
+    return index_from_bundle(b, device, out);
+}
+
+// RowBowt::build_ftab(k) + FTab::serialize (rowbowt.hpp:726-744, ftab.hpp:29-34): one text line
+// "<kmer> <lo> <hi>" for every k-mer over ACGT with a non-empty range, in std::map (lexicographic) order
+int rbg_write_ftab(rbg_index *ix, uint64_t k, const char *path) {
+    if (!queryable(ix)) return RBG_ENODEV;
+    if (!path || k == 0 || k > 16) return RBG_EARG;
+    FILE *fp = std::fopen(path, "wb");
+    if (!fp) return RBG_EIO;
+    const uint64_t total = uint64_t(1) << (2 * k);
+    const uint64_t chunk = std::min<uint64_t>(total, uint64_t(1) << 21);
+    std::vector<uint8_t> seqs(chunk * k);
+    std::vector<uint64_t> off(chunk + 1), lo(chunk), hi(chunk);
+    for (uint64_t i = 0; i <= chunk; ++i) off[i] = i * k;
+    std::string text;
+    int rc = RBG_OK;
+    for (uint64_t base = 0; base < total && !rc; base += chunk) {
+        for (uint64_t i = 0; i < chunk; ++i) {
+            const uint64_t L = base + i;  // lexicographic rank: first character most significant
+            for (uint64_t j = 0; j < k; ++j) seqs[i * k + j] = static_cast<uint8_t>("ACGT"[(L >> (2 * (k - 1 - j))) & 3]);
+        }
+        rc = rbg_find_range(ix, seqs.data(), off.data(), chunk, lo.data(), hi.data());
+        if (rc) break;
+        text.clear();
+        for (uint64_t i = 0; i < chunk; ++i) {
+            if (lo[i] > hi[i]) continue;  // rowbowt.hpp:737
+            text.append(reinterpret_cast<const char *>(&seqs[i * k]), k);
+            text += ' ';
+            text += std::to_string(lo[i]);
+            text += ' ';
+            text += std::to_string(hi[i]);
+            text += '\n';
+        }
+        if (!text.empty() && std::fwrite(text.data(), 1, text.size(), fp) != text.size()) rc = RBG_EIO;
     }
-    rbg_index *ix = new (std::nothrow) rbg_index();
-    if (!ix) return RBG_ENOMEM;
-    rc = flatten(rle, ssa_fname ? &tsa : nullptr, current_options(), ix->host);
-    if (rc) { delete ix; return rc; }
-    return finish(ix, device, out);
+    if (std::fclose(fp) != 0 && !rc) rc = RBG_EIO;
+    return rc;
 }
 
 int rbg_set_markers(rbg_index *ix, const uint64_t *run_start, const uint64_t *run_end, uint64_t nruns,

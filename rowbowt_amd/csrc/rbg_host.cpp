@@ -383,6 +383,218 @@ int parse_docs(const std::string &fname, RawDocs &out) {
     return RBG_OK;
 }
 
+// ---- native cache file ------------------------------------------------------------------------------
+namespace {
+constexpr char kFlatMagic[8] = {'R', 'B', 'G', 'P', 'U', 'I', 'X', '1'};
+
+struct FlatSum {  // order-sensitive 64-bit checksum over 8-byte words
+    uint64_t h = 0x9E3779B97F4A7C15ull;
+    void words(const uint64_t *w, size_t n) {
+        for (size_t i = 0; i < n; ++i) {
+            h ^= w[i];
+            h *= 0xFF51AFD7ED558CCDull;
+            h = (h << 29) | (h >> 35);
+        }
+    }
+};
+
+class FlatWriter {
+   public:
+    explicit FlatWriter(const std::string &fname) : fp_(std::fopen(fname.c_str(), "wb")) {}
+    ~FlatWriter() { if (fp_) std::fclose(fp_); }
+    bool ok() const { return fp_ && ok_; }
+    void u64(uint64_t v) { raw(&v, 8); }
+    // section of `count` values narrowed to `width` bytes, zero-padded to a multiple of 8
+    void section(const uint64_t *v, uint64_t count, unsigned width) {
+        if (width == 8) { raw(v, count * 8); return; }
+        std::vector<uint32_t> tmp(1 << 16);
+        for (uint64_t i = 0; i < count; i += tmp.size()) {
+            const uint64_t m = std::min<uint64_t>(tmp.size(), count - i);
+            for (uint64_t t = 0; t < m; ++t) tmp[t] = static_cast<uint32_t>(v[i + t]);
+            raw(tmp.data(), m * 4);
+        }
+        pad();
+    }
+    void bytes(const void *p, uint64_t count) { raw(p, count); pad(); }
+    bool finish() {
+        pad();
+        const uint64_t h = sum_.h;
+        if (fp_ && std::fwrite(&h, 8, 1, fp_) != 1) ok_ = false;
+        if (fp_ && std::fclose(fp_) != 0) ok_ = false;
+        fp_ = nullptr;
+        return ok_;
+    }
+
+   private:
+    void raw(const void *p, uint64_t nbytes) {  // checksum runs over whole words; carry_ holds a partial one
+        const unsigned char *c = static_cast<const unsigned char *>(p);
+        if (fp_ && nbytes && std::fwrite(c, 1, nbytes, fp_) != nbytes) ok_ = false;
+        while (nbytes) {
+            if (ncarry_ == 0 && nbytes >= 8) {
+                const uint64_t nw = nbytes / 8;
+                if ((reinterpret_cast<uintptr_t>(c) & 7) == 0) {
+                    sum_.words(reinterpret_cast<const uint64_t *>(c), nw);
+                } else {
+                    for (uint64_t i = 0; i < nw; ++i) { uint64_t w; std::memcpy(&w, c + 8 * i, 8); sum_.words(&w, 1); }
+                }
+                c += nw * 8;
+                nbytes -= nw * 8;
+                continue;
+            }
+            carry_[ncarry_++] = *c++;
+            --nbytes;
+            if (ncarry_ == 8) { uint64_t w; std::memcpy(&w, carry_, 8); sum_.words(&w, 1); ncarry_ = 0; }
+        }
+    }
+    void pad() {
+        static const unsigned char zeros[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (ncarry_) raw(zeros, 8 - ncarry_);
+    }
+    FILE *fp_;
+    bool ok_ = true;
+    FlatSum sum_;
+    unsigned char carry_[8];
+    unsigned ncarry_ = 0;
+};
+
+uint64_t padded8(uint64_t nbytes) { return (nbytes + 7) & ~uint64_t(7); }
+
+void widen(const unsigned char *src, uint64_t count, unsigned width, std::vector<uint64_t> &out) {
+    out.resize(count);
+    if (width == 8) { if (count) std::memcpy(out.data(), src, count * 8); return; }
+    for (uint64_t i = 0; i < count; ++i) { uint32_t v; std::memcpy(&v, src + 4 * i, 4); out[i] = v; }
+}
+}  // namespace
+
+int write_flat(const std::string &fname, const FlatBundle &b) {
+    const RawRle &r = b.rle;
+    if (r.R == 0 || r.heads.size() != r.R || r.lens.size() != r.R) return RBG_EARG;
+    uint64_t max_len = 0;
+    for (uint64_t l : r.lens) max_len = std::max(max_len, l);
+    const unsigned len_width = max_len < (uint64_t(1) << 32) ? 4 : 8;
+    const unsigned pos_width = r.n < (uint64_t(1) << 32) ? 4 : 8;
+    std::string docs;
+    if (b.has_dl)
+        for (size_t i = 0; i < b.dl.names.size(); ++i) docs += b.dl.names[i] + " " + std::to_string(b.dl.starts[i]) + "\n";
+    FlatWriter w(fname);
+    if (!w.ok()) return RBG_EIO;
+    w.bytes(kFlatMagic, 8);
+    w.u64((b.has_tsa ? 1u : 0u) | (b.has_ma ? 2u : 0u) | (b.has_dl ? 4u : 0u));
+    w.u64(r.n); w.u64(r.R); w.u64(r.B); w.u64(len_width); w.u64(pos_width);
+    w.u64(b.has_ma ? b.ma.start.size() : 0);
+    w.u64(b.has_ma ? b.ma.vals.size() : 0);
+    w.u64(static_cast<uint64_t>(static_cast<int64_t>(b.has_ma ? b.ma.wsize : 0)));
+    w.u64(docs.size());
+    w.bytes(r.heads.data(), r.R);
+    w.section(r.lens.data(), r.R, len_width);
+    if (b.has_tsa) {
+        if (b.tsa.pred_pos.size() != r.R || b.tsa.samples_last.size() != r.R || b.tsa.pred_to_run.size() != r.R) return RBG_EARG;
+        w.section(b.tsa.pred_pos.data(), r.R, pos_width);
+        w.section(b.tsa.samples_last.data(), r.R, pos_width);
+        w.section(b.tsa.pred_to_run.data(), r.R, pos_width);
+    }
+    if (b.has_ma) {
+        const uint64_t nr = b.ma.start.size();
+        if (b.ma.end.size() != nr || b.ma.off.size() != nr + 1 || b.ma.off[nr] != b.ma.vals.size()) return RBG_EARG;
+        w.section(b.ma.start.data(), nr, pos_width);
+        w.section(b.ma.end.data(), nr, pos_width);
+        w.section(b.ma.off.data(), nr + 1, 8);
+        w.section(b.ma.vals.data(), b.ma.vals.size(), 8);
+    }
+    if (b.has_dl) w.bytes(docs.data(), docs.size());
+    return w.finish() ? RBG_OK : RBG_EIO;
+}
+
+int read_flat(const std::string &fname, FlatBundle &b) {
+    std::ifstream ifs(fname, std::ios::binary | std::ios::ate);
+    if (!ifs.good()) return RBG_EIO;
+    const uint64_t sz = static_cast<uint64_t>(ifs.tellg());
+    constexpr uint64_t kHeader = 8 * 11;
+    if (sz < kHeader + 8 || (sz & 7)) return RBG_EFORMAT;
+    std::vector<uint64_t> file(sz / 8);
+    ifs.seekg(0);
+    ifs.read(reinterpret_cast<char *>(file.data()), static_cast<std::streamsize>(sz));
+    if (static_cast<uint64_t>(ifs.gcount()) != sz) return RBG_EIO;
+    if (std::memcmp(file.data(), kFlatMagic, 8) != 0) return RBG_EFORMAT;
+    FlatSum sum;
+    sum.words(file.data(), file.size() - 1);
+    if (sum.h != file.back()) return RBG_EFORMAT;
+    b = FlatBundle();
+    const uint64_t flags = file[1];
+    RawRle &r = b.rle;
+    r.n = file[2]; r.R = file[3]; r.B = file[4];
+    const uint64_t len_width = file[5], pos_width = file[6], ma_nruns = file[7], ma_nvals = file[8], docs_bytes = file[10];
+    b.ma.wsize = static_cast<int32_t>(static_cast<int64_t>(file[9]));
+    b.has_tsa = flags & 1; b.has_ma = flags & 2; b.has_dl = flags & 4;
+    if ((flags & ~uint64_t(7)) || r.n == 0 || r.R == 0 || r.R > r.n || r.B == 0) return RBG_EFORMAT;
+    if ((len_width != 4 && len_width != 8) || (pos_width != 4 && pos_width != 8)) return RBG_EFORMAT;
+    if (pos_width == 4 && r.n >= (uint64_t(1) << 32)) return RBG_EFORMAT;
+    if (!b.has_ma && (ma_nruns || ma_nvals)) return RBG_EFORMAT;
+    if (!b.has_dl && docs_bytes) return RBG_EFORMAT;
+    const uint64_t body = sz - kHeader - 8;
+    // every count is bounded by the file size before anything is multiplied or allocated
+    if (r.R > body || ma_nruns > body / 4 || ma_nvals > body / 8 || docs_bytes > body) return RBG_EFORMAT;
+    uint64_t need = padded8(r.R) + padded8(r.R * len_width);
+    if (b.has_tsa) need += 3 * padded8(r.R * pos_width);
+    if (b.has_ma) need += 2 * padded8(ma_nruns * pos_width) + (ma_nruns + 1) * 8 + ma_nvals * 8;
+    need += padded8(docs_bytes);
+    if (need != body) return RBG_EFORMAT;
+    const unsigned char *p = reinterpret_cast<const unsigned char *>(file.data()) + kHeader;
+    r.heads.assign(p, p + r.R);
+    p += padded8(r.R);
+    widen(p, r.R, static_cast<unsigned>(len_width), r.lens);
+    p += padded8(r.R * len_width);
+    uint64_t total = 0;
+    for (uint64_t i = 0; i < r.R; ++i) {
+        if (r.lens[i] == 0 || r.lens[i] > r.n - total) return RBG_EFORMAT;
+        if (i && r.heads[i] == r.heads[i - 1]) return RBG_EFORMAT;  // runs are maximal
+        total += r.lens[i];
+    }
+    if (total != r.n) return RBG_EFORMAT;
+    if (b.has_tsa) {
+        RawTsa &t = b.tsa;
+        t.r = r.R; t.n = r.n;
+        widen(p, r.R, static_cast<unsigned>(pos_width), t.pred_pos);
+        p += padded8(r.R * pos_width);
+        widen(p, r.R, static_cast<unsigned>(pos_width), t.samples_last);
+        p += padded8(r.R * pos_width);
+        widen(p, r.R, static_cast<unsigned>(pos_width), t.pred_to_run);
+        p += padded8(r.R * pos_width);
+        for (uint64_t i = 0; i < r.R; ++i) {
+            if (t.pred_pos[i] >= r.n || (i && t.pred_pos[i] <= t.pred_pos[i - 1])) return RBG_EFORMAT;
+            if (t.samples_last[i] >= r.n || t.pred_to_run[i] >= r.R) return RBG_EFORMAT;
+        }
+    }
+    if (b.has_ma) {
+        RawMarkers &m = b.ma;
+        widen(p, ma_nruns, static_cast<unsigned>(pos_width), m.start);
+        p += padded8(ma_nruns * pos_width);
+        widen(p, ma_nruns, static_cast<unsigned>(pos_width), m.end);
+        p += padded8(ma_nruns * pos_width);
+        widen(p, ma_nruns + 1, 8, m.off);
+        p += (ma_nruns + 1) * 8;
+        widen(p, ma_nvals, 8, m.vals);
+        p += ma_nvals * 8;
+        if (m.off[0] != 0 || m.off[ma_nruns] != ma_nvals) return RBG_EFORMAT;
+        for (uint64_t i = 0; i < ma_nruns; ++i) {
+            if (m.end[i] < m.start[i] || m.end[i] >= r.n || m.off[i + 1] < m.off[i]) return RBG_EFORMAT;
+            if (i && m.start[i] <= m.end[i - 1]) return RBG_EFORMAT;
+        }
+    }
+    if (b.has_dl) {
+        std::istringstream ss(std::string(reinterpret_cast<const char *>(p), docs_bytes));
+        std::string name;
+        uint64_t pos = 0;
+        while (ss >> name >> pos) {
+            b.dl.names.push_back(name);
+            b.dl.starts.push_back(pos);
+        }
+        b.dl.sorted = b.dl.starts;
+        std::sort(b.dl.sorted.begin(), b.dl.sorted.end());
+    }
+    return RBG_OK;
+}
+
 // ---- flatten -------------------------------------------------------------------------------------
 namespace {
 // largest shift <= 8 (slot offsets are 8-bit, rbg_dev.h) with at most `per_slot` items per bucket on average

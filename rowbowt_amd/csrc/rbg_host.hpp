@@ -53,6 +53,26 @@ int read_raw_samples(const std::string &fname, std::vector<uint64_t> &y_out);
 // raw .ssa/.esa y values -> RawTsa (toehold_sa.hpp:105-155)
 void tsa_from_samples(uint64_t n, uint64_t r, const uint64_t *ssa_y, const uint64_t *esa_y, RawTsa &out);
 
+// ---- native cache file (next-row f1): everything the reference's .rbwt/.tsa/.mab/.docs hold, as flat
+// little-endian arrays ("<prefix>.rbgpu").  Loading it is a handful of freads: no wavelet-tree or
+// sd_vector decoding (rle_string::load, rle_string.hpp:265-275) and no re-encoding of a raw BWT
+// (rle_string.hpp:44-97).  Layout (all u64 unless noted, sections padded to 8 bytes):
+//   "RBGPUIX1" | flags (bit0 tsa, bit1 markers, bit2 docs) | n | R | B | len_width (4|8) | pos_width (4|8)
+//   | ma_nruns | ma_nvals | ma_wsize | docs_bytes
+//   | heads u8[R] | lens len_width[R]
+//   | tsa:  pred_pos pos_width[R] | samples_last pos_width[R] | pred_to_run pos_width[R]
+//   | ma:   start pos_width[nruns] | end pos_width[nruns] | off u64[nruns+1] | vals u64[nvals]
+//   | docs: the .docs text (doclist.hpp:57-73) | checksum of every preceding 8-byte word
+struct FlatBundle {
+    RawRle rle;
+    bool has_tsa = false, has_ma = false, has_dl = false;
+    RawTsa tsa;
+    RawMarkers ma;
+    RawDocs dl;
+};
+int write_flat(const std::string &fname, const FlatBundle &b);
+int read_flat(const std::string &fname, FlatBundle &b);  // RBG_EIO / RBG_EFORMAT on a missing, torn or inconsistent file
+
 // ---- the flat layout, host copy ------------------------------------------------------------------
 // One table per distinct BWT symbol ("slot").  Entry k describes the k-th run of that symbol:
 //   start[k] = BWT position where the run begins (ascending),

@@ -33,6 +33,6 @@ def _build_oracle():
     cli = os.path.join(ROOT, "rowbowt_amd", "rb_align")
     newest = max(os.path.getmtime(os.path.join(csrc, f)) for f in os.listdir(csrc) if f.endswith((".hip", ".cpp", ".h", ".hpp")))
     cli2 = os.path.join(ROOT, "rowbowt_amd", "rb_markers")
-    if not os.path.exists(lib) or not os.path.exists(cli) or not os.path.exists(cli2) or os.path.getmtime(lib) < newest:
+    if not os.path.exists(lib) or not os.path.exists(cli) or not os.path.exists(cli2) or not os.path.exists(os.path.join(ROOT, "rowbowt_amd", "rb_build")) or os.path.getmtime(lib) < newest:
         subprocess.check_call(["make", "-C", csrc, "-j4"])
     yield

@@ -175,3 +175,98 @@ def test_build_from_raw_files(tmp_path):
     with pytest.raises(ra.RbgError) as e:
         ra.RowBowt.from_files(str(tmp_path / "missing.bwt"), device=capi.DEVICE_NONE)
     assert e.value.code == -1
+
+
+HOST_ARRAYS = (capi.ARR_RUN_HEADS, capi.ARR_RUN_START, capi.ARR_SAMPLES_LAST, capi.ARR_PRED_POS, capi.ARR_PHI_BASE,
+               capi.ARR_MARKER_START, capi.ARR_MARKER_END, capi.ARR_MARKER_OFF, capi.ARR_MARKER_VALS)
+
+
+def _same_index(a, b, arrays=HOST_ARRAYS):
+    for which in arrays:
+        assert (a.host_array(which) == b.host_array(which)).all(), which
+    assert (a.get_f() == b.get_f()).all()
+    ia, ib = a.info(), b.info()
+    assert (ia.n, ia.r, ia.sigma, ia.has_tsa, ia.has_markers, ia.has_docs) == (ib.n, ib.r, ib.sigma, ib.has_tsa, ib.has_markers, ib.has_docs)
+
+
+def test_native_cache_from_reference_index(tmp_path, data_dir, small_host):
+    """next-row f1: .rbwt/.tsa/.mab/.docs -> flat .rbgpu -> the same host index; rbg_load falls back to it"""
+    import shutil
+    pre = os.path.join(data_dir, "small.fa")
+    for suf in (".rbwt", ".tsa", ".mab"):
+        shutil.copy(pre + suf, tmp_path / ("idx" + suf))
+    (tmp_path / "idx.docs").write_text("ref 0\nhap1 10010\nhap2 20020\n")
+    ALL = ra.LoadRbwtFlag.SA | ra.LoadRbwtFlag.MA | ra.LoadRbwtFlag.DL
+    cache = tmp_path / "only" / "idx.rbgpu"
+    cache.parent.mkdir()
+    capi.convert_index(str(tmp_path / "idx"), ALL, str(cache))
+    ref = ra.load_rowbowt(str(tmp_path / "idx"), ALL, device=capi.DEVICE_NONE)
+    a = ra.RowBowt.from_cache(str(cache), ALL, device=capi.DEVICE_NONE)
+    _same_index(a, ref)
+    assert a.resolve_offset(20306) == ref.resolve_offset(20306) == ("hap2", 286)
+    # prefix with no .rbwt next to it: rbg_load picks the cache up (what rb_align does after rb_build)
+    b = ra.load_rowbowt(str(tmp_path / "only" / "idx"), ALL, device=capi.DEVICE_NONE)
+    _same_index(b, ref)
+    # parts are selectable; a part the file lacks is a missing file
+    c = ra.RowBowt.from_cache(str(cache), ra.LoadRbwtFlag.NONE, device=capi.DEVICE_NONE)
+    assert not c.info().has_tsa and not c.info().has_markers and c.info().r == ref.info().r
+    capi.convert_index(str(tmp_path / "idx"), ra.LoadRbwtFlag.NONE, str(tmp_path / "bare.rbgpu"))
+    with pytest.raises(ra.RbgError) as e:
+        ra.RowBowt.from_cache(str(tmp_path / "bare.rbgpu"), ra.LoadRbwtFlag.SA, device=capi.DEVICE_NONE)
+    assert e.value.code == -1
+    # the cache is smaller than the decoded arrays and a torn one is refused
+    blob = cache.read_bytes()
+    assert blob[:8] == b"RBGPUIX1" and len(blob) % 8 == 0
+    for bad in (blob[:-8], blob[:1000], blob[:40] + bytes([blob[40] ^ 1]) + blob[41:], b"RBGPUIX1" + bytes(200)):
+        (tmp_path / "bad.rbgpu").write_bytes(bad)
+        with pytest.raises(ra.RbgError) as e:
+            ra.RowBowt.from_cache(str(tmp_path / "bad.rbgpu"), ra.LoadRbwtFlag.NONE, device=capi.DEVICE_NONE)
+        assert e.value.code == -2
+    with pytest.raises(ra.RbgError) as e:
+        ra.RowBowt.from_cache(str(tmp_path / "nope.rbgpu"), device=capi.DEVICE_NONE)
+    assert e.value.code == -1
+
+
+def test_rb_build_cli_raw_inputs(tmp_path):
+    """rb_build on rb_build's raw inputs (.bwt/.ssa/.esa/.docs, rb_build.cpp:83-93) -> .rbgpu == building from runs"""
+    import subprocess
+    import naive
+    from synth import SynthIndex
+    S = SynthIndex(L=700, H=5, n_sites=15, seed=8)
+    bwt = naive.bwt_from_sa(S.text, S.fm.sa).copy()
+    (tmp_path / "x.bwt").write_bytes(bwt.tobytes().replace(b"\x01", b"\x00"))
+    pairs = lambda y: np.stack([np.zeros(len(y), dtype=np.uint64), y.astype(np.uint64)], axis=1).tobytes()
+    (tmp_path / "x.ssa").write_bytes(pairs(S.ssa))
+    (tmp_path / "x.esa").write_bytes(pairs(S.esa))
+    (tmp_path / "x.docs").write_text("a 0\nb 701\n")
+    exe = os.path.join(ROOT, "rowbowt_amd", "rb_build")
+    (tmp_path / "out").mkdir()
+    p = subprocess.run([exe, "-s", "-l", "-o", str(tmp_path / "out" / "y"), str(tmp_path / "x")], capture_output=True, timeout=60)
+    assert p.returncode == 0, p.stderr.decode()
+    assert (tmp_path / "out" / "y.docs").read_text() == "a 0\nb 701\n"   # copied, rowbowt_io.hpp:73-80
+    got = ra.load_rowbowt(str(tmp_path / "out" / "y"), ra.LoadRbwtFlag.SA | ra.LoadRbwtFlag.DL, device=capi.DEVICE_NONE)
+    want = ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=capi.DEVICE_NONE)
+    for which in HOST_ARRAYS[:5]:
+        assert (got.host_array(which) == want.host_array(which)).all()
+    assert got.resolve_offset(705) == ("b", 4)
+    # without -s no toehold SA is stored; asking for it later is a missing file
+    p = subprocess.run([exe, "-o", str(tmp_path / "out" / "z"), str(tmp_path / "x")], capture_output=True, timeout=60)
+    assert p.returncode == 0
+    with pytest.raises(ra.RbgError):
+        ra.load_rowbowt(str(tmp_path / "out" / "z"), ra.LoadRbwtFlag.SA, device=capi.DEVICE_NONE)
+    # error paths: missing input ("does not exist", rowbowt_io.hpp:23-26), no argument, raw .ma, fbb
+    p = subprocess.run([exe, "-s", str(tmp_path / "nope")], capture_output=True, timeout=60)
+    assert p.returncode == 1 and b"does not exist" in p.stderr
+    p = subprocess.run([exe], capture_output=True, timeout=60)
+    assert p.returncode == 1 and b"no argument provided" in p.stderr
+    p = subprocess.run([exe, "-m", str(tmp_path / "x")], capture_output=True, timeout=60)
+    assert p.returncode == 1 and b".mab" in p.stderr
+    p = subprocess.run([exe, "-x", str(tmp_path / "x")], capture_output=True, timeout=60)
+    assert p.returncode == 1
+    # --from-index converts a reference-built index
+    data = os.path.join(ROOT, "tests", "data", "small.fa")
+    p = subprocess.run([exe, "--from-index", "-s", "-m", "-o", str(tmp_path / "out" / "small"), data], capture_output=True, timeout=60)
+    assert p.returncode == 0, p.stderr.decode()
+    a = ra.load_rowbowt(str(tmp_path / "out" / "small"), ra.LoadRbwtFlag.SA | ra.LoadRbwtFlag.MA, device=capi.DEVICE_NONE)
+    b = ra.load_rowbowt(data, ra.LoadRbwtFlag.SA | ra.LoadRbwtFlag.MA, device=capi.DEVICE_NONE)
+    _same_index(a, b)

@@ -460,6 +460,52 @@ def test_cli_rb_markers_stdout(data_dir, tmp_path, small):
     assert rc == 1 and "bad file" in err
 
 
+# ---- next-row f1: rb_build outputs (native cache, the reference's text .ftab) ----------------------
+def test_ftab_file_and_cache_only_prefix(data_dir, tmp_path, small, simple_reads):
+    import itertools
+    import subprocess
+    rb, o = small
+    # RowBowt::build_ftab(k) + FTab::serialize (rowbowt.hpp:726-744, ftab.hpp:29-34) against the oracle
+    for k in (1, 3, 5):
+        rb.write_ftab(k, str(tmp_path / f"k{k}.ftab"))
+        want = ""
+        for kmer in sorted("".join(t) for t in itertools.product("ACGT", repeat=k)):   # std::map order
+            lo, hi = o.find_range(kmer.encode())
+            if lo <= hi:
+                want += f"{kmer} {lo} {hi}\n"
+        assert (tmp_path / f"k{k}.ftab").read_text() == want
+    # rb_build --from-index -f -k 10: cache + .ftab holding the FTab tests' answers (rb_tests.cpp:147-173)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "rowbowt_amd", "rb_build")
+    out = tmp_path / "built" / "small"
+    out.parent.mkdir()
+    p = subprocess.run([exe, "--from-index", "-s", "-m", "-f", "-k", "10", "-o", str(out), os.path.join(data_dir, "small.fa")],
+                       capture_output=True, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()
+    lines = (tmp_path / "built" / "small.ftab").read_text().splitlines()
+    assert lines == sorted(lines) and all(len(l.split()[0]) == 10 for l in lines)
+    table = {l.split()[0]: (int(l.split()[1]), int(l.split()[2])) for l in lines}
+    assert table["TTCGTCGTAA"] == G.KMER_RANGES[b"TTCGTCGTAA"] == (28942, 28944)
+    n_kmers = 0
+    for kmer, (lo, hi) in list(table.items())[::97]:
+        assert o.find_range(kmer.encode()) == (lo, hi)
+        n_kmers += 1
+    assert n_kmers > 100 and len(table) <= 30031
+    # the CLIs run from a prefix that only has the cache (no .rbwt/.tsa/.mab): same bytes as from the reference's files
+    (tmp_path / "built" / "small.docs").write_text("ref 0\nhap1 10010\nhap2 20020\n")
+    import shutil
+    for suf in (".rbwt", ".tsa", ".mab"):
+        shutil.copy(os.path.join(data_dir, "small.fa" + suf), tmp_path / ("full" + suf))
+    (tmp_path / "full.docs").write_text("ref 0\nhap1 10010\nhap2 20020\n")
+    fq = os.path.join(data_dir, "simple_query.fq")
+    a = _run_cli(["-s", "-m", str(out), fq])
+    b = _run_cli(["-s", "-m", str(tmp_path / "full"), fq])
+    assert a[0] == b[0] == 0 and a[1] == b[1] and "20306/hap2:286" in a[1]
+    a = _run_rb_markers([str(out), fq])
+    b = _run_rb_markers([os.path.join(data_dir, "small.fa"), fq])
+    assert a[0] == b[0] == 0 and a[1] == b[1] and a[1]
+
+
 # ---- mid-scale (n ~ 4e6) synthetic pangenome built with the bench's own generator on the GPU:
 # count, toehold, locate, markers (BASELINE configs 2, 3, 5 in miniature) against the oracle -----
 def test_midscale_pangenome_all_queries():

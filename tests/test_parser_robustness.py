@@ -94,6 +94,23 @@ int main(int argc, char** argv) {
     if (!a && !b) { HostIndex ix; FlattenOptions o; d = flatten(rle, &tsa, o, ix);
         if (!d) std::printf("n=%llu r=%llu sigma=%u pairs=%zu triples=%zu\n", (unsigned long long)ix.n, (unsigned long long)ix.r, ix.sigma, ix.pair.size(), ix.triple.size()); }
     std::printf("rc %d %d %d %d\n", a, b, c, d);
+    if (argc > 2) {   // native cache: write from the decoded files, read back; then read a (damaged) copy
+        std::string cache = argv[2];
+        if (!a && !b && !c && argc > 3) {
+            FlatBundle fb; fb.rle = rle; fb.tsa = tsa; fb.ma = ma; fb.has_tsa = fb.has_ma = true;
+            fb.dl.names = {"ref", "hap1"}; fb.dl.starts = {0, 10010}; fb.has_dl = true;
+            int w = write_flat(cache, fb);
+            FlatBundle back; int r = read_flat(cache, back);
+            bool same = !r && back.rle.heads == rle.heads && back.rle.lens == rle.lens && back.tsa.pred_pos == tsa.pred_pos &&
+                        back.tsa.samples_last == tsa.samples_last && back.tsa.pred_to_run == tsa.pred_to_run && back.ma.vals == ma.vals &&
+                        back.ma.start == ma.start && back.ma.end == ma.end && back.ma.off == ma.off && back.dl.names == fb.dl.names &&
+                        back.dl.starts == fb.dl.starts && back.ma.wsize == ma.wsize;
+            std::printf("flat %d %d %d\n", w, r, same ? 1 : 0);
+        } else {
+            FlatBundle back; int r = read_flat(cache, back);
+            std::printf("flatread %d\n", r);
+        }
+    }
     return 0;
 }
 ''')
@@ -105,6 +122,27 @@ int main(int argc, char** argv) {
     p = subprocess.run([str(exe), good], capture_output=True, timeout=120)
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     assert b"n=30031 r=7573 sigma=5 pairs=16 triples=64" in p.stdout and b"rc 0 0 0 0" in p.stdout
+    cache = tmp_path / "c.rbgpu"
+    p = subprocess.run([str(exe), good, str(cache), "write"], capture_output=True, timeout=120)
+    assert p.returncode == 0 and b"flat 0 0 1" in p.stdout, p.stderr.decode()[-3000:]
+    blob = cache.read_bytes()
+    rng = np.random.default_rng(11)
+    n_rejected = 0
+    for trial in range(80):
+        b = bytearray(blob)
+        if trial % 4 == 0:
+            b = b[: int(rng.integers(0, len(b)))]
+        elif trial % 4 == 1:
+            pos = int(rng.integers(0, len(b))); b[pos] ^= 1 << int(rng.integers(0, 8))
+        elif trial % 4 == 2:   # plausible header edits with the checksum recomputed would need the key; plain edits here
+            pos = 8 * int(rng.integers(1, 11)); b[pos:pos + 8] = bytes(rng.integers(0, 256, 8, dtype=np.uint8))
+        else:
+            b += bytes(8 * int(rng.integers(1, 4)))
+        (tmp_path / "d.rbgpu").write_bytes(bytes(b))
+        p = subprocess.run([str(exe), good, str(tmp_path / "d.rbgpu")], capture_output=True, timeout=120)
+        assert p.returncode == 0, (trial, p.stderr.decode()[-3000:])
+        n_rejected += b"flatread -2" in p.stdout
+    assert n_rejected == 80
     rng = np.random.default_rng(7)
     for trial in range(60):
         for suf in (".rbwt", ".tsa", ".mab"):
