@@ -98,6 +98,10 @@ int rbg_load_cache(const char *path, int flags, int device, rbg_index **out);
 /* RowBowt::build_ftab(k) + FTab::serialize (rowbowt.hpp:726-744, ftab.hpp:29-34): the reference's
  * text .ftab ("<kmer> <lo> <hi>" per line, lexicographic), computed with the search kernel. 1 <= k <= 16. */
 int rbg_write_ftab(rbg_index *, uint64_t k, const char *path);
+/* What loading a .ftab amounts to here (LoadRbwtFlag::FT, rowbowt_io.hpp:187; FTab::load, ftab.hpp:15-27):
+ * the file must be, byte for byte, the table build_ftab(k) makes for this index (RBG_EFORMAT if not);
+ * *k_out = its k-mer size, the `ftab_k` argument of the marker-seed calls below. */
+int rbg_check_ftab(rbg_index *, const char *path, uint64_t *k_out);
 /* MarkerArray contents (pfbwt-f marker_array.hpp, loaded at rowbowt_io.hpp:185):
  * inclusive SA-index runs + mk_off[nruns+1] offsets into mk_vals. */
 int rbg_set_markers(rbg_index *, const uint64_t *run_start, const uint64_t *run_end, uint64_t nruns,
@@ -178,8 +182,13 @@ int rbg_find_range_w_markers(rbg_index *, const uint8_t *seqs, const uint64_t *o
                              uint64_t wsize, uint64_t max_range,
                              uint64_t *lo, uint64_t *hi, uint64_t *mk_off, uint64_t **mk);
 /* Next-row f4 (marker seeds).  RowBowt::get_markers_greedy_seeding(query, wsize, max_range, fn),
- * rowbowt.hpp:406-482, in the form rb_markers runs it (no ftab: rb_markers.cpp:25,411-413): one
- * record per call of the callback fn(range, (q.first, q.second), mbuf), in call order.  The
+ * rowbowt.hpp:406-482, as rb_markers runs it (rb_markers.cpp:411-413): one record per call of the
+ * callback fn(range, (q.first, q.second), mbuf), in call order.  ftab_k = 0: no ftab loaded
+ * (rb_markers' default, rb_markers.cpp:25); ftab_k = K > 0: with the ftab of k-mer size K loaded
+ * (rb_markers --ftab): the first K bases and every restart after a failed seed go through
+ * search_ftab (rowbowt.hpp:430-433, :454-464), computed as find_range of the ACGT-only k-mer (see
+ * rbg_check_ftab).  A read shorter than K makes the reference throw (substr, :431); here its
+ * first lookup counts as a miss.  The reference requires K - 1 <= wsize (:423-426).  The
  * markers are NOT sorted or deduplicated (the caller's out_fn does that, rb_markers.cpp:374-380).
  * Works without a marker array too (every mbuf empty), like the reference (:273, :283). */
 typedef struct rbg_marker_seed {
@@ -192,7 +201,7 @@ typedef struct rbg_marker_seed {
 /* seed_off[N+1] written; *seeds (seed_off[N] records) and *mk are malloc()ed by the library:
  * release both with rbg_free_buffer. */
 int rbg_get_markers_greedy_seeding(rbg_index *, const uint8_t *seqs, const uint64_t *off, uint64_t N,
-                                   uint64_t wsize, uint64_t max_range,
+                                   uint64_t wsize, uint64_t max_range, uint64_t ftab_k,
                                    uint64_t *seed_off, rbg_marker_seed_t **seeds, uint64_t **mk);
 /* Next-row f4 (greedy seeding).  RowBowt::get_seeds_greedy_w_sample(query, min_length),
  * rowbowt.hpp:222-256, reduced by the choice locate_from_longest_seed makes (rowbowt.hpp:669-677):
@@ -243,10 +252,10 @@ int rbg_greedy_longest_seed_dev(rbg_index *, const uint8_t *d_seqs, const uint64
 /* marker seeds, two-phase: plan writes the exclusive scans d_seed_off[N+1] (records per read) and
  * d_mk_off[N+1] (markers per read); the caller sizes d_seeds / d_mk from their last entries. */
 int rbg_marker_seeds_plan_dev(rbg_index *, const uint8_t *d_seqs, const uint64_t *d_off, uint64_t N, uint64_t wsize,
-                              uint64_t max_range, uint64_t *d_seed_off, uint64_t *d_mk_off, void *d_tmp, size_t tmp_bytes,
+                              uint64_t max_range, uint64_t ftab_k, uint64_t *d_seed_off, uint64_t *d_mk_off, void *d_tmp, size_t tmp_bytes,
                               void *stream);
 int rbg_marker_seeds_fill_dev(rbg_index *, const uint8_t *d_seqs, const uint64_t *d_off, uint64_t N, uint64_t wsize,
-                              uint64_t max_range, const uint64_t *d_seed_off, const uint64_t *d_mk_off,
+                              uint64_t max_range, uint64_t ftab_k, const uint64_t *d_seed_off, const uint64_t *d_mk_off,
                               rbg_marker_seed_t *d_seeds, uint64_t *d_mk, void *stream);
 /* markers, same two-phase shape */
 int rbg_markers_plan_dev(rbg_index *, const uint64_t *d_lo, const uint64_t *d_hi, uint64_t N,

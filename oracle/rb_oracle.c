@@ -519,13 +519,26 @@ uint64_t orc_find_range_w_markers(const orc_index *x, const uint8_t *q, uint64_t
     return total;
 }
 
-/* rowbowt.hpp:406-482 with ft_ == nullptr.  mbuf is appended to by every update_mbuf (markers_at
- * does not clear, :271-285, :437-441) and cleared only after a failed seed was reported (:449). */
-uint64_t orc_markers_greedy_seeding(const orc_index *x, const uint8_t *q, uint64_t m, uint64_t wsize, uint64_t max_range,
-                                    uint64_t *seeds, uint64_t cap_seeds, uint64_t *mk_out, uint64_t cap_mk, uint64_t *nmk) {
+/* search_ftab (rowbowt.hpp:746-758) for the k-mer q[e-K, e) when the ftab is the one build_ftab(K)
+ * makes for this index (rowbowt.hpp:726-744): its keys are the k-mers over ACGT with a non-empty
+ * range and its values are find_range's, so a lookup is find_range on an ACGT-only k-mer. */
+static int ftab_hit(const orc_index *x, const uint8_t *q, uint64_t e, uint64_t K, uint64_t *l, uint64_t *h) {
+    for (uint64_t t = e - K; t < e; ++t)
+        if (q[t] != 'A' && q[t] != 'C' && q[t] != 'G' && q[t] != 'T') return 0;
+    orc_find_range(x, q + (e - K), K, l, h);
+    return *h >= *l;
+}
+
+/* rowbowt.hpp:406-482.  K == 0: ft_ == nullptr (rb_markers' default).  K > 0: with the ftab of
+ * k-mer size K loaded (rb_markers --ftab): the first K bases and every restart after a failed seed
+ * go through search_ftab (:430-433, :454-464).  mbuf is appended to by every update_mbuf (markers_at
+ * does not clear, :271-285, :437-441) and cleared only after a failed seed was reported (:449).
+ * A read shorter than K makes the reference throw (substr, :431); here it is treated as a miss. */
+uint64_t orc_markers_greedy_seeding_ftab(const orc_index *x, const uint8_t *q, uint64_t m, uint64_t wsize, uint64_t max_range,
+                                         uint64_t K, uint64_t *seeds, uint64_t cap_seeds, uint64_t *mk_out, uint64_t cap_mk,
+                                         uint64_t *nmk) {
     const uint64_t fl = 0, fh = x->n - 1;          /* full_range(), :115-118 */
     uint64_t l = fl, h = fh, pl = fl, ph = fh;     /* range, prev_range :427-428 */
-    uint64_t window_ei = m, seed_ei = m;           /* :434 */
     uint64_t ns = 0, tot = 0, mb_begin = 0;        /* mbuf == markers [mb_begin, tot) */
 #define UPDATE_MBUF(L_, H_)                                                                \
     do {                                                                                   \
@@ -543,8 +556,14 @@ uint64_t orc_markers_greedy_seeding(const orc_index *x, const uint8_t *q, uint64
         }                                                                                  \
         ++ns;                                                                              \
     } while (0)
-    uint64_t i;
-    for (i = 0; i < m; ++i) {
+    uint64_t i = 0;
+    if (K && m >= K) {                             /* :430-433 */
+        uint64_t tl, th;
+        if (ftab_hit(x, q, m, K, &tl, &th)) { l = tl; h = th; i = K; }
+        pl = l; ph = h;
+    }
+    uint64_t window_ei = m, seed_ei = m;           /* :434 */
+    for (; i < m; ++i) {
         orc_LF(x, l, h, q[m - i - 1], &l, &h);     /* :443 */
         if (h < l) {                               /* :444 the seed fails */
             if (seed_ei - (m - i) >= wsize) UPDATE_MBUF(pl, ph);   /* :445-447 */
@@ -553,7 +572,19 @@ uint64_t orc_markers_greedy_seeding(const orc_index *x, const uint8_t *q, uint64
             pl = fl; ph = fh;                      /* :450 */
             seed_ei = m - i - 1;                   /* :452-453 */
             window_ei = m - i - 1;
-            l = fl; h = fh;                        /* :466 */
+            if (K && m - i - 1 >= K) {             /* :454-464 slide left until a k-mer is in the ftab */
+                for (; m - i - 1 >= K; ++i) {
+                    seed_ei = m - i - 1;
+                    window_ei = m - i - 1;
+                    uint64_t tl, th;
+                    if (ftab_hit(x, q, m - i - 1, K, &tl, &th)) {
+                        l = tl; h = th;
+                        i += K;                    /* :460, then the outer ++i */
+                        pl = l; ph = h;
+                        break;
+                    } else { l = fl; h = fh; }     /* :463 */
+                }
+            } else { l = fl; h = fh; }             /* :466 */
         } else {
             if (window_ei - (m - i - 1) >= wsize) {    /* :469-472 */
                 UPDATE_MBUF(l, h);
@@ -568,6 +599,11 @@ uint64_t orc_markers_greedy_seeding(const orc_index *x, const uint8_t *q, uint64
 #undef EMIT
     if (nmk) *nmk = tot;
     return ns;
+}
+
+uint64_t orc_markers_greedy_seeding(const orc_index *x, const uint8_t *q, uint64_t m, uint64_t wsize, uint64_t max_range,
+                                    uint64_t *seeds, uint64_t cap_seeds, uint64_t *mk_out, uint64_t cap_mk, uint64_t *nmk) {
+    return orc_markers_greedy_seeding_ftab(x, q, m, wsize, max_range, 0, seeds, cap_seeds, mk_out, cap_mk, nmk);
 }
 
 /* rowbowt.hpp:222-256 + :664-685 */

@@ -100,6 +100,11 @@ uint64_t orc_greedy_locate(const orc_index *, const uint8_t *q, uint64_t m, uint
  * of records, *nmk = number of markers. */
 uint64_t orc_markers_greedy_seeding(const orc_index *, const uint8_t *q, uint64_t m, uint64_t wsize, uint64_t max_range,
                                     uint64_t *seeds, uint64_t cap_seeds, uint64_t *mk_out, uint64_t cap_mk, uint64_t *nmk);
+/* the same with the ftab of k-mer size K loaded (rb_markers --ftab; rowbowt.hpp:430-433, :454-464); K = 0 is the
+ * function above.  The ftab is the one build_ftab(K) makes for this index (rowbowt.hpp:726-744). */
+uint64_t orc_markers_greedy_seeding_ftab(const orc_index *, const uint8_t *q, uint64_t m, uint64_t wsize, uint64_t max_range,
+                                         uint64_t K, uint64_t *seeds, uint64_t cap_seeds, uint64_t *mk_out, uint64_t cap_mk,
+                                         uint64_t *nmk);
 /* rowbowt.hpp:623-625 -> doclist.hpp:46-50.  Returns pointer to the doc name (owned by index), offset in *off. */
 const char *orc_resolve_offset(const orc_index *, uint64_t i, uint64_t *off);
 

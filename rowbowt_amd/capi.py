@@ -59,6 +59,7 @@ _PROTOS = [
     ("rbg_convert_raw", C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p]),
     ("rbg_load_cache", C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(VP)]),
     ("rbg_write_ftab", C.c_int, [VP, U64, C.c_char_p]),
+    ("rbg_check_ftab", C.c_int, [VP, C.c_char_p, C.POINTER(U64)]),
     ("rbg_set_markers", C.c_int, [VP, VP, VP, U64, VP, VP]),
     ("rbg_set_docs", C.c_int, [VP, C.c_char_p, VP, U64]),
     ("rbg_free", None, [VP]),
@@ -73,7 +74,7 @@ _PROTOS = [
     ("rbg_locs_at", C.c_int, [VP, VP, VP, VP, U64, U64, VP, C.POINTER(VP)]),
     ("rbg_markers_at", C.c_int, [VP, VP, VP, U64, VP, C.POINTER(VP)]),
     ("rbg_find_range_w_markers", C.c_int, [VP, VP, VP, U64, U64, U64, VP, VP, VP, C.POINTER(VP)]),
-    ("rbg_get_markers_greedy_seeding", C.c_int, [VP, VP, VP, U64, U64, U64, VP, C.POINTER(VP), C.POINTER(VP)]),
+    ("rbg_get_markers_greedy_seeding", C.c_int, [VP, VP, VP, U64, U64, U64, U64, VP, C.POINTER(VP), C.POINTER(VP)]),
     ("rbg_greedy_longest_seed", C.c_int, [VP, VP, VP, U64, U64, VP, VP, VP, VP, VP]),
     ("rbg_find_locs_greedy_seeding", C.c_int, [VP, VP, VP, U64, U64, U64, VP, C.POINTER(VP)]),
     ("rbg_free_buffer", None, [VP]),
@@ -87,8 +88,8 @@ _PROTOS = [
     ("rbg_locate_fill_dev", C.c_int, [VP, VP, VP, VP, U64, U64, VP, VP, VP, VP]),
     ("rbg_locate_fill_offset_dev", C.c_int, [VP, VP, VP, VP, U64, U64, VP, VP, VP, VP, VP]),
     ("rbg_greedy_longest_seed_dev", C.c_int, [VP, VP, VP, U64, U64, VP, VP, VP, VP, VP, VP]),
-    ("rbg_marker_seeds_plan_dev", C.c_int, [VP, VP, VP, U64, U64, U64, VP, VP, VP, C.c_size_t, VP]),
-    ("rbg_marker_seeds_fill_dev", C.c_int, [VP, VP, VP, U64, U64, U64, VP, VP, VP, VP, VP]),
+    ("rbg_marker_seeds_plan_dev", C.c_int, [VP, VP, VP, U64, U64, U64, U64, VP, VP, VP, C.c_size_t, VP]),
+    ("rbg_marker_seeds_fill_dev", C.c_int, [VP, VP, VP, U64, U64, U64, U64, VP, VP, VP, VP, VP]),
     ("rbg_markers_plan_dev", C.c_int, [VP, VP, VP, U64, VP, VP, C.c_size_t, VP]),
     ("rbg_markers_fill_dev", C.c_int, [VP, VP, VP, U64, VP, VP, VP]),
     ("rbg_counters", C.c_int, [VP, VP]),
@@ -217,6 +218,12 @@ class RowBowt:
         """RowBowt::build_ftab(k) + FTab::serialize (rowbowt.hpp:726-744, ftab.hpp:29-34)"""
         _check(self.L.rbg_write_ftab(self.h, k, os.fsencode(path)), "rbg_write_ftab")
 
+    def check_ftab(self, path):
+        """-> k of a .ftab file that is exactly build_ftab(k) of this index (LoadRbwtFlag::FT), else RbgError"""
+        k = U64()
+        _check(self.L.rbg_check_ftab(self.h, os.fsencode(path), C.byref(k)), "rbg_check_ftab")
+        return k.value
+
     # ---- introspection
     def info(self):
         i = Info()
@@ -293,13 +300,13 @@ class RowBowt:
                                                _p(lo), _p(hi), _p(mk_off), C.byref(ptr)), "rbg_find_range_w_markers")
         return lo, hi, mk_off, _take(ptr, int(mk_off[N]))
 
-    def get_markers_greedy_seeding(self, seqs, off, wsize, max_range=MAXU):
-        """RowBowt::get_markers_greedy_seeding without ftab (rowbowt.hpp:406-482): -> seed_off[N+1],
-        seeds[S,6] = (lo, hi, qstart, qend, mk_begin, mk_end), mk"""
+    def get_markers_greedy_seeding(self, seqs, off, wsize, max_range=MAXU, ftab_k=0):
+        """RowBowt::get_markers_greedy_seeding (rowbowt.hpp:406-482), ftab_k = k-mer size of the loaded
+        ftab or 0: -> seed_off[N+1], seeds[S,6] = (lo, hi, qstart, qend, mk_begin, mk_end), mk"""
         N = len(off) - 1
         seed_off = np.zeros(N + 1, np.uint64)
         ps, pm = VP(), VP()
-        _check(self.L.rbg_get_markers_greedy_seeding(self.h, _p(seqs), _p(off), N, wsize, max_range & MAXU, _p(seed_off),
+        _check(self.L.rbg_get_markers_greedy_seeding(self.h, _p(seqs), _p(off), N, wsize, max_range & MAXU, ftab_k, _p(seed_off),
                                                      C.byref(ps), C.byref(pm)), "rbg_get_markers_greedy_seeding")
         S = int(seed_off[N])
         seeds = _take(ps, 6 * S).reshape(S, 6)

@@ -10,10 +10,12 @@
 // One stdout line per seed (rb_markers.cpp:253-262):
 //   "<name> <range_size> <+|-> <query_start> <query_len>" { " <seq>/<pos>/<allele>" | " ." } "\n"
 //
+// --ftab/-f loads <index_prefix>.ftab like the reference (LoadRbwtFlag::FT): the file must be the one
+// `rb_build -f` makes for this index (checked), and seeding then goes through search_ftab
+// (rowbowt.hpp:430-433, :454-464).
+//
 // Not carried over (each exits 1 with a message, like the reference does for --overlap):
-//   --ftab/-f   the reference's ftab-seeded variant (rowbowt.hpp:430-433, :454-464) finds different
-//               seeds; only the default no-ftab path is built here
-//   --lmem      needs the ftab (rowbowt.hpp:346-349 exits 1 without it)
+//   --lmem      get_markers_lmems (rowbowt.hpp:341-404) prints debugging text per step and is O(m^2)
 //   --fbb/-x    other string type, other index file
 #include <getopt.h>
 #include <zlib.h>
@@ -107,11 +109,7 @@ RbMarkersArgs parse_args(int argc, char **argv) {  // rb_markers.cpp:56-134
         exit(1);
     }
     if (args.lmem) {  // without an ftab the reference stops at rowbowt.hpp:346-349
-        fprintf(stderr, "ftab must be enabled!\n");
-        exit(1);
-    }
-    if (args.ftab) {
-        fprintf(stderr, "rb_markers: the ftab-seeded variant (--ftab) is not built in this engine; run without it\n");
+        fprintf(stderr, args.ftab ? "rb_markers: --lmem is not built in this engine\n" : "ftab must be enabled!\n");
         exit(1);
     }
     if (args.fbb) {
@@ -318,13 +316,20 @@ struct RandomBoolGenerator {
 void report_batch(const rbwt::RowBowt<> &rb, const RbMarkersArgs &args, const PackedBatch &b, RandomBoolGenerator &booler,
                   std::vector<std::string> &pieces) {
     const size_t N = b.size();
+    const uint64_t ft_k = rb.ftab_k();
+    if (ft_k)
+        for (size_t i = 0; i < N; ++i)
+            if (b.off[i + 1] - b.off[i] < ft_k) {  // the reference dies in std::string::substr (rowbowt.hpp:431)
+                fprintf(stderr, "ERROR: read shorter than the ftab k-mer size (%llu)\n", static_cast<unsigned long long>(ft_k));
+                exit(1);
+            }
     std::string seqs;
     std::vector<uint64_t> off;
     make_strands(b, seqs, off);
     BatchSeeds r;
     r.seed_off.resize(2 * N + 1);
     rbwt::detail::check(rbg_get_markers_greedy_seeding(rb.handle(), reinterpret_cast<const uint8_t *>(seqs.data()), off.data(), 2 * N,
-                                                       args.wsize, args.max_range, r.seed_off.data(), &r.seeds, &r.mk),
+                                                       args.wsize, args.max_range, ft_k, r.seed_off.data(), &r.seeds, &r.mk),
                         "rbg_get_markers_greedy_seeding");
     std::vector<uint8_t> first_fwd(N, 1);
     if (args.heuristic)
@@ -343,8 +348,14 @@ void report_batch(const rbwt::RowBowt<> &rb, const RbMarkersArgs &args, const Pa
 int main(int argc, char **argv) {
     const RbMarkersArgs args = parse_args(argc, argv);
     auto start = std::chrono::high_resolution_clock::now();
-    std::cerr << "(rle_string_sd) loading rowbowt + markers" << std::endl;  // rb_markers.cpp:553-557
-    rbwt::RowBowt<> rb = rbwt::load_rowbowt<>(args.inpre, rbwt::LoadRbwtFlag::MA, args.device);  // :541-546
+    std::cerr << "(rle_string_sd) loading rowbowt + markers" << (args.ftab ? " and ftab" : "") << std::endl;  // rb_markers.cpp:553-557
+    rbwt::LoadRbwtFlag flag = rbwt::LoadRbwtFlag::MA;  // :541-546
+    if (args.ftab) flag = flag | rbwt::LoadRbwtFlag::FT;
+    rbwt::RowBowt<> rb = rbwt::load_rowbowt<>(args.inpre, flag, args.device);
+    if (rb.ftab_k() && rb.ftab_k() - 1 > args.wsize) {  // rowbowt.hpp:423-426
+        std::cerr << "ERROR: wsize cannot be greater than or equal to ftab k size. please rebuild ftab with smaller k\n";
+        exit(1);
+    }
     auto stop = std::chrono::high_resolution_clock::now();
     std::chrono::duration<double> diff = stop - start;
     std::cerr << "loading rowbowt + markers took: " << diff.count() << " seconds\n";

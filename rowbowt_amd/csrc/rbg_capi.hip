@@ -564,6 +564,39 @@ int bundle_from_raw_files(const char *bwt_fname, const char *ssa_fname, const ch
     return RBG_OK;
 }
 
+// RowBowt::build_ftab(k) + FTab::serialize (rowbowt.hpp:726-744, ftab.hpp:29-34): one text line
+// "<kmer> <lo> <hi>" for every k-mer over ACGT with a non-empty range, in std::map (lexicographic)
+// order, produced chunk by chunk; sink(text) returns false to stop early
+template <typename Sink>
+int ftab_stream(rbg_index *ix, uint64_t k, Sink sink) {
+    const uint64_t total = uint64_t(1) << (2 * k);
+    const uint64_t chunk = std::min<uint64_t>(total, uint64_t(1) << 21);
+    std::vector<uint8_t> seqs(chunk * k);
+    std::vector<uint64_t> off(chunk + 1), lo(chunk), hi(chunk);
+    for (uint64_t i = 0; i <= chunk; ++i) off[i] = i * k;
+    std::string text;
+    for (uint64_t base = 0; base < total; base += chunk) {
+        for (uint64_t i = 0; i < chunk; ++i) {
+            const uint64_t L = base + i;  // lexicographic rank: first character most significant
+            for (uint64_t j = 0; j < k; ++j) seqs[i * k + j] = static_cast<uint8_t>("ACGT"[(L >> (2 * (k - 1 - j))) & 3]);
+        }
+        const int rc = rbg_find_range(ix, seqs.data(), off.data(), chunk, lo.data(), hi.data());
+        if (rc) return rc;
+        text.clear();
+        for (uint64_t i = 0; i < chunk; ++i) {
+            if (lo[i] > hi[i]) continue;  // rowbowt.hpp:737
+            text.append(reinterpret_cast<const char *>(&seqs[i * k]), k);
+            text += ' ';
+            text += std::to_string(lo[i]);
+            text += ' ';
+            text += std::to_string(hi[i]);
+            text += '\n';
+        }
+        if (!sink(text)) break;
+    }
+    return RBG_OK;
+}
+
 int index_from_bundle(FlatBundle &b, int device, rbg_index **out) {
     rbg_index *ix = new (std::nothrow) rbg_index();
     if (!ix) return RBG_ENOMEM;
@@ -729,41 +762,48 @@ int rbg_build_from_files(const char *bwt_fname, const char *ssa_fname, const cha
     return index_from_bundle(b, device, out);
 }
 
-// RowBowt::build_ftab(k) + FTab::serialize (rowbowt.hpp:726-744, ftab.hpp:29-34): one text line
-// "<kmer> <lo> <hi>" for every k-mer over ACGT with a non-empty range, in std::map (lexicographic) order
 int rbg_write_ftab(rbg_index *ix, uint64_t k, const char *path) {
     if (!queryable(ix)) return RBG_ENODEV;
     if (!path || k == 0 || k > 16) return RBG_EARG;
     FILE *fp = std::fopen(path, "wb");
     if (!fp) return RBG_EIO;
-    const uint64_t total = uint64_t(1) << (2 * k);
-    const uint64_t chunk = std::min<uint64_t>(total, uint64_t(1) << 21);
-    std::vector<uint8_t> seqs(chunk * k);
-    std::vector<uint64_t> off(chunk + 1), lo(chunk), hi(chunk);
-    for (uint64_t i = 0; i <= chunk; ++i) off[i] = i * k;
-    std::string text;
-    int rc = RBG_OK;
-    for (uint64_t base = 0; base < total && !rc; base += chunk) {
-        for (uint64_t i = 0; i < chunk; ++i) {
-            const uint64_t L = base + i;  // lexicographic rank: first character most significant
-            for (uint64_t j = 0; j < k; ++j) seqs[i * k + j] = static_cast<uint8_t>("ACGT"[(L >> (2 * (k - 1 - j))) & 3]);
-        }
-        rc = rbg_find_range(ix, seqs.data(), off.data(), chunk, lo.data(), hi.data());
-        if (rc) break;
-        text.clear();
-        for (uint64_t i = 0; i < chunk; ++i) {
-            if (lo[i] > hi[i]) continue;  // rowbowt.hpp:737
-            text.append(reinterpret_cast<const char *>(&seqs[i * k]), k);
-            text += ' ';
-            text += std::to_string(lo[i]);
-            text += ' ';
-            text += std::to_string(hi[i]);
-            text += '\n';
-        }
-        if (!text.empty() && std::fwrite(text.data(), 1, text.size(), fp) != text.size()) rc = RBG_EIO;
-    }
-    if (std::fclose(fp) != 0 && !rc) rc = RBG_EIO;
+    bool io_ok = true;
+    int rc = ftab_stream(ix, k, [&](const std::string &t) {
+        if (!t.empty() && std::fwrite(t.data(), 1, t.size(), fp) != t.size()) io_ok = false;
+        return io_ok;
+    });
+    if (std::fclose(fp) != 0) io_ok = false;
+    if (!rc && !io_ok) rc = RBG_EIO;
     return rc;
+}
+
+// FTab::load (ftab.hpp:15-27) keeps k = length of the last line's k-mer.  The file is accepted only if
+// it is, byte for byte, the table build_ftab(k) gives for this index: then search_ftab(q) is
+// "find_range(q) when q is over ACGT and occurs", which is how the ftab variants are computed here.
+int rbg_check_ftab(rbg_index *ix, const char *path, uint64_t *k_out) {
+    if (!queryable(ix)) return RBG_ENODEV;
+    if (!path || !k_out) return RBG_EARG;
+    *k_out = 0;
+    FILE *fp = std::fopen(path, "rb");
+    if (!fp) return RBG_EIO;
+    char first[64];
+    uint64_t k = 0;
+    if (std::fgets(first, sizeof first, fp)) while (k < sizeof first && first[k] && first[k] != ' ' && first[k] != '\n') ++k;
+    if (k == 0 || k > 16) { std::fclose(fp); return RBG_EFORMAT; }
+    std::rewind(fp);
+    bool same = true;
+    std::vector<char> buf;
+    int rc = ftab_stream(ix, k, [&](const std::string &t) {
+        buf.resize(t.size());
+        if (!t.empty() && (std::fread(buf.data(), 1, t.size(), fp) != t.size() || std::memcmp(buf.data(), t.data(), t.size()) != 0)) same = false;
+        return same;
+    });
+    if (!rc && same && std::fgetc(fp) != EOF) same = false;  // nothing may follow
+    std::fclose(fp);
+    if (rc) return rc;
+    if (!same) return RBG_EFORMAT;
+    *k_out = k;
+    return RBG_OK;
 }
 
 int rbg_set_markers(rbg_index *ix, const uint64_t *run_start, const uint64_t *run_end, uint64_t nruns,
@@ -1117,28 +1157,28 @@ int rbg_find_range_w_markers(rbg_index *ix, const uint8_t *seqs, const uint64_t 
 // ---- marker seeds (next-row f4): get_markers_greedy_seeding, rowbowt.hpp:406-482 ---------------------
 
 int rbg_marker_seeds_plan_dev(rbg_index *ix, const uint8_t *d_seqs, const uint64_t *d_off, uint64_t N, uint64_t wsize,
-                              uint64_t max_range, uint64_t *d_seed_off, uint64_t *d_mk_off, void *d_tmp, size_t tmp_bytes,
+                              uint64_t max_range, uint64_t ftab_k, uint64_t *d_seed_off, uint64_t *d_mk_off, void *d_tmp, size_t tmp_bytes,
                               void *stream) {
     if (!queryable(ix)) return RBG_ENODEV;
     if (!d_seed_off || !d_mk_off || (N && (!d_seqs || !d_off))) return RBG_EARG;
     if (reinterpret_cast<uintptr_t>(d_seqs) & 15) return RBG_EARG;
     if (tmp_bytes < scan_tmp_bytes(N) || (N && !d_tmp)) return RBG_EARG;
-    return launch_marker_seeds_plan(ix->dev, ix->cfg, d_seqs, d_off, N, wsize, max_range, d_seed_off, d_mk_off, d_tmp, tmp_bytes,
+    return launch_marker_seeds_plan(ix->dev, ix->cfg, d_seqs, d_off, N, wsize, max_range, ftab_k, d_seed_off, d_mk_off, d_tmp, tmp_bytes,
                                     stream) ? RBG_ENODEV : RBG_OK;
 }
 
 int rbg_marker_seeds_fill_dev(rbg_index *ix, const uint8_t *d_seqs, const uint64_t *d_off, uint64_t N, uint64_t wsize,
-                              uint64_t max_range, const uint64_t *d_seed_off, const uint64_t *d_mk_off,
+                              uint64_t max_range, uint64_t ftab_k, const uint64_t *d_seed_off, const uint64_t *d_mk_off,
                               rbg_marker_seed_t *d_seeds, uint64_t *d_mk, void *stream) {
     if (!queryable(ix)) return RBG_ENODEV;
     if (N && (!d_seqs || !d_off || !d_seed_off || !d_mk_off || !d_seeds)) return RBG_EARG;
     if (reinterpret_cast<uintptr_t>(d_seqs) & 15) return RBG_EARG;
-    return launch_marker_seeds_fill(ix->dev, ix->cfg, d_seqs, d_off, N, wsize, max_range, d_seed_off, d_mk_off,
+    return launch_marker_seeds_fill(ix->dev, ix->cfg, d_seqs, d_off, N, wsize, max_range, ftab_k, d_seed_off, d_mk_off,
                                     reinterpret_cast<uint64_t *>(d_seeds), d_mk, stream) ? RBG_ENODEV : RBG_OK;
 }
 
 int rbg_get_markers_greedy_seeding(rbg_index *ix, const uint8_t *seqs, const uint64_t *off, uint64_t N, uint64_t wsize,
-                                   uint64_t max_range, uint64_t *seed_off, rbg_marker_seed_t **seeds, uint64_t **mk) {
+                                   uint64_t max_range, uint64_t ftab_k, uint64_t *seed_off, rbg_marker_seed_t **seeds, uint64_t **mk) {
     if (!queryable(ix)) return RBG_ENODEV;
     if (!seed_off || !seeds || !mk || (N && !off)) return RBG_EARG;
     *seeds = nullptr;
@@ -1153,7 +1193,7 @@ int rbg_get_markers_greedy_seeding(rbg_index *ix, const uint8_t *seqs, const uin
     DevBuf dsoff, dmoff, dtmp, dseeds, dmk;
     const size_t tmp_bytes = scan_tmp_bytes(N);
     if ((rc = dsoff.alloc((N + 1) * 8)) || (rc = dmoff.alloc((N + 1) * 8)) || (rc = dtmp.alloc(tmp_bytes))) return rc;
-    if (launch_marker_seeds_plan(ix->dev, ix->cfg, rb.seqs.as<uint8_t>(), rb.off.as<uint64_t>(), N, wsize, max_range,
+    if (launch_marker_seeds_plan(ix->dev, ix->cfg, rb.seqs.as<uint8_t>(), rb.off.as<uint64_t>(), N, wsize, max_range, ftab_k,
                                  dsoff.as<uint64_t>(), dmoff.as<uint64_t>(), dtmp.p, tmp_bytes, st))
         return RBG_ENODEV;
     uint64_t total_mk = 0;
@@ -1167,7 +1207,7 @@ int rbg_get_markers_greedy_seeding(rbg_index *ix, const uint8_t *seqs, const uin
     rc = RBG_OK;
     if (total_seeds) {
         if (!(rc = dseeds.alloc(total_seeds * sizeof(rbg_marker_seed_t))) && !(rc = dmk.alloc(total_mk ? total_mk * 8 : 8))) {
-            if (launch_marker_seeds_fill(ix->dev, ix->cfg, rb.seqs.as<uint8_t>(), rb.off.as<uint64_t>(), N, wsize, max_range,
+            if (launch_marker_seeds_fill(ix->dev, ix->cfg, rb.seqs.as<uint8_t>(), rb.off.as<uint64_t>(), N, wsize, max_range, ftab_k,
                                          dsoff.as<uint64_t>(), dmoff.as<uint64_t>(), dseeds.as<uint64_t>(), dmk.as<uint64_t>(), st))
                 rc = RBG_ENODEV;
             hipError_t e = hipSuccess;

@@ -685,7 +685,7 @@ __global__ __launch_bounds__(256) void k_greedy_seed(const DevIndex ix, const ui
 template <typename P, bool FILL>
 __global__ __launch_bounds__(256) void k_marker_seeds(const DevIndex ix, const uint8_t *__restrict__ seqs,
                                                       const uint64_t *__restrict__ off, const uint64_t N,
-                                                      const uint64_t wsize, const uint64_t max_range,
+                                                      const uint64_t wsize, const uint64_t max_range, const uint64_t ftab_k,
                                                       uint64_t *__restrict__ seed_cnt, uint64_t *__restrict__ mk_cnt,
                                                       const uint64_t *__restrict__ seed_off,
                                                       const uint64_t *__restrict__ mk_off,
@@ -738,6 +738,97 @@ __global__ __launch_bounds__(256) void k_marker_seeds(const DevIndex ix, const u
             ++ns;
         };
         ByteCursor rd{reinterpret_cast<const uint4 *>(seqs), ~uint64_t(0), make_uint4(0, 0, 0, 0)};
+        // one reference LF step on (lo,hi) with symbol c; false = empty range, (lo,hi) untouched
+        auto lf1 = [&](uint32_t c) -> bool {
+            const uint32_t slot = s_lut[c];
+            if (slot == 0xFFu) return false;
+            const DevSym S = slot < static_cast<uint32_t>(kLdsSyms) ? s_sym[slot] : ix.syms[slot];
+            RankAux q;
+            uint64_t c_before, c_upto, bh;
+            rank_pair<P>(S, lo, hi + 1, &c_before, &c_upto, &bh, &q);
+            if (c_upto <= c_before) return false;
+            lo = S.F + c_before;
+            hi = lo + (c_upto - c_before) - 1;
+            return true;
+        };
+        // up to `want` (2 or 3) symbols ending at byte p with one gather; 0 = not applicable or empty
+        auto lfk = [&](uint64_t p, uint32_t c, uint64_t avail) -> uint32_t {
+            const uint32_t m0 = s_lut2[c];
+            if (m0 == 0xFFu || avail < 2) return 0;
+            const uint32_t m1 = s_lut2[rd.at(p - 1)];
+            if (m1 == 0xFFu) return 0;
+            uint32_t m2 = 0xFFu;
+            if (use3 && avail >= 3) m2 = s_lut2[rd.at(p - 2)];
+            const DevSym S = m2 != 0xFFu ? s_tri[(m2 * M + m1) * M + m0] : s_pair[m1 * M + m0];
+            RankAux q;
+            uint64_t c_before, c_upto, bh;
+            rank_pair<P>(S, lo, hi + 1, &c_before, &c_upto, &bh, &q);
+            if (c_upto <= c_before) return 0;
+            lo = S.F + c_before;
+            hi = lo + (c_upto - c_before) - 1;
+            return m2 != 0xFFu ? 3u : 2u;
+        };
+        if (ftab_k) {
+            // ---- with the ftab of k-mer size K (rb_markers --ftab): the reference's loop in its own
+            // index i; search_ftab (:746-758) on the table build_ftab(K) makes for this index (:726-744)
+            // is find_range of an ACGT-only k-mer, done here as K steps from the full range
+            const uint64_t K = ftab_k;
+            auto ftab_hit = [&](uint64_t e) -> bool {   // k-mer q[e-K, e); on a hit (lo,hi) is its range
+                for (uint64_t t = e - K; t < e; ++t) {
+                    const uint32_t c = rd.at(beg + t);
+                    if (c != 'A' && c != 'C' && c != 'G' && c != 'T') return false;
+                }
+                lo = 0; hi = fhi;
+                uint64_t e2 = e;
+                while (e2 > e - K) {
+                    const uint64_t p = beg + e2 - 1;
+                    const uint32_t c = rd.at(p);
+                    uint32_t adv = lfk(p, c, e2 - (e - K));
+                    if (!adv) { if (!lf1(c)) return false; adv = 1; }
+                    e2 -= adv;
+                }
+                return true;
+            };
+            uint64_t i2 = 0;
+            if (m >= K) {                                  // :430-433 (a shorter read makes the reference throw)
+                if (ftab_hit(m)) i2 = K; else { lo = 0; hi = fhi; }
+                plo = lo; phi = hi;
+            }
+            for (; i2 < m; ++i2) {
+                if (lf1(rd.at(beg + m - i2 - 1))) {        // :443
+                    if (window_ei - (m - i2 - 1) >= wsize) {   // :469-472
+                        update_mbuf(lo, hi);
+                        window_ei = m - i2 - 1;
+                    }
+                    plo = lo; phi = hi;                    // :473
+                } else {                                   // :444-467
+                    if (seed_ei - (m - i2) >= wsize) update_mbuf(plo, phi);
+                    emit(plo, phi, m - i2, seed_ei);
+                    mb_begin = tot;
+                    plo = 0; phi = fhi;
+                    seed_ei = m - i2 - 1;
+                    window_ei = m - i2 - 1;
+                    lo = 0; hi = fhi;
+                    for (; m - i2 - 1 >= K; ++i2) {        // :454-464 slide left until a k-mer is in the ftab
+                        seed_ei = m - i2 - 1;
+                        window_ei = m - i2 - 1;
+                        if (ftab_hit(m - i2 - 1)) {
+                            i2 += K;                       // :460, then the outer ++i2
+                            plo = lo; phi = hi;
+                            break;
+                        }
+                        lo = 0; hi = fhi;                  // :463
+                    }
+                }
+            }
+            if (hi >= lo && seed_ei - (m - i2) >= wsize) update_mbuf(lo, hi);   // :478-480
+            emit(lo, hi, m - i2, seed_ei);                                      // :481
+            if (!FILL) {
+                seed_cnt[i + 1] = ns;
+                mk_cnt[i + 1] = tot;
+            }
+            continue;
+        }
         uint64_t j = m;  // m - i of the reference; the next symbol consumed is q[j-1]
         while (j > 0) {
             const uint64_t p = beg + j - 1;
@@ -746,38 +837,11 @@ __global__ __launch_bounds__(256) void k_marker_seeds(const DevIndex ix, const u
             // leaves j' with j' + wsize <= window_ei, :469)
             uint64_t dist = j + wsize > window_ei ? j + wsize - window_ei : 1;
             if (dist == 0) dist = 1;
-            const uint32_t m0 = s_lut2[c];
-            uint32_t m1 = 0xFFu, adv = 0;
-            if (m0 != 0xFFu && j > 1 && dist >= 2) m1 = s_lut2[rd.at(p - 1)];
-            if (m1 != 0xFFu) {
-                uint32_t m2 = 0xFFu;
-                if (use3 && j > 2 && dist >= 3) m2 = s_lut2[rd.at(p - 2)];
-                const DevSym S = m2 != 0xFFu ? s_tri[(m2 * M + m1) * M + m0] : s_pair[m1 * M + m0];
-                const uint32_t want = m2 != 0xFFu ? 3u : 2u;
-                RankAux q;
-                uint64_t c_before, c_upto, bh;
-                rank_pair<P>(S, lo, hi + 1, &c_before, &c_upto, &bh, &q);
-                if (c_upto > c_before) {
-                    lo = S.F + c_before;
-                    hi = lo + (c_upto - c_before) - 1;
-                    adv = want;
-                }
-            }
+            uint32_t adv = lfk(p, c, dist < j ? dist : j);
             bool ok = adv != 0;
             if (!ok) {
                 adv = 1;
-                const uint32_t slot = s_lut[c];
-                if (slot != 0xFFu) {
-                    const DevSym S = slot < static_cast<uint32_t>(kLdsSyms) ? s_sym[slot] : ix.syms[slot];
-                    RankAux q;
-                    uint64_t c_before, c_upto, bh;
-                    rank_pair<P>(S, lo, hi + 1, &c_before, &c_upto, &bh, &q);
-                    if (c_upto > c_before) {
-                        lo = S.F + c_before;
-                        hi = lo + (c_upto - c_before) - 1;
-                        ok = true;
-                    }
-                }
+                ok = lf1(c);
             }
             if (ok) {
                 j -= adv;
@@ -1073,14 +1137,14 @@ int launch_find_range_markers_fill(const DevIndex &ix, const LaunchCfg &cfg, con
 }
 
 int launch_marker_seeds_plan(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
-                             uint64_t wsize, uint64_t max_range, uint64_t *seed_off, uint64_t *mk_off, void *tmp,
+                             uint64_t wsize, uint64_t max_range, uint64_t ftab_k, uint64_t *seed_off, uint64_t *mk_off, void *tmp,
                              size_t tmp_bytes, void *stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid(grid_for(cfg, N)), block(cfg.block_threads);
     if (ix.pos_bytes == 4)
-        hipLaunchKernelGGL((k_marker_seeds<uint32_t, false>), grid, block, 0, st, ix, seqs, off, N, wsize, max_range, seed_off, mk_off, nullptr, nullptr, nullptr, nullptr);
+        hipLaunchKernelGGL((k_marker_seeds<uint32_t, false>), grid, block, 0, st, ix, seqs, off, N, wsize, max_range, ftab_k, seed_off, mk_off, nullptr, nullptr, nullptr, nullptr);
     else
-        hipLaunchKernelGGL((k_marker_seeds<uint64_t, false>), grid, block, 0, st, ix, seqs, off, N, wsize, max_range, seed_off, mk_off, nullptr, nullptr, nullptr, nullptr);
+        hipLaunchKernelGGL((k_marker_seeds<uint64_t, false>), grid, block, 0, st, ix, seqs, off, N, wsize, max_range, ftab_k, seed_off, mk_off, nullptr, nullptr, nullptr, nullptr);
     int rc = static_cast<int>(hipGetLastError());
     if (rc) return rc;
     rc = scan_in_place(seed_off + 1, N, tmp, tmp_bytes, st);
@@ -1089,15 +1153,15 @@ int launch_marker_seeds_plan(const DevIndex &ix, const LaunchCfg &cfg, const uin
 }
 
 int launch_marker_seeds_fill(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
-                             uint64_t wsize, uint64_t max_range, const uint64_t *seed_off, const uint64_t *mk_off,
+                             uint64_t wsize, uint64_t max_range, uint64_t ftab_k, const uint64_t *seed_off, const uint64_t *mk_off,
                              uint64_t *seeds, uint64_t *mk, void *stream) {
     if (N == 0) return 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid(grid_for(cfg, N)), block(cfg.block_threads);
     if (ix.pos_bytes == 4)
-        hipLaunchKernelGGL((k_marker_seeds<uint32_t, true>), grid, block, 0, st, ix, seqs, off, N, wsize, max_range, nullptr, nullptr, seed_off, mk_off, seeds, mk);
+        hipLaunchKernelGGL((k_marker_seeds<uint32_t, true>), grid, block, 0, st, ix, seqs, off, N, wsize, max_range, ftab_k, nullptr, nullptr, seed_off, mk_off, seeds, mk);
     else
-        hipLaunchKernelGGL((k_marker_seeds<uint64_t, true>), grid, block, 0, st, ix, seqs, off, N, wsize, max_range, nullptr, nullptr, seed_off, mk_off, seeds, mk);
+        hipLaunchKernelGGL((k_marker_seeds<uint64_t, true>), grid, block, 0, st, ix, seqs, off, N, wsize, max_range, ftab_k, nullptr, nullptr, seed_off, mk_off, seeds, mk);
     return static_cast<int>(hipGetLastError());
 }
 

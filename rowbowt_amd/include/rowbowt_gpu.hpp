@@ -13,8 +13,8 @@
 // (rowbowt.hpp:171, :273, :294-297); a failed search is in-band {1,0}.  Anything the reference
 // would not survive (no GPU, HIP failure) also goes to stderr + exit(1).
 //
-// Also offered (next-row f4): find_locs_greedy_seeding.  Not implemented here: ftab (result-neutral,
-// never loaded by rb_align), lmem seeding, the marker-seeding variants of rb_markers.
+// Also offered (next-row f4): find_locs_greedy_seeding, get_markers_greedy_seeding (with and without
+// a loaded ftab).  Not implemented here: lmem and overlap seeding.
 #pragma once
 
 #include <cstdint>
@@ -198,16 +198,26 @@ class RowBowt {
         return lf;
     }
 
-    // rowbowt.hpp:406-482, the variant without an ftab: fn(range, (q.first, q.second), mbuf) once per seed,
-    // right to left, exactly as the reference calls it (q.second = q.first - 1, wrapped, for an empty seed)
+    // rowbowt.hpp:406-482: fn(range, (q.first, q.second), mbuf) once per seed, right to left, exactly as the
+    // reference calls it (q.second = q.first - 1, wrapped, for an empty seed); goes through the ftab when
+    // one was loaded with LoadRbwtFlag::FT and not disabled (:430)
     template <typename F>
     void get_markers_greedy_seeding(const std::string query, uint64_t wsize, uint64_t max_range, F fn) const {
+        const uint64_t ft_k = disable_ft_ ? 0 : ft_k_;
+        if (ft_k_ && ft_k_ - 1 > wsize) {  // :423-426
+            std::cerr << "ERROR: wsize cannot be greater than or equal to ftab k size. please rebuild ftab with smaller k\n";
+            std::exit(1);
+        }
+        if (ft_k && query.size() < ft_k) {  // std::string::substr(pos > size()) throws in the reference (:431)
+            std::cerr << "rowbowt_gpu: query shorter than the ftab k-mer size" << std::endl;
+            std::exit(1);
+        }
         const uint64_t off[2] = {0, query.size()};
         uint64_t seed_off[2];
         rbg_marker_seed_t *seeds = nullptr;
         detail::LibBuf mk;
         detail::check(rbg_get_markers_greedy_seeding(ix_.get(), reinterpret_cast<const uint8_t *>(query.data()), off, 1, wsize,
-                                                     max_range, seed_off, &seeds, &mk.p), "rbg_get_markers_greedy_seeding");
+                                                     max_range, ft_k, seed_off, &seeds, &mk.p), "rbg_get_markers_greedy_seeding");
         std::unique_ptr<rbg_marker_seed_t, void (*)(void *)> hold(seeds, rbg_free_buffer);
         for (uint64_t s = 0; s < seed_off[1]; ++s) {
             const rbg_marker_seed_t &d = seeds[s];
@@ -244,6 +254,17 @@ class RowBowt {
     }
 
     const std::vector<uint64_t> &get_f() const { return f_; }  // rowbowt.hpp:719
+
+    // ftab (LoadRbwtFlag::FT): find_range is result-neutral under it (rowbowt.hpp:124-125); the marker-seed
+    // variant is not.  load_ftab verifies the file is build_ftab(k) of this index and keeps k (ftab.hpp:15-27).
+    void load_ftab(const std::string &fname) {
+        const int rc = rbg_check_ftab(ix_.get(), fname.c_str(), &ft_k_);
+        if (rc == RBG_EIO) { std::cerr << "bad file" << std::endl; std::exit(1); }  // rowbowt_io.hpp:167
+        detail::check(rc, "load_ftab (the .ftab must be the one rb_build -f made for this index)");
+    }
+    uint64_t ftab_k() const { return ft_k_; }
+    void disable_ft() { disable_ft_ = true; }   // rowbowt.hpp:760-766
+    void enable_ft() { disable_ft_ = false; }
 
     // ---- batched forms (one launch for all reads) ------------------------------------------------
     void find_range_batch(const std::vector<std::string> &queries, std::vector<range_t> &out) const {
@@ -290,7 +311,8 @@ class RowBowt {
    private:
     std::shared_ptr<rbg_index> ix_;
     uint64_t n_ = 0;
-    bool has_tsa_ = false, has_ma_ = false;
+    bool has_tsa_ = false, has_ma_ = false, disable_ft_ = false;
+    uint64_t ft_k_ = 0;
     std::vector<uint64_t> f_;
 };
 
@@ -305,7 +327,9 @@ RowBowt<StringT> load_rowbowt(std::string prefix, LoadRbwtFlag flag, int device 
         std::exit(1);
     }
     detail::check(rc, "load_rowbowt");
-    return RowBowt<StringT>(ix);
+    RowBowt<StringT> rb(ix);
+    if (static_cast<int>(flag & LoadRbwtFlag::FT)) rb.load_ftab(prefix + ".ftab");  // rowbowt_io.hpp:21,187
+    return rb;
 }
 
 }  // namespace rbwt

@@ -61,8 +61,8 @@ def lib():
         L.orc_find_range_w_markers.argtypes = [VP, C.c_char_p, U64, U64, U64, P64, P64, VP, U64]
         L.orc_greedy_locate.restype = U64
         L.orc_greedy_locate.argtypes = [VP, C.c_char_p, U64, U64, U64, VP, U64, P64, P64, P64, P64, P64]
-        L.orc_markers_greedy_seeding.restype = U64
-        L.orc_markers_greedy_seeding.argtypes = [VP, C.c_char_p, U64, U64, U64, VP, U64, VP, U64, P64]
+        L.orc_markers_greedy_seeding_ftab.restype = U64
+        L.orc_markers_greedy_seeding_ftab.argtypes = [VP, C.c_char_p, U64, U64, U64, U64, VP, U64, VP, U64, P64]
         L.orc_resolve_offset.restype = C.c_char_p
         L.orc_resolve_offset.argtypes = [VP, U64, P64]
         L.orc_find_range_batch.argtypes = [VP, VP, VP, U64, VP, VP, C.c_int]
@@ -222,13 +222,14 @@ class Oracle:
         n = self.L.orc_greedy_locate(self.h, q, len(q), min_length, max_hits, _p(out), max(n, 1), *s)
         return out[:n].tolist(), tuple(v.value for v in s)
 
-    def markers_greedy_seeding(self, q, wsize, max_range):
-        """-> list of (lo, hi, q_first, q_end_exclusive, [markers]) in callback order (rowbowt.hpp:406-482)"""
+    def markers_greedy_seeding(self, q, wsize, max_range, ftab_k=0):
+        """-> list of (lo, hi, q_first, q_end_exclusive, [markers]) in callback order (rowbowt.hpp:406-482);
+        ftab_k > 0: with the ftab of that k-mer size loaded"""
         nmk = U64(0)
-        ns = lib().orc_markers_greedy_seeding(self.h, q, len(q), wsize, max_range, None, 0, None, 0, C.byref(nmk))
+        ns = lib().orc_markers_greedy_seeding_ftab(self.h, q, len(q), wsize, max_range, ftab_k, None, 0, None, 0, C.byref(nmk))
         seeds = np.zeros(6 * max(ns, 1), dtype=np.uint64)
         mk = np.zeros(max(nmk.value, 1), dtype=np.uint64)
-        lib().orc_markers_greedy_seeding(self.h, q, len(q), wsize, max_range, _p(seeds), ns, _p(mk), nmk.value, C.byref(nmk))
+        lib().orc_markers_greedy_seeding_ftab(self.h, q, len(q), wsize, max_range, ftab_k, _p(seeds), ns, _p(mk), nmk.value, C.byref(nmk))
         out = []
         for s_ in range(ns):
             lo, hi, qs, qe, b, e = (int(v) for v in seeds[6 * s_:6 * s_ + 6])

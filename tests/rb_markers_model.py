@@ -90,7 +90,7 @@ def clear_if_conflicting(markers, read_len):  # rb_markers.cpp:279-284
 
 
 def expected_stdout(o, records, wsize=19, max_range=1000, min_range=0, heuristic=False, best_strand=False, min_seed_len=0,
-                    read_len=101, clear_conflicting=False, clear_identical=False):
+                    read_len=101, clear_conflicting=False, clear_identical=False, ftab_k=0):
     """records = [(name bytes, seq bytes)] in file order -> the text rb_markers prints"""
     out = []
     booler = Booler()
@@ -102,7 +102,7 @@ def expected_stdout(o, records, wsize=19, max_range=1000, min_range=0, heuristic
 
         def run(seq, strand):
             stop = False
-            for lo, hi, qs, qe, mk in o.markers_greedy_seeding(seq, wsize, max_range):
+            for lo, hi, qs, qe, mk in o.markers_greedy_seeding(seq, wsize, max_range, ftab_k):
                 range_size = (hi - lo + 1) & M64
                 qstart = ((n - qs - 1) & M64) if strand == "-" else qs        # :371
                 qlen = (qe - qs) & M64                                         # :372

@@ -185,12 +185,12 @@ def test_synth_markers(synth):
     o.close()
 
 
-def _check_marker_seeds(rb, o, reads, wsize, max_range):
+def _check_marker_seeds(rb, o, reads, wsize, max_range, ftab_k=0):
     seqs, off = ra.pack_reads(reads)
-    seed_off, seeds, mk = rb.get_markers_greedy_seeding(seqs, off, wsize, max_range)
+    seed_off, seeds, mk = rb.get_markers_greedy_seeding(seqs, off, wsize, max_range, ftab_k)
     nseed = nmk = 0
     for i, q in enumerate(reads):
-        want = o.markers_greedy_seeding(q, wsize, max_range)
+        want = o.markers_greedy_seeding(q, wsize, max_range, ftab_k)
         got = seeds[int(seed_off[i]):int(seed_off[i + 1])]
         assert len(got) == len(want), (i, q)
         for g, (wl, wh, wqs, wqe, wm) in zip(got, want):
@@ -208,6 +208,9 @@ def test_marker_seeds_small(small, simple_reads, error_reads):
     for wsize, max_range in ((19, 1000), (5, 1000), (1, MAXU), (0, 10), (10, 2), (21, 1000)):
         nseed, _ = _check_marker_seeds(rb, o, reads, wsize, max_range)
         assert nseed >= len(reads)
+    # with an ftab loaded (rowbowt.hpp:430-433, :454-464); reads shorter than K take the documented miss
+    for K, wsize in ((4, 5), (6, 19), (10, 9), (1, 3), (12, 19)):
+        _check_marker_seeds(rb, o, reads, wsize, 1000, ftab_k=K)
 
 
 def test_marker_seeds_synth(synth):
@@ -227,12 +230,18 @@ def test_marker_seeds_synth(synth):
         assert nseed == nseed0   # seeds do not depend on the windows
         tot += nmk
     assert tot > 1000
+    differs = 0
+    for K, wsize in ((5, 10), (8, 7), (10, 19), (3, 2)):
+        _check_marker_seeds(rb, o, reads, wsize, 1000, ftab_k=K)
+        differs += any(o.markers_greedy_seeding(q, wsize, 1000, K) != o.markers_greedy_seeding(q, wsize, 1000) for q in reads[:300])
+    assert differs >= 1   # the ftab variant really is a different seeding (k-mer misses restart further left)
     for ks in (1, 2, 3):
         capi.set_default_option(capi.OPT_KMER_STEPS, ks)
         try:
             rb2 = ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0)
             rb2.set_markers(ms, me, mo, mv)
             _check_marker_seeds(rb2, o, reads[:400], 10, 1000)
+            _check_marker_seeds(rb2, o, reads[:400], 10, 1000, ftab_k=7)
             rb2.close()
         finally:
             capi.set_default_option(capi.OPT_KMER_STEPS, 4)
@@ -450,8 +459,34 @@ def test_cli_rb_markers_stdout(data_dir, tmp_path, small):
         rc, out, err = _run_rb_markers(args + [idx, str(fq)])
         assert rc == 0, err
         assert out == RM.expected_stdout(o, recs, **kw), args
-    # modes the reference itself refuses or that need structures this engine does not build
-    for flag in ("--overlap", "--lmem", "--ftab", "--fbb"):
+    # --ftab: the index prefix needs its .ftab (rb_build -f); seeds then go through search_ftab
+    import shutil
+    for suf in (".rbwt", ".mab"):
+        shutil.copy(idx + suf, tmp_path / ("fx" + suf))
+    rc, _, err = _run_rb_markers(["--ftab", str(tmp_path / "fx"), str(fq)])
+    assert rc == 1 and "bad file" in err                      # no .ftab yet (rowbowt_io.hpp:166-169)
+    rb.write_ftab(6, str(tmp_path / "fx.ftab"))
+    long_recs = [r for r in recs if len(r[1]) >= 6]
+    fq2 = tmp_path / "long.fq"
+    with open(fq2, "wb") as f:
+        for name, seq in long_recs:
+            f.write(b"@" + name + b"\n" + seq + b"\n+\n" + b"I" * len(seq) + b"\n")
+    rc, out, err = _run_rb_markers(["--ftab", "-w", "8", str(tmp_path / "fx"), str(fq2)])
+    assert rc == 0, err
+    assert out == RM.expected_stdout(o, long_recs, wsize=8, ftab_k=6)
+    assert out != RM.expected_stdout(o, long_recs, wsize=8)
+    rc, out, err = _run_rb_markers(["-f", "--heuristic", "--best-strand-only", "-y", "20", str(tmp_path / "fx"), str(fq2)])
+    assert rc == 0 and out == RM.expected_stdout(o, long_recs, heuristic=True, best_strand=True, min_seed_len=20, ftab_k=6)
+    rc, _, err = _run_rb_markers(["--ftab", "-w", "4", str(tmp_path / "fx"), str(fq2)])
+    assert rc == 1 and "wsize cannot be greater" in err       # rowbowt.hpp:423-426 (k - 1 > wsize)
+    rc, _, err = _run_rb_markers(["--ftab", str(tmp_path / "fx"), str(fq)])
+    assert rc == 1 and "shorter than the ftab" in err         # the reference dies in substr (rowbowt.hpp:431)
+    text_ftab = (tmp_path / "fx.ftab").read_text().splitlines()
+    (tmp_path / "fx.ftab").write_text("\n".join(text_ftab[:-1] + [text_ftab[-1].rsplit(" ", 1)[0] + " 0"]) + "\n")
+    rc, _, err = _run_rb_markers(["--ftab", str(tmp_path / "fx"), str(fq2)])
+    assert rc == 1 and "ftab" in err                          # a table that is not this index's is refused
+    # modes the reference itself refuses or that this engine does not build
+    for flag in ("--overlap", "--lmem", "--fbb"):
         rc, _, err = _run_rb_markers([flag, idx, str(fq)])
         assert rc == 1 and err
     rc, _, err = _run_rb_markers([idx])
