@@ -278,6 +278,42 @@ def main():
                     "marker_runs": int(len(marker_arrays[0])), "marker_values": int(len(marker_arrays[3])),
                     "markers_reported": total_mk, "reads_with_markers": n_with}
 
+        # rb_markers' kernel (next-row f4): get_markers_greedy_seeding on every read and its reverse
+        # complement (rb_markers.cpp:396-413), wsize 19 / max_range 1000 = rb_markers' defaults
+        comp = torch.arange(256, dtype=torch.uint8, device=dev)
+        for a_, b_ in zip(b"ACGT", b"TGCA"):
+            comp[a_] = b_
+        rc_reads = comp[reads.flip(1).long()]
+        d_seqs2 = torch.cat([reads.reshape(-1), rc_reads.reshape(-1), torch.zeros(16, dtype=torch.uint8, device=dev)])
+        del rc_reads
+        d_off2 = (torch.arange(2 * N + 1, device=dev, dtype=torch.int64) * m)
+        d_soff = torch.empty(2 * N + 1, dtype=torch.int64, device=dev)
+        d_moff = torch.empty(2 * N + 1, dtype=torch.int64, device=dev)
+        tmp2 = int(L.rbg_locate_plan_tmp_bytes(2 * N))
+        d_tmp2 = torch.empty(tmp2, dtype=torch.uint8, device=dev)
+        WS, MR = 19, 1000
+
+        def k_splan():
+            chk(L.rbg_marker_seeds_plan_dev(rb.h, d_seqs2.data_ptr(), d_off2.data_ptr(), 2 * N, WS, MR, 0, d_soff.data_ptr(),
+                                            d_moff.data_ptr(), d_tmp2.data_ptr(), tmp2, st), "marker_seeds_plan")
+
+        k_splan()
+        n_seeds, n_smk = int(d_soff[-1].item()), int(d_moff[-1].item())
+        d_srec = torch.empty(max(n_seeds, 1) * 6, dtype=torch.int64, device=dev)
+        d_smk = torch.empty(max(n_smk, 1), dtype=torch.int64, device=dev)
+
+        def sstep():
+            k_splan()
+            chk(L.rbg_marker_seeds_fill_dev(rb.h, d_seqs2.data_ptr(), d_off2.data_ptr(), 2 * N, WS, MR, 0, d_soff.data_ptr(),
+                                            d_moff.data_ptr(), d_srec.data_ptr(), d_smk.data_ptr(), st), "marker_seeds_fill")
+
+        sstep()
+        el_sd = timed(sstep, K)
+        mk_block["marker_seeds"] = {"value": N * K / el_sd, "unit": "reads/s (this rank; each read = both strands)",
+                                    "ms_per_step": el_sd / K * 1e3, "wsize": WS, "max_range": MR,
+                                    "seed_records": n_seeds, "markers_collected": n_smk,
+                                    "workload": "rb_markers default mode: get_markers_greedy_seeding on read + reverse complement"}
+
     # max over ranks, counters over RCCL
     t_el = torch.tensor([el, el_count, el_pipe], dtype=torch.float64, device=dev)
     if use_dist:
@@ -424,6 +460,33 @@ def main():
                     okm = False
                     break
             out["markers"]["parity"] = {"reads_checked": nchk, "markers_checked": int(m_off[-1]), "bit_exact_vs_oracle": okm}
+            # marker seeds: first ncs forward reads and first ncs reverse complements against the oracle
+            ncs = min(nchk, 4000)
+            sstep()
+            torch.cuda.synchronize()
+            oks, n_rec = True, 0
+            for base in (0, N):
+                so = d_soff[base:base + ncs + 1].cpu().numpy().view(np.uint64)
+                rec = d_srec[6 * int(so[0]):6 * int(so[-1])].cpu().numpy().view(np.uint64).reshape(-1, 6)
+                mlo, mhi = (int(rec[0, 4]), int(rec[-1, 5])) if len(rec) else (0, 0)
+                mkv = d_smk[mlo:mhi].cpu().numpy().view(np.uint64)
+                sq = d_seqs2[base * m:(base + ncs) * m].cpu().numpy().reshape(ncs, m)
+                for i in range(ncs):
+                    want = o.markers_greedy_seeding(sq[i].tobytes(), WS, MR)
+                    got = rec[int(so[i] - so[0]):int(so[i + 1] - so[0])]
+                    if len(got) != len(want):
+                        oks = False
+                        break
+                    for g, (wl, wh, wqs, wqe, wm) in zip(got, want):
+                        if (int(g[0]), int(g[1]), int(g[2]), int(g[3])) != (wl, wh, wqs, wqe) or mkv[int(g[4]) - mlo:int(g[5]) - mlo].tolist() != wm:
+                            oks = False
+                    n_rec += len(want)
+                    if not oks:
+                        break
+            out["markers"]["marker_seeds"]["parity"] = {"sequences_checked": 2 * ncs, "seed_records_checked": n_rec, "bit_exact_vs_oracle": oks}
+            if not oks:
+                print(json.dumps(out))
+                raise SystemExit("PARITY FAILURE (marker seeds): HIP path disagrees with the oracle")
             if not okm:
                 print(json.dumps(out))
                 raise SystemExit("PARITY FAILURE (markers): HIP path disagrees with the oracle")
