@@ -19,7 +19,7 @@ VP = C.c_void_p
 MAXU = 2**64 - 1
 DEVICE_NONE = -1
 
-OPT_BLOCK_THREADS, OPT_RANK_BUCKET_SHIFT, OPT_PHI_BUCKET_SHIFT, OPT_POS_BYTES, OPT_KMER_STEPS, OPT_HBM_BUDGET_MB, OPT_FTAB_K = 1, 2, 3, 4, 5, 6, 7
+OPT_BLOCK_THREADS, OPT_RANK_BUCKET_SHIFT, OPT_PHI_BUCKET_SHIFT, OPT_POS_BYTES, OPT_KMER_STEPS, OPT_HBM_BUDGET_MB, OPT_FTAB_K, OPT_PACKED_READS = 1, 2, 3, 4, 5, 6, 7, 8
 (ARR_RUN_HEADS, ARR_RUN_START, ARR_SAMPLES_LAST, ARR_PRED_POS, ARR_PHI_BASE,
  ARR_MARKER_START, ARR_MARKER_END, ARR_MARKER_OFF, ARR_MARKER_VALS) = range(9)
 
@@ -81,6 +81,10 @@ _PROTOS = [
     ("rbg_resolve_offset", C.c_int, [VP, U64, C.POINTER(C.c_char_p), C.POINTER(U64)]),
     ("rbg_find_range_dev", C.c_int, [VP, VP, VP, U64, VP, VP, VP]),
     ("rbg_find_range_w_toehold_dev", C.c_int, [VP, VP, VP, U64, VP, VP, VP, VP]),
+    ("rbg_pack_ws_bytes", C.c_size_t, [U64, U64]),
+    ("rbg_pack_reads_dev", C.c_int, [VP, VP, VP, U64, U64, VP, C.c_size_t, VP]),
+    ("rbg_find_range_packed_dev", C.c_int, [VP, VP, VP, VP, U64, U64, VP, VP, VP]),
+    ("rbg_find_range_w_toehold_packed_dev", C.c_int, [VP, VP, VP, VP, U64, U64, VP, VP, VP, VP]),
     ("rbg_locate_plan_tmp_bytes", C.c_size_t, [U64]),
     ("rbg_locate_plan_dev", C.c_int, [VP, VP, VP, U64, U64, VP, VP, C.c_size_t, VP]),
     ("rbg_locate_order_ws_bytes", C.c_size_t, [U64]),

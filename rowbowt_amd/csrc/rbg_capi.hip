@@ -43,6 +43,7 @@ std::atomic<int64_t> g_opt_pos_bytes{0};
 std::atomic<int64_t> g_opt_kmer_steps{4};
 std::atomic<int64_t> g_opt_hbm_budget_mb{0};
 std::atomic<int64_t> g_opt_ftab_k{-1};
+std::atomic<int64_t> g_opt_packed_reads{0};  // host-pointer calls: 0 never pack (default), 1 pack large batches, 2 always pack
 
 #define HIP_TRY(expr)                                                                             \
     do {                                                                                          \
@@ -649,6 +650,9 @@ int rbg_set_default_option(int opt, int64_t value) {
         case RBG_OPT_KMER_STEPS:
             if (value < 1 || value > 4) return RBG_EARG;
             g_opt_kmer_steps = value; return RBG_OK;
+        case RBG_OPT_PACKED_READS:
+            if (value < 0 || value > 2) return RBG_EARG;
+            g_opt_packed_reads = value; return RBG_OK;
         default: return RBG_EARG;
     }
 }
@@ -952,6 +956,43 @@ int rbg_find_range_w_toehold_dev(rbg_index *ix, const uint8_t *d_seqs, const uin
     return launch_find_range(ix->dev, ix->cfg, d_seqs, d_off, N, d_lo, d_hi, d_ssamp, stream) ? RBG_ENODEV : RBG_OK;
 }
 
+// ---- packed reads (device API) ------------------------------------------------------------------
+size_t rbg_pack_ws_bytes(uint64_t N, uint64_t total_bytes) { return pack_ws_bytes(N, total_bytes); }
+
+static int packed_args_ok(const rbg_index *ix, const void *d_ws, const uint8_t *d_seqs, const uint64_t *d_off, uint64_t N,
+                          uint64_t total_bytes) {
+    if (!queryable(ix)) return RBG_ENODEV;
+    if (N && (!d_ws || !d_seqs || !d_off)) return RBG_EARG;
+    if (reinterpret_cast<uintptr_t>(d_seqs) & 15 || reinterpret_cast<uintptr_t>(d_ws) & 15) return RBG_EARG;
+    if (total_bytes / 64 + N + 1 >= (uint64_t(1) << 32)) return RBG_EARG;  // chunk indices are 32-bit
+    return RBG_OK;
+}
+
+int rbg_pack_reads_dev(rbg_index *ix, const uint8_t *d_seqs, const uint64_t *d_off, uint64_t N, uint64_t total_bytes,
+                       void *d_ws, size_t ws_bytes, void *stream) {
+    int rc = packed_args_ok(ix, d_ws, d_seqs, d_off, N, total_bytes);
+    if (rc) return rc;
+    if (ws_bytes < pack_ws_bytes(N, total_bytes)) return RBG_EARG;
+    return launch_pack_reads(ix->dev, ix->cfg, d_seqs, d_off, N, total_bytes, d_ws, ws_bytes, stream) ? RBG_ENODEV : RBG_OK;
+}
+
+int rbg_find_range_packed_dev(rbg_index *ix, const void *d_ws, const uint8_t *d_seqs, const uint64_t *d_off, uint64_t N,
+                              uint64_t total_bytes, uint64_t *d_lo, uint64_t *d_hi, void *stream) {
+    int rc = packed_args_ok(ix, d_ws, d_seqs, d_off, N, total_bytes);
+    if (rc) return rc;
+    if (N && (!d_lo || !d_hi)) return RBG_EARG;
+    return launch_find_range_packed(ix->dev, ix->cfg, d_ws, d_seqs, d_off, N, total_bytes, d_lo, d_hi, nullptr, stream) ? RBG_ENODEV : RBG_OK;
+}
+
+int rbg_find_range_w_toehold_packed_dev(rbg_index *ix, const void *d_ws, const uint8_t *d_seqs, const uint64_t *d_off, uint64_t N,
+                                        uint64_t total_bytes, uint64_t *d_lo, uint64_t *d_hi, uint64_t *d_ssamp, void *stream) {
+    int rc = packed_args_ok(ix, d_ws, d_seqs, d_off, N, total_bytes);
+    if (rc) return rc;
+    if (!ix->host.has_tsa) return RBG_ENOTLOADED;
+    if (N && (!d_lo || !d_hi || !d_ssamp)) return RBG_EARG;
+    return launch_find_range_packed(ix->dev, ix->cfg, d_ws, d_seqs, d_off, N, total_bytes, d_lo, d_hi, d_ssamp, stream) ? RBG_ENODEV : RBG_OK;
+}
+
 size_t rbg_locate_plan_tmp_bytes(uint64_t N) { return scan_tmp_bytes(N); }
 
 int rbg_locate_plan_dev(rbg_index *ix, const uint64_t *d_lo, const uint64_t *d_hi, uint64_t N, uint64_t max_hits,
@@ -1013,9 +1054,21 @@ static int find_range_host(rbg_index *ix, const uint8_t *seqs, const uint64_t *o
     DevBuf dlo, dhi, dss, dcnt;
     if ((rc = dlo.alloc(N * 8)) || (rc = dhi.alloc(N * 8))) return rc;
     if (ssamp && (rc = dss.alloc(N * 8))) return rc;
-    if (launch_find_range(ix->dev, ix->cfg, rb.seqs.as<uint8_t>(), rb.off.as<uint64_t>(), N, dlo.as<uint64_t>(),
-                          dhi.as<uint64_t>(), ssamp ? dss.as<uint64_t>() : nullptr, st))
+    const int64_t pk = g_opt_packed_reads.load();
+    const uint64_t total_bytes = off[N];
+    if ((pk == 2 || (pk == 1 && N >= 4096)) && total_bytes / 64 + N + 1 < (uint64_t(1) << 32)) {
+        DevBuf dws;  // pack once (coalesced), search the 2-bit form; same results
+        const size_t ws_bytes = pack_ws_bytes(N, total_bytes);
+        if ((rc = dws.alloc(ws_bytes))) return rc;
+        if (launch_pack_reads(ix->dev, ix->cfg, rb.seqs.as<uint8_t>(), rb.off.as<uint64_t>(), N, total_bytes, dws.p, ws_bytes, st) ||
+            launch_find_range_packed(ix->dev, ix->cfg, dws.p, rb.seqs.as<uint8_t>(), rb.off.as<uint64_t>(), N, total_bytes,
+                                     dlo.as<uint64_t>(), dhi.as<uint64_t>(), ssamp ? dss.as<uint64_t>() : nullptr, st))
+            return RBG_ENODEV;
+        HIP_TRY(hipStreamSynchronize(st));  // dws is released at scope end
+    } else if (launch_find_range(ix->dev, ix->cfg, rb.seqs.as<uint8_t>(), rb.off.as<uint64_t>(), N, dlo.as<uint64_t>(),
+                                 dhi.as<uint64_t>(), ssamp ? dss.as<uint64_t>() : nullptr, st)) {
         return RBG_ENODEV;
+    }
     if (count) {
         if ((rc = dcnt.alloc(N * 8))) return rc;
         if (launch_count_from_ranges(dlo.as<uint64_t>(), dhi.as<uint64_t>(), N, dcnt.as<uint64_t>(), st)) return RBG_ENODEV;

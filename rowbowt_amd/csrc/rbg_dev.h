@@ -118,6 +118,12 @@ int launch_locate_fill(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t 
 size_t locate_order_ws_bytes(uint64_t N);
 int launch_locate_order(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t *k, uint64_t N, void *ws, size_t ws_bytes,
                         void *stream);
+// packed reads (2 bits per symbol): pack the byte batch once, then search the packed form
+size_t pack_ws_bytes(uint64_t N, uint64_t total_bytes);
+int launch_pack_reads(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
+                      uint64_t total_bytes, void *ws, size_t ws_bytes, void *stream);
+int launch_find_range_packed(const DevIndex &ix, const LaunchCfg &cfg, const void *ws, const uint8_t *seqs, const uint64_t *off,
+                             uint64_t N, uint64_t total_bytes, uint64_t *lo, uint64_t *hi, uint64_t *ssamp, void *stream);
 int launch_marker_seeds_plan(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
                              uint64_t wsize, uint64_t max_range, uint64_t ftab_k, uint64_t *seed_off, uint64_t *mk_off, void *tmp,
                              size_t tmp_bytes, void *stream);

@@ -14,6 +14,8 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <algorithm>
+
 #include "rbg_dev.h"
 
 namespace rbg {
@@ -182,17 +184,22 @@ template <typename P, bool TOEHOLD, bool USE_FTAB>
 __global__ __launch_bounds__(256, 8) void k_find_range(const DevIndex ix, const uint8_t *__restrict__ seqs,
                                                     const uint64_t *__restrict__ off, const uint64_t N,
                                                     uint64_t *__restrict__ lo_out, uint64_t *__restrict__ hi_out,
-                                                    uint64_t *__restrict__ ss_out) {
+                                                    uint64_t *__restrict__ ss_out, const uint32_t *__restrict__ sel,
+                                                    const uint32_t *__restrict__ nsel) {
     __shared__ uint8_t s_lut[256];
     __shared__ uint8_t s_lut2[256];
     __shared__ DevSym s_tab[kTabMax];
+    // sel != nullptr: only the reads sel[0 .. *nsel) (the ones the packed path hands back)
+    const uint64_t Neff = sel ? static_cast<uint64_t>(*nsel) : N;
+    if (Neff == 0) return;
     stage_tables(ix, s_tab, s_lut, s_lut2);
     const uint32_t M = ix.nmajor;
     const uint32_t ksteps = ix.kmer_steps;
 
     unsigned long long c_reads = 0, c_matched = 0, c_occ = 0;
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
-    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < N; i += stride) {
+    for (uint64_t j_ = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j_ < Neff; j_ += stride) {
+        const uint64_t i = sel ? static_cast<uint64_t>(sel[j_]) : j_;
         const uint64_t beg = off[i];
         uint64_t p = off[i + 1];
         uint64_t lo = 0, hi = ix.n - 1;  // full_range(), rowbowt.hpp:115-118
@@ -308,6 +315,205 @@ __global__ __launch_bounds__(256, 8) void k_find_range(const DevIndex ix, const 
             k = static_cast<uint64_t>(static_cast<const P *>(pend_samp)[j]);
         }
         if (!alive) { lo = 1; hi = 0; k = 0; }  // {1,0}; LFData::clear rowbowt.hpp:153-159
+        lo_out[i] = lo;
+        hi_out[i] = hi;
+        if (TOEHOLD) ss_out[i] = k;
+        c_reads += 1;
+        if (alive) { c_matched += 1; c_occ += hi - lo + 1; }
+    }
+    c_reads = wave_sum(c_reads);
+    c_matched = wave_sum(c_matched);
+    c_occ = wave_sum(c_occ);
+    if ((threadIdx.x & (kWave - 1)) == 0 && c_reads) {
+        atomicAdd(&ix.counters[0], c_reads);
+        if (c_matched) atomicAdd(&ix.counters[1], c_matched);
+        if (c_occ) atomicAdd(&ix.counters[2], c_occ);
+    }
+}
+
+// ---- packed reads (2 bits per symbol) ------------------------------------------------------------
+// One lane per read fetching its own bytes costs 7 uncoalesced 16-byte requests per 100 bp read,
+// a fifth of all L2 requests of K1/K2.  k_pack_reads reads the byte stream once with
+// coalesced loads and rewrites each read as 2-bit codes of the major alphabet in the order the
+// search consumes them (symbol q[m-1-t] at bits [2t, 2t+2)), 64 symbols per 16-byte chunk.  The
+// packed search kernel then needs ceil(m/64) requests per read, and a k-mer step's table index is the
+// next 2k bits of the stream (no per-symbol LUT lookups).  A read with a symbol outside the major
+// alphabet is flagged and listed in sel[] for the byte kernel.
+constexpr int kPackLdsBytes = 40 * 1024;
+
+__global__ __launch_bounds__(256) void k_pack_count(const uint64_t *__restrict__ off, const uint64_t N,
+                                                    uint64_t *__restrict__ chunk_off, uint32_t *__restrict__ nsel) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < N; i += stride)
+        chunk_off[i + 1] = (off[i + 1] - off[i] + 63) >> 6;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { chunk_off[0] = 0; *nsel = 0; }
+}
+
+__global__ __launch_bounds__(256) void k_pack_reads(const DevIndex ix, const uint8_t *__restrict__ seqs,
+                                                    const uint64_t *__restrict__ off, const uint64_t N,
+                                                    const uint64_t *__restrict__ chunk_off, uint2 *__restrict__ meta,
+                                                    uint4 *__restrict__ chunks, uint32_t *__restrict__ sel,
+                                                    uint32_t *__restrict__ nsel) {
+    __shared__ uint4 s_raw[kPackLdsBytes / 16];
+    __shared__ uint8_t s_lut2[256];
+    const bool usable = ix.nmajor == 4;  // 2-bit codes are indices into a 4-symbol major alphabet
+    for (int t = threadIdx.x; t < 256; t += blockDim.x) s_lut2[t] = usable ? ix.lut2[t] : 0xFFu;
+    const uint4 *__restrict__ gsrc = reinterpret_cast<const uint4 *>(seqs);
+    const uint64_t ngroups = (N + blockDim.x - 1) / blockDim.x;
+    for (uint64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        const uint64_t i0 = g * blockDim.x;
+        const uint64_t i1 = i0 + blockDim.x < N ? i0 + blockDim.x : N;
+        const uint64_t b0 = off[i0], b1 = off[i1];
+        const uint64_t a0 = b0 & ~uint64_t(15);
+        const bool fits = b1 - a0 <= static_cast<uint64_t>(kPackLdsBytes);
+        __syncthreads();  // previous group's readers are done with s_raw (and s_lut2 is staged)
+        if (fits) {
+            const uint64_t nch = (b1 - a0 + 15) >> 4;
+            for (uint64_t c = threadIdx.x; c < nch; c += blockDim.x) s_raw[c] = gsrc[(a0 >> 4) + c];
+        }
+        __syncthreads();
+        const uint64_t i = i0 + threadIdx.x;
+        if (i < i1) {
+            const uint64_t beg = off[i], m = off[i + 1] - beg;
+            const uint8_t *lsrc = reinterpret_cast<const uint8_t *>(s_raw) + (beg - a0);
+            uint4 *dst = chunks + chunk_off[i];
+            uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, bad = 0;
+            for (uint64_t t0 = 0; t0 < m; t0 += 16) {  // 16 symbols = one 32-bit word
+                uint32_t acc = 0;
+                const uint32_t lim = m - t0 < 16 ? static_cast<uint32_t>(m - t0) : 16u;
+                for (uint32_t u = 0; u < lim; ++u) {
+                    const uint64_t pos = m - 1 - (t0 + u);
+                    const uint32_t code = s_lut2[fits ? lsrc[pos] : seqs[beg + pos]];
+                    bad |= code == 0xFFu;
+                    acc |= (code & 3u) << (2 * u);
+                }
+                const uint32_t wi = static_cast<uint32_t>(t0 >> 4) & 3u;
+                if (wi == 0) w0 = acc; else if (wi == 1) w1 = acc; else if (wi == 2) w2 = acc; else w3 = acc;
+                if (wi == 3 || t0 + 16 >= m) {
+                    dst[t0 >> 6] = make_uint4(w0, w1, w2, w3);
+                    w0 = w1 = w2 = w3 = 0;
+                }
+            }
+            meta[i] = make_uint2(static_cast<uint32_t>(chunk_off[i]), static_cast<uint32_t>(m) | (bad ? 0x80000000u : 0u));
+            if (bad) sel[atomicAdd(nsel, 1u)] = static_cast<uint32_t>(i);
+        }
+    }
+}
+
+// per-lane reader of a packed read: take(nb) returns the next nb (<= 32) bits
+struct BitStream {
+    const uint4 *__restrict__ cp;
+    uint4 w;
+    uint32_t widx;    // next word of w to hand out; 4 = fetch the next chunk first
+    uint32_t navail;
+    uint64_t sr;
+    __device__ __forceinline__ uint32_t next_word() {
+        if (widx == 4) { w = *cp++; widx = 0; }
+        const uint32_t v = widx == 0 ? w.x : widx == 1 ? w.y : widx == 2 ? w.z : w.w;
+        ++widx;
+        return v;
+    }
+    __device__ __forceinline__ uint32_t take(uint32_t nb) {
+        if (navail < nb) {
+            sr |= static_cast<uint64_t>(next_word()) << navail;
+            navail += 32;
+        }
+        const uint32_t v = static_cast<uint32_t>(sr & ((uint64_t(1) << nb) - 1));
+        sr >>= nb;
+        navail -= nb;
+        return v;
+    }
+};
+
+// k_find_range over packed reads: the same steps in the same order as the byte kernel takes for a
+// read made of major symbols only (ftab word, then min(kmer_steps, remaining) symbols per gather),
+// so ranges and toeholds are identical; flagged reads are left to the byte kernel (sel list).
+template <typename P, bool TOEHOLD>
+__global__ __launch_bounds__(256, 8) void k_find_range_packed(const DevIndex ix, const uint2 *__restrict__ meta,
+                                                           const uint4 *__restrict__ chunks, const uint64_t N,
+                                                           uint64_t *__restrict__ lo_out, uint64_t *__restrict__ hi_out,
+                                                           uint64_t *__restrict__ ss_out) {
+    __shared__ uint8_t s_lut[256];
+    __shared__ uint8_t s_lut2[256];
+    __shared__ uint8_t s_mslot[4];
+    __shared__ DevSym s_tab[kTabMax];
+    stage_tables(ix, s_tab, s_lut, s_lut2);
+    for (int t = threadIdx.x; t < 256; t += blockDim.x)
+        if (s_lut2[t] != 0xFFu) s_mslot[s_lut2[t] & 3u] = s_lut[t];  // major index -> symbol slot
+    __syncthreads();
+    const uint32_t ksteps = ix.kmer_steps;
+
+    unsigned long long c_reads = 0, c_matched = 0, c_occ = 0;
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < N; i += stride) {
+        const uint2 mt = meta[i];
+        if (mt.y & 0x80000000u) continue;  // has a non-major symbol: byte kernel
+        uint32_t r = mt.y;                 // symbols still to consume
+        uint64_t lo = 0, hi = ix.n - 1;    // full_range(), rowbowt.hpp:115-118
+        uint64_t k = TOEHOLD ? ix.last_run_sample : 0;
+        bool pend = false;                 // deferred toehold re-sample, as in k_find_range
+        const void *pend_samp = nullptr;
+        const uint32_t *pend_ord = nullptr;
+        uint64_t pend_b = 0;
+        int64_t pend_j = 0;
+        bool pend_abs = false;
+        BitStream bs{chunks + mt.x, make_uint4(0, 0, 0, 0), 4u, 0u, 0ull};
+        bool alive = true;
+        if (ix.ftab_k && r >= ix.ftab_k) {  // the first ftab_k symbols are the low 2*ftab_k bits
+            const uint64_t idx = bs.take(2 * ix.ftab_k);
+            const ulonglong4 e = *reinterpret_cast<const ulonglong4 *>(ix.ftab + 4 * idx);
+            lo = e.x; hi = e.y; k = e.z;
+            r -= ix.ftab_k;
+            if (hi < lo) { alive = false; r = 0; }
+        }
+        auto step = [&](const DevSym &S, uint32_t adv) -> bool {
+            RankAux q;
+            uint64_t c_before, c_upto, bh;
+            rank_pair<P>(S, lo, hi + 1, &c_before, &c_upto, &bh, &q);      // rowbowt.hpp:79,83
+            const uint64_t c_inside = c_upto - c_before;
+            if (c_inside == 0) return false;                               // rowbowt.hpp:85
+            if (TOEHOLD) {                                                 // LF_w_loc, rowbowt.hpp:559-566
+                if (q.inside) {
+                    if (pend) {
+                        const uint64_t j = pend_abs ? static_cast<uint64_t>(pend_j) : static_cast<uint64_t>(pend_ord[pend_b]) + pend_j;
+                        k = static_cast<uint64_t>(static_cast<const P *>(pend_samp)[j]);
+                        pend = false;
+                    }
+                    k = k - adv;
+                } else {
+                    pend = true;
+                    pend_samp = S.samp;
+                    pend_ord = S.ord;
+                    pend_b = bh;
+                    pend_abs = q.ovf;
+                    pend_j = q.ovf ? q.pred : static_cast<int64_t>(q.nbefore) - 1;
+                }
+            }
+            lo = S.F + c_before;           // rowbowt.hpp:86
+            hi = lo + c_inside - 1;        // rowbowt.hpp:87
+            return true;
+        };
+        while (r > 0) {
+            const uint32_t a = r < ksteps ? r : ksteps;
+            const uint32_t v = bs.take(2 * a);
+            bool ok;
+            if (a == 1) {
+                const uint32_t slot = s_mslot[v];
+                if (slot < static_cast<uint32_t>(kLdsSyms)) { const DevSym Sc = s_tab[slot]; ok = step(Sc, 1u); }
+                else ok = step(ix.syms[slot], 1u);
+            } else {
+                const uint32_t idx = (a == 4 ? kOff4 : a == 3 ? kOff3 : kOff2) + v;
+                const DevSym Sc = s_tab[idx];
+                ok = step(Sc, a);
+            }
+            if (!ok) { alive = false; break; }
+            r -= a;
+        }
+        if (TOEHOLD && alive && pend) {
+            const uint64_t j = pend_abs ? static_cast<uint64_t>(pend_j) : static_cast<uint64_t>(pend_ord[pend_b]) + pend_j;
+            k = static_cast<uint64_t>(static_cast<const P *>(pend_samp)[j]);
+        }
+        if (!alive) { lo = 1; hi = 0; k = 0; }
         lo_out[i] = lo;
         hi_out[i] = hi;
         if (TOEHOLD) ss_out[i] = k;
@@ -913,17 +1119,18 @@ int grid_for(const LaunchCfg &cfg, uint64_t N) {
 
 template <bool USE_FTAB>
 int launch_find_range_impl(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
-                           uint64_t *lo, uint64_t *hi, uint64_t *ssamp, void *stream) {
+                           uint64_t *lo, uint64_t *hi, uint64_t *ssamp, const uint32_t *sel, const uint32_t *nsel, void *stream) {
     if (N == 0) return 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const dim3 grid(grid_for(cfg, N)), block(cfg.block_threads);
+    // sel mode: the number of reads is only known on the device; a fixed modest grid loops over it
+    const dim3 grid(sel ? std::min(grid_for(cfg, N), 512) : grid_for(cfg, N)), block(cfg.block_threads);
     const bool toe = ssamp != nullptr;
     if (ix.pos_bytes == 4) {
-        if (toe) hipLaunchKernelGGL((k_find_range<uint32_t, true, USE_FTAB>), grid, block, 0, st, ix, seqs, off, N, lo, hi, ssamp);
-        else hipLaunchKernelGGL((k_find_range<uint32_t, false, USE_FTAB>), grid, block, 0, st, ix, seqs, off, N, lo, hi, ssamp);
+        if (toe) hipLaunchKernelGGL((k_find_range<uint32_t, true, USE_FTAB>), grid, block, 0, st, ix, seqs, off, N, lo, hi, ssamp, sel, nsel);
+        else hipLaunchKernelGGL((k_find_range<uint32_t, false, USE_FTAB>), grid, block, 0, st, ix, seqs, off, N, lo, hi, ssamp, sel, nsel);
     } else {
-        if (toe) hipLaunchKernelGGL((k_find_range<uint64_t, true, USE_FTAB>), grid, block, 0, st, ix, seqs, off, N, lo, hi, ssamp);
-        else hipLaunchKernelGGL((k_find_range<uint64_t, false, USE_FTAB>), grid, block, 0, st, ix, seqs, off, N, lo, hi, ssamp);
+        if (toe) hipLaunchKernelGGL((k_find_range<uint64_t, true, USE_FTAB>), grid, block, 0, st, ix, seqs, off, N, lo, hi, ssamp, sel, nsel);
+        else hipLaunchKernelGGL((k_find_range<uint64_t, false, USE_FTAB>), grid, block, 0, st, ix, seqs, off, N, lo, hi, ssamp, sel, nsel);
     }
     return static_cast<int>(hipGetLastError());
 }
@@ -932,8 +1139,82 @@ int launch_find_range(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *s
                       uint64_t *lo, uint64_t *hi, uint64_t *ssamp, void *stream) {
     // without a table the table-free instantiation runs (it is also the one that BUILDS the table,
     // so profiles show that one-off launch under its own kernel name)
-    return ix.ftab_k ? launch_find_range_impl<true>(ix, cfg, seqs, off, N, lo, hi, ssamp, stream)
-                     : launch_find_range_impl<false>(ix, cfg, seqs, off, N, lo, hi, ssamp, stream);
+    return ix.ftab_k ? launch_find_range_impl<true>(ix, cfg, seqs, off, N, lo, hi, ssamp, nullptr, nullptr, stream)
+                     : launch_find_range_impl<false>(ix, cfg, seqs, off, N, lo, hi, ssamp, nullptr, nullptr, stream);
+}
+
+static int scan_in_place(uint64_t *vals, uint64_t N, void *tmp, size_t tmp_bytes, hipStream_t st);
+
+// ---- packed reads: workspace layout, pack, search -------------------------------------------------
+// [ meta uint2[N] | nsel u32 (+pad to 16) | sel u32[N] | chunk_off u64[N+1] | scan temp | chunks uint4[total/64 + N] ]
+namespace {
+struct PackLayout {
+    size_t meta, nsel, sel, chunk_off, scan_tmp, scan_tmp_bytes, chunks, total;
+};
+PackLayout pack_layout(uint64_t N, uint64_t total_bytes) {
+    auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
+    PackLayout L;
+    size_t o = 0;
+    L.meta = o; o = up(o + N * sizeof(uint2));
+    L.nsel = o; o = up(o + 16);
+    L.sel = o; o = up(o + N * 4);
+    L.chunk_off = o; o = up(o + (N + 1) * 8);
+    size_t tb = 0;
+    (void)hipcub::DeviceScan::InclusiveSum(nullptr, tb, static_cast<uint64_t *>(nullptr), static_cast<uint64_t *>(nullptr), static_cast<int64_t>(N ? N : 1));
+    L.scan_tmp_bytes = tb;
+    L.scan_tmp = o; o = up(o + tb);
+    L.chunks = o; o = up(o + (total_bytes / 64 + N + 1) * 16);
+    L.total = o;
+    return L;
+}
+}  // namespace
+
+size_t pack_ws_bytes(uint64_t N, uint64_t total_bytes) { return pack_layout(N, total_bytes).total; }
+
+int launch_pack_reads(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
+                      uint64_t total_bytes, void *ws, size_t ws_bytes, void *stream) {
+    if (N == 0) return 0;
+    const PackLayout L = pack_layout(N, total_bytes);
+    if (ws_bytes < L.total) return -1;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char *b = static_cast<char *>(ws);
+    uint64_t *chunk_off = reinterpret_cast<uint64_t *>(b + L.chunk_off);
+    uint32_t *nsel = reinterpret_cast<uint32_t *>(b + L.nsel);
+    hipLaunchKernelGGL(k_pack_count, dim3(grid_for(cfg, N)), dim3(256), 0, st, off, N, chunk_off, nsel);
+    int rc = static_cast<int>(hipGetLastError());
+    if (rc) return rc;
+    rc = scan_in_place(chunk_off + 1, N, b + L.scan_tmp, L.scan_tmp_bytes, st);
+    if (rc) return rc;
+    const uint64_t groups = (N + 255) / 256;
+    const int grid = static_cast<int>(std::min<uint64_t>(groups, 256ull * 8));
+    hipLaunchKernelGGL(k_pack_reads, dim3(grid), dim3(256), 0, st, ix, seqs, off, N, chunk_off, reinterpret_cast<uint2 *>(b + L.meta),
+                       reinterpret_cast<uint4 *>(b + L.chunks), reinterpret_cast<uint32_t *>(b + L.sel), nsel);
+    return static_cast<int>(hipGetLastError());
+}
+
+int launch_find_range_packed(const DevIndex &ix, const LaunchCfg &cfg, const void *ws, const uint8_t *seqs, const uint64_t *off,
+                             uint64_t N, uint64_t total_bytes, uint64_t *lo, uint64_t *hi, uint64_t *ssamp, void *stream) {
+    if (N == 0) return 0;
+    const PackLayout L = pack_layout(N, total_bytes);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const char *b = static_cast<const char *>(ws);
+    const uint2 *meta = reinterpret_cast<const uint2 *>(b + L.meta);
+    const uint4 *chunks = reinterpret_cast<const uint4 *>(b + L.chunks);
+    const dim3 grid(grid_for(cfg, N)), block(cfg.block_threads);
+    const bool toe = ssamp != nullptr;
+    if (ix.pos_bytes == 4) {
+        if (toe) hipLaunchKernelGGL((k_find_range_packed<uint32_t, true>), grid, block, 0, st, ix, meta, chunks, N, lo, hi, ssamp);
+        else hipLaunchKernelGGL((k_find_range_packed<uint32_t, false>), grid, block, 0, st, ix, meta, chunks, N, lo, hi, ssamp);
+    } else {
+        if (toe) hipLaunchKernelGGL((k_find_range_packed<uint64_t, true>), grid, block, 0, st, ix, meta, chunks, N, lo, hi, ssamp);
+        else hipLaunchKernelGGL((k_find_range_packed<uint64_t, false>), grid, block, 0, st, ix, meta, chunks, N, lo, hi, ssamp);
+    }
+    int rc = static_cast<int>(hipGetLastError());
+    if (rc) return rc;
+    // the reads the packed form cannot express (a symbol outside the major alphabet)
+    const uint32_t *sel = reinterpret_cast<const uint32_t *>(b + L.sel), *nsel = reinterpret_cast<const uint32_t *>(b + L.nsel);
+    return ix.ftab_k ? launch_find_range_impl<true>(ix, cfg, seqs, off, N, lo, hi, ssamp, sel, nsel, stream)
+                     : launch_find_range_impl<false>(ix, cfg, seqs, off, N, lo, hi, ssamp, sel, nsel, stream);
 }
 
 // ---- ftab construction: search every word of k major symbols with the step kernel itself ---------

@@ -120,8 +120,11 @@ def synth():
 @pytest.mark.parametrize("pos_bytes,rshift,pshift,ksteps",
                          [(0, -1, -1, 4), (0, -1, -1, 3), (0, -1, -1, 2), (0, -1, -1, 1), (8, -1, -1, 4), (4, 0, 0, 2),
                           (8, 3, 2, 1), (4, 8, 8, 3), (8, 8, 7, 4), (4, 5, 6, 1), (4, 2, 2, 4)])
-def test_synth_all_paths(synth, pos_bytes, rshift, pshift, ksteps):
+@pytest.mark.parametrize("packed", [0, 2])
+def test_synth_all_paths(synth, pos_bytes, rshift, pshift, ksteps, packed, request):
     S = synth
+    ra.set_default_option(capi.OPT_PACKED_READS, packed)   # byte kernels / 2-bit packed reads: same answers
+    request.addfinalizer(lambda: ra.set_default_option(capi.OPT_PACKED_READS, 0))
     ra.set_default_option(capi.OPT_POS_BYTES, pos_bytes)
     ra.set_default_option(capi.OPT_RANK_BUCKET_SHIFT, rshift)
     ra.set_default_option(capi.OPT_PHI_BUCKET_SHIFT, pshift)
@@ -319,6 +322,51 @@ def test_device_resident_api(synth):
     assert L.rbg_find_range_dev(rb.h, d_seqs.data_ptr() + 1, d_off.data_ptr(), N, d_lo.data_ptr(), d_hi.data_ptr(), st) == -4
     rb.close()
     o.close()
+
+
+def test_packed_reads_device_api(synth):
+    """rbg_pack_reads_dev + *_packed_dev against the byte kernels on the same batch: ranges, toeholds and
+    the device counters; reads with symbols outside the major alphabet go through the sel list."""
+    import torch
+    S = synth
+    rb = ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0)
+    reads = S.sample_reads(6000, 100, seed=13, sub_rate=0.1, ragged=True)
+    rng = np.random.default_rng(3)
+    for i in range(0, len(reads), 17):   # sprinkle non-major symbols: absent (N), present but minor (terminator 1)
+        q = bytearray(reads[i])
+        if q:
+            q[int(rng.integers(0, len(q)))] = b"N\x01n"[i % 3]
+        reads[i] = bytes(q)
+    reads += [b"", b"A", b"ACGT" * 40, S.text[:3000].tobytes(), b"", S.text[100:165].tobytes(), S.text[100:164].tobytes(), S.text[100:163].tobytes()]
+    seqs, off = ra.pack_reads(reads)
+    N, total = len(reads), int(off[-1])
+    dev = torch.device("cuda:0")
+    d_seqs = torch.from_numpy(np.concatenate([seqs, np.zeros(16 + (-len(seqs)) % 16, np.uint8)])).to(dev)
+    d_off = torch.from_numpy(off.view(np.int64)).to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    L = ra.lib()
+    outs = {}
+    for name in ("bytes", "packed"):
+        d_lo, d_hi, d_k, d_lo2, d_hi2 = (torch.full((N,), -7, dtype=torch.int64, device=dev) for _ in range(5))
+        L.rbg_counters_reset(rb.h)
+        if name == "bytes":
+            assert L.rbg_find_range_w_toehold_dev(rb.h, d_seqs.data_ptr(), d_off.data_ptr(), N, d_lo.data_ptr(), d_hi.data_ptr(), d_k.data_ptr(), st) == 0
+            assert L.rbg_find_range_dev(rb.h, d_seqs.data_ptr(), d_off.data_ptr(), N, d_lo2.data_ptr(), d_hi2.data_ptr(), st) == 0
+        else:
+            wsb = L.rbg_pack_ws_bytes(N, total)
+            d_ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            assert L.rbg_pack_reads_dev(rb.h, d_seqs.data_ptr(), d_off.data_ptr(), N, total, d_ws.data_ptr(), wsb - 1, st) == -4
+            assert L.rbg_pack_reads_dev(rb.h, d_seqs.data_ptr(), d_off.data_ptr(), N, total, d_ws.data_ptr(), wsb, st) == 0
+            assert L.rbg_find_range_w_toehold_packed_dev(rb.h, d_ws.data_ptr(), d_seqs.data_ptr(), d_off.data_ptr(), N, total,
+                                                         d_lo.data_ptr(), d_hi.data_ptr(), d_k.data_ptr(), st) == 0
+            assert L.rbg_find_range_packed_dev(rb.h, d_ws.data_ptr(), d_seqs.data_ptr(), d_off.data_ptr(), N, total,
+                                               d_lo2.data_ptr(), d_hi2.data_ptr(), st) == 0
+        torch.cuda.synchronize()
+        outs[name] = [t.cpu().numpy() for t in (d_lo, d_hi, d_k, d_lo2, d_hi2)] + [rb.counters()]
+    for a, b in zip(outs["bytes"], outs["packed"]):
+        assert (a == b).all()
+    assert (outs["packed"][0] != -7).all() and int(outs["packed"][5][0]) == 2 * N   # every read answered exactly once per call
+    rb.close()
 
 
 def test_size_independent_properties(synth):
@@ -678,10 +726,14 @@ def test_cpp_shim_reference_goldens(tmp_path, data_dir):
     assert b"shim goldens ok" in p.stdout
 
 
-def test_long_and_ragged_reads(synth):
+@pytest.mark.parametrize("packed", [0, 2])
+def test_long_and_ragged_reads(synth, packed, request):
     """Reads far longer than the 100 bp of the bench (whole haplotypes, the whole text, longer than the
-    text), mixed with tiny ones in one batch."""
+    text), mixed with tiny ones in one batch (with packed reads: groups that do not fit the pack
+    kernel's LDS staging take its direct path)."""
     S = synth
+    ra.set_default_option(capi.OPT_PACKED_READS, packed)
+    request.addfinalizer(lambda: ra.set_default_option(capi.OPT_PACKED_READS, 0))
     rb = ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0)
     o = orc.Oracle.from_runs(S.heads, S.lens, S.ssa, S.esa)
     unit = S.L + S.pad

@@ -58,6 +58,11 @@ for cfg in args.configs.split(","):
         return e[0].elapsed_time(e[1]) / reps
     ms_c = t(lambda: L.rbg_find_range_dev(rb.h, d_seqs.data_ptr(), d_off.data_ptr(), N, d_lo.data_ptr(), d_hi.data_ptr(), st))
     ms_t = t(lambda: L.rbg_find_range_w_toehold_dev(rb.h, d_seqs.data_ptr(), d_off.data_ptr(), N, d_lo.data_ptr(), d_hi.data_ptr(), d_k.data_ptr(), st))
+    wsb_p = L.rbg_pack_ws_bytes(N, N * m)
+    d_pws = torch.empty(wsb_p, dtype=torch.uint8, device=dev)
+    ms_pk = t(lambda: L.rbg_pack_reads_dev(rb.h, d_seqs.data_ptr(), d_off.data_ptr(), N, N * m, d_pws.data_ptr(), wsb_p, st))
+    ms_pc = t(lambda: L.rbg_find_range_packed_dev(rb.h, d_pws.data_ptr(), d_seqs.data_ptr(), d_off.data_ptr(), N, N * m, d_lo.data_ptr(), d_hi.data_ptr(), st))
+    ms_pt = t(lambda: L.rbg_find_range_w_toehold_packed_dev(rb.h, d_pws.data_ptr(), d_seqs.data_ptr(), d_off.data_ptr(), N, N * m, d_lo.data_ptr(), d_hi.data_ptr(), d_k.data_ptr(), st))
     L.rbg_locate_plan_dev(rb.h, d_lo.data_ptr(), d_hi.data_ptr(), N, MAXU, d_loc_off.data_ptr(), d_tmp.data_ptr(), tmp_bytes, st)
     if d_locs is None:
         d_locs = torch.empty(int(d_loc_off[-1].item()), dtype=torch.int64, device=dev)
@@ -68,5 +73,5 @@ for cfg in args.configs.split(","):
     ms_f = t(lambda: L.rbg_locate_fill_dev(rb.h, d_lo.data_ptr(), d_hi.data_ptr(), d_k.data_ptr(), N, MAXU, d_loc_off.data_ptr(), d_locs.data_ptr(), d_ws.data_ptr(), st))
     print(f"cfg pos_bytes={i.pos_bytes} kmer_steps={i.kmer_steps} pair_runs={i.pair_runs} triple_runs={i.triple_runs} quad_runs={i.quad_runs} rank_shift={i.rank_bucket_shift}({rs}) phi_shift={i.phi_bucket_shift}({ps}) block={bt}: hbm={i.hbm_bytes/1e9:.2f}GB "
           f"rank_ovf={i.rank_slots_overflow}/{i.rank_slots} phi_ovf={i.phi_slots_overflow}/{i.phi_slots}  "
-          f"count={ms_c:.2f}ms toehold={ms_t:.2f}ms fill(unordered)={ms_f0:.2f}ms order={ms_o:.2f}ms fill={ms_f:.2f}ms  build={time.time()-t0:.1f}s", flush=True)
+          f"count={ms_c:.2f}ms toehold={ms_t:.2f}ms pack={ms_pk:.2f}ms packed_count={ms_pc:.2f}ms packed_toehold={ms_pt:.2f}ms fill(unordered)={ms_f0:.2f}ms order={ms_o:.2f}ms fill={ms_f:.2f}ms  build={time.time()-t0:.1f}s", flush=True)
     rb.close()
