@@ -324,6 +324,61 @@ def test_device_resident_api(synth):
     o.close()
 
 
+def test_device_pipeline_is_graph_capturable(synth):
+    """The *_dev entry points neither allocate nor synchronise: the whole count+locate step is captured
+    into one HIP graph and replayed on new reads in the same buffers."""
+    import torch
+    S = synth
+    rb = ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0)
+    o = orc.Oracle.from_runs(S.heads, S.lens, S.ssa, S.esa)
+    N, m = 4096, 64
+    dev = torch.device("cuda:0")
+    L = ra.lib()
+    batches = [S.sample_reads(N, m, seed=s_, sub_rate=0.1) for s_ in (31, 32, 33)]
+    d_seqs = torch.zeros(N * m + 16, dtype=torch.uint8, device=dev)
+    d_off = torch.arange(N + 1, dtype=torch.int64, device=dev) * m
+    d_lo, d_hi, d_k = (torch.empty(N, dtype=torch.int64, device=dev) for _ in range(3))
+    d_loc_off = torch.empty(N + 1, dtype=torch.int64, device=dev)
+    tmp_bytes, ws_bytes = L.rbg_locate_plan_tmp_bytes(N), L.rbg_locate_order_ws_bytes(N)
+    d_tmp = torch.empty(tmp_bytes, dtype=torch.uint8, device=dev)
+    d_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    cap = N * 8 * 64   # at most H = 8 haplotype copies (+ chance hits) per read; checked below
+    d_locs = torch.empty(cap, dtype=torch.int64, device=dev)
+
+    def step(st):
+        assert L.rbg_find_range_w_toehold_dev(rb.h, d_seqs.data_ptr(), d_off.data_ptr(), N, d_lo.data_ptr(), d_hi.data_ptr(), d_k.data_ptr(), st) == 0
+        assert L.rbg_locate_plan_dev(rb.h, d_lo.data_ptr(), d_hi.data_ptr(), N, MAXU, d_loc_off.data_ptr(), d_tmp.data_ptr(), tmp_bytes, st) == 0
+        assert L.rbg_locate_order_dev(rb.h, d_k.data_ptr(), N, d_ws.data_ptr(), ws_bytes, st) == 0
+        assert L.rbg_locate_fill_dev(rb.h, d_lo.data_ptr(), d_hi.data_ptr(), d_k.data_ptr(), N, MAXU, d_loc_off.data_ptr(),
+                                     d_locs.data_ptr(), d_ws.data_ptr(), st) == 0
+
+    def load(reads):
+        seqs, _ = ra.pack_reads(reads)
+        d_seqs[:N * m].copy_(torch.from_numpy(seqs).to(dev))
+
+    load(batches[0])
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):      # warm-up outside capture
+        step(side.cuda_stream)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        step(torch.cuda.current_stream().cuda_stream)
+    for reads in batches[1:]:
+        load(reads)
+        g.replay()
+        torch.cuda.synchronize()
+        seqs, off = ra.pack_reads(reads)
+        wlo, whi, wk = o.find_range_w_toehold_batch(seqs, off, nthreads=4)
+        woff, wlocs = o.locs_at_batch(wlo, whi, wk, nthreads=4)
+        assert int(woff[-1]) <= cap
+        assert (d_lo.cpu().numpy().view(np.uint64) == wlo).all() and (d_k.cpu().numpy().view(np.uint64) == wk).all()
+        assert (d_loc_off.cpu().numpy().view(np.uint64) == woff).all()
+        assert (d_locs.cpu().numpy().view(np.uint64)[:int(woff[-1])] == wlocs).all()
+    rb.close()
+    o.close()
+
+
 def test_packed_reads_device_api(synth):
     """rbg_pack_reads_dev + *_packed_dev against the byte kernels on the same batch: ranges, toeholds and
     the device counters; reads with symbols outside the major alphabet go through the sel list."""
