@@ -580,7 +580,8 @@ __device__ __forceinline__ uint64_t phi_step(const DevIndex &ix, uint64_t i) {
 // at a time, and flushed with kChunk lanes writing one read's (8 * kChunk)-byte segment: a store
 // instruction then touches a handful of lines instead of 64.  Measured per 10M reads: unordered
 // chains 10.5 / 8.6 / 7.6 ms at kChunk 8 / 16 / 32 (7.3 at 32 in a later build); with the chains in
-// toehold order (the default) 3.5 / 3.1 / 3.5 ms, hence 16 (35 KB of LDS per workgroup).
+// toehold order (the default) 3.5 / 3.1 / 3.5 ms, hence 16 (staged as uint64: 39 KB of LDS per workgroup;
+// staged at the position width since: 24 KB at 4-byte positions, 3.1 -> 3.0 ms).
 constexpr int kChunk = 16;
 
 __device__ __forceinline__ void wave_lds_sync() {
@@ -597,9 +598,12 @@ __global__ __launch_bounds__(256) void k_locate_fill(const DevIndex ix, const ui
                                                      const uint64_t N, const uint64_t max_hits,
                                                      const uint64_t *__restrict__ loc_off, uint64_t *__restrict__ locs,
                                                      const uint64_t *__restrict__ sub, const uint32_t *__restrict__ order) {
-    __shared__ uint64_t s_val[4][kWave][kChunk + 1];  // +1: keeps the per-lane rows off the same banks
+    // staged at the position width: text positions fit P, and at 4 bytes the workgroup's LDS drops from
+    // 39 KB to 24 KB (6 instead of 4 waves per SIMD); the per-read offset is applied when flushing
+    __shared__ P s_val[4][kWave][kChunk + 1];  // +1: keeps the per-lane rows off the same banks
     __shared__ uint64_t s_dst[4][kWave];
     __shared__ uint64_t s_occ[4][kWave];
+    __shared__ uint64_t s_minus[4][kWave];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
     unsigned long long c_locs = 0;
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
@@ -621,6 +625,7 @@ __global__ __launch_bounds__(256) void k_locate_fill(const DevIndex ix, const ui
         const uint64_t minus = (sub && i < N) ? sub[i] : 0;  // locate_from_longest_seed, rowbowt.hpp:681-683
         s_dst[wv][lane] = dst;
         s_occ[wv][lane] = occ;
+        s_minus[wv][lane] = minus;
         c_locs += occ;
         uint64_t wmax = occ;
 #pragma unroll
@@ -634,7 +639,7 @@ __global__ __launch_bounds__(256) void k_locate_fill(const DevIndex ix, const ui
                 const uint64_t t = t0 + e;
                 if (t < occ) {
                     if (t) k1 = phi_step<P>(ix, k1);  // toehold_sa.hpp:44
-                    s_val[wv][lane][e] = k1 - minus;
+                    s_val[wv][lane][e] = static_cast<P>(k1);
                 }
             }
             wave_lds_sync();
@@ -644,9 +649,9 @@ __global__ __launch_bounds__(256) void k_locate_fill(const DevIndex ix, const ui
                 const int e = lane & (kChunk - 1);
                 const uint64_t t = t0 + e;
 #ifdef RBG_ABLATE_STORES  /* timing experiment only: keep the values live, drop the stores */
-                if (t < s_occ[wv][s] && s_val[wv][s][e] == 0xFFFFFFFFFFFFFFFEull) locs[s_dst[wv][s] + t] = 1;
+                if (t < s_occ[wv][s] && s_val[wv][s][e] == static_cast<P>(~uint64_t(1))) locs[s_dst[wv][s] + t] = 1;
 #else
-                if (t < s_occ[wv][s]) locs[s_dst[wv][s] + t] = s_val[wv][s][e];
+                if (t < s_occ[wv][s]) locs[s_dst[wv][s] + t] = static_cast<uint64_t>(s_val[wv][s][e]) - s_minus[wv][s];
 #endif
             }
             wave_lds_sync();
