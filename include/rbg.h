@@ -225,10 +225,6 @@ int rbg_find_range_dev(rbg_index *, const uint8_t *d_seqs, const uint64_t *d_off
                        uint64_t *d_lo, uint64_t *d_hi, void *stream);
 int rbg_find_range_w_toehold_dev(rbg_index *, const uint8_t *d_seqs, const uint64_t *d_off, uint64_t N,
                                  uint64_t *d_lo, uint64_t *d_hi, uint64_t *d_ssamp, void *stream);
-/* locate, two-phase because the output is ragged:
- *  1. rbg_locate_plan_dev writes d_loc_off[N+1]; d_tmp/tmp_bytes is scratch (query the size with
- *     rbg_locate_plan_tmp_bytes).  Read d_loc_off[N] to size d_locs.
- *  2. (optional) rbg_locate_order_dev; 3. rbg_locate_fill_dev walks the phi chains into d_locs. */
 /* Packed reads: the same searches over a 2-bit form of the batch.  One lane per read fetching its
  * own bytes is 7 uncoalesced 16-byte requests per 100 bp; rbg_pack_reads_dev reads the bytes once,
  * coalesced, and writes every read as 2-bit codes in consumption order (64 symbols per 16 bytes)
@@ -245,6 +241,10 @@ int rbg_find_range_packed_dev(rbg_index *, const void *d_ws, const uint8_t *d_se
                               uint64_t total_bytes, uint64_t *d_lo, uint64_t *d_hi, void *stream);
 int rbg_find_range_w_toehold_packed_dev(rbg_index *, const void *d_ws, const uint8_t *d_seqs, const uint64_t *d_off, uint64_t N,
                                         uint64_t total_bytes, uint64_t *d_lo, uint64_t *d_hi, uint64_t *d_ssamp, void *stream);
+/* locate, two-phase because the output is ragged:
+ *  1. rbg_locate_plan_dev writes d_loc_off[N+1]; d_tmp/tmp_bytes is scratch (query the size with
+ *     rbg_locate_plan_tmp_bytes).  Read d_loc_off[N] to size d_locs.
+ *  2. (optional) rbg_locate_order_dev; 3. rbg_locate_fill_dev walks the phi chains into d_locs. */
 size_t rbg_locate_plan_tmp_bytes(uint64_t N);
 int rbg_locate_plan_dev(rbg_index *, const uint64_t *d_lo, const uint64_t *d_hi, uint64_t N, uint64_t max_hits,
                         uint64_t *d_loc_off, void *d_tmp, size_t tmp_bytes, void *stream);
@@ -254,7 +254,9 @@ int rbg_locate_plan_dev(rbg_index *, const uint64_t *d_lo, const uint64_t *d_hi,
  * index; the sort costs ~0.5 ms).  Results are unchanged.  d_ws: 256-byte aligned, N < 2^32-1. */
 size_t rbg_locate_order_ws_bytes(uint64_t N);
 int rbg_locate_order_dev(rbg_index *, const uint64_t *d_k, uint64_t N, void *d_ws, size_t ws_bytes, void *stream);
-/* d_order: the workspace prepared by rbg_locate_order_dev for the same d_k, or NULL (input order). */
+/* d_order: the workspace prepared by rbg_locate_order_dev for the same d_k, or NULL (input order).
+ * With d_order the walk takes each read's toehold from the workspace (it travelled with the sort) and
+ * its count from d_loc_off (rbg_locate_plan_dev with the same max_hits): d_lo/d_hi/d_k are then not read. */
 int rbg_locate_fill_dev(rbg_index *, const uint64_t *d_lo, const uint64_t *d_hi, const uint64_t *d_k, uint64_t N,
                         uint64_t max_hits, const uint64_t *d_loc_off, uint64_t *d_locs, const void *d_order, void *stream);
 /* locate_fill with a per-read value subtracted from every location (d_sub nullable): the

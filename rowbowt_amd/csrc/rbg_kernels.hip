@@ -597,7 +597,8 @@ __global__ __launch_bounds__(256) void k_locate_fill(const DevIndex ix, const ui
                                                      const uint64_t *__restrict__ hi, const uint64_t *__restrict__ k,
                                                      const uint64_t N, const uint64_t max_hits,
                                                      const uint64_t *__restrict__ loc_off, uint64_t *__restrict__ locs,
-                                                     const uint64_t *__restrict__ sub, const uint32_t *__restrict__ order) {
+                                                     const uint64_t *__restrict__ sub, const uint32_t *__restrict__ order,
+                                                     const uint64_t *__restrict__ skeys) {
     // staged at the position width: text positions fit P, and at 4 bytes the workgroup's LDS drops from
     // 39 KB to 24 KB (6 instead of 4 waves per SIMD); the per-read offset is applied when flushing
     __shared__ P s_val[4][kWave][kChunk + 1];  // +1: keeps the per-lane rows off the same banks
@@ -612,15 +613,24 @@ __global__ __launch_bounds__(256) void k_locate_fill(const DevIndex ix, const ui
         // neighbouring phi slots (same DRAM rows / L2 lines) for the whole chain, because the chains of
         // reads from nearby loci visit the haplotypes in the same order.  Results land at loc_off[i]
         // whatever the processing order.
-        uint64_t i = base + lane;
-        if (order && i < N) i = order[i];
+        const uint64_t j = base + lane;
+        uint64_t i = j;
+        if (order && j < N) i = order[j];
         uint64_t occ = 0, k1 = 0, dst = 0;
         if (i < N) {
-            const uint64_t l = lo[i], h = hi[i];
-            occ = h >= l ? h - l + 1 : 0;  // toehold_sa.hpp:38-39
-            if (occ > max_hits) occ = max_hits;
-            k1 = k[i];
             dst = loc_off[i];
+            if (skeys) {
+                // ordered walk: the toehold travels with the sort (sequential read) and the count is the
+                // planned one, loc_off[i+1] - loc_off[i] = min(occ, max_hits): one random 64-byte sector
+                // per read instead of four (lo, hi, k, loc_off)
+                k1 = skeys[j];
+                occ = loc_off[i + 1] - dst;
+            } else {
+                const uint64_t l = lo[i], h = hi[i];
+                occ = h >= l ? h - l + 1 : 0;  // toehold_sa.hpp:38-39
+                if (occ > max_hits) occ = max_hits;
+                k1 = k[i];
+            }
         }
         const uint64_t minus = (sub && i < N) ? sub[i] : 0;  // locate_from_longest_seed, rowbowt.hpp:681-683
         s_dst[wv][lane] = dst;
@@ -1372,8 +1382,10 @@ int launch_locate_fill(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t 
     if (N == 0) return 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid(grid_for(cfg, N)), block(cfg.block_threads);
-    if (ix.pos_bytes == 4) hipLaunchKernelGGL((k_locate_fill<uint32_t>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, locs, sub, static_cast<const uint32_t *>(order));
-    else hipLaunchKernelGGL((k_locate_fill<uint64_t>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, locs, sub, static_cast<const uint32_t *>(order));
+    // the order workspace also holds the toeholds in sorted order (launch_locate_order's key output)
+    const uint64_t *skeys = order ? reinterpret_cast<const uint64_t *>(static_cast<const char *>(order) + order_layout(N).keys) : nullptr;
+    if (ix.pos_bytes == 4) hipLaunchKernelGGL((k_locate_fill<uint32_t>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, locs, sub, static_cast<const uint32_t *>(order), skeys);
+    else hipLaunchKernelGGL((k_locate_fill<uint64_t>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, locs, sub, static_cast<const uint32_t *>(order), skeys);
     return static_cast<int>(hipGetLastError());
 }
 
