@@ -379,6 +379,61 @@ def test_device_pipeline_is_graph_capturable(synth):
     o.close()
 
 
+@pytest.mark.parametrize("sigma,skew", [(2, 1.0), (3, 0.5), (4, 2.0), (6, 1.0), (12, 1.5), (40, 1.2), (200, 1.0)])
+def test_random_alphabets(sigma, skew):
+    """Nothing in the engine is DNA-specific: random repetitive texts over 2..200 symbols (fewer than 4
+    'major' symbols, more symbols than the LDS keeps records for, skewed frequencies), every query path
+    against the oracle."""
+    import naive
+    rng = np.random.default_rng(1000 + sigma)
+    alphabet = np.sort(rng.choice(np.arange(2, 256), size=sigma, replace=False)).astype(np.uint8)
+    p = 1.0 / np.arange(1, sigma + 1) ** skew
+    block = rng.choice(alphabet, size=700, p=p / p.sum())
+    pieces = []
+    for c in range(6):                       # six mutated copies: a repetitive collection
+        b = block.copy()
+        pos = rng.choice(len(b), size=12, replace=False)
+        b[pos] = rng.choice(alphabet, size=12)
+        pieces.append(b)
+    text = np.concatenate(pieces + [np.array([1], np.uint8)])   # terminator = smallest symbol, unique
+    sa = naive.suffix_array(text)
+    heads, lens, brk = naive.rle(naive.bwt_from_sa(text, sa))
+    ssa, esa = naive.run_samples(sa, brk, len(text))
+    rb = ra.RowBowt.from_runs(heads, lens, ssa, esa, device=0)
+    o = orc.Oracle.from_runs(heads, lens, ssa, esa)
+    assert rb.info().sigma == len(np.unique(text))
+    tb = text.tobytes()
+    reads = []
+    for _ in range(1500):
+        a = int(rng.integers(0, len(tb) - 2))
+        q = bytearray(tb[a:a + int(rng.integers(1, 60))])
+        if rng.random() < 0.3 and q:
+            q[int(rng.integers(0, len(q)))] = int(rng.integers(0, 256))   # any byte, present in the text or not
+        reads.append(bytes(q))
+    reads += [b"", bytes([1]), bytes([0]), bytes([255]), tb[-5:], tb[:80]]
+    seqs, off = ra.pack_reads(reads)
+    for packed in (0, 2):
+        ra.set_default_option(capi.OPT_PACKED_READS, packed)
+        try:
+            lo, hi, k = rb.find_range_w_toehold(seqs, off)
+            lo2, hi2 = rb.find_range(seqs, off)
+        finally:
+            ra.set_default_option(capi.OPT_PACKED_READS, 0)
+        wlo, whi, wk = o.find_range_w_toehold_batch(seqs, off)
+        assert (lo == wlo).all() and (hi == whi).all() and (k == wk).all() and (lo2 == wlo).all() and (hi2 == whi).all()
+    assert int((hi >= lo).sum()) > 800
+    loc_off, locs = rb.locs_at(lo, hi, k)
+    woff, wlocs = o.locs_at_batch(wlo, whi, wk)
+    assert (loc_off == woff).all() and (locs == wlocs).all()
+    goff, glocs = rb.find_locs_greedy_seeding(seqs, off, 8)
+    for i in range(0, len(reads), 7):
+        assert glocs[int(goff[i]):int(goff[i + 1])].tolist() == o.greedy_locate(reads[i], 8)[0]
+    _check_marker_seeds(rb, o, reads[::5], 6, 1000)
+    _check_marker_seeds(rb, o, reads[::9], 6, 1000, ftab_k=3)
+    rb.close()
+    o.close()
+
+
 def test_packed_reads_device_api(synth):
     """rbg_pack_reads_dev + *_packed_dev against the byte kernels on the same batch: ranges, toeholds and
     the device counters; reads with symbols outside the major alphabet go through the sel list."""
