@@ -340,6 +340,26 @@ int upload_markers(rbg_index *ix) {
     if ((rc = dev_upload(ix, m.vals.data(), m.vals.size() * 8, &p))) return rc;
     ix->dev.mk_vals = static_cast<const uint64_t *>(p);
     ix->dev.mk_nruns = m.start.size();
+    ix->dev.mk_bucket = nullptr;
+    ix->dev.mk_shift = 0;
+    const uint64_t nruns = m.start.size(), n = ix->host.n;
+    if (nruns && nruns < 0xFFFFFFFFull) {
+        // about two buckets per run: at_range's two predecessor searches (2 x log2(nruns) dependent
+        // loads) become one table read and a scan over the runs of one bucket
+        uint32_t shift = 0;
+        while (shift < 20 && (n >> shift) > 2 * nruns) ++shift;
+        const uint64_t nb = (n >> shift) + 2;
+        std::vector<uint32_t> bucket(nb);
+        uint64_t j = 0;
+        for (uint64_t b = 0; b < nb; ++b) {
+            const uint64_t first_row = b << shift;
+            while (j < nruns && m.end[j] < first_row) ++j;
+            bucket[b] = static_cast<uint32_t>(j);
+        }
+        if ((rc = dev_upload(ix, bucket.data(), nb * 4, &p))) return rc;
+        ix->dev.mk_bucket = static_cast<const uint32_t *>(p);
+        ix->dev.mk_shift = shift;
+    }
     return RBG_OK;
 }
 

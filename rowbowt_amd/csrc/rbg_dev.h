@@ -79,6 +79,11 @@ struct DevIndex {
     // markers
     const uint64_t *mk_start, *mk_end, *mk_off, *mk_vals;
     uint64_t mk_nruns;
+    // direct-addressed entry into the marker runs: mk_bucket[b] = index of the first run whose end is
+    // >= b << mk_shift (mk_nruns if none); (n >> mk_shift) + 2 entries; nullptr = binary search only
+    const uint32_t *mk_bucket;
+    uint32_t mk_shift;
+    uint32_t pad4;
     // {reads, matched, sum occ, sum locs}
     unsigned long long *counters;
     const uint8_t *lut;  // 256 bytes, device memory

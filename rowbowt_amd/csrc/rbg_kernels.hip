@@ -676,6 +676,22 @@ __global__ __launch_bounds__(256) void k_locate_fill(const DevIndex ix, const ui
 // runs are disjoint, ascending inclusive SA-index intervals; at_range(lo,hi) = values of all runs
 // with start <= hi && end >= lo, in run order.
 __device__ __forceinline__ void marker_span(const DevIndex &ix, uint64_t lo, uint64_t hi, uint64_t *first, uint64_t *last) {
+    if (ix.mk_bucket) {
+        if (lo >= ix.n) { *first = *last = ix.mk_nruns; return; }  // caller-supplied rows beyond the BWT: nothing
+        if (hi >= ix.n) hi = ix.n - 1;
+        // first run with end >= lo: the bucket table gives the first run ending at or after the start of
+        // lo's bucket; the answer is at most a bucket's worth of runs further on
+        uint64_t a = ix.mk_bucket[lo >> ix.mk_shift];
+        while (a < ix.mk_nruns && ix.mk_end[a] < lo) ++a;
+        *first = a;
+        // one past the last run with start <= hi: every run before the entry of hi's bucket ends, hence
+        // starts, before hi
+        uint64_t z = ix.mk_bucket[hi >> ix.mk_shift];
+        if (z < a) z = a;
+        while (z < ix.mk_nruns && ix.mk_start[z] <= hi) ++z;
+        *last = z;
+        return;
+    }
     uint64_t a = 0, z = ix.mk_nruns;
     while (a < z) { const uint64_t m = a + ((z - a) >> 1); if (ix.mk_end[m] < lo) a = m + 1; else z = m; }
     *first = a;  // first run with end >= lo
