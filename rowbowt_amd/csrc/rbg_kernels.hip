@@ -917,8 +917,9 @@ __global__ __launch_bounds__(256) void k_greedy_seed(const DevIndex ix, const ui
 // one past last marker}; the markers of a seed are what every window query along it appended to
 // mbuf (:437-441, :469-472), plus one more query when the seed ends or the read does (:445-447,
 // :478-480).  FILL=false counts records and markers per read; FILL=true re-walks and writes.
-// k-mer steps are used where no window query can fall inside them; a k-mer step that comes back
-// empty is retried symbol by symbol so the failing base is the reference's.
+// k-mer steps are used where no window query can fall inside them and a fresh seed takes its first
+// ftab_k symbols from the device state table; a k-mer step that comes back empty is narrowed down with
+// two more gathers so the failing base is the reference's.
 template <typename P, bool FILL>
 __global__ __launch_bounds__(256) void k_marker_seeds(const DevIndex ix, const uint8_t *__restrict__ seqs,
                                                       const uint64_t *__restrict__ off, const uint64_t N,
@@ -929,21 +930,10 @@ __global__ __launch_bounds__(256) void k_marker_seeds(const DevIndex ix, const u
                                                       uint64_t *__restrict__ seeds, uint64_t *__restrict__ mk) {
     __shared__ uint8_t s_lut[256];
     __shared__ uint8_t s_lut2[256];
-    __shared__ DevSym s_sym[kLdsSyms];
-    __shared__ DevSym s_pair[kMaxMajor * kMaxMajor];
-    __shared__ DevSym s_tri[kMaxMajor * kMaxMajor * kMaxMajor];
+    __shared__ DevSym s_tab[kTabMax];
+    stage_tables(ix, s_tab, s_lut, s_lut2);
     const uint32_t M = ix.nmajor;
-    const bool use3 = ix.kmer_steps >= 3;
-    for (int t = threadIdx.x; t < 256; t += blockDim.x) {
-        s_lut[t] = ix.lut[t];
-        s_lut2[t] = M ? ix.lut2[t] : 0xFFu;
-    }
-    const int nlds = ix.sigma < static_cast<uint32_t>(kLdsSyms) ? static_cast<int>(ix.sigma) : kLdsSyms;
-    for (int t = threadIdx.x; t < nlds; t += blockDim.x) s_sym[t] = ix.syms[t];
-    for (int t = threadIdx.x; t < static_cast<int>(M * M); t += blockDim.x) s_pair[t] = ix.pairs[t];
-    if (use3)
-        for (int t = threadIdx.x; t < static_cast<int>(M * M * M); t += blockDim.x) s_tri[t] = ix.triples[t];
-    __syncthreads();
+    const uint32_t ksteps = ix.kmer_steps;
     if (!FILL && blockIdx.x == 0 && threadIdx.x == 0) { seed_cnt[0] = 0; mk_cnt[0] = 0; }
     const bool have_ma = ix.mk_nruns != 0;
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
@@ -979,7 +969,7 @@ __global__ __launch_bounds__(256) void k_marker_seeds(const DevIndex ix, const u
         auto lf1 = [&](uint32_t c) -> bool {
             const uint32_t slot = s_lut[c];
             if (slot == 0xFFu) return false;
-            const DevSym S = slot < static_cast<uint32_t>(kLdsSyms) ? s_sym[slot] : ix.syms[slot];
+            const DevSym S = slot < static_cast<uint32_t>(kLdsSyms) ? s_tab[slot] : ix.syms[slot];
             RankAux q;
             uint64_t c_before, c_upto, bh;
             rank_pair<P>(S, lo, hi + 1, &c_before, &c_upto, &bh, &q);
@@ -988,22 +978,35 @@ __global__ __launch_bounds__(256) void k_marker_seeds(const DevIndex ix, const u
             hi = lo + (c_upto - c_before) - 1;
             return true;
         };
-        // up to `want` (2 or 3) symbols ending at byte p with one gather; 0 = not applicable or empty
-        auto lfk = [&](uint64_t p, uint32_t c, uint64_t avail) -> uint32_t {
+        // the longest k-mer (2..min(cap, kmer_steps) symbols, all with k-mer tables) ending at byte p:
+        // *len = its length (0: none applies); returns true when the range survived it
+        auto lfk = [&](uint64_t p, uint32_t c, uint64_t cap, uint32_t *len) -> bool {
+            *len = 0;
             const uint32_t m0 = s_lut2[c];
-            if (m0 == 0xFFu || avail < 2) return 0;
+            if (m0 == 0xFFu || cap < 2 || ksteps < 2) return false;
             const uint32_t m1 = s_lut2[rd.at(p - 1)];
-            if (m1 == 0xFFu) return 0;
-            uint32_t m2 = 0xFFu;
-            if (use3 && avail >= 3) m2 = s_lut2[rd.at(p - 2)];
-            const DevSym S = m2 != 0xFFu ? s_tri[(m2 * M + m1) * M + m0] : s_pair[m1 * M + m0];
+            if (m1 == 0xFFu) return false;
+            uint32_t adv = 2, idx = kOff2 + m1 * M + m0;
+            if (ksteps >= 3 && cap >= 3) {
+                const uint32_t m2 = s_lut2[rd.at(p - 2)];
+                if (m2 != 0xFFu) {
+                    adv = 3;
+                    idx = kOff3 + (m2 * M + m1) * M + m0;
+                    if (ksteps >= 4 && cap >= 4) {
+                        const uint32_t m3 = s_lut2[rd.at(p - 3)];
+                        if (m3 != 0xFFu) { adv = 4; idx = kOff4 + ((m3 * M + m2) * M + m1) * M + m0; }
+                    }
+                }
+            }
+            *len = adv;
+            const DevSym S = s_tab[idx];
             RankAux q;
             uint64_t c_before, c_upto, bh;
             rank_pair<P>(S, lo, hi + 1, &c_before, &c_upto, &bh, &q);
-            if (c_upto <= c_before) return 0;
+            if (c_upto <= c_before) return false;
             lo = S.F + c_before;
             hi = lo + (c_upto - c_before) - 1;
-            return m2 != 0xFFu ? 3u : 2u;
+            return true;
         };
         if (ftab_k) {
             // ---- with the ftab of k-mer size K (rb_markers --ftab): the reference's loop in its own
@@ -1020,8 +1023,12 @@ __global__ __launch_bounds__(256) void k_marker_seeds(const DevIndex ix, const u
                 while (e2 > e - K) {
                     const uint64_t p = beg + e2 - 1;
                     const uint32_t c = rd.at(p);
-                    uint32_t adv = lfk(p, c, e2 - (e - K));
-                    if (!adv) { if (!lf1(c)) return false; adv = 1; }
+                    uint32_t adv;
+                    if (!lfk(p, c, e2 - (e - K), &adv)) {
+                        if (adv) return false;       // a k-mer of the word is absent: so is the word
+                        if (!lf1(c)) return false;
+                        adv = 1;
+                    }
                     e2 -= adv;
                 }
                 return true;
@@ -1067,6 +1074,23 @@ __global__ __launch_bounds__(256) void k_marker_seeds(const DevIndex ix, const u
             continue;
         }
         uint64_t j = m;  // m - i of the reference; the next symbol consumed is q[j-1]
+        auto on_ok = [&](uint32_t adv) {              // adv symbols consumed, range still non-empty
+            j -= adv;
+            if (window_ei - j >= wsize) {             // :469-472 (m-i-1 == j after the step)
+                update_mbuf(lo, hi);
+                window_ei = j;
+            }
+            plo = lo; phi = hi;                       // :473
+        };
+        auto on_fail = [&]() {                        // q[j-1] empties the range: the seed q[j, seed_ei) ends (:444-466)
+            if (seed_ei - j >= wsize) update_mbuf(plo, phi);
+            emit(plo, phi, j, seed_ei);
+            mb_begin = tot;
+            plo = 0; phi = fhi; lo = 0; hi = fhi;
+            j -= 1;                                   // the failing base is skipped
+            seed_ei = j;
+            window_ei = j;
+        };
         while (j > 0) {
             const uint64_t p = beg + j - 1;
             const uint32_t c = rd.at(p);
@@ -1074,28 +1098,49 @@ __global__ __launch_bounds__(256) void k_marker_seeds(const DevIndex ix, const u
             // leaves j' with j' + wsize <= window_ei, :469)
             uint64_t dist = j + wsize > window_ei ? j + wsize - window_ei : 1;
             if (dist == 0) dist = 1;
-            uint32_t adv = lfk(p, c, dist < j ? dist : j);
-            bool ok = adv != 0;
-            if (!ok) {
-                adv = 1;
-                ok = lf1(c);
-            }
-            if (ok) {
-                j -= adv;
-                if (window_ei - j >= wsize) {             // :469-472 (m-i-1 == j after the step)
-                    update_mbuf(lo, hi);
-                    window_ei = j;
+            const uint64_t cap = dist < j ? dist : j;
+            // a fresh seed starts from the full range: the state after its first ftab_k symbols is one
+            // gather in the device table (what k_find_range computes for that word; empty = the word does
+            // not occur, then the steps below find where it stops)
+            if (j == seed_ei && ix.ftab_k && cap >= ix.ftab_k) {
+                uint64_t idx = 0, pw = 1;
+                bool all_major = true;
+                for (uint32_t t = 0; t < ix.ftab_k; ++t) {
+                    const uint32_t mm = s_lut2[rd.at(p - t)];
+                    all_major = all_major && mm != 0xFFu;
+                    idx += (mm & 3u) * pw;
+                    pw *= M;
                 }
-                plo = lo; phi = hi;                       // :473
+                if (all_major) {
+                    const ulonglong4 e = *reinterpret_cast<const ulonglong4 *>(ix.ftab + 4 * idx);
+                    if (e.x <= e.y) {
+                        lo = e.x; hi = e.y;
+                        on_ok(ix.ftab_k);
+                        continue;
+                    }
+                }
+            }
+            uint32_t len;
+            if (lfk(p, c, cap, &len)) { on_ok(len); continue; }
+            if (len == 0) {                           // no k-mer applies: one reference step (:443)
+                if (lf1(c)) on_ok(1u); else on_fail();
+                continue;
+            }
+            // the range died inside q[j-len, j): two more gathers say where (lo/hi are untouched)
+            if (len == 2) {
+                if (lf1(c)) { on_ok(1u); on_fail(); } else on_fail();
             } else {
-                // the seed q[j, seed_ei) ends here; q[j-1] is skipped (:444-466)
-                if (seed_ei - j >= wsize) update_mbuf(plo, phi);
-                emit(plo, phi, j, seed_ei);
-                mb_begin = tot;
-                plo = 0; phi = fhi; lo = 0; hi = fhi;
-                j -= 1;
-                seed_ei = j;
-                window_ei = j;
+                uint32_t l2;
+                const bool first_two = len == 4 ? lfk(p, c, 2, &l2) : lf1(c);
+                const uint32_t took = len == 4 ? 2u : 1u;
+                if (first_two) {
+                    on_ok(took);                      // then exactly one of the next two symbols fails
+                    if (lf1(rd.at(beg + j - 1))) { on_ok(1u); on_fail(); } else on_fail();
+                } else if (len == 4) {
+                    if (lf1(c)) { on_ok(1u); on_fail(); } else on_fail();
+                } else {
+                    on_fail();
+                }
             }
         }
         if (hi >= lo && seed_ei >= wsize) update_mbuf(lo, hi);   // :478-480 (m-i == 0)
