@@ -8,6 +8,7 @@ The library must be present: a missing or unloadable librbg.so is an error, neve
 import ctypes as C
 import enum
 import os
+import weakref
 
 import numpy as np
 
@@ -157,12 +158,14 @@ def set_default_option(opt, value):
 
 
 def _take(ptr, n):
-    """copy a library-malloc'ed uint64 buffer into numpy and release it"""
-    out = np.zeros(n, dtype=np.uint64)
-    if n:
-        C.memmove(out.ctypes.data, ptr.value, n * 8)
-    lib().rbg_free_buffer(ptr)
-    return out
+    """a library-malloc'ed uint64 result as a numpy array, without copying (gigabytes of locations); the
+    buffer is released (rbg_free_buffer) when the last array viewing it is gone"""
+    if n == 0 or not ptr.value:
+        lib().rbg_free_buffer(ptr)
+        return np.zeros(0, dtype=np.uint64)
+    mem = (C.c_char * (n * 8)).from_address(ptr.value)
+    weakref.finalize(mem, lib().rbg_free_buffer, VP(ptr.value))
+    return np.frombuffer(mem, dtype=np.uint64)   # .base is `mem`: every view keeps it alive
 
 
 class RowBowt:

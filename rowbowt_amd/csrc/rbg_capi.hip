@@ -2,6 +2,7 @@
 // HBM replica, stages host batches, launches the kernels of rbg_kernels.hip.
 // There is deliberately no CPU compute path in this library.
 #include <hip/hip_runtime.h>
+#include <sys/mman.h>
 
 #include <algorithm>
 #include <atomic>
@@ -517,13 +518,30 @@ int check_offsets(const uint64_t *off, uint64_t N) {
     return RBG_OK;
 }
 
+// Host memory for a ragged result (released by rbg_free_buffer = free).  The device-to-host copy is the
+// first touch of this memory, and for gigabytes of locations the page faults cost more than the PCIe
+// transfer (tools/d2h_probe.hip: 3 GB in 0.22 s into fresh malloc memory, 0.13-0.16 s into 2 MB-aligned
+// memory marked for transparent huge pages, 0.06 s once touched), so large results ask for huge pages.
+void *alloc_result(size_t bytes) {
+    constexpr size_t kHuge = size_t(2) << 20;
+    if (bytes >= 4 * kHuge) {
+        const size_t rounded = (bytes + kHuge - 1) & ~(kHuge - 1);
+        void *p = std::aligned_alloc(kHuge, rounded);
+        if (p) {
+            (void)madvise(p, rounded, MADV_HUGEPAGE);
+            return p;
+        }
+    }
+    return std::malloc(bytes ? bytes : 8);
+}
+
 // shared tail of the ragged-output host calls: d_off[N+1] is planned on the device; size, fill, copy back
 template <typename FillFn>
 int ragged_finish(uint64_t N, DevBuf &d_off, uint64_t *h_off, uint64_t **h_vals, hipStream_t st, FillFn fill) {
     HIP_TRY(hipMemcpyAsync(h_off, d_off.p, (N + 1) * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     const uint64_t total = h_off[N];
-    *h_vals = static_cast<uint64_t *>(std::malloc(total ? total * 8 : 8));
+    *h_vals = static_cast<uint64_t *>(alloc_result(total * 8));
     if (!*h_vals) return RBG_ENOMEM;
     if (total == 0) return RBG_OK;
     DevBuf d_vals;
@@ -1274,8 +1292,8 @@ int rbg_get_markers_greedy_seeding(rbg_index *ix, const uint8_t *seqs, const uin
     HIP_TRY(hipMemcpyAsync(&total_mk, dmoff.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     const uint64_t total_seeds = seed_off[N];
-    auto *h_seeds = static_cast<rbg_marker_seed_t *>(std::malloc(total_seeds ? total_seeds * sizeof(rbg_marker_seed_t) : 8));
-    auto *h_mk = static_cast<uint64_t *>(std::malloc(total_mk ? total_mk * 8 : 8));
+    auto *h_seeds = static_cast<rbg_marker_seed_t *>(alloc_result(total_seeds * sizeof(rbg_marker_seed_t)));
+    auto *h_mk = static_cast<uint64_t *>(alloc_result(total_mk * 8));
     if (!h_seeds || !h_mk) { std::free(h_seeds); std::free(h_mk); return RBG_ENOMEM; }
     rc = RBG_OK;
     if (total_seeds) {
