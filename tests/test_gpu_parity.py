@@ -1055,3 +1055,26 @@ def test_cli_parser_matches_kseq(data_dir, tmp_path, small):
         want += f"{name.decode()} ({lo},{hi}), count={(hi - lo + 1) % 2**64}\n"
     assert out == want
     assert "(1,0), count=0" in out.splitlines()[2]  # the blank inside the sequence is kept, as kseq does
+
+
+def test_full_size_properties_and_parity_sample():
+    """BASELINE.json's size (n = 2.0e9, r = 3.7e7, 10 M x 100 bp reads) through the size-independent
+    properties and an oracle sample: one bench.py step in a subprocess (about a minute and a half: the
+    index synthesis dominates)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
+                        "--check-reads", "5000", "--property-reads", "300000", "--markers"],
+                       capture_output=True, timeout=1500, cwd=root)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    d = json.loads(p.stdout.decode().strip().splitlines()[-1])
+    assert d["config"]["index"]["n"] > 2_000_000_000 and d["config"]["index"]["r"] > 30_000_000
+    props = d["properties_full_size"]
+    assert props["reads"] == 300000 and props["locations"] > 5_000_000
+    assert all(props[k] for k in ("every_location_is_an_occurrence", "locations_distinct", "occ_equals_range_width", "empty_is_{1,0}"))
+    assert d["parity"]["bit_exact_vs_oracle"] and d["parity"]["locs_checked"] > 100_000
+    assert d["markers"]["parity"]["bit_exact_vs_oracle"] and d["markers"]["marker_seeds"]["parity"]["bit_exact_vs_oracle"]
+    c = d["counters"]
+    assert c["reads"] == 10_000_000 and c["sum_occ"] == c["sum_locs"] > 300_000_000   # sum of range widths == locations written
