@@ -43,7 +43,7 @@ struct RbMarkersArgs {  // rb_markers.cpp:22-40
     std::string inpre, fastq_fname;
     int ftab = 0, fbb = 0, overlap = 0, lmem = 0;
     uint64_t wsize = 19, max_range = 1000, min_range = 0;
-    uint64_t threads = 1, max_tasks = 1024, read_len = 101, min_seed_len = 0;
+    uint64_t threads = 8, max_tasks = 1024, read_len = 101, min_seed_len = 0;  // threads: host formatting workers (the reference's default of 1 is its search pool)
     int clear_conflicting = 0, clear_identical = 0, best_strand = 0, heuristic = 0;
     int device = 0;
     uint64_t batch = 1u << 19;

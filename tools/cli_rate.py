@@ -28,3 +28,12 @@ for flags in ([], ["-s"], ["-s", "-m"]):
     sz = os.path.getsize("/tmp/cli_out.txt")
     print(f"rb_align {' '.join(flags) or '(count)':8s}: {N} x {m} bp FASTQ ({os.path.getsize(path)/1e6:.0f} MB) -> {sz/1e6:.0f} MB of text in {dt:.2f} s = {N/dt:.3e} reads/s"
           f"   [stderr: {p.stderr.decode().strip().splitlines()[-1]}]")
+
+exe2 = os.path.join(ROOT, "rowbowt_amd", "rb_markers")
+for flags in ([], ["--threads", "16"], ["--heuristic", "--best-strand-only", "--min-seed-length", "30", "--threads", "16"]):
+    t0 = time.perf_counter()
+    p = subprocess.run([exe2] + flags + ["/tmp/cli_idx/idx", path], stdout=open("/tmp/cli_out.txt", "wb"), stderr=subprocess.PIPE)
+    dt = time.perf_counter() - t0
+    sz = os.path.getsize("/tmp/cli_out.txt")
+    print(f"rb_markers {' '.join(flags) or '(defaults)'}: {N} x {m} bp FASTQ -> {sz/1e6:.0f} MB of text in {dt:.2f} s = {N/dt:.3e} reads/s"
+          f"   [stderr: {p.stderr.decode().strip().splitlines()[-1]}]")
