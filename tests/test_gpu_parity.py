@@ -77,6 +77,39 @@ def test_golden_markers(small, simple_reads):
             assert (G.get_pos(got[0]), G.get_allele(got[0])) == want
 
 
+def test_golden_files_through_the_hip_path(small, simple_reads, error_reads, data_dir, tmp_path):
+    """tests/golden/ (oracle-made, committed) against the HIP path, no oracle in the loop"""
+    import json
+    rb, _ = small
+    gd = G.GOLDEN_DIR
+    # get_markers_greedy_seeding records
+    reads = simple_reads + error_reads
+    seqs, off = ra.pack_reads(reads)
+    for case in json.load(open(os.path.join(gd, "toy_marker_seeds.json")))["cases"]:
+        seed_off, seeds, mk = rb.get_markers_greedy_seeding(seqs, off, case["wsize"], case["max_range"], case["ftab_k"])
+        assert len(case["reads"]) == len(reads)
+        for i, want in enumerate(case["reads"]):
+            got = seeds[int(seed_off[i]):int(seed_off[i + 1])]
+            assert [[int(g[0]), int(g[1]), int(g[2]), int(g[3]), mk[int(g[4]):int(g[5])].tolist()] for g in got] == want["seeds"], (case, i)
+    # locate on error_query.fq
+    lo, hi, k = rb.find_range_w_toehold(*ra.pack_reads(error_reads))
+    loc_off, locs = rb.locs_at(lo, hi, k)
+    for i, want in enumerate(json.load(open(os.path.join(gd, "toy_error_query_locate.json")))["reads"]):
+        assert (int(lo[i]), int(hi[i]), int(k[i])) == (want["lo"], want["hi"], want["toehold"])
+        assert locs[int(loc_off[i]):int(loc_off[i + 1])].tolist() == want["locs"]
+    # the reference-format ftab
+    rb.write_ftab(4, str(tmp_path / "k4.ftab"))
+    assert (tmp_path / "k4.ftab").read_bytes() == open(os.path.join(gd, "toy_k4.ftab"), "rb").read()
+    assert rb.check_ftab(os.path.join(gd, "toy_k4.ftab")) == 4
+    # rb_markers stdout
+    both = tmp_path / "both.fq"
+    both.write_bytes(open(os.path.join(data_dir, "simple_query.fq"), "rb").read() + open(os.path.join(data_dir, "error_query.fq"), "rb").read())
+    rc, out, err = _run_rb_markers([os.path.join(data_dir, "small.fa"), str(both)])
+    assert rc == 0 and out == open(os.path.join(gd, "toy_rb_markers_default.txt")).read(), err
+    rc, out, err = _run_rb_markers(["--heuristic", "--best-strand-only", "-y", "5", "-l", "20", "-w", "8", os.path.join(data_dir, "small.fa"), str(both)])
+    assert rc == 0 and out == open(os.path.join(gd, "toy_rb_markers_heuristic.txt")).read(), err
+
+
 def test_error_reads(small, error_reads):
     rb, o = small
     seqs, off = ra.pack_reads(error_reads)

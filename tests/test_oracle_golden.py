@@ -152,3 +152,19 @@ def test_oracle_marker_seeds_fixture(small_oracle=None):
                     l2, h2 = o.find_range(q[qs - 1:qe])
                     assert h2 < l2
     o.close()
+
+
+def test_oracle_reproduces_committed_golden_files(tmp_path):
+    """tests/golden/*: regenerate with the generator script into a scratch directory and compare byte for byte"""
+    import importlib.util
+    import os
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(gold, "make_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.main(str(tmp_path))
+    made = sorted(os.listdir(tmp_path))
+    assert made == ["toy_error_query_locate.json", "toy_k4.ftab", "toy_marker_seeds.json", "toy_rb_markers_default.txt",
+                    "toy_rb_markers_heuristic.txt"]
+    for f in made:
+        assert open(tmp_path / f, "rb").read() == open(os.path.join(gold, f), "rb").read(), f
