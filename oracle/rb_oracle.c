@@ -391,7 +391,11 @@ uint64_t orc_phi(const orc_index *x, uint64_t i) {
     uint64_t jr = sdv_pred_rank_circular(&x->pred, i);
     uint64_t j = sdv_select(&x->pred, jr);
     uint64_t delta = j < i ? i - j : i + 1;
-    uint64_t prev_sample = x->samples_last[x->pred_to_run[jr] - 1];
+    /* the reference asserts pred_to_run_[jr] > 0 (:67): phi(SA[0]) is outside its domain.  It is reached
+     * only through a toehold that wrapped below zero (a match at text position 0); 0 stands in there so
+     * that this checker never reads out of bounds */
+    uint64_t run = x->pred_to_run[jr];
+    uint64_t prev_sample = run ? x->samples_last[run - 1] : 0;
     return (prev_sample + delta) % x->tsa_n;
 }
 

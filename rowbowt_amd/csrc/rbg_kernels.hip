@@ -545,6 +545,15 @@ __global__ __launch_bounds__(256) void k_occ(const uint64_t *__restrict__ lo, co
 template <typename P>
 __device__ __forceinline__ uint64_t phi_step(const DevIndex &ix, uint64_t i) {
     const PhiSlot<P> *__restrict__ slots = static_cast<const PhiSlot<P> *>(ix.phi_slots);
+    if (i >= ix.n) {
+        // Only a toehold that wrapped below zero gets here: a match at text position 0 leaves k - 1 =
+        // 2^64 - 1 (LF_w_loc, rowbowt.hpp:561).  The reference's phi is outside its domain there
+        // (toehold_sa.hpp:57-59 assert); its arithmetic on the last sampled position is followed, and no
+        // table is indexed with the out-of-range value.
+        const PhiEnt<P> e = static_cast<const PhiEnt<P> *>(ix.phi_ent)[ix.r - 1];
+        const uint64_t sum = static_cast<uint64_t>(e.base) + (i - static_cast<uint64_t>(e.pos));  // wraps like uint64_t there
+        return sum % ix.n;
+    }
     const uint64_t b = i >> ix.phi_shift;
     const PhiSlot<P> sl = load_slot(slots + b);
     const uint32_t meta = static_cast<uint32_t>(sl.meta);
@@ -605,6 +614,7 @@ __global__ __launch_bounds__(256) void k_locate_fill(const DevIndex ix, const ui
     __shared__ uint64_t s_dst[4][kWave];
     __shared__ uint64_t s_occ[4][kWave];
     __shared__ uint64_t s_minus[4][kWave];
+    __shared__ uint64_t s_first[4][kWave];  // the toehold itself is not a text position when it wrapped (2^64 - 1)
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
     unsigned long long c_locs = 0;
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
@@ -636,6 +646,7 @@ __global__ __launch_bounds__(256) void k_locate_fill(const DevIndex ix, const ui
         s_dst[wv][lane] = dst;
         s_occ[wv][lane] = occ;
         s_minus[wv][lane] = minus;
+        s_first[wv][lane] = k1;
         c_locs += occ;
         uint64_t wmax = occ;
 #pragma unroll
@@ -661,7 +672,7 @@ __global__ __launch_bounds__(256) void k_locate_fill(const DevIndex ix, const ui
 #ifdef RBG_ABLATE_STORES  /* timing experiment only: keep the values live, drop the stores */
                 if (t < s_occ[wv][s] && s_val[wv][s][e] == static_cast<P>(~uint64_t(1))) locs[s_dst[wv][s] + t] = 1;
 #else
-                if (t < s_occ[wv][s]) locs[s_dst[wv][s] + t] = static_cast<uint64_t>(s_val[wv][s][e]) - s_minus[wv][s];
+                if (t < s_occ[wv][s]) locs[s_dst[wv][s] + t] = (t ? static_cast<uint64_t>(s_val[wv][s][e]) : s_first[wv][s]) - s_minus[wv][s];
 #endif
             }
             wave_lds_sync();

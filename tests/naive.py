@@ -28,7 +28,7 @@ def invert_bwt(bwt):
 def suffix_array(text):
     """Prefix doubling, O(n log^2 n) with numpy sorts.  text: uint8 array (any bytes)."""
     n = len(text)
-    rank = text.astype(np.int64)
+    rank = np.unique(text, return_inverse=True)[1].astype(np.int64)  # dense: the doubling key needs ranks < n + 2
     k = 1
     sa = np.argsort(rank, kind="stable")
     while True:

@@ -467,6 +467,45 @@ def test_random_alphabets(sigma, skew):
     o.close()
 
 
+@pytest.mark.parametrize("body", [b"A", b"AAAAAAAAAAAA", b"ACGT", b"ABABABABAB", b"TTTTTTTTCTTTTTTTT", b"ACGTACGTACGTACGTACGTACGTACGTACGTACGTACGT" * 8])
+def test_tiny_indexes(body):
+    """Degenerate texts (two symbols long, one long run, pure repeats): table sizing, the automatic
+    shifts and the ftab word length must not assume anything about n"""
+    import naive
+    text = np.frombuffer(body + bytes([1]), dtype=np.uint8)
+    sa = naive.suffix_array(text)
+    heads, lens, brk = naive.rle(naive.bwt_from_sa(text, sa))
+    ssa, esa = naive.run_samples(sa, brk, len(text))
+    rb = ra.RowBowt.from_runs(heads, lens, ssa, esa, device=0)
+    o = orc.Oracle.from_runs(heads, lens, ssa, esa)
+    alphabet = sorted(set(body)) + [ord("N"), 1]
+    rng = np.random.default_rng(len(body))
+    reads = [bytes(rng.choice(alphabet, size=int(rng.integers(0, 9))).astype(np.uint8)) for _ in range(300)]
+    reads += [body, body[:1], body[-1:], body + body, b"", body[1:], body[:-1]]
+    seqs, off = ra.pack_reads(reads)
+    for packed in (0, 2):
+        ra.set_default_option(capi.OPT_PACKED_READS, packed)
+        try:
+            lo, hi, k = rb.find_range_w_toehold(seqs, off)
+        finally:
+            ra.set_default_option(capi.OPT_PACKED_READS, 0)
+        wlo, whi, wk = o.find_range_w_toehold_batch(seqs, off)
+        assert (lo == wlo).all() and (hi == whi).all() and (k == wk).all()
+    loc_off, locs = rb.locs_at(lo, hi, k)
+    woff, wlocs = o.locs_at_batch(wlo, whi, wk)
+    assert (loc_off == woff).all() and (locs == wlocs).all()
+    goff, glocs = rb.find_locs_greedy_seeding(seqs, off, 2)
+    for i in range(len(reads)):
+        assert glocs[int(goff[i]):int(goff[i + 1])].tolist() == o.greedy_locate(reads[i], 2)[0]
+    _check_marker_seeds(rb, o, reads, 2, 1000)
+    _check_marker_seeds(rb, o, reads, 3, 1000, ftab_k=2)
+    nlo, nhi = rb.LF(np.zeros(len(alphabet), np.uint64), np.full(len(alphabet), len(text) - 1, np.uint64), np.array(alphabet, np.uint8))
+    for j, c in enumerate(alphabet):
+        assert (int(nlo[j]), int(nhi[j])) == o.LF(0, len(text) - 1, c)
+    rb.close()
+    o.close()
+
+
 def test_packed_reads_device_api(synth):
     """rbg_pack_reads_dev + *_packed_dev against the byte kernels on the same batch: ranges, toeholds and
     the device counters; reads with symbols outside the major alphabet go through the sel list."""
