@@ -782,12 +782,18 @@ int rbg_build_from_runs(const uint8_t *heads, const uint64_t *lens, uint64_t R, 
     rle.lens.assign(lens, lens + R);
     uint64_t n = 0;
     for (uint64_t i = 0; i < R; ++i) {
-        if (i && heads[i] == heads[i - 1]) return RBG_EARG;  // runs must be maximal
+        if (lens[i] == 0 || (i && heads[i] == heads[i - 1])) return RBG_EARG;  // runs are non-empty and maximal
         n += lens[i];
     }
     rle.n = n;
     RawTsa tsa;
-    if (ssa_y) tsa_from_samples(n, R, ssa_y, esa_y, tsa);
+    if (ssa_y) {
+        for (uint64_t i = 0; i < R; ++i)
+            if (ssa_y[i] > n || esa_y[i] > n) return RBG_EARG;  // SA values of an n-symbol text
+        tsa_from_samples(n, R, ssa_y, esa_y, tsa);
+        for (uint64_t j = 1; j < R; ++j)
+            if (tsa.pred_pos[j] == tsa.pred_pos[j - 1]) return RBG_EARG;  // run-start samples must be distinct
+    }
     rbg_index *ix = new (std::nothrow) rbg_index();
     if (!ix) return RBG_ENOMEM;
     int rc = flatten(rle, ssa_y ? &tsa : nullptr, current_options(), ix->host);

@@ -377,8 +377,9 @@ __global__ __launch_bounds__(256) void k_pack_reads(const DevIndex ix, const uin
             const uint64_t beg = off[i], m = off[i + 1] - beg;
             const uint8_t *lsrc = reinterpret_cast<const uint8_t *>(s_raw) + (beg - a0);
             uint4 *dst = chunks + chunk_off[i];
-            uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, bad = 0;
-            for (uint64_t t0 = 0; t0 < m; t0 += 16) {  // 16 symbols = one 32-bit word
+            uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+            uint32_t bad = m >= 0x80000000ull;  // the packed length field is 31 bits: such a read goes to the byte kernel
+            for (uint64_t t0 = 0; t0 < m && !bad; t0 += 16) {  // 16 symbols = one 32-bit word
                 uint32_t acc = 0;
                 const uint32_t lim = m - t0 < 16 ? static_cast<uint32_t>(m - t0) : 16u;
                 for (uint32_t u = 0; u < lim; ++u) {
@@ -394,7 +395,7 @@ __global__ __launch_bounds__(256) void k_pack_reads(const DevIndex ix, const uin
                     w0 = w1 = w2 = w3 = 0;
                 }
             }
-            meta[i] = make_uint2(static_cast<uint32_t>(chunk_off[i]), static_cast<uint32_t>(m) | (bad ? 0x80000000u : 0u));
+            meta[i] = make_uint2(static_cast<uint32_t>(chunk_off[i]), bad ? 0x80000000u : static_cast<uint32_t>(m));
             if (bad) sel[atomicAdd(nsel, 1u)] = static_cast<uint32_t>(i);
         }
     }

@@ -270,3 +270,33 @@ def test_rb_build_cli_raw_inputs(tmp_path):
     a = ra.load_rowbowt(str(tmp_path / "out" / "small"), ra.LoadRbwtFlag.SA | ra.LoadRbwtFlag.MA, device=capi.DEVICE_NONE)
     b = ra.load_rowbowt(data, ra.LoadRbwtFlag.SA | ra.LoadRbwtFlag.MA, device=capi.DEVICE_NONE)
     _same_index(a, b)
+
+
+def test_build_from_runs_rejects_inconsistent_input():
+    """garbage in the caller's arrays is RBG_EARG, not a table indexed out of bounds later"""
+    from synth import SynthIndex
+    S = SynthIndex(L=300, H=3, n_sites=5, seed=4)
+    ok = ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=capi.DEVICE_NONE)
+    n = ok.info().n
+    ok.close()
+    cases = []
+    bad = S.lens.copy(); bad[3] = 0; cases.append((S.heads, bad, S.ssa, S.esa))                    # empty run
+    bad = S.heads.copy(); bad[5] = bad[4]; cases.append((bad, S.lens, S.ssa, S.esa))               # not maximal
+    bad = S.ssa.copy(); bad[2] = n + 1; cases.append((S.heads, S.lens, bad, S.esa))                # sample beyond the text
+    bad = S.esa.copy(); bad[7] = 2**63; cases.append((S.heads, S.lens, S.ssa, bad))
+    bad = S.ssa.copy(); bad[1] = bad[0]; cases.append((S.heads, S.lens, bad, S.esa))               # two runs starting at one text position
+    for heads, lens, ssa, esa in cases:
+        with pytest.raises(ra.RbgError) as e:
+            ra.RowBowt.from_runs(heads, lens, ssa, esa, device=capi.DEVICE_NONE)
+        assert e.value.code == -4
+    rng = np.random.default_rng(0)
+    for _ in range(200):   # random garbage never crashes: either rejected or a (meaningless) index
+        R = int(rng.integers(1, 40))
+        heads = rng.integers(0, 6, R).astype(np.uint8)
+        lens = rng.integers(0, 5, R).astype(np.uint64)
+        ssa = rng.integers(0, 200, R).astype(np.uint64)
+        esa = rng.integers(0, 200, R).astype(np.uint64)
+        try:
+            ra.RowBowt.from_runs(heads, lens, ssa, esa, device=capi.DEVICE_NONE).close()
+        except ra.RbgError as e:
+            assert e.code in (-2, -4)

@@ -94,6 +94,41 @@ int main(int argc, char** argv) {
     if (!a && !b) { HostIndex ix; FlattenOptions o; d = flatten(rle, &tsa, o, ix);
         if (!d) std::printf("n=%llu r=%llu sigma=%u pairs=%zu triples=%zu\n", (unsigned long long)ix.n, (unsigned long long)ix.r, ix.sigma, ix.pair.size(), ix.triple.size()); }
     std::printf("rc %d %d %d %d\n", a, b, c, d);
+    if (argc == 2 && std::string(argv[1]) == "garbage") {
+        // run-length BWTs and samples that satisfy what the C-ABI checks (non-empty maximal runs, samples
+        // <= n, distinct run-start samples) but belong to no text: flatten and the k-mer composition must
+        // stay inside their arrays
+        uint64_t x = 88172645463325252ull;
+        auto rnd = [&](uint64_t m) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x % m; };
+        int built = 0;
+        for (int trial = 0; trial < 300; ++trial) {
+            RawRle g; g.B = 2;
+            const uint64_t R = 1 + rnd(60), sigma = 2 + rnd(5);
+            for (uint64_t i = 0; i < R; ++i) {
+                uint8_t h = static_cast<uint8_t>(1 + rnd(sigma));
+                if (i && h == g.heads.back()) h = static_cast<uint8_t>(h % sigma + 1);
+                if (i && h == g.heads.back()) continue;
+                g.heads.push_back(h); g.lens.push_back(1 + rnd(9)); g.n += g.lens.back();
+            }
+            g.R = g.heads.size();
+            std::vector<uint64_t> ssa(g.R), esa(g.R);
+            std::vector<char> used(g.n + 1, 0);
+            bool ok = g.R <= g.n;
+            for (uint64_t i = 0; i < g.R && ok; ++i) {
+                uint64_t v = rnd(g.n + 1), tries = 0;
+                while (used[v ? v - 1 : g.n - 1] && tries++ < 4 * g.n) v = rnd(g.n + 1);
+                if (used[v ? v - 1 : g.n - 1]) { ok = false; break; }
+                used[v ? v - 1 : g.n - 1] = 1;
+                ssa[i] = v; esa[i] = rnd(g.n + 1);
+            }
+            if (!ok) continue;
+            RawTsa t; tsa_from_samples(g.n, g.R, ssa.data(), esa.data(), t);
+            HostIndex ix; FlattenOptions o; o.kmer_steps = 1 + static_cast<int>(rnd(4));
+            if (flatten(g, &t, o, ix) == 0) ++built;
+        }
+        std::printf("garbage built %d\n", built);
+        return 0;
+    }
     if (argc > 2) {   // native cache: write from the decoded files, read back; then read a (damaged) copy
         std::string cache = argv[2];
         if (!a && !b && !c && argc > 3) {
@@ -122,6 +157,9 @@ int main(int argc, char** argv) {
     p = subprocess.run([str(exe), good], capture_output=True, timeout=120)
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     assert b"n=30031 r=7573 sigma=5 pairs=16 triples=64" in p.stdout and b"rc 0 0 0 0" in p.stdout
+    p = subprocess.run([str(exe), "garbage"], capture_output=True, timeout=300)
+    assert p.returncode == 0 and b"garbage built" in p.stdout, p.stderr.decode()[-3000:]
+    assert int(p.stdout.split(b"garbage built")[1].split()[0]) > 100
     cache = tmp_path / "c.rbgpu"
     p = subprocess.run([str(exe), good, str(cache), "write"], capture_output=True, timeout=120)
     assert p.returncode == 0 and b"flat 0 0 1" in p.stdout, p.stderr.decode()[-3000:]
