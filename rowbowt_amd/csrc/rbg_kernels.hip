@@ -670,11 +670,7 @@ __global__ __launch_bounds__(256) void k_locate_fill(const DevIndex ix, const ui
                 const int s = pass * (kWave / kChunk) + lane / kChunk;
                 const int e = lane & (kChunk - 1);
                 const uint64_t t = t0 + e;
-#ifdef RBG_ABLATE_STORES  /* timing experiment only: keep the values live, drop the stores */
-                if (t < s_occ[wv][s] && s_val[wv][s][e] == static_cast<P>(~uint64_t(1))) locs[s_dst[wv][s] + t] = 1;
-#else
                 if (t < s_occ[wv][s]) locs[s_dst[wv][s] + t] = (t ? static_cast<uint64_t>(s_val[wv][s][e]) : s_first[wv][s]) - s_minus[wv][s];
-#endif
             }
             wave_lds_sync();
         }
