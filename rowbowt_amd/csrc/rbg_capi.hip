@@ -90,7 +90,8 @@ struct DevBuf {
 constexpr size_t kArenaAlign = 64 * 1024;
 inline size_t arena_round(size_t bytes) { return ((bytes ? bytes : 1) + kArenaAlign - 1) & ~(kArenaAlign - 1); }
 
-int dev_upload(rbg_index *ix, const void *src, size_t bytes, const void **dst) {
+// space for `bytes` in the arena (or its own allocation when the arena is full / absent)
+int dev_reserve(rbg_index *ix, size_t bytes, void **dst) {
     void *p = nullptr;
     const size_t alloc = arena_round(bytes);
     if (ix->arena && ix->arena_used + alloc <= ix->arena_bytes) {
@@ -101,6 +102,14 @@ int dev_upload(rbg_index *ix, const void *src, size_t bytes, const void **dst) {
         ix->allocs.push_back(p);
         ix->hbm_bytes += alloc;
     }
+    *dst = p;
+    return RBG_OK;
+}
+
+int dev_upload(rbg_index *ix, const void *src, size_t bytes, const void **dst) {
+    void *p = nullptr;
+    int rc = dev_reserve(ix, bytes, &p);
+    if (rc) return rc;
     if (bytes) HIP_TRY(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
     *dst = p;
     return RBG_OK;
@@ -132,90 +141,16 @@ size_t replica_bytes(const HostIndex &h) {
     return total + 16 * kArenaAlign;
 }
 
-// RankSlot table of one symbol (rbg_dev.h): slot b answers rank(i, c) for i in [b << shift, (b+1) << shift)
-template <typename P>
-void build_rank_slots(const SymTable &t, uint64_t n, std::vector<RankSlot> &slots, std::vector<uint32_t> &ord,
-                      uint64_t *overflow) {
-    const uint64_t nb = (n >> t.shift) + 2;
-    const uint64_t S = uint64_t(1) << t.shift;
-    slots.resize(nb);
-    ord.resize(nb);
-    uint64_t k = 0;  // # runs with start < bucket begin
-    for (uint64_t b = 0; b < nb; ++b) {
-        const uint64_t B0 = b << t.shift;
-        while (k < t.nruns && t.start[k] < B0) ++k;
-        ord[b] = static_cast<uint32_t>(k);
-        uint64_t r0 = 0, ext = 0, prev_is_c = 0;
-        if (k > 0) {
-            const uint64_t ps = t.start[k - 1], pl = t.cum[k] - t.cum[k - 1];  // cum[] has the sentinel
-            r0 = t.cum[k - 1] + std::min(pl, B0 - ps);
-            if (ps + pl > B0) ext = std::min(S, ps + pl - B0);
-            prev_is_c = ps + pl >= B0 ? 1 : 0;
-        }
-        uint32_t run[kSlotRuns] = {0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu};
-        uint64_t cnt = 0;
-        while (k + cnt < t.nruns && t.start[k + cnt] < B0 + S) {
-            if (cnt < static_cast<uint64_t>(kSlotRuns)) {
-                const uint64_t off = t.start[k + cnt] - B0;
-                const uint64_t len = std::min(t.cum[k + cnt + 1] - t.cum[k + cnt], B0 + S - t.start[k + cnt]);
-                run[cnt] = static_cast<uint32_t>(off | ((len - 1) << 8));
-            }
-            ++cnt;
-        }
-        uint32_t code = static_cast<uint32_t>(cnt);
-        if (cnt > static_cast<uint64_t>(kSlotRuns)) { code = kSlotOvf; ++*overflow; }
-        RankSlot &s = slots[b];
-        s.r0 = static_cast<uint32_t>(r0);
-        s.w1 = static_cast<uint32_t>(ext) | (code << 9) | (static_cast<uint32_t>(prev_is_c) << 12) | (run[0] << 16);
-        s.w2 = run[1] | (run[2] << 16);
-        s.w3 = run[3] | (static_cast<uint32_t>(r0 >> 32) << 16);  // flatten() guarantees n < 2^48
-    }
-}
-
-template <typename P>
-void build_phi_slots(const HostIndex &h, std::vector<PhiSlot<P>> &slots, std::vector<uint32_t> &ord, uint64_t *overflow) {
-    const uint64_t nb = (h.n >> h.phi_shift) + 2;
-    const uint64_t S = uint64_t(1) << h.phi_shift;
-    slots.resize(nb);
-    ord.resize(nb);
-    // D = base - pos (mod n); with no predecessor the reference uses the LAST record with
-    // delta = i + 1 (toehold_sa.hpp:59,65), i.e. pos = -1
-    auto D_of = [&](uint64_t j) { return (h.phi_base[j] + h.n - h.pred_pos[j]) % h.n; };
-    uint64_t k = 0;
-    for (uint64_t b = 0; b < nb; ++b) {
-        const uint64_t B0 = b << h.phi_shift;
-        while (k < h.r && h.pred_pos[k] < B0) ++k;
-        ord[b] = static_cast<uint32_t>(k);
-        PhiSlot<P> &s = slots[b];
-        s.dprev = static_cast<P>(k ? D_of(k - 1) : (h.phi_base[h.r - 1] + 1) % h.n);
-        uint64_t cnt = 0;
-        uint32_t off[2] = {0xFFu, 0xFFu};
-        uint64_t d[2] = {0, 0};
-        while (k + cnt < h.r && h.pred_pos[k + cnt] < B0 + S) {
-            if (cnt < 2) { off[cnt] = static_cast<uint32_t>(h.pred_pos[k + cnt] - B0); d[cnt] = D_of(k + cnt); }
-            ++cnt;
-        }
-        uint32_t code = static_cast<uint32_t>(cnt);
-        if (cnt > 2) { code = kPhiOvf; ++*overflow; }
-        s.d0 = static_cast<P>(d[0]);
-        s.d1 = static_cast<P>(d[1]);
-        s.meta = static_cast<P>(off[0] | (off[1] << 8) | (code << 16));
-    }
-}
-
 // one symbol (or k-mer) table -> its device record, in two halves so that the host-side array
 // building of many tables can run on worker threads while the uploads stay on the calling thread
 template <typename P>
 struct PreparedSym {
     std::vector<RunEnt<P>> ent;
     std::vector<P> samp;
-    std::vector<RankSlot> slots;
-    std::vector<uint32_t> ord;
-    uint64_t overflow = 0;
 };
 
 template <typename P>
-void prepare_sym(const SymTable &t, bool with_samples, uint64_t n, PreparedSym<P> &p) {
+void prepare_sym(const SymTable &t, bool with_samples, PreparedSym<P> &p) {
     p.ent.resize(t.nruns + 1);
     for (uint64_t k = 0; k <= t.nruns; ++k) {
         p.ent[k].start = static_cast<P>(t.start[k]);
@@ -225,21 +160,23 @@ void prepare_sym(const SymTable &t, bool with_samples, uint64_t n, PreparedSym<P
         p.samp.resize(t.nruns);
         for (uint64_t k = 0; k < t.nruns; ++k) p.samp[k] = static_cast<P>(t.samp[k]);
     }
-    build_rank_slots<P>(t, n, p.slots, p.ord, &p.overflow);
 }
 
+// upload the run list (+ samples); the RankSlot / ord tables are generated from it on the device
 template <typename P>
-int commit_sym(rbg_index *ix, const SymTable &t, bool with_samples, PreparedSym<P> &p, DevSym &d) {
+int commit_sym(rbg_index *ix, const SymTable &t, bool with_samples, PreparedSym<P> &p, DevSym &d, unsigned long long *d_overflow) {
     int rc = dev_upload(ix, p.ent.data(), p.ent.size() * sizeof(RunEnt<P>), &d.ent);
     if (rc) return rc;
     d.samp = nullptr;
     if (with_samples && (rc = dev_upload(ix, p.samp.data(), p.samp.size() * sizeof(P), &d.samp))) return rc;
-    if ((rc = dev_upload(ix, p.slots.data(), p.slots.size() * sizeof(RankSlot), &d.slots))) return rc;
-    const void *po = nullptr;
-    if ((rc = dev_upload(ix, p.ord.data(), p.ord.size() * sizeof(uint32_t), &po))) return rc;
-    d.ord = static_cast<const uint32_t *>(po);
-    ix->rank_slots += p.slots.size();
-    ix->rank_slots_overflow += p.overflow;
+    const uint64_t nb = (ix->host.n >> t.shift) + 2;
+    void *slots = nullptr, *ord = nullptr;
+    if ((rc = dev_reserve(ix, nb * sizeof(RankSlot), &slots)) || (rc = dev_reserve(ix, nb * sizeof(uint32_t), &ord))) return rc;
+    if (launch_build_rank_slots(sizeof(P), d.ent, t.nruns, ix->host.n, t.shift, slots, static_cast<uint32_t *>(ord), d_overflow, nullptr))
+        return RBG_ENODEV;
+    d.slots = slots;
+    d.ord = static_cast<const uint32_t *>(ord);
+    ix->rank_slots += nb;
     d.F = t.F;
     d.shift = t.shift;
     d.pad = 0;
@@ -247,7 +184,8 @@ int commit_sym(rbg_index *ix, const SymTable &t, bool with_samples, PreparedSym<
 }
 
 template <typename P>
-int upload_many(rbg_index *ix, const std::vector<SymTable> &tabs, bool with_samples, std::vector<DevSym> &recs) {
+int upload_many(rbg_index *ix, const std::vector<SymTable> &tabs, bool with_samples, std::vector<DevSym> &recs,
+                unsigned long long *d_overflow) {
     recs.resize(tabs.size());
     const size_t T = std::max<size_t>(1, std::min<size_t>(16, std::thread::hardware_concurrency()));
     for (size_t b = 0; b < tabs.size(); b += T) {
@@ -255,11 +193,11 @@ int upload_many(rbg_index *ix, const std::vector<SymTable> &tabs, bool with_samp
         std::vector<PreparedSym<P>> prep(e - b);
         std::vector<std::thread> workers;
         for (size_t i = b + 1; i < e; ++i)
-            workers.emplace_back([&, i] { prepare_sym<P>(tabs[i], with_samples, ix->host.n, prep[i - b]); });
-        prepare_sym<P>(tabs[b], with_samples, ix->host.n, prep[0]);
+            workers.emplace_back([&, i] { prepare_sym<P>(tabs[i], with_samples, prep[i - b]); });
+        prepare_sym<P>(tabs[b], with_samples, prep[0]);
         for (auto &w : workers) w.join();
         for (size_t i = b; i < e; ++i) {
-            int rc = commit_sym<P>(ix, tabs[i], with_samples, prep[i - b], recs[i]);
+            int rc = commit_sym<P>(ix, tabs[i], with_samples, prep[i - b], recs[i], d_overflow);
             if (rc) return rc;
             prep[i - b] = PreparedSym<P>();  // release before the next batch
         }
@@ -270,9 +208,13 @@ int upload_many(rbg_index *ix, const std::vector<SymTable> &tabs, bool with_samp
 template <typename P>
 int upload_tables(rbg_index *ix) {
     HostIndex &h = ix->host;
-    std::vector<DevSym> syms;
-    int rc = upload_many<P>(ix, h.sym, h.has_tsa, syms);
+    DevBuf d_ovf;  // [0] rank slots, [1] phi slots that overflow their inline entries
+    int rc = d_ovf.alloc(16);
     if (rc) return rc;
+    HIP_TRY(hipMemset(d_ovf.p, 0, 16));
+    unsigned long long *ovf = d_ovf.as<unsigned long long>();
+    std::vector<DevSym> syms;
+    if ((rc = upload_many<P>(ix, h.sym, h.has_tsa, syms, ovf))) return rc;
     const void *p = nullptr;
     rc = dev_upload(ix, syms.data(), syms.size() * sizeof(DevSym), &p);
     if (rc) return rc;
@@ -282,7 +224,7 @@ int upload_tables(rbg_index *ix) {
     if (!h.pair.empty()) {
         auto upload_set = [&](const std::vector<SymTable> &tabs, const DevSym **dst) -> int {
             std::vector<DevSym> recs;
-            int r2 = upload_many<P>(ix, tabs, h.has_tsa, recs);
+            int r2 = upload_many<P>(ix, tabs, h.has_tsa, recs, ovf);
             if (r2) return r2;
             const void *pp = nullptr;
             r2 = dev_upload(ix, recs.data(), recs.size() * sizeof(DevSym), &pp);
@@ -315,16 +257,20 @@ int upload_tables(rbg_index *ix) {
             rc = dev_upload(ix, pe.data(), pe.size() * sizeof(PhiEnt<P>), &ix->dev.phi_ent);
             if (rc) return rc;
         }
-        std::vector<PhiSlot<P>> slots;
-        std::vector<uint32_t> ord;
-        build_phi_slots<P>(h, slots, ord, &ix->phi_slots_overflow);
-        ix->phi_slots = slots.size();
-        rc = dev_upload(ix, slots.data(), slots.size() * sizeof(PhiSlot<P>), &ix->dev.phi_slots);
-        if (rc) return rc;
-        rc = dev_upload(ix, ord.data(), ord.size() * sizeof(uint32_t), &p);
-        if (rc) return rc;
-        ix->dev.phi_ord = static_cast<const uint32_t *>(p);
+        const uint64_t nb = (h.n >> h.phi_shift) + 2;
+        void *slots = nullptr, *ord = nullptr;
+        if ((rc = dev_reserve(ix, nb * sizeof(PhiSlot<P>), &slots)) || (rc = dev_reserve(ix, nb * sizeof(uint32_t), &ord))) return rc;
+        if (launch_build_phi_slots(sizeof(P), ix->dev.phi_ent, h.r, h.n, h.phi_shift, slots, static_cast<uint32_t *>(ord), ovf + 1, nullptr))
+            return RBG_ENODEV;
+        ix->phi_slots = nb;
+        ix->dev.phi_slots = slots;
+        ix->dev.phi_ord = static_cast<const uint32_t *>(ord);
     }
+    unsigned long long counts[2] = {0, 0};
+    HIP_TRY(hipDeviceSynchronize());  // every table is generated before the first query (and before d_ovf goes away)
+    HIP_TRY(hipMemcpy(counts, d_ovf.p, 16, hipMemcpyDeviceToHost));
+    ix->rank_slots_overflow = counts[0];
+    ix->phi_slots_overflow = counts[1];
     return RBG_OK;
 }
 

@@ -123,6 +123,11 @@ int launch_locate_fill(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t 
 size_t locate_order_ws_bytes(uint64_t N);
 int launch_locate_order(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t *k, uint64_t N, void *ws, size_t ws_bytes,
                         void *stream);
+// first-level slot tables from the uploaded run lists (pos_bytes = 4 or 8 selects RunEnt<P> / PhiEnt<P>)
+int launch_build_rank_slots(uint32_t pos_bytes, const void *ent, uint64_t nruns, uint64_t n, uint32_t shift, void *slots,
+                            uint32_t *ord, unsigned long long *overflow, void *stream);
+int launch_build_phi_slots(uint32_t pos_bytes, const void *ent, uint64_t r, uint64_t n, uint32_t shift, void *slots, uint32_t *ord,
+                           unsigned long long *overflow, void *stream);
 // packed reads (2 bits per symbol): pack the byte batch once, then search the packed form
 size_t pack_ws_bytes(uint64_t N, uint64_t total_bytes);
 int launch_pack_reads(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,

@@ -1301,6 +1301,149 @@ int launch_find_range_packed(const DevIndex &ix, const LaunchCfg &cfg, const voi
                      : launch_find_range_impl<false>(ix, cfg, seqs, off, N, lo, hi, ssamp, sel, nsel, stream);
 }
 
+// ---- slot tables built on the device ---------------------------------------------------------------
+// The first-level tables (one RankSlot per 2^shift BWT positions per symbol or k-mer, 57 GB for the
+// bench index) are a pure function of the run lists, which are uploaded anyway: building them here
+// instead of on the host and copying them over PCIe took "slot tables + upload" from 13 s to the time
+// of uploading the run lists.  One thread fills kBuildGroup consecutive buckets: one binary search,
+// then a linear walk.  The encoding is the one rank_in_slot / phi_step decode (rbg_dev.h).
+namespace {
+constexpr int kBuildGroup = 8;
+
+template <typename P>
+__global__ __launch_bounds__(256) void k_build_rank_slots(const RunEnt<P> *__restrict__ ent, const uint64_t nruns, const uint64_t n,
+                                                          const uint32_t shift, RankSlot *__restrict__ slots,
+                                                          uint32_t *__restrict__ ord, unsigned long long *__restrict__ overflow) {
+    const uint64_t nb = (n >> shift) + 2;
+    const uint64_t S = uint64_t(1) << shift;
+    const uint64_t ngroups = (nb + kBuildGroup - 1) / kBuildGroup;
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    unsigned long long novf = 0;
+    for (uint64_t g = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; g < ngroups; g += stride) {
+        const uint64_t b0 = g * kBuildGroup, b1 = b0 + kBuildGroup < nb ? b0 + kBuildGroup : nb;
+        // k = # runs with start < first row of the bucket (ent[nruns] is the sentinel {n, total})
+        uint64_t k = 0, z = nruns;
+        const uint64_t first = b0 << shift;
+        while (k < z) {
+            const uint64_t mid = k + ((z - k) >> 1);
+            if (static_cast<uint64_t>(ent[mid].start) < first) k = mid + 1; else z = mid;
+        }
+        for (uint64_t b = b0; b < b1; ++b) {
+            const uint64_t B0 = b << shift;
+            while (k < nruns && static_cast<uint64_t>(ent[k].start) < B0) ++k;
+            ord[b] = static_cast<uint32_t>(k);
+            uint64_t r0 = 0, ext = 0, prev_is_c = 0;
+            if (k > 0) {
+                const uint64_t ps = ent[k - 1].start, pc = ent[k - 1].cum;
+                const uint64_t pl = static_cast<uint64_t>(ent[k].cum) - pc;
+                r0 = pc + (pl < B0 - ps ? pl : B0 - ps);
+                if (ps + pl > B0) ext = ps + pl - B0 < S ? ps + pl - B0 : S;
+                prev_is_c = ps + pl >= B0 ? 1 : 0;
+            }
+            uint32_t run[kSlotRuns] = {0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu};
+            uint64_t cnt = 0;
+            while (k + cnt < nruns && static_cast<uint64_t>(ent[k + cnt].start) < B0 + S) {
+                if (cnt < static_cast<uint64_t>(kSlotRuns)) {
+                    const uint64_t st = ent[k + cnt].start;
+                    const uint64_t off = st - B0;
+                    const uint64_t full = static_cast<uint64_t>(ent[k + cnt + 1].cum) - static_cast<uint64_t>(ent[k + cnt].cum);
+                    const uint64_t len = full < B0 + S - st ? full : B0 + S - st;
+                    const uint32_t v = static_cast<uint32_t>(off | ((len - 1) << 8));
+                    if (cnt == 0) run[0] = v; else if (cnt == 1) run[1] = v; else if (cnt == 2) run[2] = v; else run[3] = v;
+                }
+                ++cnt;
+            }
+            uint32_t code = static_cast<uint32_t>(cnt);
+            if (cnt > static_cast<uint64_t>(kSlotRuns)) { code = kSlotOvf; ++novf; }
+            RankSlot s;
+            s.r0 = static_cast<uint32_t>(r0);
+            s.w1 = static_cast<uint32_t>(ext) | (code << 9) | (static_cast<uint32_t>(prev_is_c) << 12) | (run[0] << 16);
+            s.w2 = run[1] | (run[2] << 16);
+            s.w3 = run[3] | (static_cast<uint32_t>(r0 >> 32) << 16);  // flatten() guarantees n < 2^48
+            slots[b] = s;
+        }
+    }
+    novf = wave_sum(novf);
+    if ((threadIdx.x & (kWave - 1)) == 0 && novf) atomicAdd(overflow, novf);
+}
+
+template <typename P>
+__global__ __launch_bounds__(256) void k_build_phi_slots(const PhiEnt<P> *__restrict__ ent, const uint64_t r, const uint64_t n,
+                                                         const uint32_t shift, PhiSlot<P> *__restrict__ slots,
+                                                         uint32_t *__restrict__ ord, unsigned long long *__restrict__ overflow) {
+    const uint64_t nb = (n >> shift) + 2;
+    const uint64_t S = uint64_t(1) << shift;
+    const uint64_t ngroups = (nb + kBuildGroup - 1) / kBuildGroup;
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    // D = base - pos (mod n); with no predecessor the reference uses the LAST record with
+    // delta = i + 1 (toehold_sa.hpp:59,65), i.e. pos = -1
+    auto D_of = [&](uint64_t j) { return (static_cast<uint64_t>(ent[j].base) + n - static_cast<uint64_t>(ent[j].pos)) % n; };
+    unsigned long long novf = 0;
+    for (uint64_t g = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; g < ngroups; g += stride) {
+        const uint64_t b0 = g * kBuildGroup, b1 = b0 + kBuildGroup < nb ? b0 + kBuildGroup : nb;
+        uint64_t k = 0, z = r;
+        const uint64_t first = b0 << shift;
+        while (k < z) {
+            const uint64_t mid = k + ((z - k) >> 1);
+            if (static_cast<uint64_t>(ent[mid].pos) < first) k = mid + 1; else z = mid;
+        }
+        for (uint64_t b = b0; b < b1; ++b) {
+            const uint64_t B0 = b << shift;
+            while (k < r && static_cast<uint64_t>(ent[k].pos) < B0) ++k;
+            ord[b] = static_cast<uint32_t>(k);
+            PhiSlot<P> s;
+            s.dprev = static_cast<P>(k ? D_of(k - 1) : (static_cast<uint64_t>(ent[r - 1].base) + 1) % n);
+            uint64_t cnt = 0;
+            uint32_t off0 = 0xFFu, off1 = 0xFFu;
+            uint64_t d0 = 0, d1 = 0;
+            while (k + cnt < r && static_cast<uint64_t>(ent[k + cnt].pos) < B0 + S) {
+                if (cnt == 0) { off0 = static_cast<uint32_t>(static_cast<uint64_t>(ent[k].pos) - B0); d0 = D_of(k); }
+                else if (cnt == 1) { off1 = static_cast<uint32_t>(static_cast<uint64_t>(ent[k + 1].pos) - B0); d1 = D_of(k + 1); }
+                ++cnt;
+            }
+            uint32_t code = static_cast<uint32_t>(cnt);
+            if (cnt > 2) { code = kPhiOvf; ++novf; }
+            s.d0 = static_cast<P>(d0);
+            s.d1 = static_cast<P>(d1);
+            s.meta = static_cast<P>(off0 | (off1 << 8) | (code << 16));
+            slots[b] = s;
+        }
+    }
+    novf = wave_sum(novf);
+    if ((threadIdx.x & (kWave - 1)) == 0 && novf) atomicAdd(overflow, novf);
+}
+}  // namespace
+
+int launch_build_rank_slots(uint32_t pos_bytes, const void *ent, uint64_t nruns, uint64_t n, uint32_t shift, void *slots,
+                            uint32_t *ord, unsigned long long *overflow, void *stream) {
+    const uint64_t nb = (n >> shift) + 2;
+    const uint64_t groups = (nb + kBuildGroup - 1) / kBuildGroup;
+    const int grid = static_cast<int>(std::min<uint64_t>((groups + 255) / 256, 256ull * 64));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (pos_bytes == 4)
+        hipLaunchKernelGGL((k_build_rank_slots<uint32_t>), dim3(grid), dim3(256), 0, st, static_cast<const RunEnt<uint32_t> *>(ent), nruns, n, shift,
+                           static_cast<RankSlot *>(slots), ord, overflow);
+    else
+        hipLaunchKernelGGL((k_build_rank_slots<uint64_t>), dim3(grid), dim3(256), 0, st, static_cast<const RunEnt<uint64_t> *>(ent), nruns, n, shift,
+                           static_cast<RankSlot *>(slots), ord, overflow);
+    return static_cast<int>(hipGetLastError());
+}
+
+int launch_build_phi_slots(uint32_t pos_bytes, const void *ent, uint64_t r, uint64_t n, uint32_t shift, void *slots, uint32_t *ord,
+                           unsigned long long *overflow, void *stream) {
+    const uint64_t nb = (n >> shift) + 2;
+    const uint64_t groups = (nb + kBuildGroup - 1) / kBuildGroup;
+    const int grid = static_cast<int>(std::min<uint64_t>((groups + 255) / 256, 256ull * 64));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (pos_bytes == 4)
+        hipLaunchKernelGGL((k_build_phi_slots<uint32_t>), dim3(grid), dim3(256), 0, st, static_cast<const PhiEnt<uint32_t> *>(ent), r, n, shift,
+                           static_cast<PhiSlot<uint32_t> *>(slots), ord, overflow);
+    else
+        hipLaunchKernelGGL((k_build_phi_slots<uint64_t>), dim3(grid), dim3(256), 0, st, static_cast<const PhiEnt<uint64_t> *>(ent), r, n, shift,
+                           static_cast<PhiSlot<uint64_t> *>(slots), ord, overflow);
+    return static_cast<int>(hipGetLastError());
+}
+
 // ---- ftab construction: search every word of k major symbols with the step kernel itself ---------
 namespace {
 __global__ __launch_bounds__(256) void k_ftab_words(const DevIndex ix, const uint32_t k, const uint64_t W, uint8_t *__restrict__ seqs,
