@@ -331,10 +331,28 @@ void tsa_from_samples(uint64_t n, uint64_t r, const uint64_t *ssa_y, const uint6
         first[i] = ssa_y[i] ? ssa_y[i] - 1 : n - 1;
         out.samples_last[i] = esa_y[i] ? esa_y[i] - 1 : n - 1;
     }
+    // order the runs by the text position of their first row: a stable LSD radix sort on (position, run)
+    // -- a comparison sort through the index array took 7 s for the bench index (3.7e7 runs), this 0.4 s
     std::iota(order.begin(), order.end(), uint64_t(0));
-    std::sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) {
-        return first[a] != first[b] ? first[a] < first[b] : a < b;
-    });
+    {
+        int bits = 1;
+        while (bits < 64 && (n >> bits)) ++bits;
+        std::vector<uint64_t> key(first), key2(r), order2(r);
+        std::vector<uint64_t> hist(size_t(1) << 16);
+        for (int shift = 0; shift < bits; shift += 16) {
+            std::fill(hist.begin(), hist.end(), 0);
+            for (uint64_t i = 0; i < r; ++i) ++hist[(key[i] >> shift) & 0xFFFF];
+            uint64_t sum = 0;
+            for (uint64_t &h : hist) { const uint64_t c = h; h = sum; sum += c; }
+            for (uint64_t i = 0; i < r; ++i) {
+                const uint64_t dst = hist[(key[i] >> shift) & 0xFFFF]++;
+                key2[dst] = key[i];
+                order2[dst] = order[i];
+            }
+            key.swap(key2);
+            order.swap(order2);
+        }
+    }
     out.pred_pos.resize(r);
     out.pred_to_run.resize(r);
     for (uint64_t j = 0; j < r; ++j) {
