@@ -643,18 +643,38 @@ struct Segmentation {          // row-ordered cover of [0,n): segment g = [start
 };
 constexpr uint32_t kNoId = 0xFFFFFFFFu;
 
+// `next` (optional): the row-ordered segmentation by depth-(d+1) id, for composing the level after this one.
+// The pieces a worker finds are already in row order within its symbol, so G_{d+1} is an M-way merge of M
+// lists (a heap merge over all n_ids * M tables took as long as the composition itself).
 int compose(const HostIndex &ix, const std::vector<uint32_t> &major_slot, const Segmentation &G, uint32_t depth,
             uint32_t n_ids, const std::vector<SymTable> &prev, bool with_samples, const FlattenOptions &opt,
-            std::vector<SymTable> &out) {
+            std::vector<SymTable> &out, Segmentation *next) {
     const uint32_t M = static_cast<uint32_t>(major_slot.size());
     out.assign(static_cast<size_t>(n_ids) * M, SymTable());
-    // one worker per symbol: worker m only touches the tables (id, m)
-    std::vector<int> rcs(M, RBG_OK);
-    auto work = [&](uint32_t m) {
+    // The runs of symbol m are cut into C chunks at run boundaries; worker (m, c) walks its chunk and keeps
+    // what it finds per depth-d id with counts relative to the chunk (a piece never spans two c-runs, so
+    // chunks need no stitching); a second step per symbol turns them into the tables (id, m).
+    const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
+    const uint32_t C = std::max(1u, std::min(8u, hw / std::max(1u, M)));
+    struct Piece { uint64_t start, len, samp; uint32_t id; };
+    struct Part {
+        std::vector<std::vector<uint64_t>> start, cum, samp;  // per id
+        std::vector<uint64_t> total;                          // rows per id in this chunk
+        std::vector<Piece> rows;                              // the same pieces in row order (only for `next`)
+        int rc = RBG_OK;
+    };
+    std::vector<Part> parts(static_cast<size_t>(M) * C);
+    auto walk = [&](uint32_t m, uint32_t c) {
+        Part &P = parts[static_cast<size_t>(m) * C + c];
+        P.start.assign(n_ids, {}); P.cum.assign(n_ids, {}); P.samp.assign(n_ids, {}); P.total.assign(n_ids, 0);
         const SymTable &tc = ix.sym[major_slot[m]];
-        std::vector<uint64_t> seen(n_ids, 0);
-        uint64_t g = 0;
-        for (uint64_t k = 0; k < tc.nruns; ++k) {
+        const uint64_t k0 = tc.nruns * c / C, k1 = tc.nruns * (c + 1) / C;
+        if (k0 >= k1) return;
+        // first segment of G that can overlap the LF image of run k0
+        const uint64_t Q0 = tc.F + tc.cum[k0];
+        uint64_t g = static_cast<uint64_t>(std::upper_bound(G.start.begin(), G.start.end(), Q0) - G.start.begin());
+        g = g ? g - 1 : 0;
+        for (uint64_t k = k0; k < k1; ++k) {
             const uint64_t s = tc.start[k], len = tc.cum[k + 1] - tc.cum[k];
             const uint64_t Q = tc.F + tc.cum[k];  // LF of row s (rowbowt.hpp:65-68)
             uint64_t q = Q;
@@ -663,29 +683,58 @@ int compose(const HostIndex &ix, const std::vector<uint32_t> &major_slot, const 
                 const uint64_t qend = std::min(Q + len, G.start[g + 1]);
                 const uint32_t id = G.id[g];
                 if (id != kNoId) {
-                    SymTable &t = out[static_cast<size_t>(id) * M + m];
-                    t.start.push_back(s + (q - Q));
-                    t.cum.push_back(seen[id]);
-                    seen[id] += qend - q;
+                    P.start[id].push_back(s + (q - Q));
+                    P.cum[id].push_back(P.total[id]);
+                    P.total[id] += qend - q;
                     if (with_samples) {
                         uint64_t v;
                         if (qend == G.start[g + 1]) v = G.samp[g];
                         else {
-                            if (tc.samp[k] < depth) { rcs[m] = RBG_EFORMAT; return; }  // would need the terminator inside the k-mer
+                            if (tc.samp[k] < depth) { P.rc = RBG_EFORMAT; return; }  // would need the terminator inside the k-mer
                             v = tc.samp[k] - depth;
                         }
-                        t.samp.push_back(v);
+                        P.samp[id].push_back(v);
                     }
+                    if (next) P.rows.push_back(Piece{s + (q - Q), qend - q, with_samples ? P.samp[id].back() : 0, id * M + m});
                 }
                 q = qend;
             }
         }
+    };
+    {
+        std::vector<std::thread> workers;
+        for (uint32_t m = 0; m < M; ++m)
+            for (uint32_t c = 0; c < C; ++c)
+                if (m || c) workers.emplace_back(walk, m, c);
+        walk(0, 0);
+        for (auto &w : workers) w.join();
+    }
+    std::vector<int> rcs(M, RBG_OK);
+    auto work = [&](uint32_t m) {
+        const SymTable &tc = ix.sym[major_slot[m]];
+        for (uint32_t c = 0; c < C; ++c)
+            if (parts[static_cast<size_t>(m) * C + c].rc) { rcs[m] = parts[static_cast<size_t>(m) * C + c].rc; return; }
         for (uint32_t id = 0; id < n_ids; ++id) {
             SymTable &t = out[static_cast<size_t>(id) * M + m];
+            size_t nr = 0;
+            for (uint32_t c = 0; c < C; ++c) nr += parts[static_cast<size_t>(m) * C + c].start[id].size();
+            t.start.reserve(nr + 1); t.cum.reserve(nr + 1);
+            if (with_samples) t.samp.reserve(nr);
+            uint64_t base = 0;
+            for (uint32_t c = 0; c < C; ++c) {
+                Part &P = parts[static_cast<size_t>(m) * C + c];
+                t.start.insert(t.start.end(), P.start[id].begin(), P.start[id].end());
+                for (uint64_t v : P.cum[id]) t.cum.push_back(base + v);
+                if (with_samples) t.samp.insert(t.samp.end(), P.samp[id].begin(), P.samp[id].end());
+                base += P.total[id];
+                std::vector<uint64_t>().swap(P.start[id]);
+                std::vector<uint64_t>().swap(P.cum[id]);
+                std::vector<uint64_t>().swap(P.samp[id]);
+            }
             const SymTable &tp = prev[id];
             t.byte = tc.byte;
             t.nruns = t.start.size();
-            t.total = seen[id];
+            t.total = base;
             t.start.push_back(ix.n);
             t.cum.push_back(t.total);
             // F_{d+1}[id, c] = F_d[id] + rank_d(F[c], id): rows of the id-interval followed by a smaller symbol
@@ -704,42 +753,44 @@ int compose(const HostIndex &ix, const std::vector<uint32_t> &major_slot, const 
     for (auto &w : workers) w.join();
     for (int rc : rcs)
         if (rc) return rc;
-    return RBG_OK;
-}
-
-// row-ordered segmentation from a set of tables (their runs are disjoint); uncovered rows get kNoId
-void segmentation_of(const std::vector<SymTable> &tabs, uint64_t n, bool with_samples, Segmentation &G) {
-    G.start.clear(); G.id.clear(); G.samp.clear();
-    uint64_t total = 0;
-    for (const SymTable &t : tabs) total += t.nruns;
-    G.start.reserve(2 * total + 2); G.id.reserve(2 * total + 2);
-    if (with_samples) G.samp.reserve(2 * total + 2);
-    // k-way merge of the tables' (already sorted) run lists by start row
-    using Item = std::pair<uint64_t, uint32_t>;  // (start, table)
-    std::priority_queue<Item, std::vector<Item>, std::greater<Item>> heap;
-    std::vector<uint64_t> cur(tabs.size(), 0);
-    for (size_t i = 0; i < tabs.size(); ++i)
-        if (tabs[i].nruns) heap.push(Item(tabs[i].start[0], static_cast<uint32_t>(i)));
-    uint64_t pos = 0;
-    while (!heap.empty()) {
-        const Item it = heap.top();
-        heap.pop();
-        const SymTable &t = tabs[it.second];
-        const uint64_t k = cur[it.second]++;
-        if (cur[it.second] < t.nruns) heap.push(Item(t.start[cur[it.second]], it.second));
-        if (it.first > pos) {  // gap: rows whose context leaves the major alphabet
-            G.start.push_back(pos); G.id.push_back(kNoId);
-            if (with_samples) G.samp.push_back(0);
+    if (next) {
+        size_t total = 0;
+        for (const Part &P : parts) total += P.rows.size();
+        next->start.clear(); next->id.clear(); next->samp.clear();
+        next->start.reserve(2 * total + 2); next->id.reserve(2 * total + 2);
+        if (with_samples) next->samp.reserve(2 * total + 2);
+        // cursor per symbol over its chunks' lists (chunk lists of one symbol follow each other in row order)
+        std::vector<uint32_t> chunk(M, 0);
+        std::vector<size_t> at(M, 0);
+        auto head = [&](uint32_t m) -> const Piece * {
+            while (chunk[m] < C && at[m] >= parts[static_cast<size_t>(m) * C + chunk[m]].rows.size()) { ++chunk[m]; at[m] = 0; }
+            return chunk[m] < C ? &parts[static_cast<size_t>(m) * C + chunk[m]].rows[at[m]] : nullptr;
+        };
+        uint64_t pos = 0;
+        while (true) {
+            const Piece *best = nullptr;
+            uint32_t bm = 0;
+            for (uint32_t m = 0; m < M; ++m) {
+                const Piece *h = head(m);
+                if (h && (!best || h->start < best->start)) { best = h; bm = m; }
+            }
+            if (!best) break;
+            if (best->start > pos) {  // gap: rows whose context leaves the major alphabet
+                next->start.push_back(pos); next->id.push_back(kNoId);
+                if (with_samples) next->samp.push_back(0);
+            }
+            next->start.push_back(best->start); next->id.push_back(best->id);
+            if (with_samples) next->samp.push_back(best->samp);
+            pos = best->start + best->len;
+            ++at[bm];
         }
-        G.start.push_back(it.first); G.id.push_back(it.second);
-        if (with_samples) G.samp.push_back(t.samp[k]);
-        pos = it.first + (t.cum[k + 1] - t.cum[k]);
+        if (pos < ix.n) {
+            next->start.push_back(pos); next->id.push_back(kNoId);
+            if (with_samples) next->samp.push_back(0);
+        }
+        next->start.push_back(ix.n);
     }
-    if (pos < n) {
-        G.start.push_back(pos); G.id.push_back(kNoId);
-        if (with_samples) G.samp.push_back(0);
-    }
-    G.start.push_back(n);
+    return RBG_OK;
 }
 
 int build_kmer_tables(HostIndex &out, const RawTsa *tsa, const FlattenOptions &opt) {
@@ -776,16 +827,16 @@ int build_kmer_tables(HostIndex &out, const RawTsa *tsa, const FlattenOptions &o
     if (tsa) G.samp = tsa->samples_last;
     std::vector<SymTable> depth1(M);
     for (uint32_t m = 0; m < M; ++m) depth1[m] = out.sym[order[m]];
-    int rc = compose(out, order, G, 1, M, depth1, tsa != nullptr, opt, out.pair);
+    Segmentation G2, G3;
+    int rc = compose(out, order, G, 1, M, depth1, tsa != nullptr, opt, out.pair, opt.kmer_steps >= 3 ? &G2 : nullptr);
     if (rc) return rc;
+    Segmentation().start.swap(G.start);
     if (opt.kmer_steps >= 3) {
-        segmentation_of(out.pair, out.n, tsa != nullptr, G);
-        rc = compose(out, order, G, 2, M * M, out.pair, tsa != nullptr, opt, out.triple);
+        rc = compose(out, order, G2, 2, M * M, out.pair, tsa != nullptr, opt, out.triple, opt.kmer_steps >= 4 ? &G3 : nullptr);
         if (rc) return rc;
     }
     if (opt.kmer_steps >= 4) {
-        segmentation_of(out.triple, out.n, tsa != nullptr, G);
-        rc = compose(out, order, G, 3, M * M * M, out.triple, tsa != nullptr, opt, out.quad);
+        rc = compose(out, order, G3, 3, M * M * M, out.triple, tsa != nullptr, opt, out.quad, nullptr);
         if (rc) return rc;
     }
     return RBG_OK;
