@@ -162,6 +162,7 @@ constexpr int kOff2 = kLdsSyms;
 constexpr int kOff3 = kOff2 + kMaxMajor * kMaxMajor;
 constexpr int kOff4 = kOff3 + kMaxMajor * kMaxMajor * kMaxMajor;
 constexpr int kTabMax = kOff4 + kMaxMajor * kMaxMajor * kMaxMajor * kMaxMajor;
+constexpr uint32_t kHbmRec = 0x80000000u;  // record reference: symbol slot whose DevSym lives in HBM (ix.syms), not in s_tab
 
 __device__ __forceinline__ void stage_tables(const DevIndex &ix, DevSym *s_tab, uint8_t *s_lut, uint8_t *s_lut2) {
     const uint32_t M = ix.nmajor;
@@ -209,11 +210,18 @@ __global__ __launch_bounds__(256, 8) void k_find_range(const DevIndex ix, const 
         // (bwt[hi] is a random symbol), so the two gathers of a re-sample (run ordinal, sample) are
         // deferred until a later step or the end of the read actually needs the value.
         bool pend = false;
-        const void *pend_samp = nullptr;
-        const uint32_t *pend_ord = nullptr;
+        uint32_t pend_tab = 0;   // which record to re-sample from: s_tab index, or kHbmRec | symbol slot
         uint64_t pend_b = 0;
-        int64_t pend_j = 0;  // ordinal offset (slot path) or absolute ordinal (overflow path)
+        uint32_t pend_v = 0;     // runs before the position inside the bucket (slot path) or the absolute ordinal (overflow path)
         bool pend_abs = false;
+        // the two gathers of a deferred re-sample: run ordinal from `ord`, then the run's sample
+        auto resample = [&]() -> uint64_t {
+            const DevSym *rec = (pend_tab & kHbmRec) ? ix.syms + (pend_tab & ~kHbmRec) : s_tab + pend_tab;
+            const uint32_t *ord = rec->ord;
+            const void *samp = rec->samp;
+            const uint64_t j = pend_abs ? static_cast<uint64_t>(pend_v) : static_cast<uint64_t>(ord[pend_b]) + pend_v - 1;
+            return static_cast<uint64_t>(static_cast<const P *>(samp)[j]);
+        };
         ByteCursor rd{reinterpret_cast<const uint4 *>(seqs), ~uint64_t(0), make_uint4(0, 0, 0, 0)};
         bool alive = true;
         // ftab (rowbowt.hpp:124-125, :745-758): while the range is still wide a step costs two slot
@@ -237,7 +245,7 @@ __global__ __launch_bounds__(256, 8) void k_find_range(const DevIndex ix, const 
             }
         }
         // one LF step (or several nested ones) through the record S; false = range emptied
-        auto step = [&](const DevSym &S, uint32_t adv) -> bool {
+        auto step = [&](const DevSym &S, uint32_t adv, uint32_t tab) -> bool {
             RankAux q;
             uint64_t c_before, c_upto, bh;
             rank_pair<P>(S, lo, hi + 1, &c_before, &c_upto, &bh, &q);      // rowbowt.hpp:79,83
@@ -248,19 +256,14 @@ __global__ __launch_bounds__(256, 8) void k_find_range(const DevIndex ix, const 
                 // nested step), or the last run starting before hi ends before hi and its last row
                 // is select(rank(hi,c)-1,c), whose run-end sample is samples_last_[run] (resp. SA-adv).
                 if (q.inside) {
-                    if (pend) {
-                        const uint64_t j = pend_abs ? static_cast<uint64_t>(pend_j) : static_cast<uint64_t>(pend_ord[pend_b]) + pend_j;
-                        k = static_cast<uint64_t>(static_cast<const P *>(pend_samp)[j]);
-                        pend = false;
-                    }
+                    if (pend) { k = resample(); pend = false; }
                     k = k - adv;
                 } else {
                     pend = true;
-                    pend_samp = S.samp;
-                    pend_ord = S.ord;
+                    pend_tab = tab;
                     pend_b = bh;
                     pend_abs = q.ovf;
-                    pend_j = q.ovf ? q.pred : static_cast<int64_t>(q.nbefore) - 1;
+                    pend_v = q.ovf ? static_cast<uint32_t>(q.pred) : q.nbefore;
                 }
             }
             lo = S.F + c_before;           // rowbowt.hpp:86
@@ -299,21 +302,18 @@ __global__ __launch_bounds__(256, 8) void k_find_range(const DevIndex ix, const 
             if (adv == 1) {
                 const uint32_t slot = s_lut[c];
                 if (slot == 0xFFu) { alive = false; break; }  // symbol absent: f_[c] >= f_[c+1], rowbowt.hpp:76
-                if (slot < static_cast<uint32_t>(kLdsSyms)) { const DevSym Sc = s_tab[slot]; ok = step(Sc, 1u); }
-                else ok = step(ix.syms[slot], 1u);  // rare symbols: record read from HBM field by field
+                if (slot < static_cast<uint32_t>(kLdsSyms)) { const DevSym Sc = s_tab[slot]; ok = step(Sc, 1u, slot); }
+                else ok = step(ix.syms[slot], 1u, kHbmRec | slot);  // rare symbols: record read from HBM field by field
             } else {
                 // copy the 64-byte record with four wide LDS reads: reading it field by field makes
                 // every lane hit the same two banks (records are 16 dwords apart)
                 const DevSym Sc = s_tab[idx];
-                ok = step(Sc, adv);
+                ok = step(Sc, adv, idx);
             }
             if (!ok) { alive = false; break; }
             p -= adv - 1;                  // the left neighbours are consumed too
         }
-        if (TOEHOLD && alive && pend) {
-            const uint64_t j = pend_abs ? static_cast<uint64_t>(pend_j) : static_cast<uint64_t>(pend_ord[pend_b]) + pend_j;
-            k = static_cast<uint64_t>(static_cast<const P *>(pend_samp)[j]);
-        }
+        if (TOEHOLD && alive && pend) k = resample();
         if (!alive) { lo = 1; hi = 0; k = 0; }  // {1,0}; LFData::clear rowbowt.hpp:153-159
         lo_out[i] = lo;
         hi_out[i] = hi;
@@ -453,11 +453,17 @@ __global__ __launch_bounds__(256, 8) void k_find_range_packed(const DevIndex ix,
         uint64_t lo = 0, hi = ix.n - 1;    // full_range(), rowbowt.hpp:115-118
         uint64_t k = TOEHOLD ? ix.last_run_sample : 0;
         bool pend = false;                 // deferred toehold re-sample, as in k_find_range
-        const void *pend_samp = nullptr;
-        const uint32_t *pend_ord = nullptr;
+        uint32_t pend_tab = 0;
         uint64_t pend_b = 0;
-        int64_t pend_j = 0;
+        uint32_t pend_v = 0;
         bool pend_abs = false;
+        auto resample = [&]() -> uint64_t {
+            const DevSym *rec = (pend_tab & kHbmRec) ? ix.syms + (pend_tab & ~kHbmRec) : s_tab + pend_tab;
+            const uint32_t *ord = rec->ord;
+            const void *samp = rec->samp;
+            const uint64_t j = pend_abs ? static_cast<uint64_t>(pend_v) : static_cast<uint64_t>(ord[pend_b]) + pend_v - 1;
+            return static_cast<uint64_t>(static_cast<const P *>(samp)[j]);
+        };
         BitStream bs{chunks + mt.x, make_uint4(0, 0, 0, 0), 4u, 0u, 0ull};
         bool alive = true;
         if (ix.ftab_k && r >= ix.ftab_k) {  // the first ftab_k symbols are the low 2*ftab_k bits
@@ -467,7 +473,7 @@ __global__ __launch_bounds__(256, 8) void k_find_range_packed(const DevIndex ix,
             r -= ix.ftab_k;
             if (hi < lo) { alive = false; r = 0; }
         }
-        auto step = [&](const DevSym &S, uint32_t adv) -> bool {
+        auto step = [&](const DevSym &S, uint32_t adv, uint32_t tab) -> bool {
             RankAux q;
             uint64_t c_before, c_upto, bh;
             rank_pair<P>(S, lo, hi + 1, &c_before, &c_upto, &bh, &q);      // rowbowt.hpp:79,83
@@ -475,19 +481,14 @@ __global__ __launch_bounds__(256, 8) void k_find_range_packed(const DevIndex ix,
             if (c_inside == 0) return false;                               // rowbowt.hpp:85
             if (TOEHOLD) {                                                 // LF_w_loc, rowbowt.hpp:559-566
                 if (q.inside) {
-                    if (pend) {
-                        const uint64_t j = pend_abs ? static_cast<uint64_t>(pend_j) : static_cast<uint64_t>(pend_ord[pend_b]) + pend_j;
-                        k = static_cast<uint64_t>(static_cast<const P *>(pend_samp)[j]);
-                        pend = false;
-                    }
+                    if (pend) { k = resample(); pend = false; }
                     k = k - adv;
                 } else {
                     pend = true;
-                    pend_samp = S.samp;
-                    pend_ord = S.ord;
+                    pend_tab = tab;
                     pend_b = bh;
                     pend_abs = q.ovf;
-                    pend_j = q.ovf ? q.pred : static_cast<int64_t>(q.nbefore) - 1;
+                    pend_v = q.ovf ? static_cast<uint32_t>(q.pred) : q.nbefore;
                 }
             }
             lo = S.F + c_before;           // rowbowt.hpp:86
@@ -500,20 +501,17 @@ __global__ __launch_bounds__(256, 8) void k_find_range_packed(const DevIndex ix,
             bool ok;
             if (a == 1) {
                 const uint32_t slot = s_mslot[v];
-                if (slot < static_cast<uint32_t>(kLdsSyms)) { const DevSym Sc = s_tab[slot]; ok = step(Sc, 1u); }
-                else ok = step(ix.syms[slot], 1u);
+                if (slot < static_cast<uint32_t>(kLdsSyms)) { const DevSym Sc = s_tab[slot]; ok = step(Sc, 1u, slot); }
+                else ok = step(ix.syms[slot], 1u, kHbmRec | slot);
             } else {
                 const uint32_t idx = (a == 4 ? kOff4 : a == 3 ? kOff3 : kOff2) + v;
                 const DevSym Sc = s_tab[idx];
-                ok = step(Sc, a);
+                ok = step(Sc, a, idx);
             }
             if (!ok) { alive = false; break; }
             r -= a;
         }
-        if (TOEHOLD && alive && pend) {
-            const uint64_t j = pend_abs ? static_cast<uint64_t>(pend_j) : static_cast<uint64_t>(pend_ord[pend_b]) + pend_j;
-            k = static_cast<uint64_t>(static_cast<const P *>(pend_samp)[j]);
-        }
+        if (TOEHOLD && alive && pend) k = resample();
         if (!alive) { lo = 1; hi = 0; k = 0; }
         lo_out[i] = lo;
         hi_out[i] = hi;
