@@ -384,12 +384,13 @@ int upload(rbg_index *ix) {
         // the table plus the scratch of building it (word bytes, offsets, three result arrays)
         if (words * (32.0 + fk + 40.0) < 0.5 * static_cast<double>(free_b) && words < 4.0e9) {
             const uint64_t W = static_cast<uint64_t>(words);
+            const size_t entry = h.pos_bytes == 4 ? 16 : 32;
             void *tab = nullptr;
-            HIP_TRY(hipMalloc(&tab, W * 32));
+            HIP_TRY(hipMalloc(&tab, W * entry));
             ix->allocs.push_back(tab);
-            ix->hbm_bytes += W * 32;
-            if (launch_build_ftab(d, ix->cfg, static_cast<uint32_t>(fk), static_cast<unsigned long long *>(tab), nullptr)) return RBG_ENODEV;
-            d.ftab = static_cast<const unsigned long long *>(tab);
+            ix->hbm_bytes += W * entry;
+            if (launch_build_ftab(d, ix->cfg, static_cast<uint32_t>(fk), tab, nullptr)) return RBG_ENODEV;
+            d.ftab = tab;
             d.ftab_k = static_cast<uint32_t>(fk);
             HIP_TRY(hipMemset(d.counters, 0, 4 * sizeof(uint64_t)));  // the build's own searches are not user queries
         }

@@ -98,9 +98,9 @@ struct DevIndex {
     uint32_t kmer_steps;    // 1 .. 4
     // ftab (reference: RowBowt::search_ftab, rowbowt.hpp:745-758; result-neutral by construction,
     // :124-125): for every word of ftab_k major symbols the state after searching it -- {lo, hi,
-    // toehold, 0} as 4 x u64 -- indexed by the word read as a base-nmajor number, most significant
+    // toehold, 0} (4 x u32 at 4-byte positions, else 4 x u64) -- indexed by the word read as a base-nmajor number, most significant
     // digit = leftmost symbol.  Built on the GPU at load time with k_find_range itself.  0 = none.
-    const unsigned long long *ftab;
+    const void *ftab;       // 16-byte entries at 4-byte positions, 32-byte entries at 8-byte positions
     uint32_t ftab_k;
     uint32_t pad3;
 };
@@ -155,7 +155,7 @@ int launch_find_range_markers_fill(const DevIndex &ix, const LaunchCfg &cfg, con
 int launch_lf(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t *lo, const uint64_t *hi, const uint8_t *sym,
               uint64_t N, uint64_t *lo_out, uint64_t *hi_out, void *stream);
 // fills ix.ftab-shaped table `tab` (nmajor^k entries x 4 u64) by searching every k-symbol word
-int launch_build_ftab(const DevIndex &ix, const LaunchCfg &cfg, uint32_t k, unsigned long long *tab, void *stream);
+int launch_build_ftab(const DevIndex &ix, const LaunchCfg &cfg, uint32_t k, void *tab, void *stream);
 int launch_count_from_ranges(const uint64_t *lo, const uint64_t *hi, uint64_t N, uint64_t *count, void *stream);
 
 }  // namespace rbg

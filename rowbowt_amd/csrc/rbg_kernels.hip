@@ -181,6 +181,24 @@ __device__ __forceinline__ void stage_tables(const DevIndex &ix, DevSym *s_tab, 
     __syncthreads();
 }
 
+// ftab entry: the state {lo, hi, toehold} after the word.  At 4-byte positions it is 16 bytes (one request)
+// {lo, hi, toehold, 0}: a toehold of 2^64 - 1 (the word's last row is text position 0) is stored as
+// 0xFFFFFFFF, and a word whose toehold fits neither is stored as {2, 0}: "search it step by step".  At
+// 8-byte positions it is 4 x u64.  Returns false for the step-by-step marker.
+template <typename P>
+__device__ __forceinline__ bool ftab_lookup(const DevIndex &ix, uint64_t idx, uint64_t &lo, uint64_t &hi, uint64_t &k) {
+    if constexpr (sizeof(P) == 4) {
+        const uint4 e = static_cast<const uint4 *>(ix.ftab)[idx];
+        if (e.x > e.y && e.x != 1u) return false;
+        lo = e.x; hi = e.y;
+        k = e.z == 0xFFFFFFFFu ? ~uint64_t(0) : static_cast<uint64_t>(e.z);
+    } else {
+        const ulonglong4 e = static_cast<const ulonglong4 *>(ix.ftab)[idx];
+        lo = e.x; hi = e.y; k = e.z;
+    }
+    return true;
+}
+
 template <typename P, bool TOEHOLD, bool USE_FTAB>
 __global__ __launch_bounds__(256, 8) void k_find_range(const DevIndex ix, const uint8_t *__restrict__ seqs,
                                                     const uint64_t *__restrict__ off, const uint64_t N,
@@ -237,9 +255,10 @@ __global__ __launch_bounds__(256, 8) void k_find_range(const DevIndex ix, const 
                 idx += (mm & 3u) * pw;
                 pw *= M;
             }
-            if (all_major) {
-                const ulonglong4 e = *reinterpret_cast<const ulonglong4 *>(ix.ftab + 4 * idx);
-                lo = e.x; hi = e.y; k = e.z;
+            uint64_t flo, fhi2, fk;
+            if (all_major && ftab_lookup<P>(ix, idx, flo, fhi2, fk)) {
+                lo = flo; hi = fhi2;
+                if (TOEHOLD) k = fk;
                 p -= ix.ftab_k;
                 if (hi < lo) { alive = false; p = beg; }
             }
@@ -467,11 +486,16 @@ __global__ __launch_bounds__(256, 8) void k_find_range_packed(const DevIndex ix,
         BitStream bs{chunks + mt.x, make_uint4(0, 0, 0, 0), 4u, 0u, 0ull};
         bool alive = true;
         if (ix.ftab_k && r >= ix.ftab_k) {  // the first ftab_k symbols are the low 2*ftab_k bits
-            const uint64_t idx = bs.take(2 * ix.ftab_k);
-            const ulonglong4 e = *reinterpret_cast<const ulonglong4 *>(ix.ftab + 4 * idx);
-            lo = e.x; hi = e.y; k = e.z;
-            r -= ix.ftab_k;
-            if (hi < lo) { alive = false; r = 0; }
+            BitStream probe = bs;           // consumed only if the entry is usable
+            const uint64_t idx = probe.take(2 * ix.ftab_k);
+            uint64_t flo, fhi2, fk;
+            if (ftab_lookup<P>(ix, idx, flo, fhi2, fk)) {
+                bs = probe;
+                lo = flo; hi = fhi2;
+                if (TOEHOLD) k = fk;
+                r -= ix.ftab_k;
+                if (hi < lo) { alive = false; r = 0; }
+            }
         }
         auto step = [&](const DevSym &S, uint32_t adv, uint32_t tab) -> bool {
             RankAux q;
@@ -1117,13 +1141,11 @@ __global__ __launch_bounds__(256) void k_marker_seeds(const DevIndex ix, const u
                     idx += (mm & 3u) * pw;
                     pw *= M;
                 }
-                if (all_major) {
-                    const ulonglong4 e = *reinterpret_cast<const ulonglong4 *>(ix.ftab + 4 * idx);
-                    if (e.x <= e.y) {
-                        lo = e.x; hi = e.y;
-                        on_ok(ix.ftab_k);
-                        continue;
-                    }
+                uint64_t flo, fhi2, fk;
+                if (all_major && ftab_lookup<P>(ix, idx, flo, fhi2, fk) && flo <= fhi2) {
+                    lo = flo; hi = fhi2;
+                    on_ok(ix.ftab_k);
+                    continue;
                 }
             }
             uint32_t len;
@@ -1457,19 +1479,25 @@ __global__ __launch_bounds__(256) void k_ftab_words(const DevIndex ix, const uin
         }
     }
 }
+template <typename P>
 __global__ __launch_bounds__(256) void k_ftab_pack(const uint64_t W, const uint64_t *__restrict__ lo, const uint64_t *__restrict__ hi,
-                                                   const uint64_t *__restrict__ ss, unsigned long long *__restrict__ tab) {
+                                                   const uint64_t *__restrict__ ss, void *__restrict__ tab) {
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
     for (uint64_t w = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; w < W; w += stride) {
-        tab[4 * w + 0] = lo[w];
-        tab[4 * w + 1] = hi[w];
-        tab[4 * w + 2] = ss ? ss[w] : 0;
-        tab[4 * w + 3] = 0;
+        const uint64_t k = ss ? ss[w] : 0;
+        if constexpr (sizeof(P) == 4) {
+            uint4 e = make_uint4(static_cast<uint32_t>(lo[w]), static_cast<uint32_t>(hi[w]), static_cast<uint32_t>(k), 0u);
+            if (k == ~uint64_t(0)) e.z = 0xFFFFFFFFu;
+            else if (k >= 0xFFFFFFF0ull) e = make_uint4(2u, 0u, 0u, 0u);  // not expressible: search this word step by step
+            static_cast<uint4 *>(tab)[w] = e;
+        } else {
+            static_cast<ulonglong4 *>(tab)[w] = make_ulonglong4(lo[w], hi[w], k, 0);
+        }
     }
 }
 }  // namespace
 
-int launch_build_ftab(const DevIndex &ix, const LaunchCfg &cfg, uint32_t k, unsigned long long *tab, void *stream) {
+int launch_build_ftab(const DevIndex &ix, const LaunchCfg &cfg, uint32_t k, void *tab, void *stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     uint64_t W = 1;
     for (uint32_t t = 0; t < k; ++t) W *= ix.nmajor;
@@ -1499,7 +1527,8 @@ int launch_build_ftab(const DevIndex &ix, const LaunchCfg &cfg, uint32_t k, unsi
         rc = static_cast<int>(hipGetLastError());
         if (!rc) rc = launch_find_range(plain, cfg, seqs, off, W, lo, hi, ss, st);
         if (!rc) {
-            hipLaunchKernelGGL(k_ftab_pack, dim3(grid_for(cfg, W)), dim3(256), 0, st, W, lo, hi, ss, tab);
+            if (ix.pos_bytes == 4) hipLaunchKernelGGL(k_ftab_pack<uint32_t>, dim3(grid_for(cfg, W)), dim3(256), 0, st, W, lo, hi, ss, tab);
+            else hipLaunchKernelGGL(k_ftab_pack<uint64_t>, dim3(grid_for(cfg, W)), dim3(256), 0, st, W, lo, hi, ss, tab);
             rc = static_cast<int>(hipGetLastError());
         }
         if (!rc) rc = static_cast<int>(hipStreamSynchronize(st));
