@@ -871,66 +871,105 @@ __global__ __launch_bounds__(256) void k_greedy_seed(const DevIndex ix, const ui
                                                      uint64_t *__restrict__ qe_out, uint64_t *__restrict__ ss_out) {
     __shared__ uint8_t s_lut[256];
     __shared__ uint8_t s_lut2[256];
-    __shared__ DevSym s_sym[kLdsSyms];
-    __shared__ DevSym s_pair[kMaxMajor * kMaxMajor];
-    __shared__ DevSym s_tri[kMaxMajor * kMaxMajor * kMaxMajor];
+    __shared__ DevSym s_tab[kTabMax];
+    stage_tables(ix, s_tab, s_lut, s_lut2);
     const uint32_t M = ix.nmajor;
-    const bool use3 = ix.kmer_steps >= 3;
-    for (int t = threadIdx.x; t < 256; t += blockDim.x) {
-        s_lut[t] = ix.lut[t];
-        s_lut2[t] = M ? ix.lut2[t] : 0xFFu;
-    }
-    const int nlds = ix.sigma < static_cast<uint32_t>(kLdsSyms) ? static_cast<int>(ix.sigma) : kLdsSyms;
-    for (int t = threadIdx.x; t < nlds; t += blockDim.x) s_sym[t] = ix.syms[t];
-    for (int t = threadIdx.x; t < static_cast<int>(M * M); t += blockDim.x) s_pair[t] = ix.pairs[t];
-    if (use3)
-        for (int t = threadIdx.x; t < static_cast<int>(M * M * M); t += blockDim.x) s_tri[t] = ix.triples[t];
-    __syncthreads();
+    const uint32_t ksteps = ix.kmer_steps;
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
     for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < N; i += stride) {
         const uint64_t beg = off[i], m = off[i + 1] - beg;
         const uint64_t first_k = ix.last_run_sample;  // rowbowt.hpp:230
-        uint64_t lo = 0, hi = ix.n - 1, plo = 0, phi = ix.n - 1;
+        const uint64_t fhi = ix.n - 1;
+        uint64_t lo = 0, hi = fhi, plo = 0, phi = fhi;
         uint64_t k = first_k, pk = ~uint64_t(0), ei = m;
         uint64_t b_lo = 1, b_hi = 0, b_qs = 0, b_qe = 0, b_k = 0, b_len = 0;
         ByteCursor rd{reinterpret_cast<const uint4 *>(seqs), ~uint64_t(0), make_uint4(0, 0, 0, 0)};
         uint64_t j = m;  // next symbol to consume is q[j-1]
+        auto lf1 = [&](uint32_t c) -> bool {  // one reference step (rowbowt.hpp:235); an absent symbol is an empty range (:76)
+            const uint32_t slot = s_lut[c];
+            if (slot == 0xFFu) return false;
+            if (slot < static_cast<uint32_t>(kLdsSyms)) { const DevSym S = s_tab[slot]; return lf_w_loc<P>(S, 1u, lo, hi, k); }
+            return lf_w_loc<P>(ix.syms[slot], 1u, lo, hi, k);
+        };
+        // the longest k-mer (2..min(cap, kmer_steps) symbols, all with k-mer tables) ending at byte p; success
+        // is identical to *len nested LF_w_loc calls
+        auto lfk = [&](uint64_t p, uint32_t c, uint64_t cap, uint32_t *len) -> bool {
+            *len = 0;
+            const uint32_t m0 = s_lut2[c];
+            if (m0 == 0xFFu || cap < 2 || ksteps < 2) return false;
+            const uint32_t m1 = s_lut2[rd.at(p - 1)];
+            if (m1 == 0xFFu) return false;
+            uint32_t adv = 2, idx = kOff2 + m1 * M + m0;
+            if (ksteps >= 3 && cap >= 3) {
+                const uint32_t m2 = s_lut2[rd.at(p - 2)];
+                if (m2 != 0xFFu) {
+                    adv = 3;
+                    idx = kOff3 + (m2 * M + m1) * M + m0;
+                    if (ksteps >= 4 && cap >= 4) {
+                        const uint32_t m3 = s_lut2[rd.at(p - 3)];
+                        if (m3 != 0xFFu) { adv = 4; idx = kOff4 + ((m3 * M + m2) * M + m1) * M + m0; }
+                    }
+                }
+            }
+            *len = adv;
+            const DevSym S = s_tab[idx];
+            return lf_w_loc<P>(S, adv, lo, hi, k);
+        };
+        auto on_ok = [&](uint32_t adv) {
+            j -= adv;
+            plo = lo; phi = hi; pk = k;  // rowbowt.hpp:248-249
+        };
+        auto on_fail = [&]() {  // q[j-1] ends the seed q[j, ei)  (rowbowt.hpp:236-246; m-i == j here)
+            if (ei - j >= min_length && ei - j > b_len) { b_len = ei - j; b_lo = plo; b_hi = phi; b_qs = j; b_qe = ei; b_k = pk; }
+            k = first_k;
+            lo = 0; hi = fhi; plo = 0; phi = fhi;
+            j -= 1;      // skip the base that failed
+            ei = j;
+        };
         while (j > 0) {
             const uint64_t p = beg + j - 1;
             const uint32_t c = rd.at(p);
-            // k-mer attempt; success is identical to adv nested LF_w_loc calls
-            const uint32_t m0 = s_lut2[c];
-            uint32_t m1 = 0xFFu, adv = 0;
-            if (m0 != 0xFFu && j > 1) m1 = s_lut2[rd.at(p - 1)];
-            if (m1 != 0xFFu) {
-                uint32_t m2 = 0xFFu;
-                if (use3 && j > 2) m2 = s_lut2[rd.at(p - 2)];
-                const DevSym S = m2 != 0xFFu ? s_tri[(m2 * M + m1) * M + m0] : s_pair[m1 * M + m0];
-                const uint32_t want = m2 != 0xFFu ? 3u : 2u;
-                if (lf_w_loc<P>(S, want, lo, hi, k)) adv = want;
+            // a fresh seed: the state after its first ftab_k symbols (range and toehold, searched from
+            // first_k like here) is one gather in the device table; an empty entry means the word does not
+            // occur and the steps below find where it stops
+            if (j == ei && ix.ftab_k && j >= ix.ftab_k) {
+                uint64_t idx = 0, pw = 1;
+                bool all_major = true;
+                for (uint32_t t = 0; t < ix.ftab_k; ++t) {
+                    const uint32_t mm = s_lut2[rd.at(p - t)];
+                    all_major = all_major && mm != 0xFFu;
+                    idx += (mm & 3u) * pw;
+                    pw *= M;
+                }
+                uint64_t flo, fhi2, fk;
+                if (all_major && ftab_lookup<P>(ix, idx, flo, fhi2, fk) && flo <= fhi2) {
+                    lo = flo; hi = fhi2; k = fk;
+                    on_ok(ix.ftab_k);
+                    continue;
+                }
             }
-            if (adv) {
-                plo = lo; phi = hi; pk = k;  // rowbowt.hpp:248-249
-                j -= adv;
+            uint32_t len;
+            if (lfk(p, c, j, &len)) { on_ok(len); continue; }
+            if (len == 0) {
+                if (lf1(c)) on_ok(1u); else on_fail();
                 continue;
             }
-            // one reference step (rowbowt.hpp:235); an absent symbol is an empty range (:76)
-            const uint32_t slot = s_lut[c];
-            bool ok = false;
-            if (slot != 0xFFu) {
-                const DevSym S = slot < static_cast<uint32_t>(kLdsSyms) ? s_sym[slot] : ix.syms[slot];
-                ok = lf_w_loc<P>(S, 1u, lo, hi, k);
-            }
-            if (ok) {
-                plo = lo; phi = hi; pk = k;
+            // the range died inside q[j-len, j): two more gathers say where (lo/hi/k are untouched by a failed step)
+            if (len == 2) {
+                if (lf1(c)) { on_ok(1u); on_fail(); } else on_fail();
             } else {
-                // the seed covered q[j, ei)  (rowbowt.hpp:236-246; m-i == j here)
-                if (ei - j >= min_length && ei - j > b_len) { b_len = ei - j; b_lo = plo; b_hi = phi; b_qs = j; b_qe = ei; b_k = pk; }
-                k = first_k;
-                lo = 0; hi = ix.n - 1; plo = 0; phi = ix.n - 1;
-                ei = j - 1;  // skip the base that failed
+                uint32_t l2;
+                const bool first_part = len == 4 ? lfk(p, c, 2, &l2) : lf1(c);
+                const uint32_t took = len == 4 ? 2u : 1u;
+                if (first_part) {
+                    on_ok(took);  // then exactly one of the next two symbols fails
+                    if (lf1(rd.at(beg + j - 1))) { on_ok(1u); on_fail(); } else on_fail();
+                } else if (len == 4) {
+                    if (lf1(c)) { on_ok(1u); on_fail(); } else on_fail();
+                } else {
+                    on_fail();
+                }
             }
-            j -= 1;
         }
         if (ei >= min_length && ei > b_len) { b_len = ei; b_lo = plo; b_hi = phi; b_qs = 0; b_qe = ei; b_k = pk; }  // :252-254
         lo_out[i] = b_lo;
