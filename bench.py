@@ -218,6 +218,23 @@ def main():
     el_count = timed(count_ev, K, events=True)
     ms_count = float(np.mean([evc[s][0].elapsed_time(evc[s][1]) for s in range(K)]))
 
+    # ---- capped locate (SURVEY 8d config 3's diagnostic): the same step with max_hits = 1 ----------
+    d_loc_off1 = torch.empty(N + 1, dtype=torch.int64, device=dev)
+    d_locs1 = torch.empty(N, dtype=torch.int64, device=dev)
+
+    def step_capped():
+        k_toehold()
+        chk(L.rbg_locate_plan_dev(rb.h, d_lo.data_ptr(), d_hi.data_ptr(), N, 1, d_loc_off1.data_ptr(), d_tmp.data_ptr(), tmp_bytes, st), "locate_plan")
+        k_order()
+        chk(L.rbg_locate_fill_dev(rb.h, d_lo.data_ptr(), d_hi.data_ptr(), d_k.data_ptr(), N, 1, d_loc_off1.data_ptr(), d_locs1.data_ptr(),
+                                  d_ws.data_ptr(), st), "locate_fill")
+
+    step_capped()
+    el_cap = timed(step_capped, K)
+    capped_ok = bool((d_locs1[:int(d_loc_off1[-1].item())] == d_k[d_hi >= d_lo]).all().item())  # the first location is the toehold
+    del d_loc_off1, d_locs1
+    step()  # leave the uncapped results in the buffers for the checks below
+
     # ---- the same K count+locate steps as successive batches on two HIP streams (informational) --
     # K2 is bound by gather requests, the toehold-ordered K3 is not: the next batch's search overlaps
     # this batch's locate.  Outputs are double-buffered; the headline `value` stays the plain
@@ -372,6 +389,9 @@ def main():
                                      "workload": "the same K count+locate steps issued as successive batches on two HIP streams"}
                                     if args.two_stream else None),
             "markers": mk_block,
+            "capped_max_hits_1": {"value": N * K / el_cap, "unit": "reads/s (this rank)", "ms_per_step": el_cap / K * 1e3,
+                                  "first_location_is_the_toehold": capped_ok,
+                                  "workload": "count+locate with max_hits = 1 (diagnostic: search cost without the phi walks)"},
             "count_only": {"value": N * world * K / el_count, "unit": "reads/s", "ms_per_step": el_count / K * 1e3,
                            "workload": "BASELINE.json configs[1]: find_range only"},
             "counters": {"reads": g_counters[0], "matched": g_counters[1], "sum_occ": g_counters[2], "sum_locs": g_counters[3],
@@ -379,6 +399,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "measured_traffic_GBps": (traffic / (kernels[dom]["ms"] * 1e-3) / 1e9) if traffic else None,
+                         "gather_efficiency": (kernels[dom]["alg_bytes"] / traffic) if traffic else None,
                          "note": "achieved = algorithmic bytes of the reference's one-symbol-per-step algorithm (SURVEY 8d: 57m+24 per "
                                  "read, 24 per located position) / kernel time; it can exceed the HBM peak because the k-mer steps and the "
                                  "ordered phi chains move fewer bytes than that algorithm needs: traffic = FETCH_SIZE+WRITE_SIZE of "
