@@ -300,3 +300,18 @@ def test_build_from_runs_rejects_inconsistent_input():
             ra.RowBowt.from_runs(heads, lens, ssa, esa, device=capi.DEVICE_NONE).close()
         except ra.RbgError as e:
             assert e.code in (-2, -4)
+
+
+def _compile_c_example(tmp_path):
+    import subprocess
+    exe = tmp_path / "abi_usage"
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "abi_usage.c"), "-o", str(exe),
+                           "-L", os.path.join(ROOT, "rowbowt_amd"), "-lrbg", "-Wl,-rpath," + os.path.join(ROOT, "rowbowt_amd")])
+    return exe
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/rbg.h is consumed by a C11 compiler with -pedantic -Werror, and the example of INTEGRATION.md
+    section 2 links against librbg.so (it runs in the GPU suite)"""
+    assert _compile_c_example(tmp_path).exists()

@@ -908,6 +908,15 @@ def test_cpp_shim_reference_goldens(tmp_path, data_dir):
     assert b"shim goldens ok" in p.stdout
 
 
+def test_c_abi_example_program(tmp_path, data_dir):
+    """tests/c/abi_usage.c (plain C11 over include/rbg.h): the reference's golden values through the C-ABI"""
+    import subprocess
+    from test_capi_host import _compile_c_example
+    exe = _compile_c_example(tmp_path)
+    p = subprocess.run([str(exe), os.path.join(data_dir, "small.fa")], capture_output=True, timeout=120)
+    assert p.returncode == 0 and b"abi_usage ok" in p.stdout, p.stderr.decode()
+
+
 @pytest.mark.parametrize("packed", [0, 2])
 def test_long_and_ragged_reads(synth, packed, request):
     """Reads far longer than the 100 bp of the bench (whole haplotypes, the whole text, longer than the
