@@ -250,8 +250,8 @@ int rbg_locate_plan_dev(rbg_index *, const uint64_t *d_lo, const uint64_t *d_hi,
                         uint64_t *d_loc_off, void *d_tmp, size_t tmp_bytes, void *stream);
 /* Optional, any time before fill: order the phi chains by toehold text position.  Chains of reads
  * from nearby loci visit the haplotypes in the same order, so neighbouring lanes then touch
- * neighbouring slots for the whole walk (k_locate_fill 7.3 -> 3.1 ms per 10M reads on the bench
- * index; the sort costs ~0.5 ms).  Results are unchanged.  d_ws: 256-byte aligned, N < 2^32-1. */
+ * neighbouring slots for the whole walk (k_locate_fill 9 -> 2.3 ms per 10M reads on the bench
+ * index; the sort costs 0.36 ms).  Results are unchanged.  d_ws: 256-byte aligned, N < 2^32-1. */
 size_t rbg_locate_order_ws_bytes(uint64_t N);
 int rbg_locate_order_dev(rbg_index *, const uint64_t *d_k, uint64_t N, void *d_ws, size_t ws_bytes, void *stream);
 /* d_order: the workspace prepared by rbg_locate_order_dev for the same d_k, or NULL (input order).
