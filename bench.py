@@ -380,7 +380,7 @@ def main():
                             f"synthetic chr22-scale pangenome r-index, {N} x {m} bp reads per GPU per step (BASELINE.json configs[2])",
                 "index": {"L": args.L, "H": args.H, "n": int(inp["n"]), "r": int(inp["r"]), "site_rate": args.site_rate,
                           "hbm_bytes": int(ix.hbm_bytes), "pos_bytes": int(ix.pos_bytes), "seed": args.seed,
-                          "symbols_per_gather": int(ix.kmer_steps), "pair_runs": int(ix.pair_runs), "triple_runs": int(ix.triple_runs), "quad_runs": int(ix.quad_runs)},
+                          "symbols_per_gather": int(ix.kmer_steps), "pair_runs": int(ix.pair_runs), "triple_runs": int(ix.triple_runs), "quad_runs": int(ix.quad_runs), "quint_runs": int(ix.quint_runs)},
                 "reads_per_gpu": N, "read_len": m, "substituted_fraction": 0.1,
                 "parallelism": f"index replicated x{world}, reads sharded, no data-path collective",
             },

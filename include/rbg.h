@@ -126,11 +126,12 @@ typedef struct rbg_info_t {
     uint32_t reserved;
     /* first-level slot tables: totals and how many buckets overflow their 2 inline entries */
     uint64_t rank_slots, rank_slots_overflow, phi_slots, phi_slots_overflow;
-    /* multi-symbol LF steps: symbols consumed per gather (1..4), size of the major alphabet that has
+    /* multi-symbol LF steps: symbols consumed per gather (1..5), size of the major alphabet that has
      * k-mer tables (0 = none), total runs of the 2-mer and 3-mer tables */
     uint64_t kmer_steps, kmer_symbols, pair_runs, triple_runs, quad_runs;
     /* ftab (RowBowt::build_ftab / search_ftab, rowbowt.hpp:726-758): word length of the device table, 0 = none */
     uint64_t ftab_k;
+    uint64_t quint_runs;    /* total runs of the 5-mer tables (kmer_steps == 5) */
 } rbg_info_t;
 int rbg_info(const rbg_index *, rbg_info_t *out);
 
@@ -290,7 +291,7 @@ int rbg_counters_reset(rbg_index *);
 /* ---- tuning (never changes results) -------------------------------------------------------- */
 /* Process-wide defaults read when an index is built/loaded: BLOCK_THREADS (64, 128, 192 or 256),
  * RANK/PHI_BUCKET_SHIFT (-1 = automatic, else 0..8), POS_BYTES (0 = automatic, 4 or 8 to force a width),
- * KMER_STEPS (1..4: symbols the backward search consumes per gather; 2..4 build the k-mer
+ * KMER_STEPS (1..5, default 5: symbols the backward search consumes per gather; 2..5 build the k-mer
  * tables of DESIGN.md 2b; 1 keeps the reference's one-symbol steps only; the deepest levels are dropped
  * automatically when the replica would not fit), HBM_BUDGET_MB (0 = three quarters of the free HBM:
  * upper bound for the replica, deciding how many k-mer levels are kept), FTAB_K (-1 = automatic (12),

@@ -46,7 +46,7 @@ class Info(C.Structure):
                 ("hbm_bytes", U64), ("marker_runs", U64), ("marker_vals", U64),
                 ("rank_bucket_shift", C.c_uint32), ("phi_bucket_shift", C.c_uint32), ("reserved", C.c_uint32),
                 ("rank_slots", U64), ("rank_slots_overflow", U64), ("phi_slots", U64), ("phi_slots_overflow", U64),
-                ("kmer_steps", U64), ("kmer_symbols", U64), ("pair_runs", U64), ("triple_runs", U64), ("quad_runs", U64), ("ftab_k", U64)]
+                ("kmer_steps", U64), ("kmer_symbols", U64), ("pair_runs", U64), ("triple_runs", U64), ("quad_runs", U64), ("ftab_k", U64), ("quint_runs", U64)]
 
 
 # every symbol include/rbg.h declares: (name, restype, argtypes)

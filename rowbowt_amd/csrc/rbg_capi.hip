@@ -41,7 +41,7 @@ std::atomic<int64_t> g_opt_block_threads{256};
 std::atomic<int64_t> g_opt_rank_shift{-1};
 std::atomic<int64_t> g_opt_phi_shift{-1};
 std::atomic<int64_t> g_opt_pos_bytes{0};
-std::atomic<int64_t> g_opt_kmer_steps{4};
+std::atomic<int64_t> g_opt_kmer_steps{5};
 std::atomic<int64_t> g_opt_hbm_budget_mb{0};
 std::atomic<int64_t> g_opt_ftab_k{-1};
 std::atomic<int64_t> g_opt_packed_reads{0};  // host-pointer calls: 0 never pack (default), 1 pack large batches, 2 always pack
@@ -129,8 +129,10 @@ size_t replica_bytes(const HostIndex &h) {
     for (const SymTable &t : h.pair) total += table_bytes<P>(t, h.has_tsa, h.n);
     for (const SymTable &t : h.triple) total += table_bytes<P>(t, h.has_tsa, h.n);
     for (const SymTable &t : h.quad) total += table_bytes<P>(t, h.has_tsa, h.n);
+    for (const SymTable &t : h.quint) total += table_bytes<P>(t, h.has_tsa, h.n);
     total += arena_round(h.sym.size() * sizeof(DevSym)) + arena_round(h.pair.size() * sizeof(DevSym)) +
-             arena_round(h.triple.size() * sizeof(DevSym)) + arena_round(h.quad.size() * sizeof(DevSym)) + 3 * arena_round(256);
+             arena_round(h.triple.size() * sizeof(DevSym)) + arena_round(h.quad.size() * sizeof(DevSym)) +
+             arena_round(h.quint.size() * sizeof(DevSym)) + 3 * arena_round(256);
     if (h.has_tsa) {
         const uint64_t nb = (h.n >> h.phi_shift) + 2;
         total += arena_round(h.r * sizeof(PhiEnt<P>)) + arena_round(nb * sizeof(PhiSlot<P>)) + arena_round(nb * sizeof(uint32_t));
@@ -242,6 +244,10 @@ int upload_tables(rbg_index *ix) {
             if ((rc = upload_set(h.quad, &ix->dev.quads))) return rc;
             ix->dev.kmer_steps = 4;
         }
+        if (!h.quint.empty()) {
+            if ((rc = upload_set(h.quint, &ix->dev.quints))) return rc;
+            ix->dev.kmer_steps = 5;
+        }
         rc = dev_upload(ix, h.major_of, 256, &p);
         if (rc) return rc;
         ix->dev.lut2 = static_cast<const uint8_t *>(p);
@@ -342,7 +348,7 @@ int upload(rbg_index *ix) {
     const size_t budget = opt_mb > 0 ? static_cast<size_t>(opt_mb) << 20 : free_b - free_b / 4;
     auto need = [&] { return h.pos_bytes == 4 ? replica_bytes<uint32_t>(h) : replica_bytes<uint64_t>(h); };
     while (need() > budget && !h.pair.empty()) {
-        std::vector<SymTable> &deepest = !h.quad.empty() ? h.quad : !h.triple.empty() ? h.triple : h.pair;
+        std::vector<SymTable> &deepest = !h.quint.empty() ? h.quint : !h.quad.empty() ? h.quad : !h.triple.empty() ? h.triple : h.pair;
         std::fprintf(stderr, "rbg: replica of %.1f GB exceeds the %.1f GB budget: dropping the %zu-table k-mer level\n",
                      need() / 1e9, budget / 1e9, deepest.size());
         std::vector<SymTable>().swap(deepest);
@@ -633,7 +639,7 @@ int rbg_set_default_option(int opt, int64_t value) {
             if (value < 0) return RBG_EARG;
             g_opt_hbm_budget_mb = value; return RBG_OK;
         case RBG_OPT_KMER_STEPS:
-            if (value < 1 || value > 4) return RBG_EARG;
+            if (value < 1 || value > 5) return RBG_EARG;
             g_opt_kmer_steps = value; return RBG_OK;
         case RBG_OPT_PACKED_READS:
             if (value < 0 || value > 2) return RBG_EARG;
@@ -869,12 +875,13 @@ int rbg_info(const rbg_index *ix, rbg_info_t *out) {
     out->rank_slots_overflow = ix->rank_slots_overflow;
     out->phi_slots = ix->phi_slots;
     out->phi_slots_overflow = ix->phi_slots_overflow;
-    out->kmer_steps = !ix->host.quad.empty() ? 4 : !ix->host.triple.empty() ? 3 : !ix->host.pair.empty() ? 2 : 1;
+    out->kmer_steps = !ix->host.quint.empty() ? 5 : !ix->host.quad.empty() ? 4 : !ix->host.triple.empty() ? 3 : !ix->host.pair.empty() ? 2 : 1;
     out->kmer_symbols = ix->host.pair.empty() ? 0 : ix->host.nmajor;
     out->ftab_k = ix->dev.ftab_k;
     for (const SymTable &t : ix->host.pair) out->pair_runs += t.nruns;
     for (const SymTable &t : ix->host.triple) out->triple_runs += t.nruns;
     for (const SymTable &t : ix->host.quad) out->quad_runs += t.nruns;
+    for (const SymTable &t : ix->host.quint) out->quint_runs += t.nruns;
     return RBG_OK;
 }
 

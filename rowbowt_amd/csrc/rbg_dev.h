@@ -92,10 +92,11 @@ struct DevIndex {
     // pair-run ends); lut2 maps a byte to its major index 0..nmajor-1 or 0xFF.  nmajor == 0: off.
     const DevSym *pairs;    // nmajor^2
     const DevSym *triples;  // nmajor^3 (kmer_steps >= 3)
-    const DevSym *quads;    // nmajor^4 (kmer_steps == 4)
+    const DevSym *quads;    // nmajor^4 (kmer_steps >= 4)
+    const DevSym *quints;   // nmajor^5 (kmer_steps == 5)
     const uint8_t *lut2;
     uint32_t nmajor;
-    uint32_t kmer_steps;    // 1 .. 4
+    uint32_t kmer_steps;    // 1 .. 5
     // ftab (reference: RowBowt::search_ftab, rowbowt.hpp:745-758; result-neutral by construction,
     // :124-125): for every word of ftab_k major symbols the state after searching it -- {lo, hi,
     // toehold, 0} (4 x u32 at 4-byte positions, else 4 x u64) -- indexed by the word read as a base-nmajor number, most significant

@@ -799,6 +799,7 @@ int build_kmer_tables(HostIndex &out, const RawTsa *tsa, const FlattenOptions &o
     out.pair.clear();
     out.triple.clear();
     out.quad.clear();
+    out.quint.clear();
     if (opt.kmer_steps < 2 || out.sigma < 2) return RBG_OK;
     // the terminator: the smallest symbol, occurring once (rle_string.hpp:59,62 maps 0 -> 1).
     // Without one the wrap argument of DESIGN.md 2b does not hold: keep single steps only.
@@ -827,7 +828,7 @@ int build_kmer_tables(HostIndex &out, const RawTsa *tsa, const FlattenOptions &o
     if (tsa) G.samp = tsa->samples_last;
     std::vector<SymTable> depth1(M);
     for (uint32_t m = 0; m < M; ++m) depth1[m] = out.sym[order[m]];
-    Segmentation G2, G3;
+    Segmentation G2, G3, G4;
     int rc = compose(out, order, G, 1, M, depth1, tsa != nullptr, opt, out.pair, opt.kmer_steps >= 3 ? &G2 : nullptr);
     if (rc) return rc;
     Segmentation().start.swap(G.start);
@@ -836,7 +837,11 @@ int build_kmer_tables(HostIndex &out, const RawTsa *tsa, const FlattenOptions &o
         if (rc) return rc;
     }
     if (opt.kmer_steps >= 4) {
-        rc = compose(out, order, G3, 3, M * M * M, out.triple, tsa != nullptr, opt, out.quad, nullptr);
+        rc = compose(out, order, G3, 3, M * M * M, out.triple, tsa != nullptr, opt, out.quad, opt.kmer_steps >= 5 ? &G4 : nullptr);
+        if (rc) return rc;
+    }
+    if (opt.kmer_steps >= 5) {
+        rc = compose(out, order, G4, 4, M * M * M * M, out.quad, tsa != nullptr, opt, out.quint, nullptr);
         if (rc) return rc;
     }
     return RBG_OK;

@@ -108,6 +108,7 @@ struct HostIndex {
     std::vector<SymTable> pair;        // nmajor^2, or empty (multi-symbol steps disabled)
     std::vector<SymTable> triple;      // nmajor^3, or empty
     std::vector<SymTable> quad;        // nmajor^4, or empty
+    std::vector<SymTable> quint;       // nmajor^5, or empty
     bool has_tsa = false;
     uint64_t last_run_sample = 0;      // toehold_sa.hpp:97-99
     std::vector<uint64_t> samples_last, pred_pos, phi_base;
@@ -122,7 +123,7 @@ struct FlattenOptions {
     int rank_bucket_shift = -1;  // <0: automatic (about one run per two buckets)
     int phi_bucket_shift = -1;
     int force_pos_bytes = 0;     // 0: 4 when n fits, else 8
-    int kmer_steps = 4;          // symbols consumed per gather: 1 (reference shape) .. 4
+    int kmer_steps = 5;          // symbols consumed per gather: 1 (reference shape) .. 5
 };
 
 int flatten(const RawRle &rle, const RawTsa *tsa, const FlattenOptions &opt, HostIndex &out);

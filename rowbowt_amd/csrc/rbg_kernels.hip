@@ -161,10 +161,12 @@ struct ByteCursor {
 constexpr int kOff2 = kLdsSyms;
 constexpr int kOff3 = kOff2 + kMaxMajor * kMaxMajor;
 constexpr int kOff4 = kOff3 + kMaxMajor * kMaxMajor * kMaxMajor;
-constexpr int kTabMax = kOff4 + kMaxMajor * kMaxMajor * kMaxMajor * kMaxMajor;
+constexpr int kOff5 = kOff4 + kMaxMajor * kMaxMajor * kMaxMajor * kMaxMajor;
+constexpr int kTabMax = kOff5;                 // statically staged levels: singles .. 4-mers
+constexpr int kTab5 = kOff5 + kMaxMajor * kMaxMajor * kMaxMajor * kMaxMajor * kMaxMajor;  // with the 5-mers (k_find_range's dynamic LDS)
 constexpr uint32_t kHbmRec = 0x80000000u;  // record reference: symbol slot whose DevSym lives in HBM (ix.syms), not in s_tab
 
-__device__ __forceinline__ void stage_tables(const DevIndex &ix, DevSym *s_tab, uint8_t *s_lut, uint8_t *s_lut2) {
+__device__ __forceinline__ void stage_tables(const DevIndex &ix, DevSym *s_tab, uint8_t *s_lut, uint8_t *s_lut2, bool with5 = false) {
     const uint32_t M = ix.nmajor;
     for (int t = threadIdx.x; t < 256; t += blockDim.x) {
         s_lut[t] = ix.lut[t];
@@ -178,6 +180,8 @@ __device__ __forceinline__ void stage_tables(const DevIndex &ix, DevSym *s_tab, 
         for (int t = threadIdx.x; t < static_cast<int>(M * M * M); t += blockDim.x) s_tab[kOff3 + t] = ix.triples[t];
     if (ix.kmer_steps >= 4)
         for (int t = threadIdx.x; t < static_cast<int>(M * M * M * M); t += blockDim.x) s_tab[kOff4 + t] = ix.quads[t];
+    if (with5 && ix.kmer_steps >= 5)
+        for (int t = threadIdx.x; t < static_cast<int>(M * M * M * M * M); t += blockDim.x) s_tab[kOff5 + t] = ix.quints[t];
     __syncthreads();
 }
 
@@ -199,28 +203,37 @@ __device__ __forceinline__ bool ftab_lookup(const DevIndex &ix, uint64_t idx, ui
     return true;
 }
 
+// The record table lives in dynamic LDS: kTabMax records (17 KB) up to 4-mer steps, kTab5 (66 KB) with the
+// 5-mer level, then launched as 1024-thread workgroups so that two of them still give 8 waves per SIMD.
 template <typename P, bool TOEHOLD, bool USE_FTAB>
-__global__ __launch_bounds__(256, 8) void k_find_range(const DevIndex ix, const uint8_t *__restrict__ seqs,
+__global__ __launch_bounds__(1024, 8) void k_find_range(const DevIndex ix, const uint8_t *__restrict__ seqs,
                                                     const uint64_t *__restrict__ off, const uint64_t N,
                                                     uint64_t *__restrict__ lo_out, uint64_t *__restrict__ hi_out,
                                                     uint64_t *__restrict__ ss_out, const uint32_t *__restrict__ sel,
                                                     const uint32_t *__restrict__ nsel) {
     __shared__ uint8_t s_lut[256];
     __shared__ uint8_t s_lut2[256];
-    __shared__ DevSym s_tab[kTabMax];
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    DevSym *s_tab = reinterpret_cast<DevSym *>(s_dyn);
     // sel != nullptr: only the reads sel[0 .. *nsel) (the ones the packed path hands back)
     const uint64_t Neff = sel ? static_cast<uint64_t>(*nsel) : N;
     if (Neff == 0) return;
-    stage_tables(ix, s_tab, s_lut, s_lut2);
+    stage_tables(ix, s_tab, s_lut, s_lut2, true);
     const uint32_t M = ix.nmajor;
     const uint32_t ksteps = ix.kmer_steps;
 
-    unsigned long long c_reads = 0, c_matched = 0, c_occ = 0;
+    // reads handled by this lane follow from the loop bounds; only the matches and their widths are accumulated
+    unsigned long long c_occ = 0;
+    uint32_t c_matched = 0;
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
-    for (uint64_t j_ = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j_ < Neff; j_ += stride) {
-        const uint64_t i = sel ? static_cast<uint64_t>(sel[j_]) : j_;
-        const uint64_t beg = off[i];
-        uint64_t p = off[i + 1];
+    const uint64_t first_ = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    for (uint64_t j_ = first_; j_ < Neff; j_ += stride) {
+        uint64_t beg, p;
+        {
+            const uint64_t i0 = sel ? static_cast<uint64_t>(sel[j_]) : j_;
+            beg = off[i0];
+            p = off[i0 + 1];
+        }
         uint64_t lo = 0, hi = ix.n - 1;  // full_range(), rowbowt.hpp:115-118
         uint64_t k = TOEHOLD ? ix.last_run_sample : 0;
         // The toehold only flows forward through "k - adv" (row hi carries the symbol); a step that
@@ -299,23 +312,20 @@ __global__ __launch_bounds__(256, 8) void k_find_range(const DevIndex ix, const 
             // nested steps emptied it.  Otherwise: one reference step (rowbowt.hpp:74-88, :555-573).
             uint32_t adv = 1, idx = 0;
             const uint32_t m0 = s_lut2[c];
-            if (m0 != 0xFFu && ksteps >= 2 && p > beg) {
-                const uint32_t m1 = s_lut2[rd.at(p - 1)];
-                if (m1 != 0xFFu) {
-                    adv = 2;
-                    idx = kOff2 + m1 * M + m0;
-                    if (ksteps >= 3 && p > beg + 1) {
-                        const uint32_t m2 = s_lut2[rd.at(p - 2)];
-                        if (m2 != 0xFFu) {
-                            adv = 3;
-                            idx = kOff3 + (m2 * M + m1) * M + m0;
-                            if (ksteps >= 4 && p > beg + 2) {
-                                const uint32_t m3 = s_lut2[rd.at(p - 3)];
-                                if (m3 != 0xFFu) { adv = 4; idx = kOff4 + ((m3 * M + m2) * M + m1) * M + m0; }
-                            }
-                        }
-                    }
+            if (m0 != 0xFFu) {
+                // extend to the left while the symbols have k-mer tables: the table index is the k-mer read as
+                // a base-M number whose least significant digit is the symbol next to the suffix
+                uint32_t acc = m0, pw = M;
+#pragma unroll 1  // unrolled, the five table-index computations stay live together and spill
+                for (uint32_t t = 1; t < 5; ++t) {
+                    if (t >= ksteps || p < beg + t) break;
+                    const uint32_t mm = s_lut2[rd.at(p - t)];
+                    if (mm == 0xFFu) break;
+                    acc += mm * pw;
+                    pw *= M;
+                    adv = t + 1;
                 }
+                idx = (adv == 5 ? kOff5 : adv == 4 ? kOff4 : adv == 3 ? kOff3 : kOff2) + acc;
             }
             bool ok;
             if (adv == 1) {
@@ -334,18 +344,19 @@ __global__ __launch_bounds__(256, 8) void k_find_range(const DevIndex ix, const 
         }
         if (TOEHOLD && alive && pend) k = resample();
         if (!alive) { lo = 1; hi = 0; k = 0; }  // {1,0}; LFData::clear rowbowt.hpp:153-159
+        const uint64_t i = sel ? static_cast<uint64_t>(sel[j_]) : j_;  // (re-read rather than kept live through the search)
         lo_out[i] = lo;
         hi_out[i] = hi;
         if (TOEHOLD) ss_out[i] = k;
-        c_reads += 1;
         if (alive) { c_matched += 1; c_occ += hi - lo + 1; }
     }
+    unsigned long long c_reads = first_ < Neff ? (Neff - first_ + stride - 1) / stride : 0;
     c_reads = wave_sum(c_reads);
-    c_matched = wave_sum(c_matched);
+    const unsigned long long w_matched = wave_sum(static_cast<unsigned long long>(c_matched));
     c_occ = wave_sum(c_occ);
     if ((threadIdx.x & (kWave - 1)) == 0 && c_reads) {
         atomicAdd(&ix.counters[0], c_reads);
-        if (c_matched) atomicAdd(&ix.counters[1], c_matched);
+        if (w_matched) atomicAdd(&ix.counters[1], w_matched);
         if (c_occ) atomicAdd(&ix.counters[2], c_occ);
     }
 }
@@ -461,7 +472,7 @@ __global__ __launch_bounds__(256, 8) void k_find_range_packed(const DevIndex ix,
     for (int t = threadIdx.x; t < 256; t += blockDim.x)
         if (s_lut2[t] != 0xFFu) s_mslot[s_lut2[t] & 3u] = s_lut[t];  // major index -> symbol slot
     __syncthreads();
-    const uint32_t ksteps = ix.kmer_steps;
+    const uint32_t ksteps = ix.kmer_steps < 4 ? ix.kmer_steps : 4;  // this kernel stages up to the 4-mer level
 
     unsigned long long c_reads = 0, c_matched = 0, c_occ = 0;
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
@@ -874,7 +885,7 @@ __global__ __launch_bounds__(256) void k_greedy_seed(const DevIndex ix, const ui
     __shared__ DevSym s_tab[kTabMax];
     stage_tables(ix, s_tab, s_lut, s_lut2);
     const uint32_t M = ix.nmajor;
-    const uint32_t ksteps = ix.kmer_steps;
+    const uint32_t ksteps = ix.kmer_steps < 4 ? ix.kmer_steps : 4;  // this kernel stages up to the 4-mer level
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
     for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < N; i += stride) {
         const uint64_t beg = off[i], m = off[i + 1] - beg;
@@ -1002,7 +1013,7 @@ __global__ __launch_bounds__(256) void k_marker_seeds(const DevIndex ix, const u
     __shared__ DevSym s_tab[kTabMax];
     stage_tables(ix, s_tab, s_lut, s_lut2);
     const uint32_t M = ix.nmajor;
-    const uint32_t ksteps = ix.kmer_steps;
+    const uint32_t ksteps = ix.kmer_steps < 4 ? ix.kmer_steps : 4;  // this kernel stages up to the 4-mer level
     if (!FILL && blockIdx.x == 0 && threadIdx.x == 0) { seed_cnt[0] = 0; mk_cnt[0] = 0; }
     const bool have_ma = ix.mk_nruns != 0;
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
@@ -1265,15 +1276,32 @@ int launch_find_range_impl(const DevIndex &ix, const LaunchCfg &cfg, const uint8
                            uint64_t *lo, uint64_t *hi, uint64_t *ssamp, const uint32_t *sel, const uint32_t *nsel, void *stream) {
     if (N == 0) return 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    // with the 5-mer level the record table is 66 KB of LDS: 1024-thread workgroups keep 8 waves per SIMD
+    const bool five = ix.kmer_steps >= 5;
+    LaunchCfg c5 = cfg;
+    if (five) { c5.block_threads = 1024; c5.max_blocks = cfg.max_blocks > 0 ? std::max(1, cfg.max_blocks / 4) : 256 * 8; }
+    const size_t lds = static_cast<size_t>(five ? kTab5 : kTabMax) * sizeof(DevSym);
     // sel mode: the number of reads is only known on the device; a fixed modest grid loops over it
-    const dim3 grid(sel ? std::min(grid_for(cfg, N), 512) : grid_for(cfg, N)), block(cfg.block_threads);
+    const dim3 grid(sel ? std::min(grid_for(c5, N), five ? 128 : 512) : grid_for(c5, N)), block(c5.block_threads);
     const bool toe = ssamp != nullptr;
+    static bool attr_set = false;  // more than 64 KB of dynamic LDS has to be allowed once per kernel
+    if (five && !attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_find_range<uint32_t, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_find_range<uint32_t, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_find_range<uint64_t, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_find_range<uint64_t, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_find_range<uint32_t, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_find_range<uint32_t, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_find_range<uint64_t, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_find_range<uint64_t, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        attr_set = true;
+    }
     if (ix.pos_bytes == 4) {
-        if (toe) hipLaunchKernelGGL((k_find_range<uint32_t, true, USE_FTAB>), grid, block, 0, st, ix, seqs, off, N, lo, hi, ssamp, sel, nsel);
-        else hipLaunchKernelGGL((k_find_range<uint32_t, false, USE_FTAB>), grid, block, 0, st, ix, seqs, off, N, lo, hi, ssamp, sel, nsel);
+        if (toe) hipLaunchKernelGGL((k_find_range<uint32_t, true, USE_FTAB>), grid, block, lds, st, ix, seqs, off, N, lo, hi, ssamp, sel, nsel);
+        else hipLaunchKernelGGL((k_find_range<uint32_t, false, USE_FTAB>), grid, block, lds, st, ix, seqs, off, N, lo, hi, ssamp, sel, nsel);
     } else {
-        if (toe) hipLaunchKernelGGL((k_find_range<uint64_t, true, USE_FTAB>), grid, block, 0, st, ix, seqs, off, N, lo, hi, ssamp, sel, nsel);
-        else hipLaunchKernelGGL((k_find_range<uint64_t, false, USE_FTAB>), grid, block, 0, st, ix, seqs, off, N, lo, hi, ssamp, sel, nsel);
+        if (toe) hipLaunchKernelGGL((k_find_range<uint64_t, true, USE_FTAB>), grid, block, lds, st, ix, seqs, off, N, lo, hi, ssamp, sel, nsel);
+        else hipLaunchKernelGGL((k_find_range<uint64_t, false, USE_FTAB>), grid, block, lds, st, ix, seqs, off, N, lo, hi, ssamp, sel, nsel);
     }
     return static_cast<int>(hipGetLastError());
 }

@@ -66,8 +66,9 @@ def test_loader_matches_oracle_reader(small_host, small_orc):
 
 def test_two_step_tables_built(small_host):
     i = small_host.info()
-    assert i.kmer_steps == 4 and i.kmer_symbols == 4
+    assert i.kmer_steps == 5 and i.kmer_symbols == 4
     assert 0 < i.pair_runs <= 2 * i.r and i.pair_runs <= i.triple_runs <= 3 * i.r and i.triple_runs <= i.quad_runs <= 4 * i.r
+    assert i.quad_runs <= i.quint_runs <= 5 * i.r
 
 
 def test_greedy_seeding_fixture(data_dir):

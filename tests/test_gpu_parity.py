@@ -151,7 +151,7 @@ def synth():
 
 
 @pytest.mark.parametrize("pos_bytes,rshift,pshift,ksteps",
-                         [(0, -1, -1, 4), (0, -1, -1, 3), (0, -1, -1, 2), (0, -1, -1, 1), (8, -1, -1, 4), (4, 0, 0, 2),
+                         [(0, -1, -1, 5), (8, 3, 3, 5), (0, -1, -1, 4), (0, -1, -1, 3), (0, -1, -1, 2), (0, -1, -1, 1), (8, -1, -1, 4), (4, 0, 0, 2),
                           (8, 3, 2, 1), (4, 8, 8, 3), (8, 8, 7, 4), (4, 5, 6, 1), (4, 2, 2, 4)])
 @pytest.mark.parametrize("packed", [0, 2])
 def test_synth_all_paths(synth, pos_bytes, rshift, pshift, ksteps, packed, request):
@@ -167,11 +167,11 @@ def test_synth_all_paths(synth, pos_bytes, rshift, pshift, ksteps, packed, reque
     finally:
         for o_ in (capi.OPT_POS_BYTES, capi.OPT_RANK_BUCKET_SHIFT, capi.OPT_PHI_BUCKET_SHIFT):
             ra.set_default_option(o_, 0 if o_ == capi.OPT_POS_BYTES else -1)
-        ra.set_default_option(capi.OPT_KMER_STEPS, 4)
+        ra.set_default_option(capi.OPT_KMER_STEPS, 5)
     o = orc.Oracle.from_runs(S.heads, S.lens, S.ssa, S.esa)
     assert rb.info().pos_bytes == (pos_bytes or 4)
     assert rb.info().kmer_steps == ksteps and rb.info().kmer_symbols == (4 if ksteps > 1 else 0)
-    assert (rb.info().quad_runs > 0) == (ksteps == 4)
+    assert (rb.info().quad_runs > 0) == (ksteps >= 4) and (rb.info().quint_runs > 0) == (ksteps == 5)
     reads = S.sample_reads(3000, 60, seed=5, sub_rate=0.15, ragged=True)
     reads += [b"", b"A", b"N", b"ACGTN", b"NACGT", b"ACNGT", b"AC", b"ACG", b"acgt", bytes([1]), bytes([255]) * 3, bytes([0]),
               S.text[:500].tobytes(), S.text[:501].tobytes(), b"A" + bytes([1]), bytes([1]) + b"A",
@@ -271,7 +271,7 @@ def test_marker_seeds_synth(synth):
         _check_marker_seeds(rb, o, reads, wsize, 1000, ftab_k=K)
         differs += any(o.markers_greedy_seeding(q, wsize, 1000, K) != o.markers_greedy_seeding(q, wsize, 1000) for q in reads[:300])
     assert differs >= 1   # the ftab variant really is a different seeding (k-mer misses restart further left)
-    for ks in (1, 2, 3):
+    for ks in (1, 2, 3, 4):
         capi.set_default_option(capi.OPT_KMER_STEPS, ks)
         try:
             rb2 = ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0)
@@ -280,7 +280,7 @@ def test_marker_seeds_synth(synth):
             _check_marker_seeds(rb2, o, reads[:400], 10, 1000, ftab_k=7)
             rb2.close()
         finally:
-            capi.set_default_option(capi.OPT_KMER_STEPS, 4)
+            capi.set_default_option(capi.OPT_KMER_STEPS, 5)
     rb.close()
     o.close()
 
@@ -783,7 +783,7 @@ def test_midscale_pangenome_all_queries():
     n, unit, H, L = info["n"], info["unit"], info["H"], info["L"]
     rb = ra.RowBowt.from_runs(inp["heads"], inp["lens"], inp["ssa"], inp["esa"], device=0)
     o = orc.Oracle.from_runs(inp["heads"], inp["lens"], inp["ssa"], inp["esa"])
-    assert rb.info().kmer_steps == 4 and rb.info().kmer_symbols == 4
+    assert rb.info().kmer_steps == 5 and rb.info().kmer_symbols == 4
     # marker array like small.fa.mab: rows whose suffix starts within w bases before a variant site
     w = 10
     tcpu = text.cpu().numpy()
@@ -865,7 +865,7 @@ def test_greedy_seeding_vs_oracle(synth, ksteps):
     try:
         rb = ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0)
     finally:
-        ra.set_default_option(capi.OPT_KMER_STEPS, 4)
+        ra.set_default_option(capi.OPT_KMER_STEPS, 5)
     o = orc.Oracle.from_runs(S.heads, S.lens, S.ssa, S.esa)
     rng = np.random.default_rng(17)
     reads = []
@@ -952,7 +952,7 @@ def test_hbm_budget_drops_kmer_levels(synth):
     want = o.find_range_w_toehold_batch(seqs, off)
     rb = ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0)
     full = rb.info().hbm_bytes
-    assert rb.info().kmer_steps == 4
+    assert rb.info().kmer_steps == 5
     rb.close()
     seen = set()
     for frac in (0.7, 0.3, 0.08, 0.02):
@@ -969,7 +969,7 @@ def test_hbm_budget_drops_kmer_levels(synth):
         got = rb.find_range_w_toehold(seqs, off)
         assert all((g == w).all() for g, w in zip(got, want))
         rb.close()
-    assert len(seen) >= 2 and min(seen) < 4
+    assert len(seen) >= 2 and min(seen) < 5
     o.close()
 
 

@@ -123,7 +123,7 @@ int main(int argc, char** argv) {
             }
             if (!ok) continue;
             RawTsa t; tsa_from_samples(g.n, g.R, ssa.data(), esa.data(), t);
-            HostIndex ix; FlattenOptions o; o.kmer_steps = 1 + static_cast<int>(rnd(4));
+            HostIndex ix; FlattenOptions o; o.kmer_steps = 1 + static_cast<int>(rnd(5));
             if (flatten(g, &t, o, ix) == 0) ++built;
         }
         std::printf("garbage built %d\n", built);
