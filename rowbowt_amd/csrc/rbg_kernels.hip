@@ -460,19 +460,20 @@ struct BitStream {
 // read made of major symbols only (ftab word, then min(kmer_steps, remaining) symbols per gather),
 // so ranges and toeholds are identical; flagged reads are left to the byte kernel (sel list).
 template <typename P, bool TOEHOLD>
-__global__ __launch_bounds__(256, 8) void k_find_range_packed(const DevIndex ix, const uint2 *__restrict__ meta,
+__global__ __launch_bounds__(1024, 8) void k_find_range_packed(const DevIndex ix, const uint2 *__restrict__ meta,
                                                            const uint4 *__restrict__ chunks, const uint64_t N,
                                                            uint64_t *__restrict__ lo_out, uint64_t *__restrict__ hi_out,
                                                            uint64_t *__restrict__ ss_out) {
     __shared__ uint8_t s_lut[256];
     __shared__ uint8_t s_lut2[256];
     __shared__ uint8_t s_mslot[4];
-    __shared__ DevSym s_tab[kTabMax];
-    stage_tables(ix, s_tab, s_lut, s_lut2);
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    DevSym *s_tab = reinterpret_cast<DevSym *>(s_dyn);
+    stage_tables(ix, s_tab, s_lut, s_lut2, true);
     for (int t = threadIdx.x; t < 256; t += blockDim.x)
         if (s_lut2[t] != 0xFFu) s_mslot[s_lut2[t] & 3u] = s_lut[t];  // major index -> symbol slot
     __syncthreads();
-    const uint32_t ksteps = ix.kmer_steps < 4 ? ix.kmer_steps : 4;  // this kernel stages up to the 4-mer level
+    const uint32_t ksteps = ix.kmer_steps;
 
     unsigned long long c_reads = 0, c_matched = 0, c_occ = 0;
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
@@ -539,7 +540,7 @@ __global__ __launch_bounds__(256, 8) void k_find_range_packed(const DevIndex ix,
                 if (slot < static_cast<uint32_t>(kLdsSyms)) { const DevSym Sc = s_tab[slot]; ok = step(Sc, 1u, slot); }
                 else ok = step(ix.syms[slot], 1u, kHbmRec | slot);
             } else {
-                const uint32_t idx = (a == 4 ? kOff4 : a == 3 ? kOff3 : kOff2) + v;
+                const uint32_t idx = (a == 5 ? kOff5 : a == 4 ? kOff4 : a == 3 ? kOff3 : kOff2) + v;
                 const DevSym Sc = s_tab[idx];
                 ok = step(Sc, a, idx);
             }
@@ -875,17 +876,19 @@ __device__ __forceinline__ bool lf_w_loc(const DevSym &S, uint32_t adv, uint64_t
 }
 
 template <typename P>
-__global__ __launch_bounds__(256) void k_greedy_seed(const DevIndex ix, const uint8_t *__restrict__ seqs,
+__global__ __launch_bounds__(1024) void k_greedy_seed(const DevIndex ix, const uint8_t *__restrict__ seqs,
                                                      const uint64_t *__restrict__ off, const uint64_t N,
                                                      const uint64_t min_length, uint64_t *__restrict__ lo_out,
                                                      uint64_t *__restrict__ hi_out, uint64_t *__restrict__ qs_out,
-                                                     uint64_t *__restrict__ qe_out, uint64_t *__restrict__ ss_out) {
+                                                     uint64_t *__restrict__ qe_out, uint64_t *__restrict__ ss_out,
+                                                     const uint32_t max_k) {
     __shared__ uint8_t s_lut[256];
     __shared__ uint8_t s_lut2[256];
-    __shared__ DevSym s_tab[kTabMax];
-    stage_tables(ix, s_tab, s_lut, s_lut2);
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    DevSym *s_tab = reinterpret_cast<DevSym *>(s_dyn);
+    const uint32_t ksteps = ix.kmer_steps < max_k ? ix.kmer_steps : max_k;  // deepest level staged (the launcher sized the LDS for it)
+    stage_tables(ix, s_tab, s_lut, s_lut2, ksteps >= 5);
     const uint32_t M = ix.nmajor;
-    const uint32_t ksteps = ix.kmer_steps < 4 ? ix.kmer_steps : 4;  // this kernel stages up to the 4-mer level
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
     for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < N; i += stride) {
         const uint64_t beg = off[i], m = off[i + 1] - beg;
@@ -918,7 +921,14 @@ __global__ __launch_bounds__(256) void k_greedy_seed(const DevIndex ix, const ui
                     idx = kOff3 + (m2 * M + m1) * M + m0;
                     if (ksteps >= 4 && cap >= 4) {
                         const uint32_t m3 = s_lut2[rd.at(p - 3)];
-                        if (m3 != 0xFFu) { adv = 4; idx = kOff4 + ((m3 * M + m2) * M + m1) * M + m0; }
+                        if (m3 != 0xFFu) {
+                            adv = 4;
+                            idx = kOff4 + ((m3 * M + m2) * M + m1) * M + m0;
+                            if (ksteps >= 5 && cap >= 5) {
+                                const uint32_t m4 = s_lut2[rd.at(p - 4)];
+                                if (m4 != 0xFFu) { adv = 5; idx = kOff5 + (((m4 * M + m3) * M + m2) * M + m1) * M + m0; }
+                            }
+                        }
                     }
                 }
             }
@@ -965,22 +975,17 @@ __global__ __launch_bounds__(256) void k_greedy_seed(const DevIndex ix, const ui
                 if (lf1(c)) on_ok(1u); else on_fail();
                 continue;
             }
-            // the range died inside q[j-len, j): two more gathers say where (lo/hi/k are untouched by a failed step)
-            if (len == 2) {
-                if (lf1(c)) { on_ok(1u); on_fail(); } else on_fail();
-            } else {
+            // the range died inside q[j-len, j) (lo/hi/k are untouched by a failed step): halve the window
+            // until one symbol is left -- at most three more gathers -- that symbol is the failing base
+            while (len > 1) {
+                const uint32_t half = len / 2;
+                const uint64_t p2 = beg + j - 1;
+                const uint32_t c2 = rd.at(p2);
                 uint32_t l2;
-                const bool first_part = len == 4 ? lfk(p, c, 2, &l2) : lf1(c);
-                const uint32_t took = len == 4 ? 2u : 1u;
-                if (first_part) {
-                    on_ok(took);  // then exactly one of the next two symbols fails
-                    if (lf1(rd.at(beg + j - 1))) { on_ok(1u); on_fail(); } else on_fail();
-                } else if (len == 4) {
-                    if (lf1(c)) { on_ok(1u); on_fail(); } else on_fail();
-                } else {
-                    on_fail();
-                }
+                const bool ok2 = half >= 2 ? lfk(p2, c2, half, &l2) : lf1(c2);
+                if (ok2) { on_ok(half); len -= half; } else len = half;
             }
+            on_fail();
         }
         if (ei >= min_length && ei > b_len) { b_len = ei; b_lo = plo; b_hi = phi; b_qs = 0; b_qe = ei; b_k = pk; }  // :252-254
         lo_out[i] = b_lo;
@@ -1001,19 +1006,20 @@ __global__ __launch_bounds__(256) void k_greedy_seed(const DevIndex ix, const ui
 // ftab_k symbols from the device state table; a k-mer step that comes back empty is narrowed down with
 // two more gathers so the failing base is the reference's.
 template <typename P, bool FILL>
-__global__ __launch_bounds__(256) void k_marker_seeds(const DevIndex ix, const uint8_t *__restrict__ seqs,
+__global__ __launch_bounds__(1024) void k_marker_seeds(const DevIndex ix, const uint8_t *__restrict__ seqs,
                                                       const uint64_t *__restrict__ off, const uint64_t N,
                                                       const uint64_t wsize, const uint64_t max_range, const uint64_t ftab_k,
                                                       uint64_t *__restrict__ seed_cnt, uint64_t *__restrict__ mk_cnt,
                                                       const uint64_t *__restrict__ seed_off,
                                                       const uint64_t *__restrict__ mk_off,
-                                                      uint64_t *__restrict__ seeds, uint64_t *__restrict__ mk) {
+                                                      uint64_t *__restrict__ seeds, uint64_t *__restrict__ mk, const uint32_t max_k) {
     __shared__ uint8_t s_lut[256];
     __shared__ uint8_t s_lut2[256];
-    __shared__ DevSym s_tab[kTabMax];
-    stage_tables(ix, s_tab, s_lut, s_lut2);
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    DevSym *s_tab = reinterpret_cast<DevSym *>(s_dyn);
+    const uint32_t ksteps = ix.kmer_steps < max_k ? ix.kmer_steps : max_k;  // deepest level staged (the launcher sized the LDS for it)
+    stage_tables(ix, s_tab, s_lut, s_lut2, ksteps >= 5);
     const uint32_t M = ix.nmajor;
-    const uint32_t ksteps = ix.kmer_steps < 4 ? ix.kmer_steps : 4;  // this kernel stages up to the 4-mer level
     if (!FILL && blockIdx.x == 0 && threadIdx.x == 0) { seed_cnt[0] = 0; mk_cnt[0] = 0; }
     const bool have_ma = ix.mk_nruns != 0;
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
@@ -1074,7 +1080,14 @@ __global__ __launch_bounds__(256) void k_marker_seeds(const DevIndex ix, const u
                     idx = kOff3 + (m2 * M + m1) * M + m0;
                     if (ksteps >= 4 && cap >= 4) {
                         const uint32_t m3 = s_lut2[rd.at(p - 3)];
-                        if (m3 != 0xFFu) { adv = 4; idx = kOff4 + ((m3 * M + m2) * M + m1) * M + m0; }
+                        if (m3 != 0xFFu) {
+                            adv = 4;
+                            idx = kOff4 + ((m3 * M + m2) * M + m1) * M + m0;
+                            if (ksteps >= 5 && cap >= 5) {
+                                const uint32_t m4 = s_lut2[rd.at(p - 4)];
+                                if (m4 != 0xFFu) { adv = 5; idx = kOff5 + (((m4 * M + m3) * M + m2) * M + m1) * M + m0; }
+                            }
+                        }
                     }
                 }
             }
@@ -1204,22 +1217,17 @@ __global__ __launch_bounds__(256) void k_marker_seeds(const DevIndex ix, const u
                 if (lf1(c)) on_ok(1u); else on_fail();
                 continue;
             }
-            // the range died inside q[j-len, j): two more gathers say where (lo/hi are untouched)
-            if (len == 2) {
-                if (lf1(c)) { on_ok(1u); on_fail(); } else on_fail();
-            } else {
+            // the range died inside q[j-len, j) (lo/hi are untouched by a failed step): halve the window until
+            // one symbol is left -- at most three more gathers -- that symbol is the failing base
+            while (len > 1) {
+                const uint32_t half = len / 2;
+                const uint64_t p2 = beg + j - 1;
+                const uint32_t c2 = rd.at(p2);
                 uint32_t l2;
-                const bool first_two = len == 4 ? lfk(p, c, 2, &l2) : lf1(c);
-                const uint32_t took = len == 4 ? 2u : 1u;
-                if (first_two) {
-                    on_ok(took);                      // then exactly one of the next two symbols fails
-                    if (lf1(rd.at(beg + j - 1))) { on_ok(1u); on_fail(); } else on_fail();
-                } else if (len == 4) {
-                    if (lf1(c)) { on_ok(1u); on_fail(); } else on_fail();
-                } else {
-                    on_fail();
-                }
+                const bool ok2 = half >= 2 ? lfk(p2, c2, half, &l2) : lf1(c2);
+                if (ok2) { on_ok(half); len -= half; } else len = half;
             }
+            on_fail();
         }
         if (hi >= lo && seed_ei >= wsize) update_mbuf(lo, hi);   // :478-480 (m-i == 0)
         emit(lo, hi, 0, seed_ei);                                // :481
@@ -1269,6 +1277,34 @@ int grid_for(const LaunchCfg &cfg, uint64_t N) {
     return static_cast<int>(blocks);
 }
 
+
+// Launch geometry of the kernels that stage the k-mer records in dynamic LDS: 17 KB and the configured
+// workgroup size up to the 4-mer level; 66 KB with the 5-mer level, then 1024-thread workgroups so that
+// two of them still give 8 waves per SIMD.  The first launch of a kernel with more than 64 KB of dynamic
+// LDS has to raise its limit.
+// The seeding kernels (k_greedy_seed, k_marker_seeds) need more registers per lane; with the 66 KB table and
+// 1024-thread workgroups they drop to 4 waves per SIMD and lose more than the fifth symbol gains
+// (k_marker_seeds 47-50 -> 52 ms per 10M reads): they stage the levels up to 4.
+constexpr uint32_t kSeedKmerLevel = 4;
+
+struct KmerLaunch {
+    dim3 grid, block;
+    size_t lds;
+};
+template <typename Kernel>
+KmerLaunch kmer_launch(const DevIndex &ix, const LaunchCfg &cfg, uint64_t N, Kernel kernel, int grid_cap = 0, uint32_t max_k = 5) {
+    const bool five = ix.kmer_steps >= 5 && max_k >= 5;
+    LaunchCfg c = cfg;
+    if (five) { c.block_threads = 1024; c.max_blocks = cfg.max_blocks > 0 ? std::max(1, cfg.max_blocks / 4) : 256 * 8; }
+    KmerLaunch L;
+    int g = grid_for(c, N);
+    if (grid_cap > 0) g = std::min(g, five ? std::max(1, grid_cap / 4) : grid_cap);
+    L.grid = dim3(g);
+    L.block = dim3(c.block_threads);
+    L.lds = static_cast<size_t>(five ? kTab5 : kTabMax) * sizeof(DevSym);
+    if (five) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(L.lds));
+    return L;
+}
 }  // namespace
 
 template <bool USE_FTAB>
@@ -1276,33 +1312,21 @@ int launch_find_range_impl(const DevIndex &ix, const LaunchCfg &cfg, const uint8
                            uint64_t *lo, uint64_t *hi, uint64_t *ssamp, const uint32_t *sel, const uint32_t *nsel, void *stream) {
     if (N == 0) return 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    // with the 5-mer level the record table is 66 KB of LDS: 1024-thread workgroups keep 8 waves per SIMD
-    const bool five = ix.kmer_steps >= 5;
-    LaunchCfg c5 = cfg;
-    if (five) { c5.block_threads = 1024; c5.max_blocks = cfg.max_blocks > 0 ? std::max(1, cfg.max_blocks / 4) : 256 * 8; }
-    const size_t lds = static_cast<size_t>(five ? kTab5 : kTabMax) * sizeof(DevSym);
-    // sel mode: the number of reads is only known on the device; a fixed modest grid loops over it
-    const dim3 grid(sel ? std::min(grid_for(c5, N), five ? 128 : 512) : grid_for(c5, N)), block(c5.block_threads);
     const bool toe = ssamp != nullptr;
-    static bool attr_set = false;  // more than 64 KB of dynamic LDS has to be allowed once per kernel
-    if (five && !attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_find_range<uint32_t, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_find_range<uint32_t, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_find_range<uint64_t, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_find_range<uint64_t, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_find_range<uint32_t, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_find_range<uint32_t, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_find_range<uint64_t, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_find_range<uint64_t, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-        attr_set = true;
-    }
+    // sel mode: the number of reads is only known on the device; a fixed modest grid loops over it
+    const int cap = sel ? 512 : 0;
+#define RBG_LAUNCH_FR(PT, TOE)                                                                                      \
+    do {                                                                                                            \
+        auto kern = k_find_range<PT, TOE, USE_FTAB>;                                                                \
+        const KmerLaunch L = kmer_launch(ix, cfg, N, kern, cap);                                                    \
+        hipLaunchKernelGGL(kern, L.grid, L.block, L.lds, st, ix, seqs, off, N, lo, hi, ssamp, sel, nsel);           \
+    } while (0)
     if (ix.pos_bytes == 4) {
-        if (toe) hipLaunchKernelGGL((k_find_range<uint32_t, true, USE_FTAB>), grid, block, lds, st, ix, seqs, off, N, lo, hi, ssamp, sel, nsel);
-        else hipLaunchKernelGGL((k_find_range<uint32_t, false, USE_FTAB>), grid, block, lds, st, ix, seqs, off, N, lo, hi, ssamp, sel, nsel);
+        if (toe) RBG_LAUNCH_FR(uint32_t, true); else RBG_LAUNCH_FR(uint32_t, false);
     } else {
-        if (toe) hipLaunchKernelGGL((k_find_range<uint64_t, true, USE_FTAB>), grid, block, lds, st, ix, seqs, off, N, lo, hi, ssamp, sel, nsel);
-        else hipLaunchKernelGGL((k_find_range<uint64_t, false, USE_FTAB>), grid, block, lds, st, ix, seqs, off, N, lo, hi, ssamp, sel, nsel);
+        if (toe) RBG_LAUNCH_FR(uint64_t, true); else RBG_LAUNCH_FR(uint64_t, false);
     }
+#undef RBG_LAUNCH_FR
     return static_cast<int>(hipGetLastError());
 }
 
@@ -1371,15 +1395,19 @@ int launch_find_range_packed(const DevIndex &ix, const LaunchCfg &cfg, const voi
     const char *b = static_cast<const char *>(ws);
     const uint2 *meta = reinterpret_cast<const uint2 *>(b + L.meta);
     const uint4 *chunks = reinterpret_cast<const uint4 *>(b + L.chunks);
-    const dim3 grid(grid_for(cfg, N)), block(cfg.block_threads);
     const bool toe = ssamp != nullptr;
+#define RBG_LAUNCH_FRP(PT, TOE)                                                                       \
+    do {                                                                                              \
+        auto kern = k_find_range_packed<PT, TOE>;                                                     \
+        const KmerLaunch L = kmer_launch(ix, cfg, N, kern);                                           \
+        hipLaunchKernelGGL(kern, L.grid, L.block, L.lds, st, ix, meta, chunks, N, lo, hi, ssamp);     \
+    } while (0)
     if (ix.pos_bytes == 4) {
-        if (toe) hipLaunchKernelGGL((k_find_range_packed<uint32_t, true>), grid, block, 0, st, ix, meta, chunks, N, lo, hi, ssamp);
-        else hipLaunchKernelGGL((k_find_range_packed<uint32_t, false>), grid, block, 0, st, ix, meta, chunks, N, lo, hi, ssamp);
+        if (toe) RBG_LAUNCH_FRP(uint32_t, true); else RBG_LAUNCH_FRP(uint32_t, false);
     } else {
-        if (toe) hipLaunchKernelGGL((k_find_range_packed<uint64_t, true>), grid, block, 0, st, ix, meta, chunks, N, lo, hi, ssamp);
-        else hipLaunchKernelGGL((k_find_range_packed<uint64_t, false>), grid, block, 0, st, ix, meta, chunks, N, lo, hi, ssamp);
+        if (toe) RBG_LAUNCH_FRP(uint64_t, true); else RBG_LAUNCH_FRP(uint64_t, false);
     }
+#undef RBG_LAUNCH_FRP
     int rc = static_cast<int>(hipGetLastError());
     if (rc) return rc;
     // the reads the packed form cannot express (a symbol outside the major alphabet)
@@ -1744,11 +1772,15 @@ int launch_marker_seeds_plan(const DevIndex &ix, const LaunchCfg &cfg, const uin
                              uint64_t wsize, uint64_t max_range, uint64_t ftab_k, uint64_t *seed_off, uint64_t *mk_off, void *tmp,
                              size_t tmp_bytes, void *stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const dim3 grid(grid_for(cfg, N)), block(cfg.block_threads);
-    if (ix.pos_bytes == 4)
-        hipLaunchKernelGGL((k_marker_seeds<uint32_t, false>), grid, block, 0, st, ix, seqs, off, N, wsize, max_range, ftab_k, seed_off, mk_off, nullptr, nullptr, nullptr, nullptr);
-    else
-        hipLaunchKernelGGL((k_marker_seeds<uint64_t, false>), grid, block, 0, st, ix, seqs, off, N, wsize, max_range, ftab_k, seed_off, mk_off, nullptr, nullptr, nullptr, nullptr);
+    if (ix.pos_bytes == 4) {
+        auto kern = k_marker_seeds<uint32_t, false>;
+        const KmerLaunch L = kmer_launch(ix, cfg, N, kern, 0, kSeedKmerLevel);
+        hipLaunchKernelGGL(kern, L.grid, L.block, L.lds, st, ix, seqs, off, N, wsize, max_range, ftab_k, seed_off, mk_off, nullptr, nullptr, nullptr, nullptr, kSeedKmerLevel);
+    } else {
+        auto kern = k_marker_seeds<uint64_t, false>;
+        const KmerLaunch L = kmer_launch(ix, cfg, N, kern, 0, kSeedKmerLevel);
+        hipLaunchKernelGGL(kern, L.grid, L.block, L.lds, st, ix, seqs, off, N, wsize, max_range, ftab_k, seed_off, mk_off, nullptr, nullptr, nullptr, nullptr, kSeedKmerLevel);
+    }
     int rc = static_cast<int>(hipGetLastError());
     if (rc) return rc;
     rc = scan_in_place(seed_off + 1, N, tmp, tmp_bytes, st);
@@ -1761,11 +1793,15 @@ int launch_marker_seeds_fill(const DevIndex &ix, const LaunchCfg &cfg, const uin
                              uint64_t *seeds, uint64_t *mk, void *stream) {
     if (N == 0) return 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const dim3 grid(grid_for(cfg, N)), block(cfg.block_threads);
-    if (ix.pos_bytes == 4)
-        hipLaunchKernelGGL((k_marker_seeds<uint32_t, true>), grid, block, 0, st, ix, seqs, off, N, wsize, max_range, ftab_k, nullptr, nullptr, seed_off, mk_off, seeds, mk);
-    else
-        hipLaunchKernelGGL((k_marker_seeds<uint64_t, true>), grid, block, 0, st, ix, seqs, off, N, wsize, max_range, ftab_k, nullptr, nullptr, seed_off, mk_off, seeds, mk);
+    if (ix.pos_bytes == 4) {
+        auto kern = k_marker_seeds<uint32_t, true>;
+        const KmerLaunch L = kmer_launch(ix, cfg, N, kern, 0, kSeedKmerLevel);
+        hipLaunchKernelGGL(kern, L.grid, L.block, L.lds, st, ix, seqs, off, N, wsize, max_range, ftab_k, nullptr, nullptr, seed_off, mk_off, seeds, mk, kSeedKmerLevel);
+    } else {
+        auto kern = k_marker_seeds<uint64_t, true>;
+        const KmerLaunch L = kmer_launch(ix, cfg, N, kern, 0, kSeedKmerLevel);
+        hipLaunchKernelGGL(kern, L.grid, L.block, L.lds, st, ix, seqs, off, N, wsize, max_range, ftab_k, nullptr, nullptr, seed_off, mk_off, seeds, mk, kSeedKmerLevel);
+    }
     return static_cast<int>(hipGetLastError());
 }
 
@@ -1773,9 +1809,15 @@ int launch_greedy_seed(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *
                        uint64_t min_length, uint64_t *lo, uint64_t *hi, uint64_t *qs, uint64_t *qe, uint64_t *ss, void *stream) {
     if (N == 0) return 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const dim3 grid(grid_for(cfg, N)), block(cfg.block_threads);
-    if (ix.pos_bytes == 4) hipLaunchKernelGGL((k_greedy_seed<uint32_t>), grid, block, 0, st, ix, seqs, off, N, min_length, lo, hi, qs, qe, ss);
-    else hipLaunchKernelGGL((k_greedy_seed<uint64_t>), grid, block, 0, st, ix, seqs, off, N, min_length, lo, hi, qs, qe, ss);
+    if (ix.pos_bytes == 4) {
+        auto kern = k_greedy_seed<uint32_t>;
+        const KmerLaunch L = kmer_launch(ix, cfg, N, kern, 0, kSeedKmerLevel);
+        hipLaunchKernelGGL(kern, L.grid, L.block, L.lds, st, ix, seqs, off, N, min_length, lo, hi, qs, qe, ss, kSeedKmerLevel);
+    } else {
+        auto kern = k_greedy_seed<uint64_t>;
+        const KmerLaunch L = kmer_launch(ix, cfg, N, kern, 0, kSeedKmerLevel);
+        hipLaunchKernelGGL(kern, L.grid, L.block, L.lds, st, ix, seqs, off, N, min_length, lo, hi, qs, qe, ss, kSeedKmerLevel);
+    }
     return static_cast<int>(hipGetLastError());
 }
 
