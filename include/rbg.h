@@ -289,10 +289,12 @@ int rbg_counters(rbg_index *, uint64_t out[4]);
 int rbg_counters_reset(rbg_index *);
 
 /* ---- tuning (never changes results) -------------------------------------------------------- */
-/* Process-wide defaults read when an index is built/loaded: BLOCK_THREADS (64, 128, 192 or 256),
+/* Process-wide defaults read when an index is built/loaded: BLOCK_THREADS (64, 128, 192 or 256; the search
+ * kernels use 1024-thread workgroups instead while the 5-mer level is resident),
  * RANK/PHI_BUCKET_SHIFT (-1 = automatic, else 0..8), POS_BYTES (0 = automatic, 4 or 8 to force a width),
  * KMER_STEPS (1..5, default 5: symbols the backward search consumes per gather; 2..5 build the k-mer
- * tables of DESIGN.md 2b; 1 keeps the reference's one-symbol steps only; the deepest levels are dropped
+ * tables of DESIGN.md 2b -- each level is four times the tables of the one before, 218 GB in all for a
+ * 2-Gbase index; 1 keeps the reference's one-symbol steps only; the deepest levels are dropped
  * automatically when the replica would not fit), HBM_BUDGET_MB (0 = three quarters of the free HBM:
  * upper bound for the replica, deciding how many k-mer levels are kept), FTAB_K (-1 = automatic (12),
  * 0 = no ftab, else the word length of the ftab built on the GPU at load time: the state after the
