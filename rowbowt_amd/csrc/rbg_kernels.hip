@@ -6,6 +6,8 @@
 //         toehold update of LF_w_loc (:555-573).
 //  K3     k_locate_fill<P>         phi chains, ToeholdSA::locate_range toehold_sa.hpp:37-49 / phi :56-72.
 //  K4     k_markers_*              MarkerArray::at_range behind RowBowt::markers_at rowbowt.hpp:282-285.
+//  also   k_find_range_markers, k_greedy_seed, k_marker_seeds (windowed / greedy seeding, rowbowt.hpp:222-339, :406-482),
+//         k_pack_reads + k_find_range_packed (opt-in 2-bit reads), k_build_rank_slots / k_build_phi_slots (tables at load).
 //
 // Integer gather kernels: no MFMA (nothing here is a contraction).  The bound is HBM / fabric
 // transactions per LF step, so the layout (rbg_dev.h) makes one rank = ONE aligned 4-word slot
@@ -157,12 +159,12 @@ struct ByteCursor {
     }
 };
 
-// LDS table of symbol / k-mer records: [singles | 2-mers | 3-mers | 4-mers]
+// LDS table of symbol / k-mer records: [singles | 2-mers | 3-mers | 4-mers | 5-mers]
 constexpr int kOff2 = kLdsSyms;
 constexpr int kOff3 = kOff2 + kMaxMajor * kMaxMajor;
 constexpr int kOff4 = kOff3 + kMaxMajor * kMaxMajor * kMaxMajor;
 constexpr int kOff5 = kOff4 + kMaxMajor * kMaxMajor * kMaxMajor * kMaxMajor;
-constexpr int kTabMax = kOff5;                 // statically staged levels: singles .. 4-mers
+constexpr int kTabMax = kOff5;                 // levels up to the 4-mers
 constexpr int kTab5 = kOff5 + kMaxMajor * kMaxMajor * kMaxMajor * kMaxMajor * kMaxMajor;  // with the 5-mers (k_find_range's dynamic LDS)
 constexpr uint32_t kHbmRec = 0x80000000u;  // record reference: symbol slot whose DevSym lives in HBM (ix.syms), not in s_tab
 
@@ -305,7 +307,7 @@ __global__ __launch_bounds__(1024, 8) void k_find_range(const DevIndex ix, const
         while (p > beg) {  // right-to-left over the read (rowbowt.hpp:127-129, :175-181)
             --p;
             const uint32_t c = rd.at(p);
-            // Up to four reference iterations in one gather: when this symbol and its left
+            // Up to five reference iterations in one gather: when this symbol and its left
             // neighbours all have k-mer tables, LF(LF(LF(range,x0),x1),x2) == F3[x2x1x0] + rank3(.),
             // and the toehold after the nested LF_w_loc calls is k-adv if row hi carries the k-mer,
             // else the k-mer run sample.  An empty result is {1,0} whichever of the
@@ -334,7 +336,7 @@ __global__ __launch_bounds__(1024, 8) void k_find_range(const DevIndex ix, const
                 if (slot < static_cast<uint32_t>(kLdsSyms)) { const DevSym Sc = s_tab[slot]; ok = step(Sc, 1u, slot); }
                 else ok = step(ix.syms[slot], 1u, kHbmRec | slot);  // rare symbols: record read from HBM field by field
             } else {
-                // copy the 64-byte record with four wide LDS reads: reading it field by field makes
+                // copy the 48-byte record with three wide LDS reads: reading it field by field makes
                 // every lane hit the same two banks (records are 16 dwords apart)
                 const DevSym Sc = s_tab[idx];
                 ok = step(Sc, adv, idx);
