@@ -291,7 +291,8 @@ int rbg_counters_reset(rbg_index *);
 /* ---- tuning (never changes results) -------------------------------------------------------- */
 /* Process-wide defaults read when an index is built/loaded: BLOCK_THREADS (64, 128, 192 or 256; the search
  * kernels use 1024-thread workgroups instead while the 5-mer level is resident),
- * RANK/PHI_BUCKET_SHIFT (-1 = automatic, else 0..8), POS_BYTES (0 = automatic, 4 or 8 to force a width),
+ * RANK/PHI_BUCKET_SHIFT (-1 = automatic, else 0..8; RANK also 9..12 = wide buckets), DEEP_BUCKET_SHIFT (-1 = like
+ * RANK, else the bucket shift of the 4-mer and deeper tables only, whose runs are sparse), POS_BYTES (0 = automatic, 4 or 8 to force a width),
  * KMER_STEPS (1..5, default 5: symbols the backward search consumes per gather; 2..5 build the k-mer
  * tables of DESIGN.md 2b -- each level is four times the tables of the one before, 218 GB in all for a
  * 2-Gbase index; 1 keeps the reference's one-symbol steps only; the deepest levels are dropped
@@ -304,7 +305,8 @@ int rbg_counters_reset(rbg_index *);
  * stream the pack costs what the packed search saves), 1 = pack batches of >= 4096 reads,
  * 2 = always pack. */
 enum { RBG_OPT_BLOCK_THREADS = 1, RBG_OPT_RANK_BUCKET_SHIFT = 2, RBG_OPT_PHI_BUCKET_SHIFT = 3, RBG_OPT_POS_BYTES = 4,
-       RBG_OPT_KMER_STEPS = 5, RBG_OPT_HBM_BUDGET_MB = 6, RBG_OPT_FTAB_K = 7, RBG_OPT_PACKED_READS = 8 };
+       RBG_OPT_KMER_STEPS = 5, RBG_OPT_HBM_BUDGET_MB = 6, RBG_OPT_FTAB_K = 7, RBG_OPT_PACKED_READS = 8,
+       RBG_OPT_DEEP_BUCKET_SHIFT = 9 };
 int rbg_set_default_option(int opt, int64_t value);
 
 #ifdef __cplusplus

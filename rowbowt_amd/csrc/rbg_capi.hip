@@ -44,6 +44,7 @@ std::atomic<int64_t> g_opt_pos_bytes{0};
 std::atomic<int64_t> g_opt_kmer_steps{5};
 std::atomic<int64_t> g_opt_hbm_budget_mb{0};
 std::atomic<int64_t> g_opt_ftab_k{-1};
+std::atomic<int64_t> g_opt_deep_shift{-1};
 std::atomic<int64_t> g_opt_packed_reads{0};  // host-pointer calls: 0 never pack (default), 1 pack large batches, 2 always pack
 
 #define HIP_TRY(expr)                                                                             \
@@ -407,6 +408,7 @@ int upload(rbg_index *ix) {
 FlattenOptions current_options() {
     FlattenOptions o;
     o.rank_bucket_shift = static_cast<int>(g_opt_rank_shift.load());
+    o.deep_bucket_shift = static_cast<int>(g_opt_deep_shift.load());
     o.phi_bucket_shift = static_cast<int>(g_opt_phi_shift.load());
     o.force_pos_bytes = static_cast<int>(g_opt_pos_bytes.load());
     o.kmer_steps = static_cast<int>(g_opt_kmer_steps.load());
@@ -624,8 +626,11 @@ int rbg_set_default_option(int opt, int64_t value) {
             if (value < 64 || value > 256 || value % 64) return RBG_EARG;  // kernels are built for <= 4 waves per workgroup
             g_opt_block_threads = value; return RBG_OK;
         case RBG_OPT_RANK_BUCKET_SHIFT:
-            if (value < -1 || value > 8) return RBG_EARG;  // slot offsets are 8-bit
+            if (value < -1 || value > 12) return RBG_EARG;  // 8-bit slot offsets up to 8, the wide encoding up to 12
             g_opt_rank_shift = value; return RBG_OK;
+        case RBG_OPT_DEEP_BUCKET_SHIFT:
+            if (value < -1 || value > 12) return RBG_EARG;
+            g_opt_deep_shift = value; return RBG_OK;
         case RBG_OPT_PHI_BUCKET_SHIFT:
             if (value < -1 || value > 8) return RBG_EARG;
             g_opt_phi_shift = value; return RBG_OK;

@@ -35,10 +35,19 @@ struct PhiEnt {
 //   run = off (8 bits, start - B0) | (len - 1) << 8, len clipped to the bucket; absent = 0xFFFF
 //   rank(i) = r0 + min(o, ext) + sum_t clamp(o - off_t, 0, len_t),  o = i - B0
 // cnt == 7 falls back to the run list ent[ord[b] .. ord[b+1]).
+//
+// Wide buckets (8 < shift <= 12, meant for the deep k-mer levels whose runs are sparse: 0.01 run starts per
+// 256 rows at depth 5) keep the 16 bytes but spend them differently, for rank values below 2^40:
+//   r0  = low 32 bits of rank(B0, c)
+//   w1  = rank(B0,c)[39:32] (bits 0-7) | ext (bits 8-20, 0..4096) | cnt (bits 21-23: 0..2; 7 = more than 2)
+//         | prev_is_c (bit 24)
+//   w2  = run0, w3 = run1;   run = off (12 bits) | (len - 1) << 12, absent = 0xFFFFFF
 struct alignas(16) RankSlot {
     uint32_t r0, w1, w2, w3;
 };
 constexpr int kSlotRuns = 4;
+constexpr int kSlotRunsWide = 2;
+constexpr uint32_t kMaxNarrowShift = 8, kMaxWideShift = 12;
 // phi's first level over text positions: phi(i) = (D + i) mod n where D = base - pos (mod n) of
 // the last sampled position strictly before i.  dprev is that D at the bucket begin; d0/d1 belong
 // to the first two sampled positions inside the bucket.

@@ -744,6 +744,7 @@ int compose(const HostIndex &ix, const std::vector<uint32_t> &major_slot, const 
             if (kk > 0) rk = tp.cum[kk - 1] + std::min(i - tp.start[kk - 1], tp.cum[kk] - tp.cum[kk - 1]);
             t.F = tp.F + rk;
             t.shift = opt.rank_bucket_shift >= 0 ? static_cast<uint32_t>(opt.rank_bucket_shift) : auto_shift(ix.n, t.nruns, 1.5);
+            if (depth + 1 >= 4 && opt.deep_bucket_shift >= 0) t.shift = static_cast<uint32_t>(opt.deep_bucket_shift);  // levels of 4-mers and deeper
             if (t.nruns >= 0xFFFFFFF0ull) { rcs[m] = RBG_EARG; return; }
         }
     };
@@ -923,7 +924,7 @@ int flatten(const RawRle &rle, const RawTsa *tsa, const FlattenOptions &opt, Hos
         t.start.push_back(out.n);
         t.cum.push_back(t.total);
         t.shift = opt.rank_bucket_shift >= 0 ? static_cast<uint32_t>(opt.rank_bucket_shift) : auto_shift(out.n, t.nruns, 1.5);
-        if (t.shift > 8) return RBG_EARG;
+        if (t.shift > 12 || (t.shift > 8 && (out.n >> 40))) return RBG_EARG;  // wide buckets carry 40-bit ranks (rbg_dev.h)
     }
     if (tsa) {
         out.has_tsa = true;

@@ -120,7 +120,8 @@ struct HostIndex {
 };
 
 struct FlattenOptions {
-    int rank_bucket_shift = -1;  // <0: automatic (about one run per two buckets)
+    int rank_bucket_shift = -1;  // <0: automatic (about one run per two buckets, at most 8); 9..12 = wide buckets (rbg_dev.h)
+    int deep_bucket_shift = -1;  // >= 0: bucket shift of the 4-mer and deeper levels (their runs are sparse)
     int phi_bucket_shift = -1;
     int force_pos_bytes = 0;     // 0: 4 when n fits, else 8
     int kmer_steps = 5;          // symbols consumed per gather: 1 (reference shape) .. 5

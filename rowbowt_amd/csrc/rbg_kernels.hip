@@ -64,7 +64,34 @@ template <typename P>
 __device__ __forceinline__ uint64_t rank_in_slot(const DevSym &S, const RankSlot &sl, uint64_t b, uint64_t i,
                                                  RankAux *aux) {
     const uint32_t w1 = sl.w1, w2 = sl.w2, w3 = sl.w3;
-    const uint32_t cnt = (w1 >> 9) & 7u;
+    const bool wide = S.shift > kMaxNarrowShift;
+    const uint32_t cnt = wide ? (w1 >> 21) & 7u : (w1 >> 9) & 7u;
+    if (wide && cnt != kSlotOvf) {  // wide-bucket encoding (rbg_dev.h); overflow buckets share the path below
+        const uint32_t o = static_cast<uint32_t>(i - (b << S.shift));
+        const uint32_t ext = (w1 >> 8) & 0x1FFFu;
+        uint32_t add = o < ext ? o : ext;
+        bool in = o ? (o <= ext) : ((w1 >> 24) & 1u);
+        uint32_t nb = 0;
+#define RBG_RUNW(field)                                           \
+    {                                                             \
+        const uint32_t run_ = (field) & 0xFFFFFFu;                \
+        const uint32_t off_ = run_ & 0xFFFu;                      \
+        const uint32_t len_ = (run_ >> 12) + 1u;                  \
+        if (run_ != 0xFFFFFFu && o > off_) {                      \
+            const uint32_t d_ = o - off_;                         \
+            add += d_ < len_ ? d_ : len_;                         \
+            in = in || d_ <= len_;                                \
+            ++nb;                                                 \
+        }                                                         \
+    }
+        RBG_RUNW(w2)
+        RBG_RUNW(w3)
+#undef RBG_RUNW
+        aux->ovf = false;
+        aux->nbefore = nb;
+        aux->inside = in;
+        return (static_cast<uint64_t>(sl.r0) | (static_cast<uint64_t>(w1 & 0xFFu) << 32)) + add;
+    }
     if (cnt == kSlotOvf) {
         const RunEnt<P> *__restrict__ ent = static_cast<const RunEnt<P> *>(S.ent);
         uint64_t a = S.ord[b], z = S.ord[b + 1];
@@ -1457,26 +1484,35 @@ __global__ __launch_bounds__(256) void k_build_rank_slots(const RunEnt<P> *__res
                 if (ps + pl > B0) ext = ps + pl - B0 < S ? ps + pl - B0 : S;
                 prev_is_c = ps + pl >= B0 ? 1 : 0;
             }
-            uint32_t run[kSlotRuns] = {0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu};
+            const bool wide = shift > kMaxNarrowShift;
+            const uint64_t inline_runs = wide ? kSlotRunsWide : kSlotRuns;
+            const uint32_t absent = wide ? 0xFFFFFFu : 0xFFFFu;
+            uint32_t run[kSlotRuns] = {absent, absent, absent, absent};
             uint64_t cnt = 0;
             while (k + cnt < nruns && static_cast<uint64_t>(ent[k + cnt].start) < B0 + S) {
-                if (cnt < static_cast<uint64_t>(kSlotRuns)) {
+                if (cnt < inline_runs) {
                     const uint64_t st = ent[k + cnt].start;
                     const uint64_t off = st - B0;
                     const uint64_t full = static_cast<uint64_t>(ent[k + cnt + 1].cum) - static_cast<uint64_t>(ent[k + cnt].cum);
                     const uint64_t len = full < B0 + S - st ? full : B0 + S - st;
-                    const uint32_t v = static_cast<uint32_t>(off | ((len - 1) << 8));
+                    const uint32_t v = static_cast<uint32_t>(off | ((len - 1) << (wide ? 12 : 8)));
                     if (cnt == 0) run[0] = v; else if (cnt == 1) run[1] = v; else if (cnt == 2) run[2] = v; else run[3] = v;
                 }
                 ++cnt;
             }
             uint32_t code = static_cast<uint32_t>(cnt);
-            if (cnt > static_cast<uint64_t>(kSlotRuns)) { code = kSlotOvf; ++novf; }
+            if (cnt > inline_runs) { code = kSlotOvf; ++novf; }
             RankSlot s;
             s.r0 = static_cast<uint32_t>(r0);
-            s.w1 = static_cast<uint32_t>(ext) | (code << 9) | (static_cast<uint32_t>(prev_is_c) << 12) | (run[0] << 16);
-            s.w2 = run[1] | (run[2] << 16);
-            s.w3 = run[3] | (static_cast<uint32_t>(r0 >> 32) << 16);  // flatten() guarantees n < 2^48
+            if (wide) {  // flatten() guarantees n < 2^40 for wide buckets
+                s.w1 = static_cast<uint32_t>(r0 >> 32) | (static_cast<uint32_t>(ext) << 8) | (code << 21) | (static_cast<uint32_t>(prev_is_c) << 24);
+                s.w2 = run[0];
+                s.w3 = run[1];
+            } else {
+                s.w1 = static_cast<uint32_t>(ext) | (code << 9) | (static_cast<uint32_t>(prev_is_c) << 12) | (run[0] << 16);
+                s.w2 = run[1] | (run[2] << 16);
+                s.w3 = run[3] | (static_cast<uint32_t>(r0 >> 32) << 16);  // flatten() guarantees n < 2^48
+            }
             slots[b] = s;
         }
     }

@@ -151,7 +151,7 @@ def synth():
 
 
 @pytest.mark.parametrize("pos_bytes,rshift,pshift,ksteps",
-                         [(0, -1, -1, 5), (8, 3, 3, 5), (0, -1, -1, 4), (0, -1, -1, 3), (0, -1, -1, 2), (0, -1, -1, 1), (8, -1, -1, 4), (4, 0, 0, 2),
+                         [(0, -1, -1, 5), (8, 3, 3, 5), (0, 9, -1, 5), (0, 12, 4, 4), (8, 10, -1, 2), (4, 11, 8, 1), (0, -1, -1, 4), (0, -1, -1, 3), (0, -1, -1, 2), (0, -1, -1, 1), (8, -1, -1, 4), (4, 0, 0, 2),
                           (8, 3, 2, 1), (4, 8, 8, 3), (8, 8, 7, 4), (4, 5, 6, 1), (4, 2, 2, 4)])
 @pytest.mark.parametrize("packed", [0, 2])
 def test_synth_all_paths(synth, pos_bytes, rshift, pshift, ksteps, packed, request):
@@ -970,6 +970,35 @@ def test_hbm_budget_drops_kmer_levels(synth):
         assert all((g == w).all() for g, w in zip(got, want))
         rb.close()
     assert len(seen) >= 2 and min(seen) < 5
+    o.close()
+
+
+@pytest.mark.parametrize("deep", [9, 10, 12])
+def test_wide_buckets_on_the_deep_levels(synth, deep):
+    """The 4-mer and deeper tables in the wide-bucket encoding (rbg_dev.h): same answers, smaller replica"""
+    S = synth
+    o = orc.Oracle.from_runs(S.heads, S.lens, S.ssa, S.esa)
+    base = ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0)
+    ra.set_default_option(capi.OPT_DEEP_BUCKET_SHIFT, deep)
+    try:
+        rb = ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0)
+    finally:
+        ra.set_default_option(capi.OPT_DEEP_BUCKET_SHIFT, -1)
+    assert rb.info().kmer_steps == 5 and rb.info().hbm_bytes <= base.info().hbm_bytes
+    reads = S.sample_reads(3000, 80, seed=17, sub_rate=0.2, ragged=True) + [b"", b"ACGTN", S.text[:400].tobytes()]
+    seqs, off = ra.pack_reads(reads)
+    lo, hi, k = rb.find_range_w_toehold(seqs, off)
+    wlo, whi, wk = o.find_range_w_toehold_batch(seqs, off)
+    assert (lo == wlo).all() and (hi == whi).all() and (k == wk).all()
+    loc_off, locs = rb.locs_at(lo, hi, k)
+    woff, wlocs = o.locs_at_batch(wlo, whi, wk)
+    assert (loc_off == woff).all() and (locs == wlocs).all()
+    _check_marker_seeds(rb, o, reads[::7], 10, 1000)
+    goff, glocs = rb.find_locs_greedy_seeding(seqs, off, 10)
+    for i in range(0, len(reads), 11):
+        assert glocs[int(goff[i]):int(goff[i + 1])].tolist() == o.greedy_locate(reads[i], 10)[0]
+    rb.close()
+    base.close()
     o.close()
 
 

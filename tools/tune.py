@@ -46,6 +46,8 @@ for cfg in args.configs.split(","):
     ra.set_default_option(capi.OPT_RANK_BUCKET_SHIFT, rs)
     ra.set_default_option(capi.OPT_PHI_BUCKET_SHIFT, ps)
     ra.set_default_option(capi.OPT_BLOCK_THREADS, bt)
+    if os.environ.get("RBG_TUNE_DEEP_SHIFT"):
+        ra.set_default_option(capi.OPT_DEEP_BUCKET_SHIFT, int(os.environ["RBG_TUNE_DEEP_SHIFT"]))
     if os.environ.get("RBG_TUNE_BUDGET_MB"):
         ra.set_default_option(capi.OPT_HBM_BUDGET_MB, int(os.environ["RBG_TUNE_BUDGET_MB"]))
     t0 = time.time()
