@@ -756,6 +756,15 @@ def test_ftab_file_and_cache_only_prefix(data_dir, tmp_path, small, simple_reads
         assert o.find_range(kmer.encode()) == (lo, hi)
         n_kmers += 1
     assert n_kmers > 100 and len(table) <= 30031
+    # -a / --ftab-only (rb_build.cpp:108-109): only the table, from the index already at the output prefix
+    p = subprocess.run([exe, "-a", "-k", "3", "-o", str(out), os.path.join(data_dir, "small.fa")], capture_output=True, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()
+    want3 = ""
+    for kmer in sorted("".join(t) for t in itertools.product("ACGT", repeat=3)):
+        lo, hi = o.find_range(kmer.encode())
+        if lo <= hi:
+            want3 += f"{kmer} {lo} {hi}\n"
+    assert (tmp_path / "built" / "small.ftab").read_text() == want3
     # the CLIs run from a prefix that only has the cache (no .rbwt/.tsa/.mab): same bytes as from the reference's files
     (tmp_path / "built" / "small.docs").write_text("ref 0\nhap1 10010\nhap2 20020\n")
     import shutil
