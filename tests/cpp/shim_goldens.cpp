@@ -113,6 +113,38 @@ int main(int argc, char **argv) {
         EXPECT_EQ(ranges[1], range_t(24205, 24294));
         EXPECT_EQ(qs[1], (std::pair<size_t, size_t>(0, 3)));
     }
+    // LoadRbwtFlag::FT (rowbowt_io.hpp:187): the .ftab written for this index is accepted, its k drives the ftab
+    // variant of the seeding (rowbowt.hpp:430-433), disable_ft()/enable_ft() (:760-766) switch it
+    {
+        const std::string ft = std::string(argv[2]) + ".ftab";
+        EXPECT_EQ(rbg_write_ftab(rb.handle(), 6, ft.c_str()), 0);
+        rb.load_ftab(ft);
+        EXPECT_EQ(rb.ftab_k(), 6u);
+        auto collect = [&](const std::string &q, uint64_t w) {
+            std::vector<std::pair<range_t, std::pair<size_t, size_t>>> v;
+            rb.get_markers_greedy_seeding(q, w, 1000, [&](range_t p, std::pair<size_t, size_t> qq, std::vector<MarkerT>) { v.emplace_back(p, qq); });
+            return v;
+        };
+        auto direct = [&](const std::string &q, uint64_t w, uint64_t k) {
+            const uint64_t off[2] = {0, q.size()};
+            uint64_t so[2], *mk = nullptr;
+            rbg_marker_seed_t *sd = nullptr;
+            EXPECT_EQ(rbg_get_markers_greedy_seeding(rb.handle(), reinterpret_cast<const uint8_t *>(q.data()), off, 1, w, 1000, k, so, &sd, &mk), 0);
+            std::vector<std::pair<range_t, std::pair<size_t, size_t>>> v;
+            for (uint64_t s = 0; s < so[1]; ++s) v.emplace_back(range_t(sd[s].lo, sd[s].hi), std::make_pair(size_t(sd[s].qstart), size_t(sd[s].qend - 1)));
+            rbg_free_buffer(sd);
+            rbg_free_buffer(mk);
+            return v;
+        };
+        for (int i = 0; i < 6; ++i) {
+            EXPECT_EQ(collect(errq[i], 8) == direct(errq[i], 8, 6), true);
+            rb.disable_ft();
+            EXPECT_EQ(collect(errq[i], 8) == direct(errq[i], 8, 0), true);
+            rb.enable_ft();
+        }
+        RB rbf = rbwt::load_rowbowt<>(argv[2], rbwt::LoadRbwtFlag::SA | rbwt::LoadRbwtFlag::FT);
+        EXPECT_EQ(rbf.ftab_k(), 6u);
+    }
     // resolve_offset through a .docs file (rowbowt.hpp:623-625)
     RB rb2 = rbwt::load_rowbowt<>(argv[2], rbwt::LoadRbwtFlag::SA | rbwt::LoadRbwtFlag::DL);
     auto x = rb2.resolve_offset(20306);
