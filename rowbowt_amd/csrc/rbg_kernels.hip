@@ -17,6 +17,9 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <mutex>
+#include <set>
+#include <utility>
 
 #include "rbg_dev.h"
 
@@ -1331,7 +1334,16 @@ KmerLaunch kmer_launch(const DevIndex &ix, const LaunchCfg &cfg, uint64_t N, Ker
     L.grid = dim3(g);
     L.block = dim3(c.block_threads);
     L.lds = static_cast<size_t>(five ? kTab5 : kTabMax) * sizeof(DevSym);
-    if (five) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(L.lds));
+    if (five) {  // once per kernel (and device): later launches only look the pointer up
+        static std::mutex mu;
+        static std::set<std::pair<int, const void *>> raised;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const auto key = std::make_pair(dev, reinterpret_cast<const void *>(kernel));
+        std::lock_guard<std::mutex> g(mu);
+        if (raised.insert(key).second)
+            (void)hipFuncSetAttribute(key.second, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(L.lds));
+    }
     return L;
 }
 }  // namespace
