@@ -301,12 +301,15 @@ int rbg_counters_reset(rbg_index *);
  * 0 = no ftab, else the word length of the ftab built on the GPU at load time: the state after the
  * last FTAB_K symbols of a read is one gather; result-neutral like the reference's ftab,
  * rowbowt.hpp:124-125,726-758).
+ * DENSE_OVERFLOW (1 = default): buckets with more run starts than a slot holds get a two-bytes-per-row table
+ * (512 bytes per such bucket, about 1.2 % on top of the replica) so that their rank is one more load
+ * instead of a search of the run list; 0 = search the run list.
  * PACKED_READS applies to the host-pointer search calls, at call time: 0 = never pack (default: on one
  * stream the pack costs what the packed search saves), 1 = pack batches of >= 4096 reads,
  * 2 = always pack. */
 enum { RBG_OPT_BLOCK_THREADS = 1, RBG_OPT_RANK_BUCKET_SHIFT = 2, RBG_OPT_PHI_BUCKET_SHIFT = 3, RBG_OPT_POS_BYTES = 4,
        RBG_OPT_KMER_STEPS = 5, RBG_OPT_HBM_BUDGET_MB = 6, RBG_OPT_FTAB_K = 7, RBG_OPT_PACKED_READS = 8,
-       RBG_OPT_DEEP_BUCKET_SHIFT = 9 };
+       RBG_OPT_DEEP_BUCKET_SHIFT = 9, RBG_OPT_DENSE_OVERFLOW = 10 };
 int rbg_set_default_option(int opt, int64_t value);
 
 #ifdef __cplusplus

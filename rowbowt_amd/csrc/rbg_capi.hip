@@ -32,6 +32,7 @@ struct rbg_index {
     void *arena = nullptr;       // one allocation holding every table of the replica
     size_t arena_bytes = 0, arena_used = 0;
     uint64_t rank_slots = 0, rank_slots_overflow = 0, phi_slots = 0, phi_slots_overflow = 0;
+    std::vector<DevSym> dense_todo;  // load time only: rank tables whose overflow buckets still need their dense tables
     std::mutex mu;               // guards marker/doc attachment only; queries are lock-free
 };
 
@@ -45,6 +46,7 @@ std::atomic<int64_t> g_opt_kmer_steps{5};
 std::atomic<int64_t> g_opt_hbm_budget_mb{0};
 std::atomic<int64_t> g_opt_ftab_k{-1};
 std::atomic<int64_t> g_opt_deep_shift{-1};
+std::atomic<int64_t> g_opt_dense_overflow{1};
 std::atomic<int64_t> g_opt_packed_reads{0};  // host-pointer calls: 0 never pack (default), 1 pack large batches, 2 always pack
 
 #define HIP_TRY(expr)                                                                             \
@@ -175,7 +177,9 @@ int commit_sym(rbg_index *ix, const SymTable &t, bool with_samples, PreparedSym<
     const uint64_t nb = (ix->host.n >> t.shift) + 2;
     void *slots = nullptr, *ord = nullptr;
     if ((rc = dev_reserve(ix, nb * sizeof(RankSlot), &slots)) || (rc = dev_reserve(ix, nb * sizeof(uint32_t), &ord))) return rc;
-    if (launch_build_rank_slots(sizeof(P), d.ent, t.nruns, ix->host.n, t.shift, slots, static_cast<uint32_t *>(ord), d_overflow, nullptr))
+    const bool dense = g_opt_dense_overflow.load() != 0;
+    if (launch_build_rank_slots(sizeof(P), d.ent, t.nruns, ix->host.n, t.shift, slots, static_cast<uint32_t *>(ord), d_overflow,
+                                dense ? d_overflow + 2 : nullptr, nullptr))
         return RBG_ENODEV;
     d.slots = slots;
     d.ord = static_cast<const uint32_t *>(ord);
@@ -183,6 +187,7 @@ int commit_sym(rbg_index *ix, const SymTable &t, bool with_samples, PreparedSym<
     d.F = t.F;
     d.shift = t.shift;
     d.pad = 0;
+    if (dense) ix->dense_todo.push_back(d);
     return RBG_OK;
 }
 
@@ -211,10 +216,12 @@ int upload_many(rbg_index *ix, const std::vector<SymTable> &tabs, bool with_samp
 template <typename P>
 int upload_tables(rbg_index *ix) {
     HostIndex &h = ix->host;
-    DevBuf d_ovf;  // [0] rank slots, [1] phi slots that overflow their inline entries
-    int rc = d_ovf.alloc(16);
+    DevBuf d_ovf;  // [0] rank slots, [1] phi slots that overflow their inline entries; [2] dense-table space handed out (16-byte units)
+    int rc = d_ovf.alloc(32);
     if (rc) return rc;
-    HIP_TRY(hipMemset(d_ovf.p, 0, 16));
+    HIP_TRY(hipMemset(d_ovf.p, 0, 32));
+    ix->dense_todo.clear();
+    ix->dev.dense = nullptr;
     unsigned long long *ovf = d_ovf.as<unsigned long long>();
     std::vector<DevSym> syms;
     if ((rc = upload_many<P>(ix, h.sym, h.has_tsa, syms, ovf))) return rc;
@@ -273,11 +280,30 @@ int upload_tables(rbg_index *ix) {
         ix->dev.phi_slots = slots;
         ix->dev.phi_ord = static_cast<const uint32_t *>(ord);
     }
-    unsigned long long counts[2] = {0, 0};
+    unsigned long long counts[3] = {0, 0, 0};
     HIP_TRY(hipDeviceSynchronize());  // every table is generated before the first query (and before d_ovf goes away)
-    HIP_TRY(hipMemcpy(counts, d_ovf.p, 16, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(counts, d_ovf.p, 24, hipMemcpyDeviceToHost));
     ix->rank_slots_overflow = counts[0];
     ix->phi_slots_overflow = counts[1];
+    // second pass over the rank tables: now that the number of overflow buckets is known, give each its
+    // dense table (rbg_dev.h).  The slots hold 32-bit offsets in 16-byte units: a pool beyond 64 GB (never seen:
+    // 2.7 GB for the bench index) leaves the run-list search in place, as does an allocation failure.
+    if (counts[2] > 0 && counts[2] < (1ull << 32)) {
+        void *pool = nullptr;
+        const size_t bytes = static_cast<size_t>(counts[2]) * 16 + 64;
+        if (hipMalloc(&pool, bytes) == hipSuccess) {
+            ix->allocs.push_back(pool);
+            ix->hbm_bytes += bytes;
+            for (const DevSym &d : ix->dense_todo)
+                if (launch_fill_dense(sizeof(P), d.ent, h.n, d.shift, d.slots, d.ord, static_cast<uint8_t *>(pool), nullptr)) return RBG_ENODEV;
+            HIP_TRY(hipDeviceSynchronize());
+            ix->dev.dense = static_cast<const uint8_t *>(pool);
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    ix->dense_todo.clear();
+    ix->dense_todo.shrink_to_fit();
     return RBG_OK;
 }
 
@@ -631,6 +657,9 @@ int rbg_set_default_option(int opt, int64_t value) {
         case RBG_OPT_DEEP_BUCKET_SHIFT:
             if (value < -1 || value > 12) return RBG_EARG;
             g_opt_deep_shift = value; return RBG_OK;
+        case RBG_OPT_DENSE_OVERFLOW:
+            if (value != 0 && value != 1) return RBG_EARG;
+            g_opt_dense_overflow = value; return RBG_OK;
         case RBG_OPT_PHI_BUCKET_SHIFT:
             if (value < -1 || value > 8) return RBG_EARG;
             g_opt_phi_shift = value; return RBG_OK;

@@ -34,7 +34,13 @@ struct PhiEnt {
 //   w2  = run1 | run2 << 16,   w3 = run3 | rank(B0,c)[47:32] << 16
 //   run = off (8 bits, start - B0) | (len - 1) << 8, len clipped to the bucket; absent = 0xFFFF
 //   rank(i) = r0 + min(o, ext) + sum_t clamp(o - off_t, 0, len_t),  o = i - B0
-// cnt == 7 falls back to the run list ent[ord[b] .. ord[b+1]).
+// cnt == 7 (an "overflow" bucket): w2 = offset (16-byte units) of the bucket's dense table in
+// DevIndex::dense -- two bytes per row o: rank(B0 + o, c) - r0, and 255 if row B0 + o - 1 holds c, else the
+// number of runs of c that start in [B0, B0 + o) (<= 128) -- so rank, "inside" and the predecessor run's
+// ordinal are one more 2-byte load.  Reads
+// sampled from the text land in these buckets 40x more often than their share of the table (2 % of all
+// ranks on the bench, 72 % of the wave-steps have at least one such lane: DESIGN.md 4).  Without a dense
+// pool (or for wide buckets) the run list ent[ord[b] .. ord[b+1]) is searched.
 //
 // Wide buckets (8 < shift <= 12, meant for the deep k-mer levels whose runs are sparse: 0.01 run starts per
 // 256 rows at depth 5) keep the 16 bytes but spend them differently, for rank values below 2^40:
@@ -113,6 +119,7 @@ struct DevIndex {
     const void *ftab;       // 16-byte entries at 4-byte positions, 32-byte entries at 8-byte positions
     uint32_t ftab_k;
     uint32_t pad3;
+    const uint8_t *dense;   // dense tables of the overflow buckets of every narrow rank table (RankSlot); nullptr = none
 };
 
 struct LaunchCfg {
@@ -134,8 +141,12 @@ size_t locate_order_ws_bytes(uint64_t N);
 int launch_locate_order(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t *k, uint64_t N, void *ws, size_t ws_bytes,
                         void *stream);
 // first-level slot tables from the uploaded run lists (pos_bytes = 4 or 8 selects RunEnt<P> / PhiEnt<P>)
+// dense_cursor (nullable): running total of dense-table space handed to overflow buckets, in 16-byte units
 int launch_build_rank_slots(uint32_t pos_bytes, const void *ent, uint64_t nruns, uint64_t n, uint32_t shift, void *slots,
-                            uint32_t *ord, unsigned long long *overflow, void *stream);
+                            uint32_t *ord, unsigned long long *overflow, unsigned long long *dense_cursor, void *stream);
+// second pass, once the pool of dense_cursor * 16 bytes exists: fills the dense tables of one rank table
+int launch_fill_dense(uint32_t pos_bytes, const void *ent, uint64_t n, uint32_t shift, const void *slots, const uint32_t *ord,
+                      uint8_t *dense, void *stream);
 int launch_build_phi_slots(uint32_t pos_bytes, const void *ent, uint64_t r, uint64_t n, uint32_t shift, void *slots, uint32_t *ord,
                            unsigned long long *overflow, void *stream);
 // packed reads (2 bits per symbol): pack the byte batch once, then search the packed form

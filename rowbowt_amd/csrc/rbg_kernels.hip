@@ -57,15 +57,30 @@ __device__ __forceinline__ SlotT load_slot(const SlotT *p) {
 // *nbefore = # runs of the symbol that start in [B0, i)  (-> ordinal of the predecessor run),
 // *inside  = position i-1 holds the symbol; both feed the toehold update.
 struct RankAux {
-    uint32_t nbefore;
+    uint32_t nbefore;  // overflow bucket: i - B0 instead (the run ordinal is searched only if it is needed)
     bool inside;
     bool ovf;
-    int64_t pred;  // valid when ovf
 };
+
+// # runs of the symbol that start before i, searched in the run list of bucket b (overflow buckets without
+// a dense table only)
+template <typename P>
+__device__ __forceinline__ uint64_t search_runs(const RunEnt<P> *__restrict__ ent, uint64_t a, uint64_t z, uint64_t i) {
+    while (z - a > 4) {
+        const uint64_t mid = a + ((z - a) >> 1);
+        if (static_cast<uint64_t>(ent[mid].start) < i) a = mid + 1; else z = mid;
+    }
+    while (a < z && static_cast<uint64_t>(ent[a].start) < i) ++a;
+    return a;
+}
+template <typename P>
+__device__ __forceinline__ uint64_t runs_before(const DevSym &S, uint64_t b, uint64_t i) {
+    return search_runs<P>(static_cast<const RunEnt<P> *>(S.ent), S.ord[b], S.ord[b + 1], i);
+}
 
 template <typename P>
 __device__ __forceinline__ uint64_t rank_in_slot(const DevSym &S, const RankSlot &sl, uint64_t b, uint64_t i,
-                                                 RankAux *aux) {
+                                                 const uint8_t *__restrict__ dense, RankAux *aux) {
     const uint32_t w1 = sl.w1, w2 = sl.w2, w3 = sl.w3;
     const bool wide = S.shift > kMaxNarrowShift;
     const uint32_t cnt = wide ? (w1 >> 21) & 7u : (w1 >> 9) & 7u;
@@ -96,20 +111,24 @@ __device__ __forceinline__ uint64_t rank_in_slot(const DevSym &S, const RankSlot
         return (static_cast<uint64_t>(sl.r0) | (static_cast<uint64_t>(w1 & 0xFFu) << 32)) + add;
     }
     if (cnt == kSlotOvf) {
-        const RunEnt<P> *__restrict__ ent = static_cast<const RunEnt<P> *>(S.ent);
-        uint64_t a = S.ord[b], z = S.ord[b + 1];
-        while (z - a > 4) {
-            const uint64_t mid = a + ((z - a) >> 1);
-            if (static_cast<uint64_t>(ent[mid].start) < i) a = mid + 1; else z = mid;
+        const uint32_t o = static_cast<uint32_t>(i - (b << S.shift));
+        if (dense && !wide) {
+            // dense bucket (rbg_dev.h): two bytes per row -- rank(B0 + o) - rank(B0), and 255 if position
+            // i-1 holds the symbol, else the number of runs that start in [B0, i)
+            const uint32_t e = reinterpret_cast<const uint16_t *>(dense + (static_cast<uint64_t>(w2) << 4))[o];
+            aux->ovf = false;
+            aux->nbefore = e >> 8;
+            aux->inside = (e >> 8) == 255u;
+            return (static_cast<uint64_t>(sl.r0) | (static_cast<uint64_t>(w3 >> 16) << 32)) + (e & 0xFFu);
         }
-        while (a < z && static_cast<uint64_t>(ent[a].start) < i) ++a;
         aux->ovf = true;
-        aux->nbefore = 0;
-        if (a == 0) { aux->pred = -1; aux->inside = false; return 0; }
+        aux->nbefore = o;
+        const RunEnt<P> *__restrict__ ent = static_cast<const RunEnt<P> *>(S.ent);
+        const uint64_t a = runs_before<P>(S, b, i);
+        if (a == 0) { aux->inside = false; return 0; }
         const RunEnt<P> e = ent[a - 1];
         const uint64_t len = static_cast<uint64_t>(ent[a].cum) - static_cast<uint64_t>(e.cum);
         const uint64_t d = i - static_cast<uint64_t>(e.start);
-        aux->pred = static_cast<int64_t>(a) - 1;
         aux->inside = d <= len;
         return static_cast<uint64_t>(e.cum) + (d < len ? d : len);
     }
@@ -144,25 +163,30 @@ __device__ __forceinline__ uint64_t rank_in_slot(const DevSym &S, const RankSlot
 // both ranks of one LF step (rowbowt.hpp:79,83).  lo and hi+1 usually share a bucket late in the
 // search (the range has narrowed to a few dozen rows), so the step is ONE 4-word load.
 template <typename P>
-__device__ __forceinline__ void rank_pair(const DevSym &S, uint64_t lo, uint64_t hi1, uint64_t *c_before, uint64_t *c_upto,
-                                          uint64_t *bh_out, RankAux *qaux) {
+__device__ __forceinline__ void rank_pair(const DevSym &S, const uint8_t *__restrict__ dense, uint64_t lo, uint64_t hi1,
+                                          uint64_t *c_before, uint64_t *c_upto, uint64_t *bh_out, RankAux *qaux) {
     const RankSlot *__restrict__ slots = static_cast<const RankSlot *>(S.slots);
     const uint64_t bl = lo >> S.shift, bh = hi1 >> S.shift;
     const RankSlot sl = load_slot(slots + bl);
     RankSlot sh = sl;
     if (bh != bl) sh = load_slot(slots + bh);
     RankAux paux;
-    *c_before = rank_in_slot<P>(S, sl, bl, lo, &paux);
-    *c_upto = rank_in_slot<P>(S, sh, bh, hi1, qaux);
+    *c_before = rank_in_slot<P>(S, sl, bl, lo, dense, &paux);
+    *c_upto = rank_in_slot<P>(S, sh, bh, hi1, dense, qaux);
     *bh_out = bh;
+}
+
+// ordinal of the last run of the symbol that starts before the position a RankAux describes
+template <typename P>
+__device__ __forceinline__ uint64_t pred_run(const DevSym &S, uint64_t b, bool ovf, uint32_t v) {
+    return (ovf ? runs_before<P>(S, b, (b << S.shift) + v) : static_cast<uint64_t>(S.ord[b]) + v) - 1;
 }
 
 // samples_last_ of the last run of the symbol that starts before i (LF_w_loc, rowbowt.hpp:563-566);
 // only taken when position i-1 does not hold the symbol, which is the rare case.
 template <typename P>
 __device__ __forceinline__ uint64_t pred_sample(const DevSym &S, uint64_t b, const RankAux &aux) {
-    const uint64_t j = aux.ovf ? static_cast<uint64_t>(aux.pred) : static_cast<uint64_t>(S.ord[b]) + aux.nbefore - 1;
-    return static_cast<uint64_t>(static_cast<const P *>(S.samp)[j]);
+    return static_cast<uint64_t>(static_cast<const P *>(S.samp)[pred_run<P>(S, b, aux.ovf, aux.nbefore)]);
 }
 
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
@@ -275,14 +299,13 @@ __global__ __launch_bounds__(1024, 8) void k_find_range(const DevIndex ix, const
         bool pend = false;
         uint32_t pend_tab = 0;   // which record to re-sample from: s_tab index, or kHbmRec | symbol slot
         uint64_t pend_b = 0;
-        uint32_t pend_v = 0;     // runs before the position inside the bucket (slot path) or the absolute ordinal (overflow path)
+        uint32_t pend_v = 0;     // runs before the position inside the bucket, or (overflow bucket) the position's offset in it
         bool pend_abs = false;
         // the two gathers of a deferred re-sample: run ordinal from `ord`, then the run's sample
         auto resample = [&]() -> uint64_t {
             const DevSym *rec = (pend_tab & kHbmRec) ? ix.syms + (pend_tab & ~kHbmRec) : s_tab + pend_tab;
-            const uint32_t *ord = rec->ord;
             const void *samp = rec->samp;
-            const uint64_t j = pend_abs ? static_cast<uint64_t>(pend_v) : static_cast<uint64_t>(ord[pend_b]) + pend_v - 1;
+            const uint64_t j = pred_run<P>(*rec, pend_b, pend_abs, pend_v);
             return static_cast<uint64_t>(static_cast<const P *>(samp)[j]);
         };
         ByteCursor rd{reinterpret_cast<const uint4 *>(seqs), ~uint64_t(0), make_uint4(0, 0, 0, 0)};
@@ -312,7 +335,7 @@ __global__ __launch_bounds__(1024, 8) void k_find_range(const DevIndex ix, const
         auto step = [&](const DevSym &S, uint32_t adv, uint32_t tab) -> bool {
             RankAux q;
             uint64_t c_before, c_upto, bh;
-            rank_pair<P>(S, lo, hi + 1, &c_before, &c_upto, &bh, &q);      // rowbowt.hpp:79,83
+            rank_pair<P>(S, ix.dense, lo, hi + 1, &c_before, &c_upto, &bh, &q);      // rowbowt.hpp:79,83
             const uint64_t c_inside = c_upto - c_before;
             if (c_inside == 0) return false;                               // rowbowt.hpp:85
             if (TOEHOLD) {
@@ -327,7 +350,7 @@ __global__ __launch_bounds__(1024, 8) void k_find_range(const DevIndex ix, const
                     pend_tab = tab;
                     pend_b = bh;
                     pend_abs = q.ovf;
-                    pend_v = q.ovf ? static_cast<uint32_t>(q.pred) : q.nbefore;
+                    pend_v = q.nbefore;
                 }
             }
             lo = S.F + c_before;           // rowbowt.hpp:86
@@ -522,9 +545,8 @@ __global__ __launch_bounds__(1024, 8) void k_find_range_packed(const DevIndex ix
         bool pend_abs = false;
         auto resample = [&]() -> uint64_t {
             const DevSym *rec = (pend_tab & kHbmRec) ? ix.syms + (pend_tab & ~kHbmRec) : s_tab + pend_tab;
-            const uint32_t *ord = rec->ord;
             const void *samp = rec->samp;
-            const uint64_t j = pend_abs ? static_cast<uint64_t>(pend_v) : static_cast<uint64_t>(ord[pend_b]) + pend_v - 1;
+            const uint64_t j = pred_run<P>(*rec, pend_b, pend_abs, pend_v);
             return static_cast<uint64_t>(static_cast<const P *>(samp)[j]);
         };
         BitStream bs{chunks + mt.x, make_uint4(0, 0, 0, 0), 4u, 0u, 0ull};
@@ -544,7 +566,7 @@ __global__ __launch_bounds__(1024, 8) void k_find_range_packed(const DevIndex ix
         auto step = [&](const DevSym &S, uint32_t adv, uint32_t tab) -> bool {
             RankAux q;
             uint64_t c_before, c_upto, bh;
-            rank_pair<P>(S, lo, hi + 1, &c_before, &c_upto, &bh, &q);      // rowbowt.hpp:79,83
+            rank_pair<P>(S, ix.dense, lo, hi + 1, &c_before, &c_upto, &bh, &q);      // rowbowt.hpp:79,83
             const uint64_t c_inside = c_upto - c_before;
             if (c_inside == 0) return false;                               // rowbowt.hpp:85
             if (TOEHOLD) {                                                 // LF_w_loc, rowbowt.hpp:559-566
@@ -556,7 +578,7 @@ __global__ __launch_bounds__(1024, 8) void k_find_range_packed(const DevIndex ix
                     pend_tab = tab;
                     pend_b = bh;
                     pend_abs = q.ovf;
-                    pend_v = q.ovf ? static_cast<uint32_t>(q.pred) : q.nbefore;
+                    pend_v = q.nbefore;
                 }
             }
             lo = S.F + c_before;           // rowbowt.hpp:86
@@ -854,7 +876,7 @@ __global__ __launch_bounds__(256) void k_find_range_markers(const DevIndex ix, c
                     const DevSym S = slot < static_cast<uint32_t>(kLdsSyms) ? s_sym[slot] : ix.syms[slot];
                     RankAux q;
                     uint64_t c_before, c_upto, bh;
-                    rank_pair<P>(S, lo, hi + 1, &c_before, &c_upto, &bh, &q);
+                    rank_pair<P>(S, ix.dense, lo, hi + 1, &c_before, &c_upto, &bh, &q);
                     const uint64_t c_inside = c_upto - c_before;
                     if (c_inside == 0) { alive = false; break; }
                     lo = S.F + c_before;
@@ -894,10 +916,11 @@ __global__ __launch_bounds__(256) void k_find_range_markers(const DevIndex ix, c
 // the base that ends a seed is skipped.  A k-mer gather is attempted first; when it comes back
 // empty the symbol that actually ends the seed is found with single reference steps.
 template <typename P>
-__device__ __forceinline__ bool lf_w_loc(const DevSym &S, uint32_t adv, uint64_t &lo, uint64_t &hi, uint64_t &k) {
+__device__ __forceinline__ bool lf_w_loc(const DevSym &S, const uint8_t *__restrict__ dense, uint32_t adv, uint64_t &lo, uint64_t &hi,
+                                         uint64_t &k) {
     RankAux q;
     uint64_t c_before, c_upto, bh;
-    rank_pair<P>(S, lo, hi + 1, &c_before, &c_upto, &bh, &q);
+    rank_pair<P>(S, dense, lo, hi + 1, &c_before, &c_upto, &bh, &q);
     const uint64_t c_inside = c_upto - c_before;
     if (c_inside == 0) return false;
     if (q.inside) k = k - adv;
@@ -934,8 +957,8 @@ __global__ __launch_bounds__(1024) void k_greedy_seed(const DevIndex ix, const u
         auto lf1 = [&](uint32_t c) -> bool {  // one reference step (rowbowt.hpp:235); an absent symbol is an empty range (:76)
             const uint32_t slot = s_lut[c];
             if (slot == 0xFFu) return false;
-            if (slot < static_cast<uint32_t>(kLdsSyms)) { const DevSym S = s_tab[slot]; return lf_w_loc<P>(S, 1u, lo, hi, k); }
-            return lf_w_loc<P>(ix.syms[slot], 1u, lo, hi, k);
+            if (slot < static_cast<uint32_t>(kLdsSyms)) { const DevSym S = s_tab[slot]; return lf_w_loc<P>(S, ix.dense, 1u, lo, hi, k); }
+            return lf_w_loc<P>(ix.syms[slot], ix.dense, 1u, lo, hi, k);
         };
         // the longest k-mer (2..min(cap, kmer_steps) symbols, all with k-mer tables) ending at byte p; success
         // is identical to *len nested LF_w_loc calls
@@ -966,7 +989,7 @@ __global__ __launch_bounds__(1024) void k_greedy_seed(const DevIndex ix, const u
             }
             *len = adv;
             const DevSym S = s_tab[idx];
-            return lf_w_loc<P>(S, adv, lo, hi, k);
+            return lf_w_loc<P>(S, ix.dense, adv, lo, hi, k);
         };
         auto on_ok = [&](uint32_t adv) {
             j -= adv;
@@ -1090,7 +1113,7 @@ __global__ __launch_bounds__(1024) void k_marker_seeds(const DevIndex ix, const 
             const DevSym S = slot < static_cast<uint32_t>(kLdsSyms) ? s_tab[slot] : ix.syms[slot];
             RankAux q;
             uint64_t c_before, c_upto, bh;
-            rank_pair<P>(S, lo, hi + 1, &c_before, &c_upto, &bh, &q);
+            rank_pair<P>(S, ix.dense, lo, hi + 1, &c_before, &c_upto, &bh, &q);
             if (c_upto <= c_before) return false;
             lo = S.F + c_before;
             hi = lo + (c_upto - c_before) - 1;
@@ -1127,7 +1150,7 @@ __global__ __launch_bounds__(1024) void k_marker_seeds(const DevIndex ix, const 
             const DevSym S = s_tab[idx];
             RankAux q;
             uint64_t c_before, c_upto, bh;
-            rank_pair<P>(S, lo, hi + 1, &c_before, &c_upto, &bh, &q);
+            rank_pair<P>(S, ix.dense, lo, hi + 1, &c_before, &c_upto, &bh, &q);
             if (c_upto <= c_before) return false;
             lo = S.F + c_before;
             hi = lo + (c_upto - c_before) - 1;
@@ -1285,7 +1308,7 @@ __global__ __launch_bounds__(256) void k_lf(const DevIndex ix, const uint64_t *_
             const DevSym S = ix.syms[slot];
             RankAux q;
             uint64_t c_before, c_upto, bh;
-            rank_pair<P>(S, lo, hi + 1, &c_before, &c_upto, &bh, &q);
+            rank_pair<P>(S, ix.dense, lo, hi + 1, &c_before, &c_upto, &bh, &q);
             if (c_upto > c_before) { nlo = S.F + c_before; nhi = nlo + (c_upto - c_before) - 1; }
         }
         lo_out[i] = nlo;
@@ -1469,7 +1492,8 @@ constexpr int kBuildGroup = 8;
 template <typename P>
 __global__ __launch_bounds__(256) void k_build_rank_slots(const RunEnt<P> *__restrict__ ent, const uint64_t nruns, const uint64_t n,
                                                           const uint32_t shift, RankSlot *__restrict__ slots,
-                                                          uint32_t *__restrict__ ord, unsigned long long *__restrict__ overflow) {
+                                                          uint32_t *__restrict__ ord, unsigned long long *__restrict__ overflow,
+                                                          unsigned long long *__restrict__ dense_cursor) {
     const uint64_t nb = (n >> shift) + 2;
     const uint64_t S = uint64_t(1) << shift;
     const uint64_t ngroups = (nb + kBuildGroup - 1) / kBuildGroup;
@@ -1524,12 +1548,57 @@ __global__ __launch_bounds__(256) void k_build_rank_slots(const RunEnt<P> *__res
                 s.w1 = static_cast<uint32_t>(ext) | (code << 9) | (static_cast<uint32_t>(prev_is_c) << 12) | (run[0] << 16);
                 s.w2 = run[1] | (run[2] << 16);
                 s.w3 = run[3] | (static_cast<uint32_t>(r0 >> 32) << 16);  // flatten() guarantees n < 2^48
+                // overflow bucket: w2 = where its dense table will live (16-byte units; k_fill_dense writes it
+                // once the total is known and the pool exists)
+                if (code == kSlotOvf && dense_cursor)
+                    s.w2 = static_cast<uint32_t>(atomicAdd(dense_cursor, static_cast<unsigned long long>(S < 8 ? 1 : S >> 3)));
             }
             slots[b] = s;
         }
     }
     novf = wave_sum(novf);
     if ((threadIdx.x & (kWave - 1)) == 0 && novf) atomicAdd(overflow, novf);
+}
+
+// Dense tables of the overflow buckets (rbg_dev.h): two bytes per row o -- # of the symbol in [B0, B0 + o), and
+// 255 if row B0 + o - 1 holds the symbol, else # runs of it that start in [B0, B0 + o) (at most 128).
+// One thread per bucket; only the few overflow buckets do any work (0.05-1 % of them).
+template <typename P>
+__global__ __launch_bounds__(256) void k_fill_dense(const RunEnt<P> *__restrict__ ent, const uint64_t n, const uint32_t shift,
+                                                    const RankSlot *__restrict__ slots, const uint32_t *__restrict__ ord,
+                                                    uint8_t *__restrict__ dense) {
+    const uint64_t nb = (n >> shift) + 2;
+    const uint64_t S = uint64_t(1) << shift;
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t b = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; b + 1 < nb; b += stride) {
+        const uint32_t w1 = slots[b].w1;
+        if (((w1 >> 9) & 7u) != kSlotOvf) continue;
+        uint32_t *out = reinterpret_cast<uint32_t *>(dense + (static_cast<uint64_t>(slots[b].w2) << 4));
+        uint64_t k = ord[b];
+        const uint64_t kend = ord[b + 1];
+        const uint64_t B0 = b << shift;
+        uint64_t cur_end = 0;  // end (exclusive) of the last run of the symbol that began at or before the current row
+        if (k > 0) cur_end = static_cast<uint64_t>(ent[k - 1].start) + (static_cast<uint64_t>(ent[k].cum) - static_cast<uint64_t>(ent[k - 1].cum));
+        uint64_t next_start = k < kend ? static_cast<uint64_t>(ent[k].start) : ~uint64_t(0);
+        bool prev_c = (w1 >> 12) & 1u;  // row B0 - 1 holds the symbol
+        uint32_t d = 0, starts = 0;
+        for (uint64_t o = 0; o < S; o += 2) {
+            uint32_t word = 0;
+            for (uint32_t t = 0; t < 2; ++t) {
+                const uint64_t pos = B0 + o + t;
+                word |= ((d & 0xFFu) | ((prev_c ? 255u : starts) << 8)) << (16 * t);
+                if (pos == next_start) {
+                    cur_end = pos + (static_cast<uint64_t>(ent[k + 1].cum) - static_cast<uint64_t>(ent[k].cum));
+                    ++k;
+                    ++starts;
+                    next_start = k < kend ? static_cast<uint64_t>(ent[k].start) : ~uint64_t(0);
+                }
+                prev_c = pos < cur_end;
+                if (prev_c) ++d;
+            }
+            out[o >> 1] = word;
+        }
+    }
 }
 
 template <typename P>
@@ -1580,17 +1649,33 @@ __global__ __launch_bounds__(256) void k_build_phi_slots(const PhiEnt<P> *__rest
 }  // namespace
 
 int launch_build_rank_slots(uint32_t pos_bytes, const void *ent, uint64_t nruns, uint64_t n, uint32_t shift, void *slots,
-                            uint32_t *ord, unsigned long long *overflow, void *stream) {
+                            uint32_t *ord, unsigned long long *overflow, unsigned long long *dense_cursor, void *stream) {
+    if (shift > kMaxNarrowShift) dense_cursor = nullptr;  // wide buckets keep the run-list search
     const uint64_t nb = (n >> shift) + 2;
     const uint64_t groups = (nb + kBuildGroup - 1) / kBuildGroup;
     const int grid = static_cast<int>(std::min<uint64_t>((groups + 255) / 256, 256ull * 64));
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (pos_bytes == 4)
         hipLaunchKernelGGL((k_build_rank_slots<uint32_t>), dim3(grid), dim3(256), 0, st, static_cast<const RunEnt<uint32_t> *>(ent), nruns, n, shift,
-                           static_cast<RankSlot *>(slots), ord, overflow);
+                           static_cast<RankSlot *>(slots), ord, overflow, dense_cursor);
     else
         hipLaunchKernelGGL((k_build_rank_slots<uint64_t>), dim3(grid), dim3(256), 0, st, static_cast<const RunEnt<uint64_t> *>(ent), nruns, n, shift,
-                           static_cast<RankSlot *>(slots), ord, overflow);
+                           static_cast<RankSlot *>(slots), ord, overflow, dense_cursor);
+    return static_cast<int>(hipGetLastError());
+}
+
+int launch_fill_dense(uint32_t pos_bytes, const void *ent, uint64_t n, uint32_t shift, const void *slots, const uint32_t *ord,
+                      uint8_t *dense, void *stream) {
+    if (shift > kMaxNarrowShift) return 0;
+    const uint64_t nb = (n >> shift) + 2;
+    const int grid = static_cast<int>(std::min<uint64_t>((nb + 255) / 256, 256ull * 64));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (pos_bytes == 4)
+        hipLaunchKernelGGL((k_fill_dense<uint32_t>), dim3(grid), dim3(256), 0, st, static_cast<const RunEnt<uint32_t> *>(ent), n, shift,
+                           static_cast<const RankSlot *>(slots), ord, dense);
+    else
+        hipLaunchKernelGGL((k_fill_dense<uint64_t>), dim3(grid), dim3(256), 0, st, static_cast<const RunEnt<uint64_t> *>(ent), n, shift,
+                           static_cast<const RankSlot *>(slots), ord, dense);
     return static_cast<int>(hipGetLastError());
 }
 

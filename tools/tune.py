@@ -8,6 +8,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import rowbowt_amd as ra
 from rowbowt_amd import capi
+if os.environ.get("RBG_TUNE_LIB"):  # A/B of two builds of the library
+    capi._SO = os.path.join(ROOT, "rowbowt_amd", os.environ["RBG_TUNE_LIB"])
 from rowbowt_amd.tools import synth_pangenome as sp
 
 ap = argparse.ArgumentParser()
@@ -48,6 +50,8 @@ for cfg in args.configs.split(","):
     ra.set_default_option(capi.OPT_BLOCK_THREADS, bt)
     if os.environ.get("RBG_TUNE_DEEP_SHIFT"):
         ra.set_default_option(capi.OPT_DEEP_BUCKET_SHIFT, int(os.environ["RBG_TUNE_DEEP_SHIFT"]))
+    if os.environ.get("RBG_TUNE_DENSE"):
+        ra.set_default_option(capi.OPT_DENSE_OVERFLOW, int(os.environ["RBG_TUNE_DENSE"]))
     if os.environ.get("RBG_TUNE_BUDGET_MB"):
         ra.set_default_option(capi.OPT_HBM_BUDGET_MB, int(os.environ["RBG_TUNE_BUDGET_MB"]))
     t0 = time.time()
