@@ -1011,6 +1011,57 @@ def test_wide_buckets_on_the_deep_levels(synth, deep):
     o.close()
 
 
+@pytest.mark.parametrize("rshift", [8, 5, 1])
+@pytest.mark.parametrize("pos_bytes", [4, 8])
+def test_dense_overflow_buckets(rshift, pos_bytes):
+    """Buckets with more run starts than a slot holds (rbg_dev.h): with their dense tables (default) and with
+    the run-list search (RBG_OPT_DENSE_OVERFLOW = 0) the answers are the oracle's.  A near-random text over
+    five symbols puts almost every 256-row bucket of every table in that state."""
+    import naive
+    rng = np.random.default_rng(77)
+    body = rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), size=6000, p=[0.3, 0.25, 0.25, 0.19, 0.01])
+    body[2000:2600] = body[100:700]          # some repetition, so that reads match more than once
+    body[4000:4300] = ord("A")               # and one long run next to the busy rows
+    text = np.concatenate([body, np.array([1], np.uint8)])
+    sa = naive.suffix_array(text)
+    heads, lens, brk = naive.rle(naive.bwt_from_sa(text, sa))
+    ssa, esa = naive.run_samples(sa, brk, len(text))
+    o = orc.Oracle.from_runs(heads, lens, ssa, esa)
+    tb = text.tobytes()
+    reads = [tb[a:a + int(rng.integers(1, 50))] for a in rng.integers(0, len(tb) - 1, size=3000)]
+    reads += [b"", tb[:300], tb[-40:], b"A" * 200, b"AC" * 30]
+    seqs, off = ra.pack_reads(reads)
+    wlo, whi, wk = o.find_range_w_toehold_batch(seqs, off)
+    woff, wlocs = o.locs_at_batch(wlo, whi, wk)
+    sizes = {}
+    for dense in (1, 0):
+        ra.set_default_option(capi.OPT_DENSE_OVERFLOW, dense)
+        ra.set_default_option(capi.OPT_RANK_BUCKET_SHIFT, rshift)
+        ra.set_default_option(capi.OPT_POS_BYTES, pos_bytes)
+        try:
+            rb = ra.RowBowt.from_runs(heads, lens, ssa, esa, device=0)
+        finally:
+            ra.set_default_option(capi.OPT_DENSE_OVERFLOW, 1)
+            ra.set_default_option(capi.OPT_RANK_BUCKET_SHIFT, -1)
+            ra.set_default_option(capi.OPT_POS_BYTES, 0)
+        i = rb.info()
+        sizes[dense] = i.hbm_bytes
+        if rshift == 8:   # (rank_slots counts the 1365 tables of all five k-mer levels, most of them nearly empty here)
+            assert i.rank_slots_overflow >= 60
+        lo, hi, k = rb.find_range_w_toehold(seqs, off)
+        lo2, hi2 = rb.find_range(seqs, off)
+        assert (lo == wlo).all() and (hi == whi).all() and (k == wk).all() and (lo2 == wlo).all() and (hi2 == whi).all()
+        loc_off, locs = rb.locs_at(lo, hi, k)
+        assert (loc_off == woff).all() and (locs == wlocs).all()
+        goff, glocs = rb.find_locs_greedy_seeding(seqs, off, 6)
+        for j in range(0, len(reads), 13):
+            assert glocs[int(goff[j]):int(goff[j + 1])].tolist() == o.greedy_locate(reads[j], 6)[0]
+        _check_marker_seeds(rb, o, reads[::11], 5, 1000)
+        rb.close()
+    assert sizes[1] >= sizes[0]
+    o.close()
+
+
 @pytest.mark.parametrize("fk", [0, -1, 1, 3, 7])
 def test_ftab_is_result_neutral(synth, fk):
     """The device ftab (rowbowt.hpp:124-125, :726-758) changes no answer, whatever its word length; reads
