@@ -404,20 +404,22 @@ int upload(rbg_index *ix) {
     d.ftab = nullptr;
     d.ftab_k = 0;
     int64_t fk = g_opt_ftab_k.load();
-    if (fk < 0) {  // automatic: the longest word <= 12 with nmajor^k <= n/16 (4^12 words x 32 B = 537 MB)
+    if (fk < 0) {  // automatic: the longest word <= 13 with nmajor^k <= n/16 (4^13 words x 16 B = 1.07 GB)
         fk = 0;
         double w = 1;
-        while (d.nmajor >= 2 && fk < 12 && w * d.nmajor <= static_cast<double>(h.n) / 16) { w *= d.nmajor; ++fk; }
+        while (d.nmajor >= 2 && fk < 13 && w * d.nmajor <= static_cast<double>(h.n) / 16) { w *= d.nmajor; ++fk; }
     }
     if (fk > 0 && d.nmajor >= 2) {
         double words = 1;
         for (int64_t t = 0; t < fk; ++t) words *= d.nmajor;
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        // the table plus the scratch of building it (word bytes, offsets, three result arrays)
-        if (words * (32.0 + fk + 40.0) < 0.5 * static_cast<double>(free_b) && words < 4.0e9) {
+        // the table plus the scratch of building it (in chunks) must leave half of the free memory to the queries
+        const size_t entry = h.pos_bytes == 4 ? 16 : 32;
+        if (words < 4.0e9 &&
+            words * static_cast<double>(entry) + static_cast<double>(ftab_build_scratch_bytes(static_cast<uint64_t>(words), static_cast<uint32_t>(fk))) <
+                0.5 * static_cast<double>(free_b)) {
             const uint64_t W = static_cast<uint64_t>(words);
-            const size_t entry = h.pos_bytes == 4 ? 16 : 32;
             void *tab = nullptr;
             HIP_TRY(hipMalloc(&tab, W * entry));
             ix->allocs.push_back(tab);

@@ -177,6 +177,7 @@ int launch_lf(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t *lo, cons
               uint64_t N, uint64_t *lo_out, uint64_t *hi_out, void *stream);
 // fills ix.ftab-shaped table `tab` (nmajor^k entries x 4 u64) by searching every k-symbol word
 int launch_build_ftab(const DevIndex &ix, const LaunchCfg &cfg, uint32_t k, void *tab, void *stream);
+size_t ftab_build_scratch_bytes(uint64_t words, uint32_t k);  // device scratch the build takes besides the table
 int launch_count_from_ranges(const uint64_t *lo, const uint64_t *hi, uint64_t N, uint64_t *count, void *stream);
 
 }  // namespace rbg

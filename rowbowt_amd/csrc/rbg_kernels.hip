@@ -1696,13 +1696,15 @@ int launch_build_phi_slots(uint32_t pos_bytes, const void *ent, uint64_t r, uint
 
 // ---- ftab construction: search every word of k major symbols with the step kernel itself ---------
 namespace {
-__global__ __launch_bounds__(256) void k_ftab_words(const DevIndex ix, const uint32_t k, const uint64_t W, uint8_t *__restrict__ seqs,
-                                                    uint64_t *__restrict__ off, const uint8_t *__restrict__ major_byte) {
+// words base .. base + W of the table, as a batch of W reads
+__global__ __launch_bounds__(256) void k_ftab_words(const DevIndex ix, const uint32_t k, const uint64_t base, const uint64_t W,
+                                                    uint8_t *__restrict__ seqs, uint64_t *__restrict__ off,
+                                                    const uint8_t *__restrict__ major_byte) {
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
     for (uint64_t w = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; w <= W; w += stride) {
         off[w] = w * k;
         if (w == W) break;
-        uint64_t x = w;
+        uint64_t x = base + w;
         for (uint32_t t = k; t > 0; --t) {  // least significant digit = rightmost symbol
             seqs[w * k + t - 1] = major_byte[x % ix.nmajor];
             x /= ix.nmajor;
@@ -1727,17 +1729,25 @@ __global__ __launch_bounds__(256) void k_ftab_pack(const uint64_t W, const uint6
 }
 }  // namespace
 
+// scratch of one build chunk: word bytes, offsets, three result arrays
+constexpr uint64_t kFtabChunk = uint64_t(1) << 26;
+size_t ftab_build_scratch_bytes(uint64_t words, uint32_t k) {
+    const uint64_t C = std::min<uint64_t>(words, kFtabChunk);
+    return static_cast<size_t>(C * (k + 32ull) + 1024);
+}
+
 int launch_build_ftab(const DevIndex &ix, const LaunchCfg &cfg, uint32_t k, void *tab, void *stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     uint64_t W = 1;
     for (uint32_t t = 0; t < k; ++t) W *= ix.nmajor;
+    const uint64_t C = std::min<uint64_t>(W, kFtabChunk);  // words per pass: bounds the scratch whatever the table size
     uint8_t *seqs = nullptr, *mb = nullptr;
     uint64_t *off = nullptr, *lo = nullptr, *hi = nullptr, *ss = nullptr;
-    hipError_t e = hipMalloc(&seqs, W * k + 64);
-    if (e == hipSuccess) e = hipMalloc(&off, (W + 1) * 8);
-    if (e == hipSuccess) e = hipMalloc(&lo, W * 8);
-    if (e == hipSuccess) e = hipMalloc(&hi, W * 8);
-    if (e == hipSuccess && ix.has_tsa) e = hipMalloc(&ss, W * 8);
+    hipError_t e = hipMalloc(&seqs, C * k + 64);
+    if (e == hipSuccess) e = hipMalloc(&off, (C + 1) * 8);
+    if (e == hipSuccess) e = hipMalloc(&lo, C * 8);
+    if (e == hipSuccess) e = hipMalloc(&hi, C * 8);
+    if (e == hipSuccess && ix.has_tsa) e = hipMalloc(&ss, C * 8);
     if (e == hipSuccess) e = hipMalloc(&mb, 256);
     if (e == hipSuccess) {
         // major index -> byte, recovered from lut2 on the host side of the caller would need another
@@ -1749,20 +1759,23 @@ int launch_build_ftab(const DevIndex &ix, const LaunchCfg &cfg, uint32_t k, void
         if (e == hipSuccess) e = hipMemcpy(mb, inv, 256, hipMemcpyHostToDevice);
     }
     int rc = static_cast<int>(e);
-    if (!rc) {
-        DevIndex plain = ix;  // the words are searched WITHOUT a table
-        plain.ftab = nullptr;
-        plain.ftab_k = 0;
-        hipLaunchKernelGGL(k_ftab_words, dim3(grid_for(cfg, W + 1)), dim3(256), 0, st, plain, k, W, seqs, off, mb);
+    DevIndex plain = ix;  // the words are searched WITHOUT a table
+    plain.ftab = nullptr;
+    plain.ftab_k = 0;
+    const size_t entry = ix.pos_bytes == 4 ? 16 : 32;
+    for (uint64_t base = 0; !rc && base < W; base += C) {
+        const uint64_t cnt = std::min<uint64_t>(C, W - base);
+        void *dst = static_cast<char *>(tab) + base * entry;
+        hipLaunchKernelGGL(k_ftab_words, dim3(grid_for(cfg, cnt + 1)), dim3(256), 0, st, plain, k, base, cnt, seqs, off, mb);
         rc = static_cast<int>(hipGetLastError());
-        if (!rc) rc = launch_find_range(plain, cfg, seqs, off, W, lo, hi, ss, st);
+        if (!rc) rc = launch_find_range(plain, cfg, seqs, off, cnt, lo, hi, ss, st);
         if (!rc) {
-            if (ix.pos_bytes == 4) hipLaunchKernelGGL(k_ftab_pack<uint32_t>, dim3(grid_for(cfg, W)), dim3(256), 0, st, W, lo, hi, ss, tab);
-            else hipLaunchKernelGGL(k_ftab_pack<uint64_t>, dim3(grid_for(cfg, W)), dim3(256), 0, st, W, lo, hi, ss, tab);
+            if (ix.pos_bytes == 4) hipLaunchKernelGGL(k_ftab_pack<uint32_t>, dim3(grid_for(cfg, cnt)), dim3(256), 0, st, cnt, lo, hi, ss, dst);
+            else hipLaunchKernelGGL(k_ftab_pack<uint64_t>, dim3(grid_for(cfg, cnt)), dim3(256), 0, st, cnt, lo, hi, ss, dst);
             rc = static_cast<int>(hipGetLastError());
         }
-        if (!rc) rc = static_cast<int>(hipStreamSynchronize(st));
     }
+    if (!rc) rc = static_cast<int>(hipStreamSynchronize(st));
     (void)hipFree(seqs); (void)hipFree(off); (void)hipFree(lo); (void)hipFree(hi); (void)hipFree(ss); (void)hipFree(mb);
     return rc;
 }
