@@ -357,13 +357,14 @@ def main():
         ach = kernels[dom]["alg_bytes"] / (kernels[dom]["ms"] * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
+        default_workload = (args.L, args.H, args.reads, args.read_len, args.site_rate) == (40_000_000, 50, 10_000_000, 100, 0.01)
+        if os.path.exists(pmc) and default_workload:  # the committed PMC passes were taken on the default workload only
             try:
                 traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
-            "metric": "reads/s (100 bp, count+locate)",
+            "metric": f"reads/s ({args.read_len} bp, count+locate)",
             "value": value,
             "unit": "reads/s",
             "n_gpus": world,

@@ -297,7 +297,7 @@ int rbg_counters_reset(rbg_index *);
  * tables of DESIGN.md 2b -- each level is four times the tables of the one before, 218 GB in all for a
  * 2-Gbase index; 1 keeps the reference's one-symbol steps only; the deepest levels are dropped
  * automatically when the replica would not fit), HBM_BUDGET_MB (0 = three quarters of the free HBM:
- * upper bound for the replica, deciding how many k-mer levels are kept), FTAB_K (-1 = automatic (the longest word of at most 13 symbols with 4^k <= n/16),
+ * upper bound for the replica, deciding how many k-mer levels are kept), FTAB_K (-1 = automatic (the longest word of at most 12 symbols with 4^k <= n/16),
  * 0 = no ftab, else the word length of the ftab built on the GPU at load time: the state after the
  * last FTAB_K symbols of a read is one gather; result-neutral like the reference's ftab,
  * rowbowt.hpp:124-125,726-758).

@@ -404,10 +404,10 @@ int upload(rbg_index *ix) {
     d.ftab = nullptr;
     d.ftab_k = 0;
     int64_t fk = g_opt_ftab_k.load();
-    if (fk < 0) {  // automatic: the longest word <= 13 with nmajor^k <= n/16 (4^13 words x 16 B = 1.07 GB)
+    if (fk < 0) {  // automatic: the longest word <= 12 with nmajor^k <= n/16 (4^12 words x 16 B = 268 MB; DESIGN.md 4 on why not longer)
         fk = 0;
         double w = 1;
-        while (d.nmajor >= 2 && fk < 13 && w * d.nmajor <= static_cast<double>(h.n) / 16) { w *= d.nmajor; ++fk; }
+        while (d.nmajor >= 2 && fk < 12 && w * d.nmajor <= static_cast<double>(h.n) / 16) { w *= d.nmajor; ++fk; }
     }
     if (fk > 0 && d.nmajor >= 2) {
         double words = 1;
