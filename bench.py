@@ -356,11 +356,16 @@ def main():
         dom = max(("k_find_range<toehold>", "k_locate_fill"), key=lambda k: kernels[k]["ms"])
         ach = kernels[dom]["alg_bytes"] / (kernels[dom]["ms"] * 1e-3) / 1e9
         traffic = None
+        misses = None
+        miss_peak = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         default_workload = (args.L, args.H, args.reads, args.read_len, args.site_rate) == (40_000_000, 50, 10_000_000, 100, 0.01)
         if os.path.exists(pmc) and default_workload:  # the committed PMC passes were taken on the default workload only
             try:
-                traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
+                pj = json.load(open(pmc))
+                traffic = pj.get(dom, {}).get("hbm_bytes_per_launch")
+                misses = pj.get(dom, {}).get("tcc_miss_per_launch")
+                miss_peak = pj.get("_gather_roof", {}).get("peak_G_misses_per_s")
             except Exception:
                 traffic = None
         out = {
@@ -401,6 +406,11 @@ def main():
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "measured_traffic_GBps": (traffic / (kernels[dom]["ms"] * 1e-3) / 1e9) if traffic else None,
                          "gather_efficiency": (kernels[dom]["alg_bytes"] / traffic) if traffic else None,
+                         # what actually bounds the kernel: L2 misses per second against the measured rate of dependent
+                         # random gathers on this chip (tools/gather_roof.hip); TCC_MISS_sum from the same PMC passes
+                         "request_roof": ({"unit": "G L2 misses/s", "achieved": misses / (kernels[dom]["ms"] * 1e-3) / 1e9, "peak": miss_peak,
+                                           "frac": misses / (kernels[dom]["ms"] * 1e-3) / 1e9 / miss_peak, "misses_per_launch": misses}
+                                          if misses and miss_peak else None),
                          "note": "achieved = algorithmic bytes of the reference's one-symbol-per-step algorithm (SURVEY 8d: 57m+24 per "
                                  "read, 24 per located position) / kernel time; it can exceed the HBM peak because the k-mer steps and the "
                                  "ordered phi chains move fewer bytes than that algorithm needs: traffic = FETCH_SIZE+WRITE_SIZE of "
