@@ -1062,6 +1062,76 @@ def test_dense_overflow_buckets(rshift, pos_bytes):
     o.close()
 
 
+def test_positions_beyond_32_bits():
+    """n > 2^32: 8-byte positions chosen automatically, rank values above 2^32 in the 16-byte slots, 64-bit phi
+    slots, and the HBM-budget rule dropping the deepest k-mer level by itself (five levels would need 530 GB).
+    No text of that size is needed: rank, LF, the toehold bookkeeping and phi are arithmetic on the run-length
+    BWT and its run-boundary samples, so a synthetic run list (random heads and lengths, distinct random
+    samples) defines them completely -- for the oracle and for the device alike.  Reads that match are read off
+    LF walks: c0 = bwt[i0], i1 = LF(i0), c1 = bwt[i1], ... is matched by the pattern c_k ... c1 c0."""
+    rng = np.random.default_rng(4242)
+    r = 20_000_000
+    sym = np.frombuffer(b"ACGT", dtype=np.uint8)
+    step = rng.integers(1, 4, size=r, dtype=np.int64)
+    step[0] = 0
+    heads = sym[np.cumsum(step) % 4]                       # neighbouring runs differ
+    lens = rng.integers(1, 500, size=r, dtype=np.int64).astype(np.uint64)
+    heads[r // 3], lens[r // 3] = 1, 1                     # one terminator, as every BWT of a text has (the k-mer levels ask for it)
+    n = int(lens.sum())
+    assert n > (1 << 32) + (1 << 29)
+    stride = n // (2 * r)
+    vals = (np.arange(2 * r, dtype=np.uint64) * np.uint64(stride) + rng.integers(0, stride, size=2 * r).astype(np.uint64))
+    rng.shuffle(vals)                                      # distinct sample values below n
+    ssa, esa = vals[:r].copy(), vals[r:].copy()
+    o = orc.Oracle.from_runs(heads, lens, ssa, esa)
+    starts = np.concatenate([[0], np.cumsum(lens.astype(np.int64))])
+    reads = []
+    for row in rng.integers(0, n, size=1500):
+        row, m, q = int(row), int(rng.integers(1, 120)), bytearray()
+        for _ in range(m):
+            c = int(heads[np.searchsorted(starts, row, side="right") - 1])
+            q.append(c)
+            row = o.LF(row, row, c)[0]
+        reads.append(bytes(q[::-1]))
+    reads += [bytes(rng.choice(sym, size=int(rng.integers(1, 40)))) for _ in range(500)] + [b"", b"ACGTN"]
+    seqs, off = ra.pack_reads(reads)
+    wlo, whi, wk = o.find_range_w_toehold_batch(seqs, off)
+    woff, wlocs = o.locs_at_batch(wlo, whi, wk, max_hits=64)
+    assert int((whi >= wlo).sum()) >= 1500 and int(wlo.max()) > (1 << 32) and int(wlocs.max()) > (1 << 32)
+    # single-symbol steps: ranges, toeholds and locations
+    ra.set_default_option(capi.OPT_KMER_STEPS, 1)
+    try:
+        rb1 = ra.RowBowt.from_runs(heads, lens, ssa, esa, device=0)
+    finally:
+        ra.set_default_option(capi.OPT_KMER_STEPS, 5)
+    assert rb1.info().n == n and rb1.info().pos_bytes == 8 and rb1.info().kmer_steps == 1
+    lo, hi, k = rb1.find_range_w_toehold(seqs, off)
+    assert (lo == wlo).all() and (hi == whi).all() and (k == wk).all()
+    loc_off, locs = rb1.locs_at(lo, hi, k, max_hits=64)
+    assert (loc_off == woff).all() and (locs == wlocs).all()
+    rb1.close()
+    # k-mer levels (the deepest one dropped by the budget rule): ranges, and the phi walks from the oracle's
+    # toeholds.  The toeholds of k-mer steps are not compared here: composing the run-end samples of a k-mer
+    # table presumes samples that are the suffix array's (DESIGN.md 2b), which random ones are not.
+    rb = ra.RowBowt.from_runs(heads, lens, ssa, esa, device=0)
+    i = rb.info()
+    assert i.n == n and i.pos_bytes == 8 and 2 <= i.kmer_steps <= 4 and i.hbm_bytes < 235e9
+    lo, hi, _ = rb.find_range_w_toehold(seqs, off)
+    lo2, hi2 = rb.find_range(seqs, off)
+    assert (lo == wlo).all() and (hi == whi).all() and (lo2 == wlo).all() and (hi2 == whi).all()
+    loc_off, locs = rb.locs_at(wlo, whi, wk, max_hits=64)
+    assert (loc_off == woff).all() and (locs == wlocs).all()
+    rows = rng.integers(0, n, size=4000).astype(np.uint64)
+    width = rng.integers(0, 3000, size=4000).astype(np.uint64)
+    his = np.minimum(rows + width, np.uint64(n - 1))
+    cs = rng.choice(sym, size=4000)
+    nlo, nhi = rb.LF(rows, his, cs)
+    for j in range(0, 4000, 7):
+        assert (int(nlo[j]), int(nhi[j])) == o.LF(int(rows[j]), int(his[j]), int(cs[j]))
+    rb.close()
+    o.close()
+
+
 @pytest.mark.parametrize("fk", [0, -1, 1, 3, 7])
 def test_ftab_is_result_neutral(synth, fk):
     """The device ftab (rowbowt.hpp:124-125, :726-758) changes no answer, whatever its word length; reads
