@@ -1,0 +1,306 @@
+// k_build.hip -- load-time kernels: first-level slot tables and dense overflow tables from the uploaded run lists, the ftab.
+#include "rbg_device.hpp"
+
+namespace rbg {
+
+// ---- slot tables built on the device ---------------------------------------------------------------
+// The first-level tables (one RankSlot per 2^shift BWT positions per symbol or k-mer, 57 GB for the
+// bench index) are a pure function of the run lists, which are uploaded anyway: building them here
+// instead of on the host and copying them over PCIe took "slot tables + upload" from 13 s to the time
+// of uploading the run lists.  One thread fills kBuildGroup consecutive buckets: one binary search,
+// then a linear walk.  The encoding is the one rank_in_slot / phi_step decode (rbg_dev.h).
+namespace {
+constexpr int kBuildGroup = 8;
+
+template <typename P>
+__global__ __launch_bounds__(256) void k_build_rank_slots(const RunEnt<P> *__restrict__ ent, const uint64_t nruns, const uint64_t n,
+                                                          const uint32_t shift, RankSlot *__restrict__ slots,
+                                                          uint32_t *__restrict__ ord, unsigned long long *__restrict__ overflow,
+                                                          unsigned long long *__restrict__ dense_cursor) {
+    const uint64_t nb = (n >> shift) + 2;
+    const uint64_t S = uint64_t(1) << shift;
+    const uint64_t ngroups = (nb + kBuildGroup - 1) / kBuildGroup;
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    unsigned long long novf = 0;
+    for (uint64_t g = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; g < ngroups; g += stride) {
+        const uint64_t b0 = g * kBuildGroup, b1 = b0 + kBuildGroup < nb ? b0 + kBuildGroup : nb;
+        // k = # runs with start < first row of the bucket (ent[nruns] is the sentinel {n, total})
+        uint64_t k = 0, z = nruns;
+        const uint64_t first = b0 << shift;
+        while (k < z) {
+            const uint64_t mid = k + ((z - k) >> 1);
+            if (static_cast<uint64_t>(ent[mid].start) < first) k = mid + 1; else z = mid;
+        }
+        for (uint64_t b = b0; b < b1; ++b) {
+            const uint64_t B0 = b << shift;
+            while (k < nruns && static_cast<uint64_t>(ent[k].start) < B0) ++k;
+            ord[b] = static_cast<uint32_t>(k);
+            uint64_t r0 = 0, ext = 0, prev_is_c = 0;
+            if (k > 0) {
+                const uint64_t ps = ent[k - 1].start, pc = ent[k - 1].cum;
+                const uint64_t pl = static_cast<uint64_t>(ent[k].cum) - pc;
+                r0 = pc + (pl < B0 - ps ? pl : B0 - ps);
+                if (ps + pl > B0) ext = ps + pl - B0 < S ? ps + pl - B0 : S;
+                prev_is_c = ps + pl >= B0 ? 1 : 0;
+            }
+            const bool wide = shift > kMaxNarrowShift;
+            const uint64_t inline_runs = wide ? kSlotRunsWide : kSlotRuns;
+            const uint32_t absent = wide ? 0xFFFFFFu : 0xFFFFu;
+            uint32_t run[kSlotRuns] = {absent, absent, absent, absent};
+            uint64_t cnt = 0;
+            while (k + cnt < nruns && static_cast<uint64_t>(ent[k + cnt].start) < B0 + S) {
+                if (cnt < inline_runs) {
+                    const uint64_t st = ent[k + cnt].start;
+                    const uint64_t off = st - B0;
+                    const uint64_t full = static_cast<uint64_t>(ent[k + cnt + 1].cum) - static_cast<uint64_t>(ent[k + cnt].cum);
+                    const uint64_t len = full < B0 + S - st ? full : B0 + S - st;
+                    const uint32_t v = static_cast<uint32_t>(off | ((len - 1) << (wide ? 12 : 8)));
+                    if (cnt == 0) run[0] = v; else if (cnt == 1) run[1] = v; else if (cnt == 2) run[2] = v; else run[3] = v;
+                }
+                ++cnt;
+            }
+            uint32_t code = static_cast<uint32_t>(cnt);
+            if (cnt > inline_runs) { code = kSlotOvf; ++novf; }
+            RankSlot s;
+            s.r0 = static_cast<uint32_t>(r0);
+            if (wide) {  // flatten() guarantees n < 2^40 for wide buckets
+                s.w1 = static_cast<uint32_t>(r0 >> 32) | (static_cast<uint32_t>(ext) << 8) | (code << 21) | (static_cast<uint32_t>(prev_is_c) << 24);
+                s.w2 = run[0];
+                s.w3 = run[1];
+            } else {
+                s.w1 = static_cast<uint32_t>(ext) | (code << 9) | (static_cast<uint32_t>(prev_is_c) << 12) | (run[0] << 16);
+                s.w2 = run[1] | (run[2] << 16);
+                s.w3 = run[3] | (static_cast<uint32_t>(r0 >> 32) << 16);  // flatten() guarantees n < 2^48
+                // overflow bucket: w2 = where its dense table will live (16-byte units; k_fill_dense writes it
+                // once the total is known and the pool exists)
+                if (code == kSlotOvf && dense_cursor)
+                    s.w2 = static_cast<uint32_t>(atomicAdd(dense_cursor, static_cast<unsigned long long>(S < 8 ? 1 : S >> 3)));
+            }
+            slots[b] = s;
+        }
+    }
+    novf = wave_sum(novf);
+    if ((threadIdx.x & (kWave - 1)) == 0 && novf) atomicAdd(overflow, novf);
+}
+
+// Dense tables of the overflow buckets (rbg_dev.h): two bytes per row o -- # of the symbol in [B0, B0 + o), and
+// 255 if row B0 + o - 1 holds the symbol, else # runs of it that start in [B0, B0 + o) (at most 128).
+// One thread per bucket; only the few overflow buckets do any work (0.05-1 % of them).
+template <typename P>
+__global__ __launch_bounds__(256) void k_fill_dense(const RunEnt<P> *__restrict__ ent, const uint64_t n, const uint32_t shift,
+                                                    const RankSlot *__restrict__ slots, const uint32_t *__restrict__ ord,
+                                                    uint8_t *__restrict__ dense) {
+    const uint64_t nb = (n >> shift) + 2;
+    const uint64_t S = uint64_t(1) << shift;
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t b = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; b + 1 < nb; b += stride) {
+        const uint32_t w1 = slots[b].w1;
+        if (((w1 >> 9) & 7u) != kSlotOvf) continue;
+        uint32_t *out = reinterpret_cast<uint32_t *>(dense + (static_cast<uint64_t>(slots[b].w2) << 4));
+        uint64_t k = ord[b];
+        const uint64_t kend = ord[b + 1];
+        const uint64_t B0 = b << shift;
+        uint64_t cur_end = 0;  // end (exclusive) of the last run of the symbol that began at or before the current row
+        if (k > 0) cur_end = static_cast<uint64_t>(ent[k - 1].start) + (static_cast<uint64_t>(ent[k].cum) - static_cast<uint64_t>(ent[k - 1].cum));
+        uint64_t next_start = k < kend ? static_cast<uint64_t>(ent[k].start) : ~uint64_t(0);
+        bool prev_c = (w1 >> 12) & 1u;  // row B0 - 1 holds the symbol
+        uint32_t d = 0, starts = 0;
+        for (uint64_t o = 0; o < S; o += 2) {
+            uint32_t word = 0;
+            for (uint32_t t = 0; t < 2; ++t) {
+                const uint64_t pos = B0 + o + t;
+                word |= ((d & 0xFFu) | ((prev_c ? 255u : starts) << 8)) << (16 * t);
+                if (pos == next_start) {
+                    cur_end = pos + (static_cast<uint64_t>(ent[k + 1].cum) - static_cast<uint64_t>(ent[k].cum));
+                    ++k;
+                    ++starts;
+                    next_start = k < kend ? static_cast<uint64_t>(ent[k].start) : ~uint64_t(0);
+                }
+                prev_c = pos < cur_end;
+                if (prev_c) ++d;
+            }
+            out[o >> 1] = word;
+        }
+    }
+}
+
+template <typename P>
+__global__ __launch_bounds__(256) void k_build_phi_slots(const PhiEnt<P> *__restrict__ ent, const uint64_t r, const uint64_t n,
+                                                         const uint32_t shift, PhiSlot<P> *__restrict__ slots,
+                                                         uint32_t *__restrict__ ord, unsigned long long *__restrict__ overflow) {
+    const uint64_t nb = (n >> shift) + 2;
+    const uint64_t S = uint64_t(1) << shift;
+    const uint64_t ngroups = (nb + kBuildGroup - 1) / kBuildGroup;
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    // D = base - pos (mod n); with no predecessor the reference uses the LAST record with
+    // delta = i + 1 (toehold_sa.hpp:59,65), i.e. pos = -1
+    auto D_of = [&](uint64_t j) { return (static_cast<uint64_t>(ent[j].base) + n - static_cast<uint64_t>(ent[j].pos)) % n; };
+    unsigned long long novf = 0;
+    for (uint64_t g = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; g < ngroups; g += stride) {
+        const uint64_t b0 = g * kBuildGroup, b1 = b0 + kBuildGroup < nb ? b0 + kBuildGroup : nb;
+        uint64_t k = 0, z = r;
+        const uint64_t first = b0 << shift;
+        while (k < z) {
+            const uint64_t mid = k + ((z - k) >> 1);
+            if (static_cast<uint64_t>(ent[mid].pos) < first) k = mid + 1; else z = mid;
+        }
+        for (uint64_t b = b0; b < b1; ++b) {
+            const uint64_t B0 = b << shift;
+            while (k < r && static_cast<uint64_t>(ent[k].pos) < B0) ++k;
+            ord[b] = static_cast<uint32_t>(k);
+            PhiSlot<P> s;
+            s.dprev = static_cast<P>(k ? D_of(k - 1) : (static_cast<uint64_t>(ent[r - 1].base) + 1) % n);
+            uint64_t cnt = 0;
+            uint32_t off0 = 0xFFu, off1 = 0xFFu;
+            uint64_t d0 = 0, d1 = 0;
+            while (k + cnt < r && static_cast<uint64_t>(ent[k + cnt].pos) < B0 + S) {
+                if (cnt == 0) { off0 = static_cast<uint32_t>(static_cast<uint64_t>(ent[k].pos) - B0); d0 = D_of(k); }
+                else if (cnt == 1) { off1 = static_cast<uint32_t>(static_cast<uint64_t>(ent[k + 1].pos) - B0); d1 = D_of(k + 1); }
+                ++cnt;
+            }
+            uint32_t code = static_cast<uint32_t>(cnt);
+            if (cnt > 2) { code = kPhiOvf; ++novf; }
+            s.d0 = static_cast<P>(d0);
+            s.d1 = static_cast<P>(d1);
+            s.meta = static_cast<P>(off0 | (off1 << 8) | (code << 16));
+            slots[b] = s;
+        }
+    }
+    novf = wave_sum(novf);
+    if ((threadIdx.x & (kWave - 1)) == 0 && novf) atomicAdd(overflow, novf);
+}
+}  // namespace
+
+int launch_build_rank_slots(uint32_t pos_bytes, const void *ent, uint64_t nruns, uint64_t n, uint32_t shift, void *slots,
+                            uint32_t *ord, unsigned long long *overflow, unsigned long long *dense_cursor, void *stream) {
+    if (shift > kMaxNarrowShift) dense_cursor = nullptr;  // wide buckets keep the run-list search
+    const uint64_t nb = (n >> shift) + 2;
+    const uint64_t groups = (nb + kBuildGroup - 1) / kBuildGroup;
+    const int grid = static_cast<int>(std::min<uint64_t>((groups + 255) / 256, 256ull * 64));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (pos_bytes == 4)
+        hipLaunchKernelGGL((k_build_rank_slots<uint32_t>), dim3(grid), dim3(256), 0, st, static_cast<const RunEnt<uint32_t> *>(ent), nruns, n, shift,
+                           static_cast<RankSlot *>(slots), ord, overflow, dense_cursor);
+    else
+        hipLaunchKernelGGL((k_build_rank_slots<uint64_t>), dim3(grid), dim3(256), 0, st, static_cast<const RunEnt<uint64_t> *>(ent), nruns, n, shift,
+                           static_cast<RankSlot *>(slots), ord, overflow, dense_cursor);
+    return static_cast<int>(hipGetLastError());
+}
+
+int launch_fill_dense(uint32_t pos_bytes, const void *ent, uint64_t n, uint32_t shift, const void *slots, const uint32_t *ord,
+                      uint8_t *dense, void *stream) {
+    if (shift > kMaxNarrowShift) return 0;
+    const uint64_t nb = (n >> shift) + 2;
+    const int grid = static_cast<int>(std::min<uint64_t>((nb + 255) / 256, 256ull * 64));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (pos_bytes == 4)
+        hipLaunchKernelGGL((k_fill_dense<uint32_t>), dim3(grid), dim3(256), 0, st, static_cast<const RunEnt<uint32_t> *>(ent), n, shift,
+                           static_cast<const RankSlot *>(slots), ord, dense);
+    else
+        hipLaunchKernelGGL((k_fill_dense<uint64_t>), dim3(grid), dim3(256), 0, st, static_cast<const RunEnt<uint64_t> *>(ent), n, shift,
+                           static_cast<const RankSlot *>(slots), ord, dense);
+    return static_cast<int>(hipGetLastError());
+}
+
+int launch_build_phi_slots(uint32_t pos_bytes, const void *ent, uint64_t r, uint64_t n, uint32_t shift, void *slots, uint32_t *ord,
+                           unsigned long long *overflow, void *stream) {
+    const uint64_t nb = (n >> shift) + 2;
+    const uint64_t groups = (nb + kBuildGroup - 1) / kBuildGroup;
+    const int grid = static_cast<int>(std::min<uint64_t>((groups + 255) / 256, 256ull * 64));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (pos_bytes == 4)
+        hipLaunchKernelGGL((k_build_phi_slots<uint32_t>), dim3(grid), dim3(256), 0, st, static_cast<const PhiEnt<uint32_t> *>(ent), r, n, shift,
+                           static_cast<PhiSlot<uint32_t> *>(slots), ord, overflow);
+    else
+        hipLaunchKernelGGL((k_build_phi_slots<uint64_t>), dim3(grid), dim3(256), 0, st, static_cast<const PhiEnt<uint64_t> *>(ent), r, n, shift,
+                           static_cast<PhiSlot<uint64_t> *>(slots), ord, overflow);
+    return static_cast<int>(hipGetLastError());
+}
+
+// ---- ftab construction: search every word of k major symbols with the step kernel itself ---------
+namespace {
+// words base .. base + W of the table, as a batch of W reads
+__global__ __launch_bounds__(256) void k_ftab_words(const DevIndex ix, const uint32_t k, const uint64_t base, const uint64_t W,
+                                                    uint8_t *__restrict__ seqs, uint64_t *__restrict__ off,
+                                                    const uint8_t *__restrict__ major_byte) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t w = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; w <= W; w += stride) {
+        off[w] = w * k;
+        if (w == W) break;
+        uint64_t x = base + w;
+        for (uint32_t t = k; t > 0; --t) {  // least significant digit = rightmost symbol
+            seqs[w * k + t - 1] = major_byte[x % ix.nmajor];
+            x /= ix.nmajor;
+        }
+    }
+}
+template <typename P>
+__global__ __launch_bounds__(256) void k_ftab_pack(const uint64_t W, const uint64_t *__restrict__ lo, const uint64_t *__restrict__ hi,
+                                                   const uint64_t *__restrict__ ss, void *__restrict__ tab) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t w = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; w < W; w += stride) {
+        const uint64_t k = ss ? ss[w] : 0;
+        if constexpr (sizeof(P) == 4) {
+            uint4 e = make_uint4(static_cast<uint32_t>(lo[w]), static_cast<uint32_t>(hi[w]), static_cast<uint32_t>(k), 0u);
+            if (k == ~uint64_t(0)) e.z = 0xFFFFFFFFu;
+            else if (k >= 0xFFFFFFF0ull) e = make_uint4(2u, 0u, 0u, 0u);  // not expressible: search this word step by step
+            static_cast<uint4 *>(tab)[w] = e;
+        } else {
+            static_cast<ulonglong4 *>(tab)[w] = make_ulonglong4(lo[w], hi[w], k, 0);
+        }
+    }
+}
+}  // namespace
+
+// scratch of one build chunk: word bytes, offsets, three result arrays
+constexpr uint64_t kFtabChunk = uint64_t(1) << 26;
+size_t ftab_build_scratch_bytes(uint64_t words, uint32_t k) {
+    const uint64_t C = std::min<uint64_t>(words, kFtabChunk);
+    return static_cast<size_t>(C * (k + 32ull) + 1024);
+}
+
+int launch_build_ftab(const DevIndex &ix, const LaunchCfg &cfg, uint32_t k, void *tab, void *stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    uint64_t W = 1;
+    for (uint32_t t = 0; t < k; ++t) W *= ix.nmajor;
+    const uint64_t C = std::min<uint64_t>(W, kFtabChunk);  // words per pass: bounds the scratch whatever the table size
+    uint8_t *seqs = nullptr, *mb = nullptr;
+    uint64_t *off = nullptr, *lo = nullptr, *hi = nullptr, *ss = nullptr;
+    hipError_t e = hipMalloc(&seqs, C * k + 64);
+    if (e == hipSuccess) e = hipMalloc(&off, (C + 1) * 8);
+    if (e == hipSuccess) e = hipMalloc(&lo, C * 8);
+    if (e == hipSuccess) e = hipMalloc(&hi, C * 8);
+    if (e == hipSuccess && ix.has_tsa) e = hipMalloc(&ss, C * 8);
+    if (e == hipSuccess) e = hipMalloc(&mb, 256);
+    if (e == hipSuccess) {
+        // major index -> byte, recovered from lut2 on the host side of the caller would need another
+        // argument; derive it here from the device lut2 with a tiny copy
+        uint8_t lut2[256], inv[256] = {0};
+        e = hipMemcpy(lut2, ix.lut2, 256, hipMemcpyDeviceToHost);
+        for (int b = 0; b < 256; ++b)
+            if (lut2[b] != 0xFF) inv[lut2[b]] = static_cast<uint8_t>(b);
+        if (e == hipSuccess) e = hipMemcpy(mb, inv, 256, hipMemcpyHostToDevice);
+    }
+    int rc = static_cast<int>(e);
+    DevIndex plain = ix;  // the words are searched WITHOUT a table
+    plain.ftab = nullptr;
+    plain.ftab_k = 0;
+    const size_t entry = ix.pos_bytes == 4 ? 16 : 32;
+    for (uint64_t base = 0; !rc && base < W; base += C) {
+        const uint64_t cnt = std::min<uint64_t>(C, W - base);
+        void *dst = static_cast<char *>(tab) + base * entry;
+        hipLaunchKernelGGL(k_ftab_words, dim3(grid_for(cfg, cnt + 1)), dim3(256), 0, st, plain, k, base, cnt, seqs, off, mb);
+        rc = static_cast<int>(hipGetLastError());
+        if (!rc) rc = launch_find_range(plain, cfg, seqs, off, cnt, lo, hi, ss, st);
+        if (!rc) {
+            if (ix.pos_bytes == 4) hipLaunchKernelGGL(k_ftab_pack<uint32_t>, dim3(grid_for(cfg, cnt)), dim3(256), 0, st, cnt, lo, hi, ss, dst);
+            else hipLaunchKernelGGL(k_ftab_pack<uint64_t>, dim3(grid_for(cfg, cnt)), dim3(256), 0, st, cnt, lo, hi, ss, dst);
+            rc = static_cast<int>(hipGetLastError());
+        }
+    }
+    if (!rc) rc = static_cast<int>(hipStreamSynchronize(st));
+    (void)hipFree(seqs); (void)hipFree(off); (void)hipFree(lo); (void)hipFree(hi); (void)hipFree(ss); (void)hipFree(mb);
+    return rc;
+}
+
+}  // namespace rbg

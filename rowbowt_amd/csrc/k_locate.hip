@@ -1,0 +1,241 @@
+// k_locate.hip -- K3: phi chains (ToeholdSA::locate_range, toehold_sa.hpp:37-49), their plan (counts + scan) and their order (radix sort of the toeholds)
+#include "rbg_device.hpp"
+
+namespace rbg {
+namespace {
+
+// ---- K3: locate ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_occ(const uint64_t *__restrict__ lo, const uint64_t *__restrict__ hi,
+                                             const uint64_t N, const uint64_t max_hits, uint64_t *__restrict__ out) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < N; i += stride) {
+        uint64_t occ = hi[i] >= lo[i] ? hi[i] - lo[i] + 1 : 0;  // toehold_sa.hpp:38-39
+        if (occ > max_hits) occ = max_hits;
+        out[i + 1] = occ;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[0] = 0;
+}
+
+template <typename P>
+__device__ __forceinline__ uint64_t phi_step(const DevIndex &ix, uint64_t i) {
+    const PhiSlot<P> *__restrict__ slots = static_cast<const PhiSlot<P> *>(ix.phi_slots);
+    if (i >= ix.n) {
+        // Only a toehold that wrapped below zero gets here: a match at text position 0 leaves k - 1 =
+        // 2^64 - 1 (LF_w_loc, rowbowt.hpp:561).  The reference's phi is outside its domain there
+        // (toehold_sa.hpp:57-59 assert); its arithmetic on the last sampled position is followed, and no
+        // table is indexed with the out-of-range value.
+        const PhiEnt<P> e = static_cast<const PhiEnt<P> *>(ix.phi_ent)[ix.r - 1];
+        const uint64_t sum = static_cast<uint64_t>(e.base) + (i - static_cast<uint64_t>(e.pos));  // wraps like uint64_t there
+        return sum % ix.n;
+    }
+    const uint64_t b = i >> ix.phi_shift;
+    const PhiSlot<P> sl = load_slot(slots + b);
+    const uint32_t meta = static_cast<uint32_t>(sl.meta);
+    uint64_t s;
+    if (((meta >> 16) & 3u) == kPhiOvf) {
+        const PhiEnt<P> *__restrict__ ent = static_cast<const PhiEnt<P> *>(ix.phi_ent);
+        uint64_t a = ix.phi_ord[b], z = ix.phi_ord[b + 1];
+        while (z - a > 4) {
+            const uint64_t mid = a + ((z - a) >> 1);
+            if (static_cast<uint64_t>(ent[mid].pos) < i) a = mid + 1; else z = mid;
+        }
+        while (a < z && static_cast<uint64_t>(ent[a].pos) < i) ++a;
+        // a == pred_.rank(i); circular predecessor (sparse_sd_vector.hpp:141-143)
+        const PhiEnt<P> e = ent[a ? a - 1 : ix.r - 1];
+        const uint64_t j = e.pos;
+        const uint64_t delta = j < i ? i - j : i + 1;  // toehold_sa.hpp:65
+        s = static_cast<uint64_t>(e.base) + delta;
+    } else {
+        const uint32_t o = static_cast<uint32_t>(i - (b << ix.phi_shift));
+        uint64_t D = sl.dprev;
+        if (o > (meta & 0xFFu)) D = sl.d0;
+        if (o > ((meta >> 8) & 0xFFu)) D = sl.d1;
+        s = D + i;  // D = (base - pos) mod n of the predecessor: base + (i - pos)
+    }
+    if (s >= ix.n) s -= ix.n;  // (prev_sample + delta) % n_ (toehold_sa.hpp:71); s < 2n
+    return s;
+}
+
+// One lane walks one read's phi chain (toehold_sa.hpp:37-49); the chain is serial, the reads are
+// not.  The locations of a read are contiguous in `locs`, but a lane storing its own values would
+// make every store instruction touch 64 different lines, and stores are gather-class requests just
+// like the slot loads (tools/gather_roof.hip).  So values are staged per wave in LDS, kChunk steps
+// at a time, and flushed with kChunk lanes writing one read's (8 * kChunk)-byte segment: a store
+// instruction then touches a handful of lines instead of 64.  Measured per 10M reads: unordered
+// chains 10.5 / 8.6 / 7.6 ms at kChunk 8 / 16 / 32 (7.3 at 32 in a later build); with the chains in
+// toehold order (the default) 3.5 / 3.1 / 3.5 ms, hence 16 (staged as uint64: 39 KB of LDS per workgroup;
+// staged at the position width since: 24 KB at 4-byte positions, 3.1 -> 3.0 ms).
+constexpr int kChunk = 16;
+
+__device__ __forceinline__ void wave_lds_sync() {
+    // LDS operations of one wave execute in issue order; this only stops the compiler from moving
+    // the cross-lane reads above the writes (and vice versa)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <typename P>
+__global__ __launch_bounds__(256) void k_locate_fill(const DevIndex ix, const uint64_t *__restrict__ lo,
+                                                     const uint64_t *__restrict__ hi, const uint64_t *__restrict__ k,
+                                                     const uint64_t N, const uint64_t max_hits,
+                                                     const uint64_t *__restrict__ loc_off, uint64_t *__restrict__ locs,
+                                                     const uint64_t *__restrict__ sub, const uint32_t *__restrict__ order,
+                                                     const uint64_t *__restrict__ skeys) {
+    // staged at the position width: text positions fit P, and at 4 bytes the workgroup's LDS drops from
+    // 39 KB to 24 KB (6 instead of 4 waves per SIMD); the per-read offset is applied when flushing
+    __shared__ P s_val[4][kWave][kChunk + 1];  // +1: keeps the per-lane rows off the same banks
+    __shared__ uint64_t s_dst[4][kWave];
+    __shared__ uint64_t s_occ[4][kWave];
+    __shared__ uint64_t s_minus[4][kWave];
+    __shared__ uint64_t s_first[4][kWave];  // the toehold itself is not a text position when it wrapped (2^64 - 1)
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
+    unsigned long long c_locs = 0;
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t base = static_cast<uint64_t>(blockIdx.x) * blockDim.x + wv * kWave; base < N; base += stride) {
+        // `order` (optional) lists the reads by toehold text position: neighbouring lanes then walk
+        // neighbouring phi slots (same DRAM rows / L2 lines) for the whole chain, because the chains of
+        // reads from nearby loci visit the haplotypes in the same order.  Results land at loc_off[i]
+        // whatever the processing order.
+        const uint64_t j = base + lane;
+        uint64_t i = j;
+        if (order && j < N) i = order[j];
+        uint64_t occ = 0, k1 = 0, dst = 0;
+        if (i < N) {
+            dst = loc_off[i];
+            if (skeys) {
+                // ordered walk: the toehold travels with the sort (sequential read) and the count is the
+                // planned one, loc_off[i+1] - loc_off[i] = min(occ, max_hits): one random 64-byte sector
+                // per read instead of four (lo, hi, k, loc_off)
+                k1 = skeys[j];
+                occ = loc_off[i + 1] - dst;
+            } else {
+                const uint64_t l = lo[i], h = hi[i];
+                occ = h >= l ? h - l + 1 : 0;  // toehold_sa.hpp:38-39
+                if (occ > max_hits) occ = max_hits;
+                k1 = k[i];
+            }
+        }
+        const uint64_t minus = (sub && i < N) ? sub[i] : 0;  // locate_from_longest_seed, rowbowt.hpp:681-683
+        s_dst[wv][lane] = dst;
+        s_occ[wv][lane] = occ;
+        s_minus[wv][lane] = minus;
+        s_first[wv][lane] = k1;
+        c_locs += occ;
+        uint64_t wmax = occ;
+#pragma unroll
+        for (int o = kWave / 2; o > 0; o >>= 1) {
+            const uint64_t other = __shfl_xor(wmax, o, kWave);
+            wmax = other > wmax ? other : wmax;
+        }
+        for (uint64_t t0 = 0; t0 < wmax; t0 += kChunk) {
+#pragma unroll
+            for (int e = 0; e < kChunk; ++e) {
+                const uint64_t t = t0 + e;
+                if (t < occ) {
+                    if (t) k1 = phi_step<P>(ix, k1);  // toehold_sa.hpp:44
+                    s_val[wv][lane][e] = static_cast<P>(k1);
+                }
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int pass = 0; pass < kChunk; ++pass) {  // kWave/kChunk reads per pass, kChunk lanes each
+                const int s = pass * (kWave / kChunk) + lane / kChunk;
+                const int e = lane & (kChunk - 1);
+                const uint64_t t = t0 + e;
+                if (t < s_occ[wv][s]) locs[s_dst[wv][s] + t] = (t ? static_cast<uint64_t>(s_val[wv][s][e]) : s_first[wv][s]) - s_minus[wv][s];
+            }
+            wave_lds_sync();
+        }
+        wave_lds_sync();
+    }
+    c_locs = wave_sum(c_locs);
+    if (lane == 0 && c_locs) atomicAdd(&ix.counters[3], c_locs);
+}
+
+}  // namespace
+
+// ---- chain ordering for locate: permutation of the reads by toehold value (radix sort) ----------
+namespace {
+__global__ __launch_bounds__(256) void k_iota(uint32_t *__restrict__ v, const uint64_t N) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < N; i += stride) v[i] = static_cast<uint32_t>(i);
+}
+struct OrderWs {
+    size_t perm, iota, keys, sort, sort_bytes, total;
+};
+OrderWs order_layout(uint64_t N) {
+    auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
+    OrderWs w{};
+    w.perm = 0;
+    w.iota = up(w.perm + N * 4);
+    w.keys = up(w.iota + N * 4);
+    w.sort = up(w.keys + N * 8);
+    size_t bytes = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, static_cast<const uint64_t *>(nullptr), static_cast<uint64_t *>(nullptr),
+                                             static_cast<const uint32_t *>(nullptr), static_cast<uint32_t *>(nullptr),
+                                             static_cast<int64_t>(N ? N : 1), 0, 64);
+    w.sort_bytes = bytes;
+    w.total = up(w.sort + bytes) + 256;
+    return w;
+}
+}  // namespace
+
+size_t locate_order_ws_bytes(uint64_t N) { return order_layout(N).total; }
+
+int launch_locate_order(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t *k, uint64_t N, void *ws, size_t ws_bytes,
+                        void *stream) {
+    if (N == 0) return 0;
+    if (N >= 0xFFFFFFFFull) return static_cast<int>(hipErrorInvalidValue);  // permutation entries are 32-bit
+    const OrderWs w = order_layout(N);
+    if (ws_bytes < w.total || (reinterpret_cast<uintptr_t>(ws) & 255)) return static_cast<int>(hipErrorInvalidValue);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char *base = static_cast<char *>(ws);
+    uint32_t *perm = reinterpret_cast<uint32_t *>(base + w.perm);
+    uint32_t *iota = reinterpret_cast<uint32_t *>(base + w.iota);
+    uint64_t *keys = reinterpret_cast<uint64_t *>(base + w.keys);
+    hipLaunchKernelGGL(k_iota, dim3(grid_for(cfg, N)), dim3(256), 0, st, iota, N);
+    int rc = static_cast<int>(hipGetLastError());
+    if (rc) return rc;
+    int end_bit = 1;
+    while (end_bit < 64 && (ix.n >> end_bit)) ++end_bit;  // toeholds are text positions < n
+    // the order only has to bring chains of nearby text positions together: the low bits (positions
+    // inside one 64-byte line of phi slots) need no sorting, which saves a radix pass
+    int begin_bit = static_cast<int>(ix.phi_shift) + 2;
+    if (end_bit - begin_bit < 8) begin_bit = 0;
+    size_t bytes = w.sort_bytes;
+    return static_cast<int>(hipcub::DeviceRadixSort::SortPairs(base + w.sort, bytes, k, keys, iota, perm, static_cast<int64_t>(N),
+                                                               begin_bit, end_bit, st));
+}
+
+size_t scan_tmp_bytes(uint64_t N) {
+    size_t bytes = 0;
+    uint64_t *p = nullptr;
+    (void)hipcub::DeviceScan::InclusiveSum(nullptr, bytes, p, p, static_cast<int64_t>(N ? N : 1));
+    return bytes + 256;
+}
+
+int launch_locate_plan(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t *lo, const uint64_t *hi, uint64_t N,
+                       uint64_t max_hits, uint64_t *loc_off, void *tmp, size_t tmp_bytes, void *stream) {
+    (void)ix;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(k_occ, dim3(grid_for(cfg, N)), dim3(cfg.block_threads), 0, st, lo, hi, N, max_hits, loc_off);
+    int rc = static_cast<int>(hipGetLastError());
+    if (rc) return rc;
+    return scan_in_place(loc_off + 1, N, tmp, tmp_bytes, st);
+}
+
+int launch_locate_fill(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t *lo, const uint64_t *hi,
+                       const uint64_t *k, uint64_t N, uint64_t max_hits, const uint64_t *loc_off, uint64_t *locs,
+                       const uint64_t *sub, const void *order, void *stream) {
+    if (N == 0) return 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid(grid_for(cfg, N)), block(cfg.block_threads);
+    // the order workspace also holds the toeholds in sorted order (launch_locate_order's key output)
+    const uint64_t *skeys = order ? reinterpret_cast<const uint64_t *>(static_cast<const char *>(order) + order_layout(N).keys) : nullptr;
+    if (ix.pos_bytes == 4) hipLaunchKernelGGL((k_locate_fill<uint32_t>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, locs, sub, static_cast<const uint32_t *>(order), skeys);
+    else hipLaunchKernelGGL((k_locate_fill<uint64_t>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, locs, sub, static_cast<const uint32_t *>(order), skeys);
+    return static_cast<int>(hipGetLastError());
+}
+
+}  // namespace rbg

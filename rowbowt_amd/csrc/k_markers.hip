@@ -1,0 +1,679 @@
+// k_markers.hip -- K4 and the seeding kernels: markers_at, find_range_w_markers, greedy seeds, marker seeds, single LF steps (rowbowt.hpp:74-88, :222-339, :406-482)
+#include "rbg_device.hpp"
+
+namespace rbg {
+namespace {
+
+// ---- K4: markers --------------------------------------------------------------------------------
+// runs are disjoint, ascending inclusive SA-index intervals; at_range(lo,hi) = values of all runs
+// with start <= hi && end >= lo, in run order.
+__device__ __forceinline__ void marker_span(const DevIndex &ix, uint64_t lo, uint64_t hi, uint64_t *first, uint64_t *last) {
+    if (ix.mk_bucket) {
+        if (lo >= ix.n) { *first = *last = ix.mk_nruns; return; }  // caller-supplied rows beyond the BWT: nothing
+        if (hi >= ix.n) hi = ix.n - 1;
+        // first run with end >= lo: the bucket table gives the first run ending at or after the start of
+        // lo's bucket; the answer is at most a bucket's worth of runs further on
+        uint64_t a = ix.mk_bucket[lo >> ix.mk_shift];
+        while (a < ix.mk_nruns && ix.mk_end[a] < lo) ++a;
+        *first = a;
+        // one past the last run with start <= hi: every run before the entry of hi's bucket ends, hence
+        // starts, before hi
+        uint64_t z = ix.mk_bucket[hi >> ix.mk_shift];
+        if (z < a) z = a;
+        while (z < ix.mk_nruns && ix.mk_start[z] <= hi) ++z;
+        *last = z;
+        return;
+    }
+    uint64_t a = 0, z = ix.mk_nruns;
+    while (a < z) { const uint64_t m = a + ((z - a) >> 1); if (ix.mk_end[m] < lo) a = m + 1; else z = m; }
+    *first = a;  // first run with end >= lo
+    a = 0; z = ix.mk_nruns;
+    while (a < z) { const uint64_t m = a + ((z - a) >> 1); if (ix.mk_start[m] <= hi) a = m + 1; else z = m; }
+    *last = a;   // one past the last run with start <= hi
+}
+
+__global__ __launch_bounds__(256) void k_markers_count(const DevIndex ix, const uint64_t *__restrict__ lo,
+                                                       const uint64_t *__restrict__ hi, const uint64_t N,
+                                                       uint64_t *__restrict__ out) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < N; i += stride) {
+        uint64_t cnt = 0;
+        if (hi[i] >= lo[i]) {
+            uint64_t f, l;
+            marker_span(ix, lo[i], hi[i], &f, &l);
+            if (l > f) cnt = ix.mk_off[l] - ix.mk_off[f];
+        }
+        out[i + 1] = cnt;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[0] = 0;
+}
+
+__global__ __launch_bounds__(256) void k_markers_fill(const DevIndex ix, const uint64_t *__restrict__ lo,
+                                                      const uint64_t *__restrict__ hi, const uint64_t N,
+                                                      const uint64_t *__restrict__ mk_off, uint64_t *__restrict__ mk) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < N; i += stride) {
+        if (hi[i] < lo[i]) continue;
+        uint64_t f, l;
+        marker_span(ix, lo[i], hi[i], &f, &l);
+        if (l <= f) continue;
+        const uint64_t src = ix.mk_off[f], cnt = ix.mk_off[l] - src;
+        uint64_t *dst = mk + mk_off[i];
+        for (uint64_t t = 0; t < cnt; ++t) dst[t] = ix.mk_vals[src + t];
+    }
+}
+
+
+// ---- find_range_w_markers (rowbowt.hpp:292-339) --------------------------------------------------
+// Backward search that queries the marker array at every window end (:315-323) and once more at
+// the end when (m-1) % wsize != 0 (:328-335).  Window results are PREPENDED in the reference
+// (:320,:333), so query q's markers land at  total - (c_0 + ... + c_q).
+// FILL=false: count pass (writes lo/hi and per-read totals to cnt_out[i+1]);
+// FILL=true : re-walks the read and writes the markers at mk_off[i].
+template <typename P, bool FILL>
+__global__ __launch_bounds__(256) void k_find_range_markers(const DevIndex ix, const uint8_t *__restrict__ seqs,
+                                                            const uint64_t *__restrict__ off, const uint64_t N,
+                                                            const uint64_t wsize, const uint64_t max_range,
+                                                            uint64_t *__restrict__ lo_out, uint64_t *__restrict__ hi_out,
+                                                            uint64_t *__restrict__ cnt_out,
+                                                            const uint64_t *__restrict__ mk_off, uint64_t *__restrict__ mk) {
+    __shared__ uint8_t s_lut[256];
+    __shared__ DevSym s_sym[kLdsSyms];
+    for (int t = threadIdx.x; t < 256; t += blockDim.x) s_lut[t] = ix.lut[t];
+    const int nlds = ix.sigma < static_cast<uint32_t>(kLdsSyms) ? static_cast<int>(ix.sigma) : kLdsSyms;
+    for (int t = threadIdx.x; t < nlds; t += blockDim.x) s_sym[t] = ix.syms[t];
+    __syncthreads();
+    const uint64_t *__restrict__ words = reinterpret_cast<const uint64_t *>(seqs);
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    if (!FILL && blockIdx.x == 0 && threadIdx.x == 0) cnt_out[0] = 0;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < N; i += stride) {
+        const uint64_t beg = off[i], end = off[i + 1], m = end - beg;
+        uint64_t total = 0;
+        uint64_t lo = 1, hi = 0;
+        bool alive = m >= wsize;  // rowbowt.hpp:299-302: shorter queries return the default LFData
+        // fill pass: a read with nothing to emit (including every read that dies: lf.clear() drops
+        // what earlier windows collected) must not write at all
+        if (FILL && mk_off[i + 1] == mk_off[i]) continue;
+        if (alive) {
+            lo = 0; hi = ix.n - 1;
+            uint64_t window_ei = m, acc = 0;
+            const uint64_t want = FILL ? mk_off[i + 1] - mk_off[i] : 0;
+            uint64_t *dst = FILL ? mk + mk_off[i] : nullptr;
+            uint64_t cur_wi = ~uint64_t(0), w = 0;
+            for (uint64_t s = 0; s <= m; ++s) {
+                bool query;
+                if (s < m) {
+                    const uint64_t p = end - 1 - s;
+                    const uint64_t wi = p >> 3;
+                    if (wi != cur_wi) { w = words[wi]; cur_wi = wi; }
+                    const uint32_t c = static_cast<uint32_t>(w >> ((p & 7) * 8)) & 0xFFu;
+                    const uint32_t slot = s_lut[c];
+                    if (slot == 0xFFu) { alive = false; break; }
+                    const DevSym S = slot < static_cast<uint32_t>(kLdsSyms) ? s_sym[slot] : ix.syms[slot];
+                    RankAux q;
+                    uint64_t c_before, c_upto, bh;
+                    rank_pair<P>(S, ix.dense, lo, hi + 1, &c_before, &c_upto, &bh, &q);
+                    const uint64_t c_inside = c_upto - c_before;
+                    if (c_inside == 0) { alive = false; break; }
+                    lo = S.F + c_before;
+                    hi = lo + c_inside - 1;
+                    query = window_ei - (m - s) >= wsize;  // :315
+                    if (query) window_ei = m - s;          // :322
+                } else {
+                    query = (m - 1) % wsize != 0;          // :328
+                }
+                if (query && hi - lo + 1 <= max_range) {   // :318,:331
+                    uint64_t f, l;
+                    marker_span(ix, lo, hi, &f, &l);
+                    if (l > f) {
+                        const uint64_t src = ix.mk_off[f], cnt = ix.mk_off[l] - src;
+                        acc += cnt;
+                        if (FILL) {
+                            uint64_t *d = dst + (want - acc);
+                            for (uint64_t t = 0; t < cnt; ++t) d[t] = ix.mk_vals[src + t];
+                        }
+                    }
+                }
+            }
+            total = alive ? acc : 0;
+            if (!alive) { lo = 1; hi = 0; }  // lf.clear(), :311-313
+        }
+        if (!FILL) {
+            lo_out[i] = lo;
+            hi_out[i] = hi;
+            cnt_out[i + 1] = total;
+        }
+    }
+}
+
+// ---- greedy seeding (next-row f4): RowBowt::get_seeds_greedy_w_sample (rowbowt.hpp:222-256)
+// reduced on the fly by locate_from_longest_seed's choice (rowbowt.hpp:669-677): per read, the
+// first seed of strictly greatest length.  Seeds are maximal exact matches found right to left;
+// the base that ends a seed is skipped.  A k-mer gather is attempted first; when it comes back
+// empty the symbol that actually ends the seed is found with single reference steps.
+template <typename P>
+__device__ __forceinline__ bool lf_w_loc(const DevSym &S, const uint8_t *__restrict__ dense, uint32_t adv, uint64_t &lo, uint64_t &hi,
+                                         uint64_t &k) {
+    RankAux q;
+    uint64_t c_before, c_upto, bh;
+    rank_pair<P>(S, dense, lo, hi + 1, &c_before, &c_upto, &bh, &q);
+    const uint64_t c_inside = c_upto - c_before;
+    if (c_inside == 0) return false;
+    if (q.inside) k = k - adv;
+    else k = pred_sample<P>(S, bh, q);
+    lo = S.F + c_before;
+    hi = lo + c_inside - 1;
+    return true;
+}
+
+template <typename P>
+__global__ __launch_bounds__(1024) void k_greedy_seed(const DevIndex ix, const uint8_t *__restrict__ seqs,
+                                                     const uint64_t *__restrict__ off, const uint64_t N,
+                                                     const uint64_t min_length, uint64_t *__restrict__ lo_out,
+                                                     uint64_t *__restrict__ hi_out, uint64_t *__restrict__ qs_out,
+                                                     uint64_t *__restrict__ qe_out, uint64_t *__restrict__ ss_out,
+                                                     const uint32_t max_k) {
+    __shared__ uint8_t s_lut[256];
+    __shared__ uint8_t s_lut2[256];
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    DevSym *s_tab = reinterpret_cast<DevSym *>(s_dyn);
+    const uint32_t ksteps = ix.kmer_steps < max_k ? ix.kmer_steps : max_k;  // deepest level staged (the launcher sized the LDS for it)
+    stage_tables(ix, s_tab, s_lut, s_lut2, ksteps >= 5);
+    const uint32_t M = ix.nmajor;
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < N; i += stride) {
+        const uint64_t beg = off[i], m = off[i + 1] - beg;
+        const uint64_t first_k = ix.last_run_sample;  // rowbowt.hpp:230
+        const uint64_t fhi = ix.n - 1;
+        uint64_t lo = 0, hi = fhi, plo = 0, phi = fhi;
+        uint64_t k = first_k, pk = ~uint64_t(0), ei = m;
+        uint64_t b_lo = 1, b_hi = 0, b_qs = 0, b_qe = 0, b_k = 0, b_len = 0;
+        ByteCursor rd{reinterpret_cast<const uint4 *>(seqs), ~uint64_t(0), make_uint4(0, 0, 0, 0)};
+        uint64_t j = m;  // next symbol to consume is q[j-1]
+        auto lf1 = [&](uint32_t c) -> bool {  // one reference step (rowbowt.hpp:235); an absent symbol is an empty range (:76)
+            const uint32_t slot = s_lut[c];
+            if (slot == 0xFFu) return false;
+            if (slot < static_cast<uint32_t>(kLdsSyms)) { const DevSym S = s_tab[slot]; return lf_w_loc<P>(S, ix.dense, 1u, lo, hi, k); }
+            return lf_w_loc<P>(ix.syms[slot], ix.dense, 1u, lo, hi, k);
+        };
+        // the longest k-mer (2..min(cap, kmer_steps) symbols, all with k-mer tables) ending at byte p; success
+        // is identical to *len nested LF_w_loc calls
+        auto lfk = [&](uint64_t p, uint32_t c, uint64_t cap, uint32_t *len) -> bool {
+            *len = 0;
+            const uint32_t m0 = s_lut2[c];
+            if (m0 == 0xFFu || cap < 2 || ksteps < 2) return false;
+            const uint32_t m1 = s_lut2[rd.at(p - 1)];
+            if (m1 == 0xFFu) return false;
+            uint32_t adv = 2, idx = kOff2 + m1 * M + m0;
+            if (ksteps >= 3 && cap >= 3) {
+                const uint32_t m2 = s_lut2[rd.at(p - 2)];
+                if (m2 != 0xFFu) {
+                    adv = 3;
+                    idx = kOff3 + (m2 * M + m1) * M + m0;
+                    if (ksteps >= 4 && cap >= 4) {
+                        const uint32_t m3 = s_lut2[rd.at(p - 3)];
+                        if (m3 != 0xFFu) {
+                            adv = 4;
+                            idx = kOff4 + ((m3 * M + m2) * M + m1) * M + m0;
+                            if (ksteps >= 5 && cap >= 5) {
+                                const uint32_t m4 = s_lut2[rd.at(p - 4)];
+                                if (m4 != 0xFFu) { adv = 5; idx = kOff5 + (((m4 * M + m3) * M + m2) * M + m1) * M + m0; }
+                            }
+                        }
+                    }
+                }
+            }
+            *len = adv;
+            const DevSym S = s_tab[idx];
+            return lf_w_loc<P>(S, ix.dense, adv, lo, hi, k);
+        };
+        auto on_ok = [&](uint32_t adv) {
+            j -= adv;
+            plo = lo; phi = hi; pk = k;  // rowbowt.hpp:248-249
+        };
+        auto on_fail = [&]() {  // q[j-1] ends the seed q[j, ei)  (rowbowt.hpp:236-246; m-i == j here)
+            if (ei - j >= min_length && ei - j > b_len) { b_len = ei - j; b_lo = plo; b_hi = phi; b_qs = j; b_qe = ei; b_k = pk; }
+            k = first_k;
+            lo = 0; hi = fhi; plo = 0; phi = fhi;
+            j -= 1;      // skip the base that failed
+            ei = j;
+        };
+        while (j > 0) {
+            const uint64_t p = beg + j - 1;
+            const uint32_t c = rd.at(p);
+            // a fresh seed: the state after its first ftab_k symbols (range and toehold, searched from
+            // first_k like here) is one gather in the device table; an empty entry means the word does not
+            // occur and the steps below find where it stops
+            if (j == ei && ix.ftab_k && j >= ix.ftab_k) {
+                uint64_t idx = 0, pw = 1;
+                bool all_major = true;
+                for (uint32_t t = 0; t < ix.ftab_k; ++t) {
+                    const uint32_t mm = s_lut2[rd.at(p - t)];
+                    all_major = all_major && mm != 0xFFu;
+                    idx += (mm & 3u) * pw;
+                    pw *= M;
+                }
+                uint64_t flo, fhi2, fk;
+                if (all_major && ftab_lookup<P>(ix, idx, flo, fhi2, fk) && flo <= fhi2) {
+                    lo = flo; hi = fhi2; k = fk;
+                    on_ok(ix.ftab_k);
+                    continue;
+                }
+            }
+            uint32_t len;
+            if (lfk(p, c, j, &len)) { on_ok(len); continue; }
+            if (len == 0) {
+                if (lf1(c)) on_ok(1u); else on_fail();
+                continue;
+            }
+            // the range died inside q[j-len, j) (lo/hi/k are untouched by a failed step): halve the window
+            // until one symbol is left -- at most three more gathers -- that symbol is the failing base
+            while (len > 1) {
+                const uint32_t half = len / 2;
+                const uint64_t p2 = beg + j - 1;
+                const uint32_t c2 = rd.at(p2);
+                uint32_t l2;
+                const bool ok2 = half >= 2 ? lfk(p2, c2, half, &l2) : lf1(c2);
+                if (ok2) { on_ok(half); len -= half; } else len = half;
+            }
+            on_fail();
+        }
+        if (ei >= min_length && ei > b_len) { b_len = ei; b_lo = plo; b_hi = phi; b_qs = 0; b_qe = ei; b_k = pk; }  // :252-254
+        lo_out[i] = b_lo;
+        hi_out[i] = b_hi;
+        qs_out[i] = b_qs;
+        qe_out[i] = b_qe;
+        ss_out[i] = b_k;
+    }
+}
+
+// ---- marker seeds (next-row f4): RowBowt::get_markers_greedy_seeding without an ftab
+// (rowbowt.hpp:406-482; rb_markers' default path, rb_markers.cpp:411-413).  One record per call of
+// the reference's callback: {range lo, range hi, q.first, seed_ei (= q.second + 1), first marker,
+// one past last marker}; the markers of a seed are what every window query along it appended to
+// mbuf (:437-441, :469-472), plus one more query when the seed ends or the read does (:445-447,
+// :478-480).  FILL=false counts records and markers per read; FILL=true re-walks and writes.
+// k-mer steps are used where no window query can fall inside them and a fresh seed takes its first
+// ftab_k symbols from the device state table; a k-mer step that comes back empty is narrowed down with
+// two more gathers so the failing base is the reference's.
+template <typename P, bool FILL>
+__global__ __launch_bounds__(1024) void k_marker_seeds(const DevIndex ix, const uint8_t *__restrict__ seqs,
+                                                      const uint64_t *__restrict__ off, const uint64_t N,
+                                                      const uint64_t wsize, const uint64_t max_range, const uint64_t ftab_k,
+                                                      uint64_t *__restrict__ seed_cnt, uint64_t *__restrict__ mk_cnt,
+                                                      const uint64_t *__restrict__ seed_off,
+                                                      const uint64_t *__restrict__ mk_off,
+                                                      uint64_t *__restrict__ seeds, uint64_t *__restrict__ mk, const uint32_t max_k) {
+    __shared__ uint8_t s_lut[256];
+    __shared__ uint8_t s_lut2[256];
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    DevSym *s_tab = reinterpret_cast<DevSym *>(s_dyn);
+    const uint32_t ksteps = ix.kmer_steps < max_k ? ix.kmer_steps : max_k;  // deepest level staged (the launcher sized the LDS for it)
+    stage_tables(ix, s_tab, s_lut, s_lut2, ksteps >= 5);
+    const uint32_t M = ix.nmajor;
+    if (!FILL && blockIdx.x == 0 && threadIdx.x == 0) { seed_cnt[0] = 0; mk_cnt[0] = 0; }
+    const bool have_ma = ix.mk_nruns != 0;
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < N; i += stride) {
+        const uint64_t beg = off[i], m = off[i + 1] - beg;
+        const uint64_t fhi = ix.n - 1;
+        uint64_t lo = 0, hi = fhi, plo = 0, phi = fhi;    // range, prev_range (:427-428)
+        uint64_t window_ei = m, seed_ei = m;              // :434
+        uint64_t ns = 0, tot = 0, mb_begin = 0;           // mbuf == markers [mb_begin, tot) of this read
+        uint64_t *srec = FILL ? seeds + 6 * seed_off[i] : nullptr;
+        const uint64_t mbase = FILL ? mk_off[i] : 0;
+        auto update_mbuf = [&](uint64_t l, uint64_t h) {  // :437-441
+            if (!have_ma || h - l + 1 > max_range) return;
+            uint64_t f, e;
+            marker_span(ix, l, h, &f, &e);
+            if (e <= f) return;
+            const uint64_t src = ix.mk_off[f], cnt = ix.mk_off[e] - src;
+            if (FILL) {
+                uint64_t *d = mk + mbase + tot;
+                for (uint64_t t = 0; t < cnt; ++t) d[t] = ix.mk_vals[src + t];
+            }
+            tot += cnt;
+        };
+        auto emit = [&](uint64_t l, uint64_t h, uint64_t qs, uint64_t qe) {  // fn(range, (qs, qe-1), mbuf)
+            if (FILL) {
+                uint64_t *d = srec + 6 * ns;
+                d[0] = l; d[1] = h; d[2] = qs; d[3] = qe; d[4] = mbase + mb_begin; d[5] = mbase + tot;
+            }
+            ++ns;
+        };
+        ByteCursor rd{reinterpret_cast<const uint4 *>(seqs), ~uint64_t(0), make_uint4(0, 0, 0, 0)};
+        // one reference LF step on (lo,hi) with symbol c; false = empty range, (lo,hi) untouched
+        auto lf1 = [&](uint32_t c) -> bool {
+            const uint32_t slot = s_lut[c];
+            if (slot == 0xFFu) return false;
+            const DevSym S = slot < static_cast<uint32_t>(kLdsSyms) ? s_tab[slot] : ix.syms[slot];
+            RankAux q;
+            uint64_t c_before, c_upto, bh;
+            rank_pair<P>(S, ix.dense, lo, hi + 1, &c_before, &c_upto, &bh, &q);
+            if (c_upto <= c_before) return false;
+            lo = S.F + c_before;
+            hi = lo + (c_upto - c_before) - 1;
+            return true;
+        };
+        // the longest k-mer (2..min(cap, kmer_steps) symbols, all with k-mer tables) ending at byte p:
+        // *len = its length (0: none applies); returns true when the range survived it
+        auto lfk = [&](uint64_t p, uint32_t c, uint64_t cap, uint32_t *len) -> bool {
+            *len = 0;
+            const uint32_t m0 = s_lut2[c];
+            if (m0 == 0xFFu || cap < 2 || ksteps < 2) return false;
+            const uint32_t m1 = s_lut2[rd.at(p - 1)];
+            if (m1 == 0xFFu) return false;
+            uint32_t adv = 2, idx = kOff2 + m1 * M + m0;
+            if (ksteps >= 3 && cap >= 3) {
+                const uint32_t m2 = s_lut2[rd.at(p - 2)];
+                if (m2 != 0xFFu) {
+                    adv = 3;
+                    idx = kOff3 + (m2 * M + m1) * M + m0;
+                    if (ksteps >= 4 && cap >= 4) {
+                        const uint32_t m3 = s_lut2[rd.at(p - 3)];
+                        if (m3 != 0xFFu) {
+                            adv = 4;
+                            idx = kOff4 + ((m3 * M + m2) * M + m1) * M + m0;
+                            if (ksteps >= 5 && cap >= 5) {
+                                const uint32_t m4 = s_lut2[rd.at(p - 4)];
+                                if (m4 != 0xFFu) { adv = 5; idx = kOff5 + (((m4 * M + m3) * M + m2) * M + m1) * M + m0; }
+                            }
+                        }
+                    }
+                }
+            }
+            *len = adv;
+            const DevSym S = s_tab[idx];
+            RankAux q;
+            uint64_t c_before, c_upto, bh;
+            rank_pair<P>(S, ix.dense, lo, hi + 1, &c_before, &c_upto, &bh, &q);
+            if (c_upto <= c_before) return false;
+            lo = S.F + c_before;
+            hi = lo + (c_upto - c_before) - 1;
+            return true;
+        };
+        if (ftab_k) {
+            // ---- with the ftab of k-mer size K (rb_markers --ftab): the reference's loop in its own
+            // index i; search_ftab (:746-758) on the table build_ftab(K) makes for this index (:726-744)
+            // is find_range of an ACGT-only k-mer, done here as K steps from the full range
+            const uint64_t K = ftab_k;
+            auto ftab_hit = [&](uint64_t e) -> bool {   // k-mer q[e-K, e); on a hit (lo,hi) is its range
+                for (uint64_t t = e - K; t < e; ++t) {
+                    const uint32_t c = rd.at(beg + t);
+                    if (c != 'A' && c != 'C' && c != 'G' && c != 'T') return false;
+                }
+                lo = 0; hi = fhi;
+                uint64_t e2 = e;
+                while (e2 > e - K) {
+                    const uint64_t p = beg + e2 - 1;
+                    const uint32_t c = rd.at(p);
+                    uint32_t adv;
+                    if (!lfk(p, c, e2 - (e - K), &adv)) {
+                        if (adv) return false;       // a k-mer of the word is absent: so is the word
+                        if (!lf1(c)) return false;
+                        adv = 1;
+                    }
+                    e2 -= adv;
+                }
+                return true;
+            };
+            uint64_t i2 = 0;
+            if (m >= K) {                                  // :430-433 (a shorter read makes the reference throw)
+                if (ftab_hit(m)) i2 = K; else { lo = 0; hi = fhi; }
+                plo = lo; phi = hi;
+            }
+            for (; i2 < m; ++i2) {
+                if (lf1(rd.at(beg + m - i2 - 1))) {        // :443
+                    if (window_ei - (m - i2 - 1) >= wsize) {   // :469-472
+                        update_mbuf(lo, hi);
+                        window_ei = m - i2 - 1;
+                    }
+                    plo = lo; phi = hi;                    // :473
+                } else {                                   // :444-467
+                    if (seed_ei - (m - i2) >= wsize) update_mbuf(plo, phi);
+                    emit(plo, phi, m - i2, seed_ei);
+                    mb_begin = tot;
+                    plo = 0; phi = fhi;
+                    seed_ei = m - i2 - 1;
+                    window_ei = m - i2 - 1;
+                    lo = 0; hi = fhi;
+                    for (; m - i2 - 1 >= K; ++i2) {        // :454-464 slide left until a k-mer is in the ftab
+                        seed_ei = m - i2 - 1;
+                        window_ei = m - i2 - 1;
+                        if (ftab_hit(m - i2 - 1)) {
+                            i2 += K;                       // :460, then the outer ++i2
+                            plo = lo; phi = hi;
+                            break;
+                        }
+                        lo = 0; hi = fhi;                  // :463
+                    }
+                }
+            }
+            if (hi >= lo && seed_ei - (m - i2) >= wsize) update_mbuf(lo, hi);   // :478-480
+            emit(lo, hi, m - i2, seed_ei);                                      // :481
+            if (!FILL) {
+                seed_cnt[i + 1] = ns;
+                mk_cnt[i + 1] = tot;
+            }
+            continue;
+        }
+        uint64_t j = m;  // m - i of the reference; the next symbol consumed is q[j-1]
+        auto on_ok = [&](uint32_t adv) {              // adv symbols consumed, range still non-empty
+            j -= adv;
+            if (window_ei - j >= wsize) {             // :469-472 (m-i-1 == j after the step)
+                update_mbuf(lo, hi);
+                window_ei = j;
+            }
+            plo = lo; phi = hi;                       // :473
+        };
+        auto on_fail = [&]() {                        // q[j-1] empties the range: the seed q[j, seed_ei) ends (:444-466)
+            if (seed_ei - j >= wsize) update_mbuf(plo, phi);
+            emit(plo, phi, j, seed_ei);
+            mb_begin = tot;
+            plo = 0; phi = fhi; lo = 0; hi = fhi;
+            j -= 1;                                   // the failing base is skipped
+            seed_ei = j;
+            window_ei = j;
+        };
+        while (j > 0) {
+            const uint64_t p = beg + j - 1;
+            const uint32_t c = rd.at(p);
+            // symbols that may be consumed before the next window query fires (after the step that
+            // leaves j' with j' + wsize <= window_ei, :469)
+            uint64_t dist = j + wsize > window_ei ? j + wsize - window_ei : 1;
+            if (dist == 0) dist = 1;
+            const uint64_t cap = dist < j ? dist : j;
+            // a fresh seed starts from the full range: the state after its first ftab_k symbols is one
+            // gather in the device table (what k_find_range computes for that word; empty = the word does
+            // not occur, then the steps below find where it stops)
+            if (j == seed_ei && ix.ftab_k && cap >= ix.ftab_k) {
+                uint64_t idx = 0, pw = 1;
+                bool all_major = true;
+                for (uint32_t t = 0; t < ix.ftab_k; ++t) {
+                    const uint32_t mm = s_lut2[rd.at(p - t)];
+                    all_major = all_major && mm != 0xFFu;
+                    idx += (mm & 3u) * pw;
+                    pw *= M;
+                }
+                uint64_t flo, fhi2, fk;
+                if (all_major && ftab_lookup<P>(ix, idx, flo, fhi2, fk) && flo <= fhi2) {
+                    lo = flo; hi = fhi2;
+                    on_ok(ix.ftab_k);
+                    continue;
+                }
+            }
+            uint32_t len;
+            if (lfk(p, c, cap, &len)) { on_ok(len); continue; }
+            if (len == 0) {                           // no k-mer applies: one reference step (:443)
+                if (lf1(c)) on_ok(1u); else on_fail();
+                continue;
+            }
+            // the range died inside q[j-len, j) (lo/hi are untouched by a failed step): halve the window until
+            // one symbol is left -- at most three more gathers -- that symbol is the failing base
+            while (len > 1) {
+                const uint32_t half = len / 2;
+                const uint64_t p2 = beg + j - 1;
+                const uint32_t c2 = rd.at(p2);
+                uint32_t l2;
+                const bool ok2 = half >= 2 ? lfk(p2, c2, half, &l2) : lf1(c2);
+                if (ok2) { on_ok(half); len -= half; } else len = half;
+            }
+            on_fail();
+        }
+        if (hi >= lo && seed_ei >= wsize) update_mbuf(lo, hi);   // :478-480 (m-i == 0)
+        emit(lo, hi, 0, seed_ei);                                // :481
+        if (!FILL) {
+            seed_cnt[i + 1] = ns;
+            mk_cnt[i + 1] = tot;
+        }
+    }
+}
+
+// ---- single LF step for N (range, symbol) triples: RowBowt::LF(range_t, uint8_t), rowbowt.hpp:74-88
+template <typename P>
+__global__ __launch_bounds__(256) void k_lf(const DevIndex ix, const uint64_t *__restrict__ lo_in,
+                                            const uint64_t *__restrict__ hi_in, const uint8_t *__restrict__ sym,
+                                            const uint64_t N, uint64_t *__restrict__ lo_out, uint64_t *__restrict__ hi_out) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < N; i += stride) {
+        const uint64_t lo = lo_in[i], hi = hi_in[i];
+        const uint32_t slot = ix.lut[sym[i]];
+        uint64_t nlo = 1, nhi = 0;
+        // hi >= n is outside rle_string::rank's domain (assert(i<=n), rle_string.hpp:132): answer {1,0}
+        if (slot != 0xFFu && hi < ix.n && lo <= hi + 1) {
+            const DevSym S = ix.syms[slot];
+            RankAux q;
+            uint64_t c_before, c_upto, bh;
+            rank_pair<P>(S, ix.dense, lo, hi + 1, &c_before, &c_upto, &bh, &q);
+            if (c_upto > c_before) { nlo = S.F + c_before; nhi = nlo + (c_upto - c_before) - 1; }
+        }
+        lo_out[i] = nlo;
+        hi_out[i] = nhi;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_count(const uint64_t *__restrict__ lo, const uint64_t *__restrict__ hi,
+                                               const uint64_t N, uint64_t *__restrict__ out) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < N; i += stride)
+        out[i] = hi[i] >= lo[i] ? hi[i] - lo[i] + 1 : 0;  // RowBowt::count, rowbowt.hpp:266-269
+}
+
+}  // namespace
+
+int launch_markers_plan(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t *lo, const uint64_t *hi, uint64_t N,
+                        uint64_t *mk_off, void *tmp, size_t tmp_bytes, void *stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(k_markers_count, dim3(grid_for(cfg, N)), dim3(cfg.block_threads), 0, st, ix, lo, hi, N, mk_off);
+    int rc = static_cast<int>(hipGetLastError());
+    if (rc) return rc;
+    return scan_in_place(mk_off + 1, N, tmp, tmp_bytes, st);
+}
+
+int launch_markers_fill(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t *lo, const uint64_t *hi, uint64_t N,
+                        const uint64_t *mk_off, uint64_t *mk, void *stream) {
+    if (N == 0) return 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(k_markers_fill, dim3(grid_for(cfg, N)), dim3(cfg.block_threads), 0, st, ix, lo, hi, N, mk_off, mk);
+    return static_cast<int>(hipGetLastError());
+}
+
+
+int launch_find_range_markers_plan(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off,
+                                   uint64_t N, uint64_t wsize, uint64_t max_range, uint64_t *lo, uint64_t *hi,
+                                   uint64_t *mk_off, void *tmp, size_t tmp_bytes, void *stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid(grid_for(cfg, N)), block(cfg.block_threads);
+    if (ix.pos_bytes == 4)
+        hipLaunchKernelGGL((k_find_range_markers<uint32_t, false>), grid, block, 0, st, ix, seqs, off, N, wsize, max_range, lo, hi, mk_off, nullptr, nullptr);
+    else
+        hipLaunchKernelGGL((k_find_range_markers<uint64_t, false>), grid, block, 0, st, ix, seqs, off, N, wsize, max_range, lo, hi, mk_off, nullptr, nullptr);
+    int rc = static_cast<int>(hipGetLastError());
+    if (rc) return rc;
+    return scan_in_place(mk_off + 1, N, tmp, tmp_bytes, st);
+}
+
+int launch_find_range_markers_fill(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off,
+                                   uint64_t N, uint64_t wsize, uint64_t max_range, const uint64_t *mk_off, uint64_t *mk,
+                                   void *stream) {
+    if (N == 0) return 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid(grid_for(cfg, N)), block(cfg.block_threads);
+    if (ix.pos_bytes == 4)
+        hipLaunchKernelGGL((k_find_range_markers<uint32_t, true>), grid, block, 0, st, ix, seqs, off, N, wsize, max_range, nullptr, nullptr, nullptr, mk_off, mk);
+    else
+        hipLaunchKernelGGL((k_find_range_markers<uint64_t, true>), grid, block, 0, st, ix, seqs, off, N, wsize, max_range, nullptr, nullptr, nullptr, mk_off, mk);
+    return static_cast<int>(hipGetLastError());
+}
+
+int launch_marker_seeds_plan(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
+                             uint64_t wsize, uint64_t max_range, uint64_t ftab_k, uint64_t *seed_off, uint64_t *mk_off, void *tmp,
+                             size_t tmp_bytes, void *stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (ix.pos_bytes == 4) {
+        auto kern = k_marker_seeds<uint32_t, false>;
+        const KmerLaunch L = kmer_launch(ix, cfg, N, kern, 0, kSeedKmerLevel);
+        hipLaunchKernelGGL(kern, L.grid, L.block, L.lds, st, ix, seqs, off, N, wsize, max_range, ftab_k, seed_off, mk_off, nullptr, nullptr, nullptr, nullptr, kSeedKmerLevel);
+    } else {
+        auto kern = k_marker_seeds<uint64_t, false>;
+        const KmerLaunch L = kmer_launch(ix, cfg, N, kern, 0, kSeedKmerLevel);
+        hipLaunchKernelGGL(kern, L.grid, L.block, L.lds, st, ix, seqs, off, N, wsize, max_range, ftab_k, seed_off, mk_off, nullptr, nullptr, nullptr, nullptr, kSeedKmerLevel);
+    }
+    int rc = static_cast<int>(hipGetLastError());
+    if (rc) return rc;
+    rc = scan_in_place(seed_off + 1, N, tmp, tmp_bytes, st);
+    if (rc) return rc;
+    return scan_in_place(mk_off + 1, N, tmp, tmp_bytes, st);
+}
+
+int launch_marker_seeds_fill(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
+                             uint64_t wsize, uint64_t max_range, uint64_t ftab_k, const uint64_t *seed_off, const uint64_t *mk_off,
+                             uint64_t *seeds, uint64_t *mk, void *stream) {
+    if (N == 0) return 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (ix.pos_bytes == 4) {
+        auto kern = k_marker_seeds<uint32_t, true>;
+        const KmerLaunch L = kmer_launch(ix, cfg, N, kern, 0, kSeedKmerLevel);
+        hipLaunchKernelGGL(kern, L.grid, L.block, L.lds, st, ix, seqs, off, N, wsize, max_range, ftab_k, nullptr, nullptr, seed_off, mk_off, seeds, mk, kSeedKmerLevel);
+    } else {
+        auto kern = k_marker_seeds<uint64_t, true>;
+        const KmerLaunch L = kmer_launch(ix, cfg, N, kern, 0, kSeedKmerLevel);
+        hipLaunchKernelGGL(kern, L.grid, L.block, L.lds, st, ix, seqs, off, N, wsize, max_range, ftab_k, nullptr, nullptr, seed_off, mk_off, seeds, mk, kSeedKmerLevel);
+    }
+    return static_cast<int>(hipGetLastError());
+}
+
+int launch_greedy_seed(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
+                       uint64_t min_length, uint64_t *lo, uint64_t *hi, uint64_t *qs, uint64_t *qe, uint64_t *ss, void *stream) {
+    if (N == 0) return 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (ix.pos_bytes == 4) {
+        auto kern = k_greedy_seed<uint32_t>;
+        const KmerLaunch L = kmer_launch(ix, cfg, N, kern, 0, kSeedKmerLevel);
+        hipLaunchKernelGGL(kern, L.grid, L.block, L.lds, st, ix, seqs, off, N, min_length, lo, hi, qs, qe, ss, kSeedKmerLevel);
+    } else {
+        auto kern = k_greedy_seed<uint64_t>;
+        const KmerLaunch L = kmer_launch(ix, cfg, N, kern, 0, kSeedKmerLevel);
+        hipLaunchKernelGGL(kern, L.grid, L.block, L.lds, st, ix, seqs, off, N, min_length, lo, hi, qs, qe, ss, kSeedKmerLevel);
+    }
+    return static_cast<int>(hipGetLastError());
+}
+
+int launch_lf(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t *lo, const uint64_t *hi, const uint8_t *sym,
+              uint64_t N, uint64_t *lo_out, uint64_t *hi_out, void *stream) {
+    if (N == 0) return 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid(grid_for(cfg, N)), block(cfg.block_threads);
+    if (ix.pos_bytes == 4) hipLaunchKernelGGL((k_lf<uint32_t>), grid, block, 0, st, ix, lo, hi, sym, N, lo_out, hi_out);
+    else hipLaunchKernelGGL((k_lf<uint64_t>), grid, block, 0, st, ix, lo, hi, sym, N, lo_out, hi_out);
+    return static_cast<int>(hipGetLastError());
+}
+
+int launch_count_from_ranges(const uint64_t *lo, const uint64_t *hi, uint64_t N, uint64_t *count, void *stream) {
+    if (N == 0) return 0;
+    LaunchCfg cfg;
+    hipLaunchKernelGGL(k_count, dim3(grid_for(cfg, N)), dim3(256), 0, static_cast<hipStream_t>(stream), lo, hi, N, count);
+    return static_cast<int>(hipGetLastError());
+}
+
+}  // namespace rbg

@@ -1,5 +1,5 @@
 // rbg_capi.hip -- the C-ABI of include/rbg.h: owns the host copy of the flat index and its
-// HBM replica, stages host batches, launches the kernels of rbg_kernels.hip.
+// HBM replica, stages host batches, launches the kernels of k_search.hip / k_locate.hip / k_markers.hip / k_build.hip.
 // There is deliberately no CPU compute path in this library.
 #include <hip/hip_runtime.h>
 #include <sys/mman.h>

@@ -127,7 +127,7 @@ struct LaunchCfg {
     int max_blocks = 0;  // 0: derive from the device
 };
 
-// launchers (rbg_kernels.hip).  All asynchronous on `stream`; return hipError_t as int.
+// launchers (k_search.hip, k_locate.hip, k_markers.hip, k_build.hip).  All asynchronous on `stream`; return hipError_t as int.
 int launch_find_range(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
                       uint64_t *lo, uint64_t *hi, uint64_t *ssamp /*nullable*/, void *stream);
 size_t scan_tmp_bytes(uint64_t N);

@@ -1,0 +1,310 @@
+// rbg_device.hpp -- device-side building blocks shared by the kernel translation units (k_search.hip,
+// k_locate.hip, k_markers.hip, k_build.hip): the rank over one slot table, the staged record table, the read
+// cursor, and the host-side launch geometry.  Everything lives in an anonymous namespace: each unit gets its
+// own inlined copy.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <mutex>
+#include <set>
+#include <utility>
+
+#include "rbg_dev.h"
+
+namespace rbg {
+namespace {
+
+constexpr int kWave = 64;
+
+// A slot is 4 words and must arrive as ONE request: left to itself the compiler fetches the word
+// that decides a branch first and the rest later (two gather requests instead of one; seen in the
+// ISA of k_locate_fill), so slots are loaded through a vector type.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+
+template <typename SlotT>
+__device__ __forceinline__ SlotT load_slot(const SlotT *p) {
+    SlotT s;
+    if constexpr (sizeof(SlotT) == 16) {
+        const u32x4 t = *reinterpret_cast<const u32x4 *>(p);
+        __builtin_memcpy(&s, &t, 16);
+    } else {
+        static_assert(sizeof(SlotT) == 32, "slot is 4 words of 4 or 8 bytes");
+        const u64x2 a = *reinterpret_cast<const u64x2 *>(p);
+        const u64x2 b = *(reinterpret_cast<const u64x2 *>(p) + 1);
+        __builtin_memcpy(&s, &a, 16);
+        __builtin_memcpy(reinterpret_cast<char *>(&s) + 16, &b, 16);
+    }
+    return s;
+}
+
+// ---- rank over one symbol table -----------------------------------------------------------------
+// Returns # of the symbol in BWT[0,i)  ==  rle_string::rank(i,c) (rle_string.hpp:131-161).
+// `sl` is the RankSlot of bucket b = i >> shift, already in registers (rbg_dev.h): nothing else is
+// read unless the bucket holds more than 4 run starts.
+// *nbefore = # runs of the symbol that start in [B0, i)  (-> ordinal of the predecessor run),
+// *inside  = position i-1 holds the symbol; both feed the toehold update.
+struct RankAux {
+    uint32_t nbefore;  // overflow bucket: i - B0 instead (the run ordinal is searched only if it is needed)
+    bool inside;
+    bool ovf;
+};
+
+// # runs of the symbol that start before i, searched in the run list of bucket b (overflow buckets without
+// a dense table only)
+template <typename P>
+__device__ __forceinline__ uint64_t search_runs(const RunEnt<P> *__restrict__ ent, uint64_t a, uint64_t z, uint64_t i) {
+    while (z - a > 4) {
+        const uint64_t mid = a + ((z - a) >> 1);
+        if (static_cast<uint64_t>(ent[mid].start) < i) a = mid + 1; else z = mid;
+    }
+    while (a < z && static_cast<uint64_t>(ent[a].start) < i) ++a;
+    return a;
+}
+template <typename P>
+__device__ __forceinline__ uint64_t runs_before(const DevSym &S, uint64_t b, uint64_t i) {
+    return search_runs<P>(static_cast<const RunEnt<P> *>(S.ent), S.ord[b], S.ord[b + 1], i);
+}
+
+template <typename P>
+__device__ __forceinline__ uint64_t rank_in_slot(const DevSym &S, const RankSlot &sl, uint64_t b, uint64_t i,
+                                                 const uint8_t *__restrict__ dense, RankAux *aux) {
+    const uint32_t w1 = sl.w1, w2 = sl.w2, w3 = sl.w3;
+    const bool wide = S.shift > kMaxNarrowShift;
+    const uint32_t cnt = wide ? (w1 >> 21) & 7u : (w1 >> 9) & 7u;
+    if (wide && cnt != kSlotOvf) {  // wide-bucket encoding (rbg_dev.h); overflow buckets share the path below
+        const uint32_t o = static_cast<uint32_t>(i - (b << S.shift));
+        const uint32_t ext = (w1 >> 8) & 0x1FFFu;
+        uint32_t add = o < ext ? o : ext;
+        bool in = o ? (o <= ext) : ((w1 >> 24) & 1u);
+        uint32_t nb = 0;
+#define RBG_RUNW(field)                                           \
+    {                                                             \
+        const uint32_t run_ = (field) & 0xFFFFFFu;                \
+        const uint32_t off_ = run_ & 0xFFFu;                      \
+        const uint32_t len_ = (run_ >> 12) + 1u;                  \
+        if (run_ != 0xFFFFFFu && o > off_) {                      \
+            const uint32_t d_ = o - off_;                         \
+            add += d_ < len_ ? d_ : len_;                         \
+            in = in || d_ <= len_;                                \
+            ++nb;                                                 \
+        }                                                         \
+    }
+        RBG_RUNW(w2)
+        RBG_RUNW(w3)
+#undef RBG_RUNW
+        aux->ovf = false;
+        aux->nbefore = nb;
+        aux->inside = in;
+        return (static_cast<uint64_t>(sl.r0) | (static_cast<uint64_t>(w1 & 0xFFu) << 32)) + add;
+    }
+    if (cnt == kSlotOvf) {
+        const uint32_t o = static_cast<uint32_t>(i - (b << S.shift));
+        if (dense && !wide) {
+            // dense bucket (rbg_dev.h): two bytes per row -- rank(B0 + o) - rank(B0), and 255 if position
+            // i-1 holds the symbol, else the number of runs that start in [B0, i)
+            const uint32_t e = reinterpret_cast<const uint16_t *>(dense + (static_cast<uint64_t>(w2) << 4))[o];
+            aux->ovf = false;
+            aux->nbefore = e >> 8;
+            aux->inside = (e >> 8) == 255u;
+            return (static_cast<uint64_t>(sl.r0) | (static_cast<uint64_t>(w3 >> 16) << 32)) + (e & 0xFFu);
+        }
+        aux->ovf = true;
+        aux->nbefore = o;
+        const RunEnt<P> *__restrict__ ent = static_cast<const RunEnt<P> *>(S.ent);
+        const uint64_t a = runs_before<P>(S, b, i);
+        if (a == 0) { aux->inside = false; return 0; }
+        const RunEnt<P> e = ent[a - 1];
+        const uint64_t len = static_cast<uint64_t>(ent[a].cum) - static_cast<uint64_t>(e.cum);
+        const uint64_t d = i - static_cast<uint64_t>(e.start);
+        aux->inside = d <= len;
+        return static_cast<uint64_t>(e.cum) + (d < len ? d : len);
+    }
+    const uint32_t o = static_cast<uint32_t>(i - (b << S.shift));
+    const uint32_t ext = w1 & 0x1FFu;
+    uint32_t add = o < ext ? o : ext;
+    bool in = o ? (o <= ext) : ((w1 >> 12) & 1u);
+    uint32_t nb = 0;
+#define RBG_RUN(field)                                            \
+    {                                                             \
+        const uint32_t run_ = (field);                            \
+        const uint32_t off_ = run_ & 0xFFu;                       \
+        const uint32_t len_ = ((run_ >> 8) & 0xFFu) + 1u;         \
+        if (o > off_) {                                           \
+            const uint32_t d_ = o - off_;                         \
+            add += d_ < len_ ? d_ : len_;                         \
+            in = in || d_ <= len_;                                \
+            ++nb;                                                 \
+        }                                                         \
+    }
+    RBG_RUN(w1 >> 16)
+    RBG_RUN(w2 & 0xFFFFu)
+    RBG_RUN(w2 >> 16)
+    RBG_RUN(w3 & 0xFFFFu)
+#undef RBG_RUN
+    aux->ovf = false;
+    aux->nbefore = nb;
+    aux->inside = in;
+    return (static_cast<uint64_t>(sl.r0) | (static_cast<uint64_t>(w3 >> 16) << 32)) + add;
+}
+
+// both ranks of one LF step (rowbowt.hpp:79,83).  lo and hi+1 usually share a bucket late in the
+// search (the range has narrowed to a few dozen rows), so the step is ONE 4-word load.
+template <typename P>
+__device__ __forceinline__ void rank_pair(const DevSym &S, const uint8_t *__restrict__ dense, uint64_t lo, uint64_t hi1,
+                                          uint64_t *c_before, uint64_t *c_upto, uint64_t *bh_out, RankAux *qaux) {
+    const RankSlot *__restrict__ slots = static_cast<const RankSlot *>(S.slots);
+    const uint64_t bl = lo >> S.shift, bh = hi1 >> S.shift;
+    const RankSlot sl = load_slot(slots + bl);
+    RankSlot sh = sl;
+    if (bh != bl) sh = load_slot(slots + bh);
+    RankAux paux;
+    *c_before = rank_in_slot<P>(S, sl, bl, lo, dense, &paux);
+    *c_upto = rank_in_slot<P>(S, sh, bh, hi1, dense, qaux);
+    *bh_out = bh;
+}
+
+// ordinal of the last run of the symbol that starts before the position a RankAux describes
+template <typename P>
+__device__ __forceinline__ uint64_t pred_run(const DevSym &S, uint64_t b, bool ovf, uint32_t v) {
+    return (ovf ? runs_before<P>(S, b, (b << S.shift) + v) : static_cast<uint64_t>(S.ord[b]) + v) - 1;
+}
+
+// samples_last_ of the last run of the symbol that starts before i (LF_w_loc, rowbowt.hpp:563-566);
+// only taken when position i-1 does not hold the symbol, which is the rare case.
+template <typename P>
+__device__ __forceinline__ uint64_t pred_sample(const DevSym &S, uint64_t b, const RankAux &aux) {
+    return static_cast<uint64_t>(static_cast<const P *>(S.samp)[pred_run<P>(S, b, aux.ovf, aux.nbefore)]);
+}
+
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+    return v;
+}
+
+// ---- K1 / K2 ------------------------------------------------------------------------------------
+// per-lane cursor over the read bytes, fetched as aligned 16-byte chunks while walking right to left
+struct ByteCursor {
+    const uint4 *__restrict__ chunks;
+    uint64_t cur_ci;
+    uint4 w;
+    __device__ __forceinline__ uint32_t at(uint64_t p) {
+        const uint64_t ci = p >> 4;
+        if (ci != cur_ci) { w = chunks[ci]; cur_ci = ci; }
+        // select + shift (indexing the vector by a run-time lane value makes the compiler spill it)
+        const uint32_t sel = static_cast<uint32_t>(p) & 15u;
+        const uint64_t lo64 = (static_cast<uint64_t>(w.y) << 32) | w.x;
+        const uint64_t hi64 = (static_cast<uint64_t>(w.w) << 32) | w.z;
+        const uint64_t half = (sel & 8u) ? hi64 : lo64;
+        return static_cast<uint32_t>(half >> ((sel & 7u) * 8)) & 0xFFu;
+    }
+};
+
+// LDS table of symbol / k-mer records: [singles | 2-mers | 3-mers | 4-mers | 5-mers]
+constexpr int kOff2 = kLdsSyms;
+constexpr int kOff3 = kOff2 + kMaxMajor * kMaxMajor;
+constexpr int kOff4 = kOff3 + kMaxMajor * kMaxMajor * kMaxMajor;
+constexpr int kOff5 = kOff4 + kMaxMajor * kMaxMajor * kMaxMajor * kMaxMajor;
+constexpr int kTabMax = kOff5;                 // levels up to the 4-mers
+constexpr int kTab5 = kOff5 + kMaxMajor * kMaxMajor * kMaxMajor * kMaxMajor * kMaxMajor;  // with the 5-mers (k_find_range's dynamic LDS)
+constexpr uint32_t kHbmRec = 0x80000000u;  // record reference: symbol slot whose DevSym lives in HBM (ix.syms), not in s_tab
+
+__device__ __forceinline__ void stage_tables(const DevIndex &ix, DevSym *s_tab, uint8_t *s_lut, uint8_t *s_lut2, bool with5 = false) {
+    const uint32_t M = ix.nmajor;
+    for (int t = threadIdx.x; t < 256; t += blockDim.x) {
+        s_lut[t] = ix.lut[t];
+        s_lut2[t] = M ? ix.lut2[t] : 0xFFu;
+    }
+    const int nlds = ix.sigma < static_cast<uint32_t>(kLdsSyms) ? static_cast<int>(ix.sigma) : kLdsSyms;
+    for (int t = threadIdx.x; t < nlds; t += blockDim.x) s_tab[t] = ix.syms[t];
+    if (ix.kmer_steps >= 2)
+        for (int t = threadIdx.x; t < static_cast<int>(M * M); t += blockDim.x) s_tab[kOff2 + t] = ix.pairs[t];
+    if (ix.kmer_steps >= 3)
+        for (int t = threadIdx.x; t < static_cast<int>(M * M * M); t += blockDim.x) s_tab[kOff3 + t] = ix.triples[t];
+    if (ix.kmer_steps >= 4)
+        for (int t = threadIdx.x; t < static_cast<int>(M * M * M * M); t += blockDim.x) s_tab[kOff4 + t] = ix.quads[t];
+    if (with5 && ix.kmer_steps >= 5)
+        for (int t = threadIdx.x; t < static_cast<int>(M * M * M * M * M); t += blockDim.x) s_tab[kOff5 + t] = ix.quints[t];
+    __syncthreads();
+}
+
+// ftab entry: the state {lo, hi, toehold} after the word.  At 4-byte positions it is 16 bytes (one request)
+// {lo, hi, toehold, 0}: a toehold of 2^64 - 1 (the word's last row is text position 0) is stored as
+// 0xFFFFFFFF, and a word whose toehold fits neither is stored as {2, 0}: "search it step by step".  At
+// 8-byte positions it is 4 x u64.  Returns false for the step-by-step marker.
+template <typename P>
+__device__ __forceinline__ bool ftab_lookup(const DevIndex &ix, uint64_t idx, uint64_t &lo, uint64_t &hi, uint64_t &k) {
+    if constexpr (sizeof(P) == 4) {
+        const uint4 e = static_cast<const uint4 *>(ix.ftab)[idx];
+        if (e.x > e.y && e.x != 1u) return false;
+        lo = e.x; hi = e.y;
+        k = e.z == 0xFFFFFFFFu ? ~uint64_t(0) : static_cast<uint64_t>(e.z);
+    } else {
+        const ulonglong4 e = static_cast<const ulonglong4 *>(ix.ftab)[idx];
+        lo = e.x; hi = e.y; k = e.z;
+    }
+    return true;
+}
+
+// ---- host side: launch geometry, in-place scan ------------------------------------------------------
+inline int grid_for(const LaunchCfg &cfg, uint64_t N) {
+    const int bt = cfg.block_threads;
+    uint64_t blocks = (N + bt - 1) / bt;
+    const uint64_t cap = cfg.max_blocks > 0 ? static_cast<uint64_t>(cfg.max_blocks) : 256ull * 32;
+    if (blocks > cap) blocks = cap;
+    if (blocks == 0) blocks = 1;
+    return static_cast<int>(blocks);
+}
+
+
+// Launch geometry of the kernels that stage the k-mer records in dynamic LDS: 17 KB and the configured
+// workgroup size up to the 4-mer level; 66 KB with the 5-mer level, then 1024-thread workgroups so that
+// two of them still give 8 waves per SIMD.  The first launch of a kernel with more than 64 KB of dynamic
+// LDS has to raise its limit.
+// The seeding kernels (k_greedy_seed, k_marker_seeds) need more registers per lane; with the 66 KB table and
+// 1024-thread workgroups they drop to 4 waves per SIMD and lose more than the fifth symbol gains
+// (k_marker_seeds 47-50 -> 52 ms per 10M reads): they stage the levels up to 4.
+constexpr uint32_t kSeedKmerLevel = 4;
+
+struct KmerLaunch {
+    dim3 grid, block;
+    size_t lds;
+};
+template <typename Kernel>
+KmerLaunch kmer_launch(const DevIndex &ix, const LaunchCfg &cfg, uint64_t N, Kernel kernel, int grid_cap = 0, uint32_t max_k = 5) {
+    const bool five = ix.kmer_steps >= 5 && max_k >= 5;
+    LaunchCfg c = cfg;
+    if (five) { c.block_threads = 1024; c.max_blocks = cfg.max_blocks > 0 ? std::max(1, cfg.max_blocks / 4) : 256 * 8; }
+    KmerLaunch L;
+    int g = grid_for(c, N);
+    if (grid_cap > 0) g = std::min(g, five ? std::max(1, grid_cap / 4) : grid_cap);
+    L.grid = dim3(g);
+    L.block = dim3(c.block_threads);
+    L.lds = static_cast<size_t>(five ? kTab5 : kTabMax) * sizeof(DevSym);
+    if (five) {  // once per kernel (and device): later launches only look the pointer up
+        static std::mutex mu;
+        static std::set<std::pair<int, const void *>> raised;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const auto key = std::make_pair(dev, reinterpret_cast<const void *>(kernel));
+        std::lock_guard<std::mutex> g(mu);
+        if (raised.insert(key).second)
+            (void)hipFuncSetAttribute(key.second, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(L.lds));
+    }
+    return L;
+}
+
+inline int scan_in_place(uint64_t *vals, uint64_t N, void *tmp, size_t tmp_bytes, hipStream_t st) {
+    if (N == 0) return 0;
+    size_t need = 0;
+    (void)hipcub::DeviceScan::InclusiveSum(nullptr, need, vals, vals, static_cast<int64_t>(N));
+    if (need > tmp_bytes) return static_cast<int>(hipErrorInvalidValue);
+    return static_cast<int>(hipcub::DeviceScan::InclusiveSum(tmp, need, vals, vals, static_cast<int64_t>(N), st));
+}
+
+}  // namespace
+}  // namespace rbg
