@@ -54,7 +54,9 @@ __global__ __launch_bounds__(1024, 8) void k_find_range(const DevIndex ix, const
         // The toehold only flows forward through "k - adv" (row hi carries the symbol); a step that
         // re-samples overwrites it.  While the range is still wide almost every step re-samples
         // (bwt[hi] is a random symbol), so the two gathers of a re-sample (run ordinal, sample) are
-        // deferred until a later step or the end of the read actually needs the value.
+        // deferred to the end of the read: only the LAST re-sample of a read is ever used, and what the
+        // later steps subtract from it is accumulated in k itself (k = 0 at the re-sample, k -= adv after
+        // it, toehold = sample + k in wrapping 64-bit arithmetic, exactly the reference's chain of k - 1).
         bool pend = false;
         uint32_t pend_tab = 0;   // which record to re-sample from: s_tab index, or kHbmRec | symbol slot
         uint64_t pend_b = 0;
@@ -102,14 +104,14 @@ __global__ __launch_bounds__(1024, 8) void k_find_range(const DevIndex ix, const
                 // nested step), or the last run starting before hi ends before hi and its last row
                 // is select(rank(hi,c)-1,c), whose run-end sample is samples_last_[run] (resp. SA-adv).
                 if (q.inside) {
-                    if (pend) { k = resample(); pend = false; }
-                    k = k - adv;
+                    k = k - adv;   // with a re-sample pending, k is minus the distance walked since it
                 } else {
                     pend = true;
                     pend_tab = tab;
                     pend_b = bh;
                     pend_abs = q.ovf;
                     pend_v = q.nbefore;
+                    k = 0;
                 }
             }
             lo = S.F + c_before;           // rowbowt.hpp:86
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(1024, 8) void k_find_range(const DevIndex ix, const
             if (!ok) { alive = false; break; }
             p -= adv - 1;                  // the left neighbours are consumed too
         }
-        if (TOEHOLD && alive && pend) k = resample();
+        if (TOEHOLD && alive && pend) k += resample();
         if (!alive) { lo = 1; hi = 0; k = 0; }  // {1,0}; LFData::clear rowbowt.hpp:153-159
         const uint64_t i = sel ? static_cast<uint64_t>(sel[j_]) : j_;  // (re-read rather than kept live through the search)
         lo_out[i] = lo;
@@ -330,14 +332,14 @@ __global__ __launch_bounds__(1024, 8) void k_find_range_packed(const DevIndex ix
             if (c_inside == 0) return false;                               // rowbowt.hpp:85
             if (TOEHOLD) {                                                 // LF_w_loc, rowbowt.hpp:559-566
                 if (q.inside) {
-                    if (pend) { k = resample(); pend = false; }
-                    k = k - adv;
+                    k = k - adv;   // with a re-sample pending, k is minus the distance walked since it
                 } else {
                     pend = true;
                     pend_tab = tab;
                     pend_b = bh;
                     pend_abs = q.ovf;
                     pend_v = q.nbefore;
+                    k = 0;
                 }
             }
             lo = S.F + c_before;           // rowbowt.hpp:86
@@ -360,7 +362,7 @@ __global__ __launch_bounds__(1024, 8) void k_find_range_packed(const DevIndex ix
             if (!ok) { alive = false; break; }
             r -= a;
         }
-        if (TOEHOLD && alive && pend) k = resample();
+        if (TOEHOLD && alive && pend) k += resample();
         if (!alive) { lo = 1; hi = 0; k = 0; }
         lo_out[i] = lo;
         hi_out[i] = hi;
