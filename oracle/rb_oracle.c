@@ -535,7 +535,8 @@ static int ftab_hit(const orc_index *x, const uint8_t *q, uint64_t e, uint64_t K
 
 /* rowbowt.hpp:406-482.  K == 0: ft_ == nullptr (rb_markers' default).  K > 0: with the ftab of
  * k-mer size K loaded (rb_markers --ftab): the first K bases and every restart after a failed seed
- * go through search_ftab (:430-433, :454-464).  mbuf is appended to by every update_mbuf (markers_at
+ * go through search_ftab (:430-433, :454-464; a k-mer absent from the table restarts from the full
+ * range K bases further left, as the reference's loop does).  mbuf is appended to by every update_mbuf (markers_at
  * does not clear, :271-285, :437-441) and cleared only after a failed seed was reported (:449).
  * A read shorter than K makes the reference throw (substr, :431); here it is treated as a miss. */
 uint64_t orc_markers_greedy_seeding_ftab(const orc_index *x, const uint8_t *q, uint64_t m, uint64_t wsize, uint64_t max_range,
@@ -576,18 +577,16 @@ uint64_t orc_markers_greedy_seeding_ftab(const orc_index *x, const uint8_t *q, u
             pl = fl; ph = fh;                      /* :450 */
             seed_ei = m - i - 1;                   /* :452-453 */
             window_ei = m - i - 1;
-            if (K && m - i - 1 >= K) {             /* :454-464 slide left until a k-mer is in the ftab */
-                for (; m - i - 1 >= K; ++i) {
-                    seed_ei = m - i - 1;
-                    window_ei = m - i - 1;
-                    uint64_t tl, th;
-                    if (ftab_hit(x, q, m - i - 1, K, &tl, &th)) {
-                        l = tl; h = th;
-                        i += K;                    /* :460, then the outer ++i */
-                        pl = l; ph = h;
-                        break;
-                    } else { l = fl; h = fh; }     /* :463 */
-                }
+            if (K && m - i - 1 >= K) {
+                /* :454-464.  search_ftab answers a k-mer that is NOT in the table with {full_range(), 0}
+                 * (:757), so the test "range.first <= range.second" (:459) holds for a miss as well: the
+                 * loop always leaves on its first iteration -- a hit continues from the k-mer's range, a
+                 * miss continues from the FULL range with the K bases skipped (i += K either way). */
+                uint64_t tl, th;
+                if (ftab_hit(x, q, m - i - 1, K, &tl, &th)) { l = tl; h = th; }
+                else { l = fl; h = fh; }
+                i += K;                            /* :460, then the outer ++i */
+                pl = l; ph = h;                    /* :461 */
             } else { l = fl; h = fh; }             /* :466 */
         } else {
             if (window_ei - (m - i - 1) >= wsize) {    /* :469-472 */

@@ -25,22 +25,35 @@ struct PackedBatch {
 class FastxReader {
    public:
     explicit FastxReader(gzFile fp) : fp_(fp), buf_(1 << 22) {}
-    // 0 = record appended, -1 = EOF, -2 = truncated quality string, -3 = stream error
+    // 0 = record appended, -1 = EOF, -2 = truncated quality string, -3 = stream error.  On -2 / -3 the
+    // batch is left exactly as it was at entry: kseq_read's caller never sees that record either
+    // (`while ((err = kseq_read(seq)) >= 0)`, rb_align.cpp:176).
     int next(PackedBatch &b) {
+        const size_t names0 = b.names.size(), seqs0 = b.seqs.size(), nrec0 = b.off.size();
+        auto rollback = [&](int code) {
+            b.names.resize(names0);
+            b.seqs.resize(seqs0);
+            b.name_off.resize(nrec0);
+            b.off.resize(nrec0);
+            return code;
+        };
         int c;
         if (last_char_ == 0) {  // jump to the next header character (kseq.h:183-187)
             while ((c = getc()) >= 0 && c != '>' && c != '@') {}
             if (c < 0) return c;
             last_char_ = c;
         }
-        // name = up to the first whitespace; rest of the line is the comment (kseq.h:189-190)
+        // name = up to the first whitespace (kseq.h:189: an error while reading it ends the call with -3,
+        // end of file before any byte of it with -1); the rest of the line is the comment (kseq.h:190:
+        // its return value is ignored, an error there surfaces in the sequence loop below)
         bool in_name = true, got_any = false;
         while ((c = getc()) >= 0 && c != '\n') {
             got_any = true;
             if (in_name && !isspace(c)) b.names.push_back(static_cast<char>(c));
             else in_name = false;
         }
-        if (c < 0 && !got_any) return c == -3 ? -3 : -1;
+        if (c == -3 && in_name) return rollback(-3);
+        if (c == -1 && !got_any) return rollback(-1);
         b.name_off.push_back(b.names.size());
         // sequence lines until a line starting with '>', '+' or '@' (kseq.h:195-199)
         const size_t seq_begin = b.seqs.size();
@@ -52,26 +65,31 @@ class FastxReader {
         last_char_ = (c == '>' || c == '@') ? c : 0;
         const size_t seq_len = b.seqs.size() - seq_begin;
         b.off.push_back(b.seqs.size());
-        if (c != '+') return c == -3 ? -3 : 0;  // FASTA
+        // FASTA (kseq.h:207): the record read so far is returned even when the stream failed under it;
+        // the error is reported by the NEXT call (ks_getc's sticky ks_err, kseq.h:70)
+        if (c != '+') return 0;
         while ((c = getc()) >= 0 && c != '\n') {}  // rest of the '+' line
-        if (c < 0) return -2;                      // no quality string
+        if (c == -1) return rollback(-2);          // no quality string (kseq.h:213)
         size_t qlen = 0;
         qual_.clear();
-        do {  // kseq.h:212: at least one line, then until the quality is as long as the sequence
+        do {  // kseq.h:214: at least one line, then until the quality is as long as the sequence
             const size_t before = qual_.size();
             if (!read_line_into(qual_, 0)) break;
             qlen += qual_.size() - before;
         } while (qlen < seq_len);
+        // kseq.h:215 tests `c == -3`, but c holds the loop's boolean there (operator precedence): a stream
+        // error inside the quality string comes out as a length mismatch (-2) like a truncated one
         last_char_ = 0;
-        return qlen == seq_len ? 0 : -2;
+        return qlen == seq_len ? 0 : rollback(-2);
     }
 
    private:
     int getc() {
+        if (err_) return -3;  // ks_err is sticky (kseq.h:70)
         if (begin_ >= end_) {
             if (eof_) return -1;
             const int got = gzread(fp_, buf_.data(), static_cast<unsigned>(buf_.size()));
-            if (got < 0) { eof_ = true; return -3; }
+            if (got < 0) { eof_ = true; err_ = true; return -3; }
             if (got == 0) { eof_ = true; return -1; }
             begin_ = 0;
             end_ = static_cast<size_t>(got);
@@ -102,7 +120,7 @@ class FastxReader {
     gzFile fp_;
     std::vector<char> buf_;
     size_t begin_ = 0, end_ = 0;
-    bool eof_ = false;
+    bool eof_ = false, err_ = false;
     int last_char_ = 0;
     std::string qual_;
 };

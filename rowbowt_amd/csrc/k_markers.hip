@@ -437,15 +437,14 @@ __global__ __launch_bounds__(1024) void k_marker_seeds(const DevIndex ix, const 
                     seed_ei = m - i2 - 1;
                     window_ei = m - i2 - 1;
                     lo = 0; hi = fhi;
-                    for (; m - i2 - 1 >= K; ++i2) {        // :454-464 slide left until a k-mer is in the ftab
-                        seed_ei = m - i2 - 1;
-                        window_ei = m - i2 - 1;
-                        if (ftab_hit(m - i2 - 1)) {
-                            i2 += K;                       // :460, then the outer ++i2
-                            plo = lo; phi = hi;
-                            break;
-                        }
-                        lo = 0; hi = fhi;                  // :463
+                    if (m - i2 - 1 >= K) {
+                        // :454-464.  search_ftab answers an absent k-mer with {full_range(), 0} (:757), so the
+                        // reference's test `range.first <= range.second` (:459) holds for a miss too and its loop
+                        // always leaves on the first iteration: a hit continues from the k-mer's range, a miss
+                        // from the FULL range, the K bases skipped either way (i += K, then the outer ++i)
+                        if (!ftab_hit(m - i2 - 1)) { lo = 0; hi = fhi; }
+                        i2 += K;                           // :460
+                        plo = lo; phi = hi;                // :461
                     }
                 }
             }

@@ -226,9 +226,17 @@ int main(int argc, char **argv) {
     stop = std::chrono::high_resolution_clock::now();
     const std::chrono::duration<double> total_query_time = stop - start;
     gzclose(fq_fp);
-    if (err == -2) {  // rb_align.cpp:182-191
-        fprintf(stderr, "ERROR: truncated quality string\n");
-        exit(1);
+    switch (err) {  // rb_align.cpp:182-191
+        case -2:
+            fprintf(stderr, "ERROR: truncated quality string\n");
+            exit(1);
+            break;
+        case -3:
+            fprintf(stderr, "ERROR: error reading stream\n");
+            exit(1);
+            break;
+        default:
+            break;
     }
     std::cerr << index_load_time.count() << " " << total_query_time.count() << std::endl;  // rb_align.cpp:192
     return 0;

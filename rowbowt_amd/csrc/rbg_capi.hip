@@ -12,6 +12,7 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <vector>
@@ -629,6 +630,21 @@ int index_from_bundle(FlatBundle &b, int device, rbg_index **out) {
     return finish(ix, device, out);
 }
 
+// No exception leaves the C ABI: a corrupt file that makes a reader allocate absurdly, or plain memory
+// exhaustion on the host, comes back as an error code (the callers are C, cgo-style bindings, ctypes).
+template <typename F>
+int guarded(F &&f) noexcept {
+    try {
+        return f();
+    } catch (const std::bad_alloc &) {
+        return RBG_ENOMEM;
+    } catch (const std::length_error &) {
+        return RBG_ENOMEM;
+    } catch (...) {
+        return RBG_EFORMAT;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -649,6 +665,7 @@ const char *rbg_strerror(int code) {
 }
 
 int rbg_set_default_option(int opt, int64_t value) {
+    return guarded([&]() -> int {
     switch (opt) {
         case RBG_OPT_BLOCK_THREADS:
             if (value < 64 || value > 256 || value % 64) return RBG_EARG;  // kernels are built for <= 4 waves per workgroup
@@ -682,9 +699,11 @@ int rbg_set_default_option(int opt, int64_t value) {
             g_opt_packed_reads = value; return RBG_OK;
         default: return RBG_EARG;
     }
+    });
 }
 
 int rbg_load(const char *prefix, int flags, int device, rbg_index **out) {
+    return guarded([&]() -> int {
     if (!prefix || !out) return RBG_EARG;
     *out = nullptr;
     FlatBundle b;
@@ -717,9 +736,11 @@ int rbg_load(const char *prefix, int flags, int device, rbg_index **out) {
     }
     if (rc) return rc;
     return index_from_bundle(b, device, out);
+    });
 }
 
 int rbg_load_cache(const char *path, int flags, int device, rbg_index **out) {
+    return guarded([&]() -> int {
     if (!path || !out) return RBG_EARG;
     *out = nullptr;
     FlatBundle b;
@@ -732,18 +753,22 @@ int rbg_load_cache(const char *path, int flags, int device, rbg_index **out) {
     b.has_ma = b.has_ma && (flags & RBG_LOAD_MA);
     b.has_dl = b.has_dl && (flags & RBG_LOAD_DL);
     return index_from_bundle(b, device, out);
+    });
 }
 
 int rbg_convert_index(const char *prefix, int flags, const char *out_path) {
+    return guarded([&]() -> int {
     if (!prefix || !out_path) return RBG_EARG;
     FlatBundle b;
     int rc = bundle_from_index_files(prefix, flags, b);
     if (rc) return rc;
     return write_flat(out_path, b);
+    });
 }
 
 int rbg_convert_raw(const char *bwt_fname, const char *ssa_fname, const char *esa_fname, const char *mab_fname,
                     const char *docs_fname, const char *out_path) {
+    return guarded([&]() -> int {
     if (!bwt_fname || !out_path || (!!ssa_fname != !!esa_fname)) return RBG_EARG;
     FlatBundle b;
     int rc = bundle_from_raw_files(bwt_fname, ssa_fname, esa_fname, b);
@@ -758,10 +783,12 @@ int rbg_convert_raw(const char *bwt_fname, const char *ssa_fname, const char *es
         b.has_dl = true;
     }
     return write_flat(out_path, b);
+    });
 }
 
 int rbg_build_from_runs(const uint8_t *heads, const uint64_t *lens, uint64_t R, const uint64_t *ssa_y,
                         const uint64_t *esa_y, int device, rbg_index **out) {
+    return guarded([&]() -> int {
     if (!heads || !lens || !out || R == 0 || (!!ssa_y != !!esa_y)) return RBG_EARG;
     *out = nullptr;
     RawRle rle;
@@ -788,18 +815,22 @@ int rbg_build_from_runs(const uint8_t *heads, const uint64_t *lens, uint64_t R, 
     int rc = flatten(rle, ssa_y ? &tsa : nullptr, current_options(), ix->host);
     if (rc) { delete ix; return rc; }
     return finish(ix, device, out);
+    });
 }
 
 int rbg_build_from_files(const char *bwt_fname, const char *ssa_fname, const char *esa_fname, int device, rbg_index **out) {
+    return guarded([&]() -> int {
     if (!bwt_fname || !out || (!!ssa_fname != !!esa_fname)) return RBG_EARG;
     *out = nullptr;
     FlatBundle b;
     int rc = bundle_from_raw_files(bwt_fname, ssa_fname, esa_fname, b);
     if (rc) return rc;
     return index_from_bundle(b, device, out);
+    });
 }
 
 int rbg_write_ftab(rbg_index *ix, uint64_t k, const char *path) {
+    return guarded([&]() -> int {
     if (!queryable(ix)) return RBG_ENODEV;
     if (!path || k == 0 || k > 16) return RBG_EARG;
     FILE *fp = std::fopen(path, "wb");
@@ -812,12 +843,14 @@ int rbg_write_ftab(rbg_index *ix, uint64_t k, const char *path) {
     if (std::fclose(fp) != 0) io_ok = false;
     if (!rc && !io_ok) rc = RBG_EIO;
     return rc;
+    });
 }
 
 // FTab::load (ftab.hpp:15-27) keeps k = length of the last line's k-mer.  The file is accepted only if
 // it is, byte for byte, the table build_ftab(k) gives for this index: then search_ftab(q) is
 // "find_range(q) when q is over ACGT and occurs", which is how the ftab variants are computed here.
 int rbg_check_ftab(rbg_index *ix, const char *path, uint64_t *k_out) {
+    return guarded([&]() -> int {
     if (!queryable(ix)) return RBG_ENODEV;
     if (!path || !k_out) return RBG_EARG;
     *k_out = 0;
@@ -841,10 +874,12 @@ int rbg_check_ftab(rbg_index *ix, const char *path, uint64_t *k_out) {
     if (!same) return RBG_EFORMAT;
     *k_out = k;
     return RBG_OK;
+    });
 }
 
 int rbg_set_markers(rbg_index *ix, const uint64_t *run_start, const uint64_t *run_end, uint64_t nruns,
                     const uint64_t *mk_off, const uint64_t *mk_vals) {
+    return guarded([&]() -> int {
     if (!ix || !run_start || !run_end || !mk_off || (!mk_vals && mk_off[nruns])) return RBG_EARG;
     if (!markers_valid(run_start, run_end, nruns, mk_off)) return RBG_EARG;
     std::lock_guard<std::mutex> g(ix->mu);
@@ -861,9 +896,11 @@ int rbg_set_markers(rbg_index *ix, const uint64_t *run_start, const uint64_t *ru
         return upload_markers(ix);
     }
     return RBG_OK;
+    });
 }
 
 int rbg_set_docs(rbg_index *ix, const char *names_joined, const uint64_t *starts, uint64_t ndocs) {
+    return guarded([&]() -> int {
     if (!ix || !names_joined || !starts) return RBG_EARG;
     std::lock_guard<std::mutex> g(ix->mu);
     RawDocs &d = ix->host.dl;
@@ -878,6 +915,7 @@ int rbg_set_docs(rbg_index *ix, const char *names_joined, const uint64_t *starts
     std::sort(d.sorted.begin(), d.sorted.end());
     ix->host.has_dl = true;
     return RBG_OK;
+    });
 }
 
 void rbg_free(rbg_index *ix) {
@@ -892,6 +930,7 @@ void rbg_free(rbg_index *ix) {
 void rbg_free_buffer(void *p) { std::free(p); }
 
 int rbg_info(const rbg_index *ix, rbg_info_t *out) {
+    return guarded([&]() -> int {
     if (!ix || !out) return RBG_EARG;
     std::memset(out, 0, sizeof(*out));
     out->n = ix->host.n;
@@ -919,22 +958,28 @@ int rbg_info(const rbg_index *ix, rbg_info_t *out) {
     for (const SymTable &t : ix->host.quad) out->quad_runs += t.nruns;
     for (const SymTable &t : ix->host.quint) out->quint_runs += t.nruns;
     return RBG_OK;
+    });
 }
 
 int rbg_get_f(const rbg_index *ix, uint64_t f_out[256]) {
+    return guarded([&]() -> int {
     if (!ix || !f_out) return RBG_EARG;
     std::memcpy(f_out, ix->host.f, 256 * sizeof(uint64_t));
     return RBG_OK;
+    });
 }
 
 int rbg_last_run_sample(const rbg_index *ix, uint64_t *out) {
+    return guarded([&]() -> int {
     if (!ix || !out) return RBG_EARG;
     if (!ix->host.has_tsa) return RBG_ENOTLOADED;
     *out = ix->host.last_run_sample;
     return RBG_OK;
+    });
 }
 
 int rbg_host_array(const rbg_index *ix, int which, uint64_t *dst, uint64_t cap, uint64_t *count) {
+    return guarded([&]() -> int {
     if (!ix || !count) return RBG_EARG;
     const HostIndex &h = ix->host;
     const std::vector<uint64_t> *v = nullptr;
@@ -954,9 +999,11 @@ int rbg_host_array(const rbg_index *ix, int which, uint64_t *dst, uint64_t cap, 
     *count = v->size();
     if (dst) std::memcpy(dst, v->data(), std::min<uint64_t>(cap, v->size()) * 8);
     return RBG_OK;
+    });
 }
 
 int rbg_resolve_offset(const rbg_index *ix, uint64_t i, const char **name, uint64_t *offset) {
+    return guarded([&]() -> int {
     if (!ix || !name || !offset) return RBG_EARG;
     if (!ix->host.has_dl || ix->host.dl.names.empty()) return RBG_ENOTLOADED;
     const RawDocs &d = ix->host.dl;
@@ -969,25 +1016,30 @@ int rbg_resolve_offset(const rbg_index *ix, uint64_t i, const char **name, uint6
     *offset = i - d.sorted[rank - 1];           // doclist.hpp:48
     *name = d.names[rank - 1].c_str();          // doclist.hpp:49
     return RBG_OK;
+    });
 }
 
 // ---- device-resident entry points ------------------------------------------------------------------
 
 int rbg_find_range_dev(rbg_index *ix, const uint8_t *d_seqs, const uint64_t *d_off, uint64_t N, uint64_t *d_lo,
                        uint64_t *d_hi, void *stream) {
+    return guarded([&]() -> int {
     if (!queryable(ix)) return RBG_ENODEV;
     if (N && (!d_seqs || !d_off || !d_lo || !d_hi)) return RBG_EARG;
     if (reinterpret_cast<uintptr_t>(d_seqs) & 15) return RBG_EARG;  // reads are fetched as aligned 16-byte chunks
     return launch_find_range(ix->dev, ix->cfg, d_seqs, d_off, N, d_lo, d_hi, nullptr, stream) ? RBG_ENODEV : RBG_OK;
+    });
 }
 
 int rbg_find_range_w_toehold_dev(rbg_index *ix, const uint8_t *d_seqs, const uint64_t *d_off, uint64_t N,
                                  uint64_t *d_lo, uint64_t *d_hi, uint64_t *d_ssamp, void *stream) {
+    return guarded([&]() -> int {
     if (!queryable(ix)) return RBG_ENODEV;
     if (!ix->host.has_tsa) return RBG_ENOTLOADED;
     if (N && (!d_seqs || !d_off || !d_lo || !d_hi || !d_ssamp)) return RBG_EARG;
     if (reinterpret_cast<uintptr_t>(d_seqs) & 15) return RBG_EARG;
     return launch_find_range(ix->dev, ix->cfg, d_seqs, d_off, N, d_lo, d_hi, d_ssamp, stream) ? RBG_ENODEV : RBG_OK;
+    });
 }
 
 // ---- packed reads (device API) ------------------------------------------------------------------
@@ -1004,71 +1056,87 @@ static int packed_args_ok(const rbg_index *ix, const void *d_ws, const uint8_t *
 
 int rbg_pack_reads_dev(rbg_index *ix, const uint8_t *d_seqs, const uint64_t *d_off, uint64_t N, uint64_t total_bytes,
                        void *d_ws, size_t ws_bytes, void *stream) {
+    return guarded([&]() -> int {
     int rc = packed_args_ok(ix, d_ws, d_seqs, d_off, N, total_bytes);
     if (rc) return rc;
     if (ws_bytes < pack_ws_bytes(N, total_bytes)) return RBG_EARG;
     return launch_pack_reads(ix->dev, ix->cfg, d_seqs, d_off, N, total_bytes, d_ws, ws_bytes, stream) ? RBG_ENODEV : RBG_OK;
+    });
 }
 
 int rbg_find_range_packed_dev(rbg_index *ix, const void *d_ws, const uint8_t *d_seqs, const uint64_t *d_off, uint64_t N,
                               uint64_t total_bytes, uint64_t *d_lo, uint64_t *d_hi, void *stream) {
+    return guarded([&]() -> int {
     int rc = packed_args_ok(ix, d_ws, d_seqs, d_off, N, total_bytes);
     if (rc) return rc;
     if (N && (!d_lo || !d_hi)) return RBG_EARG;
     return launch_find_range_packed(ix->dev, ix->cfg, d_ws, d_seqs, d_off, N, total_bytes, d_lo, d_hi, nullptr, stream) ? RBG_ENODEV : RBG_OK;
+    });
 }
 
 int rbg_find_range_w_toehold_packed_dev(rbg_index *ix, const void *d_ws, const uint8_t *d_seqs, const uint64_t *d_off, uint64_t N,
                                         uint64_t total_bytes, uint64_t *d_lo, uint64_t *d_hi, uint64_t *d_ssamp, void *stream) {
+    return guarded([&]() -> int {
     int rc = packed_args_ok(ix, d_ws, d_seqs, d_off, N, total_bytes);
     if (rc) return rc;
     if (!ix->host.has_tsa) return RBG_ENOTLOADED;
     if (N && (!d_lo || !d_hi || !d_ssamp)) return RBG_EARG;
     return launch_find_range_packed(ix->dev, ix->cfg, d_ws, d_seqs, d_off, N, total_bytes, d_lo, d_hi, d_ssamp, stream) ? RBG_ENODEV : RBG_OK;
+    });
 }
 
 size_t rbg_locate_plan_tmp_bytes(uint64_t N) { return scan_tmp_bytes(N); }
 
 int rbg_locate_plan_dev(rbg_index *ix, const uint64_t *d_lo, const uint64_t *d_hi, uint64_t N, uint64_t max_hits,
                         uint64_t *d_loc_off, void *d_tmp, size_t tmp_bytes, void *stream) {
+    return guarded([&]() -> int {
     if (!queryable(ix)) return RBG_ENODEV;
     if (!ix->host.has_tsa) return RBG_ENOTLOADED;
     if (!d_loc_off || (N && (!d_lo || !d_hi || !d_tmp))) return RBG_EARG;
     return launch_locate_plan(ix->dev, ix->cfg, d_lo, d_hi, N, max_hits, d_loc_off, d_tmp, tmp_bytes, stream) ? RBG_ENODEV : RBG_OK;
+    });
 }
 
 size_t rbg_locate_order_ws_bytes(uint64_t N) { return locate_order_ws_bytes(N); }
 
 int rbg_locate_order_dev(rbg_index *ix, const uint64_t *d_k, uint64_t N, void *d_ws, size_t ws_bytes, void *stream) {
+    return guarded([&]() -> int {
     if (!queryable(ix)) return RBG_ENODEV;
     if (!ix->host.has_tsa) return RBG_ENOTLOADED;
     if (N && (!d_k || !d_ws)) return RBG_EARG;
     if (N >= 0xFFFFFFFFull || ws_bytes < locate_order_ws_bytes(N) || (reinterpret_cast<uintptr_t>(d_ws) & 255)) return RBG_EARG;
     return launch_locate_order(ix->dev, ix->cfg, d_k, N, d_ws, ws_bytes, stream) ? RBG_ENODEV : RBG_OK;
+    });
 }
 
 int rbg_locate_fill_dev(rbg_index *ix, const uint64_t *d_lo, const uint64_t *d_hi, const uint64_t *d_k, uint64_t N,
                         uint64_t max_hits, const uint64_t *d_loc_off, uint64_t *d_locs, const void *d_order, void *stream) {
+    return guarded([&]() -> int {
     if (!queryable(ix)) return RBG_ENODEV;
     if (!ix->host.has_tsa) return RBG_ENOTLOADED;
     if (N && (!d_lo || !d_hi || !d_k || !d_loc_off || !d_locs)) return RBG_EARG;
     return launch_locate_fill(ix->dev, ix->cfg, d_lo, d_hi, d_k, N, max_hits, d_loc_off, d_locs, nullptr, d_order, stream) ? RBG_ENODEV : RBG_OK;
+    });
 }
 
 int rbg_markers_plan_dev(rbg_index *ix, const uint64_t *d_lo, const uint64_t *d_hi, uint64_t N, uint64_t *d_mk_off,
                          void *d_tmp, size_t tmp_bytes, void *stream) {
+    return guarded([&]() -> int {
     if (!queryable(ix)) return RBG_ENODEV;
     if (!ix->host.has_ma) return RBG_ENOTLOADED;
     if (!d_mk_off || (N && (!d_lo || !d_hi || !d_tmp))) return RBG_EARG;
     return launch_markers_plan(ix->dev, ix->cfg, d_lo, d_hi, N, d_mk_off, d_tmp, tmp_bytes, stream) ? RBG_ENODEV : RBG_OK;
+    });
 }
 
 int rbg_markers_fill_dev(rbg_index *ix, const uint64_t *d_lo, const uint64_t *d_hi, uint64_t N,
                          const uint64_t *d_mk_off, uint64_t *d_mk, void *stream) {
+    return guarded([&]() -> int {
     if (!queryable(ix)) return RBG_ENODEV;
     if (!ix->host.has_ma) return RBG_ENOTLOADED;
     if (N && (!d_lo || !d_hi || !d_mk_off || !d_mk)) return RBG_EARG;
     return launch_markers_fill(ix->dev, ix->cfg, d_lo, d_hi, N, d_mk_off, d_mk, stream) ? RBG_ENODEV : RBG_OK;
+    });
 }
 
 // ---- host-buffer entry points ----------------------------------------------------------------------
@@ -1117,6 +1185,7 @@ static int find_range_host(rbg_index *ix, const uint8_t *seqs, const uint64_t *o
 
 int rbg_lf(rbg_index *ix, const uint64_t *lo, const uint64_t *hi, const uint8_t *sym, uint64_t N, uint64_t *lo_out,
            uint64_t *hi_out) {
+    return guarded([&]() -> int {
     if (!queryable(ix)) return RBG_ENODEV;
     if (N == 0) return RBG_OK;
     if (!lo || !hi || !sym || !lo_out || !hi_out) return RBG_EARG;
@@ -1136,27 +1205,35 @@ int rbg_lf(rbg_index *ix, const uint64_t *lo, const uint64_t *hi, const uint8_t 
     HIP_TRY(hipMemcpyAsync(hi_out, dhi2.p, N * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return RBG_OK;
+    });
 }
 
 int rbg_find_range(rbg_index *ix, const uint8_t *seqs, const uint64_t *off, uint64_t N, uint64_t *lo, uint64_t *hi) {
+    return guarded([&]() -> int {
     if (N && (!lo || !hi)) return RBG_EARG;
     return find_range_host(ix, seqs, off, N, lo, hi, nullptr, nullptr);
+    });
 }
 
 int rbg_count(rbg_index *ix, const uint8_t *seqs, const uint64_t *off, uint64_t N, uint64_t *count) {
+    return guarded([&]() -> int {
     if (N && !count) return RBG_EARG;
     return find_range_host(ix, seqs, off, N, nullptr, nullptr, nullptr, count);
+    });
 }
 
 int rbg_find_range_w_toehold(rbg_index *ix, const uint8_t *seqs, const uint64_t *off, uint64_t N, uint64_t *lo,
                              uint64_t *hi, uint64_t *ssamp) {
+    return guarded([&]() -> int {
     if (ix && !ix->host.has_tsa) return RBG_ENOTLOADED;
     if (N && (!lo || !hi || !ssamp)) return RBG_EARG;
     return find_range_host(ix, seqs, off, N, lo, hi, ssamp, nullptr);
+    });
 }
 
 int rbg_locs_at(rbg_index *ix, const uint64_t *lo, const uint64_t *hi, const uint64_t *k, uint64_t N,
                 uint64_t max_hits, uint64_t *loc_off, uint64_t **locs) {
+    return guarded([&]() -> int {
     if (!queryable(ix)) return RBG_ENODEV;
     if (!ix->host.has_tsa) return RBG_ENOTLOADED;
     if (!loc_off || !locs || (N && (!lo || !hi || !k))) return RBG_EARG;
@@ -1184,9 +1261,11 @@ int rbg_locs_at(rbg_index *ix, const uint64_t *lo, const uint64_t *hi, const uin
         return launch_locate_fill(ix->dev, ix->cfg, dlo.as<uint64_t>(), dhi.as<uint64_t>(), dk.as<uint64_t>(), N, max_hits,
                                   doff.as<uint64_t>(), d_vals, nullptr, order, st) ? RBG_ENODEV : RBG_OK;
     });
+    });
 }
 
 int rbg_markers_at(rbg_index *ix, const uint64_t *lo, const uint64_t *hi, uint64_t N, uint64_t *mk_off, uint64_t **mk) {
+    return guarded([&]() -> int {
     if (!queryable(ix)) return RBG_ENODEV;
     if (!ix->host.has_ma) return RBG_ENOTLOADED;
     if (!mk_off || !mk || (N && (!lo || !hi))) return RBG_EARG;
@@ -1209,10 +1288,12 @@ int rbg_markers_at(rbg_index *ix, const uint64_t *lo, const uint64_t *hi, uint64
         return launch_markers_fill(ix->dev, ix->cfg, dlo.as<uint64_t>(), dhi.as<uint64_t>(), N, doff.as<uint64_t>(), d_vals, st)
                    ? RBG_ENODEV : RBG_OK;
     });
+    });
 }
 
 int rbg_find_range_w_markers(rbg_index *ix, const uint8_t *seqs, const uint64_t *off, uint64_t N, uint64_t wsize,
                              uint64_t max_range, uint64_t *lo, uint64_t *hi, uint64_t *mk_off, uint64_t **mk) {
+    return guarded([&]() -> int {
     if (!queryable(ix)) return RBG_ENODEV;
     if (!ix->host.has_ma) return RBG_ENOTLOADED;  // reference: "warning: no marker array found!", default LFData
     if (!mk_off || !mk || wsize == 0 || (N && (!lo || !hi || !off))) return RBG_EARG;
@@ -1239,6 +1320,7 @@ int rbg_find_range_w_markers(rbg_index *ix, const uint8_t *seqs, const uint64_t 
         return launch_find_range_markers_fill(ix->dev, ix->cfg, rb.seqs.as<uint8_t>(), rb.off.as<uint64_t>(), N, wsize,
                                               max_range, doff.as<uint64_t>(), d_vals, st) ? RBG_ENODEV : RBG_OK;
     });
+    });
 }
 
 // ---- marker seeds (next-row f4): get_markers_greedy_seeding, rowbowt.hpp:406-482 ---------------------
@@ -1246,26 +1328,31 @@ int rbg_find_range_w_markers(rbg_index *ix, const uint8_t *seqs, const uint64_t 
 int rbg_marker_seeds_plan_dev(rbg_index *ix, const uint8_t *d_seqs, const uint64_t *d_off, uint64_t N, uint64_t wsize,
                               uint64_t max_range, uint64_t ftab_k, uint64_t *d_seed_off, uint64_t *d_mk_off, void *d_tmp, size_t tmp_bytes,
                               void *stream) {
+    return guarded([&]() -> int {
     if (!queryable(ix)) return RBG_ENODEV;
     if (!d_seed_off || !d_mk_off || (N && (!d_seqs || !d_off))) return RBG_EARG;
     if (reinterpret_cast<uintptr_t>(d_seqs) & 15) return RBG_EARG;
     if (tmp_bytes < scan_tmp_bytes(N) || (N && !d_tmp)) return RBG_EARG;
     return launch_marker_seeds_plan(ix->dev, ix->cfg, d_seqs, d_off, N, wsize, max_range, ftab_k, d_seed_off, d_mk_off, d_tmp, tmp_bytes,
                                     stream) ? RBG_ENODEV : RBG_OK;
+    });
 }
 
 int rbg_marker_seeds_fill_dev(rbg_index *ix, const uint8_t *d_seqs, const uint64_t *d_off, uint64_t N, uint64_t wsize,
                               uint64_t max_range, uint64_t ftab_k, const uint64_t *d_seed_off, const uint64_t *d_mk_off,
                               rbg_marker_seed_t *d_seeds, uint64_t *d_mk, void *stream) {
+    return guarded([&]() -> int {
     if (!queryable(ix)) return RBG_ENODEV;
     if (N && (!d_seqs || !d_off || !d_seed_off || !d_mk_off || !d_seeds)) return RBG_EARG;
     if (reinterpret_cast<uintptr_t>(d_seqs) & 15) return RBG_EARG;
     return launch_marker_seeds_fill(ix->dev, ix->cfg, d_seqs, d_off, N, wsize, max_range, ftab_k, d_seed_off, d_mk_off,
                                     reinterpret_cast<uint64_t *>(d_seeds), d_mk, stream) ? RBG_ENODEV : RBG_OK;
+    });
 }
 
 int rbg_get_markers_greedy_seeding(rbg_index *ix, const uint8_t *seqs, const uint64_t *off, uint64_t N, uint64_t wsize,
                                    uint64_t max_range, uint64_t ftab_k, uint64_t *seed_off, rbg_marker_seed_t **seeds, uint64_t **mk) {
+    return guarded([&]() -> int {
     if (!queryable(ix)) return RBG_ENODEV;
     if (!seed_off || !seeds || !mk || (N && !off)) return RBG_EARG;
     *seeds = nullptr;
@@ -1308,6 +1395,7 @@ int rbg_get_markers_greedy_seeding(rbg_index *ix, const uint8_t *seqs, const uin
     *seeds = h_seeds;
     *mk = h_mk;
     return RBG_OK;
+    });
 }
 
 // ---- greedy seeding (next-row f4) -----------------------------------------------------------------
@@ -1315,21 +1403,25 @@ int rbg_get_markers_greedy_seeding(rbg_index *ix, const uint8_t *seqs, const uin
 int rbg_greedy_longest_seed_dev(rbg_index *ix, const uint8_t *d_seqs, const uint64_t *d_off, uint64_t N, uint64_t min_length,
                                 uint64_t *d_lo, uint64_t *d_hi, uint64_t *d_qstart, uint64_t *d_qend, uint64_t *d_ssamp,
                                 void *stream) {
+    return guarded([&]() -> int {
     if (!queryable(ix)) return RBG_ENODEV;
     if (!ix->host.has_tsa) return RBG_ENOTLOADED;
     if (N && (!d_seqs || !d_off || !d_lo || !d_hi || !d_qstart || !d_qend || !d_ssamp)) return RBG_EARG;
     if (reinterpret_cast<uintptr_t>(d_seqs) & 15) return RBG_EARG;
     return launch_greedy_seed(ix->dev, ix->cfg, d_seqs, d_off, N, min_length, d_lo, d_hi, d_qstart, d_qend, d_ssamp, stream)
                ? RBG_ENODEV : RBG_OK;
+    });
 }
 
 int rbg_locate_fill_offset_dev(rbg_index *ix, const uint64_t *d_lo, const uint64_t *d_hi, const uint64_t *d_k, uint64_t N,
                                uint64_t max_hits, const uint64_t *d_loc_off, uint64_t *d_locs, const uint64_t *d_sub,
                                const void *d_order, void *stream) {
+    return guarded([&]() -> int {
     if (!queryable(ix)) return RBG_ENODEV;
     if (!ix->host.has_tsa) return RBG_ENOTLOADED;
     if (N && (!d_lo || !d_hi || !d_k || !d_loc_off || !d_locs)) return RBG_EARG;
     return launch_locate_fill(ix->dev, ix->cfg, d_lo, d_hi, d_k, N, max_hits, d_loc_off, d_locs, d_sub, d_order, stream) ? RBG_ENODEV : RBG_OK;
+    });
 }
 
 static int greedy_host(rbg_index *ix, const uint8_t *seqs, const uint64_t *off, uint64_t N, uint64_t min_length,
@@ -1373,20 +1465,25 @@ static int greedy_host(rbg_index *ix, const uint8_t *seqs, const uint64_t *off, 
 
 int rbg_greedy_longest_seed(rbg_index *ix, const uint8_t *seqs, const uint64_t *off, uint64_t N, uint64_t min_length,
                             uint64_t *lo, uint64_t *hi, uint64_t *qstart, uint64_t *qend, uint64_t *ssamp) {
+    return guarded([&]() -> int {
     if (N && (!lo || !hi || !qstart || !qend || !ssamp)) return RBG_EARG;
     return greedy_host(ix, seqs, off, N, min_length, lo, hi, qstart, qend, ssamp, false, 0, nullptr, nullptr);
+    });
 }
 
 int rbg_find_locs_greedy_seeding(rbg_index *ix, const uint8_t *seqs, const uint64_t *off, uint64_t N, uint64_t min_length,
                                  uint64_t max_hits, uint64_t *loc_off, uint64_t **locs) {
+    return guarded([&]() -> int {
     if (!loc_off || !locs) return RBG_EARG;
     *locs = nullptr;
     return greedy_host(ix, seqs, off, N, min_length, nullptr, nullptr, nullptr, nullptr, nullptr, true, max_hits, loc_off, locs);
+    });
 }
 
 // ---- counters --------------------------------------------------------------------------------------
 
 int rbg_counters(rbg_index *ix, uint64_t out[4]) {
+    return guarded([&]() -> int {
     if (!queryable(ix)) return RBG_ENODEV;
     if (!out) return RBG_EARG;
     DeviceScope scope(ix->device);
@@ -1394,15 +1491,18 @@ int rbg_counters(rbg_index *ix, uint64_t out[4]) {
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out, ix->dev.counters, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return RBG_OK;
+    });
 }
 
 int rbg_counters_reset(rbg_index *ix) {
+    return guarded([&]() -> int {
     if (!queryable(ix)) return RBG_ENODEV;
     DeviceScope scope(ix->device);
     if (scope.rc) return scope.rc;
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemset(ix->dev.counters, 0, 4 * sizeof(uint64_t)));
     return RBG_OK;
+    });
 }
 
 }  // extern "C"

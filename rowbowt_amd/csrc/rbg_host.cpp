@@ -146,8 +146,11 @@ bool read_sparse(Cursor &c, uint64_t &u, std::vector<uint64_t> &ones) {
 // sdsl::wt_huff<> -> the plain symbol sequence.  Each element is recovered with the wavelet
 // tree's own access walk (bit at the node, rank inside the node, descend) over a popcount
 // directory built here; the serialised rank/select supports are skipped.
-bool read_wt_huff(Cursor &c, std::vector<uint8_t> &seq) {
+// `expect` = the length the caller already knows from data it decoded (the number of run-length entries):
+// the serialised size is never trusted for an allocation or a decode loop.
+bool read_wt_huff(Cursor &c, uint64_t expect, std::vector<uint8_t> &seq) {
     const uint64_t size = c.get<uint64_t>();
+    if (!c.ok() || size != expect) { c.fail(); return false; }
     (void)c.get<uint64_t>();  // sigma
     PackedVec bv, tmp;
     if (!read_packed(c, bv, true)) return false;
@@ -221,7 +224,12 @@ int parse_rbwt(const std::string &fname, RawRle &out) {
     std::vector<uint64_t> letter_size(256, 0);
     for (int s = 0; s < 256; ++s)
         if (!read_sparse(c, letter_size[s], letter_ones[s])) return RBG_EFORMAT;
-    if (!read_wt_huff(c, out.heads)) return RBG_EFORMAT;
+    // R as the per-letter vectors (decoded from bytes that are really in the file) give it: a header that
+    // claims more cannot make the head decoder allocate or loop beyond what the file holds
+    uint64_t letter_runs = 0;
+    for (int s = 0; s < 256; ++s) letter_runs += letter_ones[s].size();
+    if (letter_runs != out.R) return RBG_EFORMAT;
+    if (!read_wt_huff(c, out.R, out.heads)) return RBG_EFORMAT;
     if (!c.at_end() || out.heads.size() != out.R || runs_u != out.n) return RBG_EFORMAT;
     // run lengths: the k-th run of symbol s has length ones[k] - ones[k-1] in s-only space
     // (sparse_sd_vector::gapAt, sparse_sd_vector.hpp:150-154; used by rle_string::run_at :238-242)
@@ -745,6 +753,7 @@ int compose(const HostIndex &ix, const std::vector<uint32_t> &major_slot, const 
             t.F = tp.F + rk;
             t.shift = opt.rank_bucket_shift >= 0 ? static_cast<uint32_t>(opt.rank_bucket_shift) : auto_shift(ix.n, t.nruns, 1.5);
             if (depth + 1 >= 4 && opt.deep_bucket_shift >= 0) t.shift = static_cast<uint32_t>(opt.deep_bucket_shift);  // levels of 4-mers and deeper
+            if (t.shift > 12 || (t.shift > 8 && (ix.n >> 40))) { rcs[m] = RBG_EARG; return; }  // wide buckets carry 40-bit ranks (rbg_dev.h)
             if (t.nruns >= 0xFFFFFFF0ull) { rcs[m] = RBG_EARG; return; }
         }
     };

@@ -32,7 +32,7 @@ def main(out=HERE):
         recs += [(fn, n, s) for n, s in zip(names, seqs)]
     # get_markers_greedy_seeding (rowbowt.hpp:406-482) without and with an ftab
     seeds = {"source": "oracle/rb_oracle.c orc_markers_greedy_seeding_ftab on tests/data/small.fa", "cases": []}
-    for wsize, max_range, ftab_k in ((19, 1000, 0), (5, 1000, 0), (8, 1000, 6), (10, 2, 0)):
+    for wsize, max_range, ftab_k in ((19, 1000, 0), (5, 1000, 0), (8, 1000, 6), (10, 2, 0), (10, 1000, 9)):
         case = {"wsize": wsize, "max_range": max_range, "ftab_k": ftab_k, "reads": []}
         for fn, name, seq in recs:
             case["reads"].append({"file": fn, "name": name.decode(), "seeds": [[lo, hi, qs, qe, mk] for lo, hi, qs, qe, mk in

@@ -106,3 +106,72 @@ class NaiveFM:
         if hi < lo:
             return []
         return self.sa[lo:hi + 1][::-1].tolist()
+
+
+def greedy_marker_seed_bounds_literal(fm, q, wsize, K, stats=None):
+    """Seed records {range, (m-i, seed_ei-1)} of RowBowt::get_markers_greedy_seeding (rowbowt.hpp:406-482)
+    with an ftab of k-mer size K loaded (K == 0: none), written statement by statement after the
+    reference -- including the restart loop :454-464 whose `else` branch is never taken, because
+    search_ftab (:745-758) answers an absent k-mer with {full_range(), 0} and full_range() passes the
+    `range.first <= range.second` test.  LF is "extend the pattern to the left and search again" on the
+    explicit text; the ftab is the std::map build_ftab(K) makes (:726-744): k-mers over ACGT that occur.
+    Markers are left out (this pins the control flow: ranges and seed bounds).  -> [(lo, hi, qs, qe_excl)]"""
+    m = len(q)
+    full = (0, fm.n - 1)
+
+    def search_ftab(kmer):                                   # :745-758
+        if len(kmer) != K:
+            raise ValueError("only strings of size k are allowed for ftab queries")
+        if all(c in b"ACGT" for c in kmer):
+            r = fm.find_range(bytes(kmer))
+            if r[0] <= r[1]:                                 # the k-mer is a key of the map
+                return r, K
+        return full, 0                                       # :757
+
+    out = []
+    prev_range = full                                        # :427
+    rng = full                                               # :428
+    pat = b""                                                # the pattern whose range `rng` is
+    i = 0
+    if K:                                                    # :430-433
+        rng, i = search_ftab(q[m - K:])
+        prev_range = rng
+        pat = q[m - K:] if i else b""
+    window_ei, seed_ei = m, m                                # :434
+    while i < m:                                             # :442
+        c = q[m - i - 1:m - i]
+        npat = c + pat
+        nr = fm.find_range(npat) if rng[0] <= rng[1] else (1, 0)   # :443 LF(range, c)
+        if nr[1] < nr[0]:                                    # :444
+            out.append((prev_range[0], prev_range[1], m - i, seed_ei))   # :448
+            prev_range = full                                # :450
+            seed_ei = m - i - 1                              # :452
+            window_ei = m - i - 1
+            if K and m - i - 1 >= K:                         # :454
+                while m - i - 1 >= K:                        # :455
+                    seed_ei = m - i - 1
+                    window_ei = m - i - 1
+                    kmer = q[m - i - 1 - K:m - i - 1]
+                    rng, hit = search_ftab(kmer)             # :458
+                    if stats is not None and not hit:
+                        stats["restart_misses"] = stats.get("restart_misses", 0) + 1
+                    if rng[0] <= rng[1]:                     # :459 (true for a miss as well)
+                        pat = kmer if hit else b""
+                        i += K                               # :460
+                        prev_range = rng                     # :461
+                        break
+                    rng = full                               # :463 (unreachable)
+                    pat = b""
+                    i += 1
+            else:
+                rng = full                                   # :466
+                pat = b""
+        else:
+            rng = nr
+            pat = npat
+            if window_ei - (m - i - 1) >= wsize:             # :469-472
+                window_ei = m - i - 1
+            prev_range = rng                                 # :473
+        i += 1
+    out.append((rng[0], rng[1], m - i, seed_ei))             # :481
+    return out

@@ -1,0 +1,104 @@
+"""The command-line tools' FASTA/FASTQ reader (rowbowt_amd/csrc/fastx.hpp) against kseq_read's behaviour
+(reference include/kseq.h:178-219, restated in kseq_model.py), CPU only: well-formed input, truncated
+quality strings (-2: the failing record is never reported, rb_align.cpp:176) and a broken gzip stream (-3)."""
+import gzip
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from kseq_model import kseq_model
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def dump(tmp_path_factory):
+    exe = tmp_path_factory.mktemp("fx") / "fastx_dump"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", os.path.join(ROOT, "tests", "cpp", "fastx_dump.cpp"), "-o", str(exe), "-lz"])
+
+    def run(path, batch=3):
+        p = subprocess.run([str(exe), str(path), str(batch)], capture_output=True, timeout=60)
+        assert p.returncode == 0, p.stdout[-300:]
+        lines = p.stdout.split(b"\n")
+        assert lines[-1] == b"" and lines[-2].startswith(b"rc=")
+        recs = [tuple(l.split(b"\t", 1)) for l in lines[:-2]]
+        return recs, int(lines[-2][3:])
+    return run
+
+
+CASES = {
+    "fastq": b"@r1 c\nACGT\n+\nIIII\n@r2\nGGCC\nAA\n+r2\nIII\nIII\n",
+    "fasta_multi": b"junk\n>a x y\nAC\nGT\n\nAA\n>b\n>c\nTT",
+    "crlf": b"@q\r\nACGTA\r\n+\r\nIIIII\r\n>f\r\nAC\r\n",
+    "trunc_qual_short": b"@r1\nACGT\n+\nIIII\n@r2\nACGT\n+\nII\n",
+    "trunc_no_qual": b">a\nACGT\n@b\nAC\n+\n",
+    "trunc_no_plus_newline": b"@a\nACGT\n+\nIIII\n@b\nAC\n+",
+    "trunc_long_qual": b"@a\nACGT\n+\nIIIIII\n@b\nAC\n+\nII\n",
+    "header_only_eof": b">x",
+    "empty": b"",
+    "no_header": b"ACGT\nACGT\n",
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_matches_kseq_model(dump, tmp_path, name):
+    data = CASES[name]
+    want, want_rc = kseq_model(data)
+    for gz in (False, True):
+        f = tmp_path / (name + (".gz" if gz else ".fx"))
+        f.write_bytes(gzip.compress(data) if gz else data)
+        for batch in (1, 3, 100):
+            got, rc = dump(f, batch)
+            assert rc == want_rc, (name, gz, batch, got)
+            assert got == [(n, s) for n, s in want], (name, gz, batch)
+    if name.startswith("trunc"):
+        assert want_rc == -2
+
+
+def test_random_records_and_truncations(dump, tmp_path):
+    rng = np.random.default_rng(5)
+    recs = []
+    for i in range(40):
+        seq = bytes(rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), int(rng.integers(0, 90))))
+        if rng.random() < 0.5:
+            recs.append(b"@q%d some comment\n" % i + seq + b"\n+\n" + b"I" * len(seq) + b"\n")
+        else:
+            k = int(rng.integers(1, 4))
+            recs.append(b">f%d\n" % i + b"\n".join(seq[j::k] for j in range(k)) + b"\n")
+    blob = b"".join(recs)
+    for cut in [len(blob)] + [int(c) for c in rng.integers(1, len(blob), 60)]:
+        data = blob[:cut]
+        f = tmp_path / "r.fx"
+        f.write_bytes(data)
+        want, want_rc = kseq_model(data)
+        got, rc = dump(f, 4)
+        assert (got, rc) == ([(n, s) for n, s in want], want_rc), cut
+
+
+def test_broken_gzip_stream_is_minus_3(dump, tmp_path):
+    """gzread fails in the middle of the stream: the records that were complete are reported, then -3
+    ("ERROR: error reading stream", rb_align.cpp:186-188)"""
+    rng = np.random.default_rng(6)
+    recs = [(b"r%d" % i, bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 100))) for i in range(20000)]
+    blob = b"".join(b"@" + n + b"\n" + s + b"\n+\n" + b"I" * 100 + b"\n" for n, s in recs)
+    z = bytearray(gzip.compress(blob, 1))
+    mid = len(z) // 2
+    z[mid:mid + 64] = bytes(rng.integers(0, 256, 64, dtype=np.uint8))  # corrupt the deflate stream
+    f = tmp_path / "broken.fq.gz"
+    f.write_bytes(bytes(z))
+    got, rc = dump(f, 1000)
+    assert rc in (-3, -2)   # an error inside a quality string surfaces as -2 (kseq.h:214-217, see fastx.hpp)
+    assert 0 < len(got) < len(recs)
+    assert got[:5000] == recs[:5000]   # (zlib hands out some garbled bytes before it notices the damage)
+    # a gzip file cut short: this zlib's gzread hands out the good bytes and then reports plain end of file
+    # (kseq sees the same calls), so the run ends like a short file: complete records, then -1 or -2
+    f2 = tmp_path / "cut.fq.gz"
+    f2.write_bytes(gzip.compress(blob, 1)[:mid])
+    got, rc = dump(f2, 1000)
+    import zlib
+    prefix = zlib.decompressobj(31).decompress(f2.read_bytes())   # the bytes a reader gets out of the cut file
+    want, want_rc = kseq_model(prefix)
+    assert 0 < len(got) < len(recs) and got[:-1] == recs[:len(got) - 1]
+    assert (got, rc) == ([(n, s_) for n, s_ in want], want_rc) or rc == -3

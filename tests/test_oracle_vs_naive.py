@@ -137,3 +137,63 @@ def test_random_texts_build_from_runs(seed, n, sigma):
                 assert o.locs_at(lo, hi, k) == fm.locs(lo, hi)
                 assert o.locs_at(lo, hi, k, 3) == fm.locs(lo, hi)[:3]
         o.close()
+
+
+def _toy_fm(seed, n, sigma=4):
+    rng = np.random.default_rng(seed)
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)[:sigma]
+    base = alpha[rng.integers(0, sigma, n // 3)]
+    parts = []
+    for _ in range(3):
+        h = base.copy()
+        for p in rng.integers(0, len(h), 4):
+            h[p] = alpha[rng.integers(0, sigma)]
+        parts.append(h)
+    text = np.concatenate(parts + [np.array([1], dtype=np.uint8)])
+    fm = naive.NaiveFM(text)
+    heads, lens, brk = naive.rle(naive.bwt_from_sa(text, fm.sa))
+    ssa, esa = naive.run_samples(fm.sa, brk, len(text))
+    return rng, text, fm, orc.Oracle.from_runs(heads, lens, ssa, esa)
+
+
+def test_marker_seeds_ftab_miss_walkthrough():
+    """get_markers_greedy_seeding with an ftab whose restart k-mer is ABSENT (rowbowt.hpp:454-464).
+    Derived by hand from the reference's statements on T = "ACACAC" + 0x01, K = 2, wsize = 1, read
+    q = "GGTAC" (m = 5).  Suffixes in order: $ | AC$ ACAC$ ACACAC$ | C$ CAC$ CACAC$  -> "AC" = [1,3], "C" = [4,6].
+      :430-433  search_ftab("AC") hits: range [1,3], i = 2, prev_range = [1,3]
+      i = 2     LF([1,3], 'T') is empty -> fn(prev_range [1,3], (3, 4)): seed q[3,5) = "AC"; seed_ei = 2;
+                m-i-1 = 2 >= K: search_ftab(q[0,2) = "GG") MISSES and returns {full_range(), 0} (:757); the
+                test at :459 holds for [0,6], so i += 2 (-> 4), prev_range = full, break; the outer ++i -> 5
+      i = 5     loop ends; :481 fn(range = [0,6], (m-i, seed_ei-1) = (0, 1)): the "seed" q[0,2) = "GG" is
+                reported with the FULL range although GG does not occur -- the reference's behaviour."""
+    text = np.frombuffer(b"ACACAC\x01", dtype=np.uint8)
+    fm = naive.NaiveFM(text)
+    assert fm.find_range(b"AC") == (1, 3) and fm.find_range(b"GG") == (1, 0)
+    want = [(1, 3, 3, 5), (0, 6, 0, 2)]
+    assert naive.greedy_marker_seed_bounds_literal(fm, b"GGTAC", 1, 2) == want
+    heads, lens, brk = naive.rle(naive.bwt_from_sa(text, fm.sa))
+    ssa, esa = naive.run_samples(fm.sa, brk, len(text))
+    o = orc.Oracle.from_runs(heads, lens, ssa, esa)
+    assert [tuple(s[:4]) for s in o.markers_greedy_seeding(b"GGTAC", 1, 1000, 2)] == want
+    o.close()
+
+
+@pytest.mark.parametrize("seed,n,K,wsize", [(11, 240, 5, 2), (12, 400, 6, 3), (13, 900, 6, 4), (14, 150, 4, 1)])
+def test_marker_seeds_control_flow_vs_literal(seed, n, K, wsize):
+    """the oracle's get_markers_greedy_seeding (restructured) against the statement-by-statement
+    transliteration in naive.py, on reads with absent k-mers (texts this short miss many K-mers)"""
+    rng, text, fm, o = _toy_fm(seed, n)
+    stats = {}
+    for _ in range(300):
+        m = int(rng.integers(K + 1, 60))
+        s = int(rng.integers(0, len(text) - 1 - m))
+        q = bytearray(text[s:s + m].tobytes())
+        for _ in range(int(rng.integers(0, 4))):
+            q[int(rng.integers(m))] = int(rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8)))
+        q = bytes(q)
+        for kk in (0, K):
+            want = naive.greedy_marker_seed_bounds_literal(fm, q, wsize, kk, stats)
+            got = [tuple(s_[:4]) for s_ in o.markers_greedy_seeding(q, wsize, 1000, kk)]
+            assert got == want, (q, kk)
+    assert stats.get("restart_misses", 0) > 20   # restarts on an absent k-mer really occurred
+    o.close()
