@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--two-stream", action="store_true",
                     help="also time the K steps as successive batches on two HIP streams (informational; off by default so "
                          "that a profile of the default command holds undisturbed per-kernel durations)")
+    ap.add_argument("--no-space-speed", action="store_true",
+                    help="skip the space_speed block (the replica rebuilt at 4, 3, 2 and 1 symbols per gather; about a minute)")
     ap.add_argument("--property-reads", type=int, default=1_000_000,
                     help="reads whose every reported location is checked against the text on the GPU (size-independent property)")
     return ap.parse_args()
@@ -331,6 +333,29 @@ def main():
                                     "seed_records": n_seeds, "markers_collected": n_smk,
                                     "workload": "rb_markers default mode: get_markers_greedy_seeding on read + reverse complement"}
 
+    # ---- what the kernels touched: one pass of the INSTRUMENTED instantiations on the same batch (outside every
+    # timed region; same outputs).  The bytes of the algorithm as run follow from these counts.
+    d_stats = torch.zeros(16, dtype=torch.int64, device=dev)
+
+    def search_stats(toehold):
+        d_stats.zero_()
+        chk(L.rbg_find_range_stats_dev(rb.h, d_seqs.data_ptr(), d_off.data_ptr(), N, d_lo.data_ptr(), d_hi.data_ptr(),
+                                       d_k.data_ptr() if toehold else None, d_stats.data_ptr(), st), "find_range_stats")
+        torch.cuda.synchronize()
+        v = d_stats.cpu().numpy().tolist()
+        return dict(zip(("steps", "slots", "dense", "searched_ranks", "ftab", "resamples", "read_chunks", "symbols"), v[:8]))
+
+    st_count = search_stats(False)
+    st_toe = search_stats(True)
+    k_plan()
+    k_order()
+    d_stats.zero_()
+    chk(L.rbg_locate_fill_stats_dev(rb.h, d_lo.data_ptr(), d_hi.data_ptr(), d_k.data_ptr(), N, max_hits, d_loc_off.data_ptr(),
+                                    d_locs.data_ptr(), d_ws.data_ptr(), d_stats.data_ptr(), st), "locate_fill_stats")
+    torch.cuda.synchronize()
+    st_loc = dict(zip(("phi_steps", "phi_searched", "chains", "locs"), d_stats.cpu().numpy().tolist()[:4]))
+    rb.counters_reset()
+
     # max over ranks, counters over RCCL
     t_el = torch.tensor([el, el_count, el_pipe], dtype=torch.float64, device=dev)
     if use_dist:
@@ -342,32 +367,64 @@ def main():
     if rank == 0:
         total_reads = N * world * K
         value = total_reads / el
-        # algorithmic bytes (SURVEY 8d / DESIGN.md): per read 57*m+24 for count+toehold, 24 per located occurrence
-        alg_toe = (57 * m + 24) * N
-        alg_fill = 24 * total_locs
-        alg_count = (49 * m + 16) * N
+        # ---- bytes of the algorithm AS RUN, from the instrumented pass: what each kernel has to
+        # move for the steps it actually executed, at the sizes it is stored in HBM -- no sector padding, no re-reads.
+        P = int(ix.pos_bytes)
+        ftab_entry = 16 if P == 4 else 32
+
+        def search_bytes(sv, toehold):
+            # per read: its two offsets (16) and its outputs (lo, hi [, toehold]); per 16-byte read chunk fetched;
+            # per ftab entry; per 16-byte rank slot; per 2-byte dense-table row; per rank searched in a run list:
+            # two ord entries + ~3 probes of a {start, cum} pair; per materialised re-sample: ord (4) + sample (P)
+            return (N * (16 + (24 if toehold else 16)) + 16 * sv["read_chunks"] + ftab_entry * sv["ftab"] + 16 * sv["slots"]
+                    + 2 * sv["dense"] + (8 + 3 * 2 * P) * sv["searched_ranks"] + (4 + P) * sv["resamples"])
+
+        # K3, ordered walk: per read the sorted toehold (8), its permutation entry (4) and two loc_off entries (16);
+        # per phi step one PhiSlot (4 x P); per searched step two ord entries + ~3 probes of a PhiEnt; 8 per location stored
+        loc_bytes = N * 28 + 4 * P * st_loc["phi_steps"] + (8 + 3 * 2 * P) * st_loc["phi_searched"] + 8 * st_loc["locs"]
+        ref_toe = (57 * m + 24) * N      # the reference's one-symbol-per-step algorithm, for comparison only
+        ref_fill = 24 * total_locs
+        ref_count = (49 * m + 16) * N
         kernels = {
-            "k_find_range<toehold>": {"ms": ms_toe, "alg_bytes": alg_toe},
-            "k_locate_fill": {"ms": ms_fill, "alg_bytes": alg_fill},
-            "locate_plan(k_occ+scan)": {"ms": ms_plan, "alg_bytes": 24 * N},
-            "locate_order(radix sort of toeholds)": {"ms": ms_order, "alg_bytes": 24 * N},
-            "k_find_range<count>": {"ms": ms_count, "alg_bytes": alg_count},
+            "k_find_range<toehold>": {"ms": ms_toe, "alg_bytes": search_bytes(st_toe, True), "ref_alg_bytes": ref_toe, "touched": st_toe},
+            "k_locate_fill": {"ms": ms_fill, "alg_bytes": loc_bytes, "ref_alg_bytes": ref_fill, "touched": st_loc},
+            "locate_plan(k_occ+scan)": {"ms": ms_plan, "alg_bytes": 24 * N, "ref_alg_bytes": 24 * N},
+            "locate_order(radix sort of toeholds)": {"ms": ms_order, "alg_bytes": 24 * N, "ref_alg_bytes": 24 * N},
+            "k_find_range<count>": {"ms": ms_count, "alg_bytes": search_bytes(st_count, False), "ref_alg_bytes": ref_count, "touched": st_count},
         }
         dom = max(("k_find_range<toehold>", "k_locate_fill"), key=lambda k: kernels[k]["ms"])
-        ach = kernels[dom]["alg_bytes"] / (kernels[dom]["ms"] * 1e-3) / 1e9
-        traffic = None
-        misses = None
-        miss_peak = None
+        dom_s = kernels[dom]["ms"] * 1e-3
+        ach = kernels[dom]["alg_bytes"] / dom_s / 1e9
+        # PMC traffic: only the committed passes taken with THIS library build on THIS workload count
+        # (profiles/pmc_traffic.json carries the sha256 of the librbg.so that was profiled)
+        import hashlib
+        so_hash = hashlib.sha256(open(os.path.join(ROOT, "rowbowt_amd", "librbg.so"), "rb").read()).hexdigest()
+        traffic = misses = None
+        pmc_note = "no PMC passes committed for this build"
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         default_workload = (args.L, args.H, args.reads, args.read_len, args.site_rate) == (40_000_000, 50, 10_000_000, 100, 0.01)
-        if os.path.exists(pmc) and default_workload:  # the committed PMC passes were taken on the default workload only
+        if os.path.exists(pmc) and default_workload:
             try:
                 pj = json.load(open(pmc))
-                traffic = pj.get(dom, {}).get("hbm_bytes_per_launch")
-                misses = pj.get(dom, {}).get("tcc_miss_per_launch")
-                miss_peak = pj.get("_gather_roof", {}).get("peak_G_misses_per_s")
+                if pj.get("_librbg_sha256") == so_hash:
+                    traffic = pj.get(dom, {}).get("hbm_bytes_per_launch")
+                    misses = pj.get(dom, {}).get("tcc_miss_per_launch")
+                    pmc_note = pj.get("_source")
+                else:
+                    pmc_note = "profiles/pmc_traffic.json was taken with a different librbg.so build: dropped"
             except Exception:
-                traffic = None
+                traffic = misses = None
+        # request ceiling: tools/gather_ceiling.hip's sweep (committed result; measured on an MI355X of this pool)
+        ceiling = None
+        try:
+            ceiling = json.load(open(os.path.join(ROOT, "profiles", "gather_ceiling.json")))["peak_G_gathers_per_s"]
+        except Exception:
+            pass
+        # gathers the dominant kernel issues that can miss L2, from its own counts (independent of the PMC file)
+        if dom == "k_find_range<toehold>":
+            gathers = st_toe["slots"] + st_toe["dense"] + st_toe["ftab"] + 2 * st_toe["resamples"] + 4 * st_toe["searched_ranks"] + st_toe["read_chunks"]
+        else:
+            gathers = st_loc["phi_steps"] + 4 * st_loc["phi_searched"] + N
         out = {
             "metric": f"reads/s ({args.read_len} bp, count+locate)",
             "value": value,
@@ -386,7 +443,8 @@ def main():
                             f"synthetic chr22-scale pangenome r-index, {N} x {m} bp reads per GPU per step (BASELINE.json configs[2])",
                 "index": {"L": args.L, "H": args.H, "n": int(inp["n"]), "r": int(inp["r"]), "site_rate": args.site_rate,
                           "hbm_bytes": int(ix.hbm_bytes), "pos_bytes": int(ix.pos_bytes), "seed": args.seed,
-                          "symbols_per_gather": int(ix.kmer_steps), "pair_runs": int(ix.pair_runs), "triple_runs": int(ix.triple_runs), "quad_runs": int(ix.quad_runs), "quint_runs": int(ix.quint_runs)},
+                          "symbols_per_gather": int(ix.kmer_steps), "symbols_per_gather_requested": int(ix.kmer_steps_requested),
+                          "hbm_free_at_load": int(ix.hbm_free_at_load), "hbm_budget": int(ix.hbm_budget), "ftab_k": int(ix.ftab_k), "pair_runs": int(ix.pair_runs), "triple_runs": int(ix.triple_runs), "quad_runs": int(ix.quad_runs), "quint_runs": int(ix.quint_runs)},
                 "reads_per_gpu": N, "read_len": m, "substituted_fraction": 0.1,
                 "parallelism": f"index replicated x{world}, reads sharded, no data-path collective",
             },
@@ -404,18 +462,30 @@ def main():
                          "reduced_over": f"RCCL all_reduce over {world} rank(s)" if use_dist else "single GPU (no process group)"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                         "measured_traffic_GBps": (traffic / (kernels[dom]["ms"] * 1e-3) / 1e9) if traffic else None,
-                         "gather_efficiency": (kernels[dom]["alg_bytes"] / traffic) if traffic else None,
-                         # what actually bounds the kernel: L2 misses per second against the measured rate of dependent
-                         # random gathers on this chip (tools/gather_roof.hip); TCC_MISS_sum from the same PMC passes
-                         "request_roof": ({"unit": "G L2 misses/s", "achieved": misses / (kernels[dom]["ms"] * 1e-3) / 1e9, "peak": miss_peak,
-                                           "frac": misses / (kernels[dom]["ms"] * 1e-3) / 1e9 / miss_peak, "misses_per_launch": misses}
-                                          if misses and miss_peak else None),
-                         "note": "achieved = algorithmic bytes of the reference's one-symbol-per-step algorithm (SURVEY 8d: 57m+24 per "
-                                 "read, 24 per located position) / kernel time; it can exceed the HBM peak because the k-mer steps and the "
-                                 "ordered phi chains move fewer bytes than that algorithm needs: traffic = FETCH_SIZE+WRITE_SIZE of "
-                                 "profiles/pmc_traffic.json is what actually crossed the fabric"},
-            "kernels": {k: {"ms": v["ms"], "alg_GBps": v["alg_bytes"] / (v["ms"] * 1e-3) / 1e9} for k, v in kernels.items()},
+                         "alg_bytes_per_launch": kernels[dom]["alg_bytes"], "kernel_ms": kernels[dom]["ms"],
+                         # sectors the fabric moved (PMC) against the same peak, and how much of that was padding
+                         "sector_frac": (traffic / dom_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                         "padding_ratio": (traffic / kernels[dom]["alg_bytes"]) if traffic else None,
+                         # what holds a kernel of dependent 16-byte gathers: requests/s against the ceiling tools/gather_ceiling.hip
+                         # measured (profiles/gather_ceiling.json); `gathers` = the kernel's own count of loads that can miss
+                         "request_roof": ({"unit": "G gathers/s", "gathers_per_launch": gathers, "achieved": gathers / dom_s / 1e9,
+                                           "peak": ceiling, "frac": gathers / dom_s / 1e9 / ceiling,
+                                           "tcc_miss_per_launch": misses,
+                                           "miss_frac": (misses / dom_s / 1e9 / ceiling) if misses else None} if ceiling else None),
+                         "reference_byte_model": {"bytes_per_launch": kernels[dom]["ref_alg_bytes"],
+                                                  "GBps": kernels[dom]["ref_alg_bytes"] / dom_s / 1e9,
+                                                  "note": "SURVEY 8d's bytes of the reference's one-symbol-per-step algorithm over this kernel's time: a "
+                                                          "speed statement (how fast that algorithm would have to stream), not a roofline"},
+                         "pmc": pmc_note, "librbg_sha256": so_hash,
+                         "note": "achieved = bytes of the algorithm as run (counted by the instrumented instantiation of the same kernel on the "
+                                 "same batch: executed steps x slots touched x 16 + read chunks + ftab entries + re-sample gathers + offsets + "
+                                 "outputs) / mean kernel duration (HIP events on the launch stream)"},
+            "kernels": {k: {"ms": v["ms"], "alg_bytes": v["alg_bytes"], "alg_GBps": v["alg_bytes"] / (v["ms"] * 1e-3) / 1e9,
+                            "frac_of_hbm_peak": v["alg_bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "touched": v.get("touched")}
+                        for k, v in kernels.items()},
+            "per_read": {"lf_gathers": st_toe["steps"] / N, "slots": st_toe["slots"] / N, "symbols_consumed": st_toe["symbols"] / N,
+                         "read_chunks": st_toe["read_chunks"] / N, "resamples": st_toe["resamples"] / N,
+                         "phi_steps": st_loc["phi_steps"] / N},
         }
 
     # ---- full-size property check (outside the timed region): every location reported for the
@@ -474,8 +544,16 @@ def main():
             woff, wlocs = o.locs_at_batch(wlo, whi, wk, max_hits, nthreads=ncpu)
             ok = bool((g_lo == wlo).all() and (g_hi == whi).all() and (g_k == wk).all() and (g_off == woff).all()
                       and (g_locs == wlocs).all())
-            out["parity"] = {"reads_checked": nchk, "locs_checked": int(woff[-1]), "bit_exact_vs_oracle": ok}
-            if not ok:
+            # K1 (rbg_find_range_dev, the count-only kernel) against the oracle's find_range on the same reads
+            k_count()
+            torch.cuda.synchronize()
+            c_lo = d_lo[:nchk].cpu().numpy().view(np.uint64)
+            c_hi = d_hi[:nchk].cpu().numpy().view(np.uint64)
+            olo, ohi = o.find_range_batch(h_seqs, h_off, nthreads=ncpu)
+            ok1 = bool((c_lo == olo).all() and (c_hi == ohi).all())
+            out["parity"] = {"reads_checked": nchk, "locs_checked": int(woff[-1]), "bit_exact_vs_oracle": ok and ok1,
+                             "count_toehold_locate_bit_exact": ok, "count_only_kernel_bit_exact": ok1}
+            if not (ok and ok1):
                 print(json.dumps(out))
                 raise SystemExit("PARITY FAILURE: HIP path disagrees with the oracle")
         if args.markers and nchk:
@@ -551,6 +629,40 @@ def main():
             out["cpu_baseline_all_cores"] = {"value": na / dta, "unit": "reads/s", "cores": ncpu, "kind": "port",
                                              "sample": f"first {na} reads, OpenMP over reads, {dta:.1f}s"}
         o.close()
+
+    # ---- space for speed (rank 0, N=1): the same two search kernels with the replica rebuilt at fewer symbols
+    # per gather.  The headline ran at the deepest level that fitted; these rows say what the
+    # same call costs on a device with less free HBM.
+    if rank == 0 and world == 1 and not args.no_space_speed:
+        from rowbowt_amd import capi
+
+        def time_search():
+            res = {}
+            for name, fn in (("k_find_range<count>", k_count), ("k_find_range<toehold>", k_toehold)):
+                fn()
+                e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+                e[0].record(stream)
+                for t in range(3):
+                    fn()
+                    e[t + 1].record(stream)
+                torch.cuda.synchronize()
+                res[name] = min(e[t].elapsed_time(e[t + 1]) for t in range(3))
+            return res
+
+        rows = [{"symbols_per_gather": int(ix.kmer_steps), "hbm_bytes": int(ix.hbm_bytes), "ms": time_search()}]
+        top = int(ix.kmer_steps)
+        for lvl in range(top - 1, 0, -1):
+            rb.close()
+            torch.cuda.empty_cache()
+            capi.set_default_option(capi.OPT_KMER_STEPS, lvl)
+            try:
+                rb = ra.RowBowt.from_runs(inp["heads"], inp["lens"], inp["ssa"], inp["esa"], device=local_rank)
+            finally:
+                capi.set_default_option(capi.OPT_KMER_STEPS, 5)
+            rows.append({"symbols_per_gather": int(rb.info().kmer_steps), "hbm_bytes": int(rb.info().hbm_bytes), "ms": time_search()})
+        out["space_speed"] = {"unit": "ms per launch of this run's batch (best of 3)", "rows": rows,
+                              "note": "RBG_OPT_KMER_STEPS / the HBM budget rule pick the row; rbg_info reports which (symbols_per_gather, "
+                                      "hbm_free_at_load, hbm_budget)"}
 
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RBG_ABI_VERSION 1
+#define RBG_ABI_VERSION 2
 
 typedef struct rbg_index rbg_index;
 
@@ -132,7 +132,15 @@ typedef struct rbg_info_t {
     /* ftab (RowBowt::build_ftab / search_ftab, rowbowt.hpp:726-758): word length of the device table, 0 = none */
     uint64_t ftab_k;
     uint64_t quint_runs;    /* total runs of the 5-mer tables (kmer_steps == 5) */
+    /* ABI 2: how the space/speed point was chosen at load (the same call is up to 4x slower with fewer levels,
+     * DESIGN.md 2b): the depth asked for (RBG_OPT_KMER_STEPS), the free HBM seen at load, the budget the replica had
+     * to fit (three quarters of it, or RBG_OPT_HBM_BUDGET_MB); kmer_steps above is what was kept.  Also printed on
+     * stderr at load when a level is dropped (always with RBG_VERBOSE). */
+    uint64_t kmer_steps_requested, hbm_free_at_load, hbm_budget;
+    uint64_t rank_layout;   /* RBG_LAYOUT_SLOTS or RBG_LAYOUT_RUNS (what RBG_OPT_RANK_LAYOUT / the budget rule chose) */
+    uint64_t replicas;      /* devices holding a replica of this index (1 unless loaded with rbg_load_multi) */
 } rbg_info_t;
+enum { RBG_LAYOUT_AUTO = 0, RBG_LAYOUT_SLOTS = 1, RBG_LAYOUT_RUNS = 2 };
 int rbg_info(const rbg_index *, rbg_info_t *out);
 
 /* RowBowt::get_f(), rowbowt.hpp:719 / build_f :770-778: 256 entries. */
@@ -287,6 +295,33 @@ int rbg_markers_fill_dev(rbg_index *, const uint64_t *d_lo, const uint64_t *d_hi
  * accumulated on the device by every query since load / the last reset. */
 int rbg_counters(rbg_index *, uint64_t out[4]);
 int rbg_counters_reset(rbg_index *);
+
+/* ---- measurement: what a launch touched (SURVEY 8d "report mean executed steps"; the reference's only
+ * instrumentation is the stderr timer line rb_align.cpp:192) ------------------------------------------ */
+/* The *_stats_dev calls run an INSTRUMENTED instantiation of the same kernel on the same arguments (same
+ * outputs, same counters) and add what it touched to a device array of RBG_SEARCH_STATS / RBG_LOCATE_STATS
+ * 64-bit sums, which the caller zeroes first.  bench.py derives the bytes of the algorithm as run from them;
+ * the timed launches are the plain ones. */
+enum { RBG_SS_STEPS = 0,      /* LF gathers issued (single-symbol or k-mer steps) */
+       RBG_SS_SLOTS,          /* 16-byte rank slots loaded (1 per step, 2 when lo and hi+1 fall in different buckets) */
+       RBG_SS_DENSE,          /* 2-byte loads from dense overflow tables */
+       RBG_SS_SEARCH,         /* ranks answered by a run-list search (overflow bucket without a dense table) */
+       RBG_SS_FTAB,           /* ftab entries fetched */
+       RBG_SS_RESAMPLE,       /* toehold re-samples materialised (2 gathers each) */
+       RBG_SS_CHUNKS,         /* aligned 16-byte chunks of read bytes fetched */
+       RBG_SS_SYMBOLS,        /* read symbols consumed = reference LF iterations covered */
+       RBG_SEARCH_STATS };
+enum { RBG_LS_PHI_STEPS = 0,  /* phi evaluations (one phi slot each) */
+       RBG_LS_PHI_SEARCH,     /* of them: answered by a run-list search */
+       RBG_LS_CHAINS,         /* reads with at least one location */
+       RBG_LS_LOCS,           /* locations stored */
+       RBG_LOCATE_STATS };
+int rbg_find_range_stats_dev(rbg_index *, const uint8_t *d_seqs, const uint64_t *d_off, uint64_t N, uint64_t *d_lo,
+                             uint64_t *d_hi, uint64_t *d_ssamp /* NULL = count-only kernel */,
+                             uint64_t *d_stats /* RBG_SEARCH_STATS */, void *stream);
+int rbg_locate_fill_stats_dev(rbg_index *, const uint64_t *d_lo, const uint64_t *d_hi, const uint64_t *d_k, uint64_t N,
+                              uint64_t max_hits, const uint64_t *d_loc_off, uint64_t *d_locs, const void *d_order,
+                              uint64_t *d_stats /* RBG_LOCATE_STATS */, void *stream);
 
 /* ---- tuning (never changes results) -------------------------------------------------------- */
 /* Process-wide defaults read when an index is built/loaded: BLOCK_THREADS (64, 128, 192 or 256; the search

@@ -46,7 +46,8 @@ class Info(C.Structure):
                 ("hbm_bytes", U64), ("marker_runs", U64), ("marker_vals", U64),
                 ("rank_bucket_shift", C.c_uint32), ("phi_bucket_shift", C.c_uint32), ("reserved", C.c_uint32),
                 ("rank_slots", U64), ("rank_slots_overflow", U64), ("phi_slots", U64), ("phi_slots_overflow", U64),
-                ("kmer_steps", U64), ("kmer_symbols", U64), ("pair_runs", U64), ("triple_runs", U64), ("quad_runs", U64), ("ftab_k", U64), ("quint_runs", U64)]
+                ("kmer_steps", U64), ("kmer_symbols", U64), ("pair_runs", U64), ("triple_runs", U64), ("quad_runs", U64), ("ftab_k", U64), ("quint_runs", U64),
+                ("kmer_steps_requested", U64), ("hbm_free_at_load", U64), ("hbm_budget", U64), ("rank_layout", U64), ("replicas", U64)]
 
 
 # every symbol include/rbg.h declares: (name, restype, argtypes)
@@ -97,6 +98,8 @@ _PROTOS = [
     ("rbg_marker_seeds_fill_dev", C.c_int, [VP, VP, VP, U64, U64, U64, U64, VP, VP, VP, VP, VP]),
     ("rbg_markers_plan_dev", C.c_int, [VP, VP, VP, U64, VP, VP, C.c_size_t, VP]),
     ("rbg_markers_fill_dev", C.c_int, [VP, VP, VP, U64, VP, VP, VP]),
+    ("rbg_find_range_stats_dev", C.c_int, [VP, VP, VP, U64, VP, VP, VP, VP, VP]),
+    ("rbg_locate_fill_stats_dev", C.c_int, [VP, VP, VP, VP, U64, U64, VP, VP, VP, VP, VP]),
     ("rbg_counters", C.c_int, [VP, VP]),
     ("rbg_counters_reset", C.c_int, [VP]),
     ("rbg_set_default_option", C.c_int, [C.c_int, C.c_int64]),

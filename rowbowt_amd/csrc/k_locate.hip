@@ -17,7 +17,7 @@ __global__ __launch_bounds__(256) void k_occ(const uint64_t *__restrict__ lo, co
 }
 
 template <typename P>
-__device__ __forceinline__ uint64_t phi_step(const DevIndex &ix, uint64_t i) {
+__device__ __forceinline__ uint64_t phi_step(const DevIndex &ix, uint64_t i, bool *searched = nullptr) {
     const PhiSlot<P> *__restrict__ slots = static_cast<const PhiSlot<P> *>(ix.phi_slots);
     if (i >= ix.n) {
         // Only a toehold that wrapped below zero gets here: a match at text position 0 leaves k - 1 =
@@ -33,6 +33,7 @@ __device__ __forceinline__ uint64_t phi_step(const DevIndex &ix, uint64_t i) {
     const uint32_t meta = static_cast<uint32_t>(sl.meta);
     uint64_t s;
     if (((meta >> 16) & 3u) == kPhiOvf) {
+        if (searched) *searched = true;
         const PhiEnt<P> *__restrict__ ent = static_cast<const PhiEnt<P> *>(ix.phi_ent);
         uint64_t a = ix.phi_ord[b], z = ix.phi_ord[b + 1];
         while (z - a > 4) {
@@ -75,13 +76,15 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <typename P>
+// STATS = the instrumented instantiation (rbg_locate_fill_stats_dev): the same walk plus the LocateStat sums.
+template <typename P, bool STATS = false>
 __global__ __launch_bounds__(256) void k_locate_fill(const DevIndex ix, const uint64_t *__restrict__ lo,
                                                      const uint64_t *__restrict__ hi, const uint64_t *__restrict__ k,
                                                      const uint64_t N, const uint64_t max_hits,
                                                      const uint64_t *__restrict__ loc_off, uint64_t *__restrict__ locs,
                                                      const uint64_t *__restrict__ sub, const uint32_t *__restrict__ order,
-                                                     const uint64_t *__restrict__ skeys) {
+                                                     const uint64_t *__restrict__ skeys,
+                                                     unsigned long long *__restrict__ stats = nullptr) {
     // staged at the position width: text positions fit P, and at 4 bytes the workgroup's LDS drops from
     // 39 KB to 24 KB (6 instead of 4 waves per SIMD); the per-read offset is applied when flushing
     __shared__ P s_val[4][kWave][kChunk + 1];  // +1: keeps the per-lane rows off the same banks
@@ -91,6 +94,7 @@ __global__ __launch_bounds__(256) void k_locate_fill(const DevIndex ix, const ui
     __shared__ uint64_t s_first[4][kWave];  // the toehold itself is not a text position when it wrapped (2^64 - 1)
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
     unsigned long long c_locs = 0;
+    unsigned long long st_phi = 0, st_ovf = 0, st_chains = 0;  // STATS only
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
     for (uint64_t base = static_cast<uint64_t>(blockIdx.x) * blockDim.x + wv * kWave; base < N; base += stride) {
         // `order` (optional) lists the reads by toehold text position: neighbouring lanes then walk
@@ -122,6 +126,7 @@ __global__ __launch_bounds__(256) void k_locate_fill(const DevIndex ix, const ui
         s_minus[wv][lane] = minus;
         s_first[wv][lane] = k1;
         c_locs += occ;
+        if (STATS && occ) st_chains += 1;
         uint64_t wmax = occ;
 #pragma unroll
         for (int o = kWave / 2; o > 0; o >>= 1) {
@@ -133,7 +138,16 @@ __global__ __launch_bounds__(256) void k_locate_fill(const DevIndex ix, const ui
             for (int e = 0; e < kChunk; ++e) {
                 const uint64_t t = t0 + e;
                 if (t < occ) {
-                    if (t) k1 = phi_step<P>(ix, k1);  // toehold_sa.hpp:44
+                    if (STATS) {
+                        if (t) {
+                            bool searched = false;
+                            k1 = phi_step<P>(ix, k1, &searched);
+                            st_phi += 1;
+                            st_ovf += searched ? 1 : 0;
+                        }
+                    } else if (t) {
+                        k1 = phi_step<P>(ix, k1);  // toehold_sa.hpp:44
+                    }
                     s_val[wv][lane][e] = static_cast<P>(k1);
                 }
             }
@@ -151,6 +165,17 @@ __global__ __launch_bounds__(256) void k_locate_fill(const DevIndex ix, const ui
     }
     c_locs = wave_sum(c_locs);
     if (lane == 0 && c_locs) atomicAdd(&ix.counters[3], c_locs);
+    if (STATS) {
+        st_phi = wave_sum(st_phi);
+        st_ovf = wave_sum(st_ovf);
+        st_chains = wave_sum(st_chains);
+        if (lane == 0) {
+            if (st_phi) atomicAdd(&stats[kLsPhiSteps], st_phi);
+            if (st_ovf) atomicAdd(&stats[kLsPhiOvf], st_ovf);
+            if (st_chains) atomicAdd(&stats[kLsChains], st_chains);
+            if (c_locs) atomicAdd(&stats[kLsLocs], c_locs);
+        }
+    }
 }
 
 }  // namespace
@@ -227,14 +252,20 @@ int launch_locate_plan(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t 
 
 int launch_locate_fill(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t *lo, const uint64_t *hi,
                        const uint64_t *k, uint64_t N, uint64_t max_hits, const uint64_t *loc_off, uint64_t *locs,
-                       const uint64_t *sub, const void *order, void *stream) {
+                       const uint64_t *sub, const void *order, void *stream, unsigned long long *stats) {
     if (N == 0) return 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid(grid_for(cfg, N)), block(cfg.block_threads);
     // the order workspace also holds the toeholds in sorted order (launch_locate_order's key output)
     const uint64_t *skeys = order ? reinterpret_cast<const uint64_t *>(static_cast<const char *>(order) + order_layout(N).keys) : nullptr;
-    if (ix.pos_bytes == 4) hipLaunchKernelGGL((k_locate_fill<uint32_t>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, locs, sub, static_cast<const uint32_t *>(order), skeys);
-    else hipLaunchKernelGGL((k_locate_fill<uint64_t>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, locs, sub, static_cast<const uint32_t *>(order), skeys);
+    const uint32_t *perm = static_cast<const uint32_t *>(order);
+    if (stats) {
+        if (ix.pos_bytes == 4) hipLaunchKernelGGL((k_locate_fill<uint32_t, true>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, locs, sub, perm, skeys, stats);
+        else hipLaunchKernelGGL((k_locate_fill<uint64_t, true>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, locs, sub, perm, skeys, stats);
+    } else {
+        if (ix.pos_bytes == 4) hipLaunchKernelGGL((k_locate_fill<uint32_t>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, locs, sub, perm, skeys, nullptr);
+        else hipLaunchKernelGGL((k_locate_fill<uint64_t>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, locs, sub, perm, skeys, nullptr);
+    }
     return static_cast<int>(hipGetLastError());
 }
 

@@ -20,12 +20,16 @@ namespace {
 
 // The record table lives in dynamic LDS: kTabMax records (17 KB) up to 4-mer steps, kTab5 (66 KB) with the
 // 5-mer level, then launched as 1024-thread workgroups so that two of them still give 8 waves per SIMD.
-template <typename P, bool TOEHOLD, bool USE_FTAB>
+// STATS = the instrumented instantiation (rbg_find_range_stats_dev): the same walk, plus counts of what it
+// touched (rbg_dev.h SearchStat) summed into stats[]; bench.py derives the bytes of the algorithm AS RUN from
+// them.  The timed launches are the STATS = false ones (no counter exists in them).
+template <typename P, bool TOEHOLD, bool USE_FTAB, bool STATS = false>
 __global__ __launch_bounds__(1024, 8) void k_find_range(const DevIndex ix, const uint8_t *__restrict__ seqs,
                                                     const uint64_t *__restrict__ off, const uint64_t N,
                                                     uint64_t *__restrict__ lo_out, uint64_t *__restrict__ hi_out,
                                                     uint64_t *__restrict__ ss_out, const uint32_t *__restrict__ sel,
-                                                    const uint32_t *__restrict__ nsel) {
+                                                    const uint32_t *__restrict__ nsel,
+                                                    unsigned long long *__restrict__ stats = nullptr) {
     __shared__ uint8_t s_lut[256];
     __shared__ uint8_t s_lut2[256];
     extern __shared__ __align__(16) unsigned char s_dyn[];
@@ -40,6 +44,7 @@ __global__ __launch_bounds__(1024, 8) void k_find_range(const DevIndex ix, const
     // reads handled by this lane follow from the loop bounds; only the matches and their widths are accumulated
     unsigned long long c_occ = 0;
     uint32_t c_matched = 0;
+    unsigned long long st[kStatSearchN] = {0, 0, 0, 0, 0, 0, 0, 0};  // STATS only (dead code otherwise)
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
     const uint64_t first_ = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     for (uint64_t j_ = first_; j_ < Neff; j_ += stride) {
@@ -49,6 +54,8 @@ __global__ __launch_bounds__(1024, 8) void k_find_range(const DevIndex ix, const
             beg = off[i0];
             p = off[i0 + 1];
         }
+        const uint64_t p_end = p;
+        uint64_t p_min = p;  // STATS: lowest read byte fetched (the k-mer look-ahead reads left of the consumed symbols)
         uint64_t lo = 0, hi = ix.n - 1;  // full_range(), rowbowt.hpp:115-118
         uint64_t k = TOEHOLD ? ix.last_run_sample : 0;
         // The toehold only flows forward through "k - adv" (row hi carries the symbol); a step that
@@ -85,10 +92,12 @@ __global__ __launch_bounds__(1024, 8) void k_find_range(const DevIndex ix, const
                 pw *= M;
             }
             uint64_t flo, fhi2, fk;
+            if (STATS) { p_min = p - ix.ftab_k; if (all_major) st[kStFtab] += 1; }
             if (all_major && ftab_lookup<P>(ix, idx, flo, fhi2, fk)) {
                 lo = flo; hi = fhi2;
                 if (TOEHOLD) k = fk;
                 p -= ix.ftab_k;
+                if (STATS) st[kStSymbols] += ix.ftab_k;
                 if (hi < lo) { alive = false; p = beg; }
             }
         }
@@ -96,7 +105,18 @@ __global__ __launch_bounds__(1024, 8) void k_find_range(const DevIndex ix, const
         auto step = [&](const DevSym &S, uint32_t adv, uint32_t tab) -> bool {
             RankAux q;
             uint64_t c_before, c_upto, bh;
-            rank_pair<P>(S, ix.dense, lo, hi + 1, &c_before, &c_upto, &bh, &q);      // rowbowt.hpp:79,83
+            if (STATS) {
+                RankAux pa;
+                const bool two = (lo >> S.shift) != ((hi + 1) >> S.shift);
+                rank_pair<P>(S, ix.dense, lo, hi + 1, &c_before, &c_upto, &bh, &q, &pa);
+                st[kStSteps] += 1;
+                st[kStSlots] += two ? 2 : 1;
+                st[kStDense] += (pa.dense ? 1 : 0) + ((two || !pa.dense) && q.dense ? 1 : 0);
+                st[kStSearch] += (pa.ovf ? 1 : 0) + (q.ovf ? 1 : 0);
+                st[kStSymbols] += adv;
+            } else {
+                rank_pair<P>(S, ix.dense, lo, hi + 1, &c_before, &c_upto, &bh, &q);  // rowbowt.hpp:79,83
+            }
             const uint64_t c_inside = c_upto - c_before;
             if (c_inside == 0) return false;                               // rowbowt.hpp:85
             if (TOEHOLD) {
@@ -121,6 +141,7 @@ __global__ __launch_bounds__(1024, 8) void k_find_range(const DevIndex ix, const
         while (p > beg) {  // right-to-left over the read (rowbowt.hpp:127-129, :175-181)
             --p;
             const uint32_t c = rd.at(p);
+            if (STATS && p < p_min) p_min = p;
             // Up to five reference iterations in one gather: when this symbol and its left
             // neighbours all have k-mer tables, LF(LF(LF(range,x0),x1),x2) == F3[x2x1x0] + rank3(.),
             // and the toehold after the nested LF_w_loc calls is k-adv if row hi carries the k-mer,
@@ -136,6 +157,7 @@ __global__ __launch_bounds__(1024, 8) void k_find_range(const DevIndex ix, const
                 for (uint32_t t = 1; t < 5; ++t) {
                     if (t >= ksteps || p < beg + t) break;
                     const uint32_t mm = s_lut2[rd.at(p - t)];
+                    if (STATS && p - t < p_min) p_min = p - t;
                     if (mm == 0xFFu) break;
                     acc += mm * pw;
                     pw *= M;
@@ -159,6 +181,10 @@ __global__ __launch_bounds__(1024, 8) void k_find_range(const DevIndex ix, const
             p -= adv - 1;                  // the left neighbours are consumed too
         }
         if (TOEHOLD && alive && pend) k += resample();
+        if (STATS) {
+            if (TOEHOLD && alive && pend) st[kStResample] += 1;
+            if (p_end > p_min) st[kStChunks] += ((p_end - 1) >> 4) - (p_min >> 4) + 1;  // aligned 16-byte read chunks fetched
+        }
         if (!alive) { lo = 1; hi = 0; k = 0; }  // {1,0}; LFData::clear rowbowt.hpp:153-159
         const uint64_t i = sel ? static_cast<uint64_t>(sel[j_]) : j_;  // (re-read rather than kept live through the search)
         lo_out[i] = lo;
@@ -174,6 +200,13 @@ __global__ __launch_bounds__(1024, 8) void k_find_range(const DevIndex ix, const
         atomicAdd(&ix.counters[0], c_reads);
         if (w_matched) atomicAdd(&ix.counters[1], w_matched);
         if (c_occ) atomicAdd(&ix.counters[2], c_occ);
+    }
+    if (STATS) {
+#pragma unroll
+        for (int t = 0; t < kStatSearchN; ++t) {
+            const unsigned long long v = wave_sum(st[t]);
+            if ((threadIdx.x & (kWave - 1)) == 0 && v) atomicAdd(&stats[t], v);
+        }
     }
 }
 
@@ -382,9 +415,10 @@ __global__ __launch_bounds__(1024, 8) void k_find_range_packed(const DevIndex ix
 
 }  // namespace
 
-template <bool USE_FTAB>
+template <bool USE_FTAB, bool STATS = false>
 int launch_find_range_impl(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
-                           uint64_t *lo, uint64_t *hi, uint64_t *ssamp, const uint32_t *sel, const uint32_t *nsel, void *stream) {
+                           uint64_t *lo, uint64_t *hi, uint64_t *ssamp, const uint32_t *sel, const uint32_t *nsel, void *stream,
+                           unsigned long long *stats = nullptr) {
     if (N == 0) return 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool toe = ssamp != nullptr;
@@ -392,9 +426,9 @@ int launch_find_range_impl(const DevIndex &ix, const LaunchCfg &cfg, const uint8
     const int cap = sel ? 512 : 0;
 #define RBG_LAUNCH_FR(PT, TOE)                                                                                      \
     do {                                                                                                            \
-        auto kern = k_find_range<PT, TOE, USE_FTAB>;                                                                \
+        auto kern = k_find_range<PT, TOE, USE_FTAB, STATS>;                                                         \
         const KmerLaunch L = kmer_launch(ix, cfg, N, kern, cap);                                                    \
-        hipLaunchKernelGGL(kern, L.grid, L.block, L.lds, st, ix, seqs, off, N, lo, hi, ssamp, sel, nsel);           \
+        hipLaunchKernelGGL(kern, L.grid, L.block, L.lds, st, ix, seqs, off, N, lo, hi, ssamp, sel, nsel, stats);    \
     } while (0)
     if (ix.pos_bytes == 4) {
         if (toe) RBG_LAUNCH_FR(uint32_t, true); else RBG_LAUNCH_FR(uint32_t, false);
@@ -403,6 +437,12 @@ int launch_find_range_impl(const DevIndex &ix, const LaunchCfg &cfg, const uint8
     }
 #undef RBG_LAUNCH_FR
     return static_cast<int>(hipGetLastError());
+}
+
+int launch_find_range_stats(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
+                            uint64_t *lo, uint64_t *hi, uint64_t *ssamp, unsigned long long *stats, void *stream) {
+    return ix.ftab_k ? launch_find_range_impl<true, true>(ix, cfg, seqs, off, N, lo, hi, ssamp, nullptr, nullptr, stream, stats)
+                     : launch_find_range_impl<false, true>(ix, cfg, seqs, off, N, lo, hi, ssamp, nullptr, nullptr, stream, stats);
 }
 
 int launch_find_range(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,

@@ -33,6 +33,7 @@ struct rbg_index {
     void *arena = nullptr;       // one allocation holding every table of the replica
     size_t arena_bytes = 0, arena_used = 0;
     uint64_t rank_slots = 0, rank_slots_overflow = 0, phi_slots = 0, phi_slots_overflow = 0;
+    uint64_t kmer_steps_requested = 0, hbm_free_at_load = 0, hbm_budget = 0;  // how the space/speed point was chosen (rbg_info)
     std::vector<DevSym> dense_todo;  // load time only: rank tables whose overflow buckets still need their dense tables
     std::mutex mu;               // guards marker/doc attachment only; queries are lock-free
 };
@@ -375,12 +376,19 @@ int upload(rbg_index *ix) {
     const int64_t opt_mb = g_opt_hbm_budget_mb.load();
     const size_t budget = opt_mb > 0 ? static_cast<size_t>(opt_mb) << 20 : free_b - free_b / 4;
     auto need = [&] { return h.pos_bytes == 4 ? replica_bytes<uint32_t>(h) : replica_bytes<uint64_t>(h); };
+    auto levels = [&] { return !h.quint.empty() ? 5 : !h.quad.empty() ? 4 : !h.triple.empty() ? 3 : !h.pair.empty() ? 2 : 1; };
+    ix->kmer_steps_requested = static_cast<uint64_t>(levels());
+    ix->hbm_free_at_load = free_b;
+    ix->hbm_budget = budget;
     while (need() > budget && !h.pair.empty()) {
         std::vector<SymTable> &deepest = !h.quint.empty() ? h.quint : !h.quad.empty() ? h.quad : !h.triple.empty() ? h.triple : h.pair;
         std::fprintf(stderr, "rbg: replica of %.1f GB exceeds the %.1f GB budget: dropping the %zu-table k-mer level\n",
                      need() / 1e9, budget / 1e9, deepest.size());
         std::vector<SymTable>().swap(deepest);
     }
+    if (std::getenv("RBG_VERBOSE") || static_cast<uint64_t>(levels()) != ix->kmer_steps_requested)
+        std::fprintf(stderr, "rbg: device %d: %.1f GB free, replica budget %.1f GB: keeping %d of %llu symbol(s) per gather (%.1f GB)\n", ix->device,
+                     free_b / 1e9, budget / 1e9, levels(), static_cast<unsigned long long>(ix->kmer_steps_requested), need() / 1e9);
     ix->arena_bytes = need();
     if (ix->arena_bytes > free_b) {
         std::fprintf(stderr, "rbg: index needs %.1f GB of HBM, %.1f GB free\n", ix->arena_bytes / 1e9, free_b / 1e9);
@@ -953,6 +961,11 @@ int rbg_info(const rbg_index *ix, rbg_info_t *out) {
     out->kmer_steps = !ix->host.quint.empty() ? 5 : !ix->host.quad.empty() ? 4 : !ix->host.triple.empty() ? 3 : !ix->host.pair.empty() ? 2 : 1;
     out->kmer_symbols = ix->host.pair.empty() ? 0 : ix->host.nmajor;
     out->ftab_k = ix->dev.ftab_k;
+    out->kmer_steps_requested = ix->kmer_steps_requested ? ix->kmer_steps_requested : out->kmer_steps;
+    out->hbm_free_at_load = ix->hbm_free_at_load;
+    out->hbm_budget = ix->hbm_budget;
+    out->rank_layout = RBG_LAYOUT_SLOTS;
+    out->replicas = ix->device == RBG_DEVICE_NONE ? 0 : 1;
     for (const SymTable &t : ix->host.pair) out->pair_runs += t.nruns;
     for (const SymTable &t : ix->host.triple) out->triple_runs += t.nruns;
     for (const SymTable &t : ix->host.quad) out->quad_runs += t.nruns;
@@ -1039,6 +1052,33 @@ int rbg_find_range_w_toehold_dev(rbg_index *ix, const uint8_t *d_seqs, const uin
     if (N && (!d_seqs || !d_off || !d_lo || !d_hi || !d_ssamp)) return RBG_EARG;
     if (reinterpret_cast<uintptr_t>(d_seqs) & 15) return RBG_EARG;
     return launch_find_range(ix->dev, ix->cfg, d_seqs, d_off, N, d_lo, d_hi, d_ssamp, stream) ? RBG_ENODEV : RBG_OK;
+    });
+}
+
+static_assert(RBG_SEARCH_STATS == kStatSearchN && RBG_LOCATE_STATS == kStatLocateN, "rbg.h mirrors rbg_dev.h");
+static_assert(RBG_SS_CHUNKS == kStChunks && RBG_SS_SYMBOLS == kStSymbols && RBG_LS_LOCS == kLsLocs, "rbg.h mirrors rbg_dev.h");
+
+int rbg_find_range_stats_dev(rbg_index *ix, const uint8_t *d_seqs, const uint64_t *d_off, uint64_t N, uint64_t *d_lo,
+                             uint64_t *d_hi, uint64_t *d_ssamp, uint64_t *d_stats, void *stream) {
+    return guarded([&]() -> int {
+    if (!queryable(ix)) return RBG_ENODEV;
+    if (d_ssamp && !ix->host.has_tsa) return RBG_ENOTLOADED;
+    if (!d_stats || (N && (!d_seqs || !d_off || !d_lo || !d_hi))) return RBG_EARG;
+    if (reinterpret_cast<uintptr_t>(d_seqs) & 15) return RBG_EARG;
+    return launch_find_range_stats(ix->dev, ix->cfg, d_seqs, d_off, N, d_lo, d_hi, d_ssamp, reinterpret_cast<unsigned long long *>(d_stats), stream)
+               ? RBG_ENODEV : RBG_OK;
+    });
+}
+
+int rbg_locate_fill_stats_dev(rbg_index *ix, const uint64_t *d_lo, const uint64_t *d_hi, const uint64_t *d_k, uint64_t N,
+                              uint64_t max_hits, const uint64_t *d_loc_off, uint64_t *d_locs, const void *d_order, uint64_t *d_stats,
+                              void *stream) {
+    return guarded([&]() -> int {
+    if (!queryable(ix)) return RBG_ENODEV;
+    if (!ix->host.has_tsa) return RBG_ENOTLOADED;
+    if (!d_stats || (N && (!d_lo || !d_hi || !d_k || !d_loc_off || !d_locs))) return RBG_EARG;
+    return launch_locate_fill(ix->dev, ix->cfg, d_lo, d_hi, d_k, N, max_hits, d_loc_off, d_locs, nullptr, d_order, stream,
+                              reinterpret_cast<unsigned long long *>(d_stats)) ? RBG_ENODEV : RBG_OK;
     });
 }
 

@@ -122,6 +122,28 @@ struct DevIndex {
     const uint8_t *dense;   // dense tables of the overflow buckets of every narrow rank table (RankSlot); nullptr = none
 };
 
+// What the instrumented instantiations count (sums over the launch; include/rbg.h rbg_search_stats_t mirrors it).
+// bench.py turns them into the bytes of the algorithm AS RUN: ftab entry + slots x 16 + dense x 2 + read chunks x 16
+// + offsets + outputs + 2 gathers per materialised re-sample (K1/K2); phi slots + sorted keys + offsets + stores (K3).
+enum SearchStat {
+    kStSteps = 0,   // LF gathers issued (one per single-symbol or k-mer step)
+    kStSlots,       // RankSlot loads (1 per step, 2 when lo and hi+1 fall in different buckets)
+    kStDense,       // 2-byte loads from dense overflow tables
+    kStSearch,      // ranks answered by searching the run list (overflow bucket without a dense table)
+    kStFtab,        // ftab entries fetched
+    kStResample,    // toehold re-samples materialised at the end of a read (ord + samp gathers)
+    kStChunks,      // aligned 16-byte chunks of read bytes fetched
+    kStSymbols,     // read symbols consumed (reference LF iterations covered)
+    kStatSearchN
+};
+enum LocateStat {
+    kLsPhiSteps = 0,  // phi evaluations (PhiSlot loads)
+    kLsPhiOvf,        // of them: overflow buckets searched in the run list
+    kLsChains,        // reads with at least one location
+    kLsLocs,          // locations stored
+    kStatLocateN
+};
+
 struct LaunchCfg {
     int block_threads = 256;
     int max_blocks = 0;  // 0: derive from the device
@@ -130,13 +152,17 @@ struct LaunchCfg {
 // launchers (k_search.hip, k_locate.hip, k_markers.hip, k_build.hip).  All asynchronous on `stream`; return hipError_t as int.
 int launch_find_range(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
                       uint64_t *lo, uint64_t *hi, uint64_t *ssamp /*nullable*/, void *stream);
+int launch_find_range_stats(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
+                            uint64_t *lo, uint64_t *hi, uint64_t *ssamp /*nullable*/, unsigned long long *stats /*kStatSearchN*/,
+                            void *stream);
 size_t scan_tmp_bytes(uint64_t N);
 int launch_locate_plan(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t *lo, const uint64_t *hi, uint64_t N,
                        uint64_t max_hits, uint64_t *loc_off, void *tmp, size_t tmp_bytes, void *stream);
 int launch_locate_fill(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t *lo, const uint64_t *hi,
                        const uint64_t *k, uint64_t N, uint64_t max_hits, const uint64_t *loc_off, uint64_t *locs,
                        const uint64_t *sub /*nullable: per-read value subtracted from every location*/,
-                       const void *order /*nullable: workspace filled by launch_locate_order*/, void *stream);
+                       const void *order /*nullable: workspace filled by launch_locate_order*/, void *stream,
+                       unsigned long long *stats = nullptr /*kStatLocateN: launches the instrumented instantiation*/);
 size_t locate_order_ws_bytes(uint64_t N);
 int launch_locate_order(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t *k, uint64_t N, void *ws, size_t ws_bytes,
                         void *stream);

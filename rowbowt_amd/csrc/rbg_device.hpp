@@ -51,6 +51,7 @@ struct RankAux {
     uint32_t nbefore;  // overflow bucket: i - B0 instead (the run ordinal is searched only if it is needed)
     bool inside;
     bool ovf;
+    bool dense;        // answered from a dense overflow table (read by the instrumented kernels only)
 };
 
 // # runs of the symbol that start before i, searched in the run list of bucket b (overflow buckets without
@@ -74,6 +75,7 @@ __device__ __forceinline__ uint64_t rank_in_slot(const DevSym &S, const RankSlot
                                                  const uint8_t *__restrict__ dense, RankAux *aux) {
     const uint32_t w1 = sl.w1, w2 = sl.w2, w3 = sl.w3;
     const bool wide = S.shift > kMaxNarrowShift;
+    aux->dense = false;
     const uint32_t cnt = wide ? (w1 >> 21) & 7u : (w1 >> 9) & 7u;
     if (wide && cnt != kSlotOvf) {  // wide-bucket encoding (rbg_dev.h); overflow buckets share the path below
         const uint32_t o = static_cast<uint32_t>(i - (b << S.shift));
@@ -108,6 +110,7 @@ __device__ __forceinline__ uint64_t rank_in_slot(const DevSym &S, const RankSlot
             // i-1 holds the symbol, else the number of runs that start in [B0, i)
             const uint32_t e = reinterpret_cast<const uint16_t *>(dense + (static_cast<uint64_t>(w2) << 4))[o];
             aux->ovf = false;
+            aux->dense = true;
             aux->nbefore = e >> 8;
             aux->inside = (e >> 8) == 255u;
             return (static_cast<uint64_t>(sl.r0) | (static_cast<uint64_t>(w3 >> 16) << 32)) + (e & 0xFFu);
@@ -155,7 +158,8 @@ __device__ __forceinline__ uint64_t rank_in_slot(const DevSym &S, const RankSlot
 // search (the range has narrowed to a few dozen rows), so the step is ONE 4-word load.
 template <typename P>
 __device__ __forceinline__ void rank_pair(const DevSym &S, const uint8_t *__restrict__ dense, uint64_t lo, uint64_t hi1,
-                                          uint64_t *c_before, uint64_t *c_upto, uint64_t *bh_out, RankAux *qaux) {
+                                          uint64_t *c_before, uint64_t *c_upto, uint64_t *bh_out, RankAux *qaux,
+                                          RankAux *paux_out = nullptr) {
     const RankSlot *__restrict__ slots = static_cast<const RankSlot *>(S.slots);
     const uint64_t bl = lo >> S.shift, bh = hi1 >> S.shift;
     const RankSlot sl = load_slot(slots + bl);
@@ -165,6 +169,7 @@ __device__ __forceinline__ void rank_pair(const DevSym &S, const uint8_t *__rest
     *c_before = rank_in_slot<P>(S, sl, bl, lo, dense, &paux);
     *c_upto = rank_in_slot<P>(S, sh, bh, hi1, dense, qaux);
     *bh_out = bh;
+    if (paux_out) *paux_out = paux;
 }
 
 // ordinal of the last run of the symbol that starts before the position a RankAux describes

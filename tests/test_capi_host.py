@@ -23,7 +23,7 @@ def test_exports_match_header():
     L = ra.lib()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.rbg_abi_version() == 1
+    assert L.rbg_abi_version() == 2
     assert b"CPU" in L.rbg_strerror(-3)
 
 
