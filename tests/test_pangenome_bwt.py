@@ -1,0 +1,51 @@
+"""The structured pangenome BWT builder (rowbowt_amd/tools/pangenome_bwt.py: no suffix array of the text) against
+the true suffix array (prefix doubling) of the same text: run heads, run lengths and both SA samples of every
+run must be identical.  Input synthesis for the at-scale checks, CPU only here."""
+import numpy as np
+import pytest
+import torch
+
+from rowbowt_amd.tools import pangenome_bwt as pb
+from rowbowt_amd.tools import synth_pangenome as sp
+
+
+@pytest.mark.parametrize("L,H,rate,seed", [(400, 2, 0.02, 1), (1500, 5, 0.05, 2), (3000, 9, 0.01, 3), (2500, 17, 0.10, 4),
+                                           (20000, 12, 0.03, 5), (600, 3, 0.0, 6), (5000, 40, 0.2, 7)])
+def test_matches_true_suffix_array(L, H, rate, seed):
+    dev = torch.device("cpu")
+    pg = pb.make_pangenome(L, H, rate, seed, dev)
+    text = pb.materialize_text(pg)
+    assert text.numel() == pg["n"] and int(text[-1]) == 1
+    want = sp.index_inputs(text, sp.suffix_array(text))
+    got = pb.build_runs(pg)
+    assert got["n"] == want["n"] and got["r"] == want["r"]
+    for k in ("heads", "lens", "ssa", "esa"):
+        assert np.array_equal(got[k], want[k]), k
+
+
+def test_text_layout_and_alleles():
+    pg = pb.make_pangenome(2000, 6, 0.05, 11, torch.device("cpu"))
+    text = pb.materialize_text(pg).numpy()
+    L, unit = pg["L"], pg["unit"]
+    lut = np.array(pb.ACGT, dtype=np.uint8)
+    base = lut[pg["base"].numpy()]
+    assert (text[:L] == base).all()                       # haplotype 0 is the base sequence
+    for h in range(pg["H"]):
+        assert (text[h * unit + L:(h + 1) * unit] == 65).all()
+        diff = np.flatnonzero(text[h * unit:h * unit + L] != base)
+        assert np.array_equal(diff, pg["sites"].numpy()[pg["G"][:, h].numpy() != 0])
+    assert pg["sites"].min() >= pb.K and pg["sites"].max() < L - pb.K
+
+
+@pytest.mark.parametrize("L,H,rate,seed", [(3000, 30, 0.002, 21), (1000, 60, 0.004, 22), (200000, 8, 0.01, 23)])
+def test_identical_haplotypes_and_midsize(L, H, rate, seed):
+    """few sites and many haplotypes: several haplotypes are byte-identical, so their order is decided by the
+    chain of haplotypes that follow them in the text (the fixed point of the right-to-left pass)"""
+    dev = torch.device("cpu")
+    pg = pb.make_pangenome(L, H, rate, seed, dev)
+    text = pb.materialize_text(pg)
+    want = sp.index_inputs(text, sp.suffix_array(text))
+    got = pb.build_runs(pg)
+    assert got["r"] == want["r"]
+    for k in ("heads", "lens", "ssa", "esa"):
+        assert np.array_equal(got[k], want[k]), k
