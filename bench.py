@@ -420,11 +420,13 @@ def main():
             ceiling = json.load(open(os.path.join(ROOT, "profiles", "gather_ceiling.json")))["peak_G_gathers_per_s"]
         except Exception:
             pass
-        # gathers the dominant kernel issues that can miss L2, from its own counts (independent of the PMC file)
+        # dependent random gathers the search kernel issues, from its own counts (independent of the PMC file): rank
+        # slots, dense-table rows, ftab entries, the two gathers of a re-sample, run-list probes.  The read's own
+        # bytes and the outputs are NOT in it: they are sequential sectors (2-3 per read), not index gathers --
+        # TCC_MISS of the same launch = these gathers + those sectors (273M = 231M + 42M on the default workload).
+        gathers = None
         if dom == "k_find_range<toehold>":
-            gathers = st_toe["slots"] + st_toe["dense"] + st_toe["ftab"] + 2 * st_toe["resamples"] + 4 * st_toe["searched_ranks"] + st_toe["read_chunks"]
-        else:
-            gathers = st_loc["phi_steps"] + 4 * st_loc["phi_searched"] + N
+            gathers = st_toe["slots"] + st_toe["dense"] + st_toe["ftab"] + 2 * st_toe["resamples"] + 4 * st_toe["searched_ranks"]
         out = {
             "metric": f"reads/s ({args.read_len} bp, count+locate)",
             "value": value,
@@ -468,10 +470,13 @@ def main():
                          "padding_ratio": (traffic / kernels[dom]["alg_bytes"]) if traffic else None,
                          # what holds a kernel of dependent 16-byte gathers: requests/s against the ceiling tools/gather_ceiling.hip
                          # measured (profiles/gather_ceiling.json); `gathers` = the kernel's own count of loads that can miss
-                         "request_roof": ({"unit": "G gathers/s", "gathers_per_launch": gathers, "achieved": gathers / dom_s / 1e9,
+                         "request_roof": ({"unit": "G random 16-byte gathers/s", "gathers_per_launch": gathers, "achieved": gathers / dom_s / 1e9,
                                            "peak": ceiling, "frac": gathers / dom_s / 1e9 / ceiling,
                                            "tcc_miss_per_launch": misses,
-                                           "miss_frac": (misses / dom_s / 1e9 / ceiling) if misses else None} if ceiling else None),
+                                           "note": "peak = the most random 16-byte gathers per second tools/gather_ceiling.hip gets out of this chip "
+                                                   "(flat from 1 to 16 loads in flight per lane and 2 to 8 waves per SIMD: a throughput limit of the "
+                                                   "memory system, not latency); achieved = the kernel's dependent index gathers only, its sequential "
+                                                   "read/output sectors excluded"} if ceiling and gathers else None),
                          "reference_byte_model": {"bytes_per_launch": kernels[dom]["ref_alg_bytes"],
                                                   "GBps": kernels[dom]["ref_alg_bytes"] / dom_s / 1e9,
                                                   "note": "SURVEY 8d's bytes of the reference's one-symbol-per-step algorithm over this kernel's time: a "

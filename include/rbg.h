@@ -323,6 +323,17 @@ int rbg_locate_fill_stats_dev(rbg_index *, const uint64_t *d_lo, const uint64_t 
                               uint64_t max_hits, const uint64_t *d_loc_off, uint64_t *d_locs, const void *d_order,
                               uint64_t *d_stats /* RBG_LOCATE_STATS */, void *stream);
 
+/* Synthetic reads generated on the device (measurement plumbing for BASELINE.json configs[3], "1B synthetic 150 bp
+ * reads": the host cannot feed them, and the reference has no generator -- its reads come from a FASTQ,
+ * rb_align.cpp:169-178).  Counter-based: read g = first_read + i is a pure function of (seed, g): a haplotype
+ * g_h < H, an offset in [0, L - m] inside it (text position g_h * unit + offset of a text laid out as H units of
+ * `unit` symbols whose first L are the haplotype), and with probability sub_ppm / 1e6 one substituted base.
+ * Writes N reads of m bytes at stride m into d_seqs (16-byte aligned), d_off[N+1], and (optional) each read's
+ * text position.  Needs no index. */
+int rbg_sample_reads_dev(const uint8_t *d_text, uint64_t unit, uint64_t H, uint64_t L, uint64_t m, uint64_t seed,
+                         uint64_t first_read, uint64_t N, uint32_t sub_ppm, uint8_t *d_seqs, uint64_t *d_off,
+                         uint64_t *d_start /* nullable */, void *stream);
+
 /* ---- tuning (never changes results) -------------------------------------------------------- */
 /* Process-wide defaults read when an index is built/loaded: BLOCK_THREADS (64, 128, 192 or 256; the search
  * kernels use 1024-thread workgroups instead while the 5-mer level is resident),

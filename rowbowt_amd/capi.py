@@ -100,6 +100,7 @@ _PROTOS = [
     ("rbg_markers_fill_dev", C.c_int, [VP, VP, VP, U64, VP, VP, VP]),
     ("rbg_find_range_stats_dev", C.c_int, [VP, VP, VP, U64, VP, VP, VP, VP, VP]),
     ("rbg_locate_fill_stats_dev", C.c_int, [VP, VP, VP, VP, U64, U64, VP, VP, VP, VP, VP]),
+    ("rbg_sample_reads_dev", C.c_int, [VP, U64, U64, U64, U64, U64, U64, U64, C.c_uint32, VP, VP, VP, VP]),
     ("rbg_counters", C.c_int, [VP, VP]),
     ("rbg_counters_reset", C.c_int, [VP]),
     ("rbg_set_default_option", C.c_int, [C.c_int, C.c_int64]),

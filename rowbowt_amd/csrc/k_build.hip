@@ -303,4 +303,56 @@ int launch_build_ftab(const DevIndex &ix, const LaunchCfg &cfg, uint32_t k, void
     return rc;
 }
 
+// ---- synthetic reads generated on the device (BASELINE.json configs[3]: "1B synthetic 150 bp reads" -- the host
+// cannot feed 150 GB).  Counter-based: read g (a GLOBAL read index) is a pure function of (seed, g),
+// so any rank can generate its shard of any batch: haplotype = r0 % H, offset = r1 % (L - m + 1) inside the
+// haplotype (never crossing the pads), and with probability sub_ppm / 1e6 one substitution to a different base.
+namespace {
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__global__ __launch_bounds__(256) void k_sample_reads(const uint8_t *__restrict__ text, const uint64_t unit, const uint64_t H,
+                                                      const uint64_t L, const uint64_t m, const uint64_t seed, const uint64_t first,
+                                                      const uint64_t N, const uint32_t sub_ppm, uint8_t *__restrict__ seqs,
+                                                      uint64_t *__restrict__ off, uint64_t *__restrict__ start_out) {
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint64_t wave = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 6;
+    for (uint64_t i = wave; i < N; i += nwaves) {  // one wave copies one read: coalesced loads and stores
+        const uint64_t g = first + i;
+        const uint64_t r0 = splitmix64(seed ^ (g * 0xD1B54A32D192ED03ull));
+        const uint64_t r1 = splitmix64(r0), r2 = splitmix64(r1), r3 = splitmix64(r2);
+        const uint64_t start = (r0 % H) * unit + r1 % (L - m + 1);
+        const bool mutate = (r2 % 1000000ull) < sub_ppm;
+        const uint64_t mpos = (r2 >> 32) % m;
+        for (uint64_t j = lane; j < m; j += kWave) {
+            uint32_t c = text[start + j];
+            if (mutate && j == mpos) {
+                const uint32_t code = c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 0u;
+                c = "ACGT"[(code + 1u + static_cast<uint32_t>(r3 % 3)) & 3u];
+            }
+            seqs[i * m + j] = static_cast<uint8_t>(c);
+        }
+        if (lane == 0) {
+            off[i] = i * m;
+            if (i + 1 == N) off[N] = N * m;
+            if (start_out) start_out[i] = start;
+        }
+    }
+}
+}  // namespace
+
+int launch_sample_reads(const uint8_t *text, uint64_t unit, uint64_t H, uint64_t L, uint64_t m, uint64_t seed, uint64_t first,
+                        uint64_t N, uint32_t sub_ppm, uint8_t *seqs, uint64_t *off, uint64_t *start_out, void *stream) {
+    if (N == 0) return 0;
+    const uint64_t blocks = std::min<uint64_t>((N + 3) / 4, 256ull * 64);
+    hipLaunchKernelGGL(k_sample_reads, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, static_cast<hipStream_t>(stream), text, unit, H, L, m,
+                       seed, first, N, sub_ppm, seqs, off, start_out);
+    return static_cast<int>(hipGetLastError());
+}
+
 }  // namespace rbg

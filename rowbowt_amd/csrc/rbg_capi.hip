@@ -1082,6 +1082,15 @@ int rbg_locate_fill_stats_dev(rbg_index *ix, const uint64_t *d_lo, const uint64_
     });
 }
 
+int rbg_sample_reads_dev(const uint8_t *d_text, uint64_t unit, uint64_t H, uint64_t L, uint64_t m, uint64_t seed, uint64_t first_read,
+                         uint64_t N, uint32_t sub_ppm, uint8_t *d_seqs, uint64_t *d_off, uint64_t *d_start, void *stream) {
+    return guarded([&]() -> int {
+    if (!d_text || !d_seqs || !d_off) return RBG_EARG;
+    if (m == 0 || m > L || H == 0 || L > unit || sub_ppm > 1000000u) return RBG_EARG;
+    return launch_sample_reads(d_text, unit, H, L, m, seed, first_read, N, sub_ppm, d_seqs, d_off, d_start, stream) ? RBG_ENODEV : RBG_OK;
+    });
+}
+
 // ---- packed reads (device API) ------------------------------------------------------------------
 size_t rbg_pack_ws_bytes(uint64_t N, uint64_t total_bytes) { return pack_ws_bytes(N, total_bytes); }
 

@@ -204,6 +204,8 @@ int launch_lf(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t *lo, cons
 // fills ix.ftab-shaped table `tab` (nmajor^k entries x 4 u64) by searching every k-symbol word
 int launch_build_ftab(const DevIndex &ix, const LaunchCfg &cfg, uint32_t k, void *tab, void *stream);
 size_t ftab_build_scratch_bytes(uint64_t words, uint32_t k);  // device scratch the build takes besides the table
+int launch_sample_reads(const uint8_t *text, uint64_t unit, uint64_t H, uint64_t L, uint64_t m, uint64_t seed, uint64_t first,
+                        uint64_t N, uint32_t sub_ppm, uint8_t *seqs, uint64_t *off, uint64_t *start_out /*nullable*/, void *stream);
 int launch_count_from_ranges(const uint64_t *lo, const uint64_t *hi, uint64_t N, uint64_t *count, void *stream);
 
 }  // namespace rbg

@@ -1,0 +1,291 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[3] on one GPU (and, under torch.distributed.run, on N): a pangenome-scale r-index with
+positions beyond 32 bits, a stream of synthetic 150 bp reads generated ON THE DEVICE batch by batch from a
+counter-based RNG (rbg_sample_reads_dev: the host cannot feed 150 GB), count+locate per batch, global counters
+reduced over RCCL.  Prints one JSON line (rank 0).
+
+The index is a TRUE BWT: rowbowt_amd/tools/pangenome_bwt.py derives the run-length BWT and the run-boundary SA
+samples of the H-haplotype text from its structure (no suffix array of the text; checked against prefix doubling
+in tests/test_pangenome_bwt.py and, with --verify-sa, here).  Parity: ranges, toeholds (k-mer steps included) and
+locations of --check-reads reads against oracle/rb_oracle.c; size-independent properties on --property-reads reads
+(every location is an occurrence of the read in the text, locations distinct, as many as the range is wide).
+
+  python tools/pangenome_stream.py                      # n = 5.0e10 (L = 2.5e8, H = 200), 1e9 reads x 150 bp
+  python tools/pangenome_stream.py --L 44000000 --H 100 --total-reads 100000000   # n = 4.4e9: just beyond 2^32
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+MAXU = 2**64 - 1
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--L", type=int, default=250_000_000)
+    ap.add_argument("--H", type=int, default=200)
+    ap.add_argument("--site-rate", type=float, default=0.01)
+    ap.add_argument("--seed", type=int, default=20240229)
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per batch per GPU")
+    ap.add_argument("--total-reads", type=int, default=1_000_000_000, help="reads streamed over all GPUs")
+    ap.add_argument("--sub-ppm", type=int, default=100_000, help="reads with one substitution, per million")
+    ap.add_argument("--max-hits", type=int, default=-1)
+    ap.add_argument("--check-reads", type=int, default=20000)
+    ap.add_argument("--property-reads", type=int, default=200_000)
+    ap.add_argument("--verify-sa", action="store_true", help="also build the suffix array by prefix doubling and compare (n < 2.5e9 only)")
+    ap.add_argument("--count-only", action="store_true")
+    ap.add_argument("--layout", choices=("auto", "slots", "runs"), default="auto")
+    args = ap.parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        raise SystemExit("needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    use_dist = world > 1 or "RANK" in os.environ
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    def log(*a):
+        if rank == 0:
+            print("[pangenome]", *a, file=sys.stderr, flush=True)
+
+    import rowbowt_amd as ra
+    from rowbowt_amd import capi, shard
+    from rowbowt_amd.tools import pangenome_bwt as pb
+
+    Lb = ra.lib()
+    m = args.read_len
+    max_hits = MAXU if args.max_hits < 0 else args.max_hits
+
+    # ---- synthesis (outside every timed region) ---------------------------------------------------
+    t0 = time.time()
+    pg = pb.make_pangenome(args.L, args.H, args.site_rate, args.seed, dev)
+    inp = pb.build_runs(pg, log=log)
+    t_build = time.time() - t0
+    log(f"pangenome: L={args.L} H={args.H} sites={pg['n_sites']} n={inp['n']} r={inp['r']} n/r={inp['n'] / inp['r']:.1f} (runs in {t_build:.1f}s)")
+    text = pb.materialize_text(pg)
+    if args.verify_sa:
+        from rowbowt_amd.tools import synth_pangenome as sp
+        want = sp.index_inputs(text, sp.suffix_array(text))
+        same = want["r"] == inp["r"] and all(np.array_equal(want[k], inp[k]) for k in ("heads", "lens", "ssa", "esa"))
+        log(f"prefix-doubling suffix array gives the same runs and samples: {same}")
+        if not same:
+            raise SystemExit("structured BWT builder disagrees with the suffix array")
+    unit, H, L, n = pg["unit"], pg["H"], pg["L"], pg["n"]
+    del pg
+    torch.cuda.empty_cache()
+    if args.layout != "auto":
+        capi.set_default_option(capi.OPT_RANK_LAYOUT, {"slots": 1, "runs": 2}[args.layout])
+    t0 = time.time()
+    rb = ra.RowBowt.from_runs(inp["heads"], inp["lens"], inp["ssa"], inp["esa"], device=local_rank)
+    ix = rb.info()
+    t_load = time.time() - t0
+    log(f"index replica: {ix.hbm_bytes / 1e9:.1f} GB HBM, pos_bytes={ix.pos_bytes}, {ix.kmer_steps} symbol(s) per gather "
+        f"(asked {ix.kmer_steps_requested}; {ix.hbm_free_at_load / 1e9:.0f} GB free at load, budget {ix.hbm_budget / 1e9:.0f} GB), "
+        f"ftab_k={ix.ftab_k}, flatten+upload {t_load:.1f}s")
+
+    # ---- the stream: this rank owns the contiguous block of global read indices shard_bounds() gives it
+    gb, ge = shard.shard_bounds(args.total_reads, rank, world)
+    N = min(args.reads, ge - gb)
+    nbatch = (ge - gb + N - 1) // N
+    d_seqs = torch.zeros(N * m + 32, dtype=torch.uint8, device=dev)
+    d_off = torch.empty(N + 1, dtype=torch.int64, device=dev)
+    d_lo, d_hi, d_k = (torch.empty(N, dtype=torch.int64, device=dev) for _ in range(3))
+    d_loc_off = torch.empty(N + 1, dtype=torch.int64, device=dev)
+    tmp_bytes = Lb.rbg_locate_plan_tmp_bytes(N)
+    d_tmp = torch.empty(tmp_bytes, dtype=torch.uint8, device=dev)
+    ws_bytes = Lb.rbg_locate_order_ws_bytes(N)
+    d_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream()
+    st = stream.cuda_stream
+
+    def chk(rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed: {Lb.rbg_strerror(rc).decode()}")
+
+    def gen(first, cnt):
+        chk(Lb.rbg_sample_reads_dev(text.data_ptr(), unit, H, L, m, args.seed + 2, first, cnt, args.sub_ppm, d_seqs.data_ptr(),
+                                    d_off.data_ptr(), None, st), "sample_reads")
+
+    def search(cnt):
+        if args.count_only:
+            chk(Lb.rbg_find_range_dev(rb.h, d_seqs.data_ptr(), d_off.data_ptr(), cnt, d_lo.data_ptr(), d_hi.data_ptr(), st), "find_range")
+        else:
+            chk(Lb.rbg_find_range_w_toehold_dev(rb.h, d_seqs.data_ptr(), d_off.data_ptr(), cnt, d_lo.data_ptr(), d_hi.data_ptr(),
+                                                d_k.data_ptr(), st), "find_range_w_toehold")
+
+    # size the location buffer on the first batch (+25 %); a batch that needs more re-allocates (outside the timers)
+    gen(gb, N)
+    search(N)
+    d_locs = None
+    if not args.count_only:
+        chk(Lb.rbg_locate_plan_dev(rb.h, d_lo.data_ptr(), d_hi.data_ptr(), N, max_hits, d_loc_off.data_ptr(), d_tmp.data_ptr(), tmp_bytes, st), "plan")
+        cap = int(int(d_loc_off[-1].item()) * 1.25) + 1024
+        d_locs = torch.empty(cap, dtype=torch.int64, device=dev)
+        log(f"batch 0: {int(d_loc_off[-1].item())} locations for {N} reads; location buffer {cap * 8 / 1e9:.1f} GB")
+
+    def locate(cnt):
+        nonlocal d_locs
+        chk(Lb.rbg_locate_plan_dev(rb.h, d_lo.data_ptr(), d_hi.data_ptr(), cnt, max_hits, d_loc_off.data_ptr(), d_tmp.data_ptr(), tmp_bytes, st), "plan")
+        total = int(d_loc_off[cnt].item())            # (the one host round trip of a batch: the ragged output has to be sized)
+        if total > d_locs.numel():
+            d_locs = torch.empty(int(total * 1.25), dtype=torch.int64, device=dev)
+        chk(Lb.rbg_locate_order_dev(rb.h, d_k.data_ptr(), cnt, d_ws.data_ptr(), ws_bytes, st), "order")
+        chk(Lb.rbg_locate_fill_dev(rb.h, d_lo.data_ptr(), d_hi.data_ptr(), d_k.data_ptr(), cnt, max_hits, d_loc_off.data_ptr(),
+                                   d_locs.data_ptr(), d_ws.data_ptr(), st), "fill")
+        return total
+
+    def barrier():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    rb.counters_reset()
+    ev_g = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    t_gen = t_search = 0.0
+    barrier()
+    t_all = time.perf_counter()
+    done = 0
+    for b in range(nbatch):
+        first = gb + b * N
+        cnt = min(N, ge - first)
+        ev_g[0].record(stream)
+        gen(first, cnt)
+        ev_g[1].record(stream)
+        search(cnt)
+        if not args.count_only:
+            locate(cnt)
+        torch.cuda.synchronize()
+        t_gen += ev_g[0].elapsed_time(ev_g[1]) * 1e-3
+        done += cnt
+    barrier()
+    el = time.perf_counter() - t_all
+    counters = rb.counters().astype(np.int64)
+    t_el = torch.tensor([el, t_gen], dtype=torch.float64, device=dev)
+    if use_dist:
+        dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
+    el, t_gen = float(t_el[0].item()), float(t_el[1].item())
+    g_counters = shard.reduce_counters(counters, device=dev)
+
+    out = None
+    if rank == 0:
+        out = {
+            "metric": f"reads/s ({m} bp, {'count' if args.count_only else 'count+locate'}), streamed",
+            "value": args.total_reads / el, "unit": "reads/s", "n_gpus": world, "higher_is_better": True, "scaling": "strong",
+            "value_excluding_read_generation": args.total_reads / max(el - t_gen, 1e-9),
+            "seconds": el, "seconds_generating_reads": t_gen, "batches_per_gpu": nbatch, "reads_per_batch": N,
+            "dtype": "u64" if ix.pos_bytes == 8 else "u32/u64", "data": "synthetic",
+            "config": {"workload": f"BASELINE.json configs[3] shape: {args.total_reads} synthetic {m} bp reads generated on the device per batch "
+                                   f"(counter-based RNG), {'find_range' if args.count_only else 'find_range_w_toehold + locs_at'}, "
+                                   f"index replicated x{world}, reads sharded by contiguous global index, counters reduced over RCCL",
+                       "index": {"L": args.L, "H": args.H, "n": int(n), "r": int(inp["r"]), "site_rate": args.site_rate, "true_bwt": True,
+                                 "builder": "rowbowt_amd/tools/pangenome_bwt.py", "hbm_bytes": int(ix.hbm_bytes), "pos_bytes": int(ix.pos_bytes),
+                                 "symbols_per_gather": int(ix.kmer_steps), "symbols_per_gather_requested": int(ix.kmer_steps_requested),
+                                 "hbm_free_at_load": int(ix.hbm_free_at_load), "hbm_budget": int(ix.hbm_budget),
+                                 "rank_bucket_shift": int(ix.rank_bucket_shift), "phi_bucket_shift": int(ix.phi_bucket_shift),
+                                 "rank_layout": int(ix.rank_layout), "ftab_k": int(ix.ftab_k),
+                                 "build_runs_s": t_build, "flatten_upload_s": t_load}},
+            "counters": {"reads": g_counters[0], "matched": g_counters[1], "sum_occ": g_counters[2], "sum_locs": g_counters[3],
+                         "reduced_over": f"RCCL all_reduce over {world} rank(s)" if use_dist else "single GPU (no process group)"},
+        }
+        if g_counters[0] != args.total_reads:
+            print(json.dumps(out))
+            raise SystemExit(f"counter mismatch: {g_counters[0]} reads counted, {args.total_reads} streamed")
+
+    # ---- properties + parity on the first reads of this rank's stream (outside the timed region) ---------
+    if rank == 0 and (args.property_reads > 0 or args.check_reads > 0):
+        npr = min(max(args.property_reads, args.check_reads), N)
+        d_start = torch.empty(npr, dtype=torch.int64, device=dev)
+        chk(Lb.rbg_sample_reads_dev(text.data_ptr(), unit, H, L, m, args.seed + 2, gb, npr, args.sub_ppm, d_seqs.data_ptr(), d_off.data_ptr(),
+                                    d_start.data_ptr(), st), "sample_reads")
+        search(npr)
+        total = 0 if args.count_only else locate(npr)
+        torch.cuda.synchronize()
+        reads = d_seqs[:npr * m].view(npr, m)
+        lo_t, hi_t = d_lo[:npr], d_hi[:npr]
+        # an unmutated read must be found, and its own text position must be inside its match set
+        same_as_text = (text[(d_start[:, None] + torch.arange(m, device=dev)[None, :])] == reads).all(dim=1)
+        ok_found = bool((hi_t >= lo_t)[same_as_text].all().item())
+        ok_empty = bool(((hi_t >= lo_t) | ((lo_t == 1) & (hi_t == 0))).all().item())
+        props = {"reads": npr, "unmutated_reads_all_found": ok_found, "empty_is_{1,0}": ok_empty, "unmutated": int(same_as_text.sum().item())}
+        if not args.count_only:
+            offs = d_loc_off[:npr + 1]
+            occ_t = offs[1:] - offs[:-1]
+            ok_occ = bool((torch.where(hi_t >= lo_t, hi_t - lo_t + 1, torch.zeros_like(lo_t)).clamp(max=max_hits if max_hits < 2**63 else 2**63 - 1) == occ_t).all().item())
+            ridx = torch.repeat_interleave(torch.arange(npr, device=dev), occ_t)
+            locs_t = d_locs[:total]
+            bad = torch.zeros(total, dtype=torch.bool, device=dev)
+            for j in range(m):
+                bad |= text[locs_t + j] != reads[ridx, j]
+            ok_match = not bool(bad.any().item())
+            key = ridx * (int(n) + 1) + locs_t
+            ok_distinct = int(torch.unique(key).numel()) == total
+            # the read's own position is among its locations (uncapped runs only)
+            own = torch.zeros(npr, dtype=torch.bool, device=dev)
+            own.index_put_((ridx[locs_t == d_start[ridx]],), torch.tensor(True, device=dev))
+            ok_own = bool(own[same_as_text].all().item()) if max_hits == MAXU else None
+            props.update({"locations": total, "every_location_is_an_occurrence": ok_match, "locations_distinct": ok_distinct,
+                          "occ_equals_range_width": ok_occ, "own_position_reported": ok_own})
+            del ridx, locs_t, bad, key
+        out["properties"] = props
+        if not all(v for k_, v in props.items() if isinstance(v, bool)):
+            print(json.dumps(out))
+            raise SystemExit("PROPERTY FAILURE")
+        nchk = min(args.check_reads, npr)
+        if nchk:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import orc  # oracle: the checker only
+
+            t0 = time.time()
+            o = orc.Oracle.from_runs(inp["heads"], inp["lens"], inp["ssa"], inp["esa"])
+            log(f"oracle built in {time.time() - t0:.1f}s")
+            h_seqs = reads[:nchk].cpu().numpy().reshape(-1)
+            h_off = np.arange(nchk + 1, dtype=np.uint64) * m
+            ncpu = min(os.cpu_count() or 1, 64)
+            g_lo = d_lo[:nchk].cpu().numpy().view(np.uint64)
+            g_hi = d_hi[:nchk].cpu().numpy().view(np.uint64)
+            if args.count_only:
+                wlo, whi = o.find_range_batch(h_seqs, h_off, nthreads=ncpu)
+                ok = bool((g_lo == wlo).all() and (g_hi == whi).all())
+                out["parity"] = {"reads_checked": nchk, "bit_exact_vs_oracle": ok}
+            else:
+                g_k = d_k[:nchk].cpu().numpy().view(np.uint64)
+                g_off = d_loc_off[:nchk + 1].cpu().numpy().view(np.uint64)
+                g_locs = d_locs[:int(g_off[-1])].cpu().numpy().view(np.uint64)
+                wlo, whi, wk = o.find_range_w_toehold_batch(h_seqs, h_off, nthreads=ncpu)
+                woff, wlocs = o.locs_at_batch(wlo, whi, wk, max_hits, nthreads=ncpu)
+                ok = bool((g_lo == wlo).all() and (g_hi == whi).all() and (g_k == wk).all() and (g_off == woff).all() and (g_locs == wlocs).all())
+                # the count-only kernel on the same reads
+                chk(Lb.rbg_find_range_dev(rb.h, d_seqs.data_ptr(), d_off.data_ptr(), nchk, d_lo.data_ptr(), d_hi.data_ptr(), st), "find_range")
+                torch.cuda.synchronize()
+                ok1 = bool((d_lo[:nchk].cpu().numpy().view(np.uint64) == wlo).all() and (d_hi[:nchk].cpu().numpy().view(np.uint64) == whi).all())
+                out["parity"] = {"reads_checked": nchk, "locs_checked": int(woff[-1]), "toeholds_above_2^32": int((wk[whi >= wlo] >= 2**32).sum()),
+                                 "bit_exact_vs_oracle": ok and ok1, "count_only_kernel_bit_exact": ok1}
+            o.close()
+            if not out["parity"]["bit_exact_vs_oracle"]:
+                print(json.dumps(out))
+                raise SystemExit("PARITY FAILURE: HIP path disagrees with the oracle")
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    rb.close()
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
