@@ -259,6 +259,10 @@ int launch_locate_fill(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t 
     // the order workspace also holds the toeholds in sorted order (launch_locate_order's key output)
     const uint64_t *skeys = order ? reinterpret_cast<const uint64_t *>(static_cast<const char *>(order) + order_layout(N).keys) : nullptr;
     const uint32_t *perm = static_cast<const uint32_t *>(order);
+    if (ix.layout == 2) {  // run-indexed layout (k_runs.hip)
+        if (stats) return static_cast<int>(hipErrorNotSupported);
+        return launch_locate_fill_runs(ix, cfg, lo, hi, k, N, max_hits, loc_off, locs, sub, order, skeys, stream);
+    }
     if (stats) {
         if (ix.pos_bytes == 4) hipLaunchKernelGGL((k_locate_fill<uint32_t, true>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, locs, sub, perm, skeys, stats);
         else hipLaunchKernelGGL((k_locate_fill<uint64_t, true>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, locs, sub, perm, skeys, stats);

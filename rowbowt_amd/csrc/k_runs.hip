@@ -1,0 +1,467 @@
+// k_runs.hip -- the run-indexed layout (RBG_LAYOUT_RUNS, rbg_dev.h DevTree): K1/K2 and K3 with space proportional
+// to r.  rank and phi are predecessor searches over sorted run boundaries, as in the reference
+// (rle_string::rank rle_string.hpp:131-161, ToeholdSA::phi toehold_sa.hpp:56-72), done the way the hardware
+// likes them: the coarsest level of the 64-ary sampled index sits in LDS (per-lane binary search), every level
+// below it is probed by the WAVE -- one coalesced load of the 64-entry block, a 64-wide compare, a ballot and a
+// popcount -- for one lane's query after the other, several probes in flight.  One lane still owns one read
+// (K1/K2) or one phi chain (K3); lanes whose own work is finished keep serving the others' probes.
+#include "rbg_device.hpp"
+
+namespace rbg {
+namespace {
+
+constexpr int kCoopGroup = 4;  // owners whose block loads are in flight together (each up to two blocks)
+
+__device__ __forceinline__ uint32_t rl32(uint32_t v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ uint64_t rl64(uint64_t v, int lane) {
+    return (static_cast<uint64_t>(rl32(static_cast<uint32_t>(v >> 32), lane)) << 32) | rl32(static_cast<uint32_t>(v), lane);
+}
+__device__ __forceinline__ int first_lane(uint64_t mask) { return __builtin_amdgcn_readfirstlane(__builtin_ctzll(mask)); }
+
+// pair of P as the kernels load it (one request per lane)
+template <typename P> struct PairOf;
+template <> struct PairOf<uint32_t> { typedef unsigned int vec __attribute__((ext_vector_type(2))); };
+template <> struct PairOf<uint64_t> { typedef unsigned long long vec __attribute__((ext_vector_type(2))); };
+
+// # entries of s_top[off, off + n) that are < q (per lane; LDS)
+template <typename P>
+__device__ __forceinline__ uint32_t top_count(const P *s_top, uint32_t off, uint32_t n, uint64_t q) {
+    uint32_t a = 0, z = n;
+    while (a < z) {
+        const uint32_t mid = (a + z) >> 1;
+        if (static_cast<uint64_t>(s_top[off + mid]) < q) a = mid + 1; else z = mid;
+    }
+    return a;
+}
+
+// One sampled level (keys only), for up to two queries per lane.  On entry t0 / t1 = # entries of the level ABOVE
+// that are < q (>= 1 for a live query): the answer at this level lies in block t - 1.  On return t = # entries of
+// THIS level that are < q.  `pend` = lanes with a live query (wave-uniform).  Every lane of the wave must call.
+template <typename P>
+__device__ __forceinline__ void coop_level(const DevTree *s_tree, const int l, uint64_t pend, const uint32_t tid, const bool live0,
+                                           const bool live1, uint32_t &t0, uint32_t &t1, const uint64_t q0, const uint64_t q1) {
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t lv = (live0 ? 1u : 0u) | (live1 ? 2u : 0u);
+    while (pend) {
+        int own[kCoopGroup];
+        uint32_t flags[kCoopGroup], bb0[kCoopGroup], bb1[kCoopGroup];
+        P va[kCoopGroup], vb[kCoopGroup];
+#pragma unroll
+        for (int g = 0; g < kCoopGroup; ++g) {
+            own[g] = -1;
+            va[g] = vb[g] = 0;
+            flags[g] = bb0[g] = bb1[g] = 0;
+            if (pend) {
+                const int o = first_lane(pend);
+                pend &= pend - 1;
+                own[g] = o;
+                const DevTree &T = s_tree[rl32(tid, o)];
+                const P *__restrict__ keys = static_cast<const P *>(T.lvl[l]);
+                const uint32_t nl = T.lvl_n[l];
+                const uint32_t f = rl32(lv, o);
+                const uint32_t b0 = rl32(t0, o) - 1, b1 = rl32(t1, o) - 1;
+                const uint32_t first = (f & 1u) ? b0 : b1;
+                const uint64_t i0 = static_cast<uint64_t>(first) * kTreeFan + lane;
+                va[g] = i0 < nl ? keys[i0] : static_cast<P>(~P(0));
+                const bool two = f == 3u && b0 != b1;
+                if (two) {
+                    const uint64_t i1 = static_cast<uint64_t>(b1) * kTreeFan + lane;
+                    vb[g] = i1 < nl ? keys[i1] : static_cast<P>(~P(0));
+                }
+                flags[g] = f | (two ? 4u : 0u);
+                bb0[g] = b0;
+                bb1[g] = b1;
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < kCoopGroup; ++g) {
+            if (own[g] >= 0) {
+                const int o = own[g];
+                const uint64_t qq0 = rl64(q0, o), qq1 = rl64(q1, o);
+                // padding lanes hold the all-ones key, which no query exceeds (positions stay below it: flatten())
+                const uint32_t c0 = static_cast<uint32_t>(__popcll(__ballot(static_cast<uint64_t>(va[g]) < qq0)));
+                const uint32_t c1 = static_cast<uint32_t>(__popcll(__ballot(static_cast<uint64_t>((flags[g] & 4u) ? vb[g] : va[g]) < qq1)));
+                if (static_cast<int>(lane) == o) {
+                    if (flags[g] & 1u) t0 = bb0[g] * kTreeFan + c0;
+                    if (flags[g] & 2u) t1 = bb1[g] * kTreeFan + c1;
+                }
+            }
+        }
+    }
+}
+
+// The leaf level: {key, value} pairs.  For each live query returns k = # keys < q (in t), the pair before it
+// (key pk, value pv: entry k-1) and the value of entry k (nv; the arrays carry a sentinel entry).
+template <typename P>
+__device__ __forceinline__ void coop_leaf(const DevTree *s_tree, uint64_t pend, const uint32_t tid, const bool live0, const bool live1,
+                                          uint32_t &t0, uint32_t &t1, const uint64_t q0, const uint64_t q1, uint64_t &pk0, uint64_t &pv0,
+                                          uint64_t &nv0, uint64_t &pk1, uint64_t &pv1, uint64_t &nv1) {
+    typedef typename PairOf<P>::vec vec;
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t lv = (live0 ? 1u : 0u) | (live1 ? 2u : 0u);
+    bool fix0 = false, fix1 = false;  // entry k is the first of the next block: fetched by the owner afterwards
+    while (pend) {
+        int own[kCoopGroup];
+        uint32_t flags[kCoopGroup], bb0[kCoopGroup], bb1[kCoopGroup];
+        vec va[kCoopGroup], vb[kCoopGroup];
+#pragma unroll
+        for (int g = 0; g < kCoopGroup; ++g) {
+            own[g] = -1;
+            va[g] = vb[g] = vec{0, 0};
+            flags[g] = bb0[g] = bb1[g] = 0;
+            if (pend) {
+                const int o = first_lane(pend);
+                pend &= pend - 1;
+                own[g] = o;
+                const DevTree &T = s_tree[rl32(tid, o)];
+                const vec *__restrict__ ent = static_cast<const vec *>(T.ent);
+                const uint64_t m = T.m;
+                const uint32_t f = rl32(lv, o);
+                const uint32_t b0 = rl32(t0, o) - 1, b1 = rl32(t1, o) - 1;
+                const uint32_t first = (f & 1u) ? b0 : b1;
+                const uint64_t i0 = static_cast<uint64_t>(first) * kTreeFan + lane;
+                va[g] = i0 <= m ? ent[i0] : vec{static_cast<P>(~P(0)), 0};   // entry m is the sentinel (key = n: never < q)
+                const bool two = f == 3u && b0 != b1;
+                if (two) {
+                    const uint64_t i1 = static_cast<uint64_t>(b1) * kTreeFan + lane;
+                    vb[g] = i1 <= m ? ent[i1] : vec{static_cast<P>(~P(0)), 0};
+                }
+                flags[g] = f | (two ? 4u : 0u);
+                bb0[g] = b0;
+                bb1[g] = b1;
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < kCoopGroup; ++g) {
+            if (own[g] >= 0) {
+                const int o = own[g];
+                const uint64_t qq0 = rl64(q0, o), qq1 = rl64(q1, o);
+                const vec w1 = (flags[g] & 4u) ? vb[g] : va[g];
+                // the sentinel (key n) and the padding never compare below a query (q <= n)
+                const uint32_t c0 = static_cast<uint32_t>(__popcll(__ballot(static_cast<uint64_t>(va[g].x) < qq0)));
+                const uint32_t c1 = static_cast<uint32_t>(__popcll(__ballot(static_cast<uint64_t>(w1.x) < qq1)));
+                // a live query has c >= 1 (entry 64*block is the sample that was < q one level up); c - 1 and c are lanes
+                const int p0 = static_cast<int>(c0 ? c0 - 1 : 0), n0 = static_cast<int>(c0 < 64 ? c0 : 63);
+                const int p1 = static_cast<int>(c1 ? c1 - 1 : 0), n1 = static_cast<int>(c1 < 64 ? c1 : 63);
+                const uint64_t a_pk0 = rl64(static_cast<uint64_t>(va[g].x), p0), a_pv0 = rl64(static_cast<uint64_t>(va[g].y), p0);
+                const uint64_t a_nv0 = rl64(static_cast<uint64_t>(va[g].y), n0);
+                const uint64_t a_pk1 = rl64(static_cast<uint64_t>(w1.x), p1), a_pv1 = rl64(static_cast<uint64_t>(w1.y), p1);
+                const uint64_t a_nv1 = rl64(static_cast<uint64_t>(w1.y), n1);
+                if (static_cast<int>(lane) == o) {
+                    if (flags[g] & 1u) { t0 = bb0[g] * kTreeFan + c0; pk0 = a_pk0; pv0 = a_pv0; nv0 = a_nv0; fix0 = c0 == 64; }
+                    if (flags[g] & 2u) { t1 = bb1[g] * kTreeFan + c1; pk1 = a_pk1; pv1 = a_pv1; nv1 = a_nv1; fix1 = c1 == 64; }
+                }
+            }
+        }
+    }
+    if (fix0 || fix1) {
+        const vec *__restrict__ ent = static_cast<const vec *>(s_tree[tid].ent);
+        if (fix0) nv0 = static_cast<uint64_t>(ent[t0].y);
+        if (fix1) nv1 = static_cast<uint64_t>(ent[t1].y);
+    }
+}
+
+// ---- K1 / K2 over the run-indexed layout ------------------------------------------------------------------------
+// RowBowt::find_range (rowbowt.hpp:121-131) / find_range_w_toehold (:169-184): one reference LF step per iteration
+// (rowbowt.hpp:74-88, LF_w_loc :555-573), both ranks of all the wave's reads answered cooperatively.  The device
+// ftab (a constant-size state table, result-neutral) still replaces the first ftab_k steps.
+template <typename P, bool TOEHOLD>
+__global__ __launch_bounds__(256) void k_find_range_runs(const DevIndex ix, const uint8_t *__restrict__ seqs,
+                                                        const uint64_t *__restrict__ off, const uint64_t N,
+                                                        uint64_t *__restrict__ lo_out, uint64_t *__restrict__ hi_out,
+                                                        uint64_t *__restrict__ ss_out) {
+    __shared__ uint8_t s_lut[256];
+    __shared__ uint8_t s_lut2[256];
+    __shared__ DevTree s_tree[kLdsSyms];
+    __shared__ uint64_t s_F[kLdsSyms];
+    __shared__ const void *s_samp[kLdsSyms];
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    P *s_top = reinterpret_cast<P *>(s_dyn);
+    for (int t = threadIdx.x; t < 256; t += blockDim.x) {
+        s_lut[t] = ix.lut[t];
+        s_lut2[t] = ix.nmajor ? ix.lut2[t] : 0xFFu;
+    }
+    const int nsym = ix.sigma < static_cast<uint32_t>(kLdsSyms) ? static_cast<int>(ix.sigma) : kLdsSyms;
+    for (int t = threadIdx.x; t < nsym; t += blockDim.x) {
+        s_tree[t] = ix.trees[t];
+        s_F[t] = ix.syms[t].F;
+        s_samp[t] = ix.syms[t].samp;
+    }
+    for (uint32_t t = threadIdx.x; t < ix.tree_top_n; t += blockDim.x) s_top[t] = static_cast<const P *>(ix.tree_top)[t];
+    __syncthreads();
+    const int nlvl = static_cast<int>(ix.tree_nlvl);
+    const uint32_t M = ix.nmajor;
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+
+    unsigned long long c_occ = 0, c_reads = 0;
+    uint32_t c_matched = 0;
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    const uint64_t wave_first = static_cast<uint64_t>(blockIdx.x) * blockDim.x + (threadIdx.x & ~(kWave - 1));
+    for (uint64_t base = wave_first; base < N; base += stride) {  // the lanes of a wave iterate together
+        const uint64_t i = base + lane;
+        const bool valid = i < N;
+        uint64_t beg = 0, p = 0;
+        if (valid) { beg = off[i]; p = off[i + 1]; }
+        uint64_t lo = 0, hi = ix.n - 1;                       // full_range(), rowbowt.hpp:115-118
+        uint64_t k = TOEHOLD ? ix.last_run_sample : 0;
+        bool alive = valid;
+        bool pend = false;                                     // deferred toehold re-sample: run `pend_run` of symbol `pend_sym`
+        uint32_t pend_sym = 0, pend_run = 0;
+        ByteCursor rd{reinterpret_cast<const uint4 *>(seqs), ~uint64_t(0), make_uint4(0, 0, 0, 0)};
+        if (valid && ix.ftab_k && p - beg >= ix.ftab_k) {      // rowbowt.hpp:124-125, :745-758 (k_search.hip)
+            uint64_t idx = 0, pw = 1;
+            bool all_major = true;
+            for (uint32_t t = 1; t <= ix.ftab_k; ++t) {
+                const uint32_t mm = s_lut2[rd.at(p - t)];
+                all_major = all_major && mm != 0xFFu;
+                idx += (mm & 3u) * pw;
+                pw *= M;
+            }
+            uint64_t flo, fhi2, fk;
+            if (all_major && ftab_lookup<P>(ix, idx, flo, fhi2, fk)) {
+                lo = flo; hi = fhi2;
+                if (TOEHOLD) k = fk;
+                p -= ix.ftab_k;
+                if (hi < lo) { alive = false; p = beg; }
+            }
+        }
+        while (__ballot(alive && p > beg)) {                   // right-to-left over the reads (rowbowt.hpp:127-129, :175-181)
+            bool stepping = alive && p > beg;
+            uint32_t slot = 0;
+            if (stepping) {
+                --p;
+                slot = s_lut[rd.at(p)];
+                if (slot == 0xFFu || slot >= static_cast<uint32_t>(kLdsSyms)) {
+                    // symbol absent (f_[c] >= f_[c+1], rowbowt.hpp:76).  (An index with more than kLdsSyms symbols is
+                    // never given this layout: upload() keeps the slot tables for it.)
+                    alive = false;
+                    stepping = false;
+                    slot = 0;
+                }
+            }
+            const uint64_t q0 = lo, q1 = hi + 1;               // rank(lo, c), rank(hi + 1, c): rowbowt.hpp:79,83
+            uint32_t t0 = 0, t1 = 0;
+            if (stepping) {
+                const DevTree &T = s_tree[slot];
+                t0 = top_count<P>(s_top, T.top_off, T.top_n, q0);
+                t1 = top_count<P>(s_top, T.top_off, T.top_n, q1);
+            }
+            for (int l = nlvl - 1; l >= 0; --l) {
+                const bool l0 = stepping && t0 > 0, l1 = stepping && t1 > 0;
+                coop_level<P>(s_tree, l, __ballot(l0 || l1), slot, l0, l1, t0, t1, q0, q1);
+            }
+            uint64_t pk0 = 0, pv0 = 0, nv0 = 0, pk1 = 0, pv1 = 0, nv1 = 0;
+            {
+                const bool l0 = stepping && t0 > 0, l1 = stepping && t1 > 0;
+                coop_leaf<P>(s_tree, __ballot(l0 || l1), slot, l0, l1, t0, t1, q0, q1, pk0, pv0, nv0, pk1, pv1, nv1);
+            }
+            if (stepping) {
+                // rle_string::rank: occurrences before the predecessor run + the part of it below the position
+                uint64_t c_before = 0, c_upto = 0;
+                bool inside = false;
+                if (t0 > 0) { const uint64_t len = nv0 - pv0, d = q0 - pk0; c_before = pv0 + (d < len ? d : len); }
+                if (t1 > 0) { const uint64_t len = nv1 - pv1, d = q1 - pk1; c_upto = pv1 + (d < len ? d : len); inside = d <= len; }
+                const uint64_t c_inside = c_upto - c_before;
+                if (c_inside == 0) {                            // rowbowt.hpp:85
+                    alive = false;
+                } else {
+                    if (TOEHOLD) {                              // LF_w_loc, rowbowt.hpp:559-566
+                        if (inside) k = k - 1;
+                        else { pend = true; pend_sym = slot; pend_run = t1 - 1; k = 0; }
+                    }
+                    lo = s_F[slot] + c_before;                  // rowbowt.hpp:86
+                    hi = lo + c_inside - 1;                     // rowbowt.hpp:87
+                }
+            }
+        }
+        if (TOEHOLD && alive && pend) k += static_cast<uint64_t>(static_cast<const P *>(s_samp[pend_sym])[pend_run]);
+        if (!alive) { lo = 1; hi = 0; k = 0; }                 // {1,0}; LFData::clear rowbowt.hpp:153-159
+        if (valid) {
+            lo_out[i] = lo;
+            hi_out[i] = hi;
+            if (TOEHOLD) ss_out[i] = k;
+            c_reads += 1;
+            if (alive) { c_matched += 1; c_occ += hi - lo + 1; }
+        }
+    }
+    c_reads = wave_sum(c_reads);
+    const unsigned long long w_matched = wave_sum(static_cast<unsigned long long>(c_matched));
+    c_occ = wave_sum(c_occ);
+    if (lane == 0 && c_reads) {
+        atomicAdd(&ix.counters[0], c_reads);
+        if (w_matched) atomicAdd(&ix.counters[1], w_matched);
+        if (c_occ) atomicAdd(&ix.counters[2], c_occ);
+    }
+}
+
+// ---- K3 over the run-indexed layout -------------------------------------------------------------------------------
+// ToeholdSA::locate_range (toehold_sa.hpp:37-49): the phi chains as in k_locate_fill (LDS-staged values, chains in
+// toehold order), phi itself (toehold_sa.hpp:56-72) as a cooperative predecessor search over the sampled positions.
+constexpr int kChunkR = 16;
+
+__device__ __forceinline__ void wave_lds_sync() {  // as in k_locate.hip: orders the wave's own LDS writes and cross-lane reads
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <typename P>
+__global__ __launch_bounds__(256) void k_locate_fill_runs(const DevIndex ix, const uint64_t *__restrict__ lo,
+                                                          const uint64_t *__restrict__ hi, const uint64_t *__restrict__ k,
+                                                          const uint64_t N, const uint64_t max_hits,
+                                                          const uint64_t *__restrict__ loc_off, uint64_t *__restrict__ locs,
+                                                          const uint64_t *__restrict__ sub, const uint32_t *__restrict__ order,
+                                                          const uint64_t *__restrict__ skeys) {
+    __shared__ P s_val[4][kWave][kChunkR + 1];
+    __shared__ uint64_t s_dst[4][kWave];
+    __shared__ uint64_t s_occ[4][kWave];
+    __shared__ uint64_t s_minus[4][kWave];
+    __shared__ uint64_t s_first[4][kWave];
+    __shared__ DevTree s_tree[1];
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    P *s_top = reinterpret_cast<P *>(s_dyn);
+    if (threadIdx.x == 0) s_tree[0] = ix.phi_tree;
+    for (uint32_t t = threadIdx.x; t < ix.phi_tree.top_n; t += blockDim.x) s_top[t] = static_cast<const P *>(ix.phi_top)[t];
+    __syncthreads();
+    const int nlvl = static_cast<int>(ix.phi_nlvl);
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
+    const PhiEnt<P> *__restrict__ pent = static_cast<const PhiEnt<P> *>(ix.phi_ent);
+    unsigned long long c_locs = 0;
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t base = static_cast<uint64_t>(blockIdx.x) * blockDim.x + wv * kWave; base < N; base += stride) {
+        const uint64_t j = base + lane;
+        uint64_t i = j;
+        if (order && j < N) i = order[j];
+        uint64_t occ = 0, k1 = 0, dst = 0;
+        if (i < N && j < N) {
+            dst = loc_off[i];
+            if (skeys) {
+                k1 = skeys[j];
+                occ = loc_off[i + 1] - dst;
+            } else {
+                const uint64_t l = lo[i], h = hi[i];
+                occ = h >= l ? h - l + 1 : 0;                  // toehold_sa.hpp:38-39
+                if (occ > max_hits) occ = max_hits;
+                k1 = k[i];
+            }
+        }
+        const uint64_t minus = (sub && i < N && j < N) ? sub[i] : 0;
+        s_dst[wv][lane] = dst;
+        s_occ[wv][lane] = occ;
+        s_minus[wv][lane] = minus;
+        s_first[wv][lane] = k1;
+        c_locs += occ;
+        uint64_t wmax = occ;
+#pragma unroll
+        for (int o = kWave / 2; o > 0; o >>= 1) {
+            const uint64_t other = __shfl_xor(wmax, o, kWave);
+            wmax = other > wmax ? other : wmax;
+        }
+        for (uint64_t t0 = 0; t0 < wmax; t0 += kChunkR) {
+#pragma unroll 1
+            for (int e = 0; e < kChunkR; ++e) {
+                const uint64_t t = t0 + e;
+                const bool need = t < occ && t > 0;            // toehold_sa.hpp:44: k = phi(k)
+                const bool wrapped = need && k1 >= ix.n;        // a toehold below zero (k_locate.hip phi_step): outside phi's domain
+                const bool coop = need && !wrapped;
+                uint32_t tq = 0, unused_t = 0;
+                if (coop) tq = top_count<P>(s_top, 0, s_tree[0].top_n, k1);
+                for (int l = nlvl - 1; l >= 0; --l) {
+                    const bool lv0 = coop && tq > 0;
+                    coop_level<P>(s_tree, l, __ballot(lv0), 0u, lv0, false, tq, unused_t, k1, 0);
+                }
+                uint64_t pk = 0, pv = 0, nv = 0, u1 = 0, u2 = 0, u3 = 0;
+                {
+                    const bool lv0 = coop && tq > 0;
+                    coop_leaf<P>(s_tree, __ballot(lv0), 0u, lv0, false, tq, unused_t, k1, 0, pk, pv, nv, u1, u2, u3);
+                }
+                if (need) {
+                    uint64_t s;
+                    if (wrapped) {
+                        const PhiEnt<P> e2 = pent[ix.r - 1];
+                        s = (static_cast<uint64_t>(e2.base) + (k1 - static_cast<uint64_t>(e2.pos))) % ix.n;
+                    } else if (tq == 0) {
+                        // no sampled position before k1: circular predecessor = the last one, delta = i + 1
+                        // (sparse_sd_vector.hpp:141-143, toehold_sa.hpp:59,65)
+                        s = static_cast<uint64_t>(pent[ix.r - 1].base) + k1 + 1;
+                        if (s >= ix.n) s -= ix.n;
+                    } else {
+                        s = pv + (k1 - pk);                    // prev_sample + delta (toehold_sa.hpp:65-71)
+                        if (s >= ix.n) s -= ix.n;
+                    }
+                    k1 = s;
+                }
+                if (t < occ) s_val[wv][lane][e] = static_cast<P>(k1);
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int pass = 0; pass < kChunkR; ++pass) {
+                const int s = pass * (kWave / kChunkR) + lane / kChunkR;
+                const int e = lane & (kChunkR - 1);
+                const uint64_t t = t0 + e;
+                if (t < s_occ[wv][s]) locs[s_dst[wv][s] + t] = (t ? static_cast<uint64_t>(s_val[wv][s][e]) : s_first[wv][s]) - s_minus[wv][s];
+            }
+            wave_lds_sync();
+        }
+        wave_lds_sync();
+    }
+    c_locs = wave_sum(c_locs);
+    if (lane == 0 && c_locs) atomicAdd(&ix.counters[3], c_locs);
+}
+
+template <typename Kernel>
+void raise_lds(Kernel kernel, size_t bytes) {
+    if (bytes <= 48 * 1024) return;
+    static std::mutex mu;
+    static std::set<std::pair<int, const void *>> raised;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const auto key = std::make_pair(dev, reinterpret_cast<const void *>(kernel));
+    std::lock_guard<std::mutex> g(mu);
+    if (raised.insert(key).second) (void)hipFuncSetAttribute(key.second, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+}
+
+}  // namespace
+
+int launch_find_range_runs(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
+                           uint64_t *lo, uint64_t *hi, uint64_t *ssamp, void *stream) {
+    if (N == 0) return 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t lds = static_cast<size_t>(ix.tree_top_n) * ix.pos_bytes + 16;
+    const dim3 grid(grid_for(cfg, N)), block(256);
+#define RBG_LAUNCH_FRR(PT, TOE)                                                                        \
+    do {                                                                                               \
+        auto kern = k_find_range_runs<PT, TOE>;                                                        \
+        raise_lds(kern, lds);                                                                          \
+        hipLaunchKernelGGL(kern, grid, block, lds, st, ix, seqs, off, N, lo, hi, ssamp);               \
+    } while (0)
+    if (ix.pos_bytes == 4) {
+        if (ssamp) RBG_LAUNCH_FRR(uint32_t, true); else RBG_LAUNCH_FRR(uint32_t, false);
+    } else {
+        if (ssamp) RBG_LAUNCH_FRR(uint64_t, true); else RBG_LAUNCH_FRR(uint64_t, false);
+    }
+#undef RBG_LAUNCH_FRR
+    return static_cast<int>(hipGetLastError());
+}
+
+int launch_locate_fill_runs(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t *lo, const uint64_t *hi, const uint64_t *k,
+                            uint64_t N, uint64_t max_hits, const uint64_t *loc_off, uint64_t *locs, const uint64_t *sub,
+                            const void *order, const uint64_t *skeys, void *stream) {
+    if (N == 0) return 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t lds = static_cast<size_t>(ix.phi_tree.top_n) * ix.pos_bytes + 16;
+    const dim3 grid(grid_for(cfg, N)), block(256);
+    const uint32_t *perm = static_cast<const uint32_t *>(order);
+    if (ix.pos_bytes == 4) {
+        auto kern = k_locate_fill_runs<uint32_t>;
+        raise_lds(kern, lds);
+        hipLaunchKernelGGL(kern, grid, block, lds, st, ix, lo, hi, k, N, max_hits, loc_off, locs, sub, perm, skeys);
+    } else {
+        auto kern = k_locate_fill_runs<uint64_t>;
+        raise_lds(kern, lds);
+        hipLaunchKernelGGL(kern, grid, block, lds, st, ix, lo, hi, k, N, max_hits, loc_off, locs, sub, perm, skeys);
+    }
+    return static_cast<int>(hipGetLastError());
+}
+
+}  // namespace rbg

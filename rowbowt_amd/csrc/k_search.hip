@@ -441,12 +441,14 @@ int launch_find_range_impl(const DevIndex &ix, const LaunchCfg &cfg, const uint8
 
 int launch_find_range_stats(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
                             uint64_t *lo, uint64_t *hi, uint64_t *ssamp, unsigned long long *stats, void *stream) {
+    if (ix.layout == 2) return static_cast<int>(hipErrorNotSupported);  // the instrumented walk exists for the slot tables only
     return ix.ftab_k ? launch_find_range_impl<true, true>(ix, cfg, seqs, off, N, lo, hi, ssamp, nullptr, nullptr, stream, stats)
                      : launch_find_range_impl<false, true>(ix, cfg, seqs, off, N, lo, hi, ssamp, nullptr, nullptr, stream, stats);
 }
 
 int launch_find_range(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
                       uint64_t *lo, uint64_t *hi, uint64_t *ssamp, void *stream) {
+    if (ix.layout == 2) return launch_find_range_runs(ix, cfg, seqs, off, N, lo, hi, ssamp, stream);  // run-indexed layout (k_runs.hip)
     // without a table the table-free instantiation runs (it is also the one that BUILDS the table,
     // so profiles show that one-off launch under its own kernel name)
     return ix.ftab_k ? launch_find_range_impl<true>(ix, cfg, seqs, off, N, lo, hi, ssamp, nullptr, nullptr, stream)

@@ -34,6 +34,7 @@ struct rbg_index {
     size_t arena_bytes = 0, arena_used = 0;
     uint64_t rank_slots = 0, rank_slots_overflow = 0, phi_slots = 0, phi_slots_overflow = 0;
     uint64_t kmer_steps_requested = 0, hbm_free_at_load = 0, hbm_budget = 0;  // how the space/speed point was chosen (rbg_info)
+    bool runs_layout = false;
     std::vector<DevSym> dense_todo;  // load time only: rank tables whose overflow buckets still need their dense tables
     std::mutex mu;               // guards marker/doc attachment only; queries are lock-free
 };
@@ -49,6 +50,8 @@ std::atomic<int64_t> g_opt_hbm_budget_mb{0};
 std::atomic<int64_t> g_opt_ftab_k{-1};
 std::atomic<int64_t> g_opt_deep_shift{-1};
 std::atomic<int64_t> g_opt_dense_overflow{1};
+std::atomic<int64_t> g_opt_rank_layout{0};    // RBG_LAYOUT_AUTO / _SLOTS / _RUNS
+std::atomic<int64_t> g_opt_tree_top_kb{48};   // LDS the staged top levels of the run-indexed search may take per workgroup
 std::atomic<int64_t> g_opt_packed_reads{0};  // host-pointer calls: 0 never pack (default), 1 pack large batches, 2 always pack
 
 #define HIP_TRY(expr)                                                                             \
@@ -188,7 +191,7 @@ int commit_sym(rbg_index *ix, const SymTable &t, bool with_samples, PreparedSym<
     ix->rank_slots += nb;
     d.F = t.F;
     d.shift = t.shift;
-    d.pad = 0;
+    d.nruns = static_cast<uint32_t>(t.nruns);
     if (dense) ix->dense_todo.push_back(d);
     return RBG_OK;
 }
@@ -309,6 +312,118 @@ int upload_tables(rbg_index *ix) {
     return RBG_OK;
 }
 
+// ---- run-indexed layout (rbg_dev.h DevTree): the run lists as they are plus a 64-ary sampled index over their keys
+// every 64th key, every 64th of those, ... until what is left of ALL trees of the kernel fits the LDS budget: that
+// coarsest level is staged in LDS, the ones below it live in HBM.  Space: (1 + 1/63) keys per run.
+template <typename P>
+struct TreeBuild {
+    std::vector<std::vector<P>> lvl;  // lvl[0] = every 64th key, ...
+};
+
+template <typename P, typename KeyAt>
+void sample_levels(uint64_t m, KeyAt key_at, uint32_t nlevels_total, TreeBuild<P> &tb) {
+    tb.lvl.clear();
+    uint64_t step = kTreeFan;
+    for (uint32_t l = 0; l < nlevels_total; ++l) {
+        std::vector<P> v((m + step - 1) / step);
+        for (uint64_t j = 0; j < v.size(); ++j) v[j] = static_cast<P>(key_at(j * step));
+        tb.lvl.push_back(std::move(v));
+        step *= kTreeFan;
+    }
+}
+
+// number of HBM-resident levels so that the coarsest level of every tree together takes at most `budget_keys`
+uint32_t tree_levels_for(const std::vector<uint64_t> &sizes, uint64_t budget_keys) {
+    for (uint32_t nl = 0; nl <= kMaxTreeLevels; ++nl) {
+        uint64_t total = 0, step = kTreeFan;
+        for (uint32_t t = 0; t < nl; ++t) step *= kTreeFan;
+        for (uint64_t m : sizes) total += (m + step - 1) / step;
+        if (total <= budget_keys) return nl;
+    }
+    return kMaxTreeLevels + 1;
+}
+
+template <typename P, typename KeyAt>
+int upload_tree(rbg_index *ix, const void *d_ent, uint64_t m, KeyAt key_at, uint32_t nlvl, std::vector<P> &top_all, DevTree &T) {
+    TreeBuild<P> tb;
+    sample_levels<P>(m, key_at, nlvl + 1, tb);
+    T = DevTree{};
+    T.ent = d_ent;
+    T.m = m;
+    for (uint32_t l = 0; l < nlvl; ++l) {
+        int rc = dev_upload(ix, tb.lvl[l].data(), tb.lvl[l].size() * sizeof(P), &T.lvl[l]);
+        if (rc) return rc;
+        T.lvl_n[l] = static_cast<uint32_t>(tb.lvl[l].size());
+    }
+    T.top_off = static_cast<uint32_t>(top_all.size());
+    T.top_n = static_cast<uint32_t>(tb.lvl[nlvl].size());
+    top_all.insert(top_all.end(), tb.lvl[nlvl].begin(), tb.lvl[nlvl].end());
+    return RBG_OK;
+}
+
+template <typename P>
+int upload_tables_runs(rbg_index *ix) {
+    HostIndex &h = ix->host;
+    const uint64_t budget_keys = g_opt_tree_top_kb.load() ? static_cast<uint64_t>(g_opt_tree_top_kb.load()) * 1024 / sizeof(P) : 16;
+    std::vector<DevSym> syms(h.sym.size());
+    std::vector<DevTree> trees(h.sym.size());
+    std::vector<uint64_t> sizes;
+    for (const SymTable &t : h.sym) sizes.push_back(t.nruns);
+    const uint32_t nlvl = tree_levels_for(sizes, budget_keys);
+    if (nlvl > kMaxTreeLevels) return RBG_EARG;
+    std::vector<P> top_all;
+    int rc;
+    for (size_t s = 0; s < h.sym.size(); ++s) {
+        const SymTable &t = h.sym[s];
+        PreparedSym<P> prep;
+        prepare_sym<P>(t, h.has_tsa, prep);
+        DevSym &d = syms[s];
+        d = DevSym{};
+        if ((rc = dev_upload(ix, prep.ent.data(), prep.ent.size() * sizeof(RunEnt<P>), &d.ent))) return rc;
+        if (h.has_tsa && (rc = dev_upload(ix, prep.samp.data(), prep.samp.size() * sizeof(P), &d.samp))) return rc;
+        d.F = t.F;
+        d.shift = 0;
+        d.nruns = static_cast<uint32_t>(t.nruns);
+        if ((rc = upload_tree<P>(ix, d.ent, t.nruns, [&](uint64_t j) { return t.start[j]; }, nlvl, top_all, trees[s]))) return rc;
+    }
+    const void *p = nullptr;
+    if ((rc = dev_upload(ix, syms.data(), syms.size() * sizeof(DevSym), &p))) return rc;
+    ix->dev.syms = static_cast<const DevSym *>(p);
+    if ((rc = dev_upload(ix, trees.data(), trees.size() * sizeof(DevTree), &p))) return rc;
+    ix->dev.trees = static_cast<const DevTree *>(p);
+    if ((rc = dev_upload(ix, top_all.data(), top_all.size() * sizeof(P), &ix->dev.tree_top))) return rc;
+    ix->dev.tree_top_n = static_cast<uint32_t>(top_all.size());
+    ix->dev.tree_nlvl = nlvl;
+    ix->dev.layout = RBG_LAYOUT_RUNS;
+    ix->dev.kmer_steps = 1;
+    ix->dev.nmajor = 0;
+    if (h.nmajor >= 2) {  // the ftab's word index needs the major alphabet
+        if ((rc = dev_upload(ix, h.major_of, 256, &p))) return rc;
+        ix->dev.lut2 = static_cast<const uint8_t *>(p);
+        ix->dev.nmajor = h.nmajor;
+    }
+    if (h.has_tsa) {
+        std::vector<PhiEnt<P>> pe(h.r + 1);
+        for (uint64_t j = 0; j < h.r; ++j) {
+            pe[j].pos = static_cast<P>(h.pred_pos[j]);
+            pe[j].base = static_cast<P>(h.phi_base[j]);
+        }
+        pe[h.r].pos = static_cast<P>(h.n);  // sentinel: never below a query
+        pe[h.r].base = 0;
+        if ((rc = dev_upload(ix, pe.data(), pe.size() * sizeof(PhiEnt<P>), &ix->dev.phi_ent))) return rc;
+        const uint32_t pl = tree_levels_for({h.r}, budget_keys);
+        if (pl > kMaxTreeLevels) return RBG_EARG;
+        std::vector<P> ptop;
+        if ((rc = upload_tree<P>(ix, ix->dev.phi_ent, h.r, [&](uint64_t j) { return h.pred_pos[j]; }, pl, ptop, ix->dev.phi_tree))) return rc;
+        if ((rc = dev_upload(ix, ptop.data(), ptop.size() * sizeof(P), &ix->dev.phi_top))) return rc;
+        ix->dev.phi_nlvl = pl;
+        ix->dev.phi_slots = nullptr;
+        ix->dev.phi_ord = nullptr;
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    return RBG_OK;
+}
+
 int upload_markers(rbg_index *ix) {
     const RawMarkers &m = ix->host.ma;
     const void *p = nullptr;
@@ -376,6 +491,31 @@ int upload(rbg_index *ix) {
     const int64_t opt_mb = g_opt_hbm_budget_mb.load();
     const size_t budget = opt_mb > 0 ? static_cast<size_t>(opt_mb) << 20 : free_b - free_b / 4;
     auto need = [&] { return h.pos_bytes == 4 ? replica_bytes<uint32_t>(h) : replica_bytes<uint64_t>(h); };
+    // Layout: the slot tables cost n/16 bytes per table + n/2 (n at 8-byte positions) for phi, whatever r is.  When
+    // even the single-symbol level does not fit the budget -- or on request -- the run-indexed layout takes over
+    // (space proportional to r; wave-cooperative predecessor search, k_runs.hip).
+    bool runs_layout = g_opt_rank_layout.load() == RBG_LAYOUT_RUNS;
+    if (g_opt_rank_layout.load() == RBG_LAYOUT_AUTO) {
+        size_t lvl1 = 0;  // the single-symbol level alone
+        {
+            std::vector<SymTable> p2, p3, p4, p5;
+            p2.swap(h.pair); p3.swap(h.triple); p4.swap(h.quad); p5.swap(h.quint);
+            lvl1 = need();
+            p2.swap(h.pair); p3.swap(h.triple); p4.swap(h.quad); p5.swap(h.quint);
+        }
+        runs_layout = lvl1 > budget;
+    }
+    if (runs_layout && h.sigma > static_cast<uint32_t>(kLdsSyms)) {
+        std::fprintf(stderr, "rbg: %u distinct symbols: the run-indexed layout serves at most %d; keeping the slot tables\n", h.sigma, kLdsSyms);
+        runs_layout = false;
+    }
+    ix->runs_layout = runs_layout;
+    if (runs_layout) {
+        std::vector<SymTable>().swap(h.pair);
+        std::vector<SymTable>().swap(h.triple);
+        std::vector<SymTable>().swap(h.quad);
+        std::vector<SymTable>().swap(h.quint);
+    }
     auto levels = [&] { return !h.quint.empty() ? 5 : !h.quad.empty() ? 4 : !h.triple.empty() ? 3 : !h.pair.empty() ? 2 : 1; };
     ix->kmer_steps_requested = static_cast<uint64_t>(levels());
     ix->hbm_free_at_load = free_b;
@@ -389,17 +529,25 @@ int upload(rbg_index *ix) {
     if (std::getenv("RBG_VERBOSE") || static_cast<uint64_t>(levels()) != ix->kmer_steps_requested)
         std::fprintf(stderr, "rbg: device %d: %.1f GB free, replica budget %.1f GB: keeping %d of %llu symbol(s) per gather (%.1f GB)\n", ix->device,
                      free_b / 1e9, budget / 1e9, levels(), static_cast<unsigned long long>(ix->kmer_steps_requested), need() / 1e9);
-    ix->arena_bytes = need();
-    if (ix->arena_bytes > free_b) {
-        std::fprintf(stderr, "rbg: index needs %.1f GB of HBM, %.1f GB free\n", ix->arena_bytes / 1e9, free_b / 1e9);
-        return RBG_ENOMEM;
+    int rc;
+    d.layout = RBG_LAYOUT_SLOTS;
+    if (runs_layout) {
+        if (std::getenv("RBG_VERBOSE")) std::fprintf(stderr, "rbg: device %d: run-indexed layout (space proportional to r)\n", ix->device);
+        rc = h.pos_bytes == 4 ? upload_tables_runs<uint32_t>(ix) : upload_tables_runs<uint64_t>(ix);
+        if (rc) return rc;
+    } else {
+        ix->arena_bytes = need();
+        if (ix->arena_bytes > free_b) {
+            std::fprintf(stderr, "rbg: index needs %.1f GB of HBM, %.1f GB free\n", ix->arena_bytes / 1e9, free_b / 1e9);
+            return RBG_ENOMEM;
+        }
+        HIP_TRY(hipMalloc(&ix->arena, ix->arena_bytes));
+        ix->allocs.push_back(ix->arena);
+        ix->hbm_bytes += ix->arena_bytes;
+        ix->arena_used = 0;
+        rc = h.pos_bytes == 4 ? upload_tables<uint32_t>(ix) : upload_tables<uint64_t>(ix);
+        if (rc) return rc;
     }
-    HIP_TRY(hipMalloc(&ix->arena, ix->arena_bytes));
-    ix->allocs.push_back(ix->arena);
-    ix->hbm_bytes += ix->arena_bytes;
-    ix->arena_used = 0;
-    int rc = h.pos_bytes == 4 ? upload_tables<uint32_t>(ix) : upload_tables<uint64_t>(ix);
-    if (rc) return rc;
     const void *p = nullptr;
     if ((rc = dev_upload(ix, h.lut, 256, &p))) return rc;
     d.lut = static_cast<const uint8_t *>(p);
@@ -705,6 +853,12 @@ int rbg_set_default_option(int opt, int64_t value) {
         case RBG_OPT_PACKED_READS:
             if (value < 0 || value > 2) return RBG_EARG;
             g_opt_packed_reads = value; return RBG_OK;
+        case RBG_OPT_RANK_LAYOUT:
+            if (value != RBG_LAYOUT_AUTO && value != RBG_LAYOUT_SLOTS && value != RBG_LAYOUT_RUNS) return RBG_EARG;
+            g_opt_rank_layout = value; return RBG_OK;
+        case RBG_OPT_TREE_TOP_KB:
+            if (value < 0 || value > 96) return RBG_EARG;  // 0 = 16 keys in all: the deepest tree (tests)
+            g_opt_tree_top_kb = value; return RBG_OK;
         default: return RBG_EARG;
     }
     });
@@ -964,7 +1118,7 @@ int rbg_info(const rbg_index *ix, rbg_info_t *out) {
     out->kmer_steps_requested = ix->kmer_steps_requested ? ix->kmer_steps_requested : out->kmer_steps;
     out->hbm_free_at_load = ix->hbm_free_at_load;
     out->hbm_budget = ix->hbm_budget;
-    out->rank_layout = RBG_LAYOUT_SLOTS;
+    out->rank_layout = ix->runs_layout ? RBG_LAYOUT_RUNS : RBG_LAYOUT_SLOTS;
     out->replicas = ix->device == RBG_DEVICE_NONE ? 0 : 1;
     for (const SymTable &t : ix->host.pair) out->pair_runs += t.nruns;
     for (const SymTable &t : ix->host.triple) out->triple_runs += t.nruns;

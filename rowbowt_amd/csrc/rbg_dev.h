@@ -69,11 +69,30 @@ constexpr uint32_t kMaxSlotShift = 8;
 struct DevSym {        // 48 bytes: 344 of them (symbols + 2/3/4-mers) are staged in LDS per workgroup
     const void *ent;    // RunEnt<P>[nruns + 1] (sentinel: start = n, cum = total): overflow buckets
     const void *samp;   // P[nruns]: samples_last_ of each run (nullptr without toehold SA)
-    const void *slots;  // RankSlot[(n >> shift) + 2]
-    const uint32_t *ord;  // (n >> shift) + 2: # runs of the symbol starting before each bucket
+    const void *slots;  // RankSlot[(n >> shift) + 2]; nullptr in the run-indexed layout (the run list is searched)
+    const uint32_t *ord;  // (n >> shift) + 2: # runs of the symbol starting before each bucket; nullptr likewise
     uint64_t F;      // RowBowt::f_[byte] (k-mer: first row of its SA interval)
     uint32_t shift;
-    uint32_t pad;
+    uint32_t nruns;
+};
+
+// ---- run-indexed layout (RBG_LAYOUT_RUNS): space proportional to r, nothing proportional to n ------------------
+// rank(i, c) = predecessor search over the symbol's sorted run starts (the reference's own structure is O(r) too:
+// rle_string::rank, rle_string.hpp:131-161 over sparse_sd_vector, :110-163), phi(i) = predecessor search over the
+// sampled text positions (toehold_sa.hpp:56-72).  The sorted keys carry a 64-ary sampled index: lvl[0] = every
+// 64th key, lvl[1] = every 64th of those, ...; the coarsest level ("top") is staged in LDS by every workgroup.
+// A probe of one level is ONE coalesced wave-wide load of a 64-entry block (256 B of keys, 512 B of {key, value}
+// pairs at 4-byte positions) compared 64-wide with a ballot: the wave serves its lanes' queries one after the
+// other (k_find_range_runs / k_locate_fill_runs).  Every tree of an index has the same number of levels.
+constexpr int kTreeFan = 64;
+constexpr int kMaxTreeLevels = 4;
+constexpr uint32_t kTreeTopBytes = 48 * 1024;  // LDS budget for the staged top levels of all trees of a kernel
+struct DevTree {
+    const void *ent;                    // {key, value} pairs of P each (RunEnt<P> / PhiEnt<P>): m entries + 1 sentinel
+    const void *lvl[kMaxTreeLevels];    // lvl[i][j] = key (64^(i+1)) * j; P each; levels [0, nlvl) live in HBM
+    uint64_t m;
+    uint32_t lvl_n[kMaxTreeLevels];
+    uint32_t top_off, top_n;            // this tree's slice of DevIndex::tree_top (level nlvl, staged in LDS)
 };
 
 constexpr int kLdsSyms = 8;
@@ -120,6 +139,15 @@ struct DevIndex {
     uint32_t ftab_k;
     uint32_t pad3;
     const uint8_t *dense;   // dense tables of the overflow buckets of every narrow rank table (RankSlot); nullptr = none
+    // run-indexed layout (layout == 2): one tree per symbol (first kLdsSyms symbols) and one over the phi samples
+    uint32_t layout;        // 1 = slot tables (RBG_LAYOUT_SLOTS), 2 = run-indexed (RBG_LAYOUT_RUNS)
+    uint32_t tree_nlvl;     // HBM-resident sampled levels of every rank tree
+    const DevTree *trees;   // sigma entries
+    const void *tree_top;   // P keys: the top levels of all rank trees, back to back
+    uint32_t tree_top_n;
+    uint32_t phi_nlvl;
+    DevTree phi_tree;
+    const void *phi_top;    // P keys
 };
 
 // What the instrumented instantiations count (sums over the launch; include/rbg.h rbg_search_stats_t mirrors it).
@@ -152,6 +180,12 @@ struct LaunchCfg {
 // launchers (k_search.hip, k_locate.hip, k_markers.hip, k_build.hip).  All asynchronous on `stream`; return hipError_t as int.
 int launch_find_range(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
                       uint64_t *lo, uint64_t *hi, uint64_t *ssamp /*nullable*/, void *stream);
+// run-indexed layout (k_runs.hip)
+int launch_find_range_runs(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
+                           uint64_t *lo, uint64_t *hi, uint64_t *ssamp /*nullable*/, void *stream);
+int launch_locate_fill_runs(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t *lo, const uint64_t *hi, const uint64_t *k,
+                            uint64_t N, uint64_t max_hits, const uint64_t *loc_off, uint64_t *locs, const uint64_t *sub,
+                            const void *order, const uint64_t *skeys, void *stream);
 int launch_find_range_stats(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
                             uint64_t *lo, uint64_t *hi, uint64_t *ssamp /*nullable*/, unsigned long long *stats /*kStatSearchN*/,
                             void *stream);

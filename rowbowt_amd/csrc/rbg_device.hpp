@@ -154,6 +154,24 @@ __device__ __forceinline__ uint64_t rank_in_slot(const DevSym &S, const RankSlot
     return (static_cast<uint64_t>(sl.r0) | (static_cast<uint64_t>(w3 >> 16) << 32)) + add;
 }
 
+// Run-indexed layout, one lane on its own: binary search of the run list (the kernels that are not on the
+// rb_align path -- seeding, windowed markers, single LF steps -- answer their ranks this way there; K1/K2/K3 have
+// the wave-cooperative search of k_runs.hip).  aux->nbefore = # runs starting before i (pred_run needs no ord[]).
+template <typename P>
+__device__ __forceinline__ uint64_t rank_runs_lane(const DevSym &S, uint64_t i, RankAux *aux) {
+    const RunEnt<P> *__restrict__ ent = static_cast<const RunEnt<P> *>(S.ent);
+    const uint64_t a = search_runs<P>(ent, 0, S.nruns, i);
+    aux->ovf = false;
+    aux->dense = false;
+    aux->nbefore = static_cast<uint32_t>(a);
+    if (a == 0) { aux->inside = false; return 0; }
+    const RunEnt<P> e = ent[a - 1];
+    const uint64_t len = static_cast<uint64_t>(ent[a].cum) - static_cast<uint64_t>(e.cum);
+    const uint64_t d = i - static_cast<uint64_t>(e.start);
+    aux->inside = d <= len;
+    return static_cast<uint64_t>(e.cum) + (d < len ? d : len);
+}
+
 // both ranks of one LF step (rowbowt.hpp:79,83).  lo and hi+1 usually share a bucket late in the
 // search (the range has narrowed to a few dozen rows), so the step is ONE 4-word load.
 template <typename P>
@@ -161,6 +179,14 @@ __device__ __forceinline__ void rank_pair(const DevSym &S, const uint8_t *__rest
                                           uint64_t *c_before, uint64_t *c_upto, uint64_t *bh_out, RankAux *qaux,
                                           RankAux *paux_out = nullptr) {
     const RankSlot *__restrict__ slots = static_cast<const RankSlot *>(S.slots);
+    if (slots == nullptr) {  // run-indexed layout
+        RankAux pa;
+        *c_before = rank_runs_lane<P>(S, lo, &pa);
+        *c_upto = rank_runs_lane<P>(S, hi1, qaux);
+        *bh_out = 0;
+        if (paux_out) *paux_out = pa;
+        return;
+    }
     const uint64_t bl = lo >> S.shift, bh = hi1 >> S.shift;
     const RankSlot sl = load_slot(slots + bl);
     RankSlot sh = sl;
@@ -175,6 +201,7 @@ __device__ __forceinline__ void rank_pair(const DevSym &S, const uint8_t *__rest
 // ordinal of the last run of the symbol that starts before the position a RankAux describes
 template <typename P>
 __device__ __forceinline__ uint64_t pred_run(const DevSym &S, uint64_t b, bool ovf, uint32_t v) {
+    if (S.ord == nullptr) return static_cast<uint64_t>(v) - 1;  // run-indexed layout: v already counts from the first run
     return (ovf ? runs_before<P>(S, b, (b << S.shift) + v) : static_cast<uint64_t>(S.ord[b]) + v) - 1;
 }
 

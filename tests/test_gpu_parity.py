@@ -503,6 +503,12 @@ def test_tiny_indexes(body):
     for j, c in enumerate(alphabet):
         assert (int(nlo[j]), int(nhi[j])) == o.LF(0, len(text) - 1, c)
     rb.close()
+    rbr = _with_layout(capi.LAYOUT_RUNS, 0, lambda: ra.RowBowt.from_runs(heads, lens, ssa, esa, device=0))
+    lo, hi, k = rbr.find_range_w_toehold(seqs, off)
+    assert (lo == wlo).all() and (hi == whi).all() and (k == wk).all()
+    loc_off, locs = rbr.locs_at(lo, hi, k)
+    assert (loc_off == woff).all() and (locs == wlocs).all()
+    rbr.close()
     o.close()
 
 
@@ -1121,6 +1127,16 @@ def test_positions_beyond_32_bits():
     assert (lo == wlo).all() and (hi == whi).all() and (lo2 == wlo).all() and (hi2 == whi).all()
     loc_off, locs = rb.locs_at(wlo, whi, wk, max_hits=64)
     assert (loc_off == woff).all() and (locs == wlocs).all()
+    # the run-indexed layout at this size: 3 GB instead of 140, sampled index three levels deep with a 16-key top
+    for top_kb in (48, 0):
+        rbr = _with_layout(capi.LAYOUT_RUNS, top_kb, lambda: ra.RowBowt.from_runs(heads, lens, ssa, esa, device=0))
+        ir = rbr.info()
+        assert ir.rank_layout == capi.LAYOUT_RUNS and ir.pos_bytes == 8 and ir.hbm_bytes < 4e9
+        lo, hi, k = rbr.find_range_w_toehold(seqs, off)
+        assert (lo == wlo).all() and (hi == whi).all() and (k == wk).all()
+        loc_off, locs = rbr.locs_at(lo, hi, k, max_hits=64)
+        assert (loc_off == woff).all() and (locs == wlocs).all()
+        rbr.close()
     rows = rng.integers(0, n, size=4000).astype(np.uint64)
     width = rng.integers(0, 3000, size=4000).astype(np.uint64)
     his = np.minimum(rows + width, np.uint64(n - 1))
@@ -1130,6 +1146,102 @@ def test_positions_beyond_32_bits():
         assert (int(nlo[j]), int(nhi[j])) == o.LF(int(rows[j]), int(his[j]), int(cs[j]))
     rb.close()
     o.close()
+
+
+def _with_layout(layout, top_kb, build):
+    ra.set_default_option(capi.OPT_RANK_LAYOUT, layout)
+    ra.set_default_option(capi.OPT_TREE_TOP_KB, top_kb)
+    try:
+        return build()
+    finally:
+        ra.set_default_option(capi.OPT_RANK_LAYOUT, capi.LAYOUT_AUTO)
+        ra.set_default_option(capi.OPT_TREE_TOP_KB, 48)
+
+
+@pytest.mark.parametrize("pos_bytes,top_kb,fk", [(0, 48, -1), (8, 48, -1), (0, 0, -1), (8, 0, 3), (0, 1, 0)])
+def test_run_indexed_layout(synth, pos_bytes, top_kb, fk):
+    """RBG_LAYOUT_RUNS (k_runs.hip): space proportional to r, rank and phi as wave-cooperative predecessor searches
+    over the run lists (rle_string.hpp:131-161, toehold_sa.hpp:56-72) -- same answers as the slot tables, i.e. as
+    the oracle, on every read shape of test_synth_all_paths; top_kb = 0 forces the deepest sampled index."""
+    S = synth
+    ra.set_default_option(capi.OPT_POS_BYTES, pos_bytes)
+    ra.set_default_option(capi.OPT_FTAB_K, fk)
+    try:
+        rb = _with_layout(capi.LAYOUT_RUNS, top_kb, lambda: ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0))
+    finally:
+        ra.set_default_option(capi.OPT_POS_BYTES, 0)
+        ra.set_default_option(capi.OPT_FTAB_K, -1)
+    o = orc.Oracle.from_runs(S.heads, S.lens, S.ssa, S.esa)
+    info = rb.info()
+    assert info.rank_layout == capi.LAYOUT_RUNS and info.kmer_steps == 1 and info.pos_bytes == (pos_bytes or 4)
+    assert info.rank_slots == 0 and info.phi_slots == 0
+    reads = S.sample_reads(3000, 60, seed=5, sub_rate=0.15, ragged=True)
+    reads += [b"", b"A", b"N", b"ACGTN", b"NACGT", b"ACNGT", b"AC", b"ACG", b"acgt", bytes([1]), bytes([255]) * 3, bytes([0]),
+              S.text[:500].tobytes(), S.text[:501].tobytes(), b"A" + bytes([1]), bytes([1]) + b"A",
+              S.text[-30:].tobytes(), S.text[-31:-1].tobytes(), S.text[-2:].tobytes()]
+    seqs, off = ra.pack_reads(reads)
+    lo, hi, k = rb.find_range_w_toehold(seqs, off)
+    lo1, hi1 = rb.find_range(seqs, off)
+    wlo, whi, wk = o.find_range_w_toehold_batch(seqs, off)
+    assert (lo == wlo).all() and (hi == whi).all() and (k == wk).all()
+    assert (lo1 == wlo).all() and (hi1 == whi).all()
+    for max_hits in (MAXU, 1, 3, 0):
+        loc_off, locs = rb.locs_at(lo, hi, k, max_hits)
+        woff, wlocs = o.locs_at_batch(wlo, whi, wk, max_hits)
+        assert (loc_off == woff).all() and (locs == wlocs).all()
+    # batches that do not fill a wave, and a single read
+    for cnt in (1, 63, 65, 130):
+        s2, o2 = ra.pack_reads(reads[:cnt])
+        l2, h2, k2 = rb.find_range_w_toehold(s2, o2)
+        assert (l2 == wlo[:cnt]).all() and (h2 == whi[:cnt]).all() and (k2 == wk[:cnt]).all()
+    # the kernels that are not on the rb_align path answer their ranks lane by lane there
+    rng = np.random.default_rng(3)
+    rows = rng.integers(0, S.n, 500).astype(np.uint64)
+    his = np.minimum(rows + rng.integers(0, 50, 500).astype(np.uint64), np.uint64(S.n - 1))
+    cs = rng.choice(np.frombuffer(b"ACGT\x01N", dtype=np.uint8), 500)
+    nlo, nhi = rb.LF(rows, his, cs)
+    for j in range(500):
+        assert (int(nlo[j]), int(nhi[j])) == o.LF(int(rows[j]), int(his[j]), int(cs[j]))
+    ms, me, mo, mv = S.markers(wsize=10)
+    rb.set_markers(ms, me, mo, mv)
+    o.set_markers(ms, me, mo, mv)
+    _check_marker_seeds(rb, o, reads[:300], 10, 1000)
+    goff, glocs = rb.find_locs_greedy_seeding(*ra.pack_reads(reads[:200]), 10)
+    for i in range(200):
+        assert glocs[int(goff[i]):int(goff[i + 1])].tolist() == o.greedy_locate(reads[i], 10)[0]
+    rb.close()
+    o.close()
+
+
+def test_run_indexed_layout_goldens_and_budget_rule(small, simple_reads, error_reads, data_dir):
+    """the reference's fixture through the run-indexed layout (goldens rb_tests.cpp:47-58,115-120), and the
+    automatic choice: a budget below the single-symbol slot tables selects it by itself"""
+    _rb, o = small
+    rb = _with_layout(capi.LAYOUT_RUNS, 48, lambda: ra.load_rowbowt(os.path.join(data_dir, "small.fa"), ra.LoadRbwtFlag.SA | ra.LoadRbwtFlag.MA, device=0))
+    assert rb.info().rank_layout == capi.LAYOUT_RUNS
+    seqs, off = ra.pack_reads(simple_reads + error_reads)
+    lo, hi, k = rb.find_range_w_toehold(seqs, off)
+    wlo, whi, wk = o.find_range_w_toehold_batch(seqs, off)
+    assert (lo == wlo).all() and (hi == whi).all() and (k == wk).all()
+    assert (int(lo[0]), int(hi[0])) == (24279, 24280)              # rb_tests.cpp:115
+    loc_off, locs = rb.locs_at(lo, hi, k)
+    woff, wlocs = o.locs_at_batch(wlo, whi, wk)
+    assert (loc_off == woff).all() and (locs == wlocs).all()
+    assert locs[:2].tolist() == [20306, 286]                       # rb_tests.cpp:47-48
+    hbm_runs = rb.info().hbm_bytes
+    rb.close()
+    ra.set_default_option(capi.OPT_HBM_BUDGET_MB, 1)               # small.fa's slot tables need more than 1 MB
+    ra.set_default_option(capi.OPT_RANK_BUCKET_SHIFT, 0)
+    try:
+        rb2 = ra.load_rowbowt(os.path.join(data_dir, "small.fa"), ra.LoadRbwtFlag.SA, device=0)
+    finally:
+        ra.set_default_option(capi.OPT_HBM_BUDGET_MB, 0)
+        ra.set_default_option(capi.OPT_RANK_BUCKET_SHIFT, -1)
+    assert rb2.info().rank_layout == capi.LAYOUT_RUNS
+    l2, h2, k2 = rb2.find_range_w_toehold(seqs, off)
+    assert (l2 == wlo).all() and (h2 == whi).all() and (k2 == wk).all()
+    rb2.close()
+    assert hbm_runs < 2_000_000
 
 
 @pytest.mark.parametrize("fk", [0, -1, 1, 3, 7])
