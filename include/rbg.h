@@ -296,6 +296,26 @@ int rbg_markers_fill_dev(rbg_index *, const uint64_t *d_lo, const uint64_t *d_hi
 int rbg_counters(rbg_index *, uint64_t out[4]);
 int rbg_counters_reset(rbg_index *);
 
+/* ---- several GPUs (index replicated, read stream sharded, no data-path collective; the reference is
+ * single-device, its only parallel dispatcher is rb_markers' thread pool, rb_markers.cpp:318-535) --------------- */
+/* A further replica of `primary`'s device index on `device`: built once, copied peer to peer (hipMemcpyPeer over
+ * xGMI), its pointer-bearing records re-pointed.  The handle works with every query entry point above (host or
+ * *_dev), shares the host-side index with the primary and must be freed before it; markers / docs are attached
+ * to the primary BEFORE replicating. */
+int rbg_replicate(rbg_index *primary, int device, rbg_index **replica_out);
+/* contiguous block [begin, end) of `rank` out of `world` (sizes differ by at most one; concatenating the ranks'
+ * outputs restores the input order): read i of N goes to rank i * world / N */
+int rbg_shard_bounds(uint64_t n_items, int rank, int world, uint64_t *begin, uint64_t *end);
+/* find_range (ssamp == NULL) / find_range_w_toehold over G replicas: shard g of the batch runs on replicas[g],
+ * the G shards concurrently; outputs in input order. */
+int rbg_find_range_sharded(rbg_index *const *replicas, int G, const uint8_t *seqs, const uint64_t *off, uint64_t N,
+                           uint64_t *lo, uint64_t *hi, uint64_t *ssamp /* nullable */);
+/* The run's only collective: one RCCL all-reduce (sum) of the four counters of rbg_counters.  `nccl_comm` is the
+ * caller's ncclComm_t for this replica's device (one rank per GPU), `stream` a HIP stream or NULL. */
+int rbg_counters_allreduce(rbg_index *, void *nccl_comm, void *stream, uint64_t out[4]);
+/* the same for G replicas on G distinct devices held by one process (ncclCommInitAll + one grouped all-reduce) */
+int rbg_counters_allreduce_local(rbg_index *const *replicas, int G, uint64_t out[4]);
+
 /* ---- measurement: what a launch touched (SURVEY 8d "report mean executed steps"; the reference's only
  * instrumentation is the stderr timer line rb_align.cpp:192) ------------------------------------------ */
 /* The *_stats_dev calls run an INSTRUMENTED instantiation of the same kernel on the same arguments (same

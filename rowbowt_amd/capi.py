@@ -102,6 +102,11 @@ _PROTOS = [
     ("rbg_find_range_stats_dev", C.c_int, [VP, VP, VP, U64, VP, VP, VP, VP, VP]),
     ("rbg_locate_fill_stats_dev", C.c_int, [VP, VP, VP, VP, U64, U64, VP, VP, VP, VP, VP]),
     ("rbg_sample_reads_dev", C.c_int, [VP, U64, U64, U64, U64, U64, U64, U64, C.c_uint32, VP, VP, VP, VP]),
+    ("rbg_replicate", C.c_int, [VP, C.c_int, C.POINTER(VP)]),
+    ("rbg_shard_bounds", C.c_int, [U64, C.c_int, C.c_int, C.POINTER(U64), C.POINTER(U64)]),
+    ("rbg_find_range_sharded", C.c_int, [VP, C.c_int, VP, VP, U64, VP, VP, VP]),
+    ("rbg_counters_allreduce", C.c_int, [VP, VP, VP, VP]),
+    ("rbg_counters_allreduce_local", C.c_int, [VP, C.c_int, VP]),
     ("rbg_counters", C.c_int, [VP, VP]),
     ("rbg_counters_reset", C.c_int, [VP]),
     ("rbg_set_default_option", C.c_int, [C.c_int, C.c_int64]),
@@ -351,6 +356,39 @@ class RowBowt:
         out = np.zeros(4, np.uint64)
         _check(self.L.rbg_counters(self.h, _p(out)), "rbg_counters")
         return out
+
+    # ---- several GPUs in one process
+    def replicate(self, device):
+        """a further replica of the device index on `device` (peer copy); free it before this one"""
+        h = VP()
+        _check(self.L.rbg_replicate(self.h, device, C.byref(h)), "rbg_replicate")
+        r = RowBowt(h)
+        r._primary = self   # keeps the primary alive
+        return r
+
+
+def shard_bounds(n_items, rank, world):
+    b, e = U64(), U64()
+    _check(lib().rbg_shard_bounds(n_items, rank, world, C.byref(b), C.byref(e)), "rbg_shard_bounds")
+    return b.value, e.value
+
+
+def find_range_sharded(replicas, seqs, off, toehold=False):
+    """find_range / find_range_w_toehold with the batch sharded over the replicas (contiguous blocks, concurrently)"""
+    N = len(off) - 1
+    hs = (VP * len(replicas))(*[r.h for r in replicas])
+    lo, hi = np.zeros(N, np.uint64), np.zeros(N, np.uint64)
+    k = np.zeros(N, np.uint64) if toehold else None
+    _check(lib().rbg_find_range_sharded(hs, len(replicas), _p(seqs), _p(off), N, _p(lo), _p(hi), _p(k)), "rbg_find_range_sharded")
+    return (lo, hi, k) if toehold else (lo, hi)
+
+
+def counters_allreduce_local(replicas):
+    """one RCCL all-reduce of the four counters over replicas on distinct devices of this process"""
+    hs = (VP * len(replicas))(*[r.h for r in replicas])
+    out = np.zeros(4, np.uint64)
+    _check(lib().rbg_counters_allreduce_local(hs, len(replicas), _p(out)), "rbg_counters_allreduce_local")
+    return out
 
     def counters_reset(self):
         _check(self.L.rbg_counters_reset(self.h), "rbg_counters_reset")

@@ -36,6 +36,8 @@ struct RbAlignArgs {  // rb_align.cpp:17-24
     std::string inpre, fastq_fname, outpre;
     int sam = 0, markers = 0;
     int device = 0;
+    int gpus = 1;     // replicas: devices device .. device + gpus - 1; every batch is sharded over them
+    std::vector<int> devices;  // --devices a,b,...: the replicas' devices, in shard order (overrides --gpu/--gpus)
     uint64_t batch = 1u << 20;
     int threads = 8;  // output formatting workers
 };
@@ -47,6 +49,8 @@ void print_help() {  // rb_align.cpp:26-35
     fprintf(stderr, "    --markers/-m                     print markers\n");
     fprintf(stderr, "    --sam/-s                         print locations\n");
     fprintf(stderr, "    --gpu <n>                        HIP device ordinal (default 0)\n");
+    fprintf(stderr, "    --gpus <G>                       replicate the index on G devices (from --gpu on) and shard every batch over them\n");
+    fprintf(stderr, "    --devices <a,b,...>              the same with an explicit device list\n");
     fprintf(stderr, "    --batch <n>                      reads per GPU batch (default 1048576)\n");
     fprintf(stderr, "    --threads <n>                    output formatting threads (default 8)\n");
     fprintf(stderr, "    <input_prefix>                   index prefix\n");
@@ -59,6 +63,8 @@ RbAlignArgs parse_args(int argc, char **argv) {  // rb_align.cpp:37-84
                                            {"markers", no_argument, 0, 'm'},
                                            {"sam", no_argument, 0, 's'},
                                            {"gpu", required_argument, 0, 'g'},
+                                           {"gpus", required_argument, 0, 'G'},
+                                           {"devices", required_argument, 0, 'D'},
                                            {"batch", required_argument, 0, 'b'},
                                            {"threads", required_argument, 0, 't'},
                                            {0, 0, 0, 0}};
@@ -70,6 +76,14 @@ RbAlignArgs parse_args(int argc, char **argv) {  // rb_align.cpp:37-84
             case 's': args.sam = 1; break;
             case 'm': args.markers = 1; break;
             case 'g': args.device = atoi(optarg); break;
+            case 'G': args.gpus = atoi(optarg); break;
+            case 'D':
+                for (const char *p = optarg; *p;) {
+                    args.devices.push_back(atoi(p));
+                    while (*p && *p != ',') ++p;
+                    if (*p == ',') ++p;
+                }
+                break;
             case 'b': args.batch = strtoull(optarg, nullptr, 10); break;
             case 't': args.threads = atoi(optarg); break;
             default: print_help(); exit(1);
@@ -83,29 +97,47 @@ RbAlignArgs parse_args(int argc, char **argv) {  // rb_align.cpp:37-84
     args.fastq_fname = argv[optind++];
     if (args.outpre.empty()) args.outpre = args.inpre;
     if (args.batch == 0) args.batch = 1;
+    if (args.gpus < 1) args.gpus = 1;
+    if (args.devices.empty())
+        for (int g = 0; g < args.gpus; ++g) args.devices.push_back(args.device + g);
+    args.device = args.devices[0];
     return args;
 }
 
+// results of one shard of a batch: reads [begin, end) of the batch, answered by one replica
 struct BatchResult {
+    uint64_t begin = 0, end = 0;
     std::vector<uint64_t> lo, hi, k, loc_off, mk_off;
     uint64_t *locs = nullptr, *mk = nullptr;
+    BatchResult() = default;
+    BatchResult(const BatchResult &) = delete;
+    BatchResult &operator=(const BatchResult &) = delete;
     ~BatchResult() { rbg_free_buffer(locs); rbg_free_buffer(mk); }
 };
 
-// rb_get_range + locs_at + markers_at (rb_align.cpp:95-145) for a whole batch, through the C-ABI
-void query_batch(const rbwt::RowBowt<> &rb, const RbAlignArgs &args, const PackedBatch &b, BatchResult &r) {
-    const uint64_t N = b.size();
-    const uint8_t *seqs = reinterpret_cast<const uint8_t *>(b.seqs.data());
-    rbg_index *ix = rb.handle();
+// rb_get_range + locs_at + markers_at (rb_align.cpp:95-145) for reads [begin, end) of a batch on one replica
+void query_shard(rbg_index *ix, const RbAlignArgs &args, const PackedBatch &b, uint64_t begin, uint64_t end, BatchResult &r) {
+    r.begin = begin;
+    r.end = end;
+    const uint64_t N = end - begin;
+    if (N == 0) return;
+    const uint8_t *seqs = reinterpret_cast<const uint8_t *>(b.seqs.data()) + b.off[begin];
+    std::vector<uint64_t> off_local;
+    const uint64_t *off = b.off.data();
+    if (begin) {  // the shard's offsets, re-based
+        off_local.resize(N + 1);
+        for (uint64_t i = 0; i <= N; ++i) off_local[i] = b.off[begin + i] - b.off[begin];
+        off = off_local.data();
+    }
     r.lo.resize(N); r.hi.resize(N);
     if (args.sam) {  // rb_get_range(sa=true), rb_align.cpp:99-103
         r.k.resize(N);
-        rbwt::detail::check(rbg_find_range_w_toehold(ix, seqs, b.off.data(), N, r.lo.data(), r.hi.data(), r.k.data()), "rbg_find_range_w_toehold");
+        rbwt::detail::check(rbg_find_range_w_toehold(ix, seqs, off, N, r.lo.data(), r.hi.data(), r.k.data()), "rbg_find_range_w_toehold");
         r.loc_off.resize(N + 1);
         rbwt::detail::check(rbg_locs_at(ix, r.lo.data(), r.hi.data(), r.k.data(), N, static_cast<uint64_t>(-1), r.loc_off.data(), &r.locs),
                             "rbg_locs_at");  // rb_align.cpp:125
     } else {
-        rbwt::detail::check(rbg_find_range(ix, seqs, b.off.data(), N, r.lo.data(), r.hi.data()), "rbg_find_range");
+        rbwt::detail::check(rbg_find_range(ix, seqs, off, N, r.lo.data(), r.hi.data()), "rbg_find_range");
     }
     if (args.markers) {  // rb_align.cpp:138
         r.mk_off.resize(N + 1);
@@ -114,10 +146,11 @@ void query_batch(const rbwt::RowBowt<> &rb, const RbAlignArgs &args, const Packe
 }
 
 // the text of rb_report (rb_align.cpp:118-145) for reads [i0, i1)
-void format_range(const rbwt::RowBowt<> &rb, const RbAlignArgs &args, const PackedBatch &b, const BatchResult &r, size_t i0,
-                  size_t i1, std::string &out) {
-    for (size_t i = i0; i < i1; ++i) {
-        out.append(b.names, b.name_off[i], b.name_off[i + 1] - b.name_off[i]);
+void format_range(const rbwt::RowBowt<> &rb, const RbAlignArgs &args, const PackedBatch &b, const BatchResult &r, size_t g0,
+                  size_t g1, std::string &out) {
+    for (size_t gi = g0; gi < g1; ++gi) {   // gi: index in the batch; i: index in the shard's results
+        const size_t i = gi - r.begin;
+        out.append(b.names, b.name_off[gi], b.name_off[gi + 1] - b.name_off[gi]);
         out += " (";
         put_u64(out, r.lo[i]);
         out.push_back(',');
@@ -154,17 +187,42 @@ void format_range(const rbwt::RowBowt<> &rb, const RbAlignArgs &args, const Pack
     }
 }
 
-// query + format one batch; formatting is split over worker threads, pieces concatenated in order
-void report_batch(const rbwt::RowBowt<> &rb, const RbAlignArgs &args, const PackedBatch &b, std::vector<std::string> &pieces) {
-    BatchResult r;
-    query_batch(rb, args, b, r);
+// query + format one batch: the batch is sharded over the replicas (contiguous blocks), the shards are
+// queried concurrently, formatting is split over worker threads, pieces concatenated in read order
+void report_batch(const rbwt::RowBowt<> &rb, const std::vector<rbg_index *> &reps, const RbAlignArgs &args, const PackedBatch &b,
+                  std::vector<std::string> &pieces) {
     const size_t N = b.size();
+    const int G = static_cast<int>(reps.size());
+    std::vector<BatchResult> res(G);
+    {
+        std::vector<std::thread> th;
+        auto work = [&](int g) {
+            uint64_t s0 = 0, s1 = 0;
+            (void)rbg_shard_bounds(N, g, G, &s0, &s1);
+            query_shard(reps[g], args, b, s0, s1, res[g]);
+        };
+        for (int g = 1; g < G; ++g) th.emplace_back(work, g);
+        work(0);
+        for (auto &t : th) t.join();
+    }
     const size_t T = std::max<size_t>(1, std::min<size_t>({static_cast<size_t>(args.threads), (N + 4095) / 4096, size_t(64)}));
-    pieces.assign(T, std::string());
+    // piece (g, t): reads of shard g, t-th slice
+    pieces.assign(static_cast<size_t>(G) * T, std::string());
     std::vector<std::thread> workers;
-    for (size_t t = 1; t < T; ++t)
-        workers.emplace_back([&, t] { format_range(rb, args, b, r, N * t / T, N * (t + 1) / T, pieces[t]); });
-    format_range(rb, args, b, r, 0, N / T, pieces[0]);
+    for (int g = 0; g < G; ++g)
+        for (size_t t = 0; t < T; ++t) {
+            const size_t n = res[g].end - res[g].begin;
+            const size_t a = res[g].begin + n * t / T, z = res[g].begin + n * (t + 1) / T;
+            if (a == z) continue;
+            std::string *dst = &pieces[static_cast<size_t>(g) * T + t];
+            const BatchResult *r = &res[g];
+            if (g == 0 && t == 0) continue;  // done on this thread below
+            workers.emplace_back([&rb, &args, &b, r, a, z, dst] { format_range(rb, args, b, *r, a, z, *dst); });
+        }
+    {
+        const size_t n = res[0].end - res[0].begin;
+        format_range(rb, args, b, res[0], res[0].begin, res[0].begin + n / T, pieces[0]);
+    }
     for (auto &w : workers) w.join();
 }
 
@@ -183,6 +241,22 @@ int main(int argc, char **argv) {
         flag = flag | rbwt::LoadRbwtFlag::MA;
     }
     rbwt::RowBowt<> rb = rbwt::load_rowbowt<>(args.inpre, flag, args.device);
+    // --gpus G: the device index is built once and copied peer to peer to the other devices
+    std::vector<rbg_index *> reps{rb.handle()};
+    struct Replicas {
+        std::vector<rbg_index *> owned;
+        ~Replicas() { for (rbg_index *r : owned) rbg_free(r); }
+    } replicas;
+    for (size_t g = 1; g < args.devices.size(); ++g) {
+        rbg_index *r = nullptr;
+        const int rc = rbg_replicate(rb.handle(), args.devices[g], &r);
+        if (rc) {
+            fprintf(stderr, "rb_align: replica on device %d: %s\n", args.devices[g], rbg_strerror(rc));
+            exit(1);
+        }
+        replicas.owned.push_back(r);
+        reps.push_back(r);
+    }
     auto stop = std::chrono::high_resolution_clock::now();
     const std::chrono::duration<double> index_load_time = stop - start;
 
@@ -210,7 +284,7 @@ int main(int argc, char **argv) {
         std::future<int> parser;
         const bool more = err == 0;
         if (more) parser = std::async(std::launch::async, parse, std::ref(nxt));
-        report_batch(rb, args, cur, pieces);
+        report_batch(rb, reps, args, cur, pieces);
         if (writer.valid()) writer.get();
         writing.swap(pieces);
         writer = std::async(std::launch::async, [&writing] {

@@ -17,18 +17,35 @@
 #include <thread>
 #include <vector>
 
+#include <rccl/rccl.h>
+
 #include "../../include/rbg.h"
 #include "rbg_dev.h"
 #include "rbg_host.hpp"
 
 using namespace rbg;
 
+struct DevAlloc {
+    void *p;
+    size_t bytes;
+};
+// a device array of records that hold device pointers (DevSym / DevTree): what a peer copy has to re-point
+struct PtrTable {
+    const void *d_ptr;
+    size_t count, stride;
+    std::vector<size_t> ptr_offsets;
+};
+
 struct rbg_index {
     HostIndex host;
+    rbg_index *primary = nullptr;  // set in a replica handle (rbg_replicate): the host-side index lives in the primary
+    HostIndex &H() { return primary ? primary->host : host; }
+    const HostIndex &H() const { return primary ? primary->host : host; }
     int device = RBG_DEVICE_NONE;
     DevIndex dev{};
     LaunchCfg cfg;
-    std::vector<void *> allocs;  // every device allocation of the replica
+    std::vector<DevAlloc> allocs;  // every device allocation of the replica
+    std::vector<PtrTable> ptr_tables;
     uint64_t hbm_bytes = 0;
     void *arena = nullptr;       // one allocation holding every table of the replica
     size_t arena_bytes = 0, arena_used = 0;
@@ -107,7 +124,7 @@ int dev_reserve(rbg_index *ix, size_t bytes, void **dst) {
         ix->arena_used += alloc;
     } else {
         HIP_TRY(hipMalloc(&p, alloc));
-        ix->allocs.push_back(p);
+        ix->allocs.push_back({p, alloc});
         ix->hbm_bytes += alloc;
     }
     *dst = p;
@@ -179,11 +196,11 @@ int commit_sym(rbg_index *ix, const SymTable &t, bool with_samples, PreparedSym<
     if (rc) return rc;
     d.samp = nullptr;
     if (with_samples && (rc = dev_upload(ix, p.samp.data(), p.samp.size() * sizeof(P), &d.samp))) return rc;
-    const uint64_t nb = (ix->host.n >> t.shift) + 2;
+    const uint64_t nb = (ix->H().n >> t.shift) + 2;
     void *slots = nullptr, *ord = nullptr;
     if ((rc = dev_reserve(ix, nb * sizeof(RankSlot), &slots)) || (rc = dev_reserve(ix, nb * sizeof(uint32_t), &ord))) return rc;
     const bool dense = g_opt_dense_overflow.load() != 0;
-    if (launch_build_rank_slots(sizeof(P), d.ent, t.nruns, ix->host.n, t.shift, slots, static_cast<uint32_t *>(ord), d_overflow,
+    if (launch_build_rank_slots(sizeof(P), d.ent, t.nruns, ix->H().n, t.shift, slots, static_cast<uint32_t *>(ord), d_overflow,
                                 dense ? d_overflow + 2 : nullptr, nullptr))
         return RBG_ENODEV;
     d.slots = slots;
@@ -220,7 +237,7 @@ int upload_many(rbg_index *ix, const std::vector<SymTable> &tabs, bool with_samp
 
 template <typename P>
 int upload_tables(rbg_index *ix) {
-    HostIndex &h = ix->host;
+    HostIndex &h = ix->H();
     DevBuf d_ovf;  // [0] rank slots, [1] phi slots that overflow their inline entries; [2] dense-table space handed out (16-byte units)
     int rc = d_ovf.alloc(32);
     if (rc) return rc;
@@ -234,6 +251,7 @@ int upload_tables(rbg_index *ix) {
     rc = dev_upload(ix, syms.data(), syms.size() * sizeof(DevSym), &p);
     if (rc) return rc;
     ix->dev.syms = static_cast<const DevSym *>(p);
+    ix->ptr_tables.push_back({p, syms.size(), sizeof(DevSym), {offsetof(DevSym, ent), offsetof(DevSym, samp), offsetof(DevSym, slots), offsetof(DevSym, ord)}});
     ix->dev.nmajor = 0;
     ix->dev.kmer_steps = 1;
     if (!h.pair.empty()) {
@@ -244,6 +262,7 @@ int upload_tables(rbg_index *ix) {
             const void *pp = nullptr;
             r2 = dev_upload(ix, recs.data(), recs.size() * sizeof(DevSym), &pp);
             if (r2) return r2;
+            ix->ptr_tables.push_back({pp, recs.size(), sizeof(DevSym), {offsetof(DevSym, ent), offsetof(DevSym, samp), offsetof(DevSym, slots), offsetof(DevSym, ord)}});
             *dst = static_cast<const DevSym *>(pp);
             return RBG_OK;
         };
@@ -297,7 +316,7 @@ int upload_tables(rbg_index *ix) {
         void *pool = nullptr;
         const size_t bytes = static_cast<size_t>(counts[2]) * 16 + 64;
         if (hipMalloc(&pool, bytes) == hipSuccess) {
-            ix->allocs.push_back(pool);
+            ix->allocs.push_back({pool, bytes});
             ix->hbm_bytes += bytes;
             for (const DevSym &d : ix->dense_todo)
                 if (launch_fill_dense(sizeof(P), d.ent, h.n, d.shift, d.slots, d.ord, static_cast<uint8_t *>(pool), nullptr)) return RBG_ENODEV;
@@ -363,7 +382,7 @@ int upload_tree(rbg_index *ix, const void *d_ent, uint64_t m, KeyAt key_at, uint
 
 template <typename P>
 int upload_tables_runs(rbg_index *ix) {
-    HostIndex &h = ix->host;
+    HostIndex &h = ix->H();
     const uint64_t budget_keys = g_opt_tree_top_kb.load() ? static_cast<uint64_t>(g_opt_tree_top_kb.load()) * 1024 / sizeof(P) : 16;
     std::vector<DevSym> syms(h.sym.size());
     std::vector<DevTree> trees(h.sym.size());
@@ -389,8 +408,11 @@ int upload_tables_runs(rbg_index *ix) {
     const void *p = nullptr;
     if ((rc = dev_upload(ix, syms.data(), syms.size() * sizeof(DevSym), &p))) return rc;
     ix->dev.syms = static_cast<const DevSym *>(p);
+    ix->ptr_tables.push_back({p, syms.size(), sizeof(DevSym), {offsetof(DevSym, ent), offsetof(DevSym, samp), offsetof(DevSym, slots), offsetof(DevSym, ord)}});
     if ((rc = dev_upload(ix, trees.data(), trees.size() * sizeof(DevTree), &p))) return rc;
     ix->dev.trees = static_cast<const DevTree *>(p);
+    ix->ptr_tables.push_back({p, trees.size(), sizeof(DevTree),
+                              {offsetof(DevTree, ent), offsetof(DevTree, lvl), offsetof(DevTree, lvl) + 8, offsetof(DevTree, lvl) + 16, offsetof(DevTree, lvl) + 24}});
     if ((rc = dev_upload(ix, top_all.data(), top_all.size() * sizeof(P), &ix->dev.tree_top))) return rc;
     ix->dev.tree_top_n = static_cast<uint32_t>(top_all.size());
     ix->dev.tree_nlvl = nlvl;
@@ -425,7 +447,7 @@ int upload_tables_runs(rbg_index *ix) {
 }
 
 int upload_markers(rbg_index *ix) {
-    const RawMarkers &m = ix->host.ma;
+    const RawMarkers &m = ix->H().ma;
     const void *p = nullptr;
     int rc;
     if ((rc = dev_upload(ix, m.start.data(), m.start.size() * 8, &p))) return rc;
@@ -439,7 +461,7 @@ int upload_markers(rbg_index *ix) {
     ix->dev.mk_nruns = m.start.size();
     ix->dev.mk_bucket = nullptr;
     ix->dev.mk_shift = 0;
-    const uint64_t nruns = m.start.size(), n = ix->host.n;
+    const uint64_t nruns = m.start.size(), n = ix->H().n;
     if (nruns && nruns < 0xFFFFFFFFull) {
         // about two buckets per run: at_range's two predecessor searches (2 x log2(nruns) dependent
         // loads) become one table read and a scan over the runs of one bucket
@@ -474,7 +496,7 @@ int upload(rbg_index *ix) {
     }
     DeviceScope scope(ix->device);
     if (scope.rc) return scope.rc;
-    HostIndex &h = ix->host;
+    HostIndex &h = ix->H();
     DevIndex &d = ix->dev;
     d = DevIndex{};
     d.n = h.n;
@@ -542,7 +564,7 @@ int upload(rbg_index *ix) {
             return RBG_ENOMEM;
         }
         HIP_TRY(hipMalloc(&ix->arena, ix->arena_bytes));
-        ix->allocs.push_back(ix->arena);
+        ix->allocs.push_back({ix->arena, ix->arena_bytes});
         ix->hbm_bytes += ix->arena_bytes;
         ix->arena_used = 0;
         rc = h.pos_bytes == 4 ? upload_tables<uint32_t>(ix) : upload_tables<uint64_t>(ix);
@@ -579,7 +601,7 @@ int upload(rbg_index *ix) {
             const uint64_t W = static_cast<uint64_t>(words);
             void *tab = nullptr;
             HIP_TRY(hipMalloc(&tab, W * entry));
-            ix->allocs.push_back(tab);
+            ix->allocs.push_back({tab, static_cast<size_t>(W * entry)});
             ix->hbm_bytes += W * entry;
             if (launch_build_ftab(d, ix->cfg, static_cast<uint32_t>(fk), tab, nullptr)) return RBG_ENODEV;
             d.ftab = tab;
@@ -781,8 +803,8 @@ int index_from_bundle(FlatBundle &b, int device, rbg_index **out) {
     if (!ix) return RBG_ENOMEM;
     int rc = flatten(b.rle, b.has_tsa ? &b.tsa : nullptr, current_options(), ix->host);
     if (rc) { delete ix; return rc; }
-    if (b.has_ma) { ix->host.ma = std::move(b.ma); ix->host.has_ma = true; }
-    if (b.has_dl) { ix->host.dl = std::move(b.dl); ix->host.has_dl = true; }
+    if (b.has_ma) { ix->H().ma = std::move(b.ma); ix->H().has_ma = true; }
+    if (b.has_dl) { ix->H().dl = std::move(b.dl); ix->H().has_dl = true; }
     return finish(ix, device, out);
 }
 
@@ -801,6 +823,22 @@ int guarded(F &&f) noexcept {
     }
 }
 
+}  // namespace
+
+namespace {
+struct Reloc {
+    std::vector<DevAlloc> from, to;
+    const void *operator()(const void *p) const {
+        if (!p) return nullptr;
+        const char *c = static_cast<const char *>(p);
+        for (size_t i = 0; i < from.size(); ++i) {
+            const char *b = static_cast<const char *>(from[i].p);
+            if (c >= b && c < b + from[i].bytes) return static_cast<const char *>(to[i].p) + (c - b);
+        }
+        return nullptr;  // not a pointer into the replica
+    }
+    template <typename T> void fix(T *&p) const { p = static_cast<T *>(const_cast<void *>((*this)(p))); }
+};
 }  // namespace
 
 extern "C" {
@@ -1044,14 +1082,15 @@ int rbg_set_markers(rbg_index *ix, const uint64_t *run_start, const uint64_t *ru
     return guarded([&]() -> int {
     if (!ix || !run_start || !run_end || !mk_off || (!mk_vals && mk_off[nruns])) return RBG_EARG;
     if (!markers_valid(run_start, run_end, nruns, mk_off)) return RBG_EARG;
+    if (ix->primary) return RBG_EARG;    // attach to the primary, before rbg_replicate
     std::lock_guard<std::mutex> g(ix->mu);
-    if (ix->host.has_ma) return RBG_EARG;  // immutable once attached
-    RawMarkers &m = ix->host.ma;
+    if (ix->H().has_ma) return RBG_EARG;  // immutable once attached
+    RawMarkers &m = ix->H().ma;
     m.start.assign(run_start, run_start + nruns);
     m.end.assign(run_end, run_end + nruns);
     m.off.assign(mk_off, mk_off + nruns + 1);
     m.vals.assign(mk_vals, mk_vals + mk_off[nruns]);
-    ix->host.has_ma = true;
+    ix->H().has_ma = true;
     if (ix->device != RBG_DEVICE_NONE) {
         DeviceScope scope(ix->device);
         if (scope.rc) return scope.rc;
@@ -1063,9 +1102,9 @@ int rbg_set_markers(rbg_index *ix, const uint64_t *run_start, const uint64_t *ru
 
 int rbg_set_docs(rbg_index *ix, const char *names_joined, const uint64_t *starts, uint64_t ndocs) {
     return guarded([&]() -> int {
-    if (!ix || !names_joined || !starts) return RBG_EARG;
+    if (!ix || !names_joined || !starts || ix->primary) return RBG_EARG;
     std::lock_guard<std::mutex> g(ix->mu);
-    RawDocs &d = ix->host.dl;
+    RawDocs &d = ix->H().dl;
     d = RawDocs();
     const char *p = names_joined;
     for (uint64_t i = 0; i < ndocs; ++i) {
@@ -1075,7 +1114,7 @@ int rbg_set_docs(rbg_index *ix, const char *names_joined, const uint64_t *starts
     }
     d.sorted = d.starts;
     std::sort(d.sorted.begin(), d.sorted.end());
-    ix->host.has_dl = true;
+    ix->H().has_dl = true;
     return RBG_OK;
     });
 }
@@ -1084,7 +1123,7 @@ void rbg_free(rbg_index *ix) {
     if (!ix) return;
     if (ix->device != RBG_DEVICE_NONE && !ix->allocs.empty()) {
         DeviceScope scope(ix->device);
-        for (void *p : ix->allocs) (void)hipFree(p);
+        for (const DevAlloc &a : ix->allocs) (void)hipFree(a.p);
     }
     delete ix;
 }
@@ -1095,35 +1134,35 @@ int rbg_info(const rbg_index *ix, rbg_info_t *out) {
     return guarded([&]() -> int {
     if (!ix || !out) return RBG_EARG;
     std::memset(out, 0, sizeof(*out));
-    out->n = ix->host.n;
-    out->r = ix->host.r;
-    out->sigma = ix->host.sigma;
-    out->pos_bytes = ix->host.pos_bytes;
+    out->n = ix->H().n;
+    out->r = ix->H().r;
+    out->sigma = ix->H().sigma;
+    out->pos_bytes = ix->H().pos_bytes;
     out->device = ix->device;
-    out->has_tsa = ix->host.has_tsa;
-    out->has_markers = ix->host.has_ma;
-    out->has_docs = ix->host.has_dl;
+    out->has_tsa = ix->H().has_tsa;
+    out->has_markers = ix->H().has_ma;
+    out->has_docs = ix->H().has_dl;
     out->hbm_bytes = ix->hbm_bytes;
-    out->marker_runs = ix->host.ma.start.size();
-    out->marker_vals = ix->host.ma.vals.size();
-    out->rank_bucket_shift = ix->host.sym.empty() ? 0 : ix->host.sym.back().shift;
-    out->phi_bucket_shift = ix->host.phi_shift;
+    out->marker_runs = ix->H().ma.start.size();
+    out->marker_vals = ix->H().ma.vals.size();
+    out->rank_bucket_shift = ix->H().sym.empty() ? 0 : ix->H().sym.back().shift;
+    out->phi_bucket_shift = ix->H().phi_shift;
     out->rank_slots = ix->rank_slots;
     out->rank_slots_overflow = ix->rank_slots_overflow;
     out->phi_slots = ix->phi_slots;
     out->phi_slots_overflow = ix->phi_slots_overflow;
-    out->kmer_steps = !ix->host.quint.empty() ? 5 : !ix->host.quad.empty() ? 4 : !ix->host.triple.empty() ? 3 : !ix->host.pair.empty() ? 2 : 1;
-    out->kmer_symbols = ix->host.pair.empty() ? 0 : ix->host.nmajor;
+    out->kmer_steps = !ix->H().quint.empty() ? 5 : !ix->H().quad.empty() ? 4 : !ix->H().triple.empty() ? 3 : !ix->H().pair.empty() ? 2 : 1;
+    out->kmer_symbols = ix->H().pair.empty() ? 0 : ix->H().nmajor;
     out->ftab_k = ix->dev.ftab_k;
     out->kmer_steps_requested = ix->kmer_steps_requested ? ix->kmer_steps_requested : out->kmer_steps;
     out->hbm_free_at_load = ix->hbm_free_at_load;
     out->hbm_budget = ix->hbm_budget;
     out->rank_layout = ix->runs_layout ? RBG_LAYOUT_RUNS : RBG_LAYOUT_SLOTS;
     out->replicas = ix->device == RBG_DEVICE_NONE ? 0 : 1;
-    for (const SymTable &t : ix->host.pair) out->pair_runs += t.nruns;
-    for (const SymTable &t : ix->host.triple) out->triple_runs += t.nruns;
-    for (const SymTable &t : ix->host.quad) out->quad_runs += t.nruns;
-    for (const SymTable &t : ix->host.quint) out->quint_runs += t.nruns;
+    for (const SymTable &t : ix->H().pair) out->pair_runs += t.nruns;
+    for (const SymTable &t : ix->H().triple) out->triple_runs += t.nruns;
+    for (const SymTable &t : ix->H().quad) out->quad_runs += t.nruns;
+    for (const SymTable &t : ix->H().quint) out->quint_runs += t.nruns;
     return RBG_OK;
     });
 }
@@ -1131,7 +1170,7 @@ int rbg_info(const rbg_index *ix, rbg_info_t *out) {
 int rbg_get_f(const rbg_index *ix, uint64_t f_out[256]) {
     return guarded([&]() -> int {
     if (!ix || !f_out) return RBG_EARG;
-    std::memcpy(f_out, ix->host.f, 256 * sizeof(uint64_t));
+    std::memcpy(f_out, ix->H().f, 256 * sizeof(uint64_t));
     return RBG_OK;
     });
 }
@@ -1139,8 +1178,8 @@ int rbg_get_f(const rbg_index *ix, uint64_t f_out[256]) {
 int rbg_last_run_sample(const rbg_index *ix, uint64_t *out) {
     return guarded([&]() -> int {
     if (!ix || !out) return RBG_EARG;
-    if (!ix->host.has_tsa) return RBG_ENOTLOADED;
-    *out = ix->host.last_run_sample;
+    if (!ix->H().has_tsa) return RBG_ENOTLOADED;
+    *out = ix->H().last_run_sample;
     return RBG_OK;
     });
 }
@@ -1148,7 +1187,7 @@ int rbg_last_run_sample(const rbg_index *ix, uint64_t *out) {
 int rbg_host_array(const rbg_index *ix, int which, uint64_t *dst, uint64_t cap, uint64_t *count) {
     return guarded([&]() -> int {
     if (!ix || !count) return RBG_EARG;
-    const HostIndex &h = ix->host;
+    const HostIndex &h = ix->H();
     const std::vector<uint64_t> *v = nullptr;
     std::vector<uint64_t> tmp;
     switch (which) {
@@ -1172,8 +1211,8 @@ int rbg_host_array(const rbg_index *ix, int which, uint64_t *dst, uint64_t cap, 
 int rbg_resolve_offset(const rbg_index *ix, uint64_t i, const char **name, uint64_t *offset) {
     return guarded([&]() -> int {
     if (!ix || !name || !offset) return RBG_EARG;
-    if (!ix->host.has_dl || ix->host.dl.names.empty()) return RBG_ENOTLOADED;
-    const RawDocs &d = ix->host.dl;
+    if (!ix->H().has_dl || ix->H().dl.names.empty()) return RBG_ENOTLOADED;
+    const RawDocs &d = ix->H().dl;
     // DocList::doc_bounds_rank, doclist.hpp:77-79: rank(min(i+1, size)) over a bit-vector whose
     // size is the LAST start read + 1 (doclist.hpp:66)
     const uint64_t size = d.starts.back() + 1;
@@ -1202,7 +1241,7 @@ int rbg_find_range_w_toehold_dev(rbg_index *ix, const uint8_t *d_seqs, const uin
                                  uint64_t *d_lo, uint64_t *d_hi, uint64_t *d_ssamp, void *stream) {
     return guarded([&]() -> int {
     if (!queryable(ix)) return RBG_ENODEV;
-    if (!ix->host.has_tsa) return RBG_ENOTLOADED;
+    if (!ix->H().has_tsa) return RBG_ENOTLOADED;
     if (N && (!d_seqs || !d_off || !d_lo || !d_hi || !d_ssamp)) return RBG_EARG;
     if (reinterpret_cast<uintptr_t>(d_seqs) & 15) return RBG_EARG;
     return launch_find_range(ix->dev, ix->cfg, d_seqs, d_off, N, d_lo, d_hi, d_ssamp, stream) ? RBG_ENODEV : RBG_OK;
@@ -1216,7 +1255,7 @@ int rbg_find_range_stats_dev(rbg_index *ix, const uint8_t *d_seqs, const uint64_
                              uint64_t *d_hi, uint64_t *d_ssamp, uint64_t *d_stats, void *stream) {
     return guarded([&]() -> int {
     if (!queryable(ix)) return RBG_ENODEV;
-    if (d_ssamp && !ix->host.has_tsa) return RBG_ENOTLOADED;
+    if (d_ssamp && !ix->H().has_tsa) return RBG_ENOTLOADED;
     if (!d_stats || (N && (!d_seqs || !d_off || !d_lo || !d_hi))) return RBG_EARG;
     if (reinterpret_cast<uintptr_t>(d_seqs) & 15) return RBG_EARG;
     return launch_find_range_stats(ix->dev, ix->cfg, d_seqs, d_off, N, d_lo, d_hi, d_ssamp, reinterpret_cast<unsigned long long *>(d_stats), stream)
@@ -1229,7 +1268,7 @@ int rbg_locate_fill_stats_dev(rbg_index *ix, const uint64_t *d_lo, const uint64_
                               void *stream) {
     return guarded([&]() -> int {
     if (!queryable(ix)) return RBG_ENODEV;
-    if (!ix->host.has_tsa) return RBG_ENOTLOADED;
+    if (!ix->H().has_tsa) return RBG_ENOTLOADED;
     if (!d_stats || (N && (!d_lo || !d_hi || !d_k || !d_loc_off || !d_locs))) return RBG_EARG;
     return launch_locate_fill(ix->dev, ix->cfg, d_lo, d_hi, d_k, N, max_hits, d_loc_off, d_locs, nullptr, d_order, stream,
                               reinterpret_cast<unsigned long long *>(d_stats)) ? RBG_ENODEV : RBG_OK;
@@ -1282,7 +1321,7 @@ int rbg_find_range_w_toehold_packed_dev(rbg_index *ix, const void *d_ws, const u
     return guarded([&]() -> int {
     int rc = packed_args_ok(ix, d_ws, d_seqs, d_off, N, total_bytes);
     if (rc) return rc;
-    if (!ix->host.has_tsa) return RBG_ENOTLOADED;
+    if (!ix->H().has_tsa) return RBG_ENOTLOADED;
     if (N && (!d_lo || !d_hi || !d_ssamp)) return RBG_EARG;
     return launch_find_range_packed(ix->dev, ix->cfg, d_ws, d_seqs, d_off, N, total_bytes, d_lo, d_hi, d_ssamp, stream) ? RBG_ENODEV : RBG_OK;
     });
@@ -1294,7 +1333,7 @@ int rbg_locate_plan_dev(rbg_index *ix, const uint64_t *d_lo, const uint64_t *d_h
                         uint64_t *d_loc_off, void *d_tmp, size_t tmp_bytes, void *stream) {
     return guarded([&]() -> int {
     if (!queryable(ix)) return RBG_ENODEV;
-    if (!ix->host.has_tsa) return RBG_ENOTLOADED;
+    if (!ix->H().has_tsa) return RBG_ENOTLOADED;
     if (!d_loc_off || (N && (!d_lo || !d_hi || !d_tmp))) return RBG_EARG;
     return launch_locate_plan(ix->dev, ix->cfg, d_lo, d_hi, N, max_hits, d_loc_off, d_tmp, tmp_bytes, stream) ? RBG_ENODEV : RBG_OK;
     });
@@ -1305,7 +1344,7 @@ size_t rbg_locate_order_ws_bytes(uint64_t N) { return locate_order_ws_bytes(N); 
 int rbg_locate_order_dev(rbg_index *ix, const uint64_t *d_k, uint64_t N, void *d_ws, size_t ws_bytes, void *stream) {
     return guarded([&]() -> int {
     if (!queryable(ix)) return RBG_ENODEV;
-    if (!ix->host.has_tsa) return RBG_ENOTLOADED;
+    if (!ix->H().has_tsa) return RBG_ENOTLOADED;
     if (N && (!d_k || !d_ws)) return RBG_EARG;
     if (N >= 0xFFFFFFFFull || ws_bytes < locate_order_ws_bytes(N) || (reinterpret_cast<uintptr_t>(d_ws) & 255)) return RBG_EARG;
     return launch_locate_order(ix->dev, ix->cfg, d_k, N, d_ws, ws_bytes, stream) ? RBG_ENODEV : RBG_OK;
@@ -1316,7 +1355,7 @@ int rbg_locate_fill_dev(rbg_index *ix, const uint64_t *d_lo, const uint64_t *d_h
                         uint64_t max_hits, const uint64_t *d_loc_off, uint64_t *d_locs, const void *d_order, void *stream) {
     return guarded([&]() -> int {
     if (!queryable(ix)) return RBG_ENODEV;
-    if (!ix->host.has_tsa) return RBG_ENOTLOADED;
+    if (!ix->H().has_tsa) return RBG_ENOTLOADED;
     if (N && (!d_lo || !d_hi || !d_k || !d_loc_off || !d_locs)) return RBG_EARG;
     return launch_locate_fill(ix->dev, ix->cfg, d_lo, d_hi, d_k, N, max_hits, d_loc_off, d_locs, nullptr, d_order, stream) ? RBG_ENODEV : RBG_OK;
     });
@@ -1326,7 +1365,7 @@ int rbg_markers_plan_dev(rbg_index *ix, const uint64_t *d_lo, const uint64_t *d_
                          void *d_tmp, size_t tmp_bytes, void *stream) {
     return guarded([&]() -> int {
     if (!queryable(ix)) return RBG_ENODEV;
-    if (!ix->host.has_ma) return RBG_ENOTLOADED;
+    if (!ix->H().has_ma) return RBG_ENOTLOADED;
     if (!d_mk_off || (N && (!d_lo || !d_hi || !d_tmp))) return RBG_EARG;
     return launch_markers_plan(ix->dev, ix->cfg, d_lo, d_hi, N, d_mk_off, d_tmp, tmp_bytes, stream) ? RBG_ENODEV : RBG_OK;
     });
@@ -1336,7 +1375,7 @@ int rbg_markers_fill_dev(rbg_index *ix, const uint64_t *d_lo, const uint64_t *d_
                          const uint64_t *d_mk_off, uint64_t *d_mk, void *stream) {
     return guarded([&]() -> int {
     if (!queryable(ix)) return RBG_ENODEV;
-    if (!ix->host.has_ma) return RBG_ENOTLOADED;
+    if (!ix->H().has_ma) return RBG_ENOTLOADED;
     if (N && (!d_lo || !d_hi || !d_mk_off || !d_mk)) return RBG_EARG;
     return launch_markers_fill(ix->dev, ix->cfg, d_lo, d_hi, N, d_mk_off, d_mk, stream) ? RBG_ENODEV : RBG_OK;
     });
@@ -1428,7 +1467,7 @@ int rbg_count(rbg_index *ix, const uint8_t *seqs, const uint64_t *off, uint64_t 
 int rbg_find_range_w_toehold(rbg_index *ix, const uint8_t *seqs, const uint64_t *off, uint64_t N, uint64_t *lo,
                              uint64_t *hi, uint64_t *ssamp) {
     return guarded([&]() -> int {
-    if (ix && !ix->host.has_tsa) return RBG_ENOTLOADED;
+    if (ix && !ix->H().has_tsa) return RBG_ENOTLOADED;
     if (N && (!lo || !hi || !ssamp)) return RBG_EARG;
     return find_range_host(ix, seqs, off, N, lo, hi, ssamp, nullptr);
     });
@@ -1438,7 +1477,7 @@ int rbg_locs_at(rbg_index *ix, const uint64_t *lo, const uint64_t *hi, const uin
                 uint64_t max_hits, uint64_t *loc_off, uint64_t **locs) {
     return guarded([&]() -> int {
     if (!queryable(ix)) return RBG_ENODEV;
-    if (!ix->host.has_tsa) return RBG_ENOTLOADED;
+    if (!ix->H().has_tsa) return RBG_ENOTLOADED;
     if (!loc_off || !locs || (N && (!lo || !hi || !k))) return RBG_EARG;
     *locs = nullptr;
     DeviceScope scope(ix->device);
@@ -1470,7 +1509,7 @@ int rbg_locs_at(rbg_index *ix, const uint64_t *lo, const uint64_t *hi, const uin
 int rbg_markers_at(rbg_index *ix, const uint64_t *lo, const uint64_t *hi, uint64_t N, uint64_t *mk_off, uint64_t **mk) {
     return guarded([&]() -> int {
     if (!queryable(ix)) return RBG_ENODEV;
-    if (!ix->host.has_ma) return RBG_ENOTLOADED;
+    if (!ix->H().has_ma) return RBG_ENOTLOADED;
     if (!mk_off || !mk || (N && (!lo || !hi))) return RBG_EARG;
     *mk = nullptr;
     DeviceScope scope(ix->device);
@@ -1498,7 +1537,7 @@ int rbg_find_range_w_markers(rbg_index *ix, const uint8_t *seqs, const uint64_t 
                              uint64_t max_range, uint64_t *lo, uint64_t *hi, uint64_t *mk_off, uint64_t **mk) {
     return guarded([&]() -> int {
     if (!queryable(ix)) return RBG_ENODEV;
-    if (!ix->host.has_ma) return RBG_ENOTLOADED;  // reference: "warning: no marker array found!", default LFData
+    if (!ix->H().has_ma) return RBG_ENOTLOADED;  // reference: "warning: no marker array found!", default LFData
     if (!mk_off || !mk || wsize == 0 || (N && (!lo || !hi || !off))) return RBG_EARG;
     *mk = nullptr;
     int rc = check_offsets(off, N);
@@ -1608,7 +1647,7 @@ int rbg_greedy_longest_seed_dev(rbg_index *ix, const uint8_t *d_seqs, const uint
                                 void *stream) {
     return guarded([&]() -> int {
     if (!queryable(ix)) return RBG_ENODEV;
-    if (!ix->host.has_tsa) return RBG_ENOTLOADED;
+    if (!ix->H().has_tsa) return RBG_ENOTLOADED;
     if (N && (!d_seqs || !d_off || !d_lo || !d_hi || !d_qstart || !d_qend || !d_ssamp)) return RBG_EARG;
     if (reinterpret_cast<uintptr_t>(d_seqs) & 15) return RBG_EARG;
     return launch_greedy_seed(ix->dev, ix->cfg, d_seqs, d_off, N, min_length, d_lo, d_hi, d_qstart, d_qend, d_ssamp, stream)
@@ -1621,7 +1660,7 @@ int rbg_locate_fill_offset_dev(rbg_index *ix, const uint64_t *d_lo, const uint64
                                const void *d_order, void *stream) {
     return guarded([&]() -> int {
     if (!queryable(ix)) return RBG_ENODEV;
-    if (!ix->host.has_tsa) return RBG_ENOTLOADED;
+    if (!ix->H().has_tsa) return RBG_ENOTLOADED;
     if (N && (!d_lo || !d_hi || !d_k || !d_loc_off || !d_locs)) return RBG_EARG;
     return launch_locate_fill(ix->dev, ix->cfg, d_lo, d_hi, d_k, N, max_hits, d_loc_off, d_locs, d_sub, d_order, stream) ? RBG_ENODEV : RBG_OK;
     });
@@ -1631,7 +1670,7 @@ static int greedy_host(rbg_index *ix, const uint8_t *seqs, const uint64_t *off, 
                        uint64_t *lo, uint64_t *hi, uint64_t *qs, uint64_t *qe, uint64_t *ss, bool locate, uint64_t max_hits,
                        uint64_t *loc_off, uint64_t **locs) {
     if (!queryable(ix)) return RBG_ENODEV;
-    if (!ix->host.has_tsa) return RBG_ENOTLOADED;
+    if (!ix->H().has_tsa) return RBG_ENOTLOADED;
     if (N && !off) return RBG_EARG;
     int rc = check_offsets(off, N);
     if (rc) return rc;
@@ -1683,6 +1722,132 @@ int rbg_find_locs_greedy_seeding(rbg_index *ix, const uint8_t *seqs, const uint6
     });
 }
 
+// ---- more than one GPU in one process (index replicated, reads sharded, no data-path collective) ----
+// The replica is built ONCE (load / build on the primary's device) and copied to the other devices peer to peer
+// (xGMI); records that hold device pointers (DevSym / DevTree arrays, DevIndex) are re-pointed into the copy.
+
+
+int rbg_replicate(rbg_index *src, int device, rbg_index **out) {
+    return guarded([&]() -> int {
+    if (!src || !out) return RBG_EARG;
+    *out = nullptr;
+    if (!queryable(src)) return RBG_ENODEV;
+    if (src->primary) return RBG_EARG;  // replicate the primary, not a replica
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return RBG_ENODEV;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return RBG_ENODEV;
+    {
+        DeviceScope s0(src->device);
+        if (s0.rc) return s0.rc;
+        HIP_TRY(hipDeviceSynchronize());
+    }
+    rbg_index *r = new (std::nothrow) rbg_index();
+    if (!r) return RBG_ENOMEM;
+    r->primary = src;
+    r->device = device;
+    r->cfg = src->cfg;
+    r->cfg.max_blocks = prop.multiProcessorCount * 32;
+    r->runs_layout = src->runs_layout;
+    r->rank_slots = src->rank_slots; r->rank_slots_overflow = src->rank_slots_overflow;
+    r->phi_slots = src->phi_slots; r->phi_slots_overflow = src->phi_slots_overflow;
+    r->kmer_steps_requested = src->kmer_steps_requested;
+    DeviceScope scope(device);
+    if (scope.rc) { delete r; return scope.rc; }
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { delete r; return RBG_ENODEV; }
+    r->hbm_free_at_load = free_b;
+    r->hbm_budget = src->hbm_budget;
+    if (device != src->device) {
+        int can = 0;
+        (void)hipDeviceCanAccessPeer(&can, device, src->device);
+        if (can) (void)hipDeviceEnablePeerAccess(src->device, 0);  // already enabled is fine
+        (void)hipGetLastError();
+    }
+    Reloc reloc;
+    for (const DevAlloc &a : src->allocs) {
+        void *p = nullptr;
+        hipError_t e = hipMalloc(&p, a.bytes);
+        if (e == hipSuccess) {
+            r->allocs.push_back({p, a.bytes});
+            r->hbm_bytes += a.bytes;
+            e = hipMemcpyPeer(p, device, a.p, src->device, a.bytes);
+        }
+        if (e != hipSuccess) {
+            std::fprintf(stderr, "rbg: replicating %.1f GB to device %d failed: %s\n", src->hbm_bytes / 1e9, device, hipGetErrorString(e));
+            rbg_free(r);
+            return e == hipErrorOutOfMemory ? RBG_ENOMEM : RBG_ENODEV;
+        }
+        reloc.from.push_back(a);
+        reloc.to.push_back({p, a.bytes});
+    }
+    // records with device pointers inside: fetch from the copy, re-point, write back
+    for (const PtrTable &t : src->ptr_tables) {
+        std::vector<char> buf(t.count * t.stride);
+        void *dst = const_cast<void *>(reloc(t.d_ptr));
+        if (!dst) { rbg_free(r); return RBG_ENODEV; }
+        if (hipMemcpy(buf.data(), dst, buf.size(), hipMemcpyDeviceToHost) != hipSuccess) { rbg_free(r); return RBG_ENODEV; }
+        for (size_t i = 0; i < t.count; ++i)
+            for (size_t o : t.ptr_offsets) {
+                const void *old;
+                std::memcpy(&old, buf.data() + i * t.stride + o, sizeof(old));
+                const void *nw = reloc(old);
+                std::memcpy(buf.data() + i * t.stride + o, &nw, sizeof(nw));
+            }
+        if (hipMemcpy(dst, buf.data(), buf.size(), hipMemcpyHostToDevice) != hipSuccess) { rbg_free(r); return RBG_ENODEV; }
+        r->ptr_tables.push_back({dst, t.count, t.stride, t.ptr_offsets});
+    }
+    DevIndex d = src->dev;
+    reloc.fix(d.syms); reloc.fix(d.phi_ent); reloc.fix(d.phi_slots); reloc.fix(d.phi_ord);
+    reloc.fix(d.mk_start); reloc.fix(d.mk_end); reloc.fix(d.mk_off); reloc.fix(d.mk_vals); reloc.fix(d.mk_bucket);
+    reloc.fix(d.counters); reloc.fix(d.lut); reloc.fix(d.pairs); reloc.fix(d.triples); reloc.fix(d.quads); reloc.fix(d.quints);
+    reloc.fix(d.lut2); reloc.fix(d.ftab); reloc.fix(d.dense); reloc.fix(d.trees); reloc.fix(d.tree_top); reloc.fix(d.phi_top);
+    reloc.fix(d.phi_tree.ent);
+    for (int l = 0; l < kMaxTreeLevels; ++l) reloc.fix(d.phi_tree.lvl[l]);
+    r->dev = d;
+    if (hipMemset(d.counters, 0, 4 * sizeof(uint64_t)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { rbg_free(r); return RBG_ENODEV; }
+    *out = r;
+    return RBG_OK;
+    });
+}
+
+int rbg_shard_bounds(uint64_t n_items, int rank, int world, uint64_t *begin, uint64_t *end) {
+    if (world <= 0 || rank < 0 || rank >= world || !begin || !end) return RBG_EARG;
+    *begin = static_cast<uint64_t>((static_cast<unsigned __int128>(n_items) * static_cast<unsigned>(rank)) / static_cast<unsigned>(world));
+    *end = static_cast<uint64_t>((static_cast<unsigned __int128>(n_items) * (static_cast<unsigned>(rank) + 1u)) / static_cast<unsigned>(world));
+    return RBG_OK;
+}
+
+int rbg_find_range_sharded(rbg_index *const *replicas, int G, const uint8_t *seqs, const uint64_t *off, uint64_t N, uint64_t *lo,
+                           uint64_t *hi, uint64_t *ssamp) {
+    return guarded([&]() -> int {
+    if (!replicas || G <= 0) return RBG_EARG;
+    for (int g = 0; g < G; ++g)
+        if (!queryable(replicas[g])) return RBG_ENODEV;
+    if (N == 0) return RBG_OK;
+    if (!off || !lo || !hi || (!seqs && off[N])) return RBG_EARG;
+    int rc0 = check_offsets(off, N);
+    if (rc0) return rc0;
+    std::vector<int> rcs(G, RBG_OK);
+    auto work = [&](int g) {
+        uint64_t b, e;
+        (void)rbg_shard_bounds(N, g, G, &b, &e);
+        if (e == b) return;
+        std::vector<uint64_t> o(e - b + 1);  // the shard's offsets, re-based
+        for (uint64_t i = b; i <= e; ++i) o[i - b] = off[i] - off[b];
+        rcs[g] = find_range_host(replicas[g], seqs + off[b], o.data(), e - b, lo + b, hi + b, ssamp ? ssamp + b : nullptr, nullptr);
+    };
+    std::vector<std::thread> th;
+    for (int g = 1; g < G; ++g) th.emplace_back(work, g);
+    work(0);
+    for (auto &t : th) t.join();
+    for (int rc : rcs)
+        if (rc) return rc;
+    return RBG_OK;
+    });
+}
+
 // ---- counters --------------------------------------------------------------------------------------
 
 int rbg_counters(rbg_index *ix, uint64_t out[4]) {
@@ -1705,6 +1870,65 @@ int rbg_counters_reset(rbg_index *ix) {
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemset(ix->dev.counters, 0, 4 * sizeof(uint64_t)));
     return RBG_OK;
+    });
+}
+
+// One RCCL all-reduce (sum) of the four 64-bit counters over the communicator's ranks: the run's only collective
+// (the reference has none).  `nccl_comm` is the caller's ncclComm_t for this replica's device.
+int rbg_counters_allreduce(rbg_index *ix, void *nccl_comm, void *stream, uint64_t out[4]) {
+    return guarded([&]() -> int {
+    if (!queryable(ix)) return RBG_ENODEV;
+    if (!nccl_comm || !out) return RBG_EARG;
+    DeviceScope scope(ix->device);
+    if (scope.rc) return scope.rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    DevBuf sum;
+    int rc = sum.alloc(4 * sizeof(uint64_t));
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());  // every query launched so far has added its counts
+    if (ncclAllReduce(ix->dev.counters, sum.p, 4, ncclUint64, ncclSum, static_cast<ncclComm_t>(nccl_comm), st) != ncclSuccess) return RBG_ENODEV;
+    HIP_TRY(hipMemcpyAsync(out, sum.p, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return RBG_OK;
+    });
+}
+
+// The same for G replicas held by ONE process: a communicator clique over their devices (ncclCommInitAll), one
+// grouped all-reduce, every replica ends with the same sums.  Needs G distinct devices.
+int rbg_counters_allreduce_local(rbg_index *const *replicas, int G, uint64_t out[4]) {
+    return guarded([&]() -> int {
+    if (!replicas || G <= 0 || !out) return RBG_EARG;
+    std::vector<int> devs(G);
+    for (int g = 0; g < G; ++g) {
+        if (!queryable(replicas[g])) return RBG_ENODEV;
+        devs[g] = replicas[g]->device;
+        for (int h = 0; h < g; ++h)
+            if (devs[h] == devs[g]) return RBG_EARG;
+    }
+    std::vector<ncclComm_t> comms(G);
+    if (ncclCommInitAll(comms.data(), G, devs.data()) != ncclSuccess) return RBG_ENODEV;
+    std::vector<void *> sums(G, nullptr);
+    int rc = RBG_OK;
+    for (int g = 0; g < G && !rc; ++g) {
+        DeviceScope scope(devs[g]);
+        if (hipDeviceSynchronize() != hipSuccess || hipMalloc(&sums[g], 32) != hipSuccess) rc = RBG_ENODEV;
+    }
+    if (!rc) {
+        (void)ncclGroupStart();
+        for (int g = 0; g < G; ++g) {
+            DeviceScope scope(devs[g]);
+            if (ncclAllReduce(replicas[g]->dev.counters, sums[g], 4, ncclUint64, ncclSum, comms[g], nullptr) != ncclSuccess) rc = RBG_ENODEV;
+        }
+        if (ncclGroupEnd() != ncclSuccess) rc = RBG_ENODEV;
+    }
+    for (int g = 0; g < G; ++g) {
+        DeviceScope scope(devs[g]);
+        if (!rc && hipDeviceSynchronize() != hipSuccess) rc = RBG_ENODEV;
+        if (!rc && g == 0 && hipMemcpy(out, sums[0], 32, hipMemcpyDeviceToHost) != hipSuccess) rc = RBG_ENODEV;
+        if (sums[g]) (void)hipFree(sums[g]);
+        (void)ncclCommDestroy(comms[g]);
+    }
+    return rc;
     });
 }
 

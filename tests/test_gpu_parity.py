@@ -8,6 +8,7 @@ import pytest
 import golden_values as G
 import orc
 import rowbowt_amd as ra
+from rowbowt_amd.shard import shard_bounds
 from rowbowt_amd import capi
 from synth import SynthIndex
 
@@ -634,6 +635,18 @@ def test_cli_locs_and_markers_stdout(data_dir, tmp_path, small, simple_reads):
     # batching is invisible: one read per GPU batch gives the same bytes
     rc, out1, _ = _run_cli(["-s", "-m", "--batch", "1", str(tmp_path / "idx"), str(fq)])
     assert rc == 0 and out1 == want
+    # replicas are invisible too: every batch sharded over three replicas (on this box's one GPU the same device
+    # three times; `--gpus G` puts them on G devices), with batches smaller than, equal to and larger than the shards
+    for extra in (["--devices", "0,0,0"], ["--devices", "0,0", "--batch", "3"], ["--gpus", "1", "--batch", "2"]):
+        rc, outg, err = _run_cli(["-s", "-m"] + extra + [str(tmp_path / "idx"), str(fq)])
+        assert rc == 0 and outg == want, err
+    # a truncated record ends the run like kseq's -2 without being reported; the reads before it are
+    # (rb_align.cpp:176-185: the loop stops at the failing kseq_read)
+    part = tmp_path / "part.fq"
+    part.write_text("".join(f"@read{i}\n{q.decode()}\n+\n{'~' * len(q)}\n" for i, q in enumerate(simple_reads[:3])) + "@bad\nACGT\n+\n~~\n")
+    rc, outp, err = _run_cli([str(tmp_path / "idx"), str(part)])
+    assert rc == 1 and "truncated quality string" in err
+    assert outp.count("\n") == 3 and "bad" not in outp and outp.startswith("read0 ")
     # missing index -> "bad file", exit(1) (rowbowt_io.hpp:166-169)
     rc, _, err = _run_cli([str(tmp_path / "nope"), str(fq)])
     assert rc == 1 and "bad file" in err
@@ -1242,6 +1255,68 @@ def test_run_indexed_layout_goldens_and_budget_rule(small, simple_reads, error_r
     assert (l2 == wlo).all() and (h2 == whi).all() and (k2 == wk).all()
     rb2.close()
     assert hbm_runs < 2_000_000
+
+
+@pytest.mark.parametrize("layout", [capi.LAYOUT_AUTO, capi.LAYOUT_RUNS])
+def test_replicas_sharded_queries_and_rccl_counters(synth, layout):
+    """More than one replica in one process (include/rbg.h "several GPUs"): rbg_replicate copies the device index
+    peer to peer and re-points it -- onto the SAME device here when the box has one GPU, which exercises every
+    relocation -- rbg_find_range_sharded splits a batch by rbg_shard_bounds, and the counters are reduced by
+    RCCL (a one-rank clique on a single GPU; one rank per device when there are more)."""
+    import torch
+    S = synth
+    rb = _with_layout(layout, 48, lambda: ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0))
+    ms, me, mo, mv = S.markers(wsize=10)
+    rb.set_markers(ms, me, mo, mv)
+    o = orc.Oracle.from_runs(S.heads, S.lens, S.ssa, S.esa)
+    o.set_markers(ms, me, mo, mv)
+    ndev = torch.cuda.device_count()
+    rep = rb.replicate(1 if ndev > 1 else 0)
+    assert rep.info().hbm_bytes == rb.info().hbm_bytes and rep.info().rank_layout == rb.info().rank_layout
+    with pytest.raises(ra.RbgError):
+        rep.replicate(0)                       # replicas are made from the primary
+    with pytest.raises(ra.RbgError):
+        rep.set_markers(ms, me, mo, mv)        # ... and everything is attached before replicating
+    reads = S.sample_reads(2001, 70, seed=77, sub_rate=0.2, ragged=True) + [b"", b"ACGTN"]
+    seqs, off = ra.pack_reads(reads)
+    wlo, whi, wk = o.find_range_w_toehold_batch(seqs, off)
+    woff, wlocs = o.locs_at_batch(wlo, whi, wk)
+    # the replica answers everything the primary does
+    lo, hi, k = rep.find_range_w_toehold(seqs, off)
+    assert (lo == wlo).all() and (hi == whi).all() and (k == wk).all()
+    loc_off, locs = rep.locs_at(lo, hi, k)
+    assert (loc_off == woff).all() and (locs == wlocs).all()
+    mk_off, mk = rep.markers_at(lo, hi)
+    got = split(mk_off, mk)
+    for i in range(0, len(reads), 11):
+        assert got[i] == o.markers_at(int(lo[i]), int(hi[i]))
+    _check_marker_seeds(rep, o, reads[:200], 10, 1000)
+    # sharded over both replicas (and over one: the degenerate G = 1 path)
+    for reps in ([rb, rep], [rb], [rep, rb, rep]):
+        rb.counters_reset(); rep.counters_reset()
+        lo2, hi2, k2 = capi.find_range_sharded(reps, seqs, off, toehold=True)
+        assert (lo2 == wlo).all() and (hi2 == whi).all() and (k2 == wk).all()
+        lo3, hi3 = capi.find_range_sharded(reps, seqs, off)
+        assert (lo3 == wlo).all() and (hi3 == whi).all()
+        tot = rb.counters().astype(np.int64) + rep.counters().astype(np.int64)
+        assert tot[0] == 2 * len(reads) and tot[1] == 2 * int((whi >= wlo).sum())
+    for g, G in ((0, 1), (0, 3), (2, 3), (6, 7)):
+        assert capi.shard_bounds(len(reads), g, G) == shard_bounds(len(reads), g, G)
+    # RCCL: one clique per process over distinct devices
+    rb.counters_reset(); rep.counters_reset()
+    rb.find_range(seqs, off)
+    want0 = rb.counters()
+    if ndev > 1:
+        rep.find_range(seqs, off)
+        red = capi.counters_allreduce_local([rb, rep])
+        assert (red == 2 * want0).all()
+    red1 = capi.counters_allreduce_local([rb])
+    assert (red1 == want0).all() and int(red1[0]) == len(reads)
+    with pytest.raises(ra.RbgError):
+        capi.counters_allreduce_local([rb, rb])   # the same device twice is not a clique
+    rep.close()
+    rb.close()
+    o.close()
 
 
 @pytest.mark.parametrize("fk", [0, -1, 1, 3, 7])
