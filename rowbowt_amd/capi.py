@@ -367,6 +367,17 @@ class RowBowt:
         return r
 
 
+    def counters_reset(self):
+        _check(self.L.rbg_counters_reset(self.h), "rbg_counters_reset")
+
+
+def load_rowbowt(prefix, flag=LoadRbwtFlag.NONE, device=0):
+    """rbwt::load_rowbowt(prefix, flag), rowbowt_io.hpp:176-189"""
+    h = VP()
+    _check(lib().rbg_load(os.fsencode(prefix), int(flag), device, C.byref(h)), f"rbg_load({prefix})")
+    return RowBowt(h)
+
+
 def shard_bounds(n_items, rank, world):
     b, e = U64(), U64()
     _check(lib().rbg_shard_bounds(n_items, rank, world, C.byref(b), C.byref(e)), "rbg_shard_bounds")
@@ -389,13 +400,3 @@ def counters_allreduce_local(replicas):
     out = np.zeros(4, np.uint64)
     _check(lib().rbg_counters_allreduce_local(hs, len(replicas), _p(out)), "rbg_counters_allreduce_local")
     return out
-
-    def counters_reset(self):
-        _check(self.L.rbg_counters_reset(self.h), "rbg_counters_reset")
-
-
-def load_rowbowt(prefix, flag=LoadRbwtFlag.NONE, device=0):
-    """rbwt::load_rowbowt(prefix, flag), rowbowt_io.hpp:176-189"""
-    h = VP()
-    _check(lib().rbg_load(os.fsencode(prefix), int(flag), device, C.byref(h)), f"rbg_load({prefix})")
-    return RowBowt(h)

@@ -1,0 +1,192 @@
+// rbg_hostpath.hpp -- the host-pointer search calls (rbg_find_range, rbg_count, rbg_find_range_w_toehold and the
+// span variants the command-line tools use) as a pipeline that keeps up with the kernels (next-row f2):
+//   * no allocation per call: device buffers and pinned staging live in a workspace kept with the index (one per
+//     concurrent caller, grown on demand, released by rbg_free);
+//   * reads cross PCIe as 2-bit codes when the index's k-mer alphabet is ACGT: worker threads pack each read
+//     straight from the caller's bytes into the layout k_find_range_packed consumes (a quarter of the bytes, and no
+//     pack kernel: the bytes are touched once, on the host, where the copy into pinned memory had to touch them
+//     anyway); reads with any other symbol go through the byte kernel afterwards;
+//   * chunks of the batch are double-buffered on two streams: packing chunk c+1 overlaps the copy, the search and
+//     the copy back of chunk c; results leave through pinned memory.
+// Included by rbg_capi.hip only (it needs rbg_index).
+#pragma once
+
+#include <condition_variable>
+#include <functional>
+
+namespace rbg_hostpath {
+
+// ---- a team of worker threads that runs one function on every member and waits ------------------------------------
+class ThreadTeam {
+   public:
+    explicit ThreadTeam(unsigned n) : n_(n ? n : 1) {
+        for (unsigned t = 1; t < n_; ++t) th_.emplace_back([this, t] { loop(t); });
+    }
+    ~ThreadTeam() {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            stop_ = true;
+            ++gen_;
+        }
+        cv_.notify_all();
+        for (auto &t : th_) t.join();
+    }
+    unsigned size() const { return n_; }
+    void run(const std::function<void(unsigned)> &fn) {  // fn(member) on every member; returns when all are done
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            fn_ = &fn;
+            left_ = n_ - 1;
+            ++gen_;
+        }
+        cv_.notify_all();
+        fn(0);
+        std::unique_lock<std::mutex> g(mu_);
+        done_.wait(g, [this] { return left_ == 0; });
+        fn_ = nullptr;
+    }
+
+   private:
+    void loop(unsigned t) {
+        uint64_t seen = 0;
+        while (true) {
+            const std::function<void(unsigned)> *fn;
+            {
+                std::unique_lock<std::mutex> g(mu_);
+                cv_.wait(g, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (stop_) return;
+                fn = fn_;
+            }
+            (*fn)(t);
+            {
+                std::lock_guard<std::mutex> g(mu_);
+                if (--left_ == 0) done_.notify_one();
+            }
+        }
+    }
+    unsigned n_;
+    std::vector<std::thread> th_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_;
+    const std::function<void(unsigned)> *fn_ = nullptr;
+    unsigned left_ = 0;
+    uint64_t gen_ = 0;
+    bool stop_ = false;
+};
+
+// ---- 2-bit packing of one read, in the order the search consumes it --------------------------------------------------
+// Symbol t of the stream is q[m-1-t] (the search runs right to left, rowbowt.hpp:127-129) at bits [2t, 2t+2): code
+// 0..3 = A, C, G, T.  dst receives ceil(m / 64) 16-byte chunks (zero padded).  Returns false when the read holds
+// anything else (it is then searched from its bytes).
+inline bool pack_read_acgt(const uint8_t *q, uint64_t m, uint32_t *dst) {
+    const uint64_t nwords = ((m + 63) / 64) * 4;
+    uint16_t *d16 = reinterpret_cast<uint16_t *>(dst);
+    const uint64_t nhalf = nwords * 2;
+    uint64_t t = 0;        // symbols packed so far
+    uint64_t bad = 0;
+    while (t + 8 <= m) {   // eight symbols per step, SWAR
+        uint64_t w;
+        std::memcpy(&w, q + (m - t - 8), 8);
+        w = __builtin_bswap64(w);  // q[m-1-t] into the lowest byte
+        const uint64_t x = (w >> 1) & 0x0303030303030303ull;            // A 0, C 1, T 2, G 3
+        const uint64_t hi = (x >> 1) & 0x0101010101010101ull;
+        const uint64_t code = x ^ hi;                                     // A 0, C 1, G 2, T 3
+        // the character each code stands for: 0x41 + {0, 2, 6, 0x13}; anything else in the input shows up as a difference
+        const uint64_t lo1 = code & 0x0101010101010101ull, hi1 = (code >> 1) & 0x0101010101010101ull, both = lo1 & hi1;
+        const uint64_t expect = 0x4141414141414141ull + (lo1 << 1) + (hi1 << 1) + (hi1 << 2) + both + (both << 1) + (both << 3);
+        bad |= expect ^ w;
+        uint64_t y = code;
+        y = (y | (y >> 6)) & 0x000F000F000F000Full;
+        y = (y | (y >> 12)) & 0x000000FF000000FFull;
+        y = (y | (y >> 24)) & 0xFFFFull;
+        d16[t >> 3] = static_cast<uint16_t>(y);
+        t += 8;
+    }
+    uint64_t filled = t >> 3;
+    if (t < m) {  // the read's first (m mod 8) symbols
+        uint32_t y = 0;
+        for (uint64_t u = 0; t + u < m; ++u) {
+            const uint8_t c = q[m - 1 - (t + u)];
+            const uint32_t code = c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 4u;
+            if (code > 3u) bad = 1;
+            y |= (code & 3u) << (2 * u);
+        }
+        d16[filled++] = static_cast<uint16_t>(y);
+    }
+    for (; filled < nhalf; ++filled) d16[filled] = 0;
+    return bad == 0;
+}
+
+// the same for an arbitrary 4-symbol major alphabet (lut2: byte -> 0..3 or 0xFF)
+inline bool pack_read_lut(const uint8_t *q, uint64_t m, const uint8_t *lut2, uint32_t *dst) {
+    const uint64_t nwords = ((m + 63) / 64) * 4;
+    for (uint64_t w = 0; w < nwords; ++w) dst[w] = 0;
+    bool ok = true;
+    for (uint64_t t = 0; t < m; ++t) {
+        const uint32_t code = lut2[q[m - 1 - t]];
+        if (code > 3u) { ok = false; break; }
+        dst[t >> 4] |= code << (2 * (t & 15));
+    }
+    return ok;
+}
+
+// ---- pinned + device buffers of one in-flight chunk ------------------------------------------------------------------
+struct Slot {
+    void *h_in = nullptr, *d_in = nullptr;     // packed: [meta uint2[C] | chunks];  raw: [off u64[C+1] | bytes]
+    size_t in_cap = 0;
+    void *h_out = nullptr, *d_out = nullptr;   // lo | hi | ssamp (or count), C entries each
+    size_t out_cap = 0;
+    hipStream_t st = nullptr;
+    hipEvent_t done = nullptr;
+    // what is in flight in it
+    uint64_t begin = 0, cnt = 0;
+    bool busy = false;
+};
+
+struct Workspace {
+    int device = -1;
+    Slot slot[2];
+    std::unique_ptr<ThreadTeam> team;
+    std::vector<std::vector<uint64_t>> bad;  // per team member: reads (batch indices) the packed form cannot express
+    ~Workspace() { release(); }
+    void release() {
+        for (Slot &s : slot) {
+            if (s.h_in) (void)hipHostFree(s.h_in);
+            if (s.d_in) (void)hipFree(s.d_in);
+            if (s.h_out) (void)hipHostFree(s.h_out);
+            if (s.d_out) (void)hipFree(s.d_out);
+            if (s.done) (void)hipEventDestroy(s.done);
+            if (s.st) (void)hipStreamDestroy(s.st);
+            s = Slot();
+        }
+    }
+    // 0 on success
+    int ensure(Slot &s, size_t in_bytes, size_t out_bytes) {
+        if (!s.st && hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking) != hipSuccess) return 1;
+        if (!s.done && hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess) return 1;
+        if (in_bytes > s.in_cap) {
+            if (s.h_in) (void)hipHostFree(s.h_in);
+            if (s.d_in) (void)hipFree(s.d_in);
+            s.h_in = s.d_in = nullptr;
+            s.in_cap = 0;
+            const size_t cap = in_bytes + in_bytes / 4 + 4096;
+            if (hipHostMalloc(&s.h_in, cap, hipHostMallocDefault) != hipSuccess) return 2;
+            if (hipMalloc(&s.d_in, cap) != hipSuccess) return 2;
+            s.in_cap = cap;
+        }
+        if (out_bytes > s.out_cap) {
+            if (s.h_out) (void)hipHostFree(s.h_out);
+            if (s.d_out) (void)hipFree(s.d_out);
+            s.h_out = s.d_out = nullptr;
+            s.out_cap = 0;
+            const size_t cap = out_bytes + out_bytes / 4 + 4096;
+            if (hipHostMalloc(&s.h_out, cap, hipHostMallocDefault) != hipSuccess) return 2;
+            if (hipMalloc(&s.d_out, cap) != hipSuccess) return 2;
+            s.out_cap = cap;
+        }
+        return 0;
+    }
+};
+
+}  // namespace rbg_hostpath

@@ -110,6 +110,18 @@ def test_errors(tmp_path, data_dir):
     assert e.value.code == -1
 
 
+def test_python_binding_surface():
+    """the ctypes wrapper the tests and bench.py drive the ABI through keeps its methods (a misplaced edit once
+    turned one into dead code)"""
+    for m in ("find_range", "count", "find_range_w_toehold", "locs_at", "markers_at", "find_range_w_markers", "get_markers_greedy_seeding",
+              "greedy_longest_seed", "find_locs_greedy_seeding", "LF", "counters", "counters_reset", "replicate", "info", "set_markers",
+              "set_docs", "write_ftab", "check_ftab", "resolve_offset", "close"):
+        assert callable(getattr(capi.RowBowt, m)), m
+    for f in ("shard_bounds", "find_range_sharded", "counters_allreduce_local", "set_default_option", "lib"):
+        assert callable(getattr(capi, f)), f
+    assert capi.shard_bounds(10, 1, 3) == (3, 6)
+
+
 def test_tuning_options_are_range_checked():
     """rbg_set_default_option (include/rbg.h "tuning"): every knob refuses values outside its documented range
     (RBG_EARG) and leaves the previous value in force; the defaults are restored afterwards."""
