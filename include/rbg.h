@@ -172,6 +172,12 @@ int rbg_find_range(rbg_index *, const uint8_t *seqs, const uint64_t *off, uint64
                    uint64_t *lo, uint64_t *hi);
 /* RowBowt::count, rowbowt.hpp:266-269. */
 int rbg_count(rbg_index *, const uint8_t *seqs, const uint64_t *off, uint64_t N, uint64_t *count);
+/* find_range (ssamp == NULL) / find_range_w_toehold for reads that lie scattered in a larger host buffer: read i =
+ * base[begin[i], begin[i] + len[i]).  What a FASTA/FASTQ parser that leaves the sequence bytes in its input buffer
+ * hands over (the reference copies every read into a std::string first, rb_align.cpp:97): no gather on the host. */
+int rbg_find_range_spans(rbg_index *, const uint8_t *base, const uint64_t *begin, const uint32_t *len, uint64_t N,
+                         uint64_t *lo, uint64_t *hi, uint64_t *ssamp /* nullable */);
+
 /* RowBowt::find_range_w_toehold, rowbowt.hpp:169-184 (LFData.rn / .ssamp); a failed read gets
  * {1,0}, ssamp=0 (LFData::clear :153-159).  RBG_ENOTLOADED without a toehold SA. */
 int rbg_find_range_w_toehold(rbg_index *, const uint8_t *seqs, const uint64_t *off, uint64_t N,
@@ -370,9 +376,10 @@ int rbg_sample_reads_dev(const uint8_t *d_text, uint64_t unit, uint64_t H, uint6
  * DENSE_OVERFLOW (1 = default): buckets with more run starts than a slot holds get a two-bytes-per-row table
  * (512 bytes per such bucket, about 1.2 % on top of the replica) so that their rank is one more load
  * instead of a search of the run list; 0 = search the run list.
- * PACKED_READS applies to the host-pointer search calls, at call time: 0 = never pack (default: on one
- * stream the pack costs what the packed search saves), 1 = pack batches of >= 4096 reads,
- * 2 = always pack.
+ * PACKED_READS applies to the host-pointer search calls, at call time: how the reads cross PCIe -- 0 = as bytes,
+ * 1 (default) = as 2-bit codes packed by CPU threads for batches of >= 4096 reads (a quarter of the bytes; reads
+ * holding symbols outside the index's four k-mer symbols are searched from their bytes afterwards), 2 = always
+ * as 2-bit codes.  (Packing a batch that is already in HBM is rbg_pack_reads_dev.)
  * RANK_LAYOUT: RBG_LAYOUT_AUTO (default: slot tables unless even their single-symbol level exceeds the HBM budget),
  * RBG_LAYOUT_SLOTS, RBG_LAYOUT_RUNS = the run-indexed layout: the run lists plus a 64-ary sampled index, space
  * proportional to r and nothing proportional to n; rank and phi are wave-cooperative predecessor searches

@@ -74,6 +74,7 @@ _PROTOS = [
     ("rbg_find_range", C.c_int, [VP, VP, VP, U64, VP, VP]),
     ("rbg_count", C.c_int, [VP, VP, VP, U64, VP]),
     ("rbg_find_range_w_toehold", C.c_int, [VP, VP, VP, U64, VP, VP, VP]),
+    ("rbg_find_range_spans", C.c_int, [VP, VP, VP, VP, U64, VP, VP, VP]),
     ("rbg_locs_at", C.c_int, [VP, VP, VP, VP, U64, U64, VP, C.POINTER(VP)]),
     ("rbg_markers_at", C.c_int, [VP, VP, VP, U64, VP, C.POINTER(VP)]),
     ("rbg_find_range_w_markers", C.c_int, [VP, VP, VP, U64, U64, U64, VP, VP, VP, C.POINTER(VP)]),
@@ -285,6 +286,17 @@ class RowBowt:
         cnt = np.zeros(N, np.uint64)
         _check(self.L.rbg_count(self.h, _p(seqs), _p(off), N, _p(cnt)), "rbg_count")
         return cnt
+
+    def find_range_spans(self, buf, begin, length, toehold=False):
+        """reads as spans of one host buffer (rbg_find_range_spans)"""
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        begin = _u64(begin)
+        length = np.ascontiguousarray(length, dtype=np.uint32)
+        N = len(begin)
+        lo, hi = np.zeros(N, np.uint64), np.zeros(N, np.uint64)
+        k = np.zeros(N, np.uint64) if toehold else None
+        _check(self.L.rbg_find_range_spans(self.h, _p(buf), _p(begin), _p(length), N, _p(lo), _p(hi), _p(k)), "rbg_find_range_spans")
+        return (lo, hi, k) if toehold else (lo, hi)
 
     def find_range_w_toehold(self, seqs, off):
         N = len(off) - 1

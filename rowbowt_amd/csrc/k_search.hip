@@ -503,6 +503,27 @@ int launch_pack_reads(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *s
     return static_cast<int>(hipGetLastError());
 }
 
+// the packed search alone, on a batch packed elsewhere (the host path of rbg_capi.hip packs on the CPU): flagged
+// reads (meta.y bit 31) are skipped, the caller searches them from their bytes
+int launch_find_range_packed_only(const DevIndex &ix, const LaunchCfg &cfg, const uint2 *meta, const uint4 *chunks, uint64_t N,
+                                  uint64_t *lo, uint64_t *hi, uint64_t *ssamp, void *stream) {
+    if (N == 0) return 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define RBG_LAUNCH_FRP(PT, TOE)                                                                       \
+    do {                                                                                              \
+        auto kern = k_find_range_packed<PT, TOE>;                                                     \
+        const KmerLaunch L = kmer_launch(ix, cfg, N, kern);                                           \
+        hipLaunchKernelGGL(kern, L.grid, L.block, L.lds, st, ix, meta, chunks, N, lo, hi, ssamp);     \
+    } while (0)
+    if (ix.pos_bytes == 4) {
+        if (ssamp) RBG_LAUNCH_FRP(uint32_t, true); else RBG_LAUNCH_FRP(uint32_t, false);
+    } else {
+        if (ssamp) RBG_LAUNCH_FRP(uint64_t, true); else RBG_LAUNCH_FRP(uint64_t, false);
+    }
+#undef RBG_LAUNCH_FRP
+    return static_cast<int>(hipGetLastError());
+}
+
 int launch_find_range_packed(const DevIndex &ix, const LaunchCfg &cfg, const void *ws, const uint8_t *seqs, const uint64_t *off,
                              uint64_t N, uint64_t total_bytes, uint64_t *lo, uint64_t *hi, uint64_t *ssamp, void *stream) {
     if (N == 0) return 0;

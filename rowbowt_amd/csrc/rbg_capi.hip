@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <stdexcept>
@@ -24,6 +25,8 @@
 #include "rbg_host.hpp"
 
 using namespace rbg;
+
+#include "rbg_hostpath.hpp"
 
 struct DevAlloc {
     void *p;
@@ -52,6 +55,8 @@ struct rbg_index {
     uint64_t rank_slots = 0, rank_slots_overflow = 0, phi_slots = 0, phi_slots_overflow = 0;
     uint64_t kmer_steps_requested = 0, hbm_free_at_load = 0, hbm_budget = 0;  // how the space/speed point was chosen (rbg_info)
     bool runs_layout = false;
+    std::mutex ws_mu;            // host-call workspaces (rbg_hostpath.hpp): one per concurrent caller, kept for reuse
+    std::vector<std::unique_ptr<rbg_hostpath::Workspace>> ws_free;
     std::vector<DevSym> dense_todo;  // load time only: rank tables whose overflow buckets still need their dense tables
     std::mutex mu;               // guards marker/doc attachment only; queries are lock-free
 };
@@ -69,7 +74,7 @@ std::atomic<int64_t> g_opt_deep_shift{-1};
 std::atomic<int64_t> g_opt_dense_overflow{1};
 std::atomic<int64_t> g_opt_rank_layout{0};    // RBG_LAYOUT_AUTO / _SLOTS / _RUNS
 std::atomic<int64_t> g_opt_tree_top_kb{48};   // LDS the staged top levels of the run-indexed search may take per workgroup
-std::atomic<int64_t> g_opt_packed_reads{0};  // host-pointer calls: 0 never pack (default), 1 pack large batches, 2 always pack
+std::atomic<int64_t> g_opt_packed_reads{1};  // host-pointer calls: 0 bytes over PCIe, 1 (default) 2-bit codes for batches >= 4096, 2 always
 
 #define HIP_TRY(expr)                                                                             \
     do {                                                                                          \
@@ -1121,8 +1126,9 @@ int rbg_set_docs(rbg_index *ix, const char *names_joined, const uint64_t *starts
 
 void rbg_free(rbg_index *ix) {
     if (!ix) return;
-    if (ix->device != RBG_DEVICE_NONE && !ix->allocs.empty()) {
+    if (ix->device != RBG_DEVICE_NONE) {
         DeviceScope scope(ix->device);
+        ix->ws_free.clear();  // pinned + device staging of the host-pointer calls
         for (const DevAlloc &a : ix->allocs) (void)hipFree(a.p);
     }
     delete ix;
@@ -1383,45 +1389,249 @@ int rbg_markers_fill_dev(rbg_index *ix, const uint64_t *d_lo, const uint64_t *d_
 
 // ---- host-buffer entry points ----------------------------------------------------------------------
 
-static int find_range_host(rbg_index *ix, const uint8_t *seqs, const uint64_t *off, uint64_t N, uint64_t *lo,
-                           uint64_t *hi, uint64_t *ssamp, uint64_t *count) {
+// Reads of a host batch: either the C-ABI's packed layout (read i = seqs[off[i], off[i+1])) or spans of a larger
+// buffer (read i = base[begin[i], begin[i] + len[i]): what a parser that leaves the bytes in its input buffer has).
+struct HostReads {
+    const uint8_t *base = nullptr;
+    const uint64_t *off = nullptr;     // packed layout (N + 1), or
+    const uint64_t *begin = nullptr;   // spans
+    const uint32_t *len = nullptr;
+    const uint8_t *ptr(uint64_t i) const { return base + (off ? off[i] : begin[i]); }
+    uint64_t length(uint64_t i) const { return off ? off[i + 1] - off[i] : len[i]; }
+};
+
+// a workspace of the index for the duration of one call
+struct WsLease {
+    rbg_index *ix;
+    std::unique_ptr<rbg_hostpath::Workspace> ws;
+    explicit WsLease(rbg_index *ix_) : ix(ix_) {
+        std::lock_guard<std::mutex> g(ix->ws_mu);
+        if (!ix->ws_free.empty()) { ws = std::move(ix->ws_free.back()); ix->ws_free.pop_back(); }
+        if (!ws) { ws.reset(new rbg_hostpath::Workspace()); ws->device = ix->device; }
+    }
+    ~WsLease() {
+        std::lock_guard<std::mutex> g(ix->ws_mu);
+        ix->ws_free.push_back(std::move(ws));
+    }
+};
+
+constexpr uint64_t kHostChunkReads = uint64_t(1) << 21;    // reads per in-flight chunk ...
+constexpr uint64_t kHostChunkBytes = uint64_t(384) << 20;  // ... and symbols per chunk (long reads)
+
+static int find_range_host_core(rbg_index *ix, const HostReads &R, uint64_t N, uint64_t *lo, uint64_t *hi, uint64_t *ssamp,
+                                uint64_t *count, bool allow_pack);
+
+static int find_range_host(rbg_index *ix, const uint8_t *seqs, const uint64_t *off, uint64_t N, uint64_t *lo, uint64_t *hi,
+                           uint64_t *ssamp, uint64_t *count) {
     if (!queryable(ix)) return RBG_ENODEV;
     if (N == 0) return RBG_OK;
     if (!off || (!seqs && off[N])) return RBG_EARG;
     int rc = check_offsets(off, N);
     if (rc) return rc;
+    HostReads R;
+    R.base = seqs;
+    R.off = off;
+    return find_range_host_core(ix, R, N, lo, hi, ssamp, count, true);
+}
+
+// The pipeline of rbg_hostpath.hpp.  Outputs: lo/hi (both or neither), ssamp (toehold search), count.
+static int find_range_host_core(rbg_index *ix, const HostReads &R, uint64_t N, uint64_t *lo, uint64_t *hi, uint64_t *ssamp,
+                                uint64_t *count, bool allow_pack) {
+    using rbg_hostpath::Slot;
     DeviceScope scope(ix->device);
     if (scope.rc) return scope.rc;
-    hipStream_t st = hipStreamPerThread;
-    ReadBatch rb;
-    if ((rc = rb.stage(seqs, off, N, st))) return rc;
-    DevBuf dlo, dhi, dss, dcnt;
-    if ((rc = dlo.alloc(N * 8)) || (rc = dhi.alloc(N * 8))) return rc;
-    if (ssamp && (rc = dss.alloc(N * 8))) return rc;
+    WsLease lease(ix);
+    rbg_hostpath::Workspace &W = *lease.ws;
     const int64_t pk = g_opt_packed_reads.load();
-    const uint64_t total_bytes = off[N];
-    if ((pk == 2 || (pk == 1 && N >= 4096)) && total_bytes / 64 + N + 1 < (uint64_t(1) << 32)) {
-        DevBuf dws;  // pack once (coalesced), search the 2-bit form; same results
-        const size_t ws_bytes = pack_ws_bytes(N, total_bytes);
-        if ((rc = dws.alloc(ws_bytes))) return rc;
-        if (launch_pack_reads(ix->dev, ix->cfg, rb.seqs.as<uint8_t>(), rb.off.as<uint64_t>(), N, total_bytes, dws.p, ws_bytes, st) ||
-            launch_find_range_packed(ix->dev, ix->cfg, dws.p, rb.seqs.as<uint8_t>(), rb.off.as<uint64_t>(), N, total_bytes,
-                                     dlo.as<uint64_t>(), dhi.as<uint64_t>(), ssamp ? dss.as<uint64_t>() : nullptr, st))
-            return RBG_ENODEV;
-        HIP_TRY(hipStreamSynchronize(st));  // dws is released at scope end
-    } else if (launch_find_range(ix->dev, ix->cfg, rb.seqs.as<uint8_t>(), rb.off.as<uint64_t>(), N, dlo.as<uint64_t>(),
-                                 dhi.as<uint64_t>(), ssamp ? dss.as<uint64_t>() : nullptr, st)) {
-        return RBG_ENODEV;
+    const HostIndex &h = ix->H();
+    // 2-bit transfer: needs the packed search kernel's alphabet (four k-mer symbols) and the slot-table layout
+    const bool pack = allow_pack && ix->dev.nmajor == 4 && ix->dev.layout == RBG_LAYOUT_SLOTS && (pk == 2 || (pk == 1 && N >= 4096));
+    const bool acgt = h.major_byte[0] == 'A' && h.major_byte[1] == 'C' && h.major_byte[2] == 'G' && h.major_byte[3] == 'T';
+    if (!W.team) {
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        W.team.reset(new rbg_hostpath::ThreadTeam(std::min(16u, std::max(1u, hw / 2))));
+        W.bad.resize(W.team->size());
     }
-    if (count) {
-        if ((rc = dcnt.alloc(N * 8))) return rc;
-        if (launch_count_from_ranges(dlo.as<uint64_t>(), dhi.as<uint64_t>(), N, dcnt.as<uint64_t>(), st)) return RBG_ENODEV;
-        HIP_TRY(hipMemcpyAsync(count, dcnt.p, N * 8, hipMemcpyDeviceToHost, st));
+    rbg_hostpath::ThreadTeam &team = *W.team;
+    const unsigned T = team.size();
+    // small batches (the shim's one-read calls among them) stay on the calling thread: waking the team costs more
+    auto par = [&](uint64_t work_items, const std::function<void(unsigned)> &fn) {
+        if (work_items < 16384) { for (unsigned t = 0; t < T; ++t) fn(t); }
+        else team.run(fn);
+    };
+    for (auto &v : W.bad) v.clear();
+    const int nout = (lo ? 2 : 0) + (ssamp ? 1 : 0) + (count ? 1 : 0);
+    const bool need_lohi_dev = true;  // the kernels always write lo/hi
+    (void)need_lohi_dev;
+
+    int rc = RBG_OK;
+    auto drain = [&](Slot &s) -> int {  // wait for the chunk in flight in `s`, hand its results to the caller
+        if (!s.busy) return RBG_OK;
+        if (hipEventSynchronize(s.done) != hipSuccess) return RBG_ENODEV;
+        const uint64_t *src = static_cast<const uint64_t *>(s.h_out);
+        uint64_t col = 0;
+        if (lo) {
+            std::memcpy(lo + s.begin, src + col * s.cnt, s.cnt * 8); ++col;
+            std::memcpy(hi + s.begin, src + col * s.cnt, s.cnt * 8); ++col;
+        }
+        if (ssamp) { std::memcpy(ssamp + s.begin, src + col * s.cnt, s.cnt * 8); ++col; }
+        if (count) { std::memcpy(count + s.begin, src + col * s.cnt, s.cnt * 8); ++col; }
+        s.busy = false;
+        return RBG_OK;
+    };
+
+    std::vector<uint64_t> part(T + 1);
+    uint64_t b = 0;
+    int which = 0;
+    while (b < N && !rc) {
+        // the chunk [b, e): bounded in reads and in symbols
+        uint64_t e = b, sym = 0;
+        while (e < N && e - b < kHostChunkReads && sym < kHostChunkBytes) sym += R.length(e++);
+        const uint64_t cnt = e - b;
+        Slot &s = W.slot[which];
+        which ^= 1;
+        if ((rc = drain(s))) break;
+        // device columns: lo, hi, [ssamp], [count]
+        const uint64_t dev_cols = 2 + (ssamp ? 1 : 0) + (count ? 1 : 0);
+        size_t in_bytes;
+        if (pack) in_bytes = cnt * 8 + 16 + (sym / 64 + cnt + 1) * 16;
+        else in_bytes = (cnt + 1) * 8 + 16 + sym + 32;
+        const int er = W.ensure(s, in_bytes, dev_cols * cnt * 8);
+        if (er) { rc = er == 2 ? RBG_ENOMEM : RBG_ENODEV; break; }
+        char *hin = static_cast<char *>(s.h_in);
+        char *din = static_cast<char *>(s.d_in);
+        uint64_t *dout = static_cast<uint64_t *>(s.d_out);
+        uint64_t *d_lo = dout, *d_hi = dout + cnt, *d_ss = ssamp ? dout + 2 * cnt : nullptr;
+        uint64_t *d_cnt = count ? dout + (ssamp ? 3 : 2) * cnt : nullptr;
+        size_t used = 0;
+        if (pack) {
+            uint2 *meta = reinterpret_cast<uint2 *>(hin);
+            const size_t chunks_at = (cnt * 8 + 15) & ~size_t(15);
+            uint32_t *chunks = reinterpret_cast<uint32_t *>(hin + chunks_at);
+            // 16-byte chunks per member's slice, then every member packs from its own prefix
+            par(cnt, [&](unsigned t) {
+                const uint64_t i0 = b + cnt * t / T, i1 = b + cnt * (t + 1) / T;
+                uint64_t c = 0;
+                for (uint64_t i = i0; i < i1; ++i) c += (R.length(i) + 63) >> 6;
+                part[t + 1] = c;
+            });
+            part[0] = 0;
+            for (unsigned t = 0; t < T; ++t) part[t + 1] += part[t];
+            if (part[T] >= (uint64_t(1) << 32)) { rc = RBG_EARG; break; }
+            par(cnt, [&](unsigned t) {
+                const uint64_t i0 = b + cnt * t / T, i1 = b + cnt * (t + 1) / T;
+                uint64_t c = part[t];
+                for (uint64_t i = i0; i < i1; ++i) {
+                    const uint64_t m = R.length(i);
+                    uint32_t *dst = chunks + c * 4;
+                    const bool ok = m < 0x80000000ull &&
+                                    (acgt ? rbg_hostpath::pack_read_acgt(R.ptr(i), m, dst) : rbg_hostpath::pack_read_lut(R.ptr(i), m, h.major_of, dst));
+                    meta[i - b] = make_uint2(static_cast<uint32_t>(c), ok ? static_cast<uint32_t>(m) : 0x80000000u);
+                    if (!ok) W.bad[t].push_back(i);
+                    c += (m + 63) >> 6;
+                }
+            });
+            used = chunks_at + part[T] * 16;
+            if (hipMemcpyAsync(din, hin, used, hipMemcpyHostToDevice, s.st) != hipSuccess ||
+                launch_find_range_packed_only(ix->dev, ix->cfg, reinterpret_cast<const uint2 *>(din), reinterpret_cast<const uint4 *>(din + chunks_at), cnt,
+                                              d_lo, d_hi, d_ss, s.st))
+                rc = RBG_ENODEV;
+        } else {
+            uint64_t *off2 = reinterpret_cast<uint64_t *>(hin);
+            const size_t bytes_at = ((cnt + 1) * 8 + 15) & ~size_t(15);
+            char *bytes = hin + bytes_at;
+            par(cnt, [&](unsigned t) {
+                const uint64_t i0 = b + cnt * t / T, i1 = b + cnt * (t + 1) / T;
+                uint64_t c = 0;
+                for (uint64_t i = i0; i < i1; ++i) c += R.length(i);
+                part[t + 1] = c;
+            });
+            part[0] = 0;
+            for (unsigned t = 0; t < T; ++t) part[t + 1] += part[t];
+            par(cnt, [&](unsigned t) {
+                const uint64_t i0 = b + cnt * t / T, i1 = b + cnt * (t + 1) / T;
+                uint64_t c = part[t];
+                if (R.off && i1 > i0) {  // contiguous in the source: one copy per slice
+                    std::memcpy(bytes + c, R.ptr(i0), R.off[i1] - R.off[i0]);
+                    for (uint64_t i = i0; i < i1; ++i) off2[i - b] = c + (R.off[i] - R.off[i0]);
+                } else {
+                    for (uint64_t i = i0; i < i1; ++i) {
+                        const uint64_t m = R.length(i);
+                        std::memcpy(bytes + c, R.ptr(i), m);
+                        off2[i - b] = c;
+                        c += m;
+                    }
+                }
+            });
+            off2[cnt] = part[T];
+            used = bytes_at + part[T];
+            if (hipMemcpyAsync(din, hin, used, hipMemcpyHostToDevice, s.st) != hipSuccess ||
+                launch_find_range(ix->dev, ix->cfg, reinterpret_cast<const uint8_t *>(din + bytes_at), reinterpret_cast<const uint64_t *>(din), cnt, d_lo,
+                                  d_hi, d_ss, s.st))
+                rc = RBG_ENODEV;
+        }
+        if (rc) break;
+        if (count && launch_count_from_ranges(d_lo, d_hi, cnt, d_cnt, s.st)) { rc = RBG_ENODEV; break; }
+        // results through pinned memory: [lo | hi] (when asked for) | ssamp | count, the columns the caller wants
+        {
+            char *hout = static_cast<char *>(s.h_out);
+            size_t at = 0;
+            hipError_t e2 = hipSuccess;
+            if (lo) { e2 = hipMemcpyAsync(hout, d_lo, 2 * cnt * 8, hipMemcpyDeviceToHost, s.st); at += 2 * cnt * 8; }
+            if (e2 == hipSuccess && ssamp) { e2 = hipMemcpyAsync(hout + at, d_ss, cnt * 8, hipMemcpyDeviceToHost, s.st); at += cnt * 8; }
+            if (e2 == hipSuccess && count) { e2 = hipMemcpyAsync(hout + at, d_cnt, cnt * 8, hipMemcpyDeviceToHost, s.st); at += cnt * 8; }
+            if (e2 == hipSuccess) e2 = hipEventRecord(s.done, s.st);
+            if (e2 != hipSuccess) { rc = RBG_ENODEV; break; }
+        }
+        s.begin = b;
+        s.cnt = cnt;
+        s.busy = true;
+        b = e;
     }
-    if (lo) HIP_TRY(hipMemcpyAsync(lo, dlo.p, N * 8, hipMemcpyDeviceToHost, st));
-    if (hi) HIP_TRY(hipMemcpyAsync(hi, dhi.p, N * 8, hipMemcpyDeviceToHost, st));
-    if (ssamp) HIP_TRY(hipMemcpyAsync(ssamp, dss.p, N * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    (void)nout;
+    for (Slot &s : W.slot) {
+        const int r2 = drain(s);
+        if (!rc) rc = r2;
+        if (rc && s.busy) { (void)hipStreamSynchronize(s.st); s.busy = false; }
+    }
+    if (rc) return rc;
+    // reads the 2-bit form cannot express (any symbol outside the k-mer alphabet): searched from their bytes
+    std::vector<uint64_t> bad;
+    for (auto &v : W.bad) bad.insert(bad.end(), v.begin(), v.end());
+    if (!bad.empty()) {
+        std::sort(bad.begin(), bad.end());
+        std::vector<uint64_t> bb(bad.size());
+        std::vector<uint32_t> bl(bad.size());
+        bool fits = true;
+        for (size_t j = 0; j < bad.size(); ++j) {
+            bb[j] = static_cast<uint64_t>(R.ptr(bad[j]) - R.base);
+            const uint64_t m = R.length(bad[j]);
+            if (m > 0xFFFFFFFFull) fits = false;
+            bl[j] = static_cast<uint32_t>(m);
+        }
+        std::vector<uint64_t> t_lo(bad.size()), t_hi(bad.size()), t_ss(ssamp ? bad.size() : 0), t_cnt(count ? bad.size() : 0);
+        HostReads Rb;
+        Rb.base = R.base;
+        std::vector<uint64_t> off3;
+        std::string flat;
+        if (fits) {
+            Rb.begin = bb.data();
+            Rb.len = bl.data();
+        } else {  // a read beyond 4 GB: gather into the packed layout
+            off3.assign(1, 0);
+            for (uint64_t i : bad) { flat.append(reinterpret_cast<const char *>(R.ptr(i)), R.length(i)); off3.push_back(flat.size()); }
+            Rb.base = reinterpret_cast<const uint8_t *>(flat.data());
+            Rb.off = off3.data();
+        }
+        // (the lease is still held: the recursive call takes another workspace)
+        rc = find_range_host_core(ix, Rb, bad.size(), t_lo.data(), t_hi.data(), ssamp ? t_ss.data() : nullptr, count ? t_cnt.data() : nullptr, false);
+        if (rc) return rc;
+        for (size_t j = 0; j < bad.size(); ++j) {
+            if (lo) { lo[bad[j]] = t_lo[j]; hi[bad[j]] = t_hi[j]; }
+            if (ssamp) ssamp[bad[j]] = t_ss[j];
+            if (count) count[bad[j]] = t_cnt[j];
+        }
+    }
     return RBG_OK;
 }
 
@@ -1461,6 +1671,21 @@ int rbg_count(rbg_index *ix, const uint8_t *seqs, const uint64_t *off, uint64_t 
     return guarded([&]() -> int {
     if (N && !count) return RBG_EARG;
     return find_range_host(ix, seqs, off, N, nullptr, nullptr, nullptr, count);
+    });
+}
+
+int rbg_find_range_spans(rbg_index *ix, const uint8_t *base, const uint64_t *begin, const uint32_t *len, uint64_t N, uint64_t *lo,
+                         uint64_t *hi, uint64_t *ssamp) {
+    return guarded([&]() -> int {
+    if (!queryable(ix)) return RBG_ENODEV;
+    if (ssamp && !ix->H().has_tsa) return RBG_ENOTLOADED;
+    if (N == 0) return RBG_OK;
+    if (!base || !begin || !len || !lo || !hi) return RBG_EARG;
+    HostReads R;
+    R.base = base;
+    R.begin = begin;
+    R.len = len;
+    return find_range_host_core(ix, R, N, lo, hi, ssamp, nullptr, true);
     });
 }
 

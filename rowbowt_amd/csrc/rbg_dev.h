@@ -2,6 +2,8 @@
 // C-ABI translation unit and the kernels).  Layout rationale: DESIGN.md "Data layout in HBM".
 #pragma once
 
+#include <hip/hip_runtime.h>
+
 #include <cstddef>
 #include <cstdint>
 
@@ -215,6 +217,8 @@ int launch_pack_reads(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *s
                       uint64_t total_bytes, void *ws, size_t ws_bytes, void *stream);
 int launch_find_range_packed(const DevIndex &ix, const LaunchCfg &cfg, const void *ws, const uint8_t *seqs, const uint64_t *off,
                              uint64_t N, uint64_t total_bytes, uint64_t *lo, uint64_t *hi, uint64_t *ssamp, void *stream);
+int launch_find_range_packed_only(const DevIndex &ix, const LaunchCfg &cfg, const uint2 *meta, const uint4 *chunks, uint64_t N,
+                                  uint64_t *lo, uint64_t *hi, uint64_t *ssamp /*nullable*/, void *stream);
 int launch_marker_seeds_plan(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
                              uint64_t wsize, uint64_t max_range, uint64_t ftab_k, uint64_t *seed_off, uint64_t *mk_off, void *tmp,
                              size_t tmp_bytes, void *stream);

@@ -110,6 +110,17 @@ def test_errors(tmp_path, data_dir):
     assert e.value.code == -1
 
 
+def test_host_side_2bit_packer(tmp_path):
+    """rbg_pack2bit.hpp (the packer of the host-pointer pipeline and of the tools' FASTQ front end) against a
+    bit-by-bit restatement of the device layout, under ASan + UBSan (tests/cpp/pack2bit_check.cpp)"""
+    import subprocess
+    exe = tmp_path / "pack2bit"
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           os.path.join(ROOT, "tests", "cpp", "pack2bit_check.cpp"), "-o", str(exe)])
+    p = subprocess.run([str(exe)], capture_output=True, timeout=120)
+    assert p.returncode == 0 and b"pack2bit ok" in p.stdout, p.stdout[-300:] + p.stderr[-300:]
+
+
 def test_python_binding_surface():
     """the ctypes wrapper the tests and bench.py drive the ABI through keeps its methods (a misplaced edit once
     turned one into dead code)"""
@@ -128,7 +139,7 @@ def test_tuning_options_are_range_checked():
     L = ra.lib()
     ok = {capi.OPT_BLOCK_THREADS: [64, 128, 256], capi.OPT_RANK_BUCKET_SHIFT: [0, 8, 12, -1], capi.OPT_PHI_BUCKET_SHIFT: [0, 8, -1],
           capi.OPT_POS_BYTES: [4, 8, 0], capi.OPT_KMER_STEPS: [1, 3, 5], capi.OPT_HBM_BUDGET_MB: [1, 0], capi.OPT_FTAB_K: [0, 16, -1],
-          capi.OPT_PACKED_READS: [1, 2, 0], capi.OPT_DEEP_BUCKET_SHIFT: [9, 12, -1], capi.OPT_DENSE_OVERFLOW: [0, 1],
+          capi.OPT_PACKED_READS: [0, 2, 1], capi.OPT_DEEP_BUCKET_SHIFT: [9, 12, -1], capi.OPT_DENSE_OVERFLOW: [0, 1],
           capi.OPT_RANK_LAYOUT: [1, 2, 0], capi.OPT_TREE_TOP_KB: [0, 96, 48]}
     bad = {capi.OPT_BLOCK_THREADS: [0, 100, 512], capi.OPT_RANK_BUCKET_SHIFT: [-2, 13], capi.OPT_PHI_BUCKET_SHIFT: [-2, 9],
            capi.OPT_POS_BYTES: [2, 16], capi.OPT_KMER_STEPS: [0, 6], capi.OPT_HBM_BUDGET_MB: [-1], capi.OPT_FTAB_K: [-2, 17],

@@ -102,3 +102,75 @@ def test_broken_gzip_stream_is_minus_3(dump, tmp_path):
     want, want_rc = kseq_model(prefix)
     assert 0 < len(got) < len(recs) and got[:-1] == recs[:len(got) - 1]
     assert (got, rc) == ([(n, s_) for n, s_ in want], want_rc) or rc == -3
+
+
+# ---- rb_align's record scanner (fastx_index.hpp): the same contract, input left in place ---------------------------
+@pytest.fixture(scope="module")
+def scan(tmp_path_factory):
+    exe = tmp_path_factory.mktemp("fxi") / "fastx_index_dump"
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-pthread",
+                           os.path.join(ROOT, "tests", "cpp", "fastx_index_dump.cpp"), "-o", str(exe)])
+
+    def run(path, block, threads, minseg):
+        p = subprocess.run([str(exe), str(path), str(block), str(threads), str(minseg)], capture_output=True, timeout=120)
+        assert p.returncode == 0, (p.stdout[-300:], p.stderr[-600:])
+        lines = p.stdout.split(b"\n")
+        assert lines[-1] == b"" and lines[-2].startswith(b"rc="), lines[-3:]
+        return [tuple(l.split(b"\t", 1)) for l in lines[:-2]], int(lines[-2][3:])
+    return run
+
+
+GEOMETRIES = [(1 << 20, 1, 1 << 20), (7, 1, 1), (64, 3, 1), (1000, 4, 16), (1 << 20, 8, 1), (333, 2, 100)]
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_scanner_matches_kseq_model(scan, tmp_path, name):
+    data = CASES[name]
+    want, want_rc = kseq_model(data)
+    f = tmp_path / (name + ".fx")
+    f.write_bytes(data)
+    for block, threads, minseg in GEOMETRIES:
+        got, rc = scan(f, block, threads, minseg)
+        assert (got, rc) == ([(n, s) for n, s in want], want_rc), (name, block, threads, minseg)
+
+
+def test_scanner_random_records_truncations_and_adversarial_lines(scan, tmp_path):
+    """well-formed mixes, every kind of cut, and inputs built to fool a boundary guess: quality lines that start
+    with '@' and look like headers, '>' and '@' inside sequences' neighbours, blank lines, CRLF"""
+    rng = np.random.default_rng(8)
+    recs = []
+    for i in range(60):
+        seq = bytes(rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), int(rng.integers(0, 90))))
+        kind = rng.random()
+        if kind < 0.4:
+            q = bytes(rng.choice(np.frombuffer(b"@+>I5#", dtype=np.uint8), len(seq)))   # qualities full of header characters
+            recs.append(b"@q%d some comment\n" % i + seq + b"\n+\n" + q + b"\n")
+        elif kind < 0.55:
+            recs.append(b"@c%d\r\n" % i + seq + b"\r\n+\r\n" + b"I" * len(seq) + b"\r\n")
+        elif kind < 0.7:   # a multi-line FASTQ record whose quality lines begin with '@'
+            h = len(seq) // 2
+            recs.append(b"@m%d\n" % i + seq[:h] + b"\n" + seq[h:] + b"\n+\n" + b"@" * h + b"\n" + b"@" * (len(seq) - h) + b"\n")
+        else:
+            k = int(rng.integers(1, 4))
+            recs.append(b">f%d\n" % i + b"\n".join(seq[j::k] for j in range(k)) + b"\n\n")
+    blob = b"".join(recs)
+    cuts = [len(blob)] + [int(c) for c in rng.integers(1, len(blob), 50)]
+    for cut in cuts:
+        data = blob[:cut]
+        f = tmp_path / "r.fx"
+        f.write_bytes(data)
+        want, want_rc = kseq_model(data)
+        for block, threads, minseg in ((1 << 20, 4, 1), (97, 3, 8), (1 << 20, 1, 1 << 20)):
+            got, rc = scan(f, block, threads, minseg)
+            assert (got, rc) == ([(n, s) for n, s in want], want_rc), (cut, block, threads, minseg)
+
+
+def test_scanner_large_wellformed_many_threads(scan, tmp_path):
+    rng = np.random.default_rng(9)
+    recs = [(b"read%d" % i, bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 100))) for i in range(30000)]
+    blob = b"".join(b"@" + n + b" x\n" + s + b"\n+\n" + b"@" * 100 + b"\n" for n, s in recs)   # worst-case qualities: all '@'
+    f = tmp_path / "big.fq"
+    f.write_bytes(blob)
+    for block, threads, minseg in ((1 << 30, 8, 1 << 16), (1 << 18, 4, 1 << 12)):
+        got, rc = scan(f, block, threads, minseg)
+        assert rc == -1 and got == recs

@@ -158,7 +158,7 @@ def synth():
 def test_synth_all_paths(synth, pos_bytes, rshift, pshift, ksteps, packed, request):
     S = synth
     ra.set_default_option(capi.OPT_PACKED_READS, packed)   # byte kernels / 2-bit packed reads: same answers
-    request.addfinalizer(lambda: ra.set_default_option(capi.OPT_PACKED_READS, 0))
+    request.addfinalizer(lambda: ra.set_default_option(capi.OPT_PACKED_READS, 1))
     ra.set_default_option(capi.OPT_POS_BYTES, pos_bytes)
     ra.set_default_option(capi.OPT_RANK_BUCKET_SHIFT, rshift)
     ra.set_default_option(capi.OPT_PHI_BUCKET_SHIFT, pshift)
@@ -452,7 +452,7 @@ def test_random_alphabets(sigma, skew):
             lo, hi, k = rb.find_range_w_toehold(seqs, off)
             lo2, hi2 = rb.find_range(seqs, off)
         finally:
-            ra.set_default_option(capi.OPT_PACKED_READS, 0)
+            ra.set_default_option(capi.OPT_PACKED_READS, 1)
         wlo, whi, wk = o.find_range_w_toehold_batch(seqs, off)
         assert (lo == wlo).all() and (hi == whi).all() and (k == wk).all() and (lo2 == wlo).all() and (hi2 == whi).all()
     assert int((hi >= lo).sum()) > 800
@@ -489,7 +489,7 @@ def test_tiny_indexes(body):
         try:
             lo, hi, k = rb.find_range_w_toehold(seqs, off)
         finally:
-            ra.set_default_option(capi.OPT_PACKED_READS, 0)
+            ra.set_default_option(capi.OPT_PACKED_READS, 1)
         wlo, whi, wk = o.find_range_w_toehold_batch(seqs, off)
         assert (lo == wlo).all() and (hi == whi).all() and (k == wk).all()
     loc_off, locs = rb.locs_at(lo, hi, k)
@@ -952,7 +952,7 @@ def test_long_and_ragged_reads(synth, packed, request):
     kernel's LDS staging take its direct path)."""
     S = synth
     ra.set_default_option(capi.OPT_PACKED_READS, packed)
-    request.addfinalizer(lambda: ra.set_default_option(capi.OPT_PACKED_READS, 0))
+    request.addfinalizer(lambda: ra.set_default_option(capi.OPT_PACKED_READS, 1))
     rb = ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0)
     o = orc.Oracle.from_runs(S.heads, S.lens, S.ssa, S.esa)
     unit = S.L + S.pad
@@ -1255,6 +1255,45 @@ def test_run_indexed_layout_goldens_and_budget_rule(small, simple_reads, error_r
     assert (l2 == wlo).all() and (h2 == whi).all() and (k2 == wk).all()
     rb2.close()
     assert hbm_runs < 2_000_000
+
+
+@pytest.mark.parametrize("packed", [0, 1, 2])
+def test_host_pointer_pipeline(small, packed, request):
+    """the host-pointer calls as rbg_hostpath.hpp runs them: several double-buffered chunks (2.2 M short reads), reads
+    crossing PCIe as bytes (0) or as 2-bit codes packed on the CPU (1 = default, 2 = always) with the reads that
+    hold other symbols searched from their bytes afterwards, spans of one buffer instead of the packed layout,
+    and calls too small to wake the worker threads -- same answers as the oracle every way"""
+    rb, o = small
+    ra.set_default_option(capi.OPT_PACKED_READS, packed)
+    request.addfinalizer(lambda: ra.set_default_option(capi.OPT_PACKED_READS, 1))
+    rng = np.random.default_rng(11 + packed)
+    text = np.frombuffer(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "small.fa"), "rb").read().split(b"\n", 1)[1].replace(b"\n", b""), dtype=np.uint8)
+    N = 2_200_000
+    starts = rng.integers(0, len(text) - 40, N)
+    lens = rng.integers(0, 33, N).astype(np.uint32)
+    lens[rng.integers(0, N, 2000)] = 0                                     # empty reads
+    begin = starts.astype(np.uint64)
+    buf = text.copy()
+    dirty = rng.integers(0, len(buf), 300)
+    buf[dirty] = rng.choice(np.frombuffer(b"Nacgt\x01", dtype=np.uint8), len(dirty))   # some reads hold other symbols
+    lo, hi, k = rb.find_range_spans(buf, begin, lens, toehold=True)
+    # the same reads in the packed layout, through the oracle and through the packed-layout entry points
+    idx = begin[:, None] + np.arange(32, dtype=np.uint64)[None, :]
+    mask = np.arange(32)[None, :] < lens[:, None]
+    seqs = buf[np.minimum(idx, len(buf) - 1)][mask]
+    off = np.concatenate([[0], np.cumsum(lens.astype(np.uint64))]).astype(np.uint64)
+    wlo, whi, wk = o.find_range_w_toehold_batch(seqs, off, nthreads=min(os.cpu_count() or 1, 64))
+    assert (lo == wlo).all() and (hi == whi).all() and (k == wk).all()
+    assert int(((whi < wlo)).sum()) > 100 and int((lens == 0).sum()) > 1000
+    lo2, hi2 = rb.find_range_spans(buf, begin, lens)
+    assert (lo2 == wlo).all() and (hi2 == whi).all()
+    lo3, hi3, k3 = rb.find_range_w_toehold(seqs, off)
+    assert (lo3 == wlo).all() and (hi3 == whi).all() and (k3 == wk).all()
+    cnt = rb.count(seqs, off)
+    assert (cnt == np.where(whi >= wlo, whi - wlo + 1, 0)).all()
+    for n_small in (1, 2, 100, 5000):
+        l4, h4 = rb.find_range(seqs[:int(off[n_small])], off[:n_small + 1])
+        assert (l4 == wlo[:n_small]).all() and (h4 == whi[:n_small]).all()
 
 
 @pytest.mark.parametrize("layout", [capi.LAYOUT_AUTO, capi.LAYOUT_RUNS])
