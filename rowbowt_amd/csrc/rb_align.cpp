@@ -23,14 +23,121 @@
 #include <thread>
 #include <vector>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include "../include/rowbowt_gpu.hpp"
 #include "fastx.hpp"
+#include "fastx_index.hpp"
 
 namespace {
 
-using rbg_cli::FastxReader;
-using rbg_cli::PackedBatch;
 using rbg_cli::put_u64;
+using rbg_cli::RecordSpans;
+
+// One stretch of the input with the records found in it.  The bytes stay where they are: in the mapping of a plain
+// file, or in `own` (decompressed / piped input); names and sequences are offsets from `base`.
+struct Window {
+    const char *base = nullptr;
+    std::vector<char> own;
+    RecordSpans recs;
+    size_t size() const { return recs.size(); }
+};
+
+// The input as a sequence of windows that each begin at a record boundary (fastx_index.hpp does the scanning).
+class InputSource {
+   public:
+    ~InputSource() {
+        if (map_) munmap(const_cast<char *>(map_), map_size_);
+        if (gz_) gzclose(gz_);
+    }
+    bool open(const std::string &path, unsigned threads, uint64_t window_bytes) {
+        threads_ = threads ? threads : 1;
+        window_ = window_bytes;
+        const int fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) return false;
+        struct stat sb;
+        unsigned char magic[2] = {0, 0};
+        const bool regular = fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode);
+        if (regular && sb.st_size >= 2 && pread(fd, magic, 2, 0) != 2) magic[0] = magic[1] = 0;
+        if (regular && !(magic[0] == 0x1f && magic[1] == 0x8b)) {   // a plain file: map it, scan it in place
+            map_size_ = static_cast<size_t>(sb.st_size);
+            if (map_size_) {
+                void *m = mmap(nullptr, map_size_, PROT_READ, MAP_PRIVATE, fd, 0);
+                if (m == MAP_FAILED) { ::close(fd); return false; }
+                (void)madvise(m, map_size_, MADV_SEQUENTIAL);
+                map_ = static_cast<const char *>(m);
+            }
+            mapped_ = true;
+            ::close(fd);
+            return true;
+        }
+        ::close(fd);
+        gz_ = gzopen(path.c_str(), "r");   // gzip, or anything that is not a regular file (zlib reads plain data through)
+        if (!gz_) return false;
+        gzbuffer(gz_, 1 << 20);
+        return true;
+    }
+    // the next window; returns 0 while more input follows, -1 at its end, -2 / -3 like kseq_read (the window then
+    // holds the records that came before the failure)
+    int next(Window &w) {
+        w.recs.clear();
+        w.own.clear();
+        uint64_t win = window_;
+        while (true) {
+            uint64_t resume = 0;
+            rbg_cli::ScanState rstate;
+            int rc;
+            bool final;
+            if (mapped_) {
+                const uint64_t end = std::min<uint64_t>(map_size_, pos_ + win);
+                final = end == map_size_;
+                w.base = map_ ? map_ : "";
+                rc = rbg_cli::scan_records_parallel(w.base, pos_, end, final, st_, w.recs, &resume, &rstate, threads_);
+                if (rc == rbg_cli::kScanTruncQual) return -2;
+                if (!(rc == rbg_cli::kScanEnd && final) && resume == pos_ && w.recs.size() == 0 && !final) { win *= 2; continue; }   // one record longer than the window
+                pos_ = resume;
+                st_ = rstate;
+            } else {
+                // carry-over of the previous window's unfinished record, then fresh bytes
+                w.own.assign(carry_.begin(), carry_.end());
+                const size_t have = w.own.size();
+                w.own.resize(have + win);
+                size_t got = 0;
+                bool eof = false;
+                while (got < win) {
+                    const int r = gzread(gz_, w.own.data() + have + got, static_cast<unsigned>(std::min<uint64_t>(win - got, 1u << 30)));
+                    if (r < 0) { stream_error_ = true; eof = true; break; }
+                    if (r == 0) { eof = true; break; }
+                    got += static_cast<size_t>(r);
+                }
+                w.own.resize(have + got);
+                final = eof;
+                w.base = w.own.data();
+                rc = rbg_cli::scan_records_parallel(w.base, 0, w.own.size(), final, st_, w.recs, &resume, &rstate, threads_);
+                if (rc == rbg_cli::kScanTruncQual) return stream_error_ ? -3 : -2;
+                carry_.assign(w.own.begin() + static_cast<std::ptrdiff_t>(resume), w.own.end());
+                st_ = rstate;
+                if (!final && w.recs.size() == 0) { win *= 2; continue; }
+            }
+            if (final) return stream_error_ ? -3 : -1;
+            return 0;
+        }
+    }
+
+   private:
+    const char *map_ = nullptr;
+    size_t map_size_ = 0;
+    bool mapped_ = false;
+    gzFile gz_ = nullptr;
+    uint64_t pos_ = 0, window_ = uint64_t(256) << 20;
+    unsigned threads_ = 1;
+    rbg_cli::ScanState st_;
+    std::vector<char> carry_;
+    bool stream_error_ = false;
+};
 
 struct RbAlignArgs {  // rb_align.cpp:17-24
     std::string inpre, fastq_fname, outpre;
@@ -38,8 +145,9 @@ struct RbAlignArgs {  // rb_align.cpp:17-24
     int device = 0;
     int gpus = 1;     // replicas: devices device .. device + gpus - 1; every batch is sharded over them
     std::vector<int> devices;  // --devices a,b,...: the replicas' devices, in shard order (overrides --gpu/--gpus)
-    uint64_t batch = 1u << 20;
-    int threads = 8;  // output formatting workers
+    uint64_t batch = 1u << 22;
+    int threads = 8;  // input scanning and output formatting workers
+    uint64_t window_mb = 256;  // input bytes scanned per pipeline step
 };
 
 void print_help() {  // rb_align.cpp:26-35
@@ -51,8 +159,9 @@ void print_help() {  // rb_align.cpp:26-35
     fprintf(stderr, "    --gpu <n>                        HIP device ordinal (default 0)\n");
     fprintf(stderr, "    --gpus <G>                       replicate the index on G devices (from --gpu on) and shard every batch over them\n");
     fprintf(stderr, "    --devices <a,b,...>              the same with an explicit device list\n");
-    fprintf(stderr, "    --batch <n>                      reads per GPU batch (default 1048576)\n");
-    fprintf(stderr, "    --threads <n>                    output formatting threads (default 8)\n");
+    fprintf(stderr, "    --batch <n>                      reads per GPU batch (default 4194304)\n");
+    fprintf(stderr, "    --threads <n>                    input scanning / output formatting threads (default 8)\n");
+    fprintf(stderr, "    --window-mb <n>                  input bytes scanned per pipeline step (default 256)\n");
     fprintf(stderr, "    <input_prefix>                   index prefix\n");
     fprintf(stderr, "    <input_fastq>                    input fastq\n");
 }
@@ -67,6 +176,7 @@ RbAlignArgs parse_args(int argc, char **argv) {  // rb_align.cpp:37-84
                                            {"devices", required_argument, 0, 'D'},
                                            {"batch", required_argument, 0, 'b'},
                                            {"threads", required_argument, 0, 't'},
+                                           {"window-mb", required_argument, 0, 'W'},
                                            {0, 0, 0, 0}};
     int c, long_index = 0;
     while ((c = getopt_long(argc, argv, "o:smh", long_options, &long_index)) != -1) {
@@ -86,6 +196,7 @@ RbAlignArgs parse_args(int argc, char **argv) {  // rb_align.cpp:37-84
                 break;
             case 'b': args.batch = strtoull(optarg, nullptr, 10); break;
             case 't': args.threads = atoi(optarg); break;
+            case 'W': args.window_mb = strtoull(optarg, nullptr, 10); break;
             default: print_help(); exit(1);
         }
     }
@@ -98,6 +209,8 @@ RbAlignArgs parse_args(int argc, char **argv) {  // rb_align.cpp:37-84
     if (args.outpre.empty()) args.outpre = args.inpre;
     if (args.batch == 0) args.batch = 1;
     if (args.gpus < 1) args.gpus = 1;
+    if (args.threads < 1) args.threads = 1;
+    if (args.window_mb < 1) args.window_mb = 1;
     if (args.devices.empty())
         for (int g = 0; g < args.gpus; ++g) args.devices.push_back(args.device + g);
     args.device = args.devices[0];
@@ -116,28 +229,24 @@ struct BatchResult {
 };
 
 // rb_get_range + locs_at + markers_at (rb_align.cpp:95-145) for reads [begin, end) of a batch on one replica
-void query_shard(rbg_index *ix, const RbAlignArgs &args, const PackedBatch &b, uint64_t begin, uint64_t end, BatchResult &r) {
+void query_shard(rbg_index *ix, const RbAlignArgs &args, const Window &b, uint64_t begin, uint64_t end, BatchResult &r) {
     r.begin = begin;
     r.end = end;
     const uint64_t N = end - begin;
     if (N == 0) return;
-    const uint8_t *seqs = reinterpret_cast<const uint8_t *>(b.seqs.data()) + b.off[begin];
-    std::vector<uint64_t> off_local;
-    const uint64_t *off = b.off.data();
-    if (begin) {  // the shard's offsets, re-based
-        off_local.resize(N + 1);
-        for (uint64_t i = 0; i <= N; ++i) off_local[i] = b.off[begin + i] - b.off[begin];
-        off = off_local.data();
-    }
+    // the sequences are read where the scanner found them (rbg_find_range_spans): no copy into a batch
+    const uint8_t *base = reinterpret_cast<const uint8_t *>(b.base);
+    const uint64_t *sb = b.recs.seq_begin.data() + begin;
+    const uint32_t *sl = b.recs.seq_len.data() + begin;
     r.lo.resize(N); r.hi.resize(N);
     if (args.sam) {  // rb_get_range(sa=true), rb_align.cpp:99-103
         r.k.resize(N);
-        rbwt::detail::check(rbg_find_range_w_toehold(ix, seqs, off, N, r.lo.data(), r.hi.data(), r.k.data()), "rbg_find_range_w_toehold");
+        rbwt::detail::check(rbg_find_range_spans(ix, base, sb, sl, N, r.lo.data(), r.hi.data(), r.k.data()), "rbg_find_range_spans");
         r.loc_off.resize(N + 1);
         rbwt::detail::check(rbg_locs_at(ix, r.lo.data(), r.hi.data(), r.k.data(), N, static_cast<uint64_t>(-1), r.loc_off.data(), &r.locs),
                             "rbg_locs_at");  // rb_align.cpp:125
     } else {
-        rbwt::detail::check(rbg_find_range(ix, seqs, off, N, r.lo.data(), r.hi.data()), "rbg_find_range");
+        rbwt::detail::check(rbg_find_range_spans(ix, base, sb, sl, N, r.lo.data(), r.hi.data(), nullptr), "rbg_find_range_spans");
     }
     if (args.markers) {  // rb_align.cpp:138
         r.mk_off.resize(N + 1);
@@ -146,11 +255,12 @@ void query_shard(rbg_index *ix, const RbAlignArgs &args, const PackedBatch &b, u
 }
 
 // the text of rb_report (rb_align.cpp:118-145) for reads [i0, i1)
-void format_range(const rbwt::RowBowt<> &rb, const RbAlignArgs &args, const PackedBatch &b, const BatchResult &r, size_t g0,
+void format_range(const rbwt::RowBowt<> &rb, const RbAlignArgs &args, const Window &b, const BatchResult &r, size_t g0,
                   size_t g1, std::string &out) {
-    for (size_t gi = g0; gi < g1; ++gi) {   // gi: index in the batch; i: index in the shard's results
+    out.reserve(out.size() + (g1 - g0) * 48);
+    for (size_t gi = g0; gi < g1; ++gi) {   // gi: index in the window; i: index in the shard's results
         const size_t i = gi - r.begin;
-        out.append(b.names, b.name_off[gi], b.name_off[gi + 1] - b.name_off[gi]);
+        out.append(b.base + b.recs.name_begin[gi], b.recs.name_len[gi]);
         out += " (";
         put_u64(out, r.lo[i]);
         out.push_back(',');
@@ -189,9 +299,9 @@ void format_range(const rbwt::RowBowt<> &rb, const RbAlignArgs &args, const Pack
 
 // query + format one batch: the batch is sharded over the replicas (contiguous blocks), the shards are
 // queried concurrently, formatting is split over worker threads, pieces concatenated in read order
-void report_batch(const rbwt::RowBowt<> &rb, const std::vector<rbg_index *> &reps, const RbAlignArgs &args, const PackedBatch &b,
-                  std::vector<std::string> &pieces) {
-    const size_t N = b.size();
+void report_batch(const rbwt::RowBowt<> &rb, const std::vector<rbg_index *> &reps, const RbAlignArgs &args, const Window &b, size_t w0,
+                  size_t w1, std::vector<std::string> &pieces) {
+    const size_t N = w1 - w0;
     const int G = static_cast<int>(reps.size());
     std::vector<BatchResult> res(G);
     {
@@ -199,7 +309,7 @@ void report_batch(const rbwt::RowBowt<> &rb, const std::vector<rbg_index *> &rep
         auto work = [&](int g) {
             uint64_t s0 = 0, s1 = 0;
             (void)rbg_shard_bounds(N, g, G, &s0, &s1);
-            query_shard(reps[g], args, b, s0, s1, res[g]);
+            query_shard(reps[g], args, b, w0 + s0, w0 + s1, res[g]);
         };
         for (int g = 1; g < G; ++g) th.emplace_back(work, g);
         work(0);
@@ -207,21 +317,22 @@ void report_batch(const rbwt::RowBowt<> &rb, const std::vector<rbg_index *> &rep
     }
     const size_t T = std::max<size_t>(1, std::min<size_t>({static_cast<size_t>(args.threads), (N + 4095) / 4096, size_t(64)}));
     // piece (g, t): reads of shard g, t-th slice
-    pieces.assign(static_cast<size_t>(G) * T, std::string());
+    const size_t first_piece = pieces.size();
+    pieces.resize(first_piece + static_cast<size_t>(G) * T);
     std::vector<std::thread> workers;
     for (int g = 0; g < G; ++g)
         for (size_t t = 0; t < T; ++t) {
             const size_t n = res[g].end - res[g].begin;
             const size_t a = res[g].begin + n * t / T, z = res[g].begin + n * (t + 1) / T;
             if (a == z) continue;
-            std::string *dst = &pieces[static_cast<size_t>(g) * T + t];
+            std::string *dst = &pieces[first_piece + static_cast<size_t>(g) * T + t];
             const BatchResult *r = &res[g];
             if (g == 0 && t == 0) continue;  // done on this thread below
             workers.emplace_back([&rb, &args, &b, r, a, z, dst] { format_range(rb, args, b, *r, a, z, *dst); });
         }
     {
         const size_t n = res[0].end - res[0].begin;
-        format_range(rb, args, b, res[0], res[0].begin, res[0].begin + n / T, pieces[0]);
+        format_range(rb, args, b, res[0], res[0].begin, res[0].begin + n / T, pieces[first_piece]);
     }
     for (auto &w : workers) w.join();
 }
@@ -260,46 +371,38 @@ int main(int argc, char **argv) {
     auto stop = std::chrono::high_resolution_clock::now();
     const std::chrono::duration<double> index_load_time = stop - start;
 
-    gzFile fq_fp = gzopen(args.fastq_fname.data(), "r");  // rb_align.cpp:169-173
-    if (fq_fp == NULL) {
+    InputSource input;  // rb_align.cpp:169-173
+    if (!input.open(args.fastq_fname, static_cast<unsigned>(args.threads), args.window_mb << 20)) {
         fprintf(stderr, "invalid file\n");
         exit(1);
     }
-    gzbuffer(fq_fp, 1 << 20);
-    FastxReader reader(fq_fp);
     start = std::chrono::high_resolution_clock::now();
-    // three overlapped stages: parse batch i+1 | query + format batch i | write batch i-1
+    // three overlapped stages: scan window i+1 | query + format window i (in GPU batches of --batch reads) | write window i-1
     int err = 0;
-    auto parse = [&](PackedBatch &b) {
-        b.clear();
-        int e = 0;
-        while (b.size() < args.batch && (e = reader.next(b)) == 0) {}
-        return e;
-    };
-    PackedBatch cur, nxt;
-    err = parse(cur);
+    Window cur, nxt;
+    err = input.next(cur);
     std::future<void> writer;
     std::vector<std::string> pieces, writing;
-    while (cur.size() > 0) {
-        std::future<int> parser;
+    while (true) {
+        std::future<int> scanner;
         const bool more = err == 0;
-        if (more) parser = std::async(std::launch::async, parse, std::ref(nxt));
-        report_batch(rb, reps, args, cur, pieces);
+        if (more) scanner = std::async(std::launch::async, [&input, &nxt] { return input.next(nxt); });
+        pieces.clear();
+        for (size_t w0 = 0; w0 < cur.size(); w0 += args.batch)
+            report_batch(rb, reps, args, cur, w0, std::min<size_t>(cur.size(), w0 + args.batch), pieces);
         if (writer.valid()) writer.get();
         writing.swap(pieces);
         writer = std::async(std::launch::async, [&writing] {
             for (const std::string &p : writing) fwrite(p.data(), 1, p.size(), stdout);
         });
         if (!more) break;
-        err = parser.get();
-        cur.clear();
+        err = scanner.get();
         std::swap(cur, nxt);
     }
     if (writer.valid()) writer.get();
     fflush(stdout);
     stop = std::chrono::high_resolution_clock::now();
     const std::chrono::duration<double> total_query_time = stop - start;
-    gzclose(fq_fp);
     switch (err) {  // rb_align.cpp:182-191
         case -2:
             fprintf(stderr, "ERROR: truncated quality string\n");

@@ -7,6 +7,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import rowbowt_amd as ra
+from rowbowt_amd import capi
 from rowbowt_amd.tools import synth_pangenome as sp
 
 dev = torch.device("cuda:0")
@@ -21,12 +22,30 @@ off = (np.arange(N + 1, dtype=np.uint64) * m)
 del text, reads
 torch.cuda.empty_cache()
 rb = ra.RowBowt.from_runs(inp["heads"], inp["lens"], inp["ssa"], inp["esa"], device=0)
-for rep in range(2):
-    t0 = time.perf_counter(); lo, hi = rb.find_range(seqs, off); t1 = time.perf_counter()
-    lo, hi, k = rb.find_range_w_toehold(seqs, off); t2 = time.perf_counter()
-    loc_off, locs = rb.locs_at(lo, hi, k); t3 = time.perf_counter()
-print(f"host-pointer API, {N} x {m} bp reads (1.0 GB H2D), n={inp['n']} r={inp['r']}:")
-print(f"  rbg_find_range                      {t1 - t0:.3f} s  -> {N / (t1 - t0):.3e} reads/s")
-print(f"  rbg_find_range_w_toehold            {t2 - t1:.3f} s  -> {N / (t2 - t1):.3e} reads/s")
+L = ra.lib()
+lo, hi, k, cnt = (np.zeros(N, np.uint64) for _ in range(4))
+p = lambda a: a.ctypes.data_as(capi.VP)
+print(f"host-pointer API, {N} x {m} bp reads in pageable host memory (numpy), n={inp['n']} r={inp['r']}, {os.cpu_count()} logical CPUs; best of 4 calls")
+for packed, what in ((1, "2-bit codes packed by CPU threads (default)"), (0, "bytes over PCIe")):
+    capi.set_default_option(capi.OPT_PACKED_READS, packed)
+    res = {}
+    for name, fn in (("rbg_find_range", lambda: L.rbg_find_range(rb.h, p(seqs), p(off), N, p(lo), p(hi))),
+                     ("rbg_count", lambda: L.rbg_count(rb.h, p(seqs), p(off), N, p(cnt))),
+                     ("rbg_find_range_w_toehold", lambda: L.rbg_find_range_w_toehold(rb.h, p(seqs), p(off), N, p(lo), p(hi), p(k)))):
+        best = 1e9
+        for rep in range(4):
+            t0 = time.perf_counter()
+            assert fn() == 0
+            best = min(best, time.perf_counter() - t0)
+        res[name] = best
+    print(f"  reads cross as {what}:")
+    for name, t in res.items():
+        print(f"    {name:28s} {t * 1e3:8.1f} ms  -> {N / t:.3e} reads/s")
+capi.set_default_option(capi.OPT_PACKED_READS, 1)
+t1 = time.perf_counter()
+lo, hi, k = rb.find_range_w_toehold(seqs, off)
+t2 = time.perf_counter()
+loc_off, locs = rb.locs_at(lo, hi, k)
+t3 = time.perf_counter()
 print(f"  rbg_locs_at ({len(locs)} locations, {len(locs) * 8 / 1e9:.1f} GB D2H)  {t3 - t2:.3f} s")
-print(f"  count+locate end to end            {t3 - t1:.3f} s  -> {N / (t3 - t1):.3e} reads/s (PCIe + per-call hipMalloc inclusive)")
+print(f"  count+locate end to end            {t3 - t1:.3f} s  -> {N / (t3 - t1):.3e} reads/s")
