@@ -44,6 +44,20 @@ struct ScanState {
 
 enum ScanStop { kScanEnd = 0, kScanNeedMore = 1, kScanTruncQual = -2 };
 
+// first '>' or '@' in [p, e), looked for a stretch at a time (a memchr for a character the file does not contain
+// would otherwise run to the end of the buffer for every record)
+inline const char *find_header_char(const char *p, const char *e) {
+    while (p < e) {
+        const size_t n = static_cast<size_t>(e - p) < 256 ? static_cast<size_t>(e - p) : 256;
+        const char *a = static_cast<const char *>(memchr(p, '@', n));
+        const char *b = static_cast<const char *>(memchr(p, '>', a ? static_cast<size_t>(a - p) : n));
+        if (b) return b;
+        if (a) return a;
+        p += n;
+    }
+    return nullptr;
+}
+
 // Scans buf[pos, end) as kseq_read would, appending complete records to `out`.  `final` = the buffer ends the
 // stream (otherwise a record that touches `end` is left for the next buffer: *resume = where it starts, with the
 // state to resume in).  `limit`: stop before starting a record at or beyond this offset (segment scans).
@@ -61,9 +75,7 @@ inline int scan_records(const char *buf, uint64_t pos, uint64_t end, bool final,
         const ScanState rec_state = st;
         // -- jump to the next header character, anywhere (kseq.h:183-187)
         if (st.last_char == 0) {
-            const char *a = pos < end ? static_cast<const char *>(memchr(buf + pos, '>', end - pos)) : nullptr;
-            const char *b = pos < end ? static_cast<const char *>(memchr(buf + pos, '@', a ? static_cast<size_t>(a - (buf + pos)) : end - pos)) : nullptr;
-            const char *h = b ? b : a;
+            const char *h = find_header_char(buf + pos, buf + end);
             if (!h) {
                 if (!final) return need_more(end, st);   // nothing but skippable bytes so far: they can go
                 *resume = end;

@@ -1415,7 +1415,7 @@ struct WsLease {
     }
 };
 
-constexpr uint64_t kHostChunkReads = uint64_t(1) << 21;    // reads per in-flight chunk ...
+constexpr uint64_t kHostChunkReads = uint64_t(1) << 20;    // reads per in-flight chunk ...
 constexpr uint64_t kHostChunkBytes = uint64_t(384) << 20;  // ... and symbols per chunk (long reads)
 
 static int find_range_host_core(rbg_index *ix, const HostReads &R, uint64_t N, uint64_t *lo, uint64_t *hi, uint64_t *ssamp,
@@ -1449,7 +1449,7 @@ static int find_range_host_core(rbg_index *ix, const HostReads &R, uint64_t N, u
     const bool acgt = h.major_byte[0] == 'A' && h.major_byte[1] == 'C' && h.major_byte[2] == 'G' && h.major_byte[3] == 'T';
     if (!W.team) {
         const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-        W.team.reset(new rbg_hostpath::ThreadTeam(std::min(16u, std::max(1u, hw / 2))));
+        W.team.reset(new rbg_hostpath::ThreadTeam(std::min(64u, std::max(1u, hw / 4))));
         W.bad.resize(W.team->size());
     }
     rbg_hostpath::ThreadTeam &team = *W.team;
@@ -1469,13 +1469,16 @@ static int find_range_host_core(rbg_index *ix, const HostReads &R, uint64_t N, u
         if (!s.busy) return RBG_OK;
         if (hipEventSynchronize(s.done) != hipSuccess) return RBG_ENODEV;
         const uint64_t *src = static_cast<const uint64_t *>(s.h_out);
-        uint64_t col = 0;
-        if (lo) {
-            std::memcpy(lo + s.begin, src + col * s.cnt, s.cnt * 8); ++col;
-            std::memcpy(hi + s.begin, src + col * s.cnt, s.cnt * 8); ++col;
-        }
-        if (ssamp) { std::memcpy(ssamp + s.begin, src + col * s.cnt, s.cnt * 8); ++col; }
-        if (count) { std::memcpy(count + s.begin, src + col * s.cnt, s.cnt * 8); ++col; }
+        uint64_t *dsts[4];
+        int ncol = 0;
+        if (lo) { dsts[ncol++] = lo + s.begin; dsts[ncol++] = hi + s.begin; }
+        if (ssamp) dsts[ncol++] = ssamp + s.begin;
+        if (count) dsts[ncol++] = count + s.begin;
+        const uint64_t cnt = s.cnt;
+        par(cnt, [&](unsigned t) {  // pinned -> the caller's (pageable) arrays, every member a slice of every column
+            const uint64_t i0 = cnt * t / T, i1 = cnt * (t + 1) / T;
+            for (int c = 0; c < ncol; ++c) std::memcpy(dsts[c] + i0, src + static_cast<uint64_t>(c) * cnt + i0, (i1 - i0) * 8);
+        });
         s.busy = false;
         return RBG_OK;
     };
@@ -1489,8 +1492,9 @@ static int find_range_host_core(rbg_index *ix, const HostReads &R, uint64_t N, u
         while (e < N && e - b < kHostChunkReads && sym < kHostChunkBytes) sym += R.length(e++);
         const uint64_t cnt = e - b;
         Slot &s = W.slot[which];
+        Slot &prev = W.slot[which ^ 1];
         which ^= 1;
-        if ((rc = drain(s))) break;
+        if ((rc = drain(s))) break;   // (only when more than two chunks are in flight: normally drained below)
         // device columns: lo, hi, [ssamp], [count]
         const uint64_t dev_cols = 2 + (ssamp ? 1 : 0) + (count ? 1 : 0);
         size_t in_bytes;
@@ -1587,6 +1591,8 @@ static int find_range_host_core(rbg_index *ix, const HostReads &R, uint64_t N, u
         s.cnt = cnt;
         s.busy = true;
         b = e;
+        // while the GPU works on this chunk: hand the previous one to the caller
+        if ((rc = drain(prev))) break;
     }
     (void)nout;
     for (Slot &s : W.slot) {

@@ -30,7 +30,9 @@ def write_fastq(path, n):
 
 
 path = "/tmp/cli_reads.fq"
+t0 = time.perf_counter()
 write_fastq(path, N)
+print(f"wrote {path} in {time.perf_counter() - t0:.1f} s", flush=True)
 os.makedirs("/tmp/cli_idx", exist_ok=True)
 for suf in (".rbwt", ".tsa", ".mab"):
     subprocess.check_call(["cp", os.path.join(ROOT, "tests/data/small.fa" + suf), "/tmp/cli_idx/idx" + suf])
@@ -42,12 +44,19 @@ print(f"plain FASTQ, {N} x {m} bp, {os.path.getsize(path) / 1e6:.0f} MB in the p
 for flags, out in (([], "/dev/null"), (["--threads", "16"], "/dev/null"), (["--threads", "32"], "/dev/null"), (["--threads", "16"], "/tmp/cli_out.txt"),
                    (["-s", "--threads", "16"], "/tmp/cli_out.txt"), (["-s", "-m", "--threads", "16"], "/tmp/cli_out.txt")):
     t0 = time.perf_counter()
-    p = subprocess.run([exe] + flags + ["/tmp/cli_idx/idx", path], stdout=open(out, "wb"), stderr=subprocess.PIPE)
+    try:
+        p = subprocess.run([exe] + flags + ["/tmp/cli_idx/idx", path], stdout=open(out, "wb"), stderr=subprocess.PIPE, timeout=180)
+    except subprocess.TimeoutExpired:
+        print(f"rb_align {' '.join(flags)} -> {out}: TIMEOUT after 180 s", flush=True)
+        continue
     dt = time.perf_counter() - t0
+    if p.returncode != 0:
+        print(f"rb_align {' '.join(flags)} -> {out}: exit {p.returncode}: {p.stderr.decode()[-300:]}", flush=True)
+        continue
     load_s, query_s = (float(x) for x in p.stderr.decode().strip().splitlines()[-1].split())
     sz = os.path.getsize(out) if out != "/dev/null" else 0
     print(f"rb_align {' '.join(flags) or '(count, 8 threads)':24s} -> {out:16s}: process {dt:.2f} s (index load {load_s:.2f} s); query loop {query_s:.3f} s = "
-          f"{N / query_s:.3e} reads/s" + (f"; {sz / 1e6:.0f} MB of text" if sz else ""))
+          f"{N / query_s:.3e} reads/s" + (f"; {sz / 1e6:.0f} MB of text" if sz else ""), flush=True)
 
 if NM:
     pathm = "/tmp/cli_reads_m.fq"
@@ -55,7 +64,7 @@ if NM:
     exe2 = os.path.join(ROOT, "rowbowt_amd", "rb_markers")
     for flags in (["--threads", "16"], ["--heuristic", "--best-strand-only", "--min-seed-length", "30", "--threads", "16"]):
         t0 = time.perf_counter()
-        p = subprocess.run([exe2] + flags + ["/tmp/cli_idx/idx", pathm], stdout=open("/tmp/cli_out.txt", "wb"), stderr=subprocess.PIPE)
+        p = subprocess.run([exe2] + flags + ["/tmp/cli_idx/idx", pathm], stdout=open("/tmp/cli_out.txt", "wb"), stderr=subprocess.PIPE, timeout=300)
         dt = time.perf_counter() - t0
         sz = os.path.getsize("/tmp/cli_out.txt")
         print(f"rb_markers {' '.join(flags)}: {NM} x {m} bp FASTQ -> {sz / 1e6:.0f} MB of text in {dt:.2f} s = {NM / dt:.3e} reads/s"
