@@ -146,7 +146,7 @@ struct RbAlignArgs {  // rb_align.cpp:17-24
     int gpus = 1;     // replicas: devices device .. device + gpus - 1; every batch is sharded over them
     std::vector<int> devices;  // --devices a,b,...: the replicas' devices, in shard order (overrides --gpu/--gpus)
     uint64_t batch = 1u << 22;
-    int threads = 8;  // input scanning and output formatting workers
+    int threads = static_cast<int>(std::min(32u, std::max(8u, std::thread::hardware_concurrency() / 8)));  // input scanning and output formatting workers
     uint64_t window_mb = 256;  // input bytes scanned per pipeline step
 };
 
@@ -160,7 +160,7 @@ void print_help() {  // rb_align.cpp:26-35
     fprintf(stderr, "    --gpus <G>                       replicate the index on G devices (from --gpu on) and shard every batch over them\n");
     fprintf(stderr, "    --devices <a,b,...>              the same with an explicit device list\n");
     fprintf(stderr, "    --batch <n>                      reads per GPU batch (default 4194304)\n");
-    fprintf(stderr, "    --threads <n>                    input scanning / output formatting threads (default 8)\n");
+    fprintf(stderr, "    --threads <n>                    input scanning / output formatting threads (default: an eighth of the CPUs, 8..32)\n");
     fprintf(stderr, "    --window-mb <n>                  input bytes scanned per pipeline step (default 256)\n");
     fprintf(stderr, "    <input_prefix>                   index prefix\n");
     fprintf(stderr, "    <input_fastq>                    input fastq\n");

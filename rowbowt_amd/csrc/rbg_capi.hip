@@ -1449,7 +1449,9 @@ static int find_range_host_core(rbg_index *ix, const HostReads &R, uint64_t N, u
     const bool acgt = h.major_byte[0] == 'A' && h.major_byte[1] == 'C' && h.major_byte[2] == 'G' && h.major_byte[3] == 'T';
     if (!W.team) {
         const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-        W.team.reset(new rbg_hostpath::ThreadTeam(std::min(64u, std::max(1u, hw / 4))));
+        unsigned nt = std::min(64u, std::max(1u, hw / 4));
+        if (const char *e = std::getenv("RBG_HOST_THREADS")) nt = static_cast<unsigned>(std::max(1, std::min(256, std::atoi(e))));
+        W.team.reset(new rbg_hostpath::ThreadTeam(nt));
         W.bad.resize(W.team->size());
     }
     rbg_hostpath::ThreadTeam &team = *W.team;

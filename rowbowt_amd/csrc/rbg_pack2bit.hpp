@@ -6,7 +6,46 @@
 #include <cstdint>
 #include <cstring>
 
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
+
 namespace rbg_hostpath {
+
+#if defined(__x86_64__)
+// 32 symbols per step with AVX2 (chosen at run time; the 64-bit SWAR loop below is the portable path and packs
+// what is left).  Returns the number of symbols packed (a multiple of 32); *bad is OR-ed with a non-zero value if
+// any of them is not A, C, G or T.
+__attribute__((target("avx2"))) inline uint64_t pack_blocks_avx2(const uint8_t *q, uint64_t m, uint8_t *dst_bytes, uint64_t *bad) {
+    const __m256i rev = _mm256_setr_epi8(15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0, 15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0);
+    const __m256i three = _mm256_set1_epi8(3), one = _mm256_set1_epi8(1);
+    const __m256i letters = _mm256_setr_epi8('A', 'C', 'G', 'T', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 'A', 'C', 'G', 'T', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0);
+    const __m256i w14 = _mm256_set1_epi16(0x0401), w116 = _mm256_set1_epi32(0x00100001);
+    const __m256i pick = _mm256_setr_epi8(0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1);
+    __m256i ok = _mm256_set1_epi8(-1);
+    uint64_t t = 0;
+    while (t + 32 <= m) {
+        __m256i v = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(q + (m - t - 32)));
+        v = _mm256_permute2x128_si256(_mm256_shuffle_epi8(v, rev), _mm256_shuffle_epi8(v, rev), 1);   // q[m-1-t] first
+        const __m256i x = _mm256_and_si256(_mm256_srli_epi16(v, 1), three);                             // A 0, C 1, T 2, G 3
+        const __m256i code = _mm256_xor_si256(x, _mm256_and_si256(_mm256_srli_epi16(x, 1), one));        // A 0, C 1, G 2, T 3
+        ok = _mm256_and_si256(ok, _mm256_cmpeq_epi8(_mm256_shuffle_epi8(letters, code), v));
+        const __m256i p4 = _mm256_maddubs_epi16(code, w14);      // s[2i] + 4 s[2i+1]
+        const __m256i p8 = _mm256_madd_epi16(p4, w116);          // ... + 16 (s[2i+2] + 4 s[2i+3]): one byte per 32-bit lane
+        const __m256i by = _mm256_shuffle_epi8(p8, pick);
+        const uint32_t lo4 = static_cast<uint32_t>(_mm256_extract_epi32(by, 0)), hi4 = static_cast<uint32_t>(_mm256_extract_epi32(by, 4));
+        const uint64_t out = static_cast<uint64_t>(lo4) | (static_cast<uint64_t>(hi4) << 32);
+        std::memcpy(dst_bytes + (t >> 2), &out, 8);
+        t += 32;
+    }
+    if (_mm256_movemask_epi8(ok) != -1) *bad |= 1;
+    return t;
+}
+inline bool have_avx2() {
+    static const bool v = __builtin_cpu_supports("avx2");
+    return v;
+}
+#endif
 
 // ---- 2-bit packing of one read, in the order the search consumes it --------------------------------------------------
 // Symbol t of the stream is q[m-1-t] (the search runs right to left, rowbowt.hpp:127-129) at bits [2t, 2t+2): code
@@ -18,6 +57,9 @@ inline bool pack_read_acgt(const uint8_t *q, uint64_t m, uint32_t *dst) {
     const uint64_t nhalf = nwords * 2;
     uint64_t t = 0;        // symbols packed so far
     uint64_t bad = 0;
+#if defined(__x86_64__)
+    if (m >= 32 && have_avx2()) t = pack_blocks_avx2(q, m, reinterpret_cast<uint8_t *>(dst), &bad);
+#endif
     while (t + 8 <= m) {   // eight symbols per step, SWAR
         uint64_t w;
         std::memcpy(&w, q + (m - t - 8), 8);
