@@ -1467,9 +1467,17 @@ static int find_range_host_core(rbg_index *ix, const HostReads &R, uint64_t N, u
     (void)need_lohi_dev;
 
     int rc = RBG_OK;
+    const bool trace = std::getenv("RBG_HOST_TRACE") != nullptr;   // per-call breakdown on stderr
+    double t_pack = 0, t_wait = 0, t_out = 0, t_enq = 0;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    const auto t_call = now();
     auto drain = [&](Slot &s) -> int {  // wait for the chunk in flight in `s`, hand its results to the caller
         if (!s.busy) return RBG_OK;
+        const auto tw0 = now();
         if (hipEventSynchronize(s.done) != hipSuccess) return RBG_ENODEV;
+        const auto tw1 = now();
+        t_wait += secs(tw0, tw1);
         const uint64_t *src = static_cast<const uint64_t *>(s.h_out);
         uint64_t *dsts[4];
         int ncol = 0;
@@ -1481,6 +1489,7 @@ static int find_range_host_core(rbg_index *ix, const HostReads &R, uint64_t N, u
             const uint64_t i0 = cnt * t / T, i1 = cnt * (t + 1) / T;
             for (int c = 0; c < ncol; ++c) std::memcpy(dsts[c] + i0, src + static_cast<uint64_t>(c) * cnt + i0, (i1 - i0) * 8);
         });
+        t_out += secs(tw1, now());
         s.busy = false;
         return RBG_OK;
     };
@@ -1489,9 +1498,25 @@ static int find_range_host_core(rbg_index *ix, const HostReads &R, uint64_t N, u
     uint64_t b = 0;
     int which = 0;
     while (b < N && !rc) {
-        // the chunk [b, e): bounded in reads and in symbols
-        uint64_t e = b, sym = 0;
-        while (e < N && e - b < kHostChunkReads && sym < kHostChunkBytes) sym += R.length(e++);
+        // the chunk [b, e): bounded in reads and in symbols (no pass over the reads just to find the bound: the packed
+        // layout has the symbol count in its offsets, spans are sampled and measured by the staging pass itself)
+        uint64_t e = std::min<uint64_t>(N, b + kHostChunkReads), sym = 0;
+        if (R.off) {
+            while (e > b + 1 && R.off[e] - R.off[b] > kHostChunkBytes) e = b + (e - b) / 2;
+            sym = R.off[e] - R.off[b];
+        } else {
+            uint64_t mx = 0;
+            for (uint64_t i = b; i < e; i += 1 + (e - b) / 64) mx = std::max<uint64_t>(mx, R.len[i]);
+            while (e > b + 1 && (e - b) * std::max<uint64_t>(mx, 64) > 4 * kHostChunkBytes) e = b + (e - b) / 2;   // long reads: fewer per chunk
+            std::vector<uint64_t> ps(T, 0);
+            par(e - b, [&](unsigned t) {
+                const uint64_t i0 = b + (e - b) * t / T, i1 = b + (e - b) * (t + 1) / T;
+                uint64_t c = 0;
+                for (uint64_t i = i0; i < i1; ++i) c += R.len[i];
+                ps[t] = c;
+            });
+            for (uint64_t v : ps) sym += v;
+        }
         const uint64_t cnt = e - b;
         Slot &s = W.slot[which];
         Slot &prev = W.slot[which ^ 1];
@@ -1504,6 +1529,7 @@ static int find_range_host_core(rbg_index *ix, const HostReads &R, uint64_t N, u
         else in_bytes = (cnt + 1) * 8 + 16 + sym + 32;
         const int er = W.ensure(s, in_bytes, dev_cols * cnt * 8);
         if (er) { rc = er == 2 ? RBG_ENOMEM : RBG_ENODEV; break; }
+        const auto tp0 = now();
         char *hin = static_cast<char *>(s.h_in);
         char *din = static_cast<char *>(s.d_in);
         uint64_t *dout = static_cast<uint64_t *>(s.d_out);
@@ -1538,6 +1564,7 @@ static int find_range_host_core(rbg_index *ix, const HostReads &R, uint64_t N, u
                 }
             });
             used = chunks_at + part[T] * 16;
+            t_pack += secs(tp0, now());
             if (hipMemcpyAsync(din, hin, used, hipMemcpyHostToDevice, s.st) != hipSuccess ||
                 launch_find_range_packed_only(ix->dev, ix->cfg, reinterpret_cast<const uint2 *>(din), reinterpret_cast<const uint4 *>(din + chunks_at), cnt,
                                               d_lo, d_hi, d_ss, s.st))
@@ -1571,6 +1598,7 @@ static int find_range_host_core(rbg_index *ix, const HostReads &R, uint64_t N, u
             });
             off2[cnt] = part[T];
             used = bytes_at + part[T];
+            t_pack += secs(tp0, now());
             if (hipMemcpyAsync(din, hin, used, hipMemcpyHostToDevice, s.st) != hipSuccess ||
                 launch_find_range(ix->dev, ix->cfg, reinterpret_cast<const uint8_t *>(din + bytes_at), reinterpret_cast<const uint64_t *>(din), cnt, d_lo,
                                   d_hi, d_ss, s.st))
@@ -1593,6 +1621,7 @@ static int find_range_host_core(rbg_index *ix, const HostReads &R, uint64_t N, u
         s.cnt = cnt;
         s.busy = true;
         b = e;
+        t_enq = secs(t_call, now()) - t_pack - t_wait - t_out;
         // while the GPU works on this chunk: hand the previous one to the caller
         if ((rc = drain(prev))) break;
     }
@@ -1603,6 +1632,10 @@ static int find_range_host_core(rbg_index *ix, const HostReads &R, uint64_t N, u
         if (rc && s.busy) { (void)hipStreamSynchronize(s.st); s.busy = false; }
     }
     if (rc) return rc;
+    if (trace)
+        std::fprintf(stderr, "rbg host call: %llu reads, %s, %u threads: %.2f ms = stage %.2f + enqueue/other %.2f + wait for the GPU %.2f + copy out %.2f\n",
+                     static_cast<unsigned long long>(N), pack ? "2-bit" : "bytes", T, secs(t_call, now()) * 1e3, t_pack * 1e3, t_enq * 1e3, t_wait * 1e3,
+                     t_out * 1e3);
     // reads the 2-bit form cannot express (any symbol outside the k-mer alphabet): searched from their bytes
     std::vector<uint64_t> bad;
     for (auto &v : W.bad) bad.insert(bad.end(), v.begin(), v.end());
