@@ -547,7 +547,33 @@ int upload(rbg_index *ix) {
     ix->kmer_steps_requested = static_cast<uint64_t>(levels());
     ix->hbm_free_at_load = free_b;
     ix->hbm_budget = budget;
-    while (need() > budget && !h.pair.empty()) {
+    // Over budget: first give the k-mer levels wider buckets, deepest level first (their runs are sparse: a table
+    // goes to the widest bucket that still holds about half a run start on average, at most 4096 rows, in the
+    // wide-slot encoding of rbg_dev.h -- a few per cent slower per step), then drop the deepest level
+    // and try again.  At pangenome scale this keeps a level more than dropping alone.
+    auto widen = [&](std::vector<SymTable> &lvl) {
+        if (h.n >> 40) return;  // wide slots carry 40-bit ranks
+        for (SymTable &t : lvl) {
+            const double rows_per_run = static_cast<double>(h.n) / static_cast<double>(std::max<uint64_t>(1, t.nruns));
+            uint32_t want = 0;
+            while (want < kMaxWideShift && static_cast<double>(uint64_t(2) << want) <= rows_per_run) ++want;   // 2^want <= rows_per_run / 2
+            if (want > t.shift) t.shift = want;
+        }
+    };
+    bool widened = false;
+    while (need() > budget && !h.pair.empty() && !runs_layout) {
+        if (!widened && g_opt_deep_shift.load() < 0 && g_opt_rank_shift.load() < 0) {
+            widened = true;
+            for (std::vector<SymTable> *lvl : {&h.quint, &h.quad, &h.triple, &h.pair})
+                if (!lvl->empty() && need() > budget) {
+                    const size_t before = need();
+                    widen(*lvl);
+                    if (need() != before)
+                        std::fprintf(stderr, "rbg: replica of %.1f GB exceeds the %.1f GB budget: wider buckets for the %zu-table k-mer level (%.1f GB)\n",
+                                     before / 1e9, budget / 1e9, lvl->size(), need() / 1e9);
+                }
+            continue;
+        }
         std::vector<SymTable> &deepest = !h.quint.empty() ? h.quint : !h.quad.empty() ? h.quad : !h.triple.empty() ? h.triple : h.pair;
         std::fprintf(stderr, "rbg: replica of %.1f GB exceeds the %.1f GB budget: dropping the %zu-table k-mer level\n",
                      need() / 1e9, budget / 1e9, deepest.size());
