@@ -654,8 +654,13 @@ def main():
                 res[name] = min(e[t].elapsed_time(e[t + 1]) for t in range(3))
             return res
 
-        rows = [{"symbols_per_gather": int(ix.kmer_steps), "hbm_bytes": int(ix.hbm_bytes), "ms": time_search()}]
+        rows = [{"layout": "slots", "symbols_per_gather": int(ix.kmer_steps), "hbm_bytes": int(ix.hbm_bytes), "ms": time_search()}]
         top = int(ix.kmer_steps)
+        # reference outputs of the whole batch from the slot tables (oracle-checked above on a sample), for the run-indexed row
+        step()
+        torch.cuda.synchronize()
+        ref_out = [t.clone() for t in (d_lo, d_hi, d_k, d_loc_off)]
+        ref_locs = d_locs[:total_locs].clone()
         for lvl in range(top - 1, 0, -1):
             rb.close()
             torch.cuda.empty_cache()
@@ -664,7 +669,33 @@ def main():
                 rb = ra.RowBowt.from_runs(inp["heads"], inp["lens"], inp["ssa"], inp["esa"], device=local_rank)
             finally:
                 capi.set_default_option(capi.OPT_KMER_STEPS, 5)
-            rows.append({"symbols_per_gather": int(rb.info().kmer_steps), "hbm_bytes": int(rb.info().hbm_bytes), "ms": time_search()})
+            rows.append({"layout": "slots", "symbols_per_gather": int(rb.info().kmer_steps), "hbm_bytes": int(rb.info().hbm_bytes), "ms": time_search()})
+        # the run-indexed layout (space proportional to r; wave-cooperative predecessor search): same batch, same outputs
+        rb.close()
+        torch.cuda.empty_cache()
+        capi.set_default_option(capi.OPT_RANK_LAYOUT, capi.LAYOUT_RUNS)
+        try:
+            rb = ra.RowBowt.from_runs(inp["heads"], inp["lens"], inp["ssa"], inp["esa"], device=local_rank)
+        finally:
+            capi.set_default_option(capi.OPT_RANK_LAYOUT, capi.LAYOUT_AUTO)
+        ms_r = time_search()
+        step()
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        k_toehold(); k_plan(); k_order()
+        e[0].record(stream)
+        k_fill()
+        e[1].record(stream)
+        torch.cuda.synchronize()
+        ms_r["k_locate_fill"] = e[0].elapsed_time(e[1])
+        same = all(bool((a == b).all().item()) for a, b in zip(ref_out, (d_lo, d_hi, d_k, d_loc_off))) and bool((ref_locs == d_locs[:total_locs]).all().item())
+        rows.append({"layout": "runs", "symbols_per_gather": 1, "hbm_bytes": int(rb.info().hbm_bytes), "ms": ms_r,
+                     "identical_to_slot_path_on_the_whole_batch": same,
+                     "count_locate_reads_per_s": N / ((ms_r["k_find_range<toehold>"] + ms_r["k_locate_fill"] + ms_plan + ms_order) * 1e-3)})
+        if not same:
+            out["space_speed"] = {"rows": rows}
+            print(json.dumps(out))
+            raise SystemExit("PARITY FAILURE: the run-indexed layout disagrees with the slot tables")
+        del ref_out, ref_locs
         out["space_speed"] = {"unit": "ms per launch of this run's batch (best of 3)", "rows": rows,
                               "note": "RBG_OPT_KMER_STEPS / the HBM budget rule pick the row; rbg_info reports which (symbols_per_gather, "
                                       "hbm_free_at_load, hbm_budget)"}

@@ -42,6 +42,9 @@ def main():
     ap.add_argument("--verify-sa", action="store_true", help="also build the suffix array by prefix doubling and compare (n < 2.5e9 only)")
     ap.add_argument("--count-only", action="store_true")
     ap.add_argument("--layout", choices=("auto", "slots", "runs"), default="auto")
+    ap.add_argument("--hbm-reserve-gb", type=float, default=45.0,
+                    help="HBM left to this tool's own buffers (reads, ranges, locations, sort workspace): the index replica gets the rest of "
+                         "what is free once the text is resident (0 = the library's default budget, three quarters of the free HBM)")
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -90,6 +93,9 @@ def main():
     torch.cuda.empty_cache()
     if args.layout != "auto":
         capi.set_default_option(capi.OPT_RANK_LAYOUT, {"slots": 1, "runs": 2}[args.layout])
+    if args.hbm_reserve_gb > 0:
+        free_b, _total = torch.cuda.mem_get_info(dev)
+        capi.set_default_option(capi.OPT_HBM_BUDGET_MB, max(1024, int((free_b - args.hbm_reserve_gb * 1e9) / 2**20)))
     t0 = time.time()
     rb = ra.RowBowt.from_runs(inp["heads"], inp["lens"], inp["ssa"], inp["esa"], device=local_rank)
     ix = rb.info()
