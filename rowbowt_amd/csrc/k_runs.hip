@@ -1,27 +1,36 @@
 // k_runs.hip -- the run-indexed layout (RBG_LAYOUT_RUNS, rbg_dev.h DevTree): K1/K2 and K3 with space proportional
 // to r.  rank and phi are predecessor searches over sorted run boundaries, as in the reference
 // (rle_string::rank rle_string.hpp:131-161, ToeholdSA::phi toehold_sa.hpp:56-72), done the way the hardware
-// likes them: the coarsest level of the 64-ary sampled index sits in LDS (per-lane binary search), every level
-// below it is probed by the WAVE -- one coalesced load of the 64-entry block, a 64-wide compare, a ballot and a
-// popcount -- for one lane's query after the other, several probes in flight.  One lane still owns one read
-// (K1/K2) or one phi chain (K3); lanes whose own work is finished keep serving the others' probes.
+// likes them: the coarsest level of the 16-ary sampled index sits in LDS (per-lane binary search), every level
+// below it is probed by the WAVE -- each 16-lane row loads the 16-entry block of one of its lanes' queries with one
+// coalesced request (64 B of keys, 128 B of {key, value} pairs at 4-byte positions), compares, ballots and counts;
+// four queries per load instruction, all sixteen rounds of a level in flight together.  One lane still owns one
+// read (K1/K2) or one phi chain (K3); lanes whose own work is finished keep serving the others' probes.
 #include "rbg_device.hpp"
 
 namespace rbg {
 namespace {
 
-constexpr int kCoopGroup = 4;  // owners whose block loads are in flight together (each up to two blocks)
-
-__device__ __forceinline__ uint32_t rl32(uint32_t v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
-__device__ __forceinline__ uint64_t rl64(uint64_t v, int lane) {
-    return (static_cast<uint64_t>(rl32(static_cast<uint32_t>(v >> 32), lane)) << 32) | rl32(static_cast<uint32_t>(v), lane);
-}
-__device__ __forceinline__ int first_lane(uint64_t mask) { return __builtin_amdgcn_readfirstlane(__builtin_ctzll(mask)); }
+constexpr int kFan = kTreeFan;                 // entries per block = lanes that probe one block together
+constexpr int kRows = kWave / kFan;            // blocks probed by one wave-wide load instruction
+static_assert(kFan == 16 && kRows == 4, "the probes below are written for 16-lane rows of a 64-lane wave");
 
 // pair of P as the kernels load it (one request per lane)
 template <typename P> struct PairOf;
 template <> struct PairOf<uint32_t> { typedef unsigned int vec __attribute__((ext_vector_type(2))); };
 template <> struct PairOf<uint64_t> { typedef unsigned long long vec __attribute__((ext_vector_type(2))); };
+
+// value of lane `j` of this lane's 16-lane row
+__device__ __forceinline__ uint32_t row_get(uint32_t v, uint32_t rowbase, int j) { return __shfl(v, static_cast<int>(rowbase) | j, kWave); }
+__device__ __forceinline__ uint64_t row_get(uint64_t v, uint32_t rowbase, int j) { return __shfl(v, static_cast<int>(rowbase) | j, kWave); }
+// the same from a lane chosen at run time (same in every lane of the row)
+__device__ __forceinline__ uint32_t row_pick(uint32_t v, uint32_t rowbase, uint32_t j) { return __shfl(v, static_cast<int>(rowbase | j), kWave); }
+__device__ __forceinline__ uint64_t row_pick(uint64_t v, uint32_t rowbase, uint32_t j) { return __shfl(v, static_cast<int>(rowbase | j), kWave); }
+
+// # lanes of this lane's row for which `pred` holds
+__device__ __forceinline__ uint32_t row_count(bool pred, uint32_t rowbase) {
+    return static_cast<uint32_t>(__popc(static_cast<uint32_t>(__ballot(pred) >> rowbase) & 0xFFFFu));
+}
 
 // # entries of s_top[off, off + n) that are < q (per lane; LDS)
 template <typename P>
@@ -36,128 +45,127 @@ __device__ __forceinline__ uint32_t top_count(const P *s_top, uint32_t off, uint
 
 // One sampled level (keys only), for up to two queries per lane.  On entry t0 / t1 = # entries of the level ABOVE
 // that are < q (>= 1 for a live query): the answer at this level lies in block t - 1.  On return t = # entries of
-// THIS level that are < q.  `pend` = lanes with a live query (wave-uniform).  Every lane of the wave must call.
+// THIS level that are < q.  Every lane of the wave must call.
+// The wave works in kFan rounds: in round j each 16-lane row serves the queries of ITS lane j -- the row's lanes load
+// the 16 keys of that owner's block with one coalesced request (four owners per wave-wide load instruction), the
+// owner's query is broadcast along the row, and popcount(ballot) over the row is the answer.  All 16 rounds' loads are
+// issued before the first compare, so a level costs one memory round trip per wave, not one per owner.
 template <typename P>
-__device__ __forceinline__ void coop_level(const DevTree *s_tree, const int l, uint64_t pend, const uint32_t tid, const bool live0,
-                                           const bool live1, uint32_t &t0, uint32_t &t1, const uint64_t q0, const uint64_t q1) {
-    const uint32_t lane = threadIdx.x & (kWave - 1);
-    const uint32_t lv = (live0 ? 1u : 0u) | (live1 ? 2u : 0u);
-    while (pend) {
-        int own[kCoopGroup];
-        uint32_t flags[kCoopGroup], bb0[kCoopGroup], bb1[kCoopGroup];
-        P va[kCoopGroup], vb[kCoopGroup];
+__device__ __forceinline__ void coop_level(const DevTree *s_tree, const int l, const uint32_t tid, const bool live0, const bool live1,
+                                           uint32_t &t0, uint32_t &t1, const P q0, const P q1) {
+    const uint32_t lane = threadIdx.x & (kWave - 1), sub = lane & (kFan - 1), rowbase = lane & ~static_cast<uint32_t>(kFan - 1);
+    if (!__ballot(live0 || live1)) return;
+    const uint32_t b0 = t0 - 1, b1 = t1 - 1;
+    const bool two = live0 && live1 && b0 != b1;                     // the second query needs a block of its own
+    // what the row has to know about an owner, in one word: bit 0 any query, bit 1 second block, bits 2.. tree
+    const uint32_t info = ((live0 || live1) ? 1u : 0u) | (two ? 2u : 0u) | (tid << 2);
+    const uint32_t first = live0 ? b0 : b1;
+    P va[kFan];
 #pragma unroll
-        for (int g = 0; g < kCoopGroup; ++g) {
-            own[g] = -1;
-            va[g] = vb[g] = 0;
-            flags[g] = bb0[g] = bb1[g] = 0;
-            if (pend) {
-                const int o = first_lane(pend);
-                pend &= pend - 1;
-                own[g] = o;
-                const DevTree &T = s_tree[rl32(tid, o)];
-                const P *__restrict__ keys = static_cast<const P *>(T.lvl[l]);
-                const uint32_t nl = T.lvl_n[l];
-                const uint32_t f = rl32(lv, o);
-                const uint32_t b0 = rl32(t0, o) - 1, b1 = rl32(t1, o) - 1;
-                const uint32_t first = (f & 1u) ? b0 : b1;
-                const uint64_t i0 = static_cast<uint64_t>(first) * kTreeFan + lane;
-                va[g] = i0 < nl ? keys[i0] : static_cast<P>(~P(0));
-                const bool two = f == 3u && b0 != b1;
-                if (two) {
-                    const uint64_t i1 = static_cast<uint64_t>(b1) * kTreeFan + lane;
-                    vb[g] = i1 < nl ? keys[i1] : static_cast<P>(~P(0));
-                }
-                flags[g] = f | (two ? 4u : 0u);
-                bb0[g] = b0;
-                bb1[g] = b1;
-            }
+    for (int j = 0; j < kFan; ++j) {
+        const uint32_t oi = row_get(info, rowbase, j);
+        const uint32_t ob = row_get(first, rowbase, j);
+        va[j] = static_cast<P>(~P(0));
+        if (oi & 1u) {
+            const DevTree &T = s_tree[oi >> 2];
+            const uint64_t i = static_cast<uint64_t>(ob) * kFan + sub;
+            if (i < T.lvl_n[l]) va[j] = static_cast<const P *>(T.lvl[l])[i];
         }
+    }
 #pragma unroll
-        for (int g = 0; g < kCoopGroup; ++g) {
-            if (own[g] >= 0) {
-                const int o = own[g];
-                const uint64_t qq0 = rl64(q0, o), qq1 = rl64(q1, o);
-                // padding lanes hold the all-ones key, which no query exceeds (positions stay below it: flatten())
-                const uint32_t c0 = static_cast<uint32_t>(__popcll(__ballot(static_cast<uint64_t>(va[g]) < qq0)));
-                const uint32_t c1 = static_cast<uint32_t>(__popcll(__ballot(static_cast<uint64_t>((flags[g] & 4u) ? vb[g] : va[g]) < qq1)));
-                if (static_cast<int>(lane) == o) {
-                    if (flags[g] & 1u) t0 = bb0[g] * kTreeFan + c0;
-                    if (flags[g] & 2u) t1 = bb1[g] * kTreeFan + c1;
-                }
-            }
+    for (int j = 0; j < kFan; ++j) {
+        // padding lanes hold the all-ones key, which no query exceeds (positions stay below it: flatten())
+        const uint32_t c0 = row_count(va[j] < row_get(q0, rowbase, j), rowbase);
+        const uint32_t c1 = row_count(va[j] < row_get(q1, rowbase, j), rowbase);
+        if (static_cast<int>(sub) == j) {
+            if (live0) t0 = b0 * kFan + c0;
+            if (live1 && !two) t1 = b1 * kFan + c1;
         }
+    }
+    if (!__ballot(two)) return;
+#pragma unroll
+    for (int j = 0; j < kFan; ++j) {
+        const uint32_t oi = row_get(info, rowbase, j);
+        const uint32_t ob = row_get(b1, rowbase, j);
+        va[j] = static_cast<P>(~P(0));
+        if (oi & 2u) {
+            const DevTree &T = s_tree[oi >> 2];
+            const uint64_t i = static_cast<uint64_t>(ob) * kFan + sub;
+            if (i < T.lvl_n[l]) va[j] = static_cast<const P *>(T.lvl[l])[i];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kFan; ++j) {
+        const uint32_t c1 = row_count(va[j] < row_get(q1, rowbase, j), rowbase);
+        if (static_cast<int>(sub) == j && two) t1 = b1 * kFan + c1;
     }
 }
 
-// The leaf level: {key, value} pairs.  For each live query returns k = # keys < q (in t), the pair before it
-// (key pk, value pv: entry k-1) and the value of entry k (nv; the arrays carry a sentinel entry).
+// The leaf level: {key, value} pairs, probed the same way.  For each live query returns k = # keys < q (in t), the
+// pair before it (key pk, value pv: entry k-1) and the value of entry k (nv; the arrays carry a sentinel entry).
+// Entries k-1 and k are read out of the registers of the row's lanes that loaded them: a rank costs no further gather.
 template <typename P>
-__device__ __forceinline__ void coop_leaf(const DevTree *s_tree, uint64_t pend, const uint32_t tid, const bool live0, const bool live1,
-                                          uint32_t &t0, uint32_t &t1, const uint64_t q0, const uint64_t q1, uint64_t &pk0, uint64_t &pv0,
-                                          uint64_t &nv0, uint64_t &pk1, uint64_t &pv1, uint64_t &nv1) {
+__device__ __forceinline__ void coop_leaf(const DevTree *s_tree, const uint32_t tid, const bool live0, const bool live1, uint32_t &t0,
+                                          uint32_t &t1, const P q0, const P q1, P &pk0, P &pv0, P &nv0, P &pk1, P &pv1, P &nv1) {
     typedef typename PairOf<P>::vec vec;
-    const uint32_t lane = threadIdx.x & (kWave - 1);
-    const uint32_t lv = (live0 ? 1u : 0u) | (live1 ? 2u : 0u);
+    const uint32_t lane = threadIdx.x & (kWave - 1), sub = lane & (kFan - 1), rowbase = lane & ~static_cast<uint32_t>(kFan - 1);
+    if (!__ballot(live0 || live1)) return;
+    const uint32_t b0 = t0 - 1, b1 = t1 - 1;
+    const bool two = live0 && live1 && b0 != b1;
+    const uint32_t info = ((live0 || live1) ? 1u : 0u) | (two ? 2u : 0u) | (tid << 2);
+    const uint32_t first = live0 ? b0 : b1;
     bool fix0 = false, fix1 = false;  // entry k is the first of the next block: fetched by the owner afterwards
-    while (pend) {
-        int own[kCoopGroup];
-        uint32_t flags[kCoopGroup], bb0[kCoopGroup], bb1[kCoopGroup];
-        vec va[kCoopGroup], vb[kCoopGroup];
+    vec va[kFan];
 #pragma unroll
-        for (int g = 0; g < kCoopGroup; ++g) {
-            own[g] = -1;
-            va[g] = vb[g] = vec{0, 0};
-            flags[g] = bb0[g] = bb1[g] = 0;
-            if (pend) {
-                const int o = first_lane(pend);
-                pend &= pend - 1;
-                own[g] = o;
-                const DevTree &T = s_tree[rl32(tid, o)];
-                const vec *__restrict__ ent = static_cast<const vec *>(T.ent);
-                const uint64_t m = T.m;
-                const uint32_t f = rl32(lv, o);
-                const uint32_t b0 = rl32(t0, o) - 1, b1 = rl32(t1, o) - 1;
-                const uint32_t first = (f & 1u) ? b0 : b1;
-                const uint64_t i0 = static_cast<uint64_t>(first) * kTreeFan + lane;
-                va[g] = i0 <= m ? ent[i0] : vec{static_cast<P>(~P(0)), 0};   // entry m is the sentinel (key = n: never < q)
-                const bool two = f == 3u && b0 != b1;
-                if (two) {
-                    const uint64_t i1 = static_cast<uint64_t>(b1) * kTreeFan + lane;
-                    vb[g] = i1 <= m ? ent[i1] : vec{static_cast<P>(~P(0)), 0};
-                }
-                flags[g] = f | (two ? 4u : 0u);
-                bb0[g] = b0;
-                bb1[g] = b1;
+    for (int j = 0; j < kFan; ++j) {
+        const uint32_t oi = row_get(info, rowbase, j);
+        const uint32_t ob = row_get(first, rowbase, j);
+        va[j] = vec{static_cast<P>(~P(0)), 0};
+        if (oi & 1u) {
+            const DevTree &T = s_tree[oi >> 2];
+            const uint64_t i = static_cast<uint64_t>(ob) * kFan + sub;
+            if (i <= T.m) va[j] = static_cast<const vec *>(T.ent)[i];   // entry m is the sentinel (key = n: never < q)
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kFan; ++j) {
+        // the sentinel (key n) and the padding never compare below a query (q <= n)
+        const uint32_t c0 = row_count(static_cast<P>(va[j].x) < row_get(q0, rowbase, j), rowbase);
+        const uint32_t c1 = row_count(static_cast<P>(va[j].x) < row_get(q1, rowbase, j), rowbase);
+        // a live query has c >= 1 (entry 16*block is the sample that was < q one level up); entries c - 1 and c are lanes
+        const uint32_t p0 = c0 ? c0 - 1 : 0, n0 = c0 < kFan ? c0 : kFan - 1;
+        const uint32_t p1 = c1 ? c1 - 1 : 0, n1 = c1 < kFan ? c1 : kFan - 1;
+        const P a_pk0 = row_pick(static_cast<P>(va[j].x), rowbase, p0), a_pv0 = row_pick(static_cast<P>(va[j].y), rowbase, p0), a_nv0 = row_pick(static_cast<P>(va[j].y), rowbase, n0);
+        const P a_pk1 = row_pick(static_cast<P>(va[j].x), rowbase, p1), a_pv1 = row_pick(static_cast<P>(va[j].y), rowbase, p1), a_nv1 = row_pick(static_cast<P>(va[j].y), rowbase, n1);
+        if (static_cast<int>(sub) == j) {
+            if (live0) { t0 = b0 * kFan + c0; pk0 = a_pk0; pv0 = a_pv0; nv0 = a_nv0; fix0 = c0 == kFan; }
+            if (live1 && !two) { t1 = b1 * kFan + c1; pk1 = a_pk1; pv1 = a_pv1; nv1 = a_nv1; fix1 = c1 == kFan; }
+        }
+    }
+    if (__ballot(two)) {
+#pragma unroll
+        for (int j = 0; j < kFan; ++j) {
+            const uint32_t oi = row_get(info, rowbase, j);
+            const uint32_t ob = row_get(b1, rowbase, j);
+            va[j] = vec{static_cast<P>(~P(0)), 0};
+            if (oi & 2u) {
+                const DevTree &T = s_tree[oi >> 2];
+                const uint64_t i = static_cast<uint64_t>(ob) * kFan + sub;
+                if (i <= T.m) va[j] = static_cast<const vec *>(T.ent)[i];
             }
         }
 #pragma unroll
-        for (int g = 0; g < kCoopGroup; ++g) {
-            if (own[g] >= 0) {
-                const int o = own[g];
-                const uint64_t qq0 = rl64(q0, o), qq1 = rl64(q1, o);
-                const vec w1 = (flags[g] & 4u) ? vb[g] : va[g];
-                // the sentinel (key n) and the padding never compare below a query (q <= n)
-                const uint32_t c0 = static_cast<uint32_t>(__popcll(__ballot(static_cast<uint64_t>(va[g].x) < qq0)));
-                const uint32_t c1 = static_cast<uint32_t>(__popcll(__ballot(static_cast<uint64_t>(w1.x) < qq1)));
-                // a live query has c >= 1 (entry 64*block is the sample that was < q one level up); c - 1 and c are lanes
-                const int p0 = static_cast<int>(c0 ? c0 - 1 : 0), n0 = static_cast<int>(c0 < 64 ? c0 : 63);
-                const int p1 = static_cast<int>(c1 ? c1 - 1 : 0), n1 = static_cast<int>(c1 < 64 ? c1 : 63);
-                const uint64_t a_pk0 = rl64(static_cast<uint64_t>(va[g].x), p0), a_pv0 = rl64(static_cast<uint64_t>(va[g].y), p0);
-                const uint64_t a_nv0 = rl64(static_cast<uint64_t>(va[g].y), n0);
-                const uint64_t a_pk1 = rl64(static_cast<uint64_t>(w1.x), p1), a_pv1 = rl64(static_cast<uint64_t>(w1.y), p1);
-                const uint64_t a_nv1 = rl64(static_cast<uint64_t>(w1.y), n1);
-                if (static_cast<int>(lane) == o) {
-                    if (flags[g] & 1u) { t0 = bb0[g] * kTreeFan + c0; pk0 = a_pk0; pv0 = a_pv0; nv0 = a_nv0; fix0 = c0 == 64; }
-                    if (flags[g] & 2u) { t1 = bb1[g] * kTreeFan + c1; pk1 = a_pk1; pv1 = a_pv1; nv1 = a_nv1; fix1 = c1 == 64; }
-                }
-            }
+        for (int j = 0; j < kFan; ++j) {
+            const uint32_t c1 = row_count(static_cast<P>(va[j].x) < row_get(q1, rowbase, j), rowbase);
+            const uint32_t p1 = c1 ? c1 - 1 : 0, n1 = c1 < kFan ? c1 : kFan - 1;
+            const P a_pk1 = row_pick(static_cast<P>(va[j].x), rowbase, p1), a_pv1 = row_pick(static_cast<P>(va[j].y), rowbase, p1), a_nv1 = row_pick(static_cast<P>(va[j].y), rowbase, n1);
+            if (static_cast<int>(sub) == j && two) { t1 = b1 * kFan + c1; pk1 = a_pk1; pv1 = a_pv1; nv1 = a_nv1; fix1 = c1 == kFan; }
         }
     }
     if (fix0 || fix1) {
         const vec *__restrict__ ent = static_cast<const vec *>(s_tree[tid].ent);
-        if (fix0) nv0 = static_cast<uint64_t>(ent[t0].y);
-        if (fix1) nv1 = static_cast<uint64_t>(ent[t1].y);
+        if (fix0) nv0 = static_cast<P>(ent[t0].y);
+        if (fix1) nv1 = static_cast<P>(ent[t1].y);
     }
 }
 
@@ -246,21 +254,22 @@ __global__ __launch_bounds__(256) void k_find_range_runs(const DevIndex ix, cons
                 t0 = top_count<P>(s_top, T.top_off, T.top_n, q0);
                 t1 = top_count<P>(s_top, T.top_off, T.top_n, q1);
             }
+            // (positions fit P: q1 = hi + 1 <= n, and n stays below the all-ones key, flatten())
             for (int l = nlvl - 1; l >= 0; --l) {
                 const bool l0 = stepping && t0 > 0, l1 = stepping && t1 > 0;
-                coop_level<P>(s_tree, l, __ballot(l0 || l1), slot, l0, l1, t0, t1, q0, q1);
+                coop_level<P>(s_tree, l, slot, l0, l1, t0, t1, static_cast<P>(q0), static_cast<P>(q1));
             }
-            uint64_t pk0 = 0, pv0 = 0, nv0 = 0, pk1 = 0, pv1 = 0, nv1 = 0;
+            P pk0 = 0, pv0 = 0, nv0 = 0, pk1 = 0, pv1 = 0, nv1 = 0;
             {
                 const bool l0 = stepping && t0 > 0, l1 = stepping && t1 > 0;
-                coop_leaf<P>(s_tree, __ballot(l0 || l1), slot, l0, l1, t0, t1, q0, q1, pk0, pv0, nv0, pk1, pv1, nv1);
+                coop_leaf<P>(s_tree, slot, l0, l1, t0, t1, static_cast<P>(q0), static_cast<P>(q1), pk0, pv0, nv0, pk1, pv1, nv1);
             }
             if (stepping) {
                 // rle_string::rank: occurrences before the predecessor run + the part of it below the position
                 uint64_t c_before = 0, c_upto = 0;
                 bool inside = false;
-                if (t0 > 0) { const uint64_t len = nv0 - pv0, d = q0 - pk0; c_before = pv0 + (d < len ? d : len); }
-                if (t1 > 0) { const uint64_t len = nv1 - pv1, d = q1 - pk1; c_upto = pv1 + (d < len ? d : len); inside = d <= len; }
+                if (t0 > 0) { const uint64_t len = static_cast<uint64_t>(nv0) - pv0, d = q0 - pk0; c_before = pv0 + (d < len ? d : len); }
+                if (t1 > 0) { const uint64_t len = static_cast<uint64_t>(nv1) - pv1, d = q1 - pk1; c_upto = pv1 + (d < len ? d : len); inside = d <= len; }
                 const uint64_t c_inside = c_upto - c_before;
                 if (c_inside == 0) {                            // rowbowt.hpp:85
                     alive = false;
@@ -368,12 +377,12 @@ __global__ __launch_bounds__(256) void k_locate_fill_runs(const DevIndex ix, con
                 if (coop) tq = top_count<P>(s_top, 0, s_tree[0].top_n, k1);
                 for (int l = nlvl - 1; l >= 0; --l) {
                     const bool lv0 = coop && tq > 0;
-                    coop_level<P>(s_tree, l, __ballot(lv0), 0u, lv0, false, tq, unused_t, k1, 0);
+                    coop_level<P>(s_tree, l, 0u, lv0, false, tq, unused_t, static_cast<P>(k1), P(0));   // (k1 < n here)
                 }
-                uint64_t pk = 0, pv = 0, nv = 0, u1 = 0, u2 = 0, u3 = 0;
+                P pk = 0, pv = 0, nv = 0, u1 = 0, u2 = 0, u3 = 0;
                 {
                     const bool lv0 = coop && tq > 0;
-                    coop_leaf<P>(s_tree, __ballot(lv0), 0u, lv0, false, tq, unused_t, k1, 0, pk, pv, nv, u1, u2, u3);
+                    coop_leaf<P>(s_tree, 0u, lv0, false, tq, unused_t, static_cast<P>(k1), P(0), pk, pv, nv, u1, u2, u3);
                 }
                 if (need) {
                     uint64_t s;
@@ -386,7 +395,7 @@ __global__ __launch_bounds__(256) void k_locate_fill_runs(const DevIndex ix, con
                         s = static_cast<uint64_t>(pent[ix.r - 1].base) + k1 + 1;
                         if (s >= ix.n) s -= ix.n;
                     } else {
-                        s = pv + (k1 - pk);                    // prev_sample + delta (toehold_sa.hpp:65-71)
+                        s = static_cast<uint64_t>(pv) + (k1 - pk);   // prev_sample + delta (toehold_sa.hpp:65-71)
                         if (s >= ix.n) s -= ix.n;
                     }
                     k1 = s;

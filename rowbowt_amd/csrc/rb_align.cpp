@@ -31,6 +31,7 @@
 #include "../include/rowbowt_gpu.hpp"
 #include "fastx.hpp"
 #include "fastx_index.hpp"
+#include "rbg_thread_team.hpp"
 
 namespace {
 
@@ -146,7 +147,8 @@ struct RbAlignArgs {  // rb_align.cpp:17-24
     int gpus = 1;     // replicas: devices device .. device + gpus - 1; every batch is sharded over them
     std::vector<int> devices;  // --devices a,b,...: the replicas' devices, in shard order (overrides --gpu/--gpus)
     uint64_t batch = 1u << 22;
-    int threads = static_cast<int>(std::min(32u, std::max(8u, std::thread::hardware_concurrency() / 8)));  // input scanning and output formatting workers
+    // input scanning and output formatting workers: an eighth of the CPUs, 8..32, within the container's CPU quota
+    int threads = static_cast<int>(std::min({32u, std::max(8u, std::thread::hardware_concurrency() / 8), std::max(2u, rbg_hostpath::cpu_budget())}));
     uint64_t window_mb = 256;  // input bytes scanned per pipeline step
 };
 

@@ -336,12 +336,12 @@ int upload_tables(rbg_index *ix) {
     return RBG_OK;
 }
 
-// ---- run-indexed layout (rbg_dev.h DevTree): the run lists as they are plus a 64-ary sampled index over their keys
-// every 64th key, every 64th of those, ... until what is left of ALL trees of the kernel fits the LDS budget: that
-// coarsest level is staged in LDS, the ones below it live in HBM.  Space: (1 + 1/63) keys per run.
+// ---- run-indexed layout (rbg_dev.h DevTree): the run lists as they are plus a 16-ary sampled index over their keys
+// every 16th key, every 16th of those, ... until what is left of ALL trees of the kernel fits the LDS budget: that
+// coarsest level is staged in LDS, the ones below it live in HBM.  Space: (1 + 1/15) keys per run.
 template <typename P>
 struct TreeBuild {
-    std::vector<std::vector<P>> lvl;  // lvl[0] = every 64th key, ...
+    std::vector<std::vector<P>> lvl;  // lvl[0] = every 16th key, ...
 };
 
 template <typename P, typename KeyAt>
@@ -416,8 +416,11 @@ int upload_tables_runs(rbg_index *ix) {
     ix->ptr_tables.push_back({p, syms.size(), sizeof(DevSym), {offsetof(DevSym, ent), offsetof(DevSym, samp), offsetof(DevSym, slots), offsetof(DevSym, ord)}});
     if ((rc = dev_upload(ix, trees.data(), trees.size() * sizeof(DevTree), &p))) return rc;
     ix->dev.trees = static_cast<const DevTree *>(p);
-    ix->ptr_tables.push_back({p, trees.size(), sizeof(DevTree),
-                              {offsetof(DevTree, ent), offsetof(DevTree, lvl), offsetof(DevTree, lvl) + 8, offsetof(DevTree, lvl) + 16, offsetof(DevTree, lvl) + 24}});
+    {
+        std::vector<size_t> offs{offsetof(DevTree, ent)};
+        for (int l = 0; l < kMaxTreeLevels; ++l) offs.push_back(offsetof(DevTree, lvl) + 8 * static_cast<size_t>(l));
+        ix->ptr_tables.push_back({p, trees.size(), sizeof(DevTree), offs});
+    }
     if ((rc = dev_upload(ix, top_all.data(), top_all.size() * sizeof(P), &ix->dev.tree_top))) return rc;
     ix->dev.tree_top_n = static_cast<uint32_t>(top_all.size());
     ix->dev.tree_nlvl = nlvl;
@@ -544,7 +547,7 @@ int upload(rbg_index *ix) {
         std::vector<SymTable>().swap(h.quint);
     }
     auto levels = [&] { return !h.quint.empty() ? 5 : !h.quad.empty() ? 4 : !h.triple.empty() ? 3 : !h.pair.empty() ? 2 : 1; };
-    ix->kmer_steps_requested = static_cast<uint64_t>(levels());
+    ix->kmer_steps_requested = std::max<uint64_t>(ix->kmer_steps_requested, static_cast<uint64_t>(levels()));  // options_for() may have capped the depth already
     ix->hbm_free_at_load = free_b;
     ix->hbm_budget = budget;
     // Over budget: first give the k-mer levels wider buckets, deepest level first (their runs are sparse: a table
@@ -650,6 +653,48 @@ FlattenOptions current_options() {
     o.phi_bucket_shift = static_cast<int>(g_opt_phi_shift.load());
     o.force_pos_bytes = static_cast<int>(g_opt_pos_bytes.load());
     o.kmer_steps = static_cast<int>(g_opt_kmer_steps.load());
+    return o;
+}
+
+// The options of a load that is going to `device`: k-mer levels that cannot fit the replica budget even in their
+// smallest form (every table at the widest bucket, kMaxWideShift) are not composed at all -- upload() would drop them
+// anyway, and composing the deepest level is the most expensive part of flatten() (47 of 76 s at n = 5e10).  The bound
+// is conservative: a level upload() could keep is never excluded.  *requested = the depth asked for when it was
+// capped here (else 0: upload() reports what flatten() composed).
+FlattenOptions options_for(int device, const RawRle &rle, uint64_t *requested) {
+    FlattenOptions o = current_options();
+    *requested = 0;
+    if (device == RBG_DEVICE_NONE || o.kmer_steps < 2) return o;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return o;
+    DeviceScope scope(device);
+    if (scope.rc) return o;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return o;
+    const int64_t opt_mb = g_opt_hbm_budget_mb.load();
+    const double budget = static_cast<double>(opt_mb > 0 ? static_cast<size_t>(opt_mb) << 20 : free_b - free_b / 4);
+    bool seen[256] = {};
+    unsigned sigma = 0;
+    for (uint8_t c : rle.heads)
+        if (!seen[c]) { seen[c] = true; ++sigma; }
+    const double major = static_cast<double>(std::min(4u, sigma > 1 ? sigma - 1 : 0u));  // at least this many k-mer symbols
+    if (major < 2) return o;
+    const double per_table = static_cast<double>((rle.n >> kMaxWideShift) + 2) * (sizeof(RankSlot) + sizeof(uint32_t));
+    double total = major * per_table, tables = major;
+    int keep = 1;
+    for (int k = 2; k <= o.kmer_steps; ++k) {
+        tables *= major;
+        total += tables * per_table;
+        if (total > budget) break;
+        keep = k;
+    }
+    if (keep < o.kmer_steps) {
+        if (std::getenv("RBG_VERBOSE"))
+            std::fprintf(stderr, "rbg: device %d: %.1f GB replica budget cannot hold k-mer levels beyond %d at n = %.3g: not composing them\n", device,
+                         budget / 1e9, keep, static_cast<double>(rle.n));
+        *requested = static_cast<uint64_t>(std::min(5, o.kmer_steps));
+        o.kmer_steps = keep;
+    }
     return o;
 }
 
@@ -832,7 +877,7 @@ int ftab_stream(rbg_index *ix, uint64_t k, Sink sink) {
 int index_from_bundle(FlatBundle &b, int device, rbg_index **out) {
     rbg_index *ix = new (std::nothrow) rbg_index();
     if (!ix) return RBG_ENOMEM;
-    int rc = flatten(b.rle, b.has_tsa ? &b.tsa : nullptr, current_options(), ix->host);
+    int rc = flatten(b.rle, b.has_tsa ? &b.tsa : nullptr, options_for(device, b.rle, &ix->kmer_steps_requested), ix->host);
     if (rc) { delete ix; return rc; }
     if (b.has_ma) { ix->H().ma = std::move(b.ma); ix->H().has_ma = true; }
     if (b.has_dl) { ix->H().dl = std::move(b.dl); ix->H().has_dl = true; }
@@ -1043,7 +1088,7 @@ int rbg_build_from_runs(const uint8_t *heads, const uint64_t *lens, uint64_t R, 
     }
     rbg_index *ix = new (std::nothrow) rbg_index();
     if (!ix) return RBG_ENOMEM;
-    int rc = flatten(rle, ssa_y ? &tsa : nullptr, current_options(), ix->host);
+    int rc = flatten(rle, ssa_y ? &tsa : nullptr, options_for(device, rle, &ix->kmer_steps_requested), ix->host);
     if (rc) { delete ix; return rc; }
     return finish(ix, device, out);
     });
@@ -1452,8 +1497,7 @@ static int find_range_host(rbg_index *ix, const uint8_t *seqs, const uint64_t *o
     if (!queryable(ix)) return RBG_ENODEV;
     if (N == 0) return RBG_OK;
     if (!off || (!seqs && off[N])) return RBG_EARG;
-    int rc = check_offsets(off, N);
-    if (rc) return rc;
+    if (off[0] != 0) return RBG_EARG;   // (the rest of check_offsets() is done by the staging passes, chunk by chunk, before any byte is read)
     HostReads R;
     R.base = seqs;
     R.off = off;
@@ -1474,8 +1518,9 @@ static int find_range_host_core(rbg_index *ix, const HostReads &R, uint64_t N, u
     const bool pack = allow_pack && ix->dev.nmajor == 4 && ix->dev.layout == RBG_LAYOUT_SLOTS && (pk == 2 || (pk == 1 && N >= 4096));
     const bool acgt = h.major_byte[0] == 'A' && h.major_byte[1] == 'C' && h.major_byte[2] == 'G' && h.major_byte[3] == 'T';
     if (!W.team) {
+        // a quarter of the hardware's CPUs, at most 64 and at most what the container's CPU quota lets run at once
         const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-        unsigned nt = std::min(64u, std::max(1u, hw / 4));
+        unsigned nt = std::min({64u, std::max(1u, hw / 4), rbg_hostpath::cpu_budget()});
         if (const char *e = std::getenv("RBG_HOST_THREADS")) nt = static_cast<unsigned>(std::max(1, std::min(256, std::atoi(e))));
         W.team.reset(new rbg_hostpath::ThreadTeam(nt));
         W.bad.resize(W.team->size());
@@ -1495,6 +1540,17 @@ static int find_range_host_core(rbg_index *ix, const HostReads &R, uint64_t N, u
     int rc = RBG_OK;
     const bool trace = std::getenv("RBG_HOST_TRACE") != nullptr;   // per-call breakdown on stderr
     double t_pack = 0, t_wait = 0, t_out = 0, t_enq = 0;
+    // RBG_HOST_TRACE=2: also the device-side timeline of every chunk (timing events around copy in / search / copy out)
+    const bool timeline = trace && std::atoi(std::getenv("RBG_HOST_TRACE")) >= 2;
+    const char *e_direct = std::getenv("RBG_HOST_DIRECT_OUT");
+    const bool direct_out = !(e_direct && e_direct[0] == '0');
+    struct ChunkEvents { hipEvent_t e[4]; double host_ms; };
+    std::vector<ChunkEvents> tl;
+    auto mark = [&](int which, hipStream_t st) {
+        if (!timeline) return;
+        if (which == 0) { tl.emplace_back(); for (hipEvent_t &e : tl.back().e) (void)hipEventCreate(&e); }
+        (void)hipEventRecord(tl.back().e[which], st);
+    };
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
     const auto t_call = now();
@@ -1520,34 +1576,49 @@ static int find_range_host_core(rbg_index *ix, const HostReads &R, uint64_t N, u
         return RBG_OK;
     };
 
-    std::vector<uint64_t> part(T + 1);
+    uint64_t chunk_reads = kHostChunkReads;
+    if (const char *e = std::getenv("RBG_HOST_CHUNK_READS")) chunk_reads = std::max<uint64_t>(1, std::strtoull(e, nullptr, 10));   // (tests: many chunks from a small batch)
+    std::vector<uint64_t> part(T + 1), psym(T);
+    std::atomic<bool> bad_offsets{false};   // an offset smaller than its predecessor (check_offsets), found by a sizing pass
     uint64_t b = 0;
-    int which = 0;
+    unsigned seq = 0;   // chunks enqueued so far
     while (b < N && !rc) {
         // the chunk [b, e): bounded in reads and in symbols (no pass over the reads just to find the bound: the packed
         // layout has the symbol count in its offsets, spans are sampled and measured by the staging pass itself)
-        uint64_t e = std::min<uint64_t>(N, b + kHostChunkReads), sym = 0;
+        uint64_t e = std::min<uint64_t>(N, b + chunk_reads), sym = 0;
         if (R.off) {
             while (e > b + 1 && R.off[e] - R.off[b] > kHostChunkBytes) e = b + (e - b) / 2;
-            sym = R.off[e] - R.off[b];
         } else {
             uint64_t mx = 0;
             for (uint64_t i = b; i < e; i += 1 + (e - b) / 64) mx = std::max<uint64_t>(mx, R.len[i]);
             while (e > b + 1 && (e - b) * std::max<uint64_t>(mx, 64) > 4 * kHostChunkBytes) e = b + (e - b) / 2;   // long reads: fewer per chunk
-            std::vector<uint64_t> ps(T, 0);
-            par(e - b, [&](unsigned t) {
-                const uint64_t i0 = b + (e - b) * t / T, i1 = b + (e - b) * (t + 1) / T;
-                uint64_t c = 0;
-                for (uint64_t i = i0; i < i1; ++i) c += R.len[i];
-                ps[t] = c;
-            });
-            for (uint64_t v : ps) sym += v;
         }
+        // sizing pass: every member measures its slice (symbols, or 16-byte chunks of the 2-bit form) and checks that the
+        // offsets ascend (check_offsets): nothing of the caller's read bytes is touched, and nothing sized, before that
+        const auto ts0 = now();
+        par(e - b, [&](unsigned t) {
+            const uint64_t i0 = b + (e - b) * t / T, i1 = b + (e - b) * (t + 1) / T;
+            uint64_t c = 0, sy = 0;
+            bool bad = false;
+            if (R.off) {
+                for (uint64_t i = i0; i < i1; ++i) { const uint64_t m = R.off[i + 1] - R.off[i]; bad |= R.off[i + 1] < R.off[i]; sy += m; c += (m + 63) >> 6; }
+            } else {
+                for (uint64_t i = i0; i < i1; ++i) { const uint64_t m = R.len[i]; sy += m; c += (m + 63) >> 6; }
+            }
+            if (bad) bad_offsets = true;
+            part[t + 1] = pack ? c : sy;
+            psym[t] = sy;
+        });
+        t_pack += secs(ts0, now());
+        if (bad_offsets) { rc = RBG_EARG; break; }
+        for (uint64_t v : psym) sym += v;
+        part[0] = 0;
+        for (unsigned t = 0; t < T; ++t) part[t + 1] += part[t];
+        if (pack && part[T] >= (uint64_t(1) << 32)) { rc = RBG_EARG; break; }   // chunk indices are 32-bit
         const uint64_t cnt = e - b;
-        Slot &s = W.slot[which];
-        Slot &prev = W.slot[which ^ 1];
-        which ^= 1;
-        if ((rc = drain(s))) break;   // (only when more than two chunks are in flight: normally drained below)
+        Slot &s = W.slot[seq % rbg_hostpath::kSlots];
+        ++seq;
+        if ((rc = drain(s))) break;   // (waits only when every buffer is in flight: normally drained below)
         // device columns: lo, hi, [ssamp], [count]
         const uint64_t dev_cols = 2 + (ssamp ? 1 : 0) + (count ? 1 : 0);
         size_t in_bytes;
@@ -1561,21 +1632,24 @@ static int find_range_host_core(rbg_index *ix, const HostReads &R, uint64_t N, u
         uint64_t *dout = static_cast<uint64_t *>(s.d_out);
         uint64_t *d_lo = dout, *d_hi = dout + cnt, *d_ss = ssamp ? dout + 2 * cnt : nullptr;
         uint64_t *d_cnt = count ? dout + (ssamp ? 3 : 2) * cnt : nullptr;
+        // Results leave without a copy engine: the kernels store the columns the caller wants straight into the pinned
+        // buffer (device-visible host memory; 8 bytes per lane, whole lines per wave, posted writes over PCIe).  A
+        // device-to-host copy enqueued behind the search of chunk c holds up the copy IN of chunk c + 1 on this
+        // platform until that search has finished (one engine serves both directions, in order: measured with
+        // RBG_HOST_TRACE=2), which serialised copy in / search / copy out of successive chunks.  RBG_HOST_DIRECT_OUT=0
+        // keeps the copies (A/B measurements).
+        if (direct_out) {
+            uint64_t *hcol = static_cast<uint64_t *>(s.h_out);
+            if (lo) { d_lo = hcol; d_hi = hcol + cnt; hcol += 2 * cnt; }
+            if (ssamp) { d_ss = hcol; hcol += cnt; }
+            if (count) { d_cnt = hcol; hcol += cnt; }
+        }
         size_t used = 0;
         if (pack) {
             uint2 *meta = reinterpret_cast<uint2 *>(hin);
             const size_t chunks_at = (cnt * 8 + 15) & ~size_t(15);
             uint32_t *chunks = reinterpret_cast<uint32_t *>(hin + chunks_at);
-            // 16-byte chunks per member's slice, then every member packs from its own prefix
-            par(cnt, [&](unsigned t) {
-                const uint64_t i0 = b + cnt * t / T, i1 = b + cnt * (t + 1) / T;
-                uint64_t c = 0;
-                for (uint64_t i = i0; i < i1; ++i) c += (R.length(i) + 63) >> 6;
-                part[t + 1] = c;
-            });
-            part[0] = 0;
-            for (unsigned t = 0; t < T; ++t) part[t + 1] += part[t];
-            if (part[T] >= (uint64_t(1) << 32)) { rc = RBG_EARG; break; }
+            // every member packs from its own prefix of 16-byte chunks (sizing pass above)
             par(cnt, [&](unsigned t) {
                 const uint64_t i0 = b + cnt * t / T, i1 = b + cnt * (t + 1) / T;
                 uint64_t c = part[t];
@@ -1591,22 +1665,18 @@ static int find_range_host_core(rbg_index *ix, const HostReads &R, uint64_t N, u
             });
             used = chunks_at + part[T] * 16;
             t_pack += secs(tp0, now());
-            if (hipMemcpyAsync(din, hin, used, hipMemcpyHostToDevice, s.st) != hipSuccess ||
-                launch_find_range_packed_only(ix->dev, ix->cfg, reinterpret_cast<const uint2 *>(din), reinterpret_cast<const uint4 *>(din + chunks_at), cnt,
-                                              d_lo, d_hi, d_ss, s.st))
+            mark(0, s.st);
+            if (timeline) tl.back().host_ms = secs(t_call, now()) * 1e3;
+            if (hipMemcpyAsync(din, hin, used, hipMemcpyHostToDevice, s.st) != hipSuccess) rc = RBG_ENODEV;
+            mark(1, s.st);
+            if (!rc && launch_find_range_packed_only(ix->dev, ix->cfg, reinterpret_cast<const uint2 *>(din), reinterpret_cast<const uint4 *>(din + chunks_at), cnt,
+                                                     d_lo, d_hi, d_ss, s.st))
                 rc = RBG_ENODEV;
+            mark(2, s.st);
         } else {
             uint64_t *off2 = reinterpret_cast<uint64_t *>(hin);
             const size_t bytes_at = ((cnt + 1) * 8 + 15) & ~size_t(15);
             char *bytes = hin + bytes_at;
-            par(cnt, [&](unsigned t) {
-                const uint64_t i0 = b + cnt * t / T, i1 = b + cnt * (t + 1) / T;
-                uint64_t c = 0;
-                for (uint64_t i = i0; i < i1; ++i) c += R.length(i);
-                part[t + 1] = c;
-            });
-            part[0] = 0;
-            for (unsigned t = 0; t < T; ++t) part[t + 1] += part[t];
             par(cnt, [&](unsigned t) {
                 const uint64_t i0 = b + cnt * t / T, i1 = b + cnt * (t + 1) / T;
                 uint64_t c = part[t];
@@ -1625,10 +1695,14 @@ static int find_range_host_core(rbg_index *ix, const HostReads &R, uint64_t N, u
             off2[cnt] = part[T];
             used = bytes_at + part[T];
             t_pack += secs(tp0, now());
-            if (hipMemcpyAsync(din, hin, used, hipMemcpyHostToDevice, s.st) != hipSuccess ||
-                launch_find_range(ix->dev, ix->cfg, reinterpret_cast<const uint8_t *>(din + bytes_at), reinterpret_cast<const uint64_t *>(din), cnt, d_lo,
-                                  d_hi, d_ss, s.st))
+            mark(0, s.st);
+            if (timeline) tl.back().host_ms = secs(t_call, now()) * 1e3;
+            if (hipMemcpyAsync(din, hin, used, hipMemcpyHostToDevice, s.st) != hipSuccess) rc = RBG_ENODEV;
+            mark(1, s.st);
+            if (!rc && launch_find_range(ix->dev, ix->cfg, reinterpret_cast<const uint8_t *>(din + bytes_at), reinterpret_cast<const uint64_t *>(din), cnt, d_lo,
+                                         d_hi, d_ss, s.st))
                 rc = RBG_ENODEV;
+            mark(2, s.st);
         }
         if (rc) break;
         if (count && launch_count_from_ranges(d_lo, d_hi, cnt, d_cnt, s.st)) { rc = RBG_ENODEV; break; }
@@ -1637,9 +1711,12 @@ static int find_range_host_core(rbg_index *ix, const HostReads &R, uint64_t N, u
             char *hout = static_cast<char *>(s.h_out);
             size_t at = 0;
             hipError_t e2 = hipSuccess;
-            if (lo) { e2 = hipMemcpyAsync(hout, d_lo, 2 * cnt * 8, hipMemcpyDeviceToHost, s.st); at += 2 * cnt * 8; }
-            if (e2 == hipSuccess && ssamp) { e2 = hipMemcpyAsync(hout + at, d_ss, cnt * 8, hipMemcpyDeviceToHost, s.st); at += cnt * 8; }
-            if (e2 == hipSuccess && count) { e2 = hipMemcpyAsync(hout + at, d_cnt, cnt * 8, hipMemcpyDeviceToHost, s.st); at += cnt * 8; }
+            if (!direct_out) {
+                if (lo) { e2 = hipMemcpyAsync(hout, d_lo, 2 * cnt * 8, hipMemcpyDeviceToHost, s.st); at += 2 * cnt * 8; }
+                if (e2 == hipSuccess && ssamp) { e2 = hipMemcpyAsync(hout + at, d_ss, cnt * 8, hipMemcpyDeviceToHost, s.st); at += cnt * 8; }
+                if (e2 == hipSuccess && count) { e2 = hipMemcpyAsync(hout + at, d_cnt, cnt * 8, hipMemcpyDeviceToHost, s.st); at += cnt * 8; }
+            }
+            mark(3, s.st);
             if (e2 == hipSuccess) e2 = hipEventRecord(s.done, s.st);
             if (e2 != hipSuccess) { rc = RBG_ENODEV; break; }
         }
@@ -1648,12 +1725,18 @@ static int find_range_host_core(rbg_index *ix, const HostReads &R, uint64_t N, u
         s.busy = true;
         b = e;
         t_enq = secs(t_call, now()) - t_pack - t_wait - t_out;
-        // while the GPU works on this chunk: hand the previous one to the caller
-        if ((rc = drain(prev))) break;
+        // while the GPU works: hand the chunks that have finished to the caller, oldest first, without waiting
+        for (unsigned j = 1; j < rbg_hostpath::kSlots && !rc; ++j) {
+            Slot &o = W.slot[(seq - 1 + j) % rbg_hostpath::kSlots];
+            if (!o.busy) continue;
+            if (hipEventQuery(o.done) != hipSuccess) break;
+            rc = drain(o);
+        }
     }
     (void)nout;
-    for (Slot &s : W.slot) {
-        const int r2 = drain(s);
+    for (unsigned j = 0; j < rbg_hostpath::kSlots; ++j) {   // what is still in flight, oldest first
+        Slot &s = W.slot[(seq + j) % rbg_hostpath::kSlots];
+        const int r2 = rc ? RBG_OK : drain(s);
         if (!rc) rc = r2;
         if (rc && s.busy) { (void)hipStreamSynchronize(s.st); s.busy = false; }
     }
@@ -1662,6 +1745,15 @@ static int find_range_host_core(rbg_index *ix, const HostReads &R, uint64_t N, u
         std::fprintf(stderr, "rbg host call: %llu reads, %s, %u threads: %.2f ms = stage %.2f + enqueue/other %.2f + wait for the GPU %.2f + copy out %.2f\n",
                      static_cast<unsigned long long>(N), pack ? "2-bit" : "bytes", T, secs(t_call, now()) * 1e3, t_pack * 1e3, t_enq * 1e3, t_wait * 1e3,
                      t_out * 1e3);
+    if (timeline && !tl.empty()) {
+        for (size_t c = 0; c < tl.size(); ++c) {
+            float t[4] = {0, 0, 0, 0};
+            for (int j = 0; j < 4; ++j) (void)hipEventElapsedTime(&t[j], tl[0].e[0], tl[c].e[j]);
+            std::fprintf(stderr, "  chunk %2zu: enqueued at %7.2f ms (host clock); device clock from the first copy: copy in %7.2f..%7.2f, search ..%7.2f, copy out ..%7.2f\n",
+                         c, tl[c].host_ms, t[0], t[1], t[2], t[3]);
+        }
+        for (ChunkEvents &c : tl) for (hipEvent_t &e : c.e) (void)hipEventDestroy(e);
+    }
     // reads the 2-bit form cannot express (any symbol outside the k-mer alphabet): searched from their bytes
     std::vector<uint64_t> bad;
     for (auto &v : W.bad) bad.insert(bad.end(), v.begin(), v.end());

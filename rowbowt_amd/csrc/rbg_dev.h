@@ -81,17 +81,18 @@ struct DevSym {        // 48 bytes: 344 of them (symbols + 2/3/4-mers) are stage
 // ---- run-indexed layout (RBG_LAYOUT_RUNS): space proportional to r, nothing proportional to n ------------------
 // rank(i, c) = predecessor search over the symbol's sorted run starts (the reference's own structure is O(r) too:
 // rle_string::rank, rle_string.hpp:131-161 over sparse_sd_vector, :110-163), phi(i) = predecessor search over the
-// sampled text positions (toehold_sa.hpp:56-72).  The sorted keys carry a 64-ary sampled index: lvl[0] = every
-// 64th key, lvl[1] = every 64th of those, ...; the coarsest level ("top") is staged in LDS by every workgroup.
-// A probe of one level is ONE coalesced wave-wide load of a 64-entry block (256 B of keys, 512 B of {key, value}
-// pairs at 4-byte positions) compared 64-wide with a ballot: the wave serves its lanes' queries one after the
-// other (k_find_range_runs / k_locate_fill_runs).  Every tree of an index has the same number of levels.
-constexpr int kTreeFan = 64;
-constexpr int kMaxTreeLevels = 4;
+// sampled text positions (toehold_sa.hpp:56-72).  The sorted keys carry a 16-ary sampled index: lvl[0] = every
+// 16th key, lvl[1] = every 16th of those, ...; the coarsest level ("top") is staged in LDS by every workgroup.
+// A probe of one level is ONE coalesced load of a 16-entry block by a 16-lane row of the wave (64 B of keys, 128 B of
+// {key, value} pairs at 4-byte positions: one or two sectors, where a 64-entry block cost four to eight), compared
+// 16-wide with a ballot; a wave-wide load instruction probes for four queries, and all sixteen rounds of a level
+// are in flight together (k_find_range_runs / k_locate_fill_runs).  Every tree of an index has the same number of levels.
+constexpr int kTreeFan = 16;
+constexpr int kMaxTreeLevels = 8;
 constexpr uint32_t kTreeTopBytes = 48 * 1024;  // LDS budget for the staged top levels of all trees of a kernel
 struct DevTree {
     const void *ent;                    // {key, value} pairs of P each (RunEnt<P> / PhiEnt<P>): m entries + 1 sentinel
-    const void *lvl[kMaxTreeLevels];    // lvl[i][j] = key (64^(i+1)) * j; P each; levels [0, nlvl) live in HBM
+    const void *lvl[kMaxTreeLevels];    // lvl[i][j] = key (16^(i+1)) * j; P each; levels [0, nlvl) live in HBM
     uint64_t m;
     uint32_t lvl_n[kMaxTreeLevels];
     uint32_t top_off, top_n;            // this tree's slice of DevIndex::tree_top (level nlvl, staged in LDS)

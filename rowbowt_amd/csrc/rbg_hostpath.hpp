@@ -6,76 +6,17 @@
 //     straight from the caller's bytes into the layout k_find_range_packed consumes (a quarter of the bytes, and no
 //     pack kernel: the bytes are touched once, on the host, where the copy into pinned memory had to touch them
 //     anyway); reads with any other symbol go through the byte kernel afterwards;
-//   * chunks of the batch are double-buffered on two streams: packing chunk c+1 overlaps the copy, the search and
-//     the copy back of chunk c; results leave through pinned memory.
+//   * chunks of the batch go through kSlots buffers on as many streams: the host packs ahead while up to kSlots - 1
+//     chunks are in flight (copy in, search and copy back of successive chunks overlap one another on the device), and
+//     finished chunks are handed to the caller between two packing passes without ever waiting for the GPU unless
+//     every buffer is busy; results leave through pinned memory.
 // Included by rbg_capi.hip only (it needs rbg_index).
 #pragma once
 
-#include <condition_variable>
-#include <functional>
-
 #include "rbg_pack2bit.hpp"
+#include "rbg_thread_team.hpp"
 
 namespace rbg_hostpath {
-
-// ---- a team of worker threads that runs one function on every member and waits ------------------------------------
-class ThreadTeam {
-   public:
-    explicit ThreadTeam(unsigned n) : n_(n ? n : 1) {
-        for (unsigned t = 1; t < n_; ++t) th_.emplace_back([this, t] { loop(t); });
-    }
-    ~ThreadTeam() {
-        {
-            std::lock_guard<std::mutex> g(mu_);
-            stop_ = true;
-            ++gen_;
-        }
-        cv_.notify_all();
-        for (auto &t : th_) t.join();
-    }
-    unsigned size() const { return n_; }
-    void run(const std::function<void(unsigned)> &fn) {  // fn(member) on every member; returns when all are done
-        {
-            std::lock_guard<std::mutex> g(mu_);
-            fn_ = &fn;
-            left_ = n_ - 1;
-            ++gen_;
-        }
-        cv_.notify_all();
-        fn(0);
-        std::unique_lock<std::mutex> g(mu_);
-        done_.wait(g, [this] { return left_ == 0; });
-        fn_ = nullptr;
-    }
-
-   private:
-    void loop(unsigned t) {
-        uint64_t seen = 0;
-        while (true) {
-            const std::function<void(unsigned)> *fn;
-            {
-                std::unique_lock<std::mutex> g(mu_);
-                cv_.wait(g, [&] { return gen_ != seen; });
-                seen = gen_;
-                if (stop_) return;
-                fn = fn_;
-            }
-            (*fn)(t);
-            {
-                std::lock_guard<std::mutex> g(mu_);
-                if (--left_ == 0) done_.notify_one();
-            }
-        }
-    }
-    unsigned n_;
-    std::vector<std::thread> th_;
-    std::mutex mu_;
-    std::condition_variable cv_, done_;
-    const std::function<void(unsigned)> *fn_ = nullptr;
-    unsigned left_ = 0;
-    uint64_t gen_ = 0;
-    bool stop_ = false;
-};
 
 // ---- pinned + device buffers of one in-flight chunk ------------------------------------------------------------------
 struct Slot {
@@ -90,9 +31,11 @@ struct Slot {
     bool busy = false;
 };
 
+constexpr unsigned kSlots = 4;
+
 struct Workspace {
     int device = -1;
-    Slot slot[2];
+    Slot slot[kSlots];
     std::unique_ptr<ThreadTeam> team;
     std::vector<std::vector<uint64_t>> bad;  // per team member: reads (batch indices) the packed form cannot express
     ~Workspace() { release(); }

@@ -13,33 +13,46 @@
 namespace rbg_hostpath {
 
 #if defined(__x86_64__)
-// 32 symbols per step with AVX2 (chosen at run time; the 64-bit SWAR loop below is the portable path and packs
-// what is left).  Returns the number of symbols packed (a multiple of 32); *bad is OR-ed with a non-zero value if
-// any of them is not A, C, G or T.
-__attribute__((target("avx2"))) inline uint64_t pack_blocks_avx2(const uint8_t *q, uint64_t m, uint8_t *dst_bytes, uint64_t *bad) {
+// 32 symbols per step with AVX2 (chosen at run time; the 64-bit SWAR loop below is the portable path).  Packs the whole
+// read when m >= 32: full blocks from the read's end, then ONE overlapping block over the read's first 32 characters for
+// the (m mod 32) symbols that are left -- its packed word shifted down so that only the missing symbols remain -- which
+// replaces a byte-by-byte tail whose data-dependent branches cost more than the three full blocks of a 100 bp read.
+// Returns the number of bytes of dst written (whole symbols of the read; the caller zero-fills the rest of the
+// chunks); *bad is OR-ed with a non-zero value if any symbol is not A, C, G or T.
+// the 32 characters at p, last one first, as 64 bits of codes; *ok keeps all-ones only where the characters are ACGT
+__attribute__((target("avx2"))) inline uint64_t pack_block32_avx2(const uint8_t *p, __m256i *ok) {
     const __m256i rev = _mm256_setr_epi8(15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0, 15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0);
     const __m256i three = _mm256_set1_epi8(3), one = _mm256_set1_epi8(1);
     const __m256i letters = _mm256_setr_epi8('A', 'C', 'G', 'T', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 'A', 'C', 'G', 'T', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0);
     const __m256i w14 = _mm256_set1_epi16(0x0401), w116 = _mm256_set1_epi32(0x00100001);
     const __m256i pick = _mm256_setr_epi8(0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1);
+    __m256i v = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(p));
+    v = _mm256_permute2x128_si256(_mm256_shuffle_epi8(v, rev), _mm256_shuffle_epi8(v, rev), 1);   // p[31] first
+    const __m256i x = _mm256_and_si256(_mm256_srli_epi16(v, 1), three);                             // A 0, C 1, T 2, G 3
+    const __m256i code = _mm256_xor_si256(x, _mm256_and_si256(_mm256_srli_epi16(x, 1), one));        // A 0, C 1, G 2, T 3
+    *ok = _mm256_and_si256(*ok, _mm256_cmpeq_epi8(_mm256_shuffle_epi8(letters, code), v));
+    const __m256i p4 = _mm256_maddubs_epi16(code, w14);      // s[2i] + 4 s[2i+1]
+    const __m256i p8 = _mm256_madd_epi16(p4, w116);          // ... + 16 (s[2i+2] + 4 s[2i+3]): one byte per 32-bit lane
+    const __m256i by = _mm256_shuffle_epi8(p8, pick);
+    const uint32_t lo4 = static_cast<uint32_t>(_mm256_extract_epi32(by, 0)), hi4 = static_cast<uint32_t>(_mm256_extract_epi32(by, 4));
+    return static_cast<uint64_t>(lo4) | (static_cast<uint64_t>(hi4) << 32);
+}
+__attribute__((target("avx2"))) inline uint64_t pack_read_avx2(const uint8_t *q, uint64_t m, uint8_t *dst_bytes, uint64_t *bad) {
     __m256i ok = _mm256_set1_epi8(-1);
     uint64_t t = 0;
     while (t + 32 <= m) {
-        __m256i v = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(q + (m - t - 32)));
-        v = _mm256_permute2x128_si256(_mm256_shuffle_epi8(v, rev), _mm256_shuffle_epi8(v, rev), 1);   // q[m-1-t] first
-        const __m256i x = _mm256_and_si256(_mm256_srli_epi16(v, 1), three);                             // A 0, C 1, T 2, G 3
-        const __m256i code = _mm256_xor_si256(x, _mm256_and_si256(_mm256_srli_epi16(x, 1), one));        // A 0, C 1, G 2, T 3
-        ok = _mm256_and_si256(ok, _mm256_cmpeq_epi8(_mm256_shuffle_epi8(letters, code), v));
-        const __m256i p4 = _mm256_maddubs_epi16(code, w14);      // s[2i] + 4 s[2i+1]
-        const __m256i p8 = _mm256_madd_epi16(p4, w116);          // ... + 16 (s[2i+2] + 4 s[2i+3]): one byte per 32-bit lane
-        const __m256i by = _mm256_shuffle_epi8(p8, pick);
-        const uint32_t lo4 = static_cast<uint32_t>(_mm256_extract_epi32(by, 0)), hi4 = static_cast<uint32_t>(_mm256_extract_epi32(by, 4));
-        const uint64_t out = static_cast<uint64_t>(lo4) | (static_cast<uint64_t>(hi4) << 32);
+        const uint64_t out = pack_block32_avx2(q + (m - t - 32), &ok);             // symbols t .. t+31 (symbol t = q[m-1-t])
         std::memcpy(dst_bytes + (t >> 2), &out, 8);
         t += 32;
     }
+    uint64_t written = t >> 2;
+    if (t < m) {                                                  // symbols t .. m-1 = the read's first m - t characters
+        const uint64_t out = pack_block32_avx2(q, &ok) >> (2 * (32 - (m - t)));    // q[0..31] holds symbols m-32 .. m-1
+        std::memcpy(dst_bytes + (t >> 2), &out, 8);               // (t is a multiple of 32 below m: these 8 bytes lie inside the chunks)
+        written += 8;
+    }
     if (_mm256_movemask_epi8(ok) != -1) *bad |= 1;
-    return t;
+    return written;
 }
 inline bool have_avx2() {
     static const bool v = __builtin_cpu_supports("avx2");
@@ -53,13 +66,18 @@ inline bool have_avx2() {
 // anything else (it is then searched from its bytes).
 inline bool pack_read_acgt(const uint8_t *q, uint64_t m, uint32_t *dst) {
     const uint64_t nwords = ((m + 63) / 64) * 4;
+    uint64_t bad = 0;
+#if defined(__x86_64__)
+    if (m >= 32 && have_avx2()) {
+        uint8_t *d8 = reinterpret_cast<uint8_t *>(dst);
+        const uint64_t written = pack_read_avx2(q, m, d8, &bad);
+        std::memset(d8 + written, 0, nwords * 4 - written);
+        return bad == 0;
+    }
+#endif
     uint16_t *d16 = reinterpret_cast<uint16_t *>(dst);
     const uint64_t nhalf = nwords * 2;
     uint64_t t = 0;        // symbols packed so far
-    uint64_t bad = 0;
-#if defined(__x86_64__)
-    if (m >= 32 && have_avx2()) t = pack_blocks_avx2(q, m, reinterpret_cast<uint8_t *>(dst), &bad);
-#endif
     while (t + 8 <= m) {   // eight symbols per step, SWAR
         uint64_t w;
         std::memcpy(&w, q + (m - t - 8), 8);
@@ -79,13 +97,14 @@ inline bool pack_read_acgt(const uint8_t *q, uint64_t m, uint32_t *dst) {
         t += 8;
     }
     uint64_t filled = t >> 3;
-    if (t < m) {  // the read's first (m mod 8) symbols
+    if (t < m) {  // the read's first (m mod 8) symbols, without data-dependent branches
+        static const char kLetters[4] = {'A', 'C', 'G', 'T'};
         uint32_t y = 0;
         for (uint64_t u = 0; t + u < m; ++u) {
-            const uint8_t c = q[m - 1 - (t + u)];
-            const uint32_t code = c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 4u;
-            if (code > 3u) bad = 1;
-            y |= (code & 3u) << (2 * u);
+            const uint32_t c = q[m - 1 - (t + u)];
+            const uint32_t x = (c >> 1) & 3u, code = x ^ (x >> 1);
+            bad |= static_cast<uint64_t>(c ^ static_cast<uint32_t>(kLetters[code]));
+            y |= code << (2 * u);
         }
         d16[filled++] = static_cast<uint16_t>(y);
     }

@@ -121,6 +121,16 @@ def test_host_side_2bit_packer(tmp_path):
     assert p.returncode == 0 and b"pack2bit ok" in p.stdout, p.stdout[-300:] + p.stderr[-300:]
 
 
+def test_host_thread_team(tmp_path):
+    """rbg_thread_team.hpp (spin-then-sleep worker team of the host-pointer pipeline) under ThreadSanitizer"""
+    import subprocess
+    exe = tmp_path / "team"
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=thread",
+                           os.path.join(ROOT, "tests", "cpp", "thread_team_check.cpp"), "-o", str(exe)])
+    p = subprocess.run([str(exe)], capture_output=True, timeout=300)
+    assert p.returncode == 0 and b"thread team ok" in p.stdout, p.stdout[-300:] + p.stderr[-2000:]
+
+
 def test_python_binding_surface():
     """the ctypes wrapper the tests and bench.py drive the ABI through keeps its methods (a misplaced edit once
     turned one into dead code)"""

@@ -994,6 +994,8 @@ def test_hbm_budget_drops_kmer_levels(synth):
         finally:
             ra.set_default_option(capi.OPT_HBM_BUDGET_MB, 0)
         seen.add(int(rb.info().kmer_steps))
+        # levels that cannot fit are not even composed (options_for in rbg_capi.hip); what was asked for is still reported
+        assert int(rb.info().kmer_steps_requested) == 5 and int(rb.info().hbm_budget) == max(1, int(full * frac) >> 20) << 20
         got = rb.find_range_w_toehold(seqs, off)
         assert all((g == w).all() for g, w in zip(got, want))
         rb.close()
@@ -1294,6 +1296,27 @@ def test_host_pointer_pipeline(small, packed, request):
     for n_small in (1, 2, 100, 5000):
         l4, h4 = rb.find_range(seqs[:int(off[n_small])], off[:n_small + 1])
         assert (l4 == wlo[:n_small]).all() and (h4 == whi[:n_small]).all()
+    # many more chunks than staging buffers (every buffer reused several times, chunks handed back out of lockstep)
+    os.environ["RBG_HOST_CHUNK_READS"] = "70001"
+    try:
+        lo5, hi5, k5 = rb.find_range_w_toehold(seqs, off)
+        lo6, hi6 = rb.find_range_spans(buf, begin, lens)
+    finally:
+        del os.environ["RBG_HOST_CHUNK_READS"]
+    assert (lo5 == wlo).all() and (hi5 == whi).all() and (k5 == wk).all() and (lo6 == wlo).all() and (hi6 == whi).all()
+    # offsets that do not ascend are refused (the staging passes check them chunk by chunk before reading any byte)
+    for where in (1, 4000, N // 2 + 12345, N):
+        bad = off.copy()
+        bad[where] = bad[where - 1] - 1 if bad[where - 1] else np.uint64(2**63)
+        if where < N and bad[where + 1] >= bad[where] and bad[where] >= bad[where - 1]:
+            continue
+        with pytest.raises(ra.RbgError) as ei:
+            rb.find_range(seqs, bad)
+        assert ei.value.code == -4
+    bad = off.copy()
+    bad[0] = 1
+    with pytest.raises(ra.RbgError):
+        rb.count(seqs, bad)
 
 
 @pytest.mark.parametrize("layout", [capi.LAYOUT_AUTO, capi.LAYOUT_RUNS])
