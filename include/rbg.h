@@ -301,6 +301,12 @@ int rbg_markers_fill_dev(rbg_index *, const uint64_t *d_lo, const uint64_t *d_hi
  * accumulated on the device by every query since load / the last reset. */
 int rbg_counters(rbg_index *, uint64_t out[4]);
 int rbg_counters_reset(rbg_index *);
+/* One-read calls (N = 1) of rbg_find_range / rbg_count / rbg_find_range_w_toehold / rbg_get_markers_greedy_seeding
+ * made concurrently by several host threads are combined into one batched launch per round: what lets a caller
+ * written against the reference's one-query-at-a-time methods from a thread pool (its only parallel dispatcher:
+ * rb_markers.cpp:318-535) get batched launches unmodified.  out = {launches, requests served by them} since load;
+ * requests / launches is the mean batch size.  (Environment RBG_HOST_COMBINE=0 switches the combining off.) */
+int rbg_combine_stats(rbg_index *, uint64_t out[2]);
 
 /* ---- several GPUs (index replicated, read stream sharded, no data-path collective; the reference is
  * single-device, its only parallel dispatcher is rb_markers' thread pool, rb_markers.cpp:318-535) --------------- */

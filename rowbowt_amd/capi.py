@@ -110,6 +110,7 @@ _PROTOS = [
     ("rbg_counters_allreduce_local", C.c_int, [VP, C.c_int, VP]),
     ("rbg_counters", C.c_int, [VP, VP]),
     ("rbg_counters_reset", C.c_int, [VP]),
+    ("rbg_combine_stats", C.c_int, [VP, VP]),
     ("rbg_set_default_option", C.c_int, [C.c_int, C.c_int64]),
 ]
 EXPORTS = [p[0] for p in _PROTOS]
@@ -381,6 +382,12 @@ class RowBowt:
 
     def counters_reset(self):
         _check(self.L.rbg_counters_reset(self.h), "rbg_counters_reset")
+
+    def combine_stats(self):
+        """(launches, requests) of the one-read calls that went through the micro-batching queue"""
+        out = np.zeros(2, np.uint64)
+        _check(self.L.rbg_combine_stats(self.h, _p(out)), "rbg_combine_stats")
+        return int(out[0]), int(out[1])
 
 
 def load_rowbowt(prefix, flag=LoadRbwtFlag.NONE, device=0):

@@ -55,6 +55,14 @@ struct rbg_index {
     uint64_t rank_slots = 0, rank_slots_overflow = 0, phi_slots = 0, phi_slots_overflow = 0;
     uint64_t kmer_steps_requested = 0, hbm_free_at_load = 0, hbm_budget = 0;  // how the space/speed point was chosen (rbg_info)
     bool runs_layout = false;
+    // one-read host calls from concurrent threads are combined into one launch ("group commit", see Combiner below)
+    struct Combiner {
+        std::mutex mu;
+        std::condition_variable cv;
+        bool leader = false;
+        std::vector<void *> pending;
+    } comb_range, comb_seeds;
+    std::atomic<uint64_t> comb_launches{0}, comb_requests{0};
     std::mutex ws_mu;            // host-call workspaces (rbg_hostpath.hpp): one per concurrent caller, kept for reuse
     std::vector<std::unique_ptr<rbg_hostpath::Workspace>> ws_free;
     std::vector<DevSym> dense_todo;  // load time only: rank tables whose overflow buckets still need their dense tables
@@ -1492,11 +1500,120 @@ constexpr uint64_t kHostChunkBytes = uint64_t(384) << 20;  // ... and symbols pe
 static int find_range_host_core(rbg_index *ix, const HostReads &R, uint64_t N, uint64_t *lo, uint64_t *hi, uint64_t *ssamp,
                                 uint64_t *count, bool allow_pack);
 
+// ---- micro-batching of one-read calls ---------------------------------------------------------------------------------
+// A caller written against the reference asks one read at a time (RowBowt::find_range(query), rowbowt.hpp:121-131);
+// when several of its threads do so concurrently (the reference's only parallel dispatcher is rb_markers' thread pool,
+// rb_markers.cpp:318-535) their calls are combined: whoever arrives while no launch is being prepared becomes the
+// leader, takes everything that has queued up, runs ONE batched call for it and hands the answers back; whoever arrives
+// in the meantime queues for the next round.  No timer and no added latency: a lone caller's request is a batch of
+// one, and the batch size follows the concurrency by itself.  RBG_HOST_COMBINE=0 switches it off (A/B).
+struct CombineReq {
+    bool done = false;
+    int rc = RBG_OK;
+};
+// exec(batch) answers every request of the batch (sets rc); match(a, b): may b ride in a's batch?
+extern "C++" {
+template <typename Req, typename Match, typename Exec>
+int combine_submit(rbg_index *ix, rbg_index::Combiner &C, Req &mine, Match match, Exec exec) {
+    std::unique_lock<std::mutex> lk(C.mu);
+    C.pending.push_back(&mine);
+    while (!mine.done) {
+        if (C.leader) { C.cv.wait(lk); continue; }
+        C.leader = true;
+        std::vector<Req *> batch;
+        std::vector<void *> rest;
+        for (void *p : C.pending) {
+            Req *r = static_cast<Req *>(p);
+            if (r == &mine || match(mine, *r)) batch.push_back(r); else rest.push_back(p);
+        }
+        C.pending.swap(rest);
+        lk.unlock();
+        int rc_all = RBG_OK;
+        try {
+            exec(batch);
+        } catch (const std::bad_alloc &) {
+            rc_all = RBG_ENOMEM;
+        } catch (...) {
+            rc_all = RBG_EFORMAT;
+        }
+        ix->comb_launches.fetch_add(1, std::memory_order_relaxed);
+        ix->comb_requests.fetch_add(batch.size(), std::memory_order_relaxed);
+        lk.lock();
+        for (Req *r : batch) { if (rc_all) r->rc = rc_all; r->done = true; }
+        C.leader = false;
+        C.cv.notify_all();
+    }
+    return mine.rc;
+}
+}  // extern "C++"
+inline bool combine_enabled() {
+    static const bool on = [] { const char *e = std::getenv("RBG_HOST_COMBINE"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
+struct RangeReq : CombineReq {
+    const uint8_t *seq = nullptr;
+    uint64_t len = 0;
+    bool want_ss = false;
+    uint64_t lo = 1, hi = 0, ss = 0;
+};
+
+// one read through the combiner: find_range / count / find_range_w_toehold with N = 1
+static int find_range_one(rbg_index *ix, const uint8_t *seq, uint64_t len, uint64_t *lo, uint64_t *hi, uint64_t *ssamp, uint64_t *count) {
+    RangeReq mine;
+    mine.seq = seq;
+    mine.len = len;
+    mine.want_ss = ssamp != nullptr;
+    const int rc = combine_submit(ix, ix->comb_range, mine, [](const RangeReq &a, const RangeReq &b) { return a.len <= 0xFFFFFFFFull && b.len <= 0xFFFFFFFFull; },
+        [&](std::vector<RangeReq *> &batch) {
+            const uint64_t K = batch.size();
+            bool any_ss = false;
+            const uint8_t *base = nullptr;
+            for (RangeReq *r : batch) {
+                any_ss = any_ss || r->want_ss;
+                if (r->len && (!base || r->seq < base)) base = r->seq;
+            }
+            std::vector<uint64_t> begin(K), blo(K), bhi(K), bss(any_ss ? K : 0);
+            std::vector<uint32_t> blen(K);
+            HostReads R;
+            int rc2;
+            if (K == 1 && batch[0]->len > 0xFFFFFFFFull) {   // (a read beyond 4 GB: the packed layout takes any length)
+                const uint64_t off[2] = {0, batch[0]->len};
+                R.base = batch[0]->seq;
+                R.off = off;
+                rc2 = find_range_host_core(ix, R, 1, blo.data(), bhi.data(), any_ss ? bss.data() : nullptr, nullptr, true);
+            } else {
+                static const uint8_t kNone = 0;
+                if (!base) base = &kNone;
+                for (uint64_t i = 0; i < K; ++i) {
+                    begin[i] = batch[i]->len ? static_cast<uint64_t>(batch[i]->seq - base) : 0;
+                    blen[i] = static_cast<uint32_t>(batch[i]->len);
+                }
+                R.base = base;
+                R.begin = begin.data();
+                R.len = blen.data();
+                rc2 = find_range_host_core(ix, R, K, blo.data(), bhi.data(), any_ss ? bss.data() : nullptr, nullptr, true);
+            }
+            for (uint64_t i = 0; i < K; ++i) {
+                batch[i]->rc = rc2;
+                batch[i]->lo = blo[i];
+                batch[i]->hi = bhi[i];
+                if (batch[i]->want_ss) batch[i]->ss = bss[i];
+            }
+        });
+    if (rc) return rc;
+    if (lo) { *lo = mine.lo; *hi = mine.hi; }
+    if (ssamp) *ssamp = mine.ss;
+    if (count) *count = mine.hi >= mine.lo ? mine.hi - mine.lo + 1 : 0;
+    return RBG_OK;
+}
+
 static int find_range_host(rbg_index *ix, const uint8_t *seqs, const uint64_t *off, uint64_t N, uint64_t *lo, uint64_t *hi,
                            uint64_t *ssamp, uint64_t *count) {
     if (!queryable(ix)) return RBG_ENODEV;
     if (N == 0) return RBG_OK;
     if (!off || (!seqs && off[N])) return RBG_EARG;
+    if (N == 1 && off[0] == 0 && combine_enabled()) return find_range_one(ix, seqs, off[1], lo, hi, ssamp, count);
     if (off[0] != 0) return RBG_EARG;   // (the rest of check_offsets() is done by the staging passes, chunk by chunk, before any byte is read)
     HostReads R;
     R.base = seqs;
@@ -1976,6 +2093,73 @@ int rbg_marker_seeds_fill_dev(rbg_index *ix, const uint8_t *d_seqs, const uint64
     });
 }
 
+static int marker_seeds_host(rbg_index *ix, const uint8_t *seqs, const uint64_t *off, uint64_t N, uint64_t wsize, uint64_t max_range,
+                             uint64_t ftab_k, uint64_t *seed_off, rbg_marker_seed_t **seeds, uint64_t **mk);
+
+struct SeedsReq : CombineReq {
+    const uint8_t *seq = nullptr;
+    uint64_t len = 0, wsize = 0, max_range = 0, ftab_k = 0;
+    uint64_t nseeds = 0;
+    rbg_marker_seed_t *seeds = nullptr;
+    uint64_t *mk = nullptr;
+};
+
+// one read through the combiner (get_markers_greedy_seeding(query, wsize, max_range, fn) from a thread pool):
+// requests with the same parameters share a launch; each gets its own slice, its marker offsets starting at 0
+static int marker_seeds_one(rbg_index *ix, const uint8_t *seq, uint64_t len, uint64_t wsize, uint64_t max_range, uint64_t ftab_k,
+                            uint64_t *seed_off, rbg_marker_seed_t **seeds, uint64_t **mk) {
+    SeedsReq mine;
+    mine.seq = seq; mine.len = len; mine.wsize = wsize; mine.max_range = max_range; mine.ftab_k = ftab_k;
+    const int rc = combine_submit(ix, ix->comb_seeds, mine,
+        [](const SeedsReq &a, const SeedsReq &b) { return a.wsize == b.wsize && a.max_range == b.max_range && a.ftab_k == b.ftab_k; },
+        [&](std::vector<SeedsReq *> &batch) {
+            const uint64_t K = batch.size();
+            std::vector<uint64_t> off(K + 1, 0), soff(K + 1, 0);
+            for (uint64_t i = 0; i < K; ++i) off[i + 1] = off[i] + batch[i]->len;
+            std::vector<uint8_t> flat(off[K] + 1);
+            for (uint64_t i = 0; i < K; ++i)
+                if (batch[i]->len) std::memcpy(flat.data() + off[i], batch[i]->seq, batch[i]->len);
+            rbg_marker_seed_t *all = nullptr;
+            uint64_t *allmk = nullptr;
+            int rc2 = marker_seeds_host(ix, flat.data(), off.data(), K, mine.wsize, mine.max_range, mine.ftab_k, soff.data(), &all, &allmk);
+            if (!rc2 && K == 1) {   // nothing to split
+                batch[0]->nseeds = soff[1];
+                batch[0]->seeds = all;
+                batch[0]->mk = allmk;
+                all = nullptr;
+                allmk = nullptr;
+            } else if (!rc2) {
+                for (uint64_t i = 0; i < K && !rc2; ++i) {
+                    const uint64_t s0 = soff[i], s1 = soff[i + 1];
+                    const uint64_t m0 = s1 > s0 ? all[s0].mk_begin : 0, m1 = s1 > s0 ? all[s1 - 1].mk_end : 0;
+                    auto *hs = static_cast<rbg_marker_seed_t *>(std::malloc(std::max<size_t>(1, (s1 - s0) * sizeof(rbg_marker_seed_t))));
+                    auto *hm = static_cast<uint64_t *>(std::malloc(std::max<size_t>(1, (m1 - m0) * 8)));
+                    if (!hs || !hm) { std::free(hs); std::free(hm); rc2 = RBG_ENOMEM; break; }
+                    for (uint64_t j = s0; j < s1; ++j) {
+                        hs[j - s0] = all[j];
+                        hs[j - s0].mk_begin -= m0;
+                        hs[j - s0].mk_end -= m0;
+                    }
+                    if (m1 > m0) std::memcpy(hm, allmk + m0, (m1 - m0) * 8);
+                    batch[i]->nseeds = s1 - s0;
+                    batch[i]->seeds = hs;
+                    batch[i]->mk = hm;
+                }
+            }
+            std::free(all);
+            std::free(allmk);
+            if (rc2)
+                for (SeedsReq *r : batch) { std::free(r->seeds); std::free(r->mk); r->seeds = nullptr; r->mk = nullptr; }
+            for (SeedsReq *r : batch) r->rc = rc2;
+        });
+    if (rc) return rc;
+    seed_off[0] = 0;
+    seed_off[1] = mine.nseeds;
+    *seeds = mine.seeds;
+    *mk = mine.mk;
+    return RBG_OK;
+}
+
 int rbg_get_markers_greedy_seeding(rbg_index *ix, const uint8_t *seqs, const uint64_t *off, uint64_t N, uint64_t wsize,
                                    uint64_t max_range, uint64_t ftab_k, uint64_t *seed_off, rbg_marker_seed_t **seeds, uint64_t **mk) {
     return guarded([&]() -> int {
@@ -1985,6 +2169,17 @@ int rbg_get_markers_greedy_seeding(rbg_index *ix, const uint8_t *seqs, const uin
     *mk = nullptr;
     int rc = check_offsets(off, N);
     if (rc) return rc;
+    if (N == 1 && combine_enabled()) return marker_seeds_one(ix, seqs, off[1], wsize, max_range, ftab_k, seed_off, seeds, mk);
+    return marker_seeds_host(ix, seqs, off, N, wsize, max_range, ftab_k, seed_off, seeds, mk);
+    });
+}
+
+static int marker_seeds_host(rbg_index *ix, const uint8_t *seqs, const uint64_t *off, uint64_t N, uint64_t wsize, uint64_t max_range,
+                             uint64_t ftab_k, uint64_t *seed_off, rbg_marker_seed_t **seeds, uint64_t **mk) {
+    {
+    int rc;
+    *seeds = nullptr;
+    *mk = nullptr;
     DeviceScope scope(ix->device);
     if (scope.rc) return scope.rc;
     hipStream_t st = hipStreamPerThread;
@@ -2021,7 +2216,7 @@ int rbg_get_markers_greedy_seeding(rbg_index *ix, const uint8_t *seqs, const uin
     *seeds = h_seeds;
     *mk = h_mk;
     return RBG_OK;
-    });
+    }
 }
 
 // ---- greedy seeding (next-row f4) -----------------------------------------------------------------
@@ -2244,6 +2439,14 @@ int rbg_counters(rbg_index *ix, uint64_t out[4]) {
     HIP_TRY(hipMemcpy(out, ix->dev.counters, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return RBG_OK;
     });
+}
+
+int rbg_combine_stats(rbg_index *ix, uint64_t out[2]) {
+    if (!ix || !out) return RBG_EARG;
+    rbg_index *root = ix;
+    out[0] = root->comb_launches.load(std::memory_order_relaxed);
+    out[1] = root->comb_requests.load(std::memory_order_relaxed);
+    return RBG_OK;
 }
 
 int rbg_counters_reset(rbg_index *ix) {

@@ -1,6 +1,7 @@
 """Parity tests proper: the HIP path (through the C-ABI) against the oracle and the reference's
 golden values.  Bit-exact: everything on this path is unsigned 64-bit integer work.  Need an MI355X."""
 import os
+import re
 
 import numpy as np
 import pytest
@@ -936,6 +937,27 @@ def test_cpp_shim_reference_goldens(tmp_path, data_dir):
     assert b"shim goldens ok" in p.stdout
 
 
+def test_cpp_threaded_one_read_caller(tmp_path, data_dir):
+    """tests/cpp/shim_threads.cpp: a thread pool calling the reference's one-query methods through the shim, unmodified
+    (rb_markers.cpp:318-535's shape); answers equal the batch forms, and the library's micro-batching queue serves the
+    calls with fewer launches than calls (printed: rate with and without it)"""
+    import subprocess
+    from test_capi_host import ROOT
+    exe = tmp_path / "shim_threads"
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-pthread", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "rowbowt_amd", "include"),
+                           os.path.join(ROOT, "tests", "cpp", "shim_threads.cpp"), "-o", str(exe),
+                           "-L", os.path.join(ROOT, "rowbowt_amd"), "-lrbg", "-Wl,-rpath," + os.path.join(ROOT, "rowbowt_amd")])
+    prefix, fasta = os.path.join(data_dir, "small.fa"), os.path.join(data_dir, "small.fa")
+    for combine, threads in (("1", 16), ("0", 16), ("1", 1)):
+        env = dict(os.environ, RBG_HOST_COMBINE=combine)
+        p = subprocess.run([str(exe), prefix, fasta, str(threads), "4000"], capture_output=True, timeout=600, env=env)
+        assert p.returncode == 0 and b"shim threads ok" in p.stdout, p.stdout.decode()[-500:] + p.stderr.decode()[-1500:]
+        print(f"RBG_HOST_COMBINE={combine}:", p.stdout.decode().splitlines()[0])
+        if combine == "1" and threads == 16:
+            m = re.search(r"(\d+) one-read calls in (\d+) launches", p.stdout.decode())
+            assert m and int(m.group(1)) == 9000 and int(m.group(2)) < int(m.group(1))
+
+
 def test_c_abi_example_program(tmp_path, data_dir):
     """tests/c/abi_usage.c (plain C11 over include/rbg.h): the reference's golden values through the C-ABI"""
     import subprocess
@@ -1447,6 +1469,74 @@ def test_concurrent_queries_one_index(synth):
     # the device counters saw every call exactly once: 5 rounds x (toehold search + count search), 5 x locate
     c = rb.counters()
     assert int(c[0]) == 10 * sum(len(j[1]) - 1 for j in jobs) and int(c[3]) == 5 * sum(int(j[5][-1]) for j in jobs)
+    rb.close()
+    o.close()
+
+
+def test_one_read_calls_from_threads_are_combined(synth):
+    """An unmodified threaded caller of the reference's one-query methods (rb_markers.cpp:318-535): twelve threads each
+    asking ONE read per call -- find_range, count, find_range_w_toehold, get_markers_greedy_seeding with two different
+    parameter sets -- get the oracle's answers, and the calls are served by fewer, batched launches (rbg_combine_stats)."""
+    import threading
+    S = synth
+    rb = ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0)
+    ms, me, mo, mv = S.markers(wsize=10)
+    rb.set_markers(ms, me, mo, mv)
+    o = orc.Oracle.from_runs(S.heads, S.lens, S.ssa, S.esa)
+    o.set_markers(ms, me, mo, mv)
+    T, per = 12, 120
+    reads = S.sample_reads(T * per, 70, seed=4242, sub_rate=0.2, ragged=True)
+    reads[5] = b""
+    reads[17] = b"ACGTNACGT"
+    seqs, off = ra.pack_reads(reads)
+    wlo, whi, wk = o.find_range_w_toehold_batch(seqs, off)
+    want_seeds = {}
+    for ws, mr in ((10, 1000), (7, 50)):
+        so, sd, mk = rb.get_markers_greedy_seeding(seqs, off, ws, mr)     # the batched call (itself checked against the oracle elsewhere)
+        want_seeds[(ws, mr)] = (so, sd, mk)
+    _check_marker_seeds(rb, o, reads[:60], 10, 1000)
+    l0, r0 = rb.combine_stats()
+    errors = []
+
+    def worker(t):
+        try:
+            for i in range(t * per, (t + 1) * per):
+                q = np.frombuffer(reads[i], dtype=np.uint8)
+                o1 = np.array([0, len(q)], dtype=np.uint64)
+                kind = (i + t) % 4
+                if kind == 0:
+                    lo, hi = rb.find_range(q, o1)
+                    ok = (int(lo[0]), int(hi[0])) == (int(wlo[i]), int(whi[i]))
+                elif kind == 1:
+                    c = rb.count(q, o1)
+                    ok = int(c[0]) == (int(whi[i]) - int(wlo[i]) + 1 if whi[i] >= wlo[i] else 0)
+                elif kind == 2:
+                    lo, hi, k = rb.find_range_w_toehold(q, o1)
+                    ok = (int(lo[0]), int(hi[0]), int(k[0])) == (int(wlo[i]), int(whi[i]), int(wk[i]))
+                else:
+                    ws, mr = ((10, 1000), (7, 50))[t % 2]
+                    so, sd, mk = rb.get_markers_greedy_seeding(q, o1, ws, mr)
+                    wso, wsd, wmk = want_seeds[(ws, mr)]
+                    a, b = int(wso[i]), int(wso[i + 1])
+                    ok = int(so[1]) == b - a and len(sd) == b - a
+                    if ok and b > a:
+                        m0 = int(wsd[a, 4])
+                        ok = (sd[:, :4] == wsd[a:b, :4]).all() and (sd[:, 4:] == wsd[a:b, 4:] - np.uint64(m0)).all() \
+                            and (mk == wmk[m0:int(wsd[b - 1, 5])]).all()
+                if not ok:
+                    errors.append((t, i, kind))
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:5]
+    l1, r1 = rb.combine_stats()
+    assert r1 - r0 == T * per and 0 < l1 - l0 <= r1 - r0
+    print(f"combined: {r1 - r0} one-read calls in {l1 - l0} launches ({(r1 - r0) / (l1 - l0):.1f} per launch)")
     rb.close()
     o.close()
 

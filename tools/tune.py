@@ -54,6 +54,9 @@ for cfg in args.configs.split(","):
         ra.set_default_option(capi.OPT_FTAB_K, int(os.environ["RBG_TUNE_FTAB_K"]))
     if os.environ.get("RBG_TUNE_DENSE"):
         ra.set_default_option(capi.OPT_DENSE_OVERFLOW, int(os.environ["RBG_TUNE_DENSE"]))
+    if os.environ.get("RBG_TUNE_LAYOUT"):   # "runs": the run-indexed layout (space proportional to r); optional sixth field of a config = LDS KB of its top level
+        ra.set_default_option(capi.OPT_RANK_LAYOUT, capi.LAYOUT_RUNS if os.environ["RBG_TUNE_LAYOUT"] == "runs" else capi.LAYOUT_SLOTS)
+        ra.set_default_option(capi.OPT_TREE_TOP_KB, parts[5] if len(parts) > 5 else 48)
     if os.environ.get("RBG_TUNE_BUDGET_MB"):
         ra.set_default_option(capi.OPT_HBM_BUDGET_MB, int(os.environ["RBG_TUNE_BUDGET_MB"]))
     t0 = time.time()
