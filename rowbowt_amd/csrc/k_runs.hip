@@ -43,23 +43,40 @@ __device__ __forceinline__ uint32_t top_count(const P *s_top, uint32_t off, uint
     return a;
 }
 
+// A query is a predecessor search CLAMPED to a slice [lo_t, hi_t) of the tree's entry array (one table of a k-mer
+// depth, rbg_dev.h DevRunTab; the whole array for phi): entries before the slice count as below the query, entries
+// from hi_t on as not below it.  For the 16 entries of the block that starts at entry index `gbase` of a level whose
+// entries stand `1 << sh` apart in the leaf array, that is: the first `a` lanes are below whatever their key, lanes
+// from `z` on are not; both fit five bits.
+__device__ __forceinline__ uint32_t clamp_lanes(uint64_t bound, uint64_t gbase, int sh) {
+    if (bound <= gbase) return 0;
+    const uint64_t d = (bound - gbase + ((uint64_t(1) << sh) - 1)) >> sh;
+    return d > static_cast<uint64_t>(kFan) ? static_cast<uint32_t>(kFan) : static_cast<uint32_t>(d);
+}
+// info word an owner publishes to its row for one level: bit 0 any query, bit 1 second block, bits 2-4 tree,
+// bits 5-9 / 10-14 (a, z) of the first block, bits 15-19 / 20-24 (a, z) of the second
+__device__ __forceinline__ uint32_t level_info(bool any, bool two, uint32_t tid, uint32_t first, uint32_t b1, uint32_t lo_t, uint32_t hi_t, int sh) {
+    const uint64_t g0 = (static_cast<uint64_t>(first) * kFan) << sh, g1 = (static_cast<uint64_t>(b1) * kFan) << sh;
+    return (any ? 1u : 0u) | (two ? 2u : 0u) | (tid << 2) | (clamp_lanes(lo_t, g0, sh) << 5) | (clamp_lanes(hi_t, g0, sh) << 10) |
+           (clamp_lanes(lo_t, g1, sh) << 15) | (clamp_lanes(hi_t, g1, sh) << 20);
+}
+
 // One sampled level (keys only), for up to two queries per lane.  On entry t0 / t1 = # entries of the level ABOVE
-// that are < q (>= 1 for a live query): the answer at this level lies in block t - 1.  On return t = # entries of
-// THIS level that are < q.  Every lane of the wave must call.
+// that are below q (>= 1 for a live query): the answer at this level lies in block t - 1.  On return t = # entries of
+// THIS level that are below q.  Every lane of the wave must call.
 // The wave works in kFan rounds: in round j each 16-lane row serves the queries of ITS lane j -- the row's lanes load
 // the 16 keys of that owner's block with one coalesced request (four owners per wave-wide load instruction), the
 // owner's query is broadcast along the row, and popcount(ballot) over the row is the answer.  All 16 rounds' loads are
 // issued before the first compare, so a level costs one memory round trip per wave, not one per owner.
 template <typename P>
-__device__ __forceinline__ void coop_level(const DevTree *s_tree, const int l, const uint32_t tid, const bool live0, const bool live1,
-                                           uint32_t &t0, uint32_t &t1, const P q0, const P q1) {
+__device__ __forceinline__ void coop_level(const DevTree *s_tree, const int l, const uint32_t tid, const uint32_t lo_t, const uint32_t hi_t,
+                                           const bool live0, const bool live1, uint32_t &t0, uint32_t &t1, const P q0, const P q1) {
     const uint32_t lane = threadIdx.x & (kWave - 1), sub = lane & (kFan - 1), rowbase = lane & ~static_cast<uint32_t>(kFan - 1);
     if (!__ballot(live0 || live1)) return;
     const uint32_t b0 = t0 - 1, b1 = t1 - 1;
     const bool two = live0 && live1 && b0 != b1;                     // the second query needs a block of its own
-    // what the row has to know about an owner, in one word: bit 0 any query, bit 1 second block, bits 2.. tree
-    const uint32_t info = ((live0 || live1) ? 1u : 0u) | (two ? 2u : 0u) | (tid << 2);
     const uint32_t first = live0 ? b0 : b1;
+    const uint32_t info = level_info(live0 || live1, two, tid, first, b1, lo_t, hi_t, 4 * (l + 1));
     P va[kFan];
 #pragma unroll
     for (int j = 0; j < kFan; ++j) {
@@ -67,7 +84,7 @@ __device__ __forceinline__ void coop_level(const DevTree *s_tree, const int l, c
         const uint32_t ob = row_get(first, rowbase, j);
         va[j] = static_cast<P>(~P(0));
         if (oi & 1u) {
-            const DevTree &T = s_tree[oi >> 2];
+            const DevTree &T = s_tree[(oi >> 2) & 7u];
             const uint64_t i = static_cast<uint64_t>(ob) * kFan + sub;
             if (i < T.lvl_n[l]) va[j] = static_cast<const P *>(T.lvl[l])[i];
         }
@@ -75,8 +92,13 @@ __device__ __forceinline__ void coop_level(const DevTree *s_tree, const int l, c
 #pragma unroll
     for (int j = 0; j < kFan; ++j) {
         // padding lanes hold the all-ones key, which no query exceeds (positions stay below it: flatten())
-        const uint32_t c0 = row_count(va[j] < row_get(q0, rowbase, j), rowbase);
-        const uint32_t c1 = row_count(va[j] < row_get(q1, rowbase, j), rowbase);
+        const uint32_t oi = row_get(info, rowbase, j);
+        const uint32_t a = (oi >> 5) & 31u, z = (oi >> 10) & 31u;
+        const bool in = sub < z;
+        // (the broadcasts are cross-lane operations: every lane must execute them, so they stay outside the || / &&)
+        const P oq0 = row_get(q0, rowbase, j), oq1 = row_get(q1, rowbase, j);
+        const uint32_t c0 = row_count(sub < a || (in && va[j] < oq0), rowbase);
+        const uint32_t c1 = row_count(sub < a || (in && va[j] < oq1), rowbase);
         if (static_cast<int>(sub) == j) {
             if (live0) t0 = b0 * kFan + c0;
             if (live1 && !two) t1 = b1 * kFan + c1;
@@ -89,32 +111,36 @@ __device__ __forceinline__ void coop_level(const DevTree *s_tree, const int l, c
         const uint32_t ob = row_get(b1, rowbase, j);
         va[j] = static_cast<P>(~P(0));
         if (oi & 2u) {
-            const DevTree &T = s_tree[oi >> 2];
+            const DevTree &T = s_tree[(oi >> 2) & 7u];
             const uint64_t i = static_cast<uint64_t>(ob) * kFan + sub;
             if (i < T.lvl_n[l]) va[j] = static_cast<const P *>(T.lvl[l])[i];
         }
     }
 #pragma unroll
     for (int j = 0; j < kFan; ++j) {
-        const uint32_t c1 = row_count(va[j] < row_get(q1, rowbase, j), rowbase);
+        const uint32_t oi = row_get(info, rowbase, j);
+        const uint32_t a = (oi >> 15) & 31u, z = (oi >> 20) & 31u;
+        const P oq1 = row_get(q1, rowbase, j);
+        const uint32_t c1 = row_count(sub < a || (sub < z && va[j] < oq1), rowbase);
         if (static_cast<int>(sub) == j && two) t1 = b1 * kFan + c1;
     }
 }
 
-// The leaf level: {key, value} pairs, probed the same way.  For each live query returns k = # keys < q (in t), the
-// pair before it (key pk, value pv: entry k-1) and the value of entry k (nv; the arrays carry a sentinel entry).
-// Entries k-1 and k are read out of the registers of the row's lanes that loaded them: a rank costs no further gather.
+// The leaf level: {key, value} pairs, probed the same way.  For each live query returns g = # entries below q (in t),
+// the pair before it (key pk, value pv: entry g-1) and the value of entry g (nv; every slice ends with a sentinel).
+// Entries g-1 and g are read out of the registers of the row's lanes that loaded them: a rank costs no further gather.
 template <typename P>
-__device__ __forceinline__ void coop_leaf(const DevTree *s_tree, const uint32_t tid, const bool live0, const bool live1, uint32_t &t0,
-                                          uint32_t &t1, const P q0, const P q1, P &pk0, P &pv0, P &nv0, P &pk1, P &pv1, P &nv1) {
+__device__ __forceinline__ void coop_leaf(const DevTree *s_tree, const uint32_t tid, const uint32_t lo_t, const uint32_t hi_t, const bool live0,
+                                          const bool live1, uint32_t &t0, uint32_t &t1, const P q0, const P q1, P &pk0, P &pv0, P &nv0, P &pk1,
+                                          P &pv1, P &nv1) {
     typedef typename PairOf<P>::vec vec;
     const uint32_t lane = threadIdx.x & (kWave - 1), sub = lane & (kFan - 1), rowbase = lane & ~static_cast<uint32_t>(kFan - 1);
     if (!__ballot(live0 || live1)) return;
     const uint32_t b0 = t0 - 1, b1 = t1 - 1;
     const bool two = live0 && live1 && b0 != b1;
-    const uint32_t info = ((live0 || live1) ? 1u : 0u) | (two ? 2u : 0u) | (tid << 2);
     const uint32_t first = live0 ? b0 : b1;
-    bool fix0 = false, fix1 = false;  // entry k is the first of the next block: fetched by the owner afterwards
+    const uint32_t info = level_info(live0 || live1, two, tid, first, b1, lo_t, hi_t, 0);
+    bool fix0 = false, fix1 = false;  // entry g is the first of the next block: fetched by the owner afterwards
     vec va[kFan];
 #pragma unroll
     for (int j = 0; j < kFan; ++j) {
@@ -122,17 +148,20 @@ __device__ __forceinline__ void coop_leaf(const DevTree *s_tree, const uint32_t 
         const uint32_t ob = row_get(first, rowbase, j);
         va[j] = vec{static_cast<P>(~P(0)), 0};
         if (oi & 1u) {
-            const DevTree &T = s_tree[oi >> 2];
+            const DevTree &T = s_tree[(oi >> 2) & 7u];
             const uint64_t i = static_cast<uint64_t>(ob) * kFan + sub;
-            if (i <= T.m) va[j] = static_cast<const vec *>(T.ent)[i];   // entry m is the sentinel (key = n: never < q)
+            if (i <= T.m) va[j] = static_cast<const vec *>(T.ent)[i];   // entry m is the last sentinel
         }
     }
 #pragma unroll
     for (int j = 0; j < kFan; ++j) {
-        // the sentinel (key n) and the padding never compare below a query (q <= n)
-        const uint32_t c0 = row_count(static_cast<P>(va[j].x) < row_get(q0, rowbase, j), rowbase);
-        const uint32_t c1 = row_count(static_cast<P>(va[j].x) < row_get(q1, rowbase, j), rowbase);
-        // a live query has c >= 1 (entry 16*block is the sample that was < q one level up); entries c - 1 and c are lanes
+        const uint32_t oi = row_get(info, rowbase, j);
+        const uint32_t a = (oi >> 5) & 31u, z = (oi >> 10) & 31u;
+        const bool in = sub < z;
+        const P oq0 = row_get(q0, rowbase, j), oq1 = row_get(q1, rowbase, j);   // (cross-lane: outside the || / &&)
+        const uint32_t c0 = row_count(sub < a || (in && static_cast<P>(va[j].x) < oq0), rowbase);
+        const uint32_t c1 = row_count(sub < a || (in && static_cast<P>(va[j].x) < oq1), rowbase);
+        // a live query has c >= 1 (entry 16*block is the sample that was below q one level up); entries c - 1 and c are lanes
         const uint32_t p0 = c0 ? c0 - 1 : 0, n0 = c0 < kFan ? c0 : kFan - 1;
         const uint32_t p1 = c1 ? c1 - 1 : 0, n1 = c1 < kFan ? c1 : kFan - 1;
         const P a_pk0 = row_pick(static_cast<P>(va[j].x), rowbase, p0), a_pv0 = row_pick(static_cast<P>(va[j].y), rowbase, p0), a_nv0 = row_pick(static_cast<P>(va[j].y), rowbase, n0);
@@ -149,14 +178,17 @@ __device__ __forceinline__ void coop_leaf(const DevTree *s_tree, const uint32_t 
             const uint32_t ob = row_get(b1, rowbase, j);
             va[j] = vec{static_cast<P>(~P(0)), 0};
             if (oi & 2u) {
-                const DevTree &T = s_tree[oi >> 2];
+                const DevTree &T = s_tree[(oi >> 2) & 7u];
                 const uint64_t i = static_cast<uint64_t>(ob) * kFan + sub;
                 if (i <= T.m) va[j] = static_cast<const vec *>(T.ent)[i];
             }
         }
 #pragma unroll
         for (int j = 0; j < kFan; ++j) {
-            const uint32_t c1 = row_count(static_cast<P>(va[j].x) < row_get(q1, rowbase, j), rowbase);
+            const uint32_t oi = row_get(info, rowbase, j);
+            const uint32_t a = (oi >> 15) & 31u, z = (oi >> 20) & 31u;
+            const P oq1 = row_get(q1, rowbase, j);
+            const uint32_t c1 = row_count(sub < a || (sub < z && static_cast<P>(va[j].x) < oq1), rowbase);
             const uint32_t p1 = c1 ? c1 - 1 : 0, n1 = c1 < kFan ? c1 : kFan - 1;
             const P a_pk1 = row_pick(static_cast<P>(va[j].x), rowbase, p1), a_pv1 = row_pick(static_cast<P>(va[j].y), rowbase, p1), a_nv1 = row_pick(static_cast<P>(va[j].y), rowbase, n1);
             if (static_cast<int>(sub) == j && two) { t1 = b1 * kFan + c1; pk1 = a_pk1; pv1 = a_pv1; nv1 = a_nv1; fix1 = c1 == kFan; }
@@ -169,35 +201,47 @@ __device__ __forceinline__ void coop_leaf(const DevTree *s_tree, const uint32_t 
     }
 }
 
+// per-lane search of the staged top level, clamped like the levels below: entries [a, z) of the tree's slice of s_top
+// are the ones inside the query's slice; returns # top entries below q
+template <typename P>
+__device__ __forceinline__ uint32_t top_count_clamped(const P *s_top, const DevTree &T, int top_sh, uint32_t lo_t, uint32_t hi_t, uint64_t q) {
+    const uint64_t S1 = (uint64_t(1) << top_sh) - 1;
+    uint64_t a = (static_cast<uint64_t>(lo_t) + S1) >> top_sh, z = (static_cast<uint64_t>(hi_t) + S1) >> top_sh;
+    if (z > T.top_n) z = T.top_n;
+    if (a > z) a = z;
+    return static_cast<uint32_t>(a) + top_count<P>(s_top, T.top_off + static_cast<uint32_t>(a), static_cast<uint32_t>(z - a), q);
+}
+
 // ---- K1 / K2 over the run-indexed layout ------------------------------------------------------------------------
-// RowBowt::find_range (rowbowt.hpp:121-131) / find_range_w_toehold (:169-184): one reference LF step per iteration
-// (rowbowt.hpp:74-88, LF_w_loc :555-573), both ranks of all the wave's reads answered cooperatively.  The device
-// ftab (a constant-size state table, result-neutral) still replaces the first ftab_k steps.
+// RowBowt::find_range (rowbowt.hpp:121-131) / find_range_w_toehold (:169-184).  A step consumes up to run_ksteps read
+// symbols through the k-mer depth's table, exactly as k_find_range does with its slot tables (k_search.hip; DESIGN.md
+// 2b: identical to that many nested RowBowt::LF / LF_w_loc calls, rowbowt.hpp:74-88, :555-573); both ranks of all
+// the wave's reads are answered cooperatively.  The device ftab (a constant-size state table, result-neutral) still
+// replaces the first ftab_k steps.
 template <typename P, bool TOEHOLD>
-__global__ __launch_bounds__(256) void k_find_range_runs(const DevIndex ix, const uint8_t *__restrict__ seqs,
+__global__ __launch_bounds__(512) void k_find_range_runs(const DevIndex ix, const uint8_t *__restrict__ seqs,
                                                         const uint64_t *__restrict__ off, const uint64_t N,
                                                         uint64_t *__restrict__ lo_out, uint64_t *__restrict__ hi_out,
                                                         uint64_t *__restrict__ ss_out) {
     __shared__ uint8_t s_lut[256];
     __shared__ uint8_t s_lut2[256];
-    __shared__ DevTree s_tree[kLdsSyms];
-    __shared__ uint64_t s_F[kLdsSyms];
-    __shared__ const void *s_samp[kLdsSyms];
+    __shared__ DevTree s_tree[kMaxRunDepth];
+    __shared__ uint32_t s_tab_first[kMaxRunDepth + 1];
     extern __shared__ __align__(16) unsigned char s_dyn[];
-    P *s_top = reinterpret_cast<P *>(s_dyn);
+    DevRunTab *s_tab = reinterpret_cast<DevRunTab *>(s_dyn);
+    P *s_top = reinterpret_cast<P *>(s_dyn + static_cast<size_t>(ix.run_ntabs) * sizeof(DevRunTab));
     for (int t = threadIdx.x; t < 256; t += blockDim.x) {
         s_lut[t] = ix.lut[t];
         s_lut2[t] = ix.nmajor ? ix.lut2[t] : 0xFFu;
     }
-    const int nsym = ix.sigma < static_cast<uint32_t>(kLdsSyms) ? static_cast<int>(ix.sigma) : kLdsSyms;
-    for (int t = threadIdx.x; t < nsym; t += blockDim.x) {
-        s_tree[t] = ix.trees[t];
-        s_F[t] = ix.syms[t].F;
-        s_samp[t] = ix.syms[t].samp;
-    }
+    const uint32_t D = ix.run_ksteps;
+    for (uint32_t t = threadIdx.x; t < D; t += blockDim.x) s_tree[t] = ix.trees[t];
+    for (uint32_t t = threadIdx.x; t <= static_cast<uint32_t>(kMaxRunDepth); t += blockDim.x) s_tab_first[t] = ix.run_tab_first[t];
+    for (uint32_t t = threadIdx.x; t < ix.run_ntabs; t += blockDim.x) s_tab[t] = ix.run_tabs[t];
     for (uint32_t t = threadIdx.x; t < ix.tree_top_n; t += blockDim.x) s_top[t] = static_cast<const P *>(ix.tree_top)[t];
     __syncthreads();
     const int nlvl = static_cast<int>(ix.tree_nlvl);
+    const int top_sh = 4 * (nlvl + 1);
     const uint32_t M = ix.nmajor;
     const uint32_t lane = threadIdx.x & (kWave - 1);
 
@@ -213,8 +257,8 @@ __global__ __launch_bounds__(256) void k_find_range_runs(const DevIndex ix, cons
         uint64_t lo = 0, hi = ix.n - 1;                       // full_range(), rowbowt.hpp:115-118
         uint64_t k = TOEHOLD ? ix.last_run_sample : 0;
         bool alive = valid;
-        bool pend = false;                                     // deferred toehold re-sample: run `pend_run` of symbol `pend_sym`
-        uint32_t pend_sym = 0, pend_run = 0;
+        bool pend = false;                                     // deferred toehold re-sample: entry `pend_run` of depth `pend_d`
+        uint32_t pend_d = 0, pend_run = 0;
         ByteCursor rd{reinterpret_cast<const uint4 *>(seqs), ~uint64_t(0), make_uint4(0, 0, 0, 0)};
         if (valid && ix.ftab_k && p - beg >= ix.ftab_k) {      // rowbowt.hpp:124-125, :745-758 (k_search.hip)
             uint64_t idx = 0, pw = 1;
@@ -235,55 +279,85 @@ __global__ __launch_bounds__(256) void k_find_range_runs(const DevIndex ix, cons
         }
         while (__ballot(alive && p > beg)) {                   // right-to-left over the reads (rowbowt.hpp:127-129, :175-181)
             bool stepping = alive && p > beg;
-            uint32_t slot = 0;
+            uint32_t d = 0, adv = 1, rec = 0;                  // depth index (adv - 1), symbols consumed, record in s_tab
             if (stepping) {
                 --p;
-                slot = s_lut[rd.at(p)];
-                if (slot == 0xFFu || slot >= static_cast<uint32_t>(kLdsSyms)) {
-                    // symbol absent (f_[c] >= f_[c+1], rowbowt.hpp:76).  (An index with more than kLdsSyms symbols is
-                    // never given this layout: upload() keeps the slot tables for it.)
-                    alive = false;
-                    stepping = false;
-                    slot = 0;
+                const uint32_t c = rd.at(p);
+                const uint32_t m0 = s_lut2[c];
+                uint32_t acc = m0;
+                if (m0 != 0xFFu) {                              // the longest run of major symbols among the next D (k_search.hip)
+                    uint32_t pw = M;
+#pragma unroll 1
+                    for (uint32_t t = 1; t < static_cast<uint32_t>(kMaxRunDepth); ++t) {
+                        if (t >= D || p < beg + t) break;
+                        const uint32_t mm = s_lut2[rd.at(p - t)];
+                        if (mm == 0xFFu) break;
+                        acc += mm * pw;
+                        pw *= M;
+                        adv = t + 1;
+                    }
                 }
+                if (adv == 1) {
+                    const uint32_t slot = s_lut[c];
+                    if (slot == 0xFFu || slot >= static_cast<uint32_t>(kLdsSyms)) {
+                        // symbol absent (f_[c] >= f_[c+1], rowbowt.hpp:76).  (An index with more than kLdsSyms symbols is
+                        // never given this layout: upload() keeps the slot tables for it.)
+                        alive = false;
+                        stepping = false;
+                    } else {
+                        rec = s_tab_first[0] + slot;
+                    }
+                } else {
+                    d = adv - 1;
+                    rec = s_tab_first[d] + acc;
+                }
+            }
+            uint32_t lo_t = 0, hi_t = 0;
+            uint64_t F = 0;
+            if (stepping) {
+                const DevRunTab r0 = s_tab[rec];
+                F = r0.F;
+                lo_t = static_cast<uint32_t>(r0.first);
+                hi_t = static_cast<uint32_t>(s_tab[rec + 1].first) - 1;   // the slice's sentinel: never below a query
             }
             const uint64_t q0 = lo, q1 = hi + 1;               // rank(lo, c), rank(hi + 1, c): rowbowt.hpp:79,83
             uint32_t t0 = 0, t1 = 0;
             if (stepping) {
-                const DevTree &T = s_tree[slot];
-                t0 = top_count<P>(s_top, T.top_off, T.top_n, q0);
-                t1 = top_count<P>(s_top, T.top_off, T.top_n, q1);
+                t0 = top_count_clamped<P>(s_top, s_tree[d], top_sh, lo_t, hi_t, q0);
+                t1 = top_count_clamped<P>(s_top, s_tree[d], top_sh, lo_t, hi_t, q1);
             }
             // (positions fit P: q1 = hi + 1 <= n, and n stays below the all-ones key, flatten())
             for (int l = nlvl - 1; l >= 0; --l) {
                 const bool l0 = stepping && t0 > 0, l1 = stepping && t1 > 0;
-                coop_level<P>(s_tree, l, slot, l0, l1, t0, t1, static_cast<P>(q0), static_cast<P>(q1));
+                coop_level<P>(s_tree, l, d, lo_t, hi_t, l0, l1, t0, t1, static_cast<P>(q0), static_cast<P>(q1));
             }
             P pk0 = 0, pv0 = 0, nv0 = 0, pk1 = 0, pv1 = 0, nv1 = 0;
             {
                 const bool l0 = stepping && t0 > 0, l1 = stepping && t1 > 0;
-                coop_leaf<P>(s_tree, slot, l0, l1, t0, t1, static_cast<P>(q0), static_cast<P>(q1), pk0, pv0, nv0, pk1, pv1, nv1);
+                coop_leaf<P>(s_tree, d, lo_t, hi_t, l0, l1, t0, t1, static_cast<P>(q0), static_cast<P>(q1), pk0, pv0, nv0, pk1, pv1, nv1);
             }
             if (stepping) {
-                // rle_string::rank: occurrences before the predecessor run + the part of it below the position
+                // rle_string::rank in the table: occurrences before the predecessor run + the part of it below the
+                // position; t <= lo_t: no run of this table starts before the position
                 uint64_t c_before = 0, c_upto = 0;
                 bool inside = false;
-                if (t0 > 0) { const uint64_t len = static_cast<uint64_t>(nv0) - pv0, d = q0 - pk0; c_before = pv0 + (d < len ? d : len); }
-                if (t1 > 0) { const uint64_t len = static_cast<uint64_t>(nv1) - pv1, d = q1 - pk1; c_upto = pv1 + (d < len ? d : len); inside = d <= len; }
+                if (t0 > lo_t) { const uint64_t len = static_cast<uint64_t>(nv0) - pv0, dd = q0 - pk0; c_before = pv0 + (dd < len ? dd : len); }
+                if (t1 > lo_t) { const uint64_t len = static_cast<uint64_t>(nv1) - pv1, dd = q1 - pk1; c_upto = pv1 + (dd < len ? dd : len); inside = dd <= len; }
                 const uint64_t c_inside = c_upto - c_before;
-                if (c_inside == 0) {                            // rowbowt.hpp:85
+                if (c_inside == 0) {                            // rowbowt.hpp:85 (whichever of the nested steps emptied the range)
                     alive = false;
                 } else {
-                    if (TOEHOLD) {                              // LF_w_loc, rowbowt.hpp:559-566
-                        if (inside) k = k - 1;
-                        else { pend = true; pend_sym = slot; pend_run = t1 - 1; k = 0; }
+                    if (TOEHOLD) {                              // LF_w_loc, rowbowt.hpp:559-566, `adv` times nested
+                        if (inside) k = k - adv;
+                        else { pend = true; pend_d = d; pend_run = t1 - 1; k = 0; }
                     }
-                    lo = s_F[slot] + c_before;                  // rowbowt.hpp:86
+                    lo = F + c_before;                          // rowbowt.hpp:86
                     hi = lo + c_inside - 1;                     // rowbowt.hpp:87
+                    p -= adv - 1;                               // the left neighbours are consumed too
                 }
             }
         }
-        if (TOEHOLD && alive && pend) k += static_cast<uint64_t>(static_cast<const P *>(s_samp[pend_sym])[pend_run]);
+        if (TOEHOLD && alive && pend) k += static_cast<uint64_t>(static_cast<const P *>(ix.run_samp[pend_d])[pend_run]);
         if (!alive) { lo = 1; hi = 0; k = 0; }                 // {1,0}; LFData::clear rowbowt.hpp:153-159
         if (valid) {
             lo_out[i] = lo;
@@ -333,6 +407,7 @@ __global__ __launch_bounds__(256) void k_locate_fill_runs(const DevIndex ix, con
     for (uint32_t t = threadIdx.x; t < ix.phi_tree.top_n; t += blockDim.x) s_top[t] = static_cast<const P *>(ix.phi_top)[t];
     __syncthreads();
     const int nlvl = static_cast<int>(ix.phi_nlvl);
+    const uint32_t phi_hi = static_cast<uint32_t>(ix.r);
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
     const PhiEnt<P> *__restrict__ pent = static_cast<const PhiEnt<P> *>(ix.phi_ent);
     unsigned long long c_locs = 0;
@@ -374,15 +449,16 @@ __global__ __launch_bounds__(256) void k_locate_fill_runs(const DevIndex ix, con
                 const bool wrapped = need && k1 >= ix.n;        // a toehold below zero (k_locate.hip phi_step): outside phi's domain
                 const bool coop = need && !wrapped;
                 uint32_t tq = 0, unused_t = 0;
+                // (one slice: all r sampled positions; entry r is the sentinel)
                 if (coop) tq = top_count<P>(s_top, 0, s_tree[0].top_n, k1);
                 for (int l = nlvl - 1; l >= 0; --l) {
                     const bool lv0 = coop && tq > 0;
-                    coop_level<P>(s_tree, l, 0u, lv0, false, tq, unused_t, static_cast<P>(k1), P(0));   // (k1 < n here)
+                    coop_level<P>(s_tree, l, 0u, 0u, phi_hi, lv0, false, tq, unused_t, static_cast<P>(k1), P(0));   // (k1 < n here)
                 }
                 P pk = 0, pv = 0, nv = 0, u1 = 0, u2 = 0, u3 = 0;
                 {
                     const bool lv0 = coop && tq > 0;
-                    coop_leaf<P>(s_tree, 0u, lv0, false, tq, unused_t, static_cast<P>(k1), P(0), pk, pv, nv, u1, u2, u3);
+                    coop_leaf<P>(s_tree, 0u, 0u, phi_hi, lv0, false, tq, unused_t, static_cast<P>(k1), P(0), pk, pv, nv, u1, u2, u3);
                 }
                 if (need) {
                     uint64_t s;
@@ -436,8 +512,11 @@ int launch_find_range_runs(const DevIndex &ix, const LaunchCfg &cfg, const uint8
                            uint64_t *lo, uint64_t *hi, uint64_t *ssamp, void *stream) {
     if (N == 0) return 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const size_t lds = static_cast<size_t>(ix.tree_top_n) * ix.pos_bytes + 16;
-    const dim3 grid(grid_for(cfg, N)), block(256);
+    const size_t lds = static_cast<size_t>(ix.run_ntabs) * sizeof(DevRunTab) + static_cast<size_t>(ix.tree_top_n) * ix.pos_bytes + 16;
+    LaunchCfg c = cfg;   // 512-thread workgroups: the staged tables and top level are shared by eight waves
+    c.block_threads = 512;
+    c.max_blocks = cfg.max_blocks > 0 ? std::max(1, cfg.max_blocks / 2) : 256 * 16;
+    const dim3 grid(grid_for(c, N)), block(512);
 #define RBG_LAUNCH_FRR(PT, TOE)                                                                        \
     do {                                                                                               \
         auto kern = k_find_range_runs<PT, TOE>;                                                        \

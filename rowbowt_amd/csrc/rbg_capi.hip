@@ -393,31 +393,91 @@ int upload_tree(rbg_index *ix, const void *d_ent, uint64_t m, KeyAt key_at, uint
     return RBG_OK;
 }
 
+// bytes of the run-indexed replica with the k-mer depths h holds (run lists, samples, 1/15 of sampled keys, phi)
+template <typename P>
+size_t runs_replica_bytes(const HostIndex &h) {
+    size_t total = 0;
+    for (const std::vector<SymTable> *lv : {&h.sym, &h.pair, &h.triple, &h.quad, &h.quint}) {
+        size_t entries = 0;
+        for (const SymTable &t : *lv) entries += t.nruns + 1;
+        total += entries * (sizeof(RunEnt<P>) + (h.has_tsa ? sizeof(P) : 0)) + entries * sizeof(P) / 15 + 8 * kArenaAlign;
+    }
+    if (h.has_tsa) total += (h.r + 1) * sizeof(PhiEnt<P>) + h.r * sizeof(P) / 15;
+    return total + 16 * kArenaAlign;
+}
+
 template <typename P>
 int upload_tables_runs(rbg_index *ix) {
     HostIndex &h = ix->H();
     const uint64_t budget_keys = g_opt_tree_top_kb.load() ? static_cast<uint64_t>(g_opt_tree_top_kb.load()) * 1024 / sizeof(P) : 16;
-    std::vector<DevSym> syms(h.sym.size());
-    std::vector<DevTree> trees(h.sym.size());
+    const std::vector<SymTable> *depth[kMaxRunDepth] = {&h.sym, &h.pair, &h.triple, &h.quad, &h.quint};
+    uint32_t D = 1;
+    while (D < static_cast<uint32_t>(kMaxRunDepth) && !depth[D]->empty()) ++D;
     std::vector<uint64_t> sizes;
-    for (const SymTable &t : h.sym) sizes.push_back(t.nruns);
+    for (uint32_t d = 0; d < D; ++d) {
+        uint64_t entries = 0;
+        for (const SymTable &t : *depth[d]) entries += t.nruns + 1;
+        sizes.push_back(entries);
+    }
+    // entry indices are 32-bit in the kernels: a depth with more entries than that is left out (never seen: 6.5e7 at
+    // the bench index's deepest level, 5e8 at r = 3e8)
+    while (D > 1 && sizes[D - 1] >= 0xFFFFFFF0ull) { --D; sizes.pop_back(); }
+    if (sizes[0] >= 0xFFFFFFF0ull) return RBG_EARG;
     const uint32_t nlvl = tree_levels_for(sizes, budget_keys);
     if (nlvl > kMaxTreeLevels) return RBG_EARG;
+    std::vector<DevSym> syms(h.sym.size());
+    std::vector<DevTree> trees(D);
+    std::vector<DevRunTab> tabs;
     std::vector<P> top_all;
     int rc;
-    for (size_t s = 0; s < h.sym.size(); ++s) {
-        const SymTable &t = h.sym[s];
-        PreparedSym<P> prep;
-        prepare_sym<P>(t, h.has_tsa, prep);
-        DevSym &d = syms[s];
-        d = DevSym{};
-        if ((rc = dev_upload(ix, prep.ent.data(), prep.ent.size() * sizeof(RunEnt<P>), &d.ent))) return rc;
-        if (h.has_tsa && (rc = dev_upload(ix, prep.samp.data(), prep.samp.size() * sizeof(P), &d.samp))) return rc;
-        d.F = t.F;
-        d.shift = 0;
-        d.nruns = static_cast<uint32_t>(t.nruns);
-        if ((rc = upload_tree<P>(ix, d.ent, t.nruns, [&](uint64_t j) { return t.start[j]; }, nlvl, top_all, trees[s]))) return rc;
+    for (uint32_t d = 0; d < D; ++d) {
+        // the depth's tables back to back: entries {start, cum} (each table ends with its sentinel {n, total}), samples alongside
+        const std::vector<SymTable> &T = *depth[d];
+        const uint64_t entries = sizes[d];
+        std::vector<RunEnt<P>> ent(entries);
+        std::vector<P> samp(h.has_tsa ? entries : 0);
+        std::vector<uint64_t> first(T.size() + 1, 0);
+        for (size_t t = 0; t < T.size(); ++t) first[t + 1] = first[t] + T[t].nruns + 1;
+        {
+            const size_t W = std::max<size_t>(1, std::min<size_t>({16, std::thread::hardware_concurrency(), T.size()}));
+            std::vector<std::thread> workers;
+            for (size_t w = 0; w < W; ++w)
+                workers.emplace_back([&, w] {
+                    for (size_t t = w; t < T.size(); t += W) {
+                        const SymTable &tb = T[t];
+                        RunEnt<P> *e = ent.data() + first[t];
+                        for (uint64_t k = 0; k <= tb.nruns; ++k) { e[k].start = static_cast<P>(tb.start[k]); e[k].cum = static_cast<P>(tb.cum[k]); }
+                        if (h.has_tsa) {
+                            P *sp = samp.data() + first[t];
+                            for (uint64_t k = 0; k < tb.nruns; ++k) sp[k] = static_cast<P>(tb.samp[k]);
+                            sp[tb.nruns] = 0;
+                        }
+                    }
+                });
+            for (auto &w : workers) w.join();
+        }
+        const void *d_ent = nullptr, *d_samp = nullptr;
+        if ((rc = dev_upload(ix, ent.data(), ent.size() * sizeof(RunEnt<P>), &d_ent))) return rc;
+        if (h.has_tsa && (rc = dev_upload(ix, samp.data(), samp.size() * sizeof(P), &d_samp))) return rc;
+        ix->dev.run_samp[d] = d_samp;
+        ix->dev.run_tab_first[d] = static_cast<uint32_t>(tabs.size());
+        for (size_t t = 0; t < T.size(); ++t) tabs.push_back(DevRunTab{T[t].F, first[t]});
+        tabs.push_back(DevRunTab{0, entries});   // closing record: the last table's slice ends here
+        if ((rc = upload_tree<P>(ix, d_ent, entries - 1, [&](uint64_t j) { return static_cast<uint64_t>(ent[j].start); }, nlvl, top_all, trees[d]))) return rc;
+        if (d == 0)   // the per-lane kernels (seeding, windowed markers, single LF steps) search a symbol's own slice
+            for (size_t t = 0; t < T.size(); ++t) {
+                DevSym &r = syms[t];
+                r = DevSym{};
+                r.ent = static_cast<const char *>(d_ent) + first[t] * sizeof(RunEnt<P>);
+                r.samp = d_samp ? static_cast<const char *>(d_samp) + first[t] * sizeof(P) : nullptr;
+                r.F = T[t].F;
+                r.shift = 0;
+                r.nruns = static_cast<uint32_t>(T[t].nruns);
+            }
     }
+    ix->dev.run_tab_first[D] = static_cast<uint32_t>(tabs.size());
+    for (uint32_t d = D + 1; d <= static_cast<uint32_t>(kMaxRunDepth); ++d) ix->dev.run_tab_first[d] = static_cast<uint32_t>(tabs.size());
+    if (tabs.size() > static_cast<size_t>(kMaxRunTabs)) return RBG_EARG;
     const void *p = nullptr;
     if ((rc = dev_upload(ix, syms.data(), syms.size() * sizeof(DevSym), &p))) return rc;
     ix->dev.syms = static_cast<const DevSym *>(p);
@@ -429,13 +489,17 @@ int upload_tables_runs(rbg_index *ix) {
         for (int l = 0; l < kMaxTreeLevels; ++l) offs.push_back(offsetof(DevTree, lvl) + 8 * static_cast<size_t>(l));
         ix->ptr_tables.push_back({p, trees.size(), sizeof(DevTree), offs});
     }
+    if ((rc = dev_upload(ix, tabs.data(), tabs.size() * sizeof(DevRunTab), &p))) return rc;
+    ix->dev.run_tabs = static_cast<const DevRunTab *>(p);
+    ix->dev.run_ntabs = static_cast<uint32_t>(tabs.size());
+    ix->dev.run_ksteps = D;
     if ((rc = dev_upload(ix, top_all.data(), top_all.size() * sizeof(P), &ix->dev.tree_top))) return rc;
     ix->dev.tree_top_n = static_cast<uint32_t>(top_all.size());
     ix->dev.tree_nlvl = nlvl;
     ix->dev.layout = RBG_LAYOUT_RUNS;
-    ix->dev.kmer_steps = 1;
+    ix->dev.kmer_steps = 1;   // (the per-lane kernels take single steps in this layout)
     ix->dev.nmajor = 0;
-    if (h.nmajor >= 2) {  // the ftab's word index needs the major alphabet
+    if (h.nmajor >= 2) {  // the ftab's word index and the k-mer table index need the major alphabet
         if ((rc = dev_upload(ix, h.major_of, 256, &p))) return rc;
         ix->dev.lut2 = static_cast<const uint8_t *>(p);
         ix->dev.nmajor = h.nmajor;
@@ -548,13 +612,19 @@ int upload(rbg_index *ix) {
         runs_layout = false;
     }
     ix->runs_layout = runs_layout;
-    if (runs_layout) {
-        std::vector<SymTable>().swap(h.pair);
-        std::vector<SymTable>().swap(h.triple);
-        std::vector<SymTable>().swap(h.quad);
-        std::vector<SymTable>().swap(h.quint);
-    }
     auto levels = [&] { return !h.quint.empty() ? 5 : !h.quad.empty() ? 4 : !h.triple.empty() ? 3 : !h.pair.empty() ? 2 : 1; };
+    if (runs_layout) {
+        // the k-mer depths stay (their run lists are O(r) too: DevRunTab, rbg_dev.h); the deepest goes while the replica
+        // exceeds the budget
+        if (ix->kmer_steps_requested == 0) ix->kmer_steps_requested = static_cast<uint64_t>(levels());
+        auto need_runs = [&] { return h.pos_bytes == 4 ? runs_replica_bytes<uint32_t>(h) : runs_replica_bytes<uint64_t>(h); };
+        while (need_runs() > budget && !h.pair.empty()) {
+            std::vector<SymTable> &deepest = !h.quint.empty() ? h.quint : !h.quad.empty() ? h.quad : !h.triple.empty() ? h.triple : h.pair;
+            std::fprintf(stderr, "rbg: run-indexed replica of %.1f GB exceeds the %.1f GB budget: dropping the %zu-table k-mer level\n",
+                         need_runs() / 1e9, budget / 1e9, deepest.size());
+            std::vector<SymTable>().swap(deepest);
+        }
+    }
     ix->kmer_steps_requested = std::max<uint64_t>(ix->kmer_steps_requested, static_cast<uint64_t>(levels()));  // options_for() may have capped the depth already
     ix->hbm_free_at_load = free_b;
     ix->hbm_budget = budget;
@@ -687,6 +757,15 @@ FlattenOptions options_for(int device, const RawRle &rle, uint64_t *requested) {
         if (!seen[c]) { seen[c] = true; ++sigma; }
     const double major = static_cast<double>(std::min(4u, sigma > 1 ? sigma - 1 : 0u));  // at least this many k-mer symbols
     if (major < 2) return o;
+    // the run-indexed layout keeps its k-mer depths as run lists (space proportional to r): nothing to cap when it is
+    // asked for, or when not even the single-symbol slot tables (+ phi at its widest usual bucket) fit
+    if (g_opt_rank_layout.load() == RBG_LAYOUT_RUNS) return o;
+    if (g_opt_rank_layout.load() == RBG_LAYOUT_AUTO) {
+        const double pos = (o.force_pos_bytes == 8 || rle.n >= 0xFFFFFFF0ull) ? 8 : 4;
+        const double lvl1 = static_cast<double>(sigma) * static_cast<double>((rle.n >> kMaxNarrowShift) + 2) * (sizeof(RankSlot) + sizeof(uint32_t)) +
+                            static_cast<double>((rle.n >> 6) + 2) * (4 * pos + 4);
+        if (lvl1 > budget) return o;
+    }
     const double per_table = static_cast<double>((rle.n >> kMaxWideShift) + 2) * (sizeof(RankSlot) + sizeof(uint32_t));
     double total = major * per_table, tables = major;
     int keep = 1;
@@ -1237,6 +1316,7 @@ int rbg_info(const rbg_index *ix, rbg_info_t *out) {
     out->phi_slots = ix->phi_slots;
     out->phi_slots_overflow = ix->phi_slots_overflow;
     out->kmer_steps = !ix->H().quint.empty() ? 5 : !ix->H().quad.empty() ? 4 : !ix->H().triple.empty() ? 3 : !ix->H().pair.empty() ? 2 : 1;
+    if (ix->device != RBG_DEVICE_NONE && ix->dev.layout == RBG_LAYOUT_RUNS) out->kmer_steps = ix->dev.run_ksteps;   // depths of the run-indexed search
     out->kmer_symbols = ix->H().pair.empty() ? 0 : ix->H().nmajor;
     out->ftab_k = ix->dev.ftab_k;
     out->kmer_steps_requested = ix->kmer_steps_requested ? ix->kmer_steps_requested : out->kmer_steps;
@@ -2382,6 +2462,8 @@ int rbg_replicate(rbg_index *src, int device, rbg_index **out) {
     reloc.fix(d.mk_start); reloc.fix(d.mk_end); reloc.fix(d.mk_off); reloc.fix(d.mk_vals); reloc.fix(d.mk_bucket);
     reloc.fix(d.counters); reloc.fix(d.lut); reloc.fix(d.pairs); reloc.fix(d.triples); reloc.fix(d.quads); reloc.fix(d.quints);
     reloc.fix(d.lut2); reloc.fix(d.ftab); reloc.fix(d.dense); reloc.fix(d.trees); reloc.fix(d.tree_top); reloc.fix(d.phi_top);
+    reloc.fix(d.run_tabs);
+    for (int t = 0; t < kMaxRunDepth; ++t) reloc.fix(d.run_samp[t]);
     reloc.fix(d.phi_tree.ent);
     for (int l = 0; l < kMaxTreeLevels; ++l) reloc.fix(d.phi_tree.lvl[l]);
     r->dev = d;

@@ -101,6 +101,21 @@ struct DevTree {
 constexpr int kLdsSyms = 8;
 constexpr int kMaxMajor = 4;  // symbol tables staged in LDS per workgroup; rarer slots read from HBM
 
+// Run-indexed layout, K1/K2: every k-mer depth d = 1..run_ksteps (a depth-d table lists the rows whose d
+// preceding text characters spell the k-mer, as runs) has ONE tree (DevTree) over the run lists of all its tables, laid
+// back to back in table order -- each table's entries ascend and end with its sentinel {n, total}, so the concatenation
+// is sorted by (table, start).  A rank in table t is a predecessor search CLAMPED to the table's slice
+// [first_t, first_{t+1}): entries before the slice count as below the query, entries from the sentinel on as not below
+// it, which keeps the predicate monotone over the whole array -- one sampled index per depth instead of 1364 of them.
+// DevRunTab: what a step needs to know about its table; the records of a depth are followed by one closing record
+// (first = the depth's entry count) so that first_{t+1} is always the next record.
+struct DevRunTab {
+    uint64_t F;      // first row of the k-mer's SA interval (RowBowt::f_ for a single symbol)
+    uint64_t first;  // index of the table's first entry in its depth's arrays
+};
+constexpr int kMaxRunDepth = 5;
+constexpr int kMaxRunTabs = kLdsSyms + 16 + 64 + 256 + 1024 + kMaxRunDepth;  // records staged in LDS by k_find_range_runs
+
 struct DevIndex {
     uint64_t n, r;
     uint64_t last_run_sample;
@@ -142,15 +157,20 @@ struct DevIndex {
     uint32_t ftab_k;
     uint32_t pad3;
     const uint8_t *dense;   // dense tables of the overflow buckets of every narrow rank table (RankSlot); nullptr = none
-    // run-indexed layout (layout == 2): one tree per symbol (first kLdsSyms symbols) and one over the phi samples
+    // run-indexed layout (layout == 2): one tree per k-mer depth (DevRunTab above) and one over the phi samples
     uint32_t layout;        // 1 = slot tables (RBG_LAYOUT_SLOTS), 2 = run-indexed (RBG_LAYOUT_RUNS)
     uint32_t tree_nlvl;     // HBM-resident sampled levels of every rank tree
-    const DevTree *trees;   // sigma entries
+    const DevTree *trees;   // run_ksteps entries: depth 1 first
     const void *tree_top;   // P keys: the top levels of all rank trees, back to back
     uint32_t tree_top_n;
     uint32_t phi_nlvl;
     DevTree phi_tree;
     const void *phi_top;    // P keys
+    uint32_t run_ksteps;    // symbols a step of k_find_range_runs may consume (1..5); kmer_steps stays 1 for the per-lane kernels
+    uint32_t run_ntabs;     // records in run_tabs
+    const DevRunTab *run_tabs;            // depth d's records start at run_tab_first[d - 1]
+    const void *run_samp[kMaxRunDepth];   // per depth: P per entry (run-end sample; SA - d for a depth-d run), nullptr without toehold SA
+    uint32_t run_tab_first[kMaxRunDepth + 1];
 };
 
 // What the instrumented instantiations count (sums over the launch; include/rbg.h rbg_search_stats_t mirrors it).

@@ -1165,13 +1165,19 @@ def test_positions_beyond_32_bits():
     loc_off, locs = rb.locs_at(wlo, whi, wk, max_hits=64)
     assert (loc_off == woff).all() and (locs == wlocs).all()
     # the run-indexed layout at this size: 3 GB instead of 140, sampled index three levels deep with a 16-key top
-    for top_kb in (48, 0):
-        rbr = _with_layout(capi.LAYOUT_RUNS, top_kb, lambda: ra.RowBowt.from_runs(heads, lens, ssa, esa, device=0))
+    # (single steps: toeholds compared; k-mer depths: ranges and the walks from the oracle's toeholds, as above)
+    for top_kb, ks in ((48, 1), (0, 1), (48, 5), (0, 3)):
+        ra.set_default_option(capi.OPT_KMER_STEPS, ks)
+        try:
+            rbr = _with_layout(capi.LAYOUT_RUNS, top_kb, lambda: ra.RowBowt.from_runs(heads, lens, ssa, esa, device=0))
+        finally:
+            ra.set_default_option(capi.OPT_KMER_STEPS, 5)
         ir = rbr.info()
-        assert ir.rank_layout == capi.LAYOUT_RUNS and ir.pos_bytes == 8 and ir.hbm_bytes < 4e9
+        assert ir.rank_layout == capi.LAYOUT_RUNS and ir.pos_bytes == 8 and ir.kmer_steps == ks and ir.hbm_bytes < (4e9 if ks == 1 else 12e9)
         lo, hi, k = rbr.find_range_w_toehold(seqs, off)
-        assert (lo == wlo).all() and (hi == whi).all() and (k == wk).all()
-        loc_off, locs = rbr.locs_at(lo, hi, k, max_hits=64)
+        lo2, hi2 = rbr.find_range(seqs, off)
+        assert (lo == wlo).all() and (hi == whi).all() and (lo2 == wlo).all() and (hi2 == whi).all() and (ks > 1 or (k == wk).all())
+        loc_off, locs = rbr.locs_at(wlo, whi, wk, max_hits=64)
         assert (loc_off == woff).all() and (locs == wlocs).all()
         rbr.close()
     rows = rng.integers(0, n, size=4000).astype(np.uint64)
@@ -1195,22 +1201,26 @@ def _with_layout(layout, top_kb, build):
         ra.set_default_option(capi.OPT_TREE_TOP_KB, 48)
 
 
-@pytest.mark.parametrize("pos_bytes,top_kb,fk", [(0, 48, -1), (8, 48, -1), (0, 0, -1), (8, 0, 3), (0, 1, 0)])
-def test_run_indexed_layout(synth, pos_bytes, top_kb, fk):
+@pytest.mark.parametrize("pos_bytes,top_kb,fk,ks", [(0, 48, -1, 5), (8, 48, -1, 5), (0, 0, -1, 5), (8, 0, 3, 4), (0, 1, 0, 3), (0, 48, -1, 1),
+                                                    (8, 1, -1, 2), (0, 0, 0, 1)])
+def test_run_indexed_layout(synth, pos_bytes, top_kb, fk, ks):
     """RBG_LAYOUT_RUNS (k_runs.hip): space proportional to r, rank and phi as wave-cooperative predecessor searches
-    over the run lists (rle_string.hpp:131-161, toehold_sa.hpp:56-72) -- same answers as the slot tables, i.e. as
-    the oracle, on every read shape of test_synth_all_paths; top_kb = 0 forces the deepest sampled index."""
+    over the run lists (rle_string.hpp:131-161, toehold_sa.hpp:56-72), k-mer steps through one clamped search per
+    depth (ks = symbols per step) -- same answers as the slot tables, i.e. as the oracle, on every read shape of
+    test_synth_all_paths; top_kb = 0 forces the deepest sampled index."""
     S = synth
     ra.set_default_option(capi.OPT_POS_BYTES, pos_bytes)
     ra.set_default_option(capi.OPT_FTAB_K, fk)
+    ra.set_default_option(capi.OPT_KMER_STEPS, ks)
     try:
         rb = _with_layout(capi.LAYOUT_RUNS, top_kb, lambda: ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0))
     finally:
         ra.set_default_option(capi.OPT_POS_BYTES, 0)
         ra.set_default_option(capi.OPT_FTAB_K, -1)
+        ra.set_default_option(capi.OPT_KMER_STEPS, 5)
     o = orc.Oracle.from_runs(S.heads, S.lens, S.ssa, S.esa)
     info = rb.info()
-    assert info.rank_layout == capi.LAYOUT_RUNS and info.kmer_steps == 1 and info.pos_bytes == (pos_bytes or 4)
+    assert info.rank_layout == capi.LAYOUT_RUNS and info.kmer_steps == ks and info.pos_bytes == (pos_bytes or 4)
     assert info.rank_slots == 0 and info.phi_slots == 0
     reads = S.sample_reads(3000, 60, seed=5, sub_rate=0.15, ragged=True)
     reads += [b"", b"A", b"N", b"ACGTN", b"NACGT", b"ACNGT", b"AC", b"ACG", b"acgt", bytes([1]), bytes([255]) * 3, bytes([0]),
