@@ -387,11 +387,11 @@ int rbg_sample_reads_dev(const uint8_t *d_text, uint64_t unit, uint64_t H, uint6
  * holding symbols outside the index's four k-mer symbols are searched from their bytes afterwards), 2 = always
  * as 2-bit codes.  (Packing a batch that is already in HBM is rbg_pack_reads_dev.)
  * RANK_LAYOUT: RBG_LAYOUT_AUTO (default: slot tables unless even their single-symbol level exceeds the HBM budget),
- * RBG_LAYOUT_SLOTS, RBG_LAYOUT_RUNS = the run-indexed layout: the run lists plus a 64-ary sampled index, space
- * proportional to r and nothing proportional to n; rank and phi are wave-cooperative predecessor searches
- * (rle_string::rank rle_string.hpp:131-161 / ToeholdSA::phi toehold_sa.hpp:56-72 keep their O(r) shape); one symbol
- * per step.  TREE_TOP_KB (1..96, default 48): LDS the staged top level of that index may take per workgroup
- * (0 = sixteen keys in all: the deepest possible index, for tests). */
+ * RBG_LAYOUT_SLOTS, RBG_LAYOUT_RUNS = the run-indexed layout: the run lists (of every k-mer depth KMER_STEPS asks
+ * for and the budget holds) plus a 16-ary sampled index per depth, space proportional to r and nothing proportional
+ * to n; rank and phi are wave-cooperative predecessor searches (rle_string::rank rle_string.hpp:131-161 /
+ * ToeholdSA::phi toehold_sa.hpp:56-72 keep their O(r) shape).  TREE_TOP_KB (1..96, default 48): LDS the staged top
+ * level of that index may take per workgroup (0 = sixteen keys in all: the deepest possible index, for tests). */
 enum { RBG_OPT_BLOCK_THREADS = 1, RBG_OPT_RANK_BUCKET_SHIFT = 2, RBG_OPT_PHI_BUCKET_SHIFT = 3, RBG_OPT_POS_BYTES = 4,
        RBG_OPT_KMER_STEPS = 5, RBG_OPT_HBM_BUDGET_MB = 6, RBG_OPT_FTAB_K = 7, RBG_OPT_PACKED_READS = 8,
        RBG_OPT_DEEP_BUCKET_SHIFT = 9, RBG_OPT_DENSE_OVERFLOW = 10, RBG_OPT_RANK_LAYOUT = 11, RBG_OPT_TREE_TOP_KB = 12 };

@@ -513,7 +513,9 @@ int upload_tables_runs(rbg_index *ix) {
         pe[h.r].pos = static_cast<P>(h.n);  // sentinel: never below a query
         pe[h.r].base = 0;
         if ((rc = dev_upload(ix, pe.data(), pe.size() * sizeof(PhiEnt<P>), &ix->dev.phi_ent))) return rc;
-        const uint32_t pl = tree_levels_for({h.r}, budget_keys);
+        // (k_locate_fill_runs stages 26-43 KB of values per workgroup besides the top level: 8 KB of it keeps four
+        //  workgroups per CU -- 32 ms per 10 M reads on the bench index against 44 ms with a 48 KB top level)
+        const uint32_t pl = tree_levels_for({h.r}, std::min<uint64_t>(budget_keys, 8192 / sizeof(P)));
         if (pl > kMaxTreeLevels) return RBG_EARG;
         std::vector<P> ptop;
         if ((rc = upload_tree<P>(ix, ix->dev.phi_ent, h.r, [&](uint64_t j) { return h.pred_pos[j]; }, pl, ptop, ix->dev.phi_tree))) return rc;
