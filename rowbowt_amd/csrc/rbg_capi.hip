@@ -663,8 +663,9 @@ int upload(rbg_index *ix) {
         std::vector<SymTable>().swap(deepest);
     }
     if (std::getenv("RBG_VERBOSE") || static_cast<uint64_t>(levels()) != ix->kmer_steps_requested)
-        std::fprintf(stderr, "rbg: device %d: %.1f GB free, replica budget %.1f GB: keeping %d of %llu symbol(s) per gather (%.1f GB)\n", ix->device,
-                     free_b / 1e9, budget / 1e9, levels(), static_cast<unsigned long long>(ix->kmer_steps_requested), need() / 1e9);
+        std::fprintf(stderr, "rbg: device %d: %.1f GB free, replica budget %.1f GB: keeping %d of %llu symbol(s) per %s (%.1f GB)\n", ix->device,
+                     free_b / 1e9, budget / 1e9, levels(), static_cast<unsigned long long>(ix->kmer_steps_requested), runs_layout ? "search step" : "gather",
+                     (runs_layout ? (h.pos_bytes == 4 ? runs_replica_bytes<uint32_t>(h) : runs_replica_bytes<uint64_t>(h)) : need()) / 1e9);
     int rc;
     d.layout = RBG_LAYOUT_SLOTS;
     if (runs_layout) {
