@@ -67,6 +67,9 @@ __device__ __forceinline__ uint64_t phi_step(const DevIndex &ix, uint64_t i, boo
 // toehold order (the default) 3.5 / 3.1 / 3.5 ms, hence 16 (staged as uint64: 39 KB of LDS per workgroup;
 // staged at the position width since: 24 KB at 4-byte positions, 3.1 -> 3.0 ms).
 constexpr int kChunk = 16;
+#ifndef RBG_K3_CHUNK_U64
+#define RBG_K3_CHUNK_U64 16   // steps staged per flush at 8-byte positions (A/B knob: tools/README.md)
+#endif
 
 __device__ __forceinline__ void wave_lds_sync() {
     // LDS operations of one wave execute in issue order; this only stops the compiler from moving
@@ -77,7 +80,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 
 // STATS = the instrumented instantiation (rbg_locate_fill_stats_dev): the same walk plus the LocateStat sums.
-template <typename P, bool STATS = false>
+template <typename P, bool STATS = false, int CH = (sizeof(P) == 8 ? RBG_K3_CHUNK_U64 : kChunk)>
 __global__ __launch_bounds__(256) void k_locate_fill(const DevIndex ix, const uint64_t *__restrict__ lo,
                                                      const uint64_t *__restrict__ hi, const uint64_t *__restrict__ k,
                                                      const uint64_t N, const uint64_t max_hits,
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(256) void k_locate_fill(const DevIndex ix, const ui
                                                      unsigned long long *__restrict__ stats = nullptr) {
     // staged at the position width: text positions fit P, and at 4 bytes the workgroup's LDS drops from
     // 39 KB to 24 KB (6 instead of 4 waves per SIMD); the per-read offset is applied when flushing
-    __shared__ P s_val[4][kWave][kChunk + 1];  // +1: keeps the per-lane rows off the same banks
+    __shared__ P s_val[4][kWave][CH + 1];  // +1: keeps the per-lane rows off the same banks
     __shared__ uint64_t s_dst[4][kWave];
     __shared__ uint64_t s_occ[4][kWave];
     __shared__ uint64_t s_minus[4][kWave];
@@ -133,9 +136,9 @@ __global__ __launch_bounds__(256) void k_locate_fill(const DevIndex ix, const ui
             const uint64_t other = __shfl_xor(wmax, o, kWave);
             wmax = other > wmax ? other : wmax;
         }
-        for (uint64_t t0 = 0; t0 < wmax; t0 += kChunk) {
+        for (uint64_t t0 = 0; t0 < wmax; t0 += CH) {
 #pragma unroll
-            for (int e = 0; e < kChunk; ++e) {
+            for (int e = 0; e < CH; ++e) {
                 const uint64_t t = t0 + e;
                 if (t < occ) {
                     if (STATS) {
@@ -153,9 +156,9 @@ __global__ __launch_bounds__(256) void k_locate_fill(const DevIndex ix, const ui
             }
             wave_lds_sync();
 #pragma unroll
-            for (int pass = 0; pass < kChunk; ++pass) {  // kWave/kChunk reads per pass, kChunk lanes each
-                const int s = pass * (kWave / kChunk) + lane / kChunk;
-                const int e = lane & (kChunk - 1);
+            for (int pass = 0; pass < CH; ++pass) {  // kWave/CH reads per pass, CH lanes each
+                const int s = pass * (kWave / CH) + lane / CH;
+                const int e = lane & (CH - 1);
                 const uint64_t t = t0 + e;
                 if (t < s_occ[wv][s]) locs[s_dst[wv][s] + t] = (t ? static_cast<uint64_t>(s_val[wv][s][e]) : s_first[wv][s]) - s_minus[wv][s];
             }
