@@ -68,7 +68,8 @@ __device__ __forceinline__ uint64_t phi_step(const DevIndex &ix, uint64_t i, boo
 // staged at the position width since: 24 KB at 4-byte positions, 3.1 -> 3.0 ms).
 constexpr int kChunk = 16;
 #ifndef RBG_K3_CHUNK_U64
-#define RBG_K3_CHUNK_U64 16   // steps staged per flush at 8-byte positions (A/B knob: tools/README.md)
+#define RBG_K3_CHUNK_U64 8    // steps staged per flush at 8-byte positions: 3.67 / 3.17-3.35 / 3.43 ms per 10 M reads at 16 / 8 / 4
+                              // (bench index forced to 8-byte positions; 16 costs a third of the workgroups their LDS)
 #endif
 
 __device__ __forceinline__ void wave_lds_sync() {

@@ -380,7 +380,7 @@ __global__ __launch_bounds__(512) void k_find_range_runs(const DevIndex ix, cons
 // ---- K3 over the run-indexed layout -------------------------------------------------------------------------------
 // ToeholdSA::locate_range (toehold_sa.hpp:37-49): the phi chains as in k_locate_fill (LDS-staged values, chains in
 // toehold order), phi itself (toehold_sa.hpp:56-72) as a cooperative predecessor search over the sampled positions.
-constexpr int kChunkR = 16;
+template <typename P> struct ChunkR { static constexpr int v = sizeof(P) == 8 ? 8 : 16; };   // as in k_locate.hip
 
 __device__ __forceinline__ void wave_lds_sync() {  // as in k_locate.hip: orders the wave's own LDS writes and cross-lane reads
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -395,6 +395,7 @@ __global__ __launch_bounds__(256) void k_locate_fill_runs(const DevIndex ix, con
                                                           const uint64_t *__restrict__ loc_off, uint64_t *__restrict__ locs,
                                                           const uint64_t *__restrict__ sub, const uint32_t *__restrict__ order,
                                                           const uint64_t *__restrict__ skeys) {
+    constexpr int kChunkR = ChunkR<P>::v;
     __shared__ P s_val[4][kWave][kChunkR + 1];
     __shared__ uint64_t s_dst[4][kWave];
     __shared__ uint64_t s_occ[4][kWave];
