@@ -52,7 +52,9 @@ def parse():
     ap.add_argument("--check-reads", type=int, default=20000, help="reads compared bit-exactly with the oracle")
     ap.add_argument("--markers", action="store_true",
                     help="also run BASELINE.json configs[4] (rb_align -m: find_range + markers_at on a synthetic marker array "
-                         "over the same index), checked against the oracle on --check-reads reads")
+                         "over the same index) and rb_markers' seeding kernel, checked against the oracle on --check-reads reads; "
+                         "on by default on one GPU (about 25 s), off under torch.distributed.run unless asked for")
+    ap.add_argument("--no-markers", action="store_true", help="skip the markers leg")
     ap.add_argument("--two-stream", action="store_true",
                     help="also time the K steps as successive batches on two HIP streams (informational; off by default so "
                          "that a profile of the default command holds undisturbed per-kernel durations)")
@@ -85,6 +87,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # the markers leg (BASELINE.json configs[4]) rides along on one GPU unless switched off
+    args.markers = (args.markers or (world == 1 and "RANK" not in os.environ)) and not args.no_markers
     import torch
     import torch.distributed as dist
 
