@@ -20,6 +20,8 @@
 
 #include <rccl/rccl.h>
 
+#include <map>
+
 #include "../../include/rbg.h"
 #include "rbg_dev.h"
 #include "rbg_host.hpp"
@@ -109,15 +111,96 @@ struct DeviceScope {
 };
 
 // device scratch freed at scope exit
-struct DevBuf {
-    void *p = nullptr;
-    int alloc(size_t bytes) {
-        if (bytes == 0) bytes = 8;
-        hipError_t e = hipMalloc(&p, bytes);
-        if (e != hipSuccess) { p = nullptr; return e == hipErrorOutOfMemory ? RBG_ENOMEM : RBG_ENODEV; }
+// Scratch device memory of the host-pointer calls.  hipMalloc / hipFree per call cost more than a one-read query itself
+// (and hipFree synchronises the whole device, which serialises concurrent callers), so freed blocks are kept per device
+// and size class and handed out again: in steady state a call allocates nothing.  Blocks beyond 512 MiB and whatever
+// would take the cache past 2 GiB go back to the driver at once; rbg_free() of an index trims its device's cache.
+class DevPool {
+   public:
+    static DevPool &get() { static DevPool p; return p; }
+    static size_t size_class(size_t bytes) {
+        if (bytes < 4096) return 4096;
+        if (bytes <= (size_t(64) << 20)) { size_t c = 4096; while (c < bytes) c <<= 1; return c; }
+        return (bytes + (size_t(2) << 20) - 1) & ~((size_t(2) << 20) - 1);
+    }
+    int alloc(size_t bytes, void **out, size_t *cls_out) {
+        const size_t cls = size_class(bytes);
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            auto it = free_.find({dev, cls});
+            if (it != free_.end() && !it->second.empty()) {
+                *out = it->second.back();
+                it->second.pop_back();
+                cached_ -= cls;
+                *cls_out = cls;
+                return RBG_OK;
+            }
+        }
+        void *p = nullptr;
+        hipError_t e = hipMalloc(&p, cls);
+        if (e == hipErrorOutOfMemory) {   // give the cache back and try once more
+            (void)hipGetLastError();
+            trim(dev);
+            e = hipMalloc(&p, cls);
+        }
+        if (e != hipSuccess) { (void)hipGetLastError(); return e == hipErrorOutOfMemory ? RBG_ENOMEM : RBG_ENODEV; }
+        *out = p;
+        *cls_out = cls;
         return RBG_OK;
     }
-    ~DevBuf() { if (p) (void)hipFree(p); }
+    void release(void *p, size_t cls, int dev) {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            if (cls <= kMaxBlock && cached_ + cls <= kMaxCached) {
+                free_[{dev, cls}].push_back(p);
+                cached_ += cls;
+                return;
+            }
+        }
+        (void)hipFree(p);
+    }
+    void trim(int dev) {
+        std::vector<void *> drop;
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            for (auto &kv : free_)
+                if (kv.first.first == dev) {
+                    cached_ -= kv.first.second * kv.second.size();
+                    drop.insert(drop.end(), kv.second.begin(), kv.second.end());
+                    kv.second.clear();
+                }
+        }
+        for (void *p : drop) (void)hipFree(p);
+    }
+
+   private:
+    static constexpr size_t kMaxBlock = size_t(512) << 20, kMaxCached = size_t(2) << 30;
+    std::mutex mu_;
+    std::map<std::pair<int, size_t>, std::vector<void *>> free_;
+    size_t cached_ = 0;
+};
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cls = 0;
+    int dev = 0;
+    int alloc(size_t bytes) {
+        if (bytes == 0) bytes = 8;
+        (void)hipGetDevice(&dev);
+        return DevPool::get().alloc(bytes, &p, &cls);
+    }
+    ~DevBuf() {
+        if (!p) return;
+        // every user works on hipStreamPerThread and has synchronised by the time its buffers go out of scope, except on
+        // an error path: make sure nothing still runs on the block before another caller may get it
+        (void)hipStreamSynchronize(hipStreamPerThread);
+        DevPool::get().release(p, cls, dev);
+    }
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
     template <typename T> T *as() { return static_cast<T *>(p); }
 };
 
@@ -1291,6 +1374,7 @@ void rbg_free(rbg_index *ix) {
         DeviceScope scope(ix->device);
         ix->ws_free.clear();  // pinned + device staging of the host-pointer calls
         for (const DevAlloc &a : ix->allocs) (void)hipFree(a.p);
+        DevPool::get().trim(ix->device);  // cached scratch blocks of the host-pointer calls
     }
     delete ix;
 }
