@@ -32,6 +32,8 @@ int main() {
         if (k % 3) team.run(fn);
         if (k % 3 && c.load() != 5) { std::printf("short-lived team: %d of 5\n", c.load()); return 1; }
     }
-    std::printf("thread team ok\n");
+    const unsigned budget = rbg_hostpath::cpu_budget();   // hardware, affinity mask and cgroup quota: at least one, never more than the hardware's
+    if (budget < 1 || budget > std::max(1u, std::thread::hardware_concurrency())) { std::printf("cpu_budget() = %u\n", budget); return 1; }
+    std::printf("thread team ok (cpu budget %u)\n", budget);
     return 0;
 }

@@ -55,7 +55,7 @@ for flags, out in (([], "/dev/null"), (["--threads", "16"], "/dev/null"), (["--t
         continue
     load_s, query_s = (float(x) for x in p.stderr.decode().strip().splitlines()[-1].split())
     sz = os.path.getsize(out) if out != "/dev/null" else 0
-    print(f"rb_align {' '.join(flags) or '(count, 8 threads)':24s} -> {out:16s}: process {dt:.2f} s (index load {load_s:.2f} s); query loop {query_s:.3f} s = "
+    print(f"rb_align {' '.join(flags) or '(count, default threads)':24s} -> {out:16s}: process {dt:.2f} s (index load {load_s:.2f} s); query loop {query_s:.3f} s = "
           f"{N / query_s:.3e} reads/s" + (f"; {sz / 1e6:.0f} MB of text" if sz else ""), flush=True)
 
 if NM:
