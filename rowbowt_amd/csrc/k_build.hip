@@ -124,10 +124,12 @@ __global__ __launch_bounds__(256) void k_fill_dense(const RunEnt<P> *__restrict_
     }
 }
 
-template <typename P>
+template <typename P, bool PACKED = false>
 __global__ __launch_bounds__(256) void k_build_phi_slots(const PhiEnt<P> *__restrict__ ent, const uint64_t r, const uint64_t n,
-                                                         const uint32_t shift, PhiSlot<P> *__restrict__ slots,
+                                                         const uint32_t shift, void *__restrict__ slots_v,
                                                          uint32_t *__restrict__ ord, unsigned long long *__restrict__ overflow) {
+    PhiSlot<P> *__restrict__ slots = static_cast<PhiSlot<P> *>(slots_v);
+    PhiSlotPacked *__restrict__ packed = static_cast<PhiSlotPacked *>(slots_v);
     const uint64_t nb = (n >> shift) + 2;
     const uint64_t S = uint64_t(1) << shift;
     const uint64_t ngroups = (nb + kBuildGroup - 1) / kBuildGroup;
@@ -163,7 +165,16 @@ __global__ __launch_bounds__(256) void k_build_phi_slots(const PhiEnt<P> *__rest
             s.d0 = static_cast<P>(d0);
             s.d1 = static_cast<P>(d1);
             s.meta = static_cast<P>(off0 | (off1 << 8) | (code << 16));
-            slots[b] = s;
+            if (PACKED) {   // rbg_dev.h PhiSlotPacked (offsets below 64: shift <= 6; D values below n < 2^38)
+                const uint64_t dp = static_cast<uint64_t>(s.dprev);
+                PhiSlotPacked q;
+                q.w0 = dp | ((d0 & ((uint64_t(1) << 26) - 1)) << 38);
+                q.w1 = (d0 >> 26) | (d1 << 12) | (static_cast<uint64_t>(off0 & 63u) << 50) | (static_cast<uint64_t>(off1 & 63u) << 56) |
+                       (static_cast<uint64_t>(code) << 62);
+                packed[b] = q;
+            } else {
+                slots[b] = s;
+            }
         }
     }
     novf = wave_sum(novf);
@@ -202,18 +213,21 @@ int launch_fill_dense(uint32_t pos_bytes, const void *ent, uint64_t n, uint32_t 
     return static_cast<int>(hipGetLastError());
 }
 
-int launch_build_phi_slots(uint32_t pos_bytes, const void *ent, uint64_t r, uint64_t n, uint32_t shift, void *slots, uint32_t *ord,
+int launch_build_phi_slots(uint32_t pos_bytes, bool packed, const void *ent, uint64_t r, uint64_t n, uint32_t shift, void *slots, uint32_t *ord,
                            unsigned long long *overflow, void *stream) {
     const uint64_t nb = (n >> shift) + 2;
     const uint64_t groups = (nb + kBuildGroup - 1) / kBuildGroup;
     const int grid = static_cast<int>(std::min<uint64_t>((groups + 255) / 256, 256ull * 64));
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (pos_bytes == 4)
-        hipLaunchKernelGGL((k_build_phi_slots<uint32_t>), dim3(grid), dim3(256), 0, st, static_cast<const PhiEnt<uint32_t> *>(ent), r, n, shift,
-                           static_cast<PhiSlot<uint32_t> *>(slots), ord, overflow);
+        hipLaunchKernelGGL((k_build_phi_slots<uint32_t, false>), dim3(grid), dim3(256), 0, st, static_cast<const PhiEnt<uint32_t> *>(ent), r, n, shift,
+                           slots, ord, overflow);
+    else if (packed)
+        hipLaunchKernelGGL((k_build_phi_slots<uint64_t, true>), dim3(grid), dim3(256), 0, st, static_cast<const PhiEnt<uint64_t> *>(ent), r, n, shift,
+                           slots, ord, overflow);
     else
-        hipLaunchKernelGGL((k_build_phi_slots<uint64_t>), dim3(grid), dim3(256), 0, st, static_cast<const PhiEnt<uint64_t> *>(ent), r, n, shift,
-                           static_cast<PhiSlot<uint64_t> *>(slots), ord, overflow);
+        hipLaunchKernelGGL((k_build_phi_slots<uint64_t, false>), dim3(grid), dim3(256), 0, st, static_cast<const PhiEnt<uint64_t> *>(ent), r, n, shift,
+                           slots, ord, overflow);
     return static_cast<int>(hipGetLastError());
 }
 

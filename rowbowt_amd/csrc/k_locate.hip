@@ -29,10 +29,28 @@ __device__ __forceinline__ uint64_t phi_step(const DevIndex &ix, uint64_t i, boo
         return sum % ix.n;
     }
     const uint64_t b = i >> ix.phi_shift;
-    const PhiSlot<P> sl = load_slot(slots + b);
-    const uint32_t meta = static_cast<uint32_t>(sl.meta);
+    // the slot as {dprev, d0, d1, off0, off1, cnt}: 4 x P, or the 16-byte packed form at 8-byte positions (rbg_dev.h)
+    uint64_t dprev, d0, d1;
+    uint32_t off0, off1, cnt;
+    if (sizeof(P) == 8 && ix.phi_packed) {
+        const uint4 raw = load_slot(static_cast<const uint4 *>(ix.phi_slots) + b);
+        const uint64_t w0 = static_cast<uint64_t>(raw.x) | (static_cast<uint64_t>(raw.y) << 32);
+        const uint64_t w1 = static_cast<uint64_t>(raw.z) | (static_cast<uint64_t>(raw.w) << 32);
+        constexpr uint64_t M38 = (uint64_t(1) << 38) - 1;
+        dprev = w0 & M38;
+        d0 = (w0 >> 38) | ((w1 & 0xFFFull) << 26);
+        d1 = (w1 >> 12) & M38;
+        cnt = static_cast<uint32_t>(w1 >> 62);
+        off0 = cnt >= 1 ? static_cast<uint32_t>(w1 >> 50) & 63u : 0xFFu;   // (absent offsets compare as "never above")
+        off1 = cnt == 2 ? static_cast<uint32_t>(w1 >> 56) & 63u : 0xFFu;
+    } else {
+        const PhiSlot<P> sl = load_slot(slots + b);
+        const uint32_t meta = static_cast<uint32_t>(sl.meta);
+        dprev = sl.dprev; d0 = sl.d0; d1 = sl.d1;
+        off0 = meta & 0xFFu; off1 = (meta >> 8) & 0xFFu; cnt = (meta >> 16) & 3u;
+    }
     uint64_t s;
-    if (((meta >> 16) & 3u) == kPhiOvf) {
+    if (cnt == kPhiOvf) {
         if (searched) *searched = true;
         const PhiEnt<P> *__restrict__ ent = static_cast<const PhiEnt<P> *>(ix.phi_ent);
         uint64_t a = ix.phi_ord[b], z = ix.phi_ord[b + 1];
@@ -48,9 +66,9 @@ __device__ __forceinline__ uint64_t phi_step(const DevIndex &ix, uint64_t i, boo
         s = static_cast<uint64_t>(e.base) + delta;
     } else {
         const uint32_t o = static_cast<uint32_t>(i - (b << ix.phi_shift));
-        uint64_t D = sl.dprev;
-        if (o > (meta & 0xFFu)) D = sl.d0;
-        if (o > ((meta >> 8) & 0xFFu)) D = sl.d1;
+        uint64_t D = dprev;
+        if (o > off0) D = d0;
+        if (o > off1) D = d1;
         s = D + i;  // D = (base - pos) mod n of the predecessor: base + (i - pos)
     }
     if (s >= ix.n) s -= ix.n;  // (prev_sample + delta) % n_ (toehold_sa.hpp:71); s < 2n

@@ -243,6 +243,16 @@ size_t table_bytes(const SymTable &t, bool with_samples, uint64_t n) {
            arena_round(nb * sizeof(RankSlot)) + arena_round(nb * sizeof(uint32_t));
 }
 
+// 8-byte positions with n < 2^38 and phi buckets of at most 64 positions: 16-byte packed phi slots (rbg_dev.h)
+template <typename P>
+bool phi_slots_packed(const HostIndex &h) {
+    const char *e = std::getenv("RBG_PHI_PACKED");   // "0": keep the 32-byte slots (A/B measurements, tests)
+    if (e && e[0] == '0') return false;
+    return sizeof(P) == 8 && (h.n >> kPhiPackedPosBits) == 0 && h.phi_shift <= kPhiPackedMaxShift;
+}
+template <typename P>
+size_t phi_slot_bytes(const HostIndex &h) { return phi_slots_packed<P>(h) ? sizeof(PhiSlotPacked) : sizeof(PhiSlot<P>); }
+
 template <typename P>
 size_t replica_bytes(const HostIndex &h) {
     size_t total = 0;
@@ -256,7 +266,7 @@ size_t replica_bytes(const HostIndex &h) {
              arena_round(h.quint.size() * sizeof(DevSym)) + 3 * arena_round(256);
     if (h.has_tsa) {
         const uint64_t nb = (h.n >> h.phi_shift) + 2;
-        total += arena_round(h.r * sizeof(PhiEnt<P>)) + arena_round(nb * sizeof(PhiSlot<P>)) + arena_round(nb * sizeof(uint32_t));
+        total += arena_round(h.r * sizeof(PhiEnt<P>)) + arena_round(nb * phi_slot_bytes<P>(h)) + arena_round(nb * sizeof(uint32_t));
     }
     if (h.has_ma)
         total += arena_round(h.ma.start.size() * 8) + arena_round(h.ma.end.size() * 8) + arena_round(h.ma.off.size() * 8) +
@@ -393,8 +403,10 @@ int upload_tables(rbg_index *ix) {
         }
         const uint64_t nb = (h.n >> h.phi_shift) + 2;
         void *slots = nullptr, *ord = nullptr;
-        if ((rc = dev_reserve(ix, nb * sizeof(PhiSlot<P>), &slots)) || (rc = dev_reserve(ix, nb * sizeof(uint32_t), &ord))) return rc;
-        if (launch_build_phi_slots(sizeof(P), ix->dev.phi_ent, h.r, h.n, h.phi_shift, slots, static_cast<uint32_t *>(ord), ovf + 1, nullptr))
+        const bool packed = phi_slots_packed<P>(h);
+        if ((rc = dev_reserve(ix, nb * phi_slot_bytes<P>(h), &slots)) || (rc = dev_reserve(ix, nb * sizeof(uint32_t), &ord))) return rc;
+        ix->dev.phi_packed = packed ? 1 : 0;
+        if (launch_build_phi_slots(sizeof(P), packed, ix->dev.phi_ent, h.r, h.n, h.phi_shift, slots, static_cast<uint32_t *>(ord), ovf + 1, nullptr))
             return RBG_ENODEV;
         ix->phi_slots = nb;
         ix->dev.phi_slots = slots;

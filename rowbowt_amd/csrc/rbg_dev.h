@@ -64,6 +64,14 @@ template <typename P>
 struct alignas(4 * sizeof(P)) PhiSlot {
     P dprev, d0, d1, meta;
 };
+// 8-byte positions, n < 2^38 and buckets of at most 64 positions: the same slot in 16 bytes instead of 32 (three
+// 38-bit D values, two 6-bit offsets, the 2-bit count) -- one phi step then moves half the bytes and a cache line holds
+// twice the slots (every index the slot layout can hold on 288 GB has n < 2^38).  cnt: 0..2, 3 = more than 2.
+//   w0 = dprev | (d0 & (2^26 - 1)) << 38        w1 = d0 >> 26 | d1 << 12 | off0 << 50 | off1 << 56 | cnt << 62
+struct alignas(16) PhiSlotPacked {
+    uint64_t w0, w1;
+};
+constexpr uint32_t kPhiPackedPosBits = 38, kPhiPackedMaxShift = 6;
 constexpr uint32_t kSlotOvf = 7;
 constexpr uint32_t kPhiOvf = 3;
 constexpr uint32_t kMaxSlotShift = 8;
@@ -155,7 +163,7 @@ struct DevIndex {
     // digit = leftmost symbol.  Built on the GPU at load time with k_find_range itself.  0 = none.
     const void *ftab;       // 16-byte entries at 4-byte positions, 32-byte entries at 8-byte positions
     uint32_t ftab_k;
-    uint32_t pad3;
+    uint32_t phi_packed;    // 1: phi_slots holds PhiSlotPacked (8-byte positions only)
     const uint8_t *dense;   // dense tables of the overflow buckets of every narrow rank table (RankSlot); nullptr = none
     // run-indexed layout (layout == 2): one tree per k-mer depth (DevRunTab above) and one over the phi samples
     uint32_t layout;        // 1 = slot tables (RBG_LAYOUT_SLOTS), 2 = run-indexed (RBG_LAYOUT_RUNS)
@@ -230,7 +238,7 @@ int launch_build_rank_slots(uint32_t pos_bytes, const void *ent, uint64_t nruns,
 // second pass, once the pool of dense_cursor * 16 bytes exists: fills the dense tables of one rank table
 int launch_fill_dense(uint32_t pos_bytes, const void *ent, uint64_t n, uint32_t shift, const void *slots, const uint32_t *ord,
                       uint8_t *dense, void *stream);
-int launch_build_phi_slots(uint32_t pos_bytes, const void *ent, uint64_t r, uint64_t n, uint32_t shift, void *slots, uint32_t *ord,
+int launch_build_phi_slots(uint32_t pos_bytes, bool packed, const void *ent, uint64_t r, uint64_t n, uint32_t shift, void *slots, uint32_t *ord,
                            unsigned long long *overflow, void *stream);
 // packed reads (2 bits per symbol): pack the byte batch once, then search the packed form
 size_t pack_ws_bytes(uint64_t N, uint64_t total_bytes);

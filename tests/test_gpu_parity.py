@@ -993,6 +993,42 @@ def test_long_and_ragged_reads(synth, packed, request):
     o.close()
 
 
+@pytest.mark.parametrize("phi_shift", [3, 5, 6, 7])
+def test_packed_phi_slots_at_8_byte_positions(synth, phi_shift):
+    """8-byte positions, n < 2^38, buckets of at most 64 positions: the phi slots are the 16-byte packed form
+    (rbg_dev.h PhiSlotPacked; shift 7 keeps the 32-byte form) -- same locations as the oracle and as RBG_PHI_PACKED=0,
+    buckets with 0, 1, 2 and more than 2 sampled positions, toeholds that wrapped below zero included"""
+    S = synth
+    o = orc.Oracle.from_runs(S.heads, S.lens, S.ssa, S.esa)
+    reads = S.sample_reads(3000, 60, seed=23, sub_rate=0.1, ragged=True) + [S.text[:300].tobytes(), S.text[-40:-1].tobytes(), b"A", b""]
+    seqs, off = ra.pack_reads(reads)
+    wlo, whi, wk = o.find_range_w_toehold_batch(seqs, off)
+    woff, wlocs = o.locs_at_batch(wlo, whi, wk)
+    sizes = {}
+    for packed in ("1", "0"):
+        os.environ["RBG_PHI_PACKED"] = packed
+        ra.set_default_option(capi.OPT_POS_BYTES, 8)
+        ra.set_default_option(capi.OPT_PHI_BUCKET_SHIFT, phi_shift)
+        try:
+            rb = ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0)
+        finally:
+            ra.set_default_option(capi.OPT_POS_BYTES, 0)
+            ra.set_default_option(capi.OPT_PHI_BUCKET_SHIFT, -1)
+            del os.environ["RBG_PHI_PACKED"]
+        assert rb.info().pos_bytes == 8 and rb.info().phi_bucket_shift == phi_shift
+        sizes[packed] = int(rb.info().hbm_bytes)
+        lo, hi, k = rb.find_range_w_toehold(seqs, off)
+        assert (lo == wlo).all() and (hi == whi).all() and (k == wk).all()
+        for mh in (MAXU, 3):
+            loc_off, locs = rb.locs_at(lo, hi, k, max_hits=mh)
+            w2off, w2locs = (woff, wlocs) if mh == MAXU else o.locs_at_batch(wlo, whi, wk, max_hits=mh)
+            assert (loc_off == w2off).all() and (locs == w2locs).all()
+        rb.close()
+    # (the arena rounds every array to 64 KB: on this small index the halved slots show from 8-position buckets down)
+    assert sizes["1"] <= sizes["0"] and (phi_shift != 3 or sizes["1"] < sizes["0"]) and (phi_shift <= 6 or sizes["1"] == sizes["0"])
+    o.close()
+
+
 def test_hbm_budget_drops_kmer_levels(synth):
     """A tight memory budget keeps fewer k-mer levels; answers do not change."""
     S = synth
