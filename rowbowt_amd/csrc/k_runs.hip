@@ -201,6 +201,35 @@ __device__ __forceinline__ void coop_leaf(const DevTree *s_tree, const uint32_t 
     }
 }
 
+// A row probe of the leaf array at an ARBITRARY start index (the phi directory's path): the row's lanes load entries
+// start .. start + 15 of the owner's query, and t = start + # of them below q; pk / pv = the last entry below q
+// (undefined when t == start).  One query per lane; every lane of the wave must call.
+template <typename P>
+__device__ __forceinline__ void coop_probe_at(const DevTree &T, const bool live, const uint32_t start, const P q, uint32_t &t, P &pk, P &pv) {
+    typedef typename PairOf<P>::vec vec;
+    const uint32_t lane = threadIdx.x & (kWave - 1), sub = lane & (kFan - 1), rowbase = lane & ~static_cast<uint32_t>(kFan - 1);
+    if (!__ballot(live)) return;
+    const uint32_t info = (live ? 0x80000000u : 0u) | (start & 0x7FFFFFFFu);   // (fewer than 2^31 sampled positions: upload() checks)
+    vec va[kFan];
+#pragma unroll
+    for (int j = 0; j < kFan; ++j) {
+        const uint32_t oi = row_get(info, rowbase, j);
+        va[j] = vec{static_cast<P>(~P(0)), 0};
+        if (oi & 0x80000000u) {
+            const uint64_t i = static_cast<uint64_t>(oi & 0x7FFFFFFFu) + sub;
+            if (i <= T.m) va[j] = static_cast<const vec *>(T.ent)[i];   // entry m is the sentinel (never below a query)
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kFan; ++j) {
+        const P oq = row_get(q, rowbase, j);
+        const uint32_t c = row_count(static_cast<P>(va[j].x) < oq, rowbase);
+        const uint32_t pl = c ? c - 1 : 0;
+        const P a_pk = row_pick(static_cast<P>(va[j].x), rowbase, pl), a_pv = row_pick(static_cast<P>(va[j].y), rowbase, pl);
+        if (static_cast<int>(sub) == j && live) { t = start + c; pk = a_pk; pv = a_pv; }
+    }
+}
+
 // per-lane search of the staged top level, clamped like the levels below: entries [a, z) of the tree's slice of s_top
 // are the ones inside the query's slice; returns # top entries below q
 template <typename P>
@@ -409,6 +438,8 @@ __global__ __launch_bounds__(256) void k_locate_fill_runs(const DevIndex ix, con
     __syncthreads();
     const int nlvl = static_cast<int>(ix.phi_nlvl);
     const uint32_t phi_hi = static_cast<uint32_t>(ix.r);
+    const uint32_t *__restrict__ pdir = ix.phi_dir;
+    const uint32_t pdir_shift = ix.phi_dir_shift;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
     const PhiEnt<P> *__restrict__ pent = static_cast<const PhiEnt<P> *>(ix.phi_ent);
     unsigned long long c_locs = 0;
@@ -450,16 +481,36 @@ __global__ __launch_bounds__(256) void k_locate_fill_runs(const DevIndex ix, con
                 const bool wrapped = need && k1 >= ix.n;        // a toehold below zero (k_locate.hip phi_step): outside phi's domain
                 const bool coop = need && !wrapped;
                 uint32_t tq = 0, unused_t = 0;
-                // (one slice: all r sampled positions; entry r is the sentinel)
-                if (coop) tq = top_count<P>(s_top, 0, s_tree[0].top_n, k1);
-                for (int l = nlvl - 1; l >= 0; --l) {
-                    const bool lv0 = coop && tq > 0;
-                    coop_level<P>(s_tree, l, 0u, 0u, phi_hi, lv0, false, tq, unused_t, static_cast<P>(k1), P(0));   // (k1 < n here)
-                }
                 P pk = 0, pv = 0, nv = 0, u1 = 0, u2 = 0, u3 = 0;
-                {
-                    const bool lv0 = coop && tq > 0;
-                    coop_leaf<P>(s_tree, 0u, 0u, phi_hi, lv0, false, tq, unused_t, static_cast<P>(k1), P(0), pk, pv, nv, u1, u2, u3);
+                // the directory: # sampled positions below the bucket of k1 and below the next one; when the bucket (and
+                // the predecessor before it) fit one block, ONE row probe from there answers the query
+                bool descend = coop;
+                if (pdir) {
+                    uint32_t g0 = 0, g1 = 0;
+                    if (coop) {
+                        const uint64_t b = k1 >> pdir_shift;
+                        g0 = pdir[b];
+                        g1 = pdir[b + 1];
+                    }
+                    const uint32_t start = g0 ? g0 - 1 : 0;
+                    const bool direct = coop && g1 - start <= static_cast<uint32_t>(kFan);
+                    coop_probe_at<P>(s_tree[0], direct, start, static_cast<P>(k1), tq, pk, pv);
+                    descend = coop && !direct;
+                }
+                // the descent (one slice: all r sampled positions; entry r is the sentinel)
+                if (__ballot(descend)) {
+                    uint32_t td = 0;
+                    P dk = 0, dv = 0;
+                    if (descend) td = top_count<P>(s_top, 0, s_tree[0].top_n, k1);
+                    for (int l = nlvl - 1; l >= 0; --l) {
+                        const bool lv0 = descend && td > 0;
+                        coop_level<P>(s_tree, l, 0u, 0u, phi_hi, lv0, false, td, unused_t, static_cast<P>(k1), P(0));   // (k1 < n here)
+                    }
+                    {
+                        const bool lv0 = descend && td > 0;
+                        coop_leaf<P>(s_tree, 0u, 0u, phi_hi, lv0, false, td, unused_t, static_cast<P>(k1), P(0), dk, dv, nv, u1, u2, u3);
+                    }
+                    if (descend) { tq = td; pk = dk; pv = dv; }
                 }
                 if (need) {
                     uint64_t s;

@@ -497,7 +497,7 @@ size_t runs_replica_bytes(const HostIndex &h) {
         for (const SymTable &t : *lv) entries += t.nruns + 1;
         total += entries * (sizeof(RunEnt<P>) + (h.has_tsa ? sizeof(P) : 0)) + entries * sizeof(P) / 15 + 8 * kArenaAlign;
     }
-    if (h.has_tsa) total += (h.r + 1) * sizeof(PhiEnt<P>) + h.r * sizeof(P) / 15;
+    if (h.has_tsa) total += (h.r + 1) * sizeof(PhiEnt<P>) + h.r * sizeof(P) / 15 + std::min<size_t>(h.r, size_t(1) << 29) * 4;   // (+ the phi directory: at most r entries)
     return total + 16 * kArenaAlign;
 }
 
@@ -618,6 +618,27 @@ int upload_tables_runs(rbg_index *ix) {
         ix->dev.phi_nlvl = pl;
         ix->dev.phi_slots = nullptr;
         ix->dev.phi_ord = nullptr;
+        // the directory (rbg_dev.h phi_dir): about five sampled positions per bucket; n / 2^shift * 4 bytes, which is a
+        // few per cent of the run lists (31 MB beside 3.85 GB on the bench index); left out beyond 2 GiB
+        ix->dev.phi_dir = nullptr;
+        ix->dev.phi_dir_shift = 0;
+        uint32_t ds = 4;
+        while (ds < 24 && (static_cast<double>(h.r) * static_cast<double>(uint64_t(1) << ds)) / static_cast<double>(h.n) < 4.0) ++ds;
+        const uint64_t nd = (h.n >> ds) + 2;
+        const char *e_dir = std::getenv("RBG_PHI_DIR");   // "0": descent only (A/B measurements, tests)
+        if (nd * 4 <= (uint64_t(2) << 30) && h.r < 0x7FFFFFF0ull && !(e_dir && e_dir[0] == '0')) {
+            std::vector<uint32_t> dir(nd);
+            uint64_t g = 0;
+            for (uint64_t b = 0; b < nd; ++b) {
+                const uint64_t lim = b << ds;
+                while (g < h.r && h.pred_pos[g] < lim) ++g;
+                dir[b] = static_cast<uint32_t>(g);
+            }
+            const void *dp = nullptr;
+            if ((rc = dev_upload(ix, dir.data(), dir.size() * 4, &dp))) return rc;
+            ix->dev.phi_dir = static_cast<const uint32_t *>(dp);
+            ix->dev.phi_dir_shift = ds;
+        }
     }
     HIP_TRY(hipDeviceSynchronize());
     return RBG_OK;
@@ -2562,6 +2583,7 @@ int rbg_replicate(rbg_index *src, int device, rbg_index **out) {
     reloc.fix(d.counters); reloc.fix(d.lut); reloc.fix(d.pairs); reloc.fix(d.triples); reloc.fix(d.quads); reloc.fix(d.quints);
     reloc.fix(d.lut2); reloc.fix(d.ftab); reloc.fix(d.dense); reloc.fix(d.trees); reloc.fix(d.tree_top); reloc.fix(d.phi_top);
     reloc.fix(d.run_tabs);
+    reloc.fix(d.phi_dir);
     for (int t = 0; t < kMaxRunDepth; ++t) reloc.fix(d.run_samp[t]);
     reloc.fix(d.phi_tree.ent);
     for (int l = 0; l < kMaxTreeLevels; ++l) reloc.fix(d.phi_tree.lvl[l]);

@@ -179,6 +179,13 @@ struct DevIndex {
     const DevRunTab *run_tabs;            // depth d's records start at run_tab_first[d - 1]
     const void *run_samp[kMaxRunDepth];   // per depth: P per entry (run-end sample; SA - d for a depth-d run), nullptr without toehold SA
     uint32_t run_tab_first[kMaxRunDepth + 1];
+    // run-indexed phi: a coarse directory over the sampled positions -- phi_dir[b] = # sampled positions below b << phi_dir_shift
+    // ((n >> shift) + 2 entries; the shift keeps about five sampled positions per bucket) -- so that a phi step is one 8-byte
+    // gather (two neighbouring entries) and ONE row probe of the run list instead of a descent through the sampled
+    // levels; buckets with more than 15 sampled positions still take the descent.  nullptr: descent only.
+    const uint32_t *phi_dir;
+    uint32_t phi_dir_shift;
+    uint32_t pad5;
 };
 
 // What the instrumented instantiations count (sums over the launch; include/rbg.h rbg_search_stats_t mirrors it).

@@ -1248,12 +1248,15 @@ def test_run_indexed_layout(synth, pos_bytes, top_kb, fk, ks):
     ra.set_default_option(capi.OPT_POS_BYTES, pos_bytes)
     ra.set_default_option(capi.OPT_FTAB_K, fk)
     ra.set_default_option(capi.OPT_KMER_STEPS, ks)
+    if ks in (2, 4):
+        os.environ["RBG_PHI_DIR"] = "0"   # phi by the descent through the sampled levels only (no directory)
     try:
         rb = _with_layout(capi.LAYOUT_RUNS, top_kb, lambda: ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0))
     finally:
         ra.set_default_option(capi.OPT_POS_BYTES, 0)
         ra.set_default_option(capi.OPT_FTAB_K, -1)
         ra.set_default_option(capi.OPT_KMER_STEPS, 5)
+        os.environ.pop("RBG_PHI_DIR", None)
     o = orc.Oracle.from_runs(S.heads, S.lens, S.ssa, S.esa)
     info = rb.info()
     assert info.rank_layout == capi.LAYOUT_RUNS and info.kmer_steps == ks and info.pos_bytes == (pos_bytes or 4)
