@@ -469,6 +469,56 @@ def test_random_alphabets(sigma, skew):
     o.close()
 
 
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_random_small_texts_every_layout(seed):
+    """Random texts of 2 to 400 symbols over alphabets of 1 to 6 letters (repeats, long runs, no runs at all), indexed
+    from a naive suffix array: ranges, toeholds and locations of random reads and of every kind of substring, through the
+    slot tables, the run-indexed layout at two k-mer depths and a 16-key top level, and 8-byte positions -- all equal to
+    the oracle's.  (Table sizing, clamped searches at slice boundaries, directories with empty buckets, one-run tables.)"""
+    import naive
+    rng = np.random.default_rng(1000 + seed)
+    letters = [b"A", b"AC", b"ACG", b"ACGT", b"ACGTN", b"ACGTNB"][seed % 6]
+    n_body = int(rng.integers(1, 400))
+    if seed % 3 == 0:   # repetitive: copies of a short unit with a few substitutions
+        unit = rng.choice(list(letters), size=int(rng.integers(1, 12))).astype(np.uint8)
+        body = np.tile(unit, n_body // len(unit) + 1)[:n_body].copy()
+        for _ in range(n_body // 25):
+            body[int(rng.integers(0, n_body))] = letters[int(rng.integers(0, len(letters)))]
+    else:
+        body = rng.choice(list(letters), size=n_body).astype(np.uint8)
+    body = body.tobytes()
+    text = np.frombuffer(body + bytes([1]), dtype=np.uint8)
+    sa = naive.suffix_array(text)
+    heads, lens, brk = naive.rle(naive.bwt_from_sa(text, sa))
+    ssa, esa = naive.run_samples(sa, brk, len(text))
+    o = orc.Oracle.from_runs(heads, lens, ssa, esa)
+    alphabet = sorted(set(body)) + [ord("N"), 1]
+    reads = [bytes(rng.choice(alphabet, size=int(rng.integers(0, 12))).astype(np.uint8)) for _ in range(200)]
+    for _ in range(200):
+        a = int(rng.integers(0, len(body)))
+        reads.append(body[a:a + int(rng.integers(1, 40))])
+    reads += [body, body[:1], body[-1:], body + body[:1], b"", body[1:], body[:-1]]
+    seqs, off = ra.pack_reads(reads)
+    wlo, whi, wk = o.find_range_w_toehold_batch(seqs, off)
+    woff, wlocs = o.locs_at_batch(wlo, whi, wk)
+    for layout, ks, top_kb, pb in ((capi.LAYOUT_SLOTS, 5, 48, 0), (capi.LAYOUT_RUNS, 5, 48, 0), (capi.LAYOUT_RUNS, 2, 0, 8), (capi.LAYOUT_SLOTS, 3, 48, 8)):
+        ra.set_default_option(capi.OPT_KMER_STEPS, ks)
+        ra.set_default_option(capi.OPT_POS_BYTES, pb)
+        try:
+            rb = _with_layout(layout, top_kb, lambda: ra.RowBowt.from_runs(heads, lens, ssa, esa, device=0))
+        finally:
+            ra.set_default_option(capi.OPT_KMER_STEPS, 5)
+            ra.set_default_option(capi.OPT_POS_BYTES, 0)
+        lo, hi, k = rb.find_range_w_toehold(seqs, off)
+        assert (lo == wlo).all() and (hi == whi).all() and (k == wk).all(), (layout, ks, body[:40])
+        lo2, hi2 = rb.find_range(seqs, off)
+        assert (lo2 == wlo).all() and (hi2 == whi).all()
+        loc_off, locs = rb.locs_at(lo, hi, k)
+        assert (loc_off == woff).all() and (locs == wlocs).all(), (layout, ks, body[:40])
+        rb.close()
+    o.close()
+
+
 @pytest.mark.parametrize("body", [b"A", b"AAAAAAAAAAAA", b"ACGT", b"ABABABABAB", b"TTTTTTTTCTTTTTTTT", b"ACGTACGTACGTACGTACGTACGTACGTACGTACGTACGT" * 8])
 def test_tiny_indexes(body):
     """Degenerate texts (two symbols long, one long run, pure repeats): table sizing, the automatic
