@@ -230,6 +230,77 @@ __device__ __forceinline__ void coop_probe_at(const DevTree &T, const bool live,
     }
 }
 
+// The same for the two ranks of an LF step (the rank directories' path): query 0 is answered from entries
+// s0 .. s0 + 15 of which the first z0 are candidates (the rest lie beyond the bucket, possibly in the next table's
+// slice), query 1 likewise from s1 / z1 -- sharing the load when s1 == s0.  Returns t = s + # candidates below q, the
+// pair before it (pk, pv: entry t-1, valid when t > s or the directory says an entry precedes) and the value of entry t.
+template <typename P>
+__device__ __forceinline__ void coop_probe2_at(const DevTree *s_tree, const uint32_t tid, const bool live, const uint32_t s0, const uint32_t z0,
+                                               const uint32_t s1, const uint32_t z1, const P q0, const P q1, uint32_t &t0, uint32_t &t1, P &pk0,
+                                               P &pv0, P &nv0, P &pk1, P &pv1, P &nv1) {
+    typedef typename PairOf<P>::vec vec;
+    const uint32_t lane = threadIdx.x & (kWave - 1), sub = lane & (kFan - 1), rowbase = lane & ~static_cast<uint32_t>(kFan - 1);
+    if (!__ballot(live)) return;
+    const bool two = live && s1 != s0;
+    // bit 0 live, bit 1 second block, bits 2-4 tree, bits 5-9 z0, 10-14 z1
+    const uint32_t info = (live ? 1u : 0u) | (two ? 2u : 0u) | (tid << 2) | (z0 << 5) | (z1 << 10);
+    bool fix0 = false, fix1 = false;
+    vec va[kFan];
+#pragma unroll
+    for (int j = 0; j < kFan; ++j) {
+        const uint32_t oi = row_get(info, rowbase, j);
+        const uint32_t os = row_get(s0, rowbase, j);
+        va[j] = vec{static_cast<P>(~P(0)), 0};
+        if (oi & 1u) {
+            const DevTree &T = s_tree[(oi >> 2) & 7u];
+            const uint64_t i = static_cast<uint64_t>(os) + sub;
+            if (i <= T.m) va[j] = static_cast<const vec *>(T.ent)[i];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kFan; ++j) {
+        const uint32_t oi = row_get(info, rowbase, j);
+        const P oq0 = row_get(q0, rowbase, j), oq1 = row_get(q1, rowbase, j);   // (cross-lane: outside the &&)
+        const uint32_t c0 = row_count(sub < ((oi >> 5) & 31u) && static_cast<P>(va[j].x) < oq0, rowbase);
+        const uint32_t c1 = row_count(sub < ((oi >> 10) & 31u) && static_cast<P>(va[j].x) < oq1, rowbase);
+        const uint32_t p0 = c0 ? c0 - 1 : 0, n0 = c0 < kFan ? c0 : kFan - 1;
+        const uint32_t p1 = c1 ? c1 - 1 : 0, n1 = c1 < kFan ? c1 : kFan - 1;
+        const P a_pk0 = row_pick(static_cast<P>(va[j].x), rowbase, p0), a_pv0 = row_pick(static_cast<P>(va[j].y), rowbase, p0), a_nv0 = row_pick(static_cast<P>(va[j].y), rowbase, n0);
+        const P a_pk1 = row_pick(static_cast<P>(va[j].x), rowbase, p1), a_pv1 = row_pick(static_cast<P>(va[j].y), rowbase, p1), a_nv1 = row_pick(static_cast<P>(va[j].y), rowbase, n1);
+        if (static_cast<int>(sub) == j && live) {
+            t0 = s0 + c0; pk0 = a_pk0; pv0 = a_pv0; nv0 = a_nv0; fix0 = c0 == kFan;
+            if (!two) { t1 = s1 + c1; pk1 = a_pk1; pv1 = a_pv1; nv1 = a_nv1; fix1 = c1 == kFan; }
+        }
+    }
+    if (__ballot(two)) {
+#pragma unroll
+        for (int j = 0; j < kFan; ++j) {
+            const uint32_t oi = row_get(info, rowbase, j);
+            const uint32_t os = row_get(s1, rowbase, j);
+            va[j] = vec{static_cast<P>(~P(0)), 0};
+            if (oi & 2u) {
+                const DevTree &T = s_tree[(oi >> 2) & 7u];
+                const uint64_t i = static_cast<uint64_t>(os) + sub;
+                if (i <= T.m) va[j] = static_cast<const vec *>(T.ent)[i];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kFan; ++j) {
+            const uint32_t oi = row_get(info, rowbase, j);
+            const P oq1 = row_get(q1, rowbase, j);
+            const uint32_t c1 = row_count(sub < ((oi >> 10) & 31u) && static_cast<P>(va[j].x) < oq1, rowbase);
+            const uint32_t p1 = c1 ? c1 - 1 : 0, n1 = c1 < kFan ? c1 : kFan - 1;
+            const P a_pk1 = row_pick(static_cast<P>(va[j].x), rowbase, p1), a_pv1 = row_pick(static_cast<P>(va[j].y), rowbase, p1), a_nv1 = row_pick(static_cast<P>(va[j].y), rowbase, n1);
+            if (static_cast<int>(sub) == j && two) { t1 = s1 + c1; pk1 = a_pk1; pv1 = a_pv1; nv1 = a_nv1; fix1 = c1 == kFan; }
+        }
+    }
+    if (fix0 || fix1) {
+        const vec *__restrict__ ent = static_cast<const vec *>(s_tree[tid].ent);
+        if (fix0) nv0 = static_cast<P>(ent[t0].y);
+        if (fix1) nv1 = static_cast<P>(ent[t1].y);
+    }
+}
+
 // per-lane search of the staged top level, clamped like the levels below: entries [a, z) of the tree's slice of s_top
 // are the ones inside the query's slice; returns # top entries below q
 template <typename P>
@@ -343,27 +414,52 @@ __global__ __launch_bounds__(512) void k_find_range_runs(const DevIndex ix, cons
             }
             uint32_t lo_t = 0, hi_t = 0;
             uint64_t F = 0;
+            const uint64_t q0 = lo, q1 = hi + 1;               // rank(lo, c), rank(hi + 1, c): rowbowt.hpp:79,83
+            // (positions fit P: q1 = hi + 1 <= n, and n stays below the all-ones key, flatten())
+            uint32_t t0 = 0, t1 = 0;
+            P pk0 = 0, pv0 = 0, nv0 = 0, pk1 = 0, pv1 = 0, nv1 = 0;
+            bool descend = stepping;
+            uint32_t s0 = 0, z0 = 0, s1 = 0, z1 = 0;
+            bool direct = false;
             if (stepping) {
                 const DevRunTab r0 = s_tab[rec];
                 F = r0.F;
                 lo_t = static_cast<uint32_t>(r0.first);
                 hi_t = static_cast<uint32_t>(s_tab[rec + 1].first) - 1;   // the slice's sentinel: never below a query
+                const uint32_t *__restrict__ dir = ix.run_dir[d];
+                if (dir) {
+                    // the table's directory: # runs starting below the bucket of q and below the next bucket; the
+                    // candidates are those runs and the one before them
+                    dir += r0.dir_off;
+                    const uint64_t b0 = q0 >> r0.dir_shift, b1 = q1 >> r0.dir_shift;
+                    const uint32_t a0 = dir[b0], e0 = dir[b0 + 1];
+                    uint32_t a1 = a0, e1 = e0;
+                    if (b1 != b0) { a1 = dir[b1]; e1 = dir[b1 + 1]; }
+                    s0 = lo_t + (a0 ? a0 - 1 : 0);
+                    s1 = lo_t + (a1 ? a1 - 1 : 0);
+                    z0 = lo_t + e0 - s0;
+                    z1 = lo_t + e1 - s1;
+                    direct = z0 <= static_cast<uint32_t>(kFan) && z1 <= static_cast<uint32_t>(kFan);
+                    descend = !direct;
+                }
             }
-            const uint64_t q0 = lo, q1 = hi + 1;               // rank(lo, c), rank(hi + 1, c): rowbowt.hpp:79,83
-            uint32_t t0 = 0, t1 = 0;
-            if (stepping) {
-                t0 = top_count_clamped<P>(s_top, s_tree[d], top_sh, lo_t, hi_t, q0);
-                t1 = top_count_clamped<P>(s_top, s_tree[d], top_sh, lo_t, hi_t, q1);
-            }
-            // (positions fit P: q1 = hi + 1 <= n, and n stays below the all-ones key, flatten())
-            for (int l = nlvl - 1; l >= 0; --l) {
-                const bool l0 = stepping && t0 > 0, l1 = stepping && t1 > 0;
-                coop_level<P>(s_tree, l, d, lo_t, hi_t, l0, l1, t0, t1, static_cast<P>(q0), static_cast<P>(q1));
-            }
-            P pk0 = 0, pv0 = 0, nv0 = 0, pk1 = 0, pv1 = 0, nv1 = 0;
-            {
-                const bool l0 = stepping && t0 > 0, l1 = stepping && t1 > 0;
-                coop_leaf<P>(s_tree, d, lo_t, hi_t, l0, l1, t0, t1, static_cast<P>(q0), static_cast<P>(q1), pk0, pv0, nv0, pk1, pv1, nv1);
+            coop_probe2_at<P>(s_tree, d, direct, s0, z0, s1, z1, static_cast<P>(q0), static_cast<P>(q1), t0, t1, pk0, pv0, nv0, pk1, pv1, nv1);
+            if (__ballot(descend)) {   // crowded buckets (and indexes without directories): the clamped descent
+                uint32_t d0 = 0, d1 = 0;
+                P ak0 = 0, av0 = 0, an0 = 0, ak1 = 0, av1 = 0, an1 = 0;
+                if (descend) {
+                    d0 = top_count_clamped<P>(s_top, s_tree[d], top_sh, lo_t, hi_t, q0);
+                    d1 = top_count_clamped<P>(s_top, s_tree[d], top_sh, lo_t, hi_t, q1);
+                }
+                for (int l = nlvl - 1; l >= 0; --l) {
+                    const bool l0 = descend && d0 > 0, l1 = descend && d1 > 0;
+                    coop_level<P>(s_tree, l, d, lo_t, hi_t, l0, l1, d0, d1, static_cast<P>(q0), static_cast<P>(q1));
+                }
+                {
+                    const bool l0 = descend && d0 > 0, l1 = descend && d1 > 0;
+                    coop_leaf<P>(s_tree, d, lo_t, hi_t, l0, l1, d0, d1, static_cast<P>(q0), static_cast<P>(q1), ak0, av0, an0, ak1, av1, an1);
+                }
+                if (descend) { t0 = d0; t1 = d1; pk0 = ak0; pv0 = av0; nv0 = an0; pk1 = ak1; pv1 = av1; nv1 = an1; }
             }
             if (stepping) {
                 // rle_string::rank in the table: occurrences before the predecessor run + the part of it below the

@@ -495,7 +495,7 @@ size_t runs_replica_bytes(const HostIndex &h) {
     for (const std::vector<SymTable> *lv : {&h.sym, &h.pair, &h.triple, &h.quad, &h.quint}) {
         size_t entries = 0;
         for (const SymTable &t : *lv) entries += t.nruns + 1;
-        total += entries * (sizeof(RunEnt<P>) + (h.has_tsa ? sizeof(P) : 0)) + entries * sizeof(P) / 15 + 8 * kArenaAlign;
+        total += entries * (sizeof(RunEnt<P>) + (h.has_tsa ? sizeof(P) : 0)) + entries * sizeof(P) / 15 + entries * 2 + lv->size() * 8 + 8 * kArenaAlign;   // (+ directories: at most half an entry per run)
     }
     if (h.has_tsa) total += (h.r + 1) * sizeof(PhiEnt<P>) + h.r * sizeof(P) / 15 + std::min<size_t>(h.r, size_t(1) << 29) * 4;   // (+ the phi directory: at most r entries)
     return total + 16 * kArenaAlign;
@@ -518,7 +518,10 @@ int upload_tables_runs(rbg_index *ix) {
     // the bench index's deepest level, 5e8 at r = 3e8)
     while (D > 1 && sizes[D - 1] >= 0xFFFFFFF0ull) { --D; sizes.pop_back(); }
     if (sizes[0] >= 0xFFFFFFF0ull) return RBG_EARG;
-    const uint32_t nlvl = tree_levels_for(sizes, budget_keys);
+    const char *e_rdir = std::getenv("RBG_RANK_DIR");   // "0": ranks by the descent only (A/B measurements, tests)
+    const bool use_dirs = !(e_rdir && e_rdir[0] == '0');
+    // with the directories the descent is the rare path: half the LDS for its top level leaves room for the table records
+    const uint32_t nlvl = tree_levels_for(sizes, use_dirs && budget_keys > 64 ? std::max<uint64_t>(64, budget_keys / 2) : budget_keys);
     if (nlvl > kMaxTreeLevels) return RBG_EARG;
     std::vector<DevSym> syms(h.sym.size());
     std::vector<DevTree> trees(D);
@@ -556,8 +559,45 @@ int upload_tables_runs(rbg_index *ix) {
         if (h.has_tsa && (rc = dev_upload(ix, samp.data(), samp.size() * sizeof(P), &d_samp))) return rc;
         ix->dev.run_samp[d] = d_samp;
         ix->dev.run_tab_first[d] = static_cast<uint32_t>(tabs.size());
-        for (size_t t = 0; t < T.size(); ++t) tabs.push_back(DevRunTab{T[t].F, first[t]});
-        tabs.push_back(DevRunTab{0, entries});   // closing record: the last table's slice ends here
+        // the tables' directories (rbg_dev.h DevRunTab): per table the widest bucket that still holds at most about
+        // four runs on average
+        std::vector<uint32_t> dshift(T.size(), 0);
+        std::vector<uint64_t> doff(T.size() + 1, 0);
+        for (size_t t = 0; t < T.size(); ++t) {
+            uint32_t sh = 0;
+            const double runs = static_cast<double>(std::max<uint64_t>(1, T[t].nruns));
+            while (sh < 40 && runs * static_cast<double>(uint64_t(2) << sh) <= 4.0 * static_cast<double>(h.n)) ++sh;
+            dshift[t] = sh;
+            doff[t + 1] = doff[t] + (h.n >> sh) + 2;
+        }
+        const bool with_dir = use_dirs && doff[T.size()] < 0xFFFFFFF0ull;
+        ix->dev.run_dir[d] = nullptr;
+        if (with_dir) {
+            std::vector<uint32_t> dir(doff[T.size()]);
+            const size_t W = std::max<size_t>(1, std::min<size_t>({16, std::thread::hardware_concurrency(), T.size()}));
+            std::vector<std::thread> workers;
+            for (size_t w = 0; w < W; ++w)
+                workers.emplace_back([&, w] {
+                    for (size_t t = w; t < T.size(); t += W) {
+                        const SymTable &tb = T[t];
+                        uint32_t *dt = dir.data() + doff[t];
+                        const uint64_t nb = doff[t + 1] - doff[t];
+                        uint64_t g = 0;
+                        for (uint64_t b = 0; b < nb; ++b) {
+                            const uint64_t lim = b << dshift[t];
+                            while (g < tb.nruns && tb.start[g] < lim) ++g;
+                            dt[b] = static_cast<uint32_t>(g);
+                        }
+                    }
+                });
+            for (auto &w : workers) w.join();
+            const void *dp = nullptr;
+            if ((rc = dev_upload(ix, dir.data(), dir.size() * 4, &dp))) return rc;
+            ix->dev.run_dir[d] = static_cast<const uint32_t *>(dp);
+        }
+        for (size_t t = 0; t < T.size(); ++t)
+            tabs.push_back(DevRunTab{T[t].F, first[t], with_dir ? static_cast<uint32_t>(doff[t]) : 0u, with_dir ? dshift[t] : 0u});
+        tabs.push_back(DevRunTab{0, entries, 0u, 0u});   // closing record: the last table's slice ends here
         if ((rc = upload_tree<P>(ix, d_ent, entries - 1, [&](uint64_t j) { return static_cast<uint64_t>(ent[j].start); }, nlvl, top_all, trees[d]))) return rc;
         if (d == 0)   // the per-lane kernels (seeding, windowed markers, single LF steps) search a symbol's own slice
             for (size_t t = 0; t < T.size(); ++t) {
@@ -2584,6 +2624,7 @@ int rbg_replicate(rbg_index *src, int device, rbg_index **out) {
     reloc.fix(d.lut2); reloc.fix(d.ftab); reloc.fix(d.dense); reloc.fix(d.trees); reloc.fix(d.tree_top); reloc.fix(d.phi_top);
     reloc.fix(d.run_tabs);
     reloc.fix(d.phi_dir);
+    for (int t = 0; t < kMaxRunDepth; ++t) reloc.fix(d.run_dir[t]);
     for (int t = 0; t < kMaxRunDepth; ++t) reloc.fix(d.run_samp[t]);
     reloc.fix(d.phi_tree.ent);
     for (int l = 0; l < kMaxTreeLevels; ++l) reloc.fix(d.phi_tree.lvl[l]);

@@ -117,9 +117,15 @@ constexpr int kMaxMajor = 4;  // symbol tables staged in LDS per workgroup; rare
 // it, which keeps the predicate monotone over the whole array -- one sampled index per depth instead of 1364 of them.
 // DevRunTab: what a step needs to know about its table; the records of a depth are followed by one closing record
 // (first = the depth's entry count) so that first_{t+1} is always the next record.
+// Each table also has a coarse DIRECTORY over its run starts -- dir[b] = # runs of the table starting below
+// b << dir_shift, the shift chosen per table so that a bucket holds about four runs (so the directories take about a
+// byte per run: still O(r)) -- which turns most ranks into one 8-byte gather plus ONE row probe of the run list; buckets
+// with more than 15 runs take the clamped descent.
 struct DevRunTab {
-    uint64_t F;      // first row of the k-mer's SA interval (RowBowt::f_ for a single symbol)
-    uint64_t first;  // index of the table's first entry in its depth's arrays
+    uint64_t F;          // first row of the k-mer's SA interval (RowBowt::f_ for a single symbol)
+    uint64_t first;      // index of the table's first entry in its depth's arrays
+    uint32_t dir_off;    // the table's directory starts at run_dir[depth][dir_off] ((n >> dir_shift) + 2 entries)
+    uint32_t dir_shift;
 };
 constexpr int kMaxRunDepth = 5;
 constexpr int kMaxRunTabs = kLdsSyms + 16 + 64 + 256 + 1024 + kMaxRunDepth;  // records staged in LDS by k_find_range_runs
@@ -178,6 +184,7 @@ struct DevIndex {
     uint32_t run_ntabs;     // records in run_tabs
     const DevRunTab *run_tabs;            // depth d's records start at run_tab_first[d - 1]
     const void *run_samp[kMaxRunDepth];   // per depth: P per entry (run-end sample; SA - d for a depth-d run), nullptr without toehold SA
+    const uint32_t *run_dir[kMaxRunDepth];  // per depth: the tables' directories back to back (DevRunTab::dir_off); nullptr = descent only
     uint32_t run_tab_first[kMaxRunDepth + 1];
     // run-indexed phi: a coarse directory over the sampled positions -- phi_dir[b] = # sampled positions below b << phi_dir_shift
     // ((n >> shift) + 2 entries; the shift keeps about five sampled positions per bucket) -- so that a phi step is one 8-byte
