@@ -230,6 +230,39 @@ __device__ __forceinline__ void coop_probe_at(const DevTree &T, const bool live,
     }
 }
 
+// One narrowing round for a crowded bucket: the candidates [s, s + z) of a query (z > 16) are sampled at 16 pivots a
+// stride apart, loaded by the row; the answer lies between the last pivot below q and the next one, so the range
+// shrinks to at most ceil(z / 16) candidates (s moves to that pivot, which is known to be below q -- or stays with
+// z = 1 when not even the first candidate is).  Lanes with live == false pass through.  Every lane must call.
+template <typename P>
+__device__ __forceinline__ void coop_narrow(const DevTree *s_tree, const uint32_t tid, const bool live, uint32_t &s, uint32_t &z, const P q) {
+    typedef typename PairOf<P>::vec vec;
+    const uint32_t lane = threadIdx.x & (kWave - 1), sub = lane & (kFan - 1), rowbase = lane & ~static_cast<uint32_t>(kFan - 1);
+    if (!__ballot(live)) return;
+    const uint32_t stride = (z + kFan - 1) / kFan;
+    const uint32_t flags = (live ? 1u : 0u) | (tid << 1);
+    P va[kFan];
+#pragma unroll
+    for (int j = 0; j < kFan; ++j) {
+        const uint32_t of = row_get(flags, rowbase, j), os = row_get(s, rowbase, j), oz = row_get(z, rowbase, j), ost = row_get(stride, rowbase, j);
+        va[j] = static_cast<P>(~P(0));   // pivots beyond the candidates are never below
+        if ((of & 1u) && sub * ost < oz) va[j] = static_cast<P>(static_cast<const vec *>(s_tree[(of >> 1) & 7u].ent)[static_cast<uint64_t>(os) + sub * ost].x);
+    }
+#pragma unroll
+    for (int j = 0; j < kFan; ++j) {
+        const P oq = row_get(q, rowbase, j);
+        const uint32_t c = row_count(va[j] < oq, rowbase);
+        if (static_cast<int>(sub) == j && live) {
+            if (c == 0) { z = 1; }
+            else {
+                const uint32_t adv = (c - 1) * stride;
+                s += adv;
+                z = (z - adv) < stride ? (z - adv) : stride;
+            }
+        }
+    }
+}
+
 // The same for the two ranks of an LF step (the rank directories' path): query 0 is answered from entries
 // s0 .. s0 + 15 of which the first z0 are candidates (the rest lie beyond the bucket, possibly in the next table's
 // slice), query 1 likewise from s1 / z1 -- sharing the load when s1 == s0.  Returns t = s + # candidates below q, the
@@ -318,8 +351,9 @@ __device__ __forceinline__ uint32_t top_count_clamped(const P *s_top, const DevT
 // 2b: identical to that many nested RowBowt::LF / LF_w_loc calls, rowbowt.hpp:74-88, :555-573); both ranks of all
 // the wave's reads are answered cooperatively.  The device ftab (a constant-size state table, result-neutral) still
 // replaces the first ftab_k steps.
+// (4 waves per SIMD at 4-byte positions: the toehold variant sits at 130 VGPRs without the bound, one wave per SIMD less)
 template <typename P, bool TOEHOLD>
-__global__ __launch_bounds__(512) void k_find_range_runs(const DevIndex ix, const uint8_t *__restrict__ seqs,
+__global__ __launch_bounds__(512, sizeof(P) == 4 ? 4 : 3) void k_find_range_runs(const DevIndex ix, const uint8_t *__restrict__ seqs,
                                                         const uint64_t *__restrict__ off, const uint64_t N,
                                                         uint64_t *__restrict__ lo_out, uint64_t *__restrict__ hi_out,
                                                         uint64_t *__restrict__ ss_out) {
@@ -439,9 +473,15 @@ __global__ __launch_bounds__(512) void k_find_range_runs(const DevIndex ix, cons
                     s1 = lo_t + (a1 ? a1 - 1 : 0);
                     z0 = lo_t + e0 - s0;
                     z1 = lo_t + e1 - s1;
-                    direct = z0 <= static_cast<uint32_t>(kFan) && z1 <= static_cast<uint32_t>(kFan);
-                    descend = !direct;
+                    direct = true;   // (crowded buckets are narrowed below until one row probe covers their candidates)
+                    descend = false;
                 }
+            }
+            while (__ballot(direct && (z0 > static_cast<uint32_t>(kFan) || z1 > static_cast<uint32_t>(kFan)))) {
+                const bool same = s1 == s0 && z1 == z0;     // both positions in one bucket: narrowed separately from here on
+                (void)same;
+                coop_narrow<P>(s_tree, d, direct && z0 > static_cast<uint32_t>(kFan), s0, z0, static_cast<P>(q0));
+                coop_narrow<P>(s_tree, d, direct && z1 > static_cast<uint32_t>(kFan), s1, z1, static_cast<P>(q1));
             }
             coop_probe2_at<P>(s_tree, d, direct, s0, z0, s1, z1, static_cast<P>(q0), static_cast<P>(q1), t0, t1, pk0, pv0, nv0, pk1, pv1, nv1);
             if (__ballot(descend)) {   // crowded buckets (and indexes without directories): the clamped descent
