@@ -606,7 +606,8 @@ int upload_tables_runs(rbg_index *ix) {
                 r.ent = static_cast<const char *>(d_ent) + first[t] * sizeof(RunEnt<P>);
                 r.samp = d_samp ? static_cast<const char *>(d_samp) + first[t] * sizeof(P) : nullptr;
                 r.F = T[t].F;
-                r.shift = 0;
+                r.shift = with_dir ? dshift[t] : 0;    // with slots == nullptr: ord / shift are the symbol's directory (rank_runs_lane)
+                r.ord = with_dir ? ix->dev.run_dir[0] + doff[t] : nullptr;
                 r.nruns = static_cast<uint32_t>(T[t].nruns);
             }
     }

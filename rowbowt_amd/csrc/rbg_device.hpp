@@ -160,7 +160,14 @@ __device__ __forceinline__ uint64_t rank_in_slot(const DevSym &S, const RankSlot
 template <typename P>
 __device__ __forceinline__ uint64_t rank_runs_lane(const DevSym &S, uint64_t i, RankAux *aux) {
     const RunEnt<P> *__restrict__ ent = static_cast<const RunEnt<P> *>(S.ent);
-    const uint64_t a = search_runs<P>(ent, 0, S.nruns, i);
+    uint64_t a0 = 0, z0 = S.nruns;
+    if (S.ord) {   // the symbol's directory (rbg_dev.h DevRunTab; upload_tables_runs puts it here): the runs of i's bucket and the one before
+        const uint64_t b = i >> S.shift;
+        a0 = S.ord[b];
+        z0 = S.ord[b + 1];
+        a0 = a0 ? a0 - 1 : 0;
+    }
+    const uint64_t a = search_runs<P>(ent, a0, z0, i);
     aux->ovf = false;
     aux->dense = false;
     aux->nbefore = static_cast<uint32_t>(a);
@@ -201,7 +208,7 @@ __device__ __forceinline__ void rank_pair(const DevSym &S, const uint8_t *__rest
 // ordinal of the last run of the symbol that starts before the position a RankAux describes
 template <typename P>
 __device__ __forceinline__ uint64_t pred_run(const DevSym &S, uint64_t b, bool ovf, uint32_t v) {
-    if (S.ord == nullptr) return static_cast<uint64_t>(v) - 1;  // run-indexed layout: v already counts from the first run
+    if (S.slots == nullptr) return static_cast<uint64_t>(v) - 1;  // run-indexed layout: v already counts from the first run
     return (ovf ? runs_before<P>(S, b, (b << S.shift) + v) : static_cast<uint64_t>(S.ord[b]) + v) - 1;
 }
 
