@@ -628,10 +628,11 @@ __global__ __launch_bounds__(256) void k_locate_fill_runs(const DevIndex ix, con
                         g0 = pdir[b];
                         g1 = pdir[b + 1];
                     }
-                    const uint32_t start = g0 ? g0 - 1 : 0;
-                    const bool direct = coop && g1 - start <= static_cast<uint32_t>(kFan);
-                    coop_probe_at<P>(s_tree[0], direct, start, static_cast<P>(k1), tq, pk, pv);
-                    descend = coop && !direct;
+                    uint32_t start = g0 ? g0 - 1 : 0, z = g1 - start;
+                    // a crowded bucket is narrowed by pivot probes first (coop_narrow), as the ranks' are
+                    while (__ballot(coop && z > static_cast<uint32_t>(kFan))) coop_narrow<P>(s_tree, 0u, coop && z > static_cast<uint32_t>(kFan), start, z, static_cast<P>(k1));
+                    coop_probe_at<P>(s_tree[0], coop, start, static_cast<P>(k1), tq, pk, pv);
+                    descend = false;
                 }
                 // the descent (one slice: all r sampled positions; entry r is the sentinel)
                 if (__ballot(descend)) {

@@ -659,12 +659,12 @@ int upload_tables_runs(rbg_index *ix) {
         ix->dev.phi_nlvl = pl;
         ix->dev.phi_slots = nullptr;
         ix->dev.phi_ord = nullptr;
-        // the directory (rbg_dev.h phi_dir): about five sampled positions per bucket; n / 2^shift * 4 bytes, which is a
-        // few per cent of the run lists (31 MB beside 3.85 GB on the bench index); left out beyond 2 GiB
+        // the directory (rbg_dev.h phi_dir): two to four sampled positions per bucket; n / 2^shift * 4 bytes, which is a
+        // few per cent of the run lists (61 MB beside 4.2 GB on the bench index); left out beyond 2 GiB
         ix->dev.phi_dir = nullptr;
         ix->dev.phi_dir_shift = 0;
         uint32_t ds = 4;
-        while (ds < 24 && (static_cast<double>(h.r) * static_cast<double>(uint64_t(1) << ds)) / static_cast<double>(h.n) < 4.0) ++ds;
+        while (ds < 24 && (static_cast<double>(h.r) * static_cast<double>(uint64_t(1) << ds)) / static_cast<double>(h.n) < 2.0) ++ds;
         const uint64_t nd = (h.n >> ds) + 2;
         const char *e_dir = std::getenv("RBG_PHI_DIR");   // "0": descent only (A/B measurements, tests)
         if (nd * 4 <= (uint64_t(2) << 30) && h.r < 0x7FFFFFF0ull && !(e_dir && e_dir[0] == '0')) {

@@ -187,9 +187,9 @@ struct DevIndex {
     const uint32_t *run_dir[kMaxRunDepth];  // per depth: the tables' directories back to back (DevRunTab::dir_off); nullptr = descent only
     uint32_t run_tab_first[kMaxRunDepth + 1];
     // run-indexed phi: a coarse directory over the sampled positions -- phi_dir[b] = # sampled positions below b << phi_dir_shift
-    // ((n >> shift) + 2 entries; the shift keeps about five sampled positions per bucket) -- so that a phi step is one 8-byte
-    // gather (two neighbouring entries) and ONE row probe of the run list instead of a descent through the sampled
-    // levels; buckets with more than 15 sampled positions still take the descent.  nullptr: descent only.
+    // ((n >> shift) + 2 entries; the shift keeps two to four sampled positions per bucket) -- so that a phi step is one
+    // 8-byte gather (two neighbouring entries) and ONE row probe of the run list instead of a descent through the sampled
+    // levels; a bucket with more than 15 sampled positions is narrowed by pivot probes first.  nullptr: descent only.
     const uint32_t *phi_dir;
     uint32_t phi_dir_shift;
     uint32_t pad5;

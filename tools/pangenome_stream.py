@@ -160,6 +160,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # per-kernel times of one batch (outside the timed region; HIP events on the launch stream)
+    kernel_ms = {}
+    if rank == 0:
+        def timed(fn):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            fn()
+            e1.record(stream)
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1)
+        gen(gb, N)
+        kernel_ms["sample_reads"] = timed(lambda: gen(gb, N))
+        kernel_ms["find_range" if args.count_only else "find_range_w_toehold"] = timed(lambda: search(N))
+        if not args.count_only:
+            kernel_ms["locate_plan"] = timed(lambda: chk(Lb.rbg_locate_plan_dev(rb.h, d_lo.data_ptr(), d_hi.data_ptr(), N, max_hits, d_loc_off.data_ptr(),
+                                                                                   d_tmp.data_ptr(), tmp_bytes, st), "plan"))
+            kernel_ms["locate_order"] = timed(lambda: chk(Lb.rbg_locate_order_dev(rb.h, d_k.data_ptr(), N, d_ws.data_ptr(), ws_bytes, st), "order"))
+            kernel_ms["locate_fill"] = timed(lambda: chk(Lb.rbg_locate_fill_dev(rb.h, d_lo.data_ptr(), d_hi.data_ptr(), d_k.data_ptr(), N, max_hits,
+                                                                                   d_loc_off.data_ptr(), d_locs.data_ptr(), d_ws.data_ptr(), st), "fill"))
+        log("one batch, per kernel (ms): " + ", ".join(f"{k} {v:.2f}" for k, v in kernel_ms.items()))
+
     rb.counters_reset()
     ev_g = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     t_gen = t_search = 0.0
@@ -194,6 +215,7 @@ def main():
             "value": args.total_reads / el, "unit": "reads/s", "n_gpus": world, "higher_is_better": True, "scaling": "strong",
             "value_excluding_read_generation": args.total_reads / max(el - t_gen, 1e-9),
             "seconds": el, "seconds_generating_reads": t_gen, "batches_per_gpu": nbatch, "reads_per_batch": N,
+            "kernel_ms_one_batch": kernel_ms,
             "dtype": "u64" if ix.pos_bytes == 8 else "u32/u64", "data": "synthetic",
             "config": {"workload": f"BASELINE.json configs[3] shape: {args.total_reads} synthetic {m} bp reads generated on the device per batch "
                                    f"(counter-based RNG), {'find_range' if args.count_only else 'find_range_w_toehold + locs_at'}, "
