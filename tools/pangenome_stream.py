@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--verify-sa", action="store_true", help="also build the suffix array by prefix doubling and compare (n < 2.5e9 only)")
     ap.add_argument("--count-only", action="store_true")
     ap.add_argument("--layout", choices=("auto", "slots", "runs"), default="auto")
+    ap.add_argument("--ftab-k", type=int, default=-1, help="word length of the device ftab (-1 = the library's choice)")
     ap.add_argument("--hbm-reserve-gb", type=float, default=45.0,
                     help="HBM left to this tool's own buffers (reads, ranges, locations, sort workspace): the index replica gets the rest of "
                          "what is free once the text is resident (0 = the library's default budget, three quarters of the free HBM)")
@@ -91,6 +92,8 @@ def main():
     unit, H, L, n = pg["unit"], pg["H"], pg["L"], pg["n"]
     del pg
     torch.cuda.empty_cache()
+    if args.ftab_k >= 0:
+        capi.set_default_option(capi.OPT_FTAB_K, args.ftab_k)
     if args.layout != "auto":
         capi.set_default_option(capi.OPT_RANK_LAYOUT, {"slots": 1, "runs": 2}[args.layout])
     if args.hbm_reserve_gb > 0:
