@@ -392,6 +392,12 @@ int rbg_sample_reads_dev(const uint8_t *d_text, uint64_t unit, uint64_t H, uint6
  * to n; rank and phi are wave-cooperative predecessor searches (rle_string::rank rle_string.hpp:131-161 /
  * ToeholdSA::phi toehold_sa.hpp:56-72 keep their O(r) shape).  TREE_TOP_KB (1..96, default 48): LDS the staged top
  * level of that index may take per workgroup (0 = sixteen keys in all: the deepest possible index, for tests). */
+/* Environment switches (read at load or per call; none of them changes an answer -- they exist for A/B measurements
+ * and for the tests that pin both sides):  RBG_PHI_PACKED=0 keeps 32-byte phi slots at 8-byte positions;
+ * RBG_RANK_DIR=0 / RBG_PHI_DIR=0 build the run-indexed layout without its rank / phi directories (descent through
+ * the sampled levels only);  RBG_HOST_THREADS, RBG_HOST_CHUNK_READS, RBG_HOST_DIRECT_OUT=0, RBG_HOST_COMBINE=0,
+ * RBG_HOST_TRACE=1|2 tune / trace the host-pointer pipeline;  RBG_VERBOSE=1 prints what the budget
+ * rule did. */
 enum { RBG_OPT_BLOCK_THREADS = 1, RBG_OPT_RANK_BUCKET_SHIFT = 2, RBG_OPT_PHI_BUCKET_SHIFT = 3, RBG_OPT_POS_BYTES = 4,
        RBG_OPT_KMER_STEPS = 5, RBG_OPT_HBM_BUDGET_MB = 6, RBG_OPT_FTAB_K = 7, RBG_OPT_PACKED_READS = 8,
        RBG_OPT_DEEP_BUCKET_SHIFT = 9, RBG_OPT_DENSE_OVERFLOW = 10, RBG_OPT_RANK_LAYOUT = 11, RBG_OPT_TREE_TOP_KB = 12 };
