@@ -118,6 +118,23 @@ EXPORTS = [p[0] for p in _PROTOS]
 _lib = None
 
 
+def _one_hip_runtime():
+    """A process must run ONE HIP runtime.  PyTorch's ROCm wheels bundle their own copies of the ROCm libraries: when
+    torch is imported AFTER librbg.so has pulled in /opt/rocm's, its device initialisation fails ("No HIP GPUs are
+    available"); imported first, its runtime is the one librbg.so binds to as well (same sonames) -- the configuration
+    bench.py and the tests run.  So, when PyTorch is installed and not loaded yet, load it first (about a second;
+    RBG_NO_TORCH_PRELOAD=1 skips this for processes that never touch torch)."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("RBG_NO_TORCH_PRELOAD") == "1":
+        return
+    try:
+        if importlib.util.find_spec("torch") is not None:
+            import torch  # noqa: F401
+    except Exception:  # noqa: BLE001  (a broken torch install must not keep the library from loading)
+        pass
+
+
 def lib():
     """Load librbg.so.  Fails loudly if the HIP extension has not been built."""
     global _lib
@@ -125,6 +142,7 @@ def lib():
         if not os.path.exists(_SO):
             raise ImportError(f"{_SO} is missing: build it with `make -C rowbowt_amd/csrc` "
                               "(or __graft_entry__.build()); there is no CPU fallback")
+        _one_hip_runtime()
         L = C.CDLL(_SO)
         for name, res, args in _PROTOS:
             fn = getattr(L, name)
