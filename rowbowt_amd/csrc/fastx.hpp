@@ -125,11 +125,24 @@ class FastxReader {
     std::string qual_;
 };
 
-inline void put_u64(std::string &out, uint64_t v) {
-    char tmp[24];
-    int n = 0;
-    do { tmp[n++] = static_cast<char>('0' + v % 10); v /= 10; } while (v);
-    while (n) out.push_back(tmp[--n]);
+inline void put_u64(std::string &out, uint64_t v) {   // two digits per division, one append (the tools print a number or three per read)
+    static const char lut[] =
+        "0001020304050607080910111213141516171819202122232425262728293031323334353637383940414243444546474849"
+        "5051525354555657585960616263646566676869707172737475767778798081828384858687888990919293949596979899";
+    char tmp[20];
+    char *const e = tmp + 20;
+    char *q = e;
+    while (v >= 100) {
+        const uint64_t d = v / 100;
+        const unsigned r = static_cast<unsigned>(v - d * 100);
+        v = d;
+        q -= 2;
+        q[0] = lut[2 * r];
+        q[1] = lut[2 * r + 1];
+    }
+    if (v >= 10) { q -= 2; q[0] = lut[2 * v]; q[1] = lut[2 * v + 1]; }
+    else *--q = static_cast<char>('0' + v);
+    out.append(q, static_cast<size_t>(e - q));
 }
 
 }  // namespace rbg_cli

@@ -256,87 +256,161 @@ void query_shard(rbg_index *ix, const RbAlignArgs &args, const Window &b, uint64
     }
 }
 
+// Output text is produced through a raw pointer into the piece's string (grown in bulk, trimmed at the end) with a
+// two-digits-at-a-time number writer: the formatter, not the GPU, sets the pace of this tool (150 ns per read with
+// std::string::push_back per character; rb_align -s prints a number per location).
+struct FastOut {
+    std::string &s;
+    size_t len;
+    explicit FastOut(std::string &str) : s(str), len(str.size()) {}
+    char *room(size_t n) {
+        if (len + n > s.size()) s.resize(std::max(s.size() * 2, len + n + 65536));
+        return &s[len];
+    }
+    void finish() { s.resize(len); }
+};
+inline char *fmt_u64(char *p, uint64_t v) {
+    static const char lut[] =
+        "0001020304050607080910111213141516171819202122232425262728293031323334353637383940414243444546474849"
+        "5051525354555657585960616263646566676869707172737475767778798081828384858687888990919293949596979899";
+    char tmp[20];
+    char *const e = tmp + 20;
+    char *q = e;
+    while (v >= 100) {
+        const uint64_t d = v / 100;
+        const unsigned r = static_cast<unsigned>(v - d * 100);
+        v = d;
+        q -= 2;
+        std::memcpy(q, lut + 2 * r, 2);
+    }
+    if (v >= 10) { q -= 2; std::memcpy(q, lut + 2 * v, 2); }
+    else *--q = static_cast<char>('0' + v);
+    const size_t n = static_cast<size_t>(e - q);
+    std::memcpy(p, q, n);
+    return p + n;
+}
+inline char *fmt_lit(char *p, const char *lit, size_t n) { std::memcpy(p, lit, n); return p + n; }
+
 // the text of rb_report (rb_align.cpp:118-145) for reads [i0, i1)
 void format_range(const rbwt::RowBowt<> &rb, const RbAlignArgs &args, const Window &b, const BatchResult &r, size_t g0,
-                  size_t g1, std::string &out) {
-    out.reserve(out.size() + (g1 - g0) * 48);
+                  size_t g1, std::string &out_s) {
+    static const char kNoMarkers[] = "no markers (consider building the marker array with a larger window size)";
+    FastOut out(out_s);
     for (size_t gi = g0; gi < g1; ++gi) {   // gi: index in the window; i: index in the shard's results
         const size_t i = gi - r.begin;
-        out.append(b.base + b.recs.name_begin[gi], b.recs.name_len[gi]);
-        out += " (";
-        put_u64(out, r.lo[i]);
-        out.push_back(',');
-        put_u64(out, r.hi[i]);
-        out += "), count=";
-        put_u64(out, r.hi[i] - r.lo[i] + 1);  // unsigned wrap for the empty range, like the reference
-        out.push_back('\n');
+        const size_t nl = b.recs.name_len[gi];
+        char *p = out.room(nl + 96);
+        char *const p0 = p;
+        p = fmt_lit(p, b.base + b.recs.name_begin[gi], nl);
+        p = fmt_lit(p, " (", 2);
+        p = fmt_u64(p, r.lo[i]);
+        *p++ = ',';
+        p = fmt_u64(p, r.hi[i]);
+        p = fmt_lit(p, "), count=", 9);
+        p = fmt_u64(p, r.hi[i] - r.lo[i] + 1);  // unsigned wrap for the empty range, like the reference
+        *p++ = '\n';
+        out.len += static_cast<size_t>(p - p0);
         if (args.sam) {
-            out += "\tlocs: ";
+            p = out.room(16);
+            out.len += static_cast<size_t>(fmt_lit(p, "\tlocs: ", 7) - p);
             for (uint64_t t = r.loc_off[i]; t < r.loc_off[i + 1]; ++t) {
                 const char *name = nullptr;
                 uint64_t off = 0;
                 rbwt::detail::check(rbg_resolve_offset(rb.handle(), r.locs[t], &name, &off), "rbg_resolve_offset");
-                put_u64(out, r.locs[t]);
-                out.push_back('/');
-                out += name;
-                out.push_back(':');
-                put_u64(out, off);
-                out.push_back(' ');
+                const size_t dl = std::strlen(name);
+                p = out.room(dl + 48);
+                char *const q0 = p;
+                p = fmt_u64(p, r.locs[t]);
+                *p++ = '/';
+                p = fmt_lit(p, name, dl);
+                *p++ = ':';
+                p = fmt_u64(p, off);
+                *p++ = ' ';
+                out.len += static_cast<size_t>(p - q0);
             }
-            out.push_back('\n');
+            p = out.room(1);
+            *p = '\n';
+            out.len += 1;
         }
         if (args.markers) {
-            out += "\tmarkers: ";
-            if (r.mk_off[i + 1] == r.mk_off[i]) out += "no markers (consider building the marker array with a larger window size)";
+            const uint64_t nm = r.mk_off[i + 1] - r.mk_off[i];
+            p = out.room(16 + sizeof(kNoMarkers) + nm * 44);
+            char *const q0 = p;
+            p = fmt_lit(p, "\tmarkers: ", 10);
+            if (nm == 0) p = fmt_lit(p, kNoMarkers, sizeof(kNoMarkers) - 1);
             for (uint64_t t = r.mk_off[i]; t < r.mk_off[i + 1]; ++t) {
-                put_u64(out, get_pos(r.mk[t]));
-                out.push_back('/');
-                put_u64(out, get_allele(r.mk[t]));
-                out.push_back(' ');
+                p = fmt_u64(p, get_pos(r.mk[t]));
+                *p++ = '/';
+                p = fmt_u64(p, get_allele(r.mk[t]));
+                *p++ = ' ';
             }
-            out.push_back('\n');
+            *p++ = '\n';
+            out.len += static_cast<size_t>(p - q0);
         }
     }
+    out.finish();
 }
+
+// RB_ALIGN_TRACE=1: seconds the main loop spent in the library calls, in formatting, waiting for the scanner and for the writer
+double g_trace_query = 0, g_trace_format = 0, g_trace_scan_wait = 0, g_trace_write_wait = 0;
 
 // query + format one batch: the batch is sharded over the replicas (contiguous blocks), the shards are
 // queried concurrently, formatting is split over worker threads, pieces concatenated in read order
+// (`pieces` is a pool that keeps its strings -- and their pages -- from window to window: `used` counts the ones of this
+// window; fresh 12 MB strings per batch cost more in page faults than the formatting itself)
 void report_batch(const rbwt::RowBowt<> &rb, const std::vector<rbg_index *> &reps, const RbAlignArgs &args, const Window &b, size_t w0,
-                  size_t w1, std::vector<std::string> &pieces) {
+                  size_t w1, std::vector<std::string> &pieces, size_t &used) {
     const size_t N = w1 - w0;
     const int G = static_cast<int>(reps.size());
-    std::vector<BatchResult> res(G);
+    // (kept from batch to batch like the pieces: the lo / hi / k arrays of a 4 M-read batch are 100 MB of pages)
+    static std::vector<std::unique_ptr<BatchResult>> pool;
+    while (pool.size() < static_cast<size_t>(G)) pool.emplace_back(new BatchResult());
+    std::vector<BatchResult *> resp(G);
+    for (int g = 0; g < G; ++g) {
+        resp[g] = pool[g].get();
+        rbg_free_buffer(resp[g]->locs);
+        rbg_free_buffer(resp[g]->mk);
+        resp[g]->locs = resp[g]->mk = nullptr;
+    }
+#define res(g) (*resp[(g)])
+    const auto t_q0 = std::chrono::steady_clock::now();
     {
         std::vector<std::thread> th;
         auto work = [&](int g) {
             uint64_t s0 = 0, s1 = 0;
             (void)rbg_shard_bounds(N, g, G, &s0, &s1);
-            query_shard(reps[g], args, b, w0 + s0, w0 + s1, res[g]);
+            query_shard(reps[g], args, b, w0 + s0, w0 + s1, res(g));
         };
         for (int g = 1; g < G; ++g) th.emplace_back(work, g);
         work(0);
         for (auto &t : th) t.join();
     }
+    const auto t_q1 = std::chrono::steady_clock::now();
+    g_trace_query += std::chrono::duration<double>(t_q1 - t_q0).count();
     const size_t T = std::max<size_t>(1, std::min<size_t>({static_cast<size_t>(args.threads), (N + 4095) / 4096, size_t(64)}));
     // piece (g, t): reads of shard g, t-th slice
-    const size_t first_piece = pieces.size();
-    pieces.resize(first_piece + static_cast<size_t>(G) * T);
+    const size_t first_piece = used;
+    used += static_cast<size_t>(G) * T;
+    if (pieces.size() < used) pieces.resize(used);
+    for (size_t i = first_piece; i < used; ++i) pieces[i].clear();
     std::vector<std::thread> workers;
     for (int g = 0; g < G; ++g)
         for (size_t t = 0; t < T; ++t) {
-            const size_t n = res[g].end - res[g].begin;
-            const size_t a = res[g].begin + n * t / T, z = res[g].begin + n * (t + 1) / T;
+            const size_t n = res(g).end - res(g).begin;
+            const size_t a = res(g).begin + n * t / T, z = res(g).begin + n * (t + 1) / T;
             if (a == z) continue;
             std::string *dst = &pieces[first_piece + static_cast<size_t>(g) * T + t];
-            const BatchResult *r = &res[g];
+            const BatchResult *r = &res(g);
             if (g == 0 && t == 0) continue;  // done on this thread below
             workers.emplace_back([&rb, &args, &b, r, a, z, dst] { format_range(rb, args, b, *r, a, z, *dst); });
         }
     {
-        const size_t n = res[0].end - res[0].begin;
-        format_range(rb, args, b, res[0], res[0].begin, res[0].begin + n / T, pieces[first_piece]);
+        const size_t n = res(0).end - res(0).begin;
+        format_range(rb, args, b, res(0), res(0).begin, res(0).begin + n / T, pieces[first_piece]);
     }
     for (auto &w : workers) w.join();
+    g_trace_format += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_q1).count();
+#undef res
 }
 
 }  // namespace
@@ -385,20 +459,30 @@ int main(int argc, char **argv) {
     err = input.next(cur);
     std::future<void> writer;
     std::vector<std::string> pieces, writing;
+    size_t used = 0, writing_used = 0;
     while (true) {
         std::future<int> scanner;
         const bool more = err == 0;
         if (more) scanner = std::async(std::launch::async, [&input, &nxt] { return input.next(nxt); });
-        pieces.clear();
+        used = 0;
         for (size_t w0 = 0; w0 < cur.size(); w0 += args.batch)
-            report_batch(rb, reps, args, cur, w0, std::min<size_t>(cur.size(), w0 + args.batch), pieces);
-        if (writer.valid()) writer.get();
+            report_batch(rb, reps, args, cur, w0, std::min<size_t>(cur.size(), w0 + args.batch), pieces, used);
+        {
+            const auto tw0 = std::chrono::steady_clock::now();
+            if (writer.valid()) writer.get();
+            g_trace_write_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw0).count();
+        }
         writing.swap(pieces);
-        writer = std::async(std::launch::async, [&writing] {
-            for (const std::string &p : writing) fwrite(p.data(), 1, p.size(), stdout);
+        writing_used = used;
+        writer = std::async(std::launch::async, [&writing, &writing_used] {
+            for (size_t i = 0; i < writing_used; ++i) fwrite(writing[i].data(), 1, writing[i].size(), stdout);
         });
         if (!more) break;
-        err = scanner.get();
+        {
+            const auto ts0 = std::chrono::steady_clock::now();
+            err = scanner.get();
+            g_trace_scan_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - ts0).count();
+        }
         std::swap(cur, nxt);
     }
     if (writer.valid()) writer.get();
@@ -417,6 +501,9 @@ int main(int argc, char **argv) {
         default:
             break;
     }
+    if (std::getenv("RB_ALIGN_TRACE"))
+        fprintf(stderr, "rb_align loop: library calls %.3f s, formatting %.3f s, waiting for the scanner %.3f s, for the writer %.3f s\n", g_trace_query,
+                g_trace_format, g_trace_scan_wait, g_trace_write_wait);
     std::cerr << index_load_time.count() << " " << total_query_time.count() << std::endl;  // rb_align.cpp:192
     return 0;
 }
