@@ -31,6 +31,7 @@
 #include "../include/rowbowt_gpu.hpp"
 #include "fastx.hpp"
 #include "fastx_index.hpp"
+#include "cli_input.hpp"
 #include "rbg_thread_team.hpp"
 
 namespace {
@@ -38,107 +39,8 @@ namespace {
 using rbg_cli::put_u64;
 using rbg_cli::RecordSpans;
 
-// One stretch of the input with the records found in it.  The bytes stay where they are: in the mapping of a plain
-// file, or in `own` (decompressed / piped input); names and sequences are offsets from `base`.
-struct Window {
-    const char *base = nullptr;
-    std::vector<char> own;
-    RecordSpans recs;
-    size_t size() const { return recs.size(); }
-};
-
-// The input as a sequence of windows that each begin at a record boundary (fastx_index.hpp does the scanning).
-class InputSource {
-   public:
-    ~InputSource() {
-        if (map_) munmap(const_cast<char *>(map_), map_size_);
-        if (gz_) gzclose(gz_);
-    }
-    bool open(const std::string &path, unsigned threads, uint64_t window_bytes) {
-        threads_ = threads ? threads : 1;
-        window_ = window_bytes;
-        const int fd = ::open(path.c_str(), O_RDONLY);
-        if (fd < 0) return false;
-        struct stat sb;
-        unsigned char magic[2] = {0, 0};
-        const bool regular = fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode);
-        if (regular && sb.st_size >= 2 && pread(fd, magic, 2, 0) != 2) magic[0] = magic[1] = 0;
-        if (regular && !(magic[0] == 0x1f && magic[1] == 0x8b)) {   // a plain file: map it, scan it in place
-            map_size_ = static_cast<size_t>(sb.st_size);
-            if (map_size_) {
-                void *m = mmap(nullptr, map_size_, PROT_READ, MAP_PRIVATE, fd, 0);
-                if (m == MAP_FAILED) { ::close(fd); return false; }
-                (void)madvise(m, map_size_, MADV_SEQUENTIAL);
-                map_ = static_cast<const char *>(m);
-            }
-            mapped_ = true;
-            ::close(fd);
-            return true;
-        }
-        ::close(fd);
-        gz_ = gzopen(path.c_str(), "r");   // gzip, or anything that is not a regular file (zlib reads plain data through)
-        if (!gz_) return false;
-        gzbuffer(gz_, 1 << 20);
-        return true;
-    }
-    // the next window; returns 0 while more input follows, -1 at its end, -2 / -3 like kseq_read (the window then
-    // holds the records that came before the failure)
-    int next(Window &w) {
-        w.recs.clear();
-        w.own.clear();
-        uint64_t win = window_;
-        while (true) {
-            uint64_t resume = 0;
-            rbg_cli::ScanState rstate;
-            int rc;
-            bool final;
-            if (mapped_) {
-                const uint64_t end = std::min<uint64_t>(map_size_, pos_ + win);
-                final = end == map_size_;
-                w.base = map_ ? map_ : "";
-                rc = rbg_cli::scan_records_parallel(w.base, pos_, end, final, st_, w.recs, &resume, &rstate, threads_);
-                if (rc == rbg_cli::kScanTruncQual) return -2;
-                if (!(rc == rbg_cli::kScanEnd && final) && resume == pos_ && w.recs.size() == 0 && !final) { win *= 2; continue; }   // one record longer than the window
-                pos_ = resume;
-                st_ = rstate;
-            } else {
-                // carry-over of the previous window's unfinished record, then fresh bytes
-                w.own.assign(carry_.begin(), carry_.end());
-                const size_t have = w.own.size();
-                w.own.resize(have + win);
-                size_t got = 0;
-                bool eof = false;
-                while (got < win) {
-                    const int r = gzread(gz_, w.own.data() + have + got, static_cast<unsigned>(std::min<uint64_t>(win - got, 1u << 30)));
-                    if (r < 0) { stream_error_ = true; eof = true; break; }
-                    if (r == 0) { eof = true; break; }
-                    got += static_cast<size_t>(r);
-                }
-                w.own.resize(have + got);
-                final = eof;
-                w.base = w.own.data();
-                rc = rbg_cli::scan_records_parallel(w.base, 0, w.own.size(), final, st_, w.recs, &resume, &rstate, threads_);
-                if (rc == rbg_cli::kScanTruncQual) return stream_error_ ? -3 : -2;
-                carry_.assign(w.own.begin() + static_cast<std::ptrdiff_t>(resume), w.own.end());
-                st_ = rstate;
-                if (!final && w.recs.size() == 0) { win *= 2; continue; }
-            }
-            if (final) return stream_error_ ? -3 : -1;
-            return 0;
-        }
-    }
-
-   private:
-    const char *map_ = nullptr;
-    size_t map_size_ = 0;
-    bool mapped_ = false;
-    gzFile gz_ = nullptr;
-    uint64_t pos_ = 0, window_ = uint64_t(256) << 20;
-    unsigned threads_ = 1;
-    rbg_cli::ScanState st_;
-    std::vector<char> carry_;
-    bool stream_error_ = false;
-};
+using rbg_cli::InputSource;
+using rbg_cli::Window;
 
 struct RbAlignArgs {  // rb_align.cpp:17-24
     std::string inpre, fastq_fname, outpre;
@@ -256,40 +158,9 @@ void query_shard(rbg_index *ix, const RbAlignArgs &args, const Window &b, uint64
     }
 }
 
-// Output text is produced through a raw pointer into the piece's string (grown in bulk, trimmed at the end) with a
-// two-digits-at-a-time number writer: the formatter, not the GPU, sets the pace of this tool (150 ns per read with
-// std::string::push_back per character; rb_align -s prints a number per location).
-struct FastOut {
-    std::string &s;
-    size_t len;
-    explicit FastOut(std::string &str) : s(str), len(str.size()) {}
-    char *room(size_t n) {
-        if (len + n > s.size()) s.resize(std::max(s.size() * 2, len + n + 65536));
-        return &s[len];
-    }
-    void finish() { s.resize(len); }
-};
-inline char *fmt_u64(char *p, uint64_t v) {
-    static const char lut[] =
-        "0001020304050607080910111213141516171819202122232425262728293031323334353637383940414243444546474849"
-        "5051525354555657585960616263646566676869707172737475767778798081828384858687888990919293949596979899";
-    char tmp[20];
-    char *const e = tmp + 20;
-    char *q = e;
-    while (v >= 100) {
-        const uint64_t d = v / 100;
-        const unsigned r = static_cast<unsigned>(v - d * 100);
-        v = d;
-        q -= 2;
-        std::memcpy(q, lut + 2 * r, 2);
-    }
-    if (v >= 10) { q -= 2; std::memcpy(q, lut + 2 * v, 2); }
-    else *--q = static_cast<char>('0' + v);
-    const size_t n = static_cast<size_t>(e - q);
-    std::memcpy(p, q, n);
-    return p + n;
-}
-inline char *fmt_lit(char *p, const char *lit, size_t n) { std::memcpy(p, lit, n); return p + n; }
+using rbg_cli::FastOut;
+using rbg_cli::fmt_lit;
+using rbg_cli::fmt_u64;
 
 // the text of rb_report (rb_align.cpp:118-145) for reads [i0, i1)
 void format_range(const rbwt::RowBowt<> &rb, const RbAlignArgs &args, const Window &b, const BatchResult &r, size_t g0,

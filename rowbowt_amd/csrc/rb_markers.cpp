@@ -32,11 +32,25 @@
 
 #include "../include/rowbowt_gpu.hpp"
 #include "fastx.hpp"
+#include "cli_input.hpp"
+#include "rbg_thread_team.hpp"
 
 namespace {
 
 using rbg_cli::FastxReader;
-using rbg_cli::PackedBatch;
+using rbg_cli::InputSource;
+using rbg_cli::Window;
+
+// reads [w0, w0 + n) of a window, where the scanner found them (names and sequences are spans of the window's buffer)
+struct BatchView {
+    const Window *w;
+    size_t w0, n;
+    size_t size() const { return n; }
+    const char *name(size_t i) const { return w->base + w->recs.name_begin[w0 + i]; }
+    size_t name_len(size_t i) const { return w->recs.name_len[w0 + i]; }
+    const char *seq(size_t i) const { return w->base + w->recs.seq_begin[w0 + i]; }
+    uint64_t seq_len(size_t i) const { return w->recs.seq_len[w0 + i]; }
+};
 using rbg_cli::put_u64;
 
 struct RbMarkersArgs {  // rb_markers.cpp:22-40
@@ -190,27 +204,32 @@ struct MarkerSeed {  // rb_markers.cpp:245-285
     }
 };
 
-void print_seed(std::string &out, const char *name, size_t name_len, const MarkerSeed &ms) {  // print_buf, :253-262
-    out.append(name, name_len);
-    out.push_back(' ');
-    put_u64(out, ms.range_size);
-    out += ms.strand == Strand::FWD ? " + " : " - ";
-    put_u64(out, ms.query_start);
-    out.push_back(' ');
-    put_u64(out, ms.query_len);
+void print_seed(rbg_cli::FastOut &out, const char *name, size_t name_len, const MarkerSeed &ms) {  // print_buf, :253-262
+    using rbg_cli::fmt_lit;
+    using rbg_cli::fmt_u64;
+    char *p = out.room(name_len + 80 + ms.markers.size() * 48);
+    char *const p0 = p;
+    p = fmt_lit(p, name, name_len);
+    *p++ = ' ';
+    p = fmt_u64(p, ms.range_size);
+    p = fmt_lit(p, ms.strand == Strand::FWD ? " + " : " - ", 3);
+    p = fmt_u64(p, ms.query_start);
+    *p++ = ' ';
+    p = fmt_u64(p, ms.query_len);
     if (!ms.markers.empty()) {
         for (const MarkerT m : ms.markers) {
-            out.push_back(' ');
-            put_u64(out, get_seq(m));
-            out.push_back('/');
-            put_u64(out, get_pos(m));
-            out.push_back('/');
-            put_u64(out, get_allele(m));
+            *p++ = ' ';
+            p = fmt_u64(p, get_seq(m));
+            *p++ = '/';
+            p = fmt_u64(p, get_pos(m));
+            *p++ = '/';
+            p = fmt_u64(p, get_allele(m));
         }
     } else {
-        out += " .";
+        p = fmt_lit(p, " .", 2);
     }
-    out.push_back('\n');
+    *p++ = '\n';
+    out.len += static_cast<size_t>(p - p0);
 }
 
 struct BatchSeeds {
@@ -221,8 +240,9 @@ struct BatchSeeds {
 };
 
 // the reference's out_fn (rb_markers.cpp:365-382 / :439-464) for one callback record
-MarkerSeed make_seed(const RbMarkersArgs &args, const BatchSeeds &r, const rbg_marker_seed_t &s, Strand strand, uint64_t seq_len) {
-    MarkerSeed ms;
+// (fills `ms` in place: its marker vector keeps its capacity from seed to seed -- nine seeds per read, no allocation)
+void make_seed(const RbMarkersArgs &args, const BatchSeeds &r, const rbg_marker_seed_t &s, Strand strand, uint64_t seq_len, MarkerSeed &ms) {
+    ms.markers.clear();
     ms.strand = strand;
     ms.range_size = s.hi - s.lo + 1;
     ms.query_start = strand == Strand::REV ? seq_len - s.qstart - 1 : s.qstart;
@@ -232,29 +252,33 @@ MarkerSeed make_seed(const RbMarkersArgs &args, const BatchSeeds &r, const rbg_m
         std::sort(ms.markers.begin(), ms.markers.end(), marker_cmp);
         ms.markers.erase(std::unique(ms.markers.begin(), ms.markers.end()), ms.markers.end());
     }
-    return ms;
 }
 
 // text for reads [i0, i1); first_fwd[i] is the heuristic worker's coin for read i
-void format_range(const RbMarkersArgs &args, const PackedBatch &b, const BatchSeeds &r, const std::vector<uint8_t> &first_fwd,
-                  size_t i0, size_t i1, std::string &out) {
+void format_range(const RbMarkersArgs &args, const BatchView &b, const BatchSeeds &r, const std::vector<uint8_t> &first_fwd,
+                  size_t i0, size_t i1, std::string &out_s) {
+    rbg_cli::FastOut out(out_s);
     std::vector<MarkerSeed> seeds;
+    MarkerSeed one;   // the default mode prints a seed as soon as it is made
     for (size_t i = i0; i < i1; ++i) {
-        const char *name = b.names.data() + b.name_off[i];
-        const size_t name_len = b.name_off[i + 1] - b.name_off[i];
-        const uint64_t seq_len = b.off[i + 1] - b.off[i];
+        const char *name = b.name(i);
+        const size_t name_len = b.name_len(i);
+        const uint64_t seq_len = b.seq_len(i);
         seeds.clear();
         if (!args.heuristic) {  // worker, rb_markers.cpp:357-428: forward, then reverse complement
             for (int st = 0; st < 2; ++st)
-                for (uint64_t s = r.seed_off[2 * i + st]; s < r.seed_off[2 * i + st + 1]; ++s)
-                    seeds.push_back(make_seed(args, r, r.seeds[s], st ? Strand::REV : Strand::FWD, seq_len));
+                for (uint64_t s = r.seed_off[2 * i + st]; s < r.seed_off[2 * i + st + 1]; ++s) {
+                    make_seed(args, r, r.seeds[s], st ? Strand::REV : Strand::FWD, seq_len, one);
+                    print_seed(out, name, name_len, one);
+                }
         } else {  // worker_heuristic, rb_markers.cpp:429-519
             bool stop = false;
             for (int pass = 0; pass < 2 && !stop; ++pass) {
                 const bool fwd = (pass == 0) == (first_fwd[i] != 0);
                 const int st = fwd ? 0 : 1;
                 for (uint64_t s = r.seed_off[2 * i + st]; s < r.seed_off[2 * i + st + 1]; ++s) {
-                    MarkerSeed ms = make_seed(args, r, r.seeds[s], fwd ? Strand::FWD : Strand::REV, seq_len);
+                    MarkerSeed ms;
+                    make_seed(args, r, r.seeds[s], fwd ? Strand::FWD : Strand::REV, seq_len, ms);
                     if (ms.query_len < args.min_seed_len) {  // :447 (before any marker work; same result)
                         continue;
                     }
@@ -278,22 +302,35 @@ void format_range(const RbMarkersArgs &args, const PackedBatch &b, const BatchSe
         }
         for (const MarkerSeed &ms : seeds) print_seed(out, name, name_len, ms);
     }
+    out.finish();
 }
 
-// forward (through the nt table) and reverse-complement copies of every read, interleaved
-void make_strands(const PackedBatch &b, std::string &seqs, std::vector<uint64_t> &off) {
+// forward (through the nt table) and reverse-complement copies of every read, interleaved; the reads are split
+// over `threads` workers once their offsets are known
+void make_strands(const BatchView &b, std::string &seqs, std::vector<uint64_t> &off, size_t threads) {
     const size_t N = b.size();
-    seqs.resize(2 * b.seqs.size());
     off.resize(2 * N + 1);
     off[0] = 0;
     for (size_t i = 0; i < N; ++i) {
-        const size_t beg = b.off[i], len = b.off[i + 1] - beg;
-        char *f = &seqs[2 * beg], *rc = f + len;
-        for (size_t t = 0; t < len; ++t) f[t] = static_cast<char>(kNt.t[static_cast<uint8_t>(b.seqs[beg + t])]);
-        for (size_t t = 0; t < len; ++t) rc[t] = comp(f[len - 1 - t]);  // revc_in_place, rb_markers.cpp:189-198
-        off[2 * i + 1] = 2 * beg + len;
-        off[2 * i + 2] = 2 * beg + 2 * len;
+        const uint64_t len = b.seq_len(i);
+        off[2 * i + 1] = off[2 * i] + len;
+        off[2 * i + 2] = off[2 * i] + 2 * len;
     }
+    seqs.resize(off[2 * N]);
+    const size_t T = std::max<size_t>(1, std::min<size_t>(threads, (N + 16383) / 16384));
+    auto work = [&](size_t t) {
+        for (size_t i = N * t / T; i < N * (t + 1) / T; ++i) {
+            const char *src = b.seq(i);
+            const size_t len = b.seq_len(i);
+            char *f = &seqs[off[2 * i]], *rc = f + len;
+            for (size_t u = 0; u < len; ++u) f[u] = static_cast<char>(kNt.t[static_cast<uint8_t>(src[u])]);
+            for (size_t u = 0; u < len; ++u) rc[u] = comp(f[len - 1 - u]);  // revc_in_place, rb_markers.cpp:189-198
+        }
+    };
+    std::vector<std::thread> th;
+    for (size_t t = 1; t < T; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto &x : th) x.join();
 }
 
 // std::mt19937 with its default seed, one bit per read, low bit first (RandomBoolGenerator, :210-225)
@@ -313,34 +350,44 @@ struct RandomBoolGenerator {
     int bit_count = 0;
 };
 
-void report_batch(const rbwt::RowBowt<> &rb, const RbMarkersArgs &args, const PackedBatch &b, RandomBoolGenerator &booler,
+double g_trace[3] = {0, 0, 0};   // RB_ALIGN_TRACE=1: seconds building the strands, in the library call, sorting + formatting
+
+void report_batch(const rbwt::RowBowt<> &rb, const RbMarkersArgs &args, const BatchView &b, RandomBoolGenerator &booler,
                   std::vector<std::string> &pieces) {
     const size_t N = b.size();
     const uint64_t ft_k = rb.ftab_k();
     if (ft_k)
         for (size_t i = 0; i < N; ++i)
-            if (b.off[i + 1] - b.off[i] < ft_k) {  // the reference dies in std::string::substr (rowbowt.hpp:431)
+            if (b.seq_len(i) < ft_k) {  // the reference dies in std::string::substr (rowbowt.hpp:431)
                 fprintf(stderr, "ERROR: read shorter than the ftab k-mer size (%llu)\n", static_cast<unsigned long long>(ft_k));
                 exit(1);
             }
     std::string seqs;
     std::vector<uint64_t> off;
-    make_strands(b, seqs, off);
+    const auto t0 = std::chrono::steady_clock::now();
+    make_strands(b, seqs, off, static_cast<size_t>(args.threads));
+    const auto t1 = std::chrono::steady_clock::now();
     BatchSeeds r;
     r.seed_off.resize(2 * N + 1);
     rbwt::detail::check(rbg_get_markers_greedy_seeding(rb.handle(), reinterpret_cast<const uint8_t *>(seqs.data()), off.data(), 2 * N,
                                                        args.wsize, args.max_range, ft_k, r.seed_off.data(), &r.seeds, &r.mk),
                         "rbg_get_markers_greedy_seeding");
+    const auto t2 = std::chrono::steady_clock::now();
     std::vector<uint8_t> first_fwd(N, 1);
     if (args.heuristic)
         for (size_t i = 0; i < N; ++i) first_fwd[i] = booler.get_bool() ? 1 : 0;  // :483
     const size_t T = std::max<size_t>(1, std::min<size_t>({static_cast<size_t>(args.threads), (N + 4095) / 4096, size_t(64)}));
-    pieces.assign(T, std::string());
+    const size_t first_piece = pieces.size();
+    pieces.resize(first_piece + T);
     std::vector<std::thread> workers;
     for (size_t t = 1; t < T; ++t)
-        workers.emplace_back([&, t] { format_range(args, b, r, first_fwd, N * t / T, N * (t + 1) / T, pieces[t]); });
-    format_range(args, b, r, first_fwd, 0, N / T, pieces[0]);
+        workers.emplace_back([&, t] { format_range(args, b, r, first_fwd, N * t / T, N * (t + 1) / T, pieces[first_piece + t]); });
+    format_range(args, b, r, first_fwd, 0, N / T, pieces[first_piece]);
     for (auto &w : workers) w.join();
+    const auto t3 = std::chrono::steady_clock::now();
+    g_trace[0] += std::chrono::duration<double>(t1 - t0).count();
+    g_trace[1] += std::chrono::duration<double>(t2 - t1).count();
+    g_trace[2] += std::chrono::duration<double>(t3 - t2).count();
 }
 
 }  // namespace
@@ -361,43 +408,38 @@ int main(int argc, char **argv) {
     std::cerr << "loading rowbowt + markers took: " << diff.count() << " seconds\n";
 
     start = std::chrono::high_resolution_clock::now();
-    gzFile fq_fp = gzopen(args.fastq_fname.data(), "r");  // :568-572
-    if (fq_fp == NULL) {
+    InputSource input;  // :568-572 (the file is scanned in place, window by window: cli_input.hpp)
+    if (!input.open(args.fastq_fname, static_cast<unsigned>(std::max<uint64_t>(1, args.threads)), uint64_t(256) << 20)) {
         fprintf(stderr, "invalid file\n");
         exit(1);
     }
-    gzbuffer(fq_fp, 1 << 20);
-    FastxReader reader(fq_fp);
     RandomBoolGenerator booler;
+    // three overlapped stages: scan window i+1 | query + format window i (in batches of --batch reads) | write window i-1
     int err = 0;
-    auto parse = [&](PackedBatch &b) {
-        b.clear();
-        int e = 0;
-        while (b.size() < args.batch && (e = reader.next(b)) == 0) {}
-        return e;
-    };
-    PackedBatch cur, nxt;
-    err = parse(cur);
+    Window cur, nxt;
+    err = input.next(cur);
     std::future<void> writer;
     std::vector<std::string> pieces, writing;
-    while (cur.size() > 0) {
-        std::future<int> parser;
+    while (true) {
+        std::future<int> scanner;
         const bool more = err == 0;
-        if (more) parser = std::async(std::launch::async, parse, std::ref(nxt));
-        report_batch(rb, args, cur, booler, pieces);
+        if (more) scanner = std::async(std::launch::async, [&input, &nxt] { return input.next(nxt); });
+        pieces.clear();
+        for (size_t w0 = 0; w0 < cur.size(); w0 += args.batch) {
+            const BatchView view{&cur, w0, std::min<size_t>(cur.size() - w0, args.batch)};
+            report_batch(rb, args, view, booler, pieces);
+        }
         if (writer.valid()) writer.get();
         writing.swap(pieces);
         writer = std::async(std::launch::async, [&writing] {
             for (const std::string &p : writing) fwrite(p.data(), 1, p.size(), stdout);
         });
         if (!more) break;
-        err = parser.get();
-        cur.clear();
+        err = scanner.get();
         std::swap(cur, nxt);
     }
     if (writer.valid()) writer.get();
     fflush(stdout);
-    gzclose(fq_fp);
     switch (err) {  // rb_markers.cpp:581-590
         case -2: fprintf(stderr, "ERROR: truncated quality string\n"); exit(1);
         case -3: fprintf(stderr, "ERROR: error reading stream\n"); exit(1);
@@ -405,6 +447,8 @@ int main(int argc, char **argv) {
     }
     stop = std::chrono::high_resolution_clock::now();
     diff = stop - start;
+    if (std::getenv("RB_ALIGN_TRACE"))
+        fprintf(stderr, "rb_markers loop: strands %.3f s, library call %.3f s, seeds -> text %.3f s\n", g_trace[0], g_trace[1], g_trace[2]);
     std::cerr << "counting markers took: " << diff.count() << " seconds" << std::endl;
     return 0;
 }
