@@ -478,8 +478,6 @@ __global__ __launch_bounds__(512, sizeof(P) == 4 ? 4 : 3) void k_find_range_runs
                 }
             }
             while (__ballot(direct && (z0 > static_cast<uint32_t>(kFan) || z1 > static_cast<uint32_t>(kFan)))) {
-                const bool same = s1 == s0 && z1 == z0;     // both positions in one bucket: narrowed separately from here on
-                (void)same;
                 coop_narrow<P>(s_tree, d, direct && z0 > static_cast<uint32_t>(kFan), s0, z0, static_cast<P>(q0));
                 coop_narrow<P>(s_tree, d, direct && z1 > static_cast<uint32_t>(kFan), s1, z1, static_cast<P>(q1));
             }

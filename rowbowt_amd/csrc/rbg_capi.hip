@@ -1040,26 +1040,15 @@ struct PinnedStage {
     }
 };
 
-// shared tail of the ragged-output host calls: d_off[N+1] is planned on the device; size, fill, copy back
-template <typename FillFn>
-int ragged_finish(uint64_t N, DevBuf &d_off, uint64_t *h_off, uint64_t **h_vals, hipStream_t st, FillFn fill) {
-    HIP_TRY(hipMemcpyAsync(h_off, d_off.p, (N + 1) * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    const uint64_t total = h_off[N];
-    *h_vals = static_cast<uint64_t *>(alloc_result(total * 8));
-    if (!*h_vals) return RBG_ENOMEM;
-    if (total == 0) return RBG_OK;
-    DevBuf d_vals;
-    int rc = d_vals.alloc(total * 8);
-    if (!rc) rc = fill(d_vals.as<uint64_t>());
-    // Big results leave through pinned staging: a device-to-host copy straight into fresh pageable memory is the first
-    // touch of its pages, and for gigabytes of locations the page faults (and the driver's own staging) cost more than
-    // the transfer (tools/d2h_probe.hip: 3 GB in 0.2 s; 0.06 s for the DMA alone).  Chunks of 64 MB are copied into four
-    // pinned buffers, two copies ahead, and a team of worker threads moves each finished chunk to its place -- which is
-    // where the pages get touched, by sixteen threads at once and alongside the next chunks' DMA.
-    const size_t bytes = total * 8;
-    bool done = false;
-    if (!rc && bytes >= (size_t(64) << 20)) {
+// Device-to-host copy of a (possibly huge) result into memory that may never have been touched.  Big results leave
+// through pinned staging: a copy straight into fresh pageable memory is the first touch of its pages, and for gigabytes
+// of locations the page faults (and the driver's own staging) cost more than the transfer (tools/d2h_probe.hip: 3 GB in
+// 0.2 s; 0.06 s for the DMA alone).  Chunks of 64 MB are copied into four pinned buffers, two copies ahead, and a team
+// of worker threads moves each finished chunk to its place -- which is where the pages get touched, by sixteen threads
+// at once and alongside the next chunks' DMA.  Blocks until the data has arrived.
+int d2h_result(void *h_dst, const void *d_src, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return RBG_OK;
+    if (bytes >= (size_t(64) << 20)) {
         PinnedStage &ps = PinnedStage::get();
         std::unique_lock<std::mutex> lk(ps.mu, std::try_to_lock);   // (one big result at a time goes this way; a second caller takes the plain copy)
         if (lk.owns_lock() && ps.ensure()) {
@@ -1067,8 +1056,8 @@ int ragged_finish(uint64_t N, DevBuf &d_off, uint64_t *h_off, uint64_t **h_vals,
             const size_t nb = (bytes + chunk - 1) / chunk;
             const unsigned T = std::max(1u, std::min(16u, rbg_hostpath::cpu_budget()));
             rbg_hostpath::ThreadTeam team(T);
-            char *dst = reinterpret_cast<char *>(*h_vals);
-            const char *src = static_cast<const char *>(d_vals.p);
+            char *dst = static_cast<char *>(h_dst);
+            const char *src = static_cast<const char *>(d_src);
             hipError_t e = hipSuccess;
             hipEvent_t ev[PinnedStage::kBufs] = {nullptr, nullptr, nullptr, nullptr};   // (per call: events belong to the current device)
             for (hipEvent_t &x : ev)
@@ -1092,17 +1081,31 @@ int ragged_finish(uint64_t N, DevBuf &d_off, uint64_t *h_off, uint64_t **h_vals,
                 };
                 team.run(mv);
             }
+            int rc = RBG_OK;
             if (e != hipSuccess) { (void)hipStreamSynchronize(st); (void)hipGetLastError(); rc = RBG_ENODEV; }
             for (hipEvent_t x : ev)
                 if (x) (void)hipEventDestroy(x);
-            done = true;
+            return rc;
         }
     }
-    if (!rc && !done) {
-        hipError_t e = hipMemcpyAsync(*h_vals, d_vals.p, total * 8, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-        if (e != hipSuccess) rc = RBG_ENODEV;
-    }
+    hipError_t e = hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    return e == hipSuccess ? RBG_OK : RBG_ENODEV;
+}
+
+// shared tail of the ragged-output host calls: d_off[N+1] is planned on the device; size, fill, copy back
+template <typename FillFn>
+int ragged_finish(uint64_t N, DevBuf &d_off, uint64_t *h_off, uint64_t **h_vals, hipStream_t st, FillFn fill) {
+    HIP_TRY(hipMemcpyAsync(h_off, d_off.p, (N + 1) * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const uint64_t total = h_off[N];
+    *h_vals = static_cast<uint64_t *>(alloc_result(total * 8));
+    if (!*h_vals) return RBG_ENOMEM;
+    if (total == 0) return RBG_OK;
+    DevBuf d_vals;
+    int rc = d_vals.alloc(total * 8);
+    if (!rc) rc = fill(d_vals.as<uint64_t>());
+    if (!rc) rc = d2h_result(*h_vals, d_vals.p, total * 8, st);
     if (rc) { std::free(*h_vals); *h_vals = nullptr; }
     return rc;
 }
@@ -2512,11 +2515,8 @@ static int marker_seeds_host(rbg_index *ix, const uint8_t *seqs, const uint64_t 
             if (launch_marker_seeds_fill(ix->dev, ix->cfg, rb.seqs.as<uint8_t>(), rb.off.as<uint64_t>(), N, wsize, max_range, ftab_k,
                                          dsoff.as<uint64_t>(), dmoff.as<uint64_t>(), dseeds.as<uint64_t>(), dmk.as<uint64_t>(), st))
                 rc = RBG_ENODEV;
-            hipError_t e = hipSuccess;
-            if (!rc) e = hipMemcpyAsync(h_seeds, dseeds.p, total_seeds * sizeof(rbg_marker_seed_t), hipMemcpyDeviceToHost, st);
-            if (!rc && e == hipSuccess && total_mk) e = hipMemcpyAsync(h_mk, dmk.p, total_mk * 8, hipMemcpyDeviceToHost, st);
-            if (!rc && e == hipSuccess) e = hipStreamSynchronize(st);
-            if (e != hipSuccess) rc = RBG_ENODEV;
+            if (!rc) rc = d2h_result(h_seeds, dseeds.p, total_seeds * sizeof(rbg_marker_seed_t), st);
+            if (!rc && total_mk) rc = d2h_result(h_mk, dmk.p, total_mk * 8, st);
         }
     }
     if (rc) { std::free(h_seeds); std::free(h_mk); return rc; }
