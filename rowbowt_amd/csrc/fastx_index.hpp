@@ -89,7 +89,8 @@ inline int scan_records(const char *buf, uint64_t pos, uint64_t end, bool final,
                 return kScanEnd;
             }
             ++pos;
-        } else if (rec_at - 1 >= limit) {   // the header character (already consumed, at rec_at - 1) opens the next segment
+        } else if (rec_at > limit) {   // the header character (already consumed, at rec_at - 1) opens the next segment;
+                                       // rec_at == 0: a carried-over buffer that begins after it (cli_input.hpp, zlib path)
             *resume = rec_at;
             *resume_state = st;
             return kScanEnd;

@@ -123,6 +123,40 @@ def scan(tmp_path_factory):
 GEOMETRIES = [(1 << 20, 1, 1 << 20), (7, 1, 1), (64, 3, 1), (1000, 4, 16), (1 << 20, 8, 1), (333, 2, 100)]
 
 
+@pytest.fixture(scope="module")
+def cli_input(tmp_path_factory):
+    """the tools' InputSource itself (cli_input.hpp): mapped plain files and the zlib path, windows of any size"""
+    exe = tmp_path_factory.mktemp("cin") / "cli_input_dump"
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-pthread",
+                           os.path.join(ROOT, "tests", "cpp", "cli_input_dump.cpp"), "-o", str(exe), "-lz"])
+
+    def run(path, window, threads):
+        p = subprocess.run([str(exe), str(path), str(window), str(threads)], capture_output=True, timeout=120)
+        assert p.returncode == 0, (p.stdout[-300:], p.stderr[-600:])
+        lines = p.stdout.split(b"\n")
+        assert lines[-1] == b"" and lines[-2].startswith(b"rc="), lines[-3:]
+        return [tuple(l.split(b"\t", 1)) for l in lines[:-2]], int(lines[-2][3:])
+    return run
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_input_source_plain_and_gzip_match_kseq_model(cli_input, tmp_path, name):
+    """what rb_align / rb_markers read: the same records and end code as kseq_read, from the mapped file and through
+    zlib, whatever the window size (records longer than a window, windows of a few bytes, carry-over between them)"""
+    import gzip
+    data = CASES[name]
+    want, want_rc = kseq_model(data)
+    plain = tmp_path / (name + ".fx")
+    plain.write_bytes(data)
+    gz = tmp_path / (name + ".fx.gz")
+    with gzip.open(gz, "wb") as f:
+        f.write(data)
+    for path in (plain, gz):
+        for window, threads in ((1 << 20, 1), (5, 1), (64, 3), (1000, 4)):
+            got, rc = cli_input(path, window, threads)
+            assert (got, rc) == ([(n, s) for n, s in want], want_rc), (name, path.name, window, threads)
+
+
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_scanner_matches_kseq_model(scan, tmp_path, name):
     data = CASES[name]
