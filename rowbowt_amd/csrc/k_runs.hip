@@ -27,6 +27,30 @@ __device__ __forceinline__ uint64_t row_get(uint64_t v, uint32_t rowbase, int j)
 __device__ __forceinline__ uint32_t row_pick(uint32_t v, uint32_t rowbase, uint32_t j) { return __shfl(v, static_cast<int>(rowbase | j), kWave); }
 __device__ __forceinline__ uint64_t row_pick(uint64_t v, uint32_t rowbase, uint32_t j) { return __shfl(v, static_cast<int>(rowbase | j), kWave); }
 
+__device__ __forceinline__ void wave_lds_sync() {  // as in k_locate.hip: orders the wave's own LDS writes and cross-lane reads
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// the next lane's value within the 16-lane row (a DPP move: no LDS traffic; lane 15 of a row gets 0)
+__device__ __forceinline__ uint32_t row_next(uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x101, 0xF, 0xF, false)); }
+__device__ __forceinline__ uint64_t row_next(uint64_t v) {
+    return (static_cast<uint64_t>(row_next(static_cast<uint32_t>(v >> 32))) << 32) | row_next(static_cast<uint32_t>(v));
+}
+
+// REQUEST SLOTS.  The kernels below are bound by the LDS pipe, not by memory, when every value an owner shares with its
+// row travels by ds_bpermute (372 of them per wave and LF step in round 2's first kernels: SQ_ACTIVE_INST_LDS at the
+// CU's limit, profiles/).  So an owner WRITES what its row needs to know -- where to probe, how many candidates, the two
+// positions -- into its own slots of an LDS area once per pass (kReqSlots x 16 bytes per lane), and in round j the row's
+// lanes read owner j's slot with one broadcast ds_read_b128; the rank itself is computed by the lane that holds the run
+// (its neighbour's count arrives by DPP), so what travels back is one value per position.
+template <typename P> struct ReqSlots { static constexpr int v = sizeof(P) == 8 ? 3 : 2; };
+
+// does round j serve anyone?  (m = ballot of the lanes with a query; round j serves lane j of each row: the test is
+// uniform over the wave, so a round without an owner costs a scalar branch instead of its cross-lane traffic)
+__device__ __forceinline__ bool round_has_owner(uint64_t m, int j) { return (m & (0x0001000100010001ull << j)) != 0; }
+
 // # lanes of this lane's row for which `pred` holds
 __device__ __forceinline__ uint32_t row_count(bool pred, uint32_t rowbase) {
     return static_cast<uint32_t>(__popc(static_cast<uint32_t>(__ballot(pred) >> rowbase) & 0xFFFFu));
@@ -72,7 +96,8 @@ template <typename P>
 __device__ __forceinline__ void coop_level(const DevTree *s_tree, const int l, const uint32_t tid, const uint32_t lo_t, const uint32_t hi_t,
                                            const bool live0, const bool live1, uint32_t &t0, uint32_t &t1, const P q0, const P q1) {
     const uint32_t lane = threadIdx.x & (kWave - 1), sub = lane & (kFan - 1), rowbase = lane & ~static_cast<uint32_t>(kFan - 1);
-    if (!__ballot(live0 || live1)) return;
+    const uint64_t m_live = __ballot(live0 || live1);
+    if (!m_live) return;
     const uint32_t b0 = t0 - 1, b1 = t1 - 1;
     const bool two = live0 && live1 && b0 != b1;                     // the second query needs a block of its own
     const uint32_t first = live0 ? b0 : b1;
@@ -80,6 +105,7 @@ __device__ __forceinline__ void coop_level(const DevTree *s_tree, const int l, c
     P va[kFan];
 #pragma unroll
     for (int j = 0; j < kFan; ++j) {
+        if (!round_has_owner(m_live, j)) continue;
         const uint32_t oi = row_get(info, rowbase, j);
         const uint32_t ob = row_get(first, rowbase, j);
         va[j] = static_cast<P>(~P(0));
@@ -91,6 +117,7 @@ __device__ __forceinline__ void coop_level(const DevTree *s_tree, const int l, c
     }
 #pragma unroll
     for (int j = 0; j < kFan; ++j) {
+        if (!round_has_owner(m_live, j)) continue;
         // padding lanes hold the all-ones key, which no query exceeds (positions stay below it: flatten())
         const uint32_t oi = row_get(info, rowbase, j);
         const uint32_t a = (oi >> 5) & 31u, z = (oi >> 10) & 31u;
@@ -104,9 +131,11 @@ __device__ __forceinline__ void coop_level(const DevTree *s_tree, const int l, c
             if (live1 && !two) t1 = b1 * kFan + c1;
         }
     }
-    if (!__ballot(two)) return;
+    const uint64_t m_two = __ballot(two);
+    if (!m_two) return;
 #pragma unroll
     for (int j = 0; j < kFan; ++j) {
+        if (!round_has_owner(m_two, j)) continue;
         const uint32_t oi = row_get(info, rowbase, j);
         const uint32_t ob = row_get(b1, rowbase, j);
         va[j] = static_cast<P>(~P(0));
@@ -118,6 +147,7 @@ __device__ __forceinline__ void coop_level(const DevTree *s_tree, const int l, c
     }
 #pragma unroll
     for (int j = 0; j < kFan; ++j) {
+        if (!round_has_owner(m_two, j)) continue;
         const uint32_t oi = row_get(info, rowbase, j);
         const uint32_t a = (oi >> 15) & 31u, z = (oi >> 20) & 31u;
         const P oq1 = row_get(q1, rowbase, j);
@@ -135,7 +165,8 @@ __device__ __forceinline__ void coop_leaf(const DevTree *s_tree, const uint32_t 
                                           P &pv1, P &nv1) {
     typedef typename PairOf<P>::vec vec;
     const uint32_t lane = threadIdx.x & (kWave - 1), sub = lane & (kFan - 1), rowbase = lane & ~static_cast<uint32_t>(kFan - 1);
-    if (!__ballot(live0 || live1)) return;
+    const uint64_t m_live = __ballot(live0 || live1);
+    if (!m_live) return;
     const uint32_t b0 = t0 - 1, b1 = t1 - 1;
     const bool two = live0 && live1 && b0 != b1;
     const uint32_t first = live0 ? b0 : b1;
@@ -144,6 +175,7 @@ __device__ __forceinline__ void coop_leaf(const DevTree *s_tree, const uint32_t 
     vec va[kFan];
 #pragma unroll
     for (int j = 0; j < kFan; ++j) {
+        if (!round_has_owner(m_live, j)) continue;
         const uint32_t oi = row_get(info, rowbase, j);
         const uint32_t ob = row_get(first, rowbase, j);
         va[j] = vec{static_cast<P>(~P(0)), 0};
@@ -155,6 +187,7 @@ __device__ __forceinline__ void coop_leaf(const DevTree *s_tree, const uint32_t 
     }
 #pragma unroll
     for (int j = 0; j < kFan; ++j) {
+        if (!round_has_owner(m_live, j)) continue;
         const uint32_t oi = row_get(info, rowbase, j);
         const uint32_t a = (oi >> 5) & 31u, z = (oi >> 10) & 31u;
         const bool in = sub < z;
@@ -171,9 +204,11 @@ __device__ __forceinline__ void coop_leaf(const DevTree *s_tree, const uint32_t 
             if (live1 && !two) { t1 = b1 * kFan + c1; pk1 = a_pk1; pv1 = a_pv1; nv1 = a_nv1; fix1 = c1 == kFan; }
         }
     }
-    if (__ballot(two)) {
+    const uint64_t m_two = __ballot(two);
+    if (m_two) {
 #pragma unroll
         for (int j = 0; j < kFan; ++j) {
+            if (!round_has_owner(m_two, j)) continue;
             const uint32_t oi = row_get(info, rowbase, j);
             const uint32_t ob = row_get(b1, rowbase, j);
             va[j] = vec{static_cast<P>(~P(0)), 0};
@@ -185,6 +220,7 @@ __device__ __forceinline__ void coop_leaf(const DevTree *s_tree, const uint32_t 
         }
 #pragma unroll
         for (int j = 0; j < kFan; ++j) {
+            if (!round_has_owner(m_two, j)) continue;
             const uint32_t oi = row_get(info, rowbase, j);
             const uint32_t a = (oi >> 15) & 31u, z = (oi >> 20) & 31u;
             const P oq1 = row_get(q1, rowbase, j);
@@ -230,12 +266,13 @@ __device__ __forceinline__ void coop_probe_at(const DevTree &T, const bool live,
     }
 }
 
-// One narrowing round for a crowded bucket: the candidates [s, s + z) of a query (z > 16) are sampled at 16 pivots a
+// coop_narrow with the owner's values broadcast by ds_bpermute (K3's path: its chains walk in toehold order, the probes
+// of a wave overlap in memory and the request slots cost more than they save there).  One narrowing round for a crowded bucket: the candidates [s, s + z) of a query (z > 16) are sampled at 16 pivots a
 // stride apart, loaded by the row; the answer lies between the last pivot below q and the next one, so the range
 // shrinks to at most ceil(z / 16) candidates (s moves to that pivot, which is known to be below q -- or stays with
 // z = 1 when not even the first candidate is).  Lanes with live == false pass through.  Every lane must call.
 template <typename P>
-__device__ __forceinline__ void coop_narrow(const DevTree *s_tree, const uint32_t tid, const bool live, uint32_t &s, uint32_t &z, const P q) {
+__device__ __forceinline__ void coop_narrow_shfl(const DevTree *s_tree, const uint32_t tid, const bool live, uint32_t &s, uint32_t &z, const P q) {
     typedef typename PairOf<P>::vec vec;
     const uint32_t lane = threadIdx.x & (kWave - 1), sub = lane & (kFan - 1), rowbase = lane & ~static_cast<uint32_t>(kFan - 1);
     if (!__ballot(live)) return;
@@ -263,74 +300,287 @@ __device__ __forceinline__ void coop_narrow(const DevTree *s_tree, const uint32_
     }
 }
 
-// The same for the two ranks of an LF step (the rank directories' path): query 0 is answered from entries
-// s0 .. s0 + 15 of which the first z0 are candidates (the rest lie beyond the bucket, possibly in the next table's
-// slice), query 1 likewise from s1 / z1 -- sharing the load when s1 == s0.  Returns t = s + # candidates below q, the
-// pair before it (pk, pv: entry t-1, valid when t > s or the directory says an entry precedes) and the value of entry t.
+// The phi directory's probe with request slots: the row's lanes load the z candidates start .. start + z - 1 of the
+// owner's position (lanes beyond them re-read the last one: the probe touches only the sectors that hold them), the lane
+// that holds the last sampled position below q computes phi's value base + (q - pos) itself, and t = start + # of them
+// below q travels back with it (val undefined when t == start).  One query per lane; every lane of the wave must call.
 template <typename P>
-__device__ __forceinline__ void coop_probe2_at(const DevTree *s_tree, const uint32_t tid, const bool live, const uint32_t s0, const uint32_t z0,
-                                               const uint32_t s1, const uint32_t z1, const P q0, const P q1, uint32_t &t0, uint32_t &t1, P &pk0,
-                                               P &pv0, P &nv0, P &pk1, P &pv1, P &nv1) {
+__device__ __forceinline__ void coop_probe_phi(const DevTree &T, uint4 *req, const bool live, const uint32_t start, const uint32_t z, const P q, uint32_t &t,
+                                               P &val) {
     typedef typename PairOf<P>::vec vec;
+    constexpr int NS = ReqSlots<P>::v;
     const uint32_t lane = threadIdx.x & (kWave - 1), sub = lane & (kFan - 1), rowbase = lane & ~static_cast<uint32_t>(kFan - 1);
-    if (!__ballot(live)) return;
+    const uint64_t m_live = __ballot(live);
+    if (!m_live) return;
+    const uint32_t zz = z > static_cast<uint32_t>(kFan) ? static_cast<uint32_t>(kFan) : z;
+    wave_lds_sync();
+    req[lane * NS + 0] = make_uint4(start, (live ? 1u : 0u) | (zz << 1), static_cast<uint32_t>(q), static_cast<uint32_t>(static_cast<uint64_t>(q) >> 32));
+    wave_lds_sync();
+    vec va[kFan];
+#pragma unroll
+    for (int j = 0; j < kFan; ++j) {
+        if (!round_has_owner(m_live, j)) continue;
+        const uint4 a = req[(rowbase + j) * NS + 0];
+        va[j] = vec{static_cast<P>(~P(0)), 0};
+        if (a.y & 1u) {
+            const uint32_t oz = a.y >> 1, last = oz ? oz - 1 : 0;
+            uint64_t i = static_cast<uint64_t>(a.x) + (sub < last ? sub : last);
+            if (i > T.m) i = T.m;   // entry m is the sentinel (never below a query)
+            va[j] = static_cast<const vec *>(T.ent)[i];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kFan; ++j) {
+        if (!round_has_owner(m_live, j)) continue;
+        const uint4 a = req[(rowbase + j) * NS + 0];
+        const P oq = sizeof(P) == 8 ? static_cast<P>((static_cast<uint64_t>(a.w) << 32) | a.z) : static_cast<P>(a.z);
+        const P key = static_cast<P>(va[j].x);
+        const uint32_t c = row_count(sub < (a.y >> 1) && key < oq, rowbase);
+        const P v = static_cast<P>(va[j].y) + (oq - key);
+        const P a_v = row_pick(v, rowbase, c ? c - 1 : 0);
+        if (static_cast<int>(sub) == j && live) { t = start + c; val = a_v; }
+    }
+}
+
+// One narrowing round for a crowded bucket: the candidates [s, s + z) of a query (z > 16) are sampled at 16 pivots a
+// stride apart, loaded by the row; the answer lies between the last pivot below q and the next one, so the range
+// shrinks to at most ceil(z / 16) candidates (s moves to that pivot, which is known to be below q -- or stays with
+// z = 1 when not even the first candidate is).  Lanes with live == false pass through.  Every lane must call.
+// (req: the wave's request area -- the owner's (s, z, tree, q) reach its row through it.)
+template <typename P>
+__device__ __forceinline__ void coop_narrow(const DevTree *s_tree, uint4 *req, const uint32_t tid, const bool live, uint32_t &s, uint32_t &z, const P q) {
+    typedef typename PairOf<P>::vec vec;
+    constexpr int NS = ReqSlots<P>::v;
+    const uint32_t lane = threadIdx.x & (kWave - 1), sub = lane & (kFan - 1), rowbase = lane & ~static_cast<uint32_t>(kFan - 1);
+    const uint64_t m_live = __ballot(live);
+    if (!m_live) return;
+    const uint32_t stride = (z + kFan - 1) / kFan;
+    wave_lds_sync();
+    req[lane * NS + 0] = make_uint4(s, z, (live ? 1u : 0u) | (tid << 1), static_cast<uint32_t>(q));
+    if (sizeof(P) == 8) req[lane * NS + 1] = make_uint4(static_cast<uint32_t>(static_cast<uint64_t>(q) >> 32), 0u, 0u, 0u);
+    wave_lds_sync();
+    P va[kFan];
+#pragma unroll
+    for (int j = 0; j < kFan; ++j) {
+        if (!round_has_owner(m_live, j)) continue;
+        const uint4 a = req[(rowbase + j) * NS + 0];
+        const uint32_t ost = (a.y + kFan - 1) / kFan;
+        va[j] = static_cast<P>(~P(0));   // pivots beyond the candidates are never below
+        if ((a.z & 1u) && sub * ost < a.y) va[j] = static_cast<P>(static_cast<const vec *>(s_tree[(a.z >> 1) & 7u].ent)[static_cast<uint64_t>(a.x) + sub * ost].x);
+    }
+#pragma unroll
+    for (int j = 0; j < kFan; ++j) {
+        if (!round_has_owner(m_live, j)) continue;
+        const uint4 a = req[(rowbase + j) * NS + 0];
+        P oq = static_cast<P>(a.w);
+        if (sizeof(P) == 8) oq = static_cast<P>((static_cast<uint64_t>(req[(rowbase + j) * NS + 1].x) << 32) | a.w);
+        const uint32_t c = row_count(va[j] < oq, rowbase);
+        if (static_cast<int>(sub) == j && live) {
+            if (c == 0) { z = 1; }
+            else {
+                const uint32_t adv = (c - 1) * stride;
+                s += adv;
+                z = (z - adv) < stride ? (z - adv) : stride;
+            }
+        }
+    }
+}
+
+// The two ranks of an LF step through the directories (K1/K2), with request slots and in-row ranks: position 0 is answered
+// from entries s0 .. s0 + 15 of which the first z0 are candidates (the rest lie beyond the bucket, possibly in the next
+// table's slice), position 1 likewise from s1 / z1 -- sharing the load when s1 == s0.  Returns for each
+// position t = s + # candidates below it, the RANK rk = cum[t-1] + min(q - start[t-1], cum[t] - cum[t-1]) (valid when
+// t > s or an entry precedes s) and, for the second position, whether it lies inside that run (q - start <= length: the
+// toehold test of the caller).  The row's lanes beyond the candidates re-read the entry after the last one, so a probe
+// touches only the sectors that hold its z + 1 entries.  req: the wave's request area (64 x ReqSlots<P>::v x 16 bytes).
+template <typename P>
+__device__ __forceinline__ void coop_probe2_rank(const DevTree *s_tree, uint4 *req, const uint32_t tid, const bool live, const uint32_t s0, const uint32_t z0,
+                                                 const uint32_t s1, const uint32_t z1, const P q0, const P q1, uint32_t &t0, uint32_t &t1, P &rk0,
+                                                 P &rk1, bool &ins1) {
+    typedef typename PairOf<P>::vec vec;
+    constexpr int NS = ReqSlots<P>::v;
+    const uint32_t lane = threadIdx.x & (kWave - 1), sub = lane & (kFan - 1), rowbase = lane & ~static_cast<uint32_t>(kFan - 1);
+    const uint64_t m_live = __ballot(live);
+    if (!m_live) return;
     const bool two = live && s1 != s0;
     // bit 0 live, bit 1 second block, bits 2-4 tree, bits 5-9 z0, 10-14 z1
     const uint32_t info = (live ? 1u : 0u) | (two ? 2u : 0u) | (tid << 2) | (z0 << 5) | (z1 << 10);
+    wave_lds_sync();   // (the area's previous readers are done)
+    req[lane * NS + 0] = make_uint4(s0, info, static_cast<uint32_t>(q0), static_cast<uint32_t>(q1));
+    req[lane * NS + 1] = make_uint4(s1, info, static_cast<uint32_t>(q1), static_cast<uint32_t>(static_cast<uint64_t>(q1) >> 32));
+    if (sizeof(P) == 8) req[lane * NS + (NS - 1)] = make_uint4(static_cast<uint32_t>(static_cast<uint64_t>(q0) >> 32), static_cast<uint32_t>(static_cast<uint64_t>(q1) >> 32), 0u, 0u);
+    wave_lds_sync();
     bool fix0 = false, fix1 = false;
     vec va[kFan];
 #pragma unroll
     for (int j = 0; j < kFan; ++j) {
-        const uint32_t oi = row_get(info, rowbase, j);
-        const uint32_t os = row_get(s0, rowbase, j);
+        if (!round_has_owner(m_live, j)) continue;
+        const uint4 a = req[(rowbase + j) * NS + 0];
         va[j] = vec{static_cast<P>(~P(0)), 0};
-        if (oi & 1u) {
-            const DevTree &T = s_tree[(oi >> 2) & 7u];
-            const uint64_t i = static_cast<uint64_t>(os) + sub;
-            if (i <= T.m) va[j] = static_cast<const vec *>(T.ent)[i];
+        if (a.y & 1u) {
+            const DevTree &T = s_tree[(a.y >> 2) & 7u];
+            const uint32_t za = (a.y >> 5) & 31u, zb = (a.y & 2u) ? 0u : (a.y >> 10) & 31u;
+            uint32_t zc = za > zb ? za : zb;                      // entries 0 .. zc of the stretch are needed (zc: the one after the last candidate)
+            if (zc > static_cast<uint32_t>(kFan - 1)) zc = kFan - 1;
+            uint64_t i = static_cast<uint64_t>(a.x) + (sub < zc ? sub : zc);
+            if (i > T.m) i = T.m;                                  // entry m is the last sentinel
+            va[j] = static_cast<const vec *>(T.ent)[i];
         }
     }
 #pragma unroll
     for (int j = 0; j < kFan; ++j) {
-        const uint32_t oi = row_get(info, rowbase, j);
-        const P oq0 = row_get(q0, rowbase, j), oq1 = row_get(q1, rowbase, j);   // (cross-lane: outside the &&)
-        const uint32_t c0 = row_count(sub < ((oi >> 5) & 31u) && static_cast<P>(va[j].x) < oq0, rowbase);
-        const uint32_t c1 = row_count(sub < ((oi >> 10) & 31u) && static_cast<P>(va[j].x) < oq1, rowbase);
-        const uint32_t p0 = c0 ? c0 - 1 : 0, n0 = c0 < kFan ? c0 : kFan - 1;
-        const uint32_t p1 = c1 ? c1 - 1 : 0, n1 = c1 < kFan ? c1 : kFan - 1;
-        const P a_pk0 = row_pick(static_cast<P>(va[j].x), rowbase, p0), a_pv0 = row_pick(static_cast<P>(va[j].y), rowbase, p0), a_nv0 = row_pick(static_cast<P>(va[j].y), rowbase, n0);
-        const P a_pk1 = row_pick(static_cast<P>(va[j].x), rowbase, p1), a_pv1 = row_pick(static_cast<P>(va[j].y), rowbase, p1), a_nv1 = row_pick(static_cast<P>(va[j].y), rowbase, n1);
+        if (!round_has_owner(m_live, j)) continue;
+        const uint4 a = req[(rowbase + j) * NS + 0];
+        P oq0 = static_cast<P>(a.z), oq1 = static_cast<P>(a.w);
+        if (sizeof(P) == 8) {
+            const uint4 c = req[(rowbase + j) * NS + (NS - 1)];
+            oq0 = static_cast<P>((static_cast<uint64_t>(c.x) << 32) | a.z);
+            oq1 = static_cast<P>((static_cast<uint64_t>(c.y) << 32) | a.w);
+        }
+        const P key = static_cast<P>(va[j].x), cum = static_cast<P>(va[j].y);
+        const P len = row_next(cum) - cum;                         // (lane 15: fixed up by the owner below)
+        const uint32_t c0 = row_count(sub < ((a.y >> 5) & 31u) && key < oq0, rowbase);
+        const uint32_t c1 = row_count(sub < ((a.y >> 10) & 31u) && key < oq1, rowbase);
+        const P d0 = oq0 - key, d1 = oq1 - key;
+        const P r0 = cum + (d0 < len ? d0 : len), r1 = cum + (d1 < len ? d1 : len);
+        const uint64_t in1 = __ballot(d1 <= len);
+        const uint32_t p0 = c0 ? c0 - 1 : 0, p1 = c1 ? c1 - 1 : 0;
+        const P a_r0 = row_pick(r0, rowbase, p0), a_r1 = row_pick(r1, rowbase, p1);
         if (static_cast<int>(sub) == j && live) {
-            t0 = s0 + c0; pk0 = a_pk0; pv0 = a_pv0; nv0 = a_nv0; fix0 = c0 == kFan;
-            if (!two) { t1 = s1 + c1; pk1 = a_pk1; pv1 = a_pv1; nv1 = a_nv1; fix1 = c1 == kFan; }
+            t0 = s0 + c0; rk0 = a_r0; fix0 = c0 == kFan;
+            if (!two) { t1 = s1 + c1; rk1 = a_r1; ins1 = ((in1 >> (rowbase + p1)) & 1u) != 0; fix1 = c1 == kFan; }
         }
     }
-    if (__ballot(two)) {
+    const uint64_t m_two = __ballot(two);
+    if (m_two) {
 #pragma unroll
         for (int j = 0; j < kFan; ++j) {
-            const uint32_t oi = row_get(info, rowbase, j);
-            const uint32_t os = row_get(s1, rowbase, j);
+            if (!round_has_owner(m_two, j)) continue;
+            const uint4 b = req[(rowbase + j) * NS + 1];
             va[j] = vec{static_cast<P>(~P(0)), 0};
-            if (oi & 2u) {
-                const DevTree &T = s_tree[(oi >> 2) & 7u];
-                const uint64_t i = static_cast<uint64_t>(os) + sub;
-                if (i <= T.m) va[j] = static_cast<const vec *>(T.ent)[i];
+            if (b.y & 2u) {
+                const DevTree &T = s_tree[(b.y >> 2) & 7u];
+                uint32_t zc = (b.y >> 10) & 31u;
+                if (zc > static_cast<uint32_t>(kFan - 1)) zc = kFan - 1;
+                uint64_t i = static_cast<uint64_t>(b.x) + (sub < zc ? sub : zc);
+                if (i > T.m) i = T.m;
+                va[j] = static_cast<const vec *>(T.ent)[i];
             }
         }
 #pragma unroll
         for (int j = 0; j < kFan; ++j) {
-            const uint32_t oi = row_get(info, rowbase, j);
-            const P oq1 = row_get(q1, rowbase, j);
-            const uint32_t c1 = row_count(sub < ((oi >> 10) & 31u) && static_cast<P>(va[j].x) < oq1, rowbase);
-            const uint32_t p1 = c1 ? c1 - 1 : 0, n1 = c1 < kFan ? c1 : kFan - 1;
-            const P a_pk1 = row_pick(static_cast<P>(va[j].x), rowbase, p1), a_pv1 = row_pick(static_cast<P>(va[j].y), rowbase, p1), a_nv1 = row_pick(static_cast<P>(va[j].y), rowbase, n1);
-            if (static_cast<int>(sub) == j && two) { t1 = s1 + c1; pk1 = a_pk1; pv1 = a_pv1; nv1 = a_nv1; fix1 = c1 == kFan; }
+            if (!round_has_owner(m_two, j)) continue;
+            const uint4 b = req[(rowbase + j) * NS + 1];
+            const P oq1 = sizeof(P) == 8 ? static_cast<P>((static_cast<uint64_t>(b.w) << 32) | b.z) : static_cast<P>(b.z);
+            const P key = static_cast<P>(va[j].x), cum = static_cast<P>(va[j].y);
+            const P len = row_next(cum) - cum;
+            const uint32_t c1 = row_count(sub < ((b.y >> 10) & 31u) && key < oq1, rowbase);
+            const P d1 = oq1 - key;
+            const P r1 = cum + (d1 < len ? d1 : len);
+            const uint64_t in1 = __ballot(d1 <= len);
+            const uint32_t p1 = c1 ? c1 - 1 : 0;
+            const P a_r1 = row_pick(r1, rowbase, p1);
+            if (static_cast<int>(sub) == j && two) { t1 = s1 + c1; rk1 = a_r1; ins1 = ((in1 >> (rowbase + p1)) & 1u) != 0; fix1 = c1 == kFan; }
         }
     }
-    if (fix0 || fix1) {
+    if (fix0 || fix1) {   // all 16 loaded entries lie below the position: the run it lands in ends in the next block
         const vec *__restrict__ ent = static_cast<const vec *>(s_tree[tid].ent);
-        if (fix0) nv0 = static_cast<P>(ent[t0].y);
-        if (fix1) nv1 = static_cast<P>(ent[t1].y);
+        if (fix0) {
+            const vec e = ent[t0 - 1];
+            const P len = static_cast<P>(ent[t0].y) - static_cast<P>(e.y), d = q0 - static_cast<P>(e.x);
+            rk0 = static_cast<P>(e.y) + (d < len ? d : len);
+        }
+        if (fix1) {
+            const vec e = ent[t1 - 1];
+            const P len = static_cast<P>(ent[t1].y) - static_cast<P>(e.y), d = q1 - static_cast<P>(e.x);
+            rk1 = static_cast<P>(e.y) + (d < len ? d : len);
+            ins1 = d <= len;
+        }
+    }
+}
+
+// The two ranks of an LF step through the BUCKET RECORDS (rbg_dev.h RunRec): the row's lanes load the 128-byte record of
+// the owner's bucket with one coalesced request (lane 0 the header, lane 1 the rank at the bucket's start, lanes 2-15
+// the pairs); each pair's lane computes the rank the position would have if it fell into ITS run, popcount(ballot)
+// finds the run it does fall into, and one value per position travels back -- no directory gather, no second round
+// trip.  r0 / r1: the records (index into the depth's array) of the two positions, o0 / o1 their offsets in the bucket.
+// Returns per position c = # runs of the record that start below it (0: no run of the table starts below it at all),
+// the rank rk (valid when c > 0) and for the second whether it lies inside its run; ov = one of the two buckets
+// holds more runs than a record (the caller reads (e0, count) from the headers and goes through the run list).
+template <typename P>
+__device__ __forceinline__ void coop_rec2(const RunRec *const *s_rec, uint4 *req, const uint32_t tid, const bool live, const uint32_t r0, const uint32_t r1,
+                                          const uint32_t o0, const uint32_t o1, uint32_t &c0, uint32_t &c1, P &rk0, P &rk1, bool &ins1, bool &ov) {
+    typedef unsigned int vec2 __attribute__((ext_vector_type(2)));
+    constexpr int NS = ReqSlots<P>::v;
+    const uint32_t lane = threadIdx.x & (kWave - 1), sub = lane & (kFan - 1), rowbase = lane & ~static_cast<uint32_t>(kFan - 1);
+    const uint64_t m_live = __ballot(live);
+    if (!m_live) return;
+    const bool two = live && r1 != r0;
+    const uint32_t info = (live ? 1u : 0u) | (two ? 2u : 0u) | (tid << 2);
+    wave_lds_sync();
+    req[lane * NS + 0] = make_uint4(r0, info, o0, o1);
+    req[lane * NS + 1] = make_uint4(r1, info, o1, 0u);
+    wave_lds_sync();
+    vec2 va[kFan];
+#pragma unroll
+    for (int j = 0; j < kFan; ++j) {
+        if (!round_has_owner(m_live, j)) continue;
+        const uint4 a = req[(rowbase + j) * NS + 0];
+        va[j] = vec2{kRecNoPair, 0u};
+        if (a.y & 1u) va[j] = reinterpret_cast<const vec2 *>(s_rec[(a.y >> 2) & 7u] + a.x)[sub];
+    }
+#pragma unroll
+    for (int j = 0; j < kFan; ++j) {
+        if (!round_has_owner(m_live, j)) continue;
+        const uint4 a = req[(rowbase + j) * NS + 0];
+        const uint32_t off = va[j].x, cl = va[j].y;
+        const uint32_t len = row_next(cl) - cl;                   // (lane 15 holds the closing pair: never chosen)
+        const bool pair_lane = sub >= 2u;
+        const uint32_t n0 = row_count(pair_lane && static_cast<int32_t>(off) < static_cast<int32_t>(a.z), rowbase);
+        const uint32_t n1 = row_count(pair_lane && static_cast<int32_t>(off) < static_cast<int32_t>(a.w), rowbase);
+        const uint32_t d0 = a.z - off, d1 = a.w - off;
+        const uint32_t v0 = cl + (d0 < len ? d0 : len), v1 = cl + (d1 < len ? d1 : len);
+        const uint64_t in1 = __ballot(d1 <= len);
+        const uint64_t ovm = __ballot(sub == 0u && (cl & kRecOverflow));   // (the header's flags sit in lane 0's second word)
+        // pair n - 1 sits in lane n + 1
+        const uint32_t a_v0 = row_pick(v0, rowbase, n0 + 1u), a_v1 = row_pick(v1, rowbase, n1 + 1u);
+        uint32_t blo = 0, bhi = 0;
+        if (sizeof(P) == 8) { blo = row_pick(off, rowbase, 1u); bhi = row_pick(cl, rowbase, 1u); }
+        if (static_cast<int>(sub) == j && live) {
+            const P base = static_cast<P>((static_cast<uint64_t>(bhi) << 32) | blo);   // (0 at 4-byte positions: the pairs carry the rank itself)
+            ov = ((ovm >> rowbase) & 1u) != 0;
+            c0 = n0; rk0 = base + static_cast<P>(a_v0);
+            if (!two) { c1 = n1; rk1 = base + static_cast<P>(a_v1); ins1 = ((in1 >> (rowbase + n1 + 1u)) & 1u) != 0; }
+        }
+    }
+    const uint64_t m_two = __ballot(two);
+    if (!m_two) return;
+#pragma unroll
+    for (int j = 0; j < kFan; ++j) {
+        if (!round_has_owner(m_two, j)) continue;
+        const uint4 b = req[(rowbase + j) * NS + 1];
+        va[j] = vec2{kRecNoPair, 0u};
+        if (b.y & 2u) va[j] = reinterpret_cast<const vec2 *>(s_rec[(b.y >> 2) & 7u] + b.x)[sub];
+    }
+#pragma unroll
+    for (int j = 0; j < kFan; ++j) {
+        if (!round_has_owner(m_two, j)) continue;
+        const uint4 b = req[(rowbase + j) * NS + 1];
+        const uint32_t off = va[j].x, cl = va[j].y;
+        const uint32_t len = row_next(cl) - cl;
+        const uint32_t n1 = row_count(sub >= 2u && static_cast<int32_t>(off) < static_cast<int32_t>(b.z), rowbase);
+        const uint32_t d1 = b.z - off;
+        const uint32_t v1 = cl + (d1 < len ? d1 : len);
+        const uint64_t in1 = __ballot(d1 <= len);
+        const uint64_t ovm = __ballot(sub == 0u && (cl & kRecOverflow));
+        const uint32_t a_v1 = row_pick(v1, rowbase, n1 + 1u);
+        uint32_t blo = 0, bhi = 0;
+        if (sizeof(P) == 8) { blo = row_pick(off, rowbase, 1u); bhi = row_pick(cl, rowbase, 1u); }
+        if (static_cast<int>(sub) == j && two) {
+            const P base = static_cast<P>((static_cast<uint64_t>(bhi) << 32) | blo);
+            ov = ov || ((ovm >> rowbase) & 1u) != 0;
+            c1 = n1; rk1 = base + static_cast<P>(a_v1); ins1 = ((in1 >> (rowbase + n1 + 1u)) & 1u) != 0;
+        }
     }
 }
 
@@ -361,9 +611,13 @@ __global__ __launch_bounds__(512, sizeof(P) == 4 ? 4 : 3) void k_find_range_runs
     __shared__ uint8_t s_lut2[256];
     __shared__ DevTree s_tree[kMaxRunDepth];
     __shared__ uint32_t s_tab_first[kMaxRunDepth + 1];
+    __shared__ const RunRec *s_rec[8];
+    __shared__ uint4 s_req[8][kWave * ReqSlots<P>::v];   // request slots, per wave (512-thread workgroups)
+    uint4 *req = s_req[threadIdx.x >> 6];
     extern __shared__ __align__(16) unsigned char s_dyn[];
     DevRunTab *s_tab = reinterpret_cast<DevRunTab *>(s_dyn);
     P *s_top = reinterpret_cast<P *>(s_dyn + static_cast<size_t>(ix.run_ntabs) * sizeof(DevRunTab));
+    if (threadIdx.x < 8) s_rec[threadIdx.x] = threadIdx.x < static_cast<uint32_t>(kMaxRunDepth) ? ix.run_rec[threadIdx.x] : nullptr;
     for (int t = threadIdx.x; t < 256; t += blockDim.x) {
         s_lut[t] = ix.lut[t];
         s_lut2[t] = ix.nmajor ? ix.lut2[t] : 0xFFu;
@@ -392,7 +646,7 @@ __global__ __launch_bounds__(512, sizeof(P) == 4 ? 4 : 3) void k_find_range_runs
         uint64_t k = TOEHOLD ? ix.last_run_sample : 0;
         bool alive = valid;
         bool pend = false;                                     // deferred toehold re-sample: entry `pend_run` of depth `pend_d`
-        uint32_t pend_d = 0, pend_run = 0;
+        uint32_t pend_d = 0, pend_run = 0, pend_c = 0;          // pend_c > 0: pend_run is a bucket record, the entry its pend_c-th
         ByteCursor rd{reinterpret_cast<const uint4 *>(seqs), ~uint64_t(0), make_uint4(0, 0, 0, 0)};
         if (valid && ix.ftab_k && p - beg >= ix.ftab_k) {      // rowbowt.hpp:124-125, :745-758 (k_search.hip)
             uint64_t idx = 0, pw = 1;
@@ -454,14 +708,24 @@ __global__ __launch_bounds__(512, sizeof(P) == 4 ? 4 : 3) void k_find_range_runs
             P pk0 = 0, pv0 = 0, nv0 = 0, pk1 = 0, pv1 = 0, nv1 = 0;
             bool descend = stepping;
             uint32_t s0 = 0, z0 = 0, s1 = 0, z1 = 0;
-            bool direct = false;
+            bool direct = false, by_rec = false, ov = false;
+            uint32_t rc0 = 0, rc1 = 0, o0 = 0, o1 = 0;
             if (stepping) {
                 const DevRunTab r0 = s_tab[rec];
                 F = r0.F;
                 lo_t = static_cast<uint32_t>(r0.first);
                 hi_t = static_cast<uint32_t>(s_tab[rec + 1].first) - 1;   // the slice's sentinel: never below a query
                 const uint32_t *__restrict__ dir = ix.run_dir[d];
-                if (dir) {
+                if (s_rec[d]) {
+                    // the table's bucket records: one record per position answers its rank
+                    const uint64_t b0 = q0 >> r0.dir_shift, b1 = q1 >> r0.dir_shift;
+                    rc0 = r0.dir_off + static_cast<uint32_t>(b0);
+                    rc1 = r0.dir_off + static_cast<uint32_t>(b1);
+                    o0 = static_cast<uint32_t>(q0 - (b0 << r0.dir_shift));
+                    o1 = static_cast<uint32_t>(q1 - (b1 << r0.dir_shift));
+                    by_rec = true;
+                    descend = false;
+                } else if (dir) {
                     // the table's directory: # runs starting below the bucket of q and below the next bucket; the
                     // candidates are those runs and the one before them
                     dir += r0.dir_off;
@@ -473,15 +737,29 @@ __global__ __launch_bounds__(512, sizeof(P) == 4 ? 4 : 3) void k_find_range_runs
                     s1 = lo_t + (a1 ? a1 - 1 : 0);
                     z0 = lo_t + e0 - s0;
                     z1 = lo_t + e1 - s1;
+                    // neighbouring buckets: when the second position's candidates end within 16 entries of the first's start, one
+                    // probe from there answers both (every entry before s1 is below q1 anyway)
+                    if (s1 != s0 && s1 + z1 - s0 <= static_cast<uint32_t>(kFan)) { z1 = s1 + z1 - s0; s1 = s0; }
                     direct = true;   // (crowded buckets are narrowed below until one row probe covers their candidates)
                     descend = false;
                 }
             }
-            while (__ballot(direct && (z0 > static_cast<uint32_t>(kFan) || z1 > static_cast<uint32_t>(kFan)))) {
-                coop_narrow<P>(s_tree, d, direct && z0 > static_cast<uint32_t>(kFan), s0, z0, static_cast<P>(q0));
-                coop_narrow<P>(s_tree, d, direct && z1 > static_cast<uint32_t>(kFan), s1, z1, static_cast<P>(q1));
+            P rk0 = 0, rk1 = 0;
+            bool ins1 = false;
+            uint32_t cn0 = 0, cn1 = 0;
+            coop_rec2<P>(s_rec, req, d, by_rec, rc0, rc1, o0, o1, cn0, cn1, rk0, rk1, ins1, ov);
+            if (by_rec && ov) {   // a bucket with more runs than a record holds: through the run list, like a directory's
+                const RunRec *__restrict__ R = s_rec[d];
+                const uint32_t f0 = R[rc0].flags, f1 = R[rc1].flags;
+                s0 = R[rc0].e0; z0 = (f0 & kRecOverflow) ? (f0 & 0x7FFFFFFFu) : (f0 & 0xFFu);
+                s1 = R[rc1].e0; z1 = (f1 & kRecOverflow) ? (f1 & 0x7FFFFFFFu) : (f1 & 0xFFu);
+                direct = true;
             }
-            coop_probe2_at<P>(s_tree, d, direct, s0, z0, s1, z1, static_cast<P>(q0), static_cast<P>(q1), t0, t1, pk0, pv0, nv0, pk1, pv1, nv1);
+            while (__ballot(direct && (z0 > static_cast<uint32_t>(kFan) || z1 > static_cast<uint32_t>(kFan)))) {
+                coop_narrow<P>(s_tree, req, d, direct && z0 > static_cast<uint32_t>(kFan), s0, z0, static_cast<P>(q0));
+                coop_narrow<P>(s_tree, req, d, direct && z1 > static_cast<uint32_t>(kFan), s1, z1, static_cast<P>(q1));
+            }
+            coop_probe2_rank<P>(s_tree, req, d, direct, s0, z0, s1, z1, static_cast<P>(q0), static_cast<P>(q1), t0, t1, rk0, rk1, ins1);
             if (__ballot(descend)) {   // crowded buckets (and indexes without directories): the clamped descent
                 uint32_t d0 = 0, d1 = 0;
                 P ak0 = 0, av0 = 0, an0 = 0, ak1 = 0, av1 = 0, an1 = 0;
@@ -504,15 +782,24 @@ __global__ __launch_bounds__(512, sizeof(P) == 4 ? 4 : 3) void k_find_range_runs
                 // position; t <= lo_t: no run of this table starts before the position
                 uint64_t c_before = 0, c_upto = 0;
                 bool inside = false;
-                if (t0 > lo_t) { const uint64_t len = static_cast<uint64_t>(nv0) - pv0, dd = q0 - pk0; c_before = pv0 + (dd < len ? dd : len); }
-                if (t1 > lo_t) { const uint64_t len = static_cast<uint64_t>(nv1) - pv1, dd = q1 - pk1; c_upto = pv1 + (dd < len ? dd : len); inside = dd <= len; }
+                if (direct) {   // (the row computed the ranks)
+                    if (t0 > lo_t) c_before = rk0;
+                    if (t1 > lo_t) { c_upto = rk1; inside = ins1; }
+                } else if (by_rec) {
+                    if (cn0) c_before = rk0;
+                    if (cn1) { c_upto = rk1; inside = ins1; }
+                } else {
+                    if (t0 > lo_t) { const uint64_t len = static_cast<uint64_t>(nv0) - pv0, dd = q0 - pk0; c_before = pv0 + (dd < len ? dd : len); }
+                    if (t1 > lo_t) { const uint64_t len = static_cast<uint64_t>(nv1) - pv1, dd = q1 - pk1; c_upto = pv1 + (dd < len ? dd : len); inside = dd <= len; }
+                }
                 const uint64_t c_inside = c_upto - c_before;
                 if (c_inside == 0) {                            // rowbowt.hpp:85 (whichever of the nested steps emptied the range)
                     alive = false;
                 } else {
                     if (TOEHOLD) {                              // LF_w_loc, rowbowt.hpp:559-566, `adv` times nested
                         if (inside) k = k - adv;
-                        else { pend = true; pend_d = d; pend_run = t1 - 1; k = 0; }
+                        else if (by_rec && !direct) { pend = true; pend_d = d; pend_run = rc1; pend_c = cn1; k = 0; }   // entry e0 + cn1 - 1 of the record's header
+                        else { pend = true; pend_d = d; pend_run = t1 - 1; pend_c = 0; k = 0; }
                     }
                     lo = F + c_before;                          // rowbowt.hpp:86
                     hi = lo + c_inside - 1;                     // rowbowt.hpp:87
@@ -520,7 +807,10 @@ __global__ __launch_bounds__(512, sizeof(P) == 4 ? 4 : 3) void k_find_range_runs
                 }
             }
         }
-        if (TOEHOLD && alive && pend) k += static_cast<uint64_t>(static_cast<const P *>(ix.run_samp[pend_d])[pend_run]);
+        if (TOEHOLD && alive && pend) {
+            if (pend_c) pend_run = s_rec[pend_d][pend_run].e0 + pend_c - 1;
+            k += static_cast<uint64_t>(static_cast<const P *>(ix.run_samp[pend_d])[pend_run]);
+        }
         if (!alive) { lo = 1; hi = 0; k = 0; }                 // {1,0}; LFData::clear rowbowt.hpp:153-159
         if (valid) {
             lo_out[i] = lo;
@@ -545,14 +835,9 @@ __global__ __launch_bounds__(512, sizeof(P) == 4 ? 4 : 3) void k_find_range_runs
 // toehold order), phi itself (toehold_sa.hpp:56-72) as a cooperative predecessor search over the sampled positions.
 template <typename P> struct ChunkR { static constexpr int v = sizeof(P) == 8 ? 8 : 16; };   // as in k_locate.hip
 
-__device__ __forceinline__ void wave_lds_sync() {  // as in k_locate.hip: orders the wave's own LDS writes and cross-lane reads
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-template <typename P>
-__global__ __launch_bounds__(256) void k_locate_fill_runs(const DevIndex ix, const uint64_t *__restrict__ lo,
+// ORDERED: the chains come in toehold order (launch_locate_order): neighbouring lanes probe neighbouring entries
+template <typename P, bool ORDERED>
+__global__ __launch_bounds__(256, sizeof(P) == 4 ? 4 : 3) void k_locate_fill_runs(const DevIndex ix, const uint64_t *__restrict__ lo,
                                                           const uint64_t *__restrict__ hi, const uint64_t *__restrict__ k,
                                                           const uint64_t N, const uint64_t max_hits,
                                                           const uint64_t *__restrict__ loc_off, uint64_t *__restrict__ locs,
@@ -565,6 +850,8 @@ __global__ __launch_bounds__(256) void k_locate_fill_runs(const DevIndex ix, con
     __shared__ uint64_t s_minus[4][kWave];
     __shared__ uint64_t s_first[4][kWave];
     __shared__ DevTree s_tree[1];
+    __shared__ uint4 s_req[4][kWave * ReqSlots<P>::v];   // request slots, per wave (256-thread workgroups)
+    uint4 *req = s_req[threadIdx.x >> 6];
     extern __shared__ __align__(16) unsigned char s_dyn[];
     P *s_top = reinterpret_cast<P *>(s_dyn);
     if (threadIdx.x == 0) s_tree[0] = ix.phi_tree;
@@ -615,7 +902,8 @@ __global__ __launch_bounds__(256) void k_locate_fill_runs(const DevIndex ix, con
                 const bool wrapped = need && k1 >= ix.n;        // a toehold below zero (k_locate.hip phi_step): outside phi's domain
                 const bool coop = need && !wrapped;
                 uint32_t tq = 0, unused_t = 0;
-                P pk = 0, pv = 0, nv = 0, u1 = 0, u2 = 0, u3 = 0;
+                P pk = 0, pv = 0, nv = 0, u1 = 0, u2 = 0, u3 = 0, pval = 0;
+                bool by_dir = false;   // pval = prev_sample + delta already (the row computed it)
                 // the directory: # sampled positions below the bucket of k1 and below the next one; when the bucket (and
                 // the predecessor before it) fit one block, ONE row probe from there answers the query
                 bool descend = coop;
@@ -628,8 +916,14 @@ __global__ __launch_bounds__(256) void k_locate_fill_runs(const DevIndex ix, con
                     }
                     uint32_t start = g0 ? g0 - 1 : 0, z = g1 - start;
                     // a crowded bucket is narrowed by pivot probes first (coop_narrow), as the ranks' are
-                    while (__ballot(coop && z > static_cast<uint32_t>(kFan))) coop_narrow<P>(s_tree, 0u, coop && z > static_cast<uint32_t>(kFan), start, z, static_cast<P>(k1));
-                    coop_probe_at<P>(s_tree[0], coop, start, static_cast<P>(k1), tq, pk, pv);
+                    if (ORDERED) {
+                        while (__ballot(coop && z > static_cast<uint32_t>(kFan))) coop_narrow_shfl<P>(s_tree, 0u, coop && z > static_cast<uint32_t>(kFan), start, z, static_cast<P>(k1));
+                        coop_probe_at<P>(s_tree[0], coop, start, static_cast<P>(k1), tq, pk, pv);
+                    } else {
+                        while (__ballot(coop && z > static_cast<uint32_t>(kFan))) coop_narrow<P>(s_tree, req, 0u, coop && z > static_cast<uint32_t>(kFan), start, z, static_cast<P>(k1));
+                        coop_probe_phi<P>(s_tree[0], req, coop, start, z, static_cast<P>(k1), tq, pval);
+                        by_dir = coop;
+                    }
                     descend = false;
                 }
                 // the descent (one slice: all r sampled positions; entry r is the sentinel)
@@ -658,7 +952,7 @@ __global__ __launch_bounds__(256) void k_locate_fill_runs(const DevIndex ix, con
                         s = static_cast<uint64_t>(pent[ix.r - 1].base) + k1 + 1;
                         if (s >= ix.n) s -= ix.n;
                     } else {
-                        s = static_cast<uint64_t>(pv) + (k1 - pk);   // prev_sample + delta (toehold_sa.hpp:65-71)
+                        s = by_dir ? static_cast<uint64_t>(pval) : static_cast<uint64_t>(pv) + (k1 - pk);   // prev_sample + delta (toehold_sa.hpp:65-71)
                         if (s >= ix.n) s -= ix.n;
                     }
                     k1 = s;
@@ -727,15 +1021,18 @@ int launch_locate_fill_runs(const DevIndex &ix, const LaunchCfg &cfg, const uint
     const size_t lds = static_cast<size_t>(ix.phi_tree.top_n) * ix.pos_bytes + 16;
     const dim3 grid(grid_for(cfg, N)), block(256);
     const uint32_t *perm = static_cast<const uint32_t *>(order);
+#define RBG_LAUNCH_LFR(PT, ORD)                                                                                         \
+    do {                                                                                                               \
+        auto kern = k_locate_fill_runs<PT, ORD>;                                                                       \
+        raise_lds(kern, lds);                                                                                          \
+        hipLaunchKernelGGL(kern, grid, block, lds, st, ix, lo, hi, k, N, max_hits, loc_off, locs, sub, perm, skeys);   \
+    } while (0)
     if (ix.pos_bytes == 4) {
-        auto kern = k_locate_fill_runs<uint32_t>;
-        raise_lds(kern, lds);
-        hipLaunchKernelGGL(kern, grid, block, lds, st, ix, lo, hi, k, N, max_hits, loc_off, locs, sub, perm, skeys);
+        if (perm) RBG_LAUNCH_LFR(uint32_t, true); else RBG_LAUNCH_LFR(uint32_t, false);
     } else {
-        auto kern = k_locate_fill_runs<uint64_t>;
-        raise_lds(kern, lds);
-        hipLaunchKernelGGL(kern, grid, block, lds, st, ix, lo, hi, k, N, max_hits, loc_off, locs, sub, perm, skeys);
+        if (perm) RBG_LAUNCH_LFR(uint64_t, true); else RBG_LAUNCH_LFR(uint64_t, false);
     }
+#undef RBG_LAUNCH_LFR
     return static_cast<int>(hipGetLastError());
 }
 

@@ -488,14 +488,26 @@ int upload_tree(rbg_index *ix, const void *d_ent, uint64_t m, KeyAt key_at, uint
     return RBG_OK;
 }
 
+// RBG_RANK_REC=<t> (rbg_dev.h RunRec): build bucket records with at most t runs per bucket on average (t >= 1; fewer
+// runs per bucket = fewer overflowing buckets, more records).  Off by default: on the bench index they buy 5 % of
+// K1 for 3.7 times the space, the directories and run lists are the layout of choice.
+double rank_rec_target() {
+    const char *e_rdir = std::getenv("RBG_RANK_DIR"), *e_rec = std::getenv("RBG_RANK_REC");
+    if ((e_rdir && e_rdir[0] == '0') || !e_rec) return 0.0;
+    const double t = std::atof(e_rec);
+    return t >= 1.0 ? t : 0.0;
+}
+
 // bytes of the run-indexed replica with the k-mer depths h holds (run lists, samples, 1/15 of sampled keys, phi)
 template <typename P>
 size_t runs_replica_bytes(const HostIndex &h) {
     size_t total = 0;
+    const double rec_target = rank_rec_target();
     for (const std::vector<SymTable> *lv : {&h.sym, &h.pair, &h.triple, &h.quad, &h.quint}) {
         size_t entries = 0;
         for (const SymTable &t : *lv) entries += t.nruns + 1;
         total += entries * (sizeof(RunEnt<P>) + (h.has_tsa ? sizeof(P) : 0)) + entries * sizeof(P) / 15 + entries * 2 + lv->size() * 8 + 8 * kArenaAlign;   // (+ directories: at most half an entry per run)
+        if (rec_target > 0) total += static_cast<size_t>(2.0 * static_cast<double>(entries) / rec_target + static_cast<double>(lv->size())) * sizeof(RunRec);   // (+ bucket records)
     }
     if (h.has_tsa) total += (h.r + 1) * sizeof(PhiEnt<P>) + h.r * sizeof(P) / 15 + std::min<size_t>(h.r, size_t(1) << 29) * 4;   // (+ the phi directory: at most r entries)
     return total + 16 * kArenaAlign;
@@ -520,6 +532,11 @@ int upload_tables_runs(rbg_index *ix) {
     if (sizes[0] >= 0xFFFFFFF0ull) return RBG_EARG;
     const char *e_rdir = std::getenv("RBG_RANK_DIR");   // "0": ranks by the descent only (A/B measurements, tests)
     const bool use_dirs = !(e_rdir && e_rdir[0] == '0');
+    const double rec_target = rank_rec_target();   // bucket records (rbg_dev.h RunRec)
+    // RBG_RANK_DIR_RUNS: runs per directory bucket at most this on average (default 4; a directory entry is 4 bytes per bucket)
+    const char *e_dt = std::getenv("RBG_RANK_DIR_RUNS");
+    const double dir_target = e_dt && std::atof(e_dt) > 0 ? std::atof(e_dt) : 4.0;
+    const bool use_recs = rec_target > 0;
     // with the directories the descent is the rare path: half the LDS for its top level leaves room for the table records
     const uint32_t nlvl = tree_levels_for(sizes, use_dirs && budget_keys > 64 ? std::max<uint64_t>(64, budget_keys / 2) : budget_keys);
     if (nlvl > kMaxTreeLevels) return RBG_EARG;
@@ -566,11 +583,81 @@ int upload_tables_runs(rbg_index *ix) {
         for (size_t t = 0; t < T.size(); ++t) {
             uint32_t sh = 0;
             const double runs = static_cast<double>(std::max<uint64_t>(1, T[t].nruns));
-            while (sh < 40 && runs * static_cast<double>(uint64_t(2) << sh) <= 4.0 * static_cast<double>(h.n)) ++sh;
+            while (sh < 40 && runs * static_cast<double>(uint64_t(2) << sh) <= dir_target * static_cast<double>(h.n)) ++sh;
             dshift[t] = sh;
             doff[t + 1] = doff[t] + (h.n >> sh) + 2;
         }
-        const bool with_dir = use_dirs && doff[T.size()] < 0xFFFFFFF0ull;
+        // bucket records (rbg_dev.h RunRec): per table the widest bucket that holds at most rec_target runs on average
+        std::vector<uint32_t> rshift(T.size(), 0);
+        std::vector<uint64_t> roff(T.size() + 1, 0);
+        for (size_t t = 0; t < T.size(); ++t) {
+            uint32_t sh = 0;
+            const double runs = static_cast<double>(std::max<uint64_t>(1, T[t].nruns));
+            while (sh < kRecMaxShift && runs * static_cast<double>(uint64_t(2) << sh) <= rec_target * static_cast<double>(h.n)) ++sh;
+            rshift[t] = sh;
+            roff[t + 1] = roff[t] + (h.n >> sh) + 1;
+        }
+        const bool with_rec = use_recs && roff[T.size()] < 0xFFFFFFF0ull;
+        ix->dev.run_rec[d] = nullptr;
+        if (with_rec) {
+            std::vector<RunRec> recs(roff[T.size()]);
+            const size_t W = std::max<size_t>(1, std::min<size_t>({16, std::thread::hardware_concurrency(), T.size()}));
+            std::vector<std::thread> workers;
+            for (size_t w = 0; w < W; ++w)
+                workers.emplace_back([&, w] {
+                    for (size_t t = w; t < T.size(); t += W) {
+                        const SymTable &tb = T[t];
+                        RunRec *rt = recs.data() + roff[t];
+                        const uint64_t nb = roff[t + 1] - roff[t], width = uint64_t(1) << rshift[t];
+                        // entries 0 .. nruns of the table (the last is its sentinel {n, total}, a run of length 0)
+                        auto len_of = [&](uint64_t j) { return j < tb.nruns ? tb.cum[j + 1] - tb.cum[j] : uint64_t(0); };
+                        uint64_t g = 0;   // # entries that start below the bucket
+                        for (uint64_t b = 0; b < nb; ++b) {
+                            const uint64_t B = b << rshift[t];
+                            while (g <= tb.nruns && tb.start[g] < B) ++g;
+                            uint64_t e = g;   // entries that start inside the bucket: [g, e)
+                            while (e <= tb.nruns && tb.start[e] - B < width) ++e;
+                            const bool has_pred = g > 0;
+                            const uint64_t k = (has_pred ? 1 : 0) + (e - g);
+                            RunRec &r = rt[b];
+                            r.e0 = static_cast<uint32_t>(first[t] + (has_pred ? g - 1 : 0));
+                            r.base = 0;
+                            if (k > static_cast<uint64_t>(kRecRuns)) {
+                                r.flags = kRecOverflow | static_cast<uint32_t>(k);
+                                for (auto &pr : r.pair) pr = RunRecPair{kRecNoPair, 0};
+                                continue;
+                            }
+                            // cl: occurrences before the pair's run -- from `base` at 8-byte positions, absolute at 4-byte ones
+                            uint32_t np = 0;
+                            uint64_t cl = 0;   // relative to base
+                            uint64_t base = 0;
+                            if (has_pred) {
+                                const uint64_t gone = B - tb.start[g - 1], len = len_of(g - 1), used = std::min(gone, len);
+                                base = tb.cum[g - 1] + used;
+                                // the run continues into the bucket (or ends exactly at B): one position and one occurrence are
+                                // lent to the pair (off = -1); it ended earlier: an empty run
+                                const bool ended = gone > len;
+                                r.pair[np++] = RunRecPair{kRecPred, static_cast<uint32_t>((sizeof(P) == 4 ? base : 0) - (ended ? 0 : 1))};
+                                cl = std::min(len - used, width);
+                            }
+                            r.base = base;
+                            for (uint64_t j = g; j < e; ++j) {
+                                const uint64_t off = tb.start[j] - B;
+                                r.pair[np++] = RunRecPair{static_cast<uint32_t>(off), static_cast<uint32_t>((sizeof(P) == 4 ? base : 0) + cl)};
+                                cl += std::min(len_of(j), width - off);
+                            }
+                            for (; np <= static_cast<uint32_t>(kRecRuns); ++np) r.pair[np] = RunRecPair{kRecNoPair, static_cast<uint32_t>((sizeof(P) == 4 ? base : 0) + cl)};
+                            r.flags = static_cast<uint32_t>(k);
+                        }
+                    }
+                });
+            for (auto &w : workers) w.join();
+            const void *rp = nullptr;
+            if ((rc = dev_upload(ix, recs.data(), recs.size() * sizeof(RunRec), &rp))) return rc;
+            ix->dev.run_rec[d] = static_cast<const RunRec *>(rp);
+        }
+        // (with records the main kernels need no directory; the per-lane kernels use the first depth's)
+        const bool with_dir = use_dirs && (d == 0 || !with_rec) && doff[T.size()] < 0xFFFFFFF0ull;
         ix->dev.run_dir[d] = nullptr;
         if (with_dir) {
             std::vector<uint32_t> dir(doff[T.size()]);
@@ -596,7 +683,8 @@ int upload_tables_runs(rbg_index *ix) {
             ix->dev.run_dir[d] = static_cast<const uint32_t *>(dp);
         }
         for (size_t t = 0; t < T.size(); ++t)
-            tabs.push_back(DevRunTab{T[t].F, first[t], with_dir ? static_cast<uint32_t>(doff[t]) : 0u, with_dir ? dshift[t] : 0u});
+            tabs.push_back(with_rec ? DevRunTab{T[t].F, first[t], static_cast<uint32_t>(roff[t]), rshift[t]}
+                                    : DevRunTab{T[t].F, first[t], with_dir ? static_cast<uint32_t>(doff[t]) : 0u, with_dir ? dshift[t] : 0u});
         tabs.push_back(DevRunTab{0, entries, 0u, 0u});   // closing record: the last table's slice ends here
         if ((rc = upload_tree<P>(ix, d_ent, entries - 1, [&](uint64_t j) { return static_cast<uint64_t>(ent[j].start); }, nlvl, top_all, trees[d]))) return rc;
         if (d == 0)   // the per-lane kernels (seeding, windowed markers, single LF steps) search a symbol's own slice
@@ -2693,6 +2781,7 @@ int rbg_replicate(rbg_index *src, int device, rbg_index **out) {
     reloc.fix(d.phi_dir);
     for (int t = 0; t < kMaxRunDepth; ++t) reloc.fix(d.run_dir[t]);
     for (int t = 0; t < kMaxRunDepth; ++t) reloc.fix(d.run_samp[t]);
+    for (int t = 0; t < kMaxRunDepth; ++t) reloc.fix(d.run_rec[t]);
     reloc.fix(d.phi_tree.ent);
     for (int l = 0; l < kMaxTreeLevels; ++l) reloc.fix(d.phi_tree.lvl[l]);
     r->dev = d;

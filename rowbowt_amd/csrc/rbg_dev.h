@@ -127,6 +127,30 @@ struct DevRunTab {
     uint32_t dir_off;    // the table's directory starts at run_dir[depth][dir_off] ((n >> dir_shift) + 2 entries)
     uint32_t dir_shift;
 };
+// BUCKET RECORDS (RBG_RANK_REC): the directory and the runs it points at, fused.  One aligned 128-byte record per
+// directory bucket [B, B + W), W = 1 << shift, read by a 16-lane row with ONE coalesced request (8 bytes per lane):
+// lane 0 the header, lane 1 `base` = the rank at B, lanes 2-15 up to 14 PAIRS (off, cl): the run before the bucket, then
+// the runs that start inside it, then a closing pair.  A pair says "a run starts at B + off, and cl occurrences of the
+// k-mer precede it" -- cl counts from `base` at 8-byte positions and is the rank itself at 4-byte positions (one value
+// less to fetch) -- so the lane that holds the last pair with off < o = i - B (signed compare) computes the rank at i
+// by itself: cl + min(o - off, cl_next - cl), its right neighbour's cl arriving by DPP.  The run before the bucket is
+// stored as off = -1 and cl one below the rank at B (the run continues into the bucket: the arithmetic then yields
+// base + min(o, what is left of it), and "i inside the run" stays o - off <= cl_next - cl), or cl = the rank at B
+// with an empty run when it ended earlier.  Unused pairs carry off = INT32_MAX, never below an offset.  A bucket with
+// more than kRecRuns runs is flagged: the header's (e0, count) then send the search through the run list.
+// DevRunTab::dir_off / dir_shift are the table's first record and bucket shift when its depth has records.
+constexpr int kRecRuns = 13;
+struct RunRecPair { uint32_t off, cl; };
+struct RunRec {
+    uint32_t e0;       // entry index (in the depth's arrays) of the first pair: the run before the bucket, or the table's first run
+    uint32_t flags;    // bits 0-7 pairs in use; bit 31: too many runs -- bits 0-30 = candidates from e0 on
+    uint64_t base;     // rank at B
+    RunRecPair pair[kRecRuns + 1];
+};
+static_assert(sizeof(RunRec) == 128, "one 128-byte line per bucket");
+constexpr uint32_t kRecOverflow = 0x80000000u, kRecPred = 0xFFFFFFFFu, kRecNoPair = 0x7FFFFFFFu;
+constexpr uint32_t kRecMaxShift = 30;   // offsets and occurrence counts within a bucket stay below 2^31
+
 constexpr int kMaxRunDepth = 5;
 constexpr int kMaxRunTabs = kLdsSyms + 16 + 64 + 256 + 1024 + kMaxRunDepth;  // records staged in LDS by k_find_range_runs
 
@@ -193,6 +217,7 @@ struct DevIndex {
     const uint32_t *phi_dir;
     uint32_t phi_dir_shift;
     uint32_t pad5;
+    const RunRec *run_rec[kMaxRunDepth];  // per depth: the tables' bucket records back to back; nullptr = directory / descent
 };
 
 // What the instrumented instantiations count (sums over the launch; include/rbg.h rbg_search_stats_t mirrors it).

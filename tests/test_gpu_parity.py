@@ -501,14 +501,18 @@ def test_random_small_texts_every_layout(seed):
     seqs, off = ra.pack_reads(reads)
     wlo, whi, wk = o.find_range_w_toehold_batch(seqs, off)
     woff, wlocs = o.locs_at_batch(wlo, whi, wk)
-    for layout, ks, top_kb, pb in ((capi.LAYOUT_SLOTS, 5, 48, 0), (capi.LAYOUT_RUNS, 5, 48, 0), (capi.LAYOUT_RUNS, 2, 0, 8), (capi.LAYOUT_SLOTS, 3, 48, 8)):
+    for layout, ks, top_kb, pb, rec in ((capi.LAYOUT_SLOTS, 5, 48, 0, None), (capi.LAYOUT_RUNS, 5, 48, 0, None), (capi.LAYOUT_RUNS, 2, 0, 8, None),
+                                        (capi.LAYOUT_SLOTS, 3, 48, 8, None), (capi.LAYOUT_RUNS, 5, 48, 0, "2"), (capi.LAYOUT_RUNS, 3, 48, 8, "1")):
         ra.set_default_option(capi.OPT_KMER_STEPS, ks)
         ra.set_default_option(capi.OPT_POS_BYTES, pb)
+        if rec is not None:
+            os.environ["RBG_RANK_REC"] = rec   # bucket records (rbg_dev.h RunRec)
         try:
             rb = _with_layout(layout, top_kb, lambda: ra.RowBowt.from_runs(heads, lens, ssa, esa, device=0))
         finally:
             ra.set_default_option(capi.OPT_KMER_STEPS, 5)
             ra.set_default_option(capi.OPT_POS_BYTES, 0)
+            os.environ.pop("RBG_RANK_REC", None)
         lo, hi, k = rb.find_range_w_toehold(seqs, off)
         assert (lo == wlo).all() and (hi == whi).all() and (k == wk).all(), (layout, ks, body[:40])
         lo2, hi2 = rb.find_range(seqs, off)
@@ -1287,13 +1291,16 @@ def _with_layout(layout, top_kb, build):
         ra.set_default_option(capi.OPT_TREE_TOP_KB, 48)
 
 
-@pytest.mark.parametrize("pos_bytes,top_kb,fk,ks", [(0, 48, -1, 5), (8, 48, -1, 5), (0, 0, -1, 5), (8, 0, 3, 4), (0, 1, 0, 3), (0, 48, -1, 1),
-                                                    (8, 1, -1, 2), (0, 0, 0, 1)])
-def test_run_indexed_layout(synth, pos_bytes, top_kb, fk, ks):
+@pytest.mark.parametrize("pos_bytes,top_kb,fk,ks,rec", [(0, 48, -1, 5, None), (8, 48, -1, 5, None), (0, 0, -1, 5, "200"), (8, 0, 3, 4, None),
+                                                        (0, 1, 0, 3, None), (0, 48, -1, 1, "1"), (8, 1, -1, 2, "40"), (0, 0, 0, 1, "8"),
+                                                        (8, 48, 0, 5, "3"), (0, 48, 0, 5, "8")])
+def test_run_indexed_layout(synth, pos_bytes, top_kb, fk, ks, rec):
     """RBG_LAYOUT_RUNS (k_runs.hip): space proportional to r, rank and phi as wave-cooperative predecessor searches
     over the run lists (rle_string.hpp:131-161, toehold_sa.hpp:56-72), k-mer steps through one clamped search per
     depth (ks = symbols per step) -- same answers as the slot tables, i.e. as the oracle, on every read shape of
-    test_synth_all_paths; top_kb = 0 forces the deepest sampled index."""
+    test_synth_all_paths; top_kb = 0 forces the deepest sampled index.  rec: RBG_RANK_REC, the average number of runs
+    per bucket record (None: no records, directories and run lists only; a large value: most buckets overflow their
+    record and go through the run list; a small one: narrow buckets, clipped predecessors everywhere)."""
     S = synth
     ra.set_default_option(capi.OPT_POS_BYTES, pos_bytes)
     ra.set_default_option(capi.OPT_FTAB_K, fk)
@@ -1302,6 +1309,8 @@ def test_run_indexed_layout(synth, pos_bytes, top_kb, fk, ks):
         os.environ["RBG_PHI_DIR"] = "0"   # phi by the descent through the sampled levels only (no directory)
     if ks in (3, 4):
         os.environ["RBG_RANK_DIR"] = "0"  # ranks likewise
+    if rec is not None:
+        os.environ["RBG_RANK_REC"] = rec
     try:
         rb = _with_layout(capi.LAYOUT_RUNS, top_kb, lambda: ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0))
     finally:
@@ -1310,6 +1319,7 @@ def test_run_indexed_layout(synth, pos_bytes, top_kb, fk, ks):
         ra.set_default_option(capi.OPT_KMER_STEPS, 5)
         os.environ.pop("RBG_PHI_DIR", None)
         os.environ.pop("RBG_RANK_DIR", None)
+        os.environ.pop("RBG_RANK_REC", None)
     o = orc.Oracle.from_runs(S.heads, S.lens, S.ssa, S.esa)
     info = rb.info()
     assert info.rank_layout == capi.LAYOUT_RUNS and info.kmer_steps == ks and info.pos_bytes == (pos_bytes or 4)

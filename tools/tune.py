@@ -57,6 +57,14 @@ for cfg in args.configs.split(","):
     if os.environ.get("RBG_TUNE_LAYOUT"):   # "runs": the run-indexed layout (space proportional to r); optional sixth field of a config = LDS KB of its top level
         ra.set_default_option(capi.OPT_RANK_LAYOUT, capi.LAYOUT_RUNS if os.environ["RBG_TUNE_LAYOUT"] == "runs" else capi.LAYOUT_SLOTS)
         ra.set_default_option(capi.OPT_TREE_TOP_KB, parts[5] if len(parts) > 5 else 48)
+        if len(parts) > 6:   # seventh field: RBG_RANK_REC (runs per bucket record; 0 = directories and run lists only)
+            os.environ["RBG_RANK_REC"] = str(parts[6])
+        else:
+            os.environ.pop("RBG_RANK_REC", None)
+        if len(parts) > 7:   # eighth field: RBG_RANK_DIR_RUNS x 4 (runs per directory bucket, in quarters)
+            os.environ["RBG_RANK_DIR_RUNS"] = str(parts[7] / 4)
+        else:
+            os.environ.pop("RBG_RANK_DIR_RUNS", None)
     if os.environ.get("RBG_TUNE_BUDGET_MB"):
         ra.set_default_option(capi.OPT_HBM_BUDGET_MB, int(os.environ["RBG_TUNE_BUDGET_MB"]))
     t0 = time.time()
