@@ -300,6 +300,45 @@ __device__ __forceinline__ void coop_narrow_shfl(const DevTree *s_tree, const ui
     }
 }
 
+// The phi directory's probe by HALF-ROWS (K3's ordered walk): eight lanes serve an owner, each holding two consecutive
+// entries of the 16 from `start` on, so a pass takes eight rounds; the lane whose pair holds the last sampled position
+// below q computes phi's value base + (q - pos) itself and one value travels back.  t = start + # entries below q
+// (val undefined when t == start).  The owner's values reach its lanes by ds_bpermute: the chains walk in toehold order,
+// the probes of a wave overlap in memory, and there the request slots cost more than they save.
+template <typename P>
+__device__ __forceinline__ void coop_probe_phi8(const DevTree &T, const bool live, const uint32_t start, const P q, uint32_t &t, P &val) {
+    typedef typename PairOf<P>::vec vec;
+    constexpr int kHalf = kFan / 2;
+    const uint32_t lane = threadIdx.x & (kWave - 1), sub = lane & (kHalf - 1), gbase = lane & ~static_cast<uint32_t>(kHalf - 1);
+    if (!__ballot(live)) return;
+    const uint32_t info = (live ? 0x80000000u : 0u) | (start & 0x7FFFFFFFu);   // (fewer than 2^31 sampled positions: upload() checks)
+    vec ve[kHalf], vo[kHalf];
+#pragma unroll
+    for (int j = 0; j < kHalf; ++j) {
+        const uint32_t oi = row_get(info, gbase, j);
+        ve[j] = vec{static_cast<P>(~P(0)), 0};
+        vo[j] = ve[j];
+        if (oi & 0x80000000u) {
+            uint64_t g0 = static_cast<uint64_t>(oi & 0x7FFFFFFFu) + 2u * sub, g1 = g0 + 1;
+            if (g0 > T.m) g0 = T.m;   // entry m is the sentinel (never below a query)
+            if (g1 > T.m) g1 = T.m;
+            ve[j] = static_cast<const vec *>(T.ent)[g0];
+            vo[j] = static_cast<const vec *>(T.ent)[g1];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kHalf; ++j) {
+        const P oq = row_get(q, gbase, j);
+        const P ke = static_cast<P>(ve[j].x), ko = static_cast<P>(vo[j].x);
+        const bool be = ke < oq, bo = ko < oq;
+        const uint64_t me = __ballot(be), mo = __ballot(bo);
+        const uint32_t c = static_cast<uint32_t>(__popc(static_cast<uint32_t>(me >> gbase) & 0xFFu) + __popc(static_cast<uint32_t>(mo >> gbase) & 0xFFu));
+        const P v = bo ? static_cast<P>(vo[j].y) + (oq - ko) : static_cast<P>(ve[j].y) + (oq - ke);
+        const P a_v = row_pick(v, gbase, c ? (c - 1) >> 1 : 0);
+        if (static_cast<int>(sub) == j && live) { t = start + c; val = a_v; }
+    }
+}
+
 // The phi directory's probe with request slots: the row's lanes load the z candidates start .. start + z - 1 of the
 // owner's position (lanes beyond them re-read the last one: the probe touches only the sectors that hold them), the lane
 // that holds the last sampled position below q computes phi's value base + (q - pos) itself, and t = start + # of them
@@ -1051,7 +1090,8 @@ __global__ __launch_bounds__(256, sizeof(P) == 4 ? 4 : 3) void k_locate_fill_run
                     // a crowded bucket is narrowed by pivot probes first (coop_narrow), as the ranks' are
                     if (ORDERED) {
                         while (__ballot(coop && z > static_cast<uint32_t>(kFan))) coop_narrow_shfl<P>(s_tree, 0u, coop && z > static_cast<uint32_t>(kFan), start, z, static_cast<P>(k1));
-                        coop_probe_at<P>(s_tree[0], coop, start, static_cast<P>(k1), tq, pk, pv);
+                        coop_probe_phi8<P>(s_tree[0], coop, start, static_cast<P>(k1), tq, pval);
+                        by_dir = coop;
                     } else {
                         while (__ballot(coop && z > static_cast<uint32_t>(kFan))) coop_narrow<P>(s_tree, req, 0u, coop && z > static_cast<uint32_t>(kFan), start, z, static_cast<P>(k1));
                         coop_probe_phi<P>(s_tree[0], req, coop, start, z, static_cast<P>(k1), tq, pval);
