@@ -6,6 +6,11 @@
 // coalesced request (64 B of keys, 128 B of {key, value} pairs at 4-byte positions), compares, ballots and counts;
 // four queries per load instruction, all sixteen rounds of a level in flight together.  One lane still owns one
 // read (K1/K2) or one phi chain (K3); lanes whose own work is finished keep serving the others' probes.
+// With the directories (the default) a rank is one directory gather and ONE probe of the run list from the entry
+// the directory names; those probes are made by smaller groups -- quads at 4-byte positions (four entries per lane,
+// everything cross-lane by DPP), half-rows at 8-byte ones and on phi's ordered walk (two entries per lane) -- and the
+// lane that holds the run computes the rank or phi's value itself: the first version of these kernels (16-lane rows,
+// every value by ds_bpermute) was bound by the LDS pipe, not by memory (profiles/).
 #include "rbg_device.hpp"
 
 namespace rbg {
@@ -425,124 +430,18 @@ __device__ __forceinline__ void coop_narrow(const DevTree *s_tree, uint4 *req, c
     }
 }
 
-// The two ranks of an LF step through the directories (K1/K2), with request slots and in-row ranks: position 0 is answered
-// from entries s0 .. s0 + 15 of which the first z0 are candidates (the rest lie beyond the bucket, possibly in the next
-// table's slice), position 1 likewise from s1 / z1 -- sharing the load when s1 == s0.  Returns for each
-// position t = s + # candidates below it, the RANK rk = cum[t-1] + min(q - start[t-1], cum[t] - cum[t-1]) (valid when
-// t > s or an entry precedes s) and, for the second position, whether it lies inside that run (q - start <= length: the
-// toehold test of the caller).  The row's lanes beyond the candidates re-read the entry after the last one, so a probe
-// touches only the sectors that hold its z + 1 entries.  req: the wave's request area (64 x ReqSlots<P>::v x 16 bytes).
-template <typename P>
-__device__ __forceinline__ void coop_probe2_rank(const DevTree *s_tree, uint4 *req, const uint32_t tid, const bool live, const uint32_t s0, const uint32_t z0,
-                                                 const uint32_t s1, const uint32_t z1, const P q0, const P q1, uint32_t &t0, uint32_t &t1, P &rk0,
-                                                 P &rk1, bool &ins1) {
-    typedef typename PairOf<P>::vec vec;
-    constexpr int NS = ReqSlots<P>::v;
-    const uint32_t lane = threadIdx.x & (kWave - 1), sub = lane & (kFan - 1), rowbase = lane & ~static_cast<uint32_t>(kFan - 1);
-    const uint64_t m_live = __ballot(live);
-    if (!m_live) return;
-    const bool two = live && s1 != s0;
-    // bit 0 live, bit 1 second block, bits 2-4 tree, bits 5-9 z0, 10-14 z1
-    const uint32_t info = (live ? 1u : 0u) | (two ? 2u : 0u) | (tid << 2) | (z0 << 5) | (z1 << 10);
-    wave_lds_sync();   // (the area's previous readers are done)
-    req[lane * NS + 0] = make_uint4(s0, info, static_cast<uint32_t>(q0), static_cast<uint32_t>(q1));
-    req[lane * NS + 1] = make_uint4(s1, info, static_cast<uint32_t>(q1), static_cast<uint32_t>(static_cast<uint64_t>(q1) >> 32));
-    if (sizeof(P) == 8) req[lane * NS + (NS - 1)] = make_uint4(static_cast<uint32_t>(static_cast<uint64_t>(q0) >> 32), static_cast<uint32_t>(static_cast<uint64_t>(q1) >> 32), 0u, 0u);
-    wave_lds_sync();
-    bool fix0 = false, fix1 = false;
-    vec va[kFan];
-#pragma unroll
-    for (int j = 0; j < kFan; ++j) {
-        if (!round_has_owner(m_live, j)) continue;
-        const uint4 a = req[(rowbase + j) * NS + 0];
-        va[j] = vec{static_cast<P>(~P(0)), 0};
-        if (a.y & 1u) {
-            const DevTree &T = s_tree[(a.y >> 2) & 7u];
-            const uint32_t za = (a.y >> 5) & 31u, zb = (a.y & 2u) ? 0u : (a.y >> 10) & 31u;
-            uint32_t zc = za > zb ? za : zb;                      // entries 0 .. zc of the stretch are needed (zc: the one after the last candidate)
-            if (zc > static_cast<uint32_t>(kFan - 1)) zc = kFan - 1;
-            uint64_t i = static_cast<uint64_t>(a.x) + (sub < zc ? sub : zc);
-            if (i > T.m) i = T.m;                                  // entry m is the last sentinel
-            va[j] = static_cast<const vec *>(T.ent)[i];
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < kFan; ++j) {
-        if (!round_has_owner(m_live, j)) continue;
-        const uint4 a = req[(rowbase + j) * NS + 0];
-        P oq0 = static_cast<P>(a.z), oq1 = static_cast<P>(a.w);
-        if (sizeof(P) == 8) {
-            const uint4 c = req[(rowbase + j) * NS + (NS - 1)];
-            oq0 = static_cast<P>((static_cast<uint64_t>(c.x) << 32) | a.z);
-            oq1 = static_cast<P>((static_cast<uint64_t>(c.y) << 32) | a.w);
-        }
-        const P key = static_cast<P>(va[j].x), cum = static_cast<P>(va[j].y);
-        const P len = row_next(cum) - cum;                         // (lane 15: fixed up by the owner below)
-        const uint32_t c0 = row_count(sub < ((a.y >> 5) & 31u) && key < oq0, rowbase);
-        const uint32_t c1 = row_count(sub < ((a.y >> 10) & 31u) && key < oq1, rowbase);
-        const P d0 = oq0 - key, d1 = oq1 - key;
-        const P r0 = cum + (d0 < len ? d0 : len), r1 = cum + (d1 < len ? d1 : len);
-        const uint64_t in1 = __ballot(d1 <= len);
-        const uint32_t p0 = c0 ? c0 - 1 : 0, p1 = c1 ? c1 - 1 : 0;
-        const P a_r0 = row_pick(r0, rowbase, p0), a_r1 = row_pick(r1, rowbase, p1);
-        if (static_cast<int>(sub) == j && live) {
-            t0 = s0 + c0; rk0 = a_r0; fix0 = c0 == kFan;
-            if (!two) { t1 = s1 + c1; rk1 = a_r1; ins1 = ((in1 >> (rowbase + p1)) & 1u) != 0; fix1 = c1 == kFan; }
-        }
-    }
-    const uint64_t m_two = __ballot(two);
-    if (m_two) {
-#pragma unroll
-        for (int j = 0; j < kFan; ++j) {
-            if (!round_has_owner(m_two, j)) continue;
-            const uint4 b = req[(rowbase + j) * NS + 1];
-            va[j] = vec{static_cast<P>(~P(0)), 0};
-            if (b.y & 2u) {
-                const DevTree &T = s_tree[(b.y >> 2) & 7u];
-                uint32_t zc = (b.y >> 10) & 31u;
-                if (zc > static_cast<uint32_t>(kFan - 1)) zc = kFan - 1;
-                uint64_t i = static_cast<uint64_t>(b.x) + (sub < zc ? sub : zc);
-                if (i > T.m) i = T.m;
-                va[j] = static_cast<const vec *>(T.ent)[i];
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < kFan; ++j) {
-            if (!round_has_owner(m_two, j)) continue;
-            const uint4 b = req[(rowbase + j) * NS + 1];
-            const P oq1 = sizeof(P) == 8 ? static_cast<P>((static_cast<uint64_t>(b.w) << 32) | b.z) : static_cast<P>(b.z);
-            const P key = static_cast<P>(va[j].x), cum = static_cast<P>(va[j].y);
-            const P len = row_next(cum) - cum;
-            const uint32_t c1 = row_count(sub < ((b.y >> 10) & 31u) && key < oq1, rowbase);
-            const P d1 = oq1 - key;
-            const P r1 = cum + (d1 < len ? d1 : len);
-            const uint64_t in1 = __ballot(d1 <= len);
-            const uint32_t p1 = c1 ? c1 - 1 : 0;
-            const P a_r1 = row_pick(r1, rowbase, p1);
-            if (static_cast<int>(sub) == j && two) { t1 = s1 + c1; rk1 = a_r1; ins1 = ((in1 >> (rowbase + p1)) & 1u) != 0; fix1 = c1 == kFan; }
-        }
-    }
-    if (fix0 || fix1) {   // all 16 loaded entries lie below the position: the run it lands in ends in the next block
-        const vec *__restrict__ ent = static_cast<const vec *>(s_tree[tid].ent);
-        if (fix0) {
-            const vec e = ent[t0 - 1];
-            const P len = static_cast<P>(ent[t0].y) - static_cast<P>(e.y), d = q0 - static_cast<P>(e.x);
-            rk0 = static_cast<P>(e.y) + (d < len ? d : len);
-        }
-        if (fix1) {
-            const vec e = ent[t1 - 1];
-            const P len = static_cast<P>(ent[t1].y) - static_cast<P>(e.y), d = q1 - static_cast<P>(e.x);
-            rk1 = static_cast<P>(e.y) + (d < len ? d : len);
-            ins1 = d <= len;
-        }
-    }
-}
-
-// coop_probe2_rank with HALF-ROWS: eight lanes serve an owner, each holding TWO consecutive entries of its stretch, so a
-// wave-wide load instruction serves eight owners and a pass takes eight rounds instead of sixteen -- the per-round
-// cost (request read, ballots, the value's way back) is what bounds these kernels once the LDS traffic is gone.  The
-// lane whose pair holds the last entry below the position computes the rank (the odd entry's length needs the next
-// lane's even count: DPP; entry 15's is fetched by the owner when all sixteen lie below).  Same contract as above.
+// The two ranks of an LF step through the directories (K1/K2 at 8-byte positions): position 0 is answered from entries
+// s0 .. s0 + 15 of which the first z0 are candidates (the rest lie beyond the bucket, possibly in the next table's
+// slice), position 1 likewise from s1 / z1 -- sharing the load when s1 == s0.  Returns for each position t = s + #
+// candidates below it, the RANK rk = cum[t-1] + min(q - start[t-1], cum[t] - cum[t-1]) (valid when t > s or an entry
+// precedes s) and, for the second position, whether it lies inside that run (q - start <= length: the toehold test of
+// the caller).  The lanes beyond the candidates re-read the entry after the last one, so a probe touches only the
+// sectors that hold its z + 1 entries.  req: the wave's request area (64 x ReqSlots<P>::v x 16 bytes).
+// HALF-ROWS: eight lanes serve an owner, each holding TWO consecutive entries of its stretch, so a wave-wide load
+// instruction serves eight owners and a pass takes eight rounds instead of sixteen -- the per-round cost (request
+// read, ballots, the value's way back) is what bounds these kernels once the LDS traffic is gone.  The lane whose pair
+// holds the last entry below the position computes the rank (the odd entry's length needs the next lane's even count:
+// DPP; entry 15's is fetched by the owner when all sixteen lie below).
 __device__ __forceinline__ bool round_has_owner8(uint64_t m, int j) { return (m & (0x0101010101010101ull << j)) != 0; }
 
 template <typename P>
@@ -654,6 +553,164 @@ __device__ __forceinline__ void coop_probe2_rank8(const DevTree *s_tree, uint4 *
             const P a_r1 = row_pick(r1, gbase, p1);
             if (static_cast<int>(sub) == j && two) { t1 = s1 + c1; rk1 = a_r1; ins1 = ((in1 >> (gbase + p1)) & 1u) != 0; fix1 = c1 == kFan; }
         }
+    }
+    if (fix0 || fix1) {   // all 16 loaded entries lie below the position: the run it lands in ends in the next block
+        const vec *__restrict__ ent = static_cast<const vec *>(s_tree[tid].ent);
+        if (fix0) {
+            const vec e = ent[t0 - 1];
+            const P len = static_cast<P>(ent[t0].y) - static_cast<P>(e.y), d = q0 - static_cast<P>(e.x);
+            rk0 = static_cast<P>(e.y) + (d < len ? d : len);
+        }
+        if (fix1) {
+            const vec e = ent[t1 - 1];
+            const P len = static_cast<P>(ent[t1].y) - static_cast<P>(e.y), d = q1 - static_cast<P>(e.x);
+            rk1 = static_cast<P>(e.y) + (d < len ? d : len);
+            ins1 = d <= len;
+        }
+    }
+}
+
+// QUADS: four lanes serve an owner, each holding FOUR consecutive entries of its stretch, so one wave-wide load
+// instruction serves sixteen owners and a pass takes four rounds -- and everything the owner and its lanes tell each
+// other travels by DPP quad permutes (a VALU move: no LDS traffic, no request area, no synchronisation): in round J
+// the owner is lane J of each quad, its values are broadcast with quad_perm:[J,J,J,J], the number of candidates below
+// the position is a quad sum, and the rank computed by the lane that holds the run comes back as a quad OR (the other
+// three lanes contribute 0).  Same contract as coop_probe2_rank8; used at 4-byte positions, where a lane's four entries
+// are two 16-byte requests.
+template <int J> __device__ __forceinline__ uint32_t quad_get(uint32_t v) {
+    return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), J * 0x55, 0xF, 0xF, false));
+}
+template <int J> __device__ __forceinline__ uint64_t quad_get(uint64_t v) {
+    return (static_cast<uint64_t>(quad_get<J>(static_cast<uint32_t>(v >> 32))) << 32) | quad_get<J>(static_cast<uint32_t>(v));
+}
+template <int CTRL> __device__ __forceinline__ uint32_t quad_perm(uint32_t v) {
+    return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ uint32_t quad_sum(uint32_t v) {
+    v += quad_perm<0xB1>(v);   // [1,0,3,2]
+    v += quad_perm<0x4E>(v);   // [2,3,0,1]
+    return v;
+}
+__device__ __forceinline__ uint32_t quad_or(uint32_t v) {
+    v |= quad_perm<0xB1>(v);
+    v |= quad_perm<0x4E>(v);
+    return v;
+}
+__device__ __forceinline__ uint64_t quad_or(uint64_t v) {
+    return (static_cast<uint64_t>(quad_or(static_cast<uint32_t>(v >> 32))) << 32) | quad_or(static_cast<uint32_t>(v));
+}
+__device__ __forceinline__ bool round_has_owner4(uint64_t m, int j) { return (m & (0x1111111111111111ull << j)) != 0; }
+
+// the four entries start + 4 * sub .. + 3 of the owner's stretch (clamped to entry zc of the stretch and to the array's sentinel)
+template <typename P, int J>
+__device__ __forceinline__ void quad_load(const DevTree *s_tree, const uint32_t sub, const uint32_t start, const uint32_t info, const bool second,
+                                          typename PairOf<P>::vec (&e)[4]) {
+    typedef typename PairOf<P>::vec vec;
+    const uint32_t os = quad_get<J>(start), oi = quad_get<J>(info);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) e[i] = vec{static_cast<P>(~P(0)), 0};
+    if (oi & (second ? 2u : 1u)) {
+        const DevTree &T = s_tree[(oi >> 2) & 7u];
+        const uint32_t za = second ? 0u : (oi >> 5) & 31u, zb = (!second && (oi & 2u)) ? 0u : (oi >> 10) & 31u;
+        uint32_t zc = za > zb ? za : zb;                      // entries 0 .. zc of the stretch are needed (zc: the one after the last candidate)
+        if (zc > static_cast<uint32_t>(kFan - 1)) zc = kFan - 1;
+        if (sizeof(P) == 4) {
+            // two entries per request (16 bytes at any 8-byte boundary; the arrays end with one spare entry after the sentinel)
+            typedef unsigned int vec4 __attribute__((ext_vector_type(4), aligned(8)));
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t idx = 4u * sub + 2u * h;
+                uint64_t g = static_cast<uint64_t>(os) + (idx < zc ? idx : zc);
+                if (g > T.m) g = T.m;                          // entry m is the last sentinel
+                const vec4 w = *reinterpret_cast<const vec4 *>(static_cast<const vec *>(T.ent) + g);
+                e[2 * h] = vec{static_cast<P>(w.x), static_cast<P>(w.y)};
+                e[2 * h + 1] = vec{static_cast<P>(w.z), static_cast<P>(w.w)};
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t idx = 4u * sub + i;
+                uint64_t g = static_cast<uint64_t>(os) + (idx < zc ? idx : zc);
+                if (g > T.m) g = T.m;
+                e[i] = static_cast<const vec *>(T.ent)[g];
+            }
+        }
+    }
+}
+
+// one position against the quad's sixteen entries: c = # candidates (the first z entries) below q, rk = the rank, ins = q inside that run
+template <typename P>
+__device__ __forceinline__ void quad_rank(const uint32_t sub, const typename PairOf<P>::vec (&e)[4], const P next_cum, const uint32_t z, const P q,
+                                          uint32_t &c, P &rk, bool &ins) {
+    uint32_t n = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) n += (4u * sub + i < z && static_cast<P>(e[i].x) < q) ? 1u : 0u;
+    c = quad_sum(n);
+    const bool mine = n > 0 && ((c - 1) >> 2) == sub;          // the last entry below q is this lane's n-th
+    // this lane's n-th entry and the count of the one after it (the next lane's first for the fourth)
+    P k = static_cast<P>(e[0].x), v = static_cast<P>(e[0].y), vn = static_cast<P>(e[1].y);
+    if (n == 2u) { k = static_cast<P>(e[1].x); v = static_cast<P>(e[1].y); vn = static_cast<P>(e[2].y); }
+    if (n == 3u) { k = static_cast<P>(e[2].x); v = static_cast<P>(e[2].y); vn = static_cast<P>(e[3].y); }
+    if (n == 4u) { k = static_cast<P>(e[3].x); v = static_cast<P>(e[3].y); vn = next_cum; }
+    const P l = vn - v;
+    const P d = q - k;
+    const P r = v + (d < l ? d : l);
+    rk = quad_or(mine ? r : P(0));
+    ins = quad_or((mine && d <= l) ? 1u : 0u) != 0;
+}
+
+template <typename P, int J>
+__device__ __forceinline__ void quad_round(const uint32_t sub, const bool second, const bool live, const bool two, const uint32_t s0, const uint32_t s1,
+                                           const uint32_t info, const P q0, const P q1, const typename PairOf<P>::vec (&e)[4], uint32_t &t0, uint32_t &t1,
+                                           P &rk0, P &rk1, bool &ins1, bool &fix0, bool &fix1) {
+    const uint32_t oi = quad_get<J>(info);
+    const P oq0 = quad_get<J>(q0), oq1 = quad_get<J>(q1);
+    const P next_cum = row_next(static_cast<P>(e[0].y));   // (the quad's last lane: entry 15's run, fixed up by the owner)
+    uint32_t c0 = 0, c1 = 0;
+    P a_r0 = 0, a_r1 = 0;
+    bool a_i0 = false, a_i1 = false;
+    if (!second) quad_rank<P>(sub, e, next_cum, (oi >> 5) & 31u, oq0, c0, a_r0, a_i0);
+    quad_rank<P>(sub, e, next_cum, (oi >> 10) & 31u, oq1, c1, a_r1, a_i1);
+    if (static_cast<int>(sub) == J) {
+        if (!second && live) {
+            t0 = s0 + c0; rk0 = a_r0; fix0 = c0 == kFan;
+            if (!two) { t1 = s1 + c1; rk1 = a_r1; ins1 = a_i1; fix1 = c1 == kFan; }
+        }
+        if (second && two) { t1 = s1 + c1; rk1 = a_r1; ins1 = a_i1; fix1 = c1 == kFan; }
+    }
+}
+
+template <typename P>
+__device__ __forceinline__ void coop_probe2_rank4(const DevTree *s_tree, const uint32_t tid, const bool live, const uint32_t s0, const uint32_t z0,
+                                                  const uint32_t s1, const uint32_t z1, const P q0, const P q1, uint32_t &t0, uint32_t &t1, P &rk0,
+                                                  P &rk1, bool &ins1) {
+    typedef typename PairOf<P>::vec vec;
+    const uint32_t lane = threadIdx.x & (kWave - 1), sub = lane & 3u;
+    const uint64_t m_live = __ballot(live);
+    if (!m_live) return;
+    const bool two = live && s1 != s0;
+    // bit 0 live, bit 1 second block, bits 2-4 tree, bits 5-9 z0, 10-14 z1
+    const uint32_t info = (live ? 1u : 0u) | (two ? 2u : 0u) | (tid << 2) | (z0 << 5) | (z1 << 10);
+    bool fix0 = false, fix1 = false;
+    vec e0[4], e1[4], e2[4], e3[4];
+    if (round_has_owner4(m_live, 0)) quad_load<P, 0>(s_tree, sub, s0, info, false, e0);
+    if (round_has_owner4(m_live, 1)) quad_load<P, 1>(s_tree, sub, s0, info, false, e1);
+    if (round_has_owner4(m_live, 2)) quad_load<P, 2>(s_tree, sub, s0, info, false, e2);
+    if (round_has_owner4(m_live, 3)) quad_load<P, 3>(s_tree, sub, s0, info, false, e3);
+    if (round_has_owner4(m_live, 0)) quad_round<P, 0>(sub, false, live, two, s0, s1, info, q0, q1, e0, t0, t1, rk0, rk1, ins1, fix0, fix1);
+    if (round_has_owner4(m_live, 1)) quad_round<P, 1>(sub, false, live, two, s0, s1, info, q0, q1, e1, t0, t1, rk0, rk1, ins1, fix0, fix1);
+    if (round_has_owner4(m_live, 2)) quad_round<P, 2>(sub, false, live, two, s0, s1, info, q0, q1, e2, t0, t1, rk0, rk1, ins1, fix0, fix1);
+    if (round_has_owner4(m_live, 3)) quad_round<P, 3>(sub, false, live, two, s0, s1, info, q0, q1, e3, t0, t1, rk0, rk1, ins1, fix0, fix1);
+    const uint64_t m_two = __ballot(two);
+    if (m_two) {
+        if (round_has_owner4(m_two, 0)) quad_load<P, 0>(s_tree, sub, s1, info, true, e0);
+        if (round_has_owner4(m_two, 1)) quad_load<P, 1>(s_tree, sub, s1, info, true, e1);
+        if (round_has_owner4(m_two, 2)) quad_load<P, 2>(s_tree, sub, s1, info, true, e2);
+        if (round_has_owner4(m_two, 3)) quad_load<P, 3>(s_tree, sub, s1, info, true, e3);
+        if (round_has_owner4(m_two, 0)) quad_round<P, 0>(sub, true, live, two, s0, s1, info, q0, q1, e0, t0, t1, rk0, rk1, ins1, fix0, fix1);
+        if (round_has_owner4(m_two, 1)) quad_round<P, 1>(sub, true, live, two, s0, s1, info, q0, q1, e1, t0, t1, rk0, rk1, ins1, fix0, fix1);
+        if (round_has_owner4(m_two, 2)) quad_round<P, 2>(sub, true, live, two, s0, s1, info, q0, q1, e2, t0, t1, rk0, rk1, ins1, fix0, fix1);
+        if (round_has_owner4(m_two, 3)) quad_round<P, 3>(sub, true, live, two, s0, s1, info, q0, q1, e3, t0, t1, rk0, rk1, ins1, fix0, fix1);
     }
     if (fix0 || fix1) {   // all 16 loaded entries lie below the position: the run it lands in ends in the next block
         const vec *__restrict__ ent = static_cast<const vec *>(s_tree[tid].ent);
@@ -931,7 +988,8 @@ __global__ __launch_bounds__(512, sizeof(P) == 4 ? 4 : 3) void k_find_range_runs
                 coop_narrow<P>(s_tree, req, d, direct && z0 > static_cast<uint32_t>(kFan), s0, z0, static_cast<P>(q0));
                 coop_narrow<P>(s_tree, req, d, direct && z1 > static_cast<uint32_t>(kFan), s1, z1, static_cast<P>(q1));
             }
-            coop_probe2_rank8<P>(s_tree, req, d, direct, s0, z0, s1, z1, static_cast<P>(q0), static_cast<P>(q1), t0, t1, rk0, rk1, ins1);
+            if (sizeof(P) == 4) coop_probe2_rank4<P>(s_tree, d, direct, s0, z0, s1, z1, static_cast<P>(q0), static_cast<P>(q1), t0, t1, rk0, rk1, ins1);
+            else coop_probe2_rank8<P>(s_tree, req, d, direct, s0, z0, s1, z1, static_cast<P>(q0), static_cast<P>(q1), t0, t1, rk0, rk1, ins1);
             if (__ballot(descend)) {   // crowded buckets (and indexes without directories): the clamped descent
                 uint32_t d0 = 0, d1 = 0;
                 P ak0 = 0, av0 = 0, an0 = 0, ak1 = 0, av1 = 0, an1 = 0;

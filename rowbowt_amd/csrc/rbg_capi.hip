@@ -549,7 +549,7 @@ int upload_tables_runs(rbg_index *ix) {
         // the depth's tables back to back: entries {start, cum} (each table ends with its sentinel {n, total}), samples alongside
         const std::vector<SymTable> &T = *depth[d];
         const uint64_t entries = sizes[d];
-        std::vector<RunEnt<P>> ent(entries);
+        std::vector<RunEnt<P>> ent(entries + 1);   // (one spare entry after the last sentinel: the kernels' two-entry loads may touch it)
         std::vector<P> samp(h.has_tsa ? entries : 0);
         std::vector<uint64_t> first(T.size() + 1, 0);
         for (size_t t = 0; t < T.size(); ++t) first[t + 1] = first[t] + T[t].nruns + 1;
@@ -562,6 +562,7 @@ int upload_tables_runs(rbg_index *ix) {
                         const SymTable &tb = T[t];
                         RunEnt<P> *e = ent.data() + first[t];
                         for (uint64_t k = 0; k <= tb.nruns; ++k) { e[k].start = static_cast<P>(tb.start[k]); e[k].cum = static_cast<P>(tb.cum[k]); }
+                        if (t + 1 == T.size()) e[tb.nruns + 1] = e[tb.nruns];
                         if (h.has_tsa) {
                             P *sp = samp.data() + first[t];
                             for (uint64_t k = 0; k < tb.nruns; ++k) sp[k] = static_cast<P>(tb.samp[k]);
