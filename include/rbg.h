@@ -395,7 +395,8 @@ int rbg_sample_reads_dev(const uint8_t *d_text, uint64_t unit, uint64_t H, uint6
 /* Environment switches (read at load or per call; none of them changes an answer -- they exist for A/B measurements
  * and for the tests that pin both sides):  RBG_PHI_PACKED=0 keeps 32-byte phi slots at 8-byte positions;
  * RBG_RANK_DIR=0 / RBG_PHI_DIR=0 build the run-indexed layout without its rank / phi directories (descent through
- * the sampled levels only);  RBG_HOST_THREADS, RBG_HOST_CHUNK_READS, RBG_HOST_DIRECT_OUT=0, RBG_HOST_COMBINE=0,
+ * the sampled levels only), RBG_RANK_DIR_RUNS=<x> sets the runs per rank-directory bucket (default 4),
+ * RBG_RANK_REC=<t> adds bucket records with at most t runs each (off by default: DESIGN.md 2c);  RBG_HOST_THREADS, RBG_HOST_CHUNK_READS, RBG_HOST_DIRECT_OUT=0, RBG_HOST_COMBINE=0,
  * RBG_HOST_TRACE=1|2 tune / trace the host-pointer pipeline;  RBG_VERBOSE=1 prints what the budget
  * rule did. */
 enum { RBG_OPT_BLOCK_THREADS = 1, RBG_OPT_RANK_BUCKET_SHIFT = 2, RBG_OPT_PHI_BUCKET_SHIFT = 3, RBG_OPT_POS_BYTES = 4,
