@@ -1362,6 +1362,67 @@ def test_run_indexed_layout(synth, pos_bytes, top_kb, fk, ks, rec):
     o.close()
 
 
+@pytest.mark.parametrize("pos_bytes,rec,dir_runs", [(0, None, None), (8, None, "64"), (0, None, "64"), (0, "6", None), (8, "3", None)])
+def test_run_indexed_crowded_buckets(pos_bytes, rec, dir_runs):
+    """Directory buckets with a hundred and more runs (k_runs.hip: narrowing rounds, one after the other when the
+    directory is coarse -- dir_runs = RBG_RANK_DIR_RUNS; probes whose sixteen candidates all lie below the position;
+    bucket records that overflow) beside buckets with none: a text that is 2 000 bases repeated 300 times, then
+    1 500 x (one of A,C,G,T + the same 14-mer + 10 random bases) -- the rows of the suffixes that start with the 14-mer
+    are consecutive and their BWT symbols change at nearly every row, while the average run is 39 rows long and sets
+    the bucket width.  Quads at 4-byte positions, half-rows at 8."""
+    import naive
+    rng = np.random.default_rng(7)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    block, x = acgt[rng.integers(0, 4, 2000)], acgt[rng.integers(0, 4, 14)]
+    parts = [block] * 300 + [np.concatenate([acgt[[i % 4]], x, acgt[rng.integers(0, 4, 10)]]) for i in range(1500)]
+    text = np.concatenate(parts + [np.array([1], np.uint8)])
+    n, dense_at = len(text), 2000 * 300
+    sa = naive.suffix_array(text)
+    heads, lens, brk = naive.rle(naive.bwt_from_sa(text, sa))
+    ssa, esa = naive.run_samples(sa, brk, n)
+    starts = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
+    crowded = 0
+    for c in b"ACGT":   # the directory's rule (rbg_capi.hip upload_tables_runs): at most dir_runs (4) runs per bucket on average
+        st = starts[heads == c]
+        sh = 0
+        while len(st) * (2 << sh) <= float(dir_runs or 4) * n:
+            sh += 1
+        crowded = max(crowded, int(np.bincount(st >> sh).max()))
+    assert crowded > (256 if dir_runs else 64), crowded   # one narrowing round at least; two with the coarse directory
+    ra.set_default_option(capi.OPT_POS_BYTES, pos_bytes)
+    if rec is not None:
+        os.environ["RBG_RANK_REC"] = rec
+    if dir_runs is not None:
+        os.environ["RBG_RANK_DIR_RUNS"] = dir_runs
+    try:
+        rb = _with_layout(capi.LAYOUT_RUNS, 48, lambda: ra.RowBowt.from_runs(heads, lens, ssa, esa, device=0))
+    finally:
+        ra.set_default_option(capi.OPT_POS_BYTES, 0)
+        os.environ.pop("RBG_RANK_REC", None)
+        os.environ.pop("RBG_RANK_DIR_RUNS", None)
+    o = orc.Oracle.from_runs(heads, lens, ssa, esa)
+    assert rb.info().rank_layout == capi.LAYOUT_RUNS and rb.info().pos_bytes == (pos_bytes or 4)
+    reads = []
+    for _ in range(6000):   # reads across the 14-mer's occurrences (every length, so that ranges end inside the crowded rows) ...
+        a = dense_at + int(rng.integers(0, 1500 * 25 - 30))
+        reads.append(text[a:a + int(rng.integers(1, 31))].tobytes())
+    for _ in range(2000):   # ... and from the repeats (rows in buckets without a run)
+        a = int(rng.integers(0, dense_at - 80))
+        reads.append(text[a:a + int(rng.integers(1, 80))].tobytes())
+    reads += [x.tobytes(), x[1:].tobytes(), x[:-1].tobytes(), b"A" + x.tobytes(), x.tobytes() + b"C"]
+    seqs, off = ra.pack_reads(reads)
+    lo, hi, k = rb.find_range_w_toehold(seqs, off)
+    lo1, hi1 = rb.find_range(seqs, off)
+    wlo, whi, wk = o.find_range_w_toehold_batch(seqs, off)
+    assert (lo == wlo).all() and (hi == whi).all() and (k == wk).all()
+    assert (lo1 == wlo).all() and (hi1 == whi).all()
+    loc_off, locs = rb.locs_at(lo, hi, k, 20)
+    woff, wlocs = o.locs_at_batch(wlo, whi, wk, 20)
+    assert (loc_off == woff).all() and (locs == wlocs).all()
+    rb.close()
+    o.close()
+
+
 def test_run_indexed_layout_goldens_and_budget_rule(small, simple_reads, error_reads, data_dir):
     """the reference's fixture through the run-indexed layout (goldens rb_tests.cpp:47-58,115-120), and the
     automatic choice: a budget below the single-symbol slot tables selects it by itself"""
