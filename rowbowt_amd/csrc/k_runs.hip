@@ -728,6 +728,74 @@ __device__ __forceinline__ void coop_probe2_rank4(const DevTree *s_tree, const u
     }
 }
 
+// The phi directory's probe by QUADS (K3's ordered walk at 4-byte positions): four lanes per owner, four consecutive
+// sampled positions per lane (two 16-byte requests), the owner's start and position by DPP quad permutes, the number
+// of samples below the position as a quad sum, phi's value base + (q - pos) from the lane that holds the last of them
+// as a quad OR.  t = start + # entries below q (val undefined when t == start).
+template <typename P, int J>
+__device__ __forceinline__ void phi_quad_load(const DevTree &T, const uint32_t sub, const uint32_t info, typename PairOf<P>::vec (&e)[4]) {
+    typedef typename PairOf<P>::vec vec;
+    const uint32_t oi = quad_get<J>(info);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) e[i] = vec{static_cast<P>(~P(0)), 0};
+    if (oi & 0x80000000u) {
+        const uint64_t first = static_cast<uint64_t>(oi & 0x7FFFFFFFu) + 4u * sub;
+        if (sizeof(P) == 4) {   // (the array ends with one spare entry after the sentinel)
+            typedef unsigned int vec4 __attribute__((ext_vector_type(4), aligned(8)));
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                uint64_t g = first + 2u * h;
+                if (g > T.m) g = T.m;   // entry m is the sentinel (never below a query)
+                const vec4 w = *reinterpret_cast<const vec4 *>(static_cast<const vec *>(T.ent) + g);
+                e[2 * h] = vec{static_cast<P>(w.x), static_cast<P>(w.y)};
+                e[2 * h + 1] = vec{static_cast<P>(w.z), static_cast<P>(w.w)};
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                uint64_t g = first + i;
+                if (g > T.m) g = T.m;
+                e[i] = static_cast<const vec *>(T.ent)[g];
+            }
+        }
+    }
+}
+
+template <typename P, int J>
+__device__ __forceinline__ void phi_quad_round(const uint32_t sub, const bool live, const uint32_t start, const P q, const typename PairOf<P>::vec (&e)[4],
+                                               uint32_t &t, P &val) {
+    const P oq = quad_get<J>(q);
+    uint32_t n = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) n += static_cast<P>(e[i].x) < oq ? 1u : 0u;
+    const uint32_t c = quad_sum(n);
+    const bool mine = n > 0 && ((c - 1) >> 2) == sub;
+    P k = static_cast<P>(e[0].x), v = static_cast<P>(e[0].y);
+    if (n == 2u) { k = static_cast<P>(e[1].x); v = static_cast<P>(e[1].y); }
+    if (n == 3u) { k = static_cast<P>(e[2].x); v = static_cast<P>(e[2].y); }
+    if (n == 4u) { k = static_cast<P>(e[3].x); v = static_cast<P>(e[3].y); }
+    const P a_v = quad_or(mine ? v + (oq - k) : P(0));
+    if (static_cast<int>(sub) == J && live) { t = start + c; val = a_v; }
+}
+
+template <typename P>
+__device__ __forceinline__ void coop_probe_phi4(const DevTree &T, const bool live, const uint32_t start, const P q, uint32_t &t, P &val) {
+    typedef typename PairOf<P>::vec vec;
+    const uint32_t lane = threadIdx.x & (kWave - 1), sub = lane & 3u;
+    const uint64_t m_live = __ballot(live);
+    if (!m_live) return;
+    const uint32_t info = (live ? 0x80000000u : 0u) | (start & 0x7FFFFFFFu);   // (fewer than 2^31 sampled positions: upload() checks)
+    vec e0[4], e1[4], e2[4], e3[4];
+    if (round_has_owner4(m_live, 0)) phi_quad_load<P, 0>(T, sub, info, e0);
+    if (round_has_owner4(m_live, 1)) phi_quad_load<P, 1>(T, sub, info, e1);
+    if (round_has_owner4(m_live, 2)) phi_quad_load<P, 2>(T, sub, info, e2);
+    if (round_has_owner4(m_live, 3)) phi_quad_load<P, 3>(T, sub, info, e3);
+    if (round_has_owner4(m_live, 0)) phi_quad_round<P, 0>(sub, live, start, q, e0, t, val);
+    if (round_has_owner4(m_live, 1)) phi_quad_round<P, 1>(sub, live, start, q, e1, t, val);
+    if (round_has_owner4(m_live, 2)) phi_quad_round<P, 2>(sub, live, start, q, e2, t, val);
+    if (round_has_owner4(m_live, 3)) phi_quad_round<P, 3>(sub, live, start, q, e3, t, val);
+}
+
 // The two ranks of an LF step through the BUCKET RECORDS (rbg_dev.h RunRec): the row's lanes load the 128-byte record of
 // the owner's bucket with one coalesced request (lane 0 the header, lane 1 the rank at the bucket's start, lanes 2-15
 // the pairs); each pair's lane computes the rank the position would have if it fell into ITS run, popcount(ballot)
@@ -1148,7 +1216,7 @@ __global__ __launch_bounds__(256, sizeof(P) == 4 ? 4 : 3) void k_locate_fill_run
                     // a crowded bucket is narrowed by pivot probes first (coop_narrow), as the ranks' are
                     if (ORDERED) {
                         while (__ballot(coop && z > static_cast<uint32_t>(kFan))) coop_narrow_shfl<P>(s_tree, 0u, coop && z > static_cast<uint32_t>(kFan), start, z, static_cast<P>(k1));
-                        coop_probe_phi8<P>(s_tree[0], coop, start, static_cast<P>(k1), tq, pval);
+                        coop_probe_phi4<P>(s_tree[0], coop, start, static_cast<P>(k1), tq, pval);
                         by_dir = coop;
                     } else {
                         while (__ballot(coop && z > static_cast<uint32_t>(kFan))) coop_narrow<P>(s_tree, req, 0u, coop && z > static_cast<uint32_t>(kFan), start, z, static_cast<P>(k1));

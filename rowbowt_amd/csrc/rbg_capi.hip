@@ -730,13 +730,14 @@ int upload_tables_runs(rbg_index *ix) {
         ix->dev.nmajor = h.nmajor;
     }
     if (h.has_tsa) {
-        std::vector<PhiEnt<P>> pe(h.r + 1);
+        std::vector<PhiEnt<P>> pe(h.r + 2);   // (the sentinel and one spare entry after it: the kernels' two-entry loads may touch it)
         for (uint64_t j = 0; j < h.r; ++j) {
             pe[j].pos = static_cast<P>(h.pred_pos[j]);
             pe[j].base = static_cast<P>(h.phi_base[j]);
         }
         pe[h.r].pos = static_cast<P>(h.n);  // sentinel: never below a query
         pe[h.r].base = 0;
+        pe[h.r + 1] = pe[h.r];
         if ((rc = dev_upload(ix, pe.data(), pe.size() * sizeof(PhiEnt<P>), &ix->dev.phi_ent))) return rc;
         // (k_locate_fill_runs stages 26-43 KB of values per workgroup besides the top level: 8 KB of it keeps four
         //  workgroups per CU -- 32 ms per 10 M reads on the bench index against 44 ms with a 48 KB top level)
