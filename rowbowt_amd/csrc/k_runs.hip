@@ -7,10 +7,11 @@
 // four queries per load instruction, all sixteen rounds of a level in flight together.  One lane still owns one
 // read (K1/K2) or one phi chain (K3); lanes whose own work is finished keep serving the others' probes.
 // With the directories (the default) a rank is one directory gather and ONE probe of the run list from the entry
-// the directory names; those probes are made by smaller groups -- quads at 4-byte positions (four entries per lane,
-// everything cross-lane by DPP), half-rows at 8-byte ones and on phi's ordered walk (two entries per lane) -- and the
-// lane that holds the run computes the rank or phi's value itself: the first version of these kernels (16-lane rows,
-// every value by ds_bpermute) was bound by the LDS pipe, not by memory (profiles/).
+// the directory names; those probes are made by QUADS (four lanes per owner, four entries per lane, everything
+// cross-lane by DPP quad permutes), and the lane that holds the run computes the rank or phi's value itself: the
+// first version of these kernels (16-lane rows, every value by ds_bpermute) was bound by the LDS pipe, not by
+// memory (profiles/).  The 16-lane rows remain for the narrowing of crowded buckets, the descent of an
+// index built without directories, the unordered phi walk and the optional bucket records.
 #include "rbg_device.hpp"
 
 namespace rbg {
@@ -305,45 +306,6 @@ __device__ __forceinline__ void coop_narrow_shfl(const DevTree *s_tree, const ui
     }
 }
 
-// The phi directory's probe by HALF-ROWS (K3's ordered walk): eight lanes serve an owner, each holding two consecutive
-// entries of the 16 from `start` on, so a pass takes eight rounds; the lane whose pair holds the last sampled position
-// below q computes phi's value base + (q - pos) itself and one value travels back.  t = start + # entries below q
-// (val undefined when t == start).  The owner's values reach its lanes by ds_bpermute: the chains walk in toehold order,
-// the probes of a wave overlap in memory, and there the request slots cost more than they save.
-template <typename P>
-__device__ __forceinline__ void coop_probe_phi8(const DevTree &T, const bool live, const uint32_t start, const P q, uint32_t &t, P &val) {
-    typedef typename PairOf<P>::vec vec;
-    constexpr int kHalf = kFan / 2;
-    const uint32_t lane = threadIdx.x & (kWave - 1), sub = lane & (kHalf - 1), gbase = lane & ~static_cast<uint32_t>(kHalf - 1);
-    if (!__ballot(live)) return;
-    const uint32_t info = (live ? 0x80000000u : 0u) | (start & 0x7FFFFFFFu);   // (fewer than 2^31 sampled positions: upload() checks)
-    vec ve[kHalf], vo[kHalf];
-#pragma unroll
-    for (int j = 0; j < kHalf; ++j) {
-        const uint32_t oi = row_get(info, gbase, j);
-        ve[j] = vec{static_cast<P>(~P(0)), 0};
-        vo[j] = ve[j];
-        if (oi & 0x80000000u) {
-            uint64_t g0 = static_cast<uint64_t>(oi & 0x7FFFFFFFu) + 2u * sub, g1 = g0 + 1;
-            if (g0 > T.m) g0 = T.m;   // entry m is the sentinel (never below a query)
-            if (g1 > T.m) g1 = T.m;
-            ve[j] = static_cast<const vec *>(T.ent)[g0];
-            vo[j] = static_cast<const vec *>(T.ent)[g1];
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < kHalf; ++j) {
-        const P oq = row_get(q, gbase, j);
-        const P ke = static_cast<P>(ve[j].x), ko = static_cast<P>(vo[j].x);
-        const bool be = ke < oq, bo = ko < oq;
-        const uint64_t me = __ballot(be), mo = __ballot(bo);
-        const uint32_t c = static_cast<uint32_t>(__popc(static_cast<uint32_t>(me >> gbase) & 0xFFu) + __popc(static_cast<uint32_t>(mo >> gbase) & 0xFFu));
-        const P v = bo ? static_cast<P>(vo[j].y) + (oq - ko) : static_cast<P>(ve[j].y) + (oq - ke);
-        const P a_v = row_pick(v, gbase, c ? (c - 1) >> 1 : 0);
-        if (static_cast<int>(sub) == j && live) { t = start + c; val = a_v; }
-    }
-}
-
 // The phi directory's probe with request slots: the row's lanes load the z candidates start .. start + z - 1 of the
 // owner's position (lanes beyond them re-read the last one: the probe touches only the sectors that hold them), the lane
 // that holds the last sampled position below q computes phi's value base + (q - pos) itself, and t = start + # of them
@@ -430,153 +392,22 @@ __device__ __forceinline__ void coop_narrow(const DevTree *s_tree, uint4 *req, c
     }
 }
 
-// The two ranks of an LF step through the directories (K1/K2 at 8-byte positions): position 0 is answered from entries
-// s0 .. s0 + 15 of which the first z0 are candidates (the rest lie beyond the bucket, possibly in the next table's
-// slice), position 1 likewise from s1 / z1 -- sharing the load when s1 == s0.  Returns for each position t = s + #
-// candidates below it, the RANK rk = cum[t-1] + min(q - start[t-1], cum[t] - cum[t-1]) (valid when t > s or an entry
-// precedes s) and, for the second position, whether it lies inside that run (q - start <= length: the toehold test of
-// the caller).  The lanes beyond the candidates re-read the entry after the last one, so a probe touches only the
-// sectors that hold its z + 1 entries.  req: the wave's request area (64 x ReqSlots<P>::v x 16 bytes).
-// HALF-ROWS: eight lanes serve an owner, each holding TWO consecutive entries of its stretch, so a wave-wide load
-// instruction serves eight owners and a pass takes eight rounds instead of sixteen -- the per-round cost (request
-// read, ballots, the value's way back) is what bounds these kernels once the LDS traffic is gone.  The lane whose pair
-// holds the last entry below the position computes the rank (the odd entry's length needs the next lane's even count:
-// DPP; entry 15's is fetched by the owner when all sixteen lie below).
-__device__ __forceinline__ bool round_has_owner8(uint64_t m, int j) { return (m & (0x0101010101010101ull << j)) != 0; }
-
-template <typename P>
-__device__ __forceinline__ void coop_probe2_rank8(const DevTree *s_tree, uint4 *req, const uint32_t tid, const bool live, const uint32_t s0, const uint32_t z0,
-                                                  const uint32_t s1, const uint32_t z1, const P q0, const P q1, uint32_t &t0, uint32_t &t1, P &rk0,
-                                                  P &rk1, bool &ins1) {
-    typedef typename PairOf<P>::vec vec;
-    constexpr int NS = ReqSlots<P>::v;
-    constexpr int kHalf = kFan / 2;
-    const uint32_t lane = threadIdx.x & (kWave - 1), sub = lane & (kHalf - 1), gbase = lane & ~static_cast<uint32_t>(kHalf - 1);
-    const uint64_t m_live = __ballot(live);
-    if (!m_live) return;
-    const bool two = live && s1 != s0;
-    // bit 0 live, bit 1 second block, bits 2-4 tree, bits 5-9 z0, 10-14 z1
-    const uint32_t info = (live ? 1u : 0u) | (two ? 2u : 0u) | (tid << 2) | (z0 << 5) | (z1 << 10);
-    wave_lds_sync();   // (the area's previous readers are done)
-    req[lane * NS + 0] = make_uint4(s0, info, static_cast<uint32_t>(q0), static_cast<uint32_t>(q1));
-    req[lane * NS + 1] = make_uint4(s1, info, static_cast<uint32_t>(q1), static_cast<uint32_t>(static_cast<uint64_t>(q1) >> 32));
-    if (sizeof(P) == 8) req[lane * NS + (NS - 1)] = make_uint4(static_cast<uint32_t>(static_cast<uint64_t>(q0) >> 32), static_cast<uint32_t>(static_cast<uint64_t>(q1) >> 32), 0u, 0u);
-    wave_lds_sync();
-    bool fix0 = false, fix1 = false;
-    vec ve[kHalf], vo[kHalf];   // the even and the odd entry of this lane's pair, per round
-    // # lanes of this lane's half-row for which the predicate's ballot has a bit
-    auto half_count = [&](uint64_t ballot) { return static_cast<uint32_t>(__popc(static_cast<uint32_t>(ballot >> gbase) & 0xFFu)); };
-#pragma unroll
-    for (int j = 0; j < kHalf; ++j) {
-        if (!round_has_owner8(m_live, j)) continue;
-        const uint4 a = req[(gbase + j) * NS + 0];
-        ve[j] = vec{static_cast<P>(~P(0)), 0};
-        vo[j] = ve[j];
-        if (a.y & 1u) {
-            const DevTree &T = s_tree[(a.y >> 2) & 7u];
-            const uint32_t za = (a.y >> 5) & 31u, zb = (a.y & 2u) ? 0u : (a.y >> 10) & 31u;
-            uint32_t zc = za > zb ? za : zb;                      // entries 0 .. zc of the stretch are needed (zc: the one after the last candidate)
-            if (zc > static_cast<uint32_t>(kFan - 1)) zc = kFan - 1;
-            const uint32_t i0 = 2u * sub, i1 = 2u * sub + 1u;
-            uint64_t g0 = static_cast<uint64_t>(a.x) + (i0 < zc ? i0 : zc), g1 = static_cast<uint64_t>(a.x) + (i1 < zc ? i1 : zc);
-            if (g0 > T.m) g0 = T.m;                                // entry m is the last sentinel
-            if (g1 > T.m) g1 = T.m;
-            ve[j] = static_cast<const vec *>(T.ent)[g0];
-            vo[j] = static_cast<const vec *>(T.ent)[g1];
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < kHalf; ++j) {
-        if (!round_has_owner8(m_live, j)) continue;
-        const uint4 a = req[(gbase + j) * NS + 0];
-        P oq0 = static_cast<P>(a.z), oq1 = static_cast<P>(a.w);
-        if (sizeof(P) == 8) {
-            const uint4 c = req[(gbase + j) * NS + (NS - 1)];
-            oq0 = static_cast<P>((static_cast<uint64_t>(c.x) << 32) | a.z);
-            oq1 = static_cast<P>((static_cast<uint64_t>(c.y) << 32) | a.w);
-        }
-        const P ke = static_cast<P>(ve[j].x), ce = static_cast<P>(ve[j].y), ko = static_cast<P>(vo[j].x), co = static_cast<P>(vo[j].y);
-        const P len_e = co - ce, len_o = row_next(ce) - co;        // (the last lane's odd entry: fixed up by the owner below)
-        const uint32_t za = (a.y >> 5) & 31u, zb = (a.y >> 10) & 31u;
-        const bool be0 = 2u * sub < za && ke < oq0, bo0 = 2u * sub + 1u < za && ko < oq0;
-        const bool be1 = 2u * sub < zb && ke < oq1, bo1 = 2u * sub + 1u < zb && ko < oq1;
-        const uint32_t c0 = half_count(__ballot(be0)) + half_count(__ballot(bo0));
-        const uint32_t c1 = half_count(__ballot(be1)) + half_count(__ballot(bo1));
-        // the rank if the position's run is one of this lane's two: the odd entry when it, too, starts below the position
-        const P k0 = bo0 ? ko : ke, v0 = bo0 ? co : ce, l0 = bo0 ? len_o : len_e;
-        const P k1 = bo1 ? ko : ke, v1 = bo1 ? co : ce, l1 = bo1 ? len_o : len_e;
-        const P d0 = oq0 - k0, d1 = oq1 - k1;
-        const P r0 = v0 + (d0 < l0 ? d0 : l0), r1 = v1 + (d1 < l1 ? d1 : l1);
-        const uint64_t in1 = __ballot(d1 <= l1);
-        const uint32_t p0 = c0 ? (c0 - 1) >> 1 : 0, p1 = c1 ? (c1 - 1) >> 1 : 0;
-        const P a_r0 = row_pick(r0, gbase, p0), a_r1 = row_pick(r1, gbase, p1);
-        if (static_cast<int>(sub) == j && live) {
-            t0 = s0 + c0; rk0 = a_r0; fix0 = c0 == kFan;
-            if (!two) { t1 = s1 + c1; rk1 = a_r1; ins1 = ((in1 >> (gbase + p1)) & 1u) != 0; fix1 = c1 == kFan; }
-        }
-    }
-    const uint64_t m_two = __ballot(two);
-    if (m_two) {
-#pragma unroll
-        for (int j = 0; j < kHalf; ++j) {
-            if (!round_has_owner8(m_two, j)) continue;
-            const uint4 b = req[(gbase + j) * NS + 1];
-            ve[j] = vec{static_cast<P>(~P(0)), 0};
-            vo[j] = ve[j];
-            if (b.y & 2u) {
-                const DevTree &T = s_tree[(b.y >> 2) & 7u];
-                uint32_t zc = (b.y >> 10) & 31u;
-                if (zc > static_cast<uint32_t>(kFan - 1)) zc = kFan - 1;
-                const uint32_t i0 = 2u * sub, i1 = 2u * sub + 1u;
-                uint64_t g0 = static_cast<uint64_t>(b.x) + (i0 < zc ? i0 : zc), g1 = static_cast<uint64_t>(b.x) + (i1 < zc ? i1 : zc);
-                if (g0 > T.m) g0 = T.m;
-                if (g1 > T.m) g1 = T.m;
-                ve[j] = static_cast<const vec *>(T.ent)[g0];
-                vo[j] = static_cast<const vec *>(T.ent)[g1];
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < kHalf; ++j) {
-            if (!round_has_owner8(m_two, j)) continue;
-            const uint4 b = req[(gbase + j) * NS + 1];
-            const P oq1 = sizeof(P) == 8 ? static_cast<P>((static_cast<uint64_t>(b.w) << 32) | b.z) : static_cast<P>(b.z);
-            const P ke = static_cast<P>(ve[j].x), ce = static_cast<P>(ve[j].y), ko = static_cast<P>(vo[j].x), co = static_cast<P>(vo[j].y);
-            const P len_e = co - ce, len_o = row_next(ce) - co;
-            const uint32_t zb = (b.y >> 10) & 31u;
-            const bool be1 = 2u * sub < zb && ke < oq1, bo1 = 2u * sub + 1u < zb && ko < oq1;
-            const uint32_t c1 = half_count(__ballot(be1)) + half_count(__ballot(bo1));
-            const P k1 = bo1 ? ko : ke, v1 = bo1 ? co : ce, l1 = bo1 ? len_o : len_e;
-            const P d1 = oq1 - k1;
-            const P r1 = v1 + (d1 < l1 ? d1 : l1);
-            const uint64_t in1 = __ballot(d1 <= l1);
-            const uint32_t p1 = c1 ? (c1 - 1) >> 1 : 0;
-            const P a_r1 = row_pick(r1, gbase, p1);
-            if (static_cast<int>(sub) == j && two) { t1 = s1 + c1; rk1 = a_r1; ins1 = ((in1 >> (gbase + p1)) & 1u) != 0; fix1 = c1 == kFan; }
-        }
-    }
-    if (fix0 || fix1) {   // all 16 loaded entries lie below the position: the run it lands in ends in the next block
-        const vec *__restrict__ ent = static_cast<const vec *>(s_tree[tid].ent);
-        if (fix0) {
-            const vec e = ent[t0 - 1];
-            const P len = static_cast<P>(ent[t0].y) - static_cast<P>(e.y), d = q0 - static_cast<P>(e.x);
-            rk0 = static_cast<P>(e.y) + (d < len ? d : len);
-        }
-        if (fix1) {
-            const vec e = ent[t1 - 1];
-            const P len = static_cast<P>(ent[t1].y) - static_cast<P>(e.y), d = q1 - static_cast<P>(e.x);
-            rk1 = static_cast<P>(e.y) + (d < len ? d : len);
-            ins1 = d <= len;
-        }
-    }
-}
-
-// QUADS: four lanes serve an owner, each holding FOUR consecutive entries of its stretch, so one wave-wide load
-// instruction serves sixteen owners and a pass takes four rounds -- and everything the owner and its lanes tell each
-// other travels by DPP quad permutes (a VALU move: no LDS traffic, no request area, no synchronisation): in round J
-// the owner is lane J of each quad, its values are broadcast with quad_perm:[J,J,J,J], the number of candidates below
-// the position is a quad sum, and the rank computed by the lane that holds the run comes back as a quad OR (the other
-// three lanes contribute 0).  Same contract as coop_probe2_rank8; used at 4-byte positions, where a lane's four entries
-// are two 16-byte requests.
+// The two ranks of an LF step through the directories (K1/K2): position 0 is answered from entries s0 .. s0 + 15 of
+// which the first z0 are candidates (the rest lie beyond the bucket, possibly in the next table's slice), position 1
+// likewise from s1 / z1 -- sharing the load when s1 == s0.  Returns for each position t = s + # candidates below it, the
+// RANK rk = cum[t-1] + min(q - start[t-1], cum[t] - cum[t-1]) (valid when t > s or an entry precedes s) and, for the
+// second position, whether it lies inside that run (q - start <= length: the toehold test of the caller).  The lanes
+// beyond the candidates re-read the entry after the last one, so a probe touches only the sectors that hold its z + 1
+// entries.
+// QUADS: four lanes serve an owner, each holding FOUR consecutive entries of its stretch (two 16-byte requests at
+// 4-byte positions, four at 8-byte ones), so one wave-wide load instruction serves sixteen owners and a pass takes
+// four rounds -- and everything the owner and its lanes tell each other travels by DPP quad permutes (a VALU move: no
+// LDS traffic, no request area, no synchronisation): in round J the owner is lane J of each quad, its values are
+// broadcast with quad_perm:[J,J,J,J], the number of candidates below the position is a quad sum, and the rank
+// computed by the lane that holds the run (its fourth entry's length needs the next lane's first count: DPP row_shl;
+// entry 15's is fetched by the owner when all sixteen lie below) comes back as a quad OR, the other three lanes
+// contributing 0.  (Half-rows -- eight lanes per owner, two entries per lane, the owner's values through LDS request
+// slots -- were the step before: 8.3 / 13.3 ms per 10 M reads at 4- / 8-byte positions against 8.2 / 11.4.)
 template <int J> __device__ __forceinline__ uint32_t quad_get(uint32_t v) {
     return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), J * 0x55, 0xF, 0xF, false));
 }
@@ -728,8 +559,8 @@ __device__ __forceinline__ void coop_probe2_rank4(const DevTree *s_tree, const u
     }
 }
 
-// The phi directory's probe by QUADS (K3's ordered walk at 4-byte positions): four lanes per owner, four consecutive
-// sampled positions per lane (two 16-byte requests), the owner's start and position by DPP quad permutes, the number
+// The phi directory's probe by QUADS (K3's ordered walk): four lanes per owner, four consecutive sampled positions per
+// lane (two 16-byte requests at 4-byte positions), the owner's start and position by DPP quad permutes, the number
 // of samples below the position as a quad sum, phi's value base + (q - pos) from the lane that holds the last of them
 // as a quad OR.  t = start + # entries below q (val undefined when t == start).
 template <typename P, int J>
@@ -1056,8 +887,7 @@ __global__ __launch_bounds__(512, sizeof(P) == 4 ? 4 : 3) void k_find_range_runs
                 coop_narrow<P>(s_tree, req, d, direct && z0 > static_cast<uint32_t>(kFan), s0, z0, static_cast<P>(q0));
                 coop_narrow<P>(s_tree, req, d, direct && z1 > static_cast<uint32_t>(kFan), s1, z1, static_cast<P>(q1));
             }
-            if (sizeof(P) == 4) coop_probe2_rank4<P>(s_tree, d, direct, s0, z0, s1, z1, static_cast<P>(q0), static_cast<P>(q1), t0, t1, rk0, rk1, ins1);
-            else coop_probe2_rank8<P>(s_tree, req, d, direct, s0, z0, s1, z1, static_cast<P>(q0), static_cast<P>(q1), t0, t1, rk0, rk1, ins1);
+            coop_probe2_rank4<P>(s_tree, d, direct, s0, z0, s1, z1, static_cast<P>(q0), static_cast<P>(q1), t0, t1, rk0, rk1, ins1);
             if (__ballot(descend)) {   // crowded buckets (and indexes without directories): the clamped descent
                 uint32_t d0 = 0, d1 = 0;
                 P ak0 = 0, av0 = 0, an0 = 0, ak1 = 0, av1 = 0, an1 = 0;
