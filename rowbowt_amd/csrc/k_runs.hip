@@ -243,69 +243,6 @@ __device__ __forceinline__ void coop_leaf(const DevTree *s_tree, const uint32_t 
     }
 }
 
-// A row probe of the leaf array at an ARBITRARY start index (the phi directory's path): the row's lanes load entries
-// start .. start + 15 of the owner's query, and t = start + # of them below q; pk / pv = the last entry below q
-// (undefined when t == start).  One query per lane; every lane of the wave must call.
-template <typename P>
-__device__ __forceinline__ void coop_probe_at(const DevTree &T, const bool live, const uint32_t start, const P q, uint32_t &t, P &pk, P &pv) {
-    typedef typename PairOf<P>::vec vec;
-    const uint32_t lane = threadIdx.x & (kWave - 1), sub = lane & (kFan - 1), rowbase = lane & ~static_cast<uint32_t>(kFan - 1);
-    if (!__ballot(live)) return;
-    const uint32_t info = (live ? 0x80000000u : 0u) | (start & 0x7FFFFFFFu);   // (fewer than 2^31 sampled positions: upload() checks)
-    vec va[kFan];
-#pragma unroll
-    for (int j = 0; j < kFan; ++j) {
-        const uint32_t oi = row_get(info, rowbase, j);
-        va[j] = vec{static_cast<P>(~P(0)), 0};
-        if (oi & 0x80000000u) {
-            const uint64_t i = static_cast<uint64_t>(oi & 0x7FFFFFFFu) + sub;
-            if (i <= T.m) va[j] = static_cast<const vec *>(T.ent)[i];   // entry m is the sentinel (never below a query)
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < kFan; ++j) {
-        const P oq = row_get(q, rowbase, j);
-        const uint32_t c = row_count(static_cast<P>(va[j].x) < oq, rowbase);
-        const uint32_t pl = c ? c - 1 : 0;
-        const P a_pk = row_pick(static_cast<P>(va[j].x), rowbase, pl), a_pv = row_pick(static_cast<P>(va[j].y), rowbase, pl);
-        if (static_cast<int>(sub) == j && live) { t = start + c; pk = a_pk; pv = a_pv; }
-    }
-}
-
-// coop_narrow with the owner's values broadcast by ds_bpermute (K3's path: its chains walk in toehold order, the probes
-// of a wave overlap in memory and the request slots cost more than they save there).  One narrowing round for a crowded bucket: the candidates [s, s + z) of a query (z > 16) are sampled at 16 pivots a
-// stride apart, loaded by the row; the answer lies between the last pivot below q and the next one, so the range
-// shrinks to at most ceil(z / 16) candidates (s moves to that pivot, which is known to be below q -- or stays with
-// z = 1 when not even the first candidate is).  Lanes with live == false pass through.  Every lane must call.
-template <typename P>
-__device__ __forceinline__ void coop_narrow_shfl(const DevTree *s_tree, const uint32_t tid, const bool live, uint32_t &s, uint32_t &z, const P q) {
-    typedef typename PairOf<P>::vec vec;
-    const uint32_t lane = threadIdx.x & (kWave - 1), sub = lane & (kFan - 1), rowbase = lane & ~static_cast<uint32_t>(kFan - 1);
-    if (!__ballot(live)) return;
-    const uint32_t stride = (z + kFan - 1) / kFan;
-    const uint32_t flags = (live ? 1u : 0u) | (tid << 1);
-    P va[kFan];
-#pragma unroll
-    for (int j = 0; j < kFan; ++j) {
-        const uint32_t of = row_get(flags, rowbase, j), os = row_get(s, rowbase, j), oz = row_get(z, rowbase, j), ost = row_get(stride, rowbase, j);
-        va[j] = static_cast<P>(~P(0));   // pivots beyond the candidates are never below
-        if ((of & 1u) && sub * ost < oz) va[j] = static_cast<P>(static_cast<const vec *>(s_tree[(of >> 1) & 7u].ent)[static_cast<uint64_t>(os) + sub * ost].x);
-    }
-#pragma unroll
-    for (int j = 0; j < kFan; ++j) {
-        const P oq = row_get(q, rowbase, j);
-        const uint32_t c = row_count(va[j] < oq, rowbase);
-        if (static_cast<int>(sub) == j && live) {
-            if (c == 0) { z = 1; }
-            else {
-                const uint32_t adv = (c - 1) * stride;
-                s += adv;
-                z = (z - adv) < stride ? (z - adv) : stride;
-            }
-        }
-    }
-}
-
 // The phi directory's probe with request slots: the row's lanes load the z candidates start .. start + z - 1 of the
 // owner's position (lanes beyond them re-read the last one: the probe touches only the sectors that hold them), the lane
 // that holds the last sampled position below q computes phi's value base + (q - pos) itself, and t = start + # of them
@@ -345,50 +282,6 @@ __device__ __forceinline__ void coop_probe_phi(const DevTree &T, uint4 *req, con
         const P v = static_cast<P>(va[j].y) + (oq - key);
         const P a_v = row_pick(v, rowbase, c ? c - 1 : 0);
         if (static_cast<int>(sub) == j && live) { t = start + c; val = a_v; }
-    }
-}
-
-// One narrowing round for a crowded bucket: the candidates [s, s + z) of a query (z > 16) are sampled at 16 pivots a
-// stride apart, loaded by the row; the answer lies between the last pivot below q and the next one, so the range
-// shrinks to at most ceil(z / 16) candidates (s moves to that pivot, which is known to be below q -- or stays with
-// z = 1 when not even the first candidate is).  Lanes with live == false pass through.  Every lane must call.
-// (req: the wave's request area -- the owner's (s, z, tree, q) reach its row through it.)
-template <typename P>
-__device__ __forceinline__ void coop_narrow(const DevTree *s_tree, uint4 *req, const uint32_t tid, const bool live, uint32_t &s, uint32_t &z, const P q) {
-    typedef typename PairOf<P>::vec vec;
-    constexpr int NS = ReqSlots<P>::v;
-    const uint32_t lane = threadIdx.x & (kWave - 1), sub = lane & (kFan - 1), rowbase = lane & ~static_cast<uint32_t>(kFan - 1);
-    const uint64_t m_live = __ballot(live);
-    if (!m_live) return;
-    const uint32_t stride = (z + kFan - 1) / kFan;
-    wave_lds_sync();
-    req[lane * NS + 0] = make_uint4(s, z, (live ? 1u : 0u) | (tid << 1), static_cast<uint32_t>(q));
-    if (sizeof(P) == 8) req[lane * NS + 1] = make_uint4(static_cast<uint32_t>(static_cast<uint64_t>(q) >> 32), 0u, 0u, 0u);
-    wave_lds_sync();
-    P va[kFan];
-#pragma unroll
-    for (int j = 0; j < kFan; ++j) {
-        if (!round_has_owner(m_live, j)) continue;
-        const uint4 a = req[(rowbase + j) * NS + 0];
-        const uint32_t ost = (a.y + kFan - 1) / kFan;
-        va[j] = static_cast<P>(~P(0));   // pivots beyond the candidates are never below
-        if ((a.z & 1u) && sub * ost < a.y) va[j] = static_cast<P>(static_cast<const vec *>(s_tree[(a.z >> 1) & 7u].ent)[static_cast<uint64_t>(a.x) + sub * ost].x);
-    }
-#pragma unroll
-    for (int j = 0; j < kFan; ++j) {
-        if (!round_has_owner(m_live, j)) continue;
-        const uint4 a = req[(rowbase + j) * NS + 0];
-        P oq = static_cast<P>(a.w);
-        if (sizeof(P) == 8) oq = static_cast<P>((static_cast<uint64_t>(req[(rowbase + j) * NS + 1].x) << 32) | a.w);
-        const uint32_t c = row_count(va[j] < oq, rowbase);
-        if (static_cast<int>(sub) == j && live) {
-            if (c == 0) { z = 1; }
-            else {
-                const uint32_t adv = (c - 1) * stride;
-                s += adv;
-                z = (z - adv) < stride ? (z - adv) : stride;
-            }
-        }
     }
 }
 
@@ -625,6 +518,59 @@ __device__ __forceinline__ void coop_probe_phi4(const DevTree &T, const bool liv
     if (round_has_owner4(m_live, 1)) phi_quad_round<P, 1>(sub, live, start, q, e1, t, val);
     if (round_has_owner4(m_live, 2)) phi_quad_round<P, 2>(sub, live, start, q, e2, t, val);
     if (round_has_owner4(m_live, 3)) phi_quad_round<P, 3>(sub, live, start, q, e3, t, val);
+}
+
+// One narrowing round for a crowded bucket: the candidates [s, s + z) of a query (z > 16) are sampled at 16 pivots a
+// stride apart; the answer lies between the last pivot below q and the next one, so the range shrinks to at most
+// ceil(z / 16) candidates (s moves to that pivot, which is known to be below q -- or stays with z = 1 when not even
+// the first candidate is).  Lanes with live == false pass through.  Every lane must call.  By QUADS: the sixteen
+// pivots are four per lane of the owner's quad, its (s, z, tree, q) reach the quad by DPP and the number of pivots
+// below q is a quad sum -- no LDS traffic.
+template <typename P, int J>
+__device__ __forceinline__ void narrow_quad_load(const DevTree *s_tree, const uint32_t sub, const uint32_t flags, const uint32_t s, const uint32_t z, P (&key)[4]) {
+    typedef typename PairOf<P>::vec vec;
+    const uint32_t of = quad_get<J>(flags), os = quad_get<J>(s), oz = quad_get<J>(z);
+    const uint32_t ost = (oz + kFan - 1) / kFan;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        key[i] = static_cast<P>(~P(0));   // pivots beyond the candidates are never below
+        const uint32_t at = (4u * sub + i) * ost;
+        if ((of & 1u) && at < oz) key[i] = static_cast<P>(static_cast<const vec *>(s_tree[(of >> 1) & 7u].ent)[static_cast<uint64_t>(os) + at].x);
+    }
+}
+template <typename P, int J>
+__device__ __forceinline__ void narrow_quad_round(const uint32_t sub, const bool live, const uint32_t stride, const P q, const P (&key)[4], uint32_t &s, uint32_t &z) {
+    const P oq = quad_get<J>(q);
+    uint32_t n = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) n += key[i] < oq ? 1u : 0u;
+    const uint32_t c = quad_sum(n);
+    if (static_cast<int>(sub) == J && live) {
+        if (c == 0) { z = 1; }
+        else {
+            const uint32_t adv = (c - 1) * stride;
+            s += adv;
+            z = (z - adv) < stride ? (z - adv) : stride;
+        }
+    }
+}
+template <typename P>
+__device__ __forceinline__ void coop_narrow4(const DevTree *s_tree, const uint32_t tid, const bool live, uint32_t &s, uint32_t &z, const P q) {
+    const uint32_t lane = threadIdx.x & (kWave - 1), sub = lane & 3u;
+    const uint64_t m_live = __ballot(live);
+    if (!m_live) return;
+    const uint32_t stride = (z + kFan - 1) / kFan;
+    const uint32_t flags = (live ? 1u : 0u) | (tid << 1);
+    const uint32_t s_in = s, z_in = z;   // (the owners update s and z while later rounds still broadcast the others')
+    P k0[4], k1[4], k2[4], k3[4];
+    if (round_has_owner4(m_live, 0)) narrow_quad_load<P, 0>(s_tree, sub, flags, s_in, z_in, k0);
+    if (round_has_owner4(m_live, 1)) narrow_quad_load<P, 1>(s_tree, sub, flags, s_in, z_in, k1);
+    if (round_has_owner4(m_live, 2)) narrow_quad_load<P, 2>(s_tree, sub, flags, s_in, z_in, k2);
+    if (round_has_owner4(m_live, 3)) narrow_quad_load<P, 3>(s_tree, sub, flags, s_in, z_in, k3);
+    if (round_has_owner4(m_live, 0)) narrow_quad_round<P, 0>(sub, live, stride, q, k0, s, z);
+    if (round_has_owner4(m_live, 1)) narrow_quad_round<P, 1>(sub, live, stride, q, k1, s, z);
+    if (round_has_owner4(m_live, 2)) narrow_quad_round<P, 2>(sub, live, stride, q, k2, s, z);
+    if (round_has_owner4(m_live, 3)) narrow_quad_round<P, 3>(sub, live, stride, q, k3, s, z);
 }
 
 // The two ranks of an LF step through the BUCKET RECORDS (rbg_dev.h RunRec): the row's lanes load the 128-byte record of
@@ -884,8 +830,8 @@ __global__ __launch_bounds__(512, sizeof(P) == 4 ? 4 : 3) void k_find_range_runs
                 direct = true;
             }
             while (__ballot(direct && (z0 > static_cast<uint32_t>(kFan) || z1 > static_cast<uint32_t>(kFan)))) {
-                coop_narrow<P>(s_tree, req, d, direct && z0 > static_cast<uint32_t>(kFan), s0, z0, static_cast<P>(q0));
-                coop_narrow<P>(s_tree, req, d, direct && z1 > static_cast<uint32_t>(kFan), s1, z1, static_cast<P>(q1));
+                coop_narrow4<P>(s_tree, d, direct && z0 > static_cast<uint32_t>(kFan), s0, z0, static_cast<P>(q0));
+                coop_narrow4<P>(s_tree, d, direct && z1 > static_cast<uint32_t>(kFan), s1, z1, static_cast<P>(q1));
             }
             coop_probe2_rank4<P>(s_tree, d, direct, s0, z0, s1, z1, static_cast<P>(q0), static_cast<P>(q1), t0, t1, rk0, rk1, ins1);
             if (__ballot(descend)) {   // crowded buckets (and indexes without directories): the clamped descent
@@ -1045,11 +991,11 @@ __global__ __launch_bounds__(256, sizeof(P) == 4 ? 4 : 3) void k_locate_fill_run
                     uint32_t start = g0 ? g0 - 1 : 0, z = g1 - start;
                     // a crowded bucket is narrowed by pivot probes first (coop_narrow), as the ranks' are
                     if (ORDERED) {
-                        while (__ballot(coop && z > static_cast<uint32_t>(kFan))) coop_narrow_shfl<P>(s_tree, 0u, coop && z > static_cast<uint32_t>(kFan), start, z, static_cast<P>(k1));
+                        while (__ballot(coop && z > static_cast<uint32_t>(kFan))) coop_narrow4<P>(s_tree, 0u, coop && z > static_cast<uint32_t>(kFan), start, z, static_cast<P>(k1));
                         coop_probe_phi4<P>(s_tree[0], coop, start, static_cast<P>(k1), tq, pval);
                         by_dir = coop;
                     } else {
-                        while (__ballot(coop && z > static_cast<uint32_t>(kFan))) coop_narrow<P>(s_tree, req, 0u, coop && z > static_cast<uint32_t>(kFan), start, z, static_cast<P>(k1));
+                        while (__ballot(coop && z > static_cast<uint32_t>(kFan))) coop_narrow4<P>(s_tree, 0u, coop && z > static_cast<uint32_t>(kFan), start, z, static_cast<P>(k1));
                         coop_probe_phi<P>(s_tree[0], req, coop, start, z, static_cast<P>(k1), tq, pval);
                         by_dir = coop;
                     }
