@@ -1741,6 +1741,48 @@ def test_cli_parser_matches_kseq(data_dir, tmp_path, small):
     assert "(1,0), count=0" in out.splitlines()[2]  # the blank inside the sequence is kept, as kseq does
 
 
+@pytest.mark.parametrize("fmt", ["fasta", "fastq"])
+@pytest.mark.parametrize("gz", [False, True])
+def test_cli_many_windows(data_dir, tmp_path, small, fmt, gz):
+    """an input several windows long (rb_align --window-mb 1; more than 3 MB of records), plain (memory-mapped) and gzip (zlib,
+    with the unfinished record carried from window to window): every record answered once, in order, as
+    rb_align.cpp:176-191 prints it.  FASTA is the case where a window ends right after the next record's '>' has been
+    consumed (kseq.h:195-199), which the zlib path once mishandled."""
+    import gzip
+    rb, o = small
+    t = open(os.path.join(data_dir, "small.fa"), "rb").read().split(b"\n", 1)[1].replace(b"\n", b"")
+    rng = np.random.default_rng(12)
+    recs, blob = [], bytearray()
+    for i in range(36000):
+        a, m = int(rng.integers(0, len(t) - 160)), int(rng.integers(20, 150))
+        seq = bytearray(t[a:a + m])
+        if rng.random() < 0.2:
+            seq[int(rng.integers(m))] = ord("ACGT"[int(rng.integers(4))])
+        seq = bytes(seq)
+        recs.append((b"r%d" % i, seq))
+        if fmt == "fasta":
+            blob += b">r%d some text\n" % i + seq[:60] + b"\n" + (seq[60:] + b"\n" if len(seq) > 60 else b"")
+        else:
+            blob += b"@r%d\n" % i + seq + b"\n+\n" + b"I" * len(seq) + b"\n"
+    assert len(blob) > (3 << 20)
+    path = tmp_path / ("reads." + fmt + (".gz" if gz else ""))
+    if gz:
+        with gzip.open(path, "wb") as f:
+            f.write(bytes(blob))
+    else:
+        path.write_bytes(bytes(blob))
+    rc, out, errtxt = _run_cli(["--window-mb", "1", os.path.join(data_dir, "small.fa"), str(path)])
+    assert rc == 0, errtxt
+    seqs, off = ra.pack_reads([r[1] for r in recs])
+    wlo, whi = o.find_range_batch(seqs, off) if hasattr(o, "find_range_batch") else o.find_range_w_toehold_batch(seqs, off)[:2]
+    lines = out.splitlines()
+    assert len(lines) == len(recs)
+    for i in (0, 1, 5000, 11000, 35999):
+        assert lines[i] == f"r{i} ({int(wlo[i])},{int(whi[i])}), count={(int(whi[i]) - int(wlo[i]) + 1) % 2**64}"
+    want = "".join(f"r{i} ({int(wlo[i])},{int(whi[i])}), count={(int(whi[i]) - int(wlo[i]) + 1) % 2**64}\n" for i in range(len(recs)))
+    assert out == want
+
+
 def test_full_size_properties_and_parity_sample():
     """BASELINE.json's size (n = 2.0e9, r = 3.7e7, 10 M x 100 bp reads) through the size-independent
     properties and an oracle sample: one bench.py step in a subprocess (about a minute and a half: the
