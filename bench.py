@@ -17,7 +17,11 @@ construction, read synthesis, oracle construction and the CPU baseline are all O
 region.  Multi-GPU: the index is replicated, reads are sharded (each rank its own batch: weak
 scaling), no data-path collective; one RCCL all-reduce carries the 4 global counters.
 
-Launch: python bench.py [--gpus N --steps K --warmup W]; for N>1 under torch.distributed.run.
+Launch: python bench.py [--gpus N --steps K --warmup W].  With N > 1 and no RANK in the environment this
+process only LAUNCHES: before importing torch or touching HIP it starts N fresh children of itself (one rank
+per GPU, rowbowt_amd/launch.py), relays rank 0's JSON line and exits non-zero if any rank does.  Under
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` the ranks already exist and --gpus
+must equal WORLD_SIZE.  `n_gpus` in the line is the size of the RCCL group that was actually formed.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -35,9 +39,23 @@ MAXU = 2**64 - 1
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+def load_launch():
+    """rowbowt_amd/launch.py by file path: stdlib only, so the launching parent imports neither torch nor the
+    package's ctypes binding"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("rbg_launch", os.path.join(ROOT, "rowbowt_amd", "launch.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1,
+                    help="GPUs of this node = ranks; N > 1 without RANK in the environment starts the N ranks itself")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="start the ranks as --gpus asks, have each print the environment it was given as one JSON line and exit "
+                         "(no GPU is touched: the launcher's own test)")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step")
@@ -84,9 +102,19 @@ def cpu_budget():
 
 def main():
     args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    launch = load_launch()
+    if not launch.under_launcher():
+        if args.gpus > 1:
+            # the parent: no torch, no HIP -- N fresh children, one rank each (never re-exec a process that holds a GPU)
+            raise SystemExit(launch.run_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus, check_devices=not args.launch_check))
+        if args.gpus < 1:
+            raise SystemExit("--gpus must be at least 1")
+        rank, local_rank, world = 0, 0, 1
+    else:
+        rank, local_rank, world = launch.check_world(args.gpus)   # refuses --gpus != WORLD_SIZE
+    if args.launch_check:
+        launch.echo_rank()
+        return
     # the markers leg (BASELINE.json configs[4]) rides along on one GPU unless switched off
     args.markers = (args.markers or (world == 1 and "RANK" not in os.environ)) and not args.no_markers
     import torch
@@ -94,6 +122,9 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible -- "
+                         f"--gpus {args.gpus} exceeds this node")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or "RANK" in os.environ  # under torch.distributed.run: always go through RCCL
@@ -101,6 +132,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"RCCL group has {dist.get_world_size()} ranks, --gpus asked for {args.gpus}")
+        world = dist.get_world_size()   # n_gpus of the line = the group that was actually formed
 
     import rowbowt_amd as ra
     from rowbowt_amd import shard
@@ -682,20 +716,14 @@ def main():
         for lvl in range(top - 1, 0, -1):
             rb.close()
             torch.cuda.empty_cache()
-            capi.set_default_option(capi.OPT_KMER_STEPS, lvl)
-            try:
+            with capi.default_option(capi.OPT_KMER_STEPS, lvl):   # the caller's own setting is put back afterwards
                 rb = ra.RowBowt.from_runs(inp["heads"], inp["lens"], inp["ssa"], inp["esa"], device=local_rank)
-            finally:
-                capi.set_default_option(capi.OPT_KMER_STEPS, 5)
             rows.append({"layout": "slots", "symbols_per_gather": int(rb.info().kmer_steps), "hbm_bytes": int(rb.info().hbm_bytes), "ms": time_search()})
         # the run-indexed layout (space proportional to r; wave-cooperative predecessor search): same batch, same outputs
         rb.close()
         torch.cuda.empty_cache()
-        capi.set_default_option(capi.OPT_RANK_LAYOUT, capi.LAYOUT_RUNS)
-        try:
+        with capi.default_option(capi.OPT_RANK_LAYOUT, capi.LAYOUT_RUNS):
             rb = ra.RowBowt.from_runs(inp["heads"], inp["lens"], inp["ssa"], inp["esa"], device=local_rank)
-        finally:
-            capi.set_default_option(capi.OPT_RANK_LAYOUT, capi.LAYOUT_AUTO)
         ms_r = time_search()
         step()
         e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]

@@ -403,6 +403,8 @@ enum { RBG_OPT_BLOCK_THREADS = 1, RBG_OPT_RANK_BUCKET_SHIFT = 2, RBG_OPT_PHI_BUC
        RBG_OPT_KMER_STEPS = 5, RBG_OPT_HBM_BUDGET_MB = 6, RBG_OPT_FTAB_K = 7, RBG_OPT_PACKED_READS = 8,
        RBG_OPT_DEEP_BUCKET_SHIFT = 9, RBG_OPT_DENSE_OVERFLOW = 10, RBG_OPT_RANK_LAYOUT = 11, RBG_OPT_TREE_TOP_KB = 12 };
 int rbg_set_default_option(int opt, int64_t value);
+/* the value a later load would use (so that a caller can change a knob for one load and put it back) */
+int rbg_get_default_option(int opt, int64_t *value);
 
 #ifdef __cplusplus
 }

@@ -112,6 +112,7 @@ _PROTOS = [
     ("rbg_counters_reset", C.c_int, [VP]),
     ("rbg_combine_stats", C.c_int, [VP, VP]),
     ("rbg_set_default_option", C.c_int, [C.c_int, C.c_int64]),
+    ("rbg_get_default_option", C.c_int, [C.c_int, C.POINTER(C.c_int64)]),
 ]
 EXPORTS = [p[0] for p in _PROTOS]
 
@@ -185,6 +186,28 @@ def convert_raw(bwt, ssa=None, esa=None, mab=None, docs=None, out_path=None):
 
 def set_default_option(opt, value):
     _check(lib().rbg_set_default_option(opt, value), "rbg_set_default_option")
+
+
+def get_default_option(opt):
+    v = C.c_int64(0)
+    _check(lib().rbg_get_default_option(opt, C.byref(v)), "rbg_get_default_option")
+    return int(v.value)
+
+
+class default_option:
+    """with default_option(OPT_X, v): ... -- one knob changed for the loads inside, put back afterwards"""
+
+    def __init__(self, opt, value):
+        self.opt, self.value = opt, value
+
+    def __enter__(self):
+        self.prev = get_default_option(self.opt)
+        set_default_option(self.opt, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        set_default_option(self.opt, self.prev)
+        return False
 
 
 def _take(ptr, n):

@@ -1384,6 +1384,27 @@ int rbg_set_default_option(int opt, int64_t value) {
     });
 }
 
+int rbg_get_default_option(int opt, int64_t *value) {
+    return guarded([&]() -> int {
+    if (!value) return RBG_EARG;
+    switch (opt) {
+        case RBG_OPT_BLOCK_THREADS: *value = g_opt_block_threads.load(); return RBG_OK;
+        case RBG_OPT_RANK_BUCKET_SHIFT: *value = g_opt_rank_shift.load(); return RBG_OK;
+        case RBG_OPT_DEEP_BUCKET_SHIFT: *value = g_opt_deep_shift.load(); return RBG_OK;
+        case RBG_OPT_DENSE_OVERFLOW: *value = g_opt_dense_overflow.load(); return RBG_OK;
+        case RBG_OPT_PHI_BUCKET_SHIFT: *value = g_opt_phi_shift.load(); return RBG_OK;
+        case RBG_OPT_POS_BYTES: *value = g_opt_pos_bytes.load(); return RBG_OK;
+        case RBG_OPT_FTAB_K: *value = g_opt_ftab_k.load(); return RBG_OK;
+        case RBG_OPT_HBM_BUDGET_MB: *value = g_opt_hbm_budget_mb.load(); return RBG_OK;
+        case RBG_OPT_KMER_STEPS: *value = g_opt_kmer_steps.load(); return RBG_OK;
+        case RBG_OPT_PACKED_READS: *value = g_opt_packed_reads.load(); return RBG_OK;
+        case RBG_OPT_RANK_LAYOUT: *value = g_opt_rank_layout.load(); return RBG_OK;
+        case RBG_OPT_TREE_TOP_KB: *value = g_opt_tree_top_kb.load(); return RBG_OK;
+        default: return RBG_EARG;
+    }
+    });
+}
+
 int rbg_load(const char *prefix, int flags, int device, rbg_index **out) {
     return guarded([&]() -> int {
     if (!prefix || !out) return RBG_EARG;

@@ -1,0 +1,98 @@
+"""The N-rank launcher of bench.py / tools/pangenome_stream.py (rowbowt_amd/launch.py), on the CPU: `--gpus N` without
+RANK starts N fresh children with the right environment from a parent that has imported neither torch nor the HIP
+library; `--gpus` that disagrees with WORLD_SIZE, or exceeds the node's GPUs, is refused with a non-zero exit; a
+failing rank takes the job down.  The loop the ranks shard is the reference's rb_align.cpp:176-178."""
+import importlib.util
+import json
+import os
+import subprocess
+import sys
+import time
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SCRIPTS = [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "tools", "pangenome_stream.py")]
+
+
+def clean_env(**kw):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(kw)
+    return env
+
+
+def load_launch():
+    spec = importlib.util.spec_from_file_location("rbg_launch_t", os.path.join(ROOT, "rowbowt_amd", "launch.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("script", SCRIPTS)
+@pytest.mark.parametrize("n", [2, 3])
+def test_gpus_n_starts_n_ranks(script, n):
+    p = subprocess.run([sys.executable, script, "--gpus", str(n), "--launch-check", "--seed", "7"], env=clean_env(),
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    out_lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+    err_lines = [json.loads(l.split("] ", 1)[1]) for l in p.stderr.splitlines() if l.startswith("[rank ")]
+    assert len(out_lines) == 1 and out_lines[0]["RANK"] == "0"          # only rank 0's line reaches stdout
+    ranks = out_lines + err_lines
+    assert sorted(r["RANK"] for r in ranks) == [str(i) for i in range(n)]
+    assert all(r["LOCAL_RANK"] == r["RANK"] and r["WORLD_SIZE"] == str(n) and r["MASTER_ADDR"] == "127.0.0.1" for r in ranks)
+    assert len({r["MASTER_PORT"] for r in ranks}) == 1 and len({r["ppid"] for r in ranks}) == 1 and len({r["pid"] for r in ranks}) == n
+    assert not any(r["torch_imported"] for r in ranks)                  # the check path touches neither torch nor a GPU
+    assert all("--seed" in r["argv"] and "7" in r["argv"] for r in ranks)   # the command line travels unchanged
+
+
+@pytest.mark.parametrize("script", SCRIPTS)
+def test_gpus_must_equal_world_size(script):
+    # as torch.distributed.run would start it, but with the wrong --gpus
+    p = subprocess.run([sys.executable, script, "--gpus", "2", "--launch-check"], capture_output=True, text=True, timeout=60,
+                       env=clean_env(RANK="0", LOCAL_RANK="0", WORLD_SIZE="4", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533"))
+    assert p.returncode != 0 and "WORLD_SIZE=4" in p.stderr
+    p = subprocess.run([sys.executable, script, "--gpus", "4", "--launch-check"], capture_output=True, text=True, timeout=60,
+                       env=clean_env(RANK="3", LOCAL_RANK="3", WORLD_SIZE="4", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533"))
+    assert p.returncode == 0 and json.loads(p.stdout)["RANK"] == "3"
+
+
+def test_more_gpus_than_the_node_has_is_refused_by_the_parent():
+    """here: no GPU at all.  The parent asks a throw-away child for torch.cuda.device_count() and refuses; it never
+    imports torch itself (run_ranks asserts that)."""
+    p = subprocess.run([sys.executable, SCRIPTS[0], "--gpus", "2"], env=clean_env(), capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0 and p.stdout.strip() == ""
+    assert "GPU(s)" in p.stderr and "refusing" in p.stderr
+
+
+def test_failing_rank_stops_the_job(tmp_path):
+    launch = load_launch()
+    child = tmp_path / "child.py"
+    child.write_text("import os, sys, time\n"
+                     "r = int(os.environ['RANK'])\n"
+                     "print('hello from', r, flush=True)\n"
+                     "if r == 1:\n    sys.exit(3)\n"
+                     "time.sleep(120)\n")
+    # in a fresh interpreter: run_ranks refuses to run in a process that has imported torch (this pytest process may have)
+    driver = ("import importlib.util, sys\n"
+              f"spec = importlib.util.spec_from_file_location('l', {os.path.join(ROOT, 'rowbowt_amd', 'launch.py')!r})\n"
+              "m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)\n"
+              f"sys.exit(m.run_ranks({str(child)!r}, [], 3, check_devices=False))\n")
+    t0 = time.time()
+    p = subprocess.run([sys.executable, "-c", driver], env=clean_env(), capture_output=True, text=True, timeout=100)
+    assert p.returncode == 3 and time.time() - t0 < 60
+    assert "hello from 0" in p.stdout and "[rank 1] hello from 1" in p.stderr and "rank 1 exited with 3" in p.stderr
+    import torch  # noqa: F401  -- and with torch imported the parent refuses to launch at all
+    with pytest.raises(AssertionError):
+        launch.run_ranks(str(child), [], 2, check_devices=False)
+
+
+def test_rank_env_and_check_world():
+    launch = load_launch()
+    e = launch.rank_env(2, 8, 1234, base={})
+    assert (e["RANK"], e["LOCAL_RANK"], e["WORLD_SIZE"], e["MASTER_ADDR"], e["MASTER_PORT"]) == ("2", "2", "8", "127.0.0.1", "1234")
+    assert e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert launch.check_world(8, env=e) == (2, 2, 8)
+    with pytest.raises(SystemExit):
+        launch.check_world(4, env=e)
+    with pytest.raises(SystemExit):
+        launch.run_ranks("x.py", [], 0, check_devices=False)

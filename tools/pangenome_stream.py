@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """BASELINE.json configs[3] on one GPU (and, under torch.distributed.run, on N): a pangenome-scale r-index with
-positions beyond 32 bits, a stream of synthetic 150 bp reads generated ON THE DEVICE batch by batch from a
+positions beyond 32 bits (with --gpus N this process starts the N ranks itself), a stream of synthetic 150 bp reads generated ON THE DEVICE batch by batch from a
 counter-based RNG (rbg_sample_reads_dev: the host cannot feed 150 GB), count+locate per batch, global counters
 reduced over RCCL.  Prints one JSON line (rank 0).
 
@@ -46,15 +46,32 @@ def main():
     ap.add_argument("--hbm-reserve-gb", type=float, default=45.0,
                     help="HBM left to this tool's own buffers (reads, ranges, locations, sort workspace): the index replica gets the rest of "
                          "what is free once the text is resident (0 = the library's default budget, three quarters of the free HBM)")
+    ap.add_argument("--gpus", type=int, default=1,
+                    help="GPUs of this node = ranks; N > 1 without RANK in the environment starts the N ranks itself (rowbowt_amd/launch.py)")
+    ap.add_argument("--launch-check", action="store_true", help="start the ranks, print what each was given, touch no GPU")
     args = ap.parse_args()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("rbg_launch", os.path.join(ROOT, "rowbowt_amd", "launch.py"))
+    launch = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(launch)
+    if not launch.under_launcher():
+        if args.gpus > 1:   # the parent: no torch, no HIP -- N fresh children, one rank each
+            raise SystemExit(launch.run_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus, check_devices=not args.launch_check))
+        if args.gpus < 1:
+            raise SystemExit("--gpus must be at least 1")
+        rank, local_rank, world = 0, 0, 1
+    else:
+        rank, local_rank, world = launch.check_world(args.gpus)
+    if args.launch_check:
+        launch.echo_rank()
+        return
     import torch
     import torch.distributed as dist
 
     if not torch.cuda.is_available():
         raise SystemExit("needs an MI355X: the hot path has no CPU fallback")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or "RANK" in os.environ
@@ -62,6 +79,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"RCCL group has {dist.get_world_size()} ranks, --gpus asked for {args.gpus}")
+        world = dist.get_world_size()
 
     def log(*a):
         if rank == 0:
