@@ -138,7 +138,8 @@ typedef struct rbg_info_t {
      * stderr at load when a level is dropped (always with RBG_VERBOSE). */
     uint64_t kmer_steps_requested, hbm_free_at_load, hbm_budget;
     uint64_t rank_layout;   /* RBG_LAYOUT_SLOTS or RBG_LAYOUT_RUNS (what RBG_OPT_RANK_LAYOUT / the budget rule chose) */
-    uint64_t replicas;      /* devices holding a replica of this index (1 unless loaded with rbg_load_multi) */
+    uint64_t replicas;      /* per handle: 1 when this handle holds a device replica, 0 for a host-only index
+                             * (RBG_DEVICE_NONE); further replicas are handles of their own (rbg_replicate[_many]) */
 } rbg_info_t;
 enum { RBG_LAYOUT_AUTO = 0, RBG_LAYOUT_SLOTS = 1, RBG_LAYOUT_RUNS = 2 };
 int rbg_info(const rbg_index *, rbg_info_t *out);
@@ -315,6 +316,10 @@ int rbg_combine_stats(rbg_index *, uint64_t out[2]);
  * *_dev), shares the host-side index with the primary and must be freed before it; markers / docs are attached
  * to the primary BEFORE replicating. */
 int rbg_replicate(rbg_index *primary, int device, rbg_index **replica_out);
+/* G replicas at once: every target's peer copies are enqueued (one stream per target) before any is waited for, so the
+ * transfers overlap -- each MI355X has its own xGMI link to the primary, the fan-out takes about one copy's time.
+ * All or nothing: on failure no replica is left behind.  devices[] may repeat (tests put several on one device). */
+int rbg_replicate_many(rbg_index *primary, const int *devices, int G, rbg_index **replicas_out /* [G] */);
 /* contiguous block [begin, end) of `rank` out of `world` (sizes differ by at most one; concatenating the ranks'
  * outputs restores the input order): read i of N goes to rank i * world / N */
 int rbg_shard_bounds(uint64_t n_items, int rank, int world, uint64_t *begin, uint64_t *end);
@@ -325,8 +330,12 @@ int rbg_find_range_sharded(rbg_index *const *replicas, int G, const uint8_t *seq
 /* The run's only collective: one RCCL all-reduce (sum) of the four counters of rbg_counters.  `nccl_comm` is the
  * caller's ncclComm_t for this replica's device (one rank per GPU), `stream` a HIP stream or NULL. */
 int rbg_counters_allreduce(rbg_index *, void *nccl_comm, void *stream, uint64_t out[4]);
-/* the same for G replicas on G distinct devices held by one process (ncclCommInitAll + one grouped all-reduce) */
+/* the same for G replicas on G distinct devices held by one process: one grouped all-reduce over a communicator
+ * clique that is made on the first call for that set of devices (ncclCommInitAll) and kept for the later ones;
+ * rbg_comm_cache_clear() destroys the kept cliques.  RCCL itself is opened on the first call that needs it
+ * (dlopen): librbg.so does not link it, and RBG_ENODEV is the answer where it is absent. */
 int rbg_counters_allreduce_local(rbg_index *const *replicas, int G, uint64_t out[4]);
+int rbg_comm_cache_clear(void);
 
 /* ---- measurement: what a launch touched (SURVEY 8d "report mean executed steps"; the reference's only
  * instrumentation is the stderr timer line rb_align.cpp:192) ------------------------------------------ */

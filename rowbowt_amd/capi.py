@@ -104,6 +104,8 @@ _PROTOS = [
     ("rbg_locate_fill_stats_dev", C.c_int, [VP, VP, VP, VP, U64, U64, VP, VP, VP, VP, VP]),
     ("rbg_sample_reads_dev", C.c_int, [VP, U64, U64, U64, U64, U64, U64, U64, C.c_uint32, VP, VP, VP, VP]),
     ("rbg_replicate", C.c_int, [VP, C.c_int, C.POINTER(VP)]),
+    ("rbg_replicate_many", C.c_int, [VP, C.POINTER(C.c_int), C.c_int, C.POINTER(VP)]),
+    ("rbg_comm_cache_clear", C.c_int, []),
     ("rbg_shard_bounds", C.c_int, [U64, C.c_int, C.c_int, C.POINTER(U64), C.POINTER(U64)]),
     ("rbg_find_range_sharded", C.c_int, [VP, C.c_int, VP, VP, U64, VP, VP, VP]),
     ("rbg_counters_allreduce", C.c_int, [VP, VP, VP, VP]),
@@ -420,6 +422,18 @@ class RowBowt:
         r._primary = self   # keeps the primary alive
         return r
 
+    def replicate_many(self, devices):
+        """replicas on every device of `devices` at once (the peer copies overlap); free them before this one"""
+        G = len(devices)
+        devs = (C.c_int * G)(*devices)
+        hs = (VP * G)()
+        _check(self.L.rbg_replicate_many(self.h, devs, G, hs), "rbg_replicate_many")
+        out = []
+        for g in range(G):
+            r = RowBowt(VP(hs[g]))
+            r._primary = self
+            out.append(r)
+        return out
 
     def counters_reset(self):
         _check(self.L.rbg_counters_reset(self.h), "rbg_counters_reset")

@@ -36,9 +36,10 @@ class InputSource {
         if (map_) munmap(const_cast<char *>(map_), map_size_);
         if (gz_) gzclose(gz_);
     }
-    bool open(const std::string &path, unsigned threads, uint64_t window_bytes) {
+    bool open(const std::string &path, unsigned threads, uint64_t window_bytes, uint64_t min_segment = uint64_t(4) << 20) {
         threads_ = threads ? threads : 1;
         window_ = window_bytes;
+        min_segment_ = min_segment ? min_segment : 1;
         const int fd = ::open(path.c_str(), O_RDONLY);
         if (fd < 0) return false;
         struct stat sb;
@@ -78,7 +79,7 @@ class InputSource {
                 const uint64_t end = std::min<uint64_t>(map_size_, pos_ + win);
                 final = end == map_size_;
                 w.base = map_ ? map_ : "";
-                rc = rbg_cli::scan_records_parallel(w.base, pos_, end, final, st_, w.recs, &resume, &rstate, threads_);
+                rc = rbg_cli::scan_records_parallel(w.base, pos_, end, final, st_, w.recs, &resume, &rstate, threads_, min_segment_);
                 if (rc == rbg_cli::kScanTruncQual) return -2;
                 if (!(rc == rbg_cli::kScanEnd && final) && resume == pos_ && w.recs.size() == 0 && !final) { win *= 2; continue; }   // one record longer than the window
                 pos_ = resume;
@@ -99,7 +100,7 @@ class InputSource {
                 w.own.resize(have + got);
                 final = eof;
                 w.base = w.own.data();
-                rc = rbg_cli::scan_records_parallel(w.base, 0, w.own.size(), final, st_, w.recs, &resume, &rstate, threads_);
+                rc = rbg_cli::scan_records_parallel(w.base, 0, w.own.size(), final, st_, w.recs, &resume, &rstate, threads_, min_segment_);
                 if (rc == rbg_cli::kScanTruncQual) return stream_error_ ? -3 : -2;
                 carry_.assign(w.own.begin() + static_cast<std::ptrdiff_t>(resume), w.own.end());
                 st_ = rstate;
@@ -115,7 +116,7 @@ class InputSource {
     size_t map_size_ = 0;
     bool mapped_ = false;
     gzFile gz_ = nullptr;
-    uint64_t pos_ = 0, window_ = uint64_t(256) << 20;
+    uint64_t pos_ = 0, window_ = uint64_t(256) << 20, min_segment_ = uint64_t(4) << 20;
     unsigned threads_ = 1;
     rbg_cli::ScanState st_;
     std::vector<char> carry_;

@@ -17,6 +17,7 @@
 #include <cstdint>
 #include <cstring>
 #include <string>
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -219,17 +220,26 @@ inline uint64_t guess_boundary(const char *buf, uint64_t from, uint64_t end) {
     return end;
 }
 
+// how many buffers went through the multi-threaded path (tests assert that it is taken)
+inline std::atomic<uint64_t> &parallel_scans() {
+    static std::atomic<uint64_t> n{0};
+    return n;
+}
+
 // The whole buffer [pos, end) with `threads` workers; same contract as scan_records (limit = end).
 inline int scan_records_parallel(const char *buf, uint64_t pos, uint64_t end, bool final, ScanState &st, RecordSpans &out, uint64_t *resume,
                                  ScanState *resume_state, unsigned threads, uint64_t min_segment = uint64_t(4) << 20) {
     const uint64_t span = end - pos;
     unsigned K = threads ? threads : 1;
     if (span / K < min_segment) K = static_cast<unsigned>(span / min_segment);
-    if (K <= 1 || st.last_char != 0) {
+    // (a window that begins right after an already consumed '>' / '@' -- every FASTA window but the first -- is no
+    // reason to go serial: segment 0 starts from `st`, and the stitch places the next header at `at - 1` then)
+    if (K <= 1) {
         const int rc = scan_records(buf, pos, end, final, end, st, out, resume, resume_state);
         finish_arena(buf, out);
         return rc;
     }
+    parallel_scans().fetch_add(1, std::memory_order_relaxed);
     std::vector<uint64_t> cut(K + 1);
     cut[0] = pos;
     cut[K] = end;

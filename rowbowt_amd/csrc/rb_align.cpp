@@ -132,29 +132,41 @@ struct BatchResult {
     ~BatchResult() { rbg_free_buffer(locs); rbg_free_buffer(mk); }
 };
 
-// rb_get_range + locs_at + markers_at (rb_align.cpp:95-145) for reads [begin, end) of a batch on one replica
-void query_shard(rbg_index *ix, const RbAlignArgs &args, const Window &b, uint64_t begin, uint64_t end, BatchResult &r) {
-    r.begin = begin;
-    r.end = end;
-    const uint64_t N = end - begin;
-    if (N == 0) return;
-    // the sequences are read where the scanner found them (rbg_find_range_spans): no copy into a batch
-    const uint8_t *base = reinterpret_cast<const uint8_t *>(b.base);
-    const uint64_t *sb = b.recs.seq_begin.data() + begin;
-    const uint32_t *sl = b.recs.seq_len.data() + begin;
-    r.lo.resize(N); r.hi.resize(N);
-    if (args.sam) {  // rb_get_range(sa=true), rb_align.cpp:99-103
-        r.k.resize(N);
-        rbwt::detail::check(rbg_find_range_spans(ix, base, sb, sl, N, r.lo.data(), r.hi.data(), r.k.data()), "rbg_find_range_spans");
-        r.loc_off.resize(N + 1);
-        rbwt::detail::check(rbg_locs_at(ix, r.lo.data(), r.hi.data(), r.k.data(), N, static_cast<uint64_t>(-1), r.loc_off.data(), &r.locs),
-                            "rbg_locs_at");  // rb_align.cpp:125
-    } else {
-        rbwt::detail::check(rbg_find_range_spans(ix, base, sb, sl, N, r.lo.data(), r.hi.data(), nullptr), "rbg_find_range_spans");
-    }
-    if (args.markers) {  // rb_align.cpp:138
-        r.mk_off.resize(N + 1);
-        rbwt::detail::check(rbg_markers_at(ix, r.lo.data(), r.hi.data(), N, r.mk_off.data(), &r.mk), "rbg_markers_at");
+// rb_get_range + locs_at + markers_at (rb_align.cpp:95-145) for reads [begin, end) of a batch on one replica.
+// Runs on one worker thread per replica: a failing library call is RETURNED (code + the call's name) and reported by
+// the main thread after the join -- exiting or throwing from a worker would take the process down mid-write.
+struct ShardError {
+    int rc = RBG_OK;
+    const char *what = "";
+};
+ShardError query_shard(rbg_index *ix, const RbAlignArgs &args, const Window &b, uint64_t begin, uint64_t end, BatchResult &r) {
+    try {
+        r.begin = begin;
+        r.end = end;
+        const uint64_t N = end - begin;
+        if (N == 0) return {};
+        // the sequences are read where the scanner found them (rbg_find_range_spans): no copy into a batch
+        const uint8_t *base = reinterpret_cast<const uint8_t *>(b.base);
+        const uint64_t *sb = b.recs.seq_begin.data() + begin;
+        const uint32_t *sl = b.recs.seq_len.data() + begin;
+        int rc;
+        r.lo.resize(N); r.hi.resize(N);
+        if (args.sam) {  // rb_get_range(sa=true), rb_align.cpp:99-103
+            r.k.resize(N);
+            if ((rc = rbg_find_range_spans(ix, base, sb, sl, N, r.lo.data(), r.hi.data(), r.k.data()))) return {rc, "rbg_find_range_spans"};
+            r.loc_off.resize(N + 1);
+            if ((rc = rbg_locs_at(ix, r.lo.data(), r.hi.data(), r.k.data(), N, static_cast<uint64_t>(-1), r.loc_off.data(), &r.locs)))
+                return {rc, "rbg_locs_at"};  // rb_align.cpp:125
+        } else {
+            if ((rc = rbg_find_range_spans(ix, base, sb, sl, N, r.lo.data(), r.hi.data(), nullptr))) return {rc, "rbg_find_range_spans"};
+        }
+        if (args.markers) {  // rb_align.cpp:138
+            r.mk_off.resize(N + 1);
+            if ((rc = rbg_markers_at(ix, r.lo.data(), r.hi.data(), N, r.mk_off.data(), &r.mk))) return {rc, "rbg_markers_at"};
+        }
+        return {};
+    } catch (const std::bad_alloc &) {
+        return {RBG_ENOMEM, "result arrays of a batch"};
     }
 }
 
@@ -247,14 +259,20 @@ void report_batch(const rbwt::RowBowt<> &rb, const std::vector<rbg_index *> &rep
     const auto t_q0 = std::chrono::steady_clock::now();
     {
         std::vector<std::thread> th;
+        std::vector<ShardError> err(G);
         auto work = [&](int g) {
             uint64_t s0 = 0, s1 = 0;
             (void)rbg_shard_bounds(N, g, G, &s0, &s1);
-            query_shard(reps[g], args, b, w0 + s0, w0 + s1, res(g));
+            err[g] = query_shard(reps[g], args, b, w0 + s0, w0 + s1, res(g));
         };
         for (int g = 1; g < G; ++g) th.emplace_back(work, g);
         work(0);
         for (auto &t : th) t.join();
+        for (int g = 0; g < G; ++g)
+            if (err[g].rc) {   // what the single-replica path says, from the main thread, once every worker is done
+                fprintf(stderr, "%s (replica %d): %s\n", err[g].what, g, rbg_strerror(err[g].rc));
+                exit(1);
+            }
     }
     const auto t_q1 = std::chrono::steady_clock::now();
     g_trace_query += std::chrono::duration<double>(t_q1 - t_q0).count();
@@ -280,6 +298,13 @@ void report_batch(const rbwt::RowBowt<> &rb, const std::vector<rbg_index *> &rep
         format_range(rb, args, b, res(0), res(0).begin, res(0).begin + n / T, pieces[first_piece]);
     }
     for (auto &w : workers) w.join();
+    // the text is made: the ragged buffers (3 GB of locations per 10 M reads on a pangenome index) go back now, the
+    // fixed-size arrays stay for the next batch
+    for (int g = 0; g < G; ++g) {
+        rbg_free_buffer(res(g).locs);
+        rbg_free_buffer(res(g).mk);
+        res(g).locs = res(g).mk = nullptr;
+    }
     g_trace_format += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_q1).count();
 #undef res
 }
@@ -305,15 +330,18 @@ int main(int argc, char **argv) {
         std::vector<rbg_index *> owned;
         ~Replicas() { for (rbg_index *r : owned) rbg_free(r); }
     } replicas;
-    for (size_t g = 1; g < args.devices.size(); ++g) {
-        rbg_index *r = nullptr;
-        const int rc = rbg_replicate(rb.handle(), args.devices[g], &r);
+    if (args.devices.size() > 1) {   // every further device at once: the peer copies overlap (one xGMI link per target)
+        const int G = static_cast<int>(args.devices.size()) - 1;
+        std::vector<rbg_index *> more(G, nullptr);
+        const int rc = rbg_replicate_many(rb.handle(), args.devices.data() + 1, G, more.data());
         if (rc) {
-            fprintf(stderr, "rb_align: replica on device %d: %s\n", args.devices[g], rbg_strerror(rc));
+            fprintf(stderr, "rb_align: replicas on %d further device(s): %s\n", G, rbg_strerror(rc));
             exit(1);
         }
-        replicas.owned.push_back(r);
-        reps.push_back(r);
+        for (rbg_index *r : more) {
+            replicas.owned.push_back(r);
+            reps.push_back(r);
+        }
     }
     auto stop = std::chrono::high_resolution_clock::now();
     const std::chrono::duration<double> index_load_time = stop - start;

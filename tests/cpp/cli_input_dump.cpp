@@ -1,7 +1,8 @@
 // Test harness (CPU only): the tools' input side as they use it (rowbowt_amd/csrc/cli_input.hpp: InputSource over a
 // memory-mapped plain file, or through zlib for gzip and pipes) -- window after window, printing "name<TAB>seq" per
 // record, then "rc=<code>" (-1 end of input, -2 truncated quality string, -3 stream error).
-// usage: cli_input_dump <file> <window bytes> <threads>
+// usage: cli_input_dump <file> <window bytes> <threads> [<min bytes per scanning thread>]
+// stderr: "windows=<n> parallel=<n>" -- how many windows there were and how many were scanned by more than one thread
 #include <cstdio>
 #include <cstdlib>
 
@@ -10,14 +11,17 @@
 int main(int argc, char **argv) {
     if (argc < 4) return 2;
     rbg_cli::InputSource in;
-    if (!in.open(argv[1], static_cast<unsigned>(std::atoi(argv[3])), std::strtoull(argv[2], nullptr, 10))) {
+    const unsigned long long minseg = argc > 4 ? std::strtoull(argv[4], nullptr, 10) : (4ull << 20);
+    if (!in.open(argv[1], static_cast<unsigned>(std::atoi(argv[3])), std::strtoull(argv[2], nullptr, 10), minseg)) {
         std::printf("invalid file\n");
         return 3;
     }
     rbg_cli::Window w;
     int rc;
+    unsigned long long windows = 0;
     do {
         rc = in.next(w);
+        ++windows;
         for (size_t i = 0; i < w.size(); ++i) {
             std::fwrite(w.base + w.recs.name_begin[i], 1, w.recs.name_len[i], stdout);
             std::fputc('\t', stdout);
@@ -26,5 +30,6 @@ int main(int argc, char **argv) {
         }
     } while (rc == 0);
     std::printf("rc=%d\n", rc);
+    std::fprintf(stderr, "windows=%llu parallel=%llu\n", windows, static_cast<unsigned long long>(rbg_cli::parallel_scans().load()));
     return 0;
 }

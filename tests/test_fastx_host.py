@@ -130,12 +130,16 @@ def cli_input(tmp_path_factory):
     subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-pthread",
                            os.path.join(ROOT, "tests", "cpp", "cli_input_dump.cpp"), "-o", str(exe), "-lz"])
 
-    def run(path, window, threads):
-        p = subprocess.run([str(exe), str(path), str(window), str(threads)], capture_output=True, timeout=120)
+    def run(path, window, threads, minseg=None, stats=False):
+        p = subprocess.run([str(exe), str(path), str(window), str(threads)] + ([str(minseg)] if minseg else []), capture_output=True, timeout=120)
         assert p.returncode == 0, (p.stdout[-300:], p.stderr[-600:])
         lines = p.stdout.split(b"\n")
         assert lines[-1] == b"" and lines[-2].startswith(b"rc="), lines[-3:]
-        return [tuple(l.split(b"\t", 1)) for l in lines[:-2]], int(lines[-2][3:])
+        res = [tuple(l.split(b"\t", 1)) for l in lines[:-2]], int(lines[-2][3:])
+        if stats:   # "windows=<n> parallel=<n>" on stderr
+            st = dict(kv.split(b"=") for kv in p.stderr.split(b"\n")[-2].split())
+            return res + (int(st[b"windows"]), int(st[b"parallel"]))
+        return res
     return run
 
 
@@ -155,6 +159,31 @@ def test_input_source_plain_and_gzip_match_kseq_model(cli_input, tmp_path, name)
         for window, threads in ((1 << 20, 1), (5, 1), (64, 3), (1000, 4)):
             got, rc = cli_input(path, window, threads)
             assert (got, rc) == ([(n, s) for n, s in want], want_rc), (name, path.name, window, threads)
+
+
+def test_input_source_every_window_is_scanned_in_parallel(cli_input, tmp_path):
+    """FASTA and FASTQ over many windows with several scanning threads, mapped and through zlib: same records as
+    kseq_read, and EVERY window goes through the multi-threaded scan -- also the FASTA windows that begin right after an
+    already consumed '>' (ScanState::last_char set), which used to fall back to one thread"""
+    import gzip
+    rng = np.random.default_rng(21)
+    seqs = [bytes(rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), int(rng.integers(1, 300)))) for _ in range(4000)]
+    fa = b"".join(b">r%d c\n" % i + b"\n".join(s[j:j + 60] for j in range(0, len(s), 60)) + b"\n" for i, s in enumerate(seqs))
+    fq = b"".join(b"@r%d c\n" % i + s + b"\n+\n" + b"@" * len(s) + b"\n" for i, s in enumerate(seqs))
+    for name, data in (("multi.fa", fa), ("multi.fq", fq)):
+        want, want_rc = kseq_model(data)
+        plain = tmp_path / name
+        plain.write_bytes(data)
+        gz = tmp_path / (name + ".gz")
+        with gzip.open(gz, "wb") as f:
+            f.write(data)
+        for path in (plain, gz):
+            for window, threads, minseg in ((60000, 4, 2000), (17000, 3, 500)):
+                got, rc, windows, parallel = cli_input(path, window, threads, minseg, stats=True)
+                assert (got, rc) == ([(n, s) for n, s in want], want_rc), (path.name, window, threads)
+                assert windows >= 8, windows
+                # the last window may be shorter than two segments; every other one must have taken the threaded path
+                assert parallel >= windows - 1, (path.name, window, windows, parallel)
 
 
 @pytest.mark.parametrize("name", sorted(CASES))

@@ -1281,6 +1281,148 @@ def test_positions_beyond_32_bits():
     o.close()
 
 
+def _random_run_index(rng, r, max_len, term_at=None):
+    """A synthetic run list (random heads over ACGT with neighbouring runs different, random lengths, distinct random
+    samples below n) with one terminator run: rank, LF, the toehold bookkeeping and phi are arithmetic on these arrays
+    alone, so they define the answers completely -- for the oracle and for the device alike (no text needed)."""
+    sym = np.frombuffer(b"ACGT", dtype=np.uint8)
+    step = rng.integers(1, 4, size=r, dtype=np.int64)
+    step[0] = 0
+    heads = sym[np.cumsum(step) % 4]
+    lens = rng.integers(1, max_len, size=r, dtype=np.int64).astype(np.uint64)
+    t = r // 3 if term_at is None else term_at
+    heads[t], lens[t] = 1, 1
+    n = int(lens.sum())
+    stride = n // (2 * r)
+    vals = (np.arange(2 * r, dtype=np.uint64) * np.uint64(stride) + rng.integers(0, stride, size=2 * r).astype(np.uint64))
+    rng.shuffle(vals)
+    return heads, lens, vals[:r].copy(), vals[r:].copy(), n
+
+
+def _lf_walk_reads(o, heads, lens, n, rng, count, max_len):
+    """reads that match: c0 = bwt[i0], i1 = LF(i0), c1 = bwt[i1], ... is matched by the pattern c_k ... c1 c0"""
+    starts = np.concatenate([[0], np.cumsum(lens.astype(np.int64))])
+    reads = []
+    for row in rng.integers(0, n, size=count):
+        row, m, q = int(row), int(rng.integers(1, max_len)), bytearray()
+        for _ in range(m):
+            c = int(heads[np.searchsorted(starts, row, side="right") - 1])
+            q.append(c)
+            row = o.LF(row, row, c)[0]
+        reads.append(bytes(q[::-1]))
+    return reads
+
+
+def test_width_limits_2_38_and_2_40():
+    """The position widths the layouts are built around, each crossed by a test (the reference computes in plain
+    uint64_t: toehold_sa.hpp:56-72, rowbowt.hpp:555-573, rle_string.hpp:131-161):
+      * n >= 2^38: phi slots can no longer be packed into 16 bytes (PhiSlotPacked holds 38-bit values) -- the slot
+        layout must fall back to the 32-byte PhiSlot<uint64_t>; ranks above 2^38 in the 48-bit RankSlot;
+      * n just below 2^40: the wide-bucket slot encoding (40-bit ranks, rbg_dev.h) at its largest values;
+      * n >= 2^40: wide buckets are refused when forced (RBG_EARG) and never chosen by the budget rule; the
+        run-indexed layout (8-byte positions throughout) is what serves such an index;
+      * n >= 2^48: refused at flatten (RankSlot carries 48-bit ranks).
+    Run lists are synthetic (r = 2*10^7, mean run 1.4*10^4 .. 5.5*10^4): see _random_run_index."""
+    sym = np.frombuffer(b"ACGT", dtype=np.uint8)
+    rng = np.random.default_rng(3838)
+    r = 20_000_000
+
+    def case(max_len):
+        heads, lens, ssa, esa, n = _random_run_index(rng, r, max_len)
+        o = orc.Oracle.from_runs(heads, lens, ssa, esa)
+        reads = _lf_walk_reads(o, heads, lens, n, rng, 1200, 100)
+        reads += [bytes(rng.choice(sym, size=int(rng.integers(1, 30)))) for _ in range(400)] + [b"", b"ACGTN"]
+        seqs, off = ra.pack_reads(reads)
+        wlo, whi, wk = o.find_range_w_toehold_batch(seqs, off)
+        woff, wlocs = o.locs_at_batch(wlo, whi, wk, max_hits=48)
+        return heads, lens, ssa, esa, n, o, seqs, off, wlo, whi, wk, woff, wlocs
+
+    def check(rb, c, toeholds=True):
+        heads, lens, ssa, esa, n, o, seqs, off, wlo, whi, wk, woff, wlocs = c
+        lo, hi, k = rb.find_range_w_toehold(seqs, off)
+        lo2, hi2 = rb.find_range(seqs, off)
+        assert (lo == wlo).all() and (hi == whi).all() and (lo2 == wlo).all() and (hi2 == whi).all()
+        assert not toeholds or (k == wk).all()
+        loc_off, locs = rb.locs_at(wlo, whi, wk, max_hits=48)
+        assert (loc_off == woff).all() and (locs == wlocs).all()
+
+    # ---- n in (2^38, 2^40): 2^38 = 2.75e11 ----------------------------------------------------------------------------
+    c = case(30_000)
+    n = c[4]
+    assert (1 << 38) < n < (1 << 40) and int(c[8].max()) > (1 << 38) and int(c[12].max()) > (1 << 38)
+    # run-indexed: single steps (toeholds compared) and k-mer depths (ranges + walks from the oracle's toeholds: the
+    # k-mer tables' run-end samples presume a suffix array's samples, DESIGN.md 2b)
+    for ks in (1, 5):
+        with capi.default_option(capi.OPT_KMER_STEPS, ks):
+            rbr = _with_layout(capi.LAYOUT_RUNS, 48, lambda: ra.RowBowt.from_runs(*c[:4], device=0))
+        ir = rbr.info()
+        assert ir.rank_layout == capi.LAYOUT_RUNS and ir.pos_bytes == 8 and ir.n == n and ir.hbm_bytes < 16e9
+        check(rbr, c, toeholds=ks == 1)
+        rbr.close()
+    # slot tables, single-symbol level, 256-row rank buckets and 256-position phi buckets: n/256 x (5 x 20 + 36) bytes
+    with capi.default_option(capi.OPT_KMER_STEPS, 1), capi.default_option(capi.OPT_PHI_BUCKET_SHIFT, 8):
+        rbs = _with_layout(capi.LAYOUT_SLOTS, 48, lambda: ra.RowBowt.from_runs(*c[:4], device=0))
+    i = rbs.info()
+    assert i.rank_layout == capi.LAYOUT_SLOTS and i.pos_bytes == 8 and i.phi_bucket_shift == 8 and i.kmer_steps == 1
+    # 32-byte phi slots: (n >> 8) x 32 bytes alone exceed what packed 16-byte slots would take for the whole table
+    assert i.hbm_bytes > (n >> 8) * (5 * 20 + 36)
+    check(rbs, c)
+    rows = rng.integers(0, n, size=3000).astype(np.uint64)
+    his = np.minimum(rows + rng.integers(0, 100_000, size=3000).astype(np.uint64), np.uint64(n - 1))
+    cs = rng.choice(sym, size=3000)
+    nlo, nhi = rbs.LF(rows, his, cs)
+    for j in range(0, 3000, 5):
+        assert (int(nlo[j]), int(nhi[j])) == c[5].LF(int(rows[j]), int(his[j]), int(cs[j]))
+    rbs.close()
+    c[5].close()
+    del c
+
+    # ---- n just below 2^40: the wide-bucket encoding (4096-row buckets, 40-bit ranks) at the top of its range --------
+    c = case(109_000)
+    n = c[4]
+    assert (1 << 40) - (1 << 36) < n < (1 << 40), n
+    with capi.default_option(capi.OPT_KMER_STEPS, 1), capi.default_option(capi.OPT_RANK_BUCKET_SHIFT, 12), \
+            capi.default_option(capi.OPT_PHI_BUCKET_SHIFT, 8), capi.default_option(capi.OPT_HBM_BUDGET_MB, 240_000):
+        rbw = _with_layout(capi.LAYOUT_SLOTS, 48, lambda: ra.RowBowt.from_runs(*c[:4], device=0))
+    i = rbw.info()
+    assert i.rank_layout == capi.LAYOUT_SLOTS and i.rank_bucket_shift == 12 and i.pos_bytes == 8
+    assert int(c[8].max()) > (1 << 39)                     # ranks in the top half of the 40-bit range
+    check(rbw, c)
+    rbw.close()
+    c[5].close()
+    del c
+
+    # ---- n just above 2^40: wide buckets refused, run-indexed layout serves ---------------------------------------------
+    c = case(112_000)
+    n = c[4]
+    assert (1 << 40) < n < (1 << 40) + (1 << 37), n
+    with capi.default_option(capi.OPT_KMER_STEPS, 1), capi.default_option(capi.OPT_RANK_BUCKET_SHIFT, 12), \
+            capi.default_option(capi.OPT_PHI_BUCKET_SHIFT, 8):
+        with pytest.raises(ra.RbgError) as ei:
+            _with_layout(capi.LAYOUT_SLOTS, 48, lambda: ra.RowBowt.from_runs(*c[:4], device=0))
+        assert ei.value.code == -4                          # RBG_EARG: 40-bit ranks cannot hold this index
+    rba = ra.RowBowt.from_runs(*c[:4], device=0)            # AUTO: the single-symbol slot level (n/256 x 100 B = 430 GB) does not fit
+    ia = rba.info()
+    assert ia.rank_layout == capi.LAYOUT_RUNS and ia.pos_bytes == 8 and ia.hbm_bytes < 16e9
+    check(rba, c, toeholds=False)                           # (k-mer depths: see above)
+    rba.close()
+    with capi.default_option(capi.OPT_KMER_STEPS, 1):
+        rb1 = ra.RowBowt.from_runs(*c[:4], device=0)
+    assert rb1.info().rank_layout == capi.LAYOUT_RUNS and int(c[12].max()) > (1 << 40)
+    check(rb1, c)
+    rb1.close()
+    c[5].close()
+    del c
+
+    # ---- n >= 2^48: refused (48-bit ranks in RankSlot; the run-indexed tables share flatten()) ---------------------------
+    heads, lens, ssa, esa, n = _random_run_index(rng, 2_000_000, 300_000_000)
+    assert n > (1 << 48)
+    for layout in (capi.LAYOUT_SLOTS, capi.LAYOUT_RUNS):
+        with pytest.raises(ra.RbgError) as ei:
+            _with_layout(layout, 48, lambda: ra.RowBowt.from_runs(heads, lens, ssa, esa, device=0))
+        assert ei.value.code == -4
+
+
 def _with_layout(layout, top_kb, build):
     ra.set_default_option(capi.OPT_RANK_LAYOUT, layout)
     ra.set_default_option(capi.OPT_TREE_TOP_KB, top_kb)
@@ -1569,8 +1711,30 @@ def test_replicas_sharded_queries_and_rccl_counters(synth, layout):
         assert (red == 2 * want0).all()
     red1 = capi.counters_allreduce_local([rb])
     assert (red1 == want0).all() and int(red1[0]) == len(reads)
+    # the clique of a device set is made once and kept (rbg_comm_cache_clear drops it; the next call makes a new one)
+    import time
+    t0 = time.perf_counter(); capi.counters_allreduce_local([rb]); t_again = time.perf_counter() - t0
+    assert (capi.counters_allreduce_local([rb]) == want0).all()
+    assert ra.lib().rbg_comm_cache_clear() == 0
+    t0 = time.perf_counter(); red2 = capi.counters_allreduce_local([rb]); t_fresh = time.perf_counter() - t0
+    assert (red2 == want0).all()
+    print(f"counters all-reduce: {t_again * 1e3:.2f} ms with the kept clique, {t_fresh * 1e3:.2f} ms making one")
     with pytest.raises(ra.RbgError):
         capi.counters_allreduce_local([rb, rb])   # the same device twice is not a clique
+    # several replicas at once (rbg_replicate_many: the peer copies of all targets are in flight together)
+    many = rb.replicate_many([1 if ndev > 1 else 0, 0, (2 if ndev > 2 else 0)])
+    assert len(many) == 3 and all(r.info().hbm_bytes == rb.info().hbm_bytes for r in many)
+    for r in many:
+        lo4, hi4, k4 = r.find_range_w_toehold(seqs, off)
+        assert (lo4 == wlo).all() and (hi4 == whi).all() and (k4 == wk).all()
+        o4, l4 = r.locs_at(lo4, hi4, k4)
+        assert (o4 == woff).all() and (l4 == wlocs).all()
+    lo5, hi5, k5 = capi.find_range_sharded(many, seqs, off, toehold=True)
+    assert (lo5 == wlo).all() and (hi5 == whi).all() and (k5 == wk).all()
+    with pytest.raises(ra.RbgError):
+        rb.replicate_many([0, 4096])              # all or nothing: a bad device leaves no replica behind
+    for r in many:
+        r.close()
     rep.close()
     rb.close()
     o.close()
@@ -1804,3 +1968,36 @@ def test_full_size_properties_and_parity_sample():
     assert d["markers"]["parity"]["bit_exact_vs_oracle"] and d["markers"]["marker_seeds"]["parity"]["bit_exact_vs_oracle"]
     c = d["counters"]
     assert c["reads"] == 10_000_000 and c["sum_occ"] == c["sum_locs"] > 300_000_000   # sum of range widths == locations written
+
+
+@pytest.mark.parametrize("layout", ["slots", "runs"])
+def test_pangenome_stream_true_bwt_beyond_32_bits(layout):
+    """BASELINE.json configs[3]'s single-GPU shape under the driver's own test run: a TRUE BWT with n = 4.4e9 > 2^32
+    (rowbowt_amd/tools/pangenome_bwt.py: run heads, lengths and both samples of every run derived from the text's
+    structure), 150 bp reads generated on the device, streamed count+locate in batches, through
+    tools/pangenome_stream.py in a subprocess -- both layouts.  Ranges, toeholds (the k-mer steps' re-sampled ones
+    included, some of them above 2^32: rowbowt.hpp:555-573 over toehold_sa.hpp:56-72), locations and the count-only
+    kernel bit-exact against the oracle on 5 000 reads; the size-independent properties on 100 000."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "pangenome_stream.py"), "--L", "44000000", "--H", "100",
+                        "--total-reads", "20000000", "--reads", "5000000", "--check-reads", "5000", "--property-reads", "100000",
+                        "--layout", layout, "--gpus", "1"],
+                       capture_output=True, timeout=1200, cwd=root)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    d = json.loads(p.stdout.decode().strip().splitlines()[-1])
+    ix = d["config"]["index"]
+    assert ix["n"] > (1 << 32) and ix["true_bwt"] and ix["pos_bytes"] == 8 and ix["rank_layout"] == {"slots": 1, "runs": 2}[layout]
+    assert ix["symbols_per_gather"] >= 4 and d["n_gpus"] == 1
+    par = d["parity"]
+    assert par["reads_checked"] == 5000 and par["bit_exact_vs_oracle"] and par["count_only_kernel_bit_exact"]
+    assert par["toeholds_above_2^32"] > 20 and par["locs_checked"] > 100_000
+    props = d["properties"]
+    assert props["reads"] == 100000 and props["locations"] > 2_000_000
+    assert all(props[k] for k in ("unmutated_reads_all_found", "empty_is_{1,0}", "every_location_is_an_occurrence", "locations_distinct",
+                                  "occ_equals_range_width", "own_position_reported"))
+    c = d["counters"]
+    assert c["reads"] == 20_000_000 and c["sum_occ"] == c["sum_locs"] > 500_000_000
+    print(f"n = {ix['n']:.3e}, {layout}: {d['value']:.3e} reads/s streamed, {ix['hbm_bytes'] / 1e9:.1f} GB replica")
