@@ -287,6 +287,35 @@ def main():
     del d_loc_off1, d_locs1
     step()  # leave the uncapped results in the buffers for the checks below
 
+    # ---- the same step storing 4-byte locations (rbg_locate_fill_dev32: device pipelines on an index with 4-byte
+    # positions; informational -- `value` keeps the API's 64-bit locations, toehold_sa.hpp:37-49) -----------------
+    u32_block = None
+    if ix.pos_bytes == 4:
+        d_locs32 = torch.empty(max(total_locs, 1), dtype=torch.int32, device=dev)
+
+        def k_fill32():
+            chk(L.rbg_locate_fill_dev32(rb.h, d_lo.data_ptr(), d_hi.data_ptr(), d_k.data_ptr(), N, max_hits, d_loc_off.data_ptr(),
+                                        d_locs32.data_ptr(), d_ws.data_ptr(), st), "locate_fill_dev32")
+
+        def step32():
+            k_toehold()
+            k_plan()
+            k_order()
+            k_fill32()
+
+        step32()
+        el32 = timed(step32, K)
+        ev32 = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        ev32[0].record(stream)
+        k_fill32()
+        ev32[1].record(stream)
+        torch.cuda.synchronize()
+        same32 = bool(((d_locs32[:total_locs].to(torch.int64) & 0xFFFFFFFF) == (d_locs[:total_locs] & 0xFFFFFFFF)).all().item())
+        u32_block = {"value": N * K / el32, "unit": "reads/s (this rank)", "ms_per_step": el32 / K * 1e3, "k_locate_fill_ms": ev32[0].elapsed_time(ev32[1]),
+                     "same_locations_as_the_64_bit_walk": same32,
+                     "workload": "count+locate with the locations stored as 32 bits (rbg_locate_fill_dev32; informational)"}
+        del d_locs32
+
     # ---- the same K count+locate steps as successive batches on two HIP streams (informational) --
     # K2 is bound by gather requests, the toehold-ordered K3 is not: the next batch's search overlaps
     # this batch's locate.  Outputs are double-buffered; the headline `value` stays the plain
@@ -387,7 +416,7 @@ def main():
     # timed region; same outputs).  The bytes of the algorithm as run follow from these counts.
     d_stats = torch.zeros(16, dtype=torch.int64, device=dev)
 
-    def search_stats(toehold):
+    def search_stats(toehold):   # (works on both layouts; on the run-indexed one the sums count that layout's accesses: include/rbg.h)
         d_stats.zero_()
         chk(L.rbg_find_range_stats_dev(rb.h, d_seqs.data_ptr(), d_off.data_ptr(), N, d_lo.data_ptr(), d_hi.data_ptr(),
                                        d_k.data_ptr() if toehold else None, d_stats.data_ptr(), st), "find_range_stats")
@@ -505,6 +534,7 @@ def main():
                                      "workload": "the same K count+locate steps issued as successive batches on two HIP streams"}
                                     if args.two_stream else None),
             "markers": mk_block,
+            "locations_u32": u32_block,
             "capped_max_hits_1": {"value": N * K / el_cap, "unit": "reads/s (this rank)", "ms_per_step": el_cap / K * 1e3,
                                   "first_location_is_the_toehold": capped_ok,
                                   "workload": "count+locate with max_hits = 1 (diagnostic: search cost without the phi walks)"},
@@ -733,9 +763,35 @@ def main():
         e[1].record(stream)
         torch.cuda.synchronize()
         ms_r["k_locate_fill"] = e[0].elapsed_time(e[1])
+        # bytes of the run-indexed kernels AS RUN (instrumented instantiations; sums as include/rbg.h lists them for this
+        # layout): per read its offsets + outputs + read chunks + ftab entry; per directory gather 8; per run-list entry a
+        # probe needed 2P; per narrowing round 16 pivot keys of P; per materialised re-sample P.  K3: per read 28, per phi
+        # step one 8-byte directory gather, per sampled position a probe needed 2P, 8 per location stored.
+        Pr = int(rb.info().pos_bytes)
+        rs_count, rs_toe = search_stats(False), search_stats(True)
+        k_toehold(); k_plan(); k_order()
+        d_stats.zero_()
+        chk(L.rbg_locate_fill_stats_dev(rb.h, d_lo.data_ptr(), d_hi.data_ptr(), d_k.data_ptr(), N, max_hits, d_loc_off.data_ptr(),
+                                        d_locs.data_ptr(), d_ws.data_ptr(), d_stats.data_ptr(), st), "locate_fill_stats")
+        torch.cuda.synchronize()
+        rs_loc = dict(zip(("phi_steps", "probe_entries", "chains", "locs"), d_stats.cpu().numpy().tolist()[:4]))
+        rb.counters_reset()
+
+        def run_search_bytes(sv, toehold):
+            return (N * (16 + (24 if toehold else 16)) + 16 * sv["read_chunks"] + (16 if Pr == 4 else 32) * sv["ftab"] + 8 * sv["slots"]
+                    + 2 * Pr * sv["dense"] + 16 * Pr * sv["searched_ranks"] + Pr * sv["resamples"])
+
+        run_alg = {"k_find_range<count>": run_search_bytes(rs_count, False), "k_find_range<toehold>": run_search_bytes(rs_toe, True),
+                   "k_locate_fill": N * 28 + 8 * rs_loc["phi_steps"] + 2 * Pr * rs_loc["probe_entries"] + 8 * rs_loc["locs"]}
+        run_roof = {kk: {"alg_bytes": v, "alg_GBps": v / (ms_r[kk] * 1e-3) / 1e9, "frac_of_hbm_peak": v / (ms_r[kk] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                    for kk, v in run_alg.items()}
+        run_touched = {"per_read": {"search_steps": rs_toe["steps"] / N, "directory_gathers": rs_toe["slots"] / N, "run_list_entries_probed": rs_toe["dense"] / N,
+                                    "narrowing_rounds": rs_toe["searched_ranks"] / N, "resamples": rs_toe["resamples"] / N,
+                                    "phi_steps": rs_loc["phi_steps"] / N, "phi_entries_probed": rs_loc["probe_entries"] / N},
+                       "search": rs_toe, "locate": rs_loc}
         same = all(bool((a == b).all().item()) for a, b in zip(ref_out, (d_lo, d_hi, d_k, d_loc_off))) and bool((ref_locs == d_locs[:total_locs]).all().item())
         rows.append({"layout": "runs", "symbols_per_gather": int(rb.info().kmer_steps), "hbm_bytes": int(rb.info().hbm_bytes), "ms": ms_r,
-                     "identical_to_slot_path_on_the_whole_batch": same,
+                     "identical_to_slot_path_on_the_whole_batch": same, "roofline": run_roof, "touched": run_touched,
                      "count_locate_reads_per_s": N / ((ms_r["k_find_range<toehold>"] + ms_r["k_locate_fill"] + ms_plan + ms_order) * 1e-3)})
         if not same:
             out["space_speed"] = {"rows": rows}

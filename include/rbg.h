@@ -277,6 +277,13 @@ int rbg_locate_fill_dev(rbg_index *, const uint64_t *d_lo, const uint64_t *d_hi,
                         uint64_t max_hits, const uint64_t *d_loc_off, uint64_t *d_locs, const void *d_order, void *stream);
 /* locate_fill with a per-read value subtracted from every location (d_sub nullable): the
  * `locs[i] - best_range.qstart` of locate_from_longest_seed, rowbowt.hpp:681-683 */
+/* The same walk storing each location as 32 bits (d_loc_off still counts locations): for device pipelines on an
+ * index with 4-byte positions (rbg_info().pos_bytes == 4, i.e. n < 2^32 - 16; RBG_EARG otherwise) -- half the write
+ * requests of the step that dominates count+locate.  The values are the low 32 bits of rbg_locate_fill_dev's, so a
+ * toehold that wrapped below zero (a match at text position 0 of a range wider than one row) reads 0xFFFFFFFF.
+ * The host API and the reference's signature (vector<uint64_t>, toehold_sa.hpp:37-49) keep 64 bits. */
+int rbg_locate_fill_dev32(rbg_index *, const uint64_t *d_lo, const uint64_t *d_hi, const uint64_t *d_k, uint64_t N,
+                          uint64_t max_hits, const uint64_t *d_loc_off, uint32_t *d_locs32, const void *d_order, void *stream);
 int rbg_locate_fill_offset_dev(rbg_index *, const uint64_t *d_lo, const uint64_t *d_hi, const uint64_t *d_k, uint64_t N,
                                uint64_t max_hits, const uint64_t *d_loc_off, uint64_t *d_locs, const uint64_t *d_sub,
                                const void *d_order, void *stream);
@@ -343,6 +350,11 @@ int rbg_comm_cache_clear(void);
  * outputs, same counters) and add what it touched to a device array of RBG_SEARCH_STATS / RBG_LOCATE_STATS
  * 64-bit sums, which the caller zeroes first.  bench.py derives the bytes of the algorithm as run from them;
  * the timed launches are the plain ones. */
+/* On the run-indexed layout (RBG_LAYOUT_RUNS) the same sums count that layout's accesses: RBG_SS_SLOTS = directory
+ * gathers (8 bytes each), RBG_SS_DENSE = run-list entries the probes needed (2 positions' width each; at most 16 per
+ * probe), RBG_SS_SEARCH = narrowing rounds of crowded buckets (16 pivot keys each), RBG_SS_RESAMPLE = one sample gather
+ * each; RBG_LS_PHI_STEPS = phi evaluations (one 8-byte directory gather + one probe each), RBG_LS_PHI_SEARCH = sampled
+ * positions those probes and their narrowing rounds needed. */
 enum { RBG_SS_STEPS = 0,      /* LF gathers issued (single-symbol or k-mer steps) */
        RBG_SS_SLOTS,          /* 16-byte rank slots loaded (1 per step, 2 when lo and hi+1 fall in different buckets) */
        RBG_SS_DENSE,          /* 2-byte loads from dense overflow tables */

@@ -99,11 +99,14 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 
 // STATS = the instrumented instantiation (rbg_locate_fill_stats_dev): the same walk plus the LocateStat sums.
-template <typename P, bool STATS = false, int CH = (sizeof(P) == 8 ? RBG_K3_CHUNK_U64 : kChunk)>
+// OUT = the width a location is stored at: uint64_t (the API's, toehold_sa.hpp:37-49 fills a vector<uint64_t>) or, for
+// device pipelines on an index with 4-byte positions, uint32_t (rbg_locate_fill_dev32: half the write requests; the low
+// 32 bits of the same values, so a toehold that wrapped below zero reads 0xFFFFFFFF).
+template <typename P, bool STATS = false, typename OUT = uint64_t, int CH = (sizeof(P) == 8 ? RBG_K3_CHUNK_U64 : kChunk)>
 __global__ __launch_bounds__(256) void k_locate_fill(const DevIndex ix, const uint64_t *__restrict__ lo,
                                                      const uint64_t *__restrict__ hi, const uint64_t *__restrict__ k,
                                                      const uint64_t N, const uint64_t max_hits,
-                                                     const uint64_t *__restrict__ loc_off, uint64_t *__restrict__ locs,
+                                                     const uint64_t *__restrict__ loc_off, OUT *__restrict__ locs,
                                                      const uint64_t *__restrict__ sub, const uint32_t *__restrict__ order,
                                                      const uint64_t *__restrict__ skeys,
                                                      unsigned long long *__restrict__ stats = nullptr) {
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(256) void k_locate_fill(const DevIndex ix, const ui
                 const int s = pass * (kWave / CH) + lane / CH;
                 const int e = lane & (CH - 1);
                 const uint64_t t = t0 + e;
-                if (t < s_occ[wv][s]) locs[s_dst[wv][s] + t] = (t ? static_cast<uint64_t>(s_val[wv][s][e]) : s_first[wv][s]) - s_minus[wv][s];
+                if (t < s_occ[wv][s]) locs[s_dst[wv][s] + t] = static_cast<OUT>((t ? static_cast<uint64_t>(s_val[wv][s][e]) : s_first[wv][s]) - s_minus[wv][s]);
             }
             wave_lds_sync();
         }
@@ -274,7 +277,7 @@ int launch_locate_plan(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t 
 
 int launch_locate_fill(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t *lo, const uint64_t *hi,
                        const uint64_t *k, uint64_t N, uint64_t max_hits, const uint64_t *loc_off, uint64_t *locs,
-                       const uint64_t *sub, const void *order, void *stream, unsigned long long *stats) {
+                       const uint64_t *sub, const void *order, void *stream, unsigned long long *stats, uint32_t *locs32) {
     if (N == 0) return 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid(grid_for(cfg, N)), block(cfg.block_threads);
@@ -282,8 +285,12 @@ int launch_locate_fill(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t 
     const uint64_t *skeys = order ? reinterpret_cast<const uint64_t *>(static_cast<const char *>(order) + order_layout(N).keys) : nullptr;
     const uint32_t *perm = static_cast<const uint32_t *>(order);
     if (ix.layout == 2) {  // run-indexed layout (k_runs.hip)
-        if (stats) return static_cast<int>(hipErrorNotSupported);
-        return launch_locate_fill_runs(ix, cfg, lo, hi, k, N, max_hits, loc_off, locs, sub, order, skeys, stream);
+        return launch_locate_fill_runs(ix, cfg, lo, hi, k, N, max_hits, loc_off, locs, sub, order, skeys, stream, stats, locs32);
+    }
+    if (locs32) {   // 4-byte locations (4-byte positions only; the caller checked)
+        if (stats || ix.pos_bytes != 4) return static_cast<int>(hipErrorInvalidValue);
+        hipLaunchKernelGGL((k_locate_fill<uint32_t, false, uint32_t>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, locs32, sub, perm, skeys, nullptr);
+        return static_cast<int>(hipGetLastError());
     }
     if (stats) {
         if (ix.pos_bytes == 4) hipLaunchKernelGGL((k_locate_fill<uint32_t, true>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, locs, sub, perm, skeys, stats);

@@ -582,6 +582,11 @@ int launch_find_range_markers_plan(const DevIndex &ix, const LaunchCfg &cfg, con
                                    uint64_t N, uint64_t wsize, uint64_t max_range, uint64_t *lo, uint64_t *hi,
                                    uint64_t *mk_off, void *tmp, size_t tmp_bytes, void *stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (ix.layout == 2) {   // run-indexed layout: the cooperative kernel (k_runs_seeds.hip)
+        const int rc2 = launch_find_range_markers_runs(ix, cfg, seqs, off, N, wsize, max_range, lo, hi, mk_off, nullptr, nullptr, false, stream);
+        if (rc2) return rc2;
+        return scan_in_place(mk_off + 1, N, tmp, tmp_bytes, st);
+    }
     const dim3 grid(grid_for(cfg, N)), block(cfg.block_threads);
     if (ix.pos_bytes == 4)
         hipLaunchKernelGGL((k_find_range_markers<uint32_t, false>), grid, block, 0, st, ix, seqs, off, N, wsize, max_range, lo, hi, mk_off, nullptr, nullptr);
@@ -596,6 +601,7 @@ int launch_find_range_markers_fill(const DevIndex &ix, const LaunchCfg &cfg, con
                                    uint64_t N, uint64_t wsize, uint64_t max_range, const uint64_t *mk_off, uint64_t *mk,
                                    void *stream) {
     if (N == 0) return 0;
+    if (ix.layout == 2) return launch_find_range_markers_runs(ix, cfg, seqs, off, N, wsize, max_range, nullptr, nullptr, nullptr, mk_off, mk, true, stream);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid(grid_for(cfg, N)), block(cfg.block_threads);
     if (ix.pos_bytes == 4)
@@ -609,6 +615,13 @@ int launch_marker_seeds_plan(const DevIndex &ix, const LaunchCfg &cfg, const uin
                              uint64_t wsize, uint64_t max_range, uint64_t ftab_k, uint64_t *seed_off, uint64_t *mk_off, void *tmp,
                              size_t tmp_bytes, void *stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (ix.layout == 2 && ftab_k == 0) {   // run-indexed layout, the tool's default mode: the cooperative kernel (k_runs_seeds.hip)
+        int rc2 = launch_marker_seeds_runs(ix, cfg, seqs, off, N, wsize, max_range, seed_off, mk_off, nullptr, nullptr, nullptr, nullptr, false, stream);
+        if (rc2) return rc2;
+        rc2 = scan_in_place(seed_off + 1, N, tmp, tmp_bytes, st);
+        if (rc2) return rc2;
+        return scan_in_place(mk_off + 1, N, tmp, tmp_bytes, st);
+    }
     if (ix.pos_bytes == 4) {
         auto kern = k_marker_seeds<uint32_t, false>;
         const KmerLaunch L = kmer_launch(ix, cfg, N, kern, 0, kSeedKmerLevel);
@@ -629,6 +642,8 @@ int launch_marker_seeds_fill(const DevIndex &ix, const LaunchCfg &cfg, const uin
                              uint64_t wsize, uint64_t max_range, uint64_t ftab_k, const uint64_t *seed_off, const uint64_t *mk_off,
                              uint64_t *seeds, uint64_t *mk, void *stream) {
     if (N == 0) return 0;
+    if (ix.layout == 2 && ftab_k == 0)
+        return launch_marker_seeds_runs(ix, cfg, seqs, off, N, wsize, max_range, nullptr, nullptr, seed_off, mk_off, seeds, mk, true, stream);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (ix.pos_bytes == 4) {
         auto kern = k_marker_seeds<uint32_t, true>;
@@ -645,6 +660,7 @@ int launch_marker_seeds_fill(const DevIndex &ix, const LaunchCfg &cfg, const uin
 int launch_greedy_seed(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
                        uint64_t min_length, uint64_t *lo, uint64_t *hi, uint64_t *qs, uint64_t *qe, uint64_t *ss, void *stream) {
     if (N == 0) return 0;
+    if (ix.layout == 2) return launch_greedy_seed_runs(ix, cfg, seqs, off, N, min_length, lo, hi, qs, qe, ss, stream);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (ix.pos_bytes == 4) {
         auto kern = k_greedy_seed<uint32_t>;
@@ -661,6 +677,7 @@ int launch_greedy_seed(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *
 int launch_lf(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t *lo, const uint64_t *hi, const uint8_t *sym,
               uint64_t N, uint64_t *lo_out, uint64_t *hi_out, void *stream) {
     if (N == 0) return 0;
+    if (ix.layout == 2) return launch_lf_runs(ix, cfg, lo, hi, sym, N, lo_out, hi_out, stream);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid(grid_for(cfg, N)), block(cfg.block_threads);
     if (ix.pos_bytes == 4) hipLaunchKernelGGL((k_lf<uint32_t>), grid, block, 0, st, ix, lo, hi, sym, N, lo_out, hi_out);

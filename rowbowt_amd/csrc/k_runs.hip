@@ -12,662 +12,10 @@
 // first version of these kernels (16-lane rows, every value by ds_bpermute) was bound by the LDS pipe, not by
 // memory (profiles/).  The 16-lane rows remain for the narrowing of crowded buckets, the descent of an
 // index built without directories, the unordered phi walk and the optional bucket records.
-#include "rbg_device.hpp"
+#include "rbg_runs_device.hpp"
 
 namespace rbg {
 namespace {
-
-constexpr int kFan = kTreeFan;                 // entries per block = lanes that probe one block together
-constexpr int kRows = kWave / kFan;            // blocks probed by one wave-wide load instruction
-static_assert(kFan == 16 && kRows == 4, "the probes below are written for 16-lane rows of a 64-lane wave");
-
-// pair of P as the kernels load it (one request per lane)
-template <typename P> struct PairOf;
-template <> struct PairOf<uint32_t> { typedef unsigned int vec __attribute__((ext_vector_type(2))); };
-template <> struct PairOf<uint64_t> { typedef unsigned long long vec __attribute__((ext_vector_type(2))); };
-
-// value of lane `j` of this lane's 16-lane row
-__device__ __forceinline__ uint32_t row_get(uint32_t v, uint32_t rowbase, int j) { return __shfl(v, static_cast<int>(rowbase) | j, kWave); }
-__device__ __forceinline__ uint64_t row_get(uint64_t v, uint32_t rowbase, int j) { return __shfl(v, static_cast<int>(rowbase) | j, kWave); }
-// the same from a lane chosen at run time (same in every lane of the row)
-__device__ __forceinline__ uint32_t row_pick(uint32_t v, uint32_t rowbase, uint32_t j) { return __shfl(v, static_cast<int>(rowbase | j), kWave); }
-__device__ __forceinline__ uint64_t row_pick(uint64_t v, uint32_t rowbase, uint32_t j) { return __shfl(v, static_cast<int>(rowbase | j), kWave); }
-
-__device__ __forceinline__ void wave_lds_sync() {  // as in k_locate.hip: orders the wave's own LDS writes and cross-lane reads
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// the next lane's value within the 16-lane row (a DPP move: no LDS traffic; lane 15 of a row gets 0)
-__device__ __forceinline__ uint32_t row_next(uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x101, 0xF, 0xF, false)); }
-__device__ __forceinline__ uint64_t row_next(uint64_t v) {
-    return (static_cast<uint64_t>(row_next(static_cast<uint32_t>(v >> 32))) << 32) | row_next(static_cast<uint32_t>(v));
-}
-
-// REQUEST SLOTS.  The kernels below are bound by the LDS pipe, not by memory, when every value an owner shares with its
-// row travels by ds_bpermute (372 of them per wave and LF step in round 2's first kernels: SQ_ACTIVE_INST_LDS at the
-// CU's limit, profiles/).  So an owner WRITES what its row needs to know -- where to probe, how many candidates, the two
-// positions -- into its own slots of an LDS area once per pass (kReqSlots x 16 bytes per lane), and in round j the row's
-// lanes read owner j's slot with one broadcast ds_read_b128; the rank itself is computed by the lane that holds the run
-// (its neighbour's count arrives by DPP), so what travels back is one value per position.
-template <typename P> struct ReqSlots { static constexpr int v = sizeof(P) == 8 ? 3 : 2; };
-
-// does round j serve anyone?  (m = ballot of the lanes with a query; round j serves lane j of each row: the test is
-// uniform over the wave, so a round without an owner costs a scalar branch instead of its cross-lane traffic)
-__device__ __forceinline__ bool round_has_owner(uint64_t m, int j) { return (m & (0x0001000100010001ull << j)) != 0; }
-
-// # lanes of this lane's row for which `pred` holds
-__device__ __forceinline__ uint32_t row_count(bool pred, uint32_t rowbase) {
-    return static_cast<uint32_t>(__popc(static_cast<uint32_t>(__ballot(pred) >> rowbase) & 0xFFFFu));
-}
-
-// # entries of s_top[off, off + n) that are < q (per lane; LDS)
-template <typename P>
-__device__ __forceinline__ uint32_t top_count(const P *s_top, uint32_t off, uint32_t n, uint64_t q) {
-    uint32_t a = 0, z = n;
-    while (a < z) {
-        const uint32_t mid = (a + z) >> 1;
-        if (static_cast<uint64_t>(s_top[off + mid]) < q) a = mid + 1; else z = mid;
-    }
-    return a;
-}
-
-// A query is a predecessor search CLAMPED to a slice [lo_t, hi_t) of the tree's entry array (one table of a k-mer
-// depth, rbg_dev.h DevRunTab; the whole array for phi): entries before the slice count as below the query, entries
-// from hi_t on as not below it.  For the 16 entries of the block that starts at entry index `gbase` of a level whose
-// entries stand `1 << sh` apart in the leaf array, that is: the first `a` lanes are below whatever their key, lanes
-// from `z` on are not; both fit five bits.
-__device__ __forceinline__ uint32_t clamp_lanes(uint64_t bound, uint64_t gbase, int sh) {
-    if (bound <= gbase) return 0;
-    const uint64_t d = (bound - gbase + ((uint64_t(1) << sh) - 1)) >> sh;
-    return d > static_cast<uint64_t>(kFan) ? static_cast<uint32_t>(kFan) : static_cast<uint32_t>(d);
-}
-// info word an owner publishes to its row for one level: bit 0 any query, bit 1 second block, bits 2-4 tree,
-// bits 5-9 / 10-14 (a, z) of the first block, bits 15-19 / 20-24 (a, z) of the second
-__device__ __forceinline__ uint32_t level_info(bool any, bool two, uint32_t tid, uint32_t first, uint32_t b1, uint32_t lo_t, uint32_t hi_t, int sh) {
-    const uint64_t g0 = (static_cast<uint64_t>(first) * kFan) << sh, g1 = (static_cast<uint64_t>(b1) * kFan) << sh;
-    return (any ? 1u : 0u) | (two ? 2u : 0u) | (tid << 2) | (clamp_lanes(lo_t, g0, sh) << 5) | (clamp_lanes(hi_t, g0, sh) << 10) |
-           (clamp_lanes(lo_t, g1, sh) << 15) | (clamp_lanes(hi_t, g1, sh) << 20);
-}
-
-// One sampled level (keys only), for up to two queries per lane.  On entry t0 / t1 = # entries of the level ABOVE
-// that are below q (>= 1 for a live query): the answer at this level lies in block t - 1.  On return t = # entries of
-// THIS level that are below q.  Every lane of the wave must call.
-// The wave works in kFan rounds: in round j each 16-lane row serves the queries of ITS lane j -- the row's lanes load
-// the 16 keys of that owner's block with one coalesced request (four owners per wave-wide load instruction), the
-// owner's query is broadcast along the row, and popcount(ballot) over the row is the answer.  All 16 rounds' loads are
-// issued before the first compare, so a level costs one memory round trip per wave, not one per owner.
-template <typename P>
-__device__ __forceinline__ void coop_level(const DevTree *s_tree, const int l, const uint32_t tid, const uint32_t lo_t, const uint32_t hi_t,
-                                           const bool live0, const bool live1, uint32_t &t0, uint32_t &t1, const P q0, const P q1) {
-    const uint32_t lane = threadIdx.x & (kWave - 1), sub = lane & (kFan - 1), rowbase = lane & ~static_cast<uint32_t>(kFan - 1);
-    const uint64_t m_live = __ballot(live0 || live1);
-    if (!m_live) return;
-    const uint32_t b0 = t0 - 1, b1 = t1 - 1;
-    const bool two = live0 && live1 && b0 != b1;                     // the second query needs a block of its own
-    const uint32_t first = live0 ? b0 : b1;
-    const uint32_t info = level_info(live0 || live1, two, tid, first, b1, lo_t, hi_t, 4 * (l + 1));
-    P va[kFan];
-#pragma unroll
-    for (int j = 0; j < kFan; ++j) {
-        if (!round_has_owner(m_live, j)) continue;
-        const uint32_t oi = row_get(info, rowbase, j);
-        const uint32_t ob = row_get(first, rowbase, j);
-        va[j] = static_cast<P>(~P(0));
-        if (oi & 1u) {
-            const DevTree &T = s_tree[(oi >> 2) & 7u];
-            const uint64_t i = static_cast<uint64_t>(ob) * kFan + sub;
-            if (i < T.lvl_n[l]) va[j] = static_cast<const P *>(T.lvl[l])[i];
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < kFan; ++j) {
-        if (!round_has_owner(m_live, j)) continue;
-        // padding lanes hold the all-ones key, which no query exceeds (positions stay below it: flatten())
-        const uint32_t oi = row_get(info, rowbase, j);
-        const uint32_t a = (oi >> 5) & 31u, z = (oi >> 10) & 31u;
-        const bool in = sub < z;
-        // (the broadcasts are cross-lane operations: every lane must execute them, so they stay outside the || / &&)
-        const P oq0 = row_get(q0, rowbase, j), oq1 = row_get(q1, rowbase, j);
-        const uint32_t c0 = row_count(sub < a || (in && va[j] < oq0), rowbase);
-        const uint32_t c1 = row_count(sub < a || (in && va[j] < oq1), rowbase);
-        if (static_cast<int>(sub) == j) {
-            if (live0) t0 = b0 * kFan + c0;
-            if (live1 && !two) t1 = b1 * kFan + c1;
-        }
-    }
-    const uint64_t m_two = __ballot(two);
-    if (!m_two) return;
-#pragma unroll
-    for (int j = 0; j < kFan; ++j) {
-        if (!round_has_owner(m_two, j)) continue;
-        const uint32_t oi = row_get(info, rowbase, j);
-        const uint32_t ob = row_get(b1, rowbase, j);
-        va[j] = static_cast<P>(~P(0));
-        if (oi & 2u) {
-            const DevTree &T = s_tree[(oi >> 2) & 7u];
-            const uint64_t i = static_cast<uint64_t>(ob) * kFan + sub;
-            if (i < T.lvl_n[l]) va[j] = static_cast<const P *>(T.lvl[l])[i];
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < kFan; ++j) {
-        if (!round_has_owner(m_two, j)) continue;
-        const uint32_t oi = row_get(info, rowbase, j);
-        const uint32_t a = (oi >> 15) & 31u, z = (oi >> 20) & 31u;
-        const P oq1 = row_get(q1, rowbase, j);
-        const uint32_t c1 = row_count(sub < a || (sub < z && va[j] < oq1), rowbase);
-        if (static_cast<int>(sub) == j && two) t1 = b1 * kFan + c1;
-    }
-}
-
-// The leaf level: {key, value} pairs, probed the same way.  For each live query returns g = # entries below q (in t),
-// the pair before it (key pk, value pv: entry g-1) and the value of entry g (nv; every slice ends with a sentinel).
-// Entries g-1 and g are read out of the registers of the row's lanes that loaded them: a rank costs no further gather.
-template <typename P>
-__device__ __forceinline__ void coop_leaf(const DevTree *s_tree, const uint32_t tid, const uint32_t lo_t, const uint32_t hi_t, const bool live0,
-                                          const bool live1, uint32_t &t0, uint32_t &t1, const P q0, const P q1, P &pk0, P &pv0, P &nv0, P &pk1,
-                                          P &pv1, P &nv1) {
-    typedef typename PairOf<P>::vec vec;
-    const uint32_t lane = threadIdx.x & (kWave - 1), sub = lane & (kFan - 1), rowbase = lane & ~static_cast<uint32_t>(kFan - 1);
-    const uint64_t m_live = __ballot(live0 || live1);
-    if (!m_live) return;
-    const uint32_t b0 = t0 - 1, b1 = t1 - 1;
-    const bool two = live0 && live1 && b0 != b1;
-    const uint32_t first = live0 ? b0 : b1;
-    const uint32_t info = level_info(live0 || live1, two, tid, first, b1, lo_t, hi_t, 0);
-    bool fix0 = false, fix1 = false;  // entry g is the first of the next block: fetched by the owner afterwards
-    vec va[kFan];
-#pragma unroll
-    for (int j = 0; j < kFan; ++j) {
-        if (!round_has_owner(m_live, j)) continue;
-        const uint32_t oi = row_get(info, rowbase, j);
-        const uint32_t ob = row_get(first, rowbase, j);
-        va[j] = vec{static_cast<P>(~P(0)), 0};
-        if (oi & 1u) {
-            const DevTree &T = s_tree[(oi >> 2) & 7u];
-            const uint64_t i = static_cast<uint64_t>(ob) * kFan + sub;
-            if (i <= T.m) va[j] = static_cast<const vec *>(T.ent)[i];   // entry m is the last sentinel
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < kFan; ++j) {
-        if (!round_has_owner(m_live, j)) continue;
-        const uint32_t oi = row_get(info, rowbase, j);
-        const uint32_t a = (oi >> 5) & 31u, z = (oi >> 10) & 31u;
-        const bool in = sub < z;
-        const P oq0 = row_get(q0, rowbase, j), oq1 = row_get(q1, rowbase, j);   // (cross-lane: outside the || / &&)
-        const uint32_t c0 = row_count(sub < a || (in && static_cast<P>(va[j].x) < oq0), rowbase);
-        const uint32_t c1 = row_count(sub < a || (in && static_cast<P>(va[j].x) < oq1), rowbase);
-        // a live query has c >= 1 (entry 16*block is the sample that was below q one level up); entries c - 1 and c are lanes
-        const uint32_t p0 = c0 ? c0 - 1 : 0, n0 = c0 < kFan ? c0 : kFan - 1;
-        const uint32_t p1 = c1 ? c1 - 1 : 0, n1 = c1 < kFan ? c1 : kFan - 1;
-        const P a_pk0 = row_pick(static_cast<P>(va[j].x), rowbase, p0), a_pv0 = row_pick(static_cast<P>(va[j].y), rowbase, p0), a_nv0 = row_pick(static_cast<P>(va[j].y), rowbase, n0);
-        const P a_pk1 = row_pick(static_cast<P>(va[j].x), rowbase, p1), a_pv1 = row_pick(static_cast<P>(va[j].y), rowbase, p1), a_nv1 = row_pick(static_cast<P>(va[j].y), rowbase, n1);
-        if (static_cast<int>(sub) == j) {
-            if (live0) { t0 = b0 * kFan + c0; pk0 = a_pk0; pv0 = a_pv0; nv0 = a_nv0; fix0 = c0 == kFan; }
-            if (live1 && !two) { t1 = b1 * kFan + c1; pk1 = a_pk1; pv1 = a_pv1; nv1 = a_nv1; fix1 = c1 == kFan; }
-        }
-    }
-    const uint64_t m_two = __ballot(two);
-    if (m_two) {
-#pragma unroll
-        for (int j = 0; j < kFan; ++j) {
-            if (!round_has_owner(m_two, j)) continue;
-            const uint32_t oi = row_get(info, rowbase, j);
-            const uint32_t ob = row_get(b1, rowbase, j);
-            va[j] = vec{static_cast<P>(~P(0)), 0};
-            if (oi & 2u) {
-                const DevTree &T = s_tree[(oi >> 2) & 7u];
-                const uint64_t i = static_cast<uint64_t>(ob) * kFan + sub;
-                if (i <= T.m) va[j] = static_cast<const vec *>(T.ent)[i];
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < kFan; ++j) {
-            if (!round_has_owner(m_two, j)) continue;
-            const uint32_t oi = row_get(info, rowbase, j);
-            const uint32_t a = (oi >> 15) & 31u, z = (oi >> 20) & 31u;
-            const P oq1 = row_get(q1, rowbase, j);
-            const uint32_t c1 = row_count(sub < a || (sub < z && static_cast<P>(va[j].x) < oq1), rowbase);
-            const uint32_t p1 = c1 ? c1 - 1 : 0, n1 = c1 < kFan ? c1 : kFan - 1;
-            const P a_pk1 = row_pick(static_cast<P>(va[j].x), rowbase, p1), a_pv1 = row_pick(static_cast<P>(va[j].y), rowbase, p1), a_nv1 = row_pick(static_cast<P>(va[j].y), rowbase, n1);
-            if (static_cast<int>(sub) == j && two) { t1 = b1 * kFan + c1; pk1 = a_pk1; pv1 = a_pv1; nv1 = a_nv1; fix1 = c1 == kFan; }
-        }
-    }
-    if (fix0 || fix1) {
-        const vec *__restrict__ ent = static_cast<const vec *>(s_tree[tid].ent);
-        if (fix0) nv0 = static_cast<P>(ent[t0].y);
-        if (fix1) nv1 = static_cast<P>(ent[t1].y);
-    }
-}
-
-// The phi directory's probe with request slots: the row's lanes load the z candidates start .. start + z - 1 of the
-// owner's position (lanes beyond them re-read the last one: the probe touches only the sectors that hold them), the lane
-// that holds the last sampled position below q computes phi's value base + (q - pos) itself, and t = start + # of them
-// below q travels back with it (val undefined when t == start).  One query per lane; every lane of the wave must call.
-template <typename P>
-__device__ __forceinline__ void coop_probe_phi(const DevTree &T, uint4 *req, const bool live, const uint32_t start, const uint32_t z, const P q, uint32_t &t,
-                                               P &val) {
-    typedef typename PairOf<P>::vec vec;
-    constexpr int NS = ReqSlots<P>::v;
-    const uint32_t lane = threadIdx.x & (kWave - 1), sub = lane & (kFan - 1), rowbase = lane & ~static_cast<uint32_t>(kFan - 1);
-    const uint64_t m_live = __ballot(live);
-    if (!m_live) return;
-    const uint32_t zz = z > static_cast<uint32_t>(kFan) ? static_cast<uint32_t>(kFan) : z;
-    wave_lds_sync();
-    req[lane * NS + 0] = make_uint4(start, (live ? 1u : 0u) | (zz << 1), static_cast<uint32_t>(q), static_cast<uint32_t>(static_cast<uint64_t>(q) >> 32));
-    wave_lds_sync();
-    vec va[kFan];
-#pragma unroll
-    for (int j = 0; j < kFan; ++j) {
-        if (!round_has_owner(m_live, j)) continue;
-        const uint4 a = req[(rowbase + j) * NS + 0];
-        va[j] = vec{static_cast<P>(~P(0)), 0};
-        if (a.y & 1u) {
-            const uint32_t oz = a.y >> 1, last = oz ? oz - 1 : 0;
-            uint64_t i = static_cast<uint64_t>(a.x) + (sub < last ? sub : last);
-            if (i > T.m) i = T.m;   // entry m is the sentinel (never below a query)
-            va[j] = static_cast<const vec *>(T.ent)[i];
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < kFan; ++j) {
-        if (!round_has_owner(m_live, j)) continue;
-        const uint4 a = req[(rowbase + j) * NS + 0];
-        const P oq = sizeof(P) == 8 ? static_cast<P>((static_cast<uint64_t>(a.w) << 32) | a.z) : static_cast<P>(a.z);
-        const P key = static_cast<P>(va[j].x);
-        const uint32_t c = row_count(sub < (a.y >> 1) && key < oq, rowbase);
-        const P v = static_cast<P>(va[j].y) + (oq - key);
-        const P a_v = row_pick(v, rowbase, c ? c - 1 : 0);
-        if (static_cast<int>(sub) == j && live) { t = start + c; val = a_v; }
-    }
-}
-
-// The two ranks of an LF step through the directories (K1/K2): position 0 is answered from entries s0 .. s0 + 15 of
-// which the first z0 are candidates (the rest lie beyond the bucket, possibly in the next table's slice), position 1
-// likewise from s1 / z1 -- sharing the load when s1 == s0.  Returns for each position t = s + # candidates below it, the
-// RANK rk = cum[t-1] + min(q - start[t-1], cum[t] - cum[t-1]) (valid when t > s or an entry precedes s) and, for the
-// second position, whether it lies inside that run (q - start <= length: the toehold test of the caller).  The lanes
-// beyond the candidates re-read the entry after the last one, so a probe touches only the sectors that hold its z + 1
-// entries.
-// QUADS: four lanes serve an owner, each holding FOUR consecutive entries of its stretch (two 16-byte requests at
-// 4-byte positions, four at 8-byte ones), so one wave-wide load instruction serves sixteen owners and a pass takes
-// four rounds -- and everything the owner and its lanes tell each other travels by DPP quad permutes (a VALU move: no
-// LDS traffic, no request area, no synchronisation): in round J the owner is lane J of each quad, its values are
-// broadcast with quad_perm:[J,J,J,J], the number of candidates below the position is a quad sum, and the rank
-// computed by the lane that holds the run (its fourth entry's length needs the next lane's first count: DPP row_shl;
-// entry 15's is fetched by the owner when all sixteen lie below) comes back as a quad OR, the other three lanes
-// contributing 0.  (Half-rows -- eight lanes per owner, two entries per lane, the owner's values through LDS request
-// slots -- were the step before: 8.3 / 13.3 ms per 10 M reads at 4- / 8-byte positions against 8.2 / 11.4.)
-template <int J> __device__ __forceinline__ uint32_t quad_get(uint32_t v) {
-    return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), J * 0x55, 0xF, 0xF, false));
-}
-template <int J> __device__ __forceinline__ uint64_t quad_get(uint64_t v) {
-    return (static_cast<uint64_t>(quad_get<J>(static_cast<uint32_t>(v >> 32))) << 32) | quad_get<J>(static_cast<uint32_t>(v));
-}
-template <int CTRL> __device__ __forceinline__ uint32_t quad_perm(uint32_t v) {
-    return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), CTRL, 0xF, 0xF, false));
-}
-__device__ __forceinline__ uint32_t quad_sum(uint32_t v) {
-    v += quad_perm<0xB1>(v);   // [1,0,3,2]
-    v += quad_perm<0x4E>(v);   // [2,3,0,1]
-    return v;
-}
-__device__ __forceinline__ uint32_t quad_or(uint32_t v) {
-    v |= quad_perm<0xB1>(v);
-    v |= quad_perm<0x4E>(v);
-    return v;
-}
-__device__ __forceinline__ uint64_t quad_or(uint64_t v) {
-    return (static_cast<uint64_t>(quad_or(static_cast<uint32_t>(v >> 32))) << 32) | quad_or(static_cast<uint32_t>(v));
-}
-__device__ __forceinline__ bool round_has_owner4(uint64_t m, int j) { return (m & (0x1111111111111111ull << j)) != 0; }
-
-// the four entries start + 4 * sub .. + 3 of the owner's stretch (clamped to entry zc of the stretch and to the array's sentinel)
-template <typename P, int J>
-__device__ __forceinline__ void quad_load(const DevTree *s_tree, const uint32_t sub, const uint32_t start, const uint32_t info, const bool second,
-                                          typename PairOf<P>::vec (&e)[4]) {
-    typedef typename PairOf<P>::vec vec;
-    const uint32_t os = quad_get<J>(start), oi = quad_get<J>(info);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) e[i] = vec{static_cast<P>(~P(0)), 0};
-    if (oi & (second ? 2u : 1u)) {
-        const DevTree &T = s_tree[(oi >> 2) & 7u];
-        const uint32_t za = second ? 0u : (oi >> 5) & 31u, zb = (!second && (oi & 2u)) ? 0u : (oi >> 10) & 31u;
-        uint32_t zc = za > zb ? za : zb;                      // entries 0 .. zc of the stretch are needed (zc: the one after the last candidate)
-        if (zc > static_cast<uint32_t>(kFan - 1)) zc = kFan - 1;
-        if (sizeof(P) == 4) {
-            // two entries per request (16 bytes at any 8-byte boundary; the arrays end with one spare entry after the sentinel)
-            typedef unsigned int vec4 __attribute__((ext_vector_type(4), aligned(8)));
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const uint32_t idx = 4u * sub + 2u * h;
-                uint64_t g = static_cast<uint64_t>(os) + (idx < zc ? idx : zc);
-                if (g > T.m) g = T.m;                          // entry m is the last sentinel
-                const vec4 w = *reinterpret_cast<const vec4 *>(static_cast<const vec *>(T.ent) + g);
-                e[2 * h] = vec{static_cast<P>(w.x), static_cast<P>(w.y)};
-                e[2 * h + 1] = vec{static_cast<P>(w.z), static_cast<P>(w.w)};
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint32_t idx = 4u * sub + i;
-                uint64_t g = static_cast<uint64_t>(os) + (idx < zc ? idx : zc);
-                if (g > T.m) g = T.m;
-                e[i] = static_cast<const vec *>(T.ent)[g];
-            }
-        }
-    }
-}
-
-// one position against the quad's sixteen entries: c = # candidates (the first z entries) below q, rk = the rank, ins = q inside that run
-template <typename P>
-__device__ __forceinline__ void quad_rank(const uint32_t sub, const typename PairOf<P>::vec (&e)[4], const P next_cum, const uint32_t z, const P q,
-                                          uint32_t &c, P &rk, bool &ins) {
-    uint32_t n = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) n += (4u * sub + i < z && static_cast<P>(e[i].x) < q) ? 1u : 0u;
-    c = quad_sum(n);
-    const bool mine = n > 0 && ((c - 1) >> 2) == sub;          // the last entry below q is this lane's n-th
-    // this lane's n-th entry and the count of the one after it (the next lane's first for the fourth)
-    P k = static_cast<P>(e[0].x), v = static_cast<P>(e[0].y), vn = static_cast<P>(e[1].y);
-    if (n == 2u) { k = static_cast<P>(e[1].x); v = static_cast<P>(e[1].y); vn = static_cast<P>(e[2].y); }
-    if (n == 3u) { k = static_cast<P>(e[2].x); v = static_cast<P>(e[2].y); vn = static_cast<P>(e[3].y); }
-    if (n == 4u) { k = static_cast<P>(e[3].x); v = static_cast<P>(e[3].y); vn = next_cum; }
-    const P l = vn - v;
-    const P d = q - k;
-    const P r = v + (d < l ? d : l);
-    rk = quad_or(mine ? r : P(0));
-    ins = quad_or((mine && d <= l) ? 1u : 0u) != 0;
-}
-
-template <typename P, int J>
-__device__ __forceinline__ void quad_round(const uint32_t sub, const bool second, const bool live, const bool two, const uint32_t s0, const uint32_t s1,
-                                           const uint32_t info, const P q0, const P q1, const typename PairOf<P>::vec (&e)[4], uint32_t &t0, uint32_t &t1,
-                                           P &rk0, P &rk1, bool &ins1, bool &fix0, bool &fix1) {
-    const uint32_t oi = quad_get<J>(info);
-    const P oq0 = quad_get<J>(q0), oq1 = quad_get<J>(q1);
-    const P next_cum = row_next(static_cast<P>(e[0].y));   // (the quad's last lane: entry 15's run, fixed up by the owner)
-    uint32_t c0 = 0, c1 = 0;
-    P a_r0 = 0, a_r1 = 0;
-    bool a_i0 = false, a_i1 = false;
-    if (!second) quad_rank<P>(sub, e, next_cum, (oi >> 5) & 31u, oq0, c0, a_r0, a_i0);
-    quad_rank<P>(sub, e, next_cum, (oi >> 10) & 31u, oq1, c1, a_r1, a_i1);
-    if (static_cast<int>(sub) == J) {
-        if (!second && live) {
-            t0 = s0 + c0; rk0 = a_r0; fix0 = c0 == kFan;
-            if (!two) { t1 = s1 + c1; rk1 = a_r1; ins1 = a_i1; fix1 = c1 == kFan; }
-        }
-        if (second && two) { t1 = s1 + c1; rk1 = a_r1; ins1 = a_i1; fix1 = c1 == kFan; }
-    }
-}
-
-template <typename P>
-__device__ __forceinline__ void coop_probe2_rank4(const DevTree *s_tree, const uint32_t tid, const bool live, const uint32_t s0, const uint32_t z0,
-                                                  const uint32_t s1, const uint32_t z1, const P q0, const P q1, uint32_t &t0, uint32_t &t1, P &rk0,
-                                                  P &rk1, bool &ins1) {
-    typedef typename PairOf<P>::vec vec;
-    const uint32_t lane = threadIdx.x & (kWave - 1), sub = lane & 3u;
-    const uint64_t m_live = __ballot(live);
-    if (!m_live) return;
-    const bool two = live && s1 != s0;
-    // bit 0 live, bit 1 second block, bits 2-4 tree, bits 5-9 z0, 10-14 z1
-    const uint32_t info = (live ? 1u : 0u) | (two ? 2u : 0u) | (tid << 2) | (z0 << 5) | (z1 << 10);
-    bool fix0 = false, fix1 = false;
-    vec e0[4], e1[4], e2[4], e3[4];
-    if (round_has_owner4(m_live, 0)) quad_load<P, 0>(s_tree, sub, s0, info, false, e0);
-    if (round_has_owner4(m_live, 1)) quad_load<P, 1>(s_tree, sub, s0, info, false, e1);
-    if (round_has_owner4(m_live, 2)) quad_load<P, 2>(s_tree, sub, s0, info, false, e2);
-    if (round_has_owner4(m_live, 3)) quad_load<P, 3>(s_tree, sub, s0, info, false, e3);
-    if (round_has_owner4(m_live, 0)) quad_round<P, 0>(sub, false, live, two, s0, s1, info, q0, q1, e0, t0, t1, rk0, rk1, ins1, fix0, fix1);
-    if (round_has_owner4(m_live, 1)) quad_round<P, 1>(sub, false, live, two, s0, s1, info, q0, q1, e1, t0, t1, rk0, rk1, ins1, fix0, fix1);
-    if (round_has_owner4(m_live, 2)) quad_round<P, 2>(sub, false, live, two, s0, s1, info, q0, q1, e2, t0, t1, rk0, rk1, ins1, fix0, fix1);
-    if (round_has_owner4(m_live, 3)) quad_round<P, 3>(sub, false, live, two, s0, s1, info, q0, q1, e3, t0, t1, rk0, rk1, ins1, fix0, fix1);
-    const uint64_t m_two = __ballot(two);
-    if (m_two) {
-        if (round_has_owner4(m_two, 0)) quad_load<P, 0>(s_tree, sub, s1, info, true, e0);
-        if (round_has_owner4(m_two, 1)) quad_load<P, 1>(s_tree, sub, s1, info, true, e1);
-        if (round_has_owner4(m_two, 2)) quad_load<P, 2>(s_tree, sub, s1, info, true, e2);
-        if (round_has_owner4(m_two, 3)) quad_load<P, 3>(s_tree, sub, s1, info, true, e3);
-        if (round_has_owner4(m_two, 0)) quad_round<P, 0>(sub, true, live, two, s0, s1, info, q0, q1, e0, t0, t1, rk0, rk1, ins1, fix0, fix1);
-        if (round_has_owner4(m_two, 1)) quad_round<P, 1>(sub, true, live, two, s0, s1, info, q0, q1, e1, t0, t1, rk0, rk1, ins1, fix0, fix1);
-        if (round_has_owner4(m_two, 2)) quad_round<P, 2>(sub, true, live, two, s0, s1, info, q0, q1, e2, t0, t1, rk0, rk1, ins1, fix0, fix1);
-        if (round_has_owner4(m_two, 3)) quad_round<P, 3>(sub, true, live, two, s0, s1, info, q0, q1, e3, t0, t1, rk0, rk1, ins1, fix0, fix1);
-    }
-    if (fix0 || fix1) {   // all 16 loaded entries lie below the position: the run it lands in ends in the next block
-        const vec *__restrict__ ent = static_cast<const vec *>(s_tree[tid].ent);
-        if (fix0) {
-            const vec e = ent[t0 - 1];
-            const P len = static_cast<P>(ent[t0].y) - static_cast<P>(e.y), d = q0 - static_cast<P>(e.x);
-            rk0 = static_cast<P>(e.y) + (d < len ? d : len);
-        }
-        if (fix1) {
-            const vec e = ent[t1 - 1];
-            const P len = static_cast<P>(ent[t1].y) - static_cast<P>(e.y), d = q1 - static_cast<P>(e.x);
-            rk1 = static_cast<P>(e.y) + (d < len ? d : len);
-            ins1 = d <= len;
-        }
-    }
-}
-
-// The phi directory's probe by QUADS (K3's ordered walk): four lanes per owner, four consecutive sampled positions per
-// lane (two 16-byte requests at 4-byte positions), the owner's start and position by DPP quad permutes, the number
-// of samples below the position as a quad sum, phi's value base + (q - pos) from the lane that holds the last of them
-// as a quad OR.  t = start + # entries below q (val undefined when t == start).
-template <typename P, int J>
-__device__ __forceinline__ void phi_quad_load(const DevTree &T, const uint32_t sub, const uint32_t info, typename PairOf<P>::vec (&e)[4]) {
-    typedef typename PairOf<P>::vec vec;
-    const uint32_t oi = quad_get<J>(info);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) e[i] = vec{static_cast<P>(~P(0)), 0};
-    if (oi & 0x80000000u) {
-        const uint64_t first = static_cast<uint64_t>(oi & 0x7FFFFFFFu) + 4u * sub;
-        if (sizeof(P) == 4) {   // (the array ends with one spare entry after the sentinel)
-            typedef unsigned int vec4 __attribute__((ext_vector_type(4), aligned(8)));
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                uint64_t g = first + 2u * h;
-                if (g > T.m) g = T.m;   // entry m is the sentinel (never below a query)
-                const vec4 w = *reinterpret_cast<const vec4 *>(static_cast<const vec *>(T.ent) + g);
-                e[2 * h] = vec{static_cast<P>(w.x), static_cast<P>(w.y)};
-                e[2 * h + 1] = vec{static_cast<P>(w.z), static_cast<P>(w.w)};
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                uint64_t g = first + i;
-                if (g > T.m) g = T.m;
-                e[i] = static_cast<const vec *>(T.ent)[g];
-            }
-        }
-    }
-}
-
-template <typename P, int J>
-__device__ __forceinline__ void phi_quad_round(const uint32_t sub, const bool live, const uint32_t start, const P q, const typename PairOf<P>::vec (&e)[4],
-                                               uint32_t &t, P &val) {
-    const P oq = quad_get<J>(q);
-    uint32_t n = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) n += static_cast<P>(e[i].x) < oq ? 1u : 0u;
-    const uint32_t c = quad_sum(n);
-    const bool mine = n > 0 && ((c - 1) >> 2) == sub;
-    P k = static_cast<P>(e[0].x), v = static_cast<P>(e[0].y);
-    if (n == 2u) { k = static_cast<P>(e[1].x); v = static_cast<P>(e[1].y); }
-    if (n == 3u) { k = static_cast<P>(e[2].x); v = static_cast<P>(e[2].y); }
-    if (n == 4u) { k = static_cast<P>(e[3].x); v = static_cast<P>(e[3].y); }
-    const P a_v = quad_or(mine ? v + (oq - k) : P(0));
-    if (static_cast<int>(sub) == J && live) { t = start + c; val = a_v; }
-}
-
-template <typename P>
-__device__ __forceinline__ void coop_probe_phi4(const DevTree &T, const bool live, const uint32_t start, const P q, uint32_t &t, P &val) {
-    typedef typename PairOf<P>::vec vec;
-    const uint32_t lane = threadIdx.x & (kWave - 1), sub = lane & 3u;
-    const uint64_t m_live = __ballot(live);
-    if (!m_live) return;
-    const uint32_t info = (live ? 0x80000000u : 0u) | (start & 0x7FFFFFFFu);   // (fewer than 2^31 sampled positions: upload() checks)
-    vec e0[4], e1[4], e2[4], e3[4];
-    if (round_has_owner4(m_live, 0)) phi_quad_load<P, 0>(T, sub, info, e0);
-    if (round_has_owner4(m_live, 1)) phi_quad_load<P, 1>(T, sub, info, e1);
-    if (round_has_owner4(m_live, 2)) phi_quad_load<P, 2>(T, sub, info, e2);
-    if (round_has_owner4(m_live, 3)) phi_quad_load<P, 3>(T, sub, info, e3);
-    if (round_has_owner4(m_live, 0)) phi_quad_round<P, 0>(sub, live, start, q, e0, t, val);
-    if (round_has_owner4(m_live, 1)) phi_quad_round<P, 1>(sub, live, start, q, e1, t, val);
-    if (round_has_owner4(m_live, 2)) phi_quad_round<P, 2>(sub, live, start, q, e2, t, val);
-    if (round_has_owner4(m_live, 3)) phi_quad_round<P, 3>(sub, live, start, q, e3, t, val);
-}
-
-// One narrowing round for a crowded bucket: the candidates [s, s + z) of a query (z > 16) are sampled at 16 pivots a
-// stride apart; the answer lies between the last pivot below q and the next one, so the range shrinks to at most
-// ceil(z / 16) candidates (s moves to that pivot, which is known to be below q -- or stays with z = 1 when not even
-// the first candidate is).  Lanes with live == false pass through.  Every lane must call.  By QUADS: the sixteen
-// pivots are four per lane of the owner's quad, its (s, z, tree, q) reach the quad by DPP and the number of pivots
-// below q is a quad sum -- no LDS traffic.
-template <typename P, int J>
-__device__ __forceinline__ void narrow_quad_load(const DevTree *s_tree, const uint32_t sub, const uint32_t flags, const uint32_t s, const uint32_t z, P (&key)[4]) {
-    typedef typename PairOf<P>::vec vec;
-    const uint32_t of = quad_get<J>(flags), os = quad_get<J>(s), oz = quad_get<J>(z);
-    const uint32_t ost = (oz + kFan - 1) / kFan;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        key[i] = static_cast<P>(~P(0));   // pivots beyond the candidates are never below
-        const uint32_t at = (4u * sub + i) * ost;
-        if ((of & 1u) && at < oz) key[i] = static_cast<P>(static_cast<const vec *>(s_tree[(of >> 1) & 7u].ent)[static_cast<uint64_t>(os) + at].x);
-    }
-}
-template <typename P, int J>
-__device__ __forceinline__ void narrow_quad_round(const uint32_t sub, const bool live, const uint32_t stride, const P q, const P (&key)[4], uint32_t &s, uint32_t &z) {
-    const P oq = quad_get<J>(q);
-    uint32_t n = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) n += key[i] < oq ? 1u : 0u;
-    const uint32_t c = quad_sum(n);
-    if (static_cast<int>(sub) == J && live) {
-        if (c == 0) { z = 1; }
-        else {
-            const uint32_t adv = (c - 1) * stride;
-            s += adv;
-            z = (z - adv) < stride ? (z - adv) : stride;
-        }
-    }
-}
-template <typename P>
-__device__ __forceinline__ void coop_narrow4(const DevTree *s_tree, const uint32_t tid, const bool live, uint32_t &s, uint32_t &z, const P q) {
-    const uint32_t lane = threadIdx.x & (kWave - 1), sub = lane & 3u;
-    const uint64_t m_live = __ballot(live);
-    if (!m_live) return;
-    const uint32_t stride = (z + kFan - 1) / kFan;
-    const uint32_t flags = (live ? 1u : 0u) | (tid << 1);
-    const uint32_t s_in = s, z_in = z;   // (the owners update s and z while later rounds still broadcast the others')
-    P k0[4], k1[4], k2[4], k3[4];
-    if (round_has_owner4(m_live, 0)) narrow_quad_load<P, 0>(s_tree, sub, flags, s_in, z_in, k0);
-    if (round_has_owner4(m_live, 1)) narrow_quad_load<P, 1>(s_tree, sub, flags, s_in, z_in, k1);
-    if (round_has_owner4(m_live, 2)) narrow_quad_load<P, 2>(s_tree, sub, flags, s_in, z_in, k2);
-    if (round_has_owner4(m_live, 3)) narrow_quad_load<P, 3>(s_tree, sub, flags, s_in, z_in, k3);
-    if (round_has_owner4(m_live, 0)) narrow_quad_round<P, 0>(sub, live, stride, q, k0, s, z);
-    if (round_has_owner4(m_live, 1)) narrow_quad_round<P, 1>(sub, live, stride, q, k1, s, z);
-    if (round_has_owner4(m_live, 2)) narrow_quad_round<P, 2>(sub, live, stride, q, k2, s, z);
-    if (round_has_owner4(m_live, 3)) narrow_quad_round<P, 3>(sub, live, stride, q, k3, s, z);
-}
-
-// The two ranks of an LF step through the BUCKET RECORDS (rbg_dev.h RunRec): the row's lanes load the 128-byte record of
-// the owner's bucket with one coalesced request (lane 0 the header, lane 1 the rank at the bucket's start, lanes 2-15
-// the pairs); each pair's lane computes the rank the position would have if it fell into ITS run, popcount(ballot)
-// finds the run it does fall into, and one value per position travels back -- no directory gather, no second round
-// trip.  r0 / r1: the records (index into the depth's array) of the two positions, o0 / o1 their offsets in the bucket.
-// Returns per position c = # runs of the record that start below it (0: no run of the table starts below it at all),
-// the rank rk (valid when c > 0) and for the second whether it lies inside its run; ov = one of the two buckets
-// holds more runs than a record (the caller reads (e0, count) from the headers and goes through the run list).
-template <typename P>
-__device__ __forceinline__ void coop_rec2(const RunRec *const *s_rec, uint4 *req, const uint32_t tid, const bool live, const uint32_t r0, const uint32_t r1,
-                                          const uint32_t o0, const uint32_t o1, uint32_t &c0, uint32_t &c1, P &rk0, P &rk1, bool &ins1, bool &ov) {
-    typedef unsigned int vec2 __attribute__((ext_vector_type(2)));
-    constexpr int NS = ReqSlots<P>::v;
-    const uint32_t lane = threadIdx.x & (kWave - 1), sub = lane & (kFan - 1), rowbase = lane & ~static_cast<uint32_t>(kFan - 1);
-    const uint64_t m_live = __ballot(live);
-    if (!m_live) return;
-    const bool two = live && r1 != r0;
-    const uint32_t info = (live ? 1u : 0u) | (two ? 2u : 0u) | (tid << 2);
-    wave_lds_sync();
-    req[lane * NS + 0] = make_uint4(r0, info, o0, o1);
-    req[lane * NS + 1] = make_uint4(r1, info, o1, 0u);
-    wave_lds_sync();
-    vec2 va[kFan];
-#pragma unroll
-    for (int j = 0; j < kFan; ++j) {
-        if (!round_has_owner(m_live, j)) continue;
-        const uint4 a = req[(rowbase + j) * NS + 0];
-        va[j] = vec2{kRecNoPair, 0u};
-        if (a.y & 1u) va[j] = reinterpret_cast<const vec2 *>(s_rec[(a.y >> 2) & 7u] + a.x)[sub];
-    }
-#pragma unroll
-    for (int j = 0; j < kFan; ++j) {
-        if (!round_has_owner(m_live, j)) continue;
-        const uint4 a = req[(rowbase + j) * NS + 0];
-        const uint32_t off = va[j].x, cl = va[j].y;
-        const uint32_t len = row_next(cl) - cl;                   // (lane 15 holds the closing pair: never chosen)
-        const bool pair_lane = sub >= 2u;
-        const uint32_t n0 = row_count(pair_lane && static_cast<int32_t>(off) < static_cast<int32_t>(a.z), rowbase);
-        const uint32_t n1 = row_count(pair_lane && static_cast<int32_t>(off) < static_cast<int32_t>(a.w), rowbase);
-        const uint32_t d0 = a.z - off, d1 = a.w - off;
-        const uint32_t v0 = cl + (d0 < len ? d0 : len), v1 = cl + (d1 < len ? d1 : len);
-        const uint64_t in1 = __ballot(d1 <= len);
-        const uint64_t ovm = __ballot(sub == 0u && (cl & kRecOverflow));   // (the header's flags sit in lane 0's second word)
-        // pair n - 1 sits in lane n + 1
-        const uint32_t a_v0 = row_pick(v0, rowbase, n0 + 1u), a_v1 = row_pick(v1, rowbase, n1 + 1u);
-        uint32_t blo = 0, bhi = 0;
-        if (sizeof(P) == 8) { blo = row_pick(off, rowbase, 1u); bhi = row_pick(cl, rowbase, 1u); }
-        if (static_cast<int>(sub) == j && live) {
-            const P base = static_cast<P>((static_cast<uint64_t>(bhi) << 32) | blo);   // (0 at 4-byte positions: the pairs carry the rank itself)
-            ov = ((ovm >> rowbase) & 1u) != 0;
-            c0 = n0; rk0 = base + static_cast<P>(a_v0);
-            if (!two) { c1 = n1; rk1 = base + static_cast<P>(a_v1); ins1 = ((in1 >> (rowbase + n1 + 1u)) & 1u) != 0; }
-        }
-    }
-    const uint64_t m_two = __ballot(two);
-    if (!m_two) return;
-#pragma unroll
-    for (int j = 0; j < kFan; ++j) {
-        if (!round_has_owner(m_two, j)) continue;
-        const uint4 b = req[(rowbase + j) * NS + 1];
-        va[j] = vec2{kRecNoPair, 0u};
-        if (b.y & 2u) va[j] = reinterpret_cast<const vec2 *>(s_rec[(b.y >> 2) & 7u] + b.x)[sub];
-    }
-#pragma unroll
-    for (int j = 0; j < kFan; ++j) {
-        if (!round_has_owner(m_two, j)) continue;
-        const uint4 b = req[(rowbase + j) * NS + 1];
-        const uint32_t off = va[j].x, cl = va[j].y;
-        const uint32_t len = row_next(cl) - cl;
-        const uint32_t n1 = row_count(sub >= 2u && static_cast<int32_t>(off) < static_cast<int32_t>(b.z), rowbase);
-        const uint32_t d1 = b.z - off;
-        const uint32_t v1 = cl + (d1 < len ? d1 : len);
-        const uint64_t in1 = __ballot(d1 <= len);
-        const uint64_t ovm = __ballot(sub == 0u && (cl & kRecOverflow));
-        const uint32_t a_v1 = row_pick(v1, rowbase, n1 + 1u);
-        uint32_t blo = 0, bhi = 0;
-        if (sizeof(P) == 8) { blo = row_pick(off, rowbase, 1u); bhi = row_pick(cl, rowbase, 1u); }
-        if (static_cast<int>(sub) == j && two) {
-            const P base = static_cast<P>((static_cast<uint64_t>(bhi) << 32) | blo);
-            ov = ov || ((ovm >> rowbase) & 1u) != 0;
-            c1 = n1; rk1 = base + static_cast<P>(a_v1); ins1 = ((in1 >> (rowbase + n1 + 1u)) & 1u) != 0;
-        }
-    }
-}
-
-// per-lane search of the staged top level, clamped like the levels below: entries [a, z) of the tree's slice of s_top
-// are the ones inside the query's slice; returns # top entries below q
-template <typename P>
-__device__ __forceinline__ uint32_t top_count_clamped(const P *s_top, const DevTree &T, int top_sh, uint32_t lo_t, uint32_t hi_t, uint64_t q) {
-    const uint64_t S1 = (uint64_t(1) << top_sh) - 1;
-    uint64_t a = (static_cast<uint64_t>(lo_t) + S1) >> top_sh, z = (static_cast<uint64_t>(hi_t) + S1) >> top_sh;
-    if (z > T.top_n) z = T.top_n;
-    if (a > z) a = z;
-    return static_cast<uint32_t>(a) + top_count<P>(s_top, T.top_off + static_cast<uint32_t>(a), static_cast<uint32_t>(z - a), q);
-}
 
 // ---- K1 / K2 over the run-indexed layout ------------------------------------------------------------------------
 // RowBowt::find_range (rowbowt.hpp:121-131) / find_range_w_toehold (:169-184).  A step consumes up to run_ksteps read
@@ -676,215 +24,183 @@ __device__ __forceinline__ uint32_t top_count_clamped(const P *s_top, const DevT
 // the wave's reads are answered cooperatively.  The device ftab (a constant-size state table, result-neutral) still
 // replaces the first ftab_k steps.
 // (4 waves per SIMD at 4-byte positions: the toehold variant sits at 130 VGPRs without the bound, one wave per SIMD less)
-template <typename P, bool TOEHOLD>
-__global__ __launch_bounds__(512, sizeof(P) == 4 ? 4 : 3) void k_find_range_runs(const DevIndex ix, const uint8_t *__restrict__ seqs,
-                                                        const uint64_t *__restrict__ off, const uint64_t N,
+// PACKED: the reads arrive as 2-bit codes (k_pack_reads / the host path's CPU packer: meta[i] = {first chunk, length or
+// bit 31 = "has a symbol outside the k-mer alphabet: byte kernel"}, 64 symbols per 16-byte chunk in consumption order);
+// same steps in the same order as the byte form takes for a read of k-mer symbols only.
+// STATS: the instrumented instantiation (rbg_find_range_stats_dev), sums as listed in rbg_runs_device.hpp.
+struct PackedBits {   // per-lane reader of a packed read: peek / drop of up to 32 bits
+    const uint4 *__restrict__ cp;
+    uint4 w;
+    uint32_t widx, navail;
+    uint64_t sr;
+    __device__ __forceinline__ uint32_t next_word() {
+        if (widx == 4) { w = *cp++; widx = 0; }
+        const uint32_t v = widx == 0 ? w.x : widx == 1 ? w.y : widx == 2 ? w.z : w.w;
+        ++widx;
+        return v;
+    }
+    __device__ __forceinline__ uint32_t take(uint32_t nb) {
+        if (navail < nb) { sr |= static_cast<uint64_t>(next_word()) << navail; navail += 32; }
+        const uint32_t v = static_cast<uint32_t>(sr & ((uint64_t(1) << nb) - 1));
+        sr >>= nb;
+        navail -= nb;
+        return v;
+    }
+};
+
+template <typename P, bool TOEHOLD, bool PACKED = false, bool STATS = false>
+__global__ __launch_bounds__(512, sizeof(P) == 4 ? 4 : 3) void k_find_range_runs(const DevIndex ix, const void *__restrict__ src_a,
+                                                        const void *__restrict__ src_b, const uint64_t N,
                                                         uint64_t *__restrict__ lo_out, uint64_t *__restrict__ hi_out,
-                                                        uint64_t *__restrict__ ss_out) {
+                                                        uint64_t *__restrict__ ss_out, unsigned long long *__restrict__ stats,
+                                                        const uint32_t *__restrict__ sel, const uint32_t *__restrict__ nsel) {
+    // byte form: src_a = seqs, src_b = off;  packed form: src_a = chunks (uint4), src_b = meta (uint2)
+    // sel != nullptr (byte form): only the reads sel[0 .. *nsel) -- the ones the packed form could not express
+    const uint64_t Neff = sel ? static_cast<uint64_t>(*nsel) : N;
+    const uint8_t *__restrict__ seqs = static_cast<const uint8_t *>(src_a);
+    const uint64_t *__restrict__ off = static_cast<const uint64_t *>(src_b);
+    const uint4 *__restrict__ chunks = static_cast<const uint4 *>(src_a);
+    const uint2 *__restrict__ meta = static_cast<const uint2 *>(src_b);
     __shared__ uint8_t s_lut[256];
     __shared__ uint8_t s_lut2[256];
-    __shared__ DevTree s_tree[kMaxRunDepth];
-    __shared__ uint32_t s_tab_first[kMaxRunDepth + 1];
-    __shared__ const RunRec *s_rec[8];
-    __shared__ uint4 s_req[8][kWave * ReqSlots<P>::v];   // request slots, per wave (512-thread workgroups)
-    uint4 *req = s_req[threadIdx.x >> 6];
-    extern __shared__ __align__(16) unsigned char s_dyn[];
-    DevRunTab *s_tab = reinterpret_cast<DevRunTab *>(s_dyn);
-    P *s_top = reinterpret_cast<P *>(s_dyn + static_cast<size_t>(ix.run_ntabs) * sizeof(DevRunTab));
-    if (threadIdx.x < 8) s_rec[threadIdx.x] = threadIdx.x < static_cast<uint32_t>(kMaxRunDepth) ? ix.run_rec[threadIdx.x] : nullptr;
+    __shared__ uint8_t s_mslot[4];
+    RBG_RUN_SEARCH_SHARED(P, 8);   // 512-thread workgroups
     for (int t = threadIdx.x; t < 256; t += blockDim.x) {
         s_lut[t] = ix.lut[t];
         s_lut2[t] = ix.nmajor ? ix.lut2[t] : 0xFFu;
     }
+    const RunSearch<P> S = stage_run_search<P, 8>(ix, s_tree, s_tab_first, s_rec, s_req, s_dyn);
+    if (PACKED) {
+        for (int t = threadIdx.x; t < 256; t += blockDim.x)
+            if (s_lut2[t] != 0xFFu) s_mslot[s_lut2[t] & 3u] = s_lut[t];   // major index -> symbol slot
+        __syncthreads();
+    }
     const uint32_t D = ix.run_ksteps;
-    for (uint32_t t = threadIdx.x; t < D; t += blockDim.x) s_tree[t] = ix.trees[t];
-    for (uint32_t t = threadIdx.x; t <= static_cast<uint32_t>(kMaxRunDepth); t += blockDim.x) s_tab_first[t] = ix.run_tab_first[t];
-    for (uint32_t t = threadIdx.x; t < ix.run_ntabs; t += blockDim.x) s_tab[t] = ix.run_tabs[t];
-    for (uint32_t t = threadIdx.x; t < ix.tree_top_n; t += blockDim.x) s_top[t] = static_cast<const P *>(ix.tree_top)[t];
-    __syncthreads();
-    const int nlvl = static_cast<int>(ix.tree_nlvl);
-    const int top_sh = 4 * (nlvl + 1);
     const uint32_t M = ix.nmajor;
     const uint32_t lane = threadIdx.x & (kWave - 1);
 
     unsigned long long c_occ = 0, c_reads = 0;
     uint32_t c_matched = 0;
+    unsigned long long st[kStatSearchN] = {0, 0, 0, 0, 0, 0, 0, 0};   // STATS only (dead code otherwise)
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
     const uint64_t wave_first = static_cast<uint64_t>(blockIdx.x) * blockDim.x + (threadIdx.x & ~(kWave - 1));
-    for (uint64_t base = wave_first; base < N; base += stride) {  // the lanes of a wave iterate together
-        const uint64_t i = base + lane;
-        const bool valid = i < N;
+    for (uint64_t base = wave_first; base < Neff; base += stride) {  // the lanes of a wave iterate together
+        bool valid = base + lane < Neff;
+        const uint64_t i = (sel && valid) ? static_cast<uint64_t>(sel[base + lane]) : base + lane;
         uint64_t beg = 0, p = 0;
-        if (valid) { beg = off[i]; p = off[i + 1]; }
+        PackedBits bs{chunks, make_uint4(0, 0, 0, 0), 4u, 0u, 0ull};
+        if (PACKED) {
+            if (valid) {
+                const uint2 mt = meta[i];
+                if (mt.y & 0x80000000u) valid = false;           // has a non-major symbol: the byte kernel answers it
+                else { p = mt.y; bs.cp = chunks + mt.x; }        // p = symbols still to consume (beg = 0)
+            }
+        } else if (valid) { beg = off[i]; p = off[i + 1]; }
+        const uint64_t p_end = p;
+        uint64_t p_min = p;                                    // STATS: lowest read byte fetched
         uint64_t lo = 0, hi = ix.n - 1;                       // full_range(), rowbowt.hpp:115-118
         uint64_t k = TOEHOLD ? ix.last_run_sample : 0;
         bool alive = valid;
-        bool pend = false;                                     // deferred toehold re-sample: entry `pend_run` of depth `pend_d`
-        uint32_t pend_d = 0, pend_run = 0, pend_c = 0;          // pend_c > 0: pend_run is a bucket record, the entry its pend_c-th
+        bool pend = false;                                     // deferred toehold re-sample (k_search.hip): the last one is the only one used
+        uint32_t pend_d = 0, pend_run = 0, pend_c = 0;
         ByteCursor rd{reinterpret_cast<const uint4 *>(seqs), ~uint64_t(0), make_uint4(0, 0, 0, 0)};
         if (valid && ix.ftab_k && p - beg >= ix.ftab_k) {      // rowbowt.hpp:124-125, :745-758 (k_search.hip)
-            uint64_t idx = 0, pw = 1;
+            uint64_t idx = 0;
             bool all_major = true;
-            for (uint32_t t = 1; t <= ix.ftab_k; ++t) {
-                const uint32_t mm = s_lut2[rd.at(p - t)];
-                all_major = all_major && mm != 0xFFu;
-                idx += (mm & 3u) * pw;
-                pw *= M;
+            PackedBits probe = bs;                             // consumed only if the entry is usable
+            if (PACKED) {
+                idx = probe.take(2 * ix.ftab_k);               // the first ftab_k symbols are the low 2 * ftab_k bits
+            } else {
+                uint64_t pw = 1;
+                for (uint32_t t = 1; t <= ix.ftab_k; ++t) {
+                    const uint32_t mm = s_lut2[rd.at(p - t)];
+                    all_major = all_major && mm != 0xFFu;
+                    idx += (mm & 3u) * pw;
+                    pw *= M;
+                }
             }
             uint64_t flo, fhi2, fk;
+            if (STATS) { p_min = p - ix.ftab_k; if (all_major) st[kStFtab] += 1; }
             if (all_major && ftab_lookup<P>(ix, idx, flo, fhi2, fk)) {
+                if (PACKED) bs = probe;
                 lo = flo; hi = fhi2;
                 if (TOEHOLD) k = fk;
                 p -= ix.ftab_k;
+                if (STATS) st[kStSymbols] += ix.ftab_k;
                 if (hi < lo) { alive = false; p = beg; }
             }
         }
         while (__ballot(alive && p > beg)) {                   // right-to-left over the reads (rowbowt.hpp:127-129, :175-181)
             bool stepping = alive && p > beg;
-            uint32_t d = 0, adv = 1, rec = 0;                  // depth index (adv - 1), symbols consumed, record in s_tab
+            uint32_t d = 0, adv = 1, rec = 0;                  // depth index (adv - 1), symbols consumed, record in S.tab
             if (stepping) {
-                --p;
-                const uint32_t c = rd.at(p);
-                const uint32_t m0 = s_lut2[c];
-                uint32_t acc = m0;
-                if (m0 != 0xFFu) {                              // the longest run of major symbols among the next D (k_search.hip)
-                    uint32_t pw = M;
-#pragma unroll 1
-                    for (uint32_t t = 1; t < static_cast<uint32_t>(kMaxRunDepth); ++t) {
-                        if (t >= D || p < beg + t) break;
-                        const uint32_t mm = s_lut2[rd.at(p - t)];
-                        if (mm == 0xFFu) break;
-                        acc += mm * pw;
-                        pw *= M;
-                        adv = t + 1;
-                    }
-                }
-                if (adv == 1) {
-                    const uint32_t slot = s_lut[c];
-                    if (slot == 0xFFu || slot >= static_cast<uint32_t>(kLdsSyms)) {
-                        // symbol absent (f_[c] >= f_[c+1], rowbowt.hpp:76).  (An index with more than kLdsSyms symbols is
-                        // never given this layout: upload() keeps the slot tables for it.)
-                        alive = false;
-                        stepping = false;
-                    } else {
-                        rec = s_tab_first[0] + slot;
-                    }
-                } else {
+                if (PACKED) {
+                    adv = p < D ? static_cast<uint32_t>(p) : D;
+                    const uint32_t v = bs.take(2 * adv);
+                    rec = run_record(s_tab_first, adv, adv == 1 ? static_cast<uint32_t>(s_mslot[v]) : v);
                     d = adv - 1;
-                    rec = s_tab_first[d] + acc;
-                }
-            }
-            uint32_t lo_t = 0, hi_t = 0;
-            uint64_t F = 0;
-            const uint64_t q0 = lo, q1 = hi + 1;               // rank(lo, c), rank(hi + 1, c): rowbowt.hpp:79,83
-            // (positions fit P: q1 = hi + 1 <= n, and n stays below the all-ones key, flatten())
-            uint32_t t0 = 0, t1 = 0;
-            P pk0 = 0, pv0 = 0, nv0 = 0, pk1 = 0, pv1 = 0, nv1 = 0;
-            bool descend = stepping;
-            uint32_t s0 = 0, z0 = 0, s1 = 0, z1 = 0;
-            bool direct = false, by_rec = false, ov = false;
-            uint32_t rc0 = 0, rc1 = 0, o0 = 0, o1 = 0;
-            if (stepping) {
-                const DevRunTab r0 = s_tab[rec];
-                F = r0.F;
-                lo_t = static_cast<uint32_t>(r0.first);
-                hi_t = static_cast<uint32_t>(s_tab[rec + 1].first) - 1;   // the slice's sentinel: never below a query
-                const uint32_t *__restrict__ dir = ix.run_dir[d];
-                if (s_rec[d]) {
-                    // the table's bucket records: one record per position answers its rank
-                    const uint64_t b0 = q0 >> r0.dir_shift, b1 = q1 >> r0.dir_shift;
-                    rc0 = r0.dir_off + static_cast<uint32_t>(b0);
-                    rc1 = r0.dir_off + static_cast<uint32_t>(b1);
-                    o0 = static_cast<uint32_t>(q0 - (b0 << r0.dir_shift));
-                    o1 = static_cast<uint32_t>(q1 - (b1 << r0.dir_shift));
-                    by_rec = true;
-                    descend = false;
-                } else if (dir) {
-                    // the table's directory: # runs starting below the bucket of q and below the next bucket; the
-                    // candidates are those runs and the one before them
-                    dir += r0.dir_off;
-                    const uint64_t b0 = q0 >> r0.dir_shift, b1 = q1 >> r0.dir_shift;
-                    const uint32_t a0 = dir[b0], e0 = dir[b0 + 1];
-                    uint32_t a1 = a0, e1 = e0;
-                    if (b1 != b0) { a1 = dir[b1]; e1 = dir[b1 + 1]; }
-                    s0 = lo_t + (a0 ? a0 - 1 : 0);
-                    s1 = lo_t + (a1 ? a1 - 1 : 0);
-                    z0 = lo_t + e0 - s0;
-                    z1 = lo_t + e1 - s1;
-                    // neighbouring buckets: when the second position's candidates end within 16 entries of the first's start, one
-                    // probe from there answers both (every entry before s1 is below q1 anyway)
-                    if (s1 != s0 && s1 + z1 - s0 <= static_cast<uint32_t>(kFan)) { z1 = s1 + z1 - s0; s1 = s0; }
-                    direct = true;   // (crowded buckets are narrowed below until one row probe covers their candidates)
-                    descend = false;
-                }
-            }
-            P rk0 = 0, rk1 = 0;
-            bool ins1 = false;
-            uint32_t cn0 = 0, cn1 = 0;
-            coop_rec2<P>(s_rec, req, d, by_rec, rc0, rc1, o0, o1, cn0, cn1, rk0, rk1, ins1, ov);
-            if (by_rec && ov) {   // a bucket with more runs than a record holds: through the run list, like a directory's
-                const RunRec *__restrict__ R = s_rec[d];
-                const uint32_t f0 = R[rc0].flags, f1 = R[rc1].flags;
-                s0 = R[rc0].e0; z0 = (f0 & kRecOverflow) ? (f0 & 0x7FFFFFFFu) : (f0 & 0xFFu);
-                s1 = R[rc1].e0; z1 = (f1 & kRecOverflow) ? (f1 & 0x7FFFFFFFu) : (f1 & 0xFFu);
-                direct = true;
-            }
-            while (__ballot(direct && (z0 > static_cast<uint32_t>(kFan) || z1 > static_cast<uint32_t>(kFan)))) {
-                coop_narrow4<P>(s_tree, d, direct && z0 > static_cast<uint32_t>(kFan), s0, z0, static_cast<P>(q0));
-                coop_narrow4<P>(s_tree, d, direct && z1 > static_cast<uint32_t>(kFan), s1, z1, static_cast<P>(q1));
-            }
-            coop_probe2_rank4<P>(s_tree, d, direct, s0, z0, s1, z1, static_cast<P>(q0), static_cast<P>(q1), t0, t1, rk0, rk1, ins1);
-            if (__ballot(descend)) {   // crowded buckets (and indexes without directories): the clamped descent
-                uint32_t d0 = 0, d1 = 0;
-                P ak0 = 0, av0 = 0, an0 = 0, ak1 = 0, av1 = 0, an1 = 0;
-                if (descend) {
-                    d0 = top_count_clamped<P>(s_top, s_tree[d], top_sh, lo_t, hi_t, q0);
-                    d1 = top_count_clamped<P>(s_top, s_tree[d], top_sh, lo_t, hi_t, q1);
-                }
-                for (int l = nlvl - 1; l >= 0; --l) {
-                    const bool l0 = descend && d0 > 0, l1 = descend && d1 > 0;
-                    coop_level<P>(s_tree, l, d, lo_t, hi_t, l0, l1, d0, d1, static_cast<P>(q0), static_cast<P>(q1));
-                }
-                {
-                    const bool l0 = descend && d0 > 0, l1 = descend && d1 > 0;
-                    coop_leaf<P>(s_tree, d, lo_t, hi_t, l0, l1, d0, d1, static_cast<P>(q0), static_cast<P>(q1), ak0, av0, an0, ak1, av1, an1);
-                }
-                if (descend) { t0 = d0; t1 = d1; pk0 = ak0; pv0 = av0; nv0 = an0; pk1 = ak1; pv1 = av1; nv1 = an1; }
-            }
-            if (stepping) {
-                // rle_string::rank in the table: occurrences before the predecessor run + the part of it below the
-                // position; t <= lo_t: no run of this table starts before the position
-                uint64_t c_before = 0, c_upto = 0;
-                bool inside = false;
-                if (direct) {   // (the row computed the ranks)
-                    if (t0 > lo_t) c_before = rk0;
-                    if (t1 > lo_t) { c_upto = rk1; inside = ins1; }
-                } else if (by_rec) {
-                    if (cn0) c_before = rk0;
-                    if (cn1) { c_upto = rk1; inside = ins1; }
+                    p -= 1;                                     // (the byte form's --p; the rest of adv is taken off after the step)
                 } else {
-                    if (t0 > lo_t) { const uint64_t len = static_cast<uint64_t>(nv0) - pv0, dd = q0 - pk0; c_before = pv0 + (dd < len ? dd : len); }
-                    if (t1 > lo_t) { const uint64_t len = static_cast<uint64_t>(nv1) - pv1, dd = q1 - pk1; c_upto = pv1 + (dd < len ? dd : len); inside = dd <= len; }
+                    --p;
+                    const uint32_t c = rd.at(p);
+                    if (STATS && p < p_min) p_min = p;
+                    const uint32_t m0 = s_lut2[c];
+                    uint32_t acc = m0;
+                    if (m0 != 0xFFu) {                          // the longest run of major symbols among the next D (k_search.hip)
+                        uint32_t pw = M;
+#pragma unroll 1
+                        for (uint32_t t = 1; t < static_cast<uint32_t>(kMaxRunDepth); ++t) {
+                            if (t >= D || p < beg + t) break;
+                            const uint32_t mm = s_lut2[rd.at(p - t)];
+                            if (STATS && p - t < p_min) p_min = p - t;
+                            if (mm == 0xFFu) break;
+                            acc += mm * pw;
+                            pw *= M;
+                            adv = t + 1;
+                        }
+                    }
+                    if (adv == 1) {
+                        const uint32_t slot = s_lut[c];
+                        if (slot == 0xFFu || slot >= static_cast<uint32_t>(kLdsSyms)) {
+                            // symbol absent (f_[c] >= f_[c+1], rowbowt.hpp:76).  (An index with more than kLdsSyms symbols is
+                            // never given this layout: upload() keeps the slot tables for it.)
+                            alive = false;
+                            stepping = false;
+                        } else {
+                            rec = run_record(s_tab_first, 1u, slot);
+                        }
+                    } else {
+                        d = adv - 1;
+                        rec = run_record(s_tab_first, adv, acc);
+                    }
                 }
-                const uint64_t c_inside = c_upto - c_before;
+            }
+            RunStep r;
+            coop_lf2<P, STATS>(ix, S, stepping, d, rec, lo, hi + 1, r, st);   // rank(lo, c), rank(hi + 1, c): rowbowt.hpp:79,83
+            if (stepping) {
+                if (STATS) st[kStSymbols] += adv;
+                const uint64_t c_inside = r.c_upto - r.c_before;
                 if (c_inside == 0) {                            // rowbowt.hpp:85 (whichever of the nested steps emptied the range)
                     alive = false;
                 } else {
                     if (TOEHOLD) {                              // LF_w_loc, rowbowt.hpp:559-566, `adv` times nested
-                        if (inside) k = k - adv;
-                        else if (by_rec && !direct) { pend = true; pend_d = d; pend_run = rc1; pend_c = cn1; k = 0; }   // entry e0 + cn1 - 1 of the record's header
-                        else { pend = true; pend_d = d; pend_run = t1 - 1; pend_c = 0; k = 0; }
+                        if (r.inside) k = k - adv;
+                        else { pend = true; pend_d = d; pend_run = r.samp_run; pend_c = r.samp_c; k = 0; }
                     }
-                    lo = F + c_before;                          // rowbowt.hpp:86
+                    lo = r.F + r.c_before;                      // rowbowt.hpp:86
                     hi = lo + c_inside - 1;                     // rowbowt.hpp:87
                     p -= adv - 1;                               // the left neighbours are consumed too
                 }
             }
         }
         if (TOEHOLD && alive && pend) {
-            if (pend_c) pend_run = s_rec[pend_d][pend_run].e0 + pend_c - 1;
-            k += static_cast<uint64_t>(static_cast<const P *>(ix.run_samp[pend_d])[pend_run]);
+            RunStep ps;
+            ps.samp_run = pend_run; ps.samp_c = pend_c;
+            k += run_step_sample<P>(ix, s_rec, pend_d, ps);
+            if (STATS) st[kStResample] += 1;
         }
+        if (STATS && !PACKED && p_end > p_min) st[kStChunks] += ((p_end - 1) >> 4) - (p_min >> 4) + 1;
+        if (STATS && PACKED && valid) st[kStChunks] += (p_end + 63) >> 6;
         if (!alive) { lo = 1; hi = 0; k = 0; }                 // {1,0}; LFData::clear rowbowt.hpp:153-159
         if (valid) {
             lo_out[i] = lo;
@@ -902,6 +218,13 @@ __global__ __launch_bounds__(512, sizeof(P) == 4 ? 4 : 3) void k_find_range_runs
         if (w_matched) atomicAdd(&ix.counters[1], w_matched);
         if (c_occ) atomicAdd(&ix.counters[2], c_occ);
     }
+    if (STATS) {
+#pragma unroll
+        for (int t = 0; t < kStatSearchN; ++t) {
+            const unsigned long long v = wave_sum(st[t]);
+            if (lane == 0 && v) atomicAdd(&stats[t], v);
+        }
+    }
 }
 
 // ---- K3 over the run-indexed layout -------------------------------------------------------------------------------
@@ -910,13 +233,16 @@ __global__ __launch_bounds__(512, sizeof(P) == 4 ? 4 : 3) void k_find_range_runs
 template <typename P> struct ChunkR { static constexpr int v = sizeof(P) == 8 ? 8 : 16; };   // as in k_locate.hip
 
 // ORDERED: the chains come in toehold order (launch_locate_order): neighbouring lanes probe neighbouring entries
-template <typename P, bool ORDERED>
+// OUT: width a location is stored at (k_locate.hip); STATS: the instrumented instantiation -- [kLsPhiSteps] phi
+// evaluations (each: one 8-byte directory gather + one probe), [kLsPhiOvf] sampled positions those probes and the
+// narrowing rounds needed (2P bytes each), [kLsChains], [kLsLocs]
+template <typename P, bool ORDERED, typename OUT = uint64_t, bool STATS = false>
 __global__ __launch_bounds__(256, sizeof(P) == 4 ? 4 : 3) void k_locate_fill_runs(const DevIndex ix, const uint64_t *__restrict__ lo,
                                                           const uint64_t *__restrict__ hi, const uint64_t *__restrict__ k,
                                                           const uint64_t N, const uint64_t max_hits,
-                                                          const uint64_t *__restrict__ loc_off, uint64_t *__restrict__ locs,
+                                                          const uint64_t *__restrict__ loc_off, OUT *__restrict__ locs,
                                                           const uint64_t *__restrict__ sub, const uint32_t *__restrict__ order,
-                                                          const uint64_t *__restrict__ skeys) {
+                                                          const uint64_t *__restrict__ skeys, unsigned long long *__restrict__ stats) {
     constexpr int kChunkR = ChunkR<P>::v;
     __shared__ P s_val[4][kWave][kChunkR + 1];
     __shared__ uint64_t s_dst[4][kWave];
@@ -938,6 +264,7 @@ __global__ __launch_bounds__(256, sizeof(P) == 4 ? 4 : 3) void k_locate_fill_run
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
     const PhiEnt<P> *__restrict__ pent = static_cast<const PhiEnt<P> *>(ix.phi_ent);
     unsigned long long c_locs = 0;
+    unsigned long long st_phi = 0, st_ent = 0, st_chains = 0;   // STATS only
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
     for (uint64_t base = static_cast<uint64_t>(blockIdx.x) * blockDim.x + wv * kWave; base < N; base += stride) {
         const uint64_t j = base + lane;
@@ -962,6 +289,7 @@ __global__ __launch_bounds__(256, sizeof(P) == 4 ? 4 : 3) void k_locate_fill_run
         s_minus[wv][lane] = minus;
         s_first[wv][lane] = k1;
         c_locs += occ;
+        if (STATS && occ) st_chains += 1;
         uint64_t wmax = occ;
 #pragma unroll
         for (int o = kWave / 2; o > 0; o >>= 1) {
@@ -989,6 +317,12 @@ __global__ __launch_bounds__(256, sizeof(P) == 4 ? 4 : 3) void k_locate_fill_run
                         g1 = pdir[b + 1];
                     }
                     uint32_t start = g0 ? g0 - 1 : 0, z = g1 - start;
+                    if (STATS && coop) {   // (counted before the narrowing changes z: 16 pivots per round, then the candidates + 1)
+                        st_phi += 1;
+                        uint32_t zz = z;
+                        while (zz > static_cast<uint32_t>(kFan)) { st_ent += kFan; zz = (zz + kFan - 1) / kFan; }
+                        st_ent += zz + 1 > static_cast<uint32_t>(kFan) ? kFan : zz + 1;
+                    }
                     // a crowded bucket is narrowed by pivot probes first (coop_narrow), as the ranks' are
                     if (ORDERED) {
                         while (__ballot(coop && z > static_cast<uint32_t>(kFan))) coop_narrow4<P>(s_tree, 0u, coop && z > static_cast<uint32_t>(kFan), start, z, static_cast<P>(k1));
@@ -1040,7 +374,7 @@ __global__ __launch_bounds__(256, sizeof(P) == 4 ? 4 : 3) void k_locate_fill_run
                 const int s = pass * (kWave / kChunkR) + lane / kChunkR;
                 const int e = lane & (kChunkR - 1);
                 const uint64_t t = t0 + e;
-                if (t < s_occ[wv][s]) locs[s_dst[wv][s] + t] = (t ? static_cast<uint64_t>(s_val[wv][s][e]) : s_first[wv][s]) - s_minus[wv][s];
+                if (t < s_occ[wv][s]) locs[s_dst[wv][s] + t] = static_cast<OUT>((t ? static_cast<uint64_t>(s_val[wv][s][e]) : s_first[wv][s]) - s_minus[wv][s]);
             }
             wave_lds_sync();
         }
@@ -1048,64 +382,94 @@ __global__ __launch_bounds__(256, sizeof(P) == 4 ? 4 : 3) void k_locate_fill_run
     }
     c_locs = wave_sum(c_locs);
     if (lane == 0 && c_locs) atomicAdd(&ix.counters[3], c_locs);
-}
-
-template <typename Kernel>
-void raise_lds(Kernel kernel, size_t bytes) {
-    if (bytes <= 48 * 1024) return;
-    static std::mutex mu;
-    static std::set<std::pair<int, const void *>> raised;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    const auto key = std::make_pair(dev, reinterpret_cast<const void *>(kernel));
-    std::lock_guard<std::mutex> g(mu);
-    if (raised.insert(key).second) (void)hipFuncSetAttribute(key.second, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+    if (STATS) {
+        st_phi = wave_sum(st_phi);
+        st_ent = wave_sum(st_ent);
+        st_chains = wave_sum(st_chains);
+        if (lane == 0) {
+            if (st_phi) atomicAdd(&stats[kLsPhiSteps], st_phi);
+            if (st_ent) atomicAdd(&stats[kLsPhiOvf], st_ent);
+            if (st_chains) atomicAdd(&stats[kLsChains], st_chains);
+            if (c_locs) atomicAdd(&stats[kLsLocs], c_locs);
+        }
+    }
 }
 
 }  // namespace
 
-int launch_find_range_runs(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
-                           uint64_t *lo, uint64_t *hi, uint64_t *ssamp, void *stream) {
+// `packed`: src_a = chunks, src_b = meta (see the kernel); stats != nullptr: the instrumented instantiation
+int launch_find_range_runs_impl(const DevIndex &ix, const LaunchCfg &cfg, const void *src_a, const void *src_b, uint64_t N,
+                                uint64_t *lo, uint64_t *hi, uint64_t *ssamp, void *stream, bool packed, unsigned long long *stats,
+                                const uint32_t *sel = nullptr, const uint32_t *nsel = nullptr) {
     if (N == 0) return 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const size_t lds = static_cast<size_t>(ix.run_ntabs) * sizeof(DevRunTab) + static_cast<size_t>(ix.tree_top_n) * ix.pos_bytes + 16;
+    const size_t lds = run_search_lds(ix);
     LaunchCfg c = cfg;   // 512-thread workgroups: the staged tables and top level are shared by eight waves
     c.block_threads = 512;
     c.max_blocks = cfg.max_blocks > 0 ? std::max(1, cfg.max_blocks / 2) : 256 * 16;
-    const dim3 grid(grid_for(c, N)), block(512);
-#define RBG_LAUNCH_FRR(PT, TOE)                                                                        \
+    // sel mode: the number of reads is only known on the device; a fixed modest grid loops over it
+    const dim3 grid(sel ? std::min(grid_for(c, N), 256) : grid_for(c, N)), block(512);
+#define RBG_LAUNCH_FRR(PT, TOE, PK, STS)                                                               \
     do {                                                                                               \
-        auto kern = k_find_range_runs<PT, TOE>;                                                        \
+        auto kern = k_find_range_runs<PT, TOE, PK, STS>;                                               \
         raise_lds(kern, lds);                                                                          \
-        hipLaunchKernelGGL(kern, grid, block, lds, st, ix, seqs, off, N, lo, hi, ssamp);               \
+        hipLaunchKernelGGL(kern, grid, block, lds, st, ix, src_a, src_b, N, lo, hi, ssamp, stats, sel, nsel);     \
+    } while (0)
+#define RBG_LAUNCH_FRR2(PT, TOE)                                                                       \
+    do {                                                                                               \
+        if (stats) { if (packed) return static_cast<int>(hipErrorNotSupported); RBG_LAUNCH_FRR(PT, TOE, false, true); } \
+        else if (packed) RBG_LAUNCH_FRR(PT, TOE, true, false);                                         \
+        else RBG_LAUNCH_FRR(PT, TOE, false, false);                                                    \
     } while (0)
     if (ix.pos_bytes == 4) {
-        if (ssamp) RBG_LAUNCH_FRR(uint32_t, true); else RBG_LAUNCH_FRR(uint32_t, false);
+        if (ssamp) RBG_LAUNCH_FRR2(uint32_t, true); else RBG_LAUNCH_FRR2(uint32_t, false);
     } else {
-        if (ssamp) RBG_LAUNCH_FRR(uint64_t, true); else RBG_LAUNCH_FRR(uint64_t, false);
+        if (ssamp) RBG_LAUNCH_FRR2(uint64_t, true); else RBG_LAUNCH_FRR2(uint64_t, false);
     }
+#undef RBG_LAUNCH_FRR2
 #undef RBG_LAUNCH_FRR
     return static_cast<int>(hipGetLastError());
 }
 
+int launch_find_range_runs(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
+                           uint64_t *lo, uint64_t *hi, uint64_t *ssamp, void *stream, unsigned long long *stats) {
+    return launch_find_range_runs_impl(ix, cfg, seqs, off, N, lo, hi, ssamp, stream, false, stats);
+}
+
+int launch_find_range_runs_sel(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N, uint64_t *lo,
+                               uint64_t *hi, uint64_t *ssamp, const uint32_t *sel, const uint32_t *nsel, void *stream) {
+    return launch_find_range_runs_impl(ix, cfg, seqs, off, N, lo, hi, ssamp, stream, false, nullptr, sel, nsel);
+}
+
+int launch_find_range_runs_packed(const DevIndex &ix, const LaunchCfg &cfg, const uint2 *meta, const uint4 *chunks, uint64_t N,
+                                  uint64_t *lo, uint64_t *hi, uint64_t *ssamp, void *stream) {
+    return launch_find_range_runs_impl(ix, cfg, chunks, meta, N, lo, hi, ssamp, stream, true, nullptr);
+}
+
 int launch_locate_fill_runs(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t *lo, const uint64_t *hi, const uint64_t *k,
                             uint64_t N, uint64_t max_hits, const uint64_t *loc_off, uint64_t *locs, const uint64_t *sub,
-                            const void *order, const uint64_t *skeys, void *stream) {
+                            const void *order, const uint64_t *skeys, void *stream, unsigned long long *stats, uint32_t *locs32) {
     if (N == 0) return 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const size_t lds = static_cast<size_t>(ix.phi_tree.top_n) * ix.pos_bytes + 16;
     const dim3 grid(grid_for(cfg, N)), block(256);
     const uint32_t *perm = static_cast<const uint32_t *>(order);
-#define RBG_LAUNCH_LFR(PT, ORD)                                                                                         \
+#define RBG_LAUNCH_LFR(PT, ORD, OUT, STS, DST)                                                                          \
     do {                                                                                                               \
-        auto kern = k_locate_fill_runs<PT, ORD>;                                                                       \
+        auto kern = k_locate_fill_runs<PT, ORD, OUT, STS>;                                                             \
         raise_lds(kern, lds);                                                                                          \
-        hipLaunchKernelGGL(kern, grid, block, lds, st, ix, lo, hi, k, N, max_hits, loc_off, locs, sub, perm, skeys);   \
+        hipLaunchKernelGGL(kern, grid, block, lds, st, ix, lo, hi, k, N, max_hits, loc_off, DST, sub, perm, skeys, stats);   \
     } while (0)
-    if (ix.pos_bytes == 4) {
-        if (perm) RBG_LAUNCH_LFR(uint32_t, true); else RBG_LAUNCH_LFR(uint32_t, false);
+    if (locs32) {
+        if (stats || ix.pos_bytes != 4) return static_cast<int>(hipErrorInvalidValue);
+        if (perm) RBG_LAUNCH_LFR(uint32_t, true, uint32_t, false, locs32); else RBG_LAUNCH_LFR(uint32_t, false, uint32_t, false, locs32);
+    } else if (stats) {
+        if (!perm) return static_cast<int>(hipErrorNotSupported);   // the instrumented walk is the ordered one
+        if (ix.pos_bytes == 4) RBG_LAUNCH_LFR(uint32_t, true, uint64_t, true, locs); else RBG_LAUNCH_LFR(uint64_t, true, uint64_t, true, locs);
+    } else if (ix.pos_bytes == 4) {
+        if (perm) RBG_LAUNCH_LFR(uint32_t, true, uint64_t, false, locs); else RBG_LAUNCH_LFR(uint32_t, false, uint64_t, false, locs);
     } else {
-        if (perm) RBG_LAUNCH_LFR(uint64_t, true); else RBG_LAUNCH_LFR(uint64_t, false);
+        if (perm) RBG_LAUNCH_LFR(uint64_t, true, uint64_t, false, locs); else RBG_LAUNCH_LFR(uint64_t, false, uint64_t, false, locs);
     }
 #undef RBG_LAUNCH_LFR
     return static_cast<int>(hipGetLastError());

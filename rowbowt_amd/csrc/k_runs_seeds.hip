@@ -1,0 +1,477 @@
+// k_runs_seeds.hip -- the kernels beside the rb_align path on the run-indexed layout (RBG_LAYOUT_RUNS): single LF steps
+// (RowBowt::LF, rowbowt.hpp:74-88), find_range_w_markers (:292-339), greedy seeds (:222-256 reduced by :669-677) and
+// marker seeds (get_markers_greedy_seeding, :406-482).  Same outputs as their slot-table versions in k_markers.hip; what
+// differs is how a rank is answered: there one lane reads one slot, here the WAVE answers the two ranks of every lane's
+// step together (coop_lf2, rbg_runs_device.hpp: directory gather + one probe of the run list by a quad of lanes), and a
+// step may consume up to run_ksteps symbols through the k-mer depth's run list.  So each kernel is written as a state
+// machine: per round every lane that still has work names its next step (or does lane-local work that needs no rank:
+// ftab entries, absent symbols, marker queries), the wave answers all the steps, every lane applies its result.
+// (Round 2 answered these kernels' ranks lane by lane with a binary search from the symbol's directory, single symbols
+// only: 104 ms per 10 M reads for the greedy seeds on the bench index against 8 ms for K1.)
+#include "rbg_runs_device.hpp"
+
+namespace rbg {
+namespace {
+
+// runs are disjoint, ascending inclusive SA-index intervals; at_range(lo,hi) = values of all runs with start <= hi &&
+// end >= lo, in run order (k_markers.hip marker_span)
+__device__ __forceinline__ void marker_span_r(const DevIndex &ix, uint64_t lo, uint64_t hi, uint64_t *first, uint64_t *last) {
+    if (ix.mk_bucket) {
+        if (lo >= ix.n) { *first = *last = ix.mk_nruns; return; }
+        if (hi >= ix.n) hi = ix.n - 1;
+        uint64_t a = ix.mk_bucket[lo >> ix.mk_shift];
+        while (a < ix.mk_nruns && ix.mk_end[a] < lo) ++a;
+        *first = a;
+        uint64_t z = ix.mk_bucket[hi >> ix.mk_shift];
+        if (z < a) z = a;
+        while (z < ix.mk_nruns && ix.mk_start[z] <= hi) ++z;
+        *last = z;
+        return;
+    }
+    uint64_t a = 0, z = ix.mk_nruns;
+    while (a < z) { const uint64_t m = a + ((z - a) >> 1); if (ix.mk_end[m] < lo) a = m + 1; else z = m; }
+    *first = a;
+    a = 0; z = ix.mk_nruns;
+    while (a < z) { const uint64_t m = a + ((z - a) >> 1); if (ix.mk_start[m] <= hi) a = m + 1; else z = m; }
+    *last = a;
+}
+
+// the step that consumes the longest k-mer of at most `cap` symbols (all of them k-mer symbols) ending at byte p:
+// adv = its length, (d, rec) = depth index and record of its table.  adv == 1: the single symbol's table, or
+// ok = false when the byte does not occur in the index (f_[c] >= f_[c+1], rowbowt.hpp:76: an empty range).
+struct StepPick {
+    uint32_t adv, d, rec;
+    bool ok;
+};
+__device__ __forceinline__ StepPick pick_step(ByteCursor &rd, const uint8_t *s_lut, const uint8_t *s_lut2, const uint32_t *s_tab_first,
+                                              const uint64_t p, const uint64_t cap, const uint32_t D, const uint32_t M) {
+    StepPick s{1u, 0u, 0u, true};
+    const uint32_t c = rd.at(p);
+    const uint32_t m0 = s_lut2[c];
+    uint32_t acc = m0;
+    if (m0 != 0xFFu) {
+        uint32_t pw = M;
+#pragma unroll 1
+        for (uint32_t t = 1; t < static_cast<uint32_t>(kMaxRunDepth); ++t) {
+            if (t >= D || t >= cap) break;
+            const uint32_t mm = s_lut2[rd.at(p - t)];
+            if (mm == 0xFFu) break;
+            acc += mm * pw;
+            pw *= M;
+            s.adv = t + 1;
+        }
+    }
+    if (s.adv == 1) {
+        const uint32_t slot = s_lut[c];
+        if (slot == 0xFFu || slot >= static_cast<uint32_t>(kLdsSyms)) s.ok = false;   // (more than kLdsSyms symbols never get this layout)
+        else s.rec = run_record(s_tab_first, 1u, slot);
+    } else {
+        s.d = s.adv - 1;
+        s.rec = run_record(s_tab_first, s.adv, acc);
+    }
+    return s;
+}
+
+// the state after the word of ftab_k k-mer symbols that ends at byte p, from the device table; false: not usable
+// (a symbol outside the k-mer alphabet, the "search it step by step" marker, or a word that does not occur)
+template <typename P>
+__device__ __forceinline__ bool ftab_state(const DevIndex &ix, ByteCursor &rd, const uint8_t *s_lut2, const uint64_t p, const uint32_t M, uint64_t &lo,
+                                           uint64_t &hi, uint64_t &k) {
+    uint64_t idx = 0, pw = 1;
+    bool all_major = true;
+    for (uint32_t t = 0; t < ix.ftab_k; ++t) {
+        const uint32_t mm = s_lut2[rd.at(p - t)];
+        all_major = all_major && mm != 0xFFu;
+        idx += (mm & 3u) * pw;
+        pw *= M;
+    }
+    uint64_t flo, fhi, fk;
+    if (!all_major || !ftab_lookup<P>(ix, idx, flo, fhi, fk) || flo > fhi) return false;
+    lo = flo; hi = fhi; k = fk;
+    return true;
+}
+
+#define RBG_SEED_KERNEL_PROLOGUE(P, WAVES)                                                        \
+    __shared__ uint8_t s_lut[256];                                                                \
+    __shared__ uint8_t s_lut2[256];                                                               \
+    RBG_RUN_SEARCH_SHARED(P, WAVES);                                                              \
+    for (int t = threadIdx.x; t < 256; t += blockDim.x) {                                         \
+        s_lut[t] = ix.lut[t];                                                                     \
+        s_lut2[t] = ix.nmajor ? ix.lut2[t] : 0xFFu;                                               \
+    }                                                                                             \
+    const RunSearch<P> S = stage_run_search<P, WAVES>(ix, s_tree, s_tab_first, s_rec, s_req, s_dyn); \
+    const uint32_t D = ix.run_ksteps, M = ix.nmajor;                                              \
+    const uint32_t lane = threadIdx.x & (kWave - 1);                                              \
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;                        \
+    const uint64_t wave_first = static_cast<uint64_t>(blockIdx.x) * blockDim.x + (threadIdx.x & ~(kWave - 1))
+
+// ---- single LF step for N (range, symbol) triples: RowBowt::LF(range_t, uint8_t), rowbowt.hpp:74-88 -------------------
+template <typename P>
+__global__ __launch_bounds__(512, sizeof(P) == 4 ? 4 : 3) void k_lf_runs(const DevIndex ix, const uint64_t *__restrict__ lo_in,
+                                                                        const uint64_t *__restrict__ hi_in, const uint8_t *__restrict__ sym,
+                                                                        const uint64_t N, uint64_t *__restrict__ lo_out, uint64_t *__restrict__ hi_out) {
+    RBG_SEED_KERNEL_PROLOGUE(P, 8);
+    (void)D; (void)M; (void)s_lut2;
+    for (uint64_t base = wave_first; base < N; base += stride) {
+        const uint64_t i = base + lane;
+        const bool valid = i < N;
+        uint64_t lo = 0, hi = 0;
+        uint32_t rec = 0;
+        bool stepping = false;
+        if (valid) {
+            lo = lo_in[i]; hi = hi_in[i];
+            const uint32_t slot = s_lut[sym[i]];
+            // hi >= n is outside rle_string::rank's domain (assert(i<=n), rle_string.hpp:132): answer {1,0}
+            stepping = slot != 0xFFu && slot < static_cast<uint32_t>(kLdsSyms) && hi < ix.n && lo <= hi + 1;
+            if (stepping) rec = run_record(s_tab_first, 1u, slot);
+        }
+        RunStep r;
+        coop_lf2<P>(ix, S, stepping, 0u, rec, lo, hi + 1, r);
+        if (valid) {
+            uint64_t nlo = 1, nhi = 0;
+            if (stepping && r.c_upto > r.c_before) { nlo = r.F + r.c_before; nhi = nlo + (r.c_upto - r.c_before) - 1; }
+            lo_out[i] = nlo;
+            hi_out[i] = nhi;
+        }
+    }
+}
+
+// ---- find_range_w_markers (rowbowt.hpp:292-339): single steps, a marker query at every window end ---------------------
+// (k_markers.hip k_find_range_markers; window results are PREPENDED in the reference, :320,:333)
+template <typename P, bool FILL>
+__global__ __launch_bounds__(512, sizeof(P) == 4 ? 4 : 3) void k_find_range_markers_runs(const DevIndex ix, const uint8_t *__restrict__ seqs,
+                                                            const uint64_t *__restrict__ off, const uint64_t N,
+                                                            const uint64_t wsize, const uint64_t max_range,
+                                                            uint64_t *__restrict__ lo_out, uint64_t *__restrict__ hi_out,
+                                                            uint64_t *__restrict__ cnt_out,
+                                                            const uint64_t *__restrict__ mk_off, uint64_t *__restrict__ mk) {
+    RBG_SEED_KERNEL_PROLOGUE(P, 8);
+    (void)D; (void)M;
+    if (!FILL && blockIdx.x == 0 && threadIdx.x == 0) cnt_out[0] = 0;
+    for (uint64_t base = wave_first; base < N; base += stride) {
+        const uint64_t i = base + lane;
+        const bool valid = i < N;
+        uint64_t beg = 0, end = 0, m = 0;
+        if (valid) { beg = off[i]; end = off[i + 1]; m = end - beg; }
+        uint64_t lo = 1, hi = 0;
+        bool alive = valid && m >= wsize;              // rowbowt.hpp:299-302: shorter queries return the default LFData
+        // fill pass: a read with nothing to emit (every read that dies: lf.clear() drops what earlier windows collected) writes nothing
+        if (FILL && valid && mk_off[i + 1] == mk_off[i]) alive = false;
+        const bool started = alive;
+        uint64_t window_ei = m, acc = 0, s = 0;
+        const uint64_t want = (FILL && valid) ? mk_off[i + 1] - mk_off[i] : 0;
+        uint64_t *dst = (FILL && valid) ? mk + mk_off[i] : nullptr;
+        if (alive) { lo = 0; hi = ix.n - 1; }
+        ByteCursor rd{reinterpret_cast<const uint4 *>(seqs), ~uint64_t(0), make_uint4(0, 0, 0, 0)};
+        auto query = [&]() {                           // :318,:331
+            if (hi - lo + 1 > max_range) return;
+            uint64_t f, l;
+            marker_span_r(ix, lo, hi, &f, &l);
+            if (l <= f) return;
+            const uint64_t src = ix.mk_off[f], cnt = ix.mk_off[l] - src;
+            acc += cnt;
+            if (FILL) {
+                uint64_t *d = dst + (want - acc);
+                for (uint64_t t = 0; t < cnt; ++t) d[t] = ix.mk_vals[src + t];
+            }
+        };
+        while (__ballot(alive && s < m)) {
+            bool stepping = alive && s < m;
+            uint32_t rec = 0;
+            if (stepping) {
+                const uint32_t slot = s_lut[rd.at(end - 1 - s)];
+                if (slot == 0xFFu || slot >= static_cast<uint32_t>(kLdsSyms)) { alive = false; stepping = false; }
+                else rec = run_record(s_tab_first, 1u, slot);
+            }
+            RunStep r;
+            coop_lf2<P>(ix, S, stepping, 0u, rec, lo, hi + 1, r);
+            if (stepping) {
+                const uint64_t c_inside = r.c_upto - r.c_before;
+                if (c_inside == 0) alive = false;
+                else {
+                    lo = r.F + r.c_before;
+                    hi = lo + c_inside - 1;
+                    if (window_ei - (m - s) >= wsize) {     // :315
+                        window_ei = m - s;                  // :322
+                        query();
+                    }
+                    ++s;
+                }
+            }
+        }
+        if (alive && (m - 1) % wsize != 0) query();         // :328 (s == m)
+        if (!FILL && valid) {
+            if (started && !alive) { lo = 1; hi = 0; }      // lf.clear(), :311-313
+            lo_out[i] = lo;
+            hi_out[i] = hi;
+            cnt_out[i + 1] = (started && alive) ? acc : 0;
+        }
+    }
+}
+
+// ---- greedy seeding: RowBowt::get_seeds_greedy_w_sample (rowbowt.hpp:222-256) reduced on the fly by
+// locate_from_longest_seed's choice (:669-677): per read the first seed of strictly greatest length (k_markers.hip
+// k_greedy_seed).  A k-mer step that comes back empty is narrowed by halving until the failing base is the reference's.
+template <typename P>
+__global__ __launch_bounds__(512, sizeof(P) == 4 ? 4 : 3) void k_greedy_seed_runs(const DevIndex ix, const uint8_t *__restrict__ seqs,
+                                                     const uint64_t *__restrict__ off, const uint64_t N,
+                                                     const uint64_t min_length, uint64_t *__restrict__ lo_out,
+                                                     uint64_t *__restrict__ hi_out, uint64_t *__restrict__ qs_out,
+                                                     uint64_t *__restrict__ qe_out, uint64_t *__restrict__ ss_out) {
+    RBG_SEED_KERNEL_PROLOGUE(P, 8);
+    const uint64_t first_k = ix.last_run_sample;       // rowbowt.hpp:230
+    const uint64_t fhi = ix.n - 1;
+    for (uint64_t base = wave_first; base < N; base += stride) {
+        const uint64_t i = base + lane;
+        const bool valid = i < N;
+        uint64_t beg = 0, m = 0;
+        if (valid) { beg = off[i]; m = off[i + 1] - beg; }
+        uint64_t lo = 0, hi = fhi, plo = 0, phi = fhi;
+        uint64_t k = first_k, pk = ~uint64_t(0), ei = m;
+        uint64_t b_lo = 1, b_hi = 0, b_qs = 0, b_qe = 0, b_k = 0, b_len = 0;
+        uint64_t j = m;                                 // next symbol to consume is q[j-1]
+        uint32_t nlen = 0;                              // > 0: a k-mer step over q[j-nlen, j) came back empty and is being narrowed
+        ByteCursor rd{reinterpret_cast<const uint4 *>(seqs), ~uint64_t(0), make_uint4(0, 0, 0, 0)};
+        auto on_ok = [&](uint32_t adv) {
+            j -= adv;
+            plo = lo; phi = hi; pk = k;                 // rowbowt.hpp:248-249
+        };
+        auto on_fail = [&]() {                          // q[j-1] ends the seed q[j, ei)  (rowbowt.hpp:236-246; m-i == j here)
+            if (ei - j >= min_length && ei - j > b_len) { b_len = ei - j; b_lo = plo; b_hi = phi; b_qs = j; b_qe = ei; b_k = pk; }
+            k = first_k;
+            lo = 0; hi = fhi; plo = 0; phi = fhi;
+            j -= 1;                                     // skip the base that failed
+            ei = j;
+        };
+        while (__ballot(valid && j > 0)) {
+            bool stepping = false;
+            StepPick pick{1u, 0u, 0u, true};
+            while (valid && j > 0 && !stepping) {       // lane-local work until a rank is needed
+                const uint64_t p = beg + j - 1;
+                if (nlen == 0) {
+                    // a fresh seed: the state after its first ftab_k symbols is one gather in the device table
+                    if (j == ei && ix.ftab_k && j >= ix.ftab_k && ftab_state<P>(ix, rd, s_lut2, p, M, lo, hi, k)) { on_ok(ix.ftab_k); continue; }
+                    pick = pick_step(rd, s_lut, s_lut2, s_tab_first, p, j, D, M);
+                    if (!pick.ok) { on_fail(); continue; }
+                } else {
+                    pick = pick_step(rd, s_lut, s_lut2, s_tab_first, p, nlen / 2, D, M);   // == nlen / 2 symbols: the window holds k-mer symbols only
+                }
+                stepping = true;
+            }
+            RunStep r;
+            coop_lf2<P>(ix, S, stepping, pick.d, pick.rec, lo, hi + 1, r);
+            if (stepping) {
+                const uint64_t c_inside = r.c_upto - r.c_before;
+                const bool ok = c_inside != 0;
+                if (ok) {                               // LF_w_loc, rowbowt.hpp:555-573, pick.adv times nested
+                    if (r.inside) k = k - pick.adv;
+                    else k = run_step_sample<P>(ix, s_rec, pick.d, r);
+                    lo = r.F + r.c_before;
+                    hi = lo + c_inside - 1;
+                }
+                if (nlen == 0) {
+                    if (ok) on_ok(pick.adv);
+                    else if (pick.adv == 1) on_fail();
+                    else nlen = pick.adv;               // the range died inside q[j-adv, j): halve until one symbol is left
+                } else {
+                    if (ok) { on_ok(pick.adv); nlen -= pick.adv; } else nlen = pick.adv;
+                }
+                if (nlen == 1) { on_fail(); nlen = 0; }  // that symbol is the failing base
+            }
+        }
+        if (valid) {
+            if (ei >= min_length && ei > b_len) { b_len = ei; b_lo = plo; b_hi = phi; b_qs = 0; b_qe = ei; b_k = pk; }  // :252-254
+            lo_out[i] = b_lo;
+            hi_out[i] = b_hi;
+            qs_out[i] = b_qs;
+            qe_out[i] = b_qe;
+            ss_out[i] = b_k;
+        }
+    }
+}
+
+// ---- marker seeds: RowBowt::get_markers_greedy_seeding without an ftab file (rowbowt.hpp:406-482; rb_markers' default
+// path, rb_markers.cpp:411-413) -- k_markers.hip k_marker_seeds<P, FILL>'s default mode; the --ftab mode of the tool stays
+// with that kernel (lane by lane).  One record per call of the reference's callback: {range lo, range hi, q.first,
+// seed_ei, first marker, one past last marker}.
+template <typename P, bool FILL>
+__global__ __launch_bounds__(512, sizeof(P) == 4 ? 4 : 3) void k_marker_seeds_runs(const DevIndex ix, const uint8_t *__restrict__ seqs,
+                                                      const uint64_t *__restrict__ off, const uint64_t N,
+                                                      const uint64_t wsize, const uint64_t max_range,
+                                                      uint64_t *__restrict__ seed_cnt, uint64_t *__restrict__ mk_cnt,
+                                                      const uint64_t *__restrict__ seed_off, const uint64_t *__restrict__ mk_off,
+                                                      uint64_t *__restrict__ seeds, uint64_t *__restrict__ mk) {
+    RBG_SEED_KERNEL_PROLOGUE(P, 8);
+    if (!FILL && blockIdx.x == 0 && threadIdx.x == 0) { seed_cnt[0] = 0; mk_cnt[0] = 0; }
+    const bool have_ma = ix.mk_nruns != 0;
+    const uint64_t fhi = ix.n - 1;
+    for (uint64_t base = wave_first; base < N; base += stride) {
+        const uint64_t i = base + lane;
+        const bool valid = i < N;
+        uint64_t beg = 0, m = 0;
+        if (valid) { beg = off[i]; m = off[i + 1] - beg; }
+        uint64_t lo = 0, hi = fhi, plo = 0, phi = fhi;    // range, prev_range (:427-428)
+        uint64_t window_ei = m, seed_ei = m;              // :434
+        uint64_t ns = 0, tot = 0, mb_begin = 0;           // mbuf == markers [mb_begin, tot) of this read
+        uint64_t *srec = (FILL && valid) ? seeds + 6 * seed_off[i] : nullptr;
+        const uint64_t mbase = (FILL && valid) ? mk_off[i] : 0;
+        uint64_t j = m;                                   // m - i of the reference; the next symbol consumed is q[j-1]
+        uint32_t nlen = 0;
+        uint64_t unused_k = 0;
+        ByteCursor rd{reinterpret_cast<const uint4 *>(seqs), ~uint64_t(0), make_uint4(0, 0, 0, 0)};
+        auto update_mbuf = [&](uint64_t l, uint64_t h) {  // :437-441
+            if (!have_ma || h - l + 1 > max_range) return;
+            uint64_t f, e;
+            marker_span_r(ix, l, h, &f, &e);
+            if (e <= f) return;
+            const uint64_t src = ix.mk_off[f], cnt = ix.mk_off[e] - src;
+            if (FILL) {
+                uint64_t *d = mk + mbase + tot;
+                for (uint64_t t = 0; t < cnt; ++t) d[t] = ix.mk_vals[src + t];
+            }
+            tot += cnt;
+        };
+        auto emit = [&](uint64_t l, uint64_t h, uint64_t qs, uint64_t qe) {  // fn(range, (qs, qe-1), mbuf)
+            if (FILL) {
+                uint64_t *d = srec + 6 * ns;
+                d[0] = l; d[1] = h; d[2] = qs; d[3] = qe; d[4] = mbase + mb_begin; d[5] = mbase + tot;
+            }
+            ++ns;
+        };
+        auto on_ok = [&](uint32_t adv) {              // adv symbols consumed, range still non-empty
+            j -= adv;
+            if (window_ei - j >= wsize) {             // :469-472 (m-i-1 == j after the step)
+                update_mbuf(lo, hi);
+                window_ei = j;
+            }
+            plo = lo; phi = hi;                       // :473
+        };
+        auto on_fail = [&]() {                        // q[j-1] empties the range: the seed q[j, seed_ei) ends (:444-466)
+            if (seed_ei - j >= wsize) update_mbuf(plo, phi);
+            emit(plo, phi, j, seed_ei);
+            mb_begin = tot;
+            plo = 0; phi = fhi; lo = 0; hi = fhi;
+            j -= 1;                                   // the failing base is skipped
+            seed_ei = j;
+            window_ei = j;
+        };
+        while (__ballot(valid && j > 0)) {
+            bool stepping = false;
+            StepPick pick{1u, 0u, 0u, true};
+            while (valid && j > 0 && !stepping) {
+                const uint64_t p = beg + j - 1;
+                if (nlen == 0) {
+                    // symbols that may be consumed before the next window query fires (:469)
+                    uint64_t dist = j + wsize > window_ei ? j + wsize - window_ei : 1;
+                    if (dist == 0) dist = 1;
+                    const uint64_t cap = dist < j ? dist : j;
+                    if (j == seed_ei && ix.ftab_k && cap >= ix.ftab_k && ftab_state<P>(ix, rd, s_lut2, p, M, lo, hi, unused_k)) { on_ok(ix.ftab_k); continue; }
+                    pick = pick_step(rd, s_lut, s_lut2, s_tab_first, p, cap, D, M);
+                    if (!pick.ok) { on_fail(); continue; }
+                } else {
+                    pick = pick_step(rd, s_lut, s_lut2, s_tab_first, p, nlen / 2, D, M);
+                }
+                stepping = true;
+            }
+            RunStep r;
+            coop_lf2<P>(ix, S, stepping, pick.d, pick.rec, lo, hi + 1, r);
+            if (stepping) {
+                const uint64_t c_inside = r.c_upto - r.c_before;
+                const bool ok = c_inside != 0;
+                if (ok) {
+                    lo = r.F + r.c_before;
+                    hi = lo + c_inside - 1;
+                }
+                if (nlen == 0) {
+                    if (ok) on_ok(pick.adv);
+                    else if (pick.adv == 1) on_fail();
+                    else nlen = pick.adv;
+                } else {
+                    if (ok) { on_ok(pick.adv); nlen -= pick.adv; } else nlen = pick.adv;
+                }
+                if (nlen == 1) { on_fail(); nlen = 0; }
+            }
+        }
+        if (valid) {
+            if (hi >= lo && seed_ei >= wsize) update_mbuf(lo, hi);   // :478-480 (m-i == 0)
+            emit(lo, hi, 0, seed_ei);                                // :481
+            if (!FILL) {
+                seed_cnt[i + 1] = ns;
+                mk_cnt[i + 1] = tot;
+            }
+        }
+    }
+}
+
+struct SeedLaunch {
+    dim3 grid, block;
+    size_t lds;
+};
+SeedLaunch seed_launch(const DevIndex &ix, const LaunchCfg &cfg, uint64_t N) {
+    LaunchCfg c = cfg;   // 512-thread workgroups: the staged tables are shared by eight waves
+    c.block_threads = 512;
+    c.max_blocks = cfg.max_blocks > 0 ? std::max(1, cfg.max_blocks / 2) : 256 * 16;
+    return SeedLaunch{dim3(grid_for(c, N)), dim3(512), run_search_lds(ix)};
+}
+
+}  // namespace
+
+#define RBG_LAUNCH_SEEDK(KERN, ...)                                                     \
+    do {                                                                                \
+        auto kern = KERN;                                                               \
+        raise_lds(kern, L.lds);                                                         \
+        hipLaunchKernelGGL(kern, L.grid, L.block, L.lds, st, ix, __VA_ARGS__);          \
+    } while (0)
+
+int launch_lf_runs(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t *lo, const uint64_t *hi, const uint8_t *sym, uint64_t N,
+                   uint64_t *lo_out, uint64_t *hi_out, void *stream) {
+    if (N == 0) return 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const SeedLaunch L = seed_launch(ix, cfg, N);
+    if (ix.pos_bytes == 4) RBG_LAUNCH_SEEDK(k_lf_runs<uint32_t>, lo, hi, sym, N, lo_out, hi_out);
+    else RBG_LAUNCH_SEEDK(k_lf_runs<uint64_t>, lo, hi, sym, N, lo_out, hi_out);
+    return static_cast<int>(hipGetLastError());
+}
+
+int launch_find_range_markers_runs(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
+                                   uint64_t wsize, uint64_t max_range, uint64_t *lo, uint64_t *hi, uint64_t *cnt, const uint64_t *mk_off,
+                                   uint64_t *mk, bool fill, void *stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const SeedLaunch L = seed_launch(ix, cfg, N);
+    if (ix.pos_bytes == 4) {
+        if (fill) RBG_LAUNCH_SEEDK((k_find_range_markers_runs<uint32_t, true>), seqs, off, N, wsize, max_range, lo, hi, cnt, mk_off, mk);
+        else RBG_LAUNCH_SEEDK((k_find_range_markers_runs<uint32_t, false>), seqs, off, N, wsize, max_range, lo, hi, cnt, mk_off, mk);
+    } else {
+        if (fill) RBG_LAUNCH_SEEDK((k_find_range_markers_runs<uint64_t, true>), seqs, off, N, wsize, max_range, lo, hi, cnt, mk_off, mk);
+        else RBG_LAUNCH_SEEDK((k_find_range_markers_runs<uint64_t, false>), seqs, off, N, wsize, max_range, lo, hi, cnt, mk_off, mk);
+    }
+    return static_cast<int>(hipGetLastError());
+}
+
+int launch_greedy_seed_runs(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
+                            uint64_t min_length, uint64_t *lo, uint64_t *hi, uint64_t *qs, uint64_t *qe, uint64_t *ss, void *stream) {
+    if (N == 0) return 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const SeedLaunch L = seed_launch(ix, cfg, N);
+    if (ix.pos_bytes == 4) RBG_LAUNCH_SEEDK(k_greedy_seed_runs<uint32_t>, seqs, off, N, min_length, lo, hi, qs, qe, ss);
+    else RBG_LAUNCH_SEEDK(k_greedy_seed_runs<uint64_t>, seqs, off, N, min_length, lo, hi, qs, qe, ss);
+    return static_cast<int>(hipGetLastError());
+}
+
+int launch_marker_seeds_runs(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N, uint64_t wsize,
+                             uint64_t max_range, uint64_t *seed_cnt, uint64_t *mk_cnt, const uint64_t *seed_off, const uint64_t *mk_off,
+                             uint64_t *seeds, uint64_t *mk, bool fill, void *stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const SeedLaunch L = seed_launch(ix, cfg, N);
+    if (ix.pos_bytes == 4) {
+        if (fill) RBG_LAUNCH_SEEDK((k_marker_seeds_runs<uint32_t, true>), seqs, off, N, wsize, max_range, seed_cnt, mk_cnt, seed_off, mk_off, seeds, mk);
+        else RBG_LAUNCH_SEEDK((k_marker_seeds_runs<uint32_t, false>), seqs, off, N, wsize, max_range, seed_cnt, mk_cnt, seed_off, mk_off, seeds, mk);
+    } else {
+        if (fill) RBG_LAUNCH_SEEDK((k_marker_seeds_runs<uint64_t, true>), seqs, off, N, wsize, max_range, seed_cnt, mk_cnt, seed_off, mk_off, seeds, mk);
+        else RBG_LAUNCH_SEEDK((k_marker_seeds_runs<uint64_t, false>), seqs, off, N, wsize, max_range, seed_cnt, mk_cnt, seed_off, mk_off, seeds, mk);
+    }
+    return static_cast<int>(hipGetLastError());
+}
+#undef RBG_LAUNCH_SEEDK
+
+}  // namespace rbg

@@ -441,7 +441,7 @@ int launch_find_range_impl(const DevIndex &ix, const LaunchCfg &cfg, const uint8
 
 int launch_find_range_stats(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
                             uint64_t *lo, uint64_t *hi, uint64_t *ssamp, unsigned long long *stats, void *stream) {
-    if (ix.layout == 2) return static_cast<int>(hipErrorNotSupported);  // the instrumented walk exists for the slot tables only
+    if (ix.layout == 2) return launch_find_range_runs(ix, cfg, seqs, off, N, lo, hi, ssamp, stream, stats);  // (its sums mean other things: rbg.h)
     return ix.ftab_k ? launch_find_range_impl<true, true>(ix, cfg, seqs, off, N, lo, hi, ssamp, nullptr, nullptr, stream, stats)
                      : launch_find_range_impl<false, true>(ix, cfg, seqs, off, N, lo, hi, ssamp, nullptr, nullptr, stream, stats);
 }
@@ -508,6 +508,7 @@ int launch_pack_reads(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *s
 int launch_find_range_packed_only(const DevIndex &ix, const LaunchCfg &cfg, const uint2 *meta, const uint4 *chunks, uint64_t N,
                                   uint64_t *lo, uint64_t *hi, uint64_t *ssamp, void *stream) {
     if (N == 0) return 0;
+    if (ix.layout == 2) return launch_find_range_runs_packed(ix, cfg, meta, chunks, N, lo, hi, ssamp, stream);   // run-indexed layout (k_runs.hip)
     hipStream_t st = static_cast<hipStream_t>(stream);
 #define RBG_LAUNCH_FRP(PT, TOE)                                                                       \
     do {                                                                                              \
@@ -533,6 +534,13 @@ int launch_find_range_packed(const DevIndex &ix, const LaunchCfg &cfg, const voi
     const uint2 *meta = reinterpret_cast<const uint2 *>(b + L.meta);
     const uint4 *chunks = reinterpret_cast<const uint4 *>(b + L.chunks);
     const bool toe = ssamp != nullptr;
+    int rc;
+    if (ix.layout == 2) {   // run-indexed layout (k_runs.hip); the flagged reads go to its byte kernel below
+        rc = launch_find_range_runs_packed(ix, cfg, meta, chunks, N, lo, hi, ssamp, stream);
+        if (rc) return rc;
+        const uint32_t *sel2 = reinterpret_cast<const uint32_t *>(b + L.sel), *nsel2 = reinterpret_cast<const uint32_t *>(b + L.nsel);
+        return launch_find_range_runs_sel(ix, cfg, seqs, off, N, lo, hi, ssamp, sel2, nsel2, stream);
+    }
 #define RBG_LAUNCH_FRP(PT, TOE)                                                                       \
     do {                                                                                              \
         auto kern = k_find_range_packed<PT, TOE>;                                                     \
@@ -545,7 +553,7 @@ int launch_find_range_packed(const DevIndex &ix, const LaunchCfg &cfg, const voi
         if (toe) RBG_LAUNCH_FRP(uint64_t, true); else RBG_LAUNCH_FRP(uint64_t, false);
     }
 #undef RBG_LAUNCH_FRP
-    int rc = static_cast<int>(hipGetLastError());
+    rc = static_cast<int>(hipGetLastError());
     if (rc) return rc;
     // the reads the packed form cannot express (a symbol outside the major alphabet)
     const uint32_t *sel = reinterpret_cast<const uint32_t *>(b + L.sel), *nsel = reinterpret_cast<const uint32_t *>(b + L.nsel);

@@ -1868,6 +1868,17 @@ int rbg_locate_fill_dev(rbg_index *ix, const uint64_t *d_lo, const uint64_t *d_h
     });
 }
 
+int rbg_locate_fill_dev32(rbg_index *ix, const uint64_t *d_lo, const uint64_t *d_hi, const uint64_t *d_k, uint64_t N,
+                          uint64_t max_hits, const uint64_t *d_loc_off, uint32_t *d_locs32, const void *d_order, void *stream) {
+    return guarded([&]() -> int {
+    if (!queryable(ix)) return RBG_ENODEV;
+    if (!ix->H().has_tsa) return RBG_ENOTLOADED;
+    if (ix->H().pos_bytes != 4) return RBG_EARG;   // text positions beyond 32 bits: rbg_locate_fill_dev
+    if (N && (!d_lo || !d_hi || !d_k || !d_loc_off || !d_locs32)) return RBG_EARG;
+    return launch_locate_fill(ix->dev, ix->cfg, d_lo, d_hi, d_k, N, max_hits, d_loc_off, nullptr, nullptr, d_order, stream, nullptr, d_locs32) ? RBG_ENODEV : RBG_OK;
+    });
+}
+
 int rbg_markers_plan_dev(rbg_index *ix, const uint64_t *d_lo, const uint64_t *d_hi, uint64_t N, uint64_t *d_mk_off,
                          void *d_tmp, size_t tmp_bytes, void *stream) {
     return guarded([&]() -> int {
@@ -2054,7 +2065,7 @@ static int find_range_host_core(rbg_index *ix, const HostReads &R, uint64_t N, u
     const int64_t pk = g_opt_packed_reads.load();
     const HostIndex &h = ix->H();
     // 2-bit transfer: needs the packed search kernel's alphabet (four k-mer symbols) and the slot-table layout
-    const bool pack = allow_pack && ix->dev.nmajor == 4 && ix->dev.layout == RBG_LAYOUT_SLOTS && (pk == 2 || (pk == 1 && N >= 4096));
+    const bool pack = allow_pack && ix->dev.nmajor == 4 && (pk == 2 || (pk == 1 && N >= 4096));
     const bool acgt = h.major_byte[0] == 'A' && h.major_byte[1] == 'C' && h.major_byte[2] == 'G' && h.major_byte[3] == 'T';
     if (!W.team) {
         // a quarter of the hardware's CPUs, at most 64 and at most what the container's CPU quota lets run at once

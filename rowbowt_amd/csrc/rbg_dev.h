@@ -252,10 +252,27 @@ int launch_find_range(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *s
                       uint64_t *lo, uint64_t *hi, uint64_t *ssamp /*nullable*/, void *stream);
 // run-indexed layout (k_runs.hip)
 int launch_find_range_runs(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
-                           uint64_t *lo, uint64_t *hi, uint64_t *ssamp /*nullable*/, void *stream);
+                           uint64_t *lo, uint64_t *hi, uint64_t *ssamp /*nullable*/, void *stream,
+                           unsigned long long *stats = nullptr /*kStatSearchN: the instrumented instantiation*/);
+int launch_find_range_runs_sel(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N, uint64_t *lo,
+                               uint64_t *hi, uint64_t *ssamp /*nullable*/, const uint32_t *sel, const uint32_t *nsel, void *stream);
+int launch_find_range_runs_packed(const DevIndex &ix, const LaunchCfg &cfg, const uint2 *meta, const uint4 *chunks, uint64_t N,
+                                  uint64_t *lo, uint64_t *hi, uint64_t *ssamp /*nullable*/, void *stream);
 int launch_locate_fill_runs(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t *lo, const uint64_t *hi, const uint64_t *k,
                             uint64_t N, uint64_t max_hits, const uint64_t *loc_off, uint64_t *locs, const uint64_t *sub,
-                            const void *order, const uint64_t *skeys, void *stream);
+                            const void *order, const uint64_t *skeys, void *stream, unsigned long long *stats = nullptr /*kStatRunLocateN*/,
+                            uint32_t *locs32 = nullptr);
+// the kernels beside the rb_align path on the run-indexed layout (k_runs_seeds.hip): wave-cooperative ranks, k-mer steps
+int launch_lf_runs(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t *lo, const uint64_t *hi, const uint8_t *sym, uint64_t N,
+                   uint64_t *lo_out, uint64_t *hi_out, void *stream);
+int launch_find_range_markers_runs(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
+                                   uint64_t wsize, uint64_t max_range, uint64_t *lo, uint64_t *hi, uint64_t *cnt, const uint64_t *mk_off,
+                                   uint64_t *mk, bool fill, void *stream);
+int launch_greedy_seed_runs(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
+                            uint64_t min_length, uint64_t *lo, uint64_t *hi, uint64_t *qs, uint64_t *qe, uint64_t *ss, void *stream);
+int launch_marker_seeds_runs(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N, uint64_t wsize,
+                             uint64_t max_range, uint64_t *seed_cnt, uint64_t *mk_cnt, const uint64_t *seed_off, const uint64_t *mk_off,
+                             uint64_t *seeds, uint64_t *mk, bool fill, void *stream);
 int launch_find_range_stats(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
                             uint64_t *lo, uint64_t *hi, uint64_t *ssamp /*nullable*/, unsigned long long *stats /*kStatSearchN*/,
                             void *stream);
@@ -266,7 +283,8 @@ int launch_locate_fill(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t 
                        const uint64_t *k, uint64_t N, uint64_t max_hits, const uint64_t *loc_off, uint64_t *locs,
                        const uint64_t *sub /*nullable: per-read value subtracted from every location*/,
                        const void *order /*nullable: workspace filled by launch_locate_order*/, void *stream,
-                       unsigned long long *stats = nullptr /*kStatLocateN: launches the instrumented instantiation*/);
+                       unsigned long long *stats = nullptr /*kStatLocateN: launches the instrumented instantiation*/,
+                       uint32_t *locs32 = nullptr /*4-byte positions only: store the locations as uint32_t here instead of `locs`*/);
 size_t locate_order_ws_bytes(uint64_t N);
 int launch_locate_order(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t *k, uint64_t N, void *ws, size_t ws_bytes,
                         void *stream);

@@ -359,6 +359,93 @@ def test_device_resident_api(synth):
     o.close()
 
 
+@pytest.mark.parametrize("layout", [capi.LAYOUT_SLOTS, capi.LAYOUT_RUNS])
+def test_instrumented_kernels_and_32_bit_locations(synth, layout):
+    """rbg_find_range_stats_dev / rbg_locate_fill_stats_dev (the instrumented instantiations bench.py prices the kernels
+    with): same outputs as the plain kernels on both layouts, sums that add up; rbg_locate_fill_dev32: the low 32 bits of
+    rbg_locate_fill_dev's locations (toehold_sa.hpp:37-49 fills 64-bit ones), refused at 8-byte positions; the packed
+    (2-bit) search on the run-indexed layout: the cooperative kernel, same answers."""
+    import torch
+    S = synth
+    rb = _with_layout(layout, 48, lambda: ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0))
+    assert rb.info().rank_layout == layout
+    reads = S.sample_reads(4000, 80, seed=31, sub_rate=0.1, ragged=True) + [b"", b"ACGTN", b"A"]
+    seqs, off = ra.pack_reads(reads)
+    N = len(reads)
+    dev = torch.device("cuda:0")
+    d_seqs = torch.from_numpy(np.concatenate([seqs, np.zeros(16 + (-len(seqs)) % 16, np.uint8)])).to(dev)
+    d_off = torch.from_numpy(off.view(np.int64)).to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    L = ra.lib()
+    lo, hi, k = rb.find_range_w_toehold(seqs, off)
+    d_lo, d_hi, d_k = (torch.full((N,), -3, dtype=torch.int64, device=dev) for _ in range(3))
+    d_stats = torch.zeros(16, dtype=torch.int64, device=dev)
+    for toe in (True, False):
+        d_stats.zero_(); d_lo.fill_(-3); d_hi.fill_(-3)
+        assert L.rbg_find_range_stats_dev(rb.h, d_seqs.data_ptr(), d_off.data_ptr(), N, d_lo.data_ptr(), d_hi.data_ptr(),
+                                          d_k.data_ptr() if toe else None, d_stats.data_ptr(), st) == 0
+        torch.cuda.synchronize()
+        assert (d_lo.cpu().numpy().view(np.uint64) == lo).all() and (d_hi.cpu().numpy().view(np.uint64) == hi).all()
+        assert not toe or (d_k.cpu().numpy().view(np.uint64) == k).all()
+        sv = d_stats.cpu().numpy().tolist()
+        steps, slots, dense, search, ftab, resamp, chunks, symbols = sv[:8]
+        total_syms = int(off[-1])
+        assert 0 < steps <= symbols <= total_syms and slots >= steps - ftab and 0 < chunks <= total_syms // 16 + 2 * N and ftab <= N
+        # every read that matched consumed all of its symbols
+        matched = hi >= lo
+        lens = (off[1:] - off[:-1]).astype(np.int64)
+        assert symbols >= int(lens[matched].sum())
+        assert (resamp > 0) == toe or resamp == 0
+        if layout == capi.LAYOUT_RUNS:
+            assert dense >= 2 * steps - N            # at least two entries per probe (one probe per step when lo and hi + 1 share it)
+    # locations: u64, instrumented u64, u32 -- ordered walk
+    d_loc_off = torch.empty(N + 1, dtype=torch.int64, device=dev)
+    tmp_bytes = L.rbg_locate_plan_tmp_bytes(N)
+    d_tmp = torch.empty(tmp_bytes, dtype=torch.uint8, device=dev)
+    d_lo.copy_(torch.from_numpy(lo.view(np.int64))); d_hi.copy_(torch.from_numpy(hi.view(np.int64))); d_k.copy_(torch.from_numpy(k.view(np.int64)))
+    assert L.rbg_locate_plan_dev(rb.h, d_lo.data_ptr(), d_hi.data_ptr(), N, MAXU, d_loc_off.data_ptr(), d_tmp.data_ptr(), tmp_bytes, st) == 0
+    total = int(d_loc_off[-1].item())
+    ws_bytes = L.rbg_locate_order_ws_bytes(N)
+    d_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    assert L.rbg_locate_order_dev(rb.h, d_k.data_ptr(), N, d_ws.data_ptr(), ws_bytes, st) == 0
+    d_locs, d_locs_s = (torch.full((total + 1,), -1, dtype=torch.int64, device=dev) for _ in range(2))
+    d_locs32 = torch.full((total + 3,), -1, dtype=torch.int32, device=dev)
+    assert L.rbg_locate_fill_dev(rb.h, d_lo.data_ptr(), d_hi.data_ptr(), d_k.data_ptr(), N, MAXU, d_loc_off.data_ptr(), d_locs.data_ptr(), d_ws.data_ptr(), st) == 0
+    d_stats.zero_()
+    assert L.rbg_locate_fill_stats_dev(rb.h, d_lo.data_ptr(), d_hi.data_ptr(), d_k.data_ptr(), N, MAXU, d_loc_off.data_ptr(), d_locs_s.data_ptr(),
+                                       d_ws.data_ptr(), d_stats.data_ptr(), st) == 0
+    for order in (d_ws.data_ptr(), None):
+        d_locs32.fill_(-1)
+        assert L.rbg_locate_fill_dev32(rb.h, d_lo.data_ptr(), d_hi.data_ptr(), d_k.data_ptr(), N, MAXU, d_loc_off.data_ptr(), d_locs32.data_ptr(), order, st) == 0
+        torch.cuda.synchronize()
+        assert bool((d_locs32[:total].to(torch.int64) & 0xFFFFFFFF == d_locs[:total] & 0xFFFFFFFF).all().item())
+        assert d_locs32[total:].tolist() == [-1, -1, -1]           # nothing written past the end
+    assert bool((d_locs_s[:total] == d_locs[:total]).all().item())
+    woff, wlocs = rb.locs_at(lo, hi, k)
+    assert (d_locs[:total].cpu().numpy().view(np.uint64) == wlocs).all()
+    phi_steps, phi_search, chains, nlocs = d_stats.cpu().numpy().tolist()[:4]
+    assert nlocs == total and chains == int((hi >= lo).sum()) and phi_steps == total - chains
+    # the packed search on this layout (on the run-indexed one: the cooperative kernel with a bit-stream cursor)
+    wsb = L.rbg_pack_ws_bytes(N, int(off[-1]))
+    d_pws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    assert L.rbg_pack_reads_dev(rb.h, d_seqs.data_ptr(), d_off.data_ptr(), N, int(off[-1]), d_pws.data_ptr(), wsb, st) == 0
+    d_lo.fill_(-3); d_hi.fill_(-3); d_k.fill_(-3)
+    assert L.rbg_find_range_w_toehold_packed_dev(rb.h, d_pws.data_ptr(), d_seqs.data_ptr(), d_off.data_ptr(), N, int(off[-1]),
+                                                 d_lo.data_ptr(), d_hi.data_ptr(), d_k.data_ptr(), st) == 0
+    torch.cuda.synchronize()
+    assert (d_lo.cpu().numpy().view(np.uint64) == lo).all() and (d_hi.cpu().numpy().view(np.uint64) == hi).all() and (d_k.cpu().numpy().view(np.uint64) == k).all()
+    d_lo.fill_(-3); d_hi.fill_(-3)
+    assert L.rbg_find_range_packed_dev(rb.h, d_pws.data_ptr(), d_seqs.data_ptr(), d_off.data_ptr(), N, int(off[-1]), d_lo.data_ptr(), d_hi.data_ptr(), st) == 0
+    torch.cuda.synchronize()
+    assert (d_lo.cpu().numpy().view(np.uint64) == lo).all() and (d_hi.cpu().numpy().view(np.uint64) == hi).all()
+    rb.close()
+    # 8-byte positions: 32-bit locations are refused
+    with capi.default_option(capi.OPT_POS_BYTES, 8):
+        rb8 = _with_layout(layout, 48, lambda: ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0))
+    assert L.rbg_locate_fill_dev32(rb8.h, d_lo.data_ptr(), d_hi.data_ptr(), d_k.data_ptr(), N, MAXU, d_loc_off.data_ptr(), d_locs32.data_ptr(), None, st) == -4
+    rb8.close()
+
+
 def test_device_pipeline_is_graph_capturable(synth):
     """The *_dev entry points neither allocate nor synchronise: the whole count+locate step is captured
     into one HIP graph and replayed on new reads in the same buffers."""
