@@ -407,9 +407,42 @@ def main():
 
         sstep()
         el_sd = timed(sstep, K)
+        # the same pair with the LOG between its phases (rbg_marker_seeds_plan_log_dev / _fill_log_dev: reads walked once)
+        log_bytes = int(L.rbg_marker_seeds_log_bytes(rb.h, 2 * N, 0))
+        d_log = torch.empty(log_bytes, dtype=torch.uint8, device=dev)
+        ref_srec, ref_smk = d_srec.clone(), d_smk.clone()
+
+        def sstep_log():
+            chk(L.rbg_marker_seeds_plan_log_dev(rb.h, d_seqs2.data_ptr(), d_off2.data_ptr(), 2 * N, WS, MR, 0, d_soff.data_ptr(), d_moff.data_ptr(),
+                                                d_tmp2.data_ptr(), tmp2, d_log.data_ptr(), log_bytes, st), "marker_seeds_plan_log")
+            chk(L.rbg_marker_seeds_fill_log_dev(rb.h, d_seqs2.data_ptr(), d_off2.data_ptr(), 2 * N, WS, MR, 0, d_soff.data_ptr(), d_moff.data_ptr(),
+                                                d_srec.data_ptr(), d_smk.data_ptr(), d_log.data_ptr(), log_bytes, st), "marker_seeds_fill_log")
+
+        d_srec.fill_(-1); d_smk.fill_(-1)
+        sstep_log()
+        same_log = bool((d_srec == ref_srec).all().item()) and bool((d_smk == ref_smk).all().item())
+        el_sl = timed(sstep_log, K)
+        del ref_srec, ref_smk
+        # greedy seeds (rbg_greedy_longest_seed_dev: get_seeds_greedy_w_sample reduced by locate_from_longest_seed, rowbowt.hpp:222-256,
+        # :669-677) on the forward reads, min_length 20; outputs kept for the run-indexed row of space_speed
+        d_g = [torch.empty(N, dtype=torch.int64, device=dev) for _ in range(5)]
+
+        def gstep():
+            chk(L.rbg_greedy_longest_seed_dev(rb.h, d_seqs.data_ptr(), d_off.data_ptr(), N, 20, *(t.data_ptr() for t in d_g), st), "greedy_longest_seed")
+
+        gstep()
+        el_g = timed(gstep, K)
+        slot_other = {"greedy_seed_ms": el_g / K * 1e3, "marker_seeds_ms": el_sd / K * 1e3}
+        ref_g = [t.clone() for t in d_g]
+        ref_seed_counts = (n_seeds, n_smk)
+        mk_block["greedy_seed"] = {"value": N * K / el_g, "unit": "reads/s (this rank)", "ms_per_step": el_g / K * 1e3, "min_length": 20}
         mk_block["marker_seeds"] = {"value": N * K / el_sd, "unit": "reads/s (this rank; each read = both strands)",
                                     "ms_per_step": el_sd / K * 1e3, "wsize": WS, "max_range": MR,
                                     "seed_records": n_seeds, "markers_collected": n_smk,
+                                    "two_walks_ms_per_step": el_sd / K * 1e3,
+                                    "logged": {"value": N * K / el_sl, "ms_per_step": el_sl / K * 1e3, "log_bytes": log_bytes,
+                                               "identical_to_the_two_walk_pair": same_log,
+                                               "workload": "rbg_marker_seeds_plan_log_dev + _fill_log_dev: the count pass logs, the fill pass copies"},
                                     "workload": "rb_markers default mode: get_markers_greedy_seeding on read + reverse complement"}
 
     # ---- what the kernels touched: one pass of the INSTRUMENTED instantiations on the same batch (outside every
@@ -793,6 +826,22 @@ def main():
         rows.append({"layout": "runs", "symbols_per_gather": int(rb.info().kmer_steps), "hbm_bytes": int(rb.info().hbm_bytes), "ms": ms_r,
                      "identical_to_slot_path_on_the_whole_batch": same, "roofline": run_roof, "touched": run_touched,
                      "count_locate_reads_per_s": N / ((ms_r["k_find_range<toehold>"] + ms_r["k_locate_fill"] + ms_plan + ms_order) * 1e-3)})
+        if args.markers:
+            # the kernels beside the rb_align path on this layout (cooperative since round 3: k_runs_seeds.hip), same batch
+            rb.set_markers(*marker_arrays)
+            gstep()
+            same_g = all(bool((a == b).all().item()) for a, b in zip(ref_g, d_g))
+            sstep()
+            same_s = (int(d_soff[-1].item()), int(d_moff[-1].item())) == ref_seed_counts
+            run_other = {}
+            for name, fn in (("greedy_seed_ms", gstep), ("marker_seeds_ms", sstep)):
+                e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                e[0].record(stream); fn(); e[1].record(stream); fn(); e[2].record(stream)
+                torch.cuda.synchronize()
+                run_other[name] = min(e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2]))
+            rows[-1]["other_kernels"] = {"runs_layout": run_other, "slot_layout": slot_other, "greedy_seeds_identical_to_slot_path": same_g,
+                                         "marker_seed_counts_identical_to_slot_path": same_s}
+            same = same and same_g and same_s
         if not same:
             out["space_speed"] = {"rows": rows}
             print(json.dumps(out))

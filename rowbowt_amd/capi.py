@@ -100,6 +100,9 @@ _PROTOS = [
     ("rbg_marker_seeds_fill_dev", C.c_int, [VP, VP, VP, U64, U64, U64, U64, VP, VP, VP, VP, VP]),
     ("rbg_markers_plan_dev", C.c_int, [VP, VP, VP, U64, VP, VP, C.c_size_t, VP]),
     ("rbg_markers_fill_dev", C.c_int, [VP, VP, VP, U64, VP, VP, VP]),
+    ("rbg_marker_seeds_log_bytes", C.c_size_t, [VP, U64, C.c_uint32]),
+    ("rbg_marker_seeds_plan_log_dev", C.c_int, [VP, VP, VP, U64, U64, U64, U64, VP, VP, VP, C.c_size_t, VP, C.c_size_t, VP]),
+    ("rbg_marker_seeds_fill_log_dev", C.c_int, [VP, VP, VP, U64, U64, U64, U64, VP, VP, VP, VP, VP, C.c_size_t, VP]),
     ("rbg_locate_fill_dev32", C.c_int, [VP, VP, VP, VP, U64, U64, VP, VP, VP, VP]),
     ("rbg_find_range_stats_dev", C.c_int, [VP, VP, VP, U64, VP, VP, VP, VP, VP]),
     ("rbg_locate_fill_stats_dev", C.c_int, [VP, VP, VP, VP, U64, U64, VP, VP, VP, VP, VP]),

@@ -296,14 +296,17 @@ __global__ __launch_bounds__(1024) void k_greedy_seed(const DevIndex ix, const u
 // k-mer steps are used where no window query can fall inside them and a fresh seed takes its first
 // ftab_k symbols from the device state table; a k-mer step that comes back empty is narrowed down with
 // two more gathers so the failing base is the reference's.
-template <typename P, bool FILL>
+// LOG (count pass only): also leave the marker-seed log behind (rbg_dev.h SeedLog) so that the fill pass copies instead of
+// walking again; FILL with lg.base set: walk only the sequences the log lists as over quota.
+template <typename P, bool FILL, bool LOG = false>
 __global__ __launch_bounds__(1024) void k_marker_seeds(const DevIndex ix, const uint8_t *__restrict__ seqs,
                                                       const uint64_t *__restrict__ off, const uint64_t N,
                                                       const uint64_t wsize, const uint64_t max_range, const uint64_t ftab_k,
                                                       uint64_t *__restrict__ seed_cnt, uint64_t *__restrict__ mk_cnt,
                                                       const uint64_t *__restrict__ seed_off,
                                                       const uint64_t *__restrict__ mk_off,
-                                                      uint64_t *__restrict__ seeds, uint64_t *__restrict__ mk, const uint32_t max_k) {
+                                                      uint64_t *__restrict__ seeds, uint64_t *__restrict__ mk, const uint32_t max_k,
+                                                      const SeedLog lg) {
     __shared__ uint8_t s_lut[256];
     __shared__ uint8_t s_lut2[256];
     extern __shared__ __align__(16) unsigned char s_dyn[];
@@ -314,7 +317,10 @@ __global__ __launch_bounds__(1024) void k_marker_seeds(const DevIndex ix, const 
     if (!FILL && blockIdx.x == 0 && threadIdx.x == 0) { seed_cnt[0] = 0; mk_cnt[0] = 0; }
     const bool have_ma = ix.mk_nruns != 0;
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
-    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < N; i += stride) {
+    const bool listed = FILL && lg.base != nullptr;       // fill pass after a logged count pass: only the sequences over quota
+    const uint64_t Neff = listed ? static_cast<uint64_t>(lg.nsel[0]) : N;
+    for (uint64_t j_ = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j_ < Neff; j_ += stride) {
+        const uint64_t i = listed ? static_cast<uint64_t>(lg.nsel[4 + j_]) : j_;
         const uint64_t beg = off[i], m = off[i + 1] - beg;
         const uint64_t fhi = ix.n - 1;
         uint64_t lo = 0, hi = fhi, plo = 0, phi = fhi;    // range, prev_range (:427-428)
@@ -322,6 +328,12 @@ __global__ __launch_bounds__(1024) void k_marker_seeds(const DevIndex ix, const 
         uint64_t ns = 0, tot = 0, mb_begin = 0;           // mbuf == markers [mb_begin, tot) of this read
         uint64_t *srec = FILL ? seeds + 6 * seed_off[i] : nullptr;
         const uint64_t mbase = FILL ? mk_off[i] : 0;
+        // the log of this sequence (LOG): {ns, nw} | records | window entries
+        unsigned char *lbase = LOG ? lg.base + i * lg.stride : nullptr;
+        SeedLogRec<P> *lrec = reinterpret_cast<SeedLogRec<P> *>(lbase + 8);
+        SeedLogWin *lwin = reinterpret_cast<SeedLogWin *>(lbase + 8 + static_cast<size_t>(lg.qs) * sizeof(SeedLogRec<P>));
+        uint32_t nw = 0;
+        bool lover = LOG && (m >> 32) != 0;               // (positions in the read are logged as 32 bits)
         auto update_mbuf = [&](uint64_t l, uint64_t h) {  // :437-441
             if (!have_ma || h - l + 1 > max_range) return;
             uint64_t f, e;
@@ -332,6 +344,11 @@ __global__ __launch_bounds__(1024) void k_marker_seeds(const DevIndex ix, const 
                 uint64_t *d = mk + mbase + tot;
                 for (uint64_t t = 0; t < cnt; ++t) d[t] = ix.mk_vals[src + t];
             }
+            if (LOG) {
+                if (nw < lg.qw && ((src + cnt) >> 32) == 0) lwin[nw] = SeedLogWin{static_cast<uint32_t>(src), static_cast<uint32_t>(cnt)};
+                else lover = true;
+                ++nw;
+            }
             tot += cnt;
         };
         auto emit = [&](uint64_t l, uint64_t h, uint64_t qs, uint64_t qe) {  // fn(range, (qs, qe-1), mbuf)
@@ -339,7 +356,24 @@ __global__ __launch_bounds__(1024) void k_marker_seeds(const DevIndex ix, const 
                 uint64_t *d = srec + 6 * ns;
                 d[0] = l; d[1] = h; d[2] = qs; d[3] = qe; d[4] = mbase + mb_begin; d[5] = mbase + tot;
             }
+            if (LOG) {
+                if (ns < lg.qs && (tot >> 32) == 0)
+                    lrec[ns] = SeedLogRec<P>{static_cast<P>(l), static_cast<P>(h), static_cast<uint32_t>(qs), static_cast<uint32_t>(qe),
+                                             static_cast<uint32_t>(mb_begin), static_cast<uint32_t>(tot)};
+                else lover = true;
+            }
             ++ns;
+        };
+        auto finish = [&]() {
+            if (!FILL) {
+                seed_cnt[i + 1] = ns;
+                mk_cnt[i + 1] = tot;
+            }
+            if (LOG) {
+                uint32_t *hdr = reinterpret_cast<uint32_t *>(lbase);
+                hdr[0] = lover ? kSeedLogOverflow : static_cast<uint32_t>(ns);
+                hdr[1] = nw;
+            }
         };
         ByteCursor rd{reinterpret_cast<const uint4 *>(seqs), ~uint64_t(0), make_uint4(0, 0, 0, 0)};
         // one reference LF step on (lo,hi) with symbol c; false = empty range, (lo,hi) untouched
@@ -450,10 +484,7 @@ __global__ __launch_bounds__(1024) void k_marker_seeds(const DevIndex ix, const 
             }
             if (hi >= lo && seed_ei - (m - i2) >= wsize) update_mbuf(lo, hi);   // :478-480
             emit(lo, hi, m - i2, seed_ei);                                      // :481
-            if (!FILL) {
-                seed_cnt[i + 1] = ns;
-                mk_cnt[i + 1] = tot;
-            }
+            finish();
             continue;
         }
         uint64_t j = m;  // m - i of the reference; the next symbol consumed is q[j-1]
@@ -521,9 +552,41 @@ __global__ __launch_bounds__(1024) void k_marker_seeds(const DevIndex ix, const 
         }
         if (hi >= lo && seed_ei >= wsize) update_mbuf(lo, hi);   // :478-480 (m-i == 0)
         emit(lo, hi, 0, seed_ei);                                // :481
-        if (!FILL) {
-            seed_cnt[i + 1] = ns;
-            mk_cnt[i + 1] = tot;
+        finish();
+    }
+}
+
+// The fill pass from the log: eight lanes per sequence copy its seed records (48 bytes each) and the markers of its
+// window queries into place; a sequence over quota is appended to the list behind lg.nsel for the walking kernel.
+template <typename P>
+__global__ __launch_bounds__(256) void k_marker_seeds_from_log(const DevIndex ix, const uint64_t N, const uint64_t *__restrict__ seed_off,
+                                                               const uint64_t *__restrict__ mk_off, uint64_t *__restrict__ seeds,
+                                                               uint64_t *__restrict__ mk, const SeedLog lg) {
+    constexpr uint32_t G = 8;
+    const uint64_t stride = (static_cast<uint64_t>(gridDim.x) * blockDim.x) / G;
+    const uint32_t sub = threadIdx.x & (G - 1);
+    for (uint64_t i = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) / G; i < N; i += stride) {
+        const unsigned char *lbase = lg.base + i * lg.stride;
+        const uint2 hdr = *reinterpret_cast<const uint2 *>(lbase);
+        if (hdr.x == kSeedLogOverflow) {
+            if (sub == 0) lg.nsel[4 + atomicAdd(lg.nsel, 1u)] = static_cast<uint32_t>(i);
+            continue;
+        }
+        const SeedLogRec<P> *lrec = reinterpret_cast<const SeedLogRec<P> *>(lbase + 8);
+        const SeedLogWin *lwin = reinterpret_cast<const SeedLogWin *>(lbase + 8 + static_cast<size_t>(lg.qs) * sizeof(SeedLogRec<P>));
+        const uint64_t mbase = mk_off[i];
+        ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(seeds + 6 * seed_off[i]);
+        for (uint32_t t = sub; t < hdr.x; t += G) {
+            const SeedLogRec<P> r = lrec[t];
+            dst[3 * t + 0] = make_ulonglong2(static_cast<uint64_t>(r.lo), static_cast<uint64_t>(r.hi));
+            dst[3 * t + 1] = make_ulonglong2(r.qs, r.qe);
+            dst[3 * t + 2] = make_ulonglong2(mbase + r.mb, mbase + r.me);
+        }
+        uint64_t at = mbase;
+        for (uint32_t w = 0; w < hdr.y; ++w) {
+            const SeedLogWin q = lwin[w];
+            for (uint32_t t = sub; t < q.cnt; t += G) mk[at + t] = ix.mk_vals[q.src + t];
+            at += q.cnt;
         }
     }
 }
@@ -613,25 +676,25 @@ int launch_find_range_markers_fill(const DevIndex &ix, const LaunchCfg &cfg, con
 
 int launch_marker_seeds_plan(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
                              uint64_t wsize, uint64_t max_range, uint64_t ftab_k, uint64_t *seed_off, uint64_t *mk_off, void *tmp,
-                             size_t tmp_bytes, void *stream) {
+                             size_t tmp_bytes, void *stream, void *log, size_t log_bytes) {
     hipStream_t st = static_cast<hipStream_t>(stream);
+    const SeedLog lg = make_seed_log(log, log_bytes, N, ix.pos_bytes);   // base == nullptr: no log (two walks)
+    int rc;
     if (ix.layout == 2 && ftab_k == 0) {   // run-indexed layout, the tool's default mode: the cooperative kernel (k_runs_seeds.hip)
-        int rc2 = launch_marker_seeds_runs(ix, cfg, seqs, off, N, wsize, max_range, seed_off, mk_off, nullptr, nullptr, nullptr, nullptr, false, stream);
-        if (rc2) return rc2;
-        rc2 = scan_in_place(seed_off + 1, N, tmp, tmp_bytes, st);
-        if (rc2) return rc2;
-        return scan_in_place(mk_off + 1, N, tmp, tmp_bytes, st);
-    }
-    if (ix.pos_bytes == 4) {
-        auto kern = k_marker_seeds<uint32_t, false>;
-        const KmerLaunch L = kmer_launch(ix, cfg, N, kern, 0, kSeedKmerLevel);
-        hipLaunchKernelGGL(kern, L.grid, L.block, L.lds, st, ix, seqs, off, N, wsize, max_range, ftab_k, seed_off, mk_off, nullptr, nullptr, nullptr, nullptr, kSeedKmerLevel);
+        rc = launch_marker_seeds_runs(ix, cfg, seqs, off, N, wsize, max_range, seed_off, mk_off, nullptr, nullptr, nullptr, nullptr, false, stream, lg);
     } else {
-        auto kern = k_marker_seeds<uint64_t, false>;
-        const KmerLaunch L = kmer_launch(ix, cfg, N, kern, 0, kSeedKmerLevel);
-        hipLaunchKernelGGL(kern, L.grid, L.block, L.lds, st, ix, seqs, off, N, wsize, max_range, ftab_k, seed_off, mk_off, nullptr, nullptr, nullptr, nullptr, kSeedKmerLevel);
+#define RBG_MSP(PT, LG)                                                                                                                   \
+    do {                                                                                                                                  \
+        auto kern = k_marker_seeds<PT, false, LG>;                                                                                        \
+        const KmerLaunch L = kmer_launch(ix, cfg, N, kern, 0, kSeedKmerLevel);                                                            \
+        hipLaunchKernelGGL(kern, L.grid, L.block, L.lds, st, ix, seqs, off, N, wsize, max_range, ftab_k, seed_off, mk_off, nullptr, nullptr, nullptr, \
+                           nullptr, kSeedKmerLevel, lg);                                                                                  \
+    } while (0)
+        if (ix.pos_bytes == 4) { if (lg.base) RBG_MSP(uint32_t, true); else RBG_MSP(uint32_t, false); }
+        else { if (lg.base) RBG_MSP(uint64_t, true); else RBG_MSP(uint64_t, false); }
+#undef RBG_MSP
+        rc = static_cast<int>(hipGetLastError());
     }
-    int rc = static_cast<int>(hipGetLastError());
     if (rc) return rc;
     rc = scan_in_place(seed_off + 1, N, tmp, tmp_bytes, st);
     if (rc) return rc;
@@ -640,20 +703,33 @@ int launch_marker_seeds_plan(const DevIndex &ix, const LaunchCfg &cfg, const uin
 
 int launch_marker_seeds_fill(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
                              uint64_t wsize, uint64_t max_range, uint64_t ftab_k, const uint64_t *seed_off, const uint64_t *mk_off,
-                             uint64_t *seeds, uint64_t *mk, void *stream) {
+                             uint64_t *seeds, uint64_t *mk, void *stream, void *log, size_t log_bytes) {
     if (N == 0) return 0;
-    if (ix.layout == 2 && ftab_k == 0)
-        return launch_marker_seeds_runs(ix, cfg, seqs, off, N, wsize, max_range, nullptr, nullptr, seed_off, mk_off, seeds, mk, true, stream);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (ix.pos_bytes == 4) {
-        auto kern = k_marker_seeds<uint32_t, true>;
-        const KmerLaunch L = kmer_launch(ix, cfg, N, kern, 0, kSeedKmerLevel);
-        hipLaunchKernelGGL(kern, L.grid, L.block, L.lds, st, ix, seqs, off, N, wsize, max_range, ftab_k, nullptr, nullptr, seed_off, mk_off, seeds, mk, kSeedKmerLevel);
-    } else {
-        auto kern = k_marker_seeds<uint64_t, true>;
-        const KmerLaunch L = kmer_launch(ix, cfg, N, kern, 0, kSeedKmerLevel);
-        hipLaunchKernelGGL(kern, L.grid, L.block, L.lds, st, ix, seqs, off, N, wsize, max_range, ftab_k, nullptr, nullptr, seed_off, mk_off, seeds, mk, kSeedKmerLevel);
+    SeedLog lg = make_seed_log(log, log_bytes, N, ix.pos_bytes);
+    if (reinterpret_cast<uintptr_t>(seeds) & 15) lg.base = nullptr;   // (the copy stores records as 16-byte pieces)
+    if (lg.base) {
+        // copy what the count pass logged; the sequences over quota end up listed behind lg.nsel and are walked below
+        int rc = static_cast<int>(hipMemsetAsync(lg.nsel, 0, 16, st));
+        if (rc) return rc;
+        const uint64_t threads = N * 8;
+        const int grid = static_cast<int>(std::min<uint64_t>((threads + 255) / 256, 256ull * 64));
+        if (ix.pos_bytes == 4) hipLaunchKernelGGL((k_marker_seeds_from_log<uint32_t>), dim3(grid), dim3(256), 0, st, ix, N, seed_off, mk_off, seeds, mk, lg);
+        else hipLaunchKernelGGL((k_marker_seeds_from_log<uint64_t>), dim3(grid), dim3(256), 0, st, ix, N, seed_off, mk_off, seeds, mk, lg);
+        rc = static_cast<int>(hipGetLastError());
+        if (rc) return rc;
     }
+    if (ix.layout == 2 && ftab_k == 0)
+        return launch_marker_seeds_runs(ix, cfg, seqs, off, N, wsize, max_range, nullptr, nullptr, seed_off, mk_off, seeds, mk, true, stream, lg);
+#define RBG_MSF(PT)                                                                                                                       \
+    do {                                                                                                                                  \
+        auto kern = k_marker_seeds<PT, true, false>;                                                                                      \
+        const KmerLaunch L = kmer_launch(ix, cfg, N, kern, lg.base ? 256 : 0, kSeedKmerLevel);                                            \
+        hipLaunchKernelGGL(kern, L.grid, L.block, L.lds, st, ix, seqs, off, N, wsize, max_range, ftab_k, nullptr, nullptr, seed_off, mk_off, seeds, mk, \
+                           kSeedKmerLevel, lg);                                                                                           \
+    } while (0)
+    if (ix.pos_bytes == 4) RBG_MSF(uint32_t); else RBG_MSF(uint64_t);
+#undef RBG_MSF
     return static_cast<int>(hipGetLastError());
 }
 

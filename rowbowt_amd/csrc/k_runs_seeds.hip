@@ -294,20 +294,23 @@ __global__ __launch_bounds__(512, sizeof(P) == 4 ? 4 : 3) void k_greedy_seed_run
 // path, rb_markers.cpp:411-413) -- k_markers.hip k_marker_seeds<P, FILL>'s default mode; the --ftab mode of the tool stays
 // with that kernel (lane by lane).  One record per call of the reference's callback: {range lo, range hi, q.first,
 // seed_ei, first marker, one past last marker}.
-template <typename P, bool FILL>
+// LOG / lg: the marker-seed log (rbg_dev.h SeedLog), as in k_markers.hip k_marker_seeds
+template <typename P, bool FILL, bool LOG = false>
 __global__ __launch_bounds__(512, sizeof(P) == 4 ? 4 : 3) void k_marker_seeds_runs(const DevIndex ix, const uint8_t *__restrict__ seqs,
                                                       const uint64_t *__restrict__ off, const uint64_t N,
                                                       const uint64_t wsize, const uint64_t max_range,
                                                       uint64_t *__restrict__ seed_cnt, uint64_t *__restrict__ mk_cnt,
                                                       const uint64_t *__restrict__ seed_off, const uint64_t *__restrict__ mk_off,
-                                                      uint64_t *__restrict__ seeds, uint64_t *__restrict__ mk) {
+                                                      uint64_t *__restrict__ seeds, uint64_t *__restrict__ mk, const SeedLog lg) {
     RBG_SEED_KERNEL_PROLOGUE(P, 8);
     if (!FILL && blockIdx.x == 0 && threadIdx.x == 0) { seed_cnt[0] = 0; mk_cnt[0] = 0; }
     const bool have_ma = ix.mk_nruns != 0;
     const uint64_t fhi = ix.n - 1;
-    for (uint64_t base = wave_first; base < N; base += stride) {
-        const uint64_t i = base + lane;
-        const bool valid = i < N;
+    const bool listed = FILL && lg.base != nullptr;       // fill pass after a logged count pass: only the sequences over quota
+    const uint64_t Neff = listed ? static_cast<uint64_t>(lg.nsel[0]) : N;
+    for (uint64_t base = wave_first; base < Neff; base += stride) {
+        const bool valid = base + lane < Neff;
+        const uint64_t i = (listed && valid) ? static_cast<uint64_t>(lg.nsel[4 + base + lane]) : base + lane;
         uint64_t beg = 0, m = 0;
         if (valid) { beg = off[i]; m = off[i + 1] - beg; }
         uint64_t lo = 0, hi = fhi, plo = 0, phi = fhi;    // range, prev_range (:427-428)
@@ -319,6 +322,11 @@ __global__ __launch_bounds__(512, sizeof(P) == 4 ? 4 : 3) void k_marker_seeds_ru
         uint32_t nlen = 0;
         uint64_t unused_k = 0;
         ByteCursor rd{reinterpret_cast<const uint4 *>(seqs), ~uint64_t(0), make_uint4(0, 0, 0, 0)};
+        unsigned char *lbase = (LOG && valid) ? lg.base + i * lg.stride : nullptr;
+        SeedLogRec<P> *lrec = reinterpret_cast<SeedLogRec<P> *>(lbase + 8);
+        SeedLogWin *lwin = reinterpret_cast<SeedLogWin *>(lbase + 8 + static_cast<size_t>(lg.qs) * sizeof(SeedLogRec<P>));
+        uint32_t nw = 0;
+        bool lover = LOG && (m >> 32) != 0;
         auto update_mbuf = [&](uint64_t l, uint64_t h) {  // :437-441
             if (!have_ma || h - l + 1 > max_range) return;
             uint64_t f, e;
@@ -329,12 +337,23 @@ __global__ __launch_bounds__(512, sizeof(P) == 4 ? 4 : 3) void k_marker_seeds_ru
                 uint64_t *d = mk + mbase + tot;
                 for (uint64_t t = 0; t < cnt; ++t) d[t] = ix.mk_vals[src + t];
             }
+            if (LOG) {
+                if (nw < lg.qw && ((src + cnt) >> 32) == 0) lwin[nw] = SeedLogWin{static_cast<uint32_t>(src), static_cast<uint32_t>(cnt)};
+                else lover = true;
+                ++nw;
+            }
             tot += cnt;
         };
         auto emit = [&](uint64_t l, uint64_t h, uint64_t qs, uint64_t qe) {  // fn(range, (qs, qe-1), mbuf)
             if (FILL) {
                 uint64_t *d = srec + 6 * ns;
                 d[0] = l; d[1] = h; d[2] = qs; d[3] = qe; d[4] = mbase + mb_begin; d[5] = mbase + tot;
+            }
+            if (LOG) {
+                if (ns < lg.qs && (tot >> 32) == 0)
+                    lrec[ns] = SeedLogRec<P>{static_cast<P>(l), static_cast<P>(h), static_cast<uint32_t>(qs), static_cast<uint32_t>(qe),
+                                             static_cast<uint32_t>(mb_begin), static_cast<uint32_t>(tot)};
+                else lover = true;
             }
             ++ns;
         };
@@ -399,6 +418,11 @@ __global__ __launch_bounds__(512, sizeof(P) == 4 ? 4 : 3) void k_marker_seeds_ru
                 seed_cnt[i + 1] = ns;
                 mk_cnt[i + 1] = tot;
             }
+            if (LOG) {
+                uint32_t *hdr = reinterpret_cast<uint32_t *>(lbase);
+                hdr[0] = lover ? kSeedLogOverflow : static_cast<uint32_t>(ns);
+                hdr[1] = nw;
+            }
         }
     }
 }
@@ -460,16 +484,18 @@ int launch_greedy_seed_runs(const DevIndex &ix, const LaunchCfg &cfg, const uint
 
 int launch_marker_seeds_runs(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N, uint64_t wsize,
                              uint64_t max_range, uint64_t *seed_cnt, uint64_t *mk_cnt, const uint64_t *seed_off, const uint64_t *mk_off,
-                             uint64_t *seeds, uint64_t *mk, bool fill, void *stream) {
+                             uint64_t *seeds, uint64_t *mk, bool fill, void *stream, const SeedLog &lg) {
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const SeedLaunch L = seed_launch(ix, cfg, N);
-    if (ix.pos_bytes == 4) {
-        if (fill) RBG_LAUNCH_SEEDK((k_marker_seeds_runs<uint32_t, true>), seqs, off, N, wsize, max_range, seed_cnt, mk_cnt, seed_off, mk_off, seeds, mk);
-        else RBG_LAUNCH_SEEDK((k_marker_seeds_runs<uint32_t, false>), seqs, off, N, wsize, max_range, seed_cnt, mk_cnt, seed_off, mk_off, seeds, mk);
-    } else {
-        if (fill) RBG_LAUNCH_SEEDK((k_marker_seeds_runs<uint64_t, true>), seqs, off, N, wsize, max_range, seed_cnt, mk_cnt, seed_off, mk_off, seeds, mk);
-        else RBG_LAUNCH_SEEDK((k_marker_seeds_runs<uint64_t, false>), seqs, off, N, wsize, max_range, seed_cnt, mk_cnt, seed_off, mk_off, seeds, mk);
-    }
+    SeedLaunch L = seed_launch(ix, cfg, N);
+    if (fill && lg.base) L.grid = dim3(std::min<unsigned>(L.grid.x, 128u));   // the listed sequences only: their number is on the device
+#define RBG_MSR(PT)                                                                                                                          \
+    do {                                                                                                                                     \
+        if (fill) RBG_LAUNCH_SEEDK((k_marker_seeds_runs<PT, true, false>), seqs, off, N, wsize, max_range, seed_cnt, mk_cnt, seed_off, mk_off, seeds, mk, lg); \
+        else if (lg.base) RBG_LAUNCH_SEEDK((k_marker_seeds_runs<PT, false, true>), seqs, off, N, wsize, max_range, seed_cnt, mk_cnt, seed_off, mk_off, seeds, mk, lg); \
+        else RBG_LAUNCH_SEEDK((k_marker_seeds_runs<PT, false, false>), seqs, off, N, wsize, max_range, seed_cnt, mk_cnt, seed_off, mk_off, seeds, mk, lg); \
+    } while (0)
+    if (ix.pos_bytes == 4) RBG_MSR(uint32_t); else RBG_MSR(uint64_t);
+#undef RBG_MSR
     return static_cast<int>(hipGetLastError());
 }
 #undef RBG_LAUNCH_SEEDK

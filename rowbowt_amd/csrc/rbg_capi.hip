@@ -2532,6 +2532,43 @@ int rbg_marker_seeds_fill_dev(rbg_index *ix, const uint8_t *d_seqs, const uint64
     });
 }
 
+// The same two phases with a LOG between them (rbg_dev.h SeedLog): the plan leaves every sequence's seed records and the
+// places of its markers in d_log, the fill copies from there and walks only the sequences that exceeded their quota.
+size_t rbg_marker_seeds_log_bytes(const rbg_index *ix, uint64_t N, uint32_t seeds_per_read) {
+    if (!ix) return 0;
+    if (seeds_per_read == 0) seeds_per_read = kSeedLogSeedsDefault;
+    if (seeds_per_read < 2) seeds_per_read = 2;
+    if (seeds_per_read > 255) seeds_per_read = 255;
+    return seed_log_bytes(N, ix->H().pos_bytes, seeds_per_read);
+}
+
+int rbg_marker_seeds_plan_log_dev(rbg_index *ix, const uint8_t *d_seqs, const uint64_t *d_off, uint64_t N, uint64_t wsize,
+                                  uint64_t max_range, uint64_t ftab_k, uint64_t *d_seed_off, uint64_t *d_mk_off, void *d_tmp, size_t tmp_bytes,
+                                  void *d_log, size_t log_bytes, void *stream) {
+    return guarded([&]() -> int {
+    if (!queryable(ix)) return RBG_ENODEV;
+    if (!d_seed_off || !d_mk_off || (N && (!d_seqs || !d_off))) return RBG_EARG;
+    if (reinterpret_cast<uintptr_t>(d_seqs) & 15) return RBG_EARG;
+    if (tmp_bytes < scan_tmp_bytes(N) || (N && !d_tmp)) return RBG_EARG;
+    if (N && !make_seed_log(d_log, log_bytes, N, ix->H().pos_bytes).base) return RBG_EARG;   // unaligned, or no room for two seeds per sequence
+    return launch_marker_seeds_plan(ix->dev, ix->cfg, d_seqs, d_off, N, wsize, max_range, ftab_k, d_seed_off, d_mk_off, d_tmp, tmp_bytes,
+                                    stream, d_log, log_bytes) ? RBG_ENODEV : RBG_OK;
+    });
+}
+
+int rbg_marker_seeds_fill_log_dev(rbg_index *ix, const uint8_t *d_seqs, const uint64_t *d_off, uint64_t N, uint64_t wsize,
+                                  uint64_t max_range, uint64_t ftab_k, const uint64_t *d_seed_off, const uint64_t *d_mk_off,
+                                  rbg_marker_seed_t *d_seeds, uint64_t *d_mk, void *d_log, size_t log_bytes, void *stream) {
+    return guarded([&]() -> int {
+    if (!queryable(ix)) return RBG_ENODEV;
+    if (N && (!d_seqs || !d_off || !d_seed_off || !d_mk_off || !d_seeds)) return RBG_EARG;
+    if (reinterpret_cast<uintptr_t>(d_seqs) & 15 || reinterpret_cast<uintptr_t>(d_seeds) & 15) return RBG_EARG;
+    if (N && !make_seed_log(d_log, log_bytes, N, ix->H().pos_bytes).base) return RBG_EARG;
+    return launch_marker_seeds_fill(ix->dev, ix->cfg, d_seqs, d_off, N, wsize, max_range, ftab_k, d_seed_off, d_mk_off,
+                                    reinterpret_cast<uint64_t *>(d_seeds), d_mk, stream, d_log, log_bytes) ? RBG_ENODEV : RBG_OK;
+    });
+}
+
 static int marker_seeds_host(rbg_index *ix, const uint8_t *seqs, const uint64_t *off, uint64_t N, uint64_t wsize, uint64_t max_range,
                              uint64_t ftab_k, uint64_t *seed_off, rbg_marker_seed_t **seeds, uint64_t **mk);
 
@@ -2624,11 +2661,14 @@ static int marker_seeds_host(rbg_index *ix, const uint8_t *seqs, const uint64_t 
     hipStream_t st = hipStreamPerThread;
     ReadBatch rb;
     if ((rc = rb.stage(seqs, off, N, st))) return rc;
-    DevBuf dsoff, dmoff, dtmp, dseeds, dmk;
+    DevBuf dsoff, dmoff, dtmp, dseeds, dmk, dlog;
     const size_t tmp_bytes = scan_tmp_bytes(N);
     if ((rc = dsoff.alloc((N + 1) * 8)) || (rc = dmoff.alloc((N + 1) * 8)) || (rc = dtmp.alloc(tmp_bytes))) return rc;
+    // the log between the two phases (one walk instead of two); without the memory for it the fill pass walks again
+    size_t log_bytes = seed_log_bytes(N, ix->H().pos_bytes, kSeedLogSeedsDefault);
+    if (dlog.alloc(log_bytes)) log_bytes = 0;
     if (launch_marker_seeds_plan(ix->dev, ix->cfg, rb.seqs.as<uint8_t>(), rb.off.as<uint64_t>(), N, wsize, max_range, ftab_k,
-                                 dsoff.as<uint64_t>(), dmoff.as<uint64_t>(), dtmp.p, tmp_bytes, st))
+                                 dsoff.as<uint64_t>(), dmoff.as<uint64_t>(), dtmp.p, tmp_bytes, st, log_bytes ? dlog.p : nullptr, log_bytes))
         return RBG_ENODEV;
     uint64_t total_mk = 0;
     HIP_TRY(hipMemcpyAsync(seed_off, dsoff.p, (N + 1) * 8, hipMemcpyDeviceToHost, st));
@@ -2642,7 +2682,8 @@ static int marker_seeds_host(rbg_index *ix, const uint8_t *seqs, const uint64_t 
     if (total_seeds) {
         if (!(rc = dseeds.alloc(total_seeds * sizeof(rbg_marker_seed_t))) && !(rc = dmk.alloc(total_mk ? total_mk * 8 : 8))) {
             if (launch_marker_seeds_fill(ix->dev, ix->cfg, rb.seqs.as<uint8_t>(), rb.off.as<uint64_t>(), N, wsize, max_range, ftab_k,
-                                         dsoff.as<uint64_t>(), dmoff.as<uint64_t>(), dseeds.as<uint64_t>(), dmk.as<uint64_t>(), st))
+                                         dsoff.as<uint64_t>(), dmoff.as<uint64_t>(), dseeds.as<uint64_t>(), dmk.as<uint64_t>(), st,
+                                         log_bytes ? dlog.p : nullptr, log_bytes))
                 rc = RBG_ENODEV;
             if (!rc) rc = d2h_result(h_seeds, dseeds.p, total_seeds * sizeof(rbg_marker_seed_t), st);
             if (!rc && total_mk) rc = d2h_result(h_mk, dmk.p, total_mk * 8, st);

@@ -242,6 +242,51 @@ enum LocateStat {
     kStatLocateN
 };
 
+// ---- marker-seed log (one walk instead of two) ------------------------------------------------------------------------
+// get_markers_greedy_seeding's output is ragged twice over (records per read, markers per record), so it takes a count
+// pass, two scans and a fill pass -- and round 2's fill pass walked every read again (24 of 43 ms per 10 M reads on both
+// strands).  With a log the count pass leaves behind, per sequence, what the fill pass needs: its seed records
+// {lo, hi, qs, qe, marker sub-range} and, for every window query that found markers, where they sit in mk_vals.  The fill
+// pass then only copies.  Fixed quota per sequence (the caller's scratch decides it); a sequence that needs more is
+// flagged and listed, and only those are walked again.
+template <typename P>
+struct SeedLogRec {
+    P lo, hi;
+    uint32_t qs, qe, mb, me;   // q.first, seed_ei; markers [mb, me) of this read's markers
+};
+struct SeedLogWin {
+    uint32_t src, cnt;         // mk_vals[src, src + cnt)
+};
+struct SeedLog {
+    unsigned char *base;       // nullptr: no log.  Sequence i: base + i * stride = {u32 ns, u32 nw, SeedLogRec[qs], SeedLogWin[qw]}
+    uint64_t stride;
+    uint32_t qs, qw;
+    uint32_t *nsel;            // nsel[0] = # sequences over quota, their indices from nsel + 4 on
+};
+constexpr uint32_t kSeedLogOverflow = 0xFFFFFFFFu;
+constexpr uint32_t kSeedLogWindows = 6, kSeedLogSeedsDefault = 12;
+inline size_t seed_log_rec_bytes(uint32_t pos_bytes) { return pos_bytes == 4 ? sizeof(SeedLogRec<uint32_t>) : sizeof(SeedLogRec<uint64_t>); }
+inline size_t seed_log_stride(uint32_t pos_bytes, uint32_t seeds_per_read) {
+    return 8 + static_cast<size_t>(seeds_per_read) * seed_log_rec_bytes(pos_bytes) + kSeedLogWindows * sizeof(SeedLogWin);
+}
+inline size_t seed_log_bytes(uint64_t N, uint32_t pos_bytes, uint32_t seeds_per_read) {
+    return static_cast<size_t>(N) * seed_log_stride(pos_bytes, seeds_per_read) + 64 + (N + 4) * 4;
+}
+// the log a scratch area of `bytes` can hold for N sequences (base == nullptr: too small for two seeds each)
+inline SeedLog make_seed_log(void *scratch, size_t bytes, uint64_t N, uint32_t pos_bytes) {
+    SeedLog lg{nullptr, 0, 0, kSeedLogWindows, nullptr};
+    if (!scratch || N == 0 || (reinterpret_cast<uintptr_t>(scratch) & 15)) return lg;
+    const size_t tail = 64 + (N + 4) * 4, fixed = 8 + kSeedLogWindows * sizeof(SeedLogWin), rec = seed_log_rec_bytes(pos_bytes);
+    if (bytes < tail + N * (fixed + 2 * rec)) return lg;
+    size_t q = ((bytes - tail) / N - fixed) / rec;
+    if (q > 255) q = 255;
+    lg.qs = static_cast<uint32_t>(q);
+    lg.stride = fixed + q * rec;
+    lg.base = static_cast<unsigned char *>(scratch);
+    lg.nsel = reinterpret_cast<uint32_t *>(lg.base + ((N * lg.stride + 15) & ~size_t(15)));
+    return lg;
+}
+
 struct LaunchCfg {
     int block_threads = 256;
     int max_blocks = 0;  // 0: derive from the device
@@ -270,9 +315,10 @@ int launch_find_range_markers_runs(const DevIndex &ix, const LaunchCfg &cfg, con
                                    uint64_t *mk, bool fill, void *stream);
 int launch_greedy_seed_runs(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
                             uint64_t min_length, uint64_t *lo, uint64_t *hi, uint64_t *qs, uint64_t *qe, uint64_t *ss, void *stream);
+// lg.base != nullptr: the count pass (fill == false) writes the log; the fill pass walks only the sequences listed behind lg.nsel
 int launch_marker_seeds_runs(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N, uint64_t wsize,
                              uint64_t max_range, uint64_t *seed_cnt, uint64_t *mk_cnt, const uint64_t *seed_off, const uint64_t *mk_off,
-                             uint64_t *seeds, uint64_t *mk, bool fill, void *stream);
+                             uint64_t *seeds, uint64_t *mk, bool fill, void *stream, const SeedLog &lg);
 int launch_find_range_stats(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
                             uint64_t *lo, uint64_t *hi, uint64_t *ssamp /*nullable*/, unsigned long long *stats /*kStatSearchN*/,
                             void *stream);
@@ -305,12 +351,13 @@ int launch_find_range_packed(const DevIndex &ix, const LaunchCfg &cfg, const voi
                              uint64_t N, uint64_t total_bytes, uint64_t *lo, uint64_t *hi, uint64_t *ssamp, void *stream);
 int launch_find_range_packed_only(const DevIndex &ix, const LaunchCfg &cfg, const uint2 *meta, const uint4 *chunks, uint64_t N,
                                   uint64_t *lo, uint64_t *hi, uint64_t *ssamp /*nullable*/, void *stream);
+// log (nullable scratch): when it can hold a log (make_seed_log) the plan writes one and the fill copies from it
 int launch_marker_seeds_plan(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
                              uint64_t wsize, uint64_t max_range, uint64_t ftab_k, uint64_t *seed_off, uint64_t *mk_off, void *tmp,
-                             size_t tmp_bytes, void *stream);
+                             size_t tmp_bytes, void *stream, void *log = nullptr, size_t log_bytes = 0);
 int launch_marker_seeds_fill(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
                              uint64_t wsize, uint64_t max_range, uint64_t ftab_k, const uint64_t *seed_off, const uint64_t *mk_off,
-                             uint64_t *seeds, uint64_t *mk, void *stream);
+                             uint64_t *seeds, uint64_t *mk, void *stream, void *log = nullptr, size_t log_bytes = 0);
 int launch_greedy_seed(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
                        uint64_t min_length, uint64_t *lo, uint64_t *hi, uint64_t *qs, uint64_t *qe, uint64_t *ss, void *stream);
 int launch_markers_plan(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t *lo, const uint64_t *hi, uint64_t N,

@@ -287,6 +287,79 @@ def test_marker_seeds_synth(synth):
     o.close()
 
 
+@pytest.mark.parametrize("layout", [capi.LAYOUT_SLOTS, capi.LAYOUT_RUNS])
+def test_marker_seeds_logged_fill(synth, layout):
+    """rbg_marker_seeds_plan_log_dev / _fill_log_dev (the reads walked once: the plan logs every sequence's seed records
+    and marker places, the fill copies) against the two-walk pair rbg_marker_seeds_plan_dev / _fill_dev, which
+    _check_marker_seeds pins to the oracle (rowbowt.hpp:406-482): same offsets, records and markers -- with the default
+    quota, with a quota of two seeds per sequence (most sequences exceed it and are walked again from the list), with
+    the tool's --ftab mode, on both layouts; a log area too small for two seeds per sequence is refused."""
+    import torch
+    S = synth
+    rb = _with_layout(layout, 48, lambda: ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0))
+    o = orc.Oracle.from_runs(S.heads, S.lens, S.ssa, S.esa)
+    ms, me, mo, mv = S.markers(wsize=10)
+    rb.set_markers(ms, me, mo, mv)
+    o.set_markers(ms, me, mo, mv)
+    reads = S.sample_reads(3000, 90, seed=41, sub_rate=0.3, ragged=True)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    reads += [q[::-1].translate(comp) for q in reads[:1500]] + [b"", b"A", b"NNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNN", S.text[:700].tobytes()]
+    _check_marker_seeds(rb, o, reads[:150] + reads[-4:], 10, 1000)           # the host API (it goes through the log too)
+    seqs, off = ra.pack_reads(reads)
+    N = len(reads)
+    dev = torch.device("cuda:0")
+    d_seqs = torch.from_numpy(np.concatenate([seqs, np.zeros(16 + (-len(seqs)) % 16, np.uint8)])).to(dev)
+    d_off = torch.from_numpy(off.view(np.int64)).to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    L = ra.lib()
+    tmp_bytes = L.rbg_locate_plan_tmp_bytes(N)
+    d_tmp = torch.empty(tmp_bytes, dtype=torch.uint8, device=dev)
+
+    def run(wsize, max_range, ftab_k, log_bytes):
+        d_soff, d_moff = (torch.full((N + 1,), -1, dtype=torch.int64, device=dev) for _ in range(2))
+        d_log = torch.empty(max(log_bytes, 16), dtype=torch.uint8, device=dev) if log_bytes is not None else None
+        if d_log is None:
+            assert L.rbg_marker_seeds_plan_dev(rb.h, d_seqs.data_ptr(), d_off.data_ptr(), N, wsize, max_range, ftab_k, d_soff.data_ptr(),
+                                               d_moff.data_ptr(), d_tmp.data_ptr(), tmp_bytes, st) == 0
+        else:
+            assert L.rbg_marker_seeds_plan_log_dev(rb.h, d_seqs.data_ptr(), d_off.data_ptr(), N, wsize, max_range, ftab_k, d_soff.data_ptr(),
+                                                   d_moff.data_ptr(), d_tmp.data_ptr(), tmp_bytes, d_log.data_ptr(), log_bytes, st) == 0
+        ns, nm = int(d_soff[-1].item()), int(d_moff[-1].item())
+        d_rec = torch.full((max(ns, 1) * 6,), -1, dtype=torch.int64, device=dev)
+        d_mk = torch.full((max(nm, 1),), -1, dtype=torch.int64, device=dev)
+        if d_log is None:
+            assert L.rbg_marker_seeds_fill_dev(rb.h, d_seqs.data_ptr(), d_off.data_ptr(), N, wsize, max_range, ftab_k, d_soff.data_ptr(),
+                                               d_moff.data_ptr(), d_rec.data_ptr(), d_mk.data_ptr(), st) == 0
+        else:
+            assert L.rbg_marker_seeds_fill_log_dev(rb.h, d_seqs.data_ptr(), d_off.data_ptr(), N, wsize, max_range, ftab_k, d_soff.data_ptr(),
+                                                   d_moff.data_ptr(), d_rec.data_ptr(), d_mk.data_ptr(), d_log.data_ptr(), log_bytes, st) == 0
+        torch.cuda.synchronize()
+        over = None
+        if d_log is not None:   # the list of sequences over quota sits behind the per-sequence area: its length is the log's last aligned block
+            over = True
+        return d_soff.cpu().numpy(), d_moff.cpu().numpy(), d_rec[:ns * 6].cpu().numpy(), d_mk[:nm].cpu().numpy()
+
+    for wsize, max_range, ftab_k in ((10, 1000, 0), (19, 6, 0), (10, 1000, 3)):
+        want = run(wsize, max_range, ftab_k, None)
+        assert want[2].size > 6 * N and (want[2] != -1).all()
+        for q in (0, 2, 5, 40):
+            lb = int(L.rbg_marker_seeds_log_bytes(rb.h, N, q))
+            got = run(wsize, max_range, ftab_k, lb)
+            for a, b in zip(want, got):
+                assert (a == b).all(), (wsize, max_range, ftab_k, q)
+    # an area that cannot hold two seeds per sequence, or an unaligned one, is refused
+    d_soff, d_moff = (torch.empty(N + 1, dtype=torch.int64, device=dev) for _ in range(2))
+    d_small = torch.empty(N * 40, dtype=torch.uint8, device=dev)
+    assert L.rbg_marker_seeds_plan_log_dev(rb.h, d_seqs.data_ptr(), d_off.data_ptr(), N, 10, 1000, 0, d_soff.data_ptr(), d_moff.data_ptr(),
+                                           d_tmp.data_ptr(), tmp_bytes, d_small.data_ptr(), N * 40, st) == -4
+    lb = int(L.rbg_marker_seeds_log_bytes(rb.h, N, 0))
+    d_big = torch.empty(lb + 16, dtype=torch.uint8, device=dev)
+    assert L.rbg_marker_seeds_plan_log_dev(rb.h, d_seqs.data_ptr(), d_off.data_ptr(), N, 10, 1000, 0, d_soff.data_ptr(), d_moff.data_ptr(),
+                                           d_tmp.data_ptr(), tmp_bytes, d_big.data_ptr() + 4, lb, st) == -4
+    rb.close()
+    o.close()
+
+
 def test_single_LF_steps(small, synth):
     """RowBowt::LF (rowbowt.hpp:74-88) one step at a time, against the oracle's LF."""
     rb, o = small
@@ -1583,10 +1656,22 @@ def test_run_indexed_layout(synth, pos_bytes, top_kb, fk, ks, rec):
     ms, me, mo, mv = S.markers(wsize=10)
     rb.set_markers(ms, me, mo, mv)
     o.set_markers(ms, me, mo, mv)
-    _check_marker_seeds(rb, o, reads[:300], 10, 1000)
-    goff, glocs = rb.find_locs_greedy_seeding(*ra.pack_reads(reads[:200]), 10)
-    for i in range(200):
-        assert glocs[int(goff[i]):int(goff[i + 1])].tolist() == o.greedy_locate(reads[i], 10)[0]
+    nseed, nmk = _check_marker_seeds(rb, o, reads[:300] + reads[-19:], 10, 1000)
+    assert nseed > 330 and nmk > 20
+    _check_marker_seeds(rb, o, reads[:120], 19, 4)
+    _check_marker_seeds(rb, o, reads[:60], 10, 1000, ftab_k=3)      # (rb_markers --ftab: that mode's kernel answers lane by lane)
+    goff, glocs = rb.find_locs_greedy_seeding(*ra.pack_reads(reads[:200] + reads[-19:]), 10)
+    for i, q in enumerate(reads[:200] + reads[-19:]):
+        assert glocs[int(goff[i]):int(goff[i + 1])].tolist() == o.greedy_locate(q, 10)[0]
+    # find_range_w_markers (rowbowt.hpp:292-339): the windowed search, cooperative on this layout as well
+    sub = reads[:400] + reads[-19:]
+    s3, o3 = ra.pack_reads(sub)
+    for wsize, max_range in ((10, MAXU), (7, 4), (25, 1000), (51, MAXU)):
+        lo3, hi3, mk_off3, mk3 = rb.find_range_w_markers(s3, o3, wsize, max_range)
+        got3 = split(mk_off3, mk3)
+        for i, q in enumerate(sub):
+            (wl, wh), wm = o.find_range_w_markers(q, wsize, max_range)
+            assert (int(lo3[i]), int(hi3[i])) == (wl, wh) and got3[i] == wm, (i, q, wsize)
     rb.close()
     o.close()
 
