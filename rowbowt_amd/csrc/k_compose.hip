@@ -1,0 +1,490 @@
+// k_compose.hip -- the k-mer tables of DESIGN.md 2b composed ON THE DEVICE at load time.
+//
+// A depth-(d+1) table T[x_d .. x_1 x_0] lists, as runs, the rows whose d + 1 preceding text characters spell the k-mer.
+// It follows from depth d by one sweep per symbol c: LF-map every c-run of the BWT onto the row-ordered segmentation G_d
+// of [0, n) by depth-d k-mer and cut it at the segment boundaries; every piece is one depth-(d+1) run, and the SA value at
+// its last row is either the sample of the G_d segment it ends with or the c-run's own sample minus d (rbg_host.cpp
+// compose() is the same statement as serial host code and stays as the reference: RBG_HOST_COMPOSE=1, and indexes built
+// without a device).  On the host these sweeps were 4.1 of the 8.2 s a load of the bench index took and 33 of 69 s at
+// n = 5e10; they are merges, sorts and scans over O(r) elements, i.e. what a GPU does at memory speed:
+//   per symbol:  boundaries = run images (Q_k = F_c + cum[k]) merged with the G boundaries inside the symbol's image
+//                (merge by mutual binary-search ranks, duplicates dropped) -> pieces {row start, length, sample, table}
+//   per level:   stable radix sort of the pieces by table -> run lists in table order, cum by one scan; radix sort of
+//                the pieces by row -> G_{d+1} (gaps = rows whose context leaves the k-mer alphabet).
+// Outputs per level: the tables' {start, cum} pairs back to back in table order, each table closed by its sentinel
+// {n, total} -- the array shape both layouts consume (DevSym::ent slices / DevTree::ent) -- their run-end samples, and per
+// table (runs, total, F).
+#include "rbg_device.hpp"
+
+#include <vector>
+
+namespace rbg {
+namespace {
+
+constexpr uint32_t kNoTab = 0xFFFFFFFFu;
+
+#define CK(expr)                                                                         \
+    do {                                                                                 \
+        const hipError_t e_ = (expr);                                                    \
+        if (e_ != hipSuccess) {                                                          \
+            std::fprintf(stderr, "rbg: %s failed in compose: %s\n", #expr, hipGetErrorString(e_)); \
+            return e_ == hipErrorOutOfMemory ? -5 : -3;                                  \
+        }                                                                                \
+    } while (0)
+
+// RAII device temporary
+struct Tmp {
+    void *p = nullptr;
+    ~Tmp() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { if (p) { (void)hipFree(p); p = nullptr; } return hipMalloc(&p, bytes ? bytes : 16); }
+    void release() { if (p) (void)hipFree(p); p = nullptr; }
+    template <typename T> T *as() const { return static_cast<T *>(p); }
+};
+
+template <typename T>
+__device__ __forceinline__ uint64_t lower_bound_dev(const T *a, uint64_t n, uint64_t v) {   // # elements < v
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) { const uint64_t mid = lo + ((hi - lo) >> 1); if (static_cast<uint64_t>(a[mid]) < v) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+template <typename T>
+__device__ __forceinline__ uint64_t upper_bound_dev(const T *a, uint64_t n, uint64_t v) {   // # elements <= v
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) { const uint64_t mid = lo + ((hi - lo) >> 1); if (static_cast<uint64_t>(a[mid]) <= v) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+// run image k starts at row F + cum[k]; # images starting <= v (binary search over the cum column)
+template <typename P>
+__device__ __forceinline__ uint64_t images_le(const RunEnt<P> *ent, uint64_t nruns, uint64_t F, uint64_t v) {
+    uint64_t lo = 0, hi = nruns;
+    while (lo < hi) { const uint64_t mid = lo + ((hi - lo) >> 1); if (F + static_cast<uint64_t>(ent[mid].cum) <= v) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+// 1. the G boundaries strictly inside the symbol's image: is B_j = g_start[g_lo + 1 + j] also a run-image start?
+template <typename P>
+__global__ __launch_bounds__(256) void k_flag_bounds(const RunEnt<P> *__restrict__ ent, const uint64_t nruns, const uint64_t F,
+                                                     const P *__restrict__ g_start, const uint64_t g_lo, const uint64_t nB,
+                                                     uint32_t *__restrict__ keep /* nB + 1 */) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t j = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j <= nB; j += stride) {
+        if (j == nB) { keep[j] = 0; continue; }
+        const uint64_t b = g_start[g_lo + 1 + j];
+        const uint64_t la = images_le<P>(ent, nruns, F, b);
+        keep[j] = (la > 0 && F + static_cast<uint64_t>(ent[la - 1].cum) == b) ? 0u : 1u;
+    }
+}
+
+// 2. the merged boundary list of one symbol: boundary r -> (row of the image space, run k, segment g)
+template <typename P>
+__global__ __launch_bounds__(256) void k_merge_bounds(const RunEnt<P> *__restrict__ ent, const uint64_t nruns, const uint64_t F,
+                                                      const P *__restrict__ g_start, const uint64_t g_lo, const uint64_t nB,
+                                                      const uint32_t *__restrict__ keep, const uint64_t *__restrict__ posB /* exclusive scan of keep, nB + 1 */,
+                                                      uint64_t *__restrict__ bnd, uint32_t *__restrict__ bk, uint32_t *__restrict__ bg) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    const P *B = g_start + g_lo + 1;
+    for (uint64_t x = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; x < nruns + nB; x += stride) {
+        if (x < nruns) {
+            const uint64_t k = x, b = F + static_cast<uint64_t>(ent[k].cum);
+            const uint64_t j0 = lower_bound_dev<P>(B, nB, b);          // # G boundaries below b (none of them equals a later image start)
+            const uint64_t j1 = upper_bound_dev<P>(B, nB, b);          // # G boundaries at or below b: the segment that holds row b
+            const uint64_t r = k + posB[j0];
+            bnd[r] = b; bk[r] = static_cast<uint32_t>(k); bg[r] = static_cast<uint32_t>(g_lo + j1);
+        } else {
+            const uint64_t j = x - nruns;
+            if (!keep[j]) continue;
+            const uint64_t b = B[j];
+            const uint64_t la = images_le<P>(ent, nruns, F, b);         // all of them start strictly below b
+            const uint64_t r = la + posB[j];
+            bnd[r] = b; bk[r] = static_cast<uint32_t>(la - 1); bg[r] = static_cast<uint32_t>(g_lo + 1 + j);
+        }
+    }
+}
+
+// 3. boundaries -> pieces of symbol m (appended at `base` of the level's piece arrays)
+template <typename P>
+__global__ __launch_bounds__(256) void k_make_pieces(const RunEnt<P> *__restrict__ ent, const P *__restrict__ samp, const uint64_t F,
+                                                     const uint64_t total, const P *__restrict__ g_start, const uint32_t *__restrict__ g_id,
+                                                     const P *__restrict__ g_samp, const uint64_t *__restrict__ bnd, const uint32_t *__restrict__ bk,
+                                                     const uint32_t *__restrict__ bg, const uint64_t np, const uint32_t depth, const uint32_t M,
+                                                     const uint32_t m, const uint32_t T, const bool with_samples, uint32_t *__restrict__ p_tab,
+                                                     P *__restrict__ p_start, P *__restrict__ p_len, P *__restrict__ p_samp, int *__restrict__ err) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t r = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; r < np; r += stride) {
+        const uint64_t b = bnd[r], e = r + 1 < np ? bnd[r + 1] : F + total;
+        const uint32_t k = bk[r], g = bg[r];
+        const uint32_t id = g_id[g];
+        const uint64_t Q = F + static_cast<uint64_t>(ent[k].cum);
+        p_start[r] = static_cast<P>(static_cast<uint64_t>(ent[k].start) + (b - Q));
+        p_len[r] = static_cast<P>(e - b);
+        p_tab[r] = id == kNoTab ? T : id * M + m;       // T: rows whose context leaves the k-mer alphabet (sorted to the end, dropped)
+        if (with_samples) {
+            uint64_t v = 0;
+            if (id != kNoTab) {
+                if (e == static_cast<uint64_t>(g_start[g + 1])) v = g_samp[g];
+                else {
+                    const uint64_t sv = samp[k];
+                    if (sv < depth) *err = 1;           // would need the terminator inside the k-mer
+                    v = sv - depth;
+                }
+            }
+            p_samp[r] = static_cast<P>(v);
+        }
+    }
+}
+
+// 4. first index of every table's pieces in the table-sorted order (T + 2 entries: [T] = first dropped piece, [T + 1] = np)
+__global__ __launch_bounds__(256) void k_table_firsts(const uint32_t *__restrict__ sorted_tab, const uint64_t np, const uint32_t T,
+                                                      uint64_t *__restrict__ first) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > T + 1) return;
+    first[t] = t == T + 1 ? np : lower_bound_dev<uint32_t>(sorted_tab, np, t);
+}
+
+template <typename P>
+__global__ __launch_bounds__(256) void k_gather_len(const uint32_t *__restrict__ perm, const P *__restrict__ p_len, const uint64_t np,
+                                                    uint64_t *__restrict__ out /* np + 1; out[np] = 0 */) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t j = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j <= np; j += stride) out[j] = j < np ? static_cast<uint64_t>(p_len[perm[j]]) : 0;
+}
+
+// 5. the level's arrays: table t's runs at [first[t] + t, first[t + 1] + t), its sentinel behind them
+template <typename P>
+__global__ __launch_bounds__(256) void k_write_tables(const uint32_t *__restrict__ sorted_tab, const uint32_t *__restrict__ perm,
+                                                      const uint64_t *__restrict__ first, const uint64_t *__restrict__ cumlen /* exclusive scan, np + 1 */,
+                                                      const P *__restrict__ p_start, const P *__restrict__ p_samp, const uint64_t nkept, const uint32_t T,
+                                                      const uint64_t n, const bool with_samples, RunEnt<P> *__restrict__ ent, P *__restrict__ samp) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t j = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < nkept + T; j += stride) {
+        if (j < nkept) {
+            const uint32_t t = sorted_tab[j], src = perm[j];
+            RunEnt<P> e;
+            e.start = p_start[src];
+            e.cum = static_cast<P>(cumlen[j] - cumlen[first[t]]);
+            ent[j + t] = e;
+            if (with_samples) samp[j + t] = p_samp[src];
+        } else {
+            const uint32_t t = static_cast<uint32_t>(j - nkept);
+            RunEnt<P> e;
+            e.start = static_cast<P>(n);
+            e.cum = static_cast<P>(cumlen[first[t + 1]] - cumlen[first[t]]);
+            ent[first[t + 1] + t] = e;
+            if (with_samples) samp[first[t + 1] + t] = 0;
+        }
+    }
+}
+
+// 6. F_{d+1}[id, m] = F_d[id] + rank_d(F[m], id): rows of the id-interval followed by a smaller symbol (prev table id's run list)
+template <typename P>
+__global__ __launch_bounds__(256) void k_table_F(const RunEnt<P> *const *__restrict__ prev_ent, const uint64_t *__restrict__ prev_nruns,
+                                                 const uint64_t *__restrict__ prev_F, const uint64_t *__restrict__ sym_F, const uint32_t n_ids,
+                                                 const uint32_t M, uint64_t *__restrict__ out_F) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_ids * M) return;
+    const uint32_t id = t / M, m = t % M;
+    const RunEnt<P> *e = prev_ent[id];
+    const uint64_t nr = prev_nruns[id], i = sym_F[m];
+    uint64_t lo = 0, hi = nr;
+    while (lo < hi) { const uint64_t mid = lo + ((hi - lo) >> 1); if (static_cast<uint64_t>(e[mid].start) < i) lo = mid + 1; else hi = mid; }
+    uint64_t rk = 0;
+    if (lo > 0) {
+        const uint64_t d = i - static_cast<uint64_t>(e[lo - 1].start), len = static_cast<uint64_t>(e[lo].cum) - static_cast<uint64_t>(e[lo - 1].cum);
+        rk = static_cast<uint64_t>(e[lo - 1].cum) + (d < len ? d : len);
+    }
+    out_F[t] = prev_F[id] + rk;
+}
+
+// 7. the next segmentation from the kept pieces in row order: a gap segment (no table) wherever rows are missing
+template <typename P>
+__global__ __launch_bounds__(256) void k_gap_flags(const uint32_t *__restrict__ rperm, const P *__restrict__ p_start, const P *__restrict__ p_len,
+                                                   const uint64_t nkept, uint64_t *__restrict__ gap /* nkept + 1 */, const uint64_t n) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t q = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; q <= nkept; q += stride) {
+        const uint64_t prev_end = q ? static_cast<uint64_t>(p_start[rperm[q - 1]]) + static_cast<uint64_t>(p_len[rperm[q - 1]]) : 0;
+        const uint64_t here = q < nkept ? static_cast<uint64_t>(p_start[rperm[q]]) : n;
+        gap[q] = here > prev_end ? 1 : 0;
+    }
+}
+template <typename P>
+__global__ __launch_bounds__(256) void k_write_segments(const uint32_t *__restrict__ rperm, const uint32_t *__restrict__ p_tab, const P *__restrict__ p_start,
+                                                        const P *__restrict__ p_len, const P *__restrict__ p_samp, const uint64_t nkept,
+                                                        const uint64_t *__restrict__ gapx /* exclusive scan of gap, nkept + 2 */, const uint64_t n,
+                                                        const bool with_samples, P *__restrict__ g_start, uint32_t *__restrict__ g_id, P *__restrict__ g_samp) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t q = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; q <= nkept; q += stride) {
+        const uint64_t prev_end = q ? static_cast<uint64_t>(p_start[rperm[q - 1]]) + static_cast<uint64_t>(p_len[rperm[q - 1]]) : 0;
+        const uint64_t at = q + gapx[q];
+        const bool gap = gapx[q + 1] != gapx[q];
+        if (gap) { g_start[at] = static_cast<P>(prev_end); g_id[at] = kNoTab; if (with_samples) g_samp[at] = 0; }
+        if (q < nkept) {
+            const uint32_t src = rperm[q];
+            const uint64_t o = at + (gap ? 1 : 0);
+            g_start[o] = p_start[src]; g_id[o] = p_tab[src]; if (with_samples) g_samp[o] = p_samp[src];
+        } else {
+            g_start[at + (gap ? 1 : 0)] = static_cast<P>(n);   // sentinel
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_widen_flags(const uint32_t *__restrict__ in, const uint64_t n, uint64_t *__restrict__ out) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = in[i];
+}
+__global__ __launch_bounds__(256) void k_gather_u64(const uint64_t *__restrict__ src, const uint64_t *__restrict__ idx, const uint64_t n, uint64_t *__restrict__ out) {
+    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = src[idx[i]];
+}
+template <typename P>
+__global__ __launch_bounds__(256) void k_gather_pos(const uint32_t *__restrict__ perm, const P *__restrict__ src, const uint64_t n, P *__restrict__ dst) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t j = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < n; j += stride) dst[j] = src[perm[j]];
+}
+__global__ __launch_bounds__(256) void k_iota32(uint32_t *__restrict__ v, const uint64_t N) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < N; i += stride) v[i] = static_cast<uint32_t>(i);
+}
+
+inline dim3 grid_n(uint64_t n) { return dim3(static_cast<unsigned>(std::min<uint64_t>((n + 255) / 256 ? (n + 255) / 256 : 1, 256ull * 64))); }
+
+int exclusive_scan_u64(const uint64_t *in, uint64_t *out, uint64_t n, hipStream_t st) {
+    size_t bytes = 0;
+    CK(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, out, static_cast<int64_t>(n), st));
+    Tmp t;
+    CK(t.alloc(bytes));
+    CK(hipcub::DeviceScan::ExclusiveSum(t.p, bytes, in, out, static_cast<int64_t>(n), st));
+    CK(hipStreamSynchronize(st));
+    return 0;
+}
+
+template <typename K>
+int sort_pairs(const K *kin, K *kout, const uint32_t *vin, uint32_t *vout, uint64_t n, int end_bit, hipStream_t st) {
+    size_t bytes = 0;
+    CK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, kin, kout, vin, vout, static_cast<int64_t>(n), 0, end_bit, st));
+    Tmp t;
+    CK(t.alloc(bytes));
+    CK(hipcub::DeviceRadixSort::SortPairs(t.p, bytes, kin, kout, vin, vout, static_cast<int64_t>(n), 0, end_bit, st));
+    CK(hipStreamSynchronize(st));
+    return 0;
+}
+
+int bits_for(uint64_t v) { int b = 1; while (b < 64 && (v >> b)) ++b; return b; }
+
+template <typename P>
+int compose_impl(const uint64_t n, const uint32_t M, const ComposeTable *major, const void *g1_start, const uint32_t *g1_id, const void *g1_samp,
+                 const uint64_t g1_n, const uint32_t kmax, const bool with_samples, std::vector<ComposedLevel> &out, hipStream_t st) {
+    out.clear();
+    // the segmentation of the current depth (depth 1: the caller's arrays, not owned)
+    const P *g_start = static_cast<const P *>(g1_start);
+    const uint32_t *g_id = g1_id;
+    const P *g_samp = static_cast<const P *>(g1_samp);
+    uint64_t g_n = g1_n;
+    Tmp own_start, own_id, own_samp;
+    // the previous depth's tables (for F): depth 1 = the major symbols' own tables
+    std::vector<const void *> prev_ent(M);
+    std::vector<uint64_t> prev_nruns(M), prev_F(M), sym_F(M);
+    for (uint32_t m = 0; m < M; ++m) { prev_ent[m] = major[m].ent; prev_nruns[m] = major[m].nruns; prev_F[m] = major[m].F; sym_F[m] = major[m].F; }
+    Tmp d_err;
+    CK(d_err.alloc(sizeof(int)));
+    CK(hipMemsetAsync(d_err.p, 0, sizeof(int), st));
+    uint32_t n_ids = M;
+    for (uint32_t depth = 1; depth < kmax; ++depth, n_ids *= M) {
+        const uint32_t T = n_ids * M;
+        // ---- pieces of every symbol -------------------------------------------------------------------------------------
+        // which G segments a symbol's image [F, F + total) meets: two binary searches per symbol, made from the host over the
+        // device array (a few dozen 8-byte copies per level)
+        std::vector<uint64_t> g_lo(M), nB(M), np_m(M), base(M + 1, 0);
+        std::vector<Tmp> keep(M), posB(M);
+        for (uint32_t m = 0; m < M; ++m) {
+            const ComposeTable &tc = major[m];
+            if (tc.nruns == 0 || tc.total == 0) { g_lo[m] = 0; nB[m] = 0; np_m[m] = 0; base[m + 1] = base[m]; continue; }
+            // g_lo = last segment starting <= F; g_hi = last segment starting <= F + total - 1 (host-side binary search over the device array)
+            auto seg_of = [&](uint64_t row, uint64_t *res) -> int {
+                uint64_t lo = 0, hi = g_n;     // # starts <= row, minus one
+                while (lo < hi) {
+                    const uint64_t mid = lo + ((hi - lo) >> 1);
+                    P v;
+                    CK(hipMemcpy(&v, g_start + mid, sizeof(P), hipMemcpyDeviceToHost));
+                    if (static_cast<uint64_t>(v) <= row) lo = mid + 1; else hi = mid;
+                }
+                *res = lo ? lo - 1 : 0;
+                return 0;
+            };
+            uint64_t ghi = 0;
+            int rc = seg_of(tc.F, &g_lo[m]);
+            if (rc) return rc;
+            if ((rc = seg_of(tc.F + tc.total - 1, &ghi))) return rc;
+            nB[m] = ghi - g_lo[m];
+            CK(keep[m].alloc((nB[m] + 1) * 4));
+            CK(posB[m].alloc((nB[m] + 2) * 8));
+            hipLaunchKernelGGL((k_flag_bounds<P>), grid_n(nB[m] + 1), dim3(256), 0, st, static_cast<const RunEnt<P> *>(tc.ent), tc.nruns, tc.F, g_start,
+                               g_lo[m], nB[m], keep[m].as<uint32_t>());
+            CK(hipGetLastError());
+            // exclusive scan of the keep flags -> rank of every kept G boundary among the kept ones
+            {
+                Tmp k64;
+                CK(k64.alloc((nB[m] + 1) * 8));
+                hipLaunchKernelGGL(k_widen_flags, grid_n(nB[m] + 1), dim3(256), 0, st, keep[m].as<uint32_t>(), nB[m] + 1, k64.as<uint64_t>());
+                CK(hipGetLastError());
+                const int rc2 = exclusive_scan_u64(k64.as<uint64_t>(), posB[m].as<uint64_t>(), nB[m] + 1, st);
+                if (rc2) return rc2;
+            }
+            uint64_t kept = 0;
+            CK(hipMemcpy(&kept, posB[m].as<uint64_t>() + nB[m], 8, hipMemcpyDeviceToHost));
+            np_m[m] = tc.nruns + kept;
+            base[m + 1] = base[m] + np_m[m];
+        }
+        const uint64_t np = base[M];
+        if (np >= 0xFFFFFFF0ull) return -4;   // piece and run ordinals are 32-bit
+        Tmp p_tab, p_start, p_len, p_samp;
+        CK(p_tab.alloc((np + 1) * 4));
+        CK(p_start.alloc((np + 1) * sizeof(P)));
+        CK(p_len.alloc((np + 1) * sizeof(P)));
+        if (with_samples) CK(p_samp.alloc((np + 1) * sizeof(P)));
+        for (uint32_t m = 0; m < M; ++m) {
+            if (np_m[m] == 0) continue;
+            const ComposeTable &tc = major[m];
+            Tmp bnd, bk, bg;
+            CK(bnd.alloc(np_m[m] * 8));
+            CK(bk.alloc(np_m[m] * 4));
+            CK(bg.alloc(np_m[m] * 4));
+            hipLaunchKernelGGL((k_merge_bounds<P>), grid_n(tc.nruns + nB[m]), dim3(256), 0, st, static_cast<const RunEnt<P> *>(tc.ent), tc.nruns, tc.F, g_start,
+                               g_lo[m], nB[m], keep[m].as<uint32_t>(), posB[m].as<uint64_t>(), bnd.as<uint64_t>(), bk.as<uint32_t>(), bg.as<uint32_t>());
+            CK(hipGetLastError());
+            hipLaunchKernelGGL((k_make_pieces<P>), grid_n(np_m[m]), dim3(256), 0, st, static_cast<const RunEnt<P> *>(tc.ent), static_cast<const P *>(tc.samp), tc.F,
+                               tc.total, g_start, g_id, g_samp, bnd.as<uint64_t>(), bk.as<uint32_t>(), bg.as<uint32_t>(), np_m[m], depth, M, m, T, with_samples,
+                               p_tab.as<uint32_t>() + base[m], p_start.as<P>() + base[m], p_len.as<P>() + base[m],
+                               with_samples ? p_samp.as<P>() + base[m] : nullptr, d_err.as<int>());
+            CK(hipGetLastError());
+            CK(hipStreamSynchronize(st));
+            keep[m].release();
+            posB[m].release();
+        }
+        // ---- tables: stable sort by table, cum by one scan ------------------------------------------------------------------
+        Tmp iota, s_tab, perm;
+        CK(iota.alloc((np + 1) * 4));
+        CK(s_tab.alloc((np + 1) * 4));
+        CK(perm.alloc((np + 1) * 4));
+        hipLaunchKernelGGL(k_iota32, grid_n(np), dim3(256), 0, st, iota.as<uint32_t>(), np);
+        CK(hipGetLastError());
+        int rc = sort_pairs<uint32_t>(p_tab.as<uint32_t>(), s_tab.as<uint32_t>(), iota.as<uint32_t>(), perm.as<uint32_t>(), np, bits_for(T), st);
+        if (rc) return rc;
+        Tmp first;
+        CK(first.alloc((T + 2) * 8));
+        hipLaunchKernelGGL(k_table_firsts, dim3((T + 2 + 255) / 256), dim3(256), 0, st, s_tab.as<uint32_t>(), np, T, first.as<uint64_t>());
+        CK(hipGetLastError());
+        std::vector<uint64_t> h_first(T + 2);
+        CK(hipMemcpy(h_first.data(), first.p, (T + 2) * 8, hipMemcpyDeviceToHost));
+        const uint64_t nkept = h_first[T];
+        Tmp lens, cumlen;
+        CK(lens.alloc((np + 1) * 8));
+        CK(cumlen.alloc((np + 1) * 8));
+        hipLaunchKernelGGL((k_gather_len<P>), grid_n(np + 1), dim3(256), 0, st, perm.as<uint32_t>(), p_len.as<P>(), np, lens.as<uint64_t>());
+        CK(hipGetLastError());
+        if ((rc = exclusive_scan_u64(lens.as<uint64_t>(), cumlen.as<uint64_t>(), np + 1, st))) return rc;
+        lens.release();
+        ComposedLevel L;
+        L.entries = nkept + T;
+        void *d_ent = nullptr, *d_samp = nullptr;
+        CK(hipMalloc(&d_ent, (L.entries + 2) * sizeof(RunEnt<P>)));    // (+ spare entries: the run-indexed kernels' two-entry loads may touch one past the last sentinel)
+        L.ent = d_ent;
+        if (with_samples) {
+            const hipError_t e2 = hipMalloc(&d_samp, (L.entries + 2) * sizeof(P));
+            if (e2 != hipSuccess) { (void)hipFree(d_ent); return e2 == hipErrorOutOfMemory ? -5 : -3; }
+        }
+        L.samp = d_samp;
+        out.push_back(L);   // (from here on the caller owns the arrays, also on an error return)
+        ComposedLevel &Lv = out.back();
+        CK(hipMemsetAsync(static_cast<char *>(d_ent) + L.entries * sizeof(RunEnt<P>), 0xFF, 2 * sizeof(RunEnt<P>), st));
+        hipLaunchKernelGGL((k_write_tables<P>), grid_n(nkept + T), dim3(256), 0, st, s_tab.as<uint32_t>(), perm.as<uint32_t>(), first.as<uint64_t>(),
+                           cumlen.as<uint64_t>(), p_start.as<P>(), p_samp.as<P>(), nkept, T, n, with_samples, static_cast<RunEnt<P> *>(d_ent),
+                           static_cast<P *>(d_samp));
+        CK(hipGetLastError());
+        // per table: runs, total, F
+        std::vector<uint64_t> h_cum_at(T + 1);
+        {
+            Tmp d_cum_at;   // cumlen at the tables' first pieces
+            CK(d_cum_at.alloc((T + 1) * 8));
+            hipLaunchKernelGGL(k_gather_u64, dim3((T + 1 + 255) / 256), dim3(256), 0, st, cumlen.as<uint64_t>(), first.as<uint64_t>(), T + 1, d_cum_at.as<uint64_t>());
+            CK(hipGetLastError());
+            CK(hipMemcpy(h_cum_at.data(), d_cum_at.p, (T + 1) * 8, hipMemcpyDeviceToHost));
+        }
+        Tmp d_prev_ent, d_prev_nruns, d_prev_F, d_sym_F, d_F;
+        CK(d_prev_ent.alloc(n_ids * 8)); CK(d_prev_nruns.alloc(n_ids * 8)); CK(d_prev_F.alloc(n_ids * 8)); CK(d_sym_F.alloc(M * 8)); CK(d_F.alloc(T * 8));
+        CK(hipMemcpy(d_prev_ent.p, prev_ent.data(), n_ids * 8, hipMemcpyHostToDevice));
+        CK(hipMemcpy(d_prev_nruns.p, prev_nruns.data(), n_ids * 8, hipMemcpyHostToDevice));
+        CK(hipMemcpy(d_prev_F.p, prev_F.data(), n_ids * 8, hipMemcpyHostToDevice));
+        CK(hipMemcpy(d_sym_F.p, sym_F.data(), M * 8, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL((k_table_F<P>), dim3((T + 255) / 256), dim3(256), 0, st, d_prev_ent.as<const RunEnt<P> *>(), d_prev_nruns.as<uint64_t>(),
+                           d_prev_F.as<uint64_t>(), d_sym_F.as<uint64_t>(), n_ids, M, d_F.as<uint64_t>());
+        CK(hipGetLastError());
+        Lv.nruns.resize(T); Lv.total.resize(T); Lv.F.resize(T); Lv.first.resize(T);
+        CK(hipMemcpy(Lv.F.data(), d_F.p, T * 8, hipMemcpyDeviceToHost));
+        for (uint32_t t = 0; t < T; ++t) {
+            Lv.nruns[t] = h_first[t + 1] - h_first[t];
+            Lv.total[t] = h_cum_at[t + 1] - h_cum_at[t];
+            Lv.first[t] = h_first[t] + t;
+        }
+        // ---- the next depth's segmentation (not needed after the last level) ----------------------------------------------
+        if (depth + 1 < kmax) {
+            Tmp rkeys, rperm;
+            CK(rkeys.alloc((nkept + 1) * sizeof(P)));
+            CK(rperm.alloc((nkept + 1) * 4));
+            // kept pieces = perm[0 .. nkept): sort THEM by row start.  Keys = p_start gathered through perm.
+            Tmp kin;
+            CK(kin.alloc((nkept + 1) * sizeof(P)));
+            hipLaunchKernelGGL((k_gather_pos<P>), grid_n(nkept), dim3(256), 0, st, perm.as<uint32_t>(), p_start.as<P>(), nkept, kin.as<P>());
+            CK(hipGetLastError());
+            if ((rc = sort_pairs<P>(kin.as<P>(), rkeys.as<P>(), perm.as<uint32_t>(), rperm.as<uint32_t>(), nkept, bits_for(n), st))) return rc;
+            kin.release(); rkeys.release();
+            Tmp gap, gapx;
+            CK(gap.alloc((nkept + 2) * 8));
+            CK(gapx.alloc((nkept + 2) * 8));
+            hipLaunchKernelGGL((k_gap_flags<P>), grid_n(nkept + 1), dim3(256), 0, st, rperm.as<uint32_t>(), p_start.as<P>(), p_len.as<P>(), nkept, gap.as<uint64_t>(), n);
+            CK(hipGetLastError());
+            CK(hipMemsetAsync(gap.as<uint64_t>() + nkept + 1, 0, 8, st));
+            if ((rc = exclusive_scan_u64(gap.as<uint64_t>(), gapx.as<uint64_t>(), nkept + 2, st))) return rc;
+            uint64_t ngaps = 0;
+            CK(hipMemcpy(&ngaps, gapx.as<uint64_t>() + nkept + 1, 8, hipMemcpyDeviceToHost));
+            const uint64_t nseg = nkept + ngaps;
+            Tmp n_start, n_id, n_samp;
+            CK(n_start.alloc((nseg + 2) * sizeof(P)));
+            CK(n_id.alloc((nseg + 2) * 4));
+            if (with_samples) CK(n_samp.alloc((nseg + 2) * sizeof(P)));
+            hipLaunchKernelGGL((k_write_segments<P>), grid_n(nkept + 1), dim3(256), 0, st, rperm.as<uint32_t>(), p_tab.as<uint32_t>(), p_start.as<P>(),
+                               p_len.as<P>(), p_samp.as<P>(), nkept, gapx.as<uint64_t>(), n, with_samples, n_start.as<P>(), n_id.as<uint32_t>(), n_samp.as<P>());
+            CK(hipGetLastError());
+            CK(hipStreamSynchronize(st));
+            std::swap(own_start.p, n_start.p);
+            std::swap(own_id.p, n_id.p);
+            std::swap(own_samp.p, n_samp.p);
+            g_start = own_start.as<P>();
+            g_id = own_id.as<uint32_t>();
+            g_samp = own_samp.as<P>();
+            g_n = nseg;
+        }
+        CK(hipStreamSynchronize(st));
+        int h_err = 0;
+        CK(hipMemcpy(&h_err, d_err.p, sizeof(int), hipMemcpyDeviceToHost));
+        if (h_err) return -2;   // RBG_EFORMAT: a sample below the depth (the terminator inside a k-mer)
+        // the tables just made are the next level's "previous" ones
+        prev_ent.assign(T, nullptr); prev_nruns.assign(T, 0); prev_F.assign(T, 0);
+        for (uint32_t t = 0; t < T; ++t) {
+            prev_ent[t] = static_cast<const char *>(Lv.ent) + Lv.first[t] * sizeof(RunEnt<P>);
+            prev_nruns[t] = Lv.nruns[t];
+            prev_F[t] = Lv.F[t];
+        }
+    }
+    return 0;
+}
+
+}  // namespace
+
+// RBG_* codes: 0 ok, -2 EFORMAT, -3 ENODEV, -4 EARG, -5 ENOMEM (include/rbg.h)
+int compose_levels_device(uint32_t pos_bytes, uint64_t n, uint32_t M, const ComposeTable *major, const void *g_start, const uint32_t *g_id,
+                          const void *g_samp, uint64_t g_n, uint32_t kmax, bool with_samples, std::vector<ComposedLevel> &out, void *stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    return pos_bytes == 4 ? compose_impl<uint32_t>(n, M, major, g_start, g_id, g_samp, g_n, kmax, with_samples, out, st)
+                          : compose_impl<uint64_t>(n, M, major, g_start, g_id, g_samp, g_n, kmax, with_samples, out, st);
+}
+
+}  // namespace rbg

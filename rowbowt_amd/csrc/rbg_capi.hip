@@ -68,6 +68,7 @@ struct rbg_index {
     std::atomic<uint64_t> comb_launches{0}, comb_requests{0};
     std::mutex ws_mu;            // host-call workspaces (rbg_hostpath.hpp): one per concurrent caller, kept for reuse
     std::vector<std::unique_ptr<rbg_hostpath::Workspace>> ws_free;
+    std::vector<ComposedLevel> kmer_levels;  // k-mer depths composed on the device (k_compose.hip): [0] = depth 2; arrays listed in `allocs`
     std::vector<DevSym> dense_todo;  // load time only: rank tables whose overflow buckets still need their dense tables
     std::mutex mu;               // guards marker/doc attachment only; queries are lock-free
 };
@@ -237,11 +238,13 @@ int dev_upload(rbg_index *ix, const void *src, size_t bytes, const void **dst) {
     return RBG_OK;
 }
 
+// bytes of one table in the replica; in_arena: what the arena has to hold of it (a table composed on the device keeps
+// its run list and samples in the level's own allocation)
 template <typename P>
-size_t table_bytes(const SymTable &t, bool with_samples, uint64_t n) {
+size_t table_bytes(const SymTable &t, bool with_samples, uint64_t n, bool in_arena = false) {
     const uint64_t nb = (n >> t.shift) + 2;
-    return arena_round((t.nruns + 1) * sizeof(RunEnt<P>)) + (with_samples ? arena_round(t.nruns * sizeof(P)) : 0) +
-           arena_round(nb * sizeof(RankSlot)) + arena_round(nb * sizeof(uint32_t));
+    const size_t lists = (in_arena && t.dev_ent) ? 0 : arena_round((t.nruns + 1) * sizeof(RunEnt<P>)) + (with_samples ? arena_round(t.nruns * sizeof(P)) : 0);
+    return lists + arena_round(nb * sizeof(RankSlot)) + arena_round(nb * sizeof(uint32_t));
 }
 
 // 8-byte positions with n < 2^38 and phi buckets of at most 64 positions: 16-byte packed phi slots (rbg_dev.h)
@@ -255,13 +258,13 @@ template <typename P>
 size_t phi_slot_bytes(const HostIndex &h) { return phi_slots_packed<P>(h) ? sizeof(PhiSlotPacked) : sizeof(PhiSlot<P>); }
 
 template <typename P>
-size_t replica_bytes(const HostIndex &h) {
+size_t replica_bytes(const HostIndex &h, bool in_arena = false) {
     size_t total = 0;
-    for (const SymTable &t : h.sym) total += table_bytes<P>(t, h.has_tsa, h.n);
-    for (const SymTable &t : h.pair) total += table_bytes<P>(t, h.has_tsa, h.n);
-    for (const SymTable &t : h.triple) total += table_bytes<P>(t, h.has_tsa, h.n);
-    for (const SymTable &t : h.quad) total += table_bytes<P>(t, h.has_tsa, h.n);
-    for (const SymTable &t : h.quint) total += table_bytes<P>(t, h.has_tsa, h.n);
+    for (const SymTable &t : h.sym) total += table_bytes<P>(t, h.has_tsa, h.n, in_arena);
+    for (const SymTable &t : h.pair) total += table_bytes<P>(t, h.has_tsa, h.n, in_arena);
+    for (const SymTable &t : h.triple) total += table_bytes<P>(t, h.has_tsa, h.n, in_arena);
+    for (const SymTable &t : h.quad) total += table_bytes<P>(t, h.has_tsa, h.n, in_arena);
+    for (const SymTable &t : h.quint) total += table_bytes<P>(t, h.has_tsa, h.n, in_arena);
     total += arena_round(h.sym.size() * sizeof(DevSym)) + arena_round(h.pair.size() * sizeof(DevSym)) +
              arena_round(h.triple.size() * sizeof(DevSym)) + arena_round(h.quad.size() * sizeof(DevSym)) +
              arena_round(h.quint.size() * sizeof(DevSym)) + 3 * arena_round(256);
@@ -285,6 +288,7 @@ struct PreparedSym {
 
 template <typename P>
 void prepare_sym(const SymTable &t, bool with_samples, PreparedSym<P> &p) {
+    if (t.dev_ent) return;   // composed on the device: the run list is there already
     p.ent.resize(t.nruns + 1);
     for (uint64_t k = 0; k <= t.nruns; ++k) {
         p.ent[k].start = static_cast<P>(t.start[k]);
@@ -299,10 +303,15 @@ void prepare_sym(const SymTable &t, bool with_samples, PreparedSym<P> &p) {
 // upload the run list (+ samples); the RankSlot / ord tables are generated from it on the device
 template <typename P>
 int commit_sym(rbg_index *ix, const SymTable &t, bool with_samples, PreparedSym<P> &p, DevSym &d, unsigned long long *d_overflow) {
-    int rc = dev_upload(ix, p.ent.data(), p.ent.size() * sizeof(RunEnt<P>), &d.ent);
-    if (rc) return rc;
+    int rc = RBG_OK;
     d.samp = nullptr;
-    if (with_samples && (rc = dev_upload(ix, p.samp.data(), p.samp.size() * sizeof(P), &d.samp))) return rc;
+    if (t.dev_ent) {
+        d.ent = t.dev_ent;
+        if (with_samples) d.samp = t.dev_samp;
+    } else {
+        if ((rc = dev_upload(ix, p.ent.data(), p.ent.size() * sizeof(RunEnt<P>), &d.ent))) return rc;
+        if (with_samples && (rc = dev_upload(ix, p.samp.data(), p.samp.size() * sizeof(P), &d.samp))) return rc;
+    }
     const uint64_t nb = (ix->H().n >> t.shift) + 2;
     void *slots = nullptr, *ord = nullptr;
     if ((rc = dev_reserve(ix, nb * sizeof(RankSlot), &slots)) || (rc = dev_reserve(ix, nb * sizeof(uint32_t), &ord))) return rc;
@@ -514,9 +523,15 @@ size_t runs_replica_bytes(const HostIndex &h) {
     return total + 16 * kArenaAlign;
 }
 
+template <typename P> int materialize_kmer_levels(rbg_index *ix);
+
 template <typename P>
 int upload_tables_runs(rbg_index *ix) {
     HostIndex &h = ix->H();
+    {
+        const int rcm = materialize_kmer_levels<P>(ix);
+        if (rcm) return rcm;
+    }
     const uint64_t budget_keys = g_opt_tree_top_kb.load() ? static_cast<uint64_t>(g_opt_tree_top_kb.load()) * 1024 / sizeof(P) : 16;
     const std::vector<SymTable> *depth[kMaxRunDepth] = {&h.sym, &h.pair, &h.triple, &h.quad, &h.quint};
     uint32_t D = 1;
@@ -812,6 +827,148 @@ int upload_markers(rbg_index *ix) {
     return RBG_OK;
 }
 
+FlattenOptions current_options();
+
+// give back the device arrays of the k-mer level `depth` (2..5) -- a level the budget rule drops, or one the run-indexed
+// layout has copied out
+void release_kmer_level(rbg_index *ix, uint32_t depth) {
+    if (depth < 2 || depth - 2 >= ix->kmer_levels.size()) return;
+    ComposedLevel &L = ix->kmer_levels[depth - 2];
+    for (void *p : {L.ent, L.samp}) {
+        if (!p) continue;
+        for (size_t i = 0; i < ix->allocs.size(); ++i)
+            if (ix->allocs[i].p == p) { ix->hbm_bytes -= ix->allocs[i].bytes; ix->allocs.erase(ix->allocs.begin() + static_cast<std::ptrdiff_t>(i)); break; }
+        (void)hipFree(p);
+    }
+    L = ComposedLevel();
+}
+std::vector<SymTable> &kmer_level_tables(HostIndex &h, uint32_t depth) { return depth == 2 ? h.pair : depth == 3 ? h.triple : depth == 4 ? h.quad : h.quint; }
+uint32_t depth_of_level(const HostIndex &h, const std::vector<SymTable> *lvl) { return lvl == &h.pair ? 2 : lvl == &h.triple ? 3 : lvl == &h.quad ? 4 : 5; }
+void drop_kmer_level(rbg_index *ix, std::vector<SymTable> &lvl) {
+    release_kmer_level(ix, depth_of_level(ix->H(), &lvl));
+    std::vector<SymTable>().swap(lvl);
+}
+
+// Depths 2 .. kmer_deferred composed on the device (k_compose.hip) from the depth-1 tables of the k-mer alphabet and the
+// BWT's own runs; the host tables get their metadata (runs, total, F, bucket shift) and pointers into the level arrays.
+// Without the memory for it (or with RBG_HOST_COMPOSE=1 at flatten time) the host composes as before.
+template <typename P>
+int compose_on_device(rbg_index *ix) {
+    HostIndex &h = ix->H();
+    const uint32_t M = h.nmajor, K = h.kmer_deferred;
+    h.kmer_deferred = 0;
+    if (M < 1 || K < 2) return RBG_OK;
+    const FlattenOptions opt = current_options();
+    const auto t0 = std::chrono::steady_clock::now();
+    struct Hold {
+        std::vector<void *> p;
+        ~Hold() { for (void *q : p) if (q) (void)hipFree(q); }
+        int put(const void *src, size_t bytes, void **out) {
+            void *d = nullptr;
+            hipError_t e = hipMalloc(&d, bytes ? bytes : 16);
+            if (e != hipSuccess) { (void)hipGetLastError(); return e == hipErrorOutOfMemory ? RBG_ENOMEM : RBG_ENODEV; }
+            p.push_back(d);
+            if (bytes && hipMemcpy(d, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return RBG_ENODEV;
+            *out = d;
+            return RBG_OK;
+        }
+    } hold;
+    int rc = RBG_OK;
+    ComposeTable major[4];
+    for (uint32_t m = 0; m < M && !rc; ++m) {
+        const SymTable &t = h.sym[h.major_slot[m]];
+        PreparedSym<P> ps;
+        prepare_sym<P>(t, h.has_tsa, ps);
+        void *de = nullptr, *dsp = nullptr;
+        rc = hold.put(ps.ent.data(), ps.ent.size() * sizeof(RunEnt<P>), &de);
+        if (!rc && h.has_tsa) rc = hold.put(ps.samp.data(), ps.samp.size() * sizeof(P), &dsp);
+        major[m] = ComposeTable{de, dsp, t.nruns, t.total, t.F};
+    }
+    void *g_start = nullptr, *g_id = nullptr, *g_samp = nullptr;
+    if (!rc) {   // depth 1: the BWT runs themselves, id = major index of the head, sample = samples_last_ (SA - 1)
+        std::vector<P> gs(h.r + 1);
+        std::vector<uint32_t> gi(h.r);
+        for (uint64_t g = 0; g <= h.r; ++g) gs[g] = static_cast<P>(h.run_start[g]);
+        for (uint64_t g = 0; g < h.r; ++g) { const uint8_t m = h.major_of[h.run_heads[g]]; gi[g] = m == 0xFF ? 0xFFFFFFFFu : m; }
+        rc = hold.put(gs.data(), gs.size() * sizeof(P), &g_start);
+        if (!rc) rc = hold.put(gi.data(), gi.size() * 4, &g_id);
+        if (!rc && h.has_tsa) {
+            std::vector<P> sp(h.r);
+            for (uint64_t g = 0; g < h.r; ++g) sp[g] = static_cast<P>(h.samples_last[g]);
+            rc = hold.put(sp.data(), sp.size() * sizeof(P), &g_samp);
+        }
+    }
+    std::vector<ComposedLevel> levels;
+    if (!rc) rc = compose_levels_device(sizeof(P), h.n, M, major, g_start, static_cast<const uint32_t *>(g_id), g_samp, h.r, K, h.has_tsa, levels, nullptr);
+    if (rc == RBG_ENOMEM || rc == RBG_ENODEV) {   // not enough HBM for the sweeps' temporaries: the host composes instead
+        for (ComposedLevel &L : levels) { if (L.ent) (void)hipFree(L.ent); if (L.samp) (void)hipFree(L.samp); }
+        (void)hipGetLastError();
+        std::fprintf(stderr, "rbg: composing the k-mer tables on the device failed (%s): composing on the host\n", rbg_strerror(rc));
+        return compose_kmer_tables_host(h, static_cast<int>(K), opt);
+    }
+    if (rc) {
+        for (ComposedLevel &L : levels) { if (L.ent) (void)hipFree(L.ent); if (L.samp) (void)hipFree(L.samp); }
+        return rc;
+    }
+    ix->kmer_levels = std::move(levels);
+    for (uint32_t d = 2; d <= K; ++d) {
+        ComposedLevel &L = ix->kmer_levels[d - 2];
+        ix->allocs.push_back({L.ent, (L.entries + 2) * sizeof(RunEnt<P>)});
+        ix->hbm_bytes += (L.entries + 2) * sizeof(RunEnt<P>);
+        if (L.samp) { ix->allocs.push_back({L.samp, (L.entries + 2) * sizeof(P)}); ix->hbm_bytes += (L.entries + 2) * sizeof(P); }
+        std::vector<SymTable> &tabs = kmer_level_tables(h, d);
+        tabs.assign(L.nruns.size(), SymTable());
+        for (size_t t = 0; t < tabs.size(); ++t) {
+            SymTable &st = tabs[t];
+            st.byte = h.major_byte[t % M];
+            st.nruns = L.nruns[t];
+            st.total = L.total[t];
+            st.F = L.F[t];
+            st.shift = kmer_table_shift(h.n, st.nruns, d, opt);
+            if (st.shift > 12 || (st.shift > 8 && (h.n >> 40))) return RBG_EARG;  // wide buckets carry 40-bit ranks (rbg_dev.h)
+            if (st.nruns >= 0xFFFFFFF0ull) return RBG_EARG;
+            st.dev_ent = static_cast<const char *>(L.ent) + L.first[t] * sizeof(RunEnt<P>);
+            st.dev_samp = L.samp ? static_cast<const char *>(L.samp) + L.first[t] * sizeof(P) : nullptr;
+        }
+    }
+    if (std::getenv("RBG_VERBOSE"))
+        std::fprintf(stderr, "rbg: k-mer tables composed on the device %.2f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    return RBG_OK;
+}
+
+// the run-indexed layout builds its directories and sampled levels on the host: bring the composed levels back as host
+// tables (and give their device arrays back; upload_tables_runs uploads its own)
+template <typename P>
+int materialize_kmer_levels(rbg_index *ix) {
+    HostIndex &h = ix->H();
+    for (uint32_t d = 2; d <= 5; ++d) {
+        if (d - 2 >= ix->kmer_levels.size() || !ix->kmer_levels[d - 2].ent) continue;
+        ComposedLevel &L = ix->kmer_levels[d - 2];
+        std::vector<SymTable> &tabs = kmer_level_tables(h, d);
+        if (tabs.empty()) { release_kmer_level(ix, d); continue; }
+        std::vector<RunEnt<P>> ent(L.entries);
+        std::vector<P> samp(L.samp ? L.entries : 0);
+        HIP_TRY(hipMemcpy(ent.data(), L.ent, L.entries * sizeof(RunEnt<P>), hipMemcpyDeviceToHost));
+        if (L.samp) HIP_TRY(hipMemcpy(samp.data(), L.samp, L.entries * sizeof(P), hipMemcpyDeviceToHost));
+        const size_t W = std::max<size_t>(1, std::min<size_t>({16, std::thread::hardware_concurrency(), tabs.size()}));
+        std::vector<std::thread> workers;
+        for (size_t w = 0; w < W; ++w)
+            workers.emplace_back([&, w] {
+                for (size_t t = w; t < tabs.size(); t += W) {
+                    SymTable &st = tabs[t];
+                    const uint64_t f = L.first[t];
+                    st.start.resize(st.nruns + 1); st.cum.resize(st.nruns + 1);
+                    for (uint64_t k = 0; k <= st.nruns; ++k) { st.start[k] = ent[f + k].start; st.cum[k] = ent[f + k].cum; }
+                    if (L.samp) { st.samp.resize(st.nruns); for (uint64_t k = 0; k < st.nruns; ++k) st.samp[k] = samp[f + k]; }
+                    st.dev_ent = st.dev_samp = nullptr;
+                }
+            });
+        for (auto &w : workers) w.join();
+        release_kmer_level(ix, d);
+    }
+    return RBG_OK;
+}
+
 int upload(rbg_index *ix) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ix->device < 0 || ix->device >= ndev) {
@@ -836,6 +993,10 @@ int upload(rbg_index *ix) {
     d.has_tsa = h.has_tsa ? 1 : 0;
     d.last_run_sample = h.last_run_sample;
     d.phi_shift = h.phi_shift;
+    if (h.kmer_deferred) {   // depths 2.. composed on the device (flatten() only chose the k-mer alphabet)
+        const int rcc = h.pos_bytes == 4 ? compose_on_device<uint32_t>(ix) : compose_on_device<uint64_t>(ix);
+        if (rcc) return rcc;
+    }
     // The k-mer tables buy speed with memory: keep the deepest level that leaves a
     // quarter of the free HBM (or RBG_OPT_HBM_BUDGET_MB) to the caller's read / result buffers.
     size_t free_b = 0, total_b = 0;
@@ -872,7 +1033,7 @@ int upload(rbg_index *ix) {
             std::vector<SymTable> &deepest = !h.quint.empty() ? h.quint : !h.quad.empty() ? h.quad : !h.triple.empty() ? h.triple : h.pair;
             std::fprintf(stderr, "rbg: run-indexed replica of %.1f GB exceeds the %.1f GB budget: dropping the %zu-table k-mer level\n",
                          need_runs() / 1e9, budget / 1e9, deepest.size());
-            std::vector<SymTable>().swap(deepest);
+            drop_kmer_level(ix, deepest);
         }
     }
     ix->kmer_steps_requested = std::max<uint64_t>(ix->kmer_steps_requested, static_cast<uint64_t>(levels()));  // options_for() may have capped the depth already
@@ -908,7 +1069,7 @@ int upload(rbg_index *ix) {
         std::vector<SymTable> &deepest = !h.quint.empty() ? h.quint : !h.quad.empty() ? h.quad : !h.triple.empty() ? h.triple : h.pair;
         std::fprintf(stderr, "rbg: replica of %.1f GB exceeds the %.1f GB budget: dropping the %zu-table k-mer level\n",
                      need() / 1e9, budget / 1e9, deepest.size());
-        std::vector<SymTable>().swap(deepest);
+        drop_kmer_level(ix, deepest);
     }
     if (std::getenv("RBG_VERBOSE") || static_cast<uint64_t>(levels()) != ix->kmer_steps_requested)
         std::fprintf(stderr, "rbg: device %d: %.1f GB free, replica budget %.1f GB: keeping %d of %llu symbol(s) per %s (%.1f GB)\n", ix->device,
@@ -921,7 +1082,8 @@ int upload(rbg_index *ix) {
         rc = h.pos_bytes == 4 ? upload_tables_runs<uint32_t>(ix) : upload_tables_runs<uint64_t>(ix);
         if (rc) return rc;
     } else {
-        ix->arena_bytes = need();
+        ix->arena_bytes = h.pos_bytes == 4 ? replica_bytes<uint32_t>(h, true) : replica_bytes<uint64_t>(h, true);   // (without the lists that are on the device already)
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
         if (ix->arena_bytes > free_b) {
             std::fprintf(stderr, "rbg: index needs %.1f GB of HBM, %.1f GB free\n", ix->arena_bytes / 1e9, free_b / 1e9);
             return RBG_ENOMEM;
@@ -990,6 +1152,13 @@ FlattenOptions current_options() {
 // anyway, and composing the deepest level is the most expensive part of flatten() (47 of 76 s at n = 5e10).  The bound
 // is conservative: a level upload() could keep is never excluded.  *requested = the depth asked for when it was
 // capped here (else 0: upload() reports what flatten() composed).
+// the k-mer tables of an index that goes to a device are composed there (RBG_HOST_COMPOSE=1: on the host, the reference
+// statement -- A/B measurements and the test that compares the two)
+bool compose_deferred(int device) {
+    const char *e = std::getenv("RBG_HOST_COMPOSE");
+    return device != RBG_DEVICE_NONE && !(e && e[0] == '1');
+}
+
 FlattenOptions options_for(int device, const RawRle &rle, uint64_t *requested) {
     FlattenOptions o = current_options();
     *requested = 0;
@@ -1284,7 +1453,9 @@ int ftab_stream(rbg_index *ix, uint64_t k, Sink sink) {
 int index_from_bundle(FlatBundle &b, int device, rbg_index **out) {
     rbg_index *ix = new (std::nothrow) rbg_index();
     if (!ix) return RBG_ENOMEM;
-    int rc = flatten(b.rle, b.has_tsa ? &b.tsa : nullptr, options_for(device, b.rle, &ix->kmer_steps_requested), ix->host);
+    FlattenOptions fo = options_for(device, b.rle, &ix->kmer_steps_requested);
+    fo.defer_kmer = compose_deferred(device);
+    int rc = flatten(b.rle, b.has_tsa ? &b.tsa : nullptr, fo, ix->host);
     if (rc) { delete ix; return rc; }
     if (b.has_ma) { ix->H().ma = std::move(b.ma); ix->H().has_ma = true; }
     if (b.has_dl) { ix->H().dl = std::move(b.dl); ix->H().has_dl = true; }
@@ -1516,7 +1687,9 @@ int rbg_build_from_runs(const uint8_t *heads, const uint64_t *lens, uint64_t R, 
     }
     rbg_index *ix = new (std::nothrow) rbg_index();
     if (!ix) return RBG_ENOMEM;
-    int rc = flatten(rle, ssa_y ? &tsa : nullptr, options_for(device, rle, &ix->kmer_steps_requested), ix->host);
+    FlattenOptions fo = options_for(device, rle, &ix->kmer_steps_requested);
+    fo.defer_kmer = compose_deferred(device);
+    int rc = flatten(rle, ssa_y ? &tsa : nullptr, fo, ix->host);
     if (rc) { delete ix; return rc; }
     return finish(ix, device, out);
     });

@@ -6,6 +6,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <vector>
 
 namespace rbg {
 
@@ -286,6 +287,23 @@ inline SeedLog make_seed_log(void *scratch, size_t bytes, uint64_t N, uint32_t p
     lg.nsel = reinterpret_cast<uint32_t *>(lg.base + ((N * lg.stride + 15) & ~size_t(15)));
     return lg;
 }
+
+// ---- k-mer tables composed on the device at load time (k_compose.hip) ---------------------------------------------------
+struct ComposeTable {       // one major symbol's own (depth-1) table, resident on the device
+    const void *ent;        // RunEnt<P>[nruns + 1]
+    const void *samp;       // P[nruns] or nullptr
+    uint64_t nruns, total, F;
+};
+struct ComposedLevel {      // one k-mer depth: its tables back to back in table order, each closed by its sentinel {n, total}
+    void *ent = nullptr;    // RunEnt<P>[entries + 2] (hipMalloc; the caller owns it)
+    void *samp = nullptr;   // P[entries + 2] or nullptr
+    uint64_t entries = 0;   // runs of all tables + one sentinel per table
+    std::vector<uint64_t> nruns, total, F, first;   // per table; first = index of its first entry
+};
+// depths 2 .. kmax from the depth-1 tables of the M major symbols and the depth-1 segmentation (g_start[g_n + 1] with
+// sentinel n, g_id[g_n] = major index or 0xFFFFFFFF, g_samp[g_n] = samples_last or nullptr); returns an RBG_* code
+int compose_levels_device(uint32_t pos_bytes, uint64_t n, uint32_t M, const ComposeTable *major, const void *g_start, const uint32_t *g_id,
+                          const void *g_samp, uint64_t g_n, uint32_t kmax, bool with_samples, std::vector<ComposedLevel> &out, void *stream);
 
 struct LaunchCfg {
     int block_threads = 256;

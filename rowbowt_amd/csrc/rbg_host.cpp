@@ -644,6 +644,15 @@ uint32_t auto_shift(uint64_t n, uint64_t items, double per_slot) {
 // segmentation G_d of [0,n) by depth-d id; every overlap piece is one depth-(d+1) run.  The SA value
 // at a piece's last row is known: either its LF image ends a G_d segment (that segment's sample), or
 // the row ends the c-run (that run's samples_last_ minus d).
+}  // namespace
+
+uint32_t kmer_table_shift(uint64_t n, uint64_t nruns, uint32_t depth, const FlattenOptions &opt) {
+    uint32_t s = opt.rank_bucket_shift >= 0 ? static_cast<uint32_t>(opt.rank_bucket_shift) : auto_shift(n, nruns, 1.5);
+    if (depth >= 4 && opt.deep_bucket_shift >= 0) s = static_cast<uint32_t>(opt.deep_bucket_shift);  // levels of 4-mers and deeper
+    return s;
+}
+
+namespace {
 struct Segmentation {          // row-ordered cover of [0,n): segment g = [start[g], start[g+1])
     std::vector<uint64_t> start;  // + sentinel n
     std::vector<uint32_t> id;     // depth-d table index, or kNoId
@@ -751,8 +760,7 @@ int compose(const HostIndex &ix, const std::vector<uint32_t> &major_slot, const 
             uint64_t rk = 0;
             if (kk > 0) rk = tp.cum[kk - 1] + std::min(i - tp.start[kk - 1], tp.cum[kk] - tp.cum[kk - 1]);
             t.F = tp.F + rk;
-            t.shift = opt.rank_bucket_shift >= 0 ? static_cast<uint32_t>(opt.rank_bucket_shift) : auto_shift(ix.n, t.nruns, 1.5);
-            if (depth + 1 >= 4 && opt.deep_bucket_shift >= 0) t.shift = static_cast<uint32_t>(opt.deep_bucket_shift);  // levels of 4-mers and deeper
+            t.shift = kmer_table_shift(ix.n, t.nruns, depth + 1, opt);
             if (t.shift > 12 || (t.shift > 8 && (ix.n >> 40))) { rcs[m] = RBG_EARG; return; }  // wide buckets carry 40-bit ranks (rbg_dev.h)
             if (t.nruns >= 0xFFFFFFF0ull) { rcs[m] = RBG_EARG; return; }
         }
@@ -803,17 +811,19 @@ int compose(const HostIndex &ix, const std::vector<uint32_t> &major_slot, const 
     return RBG_OK;
 }
 
-int build_kmer_tables(HostIndex &out, const RawTsa *tsa, const FlattenOptions &opt) {
+// the k-mer alphabet: the <= 4 most frequent non-terminator symbols; false = no k-mer steps for this index
+bool choose_major(HostIndex &out, const FlattenOptions &opt) {
     std::memset(out.major_of, 0xFF, sizeof(out.major_of));
     out.nmajor = 0;
+    out.major_slot.clear();
     out.pair.clear();
     out.triple.clear();
     out.quad.clear();
     out.quint.clear();
-    if (opt.kmer_steps < 2 || out.sigma < 2) return RBG_OK;
+    if (opt.kmer_steps < 2 || out.sigma < 2) return false;
     // the terminator: the smallest symbol, occurring once (rle_string.hpp:59,62 maps 0 -> 1).
     // Without one the wrap argument of DESIGN.md 2b does not hold: keep single steps only.
-    if (out.sym[0].total != 1) return RBG_OK;
+    if (out.sym[0].total != 1) return false;
     std::vector<uint32_t> order;
     for (uint32_t s = 1; s < out.sigma; ++s) order.push_back(s);
     std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
@@ -827,6 +837,29 @@ int build_kmer_tables(HostIndex &out, const RawTsa *tsa, const FlattenOptions &o
         out.major_byte[m] = out.sym[order[m]].byte;
         out.major_of[out.sym[order[m]].byte] = static_cast<uint8_t>(m);
     }
+    out.major_slot = order;
+    return true;
+}
+
+int build_kmer_tables(HostIndex &out, const RawTsa *tsa, const FlattenOptions &opt) {
+    if (!choose_major(out, opt)) return RBG_OK;
+    if (opt.defer_kmer) { out.kmer_deferred = static_cast<uint32_t>(std::min(5, opt.kmer_steps)); return RBG_OK; }
+    return compose_kmer_tables_host(out, opt.kmer_steps, opt);
+}
+}  // namespace
+
+int compose_kmer_tables_host(HostIndex &out, int kmer_steps, const FlattenOptions &opt_in) {
+    FlattenOptions opt = opt_in;
+    opt.kmer_steps = kmer_steps;
+    out.pair.clear(); out.triple.clear(); out.quad.clear(); out.quint.clear();
+    out.kmer_deferred = 0;
+    if (out.nmajor == 0 || kmer_steps < 2) return RBG_OK;
+    RawTsa tsa_view;   // compose() only needs samples_last
+    const RawTsa *tsa = nullptr;
+    if (out.has_tsa) { tsa_view.samples_last = out.samples_last; tsa = &tsa_view; }
+    {
+    const std::vector<uint32_t> order = out.major_slot;
+    const uint32_t M = out.nmajor;
     // depth 1: the BWT runs themselves, id = major index of the head, sample = samples_last_ (SA - 1)
     Segmentation G;
     G.start = out.run_start;
@@ -855,8 +888,8 @@ int build_kmer_tables(HostIndex &out, const RawTsa *tsa, const FlattenOptions &o
         if (rc) return rc;
     }
     return RBG_OK;
+    }
 }
-}  // namespace
 
 namespace {
 struct StageTimer {

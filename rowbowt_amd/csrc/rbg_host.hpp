@@ -86,6 +86,9 @@ struct SymTable {
     uint64_t nruns = 0, total = 0, F = 0;
     std::vector<uint64_t> start, cum;  // nruns + 1 (sentinel: start = n, cum = total)
     std::vector<uint64_t> samp;        // nruns or empty
+    // a k-mer table composed on the device (k_compose.hip): the arrays above stay empty, the run list lives in HBM
+    // as {start, cum} pairs of the position width (+ sentinel) and its samples beside it
+    const void *dev_ent = nullptr, *dev_samp = nullptr;
 };
 
 struct HostIndex {
@@ -109,6 +112,10 @@ struct HostIndex {
     std::vector<SymTable> triple;      // nmajor^3, or empty
     std::vector<SymTable> quad;        // nmajor^4, or empty
     std::vector<SymTable> quint;       // nmajor^5, or empty
+    // > 0: flatten() only chose the k-mer alphabet and left the composition of depths 2 .. kmer_deferred to the device
+    // (FlattenOptions::defer_kmer; rbg_capi.hip upload() runs k_compose.hip before it sizes the replica)
+    uint32_t kmer_deferred = 0;
+    std::vector<uint32_t> major_slot;  // symbol slot of each major symbol, ascending
     bool has_tsa = false;
     uint64_t last_run_sample = 0;      // toehold_sa.hpp:97-99
     std::vector<uint64_t> samples_last, pred_pos, phi_base;
@@ -125,8 +132,14 @@ struct FlattenOptions {
     int phi_bucket_shift = -1;
     int force_pos_bytes = 0;     // 0: 4 when n fits, else 8
     int kmer_steps = 5;          // symbols consumed per gather: 1 (reference shape) .. 5
+    bool defer_kmer = false;     // choose the k-mer alphabet but leave the tables of depth >= 2 to the device (HostIndex::kmer_deferred)
 };
 
 int flatten(const RawRle &rle, const RawTsa *tsa, const FlattenOptions &opt, HostIndex &out);
+// depths 2 .. kmer_steps on the host from a flattened index (the reference statement of the composition; what
+// flatten() runs itself unless defer_kmer is set)
+int compose_kmer_tables_host(HostIndex &ix, int kmer_steps, const FlattenOptions &opt);
+// bucket shift of a table with `nruns` runs under the options (what compose() gives the tables it makes)
+uint32_t kmer_table_shift(uint64_t n, uint64_t nruns, uint32_t depth, const FlattenOptions &opt);
 
 }  // namespace rbg

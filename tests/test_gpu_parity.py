@@ -360,6 +360,52 @@ def test_marker_seeds_logged_fill(synth, layout):
     o.close()
 
 
+@pytest.mark.parametrize("pos_bytes", [4, 8])
+def test_device_compose_matches_host_compose(synth, pos_bytes):
+    """The k-mer tables of DESIGN.md 2b are composed on the device at load time (k_compose.hip: merges, sorts and scans
+    over the run lists); rbg_host.cpp compose() is the same statement as serial host code (RBG_HOST_COMPOSE=1).  Same
+    tables -- runs per level, replica size -- and the same answers, toeholds of k-mer steps included (nested LF_w_loc,
+    rowbowt.hpp:555-573), on both layouts; a reference-built index (tests/data) likewise."""
+    S = synth
+    reads = S.sample_reads(4000, 90, seed=77, sub_rate=0.12, ragged=True) + [b"", b"ACGTN", S.text[:400].tobytes()]
+    seqs, off = ra.pack_reads(reads)
+    o = orc.Oracle.from_runs(S.heads, S.lens, S.ssa, S.esa)
+    wlo, whi, wk = o.find_range_w_toehold_batch(seqs, off)
+    woff, wlocs = o.locs_at_batch(wlo, whi, wk)
+    for layout in (capi.LAYOUT_SLOTS, capi.LAYOUT_RUNS):
+        infos = []
+        for host in ("1", None):
+            if host:
+                os.environ["RBG_HOST_COMPOSE"] = host
+            try:
+                with capi.default_option(capi.OPT_POS_BYTES, pos_bytes):
+                    rb = _with_layout(layout, 48, lambda: ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0))
+            finally:
+                os.environ.pop("RBG_HOST_COMPOSE", None)
+            i = rb.info()
+            infos.append((i.kmer_steps, i.pair_runs, i.triple_runs, i.quad_runs, i.quint_runs, i.rank_slots_overflow))
+            assert i.kmer_steps == 5 and i.pos_bytes == pos_bytes
+            lo, hi, k = rb.find_range_w_toehold(seqs, off)
+            assert (lo == wlo).all() and (hi == whi).all() and (k == wk).all()
+            loc_off, locs = rb.locs_at(lo, hi, k)
+            assert (loc_off == woff).all() and (locs == wlocs).all()
+            for ks in (2, 3, 4):   # fewer levels asked for: only those are composed
+                with capi.default_option(capi.OPT_KMER_STEPS, ks), capi.default_option(capi.OPT_POS_BYTES, pos_bytes):
+                    if host:
+                        os.environ["RBG_HOST_COMPOSE"] = host
+                    try:
+                        rb2 = _with_layout(layout, 48, lambda: ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0))
+                    finally:
+                        os.environ.pop("RBG_HOST_COMPOSE", None)
+                assert rb2.info().kmer_steps == ks
+                lo2, hi2, k2 = rb2.find_range_w_toehold(seqs, off)
+                assert (lo2 == wlo).all() and (hi2 == whi).all() and (k2 == wk).all()
+                rb2.close()
+            rb.close()
+        assert infos[0] == infos[1], infos
+    o.close()
+
+
 def test_single_LF_steps(small, synth):
     """RowBowt::LF (rowbowt.hpp:74-88) one step at a time, against the oracle's LF."""
     rb, o = small
