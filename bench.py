@@ -78,6 +78,9 @@ def parse():
                          "that a profile of the default command holds undisturbed per-kernel durations)")
     ap.add_argument("--no-space-speed", action="store_true",
                     help="skip the space_speed block (the replica rebuilt at 4, 3, 2 and 1 symbols per gather; about a minute)")
+    ap.add_argument("--via-cache", action="store_true",
+                    help="build the replica through the native cache file even on one GPU (with --gpus N > 1 every rank does: rank 0 "
+                         "writes it to node-local shared memory once, all ranks load it)")
     ap.add_argument("--property-reads", type=int, default=1_000_000,
                     help="reads whose every reported location is checked against the text on the GPU (size-independent property)")
     return ap.parse_args()
@@ -146,19 +149,41 @@ def main():
 
     # ---- synthesis (outside the timed region) --------------------------------------------------
     t0 = time.time()
-    text, info = sp.make_text(args.L, args.H, args.site_rate, args.seed, dev)
-    sa = sp.suffix_array(text)
-    torch.cuda.synchronize()
-    t_sa = time.time() - t0
-    inp = sp.index_inputs(text, sa)
-    marker_arrays = sp.marker_array(text, info, sa, w=10) if args.markers else None
-    del sa
-    torch.cuda.empty_cache()
-    log(rank, f"synthetic pangenome: L={args.L} H={args.H} n={inp['n']} r={inp['r']} n/r={inp['n'] / inp['r']:.1f} "
-              f"(suffix array {t_sa:.1f}s)")
+    text, info = sp.make_text(args.L, args.H, args.site_rate, args.seed, dev)   # (every rank: its reads are sampled from it)
+    # The index is made ONCE per node: rank 0 builds the suffix array and the run-length BWT and writes the native cache
+    # file (rbg_convert_runs) to node-local shared memory; every rank then loads its replica from it (rbg_load_cache).
+    cache_path = None
+    if world > 1 or args.via_cache:
+        shm = "/dev/shm" if os.path.isdir("/dev/shm") else (os.environ.get("TMPDIR") or "/tmp")
+        cache_path = os.path.join(shm, f"rbg_bench_{os.environ.get('MASTER_PORT', '0')}_{args.L}_{args.H}_{args.seed}.rbgpu")
+    inp, marker_arrays, t_sa = None, None, 0.0
+    if rank == 0 or world == 1:
+        sa = sp.suffix_array(text)
+        torch.cuda.synchronize()
+        t_sa = time.time() - t0
+        inp = sp.index_inputs(text, sa)
+        marker_arrays = sp.marker_array(text, info, sa, w=10) if args.markers else None
+        del sa
+        torch.cuda.empty_cache()
+        log(rank, f"synthetic pangenome: L={args.L} H={args.H} n={inp['n']} r={inp['r']} n/r={inp['n'] / inp['r']:.1f} "
+                  f"(suffix array {t_sa:.1f}s)")
+        if cache_path:
+            from rowbowt_amd import capi as _capi
+            _capi.convert_runs(inp["heads"], inp["lens"], inp["ssa"], inp["esa"], out_path=cache_path)
     t0 = time.time()
-    rb = ra.RowBowt.from_runs(inp["heads"], inp["lens"], inp["ssa"], inp["esa"], device=local_rank)
+    if cache_path:
+        if use_dist:
+            dist.barrier()   # the file is complete
+        rb = ra.RowBowt.from_cache(cache_path, ra.LoadRbwtFlag.SA, device=local_rank)
+        if use_dist:
+            dist.barrier()   # every rank has read it
+        if rank == 0:
+            os.unlink(cache_path)
+    else:
+        rb = ra.RowBowt.from_runs(inp["heads"], inp["lens"], inp["ssa"], inp["esa"], device=local_rank)
     ix = rb.info()
+    if inp is None:   # (ranks > 0: what the line's config block and the checks need is on rank 0 only)
+        inp = {"n": int(ix.n), "r": int(ix.r)}
     log(rank, f"index replica: {ix.hbm_bytes / 1e6:.1f} MB HBM, pos_bytes={ix.pos_bytes}, sigma={ix.sigma}, "
               f"flatten+upload {time.time() - t0:.1f}s")
 

@@ -95,6 +95,10 @@ int rbg_convert_index(const char *prefix, int flags, const char *out_path);
 int rbg_convert_raw(const char *bwt_fname, const char *ssa_fname, const char *esa_fname, const char *mab_fname,
                     const char *docs_fname, const char *out_path);
 int rbg_load_cache(const char *path, int flags, int device, rbg_index **out);
+/* the cache file from a run-length BWT in memory (the arguments of rbg_build_from_runs): for builders that never write
+ * the BWT as text, and for handing one index to the ranks of a node (rank 0 writes, every rank rbg_load_cache's) */
+int rbg_convert_runs(const uint8_t *heads, const uint64_t *lens, uint64_t R, const uint64_t *ssa_y /* nullable, with esa_y */,
+                     const uint64_t *esa_y, const char *out_path);
 /* RowBowt::build_ftab(k) + FTab::serialize (rowbowt.hpp:726-744, ftab.hpp:29-34): the reference's
  * text .ftab ("<kmer> <lo> <hi>" per line, lexicographic), computed with the search kernel. 1 <= k <= 16. */
 int rbg_write_ftab(rbg_index *, uint64_t k, const char *path);

@@ -16,6 +16,8 @@
 // table (runs, total, F).
 #include "rbg_device.hpp"
 
+#include <chrono>
+#include <cstdlib>
 #include <vector>
 
 namespace rbg {
@@ -32,12 +34,50 @@ constexpr uint32_t kNoTab = 0xFFFFFFFFu;
         }                                                                                \
     } while (0)
 
-// RAII device temporary
+// The sweeps' temporaries come from a pool that lives for one composition: a block that is given back is handed out again
+// to the next request it fits (blocks are allocated a quarter larger than asked, so the next depth's slightly longer arrays
+// fit the previous depth's blocks), and everything goes back to the driver at the end.  hipMalloc / hipFree of multi-GB
+// blocks stall unpredictably on this platform (tools/alloc_probe.py: seconds), and the first version of this file spent
+// 4.5 of its 5 s at n = 5e10 in them.
+struct Pool {
+    struct Blk { void *p; size_t bytes; bool used; };
+    std::vector<Blk> blks;
+    ~Pool() { for (Blk &b : blks) (void)hipFree(b.p); }
+    hipError_t get(size_t bytes, void **out) {
+        if (bytes == 0) bytes = 16;
+        Blk *best = nullptr;
+        for (Blk &b : blks)
+            if (!b.used && b.bytes >= bytes && (!best || b.bytes < best->bytes)) best = &b;
+        if (best) { best->used = true; *out = best->p; return hipSuccess; }
+        const size_t want = bytes + bytes / 4 + 256;
+        void *p = nullptr;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {   // give the idle blocks back and ask for exactly what is needed
+            (void)hipGetLastError();
+            for (size_t i = 0; i < blks.size();)
+                if (!blks[i].used) { (void)hipFree(blks[i].p); blks.erase(blks.begin() + static_cast<std::ptrdiff_t>(i)); } else ++i;
+            e = hipMalloc(&p, bytes);
+            if (e != hipSuccess) return e;
+            blks.push_back({p, bytes, true});
+        } else {
+            blks.push_back({p, want, true});
+        }
+        *out = p;
+        return hipSuccess;
+    }
+    void put(void *p) {
+        for (Blk &b : blks)
+            if (b.p == p) { b.used = false; return; }
+    }
+};
+thread_local Pool *t_pool = nullptr;
+
+// RAII device temporary (from the composition's pool)
 struct Tmp {
     void *p = nullptr;
-    ~Tmp() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t bytes) { if (p) { (void)hipFree(p); p = nullptr; } return hipMalloc(&p, bytes ? bytes : 16); }
-    void release() { if (p) (void)hipFree(p); p = nullptr; }
+    ~Tmp() { release(); }
+    hipError_t alloc(size_t bytes) { release(); return t_pool->get(bytes, &p); }
+    void release() { if (p) t_pool->put(p); p = nullptr; }
     template <typename T> T *as() const { return static_cast<T *>(p); }
 };
 
@@ -287,8 +327,12 @@ int compose_impl(const uint64_t n, const uint32_t M, const ComposeTable *major, 
     CK(d_err.alloc(sizeof(int)));
     CK(hipMemsetAsync(d_err.p, 0, sizeof(int), st));
     uint32_t n_ids = M;
+    const bool verbose = std::getenv("RBG_VERBOSE") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
     for (uint32_t depth = 1; depth < kmax; ++depth, n_ids *= M) {
         const uint32_t T = n_ids * M;
+        const auto t_lvl = now();
         // ---- pieces of every symbol -------------------------------------------------------------------------------------
         // which G segments a symbol's image [F, F + total) meets: two binary searches per symbol, made from the host over the
         // device array (a few dozen 8-byte copies per level)
@@ -359,6 +403,7 @@ int compose_impl(const uint64_t n, const uint32_t M, const ComposeTable *major, 
             keep[m].release();
             posB[m].release();
         }
+        const auto t_pieces = now();
         // ---- tables: stable sort by table, cum by one scan ------------------------------------------------------------------
         Tmp iota, s_tab, perm;
         CK(iota.alloc((np + 1) * 4));
@@ -424,6 +469,8 @@ int compose_impl(const uint64_t n, const uint32_t M, const ComposeTable *major, 
             Lv.total[t] = h_cum_at[t + 1] - h_cum_at[t];
             Lv.first[t] = h_first[t] + t;
         }
+        CK(hipStreamSynchronize(st));
+        const auto t_tables = now();
         // ---- the next depth's segmentation (not needed after the last level) ----------------------------------------------
         if (depth + 1 < kmax) {
             Tmp rkeys, rperm;
@@ -466,6 +513,10 @@ int compose_impl(const uint64_t n, const uint32_t M, const ComposeTable *major, 
         int h_err = 0;
         CK(hipMemcpy(&h_err, d_err.p, sizeof(int), hipMemcpyDeviceToHost));
         if (h_err) return -2;   // RBG_EFORMAT: a sample below the depth (the terminator inside a k-mer)
+        if (verbose)
+            std::fprintf(stderr, "rbg:   depth %u: %llu pieces, %llu runs in %u tables: pieces %.3f s, tables %.3f s, next segmentation %.3f s\n", depth + 1,
+                         static_cast<unsigned long long>(np), static_cast<unsigned long long>(nkept), T, secs(t_lvl, t_pieces), secs(t_pieces, t_tables),
+                         secs(t_tables, now()));
         // the tables just made are the next level's "previous" ones
         prev_ent.assign(T, nullptr); prev_nruns.assign(T, 0); prev_F.assign(T, 0);
         for (uint32_t t = 0; t < T; ++t) {
@@ -483,6 +534,8 @@ int compose_impl(const uint64_t n, const uint32_t M, const ComposeTable *major, 
 int compose_levels_device(uint32_t pos_bytes, uint64_t n, uint32_t M, const ComposeTable *major, const void *g_start, const uint32_t *g_id,
                           const void *g_samp, uint64_t g_n, uint32_t kmax, bool with_samples, std::vector<ComposedLevel> &out, void *stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
+    Pool pool;
+    struct Scope { Pool *prev; explicit Scope(Pool *p) : prev(t_pool) { t_pool = p; } ~Scope() { t_pool = prev; } } scope(&pool);
     return pos_bytes == 4 ? compose_impl<uint32_t>(n, M, major, g_start, g_id, g_samp, g_n, kmax, with_samples, out, st)
                           : compose_impl<uint64_t>(n, M, major, g_start, g_id, g_samp, g_n, kmax, with_samples, out, st);
 }

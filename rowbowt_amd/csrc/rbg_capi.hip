@@ -97,6 +97,19 @@ std::atomic<int64_t> g_opt_packed_reads{1};  // host-pointer calls: 0 bytes over
         }                                                                                         \
     } while (0)
 
+// RBG_VERBOSE: seconds a stage of a load took (device work is synchronised first when `sync`)
+struct VStage {
+    const char *what;
+    bool on, sync;
+    std::chrono::steady_clock::time_point t0;
+    explicit VStage(const char *w, bool sync_ = true) : what(w), on(std::getenv("RBG_VERBOSE") != nullptr), sync(sync_), t0(std::chrono::steady_clock::now()) {}
+    ~VStage() {
+        if (!on) return;
+        if (sync) (void)hipDeviceSynchronize();
+        std::fprintf(stderr, "rbg:   %s %.2f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    }
+};
+
 // RAII: make `device` current for the scope of one API call
 struct DeviceScope {
     int prev = -1;
@@ -290,14 +303,14 @@ template <typename P>
 void prepare_sym(const SymTable &t, bool with_samples, PreparedSym<P> &p) {
     if (t.dev_ent) return;   // composed on the device: the run list is there already
     p.ent.resize(t.nruns + 1);
-    for (uint64_t k = 0; k <= t.nruns; ++k) {
-        p.ent[k].start = static_cast<P>(t.start[k]);
-        p.ent[k].cum = static_cast<P>(t.cum[k]);
-    }
-    if (with_samples) {
-        p.samp.resize(t.nruns);
-        for (uint64_t k = 0; k < t.nruns; ++k) p.samp[k] = static_cast<P>(t.samp[k]);
-    }
+    if (with_samples) p.samp.resize(t.nruns);
+    parallel_for(t.nruns + 1, [&](uint64_t b, uint64_t e, unsigned) {
+        for (uint64_t k = b; k < e; ++k) {
+            p.ent[k].start = static_cast<P>(t.start[k]);
+            p.ent[k].cum = static_cast<P>(t.cum[k]);
+            if (with_samples && k < t.nruns) p.samp[k] = static_cast<P>(t.samp[k]);
+        }
+    }, uint64_t(1) << 18);
 }
 
 // upload the run list (+ samples); the RankSlot / ord tables are generated from it on the device
@@ -362,7 +375,10 @@ int upload_tables(rbg_index *ix) {
     ix->dev.dense = nullptr;
     unsigned long long *ovf = d_ovf.as<unsigned long long>();
     std::vector<DevSym> syms;
-    if ((rc = upload_many<P>(ix, h.sym, h.has_tsa, syms, ovf))) return rc;
+    {
+        VStage vs("depth-1 tables: run lists up, slot tables built");
+        if ((rc = upload_many<P>(ix, h.sym, h.has_tsa, syms, ovf))) return rc;
+    }
     const void *p = nullptr;
     rc = dev_upload(ix, syms.data(), syms.size() * sizeof(DevSym), &p);
     if (rc) return rc;
@@ -372,6 +388,7 @@ int upload_tables(rbg_index *ix) {
     ix->dev.kmer_steps = 1;
     if (!h.pair.empty()) {
         auto upload_set = [&](const std::vector<SymTable> &tabs, const DevSym **dst) -> int {
+            VStage vs("one k-mer level: slot tables built");
             std::vector<DevSym> recs;
             int r2 = upload_many<P>(ix, tabs, h.has_tsa, recs, ovf);
             if (r2) return r2;
@@ -402,12 +419,15 @@ int upload_tables(rbg_index *ix) {
         ix->dev.nmajor = h.nmajor;
     }
     if (h.has_tsa) {
+        VStage vs("phi: entries up, slots built");
         {
             std::vector<PhiEnt<P>> pe(h.r);
-            for (uint64_t j = 0; j < h.r; ++j) {
-                pe[j].pos = static_cast<P>(h.pred_pos[j]);
-                pe[j].base = static_cast<P>(h.phi_base[j]);
-            }
+            parallel_for(h.r, [&](uint64_t b, uint64_t e, unsigned) {
+                for (uint64_t j = b; j < e; ++j) {
+                    pe[j].pos = static_cast<P>(h.pred_pos[j]);
+                    pe[j].base = static_cast<P>(h.phi_base[j]);
+                }
+            });
             rc = dev_upload(ix, pe.data(), pe.size() * sizeof(PhiEnt<P>), &ix->dev.phi_ent);
             if (rc) return rc;
         }
@@ -431,6 +451,7 @@ int upload_tables(rbg_index *ix) {
     // dense table (rbg_dev.h).  The slots hold 32-bit offsets in 16-byte units: a pool beyond 64 GB (never seen:
     // 2.7 GB for the bench index) leaves the run-list search in place, as does an allocation failure.
     if (counts[2] > 0 && counts[2] < (1ull << 32)) {
+        VStage vs("dense tables of the overflow buckets");
         void *pool = nullptr;
         const size_t bytes = static_cast<size_t>(counts[2]) * 16 + 64;
         if (hipMalloc(&pool, bytes) == hipSuccess) {
@@ -886,18 +907,23 @@ int compose_on_device(rbg_index *ix) {
     }
     void *g_start = nullptr, *g_id = nullptr, *g_samp = nullptr;
     if (!rc) {   // depth 1: the BWT runs themselves, id = major index of the head, sample = samples_last_ (SA - 1)
-        std::vector<P> gs(h.r + 1);
+        std::vector<P> gs(h.r + 1), sp(h.has_tsa ? h.r : 0);
         std::vector<uint32_t> gi(h.r);
-        for (uint64_t g = 0; g <= h.r; ++g) gs[g] = static_cast<P>(h.run_start[g]);
-        for (uint64_t g = 0; g < h.r; ++g) { const uint8_t m = h.major_of[h.run_heads[g]]; gi[g] = m == 0xFF ? 0xFFFFFFFFu : m; }
+        gs[h.r] = static_cast<P>(h.run_start[h.r]);
+        parallel_for(h.r, [&](uint64_t b, uint64_t e, unsigned) {
+            for (uint64_t g = b; g < e; ++g) {
+                gs[g] = static_cast<P>(h.run_start[g]);
+                const uint8_t m = h.major_of[h.run_heads[g]];
+                gi[g] = m == 0xFF ? 0xFFFFFFFFu : m;
+                if (h.has_tsa) sp[g] = static_cast<P>(h.samples_last[g]);
+            }
+        });
         rc = hold.put(gs.data(), gs.size() * sizeof(P), &g_start);
         if (!rc) rc = hold.put(gi.data(), gi.size() * 4, &g_id);
-        if (!rc && h.has_tsa) {
-            std::vector<P> sp(h.r);
-            for (uint64_t g = 0; g < h.r; ++g) sp[g] = static_cast<P>(h.samples_last[g]);
-            rc = hold.put(sp.data(), sp.size() * sizeof(P), &g_samp);
-        }
+        if (!rc && h.has_tsa) rc = hold.put(sp.data(), sp.size() * sizeof(P), &g_samp);
     }
+    if (std::getenv("RBG_VERBOSE"))
+        std::fprintf(stderr, "rbg:   compose: depth-1 tables and runs converted and copied in %.2f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     std::vector<ComposedLevel> levels;
     if (!rc) rc = compose_levels_device(sizeof(P), h.n, M, major, g_start, static_cast<const uint32_t *>(g_id), g_samp, h.r, K, h.has_tsa, levels, nullptr);
     if (rc == RBG_ENOMEM || rc == RBG_ENODEV) {   // not enough HBM for the sweeps' temporaries: the host composes instead
@@ -1088,7 +1114,14 @@ int upload(rbg_index *ix) {
             std::fprintf(stderr, "rbg: index needs %.1f GB of HBM, %.1f GB free\n", ix->arena_bytes / 1e9, free_b / 1e9);
             return RBG_ENOMEM;
         }
-        HIP_TRY(hipMalloc(&ix->arena, ix->arena_bytes));
+        {
+            VStage vs("arena hipMalloc");
+            // (a platform cost: fresh VRAM is mapped and cleared at some 45-70 GB/s when the memory was freed shortly before --
+            //  2.7-7 s for the bench replica's 218 GB -- and next to nothing when it has been idle: tools/alloc_probe.py,
+            //  profiles/r03_load_time.txt.  Asking for the block from a helper thread while the host flattens and the
+            //  device composes was tried: the driver serialises the composition's own allocations behind it, no gain.)
+            HIP_TRY(hipMalloc(&ix->arena, ix->arena_bytes));
+        }
         ix->allocs.push_back({ix->arena, ix->arena_bytes});
         ix->hbm_bytes += ix->arena_bytes;
         ix->arena_used = 0;
@@ -1101,7 +1134,10 @@ int upload(rbg_index *ix) {
     const unsigned long long zero[4] = {0, 0, 0, 0};
     if ((rc = dev_upload(ix, zero, sizeof(zero), &p))) return rc;
     d.counters = const_cast<unsigned long long *>(static_cast<const unsigned long long *>(p));
-    if (h.has_ma && (rc = upload_markers(ix))) return rc;
+    if (h.has_ma) {
+        VStage vs("markers");
+        if ((rc = upload_markers(ix))) return rc;
+    }
     ix->cfg.block_threads = static_cast<int>(g_opt_block_threads.load());
     ix->cfg.max_blocks = prop.multiProcessorCount * 32;
     // ftab (next-row f3): built last, with the finished replica, by searching every word on the GPU
@@ -1114,6 +1150,7 @@ int upload(rbg_index *ix) {
         while (d.nmajor >= 2 && fk < 12 && w * d.nmajor <= static_cast<double>(h.n) / 16) { w *= d.nmajor; ++fk; }
     }
     if (fk > 0 && d.nmajor >= 2) {
+        VStage vs("ftab");
         double words = 1;
         for (int64_t t = 0; t < fk; ++t) words *= d.nmajor;
         size_t free_b = 0, total_b = 0;
@@ -1661,38 +1698,74 @@ int rbg_convert_raw(const char *bwt_fname, const char *ssa_fname, const char *es
     });
 }
 
+// a run-length BWT (+ both samples of every run) in memory -> the native cache file (what rbg_convert_raw writes for
+// the same index from its .bwt/.ssa/.esa files): for builders that never materialise the BWT as text -- n = 5e10 would be
+// a 50 GB .bwt -- and for handing one index to several processes of a node (bench.py: rank 0 writes, every rank loads)
+static int runs_to_bundle(const uint8_t *heads, const uint64_t *lens, uint64_t R, const uint64_t *ssa_y, const uint64_t *esa_y, FlatBundle &b);
+
+int rbg_convert_runs(const uint8_t *heads, const uint64_t *lens, uint64_t R, const uint64_t *ssa_y, const uint64_t *esa_y, const char *out_path) {
+    return guarded([&]() -> int {
+    if (!heads || !lens || !out_path || R == 0 || (!!ssa_y != !!esa_y)) return RBG_EARG;
+    FlatBundle b;
+    const int rc = runs_to_bundle(heads, lens, R, ssa_y, esa_y, b);
+    if (rc) return rc;
+    return write_flat(out_path, b);
+    });
+}
+
 int rbg_build_from_runs(const uint8_t *heads, const uint64_t *lens, uint64_t R, const uint64_t *ssa_y,
                         const uint64_t *esa_y, int device, rbg_index **out) {
     return guarded([&]() -> int {
     if (!heads || !lens || !out || R == 0 || (!!ssa_y != !!esa_y)) return RBG_EARG;
     *out = nullptr;
-    RawRle rle;
+    FlatBundle b;
+    const int rc0 = runs_to_bundle(heads, lens, R, ssa_y, esa_y, b);
+    if (rc0) return rc0;
+    return index_from_bundle(b, device, out);
+    });
+}
+
+static int runs_to_bundle(const uint8_t *heads, const uint64_t *lens, uint64_t R, const uint64_t *ssa_y, const uint64_t *esa_y, FlatBundle &bundle) {
+    {
+    RawRle &rle = bundle.rle;
+    RawTsa &tsa = bundle.tsa;
+    bundle.has_tsa = ssa_y != nullptr;
     rle.R = R;
     rle.B = 2;
-    rle.heads.assign(heads, heads + R);
-    rle.lens.assign(lens, lens + R);
-    uint64_t n = 0;
-    for (uint64_t i = 0; i < R; ++i) {
-        if (lens[i] == 0 || (i && heads[i] == heads[i - 1])) return RBG_EARG;  // runs are non-empty and maximal
-        n += lens[i];
-    }
-    rle.n = n;
-    RawTsa tsa;
-    if (ssa_y) {
-        for (uint64_t i = 0; i < R; ++i)
-            if (ssa_y[i] > n || esa_y[i] > n) return RBG_EARG;  // SA values of an n-symbol text
-        tsa_from_samples(n, R, ssa_y, esa_y, tsa);
-        for (uint64_t j = 1; j < R; ++j)
-            if (tsa.pred_pos[j] == tsa.pred_pos[j - 1]) return RBG_EARG;  // run-start samples must be distinct
-    }
-    rbg_index *ix = new (std::nothrow) rbg_index();
-    if (!ix) return RBG_ENOMEM;
-    FlattenOptions fo = options_for(device, rle, &ix->kmer_steps_requested);
-    fo.defer_kmer = compose_deferred(device);
-    int rc = flatten(rle, ssa_y ? &tsa : nullptr, fo, ix->host);
-    if (rc) { delete ix; return rc; }
-    return finish(ix, device, out);
+    rle.heads.resize(R);
+    rle.lens.resize(R);
+    // (every loop over the runs is split over the worker threads: 3e8 runs at pangenome scale)
+    const unsigned T = load_threads();
+    std::vector<uint64_t> part(T + 1, 0);
+    std::vector<int> bad(T + 1, 0);
+    parallel_for(R, [&](uint64_t b, uint64_t e, unsigned t) {
+        uint64_t sum = 0;
+        for (uint64_t i = b; i < e; ++i) {
+            if (lens[i] == 0 || (i && heads[i] == heads[i - 1])) bad[t] = 1;  // runs are non-empty and maximal
+            sum += lens[i];
+            rle.heads[i] = heads[i];
+            rle.lens[i] = lens[i];
+        }
+        part[t] = sum;
     });
+    uint64_t n = 0;
+    for (unsigned t = 0; t <= T; ++t) { if (bad[t]) return RBG_EARG; n += part[t]; }
+    rle.n = n;
+    if (ssa_y) {
+        parallel_for(R, [&](uint64_t b, uint64_t e, unsigned t) {
+            for (uint64_t i = b; i < e; ++i)
+                if (ssa_y[i] > n || esa_y[i] > n) bad[t] = 1;  // SA values of an n-symbol text
+        });
+        for (unsigned t = 0; t <= T; ++t) if (bad[t]) return RBG_EARG;
+        tsa_from_samples(n, R, ssa_y, esa_y, tsa);
+        parallel_for(R, [&](uint64_t b, uint64_t e, unsigned t) {
+            for (uint64_t j = std::max<uint64_t>(b, 1); j < e; ++j)
+                if (tsa.pred_pos[j] == tsa.pred_pos[j - 1]) bad[t] = 1;  // run-start samples must be distinct
+        });
+        for (unsigned t = 0; t <= T; ++t) if (bad[t]) return RBG_EARG;
+    }
+    return RBG_OK;
+    }
 }
 
 int rbg_build_from_files(const char *bwt_fname, const char *ssa_fname, const char *esa_fname, int device, rbg_index **out) {

@@ -14,8 +14,30 @@
 #include <thread>
 
 #include "../../include/rbg.h"
+#include "rbg_thread_team.hpp"
 
 namespace rbg {
+
+unsigned load_threads() {
+    static const unsigned n = [] {
+        unsigned t = rbg_hostpath::cpu_budget();
+        if (const char *e = std::getenv("RBG_LOAD_THREADS")) { const int v = std::atoi(e); if (v > 0) t = static_cast<unsigned>(v); }
+        return std::max(1u, std::min(t, 64u));
+    }();
+    return n;
+}
+
+void parallel_for(uint64_t n, const std::function<void(uint64_t, uint64_t, unsigned)> &fn, uint64_t min_per_thread) {
+    unsigned T = load_threads();
+    if (min_per_thread == 0) min_per_thread = 1;
+    if (n / min_per_thread < T) T = static_cast<unsigned>(std::max<uint64_t>(1, n / min_per_thread));
+    if (T <= 1) { fn(0, n, 0); return; }
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < T; ++t) th.emplace_back([&, t] { fn(n * t / T, n * (t + 1) / T, t); });
+    fn(0, n / T, 0);
+    for (auto &w : th) w.join();
+}
+
 namespace {
 
 // ---- byte cursor over a whole file --------------------------------------------------------------
@@ -334,39 +356,67 @@ void tsa_from_samples(uint64_t n, uint64_t r, const uint64_t *ssa_y, const uint6
     out.n = n;
     out.r = r;
     out.samples_last.resize(r);
-    std::vector<uint64_t> first(r), order(r);
-    for (uint64_t i = 0; i < r; ++i) {
-        first[i] = ssa_y[i] ? ssa_y[i] - 1 : n - 1;
-        out.samples_last[i] = esa_y[i] ? esa_y[i] - 1 : n - 1;
-    }
-    // order the runs by the text position of their first row: a stable LSD radix sort on (position, run)
-    // -- a comparison sort through the index array took 7 s for the bench index (3.7e7 runs), this 0.4 s
-    std::iota(order.begin(), order.end(), uint64_t(0));
+    std::vector<uint64_t> key(r), order(r);
+    parallel_for(r, [&](uint64_t b, uint64_t e, unsigned) {
+        for (uint64_t i = b; i < e; ++i) {
+            key[i] = ssa_y[i] ? ssa_y[i] - 1 : n - 1;
+            out.samples_last[i] = esa_y[i] ? esa_y[i] - 1 : n - 1;
+            order[i] = i;
+        }
+    });
+    // order the runs by the text position of their first row: a stable LSD radix sort on (position, run), 11 bits per
+    // pass, every pass split over the worker threads (per-thread histograms, then each thread scatters its own chunk
+    // to the places the prefix sums give it) -- a comparison sort through the index array took 7 s for the bench index
+    // (3.7e7 runs), the serial radix sort 0.4 s there and 9 s at 3.1e8 runs
     {
         int bits = 1;
         while (bits < 64 && (n >> bits)) ++bits;
-        std::vector<uint64_t> key(first), key2(r), order2(r);
-        std::vector<uint64_t> hist(size_t(1) << 16);
-        for (int shift = 0; shift < bits; shift += 16) {
-            std::fill(hist.begin(), hist.end(), 0);
-            for (uint64_t i = 0; i < r; ++i) ++hist[(key[i] >> shift) & 0xFFFF];
-            uint64_t sum = 0;
-            for (uint64_t &h : hist) { const uint64_t c = h; h = sum; sum += c; }
-            for (uint64_t i = 0; i < r; ++i) {
-                const uint64_t dst = hist[(key[i] >> shift) & 0xFFFF]++;
-                key2[dst] = key[i];
-                order2[dst] = order[i];
-            }
+        constexpr int kDigit = 11;
+        constexpr size_t kBuckets = size_t(1) << kDigit;
+        std::vector<uint64_t> key2(r), order2(r);
+        const unsigned T = std::max(1u, std::min<unsigned>(load_threads(), static_cast<unsigned>(r / 65536 + 1)));
+        std::vector<uint64_t> hist(static_cast<size_t>(T) * kBuckets);
+        for (int shift = 0; shift < bits; shift += kDigit) {
+            auto chunk = [&](unsigned t, uint64_t &b, uint64_t &e) { b = r * t / T; e = r * (t + 1) / T; };
+            auto count = [&](unsigned t) {
+                uint64_t b, e;
+                chunk(t, b, e);
+                uint64_t *h = hist.data() + static_cast<size_t>(t) * kBuckets;
+                std::fill(h, h + kBuckets, 0);
+                for (uint64_t i = b; i < e; ++i) ++h[(key[i] >> shift) & (kBuckets - 1)];
+            };
+            auto scatter = [&](unsigned t) {
+                uint64_t b, e;
+                chunk(t, b, e);
+                uint64_t *h = hist.data() + static_cast<size_t>(t) * kBuckets;
+                for (uint64_t i = b; i < e; ++i) {
+                    const uint64_t dst = h[(key[i] >> shift) & (kBuckets - 1)]++;
+                    key2[dst] = key[i];
+                    order2[dst] = order[i];
+                }
+            };
+            auto on_all = [&](const std::function<void(unsigned)> &f) {
+                std::vector<std::thread> th;
+                for (unsigned t = 1; t < T; ++t) th.emplace_back(f, t);
+                f(0);
+                for (auto &w : th) w.join();
+            };
+            on_all(count);
+            uint64_t sum = 0;   // bucket-major, thread-minor: stable
+            for (size_t d = 0; d < kBuckets; ++d)
+                for (unsigned t = 0; t < T; ++t) {
+                    uint64_t &h = hist[static_cast<size_t>(t) * kBuckets + d];
+                    const uint64_t c = h;
+                    h = sum;
+                    sum += c;
+                }
+            on_all(scatter);
             key.swap(key2);
             order.swap(order2);
         }
     }
-    out.pred_pos.resize(r);
-    out.pred_to_run.resize(r);
-    for (uint64_t j = 0; j < r; ++j) {
-        out.pred_pos[j] = first[order[j]];
-        out.pred_to_run[j] = order[j];
-    }
+    out.pred_pos.swap(key);       // the sorted first-row positions
+    out.pred_to_run.swap(order);
 }
 
 // ---- .mab ----------------------------------------------------------------------------------------
@@ -487,8 +537,10 @@ uint64_t padded8(uint64_t nbytes) { return (nbytes + 7) & ~uint64_t(7); }
 
 void widen(const unsigned char *src, uint64_t count, unsigned width, std::vector<uint64_t> &out) {
     out.resize(count);
-    if (width == 8) { if (count) std::memcpy(out.data(), src, count * 8); return; }
-    for (uint64_t i = 0; i < count; ++i) { uint32_t v; std::memcpy(&v, src + 4 * i, 4); out[i] = v; }
+    parallel_for(count, [&](uint64_t b, uint64_t e, unsigned) {
+        if (width == 8) { std::memcpy(out.data() + b, src + 8 * b, (e - b) * 8); return; }
+        for (uint64_t i = b; i < e; ++i) { uint32_t v; std::memcpy(&v, src + 4 * i, 4); out[i] = v; }
+    }, uint64_t(1) << 18);
 }
 }  // namespace
 
@@ -570,13 +622,26 @@ int read_flat(const std::string &fname, FlatBundle &b) {
     p += padded8(r.R);
     widen(p, r.R, static_cast<unsigned>(len_width), r.lens);
     p += padded8(r.R * len_width);
-    uint64_t total = 0;
-    for (uint64_t i = 0; i < r.R; ++i) {
-        if (r.lens[i] == 0 || r.lens[i] > r.n - total) return RBG_EFORMAT;
-        if (i && r.heads[i] == r.heads[i - 1]) return RBG_EFORMAT;  // runs are maximal
-        total += r.lens[i];
+    {
+        const unsigned T = load_threads();
+        std::vector<uint64_t> part(T + 1, 0);
+        std::vector<int> bad(T + 1, 0);
+        parallel_for(r.R, [&](uint64_t b0, uint64_t e0, unsigned t) {
+            uint64_t sum = 0;
+            for (uint64_t i = b0; i < e0; ++i) {
+                if (r.lens[i] == 0 || r.lens[i] > r.n - sum) { bad[t] = 1; return; }   // (no chunk may exceed n by itself: no overflow)
+                if (i && r.heads[i] == r.heads[i - 1]) { bad[t] = 1; return; }           // runs are maximal
+                sum += r.lens[i];
+            }
+            part[t] = sum;
+        });
+        uint64_t total = 0;
+        for (unsigned t = 0; t <= T; ++t) {
+            if (bad[t] || part[t] > r.n - total) return RBG_EFORMAT;
+            total += part[t];
+        }
+        if (total != r.n) return RBG_EFORMAT;
     }
-    if (total != r.n) return RBG_EFORMAT;
     if (b.has_tsa) {
         RawTsa &t = b.tsa;
         t.r = r.R; t.n = r.n;
@@ -586,10 +651,14 @@ int read_flat(const std::string &fname, FlatBundle &b) {
         p += padded8(r.R * pos_width);
         widen(p, r.R, static_cast<unsigned>(pos_width), t.pred_to_run);
         p += padded8(r.R * pos_width);
-        for (uint64_t i = 0; i < r.R; ++i) {
-            if (t.pred_pos[i] >= r.n || (i && t.pred_pos[i] <= t.pred_pos[i - 1])) return RBG_EFORMAT;
-            if (t.samples_last[i] >= r.n || t.pred_to_run[i] >= r.R) return RBG_EFORMAT;
-        }
+        std::vector<int> bad(load_threads() + 1, 0);
+        parallel_for(r.R, [&](uint64_t b0, uint64_t e0, unsigned th) {
+            for (uint64_t i = b0; i < e0; ++i) {
+                if (t.pred_pos[i] >= r.n || (i && t.pred_pos[i] <= t.pred_pos[i - 1])) bad[th] = 1;
+                if (t.samples_last[i] >= r.n || t.pred_to_run[i] >= r.R) bad[th] = 1;
+            }
+        });
+        for (int v : bad) if (v) return RBG_EFORMAT;
     }
     if (b.has_ma) {
         RawMarkers &m = b.ma;
@@ -915,17 +984,45 @@ int flatten(const RawRle &rle, const RawTsa *tsa, const FlattenOptions &opt, Hos
     out.r = R;
     out.run_heads = rle.heads;
     out.run_start.resize(R + 1);
+    // Two passes over the runs, both split over the worker threads (contiguous chunks): the first sums each chunk's
+    // lengths and counts its runs and symbols per head, a prefix over the chunks then tells every chunk where its rows
+    // begin and where its runs go in each symbol's table, the second writes run_start and the tables' entries in place.
+    const unsigned T = std::max(1u, std::min<unsigned>(load_threads(), static_cast<unsigned>(R / 65536 + 1)));
+    struct ChunkSum {
+        uint64_t len = 0, cnt[256], nr[256];
+        bool zero = false;
+    };
+    std::vector<ChunkSum> cs(T);
+    auto chunk = [&](unsigned t, uint64_t &b, uint64_t &e) { b = R * t / T; e = R * (t + 1) / T; };
+    auto on_all = [&](const std::function<void(unsigned)> &f) {
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < T; ++t) th.emplace_back(f, t);
+        f(0);
+        for (auto &w : th) w.join();
+    };
+    on_all([&](unsigned t) {
+        uint64_t b, e;
+        chunk(t, b, e);
+        ChunkSum &c = cs[t];
+        std::memset(c.cnt, 0, sizeof(c.cnt));
+        std::memset(c.nr, 0, sizeof(c.nr));
+        for (uint64_t i = b; i < e; ++i) {
+            const uint64_t l = rle.lens[i];
+            if (l == 0) c.zero = true;
+            c.len += l;
+            c.cnt[rle.heads[i]] += l;
+            c.nr[rle.heads[i]]++;
+        }
+    });
     uint64_t cnt[256] = {0}, nr[256] = {0};
-    uint64_t pos = 0;
-    for (uint64_t i = 0; i < R; ++i) {
-        if (rle.lens[i] == 0) return RBG_EARG;
-        out.run_start[i] = pos;
-        pos += rle.lens[i];
-        cnt[rle.heads[i]] += rle.lens[i];
-        nr[rle.heads[i]]++;
+    std::vector<uint64_t> pos0(T + 1, 0);
+    for (unsigned t = 0; t < T; ++t) {
+        if (cs[t].zero) return RBG_EARG;
+        pos0[t + 1] = pos0[t] + cs[t].len;
+        for (int c = 0; c < 256; ++c) { cnt[c] += cs[t].cnt[c]; nr[c] += cs[t].nr[c]; }
     }
-    out.run_start[R] = pos;
-    out.n = pos;
+    out.run_start[R] = pos0[T];
+    out.n = pos0[T];
     if (out.n >> 48) return RBG_EARG;  // RankSlot carries 48-bit ranks (rbg_dev.h)
     if (tsa && tsa->n != out.n) return RBG_EFORMAT;
     // F column (RowBowt::build_f, rowbowt.hpp:770-778) and slots
@@ -941,9 +1038,6 @@ int flatten(const RawRle &rle, const RawTsa *tsa, const FlattenOptions &opt, Hos
             t.nruns = nr[s];
             t.total = cnt[s];
             t.F = out.f[s];
-            t.start.reserve(nr[s] + 1);
-            t.cum.reserve(nr[s] + 1);
-            if (tsa) t.samp.reserve(nr[s]);
             out.sym.push_back(std::move(t));
         }
     }
@@ -953,18 +1047,42 @@ int flatten(const RawRle &rle, const RawTsa *tsa, const FlattenOptions &opt, Hos
     // 32-bit positions need n below the two reserved marker values (rbg_dev.h kSent / kOvf)
     out.pos_bytes = opt.force_pos_bytes ? opt.force_pos_bytes : (out.n < 0xFFFFFFF0ull ? 4 : 8);
     if (out.pos_bytes == 4 && out.n >= 0xFFFFFFF0ull) return RBG_EARG;
-    std::vector<uint64_t> seen(out.sigma, 0);
-    for (uint64_t i = 0; i < R; ++i) {
-        const uint32_t slot = out.lut[rle.heads[i]];
-        SymTable &t = out.sym[slot];
-        t.start.push_back(out.run_start[i]);
-        t.cum.push_back(seen[slot]);
-        if (tsa) t.samp.push_back(tsa->samples_last[i]);
-        seen[slot] += rle.lens[i];
-    }
     for (SymTable &t : out.sym) {
-        t.start.push_back(out.n);
-        t.cum.push_back(t.total);
+        t.start.resize(t.nruns + 1);
+        t.cum.resize(t.nruns + 1);
+        if (tsa) t.samp.resize(t.nruns);
+    }
+    // where each chunk's runs go in each symbol's table, and how many of the symbol precede them
+    std::vector<uint64_t> ord0(static_cast<size_t>(T) * 256, 0), cum0(static_cast<size_t>(T) * 256, 0);
+    for (int c = 0; c < 256; ++c) {
+        uint64_t o = 0, q = 0;
+        for (unsigned t = 0; t < T; ++t) {
+            ord0[static_cast<size_t>(t) * 256 + c] = o;
+            cum0[static_cast<size_t>(t) * 256 + c] = q;
+            o += cs[t].nr[c];
+            q += cs[t].cnt[c];
+        }
+    }
+    on_all([&](unsigned t) {
+        uint64_t b, e;
+        chunk(t, b, e);
+        uint64_t pos = pos0[t];
+        uint64_t *o = ord0.data() + static_cast<size_t>(t) * 256, *q = cum0.data() + static_cast<size_t>(t) * 256;
+        for (uint64_t i = b; i < e; ++i) {
+            const uint8_t h = rle.heads[i];
+            SymTable &tb = out.sym[out.lut[h]];
+            const uint64_t k = o[h]++;
+            out.run_start[i] = pos;
+            tb.start[k] = pos;
+            tb.cum[k] = q[h];
+            if (tsa) tb.samp[k] = tsa->samples_last[i];
+            q[h] += rle.lens[i];
+            pos += rle.lens[i];
+        }
+    });
+    for (SymTable &t : out.sym) {
+        t.start[t.nruns] = out.n;
+        t.cum[t.nruns] = t.total;
         t.shift = opt.rank_bucket_shift >= 0 ? static_cast<uint32_t>(opt.rank_bucket_shift) : auto_shift(out.n, t.nruns, 1.5);
         if (t.shift > 12 || (t.shift > 8 && (out.n >> 40))) return RBG_EARG;  // wide buckets carry 40-bit ranks (rbg_dev.h)
     }
@@ -973,11 +1091,18 @@ int flatten(const RawRle &rle, const RawTsa *tsa, const FlattenOptions &opt, Hos
         out.samples_last = tsa->samples_last;
         out.pred_pos = tsa->pred_pos;
         out.phi_base.resize(R);
-        for (uint64_t j = 0; j < R; ++j) {
-            const uint64_t run = tsa->pred_to_run[j];
-            out.phi_base[j] = run ? tsa->samples_last[run - 1] : 0;  // toehold_sa.hpp:67-70
-            if (j && out.pred_pos[j] <= out.pred_pos[j - 1]) return RBG_EFORMAT;
-        }
+        std::vector<int> bad(T, 0);
+        on_all([&](unsigned t) {
+            uint64_t b, e;
+            chunk(t, b, e);
+            for (uint64_t j = b; j < e; ++j) {
+                const uint64_t run = tsa->pred_to_run[j];
+                out.phi_base[j] = run ? tsa->samples_last[run - 1] : 0;  // toehold_sa.hpp:67-70
+                if (j && out.pred_pos[j] <= out.pred_pos[j - 1]) bad[t] = 1;
+            }
+        });
+        for (int v : bad)
+            if (v) return RBG_EFORMAT;
         out.last_run_sample = (tsa->samples_last[R - 1] + 1) % out.n;  // toehold_sa.hpp:97-99
         out.phi_shift = opt.phi_bucket_shift >= 0 ? static_cast<uint32_t>(opt.phi_bucket_shift) : auto_shift(out.n, R, 0.75);
         if (out.phi_shift > 8) return RBG_EARG;

@@ -15,7 +15,15 @@
 #include <string>
 #include <vector>
 
+#include <functional>
+
 namespace rbg {
+
+// fn(begin, end) over [0, n) cut into contiguous chunks, one per worker thread (as many as the process may use: the
+// container's CPU quota counts, rbg_thread_team.hpp cpu_budget); runs inline when n is small.  The load path's loops
+// over the runs (3e8 of them at pangenome scale) go through this.
+void parallel_for(uint64_t n, const std::function<void(uint64_t, uint64_t, unsigned)> &fn, uint64_t min_per_thread = uint64_t(1) << 16);
+unsigned load_threads();
 
 // ---- decoded contents of the reference's files -------------------------------------------------
 struct RawRle {          // ri::rle_string, as a plain run-length BWT

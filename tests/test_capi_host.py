@@ -4,6 +4,8 @@ reader decodes, and query entry points refuse to run without a device (no CPU fa
 import ctypes as C
 import os
 import re
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -241,6 +243,42 @@ def _same_index(a, b, arrays=HOST_ARRAYS):
     assert (a.get_f() == b.get_f()).all()
     ia, ib = a.info(), b.info()
     assert (ia.n, ia.r, ia.sigma, ia.has_tsa, ia.has_markers, ia.has_docs) == (ib.n, ib.r, ib.sigma, ib.has_tsa, ib.has_markers, ib.has_docs)
+
+
+def test_cache_from_runs_in_memory(tmp_path):
+    """rbg_convert_runs: the cache file from a run-length BWT in memory (what bench.py's rank 0 hands the other ranks of a
+    node, and what a builder that never writes the BWT as text uses) loads as the same index as rbg_build_from_runs on the
+    same arrays; the parallel flatten (two passes over the runs split over threads) and the parallel radix sort of the
+    samples give what the serial loops gave -- also with one thread and with more threads than runs per chunk."""
+    from synth import SynthIndex
+    S = SynthIndex(L=900, H=5, n_sites=20, seed=11)
+    b = ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=capi.DEVICE_NONE)
+    capi.convert_runs(S.heads, S.lens, S.ssa, S.esa, out_path=str(tmp_path / "m.rbgpu"))
+    a = ra.RowBowt.from_cache(str(tmp_path / "m.rbgpu"), ra.LoadRbwtFlag.SA, device=capi.DEVICE_NONE)
+    _same_index(a, b, HOST_ARRAYS[:5])
+    assert a.last_run_sample() == b.last_run_sample()
+    capi.convert_runs(S.heads, S.lens, out_path=str(tmp_path / "n.rbgpu"))
+    c = ra.RowBowt.from_cache(str(tmp_path / "n.rbgpu"), device=capi.DEVICE_NONE)
+    assert c.info().r == b.info().r and not c.info().has_tsa
+    with pytest.raises(ra.RbgError):
+        capi.convert_runs(S.heads, S.lens, S.ssa, None, out_path=str(tmp_path / "bad.rbgpu"))
+    # a larger random run list through 1 and 7 worker threads (a fresh interpreter each: the thread count is read once)
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r); import rowbowt_amd as ra; from rowbowt_amd import capi\n"
+        "rng = np.random.default_rng(5); r = 300000\n"
+        "step = rng.integers(1, 4, size=r); step[0] = 0; heads = np.frombuffer(b'ACGT', dtype=np.uint8)[np.cumsum(step) %% 4].copy()\n"
+        "lens = rng.integers(1, 60, size=r).astype(np.uint64); heads[r // 3] = 1; lens[r // 3] = 1; n = int(lens.sum())\n"
+        "vals = rng.permutation(n)[:2 * r].astype(np.uint64) + 1; vals[vals > n] = n\n"
+        "rb = ra.RowBowt.from_runs(heads, lens, vals[:r], vals[r:], device=capi.DEVICE_NONE)\n"
+        "import hashlib; h = hashlib.sha256()\n"
+        "for w in (capi.ARR_RUN_HEADS, capi.ARR_RUN_START, capi.ARR_SAMPLES_LAST, capi.ARR_PRED_POS, capi.ARR_PHI_BASE): h.update(rb.host_array(w).tobytes())\n"
+        "h.update(rb.get_f().tobytes()); print(h.hexdigest(), rb.info().pair_runs, rb.info().quint_runs)\n" % ROOT)
+    outs = []
+    for threads in ("1", "7", "64"):
+        p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RBG_LOAD_THREADS=threads), capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs.append(p.stdout.strip())
+    assert outs[0] == outs[1] == outs[2] and len(outs[0]) > 64
 
 
 def test_native_cache_from_reference_index(tmp_path, data_dir, small_host):
