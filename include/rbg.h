@@ -99,6 +99,11 @@ int rbg_load_cache(const char *path, int flags, int device, rbg_index **out);
  * the BWT as text, and for handing one index to the ranks of a node (rank 0 writes, every rank rbg_load_cache's) */
 int rbg_convert_runs(const uint8_t *heads, const uint64_t *lens, uint64_t R, const uint64_t *ssa_y /* nullable, with esa_y */,
                      const uint64_t *esa_y, const char *out_path);
+/* the same with a marker array (the arguments of rbg_set_markers; mk_nruns = 0: none) and the text of a .docs file
+ * (nullable) stored beside it: one file that rb_align -s -m / rb_markers can run from */
+int rbg_convert_runs_markers(const uint8_t *heads, const uint64_t *lens, uint64_t R, const uint64_t *ssa_y, const uint64_t *esa_y,
+                             const uint64_t *mk_start, const uint64_t *mk_end, uint64_t mk_nruns, const uint64_t *mk_off,
+                             const uint64_t *mk_vals, const char *docs_text /* nullable */, const char *out_path);
 /* RowBowt::build_ftab(k) + FTab::serialize (rowbowt.hpp:726-744, ftab.hpp:29-34): the reference's
  * text .ftab ("<kmer> <lo> <hi>" per line, lexicographic), computed with the search kernel. 1 <= k <= 16. */
 int rbg_write_ftab(rbg_index *, uint64_t k, const char *path);
@@ -238,6 +243,10 @@ void rbg_free_buffer(void *);
 /* RowBowt::resolve_offset, rowbowt.hpp:623-625 -> DocList::doc_and_offset_at doclist.hpp:46-50.
  * *name points into the index (valid until rbg_free). */
 int rbg_resolve_offset(const rbg_index *, uint64_t i, const char **name, uint64_t *offset);
+/* The table rbg_resolve_offset answers from, for callers that resolve positions by the million: position i belongs to
+ * document names[k - 1] at offset i - sorted_starts[k - 1], k = # sorted_starts < min(i + 1, size) (doclist.hpp:46-50,
+ * :77-79; k == 0 has no answer: rbg_resolve_offset returns RBG_EARG there).  Pointers stay valid until rbg_free. */
+int rbg_doc_table(rbg_index *, uint64_t *ndocs, const uint64_t **sorted_starts, const char *const **names, uint64_t *size);
 
 /* ---- queries, device-resident buffers (HBM in, HBM out; asynchronous on `stream`) ---------- */
 

@@ -61,7 +61,9 @@ _PROTOS = [
     ("rbg_convert_index", C.c_int, [C.c_char_p, C.c_int, C.c_char_p]),
     ("rbg_convert_raw", C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p]),
     ("rbg_load_cache", C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(VP)]),
+    ("rbg_doc_table", C.c_int, [VP, C.POINTER(U64), C.POINTER(VP), C.POINTER(VP), C.POINTER(U64)]),
     ("rbg_convert_runs", C.c_int, [VP, VP, U64, VP, VP, C.c_char_p]),
+    ("rbg_convert_runs_markers", C.c_int, [VP, VP, U64, VP, VP, VP, VP, U64, VP, VP, C.c_char_p, C.c_char_p]),
     ("rbg_write_ftab", C.c_int, [VP, U64, C.c_char_p]),
     ("rbg_check_ftab", C.c_int, [VP, C.c_char_p, C.POINTER(U64)]),
     ("rbg_set_markers", C.c_int, [VP, VP, VP, U64, VP, VP]),
@@ -191,14 +193,18 @@ def convert_raw(bwt, ssa=None, esa=None, mab=None, docs=None, out_path=None):
     _check(lib().rbg_convert_raw(e(bwt), e(ssa), e(esa), e(mab), e(docs), e(out_path)), "rbg_convert_raw")
 
 
-def convert_runs(heads, lens, ssa=None, esa=None, out_path=None):
-    """the native cache file from a run-length BWT in memory (rbg_convert_runs)"""
+def convert_runs(heads, lens, ssa=None, esa=None, out_path=None, markers=None, docs_text=None):
+    """the native cache file from a run-length BWT in memory (rbg_convert_runs[_markers]); markers = (start, end, off, vals)"""
     heads = np.ascontiguousarray(heads, dtype=np.uint8)
     lens = np.ascontiguousarray(lens, dtype=np.uint64)
     ssa = None if ssa is None else np.ascontiguousarray(ssa, dtype=np.uint64)
     esa = None if esa is None else np.ascontiguousarray(esa, dtype=np.uint64)
-    _check(lib().rbg_convert_runs(_p(heads), _p(lens), len(heads), _p(ssa) if ssa is not None else None, _p(esa) if esa is not None else None,
-                                  os.fsencode(out_path)), "rbg_convert_runs")
+    mk = [None] * 4 if markers is None else [np.ascontiguousarray(a, dtype=np.uint64) for a in markers]
+    _check(lib().rbg_convert_runs_markers(_p(heads), _p(lens), len(heads), _p(ssa) if ssa is not None else None, _p(esa) if esa is not None else None,
+                                          _p(mk[0]) if markers is not None else None, _p(mk[1]) if markers is not None else None,
+                                          len(mk[0]) if markers is not None else 0, _p(mk[2]) if markers is not None else None,
+                                          _p(mk[3]) if markers is not None else None, docs_text.encode() if docs_text else None,
+                                          os.fsencode(out_path)), "rbg_convert_runs_markers")
 
 
 def set_default_option(opt, value):

@@ -8,7 +8,9 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <fcntl.h>
@@ -46,6 +48,24 @@ class InputSource {
         unsigned char magic[2] = {0, 0};
         const bool regular = fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode);
         if (regular && sb.st_size >= 2 && pread(fd, magic, 2, 0) != 2) magic[0] = magic[1] = 0;
+        if (regular && magic[0] == 0x1f && magic[1] == 0x8b && sb.st_size >= 28 && threads_ > 1) {
+            // gzip: a BGZF file (bgzip, htslib: independent blocks of at most 64 KB that carry their own compressed size in
+            // an extra field) is mapped and its blocks are inflated by the worker threads; any other gzip goes through zlib's
+            // single stream below
+            unsigned char hdr[18];
+            if (pread(fd, hdr, 18, 0) == 18 && bgzf_header(hdr)) {
+                map_size_ = static_cast<size_t>(sb.st_size);
+                void *m = mmap(nullptr, map_size_, PROT_READ, MAP_PRIVATE, fd, 0);
+                if (m != MAP_FAILED) {
+                    (void)madvise(m, map_size_, MADV_SEQUENTIAL);
+                    map_ = static_cast<const char *>(m);
+                    bgzf_ = true;
+                    ::close(fd);
+                    return true;
+                }
+                map_size_ = 0;
+            }
+        }
         if (regular && !(magic[0] == 0x1f && magic[1] == 0x8b)) {   // a plain file: map it, scan it in place
             map_size_ = static_cast<size_t>(sb.st_size);
             if (map_size_) {
@@ -75,7 +95,73 @@ class InputSource {
             rbg_cli::ScanState rstate;
             int rc;
             bool final;
-            if (mapped_) {
+            if (bgzf_) {
+                // carry-over of the previous window's unfinished record, then the next blocks worth about `win` bytes
+                w.own.assign(carry_.begin(), carry_.end());
+                const size_t have = w.own.size();
+                struct Blk { uint64_t in, in_len, out, out_len; };
+                std::vector<Blk> blks;
+                uint64_t total = 0;
+                while (pos_ < map_size_ && total < win) {
+                    const unsigned char *h = reinterpret_cast<const unsigned char *>(map_) + pos_;
+                    if (map_size_ - pos_ < 28 || !bgzf_header(h)) { stream_error_ = true; break; }
+                    const uint64_t xlen = h[10] | (static_cast<uint64_t>(h[11]) << 8);
+                    const uint64_t bsz = (h[16] | (static_cast<uint64_t>(h[17]) << 8)) + 1;
+                    if (bsz < 12 + xlen + 8 || bsz > map_size_ - pos_) { stream_error_ = true; break; }
+                    const unsigned char *t = h + bsz - 4;
+                    const uint64_t isz = t[0] | (static_cast<uint64_t>(t[1]) << 8) | (static_cast<uint64_t>(t[2]) << 16) | (static_cast<uint64_t>(t[3]) << 24);
+                    blks.push_back(Blk{pos_ + 12 + xlen, bsz - 12 - xlen - 8, total, isz});
+                    total += isz;
+                    pos_ += bsz;
+                }
+                w.own.resize(have + total);
+                const unsigned T = std::max(1u, std::min<unsigned>(threads_, static_cast<unsigned>(blks.size() / 4 + 1)));
+                std::vector<size_t> bad(T, SIZE_MAX);   // per worker: the first block of its share that did not inflate cleanly
+                auto work = [&](unsigned t) {
+                    z_stream zs;
+                    std::memset(&zs, 0, sizeof(zs));
+                    if (inflateInit2(&zs, -15) != Z_OK) { bad[t] = blks.size() * t / T; return; }
+                    for (size_t i = blks.size() * t / T; i < blks.size() * (t + 1) / T; ++i) {
+                        const Blk &b = blks[i];
+                        (void)inflateReset(&zs);
+                        zs.next_in = reinterpret_cast<Bytef *>(const_cast<char *>(map_ + b.in));
+                        zs.avail_in = static_cast<uInt>(b.in_len);
+                        zs.next_out = reinterpret_cast<Bytef *>(w.own.data() + have + b.out);
+                        zs.avail_out = static_cast<uInt>(b.out_len);
+                        const int rc = inflate(&zs, Z_FINISH);
+                        const unsigned char *tr = reinterpret_cast<const unsigned char *>(map_) + b.in + b.in_len;   // CRC32 | ISIZE
+                        const uint32_t want = tr[0] | (static_cast<uint32_t>(tr[1]) << 8) | (static_cast<uint32_t>(tr[2]) << 16) | (static_cast<uint32_t>(tr[3]) << 24);
+                        if (rc != Z_STREAM_END || zs.avail_out != 0 ||
+                            static_cast<uint32_t>(crc32(0L, reinterpret_cast<const Bytef *>(w.own.data() + have + b.out), static_cast<uInt>(b.out_len))) != want) {
+                            bad[t] = i;
+                            break;
+                        }
+                    }
+                    (void)inflateEnd(&zs);
+                };
+                {
+                    std::vector<std::thread> th;
+                    for (unsigned t = 1; t < T; ++t) th.emplace_back(work, t);
+                    work(0);
+                    for (auto &x : th) x.join();
+                }
+                {
+                    // like gzread failing in the middle: what came before the first bad block still counts, the stream ends there (-3)
+                    size_t first_bad = stream_error_ ? blks.size() : SIZE_MAX;   // (a bad header ended the walk: every block listed is good)
+                    for (size_t v : bad) first_bad = std::min(first_bad, v);
+                    if (first_bad != SIZE_MAX) {
+                        stream_error_ = true;
+                        w.own.resize(have + (first_bad < blks.size() ? blks[first_bad].out : total));
+                    }
+                }
+                final = stream_error_ || pos_ >= map_size_;
+                w.base = w.own.data();
+                rc = rbg_cli::scan_records_parallel(w.base, 0, w.own.size(), final, st_, w.recs, &resume, &rstate, threads_, min_segment_);
+                if (rc == rbg_cli::kScanTruncQual) return stream_error_ ? -3 : -2;
+                carry_.assign(w.own.begin() + static_cast<std::ptrdiff_t>(resume), w.own.end());
+                st_ = rstate;
+                if (!final && w.recs.size() == 0) { win *= 2; continue; }
+            } else if (mapped_) {
                 const uint64_t end = std::min<uint64_t>(map_size_, pos_ + win);
                 final = end == map_size_;
                 w.base = map_ ? map_ : "";
@@ -112,6 +198,11 @@ class InputSource {
     }
 
    private:
+    // a gzip member header that is a BGZF block's: FEXTRA set, first extra subfield 'B' 'C' of two bytes (the block size - 1)
+    static bool bgzf_header(const unsigned char *h) {
+        return h[0] == 0x1f && h[1] == 0x8b && h[2] == 8 && (h[3] & 4) && (h[10] | (h[11] << 8)) >= 6 && h[12] == 'B' && h[13] == 'C' && h[14] == 2 && h[15] == 0;
+    }
+    bool bgzf_ = false;
     const char *map_ = nullptr;
     size_t map_size_ = 0;
     bool mapped_ = false;

@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstring>
 #include <algorithm>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -149,35 +150,82 @@ inline void put_u64(std::string &out, uint64_t v) {   // two digits per division
 // Output text is produced through a raw pointer into the piece's string (grown in bulk, trimmed at the end) with a
 // two-digits-at-a-time number writer: the formatter, not the GPU, sets the pace of this tool (150 ns per read with
 // std::string::push_back per character; rb_align -s prints a number per location).
-struct FastOut {
-    std::string &s;
-    size_t len;
-    explicit FastOut(std::string &str) : s(str), len(str.size()) {}
-    char *room(size_t n) {
-        if (len + n > s.size()) s.resize(std::max(s.size() * 2, len + n + 65536));
-        return &s[len];
+// A piece of output text: raw bytes with a capacity that survives clear(), grown WITHOUT initialising what is about to be
+// overwritten (std::string::resize zero-fills: for a formatter that makes 10 GB of text per 10 M reads -- rb_align -s on
+// the bench index -- that doubled the memory traffic).  Pieces are recycled from batch to batch by the tools.
+struct TextBuf {
+    std::unique_ptr<char[]> p;
+    size_t cap = 0, len = 0;
+    void clear() { len = 0; }
+    const char *data() const { return p.get(); }
+    size_t size() const { return len; }
+    void reserve(size_t n) {
+        if (n <= cap) return;
+        std::unique_ptr<char[]> q(new char[n]);   // (default-initialised: no fill)
+        if (len) std::memcpy(q.get(), p.get(), len);
+        p.swap(q);
+        cap = n;
     }
-    void finish() { s.resize(len); }
 };
-inline char *fmt_u64(char *p, uint64_t v) {
-    static const char lut[] =
-        "0001020304050607080910111213141516171819202122232425262728293031323334353637383940414243444546474849"
-        "5051525354555657585960616263646566676869707172737475767778798081828384858687888990919293949596979899";
-    char tmp[20];
-    char *const e = tmp + 20;
-    char *q = e;
-    while (v >= 100) {
-        const uint64_t d = v / 100;
-        const unsigned r = static_cast<unsigned>(v - d * 100);
-        v = d;
-        q -= 2;
-        std::memcpy(q, lut + 2 * r, 2);
+// the formatters' view of a piece: room(n) guarantees n writable bytes at the current end
+struct FastOut {
+    TextBuf &s;
+    size_t len;
+    explicit FastOut(TextBuf &b) : s(b), len(b.len) {}
+    char *room(size_t n) {
+        if (len + n > s.cap) { s.len = len; s.reserve(std::max(s.cap * 2, len + n + 65536)); }
+        return s.p.get() + len;
     }
-    if (v >= 10) { q -= 2; std::memcpy(q, lut + 2 * v, 2); }
-    else *--q = static_cast<char>('0' + v);
-    const size_t n = static_cast<size_t>(e - q);
-    std::memcpy(p, q, n);
-    return p + n;
+    void finish() { s.len = len; }
+};
+
+// Decimal text of v at p, no terminator; returns the end.  Four digits per table lookup: a 10 000-entry table of
+// zero-padded quadruples, one 64-bit division by 10^8 and 32-bit arithmetic below it (positions and offsets are 8 to 11
+// digits: two or three lookups instead of five divisions by 100 and a copy through a temporary).
+struct Quads {
+    char d[10000][4];
+    Quads() {
+        for (unsigned v = 0; v < 10000; ++v) {
+            d[v][0] = static_cast<char>('0' + v / 1000);
+            d[v][1] = static_cast<char>('0' + v / 100 % 10);
+            d[v][2] = static_cast<char>('0' + v / 10 % 10);
+            d[v][3] = static_cast<char>('0' + v % 10);
+        }
+    }
+};
+inline const Quads &quads() {
+    static const Quads q;
+    return q;
+}
+inline char *fmt_lead(char *p, unsigned v, const Quads &Q) {   // 0 <= v < 10000, no leading zeros (v == 0: "0")
+    const unsigned skip = v >= 1000 ? 0u : v >= 100 ? 1u : v >= 10 ? 2u : 3u;
+    std::memcpy(p, Q.d[v] + skip, 4);   // (copies 4 bytes, keeps 4 - skip: the caller's buffer has the slack)
+    return p + (4 - skip);
+}
+inline char *fmt_u64(char *p, uint64_t v) {
+    const Quads &Q = quads();
+    if (v < 10000) return fmt_lead(p, static_cast<unsigned>(v), Q);
+    if (v < 100000000ull) {
+        const unsigned x = static_cast<unsigned>(v), hi = x / 10000, lo = x - hi * 10000;
+        p = fmt_lead(p, hi, Q);
+        std::memcpy(p, Q.d[lo], 4);
+        return p + 4;
+    }
+    if (v < 1000000000000ull) {   // up to 12 digits
+        const uint64_t top = v / 100000000ull;
+        const unsigned rest = static_cast<unsigned>(v - top * 100000000ull), hi = rest / 10000, lo = rest - hi * 10000;
+        p = fmt_lead(p, static_cast<unsigned>(top), Q);
+        std::memcpy(p, Q.d[hi], 4);
+        std::memcpy(p + 4, Q.d[lo], 4);
+        return p + 8;
+    }
+    // 13 .. 20 digits: the leading part recursively (at most twice), then eight padded digits
+    const uint64_t top = v / 100000000ull;
+    const unsigned rest = static_cast<unsigned>(v - top * 100000000ull), hi = rest / 10000, lo = rest - hi * 10000;
+    p = fmt_u64(p, top);
+    std::memcpy(p, Q.d[hi], 4);
+    std::memcpy(p + 4, Q.d[lo], 4);
+    return p + 8;
 }
 inline char *fmt_lit(char *p, const char *lit, size_t n) { std::memcpy(p, lit, n); return p + n; }
 

@@ -48,7 +48,7 @@ struct RbAlignArgs {  // rb_align.cpp:17-24
     int device = 0;
     int gpus = 1;     // replicas: devices device .. device + gpus - 1; every batch is sharded over them
     std::vector<int> devices;  // --devices a,b,...: the replicas' devices, in shard order (overrides --gpu/--gpus)
-    uint64_t batch = 1u << 22;
+    uint64_t batch = 1u << 18;   // (a 256 MB window of 100 bp FASTQ holds 1.2 M reads: several batches per window keep both pipeline stages busy)
     // input scanning and output formatting workers: an eighth of the CPUs, 8..32, within the container's CPU quota
     int threads = static_cast<int>(std::min({32u, std::max(8u, std::thread::hardware_concurrency() / 8), std::max(2u, rbg_hostpath::cpu_budget())}));
     uint64_t window_mb = 256;  // input bytes scanned per pipeline step
@@ -63,7 +63,7 @@ void print_help() {  // rb_align.cpp:26-35
     fprintf(stderr, "    --gpu <n>                        HIP device ordinal (default 0)\n");
     fprintf(stderr, "    --gpus <G>                       replicate the index on G devices (from --gpu on) and shard every batch over them\n");
     fprintf(stderr, "    --devices <a,b,...>              the same with an explicit device list\n");
-    fprintf(stderr, "    --batch <n>                      reads per GPU batch (default 4194304)\n");
+    fprintf(stderr, "    --batch <n>                      reads per GPU batch (default 262144)\n");
     fprintf(stderr, "    --threads <n>                    input scanning / output formatting threads (default: an eighth of the CPUs, 8..32)\n");
     fprintf(stderr, "    --window-mb <n>                  input bytes scanned per pipeline step (default 256)\n");
     fprintf(stderr, "    <input_prefix>                   index prefix\n");
@@ -174,9 +174,18 @@ using rbg_cli::FastOut;
 using rbg_cli::fmt_lit;
 using rbg_cli::fmt_u64;
 
+// the document table of the index (rbg_doc_table), fetched once when -s is given
+struct DocView {
+    uint64_t n = 0, size = 0;
+    const uint64_t *starts = nullptr;
+    const char *const *names = nullptr;
+    std::vector<size_t> name_len;
+    size_t max_name = 0;
+} g_docs;
+
 // the text of rb_report (rb_align.cpp:118-145) for reads [i0, i1)
 void format_range(const rbwt::RowBowt<> &rb, const RbAlignArgs &args, const Window &b, const BatchResult &r, size_t g0,
-                  size_t g1, std::string &out_s) {
+                  size_t g1, rbg_cli::TextBuf &out_s) {
     static const char kNoMarkers[] = "no markers (consider building the marker array with a larger window size)";
     FastOut out(out_s);
     for (size_t gi = g0; gi < g1; ++gi) {   // gi: index in the window; i: index in the shard's results
@@ -194,26 +203,27 @@ void format_range(const rbwt::RowBowt<> &rb, const RbAlignArgs &args, const Wind
         *p++ = '\n';
         out.len += static_cast<size_t>(p - p0);
         if (args.sam) {
-            p = out.room(16);
-            out.len += static_cast<size_t>(fmt_lit(p, "\tlocs: ", 7) - p);
+            // "\tlocs: " + per location "<pos>/<doc>:<offset> " (rb_align.cpp:126-131), resolved from the document table
+            // in place: a call per position through the ABI was a third of the formatting time (41 locations per read
+            // on the bench index)
+            const uint64_t nloc = r.loc_off[i + 1] - r.loc_off[i];
+            p = out.room(16 + nloc * (44 + g_docs.max_name));
+            char *const q0 = p;
+            p = fmt_lit(p, "\tlocs: ", 7);
             for (uint64_t t = r.loc_off[i]; t < r.loc_off[i + 1]; ++t) {
-                const char *name = nullptr;
-                uint64_t off = 0;
-                rbwt::detail::check(rbg_resolve_offset(rb.handle(), r.locs[t], &name, &off), "rbg_resolve_offset");
-                const size_t dl = std::strlen(name);
-                p = out.room(dl + 48);
-                char *const q0 = p;
-                p = fmt_u64(p, r.locs[t]);
+                const uint64_t pos = r.locs[t];
+                const uint64_t q = pos + 1 > g_docs.size ? g_docs.size : pos + 1;    // doclist.hpp:77-79 (pos + 1 wraps like the reference's)
+                const uint64_t k = static_cast<uint64_t>(std::lower_bound(g_docs.starts, g_docs.starts + g_docs.n, q) - g_docs.starts);
+                if (k == 0) rbwt::detail::die("rbg_resolve_offset", RBG_EARG);   // (the reference indexes doc_names_[-1] here)
+                p = fmt_u64(p, pos);
                 *p++ = '/';
-                p = fmt_lit(p, name, dl);
+                p = fmt_lit(p, g_docs.names[k - 1], g_docs.name_len[k - 1]);
                 *p++ = ':';
-                p = fmt_u64(p, off);
+                p = fmt_u64(p, pos - g_docs.starts[k - 1]);                                       // doclist.hpp:48
                 *p++ = ' ';
-                out.len += static_cast<size_t>(p - q0);
             }
-            p = out.room(1);
-            *p = '\n';
-            out.len += 1;
+            *p++ = '\n';
+            out.len += static_cast<size_t>(p - q0);
         }
         if (args.markers) {
             const uint64_t nm = r.mk_off[i + 1] - r.mk_off[i];
@@ -241,41 +251,48 @@ double g_trace_query = 0, g_trace_format = 0, g_trace_scan_wait = 0, g_trace_wri
 // queried concurrently, formatting is split over worker threads, pieces concatenated in read order
 // (`pieces` is a pool that keeps its strings -- and their pages -- from window to window: `used` counts the ones of this
 // window; fresh 12 MB strings per batch cost more in page faults than the formatting itself)
-void report_batch(const rbwt::RowBowt<> &rb, const std::vector<rbg_index *> &reps, const RbAlignArgs &args, const Window &b, size_t w0,
-                  size_t w1, std::vector<std::string> &pieces, size_t &used) {
+// One batch in flight between the two stages: the shards' results (one BatchResult per replica, kept from batch to batch
+// like the pieces: the lo / hi / k arrays of a 4 M-read batch are 100 MB of pages)
+struct BatchSlot {
+    std::vector<std::unique_ptr<BatchResult>> res;
+    std::vector<ShardError> err;
+    double query_s = 0;
+};
+
+// stage 1: the batch is sharded over the replicas (contiguous blocks), the shards are queried concurrently
+void query_batch(const std::vector<rbg_index *> &reps, const RbAlignArgs &args, const Window &b, size_t w0, size_t w1, BatchSlot &slot) {
     const size_t N = w1 - w0;
     const int G = static_cast<int>(reps.size());
-    // (kept from batch to batch like the pieces: the lo / hi / k arrays of a 4 M-read batch are 100 MB of pages)
-    static std::vector<std::unique_ptr<BatchResult>> pool;
-    while (pool.size() < static_cast<size_t>(G)) pool.emplace_back(new BatchResult());
-    std::vector<BatchResult *> resp(G);
-    for (int g = 0; g < G; ++g) {
-        resp[g] = pool[g].get();
-        rbg_free_buffer(resp[g]->locs);
-        rbg_free_buffer(resp[g]->mk);
-        resp[g]->locs = resp[g]->mk = nullptr;
-    }
-#define res(g) (*resp[(g)])
+    while (slot.res.size() < static_cast<size_t>(G)) slot.res.emplace_back(new BatchResult());
+    slot.err.assign(G, ShardError());
     const auto t_q0 = std::chrono::steady_clock::now();
-    {
-        std::vector<std::thread> th;
-        std::vector<ShardError> err(G);
-        auto work = [&](int g) {
-            uint64_t s0 = 0, s1 = 0;
-            (void)rbg_shard_bounds(N, g, G, &s0, &s1);
-            err[g] = query_shard(reps[g], args, b, w0 + s0, w0 + s1, res(g));
-        };
-        for (int g = 1; g < G; ++g) th.emplace_back(work, g);
-        work(0);
-        for (auto &t : th) t.join();
-        for (int g = 0; g < G; ++g)
-            if (err[g].rc) {   // what the single-replica path says, from the main thread, once every worker is done
-                fprintf(stderr, "%s (replica %d): %s\n", err[g].what, g, rbg_strerror(err[g].rc));
-                exit(1);
-            }
-    }
+    std::vector<std::thread> th;
+    auto work = [&](int g) {
+        uint64_t s0 = 0, s1 = 0;
+        (void)rbg_shard_bounds(N, g, G, &s0, &s1);
+        slot.err[g] = query_shard(reps[g], args, b, w0 + s0, w0 + s1, *slot.res[g]);
+    };
+    for (int g = 1; g < G; ++g) th.emplace_back(work, g);
+    work(0);
+    for (auto &t : th) t.join();
+    slot.query_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_q0).count();
+}
+
+// stage 2: formatting is split over worker threads, pieces concatenated in read order
+// (`pieces` is a pool that keeps its strings -- and their pages -- from window to window: `used` counts the ones of this
+// window; fresh 12 MB strings per batch cost more in page faults than the formatting itself)
+void format_batch(const rbwt::RowBowt<> &rb, const RbAlignArgs &args, const Window &b, size_t w0, size_t w1, BatchSlot &slot,
+                  std::vector<rbg_cli::TextBuf> &pieces, size_t &used) {
+    const size_t N = w1 - w0;
+    const int G = static_cast<int>(slot.err.size());
+    for (int g = 0; g < G; ++g)
+        if (slot.err[g].rc) {   // what the single-replica path says, from the main thread, once every worker is done
+            fprintf(stderr, "%s (replica %d): %s\n", slot.err[g].what, g, rbg_strerror(slot.err[g].rc));
+            exit(1);
+        }
+#define res(g) (*slot.res[(g)])
     const auto t_q1 = std::chrono::steady_clock::now();
-    g_trace_query += std::chrono::duration<double>(t_q1 - t_q0).count();
+    g_trace_query += slot.query_s;
     const size_t T = std::max<size_t>(1, std::min<size_t>({static_cast<size_t>(args.threads), (N + 4095) / 4096, size_t(64)}));
     // piece (g, t): reads of shard g, t-th slice
     const size_t first_piece = used;
@@ -288,7 +305,7 @@ void report_batch(const rbwt::RowBowt<> &rb, const std::vector<rbg_index *> &rep
             const size_t n = res(g).end - res(g).begin;
             const size_t a = res(g).begin + n * t / T, z = res(g).begin + n * (t + 1) / T;
             if (a == z) continue;
-            std::string *dst = &pieces[first_piece + static_cast<size_t>(g) * T + t];
+            rbg_cli::TextBuf *dst = &pieces[first_piece + static_cast<size_t>(g) * T + t];
             const BatchResult *r = &res(g);
             if (g == 0 && t == 0) continue;  // done on this thread below
             workers.emplace_back([&rb, &args, &b, r, a, z, dst] { format_range(rb, args, b, *r, a, z, *dst); });
@@ -343,6 +360,13 @@ int main(int argc, char **argv) {
             reps.push_back(r);
         }
     }
+    if (args.sam) {   // load_rbwt asked for the DL flag: a missing .docs has already ended the run there (rowbowt_io.hpp:166-169)
+        rbwt::detail::check(rbg_doc_table(rb.handle(), &g_docs.n, &g_docs.starts, &g_docs.names, &g_docs.size), "rbg_doc_table");
+        for (uint64_t d = 0; d < g_docs.n; ++d) {
+            g_docs.name_len.push_back(std::strlen(g_docs.names[d]));
+            g_docs.max_name = std::max(g_docs.max_name, g_docs.name_len.back());
+        }
+    }
     auto stop = std::chrono::high_resolution_clock::now();
     const std::chrono::duration<double> index_load_time = stop - start;
 
@@ -357,15 +381,34 @@ int main(int argc, char **argv) {
     Window cur, nxt;
     err = input.next(cur);
     std::future<void> writer;
-    std::vector<std::string> pieces, writing;
+    std::vector<rbg_cli::TextBuf> pieces, writing;
     size_t used = 0, writing_used = 0;
+    BatchSlot slots[2];
     while (true) {
         std::future<int> scanner;
         const bool more = err == 0;
         if (more) scanner = std::async(std::launch::async, [&input, &nxt] { return input.next(nxt); });
         used = 0;
-        for (size_t w0 = 0; w0 < cur.size(); w0 += args.batch)
-            report_batch(rb, reps, args, cur, w0, std::min<size_t>(cur.size(), w0 + args.batch), pieces, used);
+        // two stages over the window's batches: batch j + 1 is queried (library calls: packing, GPU, results back) while
+        // batch j is formatted -- with forty locations per read the text is four fifths of a batch's time
+        {
+            auto bounds = [&](size_t j, size_t &w0, size_t &w1) { w0 = j * args.batch; w1 = std::min<size_t>(cur.size(), w0 + args.batch); };
+            const size_t nb = (cur.size() + args.batch - 1) / args.batch;
+            std::future<void> ahead;
+            size_t a0 = 0, a1 = 0;
+            if (nb) { bounds(0, a0, a1); query_batch(reps, args, cur, a0, a1, slots[0]); }
+            for (size_t j = 0; j < nb; ++j) {
+                if (ahead.valid()) ahead.get();
+                size_t w0, w1;
+                bounds(j, w0, w1);
+                if (j + 1 < nb) {
+                    bounds(j + 1, a0, a1);
+                    BatchSlot *nxt_slot = &slots[(j + 1) & 1];
+                    ahead = std::async(std::launch::async, [&reps, &args, &cur, a0, a1, nxt_slot] { query_batch(reps, args, cur, a0, a1, *nxt_slot); });
+                }
+                format_batch(rb, args, cur, w0, w1, slots[j & 1], pieces, used);
+            }
+        }
         {
             const auto tw0 = std::chrono::steady_clock::now();
             if (writer.valid()) writer.get();

@@ -60,7 +60,7 @@ struct RbMarkersArgs {  // rb_markers.cpp:22-40
     uint64_t threads = 8, max_tasks = 1024, read_len = 101, min_seed_len = 0;  // threads: host formatting workers (the reference's default of 1 is its search pool)
     int clear_conflicting = 0, clear_identical = 0, best_strand = 0, heuristic = 0;
     int device = 0;
-    uint64_t batch = 1u << 19;
+    uint64_t batch = 1u << 17;   // (several batches per 256 MB window keep both stages of the loop busy)
 };
 
 void print_help() {  // rb_markers.cpp:44-54
@@ -256,7 +256,7 @@ void make_seed(const RbMarkersArgs &args, const BatchSeeds &r, const rbg_marker_
 
 // text for reads [i0, i1); first_fwd[i] is the heuristic worker's coin for read i
 void format_range(const RbMarkersArgs &args, const BatchView &b, const BatchSeeds &r, const std::vector<uint8_t> &first_fwd,
-                  size_t i0, size_t i1, std::string &out_s) {
+                  size_t i0, size_t i1, rbg_cli::TextBuf &out_s) {
     rbg_cli::FastOut out(out_s);
     std::vector<MarkerSeed> seeds;
     MarkerSeed one;   // the default mode prints a seed as soon as it is made
@@ -352,41 +352,56 @@ struct RandomBoolGenerator {
 
 double g_trace[3] = {0, 0, 0};   // RB_ALIGN_TRACE=1: seconds building the strands, in the library call, sorting + formatting
 
-void report_batch(const rbwt::RowBowt<> &rb, const RbMarkersArgs &args, const BatchView &b, RandomBoolGenerator &booler,
-                  std::vector<std::string> &pieces) {
-    const size_t N = b.size();
-    const uint64_t ft_k = rb.ftab_k();
-    if (ft_k)
-        for (size_t i = 0; i < N; ++i)
-            if (b.seq_len(i) < ft_k) {  // the reference dies in std::string::substr (rowbowt.hpp:431)
-                fprintf(stderr, "ERROR: read shorter than the ftab k-mer size (%llu)\n", static_cast<unsigned long long>(ft_k));
-                exit(1);
-            }
+// One batch between the two stages of the loop: strands + library call | seeds -> text
+struct SeedSlot {
     std::string seqs;
     std::vector<uint64_t> off;
-    const auto t0 = std::chrono::steady_clock::now();
-    make_strands(b, seqs, off, static_cast<size_t>(args.threads));
-    const auto t1 = std::chrono::steady_clock::now();
     BatchSeeds r;
-    r.seed_off.resize(2 * N + 1);
-    rbwt::detail::check(rbg_get_markers_greedy_seeding(rb.handle(), reinterpret_cast<const uint8_t *>(seqs.data()), off.data(), 2 * N,
-                                                       args.wsize, args.max_range, ft_k, r.seed_off.data(), &r.seeds, &r.mk),
-                        "rbg_get_markers_greedy_seeding");
+    int rc = RBG_OK;
+    double t_strands = 0, t_query = 0;
+};
+
+// stage 1: both strands of every read, one library call for the 2N sequences
+void query_batch(const rbwt::RowBowt<> &rb, const RbMarkersArgs &args, const BatchView &b, SeedSlot &slot) {
+    const size_t N = b.size();
+    const uint64_t ft_k = rb.ftab_k();
+    const auto t0 = std::chrono::steady_clock::now();
+    make_strands(b, slot.seqs, slot.off, static_cast<size_t>(args.threads));
+    const auto t1 = std::chrono::steady_clock::now();
+    rbg_free_buffer(slot.r.seeds);
+    rbg_free_buffer(slot.r.mk);
+    slot.r.seeds = nullptr;
+    slot.r.mk = nullptr;
+    slot.r.seed_off.resize(2 * N + 1);
+    slot.rc = rbg_get_markers_greedy_seeding(rb.handle(), reinterpret_cast<const uint8_t *>(slot.seqs.data()), slot.off.data(), 2 * N, args.wsize,
+                                             args.max_range, ft_k, slot.r.seed_off.data(), &slot.r.seeds, &slot.r.mk);
+    slot.t_strands = std::chrono::duration<double>(t1 - t0).count();
+    slot.t_query = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+}
+
+// stage 2 (`pieces` is a pool that keeps its buffers from window to window: `used` counts the ones of this window)
+void format_batch(const RbMarkersArgs &args, const BatchView &b, SeedSlot &slot, RandomBoolGenerator &booler, std::vector<rbg_cli::TextBuf> &pieces,
+                  size_t &used) {
+    const size_t N = b.size();
+    rbwt::detail::check(slot.rc, "rbg_get_markers_greedy_seeding");
+    const BatchSeeds &r = slot.r;
     const auto t2 = std::chrono::steady_clock::now();
     std::vector<uint8_t> first_fwd(N, 1);
     if (args.heuristic)
         for (size_t i = 0; i < N; ++i) first_fwd[i] = booler.get_bool() ? 1 : 0;  // :483
     const size_t T = std::max<size_t>(1, std::min<size_t>({static_cast<size_t>(args.threads), (N + 4095) / 4096, size_t(64)}));
-    const size_t first_piece = pieces.size();
-    pieces.resize(first_piece + T);
+    const size_t first_piece = used;
+    used += T;
+    if (pieces.size() < used) pieces.resize(used);
+    for (size_t i = first_piece; i < used; ++i) pieces[i].clear();
     std::vector<std::thread> workers;
     for (size_t t = 1; t < T; ++t)
         workers.emplace_back([&, t] { format_range(args, b, r, first_fwd, N * t / T, N * (t + 1) / T, pieces[first_piece + t]); });
     format_range(args, b, r, first_fwd, 0, N / T, pieces[first_piece]);
     for (auto &w : workers) w.join();
     const auto t3 = std::chrono::steady_clock::now();
-    g_trace[0] += std::chrono::duration<double>(t1 - t0).count();
-    g_trace[1] += std::chrono::duration<double>(t2 - t1).count();
+    g_trace[0] += slot.t_strands;
+    g_trace[1] += slot.t_query;
     g_trace[2] += std::chrono::duration<double>(t3 - t2).count();
 }
 
@@ -419,20 +434,41 @@ int main(int argc, char **argv) {
     Window cur, nxt;
     err = input.next(cur);
     std::future<void> writer;
-    std::vector<std::string> pieces, writing;
+    std::vector<rbg_cli::TextBuf> pieces, writing;
+    size_t used = 0, writing_used = 0;
+    SeedSlot slots[2];
     while (true) {
         std::future<int> scanner;
         const bool more = err == 0;
         if (more) scanner = std::async(std::launch::async, [&input, &nxt] { return input.next(nxt); });
-        pieces.clear();
-        for (size_t w0 = 0; w0 < cur.size(); w0 += args.batch) {
-            const BatchView view{&cur, w0, std::min<size_t>(cur.size() - w0, args.batch)};
-            report_batch(rb, args, view, booler, pieces);
+        used = 0;
+        {   // two stages over the window's batches: batch j + 1 is searched while batch j's seeds are sorted and printed
+            const uint64_t ft_k = rb.ftab_k();
+            if (ft_k)
+                for (size_t i = 0; i < cur.size(); ++i)
+                    if (cur.recs.seq_len[i] < ft_k) {  // the reference dies in std::string::substr (rowbowt.hpp:431)
+                        fprintf(stderr, "ERROR: read shorter than the ftab k-mer size (%llu)\n", static_cast<unsigned long long>(ft_k));
+                        exit(1);
+                    }
+            const size_t nb = (cur.size() + args.batch - 1) / args.batch;
+            auto view = [&](size_t j) { return BatchView{&cur, j * args.batch, std::min<size_t>(cur.size() - j * args.batch, args.batch)}; };
+            std::future<void> ahead;
+            if (nb) query_batch(rb, args, view(0), slots[0]);
+            for (size_t j = 0; j < nb; ++j) {
+                if (ahead.valid()) ahead.get();
+                if (j + 1 < nb) {
+                    SeedSlot *ns = &slots[(j + 1) & 1];
+                    const BatchView nv = view(j + 1);
+                    ahead = std::async(std::launch::async, [&rb, &args, nv, ns] { query_batch(rb, args, nv, *ns); });
+                }
+                format_batch(args, view(j), slots[j & 1], booler, pieces, used);
+            }
         }
         if (writer.valid()) writer.get();
         writing.swap(pieces);
-        writer = std::async(std::launch::async, [&writing] {
-            for (const std::string &p : writing) fwrite(p.data(), 1, p.size(), stdout);
+        writing_used = used;
+        writer = std::async(std::launch::async, [&writing, &writing_used] {
+            for (size_t i = 0; i < writing_used; ++i) fwrite(writing[i].data(), 1, writing[i].size(), stdout);
         });
         if (!more) break;
         err = scanner.get();

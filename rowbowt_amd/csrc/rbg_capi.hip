@@ -14,6 +14,7 @@
 #include <mutex>
 #include <new>
 #include <stdexcept>
+#include <sstream>
 #include <string>
 #include <thread>
 #include <vector>
@@ -70,6 +71,7 @@ struct rbg_index {
     std::vector<std::unique_ptr<rbg_hostpath::Workspace>> ws_free;
     std::vector<ComposedLevel> kmer_levels;  // k-mer depths composed on the device (k_compose.hip): [0] = depth 2; arrays listed in `allocs`
     std::vector<DevSym> dense_todo;  // load time only: rank tables whose overflow buckets still need their dense tables
+    std::vector<const char *> doc_name_ptrs;  // rbg_doc_table's view of the document names
     std::mutex mu;               // guards marker/doc attachment only; queries are lock-free
 };
 
@@ -1704,11 +1706,37 @@ int rbg_convert_raw(const char *bwt_fname, const char *ssa_fname, const char *es
 static int runs_to_bundle(const uint8_t *heads, const uint64_t *lens, uint64_t R, const uint64_t *ssa_y, const uint64_t *esa_y, FlatBundle &b);
 
 int rbg_convert_runs(const uint8_t *heads, const uint64_t *lens, uint64_t R, const uint64_t *ssa_y, const uint64_t *esa_y, const char *out_path) {
+    return rbg_convert_runs_markers(heads, lens, R, ssa_y, esa_y, nullptr, nullptr, 0, nullptr, nullptr, nullptr, out_path);
+}
+
+int rbg_convert_runs_markers(const uint8_t *heads, const uint64_t *lens, uint64_t R, const uint64_t *ssa_y, const uint64_t *esa_y,
+                             const uint64_t *mk_start, const uint64_t *mk_end, uint64_t mk_nruns, const uint64_t *mk_off, const uint64_t *mk_vals,
+                             const char *docs_text, const char *out_path) {
     return guarded([&]() -> int {
     if (!heads || !lens || !out_path || R == 0 || (!!ssa_y != !!esa_y)) return RBG_EARG;
+    if (mk_nruns && (!mk_start || !mk_end || !mk_off || !mk_vals)) return RBG_EARG;
     FlatBundle b;
-    const int rc = runs_to_bundle(heads, lens, R, ssa_y, esa_y, b);
+    int rc = runs_to_bundle(heads, lens, R, ssa_y, esa_y, b);
     if (rc) return rc;
+    if (mk_nruns) {
+        if (!markers_valid(mk_start, mk_end, mk_nruns, mk_off)) return RBG_EARG;
+        if (mk_end[mk_nruns - 1] >= b.rle.n) return RBG_EARG;
+        b.ma.start.assign(mk_start, mk_start + mk_nruns);
+        b.ma.end.assign(mk_end, mk_end + mk_nruns);
+        b.ma.off.assign(mk_off, mk_off + mk_nruns + 1);
+        b.ma.vals.assign(mk_vals, mk_vals + mk_off[mk_nruns]);
+        b.has_ma = true;
+    }
+    if (docs_text) {   // the text of a .docs file (doclist.hpp:57-73: whitespace-separated name / start pairs)
+        std::istringstream ss{std::string(docs_text)};
+        std::string name;
+        uint64_t pos = 0;
+        while (ss >> name >> pos) { b.dl.names.push_back(name); b.dl.starts.push_back(pos); }
+        if (b.dl.names.empty()) return RBG_EARG;
+        b.dl.sorted = b.dl.starts;
+        std::sort(b.dl.sorted.begin(), b.dl.sorted.end());
+        b.has_dl = true;
+    }
     return write_flat(out_path, b);
     });
 }
@@ -1974,6 +2002,29 @@ int rbg_resolve_offset(const rbg_index *ix, uint64_t i, const char **name, uint6
     if (rank == 0) return RBG_EARG;  // reference indexes doc_names_[-1] here
     *offset = i - d.sorted[rank - 1];           // doclist.hpp:48
     *name = d.names[rank - 1].c_str();          // doclist.hpp:49
+    return RBG_OK;
+    });
+}
+
+// The table rbg_resolve_offset answers from, for callers that resolve millions of positions (rb_align -s prints some
+// forty per read): a call per position through the ABI was a third of that tool's formatting time.
+int rbg_doc_table(rbg_index *ix, uint64_t *ndocs, const uint64_t **sorted_starts, const char *const **names, uint64_t *size) {
+    return guarded([&]() -> int {
+    if (!ix || !ndocs || !sorted_starts || !names || !size) return RBG_EARG;
+    rbg_index *root = ix->primary ? ix->primary : ix;
+    if (!root->H().has_dl || root->H().dl.names.empty()) return RBG_ENOTLOADED;
+    const RawDocs &d = root->H().dl;
+    {
+        std::lock_guard<std::mutex> g(root->mu);
+        if (root->doc_name_ptrs.size() != d.names.size()) {
+            root->doc_name_ptrs.clear();
+            for (const std::string &n : d.names) root->doc_name_ptrs.push_back(n.c_str());
+        }
+    }
+    *ndocs = d.names.size();
+    *sorted_starts = d.sorted.data();
+    *names = root->doc_name_ptrs.data();
+    *size = d.starts.back() + 1;
     return RBG_OK;
     });
 }

@@ -161,6 +161,56 @@ def test_input_source_plain_and_gzip_match_kseq_model(cli_input, tmp_path, name)
             assert (got, rc) == ([(n, s) for n, s in want], want_rc), (name, path.name, window, threads)
 
 
+def bgzf_bytes(data, block=65280, level=6):
+    """`data` as a BGZF file (htslib's blocked gzip): independent members of at most 64 KB, each with the extra subfield
+    'BC' holding its compressed size - 1, closed by the empty end-of-file block"""
+    import struct
+    import zlib
+    out = bytearray()
+    for a in list(range(0, len(data), block)) + [None]:
+        chunk = b"" if a is None else data[a:a + block]
+        c = zlib.compressobj(level, zlib.DEFLATED, -15)
+        payload = c.compress(chunk) + c.flush()
+        bsize = 12 + 6 + len(payload) + 8
+        out += b"\x1f\x8b\x08\x04" + b"\0\0\0\0" + b"\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize - 1)
+        out += payload + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk))
+    return bytes(out)
+
+
+def test_input_source_bgzf_blocks_inflated_in_parallel(cli_input, tmp_path):
+    """a BGZF file (bgzip / htslib output) is mapped and its blocks inflated by the worker threads: same records and end
+    code as kseq_read over the decompressed bytes, whatever the window; gzip.open reads the same file (it IS gzip); a
+    corrupted block ends the stream with -3 after the records that came before it, like a failing gzread"""
+    import gzip
+    rng = np.random.default_rng(33)
+    seqs = [bytes(rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), int(rng.integers(1, 400)))) for _ in range(3000)]
+    fq = b"".join(b"@r%d c\n" % i + s + b"\n+\n" + b"@" * len(s) + b"\n" for i, s in enumerate(seqs))
+    fa = b"".join(b">r%d\n" % i + s + b"\n" for i, s in enumerate(seqs))
+    for name, data in (("b.fq.gz", fq), ("b.fa.gz", fa), ("trunc.fq.gz", fq[:len(fq) - 57])):
+        path = tmp_path / name
+        path.write_bytes(bgzf_bytes(data, block=int(rng.integers(500, 65280))))
+        assert gzip.open(path, "rb").read() == data
+        want, want_rc = kseq_model(data)
+        for window, threads, minseg in ((1 << 20, 4, 1000), (7000, 3, 300), (100, 2, 50), (1 << 20, 1, 1 << 20)):   # (1 thread: zlib's stream)
+            got, rc = cli_input(path, window, threads, minseg)
+            assert (got, rc) == ([(n, s) for n, s in want], want_rc), (name, window, threads)
+    # corruption: flip a byte inside the payload of a block in the middle
+    blob = bytearray(bgzf_bytes(fq, block=4000))
+    pos, k = 0, 0
+    while k < 40:
+        pos += (blob[pos + 16] | (blob[pos + 17] << 8)) + 1
+        k += 1
+    blob[pos + 30] ^= 0x5A
+    bad = tmp_path / "bad.fq.gz"
+    bad.write_bytes(bytes(blob))
+    want, _ = kseq_model(fq)
+    for window, threads in ((1 << 20, 4), (9000, 3)):
+        got, rc = cli_input(bad, window, threads, 500)
+        # (the record the bad block cuts may come out shortened, as from kseq_read when gzread fails inside a sequence)
+        assert rc == -3 and 0 < len(got) < len(want) and got[:-1] == [(n, s) for n, s in want][:len(got) - 1]
+        assert len(got) >= 40 * 4000 // 900 - 30      # everything before the bad block was delivered
+
+
 def test_input_source_every_window_is_scanned_in_parallel(cli_input, tmp_path):
     """FASTA and FASTQ over many windows with several scanning threads, mapped and through zlib: same records as
     kseq_read, and EVERY window goes through the multi-threaded scan -- also the FASTA windows that begin right after an
