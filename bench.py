@@ -78,6 +78,8 @@ def parse():
                          "that a profile of the default command holds undisturbed per-kernel durations)")
     ap.add_argument("--no-space-speed", action="store_true",
                     help="skip the space_speed block (the replica rebuilt at 4, 3, 2 and 1 symbols per gather; about a minute)")
+    ap.add_argument("--slot-bytes", type=int, default=0, choices=(0, 16, 64),
+                    help="bytes per rank slot (RBG_OPT_SLOT_BYTES): 16, or 64 = the 64-byte slots of DESIGN.md 4 r03; 0 = the library's default")
     ap.add_argument("--via-cache", action="store_true",
                     help="build the replica through the native cache file even on one GPU (with --gpus N > 1 every rank does: rank 0 "
                          "writes it to node-local shared memory once, all ranks load it)")
@@ -144,6 +146,9 @@ def main():
     from rowbowt_amd.tools import synth_pangenome as sp
 
     L = ra.lib()
+    if args.slot_bytes:
+        from rowbowt_amd import capi as _c
+        _c.set_default_option(_c.OPT_SLOT_BYTES, args.slot_bytes)
     m = args.read_len
     max_hits = MAXU if args.max_hits < 0 else args.max_hits
 
@@ -507,12 +512,16 @@ def main():
         # ---- bytes of the algorithm AS RUN, from the instrumented pass: what each kernel has to
         # move for the steps it actually executed, at the sizes it is stored in HBM -- no sector padding, no re-reads.
         P = int(ix.pos_bytes)
+        slot_b = int(ix.slot_bytes) or 16
         ftab_entry = 16 if P == 4 else 32
 
         def search_bytes(sv, toehold):
             # per read: its two offsets (16) and its outputs (lo, hi [, toehold]); per 16-byte read chunk fetched;
             # per ftab entry; per 16-byte rank slot; per 2-byte dense-table row; per rank searched in a run list:
             # two ord entries + ~3 probes of a {start, cum} pair; per materialised re-sample: ord (4) + sample (P)
+            if slot_b == 64:   # 64-byte slots: a dense-table row is 4 bytes, a materialised re-sample one gather of P
+                return (N * (16 + (24 if toehold else 16)) + 16 * sv["read_chunks"] + ftab_entry * sv["ftab"] + 64 * sv["slots"]
+                        + 4 * sv["dense"] + P * sv["resamples"])
             return (N * (16 + (24 if toehold else 16)) + 16 * sv["read_chunks"] + ftab_entry * sv["ftab"] + 16 * sv["slots"]
                     + 2 * sv["dense"] + (8 + 3 * 2 * P) * sv["searched_ranks"] + (4 + P) * sv["resamples"])
 
@@ -563,7 +572,7 @@ def main():
         # TCC_MISS of the same launch = these gathers + those sectors (273M = 231M + 42M on the default workload).
         gathers = None
         if dom == "k_find_range<toehold>":
-            gathers = st_toe["slots"] + st_toe["dense"] + st_toe["ftab"] + 2 * st_toe["resamples"] + 4 * st_toe["searched_ranks"]
+            gathers = st_toe["slots"] + st_toe["dense"] + st_toe["ftab"] + (1 if slot_b == 64 else 2) * st_toe["resamples"] + 4 * st_toe["searched_ranks"]
         out = {
             "metric": f"reads/s ({args.read_len} bp, count+locate)",
             "value": value,
@@ -582,7 +591,7 @@ def main():
                             f"synthetic chr22-scale pangenome r-index, {N} x {m} bp reads per GPU per step (BASELINE.json configs[2])",
                 "index": {"L": args.L, "H": args.H, "n": int(inp["n"]), "r": int(inp["r"]), "site_rate": args.site_rate,
                           "hbm_bytes": int(ix.hbm_bytes), "pos_bytes": int(ix.pos_bytes), "seed": args.seed,
-                          "symbols_per_gather": int(ix.kmer_steps), "symbols_per_gather_requested": int(ix.kmer_steps_requested),
+                          "slot_bytes": slot_b, "symbols_per_gather": int(ix.kmer_steps), "symbols_per_gather_requested": int(ix.kmer_steps_requested),
                           "hbm_free_at_load": int(ix.hbm_free_at_load), "hbm_budget": int(ix.hbm_budget), "ftab_k": int(ix.ftab_k), "pair_runs": int(ix.pair_runs), "triple_runs": int(ix.triple_runs), "quad_runs": int(ix.quad_runs), "quint_runs": int(ix.quint_runs)},
                 "reads_per_gpu": N, "read_len": m, "substituted_fraction": 0.1,
                 "parallelism": f"index replicated x{world}, reads sharded, no data-path collective",

@@ -132,7 +132,7 @@ typedef struct rbg_info_t {
     uint64_t hbm_bytes;     /* bytes of the device replica */
     uint64_t marker_runs, marker_vals;
     uint32_t rank_bucket_shift, phi_bucket_shift;
-    uint32_t reserved;
+    uint32_t slot_bytes;    /* bytes per rank slot of the slot layout: 16, or 64 (RBG_OPT_SLOT_BYTES); 0 on the run-indexed layout or without a device */
     /* first-level slot tables: totals and how many buckets overflow their 2 inline entries */
     uint64_t rank_slots, rank_slots_overflow, phi_slots, phi_slots_overflow;
     /* multi-symbol LF steps: symbols consumed per gather (1..5), size of the major alphabet that has
@@ -448,7 +448,10 @@ int rbg_sample_reads_dev(const uint8_t *d_text, uint64_t unit, uint64_t H, uint6
  * rule did. */
 enum { RBG_OPT_BLOCK_THREADS = 1, RBG_OPT_RANK_BUCKET_SHIFT = 2, RBG_OPT_PHI_BUCKET_SHIFT = 3, RBG_OPT_POS_BYTES = 4,
        RBG_OPT_KMER_STEPS = 5, RBG_OPT_HBM_BUDGET_MB = 6, RBG_OPT_FTAB_K = 7, RBG_OPT_PACKED_READS = 8,
-       RBG_OPT_DEEP_BUCKET_SHIFT = 9, RBG_OPT_DENSE_OVERFLOW = 10, RBG_OPT_RANK_LAYOUT = 11, RBG_OPT_TREE_TOP_KB = 12 };
+       RBG_OPT_DEEP_BUCKET_SHIFT = 9, RBG_OPT_DENSE_OVERFLOW = 10, RBG_OPT_RANK_LAYOUT = 11, RBG_OPT_TREE_TOP_KB = 12,
+       RBG_OPT_SLOT_BYTES = 13 /* 16 (default) or 64: 64-byte rank slots over four times the rows -- the sector a 16-byte
+                                  gather moves anyway, fetched by a quad of lanes; slot layout only, falls
+                                  back to 16 when a table needs wide buckets; rbg_info().slot_bytes says what was built */ };
 int rbg_set_default_option(int opt, int64_t value);
 /* the value a later load would use (so that a caller can change a knob for one load and put it back) */
 int rbg_get_default_option(int opt, int64_t *value);

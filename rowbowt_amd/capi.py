@@ -20,7 +20,7 @@ VP = C.c_void_p
 MAXU = 2**64 - 1
 DEVICE_NONE = -1
 
-OPT_BLOCK_THREADS, OPT_RANK_BUCKET_SHIFT, OPT_PHI_BUCKET_SHIFT, OPT_POS_BYTES, OPT_KMER_STEPS, OPT_HBM_BUDGET_MB, OPT_FTAB_K, OPT_PACKED_READS, OPT_DEEP_BUCKET_SHIFT, OPT_DENSE_OVERFLOW, OPT_RANK_LAYOUT, OPT_TREE_TOP_KB = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12
+OPT_BLOCK_THREADS, OPT_RANK_BUCKET_SHIFT, OPT_PHI_BUCKET_SHIFT, OPT_POS_BYTES, OPT_KMER_STEPS, OPT_HBM_BUDGET_MB, OPT_FTAB_K, OPT_PACKED_READS, OPT_DEEP_BUCKET_SHIFT, OPT_DENSE_OVERFLOW, OPT_RANK_LAYOUT, OPT_TREE_TOP_KB, OPT_SLOT_BYTES = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13
 LAYOUT_AUTO, LAYOUT_SLOTS, LAYOUT_RUNS = 0, 1, 2
 (ARR_RUN_HEADS, ARR_RUN_START, ARR_SAMPLES_LAST, ARR_PRED_POS, ARR_PHI_BASE,
  ARR_MARKER_START, ARR_MARKER_END, ARR_MARKER_OFF, ARR_MARKER_VALS) = range(9)
@@ -45,7 +45,7 @@ class Info(C.Structure):
     _fields_ = [("n", U64), ("r", U64), ("sigma", C.c_uint32), ("pos_bytes", C.c_uint32), ("device", C.c_int32),
                 ("has_tsa", C.c_uint32), ("has_markers", C.c_uint32), ("has_docs", C.c_uint32),
                 ("hbm_bytes", U64), ("marker_runs", U64), ("marker_vals", U64),
-                ("rank_bucket_shift", C.c_uint32), ("phi_bucket_shift", C.c_uint32), ("reserved", C.c_uint32),
+                ("rank_bucket_shift", C.c_uint32), ("phi_bucket_shift", C.c_uint32), ("slot_bytes", C.c_uint32),
                 ("rank_slots", U64), ("rank_slots_overflow", U64), ("phi_slots", U64), ("phi_slots_overflow", U64),
                 ("kmer_steps", U64), ("kmer_symbols", U64), ("pair_runs", U64), ("triple_runs", U64), ("quad_runs", U64), ("ftab_k", U64), ("quint_runs", U64),
                 ("kmer_steps_requested", U64), ("hbm_free_at_load", U64), ("hbm_budget", U64), ("rank_layout", U64), ("replicas", U64)]

@@ -442,6 +442,7 @@ int launch_find_range_impl(const DevIndex &ix, const LaunchCfg &cfg, const uint8
 int launch_find_range_stats(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
                             uint64_t *lo, uint64_t *hi, uint64_t *ssamp, unsigned long long *stats, void *stream) {
     if (ix.layout == 2) return launch_find_range_runs(ix, cfg, seqs, off, N, lo, hi, ssamp, stream, stats);  // (its sums mean other things: rbg.h)
+    if (ix.slot_bytes == 64) return launch_find_range64(ix, cfg, seqs, off, N, lo, hi, ssamp, nullptr, nullptr, stats, stream);
     return ix.ftab_k ? launch_find_range_impl<true, true>(ix, cfg, seqs, off, N, lo, hi, ssamp, nullptr, nullptr, stream, stats)
                      : launch_find_range_impl<false, true>(ix, cfg, seqs, off, N, lo, hi, ssamp, nullptr, nullptr, stream, stats);
 }
@@ -449,6 +450,7 @@ int launch_find_range_stats(const DevIndex &ix, const LaunchCfg &cfg, const uint
 int launch_find_range(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
                       uint64_t *lo, uint64_t *hi, uint64_t *ssamp, void *stream) {
     if (ix.layout == 2) return launch_find_range_runs(ix, cfg, seqs, off, N, lo, hi, ssamp, stream);  // run-indexed layout (k_runs.hip)
+    if (ix.slot_bytes == 64) return launch_find_range64(ix, cfg, seqs, off, N, lo, hi, ssamp, nullptr, nullptr, nullptr, stream);   // 64-byte slots (k_search64.hip)
     // without a table the table-free instantiation runs (it is also the one that BUILDS the table,
     // so profiles show that one-off launch under its own kernel name)
     return ix.ftab_k ? launch_find_range_impl<true>(ix, cfg, seqs, off, N, lo, hi, ssamp, nullptr, nullptr, stream)
@@ -557,6 +559,7 @@ int launch_find_range_packed(const DevIndex &ix, const LaunchCfg &cfg, const voi
     if (rc) return rc;
     // the reads the packed form cannot express (a symbol outside the major alphabet)
     const uint32_t *sel = reinterpret_cast<const uint32_t *>(b + L.sel), *nsel = reinterpret_cast<const uint32_t *>(b + L.nsel);
+    if (ix.slot_bytes == 64) return launch_find_range64(ix, cfg, seqs, off, N, lo, hi, ssamp, sel, nsel, nullptr, stream);
     return ix.ftab_k ? launch_find_range_impl<true>(ix, cfg, seqs, off, N, lo, hi, ssamp, sel, nsel, stream)
                      : launch_find_range_impl<false>(ix, cfg, seqs, off, N, lo, hi, ssamp, sel, nsel, stream);
 }

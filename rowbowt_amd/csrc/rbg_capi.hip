@@ -88,6 +88,7 @@ std::atomic<int64_t> g_opt_deep_shift{-1};
 std::atomic<int64_t> g_opt_dense_overflow{1};
 std::atomic<int64_t> g_opt_rank_layout{0};    // RBG_LAYOUT_AUTO / _SLOTS / _RUNS
 std::atomic<int64_t> g_opt_tree_top_kb{48};   // LDS the staged top levels of the run-indexed search may take per workgroup
+std::atomic<int64_t> g_opt_slot_bytes{16};    // 16: RankSlot; 64: RankSlot64 (experiment: rbg_dev.h)
 std::atomic<int64_t> g_opt_packed_reads{1};  // host-pointer calls: 0 bytes over PCIe, 1 (default) 2-bit codes for batches >= 4096, 2 always
 
 #define HIP_TRY(expr)                                                                             \
@@ -253,12 +254,15 @@ int dev_upload(rbg_index *ix, const void *src, size_t bytes, const void **dst) {
     return RBG_OK;
 }
 
+thread_local bool t_slot64 = false;   // the load in progress on this thread builds 64-byte slots (upload() decides)
+
 // bytes of one table in the replica; in_arena: what the arena has to hold of it (a table composed on the device keeps
 // its run list and samples in the level's own allocation)
 template <typename P>
 size_t table_bytes(const SymTable &t, bool with_samples, uint64_t n, bool in_arena = false) {
     const uint64_t nb = (n >> t.shift) + 2;
     const size_t lists = (in_arena && t.dev_ent) ? 0 : arena_round((t.nruns + 1) * sizeof(RunEnt<P>)) + (with_samples ? arena_round(t.nruns * sizeof(P)) : 0);
+    if (t_slot64) return lists + arena_round(((n >> (t.shift + kSlot64Extra)) + 2) * sizeof(RankSlot64));   // (the ordinal is in the slot)
     return lists + arena_round(nb * sizeof(RankSlot)) + arena_round(nb * sizeof(uint32_t));
 }
 
@@ -326,6 +330,20 @@ int commit_sym(rbg_index *ix, const SymTable &t, bool with_samples, PreparedSym<
     } else {
         if ((rc = dev_upload(ix, p.ent.data(), p.ent.size() * sizeof(RunEnt<P>), &d.ent))) return rc;
         if (with_samples && (rc = dev_upload(ix, p.samp.data(), p.samp.size() * sizeof(P), &d.samp))) return rc;
+    }
+    if (t_slot64) {   // one 64-byte slot per 4 x 2^shift rows, built from the run list and its samples (rbg_dev.h RankSlot64)
+        const uint64_t nb64 = (ix->H().n >> (t.shift + kSlot64Extra)) + 2;
+        void *s64 = nullptr;
+        if ((rc = dev_reserve(ix, nb64 * sizeof(RankSlot64), &s64))) return rc;
+        if (launch_build_rank_slots64(sizeof(P), d.ent, d.samp, t.nruns, ix->H().n, t.shift, s64, d_overflow, d_overflow + 2, nullptr)) return RBG_ENODEV;
+        d.slots = s64;
+        d.ord = nullptr;
+        ix->rank_slots += nb64;
+        d.F = t.F;
+        d.shift = t.shift;
+        d.nruns = static_cast<uint32_t>(t.nruns);
+        ix->dense_todo.push_back(d);
+        return RBG_OK;
     }
     const uint64_t nb = (ix->H().n >> t.shift) + 2;
     void *slots = nullptr, *ord = nullptr;
@@ -452,7 +470,19 @@ int upload_tables(rbg_index *ix) {
     // second pass over the rank tables: now that the number of overflow buckets is known, give each its
     // dense table (rbg_dev.h).  The slots hold 32-bit offsets in 16-byte units: a pool beyond 64 GB (never seen:
     // 2.7 GB for the bench index) leaves the run-list search in place, as does an allocation failure.
-    if (counts[2] > 0 && counts[2] < (1ull << 32)) {
+    if (t_slot64 && counts[2] > 0) {   // 4 KB per overflow bucket (one u32 per row)
+        VStage vs("dense tables of the overflow buckets (64-byte slots)");
+        if (counts[2] >= (1ull << 32)) return RBG_ENOMEM;
+        void *pool = nullptr;
+        const size_t bytes = static_cast<size_t>(counts[2]) * 4096 + 64;
+        HIP_TRY(hipMalloc(&pool, bytes));
+        ix->allocs.push_back({pool, bytes});
+        ix->hbm_bytes += bytes;
+        for (const DevSym &d : ix->dense_todo)
+            if (launch_fill_dense64(sizeof(P), d.ent, h.n, d.shift, d.slots, static_cast<uint8_t *>(pool), nullptr)) return RBG_ENODEV;
+        HIP_TRY(hipDeviceSynchronize());
+        ix->dev.dense = static_cast<const uint8_t *>(pool);
+    } else if (counts[2] > 0 && counts[2] < (1ull << 32)) {
         VStage vs("dense tables of the overflow buckets");
         void *pool = nullptr;
         const size_t bytes = static_cast<size_t>(counts[2]) * 16 + 64;
@@ -1051,6 +1081,13 @@ int upload(rbg_index *ix) {
         runs_layout = false;
     }
     ix->runs_layout = runs_layout;
+    // 64-byte slots (experiment): only the slot layout, only while every table sits at narrow buckets (the budget rule's
+    // wider buckets keep the 16-byte encoding) and with dense tables for the overflow buckets
+    bool want64 = g_opt_slot_bytes.load() == 64 && !runs_layout && g_opt_dense_overflow.load() != 0;
+    for (const std::vector<SymTable> *lv : {&h.sym, &h.pair, &h.triple, &h.quad, &h.quint})
+        for (const SymTable &t : *lv)
+            if (t.shift > kMaxNarrowShift) want64 = false;
+    struct Slot64Scope { bool prev; explicit Slot64Scope(bool v) : prev(t_slot64) { t_slot64 = v; } ~Slot64Scope() { t_slot64 = prev; } } slot64_scope(want64);
     auto levels = [&] { return !h.quint.empty() ? 5 : !h.quad.empty() ? 4 : !h.triple.empty() ? 3 : !h.pair.empty() ? 2 : 1; };
     if (runs_layout) {
         // the k-mer depths stay (their run lists are O(r) too: DevRunTab, rbg_dev.h); the deepest goes while the replica
@@ -1073,6 +1110,7 @@ int upload(rbg_index *ix) {
     // and try again.  At pangenome scale this keeps a level more than dropping alone.
     auto widen = [&](std::vector<SymTable> &lvl) {
         if (h.n >> 40) return;  // wide slots carry 40-bit ranks
+        if (t_slot64) return;   // (64-byte slots have no wide form: levels are dropped instead)
         for (SymTable &t : lvl) {
             const double rows_per_run = static_cast<double>(h.n) / static_cast<double>(std::max<uint64_t>(1, t.nruns));
             uint32_t want = 0;
@@ -1105,6 +1143,7 @@ int upload(rbg_index *ix) {
                      (runs_layout ? (h.pos_bytes == 4 ? runs_replica_bytes<uint32_t>(h) : runs_replica_bytes<uint64_t>(h)) : need()) / 1e9);
     int rc;
     d.layout = RBG_LAYOUT_SLOTS;
+    d.slot_bytes = t_slot64 ? 64 : 16;
     if (runs_layout) {
         if (std::getenv("RBG_VERBOSE")) std::fprintf(stderr, "rbg: device %d: run-indexed layout (space proportional to r)\n", ix->device);
         rc = h.pos_bytes == 4 ? upload_tables_runs<uint32_t>(ix) : upload_tables_runs<uint64_t>(ix);
@@ -1590,6 +1629,9 @@ int rbg_set_default_option(int opt, int64_t value) {
         case RBG_OPT_TREE_TOP_KB:
             if (value < 0 || value > 96) return RBG_EARG;  // 0 = 16 keys in all: the deepest tree (tests)
             g_opt_tree_top_kb = value; return RBG_OK;
+        case RBG_OPT_SLOT_BYTES:
+            if (value != 16 && value != 64) return RBG_EARG;
+            g_opt_slot_bytes = value; return RBG_OK;
         default: return RBG_EARG;
     }
     });
@@ -1611,6 +1653,7 @@ int rbg_get_default_option(int opt, int64_t *value) {
         case RBG_OPT_PACKED_READS: *value = g_opt_packed_reads.load(); return RBG_OK;
         case RBG_OPT_RANK_LAYOUT: *value = g_opt_rank_layout.load(); return RBG_OK;
         case RBG_OPT_TREE_TOP_KB: *value = g_opt_tree_top_kb.load(); return RBG_OK;
+        case RBG_OPT_SLOT_BYTES: *value = g_opt_slot_bytes.load(); return RBG_OK;
         default: return RBG_EARG;
     }
     });
@@ -1934,6 +1977,7 @@ int rbg_info(const rbg_index *ix, rbg_info_t *out) {
     out->kmer_steps = !ix->H().quint.empty() ? 5 : !ix->H().quad.empty() ? 4 : !ix->H().triple.empty() ? 3 : !ix->H().pair.empty() ? 2 : 1;
     if (ix->device != RBG_DEVICE_NONE && ix->dev.layout == RBG_LAYOUT_RUNS) out->kmer_steps = ix->dev.run_ksteps;   // depths of the run-indexed search
     out->kmer_symbols = ix->H().pair.empty() ? 0 : ix->H().nmajor;
+    out->slot_bytes = ix->device != RBG_DEVICE_NONE && ix->dev.layout == RBG_LAYOUT_SLOTS ? ix->dev.slot_bytes : 0;
     out->ftab_k = ix->dev.ftab_k;
     out->kmer_steps_requested = ix->kmer_steps_requested ? ix->kmer_steps_requested : out->kmer_steps;
     out->hbm_free_at_load = ix->hbm_free_at_load;

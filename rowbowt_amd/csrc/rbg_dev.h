@@ -54,6 +54,27 @@ struct PhiEnt {
 struct alignas(16) RankSlot {
     uint32_t r0, w1, w2, w3;
 };
+// 64-BYTE RANK SLOTS (RBG_OPT_SLOT_BYTES = 64; experiment of round 3).  A 16-byte slot costs a 64-byte
+// sector of fabric traffic anyway, and a quad of lanes fetching the four quarters of ONE aligned 64-byte record is served at
+// the rate of 16-byte gathers (tools/slot64_probe.hip: 47-48 G records/s against 49 G/s).  So the same bytes per BWT row can
+// be spent as one 64-byte slot per 4 x 2^shift rows (1024 at the usual shift 8): fewer steps whose two positions straddle
+// two buckets, fourteen inline runs instead of 4 x 4 that rarely fill, the run ordinal inline (no `ord` array: a fifth of
+// the replica) and the predecessor run's SAMPLE inline -- a toehold re-sample that lands before the bucket's first run
+// costs no gather at all, any other one gather instead of two.
+//   w0  = rank(B0, c) bits 0-31
+//   w1  = rank bits 32-47 | ext << 16 (11 bits: 0..1024 rows from B0 covered by a run that began before) | prev_is_c << 27
+//         | cnt << 28 (runs that START inside the bucket, 0..14; 15 = more: dense table)
+//   w2  = ord: # runs of the table starting before B0
+//   w3,w4 = samples_last of run ord - 1 (the sample a re-sample needs when no run starts between B0 and the row), 0 if none
+//   w5..w13 = the runs, 20 bits each from bit 0 of w5: off (10 bits) | (len - 1) << 10, len clipped to the bucket
+//   cnt == 15: w5 = index of the bucket's dense table in DevIndex::dense (4 KB each): one u32 per row o --
+//         rank(B0 + o) - r0 (bits 0-10) | # runs starting in [B0, B0 + o) << 11 (10 bits) | (row B0 + o - 1 holds c) << 31
+// Only for tables at narrow buckets (shift <= 8: bucket shift <= 10); an index with a wide-bucket table keeps 16-byte slots.
+struct alignas(64) RankSlot64 {
+    uint32_t w[16];
+};
+constexpr int kSlot64Runs = 14;
+constexpr uint32_t kSlot64Ovf = 15, kSlot64Extra = 2;   // bucket shift = table shift + kSlot64Extra
 constexpr int kSlotRuns = 4;
 constexpr int kSlotRunsWide = 2;
 constexpr uint32_t kMaxNarrowShift = 8, kMaxWideShift = 12;
@@ -174,7 +195,7 @@ struct DevIndex {
     // >= b << mk_shift (mk_nruns if none); (n >> mk_shift) + 2 entries; nullptr = binary search only
     const uint32_t *mk_bucket;
     uint32_t mk_shift;
-    uint32_t pad4;
+    uint32_t slot_bytes;   // 16 (RankSlot) or 64 (RankSlot64; DevSym::ord is nullptr then and `shift` stays the TABLE's shift)
     // {reads, matched, sum occ, sum locs}
     unsigned long long *counters;
     const uint8_t *lut;  // 256 bytes, device memory
@@ -313,6 +334,9 @@ struct LaunchCfg {
 // launchers (k_search.hip, k_locate.hip, k_markers.hip, k_build.hip).  All asynchronous on `stream`; return hipError_t as int.
 int launch_find_range(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
                       uint64_t *lo, uint64_t *hi, uint64_t *ssamp /*nullable*/, void *stream);
+// 64-byte slots (k_search64.hip); sel / nsel / stats as in launch_find_range's variants (nullable)
+int launch_find_range64(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N, uint64_t *lo, uint64_t *hi,
+                        uint64_t *ssamp /*nullable*/, const uint32_t *sel, const uint32_t *nsel, unsigned long long *stats, void *stream);
 // run-indexed layout (k_runs.hip)
 int launch_find_range_runs(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
                            uint64_t *lo, uint64_t *hi, uint64_t *ssamp /*nullable*/, void *stream,
@@ -359,6 +383,10 @@ int launch_build_rank_slots(uint32_t pos_bytes, const void *ent, uint64_t nruns,
 // second pass, once the pool of dense_cursor * 16 bytes exists: fills the dense tables of one rank table
 int launch_fill_dense(uint32_t pos_bytes, const void *ent, uint64_t n, uint32_t shift, const void *slots, const uint32_t *ord,
                       uint8_t *dense, void *stream);
+// 64-byte slots (RankSlot64): samp = the table's samples (nullable); dense_cursor counts 4 KB dense tables handed out
+int launch_build_rank_slots64(uint32_t pos_bytes, const void *ent, const void *samp, uint64_t nruns, uint64_t n, uint32_t shift, void *slots,
+                              unsigned long long *overflow, unsigned long long *dense_cursor, void *stream);
+int launch_fill_dense64(uint32_t pos_bytes, const void *ent, uint64_t n, uint32_t shift, const void *slots, uint8_t *dense, void *stream);
 int launch_build_phi_slots(uint32_t pos_bytes, bool packed, const void *ent, uint64_t r, uint64_t n, uint32_t shift, void *slots, uint32_t *ord,
                            unsigned long long *overflow, void *stream);
 // packed reads (2 bits per symbol): pack the byte batch once, then search the packed form

@@ -406,6 +406,56 @@ def test_device_compose_matches_host_compose(synth, pos_bytes):
     o.close()
 
 
+@pytest.mark.parametrize("pos_bytes,rshift,ksteps,fk", [(4, -1, 5, -1), (8, -1, 5, -1), (4, 8, 3, 0), (4, 4, 5, 3), (8, 2, 1, -1), (4, 0, 2, -1)])
+def test_slots_of_64_bytes(synth, pos_bytes, rshift, ksteps, fk):
+    """RBG_OPT_SLOT_BYTES = 64 (rbg_dev.h RankSlot64, k_search64.hip): one 64-byte slot per 4 x 2^shift rows fetched by a
+    quad of lanes, fourteen inline runs, ordinal and predecessor sample inline, 4 KB dense tables for crowded buckets (small
+    shifts force them) -- same ranges, toeholds (LF_w_loc, rowbowt.hpp:555-573), locations and the same answers from every
+    other kernel (they read the 64 bytes lane by lane) as the 16-byte slots, i.e. as the oracle."""
+    S = synth
+    o = orc.Oracle.from_runs(S.heads, S.lens, S.ssa, S.esa)
+    with capi.default_option(capi.OPT_SLOT_BYTES, 64), capi.default_option(capi.OPT_POS_BYTES, pos_bytes), \
+            capi.default_option(capi.OPT_RANK_BUCKET_SHIFT, rshift), capi.default_option(capi.OPT_KMER_STEPS, ksteps), capi.default_option(capi.OPT_FTAB_K, fk):
+        rb = _with_layout(capi.LAYOUT_SLOTS, 48, lambda: ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0))
+    i = rb.info()
+    assert i.slot_bytes == 64 and i.pos_bytes == pos_bytes and i.kmer_steps == ksteps
+    if rshift == 8:
+        assert i.rank_slots_overflow > 0          # 1024-row buckets of the single symbols hold more than 14 run starts: dense tables
+    reads = S.sample_reads(3000, 70, seed=15, sub_rate=0.15, ragged=True)
+    reads += [b"", b"A", b"N", b"ACGTN", b"NACGT", b"AC", b"acgt", bytes([1]), bytes([255]) * 3, S.text[:600].tobytes(), bytes([1]) + b"A",
+              S.text[-30:].tobytes(), S.text[-31:-1].tobytes(), S.text[-2:].tobytes()]
+    seqs, off = ra.pack_reads(reads)
+    wlo, whi, wk = o.find_range_w_toehold_batch(seqs, off)
+    for packed in (0, 2):
+        with capi.default_option(capi.OPT_PACKED_READS, packed):
+            lo, hi, k = rb.find_range_w_toehold(seqs, off)
+            lo1, hi1 = rb.find_range(seqs, off)
+        assert (lo == wlo).all() and (hi == whi).all() and (k == wk).all() and (lo1 == wlo).all() and (hi1 == whi).all()
+    loc_off, locs = rb.locs_at(lo, hi, k)
+    woff, wlocs = o.locs_at_batch(wlo, whi, wk)
+    assert (loc_off == woff).all() and (locs == wlocs).all()
+    for cnt in (1, 3, 63, 65):     # batches that do not fill a quad / a wave
+        s2, o2 = ra.pack_reads(reads[:cnt])
+        l2, h2, k2 = rb.find_range_w_toehold(s2, o2)
+        assert (l2 == wlo[:cnt]).all() and (h2 == whi[:cnt]).all() and (k2 == wk[:cnt]).all()
+    rng = np.random.default_rng(3)
+    rows = rng.integers(0, S.n, 500).astype(np.uint64)
+    his = np.minimum(rows + rng.integers(0, 2000, 500).astype(np.uint64), np.uint64(S.n - 1))
+    cs = rng.choice(np.frombuffer(b"ACGT\x01N", dtype=np.uint8), 500)
+    nlo, nhi = rb.LF(rows, his, cs)
+    for j in range(500):
+        assert (int(nlo[j]), int(nhi[j])) == o.LF(int(rows[j]), int(his[j]), int(cs[j]))
+    ms, me, mo, mv = S.markers(wsize=10)
+    rb.set_markers(ms, me, mo, mv)
+    o.set_markers(ms, me, mo, mv)
+    _check_marker_seeds(rb, o, reads[:200], 10, 1000)
+    goff, glocs = rb.find_locs_greedy_seeding(*ra.pack_reads(reads[:150]), 10)
+    for j in range(150):
+        assert glocs[int(goff[j]):int(goff[j + 1])].tolist() == o.greedy_locate(reads[j], 10)[0]
+    rb.close()
+    o.close()
+
+
 def test_single_LF_steps(small, synth):
     """RowBowt::LF (rowbowt.hpp:74-88) one step at a time, against the oracle's LF."""
     rb, o = small
