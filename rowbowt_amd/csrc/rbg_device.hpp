@@ -252,12 +252,14 @@ __device__ __forceinline__ uint64_t rank_runs_lane(const DevSym &S, uint64_t i, 
 
 // both ranks of one LF step (rowbowt.hpp:79,83).  lo and hi+1 usually share a bucket late in the
 // search (the range has narrowed to a few dozen rows), so the step is ONE 4-word load.
-template <typename P>
+// SLOT64: also understand 64-byte slots, lane by lane (the kernels beside the hot path); K1/K2 over 16-byte slots are only
+// ever launched on an index that has none and instantiate without it -- the extra sixteen registers cost them spills
+template <typename P, bool SLOT64 = true>
 __device__ __forceinline__ void rank_pair(const DevSym &S, const uint8_t *__restrict__ dense, uint64_t lo, uint64_t hi1,
                                           uint64_t *c_before, uint64_t *c_upto, uint64_t *bh_out, RankAux *qaux,
                                           RankAux *paux_out = nullptr) {
     const RankSlot *__restrict__ slots = static_cast<const RankSlot *>(S.slots);
-    if (sym_is_slot64(S)) {  // 64-byte slots, lane by lane
+    if (SLOT64 && sym_is_slot64(S)) {  // 64-byte slots, lane by lane
         const RankSlot64 *__restrict__ s64 = static_cast<const RankSlot64 *>(S.slots);
         const uint32_t bs = S.shift + kSlot64Extra;
         const uint64_t bl = lo >> bs, bh = hi1 >> bs;

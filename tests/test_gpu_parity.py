@@ -1779,7 +1779,7 @@ def test_run_indexed_crowded_buckets(pos_bytes, rec, dir_runs):
     bucket records that overflow) beside buckets with none: a text that is 2 000 bases repeated 300 times, then
     1 500 x (one of A,C,G,T + the same 14-mer + 10 random bases) -- the rows of the suffixes that start with the 14-mer
     are consecutive and their BWT symbols change at nearly every row, while the average run is 39 rows long and sets
-    the bucket width.  Quads at 4-byte positions, half-rows at 8."""
+    the bucket width.  Quads of lanes at both position widths."""
     import naive
     rng = np.random.default_rng(7)
     acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
