@@ -80,6 +80,8 @@ def parse():
                     help="skip the space_speed block (the replica rebuilt at 4, 3, 2 and 1 symbols per gather; about a minute)")
     ap.add_argument("--slot-bytes", type=int, default=0, choices=(0, 16, 64),
                     help="bytes per rank slot (RBG_OPT_SLOT_BYTES): 16, or 64 = the 64-byte slots of DESIGN.md 4 r03; 0 = the library's default")
+    ap.add_argument("--pos-bytes", type=int, default=0, choices=(0, 4, 8), help="force the position width of the HBM layout (RBG_OPT_POS_BYTES); 0 = by n")
+    ap.add_argument("--layout", default="auto", choices=("auto", "slots", "runs"), help="RBG_OPT_RANK_LAYOUT of the headline replica")
     ap.add_argument("--via-cache", action="store_true",
                     help="build the replica through the native cache file even on one GPU (with --gpus N > 1 every rank does: rank 0 "
                          "writes it to node-local shared memory once, all ranks load it)")
@@ -149,6 +151,12 @@ def main():
     if args.slot_bytes:
         from rowbowt_amd import capi as _c
         _c.set_default_option(_c.OPT_SLOT_BYTES, args.slot_bytes)
+    if args.pos_bytes or args.layout != "auto":
+        from rowbowt_amd import capi as _c
+        if args.pos_bytes:
+            _c.set_default_option(_c.OPT_POS_BYTES, args.pos_bytes)
+        if args.layout != "auto":
+            _c.set_default_option(_c.OPT_RANK_LAYOUT, _c.LAYOUT_RUNS if args.layout == "runs" else _c.LAYOUT_SLOTS)
     m = args.read_len
     max_hits = MAXU if args.max_hits < 0 else args.max_hits
 

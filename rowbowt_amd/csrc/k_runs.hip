@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256, sizeof(P) == 4 ? 4 : 3) void k_locate_fill_run
     const uint32_t *__restrict__ pdir = ix.phi_dir;
     const uint32_t pdir_shift = ix.phi_dir_shift;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
-    const PhiEnt<P> *__restrict__ pent = static_cast<const PhiEnt<P> *>(ix.phi_ent);
+    const void *__restrict__ pent = ix.phi_ent;   // {sampled position, base} (rbg_dev.h RunsFmt)
     unsigned long long c_locs = 0;
     unsigned long long st_phi = 0, st_ent = 0, st_chains = 0;   // STATS only
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
@@ -353,12 +353,12 @@ __global__ __launch_bounds__(256, sizeof(P) == 4 ? 4 : 3) void k_locate_fill_run
                 if (need) {
                     uint64_t s;
                     if (wrapped) {
-                        const PhiEnt<P> e2 = pent[ix.r - 1];
-                        s = (static_cast<uint64_t>(e2.base) + (k1 - static_cast<uint64_t>(e2.pos))) % ix.n;
+                        const typename RunList<P>::pair e2 = RunList<P>::load(pent, ix.r - 1);
+                        s = (static_cast<uint64_t>(e2.y) + (k1 - static_cast<uint64_t>(e2.x))) % ix.n;
                     } else if (tq == 0) {
                         // no sampled position before k1: circular predecessor = the last one, delta = i + 1
                         // (sparse_sd_vector.hpp:141-143, toehold_sa.hpp:59,65)
-                        s = static_cast<uint64_t>(pent[ix.r - 1].base) + k1 + 1;
+                        s = static_cast<uint64_t>(RunList<P>::val(pent, ix.r - 1)) + k1 + 1;
                         if (s >= ix.n) s -= ix.n;
                     } else {
                         s = by_dir ? static_cast<uint64_t>(pval) : static_cast<uint64_t>(pv) + (k1 - pk);   // prev_sample + delta (toehold_sa.hpp:65-71)

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(1024, 8) void k_find_range(const DevIndex ix, const
             const DevSym *rec = (pend_tab & kHbmRec) ? ix.syms + (pend_tab & ~kHbmRec) : s_tab + pend_tab;
             const void *samp = rec->samp;
             const uint64_t j = pred_run<P>(*rec, pend_b, pend_abs, pend_v);
-            return static_cast<uint64_t>(static_cast<const P *>(samp)[j]);
+            return static_cast<uint64_t>(as_global<P>(samp)[j]);
         };
         ByteCursor rd{reinterpret_cast<const uint4 *>(seqs), ~uint64_t(0), make_uint4(0, 0, 0, 0)};
         bool alive = true;
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(1024, 8) void k_find_range_packed(const DevIndex ix
             const DevSym *rec = (pend_tab & kHbmRec) ? ix.syms + (pend_tab & ~kHbmRec) : s_tab + pend_tab;
             const void *samp = rec->samp;
             const uint64_t j = pred_run<P>(*rec, pend_b, pend_abs, pend_v);
-            return static_cast<uint64_t>(static_cast<const P *>(samp)[j]);
+            return static_cast<uint64_t>(as_global<P>(samp)[j]);
         };
         BitStream bs{chunks + mt.x, make_uint4(0, 0, 0, 0), 4u, 0u, 0ull};
         bool alive = true;

@@ -28,7 +28,7 @@ template <int J>
 __device__ __forceinline__ u32x4 q_quarter(const uint64_t addr, const uint32_t sub) {
     const uint64_t oa = q_get<J>(addr);
     u32x4 v = {0u, 0u, 0u, 0u};
-    if (oa) v = *reinterpret_cast<const u32x4 *>(oa + 16ull * sub);
+    if (oa) v = *as_global<u32x4>(reinterpret_cast<const void *>(oa + 16ull * sub));
     return v;
 }
 // word k of quarter S of MY record: lane S of the quad holds it in the register set of round `sub`
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(512, 4) void k_find_range64(const DevIndex ix, cons
         }
         if (TOEHOLD && alive && pend) {
             const DevSym *rec = (pend_tab & kHbmRec) ? ix.syms + (pend_tab & ~kHbmRec) : s_tab + pend_tab;
-            k += static_cast<uint64_t>(static_cast<const P *>(rec->samp)[pend_run]);
+            k += static_cast<uint64_t>(as_global<P>(rec->samp)[pend_run]);
             if (STATS) st[kStResample] += 1;
         }
         if (STATS && p_end > p_min) st[kStChunks] += ((p_end - 1) >> 4) - (p_min >> 4) + 1;

@@ -569,10 +569,10 @@ size_t runs_replica_bytes(const HostIndex &h) {
     for (const std::vector<SymTable> *lv : {&h.sym, &h.pair, &h.triple, &h.quad, &h.quint}) {
         size_t entries = 0;
         for (const SymTable &t : *lv) entries += t.nruns + 1;
-        total += entries * (sizeof(RunEnt<P>) + (h.has_tsa ? sizeof(P) : 0)) + entries * sizeof(P) / 15 + entries * 2 + lv->size() * 8 + 8 * kArenaAlign;   // (+ directories: at most half an entry per run)
+        total += entries * (RunsFmt<P>::ent_bytes + (h.has_tsa ? RunsFmt<P>::samp_bytes : 0)) + entries * sizeof(P) / 15 + entries * 2 + lv->size() * 8 + 8 * kArenaAlign;   // (+ directories: at most half an entry per run)
         if (rec_target > 0) total += static_cast<size_t>(2.0 * static_cast<double>(entries) / rec_target + static_cast<double>(lv->size())) * sizeof(RunRec);   // (+ bucket records)
     }
-    if (h.has_tsa) total += (h.r + 1) * sizeof(PhiEnt<P>) + h.r * sizeof(P) / 15 + std::min<size_t>(h.r, size_t(1) << 29) * 4;   // (+ the phi directory: at most r entries)
+    if (h.has_tsa) total += (h.r + 1) * RunsFmt<P>::ent_bytes + h.r * sizeof(P) / 15 + std::min<size_t>(h.r, size_t(1) << 29) * 4;   // (+ the phi directory: at most r entries)
     return total + 16 * kArenaAlign;
 }
 
@@ -618,8 +618,11 @@ int upload_tables_runs(rbg_index *ix) {
         // the depth's tables back to back: entries {start, cum} (each table ends with its sentinel {n, total}), samples alongside
         const std::vector<SymTable> &T = *depth[d];
         const uint64_t entries = sizes[d];
-        std::vector<RunEnt<P>> ent(entries + 1);   // (one spare entry after the last sentinel: the kernels' two-entry loads may touch it)
-        std::vector<P> samp(h.has_tsa ? entries : 0);
+        // (rbg_dev.h RunsFmt: 8-byte pairs + 4-byte samples, or 12-byte entries + 6-byte samples at 8-byte positions; spare
+        //  entries after the last sentinel: the kernels' two- and four-entry loads may touch them)
+        typedef RunsFmt<P> Fmt;
+        std::vector<unsigned char> ent((entries + Fmt::spare) * Fmt::ent_bytes);
+        std::vector<unsigned char> samp(h.has_tsa ? entries * Fmt::samp_bytes + 8 : 0);
         std::vector<uint64_t> first(T.size() + 1, 0);
         for (size_t t = 0; t < T.size(); ++t) first[t + 1] = first[t] + T[t].nruns + 1;
         {
@@ -629,21 +632,20 @@ int upload_tables_runs(rbg_index *ix) {
                 workers.emplace_back([&, w] {
                     for (size_t t = w; t < T.size(); t += W) {
                         const SymTable &tb = T[t];
-                        RunEnt<P> *e = ent.data() + first[t];
-                        for (uint64_t k = 0; k <= tb.nruns; ++k) { e[k].start = static_cast<P>(tb.start[k]); e[k].cum = static_cast<P>(tb.cum[k]); }
-                        if (t + 1 == T.size()) e[tb.nruns + 1] = e[tb.nruns];
+                        for (uint64_t k = 0; k <= tb.nruns; ++k) Fmt::put_ent(ent.data(), first[t] + k, tb.start[k], tb.cum[k]);
+                        if (t + 1 == T.size())
+                            for (size_t x = 1; x <= Fmt::spare; ++x) Fmt::put_ent(ent.data(), first[t] + tb.nruns + x, tb.start[tb.nruns], tb.cum[tb.nruns]);
                         if (h.has_tsa) {
-                            P *sp = samp.data() + first[t];
-                            for (uint64_t k = 0; k < tb.nruns; ++k) sp[k] = static_cast<P>(tb.samp[k]);
-                            sp[tb.nruns] = 0;
+                            for (uint64_t k = 0; k < tb.nruns; ++k) Fmt::put_samp(samp.data(), first[t] + k, tb.samp[k]);
+                            Fmt::put_samp(samp.data(), first[t] + tb.nruns, 0);
                         }
                     }
                 });
             for (auto &w : workers) w.join();
         }
         const void *d_ent = nullptr, *d_samp = nullptr;
-        if ((rc = dev_upload(ix, ent.data(), ent.size() * sizeof(RunEnt<P>), &d_ent))) return rc;
-        if (h.has_tsa && (rc = dev_upload(ix, samp.data(), samp.size() * sizeof(P), &d_samp))) return rc;
+        if ((rc = dev_upload(ix, ent.data(), ent.size(), &d_ent))) return rc;
+        if (h.has_tsa && (rc = dev_upload(ix, samp.data(), samp.size(), &d_samp))) return rc;
         ix->dev.run_samp[d] = d_samp;
         ix->dev.run_tab_first[d] = static_cast<uint32_t>(tabs.size());
         // the tables' directories (rbg_dev.h DevRunTab): per table the widest bucket that still holds at most about
@@ -756,13 +758,20 @@ int upload_tables_runs(rbg_index *ix) {
             tabs.push_back(with_rec ? DevRunTab{T[t].F, first[t], static_cast<uint32_t>(roff[t]), rshift[t]}
                                     : DevRunTab{T[t].F, first[t], with_dir ? static_cast<uint32_t>(doff[t]) : 0u, with_dir ? dshift[t] : 0u});
         tabs.push_back(DevRunTab{0, entries, 0u, 0u});   // closing record: the last table's slice ends here
-        if ((rc = upload_tree<P>(ix, d_ent, entries - 1, [&](uint64_t j) { return static_cast<uint64_t>(ent[j].start); }, nlvl, top_all, trees[d]))) return rc;
+        {
+            // key of entry j of the depth's concatenated lists
+            auto key_at = [&](uint64_t j) {
+                const size_t t = static_cast<size_t>(std::upper_bound(first.begin(), first.end(), j) - first.begin()) - 1;
+                return T[t].start[j - first[t]];
+            };
+            if ((rc = upload_tree<P>(ix, d_ent, entries - 1, key_at, nlvl, top_all, trees[d]))) return rc;
+        }
         if (d == 0)   // the per-lane kernels (seeding, windowed markers, single LF steps) search a symbol's own slice
             for (size_t t = 0; t < T.size(); ++t) {
                 DevSym &r = syms[t];
                 r = DevSym{};
-                r.ent = static_cast<const char *>(d_ent) + first[t] * sizeof(RunEnt<P>);
-                r.samp = d_samp ? static_cast<const char *>(d_samp) + first[t] * sizeof(P) : nullptr;
+                r.ent = static_cast<const char *>(d_ent) + first[t] * Fmt::ent_bytes;
+                r.samp = d_samp ? static_cast<const char *>(d_samp) + first[t] * Fmt::samp_bytes : nullptr;
                 r.F = T[t].F;
                 r.shift = with_dir ? dshift[t] : 0;    // with slots == nullptr: ord / shift are the symbol's directory (rank_runs_lane)
                 r.ord = with_dir ? ix->dev.run_dir[0] + doff[t] : nullptr;
@@ -799,15 +808,13 @@ int upload_tables_runs(rbg_index *ix) {
         ix->dev.nmajor = h.nmajor;
     }
     if (h.has_tsa) {
-        std::vector<PhiEnt<P>> pe(h.r + 2);   // (the sentinel and one spare entry after it: the kernels' two-entry loads may touch it)
-        for (uint64_t j = 0; j < h.r; ++j) {
-            pe[j].pos = static_cast<P>(h.pred_pos[j]);
-            pe[j].base = static_cast<P>(h.phi_base[j]);
-        }
-        pe[h.r].pos = static_cast<P>(h.n);  // sentinel: never below a query
-        pe[h.r].base = 0;
-        pe[h.r + 1] = pe[h.r];
-        if ((rc = dev_upload(ix, pe.data(), pe.size() * sizeof(PhiEnt<P>), &ix->dev.phi_ent))) return rc;
+        typedef RunsFmt<P> Fmt;
+        std::vector<unsigned char> pe((h.r + 1 + Fmt::spare) * Fmt::ent_bytes);   // (the sentinel and the spare entries after it)
+        parallel_for(h.r, [&](uint64_t a, uint64_t b, unsigned) {
+            for (uint64_t j = a; j < b; ++j) Fmt::put_ent(pe.data(), j, h.pred_pos[j], h.phi_base[j]);
+        });
+        for (size_t x = 0; x <= Fmt::spare; ++x) Fmt::put_ent(pe.data(), h.r + x, h.n, 0);  // sentinel: never below a query
+        if ((rc = dev_upload(ix, pe.data(), pe.size(), &ix->dev.phi_ent))) return rc;
         // (k_locate_fill_runs stages 26-43 KB of values per workgroup besides the top level: 8 KB of it keeps four
         //  workgroups per CU -- 32 ms per 10 M reads on the bench index against 44 ms with a 48 KB top level)
         const uint32_t pl = tree_levels_for({h.r}, std::min<uint64_t>(budget_keys, 8192 / sizeof(P)));

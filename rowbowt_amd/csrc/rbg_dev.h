@@ -25,6 +25,36 @@ struct PhiEnt {
     P base;
 };
 
+// THE SORTED LISTS OF THE RUN-INDEXED LAYOUT (RBG_LAYOUT_RUNS below: run lists per k-mer depth, the phi list) are
+// {key, value} pairs as above at 4-byte positions.  At 8-byte positions they are 12-byte entries -- positions stay below
+// 2^48 (rbg_host.cpp flatten()), so a pair of them is two 32-bit words and two 16-bit halves -- and the samples beside the
+// run lists 6 bytes: 18 bytes per run and depth instead of 24, and sixteen entries (what a quad of lanes probes) are 192
+// contiguous bytes = three 16-byte requests per lane instead of 256 / four.  (Round 2: 248 bytes per run over five
+// depths, 77 GB at r = 3.1e8.)
+struct Ent48 {
+    uint32_t key_lo, val_lo;
+    uint16_t key_hi, val_hi;
+};
+static_assert(sizeof(Ent48) == 12, "three words per entry");
+struct Samp48 {
+    uint16_t w[3];   // little end first
+};
+template <typename P> struct RunsFmt;
+template <> struct RunsFmt<uint32_t> {
+    static constexpr size_t ent_bytes = 8, samp_bytes = 4, spare = 1;   // spare entries after the last sentinel (the two-entry loads may touch one)
+    static void put_ent(void *base, uint64_t i, uint64_t key, uint64_t val) { static_cast<RunEnt<uint32_t> *>(base)[i] = {static_cast<uint32_t>(key), static_cast<uint32_t>(val)}; }
+    static void put_samp(void *base, uint64_t i, uint64_t v) { static_cast<uint32_t *>(base)[i] = static_cast<uint32_t>(v); }
+};
+template <> struct RunsFmt<uint64_t> {
+    static constexpr size_t ent_bytes = sizeof(Ent48), samp_bytes = sizeof(Samp48), spare = 3;   // (the four-entry loads may touch three)
+    static void put_ent(void *base, uint64_t i, uint64_t key, uint64_t val) {
+        static_cast<Ent48 *>(base)[i] = {static_cast<uint32_t>(key), static_cast<uint32_t>(val), static_cast<uint16_t>(key >> 32), static_cast<uint16_t>(val >> 32)};
+    }
+    static void put_samp(void *base, uint64_t i, uint64_t v) {
+        static_cast<Samp48 *>(base)[i] = {{static_cast<uint16_t>(v), static_cast<uint16_t>(v >> 16), static_cast<uint16_t>(v >> 32)}};
+    }
+};
+
 // First level of every rank: one record per bucket of 2^shift BWT positions (shift <= 8),
 // direct-addressed by (position >> shift), that ANSWERS rank(i, c) for every i in the bucket in
 // the common case.  Four 32-bit words = 16 bytes whatever the position width (n < 2^48), so one

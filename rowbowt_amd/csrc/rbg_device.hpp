@@ -25,16 +25,25 @@ constexpr int kWave = 64;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
 
+// A table pointer that a kernel read out of a record staged in LDS (DevSym, DevTree) has no known address space, and the
+// compiler loads through it with FLAT instructions: they count against the LDS counter as well as the memory counter, so
+// every wait for an LDS read also waits for the gathers in flight.  The index lives in device memory: say so.
+#define RBG_GLOBAL __attribute__((address_space(1)))
+template <typename T>
+__device__ __forceinline__ const RBG_GLOBAL T *as_global(const T *p) { return (const RBG_GLOBAL T *)p; }
+template <typename T>
+__device__ __forceinline__ const RBG_GLOBAL T *as_global(const void *p) { return (const RBG_GLOBAL T *)p; }
+
 template <typename SlotT>
 __device__ __forceinline__ SlotT load_slot(const SlotT *p) {
     SlotT s;
     if constexpr (sizeof(SlotT) == 16) {
-        const u32x4 t = *reinterpret_cast<const u32x4 *>(p);
+        const u32x4 t = *as_global<u32x4>(static_cast<const void *>(p));
         __builtin_memcpy(&s, &t, 16);
     } else {
         static_assert(sizeof(SlotT) == 32, "slot is 4 words of 4 or 8 bytes");
-        const u64x2 a = *reinterpret_cast<const u64x2 *>(p);
-        const u64x2 b = *(reinterpret_cast<const u64x2 *>(p) + 1);
+        const u64x2 a = *as_global<u64x2>(static_cast<const void *>(p));
+        const u64x2 b = *(as_global<u64x2>(static_cast<const void *>(p)) + 1);
         __builtin_memcpy(&s, &a, 16);
         __builtin_memcpy(reinterpret_cast<char *>(&s) + 16, &b, 16);
     }
@@ -57,7 +66,8 @@ struct RankAux {
 // # runs of the symbol that start before i, searched in the run list of bucket b (overflow buckets without
 // a dense table only)
 template <typename P>
-__device__ __forceinline__ uint64_t search_runs(const RunEnt<P> *__restrict__ ent, uint64_t a, uint64_t z, uint64_t i) {
+__device__ __forceinline__ uint64_t search_runs(const RunEnt<P> *__restrict__ ent_, uint64_t a, uint64_t z, uint64_t i) {
+    const RBG_GLOBAL RunEnt<P> *ent = as_global(ent_);
     while (z - a > 4) {
         const uint64_t mid = a + ((z - a) >> 1);
         if (static_cast<uint64_t>(ent[mid].start) < i) a = mid + 1; else z = mid;
@@ -67,7 +77,8 @@ __device__ __forceinline__ uint64_t search_runs(const RunEnt<P> *__restrict__ en
 }
 template <typename P>
 __device__ __forceinline__ uint64_t runs_before(const DevSym &S, uint64_t b, uint64_t i) {
-    return search_runs<P>(static_cast<const RunEnt<P> *>(S.ent), S.ord[b], S.ord[b + 1], i);
+    const RBG_GLOBAL uint32_t *ord = as_global(S.ord);
+    return search_runs<P>(static_cast<const RunEnt<P> *>(S.ent), ord[b], ord[b + 1], i);
 }
 
 template <typename P>
@@ -108,7 +119,7 @@ __device__ __forceinline__ uint64_t rank_in_slot(const DevSym &S, const RankSlot
         if (dense && !wide) {
             // dense bucket (rbg_dev.h): two bytes per row -- rank(B0 + o) - rank(B0), and 255 if position
             // i-1 holds the symbol, else the number of runs that start in [B0, i)
-            const uint32_t e = reinterpret_cast<const uint16_t *>(dense + (static_cast<uint64_t>(w2) << 4))[o];
+            const uint32_t e = as_global<uint16_t>(dense + (static_cast<uint64_t>(w2) << 4))[o];
             aux->ovf = false;
             aux->dense = true;
             aux->nbefore = e >> 8;
@@ -117,14 +128,14 @@ __device__ __forceinline__ uint64_t rank_in_slot(const DevSym &S, const RankSlot
         }
         aux->ovf = true;
         aux->nbefore = o;
-        const RunEnt<P> *__restrict__ ent = static_cast<const RunEnt<P> *>(S.ent);
+        const RBG_GLOBAL RunEnt<P> *ent = as_global<RunEnt<P>>(S.ent);
         const uint64_t a = runs_before<P>(S, b, i);
         if (a == 0) { aux->inside = false; return 0; }
-        const RunEnt<P> e = ent[a - 1];
-        const uint64_t len = static_cast<uint64_t>(ent[a].cum) - static_cast<uint64_t>(e.cum);
-        const uint64_t d = i - static_cast<uint64_t>(e.start);
+        const uint64_t e_start = ent[a - 1].start, e_cum = ent[a - 1].cum;
+        const uint64_t len = static_cast<uint64_t>(ent[a].cum) - e_cum;
+        const uint64_t d = i - e_start;
         aux->inside = d <= len;
-        return static_cast<uint64_t>(e.cum) + (d < len ? d : len);
+        return e_cum + (d < len ? d : len);
     }
     const uint32_t o = static_cast<uint32_t>(i - (b << S.shift));
     const uint32_t ext = w1 & 0x1FFu;
@@ -200,7 +211,7 @@ __device__ __forceinline__ uint64_t rank_in_slot64(const uint32_t (&w)[16], uint
     aux->psamp = static_cast<uint64_t>(w[3]) | (static_cast<uint64_t>(w[4]) << 32);
     aux->dense = false;
     if (cnt == kSlot64Ovf) {
-        const uint32_t e = reinterpret_cast<const uint32_t *>(dense + (static_cast<uint64_t>(w[5]) << 12))[o];
+        const uint32_t e = as_global<uint32_t>(dense + (static_cast<uint64_t>(w[5]) << 12))[o];
         aux->dense = true;
         aux->nbefore = (e >> 11) & 0x3FFu;
         aux->inside = (e >> 31) != 0;
@@ -217,7 +228,7 @@ __device__ __forceinline__ uint64_t rank_in_slot64(const uint32_t (&w)[16], uint
 }
 // one lane fetching its own 64 bytes (four requests: the kernels beside the hot path; K1/K2 fetch by quads, k_search64.hip)
 __device__ __forceinline__ void load_slot64(const RankSlot64 *p, uint32_t (&w)[16]) {
-    const u32x4 *q = reinterpret_cast<const u32x4 *>(p);
+    const RBG_GLOBAL u32x4 *q = as_global<u32x4>(static_cast<const void *>(p));
     const u32x4 a = q[0], b = q[1], c = q[2], d = q[3];
     w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
     w[8] = c.x; w[9] = c.y; w[10] = c.z; w[11] = c.w; w[12] = d.x; w[13] = d.y; w[14] = d.z; w[15] = d.w;
@@ -225,29 +236,69 @@ __device__ __forceinline__ void load_slot64(const RankSlot64 *p, uint32_t (&w)[1
 // a RankAux that stands for a Rank64Aux: nbefore = the run ordinal itself (ord + nbefore), so that pred_run needs no ord[]
 __device__ __forceinline__ bool sym_is_slot64(const DevSym &S) { return S.slots != nullptr && S.ord == nullptr; }
 
+// The sorted lists of the run-indexed layout as the kernels read them (rbg_dev.h RunsFmt: {key, value} pairs of 32-bit
+// words at 4-byte positions, 12-byte entries and 6-byte samples at 8-byte positions).
+template <typename P> struct RunList;
+template <> struct RunList<uint32_t> {
+    typedef unsigned int pair __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ uint32_t key(const void *__restrict__ b, uint64_t i) { return as_global<RunEnt<uint32_t>>(b)[i].start; }
+    static __device__ __forceinline__ uint32_t val(const void *__restrict__ b, uint64_t i) { return as_global<RunEnt<uint32_t>>(b)[i].cum; }
+    static __device__ __forceinline__ pair load(const void *__restrict__ b, uint64_t i) { return as_global<pair>(b)[i]; }
+    static __device__ __forceinline__ uint64_t samp(const void *__restrict__ b, uint64_t i) { return as_global<uint32_t>(b)[i]; }
+    static __device__ __forceinline__ pair unpack(uint32_t w0, uint32_t w1, uint32_t) { return pair{w0, w1}; }   // (12-byte entries exist at 8-byte positions only)
+};
+template <> struct RunList<uint64_t> {
+    typedef unsigned long long pair __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ uint64_t key(const void *__restrict__ b, uint64_t i) {
+        const RBG_GLOBAL uint32_t *w = as_global<uint32_t>(b) + 3 * i;
+        return static_cast<uint64_t>(w[0]) | (static_cast<uint64_t>(w[2] & 0xFFFFu) << 32);
+    }
+    static __device__ __forceinline__ uint64_t val(const void *__restrict__ b, uint64_t i) {
+        const RBG_GLOBAL uint32_t *w = as_global<uint32_t>(b) + 3 * i;
+        return static_cast<uint64_t>(w[1]) | (static_cast<uint64_t>(w[2] >> 16) << 32);
+    }
+    static __device__ __forceinline__ pair unpack(uint32_t w0, uint32_t w1, uint32_t w2) {
+        return pair{static_cast<uint64_t>(w0) | (static_cast<uint64_t>(w2 & 0xFFFFu) << 32), static_cast<uint64_t>(w1) | (static_cast<uint64_t>(w2 >> 16) << 32)};
+    }
+    static __device__ __forceinline__ pair load(const void *__restrict__ b, uint64_t i) {
+        const RBG_GLOBAL uint32_t *w = as_global<uint32_t>(b) + 3 * i;
+        return unpack(w[0], w[1], w[2]);
+    }
+    static __device__ __forceinline__ uint64_t samp(const void *__restrict__ b, uint64_t i) {
+        const RBG_GLOBAL uint16_t *h = as_global<uint16_t>(b) + 3 * i;
+        return static_cast<uint64_t>(h[0]) | (static_cast<uint64_t>(h[1]) << 16) | (static_cast<uint64_t>(h[2]) << 32);
+    }
+};
+
 // Run-indexed layout, one lane on its own: binary search of the run list (the kernels that are not on the
 // rb_align path -- seeding, windowed markers, single LF steps -- answer their ranks this way there; K1/K2/K3 have
 // the wave-cooperative search of k_runs.hip).  aux->nbefore = # runs starting before i (pred_run needs no ord[]).
 template <typename P>
 __device__ __forceinline__ uint64_t rank_runs_lane(const DevSym &S, uint64_t i, RankAux *aux) {
-    const RunEnt<P> *__restrict__ ent = static_cast<const RunEnt<P> *>(S.ent);
-    uint64_t a0 = 0, z0 = S.nruns;
+    typedef RunList<P> L;
+    const void *__restrict__ ent = S.ent;
+    uint64_t a = 0, z = S.nruns;
     if (S.ord) {   // the symbol's directory (rbg_dev.h DevRunTab; upload_tables_runs puts it here): the runs of i's bucket and the one before
         const uint64_t b = i >> S.shift;
-        a0 = S.ord[b];
-        z0 = S.ord[b + 1];
-        a0 = a0 ? a0 - 1 : 0;
+        const RBG_GLOBAL uint32_t *ord = as_global(S.ord);
+        a = ord[b];
+        z = ord[b + 1];
+        a = a ? a - 1 : 0;
     }
-    const uint64_t a = search_runs<P>(ent, a0, z0, i);
+    while (z - a > 4) {
+        const uint64_t mid = a + ((z - a) >> 1);
+        if (static_cast<uint64_t>(L::key(ent, mid)) < i) a = mid + 1; else z = mid;
+    }
+    while (a < z && static_cast<uint64_t>(L::key(ent, a)) < i) ++a;
     aux->ovf = false;
     aux->dense = false;
     aux->nbefore = static_cast<uint32_t>(a);
     if (a == 0) { aux->inside = false; return 0; }
-    const RunEnt<P> e = ent[a - 1];
-    const uint64_t len = static_cast<uint64_t>(ent[a].cum) - static_cast<uint64_t>(e.cum);
-    const uint64_t d = i - static_cast<uint64_t>(e.start);
+    const typename L::pair e = L::load(ent, a - 1);
+    const uint64_t len = static_cast<uint64_t>(L::val(ent, a)) - static_cast<uint64_t>(e.y);
+    const uint64_t d = i - static_cast<uint64_t>(e.x);
     aux->inside = d <= len;
-    return static_cast<uint64_t>(e.cum) + (d < len ? d : len);
+    return static_cast<uint64_t>(e.y) + (d < len ? d : len);
 }
 
 // both ranks of one LF step (rowbowt.hpp:79,83).  lo and hi+1 usually share a bucket late in the
@@ -298,14 +349,16 @@ __device__ __forceinline__ void rank_pair(const DevSym &S, const uint8_t *__rest
 template <typename P>
 __device__ __forceinline__ uint64_t pred_run(const DevSym &S, uint64_t b, bool ovf, uint32_t v) {
     if (S.slots == nullptr || S.ord == nullptr) return static_cast<uint64_t>(v) - 1;  // run-indexed layout / 64-byte slots: v already counts from the first run
-    return (ovf ? runs_before<P>(S, b, (b << S.shift) + v) : static_cast<uint64_t>(S.ord[b]) + v) - 1;
+    return (ovf ? runs_before<P>(S, b, (b << S.shift) + v) : static_cast<uint64_t>(as_global(S.ord)[b]) + v) - 1;
 }
 
 // samples_last_ of the last run of the symbol that starts before i (LF_w_loc, rowbowt.hpp:563-566);
 // only taken when position i-1 does not hold the symbol, which is the rare case.
 template <typename P>
 __device__ __forceinline__ uint64_t pred_sample(const DevSym &S, uint64_t b, const RankAux &aux) {
-    return static_cast<uint64_t>(static_cast<const P *>(S.samp)[pred_run<P>(S, b, aux.ovf, aux.nbefore)]);
+    const uint64_t j = pred_run<P>(S, b, aux.ovf, aux.nbefore);
+    if (sizeof(P) == 8 && S.slots == nullptr) return RunList<P>::samp(S.samp, j);   // run-indexed layout: 6-byte samples (rbg_dev.h RunsFmt)
+    return static_cast<uint64_t>(as_global<P>(S.samp)[j]);
 }
 
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {

@@ -110,7 +110,7 @@ __device__ __forceinline__ void coop_level(const DevTree *s_tree, const int l, c
         if (oi & 1u) {
             const DevTree &T = s_tree[(oi >> 2) & 7u];
             const uint64_t i = static_cast<uint64_t>(ob) * kFan + sub;
-            if (i < T.lvl_n[l]) va[j] = static_cast<const P *>(T.lvl[l])[i];
+            if (i < T.lvl_n[l]) va[j] = as_global<P>(T.lvl[l])[i];
         }
     }
 #pragma unroll
@@ -140,7 +140,7 @@ __device__ __forceinline__ void coop_level(const DevTree *s_tree, const int l, c
         if (oi & 2u) {
             const DevTree &T = s_tree[(oi >> 2) & 7u];
             const uint64_t i = static_cast<uint64_t>(ob) * kFan + sub;
-            if (i < T.lvl_n[l]) va[j] = static_cast<const P *>(T.lvl[l])[i];
+            if (i < T.lvl_n[l]) va[j] = as_global<P>(T.lvl[l])[i];
         }
     }
 #pragma unroll
@@ -180,7 +180,7 @@ __device__ __forceinline__ void coop_leaf(const DevTree *s_tree, const uint32_t 
         if (oi & 1u) {
             const DevTree &T = s_tree[(oi >> 2) & 7u];
             const uint64_t i = static_cast<uint64_t>(ob) * kFan + sub;
-            if (i <= T.m) va[j] = static_cast<const vec *>(T.ent)[i];   // entry m is the last sentinel
+            if (i <= T.m) va[j] = RunList<P>::load(T.ent, i);   // entry m is the last sentinel
         }
     }
 #pragma unroll
@@ -213,7 +213,7 @@ __device__ __forceinline__ void coop_leaf(const DevTree *s_tree, const uint32_t 
             if (oi & 2u) {
                 const DevTree &T = s_tree[(oi >> 2) & 7u];
                 const uint64_t i = static_cast<uint64_t>(ob) * kFan + sub;
-                if (i <= T.m) va[j] = static_cast<const vec *>(T.ent)[i];
+                if (i <= T.m) va[j] = RunList<P>::load(T.ent, i);
             }
         }
 #pragma unroll
@@ -229,9 +229,9 @@ __device__ __forceinline__ void coop_leaf(const DevTree *s_tree, const uint32_t 
         }
     }
     if (fix0 || fix1) {
-        const vec *__restrict__ ent = static_cast<const vec *>(s_tree[tid].ent);
-        if (fix0) nv0 = static_cast<P>(ent[t0].y);
-        if (fix1) nv1 = static_cast<P>(ent[t1].y);
+        const void *__restrict__ ent = s_tree[tid].ent;
+        if (fix0) nv0 = RunList<P>::val(ent, t0);
+        if (fix1) nv1 = RunList<P>::val(ent, t1);
     }
 }
 
@@ -261,7 +261,7 @@ __device__ __forceinline__ void coop_probe_phi(const DevTree &T, uint4 *req, con
             const uint32_t oz = a.y >> 1, last = oz ? oz - 1 : 0;
             uint64_t i = static_cast<uint64_t>(a.x) + (sub < last ? sub : last);
             if (i > T.m) i = T.m;   // entry m is the sentinel (never below a query)
-            va[j] = static_cast<const vec *>(T.ent)[i];
+            va[j] = RunList<P>::load(T.ent, i);
         }
     }
 #pragma unroll
@@ -317,40 +317,69 @@ __device__ __forceinline__ uint64_t quad_or(uint64_t v) {
 }
 __device__ __forceinline__ bool round_has_owner4(uint64_t m, int j) { return (m & (0x1111111111111111ull << j)) != 0; }
 
+// A lane's four entries AS LOADED: the words stay untouched until the round that uses them, so that the loads of all four
+// rounds are in flight together (anything done to them inside the load step makes every round wait for its own data).
+template <typename P> struct QuadRaw;
+template <> struct QuadRaw<uint32_t> {
+    typedef unsigned int vec4 __attribute__((ext_vector_type(4)));
+    typedef PairOf<uint32_t>::vec vec;
+    vec4 a, b;
+    __device__ __forceinline__ void unpack(vec (&e)[4]) const { e[0] = vec{a.x, a.y}; e[1] = vec{a.z, a.w}; e[2] = vec{b.x, b.y}; e[3] = vec{b.z, b.w}; }
+};
+template <> struct QuadRaw<uint64_t> {
+    typedef unsigned int vec4 __attribute__((ext_vector_type(4)));
+    typedef PairOf<uint64_t>::vec vec;
+    typedef unsigned int vec3 __attribute__((ext_vector_type(3)));
+    uint32_t w[12];   // four 12-byte entries, word by word (constant indices only: registers)
+    __device__ __forceinline__ void set4(vec4 a, vec4 b, vec4 c) {
+        w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w; w[8] = c.x; w[9] = c.y; w[10] = c.z; w[11] = c.w;
+    }
+    template <int I> __device__ __forceinline__ void set3(vec3 v) { w[3 * I] = v.x; w[3 * I + 1] = v.y; w[3 * I + 2] = v.z; }
+    __device__ __forceinline__ void unpack(vec (&e)[4]) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) e[i] = RunList<uint64_t>::unpack(w[3 * i], w[3 * i + 1], w[3 * i + 2]);
+    }
+};
+
 // the four entries start + 4 * sub .. + 3 of the owner's stretch (clamped to entry zc of the stretch and to the array's sentinel)
 template <typename P, int J>
 __device__ __forceinline__ void quad_load(const DevTree *s_tree, const uint32_t sub, const uint32_t start, const uint32_t info, const bool second,
-                                          typename PairOf<P>::vec (&e)[4]) {
-    typedef typename PairOf<P>::vec vec;
+                                          QuadRaw<P> &raw) {
     const uint32_t os = quad_get<J>(start), oi = quad_get<J>(info);
+    // The loads are UNCONDITIONAL: a quad whose owner has no query in this pass reads the first entries of tree 0 (always
+    // there, the same for everyone) and quad_round drops what it computes from them.  Loads under `if (owner has a query)`
+    // with "never below" defaults on the other path made the compiler wait for each round's data inside the round (the
+    // defaults and the loaded words met in different registers): four memory round trips per probe instead of one.
+    // Entry indices are 32-bit (upload_tables_runs leaves out a depth with more entries): one multiply-add per address.
+    const bool on = (oi & (second ? 2u : 1u)) != 0;
+    const DevTree &T = s_tree[on ? (oi >> 2) & 7u : 0u];
+    const uint32_t last = on ? static_cast<uint32_t>(T.m) : 0u;   // entry m is the last sentinel; no query: entry 0
+    const uint32_t za = second ? 0u : (oi >> 5) & 31u, zb = (!second && (oi & 2u)) ? 0u : (oi >> 10) & 31u;
+    uint32_t zc = za > zb ? za : zb;                      // entries 0 .. zc of the stretch are needed (zc: the one after the last candidate)
+    if (zc > static_cast<uint32_t>(kFan - 1)) zc = kFan - 1;
+    if constexpr (sizeof(P) == 4) {
+        // two entries per request (16 bytes at any 8-byte boundary; the arrays end with one spare entry after the sentinel)
+        typedef unsigned int vec4 __attribute__((ext_vector_type(4), aligned(8)));
 #pragma unroll
-    for (int i = 0; i < 4; ++i) e[i] = vec{static_cast<P>(~P(0)), 0};
-    if (oi & (second ? 2u : 1u)) {
-        const DevTree &T = s_tree[(oi >> 2) & 7u];
-        const uint32_t za = second ? 0u : (oi >> 5) & 31u, zb = (!second && (oi & 2u)) ? 0u : (oi >> 10) & 31u;
-        uint32_t zc = za > zb ? za : zb;                      // entries 0 .. zc of the stretch are needed (zc: the one after the last candidate)
-        if (zc > static_cast<uint32_t>(kFan - 1)) zc = kFan - 1;
-        if (sizeof(P) == 4) {
-            // two entries per request (16 bytes at any 8-byte boundary; the arrays end with one spare entry after the sentinel)
-            typedef unsigned int vec4 __attribute__((ext_vector_type(4), aligned(8)));
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const uint32_t idx = 4u * sub + 2u * h;
-                uint64_t g = static_cast<uint64_t>(os) + (idx < zc ? idx : zc);
-                if (g > T.m) g = T.m;                          // entry m is the last sentinel
-                const vec4 w = *reinterpret_cast<const vec4 *>(static_cast<const vec *>(T.ent) + g);
-                e[2 * h] = vec{static_cast<P>(w.x), static_cast<P>(w.y)};
-                e[2 * h + 1] = vec{static_cast<P>(w.z), static_cast<P>(w.w)};
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint32_t idx = 4u * sub + i;
-                uint64_t g = static_cast<uint64_t>(os) + (idx < zc ? idx : zc);
-                if (g > T.m) g = T.m;
-                e[i] = static_cast<const vec *>(T.ent)[g];
-            }
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t idx = 4u * sub + 2u * h;
+            const uint32_t g = min(os + min(idx, zc), last);
+            const vec4 w = *as_global<vec4>(static_cast<const void *>(static_cast<const char *>(T.ent) + static_cast<uint64_t>(g) * 8u));
+            if (h == 0) raw.a = w; else raw.b = w;
         }
+    } else {
+        // one 12-byte request per entry, each clamped to entry zc like the pairs above: the probe touches exactly the
+        // sectors that hold entries 0 .. zc.  (Three 16-byte requests for the lane's four consecutive entries reach three
+        // entries past zc: a fifth more sectors per probe, and K1/K2 at 8-byte positions took 14.0 instead of 11.8 ms.)
+        typedef unsigned int vec3 __attribute__((ext_vector_type(3), aligned(4)));
+        const RBG_GLOBAL char *base = as_global<char>(T.ent);
+        uint32_t g[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g[i] = min(os + min(4u * sub + i, zc), last);
+        raw.template set3<0>(*reinterpret_cast<const RBG_GLOBAL vec3 *>(base + static_cast<uint64_t>(g[0]) * 12u));
+        raw.template set3<1>(*reinterpret_cast<const RBG_GLOBAL vec3 *>(base + static_cast<uint64_t>(g[1]) * 12u));
+        raw.template set3<2>(*reinterpret_cast<const RBG_GLOBAL vec3 *>(base + static_cast<uint64_t>(g[2]) * 12u));
+        raw.template set3<3>(*reinterpret_cast<const RBG_GLOBAL vec3 *>(base + static_cast<uint64_t>(g[3]) * 12u));
     }
 }
 
@@ -377,8 +406,10 @@ __device__ __forceinline__ void quad_rank(const uint32_t sub, const typename Pai
 
 template <typename P, int J>
 __device__ __forceinline__ void quad_round(const uint32_t sub, const bool second, const bool live, const bool two, const uint32_t s0, const uint32_t s1,
-                                           const uint32_t info, const P q0, const P q1, const typename PairOf<P>::vec (&e)[4], uint32_t &t0, uint32_t &t1,
+                                           const uint32_t info, const P q0, const P q1, const QuadRaw<P> &raw, uint32_t &t0, uint32_t &t1,
                                            P &rk0, P &rk1, bool &ins1, bool &fix0, bool &fix1) {
+    typename PairOf<P>::vec e[4];
+    raw.unpack(e);
     const uint32_t oi = quad_get<J>(info);
     const P oq0 = quad_get<J>(q0), oq1 = quad_get<J>(q1);
     const P next_cum = row_next(static_cast<P>(e[0].y));   // (the quad's last lane: entry 15's run, fixed up by the owner)
@@ -408,17 +439,19 @@ __device__ __forceinline__ void coop_probe2_rank4(const DevTree *s_tree, const u
     // bit 0 live, bit 1 second block, bits 2-4 tree, bits 5-9 z0, 10-14 z1
     const uint32_t info = (live ? 1u : 0u) | (two ? 2u : 0u) | (tid << 2) | (z0 << 5) | (z1 << 10);
     bool fix0 = false, fix1 = false;
-    vec e0[4], e1[4], e2[4], e3[4];
-    if (round_has_owner4(m_live, 0)) quad_load<P, 0>(s_tree, sub, s0, info, false, e0);
-    if (round_has_owner4(m_live, 1)) quad_load<P, 1>(s_tree, sub, s0, info, false, e1);
-    if (round_has_owner4(m_live, 2)) quad_load<P, 2>(s_tree, sub, s0, info, false, e2);
-    if (round_has_owner4(m_live, 3)) quad_load<P, 3>(s_tree, sub, s0, info, false, e3);
+    QuadRaw<P> e0, e1, e2, e3;
+    // (all four rounds' loads in one basic block, no branch between them: every request is in flight before the first wait)
+    quad_load<P, 0>(s_tree, sub, s0, info, false, e0);
+    quad_load<P, 1>(s_tree, sub, s0, info, false, e1);
+    quad_load<P, 2>(s_tree, sub, s0, info, false, e2);
+    quad_load<P, 3>(s_tree, sub, s0, info, false, e3);
     if (round_has_owner4(m_live, 0)) quad_round<P, 0>(sub, false, live, two, s0, s1, info, q0, q1, e0, t0, t1, rk0, rk1, ins1, fix0, fix1);
     if (round_has_owner4(m_live, 1)) quad_round<P, 1>(sub, false, live, two, s0, s1, info, q0, q1, e1, t0, t1, rk0, rk1, ins1, fix0, fix1);
     if (round_has_owner4(m_live, 2)) quad_round<P, 2>(sub, false, live, two, s0, s1, info, q0, q1, e2, t0, t1, rk0, rk1, ins1, fix0, fix1);
     if (round_has_owner4(m_live, 3)) quad_round<P, 3>(sub, false, live, two, s0, s1, info, q0, q1, e3, t0, t1, rk0, rk1, ins1, fix0, fix1);
     const uint64_t m_two = __ballot(two);
     if (m_two) {
+        // (second blocks are sparse -- most rounds have no owner: skipping them saves a third of the kernel's load instructions)
         if (round_has_owner4(m_two, 0)) quad_load<P, 0>(s_tree, sub, s1, info, true, e0);
         if (round_has_owner4(m_two, 1)) quad_load<P, 1>(s_tree, sub, s1, info, true, e1);
         if (round_has_owner4(m_two, 2)) quad_load<P, 2>(s_tree, sub, s1, info, true, e2);
@@ -429,15 +462,15 @@ __device__ __forceinline__ void coop_probe2_rank4(const DevTree *s_tree, const u
         if (round_has_owner4(m_two, 3)) quad_round<P, 3>(sub, true, live, two, s0, s1, info, q0, q1, e3, t0, t1, rk0, rk1, ins1, fix0, fix1);
     }
     if (fix0 || fix1) {   // all 16 loaded entries lie below the position: the run it lands in ends in the next block
-        const vec *__restrict__ ent = static_cast<const vec *>(s_tree[tid].ent);
+        const void *__restrict__ ent = s_tree[tid].ent;
         if (fix0) {
-            const vec e = ent[t0 - 1];
-            const P len = static_cast<P>(ent[t0].y) - static_cast<P>(e.y), d = q0 - static_cast<P>(e.x);
+            const vec e = RunList<P>::load(ent, t0 - 1);
+            const P len = static_cast<P>(RunList<P>::val(ent, t0)) - static_cast<P>(e.y), d = q0 - static_cast<P>(e.x);
             rk0 = static_cast<P>(e.y) + (d < len ? d : len);
         }
         if (fix1) {
-            const vec e = ent[t1 - 1];
-            const P len = static_cast<P>(ent[t1].y) - static_cast<P>(e.y), d = q1 - static_cast<P>(e.x);
+            const vec e = RunList<P>::load(ent, t1 - 1);
+            const P len = static_cast<P>(RunList<P>::val(ent, t1)) - static_cast<P>(e.y), d = q1 - static_cast<P>(e.x);
             rk1 = static_cast<P>(e.y) + (d < len ? d : len);
             ins1 = d <= len;
         }
@@ -449,37 +482,32 @@ __device__ __forceinline__ void coop_probe2_rank4(const DevTree *s_tree, const u
 // of samples below the position as a quad sum, phi's value base + (q - pos) from the lane that holds the last of them
 // as a quad OR.  t = start + # entries below q (val undefined when t == start).
 template <typename P, int J>
-__device__ __forceinline__ void phi_quad_load(const DevTree &T, const uint32_t sub, const uint32_t info, typename PairOf<P>::vec (&e)[4]) {
-    typedef typename PairOf<P>::vec vec;
+__device__ __forceinline__ void phi_quad_load(const DevTree &T, const uint32_t sub, const uint32_t info, QuadRaw<P> &raw) {
     const uint32_t oi = quad_get<J>(info);
+    // (unconditional, as in quad_load: a quad without a query reads the list's first entries and its round's result is dropped)
+    const uint32_t first = (oi & 0x80000000u) ? (oi & 0x7FFFFFFFu) + 4u * sub : 0u;   // (fewer than 2^31 sampled positions: upload() checks)
+    const uint32_t last = static_cast<uint32_t>(T.m);   // entry m is the sentinel (never below a query)
+    if constexpr (sizeof(P) == 4) {   // (the array ends with one spare entry after the sentinel)
+        typedef unsigned int vec4 __attribute__((ext_vector_type(4), aligned(8)));
 #pragma unroll
-    for (int i = 0; i < 4; ++i) e[i] = vec{static_cast<P>(~P(0)), 0};
-    if (oi & 0x80000000u) {
-        const uint64_t first = static_cast<uint64_t>(oi & 0x7FFFFFFFu) + 4u * sub;
-        if (sizeof(P) == 4) {   // (the array ends with one spare entry after the sentinel)
-            typedef unsigned int vec4 __attribute__((ext_vector_type(4), aligned(8)));
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                uint64_t g = first + 2u * h;
-                if (g > T.m) g = T.m;   // entry m is the sentinel (never below a query)
-                const vec4 w = *reinterpret_cast<const vec4 *>(static_cast<const vec *>(T.ent) + g);
-                e[2 * h] = vec{static_cast<P>(w.x), static_cast<P>(w.y)};
-                e[2 * h + 1] = vec{static_cast<P>(w.z), static_cast<P>(w.w)};
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                uint64_t g = first + i;
-                if (g > T.m) g = T.m;
-                e[i] = static_cast<const vec *>(T.ent)[g];
-            }
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t g = min(first + 2u * h, last);
+            const vec4 w = *as_global<vec4>(static_cast<const void *>(static_cast<const char *>(T.ent) + static_cast<uint64_t>(g) * 8u));
+            if (h == 0) raw.a = w; else raw.b = w;
         }
+    } else {   // (12-byte entries, three spare ones after the sentinel: as in quad_load)
+        typedef unsigned int vec4 __attribute__((ext_vector_type(4), aligned(4)));
+        const uint32_t g = min(first, last);
+        const RBG_GLOBAL vec4 *w = as_global<vec4>(static_cast<const void *>(static_cast<const char *>(T.ent) + static_cast<uint64_t>(g) * 12u));
+        raw.set4(w[0], w[1], w[2]);
     }
 }
 
 template <typename P, int J>
-__device__ __forceinline__ void phi_quad_round(const uint32_t sub, const bool live, const uint32_t start, const P q, const typename PairOf<P>::vec (&e)[4],
+__device__ __forceinline__ void phi_quad_round(const uint32_t sub, const bool live, const uint32_t start, const P q, const QuadRaw<P> &raw,
                                                uint32_t &t, P &val) {
+    typename PairOf<P>::vec e[4];
+    raw.unpack(e);
     const P oq = quad_get<J>(q);
     uint32_t n = 0;
 #pragma unroll
@@ -496,16 +524,15 @@ __device__ __forceinline__ void phi_quad_round(const uint32_t sub, const bool li
 
 template <typename P>
 __device__ __forceinline__ void coop_probe_phi4(const DevTree &T, const bool live, const uint32_t start, const P q, uint32_t &t, P &val) {
-    typedef typename PairOf<P>::vec vec;
     const uint32_t lane = threadIdx.x & (kWave - 1), sub = lane & 3u;
     const uint64_t m_live = __ballot(live);
     if (!m_live) return;
     const uint32_t info = (live ? 0x80000000u : 0u) | (start & 0x7FFFFFFFu);   // (fewer than 2^31 sampled positions: upload() checks)
-    vec e0[4], e1[4], e2[4], e3[4];
-    if (round_has_owner4(m_live, 0)) phi_quad_load<P, 0>(T, sub, info, e0);
-    if (round_has_owner4(m_live, 1)) phi_quad_load<P, 1>(T, sub, info, e1);
-    if (round_has_owner4(m_live, 2)) phi_quad_load<P, 2>(T, sub, info, e2);
-    if (round_has_owner4(m_live, 3)) phi_quad_load<P, 3>(T, sub, info, e3);
+    QuadRaw<P> e0, e1, e2, e3;
+    phi_quad_load<P, 0>(T, sub, info, e0);
+    phi_quad_load<P, 1>(T, sub, info, e1);
+    phi_quad_load<P, 2>(T, sub, info, e2);
+    phi_quad_load<P, 3>(T, sub, info, e3);
     if (round_has_owner4(m_live, 0)) phi_quad_round<P, 0>(sub, live, start, q, e0, t, val);
     if (round_has_owner4(m_live, 1)) phi_quad_round<P, 1>(sub, live, start, q, e1, t, val);
     if (round_has_owner4(m_live, 2)) phi_quad_round<P, 2>(sub, live, start, q, e2, t, val);
@@ -520,14 +547,13 @@ __device__ __forceinline__ void coop_probe_phi4(const DevTree &T, const bool liv
 // below q is a quad sum -- no LDS traffic.
 template <typename P, int J>
 __device__ __forceinline__ void narrow_quad_load(const DevTree *s_tree, const uint32_t sub, const uint32_t flags, const uint32_t s, const uint32_t z, P (&key)[4]) {
-    typedef typename PairOf<P>::vec vec;
     const uint32_t of = quad_get<J>(flags), os = quad_get<J>(s), oz = quad_get<J>(z);
     const uint32_t ost = (oz + kFan - 1) / kFan;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         key[i] = static_cast<P>(~P(0));   // pivots beyond the candidates are never below
         const uint32_t at = (4u * sub + i) * ost;
-        if ((of & 1u) && at < oz) key[i] = static_cast<P>(static_cast<const vec *>(s_tree[(of >> 1) & 7u].ent)[static_cast<uint64_t>(os) + at].x);
+        if ((of & 1u) && at < oz) key[i] = RunList<P>::key(s_tree[(of >> 1) & 7u].ent, static_cast<uint64_t>(os) + at);
     }
 }
 template <typename P, int J>
@@ -593,7 +619,7 @@ __device__ __forceinline__ void coop_rec2(const RunRec *const *s_rec, uint4 *req
         if (!round_has_owner(m_live, j)) continue;
         const uint4 a = req[(rowbase + j) * NS + 0];
         va[j] = vec2{kRecNoPair, 0u};
-        if (a.y & 1u) va[j] = reinterpret_cast<const vec2 *>(s_rec[(a.y >> 2) & 7u] + a.x)[sub];
+        if (a.y & 1u) va[j] = as_global<vec2>(static_cast<const void *>(s_rec[(a.y >> 2) & 7u] + a.x))[sub];
     }
 #pragma unroll
     for (int j = 0; j < kFan; ++j) {
@@ -626,7 +652,7 @@ __device__ __forceinline__ void coop_rec2(const RunRec *const *s_rec, uint4 *req
         if (!round_has_owner(m_two, j)) continue;
         const uint4 b = req[(rowbase + j) * NS + 1];
         va[j] = vec2{kRecNoPair, 0u};
-        if (b.y & 2u) va[j] = reinterpret_cast<const vec2 *>(s_rec[(b.y >> 2) & 7u] + b.x)[sub];
+        if (b.y & 2u) va[j] = as_global<vec2>(static_cast<const void *>(s_rec[(b.y >> 2) & 7u] + b.x))[sub];
     }
 #pragma unroll
     for (int j = 0; j < kFan; ++j) {
@@ -735,8 +761,8 @@ struct RunStep {
 template <typename P>
 __device__ __forceinline__ uint64_t run_step_sample(const DevIndex &ix, const RunRec *const *s_rec, uint32_t d, const RunStep &r) {
     uint32_t e = r.samp_run;
-    if (r.samp_c) e = s_rec[d][r.samp_run].e0 + r.samp_c - 1;
-    return static_cast<uint64_t>(static_cast<const P *>(ix.run_samp[d])[e]);
+    if (r.samp_c) e = as_global(s_rec[d])[r.samp_run].e0 + r.samp_c - 1;
+    return RunList<P>::samp(ix.run_samp[d], e);
 }
 
 // What the instrumented instantiations count on this layout (the same eight sums as SearchStat, other meanings:
@@ -798,7 +824,7 @@ __device__ __forceinline__ void coop_lf2(const DevIndex &ix, const RunSearch<P> 
     uint32_t cn0 = 0, cn1 = 0;
     coop_rec2<P>(S.rec, S.req, d, by_rec, rc0, rc1, o0, o1, cn0, cn1, rk0, rk1, ins1, ov);
     if (by_rec && ov) {   // a bucket with more runs than a record holds: through the run list, like a directory's
-        const RunRec *__restrict__ R = S.rec[d];
+        const RBG_GLOBAL RunRec *R = as_global(S.rec[d]);
         const uint32_t f0 = R[rc0].flags, f1 = R[rc1].flags;
         s0 = R[rc0].e0; z0 = (f0 & kRecOverflow) ? (f0 & 0x7FFFFFFFu) : (f0 & 0xFFu);
         s1 = R[rc1].e0; z1 = (f1 & kRecOverflow) ? (f1 & 0x7FFFFFFFu) : (f1 & 0xFFu);
