@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256, sizeof(P) == 4 ? 4 : 3) void k_locate_fill_run
     const uint32_t *__restrict__ pdir = ix.phi_dir;
     const uint32_t pdir_shift = ix.phi_dir_shift;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
-    const void *__restrict__ pent = ix.phi_ent;   // {sampled position, base} (rbg_dev.h RunsFmt)
+    const void *__restrict__ pent = ix.phi_ent;   // {sampled position, base} (rbg_dev.h PhiFmt)
     unsigned long long c_locs = 0;
     unsigned long long st_phi = 0, st_ent = 0, st_chains = 0;   // STATS only
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
@@ -325,11 +325,11 @@ __global__ __launch_bounds__(256, sizeof(P) == 4 ? 4 : 3) void k_locate_fill_run
                     }
                     // a crowded bucket is narrowed by pivot probes first (coop_narrow), as the ranks' are
                     if (ORDERED) {
-                        while (__ballot(coop && z > static_cast<uint32_t>(kFan))) coop_narrow4<P>(s_tree, 0u, coop && z > static_cast<uint32_t>(kFan), start, z, static_cast<P>(k1));
+                        while (__ballot(coop && z > static_cast<uint32_t>(kFan))) coop_narrow4<P, PhiList<P>>(s_tree, 0u, coop && z > static_cast<uint32_t>(kFan), start, z, static_cast<P>(k1));
                         coop_probe_phi4<P>(s_tree[0], coop, start, static_cast<P>(k1), tq, pval);
                         by_dir = coop;
                     } else {
-                        while (__ballot(coop && z > static_cast<uint32_t>(kFan))) coop_narrow4<P>(s_tree, 0u, coop && z > static_cast<uint32_t>(kFan), start, z, static_cast<P>(k1));
+                        while (__ballot(coop && z > static_cast<uint32_t>(kFan))) coop_narrow4<P, PhiList<P>>(s_tree, 0u, coop && z > static_cast<uint32_t>(kFan), start, z, static_cast<P>(k1));
                         coop_probe_phi<P>(s_tree[0], req, coop, start, z, static_cast<P>(k1), tq, pval);
                         by_dir = coop;
                     }
@@ -346,19 +346,19 @@ __global__ __launch_bounds__(256, sizeof(P) == 4 ? 4 : 3) void k_locate_fill_run
                     }
                     {
                         const bool lv0 = descend && td > 0;
-                        coop_leaf<P>(s_tree, 0u, 0u, phi_hi, lv0, false, td, unused_t, static_cast<P>(k1), P(0), dk, dv, nv, u1, u2, u3);
+                        coop_leaf<P, PhiList<P>>(s_tree, 0u, 0u, phi_hi, lv0, false, td, unused_t, static_cast<P>(k1), P(0), dk, dv, nv, u1, u2, u3);
                     }
                     if (descend) { tq = td; pk = dk; pv = dv; }
                 }
                 if (need) {
                     uint64_t s;
                     if (wrapped) {
-                        const typename RunList<P>::pair e2 = RunList<P>::load(pent, ix.r - 1);
+                        const typename PhiList<P>::pair e2 = PhiList<P>::load(pent, ix.r - 1);
                         s = (static_cast<uint64_t>(e2.y) + (k1 - static_cast<uint64_t>(e2.x))) % ix.n;
                     } else if (tq == 0) {
                         // no sampled position before k1: circular predecessor = the last one, delta = i + 1
                         // (sparse_sd_vector.hpp:141-143, toehold_sa.hpp:59,65)
-                        s = static_cast<uint64_t>(RunList<P>::val(pent, ix.r - 1)) + k1 + 1;
+                        s = static_cast<uint64_t>(PhiList<P>::val(pent, ix.r - 1)) + k1 + 1;
                         if (s >= ix.n) s -= ix.n;
                     } else {
                         s = by_dir ? static_cast<uint64_t>(pval) : static_cast<uint64_t>(pv) + (k1 - pk);   // prev_sample + delta (toehold_sa.hpp:65-71)

@@ -572,7 +572,7 @@ size_t runs_replica_bytes(const HostIndex &h) {
         total += entries * (RunsFmt<P>::ent_bytes + (h.has_tsa ? RunsFmt<P>::samp_bytes : 0)) + entries * sizeof(P) / 15 + entries * 2 + lv->size() * 8 + 8 * kArenaAlign;   // (+ directories: at most half an entry per run)
         if (rec_target > 0) total += static_cast<size_t>(2.0 * static_cast<double>(entries) / rec_target + static_cast<double>(lv->size())) * sizeof(RunRec);   // (+ bucket records)
     }
-    if (h.has_tsa) total += (h.r + 1) * RunsFmt<P>::ent_bytes + h.r * sizeof(P) / 15 + std::min<size_t>(h.r, size_t(1) << 29) * 4;   // (+ the phi directory: at most r entries)
+    if (h.has_tsa) total += (h.r + 1) * PhiFmt<P>::ent_bytes + h.r * sizeof(P) / 15 + std::min<size_t>(h.r, size_t(1) << 29) * 4;   // (+ the phi directory: at most r entries)
     return total + 16 * kArenaAlign;
 }
 
@@ -808,7 +808,7 @@ int upload_tables_runs(rbg_index *ix) {
         ix->dev.nmajor = h.nmajor;
     }
     if (h.has_tsa) {
-        typedef RunsFmt<P> Fmt;
+        typedef PhiFmt<P> Fmt;
         std::vector<unsigned char> pe((h.r + 1 + Fmt::spare) * Fmt::ent_bytes);   // (the sentinel and the spare entries after it)
         parallel_for(h.r, [&](uint64_t a, uint64_t b, unsigned) {
             for (uint64_t j = a; j < b; ++j) Fmt::put_ent(pe.data(), j, h.pred_pos[j], h.phi_base[j]);

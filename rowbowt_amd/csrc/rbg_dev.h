@@ -26,18 +26,33 @@ struct PhiEnt {
 };
 
 // THE SORTED LISTS OF THE RUN-INDEXED LAYOUT (RBG_LAYOUT_RUNS below: run lists per k-mer depth, the phi list) are
-// {key, value} pairs as above at 4-byte positions.  At 8-byte positions they are 12-byte entries -- positions stay below
-// 2^48 (rbg_host.cpp flatten()), so a pair of them is two 32-bit words and two 16-bit halves -- and the samples beside the
-// run lists 6 bytes: 18 bytes per run and depth instead of 24, and sixteen entries (what a quad of lanes probes) are 192
-// contiguous bytes = three 16-byte requests per lane instead of 256 / four.  (Round 2: 248 bytes per run over five
-// depths, 77 GB at r = 3.1e8.)
+// {key, value} pairs as above at both position widths; the SAMPLES beside the run lists are 6 bytes each at 8-byte
+// positions (positions stay below 2^48: rbg_host.cpp flatten()) -- they are read once per materialised re-sample, so
+// their alignment costs nothing.  12-byte ENTRIES were tried (round 3: 18 instead of 24 bytes per run and depth, the
+// n = 5e10 replica 59 GB instead of 77, bit-exact) and not kept: the probes' unaligned 12- and 16-byte requests made K1/K2
+// 12 % slower on the bench index and 49 % slower at n = 5e10 at the same number of L2 misses and VALU instructions
+// (profiles/r03_ent48_ab.txt, tools/ent48_probe.hip; commit "experiment: 12-byte entries ...").
+struct Samp48 {
+    uint16_t w[3];   // little end first
+};
+// The PHI LIST {sampled position, base} keeps the 12-byte form at 8-byte positions: its probes always read the lane's
+// four consecutive entries (three 16-byte requests, no clamping to a candidate count), and K3's ordered walk takes 41.4
+// -> 36.8 ms per batch at n = 5e10 with it (7.2 -> 6.7 on the bench index).
 struct Ent48 {
     uint32_t key_lo, val_lo;
     uint16_t key_hi, val_hi;
 };
 static_assert(sizeof(Ent48) == 12, "three words per entry");
-struct Samp48 {
-    uint16_t w[3];   // little end first
+template <typename P> struct PhiFmt;
+template <> struct PhiFmt<uint32_t> {
+    static constexpr size_t ent_bytes = 8, spare = 1;
+    static void put_ent(void *base, uint64_t i, uint64_t key, uint64_t val) { static_cast<PhiEnt<uint32_t> *>(base)[i] = {static_cast<uint32_t>(key), static_cast<uint32_t>(val)}; }
+};
+template <> struct PhiFmt<uint64_t> {
+    static constexpr size_t ent_bytes = sizeof(Ent48), spare = 3;   // (the four-entry loads may touch three entries past the sentinel)
+    static void put_ent(void *base, uint64_t i, uint64_t key, uint64_t val) {
+        static_cast<Ent48 *>(base)[i] = {static_cast<uint32_t>(key), static_cast<uint32_t>(val), static_cast<uint16_t>(key >> 32), static_cast<uint16_t>(val >> 32)};
+    }
 };
 template <typename P> struct RunsFmt;
 template <> struct RunsFmt<uint32_t> {
@@ -46,10 +61,8 @@ template <> struct RunsFmt<uint32_t> {
     static void put_samp(void *base, uint64_t i, uint64_t v) { static_cast<uint32_t *>(base)[i] = static_cast<uint32_t>(v); }
 };
 template <> struct RunsFmt<uint64_t> {
-    static constexpr size_t ent_bytes = sizeof(Ent48), samp_bytes = sizeof(Samp48), spare = 3;   // (the four-entry loads may touch three)
-    static void put_ent(void *base, uint64_t i, uint64_t key, uint64_t val) {
-        static_cast<Ent48 *>(base)[i] = {static_cast<uint32_t>(key), static_cast<uint32_t>(val), static_cast<uint16_t>(key >> 32), static_cast<uint16_t>(val >> 32)};
-    }
+    static constexpr size_t ent_bytes = 16, samp_bytes = sizeof(Samp48), spare = 1;
+    static void put_ent(void *base, uint64_t i, uint64_t key, uint64_t val) { static_cast<RunEnt<uint64_t> *>(base)[i] = {key, val}; }
     static void put_samp(void *base, uint64_t i, uint64_t v) {
         static_cast<Samp48 *>(base)[i] = {{static_cast<uint16_t>(v), static_cast<uint16_t>(v >> 16), static_cast<uint16_t>(v >> 32)}};
     }

@@ -236,8 +236,8 @@ __device__ __forceinline__ void load_slot64(const RankSlot64 *p, uint32_t (&w)[1
 // a RankAux that stands for a Rank64Aux: nbefore = the run ordinal itself (ord + nbefore), so that pred_run needs no ord[]
 __device__ __forceinline__ bool sym_is_slot64(const DevSym &S) { return S.slots != nullptr && S.ord == nullptr; }
 
-// The sorted lists of the run-indexed layout as the kernels read them (rbg_dev.h RunsFmt: {key, value} pairs of 32-bit
-// words at 4-byte positions, 12-byte entries and 6-byte samples at 8-byte positions).
+// The sorted lists of the run-indexed layout as the kernels read them (rbg_dev.h RunsFmt: {key, value} pairs of P; samples
+// of 4 bytes, or 6 bytes at 8-byte positions).
 template <typename P> struct RunList;
 template <> struct RunList<uint32_t> {
     typedef unsigned int pair __attribute__((ext_vector_type(2)));
@@ -245,29 +245,33 @@ template <> struct RunList<uint32_t> {
     static __device__ __forceinline__ uint32_t val(const void *__restrict__ b, uint64_t i) { return as_global<RunEnt<uint32_t>>(b)[i].cum; }
     static __device__ __forceinline__ pair load(const void *__restrict__ b, uint64_t i) { return as_global<pair>(b)[i]; }
     static __device__ __forceinline__ uint64_t samp(const void *__restrict__ b, uint64_t i) { return as_global<uint32_t>(b)[i]; }
-    static __device__ __forceinline__ pair unpack(uint32_t w0, uint32_t w1, uint32_t) { return pair{w0, w1}; }   // (12-byte entries exist at 8-byte positions only)
 };
 template <> struct RunList<uint64_t> {
     typedef unsigned long long pair __attribute__((ext_vector_type(2)));
-    static __device__ __forceinline__ uint64_t key(const void *__restrict__ b, uint64_t i) {
-        const RBG_GLOBAL uint32_t *w = as_global<uint32_t>(b) + 3 * i;
-        return static_cast<uint64_t>(w[0]) | (static_cast<uint64_t>(w[2] & 0xFFFFu) << 32);
-    }
-    static __device__ __forceinline__ uint64_t val(const void *__restrict__ b, uint64_t i) {
-        const RBG_GLOBAL uint32_t *w = as_global<uint32_t>(b) + 3 * i;
-        return static_cast<uint64_t>(w[1]) | (static_cast<uint64_t>(w[2] >> 16) << 32);
-    }
-    static __device__ __forceinline__ pair unpack(uint32_t w0, uint32_t w1, uint32_t w2) {
-        return pair{static_cast<uint64_t>(w0) | (static_cast<uint64_t>(w2 & 0xFFFFu) << 32), static_cast<uint64_t>(w1) | (static_cast<uint64_t>(w2 >> 16) << 32)};
-    }
-    static __device__ __forceinline__ pair load(const void *__restrict__ b, uint64_t i) {
-        const RBG_GLOBAL uint32_t *w = as_global<uint32_t>(b) + 3 * i;
-        return unpack(w[0], w[1], w[2]);
-    }
+    static __device__ __forceinline__ uint64_t key(const void *__restrict__ b, uint64_t i) { return as_global<RunEnt<uint64_t>>(b)[i].start; }
+    static __device__ __forceinline__ uint64_t val(const void *__restrict__ b, uint64_t i) { return as_global<RunEnt<uint64_t>>(b)[i].cum; }
+    static __device__ __forceinline__ pair load(const void *__restrict__ b, uint64_t i) { return as_global<pair>(b)[i]; }
     static __device__ __forceinline__ uint64_t samp(const void *__restrict__ b, uint64_t i) {
         const RBG_GLOBAL uint16_t *h = as_global<uint16_t>(b) + 3 * i;
         return static_cast<uint64_t>(h[0]) | (static_cast<uint64_t>(h[1]) << 16) | (static_cast<uint64_t>(h[2]) << 32);
     }
+};
+
+// the phi list (rbg_dev.h PhiFmt): pairs of 32-bit words, or 12-byte entries at 8-byte positions -- one request per entry
+template <typename P> struct PhiList;
+template <> struct PhiList<uint32_t> : RunList<uint32_t> {};
+template <> struct PhiList<uint64_t> {
+    typedef unsigned long long pair __attribute__((ext_vector_type(2)));
+    typedef unsigned int vec3 __attribute__((ext_vector_type(3), aligned(4)));
+    static __device__ __forceinline__ pair unpack(uint32_t w0, uint32_t w1, uint32_t w2) {
+        return pair{static_cast<uint64_t>(w0) | (static_cast<uint64_t>(w2 & 0xFFFFu) << 32), static_cast<uint64_t>(w1) | (static_cast<uint64_t>(w2 >> 16) << 32)};
+    }
+    static __device__ __forceinline__ pair load(const void *__restrict__ b, uint64_t i) {
+        const vec3 w = *reinterpret_cast<const RBG_GLOBAL vec3 *>(as_global<uint32_t>(b) + 3 * i);
+        return unpack(w.x, w.y, w.z);
+    }
+    static __device__ __forceinline__ uint64_t key(const void *__restrict__ b, uint64_t i) { return load(b, i).x; }
+    static __device__ __forceinline__ uint64_t val(const void *__restrict__ b, uint64_t i) { return load(b, i).y; }
 };
 
 // Run-indexed layout, one lane on its own: binary search of the run list (the kernels that are not on the

@@ -157,7 +157,7 @@ __device__ __forceinline__ void coop_level(const DevTree *s_tree, const int l, c
 // The leaf level: {key, value} pairs, probed the same way.  For each live query returns g = # entries below q (in t),
 // the pair before it (key pk, value pv: entry g-1) and the value of entry g (nv; every slice ends with a sentinel).
 // Entries g-1 and g are read out of the registers of the row's lanes that loaded them: a rank costs no further gather.
-template <typename P>
+template <typename P, typename L = RunList<P>>
 __device__ __forceinline__ void coop_leaf(const DevTree *s_tree, const uint32_t tid, const uint32_t lo_t, const uint32_t hi_t, const bool live0,
                                           const bool live1, uint32_t &t0, uint32_t &t1, const P q0, const P q1, P &pk0, P &pv0, P &nv0, P &pk1,
                                           P &pv1, P &nv1) {
@@ -180,7 +180,7 @@ __device__ __forceinline__ void coop_leaf(const DevTree *s_tree, const uint32_t 
         if (oi & 1u) {
             const DevTree &T = s_tree[(oi >> 2) & 7u];
             const uint64_t i = static_cast<uint64_t>(ob) * kFan + sub;
-            if (i <= T.m) va[j] = RunList<P>::load(T.ent, i);   // entry m is the last sentinel
+            if (i <= T.m) va[j] = L::load(T.ent, i);   // entry m is the last sentinel
         }
     }
 #pragma unroll
@@ -213,7 +213,7 @@ __device__ __forceinline__ void coop_leaf(const DevTree *s_tree, const uint32_t 
             if (oi & 2u) {
                 const DevTree &T = s_tree[(oi >> 2) & 7u];
                 const uint64_t i = static_cast<uint64_t>(ob) * kFan + sub;
-                if (i <= T.m) va[j] = RunList<P>::load(T.ent, i);
+                if (i <= T.m) va[j] = L::load(T.ent, i);
             }
         }
 #pragma unroll
@@ -230,8 +230,8 @@ __device__ __forceinline__ void coop_leaf(const DevTree *s_tree, const uint32_t 
     }
     if (fix0 || fix1) {
         const void *__restrict__ ent = s_tree[tid].ent;
-        if (fix0) nv0 = RunList<P>::val(ent, t0);
-        if (fix1) nv1 = RunList<P>::val(ent, t1);
+        if (fix0) nv0 = L::val(ent, t0);
+        if (fix1) nv1 = L::val(ent, t1);
     }
 }
 
@@ -261,7 +261,7 @@ __device__ __forceinline__ void coop_probe_phi(const DevTree &T, uint4 *req, con
             const uint32_t oz = a.y >> 1, last = oz ? oz - 1 : 0;
             uint64_t i = static_cast<uint64_t>(a.x) + (sub < last ? sub : last);
             if (i > T.m) i = T.m;   // entry m is the sentinel (never below a query)
-            va[j] = RunList<P>::load(T.ent, i);
+            va[j] = PhiList<P>::load(T.ent, i);
         }
     }
 #pragma unroll
@@ -329,15 +329,26 @@ template <> struct QuadRaw<uint32_t> {
 template <> struct QuadRaw<uint64_t> {
     typedef unsigned int vec4 __attribute__((ext_vector_type(4)));
     typedef PairOf<uint64_t>::vec vec;
-    typedef unsigned int vec3 __attribute__((ext_vector_type(3)));
-    uint32_t w[12];   // four 12-byte entries, word by word (constant indices only: registers)
-    __device__ __forceinline__ void set4(vec4 a, vec4 b, vec4 c) {
-        w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w; w[8] = c.x; w[9] = c.y; w[10] = c.z; w[11] = c.w;
-    }
-    template <int I> __device__ __forceinline__ void set3(vec3 v) { w[3 * I] = v.x; w[3 * I + 1] = v.y; w[3 * I + 2] = v.z; }
+    vec4 w[4];   // one 16-byte entry each
     __device__ __forceinline__ void unpack(vec (&e)[4]) const {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) e[i] = RunList<uint64_t>::unpack(w[3 * i], w[3 * i + 1], w[3 * i + 2]);
+        for (int i = 0; i < 4; ++i)
+            e[i] = vec{static_cast<uint64_t>(w[i].x) | (static_cast<uint64_t>(w[i].y) << 32), static_cast<uint64_t>(w[i].z) | (static_cast<uint64_t>(w[i].w) << 32)};
+    }
+};
+
+// the phi list's entries as loaded (rbg_dev.h PhiFmt)
+template <typename P> struct PhiRaw;
+template <> struct PhiRaw<uint32_t> : QuadRaw<uint32_t> {};
+template <> struct PhiRaw<uint64_t> {
+    typedef unsigned int vec4 __attribute__((ext_vector_type(4)));
+    typedef PairOf<uint64_t>::vec vec;
+    vec4 a, b, c;   // four 12-byte entries
+    __device__ __forceinline__ void unpack(vec (&e)[4]) const {
+        e[0] = PhiList<uint64_t>::unpack(a.x, a.y, a.z);
+        e[1] = PhiList<uint64_t>::unpack(a.w, b.x, b.y);
+        e[2] = PhiList<uint64_t>::unpack(b.z, b.w, c.x);
+        e[3] = PhiList<uint64_t>::unpack(c.y, c.z, c.w);
     }
 };
 
@@ -368,18 +379,12 @@ __device__ __forceinline__ void quad_load(const DevTree *s_tree, const uint32_t 
             if (h == 0) raw.a = w; else raw.b = w;
         }
     } else {
-        // one 12-byte request per entry, each clamped to entry zc like the pairs above: the probe touches exactly the
-        // sectors that hold entries 0 .. zc.  (Three 16-byte requests for the lane's four consecutive entries reach three
-        // entries past zc: a fifth more sectors per probe, and K1/K2 at 8-byte positions took 14.0 instead of 11.8 ms.)
-        typedef unsigned int vec3 __attribute__((ext_vector_type(3), aligned(4)));
-        const RBG_GLOBAL char *base = as_global<char>(T.ent);
-        uint32_t g[4];
+        // one 16-byte request per entry, each clamped to entry zc like the pairs above: the probe touches only the sectors
+        // that hold entries 0 .. zc
+        typedef unsigned int vec4 __attribute__((ext_vector_type(4)));
+        const RBG_GLOBAL vec4 *base = as_global<vec4>(T.ent);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) g[i] = min(os + min(4u * sub + i, zc), last);
-        raw.template set3<0>(*reinterpret_cast<const RBG_GLOBAL vec3 *>(base + static_cast<uint64_t>(g[0]) * 12u));
-        raw.template set3<1>(*reinterpret_cast<const RBG_GLOBAL vec3 *>(base + static_cast<uint64_t>(g[1]) * 12u));
-        raw.template set3<2>(*reinterpret_cast<const RBG_GLOBAL vec3 *>(base + static_cast<uint64_t>(g[2]) * 12u));
-        raw.template set3<3>(*reinterpret_cast<const RBG_GLOBAL vec3 *>(base + static_cast<uint64_t>(g[3]) * 12u));
+        for (int i = 0; i < 4; ++i) raw.w[i] = base[min(os + min(4u * sub + i, zc), last)];
     }
 }
 
@@ -482,7 +487,7 @@ __device__ __forceinline__ void coop_probe2_rank4(const DevTree *s_tree, const u
 // of samples below the position as a quad sum, phi's value base + (q - pos) from the lane that holds the last of them
 // as a quad OR.  t = start + # entries below q (val undefined when t == start).
 template <typename P, int J>
-__device__ __forceinline__ void phi_quad_load(const DevTree &T, const uint32_t sub, const uint32_t info, QuadRaw<P> &raw) {
+__device__ __forceinline__ void phi_quad_load(const DevTree &T, const uint32_t sub, const uint32_t info, PhiRaw<P> &raw) {
     const uint32_t oi = quad_get<J>(info);
     // (unconditional, as in quad_load: a quad without a query reads the list's first entries and its round's result is dropped)
     const uint32_t first = (oi & 0x80000000u) ? (oi & 0x7FFFFFFFu) + 4u * sub : 0u;   // (fewer than 2^31 sampled positions: upload() checks)
@@ -495,16 +500,15 @@ __device__ __forceinline__ void phi_quad_load(const DevTree &T, const uint32_t s
             const vec4 w = *as_global<vec4>(static_cast<const void *>(static_cast<const char *>(T.ent) + static_cast<uint64_t>(g) * 8u));
             if (h == 0) raw.a = w; else raw.b = w;
         }
-    } else {   // (12-byte entries, three spare ones after the sentinel: as in quad_load)
+    } else {   // four 12-byte entries = three 16-byte requests at a 4-byte boundary (three spare entries follow the sentinel)
         typedef unsigned int vec4 __attribute__((ext_vector_type(4), aligned(4)));
-        const uint32_t g = min(first, last);
-        const RBG_GLOBAL vec4 *w = as_global<vec4>(static_cast<const void *>(static_cast<const char *>(T.ent) + static_cast<uint64_t>(g) * 12u));
-        raw.set4(w[0], w[1], w[2]);
+        const RBG_GLOBAL vec4 *w = as_global<vec4>(static_cast<const void *>(static_cast<const char *>(T.ent) + static_cast<uint64_t>(min(first, last)) * 12u));
+        raw.a = w[0]; raw.b = w[1]; raw.c = w[2];
     }
 }
 
 template <typename P, int J>
-__device__ __forceinline__ void phi_quad_round(const uint32_t sub, const bool live, const uint32_t start, const P q, const QuadRaw<P> &raw,
+__device__ __forceinline__ void phi_quad_round(const uint32_t sub, const bool live, const uint32_t start, const P q, const PhiRaw<P> &raw,
                                                uint32_t &t, P &val) {
     typename PairOf<P>::vec e[4];
     raw.unpack(e);
@@ -528,7 +532,7 @@ __device__ __forceinline__ void coop_probe_phi4(const DevTree &T, const bool liv
     const uint64_t m_live = __ballot(live);
     if (!m_live) return;
     const uint32_t info = (live ? 0x80000000u : 0u) | (start & 0x7FFFFFFFu);   // (fewer than 2^31 sampled positions: upload() checks)
-    QuadRaw<P> e0, e1, e2, e3;
+    PhiRaw<P> e0, e1, e2, e3;
     phi_quad_load<P, 0>(T, sub, info, e0);
     phi_quad_load<P, 1>(T, sub, info, e1);
     phi_quad_load<P, 2>(T, sub, info, e2);
@@ -545,7 +549,7 @@ __device__ __forceinline__ void coop_probe_phi4(const DevTree &T, const bool liv
 // the first candidate is).  Lanes with live == false pass through.  Every lane must call.  By QUADS: the sixteen
 // pivots are four per lane of the owner's quad, its (s, z, tree, q) reach the quad by DPP and the number of pivots
 // below q is a quad sum -- no LDS traffic.
-template <typename P, int J>
+template <typename P, int J, typename L>
 __device__ __forceinline__ void narrow_quad_load(const DevTree *s_tree, const uint32_t sub, const uint32_t flags, const uint32_t s, const uint32_t z, P (&key)[4]) {
     const uint32_t of = quad_get<J>(flags), os = quad_get<J>(s), oz = quad_get<J>(z);
     const uint32_t ost = (oz + kFan - 1) / kFan;
@@ -553,7 +557,7 @@ __device__ __forceinline__ void narrow_quad_load(const DevTree *s_tree, const ui
     for (int i = 0; i < 4; ++i) {
         key[i] = static_cast<P>(~P(0));   // pivots beyond the candidates are never below
         const uint32_t at = (4u * sub + i) * ost;
-        if ((of & 1u) && at < oz) key[i] = RunList<P>::key(s_tree[(of >> 1) & 7u].ent, static_cast<uint64_t>(os) + at);
+        if ((of & 1u) && at < oz) key[i] = L::key(s_tree[(of >> 1) & 7u].ent, static_cast<uint64_t>(os) + at);
     }
 }
 template <typename P, int J>
@@ -572,7 +576,7 @@ __device__ __forceinline__ void narrow_quad_round(const uint32_t sub, const bool
         }
     }
 }
-template <typename P>
+template <typename P, typename L = RunList<P>>
 __device__ __forceinline__ void coop_narrow4(const DevTree *s_tree, const uint32_t tid, const bool live, uint32_t &s, uint32_t &z, const P q) {
     const uint32_t lane = threadIdx.x & (kWave - 1), sub = lane & 3u;
     const uint64_t m_live = __ballot(live);
@@ -581,10 +585,10 @@ __device__ __forceinline__ void coop_narrow4(const DevTree *s_tree, const uint32
     const uint32_t flags = (live ? 1u : 0u) | (tid << 1);
     const uint32_t s_in = s, z_in = z;   // (the owners update s and z while later rounds still broadcast the others')
     P k0[4], k1[4], k2[4], k3[4];
-    if (round_has_owner4(m_live, 0)) narrow_quad_load<P, 0>(s_tree, sub, flags, s_in, z_in, k0);
-    if (round_has_owner4(m_live, 1)) narrow_quad_load<P, 1>(s_tree, sub, flags, s_in, z_in, k1);
-    if (round_has_owner4(m_live, 2)) narrow_quad_load<P, 2>(s_tree, sub, flags, s_in, z_in, k2);
-    if (round_has_owner4(m_live, 3)) narrow_quad_load<P, 3>(s_tree, sub, flags, s_in, z_in, k3);
+    if (round_has_owner4(m_live, 0)) narrow_quad_load<P, 0, L>(s_tree, sub, flags, s_in, z_in, k0);
+    if (round_has_owner4(m_live, 1)) narrow_quad_load<P, 1, L>(s_tree, sub, flags, s_in, z_in, k1);
+    if (round_has_owner4(m_live, 2)) narrow_quad_load<P, 2, L>(s_tree, sub, flags, s_in, z_in, k2);
+    if (round_has_owner4(m_live, 3)) narrow_quad_load<P, 3, L>(s_tree, sub, flags, s_in, z_in, k3);
     if (round_has_owner4(m_live, 0)) narrow_quad_round<P, 0>(sub, live, stride, q, k0, s, z);
     if (round_has_owner4(m_live, 1)) narrow_quad_round<P, 1>(sub, live, stride, q, k1, s, z);
     if (round_has_owner4(m_live, 2)) narrow_quad_round<P, 2>(sub, live, stride, q, k2, s, z);
