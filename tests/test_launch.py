@@ -96,3 +96,19 @@ def test_rank_env_and_check_world():
         launch.check_world(4, env=e)
     with pytest.raises(SystemExit):
         launch.run_ranks("x.py", [], 0, check_devices=False)
+
+
+@pytest.mark.gpu
+def test_on_the_gpu_box_one_rank_more_than_devices_is_refused_and_launch_check_names_every_rank():
+    """the same refusal where GPUs exist: --gpus (devices + 1) never starts a rank; --gpus devices passes the check and the
+    children are given ranks 0 .. devices - 1 (--launch-check: no GPU is touched by anyone)."""
+    count = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=300)
+    ndev = int(count.stdout.strip())
+    assert ndev >= 1
+    p = subprocess.run([sys.executable, SCRIPTS[0], "--gpus", str(ndev + 1)], env=clean_env(), capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0 and p.stdout.strip() == "" and "refusing" in p.stderr
+    if ndev >= 2:
+        p = subprocess.run([sys.executable, SCRIPTS[0], "--gpus", str(ndev), "--launch-check"], env=clean_env(), capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0
+        ranks = sorted(json.loads(line.split("] ", 1)[-1])["RANK"] for line in (p.stdout + p.stderr).splitlines() if '"RANK"' in line)
+        assert ranks == sorted(str(r) for r in range(ndev))
