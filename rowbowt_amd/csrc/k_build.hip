@@ -281,7 +281,74 @@ __global__ __launch_bounds__(256) void k_build_phi_slots(const PhiEnt<P> *__rest
     novf = wave_sum(novf);
     if ((threadIdx.x & (kWave - 1)) == 0 && novf) atomicAdd(overflow, novf);
 }
+// ---- run-indexed layout built from run lists that are already on the device (the k-mer levels of k_compose.hip) -----------
+// dir[doff[t] + b] = # runs of table t that start below b << dshift[t] (rbg_dev.h DevRunTab): one thread per directory entry
+template <typename P>
+__global__ __launch_bounds__(256) void k_run_dirs(const RunEnt<P> *__restrict__ ent, const uint64_t *__restrict__ first, const uint64_t *__restrict__ nruns,
+                                                  const uint64_t *__restrict__ doff, const uint32_t *__restrict__ dshift, const uint32_t T,
+                                                  const uint64_t total, uint32_t *__restrict__ dir) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += stride) {
+        uint32_t a = 0, z = T;                       // the table: last t with doff[t] <= i
+        while (z - a > 1) {
+            const uint32_t mid = (a + z) >> 1;
+            if (doff[mid] <= i) a = mid; else z = mid;
+        }
+        const uint64_t lim = (i - doff[a]) << dshift[a];
+        const RunEnt<P> *__restrict__ e = ent + first[a];
+        uint64_t lo = 0, hi = nruns[a];
+        while (lo < hi) {
+            const uint64_t mid = lo + ((hi - lo) >> 1);
+            if (static_cast<uint64_t>(e[mid].start) < lim) lo = mid + 1; else hi = mid;
+        }
+        dir[i] = static_cast<uint32_t>(lo);
+    }
+}
+// out[j] = key of entry j * step (one sampled level of a depth's index: rbg_dev.h DevTree)
+template <typename P>
+__global__ __launch_bounds__(256) void k_sample_keys(const RunEnt<P> *__restrict__ ent, const uint64_t step, const uint64_t count, P *__restrict__ out) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t j = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < count; j += stride) out[j] = ent[j * step].start;
+}
+// 8-byte samples -> the 6-byte form of the run-indexed layout (rbg_dev.h Samp48)
+__global__ __launch_bounds__(256) void k_pack_samp48(const uint64_t *__restrict__ in, const uint64_t n, uint16_t *__restrict__ out) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t j = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < n; j += stride) {
+        const uint64_t v = in[j];
+        out[3 * j] = static_cast<uint16_t>(v);
+        out[3 * j + 1] = static_cast<uint16_t>(v >> 16);
+        out[3 * j + 2] = static_cast<uint16_t>(v >> 32);
+    }
+}
 }  // namespace
+
+int launch_run_dirs(uint32_t pos_bytes, const void *ent, const uint64_t *first, const uint64_t *nruns, const uint64_t *doff, const uint32_t *dshift,
+                    uint32_t T, uint64_t total, uint32_t *dir, void *stream) {
+    if (!total) return 0;
+    const int grid = static_cast<int>(std::min<uint64_t>((total + 255) / 256, 256ull * 64));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (pos_bytes == 4)
+        hipLaunchKernelGGL((k_run_dirs<uint32_t>), dim3(grid), dim3(256), 0, st, static_cast<const RunEnt<uint32_t> *>(ent), first, nruns, doff, dshift, T, total, dir);
+    else
+        hipLaunchKernelGGL((k_run_dirs<uint64_t>), dim3(grid), dim3(256), 0, st, static_cast<const RunEnt<uint64_t> *>(ent), first, nruns, doff, dshift, T, total, dir);
+    return static_cast<int>(hipGetLastError());
+}
+int launch_sample_keys(uint32_t pos_bytes, const void *ent, uint64_t step, uint64_t count, void *out, void *stream) {
+    if (!count) return 0;
+    const int grid = static_cast<int>(std::min<uint64_t>((count + 255) / 256, 256ull * 64));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (pos_bytes == 4)
+        hipLaunchKernelGGL((k_sample_keys<uint32_t>), dim3(grid), dim3(256), 0, st, static_cast<const RunEnt<uint32_t> *>(ent), step, count, static_cast<uint32_t *>(out));
+    else
+        hipLaunchKernelGGL((k_sample_keys<uint64_t>), dim3(grid), dim3(256), 0, st, static_cast<const RunEnt<uint64_t> *>(ent), step, count, static_cast<uint64_t *>(out));
+    return static_cast<int>(hipGetLastError());
+}
+int launch_pack_samp48(const uint64_t *in, uint64_t n, void *out, void *stream) {
+    if (!n) return 0;
+    const int grid = static_cast<int>(std::min<uint64_t>((n + 255) / 256, 256ull * 64));
+    hipLaunchKernelGGL(k_pack_samp48, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), in, n, static_cast<uint16_t *>(out));
+    return static_cast<int>(hipGetLastError());
+}
 
 int launch_build_rank_slots64(uint32_t pos_bytes, const void *ent, const void *samp, uint64_t nruns, uint64_t n, uint32_t shift, void *slots,
                               unsigned long long *overflow, unsigned long long *dense_cursor, void *stream) {

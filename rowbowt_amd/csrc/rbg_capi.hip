@@ -551,6 +551,46 @@ int upload_tree(rbg_index *ix, const void *d_ent, uint64_t m, KeyAt key_at, uint
     return RBG_OK;
 }
 
+// give back one allocation the index tracks
+void free_tracked(rbg_index *ix, void *p) {
+    if (!p) return;
+    for (size_t i = 0; i < ix->allocs.size(); ++i)
+        if (ix->allocs[i].p == p) { ix->hbm_bytes -= ix->allocs[i].bytes; ix->allocs.erase(ix->allocs.begin() + static_cast<std::ptrdiff_t>(i)); break; }
+    (void)hipFree(p);
+}
+
+// upload_tree for a run list that is already on the device (a k-mer level of k_compose.hip): the sampled levels are
+// gathered there, only the top one comes to the host (it is staged in LDS with the other depths')
+template <typename P>
+int upload_tree_dev(rbg_index *ix, const void *d_ent, uint64_t m, uint32_t nlvl, std::vector<P> &top_all, DevTree &T) {
+    T = DevTree{};
+    T.ent = d_ent;
+    T.m = m;
+    uint64_t step = kTreeFan;
+    for (uint32_t l = 0; l <= nlvl; ++l, step *= kTreeFan) {
+        const uint64_t count = (m + step - 1) / step;
+        void *lv = nullptr;
+        if (l < nlvl) {
+            int rc = dev_reserve(ix, count * sizeof(P), &lv);
+            if (rc) return rc;
+            HIP_TRY(static_cast<hipError_t>(launch_sample_keys(sizeof(P), d_ent, step, count, lv, nullptr)));
+            T.lvl[l] = lv;
+            T.lvl_n[l] = static_cast<uint32_t>(count);
+        } else {
+            HIP_TRY(hipMalloc(&lv, std::max<uint64_t>(count, 1) * sizeof(P)));
+            std::vector<P> top(count);
+            hipError_t e = static_cast<hipError_t>(launch_sample_keys(sizeof(P), d_ent, step, count, lv, nullptr));
+            if (e == hipSuccess && count) e = hipMemcpy(top.data(), lv, count * sizeof(P), hipMemcpyDeviceToHost);
+            (void)hipFree(lv);
+            HIP_TRY(e);
+            T.top_off = static_cast<uint32_t>(top_all.size());
+            T.top_n = static_cast<uint32_t>(count);
+            top_all.insert(top_all.end(), top.begin(), top.end());
+        }
+    }
+    return RBG_OK;
+}
+
 // RBG_RANK_REC=<t> (rbg_dev.h RunRec): build bucket records with at most t runs per bucket on average (t >= 1; fewer
 // runs per bucket = fewer overflowing buckets, more records).  Off by default: on the bench index they buy 5 % of
 // K1 for 3.7 times the space, the directories and run lists are the layout of choice.
@@ -577,11 +617,18 @@ size_t runs_replica_bytes(const HostIndex &h) {
 }
 
 template <typename P> int materialize_kmer_levels(rbg_index *ix);
+void release_kmer_level(rbg_index *ix, uint32_t depth);
 
 template <typename P>
 int upload_tables_runs(rbg_index *ix) {
     HostIndex &h = ix->H();
-    {
+    // k-mer levels composed on the device (k_compose.hip) are adopted where they lie: their run lists ARE this layout's
+    // entry arrays, and the directories, sampled levels and 6-byte samples are made from them by kernels (k_build.hip).
+    // Bucket records (RBG_RANK_REC) and RBG_RUNS_HOST_BUILD=1 (A/B, tests) bring them to the host first, as round 2 did:
+    // 43 s of the 53 s this layout took to load at n = 5e10.
+    const char *e_hb = std::getenv("RBG_RUNS_HOST_BUILD");
+    const bool host_build = rank_rec_target() > 0 || (e_hb && e_hb[0] == '1');
+    if (host_build) {
         const int rcm = materialize_kmer_levels<P>(ix);
         if (rcm) return rcm;
     }
@@ -618,6 +665,62 @@ int upload_tables_runs(rbg_index *ix) {
         // the depth's tables back to back: entries {start, cum} (each table ends with its sentinel {n, total}), samples alongside
         const std::vector<SymTable> &T = *depth[d];
         const uint64_t entries = sizes[d];
+        ComposedLevel *L = (d >= 1 && d - 1 < ix->kmer_levels.size() && ix->kmer_levels[d - 1].ent) ? &ix->kmer_levels[d - 1] : nullptr;
+        if (L) {   // ---- the level is on the device already ----
+            if (L->entries != entries || L->first.size() != T.size()) return RBG_EARG;
+            typedef RunsFmt<P> Fmt;
+            const void *d_ent = L->ent, *d_samp = nullptr;
+            if (h.has_tsa) {
+                if (sizeof(P) == 4) {
+                    d_samp = L->samp;
+                } else {
+                    void *packed = nullptr;
+                    if ((rc = dev_reserve(ix, entries * Fmt::samp_bytes + 8, &packed))) return rc;
+                    HIP_TRY(static_cast<hipError_t>(launch_pack_samp48(static_cast<const uint64_t *>(L->samp), entries, packed, nullptr)));
+                    HIP_TRY(hipDeviceSynchronize());
+                    free_tracked(ix, L->samp);
+                    d_samp = packed;
+                }
+            }
+            L->ent = L->samp = nullptr;   // (adopted: the index's allocation list keeps them)
+            ix->dev.run_samp[d] = d_samp;
+            ix->dev.run_tab_first[d] = static_cast<uint32_t>(tabs.size());
+            ix->dev.run_rec[d] = nullptr;
+            std::vector<uint32_t> dshift(T.size(), 0);
+            std::vector<uint64_t> doff(T.size() + 1, 0), nr(T.size());
+            for (size_t t = 0; t < T.size(); ++t) {
+                uint32_t sh = 0;
+                const double runs = static_cast<double>(std::max<uint64_t>(1, T[t].nruns));
+                while (sh < 40 && runs * static_cast<double>(uint64_t(2) << sh) <= dir_target * static_cast<double>(h.n)) ++sh;
+                dshift[t] = sh;
+                doff[t + 1] = doff[t] + (h.n >> sh) + 2;
+                nr[t] = T[t].nruns;
+            }
+            const bool with_dir = use_dirs && doff[T.size()] < 0xFFFFFFF0ull;
+            ix->dev.run_dir[d] = nullptr;
+            if (with_dir) {
+                void *dp = nullptr, *tmp = nullptr;
+                if ((rc = dev_reserve(ix, doff[T.size()] * 4, &dp))) return rc;
+                const size_t nt = T.size(), bytes = (3 * nt + 1) * 8 + nt * 4;
+                HIP_TRY(hipMalloc(&tmp, bytes));
+                uint64_t *t_first = static_cast<uint64_t *>(tmp), *t_nr = t_first + nt, *t_doff = t_nr + nt;
+                uint32_t *t_sh = reinterpret_cast<uint32_t *>(t_doff + nt + 1);
+                hipError_t e = hipMemcpy(t_first, L->first.data(), nt * 8, hipMemcpyHostToDevice);
+                if (e == hipSuccess) e = hipMemcpy(t_nr, nr.data(), nt * 8, hipMemcpyHostToDevice);
+                if (e == hipSuccess) e = hipMemcpy(t_doff, doff.data(), (nt + 1) * 8, hipMemcpyHostToDevice);
+                if (e == hipSuccess) e = hipMemcpy(t_sh, dshift.data(), nt * 4, hipMemcpyHostToDevice);
+                if (e == hipSuccess) e = static_cast<hipError_t>(launch_run_dirs(sizeof(P), d_ent, t_first, t_nr, t_doff, t_sh, static_cast<uint32_t>(nt), doff[nt], static_cast<uint32_t *>(dp), nullptr));
+                if (e == hipSuccess) e = hipDeviceSynchronize();
+                (void)hipFree(tmp);
+                HIP_TRY(e);
+                ix->dev.run_dir[d] = static_cast<const uint32_t *>(dp);
+            }
+            for (size_t t = 0; t < T.size(); ++t)
+                tabs.push_back(DevRunTab{T[t].F, L->first[t], with_dir ? static_cast<uint32_t>(doff[t]) : 0u, with_dir ? dshift[t] : 0u});
+            tabs.push_back(DevRunTab{0, entries, 0u, 0u});   // closing record: the last table's slice ends here
+            if ((rc = upload_tree_dev<P>(ix, d_ent, entries - 1, nlvl, top_all, trees[d]))) return rc;
+            continue;
+        }
         // (rbg_dev.h RunsFmt: 8-byte pairs + 4-byte samples, or 12-byte entries + 6-byte samples at 8-byte positions; spare
         //  entries after the last sentinel: the kernels' two- and four-entry loads may touch them)
         typedef RunsFmt<P> Fmt;
@@ -778,6 +881,7 @@ int upload_tables_runs(rbg_index *ix) {
                 r.nruns = static_cast<uint32_t>(T[t].nruns);
             }
     }
+    for (uint32_t d = 2; d <= 5; ++d) release_kmer_level(ix, d);   // (levels beyond D, or left over: nothing points at them)
     ix->dev.run_tab_first[D] = static_cast<uint32_t>(tabs.size());
     for (uint32_t d = D + 1; d <= static_cast<uint32_t>(kMaxRunDepth); ++d) ix->dev.run_tab_first[d] = static_cast<uint32_t>(tabs.size());
     if (tabs.size() > static_cast<size_t>(kMaxRunTabs)) return RBG_EARG;

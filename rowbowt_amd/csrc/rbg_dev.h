@@ -430,6 +430,12 @@ int launch_fill_dense(uint32_t pos_bytes, const void *ent, uint64_t n, uint32_t 
 int launch_build_rank_slots64(uint32_t pos_bytes, const void *ent, const void *samp, uint64_t nruns, uint64_t n, uint32_t shift, void *slots,
                               unsigned long long *overflow, unsigned long long *dense_cursor, void *stream);
 int launch_fill_dense64(uint32_t pos_bytes, const void *ent, uint64_t n, uint32_t shift, const void *slots, uint8_t *dense, void *stream);
+// run-indexed layout from run lists already on the device (k_build.hip): the tables' directories, one sampled level of a
+// depth's index, 8-byte samples packed to 6
+int launch_run_dirs(uint32_t pos_bytes, const void *ent, const uint64_t *first, const uint64_t *nruns, const uint64_t *doff, const uint32_t *dshift,
+                    uint32_t T, uint64_t total, uint32_t *dir, void *stream);
+int launch_sample_keys(uint32_t pos_bytes, const void *ent, uint64_t step, uint64_t count, void *out, void *stream);
+int launch_pack_samp48(const uint64_t *in, uint64_t n, void *out, void *stream);
 int launch_build_phi_slots(uint32_t pos_bytes, bool packed, const void *ent, uint64_t r, uint64_t n, uint32_t shift, void *slots, uint32_t *ord,
                            unsigned long long *overflow, void *stream);
 // packed reads (2 bits per symbol): pack the byte batch once, then search the packed form

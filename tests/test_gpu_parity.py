@@ -1864,6 +1864,41 @@ def test_run_indexed_layout_goldens_and_budget_rule(small, simple_reads, error_r
     assert hbm_runs < 3_000_000   # (run lists, samples, sampled levels and directories of five depths, each array rounded to 64 KB)
 
 
+@pytest.mark.parametrize("pos_bytes", [4, 8])
+def test_run_indexed_layout_built_on_the_device_equals_the_host_build(synth, pos_bytes):
+    """The run-indexed layout adopts the k-mer levels where k_compose.hip left them and makes directories, sampled levels
+    and 6-byte samples with kernels (k_build.hip: k_run_dirs, k_sample_keys, k_pack_samp48); RBG_RUNS_HOST_BUILD=1 is the
+    round-2 way (levels copied out, everything built on the host, uploaded).  Same replica size, same answers."""
+    S = synth
+    ra.set_default_option(capi.OPT_POS_BYTES, pos_bytes)
+    built = []
+    try:
+        for host in (False, True):
+            if host:
+                os.environ["RBG_RUNS_HOST_BUILD"] = "1"
+            try:
+                built.append(_with_layout(capi.LAYOUT_RUNS, 48, lambda: ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0)))
+            finally:
+                os.environ.pop("RBG_RUNS_HOST_BUILD", None)
+    finally:
+        ra.set_default_option(capi.OPT_POS_BYTES, 0)
+    dev, host = built
+    assert dev.info().rank_layout == host.info().rank_layout == capi.LAYOUT_RUNS and dev.info().kmer_steps == host.info().kmer_steps == 5
+    assert abs(int(dev.info().hbm_bytes) - int(host.info().hbm_bytes)) <= 64 * 65536   # (the same arrays; allocations are rounded to 64 KB)
+    reads = S.sample_reads(4000, 80, seed=23, sub_rate=0.1, ragged=True) + [b"", b"A", b"N", S.text[:300].tobytes(), S.text[-40:].tobytes()]
+    seqs, off = ra.pack_reads(reads)
+    a, b = dev.find_range_w_toehold(seqs, off), host.find_range_w_toehold(seqs, off)
+    assert all((x == y).all() for x, y in zip(a, b))
+    la, lb = dev.locs_at(*a, 50), host.locs_at(*b, 50)
+    assert (la[0] == lb[0]).all() and (la[1] == lb[1]).all()
+    o = orc.Oracle.from_runs(S.heads, S.lens, S.ssa, S.esa)
+    w = o.find_range_w_toehold_batch(seqs, off)
+    assert all((x == y).all() for x, y in zip(a, w))
+    o.close()
+    dev.close()
+    host.close()
+
+
 @pytest.mark.parametrize("packed", [0, 1, 2])
 def test_host_pointer_pipeline(small, packed, request):
     """the host-pointer calls as rbg_hostpath.hpp runs them: several double-buffered chunks (2.2 M short reads), reads
