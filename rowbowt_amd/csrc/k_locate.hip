@@ -1,4 +1,6 @@
 // k_locate.hip -- K3: phi chains (ToeholdSA::locate_range, toehold_sa.hpp:37-49), their plan (counts + scan) and their order (radix sort of the toeholds)
+#include <cstdlib>
+
 #include "rbg_device.hpp"
 
 namespace rbg {
@@ -253,6 +255,8 @@ int launch_locate_order(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t
     // inside one 64-byte line of phi slots) need no sorting, which saves a radix pass
     int begin_bit = static_cast<int>(ix.phi_shift) + 2;
     if (end_bit - begin_bit < 8) begin_bit = 0;
+    static const int order_bits = [] { const char *e = std::getenv("RBG_LOCATE_ORDER_BITS"); return e ? std::atoi(e) : 0; }();   // (experiments: sort on the top bits only)
+    if (order_bits > 0 && end_bit - order_bits > begin_bit) begin_bit = end_bit - order_bits;
     size_t bytes = w.sort_bytes;
     return static_cast<int>(hipcub::DeviceRadixSort::SortPairs(base + w.sort, bytes, k, keys, iota, perm, static_cast<int64_t>(N),
                                                                begin_bit, end_bit, st));

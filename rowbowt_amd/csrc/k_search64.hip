@@ -37,11 +37,17 @@ __device__ __forceinline__ uint32_t q_word(const uint32_t sub, const uint32_t r0
     const uint32_t a = q_get<S>(r0), b = q_get<S>(r1), c = q_get<S>(r2), d = q_get<S>(r3);
     return sub == 0 ? a : sub == 1 ? b : sub == 2 ? c : d;
 }
-#define RBG_Q_ROW(S, k, field) w[4 * S + k] = q_word<S>(sub, q0.field, q1.field, q2.field, q3.field)
-// every lane of the wave calls; lanes with addr != 0 get the 64 bytes at addr in w[]
-__device__ __forceinline__ void fetch_slot64(const uint64_t addr, uint32_t (&w)[16]) {
+#define RBG_Q_ROW(S, k, field) w[4 * S + k] = q_word<S>(sub, q.q0.field, q.q1.field, q.q2.field, q.q3.field)
+// A fetch in two halves, so that the requests of BOTH slots of a step (lo's bucket and hi + 1's) are in flight before
+// the first wait: issue (every lane of the wave calls; lanes with addr != 0 want the 64 bytes at addr) ...
+struct Quarters { u32x4 q0, q1, q2, q3; };
+__device__ __forceinline__ Quarters issue_slot64(const uint64_t addr) {
     const uint32_t sub = threadIdx.x & 3u;
-    const u32x4 q0 = q_quarter<0>(addr, sub), q1 = q_quarter<1>(addr, sub), q2 = q_quarter<2>(addr, sub), q3 = q_quarter<3>(addr, sub);
+    return Quarters{q_quarter<0>(addr, sub), q_quarter<1>(addr, sub), q_quarter<2>(addr, sub), q_quarter<3>(addr, sub)};
+}
+// ... and hand the sixteen words to their owners
+__device__ __forceinline__ void take_slot64(const Quarters &q, uint32_t (&w)[16]) {
+    const uint32_t sub = threadIdx.x & 3u;
     RBG_Q_ROW(0, 0, x); RBG_Q_ROW(0, 1, y); RBG_Q_ROW(0, 2, z); RBG_Q_ROW(0, 3, w);
     RBG_Q_ROW(1, 0, x); RBG_Q_ROW(1, 1, y); RBG_Q_ROW(1, 2, z); RBG_Q_ROW(1, 3, w);
     RBG_Q_ROW(2, 0, x); RBG_Q_ROW(2, 1, y); RBG_Q_ROW(2, 2, z); RBG_Q_ROW(2, 3, w);
@@ -156,14 +162,12 @@ __global__ __launch_bounds__(512, 4) void k_find_range64(const DevIndex ix, cons
             const uint64_t q0 = lo, q1 = hi + 1;
             const uint64_t bl = q0 >> bs, bh = q1 >> bs;
             uint32_t w[16], wh[16];
-            fetch_slot64(stepping ? slots_at + bl * sizeof(RankSlot64) : 0, w);
             const bool two = stepping && bh != bl;
-            if (__ballot(two)) {   // (nearly every wave has such a lane: the second fetch is the rule)
-                fetch_slot64(two ? slots_at + bh * sizeof(RankSlot64) : 0, wh);
-                pick16<0>(two, wh, w);
-            } else {
-                pick16<0>(false, wh, w);
-            }
+            const Quarters ql = issue_slot64(stepping ? slots_at + bl * sizeof(RankSlot64) : 0);
+            const Quarters qh = issue_slot64(two ? slots_at + bh * sizeof(RankSlot64) : 0);   // (nearly every wave has such a lane)
+            take_slot64(ql, w);
+            take_slot64(qh, wh);
+            pick16<0>(two, wh, w);
             // the inline runs are decoded up to the wave's largest count (dense buckets count as none)
             uint32_t mc = 0;
             if (stepping) {
