@@ -248,6 +248,22 @@ int rbg_resolve_offset(const rbg_index *, uint64_t i, const char **name, uint64_
  * :77-79; k == 0 has no answer: rbg_resolve_offset returns RBG_EARG there).  Pointers stay valid until rbg_free. */
 int rbg_doc_table(rbg_index *, uint64_t *ndocs, const uint64_t **sorted_starts, const char *const **names, uint64_t *size);
 
+/* `rb_align -s` as text, made on the device (rb_report, rb_align.cpp:118-139): for every read
+ *     <name> (<lo>,<hi>), count=<hi - lo + 1>\n\tlocs: <pos>/<doc>:<pos - doc start> ... \n
+ * with locs_at (rowbowt.hpp:613-621, max_hits as in rbg_locs_at) and resolve_offset (:623-625, doclist.hpp:46-79) done
+ * where the ranges are: the locations never cross PCIe, the decimals are written by kernels, the host gets the finished
+ * bytes.  lo / hi / k: host arrays of N (from rbg_find_range_w_toehold / rbg_find_range_spans); the names are N spans of
+ * name_base (name_begin[i], name_len[i]).  *text points into a pinned buffer the handle owns: valid until
+ * rbg_release_text(ix, *text) (several may be out at once: a writer thread can still hold one while the next batch is
+ * made).  The call returns while the text is still being copied out (on the handle's own copy stream, under the caller's
+ * next calls): rbg_wait_text(ix, *text) before the first byte is read.  RBG_ENOTLOADED without the toehold SA or the document list; RBG_EARG when a location lies before every
+ * document (rbg_resolve_offset's error). */
+int rbg_align_text(rbg_index *, const uint64_t *lo, const uint64_t *hi, const uint64_t *k, uint64_t N, uint64_t max_hits, const char *name_base,
+                   const uint64_t *name_begin, const uint32_t *name_len, const char **text, uint64_t *text_len);
+int rbg_wait_text(rbg_index *, const char *text);
+int rbg_release_text(rbg_index *, const char *text);
+/* make `count` pinned text buffers of `bytes` now (pinning a few hundred MB takes tenths of a second: a tool does it before its clock starts) */
+int rbg_reserve_text(rbg_index *, uint64_t bytes, int count);
 /* ---- queries, device-resident buffers (HBM in, HBM out; asynchronous on `stream`) ---------- */
 
 int rbg_find_range_dev(rbg_index *, const uint8_t *d_seqs, const uint64_t *d_off, uint64_t N,

@@ -126,10 +126,15 @@ struct BatchResult {
     uint64_t begin = 0, end = 0;
     std::vector<uint64_t> lo, hi, k, loc_off, mk_off;
     uint64_t *locs = nullptr, *mk = nullptr;
+    // -s without -m: the shard's text as the library made it on the device (rbg_align_text); handed to the writer, which
+    // gives the buffer back (rbg_release_text)
+    const char *text = nullptr;
+    uint64_t text_len = 0;
+    rbg_index *text_owner = nullptr;
     BatchResult() = default;
     BatchResult(const BatchResult &) = delete;
     BatchResult &operator=(const BatchResult &) = delete;
-    ~BatchResult() { rbg_free_buffer(locs); rbg_free_buffer(mk); }
+    ~BatchResult() { rbg_free_buffer(locs); rbg_free_buffer(mk); if (text) (void)rbg_release_text(text_owner, text); }
 };
 
 // rb_get_range + locs_at + markers_at (rb_align.cpp:95-145) for reads [begin, end) of a batch on one replica.
@@ -139,6 +144,13 @@ struct ShardError {
     int rc = RBG_OK;
     const char *what = "";
 };
+// -s (without -m) prints 975 bytes per read on a pangenome index; the library writes that text with kernels unless
+// RB_ALIGN_HOST_TEXT=1 asks for the host formatter below (A/B, tests: the two are byte-identical)
+bool device_text(const RbAlignArgs &args) {
+    static const bool off = [] { const char *e = std::getenv("RB_ALIGN_HOST_TEXT"); return e && e[0] == '1'; }();
+    return args.sam && !args.markers && !off;
+}
+
 ShardError query_shard(rbg_index *ix, const RbAlignArgs &args, const Window &b, uint64_t begin, uint64_t end, BatchResult &r) {
     try {
         r.begin = begin;
@@ -154,6 +166,13 @@ ShardError query_shard(rbg_index *ix, const RbAlignArgs &args, const Window &b, 
         if (args.sam) {  // rb_get_range(sa=true), rb_align.cpp:99-103
             r.k.resize(N);
             if ((rc = rbg_find_range_spans(ix, base, sb, sl, N, r.lo.data(), r.hi.data(), r.k.data()))) return {rc, "rbg_find_range_spans"};
+            if (device_text(args)) {   // locations, documents and decimals on the device: the finished text comes back
+                r.text_owner = ix;
+                if ((rc = rbg_align_text(ix, r.lo.data(), r.hi.data(), r.k.data(), N, static_cast<uint64_t>(-1), b.base, b.recs.name_begin.data() + begin,
+                                         b.recs.name_len.data() + begin, &r.text, &r.text_len)))
+                    return {rc, "rbg_align_text"};
+                return {};
+            }
             r.loc_off.resize(N + 1);
             if ((rc = rbg_locs_at(ix, r.lo.data(), r.hi.data(), r.k.data(), N, static_cast<uint64_t>(-1), r.loc_off.data(), &r.locs)))
                 return {rc, "rbg_locs_at"};  // rb_align.cpp:125
@@ -246,6 +265,7 @@ void format_range(const rbwt::RowBowt<> &rb, const RbAlignArgs &args, const Wind
 
 // RB_ALIGN_TRACE=1: seconds the main loop spent in the library calls, in formatting, waiting for the scanner and for the writer
 double g_trace_query = 0, g_trace_format = 0, g_trace_scan_wait = 0, g_trace_write_wait = 0;
+std::shared_future<void> g_text_writer[2];   // device_text(): the last two of the chain of per-batch writes (each waits for the one before it)
 
 // query + format one batch: the batch is sharded over the replicas (contiguous blocks), the shards are
 // queried concurrently, formatting is split over worker threads, pieces concatenated in read order
@@ -293,6 +313,31 @@ void format_batch(const rbwt::RowBowt<> &rb, const RbAlignArgs &args, const Wind
 #define res(g) (*slot.res[(g)])
     const auto t_q1 = std::chrono::steady_clock::now();
     g_trace_query += slot.query_s;
+    if (device_text(args)) {
+        // nothing to format: the shards' texts go to the writer in shard order, behind the previous batch's
+        struct Out { rbg_index *ix; const char *p; uint64_t n; };
+        std::vector<Out> outs;
+        for (int g = 0; g < G; ++g) {
+            outs.push_back({res(g).text_owner, res(g).text, res(g).text_len});
+            res(g).text = nullptr;
+            res(g).text_len = 0;
+        }
+        if (g_text_writer[0].valid()) {   // at most two batches of text wait for stdout: the pinned buffers are a few hundred MB each
+            g_text_writer[0].wait();
+            g_trace_write_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_q1).count();
+        }
+        const std::shared_future<void> prev = g_text_writer[1];
+        g_text_writer[0] = prev;
+        g_text_writer[1] = std::async(std::launch::async, [outs, prev] {
+            if (prev.valid()) prev.wait();
+            for (const Out &o : outs) {
+                (void)rbg_wait_text(o.ix, o.p);   // (its copy-out ran under the next batch's search)
+                if (o.n) fwrite(o.p, 1, o.n, stdout);
+                (void)rbg_release_text(o.ix, o.p);
+            }
+        }).share();
+        return;
+    }
     const size_t T = std::max<size_t>(1, std::min<size_t>({static_cast<size_t>(args.threads), (N + 4095) / 4096, size_t(64)}));
     // piece (g, t): reads of shard g, t-th slice
     const size_t first_piece = used;
@@ -375,6 +420,19 @@ int main(int argc, char **argv) {
         fprintf(stderr, "invalid file\n");
         exit(1);
     }
+    if (device_text(args)) {
+        // RB_ALIGN_TEXT_STREAMS=<n>: every replica answers its shard as n sub-shards on n threads.  One is the default: the
+        // library copies a text out on its own stream under the caller's next calls, and more callers only compete for the
+        // CPUs that pack the reads (0.54 s per 10 M reads with one, 0.66 with two, 0.99 with four on a 16-CPU quota).
+        const char *e = std::getenv("RB_ALIGN_TEXT_STREAMS");
+        const int S = e && std::atoi(e) >= 1 ? std::min(8, std::atoi(e)) : 1;
+        const std::vector<rbg_index *> once = reps;
+        reps.clear();
+        for (rbg_index *r : once)
+            for (int t = 0; t < S; ++t) reps.push_back(r);
+        // the texts are copied out into pinned buffers: three per half-shard, made before the clock starts
+        for (rbg_index *r : once) (void)rbg_reserve_text(r, (args.batch / reps.size() + 1) * 1100 + (size_t(1) << 20), 3 * S);
+    }
     start = std::chrono::high_resolution_clock::now();
     // three overlapped stages: scan window i+1 | query + format window i (in GPU batches of --batch reads) | write window i-1
     int err = 0;
@@ -428,6 +486,11 @@ int main(int argc, char **argv) {
         std::swap(cur, nxt);
     }
     if (writer.valid()) writer.get();
+    {
+        const auto tw0 = std::chrono::steady_clock::now();
+        if (g_text_writer[1].valid()) g_text_writer[1].wait();
+        g_trace_write_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw0).count();
+    }
     fflush(stdout);
     stop = std::chrono::high_resolution_clock::now();
     const std::chrono::duration<double> total_query_time = stop - start;

@@ -893,10 +893,10 @@ def test_size_independent_properties(synth):
 
 
 # ---- the rb_align-compatible CLI: byte-exact stdout (reference src/rb_align.cpp:118-145) ---------
-def _run_cli(args):
+def _run_cli(args, env=None):
     import subprocess
     exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rowbowt_amd", "rb_align")
-    p = subprocess.run([exe] + args, capture_output=True, timeout=120)
+    p = subprocess.run([exe] + args, capture_output=True, timeout=120, env=dict(os.environ, **env) if env else None)
     return p.returncode, p.stdout.decode(), p.stderr.decode()
 
 
@@ -966,6 +966,57 @@ def test_cli_locs_and_markers_stdout(data_dir, tmp_path, small, simple_reads):
     bad.write_text("@r\nACGT\n+\n~~\n")
     rc, _, err = _run_cli([str(tmp_path / "idx"), str(bad)])
     assert rc == 1 and "truncated quality string" in err
+
+
+def test_cli_locs_text_made_on_the_device(data_dir, tmp_path, small, simple_reads, error_reads, synth):
+    """`rb_align -s` (no -m): the text comes from rbg_align_text -- locs_at, resolve_offset and the decimals on the device
+    (k_text.hip) -- and is byte-identical to the oracle's rendering of rb_report (rb_align.cpp:118-139) and to the host
+    formatter (RB_ALIGN_HOST_TEXT=1): reads without a match, names of 1 and of 700 characters (beyond what a workgroup
+    stages in LDS), descriptions, one read per batch, three replicas, and a synthetic pangenome whose reads have tens of
+    locations in 50 documents, in batches that do not divide the input."""
+    import shutil
+    rb, o = small
+    for suf in (".rbwt", ".tsa"):
+        shutil.copy(os.path.join(data_dir, "small.fa" + suf), tmp_path / ("idx" + suf))
+    long_doc = "hap2_" + "x" * 90
+    (tmp_path / "idx.docs").write_text(f"ref 0\nhap1 10010\n{long_doc} 20020\n")
+    o.set_docs(["ref", "hap1", long_doc], [0, 10010, 20020])
+    reads = list(simple_reads) + list(error_reads) + [b"ACGT", b"A", simple_reads[0][:30]]
+    names = [f"read{i}" for i in range(len(reads))]
+    names[1] = "r"
+    names[2] = "n" * 700
+    names[4] = "q" * 300
+    fq = tmp_path / "q.fq"
+    fq.write_text("".join(f"@{n} desc {i}\n{q.decode()}\n+\n{'~' * len(q)}\n" for i, (n, q) in enumerate(zip(names, reads))))
+    want = ""
+    for n, q in zip(names, reads):
+        lo, hi, k = o.find_range_w_toehold(q)
+        want += f"{n} ({lo},{hi}), count={(hi - lo + 1) % 2**64}\n\tlocs: "
+        if lo <= hi:
+            for l in o.locs_at(lo, hi, k):
+                dn, off = o.resolve_offset(l)
+                want += f"{l}/{dn}:{off} "
+        want += "\n"
+    for extra in ([], ["--batch", "1"], ["--devices", "0,0,0"], ["--devices", "0,0", "--batch", "3"]):
+        rc, out, err = _run_cli(["-s"] + extra + [str(tmp_path / "idx"), str(fq)])
+        assert rc == 0 and out == want, err
+    rc, out_h, err = _run_cli(["-s", str(tmp_path / "idx"), str(fq)], env={"RB_ALIGN_HOST_TEXT": "1"})
+    assert rc == 0 and out_h == want, err
+    # a pangenome: many locations per read, 50 documents
+    S = synth
+    unit = len(S.text) // 50
+    docs = "".join(f"hap{h} {h * unit}\n" for h in range(50))
+    capi.convert_runs(S.heads, S.lens, S.ssa, S.esa, out_path=str(tmp_path / "pg.rbgpu"), docs_text=docs)
+    rs = S.sample_reads(5000, 70, seed=31, sub_rate=0.1, ragged=True)
+    fq2 = tmp_path / "pg.fq"
+    fq2.write_text("".join(f"@pg.{i}/{i % 7}\n{q.decode()}\n+\n{'I' * len(q)}\n" for i, q in enumerate(rs) if len(q)))
+    outs = []
+    for extra, env in (([], None), (["--batch", "700", "--devices", "0,0"], None), ([], {"RB_ALIGN_HOST_TEXT": "1"})):
+        rc, out, err = _run_cli(["-s"] + extra + [str(tmp_path / "pg"), str(fq2)], env=env)
+        assert rc == 0, err
+        outs.append(out)
+    assert outs[0] == outs[2] and outs[1] == outs[2] and outs[0].count("\n") == 2 * sum(1 for q in rs if len(q))
+    assert len(outs[0]) > 200 * len(rs)
 
 
 # ---- the rb_markers-compatible CLI (reference src/rb_markers.cpp, default seeding mode) ----------

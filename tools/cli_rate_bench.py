@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--H", type=int, default=50)
     ap.add_argument("--threads", type=int, default=16)
     ap.add_argument("--dir", default="/tmp/cli_big")
+    ap.add_argument("--only-s", action="store_true", help="only the rb_align -s rows on plain FASTQ (tuning runs)")
     args = ap.parse_args()
     import torch
     from rowbowt_amd import capi
@@ -115,9 +116,12 @@ def main():
     exe = os.path.join(ROOT, "rowbowt_amd", "rb_align")
     th = ["--threads", str(args.threads)]
     out_txt = os.path.join(args.dir, "out.txt")
-    for flags, path, n, out in ((th, fq, args.reads, "/dev/null"), (["-s"] + th, fq, args.reads, "/dev/null"), (["-s"] + th, fq, args.reads, out_txt),
-                                (["-s", "-m"] + th, fq, args.reads, "/dev/null"), (th, gz, args.gz_reads, "/dev/null"), (["-s"] + th, gz, args.gz_reads, "/dev/null"),
-                                (th, gz1, n1, "/dev/null"), (["-s"] + th, gz1, n1, "/dev/null")):
+    rows = ((th, fq, args.reads, "/dev/null"), (["-s"] + th, fq, args.reads, "/dev/null"), (["-s"] + th, fq, args.reads, out_txt),
+            (["-s", "-m"] + th, fq, args.reads, "/dev/null"), (th, gz, args.gz_reads, "/dev/null"), (["-s"] + th, gz, args.gz_reads, "/dev/null"),
+            (th, gz1, n1, "/dev/null"), (["-s"] + th, gz1, n1, "/dev/null"))
+    if args.only_s:
+        rows = tuple(r for r in rows if r[0][:1] == ["-s"] and "-m" not in r[0] and r[1] == fq)
+    for flags, path, n, out in rows:
         t0 = time.perf_counter()
         env = dict(os.environ, RB_ALIGN_TRACE="1")
         try:
@@ -135,6 +139,8 @@ def main():
         sz = os.path.getsize(out) if out != "/dev/null" else 0
         print(f"rb_align {' '.join(flags):22s} {os.path.basename(path):14s} -> {os.path.basename(out):8s}: process {dt:6.2f} s (index load {load_s:5.2f} s); query loop "
               f"{query_s:6.3f} s = {n / query_s:.3e} reads/s" + (f"; {sz / 1e6:.0f} MB of text" if sz else "") + (f"   [{trace[-1][15:]}]" if trace else ""), flush=True)
+    if args.only_s:
+        return
     exe2 = os.path.join(ROOT, "rowbowt_amd", "rb_markers")
     for flags in (th, ["--heuristic", "--best-strand-only", "--min-seed-length", "30"] + th):
         t0 = time.perf_counter()
