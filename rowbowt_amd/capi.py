@@ -62,6 +62,10 @@ _PROTOS = [
     ("rbg_convert_raw", C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p]),
     ("rbg_load_cache", C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(VP)]),
     ("rbg_doc_table", C.c_int, [VP, C.POINTER(U64), C.POINTER(VP), C.POINTER(VP), C.POINTER(U64)]),
+    ("rbg_align_text", C.c_int, [VP, VP, VP, VP, U64, U64, VP, VP, VP, C.POINTER(VP), C.POINTER(U64)]),
+    ("rbg_wait_text", C.c_int, [VP, VP]),
+    ("rbg_release_text", C.c_int, [VP, VP]),
+    ("rbg_reserve_text", C.c_int, [VP, U64, C.c_int]),
     ("rbg_convert_runs", C.c_int, [VP, VP, U64, VP, VP, C.c_char_p]),
     ("rbg_convert_runs_markers", C.c_int, [VP, VP, U64, VP, VP, VP, VP, U64, VP, VP, C.c_char_p, C.c_char_p]),
     ("rbg_write_ftab", C.c_int, [VP, U64, C.c_char_p]),
@@ -428,6 +432,23 @@ class RowBowt:
         name, off = C.c_char_p(), U64()
         _check(self.L.rbg_resolve_offset(self.h, i, C.byref(name), C.byref(off)), "rbg_resolve_offset")
         return name.value.decode(), off.value
+
+    def align_text(self, lo, hi, k, names, max_hits=MAXU):
+        """rbg_align_text: the `rb_align -s` text of a batch (bytes), made on the device; names = list of bytes"""
+        lo, hi, k = (np.ascontiguousarray(a, dtype=np.uint64) for a in (lo, hi, k))
+        blob = b"".join(names)
+        nlen = np.array([len(x) for x in names], dtype=np.uint32)
+        nbeg = np.zeros(len(names), dtype=np.uint64)
+        if len(names) > 1:
+            nbeg[1:] = np.cumsum(nlen[:-1], dtype=np.uint64)
+        buf = C.create_string_buffer(blob, len(blob) + 1)
+        text, n = VP(), U64()
+        _check(self.L.rbg_align_text(self.h, _p(lo), _p(hi), _p(k), len(names), max_hits, buf, _p(nbeg), _p(nlen), C.byref(text), C.byref(n)), "rbg_align_text")
+        try:
+            _check(self.L.rbg_wait_text(self.h, text), "rbg_wait_text")
+            return C.string_at(text, n.value)
+        finally:
+            self.L.rbg_release_text(self.h, text)
 
     def counters(self):
         out = np.zeros(4, np.uint64)

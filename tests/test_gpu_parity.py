@@ -1019,6 +1019,38 @@ def test_cli_locs_text_made_on_the_device(data_dir, tmp_path, small, simple_read
     assert len(outs[0]) > 200 * len(rs)
 
 
+def test_align_text_through_the_abi(synth):
+    """rbg_align_text called directly: max_hits caps the locations per read like locs_at's (rowbowt.hpp:613-621); without the
+    document list the call says RBG_ENOTLOADED; texts of several calls may be out at once"""
+    S = synth
+    rb = ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0)
+    o = orc.Oracle.from_runs(S.heads, S.lens, S.ssa, S.esa)
+    reads = S.sample_reads(300, 50, seed=3, sub_rate=0.1)
+    seqs, off = ra.pack_reads(reads)
+    lo, hi, k = rb.find_range_w_toehold(seqs, off)
+    names = [f"r{i}".encode() for i in range(len(reads))]
+    with pytest.raises(ra.RbgError):
+        rb.align_text(lo, hi, k, names)
+    unit = len(S.text) // 4
+    starts = [0, unit, 2 * unit, 3 * unit]
+    rb.set_docs([f"d{j}" for j in range(4)], starts)
+    o.set_docs([f"d{j}" for j in range(4)], starts)
+    for max_hits in (MAXU, 3, 1, 0):
+        got = rb.align_text(lo, hi, k, names, max_hits)
+        want = ""
+        for n, a, b, kk in zip(names, lo, hi, k):
+            a, b, kk = int(a), int(b), int(kk)
+            want += f"{n.decode()} ({a},{b}), count={(b - a + 1) % 2**64}\n\tlocs: "
+            if a <= b:
+                for l in o.locs_at(a, b, kk, max_hits):
+                    dn, offs = o.resolve_offset(l)
+                    want += f"{l}/{dn}:{offs} "
+            want += "\n"
+        assert got.decode() == want
+    rb.close()
+    o.close()
+
+
 # ---- the rb_markers-compatible CLI (reference src/rb_markers.cpp, default seeding mode) ----------
 def _run_rb_markers(args):
     import subprocess
