@@ -3029,7 +3029,7 @@ int rbg_align_text(rbg_index *ix, const uint64_t *lo, const uint64_t *hi, const 
     return guarded([&]() -> int {
     if (!queryable(ix)) return RBG_ENODEV;
     if (!ix->H().has_tsa || !ix->H().has_dl) return RBG_ENOTLOADED;
-    if (!text || !text_len || (N && (!lo || !hi || !k || !name_base || !name_begin || !name_len))) return RBG_EARG;
+    if (!text || !text_len || (N >> 32) || (N && (!lo || !hi || !k || !name_base || !name_begin || !name_len))) return RBG_EARG;
     *text = nullptr;
     *text_len = 0;
     if (N == 0) return RBG_OK;
