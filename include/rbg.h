@@ -257,7 +257,8 @@ int rbg_doc_table(rbg_index *, uint64_t *ndocs, const uint64_t **sorted_starts, 
  * rbg_release_text(ix, *text) (several may be out at once: a writer thread can still hold one while the next batch is
  * made).  The call returns while the text is still being copied out (on the handle's own copy stream, under the caller's
  * next calls): rbg_wait_text(ix, *text) before the first byte is read.  RBG_ENOTLOADED without the toehold SA or the document list; RBG_EARG when a location lies before every
- * document (rbg_resolve_offset's error). */
+ * document (rbg_resolve_offset's error).  k == NULL: the report without -s, one line per read (no toehold SA or
+ * document list needed). */
 int rbg_align_text(rbg_index *, const uint64_t *lo, const uint64_t *hi, const uint64_t *k, uint64_t N, uint64_t max_hits, const char *name_base,
                    const uint64_t *name_begin, const uint32_t *name_len, const char **text, uint64_t *text_len);
 int rbg_wait_text(rbg_index *, const char *text);

@@ -435,7 +435,8 @@ class RowBowt:
 
     def align_text(self, lo, hi, k, names, max_hits=MAXU):
         """rbg_align_text: the `rb_align -s` text of a batch (bytes), made on the device; names = list of bytes"""
-        lo, hi, k = (np.ascontiguousarray(a, dtype=np.uint64) for a in (lo, hi, k))
+        lo, hi = (np.ascontiguousarray(a, dtype=np.uint64) for a in (lo, hi))
+        k = None if k is None else np.ascontiguousarray(k, dtype=np.uint64)   # None: the count-only report
         blob = b"".join(names)
         nlen = np.array([len(x) for x in names], dtype=np.uint32)
         nbeg = np.zeros(len(names), dtype=np.uint64)
@@ -443,7 +444,7 @@ class RowBowt:
             nbeg[1:] = np.cumsum(nlen[:-1], dtype=np.uint64)
         buf = C.create_string_buffer(blob, len(blob) + 1)
         text, n = VP(), U64()
-        _check(self.L.rbg_align_text(self.h, _p(lo), _p(hi), _p(k), len(names), max_hits, buf, _p(nbeg), _p(nlen), C.byref(text), C.byref(n)), "rbg_align_text")
+        _check(self.L.rbg_align_text(self.h, _p(lo), _p(hi), _p(k) if k is not None else None, len(names), max_hits, buf, _p(nbeg), _p(nlen), C.byref(text), C.byref(n)), "rbg_align_text")
         try:
             _check(self.L.rbg_wait_text(self.h, text), "rbg_wait_text")
             return C.string_at(text, n.value)

@@ -49,6 +49,7 @@ struct TextArgs {
     const char *doc_names;                         // back to back
     const uint32_t *doc_name_off;                  // [ndocs + 1]
     uint64_t ndocs, text_size;                     // text_size: DocList::size (the n of the index)
+    bool with_locs;                                // false: the count-only report (no "\tlocs:" line; loc_off is all zero)
 };
 
 __global__ __launch_bounds__(256) void k_text_mark(const uint64_t *__restrict__ loc_off, const uint64_t N, uint32_t *__restrict__ mark) {
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(256) void k_text_len(const TextArgs a, const uint32
         const uint64_t l0 = a.loc_off[i], l1 = a.loc_off[i + 1];
         if (e == i + l0) {   // head
             const uint64_t lo = a.lo[i], hi = a.hi[i];
-            len[e] = (a.name_off[i + 1] - a.name_off[i]) + 2 + dec_len(lo) + 1 + dec_len(hi) + 9 + dec_len(hi - lo + 1) + 1 + 7 + (l1 == l0 ? 1u : 0u);
+            len[e] = (a.name_off[i + 1] - a.name_off[i]) + 2 + dec_len(lo) + 1 + dec_len(hi) + 9 + dec_len(hi - lo + 1) + 1 + (a.with_locs ? 7 + (l1 == l0 ? 1u : 0u) : 0u);
         } else {
             const uint64_t t = e - i - 1, pos = a.locs[t];
             const uint64_t k = doc_of(a, pos);
@@ -108,10 +109,13 @@ __device__ __forceinline__ void put_element(const TextArgs &a, const uint64_t e,
         p += 9;
         n = dec_len(c);
         put_dec(p, c, n); p += n;
-        const char lit2[] = "\n\tlocs: ";
-        for (int j = 0; j < 8; ++j) p[j] = lit2[j];
-        p += 8;
-        if (l1 == l0) *p = '\n';
+        *p = '\n'; p += 1;
+        if (a.with_locs) {
+            const char lit2[] = "\tlocs: ";
+            for (int j = 0; j < 7; ++j) p[j] = lit2[j];
+            p += 7;
+            if (l1 == l0) *p = '\n';
+        }
     } else {
         const uint64_t t = e - i - 1, pos = a.locs[t];
         uint32_t n = dec_len(pos);
@@ -194,7 +198,7 @@ int launch_copy16(const void *pinned_src, void *dst, uint64_t bytes, void *strea
 // phase 1: element lengths and offsets.  *d_total (device, 8 bytes) = bytes of text; *d_bad != 0: a location outside every document
 int launch_text_plan(const uint64_t *lo, const uint64_t *hi, const uint64_t *loc_off, const uint64_t *locs, uint64_t N, uint64_t E, const char *names,
                      const uint32_t *name_off, const uint64_t *doc_start, const char *doc_names, const uint32_t *doc_name_off, uint64_t ndocs,
-                     uint64_t text_size, void *ws, size_t ws_bytes, unsigned int *d_bad, void *stream) {
+                     uint64_t text_size, bool with_locs, void *ws, size_t ws_bytes, unsigned int *d_bad, void *stream) {
     if (ws_bytes < text_ws_bytes(E) || (reinterpret_cast<uintptr_t>(ws) & 255)) return static_cast<int>(hipErrorInvalidValue);
     hipStream_t st = static_cast<hipStream_t>(stream);
     auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
@@ -203,7 +207,7 @@ int launch_text_plan(const uint64_t *lo, const uint64_t *hi, const uint64_t *loc
     uint64_t *at = reinterpret_cast<uint64_t *>(b + 3 * up(E * 4));
     void *tmp = b + 3 * up(E * 4) + up(E * 8 + 8);
     size_t tmp_bytes = ws_bytes - (3 * up(E * 4) + up(E * 8 + 8));
-    const TextArgs a{lo, hi, loc_off, locs, N, E, names, name_off, doc_start, doc_names, doc_name_off, ndocs, text_size};
+    const TextArgs a{lo, hi, loc_off, locs, N, E, names, name_off, doc_start, doc_names, doc_name_off, ndocs, text_size, with_locs};
     hipError_t e = hipMemsetAsync(eread, 0, E * 4, st);
     if (e != hipSuccess) return static_cast<int>(e);
     const int gN = static_cast<int>(std::min<uint64_t>((N + 255) / 256, 256ull * 32)), gE = static_cast<int>(std::min<uint64_t>((E + 255) / 256, 256ull * 32));
@@ -227,13 +231,13 @@ void text_total_ptrs(void *ws, uint64_t E, const uint64_t **last_at, const uint3
 // phase 2: the text itself (total bytes at `text`)
 int launch_text_fill(const uint64_t *lo, const uint64_t *hi, const uint64_t *loc_off, const uint64_t *locs, uint64_t N, uint64_t E, const char *names,
                      const uint32_t *name_off, const uint64_t *doc_start, const char *doc_names, const uint32_t *doc_name_off, uint64_t ndocs,
-                     uint64_t text_size, void *ws, uint64_t total, char *text, void *stream) {
+                     uint64_t text_size, bool with_locs, void *ws, uint64_t total, char *text, void *stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
     char *b = static_cast<char *>(ws);
     const uint32_t *eread = reinterpret_cast<const uint32_t *>(b), *doc = reinterpret_cast<const uint32_t *>(b + 2 * up(E * 4));
     const uint64_t *at = reinterpret_cast<const uint64_t *>(b + 3 * up(E * 4));
-    const TextArgs a{lo, hi, loc_off, locs, N, E, names, name_off, doc_start, doc_names, doc_name_off, ndocs, text_size};
+    const TextArgs a{lo, hi, loc_off, locs, N, E, names, name_off, doc_start, doc_names, doc_name_off, ndocs, text_size, with_locs};
     const int g = static_cast<int>(std::min<uint64_t>((E + 255) / 256, 256ull * 16));
     hipLaunchKernelGGL(k_text_write, dim3(g), dim3(256), 0, st, a, eread, doc, at, total, text);
     return static_cast<int>(hipGetLastError());

@@ -145,7 +145,9 @@ struct ShardError {
     const char *what = "";
 };
 // -s (without -m) prints 975 bytes per read on a pangenome index; the library writes that text with kernels unless
-// RB_ALIGN_HOST_TEXT=1 asks for the host formatter below (A/B, tests: the two are byte-identical)
+// RB_ALIGN_HOST_TEXT=1 asks for the host formatter below (A/B, tests: the two are byte-identical).  The one line per read
+// of the count-only report stays with the host formatter: its 30 bytes per read cost less there (0.05 s per 10 M reads)
+// than a library call per batch does (measured: 7.4e7 reads/s against 2.8e7 through rbg_align_text with k = NULL).
 bool device_text(const RbAlignArgs &args) {
     static const bool off = [] { const char *e = std::getenv("RB_ALIGN_HOST_TEXT"); return e && e[0] == '1'; }();
     return args.sam && !args.markers && !off;

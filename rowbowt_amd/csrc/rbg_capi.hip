@@ -3028,14 +3028,15 @@ int rbg_align_text(rbg_index *ix, const uint64_t *lo, const uint64_t *hi, const 
                    const uint64_t *name_begin, const uint32_t *name_len, const char **text, uint64_t *text_len) {
     return guarded([&]() -> int {
     if (!queryable(ix)) return RBG_ENODEV;
-    if (!ix->H().has_tsa || !ix->H().has_dl) return RBG_ENOTLOADED;
-    if (!text || !text_len || (N >> 32) || (N && (!lo || !hi || !k || !name_base || !name_begin || !name_len))) return RBG_EARG;
+    const bool with_locs = k != nullptr;   // k == NULL: the count-only report (rb_align without -s): one line per read
+    if (with_locs && (!ix->H().has_tsa || !ix->H().has_dl)) return RBG_ENOTLOADED;
+    if (!text || !text_len || (N >> 32) || (N && (!lo || !hi || !name_base || !name_begin || !name_len))) return RBG_EARG;
     *text = nullptr;
     *text_len = 0;
     if (N == 0) return RBG_OK;
     DeviceScope scope(ix->device);
     if (scope.rc) return scope.rc;
-    int rc = ensure_text_docs(ix);
+    int rc = with_locs ? ensure_text_docs(ix) : RBG_OK;
     if (rc) return rc;
     hipStream_t st = hipStreamPerThread;
     double lap_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -3064,7 +3065,7 @@ int rbg_align_text(rbg_index *ix, const uint64_t *lo, const uint64_t *hi, const 
     parallel_for(N, [&](uint64_t a, uint64_t b, unsigned) {
         std::memcpy(in.p + o_lo + a * 8, lo + a, (b - a) * 8);
         std::memcpy(in.p + o_hi + a * 8, hi + a, (b - a) * 8);
-        std::memcpy(in.p + o_k + a * 8, k + a, (b - a) * 8);
+        if (with_locs) std::memcpy(in.p + o_k + a * 8, k + a, (b - a) * 8);
         for (uint64_t i = a; i < b; ++i) std::memcpy(in.p + o_names + noff[i], name_base + name_begin[i], name_len[i]);
     });
     lap(0, false);
@@ -3076,15 +3077,19 @@ int rbg_align_text(rbg_index *ix, const uint64_t *lo, const uint64_t *hi, const 
     DevView dlo{din.as<char>() + o_lo}, dhi{din.as<char>() + o_hi}, dk{din.as<char>() + o_k}, dnoff{din.as<char>() + o_noff}, dnames{din.as<char>() + o_names};
     lap(1, true);
     // locs_at (rowbowt.hpp:613-621) on the device, as rbg_locs_at does it -- the locations never leave it
-    if (launch_locate_plan(ix->dev, ix->cfg, dlo.as<uint64_t>(), dhi.as<uint64_t>(), N, max_hits, doff.as<uint64_t>(), dtmp.p, tmp_bytes, st)) return RBG_ENODEV;
     uint64_t nlocs = 0;
-    HIP_TRY(hipMemcpyAsync(&nlocs, doff.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    if (with_locs) {
+        if (launch_locate_plan(ix->dev, ix->cfg, dlo.as<uint64_t>(), dhi.as<uint64_t>(), N, max_hits, doff.as<uint64_t>(), dtmp.p, tmp_bytes, st)) return RBG_ENODEV;
+        HIP_TRY(hipMemcpyAsync(&nlocs, doff.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    } else {
+        HIP_TRY(hipMemsetAsync(doff.p, 0, (N + 1) * 8, st));   // no locations: every read is one element
+    }
     lap(2, false);
     DevBuf dlocs, dord, dws, dtext;
     if ((rc = dlocs.alloc(nlocs * 8))) return rc;
     const void *order = nullptr;
-    if ((rc = make_order(ix, dk.as<uint64_t>(), N, dord, st, &order))) return rc;
+    if (with_locs && (rc = make_order(ix, dk.as<uint64_t>(), N, dord, st, &order))) return rc;
     if (nlocs && launch_locate_fill(ix->dev, ix->cfg, dlo.as<uint64_t>(), dhi.as<uint64_t>(), dk.as<uint64_t>(), N, max_hits, doff.as<uint64_t>(),
                                     dlocs.as<uint64_t>(), nullptr, order, st))
         return RBG_ENODEV;
@@ -3095,7 +3100,7 @@ int rbg_align_text(rbg_index *ix, const uint64_t *lo, const uint64_t *hi, const 
     if ((rc = dws.alloc(ws_bytes))) return rc;
     const auto &D = ix->text_docs;
     if (launch_text_plan(dlo.as<uint64_t>(), dhi.as<uint64_t>(), doff.as<uint64_t>(), dlocs.as<uint64_t>(), N, E, dnames.as<char>(), dnoff.as<uint32_t>(),
-                              D.start, D.names, D.name_off, D.n, D.size, dws.p, ws_bytes, dbad.as<unsigned int>(), st))
+                              D.start, D.names, D.name_off, D.n, D.size, with_locs, dws.p, ws_bytes, dbad.as<unsigned int>(), st))
         return RBG_ENODEV;
     const uint64_t *p_at = nullptr;
     const uint32_t *p_len = nullptr;
@@ -3111,7 +3116,7 @@ int rbg_align_text(rbg_index *ix, const uint64_t *lo, const uint64_t *hi, const 
     const uint64_t total = last_at + last_len;
     if ((rc = dtext.alloc(total))) return rc;
     if (launch_text_fill(dlo.as<uint64_t>(), dhi.as<uint64_t>(), doff.as<uint64_t>(), dlocs.as<uint64_t>(), N, E, dnames.as<char>(), dnoff.as<uint32_t>(),
-                              D.start, D.names, D.name_off, D.n, D.size, dws.p, total, dtext.as<char>(), st))
+                              D.start, D.names, D.name_off, D.n, D.size, with_locs, dws.p, total, dtext.as<char>(), st))
         return RBG_ENODEV;
     lap(5, true);
     char *out = nullptr;

@@ -1031,6 +1031,9 @@ def test_align_text_through_the_abi(synth):
     names = [f"r{i}".encode() for i in range(len(reads))]
     with pytest.raises(ra.RbgError):
         rb.align_text(lo, hi, k, names)
+    # k = NULL: the report without -s (rb_align.cpp:120-122), no document list needed; empty ranges print count=0
+    got = rb.align_text(lo, hi, None, names)
+    assert got.decode() == "".join(f"{n.decode()} ({int(a)},{int(b)}), count={(int(b) - int(a) + 1) % 2**64}\n" for n, a, b in zip(names, lo, hi))
     unit = len(S.text) // 4
     starts = [0, unit, 2 * unit, 3 * unit]
     rb.set_docs([f"d{j}" for j in range(4)], starts)
