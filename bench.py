@@ -82,6 +82,10 @@ def parse():
                     help="bytes per rank slot (RBG_OPT_SLOT_BYTES): 16, or 64 = the 64-byte slots of DESIGN.md 4 r03; 0 = the library's default")
     ap.add_argument("--pos-bytes", type=int, default=0, choices=(0, 4, 8), help="force the position width of the HBM layout (RBG_OPT_POS_BYTES); 0 = by n")
     ap.add_argument("--layout", default="auto", choices=("auto", "slots", "runs"), help="RBG_OPT_RANK_LAYOUT of the headline replica")
+    ap.add_argument("--rehearse-ranks", action="store_true",
+                    help="test mode, never a measurement: the N ranks of --gpus share the GPUs that exist (rank % devices) and meet over gloo, so that "
+                         "the multi-rank path -- launcher, index built once and read from the cache file by every rank, barriers, max-over-ranks "
+                         "timing, counters reduced -- runs on a one-GPU box; the line says so and carries no vs_baseline")
     ap.add_argument("--via-cache", action="store_true",
                     help="build the replica through the native cache file even on one GPU (with --gpus N > 1 every rank does: rank 0 "
                          "writes it to node-local shared memory once, all ranks load it)")
@@ -113,7 +117,7 @@ def main():
     if not launch.under_launcher():
         if args.gpus > 1:
             # the parent: no torch, no HIP -- N fresh children, one rank each (never re-exec a process that holds a GPU)
-            raise SystemExit(launch.run_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus, check_devices=not args.launch_check))
+            raise SystemExit(launch.run_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus, check_devices=not (args.launch_check or args.rehearse_ranks)))
         if args.gpus < 1:
             raise SystemExit("--gpus must be at least 1")
         rank, local_rank, world = 0, 0, 1
@@ -129,16 +133,22 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    if args.rehearse_ranks:
+        local_rank = local_rank % torch.cuda.device_count()
     if local_rank >= torch.cuda.device_count():
         raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible -- "
                          f"--gpus {args.gpus} exceeds this node")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = torch.device("cpu") if args.rehearse_ranks else dev   # where the tensors of the collectives live (gloo: host)
     use_dist = world > 1 or "RANK" in os.environ  # under torch.distributed.run: always go through RCCL
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
+        if args.rehearse_ranks:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
         if dist.get_world_size() != args.gpus:
             raise SystemExit(f"RCCL group has {dist.get_world_size()} ranks, --gpus asked for {args.gpus}")
         world = dist.get_world_size()   # n_gpus of the line = the group that was actually formed
@@ -507,11 +517,11 @@ def main():
     rb.counters_reset()
 
     # max over ranks, counters over RCCL
-    t_el = torch.tensor([el, el_count, el_pipe], dtype=torch.float64, device=dev)
+    t_el = torch.tensor([el, el_count, el_pipe], dtype=torch.float64, device=cdev)
     if use_dist:
         dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
     el, el_count, el_pipe = float(t_el[0].item()), float(t_el[1].item()), float(t_el[2].item())
-    g_counters = shard.reduce_counters(counters, device=dev)  # the only collective of the run: 4 x u64 over RCCL
+    g_counters = shard.reduce_counters(counters, device=cdev)  # the only collective of the run: 4 x u64 over RCCL
 
     out = None
     if rank == 0:
@@ -603,6 +613,8 @@ def main():
                           "hbm_free_at_load": int(ix.hbm_free_at_load), "hbm_budget": int(ix.hbm_budget), "ftab_k": int(ix.ftab_k), "pair_runs": int(ix.pair_runs), "triple_runs": int(ix.triple_runs), "quad_runs": int(ix.quad_runs), "quint_runs": int(ix.quint_runs)},
                 "reads_per_gpu": N, "read_len": m, "substituted_fraction": 0.1,
                 "parallelism": f"index replicated x{world}, reads sharded, no data-path collective",
+                **({"rehearsal": f"NOT A MEASUREMENT: {world} ranks on {torch.cuda.device_count()} GPU(s), collectives over gloo (--rehearse-ranks)"}
+                   if args.rehearse_ranks else {}),
             },
             "two_stream_pipeline": ({"value": N * world * K / el_pipe, "unit": "reads/s", "ms_per_step": el_pipe / K * 1e3,
                                      "identical_output": same_out,
@@ -616,7 +628,7 @@ def main():
             "count_only": {"value": N * world * K / el_count, "unit": "reads/s", "ms_per_step": el_count / K * 1e3,
                            "workload": "BASELINE.json configs[1]: find_range only"},
             "counters": {"reads": g_counters[0], "matched": g_counters[1], "sum_occ": g_counters[2], "sum_locs": g_counters[3],
-                         "reduced_over": f"RCCL all_reduce over {world} rank(s)" if use_dist else "single GPU (no process group)"},
+                         "reduced_over": (f"{'gloo (rehearsal)' if args.rehearse_ranks else 'RCCL'} all_reduce over {world} rank(s)" if use_dist else "single GPU (no process group)")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "alg_bytes_per_launch": kernels[dom]["alg_bytes"], "kernel_ms": kernels[dom]["ms"],

@@ -1,7 +1,9 @@
 """Parity tests proper: the HIP path (through the C-ABI) against the oracle and the reference's
 golden values.  Bit-exact: everything on this path is unsigned 64-bit integer work.  Need an MI355X."""
+import json
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -1017,6 +1019,26 @@ def test_cli_locs_text_made_on_the_device(data_dir, tmp_path, small, simple_read
         outs.append(out)
     assert outs[0] == outs[2] and outs[1] == outs[2] and outs[0].count("\n") == 2 * sum(1 for q in rs if len(q))
     assert len(outs[0]) > 200 * len(rs)
+
+
+def test_bench_two_ranks_rehearsal():
+    """`bench.py --gpus 2 --rehearse-ranks`: the whole multi-rank path on this box's one GPU -- the GPU-free parent starts two
+    ranks, rank 0 derives the BWT and writes the cache file, both load their replica from it, each searches ITS block of the
+    global batch, the timing is the max over ranks, the counters are summed (gloo stands in for RCCL, and the line says it is
+    no measurement).  n_gpus = the group's size; reads and matches of both ranks arrive in the counters."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-ranks", "--L", "1500000", "--H", "8", "--reads", "150000",
+                        "--steps", "2", "--warmup", "1", "--no-space-speed", "--no-markers", "--no-cpu-baseline", "--check-reads", "2000",
+                        "--property-reads", "20000"], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]   # (gloo announces its connections on stdout; RCCL does not)
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and "rehearsal" in d["config"] and d["vs_baseline"] is None
+    assert d["config"]["reads_per_gpu"] == 150000
+    assert d["parity"]["bit_exact_vs_oracle"] and d["counters"]["reads"] == 2 * 150000 * 2   # (two ranks x the two timed steps)
 
 
 def test_align_text_through_the_abi(synth):
