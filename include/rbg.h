@@ -259,8 +259,9 @@ int rbg_doc_table(rbg_index *, uint64_t *ndocs, const uint64_t **sorted_starts, 
  * next calls): rbg_wait_text(ix, *text) before the first byte is read.  RBG_ENOTLOADED without the toehold SA or the document list; RBG_EARG when a location lies before every
  * document (rbg_resolve_offset's error).  k == NULL: the report without -s, one line per read (no toehold SA or
  * document list needed). */
-int rbg_align_text(rbg_index *, const uint64_t *lo, const uint64_t *hi, const uint64_t *k, uint64_t N, uint64_t max_hits, const char *name_base,
-                   const uint64_t *name_begin, const uint32_t *name_len, const char **text, uint64_t *text_len);
+enum { RBG_TEXT_MARKERS = 1 };   /* flags: also "\tmarkers: <pos>/<allele> ...\n" per read (markers_at, rb_align.cpp:134-142; needs the marker array) */
+int rbg_align_text(rbg_index *, const uint64_t *lo, const uint64_t *hi, const uint64_t *k, uint64_t N, uint64_t max_hits, uint32_t flags,
+                   const char *name_base, const uint64_t *name_begin, const uint32_t *name_len, const char **text, uint64_t *text_len);
 int rbg_wait_text(rbg_index *, const char *text);
 int rbg_release_text(rbg_index *, const char *text);
 /* make `count` pinned text buffers of `bytes` now (pinning a few hundred MB takes tenths of a second: a tool does it before its clock starts) */

@@ -62,7 +62,7 @@ _PROTOS = [
     ("rbg_convert_raw", C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p]),
     ("rbg_load_cache", C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(VP)]),
     ("rbg_doc_table", C.c_int, [VP, C.POINTER(U64), C.POINTER(VP), C.POINTER(VP), C.POINTER(U64)]),
-    ("rbg_align_text", C.c_int, [VP, VP, VP, VP, U64, U64, VP, VP, VP, C.POINTER(VP), C.POINTER(U64)]),
+    ("rbg_align_text", C.c_int, [VP, VP, VP, VP, U64, U64, C.c_uint32, VP, VP, VP, C.POINTER(VP), C.POINTER(U64)]),
     ("rbg_wait_text", C.c_int, [VP, VP]),
     ("rbg_release_text", C.c_int, [VP, VP]),
     ("rbg_reserve_text", C.c_int, [VP, U64, C.c_int]),
@@ -433,7 +433,7 @@ class RowBowt:
         _check(self.L.rbg_resolve_offset(self.h, i, C.byref(name), C.byref(off)), "rbg_resolve_offset")
         return name.value.decode(), off.value
 
-    def align_text(self, lo, hi, k, names, max_hits=MAXU):
+    def align_text(self, lo, hi, k, names, max_hits=MAXU, markers=False):
         """rbg_align_text: the `rb_align -s` text of a batch (bytes), made on the device; names = list of bytes"""
         lo, hi = (np.ascontiguousarray(a, dtype=np.uint64) for a in (lo, hi))
         k = None if k is None else np.ascontiguousarray(k, dtype=np.uint64)   # None: the count-only report
@@ -444,7 +444,7 @@ class RowBowt:
             nbeg[1:] = np.cumsum(nlen[:-1], dtype=np.uint64)
         buf = C.create_string_buffer(blob, len(blob) + 1)
         text, n = VP(), U64()
-        _check(self.L.rbg_align_text(self.h, _p(lo), _p(hi), _p(k) if k is not None else None, len(names), max_hits, buf, _p(nbeg), _p(nlen), C.byref(text), C.byref(n)), "rbg_align_text")
+        _check(self.L.rbg_align_text(self.h, _p(lo), _p(hi), _p(k) if k is not None else None, len(names), max_hits, 1 if markers else 0, buf, _p(nbeg), _p(nlen), C.byref(text), C.byref(n)), "rbg_align_text")
         try:
             _check(self.L.rbg_wait_text(self.h, text), "rbg_wait_text")
             return C.string_at(text, n.value)

@@ -50,11 +50,20 @@ struct TextArgs {
     const uint32_t *doc_name_off;                  // [ndocs + 1]
     uint64_t ndocs, text_size;                     // text_size: DocList::size (the n of the index)
     bool with_locs;                                // false: the count-only report (no "\tlocs:" line; loc_off is all zero)
+    const uint64_t *mk_off, *mk;                   // -m: markers_at of every read's range (rowbowt.hpp:282-285); nullptr = no markers line
+    uint64_t per_read;                             // fixed elements per read: the head, + the markers line when there is one
 };
+// Elements of read i: its head at i * per_read + loc_off[i], its locations behind it, then (with -m) its markers line.
+__device__ __forceinline__ uint64_t head_of(const TextArgs &a, uint64_t i) { return i * a.per_read + a.loc_off[i]; }
+constexpr uint32_t kNoMarkersLen = 73;
+__device__ const char kNoMarkers[] = "no markers (consider building the marker array with a larger window size)";
+// rowbowt_gpu.hpp get_pos / get_allele (MarkerT fields)
+__device__ __forceinline__ uint64_t mk_pos(uint64_t m) { return m & ((uint64_t(1) << 48) - 1); }
+__device__ __forceinline__ uint64_t mk_allele(uint64_t m) { return (m >> 60) & 0xF; }
 
-__global__ __launch_bounds__(256) void k_text_mark(const uint64_t *__restrict__ loc_off, const uint64_t N, uint32_t *__restrict__ mark) {
+__global__ __launch_bounds__(256) void k_text_mark(const uint64_t *__restrict__ loc_off, const uint64_t N, const uint64_t per_read, uint32_t *__restrict__ mark) {
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
-    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < N; i += stride) mark[i + loc_off[i]] = static_cast<uint32_t>(i);
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < N; i += stride) mark[i * per_read + loc_off[i]] = static_cast<uint32_t>(i);
 }
 
 // doclist.hpp:46-50, :77-79: the document of text position pos = the last one starting at or before it
@@ -74,11 +83,19 @@ __global__ __launch_bounds__(256) void k_text_len(const TextArgs a, const uint32
     for (uint64_t e = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < a.E; e += stride) {
         const uint64_t i = eread[e];
         const uint64_t l0 = a.loc_off[i], l1 = a.loc_off[i + 1];
-        if (e == i + l0) {   // head
+        const uint64_t eh = head_of(a, i);
+        if (e == eh) {   // head
             const uint64_t lo = a.lo[i], hi = a.hi[i];
             len[e] = (a.name_off[i + 1] - a.name_off[i]) + 2 + dec_len(lo) + 1 + dec_len(hi) + 9 + dec_len(hi - lo + 1) + 1 + (a.with_locs ? 7 + (l1 == l0 ? 1u : 0u) : 0u);
+        } else if (a.mk_off && e == eh + (l1 - l0) + 1) {   // the markers line (rb_align.cpp:134-142)
+            const uint64_t m0 = a.mk_off[i], m1 = a.mk_off[i + 1];
+            uint32_t n = 10 + 1;
+            if (m1 == m0) n += kNoMarkersLen;
+            for (uint64_t t = m0; t < m1; ++t) n += dec_len(mk_pos(a.mk[t])) + 1 + dec_len(mk_allele(a.mk[t])) + 1;
+            len[e] = n;
+            doc[e] = 0;
         } else {
-            const uint64_t t = e - i - 1, pos = a.locs[t];
+            const uint64_t t = l0 + (e - eh - 1), pos = a.locs[t];
             const uint64_t k = doc_of(a, pos);
             if (k == 0) { atomicOr(bad, 1u); len[e] = 0; doc[e] = 0; continue; }
             const uint64_t d = k - 1;
@@ -92,7 +109,8 @@ __global__ __launch_bounds__(256) void k_text_len(const TextArgs a, const uint32
 template <typename Ptr>
 __device__ __forceinline__ void put_element(const TextArgs &a, const uint64_t e, const uint64_t i, const uint32_t d, Ptr p) {
     const uint64_t l0 = a.loc_off[i], l1 = a.loc_off[i + 1];
-    if (e == i + l0) {
+    const uint64_t eh = head_of(a, i);
+    if (e == eh) {
         const uint32_t nb = a.name_off[i], nl = a.name_off[i + 1] - nb;
         for (uint32_t j = 0; j < nl; ++j) p[j] = a.names[nb + j];
         p += nl;
@@ -116,8 +134,27 @@ __device__ __forceinline__ void put_element(const TextArgs &a, const uint64_t e,
             p += 7;
             if (l1 == l0) *p = '\n';
         }
+    } else if (a.mk_off && e == eh + (l1 - l0) + 1) {
+        const char lit[] = "\tmarkers: ";
+        for (int j = 0; j < 10; ++j) p[j] = lit[j];
+        p += 10;
+        const uint64_t m0 = a.mk_off[i], m1 = a.mk_off[i + 1];
+        if (m1 == m0) {
+            for (uint32_t j = 0; j < kNoMarkersLen; ++j) p[j] = kNoMarkers[j];
+            p += kNoMarkersLen;
+        }
+        for (uint64_t t = m0; t < m1; ++t) {
+            const uint64_t mp = mk_pos(a.mk[t]), ma = mk_allele(a.mk[t]);
+            uint32_t n = dec_len(mp);
+            put_dec(p, mp, n); p += n;
+            *p = '/'; p += 1;
+            n = dec_len(ma);
+            put_dec(p, ma, n); p += n;
+            *p = ' '; p += 1;
+        }
+        *p = '\n';
     } else {
-        const uint64_t t = e - i - 1, pos = a.locs[t];
+        const uint64_t t = l0 + (e - eh - 1), pos = a.locs[t];
         uint32_t n = dec_len(pos);
         put_dec(p, pos, n); p += n;
         *p = '/'; p += 1;
@@ -198,7 +235,7 @@ int launch_copy16(const void *pinned_src, void *dst, uint64_t bytes, void *strea
 // phase 1: element lengths and offsets.  *d_total (device, 8 bytes) = bytes of text; *d_bad != 0: a location outside every document
 int launch_text_plan(const uint64_t *lo, const uint64_t *hi, const uint64_t *loc_off, const uint64_t *locs, uint64_t N, uint64_t E, const char *names,
                      const uint32_t *name_off, const uint64_t *doc_start, const char *doc_names, const uint32_t *doc_name_off, uint64_t ndocs,
-                     uint64_t text_size, bool with_locs, void *ws, size_t ws_bytes, unsigned int *d_bad, void *stream) {
+                     uint64_t text_size, bool with_locs, const uint64_t *mk_off, const uint64_t *mk, void *ws, size_t ws_bytes, unsigned int *d_bad, void *stream) {
     if (ws_bytes < text_ws_bytes(E) || (reinterpret_cast<uintptr_t>(ws) & 255)) return static_cast<int>(hipErrorInvalidValue);
     hipStream_t st = static_cast<hipStream_t>(stream);
     auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
@@ -207,11 +244,11 @@ int launch_text_plan(const uint64_t *lo, const uint64_t *hi, const uint64_t *loc
     uint64_t *at = reinterpret_cast<uint64_t *>(b + 3 * up(E * 4));
     void *tmp = b + 3 * up(E * 4) + up(E * 8 + 8);
     size_t tmp_bytes = ws_bytes - (3 * up(E * 4) + up(E * 8 + 8));
-    const TextArgs a{lo, hi, loc_off, locs, N, E, names, name_off, doc_start, doc_names, doc_name_off, ndocs, text_size, with_locs};
+    const TextArgs a{lo, hi, loc_off, locs, N, E, names, name_off, doc_start, doc_names, doc_name_off, ndocs, text_size, with_locs, mk_off, mk, mk_off ? uint64_t(2) : uint64_t(1)};
     hipError_t e = hipMemsetAsync(eread, 0, E * 4, st);
     if (e != hipSuccess) return static_cast<int>(e);
     const int gN = static_cast<int>(std::min<uint64_t>((N + 255) / 256, 256ull * 32)), gE = static_cast<int>(std::min<uint64_t>((E + 255) / 256, 256ull * 32));
-    hipLaunchKernelGGL(k_text_mark, dim3(gN), dim3(256), 0, st, loc_off, N, eread);
+    hipLaunchKernelGGL(k_text_mark, dim3(gN), dim3(256), 0, st, loc_off, N, a.per_read, eread);
     size_t tb = tmp_bytes;
     e = hipcub::DeviceScan::InclusiveScan(tmp, tb, eread, eread, MaxOp(), static_cast<int64_t>(E), st);
     if (e != hipSuccess) return static_cast<int>(e);
@@ -231,13 +268,13 @@ void text_total_ptrs(void *ws, uint64_t E, const uint64_t **last_at, const uint3
 // phase 2: the text itself (total bytes at `text`)
 int launch_text_fill(const uint64_t *lo, const uint64_t *hi, const uint64_t *loc_off, const uint64_t *locs, uint64_t N, uint64_t E, const char *names,
                      const uint32_t *name_off, const uint64_t *doc_start, const char *doc_names, const uint32_t *doc_name_off, uint64_t ndocs,
-                     uint64_t text_size, bool with_locs, void *ws, uint64_t total, char *text, void *stream) {
+                     uint64_t text_size, bool with_locs, const uint64_t *mk_off, const uint64_t *mk, void *ws, uint64_t total, char *text, void *stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
     char *b = static_cast<char *>(ws);
     const uint32_t *eread = reinterpret_cast<const uint32_t *>(b), *doc = reinterpret_cast<const uint32_t *>(b + 2 * up(E * 4));
     const uint64_t *at = reinterpret_cast<const uint64_t *>(b + 3 * up(E * 4));
-    const TextArgs a{lo, hi, loc_off, locs, N, E, names, name_off, doc_start, doc_names, doc_name_off, ndocs, text_size, with_locs};
+    const TextArgs a{lo, hi, loc_off, locs, N, E, names, name_off, doc_start, doc_names, doc_name_off, ndocs, text_size, with_locs, mk_off, mk, mk_off ? uint64_t(2) : uint64_t(1)};
     const int g = static_cast<int>(std::min<uint64_t>((E + 255) / 256, 256ull * 16));
     hipLaunchKernelGGL(k_text_write, dim3(g), dim3(256), 0, st, a, eread, doc, at, total, text);
     return static_cast<int>(hipGetLastError());

@@ -49,7 +49,7 @@ struct RbAlignArgs {  // rb_align.cpp:17-24
     int gpus = 1;     // replicas: devices device .. device + gpus - 1; every batch is sharded over them
     std::vector<int> devices;  // --devices a,b,...: the replicas' devices, in shard order (overrides --gpu/--gpus)
     uint64_t batch = 1u << 18;   // (a 256 MB window of 100 bp FASTQ holds 1.2 M reads: several batches per window keep both pipeline stages busy)
-    bool batch_given = false;    // -s without -m doubles the default: every library call waits 3 ms for its first device operation (0.36 -> 0.28 s per 10 M reads)
+    bool batch_given = false;    // -s doubles the default: every library call waits 3 ms for its first device operation (0.36 -> 0.28 s per 10 M reads)
     // input scanning and output formatting workers: an eighth of the CPUs, 8..32, within the container's CPU quota
     int threads = static_cast<int>(std::min({32u, std::max(8u, std::thread::hardware_concurrency() / 8), std::max(2u, rbg_hostpath::cpu_budget())}));
     uint64_t window_mb = 256;  // input bytes scanned per pipeline step
@@ -64,7 +64,7 @@ void print_help() {  // rb_align.cpp:26-35
     fprintf(stderr, "    --gpu <n>                        HIP device ordinal (default 0)\n");
     fprintf(stderr, "    --gpus <G>                       replicate the index on G devices (from --gpu on) and shard every batch over them\n");
     fprintf(stderr, "    --devices <a,b,...>              the same with an explicit device list\n");
-    fprintf(stderr, "    --batch <n>                      reads per GPU batch (default 262144; 524288 with -s alone)\n");
+    fprintf(stderr, "    --batch <n>                      reads per GPU batch (default 262144; 524288 with -s)\n");
     fprintf(stderr, "    --threads <n>                    input scanning / output formatting threads (default: an eighth of the CPUs, 8..32)\n");
     fprintf(stderr, "    --window-mb <n>                  input bytes scanned per pipeline step (default 256)\n");
     fprintf(stderr, "    <input_prefix>                   index prefix\n");
@@ -113,7 +113,7 @@ RbAlignArgs parse_args(int argc, char **argv) {  // rb_align.cpp:37-84
     args.fastq_fname = argv[optind++];
     if (args.outpre.empty()) args.outpre = args.inpre;
     if (args.batch == 0) args.batch = 1;
-    if (!args.batch_given && args.sam && !args.markers) args.batch = 1u << 19;
+    if (!args.batch_given && args.sam) args.batch = 1u << 19;
     if (args.gpus < 1) args.gpus = 1;
     if (args.threads < 1) args.threads = 1;
     if (args.window_mb < 1) args.window_mb = 1;
@@ -128,7 +128,7 @@ struct BatchResult {
     uint64_t begin = 0, end = 0;
     std::vector<uint64_t> lo, hi, k, loc_off, mk_off;
     uint64_t *locs = nullptr, *mk = nullptr;
-    // -s without -m: the shard's text as the library made it on the device (rbg_align_text); handed to the writer, which
+    // -s: the shard's text as the library made it on the device (rbg_align_text); handed to the writer, which
     // gives the buffer back (rbg_release_text)
     const char *text = nullptr;
     uint64_t text_len = 0;
@@ -146,13 +146,13 @@ struct ShardError {
     int rc = RBG_OK;
     const char *what = "";
 };
-// -s (without -m) prints 975 bytes per read on a pangenome index; the library writes that text with kernels unless
+// -s (with or without -m) prints 975 bytes per read on a pangenome index; the library writes that text with kernels unless
 // RB_ALIGN_HOST_TEXT=1 asks for the host formatter below (A/B, tests: the two are byte-identical).  The one line per read
 // of the count-only report stays with the host formatter: its 30 bytes per read cost less there (0.05 s per 10 M reads)
 // than a library call per batch does (measured: 7.4e7 reads/s against 2.8e7 through rbg_align_text with k = NULL).
 bool device_text(const RbAlignArgs &args) {
     static const bool off = [] { const char *e = std::getenv("RB_ALIGN_HOST_TEXT"); return e && e[0] == '1'; }();
-    return args.sam && !args.markers && !off;
+    return args.sam && !off;
 }
 
 ShardError query_shard(rbg_index *ix, const RbAlignArgs &args, const Window &b, uint64_t begin, uint64_t end, BatchResult &r) {
@@ -172,7 +172,7 @@ ShardError query_shard(rbg_index *ix, const RbAlignArgs &args, const Window &b, 
             if ((rc = rbg_find_range_spans(ix, base, sb, sl, N, r.lo.data(), r.hi.data(), r.k.data()))) return {rc, "rbg_find_range_spans"};
             if (device_text(args)) {   // locations, documents and decimals on the device: the finished text comes back
                 r.text_owner = ix;
-                if ((rc = rbg_align_text(ix, r.lo.data(), r.hi.data(), r.k.data(), N, static_cast<uint64_t>(-1), b.base, b.recs.name_begin.data() + begin,
+                if ((rc = rbg_align_text(ix, r.lo.data(), r.hi.data(), r.k.data(), N, static_cast<uint64_t>(-1), args.markers ? RBG_TEXT_MARKERS : 0, b.base, b.recs.name_begin.data() + begin,
                                          b.recs.name_len.data() + begin, &r.text, &r.text_len)))
                     return {rc, "rbg_align_text"};
                 return {};

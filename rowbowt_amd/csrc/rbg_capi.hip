@@ -2064,6 +2064,10 @@ int rbg_set_docs(rbg_index *ix, const char *names_joined, const uint64_t *starts
     d.sorted = d.starts;
     std::sort(d.sorted.begin(), d.sorted.end());
     ix->H().has_dl = true;
+    {   // rbg_align_text keeps a device copy of the table: made again at its next call (the old arrays stay until rbg_free)
+        std::lock_guard<std::mutex> g2(ix->text_mu);
+        ix->text_docs = rbg_index::TextDocs();
+    }
     return RBG_OK;
     });
 }
@@ -3024,12 +3028,15 @@ rbg_index::TextOut *find_text_out(rbg_index *ix, const char *p) {
 }  // namespace
 extern "C" {
 
-int rbg_align_text(rbg_index *ix, const uint64_t *lo, const uint64_t *hi, const uint64_t *k, uint64_t N, uint64_t max_hits, const char *name_base,
-                   const uint64_t *name_begin, const uint32_t *name_len, const char **text, uint64_t *text_len) {
+int rbg_align_text(rbg_index *ix, const uint64_t *lo, const uint64_t *hi, const uint64_t *k, uint64_t N, uint64_t max_hits, uint32_t flags,
+                   const char *name_base, const uint64_t *name_begin, const uint32_t *name_len, const char **text, uint64_t *text_len) {
     return guarded([&]() -> int {
     if (!queryable(ix)) return RBG_ENODEV;
     const bool with_locs = k != nullptr;   // k == NULL: the count-only report (rb_align without -s): one line per read
+    const bool with_markers = (flags & RBG_TEXT_MARKERS) != 0;   // the "\tmarkers: ..." line of -m behind every read
+    if (flags & ~static_cast<uint32_t>(RBG_TEXT_MARKERS)) return RBG_EARG;
     if (with_locs && (!ix->H().has_tsa || !ix->H().has_dl)) return RBG_ENOTLOADED;
+    if (with_markers && !ix->H().has_ma) return RBG_ENOTLOADED;
     if (!text || !text_len || (N >> 32) || (N && (!lo || !hi || !name_base || !name_begin || !name_len))) return RBG_EARG;
     *text = nullptr;
     *text_len = 0;
@@ -3094,13 +3101,27 @@ int rbg_align_text(rbg_index *ix, const uint64_t *lo, const uint64_t *hi, const 
                                     dlocs.as<uint64_t>(), nullptr, order, st))
         return RBG_ENODEV;
     lap(3, true);
+    // markers_at (rowbowt.hpp:282-285) of every range, as rbg_markers_at does it -- they stay on the device too
+    DevBuf dmoff, dmk;
+    const uint64_t *d_mk_off = nullptr, *d_mk = nullptr;
+    if (with_markers) {
+        if ((rc = dmoff.alloc((N + 1) * 8))) return rc;
+        if (launch_markers_plan(ix->dev, ix->cfg, dlo.as<uint64_t>(), dhi.as<uint64_t>(), N, dmoff.as<uint64_t>(), dtmp.p, tmp_bytes, st)) return RBG_ENODEV;
+        uint64_t nmk = 0;
+        HIP_TRY(hipMemcpyAsync(&nmk, dmoff.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if ((rc = dmk.alloc(nmk * 8))) return rc;
+        if (nmk && launch_markers_fill(ix->dev, ix->cfg, dlo.as<uint64_t>(), dhi.as<uint64_t>(), N, dmoff.as<uint64_t>(), dmk.as<uint64_t>(), st)) return RBG_ENODEV;
+        d_mk_off = dmoff.as<uint64_t>();
+        d_mk = dmk.as<uint64_t>();
+    }
     // the text: lengths, offsets, bytes (k_text.hip)
-    const uint64_t E = N + nlocs;
+    const uint64_t E = N * (with_markers ? 2 : 1) + nlocs;
     const size_t ws_bytes = text_ws_bytes(E);
     if ((rc = dws.alloc(ws_bytes))) return rc;
     const auto &D = ix->text_docs;
     if (launch_text_plan(dlo.as<uint64_t>(), dhi.as<uint64_t>(), doff.as<uint64_t>(), dlocs.as<uint64_t>(), N, E, dnames.as<char>(), dnoff.as<uint32_t>(),
-                              D.start, D.names, D.name_off, D.n, D.size, with_locs, dws.p, ws_bytes, dbad.as<unsigned int>(), st))
+                              D.start, D.names, D.name_off, D.n, D.size, with_locs, d_mk_off, d_mk, dws.p, ws_bytes, dbad.as<unsigned int>(), st))
         return RBG_ENODEV;
     const uint64_t *p_at = nullptr;
     const uint32_t *p_len = nullptr;
@@ -3116,7 +3137,7 @@ int rbg_align_text(rbg_index *ix, const uint64_t *lo, const uint64_t *hi, const 
     const uint64_t total = last_at + last_len;
     if ((rc = dtext.alloc(total))) return rc;
     if (launch_text_fill(dlo.as<uint64_t>(), dhi.as<uint64_t>(), doff.as<uint64_t>(), dlocs.as<uint64_t>(), N, E, dnames.as<char>(), dnoff.as<uint32_t>(),
-                              D.start, D.names, D.name_off, D.n, D.size, with_locs, dws.p, total, dtext.as<char>(), st))
+                              D.start, D.names, D.name_off, D.n, D.size, with_locs, d_mk_off, d_mk, dws.p, total, dtext.as<char>(), st))
         return RBG_ENODEV;
     lap(5, true);
     char *out = nullptr;

@@ -431,16 +431,16 @@ int launch_build_rank_slots64(uint32_t pos_bytes, const void *ent, const void *s
                               unsigned long long *overflow, unsigned long long *dense_cursor, void *stream);
 int launch_fill_dense64(uint32_t pos_bytes, const void *ent, uint64_t n, uint32_t shift, const void *slots, uint8_t *dense, void *stream);
 // the text of `rb_align -s` on the device (k_text.hip; rbg_align_text): phase 1 = element lengths and offsets in the workspace,
-// phase 2 = the bytes.  E = N + loc_off[N] elements (a head per read, then its locations)
+// phase 2 = the bytes.  E = N + loc_off[N] elements (a head per read, then its locations), + N with a markers line per read
 size_t text_ws_bytes(uint64_t E);
 int launch_copy16(const void *pinned_src, void *dst, uint64_t bytes, void *stream);   // host-mapped memory -> device by a kernel (not the copy engine)
 int launch_text_plan(const uint64_t *lo, const uint64_t *hi, const uint64_t *loc_off, const uint64_t *locs, uint64_t N, uint64_t E, const char *names,
                      const uint32_t *name_off, const uint64_t *doc_start, const char *doc_names, const uint32_t *doc_name_off, uint64_t ndocs,
-                     uint64_t text_size, bool with_locs, void *ws, size_t ws_bytes, unsigned int *d_bad, void *stream);
+                     uint64_t text_size, bool with_locs, const uint64_t *mk_off, const uint64_t *mk, void *ws, size_t ws_bytes, unsigned int *d_bad, void *stream);
 void text_total_ptrs(void *ws, uint64_t E, const uint64_t **last_at, const uint32_t **last_len);
 int launch_text_fill(const uint64_t *lo, const uint64_t *hi, const uint64_t *loc_off, const uint64_t *locs, uint64_t N, uint64_t E, const char *names,
                      const uint32_t *name_off, const uint64_t *doc_start, const char *doc_names, const uint32_t *doc_name_off, uint64_t ndocs,
-                     uint64_t text_size, bool with_locs, void *ws, uint64_t total, char *text, void *stream);
+                     uint64_t text_size, bool with_locs, const uint64_t *mk_off, const uint64_t *mk, void *ws, uint64_t total, char *text, void *stream);
 // run-indexed layout from run lists already on the device (k_build.hip): the tables' directories, one sampled level of a
 // depth's index, 8-byte samples packed to 6
 int launch_run_dirs(uint32_t pos_bytes, const void *ent, const uint64_t *first, const uint64_t *nruns, const uint64_t *doff, const uint32_t *dshift,

@@ -945,6 +945,9 @@ def test_cli_locs_and_markers_stdout(data_dir, tmp_path, small, simple_reads):
         want += "\n"
     assert out == want
     assert "20306/hap2:286 286/ref:286" in out
+    # (-s -m is made on the device too, markers line included; the host formatter gives the same bytes)
+    rc, out_h, _ = _run_cli(["-s", "-m", str(tmp_path / "idx"), str(fq)], env={"RB_ALIGN_HOST_TEXT": "1"})
+    assert rc == 0 and out_h == want
     # batching is invisible: one read per GPU batch gives the same bytes
     rc, out1, _ = _run_cli(["-s", "-m", "--batch", "1", str(tmp_path / "idx"), str(fq)])
     assert rc == 0 and out1 == want
@@ -1039,6 +1042,39 @@ def test_bench_two_ranks_rehearsal():
     assert d["n_gpus"] == 2 and d["value"] > 0 and "rehearsal" in d["config"] and d["vs_baseline"] is None
     assert d["config"]["reads_per_gpu"] == 150000
     assert d["parity"]["bit_exact_vs_oracle"] and d["counters"]["reads"] == 2 * 150000 * 2   # (two ranks x the two timed steps)
+
+
+def test_align_text_markers_line(small, simple_reads, error_reads):
+    """RBG_TEXT_MARKERS through the ABI on the reference's fixture: with and without the locations' line, reads with and
+    without markers and without a match (rb_align.cpp:118-145)"""
+    rb, o = small
+    o.set_docs(["ref", "hap1", "hap2"], [0, 10010, 20020])
+    rb.set_docs(["ref", "hap1", "hap2"], [0, 10010, 20020])
+    reads = list(simple_reads) + list(error_reads) + [b"ACGT", simple_reads[0][:25]]
+    seqs, off = ra.pack_reads(reads)
+    lo, hi, k = rb.find_range_w_toehold(seqs, off)
+    names = [f"q{i}".encode() for i in range(len(reads))]
+    for with_locs in (True, False):
+        got = rb.align_text(lo, hi, k if with_locs else None, names, markers=True).decode()
+        want = ""
+        for n, a, b, kk in zip(names, lo, hi, k):
+            a, b, kk = int(a), int(b), int(kk)
+            want += f"{n.decode()} ({a},{b}), count={(b - a + 1) % 2**64}\n"
+            if with_locs:
+                want += "\tlocs: "
+                if a <= b:
+                    for l in o.locs_at(a, b, kk):
+                        dn, offs = o.resolve_offset(l)
+                        want += f"{l}/{dn}:{offs} "
+                want += "\n"
+            want += "\tmarkers: "
+            mk = o.markers_at(a, b) if a <= b else []
+            if not mk:
+                want += "no markers (consider building the marker array with a larger window size)"
+            for m_ in mk:
+                want += f"{G.get_pos(m_)}/{G.get_allele(m_)} "
+            want += "\n"
+        assert got == want
 
 
 def test_align_text_through_the_abi(synth):
