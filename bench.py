@@ -802,6 +802,24 @@ def main():
             dta = time.perf_counter() - t0
             out["cpu_baseline_all_cores"] = {"value": na / dta, "unit": "reads/s", "cores": ncpu, "kind": "port",
                                              "sample": f"first {na} reads, OpenMP over reads, {dta:.1f}s"}
+            # SURVEY 8d's optional mode: the same port answering rank / select / access from Elias-Fano vectors and a
+            # Huffman-shaped wavelet tree (what sdsl holds for the reference) instead of decoded arrays -- the reference's
+            # memory behaviour; a third of the sample, one thread; results must be the plain mode's
+            o.set_reference_shaped(True)
+            nr_ = max(probe, ns // 3)
+            r_off = (np.arange(nr_ + 1, dtype=np.uint64) * m)
+            t0 = time.perf_counter()
+            rlo, rhi, rk_ = o.find_range_w_toehold_batch(h_seqs[:nr_ * m], r_off, nthreads=1)
+            _r_off, r_locs = o.locs_at_batch(rlo, rhi, rk_, max_hits, nthreads=1)
+            dtr = time.perf_counter() - t0
+            o.set_reference_shaped(False)
+            same_r = bool((rlo == slo[:nr_]).all() and (rhi == shi[:nr_]).all() and (rk_ == sk[:nr_]).all())
+            out["cpu_baseline"]["reference_shaped"] = {"value": nr_ / dtr, "unit": "reads/s", "cores": 1,
+                                                       "sample": f"first {nr_} reads, sd_vector-like Elias-Fano + wt_huff-like wavelet tree in the port (orc_set_reference_shaped), {dtr:.1f}s",
+                                                       "same_results_as_the_arrays": same_r}
+            if not same_r:
+                print(json.dumps(out))
+                raise SystemExit("oracle: reference-shaped mode disagrees with the decoded arrays")
         o.close()
 
     # ---- space for speed (rank 0, N=1): the same two search kernels with the replica rebuilt at fewer symbols

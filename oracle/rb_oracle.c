@@ -9,6 +9,8 @@
  *   sdsl::sd_vector<> + rank_1/select_1   -> sorted array of one-positions (sdv_t)
  *   sdsl::wt_huff<>                        -> heads[R] + per-symbol sorted run-index lists (hs_t)
  *   sdsl::int_vector<>                     -> uint64_t[]
+ * (orc_set_reference_shaped switches the first two to Elias-Fano vectors and a Huffman-shaped wavelet tree: the structures
+ * sdsl holds, restated from their published layouts -- same answers, the reference's memory behaviour)
  * The sdsl on-disk layout read here is the one the reference's shipped fixtures use
  * (SURVEY.md section 8b-format); the reader consumes each fixture to exact EOF or fails.
  */
@@ -103,14 +105,95 @@ static void skip_select_mcl(rd_t *r) {
 /* ------------------------------------------------------------------------------------------ */
 /* sparse_sd_vector restated: sorted one-positions                                            */
 /* ------------------------------------------------------------------------------------------ */
+/* REFERENCE-SHAPED MODE (orc_set_reference_shaped; SURVEY 8d's optional CPU mode).  The plain arrays above answer rank by
+ * binary search -- not what sdsl does.  With `ef` set an sdv_t answers from the structure sdsl::sd_vector<> holds (Elias-Fano:
+ * the low wl bits of every position packed in `low`, the high parts in unary in the bit-vector `high`, one sampled position per
+ * 64 ones / 64 zeros standing in for select_support_mcl), rank as rank_support_sd does it (select_0 of the high part, then a
+ * scan of the bucket) and select as select_support_sd does (select_1 on `high`, low bits appended): the memory behaviour of
+ * the reference's rle_string::rank, restated from the published layout, not from sdsl's sources (absent here). */
+typedef struct {
+    unsigned wl;
+    uint64_t *low;        /* m entries of wl bits, LSB-first */
+    uint64_t *high;       /* m ones, (u >> wl) + 1 zeros: bucket b = its ones, then a zero */
+    uint64_t high_bits;
+    uint64_t *sel1, *sel0; /* position in `high` of one / zero number 64 j */
+} ef_t;
 typedef struct {
     uint64_t u;    /* universe (size()) */
     uint64_t m;    /* number_of_1() */
     uint64_t *ones;
+    ef_t *ef;      /* reference-shaped mode, else NULL */
 } sdv_t;
+
+static inline uint64_t ef_low(const ef_t *e, uint64_t i) {
+    if (!e->wl) return 0;
+    const uint64_t bit = i * e->wl, w = bit >> 6, o = bit & 63;
+    uint64_t v = e->low[w] >> o;
+    if (o + e->wl > 64) v |= e->low[w + 1] << (64 - o);
+    return v & ((UINT64_C(1) << e->wl) - 1);
+}
+/* position of the r-th (0-based) set bit of w (r < popcount(w)) */
+static inline unsigned word_select(uint64_t w, unsigned r) {
+    unsigned base = 0;
+    for (;;) {   /* a byte at a time, then bit by bit */
+        const unsigned c = (unsigned)__builtin_popcount((unsigned)(w & 0xFF));
+        if (r < c) break;
+        r -= c; w >>= 8; base += 8;
+    }
+    while (r--) w &= w - 1;
+    return base + (unsigned)__builtin_ctzll(w);
+}
+/* position in `high` of one number i (ones != 0) or zero number i (ones == 0) */
+static inline uint64_t ef_select_high(const ef_t *e, uint64_t i, int ones) {
+    uint64_t p = (ones ? e->sel1 : e->sel0)[i >> 6];
+    unsigned r = (unsigned)(i & 63);
+    uint64_t wi = p >> 6;
+    uint64_t w = (ones ? e->high[wi] : ~e->high[wi]) & (~UINT64_C(0) << (p & 63));
+    for (;;) {
+        const unsigned c = (unsigned)__builtin_popcountll(w);
+        if (r < c) return (wi << 6) + word_select(w, r);
+        r -= c;
+        ++wi;
+        w = ones ? e->high[wi] : ~e->high[wi];
+    }
+}
+static void ef_build(sdv_t *s) {
+    if (s->ef || s->m == 0) return;
+    ef_t *e = (ef_t *)calloc(1, sizeof(ef_t));
+    uint64_t q = s->u / s->m;
+    e->wl = 0;
+    while ((q >> 1) >= 1) { q >>= 1; e->wl++; }   /* floor(log2(u / m)): sd_vector's split between low and high bits */
+    e->low = (uint64_t *)calloc((s->m * e->wl + 63) / 64 + 2, 8);
+    e->high_bits = s->m + (s->u >> e->wl) + 2;
+    e->high = (uint64_t *)calloc(e->high_bits / 64 + 2, 8);
+    for (uint64_t i = 0; i < s->m; ++i) {
+        const uint64_t v = s->ones[i], hp = (v >> e->wl) + i;
+        e->high[hp >> 6] |= UINT64_C(1) << (hp & 63);
+        if (e->wl) {
+            const uint64_t lo = v & ((UINT64_C(1) << e->wl) - 1), bit = i * e->wl, w = bit >> 6, o = bit & 63;
+            e->low[w] |= lo << o;
+            if (o + e->wl > 64) e->low[w + 1] |= lo >> (64 - o);
+        }
+    }
+    const uint64_t nz = e->high_bits - s->m;
+    e->sel1 = (uint64_t *)malloc((s->m / 64 + 2) * 8);
+    e->sel0 = (uint64_t *)malloc((nz / 64 + 2) * 8);
+    uint64_t k1 = 0, k0 = 0;
+    for (uint64_t p = 0; p < e->high_bits; ++p) {
+        if ((e->high[p >> 6] >> (p & 63)) & 1) { if ((k1 & 63) == 0) e->sel1[k1 >> 6] = p; ++k1; }
+        else { if ((k0 & 63) == 0) e->sel0[k0 >> 6] = p; ++k0; }
+    }
+    s->ef = e;
+}
+static void ef_free(sdv_t *s) {
+    if (!s->ef) return;
+    free(s->ef->low); free(s->ef->high); free(s->ef->sel1); free(s->ef->sel0); free(s->ef);
+    s->ef = NULL;
+}
 
 /* sdsl::sd_vector<>::load: size, wl, low, high, select_1 support, select_0 support */
 static void sdv_read_raw(rd_t *r, sdv_t *s) {
+    s->ef = NULL;
     uint64_t size = rd_u64(r);
     unsigned wl = rd_u8(r);
     iv_t low, high;
@@ -137,11 +220,21 @@ static void sdv_read(rd_t *r, sdv_t *s) {
     s->u = rd_u64(r);
     s->m = 0;
     s->ones = NULL;
+    s->ef = NULL;
     if (s->u == 0) return;
     sdv_read_raw(r, s);
 }
 /* sparse_sd_vector.hpp:110-113: ones in [0,i) */
 static inline uint64_t sdv_rank(const sdv_t *s, uint64_t i) {
+    if (s->ef) {   /* rank_support_sd: the bucket of i's high part starts behind zero number hi - 1; scan its ones */
+        const ef_t *e = s->ef;
+        if (i >= s->u) return s->m;
+        const uint64_t hb = i >> e->wl, lb = e->wl ? (i & ((UINT64_C(1) << e->wl) - 1)) : 0;
+        uint64_t p = hb ? ef_select_high(e, hb - 1, 0) + 1 : 0;   /* first bit of bucket hb */
+        uint64_t idx = p - hb;                                      /* ones before it */
+        while (((e->high[p >> 6] >> (p & 63)) & 1) && ef_low(e, idx) < lb) { ++p; ++idx; }
+        return idx;
+    }
     uint64_t lo = 0, hi = s->m;
     while (lo < hi) {
         uint64_t mid = (lo + hi) >> 1;
@@ -150,7 +243,10 @@ static inline uint64_t sdv_rank(const sdv_t *s, uint64_t i) {
     return lo;
 }
 /* sparse_sd_vector.hpp:160-163: 0-based select */
-static inline uint64_t sdv_select(const sdv_t *s, uint64_t i) { return s->ones[i]; }
+static inline uint64_t sdv_select(const sdv_t *s, uint64_t i) {
+    if (s->ef) return ((ef_select_high(s->ef, i, 1) - i) << s->ef->wl) | ef_low(s->ef, i);   /* select_support_sd */
+    return s->ones[i];
+}
 /* sparse_sd_vector.hpp:150-154 */
 static inline uint64_t sdv_gapAt(const sdv_t *s, uint64_t i) {
     if (i == 0) return sdv_select(s, 0) + 1;
@@ -161,17 +257,124 @@ static inline uint64_t sdv_pred_rank_circular(const sdv_t *s, uint64_t i) {
     uint64_t rk = sdv_rank(s, i);
     return rk == 0 ? s->m - 1 : rk - 1;
 }
-static void sdv_free(sdv_t *s) { free(s->ones); s->ones = NULL; }
+static void sdv_free(sdv_t *s) { ef_free(s); free(s->ones); s->ones = NULL; }
 
 /* ------------------------------------------------------------------------------------------ */
 /* huff_string restated: heads[] + per-symbol sorted lists of run indices                     */
 /* ------------------------------------------------------------------------------------------ */
+/* Reference-shaped mode: a Huffman-shaped wavelet tree over the run heads (sdsl::wt_huff<> behind huff_string): one bit per
+ * head and tree level in a single bit-vector, rank by 512-bit blocks (a cumulative count per block + popcounts inside it, as
+ * rank_support_v), access / rank top-down along the symbol's code, select bottom-up by binary search over ranks. */
+typedef struct {
+    uint64_t off, len, ones_before;   /* this node's stretch of `bv`; ones of `bv` before it */
+    int child[2];                     /* node index, or -1 - symbol for a leaf */
+    int parent, parent_bit;
+} wtn_t;
+typedef struct {
+    uint64_t *bv, *blk;   /* blk[j] = ones in bv[0, 512 j) */
+    uint64_t bits;
+    wtn_t *node;
+    int nnodes, root;     /* root < 0: a single symbol (-1 - symbol) */
+    int leaf_parent[256], leaf_bit[256];
+    uint32_t code[256];   /* bits from the root, first step in bit 0 */
+    uint8_t code_len[256];
+} wt_t;
 typedef struct {
     uint64_t size;
     uint8_t *heads;
     uint64_t cnt[256];
     uint64_t *pos[256];
+    wt_t *wt;             /* reference-shaped mode, else NULL */
 } hs_t;
+
+static inline uint64_t wt_rank1(const wt_t *t, uint64_t p) {   /* ones in bv[0, p) */
+    uint64_t r = t->blk[p >> 9];
+    for (uint64_t w = (p >> 9) << 3; w < (p >> 6); ++w) r += (uint64_t)__builtin_popcountll(t->bv[w]);
+    if (p & 63) r += (uint64_t)__builtin_popcountll(t->bv[p >> 6] & ((UINT64_C(1) << (p & 63)) - 1));
+    return r;
+}
+static void wt_build(hs_t *h) {
+    if (h->wt || h->size == 0) return;
+    wt_t *t = (wt_t *)calloc(1, sizeof(wt_t));
+    /* Huffman tree over the symbol counts (ties by symbol value: any prefix code gives the same answers) */
+    int alive[512], na = 0;
+    uint64_t wgt[512];
+    t->node = (wtn_t *)calloc(256, sizeof(wtn_t));
+    for (int c = 0; c < 256; ++c)
+        if (h->cnt[c]) { alive[na] = -1 - c; wgt[na] = h->cnt[c]; ++na; }
+    for (int c = 0; c < 256; ++c) { t->leaf_parent[c] = -1; t->leaf_bit[c] = 0; }
+    if (na == 1) { t->root = alive[0]; h->wt = t; return; }
+    while (na > 1) {
+        int a = 0, b = 1;
+        if (wgt[b] < wgt[a]) { int x = a; a = b; b = x; }
+        for (int j = 2; j < na; ++j) {
+            if (wgt[j] < wgt[a]) { b = a; a = j; }
+            else if (wgt[j] < wgt[b]) b = j;
+        }
+        const int id = t->nnodes++;
+        t->node[id].child[0] = alive[a];
+        t->node[id].child[1] = alive[b];
+        t->node[id].parent = -1;
+        for (int k = 0; k < 2; ++k) {
+            const int ch = t->node[id].child[k];
+            if (ch >= 0) { t->node[ch].parent = id; t->node[ch].parent_bit = k; }
+            else { t->leaf_parent[-1 - ch] = id; t->leaf_bit[-1 - ch] = k; }
+        }
+        const uint64_t w = wgt[a] + wgt[b];
+        const int lo = a < b ? a : b, hi = a < b ? b : a;
+        alive[lo] = id; wgt[lo] = w;
+        alive[hi] = alive[na - 1]; wgt[hi] = wgt[na - 1];
+        --na;
+    }
+    t->root = alive[0];
+    /* codes */
+    for (int c = 0; c < 256; ++c) {
+        if (!h->cnt[c]) continue;
+        uint32_t code = 0; int len = 0;   /* walked leaf -> root: every step pushes the earlier ones up, so bit 0 ends as the root's */
+        int nd = t->leaf_parent[c], bit = t->leaf_bit[c];
+        while (nd >= 0) { code = (code << 1) | (uint32_t)bit; ++len; bit = t->node[nd].parent_bit; nd = t->node[nd].parent; }
+        t->code[c] = code;
+        t->code_len[c] = (uint8_t)len;
+    }
+    /* node lengths: heads that pass through the node */
+    for (int id = 0; id < t->nnodes; ++id) t->node[id].len = 0;
+    for (int c = 0; c < 256; ++c) {
+        if (!h->cnt[c]) continue;
+        int nd = t->root;
+        for (int j = 0; j < t->code_len[c]; ++j) { t->node[nd].len += h->cnt[c]; const int ch = t->node[nd].child[(t->code[c] >> j) & 1]; if (ch < 0) break; nd = ch; }
+    }
+    uint64_t off = 0;
+    for (int id = 0; id < t->nnodes; ++id) { t->node[id].off = off; off += t->node[id].len; }
+    t->bits = off;
+    t->bv = (uint64_t *)calloc(off / 64 + 2, 8);
+    uint64_t *fill = (uint64_t *)calloc((size_t)t->nnodes + 1, 8);
+    for (uint64_t i = 0; i < h->size; ++i) {
+        const uint8_t c = h->heads[i];
+        int nd = t->root;
+        for (int j = 0; j < t->code_len[c]; ++j) {
+            const int b = (int)((t->code[c] >> j) & 1);
+            const uint64_t p = t->node[nd].off + fill[nd]++;
+            if (b) t->bv[p >> 6] |= UINT64_C(1) << (p & 63);
+            const int ch = t->node[nd].child[b];
+            if (ch < 0) break;
+            nd = ch;
+        }
+    }
+    free(fill);
+    t->blk = (uint64_t *)malloc((off / 512 + 2) * 8);
+    uint64_t acc = 0;
+    for (uint64_t w = 0; w <= off / 64 + 1; ++w) {
+        if ((w & 7) == 0) t->blk[w >> 3] = acc;
+        acc += (uint64_t)__builtin_popcountll(t->bv[w]);
+    }
+    for (int id = 0; id < t->nnodes; ++id) t->node[id].ones_before = wt_rank1(t, t->node[id].off);
+    h->wt = t;
+}
+static void wt_free(hs_t *h) {
+    if (!h->wt) return;
+    free(h->wt->bv); free(h->wt->blk); free(h->wt->node); free(h->wt);
+    h->wt = NULL;
+}
 
 static void hs_index(hs_t *h) {
     memset(h->cnt, 0, sizeof(h->cnt));
@@ -182,9 +385,36 @@ static void hs_index(hs_t *h) {
     for (uint64_t i = 0; i < h->size; ++i) { uint8_t c = h->heads[i]; h->pos[c][fill[c]++] = i; }
 }
 /* huff_string.hpp:30-33 */
-static inline uint8_t hs_at(const hs_t *h, uint64_t i) { return h->heads[i]; }
+static inline uint8_t hs_at(const hs_t *h, uint64_t i) {
+    if (h->wt) {   /* wt_huff::operator[]: down the tree, the position mapped by rank at every level */
+        const wt_t *t = h->wt;
+        int nd = t->root;
+        while (nd >= 0) {
+            const wtn_t *q = &t->node[nd];
+            const uint64_t p = q->off + i, r1 = wt_rank1(t, p) - q->ones_before;
+            const int b = (int)((t->bv[p >> 6] >> (p & 63)) & 1);
+            i = b ? r1 : i - r1;
+            nd = q->child[b];
+        }
+        return (uint8_t)(-1 - nd);
+    }
+    return h->heads[i];
+}
 /* huff_string.hpp:39-42: number of c in heads[0,i) */
 static inline uint64_t hs_rank(const hs_t *h, uint64_t i, uint8_t c) {
+    if (h->wt) {   /* wt_huff::rank: along c's code */
+        const wt_t *t = h->wt;
+        if (!h->cnt[c]) return 0;
+        int nd = t->root;
+        for (int j = 0; nd >= 0; ++j) {
+            const wtn_t *q = &t->node[nd];
+            const uint64_t r1 = wt_rank1(t, q->off + i) - q->ones_before;
+            const int b = (int)((t->code[c] >> j) & 1);
+            i = b ? r1 : i - r1;
+            nd = q->child[b];
+        }
+        return i;
+    }
     const uint64_t *p = h->pos[c];
     uint64_t lo = 0, hi = h->cnt[c];
     while (lo < hi) {
@@ -194,8 +424,29 @@ static inline uint64_t hs_rank(const hs_t *h, uint64_t i, uint8_t c) {
     return lo;
 }
 /* huff_string.hpp:47-49: 0-based select */
-static inline uint64_t hs_select(const hs_t *h, uint64_t i, uint8_t c) { return h->pos[c][i]; }
+static inline uint64_t hs_select(const hs_t *h, uint64_t i, uint8_t c) {
+    if (h->wt) {   /* wt_huff::select: from c's leaf up, at every node the position of the (i + 1)-th bit of the branch taken */
+        const wt_t *t = h->wt;
+        int nd = t->leaf_parent[c], b = t->leaf_bit[c];
+        while (nd >= 0) {
+            const wtn_t *q = &t->node[nd];
+            uint64_t lo = 0, hi = q->len;   /* smallest x with (# b-bits in [0, x]) == i + 1 */
+            while (lo < hi) {
+                const uint64_t mid = (lo + hi) >> 1;
+                const uint64_t r1 = wt_rank1(t, q->off + mid + 1) - q->ones_before;
+                const uint64_t cb = b ? r1 : mid + 1 - r1;
+                if (cb < i + 1) lo = mid + 1; else hi = mid;
+            }
+            i = lo;
+            b = q->parent_bit;
+            nd = q->parent;
+        }
+        return i;
+    }
+    return h->pos[c][i];
+}
 static void hs_free(hs_t *h) {
+    wt_free(h);
     free(h->heads);
     for (int c = 0; c < 256; ++c) free(h->pos[c]);
 }
@@ -854,6 +1105,24 @@ orc_index *orc_build_from_runs(const uint8_t *heads, const uint64_t *lens, uint6
         x->has_tsa = 1;
     }
     return x;
+}
+
+/* SURVEY 8d's optional "reference-shaped" CPU mode: on = answer every rank / select / access of the rle_string and of
+ * ToeholdSA's predecessor vector from Elias-Fano vectors and a Huffman-shaped wavelet tree (the structures sdsl holds for the
+ * reference) instead of from the decoded arrays; same results, the reference's memory behaviour.  off = the plain arrays. */
+void orc_set_reference_shaped(orc_index *x, int on) {
+    if (!x) return;
+    if (on) {
+        ef_build(&x->runs);
+        for (int c = 0; c < 256; ++c) ef_build(&x->rpl[c]);
+        if (x->has_tsa) ef_build(&x->pred);
+        wt_build(&x->run_heads);
+    } else {
+        ef_free(&x->runs);
+        for (int c = 0; c < 256; ++c) ef_free(&x->rpl[c]);
+        ef_free(&x->pred);
+        wt_free(&x->run_heads);
+    }
 }
 
 int orc_set_markers(orc_index *x, const uint64_t *run_start, const uint64_t *run_end, uint64_t nruns,

@@ -45,6 +45,10 @@ orc_index *orc_build_from_runs(const uint8_t *heads, const uint64_t *lens, uint6
 
 /* attach a marker array given as inclusive SA-index runs + per-run marker lists
  * (mk_off[nruns+1] offsets into mk_vals). */
+/* rank / select / access through Elias-Fano vectors and a Huffman-shaped wavelet tree (what sdsl holds for the reference)
+ * instead of the decoded arrays: same answers, the reference's memory behaviour (optional CPU mode) */
+void orc_set_reference_shaped(orc_index *x, int on);
+
 int orc_set_markers(orc_index *, const uint64_t *run_start, const uint64_t *run_end, uint64_t nruns,
                     const uint64_t *mk_off, const uint64_t *mk_vals);
 /* attach a doc list (doclist.hpp:57-73): names are '\0'-joined, starts[ndocs]. */

@@ -29,6 +29,8 @@ def lib():
         L.orc_build_from_runs.restype = VP
         L.orc_build_from_runs.argtypes = [VP, VP, U64, U64, VP, VP]
         L.orc_set_markers.argtypes = [VP, VP, VP, U64, VP, VP]
+        L.orc_set_reference_shaped.argtypes = [VP, C.c_int]
+        L.orc_set_reference_shaped.restype = None
         L.orc_set_docs.argtypes = [VP, C.c_char_p, VP, U64]
         L.orc_free.argtypes = [VP]
         for f in ("orc_n", "orc_r", "orc_marker_nruns", "orc_marker_nvals", "orc_last_run_sample"):
@@ -109,6 +111,11 @@ class Oracle:
                                       _p(ssa) if ssa is not None else None,
                                       _p(esa) if esa is not None else None)
         return cls(h)
+
+    def set_reference_shaped(self, on=True):
+        """rank / select / access through Elias-Fano vectors and a Huffman-shaped wavelet tree instead of the decoded arrays
+        (SURVEY 8d's optional CPU mode): same answers, the reference's memory behaviour"""
+        self.L.orc_set_reference_shaped(self.h, 1 if on else 0)
 
     def set_markers(self, run_start, run_end, mk_off, mk_vals):
         a = [np.ascontiguousarray(v, dtype=np.uint64) for v in (run_start, run_end, mk_off, mk_vals)]

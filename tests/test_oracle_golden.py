@@ -11,9 +11,13 @@ import golden_values as G
 import orc
 
 
-@pytest.fixture(scope="module")
-def small(data_dir):
+@pytest.fixture(scope="module", params=["arrays", "reference_shaped"])
+def small(data_dir, request):
+    """both forms of the oracle reproduce every golden value: the decoded arrays, and the reference-shaped mode (Elias-Fano
+    vectors + Huffman-shaped wavelet tree: what sdsl holds for the reference; rb_oracle.h orc_set_reference_shaped)"""
     o = orc.Oracle.load(os.path.join(data_dir, "small.fa"), orc.SA | orc.MA)
+    if request.param == "reference_shaped":
+        o.set_reference_shaped(True)
     yield o
     o.close()
 

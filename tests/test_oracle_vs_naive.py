@@ -197,3 +197,55 @@ def test_marker_seeds_control_flow_vs_literal(seed, n, K, wsize):
             assert got == want, (q, kk)
     assert stats.get("restart_misses", 0) > 20   # restarts on an absent k-mer really occurred
     o.close()
+
+
+@pytest.mark.parametrize("seed,n,sigma", [(1, 400, 4), (2, 3000, 4), (3, 5000, 2), (4, 2500, 20), (5, 64, 1), (6, 6000, 200)])
+def test_reference_shaped_mode_equals_the_arrays(seed, n, sigma):
+    """orc_set_reference_shaped: Elias-Fano rank / select and wavelet-tree access / rank / select give what the decoded
+    arrays give, on random repetitive texts of one to 200 symbols and block sizes B = 1, 2, 5: ranges, toeholds, locations
+    (i.e. rank, select, run_of_position, phi) of sampled and random reads, with the mode on, and off again; and the
+    explicit-text FM index agrees."""
+    rng = np.random.default_rng(seed)
+    alpha = rng.choice(np.arange(2, 255), size=sigma, replace=False).astype(np.uint8)
+    base = alpha[rng.integers(0, sigma, n // 4)]
+    parts = []
+    for _ in range(4):
+        h = base.copy()
+        for p in rng.integers(0, len(h), 6):
+            h[p] = alpha[rng.integers(0, sigma)]
+        parts.append(h)
+    text = np.concatenate(parts + [np.array([1], dtype=np.uint8)])
+    fm = naive.NaiveFM(text)
+    heads, lens, brk = naive.rle(naive.bwt_from_sa(text, fm.sa))
+    ssa, esa = naive.run_samples(fm.sa, brk, len(text))
+    reads = []
+    for _ in range(250):
+        m = int(rng.integers(1, 40))
+        s0 = int(rng.integers(0, max(1, len(text) - 1 - m)))
+        q = bytearray(text[s0:s0 + m].tobytes())
+        if rng.random() < 0.3:
+            q[int(rng.integers(len(q)))] = int(alpha[rng.integers(0, sigma)])
+        reads.append(bytes(q))
+    for B in (1, 2, 5):
+        o = orc.Oracle.from_runs(heads, lens, ssa, esa, B=B)
+
+        def answers():
+            out = []
+            for q in reads:
+                lo, hi, k = o.find_range_w_toehold(q)
+                out.append((lo, hi, k, tuple(o.locs_at(lo, hi, k, 25)) if lo <= hi else ()))
+            return out
+
+        plain = answers()
+        o.set_reference_shaped(True)
+        shaped = answers()
+        for i in rng.integers(0, len(text) + 1, 200):   # the primitives themselves
+            for c in (int(alpha[0]), int(alpha[-1]), 1):
+                assert o.rank(int(i), c) == int(np.count_nonzero(naive.bwt_from_sa(text, fm.sa)[: int(i)] == c))
+        o.set_reference_shaped(False)
+        again = answers()
+        assert shaped == plain and again == plain
+        for q, a in zip(reads[:60], plain):
+            assert (a[0], a[1]) == fm.find_range(q)
+        assert sum(1 for a in plain if a[0] <= a[1]) > 100
+        o.close()
