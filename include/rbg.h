@@ -238,6 +238,9 @@ int rbg_greedy_longest_seed(rbg_index *, const uint8_t *seqs, const uint64_t *of
  * locate_from_longest_seed :664-685): locations of the longest seed, each minus the seed's qstart. */
 int rbg_find_locs_greedy_seeding(rbg_index *, const uint8_t *seqs, const uint64_t *off, uint64_t N, uint64_t min_length,
                                  uint64_t max_hits, uint64_t *loc_off, uint64_t **locs);
+/* gives back a result array one of the calls above allocated (*locs, *mk, *seeds).  Always through this call, never free():
+ * large blocks are kept and handed to the next result of about that size -- their pages are already there, which is most of
+ * what a 3 GB result costs (RBG_RESULT_POOL=0 in the environment: plain malloc / free). */
 void rbg_free_buffer(void *);
 
 /* RowBowt::resolve_offset, rowbowt.hpp:623-625 -> DocList::doc_and_offset_at doclist.hpp:46-50.

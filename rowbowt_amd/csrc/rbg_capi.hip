@@ -1473,13 +1473,40 @@ int check_offsets(const uint64_t *off, uint64_t N) {
 // first touch of this memory, and for gigabytes of locations the page faults cost more than the PCIe
 // transfer (tools/d2h_probe.hip: 3 GB in 0.22 s into fresh malloc memory, 0.13-0.16 s into 2 MB-aligned
 // memory marked for transparent huge pages, 0.06 s once touched), so large results ask for huge pages.
+// Large results are RECYCLED: rbg_free_buffer keeps blocks of 8 MB and more (up to 6 GB in all) and the next result
+// of about that size gets one whose pages are already there -- a batch loop (rb_markers: 1 GB of seed records per 2 M reads;
+// rbg_locs_at: 3 GB per 10 M reads) otherwise faults the same pages in again at every call, which costs more than the copy
+// (0.098 s of copy-out per 2 M reads in rb_markers, 0.03 s with recycled blocks).  RBG_RESULT_POOL=0 switches it off.
+struct ResultPool {
+    std::mutex mu;
+    std::map<void *, size_t> live;            // blocks handed out by alloc_result (pooled sizes only)
+    std::multimap<size_t, void *> idle;
+    size_t cached = 0;
+    const bool on = !(std::getenv("RBG_RESULT_POOL") && std::getenv("RBG_RESULT_POOL")[0] == '0');
+    static constexpr size_t kMax = size_t(6) << 30;
+    static ResultPool &get() { static ResultPool p; return p; }
+    ~ResultPool() { for (auto &kv : idle) std::free(kv.second); }
+};
 void *alloc_result(size_t bytes) {
     constexpr size_t kHuge = size_t(2) << 20;
+    ResultPool &P = ResultPool::get();
     if (bytes >= 4 * kHuge) {
         const size_t rounded = (bytes + kHuge - 1) & ~(kHuge - 1);
+        if (P.on) {
+            std::lock_guard<std::mutex> g(P.mu);
+            auto it = P.idle.lower_bound(rounded);
+            if (it != P.idle.end() && it->first <= rounded + rounded / 4) {
+                void *p = it->second;
+                P.live[p] = it->first;
+                P.cached -= it->first;
+                P.idle.erase(it);
+                return p;
+            }
+        }
         void *p = std::aligned_alloc(kHuge, rounded);
         if (p) {
             (void)madvise(p, rounded, MADV_HUGEPAGE);
+            if (P.on) { std::lock_guard<std::mutex> g(P.mu); P.live[p] = rounded; }
             return p;
         }
     }
@@ -1572,7 +1599,7 @@ int ragged_finish(uint64_t N, DevBuf &d_off, uint64_t *h_off, uint64_t **h_vals,
     int rc = d_vals.alloc(total * 8);
     if (!rc) rc = fill(d_vals.as<uint64_t>());
     if (!rc) rc = d2h_result(*h_vals, d_vals.p, total * 8, st);
-    if (rc) { std::free(*h_vals); *h_vals = nullptr; }
+    if (rc) { rbg_free_buffer(*h_vals); *h_vals = nullptr; }
     return rc;
 }
 
@@ -2091,7 +2118,24 @@ void rbg_free(rbg_index *ix) {
     delete ix;
 }
 
-void rbg_free_buffer(void *p) { std::free(p); }
+void rbg_free_buffer(void *p) {
+    if (!p) return;
+    ResultPool &P = ResultPool::get();
+    {
+        std::lock_guard<std::mutex> g(P.mu);
+        auto it = P.live.find(p);
+        if (it != P.live.end()) {
+            const size_t size = it->second;
+            P.live.erase(it);
+            if (P.on && P.cached + size <= ResultPool::kMax) {
+                P.idle.emplace(size, p);
+                P.cached += size;
+                return;
+            }
+        }
+    }
+    std::free(p);
+}
 
 int rbg_info(const rbg_index *ix, rbg_info_t *out) {
     return guarded([&]() -> int {
@@ -3383,7 +3427,7 @@ static int marker_seeds_one(rbg_index *ix, const uint8_t *seq, uint64_t len, uin
                     const uint64_t m0 = s1 > s0 ? all[s0].mk_begin : 0, m1 = s1 > s0 ? all[s1 - 1].mk_end : 0;
                     auto *hs = static_cast<rbg_marker_seed_t *>(std::malloc(std::max<size_t>(1, (s1 - s0) * sizeof(rbg_marker_seed_t))));
                     auto *hm = static_cast<uint64_t *>(std::malloc(std::max<size_t>(1, (m1 - m0) * 8)));
-                    if (!hs || !hm) { std::free(hs); std::free(hm); rc2 = RBG_ENOMEM; break; }
+                    if (!hs || !hm) { std::free(hs); std::free(hm); rc2 = RBG_ENOMEM; break; }   // (plain malloc blocks)
                     for (uint64_t j = s0; j < s1; ++j) {
                         hs[j - s0] = all[j];
                         hs[j - s0].mk_begin -= m0;
@@ -3395,10 +3439,10 @@ static int marker_seeds_one(rbg_index *ix, const uint8_t *seq, uint64_t len, uin
                     batch[i]->mk = hm;
                 }
             }
-            std::free(all);
-            std::free(allmk);
+            rbg_free_buffer(all);
+            rbg_free_buffer(allmk);
             if (rc2)
-                for (SeedsReq *r : batch) { std::free(r->seeds); std::free(r->mk); r->seeds = nullptr; r->mk = nullptr; }
+                for (SeedsReq *r : batch) { rbg_free_buffer(r->seeds); rbg_free_buffer(r->mk); r->seeds = nullptr; r->mk = nullptr; }
             for (SeedsReq *r : batch) r->rc = rc2;
         });
     if (rc) return rc;
@@ -3450,7 +3494,7 @@ static int marker_seeds_host(rbg_index *ix, const uint8_t *seqs, const uint64_t 
     const uint64_t total_seeds = seed_off[N];
     auto *h_seeds = static_cast<rbg_marker_seed_t *>(alloc_result(total_seeds * sizeof(rbg_marker_seed_t)));
     auto *h_mk = static_cast<uint64_t *>(alloc_result(total_mk * 8));
-    if (!h_seeds || !h_mk) { std::free(h_seeds); std::free(h_mk); return RBG_ENOMEM; }
+    if (!h_seeds || !h_mk) { rbg_free_buffer(h_seeds); rbg_free_buffer(h_mk); return RBG_ENOMEM; }
     rc = RBG_OK;
     if (total_seeds) {
         if (!(rc = dseeds.alloc(total_seeds * sizeof(rbg_marker_seed_t))) && !(rc = dmk.alloc(total_mk ? total_mk * 8 : 8))) {
@@ -3462,7 +3506,7 @@ static int marker_seeds_host(rbg_index *ix, const uint8_t *seqs, const uint64_t 
             if (!rc && total_mk) rc = d2h_result(h_mk, dmk.p, total_mk * 8, st);
         }
     }
-    if (rc) { std::free(h_seeds); std::free(h_mk); return rc; }
+    if (rc) { rbg_free_buffer(h_seeds); rbg_free_buffer(h_mk); return rc; }
     *seeds = h_seeds;
     *mk = h_mk;
     return RBG_OK;
