@@ -857,7 +857,9 @@ def main():
         # the run-indexed layout (space proportional to r; wave-cooperative predecessor search): same batch, same outputs
         rb.close()
         torch.cuda.empty_cache()
-        with capi.default_option(capi.OPT_RANK_LAYOUT, capi.LAYOUT_RUNS):
+        # (run lists for all five k-mer depths in this row -- the roofline's instrumented counts are of this form; the rows
+        #  after it leave depths out: RBG_OPT_RUN_DEPTHS, 0x15 is the library's default)
+        with capi.default_option(capi.OPT_RANK_LAYOUT, capi.LAYOUT_RUNS), capi.default_option(capi.OPT_RUN_DEPTHS, 0x1F):
             rb = ra.RowBowt.from_runs(inp["heads"], inp["lens"], inp["ssa"], inp["esa"], device=local_rank)
         ms_r = time_search()
         step()
@@ -895,7 +897,7 @@ def main():
                                     "phi_steps": rs_loc["phi_steps"] / N, "phi_entries_probed": rs_loc["probe_entries"] / N},
                        "search": rs_toe, "locate": rs_loc}
         same = all(bool((a == b).all().item()) for a, b in zip(ref_out, (d_lo, d_hi, d_k, d_loc_off))) and bool((ref_locs == d_locs[:total_locs]).all().item())
-        rows.append({"layout": "runs", "symbols_per_gather": int(rb.info().kmer_steps), "hbm_bytes": int(rb.info().hbm_bytes), "ms": ms_r,
+        rows.append({"layout": "runs", "depths": [1, 2, 3, 4, 5][:int(rb.info().kmer_steps)], "symbols_per_gather": int(rb.info().kmer_steps), "hbm_bytes": int(rb.info().hbm_bytes), "ms": ms_r,
                      "identical_to_slot_path_on_the_whole_batch": same, "roofline": run_roof, "touched": run_touched,
                      "count_locate_reads_per_s": N / ((ms_r["k_find_range<toehold>"] + ms_r["k_locate_fill"] + ms_plan + ms_order) * 1e-3)})
         if args.markers:
@@ -914,6 +916,42 @@ def main():
             rows[-1]["other_kernels"] = {"runs_layout": run_other, "slot_layout": slot_other, "greedy_seeds_identical_to_slot_path": same_g,
                                          "marker_seed_counts_identical_to_slot_path": same_s}
             same = same and same_g and same_s
+        # the same layout with run lists for some of the k-mer depths only (RBG_OPT_RUN_DEPTHS; include/rbg.h): a step takes
+        # the longest stretch a kept depth covers -- the space of the depths left out against a step more per ragged stretch
+        for depth_mask in (() if not same else (0x15, 0x11)):
+            rb.close()
+            torch.cuda.empty_cache()
+            with capi.default_option(capi.OPT_RANK_LAYOUT, capi.LAYOUT_RUNS), capi.default_option(capi.OPT_RUN_DEPTHS, depth_mask):
+                rb = ra.RowBowt.from_runs(inp["heads"], inp["lens"], inp["ssa"], inp["esa"], device=local_rank)
+            ms_d = time_search()
+            step()
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            k_toehold(); k_plan(); k_order()
+            e[0].record(stream)
+            k_fill()
+            e[1].record(stream)
+            torch.cuda.synchronize()
+            ms_d["k_locate_fill"] = e[0].elapsed_time(e[1])
+            same_d = all(bool((a == b).all().item()) for a, b in zip(ref_out, (d_lo, d_hi, d_k, d_loc_off))) and bool((ref_locs == d_locs[:total_locs]).all().item())
+            row = {"layout": "runs", "depths": [d + 1 for d in range(5) if depth_mask >> d & 1], "symbols_per_gather": int(rb.info().kmer_steps),
+                   "hbm_bytes": int(rb.info().hbm_bytes), "ms": ms_d, "identical_to_slot_path_on_the_whole_batch": same_d,
+                   "count_locate_reads_per_s": N / ((ms_d["k_find_range<toehold>"] + ms_d["k_locate_fill"] + ms_plan + ms_order) * 1e-3)}
+            if args.markers:
+                rb.set_markers(*marker_arrays)
+                gstep()
+                same_g = all(bool((a == b).all().item()) for a, b in zip(ref_g, d_g))
+                sstep()
+                same_s = (int(d_soff[-1].item()), int(d_moff[-1].item())) == ref_seed_counts
+                other = {}
+                for name, fn in (("greedy_seed_ms", gstep), ("marker_seeds_ms", sstep)):
+                    e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                    e[0].record(stream); fn(); e[1].record(stream); fn(); e[2].record(stream)
+                    torch.cuda.synchronize()
+                    other[name] = min(e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2]))
+                row["other_kernels"] = {"runs_layout": other, "greedy_seeds_identical_to_slot_path": same_g, "marker_seed_counts_identical_to_slot_path": same_s}
+                same_d = same_d and same_g and same_s
+            rows.append(row)
+            same = same and same_d
         if not same:
             out["space_speed"] = {"rows": rows}
             print(json.dumps(out))

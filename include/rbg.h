@@ -472,7 +472,15 @@ enum { RBG_OPT_BLOCK_THREADS = 1, RBG_OPT_RANK_BUCKET_SHIFT = 2, RBG_OPT_PHI_BUC
        RBG_OPT_DEEP_BUCKET_SHIFT = 9, RBG_OPT_DENSE_OVERFLOW = 10, RBG_OPT_RANK_LAYOUT = 11, RBG_OPT_TREE_TOP_KB = 12,
        RBG_OPT_SLOT_BYTES = 13 /* 16 (default) or 64: 64-byte rank slots over four times the rows -- the sector a 16-byte
                                   gather moves anyway, fetched by a quad of lanes; slot layout only, falls
-                                  back to 16 when a table needs wide buckets; rbg_info().slot_bytes says what was built */ };
+                                  back to 16 when a table needs wide buckets; rbg_info().slot_bytes says what was built */,
+       RBG_OPT_RUN_DEPTHS = 14 /* run-indexed layout: bit d - 1 set = keep run lists for the k-mer depth d (bit 0 is implied; depths
+                                  above the highest bit are not built).  A search step consumes the longest stretch a kept
+                                  depth covers, so any set gives the same answers; the lists grow with the depth (DESIGN.md
+                                  2c).  0 = default: every other depth counted down from RBG_OPT_KMER_STEPS (1, 3, 5 of
+                                  five: 62 % of the space of all five at n = 5e10, the same rate on 150 bp reads, one step
+                                  more for a stretch of 2 or 4 symbols); 0x1F keeps all five; over budget the depths
+                                  between the first and the deepest go before the deepest does.  rbg_info(): kmer_steps is
+                                  the deepest depth kept, pair_runs .. quint_runs are 0 for the depths left out */ };
 int rbg_set_default_option(int opt, int64_t value);
 /* the value a later load would use (so that a caller can change a knob for one load and put it back) */
 int rbg_get_default_option(int opt, int64_t *value);

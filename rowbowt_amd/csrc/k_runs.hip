@@ -75,7 +75,7 @@ __global__ __launch_bounds__(512, sizeof(P) == 4 ? 4 : 3) void k_find_range_runs
             if (s_lut2[t] != 0xFFu) s_mslot[s_lut2[t] & 3u] = s_lut[t];   // major index -> symbol slot
         __syncthreads();
     }
-    const uint32_t D = ix.run_ksteps;
+    const uint32_t D = ix.run_ksteps, DMASK = ix.run_depth_mask | 1u;
     const uint32_t M = ix.nmajor;
     const uint32_t lane = threadIdx.x & (kWave - 1);
 
@@ -136,6 +136,7 @@ __global__ __launch_bounds__(512, sizeof(P) == 4 ? 4 : 3) void k_find_range_runs
             if (stepping) {
                 if (PACKED) {
                     adv = p < D ? static_cast<uint32_t>(p) : D;
+                    adv = 32u - static_cast<uint32_t>(__clz(DMASK & ((2u << (adv - 1)) - 1u)));   // the deepest depth kept that fits
                     const uint32_t v = bs.take(2 * adv);
                     rec = run_record(s_tab_first, adv, adv == 1 ? static_cast<uint32_t>(s_mslot[v]) : v);
                     d = adv - 1;
@@ -147,16 +148,16 @@ __global__ __launch_bounds__(512, sizeof(P) == 4 ? 4 : 3) void k_find_range_runs
                     const uint32_t m0 = s_lut2[c];
                     uint32_t acc = m0;
                     if (m0 != 0xFFu) {                          // the longest run of major symbols among the next D (k_search.hip)
-                        uint32_t pw = M;
+                        uint32_t pw = M, run_acc = m0;            // (of its prefixes, the longest whose depth has run lists)
 #pragma unroll 1
                         for (uint32_t t = 1; t < static_cast<uint32_t>(kMaxRunDepth); ++t) {
                             if (t >= D || p < beg + t) break;
                             const uint32_t mm = s_lut2[rd.at(p - t)];
                             if (STATS && p - t < p_min) p_min = p - t;
                             if (mm == 0xFFu) break;
-                            acc += mm * pw;
+                            run_acc += mm * pw;
                             pw *= M;
-                            adv = t + 1;
+                            if ((DMASK >> t) & 1u) { adv = t + 1; acc = run_acc; }
                         }
                     }
                     if (adv == 1) {

@@ -44,21 +44,21 @@ struct StepPick {
     bool ok;
 };
 __device__ __forceinline__ StepPick pick_step(ByteCursor &rd, const uint8_t *s_lut, const uint8_t *s_lut2, const uint32_t *s_tab_first,
-                                              const uint64_t p, const uint64_t cap, const uint32_t D, const uint32_t M) {
+                                              const uint64_t p, const uint64_t cap, const uint32_t D, const uint32_t DMASK, const uint32_t M) {
     StepPick s{1u, 0u, 0u, true};
     const uint32_t c = rd.at(p);
     const uint32_t m0 = s_lut2[c];
     uint32_t acc = m0;
     if (m0 != 0xFFu) {
-        uint32_t pw = M;
+        uint32_t pw = M, run_acc = m0;   // (the longest prefix of the run whose depth has run lists: DevIndex::run_depth_mask)
 #pragma unroll 1
         for (uint32_t t = 1; t < static_cast<uint32_t>(kMaxRunDepth); ++t) {
             if (t >= D || t >= cap) break;
             const uint32_t mm = s_lut2[rd.at(p - t)];
             if (mm == 0xFFu) break;
-            acc += mm * pw;
+            run_acc += mm * pw;
             pw *= M;
-            s.adv = t + 1;
+            if ((DMASK >> t) & 1u) { s.adv = t + 1; acc = run_acc; }
         }
     }
     if (s.adv == 1) {
@@ -100,7 +100,7 @@ __device__ __forceinline__ bool ftab_state(const DevIndex &ix, ByteCursor &rd, c
         s_lut2[t] = ix.nmajor ? ix.lut2[t] : 0xFFu;                                               \
     }                                                                                             \
     const RunSearch<P> S = stage_run_search<P, WAVES>(ix, s_tree, s_tab_first, s_rec, s_req, s_dyn); \
-    const uint32_t D = ix.run_ksteps, M = ix.nmajor;                                              \
+    const uint32_t D = ix.run_ksteps, DMASK = ix.run_depth_mask | 1u, M = ix.nmajor;              \
     const uint32_t lane = threadIdx.x & (kWave - 1);                                              \
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;                        \
     const uint64_t wave_first = static_cast<uint64_t>(blockIdx.x) * blockDim.x + (threadIdx.x & ~(kWave - 1))
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(512, sizeof(P) == 4 ? 4 : 3) void k_lf_runs(const D
                                                                         const uint64_t *__restrict__ hi_in, const uint8_t *__restrict__ sym,
                                                                         const uint64_t N, uint64_t *__restrict__ lo_out, uint64_t *__restrict__ hi_out) {
     RBG_SEED_KERNEL_PROLOGUE(P, 8);
-    (void)D; (void)M; (void)s_lut2;
+    (void)D; (void)DMASK; (void)M; (void)s_lut2;
     for (uint64_t base = wave_first; base < N; base += stride) {
         const uint64_t i = base + lane;
         const bool valid = i < N;
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(512, sizeof(P) == 4 ? 4 : 3) void k_find_range_mark
                                                             uint64_t *__restrict__ cnt_out,
                                                             const uint64_t *__restrict__ mk_off, uint64_t *__restrict__ mk) {
     RBG_SEED_KERNEL_PROLOGUE(P, 8);
-    (void)D; (void)M;
+    (void)D; (void)DMASK; (void)M;
     if (!FILL && blockIdx.x == 0 && threadIdx.x == 0) cnt_out[0] = 0;
     for (uint64_t base = wave_first; base < N; base += stride) {
         const uint64_t i = base + lane;
@@ -251,10 +251,10 @@ __global__ __launch_bounds__(512, sizeof(P) == 4 ? 4 : 3) void k_greedy_seed_run
                 if (nlen == 0) {
                     // a fresh seed: the state after its first ftab_k symbols is one gather in the device table
                     if (j == ei && ix.ftab_k && j >= ix.ftab_k && ftab_state<P>(ix, rd, s_lut2, p, M, lo, hi, k)) { on_ok(ix.ftab_k); continue; }
-                    pick = pick_step(rd, s_lut, s_lut2, s_tab_first, p, j, D, M);
+                    pick = pick_step(rd, s_lut, s_lut2, s_tab_first, p, j, D, DMASK, M);
                     if (!pick.ok) { on_fail(); continue; }
                 } else {
-                    pick = pick_step(rd, s_lut, s_lut2, s_tab_first, p, nlen / 2, D, M);   // == nlen / 2 symbols: the window holds k-mer symbols only
+                    pick = pick_step(rd, s_lut, s_lut2, s_tab_first, p, nlen / 2, D, DMASK, M);   // == nlen / 2 symbols: the window holds k-mer symbols only
                 }
                 stepping = true;
             }
@@ -385,10 +385,10 @@ __global__ __launch_bounds__(512, sizeof(P) == 4 ? 4 : 3) void k_marker_seeds_ru
                     if (dist == 0) dist = 1;
                     const uint64_t cap = dist < j ? dist : j;
                     if (j == seed_ei && ix.ftab_k && cap >= ix.ftab_k && ftab_state<P>(ix, rd, s_lut2, p, M, lo, hi, unused_k)) { on_ok(ix.ftab_k); continue; }
-                    pick = pick_step(rd, s_lut, s_lut2, s_tab_first, p, cap, D, M);
+                    pick = pick_step(rd, s_lut, s_lut2, s_tab_first, p, cap, D, DMASK, M);
                     if (!pick.ok) { on_fail(); continue; }
                 } else {
-                    pick = pick_step(rd, s_lut, s_lut2, s_tab_first, p, nlen / 2, D, M);
+                    pick = pick_step(rd, s_lut, s_lut2, s_tab_first, p, nlen / 2, D, DMASK, M);
                 }
                 stepping = true;
             }

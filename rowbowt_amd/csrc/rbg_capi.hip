@@ -59,6 +59,7 @@ struct rbg_index {
     uint64_t rank_slots = 0, rank_slots_overflow = 0, phi_slots = 0, phi_slots_overflow = 0;
     uint64_t kmer_steps_requested = 0, hbm_free_at_load = 0, hbm_budget = 0;  // how the space/speed point was chosen (rbg_info)
     bool runs_layout = false;
+    uint32_t run_depth_mask = 0;   // run-indexed layout: the k-mer depths that have run lists (bit d - 1)
     // one-read host calls from concurrent threads are combined into one launch ("group commit", see Combiner below)
     struct Combiner {
         std::mutex mu;
@@ -99,6 +100,7 @@ std::atomic<int64_t> g_opt_deep_shift{-1};
 std::atomic<int64_t> g_opt_dense_overflow{1};
 std::atomic<int64_t> g_opt_rank_layout{0};    // RBG_LAYOUT_AUTO / _SLOTS / _RUNS
 std::atomic<int64_t> g_opt_tree_top_kb{48};   // LDS the staged top levels of the run-indexed search may take per workgroup
+std::atomic<int64_t> g_opt_run_depths{0};    // run-indexed layout: bit d - 1 = keep the k-mer depth d (0 = every other depth from the deepest down)
 std::atomic<int64_t> g_opt_slot_bytes{16};    // 16: RankSlot; 64: RankSlot64 (experiment: rbg_dev.h)
 std::atomic<int64_t> g_opt_packed_reads{1};  // host-pointer calls: 0 bytes over PCIe, 1 (default) 2-bit codes for batches >= 4096, 2 always
 
@@ -618,12 +620,15 @@ double rank_rec_target() {
     return t >= 1.0 ? t : 0.0;
 }
 
-// bytes of the run-indexed replica with the k-mer depths h holds (run lists, samples, 1/15 of sampled keys, phi)
+// bytes of the run-indexed replica with the k-mer depths of `mask` (bit d - 1) among those h holds (run lists, samples,
+// 1/15 of sampled keys, phi)
 template <typename P>
-size_t runs_replica_bytes(const HostIndex &h) {
+size_t runs_replica_bytes(const HostIndex &h, uint32_t mask = ~0u) {
     size_t total = 0;
     const double rec_target = rank_rec_target();
+    uint32_t di = 0;
     for (const std::vector<SymTable> *lv : {&h.sym, &h.pair, &h.triple, &h.quad, &h.quint}) {
+        if (!((mask | 1u) >> di++ & 1u)) continue;
         size_t entries = 0;
         for (const SymTable &t : *lv) entries += t.nruns + 1;
         total += entries * (RunsFmt<P>::ent_bytes + (h.has_tsa ? RunsFmt<P>::samp_bytes : 0)) + entries * sizeof(P) / 15 + entries * 2 + lv->size() * 8 + 8 * kArenaAlign;   // (+ directories: at most half an entry per run)
@@ -635,6 +640,7 @@ size_t runs_replica_bytes(const HostIndex &h) {
 
 template <typename P> int materialize_kmer_levels(rbg_index *ix);
 void release_kmer_level(rbg_index *ix, uint32_t depth);
+std::vector<SymTable> &kmer_level_tables(HostIndex &h, uint32_t depth);
 
 template <typename P>
 int upload_tables_runs(rbg_index *ix) {
@@ -663,6 +669,12 @@ int upload_tables_runs(rbg_index *ix) {
     // the bench index's deepest level, 5e8 at r = 3e8)
     while (D > 1 && sizes[D - 1] >= 0xFFFFFFF0ull) { --D; sizes.pop_back(); }
     if (sizes[0] >= 0xFFFFFFF0ull) return RBG_EARG;
+    // depths without run lists (rbg_index::run_depth_mask; the deepest is always kept: the kernels step by it)
+    uint32_t mask = (ix->run_depth_mask ? ix->run_depth_mask : ~0u) & ((1u << D) - 1u);
+    mask |= 1u | (1u << (D - 1));
+    std::vector<uint64_t> kept_sizes;
+    for (uint32_t d = 0; d < D; ++d)
+        if (mask >> d & 1u) kept_sizes.push_back(sizes[d]);
     const char *e_rdir = std::getenv("RBG_RANK_DIR");   // "0": ranks by the descent only (A/B measurements, tests)
     const bool use_dirs = !(e_rdir && e_rdir[0] == '0');
     const double rec_target = rank_rec_target();   // bucket records (rbg_dev.h RunRec)
@@ -671,7 +683,7 @@ int upload_tables_runs(rbg_index *ix) {
     const double dir_target = e_dt && std::atof(e_dt) > 0 ? std::atof(e_dt) : 4.0;
     const bool use_recs = rec_target > 0;
     // with the directories the descent is the rare path: half the LDS for its top level leaves room for the table records
-    const uint32_t nlvl = tree_levels_for(sizes, use_dirs && budget_keys > 64 ? std::max<uint64_t>(64, budget_keys / 2) : budget_keys);
+    const uint32_t nlvl = tree_levels_for(kept_sizes, use_dirs && budget_keys > 64 ? std::max<uint64_t>(64, budget_keys / 2) : budget_keys);
     if (nlvl > kMaxTreeLevels) return RBG_EARG;
     std::vector<DevSym> syms(h.sym.size());
     std::vector<DevTree> trees(D);
@@ -682,6 +694,16 @@ int upload_tables_runs(rbg_index *ix) {
         // the depth's tables back to back: entries {start, cum} (each table ends with its sentinel {n, total}), samples alongside
         const std::vector<SymTable> &T = *depth[d];
         const uint64_t entries = sizes[d];
+        if (!(mask >> d & 1u)) {   // no run lists at this depth: no records, nothing to step by
+            release_kmer_level(ix, d + 1);
+            for (SymTable &st : kmer_level_tables(h, d + 1)) st.dev_ent = st.dev_samp = nullptr;
+            ix->dev.run_samp[d] = nullptr;
+            ix->dev.run_dir[d] = nullptr;
+            ix->dev.run_rec[d] = nullptr;
+            ix->dev.run_tab_first[d] = static_cast<uint32_t>(tabs.size());
+            trees[d] = DevTree{};
+            continue;
+        }
         ComposedLevel *L = (d >= 1 && d - 1 < ix->kmer_levels.size() && ix->kmer_levels[d - 1].ent) ? &ix->kmer_levels[d - 1] : nullptr;
         if (L) {   // ---- the level is on the device already ----
             if (L->entries != entries || L->first.size() != T.size()) return RBG_EARG;
@@ -917,6 +939,8 @@ int upload_tables_runs(rbg_index *ix) {
     ix->dev.run_tabs = static_cast<const DevRunTab *>(p);
     ix->dev.run_ntabs = static_cast<uint32_t>(tabs.size());
     ix->dev.run_ksteps = D;
+    ix->dev.run_depth_mask = mask;
+    ix->run_depth_mask = mask;
     if ((rc = dev_upload(ix, top_all.data(), top_all.size() * sizeof(P), &ix->dev.tree_top))) return rc;
     ix->dev.tree_top_n = static_cast<uint32_t>(top_all.size());
     ix->dev.tree_nlvl = nlvl;
@@ -1131,7 +1155,7 @@ int materialize_kmer_levels(rbg_index *ix) {
         if (d - 2 >= ix->kmer_levels.size() || !ix->kmer_levels[d - 2].ent) continue;
         ComposedLevel &L = ix->kmer_levels[d - 2];
         std::vector<SymTable> &tabs = kmer_level_tables(h, d);
-        if (tabs.empty()) { release_kmer_level(ix, d); continue; }
+        if (tabs.empty() || (ix->run_depth_mask && !(ix->run_depth_mask >> (d - 1) & 1u))) { release_kmer_level(ix, d); continue; }
         std::vector<RunEnt<P>> ent(L.entries);
         std::vector<P> samp(L.samp ? L.entries : 0);
         HIP_TRY(hipMemcpy(ent.data(), L.ent, L.entries * sizeof(RunEnt<P>), hipMemcpyDeviceToHost));
@@ -1221,13 +1245,39 @@ int upload(rbg_index *ix) {
         // the k-mer depths stay (their run lists are O(r) too: DevRunTab, rbg_dev.h); the deepest goes while the replica
         // exceeds the budget
         if (ix->kmer_steps_requested == 0) ix->kmer_steps_requested = static_cast<uint64_t>(levels());
-        auto need_runs = [&] { return h.pos_bytes == 4 ? runs_replica_bytes<uint32_t>(h) : runs_replica_bytes<uint64_t>(h); };
-        while (need_runs() > budget && !h.pair.empty()) {
-            std::vector<SymTable> &deepest = !h.quint.empty() ? h.quint : !h.quad.empty() ? h.quad : !h.triple.empty() ? h.triple : h.pair;
+        // RBG_OPT_RUN_DEPTHS: a step needs no table of every depth below the deepest -- a stretch of 4 symbols is a depth-3
+        // step and a single one where depth 4 is left out -- and the deepest lists are the largest (2.4 entries
+        // per run at depth 5 of the H = 200 pangenome, 9.3 over the five).  Over budget the depths between the first and the
+        // deepest go first (deepest of them first), then the deepest itself.
+        // Default: every other depth counted from the deepest (1, 3, 5 of five) -- two thirds of the space and the same
+        // rate on whole reads, a few per cent more steps where stretches are ragged (marker seeds); 0x1F keeps them all.
+        uint32_t mask = g_opt_run_depths.load() ? static_cast<uint32_t>(g_opt_run_depths.load()) | 1u : 1u;
+        if (!g_opt_run_depths.load())
+            for (int d = levels(); d >= 1; d -= 2) mask |= 1u << (d - 1);
+        auto deepest_of = [&]() -> std::vector<SymTable> & { return !h.quint.empty() ? h.quint : !h.quad.empty() ? h.quad : !h.triple.empty() ? h.triple : h.pair; };
+        while (levels() > 1 && !(mask >> (levels() - 1) & 1u)) drop_kmer_level(ix, deepest_of());   // (nothing steps by a depth above the deepest kept)
+        mask &= (1u << levels()) - 1u;
+        auto need_runs = [&] { return h.pos_bytes == 4 ? runs_replica_bytes<uint32_t>(h, mask) : runs_replica_bytes<uint64_t>(h, mask); };
+        while (need_runs() > budget && levels() > 1) {
+            uint32_t mid = 0;
+            for (int d = levels() - 1; d >= 2 && !mid; --d)
+                if (mask >> (d - 1) & 1u) mid = static_cast<uint32_t>(d);
+            if (mid) {
+                std::fprintf(stderr, "rbg: run-indexed replica of %.1f GB exceeds the %.1f GB budget: leaving out the run lists of depth %u\n", need_runs() / 1e9, budget / 1e9, mid);
+                mask &= ~(1u << (mid - 1));
+                continue;
+            }
             std::fprintf(stderr, "rbg: run-indexed replica of %.1f GB exceeds the %.1f GB budget: dropping the %zu-table k-mer level\n",
-                         need_runs() / 1e9, budget / 1e9, deepest.size());
-            drop_kmer_level(ix, deepest);
+                         need_runs() / 1e9, budget / 1e9, deepest_of().size());
+            drop_kmer_level(ix, deepest_of());
+            mask = (mask & ((1u << levels()) - 1u)) | (1u << (levels() - 1));   // (the new deepest level is stepped by again)
         }
+        for (int d = 2; d < levels(); ++d)   // the depths left out give their device arrays back now
+            if (!(mask >> (d - 1) & 1u)) {
+                release_kmer_level(ix, static_cast<uint32_t>(d));
+                for (SymTable &st : kmer_level_tables(h, static_cast<uint32_t>(d))) st.dev_ent = st.dev_samp = nullptr;
+            }
+        ix->run_depth_mask = mask;
     }
     ix->kmer_steps_requested = std::max<uint64_t>(ix->kmer_steps_requested, static_cast<uint64_t>(levels()));  // options_for() may have capped the depth already
     ix->hbm_free_at_load = free_b;
@@ -1268,7 +1318,8 @@ int upload(rbg_index *ix) {
     if (std::getenv("RBG_VERBOSE") || static_cast<uint64_t>(levels()) != ix->kmer_steps_requested)
         std::fprintf(stderr, "rbg: device %d: %.1f GB free, replica budget %.1f GB: keeping %d of %llu symbol(s) per %s (%.1f GB)\n", ix->device,
                      free_b / 1e9, budget / 1e9, levels(), static_cast<unsigned long long>(ix->kmer_steps_requested), runs_layout ? "search step" : "gather",
-                     (runs_layout ? (h.pos_bytes == 4 ? runs_replica_bytes<uint32_t>(h) : runs_replica_bytes<uint64_t>(h)) : need()) / 1e9);
+                     (runs_layout ? (h.pos_bytes == 4 ? runs_replica_bytes<uint32_t>(h, ix->run_depth_mask) : runs_replica_bytes<uint64_t>(h, ix->run_depth_mask)) : need()) / 1e9);
+    if (runs_layout && std::getenv("RBG_VERBOSE")) std::fprintf(stderr, "rbg: device %d: k-mer depths with run lists: mask 0x%x\n", ix->device, ix->run_depth_mask);
     int rc;
     d.layout = RBG_LAYOUT_SLOTS;
     d.slot_bytes = t_slot64 ? 64 : 16;
@@ -1787,6 +1838,9 @@ int rbg_set_default_option(int opt, int64_t value) {
         case RBG_OPT_SLOT_BYTES:
             if (value != 16 && value != 64) return RBG_EARG;
             g_opt_slot_bytes = value; return RBG_OK;
+        case RBG_OPT_RUN_DEPTHS:
+            if (value < 0 || value >= (1 << kMaxRunDepth)) return RBG_EARG;
+            g_opt_run_depths = value; return RBG_OK;
         default: return RBG_EARG;
     }
     });
@@ -1809,6 +1863,7 @@ int rbg_get_default_option(int opt, int64_t *value) {
         case RBG_OPT_RANK_LAYOUT: *value = g_opt_rank_layout.load(); return RBG_OK;
         case RBG_OPT_TREE_TOP_KB: *value = g_opt_tree_top_kb.load(); return RBG_OK;
         case RBG_OPT_SLOT_BYTES: *value = g_opt_slot_bytes.load(); return RBG_OK;
+        case RBG_OPT_RUN_DEPTHS: *value = g_opt_run_depths.load(); return RBG_OK;
         default: return RBG_EARG;
     }
     });
@@ -2172,6 +2227,13 @@ int rbg_info(const rbg_index *ix, rbg_info_t *out) {
     for (const SymTable &t : ix->H().triple) out->triple_runs += t.nruns;
     for (const SymTable &t : ix->H().quad) out->quad_runs += t.nruns;
     for (const SymTable &t : ix->H().quint) out->quint_runs += t.nruns;
+    if (ix->device != RBG_DEVICE_NONE && ix->dev.layout == RBG_LAYOUT_RUNS) {   // depths left without run lists (RBG_OPT_RUN_DEPTHS) report none
+        const uint32_t m = ix->dev.run_depth_mask;
+        if (!(m >> 1 & 1u)) out->pair_runs = 0;
+        if (!(m >> 2 & 1u)) out->triple_runs = 0;
+        if (!(m >> 3 & 1u)) out->quad_runs = 0;
+        if (!(m >> 4 & 1u)) out->quint_runs = 0;
+    }
     return RBG_OK;
     });
 }
@@ -3627,6 +3689,7 @@ int replicate_begin(rbg_index *src, int device, ReplicaJob &job) {
     r->cfg = src->cfg;
     r->cfg.max_blocks = prop.multiProcessorCount * 32;
     r->runs_layout = src->runs_layout;
+    r->run_depth_mask = src->run_depth_mask;
     r->rank_slots = src->rank_slots; r->rank_slots_overflow = src->rank_slots_overflow;
     r->phi_slots = src->phi_slots; r->phi_slots_overflow = src->phi_slots_overflow;
     r->kmer_steps_requested = src->kmer_steps_requested;

@@ -281,7 +281,7 @@ struct DevIndex {
     // levels; a bucket with more than 15 sampled positions is narrowed by pivot probes first.  nullptr: descent only.
     const uint32_t *phi_dir;
     uint32_t phi_dir_shift;
-    uint32_t pad5;
+    uint32_t run_depth_mask;   // bit d - 1: the k-mer depth d has run lists (bit 0 always; RBG_OPT_RUN_DEPTHS / the budget rule may leave depths out)
     const RunRec *run_rec[kMaxRunDepth];  // per depth: the tables' bucket records back to back; nullptr = directory / descent
 };
 

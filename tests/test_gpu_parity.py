@@ -1853,9 +1853,12 @@ def test_run_indexed_layout(synth, pos_bytes, top_kb, fk, ks, rec):
         os.environ["RBG_RANK_DIR"] = "0"  # ranks likewise
     if rec is not None:
         os.environ["RBG_RANK_REC"] = rec
+    if rec is not None or ks == 4:   # run lists at every depth (otherwise the default: every other depth from the deepest down)
+        ra.set_default_option(capi.OPT_RUN_DEPTHS, (1 << ks) - 1)
     try:
         rb = _with_layout(capi.LAYOUT_RUNS, top_kb, lambda: ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0))
     finally:
+        ra.set_default_option(capi.OPT_RUN_DEPTHS, 0)
         ra.set_default_option(capi.OPT_POS_BYTES, 0)
         ra.set_default_option(capi.OPT_FTAB_K, -1)
         ra.set_default_option(capi.OPT_KMER_STEPS, 5)
@@ -1866,6 +1869,8 @@ def test_run_indexed_layout(synth, pos_bytes, top_kb, fk, ks, rec):
     info = rb.info()
     assert info.rank_layout == capi.LAYOUT_RUNS and info.kmer_steps == ks and info.pos_bytes == (pos_bytes or 4)
     assert info.rank_slots == 0 and info.phi_slots == 0
+    lists = [d for d, x in ((2, info.pair_runs), (3, info.triple_runs), (4, info.quad_runs), (5, info.quint_runs)) if x]
+    assert lists == ([d for d in range(2, ks + 1)] if rec is not None or ks == 4 else [d for d in range(2, ks + 1) if (ks - d) % 2 == 0])
     reads = S.sample_reads(3000, 60, seed=5, sub_rate=0.15, ragged=True)
     reads += [b"", b"A", b"N", b"ACGTN", b"NACGT", b"ACNGT", b"AC", b"ACG", b"acgt", bytes([1]), bytes([255]) * 3, bytes([0]),
               S.text[:500].tobytes(), S.text[:501].tobytes(), b"A" + bytes([1]), bytes([1]) + b"A",
@@ -2041,6 +2046,130 @@ def test_run_indexed_layout_built_on_the_device_equals_the_host_build(synth, pos
     o.close()
     dev.close()
     host.close()
+
+
+@pytest.mark.parametrize("pos_bytes,mask,kept,host_build", [(0, 0, 0x15, False), (0, 0x15, 0x15, False), (8, 0x11, 0x11, False), (0, 0x13, 0x13, True),
+                                                             (8, 0x0A, 0x0B, False), (0, 0x1E, 0x1F, False), (8, 0x15, 0x15, True)])
+def test_run_indexed_layout_sparse_depths(synth, pos_bytes, mask, kept, host_build):
+    """RBG_OPT_RUN_DEPTHS: run lists for some of the k-mer depths only (bit d - 1; depth 1 always, nothing above the
+    highest bit).  A step takes the longest stretch a kept depth covers (k_runs.hip, k_runs_seeds.hip pick_step), so the
+    answers are those of every other layout -- the oracle's -- in less space.  Both ways of building the layout."""
+    S = synth
+    ra.set_default_option(capi.OPT_POS_BYTES, pos_bytes)
+    if host_build:
+        os.environ["RBG_RUNS_HOST_BUILD"] = "1"
+    try:
+        with capi.default_option(capi.OPT_RUN_DEPTHS, 0x1F):
+            full = _with_layout(capi.LAYOUT_RUNS, 48, lambda: ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0))
+        with capi.default_option(capi.OPT_RUN_DEPTHS, mask):
+            rb = _with_layout(capi.LAYOUT_RUNS, 48, lambda: ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0))
+    finally:
+        ra.set_default_option(capi.OPT_POS_BYTES, 0)
+        os.environ.pop("RBG_RUNS_HOST_BUILD", None)
+    fi, info = full.info(), rb.info()
+    runs_full = [fi.r, fi.pair_runs, fi.triple_runs, fi.quad_runs, fi.quint_runs]
+    runs_kept = [info.r, info.pair_runs, info.triple_runs, info.quad_runs, info.quint_runs]
+    assert info.rank_layout == capi.LAYOUT_RUNS and info.kmer_steps == kept.bit_length() and fi.kmer_steps == 5
+    assert runs_kept == [x if kept >> d & 1 else 0 for d, x in enumerate(runs_full)]   # (rbg_info: the depths left out report no runs)
+    if kept != 0x1F:
+        assert info.hbm_bytes < fi.hbm_bytes
+    o = orc.Oracle.from_runs(S.heads, S.lens, S.ssa, S.esa)
+    reads = S.sample_reads(3000, 60, seed=9, sub_rate=0.12, ragged=True)
+    reads += [b"", b"A", b"N", b"ACGTN", b"NACGT", b"ACNGT", b"AC", b"ACG", b"ACGT", b"ACGTA", b"ACGTAC", b"acgt", bytes([1]), bytes([0]),
+              S.text[:500].tobytes(), S.text[:501].tobytes(), S.text[:502].tobytes(), S.text[:503].tobytes(), S.text[:504].tobytes(),
+              S.text[-30:].tobytes(), S.text[-31:-1].tobytes(), S.text[-2:].tobytes()]
+    seqs, off = ra.pack_reads(reads)
+    wlo, whi, wk = o.find_range_w_toehold_batch(seqs, off)
+    for b in (rb, full):
+        lo, hi, k = b.find_range_w_toehold(seqs, off)
+        lo1, hi1 = b.find_range(seqs, off)
+        assert (lo == wlo).all() and (hi == whi).all() and (k == wk).all()
+        assert (lo1 == wlo).all() and (hi1 == whi).all()
+    with capi.default_option(capi.OPT_PACKED_READS, 0):   # the byte form of the kernels (reads cross as bytes)
+        lo, hi, k = rb.find_range_w_toehold(seqs, off)
+        assert (lo == wlo).all() and (hi == whi).all() and (k == wk).all()
+    loc_off, locs = rb.locs_at(lo, hi, k, 30)
+    woff, wlocs = o.locs_at_batch(wlo, whi, wk, 30)
+    assert (loc_off == woff).all() and (locs == wlocs).all()
+    ms, me, mo, mv = S.markers(wsize=10)
+    rb.set_markers(ms, me, mo, mv)
+    o.set_markers(ms, me, mo, mv)
+    nseed, nmk = _check_marker_seeds(rb, o, reads[:300] + reads[-22:], 10, 1000)
+    assert nseed > 330 and nmk > 20
+    goff, glocs = rb.find_locs_greedy_seeding(*ra.pack_reads(reads[:200] + reads[-22:]), 10)
+    for i, q in enumerate(reads[:200] + reads[-22:]):
+        assert glocs[int(goff[i]):int(goff[i + 1])].tolist() == o.greedy_locate(q, 10)[0]
+    sub = reads[:300] + reads[-22:]
+    s3, o3 = ra.pack_reads(sub)
+    for wsize, max_range in ((10, MAXU), (7, 4)):
+        lo3, hi3, mk_off3, mk3 = rb.find_range_w_markers(s3, o3, wsize, max_range)
+        got3 = split(mk_off3, mk3)
+        for i, q in enumerate(sub):
+            (wl, wh), wm = o.find_range_w_markers(q, wsize, max_range)
+            assert (int(lo3[i]), int(hi3[i])) == (wl, wh) and got3[i] == wm, (i, q, wsize)
+    # the copy made for another handle (rbg_replicate) carries the same depths
+    rep = rb.replicate(0)
+    ri = rep.info()
+    assert ri.kmer_steps == info.kmer_steps and [ri.pair_runs, ri.triple_runs, ri.quad_runs, ri.quint_runs] == runs_kept[1:]
+    lo, hi, k = rep.find_range_w_toehold(seqs, off)
+    assert (lo == wlo).all() and (hi == whi).all() and (k == wk).all()
+    rep.close()
+    rb.close()
+    full.close()
+    o.close()
+
+
+def test_run_indexed_layout_budget_leaves_middle_depths_out():
+    """Over budget the run-indexed layout gives up the depths between the first and the deepest before the deepest
+    itself (rbg_capi.hip upload): the step length stays, the space goes down, the answers stay.  (A synthetic run list of
+    a million runs: the budget option counts MB.)"""
+    rng = np.random.default_rng(41)
+    heads, lens, ssa, esa, n = _random_run_index(rng, 1_000_000, 200)
+    def build():   # (without the device ftab: the budget is about the run lists)
+        with capi.default_option(capi.OPT_FTAB_K, 0), capi.default_option(capi.OPT_RUN_DEPTHS, depths[0]):
+            return _with_layout(capi.LAYOUT_RUNS, 48, lambda: ra.RowBowt.from_runs(heads, lens, ssa, esa, device=0))
+    depths = [0x1F]   # asked for: all five, unless stated
+    full = build()
+    hb = {}
+    for mask in (0x11, 0x17, 0x09):   # depths {1,5}, {1,2,3,5}, {1,4}
+        depths[0] = mask
+        x = build()
+        hb[mask] = int(x.info().hbm_bytes)
+        x.close()
+    depths[0] = 0x1F
+    fi = full.info()
+    hb_full, d4 = int(fi.hbm_bytes), int(fi.hbm_bytes) - hb[0x17]
+    assert d4 > (12 << 20) and hb[0x09] + (8 << 20) < hb[0x11] < hb[0x17], (hb, hb_full)   # (the estimate rounds up by a few MB)
+    # half of depth 4 too much: depth 4 alone pays for it
+    with capi.default_option(capi.OPT_HBM_BUDGET_MB, (hb_full - d4 // 2) >> 20):
+        rb4 = build()
+    i4 = rb4.info()
+    assert i4.kmer_steps == 5 and i4.quad_runs == 0 and i4.triple_runs == fi.triple_runs > 0 and i4.pair_runs == fi.pair_runs > 0
+    assert abs(int(i4.hbm_bytes) - hb[0x17]) < (1 << 20)
+    # room for the first and the deepest and half of depth 4: depths 4, 3 and 2 go, in that order, and the deepest stays
+    with capi.default_option(capi.OPT_HBM_BUDGET_MB, (hb[0x11] + d4 // 2) >> 20):
+        rb = build()
+    info = rb.info()
+    assert info.rank_layout == capi.LAYOUT_RUNS and info.kmer_steps == 5 and info.quint_runs == fi.quint_runs > 0
+    assert info.quad_runs == info.triple_runs == info.pair_runs == 0 and abs(int(info.hbm_bytes) - hb[0x11]) < (1 << 20)
+    # less than the first and the deepest need: the deepest goes, and the one below it is stepped by again
+    with capi.default_option(capi.OPT_HBM_BUDGET_MB, (hb[0x11] + hb[0x09]) // 2 >> 20):
+        rb3 = build()
+    i3 = rb3.info()
+    assert i3.kmer_steps in (3, 4) and i3.quint_runs == 0 and i3.pair_runs == 0 and int(i3.hbm_bytes) <= hb[0x09] + (1 << 20)
+    assert (i3.quad_runs == fi.quad_runs and i3.triple_runs == 0) if i3.kmer_steps == 4 else (i3.quad_runs == 0 and i3.triple_runs == fi.triple_runs)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    reads = [acgt[rng.integers(0, 4, int(rng.integers(1, 16)))].tobytes() for _ in range(20000)]
+    seqs, off = ra.pack_reads(reads)
+    want = full.find_range(seqs, off)
+    assert int((want[1] >= want[0]).sum()) > 5000
+    for b in (rb, rb4, rb3):   # (ranges only: the samples of a synthetic run list are not those of a text, so a toehold taken
+        got = b.find_range(seqs, off)   #  through other depths is another number; test_run_indexed_layout_sparse_depths has the toeholds)
+        assert all((x == y).all() for x, y in zip(got, want))
+        got = b.find_range_w_toehold(seqs, off)
+        assert (got[0] == want[0]).all() and (got[1] == want[1]).all()
+        b.close()
+    full.close()
 
 
 @pytest.mark.parametrize("packed", [0, 1, 2])

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--seed", type=int, default=20240229)
     ap.add_argument("--kmer-steps", type=int, default=0)
     ap.add_argument("--layout", choices=("auto", "slots", "runs"), default="auto")
+    ap.add_argument("--run-depths", type=lambda v: int(v, 0), default=0, help="RBG_OPT_RUN_DEPTHS (run-indexed layout; 0 = all depths)")
     args = ap.parse_args()
     import numpy as np
     import rowbowt_amd as ra
@@ -54,6 +55,8 @@ def main():
         capi.set_default_option(capi.OPT_KMER_STEPS, args.kmer_steps)
     if args.layout != "auto":
         capi.set_default_option(capi.OPT_RANK_LAYOUT, {"slots": 1, "runs": 2}[args.layout])
+    if args.run_depths:
+        capi.set_default_option(capi.OPT_RUN_DEPTHS, args.run_depths)
     ra.lib()
     t0 = time.time()
     rb = ra.RowBowt.from_cache(args.load, ra.LoadRbwtFlag.SA, device=0)

@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--verify-sa", action="store_true", help="also build the suffix array by prefix doubling and compare (n < 2.5e9 only)")
     ap.add_argument("--count-only", action="store_true")
     ap.add_argument("--layout", choices=("auto", "slots", "runs"), default="auto")
+    ap.add_argument("--run-depths", type=lambda v: int(v, 0), default=0, help="RBG_OPT_RUN_DEPTHS: bit d - 1 = keep run lists of the k-mer depth d (run-indexed layout; 0 = all)")
     ap.add_argument("--ftab-k", type=int, default=-1, help="word length of the device ftab (-1 = the library's choice)")
     ap.add_argument("--hbm-reserve-gb", type=float, default=45.0,
                     help="HBM left to this tool's own buffers (reads, ranges, locations, sort workspace): the index replica gets the rest of "
@@ -116,6 +117,8 @@ def main():
         capi.set_default_option(capi.OPT_FTAB_K, args.ftab_k)
     if args.layout != "auto":
         capi.set_default_option(capi.OPT_RANK_LAYOUT, {"slots": 1, "runs": 2}[args.layout])
+    if args.run_depths:
+        capi.set_default_option(capi.OPT_RUN_DEPTHS, args.run_depths)
     if args.hbm_reserve_gb > 0:
         free_b, _total = torch.cuda.mem_get_info(dev)
         capi.set_default_option(capi.OPT_HBM_BUDGET_MB, max(1024, int((free_b - args.hbm_reserve_gb * 1e9) / 2**20)))
@@ -246,6 +249,7 @@ def main():
                        "index": {"L": args.L, "H": args.H, "n": int(n), "r": int(inp["r"]), "site_rate": args.site_rate, "true_bwt": True,
                                  "builder": "rowbowt_amd/tools/pangenome_bwt.py", "hbm_bytes": int(ix.hbm_bytes), "pos_bytes": int(ix.pos_bytes),
                                  "symbols_per_gather": int(ix.kmer_steps), "symbols_per_gather_requested": int(ix.kmer_steps_requested),
+                                 "kmer_depths_with_tables": [1] + [d for d, x in ((2, ix.pair_runs), (3, ix.triple_runs), (4, ix.quad_runs), (5, ix.quint_runs)) if int(x)],
                                  "hbm_free_at_load": int(ix.hbm_free_at_load), "hbm_budget": int(ix.hbm_budget),
                                  "rank_bucket_shift": int(ix.rank_bucket_shift), "phi_bucket_shift": int(ix.phi_bucket_shift),
                                  "rank_layout": int(ix.rank_layout), "ftab_k": int(ix.ftab_k),
