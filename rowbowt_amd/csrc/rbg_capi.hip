@@ -241,6 +241,45 @@ struct DevBuf {
     template <typename T> T *as() { return static_cast<T *>(p); }
 };
 
+// Gigabytes of host scratch that worker threads fill (run lists converted to the device's width, phi entries): NOT
+// value-initialised -- a std::vector's zero fill is one thread touching every page first (0.5 s per 2.5 GB at r = 3e8,
+// three to five such arrays per load); here the first touch is the parallel fill itself, on huge pages where it can be.
+template <typename T>
+struct HostBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    HostBuf() = default;
+    explicit HostBuf(size_t count) { resize(count); }
+    HostBuf(const HostBuf &) = delete;
+    HostBuf &operator=(const HostBuf &) = delete;
+    HostBuf(HostBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    HostBuf &operator=(HostBuf &&o) noexcept { if (this != &o) { std::free(p); p = o.p; n = o.n; o.p = nullptr; o.n = 0; } return *this; }
+    ~HostBuf() { std::free(p); }
+    void resize(size_t count) {   // (contents are not kept)
+        std::free(p);
+        p = nullptr; n = 0;
+        if (!count) return;
+        constexpr size_t kHuge = size_t(2) << 20;
+        const size_t bytes = count * sizeof(T);
+        if (bytes >= 4 * kHuge) {
+            p = static_cast<T *>(std::aligned_alloc(kHuge, (bytes + kHuge - 1) & ~(kHuge - 1)));
+            if (p) (void)madvise(p, bytes, MADV_HUGEPAGE);
+        } else {
+            p = static_cast<T *>(std::malloc(bytes));
+        }
+        if (!p) throw std::bad_alloc();
+        n = count;
+    }
+    T *data() { return p; }
+    const T *data() const { return p; }
+    size_t size() const { return n; }
+    T &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
+};
+
+// host-to-device copy of a (possibly huge) pageable array: through pinned staging when it is big (defined beside d2h_result)
+int h2d_big(void *d_dst, const void *h_src, size_t bytes);
+
 // The replica lives in ONE device allocation (the arena) that the tables are carved out of: a
 // thousand separate hipMallocs leave the tables scattered over physical memory, and the gather
 // rate of these kernels is sensitive to that.  Anything that does not fit the
@@ -268,7 +307,7 @@ int dev_upload(rbg_index *ix, const void *src, size_t bytes, const void **dst) {
     void *p = nullptr;
     int rc = dev_reserve(ix, bytes, &p);
     if (rc) return rc;
-    if (bytes) HIP_TRY(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
+    if (bytes && (rc = h2d_big(p, src, bytes))) return rc;
     *dst = p;
     return RBG_OK;
 }
@@ -320,8 +359,8 @@ size_t replica_bytes(const HostIndex &h, bool in_arena = false) {
 // building of many tables can run on worker threads while the uploads stay on the calling thread
 template <typename P>
 struct PreparedSym {
-    std::vector<RunEnt<P>> ent;
-    std::vector<P> samp;
+    HostBuf<RunEnt<P>> ent;
+    HostBuf<P> samp;
 };
 
 template <typename P>
@@ -460,7 +499,7 @@ int upload_tables(rbg_index *ix) {
     if (h.has_tsa) {
         VStage vs("phi: entries up, slots built");
         {
-            std::vector<PhiEnt<P>> pe(h.r);
+            HostBuf<PhiEnt<P>> pe(h.r);
             parallel_for(h.r, [&](uint64_t b, uint64_t e, unsigned) {
                 for (uint64_t j = b; j < e; ++j) {
                     pe[j].pos = static_cast<P>(h.pred_pos[j]);
@@ -655,6 +694,13 @@ int upload_tables_runs(rbg_index *ix) {
         const int rcm = materialize_kmer_levels<P>(ix);
         if (rcm) return rcm;
     }
+    // (the depth-1 lists compose_on_device left on the device are the slot layout's; this layout packs the depth's tables
+    //  back to back from the host arrays)
+    for (SymTable &t : h.sym) {
+        free_tracked(ix, const_cast<void *>(t.dev_ent));
+        free_tracked(ix, const_cast<void *>(t.dev_samp));
+        t.dev_ent = t.dev_samp = nullptr;
+    }
     const uint64_t budget_keys = g_opt_tree_top_kb.load() ? static_cast<uint64_t>(g_opt_tree_top_kb.load()) * 1024 / sizeof(P) : 16;
     const std::vector<SymTable> *depth[kMaxRunDepth] = {&h.sym, &h.pair, &h.triple, &h.quad, &h.quint};
     uint32_t D = 1;
@@ -763,8 +809,9 @@ int upload_tables_runs(rbg_index *ix) {
         // (rbg_dev.h RunsFmt: 8-byte pairs + 4-byte samples, or 12-byte entries + 6-byte samples at 8-byte positions; spare
         //  entries after the last sentinel: the kernels' two- and four-entry loads may touch them)
         typedef RunsFmt<P> Fmt;
-        std::vector<unsigned char> ent((entries + Fmt::spare) * Fmt::ent_bytes);
-        std::vector<unsigned char> samp(h.has_tsa ? entries * Fmt::samp_bytes + 8 : 0);
+        HostBuf<unsigned char> ent((entries + Fmt::spare) * Fmt::ent_bytes);   // (every byte is written below)
+        HostBuf<unsigned char> samp(h.has_tsa ? entries * Fmt::samp_bytes + 8 : 0);
+        if (samp.size()) std::memset(samp.data() + samp.size() - 8, 0, 8);
         std::vector<uint64_t> first(T.size() + 1, 0);
         for (size_t t = 0; t < T.size(); ++t) first[t + 1] = first[t] + T[t].nruns + 1;
         {
@@ -954,7 +1001,7 @@ int upload_tables_runs(rbg_index *ix) {
     }
     if (h.has_tsa) {
         typedef PhiFmt<P> Fmt;
-        std::vector<unsigned char> pe((h.r + 1 + Fmt::spare) * Fmt::ent_bytes);   // (the sentinel and the spare entries after it)
+        HostBuf<unsigned char> pe((h.r + 1 + Fmt::spare) * Fmt::ent_bytes);   // (the sentinel and the spare entries after it)
         parallel_for(h.r, [&](uint64_t a, uint64_t b, unsigned) {
             for (uint64_t j = a; j < b; ++j) Fmt::put_ent(pe.data(), j, h.pred_pos[j], h.phi_base[j]);
         });
@@ -1073,7 +1120,7 @@ int compose_on_device(rbg_index *ix) {
             hipError_t e = hipMalloc(&d, bytes ? bytes : 16);
             if (e != hipSuccess) { (void)hipGetLastError(); return e == hipErrorOutOfMemory ? RBG_ENOMEM : RBG_ENODEV; }
             p.push_back(d);
-            if (bytes && hipMemcpy(d, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return RBG_ENODEV;
+            if (bytes && h2d_big(d, src, bytes) != RBG_OK) return RBG_ENODEV;
             *out = d;
             return RBG_OK;
         }
@@ -1091,8 +1138,8 @@ int compose_on_device(rbg_index *ix) {
     }
     void *g_start = nullptr, *g_id = nullptr, *g_samp = nullptr;
     if (!rc) {   // depth 1: the BWT runs themselves, id = major index of the head, sample = samples_last_ (SA - 1)
-        std::vector<P> gs(h.r + 1), sp(h.has_tsa ? h.r : 0);
-        std::vector<uint32_t> gi(h.r);
+        HostBuf<P> gs(h.r + 1), sp(h.has_tsa ? h.r : 0);
+        HostBuf<uint32_t> gi(h.r);
         gs[h.r] = static_cast<P>(h.run_start[h.r]);
         parallel_for(h.r, [&](uint64_t b, uint64_t e, unsigned) {
             for (uint64_t g = b; g < e; ++g) {
@@ -1121,6 +1168,21 @@ int compose_on_device(rbg_index *ix) {
         return rc;
     }
     ix->kmer_levels = std::move(levels);
+    // the depth-1 run lists of the k-mer alphabet are on the device in the very form the slot tables are built from
+    // (commit_sym): they stay, instead of being converted and copied a second time (5 + 2.5 GB at r = 3e8)
+    for (uint32_t m = 0; m < M; ++m) {
+        SymTable &t = h.sym[h.major_slot[m]];
+        for (void *q : {const_cast<void *>(major[m].ent), const_cast<void *>(major[m].samp)}) {
+            if (!q) continue;
+            for (void *&held : hold.p)
+                if (held == q) held = nullptr;
+            const size_t bytes = q == major[m].ent ? (t.nruns + 1) * sizeof(RunEnt<P>) : std::max<size_t>(16, t.nruns * sizeof(P));
+            ix->allocs.push_back({q, bytes});
+            ix->hbm_bytes += bytes;
+        }
+        t.dev_ent = major[m].ent;
+        t.dev_samp = major[m].samp;
+    }
     for (uint32_t d = 2; d <= K; ++d) {
         ComposedLevel &L = ix->kmer_levels[d - 2];
         ix->allocs.push_back({L.ent, (L.entries + 2) * sizeof(RunEnt<P>)});
@@ -1635,6 +1697,54 @@ int d2h_result(void *h_dst, const void *d_src, size_t bytes, hipStream_t st) {
     hipError_t e = hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     return e == hipSuccess ? RBG_OK : RBG_ENODEV;
+}
+
+// The way in for the big arrays of a load (run lists, samples, phi entries: 5-7 GB each at r = 3e8): worker threads
+// copy 64 MB chunks of the pageable source into the pinned buffers while the DMA of the chunks before runs -- the
+// driver's own path for pageable memory stages through one thread.  RBG_H2D_STAGED=0: plain hipMemcpy (A/B).
+int h2d_big(void *d_dst, const void *h_src, size_t bytes) {
+    if (bytes == 0) return RBG_OK;
+    static const bool staged = [] { const char *e = std::getenv("RBG_H2D_STAGED"); return !(e && e[0] == '0'); }();
+    if (staged && bytes >= (size_t(64) << 20)) {
+        PinnedStage &ps = PinnedStage::get();
+        std::unique_lock<std::mutex> lk(ps.mu, std::try_to_lock);
+        if (lk.owns_lock() && ps.ensure()) {
+            const size_t chunk = PinnedStage::kChunk;
+            const size_t nb = (bytes + chunk - 1) / chunk;
+            const unsigned T = std::max(1u, std::min(16u, rbg_hostpath::cpu_budget()));
+            rbg_hostpath::ThreadTeam team(T);
+            hipStream_t st = hipStreamPerThread;
+            char *dst = static_cast<char *>(d_dst);
+            const char *src = static_cast<const char *>(h_src);
+            hipError_t e = hipSuccess;
+            hipEvent_t ev[PinnedStage::kBufs] = {nullptr, nullptr, nullptr, nullptr};
+            for (hipEvent_t &x : ev)
+                if (e == hipSuccess) e = hipEventCreateWithFlags(&x, hipEventDisableTiming);
+            for (size_t c = 0; c < nb && e == hipSuccess; ++c) {
+                const int b = static_cast<int>(c % PinnedStage::kBufs);
+                if (c >= static_cast<size_t>(PinnedStage::kBufs)) e = hipEventSynchronize(ev[b]);   // chunk c - kBufs has left this buffer
+                if (e != hipSuccess) break;
+                const size_t len = std::min(chunk, bytes - c * chunk);
+                char *to = static_cast<char *>(ps.buf[b]);
+                const char *from = src + c * chunk;
+                const std::function<void(unsigned)> mv = [&](unsigned t) {
+                    const size_t a0 = (len * t / T) & ~size_t(63), z0 = t + 1 == T ? len : (len * (t + 1) / T) & ~size_t(63);
+                    if (z0 > a0) std::memcpy(to + a0, from + a0, z0 - a0);
+                };
+                team.run(mv);
+                e = hipMemcpyAsync(dst + c * chunk, ps.buf[b], len, hipMemcpyHostToDevice, st);
+                if (e == hipSuccess) e = hipEventRecord(ev[b], st);
+            }
+            const hipError_t e2 = hipStreamSynchronize(st);
+            if (e == hipSuccess) e = e2;
+            for (hipEvent_t x : ev)
+                if (x) (void)hipEventDestroy(x);
+            if (e != hipSuccess) { (void)hipGetLastError(); return RBG_ENODEV; }
+            return RBG_OK;
+        }
+    }
+    if (hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); return RBG_ENODEV; }
+    return RBG_OK;
 }
 
 // shared tail of the ragged-output host calls: d_off[N+1] is planned on the device; size, fill, copy back

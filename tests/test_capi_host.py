@@ -282,6 +282,37 @@ def test_cache_from_runs_in_memory(tmp_path):
     assert outs[0] == outs[1] == outs[2] and len(outs[0]) > 64
 
 
+def test_cache_file_of_several_checksum_chunks(tmp_path):
+    """a cache file longer than one checksum chunk (2^20 words = 8 MB; rbg_host.cpp read_flat / FlatWriter): 1.6 M runs
+    with samples make 27 MB -- written, read back as the same index, and refused when a byte of the first, a middle or the
+    last chunk is flipped, or when two chunks change places"""
+    rng = np.random.default_rng(19)
+    r = 1_600_000
+    step = rng.integers(1, 4, size=r)
+    step[0] = 0
+    heads = np.frombuffer(b"ACGT", dtype=np.uint8)[np.cumsum(step) % 4].copy()
+    lens = rng.integers(1, 40, size=r).astype(np.uint64)
+    heads[r // 3], lens[r // 3] = 1, 1
+    n = int(lens.sum())
+    vals = (rng.permutation(n)[:2 * r].astype(np.uint64))
+    path = tmp_path / "big.rbgpu"
+    capi.convert_runs(heads, lens, vals[:r], vals[r:], out_path=str(path))
+    blob = path.read_bytes()
+    CH = 8 << 20
+    assert blob[:8] == b"RBGPUIX2" and len(blob) > 2 * CH + 4096
+    a = ra.RowBowt.from_cache(str(path), ra.LoadRbwtFlag.SA, device=capi.DEVICE_NONE)
+    b = ra.RowBowt.from_runs(heads, lens, vals[:r], vals[r:], device=capi.DEVICE_NONE)
+    _same_index(a, b, HOST_ARRAYS[:5])
+    flip = lambda at: blob[:at] + bytes([blob[at] ^ 4]) + blob[at + 1:]
+    assert len(blob) > 3 * CH + 8
+    swapped = blob[:CH] + blob[2 * CH:3 * CH] + blob[CH:2 * CH] + blob[3 * CH:]
+    for bad in (flip(4096), flip(CH + 12345), flip(len(blob) - 16), swapped):
+        (tmp_path / "bad.rbgpu").write_bytes(bad)
+        with pytest.raises(ra.RbgError) as e:
+            ra.RowBowt.from_cache(str(tmp_path / "bad.rbgpu"), ra.LoadRbwtFlag.SA, device=capi.DEVICE_NONE)
+        assert e.value.code == -2
+
+
 def test_native_cache_from_reference_index(tmp_path, data_dir, small_host):
     """next-row f1: .rbwt/.tsa/.mab/.docs -> flat .rbgpu -> the same host index; rbg_load falls back to it"""
     import shutil
@@ -309,12 +340,28 @@ def test_native_cache_from_reference_index(tmp_path, data_dir, small_host):
     assert e.value.code == -1
     # the cache is smaller than the decoded arrays and a torn one is refused
     blob = cache.read_bytes()
-    assert blob[:8] == b"RBGPUIX1" and len(blob) % 8 == 0
-    for bad in (blob[:-8], blob[:1000], blob[:40] + bytes([blob[40] ^ 1]) + blob[41:], b"RBGPUIX1" + bytes(200)):
+    assert blob[:8] == b"RBGPUIX2" and len(blob) % 8 == 0
+    for bad in (blob[:-8], blob[:1000], blob[:40] + bytes([blob[40] ^ 1]) + blob[41:], b"RBGPUIX2" + bytes(200), b"RBGPUIX1" + blob[8:],
+                blob[:-9] + bytes([blob[-9] ^ 0x80]) + blob[-8:]):
         (tmp_path / "bad.rbgpu").write_bytes(bad)
         with pytest.raises(ra.RbgError) as e:
             ra.RowBowt.from_cache(str(tmp_path / "bad.rbgpu"), ra.LoadRbwtFlag.NONE, device=capi.DEVICE_NONE)
         assert e.value.code == -2
+    # version 1 of the file (one checksum chain over all words; written until round 3) is still read
+    M = (1 << 64) - 1
+
+    def flat_sum(words):
+        h = 0x9E3779B97F4A7C15
+        for w in words:
+            h = ((h ^ int(w)) * 0xFF51AFD7ED558CCD) & M
+            h = ((h << 29) | (h >> 35)) & M
+        return h
+    body = np.frombuffer(b"RBGPUIX1" + blob[8:-8], dtype="<u8")
+    (tmp_path / "v1.rbgpu").write_bytes(body.tobytes() + int(flat_sum(body)).to_bytes(8, "little"))
+    _same_index(ra.RowBowt.from_cache(str(tmp_path / "v1.rbgpu"), ALL, device=capi.DEVICE_NONE), ref)
+    # ... and version 2's last word is that sum over the sums of its chunks of 2^20 words
+    words2 = np.frombuffer(blob[:-8], dtype="<u8")
+    assert flat_sum([flat_sum(words2[i:i + (1 << 20)]) for i in range(0, len(words2), 1 << 20)]) == int.from_bytes(blob[-8:], "little")
     with pytest.raises(ra.RbgError) as e:
         ra.RowBowt.from_cache(str(tmp_path / "nope.rbgpu"), device=capi.DEVICE_NONE)
     assert e.value.code == -1

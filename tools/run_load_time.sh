@@ -29,6 +29,9 @@ mkdir -p $out
   sleep 20
   echo "### load, run-indexed layout"
   RBG_VERBOSE=1 timeout 600 python3 tools/load_time.py --load /dev/shm/pg.rbgpu --layout runs 2>&1 | grep -v amdgpu.ids
+  sleep 20
+  echo "### load, slot tables, big host arrays by plain hipMemcpy instead of the pinned staging (RBG_H2D_STAGED=0)"
+  RBG_H2D_STAGED=0 RBG_VERBOSE=1 timeout 600 python3 tools/load_time.py --load /dev/shm/pg.rbgpu 2>&1 | grep -v amdgpu.ids
   rm -f /dev/shm/pg.rbgpu
 } > $out/load_time.txt 2>&1
 grep -c . $out/load_time.txt; grep "load_s\|hipMalloc(200" $out/load_time.txt
