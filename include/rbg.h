@@ -82,7 +82,8 @@ int rbg_build_from_files(const char *bwt_fname, const char *ssa_fname, const cha
 
 /* ---- next-row f1: native cache file and the rb_build outputs ----------------------------------
  * "<prefix>.rbgpu" holds what the reference's .rbwt/.tsa/.mab/.docs hold, as flat little-endian
- * arrays with a checksum (layout: rowbowt_amd/csrc/rbg_host.hpp); loading it needs no sdsl decoding.
+ * arrays with a checksum (layout: rowbowt_amd/csrc/rbg_host.hpp; the file is mapped and checked by all loader threads:
+ * 1.2 s for the 9 GB of an n = 5e10 index); loading it needs no sdsl decoding.
  * rbg_load() falls back to "<prefix>.rbgpu" when "<prefix>.rbwt" does not exist.
  * rbg_convert_index: the reference's serialised files (rb_build's output, rowbowt_io.hpp:49-89) -> cache.
  * rbg_convert_raw:   rb_build's raw inputs <pre>.bwt [+ .ssa/.esa] (rb_build.cpp:83-93; rle_string.hpp:44-97,
@@ -465,8 +466,9 @@ int rbg_sample_reads_dev(const uint8_t *d_text, uint64_t unit, uint64_t H, uint6
  * RBG_RANK_DIR=0 / RBG_PHI_DIR=0 build the run-indexed layout without its rank / phi directories (descent through
  * the sampled levels only), RBG_RANK_DIR_RUNS=<x> sets the runs per rank-directory bucket (default 4),
  * RBG_RANK_REC=<t> adds bucket records with at most t runs each (off by default: DESIGN.md 2c);  RBG_HOST_THREADS, RBG_HOST_CHUNK_READS, RBG_HOST_DIRECT_OUT=0, RBG_HOST_COMBINE=0,
- * RBG_HOST_TRACE=1|2 tune / trace the host-pointer pipeline;  RBG_VERBOSE=1 prints what the budget
- * rule did. */
+ * RBG_HOST_TRACE=1|2 tune / trace the host-pointer pipeline;  RBG_RUNS_HOST_BUILD=1 builds the run-indexed
+ * layout's directories on the host, RBG_H2D_STAGED=0 uploads the big arrays of a load by plain hipMemcpy;  RBG_VERBOSE=1 prints
+ * what the budget rule did and the seconds of every stage of a load. */
 enum { RBG_OPT_BLOCK_THREADS = 1, RBG_OPT_RANK_BUCKET_SHIFT = 2, RBG_OPT_PHI_BUCKET_SHIFT = 3, RBG_OPT_POS_BYTES = 4,
        RBG_OPT_KMER_STEPS = 5, RBG_OPT_HBM_BUDGET_MB = 6, RBG_OPT_FTAB_K = 7, RBG_OPT_PACKED_READS = 8,
        RBG_OPT_DEEP_BUCKET_SHIFT = 9, RBG_OPT_DENSE_OVERFLOW = 10, RBG_OPT_RANK_LAYOUT = 11, RBG_OPT_TREE_TOP_KB = 12,

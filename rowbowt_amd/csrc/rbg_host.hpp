@@ -62,15 +62,18 @@ int read_raw_samples(const std::string &fname, std::vector<uint64_t> &y_out);
 void tsa_from_samples(uint64_t n, uint64_t r, const uint64_t *ssa_y, const uint64_t *esa_y, RawTsa &out);
 
 // ---- native cache file (next-row f1): everything the reference's .rbwt/.tsa/.mab/.docs hold, as flat
-// little-endian arrays ("<prefix>.rbgpu").  Loading it is a handful of freads: no wavelet-tree or
+// little-endian arrays ("<prefix>.rbgpu").  Loading it is one mapping of the file: no wavelet-tree or
 // sd_vector decoding (rle_string::load, rle_string.hpp:265-275) and no re-encoding of a raw BWT
 // (rle_string.hpp:44-97).  Layout (all u64 unless noted, sections padded to 8 bytes):
-//   "RBGPUIX1" | flags (bit0 tsa, bit1 markers, bit2 docs) | n | R | B | len_width (4|8) | pos_width (4|8)
+//   "RBGPUIX2" | flags (bit0 tsa, bit1 markers, bit2 docs) | n | R | B | len_width (4|8) | pos_width (4|8)
 //   | ma_nruns | ma_nvals | ma_wsize | docs_bytes
 //   | heads u8[R] | lens len_width[R]
 //   | tsa:  pred_pos pos_width[R] | samples_last pos_width[R] | pred_to_run pos_width[R]
 //   | ma:   start pos_width[nruns] | end pos_width[nruns] | off u64[nruns+1] | vals u64[nvals]
-//   | docs: the .docs text (doclist.hpp:57-73) | checksum of every preceding 8-byte word
+//   | docs: the .docs text (doclist.hpp:57-73) | checksum
+// Checksum: FlatSum (rbg_host.cpp) over the FlatSums of the preceding words taken in chunks of 2^20 words, so that the
+// reader's threads verify a 9 GB file in 0.14 s.  "RBGPUIX1" (one FlatSum chain over all words; written until round 3)
+// differs in nothing else and is still read.
 struct FlatBundle {
     RawRle rle;
     bool has_tsa = false, has_ma = false, has_dl = false;
