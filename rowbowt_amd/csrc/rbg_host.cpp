@@ -507,8 +507,13 @@ struct FlatSum {  // order-sensitive 64-bit checksum over 8-byte words
 
 class FlatWriter {
    public:
-    explicit FlatWriter(const std::string &fname) : fp_(std::fopen(fname.c_str(), "wb")) {}
-    ~FlatWriter() { if (fp_) std::fclose(fp_); }
+    // (written under a temporary name and renamed when complete: a reader -- another rank of the node, which maps the
+    //  file -- never sees a partial one)
+    explicit FlatWriter(const std::string &fname)
+        : final_(fname), tmp_(fname + ".tmp." + std::to_string(static_cast<long>(getpid()))), fp_(std::fopen(tmp_.c_str(), "wb")) {}
+    ~FlatWriter() {
+        if (fp_) { std::fclose(fp_); std::remove(tmp_.c_str()); }   // not finished: nothing is left behind
+    }
     bool ok() const { return fp_ && ok_; }
     void u64(uint64_t v) { raw(&v, 8); }
     // section of `count` values narrowed to `width` bytes, zero-padded to a multiple of 8
@@ -530,6 +535,8 @@ class FlatWriter {
         if (fp_ && std::fwrite(&h, 8, 1, fp_) != 1) ok_ = false;
         if (fp_ && std::fclose(fp_) != 0) ok_ = false;
         fp_ = nullptr;
+        if (ok_ && std::rename(tmp_.c_str(), final_.c_str()) != 0) ok_ = false;
+        if (!ok_) std::remove(tmp_.c_str());
         return ok_;
     }
 
@@ -566,6 +573,7 @@ class FlatWriter {
         static const unsigned char zeros[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (ncarry_) raw(zeros, 8 - ncarry_);
     }
+    std::string final_, tmp_;
     FILE *fp_;
     bool ok_ = true;
     FlatSum sum_, outer_;

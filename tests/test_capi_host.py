@@ -263,6 +263,10 @@ def test_cache_from_runs_in_memory(tmp_path):
     assert c.info().r == b.info().r and not c.info().has_tsa
     with pytest.raises(ra.RbgError):
         capi.convert_runs(S.heads, S.lens, S.ssa, None, out_path=str(tmp_path / "bad.rbgpu"))
+    with pytest.raises(ra.RbgError):
+        capi.convert_runs(S.heads, S.lens, S.ssa, S.esa, out_path=str(tmp_path / "no_such_dir" / "x.rbgpu"))
+    # the file appears under its name only when complete (written as <name>.tmp.<pid>, then renamed); a failed write leaves nothing
+    assert sorted(q.name for q in tmp_path.iterdir()) == ["m.rbgpu", "n.rbgpu"]
     # a larger random run list through 1 and 7 worker threads (a fresh interpreter each: the thread count is read once)
     code = (
         "import sys, numpy as np; sys.path.insert(0, %r); import rowbowt_amd as ra; from rowbowt_amd import capi\n"
