@@ -480,7 +480,7 @@ def main():
 
         gstep()
         el_g = timed(gstep, K)
-        slot_other = {"greedy_seed_ms": el_g / K * 1e3, "marker_seeds_ms": el_sd / K * 1e3}
+        slot_other = {"greedy_seed_ms": el_g / K * 1e3, "marker_seeds_ms": el_sd / K * 1e3, "marker_seeds_logged_ms": el_sl / K * 1e3}
         ref_g = [t.clone() for t in d_g]
         ref_seed_counts = (n_seeds, n_smk)
         mk_block["greedy_seed"] = {"value": N * K / el_g, "unit": "reads/s (this rank)", "ms_per_step": el_g / K * 1e3, "min_length": 20}
@@ -908,7 +908,10 @@ def main():
             sstep()
             same_s = (int(d_soff[-1].item()), int(d_moff[-1].item())) == ref_seed_counts
             run_other = {}
-            for name, fn in (("greedy_seed_ms", gstep), ("marker_seeds_ms", sstep)):
+            assert int(L.rbg_marker_seeds_log_bytes(rb.h, 2 * N, 0)) <= log_bytes
+            sstep_log()
+            same_s = same_s and (int(d_soff[-1].item()), int(d_moff[-1].item())) == ref_seed_counts
+            for name, fn in (("greedy_seed_ms", gstep), ("marker_seeds_ms", sstep), ("marker_seeds_logged_ms", sstep_log)):
                 e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
                 e[0].record(stream); fn(); e[1].record(stream); fn(); e[2].record(stream)
                 torch.cuda.synchronize()
@@ -943,7 +946,9 @@ def main():
                 sstep()
                 same_s = (int(d_soff[-1].item()), int(d_moff[-1].item())) == ref_seed_counts
                 other = {}
-                for name, fn in (("greedy_seed_ms", gstep), ("marker_seeds_ms", sstep)):
+                sstep_log()
+                same_s = same_s and (int(d_soff[-1].item()), int(d_moff[-1].item())) == ref_seed_counts
+                for name, fn in (("greedy_seed_ms", gstep), ("marker_seeds_ms", sstep), ("marker_seeds_logged_ms", sstep_log)):
                     e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
                     e[0].record(stream); fn(); e[1].record(stream); fn(); e[2].record(stream)
                     torch.cuda.synchronize()
