@@ -466,7 +466,9 @@ int rbg_sample_reads_dev(const uint8_t *d_text, uint64_t unit, uint64_t H, uint6
  * RBG_RANK_DIR=0 / RBG_PHI_DIR=0 build the run-indexed layout without its rank / phi directories (descent through
  * the sampled levels only), RBG_RANK_DIR_RUNS=<x> sets the runs per rank-directory bucket (default 4),
  * RBG_RANK_REC=<t> adds bucket records with at most t runs each (off by default: DESIGN.md 2c);  RBG_HOST_THREADS, RBG_HOST_CHUNK_READS, RBG_HOST_DIRECT_OUT=0, RBG_HOST_COMBINE=0,
- * RBG_HOST_TRACE=1|2 tune / trace the host-pointer pipeline;  RBG_RUNS_HOST_BUILD=1 builds the run-indexed
+ * RBG_HOST_TRACE=1|2 tune / trace the host-pointer pipeline;  RBG_LAYOUT=auto|slots|runs, RBG_RUN_DEPTHS,
+ * RBG_KMER_STEPS, RBG_HBM_BUDGET_MB, RBG_FTAB_K give the options of the same names their initial values (for the command-line
+ * tools, which keep the reference's flags; rbg_set_default_option overrides them);  RBG_RUNS_HOST_BUILD=1 builds the run-indexed
  * layout's directories on the host, RBG_H2D_STAGED=0 uploads the big arrays of a load by plain hipMemcpy;  RBG_VERBOSE=1 prints
  * what the budget rule did and the seconds of every stage of a load. */
 enum { RBG_OPT_BLOCK_THREADS = 1, RBG_OPT_RANK_BUCKET_SHIFT = 2, RBG_OPT_PHI_BUCKET_SHIFT = 3, RBG_OPT_POS_BYTES = 4,

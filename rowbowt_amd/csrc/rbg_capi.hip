@@ -89,18 +89,37 @@ struct rbg_index {
 
 namespace {
 
+// Initial values of the load-time knobs a command-line user may need (rb_align / rb_markers / rb_build keep the reference's
+// flags, so these come by environment): RBG_LAYOUT = auto | slots | runs, RBG_RUN_DEPTHS = mask, RBG_KMER_STEPS = 1..5,
+// RBG_HBM_BUDGET_MB, RBG_FTAB_K = -1..16.  rbg_set_default_option overrides them; a value out of range is reported and ignored.
+int64_t env_opt(const char *name, int64_t dflt, int64_t lo, int64_t hi) {
+    const char *e = std::getenv(name);
+    if (!e || !*e) return dflt;
+    if (std::strcmp(name, "RBG_LAYOUT") == 0) {
+        if (std::strcmp(e, "auto") == 0) return RBG_LAYOUT_AUTO;
+        if (std::strcmp(e, "slots") == 0) return RBG_LAYOUT_SLOTS;
+        if (std::strcmp(e, "runs") == 0) return RBG_LAYOUT_RUNS;
+    }
+    char *end = nullptr;
+    const long long v = std::strtoll(e, &end, 0);
+    if (end == e || *end || v < lo || v > hi) {
+        std::fprintf(stderr, "rbg: %s=%s ignored (expected %lld..%lld)\n", name, e, static_cast<long long>(lo), static_cast<long long>(hi));
+        return dflt;
+    }
+    return v;
+}
 std::atomic<int64_t> g_opt_block_threads{256};
 std::atomic<int64_t> g_opt_rank_shift{-1};
 std::atomic<int64_t> g_opt_phi_shift{-1};
 std::atomic<int64_t> g_opt_pos_bytes{0};
-std::atomic<int64_t> g_opt_kmer_steps{5};
-std::atomic<int64_t> g_opt_hbm_budget_mb{0};
-std::atomic<int64_t> g_opt_ftab_k{-1};
+std::atomic<int64_t> g_opt_kmer_steps{env_opt("RBG_KMER_STEPS", 5, 1, 5)};
+std::atomic<int64_t> g_opt_hbm_budget_mb{env_opt("RBG_HBM_BUDGET_MB", 0, 0, int64_t(1) << 40)};
+std::atomic<int64_t> g_opt_ftab_k{env_opt("RBG_FTAB_K", -1, -1, 16)};
 std::atomic<int64_t> g_opt_deep_shift{-1};
 std::atomic<int64_t> g_opt_dense_overflow{1};
-std::atomic<int64_t> g_opt_rank_layout{0};    // RBG_LAYOUT_AUTO / _SLOTS / _RUNS
+std::atomic<int64_t> g_opt_rank_layout{env_opt("RBG_LAYOUT", RBG_LAYOUT_AUTO, RBG_LAYOUT_AUTO, RBG_LAYOUT_RUNS)};    // RBG_LAYOUT_AUTO / _SLOTS / _RUNS
 std::atomic<int64_t> g_opt_tree_top_kb{48};   // LDS the staged top levels of the run-indexed search may take per workgroup
-std::atomic<int64_t> g_opt_run_depths{0};    // run-indexed layout: bit d - 1 = keep the k-mer depth d (0 = every other depth from the deepest down)
+std::atomic<int64_t> g_opt_run_depths{env_opt("RBG_RUN_DEPTHS", 0, 0, (1 << kMaxRunDepth) - 1)};    // run-indexed layout: bit d - 1 = keep the k-mer depth d (0 = every other depth from the deepest down)
 std::atomic<int64_t> g_opt_slot_bytes{16};    // 16: RankSlot; 64: RankSlot64 (experiment: rbg_dev.h)
 std::atomic<int64_t> g_opt_packed_reads{1};  // host-pointer calls: 0 bytes over PCIe, 1 (default) 2-bit codes for batches >= 4096, 2 always
 

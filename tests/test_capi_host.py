@@ -286,6 +286,27 @@ def test_cache_from_runs_in_memory(tmp_path):
     assert outs[0] == outs[1] == outs[2] and len(outs[0]) > 64
 
 
+def test_load_time_knobs_from_the_environment():
+    """RBG_LAYOUT / RBG_RUN_DEPTHS / RBG_KMER_STEPS / RBG_HBM_BUDGET_MB / RBG_FTAB_K give the options of the same names
+    their initial values (the command-line tools keep the reference's flags: include/rbg.h "Environment switches"); a value
+    out of range is reported and ignored; rbg_set_default_option still overrides."""
+    code = ("import sys; sys.path.insert(0, %r); from rowbowt_amd import capi\n"
+            "g = capi.get_default_option\n"
+            "print(g(capi.OPT_RANK_LAYOUT), g(capi.OPT_RUN_DEPTHS), g(capi.OPT_KMER_STEPS), g(capi.OPT_HBM_BUDGET_MB), g(capi.OPT_FTAB_K))\n"
+            "capi.set_default_option(capi.OPT_RANK_LAYOUT, 1); print(g(capi.OPT_RANK_LAYOUT))\n" % ROOT)
+    def run(**env):
+        p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=120)
+        assert p.returncode == 0, p.stderr[-2000:]
+        return p.stdout.split(), p.stderr
+    assert run()[0] == ["0", "0", "5", "0", "-1", "1"]
+    out, _ = run(RBG_LAYOUT="runs", RBG_RUN_DEPTHS="0x11", RBG_KMER_STEPS="4", RBG_HBM_BUDGET_MB="50000", RBG_FTAB_K="10")
+    assert out == ["2", "17", "4", "50000", "10", "1"]
+    out, err = run(RBG_LAYOUT="sideways", RBG_RUN_DEPTHS="32", RBG_KMER_STEPS="6", RBG_FTAB_K="x")
+    assert out == ["0", "0", "5", "0", "-1", "1"]
+    assert all(("rbg: %s=" % k) in err and "ignored" in err for k in ("RBG_LAYOUT", "RBG_RUN_DEPTHS", "RBG_KMER_STEPS", "RBG_FTAB_K"))
+    assert run(RBG_LAYOUT="2")[0][0] == "2"
+
+
 def test_cache_file_of_several_checksum_chunks(tmp_path):
     """a cache file longer than one checksum chunk (2^20 words = 8 MB; rbg_host.cpp read_flat / FlatWriter): 1.6 M runs
     with samples make 27 MB -- written, read back as the same index, and refused when a byte of the first, a middle or the

@@ -915,6 +915,19 @@ def test_cli_count_stdout(data_dir, simple_reads):
     assert rc == 0 and lines[0] == "r1.ref (1,0), count=0" and lines[2] == "r2.ref (27430,27432), count=3"
 
 
+def test_cli_layout_from_the_environment(data_dir):
+    """rb_align keeps the reference's flags; the library's load-time knobs reach it by environment (include/rbg.h):
+    RBG_LAYOUT=runs answers from the run-indexed layout, all depths or depths 1 and 4 only -- the same text."""
+    args = ["-s", os.path.join(data_dir, "small.fa"), os.path.join(data_dir, "simple_query.fq")]
+    rc0, out0, err0 = _run_cli(args, env={"RBG_VERBOSE": "1"})
+    assert rc0 == 0 and "run-indexed layout" not in err0, err0
+    for env in ({"RBG_LAYOUT": "runs"}, {"RBG_LAYOUT": "runs", "RBG_RUN_DEPTHS": "0x1F"}, {"RBG_LAYOUT": "runs", "RBG_RUN_DEPTHS": "9", "RBG_FTAB_K": "0"}):
+        rc, out, err = _run_cli(args, env=dict(env, RBG_VERBOSE="1"))
+        assert rc == 0 and out == out0 and "run-indexed layout" in err, err
+        mask = {None: "0x15", "0x1F": "0x1f", "9": "0x9"}[env.get("RBG_RUN_DEPTHS")]
+        assert f"k-mer depths with run lists: mask {mask}" in err, err
+
+
 def test_cli_locs_and_markers_stdout(data_dir, tmp_path, small, simple_reads):
     import gzip
     import shutil
