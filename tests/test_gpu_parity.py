@@ -915,10 +915,14 @@ def test_cli_count_stdout(data_dir, simple_reads):
     assert rc == 0 and lines[0] == "r1.ref (1,0), count=0" and lines[2] == "r2.ref (27430,27432), count=3"
 
 
-def test_cli_layout_from_the_environment(data_dir):
+def test_cli_layout_from_the_environment(data_dir, tmp_path):
     """rb_align keeps the reference's flags; the library's load-time knobs reach it by environment (include/rbg.h):
     RBG_LAYOUT=runs answers from the run-indexed layout, all depths or depths 1 and 4 only -- the same text."""
-    args = ["-s", os.path.join(data_dir, "small.fa"), os.path.join(data_dir, "simple_query.fq")]
+    import shutil
+    for suf in (".rbwt", ".tsa"):
+        shutil.copy(os.path.join(data_dir, "small.fa" + suf), tmp_path / ("idx" + suf))
+    (tmp_path / "idx.docs").write_text("ref 0\nhap1 10010\nhap2 20020\n")
+    args = ["-s", str(tmp_path / "idx"), os.path.join(data_dir, "simple_query.fq")]
     rc0, out0, err0 = _run_cli(args, env={"RBG_VERBOSE": "1"})
     assert rc0 == 0 and "run-indexed layout" not in err0, err0
     for env in ({"RBG_LAYOUT": "runs"}, {"RBG_LAYOUT": "runs", "RBG_RUN_DEPTHS": "0x1F"}, {"RBG_LAYOUT": "runs", "RBG_RUN_DEPTHS": "9", "RBG_FTAB_K": "0"}):
