@@ -4,7 +4,8 @@
 # usage: tools/lib_ab.sh cur flat cond ...   (writes gpurun_out/ab_<v>_{4,8}.json)
 set -u
 mkdir -p gpurun_out
-A="--layout runs --no-space-speed --no-markers --no-cpu-baseline --steps 3 --warmup 1"
+# RBG_AB_ARGS: other bench.py arguments (default: the run-indexed layout), e.g. "--no-space-speed --no-markers --no-cpu-baseline" for the slot tables
+A=${RBG_AB_ARGS:-"--layout runs --no-space-speed --no-markers --no-cpu-baseline --steps 3 --warmup 1"}
 for v in "$@"; do
   cp rowbowt_amd/librbg_$v.so rowbowt_amd/librbg.so || exit 1
   timeout -k 10 200 python bench.py $A > gpurun_out/ab_${v}_4.json 2> gpurun_out/ab_${v}_4.err || { echo "$v 4: failed"; exit 1; }
