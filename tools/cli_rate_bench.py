@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--threads", type=int, default=16)
     ap.add_argument("--dir", default="/tmp/cli_big")
     ap.add_argument("--only-s", action="store_true", help="only the rb_align -s rows on plain FASTQ (tuning runs)")
+    ap.add_argument("--only-sm", type=int, default=0, help="only the rb_align -s -m row on plain FASTQ, this many times (its spread)")
     args = ap.parse_args()
     import torch
     from rowbowt_amd import capi
@@ -121,6 +122,8 @@ def main():
             (th, gz1, n1, "/dev/null"), (["-s"] + th, gz1, n1, "/dev/null"))
     if args.only_s:
         rows = tuple(r for r in rows if r[0][:1] == ["-s"] and "-m" not in r[0] and r[1] == fq)
+    if args.only_sm:
+        rows = tuple(r for r in rows if "-m" in r[0]) * args.only_sm
     for flags, path, n, out in rows:
         t0 = time.perf_counter()
         env = dict(os.environ, RB_ALIGN_TRACE="1")
@@ -139,7 +142,7 @@ def main():
         sz = os.path.getsize(out) if out != "/dev/null" else 0
         print(f"rb_align {' '.join(flags):22s} {os.path.basename(path):14s} -> {os.path.basename(out):8s}: process {dt:6.2f} s (index load {load_s:5.2f} s); query loop "
               f"{query_s:6.3f} s = {n / query_s:.3e} reads/s" + (f"; {sz / 1e6:.0f} MB of text" if sz else "") + (f"   [{trace[-1][15:]}]" if trace else ""), flush=True)
-    if args.only_s:
+    if args.only_s or args.only_sm:
         return
     exe2 = os.path.join(ROOT, "rowbowt_amd", "rb_markers")
     for flags in (th, ["--heuristic", "--best-strand-only", "--min-seed-length", "30"] + th):
