@@ -2066,14 +2066,18 @@ def test_run_indexed_layout_built_on_the_device_equals_the_host_build(synth, pos
 
 
 @pytest.mark.parametrize("pos_bytes,mask,kept,host_build", [(0, 0, 0x15, False), (0, 0x15, 0x15, False), (8, 0x11, 0x11, False), (0, 0x13, 0x13, True),
-                                                             (8, 0x0A, 0x0B, False), (0, 0x1E, 0x1F, False), (8, 0x15, 0x15, True)])
+                                                             (8, 0x0A, 0x0B, False), (0, 0x1E, 0x1F, False), (8, 0x15, 0x15, True),
+                                                             (0, 0x15, 0x15, "rec"), (8, 0x09, 0x09, "rec")])
 def test_run_indexed_layout_sparse_depths(synth, pos_bytes, mask, kept, host_build):
     """RBG_OPT_RUN_DEPTHS: run lists for some of the k-mer depths only (bit d - 1; depth 1 always, nothing above the
     highest bit).  A step takes the longest stretch a kept depth covers (k_runs.hip, k_runs_seeds.hip pick_step), so the
-    answers are those of every other layout -- the oracle's -- in less space.  Both ways of building the layout."""
+    answers are those of every other layout -- the oracle's -- in less space.  Both ways of building the layout, and with
+    bucket records ("rec")."""
     S = synth
     ra.set_default_option(capi.OPT_POS_BYTES, pos_bytes)
-    if host_build:
+    if host_build == "rec":
+        os.environ["RBG_RANK_REC"] = "8"          # bucket records (built on the host) beside the depth set
+    elif host_build:
         os.environ["RBG_RUNS_HOST_BUILD"] = "1"
     try:
         with capi.default_option(capi.OPT_RUN_DEPTHS, 0x1F):
@@ -2083,6 +2087,7 @@ def test_run_indexed_layout_sparse_depths(synth, pos_bytes, mask, kept, host_bui
     finally:
         ra.set_default_option(capi.OPT_POS_BYTES, 0)
         os.environ.pop("RBG_RUNS_HOST_BUILD", None)
+        os.environ.pop("RBG_RANK_REC", None)
     fi, info = full.info(), rb.info()
     runs_full = [fi.r, fi.pair_runs, fi.triple_runs, fi.quad_runs, fi.quint_runs]
     runs_kept = [info.r, info.pair_runs, info.triple_runs, info.quad_runs, info.quint_runs]
