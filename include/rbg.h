@@ -154,6 +154,28 @@ typedef struct rbg_info_t {
 enum { RBG_LAYOUT_AUTO = 0, RBG_LAYOUT_SLOTS = 1, RBG_LAYOUT_RUNS = 2 };
 int rbg_info(const rbg_index *, rbg_info_t *out);
 
+/* What the load decided about the run-indexed layout (RBG_LAYOUT_RUNS), so that no table is left out silently: the
+ * reference's structures have no size limits (rle_string.hpp:131-161, toehold_sa.hpp:56-72 are plain uint64_t), and where
+ * this layout has one -- or the HBM budget bites -- the decision is here and on stderr.  All zero on the slot layout.
+ * out_bytes = sizeof(rbg_layout_info_t) of the caller (fields beyond it are not written: the struct may grow at its end). */
+typedef struct rbg_layout_info_t {
+    uint32_t run_fmt;                 /* RBG_OPT_RUN_FMT as built: 1 or 2 */
+    uint32_t depths_composed;         /* k-mer depths the load composed run lists for (1..5) */
+    uint32_t depth_mask_asked;        /* RBG_OPT_RUN_DEPTHS as given (0 = the default rule) */
+    uint32_t depth_mask_kept;         /* bit d - 1: depth d has run lists in HBM */
+    uint32_t depths_dropped_budget;   /* bit d - 1: depth d was left out because the replica exceeded the HBM budget */
+    uint32_t depths_dropped_limit;    /* bit d - 1: depth d was left out by a width limit (format 1: 2^32 entries per depth) */
+    uint32_t rank_directories;        /* 1: ranks go through the per-table directories */
+    uint32_t phi_directory;           /* 1: phi goes through its directory */
+    uint32_t phi_directory_dropped;   /* 1: format 1 left it out (beyond 2 GiB or r >= 2^31): phi descends the sampled levels */
+    uint32_t fill_shift;              /* format 2, 8-byte positions: entries of a table lie less than 2^fill_shift rows apart */
+    uint64_t entries[5];              /* per depth: entries of its run lists (sentinels and fillers included) */
+    uint64_t fillers[5];              /* per depth: filler entries among them (format 2, 8-byte positions; 0 unless a table has a gap >= 2^fill_shift) */
+    uint64_t dir_bytes[5];            /* per depth: bytes of its tables' directories */
+    uint64_t phi_entries, phi_fillers, phi_dir_bytes, phi_dir_shift;
+} rbg_layout_info_t;
+int rbg_layout_info(const rbg_index *, rbg_layout_info_t *out, uint64_t out_bytes);
+
 /* RowBowt::get_f(), rowbowt.hpp:719 / build_f :770-778: 256 entries. */
 int rbg_get_f(const rbg_index *, uint64_t f_out[256]);
 /* ToeholdSA::get_last_run_sample(), toehold_sa.hpp:97-99 */
@@ -465,7 +487,10 @@ int rbg_sample_reads_dev(const uint8_t *d_text, uint64_t unit, uint64_t H, uint6
  * and for the tests that pin both sides):  RBG_PHI_PACKED=0 keeps 32-byte phi slots at 8-byte positions;
  * RBG_RANK_DIR=0 / RBG_PHI_DIR=0 build the run-indexed layout without its rank / phi directories (descent through
  * the sampled levels only), RBG_RANK_DIR_RUNS=<x> sets the runs per rank-directory bucket (default 4),
- * RBG_RANK_REC=<t> adds bucket records with at most t runs each (off by default: DESIGN.md 2c);  RBG_HOST_THREADS, RBG_HOST_CHUNK_READS, RBG_HOST_DIRECT_OUT=0, RBG_HOST_COMBINE=0,
+ * RBG_RANK_REC=<t> adds bucket records with at most t runs each (off by default: DESIGN.md 2c) -- each of these three selects
+ * format 1 of the layout (RBG_OPT_RUN_FMT); RBG_PHI_DIR_PER=<x> sets the sampled positions per phi-directory bucket of format 2
+ * (default 1..2); RBG_RUN_FILL_SHIFT / RBG_PHI_SUPER_SHIFT lower format 2's filler distance / super-count spacing so that tests
+ * meet both on small indexes;  RBG_HOST_THREADS, RBG_HOST_CHUNK_READS, RBG_HOST_DIRECT_OUT=0, RBG_HOST_COMBINE=0,
  * RBG_HOST_TRACE=1|2 tune / trace the host-pointer pipeline;  RBG_LAYOUT=auto|slots|runs, RBG_RUN_DEPTHS,
  * RBG_KMER_STEPS, RBG_HBM_BUDGET_MB, RBG_FTAB_K give the options of the same names their initial values (for the command-line
  * tools, which keep the reference's flags; rbg_set_default_option overrides them);  RBG_RUNS_HOST_BUILD=1 builds the run-indexed
@@ -484,7 +509,14 @@ enum { RBG_OPT_BLOCK_THREADS = 1, RBG_OPT_RANK_BUCKET_SHIFT = 2, RBG_OPT_PHI_BUC
                                   five: 62 % of the space of all five at n = 5e10, the same rate on 150 bp reads, one step
                                   more for a stretch of 2 or 4 symbols); 0x1F keeps all five; over budget the depths
                                   between the first and the deepest go before the deepest does.  rbg_info(): kmer_steps is
-                                  the deepest depth kept, pair_runs .. quint_runs are 0 for the depths left out */ };
+                                  the deepest depth kept, pair_runs .. quint_runs are 0 for the depths left out */,
+       RBG_OPT_RUN_FMT = 15 /* run-indexed layout: 2 (default) = every lane answers its own ranks and phi steps from the few entries
+                                  its directory bucket names (at 8-byte positions the entries hold the low 32 bits of {start, cum}:
+                                  the bucket number is the high part, the same split the reference's Elias-Fano vectors make,
+                                  sparse_sd_vector.hpp:110-163; entry indices are 64-bit, nothing is left out for its size);
+                                  1 = rounds 2-3: {P, P} pairs probed by quads of lanes (kept for A/B measurements and for the
+                                  options that build an index without directories).  RBG_RUN_FMT gives the initial value.
+                                  rbg_layout_info() says what was built. */ };
 int rbg_set_default_option(int opt, int64_t value);
 /* the value a later load would use (so that a caller can change a knob for one load and put it back) */
 int rbg_get_default_option(int opt, int64_t *value);

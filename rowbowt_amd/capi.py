@@ -20,7 +20,7 @@ VP = C.c_void_p
 MAXU = 2**64 - 1
 DEVICE_NONE = -1
 
-OPT_BLOCK_THREADS, OPT_RANK_BUCKET_SHIFT, OPT_PHI_BUCKET_SHIFT, OPT_POS_BYTES, OPT_KMER_STEPS, OPT_HBM_BUDGET_MB, OPT_FTAB_K, OPT_PACKED_READS, OPT_DEEP_BUCKET_SHIFT, OPT_DENSE_OVERFLOW, OPT_RANK_LAYOUT, OPT_TREE_TOP_KB, OPT_SLOT_BYTES, OPT_RUN_DEPTHS = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14
+OPT_BLOCK_THREADS, OPT_RANK_BUCKET_SHIFT, OPT_PHI_BUCKET_SHIFT, OPT_POS_BYTES, OPT_KMER_STEPS, OPT_HBM_BUDGET_MB, OPT_FTAB_K, OPT_PACKED_READS, OPT_DEEP_BUCKET_SHIFT, OPT_DENSE_OVERFLOW, OPT_RANK_LAYOUT, OPT_TREE_TOP_KB, OPT_SLOT_BYTES, OPT_RUN_DEPTHS, OPT_RUN_FMT = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15
 LAYOUT_AUTO, LAYOUT_SLOTS, LAYOUT_RUNS = 0, 1, 2
 (ARR_RUN_HEADS, ARR_RUN_START, ARR_SAMPLES_LAST, ARR_PRED_POS, ARR_PHI_BASE,
  ARR_MARKER_START, ARR_MARKER_END, ARR_MARKER_OFF, ARR_MARKER_VALS) = range(9)
@@ -51,6 +51,15 @@ class Info(C.Structure):
                 ("kmer_steps_requested", U64), ("hbm_free_at_load", U64), ("hbm_budget", U64), ("rank_layout", U64), ("replicas", U64)]
 
 
+class LayoutInfo(C.Structure):
+    """rbg_layout_info_t"""
+    _fields_ = [("run_fmt", C.c_uint32), ("depths_composed", C.c_uint32), ("depth_mask_asked", C.c_uint32), ("depth_mask_kept", C.c_uint32),
+                ("depths_dropped_budget", C.c_uint32), ("depths_dropped_limit", C.c_uint32), ("rank_directories", C.c_uint32),
+                ("phi_directory", C.c_uint32), ("phi_directory_dropped", C.c_uint32), ("fill_shift", C.c_uint32),
+                ("entries", U64 * 5), ("fillers", U64 * 5), ("dir_bytes", U64 * 5),
+                ("phi_entries", U64), ("phi_fillers", U64), ("phi_dir_bytes", U64), ("phi_dir_shift", U64)]
+
+
 # every symbol include/rbg.h declares: (name, restype, argtypes)
 _PROTOS = [
     ("rbg_abi_version", C.c_int, []),
@@ -74,6 +83,7 @@ _PROTOS = [
     ("rbg_set_docs", C.c_int, [VP, C.c_char_p, VP, U64]),
     ("rbg_free", None, [VP]),
     ("rbg_info", C.c_int, [VP, C.POINTER(Info)]),
+    ("rbg_layout_info", C.c_int, [VP, C.POINTER(LayoutInfo), U64]),
     ("rbg_get_f", C.c_int, [VP, VP]),
     ("rbg_last_run_sample", C.c_int, [VP, C.POINTER(U64)]),
     ("rbg_host_array", C.c_int, [VP, C.c_int, VP, U64, C.POINTER(U64)]),
@@ -315,6 +325,12 @@ class RowBowt:
     def info(self):
         i = Info()
         _check(self.L.rbg_info(self.h, C.byref(i)), "rbg_info")
+        return i
+
+    def layout_info(self):
+        """what the load decided about the run-indexed layout (rbg_layout_info_t; all zero on the slot layout)"""
+        i = LayoutInfo()
+        _check(self.L.rbg_layout_info(self.h, C.byref(i), C.sizeof(i)), "rbg_layout_info")
         return i
 
     def get_f(self):

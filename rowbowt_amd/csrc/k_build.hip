@@ -322,6 +322,164 @@ __global__ __launch_bounds__(256) void k_pack_samp48(const uint64_t *__restrict_
 }
 }  // namespace
 
+// ---- format 2 of the run-indexed layout at 8-byte positions (rbg_dev.h DevRunTab2): fillers, low-word pairs, {count, hi}
+// directories, the phi list's 12-byte entries, its directory and super counts -- all from {key, value} u64 pairs on the device
+namespace {
+typedef unsigned long long u64pair __attribute__((ext_vector_type(2)));
+
+// arr[j + 1] = 1 + # fillers entry j needs (arr[0] = 0; an inclusive scan then gives every entry's place); *total += the
+// fillers.  ent: m pairs sorted by key within a table, every table closed by a sentinel with key n (phi: one table)
+__global__ __launch_bounds__(256) void k_fill_count(const u64pair *__restrict__ ent, const uint64_t m, const uint64_t n, const uint32_t fs, uint64_t *__restrict__ arr,
+                                                    unsigned long long *__restrict__ total) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    unsigned long long mine = 0;
+    for (uint64_t j = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < m; j += stride) {
+        const uint64_t key = ent[j].x;
+        uint64_t nf = 0;
+        if (key != n && j + 1 < m) {
+            const uint64_t gap = ent[j + 1].x - key;
+            nf = gap ? (gap - 1) >> fs : 0;
+        }
+        if (arr) { arr[j + 1] = 1 + nf; if (j == 0) arr[0] = 0; }
+        mine += nf;
+    }
+    mine = wave_sum(mine);
+    if ((threadIdx.x & (kWave - 1)) == 0 && mine) atomicAdd(total, mine);
+}
+// the list with its fillers: entry j goes to pos[j], its fillers behind it.  PHI: the value of a filler at key + f * G is
+// (value + f * G) mod n (phi(i) = base + (i - pos) unchanged); runs: value + min(f * G, run length) -- a continuation of
+// the run, or an empty run once it has ended -- and the run's sample again
+template <bool PHI>
+__global__ __launch_bounds__(256) void k_fill_expand(const u64pair *__restrict__ ent, const uint64_t *__restrict__ samp, const uint64_t m, const uint64_t n,
+                                                     const uint32_t fs, const uint64_t *__restrict__ pos, u64pair *__restrict__ ent_out, uint64_t *__restrict__ samp_out) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t j = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < m; j += stride) {
+        const u64pair e = ent[j];
+        const uint64_t o = pos[j], nf = pos[j + 1] - o - 1;
+        ent_out[o] = e;
+        const uint64_t sv = samp ? samp[j] : 0;
+        if (samp_out) samp_out[o] = sv;
+        if (!nf) continue;
+        const uint64_t len = PHI ? 0 : ent[j + 1].y - e.y;
+        for (uint64_t f = 1; f <= nf; ++f) {
+            const uint64_t adv = f << fs;
+            const uint64_t v = PHI ? (e.y + adv) % n : e.y + (adv < len ? adv : len);
+            ent_out[o + f] = u64pair{e.x + adv, v};
+            if (samp_out) samp_out[o + f] = sv;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_gather_u64(const uint64_t *__restrict__ src, const uint64_t *__restrict__ idx, const uint64_t count, uint64_t *__restrict__ out) {
+    const uint64_t j = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (j < count) out[j] = src[idx[j]];
+}
+// {start, cum} -> their low words (m pairs, then `spare` copies of the last)
+__global__ __launch_bounds__(256) void k_pack_pairs32(const u64pair *__restrict__ ent, const uint64_t m, const uint64_t spare, uint2 *__restrict__ out) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t j = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < m + spare; j += stride) {
+        const u64pair e = ent[j < m ? j : m - 1];
+        out[j] = make_uint2(static_cast<uint32_t>(e.x), static_cast<uint32_t>(e.y));
+    }
+}
+// {pos, base} -> PhiEnt12 (m entries incl. the sentinel, then `spare` copies of it)
+__global__ __launch_bounds__(256) void k_pack_phi12(const u64pair *__restrict__ ent, const uint64_t m, const uint64_t spare, PhiEnt12 *__restrict__ out) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t j = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < m + spare; j += stride) {
+        const u64pair e = ent[j < m ? j : m - 1];
+        out[j] = PhiEnt12{static_cast<uint32_t>(e.x), static_cast<uint32_t>(e.y), static_cast<uint32_t>(e.y >> 32)};
+    }
+}
+// RunDir64 directories of a depth's tables (k_run_dirs with the rank's high part beside the count)
+__global__ __launch_bounds__(256) void k_run_dirs2(const u64pair *__restrict__ ent, const uint64_t *__restrict__ first, const uint64_t *__restrict__ nruns,
+                                                   const uint64_t *__restrict__ doff, const uint32_t *__restrict__ dshift, const uint32_t T,
+                                                   const uint64_t total, RunDir64 *__restrict__ dir) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += stride) {
+        uint32_t a = 0, z = T;                       // the table: last t with doff[t] <= i
+        while (z - a > 1) {
+            const uint32_t mid = (a + z) >> 1;
+            if (doff[mid] <= i) a = mid; else z = mid;
+        }
+        const uint64_t lim = (i - doff[a]) << dshift[a];
+        const u64pair *__restrict__ e = ent + first[a];
+        uint64_t lo = 0, hi = nruns[a];
+        while (lo < hi) {
+            const uint64_t mid = lo + ((hi - lo) >> 1);
+            if (e[mid].x < lim) lo = mid + 1; else hi = mid;
+        }
+        dir[i] = RunDir64{static_cast<uint32_t>(lo), lo ? static_cast<uint32_t>(e[lo - 1].y >> 31) : 0u};
+    }
+}
+// the phi directory: dir[b] = low word of # entries with pos < b << shift; super[b >> ss] = that count in full (ss == 0: none)
+template <typename KeyAt>
+__device__ __forceinline__ uint64_t count_below(KeyAt key_at, uint64_t m, uint64_t lim) {
+    uint64_t lo = 0, hi = m;
+    while (lo < hi) {
+        const uint64_t mid = lo + ((hi - lo) >> 1);
+        if (key_at(mid) < lim) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+template <typename P>
+__global__ __launch_bounds__(256) void k_phi_dir(const void *__restrict__ ent, const uint64_t m, const uint32_t shift, const uint64_t nb, uint32_t *__restrict__ dir,
+                                                 const uint32_t ss, uint64_t *__restrict__ super) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t b = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; b < nb; b += stride) {
+        const uint64_t lim = b << shift;
+        uint64_t g;
+        if constexpr (sizeof(P) == 8) g = count_below([&](uint64_t j) { return static_cast<const u64pair *>(ent)[j].x; }, m, lim);
+        else g = count_below([&](uint64_t j) { return static_cast<uint64_t>(static_cast<const PhiEnt<uint32_t> *>(ent)[j].pos); }, m, lim);
+        dir[b] = static_cast<uint32_t>(g);
+        if (ss && (b & ((uint64_t(1) << ss) - 1)) == 0) super[b >> ss] = g;
+    }
+}
+inline int grid_of(uint64_t n) { return static_cast<int>(std::min<uint64_t>((n + 255) / 256, 256ull * 64)); }
+}  // namespace
+
+int launch_fill_count(const void *ent, uint64_t m, uint64_t n, uint32_t fill_shift, uint64_t *arr, unsigned long long *total, void *stream) {
+    if (!m) return 0;
+    hipLaunchKernelGGL(k_fill_count, dim3(grid_of(m)), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const u64pair *>(ent), m, n, fill_shift, arr, total);
+    return static_cast<int>(hipGetLastError());
+}
+int launch_scan_u64(uint64_t *vals, uint64_t N, void *tmp, size_t tmp_bytes, void *stream) { return scan_in_place(vals, N, tmp, tmp_bytes, static_cast<hipStream_t>(stream)); }
+int launch_fill_expand(bool phi, const void *ent, const uint64_t *samp, uint64_t m, uint64_t n, uint32_t fill_shift, const uint64_t *pos, void *ent_out, uint64_t *samp_out,
+                       void *stream) {
+    if (!m) return 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (phi) hipLaunchKernelGGL(k_fill_expand<true>, dim3(grid_of(m)), dim3(256), 0, st, static_cast<const u64pair *>(ent), samp, m, n, fill_shift, pos, static_cast<u64pair *>(ent_out), samp_out);
+    else hipLaunchKernelGGL(k_fill_expand<false>, dim3(grid_of(m)), dim3(256), 0, st, static_cast<const u64pair *>(ent), samp, m, n, fill_shift, pos, static_cast<u64pair *>(ent_out), samp_out);
+    return static_cast<int>(hipGetLastError());
+}
+int launch_gather_u64(const uint64_t *src, const uint64_t *idx, uint64_t count, uint64_t *out, void *stream) {
+    if (!count) return 0;
+    hipLaunchKernelGGL(k_gather_u64, dim3(static_cast<unsigned>((count + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), src, idx, count, out);
+    return static_cast<int>(hipGetLastError());
+}
+int launch_pack_pairs32(const void *ent, uint64_t m, uint64_t spare, void *out, void *stream) {
+    if (!m) return 0;
+    hipLaunchKernelGGL(k_pack_pairs32, dim3(grid_of(m + spare)), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const u64pair *>(ent), m, spare, static_cast<uint2 *>(out));
+    return static_cast<int>(hipGetLastError());
+}
+int launch_pack_phi12(const void *ent, uint64_t m, uint64_t spare, void *out, void *stream) {
+    if (!m) return 0;
+    hipLaunchKernelGGL(k_pack_phi12, dim3(grid_of(m + spare)), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const u64pair *>(ent), m, spare, static_cast<PhiEnt12 *>(out));
+    return static_cast<int>(hipGetLastError());
+}
+int launch_run_dirs2(const void *ent, const uint64_t *first, const uint64_t *nruns, const uint64_t *doff, const uint32_t *dshift, uint32_t T, uint64_t total,
+                     void *dir, void *stream) {
+    if (!total) return 0;
+    hipLaunchKernelGGL(k_run_dirs2, dim3(grid_of(total)), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const u64pair *>(ent), first, nruns, doff, dshift, T, total,
+                       static_cast<RunDir64 *>(dir));
+    return static_cast<int>(hipGetLastError());
+}
+int launch_phi_dir(uint32_t pos_bytes, const void *ent, uint64_t m, uint32_t shift, uint64_t nb, uint32_t *dir, uint32_t ss, uint64_t *super, void *stream) {
+    if (!nb) return 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (pos_bytes == 4) hipLaunchKernelGGL(k_phi_dir<uint32_t>, dim3(grid_of(nb)), dim3(256), 0, st, ent, m, shift, nb, dir, 0u, static_cast<uint64_t *>(nullptr));
+    else hipLaunchKernelGGL(k_phi_dir<uint64_t>, dim3(grid_of(nb)), dim3(256), 0, st, ent, m, shift, nb, dir, ss, super);
+    return static_cast<int>(hipGetLastError());
+}
+
 int launch_run_dirs(uint32_t pos_bytes, const void *ent, const uint64_t *first, const uint64_t *nruns, const uint64_t *doff, const uint32_t *dshift,
                     uint32_t T, uint64_t total, uint32_t *dir, void *stream) {
     if (!total) return 0;

@@ -686,8 +686,8 @@ int launch_marker_seeds_plan(const DevIndex &ix, const LaunchCfg &cfg, const uin
     hipStream_t st = static_cast<hipStream_t>(stream);
     const SeedLog lg = make_seed_log(log, log_bytes, N, ix.pos_bytes);   // base == nullptr: no log (two walks)
     int rc;
-    if (ix.layout == 2 && ftab_k == 0) {   // run-indexed layout, the tool's default mode: the cooperative kernel (k_runs_seeds.hip)
-        rc = launch_marker_seeds_runs(ix, cfg, seqs, off, N, wsize, max_range, seed_off, mk_off, nullptr, nullptr, nullptr, nullptr, false, stream, lg);
+    if (ix.layout == 2 && (ftab_k == 0 || ix.run_fmt == 2)) {   // run-indexed layout: k_runs_seeds.hip (format 1 with an ftab: the per-lane search below)
+        rc = launch_marker_seeds_runs(ix, cfg, seqs, off, N, wsize, max_range, seed_off, mk_off, nullptr, nullptr, nullptr, nullptr, false, stream, lg, ftab_k);
     } else {
 #define RBG_MSP1(PT, LG, SB)                                                                                                              \
     do {                                                                                                                                  \
@@ -727,8 +727,8 @@ int launch_marker_seeds_fill(const DevIndex &ix, const LaunchCfg &cfg, const uin
         rc = static_cast<int>(hipGetLastError());
         if (rc) return rc;
     }
-    if (ix.layout == 2 && ftab_k == 0)
-        return launch_marker_seeds_runs(ix, cfg, seqs, off, N, wsize, max_range, nullptr, nullptr, seed_off, mk_off, seeds, mk, true, stream, lg);
+    if (ix.layout == 2 && (ftab_k == 0 || ix.run_fmt == 2))
+        return launch_marker_seeds_runs(ix, cfg, seqs, off, N, wsize, max_range, nullptr, nullptr, seed_off, mk_off, seeds, mk, true, stream, lg, ftab_k);
 #define RBG_MSF1(PT, SB)                                                                                                                  \
     do {                                                                                                                                  \
         auto kern = k_marker_seeds<PT, true, false, SB>;                                                                                  \

@@ -12,7 +12,7 @@
 // first version of these kernels (16-lane rows, every value by ds_bpermute) was bound by the LDS pipe, not by
 // memory (profiles/).  The 16-lane rows remain for the narrowing of crowded buckets, the descent of an
 // index built without directories, the unordered phi walk and the optional bucket records.
-#include "rbg_runs_device.hpp"
+#include "rbg_runs2_device.hpp"
 
 namespace rbg {
 namespace {
@@ -48,8 +48,9 @@ struct PackedBits {   // per-lane reader of a packed read: peek / drop of up to 
     }
 };
 
-template <typename P, bool TOEHOLD, bool PACKED = false, bool STATS = false>
-__global__ __launch_bounds__(512, sizeof(P) == 4 ? 4 : 3) void k_find_range_runs(const DevIndex ix, const void *__restrict__ src_a,
+// V2: format 2 (rbg_runs2_device.hpp): every lane answers its own two ranks; the same steps in the same order
+template <typename P, bool TOEHOLD, bool PACKED = false, bool STATS = false, bool V2 = false>
+__global__ __launch_bounds__(512, (V2 || sizeof(P) == 4) ? 4 : 3) void k_find_range_runs(const DevIndex ix, const void *__restrict__ src_a,
                                                         const void *__restrict__ src_b, const uint64_t N,
                                                         uint64_t *__restrict__ lo_out, uint64_t *__restrict__ hi_out,
                                                         uint64_t *__restrict__ ss_out, unsigned long long *__restrict__ stats,
@@ -64,12 +65,24 @@ __global__ __launch_bounds__(512, sizeof(P) == 4 ? 4 : 3) void k_find_range_runs
     __shared__ uint8_t s_lut[256];
     __shared__ uint8_t s_lut2[256];
     __shared__ uint8_t s_mslot[4];
-    RBG_RUN_SEARCH_SHARED(P, 8);   // 512-thread workgroups
     for (int t = threadIdx.x; t < 256; t += blockDim.x) {
         s_lut[t] = ix.lut[t];
         s_lut2[t] = ix.nmajor ? ix.lut2[t] : 0xFFu;
     }
-    const RunSearch<P> S = stage_run_search<P, 8>(ix, s_tree, s_tab_first, s_rec, s_req, s_dyn);
+    RunSearch<P> S{};
+    RunSearch2<P> S2{};
+    const uint32_t *tab_first = nullptr;
+    const RunRec *const *rec_tabs = nullptr;
+    if constexpr (V2) {
+        RBG_RUN_SEARCH2_SHARED;
+        S2 = stage_run_search2<P>(ix, s_tab_first, s_ent2, s_dir2, s_dyn);
+        tab_first = s_tab_first;
+    } else {
+        RBG_RUN_SEARCH_SHARED(P, 8);   // 512-thread workgroups
+        S = stage_run_search<P, 8>(ix, s_tree, s_tab_first, s_rec, s_req, s_dyn);
+        tab_first = s_tab_first;
+        rec_tabs = s_rec;
+    }
     if (PACKED) {
         for (int t = threadIdx.x; t < 256; t += blockDim.x)
             if (s_lut2[t] != 0xFFu) s_mslot[s_lut2[t] & 3u] = s_lut[t];   // major index -> symbol slot
@@ -103,6 +116,7 @@ __global__ __launch_bounds__(512, sizeof(P) == 4 ? 4 : 3) void k_find_range_runs
         bool alive = valid;
         bool pend = false;                                     // deferred toehold re-sample (k_search.hip): the last one is the only one used
         uint32_t pend_d = 0, pend_run = 0, pend_c = 0;
+        uint64_t pend_e = 0;
         ByteCursor rd{reinterpret_cast<const uint4 *>(seqs), ~uint64_t(0), make_uint4(0, 0, 0, 0)};
         if (valid && ix.ftab_k && p - beg >= ix.ftab_k) {      // rowbowt.hpp:124-125, :745-758 (k_search.hip)
             uint64_t idx = 0;
@@ -138,7 +152,7 @@ __global__ __launch_bounds__(512, sizeof(P) == 4 ? 4 : 3) void k_find_range_runs
                     adv = p < D ? static_cast<uint32_t>(p) : D;
                     adv = 32u - static_cast<uint32_t>(__clz(DMASK & ((2u << (adv - 1)) - 1u)));   // the deepest depth kept that fits
                     const uint32_t v = bs.take(2 * adv);
-                    rec = run_record(s_tab_first, adv, adv == 1 ? static_cast<uint32_t>(s_mslot[v]) : v);
+                    rec = run_record(tab_first, adv, adv == 1 ? static_cast<uint32_t>(s_mslot[v]) : v);
                     d = adv - 1;
                     p -= 1;                                     // (the byte form's --p; the rest of adv is taken off after the step)
                 } else {
@@ -168,16 +182,18 @@ __global__ __launch_bounds__(512, sizeof(P) == 4 ? 4 : 3) void k_find_range_runs
                             alive = false;
                             stepping = false;
                         } else {
-                            rec = run_record(s_tab_first, 1u, slot);
+                            rec = run_record(tab_first, 1u, slot);
                         }
                     } else {
                         d = adv - 1;
-                        rec = run_record(s_tab_first, adv, acc);
+                        rec = run_record(tab_first, adv, acc);
                     }
                 }
             }
             RunStep r;
-            coop_lf2<P, STATS>(ix, S, stepping, d, rec, lo, hi + 1, r, st);   // rank(lo, c), rank(hi + 1, c): rowbowt.hpp:79,83
+            // rank(lo, c), rank(hi + 1, c): rowbowt.hpp:79,83
+            if constexpr (V2) { if (stepping) lane_lf2<P, STATS>(S2, d, rec, lo, hi + 1, r, st); }
+            else coop_lf2<P, STATS>(ix, S, stepping, d, rec, lo, hi + 1, r, st);
             if (stepping) {
                 if (STATS) st[kStSymbols] += adv;
                 const uint64_t c_inside = r.c_upto - r.c_before;
@@ -186,7 +202,7 @@ __global__ __launch_bounds__(512, sizeof(P) == 4 ? 4 : 3) void k_find_range_runs
                 } else {
                     if (TOEHOLD) {                              // LF_w_loc, rowbowt.hpp:559-566, `adv` times nested
                         if (r.inside) k = k - adv;
-                        else { pend = true; pend_d = d; pend_run = r.samp_run; pend_c = r.samp_c; k = 0; }
+                        else { pend = true; pend_d = d; pend_run = r.samp_run; pend_c = r.samp_c; pend_e = r.samp_e; k = 0; }
                     }
                     lo = r.F + r.c_before;                      // rowbowt.hpp:86
                     hi = lo + c_inside - 1;                     // rowbowt.hpp:87
@@ -195,9 +211,13 @@ __global__ __launch_bounds__(512, sizeof(P) == 4 ? 4 : 3) void k_find_range_runs
             }
         }
         if (TOEHOLD && alive && pend) {
-            RunStep ps;
-            ps.samp_run = pend_run; ps.samp_c = pend_c;
-            k += run_step_sample<P>(ix, s_rec, pend_d, ps);
+            if constexpr (V2) {
+                k += run_step_sample2<P>(ix, pend_d, pend_e);
+            } else {
+                RunStep ps;
+                ps.samp_run = pend_run; ps.samp_c = pend_c;
+                k += run_step_sample<P>(ix, rec_tabs, pend_d, ps);
+            }
             if (STATS) st[kStResample] += 1;
         }
         if (STATS && !PACKED && p_end > p_min) st[kStChunks] += ((p_end - 1) >> 4) - (p_min >> 4) + 1;
@@ -396,6 +416,112 @@ __global__ __launch_bounds__(256, sizeof(P) == 4 ? 4 : 3) void k_locate_fill_run
     }
 }
 
+
+// ---- K3, format 2: every lane walks its own chain and answers its own phi (rbg_runs2_device.hpp lane_phi) -----------------
+// Same chains, same staging of the values in LDS and the same coalesced flush as above; a phi step is one directory
+// gather (two neighbouring counts, plus the super count at 8-byte positions) and one scan of the bucket's few sampled
+// positions, no cross-lane traffic.  Works for ordered and unordered walks alike (the order only decides how well
+// neighbouring lanes share sectors).  STATS: [kLsPhiSteps] phi evaluations, [kLsPhiOvf] sampled positions the scans
+// and the narrowing rounds needed (8 or 12 bytes each; 7 pivot keys per round), [kLsChains], [kLsLocs].
+template <typename P, typename OUT = uint64_t, bool STATS = false>
+__global__ __launch_bounds__(256, 4) void k_locate_fill_runs2(const DevIndex ix, const uint64_t *__restrict__ lo,
+                                                          const uint64_t *__restrict__ hi, const uint64_t *__restrict__ k,
+                                                          const uint64_t N, const uint64_t max_hits,
+                                                          const uint64_t *__restrict__ loc_off, OUT *__restrict__ locs,
+                                                          const uint64_t *__restrict__ sub, const uint32_t *__restrict__ order,
+                                                          const uint64_t *__restrict__ skeys, unsigned long long *__restrict__ stats) {
+    constexpr int kChunkR = ChunkR<P>::v;
+    __shared__ P s_val[4][kWave][kChunkR + 1];
+    __shared__ uint64_t s_dst[4][kWave];
+    __shared__ uint64_t s_occ[4][kWave];
+    __shared__ uint64_t s_minus[4][kWave];
+    __shared__ uint64_t s_first[4][kWave];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
+    unsigned long long c_locs = 0;
+    unsigned long long st_phi = 0, st_ent = 0, st_chains = 0;   // STATS only
+    const uint64_t n = ix.n;
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t base = static_cast<uint64_t>(blockIdx.x) * blockDim.x + wv * kWave; base < N; base += stride) {
+        const uint64_t j = base + lane;
+        uint64_t i = j;
+        if (order && j < N) i = order[j];
+        uint64_t occ = 0, k1 = 0, dst = 0;
+        if (i < N && j < N) {
+            dst = loc_off[i];
+            if (skeys) {
+                k1 = skeys[j];
+                occ = loc_off[i + 1] - dst;
+            } else {
+                const uint64_t l = lo[i], h = hi[i];
+                occ = h >= l ? h - l + 1 : 0;                  // toehold_sa.hpp:38-39
+                if (occ > max_hits) occ = max_hits;
+                k1 = k[i];
+            }
+        }
+        const uint64_t minus = (sub && i < N && j < N) ? sub[i] : 0;
+        s_dst[wv][lane] = dst;
+        s_occ[wv][lane] = occ;
+        s_minus[wv][lane] = minus;
+        s_first[wv][lane] = k1;
+        c_locs += occ;
+        if (STATS && occ) st_chains += 1;
+        uint64_t wmax = occ;
+#pragma unroll
+        for (int o = kWave / 2; o > 0; o >>= 1) {
+            const uint64_t other = __shfl_xor(wmax, o, kWave);
+            wmax = other > wmax ? other : wmax;
+        }
+        for (uint64_t t0 = 0; t0 < wmax; t0 += kChunkR) {
+#pragma unroll 1
+            for (int e = 0; e < kChunkR; ++e) {
+                const uint64_t t = t0 + e;
+                if (t < occ && t > 0) {                        // toehold_sa.hpp:44: k = phi(k)
+                    uint64_t s;
+                    if (k1 >= n) {
+                        // a toehold below zero (k_locate.hip phi_step): outside phi's domain -- the last sample is its predecessor
+                        s = (ix.phi_last_base + (k1 - ix.phi_last_pos)) % n;
+                    } else {
+                        bool found;
+                        uint64_t val;
+                        uint32_t ents, rounds;
+                        lane_phi<P>(ix, k1, found, val, ents, rounds);
+                        if (STATS) { st_phi += 1; st_ent += ents + 7u * rounds; }
+                        // no sampled position before k1: circular predecessor = the last one, delta = i + 1
+                        // (sparse_sd_vector.hpp:141-143, toehold_sa.hpp:59,65); else prev_sample + delta (toehold_sa.hpp:65-71)
+                        s = found ? val : ix.phi_last_base + k1 + 1;
+                        if (s >= n) s -= n;
+                    }
+                    k1 = s;
+                }
+                if (t < occ) s_val[wv][lane][e] = static_cast<P>(k1);
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int pass = 0; pass < kChunkR; ++pass) {
+                const int s = pass * (kWave / kChunkR) + lane / kChunkR;
+                const int e = lane & (kChunkR - 1);
+                const uint64_t t = t0 + e;
+                if (t < s_occ[wv][s]) locs[s_dst[wv][s] + t] = static_cast<OUT>((t ? static_cast<uint64_t>(s_val[wv][s][e]) : s_first[wv][s]) - s_minus[wv][s]);
+            }
+            wave_lds_sync();
+        }
+        wave_lds_sync();
+    }
+    c_locs = wave_sum(c_locs);
+    if (lane == 0 && c_locs) atomicAdd(&ix.counters[3], c_locs);
+    if (STATS) {
+        st_phi = wave_sum(st_phi);
+        st_ent = wave_sum(st_ent);
+        st_chains = wave_sum(st_chains);
+        if (lane == 0) {
+            if (st_phi) atomicAdd(&stats[kLsPhiSteps], st_phi);
+            if (st_ent) atomicAdd(&stats[kLsPhiOvf], st_ent);
+            if (st_chains) atomicAdd(&stats[kLsChains], st_chains);
+            if (c_locs) atomicAdd(&stats[kLsLocs], c_locs);
+        }
+    }
+}
+
 }  // namespace
 
 // `packed`: src_a = chunks, src_b = meta (see the kernel); stats != nullptr: the instrumented instantiation
@@ -404,17 +530,22 @@ int launch_find_range_runs_impl(const DevIndex &ix, const LaunchCfg &cfg, const 
                                 const uint32_t *sel = nullptr, const uint32_t *nsel = nullptr) {
     if (N == 0) return 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const size_t lds = run_search_lds(ix);
+    const bool v2 = ix.run_fmt == 2;
+    const size_t lds = v2 ? run_search2_lds(ix) : run_search_lds(ix);
     LaunchCfg c = cfg;   // 512-thread workgroups: the staged tables and top level are shared by eight waves
     c.block_threads = 512;
     c.max_blocks = cfg.max_blocks > 0 ? std::max(1, cfg.max_blocks / 2) : 256 * 16;
     // sel mode: the number of reads is only known on the device; a fixed modest grid loops over it
     const dim3 grid(sel ? std::min(grid_for(c, N), 256) : grid_for(c, N)), block(512);
-#define RBG_LAUNCH_FRR(PT, TOE, PK, STS)                                                               \
+#define RBG_LAUNCH_FRR1(PT, TOE, PK, STS, V)                                                           \
     do {                                                                                               \
-        auto kern = k_find_range_runs<PT, TOE, PK, STS>;                                               \
+        auto kern = k_find_range_runs<PT, TOE, PK, STS, V>;                                            \
         raise_lds(kern, lds);                                                                          \
         hipLaunchKernelGGL(kern, grid, block, lds, st, ix, src_a, src_b, N, lo, hi, ssamp, stats, sel, nsel);     \
+    } while (0)
+#define RBG_LAUNCH_FRR(PT, TOE, PK, STS)                                                               \
+    do {                                                                                               \
+        if (v2) RBG_LAUNCH_FRR1(PT, TOE, PK, STS, true); else RBG_LAUNCH_FRR1(PT, TOE, PK, STS, false); \
     } while (0)
 #define RBG_LAUNCH_FRR2(PT, TOE)                                                                       \
     do {                                                                                               \
@@ -429,6 +560,7 @@ int launch_find_range_runs_impl(const DevIndex &ix, const LaunchCfg &cfg, const 
     }
 #undef RBG_LAUNCH_FRR2
 #undef RBG_LAUNCH_FRR
+#undef RBG_LAUNCH_FRR1
     return static_cast<int>(hipGetLastError());
 }
 
@@ -452,9 +584,25 @@ int launch_locate_fill_runs(const DevIndex &ix, const LaunchCfg &cfg, const uint
                             const void *order, const uint64_t *skeys, void *stream, unsigned long long *stats, uint32_t *locs32) {
     if (N == 0) return 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const size_t lds = static_cast<size_t>(ix.phi_tree.top_n) * ix.pos_bytes + 16;
     const dim3 grid(grid_for(cfg, N)), block(256);
     const uint32_t *perm = static_cast<const uint32_t *>(order);
+    if (ix.run_fmt == 2) {   // format 2: one kernel for ordered and unordered walks
+#define RBG_LAUNCH_LFR2(PT, OUT, STS, DST) \
+    hipLaunchKernelGGL((k_locate_fill_runs2<PT, OUT, STS>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, DST, sub, perm, skeys, stats)
+        if (locs32) {
+            if (stats || ix.pos_bytes != 4) return static_cast<int>(hipErrorInvalidValue);
+            RBG_LAUNCH_LFR2(uint32_t, uint32_t, false, locs32);
+        } else if (stats) {
+            if (ix.pos_bytes == 4) RBG_LAUNCH_LFR2(uint32_t, uint64_t, true, locs); else RBG_LAUNCH_LFR2(uint64_t, uint64_t, true, locs);
+        } else if (ix.pos_bytes == 4) {
+            RBG_LAUNCH_LFR2(uint32_t, uint64_t, false, locs);
+        } else {
+            RBG_LAUNCH_LFR2(uint64_t, uint64_t, false, locs);
+        }
+#undef RBG_LAUNCH_LFR2
+        return static_cast<int>(hipGetLastError());
+    }
+    const size_t lds = static_cast<size_t>(ix.phi_tree.top_n) * ix.pos_bytes + 16;
 #define RBG_LAUNCH_LFR(PT, ORD, OUT, STS, DST)                                                                          \
     do {                                                                                                               \
         auto kern = k_locate_fill_runs<PT, ORD, OUT, STS>;                                                             \

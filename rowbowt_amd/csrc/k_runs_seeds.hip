@@ -8,7 +8,7 @@
 // ftab entries, absent symbols, marker queries), the wave answers all the steps, every lane applies its result.
 // (Round 2 answered these kernels' ranks lane by lane with a binary search from the symbol's directory, single symbols
 // only: 104 ms per 10 M reads for the greedy seeds on the bench index against 8 ms for K1.)
-#include "rbg_runs_device.hpp"
+#include "rbg_runs2_device.hpp"
 
 namespace rbg {
 namespace {
@@ -91,26 +91,53 @@ __device__ __forceinline__ bool ftab_state(const DevIndex &ix, ByteCursor &rd, c
     return true;
 }
 
-#define RBG_SEED_KERNEL_PROLOGUE(P, WAVES)                                                        \
+// V2: format 2 of the layout (rbg_runs2_device.hpp): every lane answers its own ranks; the state machines stay as they are
+#define RBG_SEED_KERNEL_PROLOGUE(P, WAVES, V2)                                                    \
     __shared__ uint8_t s_lut[256];                                                                \
     __shared__ uint8_t s_lut2[256];                                                               \
-    RBG_RUN_SEARCH_SHARED(P, WAVES);                                                              \
     for (int t = threadIdx.x; t < 256; t += blockDim.x) {                                         \
         s_lut[t] = ix.lut[t];                                                                     \
         s_lut2[t] = ix.nmajor ? ix.lut2[t] : 0xFFu;                                               \
     }                                                                                             \
-    const RunSearch<P> S = stage_run_search<P, WAVES>(ix, s_tree, s_tab_first, s_rec, s_req, s_dyn); \
+    RunSearch<P> S{};                                                                             \
+    RunSearch2<P> S2{};                                                                           \
+    const uint32_t *tab_first = nullptr;                                                          \
+    const RunRec *const *rec_tabs = nullptr;                                                      \
+    if constexpr (V2) {                                                                           \
+        RBG_RUN_SEARCH2_SHARED;                                                                   \
+        S2 = stage_run_search2<P>(ix, s_tab_first, s_ent2, s_dir2, s_dyn);                        \
+        tab_first = s_tab_first;                                                                  \
+    } else {                                                                                      \
+        RBG_RUN_SEARCH_SHARED(P, WAVES);                                                          \
+        S = stage_run_search<P, WAVES>(ix, s_tree, s_tab_first, s_rec, s_req, s_dyn);             \
+        tab_first = s_tab_first;                                                                  \
+        rec_tabs = s_rec;                                                                         \
+    }                                                                                             \
+    (void)S; (void)S2; (void)rec_tabs;                                                            \
     const uint32_t D = ix.run_ksteps, DMASK = ix.run_depth_mask | 1u, M = ix.nmajor;              \
     const uint32_t lane = threadIdx.x & (kWave - 1);                                              \
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;                        \
     const uint64_t wave_first = static_cast<uint64_t>(blockIdx.x) * blockDim.x + (threadIdx.x & ~(kWave - 1))
 
+// both ranks of the step of every lane of the wave (format 1: cooperative, every lane must call; format 2: the lane's own)
+template <typename P, bool V2>
+__device__ __forceinline__ void seeds_lf2(const DevIndex &ix, const RunSearch<P> &S, const RunSearch2<P> &S2, const bool stepping, const uint32_t d,
+                                          const uint32_t rec, const uint64_t q0, const uint64_t q1, RunStep &r) {
+    if constexpr (V2) { if (stepping) lane_lf2<P>(S2, d, rec, q0, q1, r); }
+    else coop_lf2<P>(ix, S, stepping, d, rec, q0, q1, r);
+}
+template <typename P, bool V2>
+__device__ __forceinline__ uint64_t seeds_sample(const DevIndex &ix, const RunRec *const *rec_tabs, const uint32_t d, const RunStep &r) {
+    if constexpr (V2) return run_step_sample2<P>(ix, d, r.samp_e);
+    else return run_step_sample<P>(ix, rec_tabs, d, r);
+}
+
 // ---- single LF step for N (range, symbol) triples: RowBowt::LF(range_t, uint8_t), rowbowt.hpp:74-88 -------------------
-template <typename P>
-__global__ __launch_bounds__(512, sizeof(P) == 4 ? 4 : 3) void k_lf_runs(const DevIndex ix, const uint64_t *__restrict__ lo_in,
+template <typename P, bool V2>
+__global__ __launch_bounds__(512, (V2 || sizeof(P) == 4) ? 4 : 3) void k_lf_runs(const DevIndex ix, const uint64_t *__restrict__ lo_in,
                                                                         const uint64_t *__restrict__ hi_in, const uint8_t *__restrict__ sym,
                                                                         const uint64_t N, uint64_t *__restrict__ lo_out, uint64_t *__restrict__ hi_out) {
-    RBG_SEED_KERNEL_PROLOGUE(P, 8);
+    RBG_SEED_KERNEL_PROLOGUE(P, 8, V2);
     (void)D; (void)DMASK; (void)M; (void)s_lut2;
     for (uint64_t base = wave_first; base < N; base += stride) {
         const uint64_t i = base + lane;
@@ -123,10 +150,10 @@ __global__ __launch_bounds__(512, sizeof(P) == 4 ? 4 : 3) void k_lf_runs(const D
             const uint32_t slot = s_lut[sym[i]];
             // hi >= n is outside rle_string::rank's domain (assert(i<=n), rle_string.hpp:132): answer {1,0}
             stepping = slot != 0xFFu && slot < static_cast<uint32_t>(kLdsSyms) && hi < ix.n && lo <= hi + 1;
-            if (stepping) rec = run_record(s_tab_first, 1u, slot);
+            if (stepping) rec = run_record(tab_first, 1u, slot);
         }
         RunStep r;
-        coop_lf2<P>(ix, S, stepping, 0u, rec, lo, hi + 1, r);
+        seeds_lf2<P, V2>(ix, S, S2, stepping, 0u, rec, lo, hi + 1, r);
         if (valid) {
             uint64_t nlo = 1, nhi = 0;
             if (stepping && r.c_upto > r.c_before) { nlo = r.F + r.c_before; nhi = nlo + (r.c_upto - r.c_before) - 1; }
@@ -138,14 +165,14 @@ __global__ __launch_bounds__(512, sizeof(P) == 4 ? 4 : 3) void k_lf_runs(const D
 
 // ---- find_range_w_markers (rowbowt.hpp:292-339): single steps, a marker query at every window end ---------------------
 // (k_markers.hip k_find_range_markers; window results are PREPENDED in the reference, :320,:333)
-template <typename P, bool FILL>
-__global__ __launch_bounds__(512, sizeof(P) == 4 ? 4 : 3) void k_find_range_markers_runs(const DevIndex ix, const uint8_t *__restrict__ seqs,
+template <typename P, bool FILL, bool V2>
+__global__ __launch_bounds__(512, (V2 || sizeof(P) == 4) ? 4 : 3) void k_find_range_markers_runs(const DevIndex ix, const uint8_t *__restrict__ seqs,
                                                             const uint64_t *__restrict__ off, const uint64_t N,
                                                             const uint64_t wsize, const uint64_t max_range,
                                                             uint64_t *__restrict__ lo_out, uint64_t *__restrict__ hi_out,
                                                             uint64_t *__restrict__ cnt_out,
                                                             const uint64_t *__restrict__ mk_off, uint64_t *__restrict__ mk) {
-    RBG_SEED_KERNEL_PROLOGUE(P, 8);
+    RBG_SEED_KERNEL_PROLOGUE(P, 8, V2);
     (void)D; (void)DMASK; (void)M;
     if (!FILL && blockIdx.x == 0 && threadIdx.x == 0) cnt_out[0] = 0;
     for (uint64_t base = wave_first; base < N; base += stride) {
@@ -181,10 +208,10 @@ __global__ __launch_bounds__(512, sizeof(P) == 4 ? 4 : 3) void k_find_range_mark
             if (stepping) {
                 const uint32_t slot = s_lut[rd.at(end - 1 - s)];
                 if (slot == 0xFFu || slot >= static_cast<uint32_t>(kLdsSyms)) { alive = false; stepping = false; }
-                else rec = run_record(s_tab_first, 1u, slot);
+                else rec = run_record(tab_first, 1u, slot);
             }
             RunStep r;
-            coop_lf2<P>(ix, S, stepping, 0u, rec, lo, hi + 1, r);
+            seeds_lf2<P, V2>(ix, S, S2, stepping, 0u, rec, lo, hi + 1, r);
             if (stepping) {
                 const uint64_t c_inside = r.c_upto - r.c_before;
                 if (c_inside == 0) alive = false;
@@ -212,13 +239,13 @@ __global__ __launch_bounds__(512, sizeof(P) == 4 ? 4 : 3) void k_find_range_mark
 // ---- greedy seeding: RowBowt::get_seeds_greedy_w_sample (rowbowt.hpp:222-256) reduced on the fly by
 // locate_from_longest_seed's choice (:669-677): per read the first seed of strictly greatest length (k_markers.hip
 // k_greedy_seed).  A k-mer step that comes back empty is narrowed by halving until the failing base is the reference's.
-template <typename P>
-__global__ __launch_bounds__(512, sizeof(P) == 4 ? 4 : 3) void k_greedy_seed_runs(const DevIndex ix, const uint8_t *__restrict__ seqs,
+template <typename P, bool V2>
+__global__ __launch_bounds__(512, (V2 || sizeof(P) == 4) ? 4 : 3) void k_greedy_seed_runs(const DevIndex ix, const uint8_t *__restrict__ seqs,
                                                      const uint64_t *__restrict__ off, const uint64_t N,
                                                      const uint64_t min_length, uint64_t *__restrict__ lo_out,
                                                      uint64_t *__restrict__ hi_out, uint64_t *__restrict__ qs_out,
                                                      uint64_t *__restrict__ qe_out, uint64_t *__restrict__ ss_out) {
-    RBG_SEED_KERNEL_PROLOGUE(P, 8);
+    RBG_SEED_KERNEL_PROLOGUE(P, 8, V2);
     const uint64_t first_k = ix.last_run_sample;       // rowbowt.hpp:230
     const uint64_t fhi = ix.n - 1;
     for (uint64_t base = wave_first; base < N; base += stride) {
@@ -251,21 +278,21 @@ __global__ __launch_bounds__(512, sizeof(P) == 4 ? 4 : 3) void k_greedy_seed_run
                 if (nlen == 0) {
                     // a fresh seed: the state after its first ftab_k symbols is one gather in the device table
                     if (j == ei && ix.ftab_k && j >= ix.ftab_k && ftab_state<P>(ix, rd, s_lut2, p, M, lo, hi, k)) { on_ok(ix.ftab_k); continue; }
-                    pick = pick_step(rd, s_lut, s_lut2, s_tab_first, p, j, D, DMASK, M);
+                    pick = pick_step(rd, s_lut, s_lut2, tab_first, p, j, D, DMASK, M);
                     if (!pick.ok) { on_fail(); continue; }
                 } else {
-                    pick = pick_step(rd, s_lut, s_lut2, s_tab_first, p, nlen / 2, D, DMASK, M);   // == nlen / 2 symbols: the window holds k-mer symbols only
+                    pick = pick_step(rd, s_lut, s_lut2, tab_first, p, nlen / 2, D, DMASK, M);   // == nlen / 2 symbols: the window holds k-mer symbols only
                 }
                 stepping = true;
             }
             RunStep r;
-            coop_lf2<P>(ix, S, stepping, pick.d, pick.rec, lo, hi + 1, r);
+            seeds_lf2<P, V2>(ix, S, S2, stepping, pick.d, pick.rec, lo, hi + 1, r);
             if (stepping) {
                 const uint64_t c_inside = r.c_upto - r.c_before;
                 const bool ok = c_inside != 0;
                 if (ok) {                               // LF_w_loc, rowbowt.hpp:555-573, pick.adv times nested
                     if (r.inside) k = k - pick.adv;
-                    else k = run_step_sample<P>(ix, s_rec, pick.d, r);
+                    else k = seeds_sample<P, V2>(ix, rec_tabs, pick.d, r);
                     lo = r.F + r.c_before;
                     hi = lo + c_inside - 1;
                 }
@@ -295,14 +322,14 @@ __global__ __launch_bounds__(512, sizeof(P) == 4 ? 4 : 3) void k_greedy_seed_run
 // with that kernel (lane by lane).  One record per call of the reference's callback: {range lo, range hi, q.first,
 // seed_ei, first marker, one past last marker}.
 // LOG / lg: the marker-seed log (rbg_dev.h SeedLog), as in k_markers.hip k_marker_seeds
-template <typename P, bool FILL, bool LOG = false>
-__global__ __launch_bounds__(512, sizeof(P) == 4 ? 4 : 3) void k_marker_seeds_runs(const DevIndex ix, const uint8_t *__restrict__ seqs,
+template <typename P, bool FILL, bool LOG, bool V2>
+__global__ __launch_bounds__(512, (V2 || sizeof(P) == 4) ? 4 : 3) void k_marker_seeds_runs(const DevIndex ix, const uint8_t *__restrict__ seqs,
                                                       const uint64_t *__restrict__ off, const uint64_t N,
                                                       const uint64_t wsize, const uint64_t max_range,
                                                       uint64_t *__restrict__ seed_cnt, uint64_t *__restrict__ mk_cnt,
                                                       const uint64_t *__restrict__ seed_off, const uint64_t *__restrict__ mk_off,
                                                       uint64_t *__restrict__ seeds, uint64_t *__restrict__ mk, const SeedLog lg) {
-    RBG_SEED_KERNEL_PROLOGUE(P, 8);
+    RBG_SEED_KERNEL_PROLOGUE(P, 8, V2);
     if (!FILL && blockIdx.x == 0 && threadIdx.x == 0) { seed_cnt[0] = 0; mk_cnt[0] = 0; }
     const bool have_ma = ix.mk_nruns != 0;
     const uint64_t fhi = ix.n - 1;
@@ -385,15 +412,15 @@ __global__ __launch_bounds__(512, sizeof(P) == 4 ? 4 : 3) void k_marker_seeds_ru
                     if (dist == 0) dist = 1;
                     const uint64_t cap = dist < j ? dist : j;
                     if (j == seed_ei && ix.ftab_k && cap >= ix.ftab_k && ftab_state<P>(ix, rd, s_lut2, p, M, lo, hi, unused_k)) { on_ok(ix.ftab_k); continue; }
-                    pick = pick_step(rd, s_lut, s_lut2, s_tab_first, p, cap, D, DMASK, M);
+                    pick = pick_step(rd, s_lut, s_lut2, tab_first, p, cap, D, DMASK, M);
                     if (!pick.ok) { on_fail(); continue; }
                 } else {
-                    pick = pick_step(rd, s_lut, s_lut2, s_tab_first, p, nlen / 2, D, DMASK, M);
+                    pick = pick_step(rd, s_lut, s_lut2, tab_first, p, nlen / 2, D, DMASK, M);
                 }
                 stepping = true;
             }
             RunStep r;
-            coop_lf2<P>(ix, S, stepping, pick.d, pick.rec, lo, hi + 1, r);
+            seeds_lf2<P, V2>(ix, S, S2, stepping, pick.d, pick.rec, lo, hi + 1, r);
             if (stepping) {
                 const uint64_t c_inside = r.c_upto - r.c_before;
                 const bool ok = c_inside != 0;
@@ -427,6 +454,139 @@ __global__ __launch_bounds__(512, sizeof(P) == 4 ? 4 : 3) void k_marker_seeds_ru
     }
 }
 
+// ---- marker seeds with an ftab of k-mer size K (rb_markers --ftab; rowbowt.hpp:406-482 with :430-433, :454-464) on format 2:
+// the reference's loop in its own index, one lane per sequence (k_markers.hip k_marker_seeds' ftab branch, whose ranks on this
+// layout were a per-lane binary search of the symbol's run list until round 4).  search_ftab (:746-758) on the table
+// build_ftab(K) makes for this index is find_range of an ACGT-only k-mer: K symbols from the full range, taken as k-mer
+// steps through the depths' run lists; every other step of the loop is a single symbol, as in the reference.
+template <typename P, bool FILL, bool LOG>
+__global__ __launch_bounds__(512, 4) void k_marker_seeds_ftab_runs2(const DevIndex ix, const uint8_t *__restrict__ seqs, const uint64_t *__restrict__ off,
+                                                                    const uint64_t N, const uint64_t wsize, const uint64_t max_range, const uint64_t K,
+                                                                    uint64_t *__restrict__ seed_cnt, uint64_t *__restrict__ mk_cnt,
+                                                                    const uint64_t *__restrict__ seed_off, const uint64_t *__restrict__ mk_off,
+                                                                    uint64_t *__restrict__ seeds, uint64_t *__restrict__ mk, const SeedLog lg) {
+    RBG_SEED_KERNEL_PROLOGUE(P, 8, true);
+    (void)lane; (void)wave_first;
+    if (!FILL && blockIdx.x == 0 && threadIdx.x == 0) { seed_cnt[0] = 0; mk_cnt[0] = 0; }
+    const bool have_ma = ix.mk_nruns != 0;
+    const uint64_t fhi = ix.n - 1;
+    const bool listed = FILL && lg.base != nullptr;
+    const uint64_t Neff = listed ? static_cast<uint64_t>(lg.nsel[0]) : N;
+    for (uint64_t j_ = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j_ < Neff; j_ += stride) {
+        const uint64_t i = listed ? static_cast<uint64_t>(lg.nsel[4 + j_]) : j_;
+        const uint64_t beg = off[i], m = off[i + 1] - beg;
+        uint64_t lo = 0, hi = fhi, plo = 0, phi = fhi;    // range, prev_range (:427-428)
+        uint64_t window_ei = m, seed_ei = m;              // :434
+        uint64_t ns = 0, tot = 0, mb_begin = 0;
+        uint64_t *srec = FILL ? seeds + 6 * seed_off[i] : nullptr;
+        const uint64_t mbase = FILL ? mk_off[i] : 0;
+        unsigned char *lbase = LOG ? lg.base + i * lg.stride : nullptr;
+        SeedLogRec<P> *lrec = reinterpret_cast<SeedLogRec<P> *>(lbase + 8);
+        SeedLogWin *lwin = reinterpret_cast<SeedLogWin *>(lbase + 8 + static_cast<size_t>(lg.qs) * sizeof(SeedLogRec<P>));
+        uint32_t nw = 0;
+        bool lover = LOG && (m >> 32) != 0;
+        ByteCursor rd{reinterpret_cast<const uint4 *>(seqs), ~uint64_t(0), make_uint4(0, 0, 0, 0)};
+        auto update_mbuf = [&](uint64_t l, uint64_t h) {  // :437-441
+            if (!have_ma || h - l + 1 > max_range) return;
+            uint64_t f, e;
+            marker_span_r(ix, l, h, &f, &e);
+            if (e <= f) return;
+            const uint64_t src = ix.mk_off[f], cnt = ix.mk_off[e] - src;
+            if (FILL) {
+                uint64_t *d = mk + mbase + tot;
+                for (uint64_t t = 0; t < cnt; ++t) d[t] = ix.mk_vals[src + t];
+            }
+            if (LOG) {
+                if (nw < lg.qw && ((src + cnt) >> 32) == 0) lwin[nw] = SeedLogWin{static_cast<uint32_t>(src), static_cast<uint32_t>(cnt)};
+                else lover = true;
+                ++nw;
+            }
+            tot += cnt;
+        };
+        auto emit = [&](uint64_t l, uint64_t h, uint64_t qs, uint64_t qe) {  // fn(range, (qs, qe-1), mbuf)
+            if (FILL) {
+                uint64_t *d = srec + 6 * ns;
+                d[0] = l; d[1] = h; d[2] = qs; d[3] = qe; d[4] = mbase + mb_begin; d[5] = mbase + tot;
+            }
+            if (LOG) {
+                if (ns < lg.qs && (tot >> 32) == 0)
+                    lrec[ns] = SeedLogRec<P>{static_cast<P>(l), static_cast<P>(h), static_cast<uint32_t>(qs), static_cast<uint32_t>(qe),
+                                             static_cast<uint32_t>(mb_begin), static_cast<uint32_t>(tot)};
+                else lover = true;
+            }
+            ++ns;
+        };
+        // one step of at most `cap` symbols ending at byte p on (lo, hi): *adv = symbols consumed; false = empty range, (lo, hi) untouched
+        auto step = [&](uint64_t p, uint64_t cap, uint32_t *adv) -> bool {
+            const StepPick pick = pick_step(rd, s_lut, s_lut2, tab_first, p, cap, D, DMASK, M);
+            *adv = pick.adv;
+            if (!pick.ok) return false;
+            RunStep r;
+            lane_lf2<P>(S2, pick.d, pick.rec, lo, hi + 1, r);
+            if (r.c_upto <= r.c_before) return false;
+            lo = r.F + r.c_before;
+            hi = lo + (r.c_upto - r.c_before) - 1;
+            return true;
+        };
+        auto ftab_hit = [&](uint64_t e) -> bool {   // k-mer q[e-K, e); on a hit (lo,hi) is its range
+            for (uint64_t t = e - K; t < e; ++t) {
+                const uint32_t c = rd.at(beg + t);
+                if (c != 'A' && c != 'C' && c != 'G' && c != 'T') return false;
+            }
+            lo = 0; hi = fhi;
+            uint64_t e2 = e;
+            while (e2 > e - K) {
+                uint32_t adv;
+                if (!step(beg + e2 - 1, e2 - (e - K), &adv)) return false;   // a k-mer of the word is absent: so is the word
+                e2 -= adv;
+            }
+            return true;
+        };
+        uint64_t i2 = 0;
+        if (m >= K) {                                  // :430-433 (a shorter read makes the reference throw)
+            if (ftab_hit(m)) i2 = K; else { lo = 0; hi = fhi; }
+            plo = lo; phi = hi;
+        }
+        for (; i2 < m; ++i2) {
+            uint32_t adv1;
+            if (step(beg + m - i2 - 1, 1, &adv1)) {        // :443
+                if (window_ei - (m - i2 - 1) >= wsize) {   // :469-472
+                    update_mbuf(lo, hi);
+                    window_ei = m - i2 - 1;
+                }
+                plo = lo; phi = hi;                    // :473
+            } else {                                   // :444-467
+                if (seed_ei - (m - i2) >= wsize) update_mbuf(plo, phi);
+                emit(plo, phi, m - i2, seed_ei);
+                mb_begin = tot;
+                plo = 0; phi = fhi;
+                seed_ei = m - i2 - 1;
+                window_ei = m - i2 - 1;
+                lo = 0; hi = fhi;
+                if (m - i2 - 1 >= K) {
+                    // :454-464 (k_markers.hip: search_ftab answers an absent k-mer with the full range, so the reference's
+                    // loop always leaves on its first iteration: a hit continues from the k-mer's range, a miss from the
+                    // FULL range, the K bases skipped either way)
+                    if (!ftab_hit(m - i2 - 1)) { lo = 0; hi = fhi; }
+                    i2 += K;                           // :460
+                    plo = lo; phi = hi;                // :461
+                }
+            }
+        }
+        if (hi >= lo && seed_ei - (m - i2) >= wsize) update_mbuf(lo, hi);   // :478-480
+        emit(lo, hi, m - i2, seed_ei);                                      // :481
+        if (!FILL) {
+            seed_cnt[i + 1] = ns;
+            mk_cnt[i + 1] = tot;
+        }
+        if (LOG) {
+            uint32_t *hdr = reinterpret_cast<uint32_t *>(lbase);
+            hdr[0] = lover ? kSeedLogOverflow : static_cast<uint32_t>(ns);
+            hdr[1] = nw;
+        }
+    }
+}
+
 struct SeedLaunch {
     dim3 grid, block;
     size_t lds;
@@ -435,7 +595,7 @@ SeedLaunch seed_launch(const DevIndex &ix, const LaunchCfg &cfg, uint64_t N) {
     LaunchCfg c = cfg;   // 512-thread workgroups: the staged tables are shared by eight waves
     c.block_threads = 512;
     c.max_blocks = cfg.max_blocks > 0 ? std::max(1, cfg.max_blocks / 2) : 256 * 16;
-    return SeedLaunch{dim3(grid_for(c, N)), dim3(512), run_search_lds(ix)};
+    return SeedLaunch{dim3(grid_for(c, N)), dim3(512), ix.run_fmt == 2 ? run_search2_lds(ix) : run_search_lds(ix)};
 }
 
 }  // namespace
@@ -452,8 +612,9 @@ int launch_lf_runs(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t *lo,
     if (N == 0) return 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const SeedLaunch L = seed_launch(ix, cfg, N);
-    if (ix.pos_bytes == 4) RBG_LAUNCH_SEEDK(k_lf_runs<uint32_t>, lo, hi, sym, N, lo_out, hi_out);
-    else RBG_LAUNCH_SEEDK(k_lf_runs<uint64_t>, lo, hi, sym, N, lo_out, hi_out);
+    const bool v2 = ix.run_fmt == 2;
+    if (ix.pos_bytes == 4) { if (v2) RBG_LAUNCH_SEEDK((k_lf_runs<uint32_t, true>), lo, hi, sym, N, lo_out, hi_out); else RBG_LAUNCH_SEEDK((k_lf_runs<uint32_t, false>), lo, hi, sym, N, lo_out, hi_out); }
+    else { if (v2) RBG_LAUNCH_SEEDK((k_lf_runs<uint64_t, true>), lo, hi, sym, N, lo_out, hi_out); else RBG_LAUNCH_SEEDK((k_lf_runs<uint64_t, false>), lo, hi, sym, N, lo_out, hi_out); }
     return static_cast<int>(hipGetLastError());
 }
 
@@ -462,13 +623,15 @@ int launch_find_range_markers_runs(const DevIndex &ix, const LaunchCfg &cfg, con
                                    uint64_t *mk, bool fill, void *stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     const SeedLaunch L = seed_launch(ix, cfg, N);
-    if (ix.pos_bytes == 4) {
-        if (fill) RBG_LAUNCH_SEEDK((k_find_range_markers_runs<uint32_t, true>), seqs, off, N, wsize, max_range, lo, hi, cnt, mk_off, mk);
-        else RBG_LAUNCH_SEEDK((k_find_range_markers_runs<uint32_t, false>), seqs, off, N, wsize, max_range, lo, hi, cnt, mk_off, mk);
-    } else {
-        if (fill) RBG_LAUNCH_SEEDK((k_find_range_markers_runs<uint64_t, true>), seqs, off, N, wsize, max_range, lo, hi, cnt, mk_off, mk);
-        else RBG_LAUNCH_SEEDK((k_find_range_markers_runs<uint64_t, false>), seqs, off, N, wsize, max_range, lo, hi, cnt, mk_off, mk);
-    }
+#define RBG_FRM(PT, V)                                                                                                                        \
+    do {                                                                                                                                     \
+        if (fill) RBG_LAUNCH_SEEDK((k_find_range_markers_runs<PT, true, V>), seqs, off, N, wsize, max_range, lo, hi, cnt, mk_off, mk);        \
+        else RBG_LAUNCH_SEEDK((k_find_range_markers_runs<PT, false, V>), seqs, off, N, wsize, max_range, lo, hi, cnt, mk_off, mk);            \
+    } while (0)
+    const bool v2 = ix.run_fmt == 2;
+    if (ix.pos_bytes == 4) { if (v2) RBG_FRM(uint32_t, true); else RBG_FRM(uint32_t, false); }
+    else { if (v2) RBG_FRM(uint64_t, true); else RBG_FRM(uint64_t, false); }
+#undef RBG_FRM
     return static_cast<int>(hipGetLastError());
 }
 
@@ -477,24 +640,39 @@ int launch_greedy_seed_runs(const DevIndex &ix, const LaunchCfg &cfg, const uint
     if (N == 0) return 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const SeedLaunch L = seed_launch(ix, cfg, N);
-    if (ix.pos_bytes == 4) RBG_LAUNCH_SEEDK(k_greedy_seed_runs<uint32_t>, seqs, off, N, min_length, lo, hi, qs, qe, ss);
-    else RBG_LAUNCH_SEEDK(k_greedy_seed_runs<uint64_t>, seqs, off, N, min_length, lo, hi, qs, qe, ss);
+    const bool v2 = ix.run_fmt == 2;
+    if (ix.pos_bytes == 4) { if (v2) RBG_LAUNCH_SEEDK((k_greedy_seed_runs<uint32_t, true>), seqs, off, N, min_length, lo, hi, qs, qe, ss); else RBG_LAUNCH_SEEDK((k_greedy_seed_runs<uint32_t, false>), seqs, off, N, min_length, lo, hi, qs, qe, ss); }
+    else { if (v2) RBG_LAUNCH_SEEDK((k_greedy_seed_runs<uint64_t, true>), seqs, off, N, min_length, lo, hi, qs, qe, ss); else RBG_LAUNCH_SEEDK((k_greedy_seed_runs<uint64_t, false>), seqs, off, N, min_length, lo, hi, qs, qe, ss); }
     return static_cast<int>(hipGetLastError());
 }
 
 int launch_marker_seeds_runs(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N, uint64_t wsize,
                              uint64_t max_range, uint64_t *seed_cnt, uint64_t *mk_cnt, const uint64_t *seed_off, const uint64_t *mk_off,
-                             uint64_t *seeds, uint64_t *mk, bool fill, void *stream, const SeedLog &lg) {
+                             uint64_t *seeds, uint64_t *mk, bool fill, void *stream, const SeedLog &lg, uint64_t ftab_k) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     SeedLaunch L = seed_launch(ix, cfg, N);
     if (fill && lg.base) L.grid = dim3(std::min<unsigned>(L.grid.x, 128u));   // the listed sequences only: their number is on the device
-#define RBG_MSR(PT)                                                                                                                          \
+    if (ftab_k) {   // rb_markers --ftab (format 2 only: launch_marker_seeds_plan / _fill keep format 1 on the per-lane slot kernel)
+        if (ix.run_fmt != 2) return static_cast<int>(hipErrorNotSupported);
+#define RBG_MSF(PT)                                                                                                                          \
     do {                                                                                                                                     \
-        if (fill) RBG_LAUNCH_SEEDK((k_marker_seeds_runs<PT, true, false>), seqs, off, N, wsize, max_range, seed_cnt, mk_cnt, seed_off, mk_off, seeds, mk, lg); \
-        else if (lg.base) RBG_LAUNCH_SEEDK((k_marker_seeds_runs<PT, false, true>), seqs, off, N, wsize, max_range, seed_cnt, mk_cnt, seed_off, mk_off, seeds, mk, lg); \
-        else RBG_LAUNCH_SEEDK((k_marker_seeds_runs<PT, false, false>), seqs, off, N, wsize, max_range, seed_cnt, mk_cnt, seed_off, mk_off, seeds, mk, lg); \
+        if (fill) RBG_LAUNCH_SEEDK((k_marker_seeds_ftab_runs2<PT, true, false>), seqs, off, N, wsize, max_range, ftab_k, seed_cnt, mk_cnt, seed_off, mk_off, seeds, mk, lg); \
+        else if (lg.base) RBG_LAUNCH_SEEDK((k_marker_seeds_ftab_runs2<PT, false, true>), seqs, off, N, wsize, max_range, ftab_k, seed_cnt, mk_cnt, seed_off, mk_off, seeds, mk, lg); \
+        else RBG_LAUNCH_SEEDK((k_marker_seeds_ftab_runs2<PT, false, false>), seqs, off, N, wsize, max_range, ftab_k, seed_cnt, mk_cnt, seed_off, mk_off, seeds, mk, lg); \
     } while (0)
-    if (ix.pos_bytes == 4) RBG_MSR(uint32_t); else RBG_MSR(uint64_t);
+        if (ix.pos_bytes == 4) RBG_MSF(uint32_t); else RBG_MSF(uint64_t);
+#undef RBG_MSF
+        return static_cast<int>(hipGetLastError());
+    }
+#define RBG_MSR(PT, V)                                                                                                                       \
+    do {                                                                                                                                     \
+        if (fill) RBG_LAUNCH_SEEDK((k_marker_seeds_runs<PT, true, false, V>), seqs, off, N, wsize, max_range, seed_cnt, mk_cnt, seed_off, mk_off, seeds, mk, lg); \
+        else if (lg.base) RBG_LAUNCH_SEEDK((k_marker_seeds_runs<PT, false, true, V>), seqs, off, N, wsize, max_range, seed_cnt, mk_cnt, seed_off, mk_off, seeds, mk, lg); \
+        else RBG_LAUNCH_SEEDK((k_marker_seeds_runs<PT, false, false, V>), seqs, off, N, wsize, max_range, seed_cnt, mk_cnt, seed_off, mk_off, seeds, mk, lg); \
+    } while (0)
+    const bool v2 = ix.run_fmt == 2;
+    if (ix.pos_bytes == 4) { if (v2) RBG_MSR(uint32_t, true); else RBG_MSR(uint32_t, false); }
+    else { if (v2) RBG_MSR(uint64_t, true); else RBG_MSR(uint64_t, false); }
 #undef RBG_MSR
     return static_cast<int>(hipGetLastError());
 }

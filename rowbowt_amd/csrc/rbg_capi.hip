@@ -60,6 +60,16 @@ struct rbg_index {
     uint64_t kmer_steps_requested = 0, hbm_free_at_load = 0, hbm_budget = 0;  // how the space/speed point was chosen (rbg_info)
     bool runs_layout = false;
     uint32_t run_depth_mask = 0;   // run-indexed layout: the k-mer depths that have run lists (bit d - 1)
+    // what the load decided about the run-indexed layout (rbg_layout_info): nothing is left out without a line here
+    struct RunsReport {
+        uint32_t fmt = 0, depth_mask_asked = 0, depth_mask_kept = 0, depths_composed = 0;
+        uint64_t entries[kMaxRunDepth] = {0, 0, 0, 0, 0}, fillers[kMaxRunDepth] = {0, 0, 0, 0, 0}, dir_bytes[kMaxRunDepth] = {0, 0, 0, 0, 0};
+        uint64_t phi_entries = 0, phi_fillers = 0, phi_dir_bytes = 0, phi_dir_shift = 0;
+        uint32_t rank_dirs = 0, phi_dir = 0;       // 1: present
+        uint32_t depths_dropped_budget = 0;        // mask of depths the HBM budget left out
+        uint32_t depths_dropped_limit = 0;         // mask of depths a width limit left out (format 1: 2^32 entries)
+        uint32_t phi_dir_dropped = 0;              // 1: format 1 left the phi directory out (2 GiB / r >= 2^31)
+    } runs_report;
     // one-read host calls from concurrent threads are combined into one launch ("group commit", see Combiner below)
     struct Combiner {
         std::mutex mu;
@@ -120,6 +130,7 @@ std::atomic<int64_t> g_opt_dense_overflow{1};
 std::atomic<int64_t> g_opt_rank_layout{env_opt("RBG_LAYOUT", RBG_LAYOUT_AUTO, RBG_LAYOUT_AUTO, RBG_LAYOUT_RUNS)};    // RBG_LAYOUT_AUTO / _SLOTS / _RUNS
 std::atomic<int64_t> g_opt_tree_top_kb{48};   // LDS the staged top levels of the run-indexed search may take per workgroup
 std::atomic<int64_t> g_opt_run_depths{env_opt("RBG_RUN_DEPTHS", 0, 0, (1 << kMaxRunDepth) - 1)};    // run-indexed layout: bit d - 1 = keep the k-mer depth d (0 = every other depth from the deepest down)
+std::atomic<int64_t> g_opt_run_fmt{env_opt("RBG_RUN_FMT", 2, 1, 2)};   // run-indexed layout: 1 = {P, P} pairs probed by quads of lanes (rounds 2-3), 2 = per-lane probes (rbg_dev.h DevRunTab2)
 std::atomic<int64_t> g_opt_slot_bytes{16};    // 16: RankSlot; 64: RankSlot64 (experiment: rbg_dev.h)
 std::atomic<int64_t> g_opt_packed_reads{1};  // host-pointer calls: 0 bytes over PCIe, 1 (default) 2-bit codes for batches >= 4096, 2 always
 
@@ -680,19 +691,26 @@ double rank_rec_target() {
 
 // bytes of the run-indexed replica with the k-mer depths of `mask` (bit d - 1) among those h holds (run lists, samples,
 // 1/15 of sampled keys, phi)
+bool runs_format1() {   // format 2 (per-lane probes) needs the directories; the options that build an index without them, or with bucket records, keep format 1
+    const char *e_rd = std::getenv("RBG_RANK_DIR"), *e_pd = std::getenv("RBG_PHI_DIR"), *e_hb = std::getenv("RBG_RUNS_HOST_BUILD");
+    return g_opt_run_fmt.load() == 1 || (e_rd && e_rd[0] == '0') || (e_pd && e_pd[0] == '0') || rank_rec_target() > 0 || (e_hb && e_hb[0] == '1');
+}
 template <typename P>
 size_t runs_replica_bytes(const HostIndex &h, uint32_t mask = ~0u) {
     size_t total = 0;
     const double rec_target = rank_rec_target();
+    const bool f2 = !runs_format1();
+    // format 2: 8-byte entries at either width, directory entries of 4 / 8 bytes per (at most) half a run, no sampled levels
+    const size_t ent_bytes = f2 ? 8 : RunsFmt<P>::ent_bytes, dir_per_entry = f2 && sizeof(P) == 8 ? 4 : 2, lvl_per_entry = f2 ? 0 : sizeof(P);
     uint32_t di = 0;
     for (const std::vector<SymTable> *lv : {&h.sym, &h.pair, &h.triple, &h.quad, &h.quint}) {
         if (!((mask | 1u) >> di++ & 1u)) continue;
         size_t entries = 0;
         for (const SymTable &t : *lv) entries += t.nruns + 1;
-        total += entries * (RunsFmt<P>::ent_bytes + (h.has_tsa ? RunsFmt<P>::samp_bytes : 0)) + entries * sizeof(P) / 15 + entries * 2 + lv->size() * 8 + 8 * kArenaAlign;   // (+ directories: at most half an entry per run)
+        total += entries * (ent_bytes + (h.has_tsa ? RunsFmt<P>::samp_bytes : 0)) + entries * lvl_per_entry / 15 + entries * dir_per_entry + lv->size() * 8 + 8 * kArenaAlign;
         if (rec_target > 0) total += static_cast<size_t>(2.0 * static_cast<double>(entries) / rec_target + static_cast<double>(lv->size())) * sizeof(RunRec);   // (+ bucket records)
     }
-    if (h.has_tsa) total += (h.r + 1) * PhiFmt<P>::ent_bytes + h.r * sizeof(P) / 15 + std::min<size_t>(h.r, size_t(1) << 29) * 4;   // (+ the phi directory: at most r entries)
+    if (h.has_tsa) total += (h.r + 1) * PhiFmt<P>::ent_bytes + h.r * lvl_per_entry / 15 + (f2 ? h.r * 4 : std::min<size_t>(h.r, size_t(1) << 29) * 4);   // (+ the phi directory: at most r entries)
     return total + 16 * kArenaAlign;
 }
 
@@ -730,10 +748,20 @@ int upload_tables_runs(rbg_index *ix) {
         for (const SymTable &t : *depth[d]) entries += t.nruns + 1;
         sizes.push_back(entries);
     }
-    // entry indices are 32-bit in the kernels: a depth with more entries than that is left out (never seen: 6.5e7 at
-    // the bench index's deepest level, 5e8 at r = 3e8)
-    while (D > 1 && sizes[D - 1] >= 0xFFFFFFF0ull) { --D; sizes.pop_back(); }
-    if (sizes[0] >= 0xFFFFFFF0ull) return RBG_EARG;
+    // entry indices are 32-bit in THIS format's kernels (format 2, the default, has 64-bit ones: upload_tables_runs2).  Until
+    // round 4 a depth with more entries was left out without a word -- and the depth forced in its place could have been
+    // released already; now it is an error that names the way out.  RBG_RUN1_MAX_ENTRIES lowers the limit for the test.
+    const uint64_t max_entries = static_cast<uint64_t>(env_opt("RBG_RUN1_MAX_ENTRIES", 0xFFFFFFF0ll, 16, 0xFFFFFFF0ll));
+    ix->runs_report.fmt = 1;
+    ix->runs_report.depths_composed = D;
+    for (uint32_t d = 0; d < D; ++d)
+        if (sizes[d] >= max_entries && ((ix->run_depth_mask ? ix->run_depth_mask : ~0u) >> d & 1u || d == 0 || d + 1 == D)) {
+            std::fprintf(stderr, "rbg: k-mer depth %u has %llu run-list entries: format 1 of the run-indexed layout holds fewer than %llu per depth; "
+                                 "use format 2 (RBG_OPT_RUN_FMT / RBG_RUN_FMT=2, the default), whose entry indices are 64-bit\n",
+                         d + 1, static_cast<unsigned long long>(sizes[d]), static_cast<unsigned long long>(max_entries));
+            ix->runs_report.depths_dropped_limit |= 1u << d;
+            return RBG_EARG;
+        }
     // depths without run lists (rbg_index::run_depth_mask; the deepest is always kept: the kernels step by it)
     uint32_t mask = (ix->run_depth_mask ? ix->run_depth_mask : ~0u) & ((1u << D) - 1u);
     mask |= 1u | (1u << (D - 1));
@@ -1007,6 +1035,9 @@ int upload_tables_runs(rbg_index *ix) {
     ix->dev.run_ksteps = D;
     ix->dev.run_depth_mask = mask;
     ix->run_depth_mask = mask;
+    ix->runs_report.depth_mask_kept = mask;
+    for (uint32_t d = 0; d < D; ++d)
+        if (mask >> d & 1u) { ix->runs_report.entries[d] = sizes[d]; ix->runs_report.rank_dirs |= ix->dev.run_dir[d] ? 1u : 0u; }
     if ((rc = dev_upload(ix, top_all.data(), top_all.size() * sizeof(P), &ix->dev.tree_top))) return rc;
     ix->dev.tree_top_n = static_cast<uint32_t>(top_all.size());
     ix->dev.tree_nlvl = nlvl;
@@ -1044,7 +1075,8 @@ int upload_tables_runs(rbg_index *ix) {
         while (ds < 24 && (static_cast<double>(h.r) * static_cast<double>(uint64_t(1) << ds)) / static_cast<double>(h.n) < 2.0) ++ds;
         const uint64_t nd = (h.n >> ds) + 2;
         const char *e_dir = std::getenv("RBG_PHI_DIR");   // "0": descent only (A/B measurements, tests)
-        if (nd * 4 <= (uint64_t(2) << 30) && h.r < 0x7FFFFFF0ull && !(e_dir && e_dir[0] == '0')) {
+        const uint64_t dir_max = static_cast<uint64_t>(env_opt("RBG_PHI1_DIR_MAX_BYTES", int64_t(2) << 30, 16, int64_t(2) << 30));   // (lowered by the test of the line below)
+        if (nd * 4 <= dir_max && h.r < 0x7FFFFFF0ull && !(e_dir && e_dir[0] == '0')) {
             std::vector<uint32_t> dir(nd);
             uint64_t g = 0;
             for (uint64_t b = 0; b < nd; ++b) {
@@ -1056,7 +1088,334 @@ int upload_tables_runs(rbg_index *ix) {
             if ((rc = dev_upload(ix, dir.data(), dir.size() * 4, &dp))) return rc;
             ix->dev.phi_dir = static_cast<const uint32_t *>(dp);
             ix->dev.phi_dir_shift = ds;
+            ix->runs_report.phi_dir = 1;
+            ix->runs_report.phi_dir_bytes = nd * 4;
+            ix->runs_report.phi_dir_shift = ds;
+        } else if (!(e_dir && e_dir[0] == '0')) {
+            std::fprintf(stderr, "rbg: format 1 of the run-indexed layout leaves the phi directory out beyond 2 GiB or r >= 2^31 (%.2f GB, r = %llu): phi descends "
+                                 "the sampled levels, several times slower; format 2 (RBG_RUN_FMT=2, the default) has no such limit\n",
+                         nd * 4 / 1e9, static_cast<unsigned long long>(h.r));
+            ix->runs_report.phi_dir_dropped = 1;
         }
+        ix->runs_report.phi_entries = h.r;
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    return RBG_OK;
+}
+
+
+// ---- FORMAT 2 of the run-indexed layout (rbg_dev.h DevRunTab2; kernels: rbg_runs2_device.hpp) ----------------------------
+// Same inputs as upload_tables_runs: the depth-1 tables of the host index and the k-mer levels composed on the device.
+// Everything but the conversion of the depth-1 lists happens in kernels (k_build.hip): fillers (8-byte positions, only
+// where a table has a gap of 2^30 rows or more), the low-word pairs, the directories, the phi list, its directory and
+// super counts.  Nothing is left out for its size: entry indices are 64-bit, a table may hold up to 2^32 - 16 entries
+// (more is an error with a message, not a silent drop), and the phi directory has no size cap.
+struct TmpDev {   // device scratch of the load, freed at scope exit
+    void *p = nullptr;
+    ~TmpDev() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) {
+        hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+        if (e != hipSuccess) { (void)hipGetLastError(); p = nullptr; return e == hipErrorOutOfMemory ? RBG_ENOMEM : RBG_ENODEV; }
+        return RBG_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; }
+    template <typename T> T *as() { return static_cast<T *>(p); }
+};
+inline size_t scan_tmp_bytes_for(uint64_t N) { return scan_tmp_bytes(N); }
+
+// fillers for a list of m {key, value} u64 pairs at *ent (device; tables closed by sentinels with key n).  When some are
+// needed: *ent / *samp are replaced by the expanded arrays (`own` says whether the old ones are tracked allocations of the
+// index or plain hipMalloc blocks), *m by the new count, and `at` (indices into the old list) by their new places.
+int add_fillers(rbg_index *ix, bool phi, void **ent, void **samp, bool tracked, uint64_t *m, uint64_t n, std::vector<uint64_t> &at, uint64_t *fillers) {
+    *fillers = 0;
+    const uint32_t fs = ix->dev.run_fill_shift;
+    TmpDev tot;
+    int rc = tot.alloc(8);
+    if (rc) return rc;
+    HIP_TRY(hipMemset(tot.p, 0, 8));
+    HIP_TRY(static_cast<hipError_t>(launch_fill_count(*ent, *m, n, fs, nullptr, tot.as<unsigned long long>(), nullptr)));
+    unsigned long long total = 0;
+    HIP_TRY(hipMemcpy(&total, tot.p, 8, hipMemcpyDeviceToHost));
+    if (!total) return RBG_OK;
+    TmpDev arr, tmp, idx, out;
+    const size_t tb = scan_tmp_bytes_for(*m + 1);
+    if ((rc = arr.alloc((*m + 1) * 8)) || (rc = tmp.alloc(tb))) return rc;
+    HIP_TRY(hipMemset(tot.p, 0, 8));
+    HIP_TRY(static_cast<hipError_t>(launch_fill_count(*ent, *m, n, fs, arr.as<uint64_t>(), tot.as<unsigned long long>(), nullptr)));
+    HIP_TRY(static_cast<hipError_t>(launch_scan_u64(arr.as<uint64_t>(), *m + 1, tmp.p, tb, nullptr)));
+    const uint64_t m2 = *m + total;
+    void *ent2 = nullptr, *samp2 = nullptr;
+    if (tracked) {
+        if ((rc = dev_reserve(ix, (m2 + 2) * 16, &ent2))) return rc;
+        if (*samp && (rc = dev_reserve(ix, m2 * 8 + 16, &samp2))) return rc;
+    } else {
+        HIP_TRY(hipMalloc(&ent2, (m2 + 2) * 16));
+        if (*samp) HIP_TRY(hipMalloc(&samp2, m2 * 8 + 16));
+    }
+    HIP_TRY(static_cast<hipError_t>(launch_fill_expand(phi, *ent, static_cast<const uint64_t *>(*samp), *m, n, fs, arr.as<uint64_t>(), ent2, static_cast<uint64_t *>(samp2), nullptr)));
+    if (!at.empty()) {
+        if ((rc = idx.alloc(at.size() * 8)) || (rc = out.alloc(at.size() * 8))) return rc;
+        HIP_TRY(hipMemcpy(idx.p, at.data(), at.size() * 8, hipMemcpyHostToDevice));
+        HIP_TRY(static_cast<hipError_t>(launch_gather_u64(arr.as<uint64_t>(), idx.as<uint64_t>(), at.size(), out.as<uint64_t>(), nullptr)));
+        HIP_TRY(hipMemcpy(at.data(), out.p, at.size() * 8, hipMemcpyDeviceToHost));
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    if (tracked) { free_tracked(ix, *ent); if (*samp) free_tracked(ix, *samp); }
+    else { (void)hipFree(*ent); if (*samp) (void)hipFree(*samp); }
+    *ent = ent2;
+    *samp = samp2;
+    *m = m2;
+    *fillers = total;
+    return RBG_OK;
+}
+
+template <typename P>
+int upload_tables_runs2(rbg_index *ix) {
+    constexpr bool W = sizeof(P) == 8;
+    HostIndex &h = ix->H();
+    rbg_index::RunsReport &rep = ix->runs_report;
+    rep.fmt = 2;
+    for (SymTable &t : h.sym) {   // (the depth-1 lists compose_on_device left on the device are the slot layout's)
+        free_tracked(ix, const_cast<void *>(t.dev_ent));
+        free_tracked(ix, const_cast<void *>(t.dev_samp));
+        t.dev_ent = t.dev_samp = nullptr;
+    }
+    const std::vector<SymTable> *depth[kMaxRunDepth] = {&h.sym, &h.pair, &h.triple, &h.quad, &h.quint};
+    uint32_t D = 1;
+    while (D < static_cast<uint32_t>(kMaxRunDepth) && !depth[D]->empty()) ++D;
+    rep.depths_composed = D;
+    uint32_t mask = (ix->run_depth_mask ? ix->run_depth_mask : ~0u) & ((1u << D) - 1u);
+    mask |= 1u | (1u << (D - 1));   // (the deepest is always kept: the kernels step by it)
+    const char *e_dt = std::getenv("RBG_RANK_DIR_RUNS");   // runs per directory bucket at most this on average (default 4)
+    const double dir_target = e_dt && std::atof(e_dt) > 0 ? std::atof(e_dt) : 4.0;
+    // RBG_RUN_FILL_SHIFT / RBG_PHI_SUPER_SHIFT: test-only overrides so that small indexes meet fillers and several super blocks
+    ix->dev.run_fill_shift = static_cast<uint32_t>(env_opt("RBG_RUN_FILL_SHIFT", kRunFillShift, 4, kRunFillShift));
+    const uint32_t super_shift = static_cast<uint32_t>(env_opt("RBG_PHI_SUPER_SHIFT", kPhiSuperShift, 1, 24));
+    const uint32_t max_shift = W ? ix->dev.run_fill_shift : 40u;
+    std::vector<DevRunTab2> tabs;
+    std::vector<DevRunTab> tabs1;   // (format 1's records of the same tables: rbg_info and the peer copies expect the array)
+    int rc;
+    for (uint32_t d = 0; d < D; ++d) {
+        const std::vector<SymTable> &T = *depth[d];
+        ix->dev.run_tab_first[d] = static_cast<uint32_t>(tabs.size());
+        ix->dev.run_samp[d] = nullptr; ix->dev.run_dir[d] = nullptr; ix->dev.run_rec[d] = nullptr;
+        ix->dev.run_ent2[d] = nullptr; ix->dev.run_dir2[d] = nullptr;
+        if (!(mask >> d & 1u)) {   // no run lists at this depth: nothing steps by it
+            release_kmer_level(ix, d + 1);
+            for (SymTable &st : kmer_level_tables(h, d + 1)) st.dev_ent = st.dev_samp = nullptr;
+            continue;
+        }
+        uint64_t entries = 0;
+        for (const SymTable &t : T) entries += t.nruns + 1;
+        // ---- the depth's {start, cum} pairs of P, tables back to back, and its samples (P each) on the device ----
+        void *abs_ent = nullptr, *abs_samp = nullptr;
+        std::vector<uint64_t> first(T.size() + 1, 0), nr(T.size());
+        for (size_t t = 0; t < T.size(); ++t) { first[t + 1] = first[t] + T[t].nruns + 1; nr[t] = T[t].nruns; }
+        ComposedLevel *L = (d >= 1 && d - 1 < ix->kmer_levels.size() && ix->kmer_levels[d - 1].ent) ? &ix->kmer_levels[d - 1] : nullptr;
+        if (L) {
+            if (L->entries != entries || L->first.size() != T.size()) return RBG_EARG;
+            for (size_t t = 0; t < T.size(); ++t)
+                if (L->first[t] != first[t]) return RBG_EARG;
+            abs_ent = L->ent;
+            abs_samp = h.has_tsa ? L->samp : nullptr;
+            L->ent = L->samp = nullptr;   // (adopted: the index's allocation list keeps them)
+        } else {
+            HostBuf<RunEnt<P>> ent(entries + 2);
+            HostBuf<P> samp(h.has_tsa ? entries + 2 : 0);
+            const size_t Wk = std::max<size_t>(1, std::min<size_t>({16, std::thread::hardware_concurrency(), T.size()}));
+            std::vector<std::thread> workers;
+            for (size_t w = 0; w < Wk; ++w)
+                workers.emplace_back([&, w] {
+                    for (size_t t = w; t < T.size(); t += Wk) {
+                        const SymTable &tb = T[t];
+                        if (tb.start.size() != tb.nruns + 1) continue;   // (checked below)
+                        for (uint64_t k = 0; k <= tb.nruns; ++k) ent[first[t] + k] = RunEnt<P>{static_cast<P>(tb.start[k]), static_cast<P>(tb.cum[k])};
+                        if (h.has_tsa) {
+                            for (uint64_t k = 0; k < tb.nruns; ++k) samp[first[t] + k] = static_cast<P>(tb.samp[k]);
+                            samp[first[t] + tb.nruns] = 0;
+                        }
+                    }
+                });
+            for (auto &w : workers) w.join();
+            for (const SymTable &tb : T)
+                if (tb.start.size() != tb.nruns + 1) return RBG_EARG;   // a table without host arrays and without a device level
+            for (uint64_t x = 0; x < 2; ++x) { ent[entries + x] = ent[entries - 1]; if (h.has_tsa) samp[entries + x] = 0; }
+            const void *up = nullptr;
+            if ((rc = dev_upload(ix, ent.data(), (entries + 2) * sizeof(RunEnt<P>), &up))) return rc;
+            abs_ent = const_cast<void *>(up);
+            if (h.has_tsa) {
+                if ((rc = dev_upload(ix, samp.data(), (entries + 2) * sizeof(P), &up))) return rc;
+                abs_samp = const_cast<void *>(up);
+            }
+        }
+        uint64_t E2 = entries, fillers = 0;
+        if constexpr (W) {
+            std::vector<uint64_t> at;
+            for (size_t t = 0; t < T.size(); ++t) { at.push_back(first[t]); at.push_back(first[t] + nr[t]); }
+            if ((rc = add_fillers(ix, false, &abs_ent, &abs_samp, true, &E2, h.n, at, &fillers))) return rc;
+            if (fillers) {
+                for (size_t t = 0; t < T.size(); ++t) { first[t] = at[2 * t]; nr[t] = at[2 * t + 1] - at[2 * t]; }
+                first[T.size()] = E2;
+            }
+        }
+        for (size_t t = 0; t < T.size(); ++t)
+            if (nr[t] >= 0xFFFFFFF0ull) {
+                std::fprintf(stderr, "rbg: a table of k-mer depth %u has %llu entries: the run-indexed layout holds fewer than 2^32 - 16 per table\n", d + 1,
+                             static_cast<unsigned long long>(nr[t]));
+                return RBG_EARG;
+            }
+        rep.entries[d] = E2;
+        rep.fillers[d] = fillers;
+        // ---- directories: per table the widest bucket that still holds at most about dir_target entries on average ----
+        std::vector<uint32_t> dshift(T.size(), 0);
+        std::vector<uint64_t> doff(T.size() + 1, 0);
+        for (size_t t = 0; t < T.size(); ++t) {
+            uint32_t sh = 0;
+            const double runs = static_cast<double>(std::max<uint64_t>(1, nr[t]));
+            while (sh < max_shift && runs * static_cast<double>(uint64_t(2) << sh) <= dir_target * static_cast<double>(h.n)) ++sh;
+            dshift[t] = sh;
+            doff[t + 1] = doff[t] + (h.n >> sh) + 2;
+        }
+        void *dirp = nullptr;
+        const size_t dir_ent = W ? sizeof(RunDir64) : 4;
+        if ((rc = dev_reserve(ix, doff[T.size()] * dir_ent + 16, &dirp))) return rc;
+        {
+            TmpDev tmp;
+            const size_t nt = T.size(), bytes = (3 * nt + 1) * 8 + nt * 4;
+            if ((rc = tmp.alloc(bytes))) return rc;
+            uint64_t *t_first = tmp.as<uint64_t>(), *t_nr = t_first + nt, *t_doff = t_nr + nt;
+            uint32_t *t_sh = reinterpret_cast<uint32_t *>(t_doff + nt + 1);
+            HIP_TRY(hipMemcpy(t_first, first.data(), nt * 8, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(t_nr, nr.data(), nt * 8, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(t_doff, doff.data(), (nt + 1) * 8, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(t_sh, dshift.data(), nt * 4, hipMemcpyHostToDevice));
+            if constexpr (W) HIP_TRY(static_cast<hipError_t>(launch_run_dirs2(abs_ent, t_first, t_nr, t_doff, t_sh, static_cast<uint32_t>(nt), doff[nt], dirp, nullptr)));
+            else HIP_TRY(static_cast<hipError_t>(launch_run_dirs(4, abs_ent, t_first, t_nr, t_doff, t_sh, static_cast<uint32_t>(nt), doff[nt], static_cast<uint32_t *>(dirp), nullptr)));
+            HIP_TRY(hipDeviceSynchronize());
+        }
+        rep.dir_bytes[d] = doff[T.size()] * dir_ent;
+        ix->dev.run_dir2[d] = dirp;
+        // ---- the entries and samples in their final form ----
+        if constexpr (W) {
+            void *e2 = nullptr, *s6 = nullptr;
+            if ((rc = dev_reserve(ix, (E2 + 2) * 8, &e2))) return rc;
+            HIP_TRY(static_cast<hipError_t>(launch_pack_pairs32(abs_ent, E2, 2, e2, nullptr)));
+            if (abs_samp) {
+                if ((rc = dev_reserve(ix, E2 * RunsFmt<P>::samp_bytes + 8, &s6))) return rc;
+                HIP_TRY(static_cast<hipError_t>(launch_pack_samp48(static_cast<const uint64_t *>(abs_samp), E2, s6, nullptr)));
+            }
+            HIP_TRY(hipDeviceSynchronize());
+            free_tracked(ix, abs_ent);
+            if (abs_samp) free_tracked(ix, abs_samp);
+            ix->dev.run_ent2[d] = e2;
+            ix->dev.run_samp[d] = s6;
+        } else {
+            ix->dev.run_ent2[d] = abs_ent;
+            ix->dev.run_samp[d] = abs_samp;
+            ix->dev.run_dir[d] = static_cast<const uint32_t *>(dirp);   // (format 1's kernels could read the same arrays)
+        }
+        for (size_t t = 0; t < T.size(); ++t) {
+            tabs.push_back(DevRunTab2{T[t].F, first[t], doff[t], dshift[t], 0u});
+            tabs1.push_back(DevRunTab{T[t].F, first[t], static_cast<uint32_t>(doff[t]), dshift[t]});
+        }
+        tabs.push_back(DevRunTab2{0, E2, 0, 0u, 0u});   // closing record
+        tabs1.push_back(DevRunTab{0, E2, 0u, 0u});
+    }
+    for (uint32_t d = 2; d <= 5; ++d) release_kmer_level(ix, d);   // (levels beyond D, or left over: nothing points at them)
+    for (uint32_t d = D; d <= static_cast<uint32_t>(kMaxRunDepth); ++d) ix->dev.run_tab_first[d] = static_cast<uint32_t>(tabs.size());
+    if (tabs.size() > static_cast<size_t>(kMaxRunTabs)) return RBG_EARG;
+    const void *p = nullptr;
+    std::vector<DevSym> syms(h.sym.size());   // (no kernel reads a symbol record on this format: F only, for rbg_get_f-style readers)
+    for (size_t t = 0; t < syms.size(); ++t) { syms[t] = DevSym{}; syms[t].F = h.sym[t].F; syms[t].nruns = static_cast<uint32_t>(std::min<uint64_t>(h.sym[t].nruns, 0xFFFFFFFFull)); }
+    if ((rc = dev_upload(ix, syms.data(), syms.size() * sizeof(DevSym), &p))) return rc;
+    ix->dev.syms = static_cast<const DevSym *>(p);
+    if ((rc = dev_upload(ix, tabs.data(), tabs.size() * sizeof(DevRunTab2), &p))) return rc;
+    ix->dev.run_tabs2 = static_cast<const DevRunTab2 *>(p);
+    if ((rc = dev_upload(ix, tabs1.data(), tabs1.size() * sizeof(DevRunTab), &p))) return rc;
+    ix->dev.run_tabs = static_cast<const DevRunTab *>(p);
+    ix->dev.run_ntabs = static_cast<uint32_t>(tabs.size());
+    ix->dev.run_ksteps = D;
+    ix->dev.run_depth_mask = mask;
+    ix->run_depth_mask = mask;
+    rep.depth_mask_kept = mask;
+    rep.rank_dirs = 1;
+    ix->dev.trees = nullptr;
+    ix->dev.tree_top = nullptr;
+    ix->dev.tree_top_n = 0;
+    ix->dev.tree_nlvl = 0;
+    ix->dev.layout = RBG_LAYOUT_RUNS;
+    ix->dev.run_fmt = 2;
+    ix->dev.kmer_steps = 1;
+    ix->dev.nmajor = 0;
+    if (h.nmajor >= 2) {  // the ftab's word index and the k-mer table index need the major alphabet
+        if ((rc = dev_upload(ix, h.major_of, 256, &p))) return rc;
+        ix->dev.lut2 = static_cast<const uint8_t *>(p);
+        ix->dev.nmajor = h.nmajor;
+    }
+    ix->dev.phi_tree = DevTree{};
+    ix->dev.phi_top = nullptr;
+    ix->dev.phi_nlvl = 0;
+    ix->dev.phi_slots = nullptr;
+    ix->dev.phi_ord = nullptr;
+    ix->dev.phi_dir = nullptr;
+    ix->dev.phi_super = nullptr;
+    ix->dev.phi_super_shift = 0;
+    if (h.has_tsa) {
+        // sampled positions per directory bucket: between per and 2 * per on average (RBG_PHI_DIR_PER, default 1: the scan's
+        // first four requests then cover the bucket and its predecessor nineteen times in twenty)
+        const char *e_pp = std::getenv("RBG_PHI_DIR_PER");
+        const double per = e_pp && std::atof(e_pp) > 0 ? std::atof(e_pp) : 1.0;
+        uint32_t ds = 2;
+        while (ds < max_shift && ds < 30 && (static_cast<double>(h.r) * static_cast<double>(uint64_t(1) << ds)) / static_cast<double>(h.n) < per) ++ds;
+        const uint64_t nd = (h.n >> ds) + 2;
+        void *dirp = nullptr;
+        if ((rc = dev_reserve(ix, nd * 4 + 16, &dirp))) return rc;
+        uint64_t m2 = h.r, fillers = 0;
+        if constexpr (W) {
+                    HostBuf<uint64_t> pe((h.r + 1) * 2);
+            parallel_for(h.r, [&](uint64_t a, uint64_t b, unsigned) {
+                for (uint64_t j = a; j < b; ++j) { pe[2 * j] = h.pred_pos[j]; pe[2 * j + 1] = h.phi_base[j]; }
+            });
+            pe[2 * h.r] = h.n; pe[2 * h.r + 1] = 0;   // sentinel: never below a query
+            void *abs = nullptr, *none = nullptr;
+            HIP_TRY(hipMalloc(&abs, (h.r + 1 + 2) * 16));
+            if ((rc = h2d_big(abs, pe.data(), (h.r + 1) * 16))) { (void)hipFree(abs); return rc; }
+            uint64_t m_all = h.r + 1;
+            std::vector<uint64_t> at;
+            rc = add_fillers(ix, true, &abs, &none, false, &m_all, h.n, at, &fillers);
+            if (rc) { (void)hipFree(abs); return rc; }
+            m2 = m_all - 1;
+            void *e12 = nullptr, *sup = nullptr;
+            const uint64_t nsup = (nd >> super_shift) + 2;
+            rc = dev_reserve(ix, (m2 + 1 + 3) * sizeof(PhiEnt12), &e12);
+            if (!rc) rc = dev_reserve(ix, nsup * 8, &sup);
+            hipError_t e = hipSuccess;
+            if (!rc) e = static_cast<hipError_t>(launch_pack_phi12(abs, m2 + 1, 3, e12, nullptr));
+            if (!rc && e == hipSuccess) e = static_cast<hipError_t>(launch_phi_dir(8, abs, m2, ds, nd, static_cast<uint32_t *>(dirp), super_shift, static_cast<uint64_t *>(sup), nullptr));
+            if (!rc && e == hipSuccess) e = hipDeviceSynchronize();
+            (void)hipFree(abs);
+            if (rc) return rc;
+            HIP_TRY(e);
+            ix->dev.phi_ent = e12;
+            ix->dev.phi_super = static_cast<const uint64_t *>(sup);
+            ix->dev.phi_super_shift = super_shift;
+        } else {
+            typedef PhiFmt<P> Fmt;
+            HostBuf<unsigned char> pe((h.r + 1 + Fmt::spare) * Fmt::ent_bytes);
+            parallel_for(h.r, [&](uint64_t a, uint64_t b, unsigned) {
+                for (uint64_t j = a; j < b; ++j) Fmt::put_ent(pe.data(), j, h.pred_pos[j], h.phi_base[j]);
+            });
+            for (size_t x = 0; x <= Fmt::spare; ++x) Fmt::put_ent(pe.data(), h.r + x, h.n, 0);
+            if ((rc = dev_upload(ix, pe.data(), pe.size(), &ix->dev.phi_ent))) return rc;
+            HIP_TRY(static_cast<hipError_t>(launch_phi_dir(4, ix->dev.phi_ent, h.r, ds, nd, static_cast<uint32_t *>(dirp), 0, nullptr, nullptr)));
+            HIP_TRY(hipDeviceSynchronize());
+        }
+        ix->dev.phi_dir = static_cast<const uint32_t *>(dirp);
+        ix->dev.phi_dir_shift = ds;
+        ix->dev.phi_m = m2;
+        ix->dev.phi_last_pos = h.pred_pos[h.r - 1];
+        ix->dev.phi_last_base = h.phi_base[h.r - 1];
+        rep.phi_entries = m2; rep.phi_fillers = fillers; rep.phi_dir_bytes = nd * 4; rep.phi_dir_shift = ds; rep.phi_dir = 1;
     }
     HIP_TRY(hipDeviceSynchronize());
     return RBG_OK;
@@ -1332,6 +1691,8 @@ int upload(rbg_index *ix) {
         // deepest go first (deepest of them first), then the deepest itself.
         // Default: every other depth counted from the deepest (1, 3, 5 of five) -- two thirds of the space and the same
         // rate on whole reads, a few per cent more steps where stretches are ragged (marker seeds); 0x1F keeps them all.
+        ix->runs_report = rbg_index::RunsReport();
+        ix->runs_report.depth_mask_asked = static_cast<uint32_t>(g_opt_run_depths.load());
         uint32_t mask = g_opt_run_depths.load() ? static_cast<uint32_t>(g_opt_run_depths.load()) | 1u : 1u;
         if (!g_opt_run_depths.load())
             for (int d = levels(); d >= 1; d -= 2) mask |= 1u << (d - 1);
@@ -1346,10 +1707,12 @@ int upload(rbg_index *ix) {
             if (mid) {
                 std::fprintf(stderr, "rbg: run-indexed replica of %.1f GB exceeds the %.1f GB budget: leaving out the run lists of depth %u\n", need_runs() / 1e9, budget / 1e9, mid);
                 mask &= ~(1u << (mid - 1));
+                ix->runs_report.depths_dropped_budget |= 1u << (mid - 1);
                 continue;
             }
             std::fprintf(stderr, "rbg: run-indexed replica of %.1f GB exceeds the %.1f GB budget: dropping the %zu-table k-mer level\n",
                          need_runs() / 1e9, budget / 1e9, deepest_of().size());
+            ix->runs_report.depths_dropped_budget |= 1u << (levels() - 1);
             drop_kmer_level(ix, deepest_of());
             mask = (mask & ((1u << levels()) - 1u)) | (1u << (levels() - 1));   // (the new deepest level is stepped by again)
         }
@@ -1406,7 +1769,10 @@ int upload(rbg_index *ix) {
     d.slot_bytes = t_slot64 ? 64 : 16;
     if (runs_layout) {
         if (std::getenv("RBG_VERBOSE")) std::fprintf(stderr, "rbg: device %d: run-indexed layout (space proportional to r)\n", ix->device);
-        rc = h.pos_bytes == 4 ? upload_tables_runs<uint32_t>(ix) : upload_tables_runs<uint64_t>(ix);
+        const bool fmt1 = runs_format1();
+        d.run_fmt = fmt1 ? 1 : 2;
+        if (fmt1) rc = h.pos_bytes == 4 ? upload_tables_runs<uint32_t>(ix) : upload_tables_runs<uint64_t>(ix);
+        else rc = h.pos_bytes == 4 ? upload_tables_runs2<uint32_t>(ix) : upload_tables_runs2<uint64_t>(ix);
         if (rc) return rc;
     } else {
         ix->arena_bytes = h.pos_bytes == 4 ? replica_bytes<uint32_t>(h, true) : replica_bytes<uint64_t>(h, true);   // (without the lists that are on the device already)
@@ -1970,6 +2336,9 @@ int rbg_set_default_option(int opt, int64_t value) {
         case RBG_OPT_RUN_DEPTHS:
             if (value < 0 || value >= (1 << kMaxRunDepth)) return RBG_EARG;
             g_opt_run_depths = value; return RBG_OK;
+        case RBG_OPT_RUN_FMT:
+            if (value != 1 && value != 2) return RBG_EARG;
+            g_opt_run_fmt = value; return RBG_OK;
         default: return RBG_EARG;
     }
     });
@@ -1993,6 +2362,7 @@ int rbg_get_default_option(int opt, int64_t *value) {
         case RBG_OPT_TREE_TOP_KB: *value = g_opt_tree_top_kb.load(); return RBG_OK;
         case RBG_OPT_SLOT_BYTES: *value = g_opt_slot_bytes.load(); return RBG_OK;
         case RBG_OPT_RUN_DEPTHS: *value = g_opt_run_depths.load(); return RBG_OK;
+        case RBG_OPT_RUN_FMT: *value = g_opt_run_fmt.load(); return RBG_OK;
         default: return RBG_EARG;
     }
     });
@@ -2363,6 +2733,31 @@ int rbg_info(const rbg_index *ix, rbg_info_t *out) {
         if (!(m >> 3 & 1u)) out->quad_runs = 0;
         if (!(m >> 4 & 1u)) out->quint_runs = 0;
     }
+    return RBG_OK;
+    });
+}
+
+int rbg_layout_info(const rbg_index *ix, rbg_layout_info_t *out, uint64_t out_bytes) {
+    return guarded([&]() -> int {
+    if (!ix || !out || out_bytes < 8) return RBG_EARG;
+    rbg_layout_info_t v;
+    std::memset(&v, 0, sizeof(v));
+    if (ix->device != RBG_DEVICE_NONE && ix->dev.layout == RBG_LAYOUT_RUNS) {
+        const rbg_index::RunsReport &r = ix->runs_report;
+        v.run_fmt = r.fmt;
+        v.depths_composed = r.depths_composed;
+        v.depth_mask_asked = r.depth_mask_asked;
+        v.depth_mask_kept = r.depth_mask_kept;
+        v.depths_dropped_budget = r.depths_dropped_budget;
+        v.depths_dropped_limit = r.depths_dropped_limit;
+        v.rank_directories = r.rank_dirs;
+        v.phi_directory = r.phi_dir;
+        v.phi_directory_dropped = r.phi_dir_dropped;
+        v.fill_shift = r.fmt == 2 && ix->H().pos_bytes == 8 ? ix->dev.run_fill_shift : 0;
+        for (int d = 0; d < kMaxRunDepth; ++d) { v.entries[d] = r.entries[d]; v.fillers[d] = r.fillers[d]; v.dir_bytes[d] = r.dir_bytes[d]; }
+        v.phi_entries = r.phi_entries; v.phi_fillers = r.phi_fillers; v.phi_dir_bytes = r.phi_dir_bytes; v.phi_dir_shift = r.phi_dir_shift;
+    }
+    std::memcpy(out, &v, static_cast<size_t>(std::min<uint64_t>(out_bytes, sizeof(v))));
     return RBG_OK;
     });
 }
@@ -3819,6 +4214,7 @@ int replicate_begin(rbg_index *src, int device, ReplicaJob &job) {
     r->cfg.max_blocks = prop.multiProcessorCount * 32;
     r->runs_layout = src->runs_layout;
     r->run_depth_mask = src->run_depth_mask;
+    r->runs_report = src->runs_report;
     r->rank_slots = src->rank_slots; r->rank_slots_overflow = src->rank_slots_overflow;
     r->phi_slots = src->phi_slots; r->phi_slots_overflow = src->phi_slots_overflow;
     r->kmer_steps_requested = src->kmer_steps_requested;
@@ -3885,6 +4281,8 @@ int replicate_finish(rbg_index *src, ReplicaJob &job) {
     for (int t = 0; t < kMaxRunDepth; ++t) reloc.fix(d.run_dir[t]);
     for (int t = 0; t < kMaxRunDepth; ++t) reloc.fix(d.run_samp[t]);
     for (int t = 0; t < kMaxRunDepth; ++t) reloc.fix(d.run_rec[t]);
+    reloc.fix(d.run_tabs2); reloc.fix(d.phi_super);
+    for (int t = 0; t < kMaxRunDepth; ++t) { reloc.fix(d.run_ent2[t]); reloc.fix(d.run_dir2[t]); }
     reloc.fix(d.phi_tree.ent);
     for (int l = 0; l < kMaxTreeLevels; ++l) reloc.fix(d.phi_tree.lvl[l]);
     r->dev = d;

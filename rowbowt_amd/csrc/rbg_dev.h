@@ -216,6 +216,38 @@ static_assert(sizeof(RunRec) == 128, "one 128-byte line per bucket");
 constexpr uint32_t kRecOverflow = 0x80000000u, kRecPred = 0xFFFFFFFFu, kRecNoPair = 0x7FFFFFFFu;
 constexpr uint32_t kRecMaxShift = 30;   // offsets and occurrence counts within a bucket stay below 2^31
 
+// ---- run-indexed layout, FORMAT 2 (DevIndex::run_fmt == 2; the default since round 4) -------------------------------
+// Same arrays in spirit -- per kept k-mer depth the run lists of all its tables back to back, a directory per table, a
+// sample per entry -- but laid out for ONE LANE answering its own ranks (rbg_runs2_device.hpp): the directory names the
+// few entries that can hold the answer, the lane fetches them with independent 16-byte requests and scans them in
+// registers; no cross-lane traffic.  What changes at 8-byte positions (at 4-byte positions the arrays are format 1's):
+//   entries  {start mod 2^32, cum mod 2^32}: 8 bytes instead of 16.  The directory bucket (shift <= 30) bounds the
+//            answer to the runs starting inside the bucket and the one before them, and FILLER entries (a continuation
+//            of the run, or an empty run, every 2^30 rows of a gap) keep every entry within 2^30 rows of the next one
+//            of its table: all candidates of a bucket B lie in (B - 2^30, B + 2^30), so keys compare correctly as
+//            32-bit distances from the anchor B - 2^31, `position - start` and run lengths are exact in 32 bits.
+//            This is the hi/lo split Elias-Fano makes in the reference (sparse_sd_vector.hpp:110-163): the bucket
+//            number carries the high part.
+//   directory entry {count, hi}: count = # entries of the table that start below the bucket (fillers included), hi =
+//            (cum of entry count - 1) >> 31: the rank at any position of the bucket lies in [hi << 31, (hi << 31) + 2^32),
+//            so its low 32 bits (computed from the entries' low words) determine it: ONE 64-bit add per rank.
+//   entry indices are 64-bit (table's first entry, 64-bit; + count, 32-bit): no depth is left out for having 2^32 entries.
+struct DevRunTab2 {
+    uint64_t F;          // first row of the k-mer's SA interval
+    uint64_t first;      // index of the table's first entry in its depth's arrays
+    uint64_t dir_off;    // the table's directory starts at entry dir_off of its depth's directory array
+    uint32_t dir_shift, pad;
+};
+static_assert(sizeof(DevRunTab2) == 32, "two 16-byte LDS reads per record");
+struct RunDir64 { uint32_t count, hi; };   // directory entry at 8-byte positions (4-byte positions: the count alone)
+constexpr uint32_t kRunFillShift = 30;     // fillers every 2^30 rows; directory shifts stay <= 30 at 8-byte positions (DevIndex::run_fill_shift;
+                                           // RBG_RUN_FILL_SHIFT lowers it so that tests meet fillers on small indexes)
+// the phi list of format 2 at 8-byte positions: {sampled position mod 2^32, base} with fillers likewise (a filler at
+// position X after the sample (p, b) carries base (b + X - p) mod n: phi(i) = base + (i - pos) is unchanged)
+struct PhiEnt12 { uint32_t pos_lo, base_lo, base_hi; };
+static_assert(sizeof(PhiEnt12) == 12, "three words per entry");
+constexpr uint32_t kPhiSuperShift = 16;    // phi_super[j] = # entries below bucket j << 16 (64-bit); phi_dir holds the low 32 bits of the counts
+
 constexpr int kMaxRunDepth = 5;
 constexpr int kMaxRunTabs = kLdsSyms + 16 + 64 + 256 + 1024 + kMaxRunDepth;  // records staged in LDS by k_find_range_runs
 
@@ -283,6 +315,17 @@ struct DevIndex {
     uint32_t phi_dir_shift;
     uint32_t run_depth_mask;   // bit d - 1: the k-mer depth d has run lists (bit 0 always; RBG_OPT_RUN_DEPTHS / the budget rule may leave depths out)
     const RunRec *run_rec[kMaxRunDepth];  // per depth: the tables' bucket records back to back; nullptr = directory / descent
+    // format 2 (see DevRunTab2 above): one lane answers its own ranks and phi steps
+    uint32_t run_fmt;                       // 1: {P, P} pairs probed by quads of lanes; 2: per-lane probes (low-word pairs at 8-byte positions)
+    uint32_t phi_super_shift;               // 0 = no super counts (4-byte positions: r < 2^32)
+    uint32_t run_fill_shift;                // 8-byte positions: entries of a table (and of the phi list) lie less than 2^this rows apart
+    uint32_t pad_fmt2;
+    const void *run_ent2[kMaxRunDepth];     // uint2 {start, cum} (low words at 8-byte positions) + 2 spare entries
+    const void *run_dir2[kMaxRunDepth];     // uint32_t counts (4-byte positions) or RunDir64 (8-byte positions)
+    const DevRunTab2 *run_tabs2;            // run_ntabs records, depth d's from run_tab_first[d - 1]
+    const uint64_t *phi_super;              // 8-byte positions: full counts every 2^phi_super_shift buckets
+    uint64_t phi_m;                         // entries of the phi list (fillers included); entry phi_m is the sentinel
+    uint64_t phi_last_pos, phi_last_base;   // the last sampled position and its base (circular predecessor, toehold_sa.hpp:59,65)
 };
 
 // What the instrumented instantiations count (sums over the launch; include/rbg.h rbg_search_stats_t mirrors it).
@@ -403,7 +446,7 @@ int launch_greedy_seed_runs(const DevIndex &ix, const LaunchCfg &cfg, const uint
 // lg.base != nullptr: the count pass (fill == false) writes the log; the fill pass walks only the sequences listed behind lg.nsel
 int launch_marker_seeds_runs(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N, uint64_t wsize,
                              uint64_t max_range, uint64_t *seed_cnt, uint64_t *mk_cnt, const uint64_t *seed_off, const uint64_t *mk_off,
-                             uint64_t *seeds, uint64_t *mk, bool fill, void *stream, const SeedLog &lg);
+                             uint64_t *seeds, uint64_t *mk, bool fill, void *stream, const SeedLog &lg, uint64_t ftab_k = 0 /*format 2: rb_markers --ftab*/);
 int launch_find_range_stats(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
                             uint64_t *lo, uint64_t *hi, uint64_t *ssamp /*nullable*/, unsigned long long *stats /*kStatSearchN*/,
                             void *stream);
@@ -447,6 +490,16 @@ int launch_run_dirs(uint32_t pos_bytes, const void *ent, const uint64_t *first, 
                     uint32_t T, uint64_t total, uint32_t *dir, void *stream);
 int launch_sample_keys(uint32_t pos_bytes, const void *ent, uint64_t step, uint64_t count, void *out, void *stream);
 int launch_pack_samp48(const uint64_t *in, uint64_t n, void *out, void *stream);
+// format 2 of the run-indexed layout (k_build.hip): {key, value} u64 pairs on the device -> fillers, low-word pairs, directories
+int launch_fill_count(const void *ent, uint64_t m, uint64_t n, uint32_t fill_shift, uint64_t *arr /*m + 1, nullable*/, unsigned long long *total, void *stream);
+int launch_scan_u64(uint64_t *vals, uint64_t N, void *tmp, size_t tmp_bytes, void *stream);   // inclusive, in place (tmp: scan_tmp_bytes(N))
+int launch_fill_expand(bool phi, const void *ent, const uint64_t *samp, uint64_t m, uint64_t n, uint32_t fill_shift, const uint64_t *pos, void *ent_out, uint64_t *samp_out, void *stream);
+int launch_gather_u64(const uint64_t *src, const uint64_t *idx, uint64_t count, uint64_t *out, void *stream);
+int launch_pack_pairs32(const void *ent, uint64_t m, uint64_t spare, void *out, void *stream);
+int launch_pack_phi12(const void *ent, uint64_t m, uint64_t spare, void *out, void *stream);
+int launch_run_dirs2(const void *ent, const uint64_t *first, const uint64_t *nruns, const uint64_t *doff, const uint32_t *dshift, uint32_t T, uint64_t total,
+                     void *dir, void *stream);
+int launch_phi_dir(uint32_t pos_bytes, const void *ent, uint64_t m, uint32_t shift, uint64_t nb, uint32_t *dir, uint32_t ss, uint64_t *super, void *stream);
 int launch_build_phi_slots(uint32_t pos_bytes, bool packed, const void *ent, uint64_t r, uint64_t n, uint32_t shift, void *slots, uint32_t *ord,
                            unsigned long long *overflow, void *stream);
 // packed reads (2 bits per symbol): pack the byte batch once, then search the packed form

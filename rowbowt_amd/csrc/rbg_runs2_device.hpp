@@ -1,0 +1,332 @@
+// rbg_runs2_device.hpp -- FORMAT 2 of the run-indexed layout (rbg_dev.h DevRunTab2; DevIndex::run_fmt == 2): one lane
+// answers its own ranks and phi steps.  rle_string::rank (rle_string.hpp:131-161) and ToeholdSA::phi
+// (toehold_sa.hpp:56-72) stay predecessor searches over run boundaries / sampled positions in O(r) space, but the
+// directory has already cut the search down to the handful of entries of one bucket (and the one before them), so the
+// lane that owns the query fetches exactly those -- independent 16-byte requests, all in flight together -- and scans
+// them in registers.  Round 2/3's probes spread the same entries over 16, 8 and finally 4 lanes (rbg_runs_device.hpp);
+// each halving of the group was faster because the work per step is cross-lane choreography, not memory: with one lane
+// per query there is none left.  At 8-byte positions the entries carry the low 32 bits of {start, cum}
+// only (rbg_dev.h: the bucket number is the high part, as in Elias-Fano): half the bytes per entry, 32-bit compares.
+#pragma once
+
+#include "rbg_runs_device.hpp"
+
+namespace rbg {
+namespace {
+
+constexpr uint32_t kLaneMaxZ = 15;     // candidates one scan covers (16 entries = two chunks of four 16-byte requests); more: narrowed first
+constexpr uint32_t kLanePhiMaxZ = 8;   // sampled positions one phi scan covers (two chunks of four entries)
+
+template <typename P>
+struct RunSearch2 {
+    const DevRunTab2 *tab;        // LDS: the tables' records (run_ntabs of them)
+    const uint32_t *tab_first;    // LDS [kMaxRunDepth + 1]: first record of each depth
+    const void *const *ent;       // LDS [kMaxRunDepth]: entry arrays per depth
+    const void *const *dir;       // LDS [kMaxRunDepth]: directory arrays per depth
+    uint32_t fill;                // DevIndex::run_fill_shift
+};
+
+#define RBG_RUN_SEARCH2_SHARED                                            \
+    __shared__ uint32_t s_tab_first[kMaxRunDepth + 1];                    \
+    __shared__ const void *s_ent2[8];                                     \
+    __shared__ const void *s_dir2[8];                                     \
+    extern __shared__ __align__(16) unsigned char s_dyn[]
+
+inline size_t run_search2_lds(const DevIndex &ix) { return static_cast<size_t>(ix.run_ntabs) * sizeof(DevRunTab2) + 16; }
+
+// fills the arrays of RBG_RUN_SEARCH2_SHARED and returns the view of them; ends with __syncthreads()
+template <typename P>
+__device__ __forceinline__ RunSearch2<P> stage_run_search2(const DevIndex &ix, uint32_t *s_tab_first, const void **s_ent2, const void **s_dir2,
+                                                           unsigned char *s_dyn) {
+    DevRunTab2 *s_tab = reinterpret_cast<DevRunTab2 *>(s_dyn);
+    if (threadIdx.x < 8) {
+        s_ent2[threadIdx.x] = threadIdx.x < static_cast<uint32_t>(kMaxRunDepth) ? ix.run_ent2[threadIdx.x] : nullptr;
+        s_dir2[threadIdx.x] = threadIdx.x < static_cast<uint32_t>(kMaxRunDepth) ? ix.run_dir2[threadIdx.x] : nullptr;
+    }
+    for (uint32_t t = threadIdx.x; t <= static_cast<uint32_t>(kMaxRunDepth); t += blockDim.x) s_tab_first[t] = ix.run_tab_first[t];
+    {   // the records as 16-byte words (two per record)
+        const uint4 *src = reinterpret_cast<const uint4 *>(ix.run_tabs2);
+        uint4 *dst = reinterpret_cast<uint4 *>(s_tab);
+        for (uint32_t t = threadIdx.x; t < 2u * ix.run_ntabs; t += blockDim.x) dst[t] = src[t];
+    }
+    __syncthreads();
+    RunSearch2<P> S;
+    S.tab = s_tab; S.tab_first = s_tab_first; S.ent = s_ent2; S.dir = s_dir2;
+    S.fill = ix.run_fill_shift;
+    return S;
+}
+
+typedef unsigned int u32x2a4 __attribute__((ext_vector_type(2), aligned(4)));
+typedef unsigned int u32x4a8 __attribute__((ext_vector_type(4), aligned(8)));
+typedef unsigned int u32x4a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef unsigned int u32x3a4 __attribute__((ext_vector_type(3), aligned(4)));
+
+// directory entries b and b + 1 of a table: a = # entries starting below bucket b, e = # below bucket b + 1, h = the
+// high part of the rank in bucket b (rbg_dev.h RunDir64; 0 at 4-byte positions)
+template <typename P>
+__device__ __forceinline__ void load_dir2(const void *__restrict__ dir, const uint64_t at, uint32_t &a, uint32_t &h, uint32_t &e) {
+    if constexpr (sizeof(P) == 8) {
+        const u32x4a8 w = *as_global<u32x4a8>(static_cast<const void *>(static_cast<const char *>(dir) + at * 8u));
+        a = w.x; h = w.y; e = w.z;
+    } else {
+        const u32x2a4 w = *reinterpret_cast<const RBG_GLOBAL u32x2a4 *>(as_global<uint32_t>(dir) + at);   // (4-byte aligned pair)
+        a = w.x; e = w.y; h = 0;
+    }
+}
+
+// one query against a window of entries: the running state of the scan
+struct LaneQ {
+    uint32_t qa;       // the position as a distance from the anchor
+    uint32_t zlim;     // window entries [0, zlim) are its candidates
+    uint32_t c = 0;    // candidates below the position so far
+    uint32_t ks = 0, kc = 0, kn = 0;   // the last entry below it {start, cum} and the cum of the entry after that one
+    uint32_t ps = 0, pc = 0;
+    bool pb = false;
+    __device__ __forceinline__ void feed(const uint32_t gi, const uint32_t sa, const uint32_t cu) {
+        const bool nb = gi < zlim && sa < qa;
+        const bool sel = pb && !nb;      // entry gi - 1 is the last one below the position
+        ks = sel ? ps : ks;
+        kc = sel ? pc : kc;
+        kn = sel ? cu : kn;
+        c += nb ? 1u : 0u;
+        pb = nb; ps = sa; pc = cu;
+    }
+};
+
+// 8-ary narrowing of a crowded bucket by the lane itself: candidates [p, p + z) of the table (entry indices relative to
+// the table's first entry), z > kLaneMaxZ; seven pivots a stride apart are fetched together, the range shrinks to the
+// stride between the last pivot below the position and the next.  Entry p stays "below or unknown".
+__device__ __forceinline__ void lane_narrow(const char *__restrict__ tent, const uint32_t a_lo, const uint32_t qa, uint32_t &p, uint32_t &z, const uint32_t max_z,
+                                            const uint32_t ent_bytes, uint32_t &rounds) {
+    while (z > max_z) {
+        const uint32_t stride = (z + 7u) >> 3;
+        uint32_t key[7];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const uint32_t at = static_cast<uint32_t>(j + 1) * stride;
+            key[j] = at < z ? *as_global<uint32_t>(static_cast<const void *>(tent + static_cast<uint64_t>(p + at) * ent_bytes)) : 0u;
+        }
+        uint32_t m = 0;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const uint32_t at = static_cast<uint32_t>(j + 1) * stride;
+            m += (at < z && key[j] - a_lo < qa) ? 1u : 0u;
+        }
+        const uint32_t adv = m * stride;
+        p += adv;
+        z = (z - adv) < stride ? (z - adv) : stride;
+        ++rounds;
+    }
+}
+
+// scan of the window [p, p + zw] (zw + 1 <= 16 entries: the candidates and the entry after the last of them) for one or two
+// queries.  All requests -- four, or eight when the window is longer than eight entries -- are issued before the first is
+// waited for: one memory round trip per scan.
+__device__ __forceinline__ void lane_scan(const char *__restrict__ tent, const uint32_t p, const uint32_t zw, const uint32_t a_lo, LaneQ &A, LaneQ *B) {
+    const RBG_GLOBAL char *base = as_global<char>(static_cast<const void *>(tent)) + static_cast<uint64_t>(p) * 8u;
+    u32x4a8 w[4], v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        // (unconditional, clamped to the window's last pair: a pair beyond it is fed as entries past every candidate --
+        //  never below, never selected)
+        const uint32_t gj = 2u * j < zw ? 2u * j : zw;
+        w[j] = *reinterpret_cast<const RBG_GLOBAL u32x4a8 *>(base + static_cast<uint64_t>(gj) * 8u);
+    }
+    const bool more = zw >= 8u;
+    if (more) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t gj = 8u + 2u * j < zw ? 8u + 2u * j : zw;
+            v[j] = *reinterpret_cast<const RBG_GLOBAL u32x4a8 *>(base + static_cast<uint64_t>(gj) * 8u);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        A.feed(2u * j, w[j].x - a_lo, w[j].y);
+        A.feed(2u * j + 1u, w[j].z - a_lo, w[j].w);
+        if (B) {
+            B->feed(2u * j, w[j].x - a_lo, w[j].y);
+            B->feed(2u * j + 1u, w[j].z - a_lo, w[j].w);
+        }
+    }
+    if (more) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            A.feed(8u + 2u * j, v[j].x - a_lo, v[j].y);
+            A.feed(8u + 2u * j + 1u, v[j].z - a_lo, v[j].w);
+            if (B) {
+                B->feed(8u + 2u * j, v[j].x - a_lo, v[j].y);
+                B->feed(8u + 2u * j + 1u, v[j].z - a_lo, v[j].w);
+            }
+        }
+    }
+}
+
+// What the instrumented instantiations count on this format (the eight sums of SearchStat): [kStSteps] search steps,
+// [kStSlots] directory gathers (two neighbouring entries: 8 or 16 bytes), [kStDense] run-list entries the scans needed
+// (8 bytes each), [kStSearch] narrowing rounds (seven 4-byte pivots each), the rest as in rbg_runs_device.hpp.
+
+// Both ranks of one LF step of ONE lane: rle_string::rank (rle_string.hpp:131-161) in the k-mer table `rec` of depth
+// index d at positions q0 = lo and q1 = hi + 1 (q0 <= q1).  out.samp_e = the entry whose sample a toehold re-sample needs.
+template <typename P, bool STATS = false>
+__device__ __forceinline__ void lane_lf2(const RunSearch2<P> &S, const uint32_t d, const uint32_t rec, const uint64_t q0, const uint64_t q1, RunStep &out,
+                                         unsigned long long *st = nullptr) {
+    constexpr bool W = sizeof(P) == 8;
+    const DevRunTab2 R = S.tab[rec];
+    out.F = R.F;
+    const uint32_t sh = R.dir_shift;
+    const uint64_t b0 = q0 >> sh, b1 = q1 >> sh;
+    const void *__restrict__ dir = S.dir[d];
+    uint32_t a0, h0, e0, a1, h1, e1;
+    load_dir2<P>(dir, R.dir_off + b0, a0, h0, e0);
+    a1 = a0; h1 = h0; e1 = e0;
+    if (b1 != b0) load_dir2<P>(dir, R.dir_off + b1, a1, h1, e1);
+    if (STATS) st[kStSlots] += b1 != b0 ? 2 : 1;
+    const char *__restrict__ tent = static_cast<const char *>(S.ent[d]) + R.first * 8u;
+    uint32_t p0 = a0 ? a0 - 1u : 0u, z0 = e0 - p0;     // candidates: the entries of the bucket and the one before them
+    uint32_t p1 = a1 ? a1 - 1u : 0u, z1 = e1 - p1;
+    // anchors (8-byte positions): every candidate of bucket b lies above (b << sh) - 2^fill (fillers, rbg_dev.h)
+    const uint32_t al0 = W ? static_cast<uint32_t>(b0 << sh) - (1u << S.fill) : 0u;
+    const uint32_t al1 = W ? static_cast<uint32_t>(b1 << sh) - (1u << S.fill) : 0u;
+    const uint32_t qa0 = static_cast<uint32_t>(q0) - al0, qa1 = static_cast<uint32_t>(q1) - al1;
+    uint32_t rounds = 0;
+    if (z0 > kLaneMaxZ) lane_narrow(tent, al0, qa0, p0, z0, kLaneMaxZ, 8u, rounds);
+    if (z1 > kLaneMaxZ) lane_narrow(tent, al1, qa1, p1, z1, kLaneMaxZ, 8u, rounds);
+    if (STATS) st[kStSearch] += rounds;
+    // one window for both positions when the second's candidates end within reach of the first's start (the usual case: the
+    // range has narrowed to one locus); at 8-byte positions only for the same or the next bucket, so that the first
+    // bucket's anchor orders the second position too
+    const bool shared = p1 + z1 <= p0 + kLaneMaxZ && (!W || b1 - b0 <= 1u);
+    LaneQ A, B;
+    A.qa = qa0; A.zlim = z0;
+    if (shared) {
+        B.qa = static_cast<uint32_t>(q1) - al0; B.zlim = p1 + z1 - p0;
+        const uint32_t zw = B.zlim > z0 ? B.zlim : z0;
+        lane_scan(tent, p0, zw, al0, A, &B);
+        if (STATS) st[kStDense] += zw + 1u;
+        p1 = p0;
+    } else {
+        B.qa = qa1; B.zlim = z1;
+        lane_scan(tent, p0, z0, al0, A, nullptr);
+        lane_scan(tent, p1, z1, al1, B, nullptr);
+        if (STATS) st[kStDense] += z0 + z1 + 2u;
+    }
+    // rank = cum + min(position - start, length of that run); its high part from the directory (rbg_dev.h RunDir64)
+    uint64_t c_before = 0, c_upto = 0;
+    bool inside = false;
+    if (A.c) {
+        const uint32_t dd = A.qa - A.ks, len = A.kn - A.kc;
+        const uint32_t lo32 = A.kc + (dd < len ? dd : len);
+        const uint64_t y = static_cast<uint64_t>(h0) << 31;
+        c_before = W ? y + static_cast<uint32_t>(lo32 - static_cast<uint32_t>(y)) : lo32;
+    }
+    if (B.c) {
+        const uint32_t dd = B.qa - B.ks, len = B.kn - B.kc;
+        const uint32_t lo32 = B.kc + (dd < len ? dd : len);
+        const uint64_t y = static_cast<uint64_t>(h1) << 31;
+        c_upto = W ? y + static_cast<uint32_t>(lo32 - static_cast<uint32_t>(y)) : lo32;
+        inside = dd <= len;
+    }
+    out.c_before = c_before;
+    out.c_upto = c_upto;
+    out.inside = inside;
+    out.samp_e = R.first + p1 + B.c - 1u;   // (read only when B.c > 0 and the row is not inside the run)
+    if (STATS) st[kStSteps] += 1;
+}
+
+// the sample of the step's predecessor run (one gather)
+template <typename P>
+__device__ __forceinline__ uint64_t run_step_sample2(const DevIndex &ix, const uint32_t d, const uint64_t e) {
+    return RunList<P>::samp(ix.run_samp[d], e);
+}
+
+// ---- phi by one lane ------------------------------------------------------------------------------------------------------
+// ToeholdSA::phi(i) (toehold_sa.hpp:56-72) for a position q < n: found = a sampled position lies before q, val = its base +
+// (q - it) -- not yet reduced mod n; else the caller takes the circular predecessor.  ents = entries the scan needed (STATS).
+template <typename P>
+__device__ __forceinline__ void lane_phi(const DevIndex &ix, const uint64_t q, bool &found, uint64_t &val, uint32_t &ents, uint32_t &rounds) {
+    constexpr bool W = sizeof(P) == 8;
+    constexpr uint32_t EB = W ? 12u : 8u;
+    const uint32_t sh = ix.phi_dir_shift;
+    const uint64_t b = q >> sh;
+    const u32x2a4 dw = *reinterpret_cast<const RBG_GLOBAL u32x2a4 *>(as_global<uint32_t>(ix.phi_dir) + b);
+    uint64_t g0;
+    uint32_t inb = dw.y - dw.x;            // sampled positions inside the bucket (the counts' low words differ by it)
+    if constexpr (W) {
+        const uint64_t s0 = as_global<uint64_t>(ix.phi_super)[b >> ix.phi_super_shift];
+        g0 = s0 + static_cast<uint32_t>(dw.x - static_cast<uint32_t>(s0));   // (fewer than 2^32 entries per super block)
+    } else {
+        g0 = dw.x;
+    }
+    const uint64_t pred = g0 ? g0 - 1u : 0u;
+    uint32_t z = inb + (g0 ? 1u : 0u);
+    const uint32_t a_lo = W ? static_cast<uint32_t>(b << sh) - (1u << ix.run_fill_shift) : 0u;
+    const uint32_t qa = static_cast<uint32_t>(q) - a_lo;
+    const char *__restrict__ tent = static_cast<const char *>(ix.phi_ent) + pred * EB;
+    uint32_t p = 0;
+    rounds = 0;
+    if (z > kLanePhiMaxZ) lane_narrow(tent, a_lo, qa, p, z, kLanePhiMaxZ, EB, rounds);
+    ents = z;
+    const RBG_GLOBAL char *base = as_global<char>(static_cast<const void *>(tent)) + static_cast<uint64_t>(p) * EB;
+    uint32_t c = 0, ks = 0, kb_lo = 0, kb_hi = 0;
+    // (z <= 8 entries: four requests, eight when there are more than four -- all issued before the first is waited for;
+    //  requests beyond the last entry re-read it and are fed as entries past every candidate)
+    const uint32_t zl = z ? z - 1u : 0u;
+    const bool more = z > 4u;
+    if constexpr (W) {
+        u32x3a4 w[4], v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = *reinterpret_cast<const RBG_GLOBAL u32x3a4 *>(base + static_cast<uint64_t>(static_cast<uint32_t>(j) < zl ? static_cast<uint32_t>(j) : zl) * 12u);
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const RBG_GLOBAL u32x3a4 *>(base + static_cast<uint64_t>(4u + j < zl ? 4u + j : zl) * 12u);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t sa = w[j].x - a_lo;
+            const bool nb = static_cast<uint32_t>(j) < z && sa < qa;
+            ks = nb ? sa : ks; kb_lo = nb ? w[j].y : kb_lo; kb_hi = nb ? w[j].z : kb_hi;
+            c += nb ? 1u : 0u;
+        }
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t sa = v[j].x - a_lo;
+                const bool nb = 4u + j < z && sa < qa;
+                ks = nb ? sa : ks; kb_lo = nb ? v[j].y : kb_lo; kb_hi = nb ? v[j].z : kb_hi;
+                c += nb ? 1u : 0u;
+            }
+        }
+    } else {
+        u32x4a8 w[2], v[2];   // two entries per request (one spare entry follows the sentinel)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) w[j] = *reinterpret_cast<const RBG_GLOBAL u32x4a8 *>(base + static_cast<uint64_t>(2u * j < zl ? 2u * j : zl) * 8u);
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) v[j] = *reinterpret_cast<const RBG_GLOBAL u32x4a8 *>(base + static_cast<uint64_t>(4u + 2u * j < zl ? 4u + 2u * j : zl) * 8u);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bool nb0 = 2u * j < z && w[j].x < qa;
+            ks = nb0 ? w[j].x : ks; kb_lo = nb0 ? w[j].y : kb_lo;
+            const bool nb1 = 2u * j + 1u < z && w[j].z < qa;
+            ks = nb1 ? w[j].z : ks; kb_lo = nb1 ? w[j].w : kb_lo;
+            c += (nb0 ? 1u : 0u) + (nb1 ? 1u : 0u);
+        }
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const bool nb0 = 4u + 2u * j < z && v[j].x < qa;
+                ks = nb0 ? v[j].x : ks; kb_lo = nb0 ? v[j].y : kb_lo;
+                const bool nb1 = 4u + 2u * j + 1u < z && v[j].z < qa;
+                ks = nb1 ? v[j].z : ks; kb_lo = nb1 ? v[j].w : kb_lo;
+                c += (nb0 ? 1u : 0u) + (nb1 ? 1u : 0u);
+            }
+        }
+    }
+    found = c != 0;
+    val = ((static_cast<uint64_t>(kb_hi) << 32) | kb_lo) + static_cast<uint32_t>(qa - ks);
+}
+
+}  // namespace
+}  // namespace rbg

@@ -760,6 +760,7 @@ struct RunStep {
     bool inside = false;                        // row hi lies in a run of the table (LF_w_loc's fast branch, rowbowt.hpp:559-561)
     // else the predecessor run's sample: entry samp_run of depth d's arrays, or (samp_c > 0) entry e0 + samp_c - 1 of bucket record samp_run
     uint32_t samp_run = 0, samp_c = 0;
+    uint64_t samp_e = 0;                        // format 2 (rbg_runs2_device.hpp): that entry's index in the depth's arrays
 };
 // its sample (one gather by the lane itself)
 template <typename P>

@@ -1850,10 +1850,13 @@ def _with_layout(layout, top_kb, build):
         ra.set_default_option(capi.OPT_TREE_TOP_KB, 48)
 
 
-@pytest.mark.parametrize("pos_bytes,top_kb,fk,ks,rec", [(0, 48, -1, 5, None), (8, 48, -1, 5, None), (0, 0, -1, 5, "200"), (8, 0, 3, 4, None),
-                                                        (0, 1, 0, 3, None), (0, 48, -1, 1, "1"), (8, 1, -1, 2, "40"), (0, 0, 0, 1, "8"),
-                                                        (8, 48, 0, 5, "3"), (0, 48, 0, 5, "8")])
-def test_run_indexed_layout(synth, pos_bytes, top_kb, fk, ks, rec):
+@pytest.mark.parametrize("pos_bytes,top_kb,fk,ks,rec,fmt", [(0, 48, -1, 5, None, 2), (8, 48, -1, 5, None, 2), (0, 48, -1, 5, None, 1), (8, 48, -1, 5, None, 1),
+                                                            (0, 0, -1, 5, "200", 1), (8, 0, 3, 4, None, 1),
+                                                            (0, 1, 0, 3, None, 1), (0, 48, -1, 1, "1", 1), (8, 1, -1, 2, "40", 1), (0, 0, 0, 1, "8", 1),
+                                                            (8, 48, 0, 5, "3", 1), (0, 48, 0, 5, "8", 1),
+                                                            (8, 48, 0, 1, None, 2), (0, 48, 3, 3, None, 2), (8, 48, 3, 2, None, 2), (0, 48, 0, 4, None, 2),
+                                                            (8, 48, -1, 4, None, 2)])
+def test_run_indexed_layout(synth, pos_bytes, top_kb, fk, ks, rec, fmt):
     """RBG_LAYOUT_RUNS (k_runs.hip): space proportional to r, rank and phi as wave-cooperative predecessor searches
     over the run lists (rle_string.hpp:131-161, toehold_sa.hpp:56-72), k-mer steps through one clamped search per
     depth (ks = symbols per step) -- same answers as the slot tables, i.e. as the oracle, on every read shape of
@@ -1864,9 +1867,10 @@ def test_run_indexed_layout(synth, pos_bytes, top_kb, fk, ks, rec):
     ra.set_default_option(capi.OPT_POS_BYTES, pos_bytes)
     ra.set_default_option(capi.OPT_FTAB_K, fk)
     ra.set_default_option(capi.OPT_KMER_STEPS, ks)
-    if ks in (2, 4):
+    ra.set_default_option(capi.OPT_RUN_FMT, fmt)   # 2: one lane per query (rbg_runs2_device.hpp); 1: quads of lanes / the descent / bucket records
+    if fmt == 1 and ks in (2, 4):
         os.environ["RBG_PHI_DIR"] = "0"   # phi by the descent through the sampled levels only (no directory)
-    if ks in (3, 4):
+    if fmt == 1 and ks in (3, 4):
         os.environ["RBG_RANK_DIR"] = "0"  # ranks likewise
     if rec is not None:
         os.environ["RBG_RANK_REC"] = rec
@@ -1875,6 +1879,7 @@ def test_run_indexed_layout(synth, pos_bytes, top_kb, fk, ks, rec):
     try:
         rb = _with_layout(capi.LAYOUT_RUNS, top_kb, lambda: ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0))
     finally:
+        ra.set_default_option(capi.OPT_RUN_FMT, 2)
         ra.set_default_option(capi.OPT_RUN_DEPTHS, 0)
         ra.set_default_option(capi.OPT_POS_BYTES, 0)
         ra.set_default_option(capi.OPT_FTAB_K, -1)
@@ -1882,12 +1887,23 @@ def test_run_indexed_layout(synth, pos_bytes, top_kb, fk, ks, rec):
         os.environ.pop("RBG_PHI_DIR", None)
         os.environ.pop("RBG_RANK_DIR", None)
         os.environ.pop("RBG_RANK_REC", None)
-    o = orc.Oracle.from_runs(S.heads, S.lens, S.ssa, S.esa)
     info = rb.info()
     assert info.rank_layout == capi.LAYOUT_RUNS and info.kmer_steps == ks and info.pos_bytes == (pos_bytes or 4)
     assert info.rank_slots == 0 and info.phi_slots == 0
     lists = [d for d, x in ((2, info.pair_runs), (3, info.triple_runs), (4, info.quad_runs), (5, info.quint_runs)) if x]
     assert lists == ([d for d in range(2, ks + 1)] if rec is not None or ks == 4 else [d for d in range(2, ks + 1) if (ks - d) % 2 == 0])
+    li = rb.layout_info()
+    assert li.run_fmt == fmt and li.depths_dropped_budget == 0 and li.depths_dropped_limit == 0 and li.phi_directory_dropped == 0
+    assert [d + 1 for d in range(5) if li.depth_mask_kept >> d & 1] == [1] + [d for d in lists]
+    if fmt == 2:
+        assert li.rank_directories == 1 and li.phi_directory == 1 and li.phi_entries == len(S.heads) and sum(li.fillers) == 0
+        assert all((li.entries[d] > 0) == bool(li.depth_mask_kept >> d & 1) for d in range(5))
+    _run_indexed_checks(S, rb)
+
+
+def _run_indexed_checks(S, rb):
+    """every query of the run-indexed layout against the oracle (rb is closed at the end)"""
+    o = orc.Oracle.from_runs(S.heads, S.lens, S.ssa, S.esa)
     reads = S.sample_reads(3000, 60, seed=5, sub_rate=0.15, ragged=True)
     reads += [b"", b"A", b"N", b"ACGTN", b"NACGT", b"ACNGT", b"AC", b"ACG", b"acgt", bytes([1]), bytes([255]) * 3, bytes([0]),
               S.text[:500].tobytes(), S.text[:501].tobytes(), b"A" + bytes([1]), bytes([1]) + b"A",
@@ -1936,6 +1952,83 @@ def test_run_indexed_layout(synth, pos_bytes, top_kb, fk, ks, rec):
             assert (int(lo3[i]), int(hi3[i])) == (wl, wh) and got3[i] == wm, (i, q, wsize)
     rb.close()
     o.close()
+
+
+@pytest.mark.parametrize("fill_shift,super_shift,ks,depths,dir_runs,phi_per", [(6, 2, 5, 0, None, None), (4, 1, 3, 0x7, "1", "0.5"), (9, 5, 1, 0, "16", "4"),
+                                                                                (5, 3, 5, 0x1F, "40", "9")])
+def test_run_indexed_format2_fillers_and_super_counts(synth, fill_shift, super_shift, ks, depths, dir_runs, phi_per):
+    """Format 2 at 8-byte positions stores the LOW WORDS of {start, cum} and of the sampled positions; what makes that exact
+    (rbg_dev.h DevRunTab2) is (a) filler entries wherever two entries of a table lie 2^fill_shift rows or more apart, (b)
+    directory buckets no wider than that, (c) the rank's high part in the directory, (d) 64-bit super counts under the phi
+    directory's 32-bit ones.  On a real index the distance is 2^30 rows and the super blocks 2^16 buckets: never met by a
+    test-sized text.  RBG_RUN_FILL_SHIFT / RBG_PHI_SUPER_SHIFT shrink both so that this index is FULL of fillers (runs
+    longer than the distance are cut into continuation pieces, gaps get empty runs, phi entries get shifted bases) and
+    spans many super blocks -- and every query must still equal the oracle's.  dir_runs / phi_per: coarse directories on
+    top (narrowing rounds over fillers), or fine ones (most buckets empty)."""
+    S = synth
+    ra.set_default_option(capi.OPT_POS_BYTES, 8)
+    ra.set_default_option(capi.OPT_KMER_STEPS, ks)
+    ra.set_default_option(capi.OPT_RUN_DEPTHS, depths)
+    os.environ["RBG_RUN_FILL_SHIFT"] = str(fill_shift)
+    os.environ["RBG_PHI_SUPER_SHIFT"] = str(super_shift)
+    if dir_runs:
+        os.environ["RBG_RANK_DIR_RUNS"] = dir_runs
+    if phi_per:
+        os.environ["RBG_PHI_DIR_PER"] = phi_per
+    try:
+        rb = _with_layout(capi.LAYOUT_RUNS, 48, lambda: ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0))
+    finally:
+        ra.set_default_option(capi.OPT_POS_BYTES, 0)
+        ra.set_default_option(capi.OPT_KMER_STEPS, 5)
+        ra.set_default_option(capi.OPT_RUN_DEPTHS, 0)
+        for k in ("RBG_RUN_FILL_SHIFT", "RBG_PHI_SUPER_SHIFT", "RBG_RANK_DIR_RUNS", "RBG_PHI_DIR_PER"):
+            os.environ.pop(k, None)
+    li = rb.layout_info()
+    assert li.run_fmt == 2 and li.fill_shift == fill_shift and rb.info().pos_bytes == 8
+    kept = [d for d in range(5) if li.depth_mask_kept >> d & 1]
+    assert sum(li.fillers) > 0 and (fill_shift > 6 or all(li.fillers[d] > 0 for d in kept)), list(li.fillers)   # tables with gaps beyond the distance
+    assert li.phi_fillers > 0 and li.phi_entries == len(S.heads) + li.phi_fillers
+    assert (S.n >> li.phi_dir_shift) >> super_shift > 2                   # several super blocks
+    _run_indexed_checks(S, rb)
+
+
+def test_run_indexed_format1_limits_are_loud(synth, capfd):
+    """Format 1 (rounds 2-3) has two width limits that used to bite without a word: 32-bit entry indices (a depth with 2^32
+    entries was left out, and the depth forced in its place could already have been released) and a phi directory that
+    vanished beyond 2 GiB / r >= 2^31 (phi then descends the sampled levels, several times slower).  Format 2 has
+    neither.  Here both thresholds are lowered (RBG_RUN1_MAX_ENTRIES, RBG_PHI1_DIR_MAX_BYTES): the first is now an error
+    that names the way out, the second is reported on stderr and by rbg_layout_info -- and the answers stay the oracle's."""
+    S = synth
+    ra.set_default_option(capi.OPT_RUN_FMT, 1)
+    os.environ["RBG_RUN1_MAX_ENTRIES"] = "5000"
+    try:
+        with pytest.raises(ra.RbgError) as ei:
+            _with_layout(capi.LAYOUT_RUNS, 48, lambda: ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0))
+        assert ei.value.code == -4
+        assert "format 2" in capfd.readouterr().err
+        os.environ.pop("RBG_RUN1_MAX_ENTRIES")
+        os.environ["RBG_PHI1_DIR_MAX_BYTES"] = "64"
+        rb = _with_layout(capi.LAYOUT_RUNS, 48, lambda: ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0))
+        assert "leaves the phi directory out" in capfd.readouterr().err
+    finally:
+        ra.set_default_option(capi.OPT_RUN_FMT, 2)
+        os.environ.pop("RBG_RUN1_MAX_ENTRIES", None)
+        os.environ.pop("RBG_PHI1_DIR_MAX_BYTES", None)
+    li = rb.layout_info()
+    assert li.run_fmt == 1 and li.phi_directory == 0 and li.phi_directory_dropped == 1 and li.rank_directories == 1
+    o = orc.Oracle.from_runs(S.heads, S.lens, S.ssa, S.esa)
+    seqs, off = ra.pack_reads(S.sample_reads(500, 50, seed=9, sub_rate=0.1, ragged=True))
+    lo, hi, k = rb.find_range_w_toehold(seqs, off)
+    wlo, whi, wk = o.find_range_w_toehold_batch(seqs, off)
+    assert (lo == wlo).all() and (hi == whi).all() and (k == wk).all()
+    loc_off, locs = rb.locs_at(lo, hi, k, MAXU)
+    woff, wlocs = o.locs_at_batch(wlo, whi, wk, MAXU)
+    assert (loc_off == woff).all() and (locs == wlocs).all()
+    # the same index in format 2: nothing dropped, nothing to report
+    rb2 = _with_layout(capi.LAYOUT_RUNS, 48, lambda: ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0))
+    l2 = rb2.layout_info()
+    assert l2.run_fmt == 2 and l2.phi_directory == 1 and l2.phi_directory_dropped == 0 and l2.depths_dropped_limit == 0
+    rb.close(); rb2.close(); o.close()
 
 
 @pytest.mark.parametrize("pos_bytes,rec,dir_runs", [(0, None, None), (8, None, "64"), (0, None, "64"), (0, "6", None), (8, "3", None)])
