@@ -456,6 +456,12 @@ int rbg_locate_fill_stats_dev(rbg_index *, const uint64_t *d_lo, const uint64_t 
 int rbg_sample_reads_dev(const uint8_t *d_text, uint64_t unit, uint64_t H, uint64_t L, uint64_t m, uint64_t seed,
                          uint64_t first_read, uint64_t N, uint32_t sub_ppm, uint8_t *d_seqs, uint64_t *d_off,
                          uint64_t *d_start /* nullable */, void *stream);
+/* The same reads (byte for byte, for the same seed) from the STRUCTURE of such a text instead of the text: a pangenome of
+ * n = 3e11 symbols does not fit the HBM it would be sampled from.  Symbol (h, p) is d_base[p] (L bytes), or d_alt[j] when p
+ * is variant site j (d_sites: S ascending offsets) and haplotype h carries the alternative allele (d_G[j * H + h] != 0). */
+int rbg_sample_reads_pangenome_dev(const uint8_t *d_base, const uint64_t *d_sites, const uint8_t *d_alt, const uint8_t *d_G, uint64_t S,
+                                   uint64_t unit, uint64_t H, uint64_t L, uint64_t m, uint64_t seed, uint64_t first_read, uint64_t N,
+                                   uint32_t sub_ppm, uint8_t *d_seqs, uint64_t *d_off, uint64_t *d_start /* nullable */, void *stream);
 
 /* ---- tuning (never changes results) -------------------------------------------------------- */
 /* Process-wide defaults read when an index is built/loaded: BLOCK_THREADS (64, 128, 192 or 256; the search

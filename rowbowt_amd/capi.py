@@ -124,6 +124,7 @@ _PROTOS = [
     ("rbg_find_range_stats_dev", C.c_int, [VP, VP, VP, U64, VP, VP, VP, VP, VP]),
     ("rbg_locate_fill_stats_dev", C.c_int, [VP, VP, VP, VP, U64, U64, VP, VP, VP, VP, VP]),
     ("rbg_sample_reads_dev", C.c_int, [VP, U64, U64, U64, U64, U64, U64, U64, C.c_uint32, VP, VP, VP, VP]),
+    ("rbg_sample_reads_pangenome_dev", C.c_int, [VP, VP, VP, VP, U64, U64, U64, U64, U64, U64, U64, U64, C.c_uint32, VP, VP, VP, VP]),
     ("rbg_replicate", C.c_int, [VP, C.c_int, C.POINTER(VP)]),
     ("rbg_replicate_many", C.c_int, [VP, C.POINTER(C.c_int), C.c_int, C.POINTER(VP)]),
     ("rbg_comm_cache_clear", C.c_int, []),

@@ -714,7 +714,53 @@ __global__ __launch_bounds__(256) void k_sample_reads(const uint8_t *__restrict_
         }
     }
 }
+// the same reads from the pangenome's STRUCTURE instead of its text (n = 3e11 symbols do not fit the HBM they would be
+// sampled from): symbol (h, p) of the text is base[p], or alt[j] when p is variant site j and haplotype h carries the
+// alternative allele (G[j * H + h] != 0).  Read g is the same function of (seed, g) as above.
+__global__ __launch_bounds__(256) void k_sample_reads_pg(const uint8_t *__restrict__ base, const uint64_t *__restrict__ sites, const uint8_t *__restrict__ alt,
+                                                         const uint8_t *__restrict__ G, const uint64_t S, const uint64_t unit, const uint64_t H,
+                                                         const uint64_t L, const uint64_t m, const uint64_t seed, const uint64_t first,
+                                                         const uint64_t N, const uint32_t sub_ppm, uint8_t *__restrict__ seqs,
+                                                         uint64_t *__restrict__ off, uint64_t *__restrict__ start_out) {
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint64_t wave = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 6;
+    for (uint64_t i = wave; i < N; i += nwaves) {
+        const uint64_t g = first + i;
+        const uint64_t r0 = splitmix64(seed ^ (g * 0xD1B54A32D192ED03ull));
+        const uint64_t r1 = splitmix64(r0), r2 = splitmix64(r1), r3 = splitmix64(r2);
+        const uint64_t h = r0 % H, p0 = r1 % (L - m + 1);
+        const bool mutate = (r2 % 1000000ull) < sub_ppm;
+        const uint64_t mpos = (r2 >> 32) % m;
+        uint64_t a = 0, z = S;                         // first site at or after p0
+        while (a < z) { const uint64_t mid = a + ((z - a) >> 1); if (sites[mid] < p0) a = mid + 1; else z = mid; }
+        for (uint64_t j = lane; j < m; j += kWave) {
+            uint32_t c = base[p0 + j];
+            for (uint64_t t = a; t < S && sites[t] < p0 + m; ++t)
+                if (sites[t] == p0 + j && G[t * H + h]) c = alt[t];
+            if (mutate && j == mpos) {
+                const uint32_t code = c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 0u;
+                c = "ACGT"[(code + 1u + static_cast<uint32_t>(r3 % 3)) & 3u];
+            }
+            seqs[i * m + j] = static_cast<uint8_t>(c);
+        }
+        if (lane == 0) {
+            off[i] = i * m;
+            if (i + 1 == N) off[N] = N * m;
+            if (start_out) start_out[i] = h * unit + p0;
+        }
+    }
+}
 }  // namespace
+
+int launch_sample_reads_pg(const uint8_t *base, const uint64_t *sites, const uint8_t *alt, const uint8_t *G, uint64_t S, uint64_t unit, uint64_t H, uint64_t L,
+                           uint64_t m, uint64_t seed, uint64_t first, uint64_t N, uint32_t sub_ppm, uint8_t *seqs, uint64_t *off, uint64_t *start_out, void *stream) {
+    if (N == 0) return 0;
+    const uint64_t blocks = std::min<uint64_t>((N + 3) / 4, 256ull * 64);
+    hipLaunchKernelGGL(k_sample_reads_pg, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, static_cast<hipStream_t>(stream), base, sites, alt, G, S, unit, H, L, m,
+                       seed, first, N, sub_ppm, seqs, off, start_out);
+    return static_cast<int>(hipGetLastError());
+}
 
 int launch_sample_reads(const uint8_t *text, uint64_t unit, uint64_t H, uint64_t L, uint64_t m, uint64_t seed, uint64_t first,
                         uint64_t N, uint32_t sub_ppm, uint8_t *seqs, uint64_t *off, uint64_t *start_out, void *stream) {

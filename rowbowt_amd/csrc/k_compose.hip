@@ -49,7 +49,7 @@ struct Pool {
         for (Blk &b : blks)
             if (!b.used && b.bytes >= bytes && (!best || b.bytes < best->bytes)) best = &b;
         if (best) { best->used = true; *out = best->p; return hipSuccess; }
-        const size_t want = bytes + bytes / 4 + 256;
+        const size_t want = bytes + (bytes < (size_t(1) << 30) ? bytes / 4 : bytes / 64) + 256;   // (big blocks: the slack is gigabytes at r = 1e9)
         void *p = nullptr;
         hipError_t e = hipMalloc(&p, want);
         if (e != hipSuccess) {   // give the idle blocks back and ask for exactly what is needed
@@ -68,6 +68,10 @@ struct Pool {
     void put(void *p) {
         for (Blk &b : blks)
             if (b.p == p) { b.used = false; return; }
+    }
+    void purge() {   // idle blocks back to the driver (before an allocation outside the pool that may need their space)
+        for (size_t i = 0; i < blks.size();)
+            if (!blks[i].used) { (void)hipFree(blks[i].p); blks.erase(blks.begin() + static_cast<std::ptrdiff_t>(i)); } else ++i;
     }
 };
 thread_local Pool *t_pool = nullptr;
@@ -311,7 +315,7 @@ int bits_for(uint64_t v) { int b = 1; while (b < 64 && (v >> b)) ++b; return b; 
 
 template <typename P>
 int compose_impl(const uint64_t n, const uint32_t M, const ComposeTable *major, const void *g1_start, const uint32_t *g1_id, const void *g1_samp,
-                 const uint64_t g1_n, const uint32_t kmax, const bool with_samples, std::vector<ComposedLevel> &out, hipStream_t st) {
+                 const uint64_t g1_n, const uint32_t kmax, const bool with_samples, std::vector<ComposedLevel> &out, hipStream_t st, const uint32_t keep_mask) {
     out.clear();
     // the segmentation of the current depth (depth 1: the caller's arrays, not owned)
     const P *g_start = static_cast<const P *>(g1_start);
@@ -333,6 +337,29 @@ int compose_impl(const uint64_t n, const uint32_t M, const ComposeTable *major, 
     for (uint32_t depth = 1; depth < kmax; ++depth, n_ids *= M) {
         const uint32_t T = n_ids * M;
         const auto t_lvl = now();
+        // ---- F of the new tables first: it is the only thing that reads the PREVIOUS depth's run lists, and a depth the caller
+        // does not keep (keep_mask: the run-indexed layout's depth set) gives its arrays back before this depth's temporaries
+        // are made -- at r = 1e9 that is 50 GB of the 300 the composition would otherwise want at once
+        Tmp d_F;
+        {
+            Tmp d_prev_ent, d_prev_nruns, d_prev_F, d_sym_F;
+            CK(d_prev_ent.alloc(n_ids * 8)); CK(d_prev_nruns.alloc(n_ids * 8)); CK(d_prev_F.alloc(n_ids * 8)); CK(d_sym_F.alloc(M * 8)); CK(d_F.alloc(T * 8));
+            CK(hipMemcpy(d_prev_ent.p, prev_ent.data(), n_ids * 8, hipMemcpyHostToDevice));
+            CK(hipMemcpy(d_prev_nruns.p, prev_nruns.data(), n_ids * 8, hipMemcpyHostToDevice));
+            CK(hipMemcpy(d_prev_F.p, prev_F.data(), n_ids * 8, hipMemcpyHostToDevice));
+            CK(hipMemcpy(d_sym_F.p, sym_F.data(), M * 8, hipMemcpyHostToDevice));
+            hipLaunchKernelGGL((k_table_F<P>), dim3((T + 255) / 256), dim3(256), 0, st, d_prev_ent.as<const RunEnt<P> *>(), d_prev_nruns.as<uint64_t>(),
+                               d_prev_F.as<uint64_t>(), d_sym_F.as<uint64_t>(), n_ids, M, d_F.as<uint64_t>());
+            CK(hipGetLastError());
+            CK(hipStreamSynchronize(st));
+        }
+        if (depth >= 2 && keep_mask && !(keep_mask >> (depth - 1) & 1u)) {   // depth `depth` = out[depth - 2]: not kept, no longer read
+            ComposedLevel &old = out[depth - 2];
+            if (old.ent) (void)hipFree(old.ent);
+            if (old.samp) (void)hipFree(old.samp);
+            old.ent = old.samp = nullptr;
+        }
+        const bool last_level = depth + 1 == kmax;
         // ---- pieces of every symbol -------------------------------------------------------------------------------------
         // which G segments a symbol's image [F, F + total) meets: two binary searches per symbol, made from the host over the
         // device array (a few dozen 8-byte copies per level)
@@ -404,6 +431,7 @@ int compose_impl(const uint64_t n, const uint32_t M, const ComposeTable *major, 
             posB[m].release();
         }
         const auto t_pieces = now();
+        if (last_level) { own_start.release(); own_id.release(); own_samp.release(); }   // (the segmentation is read by the pieces only)
         // ---- tables: stable sort by table, cum by one scan ------------------------------------------------------------------
         Tmp iota, s_tab, perm;
         CK(iota.alloc((np + 1) * 4));
@@ -413,6 +441,8 @@ int compose_impl(const uint64_t n, const uint32_t M, const ComposeTable *major, 
         CK(hipGetLastError());
         int rc = sort_pairs<uint32_t>(p_tab.as<uint32_t>(), s_tab.as<uint32_t>(), iota.as<uint32_t>(), perm.as<uint32_t>(), np, bits_for(T), st);
         if (rc) return rc;
+        iota.release();
+        if (last_level) p_tab.release();   // (the next segmentation reads it)
         Tmp first;
         CK(first.alloc((T + 2) * 8));
         hipLaunchKernelGGL(k_table_firsts, dim3((T + 2 + 255) / 256), dim3(256), 0, st, s_tab.as<uint32_t>(), np, T, first.as<uint64_t>());
@@ -427,6 +457,8 @@ int compose_impl(const uint64_t n, const uint32_t M, const ComposeTable *major, 
         CK(hipGetLastError());
         if ((rc = exclusive_scan_u64(lens.as<uint64_t>(), cumlen.as<uint64_t>(), np + 1, st))) return rc;
         lens.release();
+        if (last_level) p_len.release();
+        t_pool->purge();   // (the level's own arrays come straight from the driver)
         ComposedLevel L;
         L.entries = nkept + T;
         void *d_ent = nullptr, *d_samp = nullptr;
@@ -453,15 +485,6 @@ int compose_impl(const uint64_t n, const uint32_t M, const ComposeTable *major, 
             CK(hipGetLastError());
             CK(hipMemcpy(h_cum_at.data(), d_cum_at.p, (T + 1) * 8, hipMemcpyDeviceToHost));
         }
-        Tmp d_prev_ent, d_prev_nruns, d_prev_F, d_sym_F, d_F;
-        CK(d_prev_ent.alloc(n_ids * 8)); CK(d_prev_nruns.alloc(n_ids * 8)); CK(d_prev_F.alloc(n_ids * 8)); CK(d_sym_F.alloc(M * 8)); CK(d_F.alloc(T * 8));
-        CK(hipMemcpy(d_prev_ent.p, prev_ent.data(), n_ids * 8, hipMemcpyHostToDevice));
-        CK(hipMemcpy(d_prev_nruns.p, prev_nruns.data(), n_ids * 8, hipMemcpyHostToDevice));
-        CK(hipMemcpy(d_prev_F.p, prev_F.data(), n_ids * 8, hipMemcpyHostToDevice));
-        CK(hipMemcpy(d_sym_F.p, sym_F.data(), M * 8, hipMemcpyHostToDevice));
-        hipLaunchKernelGGL((k_table_F<P>), dim3((T + 255) / 256), dim3(256), 0, st, d_prev_ent.as<const RunEnt<P> *>(), d_prev_nruns.as<uint64_t>(),
-                           d_prev_F.as<uint64_t>(), d_sym_F.as<uint64_t>(), n_ids, M, d_F.as<uint64_t>());
-        CK(hipGetLastError());
         Lv.nruns.resize(T); Lv.total.resize(T); Lv.F.resize(T); Lv.first.resize(T);
         CK(hipMemcpy(Lv.F.data(), d_F.p, T * 8, hipMemcpyDeviceToHost));
         for (uint32_t t = 0; t < T; ++t) {
@@ -532,12 +555,12 @@ int compose_impl(const uint64_t n, const uint32_t M, const ComposeTable *major, 
 
 // RBG_* codes: 0 ok, -2 EFORMAT, -3 ENODEV, -4 EARG, -5 ENOMEM (include/rbg.h)
 int compose_levels_device(uint32_t pos_bytes, uint64_t n, uint32_t M, const ComposeTable *major, const void *g_start, const uint32_t *g_id,
-                          const void *g_samp, uint64_t g_n, uint32_t kmax, bool with_samples, std::vector<ComposedLevel> &out, void *stream) {
+                          const void *g_samp, uint64_t g_n, uint32_t kmax, bool with_samples, std::vector<ComposedLevel> &out, void *stream, uint32_t keep_mask) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     Pool pool;
     struct Scope { Pool *prev; explicit Scope(Pool *p) : prev(t_pool) { t_pool = p; } ~Scope() { t_pool = prev; } } scope(&pool);
-    return pos_bytes == 4 ? compose_impl<uint32_t>(n, M, major, g_start, g_id, g_samp, g_n, kmax, with_samples, out, st)
-                          : compose_impl<uint64_t>(n, M, major, g_start, g_id, g_samp, g_n, kmax, with_samples, out, st);
+    return pos_bytes == 4 ? compose_impl<uint32_t>(n, M, major, g_start, g_id, g_samp, g_n, kmax, with_samples, out, st, keep_mask)
+                          : compose_impl<uint64_t>(n, M, major, g_start, g_id, g_samp, g_n, kmax, with_samples, out, st, keep_mask);
 }
 
 }  // namespace rbg

@@ -59,6 +59,7 @@ struct rbg_index {
     uint64_t rank_slots = 0, rank_slots_overflow = 0, phi_slots = 0, phi_slots_overflow = 0;
     uint64_t kmer_steps_requested = 0, hbm_free_at_load = 0, hbm_budget = 0;  // how the space/speed point was chosen (rbg_info)
     bool runs_layout = false;
+    bool runs_forced = false;      // the composition already gave back the depths the run-indexed layout leaves out: no way back to slot tables
     uint32_t run_depth_mask = 0;   // run-indexed layout: the k-mer depths that have run lists (bit d - 1)
     // what the load decided about the run-indexed layout (rbg_layout_info): nothing is left out without a line here
     struct RunsReport {
@@ -133,6 +134,9 @@ std::atomic<int64_t> g_opt_run_depths{env_opt("RBG_RUN_DEPTHS", 0, 0, (1 << kMax
 std::atomic<int64_t> g_opt_run_fmt{env_opt("RBG_RUN_FMT", 2, 1, 2)};   // run-indexed layout: 1 = {P, P} pairs probed by quads of lanes (rounds 2-3), 2 = per-lane probes (rbg_dev.h DevRunTab2)
 std::atomic<int64_t> g_opt_slot_bytes{16};    // 16: RankSlot; 64: RankSlot64 (experiment: rbg_dev.h)
 std::atomic<int64_t> g_opt_packed_reads{1};  // host-pointer calls: 0 bytes over PCIe, 1 (default) 2-bit codes for batches >= 4096, 2 always
+
+// the replica's share of the free HBM when no budget is given (RBG_OPT_HBM_BUDGET_MB)
+inline size_t default_budget(size_t free_b) { return free_b - free_b / 4; }
 
 #define HIP_TRY(expr)                                                                             \
     do {                                                                                          \
@@ -1534,7 +1538,33 @@ int compose_on_device(rbg_index *ix) {
     if (std::getenv("RBG_VERBOSE"))
         std::fprintf(stderr, "rbg:   compose: depth-1 tables and runs converted and copied in %.2f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     std::vector<ComposedLevel> levels;
-    if (!rc) rc = compose_levels_device(sizeof(P), h.n, M, major, g_start, static_cast<const uint32_t *>(g_id), g_samp, h.r, K, h.has_tsa, levels, nullptr);
+    // When the run-indexed layout is certain (asked for, or not even the single-symbol slot tables fit the budget: the test
+    // options_for makes) the depths its depth set leaves out give their arrays back as soon as the next depth is made.
+    uint32_t keep_mask = 0;
+    {
+        bool runs_certain = g_opt_rank_layout.load() == RBG_LAYOUT_RUNS;
+        if (g_opt_rank_layout.load() == RBG_LAYOUT_AUTO) {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+                const int64_t opt_mb = g_opt_hbm_budget_mb.load();
+                const double budget = static_cast<double>(opt_mb > 0 ? static_cast<size_t>(opt_mb) << 20 : default_budget(free_b));
+                const double lvl1 = static_cast<double>(h.sigma) * static_cast<double>((h.n >> kMaxNarrowShift) + 2) * (sizeof(RankSlot) + sizeof(uint32_t)) +
+                                    static_cast<double>((h.n >> 6) + 2) * (4.0 * sizeof(P) + 4);
+                runs_certain = lvl1 > budget;
+            }
+        }
+        if (runs_certain && h.sigma <= static_cast<uint32_t>(kLdsSyms)) {
+            keep_mask = g_opt_run_depths.load() ? static_cast<uint32_t>(g_opt_run_depths.load()) | 1u : 1u;
+            if (!g_opt_run_depths.load())
+                for (int d = static_cast<int>(K); d >= 1; d -= 2) keep_mask |= 1u << (d - 1);
+            keep_mask |= 1u << (K - 1);
+        }
+    }
+    if (!rc) rc = compose_levels_device(sizeof(P), h.n, M, major, g_start, static_cast<const uint32_t *>(g_id), g_samp, h.r, K, h.has_tsa, levels, nullptr, keep_mask);
+    if (rc == RBG_EARG) {   // 2^32 pieces in one depth (r beyond about 1.7e9 at five symbols): the device sweeps index pieces with 32 bits, the host composition does not
+        std::fprintf(stderr, "rbg: a k-mer depth has 2^32 pieces or more: the device composition indexes them with 32 bits\n");
+        rc = RBG_ENOMEM;
+    }
     if (rc == RBG_ENOMEM || rc == RBG_ENODEV) {   // not enough HBM for the sweeps' temporaries: the host composes instead
         for (ComposedLevel &L : levels) { if (L.ent) (void)hipFree(L.ent); if (L.samp) (void)hipFree(L.samp); }
         (void)hipGetLastError();
@@ -1546,6 +1576,7 @@ int compose_on_device(rbg_index *ix) {
         return rc;
     }
     ix->kmer_levels = std::move(levels);
+    ix->runs_forced = keep_mask != 0;
     // the depth-1 run lists of the k-mer alphabet are on the device in the very form the slot tables are built from
     // (commit_sym): they stay, instead of being converted and copied a second time (5 + 2.5 GB at r = 3e8)
     for (uint32_t m = 0; m < M; ++m) {
@@ -1563,8 +1594,10 @@ int compose_on_device(rbg_index *ix) {
     }
     for (uint32_t d = 2; d <= K; ++d) {
         ComposedLevel &L = ix->kmer_levels[d - 2];
-        ix->allocs.push_back({L.ent, (L.entries + 2) * sizeof(RunEnt<P>)});
-        ix->hbm_bytes += (L.entries + 2) * sizeof(RunEnt<P>);
+        if (L.ent) {   // (a depth outside the run-indexed layout's depth set has given its arrays back already: metadata only)
+            ix->allocs.push_back({L.ent, (L.entries + 2) * sizeof(RunEnt<P>)});
+            ix->hbm_bytes += (L.entries + 2) * sizeof(RunEnt<P>);
+        }
         if (L.samp) { ix->allocs.push_back({L.samp, (L.entries + 2) * sizeof(P)}); ix->hbm_bytes += (L.entries + 2) * sizeof(P); }
         std::vector<SymTable> &tabs = kmer_level_tables(h, d);
         tabs.assign(L.nruns.size(), SymTable());
@@ -1577,7 +1610,7 @@ int compose_on_device(rbg_index *ix) {
             st.shift = kmer_table_shift(h.n, st.nruns, d, opt);
             if (st.shift > 12 || (st.shift > 8 && (h.n >> 40))) return RBG_EARG;  // wide buckets carry 40-bit ranks (rbg_dev.h)
             if (st.nruns >= 0xFFFFFFF0ull) return RBG_EARG;
-            st.dev_ent = static_cast<const char *>(L.ent) + L.first[t] * sizeof(RunEnt<P>);
+            st.dev_ent = L.ent ? static_cast<const char *>(L.ent) + L.first[t] * sizeof(RunEnt<P>) : nullptr;
             st.dev_samp = L.samp ? static_cast<const char *>(L.samp) + L.first[t] * sizeof(P) : nullptr;
         }
     }
@@ -1619,6 +1652,16 @@ int materialize_kmer_levels(rbg_index *ix) {
     return RBG_OK;
 }
 
+// does k-mer depth d (2..5) still have its run lists -- on the host, or composed on the device and not given back?
+bool level_has_data(const rbg_index *ix, uint32_t d) {
+    const std::vector<SymTable> &T = d == 2 ? ix->H().pair : d == 3 ? ix->H().triple : d == 4 ? ix->H().quad : ix->H().quint;
+    if (T.empty()) return false;
+    if (d - 2 < ix->kmer_levels.size() && ix->kmer_levels[d - 2].ent) return true;
+    for (const SymTable &t : T)
+        if (t.start.size() == t.nruns + 1) return true;
+    return false;
+}
+
 int upload(rbg_index *ix) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ix->device < 0 || ix->device >= ndev) {
@@ -1652,7 +1695,7 @@ int upload(rbg_index *ix) {
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     const int64_t opt_mb = g_opt_hbm_budget_mb.load();
-    const size_t budget = opt_mb > 0 ? static_cast<size_t>(opt_mb) << 20 : free_b - free_b / 4;
+    const size_t budget = opt_mb > 0 ? static_cast<size_t>(opt_mb) << 20 : default_budget(free_b);
     auto need = [&] { return h.pos_bytes == 4 ? replica_bytes<uint32_t>(h) : replica_bytes<uint64_t>(h); };
     // Layout: the slot tables cost n/16 bytes per table + n/2 (n at 8-byte positions) for phi, whatever r is.  When
     // even the single-symbol level does not fit the budget -- or on request -- the run-indexed layout takes over
@@ -1668,6 +1711,7 @@ int upload(rbg_index *ix) {
         }
         runs_layout = lvl1 > budget;
     }
+    if (ix->runs_forced) runs_layout = true;
     if (runs_layout && h.sigma > static_cast<uint32_t>(kLdsSyms)) {
         std::fprintf(stderr, "rbg: %u distinct symbols: the run-indexed layout serves at most %d; keeping the slot tables\n", h.sigma, kLdsSyms);
         runs_layout = false;
@@ -1714,6 +1758,8 @@ int upload(rbg_index *ix) {
                          need_runs() / 1e9, budget / 1e9, deepest_of().size());
             ix->runs_report.depths_dropped_budget |= 1u << (levels() - 1);
             drop_kmer_level(ix, deepest_of());
+            // (the new deepest depth must still have its lists: a depth the composition gave back early goes too)
+            while (levels() > 1 && !level_has_data(ix, static_cast<uint32_t>(levels()))) drop_kmer_level(ix, deepest_of());
             mask = (mask & ((1u << levels()) - 1u)) | (1u << (levels() - 1));   // (the new deepest level is stepped by again)
         }
         for (int d = 2; d < levels(); ++d)   // the depths left out give their device arrays back now
@@ -1874,7 +1920,7 @@ FlattenOptions options_for(int device, const RawRle &rle, uint64_t *requested) {
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return o;
     const int64_t opt_mb = g_opt_hbm_budget_mb.load();
-    const double budget = static_cast<double>(opt_mb > 0 ? static_cast<size_t>(opt_mb) << 20 : free_b - free_b / 4);
+    const double budget = static_cast<double>(opt_mb > 0 ? static_cast<size_t>(opt_mb) << 20 : default_budget(free_b));
     bool seen[256] = {};
     unsigned sigma = 0;
     for (uint8_t c : rle.heads)
@@ -2904,6 +2950,16 @@ int rbg_sample_reads_dev(const uint8_t *d_text, uint64_t unit, uint64_t H, uint6
 
 // ---- packed reads (device API) ------------------------------------------------------------------
 size_t rbg_pack_ws_bytes(uint64_t N, uint64_t total_bytes) { return pack_ws_bytes(N, total_bytes); }
+
+int rbg_sample_reads_pangenome_dev(const uint8_t *d_base, const uint64_t *d_sites, const uint8_t *d_alt, const uint8_t *d_G, uint64_t S, uint64_t unit, uint64_t H,
+                                   uint64_t L, uint64_t m, uint64_t seed, uint64_t first_read, uint64_t N, uint32_t sub_ppm, uint8_t *d_seqs, uint64_t *d_off,
+                                   uint64_t *d_start, void *stream) {
+    return guarded([&]() -> int {
+    if (!d_base || !d_seqs || !d_off || (S && (!d_sites || !d_alt || !d_G))) return RBG_EARG;
+    if (m == 0 || m > L || H == 0 || L > unit || sub_ppm > 1000000u) return RBG_EARG;
+    return launch_sample_reads_pg(d_base, d_sites, d_alt, d_G, S, unit, H, L, m, seed, first_read, N, sub_ppm, d_seqs, d_off, d_start, stream) ? RBG_ENODEV : RBG_OK;
+    });
+}
 
 static int packed_args_ok(const rbg_index *ix, const void *d_ws, const uint8_t *d_seqs, const uint64_t *d_off, uint64_t N,
                           uint64_t total_bytes) {

@@ -42,15 +42,16 @@ def _pbwt():
         if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
             subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", src, "-o", so])
         _lib = ctypes.CDLL(so)
-        _lib.pbwt_suffix_ranks.restype = ctypes.c_int
-        _lib.pbwt_suffix_ranks.argtypes = [ctypes.c_uint64, ctypes.c_uint32] + [ctypes.c_void_p] * 5
+        for fn in (_lib.pbwt_suffix_ranks, _lib.pbwt_suffix_ranks16):
+            fn.restype = ctypes.c_int
+            fn.argtypes = [ctypes.c_uint64, ctypes.c_uint32] + [ctypes.c_void_p] * 5
     return _lib
 
 
 def make_pangenome(L, H, site_rate, seed, device, pad=10):
     """Random base sequence (2-bit codes), SNV sites at `site_rate` (none within K of either end), U-shaped
     allele frequencies, H haplotypes (haplotype 0 = the base sequence).  Everything stays on `device`."""
-    assert 2 <= H <= 255 and L > 4 * K
+    assert 2 <= H <= 32767 and L > 4 * K   # (more than 255 haplotypes: 16-bit ranks, pbwt.c)
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     base = torch.empty(L, dtype=torch.uint8, device=device)
@@ -95,30 +96,63 @@ def materialize_text(pg):
     return text
 
 
+class TextView:
+    """text[pos] of the pangenome WITHOUT the text: symbol (h, p) is the base sequence's, or the alternative allele when p
+    is a variant site haplotype h carries; pads are 'A', the last symbol is 0x01.  Holds the structure on the pangenome's
+    device (L bytes of base sequence, the sites, the S x H allele matrix): what rbg_sample_reads_pangenome_dev samples from."""
+
+    def __init__(self, pg):
+        dev = pg["base"].device
+        lut = torch.tensor(ACGT, dtype=torch.uint8, device=dev)
+        L = pg["L"]
+        self.base_b = lut[pg["base"].long()] if L < (1 << 28) else torch.cat([lut[pg["base"][a:a + (1 << 28)].long()] for a in range(0, L, 1 << 28)])
+        self.alt_b = lut[pg["alt"].long()]
+        self.sites = pg["sites"].contiguous()
+        self.G = pg["G"].contiguous()
+        self.L, self.H, self.unit, self.n, self.S = L, pg["H"], pg["unit"], pg["n"], pg["n_sites"]
+
+    def at(self, pos):
+        """uint8 tensor of text[pos] (pos: int64 tensor of any shape, values in [0, n))"""
+        h = torch.div(pos, self.unit, rounding_mode="floor")
+        p = pos - h * self.unit
+        c = torch.where(p < self.L, self.base_b[p.clamp(max=self.L - 1)], torch.full_like(p, 65, dtype=torch.uint8))
+        if self.S:
+            j = torch.searchsorted(self.sites, p).clamp(max=self.S - 1)
+            hit = (self.sites[j] == p) & (p < self.L) & (h < self.H)
+            carry = hit & (self.G[j, h.clamp(max=self.H - 1)] != 0)
+            c = torch.where(carry, self.alt_b[j], c)
+        return torch.where(pos == self.n - 1, torch.ones_like(c), c)
+
+
 def _suffix_ranks(pg):
-    """rank[s][h] (uint8, (S+1) x H, on device): order of the haplotypes by (alleles at sites s.., what follows the
-    haplotype).  What follows haplotype h is haplotype h+1 from its start, i.e. rank[0][h+1]; the last haplotype
-    is followed by the terminator (smallest).  Fixed point of the right-to-left pass (two passes when the allele
-    vectors are distinct)."""
+    """rank[s][h] (uint8, or int16 beyond 255 haplotypes; (S+1) x H, on device): order of the haplotypes by (alleles at
+    sites s.., what follows the haplotype).  What follows haplotype h is haplotype h+1 from its start, i.e.
+    rank[0][h+1]; the last haplotype is followed by the terminator (smallest).  Fixed point of the right-to-left pass
+    (two passes when the allele vectors are distinct)."""
     dev = pg["base"].device
     S, H = pg["n_sites"], pg["H"]
+    wide = H > 255
+    rt = np.uint16 if wide else np.uint8
+    fn = _pbwt().pbwt_suffix_ranks16 if wide else _pbwt().pbwt_suffix_ranks
     alt_smaller = pg["alt"] < pg["base"][pg["sites"]]
-    small = ((pg["G"] != 0) == alt_smaller[:, None]).to(torch.uint8).cpu().numpy()
-    small = np.ascontiguousarray(small)
-    tail = np.arange(1, H + 1, dtype=np.uint8)
+    small = np.empty((S, H), dtype=np.uint8)
+    for a in range(0, S, 1 << 22):    # (chunked: the comparison makes temporaries of the chunk's size on the device)
+        b = min(S, a + (1 << 22))
+        small[a:b] = ((pg["G"][a:b] != 0) == alt_smaller[a:b, None]).to(torch.uint8).cpu().numpy()
+    tail = np.arange(1, H + 1, dtype=rt)
     tail[H - 1] = 0
-    rank = np.empty((S + 1, H), dtype=np.uint8)
-    first = np.empty(S + 1, dtype=np.uint8)
-    last = np.empty(S + 1, dtype=np.uint8)
+    rank = np.empty((S + 1, H), dtype=rt)
+    first = np.empty(S + 1, dtype=rt)
+    last = np.empty(S + 1, dtype=rt)
     for _ in range(H + 2):
-        rc = _pbwt().pbwt_suffix_ranks(S, H, small.ctypes.data, tail.ctypes.data, rank.ctypes.data, first.ctypes.data, last.ctypes.data)
+        rc = fn(S, H, small.ctypes.data, tail.ctypes.data, rank.ctypes.data, first.ctypes.data, last.ctypes.data)
         assert rc == 0
-        nxt = np.empty(H, dtype=np.uint8)
+        nxt = np.empty(H, dtype=rt)
         nxt[H - 1] = 0
         order = np.argsort(rank[0][1:], kind="stable")      # haplotypes 1..H-1 by their order from offset 0
-        nxt[order] = np.arange(1, H, dtype=np.uint8)         # haplotype h (0..H-2) is followed by haplotype h+1
+        nxt[order] = np.arange(1, H, dtype=rt)               # haplotype h (0..H-2) is followed by haplotype h+1
         if (nxt == tail).all():
-            return torch.from_numpy(rank).to(dev)
+            return torch.from_numpy(rank.view(np.int16) if wide else rank).to(dev)   # (ranks stay below 2^15)
         tail = nxt
     raise RuntimeError("haplotype order did not converge")
 
@@ -173,8 +207,9 @@ def build_runs(pg, log=None):
 
     # ---- groups of every state: haplotypes by (pattern over the window's sites, order from site j1 on)
     g_state, g_pat, g_cnt, g_first, g_last, g_col = [], [], [], [], [], []
-    order_rows = torch.empty((nst, H), dtype=torch.uint8, device=dev)   # haplotypes of each state in class-then-rank order
-    chunk = max(1, (1 << 26) // H)
+    hdt = torch.int16 if H > 255 else torch.uint8
+    order_rows = torch.empty((nst, H), dtype=hdt, device=dev)   # haplotypes of each state in class-then-rank order
+    chunk = max(1, (1 << 25) // H)
     ar_h = torch.arange(H, device=dev)
     for s0 in range(0, nst, chunk):
         s1 = min(nst, s0 + chunk)
@@ -183,10 +218,10 @@ def build_runs(pg, log=None):
             use = c[s0:s1] > t
             rows = (j0[s0:s1] + t).clamp(max=max(S - 1, 0))
             pat += (G[rows].to(torch.int32) << t) * use[:, None].to(torch.int32)
-        key = pat * 256 + rank[j1[s0:s1]].to(torch.int32)
+        key = pat.to(i64) * 65536 + rank[j1[s0:s1]].to(i64)
         skey, order = torch.sort(key, dim=1)
-        order_rows[s0:s1] = order.to(torch.uint8)
-        spat = skey >> 8
+        order_rows[s0:s1] = order.to(hdt)
+        spat = skey >> 16
         flag = torch.ones_like(spat, dtype=torch.bool)
         flag[:, 1:] = spat[:, 1:] != spat[:, :-1]
         rr, cc = torch.nonzero(flag, as_tuple=True)             # row-major: groups of a row are consecutive

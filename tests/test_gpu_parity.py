@@ -2673,9 +2673,11 @@ def test_pangenome_stream_true_bwt_beyond_32_bits(layout):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    # (the run-indexed leg samples its reads and checks its properties from the pangenome's STRUCTURE, as the n = 3e11 run of
+    #  profiles/r04_pangenome_stream_r1e9.json has to: rbg_sample_reads_pangenome_dev, pangenome_bwt.TextView)
     p = subprocess.run([sys.executable, os.path.join(root, "tools", "pangenome_stream.py"), "--L", "44000000", "--H", "100",
                         "--total-reads", "20000000", "--reads", "5000000", "--check-reads", "5000", "--property-reads", "100000",
-                        "--layout", layout, "--gpus", "1"],
+                        "--layout", layout, "--gpus", "1", "--implicit-text", "on" if layout == "runs" else "off"],
                        capture_output=True, timeout=1200, cwd=root)
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     d = json.loads(p.stdout.decode().strip().splitlines()[-1])
@@ -2691,4 +2693,35 @@ def test_pangenome_stream_true_bwt_beyond_32_bits(layout):
                                   "occ_equals_range_width", "own_position_reported"))
     c = d["counters"]
     assert c["reads"] == 20_000_000 and c["sum_occ"] == c["sum_locs"] > 500_000_000
+    if layout == "runs":
+        li = ix["layout_info"]
+        assert li["run_fmt"] == 2 and li["depths_dropped_budget"] == 0 and li["depths_dropped_limit"] == 0 and li["phi_directory"] == 1 and li["rank_directories"] == 1
     print(f"n = {ix['n']:.3e}, {layout}: {d['value']:.3e} reads/s streamed, {ix['hbm_bytes'] / 1e9:.1f} GB replica")
+
+
+@pytest.mark.gpu
+def test_reads_sampled_from_the_structure_equal_reads_sampled_from_the_text():
+    """rbg_sample_reads_pangenome_dev (reads from base sequence + sites + allele matrix) == rbg_sample_reads_dev (reads from the
+    materialised text), byte for byte and start for start, for the same seed -- so the n = 3e11 stream, whose text fits no
+    GPU, streams the reads the smaller runs stream.  More than 255 haplotypes as well (16-bit haplotype ranks in the builder)."""
+    import torch
+    from rowbowt_amd.tools import pangenome_bwt as pb
+    dev = torch.device("cuda", 0)
+    Lb = ra.lib()
+    for L, H, rate, m in ((20000, 7, 0.03, 150), (5000, 300, 0.05, 100), (4000, 3, 0.0, 64)):
+        pg = pb.make_pangenome(L, H, rate, 5, dev)
+        text = pb.materialize_text(pg)
+        tv = pb.TextView(pg)
+        N = 20000
+        a, b = (torch.zeros(N * m + 32, dtype=torch.uint8, device=dev) for _ in range(2))
+        oa, ob = (torch.empty(N + 1, dtype=torch.int64, device=dev) for _ in range(2))
+        sa, sb = (torch.empty(N, dtype=torch.int64, device=dev) for _ in range(2))
+        st = torch.cuda.current_stream().cuda_stream
+        assert Lb.rbg_sample_reads_dev(text.data_ptr(), pg["unit"], H, L, m, 77, 12345, N, 200000, a.data_ptr(), oa.data_ptr(), sa.data_ptr(), st) == 0
+        assert Lb.rbg_sample_reads_pangenome_dev(tv.base_b.data_ptr(), tv.sites.data_ptr() if tv.S else None, tv.alt_b.data_ptr() if tv.S else None,
+                                                 tv.G.data_ptr() if tv.S else None, tv.S, pg["unit"], H, L, m, 77, 12345, N, 200000, b.data_ptr(), ob.data_ptr(),
+                                                 sb.data_ptr(), st) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(a, b) and torch.equal(oa, ob) and torch.equal(sa, sb)
+        pos = torch.randint(0, pg["n"], (100000,), device=dev)
+        assert torch.equal(tv.at(pos), text[pos])

@@ -10,7 +10,8 @@ from rowbowt_amd.tools import synth_pangenome as sp
 
 
 @pytest.mark.parametrize("L,H,rate,seed", [(400, 2, 0.02, 1), (1500, 5, 0.05, 2), (3000, 9, 0.01, 3), (2500, 17, 0.10, 4),
-                                           (20000, 12, 0.03, 5), (600, 3, 0.0, 6), (5000, 40, 0.2, 7)])
+                                           (20000, 12, 0.03, 5), (600, 3, 0.0, 6), (5000, 40, 0.2, 7),
+                                           (300, 300, 0.03, 31), (1000, 400, 0.01, 32)])   # (more than 255 haplotypes: 16-bit ranks)
 def test_matches_true_suffix_array(L, H, rate, seed):
     dev = torch.device("cpu")
     pg = pb.make_pangenome(L, H, rate, seed, dev)
@@ -49,3 +50,14 @@ def test_identical_haplotypes_and_midsize(L, H, rate, seed):
     assert got["r"] == want["r"]
     for k in ("heads", "lens", "ssa", "esa"):
         assert np.array_equal(got[k], want[k]), k
+
+
+def test_implicit_text_view_equals_the_text():
+    """TextView answers text[pos] from the pangenome's structure (the n = 3e11 text of the north-star run is never
+    materialised): every position of a small text, and the layout's special places"""
+    pg = pb.make_pangenome(1500, 7, 0.04, 41, torch.device("cpu"))
+    text = pb.materialize_text(pg)
+    tv = pb.TextView(pg)
+    pos = torch.arange(pg["n"], dtype=torch.int64)
+    assert torch.equal(tv.at(pos), text)
+    assert int(tv.at(torch.tensor([pg["n"] - 1]))[0]) == 1

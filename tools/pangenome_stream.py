@@ -47,6 +47,10 @@ def main():
     ap.add_argument("--hbm-reserve-gb", type=float, default=45.0,
                     help="HBM left to this tool's own buffers (reads, ranges, locations, sort workspace): the index replica gets the rest of "
                          "what is free once the text is resident (0 = the library's default budget, three quarters of the free HBM)")
+    ap.add_argument("--implicit-text", choices=("auto", "on", "off"), default="auto",
+                    help="sample the reads (and check the properties) from the pangenome's STRUCTURE instead of its text (rbg_sample_reads_pangenome_dev, "
+                         "pangenome_bwt.TextView): the same reads byte for byte; auto = when the text would not fit (n > 1e11)")
+    ap.add_argument("--out-json", default="", help="also write the JSON line to this file")
     ap.add_argument("--gpus", type=int, default=1,
                     help="GPUs of this node = ranks; N > 1 without RANK in the environment starts the N ranks itself (rowbowt_amd/launch.py)")
     ap.add_argument("--launch-check", action="store_true", help="start the ranks, print what each was given, touch no GPU")
@@ -102,7 +106,14 @@ def main():
     inp = pb.build_runs(pg, log=log)
     t_build = time.time() - t0
     log(f"pangenome: L={args.L} H={args.H} sites={pg['n_sites']} n={inp['n']} r={inp['r']} n/r={inp['n'] / inp['r']:.1f} (runs in {t_build:.1f}s)")
-    text = pb.materialize_text(pg)
+    implicit = args.implicit_text == "on" or (args.implicit_text == "auto" and pg["n"] > 100_000_000_000)
+    tv = pb.TextView(pg)
+    text = None if implicit else pb.materialize_text(pg)
+    if implicit and args.verify_sa:
+        raise SystemExit("--verify-sa needs the text")
+
+    def text_at(pos):
+        return tv.at(pos) if implicit else text[pos]
     if args.verify_sa:
         from rowbowt_amd.tools import synth_pangenome as sp
         want = sp.index_inputs(text, sp.suffix_array(text))
@@ -112,6 +123,8 @@ def main():
             raise SystemExit("structured BWT builder disagrees with the suffix array")
     unit, H, L, n = pg["unit"], pg["H"], pg["L"], pg["n"]
     del pg
+    if not implicit:
+        tv = None
     torch.cuda.empty_cache()
     if args.ftab_k >= 0:
         capi.set_default_option(capi.OPT_FTAB_K, args.ftab_k)
@@ -149,9 +162,14 @@ def main():
         if rc != 0:
             raise RuntimeError(f"{what} failed: {Lb.rbg_strerror(rc).decode()}")
 
-    def gen(first, cnt):
-        chk(Lb.rbg_sample_reads_dev(text.data_ptr(), unit, H, L, m, args.seed + 2, first, cnt, args.sub_ppm, d_seqs.data_ptr(),
-                                    d_off.data_ptr(), None, st), "sample_reads")
+    def gen(first, cnt, start_out=None):
+        so = start_out.data_ptr() if start_out is not None else None
+        if implicit:
+            chk(Lb.rbg_sample_reads_pangenome_dev(tv.base_b.data_ptr(), tv.sites.data_ptr(), tv.alt_b.data_ptr(), tv.G.data_ptr(), tv.S, unit, H, L, m,
+                                                  args.seed + 2, first, cnt, args.sub_ppm, d_seqs.data_ptr(), d_off.data_ptr(), so, st), "sample_reads_pangenome")
+        else:
+            chk(Lb.rbg_sample_reads_dev(text.data_ptr(), unit, H, L, m, args.seed + 2, first, cnt, args.sub_ppm, d_seqs.data_ptr(),
+                                        d_off.data_ptr(), so, st), "sample_reads")
 
     def search(cnt):
         if args.count_only:
@@ -265,15 +283,14 @@ def main():
     if rank == 0 and (args.property_reads > 0 or args.check_reads > 0):
         npr = min(max(args.property_reads, args.check_reads), N)
         d_start = torch.empty(npr, dtype=torch.int64, device=dev)
-        chk(Lb.rbg_sample_reads_dev(text.data_ptr(), unit, H, L, m, args.seed + 2, gb, npr, args.sub_ppm, d_seqs.data_ptr(), d_off.data_ptr(),
-                                    d_start.data_ptr(), st), "sample_reads")
+        gen(gb, npr, d_start)
         search(npr)
         total = 0 if args.count_only else locate(npr)
         torch.cuda.synchronize()
         reads = d_seqs[:npr * m].view(npr, m)
         lo_t, hi_t = d_lo[:npr], d_hi[:npr]
         # an unmutated read must be found, and its own text position must be inside its match set
-        same_as_text = (text[(d_start[:, None] + torch.arange(m, device=dev)[None, :])] == reads).all(dim=1)
+        same_as_text = (text_at(d_start[:, None] + torch.arange(m, device=dev)[None, :]) == reads).all(dim=1)
         ok_found = bool((hi_t >= lo_t)[same_as_text].all().item())
         ok_empty = bool(((hi_t >= lo_t) | ((lo_t == 1) & (hi_t == 0))).all().item())
         props = {"reads": npr, "unmutated_reads_all_found": ok_found, "empty_is_{1,0}": ok_empty, "unmutated": int(same_as_text.sum().item())}
@@ -285,7 +302,7 @@ def main():
             locs_t = d_locs[:total]
             bad = torch.zeros(total, dtype=torch.bool, device=dev)
             for j in range(m):
-                bad |= text[locs_t + j] != reads[ridx, j]
+                bad |= text_at(locs_t + j) != reads[ridx, j]
             ok_match = not bool(bad.any().item())
             key = ridx * (int(n) + 1) + locs_t
             ok_distinct = int(torch.unique(key).numel()) == total
@@ -335,7 +352,18 @@ def main():
                 print(json.dumps(out))
                 raise SystemExit("PARITY FAILURE: HIP path disagrees with the oracle")
     if rank == 0:
+        li = rb.layout_info()
+        out["config"]["index"]["layout_info"] = {"run_fmt": int(li.run_fmt), "depth_mask_kept": int(li.depth_mask_kept), "depths_dropped_budget": int(li.depths_dropped_budget),
+                                                 "depths_dropped_limit": int(li.depths_dropped_limit), "rank_directories": int(li.rank_directories),
+                                                 "phi_directory": int(li.phi_directory), "phi_directory_dropped": int(li.phi_directory_dropped),
+                                                 "entries": [int(x) for x in li.entries], "fillers": [int(x) for x in li.fillers], "dir_bytes": [int(x) for x in li.dir_bytes],
+                                                 "phi_entries": int(li.phi_entries), "phi_fillers": int(li.phi_fillers), "phi_dir_bytes": int(li.phi_dir_bytes),
+                                                 "phi_dir_shift": int(li.phi_dir_shift)}
+        out["config"]["index"]["text"] = "implicit (sampled from the pangenome's structure)" if implicit else "materialised in HBM"
         print(json.dumps(out), flush=True)
+        if args.out_json:
+            with open(args.out_json, "w") as f:
+                f.write(json.dumps(out) + "\n")
     rb.close()
     if use_dist:
         dist.barrier()
