@@ -82,6 +82,10 @@ def parse():
                     help="bytes per rank slot (RBG_OPT_SLOT_BYTES): 16, or 64 = the 64-byte slots of DESIGN.md 4 r03; 0 = the library's default")
     ap.add_argument("--pos-bytes", type=int, default=0, choices=(0, 4, 8), help="force the position width of the HBM layout (RBG_OPT_POS_BYTES); 0 = by n")
     ap.add_argument("--layout", default="auto", choices=("auto", "slots", "runs"), help="RBG_OPT_RANK_LAYOUT of the headline replica")
+    ap.add_argument("--hbm-budget-gb", type=float, default=-1.0,
+                    help="RBG_OPT_HBM_BUDGET_MB of the headline replica: -1 (default) = three quarters of the HBM that is free at load -- the headline is the "
+                         "FASTEST point of the space/speed curve, bought with 218 GB; 0 = the library's own default (a quarter of the free HBM: what a drop-in "
+                         "caller gets, reported beside the headline as value_library_default and in space_speed)")
     ap.add_argument("--rehearse-ranks", action="store_true",
                     help="test mode, never a measurement: the N ranks of --gpus share the GPUs that exist (rank % devices) and meet over gloo, so that "
                          "the multi-rank path -- launcher, index built once and read from the cache file by every rank, barriers, max-over-ranks "
@@ -169,6 +173,13 @@ def main():
             _c.set_default_option(_c.OPT_RANK_LAYOUT, _c.LAYOUT_RUNS if args.layout == "runs" else _c.LAYOUT_SLOTS)
     m = args.read_len
     max_hits = MAXU if args.max_hits < 0 else args.max_hits
+    from rowbowt_amd import capi as _cb
+    if args.hbm_budget_gb < 0:
+        free_b, _tot = torch.cuda.mem_get_info(dev)
+        budget_mb = int(free_b * 3 // 4) >> 20
+    else:
+        budget_mb = int(args.hbm_budget_gb * 1e9) >> 20
+    _cb.set_default_option(_cb.OPT_HBM_BUDGET_MB, budget_mb)
 
     # ---- synthesis (outside the timed region) --------------------------------------------------
     t0 = time.time()
@@ -610,7 +621,9 @@ def main():
                 "index": {"L": args.L, "H": args.H, "n": int(inp["n"]), "r": int(inp["r"]), "site_rate": args.site_rate,
                           "hbm_bytes": int(ix.hbm_bytes), "pos_bytes": int(ix.pos_bytes), "seed": args.seed,
                           "slot_bytes": slot_b, "symbols_per_gather": int(ix.kmer_steps), "symbols_per_gather_requested": int(ix.kmer_steps_requested),
-                          "hbm_free_at_load": int(ix.hbm_free_at_load), "hbm_budget": int(ix.hbm_budget), "ftab_k": int(ix.ftab_k), "pair_runs": int(ix.pair_runs), "triple_runs": int(ix.triple_runs), "quad_runs": int(ix.quad_runs), "quint_runs": int(ix.quint_runs)},
+                          "hbm_free_at_load": int(ix.hbm_free_at_load), "hbm_budget": int(ix.hbm_budget),
+                          "hbm_budget_source": ("bench.py --hbm-budget-gb -1: three quarters of the free HBM, the fastest point of space_speed" if args.hbm_budget_gb < 0
+                                                else "the library's default (a quarter of the free HBM)" if args.hbm_budget_gb == 0 else f"--hbm-budget-gb {args.hbm_budget_gb}"), "ftab_k": int(ix.ftab_k), "pair_runs": int(ix.pair_runs), "triple_runs": int(ix.triple_runs), "quad_runs": int(ix.quad_runs), "quint_runs": int(ix.quint_runs)},
                 "reads_per_gpu": N, "read_len": m, "substituted_fraction": 0.1,
                 "parallelism": f"index replicated x{world}, reads sharded, no data-path collective",
                 **({"rehearsal": f"NOT A MEASUREMENT: {world} ranks on {torch.cuda.device_count()} GPU(s), collectives over gloo (--rehearse-ranks)"}
@@ -841,7 +854,23 @@ def main():
                 res[name] = min(e[t].elapsed_time(e[t + 1]) for t in range(3))
             return res
 
-        rows = [{"layout": "slots", "symbols_per_gather": int(ix.kmer_steps), "hbm_bytes": int(ix.hbm_bytes), "ms": time_search()}]
+        def time_locate(ms):
+            """K3 of the replica in `rb` on this batch (after its own K2, plan and order), and the end-to-end rate of the four launches"""
+            k_toehold(); k_plan(); k_order()
+            best = None
+            for _ in range(3):
+                e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+                e[0].record(stream)
+                k_fill()
+                e[1].record(stream)
+                torch.cuda.synchronize()
+                t = e[0].elapsed_time(e[1])
+                best = t if best is None else min(best, t)
+            ms["k_locate_fill"] = best
+            return N / ((ms["k_find_range<toehold>"] + best + ms_plan + ms_order) * 1e-3)
+
+        ms0 = time_search()
+        rows = [{"layout": "slots", "symbols_per_gather": int(ix.kmer_steps), "hbm_bytes": int(ix.hbm_bytes), "ms": ms0, "count_locate_reads_per_s": time_locate(ms0)}]
         top = int(ix.kmer_steps)
         # reference outputs of the whole batch from the slot tables (oracle-checked above on a sample), for the run-indexed row
         step()
@@ -853,7 +882,9 @@ def main():
             torch.cuda.empty_cache()
             with capi.default_option(capi.OPT_KMER_STEPS, lvl):   # the caller's own setting is put back afterwards
                 rb = ra.RowBowt.from_runs(inp["heads"], inp["lens"], inp["ssa"], inp["esa"], device=local_rank)
-            rows.append({"layout": "slots", "symbols_per_gather": int(rb.info().kmer_steps), "hbm_bytes": int(rb.info().hbm_bytes), "ms": time_search()})
+            ms_l = time_search()
+            rows.append({"layout": "slots", "symbols_per_gather": int(rb.info().kmer_steps), "hbm_bytes": int(rb.info().hbm_bytes), "ms": ms_l,
+                         "count_locate_reads_per_s": time_locate(ms_l)})
         # the run-indexed layout (space proportional to r; wave-cooperative predecessor search): same batch, same outputs
         rb.close()
         torch.cuda.empty_cache()
@@ -863,13 +894,8 @@ def main():
             rb = ra.RowBowt.from_runs(inp["heads"], inp["lens"], inp["ssa"], inp["esa"], device=local_rank)
         ms_r = time_search()
         step()
-        e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-        k_toehold(); k_plan(); k_order()
-        e[0].record(stream)
-        k_fill()
-        e[1].record(stream)
-        torch.cuda.synchronize()
-        ms_r["k_locate_fill"] = e[0].elapsed_time(e[1])
+        rate_r = time_locate(ms_r)
+        run_fmt = int(rb.layout_info().run_fmt)
         # bytes of the run-indexed kernels AS RUN (instrumented instantiations; sums as include/rbg.h lists them for this
         # layout): per read its offsets + outputs + read chunks + ftab entry; per directory gather 8; per run-list entry a
         # probe needed 2P; per narrowing round 16 pivot keys of P; per materialised re-sample P.  K3: per read 28, per phi
@@ -884,12 +910,22 @@ def main():
         rs_loc = dict(zip(("phi_steps", "probe_entries", "chains", "locs"), d_stats.cpu().numpy().tolist()[:4]))
         rb.counters_reset()
 
+        # format 2 (rbg_runs2_device.hpp; the default since round 4): a directory gather is two neighbouring entries of 4 bytes (8 at 8-byte
+        # positions: count + the rank's high part), a run-list entry 8 bytes at either width, a narrowing round seven 4-byte pivots, a sample 4 / 6
+        # bytes; a phi step reads two 4-byte counts (+ one 8-byte super count at 8-byte positions) and entries of 8 / 12 bytes.
+        if run_fmt == 2:
+            b_dir, b_ent, b_narrow, b_samp = (8 if Pr == 4 else 16), 8, 28, (4 if Pr == 4 else 6)
+            b_phi_dir, b_phi_ent = (8 if Pr == 4 else 16), (8 if Pr == 4 else 12)
+        else:
+            b_dir, b_ent, b_narrow, b_samp = 8, 2 * Pr, 16 * Pr, Pr
+            b_phi_dir, b_phi_ent = 8, 2 * Pr
+
         def run_search_bytes(sv, toehold):
-            return (N * (16 + (24 if toehold else 16)) + 16 * sv["read_chunks"] + (16 if Pr == 4 else 32) * sv["ftab"] + 8 * sv["slots"]
-                    + 2 * Pr * sv["dense"] + 16 * Pr * sv["searched_ranks"] + Pr * sv["resamples"])
+            return (N * (16 + (24 if toehold else 16)) + 16 * sv["read_chunks"] + (16 if Pr == 4 else 32) * sv["ftab"] + b_dir * sv["slots"]
+                    + b_ent * sv["dense"] + b_narrow * sv["searched_ranks"] + b_samp * sv["resamples"])
 
         run_alg = {"k_find_range<count>": run_search_bytes(rs_count, False), "k_find_range<toehold>": run_search_bytes(rs_toe, True),
-                   "k_locate_fill": N * 28 + 8 * rs_loc["phi_steps"] + 2 * Pr * rs_loc["probe_entries"] + 8 * rs_loc["locs"]}
+                   "k_locate_fill": N * 28 + b_phi_dir * rs_loc["phi_steps"] + b_phi_ent * rs_loc["probe_entries"] + 8 * rs_loc["locs"]}
         run_roof = {kk: {"alg_bytes": v, "alg_GBps": v / (ms_r[kk] * 1e-3) / 1e9, "frac_of_hbm_peak": v / (ms_r[kk] * 1e-3) / 1e9 / HBM_PEAK_GBS}
                     for kk, v in run_alg.items()}
         run_touched = {"per_read": {"search_steps": rs_toe["steps"] / N, "directory_gathers": rs_toe["slots"] / N, "run_list_entries_probed": rs_toe["dense"] / N,
@@ -898,8 +934,8 @@ def main():
                        "search": rs_toe, "locate": rs_loc}
         same = all(bool((a == b).all().item()) for a, b in zip(ref_out, (d_lo, d_hi, d_k, d_loc_off))) and bool((ref_locs == d_locs[:total_locs]).all().item())
         rows.append({"layout": "runs", "depths": [1, 2, 3, 4, 5][:int(rb.info().kmer_steps)], "symbols_per_gather": int(rb.info().kmer_steps), "hbm_bytes": int(rb.info().hbm_bytes), "ms": ms_r,
-                     "identical_to_slot_path_on_the_whole_batch": same, "roofline": run_roof, "touched": run_touched,
-                     "count_locate_reads_per_s": N / ((ms_r["k_find_range<toehold>"] + ms_r["k_locate_fill"] + ms_plan + ms_order) * 1e-3)})
+                     "identical_to_slot_path_on_the_whole_batch": same, "roofline": run_roof, "touched": run_touched, "run_fmt": run_fmt,
+                     "count_locate_reads_per_s": rate_r})
         if args.markers:
             # the kernels beside the rb_align path on this layout (cooperative since round 3: k_runs_seeds.hip), same batch
             rb.set_markers(*marker_arrays)
@@ -928,17 +964,12 @@ def main():
                 rb = ra.RowBowt.from_runs(inp["heads"], inp["lens"], inp["ssa"], inp["esa"], device=local_rank)
             ms_d = time_search()
             step()
-            e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-            k_toehold(); k_plan(); k_order()
-            e[0].record(stream)
-            k_fill()
-            e[1].record(stream)
-            torch.cuda.synchronize()
-            ms_d["k_locate_fill"] = e[0].elapsed_time(e[1])
+            rate_d = time_locate(ms_d)
+            step()
             same_d = all(bool((a == b).all().item()) for a, b in zip(ref_out, (d_lo, d_hi, d_k, d_loc_off))) and bool((ref_locs == d_locs[:total_locs]).all().item())
             row = {"layout": "runs", "depths": [d + 1 for d in range(5) if depth_mask >> d & 1], "symbols_per_gather": int(rb.info().kmer_steps),
                    "hbm_bytes": int(rb.info().hbm_bytes), "ms": ms_d, "identical_to_slot_path_on_the_whole_batch": same_d,
-                   "count_locate_reads_per_s": N / ((ms_d["k_find_range<toehold>"] + ms_d["k_locate_fill"] + ms_plan + ms_order) * 1e-3)}
+                   "count_locate_reads_per_s": rate_d}
             if args.markers:
                 rb.set_markers(*marker_arrays)
                 gstep()
@@ -962,6 +993,13 @@ def main():
             print(json.dumps(out))
             raise SystemExit("PARITY FAILURE: the run-indexed layout disagrees with the slot tables")
         del ref_out, ref_locs
+        # what the headline costs: the best count+locate rate among the replicas of at most 64 GB, and the rate of the replica a DEFAULT
+        # rbg_load builds (budget = a quarter of the free HBM: the deepest slot level that fits it)
+        within = [r_ for r_ in rows if r_["hbm_bytes"] <= 64e9]
+        out["value_at_64GB"] = max((r_["count_locate_reads_per_s"] for r_ in within), default=None)
+        dflt = [r_ for r_ in rows if r_["layout"] == "slots" and r_["hbm_bytes"] <= int(ix.hbm_free_at_load) // 4]
+        out["value_library_default"] = ({"value": dflt[0]["count_locate_reads_per_s"], "hbm_bytes": dflt[0]["hbm_bytes"], "symbols_per_gather": dflt[0]["symbols_per_gather"],
+                                         "budget": "a quarter of the HBM free at load (rbg_load without RBG_OPT_HBM_BUDGET_MB)"} if dflt else None)
         out["space_speed"] = {"unit": "ms per launch of this run's batch (best of 3)", "rows": rows,
                               "note": "RBG_OPT_KMER_STEPS / the HBM budget rule pick the row; rbg_info reports which (symbols_per_gather, "
                                       "hbm_free_at_load, hbm_budget)"}

@@ -144,7 +144,7 @@ typedef struct rbg_info_t {
     uint64_t quint_runs;    /* total runs of the 5-mer tables (kmer_steps == 5) */
     /* ABI 2: how the space/speed point was chosen at load (the same call is up to 4x slower with fewer levels,
      * DESIGN.md 2b): the depth asked for (RBG_OPT_KMER_STEPS), the free HBM seen at load, the budget the replica had
-     * to fit (three quarters of it, or RBG_OPT_HBM_BUDGET_MB); kmer_steps above is what was kept.  Also printed on
+     * to fit (a quarter of it, or RBG_OPT_HBM_BUDGET_MB); kmer_steps above is what was kept.  Also printed on
      * stderr at load when a level is dropped (always with RBG_VERBOSE). */
     uint64_t kmer_steps_requested, hbm_free_at_load, hbm_budget;
     uint64_t rank_layout;   /* RBG_LAYOUT_SLOTS or RBG_LAYOUT_RUNS (what RBG_OPT_RANK_LAYOUT / the budget rule chose) */
@@ -173,6 +173,8 @@ typedef struct rbg_layout_info_t {
     uint64_t fillers[5];              /* per depth: filler entries among them (format 2, 8-byte positions; 0 unless a table has a gap >= 2^fill_shift) */
     uint64_t dir_bytes[5];            /* per depth: bytes of its tables' directories */
     uint64_t phi_entries, phi_fillers, phi_dir_bytes, phi_dir_shift;
+    uint64_t phi_slots, phi_slot_bytes; /* format 2 with phi SLOTS (RBG_OPT_RUN_PHI): their number (buckets of 2^phi_dir_shift text positions) and the
+                                         * bytes of slots + ordinals; 0 = phi goes through the list of sampled positions and its directory */
 } rbg_layout_info_t;
 int rbg_layout_info(const rbg_index *, rbg_layout_info_t *out, uint64_t out_bytes);
 
@@ -458,10 +460,13 @@ int rbg_sample_reads_dev(const uint8_t *d_text, uint64_t unit, uint64_t H, uint6
                          uint64_t *d_start /* nullable */, void *stream);
 /* The same reads (byte for byte, for the same seed) from the STRUCTURE of such a text instead of the text: a pangenome of
  * n = 3e11 symbols does not fit the HBM it would be sampled from.  Symbol (h, p) is d_base[p] (L bytes), or d_alt[j] when p
- * is variant site j (d_sites: S ascending offsets) and haplotype h carries the alternative allele (d_G[j * H + h] != 0). */
+ * is variant site j (d_sites: S ascending offsets) and haplotype h carries the alternative allele (d_G[j * H + h] != 0).
+ * d_site_dir (nullable): d_site_dir[b] = # sites below b << site_dir_shift, (L >> site_dir_shift) + 2 entries (S < 2^32): the first
+ * site of a read is then found in its bucket instead of by a search over all sites. */
 int rbg_sample_reads_pangenome_dev(const uint8_t *d_base, const uint64_t *d_sites, const uint8_t *d_alt, const uint8_t *d_G, uint64_t S,
-                                   uint64_t unit, uint64_t H, uint64_t L, uint64_t m, uint64_t seed, uint64_t first_read, uint64_t N,
-                                   uint32_t sub_ppm, uint8_t *d_seqs, uint64_t *d_off, uint64_t *d_start /* nullable */, void *stream);
+                                   const uint32_t *d_site_dir, uint32_t site_dir_shift, uint64_t unit, uint64_t H, uint64_t L, uint64_t m,
+                                   uint64_t seed, uint64_t first_read, uint64_t N, uint32_t sub_ppm, uint8_t *d_seqs, uint64_t *d_off,
+                                   uint64_t *d_start /* nullable */, void *stream);
 
 /* ---- tuning (never changes results) -------------------------------------------------------- */
 /* Process-wide defaults read when an index is built/loaded: BLOCK_THREADS (64, 128, 192 or 256; the search
@@ -471,7 +476,7 @@ int rbg_sample_reads_pangenome_dev(const uint8_t *d_base, const uint64_t *d_site
  * KMER_STEPS (1..5, default 5: symbols the backward search consumes per gather; 2..5 build the k-mer
  * tables of DESIGN.md 2b -- each level is four times the tables of the one before, 218 GB in all for a
  * 2-Gbase index; 1 keeps the reference's one-symbol steps only; the deepest levels are dropped
- * automatically when the replica would not fit), HBM_BUDGET_MB (0 = three quarters of the free HBM:
+ * automatically when the replica would not fit), HBM_BUDGET_MB (0 = A QUARTER of the free HBM -- three quarters until round 3; a drop-in library leaves the device to its caller unless told otherwise:
  * upper bound for the replica, deciding how many k-mer levels are kept), FTAB_K (-1 = automatic (the longest word of at most 12 symbols with 4^k <= n/16),
  * 0 = no ftab, else the word length of the ftab built on the GPU at load time: the state after the
  * last FTAB_K symbols of a read is one gather; result-neutral like the reference's ftab,
@@ -522,7 +527,13 @@ enum { RBG_OPT_BLOCK_THREADS = 1, RBG_OPT_RANK_BUCKET_SHIFT = 2, RBG_OPT_PHI_BUC
                                   sparse_sd_vector.hpp:110-163; entry indices are 64-bit, nothing is left out for its size);
                                   1 = rounds 2-3: {P, P} pairs probed by quads of lanes (kept for A/B measurements and for the
                                   options that build an index without directories).  RBG_RUN_FMT gives the initial value.
-                                  rbg_layout_info() says what was built. */ };
+                                  rbg_layout_info() says what was built. */,
+       RBG_OPT_RUN_PHI = 16 /* run-indexed layout, format 2 -- how phi (toehold_sa.hpp:56-72) is answered: 1 = from the list of sampled positions
+                                  through its directory (12-16 bytes per run: two dependent sectors per step); 2 = from direct-addressed phi SLOTS
+                                  (the slot layout's PhiSlot records) whose buckets are about n / r rows wide, so that their number is proportional
+                                  to r (about 54 bytes per run at 8-byte positions: one sector per step -- at pangenome scale K3 is bound by that
+                                  count); 0 (default) = slots when the whole replica then stays within half the HBM budget.  RBG_RUN_PHI gives the
+                                  initial value; rbg_layout_info().phi_slots says what was built. */ };
 int rbg_set_default_option(int opt, int64_t value);
 /* the value a later load would use (so that a caller can change a knob for one load and put it back) */
 int rbg_get_default_option(int opt, int64_t *value);

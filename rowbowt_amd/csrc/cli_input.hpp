@@ -110,6 +110,7 @@ class InputSource {
                     if (bsz < 12 + xlen + 8 || bsz > map_size_ - pos_) { stream_error_ = true; break; }
                     const unsigned char *t = h + bsz - 4;
                     const uint64_t isz = t[0] | (static_cast<uint64_t>(t[1]) << 8) | (static_cast<uint64_t>(t[2]) << 16) | (static_cast<uint64_t>(t[3]) << 24);
+                    if (isz > 65536) { stream_error_ = true; break; }   // BGZF blocks hold at most 64 KiB: a crafted ISIZE must not size the buffer
                     blks.push_back(Blk{pos_ + 12 + xlen, bsz - 12 - xlen - 8, total, isz});
                     total += isz;
                     pos_ += bsz;

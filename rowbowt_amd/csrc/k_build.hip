@@ -718,7 +718,8 @@ __global__ __launch_bounds__(256) void k_sample_reads(const uint8_t *__restrict_
 // sampled from): symbol (h, p) of the text is base[p], or alt[j] when p is variant site j and haplotype h carries the
 // alternative allele (G[j * H + h] != 0).  Read g is the same function of (seed, g) as above.
 __global__ __launch_bounds__(256) void k_sample_reads_pg(const uint8_t *__restrict__ base, const uint64_t *__restrict__ sites, const uint8_t *__restrict__ alt,
-                                                         const uint8_t *__restrict__ G, const uint64_t S, const uint64_t unit, const uint64_t H,
+                                                         const uint8_t *__restrict__ G, const uint64_t S, const uint32_t *__restrict__ site_dir,
+                                                         const uint32_t site_dir_shift, const uint64_t unit, const uint64_t H,
                                                          const uint64_t L, const uint64_t m, const uint64_t seed, const uint64_t first,
                                                          const uint64_t N, const uint32_t sub_ppm, uint8_t *__restrict__ seqs,
                                                          uint64_t *__restrict__ off, uint64_t *__restrict__ start_out) {
@@ -732,7 +733,8 @@ __global__ __launch_bounds__(256) void k_sample_reads_pg(const uint8_t *__restri
         const uint64_t h = r0 % H, p0 = r1 % (L - m + 1);
         const bool mutate = (r2 % 1000000ull) < sub_ppm;
         const uint64_t mpos = (r2 >> 32) % m;
-        uint64_t a = 0, z = S;                         // first site at or after p0
+        uint64_t a = 0, z = S;                         // first site at or after p0 (site_dir[b] = # sites below b << shift, when given)
+        if (site_dir) { a = site_dir[p0 >> site_dir_shift]; z = site_dir[(p0 >> site_dir_shift) + 1]; }
         while (a < z) { const uint64_t mid = a + ((z - a) >> 1); if (sites[mid] < p0) a = mid + 1; else z = mid; }
         for (uint64_t j = lane; j < m; j += kWave) {
             uint32_t c = base[p0 + j];
@@ -753,11 +755,13 @@ __global__ __launch_bounds__(256) void k_sample_reads_pg(const uint8_t *__restri
 }
 }  // namespace
 
-int launch_sample_reads_pg(const uint8_t *base, const uint64_t *sites, const uint8_t *alt, const uint8_t *G, uint64_t S, uint64_t unit, uint64_t H, uint64_t L,
-                           uint64_t m, uint64_t seed, uint64_t first, uint64_t N, uint32_t sub_ppm, uint8_t *seqs, uint64_t *off, uint64_t *start_out, void *stream) {
+int launch_sample_reads_pg(const uint8_t *base, const uint64_t *sites, const uint8_t *alt, const uint8_t *G, uint64_t S, const uint32_t *site_dir, uint32_t site_dir_shift,
+                           uint64_t unit, uint64_t H, uint64_t L, uint64_t m, uint64_t seed, uint64_t first, uint64_t N, uint32_t sub_ppm, uint8_t *seqs, uint64_t *off,
+                           uint64_t *start_out, void *stream) {
     if (N == 0) return 0;
     const uint64_t blocks = std::min<uint64_t>((N + 3) / 4, 256ull * 64);
-    hipLaunchKernelGGL(k_sample_reads_pg, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, static_cast<hipStream_t>(stream), base, sites, alt, G, S, unit, H, L, m,
+    hipLaunchKernelGGL(k_sample_reads_pg, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, static_cast<hipStream_t>(stream), base, sites, alt, G, S, site_dir,
+                       site_dir_shift, unit, H, L, m,
                        seed, first, N, sub_ppm, seqs, off, start_out);
     return static_cast<int>(hipGetLastError());
 }

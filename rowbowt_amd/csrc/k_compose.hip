@@ -315,7 +315,8 @@ int bits_for(uint64_t v) { int b = 1; while (b < 64 && (v >> b)) ++b; return b; 
 
 template <typename P>
 int compose_impl(const uint64_t n, const uint32_t M, const ComposeTable *major, const void *g1_start, const uint32_t *g1_id, const void *g1_samp,
-                 const uint64_t g1_n, const uint32_t kmax, const bool with_samples, std::vector<ComposedLevel> &out, hipStream_t st, const uint32_t keep_mask) {
+                 const uint64_t g1_n, const uint32_t kmax, const bool with_samples, std::vector<ComposedLevel> &out, hipStream_t st, const uint32_t keep_mask,
+                 bool *inputs_released) {
     out.clear();
     // the segmentation of the current depth (depth 1: the caller's arrays, not owned)
     const P *g_start = static_cast<const P *>(g1_start);
@@ -432,6 +433,21 @@ int compose_impl(const uint64_t n, const uint32_t M, const ComposeTable *major, 
         }
         const auto t_pieces = now();
         if (last_level) { own_start.release(); own_id.release(); own_samp.release(); }   // (the segmentation is read by the pieces only)
+        // inputs_released != nullptr: the caller hands over its inputs -- the depth-1 segmentation (20 bytes per run) is read by the
+        // first depth's pieces only, the major symbols' own tables (24 bytes per run) by every depth's pieces and no later: 45 GB
+        // at r = 1e9 that the last depth's tables need
+        if (inputs_released && depth == 1) {
+            (void)hipFree(const_cast<void *>(g1_start)); (void)hipFree(const_cast<uint32_t *>(g1_id));
+            if (g1_samp) (void)hipFree(const_cast<void *>(g1_samp));
+            inputs_released[0] = true;
+        }
+        if (inputs_released && last_level) {
+            for (uint32_t m = 0; m < M; ++m) {
+                if (major[m].ent) (void)hipFree(const_cast<void *>(major[m].ent));
+                if (major[m].samp) (void)hipFree(const_cast<void *>(major[m].samp));
+            }
+            inputs_released[1] = true;
+        }
         // ---- tables: stable sort by table, cum by one scan ------------------------------------------------------------------
         Tmp iota, s_tab, perm;
         CK(iota.alloc((np + 1) * 4));
@@ -555,12 +571,14 @@ int compose_impl(const uint64_t n, const uint32_t M, const ComposeTable *major, 
 
 // RBG_* codes: 0 ok, -2 EFORMAT, -3 ENODEV, -4 EARG, -5 ENOMEM (include/rbg.h)
 int compose_levels_device(uint32_t pos_bytes, uint64_t n, uint32_t M, const ComposeTable *major, const void *g_start, const uint32_t *g_id,
-                          const void *g_samp, uint64_t g_n, uint32_t kmax, bool with_samples, std::vector<ComposedLevel> &out, void *stream, uint32_t keep_mask) {
+                          const void *g_samp, uint64_t g_n, uint32_t kmax, bool with_samples, std::vector<ComposedLevel> &out, void *stream, uint32_t keep_mask,
+                          bool *inputs_released) {
+    if (inputs_released) inputs_released[0] = inputs_released[1] = false;
     hipStream_t st = static_cast<hipStream_t>(stream);
     Pool pool;
     struct Scope { Pool *prev; explicit Scope(Pool *p) : prev(t_pool) { t_pool = p; } ~Scope() { t_pool = prev; } } scope(&pool);
-    return pos_bytes == 4 ? compose_impl<uint32_t>(n, M, major, g_start, g_id, g_samp, g_n, kmax, with_samples, out, st, keep_mask)
-                          : compose_impl<uint64_t>(n, M, major, g_start, g_id, g_samp, g_n, kmax, with_samples, out, st, keep_mask);
+    return pos_bytes == 4 ? compose_impl<uint32_t>(n, M, major, g_start, g_id, g_samp, g_n, kmax, with_samples, out, st, keep_mask, inputs_released)
+                          : compose_impl<uint64_t>(n, M, major, g_start, g_id, g_samp, g_n, kmax, with_samples, out, st, keep_mask, inputs_released);
 }
 
 }  // namespace rbg

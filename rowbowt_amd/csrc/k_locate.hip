@@ -288,7 +288,7 @@ int launch_locate_fill(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t 
     // the order workspace also holds the toeholds in sorted order (launch_locate_order's key output)
     const uint64_t *skeys = order ? reinterpret_cast<const uint64_t *>(static_cast<const char *>(order) + order_layout(N).keys) : nullptr;
     const uint32_t *perm = static_cast<const uint32_t *>(order);
-    if (ix.layout == 2) {  // run-indexed layout (k_runs.hip)
+    if (ix.layout == 2 && !ix.phi_slots) {  // run-indexed layout (k_runs.hip); with phi slots (RBG_OPT_RUN_PHI) the slot kernels below answer its phi
         return launch_locate_fill_runs(ix, cfg, lo, hi, k, N, max_hits, loc_off, locs, sub, order, skeys, stream, stats, locs32);
     }
     if (locs32) {   // 4-byte locations (4-byte positions only; the caller checked)

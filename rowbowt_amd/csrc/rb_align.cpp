@@ -305,6 +305,7 @@ void query_batch(const std::vector<rbg_index *> &reps, const RbAlignArgs &args, 
 // stage 2: formatting is split over worker threads, pieces concatenated in read order
 // (`pieces` is a pool that keeps its strings -- and their pages -- from window to window: `used` counts the ones of this
 // window; fresh 12 MB strings per batch cost more in page faults than the formatting itself)
+struct ShardFailure {};   // a replica's call failed (already reported): leave through main()
 void format_batch(const rbwt::RowBowt<> &rb, const RbAlignArgs &args, const Window &b, size_t w0, size_t w1, BatchSlot &slot,
                   std::vector<rbg_cli::TextBuf> &pieces, size_t &used) {
     const size_t N = w1 - w0;
@@ -312,7 +313,9 @@ void format_batch(const rbwt::RowBowt<> &rb, const RbAlignArgs &args, const Wind
     for (int g = 0; g < G; ++g)
         if (slot.err[g].rc) {   // what the single-replica path says, from the main thread, once every worker is done
             fprintf(stderr, "%s (replica %d): %s\n", slot.err[g].what, g, rbg_strerror(slot.err[g].rc));
-            exit(1);
+            // not exit(1) from here: the next batch's query and the chain of text writes may still be running on other
+            // threads, inside library calls and fwrite -- main() unwinds (the futures join), flushes and leaves
+            throw ShardFailure{};
         }
 #define res(g) (*slot.res[(g)])
     const auto t_q1 = std::chrono::steady_clock::now();
@@ -446,6 +449,7 @@ int main(int argc, char **argv) {
     std::vector<rbg_cli::TextBuf> pieces, writing;
     size_t used = 0, writing_used = 0;
     BatchSlot slots[2];
+    try {
     while (true) {
         std::future<int> scanner;
         const bool more = err == 0;
@@ -488,6 +492,12 @@ int main(int argc, char **argv) {
             g_trace_scan_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - ts0).count();
         }
         std::swap(cur, nxt);
+    }
+    } catch (const ShardFailure &) {   // (the loop's futures -- scanner, query ahead -- joined while unwinding)
+        if (writer.valid()) writer.get();
+        if (g_text_writer[1].valid()) g_text_writer[1].wait();
+        fflush(stdout);
+        return 1;
     }
     if (writer.valid()) writer.get();
     {

@@ -70,6 +70,7 @@ struct rbg_index {
         uint32_t depths_dropped_budget = 0;        // mask of depths the HBM budget left out
         uint32_t depths_dropped_limit = 0;         // mask of depths a width limit left out (format 1: 2^32 entries)
         uint32_t phi_dir_dropped = 0;              // 1: format 1 left the phi directory out (2 GiB / r >= 2^31)
+        uint64_t phi_slots = 0, phi_slot_bytes = 0;   // format 2 with phi slots (RBG_OPT_RUN_PHI): their number and bytes (slots + ordinals)
     } runs_report;
     // one-read host calls from concurrent threads are combined into one launch ("group commit", see Combiner below)
     struct Combiner {
@@ -132,11 +133,35 @@ std::atomic<int64_t> g_opt_rank_layout{env_opt("RBG_LAYOUT", RBG_LAYOUT_AUTO, RB
 std::atomic<int64_t> g_opt_tree_top_kb{48};   // LDS the staged top levels of the run-indexed search may take per workgroup
 std::atomic<int64_t> g_opt_run_depths{env_opt("RBG_RUN_DEPTHS", 0, 0, (1 << kMaxRunDepth) - 1)};    // run-indexed layout: bit d - 1 = keep the k-mer depth d (0 = every other depth from the deepest down)
 std::atomic<int64_t> g_opt_run_fmt{env_opt("RBG_RUN_FMT", 2, 1, 2)};   // run-indexed layout: 1 = {P, P} pairs probed by quads of lanes (rounds 2-3), 2 = per-lane probes (rbg_dev.h DevRunTab2)
+std::atomic<int64_t> g_opt_run_phi{env_opt("RBG_RUN_PHI", 0, 0, 2)};   // run-indexed layout, format 2: 0 = automatic, 1 = phi over the sampled-position list (12-16 bytes per run), 2 = phi SLOTS of about n/r rows (about 54 bytes per run at 8-byte positions; one sector per step instead of two)
 std::atomic<int64_t> g_opt_slot_bytes{16};    // 16: RankSlot; 64: RankSlot64 (experiment: rbg_dev.h)
 std::atomic<int64_t> g_opt_packed_reads{1};  // host-pointer calls: 0 bytes over PCIe, 1 (default) 2-bit codes for batches >= 4096, 2 always
 
-// the replica's share of the free HBM when no budget is given (RBG_OPT_HBM_BUDGET_MB)
-inline size_t default_budget(size_t free_b) { return free_b - free_b / 4; }
+// The replica's share of the free HBM when no budget is given (RBG_OPT_HBM_BUDGET_MB): A QUARTER.  Until round 3 a default
+// rbg_load took three quarters -- the bench index then got its 5-symbol slot level (218 GB) for the last 10-15 % of K1/K2's
+// speed and left its caller 80 GB of a 288 GB device.  A drop-in library should leave the device to its caller unless told
+// otherwise: with a quarter the same load keeps the 4-symbol level (58 GB), and the budget option is one call away.
+inline size_t default_budget(size_t free_b) { return free_b / 4; }
+
+// bytes of host memory this process may still take: the smaller of the machine's MemAvailable and what its cgroup (v2) has left
+double host_memory_available() {
+    double avail = 1e18;
+    if (FILE *f = std::fopen("/proc/meminfo", "r")) {
+        char line[256];
+        while (std::fgets(line, sizeof line, f)) {
+            unsigned long long kb = 0;
+            if (std::sscanf(line, "MemAvailable: %llu kB", &kb) == 1) { avail = static_cast<double>(kb) * 1024.0; break; }
+        }
+        std::fclose(f);
+    }
+    unsigned long long mx = 0, cur = 0;
+    bool have_mx = false, have_cur = false;
+    if (FILE *f = std::fopen("/sys/fs/cgroup/memory.max", "r")) { have_mx = std::fscanf(f, "%llu", &mx) == 1; std::fclose(f); }
+    if (FILE *f = std::fopen("/sys/fs/cgroup/memory.current", "r")) { have_cur = std::fscanf(f, "%llu", &cur) == 1; std::fclose(f); }
+    if (have_mx && have_cur && mx > cur) avail = std::min(avail, static_cast<double>(mx - cur));
+    else if (have_mx && have_cur) avail = 0;
+    return avail;
+}
 
 #define HIP_TRY(expr)                                                                             \
     do {                                                                                          \
@@ -1364,7 +1389,54 @@ int upload_tables_runs2(rbg_index *ix) {
     ix->dev.phi_dir = nullptr;
     ix->dev.phi_super = nullptr;
     ix->dev.phi_super_shift = 0;
+    // PHI SLOTS on this layout (RBG_OPT_RUN_PHI = 2; automatic when the whole replica then stays within half the budget): the slot
+    // layout's direct-addressed phi records (rbg_dev.h PhiSlot) with buckets of about n / r rows instead of 32-64 -- so their
+    // number is proportional to r, not n -- answer a phi step from ONE sector where the list takes two (directory, entries); at
+    // pangenome scale K3 is bound by exactly that sector count.  Cost: about 54 bytes per run at 8-byte positions against 16.
+    bool phi_by_slots = false;
+    uint32_t slot_shift = 0;
     if (h.has_tsa) {
+        const double rows_per_sample = static_cast<double>(h.n) / static_cast<double>(std::max<uint64_t>(1, h.r));
+        while (slot_shift < 8 && static_cast<double>(uint64_t(2) << slot_shift) <= rows_per_sample) ++slot_shift;   // the widest bucket with at most one sampled position on average
+        if (slot_shift < h.phi_shift) slot_shift = h.phi_shift;
+        const bool packed = sizeof(P) == 8 && (h.n >> kPhiPackedPosBits) == 0 && slot_shift <= kPhiPackedMaxShift;
+        const size_t slot_b = packed ? sizeof(PhiSlotPacked) : sizeof(PhiSlot<P>);
+        const size_t need = ((h.n >> slot_shift) + 2) * (slot_b + 4) + (h.r + 1) * sizeof(PhiEnt<P>);
+        const int64_t mode = g_opt_run_phi.load();
+        // automatic: only while the slots are O(r) -- at most two buckets per sampled position (the bucket shift stops at 8: an index with
+        // n / r far beyond 256 would get n / 256 of them) -- and the whole replica stays within half the budget
+        phi_by_slots = mode == 2 || (mode == 0 && ix->hbm_budget && ((h.n >> slot_shift) + 2) <= 2 * h.r && ix->hbm_bytes + need <= ix->hbm_budget / 2);
+        if (phi_by_slots) {
+            VStage vs("phi slots of the run-indexed layout");
+            HostBuf<PhiEnt<P>> pe(h.r + 1);
+            parallel_for(h.r, [&](uint64_t a, uint64_t b, unsigned) {
+                for (uint64_t j = a; j < b; ++j) { pe[j].pos = static_cast<P>(h.pred_pos[j]); pe[j].base = static_cast<P>(h.phi_base[j]); }
+            });
+            pe[h.r].pos = static_cast<P>(h.n); pe[h.r].base = 0;
+            if ((rc = dev_upload(ix, pe.data(), (h.r + 1) * sizeof(PhiEnt<P>), &ix->dev.phi_ent))) return rc;
+            const uint64_t nb = (h.n >> slot_shift) + 2;
+            void *slots = nullptr, *ord = nullptr;
+            if ((rc = dev_reserve(ix, nb * slot_b, &slots)) || (rc = dev_reserve(ix, nb * sizeof(uint32_t), &ord))) return rc;
+            TmpDev ovf;
+            if ((rc = ovf.alloc(8))) return rc;
+            HIP_TRY(hipMemset(ovf.p, 0, 8));
+            ix->dev.phi_packed = packed ? 1 : 0;
+            ix->dev.phi_shift = slot_shift;
+            if (launch_build_phi_slots(sizeof(P), packed, ix->dev.phi_ent, h.r, h.n, slot_shift, slots, static_cast<uint32_t *>(ord), ovf.as<unsigned long long>(), nullptr))
+                return RBG_ENODEV;
+            unsigned long long novf = 0;
+            HIP_TRY(hipMemcpy(&novf, ovf.p, 8, hipMemcpyDeviceToHost));
+            ix->phi_slots = nb;
+            ix->phi_slots_overflow = novf;
+            ix->dev.phi_slots = slots;
+            ix->dev.phi_ord = static_cast<const uint32_t *>(ord);
+            ix->dev.phi_m = h.r;
+            ix->dev.phi_last_pos = h.pred_pos[h.r - 1];
+            ix->dev.phi_last_base = h.phi_base[h.r - 1];
+            rep.phi_entries = h.r; rep.phi_dir = 0; rep.phi_dir_shift = slot_shift; rep.phi_slots = nb; rep.phi_slot_bytes = nb * (slot_b + 4);
+        }
+    }
+    if (h.has_tsa && !phi_by_slots) {
         // sampled positions per directory bucket: between per and 2 * per on average (RBG_PHI_DIR_PER, default 1: the scan's
         // first four requests then cover the bucket and its predecessor nineteen times in twenty)
         const char *e_pp = std::getenv("RBG_PHI_DIR_PER");
@@ -1560,7 +1632,20 @@ int compose_on_device(rbg_index *ix) {
             keep_mask |= 1u << (K - 1);
         }
     }
-    if (!rc) rc = compose_levels_device(sizeof(P), h.n, M, major, g_start, static_cast<const uint32_t *>(g_id), g_samp, h.r, K, h.has_tsa, levels, nullptr, keep_mask);
+    // (with the run-indexed layout certain, the composition also frees its inputs as soon as they have been read: nothing
+    //  after it needs the depth-1 lists in this form -- upload_tables_runs2 builds depth 1 from the host tables)
+    bool released[2] = {false, false};
+    if (!rc) rc = compose_levels_device(sizeof(P), h.n, M, major, g_start, static_cast<const uint32_t *>(g_id), g_samp, h.r, K, h.has_tsa, levels, nullptr, keep_mask,
+                                        keep_mask ? released : nullptr);
+    if (released[0])
+        for (void *&held : hold.p)
+            if (held == g_start || held == g_id || held == g_samp) held = nullptr;
+    if (released[1])
+        for (uint32_t m = 0; m < M; ++m) {
+            for (void *&held : hold.p)
+                if (held == major[m].ent || held == major[m].samp) held = nullptr;
+            major[m].ent = major[m].samp = nullptr;
+        }
     if (rc == RBG_EARG) {   // 2^32 pieces in one depth (r beyond about 1.7e9 at five symbols): the device sweeps index pieces with 32 bits, the host composition does not
         std::fprintf(stderr, "rbg: a k-mer depth has 2^32 pieces or more: the device composition indexes them with 32 bits\n");
         rc = RBG_ENOMEM;
@@ -1568,6 +1653,17 @@ int compose_on_device(rbg_index *ix) {
     if (rc == RBG_ENOMEM || rc == RBG_ENODEV) {   // not enough HBM for the sweeps' temporaries: the host composes instead
         for (ComposedLevel &L : levels) { if (L.ent) (void)hipFree(L.ent); if (L.samp) (void)hipFree(L.samp); }
         (void)hipGetLastError();
+        // the host composition holds every depth as three 8-byte vectors per run: 24 bytes x (about 1.6 + 2.1 + 2.6 + 3.2) runs of the
+        // BWT at pangenome scale -- it must not be what exhausts the machine (a container's memory limit kills the process, and on a
+        // shared box more than that)
+        const double need_host = 24.0 * 3.3 * static_cast<double>(K - 1) * static_cast<double>(h.r);
+        const double have_host = host_memory_available();
+        if (need_host > 0.8 * have_host) {
+            std::fprintf(stderr, "rbg: composing the k-mer tables on the device failed (%s), and the host composition would need about %.0f GB of the %.0f GB "
+                                 "this process may still use: not attempted (fewer symbols per step -- RBG_OPT_KMER_STEPS -- need less of both)\n",
+                         rbg_strerror(rc), need_host / 1e9, have_host / 1e9);
+            return RBG_ENOMEM;
+        }
         std::fprintf(stderr, "rbg: composing the k-mer tables on the device failed (%s): composing on the host\n", rbg_strerror(rc));
         return compose_kmer_tables_host(h, static_cast<int>(K), opt);
     }
@@ -1579,7 +1675,7 @@ int compose_on_device(rbg_index *ix) {
     ix->runs_forced = keep_mask != 0;
     // the depth-1 run lists of the k-mer alphabet are on the device in the very form the slot tables are built from
     // (commit_sym): they stay, instead of being converted and copied a second time (5 + 2.5 GB at r = 3e8)
-    for (uint32_t m = 0; m < M; ++m) {
+    for (uint32_t m = 0; m < M && !released[1]; ++m) {
         SymTable &t = h.sym[h.major_slot[m]];
         for (void *q : {const_cast<void *>(major[m].ent), const_cast<void *>(major[m].samp)}) {
             if (!q) continue;
@@ -1690,8 +1786,8 @@ int upload(rbg_index *ix) {
         const int rcc = h.pos_bytes == 4 ? compose_on_device<uint32_t>(ix) : compose_on_device<uint64_t>(ix);
         if (rcc) return rcc;
     }
-    // The k-mer tables buy speed with memory: keep the deepest level that leaves a
-    // quarter of the free HBM (or RBG_OPT_HBM_BUDGET_MB) to the caller's read / result buffers.
+    // The k-mer tables buy speed with memory: keep the deepest level that fits a quarter of the free HBM
+    // (default_budget above) or RBG_OPT_HBM_BUDGET_MB.
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     const int64_t opt_mb = g_opt_hbm_budget_mb.load();
@@ -2282,6 +2378,8 @@ int index_from_bundle(FlatBundle &b, int device, rbg_index **out) {
     fo.defer_kmer = compose_deferred(device);
     int rc = flatten(b.rle, b.has_tsa ? &b.tsa : nullptr, fo, ix->host);
     if (rc) { delete ix; return rc; }
+    // (the flat index holds everything the bundle held: 33 bytes per run given back before the upload's own scratch is made)
+    { RawRle().heads.swap(b.rle.heads); std::vector<uint64_t>().swap(b.rle.lens); RawTsa empty; std::swap(b.tsa, empty); }
     if (b.has_ma) { ix->H().ma = std::move(b.ma); ix->H().has_ma = true; }
     if (b.has_dl) { ix->H().dl = std::move(b.dl); ix->H().has_dl = true; }
     return finish(ix, device, out);
@@ -2385,6 +2483,9 @@ int rbg_set_default_option(int opt, int64_t value) {
         case RBG_OPT_RUN_FMT:
             if (value != 1 && value != 2) return RBG_EARG;
             g_opt_run_fmt = value; return RBG_OK;
+        case RBG_OPT_RUN_PHI:
+            if (value < 0 || value > 2) return RBG_EARG;
+            g_opt_run_phi = value; return RBG_OK;
         default: return RBG_EARG;
     }
     });
@@ -2409,6 +2510,7 @@ int rbg_get_default_option(int opt, int64_t *value) {
         case RBG_OPT_SLOT_BYTES: *value = g_opt_slot_bytes.load(); return RBG_OK;
         case RBG_OPT_RUN_DEPTHS: *value = g_opt_run_depths.load(); return RBG_OK;
         case RBG_OPT_RUN_FMT: *value = g_opt_run_fmt.load(); return RBG_OK;
+        case RBG_OPT_RUN_PHI: *value = g_opt_run_phi.load(); return RBG_OK;
         default: return RBG_EARG;
     }
     });
@@ -2802,6 +2904,7 @@ int rbg_layout_info(const rbg_index *ix, rbg_layout_info_t *out, uint64_t out_by
         v.fill_shift = r.fmt == 2 && ix->H().pos_bytes == 8 ? ix->dev.run_fill_shift : 0;
         for (int d = 0; d < kMaxRunDepth; ++d) { v.entries[d] = r.entries[d]; v.fillers[d] = r.fillers[d]; v.dir_bytes[d] = r.dir_bytes[d]; }
         v.phi_entries = r.phi_entries; v.phi_fillers = r.phi_fillers; v.phi_dir_bytes = r.phi_dir_bytes; v.phi_dir_shift = r.phi_dir_shift;
+        v.phi_slots = r.phi_slots; v.phi_slot_bytes = r.phi_slot_bytes;
     }
     std::memcpy(out, &v, static_cast<size_t>(std::min<uint64_t>(out_bytes, sizeof(v))));
     return RBG_OK;
@@ -2951,13 +3054,14 @@ int rbg_sample_reads_dev(const uint8_t *d_text, uint64_t unit, uint64_t H, uint6
 // ---- packed reads (device API) ------------------------------------------------------------------
 size_t rbg_pack_ws_bytes(uint64_t N, uint64_t total_bytes) { return pack_ws_bytes(N, total_bytes); }
 
-int rbg_sample_reads_pangenome_dev(const uint8_t *d_base, const uint64_t *d_sites, const uint8_t *d_alt, const uint8_t *d_G, uint64_t S, uint64_t unit, uint64_t H,
-                                   uint64_t L, uint64_t m, uint64_t seed, uint64_t first_read, uint64_t N, uint32_t sub_ppm, uint8_t *d_seqs, uint64_t *d_off,
-                                   uint64_t *d_start, void *stream) {
+int rbg_sample_reads_pangenome_dev(const uint8_t *d_base, const uint64_t *d_sites, const uint8_t *d_alt, const uint8_t *d_G, uint64_t S, const uint32_t *d_site_dir,
+                                   uint32_t site_dir_shift, uint64_t unit, uint64_t H, uint64_t L, uint64_t m, uint64_t seed, uint64_t first_read, uint64_t N,
+                                   uint32_t sub_ppm, uint8_t *d_seqs, uint64_t *d_off, uint64_t *d_start, void *stream) {
     return guarded([&]() -> int {
     if (!d_base || !d_seqs || !d_off || (S && (!d_sites || !d_alt || !d_G))) return RBG_EARG;
-    if (m == 0 || m > L || H == 0 || L > unit || sub_ppm > 1000000u) return RBG_EARG;
-    return launch_sample_reads_pg(d_base, d_sites, d_alt, d_G, S, unit, H, L, m, seed, first_read, N, sub_ppm, d_seqs, d_off, d_start, stream) ? RBG_ENODEV : RBG_OK;
+    if (m == 0 || m > L || H == 0 || L > unit || sub_ppm > 1000000u || (d_site_dir && (site_dir_shift > 40 || S >= 0xFFFFFFFFull))) return RBG_EARG;
+    return launch_sample_reads_pg(d_base, d_sites, d_alt, d_G, S, d_site_dir, site_dir_shift, unit, H, L, m, seed, first_read, N, sub_ppm, d_seqs, d_off, d_start, stream)
+               ? RBG_ENODEV : RBG_OK;
     });
 }
 
@@ -3657,8 +3761,13 @@ int take_text_out(rbg_index *ix, size_t bytes, char **out) {
     if (!ix->text_copy_stream && hipStreamCreateWithFlags(&ix->text_copy_stream, hipStreamNonBlocking) != hipSuccess) return RBG_ENODEV;
     for (auto &t : ix->text_out)
         if (!t.busy && t.cap >= bytes) { t.busy = true; *out = t.p; return RBG_OK; }
-    for (auto &t : ix->text_out)
-        if (!t.busy && t.p) { (void)hipHostFree(t.p); t.p = nullptr; t.cap = 0; }   // too small: replaced below
+    {   // every idle buffer is too small: ONE of them, the smallest, is replaced -- the others stay for the usual batches (one
+        // oversized batch used to discard all the buffers rbg_reserve_text had made before the clock started)
+        rbg_index::TextOut *smallest = nullptr;
+        for (auto &t : ix->text_out)
+            if (!t.busy && t.p && (!smallest || t.cap < smallest->cap)) smallest = &t;
+        if (smallest) { (void)hipHostFree(smallest->p); smallest->p = nullptr; smallest->cap = 0; }
+    }
     const size_t cap = std::max<size_t>(size_t(1) << 20, bytes + bytes / 4);
     void *p = nullptr;
     if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return RBG_ENOMEM; }

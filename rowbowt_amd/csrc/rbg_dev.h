@@ -411,7 +411,9 @@ struct ComposedLevel {      // one k-mer depth: its tables back to back in table
 // sentinel n, g_id[g_n] = major index or 0xFFFFFFFF, g_samp[g_n] = samples_last or nullptr); returns an RBG_* code
 int compose_levels_device(uint32_t pos_bytes, uint64_t n, uint32_t M, const ComposeTable *major, const void *g_start, const uint32_t *g_id,
                           const void *g_samp, uint64_t g_n, uint32_t kmax, bool with_samples, std::vector<ComposedLevel> &out, void *stream,
-                          uint32_t keep_mask = 0 /*bit d - 1: depth d's arrays are kept; others are freed once the next depth is made (their metadata stays); 0 = keep all*/);
+                          uint32_t keep_mask = 0 /*bit d - 1: depth d's arrays are kept; others are freed once the next depth is made (their metadata stays); 0 = keep all*/,
+                          bool *inputs_released = nullptr /*[2], non-null: the inputs are handed over (hipMalloc blocks) and freed as soon as they have been read --
+                                                            [0] = the depth-1 segmentation was freed, [1] = the major symbols' tables were*/);
 
 struct LaunchCfg {
     int block_threads = 256;
@@ -537,8 +539,9 @@ int launch_build_ftab(const DevIndex &ix, const LaunchCfg &cfg, uint32_t k, void
 size_t ftab_build_scratch_bytes(uint64_t words, uint32_t k);  // device scratch the build takes besides the table
 int launch_sample_reads(const uint8_t *text, uint64_t unit, uint64_t H, uint64_t L, uint64_t m, uint64_t seed, uint64_t first,
                         uint64_t N, uint32_t sub_ppm, uint8_t *seqs, uint64_t *off, uint64_t *start_out /*nullable*/, void *stream);
-int launch_sample_reads_pg(const uint8_t *base, const uint64_t *sites, const uint8_t *alt, const uint8_t *G, uint64_t S, uint64_t unit, uint64_t H, uint64_t L,
-                           uint64_t m, uint64_t seed, uint64_t first, uint64_t N, uint32_t sub_ppm, uint8_t *seqs, uint64_t *off, uint64_t *start_out, void *stream);
+int launch_sample_reads_pg(const uint8_t *base, const uint64_t *sites, const uint8_t *alt, const uint8_t *G, uint64_t S, const uint32_t *site_dir, uint32_t site_dir_shift,
+                           uint64_t unit, uint64_t H, uint64_t L, uint64_t m, uint64_t seed, uint64_t first, uint64_t N, uint32_t sub_ppm, uint8_t *seqs, uint64_t *off,
+                           uint64_t *start_out, void *stream);
 int launch_count_from_ranges(const uint64_t *lo, const uint64_t *hi, uint64_t N, uint64_t *count, void *stream);
 
 }  // namespace rbg

@@ -30,6 +30,7 @@ import torch
 
 K = 32
 ACGT = (65, 67, 71, 84)
+EXPLICIT_CHUNK = 1 << 27   # members of explicit classes expanded at once (build_runs; tests lower it)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _lib = None
 
@@ -110,6 +111,10 @@ class TextView:
         self.sites = pg["sites"].contiguous()
         self.G = pg["G"].contiguous()
         self.L, self.H, self.unit, self.n, self.S = L, pg["H"], pg["unit"], pg["n"], pg["n_sites"]
+        # site_dir[b] = # sites below b << shift (for the sampler: a read's first site without a search over all sites)
+        self.site_dir_shift = 7
+        edges = torch.arange((L >> self.site_dir_shift) + 2, device=dev, dtype=torch.int64) << self.site_dir_shift
+        self.site_dir = torch.searchsorted(self.sites, edges).to(torch.int32).contiguous() if self.S else None
 
     def at(self, pos):
         """uint8 tensor of text[pos] (pos: int64 tensor of any shape, values in [0, n))"""
@@ -291,35 +296,53 @@ def build_runs(pg, log=None):
     explicit = (~is_x) & st_explicit[st_of] & (p_s == a[st_of])
     ex_pos = torch.nonzero(explicit).flatten()
 
-    # ---- explicit classes member by member -> their pieces (maximal equal-character stretches inside the class)
+    # ---- explicit classes member by member -> their pieces (maximal equal-character stretches inside the class).  In
+    # chunks of classes: their members number S * H (3e9 at the n = 3e11 pangenome: beyond one kernel launch, and 150 GB
+    # of index tensors if expanded at once)
     ne = ex_pos.numel()
     e_g = gidx[ex_pos]
     e_cnt = g_cnt[e_g]
-    e_off = torch.cumsum(e_cnt, 0) - e_cnt
-    m_tot = int(e_cnt.sum().item())
-    m_cls = torch.repeat_interleave(torch.arange(ne, device=dev), e_cnt)
-    m_k = torch.arange(m_tot, device=dev) - e_off[m_cls]
-    m_state = g_state[e_g][m_cls]
-    m_h = order_rows[m_state, g_col[e_g][m_cls] + m_k].to(i64)
-    m_p = a[m_state]
-    m_t = m_h * unit + m_p
-    jp = torch.searchsorted(sites, (m_p - 1).clamp(min=0)).clamp(max=max(S - 1, 0))
-    if S > 0:
-        m_chr = torch.where(G[jp, m_h] != 0, lut[alt[jp].long()], lut[base[sites[jp]].long()])
-    else:
-        m_chr = torch.full((m_tot,), 65, dtype=torch.uint8, device=dev)
-    at0 = m_p == 0
-    m_chr = torch.where(at0, torch.where(m_h == 0, torch.full_like(m_chr, 1), torch.full_like(m_chr, 65)), m_chr)
-    brk = torch.ones(m_tot, dtype=torch.bool, device=dev)
-    if m_tot > 1:
-        brk[1:] = (m_chr[1:] != m_chr[:-1]) | (m_cls[1:] != m_cls[:-1])
-    pstart = torch.nonzero(brk).flatten()
-    pend = torch.empty_like(pstart)
-    pend[:-1] = pstart[1:] - 1
-    if pstart.numel():
+    per = max(1, EXPLICIT_CHUNK // H)
+    ep_cls_l, ep_chr_l, ep_len_l, ep_tf_l, ep_tl_l = [], [], [], [], []
+    for c0 in range(0, ne, per):
+        c1 = min(ne, c0 + per)
+        cnt_c = e_cnt[c0:c1]
+        off_c = torch.cumsum(cnt_c, 0) - cnt_c
+        m_tot = int(cnt_c.sum().item())
+        if m_tot == 0:
+            continue
+        eg_c = e_g[c0:c1]
+        m_cls = torch.repeat_interleave(torch.arange(c1 - c0, device=dev), cnt_c)
+        m_k = torch.arange(m_tot, device=dev) - off_c[m_cls]
+        m_state = g_state[eg_c][m_cls]
+        m_h = order_rows[m_state, g_col[eg_c][m_cls] + m_k].to(i64)
+        m_p = a[m_state]
+        m_t = m_h * unit + m_p
+        jp = torch.searchsorted(sites, (m_p - 1).clamp(min=0)).clamp(max=max(S - 1, 0))
+        if S > 0:
+            m_chr = torch.where(G[jp, m_h] != 0, lut[alt[jp].long()], lut[base[sites[jp]].long()])
+        else:
+            m_chr = torch.full((m_tot,), 65, dtype=torch.uint8, device=dev)
+        at0 = m_p == 0
+        m_chr = torch.where(at0, torch.where(m_h == 0, torch.full_like(m_chr, 1), torch.full_like(m_chr, 65)), m_chr)
+        brk = torch.ones(m_tot, dtype=torch.bool, device=dev)
+        if m_tot > 1:
+            brk[1:] = (m_chr[1:] != m_chr[:-1]) | (m_cls[1:] != m_cls[:-1])
+        pstart = torch.nonzero(brk).flatten()
+        pend = torch.empty_like(pstart)
+        pend[:-1] = pstart[1:] - 1
         pend[-1] = m_tot - 1
-    ep_cls = m_cls[pstart]
-    ep_chr, ep_len, ep_tf, ep_tl = m_chr[pstart], pend - pstart + 1, m_t[pstart], m_t[pend]
+        ep_cls_l.append(m_cls[pstart] + c0)
+        ep_chr_l.append(m_chr[pstart]); ep_len_l.append(pend - pstart + 1); ep_tf_l.append(m_t[pstart]); ep_tl_l.append(m_t[pend])
+        del m_cls, m_k, m_state, m_h, m_p, m_t, jp, m_chr, at0, brk, pstart, pend
+    if ep_cls_l:
+        ep_cls = torch.cat(ep_cls_l)
+        ep_chr, ep_len, ep_tf, ep_tl = torch.cat(ep_chr_l), torch.cat(ep_len_l), torch.cat(ep_tf_l), torch.cat(ep_tl_l)
+    else:
+        ep_cls = torch.zeros(0, dtype=i64, device=dev)
+        ep_chr = torch.zeros(0, dtype=torch.uint8, device=dev)
+        ep_len = ep_tf = ep_tl = torch.zeros(0, dtype=i64, device=dev)
+    del ep_cls_l, ep_chr_l, ep_len_l, ep_tf_l, ep_tl_l
     ep_n = torch.bincount(ep_cls, minlength=ne)
     ep_first = torch.cumsum(ep_n, 0) - ep_n
     ep_k = torch.arange(ep_cls.numel(), device=dev) - ep_first[ep_cls]
@@ -385,7 +408,8 @@ def build_runs(pg, log=None):
     csum = torch.cumsum(P_len, 0)
     lens = csum[ends] - csum[starts] + P_len[starts]
     assert int(csum[-1].item()) == n, (int(csum[-1].item()), n)
-    out = dict(heads=P_chr[starts].cpu().numpy().astype(np.uint8), lens=lens.cpu().numpy().astype(np.uint64),
-               ssa=P_tf[starts].cpu().numpy().astype(np.uint64), esa=P_tl[ends].cpu().numpy().astype(np.uint64),
+    # (views, not .astype copies: 8 bytes per run each, 8 GB at r = 1e9, on a host whose container has a memory limit)
+    out = dict(heads=P_chr[starts].cpu().numpy(), lens=lens.cpu().numpy().view(np.uint64),
+               ssa=P_tf[starts].cpu().numpy().view(np.uint64), esa=P_tl[ends].cpu().numpy().view(np.uint64),
                n=n, r=int(starts.numel()))
     return out

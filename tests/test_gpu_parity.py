@@ -1675,12 +1675,14 @@ def test_positions_beyond_32_bits():
     # (single steps: toeholds compared; k-mer depths: ranges and the walks from the oracle's toeholds, as above)
     for top_kb, ks in ((48, 1), (0, 1), (48, 5), (0, 3)):
         ra.set_default_option(capi.OPT_KMER_STEPS, ks)
+        ra.set_default_option(capi.OPT_RUN_PHI, 1 if top_kb else 2)   # phi over the list of sampled positions / through phi slots of about n / r rows
         try:
             rbr = _with_layout(capi.LAYOUT_RUNS, top_kb, lambda: ra.RowBowt.from_runs(heads, lens, ssa, esa, device=0))
         finally:
             ra.set_default_option(capi.OPT_KMER_STEPS, 5)
+            ra.set_default_option(capi.OPT_RUN_PHI, 0)
         ir = rbr.info()
-        assert ir.rank_layout == capi.LAYOUT_RUNS and ir.pos_bytes == 8 and ir.kmer_steps == ks and ir.hbm_bytes < (4e9 if ks == 1 else 12e9)
+        assert ir.rank_layout == capi.LAYOUT_RUNS and ir.pos_bytes == 8 and ir.kmer_steps == ks and ir.hbm_bytes < (4e9 if ks == 1 else 12e9) + (0 if top_kb else 3e9)
         lo, hi, k = rbr.find_range_w_toehold(seqs, off)
         lo2, hi2 = rbr.find_range(seqs, off)
         assert (lo == wlo).all() and (hi == whi).all() and (lo2 == wlo).all() and (hi2 == whi).all() and (ks > 1 or (k == wk).all())
@@ -1855,7 +1857,7 @@ def _with_layout(layout, top_kb, build):
                                                             (0, 1, 0, 3, None, 1), (0, 48, -1, 1, "1", 1), (8, 1, -1, 2, "40", 1), (0, 0, 0, 1, "8", 1),
                                                             (8, 48, 0, 5, "3", 1), (0, 48, 0, 5, "8", 1),
                                                             (8, 48, 0, 1, None, 2), (0, 48, 3, 3, None, 2), (8, 48, 3, 2, None, 2), (0, 48, 0, 4, None, 2),
-                                                            (8, 48, -1, 4, None, 2)])
+                                                            (8, 48, -1, 4, None, 2), (0, 48, -1, 5, None, 22), (8, 48, -1, 5, None, 22), (8, 48, 0, 3, None, 22)])
 def test_run_indexed_layout(synth, pos_bytes, top_kb, fk, ks, rec, fmt):
     """RBG_LAYOUT_RUNS (k_runs.hip): space proportional to r, rank and phi as wave-cooperative predecessor searches
     over the run lists (rle_string.hpp:131-161, toehold_sa.hpp:56-72), k-mer steps through one clamped search per
@@ -1864,6 +1866,11 @@ def test_run_indexed_layout(synth, pos_bytes, top_kb, fk, ks, rec, fmt):
     per bucket record (None: no records, directories and run lists only; a large value: most buckets overflow their
     record and go through the run list; a small one: narrow buckets, clipped predecessors everywhere)."""
     S = synth
+    # fmt 22 = format 2 with phi SLOTS (RBG_OPT_RUN_PHI = 2: the slot layout's direct-addressed phi records at buckets of about n / r rows);
+    # plain 2 pins phi to the list of sampled positions and its directory
+    phi_slots = fmt == 22
+    fmt = 2 if fmt == 22 else fmt
+    ra.set_default_option(capi.OPT_RUN_PHI, 2 if phi_slots else 1)
     ra.set_default_option(capi.OPT_POS_BYTES, pos_bytes)
     ra.set_default_option(capi.OPT_FTAB_K, fk)
     ra.set_default_option(capi.OPT_KMER_STEPS, ks)
@@ -1880,6 +1887,7 @@ def test_run_indexed_layout(synth, pos_bytes, top_kb, fk, ks, rec, fmt):
         rb = _with_layout(capi.LAYOUT_RUNS, top_kb, lambda: ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0))
     finally:
         ra.set_default_option(capi.OPT_RUN_FMT, 2)
+        ra.set_default_option(capi.OPT_RUN_PHI, 0)
         ra.set_default_option(capi.OPT_RUN_DEPTHS, 0)
         ra.set_default_option(capi.OPT_POS_BYTES, 0)
         ra.set_default_option(capi.OPT_FTAB_K, -1)
@@ -1889,14 +1897,15 @@ def test_run_indexed_layout(synth, pos_bytes, top_kb, fk, ks, rec, fmt):
         os.environ.pop("RBG_RANK_REC", None)
     info = rb.info()
     assert info.rank_layout == capi.LAYOUT_RUNS and info.kmer_steps == ks and info.pos_bytes == (pos_bytes or 4)
-    assert info.rank_slots == 0 and info.phi_slots == 0
+    assert info.rank_slots == 0 and (info.phi_slots == 0) != phi_slots
     lists = [d for d, x in ((2, info.pair_runs), (3, info.triple_runs), (4, info.quad_runs), (5, info.quint_runs)) if x]
     assert lists == ([d for d in range(2, ks + 1)] if rec is not None or ks == 4 else [d for d in range(2, ks + 1) if (ks - d) % 2 == 0])
     li = rb.layout_info()
     assert li.run_fmt == fmt and li.depths_dropped_budget == 0 and li.depths_dropped_limit == 0 and li.phi_directory_dropped == 0
     assert [d + 1 for d in range(5) if li.depth_mask_kept >> d & 1] == [1] + [d for d in lists]
     if fmt == 2:
-        assert li.rank_directories == 1 and li.phi_directory == 1 and li.phi_entries == len(S.heads) and sum(li.fillers) == 0
+        assert li.rank_directories == 1 and li.phi_entries == len(S.heads) and sum(li.fillers) == 0
+        assert (li.phi_slots > 0 and li.phi_directory == 0 and rb.info().phi_slots == li.phi_slots) if phi_slots else (li.phi_slots == 0 and li.phi_directory == 1)
         assert all((li.entries[d] > 0) == bool(li.depth_mask_kept >> d & 1) for d in range(5))
     _run_indexed_checks(S, rb)
 
@@ -1969,6 +1978,7 @@ def test_run_indexed_format2_fillers_and_super_counts(synth, fill_shift, super_s
     ra.set_default_option(capi.OPT_POS_BYTES, 8)
     ra.set_default_option(capi.OPT_KMER_STEPS, ks)
     ra.set_default_option(capi.OPT_RUN_DEPTHS, depths)
+    ra.set_default_option(capi.OPT_RUN_PHI, 1)    # (phi over the list of sampled positions: the structure that has fillers and super counts)
     os.environ["RBG_RUN_FILL_SHIFT"] = str(fill_shift)
     os.environ["RBG_PHI_SUPER_SHIFT"] = str(super_shift)
     if dir_runs:
@@ -1981,6 +1991,7 @@ def test_run_indexed_format2_fillers_and_super_counts(synth, fill_shift, super_s
         ra.set_default_option(capi.OPT_POS_BYTES, 0)
         ra.set_default_option(capi.OPT_KMER_STEPS, 5)
         ra.set_default_option(capi.OPT_RUN_DEPTHS, 0)
+        ra.set_default_option(capi.OPT_RUN_PHI, 0)
         for k in ("RBG_RUN_FILL_SHIFT", "RBG_PHI_SUPER_SHIFT", "RBG_RANK_DIR_RUNS", "RBG_PHI_DIR_PER"):
             os.environ.pop(k, None)
     li = rb.layout_info()
@@ -2025,7 +2036,8 @@ def test_run_indexed_format1_limits_are_loud(synth, capfd):
     woff, wlocs = o.locs_at_batch(wlo, whi, wk, MAXU)
     assert (loc_off == woff).all() and (locs == wlocs).all()
     # the same index in format 2: nothing dropped, nothing to report
-    rb2 = _with_layout(capi.LAYOUT_RUNS, 48, lambda: ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0))
+    with capi.default_option(capi.OPT_RUN_PHI, 1):
+        rb2 = _with_layout(capi.LAYOUT_RUNS, 48, lambda: ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0))
     l2 = rb2.layout_info()
     assert l2.run_fmt == 2 and l2.phi_directory == 1 and l2.phi_directory_dropped == 0 and l2.depths_dropped_limit == 0
     rb.close(); rb2.close(); o.close()
@@ -2240,8 +2252,8 @@ def test_run_indexed_layout_budget_leaves_middle_depths_out():
     a million runs: the budget option counts MB.)"""
     rng = np.random.default_rng(41)
     heads, lens, ssa, esa, n = _random_run_index(rng, 1_000_000, 200)
-    def build():   # (without the device ftab: the budget is about the run lists)
-        with capi.default_option(capi.OPT_FTAB_K, 0), capi.default_option(capi.OPT_RUN_DEPTHS, depths[0]):
+    def build():   # (without the device ftab: the budget is about the run lists; phi over the list: phi slots are the budget's to give, too)
+        with capi.default_option(capi.OPT_FTAB_K, 0), capi.default_option(capi.OPT_RUN_DEPTHS, depths[0]), capi.default_option(capi.OPT_RUN_PHI, 1):
             return _with_layout(capi.LAYOUT_RUNS, 48, lambda: ra.RowBowt.from_runs(heads, lens, ssa, esa, device=0))
     depths = [0x1F]   # asked for: all five, unless stated
     full = build()
@@ -2719,9 +2731,15 @@ def test_reads_sampled_from_the_structure_equal_reads_sampled_from_the_text():
         st = torch.cuda.current_stream().cuda_stream
         assert Lb.rbg_sample_reads_dev(text.data_ptr(), pg["unit"], H, L, m, 77, 12345, N, 200000, a.data_ptr(), oa.data_ptr(), sa.data_ptr(), st) == 0
         assert Lb.rbg_sample_reads_pangenome_dev(tv.base_b.data_ptr(), tv.sites.data_ptr() if tv.S else None, tv.alt_b.data_ptr() if tv.S else None,
-                                                 tv.G.data_ptr() if tv.S else None, tv.S, pg["unit"], H, L, m, 77, 12345, N, 200000, b.data_ptr(), ob.data_ptr(),
-                                                 sb.data_ptr(), st) == 0
+                                                 tv.G.data_ptr() if tv.S else None, tv.S, tv.site_dir.data_ptr() if tv.S else None, tv.site_dir_shift,
+                                                 pg["unit"], H, L, m, 77, 12345, N, 200000, b.data_ptr(), ob.data_ptr(), sb.data_ptr(), st) == 0
         torch.cuda.synchronize()
         assert torch.equal(a, b) and torch.equal(oa, ob) and torch.equal(sa, sb)
+        b.zero_()   # without the site directory: the search over all sites
+        assert Lb.rbg_sample_reads_pangenome_dev(tv.base_b.data_ptr(), tv.sites.data_ptr() if tv.S else None, tv.alt_b.data_ptr() if tv.S else None,
+                                                 tv.G.data_ptr() if tv.S else None, tv.S, None, 0, pg["unit"], H, L, m, 77, 12345, N, 200000, b.data_ptr(),
+                                                 ob.data_ptr(), sb.data_ptr(), st) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(a, b)
         pos = torch.randint(0, pg["n"], (100000,), device=dev)
         assert torch.equal(tv.at(pos), text[pos])

@@ -61,3 +61,13 @@ def test_implicit_text_view_equals_the_text():
     pos = torch.arange(pg["n"], dtype=torch.int64)
     assert torch.equal(tv.at(pos), text)
     assert int(tv.at(torch.tensor([pg["n"] - 1]))[0]) == 1
+
+
+def test_explicit_classes_in_chunks(monkeypatch):
+    """the member-by-member expansion of the classes before a variant site runs in chunks at pangenome scale (S * H = 3e9
+    members at n = 3e11): many chunks must give what one gives"""
+    pg = pb.make_pangenome(4000, 11, 0.05, 51, torch.device("cpu"))
+    one = pb.build_runs(pg)
+    monkeypatch.setattr(pb, "EXPLICIT_CHUNK", 40)    # three classes per chunk
+    many = pb.build_runs(pg)
+    assert one["r"] == many["r"] and all(np.array_equal(one[k], many[k]) for k in ("heads", "lens", "ssa", "esa"))

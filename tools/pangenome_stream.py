@@ -43,10 +43,11 @@ def main():
     ap.add_argument("--count-only", action="store_true")
     ap.add_argument("--layout", choices=("auto", "slots", "runs"), default="auto")
     ap.add_argument("--run-depths", type=lambda v: int(v, 0), default=0, help="RBG_OPT_RUN_DEPTHS: bit d - 1 = keep run lists of the k-mer depth d (run-indexed layout; 0 = all)")
+    ap.add_argument("--run-phi", type=int, default=0, choices=(0, 1, 2), help="RBG_OPT_RUN_PHI: 1 = phi over the list of sampled positions, 2 = phi slots, 0 = the library's choice")
     ap.add_argument("--ftab-k", type=int, default=-1, help="word length of the device ftab (-1 = the library's choice)")
     ap.add_argument("--hbm-reserve-gb", type=float, default=45.0,
                     help="HBM left to this tool's own buffers (reads, ranges, locations, sort workspace): the index replica gets the rest of "
-                         "what is free once the text is resident (0 = the library's default budget, three quarters of the free HBM)")
+                         "what is free once the text is resident (0 = the library's default budget, a quarter of the free HBM)")
     ap.add_argument("--implicit-text", choices=("auto", "on", "off"), default="auto",
                     help="sample the reads (and check the properties) from the pangenome's STRUCTURE instead of its text (rbg_sample_reads_pangenome_dev, "
                          "pangenome_bwt.TextView): the same reads byte for byte; auto = when the text would not fit (n > 1e11)")
@@ -92,6 +93,43 @@ def main():
         if rank == 0:
             print("[pangenome]", *a, file=sys.stderr, flush=True)
 
+    # ---- a guard for the machine: this tool builds indexes of r = 1e9 runs on a host whose container has a memory limit (cgroup v2
+    # memory.max; 300 GiB on the GPU boxes of this pool), and a process that runs into it takes more than itself down.  A thread
+    # samples memory.current (and the device's used HBM) once a second, keeps the peaks for the JSON line, and ends the process
+    # before the limit is reached.
+    import threading
+    peaks = {"host_bytes": 0, "hbm_bytes": 0, "host_limit": None}
+
+    def _read_int(path):
+        try:
+            with open(path) as f:
+                t = f.read().strip()
+            return None if t == "max" else int(t)
+        except Exception:
+            return None
+    peaks["host_limit"] = _read_int("/sys/fs/cgroup/memory.max")
+
+    def _watch():
+        while True:
+            cur = _read_int("/sys/fs/cgroup/memory.current")
+            if cur is not None:
+                peaks["host_bytes"] = max(peaks["host_bytes"], cur)
+                if peaks["host_limit"] and cur > 0.88 * peaks["host_limit"]:
+                    print(f"[pangenome] host memory {cur / 1e9:.0f} GB of the container's {peaks['host_limit'] / 1e9:.0f} GB: stopping before the limit does",
+                          file=sys.stderr, flush=True)
+                    os._exit(3)
+            try:
+                free_b, total_b = torch.cuda.mem_get_info(dev)
+                peaks["hbm_bytes"] = max(peaks["hbm_bytes"], total_b - free_b)
+            except Exception:
+                pass
+            time.sleep(1.0)
+    threading.Thread(target=_watch, daemon=True).start()
+
+    def mem_line(what):
+        log(f"{what}: host {(_read_int('/sys/fs/cgroup/memory.current') or 0) / 1e9:.0f} GB (peak {peaks['host_bytes'] / 1e9:.0f}), "
+            f"HBM peak {peaks['hbm_bytes'] / 1e9:.0f} GB")
+
     import rowbowt_amd as ra
     from rowbowt_amd import capi, shard
     from rowbowt_amd.tools import pangenome_bwt as pb
@@ -105,7 +143,9 @@ def main():
     pg = pb.make_pangenome(args.L, args.H, args.site_rate, args.seed, dev)
     inp = pb.build_runs(pg, log=log)
     t_build = time.time() - t0
+    torch.cuda.empty_cache()   # (before anything small is allocated: a live tensor carved out of a cached 60 GB block keeps the whole block)
     log(f"pangenome: L={args.L} H={args.H} sites={pg['n_sites']} n={inp['n']} r={inp['r']} n/r={inp['n'] / inp['r']:.1f} (runs in {t_build:.1f}s)")
+    mem_line("after the run-length BWT")
     implicit = args.implicit_text == "on" or (args.implicit_text == "auto" and pg["n"] > 100_000_000_000)
     tv = pb.TextView(pg)
     text = None if implicit else pb.materialize_text(pg)
@@ -132,6 +172,8 @@ def main():
         capi.set_default_option(capi.OPT_RANK_LAYOUT, {"slots": 1, "runs": 2}[args.layout])
     if args.run_depths:
         capi.set_default_option(capi.OPT_RUN_DEPTHS, args.run_depths)
+    if args.run_phi:
+        capi.set_default_option(capi.OPT_RUN_PHI, args.run_phi)
     if args.hbm_reserve_gb > 0:
         free_b, _total = torch.cuda.mem_get_info(dev)
         capi.set_default_option(capi.OPT_HBM_BUDGET_MB, max(1024, int((free_b - args.hbm_reserve_gb * 1e9) / 2**20)))
@@ -139,6 +181,7 @@ def main():
     rb = ra.RowBowt.from_runs(inp["heads"], inp["lens"], inp["ssa"], inp["esa"], device=local_rank)
     ix = rb.info()
     t_load = time.time() - t0
+    mem_line("after the load")
     log(f"index replica: {ix.hbm_bytes / 1e9:.1f} GB HBM, pos_bytes={ix.pos_bytes}, {ix.kmer_steps} symbol(s) per gather "
         f"(asked {ix.kmer_steps_requested}; {ix.hbm_free_at_load / 1e9:.0f} GB free at load, budget {ix.hbm_budget / 1e9:.0f} GB), "
         f"ftab_k={ix.ftab_k}, flatten+upload {t_load:.1f}s")
@@ -165,7 +208,8 @@ def main():
     def gen(first, cnt, start_out=None):
         so = start_out.data_ptr() if start_out is not None else None
         if implicit:
-            chk(Lb.rbg_sample_reads_pangenome_dev(tv.base_b.data_ptr(), tv.sites.data_ptr(), tv.alt_b.data_ptr(), tv.G.data_ptr(), tv.S, unit, H, L, m,
+            chk(Lb.rbg_sample_reads_pangenome_dev(tv.base_b.data_ptr(), tv.sites.data_ptr(), tv.alt_b.data_ptr(), tv.G.data_ptr(), tv.S,
+                                                  tv.site_dir.data_ptr() if tv.site_dir is not None else None, tv.site_dir_shift, unit, H, L, m,
                                                   args.seed + 2, first, cnt, args.sub_ppm, d_seqs.data_ptr(), d_off.data_ptr(), so, st), "sample_reads_pangenome")
         else:
             chk(Lb.rbg_sample_reads_dev(text.data_ptr(), unit, H, L, m, args.seed + 2, first, cnt, args.sub_ppm, d_seqs.data_ptr(),
@@ -325,6 +369,7 @@ def main():
             t0 = time.time()
             o = orc.Oracle.from_runs(inp["heads"], inp["lens"], inp["ssa"], inp["esa"])
             log(f"oracle built in {time.time() - t0:.1f}s")
+            mem_line("with the oracle")
             h_seqs = reads[:nchk].cpu().numpy().reshape(-1)
             h_off = np.arange(nchk + 1, dtype=np.uint64) * m
             ncpu = min(os.cpu_count() or 1, 64)
@@ -358,8 +403,9 @@ def main():
                                                  "phi_directory": int(li.phi_directory), "phi_directory_dropped": int(li.phi_directory_dropped),
                                                  "entries": [int(x) for x in li.entries], "fillers": [int(x) for x in li.fillers], "dir_bytes": [int(x) for x in li.dir_bytes],
                                                  "phi_entries": int(li.phi_entries), "phi_fillers": int(li.phi_fillers), "phi_dir_bytes": int(li.phi_dir_bytes),
-                                                 "phi_dir_shift": int(li.phi_dir_shift)}
+                                                 "phi_dir_shift": int(li.phi_dir_shift), "phi_slots": int(li.phi_slots), "phi_slot_bytes": int(li.phi_slot_bytes)}
         out["config"]["index"]["text"] = "implicit (sampled from the pangenome's structure)" if implicit else "materialised in HBM"
+        out["peaks"] = {"host_bytes": int(peaks["host_bytes"]), "host_limit_bytes": peaks["host_limit"], "hbm_bytes": int(peaks["hbm_bytes"])}
         print(json.dumps(out), flush=True)
         if args.out_json:
             with open(args.out_json, "w") as f:
