@@ -49,6 +49,10 @@ struct Pool {
         for (Blk &b : blks)
             if (!b.used && b.bytes >= bytes && (!best || b.bytes < best->bytes)) best = &b;
         if (best) { best->used = true; *out = best->p; return hipSuccess; }
+        // (no idle block is large enough.  Before the pool grows by a big block the idle ones go back to the driver: the depths' requests
+        //  grow from depth to depth, so the previous depth's blocks would never be handed out again -- they were 60-90 GB of the 230 GB the
+        //  composition held at r = 5e8)
+        if (bytes >= (size_t(256) << 20)) purge();
         const size_t want = bytes + (bytes < (size_t(1) << 30) ? bytes / 4 : bytes / 64) + 256;   // (big blocks: the slack is gigabytes at r = 1e9)
         void *p = nullptr;
         hipError_t e = hipMalloc(&p, want);
@@ -333,6 +337,8 @@ int compose_impl(const uint64_t n, const uint32_t M, const ComposeTable *major, 
     CK(hipMemsetAsync(d_err.p, 0, sizeof(int), st));
     uint32_t n_ids = M;
     const bool verbose = std::getenv("RBG_VERBOSE") != nullptr;
+    auto used_gb = [] { size_t f = 0, t = 0; (void)hipMemGetInfo(&f, &t); return static_cast<double>(t - f) / 1e9; };
+    double gb_pieces = 0, gb_tables = 0;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
     for (uint32_t depth = 1; depth < kmax; ++depth, n_ids *= M) {
@@ -365,6 +371,8 @@ int compose_impl(const uint64_t n, const uint32_t M, const ComposeTable *major, 
         // which G segments a symbol's image [F, F + total) meets: two binary searches per symbol, made from the host over the
         // device array (a few dozen 8-byte copies per level)
         std::vector<uint64_t> g_lo(M), nB(M), np_m(M), base(M + 1, 0);
+        // (the keep flags and their scan -- 12 bytes per segment boundary -- are made twice per symbol, once to count and once to merge, instead
+        //  of being held for all symbols from the first pass to the second: 26 GB at r = 1e9)
         std::vector<Tmp> keep(M), posB(M);
         for (uint32_t m = 0; m < M; ++m) {
             const ComposeTable &tc = major[m];
@@ -404,6 +412,8 @@ int compose_impl(const uint64_t n, const uint32_t M, const ComposeTable *major, 
             CK(hipMemcpy(&kept, posB[m].as<uint64_t>() + nB[m], 8, hipMemcpyDeviceToHost));
             np_m[m] = tc.nruns + kept;
             base[m + 1] = base[m] + np_m[m];
+            keep[m].release();
+            posB[m].release();
         }
         const uint64_t np = base[M];
         if (np >= 0xFFFFFFF0ull) return -4;   // piece and run ordinals are 32-bit
@@ -415,6 +425,19 @@ int compose_impl(const uint64_t n, const uint32_t M, const ComposeTable *major, 
         for (uint32_t m = 0; m < M; ++m) {
             if (np_m[m] == 0) continue;
             const ComposeTable &tc = major[m];
+            {   // the symbol's keep flags and their scan again (see above)
+                CK(keep[m].alloc((nB[m] + 1) * 4));
+                CK(posB[m].alloc((nB[m] + 2) * 8));
+                hipLaunchKernelGGL((k_flag_bounds<P>), grid_n(nB[m] + 1), dim3(256), 0, st, static_cast<const RunEnt<P> *>(tc.ent), tc.nruns, tc.F, g_start,
+                                   g_lo[m], nB[m], keep[m].as<uint32_t>());
+                CK(hipGetLastError());
+                Tmp k64;
+                CK(k64.alloc((nB[m] + 1) * 8));
+                hipLaunchKernelGGL(k_widen_flags, grid_n(nB[m] + 1), dim3(256), 0, st, keep[m].as<uint32_t>(), nB[m] + 1, k64.as<uint64_t>());
+                CK(hipGetLastError());
+                const int rc2 = exclusive_scan_u64(k64.as<uint64_t>(), posB[m].as<uint64_t>(), nB[m] + 1, st);
+                if (rc2) return rc2;
+            }
             Tmp bnd, bk, bg;
             CK(bnd.alloc(np_m[m] * 8));
             CK(bk.alloc(np_m[m] * 4));
@@ -432,6 +455,7 @@ int compose_impl(const uint64_t n, const uint32_t M, const ComposeTable *major, 
             posB[m].release();
         }
         const auto t_pieces = now();
+        if (verbose) gb_pieces = used_gb();
         if (last_level) { own_start.release(); own_id.release(); own_samp.release(); }   // (the segmentation is read by the pieces only)
         // inputs_released != nullptr: the caller hands over its inputs -- the depth-1 segmentation (20 bytes per run) is read by the
         // first depth's pieces only, the major symbols' own tables (24 bytes per run) by every depth's pieces and no later: 45 GB
@@ -510,7 +534,9 @@ int compose_impl(const uint64_t n, const uint32_t M, const ComposeTable *major, 
         }
         CK(hipStreamSynchronize(st));
         const auto t_tables = now();
+        if (verbose) gb_tables = used_gb();
         // ---- the next depth's segmentation (not needed after the last level) ----------------------------------------------
+        s_tab.release(); cumlen.release(); first.release();   // (the tables are written: 16 bytes per piece less under the segmentation's arrays)
         if (depth + 1 < kmax) {
             Tmp rkeys, rperm;
             CK(rkeys.alloc((nkept + 1) * sizeof(P)));
@@ -553,9 +579,10 @@ int compose_impl(const uint64_t n, const uint32_t M, const ComposeTable *major, 
         CK(hipMemcpy(&h_err, d_err.p, sizeof(int), hipMemcpyDeviceToHost));
         if (h_err) return -2;   // RBG_EFORMAT: a sample below the depth (the terminator inside a k-mer)
         if (verbose)
-            std::fprintf(stderr, "rbg:   depth %u: %llu pieces, %llu runs in %u tables: pieces %.3f s, tables %.3f s, next segmentation %.3f s\n", depth + 1,
+            std::fprintf(stderr, "rbg:   depth %u: %llu pieces, %llu runs in %u tables: pieces %.3f s, tables %.3f s, next segmentation %.3f s; HBM in use %.1f GB after the "
+                                 "pieces, %.1f after the tables, %.1f at the end\n", depth + 1,
                          static_cast<unsigned long long>(np), static_cast<unsigned long long>(nkept), T, secs(t_lvl, t_pieces), secs(t_pieces, t_tables),
-                         secs(t_tables, now()));
+                         secs(t_tables, now()), gb_pieces, gb_tables, used_gb());
         // the tables just made are the next level's "previous" ones
         prev_ent.assign(T, nullptr); prev_nruns.assign(T, 0); prev_F.assign(T, 0);
         for (uint32_t t = 0; t < T; ++t) {

@@ -1343,6 +1343,12 @@ int upload_tables_runs2(rbg_index *ix) {
             ix->dev.run_samp[d] = abs_samp;
             ix->dev.run_dir[d] = static_cast<const uint32_t *>(dirp);   // (format 1's kernels could read the same arrays)
         }
+        if (std::getenv("RBG_VERBOSE")) {
+            size_t f = 0, tt = 0;
+            (void)hipMemGetInfo(&f, &tt);
+            std::fprintf(stderr, "rbg:   run lists of depth %u in their final form: %llu entries (%llu fillers), directories %.2f GB; HBM in use %.1f GB\n", d + 1,
+                         static_cast<unsigned long long>(E2), static_cast<unsigned long long>(fillers), rep.dir_bytes[d] / 1e9, static_cast<double>(tt - f) / 1e9);
+        }
         for (size_t t = 0; t < T.size(); ++t) {
             tabs.push_back(DevRunTab2{T[t].F, first[t], doff[t], dshift[t], 0u});
             tabs1.push_back(DevRunTab{T[t].F, first[t], static_cast<uint32_t>(doff[t]), dshift[t]});
@@ -1558,12 +1564,32 @@ void drop_kmer_level(rbg_index *ix, std::vector<SymTable> &lvl) {
 // Depths 2 .. kmer_deferred composed on the device (k_compose.hip) from the depth-1 tables of the k-mer alphabet and the
 // BWT's own runs; the host tables get their metadata (runs, total, F, bucket shift) and pointers into the level arrays.
 // Without the memory for it (or with RBG_HOST_COMPOSE=1 at flatten time) the host composes as before.
+template <typename P> int compose_on_device_k(rbg_index *ix, uint32_t K);
+
+// Depths 2 .. kmer_deferred on the device; when neither the device (transient HBM: about 100 bytes per piece of the deepest
+// intermediate depth) nor the host (24 bytes per run and depth, refused when the container's memory would not hold it) can
+// compose that many symbols per step, one symbol less is tried -- said on stderr, and rbg_info reports the depth asked for beside
+// the depth kept.  (Round 4: an r = 1e9 index gets 3 symbols per step this way where 5 would need more than the device has.)
 template <typename P>
 int compose_on_device(rbg_index *ix) {
     HostIndex &h = ix->H();
-    const uint32_t M = h.nmajor, K = h.kmer_deferred;
+    const uint32_t M = h.nmajor, K0 = h.kmer_deferred;
     h.kmer_deferred = 0;
-    if (M < 1 || K < 2) return RBG_OK;
+    if (M < 1 || K0 < 2) return RBG_OK;
+    if (ix->kmer_steps_requested == 0) ix->kmer_steps_requested = K0;
+    for (uint32_t K = K0; K >= 2; --K) {
+        const int rc = compose_on_device_k<P>(ix, K);
+        if (rc != RBG_ENOMEM) return rc;
+        std::fprintf(stderr, "rbg: %u symbols per step cannot be composed in the memory there is: trying %u\n", K, K - 1);
+        (void)hipGetLastError();
+    }
+    return RBG_OK;   // single-symbol steps: nothing to compose
+}
+
+template <typename P>
+int compose_on_device_k(rbg_index *ix, const uint32_t K) {
+    HostIndex &h = ix->H();
+    const uint32_t M = h.nmajor;
     const FlattenOptions opt = current_options();
     const auto t0 = std::chrono::steady_clock::now();
     struct Hold {

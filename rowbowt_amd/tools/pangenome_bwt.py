@@ -278,6 +278,8 @@ def build_runs(pg, log=None):
     say(f"{ncls} suffix classes for n = {n}")
 
     # ---- the order of the classes
+    if dev.type == "cuda":
+        torch.cuda.empty_cache()   # (the cached blocks of the stages above are of other sizes than the ones that follow)
     Ws, perm = torch.sort(W ^ _SIGN)
     del W
     if ncls > 1 and bool((Ws[1:] == Ws[:-1]).any().item()):
@@ -347,6 +349,8 @@ def build_runs(pg, log=None):
     ep_first = torch.cumsum(ep_n, 0) - ep_n
     ep_k = torch.arange(ep_cls.numel(), device=dev) - ep_first[ep_cls]
 
+    if dev.type == "cuda":
+        torch.cuda.empty_cache()
     # ---- all pieces in class order
     pc = torch.ones(ncls, dtype=i64, device=dev)
     pc[ex_pos] = ep_n

@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--count-only", action="store_true")
     ap.add_argument("--layout", choices=("auto", "slots", "runs"), default="auto")
     ap.add_argument("--run-depths", type=lambda v: int(v, 0), default=0, help="RBG_OPT_RUN_DEPTHS: bit d - 1 = keep run lists of the k-mer depth d (run-indexed layout; 0 = all)")
+    ap.add_argument("--kmer-steps", type=int, default=0, choices=(0, 1, 2, 3, 4, 5), help="RBG_OPT_KMER_STEPS (0 = the library's default, 5)")
     ap.add_argument("--run-phi", type=int, default=0, choices=(0, 1, 2), help="RBG_OPT_RUN_PHI: 1 = phi over the list of sampled positions, 2 = phi slots, 0 = the library's choice")
     ap.add_argument("--ftab-k", type=int, default=-1, help="word length of the device ftab (-1 = the library's choice)")
     ap.add_argument("--hbm-reserve-gb", type=float, default=45.0,
@@ -143,7 +144,11 @@ def main():
     pg = pb.make_pangenome(args.L, args.H, args.site_rate, args.seed, dev)
     inp = pb.build_runs(pg, log=log)
     t_build = time.time() - t0
+    import gc
+    gc.collect()
     torch.cuda.empty_cache()   # (before anything small is allocated: a live tensor carved out of a cached 60 GB block keeps the whole block)
+    log(f"torch after the build: {torch.cuda.memory_allocated(dev) / 1e9:.1f} GB allocated, {torch.cuda.memory_reserved(dev) / 1e9:.1f} GB reserved, "
+        f"{torch.cuda.mem_get_info(dev)[0] / 1e9:.1f} GB free on the device")
     log(f"pangenome: L={args.L} H={args.H} sites={pg['n_sites']} n={inp['n']} r={inp['r']} n/r={inp['n'] / inp['r']:.1f} (runs in {t_build:.1f}s)")
     mem_line("after the run-length BWT")
     implicit = args.implicit_text == "on" or (args.implicit_text == "auto" and pg["n"] > 100_000_000_000)
@@ -165,7 +170,10 @@ def main():
     del pg
     if not implicit:
         tv = None
+    gc.collect()
     torch.cuda.empty_cache()
+    log(f"torch before the load: {torch.cuda.memory_allocated(dev) / 1e9:.1f} GB allocated, {torch.cuda.memory_reserved(dev) / 1e9:.1f} GB reserved, "
+        f"{torch.cuda.mem_get_info(dev)[0] / 1e9:.1f} GB free on the device")
     if args.ftab_k >= 0:
         capi.set_default_option(capi.OPT_FTAB_K, args.ftab_k)
     if args.layout != "auto":
@@ -174,6 +182,8 @@ def main():
         capi.set_default_option(capi.OPT_RUN_DEPTHS, args.run_depths)
     if args.run_phi:
         capi.set_default_option(capi.OPT_RUN_PHI, args.run_phi)
+    if args.kmer_steps:
+        capi.set_default_option(capi.OPT_KMER_STEPS, args.kmer_steps)
     if args.hbm_reserve_gb > 0:
         free_b, _total = torch.cuda.mem_get_info(dev)
         capi.set_default_option(capi.OPT_HBM_BUDGET_MB, max(1024, int((free_b - args.hbm_reserve_gb * 1e9) / 2**20)))
