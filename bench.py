@@ -896,6 +896,7 @@ def main():
         step()
         rate_r = time_locate(ms_r)
         run_fmt = int(rb.layout_info().run_fmt)
+        run_phi_slots = int(rb.layout_info().phi_slots)   # > 0: phi through slots of about n / r rows (RBG_OPT_RUN_PHI; the library's choice here)
         # bytes of the run-indexed kernels AS RUN (instrumented instantiations; sums as include/rbg.h lists them for this
         # layout): per read its offsets + outputs + read chunks + ftab entry; per directory gather 8; per run-list entry a
         # probe needed 2P; per narrowing round 16 pivot keys of P; per materialised re-sample P.  K3: per read 28, per phi
@@ -907,14 +908,15 @@ def main():
         chk(L.rbg_locate_fill_stats_dev(rb.h, d_lo.data_ptr(), d_hi.data_ptr(), d_k.data_ptr(), N, max_hits, d_loc_off.data_ptr(),
                                         d_locs.data_ptr(), d_ws.data_ptr(), d_stats.data_ptr(), st), "locate_fill_stats")
         torch.cuda.synchronize()
-        rs_loc = dict(zip(("phi_steps", "probe_entries", "chains", "locs"), d_stats.cpu().numpy().tolist()[:4]))
+        rs_loc = dict(zip(("phi_steps", "phi_searched" if run_phi_slots else "probe_entries", "chains", "locs"), d_stats.cpu().numpy().tolist()[:4]))
         rb.counters_reset()
 
         # format 2 (rbg_runs2_device.hpp; the default since round 4): a directory gather is two neighbouring entries of 4 bytes (8 at 8-byte
         # positions: count + the rank's high part), a run-list entry 8 bytes at either width, a narrowing round seven 4-byte pivots, a sample 4 / 6
         # bytes; a phi step reads two 4-byte counts (+ one 8-byte super count at 8-byte positions) and entries of 8 / 12 bytes.
+        run_recs = sum(int(x) for x in rb.layout_info().rec_bytes) > 0   # bucket records (RBG_OPT_RUN_REC): a "directory gather" is one 64-byte record
         if run_fmt == 2:
-            b_dir, b_ent, b_narrow, b_samp = (8 if Pr == 4 else 16), 8, 28, (4 if Pr == 4 else 6)
+            b_dir, b_ent, b_narrow, b_samp = (64 if run_recs else 8 if Pr == 4 else 16), 8, 28, (4 if Pr == 4 else 6)
             b_phi_dir, b_phi_ent = (8 if Pr == 4 else 16), (8 if Pr == 4 else 12)
         else:
             b_dir, b_ent, b_narrow, b_samp = 8, 2 * Pr, 16 * Pr, Pr
@@ -924,17 +926,23 @@ def main():
             return (N * (16 + (24 if toehold else 16)) + 16 * sv["read_chunks"] + (16 if Pr == 4 else 32) * sv["ftab"] + b_dir * sv["slots"]
                     + b_ent * sv["dense"] + b_narrow * sv["searched_ranks"] + b_samp * sv["resamples"])
 
-        run_alg = {"k_find_range<count>": run_search_bytes(rs_count, False), "k_find_range<toehold>": run_search_bytes(rs_toe, True),
-                   "k_locate_fill": N * 28 + b_phi_dir * rs_loc["phi_steps"] + b_phi_ent * rs_loc["probe_entries"] + 8 * rs_loc["locs"]}
+        if run_phi_slots:   # the slot kernel's K3 (k_locate_fill): one PhiSlot (4 x P; 16 packed) per step, the searched steps as on the slot layout
+            k3_bytes = N * 28 + (16 if (Pr == 4 or (int(ix.n) >> 38) == 0) else 32) * rs_loc["phi_steps"] + (8 + 3 * 2 * Pr) * rs_loc["phi_searched"] + 8 * rs_loc["locs"]
+        else:
+            k3_bytes = N * 28 + b_phi_dir * rs_loc["phi_steps"] + b_phi_ent * rs_loc["probe_entries"] + 8 * rs_loc["locs"]
+        run_alg = {"k_find_range<count>": run_search_bytes(rs_count, False), "k_find_range<toehold>": run_search_bytes(rs_toe, True), "k_locate_fill": k3_bytes}
         run_roof = {kk: {"alg_bytes": v, "alg_GBps": v / (ms_r[kk] * 1e-3) / 1e9, "frac_of_hbm_peak": v / (ms_r[kk] * 1e-3) / 1e9 / HBM_PEAK_GBS}
                     for kk, v in run_alg.items()}
         run_touched = {"per_read": {"search_steps": rs_toe["steps"] / N, "directory_gathers": rs_toe["slots"] / N, "run_list_entries_probed": rs_toe["dense"] / N,
                                     "narrowing_rounds": rs_toe["searched_ranks"] / N, "resamples": rs_toe["resamples"] / N,
-                                    "phi_steps": rs_loc["phi_steps"] / N, "phi_entries_probed": rs_loc["probe_entries"] / N},
+                                    "phi_steps": rs_loc["phi_steps"] / N, "phi_entries_probed": rs_loc.get("probe_entries", 0) / N,
+                                    "phi_steps_searched_beside_their_slot": rs_loc.get("phi_searched", 0) / N},
                        "search": rs_toe, "locate": rs_loc}
         same = all(bool((a == b).all().item()) for a, b in zip(ref_out, (d_lo, d_hi, d_k, d_loc_off))) and bool((ref_locs == d_locs[:total_locs]).all().item())
         rows.append({"layout": "runs", "depths": [1, 2, 3, 4, 5][:int(rb.info().kmer_steps)], "symbols_per_gather": int(rb.info().kmer_steps), "hbm_bytes": int(rb.info().hbm_bytes), "ms": ms_r,
                      "identical_to_slot_path_on_the_whole_batch": same, "roofline": run_roof, "touched": run_touched, "run_fmt": run_fmt,
+                     "phi": "slots of about n / r rows" if run_phi_slots else "list of sampled positions + directory",
+                     "ranks": "bucket records (one 64-byte record per bucket)" if run_recs else "directories + run lists",
                      "count_locate_reads_per_s": rate_r})
         if args.markers:
             # the kernels beside the rb_align path on this layout (cooperative since round 3: k_runs_seeds.hip), same batch
@@ -957,17 +965,23 @@ def main():
             same = same and same_g and same_s
         # the same layout with run lists for some of the k-mer depths only (RBG_OPT_RUN_DEPTHS; include/rbg.h): a step takes
         # the longest stretch a kept depth covers -- the space of the depths left out against a step more per ragged stretch
-        for depth_mask in (() if not same else (0x15, 0x11)):
+        # (0x15 twice: the library's own choice -- bucket records and phi slots on an index this small -- and the minimal form of the
+        #  layout: directories + run lists, phi over the list of sampled positions)
+        for depth_mask, minimal in (() if not same else ((0x15, False), (0x15, True), (0x11, False))):
             rb.close()
             torch.cuda.empty_cache()
-            with capi.default_option(capi.OPT_RANK_LAYOUT, capi.LAYOUT_RUNS), capi.default_option(capi.OPT_RUN_DEPTHS, depth_mask):
+            with capi.default_option(capi.OPT_RANK_LAYOUT, capi.LAYOUT_RUNS), capi.default_option(capi.OPT_RUN_DEPTHS, depth_mask), \
+                    capi.default_option(capi.OPT_RUN_REC, 1 if minimal else 0), capi.default_option(capi.OPT_RUN_PHI, 1 if minimal else 0):
                 rb = ra.RowBowt.from_runs(inp["heads"], inp["lens"], inp["ssa"], inp["esa"], device=local_rank)
             ms_d = time_search()
             step()
             rate_d = time_locate(ms_d)
             step()
             same_d = all(bool((a == b).all().item()) for a, b in zip(ref_out, (d_lo, d_hi, d_k, d_loc_off))) and bool((ref_locs == d_locs[:total_locs]).all().item())
+            li_d = rb.layout_info()
             row = {"layout": "runs", "depths": [d + 1 for d in range(5) if depth_mask >> d & 1], "symbols_per_gather": int(rb.info().kmer_steps),
+                   "ranks": "bucket records" if sum(int(x) for x in li_d.rec_bytes) > 0 else "directories + run lists",
+                   "phi": "slots of about n / r rows" if int(li_d.phi_slots) else "list of sampled positions + directory",
                    "hbm_bytes": int(rb.info().hbm_bytes), "ms": ms_d, "identical_to_slot_path_on_the_whole_batch": same_d,
                    "count_locate_reads_per_s": rate_d}
             if args.markers:

@@ -175,6 +175,8 @@ typedef struct rbg_layout_info_t {
     uint64_t phi_entries, phi_fillers, phi_dir_bytes, phi_dir_shift;
     uint64_t phi_slots, phi_slot_bytes; /* format 2 with phi SLOTS (RBG_OPT_RUN_PHI): their number (buckets of 2^phi_dir_shift text positions) and the
                                          * bytes of slots + ordinals; 0 = phi goes through the list of sampled positions and its directory */
+    uint64_t rec_bytes[5];            /* per depth: bytes of its tables' bucket records (RBG_OPT_RUN_REC; 0 = directories; rank_directories is 0 with records) */
+    uint64_t rec_overflow[5];         /* per depth: buckets with more entries than a record holds (their ranks go through the run list) */
 } rbg_layout_info_t;
 int rbg_layout_info(const rbg_index *, rbg_layout_info_t *out, uint64_t out_bytes);
 
@@ -533,7 +535,13 @@ enum { RBG_OPT_BLOCK_THREADS = 1, RBG_OPT_RANK_BUCKET_SHIFT = 2, RBG_OPT_PHI_BUC
                                   (the slot layout's PhiSlot records) whose buckets are about n / r rows wide, so that their number is proportional
                                   to r (about 54 bytes per run at 8-byte positions: one sector per step -- at pangenome scale K3 is bound by that
                                   count); 0 (default) = slots when the whole replica then stays within half the HBM budget.  RBG_RUN_PHI gives the
-                                  initial value; rbg_layout_info().phi_slots says what was built. */ };
+                                  initial value; rbg_layout_info().phi_slots says what was built. */,
+       RBG_OPT_RUN_REC = 17 /* run-indexed layout, format 2 -- BUCKET RECORDS: 2 = every bucket of a table (about three entries wide) gets one aligned
+                                  64-byte record holding its entries and the one before them, direct-addressed: a rank is ONE sector instead of a
+                                  directory sector plus an unaligned stretch of the run list (K1/K2 on this layout are bound by that count); about
+                                  21-26 bytes per entry on top of the run lists, which stay for crowded buckets and the samples; 1 = directories only;
+                                  0 (default) = records when the replica with them stays within half the HBM budget.  RBG_RUN_REC gives the initial
+                                  value, RBG_RUN_REC_PER the entries per bucket; rbg_layout_info().rec_bytes says what was built. */ };
 int rbg_set_default_option(int opt, int64_t value);
 /* the value a later load would use (so that a caller can change a knob for one load and put it back) */
 int rbg_get_default_option(int opt, int64_t *value);

@@ -410,6 +410,56 @@ __global__ __launch_bounds__(256) void k_run_dirs2(const u64pair *__restrict__ e
         dir[i] = RunDir64{static_cast<uint32_t>(lo), lo ? static_cast<uint32_t>(e[lo - 1].y >> 31) : 0u};
     }
 }
+// bucket records of a depth's tables (rbg_dev.h RunRec2): record i belongs to bucket i - roff[t] of table t
+template <typename P>
+__global__ __launch_bounds__(256) void k_run_recs2(const RunEnt<P> *__restrict__ ent, const uint64_t *__restrict__ first, const uint64_t *__restrict__ nruns,
+                                                   const uint64_t *__restrict__ roff, const uint32_t *__restrict__ rshift, const uint32_t T,
+                                                   const uint64_t total, RunRec2 *__restrict__ recs, unsigned long long *__restrict__ overflow) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    unsigned long long novf = 0;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += stride) {
+        uint32_t a = 0, z = T;                       // the table: last t with roff[t] <= i
+        while (z - a > 1) {
+            const uint32_t mid = (a + z) >> 1;
+            if (roff[mid] <= i) a = mid; else z = mid;
+        }
+        const uint32_t sh = rshift[a];
+        const uint64_t lim = (i - roff[a]) << sh, lim2 = lim + (uint64_t(1) << sh);
+        const RunEnt<P> *__restrict__ e = ent + first[a];
+        const uint64_t nr = nruns[a];
+        uint64_t lo = 0, hi = nr;
+        while (lo < hi) { const uint64_t mid = lo + ((hi - lo) >> 1); if (static_cast<uint64_t>(e[mid].start) < lim) lo = mid + 1; else hi = mid; }
+        uint64_t up = lo;                            // # entries starting below the next bucket
+        while (up < nr && up < lo + kRec2Ents + 1 && static_cast<uint64_t>(e[up].start) < lim2) ++up;
+        if (up == lo + kRec2Ents + 1) {              // more than a record holds: count them all
+            uint64_t l2 = up, h2 = nr;
+            while (l2 < h2) { const uint64_t mid = l2 + ((h2 - l2) >> 1); if (static_cast<uint64_t>(e[mid].start) < lim2) l2 = mid + 1; else h2 = mid; }
+            up = l2;
+        }
+        const uint64_t e0 = lo ? lo - 1 : 0, cnt = up - e0;
+        RunRec2 r;
+        r.e0 = static_cast<uint32_t>(e0);
+        r.hi = (sizeof(P) == 8 && lo) ? static_cast<uint32_t>(static_cast<uint64_t>(e[lo - 1].cum) >> 31) : 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < 2 * kRec2Ents; ++k) r.ent[k] = 0u;
+        if (cnt > kRec2Ents) {
+            r.meta = kRec2Overflow;
+            r.cum_end = static_cast<uint32_t>(cnt > 0xFFFFFFFFull ? 0xFFFFFFFFull : cnt);
+            ++novf;
+        } else {
+            r.meta = static_cast<uint32_t>(cnt);
+            for (uint64_t k = 0; k < cnt; ++k) {
+                r.ent[2 * k] = static_cast<uint32_t>(static_cast<uint64_t>(e[e0 + k].start));
+                r.ent[2 * k + 1] = static_cast<uint32_t>(static_cast<uint64_t>(e[e0 + k].cum));
+            }
+            r.cum_end = static_cast<uint32_t>(static_cast<uint64_t>(e[e0 + cnt].cum));   // (entry nr is the table's sentinel)
+        }
+        recs[i] = r;
+    }
+    novf = wave_sum(novf);
+    if ((threadIdx.x & (kWave - 1)) == 0 && novf && overflow) atomicAdd(overflow, novf);
+}
+
 // the phi directory: dir[b] = low word of # entries with pos < b << shift; super[b >> ss] = that count in full (ss == 0: none)
 template <typename KeyAt>
 __device__ __forceinline__ uint64_t count_below(KeyAt key_at, uint64_t m, uint64_t lim) {
@@ -470,6 +520,16 @@ int launch_run_dirs2(const void *ent, const uint64_t *first, const uint64_t *nru
     if (!total) return 0;
     hipLaunchKernelGGL(k_run_dirs2, dim3(grid_of(total)), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const u64pair *>(ent), first, nruns, doff, dshift, T, total,
                        static_cast<RunDir64 *>(dir));
+    return static_cast<int>(hipGetLastError());
+}
+int launch_run_recs2(uint32_t pos_bytes, const void *ent, const uint64_t *first, const uint64_t *nruns, const uint64_t *roff, const uint32_t *rshift, uint32_t T, uint64_t total,
+                     void *recs, unsigned long long *overflow, void *stream) {
+    if (!total) return 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (pos_bytes == 4) hipLaunchKernelGGL((k_run_recs2<uint32_t>), dim3(grid_of(total)), dim3(256), 0, st, static_cast<const RunEnt<uint32_t> *>(ent), first, nruns, roff, rshift, T, total,
+                                           static_cast<RunRec2 *>(recs), overflow);
+    else hipLaunchKernelGGL((k_run_recs2<uint64_t>), dim3(grid_of(total)), dim3(256), 0, st, static_cast<const RunEnt<uint64_t> *>(ent), first, nruns, roff, rshift, T, total,
+                            static_cast<RunRec2 *>(recs), overflow);
     return static_cast<int>(hipGetLastError());
 }
 int launch_phi_dir(uint32_t pos_bytes, const void *ent, uint64_t m, uint32_t shift, uint64_t nb, uint32_t *dir, uint32_t ss, uint64_t *super, void *stream) {

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(512, (V2 || sizeof(P) == 4) ? 4 : 3) void k_find_ra
     const RunRec *const *rec_tabs = nullptr;
     if constexpr (V2) {
         RBG_RUN_SEARCH2_SHARED;
-        S2 = stage_run_search2<P>(ix, s_tab_first, s_ent2, s_dir2, s_dyn);
+        S2 = stage_run_search2<P>(ix, s_tab_first, s_ent2, s_dir2, s_rec2, s_dyn);
         tab_first = s_tab_first;
     } else {
         RBG_RUN_SEARCH_SHARED(P, 8);   // 512-thread workgroups

@@ -105,7 +105,7 @@ __device__ __forceinline__ bool ftab_state(const DevIndex &ix, ByteCursor &rd, c
     const RunRec *const *rec_tabs = nullptr;                                                      \
     if constexpr (V2) {                                                                           \
         RBG_RUN_SEARCH2_SHARED;                                                                   \
-        S2 = stage_run_search2<P>(ix, s_tab_first, s_ent2, s_dir2, s_dyn);                        \
+        S2 = stage_run_search2<P>(ix, s_tab_first, s_ent2, s_dir2, s_rec2, s_dyn);                        \
         tab_first = s_tab_first;                                                                  \
     } else {                                                                                      \
         RBG_RUN_SEARCH_SHARED(P, WAVES);                                                          \

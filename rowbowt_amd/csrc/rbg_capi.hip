@@ -71,6 +71,7 @@ struct rbg_index {
         uint32_t depths_dropped_limit = 0;         // mask of depths a width limit left out (format 1: 2^32 entries)
         uint32_t phi_dir_dropped = 0;              // 1: format 1 left the phi directory out (2 GiB / r >= 2^31)
         uint64_t phi_slots = 0, phi_slot_bytes = 0;   // format 2 with phi slots (RBG_OPT_RUN_PHI): their number and bytes (slots + ordinals)
+        uint64_t rec_bytes[kMaxRunDepth] = {0, 0, 0, 0, 0}, rec_overflow[kMaxRunDepth] = {0, 0, 0, 0, 0};   // format 2 with bucket records (RBG_OPT_RUN_REC)
     } runs_report;
     // one-read host calls from concurrent threads are combined into one launch ("group commit", see Combiner below)
     struct Combiner {
@@ -134,6 +135,7 @@ std::atomic<int64_t> g_opt_tree_top_kb{48};   // LDS the staged top levels of th
 std::atomic<int64_t> g_opt_run_depths{env_opt("RBG_RUN_DEPTHS", 0, 0, (1 << kMaxRunDepth) - 1)};    // run-indexed layout: bit d - 1 = keep the k-mer depth d (0 = every other depth from the deepest down)
 std::atomic<int64_t> g_opt_run_fmt{env_opt("RBG_RUN_FMT", 2, 1, 2)};   // run-indexed layout: 1 = {P, P} pairs probed by quads of lanes (rounds 2-3), 2 = per-lane probes (rbg_dev.h DevRunTab2)
 std::atomic<int64_t> g_opt_run_phi{env_opt("RBG_RUN_PHI", 0, 0, 2)};   // run-indexed layout, format 2: 0 = automatic, 1 = phi over the sampled-position list (12-16 bytes per run), 2 = phi SLOTS of about n/r rows (about 54 bytes per run at 8-byte positions; one sector per step instead of two)
+std::atomic<int64_t> g_opt_run_rec{env_opt("RBG_RUN_REC", 0, 0, 2)};   // run-indexed layout, format 2: bucket records (rbg_dev.h RunRec2) -- 0 = automatic (when the replica with them stays within half the budget), 1 = off, 2 = on
 std::atomic<int64_t> g_opt_slot_bytes{16};    // 16: RankSlot; 64: RankSlot64 (experiment: rbg_dev.h)
 std::atomic<int64_t> g_opt_packed_reads{1};  // host-pointer calls: 0 bytes over PCIe, 1 (default) 2-bit codes for batches >= 4096, 2 always
 
@@ -1221,6 +1223,31 @@ int upload_tables_runs2(rbg_index *ix) {
     ix->dev.run_fill_shift = static_cast<uint32_t>(env_opt("RBG_RUN_FILL_SHIFT", kRunFillShift, 4, kRunFillShift));
     const uint32_t super_shift = static_cast<uint32_t>(env_opt("RBG_PHI_SUPER_SHIFT", kPhiSuperShift, 1, 24));
     const uint32_t max_shift = W ? ix->dev.run_fill_shift : 40u;
+    // BUCKET RECORDS (RBG_OPT_RUN_REC; rbg_dev.h RunRec2): one aligned 64-byte record per bucket of about three entries instead of
+    // the directory -- a rank is one sector.  Automatic: when all kept depths with their records (about 64 / 3 bytes per entry) and
+    // the rest of the replica stay within half the budget.  RBG_RUN_REC_PER: entries per bucket on average (default 2.5 inside the
+    // bucket; the one before them is held too).
+    const char *e_rp = std::getenv("RBG_RUN_REC_PER");
+    const double rec_target = e_rp && std::atof(e_rp) > 0 ? std::atof(e_rp) : 2.5;
+    bool use_recs = g_opt_run_rec.load() == 2;
+    if (g_opt_run_rec.load() == 0 && ix->hbm_budget) {
+        double nrec = 0;   // records of all kept depths at the bucket widths they would get (a sparse table's shift stops at max_shift: n >> 30 buckets at least)
+        for (uint32_t d = 0; d < D; ++d)
+            if (mask >> d & 1u)
+                for (const SymTable &t : *depth[d]) {
+                    uint32_t sh = 0;
+                    const double runs = static_cast<double>(std::max<uint64_t>(1, t.nruns));
+                    while (sh < max_shift && runs * static_cast<double>(uint64_t(2) << sh) <= rec_target * static_cast<double>(h.n)) ++sh;
+                    nrec += static_cast<double>((h.n >> sh) + 2);
+                }
+        const double with_recs = static_cast<double>(W ? runs_replica_bytes<uint64_t>(h, mask) : runs_replica_bytes<uint32_t>(h, mask)) + nrec * 64.0;
+        // (and only while the records are O(r): at most one per entry)
+        double entries_kept = 0;
+        for (uint32_t d = 0; d < D; ++d)
+            if (mask >> d & 1u)
+                for (const SymTable &t : *depth[d]) entries_kept += static_cast<double>(t.nruns + 1);
+        use_recs = with_recs <= 0.5 * static_cast<double>(ix->hbm_budget) && nrec <= entries_kept;
+    }
     std::vector<DevRunTab2> tabs;
     std::vector<DevRunTab> tabs1;   // (format 1's records of the same tables: rbg_info and the peer copies expect the array)
     int rc;
@@ -1307,6 +1334,35 @@ int upload_tables_runs2(rbg_index *ix) {
         }
         void *dirp = nullptr;
         const size_t dir_ent = W ? sizeof(RunDir64) : 4;
+        ix->dev.run_rec2[d] = nullptr;
+        if (use_recs) {
+            // the records' buckets: the widest with at most rec_target entries starting inside on average
+            for (size_t t = 0; t < T.size(); ++t) {
+                uint32_t sh = 0;
+                const double runs = static_cast<double>(std::max<uint64_t>(1, nr[t]));
+                while (sh < max_shift && runs * static_cast<double>(uint64_t(2) << sh) <= rec_target * static_cast<double>(h.n)) ++sh;
+                dshift[t] = sh;
+                doff[t + 1] = doff[t] + (h.n >> sh) + 2;
+            }
+            void *recp = nullptr;
+            if ((rc = dev_reserve(ix, doff[T.size()] * sizeof(RunRec2) + 64, &recp))) return rc;
+            TmpDev tmp, ovf;
+            const size_t nt = T.size(), bytes = (3 * nt + 1) * 8 + nt * 4;
+            if ((rc = tmp.alloc(bytes)) || (rc = ovf.alloc(8))) return rc;
+            HIP_TRY(hipMemset(ovf.p, 0, 8));
+            uint64_t *t_first = tmp.as<uint64_t>(), *t_nr = t_first + nt, *t_doff = t_nr + nt;
+            uint32_t *t_sh = reinterpret_cast<uint32_t *>(t_doff + nt + 1);
+            HIP_TRY(hipMemcpy(t_first, first.data(), nt * 8, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(t_nr, nr.data(), nt * 8, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(t_doff, doff.data(), (nt + 1) * 8, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(t_sh, dshift.data(), nt * 4, hipMemcpyHostToDevice));
+            HIP_TRY(static_cast<hipError_t>(launch_run_recs2(sizeof(P), abs_ent, t_first, t_nr, t_doff, t_sh, static_cast<uint32_t>(nt), doff[nt], recp, ovf.as<unsigned long long>(), nullptr)));
+            unsigned long long novf = 0;
+            HIP_TRY(hipMemcpy(&novf, ovf.p, 8, hipMemcpyDeviceToHost));
+            ix->dev.run_rec2[d] = static_cast<const RunRec2 *>(recp);
+            rep.rec_bytes[d] = doff[T.size()] * sizeof(RunRec2);
+            rep.rec_overflow[d] = novf;
+        } else {
         if ((rc = dev_reserve(ix, doff[T.size()] * dir_ent + 16, &dirp))) return rc;
         {
             TmpDev tmp;
@@ -1323,6 +1379,7 @@ int upload_tables_runs2(rbg_index *ix) {
             HIP_TRY(hipDeviceSynchronize());
         }
         rep.dir_bytes[d] = doff[T.size()] * dir_ent;
+        }
         ix->dev.run_dir2[d] = dirp;
         // ---- the entries and samples in their final form ----
         if constexpr (W) {
@@ -1341,7 +1398,7 @@ int upload_tables_runs2(rbg_index *ix) {
         } else {
             ix->dev.run_ent2[d] = abs_ent;
             ix->dev.run_samp[d] = abs_samp;
-            ix->dev.run_dir[d] = static_cast<const uint32_t *>(dirp);   // (format 1's kernels could read the same arrays)
+            ix->dev.run_dir[d] = use_recs ? nullptr : static_cast<const uint32_t *>(dirp);   // (format 1's kernels could read the same arrays)
         }
         if (std::getenv("RBG_VERBOSE")) {
             size_t f = 0, tt = 0;
@@ -1351,7 +1408,7 @@ int upload_tables_runs2(rbg_index *ix) {
         }
         for (size_t t = 0; t < T.size(); ++t) {
             tabs.push_back(DevRunTab2{T[t].F, first[t], doff[t], dshift[t], 0u});
-            tabs1.push_back(DevRunTab{T[t].F, first[t], static_cast<uint32_t>(doff[t]), dshift[t]});
+            tabs1.push_back(DevRunTab{T[t].F, first[t], static_cast<uint32_t>(std::min<uint64_t>(doff[t], 0xFFFFFFFFull)), dshift[t]});
         }
         tabs.push_back(DevRunTab2{0, E2, 0, 0u, 0u});   // closing record
         tabs1.push_back(DevRunTab{0, E2, 0u, 0u});
@@ -1373,7 +1430,7 @@ int upload_tables_runs2(rbg_index *ix) {
     ix->dev.run_depth_mask = mask;
     ix->run_depth_mask = mask;
     rep.depth_mask_kept = mask;
-    rep.rank_dirs = 1;
+    rep.rank_dirs = use_recs ? 0 : 1;
     ix->dev.trees = nullptr;
     ix->dev.tree_top = nullptr;
     ix->dev.tree_top_n = 0;
@@ -2512,6 +2569,9 @@ int rbg_set_default_option(int opt, int64_t value) {
         case RBG_OPT_RUN_PHI:
             if (value < 0 || value > 2) return RBG_EARG;
             g_opt_run_phi = value; return RBG_OK;
+        case RBG_OPT_RUN_REC:
+            if (value < 0 || value > 2) return RBG_EARG;
+            g_opt_run_rec = value; return RBG_OK;
         default: return RBG_EARG;
     }
     });
@@ -2537,6 +2597,7 @@ int rbg_get_default_option(int opt, int64_t *value) {
         case RBG_OPT_RUN_DEPTHS: *value = g_opt_run_depths.load(); return RBG_OK;
         case RBG_OPT_RUN_FMT: *value = g_opt_run_fmt.load(); return RBG_OK;
         case RBG_OPT_RUN_PHI: *value = g_opt_run_phi.load(); return RBG_OK;
+        case RBG_OPT_RUN_REC: *value = g_opt_run_rec.load(); return RBG_OK;
         default: return RBG_EARG;
     }
     });
@@ -2931,6 +2992,7 @@ int rbg_layout_info(const rbg_index *ix, rbg_layout_info_t *out, uint64_t out_by
         for (int d = 0; d < kMaxRunDepth; ++d) { v.entries[d] = r.entries[d]; v.fillers[d] = r.fillers[d]; v.dir_bytes[d] = r.dir_bytes[d]; }
         v.phi_entries = r.phi_entries; v.phi_fillers = r.phi_fillers; v.phi_dir_bytes = r.phi_dir_bytes; v.phi_dir_shift = r.phi_dir_shift;
         v.phi_slots = r.phi_slots; v.phi_slot_bytes = r.phi_slot_bytes;
+        for (int d = 0; d < kMaxRunDepth; ++d) { v.rec_bytes[d] = r.rec_bytes[d]; v.rec_overflow[d] = r.rec_overflow[d]; }
     }
     std::memcpy(out, &v, static_cast<size_t>(std::min<uint64_t>(out_bytes, sizeof(v))));
     return RBG_OK;
@@ -4473,7 +4535,7 @@ int replicate_finish(rbg_index *src, ReplicaJob &job) {
     for (int t = 0; t < kMaxRunDepth; ++t) reloc.fix(d.run_samp[t]);
     for (int t = 0; t < kMaxRunDepth; ++t) reloc.fix(d.run_rec[t]);
     reloc.fix(d.run_tabs2); reloc.fix(d.phi_super);
-    for (int t = 0; t < kMaxRunDepth; ++t) { reloc.fix(d.run_ent2[t]); reloc.fix(d.run_dir2[t]); }
+    for (int t = 0; t < kMaxRunDepth; ++t) { reloc.fix(d.run_ent2[t]); reloc.fix(d.run_dir2[t]); reloc.fix(d.run_rec2[t]); }
     reloc.fix(d.phi_tree.ent);
     for (int l = 0; l < kMaxTreeLevels; ++l) reloc.fix(d.phi_tree.lvl[l]);
     r->dev = d;

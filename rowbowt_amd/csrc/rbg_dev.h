@@ -240,6 +240,23 @@ struct DevRunTab2 {
 };
 static_assert(sizeof(DevRunTab2) == 32, "two 16-byte LDS reads per record");
 struct RunDir64 { uint32_t count, hi; };   // directory entry at 8-byte positions (4-byte positions: the count alone)
+// BUCKET RECORDS of format 2 (RBG_OPT_RUN_REC; DevIndex::run_rec2): the directory entry and the entries it names, fused into ONE
+// aligned 64-byte record per bucket of a table, direct-addressed by (position >> shift) -- a rank is then one sector instead of a
+// directory sector plus the 1.6 sectors an unaligned stretch of the run list takes, and at every scale K1/K2 on this layout are bound
+// by exactly that sector count.  The record holds up to kRec2Ents entries {start, cum} (low words at 8-byte positions): the last
+// entry that starts before the bucket, then the ones that start inside it; `cum_end` is the cum of the entry after the last one
+// held (the length of its run).  A bucket with more candidates than that says so and the lane goes through the run list
+// (e0, cum_end = their number).  About 64 / 3 bytes per entry: the price of the speed, off when the budget is short.
+constexpr uint32_t kRec2Ents = 6;
+constexpr uint32_t kRec2Overflow = 8u;   // meta bit 3
+struct alignas(64) RunRec2 {
+    uint32_t e0;        // index (relative to the table's first entry) of the first entry held -- or of the first candidate of an overflowing bucket
+    uint32_t hi;        // 8-byte positions: (cum of the entry before the bucket) >> 31 (RunDir64::hi); 0 otherwise
+    uint32_t meta;      // bits 0-2: entries held (0..6); bit 3: overflow (none held)
+    uint32_t cum_end;   // cum of the entry after the last one held; overflow: the number of candidates from e0 on
+    uint32_t ent[2 * kRec2Ents];
+};
+static_assert(sizeof(RunRec2) == 64, "one sector per bucket");
 constexpr uint32_t kRunFillShift = 30;     // fillers every 2^30 rows; directory shifts stay <= 30 at 8-byte positions (DevIndex::run_fill_shift;
                                            // RBG_RUN_FILL_SHIFT lowers it so that tests meet fillers on small indexes)
 // the phi list of format 2 at 8-byte positions: {sampled position mod 2^32, base} with fillers likewise (a filler at
@@ -323,6 +340,7 @@ struct DevIndex {
     const void *run_ent2[kMaxRunDepth];     // uint2 {start, cum} (low words at 8-byte positions) + 2 spare entries
     const void *run_dir2[kMaxRunDepth];     // uint32_t counts (4-byte positions) or RunDir64 (8-byte positions)
     const DevRunTab2 *run_tabs2;            // run_ntabs records, depth d's from run_tab_first[d - 1]
+    const RunRec2 *run_rec2[kMaxRunDepth];  // per depth: the tables' bucket records back to back (DevRunTab2::dir_off / dir_shift then address them); nullptr = directories
     const uint64_t *phi_super;              // 8-byte positions: full counts every 2^phi_super_shift buckets
     uint64_t phi_m;                         // entries of the phi list (fillers included); entry phi_m is the sentinel
     uint64_t phi_last_pos, phi_last_base;   // the last sampled position and its base (circular predecessor, toehold_sa.hpp:59,65)
@@ -502,6 +520,8 @@ int launch_pack_pairs32(const void *ent, uint64_t m, uint64_t spare, void *out, 
 int launch_pack_phi12(const void *ent, uint64_t m, uint64_t spare, void *out, void *stream);
 int launch_run_dirs2(const void *ent, const uint64_t *first, const uint64_t *nruns, const uint64_t *doff, const uint32_t *dshift, uint32_t T, uint64_t total,
                      void *dir, void *stream);
+int launch_run_recs2(uint32_t pos_bytes, const void *ent, const uint64_t *first, const uint64_t *nruns, const uint64_t *roff, const uint32_t *rshift, uint32_t T, uint64_t total,
+                     void *recs, unsigned long long *overflow, void *stream);
 int launch_phi_dir(uint32_t pos_bytes, const void *ent, uint64_t m, uint32_t shift, uint64_t nb, uint32_t *dir, uint32_t ss, uint64_t *super, void *stream);
 int launch_build_phi_slots(uint32_t pos_bytes, bool packed, const void *ent, uint64_t r, uint64_t n, uint32_t shift, void *slots, uint32_t *ord,
                            unsigned long long *overflow, void *stream);

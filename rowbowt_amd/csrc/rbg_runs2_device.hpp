@@ -23,6 +23,7 @@ struct RunSearch2 {
     const uint32_t *tab_first;    // LDS [kMaxRunDepth + 1]: first record of each depth
     const void *const *ent;       // LDS [kMaxRunDepth]: entry arrays per depth
     const void *const *dir;       // LDS [kMaxRunDepth]: directory arrays per depth
+    const void *const *rec;       // LDS [kMaxRunDepth]: bucket records per depth (nullptr: directories)
     uint32_t fill;                // DevIndex::run_fill_shift
 };
 
@@ -30,6 +31,7 @@ struct RunSearch2 {
     __shared__ uint32_t s_tab_first[kMaxRunDepth + 1];                    \
     __shared__ const void *s_ent2[8];                                     \
     __shared__ const void *s_dir2[8];                                     \
+    __shared__ const void *s_rec2[8];                                     \
     extern __shared__ __align__(16) unsigned char s_dyn[]
 
 inline size_t run_search2_lds(const DevIndex &ix) { return static_cast<size_t>(ix.run_ntabs) * sizeof(DevRunTab2) + 16; }
@@ -37,11 +39,12 @@ inline size_t run_search2_lds(const DevIndex &ix) { return static_cast<size_t>(i
 // fills the arrays of RBG_RUN_SEARCH2_SHARED and returns the view of them; ends with __syncthreads()
 template <typename P>
 __device__ __forceinline__ RunSearch2<P> stage_run_search2(const DevIndex &ix, uint32_t *s_tab_first, const void **s_ent2, const void **s_dir2,
-                                                           unsigned char *s_dyn) {
+                                                           const void **s_rec2, unsigned char *s_dyn) {
     DevRunTab2 *s_tab = reinterpret_cast<DevRunTab2 *>(s_dyn);
     if (threadIdx.x < 8) {
         s_ent2[threadIdx.x] = threadIdx.x < static_cast<uint32_t>(kMaxRunDepth) ? ix.run_ent2[threadIdx.x] : nullptr;
         s_dir2[threadIdx.x] = threadIdx.x < static_cast<uint32_t>(kMaxRunDepth) ? ix.run_dir2[threadIdx.x] : nullptr;
+        s_rec2[threadIdx.x] = threadIdx.x < static_cast<uint32_t>(kMaxRunDepth) ? static_cast<const void *>(ix.run_rec2[threadIdx.x]) : nullptr;
     }
     for (uint32_t t = threadIdx.x; t <= static_cast<uint32_t>(kMaxRunDepth); t += blockDim.x) s_tab_first[t] = ix.run_tab_first[t];
     {   // the records as 16-byte words (two per record)
@@ -51,7 +54,7 @@ __device__ __forceinline__ RunSearch2<P> stage_run_search2(const DevIndex &ix, u
     }
     __syncthreads();
     RunSearch2<P> S;
-    S.tab = s_tab; S.tab_first = s_tab_first; S.ent = s_ent2; S.dir = s_dir2;
+    S.tab = s_tab; S.tab_first = s_tab_first; S.ent = s_ent2; S.dir = s_dir2; S.rec = s_rec2;
     S.fill = ix.run_fill_shift;
     return S;
 }
@@ -162,6 +165,44 @@ __device__ __forceinline__ void lane_scan(const char *__restrict__ tent, const u
     }
 }
 
+// One bucket record in registers (rbg_dev.h RunRec2) and the rank of a position of its bucket: c = # entries of the table below the
+// position counted from the record's first (0: none below at all), lo32 = the rank's low word, inside = the position's left
+// neighbour lies in that run, e = the entry's index relative to the table's first.  An overflowing bucket goes through the run list.
+struct LaneRec {
+    uint32_t w[16];
+    __device__ __forceinline__ void load(const void *__restrict__ recs, const uint64_t at) {
+        const RBG_GLOBAL u32x4 *p = as_global<u32x4>(static_cast<const void *>(static_cast<const char *>(recs) + at * 64u));
+        const u32x4 a = p[0], b = p[1], c = p[2], d = p[3];
+        w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+        w[8] = c.x; w[9] = c.y; w[10] = c.z; w[11] = c.w; w[12] = d.x; w[13] = d.y; w[14] = d.z; w[15] = d.w;
+    }
+    __device__ __forceinline__ void rank(const char *__restrict__ tent, const uint32_t a_lo, const uint32_t qa, uint32_t &c, uint32_t &lo32, bool &inside,
+                                         uint64_t &e, uint32_t &rounds, uint32_t &ents) const {
+        LaneQ Q;
+        Q.qa = qa;
+        uint32_t p = w[0];
+        if (w[2] & kRec2Overflow) {
+            uint32_t z = w[3];
+            if (z > kLaneMaxZ) lane_narrow(tent, a_lo, qa, p, z, kLaneMaxZ, 8u, rounds);
+            Q.zlim = z;
+            lane_scan(tent, p, z, a_lo, Q, nullptr);
+            ents += z + 1u;
+        } else {
+            const uint32_t n = w[2] & 7u;
+            Q.zlim = n;
+#pragma unroll
+            for (uint32_t k = 0; k < kRec2Ents; ++k) Q.feed(k, w[4 + 2 * k] - a_lo, w[5 + 2 * k]);
+            Q.feed(kRec2Ents, 0u, w[3]);                 // (never below: closes the last run held when all six are)
+            if (n < kRec2Ents && Q.c == n && n) Q.kn = w[3];   // the last entry held is the answer: its run ends at cum_end
+        }
+        c = Q.c;
+        const uint32_t dd = Q.qa - Q.ks, len = Q.kn - Q.kc;
+        lo32 = Q.kc + (dd < len ? dd : len);
+        inside = dd <= len;
+        e = static_cast<uint64_t>(p) + Q.c - 1u;
+    }
+};
+
 // What the instrumented instantiations count on this format (the eight sums of SearchStat): [kStSteps] search steps,
 // [kStSlots] directory gathers (two neighbouring entries: 8 or 16 bytes), [kStDense] run-list entries the scans needed
 // (8 bytes each), [kStSearch] narrowing rounds (seven 4-byte pivots each), the rest as in rbg_runs_device.hpp.
@@ -176,13 +217,36 @@ __device__ __forceinline__ void lane_lf2(const RunSearch2<P> &S, const uint32_t 
     out.F = R.F;
     const uint32_t sh = R.dir_shift;
     const uint64_t b0 = q0 >> sh, b1 = q1 >> sh;
+    const char *__restrict__ tent = static_cast<const char *>(S.ent[d]) + R.first * 8u;
+    if (const void *__restrict__ recs = S.rec[d]) {   // ---- bucket records: one aligned 64-byte record per position (rbg_dev.h RunRec2) ----
+        const uint32_t al0 = W ? static_cast<uint32_t>(b0 << sh) - (1u << S.fill) : 0u;
+        const uint32_t al1 = W ? static_cast<uint32_t>(b1 << sh) - (1u << S.fill) : 0u;
+        LaneRec r0, r1;
+        r0.load(recs, R.dir_off + b0);
+        if (b1 != b0) r1.load(recs, R.dir_off + b1);
+        if (STATS) st[kStSlots] += b1 != b0 ? 2 : 1;
+        uint32_t c0, lo0, c1, lo1, h1;
+        uint64_t e1;
+        bool in0, in1;
+        uint32_t rounds = 0, ents = 0;
+        uint64_t e0;
+        r0.rank(tent, al0, static_cast<uint32_t>(q0) - al0, c0, lo0, in0, e0, rounds, ents);
+        if (b1 != b0) { r1.rank(tent, al1, static_cast<uint32_t>(q1) - al1, c1, lo1, in1, e1, rounds, ents); h1 = r1.w[1]; }
+        else { r0.rank(tent, al0, static_cast<uint32_t>(q1) - al0, c1, lo1, in1, e1, rounds, ents); h1 = r0.w[1]; }
+        if (STATS) { st[kStSearch] += rounds; st[kStDense] += ents; st[kStSteps] += 1; }
+        const uint64_t y0 = static_cast<uint64_t>(r0.w[1]) << 31, y1 = static_cast<uint64_t>(h1) << 31;
+        out.c_before = c0 ? (W ? y0 + static_cast<uint32_t>(lo0 - static_cast<uint32_t>(y0)) : lo0) : 0;
+        out.c_upto = c1 ? (W ? y1 + static_cast<uint32_t>(lo1 - static_cast<uint32_t>(y1)) : lo1) : 0;
+        out.inside = c1 != 0 && in1;
+        out.samp_e = R.first + e1;
+        return;
+    }
     const void *__restrict__ dir = S.dir[d];
     uint32_t a0, h0, e0, a1, h1, e1;
     load_dir2<P>(dir, R.dir_off + b0, a0, h0, e0);
     a1 = a0; h1 = h0; e1 = e0;
     if (b1 != b0) load_dir2<P>(dir, R.dir_off + b1, a1, h1, e1);
     if (STATS) st[kStSlots] += b1 != b0 ? 2 : 1;
-    const char *__restrict__ tent = static_cast<const char *>(S.ent[d]) + R.first * 8u;
     uint32_t p0 = a0 ? a0 - 1u : 0u, z0 = e0 - p0;     // candidates: the entries of the bucket and the one before them
     uint32_t p1 = a1 ? a1 - 1u : 0u, z1 = e1 - p1;
     // anchors (8-byte positions): every candidate of bucket b lies above (b << sh) - 2^fill (fillers, rbg_dev.h)

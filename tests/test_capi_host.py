@@ -153,18 +153,18 @@ def test_tuning_options_are_range_checked():
           capi.OPT_POS_BYTES: [4, 8, 0], capi.OPT_KMER_STEPS: [1, 3, 5], capi.OPT_HBM_BUDGET_MB: [1, 0], capi.OPT_FTAB_K: [0, 16, -1],
           capi.OPT_PACKED_READS: [0, 2, 1], capi.OPT_DEEP_BUCKET_SHIFT: [9, 12, -1], capi.OPT_DENSE_OVERFLOW: [0, 1],
           capi.OPT_RANK_LAYOUT: [1, 2, 0], capi.OPT_TREE_TOP_KB: [0, 96, 48], capi.OPT_SLOT_BYTES: [64, 16], capi.OPT_RUN_DEPTHS: [0x15, 31, 0],
-          capi.OPT_RUN_FMT: [1, 2], capi.OPT_RUN_PHI: [1, 2, 0]}
+          capi.OPT_RUN_FMT: [1, 2], capi.OPT_RUN_PHI: [1, 2, 0], capi.OPT_RUN_REC: [1, 2, 0]}
     bad = {capi.OPT_BLOCK_THREADS: [0, 100, 512], capi.OPT_RANK_BUCKET_SHIFT: [-2, 13], capi.OPT_PHI_BUCKET_SHIFT: [-2, 9],
            capi.OPT_POS_BYTES: [2, 16], capi.OPT_KMER_STEPS: [0, 6], capi.OPT_HBM_BUDGET_MB: [-1], capi.OPT_FTAB_K: [-2, 17],
            capi.OPT_PACKED_READS: [-1, 3], capi.OPT_DEEP_BUCKET_SHIFT: [-2, 13], capi.OPT_DENSE_OVERFLOW: [-1, 2],
            capi.OPT_RANK_LAYOUT: [-1, 3], capi.OPT_TREE_TOP_KB: [-1, 97], capi.OPT_SLOT_BYTES: [0, 32, 128], capi.OPT_RUN_DEPTHS: [-1, 32],
-           capi.OPT_RUN_FMT: [0, 3], capi.OPT_RUN_PHI: [-1, 3]}
+           capi.OPT_RUN_FMT: [0, 3], capi.OPT_RUN_PHI: [-1, 3], capi.OPT_RUN_REC: [-1, 3]}
     for opt, vals in ok.items():
         for v in bad[opt]:
             assert L.rbg_set_default_option(opt, v) == -4, (opt, v)   # RBG_EARG
         for v in vals:                                                 # the last value of each list is the default
             assert L.rbg_set_default_option(opt, v) == 0, (opt, v)
-    assert L.rbg_set_default_option(0, 1) == -4 and L.rbg_set_default_option(17, 1) == -4
+    assert L.rbg_set_default_option(0, 1) == -4 and L.rbg_set_default_option(18, 1) == -4
     assert all(capi.get_default_option(o) == vals[-1] for o, vals in ok.items())
 
 

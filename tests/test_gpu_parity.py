@@ -567,8 +567,10 @@ def test_instrumented_kernels_and_32_bit_locations(synth, layout):
         lens = (off[1:] - off[:-1]).astype(np.int64)
         assert symbols >= int(lens[matched].sum())
         assert (resamp > 0) == toe or resamp == 0
-        if layout == capi.LAYOUT_RUNS:
+        if layout == capi.LAYOUT_RUNS and sum(rb.layout_info().rec_bytes) == 0:
             assert dense >= 2 * steps - N            # at least two entries per probe (one probe per step when lo and hi + 1 share it)
+        elif layout == capi.LAYOUT_RUNS:             # bucket records (the library's choice on an index this small): one or two records per step, entries only for crowded buckets
+            assert steps <= slots <= 2 * steps
     # locations: u64, instrumented u64, u32 -- ordered walk
     d_loc_off = torch.empty(N + 1, dtype=torch.int64, device=dev)
     tmp_bytes = L.rbg_locate_plan_tmp_bytes(N)
@@ -1857,7 +1859,9 @@ def _with_layout(layout, top_kb, build):
                                                             (0, 1, 0, 3, None, 1), (0, 48, -1, 1, "1", 1), (8, 1, -1, 2, "40", 1), (0, 0, 0, 1, "8", 1),
                                                             (8, 48, 0, 5, "3", 1), (0, 48, 0, 5, "8", 1),
                                                             (8, 48, 0, 1, None, 2), (0, 48, 3, 3, None, 2), (8, 48, 3, 2, None, 2), (0, 48, 0, 4, None, 2),
-                                                            (8, 48, -1, 4, None, 2), (0, 48, -1, 5, None, 22), (8, 48, -1, 5, None, 22), (8, 48, 0, 3, None, 22)])
+                                                            (8, 48, -1, 4, None, 2), (0, 48, -1, 5, None, 22), (8, 48, -1, 5, None, 22), (8, 48, 0, 3, None, 22),
+                                                            (0, 48, -1, 5, None, 23), (8, 48, -1, 5, None, 23), (8, 48, 0, 4, None, 23), (0, 48, 3, 1, None, 23),
+                                                            (0, 48, -1, 5, None, 24), (8, 48, -1, 5, None, 24), (8, 48, 3, 2, None, 24)])
 def test_run_indexed_layout(synth, pos_bytes, top_kb, fk, ks, rec, fmt):
     """RBG_LAYOUT_RUNS (k_runs.hip): space proportional to r, rank and phi as wave-cooperative predecessor searches
     over the run lists (rle_string.hpp:131-161, toehold_sa.hpp:56-72), k-mer steps through one clamped search per
@@ -1868,9 +1872,11 @@ def test_run_indexed_layout(synth, pos_bytes, top_kb, fk, ks, rec, fmt):
     S = synth
     # fmt 22 = format 2 with phi SLOTS (RBG_OPT_RUN_PHI = 2: the slot layout's direct-addressed phi records at buckets of about n / r rows);
     # plain 2 pins phi to the list of sampled positions and its directory
-    phi_slots = fmt == 22
-    fmt = 2 if fmt == 22 else fmt
+    # 23 / 24 = the same two with BUCKET RECORDS instead of the rank directories (RBG_OPT_RUN_REC = 2: one aligned 64-byte record per bucket)
+    phi_slots, recs = fmt in (22, 24), fmt in (23, 24)
+    fmt = 2 if fmt in (22, 23, 24) else fmt
     ra.set_default_option(capi.OPT_RUN_PHI, 2 if phi_slots else 1)
+    ra.set_default_option(capi.OPT_RUN_REC, 2 if recs else 1)
     ra.set_default_option(capi.OPT_POS_BYTES, pos_bytes)
     ra.set_default_option(capi.OPT_FTAB_K, fk)
     ra.set_default_option(capi.OPT_KMER_STEPS, ks)
@@ -1888,6 +1894,7 @@ def test_run_indexed_layout(synth, pos_bytes, top_kb, fk, ks, rec, fmt):
     finally:
         ra.set_default_option(capi.OPT_RUN_FMT, 2)
         ra.set_default_option(capi.OPT_RUN_PHI, 0)
+        ra.set_default_option(capi.OPT_RUN_REC, 0)
         ra.set_default_option(capi.OPT_RUN_DEPTHS, 0)
         ra.set_default_option(capi.OPT_POS_BYTES, 0)
         ra.set_default_option(capi.OPT_FTAB_K, -1)
@@ -1904,7 +1911,8 @@ def test_run_indexed_layout(synth, pos_bytes, top_kb, fk, ks, rec, fmt):
     assert li.run_fmt == fmt and li.depths_dropped_budget == 0 and li.depths_dropped_limit == 0 and li.phi_directory_dropped == 0
     assert [d + 1 for d in range(5) if li.depth_mask_kept >> d & 1] == [1] + [d for d in lists]
     if fmt == 2:
-        assert li.rank_directories == 1 and li.phi_entries == len(S.heads) and sum(li.fillers) == 0
+        assert li.rank_directories == (0 if recs else 1) and li.phi_entries == len(S.heads) and sum(li.fillers) == 0
+        assert all((li.rec_bytes[d] > 0) == (recs and bool(li.depth_mask_kept >> d & 1)) for d in range(5)) and (not recs or sum(li.rec_overflow) > 0)
         assert (li.phi_slots > 0 and li.phi_directory == 0 and rb.info().phi_slots == li.phi_slots) if phi_slots else (li.phi_slots == 0 and li.phi_directory == 1)
         assert all((li.entries[d] > 0) == bool(li.depth_mask_kept >> d & 1) for d in range(5))
     _run_indexed_checks(S, rb)
@@ -1963,9 +1971,10 @@ def _run_indexed_checks(S, rb):
     o.close()
 
 
+@pytest.mark.parametrize("recs", [False, True])
 @pytest.mark.parametrize("fill_shift,super_shift,ks,depths,dir_runs,phi_per", [(6, 2, 5, 0, None, None), (4, 1, 3, 0x7, "1", "0.5"), (9, 5, 1, 0, "16", "4"),
                                                                                 (5, 3, 5, 0x1F, "40", "9")])
-def test_run_indexed_format2_fillers_and_super_counts(synth, fill_shift, super_shift, ks, depths, dir_runs, phi_per):
+def test_run_indexed_format2_fillers_and_super_counts(synth, fill_shift, super_shift, ks, depths, dir_runs, phi_per, recs):
     """Format 2 at 8-byte positions stores the LOW WORDS of {start, cum} and of the sampled positions; what makes that exact
     (rbg_dev.h DevRunTab2) is (a) filler entries wherever two entries of a table lie 2^fill_shift rows or more apart, (b)
     directory buckets no wider than that, (c) the rank's high part in the directory, (d) 64-bit super counts under the phi
@@ -1979,6 +1988,9 @@ def test_run_indexed_format2_fillers_and_super_counts(synth, fill_shift, super_s
     ra.set_default_option(capi.OPT_KMER_STEPS, ks)
     ra.set_default_option(capi.OPT_RUN_DEPTHS, depths)
     ra.set_default_option(capi.OPT_RUN_PHI, 1)    # (phi over the list of sampled positions: the structure that has fillers and super counts)
+    ra.set_default_option(capi.OPT_RUN_REC, 2 if recs else 1)   # bucket records over the same filler-laden lists (dir_runs then sets THEIR bucket width)
+    if recs and dir_runs:
+        os.environ["RBG_RUN_REC_PER"] = dir_runs
     os.environ["RBG_RUN_FILL_SHIFT"] = str(fill_shift)
     os.environ["RBG_PHI_SUPER_SHIFT"] = str(super_shift)
     if dir_runs:
@@ -1992,7 +2004,8 @@ def test_run_indexed_format2_fillers_and_super_counts(synth, fill_shift, super_s
         ra.set_default_option(capi.OPT_KMER_STEPS, 5)
         ra.set_default_option(capi.OPT_RUN_DEPTHS, 0)
         ra.set_default_option(capi.OPT_RUN_PHI, 0)
-        for k in ("RBG_RUN_FILL_SHIFT", "RBG_PHI_SUPER_SHIFT", "RBG_RANK_DIR_RUNS", "RBG_PHI_DIR_PER"):
+        ra.set_default_option(capi.OPT_RUN_REC, 0)
+        for k in ("RBG_RUN_FILL_SHIFT", "RBG_PHI_SUPER_SHIFT", "RBG_RANK_DIR_RUNS", "RBG_PHI_DIR_PER", "RBG_RUN_REC_PER"):
             os.environ.pop(k, None)
     li = rb.layout_info()
     assert li.run_fmt == 2 and li.fill_shift == fill_shift and rb.info().pos_bytes == 8
@@ -2043,7 +2056,7 @@ def test_run_indexed_format1_limits_are_loud(synth, capfd):
     rb.close(); rb2.close(); o.close()
 
 
-@pytest.mark.parametrize("pos_bytes,rec,dir_runs", [(0, None, None), (8, None, "64"), (0, None, "64"), (0, "6", None), (8, "3", None)])
+@pytest.mark.parametrize("pos_bytes,rec,dir_runs", [(0, None, None), (8, None, "64"), (0, None, "64"), (0, "6", None), (8, "3", None), (0, "fmt2", None), (8, "fmt2", "64")])
 def test_run_indexed_crowded_buckets(pos_bytes, rec, dir_runs):
     """Directory buckets with a hundred and more runs (k_runs.hip: narrowing rounds, one after the other when the
     directory is coarse -- dir_runs = RBG_RANK_DIR_RUNS; probes whose sixteen candidates all lie below the position;
@@ -2071,16 +2084,24 @@ def test_run_indexed_crowded_buckets(pos_bytes, rec, dir_runs):
         crowded = max(crowded, int(np.bincount(st >> sh).max()))
     assert crowded > (256 if dir_runs else 64), crowded   # one narrowing round at least; two with the coarse directory
     ra.set_default_option(capi.OPT_POS_BYTES, pos_bytes)
-    if rec is not None:
+    if rec == "fmt2":      # format 2's bucket records: the crowded buckets overflow them and go through the run list (narrowed by the lane)
+        ra.set_default_option(capi.OPT_RUN_REC, 2)
+        if dir_runs is not None:
+            os.environ["RBG_RUN_REC_PER"] = dir_runs
+    elif rec is not None:
         os.environ["RBG_RANK_REC"] = rec
+    else:
+        ra.set_default_option(capi.OPT_RUN_REC, 1)
     if dir_runs is not None:
         os.environ["RBG_RANK_DIR_RUNS"] = dir_runs
     try:
         rb = _with_layout(capi.LAYOUT_RUNS, 48, lambda: ra.RowBowt.from_runs(heads, lens, ssa, esa, device=0))
     finally:
         ra.set_default_option(capi.OPT_POS_BYTES, 0)
+        ra.set_default_option(capi.OPT_RUN_REC, 0)
         os.environ.pop("RBG_RANK_REC", None)
         os.environ.pop("RBG_RANK_DIR_RUNS", None)
+        os.environ.pop("RBG_RUN_REC_PER", None)
     o = orc.Oracle.from_runs(heads, lens, ssa, esa)
     assert rb.info().rank_layout == capi.LAYOUT_RUNS and rb.info().pos_bytes == (pos_bytes or 4)
     reads = []
@@ -2253,7 +2274,7 @@ def test_run_indexed_layout_budget_leaves_middle_depths_out():
     rng = np.random.default_rng(41)
     heads, lens, ssa, esa, n = _random_run_index(rng, 1_000_000, 200)
     def build():   # (without the device ftab: the budget is about the run lists; phi over the list: phi slots are the budget's to give, too)
-        with capi.default_option(capi.OPT_FTAB_K, 0), capi.default_option(capi.OPT_RUN_DEPTHS, depths[0]), capi.default_option(capi.OPT_RUN_PHI, 1):
+        with capi.default_option(capi.OPT_FTAB_K, 0), capi.default_option(capi.OPT_RUN_DEPTHS, depths[0]), capi.default_option(capi.OPT_RUN_PHI, 1), capi.default_option(capi.OPT_RUN_REC, 1):
             return _with_layout(capi.LAYOUT_RUNS, 48, lambda: ra.RowBowt.from_runs(heads, lens, ssa, esa, device=0))
     depths = [0x1F]   # asked for: all five, unless stated
     full = build()
