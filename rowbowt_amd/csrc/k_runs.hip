@@ -50,7 +50,7 @@ struct PackedBits {   // per-lane reader of a packed read: peek / drop of up to 
 
 // V2: format 2 (rbg_runs2_device.hpp): every lane answers its own two ranks; the same steps in the same order
 template <typename P, bool TOEHOLD, bool PACKED = false, bool STATS = false, bool V2 = false>
-__global__ __launch_bounds__(512, (V2 || sizeof(P) == 4) ? 4 : 3) void k_find_range_runs(const DevIndex ix, const void *__restrict__ src_a,
+__global__ __launch_bounds__(512, STATS ? 2 : (V2 || sizeof(P) == 4) ? 4 : 3) void k_find_range_runs(const DevIndex ix, const void *__restrict__ src_a,
                                                         const void *__restrict__ src_b, const uint64_t N,
                                                         uint64_t *__restrict__ lo_out, uint64_t *__restrict__ hi_out,
                                                         uint64_t *__restrict__ ss_out, unsigned long long *__restrict__ stats,

@@ -239,8 +239,10 @@ __global__ __launch_bounds__(512, (V2 || sizeof(P) == 4) ? 4 : 3) void k_find_ra
 // ---- greedy seeding: RowBowt::get_seeds_greedy_w_sample (rowbowt.hpp:222-256) reduced on the fly by
 // locate_from_longest_seed's choice (:669-677): per read the first seed of strictly greatest length (k_markers.hip
 // k_greedy_seed).  A k-mer step that comes back empty is narrowed by halving until the failing base is the reference's.
+// (format 2: three waves per SIMD -- at four the register limit of 128 sends a few of this kernel's values to scratch, and a format-2 kernel
+//  that spilled faulted on the device in round 4, profiles/r04_fault_note.txt: none of them is allowed to)
 template <typename P, bool V2>
-__global__ __launch_bounds__(512, (V2 || sizeof(P) == 4) ? 4 : 3) void k_greedy_seed_runs(const DevIndex ix, const uint8_t *__restrict__ seqs,
+__global__ __launch_bounds__(512, V2 ? 3 : sizeof(P) == 4 ? 4 : 3) void k_greedy_seed_runs(const DevIndex ix, const uint8_t *__restrict__ seqs,
                                                      const uint64_t *__restrict__ off, const uint64_t N,
                                                      const uint64_t min_length, uint64_t *__restrict__ lo_out,
                                                      uint64_t *__restrict__ hi_out, uint64_t *__restrict__ qs_out,
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(512, (V2 || sizeof(P) == 4) ? 4 : 3) void k_greedy_
 // seed_ei, first marker, one past last marker}.
 // LOG / lg: the marker-seed log (rbg_dev.h SeedLog), as in k_markers.hip k_marker_seeds
 template <typename P, bool FILL, bool LOG, bool V2>
-__global__ __launch_bounds__(512, (V2 || sizeof(P) == 4) ? 4 : 3) void k_marker_seeds_runs(const DevIndex ix, const uint8_t *__restrict__ seqs,
+__global__ __launch_bounds__(512, V2 ? 3 : sizeof(P) == 4 ? 4 : 3) void k_marker_seeds_runs(const DevIndex ix, const uint8_t *__restrict__ seqs,
                                                       const uint64_t *__restrict__ off, const uint64_t N,
                                                       const uint64_t wsize, const uint64_t max_range,
                                                       uint64_t *__restrict__ seed_cnt, uint64_t *__restrict__ mk_cnt,
@@ -460,7 +462,7 @@ __global__ __launch_bounds__(512, (V2 || sizeof(P) == 4) ? 4 : 3) void k_marker_
 // build_ftab(K) makes for this index is find_range of an ACGT-only k-mer: K symbols from the full range, taken as k-mer
 // steps through the depths' run lists; every other step of the loop is a single symbol, as in the reference.
 template <typename P, bool FILL, bool LOG>
-__global__ __launch_bounds__(512, 4) void k_marker_seeds_ftab_runs2(const DevIndex ix, const uint8_t *__restrict__ seqs, const uint64_t *__restrict__ off,
+__global__ __launch_bounds__(512, 3) void k_marker_seeds_ftab_runs2(const DevIndex ix, const uint8_t *__restrict__ seqs, const uint64_t *__restrict__ off,
                                                                     const uint64_t N, const uint64_t wsize, const uint64_t max_range, const uint64_t K,
                                                                     uint64_t *__restrict__ seed_cnt, uint64_t *__restrict__ mk_cnt,
                                                                     const uint64_t *__restrict__ seed_off, const uint64_t *__restrict__ mk_off,

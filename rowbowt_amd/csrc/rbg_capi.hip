@@ -2248,7 +2248,7 @@ struct PinnedStage {
         if (tried) return ok;
         tried = true;
         for (int i = 0; i < kBufs; ++i)
-            if (hipHostMalloc(&buf[i], kChunk, hipHostMallocPortable) != hipSuccess) {
+            if (rbg_numa::host_malloc_near(&buf[i], kChunk, hipHostMallocPortable, [] { int d = 0; (void)hipGetDevice(&d); return d; }()) != hipSuccess) {
                 (void)hipGetLastError();
                 return ok = false;
             }
@@ -3858,7 +3858,7 @@ int take_text_out(rbg_index *ix, size_t bytes, char **out) {
     }
     const size_t cap = std::max<size_t>(size_t(1) << 20, bytes + bytes / 4);
     void *p = nullptr;
-    if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return RBG_ENOMEM; }
+    if (rbg_numa::host_malloc_near(&p, cap, hipHostMallocDefault, ix->device) != hipSuccess) { (void)hipGetLastError(); return RBG_ENOMEM; }
     for (auto &t : ix->text_out)
         if (!t.p) { t.p = static_cast<char *>(p); t.cap = cap; t.busy = true; *out = t.p; return RBG_OK; }
     rbg_index::TextOut t;
@@ -3888,7 +3888,7 @@ struct TextInHold {
             if (slot == ~size_t(0)) { ix->text_in.emplace_back(); slot = ix->text_in.size() - 1; }
             const size_t cap = bytes + bytes / 4 + 4096;
             void *q = nullptr;
-            if (hipHostMalloc(&q, cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); slot = ~size_t(0); return RBG_ENOMEM; }
+            if (rbg_numa::host_malloc_near(&q, cap, hipHostMallocDefault, ix->device) != hipSuccess) { (void)hipGetLastError(); slot = ~size_t(0); return RBG_ENOMEM; }
             ix->text_in[slot].p = static_cast<char *>(q);
             ix->text_in[slot].cap = cap;
         }

@@ -13,6 +13,7 @@
 // Included by rbg_capi.hip only (it needs rbg_index).
 #pragma once
 
+#include "rbg_numa.hpp"
 #include "rbg_pack2bit.hpp"
 #include "rbg_thread_team.hpp"
 
@@ -60,7 +61,7 @@ struct Workspace {
             s.h_in = s.d_in = nullptr;
             s.in_cap = 0;
             const size_t cap = in_bytes + in_bytes / 4 + 4096;
-            if (hipHostMalloc(&s.h_in, cap, hipHostMallocDefault) != hipSuccess) return 2;
+            if (rbg_numa::host_malloc_near(&s.h_in, cap, hipHostMallocDefault, device) != hipSuccess) return 2;
             if (hipMalloc(&s.d_in, cap) != hipSuccess) return 2;
             s.in_cap = cap;
         }
@@ -70,7 +71,7 @@ struct Workspace {
             s.h_out = s.d_out = nullptr;
             s.out_cap = 0;
             const size_t cap = out_bytes + out_bytes / 4 + 4096;
-            if (hipHostMalloc(&s.h_out, cap, hipHostMallocDefault) != hipSuccess) return 2;
+            if (rbg_numa::host_malloc_near(&s.h_out, cap, hipHostMallocDefault, device) != hipSuccess) return 2;
             if (hipMalloc(&s.d_out, cap) != hipSuccess) return 2;
             s.out_cap = cap;
         }

@@ -1,0 +1,100 @@
+// rbg_numa.hpp -- pinned host buffers on the GPU's own NUMA node.
+// The copy engines move the results of a batch (3 GB of locations, 10 GB of rb_align -s text per 10 M reads) into pinned host
+// memory.  hipHostMalloc pins the pages where the allocating thread runs; on a two-socket host that is either the socket the
+// GPU hangs off or the other one, decided by where the scheduler happened to put the process -- and a copy into the far socket's
+// memory crosses the socket interconnect at about half the rate.  That was the process-to-process bimodality of `rb_align -s -m`
+// in round 3 (3.3-3.5e7 against 2.0e7 reads/s: profiles/r04_numa_probe.txt).  So the allocating thread is moved onto the CPUs of
+// the GPU's node for the duration of the allocation (sched_setaffinity; no libnuma), and put back.  RBG_PIN_NUMA=0 turns it off
+// (A/B); RBG_NUMA_TRACE=1 says on stderr where the process, the GPU and the first page of each buffer are.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <sched.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+
+#include <cctype>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+namespace rbg_numa {
+
+inline int read_int_file(const std::string &path) {
+    FILE *f = std::fopen(path.c_str(), "r");
+    if (!f) return -1;
+    int v = -1;
+    if (std::fscanf(f, "%d", &v) != 1) v = -1;
+    std::fclose(f);
+    return v;
+}
+
+// NUMA node of HIP device `device` (-1: unknown / no NUMA)
+inline int gpu_node(int device) {
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, sizeof(bus), device) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    for (char *c = bus; *c; ++c) *c = static_cast<char>(std::tolower(static_cast<unsigned char>(*c)));
+    return read_int_file(std::string("/sys/bus/pci/devices/") + bus + "/numa_node");
+}
+
+// the CPUs of a node as a cpu_set_t (false: unknown)
+inline bool node_cpus(int node, cpu_set_t *set) {
+    CPU_ZERO(set);
+    FILE *f = std::fopen(("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist").c_str(), "r");
+    if (!f) return false;
+    char buf[4096] = {0};
+    const bool ok = std::fgets(buf, sizeof(buf), f) != nullptr;
+    std::fclose(f);
+    if (!ok) return false;
+    int n = 0;
+    for (char *tok = std::strtok(buf, ",\n"); tok; tok = std::strtok(nullptr, ",\n")) {
+        int a = 0, b = 0;
+        if (std::sscanf(tok, "%d-%d", &a, &b) == 2) { for (int c = a; c <= b && c < CPU_SETSIZE; ++c) { CPU_SET(c, set); ++n; } }
+        else if (std::sscanf(tok, "%d", &a) == 1 && a < CPU_SETSIZE) { CPU_SET(a, set); ++n; }
+    }
+    return n > 0;
+}
+
+// node of the CPU this thread runs on right now (-1: unknown)
+inline int cpu_node() {
+    unsigned cpu = 0, node = 0;
+    if (syscall(SYS_getcpu, &cpu, &node, nullptr) != 0) return -1;
+    return static_cast<int>(node);
+}
+
+// node that holds the page at p (-1: unknown); the page must have been touched
+inline int page_node(const void *p) {
+    void *page = reinterpret_cast<void *>(reinterpret_cast<uintptr_t>(p) & ~uintptr_t(4095));
+    int status = -1;
+    if (syscall(SYS_move_pages, 0, 1ul, &page, nullptr, &status, 0) != 0) return -1;
+    return status;
+}
+
+inline bool enabled() {
+    const char *e = std::getenv("RBG_PIN_NUMA");
+    return !(e && e[0] == '0');
+}
+
+// pinned host memory for copies to / from `device`, on that device's NUMA node when the machine says which it is
+inline hipError_t host_malloc_near(void **p, size_t bytes, unsigned flags, int device) {
+    cpu_set_t before, near;
+    bool moved = false;
+    const int gnode = enabled() ? gpu_node(device) : -1;
+    if (gnode >= 0 && node_cpus(gnode, &near) && sched_getaffinity(0, sizeof(before), &before) == 0) {
+        cpu_set_t both;
+        CPU_AND(&both, &before, &near);          // (never outside what the process may use)
+        if (CPU_COUNT(&both) > 0 && sched_setaffinity(0, sizeof(both), &both) == 0) moved = true;
+    }
+    const int pnode = cpu_node();
+    const hipError_t e = hipHostMalloc(p, bytes, flags);
+    if (moved) (void)sched_setaffinity(0, sizeof(before), &before);
+    if (e == hipSuccess && std::getenv("RBG_NUMA_TRACE")) {
+        static_cast<volatile char *>(*p)[0] = 0;
+        std::fprintf(stderr, "rbg: pinned buffer of %.0f MB: allocating thread on NUMA node %d, GPU %d on node %d, first page on node %d (RBG_PIN_NUMA %s)\n",
+                     bytes / 1e6, pnode, device, gpu_node(device), page_node(*p), enabled() ? "on" : "off");
+    }
+    return e;
+}
+
+}  // namespace rbg_numa

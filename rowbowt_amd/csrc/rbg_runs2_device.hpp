@@ -221,20 +221,22 @@ __device__ __forceinline__ void lane_lf2(const RunSearch2<P> &S, const uint32_t 
     if (const void *__restrict__ recs = S.rec[d]) {   // ---- bucket records: one aligned 64-byte record per position (rbg_dev.h RunRec2) ----
         const uint32_t al0 = W ? static_cast<uint32_t>(b0 << sh) - (1u << S.fill) : 0u;
         const uint32_t al1 = W ? static_cast<uint32_t>(b1 << sh) - (1u << S.fill) : 0u;
-        LaneRec r0, r1;
-        r0.load(recs, R.dir_off + b0);
-        if (b1 != b0) r1.load(recs, R.dir_off + b1);
+        // (one record in registers at a time: when hi + 1 falls into another bucket -- one step in seven -- its record is fetched after
+        //  the first position is answered; holding both cost sixteen registers on every step and pushed the seeding kernels into scratch)
+        LaneRec rr;
+        rr.load(recs, R.dir_off + b0);
         if (STATS) st[kStSlots] += b1 != b0 ? 2 : 1;
-        uint32_t c0, lo0, c1, lo1, h1;
-        uint64_t e1;
+        uint32_t c0, lo0, c1, lo1;
+        uint64_t e0, e1;
         bool in0, in1;
         uint32_t rounds = 0, ents = 0;
-        uint64_t e0;
-        r0.rank(tent, al0, static_cast<uint32_t>(q0) - al0, c0, lo0, in0, e0, rounds, ents);
-        if (b1 != b0) { r1.rank(tent, al1, static_cast<uint32_t>(q1) - al1, c1, lo1, in1, e1, rounds, ents); h1 = r1.w[1]; }
-        else { r0.rank(tent, al0, static_cast<uint32_t>(q1) - al0, c1, lo1, in1, e1, rounds, ents); h1 = r0.w[1]; }
+        rr.rank(tent, al0, static_cast<uint32_t>(q0) - al0, c0, lo0, in0, e0, rounds, ents);
+        const uint32_t h0 = rr.w[1];
+        if (b1 != b0) rr.load(recs, R.dir_off + b1);
+        rr.rank(tent, al1, static_cast<uint32_t>(q1) - al1, c1, lo1, in1, e1, rounds, ents);
+        const uint32_t h1 = rr.w[1];
         if (STATS) { st[kStSearch] += rounds; st[kStDense] += ents; st[kStSteps] += 1; }
-        const uint64_t y0 = static_cast<uint64_t>(r0.w[1]) << 31, y1 = static_cast<uint64_t>(h1) << 31;
+        const uint64_t y0 = static_cast<uint64_t>(h0) << 31, y1 = static_cast<uint64_t>(h1) << 31;
         out.c_before = c0 ? (W ? y0 + static_cast<uint32_t>(lo0 - static_cast<uint32_t>(y0)) : lo0) : 0;
         out.c_upto = c1 ? (W ? y1 + static_cast<uint32_t>(lo1 - static_cast<uint32_t>(y1)) : lo1) : 0;
         out.inside = c1 != 0 && in1;

@@ -482,3 +482,33 @@ def test_header_is_plain_c_and_links(tmp_path):
     """include/rbg.h is consumed by a C11 compiler with -pedantic -Werror, and the example of INTEGRATION.md
     section 2 links against librbg.so (it runs in the GPU suite)"""
     assert _compile_c_example(tmp_path).exists()
+
+
+def test_no_format2_kernel_spills():
+    """No kernel of the run-indexed layout's format 2 may use scratch: the one instantiation that spilled (the instrumented search at
+    8-byte positions, after the bucket records had raised its register need) faulted on the device (profiles/r04_fault_note.txt).
+    hipcc cross-compiles for gfx950 without a GPU and reports every kernel's ScratchSize."""
+    import re
+    from concurrent.futures import ThreadPoolExecutor
+    csrc = os.path.join(ROOT, "rowbowt_amd", "csrc")
+
+    def usage(f):
+        p = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-c", f, "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"],
+                           cwd=csrc, capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr[-2000:]
+        out, cur = [], None
+        for line in p.stderr.splitlines():
+            m = re.search(r"remark: Function Name: (\S+)", line)
+            if m:
+                cur = m.group(1)
+            m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
+            if m and cur:
+                out.append((cur, int(m.group(1))))
+        return out
+    with ThreadPoolExecutor(2) as ex:
+        res = sum(ex.map(usage, ["k_runs.hip", "k_runs_seeds.hip"]), [])
+    names = subprocess.run(["c++filt"], input="\n".join(n for n, _ in res), capture_output=True, text=True).stdout.splitlines()
+    v2 = [(n, s) for n, (_m, s) in zip(names, res) if re.search(r"(k_find_range_runs<.*, true>|_runs<.*true>|runs2<)", n)]
+    assert len(v2) >= 20, len(v2)
+    spilled = [(n, s) for n, s in v2 if s > 0]
+    assert not spilled, spilled

@@ -58,6 +58,52 @@ def _bgzf_part(args):
     return bytes(out)
 
 
+def numa_probe(exe, prefix, fq, n, th, reps):
+    """rb_align -s -m in fresh processes: (a) pinned buffers wherever the process was started (RBG_PIN_NUMA=0), the process started on each NUMA
+    node in turn (the child sets its own affinity to that node's CPUs before anything else runs: what the scheduler's choice amounts to);
+    (b) the same with the library's default (buffers allocated from the GPU's node)."""
+    import re
+    nodes = sorted(int(d[4:]) for d in os.listdir("/sys/devices/system/node") if re.fullmatch(r"node\d+", d))
+
+    def cpus_of(node):
+        out = []
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            a, _, b = part.partition("-")
+            out += list(range(int(a), int(b or a) + 1))
+        return out
+    print(f"NUMA nodes {nodes}: " + "; ".join(f"node {k}: {len(cpus_of(k))} CPUs" for k in nodes), flush=True)
+    res = {}
+    for pin in ("0", "1"):
+        for rep in range(reps):
+            node = nodes[rep % len(nodes)]
+            cpus = cpus_of(node)
+            env = dict(os.environ, RB_ALIGN_TRACE="1", RBG_NUMA_TRACE="1", RBG_PIN_NUMA=pin)
+            t0 = time.perf_counter()
+            p = subprocess.run([exe, "-s", "-m"] + th + [prefix, fq], stdout=open("/dev/null", "wb"), stderr=subprocess.PIPE, timeout=600, env=env,
+                               preexec_fn=lambda c=cpus: os.sched_setaffinity(0, c))
+            dt = time.perf_counter() - t0
+            err = p.stderr.decode().strip().splitlines()
+            if p.returncode != 0:
+                print(f"exit {p.returncode}: {err[-3:]}", flush=True)
+                continue
+            load_s, query_s = (float(x) for x in err[-1].split())
+            pinned = [l for l in err if l.startswith("rbg: pinned buffer")]
+            where = sorted({(int(re.search(r"first page on node (-?\d+)", l).group(1)), int(re.search(r"GPU \d+ on node (-?\d+)", l).group(1))) for l in pinned})
+            trace = [l for l in err if l.startswith("rb_align loop:")]
+            rate = n / query_s
+            res.setdefault((pin, node), []).append(rate)
+            print(f"RBG_PIN_NUMA={pin} process on node {node}: {len(pinned)} pinned buffers on (buffer node, GPU node) {where}; query loop {query_s:6.3f} s = {rate:.3e} reads/s "
+                  f"(process {dt:.2f} s)" + (f"   [{trace[-1][15:]}]" if trace else ""), flush=True)
+    print("# summary: reads/s by (RBG_PIN_NUMA, node the process ran on): min / median / max")
+    for key in sorted(res):
+        v = sorted(res[key])
+        print(f"#   pin={key[0]} node={key[1]}: {v[0]:.3e} / {v[len(v) // 2]:.3e} / {v[-1]:.3e}  ({len(v)} processes)")
+    for pin in ("0", "1"):
+        allv = sorted(x for k, v in res.items() if k[0] == pin for x in v)
+        if allv:
+            print(f"#   pin={pin}, all nodes: min {allv[0]:.3e}, max {allv[-1]:.3e}, spread {(allv[-1] - allv[0]) / allv[-1] * 100:.0f} %")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reads", type=int, default=10_000_000)
@@ -69,6 +115,10 @@ def main():
     ap.add_argument("--dir", default="/tmp/cli_big")
     ap.add_argument("--only-s", action="store_true", help="only the rb_align -s rows on plain FASTQ (tuning runs)")
     ap.add_argument("--only-sm", type=int, default=0, help="only the rb_align -s -m row on plain FASTQ, this many times (its spread)")
+    ap.add_argument("--numa-probe", type=int, default=0,
+                    help="the process-to-process spread of rb_align -s -m and its cause: this many fresh processes with the pinned result buffers left where "
+                         "the scheduler put the process (RBG_PIN_NUMA=0) and as many with them on the GPU's NUMA node (the library's default), each started on "
+                         "a CPU of alternating sockets; prints where process, GPU and buffers were, the rates, and the summary (profiles/r04_numa_probe.txt)")
     args = ap.parse_args()
     import torch
     from rowbowt_amd import capi
@@ -124,6 +174,9 @@ def main():
         rows = tuple(r for r in rows if r[0][:1] == ["-s"] and "-m" not in r[0] and r[1] == fq)
     if args.only_sm:
         rows = tuple(r for r in rows if "-m" in r[0]) * args.only_sm
+    if args.numa_probe:
+        numa_probe(exe, prefix, fq, args.reads, th, args.numa_probe)
+        return
     for flags, path, n, out in rows:
         t0 = time.perf_counter()
         env = dict(os.environ, RB_ALIGN_TRACE="1")

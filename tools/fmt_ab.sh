@@ -13,6 +13,6 @@ r = d.get('roofline', {})
 print(json.dumps({'value': d['value'], 'ms_per_step': d['ms_per_step'], 'kernels_ms': r.get('kernels_ms') or d.get('kernel_ms'), 'hbm_bytes': d.get('config', {}).get('index', {}).get('hbm_bytes')}))
 open('gpurun_out/fmt_ab_%s_%s.json' % ('$pb', '$fmt'), 'w').write(json.dumps(d))
 print(json.dumps({k: round(v['ms'], 3) for k, v in (r.get('kernels') or {}).items()}))
-" || { echo FAILED; tail -5 gpurun_out/fmt_ab_${pb}_${fmt}.err; }
+" || { echo FAILED; tail -5 gpurun_out/fmt_ab_${pb}_${fmt}.err; exit 1; }
   done
 done
