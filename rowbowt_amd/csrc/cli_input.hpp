@@ -65,6 +65,35 @@ class InputSource {
                 }
                 map_size_ = 0;
             }
+            // any other gzip: when more than one place in the file looks like the start of a gzip member (concatenated files: `cat a.gz b.gz`, lanes
+            // of a sequencer written one after the other) the file is mapped and the members are inflated by the worker threads, speculatively
+            // from every candidate and checked as a chain (next_members below); a single member stays zlib's single stream
+            else {
+                const size_t sz = static_cast<size_t>(sb.st_size);
+                void *m = mmap(nullptr, sz, PROT_READ, MAP_PRIVATE, fd, 0);
+                if (m != MAP_FAILED) {
+                    const unsigned char *p = static_cast<const unsigned char *>(m);
+                    std::vector<uint64_t> cand;
+                    for (size_t i = 0; i + 10 <= sz;) {
+                        const void *hit = std::memchr(p + i, 0x1f, sz - 10 - i + 1);
+                        if (!hit) break;
+                        i = static_cast<size_t>(static_cast<const unsigned char *>(hit) - p);
+                        if (p[i + 1] == 0x8b && p[i + 2] == 8 && (p[i + 3] & 0xE0) == 0) cand.push_back(i);
+                        ++i;
+                    }
+                    if (cand.size() >= 2 && cand[0] == 0) {
+                        (void)madvise(m, sz, MADV_SEQUENTIAL);
+                        map_ = static_cast<const char *>(m);
+                        map_size_ = sz;
+                        cand.push_back(sz);
+                        cand_.swap(cand);
+                        mgz_ = true;
+                        ::close(fd);
+                        return true;
+                    }
+                    munmap(m, sz);
+                }
+            }
         }
         if (regular && !(magic[0] == 0x1f && magic[1] == 0x8b)) {   // a plain file: map it, scan it in place
             map_size_ = static_cast<size_t>(sb.st_size);
@@ -162,6 +191,16 @@ class InputSource {
                 carry_.assign(w.own.begin() + static_cast<std::ptrdiff_t>(resume), w.own.end());
                 st_ = rstate;
                 if (!final && w.recs.size() == 0) { win *= 2; continue; }
+            } else if (mgz_) {
+                w.own.assign(carry_.begin(), carry_.end());
+                const bool more = next_members(w.own, win);
+                final = stream_error_ || !more;
+                w.base = w.own.data();
+                rc = rbg_cli::scan_records_parallel(w.base, 0, w.own.size(), final, st_, w.recs, &resume, &rstate, threads_, min_segment_);
+                if (rc == rbg_cli::kScanTruncQual) return stream_error_ ? -3 : -2;
+                carry_.assign(w.own.begin() + static_cast<std::ptrdiff_t>(resume), w.own.end());
+                st_ = rstate;
+                if (!final && w.recs.size() == 0) { win *= 2; continue; }
             } else if (mapped_) {
                 const uint64_t end = std::min<uint64_t>(map_size_, pos_ + win);
                 final = end == map_size_;
@@ -199,6 +238,91 @@ class InputSource {
     }
 
    private:
+    // ---- multi-member gzip ------------------------------------------------------------------------------------------------
+    // inflate ONE gzip member that starts at file offset `from`, reading no further than `limit`: 0 = the member ended (at *end), 1 = the
+    // input ran out before it did (a candidate inside this member's data cut it short), -1 = not a valid member
+    int inflate_member(uint64_t from, uint64_t limit, std::vector<char> &out, uint64_t *end) const {
+        z_stream zs;
+        std::memset(&zs, 0, sizeof(zs));
+        if (inflateInit2(&zs, 15 + 16) != Z_OK) return -1;   // gzip wrapper: header, CRC-32 and ISIZE are checked by zlib
+        out.clear();
+        out.resize(std::max<uint64_t>(uint64_t(64) << 10, (limit - from) * 4));
+        size_t have = 0;
+        uint64_t at = from;
+        int res = 1;
+        while (true) {
+            const uint64_t in_now = std::min<uint64_t>(limit - at, uint64_t(1) << 30);
+            zs.next_in = reinterpret_cast<Bytef *>(const_cast<char *>(map_ + at));
+            zs.avail_in = static_cast<uInt>(in_now);
+            if (have == out.size()) out.resize(out.size() * 2);
+            const size_t room = std::min<size_t>(out.size() - have, size_t(1) << 30);
+            zs.next_out = reinterpret_cast<Bytef *>(out.data() + have);
+            zs.avail_out = static_cast<uInt>(room);
+            const int rc = inflate(&zs, Z_NO_FLUSH);
+            have += room - zs.avail_out;
+            at += in_now - zs.avail_in;
+            if (rc == Z_STREAM_END) { res = 0; break; }
+            if (rc != Z_OK && rc != Z_BUF_ERROR) { res = -1; break; }
+            if (at == limit && zs.avail_out != 0) { res = 1; break; }   // all input consumed, no end of stream
+        }
+        (void)inflateEnd(&zs);
+        out.resize(have);
+        *end = at;
+        return res;
+    }
+    // appends the next members (about `win` bytes of text) to `dst`; false at the end of the input
+    bool next_members(std::vector<char> &dst, uint64_t win) {
+        if (ci_ + 1 >= cand_.size()) return false;
+        // the candidates of this batch: compressed bytes of about a third of the window (text compresses three- to fourfold)
+        size_t cj = ci_;
+        while (cj + 1 < cand_.size() && (cand_[cj] - cand_[ci_]) * 3 < win && cj - ci_ < 4096) ++cj;
+        if (cj == ci_) cj = ci_ + 1;
+        const size_t nseg = cj - ci_;
+        std::vector<std::vector<char>> out(nseg);
+        std::vector<int> res(nseg, -1);
+        std::vector<uint64_t> end(nseg, 0);
+        const unsigned T = std::max(1u, std::min<unsigned>(threads_, static_cast<unsigned>(nseg)));
+        auto work = [&](unsigned t) {
+            for (size_t k = nseg * t / T; k < nseg * (t + 1) / T; ++k) res[k] = inflate_member(cand_[ci_ + k], cand_[ci_ + k + 1], out[k], &end[k]);
+        };
+        {
+            std::vector<std::thread> th;
+            for (unsigned t = 1; t < T; ++t) th.emplace_back(work, t);
+            work(0);
+            for (auto &x : th) x.join();
+        }
+        // the chain: member k must end where candidate k + 1 starts.  A candidate inside a member's data cut that member short (res 1):
+        // it is inflated again up to the candidate where it really ends, and the candidates it contains are skipped.
+        size_t k = 0;
+        while (k < nseg) {
+            uint64_t e = end[k];
+            int r = res[k];
+            std::vector<char> again;
+            const std::vector<char> *txt = &out[k];
+            if (r == 1) {
+                r = inflate_member(cand_[ci_ + k], map_size_, again, &e);
+                txt = &again;
+            }
+            if (r != 0) { stream_error_ = true; ci_ = cand_.size(); return false; }   // like gzread failing: what came before counts
+            dst.insert(dst.end(), txt->begin(), txt->end());
+            // the candidate at which the next member starts
+            size_t nxt = ci_ + k + 1;
+            while (nxt < cand_.size() && cand_[nxt] < e) ++nxt;
+            if (nxt >= cand_.size() || cand_[nxt] != e || cand_[nxt] == map_size_) {
+                // the end of the file, or bytes that start no gzip member (zero padding included): zlib's gzread -- what the reference reads
+                // through, kseq.h over gzFile -- takes them for trailing garbage and stops there as at the end of the file
+                ci_ = cand_.size();
+                return false;
+            }
+            if (nxt >= ci_ + nseg) { ci_ = nxt; return ci_ + 1 < cand_.size(); }
+            k = nxt - ci_;
+        }
+        ci_ += nseg;
+        return ci_ + 1 < cand_.size();
+    }
+    bool mgz_ = false;
+    std::vector<uint64_t> cand_;   // file offsets that look like the start of a gzip member, then the file's size
+    size_t ci_ = 0;
     // a gzip member header that is a BGZF block's: FEXTRA set, first extra subfield 'B' 'C' of two bytes (the block size - 1)
     static bool bgzf_header(const unsigned char *h) {
         return h[0] == 0x1f && h[1] == 0x8b && h[2] == 8 && (h[3] & 4) && (h[10] | (h[11] << 8)) >= 6 && h[12] == 'B' && h[13] == 'C' && h[14] == 2 && h[15] == 0;

@@ -437,8 +437,11 @@ int main(int argc, char **argv) {
         reps.clear();
         for (rbg_index *r : once)
             for (int t = 0; t < S; ++t) reps.push_back(r);
-        // the texts are copied out into pinned buffers: three per half-shard, made before the clock starts
-        for (rbg_index *r : once) (void)rbg_reserve_text(r, (args.batch / reps.size() + 1) * 1100 + (size_t(1) << 20), 3 * S);
+        // the texts are copied out into pinned buffers: FOUR per half-shard, made before the clock starts.  With three, whether a fourth had
+        // to be allocated inside the loop (0.25-0.3 s of hipHostMalloc for 0.7 GB) depended on a race between the writer giving a buffer
+        // back and the next batch's text being ready: the process-to-process bimodality of `rb_align -s -m` in round 3 (2.0e7 against
+        // 3.4e7 reads/s) -- profiles/r04_numa_probe.txt lists the pinned allocations of 32 processes beside their rates.
+        for (rbg_index *r : once) (void)rbg_reserve_text(r, (args.batch / reps.size() + 1) * 1100 + (size_t(1) << 20), 4 * S);
     }
     start = std::chrono::high_resolution_clock::now();
     // three overlapped stages: scan window i+1 | query + format window i (in GPU batches of --batch reads) | write window i-1

@@ -1,11 +1,14 @@
-// rbg_numa.hpp -- pinned host buffers on the GPU's own NUMA node.
+// rbg_numa.hpp -- pinned host buffers on the GPU's own NUMA node, and a trace of where they are.
 // The copy engines move the results of a batch (3 GB of locations, 10 GB of rb_align -s text per 10 M reads) into pinned host
-// memory.  hipHostMalloc pins the pages where the allocating thread runs; on a two-socket host that is either the socket the
-// GPU hangs off or the other one, decided by where the scheduler happened to put the process -- and a copy into the far socket's
-// memory crosses the socket interconnect at about half the rate.  That was the process-to-process bimodality of `rb_align -s -m`
-// in round 3 (3.3-3.5e7 against 2.0e7 reads/s: profiles/r04_numa_probe.txt).  So the allocating thread is moved onto the CPUs of
-// the GPU's node for the duration of the allocation (sched_setaffinity; no libnuma), and put back.  RBG_PIN_NUMA=0 turns it off
-// (A/B); RBG_NUMA_TRACE=1 says on stderr where the process, the GPU and the first page of each buffer are.
+// memory; on a two-socket host a copy into the far socket's memory crosses the socket interconnect.  Round 3 left the
+// process-to-process bimodality of `rb_align -s -m` (3.4e7 against 2.0e7 reads/s) at "a property of the process's memory", and
+// this was the suspect.  Measured (profiles/r04_numa_probe.txt, 44 fresh processes started on either socket): NOT the cause -- on
+// this platform hipHostMalloc already puts the pages on the GPU's node wherever the calling thread runs (every buffer of every
+// process: node 1 = the GPU's).  The cause was a fourth 0.7 GB text buffer allocated inside the timed loop whenever the writer had
+// not yet given one of the three reserved ones back (rb_align.cpp reserves four now: 7 % spread).  What stays of the suspicion:
+// the allocating thread is moved onto the CPUs of the GPU's node for the duration of the allocation (sched_setaffinity; no
+// libnuma), so that the placement does not depend on the runtime doing it; RBG_PIN_NUMA=0 turns that off; RBG_NUMA_TRACE=1 says on
+// stderr where the process, the GPU and the first page of each pinned buffer are -- the trace that found the real cause.
 #pragma once
 
 #include <hip/hip_runtime.h>

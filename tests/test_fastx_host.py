@@ -211,6 +211,61 @@ def test_input_source_bgzf_blocks_inflated_in_parallel(cli_input, tmp_path):
         assert len(got) >= 40 * 4000 // 900 - 30      # everything before the bad block was delivered
 
 
+def test_input_source_gzip_members_inflated_in_parallel(cli_input, tmp_path):
+    """a gzip file of several members (`cat a.gz b.gz`; not BGZF) is mapped and its members are inflated by the worker threads,
+    speculatively from every place that looks like a member's start and checked as a chain: same records and end code as kseq_read over
+    what gzip.open reads from the same file -- with members of every size, members stored uncompressed whose DATA holds gzip magic
+    bytes (false starts inside a member), zero padding between members, garbage after the last one (zlib stops there), and a corrupt
+    member (-3 after the records before it)"""
+    import gzip
+    import zlib
+    rng = np.random.default_rng(44)
+    seqs = [bytes(rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), int(rng.integers(1, 300)))) for _ in range(4000)]
+    # quality strings that contain the bytes of a gzip member header: they survive verbatim in stored (level 0) members
+    trap = b"\x1f\x8b\x08\x00"
+    fq = b"".join(b"@r%d\n" % i + s + b"\n+\n" + (trap * len(s))[:len(s)].replace(b"\n", b"!") + b"\n" for i, s in enumerate(seqs))
+
+    def members(data, sizes, levels, pad=b""):
+        out, at = bytearray(), 0
+        k = 0
+        while at < len(data):
+            n = sizes[k % len(sizes)]
+            out += gzip.compress(data[at:at + n], compresslevel=levels[k % len(levels)]) + pad
+            at += n
+            k += 1
+        return bytes(out), k
+    for name, sizes, levels, pad, tail in (("m1.fq.gz", [50000], [6], b"", b""), ("m2.fq.gz", [1, 70000, 333, 20000], [0, 6, 1], b"", b""),
+                                           ("m3.fq.gz", [9000], [0], b"\0" * 7, b""), ("m4.fq.gz", [30000, 100], [6, 0], b"", b"garbage after the last member")):
+        blob, nm = members(fq, sizes, levels, pad)
+        path = tmp_path / name
+        path.write_bytes(blob + tail)
+        assert nm > 3
+        # what zlib's gzread delivers (the reference reads through it: kseq.h over gzFile): member after member while the next bytes are
+        # a gzip header; anything else -- zero padding too -- is trailing garbage and ends the file
+        data, at, raw = b"", 0, blob + tail
+        while raw[at:at + 2] == b"\x1f\x8b":
+            d = zlib.decompressobj(31)
+            data += d.decompress(raw[at:])
+            at = len(raw) - len(d.unused_data)
+        assert data == (fq if not pad else fq[:sizes[0]])
+        want, want_rc = kseq_model(data)
+        for window, threads, minseg in ((1 << 20, 4, 1000), (5000, 3, 300), (200, 2, 50), (1 << 20, 1, 1 << 20)):   # (1 thread: zlib's stream)
+            got, rc = cli_input(path, window, threads, minseg)
+            assert (got, rc) == ([(n, s) for n, s in want], want_rc), (name, window, threads)
+    # a corrupt member in the middle: -3, everything before it delivered
+    blob, nm = members(fq, [20000], [6])
+    blob = bytearray(blob)
+    starts = [i for i in range(len(blob) - 3) if blob[i:i + 3] == b"\x1f\x8b\x08" and (i == 0 or True)]
+    mid = starts[len(starts) // 2]
+    blob[mid + 40] ^= 0x77
+    bad = tmp_path / "badm.fq.gz"
+    bad.write_bytes(bytes(blob))
+    want, _ = kseq_model(fq)
+    for window, threads in ((1 << 20, 4), (9000, 3)):
+        got, rc = cli_input(bad, window, threads, 500)
+        assert rc == -3 and 0 < len(got) < len(want) and got[:-1] == [(n, s) for n, s in want][:len(got) - 1]
+
+
 def test_input_source_every_window_is_scanned_in_parallel(cli_input, tmp_path):
     """FASTA and FASTQ over many windows with several scanning threads, mapped and through zlib: same records as
     kseq_read, and EVERY window goes through the multi-threaded scan -- also the FASTA windows that begin right after an

@@ -92,7 +92,8 @@ def numa_probe(exe, prefix, fq, n, th, reps):
             trace = [l for l in err if l.startswith("rb_align loop:")]
             rate = n / query_s
             res.setdefault((pin, node), []).append(rate)
-            print(f"RBG_PIN_NUMA={pin} process on node {node}: {len(pinned)} pinned buffers on (buffer node, GPU node) {where}; query loop {query_s:6.3f} s = {rate:.3e} reads/s "
+            sizes = [int(re.search(r"pinned buffer of (\d+) MB", l).group(1)) for l in pinned]
+            print(f"RBG_PIN_NUMA={pin} process on node {node}: {len(pinned)} pinned buffers {sizes} MB on (buffer node, GPU node) {where}; query loop {query_s:6.3f} s = {rate:.3e} reads/s "
                   f"(process {dt:.2f} s)" + (f"   [{trace[-1][15:]}]" if trace else ""), flush=True)
     print("# summary: reads/s by (RBG_PIN_NUMA, node the process ran on): min / median / max")
     for key in sorted(res):
