@@ -336,6 +336,12 @@ int compose_impl(const uint64_t n, const uint32_t M, const ComposeTable *major, 
     CK(d_err.alloc(sizeof(int)));
     CK(hipMemsetAsync(d_err.p, 0, sizeof(int), st));
     uint32_t n_ids = M;
+    Tmp d_F_next;
+    bool have_F_next = false;
+    // kept depths that went to host memory while deeper ones were composed (see spill_kept below)
+    struct Spilled { size_t level; void *h_ent, *h_samp; size_t ent_bytes, samp_bytes; };
+    std::vector<Spilled> spilled;
+    struct SpillGuard { std::vector<Spilled> &v; ~SpillGuard() { for (Spilled &x : v) { std::free(x.h_ent); std::free(x.h_samp); } } } spill_guard{spilled};
     const bool verbose = std::getenv("RBG_VERBOSE") != nullptr;
     auto used_gb = [] { size_t f = 0, t = 0; (void)hipMemGetInfo(&f, &t); return static_cast<double>(t - f) / 1e9; };
     double gb_pieces = 0, gb_tables = 0;
@@ -348,7 +354,10 @@ int compose_impl(const uint64_t n, const uint32_t M, const ComposeTable *major, 
         // does not keep (keep_mask: the run-indexed layout's depth set) gives its arrays back before this depth's temporaries
         // are made -- at r = 1e9 that is 50 GB of the 300 the composition would otherwise want at once
         Tmp d_F;
-        {
+        if (have_F_next) {   // computed at the end of the previous iteration, before that depth's arrays could be given back
+            std::swap(d_F.p, d_F_next.p);
+            have_F_next = false;
+        } else {
             Tmp d_prev_ent, d_prev_nruns, d_prev_F, d_sym_F;
             CK(d_prev_ent.alloc(n_ids * 8)); CK(d_prev_nruns.alloc(n_ids * 8)); CK(d_prev_F.alloc(n_ids * 8)); CK(d_sym_F.alloc(M * 8)); CK(d_F.alloc(T * 8));
             CK(hipMemcpy(d_prev_ent.p, prev_ent.data(), n_ids * 8, hipMemcpyHostToDevice));
@@ -367,6 +376,35 @@ int compose_impl(const uint64_t n, const uint32_t M, const ComposeTable *major, 
             old.ent = old.samp = nullptr;
         }
         const bool last_level = depth + 1 == kmax;
+        // SPILL: the sweeps of this depth take about 80 bytes per piece beside what is resident; when that is more than the device has
+        // free, the kept depths made so far (24 bytes per entry, read by nothing until the composition is over) wait in host memory and
+        // come back at the end.  r = 1e9: depth 3's 56 GB, without which depths 4 and 5 do not fit beside their own temporaries.
+        if (depth >= 2) {
+            size_t free_b = 0, total_b = 0;
+            (void)hipMemGetInfo(&free_b, &total_b);
+            const double need = 84.0 * 1.3 * static_cast<double>(g_n);
+            if (need > static_cast<double>(free_b)) {
+                t_pool->purge();
+                (void)hipMemGetInfo(&free_b, &total_b);
+            }
+            if (need > static_cast<double>(free_b) || std::getenv("RBG_COMPOSE_SPILL")) {   // (the switch: tests take the path at their size)
+                for (size_t li = 0; li < out.size(); ++li) {
+                    ComposedLevel &L = out[li];
+                    if (!L.ent) continue;
+                    const size_t eb = (L.entries + 2) * sizeof(RunEnt<P>), sb = L.samp ? (L.entries + 2) * sizeof(P) : 0;
+                    if (static_cast<double>(eb + sb) > 0.5 * host_memory_available()) break;   // (the host must not be what runs out instead)
+                    Spilled x{li, std::malloc(eb), sb ? std::malloc(sb) : nullptr, eb, sb};
+                    if (!x.h_ent || (sb && !x.h_samp)) { std::free(x.h_ent); std::free(x.h_samp); break; }
+                    spilled.push_back(x);
+                    CK(hipMemcpy(x.h_ent, L.ent, eb, hipMemcpyDeviceToHost));
+                    if (sb) CK(hipMemcpy(x.h_samp, L.samp, sb, hipMemcpyDeviceToHost));
+                    (void)hipFree(L.ent);
+                    if (L.samp) (void)hipFree(L.samp);
+                    L.ent = L.samp = nullptr;
+                    if (verbose) std::fprintf(stderr, "rbg:   depth %zu (%.1f GB) waits in host memory while depth %u is composed\n", li + 2, (eb + sb) / 1e9, depth + 1);
+                }
+            }
+        }
         // ---- pieces of every symbol -------------------------------------------------------------------------------------
         // which G segments a symbol's image [F, F + total) meets: two binary searches per symbol, made from the host over the
         // device array (a few dozen 8-byte copies per level)
@@ -456,7 +494,7 @@ int compose_impl(const uint64_t n, const uint32_t M, const ComposeTable *major, 
         }
         const auto t_pieces = now();
         if (verbose) gb_pieces = used_gb();
-        if (last_level) { own_start.release(); own_id.release(); own_samp.release(); }   // (the segmentation is read by the pieces only)
+        own_start.release(); own_id.release(); own_samp.release();   // (the segmentation is read by the pieces only: the next one is made below)
         // inputs_released != nullptr: the caller hands over its inputs -- the depth-1 segmentation (20 bytes per run) is read by the
         // first depth's pieces only, the major symbols' own tables (24 bytes per run) by every depth's pieces and no later: 45 GB
         // at r = 1e9 that the last depth's tables need
@@ -537,6 +575,33 @@ int compose_impl(const uint64_t n, const uint32_t M, const ComposeTable *major, 
         if (verbose) gb_tables = used_gb();
         // ---- the next depth's segmentation (not needed after the last level) ----------------------------------------------
         s_tab.release(); cumlen.release(); first.release();   // (the tables are written: 16 bytes per piece less under the segmentation's arrays)
+        // the tables just made are the next level's "previous" ones: its F is computed NOW, so that a depth the caller does not keep gives its
+        // arrays (24 bytes per entry) back before the segmentation's are made, not after
+        prev_ent.assign(T, nullptr); prev_nruns.assign(T, 0); prev_F.assign(T, 0);
+        for (uint32_t t = 0; t < T; ++t) {
+            prev_ent[t] = static_cast<const char *>(Lv.ent) + Lv.first[t] * sizeof(RunEnt<P>);
+            prev_nruns[t] = Lv.nruns[t];
+            prev_F[t] = Lv.F[t];
+        }
+        if (depth + 1 < kmax) {
+            const uint32_t T2 = T * M;
+            Tmp d_prev_ent, d_prev_nruns, d_prev_F, d_sym_F;
+            CK(d_prev_ent.alloc(T * 8)); CK(d_prev_nruns.alloc(T * 8)); CK(d_prev_F.alloc(T * 8)); CK(d_sym_F.alloc(M * 8)); CK(d_F_next.alloc(T2 * 8));
+            CK(hipMemcpy(d_prev_ent.p, prev_ent.data(), T * 8, hipMemcpyHostToDevice));
+            CK(hipMemcpy(d_prev_nruns.p, prev_nruns.data(), T * 8, hipMemcpyHostToDevice));
+            CK(hipMemcpy(d_prev_F.p, prev_F.data(), T * 8, hipMemcpyHostToDevice));
+            CK(hipMemcpy(d_sym_F.p, sym_F.data(), M * 8, hipMemcpyHostToDevice));
+            hipLaunchKernelGGL((k_table_F<P>), dim3((T2 + 255) / 256), dim3(256), 0, st, d_prev_ent.as<const RunEnt<P> *>(), d_prev_nruns.as<uint64_t>(),
+                               d_prev_F.as<uint64_t>(), d_sym_F.as<uint64_t>(), T, M, d_F_next.as<uint64_t>());
+            CK(hipGetLastError());
+            CK(hipStreamSynchronize(st));
+            have_F_next = true;
+            if (keep_mask && !(keep_mask >> depth & 1u)) {   // this depth (depth + 1) is not kept and nothing reads it any more
+                (void)hipFree(Lv.ent);
+                if (Lv.samp) (void)hipFree(Lv.samp);
+                Lv.ent = Lv.samp = nullptr;
+            }
+        }
         if (depth + 1 < kmax) {
             Tmp rkeys, rperm;
             CK(rkeys.alloc((nkept + 1) * sizeof(P)));
@@ -583,12 +648,19 @@ int compose_impl(const uint64_t n, const uint32_t M, const ComposeTable *major, 
                                  "pieces, %.1f after the tables, %.1f at the end\n", depth + 1,
                          static_cast<unsigned long long>(np), static_cast<unsigned long long>(nkept), T, secs(t_lvl, t_pieces), secs(t_pieces, t_tables),
                          secs(t_tables, now()), gb_pieces, gb_tables, used_gb());
-        // the tables just made are the next level's "previous" ones
-        prev_ent.assign(T, nullptr); prev_nruns.assign(T, 0); prev_F.assign(T, 0);
-        for (uint32_t t = 0; t < T; ++t) {
-            prev_ent[t] = static_cast<const char *>(Lv.ent) + Lv.first[t] * sizeof(RunEnt<P>);
-            prev_nruns[t] = Lv.nruns[t];
-            prev_F[t] = Lv.F[t];
+    }
+    // the depths that waited in host memory come back (everything the sweeps held has been given back by now)
+    if (!spilled.empty()) t_pool->purge();
+    for (Spilled &x : spilled) {
+        ComposedLevel &L = out[x.level];
+        void *de = nullptr, *ds = nullptr;
+        CK(hipMalloc(&de, x.ent_bytes));
+        L.ent = de;
+        CK(hipMemcpy(de, x.h_ent, x.ent_bytes, hipMemcpyHostToDevice));
+        if (x.samp_bytes) {
+            CK(hipMalloc(&ds, x.samp_bytes));
+            L.samp = ds;
+            CK(hipMemcpy(ds, x.h_samp, x.samp_bytes, hipMemcpyHostToDevice));
         }
     }
     return 0;

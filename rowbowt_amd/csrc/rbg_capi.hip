@@ -145,26 +145,6 @@ std::atomic<int64_t> g_opt_packed_reads{1};  // host-pointer calls: 0 bytes over
 // otherwise: with a quarter the same load keeps the 4-symbol level (58 GB), and the budget option is one call away.
 inline size_t default_budget(size_t free_b) { return free_b / 4; }
 
-// bytes of host memory this process may still take: the smaller of the machine's MemAvailable and what its cgroup (v2) has left
-double host_memory_available() {
-    double avail = 1e18;
-    if (FILE *f = std::fopen("/proc/meminfo", "r")) {
-        char line[256];
-        while (std::fgets(line, sizeof line, f)) {
-            unsigned long long kb = 0;
-            if (std::sscanf(line, "MemAvailable: %llu kB", &kb) == 1) { avail = static_cast<double>(kb) * 1024.0; break; }
-        }
-        std::fclose(f);
-    }
-    unsigned long long mx = 0, cur = 0;
-    bool have_mx = false, have_cur = false;
-    if (FILE *f = std::fopen("/sys/fs/cgroup/memory.max", "r")) { have_mx = std::fscanf(f, "%llu", &mx) == 1; std::fclose(f); }
-    if (FILE *f = std::fopen("/sys/fs/cgroup/memory.current", "r")) { have_cur = std::fscanf(f, "%llu", &cur) == 1; std::fclose(f); }
-    if (have_mx && have_cur && mx > cur) avail = std::min(avail, static_cast<double>(mx - cur));
-    else if (have_mx && have_cur) avail = 0;
-    return avail;
-}
-
 #define HIP_TRY(expr)                                                                             \
     do {                                                                                          \
         hipError_t e_ = (expr);                                                                   \

@@ -4,8 +4,10 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstddef>
 #include <cstdint>
+#include <cstdio>
 #include <vector>
 
 namespace rbg {
@@ -432,6 +434,27 @@ int compose_levels_device(uint32_t pos_bytes, uint64_t n, uint32_t M, const Comp
                           uint32_t keep_mask = 0 /*bit d - 1: depth d's arrays are kept; others are freed once the next depth is made (their metadata stays); 0 = keep all*/,
                           bool *inputs_released = nullptr /*[2], non-null: the inputs are handed over (hipMalloc blocks) and freed as soon as they have been read --
                                                             [0] = the depth-1 segmentation was freed, [1] = the major symbols' tables were*/);
+
+// bytes of host memory this process may still take: the smaller of the machine's MemAvailable and what its cgroup (v2) has left
+inline double host_memory_available() {
+    double avail = 1e18;
+    if (FILE *f = std::fopen("/proc/meminfo", "r")) {
+        char line[256];
+        while (std::fgets(line, sizeof line, f)) {
+            unsigned long long kb = 0;
+            if (std::sscanf(line, "MemAvailable: %llu kB", &kb) == 1) { avail = static_cast<double>(kb) * 1024.0; break; }
+        }
+        std::fclose(f);
+    }
+    unsigned long long mx = 0, cur = 0;
+    bool have_mx = false, have_cur = false;
+    if (FILE *f = std::fopen("/sys/fs/cgroup/memory.max", "r")) { have_mx = std::fscanf(f, "%llu", &mx) == 1; std::fclose(f); }
+    if (FILE *f = std::fopen("/sys/fs/cgroup/memory.current", "r")) { have_cur = std::fscanf(f, "%llu", &cur) == 1; std::fclose(f); }
+    if (have_mx && have_cur && mx > cur) avail = std::min(avail, static_cast<double>(mx - cur));
+    else if (have_mx && have_cur) avail = 0;
+    return avail;
+}
+
 
 struct LaunchCfg {
     int block_threads = 256;

@@ -2016,6 +2016,27 @@ def test_run_indexed_format2_fillers_and_super_counts(synth, fill_shift, super_s
     _run_indexed_checks(S, rb)
 
 
+@pytest.mark.parametrize("depths", [0, 0x15, 0x1f])
+def test_composition_spills_kept_depths_to_host_and_back(synth, depths, capfd):
+    """k_compose.hip: when a depth's sweeps do not fit beside the kept depths made so far (r = 1e9 with 5 symbols per step),
+    those wait in host memory and come back at the end.  RBG_COMPOSE_SPILL takes that path at test size: the index must be
+    the same one (every query equal to the oracle's), with the same depth set."""
+    S = synth
+    ra.set_default_option(capi.OPT_RUN_DEPTHS, depths)
+    os.environ["RBG_COMPOSE_SPILL"] = "1"
+    os.environ["RBG_VERBOSE"] = "1"
+    try:
+        rb = _with_layout(capi.LAYOUT_RUNS, 48, lambda: ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0))
+    finally:
+        ra.set_default_option(capi.OPT_RUN_DEPTHS, 0)
+        os.environ.pop("RBG_COMPOSE_SPILL", None)
+        os.environ.pop("RBG_VERBOSE", None)
+    assert "waits in host memory" in capfd.readouterr().err
+    li = rb.layout_info()
+    assert li.depths_composed == 5 and (not depths or li.depth_mask_kept == depths), (li.depths_composed, li.depth_mask_kept)
+    _run_indexed_checks(S, rb)
+
+
 def test_run_indexed_format1_limits_are_loud(synth, capfd):
     """Format 1 (rounds 2-3) has two width limits that used to bite without a word: 32-bit entry indices (a depth with 2^32
     entries was left out, and the depth forced in its place could already have been released) and a phi directory that
