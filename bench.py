@@ -544,7 +544,18 @@ def main():
         slot_b = int(ix.slot_bytes) or 16
         ftab_entry = 16 if P == 4 else 32
 
+        runs_layout = int(ix.rank_layout) == 2
+        li = rb.layout_info() if runs_layout else None
+        rec_on = bool(li and any(li.rec_bytes))
+
         def search_bytes(sv, toehold):
+            if runs_layout:
+                # run-indexed layout, format 2 (rbg_runs2_device.hpp): "slots" = bucket records fetched (64 bytes each) or, without records,
+                # directory gathers (two neighbouring entries: 8 or 16 bytes); "dense" = run-list entries the scans needed (8 bytes each);
+                # "searched_ranks" = narrowing rounds (seven 4-byte pivots each); a re-sample = one gather of P
+                per_slot = 64 if rec_on else (16 if P == 8 else 8)
+                return (N * (16 + (24 if toehold else 16)) + 16 * sv["read_chunks"] + ftab_entry * sv["ftab"] + per_slot * sv["slots"]
+                        + 8 * sv["dense"] + 28 * sv["searched_ranks"] + P * sv["resamples"])
             # per read: its two offsets (16) and its outputs (lo, hi [, toehold]); per 16-byte read chunk fetched;
             # per ftab entry; per 16-byte rank slot; per 2-byte dense-table row; per rank searched in a run list:
             # two ord entries + ~3 probes of a {start, cum} pair; per materialised re-sample: ord (4) + sample (P)
@@ -582,8 +593,9 @@ def main():
             try:
                 pj = json.load(open(pmc))
                 if pj.get("_librbg_sha256") == so_hash:
-                    traffic = pj.get(dom, {}).get("hbm_bytes_per_launch")
-                    misses = pj.get(dom, {}).get("tcc_miss_per_launch")
+                    pkey = dom + (f" [runs, pos_bytes {P}]" if runs_layout else "")
+                    traffic = pj.get(pkey, {}).get("hbm_bytes_per_launch")
+                    misses = pj.get(pkey, {}).get("tcc_miss_per_launch")
                     pmc_note = pj.get("_source")
                 else:
                     pmc_note = "profiles/pmc_traffic.json was taken with a different librbg.so build: dropped"
@@ -600,7 +612,10 @@ def main():
         # bytes and the outputs are NOT in it: they are sequential sectors (2-3 per read), not index gathers --
         # TCC_MISS of the same launch = these gathers + those sectors (273M = 231M + 42M on the default workload).
         gathers = None
-        if dom == "k_find_range<toehold>":
+        if dom == "k_find_range<toehold>" and runs_layout:
+            # records / directory gathers, one sector per eight scanned entries, one per narrowing round, ftab entries, re-samples
+            gathers = st_toe["slots"] + (st_toe["dense"] + 7) // 8 + st_toe["searched_ranks"] + st_toe["ftab"] + st_toe["resamples"]
+        elif dom == "k_find_range<toehold>":
             gathers = st_toe["slots"] + st_toe["dense"] + st_toe["ftab"] + (1 if slot_b == 64 else 2) * st_toe["resamples"] + 4 * st_toe["searched_ranks"]
         out = {
             "metric": f"reads/s ({args.read_len} bp, count+locate)",
@@ -653,6 +668,7 @@ def main():
                          "request_roof": ({"unit": "G random 16-byte gathers/s", "gathers_per_launch": gathers, "achieved": gathers / dom_s / 1e9,
                                            "peak": ceiling, "frac": gathers / dom_s / 1e9 / ceiling,
                                            "tcc_miss_per_launch": misses,
+                                           "layout": "runs (records / directory gathers + scanned sectors + rounds + ftab + re-samples)" if runs_layout else "slots",
                                            "note": "peak = the most random 16-byte gathers per second tools/gather_ceiling.hip gets out of this chip "
                                                    "(flat from 1 to 16 loads in flight per lane and 2 to 8 waves per SIMD: a throughput limit of the "
                                                    "memory system, not latency); achieved = the kernel's dependent index gathers only, its sequential "

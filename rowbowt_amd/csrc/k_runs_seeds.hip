@@ -120,10 +120,12 @@ __device__ __forceinline__ bool ftab_state(const DevIndex &ix, ByteCursor &rd, c
     const uint64_t wave_first = static_cast<uint64_t>(blockIdx.x) * blockDim.x + (threadIdx.x & ~(kWave - 1))
 
 // both ranks of the step of every lane of the wave (format 1: cooperative, every lane must call; format 2: the lane's own)
-template <typename P, bool V2>
+// LEAN: the narrow scan of crowded buckets (rbg_runs2_device.hpp lane_scan) -- for the instantiations whose state would otherwise
+// cost a workgroup per CU (512 threads: two or four waves per SIMD, nothing between); the others keep the one-round-trip scan
+template <typename P, bool V2, bool LEAN = false>
 __device__ __forceinline__ void seeds_lf2(const DevIndex &ix, const RunSearch<P> &S, const RunSearch2<P> &S2, const bool stepping, const uint32_t d,
                                           const uint32_t rec, const uint64_t q0, const uint64_t q1, RunStep &r) {
-    if constexpr (V2) { if (stepping) lane_lf2<P>(S2, d, rec, q0, q1, r); }
+    if constexpr (V2) { if (stepping) lane_lf2<P, false, LEAN>(S2, d, rec, q0, q1, r); }
     else coop_lf2<P>(ix, S, stepping, d, rec, q0, q1, r);
 }
 template <typename P, bool V2>
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(512, V2 ? 3 : sizeof(P) == 4 ? 4 : 3) void k_greedy
                 stepping = true;
             }
             RunStep r;
-            seeds_lf2<P, V2>(ix, S, S2, stepping, pick.d, pick.rec, lo, hi + 1, r);
+            seeds_lf2<P, V2, true>(ix, S, S2, stepping, pick.d, pick.rec, lo, hi + 1, r);
             if (stepping) {
                 const uint64_t c_inside = r.c_upto - r.c_before;
                 const bool ok = c_inside != 0;
@@ -352,8 +354,10 @@ __global__ __launch_bounds__(512, V2 ? 3 : sizeof(P) == 4 ? 4 : 3) void k_marker
         uint64_t unused_k = 0;
         ByteCursor rd{reinterpret_cast<const uint4 *>(seqs), ~uint64_t(0), make_uint4(0, 0, 0, 0)};
         unsigned char *lbase = (LOG && valid) ? lg.base + i * lg.stride : nullptr;
-        SeedLogRec<P> *lrec = reinterpret_cast<SeedLogRec<P> *>(lbase + 8);
-        SeedLogWin *lwin = reinterpret_cast<SeedLogWin *>(lbase + 8 + static_cast<size_t>(lg.qs) * sizeof(SeedLogRec<P>));
+        // (the log's two arrays are addressed from lbase where they are written: two more pointers held over the whole walk cost the
+        //  logging instantiation its fourth wave per SIMD)
+        auto lrec = [&]() { return reinterpret_cast<SeedLogRec<P> *>(lbase + 8); };
+        auto lwin = [&]() { return reinterpret_cast<SeedLogWin *>(lbase + 8 + static_cast<size_t>(lg.qs) * sizeof(SeedLogRec<P>)); };
         uint32_t nw = 0;
         bool lover = LOG && (m >> 32) != 0;
         auto update_mbuf = [&](uint64_t l, uint64_t h) {  // :437-441
@@ -367,7 +371,7 @@ __global__ __launch_bounds__(512, V2 ? 3 : sizeof(P) == 4 ? 4 : 3) void k_marker
                 for (uint64_t t = 0; t < cnt; ++t) d[t] = ix.mk_vals[src + t];
             }
             if (LOG) {
-                if (nw < lg.qw && ((src + cnt) >> 32) == 0) lwin[nw] = SeedLogWin{static_cast<uint32_t>(src), static_cast<uint32_t>(cnt)};
+                if (nw < lg.qw && ((src + cnt) >> 32) == 0) lwin()[nw] = SeedLogWin{static_cast<uint32_t>(src), static_cast<uint32_t>(cnt)};
                 else lover = true;
                 ++nw;
             }
@@ -380,7 +384,7 @@ __global__ __launch_bounds__(512, V2 ? 3 : sizeof(P) == 4 ? 4 : 3) void k_marker
             }
             if (LOG) {
                 if (ns < lg.qs && (tot >> 32) == 0)
-                    lrec[ns] = SeedLogRec<P>{static_cast<P>(l), static_cast<P>(h), static_cast<uint32_t>(qs), static_cast<uint32_t>(qe),
+                    lrec()[ns] = SeedLogRec<P>{static_cast<P>(l), static_cast<P>(h), static_cast<uint32_t>(qs), static_cast<uint32_t>(qe),
                                              static_cast<uint32_t>(mb_begin), static_cast<uint32_t>(tot)};
                 else lover = true;
             }
@@ -422,7 +426,7 @@ __global__ __launch_bounds__(512, V2 ? 3 : sizeof(P) == 4 ? 4 : 3) void k_marker
                 stepping = true;
             }
             RunStep r;
-            seeds_lf2<P, V2>(ix, S, S2, stepping, pick.d, pick.rec, lo, hi + 1, r);
+            seeds_lf2<P, V2, LOG>(ix, S, S2, stepping, pick.d, pick.rec, lo, hi + 1, r);
             if (stepping) {
                 const uint64_t c_inside = r.c_upto - r.c_before;
                 const bool ok = c_inside != 0;
@@ -483,8 +487,10 @@ __global__ __launch_bounds__(512, 3) void k_marker_seeds_ftab_runs2(const DevInd
         uint64_t *srec = FILL ? seeds + 6 * seed_off[i] : nullptr;
         const uint64_t mbase = FILL ? mk_off[i] : 0;
         unsigned char *lbase = LOG ? lg.base + i * lg.stride : nullptr;
-        SeedLogRec<P> *lrec = reinterpret_cast<SeedLogRec<P> *>(lbase + 8);
-        SeedLogWin *lwin = reinterpret_cast<SeedLogWin *>(lbase + 8 + static_cast<size_t>(lg.qs) * sizeof(SeedLogRec<P>));
+        // (the log's two arrays are addressed from lbase where they are written: two more pointers held over the whole walk cost the
+        //  logging instantiation its fourth wave per SIMD)
+        auto lrec = [&]() { return reinterpret_cast<SeedLogRec<P> *>(lbase + 8); };
+        auto lwin = [&]() { return reinterpret_cast<SeedLogWin *>(lbase + 8 + static_cast<size_t>(lg.qs) * sizeof(SeedLogRec<P>)); };
         uint32_t nw = 0;
         bool lover = LOG && (m >> 32) != 0;
         ByteCursor rd{reinterpret_cast<const uint4 *>(seqs), ~uint64_t(0), make_uint4(0, 0, 0, 0)};
@@ -499,7 +505,7 @@ __global__ __launch_bounds__(512, 3) void k_marker_seeds_ftab_runs2(const DevInd
                 for (uint64_t t = 0; t < cnt; ++t) d[t] = ix.mk_vals[src + t];
             }
             if (LOG) {
-                if (nw < lg.qw && ((src + cnt) >> 32) == 0) lwin[nw] = SeedLogWin{static_cast<uint32_t>(src), static_cast<uint32_t>(cnt)};
+                if (nw < lg.qw && ((src + cnt) >> 32) == 0) lwin()[nw] = SeedLogWin{static_cast<uint32_t>(src), static_cast<uint32_t>(cnt)};
                 else lover = true;
                 ++nw;
             }
@@ -512,7 +518,7 @@ __global__ __launch_bounds__(512, 3) void k_marker_seeds_ftab_runs2(const DevInd
             }
             if (LOG) {
                 if (ns < lg.qs && (tot >> 32) == 0)
-                    lrec[ns] = SeedLogRec<P>{static_cast<P>(l), static_cast<P>(h), static_cast<uint32_t>(qs), static_cast<uint32_t>(qe),
+                    lrec()[ns] = SeedLogRec<P>{static_cast<P>(l), static_cast<P>(h), static_cast<uint32_t>(qs), static_cast<uint32_t>(qe),
                                              static_cast<uint32_t>(mb_begin), static_cast<uint32_t>(tot)};
                 else lover = true;
             }

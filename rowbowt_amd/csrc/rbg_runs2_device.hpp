@@ -125,8 +125,31 @@ __device__ __forceinline__ void lane_narrow(const char *__restrict__ tent, const
 // scan of the window [p, p + zw] (zw + 1 <= 16 entries: the candidates and the entry after the last of them) for one or two
 // queries.  All requests -- four, or eight when the window is longer than eight entries -- are issued before the first is
 // waited for: one memory round trip per scan.
+// LEAN (the seeding kernels, whose walks hold enough state that the eight wide loads would cost them a wave per SIMD): four entries
+// at a time, a round trip per four -- crowded buckets are the rare case once the bucket records hold six entries.
+template <bool LEAN = false>
 __device__ __forceinline__ void lane_scan(const char *__restrict__ tent, const uint32_t p, const uint32_t zw, const uint32_t a_lo, LaneQ &A, LaneQ *B) {
     const RBG_GLOBAL char *base = as_global<char>(static_cast<const void *>(tent)) + static_cast<uint64_t>(p) * 8u;
+    if constexpr (LEAN) {
+#pragma unroll 1
+        for (uint32_t g = 0; g <= zw; g += 4u) {
+            const uint32_t g1 = g + 2u < zw ? g + 2u : zw;
+            const u32x4a8 w0 = *reinterpret_cast<const RBG_GLOBAL u32x4a8 *>(base + static_cast<uint64_t>(g < zw ? g : zw) * 8u);
+            const u32x4a8 w1 = *reinterpret_cast<const RBG_GLOBAL u32x4a8 *>(base + static_cast<uint64_t>(g1) * 8u);
+            // (a pair clamped to the window's last one is fed under its own indices: past every candidate, never below, never selected)
+            A.feed(g, w0.x - a_lo, w0.y);
+            A.feed(g + 1u, w0.z - a_lo, w0.w);
+            A.feed(g + 2u, w1.x - a_lo, w1.y);
+            A.feed(g + 3u, w1.z - a_lo, w1.w);
+            if (B) {
+                B->feed(g, w0.x - a_lo, w0.y);
+                B->feed(g + 1u, w0.z - a_lo, w0.w);
+                B->feed(g + 2u, w1.x - a_lo, w1.y);
+                B->feed(g + 3u, w1.z - a_lo, w1.w);
+            }
+        }
+        return;
+    }
     u32x4a8 w[4], v[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -176,6 +199,7 @@ struct LaneRec {
         w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
         w[8] = c.x; w[9] = c.y; w[10] = c.z; w[11] = c.w; w[12] = d.x; w[13] = d.y; w[14] = d.z; w[15] = d.w;
     }
+    template <bool LEAN = false>
     __device__ __forceinline__ void rank(const char *__restrict__ tent, const uint32_t a_lo, const uint32_t qa, uint32_t &c, uint32_t &lo32, bool &inside,
                                          uint64_t &e, uint32_t &rounds, uint32_t &ents) const {
         LaneQ Q;
@@ -185,7 +209,7 @@ struct LaneRec {
             uint32_t z = w[3];
             if (z > kLaneMaxZ) lane_narrow(tent, a_lo, qa, p, z, kLaneMaxZ, 8u, rounds);
             Q.zlim = z;
-            lane_scan(tent, p, z, a_lo, Q, nullptr);
+            lane_scan<LEAN>(tent, p, z, a_lo, Q, nullptr);
             ents += z + 1u;
         } else {
             const uint32_t n = w[2] & 7u;
@@ -209,7 +233,7 @@ struct LaneRec {
 
 // Both ranks of one LF step of ONE lane: rle_string::rank (rle_string.hpp:131-161) in the k-mer table `rec` of depth
 // index d at positions q0 = lo and q1 = hi + 1 (q0 <= q1).  out.samp_e = the entry whose sample a toehold re-sample needs.
-template <typename P, bool STATS = false>
+template <typename P, bool STATS = false, bool LEAN = false>
 __device__ __forceinline__ void lane_lf2(const RunSearch2<P> &S, const uint32_t d, const uint32_t rec, const uint64_t q0, const uint64_t q1, RunStep &out,
                                          unsigned long long *st = nullptr) {
     constexpr bool W = sizeof(P) == 8;
@@ -230,10 +254,10 @@ __device__ __forceinline__ void lane_lf2(const RunSearch2<P> &S, const uint32_t 
         uint64_t e0, e1;
         bool in0, in1;
         uint32_t rounds = 0, ents = 0;
-        rr.rank(tent, al0, static_cast<uint32_t>(q0) - al0, c0, lo0, in0, e0, rounds, ents);
+        rr.template rank<LEAN>(tent, al0, static_cast<uint32_t>(q0) - al0, c0, lo0, in0, e0, rounds, ents);
         const uint32_t h0 = rr.w[1];
         if (b1 != b0) rr.load(recs, R.dir_off + b1);
-        rr.rank(tent, al1, static_cast<uint32_t>(q1) - al1, c1, lo1, in1, e1, rounds, ents);
+        rr.template rank<LEAN>(tent, al1, static_cast<uint32_t>(q1) - al1, c1, lo1, in1, e1, rounds, ents);
         const uint32_t h1 = rr.w[1];
         if (STATS) { st[kStSearch] += rounds; st[kStDense] += ents; st[kStSteps] += 1; }
         const uint64_t y0 = static_cast<uint64_t>(h0) << 31, y1 = static_cast<uint64_t>(h1) << 31;
@@ -268,13 +292,13 @@ __device__ __forceinline__ void lane_lf2(const RunSearch2<P> &S, const uint32_t 
     if (shared) {
         B.qa = static_cast<uint32_t>(q1) - al0; B.zlim = p1 + z1 - p0;
         const uint32_t zw = B.zlim > z0 ? B.zlim : z0;
-        lane_scan(tent, p0, zw, al0, A, &B);
+        lane_scan<LEAN>(tent, p0, zw, al0, A, &B);
         if (STATS) st[kStDense] += zw + 1u;
         p1 = p0;
     } else {
         B.qa = qa1; B.zlim = z1;
-        lane_scan(tent, p0, z0, al0, A, nullptr);
-        lane_scan(tent, p1, z1, al1, B, nullptr);
+        lane_scan<LEAN>(tent, p0, z0, al0, A, nullptr);
+        lane_scan<LEAN>(tent, p1, z1, al1, B, nullptr);
         if (STATS) st[kStDense] += z0 + z1 + 2u;
     }
     // rank = cum + min(position - start, length of that run); its high part from the directory (rbg_dev.h RunDir64)
