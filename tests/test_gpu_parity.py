@@ -2749,7 +2749,9 @@ def test_pangenome_stream_true_bwt_beyond_32_bits(layout):
     assert c["reads"] == 20_000_000 and c["sum_occ"] == c["sum_locs"] > 500_000_000
     if layout == "runs":
         li = ix["layout_info"]
-        assert li["run_fmt"] == 2 and li["depths_dropped_budget"] == 0 and li["depths_dropped_limit"] == 0 and li["phi_directory"] == 1 and li["rank_directories"] == 1
+        assert li["run_fmt"] == 2 and li["depths_dropped_budget"] == 0 and li["depths_dropped_limit"] == 0
+        assert (li["rank_directories"] == 1) != (sum(li["rec_bytes"]) > 0)   # ranks: directories over the run lists, or bucket records
+        assert (li["phi_directory"] == 1) != (li["phi_slots"] > 0)      # phi: the list of sampled positions with its directory, or slots of about n / r rows
     print(f"n = {ix['n']:.3e}, {layout}: {d['value']:.3e} reads/s streamed, {ix['hbm_bytes'] / 1e9:.1f} GB replica")
 
 

@@ -28,7 +28,42 @@ def label(kernel):
     return None
 
 
+def label_runs(kernel):
+    """k_find_range_runs<P, TOEHOLD, PACKED, STATS, V2>: the byte-read, non-instrumented, format-2 launches (what bench.py --layout runs times)"""
+    k = kernel.replace("rbg::(anonymous namespace)::", "")
+    if "k_find_range_runs<" not in k:
+        return None
+    a = k.split("<", 1)[1].split(">", 1)[0].replace(" ", "").split(",")
+    if len(a) < 5 or a[2] != "false" or a[3] != "false" or a[4] != "true":
+        return None
+    pb = 8 if a[0] == "unsignedlong" else 4
+    return ("k_find_range<toehold>" if a[1] == "true" else "k_find_range<count>") + f" [runs, pos_bytes {pb}]"
+
+
+def merge_runs(target, d):
+    """--merge-runs <pmc_traffic.json> <run_indexed_pmc dir>: add the run-indexed kernels' counters (tools/pmc_run_indexed.sh) to the file"""
+    out = json.load(open(target))
+    per = collections.defaultdict(lambda: collections.defaultdict(float))
+    for f in sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True)):
+        for r in csv.DictReader(open(f)):
+            lab = label_runs(r["Kernel_Name"])
+            if lab:
+                per[(lab, r["Counter_Name"])][(f, r["Dispatch_Id"])] += float(r["Counter_Value"])
+    names = {"FETCH_SIZE": ("fetch_bytes", 1024), "WRITE_SIZE": ("write_bytes", 1024), "TCC_MISS_sum": ("tcc_miss_per_launch", 1),
+             "TCC_REQ_sum": ("tcc_req_per_launch", 1), "TCC_HIT_sum": ("tcc_hit_per_launch", 1)}
+    for (lab, ctr), disp in sorted(per.items()):
+        if ctr in names:
+            out.setdefault(lab, {})[names[ctr][0]] = max(disp.values()) * names[ctr][1]
+    for lab, v in out.items():
+        if isinstance(v, dict) and "fetch_bytes" in v and "write_bytes" in v:
+            v["hbm_bytes_per_launch"] = v["fetch_bytes"] + v["write_bytes"]
+    out["_source_runs"] = "keys with [runs, ...]: tools/pmc_run_indexed.sh (tools/tune.py, RBG_TUNE_LAYOUT=runs, the same index and batch), same library build"
+    json.dump(out, open(target, "w"), indent=1)
+
+
 def main():
+    if sys.argv[1] == "--merge-runs":
+        return merge_runs(sys.argv[2], sys.argv[3])
     d = sys.argv[1]
     per = collections.defaultdict(lambda: collections.defaultdict(float))  # (label, counter) -> dispatch -> value
     for f in sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True)):

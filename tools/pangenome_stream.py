@@ -413,7 +413,8 @@ def main():
                                                  "phi_directory": int(li.phi_directory), "phi_directory_dropped": int(li.phi_directory_dropped),
                                                  "entries": [int(x) for x in li.entries], "fillers": [int(x) for x in li.fillers], "dir_bytes": [int(x) for x in li.dir_bytes],
                                                  "phi_entries": int(li.phi_entries), "phi_fillers": int(li.phi_fillers), "phi_dir_bytes": int(li.phi_dir_bytes),
-                                                 "phi_dir_shift": int(li.phi_dir_shift), "phi_slots": int(li.phi_slots), "phi_slot_bytes": int(li.phi_slot_bytes)}
+                                                 "phi_dir_shift": int(li.phi_dir_shift), "phi_slots": int(li.phi_slots), "phi_slot_bytes": int(li.phi_slot_bytes),
+                                                 "rec_bytes": [int(x) for x in li.rec_bytes], "rec_overflow": [int(x) for x in li.rec_overflow]}
         out["config"]["index"]["text"] = "implicit (sampled from the pangenome's structure)" if implicit else "materialised in HBM"
         out["peaks"] = {"host_bytes": int(peaks["host_bytes"]), "host_limit_bytes": peaks["host_limit"], "hbm_bytes": int(peaks["hbm_bytes"])}
         print(json.dumps(out), flush=True)

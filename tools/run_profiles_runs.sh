@@ -7,6 +7,15 @@ tag=${1:-r04}
 out=gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+# PMC passes first (8- and 4-byte positions): their misses / bytes go into profiles/pmc_traffic.json beside the slot kernels' for the bench lines below
+bash tools/pmc_run_indexed.sh $tag -1:-1:256:5:8:48 > $out/pmc_run_indexed.log 2>&1
+python3 tools/make_pmc_traffic.py --merge-runs profiles/pmc_traffic.json $out/run_indexed_pmc
+mv $out/run_indexed_pmc.txt $out/run_indexed_pmc_pos8.txt
+rm -rf $out/run_indexed_pmc
+bash tools/pmc_run_indexed.sh $tag -1:-1:256:5:4:48 >> $out/pmc_run_indexed.log 2>&1
+python3 tools/make_pmc_traffic.py --merge-runs profiles/pmc_traffic.json $out/run_indexed_pmc
+mv $out/run_indexed_pmc.txt $out/run_indexed_pmc_pos4.txt
+cp profiles/pmc_traffic.json $out/pmc_traffic_with_runs.json
 for pb in 4 8; do
   timeout -k 10 600 python3 bench.py --layout runs --pos-bytes $pb --no-cpu-baseline --no-space-speed > $out/bench_runs_pos$pb.json 2> $out/bench_runs_pos$pb.err || { echo "bench --layout runs --pos-bytes $pb failed"; tail -5 $out/bench_runs_pos$pb.err; exit 1; }
 done
@@ -14,5 +23,4 @@ timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/s
 python3 tools/summarize_rocprof.py $out/stats_runs/*/*_kernel_stats.csv $out/stats_runs/*/*_kernel_trace.csv > $out/kernel_stats_run_indexed.md 2>&1
 rm -rf $out/stats_runs
 bash tools/fmt_ab.sh > $out/fmt_ab.txt 2>&1 || { echo "fmt_ab failed"; tail -5 $out/fmt_ab.txt; exit 1; }
-bash tools/pmc_run_indexed.sh $tag -1:-1:256:5:8:48 > $out/pmc_run_indexed.log 2>&1
-head -14 $out/kernel_stats_run_indexed.md; cat $out/fmt_ab.txt; head -30 $out/run_indexed_pmc.txt
+head -14 $out/kernel_stats_run_indexed.md; cat $out/fmt_ab.txt; grep -c . $out/run_indexed_pmc_pos8.txt $out/run_indexed_pmc_pos4.txt
