@@ -445,6 +445,10 @@ __global__ __launch_bounds__(256) void k_run_recs2(const RunEnt<P> *__restrict__
         if (cnt > kRec2Ents) {
             r.meta = kRec2Overflow;
             r.cum_end = static_cast<uint32_t>(cnt > 0xFFFFFFFFull ? 0xFFFFFFFFull : cnt);
+            // twelve pivots a stride apart (rbg_runs2_device.hpp LaneRec::rank): the starts of candidates stride, 2 x stride, ...
+            const uint64_t z = r.cum_end, stride = (z + 12) / 13;
+            for (uint64_t j = 0; j < 2 * kRec2Ents; ++j)
+                r.ent[j] = (j + 1) * stride < z ? static_cast<uint32_t>(static_cast<uint64_t>(e[e0 + (j + 1) * stride].start)) : 0xFFFFFFFFu;
             ++novf;
         } else {
             r.meta = static_cast<uint32_t>(cnt);

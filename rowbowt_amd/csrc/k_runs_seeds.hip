@@ -120,8 +120,9 @@ __device__ __forceinline__ bool ftab_state(const DevIndex &ix, ByteCursor &rd, c
     const uint64_t wave_first = static_cast<uint64_t>(blockIdx.x) * blockDim.x + (threadIdx.x & ~(kWave - 1))
 
 // both ranks of the step of every lane of the wave (format 1: cooperative, every lane must call; format 2: the lane's own)
-// LEAN: the narrow scan of crowded buckets (rbg_runs2_device.hpp lane_scan) -- for the instantiations whose state would otherwise
-// cost a workgroup per CU (512 threads: two or four waves per SIMD, nothing between); the others keep the one-round-trip scan
+// LEAN: one record in registers at a time (rbg_runs2_device.hpp lane_lf2) -- for the instantiation whose state would otherwise cost
+// a workgroup per CU (512 threads: two or four waves per SIMD, nothing between: the greedy seeds at 8-byte positions); the others
+// fetch both records of a step, and both scans of crowded buckets, together
 template <typename P, bool V2, bool LEAN = false>
 __device__ __forceinline__ void seeds_lf2(const DevIndex &ix, const RunSearch<P> &S, const RunSearch2<P> &S2, const bool stepping, const uint32_t d,
                                           const uint32_t rec, const uint64_t q0, const uint64_t q1, RunStep &r) {
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(512, V2 ? 3 : sizeof(P) == 4 ? 4 : 3) void k_greedy
                 stepping = true;
             }
             RunStep r;
-            seeds_lf2<P, V2, true>(ix, S, S2, stepping, pick.d, pick.rec, lo, hi + 1, r);
+            seeds_lf2<P, V2, (sizeof(P) == 8)>(ix, S, S2, stepping, pick.d, pick.rec, lo, hi + 1, r);
             if (stepping) {
                 const uint64_t c_inside = r.c_upto - r.c_before;
                 const bool ok = c_inside != 0;
@@ -426,7 +427,7 @@ __global__ __launch_bounds__(512, V2 ? 3 : sizeof(P) == 4 ? 4 : 3) void k_marker
                 stepping = true;
             }
             RunStep r;
-            seeds_lf2<P, V2, LOG>(ix, S, S2, stepping, pick.d, pick.rec, lo, hi + 1, r);
+            seeds_lf2<P, V2, false>(ix, S, S2, stepping, pick.d, pick.rec, lo, hi + 1, r);
             if (stepping) {
                 const uint64_t c_inside = r.c_upto - r.c_before;
                 const bool ok = c_inside != 0;

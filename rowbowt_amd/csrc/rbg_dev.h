@@ -247,8 +247,10 @@ struct RunDir64 { uint32_t count, hi; };   // directory entry at 8-byte position
 // directory sector plus the 1.6 sectors an unaligned stretch of the run list takes, and at every scale K1/K2 on this layout are bound
 // by exactly that sector count.  The record holds up to kRec2Ents entries {start, cum} (low words at 8-byte positions): the last
 // entry that starts before the bucket, then the ones that start inside it; `cum_end` is the cum of the entry after the last one
-// held (the length of its run).  A bucket with more candidates than that says so and the lane goes through the run list
-// (e0, cum_end = their number).  About 64 / 3 bytes per entry: the price of the speed, off when the budget is short.
+// held (the length of its run).  A bucket with more candidates than that says so (e0, cum_end = their number) and holds twelve
+// PIVOTS where the entries would be -- the starts of candidates stride, 2 x stride, ... with stride = ceil(number / 13) -- so that the
+// lane narrows thirteen-fold from the record itself and reads the run list once.  About 64 / 3 bytes per entry: the price of the
+// speed, off when the budget is short.
 constexpr uint32_t kRec2Ents = 6;
 constexpr uint32_t kRec2Overflow = 8u;   // meta bit 3
 struct alignas(64) RunRec2 {
@@ -256,7 +258,7 @@ struct alignas(64) RunRec2 {
     uint32_t hi;        // 8-byte positions: (cum of the entry before the bucket) >> 31 (RunDir64::hi); 0 otherwise
     uint32_t meta;      // bits 0-2: entries held (0..6); bit 3: overflow (none held)
     uint32_t cum_end;   // cum of the entry after the last one held; overflow: the number of candidates from e0 on
-    uint32_t ent[2 * kRec2Ents];
+    uint32_t ent[2 * kRec2Ents];   // {start, cum} of the entries held; overflow: twelve pivot starts
 };
 static_assert(sizeof(RunRec2) == 64, "one sector per bucket");
 constexpr uint32_t kRunFillShift = 30;     // fillers every 2^30 rows; directory shifts stay <= 30 at 8-byte positions (DevIndex::run_fill_shift;

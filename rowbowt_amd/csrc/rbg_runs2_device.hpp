@@ -190,7 +190,17 @@ __device__ __forceinline__ void lane_scan(const char *__restrict__ tent, const u
 
 // One bucket record in registers (rbg_dev.h RunRec2) and the rank of a position of its bucket: c = # entries of the table below the
 // position counted from the record's first (0: none below at all), lo32 = the rank's low word, inside = the position's left
-// neighbour lies in that run, e = the entry's index relative to the table's first.  An overflowing bucket goes through the run list.
+// neighbour lies in that run, e = the entry's index relative to the table's first.
+// An overflowing bucket (more candidates than a record holds) carries twelve pivots instead of entries: the lane narrows its
+// candidates thirteen-fold from the registers it already has, and what is left (eight entries or fewer up to 91 candidates; beyond
+// that lane_narrow's rounds first) is one scan of the run list -- pending(): the scan the caller still owes, so that the scans of
+// both positions of a step leave together.
+constexpr uint32_t kRecScanZ = 7u;   // candidates the scan after an overflowing record takes (+ the entry after them: four 16-byte loads)
+struct LaneRank {
+    uint32_t c = 0, lo32 = 0, p = 0, z = 0;   // (p, z): candidates [p, p + z) of the pending scan
+    bool inside = false, pending = false;
+    uint32_t qa = 0, a_lo = 0;
+};
 struct LaneRec {
     uint32_t w[16];
     __device__ __forceinline__ void load(const void *__restrict__ recs, const uint64_t at) {
@@ -199,33 +209,71 @@ struct LaneRec {
         w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
         w[8] = c.x; w[9] = c.y; w[10] = c.z; w[11] = c.w; w[12] = d.x; w[13] = d.y; w[14] = d.z; w[15] = d.w;
     }
-    template <bool LEAN = false>
-    __device__ __forceinline__ void rank(const char *__restrict__ tent, const uint32_t a_lo, const uint32_t qa, uint32_t &c, uint32_t &lo32, bool &inside,
-                                         uint64_t &e, uint32_t &rounds, uint32_t &ents) const {
+    // the part of a rank the record answers by itself
+    __device__ __forceinline__ void rank(const uint32_t a_lo, const uint32_t qa, LaneRank &out) const {
+        out.qa = qa; out.a_lo = a_lo;
+        out.p = w[0];
+        if (w[2] & kRec2Overflow) {
+            const uint32_t z = w[3], stride = (z + 12u) / 13u;
+            uint32_t m = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < 2 * kRec2Ents; ++j) m += ((j + 1u) * stride < z && w[4 + j] - a_lo < qa) ? 1u : 0u;
+            const uint32_t adv = m * stride;
+            out.p = w[0] + adv;
+            out.z = (z - adv) < stride ? (z - adv) : stride;
+            out.pending = true;
+            return;
+        }
         LaneQ Q;
         Q.qa = qa;
-        uint32_t p = w[0];
-        if (w[2] & kRec2Overflow) {
-            uint32_t z = w[3];
-            if (z > kLaneMaxZ) lane_narrow(tent, a_lo, qa, p, z, kLaneMaxZ, 8u, rounds);
-            Q.zlim = z;
-            lane_scan<LEAN>(tent, p, z, a_lo, Q, nullptr);
-            ents += z + 1u;
-        } else {
-            const uint32_t n = w[2] & 7u;
-            Q.zlim = n;
+        const uint32_t n = w[2] & 7u;
+        Q.zlim = n;
 #pragma unroll
-            for (uint32_t k = 0; k < kRec2Ents; ++k) Q.feed(k, w[4 + 2 * k] - a_lo, w[5 + 2 * k]);
-            Q.feed(kRec2Ents, 0u, w[3]);                 // (never below: closes the last run held when all six are)
-            if (n < kRec2Ents && Q.c == n && n) Q.kn = w[3];   // the last entry held is the answer: its run ends at cum_end
-        }
-        c = Q.c;
+        for (uint32_t k = 0; k < kRec2Ents; ++k) Q.feed(k, w[4 + 2 * k] - a_lo, w[5 + 2 * k]);
+        Q.feed(kRec2Ents, 0u, w[3]);                 // (never below: closes the last run held when all six are)
+        if (n < kRec2Ents && Q.c == n && n) Q.kn = w[3];   // the last entry held is the answer: its run ends at cum_end
+        out.c = Q.c;
         const uint32_t dd = Q.qa - Q.ks, len = Q.kn - Q.kc;
-        lo32 = Q.kc + (dd < len ? dd : len);
-        inside = dd <= len;
-        e = static_cast<uint64_t>(p) + Q.c - 1u;
+        out.lo32 = Q.kc + (dd < len ? dd : len);
+        out.inside = dd <= len;
+        out.pending = false;
     }
 };
+
+// the pending scans of one or two ranks (LaneRank::pending): every request of both is issued before the first is waited for
+__device__ __forceinline__ void lane_finish(const char *__restrict__ tent, LaneRank &A, LaneRank *B, uint32_t &rounds, uint32_t &ents) {
+    if (A.pending && A.z > kRecScanZ) lane_narrow(tent, A.a_lo, A.qa, A.p, A.z, kRecScanZ, 8u, rounds);
+    if (B && B->pending && B->z > kRecScanZ) lane_narrow(tent, B->a_lo, B->qa, B->p, B->z, kRecScanZ, 8u, rounds);
+    u32x4a8 wa[4], wb[4];
+    const bool pb = B && B->pending;
+    if (A.pending) {
+        const RBG_GLOBAL char *base = as_global<char>(static_cast<const void *>(tent)) + static_cast<uint64_t>(A.p) * 8u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wa[j] = *reinterpret_cast<const RBG_GLOBAL u32x4a8 *>(base + static_cast<uint64_t>(2u * j < A.z ? 2u * j : A.z) * 8u);
+    }
+    if (pb) {
+        const RBG_GLOBAL char *base = as_global<char>(static_cast<const void *>(tent)) + static_cast<uint64_t>(B->p) * 8u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wb[j] = *reinterpret_cast<const RBG_GLOBAL u32x4a8 *>(base + static_cast<uint64_t>(2u * j < B->z ? 2u * j : B->z) * 8u);
+    }
+    auto take = [&](LaneRank &R, const u32x4a8 (&w)[4]) {
+        LaneQ Q;
+        Q.qa = R.qa; Q.zlim = R.z;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // (a pair clamped to the window's last one is fed under its own indices: past every candidate, never below, never selected)
+            Q.feed(2u * j, w[j].x - R.a_lo, w[j].y);
+            Q.feed(2u * j + 1u, w[j].z - R.a_lo, w[j].w);
+        }
+        R.c = Q.c;
+        const uint32_t dd = Q.qa - Q.ks, len = Q.kn - Q.kc;
+        R.lo32 = Q.kc + (dd < len ? dd : len);
+        R.inside = dd <= len;
+        ents += R.z + 1u;
+    };
+    if (A.pending) take(A, wa);
+    if (pb) take(*B, wb);
+}
 
 // What the instrumented instantiations count on this format (the eight sums of SearchStat): [kStSteps] search steps,
 // [kStSlots] directory gathers (two neighbouring entries: 8 or 16 bytes), [kStDense] run-list entries the scans needed
@@ -245,26 +293,42 @@ __device__ __forceinline__ void lane_lf2(const RunSearch2<P> &S, const uint32_t 
     if (const void *__restrict__ recs = S.rec[d]) {   // ---- bucket records: one aligned 64-byte record per position (rbg_dev.h RunRec2) ----
         const uint32_t al0 = W ? static_cast<uint32_t>(b0 << sh) - (1u << S.fill) : 0u;
         const uint32_t al1 = W ? static_cast<uint32_t>(b1 << sh) - (1u << S.fill) : 0u;
-        // (one record in registers at a time: when hi + 1 falls into another bucket -- one step in seven -- its record is fetched after
-        //  the first position is answered; holding both cost sixteen registers on every step and pushed the seeding kernels into scratch)
-        LaneRec rr;
-        rr.load(recs, R.dir_off + b0);
-        if (STATS) st[kStSlots] += b1 != b0 ? 2 : 1;
-        uint32_t c0, lo0, c1, lo1;
-        uint64_t e0, e1;
-        bool in0, in1;
+        LaneRank A, B;
+        uint32_t h0, h1;
         uint32_t rounds = 0, ents = 0;
-        rr.template rank<LEAN>(tent, al0, static_cast<uint32_t>(q0) - al0, c0, lo0, in0, e0, rounds, ents);
-        const uint32_t h0 = rr.w[1];
-        if (b1 != b0) rr.load(recs, R.dir_off + b1);
-        rr.template rank<LEAN>(tent, al1, static_cast<uint32_t>(q1) - al1, c1, lo1, in1, e1, rounds, ents);
-        const uint32_t h1 = rr.w[1];
-        if (STATS) { st[kStSearch] += rounds; st[kStDense] += ents; st[kStSteps] += 1; }
+        if constexpr (LEAN) {
+            // (the seeding kernels: one record in registers at a time -- when hi + 1 falls into another bucket its record is fetched after
+            //  the first position is answered; holding both costs sixteen registers on every step and them a workgroup per CU)
+            LaneRec rr;
+            rr.load(recs, R.dir_off + b0);
+            rr.rank(al0, static_cast<uint32_t>(q0) - al0, A);
+            h0 = rr.w[1];
+            if (b1 != b0) {
+                lane_finish(tent, A, nullptr, rounds, ents);
+                rr.load(recs, R.dir_off + b1);
+            }
+            rr.rank(al1, static_cast<uint32_t>(q1) - al1, B);
+            h1 = rr.w[1];
+            if (b1 != b0) lane_finish(tent, B, nullptr, rounds, ents);
+            else lane_finish(tent, A, &B, rounds, ents);
+        } else {
+            // both records leave together, then both scans of the run list (overflowing buckets): the dependent round trips of a step are
+            // record -> scan [-> sample] whatever its two positions meet -- a wave waits for the longest chain among its 64 lanes
+            LaneRec r0, r1;
+            r0.load(recs, R.dir_off + b0);
+            if (b1 != b0) r1.load(recs, R.dir_off + b1);
+            r0.rank(al0, static_cast<uint32_t>(q0) - al0, A);
+            h0 = r0.w[1];
+            if (b1 != b0) { r1.rank(al1, static_cast<uint32_t>(q1) - al1, B); h1 = r1.w[1]; }
+            else { r0.rank(al1, static_cast<uint32_t>(q1) - al1, B); h1 = h0; }
+            lane_finish(tent, A, &B, rounds, ents);
+        }
+        if (STATS) { st[kStSlots] += b1 != b0 ? 2 : 1; st[kStSearch] += rounds; st[kStDense] += ents; st[kStSteps] += 1; }
         const uint64_t y0 = static_cast<uint64_t>(h0) << 31, y1 = static_cast<uint64_t>(h1) << 31;
-        out.c_before = c0 ? (W ? y0 + static_cast<uint32_t>(lo0 - static_cast<uint32_t>(y0)) : lo0) : 0;
-        out.c_upto = c1 ? (W ? y1 + static_cast<uint32_t>(lo1 - static_cast<uint32_t>(y1)) : lo1) : 0;
-        out.inside = c1 != 0 && in1;
-        out.samp_e = R.first + e1;
+        out.c_before = A.c ? (W ? y0 + static_cast<uint32_t>(A.lo32 - static_cast<uint32_t>(y0)) : A.lo32) : 0;
+        out.c_upto = B.c ? (W ? y1 + static_cast<uint32_t>(B.lo32 - static_cast<uint32_t>(y1)) : B.lo32) : 0;
+        out.inside = B.c != 0 && B.inside;
+        out.samp_e = R.first + static_cast<uint64_t>(B.p) + B.c - 1u;
         return;
     }
     const void *__restrict__ dir = S.dir[d];

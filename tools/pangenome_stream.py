@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--run-depths", type=lambda v: int(v, 0), default=0, help="RBG_OPT_RUN_DEPTHS: bit d - 1 = keep run lists of the k-mer depth d (run-indexed layout; 0 = all)")
     ap.add_argument("--kmer-steps", type=int, default=0, choices=(0, 1, 2, 3, 4, 5), help="RBG_OPT_KMER_STEPS (0 = the library's default, 5)")
     ap.add_argument("--run-phi", type=int, default=0, choices=(0, 1, 2), help="RBG_OPT_RUN_PHI: 1 = phi over the list of sampled positions, 2 = phi slots, 0 = the library's choice")
+    ap.add_argument("--run-rec", type=int, default=0, choices=(0, 1, 2), help="RBG_OPT_RUN_REC: 1 = directories over the run lists, 2 = bucket records, 0 = the library's choice")
     ap.add_argument("--ftab-k", type=int, default=-1, help="word length of the device ftab (-1 = the library's choice)")
     ap.add_argument("--hbm-reserve-gb", type=float, default=45.0,
                     help="HBM left to this tool's own buffers (reads, ranges, locations, sort workspace): the index replica gets the rest of "
@@ -182,6 +183,8 @@ def main():
         capi.set_default_option(capi.OPT_RUN_DEPTHS, args.run_depths)
     if args.run_phi:
         capi.set_default_option(capi.OPT_RUN_PHI, args.run_phi)
+    if args.run_rec:
+        capi.set_default_option(capi.OPT_RUN_REC, args.run_rec)
     if args.kmer_steps:
         capi.set_default_option(capi.OPT_KMER_STEPS, args.kmer_steps)
     if args.hbm_reserve_gb > 0:
