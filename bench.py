@@ -1022,14 +1022,33 @@ def main():
             out["space_speed"] = {"rows": rows}
             print(json.dumps(out))
             raise SystemExit("PARITY FAILURE: the run-indexed layout disagrees with the slot tables")
-        del ref_out, ref_locs
         # what the headline costs: the best count+locate rate among the replicas of at most 64 GB, and the rate of the replica a DEFAULT
-        # rbg_load builds (budget = a quarter of the free HBM: the deepest slot level that fits it)
+        # rbg_load builds -- no option set: budget = a quarter of the free HBM, RBG_LAYOUT_AUTO (slot tables if all five symbols per
+        # step fit that, else the run-indexed layout) -- built and timed here like the other rows
+        rb.close()
+        torch.cuda.empty_cache()
+        with capi.default_option(capi.OPT_HBM_BUDGET_MB, 0), capi.default_option(capi.OPT_RANK_LAYOUT, capi.LAYOUT_AUTO), capi.default_option(capi.OPT_KMER_STEPS, 5):
+            rb = ra.RowBowt.from_runs(inp["heads"], inp["lens"], inp["ssa"], inp["esa"], device=local_rank)
+        ms_df = time_search()
+        step()
+        rate_df = time_locate(ms_df)
+        step()
+        same_df = all(bool((a == b).all().item()) for a, b in zip(ref_out, (d_lo, d_hi, d_k, d_loc_off))) and bool((ref_locs == d_locs[:total_locs]).all().item())
+        ix_df, li_df = rb.info(), rb.layout_info()
+        runs_df = int(ix_df.rank_layout) == capi.LAYOUT_RUNS
+        out["value_library_default"] = {"value": rate_df, "hbm_bytes": int(ix_df.hbm_bytes), "layout": "runs" if runs_df else "slots",
+                                        "symbols_per_gather": int(ix_df.kmer_steps), "hbm_budget": int(ix_df.hbm_budget), "ms": ms_df,
+                                        "identical_to_slot_path_on_the_whole_batch": same_df,
+                                        **({"ranks": "bucket records" if sum(int(x) for x in li_df.rec_bytes) > 0 else "directories + run lists",
+                                            "phi": "slots of about n / r rows" if int(li_df.phi_slots) else "list of sampled positions + directory",
+                                            "depths": [d + 1 for d in range(5) if int(li_df.depth_mask_kept) >> d & 1]} if runs_df else {}),
+                                        "budget": "a quarter of the HBM free at load (rbg_load with no option set: RBG_LAYOUT_AUTO)"}
+        if not same_df:
+            print(json.dumps(out))
+            raise SystemExit("PARITY FAILURE: the library-default replica disagrees with the headline replica")
+        del ref_out, ref_locs
         within = [r_ for r_ in rows if r_["hbm_bytes"] <= 64e9]
         out["value_at_64GB"] = max((r_["count_locate_reads_per_s"] for r_ in within), default=None)
-        dflt = [r_ for r_ in rows if r_["layout"] == "slots" and r_["hbm_bytes"] <= int(ix.hbm_free_at_load) // 4]
-        out["value_library_default"] = ({"value": dflt[0]["count_locate_reads_per_s"], "hbm_bytes": dflt[0]["hbm_bytes"], "symbols_per_gather": dflt[0]["symbols_per_gather"],
-                                         "budget": "a quarter of the HBM free at load (rbg_load without RBG_OPT_HBM_BUDGET_MB)"} if dflt else None)
         out["space_speed"] = {"unit": "ms per launch of this run's batch (best of 3)", "rows": rows,
                               "note": "RBG_OPT_KMER_STEPS / the HBM budget rule pick the row; rbg_info reports which (symbols_per_gather, "
                                       "hbm_free_at_load, hbm_budget)"}

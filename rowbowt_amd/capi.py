@@ -21,7 +21,7 @@ MAXU = 2**64 - 1
 DEVICE_NONE = -1
 
 OPT_BLOCK_THREADS, OPT_RANK_BUCKET_SHIFT, OPT_PHI_BUCKET_SHIFT, OPT_POS_BYTES, OPT_KMER_STEPS, OPT_HBM_BUDGET_MB, OPT_FTAB_K, OPT_PACKED_READS, OPT_DEEP_BUCKET_SHIFT, OPT_DENSE_OVERFLOW, OPT_RANK_LAYOUT, OPT_TREE_TOP_KB, OPT_SLOT_BYTES, OPT_RUN_DEPTHS, OPT_RUN_FMT, OPT_RUN_PHI, OPT_RUN_REC = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17
-LAYOUT_AUTO, LAYOUT_SLOTS, LAYOUT_RUNS = 0, 1, 2
+LAYOUT_AUTO, LAYOUT_SLOTS, LAYOUT_RUNS, LAYOUT_PREFER_SLOTS = 0, 1, 2, 3
 (ARR_RUN_HEADS, ARR_RUN_START, ARR_SAMPLES_LAST, ARR_PRED_POS, ARR_PHI_BASE,
  ARR_MARKER_START, ARR_MARKER_END, ARR_MARKER_OFF, ARR_MARKER_VALS) = range(9)
 

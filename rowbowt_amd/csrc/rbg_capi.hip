@@ -59,6 +59,7 @@ struct rbg_index {
     uint64_t rank_slots = 0, rank_slots_overflow = 0, phi_slots = 0, phi_slots_overflow = 0;
     uint64_t kmer_steps_requested = 0, hbm_free_at_load = 0, hbm_budget = 0;  // how the space/speed point was chosen (rbg_info)
     bool runs_layout = false;
+    bool auto_runs = false;        // RBG_LAYOUT_AUTO chose the run-indexed layout because the slot tables of every requested symbol per step exceed the budget
     bool runs_forced = false;      // the composition already gave back the depths the run-indexed layout leaves out: no way back to slot tables
     uint32_t run_depth_mask = 0;   // run-indexed layout: the k-mer depths that have run lists (bit d - 1)
     // what the load decided about the run-indexed layout (rbg_layout_info): nothing is left out without a line here
@@ -112,6 +113,7 @@ int64_t env_opt(const char *name, int64_t dflt, int64_t lo, int64_t hi) {
         if (std::strcmp(e, "auto") == 0) return RBG_LAYOUT_AUTO;
         if (std::strcmp(e, "slots") == 0) return RBG_LAYOUT_SLOTS;
         if (std::strcmp(e, "runs") == 0) return RBG_LAYOUT_RUNS;
+        if (std::strcmp(e, "prefer-slots") == 0) return RBG_LAYOUT_PREFER_SLOTS;
     }
     char *end = nullptr;
     const long long v = std::strtoll(e, &end, 0);
@@ -130,7 +132,10 @@ std::atomic<int64_t> g_opt_hbm_budget_mb{env_opt("RBG_HBM_BUDGET_MB", 0, 0, int6
 std::atomic<int64_t> g_opt_ftab_k{env_opt("RBG_FTAB_K", -1, -1, 16)};
 std::atomic<int64_t> g_opt_deep_shift{-1};
 std::atomic<int64_t> g_opt_dense_overflow{1};
-std::atomic<int64_t> g_opt_rank_layout{env_opt("RBG_LAYOUT", RBG_LAYOUT_AUTO, RBG_LAYOUT_AUTO, RBG_LAYOUT_RUNS)};    // RBG_LAYOUT_AUTO / _SLOTS / _RUNS
+std::atomic<int64_t> g_opt_rank_layout{env_opt("RBG_LAYOUT", RBG_LAYOUT_AUTO, RBG_LAYOUT_AUTO, RBG_LAYOUT_PREFER_SLOTS)};    // RBG_LAYOUT_AUTO / _SLOTS / _RUNS / _PREFER_SLOTS
+// the two automatic settings (include/rbg.h): both take the run-indexed layout when not even the single-symbol slot tables fit the budget;
+// RBG_LAYOUT_AUTO also when the slot tables would have to give up symbols per step for it (rbg_index::auto_runs, decided by options_for)
+inline bool layout_automatic() { const int64_t v = g_opt_rank_layout.load(); return v == RBG_LAYOUT_AUTO || v == RBG_LAYOUT_PREFER_SLOTS; }
 std::atomic<int64_t> g_opt_tree_top_kb{48};   // LDS the staged top levels of the run-indexed search may take per workgroup
 std::atomic<int64_t> g_opt_run_depths{env_opt("RBG_RUN_DEPTHS", 0, 0, (1 << kMaxRunDepth) - 1)};    // run-indexed layout: bit d - 1 = keep the k-mer depth d (0 = every other depth from the deepest down)
 std::atomic<int64_t> g_opt_run_fmt{env_opt("RBG_RUN_FMT", 2, 1, 2)};   // run-indexed layout: 1 = {P, P} pairs probed by quads of lanes (rounds 2-3), 2 = per-lane probes (rbg_dev.h DevRunTab2)
@@ -1677,8 +1682,8 @@ int compose_on_device_k(rbg_index *ix, const uint32_t K) {
     // options_for makes) the depths its depth set leaves out give their arrays back as soon as the next depth is made.
     uint32_t keep_mask = 0;
     {
-        bool runs_certain = g_opt_rank_layout.load() == RBG_LAYOUT_RUNS;
-        if (g_opt_rank_layout.load() == RBG_LAYOUT_AUTO) {
+        bool runs_certain = g_opt_rank_layout.load() == RBG_LAYOUT_RUNS || ix->auto_runs;
+        if (!runs_certain && layout_automatic()) {
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
                 const int64_t opt_mb = g_opt_hbm_budget_mb.load();
@@ -1859,8 +1864,8 @@ int upload(rbg_index *ix) {
     // Layout: the slot tables cost n/16 bytes per table + n/2 (n at 8-byte positions) for phi, whatever r is.  When
     // even the single-symbol level does not fit the budget -- or on request -- the run-indexed layout takes over
     // (space proportional to r; wave-cooperative predecessor search, k_runs.hip).
-    bool runs_layout = g_opt_rank_layout.load() == RBG_LAYOUT_RUNS;
-    if (g_opt_rank_layout.load() == RBG_LAYOUT_AUTO) {
+    bool runs_layout = g_opt_rank_layout.load() == RBG_LAYOUT_RUNS || ix->auto_runs;
+    if (!runs_layout && layout_automatic()) {
         size_t lvl1 = 0;  // the single-symbol level alone
         {
             std::vector<SymTable> p2, p3, p4, p5;
@@ -1869,6 +1874,35 @@ int upload(rbg_index *ix) {
             p2.swap(h.pair); p3.swap(h.triple); p4.swap(h.quad); p5.swap(h.quint);
         }
         runs_layout = lvl1 > budget;
+    }
+    // RBG_LAYOUT_AUTO, second look (options_for's was an estimate from n alone, before anything was composed): if the slot tables of the
+    // levels at hand exceed the budget even with the wide buckets the rule below would give them, a level would now be dropped -- the
+    // run-indexed layout keeps them all instead, while it fits (about 110 bytes per run at its leanest)
+    if (!runs_layout && g_opt_rank_layout.load() == RBG_LAYOUT_AUTO && !h.pair.empty() && h.sigma <= static_cast<uint32_t>(kLdsSyms) &&
+        g_opt_slot_bytes.load() != 64 && need() > budget && 110.0 * static_cast<double>(h.r) <= static_cast<double>(budget)) {
+        std::vector<uint32_t> saved;
+        for (std::vector<SymTable> *lvl : {&h.quint, &h.quad, &h.triple, &h.pair})
+            for (SymTable &t : *lvl) saved.push_back(t.shift);
+        if (g_opt_deep_shift.load() < 0 && g_opt_rank_shift.load() < 0 && !(h.n >> 40))
+            for (std::vector<SymTable> *lvl : {&h.quint, &h.quad, &h.triple, &h.pair})
+                if (need() > budget)
+                    for (SymTable &t : *lvl) {
+                        const double rows_per_run = static_cast<double>(h.n) / static_cast<double>(std::max<uint64_t>(1, t.nruns));
+                        uint32_t want = 0;
+                        while (want < kMaxWideShift && static_cast<double>(uint64_t(2) << want) <= rows_per_run) ++want;
+                        if (want > t.shift) t.shift = want;
+                    }
+        const bool fits_widened = need() <= budget;
+        size_t k = 0;
+        for (std::vector<SymTable> *lvl : {&h.quint, &h.quad, &h.triple, &h.pair})
+            for (SymTable &t : *lvl) t.shift = saved[k++];
+        if (!fits_widened) {
+            if (std::getenv("RBG_VERBOSE"))
+                std::fprintf(stderr, "rbg: device %d: the slot tables of all k-mer levels exceed the %.1f GB replica budget: the run-indexed layout instead of fewer "
+                                     "symbols per step (RBG_LAYOUT_PREFER_SLOTS keeps slot tables)\n", ix->device, budget / 1e9);
+            runs_layout = true;
+            ix->auto_runs = true;
+        }
     }
     if (ix->runs_forced) runs_layout = true;
     if (runs_layout && h.sigma > static_cast<uint32_t>(kLdsSyms)) {
@@ -2068,9 +2102,10 @@ bool compose_deferred(int device) {
     return device != RBG_DEVICE_NONE && !(e && e[0] == '1');
 }
 
-FlattenOptions options_for(int device, const RawRle &rle, uint64_t *requested) {
+FlattenOptions options_for(int device, const RawRle &rle, uint64_t *requested, bool *auto_runs) {
     FlattenOptions o = current_options();
     *requested = 0;
+    *auto_runs = false;
     if (device == RBG_DEVICE_NONE || o.kmer_steps < 2) return o;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return o;
@@ -2089,7 +2124,7 @@ FlattenOptions options_for(int device, const RawRle &rle, uint64_t *requested) {
     // the run-indexed layout keeps its k-mer depths as run lists (space proportional to r): nothing to cap when it is
     // asked for, or when not even the single-symbol slot tables (+ phi at its widest usual bucket) fit
     if (g_opt_rank_layout.load() == RBG_LAYOUT_RUNS) return o;
-    if (g_opt_rank_layout.load() == RBG_LAYOUT_AUTO) {
+    if (layout_automatic()) {
         const double pos = (o.force_pos_bytes == 8 || rle.n >= 0xFFFFFFF0ull) ? 8 : 4;
         const double lvl1 = static_cast<double>(sigma) * static_cast<double>((rle.n >> kMaxNarrowShift) + 2) * (sizeof(RankSlot) + sizeof(uint32_t)) +
                             static_cast<double>((rle.n >> 6) + 2) * (4 * pos + 4);
@@ -2103,6 +2138,19 @@ FlattenOptions options_for(int device, const RawRle &rle, uint64_t *requested) {
         total += tables * per_table;
         if (total > budget) break;
         keep = k;
+    }
+    if (keep < o.kmer_steps && g_opt_rank_layout.load() == RBG_LAYOUT_AUTO && sigma <= static_cast<unsigned>(kLdsSyms)) {
+        // RBG_LAYOUT_AUTO: rather than give up symbols per step, the run-indexed layout (all of them, in space proportional to r) -- on
+        // the bench index 1.26e9 reads/s from 8.7 GB against 1.18e9 from the 59 GB of four symbols per step (profiles/r04_bench.json
+        // space_speed); about 110 bytes per run at its leanest (depths 1, 3, 5; phi over the list of sampled positions)
+        const double runs_least = 110.0 * static_cast<double>(rle.heads.size());
+        if (runs_least <= budget) {
+            if (std::getenv("RBG_VERBOSE"))
+                std::fprintf(stderr, "rbg: device %d: the slot tables of %d symbols per step exceed the %.1f GB replica budget (%d would fit): the run-indexed layout "
+                                     "instead (RBG_OPT_RANK_LAYOUT = RBG_LAYOUT_PREFER_SLOTS keeps slot tables with fewer symbols)\n", device, o.kmer_steps, budget / 1e9, keep);
+            *auto_runs = true;
+            return o;
+        }
     }
     if (keep < o.kmer_steps) {
         if (std::getenv("RBG_VERBOSE"))
@@ -2437,7 +2485,7 @@ int ftab_stream(rbg_index *ix, uint64_t k, Sink sink) {
 int index_from_bundle(FlatBundle &b, int device, rbg_index **out) {
     rbg_index *ix = new (std::nothrow) rbg_index();
     if (!ix) return RBG_ENOMEM;
-    FlattenOptions fo = options_for(device, b.rle, &ix->kmer_steps_requested);
+    FlattenOptions fo = options_for(device, b.rle, &ix->kmer_steps_requested, &ix->auto_runs);
     fo.defer_kmer = compose_deferred(device);
     int rc = flatten(b.rle, b.has_tsa ? &b.tsa : nullptr, fo, ix->host);
     if (rc) { delete ix; return rc; }
@@ -2532,7 +2580,7 @@ int rbg_set_default_option(int opt, int64_t value) {
             if (value < 0 || value > 2) return RBG_EARG;
             g_opt_packed_reads = value; return RBG_OK;
         case RBG_OPT_RANK_LAYOUT:
-            if (value != RBG_LAYOUT_AUTO && value != RBG_LAYOUT_SLOTS && value != RBG_LAYOUT_RUNS) return RBG_EARG;
+            if (value != RBG_LAYOUT_AUTO && value != RBG_LAYOUT_SLOTS && value != RBG_LAYOUT_RUNS && value != RBG_LAYOUT_PREFER_SLOTS) return RBG_EARG;
             g_opt_rank_layout = value; return RBG_OK;
         case RBG_OPT_TREE_TOP_KB:
             if (value < 0 || value > 96) return RBG_EARG;  // 0 = 16 keys in all: the deepest tree (tests)

@@ -152,12 +152,12 @@ def test_tuning_options_are_range_checked():
     ok = {capi.OPT_BLOCK_THREADS: [64, 128, 256], capi.OPT_RANK_BUCKET_SHIFT: [0, 8, 12, -1], capi.OPT_PHI_BUCKET_SHIFT: [0, 8, -1],
           capi.OPT_POS_BYTES: [4, 8, 0], capi.OPT_KMER_STEPS: [1, 3, 5], capi.OPT_HBM_BUDGET_MB: [1, 0], capi.OPT_FTAB_K: [0, 16, -1],
           capi.OPT_PACKED_READS: [0, 2, 1], capi.OPT_DEEP_BUCKET_SHIFT: [9, 12, -1], capi.OPT_DENSE_OVERFLOW: [0, 1],
-          capi.OPT_RANK_LAYOUT: [1, 2, 0], capi.OPT_TREE_TOP_KB: [0, 96, 48], capi.OPT_SLOT_BYTES: [64, 16], capi.OPT_RUN_DEPTHS: [0x15, 31, 0],
+          capi.OPT_RANK_LAYOUT: [1, 2, 3, 0], capi.OPT_TREE_TOP_KB: [0, 96, 48], capi.OPT_SLOT_BYTES: [64, 16], capi.OPT_RUN_DEPTHS: [0x15, 31, 0],
           capi.OPT_RUN_FMT: [1, 2], capi.OPT_RUN_PHI: [1, 2, 0], capi.OPT_RUN_REC: [1, 2, 0]}
     bad = {capi.OPT_BLOCK_THREADS: [0, 100, 512], capi.OPT_RANK_BUCKET_SHIFT: [-2, 13], capi.OPT_PHI_BUCKET_SHIFT: [-2, 9],
            capi.OPT_POS_BYTES: [2, 16], capi.OPT_KMER_STEPS: [0, 6], capi.OPT_HBM_BUDGET_MB: [-1], capi.OPT_FTAB_K: [-2, 17],
            capi.OPT_PACKED_READS: [-1, 3], capi.OPT_DEEP_BUCKET_SHIFT: [-2, 13], capi.OPT_DENSE_OVERFLOW: [-1, 2],
-           capi.OPT_RANK_LAYOUT: [-1, 3], capi.OPT_TREE_TOP_KB: [-1, 97], capi.OPT_SLOT_BYTES: [0, 32, 128], capi.OPT_RUN_DEPTHS: [-1, 32],
+           capi.OPT_RANK_LAYOUT: [-1, 4], capi.OPT_TREE_TOP_KB: [-1, 97], capi.OPT_SLOT_BYTES: [0, 32, 128], capi.OPT_RUN_DEPTHS: [-1, 32],
            capi.OPT_RUN_FMT: [0, 3], capi.OPT_RUN_PHI: [-1, 3], capi.OPT_RUN_REC: [-1, 3]}
     for opt, vals in ok.items():
         for v in bad[opt]:

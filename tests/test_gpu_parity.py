@@ -1502,9 +1502,19 @@ def test_packed_phi_slots_at_8_byte_positions(synth, phi_shift):
     o.close()
 
 
-def test_hbm_budget_drops_kmer_levels(synth):
-    """A tight memory budget keeps fewer k-mer levels; answers do not change."""
+@pytest.mark.parametrize("layout", [capi.LAYOUT_PREFER_SLOTS, capi.LAYOUT_AUTO])
+def test_hbm_budget_drops_kmer_levels(synth, layout):
+    """A tight memory budget keeps fewer k-mer levels (RBG_LAYOUT_PREFER_SLOTS) -- or, under RBG_LAYOUT_AUTO, switches to the
+    run-indexed layout with all five symbols per step while that fits (about 110 bytes per run); answers do not change."""
     S = synth
+    ra.set_default_option(capi.OPT_RANK_LAYOUT, layout)
+    try:
+        _hbm_budget_drops_kmer_levels(S, layout)
+    finally:
+        ra.set_default_option(capi.OPT_RANK_LAYOUT, capi.LAYOUT_AUTO)
+
+
+def _hbm_budget_drops_kmer_levels(S, layout):
     reads = S.sample_reads(500, 70, seed=2, sub_rate=0.1)
     seqs, off = ra.pack_reads(reads)
     o = orc.Oracle.from_runs(S.heads, S.lens, S.ssa, S.esa)
@@ -1514,7 +1524,7 @@ def test_hbm_budget_drops_kmer_levels(synth):
     assert rb.info().kmer_steps == 5
     rb.close()
     seen = set()
-    for frac in (0.7, 0.3, 0.08, 0.02):
+    for frac in (4.0, 0.7, 0.3, 0.08, 0.02):   # (the budget rule prices the replica with the composition's own lists: about 2.7 x what stays)
         ra.set_default_option(capi.OPT_HBM_BUDGET_MB, max(1, int(full * frac) >> 20))
         try:
             try:
@@ -1524,13 +1534,19 @@ def test_hbm_budget_drops_kmer_levels(synth):
                 continue
         finally:
             ra.set_default_option(capi.OPT_HBM_BUDGET_MB, 0)
-        seen.add(int(rb.info().kmer_steps))
+        runs = int(rb.info().rank_layout) == capi.LAYOUT_RUNS
+        seen.add("runs" if runs and layout == capi.LAYOUT_AUTO else int(rb.info().kmer_steps))
         # levels that cannot fit are not even composed (options_for in rbg_capi.hip); what was asked for is still reported
         assert int(rb.info().kmer_steps_requested) == 5 and int(rb.info().hbm_budget) == max(1, int(full * frac) >> 20) << 20
+        if runs and layout == capi.LAYOUT_AUTO and 110 * len(S.heads) <= int(rb.info().hbm_budget):
+            assert int(rb.info().kmer_steps) == 5        # the switch was made to keep the symbols per step
         got = rb.find_range_w_toehold(seqs, off)
         assert all((g == w).all() for g, w in zip(got, want))
         rb.close()
-    assert len(seen) >= 2 and min(seen) < 5
+    if layout == capi.LAYOUT_AUTO:
+        assert "runs" in seen and 5 in seen, seen        # five symbols from slot tables while they fit, then the run-indexed layout
+    else:
+        assert len(seen) >= 2 and min(seen) < 5
     o.close()
 
 
