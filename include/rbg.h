@@ -490,12 +490,13 @@ int rbg_sample_reads_pangenome_dev(const uint8_t *d_base, const uint64_t *d_site
  * 1 (default) = as 2-bit codes packed by CPU threads for batches of >= 4096 reads (a quarter of the bytes; reads
  * holding symbols outside the index's four k-mer symbols are searched from their bytes afterwards), 2 = always
  * as 2-bit codes.  (Packing a batch that is already in HBM is rbg_pack_reads_dev.)
- * RANK_LAYOUT: RBG_LAYOUT_AUTO (default): slot tables while those of every requested symbol per step (KMER_STEPS) fit the HBM
- * budget; otherwise the run-indexed layout rather than slot tables with fewer symbols per step (on the bench index 1.26e9
- * count+locate reads/s from 8.7 GB against 1.18e9 from the 59 GB of four symbols: profiles/r04_bench.json space_speed) -- unless
- * that does not fit either (about 110 bytes per run).  RBG_LAYOUT_PREFER_SLOTS: slot tables with as many symbols per step as
- * fit, the run-indexed layout only when not even the single-symbol level does (the rule of rounds 2-3; rb_markers asks for
- * it: its seeding kernels are faster on slot tables).  rbg_info::rank_layout reports the outcome.
+ * RANK_LAYOUT: RBG_LAYOUT_AUTO (default): slot tables while those of every requested symbol per step (KMER_STEPS), at their
+ * narrow buckets, fit the HBM budget; otherwise the run-indexed layout rather than slot tables with wider buckets or fewer
+ * symbols per step (on the bench index at the default budget 1.23e9 count+locate reads/s from 8.7 GB, against 1.13e9 from
+ * the 70 GB of five symbols in wide buckets and 1.14e9 from the 59 GB of four: profiles/r04_bench.json) -- unless that does
+ * not fit either (about 110 bytes per run).  RBG_LAYOUT_PREFER_SLOTS: slot tables with as many symbols per step as fit, the
+ * run-indexed layout only when not even the single-symbol level does (the rule of rounds 2-3; rb_markers asks for it: its
+ * seeding kernels are faster on slot tables).  rbg_info::rank_layout reports the outcome.
  * RBG_LAYOUT_SLOTS, RBG_LAYOUT_RUNS = the run-indexed layout: the run lists (of every k-mer depth KMER_STEPS asks
  * for and the budget holds) plus a 16-ary sampled index per depth, space proportional to r and nothing proportional
  * to n; rank and phi are wave-cooperative predecessor searches (rle_string::rank rle_string.hpp:131-161 /

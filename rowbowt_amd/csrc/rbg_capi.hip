@@ -1876,33 +1876,17 @@ int upload(rbg_index *ix) {
         runs_layout = lvl1 > budget;
     }
     // RBG_LAYOUT_AUTO, second look (options_for's was an estimate from n alone, before anything was composed): if the slot tables of the
-    // levels at hand exceed the budget even with the wide buckets the rule below would give them, a level would now be dropped -- the
-    // run-indexed layout keeps them all instead, while it fits (about 110 bytes per run at its leanest)
+    // levels at hand exceed the budget, the rule below would give the deep levels wider buckets and then drop levels -- the run-indexed
+    // layout keeps every level at full speed instead, while it fits (about 110 bytes per run at its leanest).  Measured on the bench
+    // index at the default budget: 1.13e9 reads/s from the 70 GB of five symbols in wide buckets, 1.14e9 from the 59 GB of four
+    // symbols, 1.23e9 from the 8.7 GB of this layout (profiles/r04_bench.json space_speed / value_library_default).
     if (!runs_layout && g_opt_rank_layout.load() == RBG_LAYOUT_AUTO && !h.pair.empty() && h.sigma <= static_cast<uint32_t>(kLdsSyms) &&
         g_opt_slot_bytes.load() != 64 && need() > budget && 110.0 * static_cast<double>(h.r) <= static_cast<double>(budget)) {
-        std::vector<uint32_t> saved;
-        for (std::vector<SymTable> *lvl : {&h.quint, &h.quad, &h.triple, &h.pair})
-            for (SymTable &t : *lvl) saved.push_back(t.shift);
-        if (g_opt_deep_shift.load() < 0 && g_opt_rank_shift.load() < 0 && !(h.n >> 40))
-            for (std::vector<SymTable> *lvl : {&h.quint, &h.quad, &h.triple, &h.pair})
-                if (need() > budget)
-                    for (SymTable &t : *lvl) {
-                        const double rows_per_run = static_cast<double>(h.n) / static_cast<double>(std::max<uint64_t>(1, t.nruns));
-                        uint32_t want = 0;
-                        while (want < kMaxWideShift && static_cast<double>(uint64_t(2) << want) <= rows_per_run) ++want;
-                        if (want > t.shift) t.shift = want;
-                    }
-        const bool fits_widened = need() <= budget;
-        size_t k = 0;
-        for (std::vector<SymTable> *lvl : {&h.quint, &h.quad, &h.triple, &h.pair})
-            for (SymTable &t : *lvl) t.shift = saved[k++];
-        if (!fits_widened) {
-            if (std::getenv("RBG_VERBOSE"))
-                std::fprintf(stderr, "rbg: device %d: the slot tables of all k-mer levels exceed the %.1f GB replica budget: the run-indexed layout instead of fewer "
-                                     "symbols per step (RBG_LAYOUT_PREFER_SLOTS keeps slot tables)\n", ix->device, budget / 1e9);
-            runs_layout = true;
-            ix->auto_runs = true;
-        }
+        if (std::getenv("RBG_VERBOSE"))
+            std::fprintf(stderr, "rbg: device %d: the slot tables of all k-mer levels (%.1f GB) exceed the %.1f GB replica budget: the run-indexed layout instead of "
+                                 "wider buckets or fewer symbols per step (RBG_LAYOUT_PREFER_SLOTS keeps slot tables)\n", ix->device, need() / 1e9, budget / 1e9);
+        runs_layout = true;
+        ix->auto_runs = true;
     }
     if (ix->runs_forced) runs_layout = true;
     if (runs_layout && h.sigma > static_cast<uint32_t>(kLdsSyms)) {
