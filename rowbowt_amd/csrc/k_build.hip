@@ -430,8 +430,9 @@ __global__ __launch_bounds__(256) void k_run_recs2(const RunEnt<P> *__restrict__
         uint64_t lo = 0, hi = nr;
         while (lo < hi) { const uint64_t mid = lo + ((hi - lo) >> 1); if (static_cast<uint64_t>(e[mid].start) < lim) lo = mid + 1; else hi = mid; }
         uint64_t up = lo;                            // # entries starting below the next bucket
-        while (up < nr && up < lo + kRec2Ents + 1 && static_cast<uint64_t>(e[up].start) < lim2) ++up;
-        if (up == lo + kRec2Ents + 1) {              // more than a record holds: count them all
+        constexpr uint64_t kScan = kRec2CompactIn + 2;   // (a compact record holds eleven; one more and the bucket overflows whatever its runs are)
+        while (up < nr && up < lo + kScan && static_cast<uint64_t>(e[up].start) < lim2) ++up;
+        if (up == lo + kScan) {                      // more than a record holds: count them all
             uint64_t l2 = up, h2 = nr;
             while (l2 < h2) { const uint64_t mid = l2 + ((h2 - l2) >> 1); if (static_cast<uint64_t>(e[mid].start) < lim2) l2 = mid + 1; else h2 = mid; }
             up = l2;
@@ -442,7 +443,27 @@ __global__ __launch_bounds__(256) void k_run_recs2(const RunEnt<P> *__restrict__
         r.hi = (sizeof(P) == 8 && lo) ? static_cast<uint32_t>(static_cast<uint64_t>(e[lo - 1].cum) >> 31) : 0u;
 #pragma unroll
         for (uint32_t k = 0; k < 2 * kRec2Ents; ++k) r.ent[k] = 0u;
-        if (cnt > kRec2Ents) {
+        bool compact = cnt >= 1 && cnt <= kRec2CompactIn + 1;
+        for (uint64_t j = 1; compact && j < cnt; ++j) {
+            const uint64_t off = static_cast<uint64_t>(e[e0 + j].start) - lim;     // (entries e0 + 1 .. start inside the bucket: lo <= e0 + 1)
+            const uint64_t len = static_cast<uint64_t>(e[e0 + j + 1].cum) - static_cast<uint64_t>(e[e0 + j].cum);
+            compact = static_cast<uint64_t>(e[e0 + j].start) >= lim && off < 0x10000ull && len < 0x10000ull;
+        }
+        if (compact) {
+            r.meta = static_cast<uint32_t>(cnt) | kRec2Compact;
+            r.cum_end = static_cast<uint32_t>(static_cast<uint64_t>(e[e0].cum));                      // cum of the first entry held
+            r.ent[0] = static_cast<uint32_t>(static_cast<uint64_t>(e[e0].start));
+            r.ent[1] = static_cast<uint32_t>(static_cast<uint64_t>(e[e0 + 1].cum) - static_cast<uint64_t>(e[e0].cum));   // its length (< 2^32: fillers)
+            for (uint64_t j = 1; j <= kRec2CompactIn; ++j) {
+                uint32_t v = 0x0000FFFFu;                                                              // (unused: offset 65535, length 0)
+                if (j < cnt) {
+                    const uint64_t off = static_cast<uint64_t>(e[e0 + j].start) - lim;
+                    const uint64_t len = static_cast<uint64_t>(e[e0 + j + 1].cum) - static_cast<uint64_t>(e[e0 + j].cum);
+                    v = static_cast<uint32_t>(off) | (static_cast<uint32_t>(len) << 16);
+                }
+                r.ent[1 + j] = v;
+            }
+        } else if (cnt > kRec2Ents) {
             r.meta = kRec2Overflow;
             r.cum_end = static_cast<uint32_t>(cnt > 0xFFFFFFFFull ? 0xFFFFFFFFull : cnt);
             // twelve pivots a stride apart (rbg_runs2_device.hpp LaneRec::rank): the starts of candidates stride, 2 x stride, ...

@@ -249,14 +249,22 @@ struct RunDir64 { uint32_t count, hi; };   // directory entry at 8-byte position
 // entry that starts before the bucket, then the ones that start inside it; `cum_end` is the cum of the entry after the last one
 // held (the length of its run).  A bucket with more candidates than that says so (e0, cum_end = their number) and holds twelve
 // PIVOTS where the entries would be -- the starts of candidates stride, 2 x stride, ... with stride = ceil(number / 13) -- so that the
-// lane narrows thirteen-fold from the record itself and reads the run list once.  About 64 / 3 bytes per entry: the price of the
-// speed, off when the budget is short.
+// lane narrows thirteen-fold from the record itself and reads the run list once.  About 64 / 2.5 bytes per entry: the price of the
+// speed, off when the budget is short.  (profiles/r04_rec_per_sweep.txt: 2.5 entries per bucket is the fastest on the bench index;
+// at n = 5e10 five per bucket run as fast from 31 GB less -- RBG_RUN_REC_PER.)
 constexpr uint32_t kRec2Ents = 6;
-constexpr uint32_t kRec2Overflow = 8u;   // meta bit 3
+constexpr uint32_t kRec2Overflow = 16u;  // meta bit 4
+// COMPACT records (meta bit 5): where every run that starts inside the bucket is shorter than 2^16 rows and starts less than 2^16 rows
+// into it -- nearly every bucket of a pangenome's deep tables -- the record holds the entry before the bucket in full
+// {cum (cum_end's place), start, length} and up to kRec2CompactIn entries inside it as {offset:16, length:16}: eleven entries instead of
+// six in the same sector, so a bucket may be twice as wide (half the records) and still overflow far less often.  rank = cum of the
+// first + the sum over the entries below the position of min(position - start, length) (the runs are disjoint and ascending).
+constexpr uint32_t kRec2Compact = 32u;
+constexpr uint32_t kRec2CompactIn = 10;
 struct alignas(64) RunRec2 {
     uint32_t e0;        // index (relative to the table's first entry) of the first entry held -- or of the first candidate of an overflowing bucket
     uint32_t hi;        // 8-byte positions: (cum of the entry before the bucket) >> 31 (RunDir64::hi); 0 otherwise
-    uint32_t meta;      // bits 0-2: entries held (0..6); bit 3: overflow (none held)
+    uint32_t meta;      // bits 0-3: entries held (0..6; 0..11 compact); bit 4: overflow (none held); bit 5: compact
     uint32_t cum_end;   // cum of the entry after the last one held; overflow: the number of candidates from e0 on
     uint32_t ent[2 * kRec2Ents];   // {start, cum} of the entries held; overflow: twelve pivot starts
 };

@@ -210,9 +210,32 @@ struct LaneRec {
         w[8] = c.x; w[9] = c.y; w[10] = c.z; w[11] = c.w; w[12] = d.x; w[13] = d.y; w[14] = d.z; w[15] = d.w;
     }
     // the part of a rank the record answers by itself
-    __device__ __forceinline__ void rank(const uint32_t a_lo, const uint32_t qa, LaneRank &out) const {
+    // o = the position's offset into its bucket (compact records)
+    __device__ __forceinline__ void rank(const uint32_t a_lo, const uint32_t qa, const uint32_t o, LaneRank &out) const {
         out.qa = qa; out.a_lo = a_lo;
         out.p = w[0];
+        if (w[2] & kRec2Compact) {
+            const uint32_t n = w[2] & 15u;
+            const uint32_t s0 = w[4] - a_lo;
+            const bool b0 = n != 0u && s0 < qa;
+            uint32_t ld = qa - s0, ll = w[5];
+            uint32_t add = b0 ? (ld < ll ? ld : ll) : 0u, c = b0 ? 1u : 0u;
+#pragma unroll
+            for (uint32_t k = 0; k < kRec2CompactIn; ++k) {
+                const uint32_t v = w[6 + k], off = v & 0xFFFFu, len = v >> 16;
+                const bool below = k + 1u < n && off < o;
+                const uint32_t d = o - off;
+                add += below ? (d < len ? d : len) : 0u;
+                c += below ? 1u : 0u;
+                ld = below ? d : ld;
+                ll = below ? len : ll;
+            }
+            out.c = c;
+            out.lo32 = w[3] + add;
+            out.inside = ld <= ll;
+            out.pending = false;
+            return;
+        }
         if (w[2] & kRec2Overflow) {
             const uint32_t z = w[3], stride = (z + 12u) / 13u;
             uint32_t m = 0;
@@ -226,7 +249,7 @@ struct LaneRec {
         }
         LaneQ Q;
         Q.qa = qa;
-        const uint32_t n = w[2] & 7u;
+        const uint32_t n = w[2] & 15u;
         Q.zlim = n;
 #pragma unroll
         for (uint32_t k = 0; k < kRec2Ents; ++k) Q.feed(k, w[4 + 2 * k] - a_lo, w[5 + 2 * k]);
@@ -301,13 +324,13 @@ __device__ __forceinline__ void lane_lf2(const RunSearch2<P> &S, const uint32_t 
             //  the first position is answered; holding both costs sixteen registers on every step and them a workgroup per CU)
             LaneRec rr;
             rr.load(recs, R.dir_off + b0);
-            rr.rank(al0, static_cast<uint32_t>(q0) - al0, A);
+            rr.rank(al0, static_cast<uint32_t>(q0) - al0, static_cast<uint32_t>(q0 - (b0 << sh)), A);
             h0 = rr.w[1];
             if (b1 != b0) {
                 lane_finish(tent, A, nullptr, rounds, ents);
                 rr.load(recs, R.dir_off + b1);
             }
-            rr.rank(al1, static_cast<uint32_t>(q1) - al1, B);
+            rr.rank(al1, static_cast<uint32_t>(q1) - al1, static_cast<uint32_t>(q1 - (b1 << sh)), B);
             h1 = rr.w[1];
             if (b1 != b0) lane_finish(tent, B, nullptr, rounds, ents);
             else lane_finish(tent, A, &B, rounds, ents);
@@ -317,10 +340,10 @@ __device__ __forceinline__ void lane_lf2(const RunSearch2<P> &S, const uint32_t 
             LaneRec r0, r1;
             r0.load(recs, R.dir_off + b0);
             if (b1 != b0) r1.load(recs, R.dir_off + b1);
-            r0.rank(al0, static_cast<uint32_t>(q0) - al0, A);
+            r0.rank(al0, static_cast<uint32_t>(q0) - al0, static_cast<uint32_t>(q0 - (b0 << sh)), A);
             h0 = r0.w[1];
-            if (b1 != b0) { r1.rank(al1, static_cast<uint32_t>(q1) - al1, B); h1 = r1.w[1]; }
-            else { r0.rank(al1, static_cast<uint32_t>(q1) - al1, B); h1 = h0; }
+            if (b1 != b0) { r1.rank(al1, static_cast<uint32_t>(q1) - al1, static_cast<uint32_t>(q1 - (b1 << sh)), B); h1 = r1.w[1]; }
+            else { r0.rank(al1, static_cast<uint32_t>(q1) - al1, static_cast<uint32_t>(q1 - (b1 << sh)), B); h1 = h0; }
             lane_finish(tent, A, &B, rounds, ents);
         }
         if (STATS) { st[kStSlots] += b1 != b0 ? 2 : 1; st[kStSearch] += rounds; st[kStDense] += ents; st[kStSteps] += 1; }

@@ -1903,6 +1903,11 @@ def test_run_indexed_layout(synth, pos_bytes, top_kb, fk, ks, rec, fmt):
         os.environ["RBG_RANK_DIR"] = "0"  # ranks likewise
     if rec is not None:
         os.environ["RBG_RANK_REC"] = rec
+    # (compact records hold eleven entries: at the default 2.5 per bucket none of this index's buckets overflows; the 8-byte variants
+    #  take buckets of about nine entries so that overflowing records -- pivots, then the run list -- are met here too)
+    rec_per = "9" if recs and pos_bytes == 8 else None
+    if rec_per:
+        os.environ["RBG_RUN_REC_PER"] = rec_per
     if rec is not None or ks == 4:   # run lists at every depth (otherwise the default: every other depth from the deepest down)
         ra.set_default_option(capi.OPT_RUN_DEPTHS, (1 << ks) - 1)
     try:
@@ -1918,6 +1923,7 @@ def test_run_indexed_layout(synth, pos_bytes, top_kb, fk, ks, rec, fmt):
         os.environ.pop("RBG_PHI_DIR", None)
         os.environ.pop("RBG_RANK_DIR", None)
         os.environ.pop("RBG_RANK_REC", None)
+        os.environ.pop("RBG_RUN_REC_PER", None)
     info = rb.info()
     assert info.rank_layout == capi.LAYOUT_RUNS and info.kmer_steps == ks and info.pos_bytes == (pos_bytes or 4)
     assert info.rank_slots == 0 and (info.phi_slots == 0) != phi_slots
@@ -1928,7 +1934,7 @@ def test_run_indexed_layout(synth, pos_bytes, top_kb, fk, ks, rec, fmt):
     assert [d + 1 for d in range(5) if li.depth_mask_kept >> d & 1] == [1] + [d for d in lists]
     if fmt == 2:
         assert li.rank_directories == (0 if recs else 1) and li.phi_entries == len(S.heads) and sum(li.fillers) == 0
-        assert all((li.rec_bytes[d] > 0) == (recs and bool(li.depth_mask_kept >> d & 1)) for d in range(5)) and (not recs or sum(li.rec_overflow) > 0)
+        assert all((li.rec_bytes[d] > 0) == (recs and bool(li.depth_mask_kept >> d & 1)) for d in range(5)) and (not rec_per or sum(li.rec_overflow) > 0)
         assert (li.phi_slots > 0 and li.phi_directory == 0 and rb.info().phi_slots == li.phi_slots) if phi_slots else (li.phi_slots == 0 and li.phi_directory == 1)
         assert all((li.entries[d] > 0) == bool(li.depth_mask_kept >> d & 1) for d in range(5))
     _run_indexed_checks(S, rb)
