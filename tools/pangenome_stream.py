@@ -262,7 +262,7 @@ def main():
         torch.cuda.synchronize()
 
     # per-kernel times of one batch (outside the timed region; HIP events on the launch stream)
-    kernel_ms = {}
+    kernel_ms, touched = {}, None
     if rank == 0:
         def timed(fn):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -281,6 +281,15 @@ def main():
             kernel_ms["locate_fill"] = timed(lambda: chk(Lb.rbg_locate_fill_dev(rb.h, d_lo.data_ptr(), d_hi.data_ptr(), d_k.data_ptr(), N, max_hits,
                                                                                    d_loc_off.data_ptr(), d_locs.data_ptr(), d_ws.data_ptr(), st), "fill"))
         log("one batch, per kernel (ms): " + ", ".join(f"{k} {v:.2f}" for k, v in kernel_ms.items()))
+        # what the search of one batch touched (the instrumented instantiation of the same kernel; include/rbg.h SearchStat): per read
+        d_stats = torch.zeros(16, dtype=torch.int64, device=dev)
+        chk(Lb.rbg_find_range_stats_dev(rb.h, d_seqs.data_ptr(), d_off.data_ptr(), N, d_lo.data_ptr(), d_hi.data_ptr(),
+                                        None if args.count_only else d_k.data_ptr(), d_stats.data_ptr(), st), "find_range_stats")
+        torch.cuda.synchronize()
+        touched = dict(zip(("steps", "slots", "dense", "searched_ranks", "ftab", "resamples", "read_chunks", "symbols"), (d_stats.cpu().numpy()[:8] / N).round(3).tolist()))
+        log("one batch, per read: " + ", ".join(f"{k} {v}" for k, v in touched.items()) +
+            "   (run-indexed layout: slots = bucket records or directory gathers, dense = run-list entries scanned, searched_ranks = narrowing rounds)")
+        rb.counters_reset()
 
     rb.counters_reset()
     ev_g = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
@@ -316,7 +325,7 @@ def main():
             "value": args.total_reads / el, "unit": "reads/s", "n_gpus": world, "higher_is_better": True, "scaling": "strong",
             "value_excluding_read_generation": args.total_reads / max(el - t_gen, 1e-9),
             "seconds": el, "seconds_generating_reads": t_gen, "batches_per_gpu": nbatch, "reads_per_batch": N,
-            "kernel_ms_one_batch": kernel_ms,
+            "kernel_ms_one_batch": kernel_ms, "search_touched_per_read": touched,
             "dtype": "u64" if ix.pos_bytes == 8 else "u32/u64", "data": "synthetic",
             "config": {"workload": f"BASELINE.json configs[3] shape: {args.total_reads} synthetic {m} bp reads generated on the device per batch "
                                    f"(counter-based RNG), {'find_range' if args.count_only else 'find_range_w_toehold + locs_at'}, "
