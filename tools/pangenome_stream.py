@@ -46,6 +46,9 @@ def main():
     ap.add_argument("--kmer-steps", type=int, default=0, choices=(0, 1, 2, 3, 4, 5), help="RBG_OPT_KMER_STEPS (0 = the library's default, 5)")
     ap.add_argument("--run-phi", type=int, default=0, choices=(0, 1, 2), help="RBG_OPT_RUN_PHI: 1 = phi over the list of sampled positions, 2 = phi slots, 0 = the library's choice")
     ap.add_argument("--run-rec", type=int, default=0, choices=(0, 1, 2), help="RBG_OPT_RUN_REC: 1 = directories over the run lists, 2 = bucket records, 0 = the library's choice")
+    ap.add_argument("--replica-probe", action="store_true",
+                    help="after the per-kernel times: copy the device index once more onto the same device (rbg_replicate: fresh allocations, no composition "
+                         "going on around them) and time the search kernel on the copy -- does the PLACEMENT of the arrays matter?")
     ap.add_argument("--ftab-k", type=int, default=-1, help="word length of the device ftab (-1 = the library's choice)")
     ap.add_argument("--hbm-reserve-gb", type=float, default=45.0,
                     help="HBM left to this tool's own buffers (reads, ranges, locations, sort workspace): the index replica gets the rest of "
@@ -281,6 +284,15 @@ def main():
             kernel_ms["locate_fill"] = timed(lambda: chk(Lb.rbg_locate_fill_dev(rb.h, d_lo.data_ptr(), d_hi.data_ptr(), d_k.data_ptr(), N, max_hits,
                                                                                    d_loc_off.data_ptr(), d_locs.data_ptr(), d_ws.data_ptr(), st), "fill"))
         log("one batch, per kernel (ms): " + ", ".join(f"{k} {v:.2f}" for k, v in kernel_ms.items()))
+        if args.replica_probe:
+            rep = rb.replicate(local_rank)
+            def search_rep():
+                chk(Lb.rbg_find_range_w_toehold_dev(rep.h, d_seqs.data_ptr(), d_off.data_ptr(), N, d_lo.data_ptr(), d_hi.data_ptr(), d_k.data_ptr(), st), "find_range_w_toehold")
+            search_rep()
+            t_rep = min(timed(search_rep) for _ in range(3))
+            t_own = min(timed(lambda: search(N)) for _ in range(3))
+            log(f"replica probe: find_range_w_toehold {t_own:.2f} ms on the index as loaded, {t_rep:.2f} ms on a copy of it in fresh allocations")
+            rep.close()
         # what the search of one batch touched (the instrumented instantiation of the same kernel; include/rbg.h SearchStat): per read
         d_stats = torch.zeros(16, dtype=torch.int64, device=dev)
         chk(Lb.rbg_find_range_stats_dev(rb.h, d_seqs.data_ptr(), d_off.data_ptr(), N, d_lo.data_ptr(), d_hi.data_ptr(),
