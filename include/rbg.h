@@ -543,7 +543,8 @@ enum { RBG_OPT_BLOCK_THREADS = 1, RBG_OPT_RANK_BUCKET_SHIFT = 2, RBG_OPT_PHI_BUC
                                   count); 0 (default) = slots when the whole replica then stays within half the HBM budget.  RBG_RUN_PHI gives the
                                   initial value; rbg_layout_info().phi_slots says what was built. */,
        RBG_OPT_RUN_REC = 17 /* run-indexed layout, format 2 -- BUCKET RECORDS: 2 = every bucket of a table (about three entries wide) gets one aligned
-                                  64-byte record holding its entries and the one before them, direct-addressed: a rank is ONE sector instead of a
+                                  64-byte record holding its entries and the one before them (up to eleven in the compact form, six otherwise; a bucket with
+                                  more holds twelve pivots into the run list instead: rbg_dev.h RunRec2), direct-addressed: a rank is ONE sector instead of a
                                   directory sector plus an unaligned stretch of the run list (K1/K2 on this layout are bound by that count); about
                                   21-26 bytes per entry on top of the run lists, which stay for crowded buckets and the samples; 1 = directories only;
                                   0 (default) = records when the replica with them stays within half the HBM budget.  RBG_RUN_REC gives the initial
