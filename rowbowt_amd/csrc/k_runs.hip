@@ -192,7 +192,7 @@ __global__ __launch_bounds__(512, STATS ? 2 : (V2 || sizeof(P) == 4) ? 4 : 3) vo
             }
             RunStep r;
             // rank(lo, c), rank(hi + 1, c): rowbowt.hpp:79,83
-            if constexpr (V2) { if (stepping) lane_lf2<P, STATS>(S2, d, rec, lo, hi + 1, r, st); }
+            if constexpr (V2) lane_lf2_quad<P, STATS>(S2, stepping, d, rec, lo, hi + 1, r, st);   // (every lane of the wave: the records are fetched by quads)
             else coop_lf2<P, STATS>(ix, S, stepping, d, rec, lo, hi + 1, r, st);
             if (stepping) {
                 if (STATS) st[kStSymbols] += adv;

@@ -123,10 +123,14 @@ __device__ __forceinline__ bool ftab_state(const DevIndex &ix, ByteCursor &rd, c
 // LEAN: one record in registers at a time (rbg_runs2_device.hpp lane_lf2) -- for the instantiation whose state would otherwise cost
 // a workgroup per CU (512 threads: two or four waves per SIMD, nothing between: the greedy seeds at 8-byte positions); the others
 // fetch both records of a step, and both scans of crowded buckets, together
-template <typename P, bool V2, bool LEAN = false>
+// QUAD: the first record of a step fetched by the lane's quad (rbg_runs2_device.hpp lane_lf2_quad); not where its registers would cost the workgroup
+template <typename P, bool V2, bool LEAN = false, bool QUAD = true>
 __device__ __forceinline__ void seeds_lf2(const DevIndex &ix, const RunSearch<P> &S, const RunSearch2<P> &S2, const bool stepping, const uint32_t d,
                                           const uint32_t rec, const uint64_t q0, const uint64_t q1, RunStep &r) {
-    if constexpr (V2) { if (stepping) lane_lf2<P, false, LEAN>(S2, d, rec, q0, q1, r); }
+    if constexpr (V2) {
+        if constexpr (QUAD) lane_lf2_quad<P, false, LEAN>(S2, stepping, d, rec, q0, q1, r);   // (every lane calls)
+        else { if (stepping) lane_lf2<P, false, LEAN>(S2, d, rec, q0, q1, r); }
+    }
     else coop_lf2<P>(ix, S, stepping, d, rec, q0, q1, r);
 }
 template <typename P, bool V2>
@@ -291,7 +295,7 @@ __global__ __launch_bounds__(512, V2 ? 3 : sizeof(P) == 4 ? 4 : 3) void k_greedy
                 stepping = true;
             }
             RunStep r;
-            seeds_lf2<P, V2, (sizeof(P) == 8)>(ix, S, S2, stepping, pick.d, pick.rec, lo, hi + 1, r);
+            seeds_lf2<P, V2, (sizeof(P) == 8), false>(ix, S, S2, stepping, pick.d, pick.rec, lo, hi + 1, r);
             if (stepping) {
                 const uint64_t c_inside = r.c_upto - r.c_before;
                 const bool ok = c_inside != 0;
@@ -427,7 +431,7 @@ __global__ __launch_bounds__(512, V2 ? 3 : sizeof(P) == 4 ? 4 : 3) void k_marker
                 stepping = true;
             }
             RunStep r;
-            seeds_lf2<P, V2, false>(ix, S, S2, stepping, pick.d, pick.rec, lo, hi + 1, r);
+            seeds_lf2<P, V2, true>(ix, S, S2, stepping, pick.d, pick.rec, lo, hi + 1, r);
             if (stepping) {
                 const uint64_t c_inside = r.c_upto - r.c_before;
                 const bool ok = c_inside != 0;

@@ -411,6 +411,99 @@ __device__ __forceinline__ void lane_lf2(const RunSearch2<P> &S, const uint32_t 
     if (STATS) st[kStSteps] += 1;
 }
 
+// ---- the same step with the FIRST record of every lane fetched by its QUAD (k_find_range_runs) ----------------------------------------
+// A lane that reads its own 64-byte record issues four 16-byte requests to one line in four instructions: four address translations and four
+// L1 lookups where the data is one sector.  Here the four lanes of a quad read the record of each of them in turn -- lane p the p-th sixteen
+// bytes, one instruction per record, the quad's four requests coalesced into one line -- and a 4 x 4 transpose through two quad permutes puts
+// every record in its owner's registers: a quarter of the L1 accesses for the same sectors (profiles/r04_scale_probe.txt: what the search pays
+// for beyond 10 GB of index is not sectors).  Called by ALL lanes of the wave; the rare second record (hi + 1 in another bucket) and the scans
+// of overflowing buckets are fetched by the lane itself as in lane_lf2.
+__device__ __forceinline__ uint32_t quad_xor1(const uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(v), 0xB1, 0xF, 0xF, true)); }   // quad_perm [1,0,3,2]
+__device__ __forceinline__ uint32_t quad_xor2(const uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(v), 0x4E, 0xF, 0xF, true)); }   // quad_perm [2,3,0,1]
+template <int C>
+__device__ __forceinline__ uint32_t quad_bcast(const uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(v), C * 0x55, 0xF, 0xF, true)); }
+// w[4 r + k] = word k of the chunk this lane read in round r (chunk p of the record of quad lane r)  ->  word k of chunk r of its OWN record
+__device__ __forceinline__ void quad_transpose16(uint32_t (&w)[16], const uint32_t p) {
+    const bool p0 = (p & 1u) != 0u, p1 = (p & 2u) != 0u;
+#pragma unroll
+    for (int b = 0; b < 4; b += 2)          // distance 1: registers (b, b + 1)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t lo = w[4 * b + k], hi = w[4 * (b + 1) + k];
+            const uint32_t t = quad_xor1(p0 ? lo : hi);
+            w[4 * b + k] = p0 ? t : lo;
+            w[4 * (b + 1) + k] = p0 ? hi : t;
+        }
+#pragma unroll
+    for (int b = 0; b < 2; ++b)             // distance 2: registers (b, b + 2)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t lo = w[4 * b + k], hi = w[4 * (b + 2) + k];
+            const uint32_t t = quad_xor2(p1 ? lo : hi);
+            w[4 * b + k] = p1 ? t : lo;
+            w[4 * (b + 2) + k] = p1 ? hi : t;
+        }
+}
+// LEAN: the second record (hi + 1 in another bucket) is fetched into the first one's registers once that is answered (the seeding kernels)
+template <typename P, bool STATS = false, bool LEAN = false>
+__device__ __forceinline__ void lane_lf2_quad(const RunSearch2<P> &S, const bool stepping, const uint32_t d, const uint32_t rec, const uint64_t q0, const uint64_t q1,
+                                              RunStep &out, unsigned long long *st = nullptr) {
+    constexpr bool W = sizeof(P) == 8;
+    if (!S.rec[0]) {                       // (uniform: directories over the run lists)
+        if (stepping) lane_lf2<P, STATS>(S, d, rec, q0, q1, out, st);
+        return;
+    }
+    const uint32_t p = threadIdx.x & 3u;
+    DevRunTab2 R = S.tab[stepping ? rec : 0u];
+    const uint32_t sh = R.dir_shift;
+    const uint64_t b0 = stepping ? q0 >> sh : 0u, b1 = stepping ? q1 >> sh : 0u;
+    const char *recs = static_cast<const char *>(S.rec[stepping ? d : 0u]);
+    const uint64_t a0 = reinterpret_cast<uint64_t>(recs) + (R.dir_off + b0) * 64u;   // (a lane that is not stepping names the first record of depth 1)
+    const uint32_t a_lo = static_cast<uint32_t>(a0), a_hi = static_cast<uint32_t>(a0 >> 32);
+    LaneRec r0, r1;
+    uint32_t (&w0)[16] = r0.w;
+#define RBG_QUAD_ROUND(r)                                                                                                             \
+    {                                                                                                                                  \
+        const uint64_t an = (static_cast<uint64_t>(quad_bcast<r>(a_hi)) << 32) | quad_bcast<r>(a_lo);                                  \
+        const u32x4 t = *as_global<u32x4>(reinterpret_cast<const void *>(an + 16u * p));                                                \
+        w0[4 * r] = t.x; w0[4 * r + 1] = t.y; w0[4 * r + 2] = t.z; w0[4 * r + 3] = t.w;                                                  \
+    }
+    RBG_QUAD_ROUND(0) RBG_QUAD_ROUND(1) RBG_QUAD_ROUND(2) RBG_QUAD_ROUND(3)
+#undef RBG_QUAD_ROUND
+    const bool two = stepping && b1 != b0;
+    if constexpr (!LEAN) { if (two) r1.load(recs, R.dir_off + b1); }
+    quad_transpose16(w0, p);
+    if (!stepping) return;
+    out.F = R.F;
+    const char *__restrict__ tent = static_cast<const char *>(S.ent[d]) + R.first * 8u;
+    const uint32_t al0 = W ? static_cast<uint32_t>(b0 << sh) - (1u << S.fill) : 0u;
+    const uint32_t al1 = W ? static_cast<uint32_t>(b1 << sh) - (1u << S.fill) : 0u;
+    LaneRank A, B;
+    uint32_t h0, h1, rounds = 0, ents = 0;
+    r0.rank(al0, static_cast<uint32_t>(q0) - al0, static_cast<uint32_t>(q0 - (b0 << sh)), A);
+    h0 = w0[1];
+    if constexpr (LEAN) {
+        if (two) {
+            lane_finish(tent, A, nullptr, rounds, ents);
+            r0.load(recs, R.dir_off + b1);
+        }
+        r0.rank(al1, static_cast<uint32_t>(q1) - al1, static_cast<uint32_t>(q1 - (b1 << sh)), B);
+        h1 = w0[1];
+        if (two) lane_finish(tent, B, nullptr, rounds, ents);
+        else lane_finish(tent, A, &B, rounds, ents);
+    } else {
+        if (two) { r1.rank(al1, static_cast<uint32_t>(q1) - al1, static_cast<uint32_t>(q1 - (b1 << sh)), B); h1 = r1.w[1]; }
+        else { r0.rank(al1, static_cast<uint32_t>(q1) - al1, static_cast<uint32_t>(q1 - (b1 << sh)), B); h1 = h0; }
+        lane_finish(tent, A, &B, rounds, ents);
+    }
+    if (STATS) { st[kStSlots] += two ? 2 : 1; st[kStSearch] += rounds; st[kStDense] += ents; st[kStSteps] += 1; }
+    const uint64_t y0 = static_cast<uint64_t>(h0) << 31, y1 = static_cast<uint64_t>(h1) << 31;
+    out.c_before = A.c ? (W ? y0 + static_cast<uint32_t>(A.lo32 - static_cast<uint32_t>(y0)) : A.lo32) : 0;
+    out.c_upto = B.c ? (W ? y1 + static_cast<uint32_t>(B.lo32 - static_cast<uint32_t>(y1)) : B.lo32) : 0;
+    out.inside = B.c != 0 && B.inside;
+    out.samp_e = R.first + static_cast<uint64_t>(B.p) + B.c - 1u;
+}
+
 // the sample of the step's predecessor run (one gather)
 template <typename P>
 __device__ __forceinline__ uint64_t run_step_sample2(const DevIndex &ix, const uint32_t d, const uint64_t e) {
