@@ -82,10 +82,10 @@ def parse():
                     help="bytes per rank slot (RBG_OPT_SLOT_BYTES): 16, or 64 = the 64-byte slots of DESIGN.md 4 r03; 0 = the library's default")
     ap.add_argument("--pos-bytes", type=int, default=0, choices=(0, 4, 8), help="force the position width of the HBM layout (RBG_OPT_POS_BYTES); 0 = by n")
     ap.add_argument("--layout", default="auto", choices=("auto", "slots", "runs"), help="RBG_OPT_RANK_LAYOUT of the headline replica")
-    ap.add_argument("--hbm-budget-gb", type=float, default=-1.0,
-                    help="RBG_OPT_HBM_BUDGET_MB of the headline replica: -1 (default) = three quarters of the HBM that is free at load -- the headline is the "
-                         "FASTEST point of the space/speed curve, bought with 218 GB; 0 = the library's own default (a quarter of the free HBM: what a drop-in "
-                         "caller gets, reported beside the headline as value_library_default and in space_speed)")
+    ap.add_argument("--hbm-budget-gb", type=float, default=0.0,
+                    help="RBG_OPT_HBM_BUDGET_MB of the headline replica: 0 (default) = the library's own default (a quarter of the free HBM: what a drop-in "
+                         "caller gets -- since round 4 the run-indexed layout, 8.7 GB for the bench index, and the fastest row of space_speed); -1 = three "
+                         "quarters of the HBM that is free at load (slot tables, five symbols per gather: 221 GB, the headline of rounds 1-3)")
     ap.add_argument("--rehearse-ranks", action="store_true",
                     help="test mode, never a measurement: the N ranks of --gpus share the GPUs that exist (rank % devices) and meet over gloo, so that "
                          "the multi-rank path -- launcher, index built once and read from the cache file by every rank, barriers, max-over-ranks "
@@ -174,9 +174,9 @@ def main():
     m = args.read_len
     max_hits = MAXU if args.max_hits < 0 else args.max_hits
     from rowbowt_amd import capi as _cb
+    free_at_start, _tot = torch.cuda.mem_get_info(dev)
     if args.hbm_budget_gb < 0:
-        free_b, _tot = torch.cuda.mem_get_info(dev)
-        budget_mb = int(free_b * 3 // 4) >> 20
+        budget_mb = int(free_at_start * 3 // 4) >> 20
     else:
         budget_mb = int(args.hbm_budget_gb * 1e9) >> 20
     _cb.set_default_option(_cb.OPT_HBM_BUDGET_MB, budget_mb)
@@ -637,7 +637,8 @@ def main():
                           "hbm_bytes": int(ix.hbm_bytes), "pos_bytes": int(ix.pos_bytes), "seed": args.seed,
                           "slot_bytes": slot_b, "symbols_per_gather": int(ix.kmer_steps), "symbols_per_gather_requested": int(ix.kmer_steps_requested),
                           "hbm_free_at_load": int(ix.hbm_free_at_load), "hbm_budget": int(ix.hbm_budget),
-                          "hbm_budget_source": ("bench.py --hbm-budget-gb -1: three quarters of the free HBM, the fastest point of space_speed" if args.hbm_budget_gb < 0
+                          "rank_layout": "runs" if int(ix.rank_layout) == 2 else "slots",
+                          "hbm_budget_source": ("bench.py --hbm-budget-gb -1: three quarters of the free HBM" if args.hbm_budget_gb < 0
                                                 else "the library's default (a quarter of the free HBM)" if args.hbm_budget_gb == 0 else f"--hbm-budget-gb {args.hbm_budget_gb}"), "ftab_k": int(ix.ftab_k), "pair_runs": int(ix.pair_runs), "triple_runs": int(ix.triple_runs), "quad_runs": int(ix.quad_runs), "quint_runs": int(ix.quint_runs)},
                 "reads_per_gpu": N, "read_len": m, "substituted_fraction": 0.1,
                 "parallelism": f"index replicated x{world}, reads sharded, no data-path collective",
@@ -885,22 +886,53 @@ def main():
             ms["k_locate_fill"] = best
             return N / ((ms["k_find_range<toehold>"] + best + ms_plan + ms_order) * 1e-3)
 
+        headline_runs = int(ix.rank_layout) == capi.LAYOUT_RUNS
+        budget34_mb = int(free_at_start * 3 // 4) >> 20   # the slot rows are built under three quarters of the free HBM whatever the headline's budget
+
+        def describe(rb_):
+            """what a replica is: layout, symbols per step, bytes -- and, run-indexed, its depth set and rank / phi structures"""
+            i_, d_ = rb_.info(), {}
+            if int(i_.rank_layout) == capi.LAYOUT_RUNS:
+                li_ = rb_.layout_info()
+                d_ = {"depths": [x + 1 for x in range(5) if int(li_.depth_mask_kept) >> x & 1],
+                      "ranks": "bucket records" if sum(int(x) for x in li_.rec_bytes) > 0 else "directories + run lists",
+                      "phi": "slots of about n / r rows" if int(li_.phi_slots) else "list of sampled positions + directory"}
+            return {"layout": "runs" if int(i_.rank_layout) == capi.LAYOUT_RUNS else "slots", **d_, "symbols_per_gather": int(i_.kmer_steps), "hbm_bytes": int(i_.hbm_bytes)}
+
         ms0 = time_search()
-        rows = [{"layout": "slots", "symbols_per_gather": int(ix.kmer_steps), "hbm_bytes": int(ix.hbm_bytes), "ms": ms0, "count_locate_reads_per_s": time_locate(ms0)}]
+        rows = [{**describe(rb), "headline_replica": True, "ms": ms0, "count_locate_reads_per_s": time_locate(ms0)}]
         top = int(ix.kmer_steps)
+        slot_other_row = None
         # reference outputs of the whole batch from the slot tables (oracle-checked above on a sample), for the run-indexed row
         step()
         torch.cuda.synchronize()
         ref_out = [t.clone() for t in (d_lo, d_hi, d_k, d_loc_off)]
         ref_locs = d_locs[:total_locs].clone()
-        for lvl in range(top - 1, 0, -1):
+        for lvl in range(5 if headline_runs else top - 1, 0, -1):
             rb.close()
             torch.cuda.empty_cache()
-            with capi.default_option(capi.OPT_KMER_STEPS, lvl):   # the caller's own setting is put back afterwards
+            with capi.default_option(capi.OPT_KMER_STEPS, lvl), capi.default_option(capi.OPT_RANK_LAYOUT, capi.LAYOUT_SLOTS), \
+                    capi.default_option(capi.OPT_HBM_BUDGET_MB, max(budget_mb, budget34_mb)):   # the caller's own settings are put back afterwards
                 rb = ra.RowBowt.from_runs(inp["heads"], inp["lens"], inp["ssa"], inp["esa"], device=local_rank)
             ms_l = time_search()
-            rows.append({"layout": "slots", "symbols_per_gather": int(rb.info().kmer_steps), "hbm_bytes": int(rb.info().hbm_bytes), "ms": ms_l,
-                         "count_locate_reads_per_s": time_locate(ms_l)})
+            rate_l = time_locate(ms_l)
+            step()
+            same_l = all(bool((a == b).all().item()) for a, b in zip(ref_out, (d_lo, d_hi, d_k, d_loc_off))) and bool((ref_locs == d_locs[:total_locs]).all().item())
+            rows.append({**describe(rb), "ms": ms_l, "identical_to_the_headline_replica_on_the_whole_batch": same_l, "count_locate_reads_per_s": rate_l})
+            if not same_l:
+                out["space_speed"] = {"rows": rows}
+                print(json.dumps(out))
+                raise SystemExit("PARITY FAILURE: a slot-table replica disagrees with the headline replica")
+            if headline_runs and args.markers and slot_other_row is None:   # the kernels beside the rb_align path on slot tables (five symbols), same batch
+                rb.set_markers(*marker_arrays)
+                gstep(); sstep(); sstep_log()
+                slot_other_row = {}
+                for name, fn in (("greedy_seed_ms", gstep), ("marker_seeds_ms", sstep), ("marker_seeds_logged_ms", sstep_log)):
+                    e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                    e[0].record(stream); fn(); e[1].record(stream); fn(); e[2].record(stream)
+                    torch.cuda.synchronize()
+                    slot_other_row[name] = min(e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2]))
+                rows[-1]["other_kernels"] = {"slot_layout": slot_other_row}
         # the run-indexed layout (space proportional to r; wave-cooperative predecessor search): same batch, same outputs
         rb.close()
         torch.cuda.empty_cache()
@@ -956,7 +988,7 @@ def main():
                        "search": rs_toe, "locate": rs_loc}
         same = all(bool((a == b).all().item()) for a, b in zip(ref_out, (d_lo, d_hi, d_k, d_loc_off))) and bool((ref_locs == d_locs[:total_locs]).all().item())
         rows.append({"layout": "runs", "depths": [1, 2, 3, 4, 5][:int(rb.info().kmer_steps)], "symbols_per_gather": int(rb.info().kmer_steps), "hbm_bytes": int(rb.info().hbm_bytes), "ms": ms_r,
-                     "identical_to_slot_path_on_the_whole_batch": same, "roofline": run_roof, "touched": run_touched, "run_fmt": run_fmt,
+                     "identical_to_the_headline_replica_on_the_whole_batch": same, "roofline": run_roof, "touched": run_touched, "run_fmt": run_fmt,
                      "phi": "slots of about n / r rows" if run_phi_slots else "list of sampled positions + directory",
                      "ranks": "bucket records (one 64-byte record per bucket)" if run_recs else "directories + run lists",
                      "count_locate_reads_per_s": rate_r})
@@ -976,7 +1008,7 @@ def main():
                 e[0].record(stream); fn(); e[1].record(stream); fn(); e[2].record(stream)
                 torch.cuda.synchronize()
                 run_other[name] = min(e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2]))
-            rows[-1]["other_kernels"] = {"runs_layout": run_other, "slot_layout": slot_other, "greedy_seeds_identical_to_slot_path": same_g,
+            rows[-1]["other_kernels"] = {"runs_layout": run_other, "slot_layout": slot_other_row if headline_runs else slot_other, "greedy_seeds_identical_to_slot_path": same_g,
                                          "marker_seed_counts_identical_to_slot_path": same_s}
             same = same and same_g and same_s
         # the same layout with run lists for some of the k-mer depths only (RBG_OPT_RUN_DEPTHS; include/rbg.h): a step takes
@@ -998,7 +1030,7 @@ def main():
             row = {"layout": "runs", "depths": [d + 1 for d in range(5) if depth_mask >> d & 1], "symbols_per_gather": int(rb.info().kmer_steps),
                    "ranks": "bucket records" if sum(int(x) for x in li_d.rec_bytes) > 0 else "directories + run lists",
                    "phi": "slots of about n / r rows" if int(li_d.phi_slots) else "list of sampled positions + directory",
-                   "hbm_bytes": int(rb.info().hbm_bytes), "ms": ms_d, "identical_to_slot_path_on_the_whole_batch": same_d,
+                   "hbm_bytes": int(rb.info().hbm_bytes), "ms": ms_d, "identical_to_the_headline_replica_on_the_whole_batch": same_d,
                    "count_locate_reads_per_s": rate_d}
             if args.markers:
                 rb.set_markers(*marker_arrays)
@@ -1025,6 +1057,7 @@ def main():
         # what the headline costs: the best count+locate rate among the replicas of at most 64 GB, and the rate of the replica a DEFAULT
         # rbg_load builds -- no option set: budget = a quarter of the free HBM, RBG_LAYOUT_AUTO (slot tables if all five symbols per
         # step fit that, else the run-indexed layout) -- built and timed here like the other rows
+        headline_is_default = args.hbm_budget_gb == 0 and args.layout == "auto" and not args.pos_bytes and not args.slot_bytes
         rb.close()
         torch.cuda.empty_cache()
         with capi.default_option(capi.OPT_HBM_BUDGET_MB, 0), capi.default_option(capi.OPT_RANK_LAYOUT, capi.LAYOUT_AUTO), capi.default_option(capi.OPT_KMER_STEPS, 5):
@@ -1038,11 +1071,12 @@ def main():
         runs_df = int(ix_df.rank_layout) == capi.LAYOUT_RUNS
         out["value_library_default"] = {"value": rate_df, "hbm_bytes": int(ix_df.hbm_bytes), "layout": "runs" if runs_df else "slots",
                                         "symbols_per_gather": int(ix_df.kmer_steps), "hbm_budget": int(ix_df.hbm_budget), "ms": ms_df,
-                                        "identical_to_slot_path_on_the_whole_batch": same_df,
+                                        "identical_to_the_headline_replica_on_the_whole_batch": same_df,
                                         **({"ranks": "bucket records" if sum(int(x) for x in li_df.rec_bytes) > 0 else "directories + run lists",
                                             "phi": "slots of about n / r rows" if int(li_df.phi_slots) else "list of sampled positions + directory",
                                             "depths": [d + 1 for d in range(5) if int(li_df.depth_mask_kept) >> d & 1]} if runs_df else {}),
-                                        "budget": "a quarter of the HBM free at load (rbg_load with no option set: RBG_LAYOUT_AUTO)"}
+                                        "budget": "a quarter of the HBM free at load (rbg_load with no option set: RBG_LAYOUT_AUTO)",
+                                        "is_the_headline_replica": headline_is_default}
         if not same_df:
             print(json.dumps(out))
             raise SystemExit("PARITY FAILURE: the library-default replica disagrees with the headline replica")

@@ -2,7 +2,7 @@
 """rocprofv3 --pmc passes (tools/pmc_passes.sh) -> profiles/pmc_traffic.json, the file bench.py reads for
 roofline.traffic / request_roof.tcc_miss_per_launch.  Stamped with the sha256 of the librbg.so that was
 profiled: bench.py drops the numbers when it runs a different build.
-usage: make_pmc_traffic.py <gpurun_out/pmc_TAG> <source note> > profiles/pmc_traffic.json"""
+usage: make_pmc_traffic.py <gpurun_out/pmc_TAG> <source note> [<more pass directories>] > profiles/pmc_traffic.json"""
 import collections
 import csv
 import glob
@@ -66,9 +66,12 @@ def main():
         return merge_runs(sys.argv[2], sys.argv[3])
     d = sys.argv[1]
     per = collections.defaultdict(lambda: collections.defaultdict(float))  # (label, counter) -> dispatch -> value
-    for f in sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True)):
+    files = []
+    for dd in [d] + sys.argv[3:]:                                           # (further directories: the passes over another headline replica)
+        files += sorted(glob.glob(dd + "/**/*counter_collection.csv", recursive=True))
+    for f in files:
         for r in csv.DictReader(open(f)):
-            lab = label(r["Kernel_Name"])
+            lab = label(r["Kernel_Name"]) or label_runs(r["Kernel_Name"])   # (the default bench's headline replica is run-indexed since round 4)
             if lab:
                 per[(lab, r["Counter_Name"])][(f, r["Dispatch_Id"])] += float(r["Counter_Value"])
     out = {"_source": sys.argv[2] if len(sys.argv) > 2 else d,
