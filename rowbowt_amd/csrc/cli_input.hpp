@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -65,24 +66,48 @@ class InputSource {
                 }
                 map_size_ = 0;
             }
-            // any other gzip: when more than one place in the file looks like the start of a gzip member (concatenated files: `cat a.gz b.gz`, lanes
-            // of a sequencer written one after the other) the file is mapped and the members are inflated by the worker threads, speculatively
-            // from every candidate and checked as a chain (next_members below); a single member stays zlib's single stream
+            // any other gzip: a file of SEVERAL members (concatenated files: `cat a.gz b.gz`, lanes of a sequencer written one after the
+            // other) is mapped and its members are inflated by the worker threads, speculatively from every place that looks like a
+            // member's start and checked as a chain (next_members below).  That mode is entered only on evidence: member 0 must END
+            // exactly where a second member's header begins (checked here by inflating it, output discarded).  The bytes of a header
+            // also turn up by chance inside deflate data, so a candidate alone proves nothing: an ordinary single-member file -- or
+            // one whose first member is too long to be worth checking -- stays zlib's single stream, as before.
             else {
                 const size_t sz = static_cast<size_t>(sb.st_size);
                 void *m = mmap(nullptr, sz, PROT_READ, MAP_PRIVATE, fd, 0);
                 if (m != MAP_FAILED) {
                     const unsigned char *p = static_cast<const unsigned char *>(m);
+                    (void)madvise(m, sz, MADV_SEQUENTIAL);
                     std::vector<uint64_t> cand;
-                    for (size_t i = 0; i + 10 <= sz;) {
-                        const void *hit = std::memchr(p + i, 0x1f, sz - 10 - i + 1);
-                        if (!hit) break;
-                        i = static_cast<size_t>(static_cast<const unsigned char *>(hit) - p);
-                        if (p[i + 1] == 0x8b && p[i + 2] == 8 && (p[i + 3] & 0xE0) == 0) cand.push_back(i);
-                        ++i;
+                    // speculative starts in [from, to): every place whose ten bytes pass the strict test
+                    auto scan = [&](size_t from, size_t to, size_t at_most) {
+                        for (size_t i = from; i < to && i + 18 <= sz && at_most; --at_most) {
+                            const void *hit = std::memchr(p + i, 0x1f, std::min(to, sz - 17) - i);
+                            if (!hit) break;
+                            i = static_cast<size_t>(static_cast<const unsigned char *>(hit) - p);
+                            if (member_header_strict(p + i)) cand.push_back(i);
+                            else ++at_most;
+                            ++i;
+                        }
+                    };
+                    // member 0 must end where a second member's header begins, within the first kVerifyMax bytes: only then is the rest scanned
+                    bool chain = false;
+                    if (member_header_loose(p)) {
+                        cand.push_back(0);
+                        scan(1, static_cast<size_t>(std::min<uint64_t>(sz, kVerifyMax)), 1);
+                        if (cand.size() >= 2) {
+                            map_ = static_cast<const char *>(m);   // (inflate_member reads through map_)
+                            map_size_ = sz;
+                            MemberJob job;
+                            inflate_member(0, cand[1], job, /*keep=*/false);
+                            chain = job.res == 0 && job.at + 18 <= sz && member_header_loose(p + job.at);
+                            if (chain && job.at != cand[1]) cand.insert(cand.begin() + 1, job.at);   // (a header only the loose test accepts)
+                            map_ = nullptr;
+                            map_size_ = 0;
+                        }
+                        if (chain) scan(static_cast<size_t>(cand.back()) + 1, sz, SIZE_MAX);
                     }
-                    if (cand.size() >= 2 && cand[0] == 0) {
-                        (void)madvise(m, sz, MADV_SEQUENTIAL);
+                    if (chain) {
                         map_ = static_cast<const char *>(m);
                         map_size_ = sz;
                         cand.push_back(sz);
@@ -237,53 +262,137 @@ class InputSource {
         }
     }
 
+    // how the input is read: "mapped", "bgzf", "members" (gzip members inflated in parallel) or "stream" (zlib's gzread)
+    const char *mode() const { return bgzf_ ? "bgzf" : mgz_ ? "members" : mapped_ ? "mapped" : "stream"; }
+
    private:
     // ---- multi-member gzip ------------------------------------------------------------------------------------------------
-    // inflate ONE gzip member that starts at file offset `from`, reading no further than `limit`: 0 = the member ended (at *end), 1 = the
-    // input ran out before it did (a candidate inside this member's data cut it short), -1 = not a valid member
-    int inflate_member(uint64_t from, uint64_t limit, std::vector<char> &out, uint64_t *end) const {
-        z_stream zs;
-        std::memset(&zs, 0, sizeof(zs));
-        if (inflateInit2(&zs, 15 + 16) != Z_OK) return -1;   // gzip wrapper: header, CRC-32 and ISIZE are checked by zlib
-        out.clear();
-        out.resize(std::max<uint64_t>(uint64_t(64) << 10, (limit - from) * 4));
+    // What a gzip member's first ten bytes look like.  LOOSE is what zlib's gzread accepts (magic, deflate, no reserved flag): the test
+    // for the place where a verified member ENDED.  STRICT adds what every writer in use produces -- XFL 0, 2 or 4 and a defined OS
+    // byte -- and is the test for SPECULATIVE starts: the loose pattern alone occurs by chance once per 134 MB of deflate data.
+    static bool member_header_loose(const unsigned char *h) { return h[0] == 0x1f && h[1] == 0x8b && h[2] == 8 && (h[3] & 0xE0) == 0; }
+    static bool member_header_strict(const unsigned char *h) {
+        return member_header_loose(h) && (h[8] == 0 || h[8] == 2 || h[8] == 4) && (h[9] <= 13 || h[9] == 255);
+    }
+    static constexpr uint64_t kVerifyMax = uint64_t(256) << 20;   // compressed bytes of member 0 the check at open() may inflate
+    static constexpr size_t kMemberOutStart = size_t(1) << 20;    // first size of a member's text buffer (doubling from there)
+    // One member being inflated: `zs` stays open while the input ran out before the member ended (res 1) so that the chain can go
+    // on from `at` instead of starting over.  (A z_stream must not move once initialised: zlib keeps a pointer back to it.)
+    struct MemberJob {
+        std::unique_ptr<z_stream> zs;
+        std::vector<char> out;   // the text so far
+        uint64_t from = 0;       // file offset of the member's first byte
+        uint64_t at = 0;         // file offset of the next compressed byte
+        int res = -1;            // 0 = the member ended at `at`; 1 = the input ran out at the limit; -1 = not a valid member / corrupt
+        ~MemberJob() { close(); }
+        MemberJob() = default;
+        MemberJob(MemberJob &&) = default;
+        MemberJob &operator=(MemberJob &&o) {
+            if (this != &o) { close(); zs = std::move(o.zs); out = std::move(o.out); from = o.from; at = o.at; res = o.res; }
+            return *this;
+        }
+        void close() {
+            if (zs) { (void)inflateEnd(zs.get()); zs.reset(); }
+        }
+    };
+    // inflate ONE gzip member that starts at file offset `from`, reading no further than `limit`.  The text goes to job.out, which
+    // starts small and doubles (never sized from the input's length); with keep == false it is discarded as it comes (the check of
+    // open()).  A corrupt member leaves the text inflated before the damage in job.out.
+    void inflate_member(uint64_t from, uint64_t limit, MemberJob &job, bool keep = true) const {
+        job.close();
+        job.out.clear();
+        job.from = job.at = from;
+        job.res = -1;
+        job.zs.reset(new z_stream);
+        std::memset(job.zs.get(), 0, sizeof(z_stream));
+        if (inflateInit2(job.zs.get(), 15 + 16) != Z_OK) { job.zs.reset(); return; }   // gzip wrapper: header, CRC-32 and ISIZE are checked by zlib
+        z_stream &zs = *job.zs;
+        job.out.resize(std::min<uint64_t>(kMemberOutStart, std::max<uint64_t>(uint64_t(64) << 10, (limit - from) * 4)));
         size_t have = 0;
-        uint64_t at = from;
-        int res = 1;
         while (true) {
-            const uint64_t in_now = std::min<uint64_t>(limit - at, uint64_t(1) << 30);
-            zs.next_in = reinterpret_cast<Bytef *>(const_cast<char *>(map_ + at));
+            const uint64_t in_now = std::min<uint64_t>(limit - job.at, uint64_t(1) << 30);
+            zs.next_in = reinterpret_cast<Bytef *>(const_cast<char *>(map_ + job.at));
             zs.avail_in = static_cast<uInt>(in_now);
-            if (have == out.size()) out.resize(out.size() * 2);
-            const size_t room = std::min<size_t>(out.size() - have, size_t(1) << 30);
-            zs.next_out = reinterpret_cast<Bytef *>(out.data() + have);
+            if (!keep) have = 0;
+            if (have == job.out.size()) job.out.resize(job.out.size() * 2);
+            const size_t room = std::min<size_t>(job.out.size() - have, size_t(1) << 30);
+            zs.next_out = reinterpret_cast<Bytef *>(job.out.data() + have);
             zs.avail_out = static_cast<uInt>(room);
             const int rc = inflate(&zs, Z_NO_FLUSH);
             have += room - zs.avail_out;
-            at += in_now - zs.avail_in;
+            job.at += in_now - zs.avail_in;
+            if (rc == Z_STREAM_END) { job.res = 0; break; }
+            if (rc != Z_OK && rc != Z_BUF_ERROR) { job.res = -1; break; }
+            if (job.at == limit && zs.avail_out != 0) { job.res = 1; break; }   // all input consumed, no end of stream
+        }
+        job.out.resize(keep ? have : 0);
+        if (job.res != 1) job.close();
+    }
+    // the member in `big_` (cut short at a speculative start inside its data, or simply long) goes on into `dst`, at most `win` bytes of
+    // text per call: 0 = it ended (at big_.at), 1 = the window is full, -1 = corrupt (the text before the damage is in dst), 2 = the file ends
+    // inside the member (gzread hands out what there is and then reports the end of the file: so does this)
+    int continue_big(std::vector<char> &dst, uint64_t win) {
+        z_stream &zs = *big_.zs;
+        const size_t have0 = dst.size();
+        dst.resize(have0 + win);
+        size_t have = have0;
+        int res = 1;
+        while (have < dst.size()) {
+            const uint64_t in_now = std::min<uint64_t>(map_size_ - big_.at, uint64_t(1) << 30);
+            zs.next_in = reinterpret_cast<Bytef *>(const_cast<char *>(map_ + big_.at));
+            zs.avail_in = static_cast<uInt>(in_now);
+            const size_t room = std::min<size_t>(dst.size() - have, size_t(1) << 30);
+            zs.next_out = reinterpret_cast<Bytef *>(dst.data() + have);
+            zs.avail_out = static_cast<uInt>(room);
+            const int rc = inflate(&zs, Z_NO_FLUSH);
+            have += room - zs.avail_out;
+            big_.at += in_now - zs.avail_in;
             if (rc == Z_STREAM_END) { res = 0; break; }
             if (rc != Z_OK && rc != Z_BUF_ERROR) { res = -1; break; }
-            if (at == limit && zs.avail_out != 0) { res = 1; break; }   // all input consumed, no end of stream
+            if (big_.at == map_size_ && zs.avail_out != 0) { res = 2; break; }   // the file ends inside the member
         }
-        (void)inflateEnd(&zs);
-        out.resize(have);
-        *end = at;
+        dst.resize(have);
+        if (res != 1) big_.close();
         return res;
+    }
+    // a verified member ended at file offset `e`: the candidate the chain goes on from; false = the end of the file, or bytes that start
+    // no gzip member (zero padding included) -- zlib's gzread, what the reference reads through (kseq.h over gzFile), takes those for
+    // trailing garbage and stops there as at the end of the file
+    bool chain_from(uint64_t e, size_t from_cand) {
+        size_t nxt = from_cand;
+        while (nxt < cand_.size() && cand_[nxt] < e) ++nxt;
+        if (e + 18 > map_size_ || !member_header_loose(reinterpret_cast<const unsigned char *>(map_) + e)) { ci_ = cand_.size(); return false; }
+        if (nxt >= cand_.size() || cand_[nxt] != e) cand_.insert(cand_.begin() + static_cast<std::ptrdiff_t>(nxt), e);   // (only the loose test accepts it)
+        ci_ = nxt;
+        return ci_ + 1 < cand_.size();
     }
     // appends the next members (about `win` bytes of text) to `dst`; false at the end of the input
     bool next_members(std::vector<char> &dst, uint64_t win) {
+        if (big_.zs) {
+            const int r = continue_big(dst, win);
+            if (r == 1) return true;
+            if (r < 0) { stream_error_ = true; ci_ = cand_.size(); return false; }   // like gzread failing: what came before counts
+            if (r == 2) { ci_ = cand_.size(); return false; }
+            return chain_from(big_.at, big_cand_);
+        }
         if (ci_ + 1 >= cand_.size()) return false;
-        // the candidates of this batch: compressed bytes of about a third of the window (text compresses three- to fourfold)
-        size_t cj = ci_;
-        while (cj + 1 < cand_.size() && (cand_[cj] - cand_[ci_]) * 3 < win && cj - ci_ < 4096) ++cj;
-        if (cj == ci_) cj = ci_ + 1;
+        // the candidates of this batch: compressed bytes of about a third of the window (text compresses three- to fourfold).  A stretch
+        // longer than two thirds of a window between two candidates is one long member: it is streamed window by window, never held whole.
+        const uint64_t long_member = std::max<uint64_t>(win, kLongFloor) * 2 / 3;
+        auto is_long = [&](size_t c) { return cand_[c + 1] - cand_[c] >= long_member; };
+        if (is_long(ci_)) {
+            inflate_member(cand_[ci_], cand_[ci_], big_);   // (opens the stream; no input yet: res 1)
+            if (!big_.zs) { stream_error_ = true; ci_ = cand_.size(); return false; }
+            big_cand_ = ci_ + 1;
+            return next_members(dst, win);
+        }
+        size_t cj = ci_ + 1;   // members ci_ .. cj - 1
+        while (cj + 1 < cand_.size() && (cand_[cj] - cand_[ci_]) * 3 < win && cj - ci_ < 4096 && !is_long(cj)) ++cj;
         const size_t nseg = cj - ci_;
-        std::vector<std::vector<char>> out(nseg);
-        std::vector<int> res(nseg, -1);
-        std::vector<uint64_t> end(nseg, 0);
+        std::vector<MemberJob> job(nseg);
         const unsigned T = std::max(1u, std::min<unsigned>(threads_, static_cast<unsigned>(nseg)));
         auto work = [&](unsigned t) {
-            for (size_t k = nseg * t / T; k < nseg * (t + 1) / T; ++k) res[k] = inflate_member(cand_[ci_ + k], cand_[ci_ + k + 1], out[k], &end[k]);
+            for (size_t k = nseg * t / T; k < nseg * (t + 1) / T; ++k) inflate_member(cand_[ci_ + k], cand_[ci_ + k + 1], job[k]);
         };
         {
             std::vector<std::thread> th;
@@ -291,38 +400,32 @@ class InputSource {
             work(0);
             for (auto &x : th) x.join();
         }
-        // the chain: member k must end where candidate k + 1 starts.  A candidate inside a member's data cut that member short (res 1):
-        // it is inflated again up to the candidate where it really ends, and the candidates it contains are skipped.
+        // the chain: a member must end where the next one starts.  A candidate inside a member's data cut that member short (res 1): its
+        // stream goes on from there, window by window (continue_big), and the candidates it contains are skipped.
         size_t k = 0;
-        while (k < nseg) {
-            uint64_t e = end[k];
-            int r = res[k];
-            std::vector<char> again;
-            const std::vector<char> *txt = &out[k];
-            if (r == 1) {
-                r = inflate_member(cand_[ci_ + k], map_size_, again, &e);
-                txt = &again;
+        while (true) {
+            MemberJob &j = job[k];
+            dst.insert(dst.end(), j.out.begin(), j.out.end());   // (a corrupt member: the text before the damage, as gzread delivers it)
+            if (j.res < 0) { stream_error_ = true; ci_ = cand_.size(); return false; }   // corrupt: gzread fails there (-3)
+            if (j.res == 1 && j.at >= map_size_) { ci_ = cand_.size(); return false; }   // the file ends inside the member: gzread hands out what there is, then reports the end of the file
+            if (j.res == 1) {
+                j.out.clear();
+                big_cand_ = ci_ + k + 1;
+                big_ = std::move(j);
+                return true;
             }
-            if (r != 0) { stream_error_ = true; ci_ = cand_.size(); return false; }   // like gzread failing: what came before counts
-            dst.insert(dst.end(), txt->begin(), txt->end());
-            // the candidate at which the next member starts
-            size_t nxt = ci_ + k + 1;
-            while (nxt < cand_.size() && cand_[nxt] < e) ++nxt;
-            if (nxt >= cand_.size() || cand_[nxt] != e || cand_[nxt] == map_size_) {
-                // the end of the file, or bytes that start no gzip member (zero padding included): zlib's gzread -- what the reference reads
-                // through, kseq.h over gzFile -- takes them for trailing garbage and stops there as at the end of the file
-                ci_ = cand_.size();
-                return false;
-            }
-            if (nxt >= ci_ + nseg) { ci_ = nxt; return ci_ + 1 < cand_.size(); }
-            k = nxt - ci_;
+            size_t k2 = k + 1;
+            while (k2 < nseg && job[k2].from < j.at) ++k2;
+            if (k2 < nseg && job[k2].from == j.at) { k = k2; continue; }
+            return chain_from(j.at, ci_ + k + 1);   // the next batch starts where this member ended (or the input ends there)
         }
-        ci_ += nseg;
-        return ci_ + 1 < cand_.size();
     }
+    static constexpr uint64_t kLongFloor = uint64_t(64) << 10;
     bool mgz_ = false;
     std::vector<uint64_t> cand_;   // file offsets that look like the start of a gzip member, then the file's size
     size_t ci_ = 0;
+    MemberJob big_;          // the member being streamed across windows, if any
+    size_t big_cand_ = 0;    // the candidates from here on may lie inside it
     // a gzip member header that is a BGZF block's: FEXTRA set, first extra subfield 'B' 'C' of two bytes (the block size - 1)
     static bool bgzf_header(const unsigned char *h) {
         return h[0] == 0x1f && h[1] == 0x8b && h[2] == 8 && (h[3] & 4) && (h[10] | (h[11] << 8)) >= 6 && h[12] == 'B' && h[13] == 'C' && h[14] == 2 && h[15] == 0;

@@ -1153,6 +1153,7 @@ int add_fillers(rbg_index *ix, bool phi, void **ent, void **samp, bool tracked, 
     unsigned long long total = 0;
     HIP_TRY(hipMemcpy(&total, tot.p, 8, hipMemcpyDeviceToHost));
     if (!total) return RBG_OK;
+    if (total > (uint64_t(1) << 40) || *m > (uint64_t(1) << 40)) return RBG_ENOMEM;   // (sizes below stay far from 2^64; no index that fits a device comes near)
     TmpDev arr, tmp, idx, out;
     const size_t tb = scan_tmp_bytes_for(*m + 1);
     if ((rc = arr.alloc((*m + 1) * 8)) || (rc = tmp.alloc(tb))) return rc;
@@ -1160,15 +1161,30 @@ int add_fillers(rbg_index *ix, bool phi, void **ent, void **samp, bool tracked, 
     HIP_TRY(static_cast<hipError_t>(launch_fill_count(*ent, *m, n, fs, arr.as<uint64_t>(), tot.as<unsigned long long>(), nullptr)));
     HIP_TRY(static_cast<hipError_t>(launch_scan_u64(arr.as<uint64_t>(), *m + 1, tmp.p, tb, nullptr)));
     const uint64_t m2 = *m + total;
-    void *ent2 = nullptr, *samp2 = nullptr;
-    if (tracked) {
-        if ((rc = dev_reserve(ix, (m2 + 2) * 16, &ent2))) return rc;
-        if (*samp && (rc = dev_reserve(ix, m2 * 8 + 16, &samp2))) return rc;
-    } else {
-        HIP_TRY(hipMalloc(&ent2, (m2 + 2) * 16));
-        if (*samp) HIP_TRY(hipMalloc(&samp2, m2 * 8 + 16));
-    }
-    HIP_TRY(static_cast<hipError_t>(launch_fill_expand(phi, *ent, static_cast<const uint64_t *>(*samp), *m, n, fs, arr.as<uint64_t>(), ent2, static_cast<uint64_t *>(samp2), nullptr)));
+    // the expanded arrays: given back on EVERY error path below (a tracked block through the index's list, a plain one by hipFree),
+    // handed to the caller only once everything has succeeded
+    struct NewBlock {
+        rbg_index *ix; bool tracked; void *p = nullptr;
+        NewBlock(rbg_index *i, bool t) : ix(i), tracked(t) {}
+        ~NewBlock() { if (!p) return; if (tracked) free_tracked(ix, p); else (void)hipFree(p); }
+        int alloc(size_t bytes) {
+            if (tracked) {
+                // (its own allocation, never a piece of the arena: free_tracked must be able to give it back)
+                hipError_t e = hipMalloc(&p, arena_round(bytes));
+                if (e != hipSuccess) { (void)hipGetLastError(); p = nullptr; return e == hipErrorOutOfMemory ? RBG_ENOMEM : RBG_ENODEV; }
+                ix->allocs.push_back({p, arena_round(bytes)});
+                ix->hbm_bytes += arena_round(bytes);
+                return RBG_OK;
+            }
+            hipError_t e = hipMalloc(&p, bytes);
+            if (e != hipSuccess) { (void)hipGetLastError(); p = nullptr; return e == hipErrorOutOfMemory ? RBG_ENOMEM : RBG_ENODEV; }
+            return RBG_OK;
+        }
+        void *release() { void *q = p; p = nullptr; return q; }
+    } ent2(ix, tracked), samp2(ix, tracked);
+    if ((rc = ent2.alloc((m2 + 2) * 16))) return rc;
+    if (*samp && (rc = samp2.alloc(m2 * 8 + 16))) return rc;
+    HIP_TRY(static_cast<hipError_t>(launch_fill_expand(phi, *ent, static_cast<const uint64_t *>(*samp), *m, n, fs, arr.as<uint64_t>(), ent2.p, static_cast<uint64_t *>(samp2.p), nullptr)));
     if (!at.empty()) {
         if ((rc = idx.alloc(at.size() * 8)) || (rc = out.alloc(at.size() * 8))) return rc;
         HIP_TRY(hipMemcpy(idx.p, at.data(), at.size() * 8, hipMemcpyHostToDevice));
@@ -1178,8 +1194,8 @@ int add_fillers(rbg_index *ix, bool phi, void **ent, void **samp, bool tracked, 
     HIP_TRY(hipDeviceSynchronize());
     if (tracked) { free_tracked(ix, *ent); if (*samp) free_tracked(ix, *samp); }
     else { (void)hipFree(*ent); if (*samp) (void)hipFree(*samp); }
-    *ent = ent2;
-    *samp = samp2;
+    *ent = ent2.release();
+    *samp = samp2.release();
     *m = m2;
     *fillers = total;
     return RBG_OK;
@@ -1620,6 +1636,11 @@ int compose_on_device(rbg_index *ix) {
     if (M < 1 || K0 < 2) return RBG_OK;
     if (ix->kmer_steps_requested == 0) ix->kmer_steps_requested = K0;
     for (uint32_t K = K0; K >= 2; --K) {
+        // (a pass that failed partway -- the host fallback included -- must leave nothing of a deeper level behind: levels() and
+        //  level_has_data() count what they find)
+        for (uint32_t d = 2; d <= 5; ++d) { release_kmer_level(ix, d); std::vector<SymTable>().swap(kmer_level_tables(h, d)); }
+        ix->kmer_levels.clear();
+        ix->runs_forced = false;
         const int rc = compose_on_device_k<P>(ix, K);
         if (rc != RBG_ENOMEM) return rc;
         std::fprintf(stderr, "rbg: %u symbols per step cannot be composed in the memory there is: trying %u\n", K, K - 1);

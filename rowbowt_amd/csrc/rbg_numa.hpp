@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 
 namespace rbg_numa {
@@ -50,13 +51,35 @@ inline bool node_cpus(int node, cpu_set_t *set) {
     const bool ok = std::fgets(buf, sizeof(buf), f) != nullptr;
     std::fclose(f);
     if (!ok) return false;
+    // "0-63,128-191": parsed by hand -- no strtok, whose hidden state is shared by every thread of the process
     int n = 0;
-    for (char *tok = std::strtok(buf, ",\n"); tok; tok = std::strtok(nullptr, ",\n")) {
-        int a = 0, b = 0;
-        if (std::sscanf(tok, "%d-%d", &a, &b) == 2) { for (int c = a; c <= b && c < CPU_SETSIZE; ++c) { CPU_SET(c, set); ++n; } }
-        else if (std::sscanf(tok, "%d", &a) == 1 && a < CPU_SETSIZE) { CPU_SET(a, set); ++n; }
+    for (const char *c = buf; *c;) {
+        if (!std::isdigit(static_cast<unsigned char>(*c))) { ++c; continue; }
+        char *end = nullptr;
+        long a = std::strtol(c, &end, 10), b = a;
+        if (*end == '-' && std::isdigit(static_cast<unsigned char>(end[1]))) b = std::strtol(end + 1, &end, 10);
+        for (long v = a; v <= b && v < CPU_SETSIZE; ++v) { CPU_SET(static_cast<int>(v), set); ++n; }
+        c = end;
     }
     return n > 0;
+}
+
+// what host_malloc_near needs to know about a device, read from the system once per device and process (the library allocates
+// pinned buffers from many threads at once: per-replica threads, workers)
+struct DeviceNode {
+    std::once_flag once;
+    int node = -1;
+    bool have_cpus = false;
+    cpu_set_t cpus;
+};
+inline DeviceNode &device_node(int device) {
+    static DeviceNode tab[64];
+    DeviceNode &d = tab[device >= 0 && device < 64 ? device : 0];
+    std::call_once(d.once, [&] {
+        d.node = gpu_node(device);
+        d.have_cpus = d.node >= 0 && node_cpus(d.node, &d.cpus);
+    });
+    return d;
 }
 
 // node of the CPU this thread runs on right now (-1: unknown)
@@ -81,12 +104,12 @@ inline bool enabled() {
 
 // pinned host memory for copies to / from `device`, on that device's NUMA node when the machine says which it is
 inline hipError_t host_malloc_near(void **p, size_t bytes, unsigned flags, int device) {
-    cpu_set_t before, near;
+    cpu_set_t before;
     bool moved = false;
-    const int gnode = enabled() ? gpu_node(device) : -1;
-    if (gnode >= 0 && node_cpus(gnode, &near) && sched_getaffinity(0, sizeof(before), &before) == 0) {
+    DeviceNode *dn = enabled() ? &device_node(device) : nullptr;
+    if (dn && dn->have_cpus && sched_getaffinity(0, sizeof(before), &before) == 0) {
         cpu_set_t both;
-        CPU_AND(&both, &before, &near);          // (never outside what the process may use)
+        CPU_AND(&both, &before, &dn->cpus);      // (never outside what the process may use)
         if (CPU_COUNT(&both) > 0 && sched_setaffinity(0, sizeof(both), &both) == 0) moved = true;
     }
     const int pnode = cpu_node();
@@ -95,7 +118,7 @@ inline hipError_t host_malloc_near(void **p, size_t bytes, unsigned flags, int d
     if (e == hipSuccess && std::getenv("RBG_NUMA_TRACE")) {
         static_cast<volatile char *>(*p)[0] = 0;
         std::fprintf(stderr, "rbg: pinned buffer of %.0f MB: allocating thread on NUMA node %d, GPU %d on node %d, first page on node %d (RBG_PIN_NUMA %s)\n",
-                     bytes / 1e6, pnode, device, gpu_node(device), page_node(*p), enabled() ? "on" : "off");
+                     bytes / 1e6, pnode, device, device_node(device).node, page_node(*p), enabled() ? "on" : "off");
     }
     return e;
 }

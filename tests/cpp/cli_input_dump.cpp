@@ -2,7 +2,8 @@
 // memory-mapped plain file, or through zlib for gzip and pipes) -- window after window, printing "name<TAB>seq" per
 // record, then "rc=<code>" (-1 end of input, -2 truncated quality string, -3 stream error).
 // usage: cli_input_dump <file> <window bytes> <threads> [<min bytes per scanning thread>]
-// stderr: "windows=<n> parallel=<n>" -- how many windows there were and how many were scanned by more than one thread
+// stderr: "windows=<n> parallel=<n> mode=<m>" -- how many windows there were, how many were scanned by more than one thread, and
+// how the input was read (InputSource::mode)
 #include <cstdio>
 #include <cstdlib>
 
@@ -30,6 +31,6 @@ int main(int argc, char **argv) {
         }
     } while (rc == 0);
     std::printf("rc=%d\n", rc);
-    std::fprintf(stderr, "windows=%llu parallel=%llu\n", windows, static_cast<unsigned long long>(rbg_cli::parallel_scans().load()));
+    std::fprintf(stderr, "windows=%llu parallel=%llu mode=%s\n", windows, static_cast<unsigned long long>(rbg_cli::parallel_scans().load()), in.mode());
     return 0;
 }

@@ -130,14 +130,16 @@ def cli_input(tmp_path_factory):
     subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-pthread",
                            os.path.join(ROOT, "tests", "cpp", "cli_input_dump.cpp"), "-o", str(exe), "-lz"])
 
-    def run(path, window, threads, minseg=None, stats=False):
-        p = subprocess.run([str(exe), str(path), str(window), str(threads)] + ([str(minseg)] if minseg else []), capture_output=True, timeout=120)
+    def run(path, window, threads, minseg=None, stats=False, mode=False):
+        p = subprocess.run([str(exe), str(path), str(window), str(threads)] + ([str(minseg)] if minseg else []), capture_output=True, timeout=300)
         assert p.returncode == 0, (p.stdout[-300:], p.stderr[-600:])
         lines = p.stdout.split(b"\n")
         assert lines[-1] == b"" and lines[-2].startswith(b"rc="), lines[-3:]
         res = [tuple(l.split(b"\t", 1)) for l in lines[:-2]], int(lines[-2][3:])
-        if stats:   # "windows=<n> parallel=<n>" on stderr
+        if stats or mode:   # "windows=<n> parallel=<n> mode=<m>" on stderr
             st = dict(kv.split(b"=") for kv in p.stderr.split(b"\n")[-2].split())
+            if mode:
+                return res + (int(st[b"windows"]), st[b"mode"].decode())
             return res + (int(st[b"windows"]), int(st[b"parallel"]))
         return res
     return run
@@ -211,19 +213,38 @@ def test_input_source_bgzf_blocks_inflated_in_parallel(cli_input, tmp_path):
         assert len(got) >= 40 * 4000 // 900 - 30      # everything before the bad block was delivered
 
 
+# ten bytes that pass even the strict test for a speculative member start (magic, deflate, no flags, mtime 0, XFL 0, OS 3 = Unix)
+GZ_TRAP = b"\x1f\x8b\x08\x00\x00\x00\x00\x00\x00\x03"
+
+
+def _gzread_model(raw):
+    """what zlib's gzread delivers (the reference reads through it: kseq.h over gzFile): member after member while the next bytes are a
+    gzip header; anything else -- zero padding too -- is trailing garbage and ends the file"""
+    import zlib
+    data, at = b"", 0
+    while raw[at:at + 2] == b"\x1f\x8b":
+        d = zlib.decompressobj(31)
+        data += d.decompress(raw[at:])
+        at = len(raw) - len(d.unused_data)
+    return data
+
+
+def _trap_fastq(rng, n, clean):
+    """FASTQ whose quality strings (from record `clean` on) hold the bytes of a gzip member header: they survive verbatim in stored
+    (level 0) members and look like member starts to a scan of the file"""
+    seqs = [bytes(rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), int(rng.integers(1, 300)))) for _ in range(n)]
+    return b"".join(b"@r%d\n" % i + s + b"\n+\n" + ((GZ_TRAP * len(s))[:len(s)] if i >= clean else b"I" * len(s)) + b"\n" for i, s in enumerate(seqs))
+
+
 def test_input_source_gzip_members_inflated_in_parallel(cli_input, tmp_path):
     """a gzip file of several members (`cat a.gz b.gz`; not BGZF) is mapped and its members are inflated by the worker threads,
     speculatively from every place that looks like a member's start and checked as a chain: same records and end code as kseq_read over
-    what gzip.open reads from the same file -- with members of every size, members stored uncompressed whose DATA holds gzip magic
-    bytes (false starts inside a member), zero padding between members, garbage after the last one (zlib stops there), and a corrupt
-    member (-3 after the records before it)"""
+    what gzip.open reads from the same file -- with members of every size (long ones are streamed across windows), members stored
+    uncompressed whose DATA holds gzip header bytes (false starts inside a member), zero padding between members, garbage after the
+    last one (zlib stops there), and a corrupt member (-3 after the records before it)"""
     import gzip
-    import zlib
     rng = np.random.default_rng(44)
-    seqs = [bytes(rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), int(rng.integers(1, 300)))) for _ in range(4000)]
-    # quality strings that contain the bytes of a gzip member header: they survive verbatim in stored (level 0) members
-    trap = b"\x1f\x8b\x08\x00"
-    fq = b"".join(b"@r%d\n" % i + s + b"\n+\n" + (trap * len(s))[:len(s)].replace(b"\n", b"!") + b"\n" for i, s in enumerate(seqs))
+    fq = _trap_fastq(rng, 4000, clean=700)   # (member 0 is free of traps: the check at open() passes and the parallel mode is entered)
 
     def members(data, sizes, levels, pad=b""):
         out, at = bytearray(), 0
@@ -235,23 +256,19 @@ def test_input_source_gzip_members_inflated_in_parallel(cli_input, tmp_path):
             k += 1
         return bytes(out), k
     for name, sizes, levels, pad, tail in (("m1.fq.gz", [50000], [6], b"", b""), ("m2.fq.gz", [1, 70000, 333, 20000], [0, 6, 1], b"", b""),
-                                           ("m3.fq.gz", [9000], [0], b"\0" * 7, b""), ("m4.fq.gz", [30000, 100], [6, 0], b"", b"garbage after the last member")):
+                                           ("m3.fq.gz", [9000], [0], b"\0" * 7, b""), ("m4.fq.gz", [30000, 100], [6, 0], b"", b"garbage after the last member"),
+                                           ("m5.fq.gz", [3000, 400000, 50, 90000], [6, 0, 0, 1], b"", b"")):
         blob, nm = members(fq, sizes, levels, pad)
         path = tmp_path / name
         path.write_bytes(blob + tail)
         assert nm > 3
-        # what zlib's gzread delivers (the reference reads through it: kseq.h over gzFile): member after member while the next bytes are
-        # a gzip header; anything else -- zero padding too -- is trailing garbage and ends the file
-        data, at, raw = b"", 0, blob + tail
-        while raw[at:at + 2] == b"\x1f\x8b":
-            d = zlib.decompressobj(31)
-            data += d.decompress(raw[at:])
-            at = len(raw) - len(d.unused_data)
+        data = _gzread_model(blob + tail)
         assert data == (fq if not pad else fq[:sizes[0]])
         want, want_rc = kseq_model(data)
         for window, threads, minseg in ((1 << 20, 4, 1000), (5000, 3, 300), (200, 2, 50), (1 << 20, 1, 1 << 20)):   # (1 thread: zlib's stream)
-            got, rc = cli_input(path, window, threads, minseg)
+            got, rc, _, mode = cli_input(path, window, threads, minseg, mode=True)
             assert (got, rc) == ([(n, s) for n, s in want], want_rc), (name, window, threads)
+            assert mode == ("stream" if threads == 1 or pad else "members"), (name, threads, mode)   # (padding: member 0 is followed by no header)
     # a corrupt member in the middle: -3, everything before it delivered
     blob, nm = members(fq, [20000], [6])
     blob = bytearray(blob)
@@ -262,8 +279,47 @@ def test_input_source_gzip_members_inflated_in_parallel(cli_input, tmp_path):
     bad.write_bytes(bytes(blob))
     want, _ = kseq_model(fq)
     for window, threads in ((1 << 20, 4), (9000, 3)):
-        got, rc = cli_input(bad, window, threads, 500)
+        got, rc, _, mode = cli_input(bad, window, threads, 500, mode=True)
+        assert mode == "members"
         assert rc == -3 and 0 < len(got) < len(want) and got[:-1] == [(n, s) for n, s in want][:len(got) - 1]
+        assert len(got) >= (len(starts) // 2 - 1) * 20000 // 330      # the members before the damaged one were delivered
+
+
+def test_input_source_single_member_gzip_with_false_member_starts_stays_a_stream(cli_input, tmp_path):
+    """ the bytes of a gzip member header turn up by chance inside deflate data -- about once per 134 MB -- so an ordinary
+    single-member .fq.gz has `candidates`.  Such a file must stay zlib's single stream: windows of the size asked for (not the whole
+    file as one window), and, cut short, every record before the cut followed by -3 -- what kseq over gzread delivers.  Here the false
+    starts are planted (a stored member whose quality strings hold header bytes that pass even the strict test)."""
+    import gzip
+    rng = np.random.default_rng(45)
+    fq = _trap_fastq(rng, 6000, clean=40)
+    blob = gzip.compress(fq, compresslevel=0)
+    assert blob.count(GZ_TRAP) > 1000
+    path = tmp_path / "single.fq.gz"
+    path.write_bytes(blob)
+    want, want_rc = kseq_model(fq)
+    for window, threads in ((100000, 4), (30000, 2), (100000, 1)):
+        got, rc, windows, mode = cli_input(path, window, threads, 500, mode=True)
+        assert mode == "stream"
+        assert (got, rc) == ([(n, s) for n, s in want], want_rc)
+        assert windows >= len(fq) // window          # never the whole file as one window
+    # the same file cut short: gzread fails at the cut; the records before it are delivered, then -3
+    cut = tmp_path / "cut.fq.gz"
+    cut.write_bytes(blob[:len(blob) * 9 // 10])
+    ref = cli_input(cut, 100000, 1, 500)             # one thread: zlib's stream, as in the base behaviour
+    assert ref[1] in (-1, -2) and len(want) * 8 // 10 < len(ref[0]) < len(want)
+    for window, threads in ((100000, 4), (30000, 3)):
+        got, rc, _, mode = cli_input(cut, window, threads, 500, mode=True)
+        assert mode == "stream" and (got, rc) == ref
+    # a real two-member file whose SECOND member is cut short: members mode, the first member and the text before the cut, the same end code
+    two = gzip.compress(fq[:200000], compresslevel=6) + gzip.compress(fq[200000:], compresslevel=0)[:-20000]
+    p2 = tmp_path / "two_cut.fq.gz"
+    p2.write_bytes(two)
+    ref = cli_input(p2, 100000, 1, 500)
+    assert ref[1] in (-1, -2) and len(want) * 8 // 10 < len(ref[0]) < len(want)
+    for window, threads in ((100000, 4), (1 << 20, 3), (3000, 2)):
+        got, rc, _, mode = cli_input(p2, window, threads, 500, mode=True)
+        assert mode == "members" and (got, rc) == ref
 
 
 def test_input_source_every_window_is_scanned_in_parallel(cli_input, tmp_path):
