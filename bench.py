@@ -78,8 +78,6 @@ def parse():
                          "that a profile of the default command holds undisturbed per-kernel durations)")
     ap.add_argument("--no-space-speed", action="store_true",
                     help="skip the space_speed block (the replica rebuilt at 4, 3, 2 and 1 symbols per gather; about a minute)")
-    ap.add_argument("--slot-bytes", type=int, default=0, choices=(0, 16, 64),
-                    help="bytes per rank slot (RBG_OPT_SLOT_BYTES): 16, or 64 = the 64-byte slots of DESIGN.md 4 r03; 0 = the library's default")
     ap.add_argument("--pos-bytes", type=int, default=0, choices=(0, 4, 8), help="force the position width of the HBM layout (RBG_OPT_POS_BYTES); 0 = by n")
     ap.add_argument("--layout", default="auto", choices=("auto", "slots", "runs"), help="RBG_OPT_RANK_LAYOUT of the headline replica")
     ap.add_argument("--hbm-budget-gb", type=float, default=0.0,
@@ -162,9 +160,6 @@ def main():
     from rowbowt_amd.tools import synth_pangenome as sp
 
     L = ra.lib()
-    if args.slot_bytes:
-        from rowbowt_amd import capi as _c
-        _c.set_default_option(_c.OPT_SLOT_BYTES, args.slot_bytes)
     if args.pos_bytes or args.layout != "auto":
         from rowbowt_amd import capi as _c
         if args.pos_bytes:
@@ -559,9 +554,6 @@ def main():
             # per read: its two offsets (16) and its outputs (lo, hi [, toehold]); per 16-byte read chunk fetched;
             # per ftab entry; per 16-byte rank slot; per 2-byte dense-table row; per rank searched in a run list:
             # two ord entries + ~3 probes of a {start, cum} pair; per materialised re-sample: ord (4) + sample (P)
-            if slot_b == 64:   # 64-byte slots: a dense-table row is 4 bytes, a materialised re-sample one gather of P
-                return (N * (16 + (24 if toehold else 16)) + 16 * sv["read_chunks"] + ftab_entry * sv["ftab"] + 64 * sv["slots"]
-                        + 4 * sv["dense"] + P * sv["resamples"])
             return (N * (16 + (24 if toehold else 16)) + 16 * sv["read_chunks"] + ftab_entry * sv["ftab"] + 16 * sv["slots"]
                     + 2 * sv["dense"] + (8 + 3 * 2 * P) * sv["searched_ranks"] + (4 + P) * sv["resamples"])
 
@@ -616,7 +608,7 @@ def main():
             # records / directory gathers, one sector per eight scanned entries, one per narrowing round, ftab entries, re-samples
             gathers = st_toe["slots"] + (st_toe["dense"] + 7) // 8 + st_toe["searched_ranks"] + st_toe["ftab"] + st_toe["resamples"]
         elif dom == "k_find_range<toehold>":
-            gathers = st_toe["slots"] + st_toe["dense"] + st_toe["ftab"] + (1 if slot_b == 64 else 2) * st_toe["resamples"] + 4 * st_toe["searched_ranks"]
+            gathers = st_toe["slots"] + st_toe["dense"] + st_toe["ftab"] + 2 * st_toe["resamples"] + 4 * st_toe["searched_ranks"]
         out = {
             "metric": f"reads/s ({args.read_len} bp, count+locate)",
             "value": value,
@@ -639,7 +631,7 @@ def main():
                           "hbm_free_at_load": int(ix.hbm_free_at_load), "hbm_budget": int(ix.hbm_budget),
                           "rank_layout": "runs" if int(ix.rank_layout) == 2 else "slots",
                           "hbm_budget_source": ("bench.py --hbm-budget-gb -1: three quarters of the free HBM" if args.hbm_budget_gb < 0
-                                                else "the library's default (a quarter of the free HBM)" if args.hbm_budget_gb == 0 else f"--hbm-budget-gb {args.hbm_budget_gb}"), "ftab_k": int(ix.ftab_k), "pair_runs": int(ix.pair_runs), "triple_runs": int(ix.triple_runs), "quad_runs": int(ix.quad_runs), "quint_runs": int(ix.quint_runs)},
+                                                else "the library's default (a quarter of the free HBM)" if args.hbm_budget_gb == 0 else f"--hbm-budget-gb {args.hbm_budget_gb}"), "ftab_k": int(ix.ftab_k), "depth_runs": [int(x) for x in ix.depth_runs]},
                 "reads_per_gpu": N, "read_len": m, "substituted_fraction": 0.1,
                 "parallelism": f"index replicated x{world}, reads sharded, no data-path collective",
                 **({"rehearsal": f"NOT A MEASUREMENT: {world} ranks on {torch.cuda.device_count()} GPU(s), collectives over gloo (--rehearse-ranks)"}
@@ -894,7 +886,7 @@ def main():
             i_, d_ = rb_.info(), {}
             if int(i_.rank_layout) == capi.LAYOUT_RUNS:
                 li_ = rb_.layout_info()
-                d_ = {"depths": [x + 1 for x in range(5) if int(li_.depth_mask_kept) >> x & 1],
+                d_ = {"depths": [x + 1 for x in range(8) if int(li_.depth_mask_kept) >> x & 1],
                       "ranks": "bucket records" if sum(int(x) for x in li_.rec_bytes) > 0 else "directories + run lists",
                       "phi": "slots of about n / r rows" if int(li_.phi_slots) else "list of sampled positions + directory"}
             return {"layout": "runs" if int(i_.rank_layout) == capi.LAYOUT_RUNS else "slots", **d_, "symbols_per_gather": int(i_.kmer_steps), "hbm_bytes": int(i_.hbm_bytes)}
@@ -936,14 +928,13 @@ def main():
         # the run-indexed layout (space proportional to r; wave-cooperative predecessor search): same batch, same outputs
         rb.close()
         torch.cuda.empty_cache()
-        # (run lists for all five k-mer depths in this row -- the roofline's instrumented counts are of this form; the rows
-        #  after it leave depths out: RBG_OPT_RUN_DEPTHS, 0x15 is the library's default)
-        with capi.default_option(capi.OPT_RANK_LAYOUT, capi.LAYOUT_RUNS), capi.default_option(capi.OPT_RUN_DEPTHS, 0x1F):
+        # (run lists for all eight k-mer depths in this row; the rows after it leave depths out: RBG_OPT_RUN_DEPTHS, 0x8B --
+        #  depths 1, 2, 4, 8 -- is the library's default)
+        with capi.default_option(capi.OPT_RANK_LAYOUT, capi.LAYOUT_RUNS), capi.default_option(capi.OPT_RUN_DEPTHS, 0xFF):
             rb = ra.RowBowt.from_runs(inp["heads"], inp["lens"], inp["ssa"], inp["esa"], device=local_rank)
         ms_r = time_search()
         step()
         rate_r = time_locate(ms_r)
-        run_fmt = int(rb.layout_info().run_fmt)
         run_phi_slots = int(rb.layout_info().phi_slots)   # > 0: phi through slots of about n / r rows (RBG_OPT_RUN_PHI; the library's choice here)
         # bytes of the run-indexed kernels AS RUN (instrumented instantiations; sums as include/rbg.h lists them for this
         # layout): per read its offsets + outputs + read chunks + ftab entry; per directory gather 8; per run-list entry a
@@ -963,12 +954,8 @@ def main():
         # positions: count + the rank's high part), a run-list entry 8 bytes at either width, a narrowing round seven 4-byte pivots, a sample 4 / 6
         # bytes; a phi step reads two 4-byte counts (+ one 8-byte super count at 8-byte positions) and entries of 8 / 12 bytes.
         run_recs = sum(int(x) for x in rb.layout_info().rec_bytes) > 0   # bucket records (RBG_OPT_RUN_REC): a "directory gather" is one 64-byte record
-        if run_fmt == 2:
-            b_dir, b_ent, b_narrow, b_samp = (64 if run_recs else 8 if Pr == 4 else 16), 8, 28, (4 if Pr == 4 else 6)
-            b_phi_dir, b_phi_ent = (8 if Pr == 4 else 16), (8 if Pr == 4 else 12)
-        else:
-            b_dir, b_ent, b_narrow, b_samp = 8, 2 * Pr, 16 * Pr, Pr
-            b_phi_dir, b_phi_ent = 8, 2 * Pr
+        b_dir, b_ent, b_narrow, b_samp = (64 if run_recs else 8 if Pr == 4 else 16), 8, 28, (4 if Pr == 4 else 6)
+        b_phi_dir, b_phi_ent = (8 if Pr == 4 else 16), (8 if Pr == 4 else 12)
 
         def run_search_bytes(sv, toehold):
             return (N * (16 + (24 if toehold else 16)) + 16 * sv["read_chunks"] + (16 if Pr == 4 else 32) * sv["ftab"] + b_dir * sv["slots"]
@@ -987,8 +974,8 @@ def main():
                                     "phi_steps_searched_beside_their_slot": rs_loc.get("phi_searched", 0) / N},
                        "search": rs_toe, "locate": rs_loc}
         same = all(bool((a == b).all().item()) for a, b in zip(ref_out, (d_lo, d_hi, d_k, d_loc_off))) and bool((ref_locs == d_locs[:total_locs]).all().item())
-        rows.append({"layout": "runs", "depths": [1, 2, 3, 4, 5][:int(rb.info().kmer_steps)], "symbols_per_gather": int(rb.info().kmer_steps), "hbm_bytes": int(rb.info().hbm_bytes), "ms": ms_r,
-                     "identical_to_the_headline_replica_on_the_whole_batch": same, "roofline": run_roof, "touched": run_touched, "run_fmt": run_fmt,
+        rows.append({"layout": "runs", "depths": [d + 1 for d in range(8) if int(rb.layout_info().depth_mask_kept) >> d & 1], "symbols_per_gather": int(rb.info().kmer_steps), "hbm_bytes": int(rb.info().hbm_bytes), "ms": ms_r,
+                     "identical_to_the_headline_replica_on_the_whole_batch": same, "roofline": run_roof, "touched": run_touched,
                      "phi": "slots of about n / r rows" if run_phi_slots else "list of sampled positions + directory",
                      "ranks": "bucket records (one 64-byte record per bucket)" if run_recs else "directories + run lists",
                      "count_locate_reads_per_s": rate_r})
@@ -1013,9 +1000,10 @@ def main():
             same = same and same_g and same_s
         # the same layout with run lists for some of the k-mer depths only (RBG_OPT_RUN_DEPTHS; include/rbg.h): a step takes
         # the longest stretch a kept depth covers -- the space of the depths left out against a step more per ragged stretch
-        # (0x15 twice: the library's own choice -- bucket records and phi slots on an index this small -- and the minimal form of the
-        #  layout: directories + run lists, phi over the list of sampled positions)
-        for depth_mask, minimal in (() if not same else ((0x15, False), (0x15, True), (0x11, False))):
+        # (0x8B twice: the library's own choice -- bucket records and phi slots on an index this small -- and the minimal form of the
+        #  layout: directories + run lists, phi over the list of sampled positions; 0x81: the first and the deepest only; 0x15: depths 1, 3, 5 --
+        #  the default replica of round 4, five symbols per step)
+        for depth_mask, minimal in (() if not same else ((0x8B, False), (0x8B, True), (0x81, False), (0x15, False))):
             rb.close()
             torch.cuda.empty_cache()
             with capi.default_option(capi.OPT_RANK_LAYOUT, capi.LAYOUT_RUNS), capi.default_option(capi.OPT_RUN_DEPTHS, depth_mask), \
@@ -1027,7 +1015,7 @@ def main():
             step()
             same_d = all(bool((a == b).all().item()) for a, b in zip(ref_out, (d_lo, d_hi, d_k, d_loc_off))) and bool((ref_locs == d_locs[:total_locs]).all().item())
             li_d = rb.layout_info()
-            row = {"layout": "runs", "depths": [d + 1 for d in range(5) if depth_mask >> d & 1], "symbols_per_gather": int(rb.info().kmer_steps),
+            row = {"layout": "runs", "depths": [d + 1 for d in range(8) if depth_mask >> d & 1], "symbols_per_gather": int(rb.info().kmer_steps),
                    "ranks": "bucket records" if sum(int(x) for x in li_d.rec_bytes) > 0 else "directories + run lists",
                    "phi": "slots of about n / r rows" if int(li_d.phi_slots) else "list of sampled positions + directory",
                    "hbm_bytes": int(rb.info().hbm_bytes), "ms": ms_d, "identical_to_the_headline_replica_on_the_whole_batch": same_d,
@@ -1057,10 +1045,10 @@ def main():
         # what the headline costs: the best count+locate rate among the replicas of at most 64 GB, and the rate of the replica a DEFAULT
         # rbg_load builds -- no option set: budget = a quarter of the free HBM, RBG_LAYOUT_AUTO (slot tables if all five symbols per
         # step fit that, else the run-indexed layout) -- built and timed here like the other rows
-        headline_is_default = args.hbm_budget_gb == 0 and args.layout == "auto" and not args.pos_bytes and not args.slot_bytes
+        headline_is_default = args.hbm_budget_gb == 0 and args.layout == "auto" and not args.pos_bytes
         rb.close()
         torch.cuda.empty_cache()
-        with capi.default_option(capi.OPT_HBM_BUDGET_MB, 0), capi.default_option(capi.OPT_RANK_LAYOUT, capi.LAYOUT_AUTO), capi.default_option(capi.OPT_KMER_STEPS, 5):
+        with capi.default_option(capi.OPT_HBM_BUDGET_MB, 0), capi.default_option(capi.OPT_RANK_LAYOUT, capi.LAYOUT_AUTO), capi.default_option(capi.OPT_KMER_STEPS, capi.MAX_KMER_DEPTH):
             rb = ra.RowBowt.from_runs(inp["heads"], inp["lens"], inp["ssa"], inp["esa"], device=local_rank)
         ms_df = time_search()
         step()
@@ -1074,7 +1062,7 @@ def main():
                                         "identical_to_the_headline_replica_on_the_whole_batch": same_df,
                                         **({"ranks": "bucket records" if sum(int(x) for x in li_df.rec_bytes) > 0 else "directories + run lists",
                                             "phi": "slots of about n / r rows" if int(li_df.phi_slots) else "list of sampled positions + directory",
-                                            "depths": [d + 1 for d in range(5) if int(li_df.depth_mask_kept) >> d & 1]} if runs_df else {}),
+                                            "depths": [d + 1 for d in range(8) if int(li_df.depth_mask_kept) >> d & 1]} if runs_df else {}),
                                         "budget": "a quarter of the HBM free at load (rbg_load with no option set: RBG_LAYOUT_AUTO)",
                                         "is_the_headline_replica": headline_is_default}
         if not same_df:

@@ -33,7 +33,14 @@
 extern "C" {
 #endif
 
-#define RBG_ABI_VERSION 2
+/* ABI 3 (round 5): RBG_OPT_KMER_STEPS goes up to 8 (default 8: the run-indexed layout steps by up to eight symbols; the slot layout by
+ * up to five); rbg_info_t ends with depth_runs[8]; rbg_layout_info_t holds eight depths and lost the fields of the retired first format;
+ * the options RBG_OPT_TREE_TOP_KB (12), RBG_OPT_SLOT_BYTES (13) and RBG_OPT_RUN_FMT (15) are gone (RBG_EARG) together with the kernels they
+ * selected.  ABI 2 -> 3 also records what round 4 changed without a bump: the default HBM budget is a
+ * quarter of the free HBM (was three quarters), RBG_LAYOUT_AUTO builds the run-indexed layout when the slot tables of every symbol per step
+ * do not fit it, rbg_layout_info / rbg_sample_reads_pangenome_dev / RBG_LAYOUT_PREFER_SLOTS / options 16-17 exist.  A binding should check
+ * rbg_abi_version() before it binds the symbols of a newer ABI (rowbowt_amd/capi.py does). */
+#define RBG_ABI_VERSION 3
 
 typedef struct rbg_index rbg_index;
 
@@ -133,7 +140,7 @@ typedef struct rbg_info_t {
     uint64_t hbm_bytes;     /* bytes of the device replica */
     uint64_t marker_runs, marker_vals;
     uint32_t rank_bucket_shift, phi_bucket_shift;
-    uint32_t slot_bytes;    /* bytes per rank slot of the slot layout: 16, or 64 (RBG_OPT_SLOT_BYTES); 0 on the run-indexed layout or without a device */
+    uint32_t slot_bytes;    /* bytes per rank slot of the slot layout: 16; 0 on the run-indexed layout or without a device */
     /* first-level slot tables: totals and how many buckets overflow their 2 inline entries */
     uint64_t rank_slots, rank_slots_overflow, phi_slots, phi_slots_overflow;
     /* multi-symbol LF steps: symbols consumed per gather (1..5), size of the major alphabet that has
@@ -150,6 +157,8 @@ typedef struct rbg_info_t {
     uint64_t rank_layout;   /* RBG_LAYOUT_SLOTS or RBG_LAYOUT_RUNS (what RBG_OPT_RANK_LAYOUT / the budget rule chose) */
     uint64_t replicas;      /* per handle: 1 when this handle holds a device replica, 0 for a host-only index
                              * (RBG_DEVICE_NONE); further replicas are handles of their own (rbg_replicate[_many]) */
+    uint64_t depth_runs[8]; /* ABI 3: [d - 1] = total runs of the tables of k-mer depth d ([0] = r; 0 for a depth that has no tables,
+                             * or no run lists on the run-indexed layout); pair_runs .. quint_runs above are [1] .. [4] */
 } rbg_info_t;
 enum { RBG_LAYOUT_AUTO = 0, RBG_LAYOUT_SLOTS = 1, RBG_LAYOUT_RUNS = 2, RBG_LAYOUT_PREFER_SLOTS = 3 };
 int rbg_info(const rbg_index *, rbg_info_t *out);
@@ -159,24 +168,22 @@ int rbg_info(const rbg_index *, rbg_info_t *out);
  * this layout has one -- or the HBM budget bites -- the decision is here and on stderr.  All zero on the slot layout.
  * out_bytes = sizeof(rbg_layout_info_t) of the caller (fields beyond it are not written: the struct may grow at its end). */
 typedef struct rbg_layout_info_t {
-    uint32_t run_fmt;                 /* RBG_OPT_RUN_FMT as built: 1 or 2 */
-    uint32_t depths_composed;         /* k-mer depths the load composed run lists for (1..5) */
+    uint32_t run_fmt;                 /* 2 (the per-lane search; the wave-cooperative format 1 of rounds 2-3 was retired in round 5) */
+    uint32_t depths_composed;         /* k-mer depths the load composed run lists for (1..8) */
     uint32_t depth_mask_asked;        /* RBG_OPT_RUN_DEPTHS as given (0 = the default rule) */
     uint32_t depth_mask_kept;         /* bit d - 1: depth d has run lists in HBM */
     uint32_t depths_dropped_budget;   /* bit d - 1: depth d was left out because the replica exceeded the HBM budget */
-    uint32_t depths_dropped_limit;    /* bit d - 1: depth d was left out by a width limit (format 1: 2^32 entries per depth) */
-    uint32_t rank_directories;        /* 1: ranks go through the per-table directories */
+    uint32_t rank_directories;        /* 1: some depth's ranks go through per-table directories (a depth with bucket records has rec_bytes > 0) */
     uint32_t phi_directory;           /* 1: phi goes through its directory */
-    uint32_t phi_directory_dropped;   /* 1: format 1 left it out (beyond 2 GiB or r >= 2^31): phi descends the sampled levels */
-    uint32_t fill_shift;              /* format 2, 8-byte positions: entries of a table lie less than 2^fill_shift rows apart */
-    uint64_t entries[5];              /* per depth: entries of its run lists (sentinels and fillers included) */
-    uint64_t fillers[5];              /* per depth: filler entries among them (format 2, 8-byte positions; 0 unless a table has a gap >= 2^fill_shift) */
-    uint64_t dir_bytes[5];            /* per depth: bytes of its tables' directories */
+    uint32_t fill_shift;              /* 8-byte positions: entries of a table lie less than 2^fill_shift rows apart */
+    uint64_t entries[8];              /* per depth: entries of its run lists (sentinels and fillers included) */
+    uint64_t fillers[8];              /* per depth: filler entries among them (8-byte positions; 0 unless a table has a gap >= 2^fill_shift) */
+    uint64_t dir_bytes[8];            /* per depth: bytes of its tables' directories */
     uint64_t phi_entries, phi_fillers, phi_dir_bytes, phi_dir_shift;
-    uint64_t phi_slots, phi_slot_bytes; /* format 2 with phi SLOTS (RBG_OPT_RUN_PHI): their number (buckets of 2^phi_dir_shift text positions) and the
+    uint64_t phi_slots, phi_slot_bytes; /* phi SLOTS (RBG_OPT_RUN_PHI): their number (buckets of 2^phi_dir_shift text positions) and the
                                          * bytes of slots + ordinals; 0 = phi goes through the list of sampled positions and its directory */
-    uint64_t rec_bytes[5];            /* per depth: bytes of its tables' bucket records (RBG_OPT_RUN_REC; 0 = directories; rank_directories is 0 with records) */
-    uint64_t rec_overflow[5];         /* per depth: buckets with more entries than a record holds (their ranks go through the run list) */
+    uint64_t rec_bytes[8];            /* per depth: bytes of its tables' bucket records (RBG_OPT_RUN_REC; 0 = directories) */
+    uint64_t rec_overflow[8];         /* per depth: buckets with more entries than a record holds (their ranks go through the run list) */
 } rbg_layout_info_t;
 int rbg_layout_info(const rbg_index *, rbg_layout_info_t *out, uint64_t out_bytes);
 
@@ -475,7 +482,7 @@ int rbg_sample_reads_pangenome_dev(const uint8_t *d_base, const uint64_t *d_site
  * kernels use 1024-thread workgroups instead while the 5-mer level is resident),
  * RANK/PHI_BUCKET_SHIFT (-1 = automatic, else 0..8; RANK also 9..12 = wide buckets), DEEP_BUCKET_SHIFT (-1 = like
  * RANK, else the bucket shift of the 4-mer and deeper tables only, whose runs are sparse), POS_BYTES (0 = automatic, 4 or 8 to force a width),
- * KMER_STEPS (1..5, default 5: symbols the backward search consumes per gather; 2..5 build the k-mer
+ * KMER_STEPS (1..8, default 8: symbols the backward search consumes per step; the slot layout takes at most 5 of them per gather; 2.. build the k-mer
  * tables of DESIGN.md 2b -- each level is four times the tables of the one before, 218 GB in all for a
  * 2-Gbase index; 1 keeps the reference's one-symbol steps only; the deepest levels are dropped
  * automatically when the replica would not fit), HBM_BUDGET_MB (0 = A QUARTER of the free HBM -- three quarters until round 3; a drop-in library leaves the device to its caller unless told otherwise:
@@ -497,52 +504,40 @@ int rbg_sample_reads_pangenome_dev(const uint8_t *d_base, const uint64_t *d_site
  * not fit either (about 110 bytes per run).  RBG_LAYOUT_PREFER_SLOTS: slot tables with as many symbols per step as fit, the
  * run-indexed layout only when not even the single-symbol level does (the rule of rounds 2-3; rb_markers asks for it: its
  * seeding kernels are faster on slot tables).  rbg_info::rank_layout reports the outcome.
- * RBG_LAYOUT_SLOTS, RBG_LAYOUT_RUNS = the run-indexed layout: the run lists (of every k-mer depth KMER_STEPS asks
- * for and the budget holds) plus a 16-ary sampled index per depth, space proportional to r and nothing proportional
- * to n; rank and phi are wave-cooperative predecessor searches (rle_string::rank rle_string.hpp:131-161 /
- * ToeholdSA::phi toehold_sa.hpp:56-72 keep their O(r) shape).  TREE_TOP_KB (1..96, default 48): LDS the staged top
- * level of that index may take per workgroup (0 = sixteen keys in all: the deepest possible index, for tests). */
+ * RBG_LAYOUT_SLOTS, RBG_LAYOUT_RUNS = the run-indexed layout: the run lists of the k-mer depths RUN_DEPTHS names (by default the
+ * deepest KMER_STEPS asks for and the budget holds, half of it, a quarter of it ... and 1) with a directory or bucket records per
+ * table, space proportional to r and nothing proportional to n; rank and phi are predecessor searches over the few entries of
+ * one bucket by the lane that owns the query (rle_string::rank rle_string.hpp:131-161 / ToeholdSA::phi toehold_sa.hpp:56-72 keep
+ * their O(r) shape). */
 /* Environment switches (read at load or per call; none of them changes an answer -- they exist for A/B measurements
  * and for the tests that pin both sides):  RBG_PHI_PACKED=0 keeps 32-byte phi slots at 8-byte positions;
- * RBG_RANK_DIR=0 / RBG_PHI_DIR=0 build the run-indexed layout without its rank / phi directories (descent through
- * the sampled levels only), RBG_RANK_DIR_RUNS=<x> sets the runs per rank-directory bucket (default 4),
- * RBG_RANK_REC=<t> adds bucket records with at most t runs each (off by default: DESIGN.md 2c) -- each of these three selects
- * format 1 of the layout (RBG_OPT_RUN_FMT); RBG_PHI_DIR_PER=<x> sets the sampled positions per phi-directory bucket of format 2
- * (default 1..2); RBG_RUN_FILL_SHIFT / RBG_PHI_SUPER_SHIFT lower format 2's filler distance / super-count spacing so that tests
+ * RBG_RANK_DIR_RUNS=<x> sets the runs per rank-directory bucket of the run-indexed layout (default 4), RBG_RUN_REC_PER=<x> the entries
+ * per bucket record (default 2.5), RBG_PHI_DIR_PER=<x> the sampled positions per phi-directory bucket (default 1..2);
+ * RBG_RUN_FILL_SHIFT / RBG_PHI_SUPER_SHIFT lower the filler distance / super-count spacing of 8-byte positions so that tests
  * meet both on small indexes;  RBG_HOST_THREADS, RBG_HOST_CHUNK_READS, RBG_HOST_DIRECT_OUT=0, RBG_HOST_COMBINE=0,
- * RBG_HOST_TRACE=1|2 tune / trace the host-pointer pipeline;  RBG_LAYOUT=auto|slots|runs, RBG_RUN_DEPTHS,
- * RBG_KMER_STEPS, RBG_HBM_BUDGET_MB, RBG_FTAB_K give the options of the same names their initial values (for the command-line
- * tools, which keep the reference's flags; rbg_set_default_option overrides them);  RBG_RUNS_HOST_BUILD=1 builds the run-indexed
- * layout's directories on the host, RBG_H2D_STAGED=0 uploads the big arrays of a load by plain hipMemcpy;  RBG_VERBOSE=1 prints
- * what the budget rule did and the seconds of every stage of a load. */
+ * RBG_HOST_TRACE=1|2 tune / trace the host-pointer pipeline;  RBG_LAYOUT=auto|slots|runs|prefer-slots, RBG_RUN_DEPTHS,
+ * RBG_KMER_STEPS, RBG_HBM_BUDGET_MB, RBG_FTAB_K, RBG_RUN_PHI, RBG_RUN_REC give the options of the same names their initial values (for
+ * the command-line tools, which keep the reference's flags; rbg_set_default_option overrides them);  RBG_H2D_STAGED=0 uploads the big
+ * arrays of a load by plain hipMemcpy;  RBG_VERBOSE=1 prints what the budget rule did and the seconds of every stage of a load. */
 enum { RBG_OPT_BLOCK_THREADS = 1, RBG_OPT_RANK_BUCKET_SHIFT = 2, RBG_OPT_PHI_BUCKET_SHIFT = 3, RBG_OPT_POS_BYTES = 4,
        RBG_OPT_KMER_STEPS = 5, RBG_OPT_HBM_BUDGET_MB = 6, RBG_OPT_FTAB_K = 7, RBG_OPT_PACKED_READS = 8,
-       RBG_OPT_DEEP_BUCKET_SHIFT = 9, RBG_OPT_DENSE_OVERFLOW = 10, RBG_OPT_RANK_LAYOUT = 11, RBG_OPT_TREE_TOP_KB = 12,
-       RBG_OPT_SLOT_BYTES = 13 /* 16 (default) or 64: 64-byte rank slots over four times the rows -- the sector a 16-byte
-                                  gather moves anyway, fetched by a quad of lanes; slot layout only, falls
-                                  back to 16 when a table needs wide buckets; rbg_info().slot_bytes says what was built */,
+       RBG_OPT_DEEP_BUCKET_SHIFT = 9, RBG_OPT_DENSE_OVERFLOW = 10, RBG_OPT_RANK_LAYOUT = 11,
+       /* 12, 13 and 15 were RBG_OPT_TREE_TOP_KB, RBG_OPT_SLOT_BYTES and RBG_OPT_RUN_FMT (retired with ABI 3: RBG_EARG) */
        RBG_OPT_RUN_DEPTHS = 14 /* run-indexed layout: bit d - 1 set = keep run lists for the k-mer depth d (bit 0 is implied; depths
                                   above the highest bit are not built).  A search step consumes the longest stretch a kept
                                   depth covers, so any set gives the same answers; the lists grow with the depth (DESIGN.md
-                                  2c).  0 = default: every other depth counted down from RBG_OPT_KMER_STEPS (1, 3, 5 of
-                                  five: 62 % of the space of all five at n = 5e10, the same rate on 150 bp reads, one step
-                                  more for a stretch of 2 or 4 symbols); 0x1F keeps all five; over budget the depths
-                                  between the first and the deepest go before the deepest does.  rbg_info(): kmer_steps is
-                                  the deepest depth kept, pair_runs .. quint_runs are 0 for the depths left out */,
-       RBG_OPT_RUN_FMT = 15 /* run-indexed layout: 2 (default) = every lane answers its own ranks and phi steps from the few entries
-                                  its directory bucket names (at 8-byte positions the entries hold the low 32 bits of {start, cum}:
-                                  the bucket number is the high part, the same split the reference's Elias-Fano vectors make,
-                                  sparse_sd_vector.hpp:110-163; entry indices are 64-bit, nothing is left out for its size);
-                                  1 = rounds 2-3: {P, P} pairs probed by quads of lanes (kept for A/B measurements and for the
-                                  options that build an index without directories).  RBG_RUN_FMT gives the initial value.
-                                  rbg_layout_info() says what was built. */,
-       RBG_OPT_RUN_PHI = 16 /* run-indexed layout, format 2 -- how phi (toehold_sa.hpp:56-72) is answered: 1 = from the list of sampled positions
+                                  2c).  0 = default: the deepest depth RBG_OPT_KMER_STEPS asks for, half of it, a quarter of
+                                  it ... and 1 (1, 2, 4, 8 of eight: whole reads go by eight symbols a step, a remainder takes
+                                  one step per set bit); 0xFF keeps all eight; over budget the depths between the first and
+                                  the deepest go before the deepest does.  rbg_info(): kmer_steps is the deepest depth kept,
+                                  depth_runs[d - 1] is 0 for the depths left out */,
+       RBG_OPT_RUN_PHI = 16 /* run-indexed layout -- how phi (toehold_sa.hpp:56-72) is answered: 1 = from the list of sampled positions
                                   through its directory (12-16 bytes per run: two dependent sectors per step); 2 = from direct-addressed phi SLOTS
                                   (the slot layout's PhiSlot records) whose buckets are about n / r rows wide, so that their number is proportional
                                   to r (about 54 bytes per run at 8-byte positions: one sector per step -- at pangenome scale K3 is bound by that
                                   count); 0 (default) = slots when the whole replica then stays within half the HBM budget.  RBG_RUN_PHI gives the
                                   initial value; rbg_layout_info().phi_slots says what was built. */,
-       RBG_OPT_RUN_REC = 17 /* run-indexed layout, format 2 -- BUCKET RECORDS: 2 = every bucket of a table (about three entries wide) gets one aligned
+       RBG_OPT_RUN_REC = 17 /* run-indexed layout -- BUCKET RECORDS: 2 = every bucket of a table (about three entries wide) gets one aligned
                                   64-byte record holding its entries and the one before them (up to eleven in the compact form, six otherwise; a bucket with
                                   more holds twelve pivots into the run list instead: rbg_dev.h RunRec2), direct-addressed: a rank is ONE sector instead of a
                                   directory sector plus an unaligned stretch of the run list (K1/K2 on this layout are bound by that count); about

@@ -20,7 +20,10 @@ VP = C.c_void_p
 MAXU = 2**64 - 1
 DEVICE_NONE = -1
 
-OPT_BLOCK_THREADS, OPT_RANK_BUCKET_SHIFT, OPT_PHI_BUCKET_SHIFT, OPT_POS_BYTES, OPT_KMER_STEPS, OPT_HBM_BUDGET_MB, OPT_FTAB_K, OPT_PACKED_READS, OPT_DEEP_BUCKET_SHIFT, OPT_DENSE_OVERFLOW, OPT_RANK_LAYOUT, OPT_TREE_TOP_KB, OPT_SLOT_BYTES, OPT_RUN_DEPTHS, OPT_RUN_FMT, OPT_RUN_PHI, OPT_RUN_REC = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17
+OPT_BLOCK_THREADS, OPT_RANK_BUCKET_SHIFT, OPT_PHI_BUCKET_SHIFT, OPT_POS_BYTES, OPT_KMER_STEPS, OPT_HBM_BUDGET_MB, OPT_FTAB_K, OPT_PACKED_READS, OPT_DEEP_BUCKET_SHIFT, OPT_DENSE_OVERFLOW, OPT_RANK_LAYOUT = range(1, 12)
+OPT_RUN_DEPTHS, OPT_RUN_PHI, OPT_RUN_REC = 14, 16, 17   # (12, 13, 15 were TREE_TOP_KB, SLOT_BYTES, RUN_FMT: retired with ABI 3)
+ABI_VERSION = 3          # include/rbg.h RBG_ABI_VERSION this binding is written against
+MAX_KMER_DEPTH = 8       # RBG_OPT_KMER_STEPS / the depth arrays of Info and LayoutInfo
 LAYOUT_AUTO, LAYOUT_SLOTS, LAYOUT_RUNS, LAYOUT_PREFER_SLOTS = 0, 1, 2, 3
 (ARR_RUN_HEADS, ARR_RUN_START, ARR_SAMPLES_LAST, ARR_PRED_POS, ARR_PHI_BASE,
  ARR_MARKER_START, ARR_MARKER_END, ARR_MARKER_OFF, ARR_MARKER_VALS) = range(9)
@@ -48,16 +51,17 @@ class Info(C.Structure):
                 ("rank_bucket_shift", C.c_uint32), ("phi_bucket_shift", C.c_uint32), ("slot_bytes", C.c_uint32),
                 ("rank_slots", U64), ("rank_slots_overflow", U64), ("phi_slots", U64), ("phi_slots_overflow", U64),
                 ("kmer_steps", U64), ("kmer_symbols", U64), ("pair_runs", U64), ("triple_runs", U64), ("quad_runs", U64), ("ftab_k", U64), ("quint_runs", U64),
-                ("kmer_steps_requested", U64), ("hbm_free_at_load", U64), ("hbm_budget", U64), ("rank_layout", U64), ("replicas", U64)]
+                ("kmer_steps_requested", U64), ("hbm_free_at_load", U64), ("hbm_budget", U64), ("rank_layout", U64), ("replicas", U64),
+                ("depth_runs", U64 * 8)]
 
 
 class LayoutInfo(C.Structure):
     """rbg_layout_info_t"""
     _fields_ = [("run_fmt", C.c_uint32), ("depths_composed", C.c_uint32), ("depth_mask_asked", C.c_uint32), ("depth_mask_kept", C.c_uint32),
-                ("depths_dropped_budget", C.c_uint32), ("depths_dropped_limit", C.c_uint32), ("rank_directories", C.c_uint32),
-                ("phi_directory", C.c_uint32), ("phi_directory_dropped", C.c_uint32), ("fill_shift", C.c_uint32),
-                ("entries", U64 * 5), ("fillers", U64 * 5), ("dir_bytes", U64 * 5),
-                ("phi_entries", U64), ("phi_fillers", U64), ("phi_dir_bytes", U64), ("phi_dir_shift", U64), ("phi_slots", U64), ("phi_slot_bytes", U64), ("rec_bytes", U64 * 5), ("rec_overflow", U64 * 5)]
+                ("depths_dropped_budget", C.c_uint32), ("rank_directories", C.c_uint32),
+                ("phi_directory", C.c_uint32), ("fill_shift", C.c_uint32),
+                ("entries", U64 * 8), ("fillers", U64 * 8), ("dir_bytes", U64 * 8),
+                ("phi_entries", U64), ("phi_fillers", U64), ("phi_dir_bytes", U64), ("phi_dir_shift", U64), ("phi_slots", U64), ("phi_slot_bytes", U64), ("rec_bytes", U64 * 8), ("rec_overflow", U64 * 8)]
 
 
 # every symbol include/rbg.h declares: (name, restype, argtypes)
@@ -169,6 +173,11 @@ def lib():
                               "(or __graft_entry__.build()); there is no CPU fallback")
         _one_hip_runtime()
         L = C.CDLL(_SO)
+        L.rbg_abi_version.restype = C.c_int
+        L.rbg_abi_version.argtypes = []
+        have = L.rbg_abi_version()
+        if have != ABI_VERSION:   # (the structs above and the option numbers are this ABI's: never bind another one's symbols blindly)
+            raise ImportError(f"{_SO} reports ABI {have}, this binding is written against ABI {ABI_VERSION}: rebuild it with `make -C rowbowt_amd/csrc`")
         for name, res, args in _PROTOS:
             fn = getattr(L, name)
             fn.restype = res

@@ -124,107 +124,6 @@ __global__ __launch_bounds__(256) void k_fill_dense(const RunEnt<P> *__restrict_
     }
 }
 
-// ---- 64-byte slots (rbg_dev.h RankSlot64): one per 4 x 2^shift rows -------------------------------------------------
-template <typename P>
-__global__ __launch_bounds__(256) void k_build_rank_slots64(const RunEnt<P> *__restrict__ ent, const P *__restrict__ samp, const uint64_t nruns,
-                                                            const uint64_t n, const uint32_t bshift, RankSlot64 *__restrict__ slots,
-                                                            unsigned long long *__restrict__ overflow, unsigned long long *__restrict__ dense_cursor) {
-    const uint64_t nb = (n >> bshift) + 2;
-    const uint64_t S = uint64_t(1) << bshift;
-    const uint64_t ngroups = (nb + kBuildGroup - 1) / kBuildGroup;
-    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
-    unsigned long long novf = 0;
-    for (uint64_t g = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; g < ngroups; g += stride) {
-        const uint64_t b0 = g * kBuildGroup, b1 = b0 + kBuildGroup < nb ? b0 + kBuildGroup : nb;
-        uint64_t k = 0, z = nruns;
-        const uint64_t first = b0 << bshift;
-        while (k < z) {
-            const uint64_t mid = k + ((z - k) >> 1);
-            if (static_cast<uint64_t>(ent[mid].start) < first) k = mid + 1; else z = mid;
-        }
-        for (uint64_t b = b0; b < b1; ++b) {
-            const uint64_t B0 = b << bshift;
-            while (k < nruns && static_cast<uint64_t>(ent[k].start) < B0) ++k;
-            uint64_t r0 = 0, ext = 0, prev_is_c = 0, psamp = 0;
-            if (k > 0) {
-                const uint64_t ps = ent[k - 1].start, pc = ent[k - 1].cum;
-                const uint64_t pl = static_cast<uint64_t>(ent[k].cum) - pc;
-                r0 = pc + (pl < B0 - ps ? pl : B0 - ps);
-                if (ps + pl > B0) ext = ps + pl - B0 < S ? ps + pl - B0 : S;
-                prev_is_c = ps + pl >= B0 ? 1 : 0;
-                if (samp) psamp = samp[k - 1];
-            }
-            RankSlot64 s;
-#pragma unroll
-            for (int t = 0; t < 16; ++t) s.w[t] = 0;
-            uint64_t cnt = 0;
-            unsigned long long bits[5] = {0, 0, 0, 0, 0};   // 14 x 20 bits = 280 bits, from bit 0 of w5
-            while (k + cnt < nruns && static_cast<uint64_t>(ent[k + cnt].start) < B0 + S) {
-                if (cnt < static_cast<uint64_t>(kSlot64Runs)) {
-                    const uint64_t st = ent[k + cnt].start;
-                    const uint64_t off = st - B0;
-                    const uint64_t full = static_cast<uint64_t>(ent[k + cnt + 1].cum) - static_cast<uint64_t>(ent[k + cnt].cum);
-                    const uint64_t len = full < B0 + S - st ? full : B0 + S - st;
-                    const unsigned long long v = off | ((len - 1) << 10);
-                    const uint64_t bit = 20 * cnt;
-                    bits[bit >> 6] |= v << (bit & 63);
-                    if ((bit & 63) > 44) bits[(bit >> 6) + 1] |= v >> (64 - (bit & 63));
-                }
-                ++cnt;
-            }
-            uint32_t code = static_cast<uint32_t>(cnt);
-            if (cnt > static_cast<uint64_t>(kSlot64Runs)) { code = kSlot64Ovf; ++novf; }
-            s.w[0] = static_cast<uint32_t>(r0);
-            s.w[1] = static_cast<uint32_t>((r0 >> 32) & 0xFFFFu) | (static_cast<uint32_t>(ext) << 16) | (static_cast<uint32_t>(prev_is_c) << 27) | (code << 28);
-            s.w[2] = static_cast<uint32_t>(k);
-            s.w[3] = static_cast<uint32_t>(psamp);
-            s.w[4] = static_cast<uint32_t>(psamp >> 32);
-            if (code == kSlot64Ovf) {
-                s.w[5] = static_cast<uint32_t>(atomicAdd(dense_cursor, 1ull));   // the bucket's dense table (k_fill_dense64)
-            } else {
-#pragma unroll
-                for (int t = 0; t < 9; ++t) s.w[5 + t] = static_cast<uint32_t>(bits[t >> 1] >> (32 * (t & 1)));
-            }
-            slots[b] = s;
-        }
-    }
-    novf = wave_sum(novf);
-    if ((threadIdx.x & (kWave - 1)) == 0 && novf) atomicAdd(overflow, novf);
-}
-
-// dense tables of the overflow buckets: one u32 per row (rbg_dev.h); one thread per bucket, few buckets do any work
-template <typename P>
-__global__ __launch_bounds__(256) void k_fill_dense64(const RunEnt<P> *__restrict__ ent, const uint64_t n, const uint32_t bshift,
-                                                      const RankSlot64 *__restrict__ slots, uint8_t *__restrict__ dense) {
-    const uint64_t nb = (n >> bshift) + 2;
-    const uint64_t S = uint64_t(1) << bshift;
-    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
-    for (uint64_t b = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; b < nb; b += stride) {
-        const uint32_t w1 = slots[b].w[1];
-        if ((w1 >> 28) != kSlot64Ovf) continue;
-        uint32_t *out = reinterpret_cast<uint32_t *>(dense + (static_cast<uint64_t>(slots[b].w[5]) << 12));
-        uint64_t k = slots[b].w[2];
-        const uint64_t B0 = b << bshift;
-        uint64_t cur_end = 0;   // end (exclusive) of the last run that began at or before the current row
-        if (k > 0) cur_end = static_cast<uint64_t>(ent[k - 1].start) + (static_cast<uint64_t>(ent[k].cum) - static_cast<uint64_t>(ent[k - 1].cum));
-        uint64_t next_start = static_cast<uint64_t>(ent[k].start);   // (the sentinel {n, total} ends every list)
-        bool prev_c = (w1 >> 27) & 1u;
-        uint32_t d = 0, starts = 0;
-        for (uint64_t o = 0; o < S; ++o) {
-            const uint64_t pos = B0 + o;
-            out[o] = (d & 0x7FFu) | ((starts & 0x3FFu) << 11) | (prev_c ? 0x80000000u : 0u);
-            if (pos == next_start && pos < n) {
-                cur_end = pos + (static_cast<uint64_t>(ent[k + 1].cum) - static_cast<uint64_t>(ent[k].cum));
-                ++k;
-                ++starts;
-                next_start = static_cast<uint64_t>(ent[k].start);
-            }
-            prev_c = pos < cur_end;
-            if (prev_c) ++d;
-        }
-    }
-}
-
 template <typename P, bool PACKED = false>
 __global__ __launch_bounds__(256) void k_build_phi_slots(const PhiEnt<P> *__restrict__ ent, const uint64_t r, const uint64_t n,
                                                          const uint32_t shift, void *__restrict__ slots_v,
@@ -282,7 +181,7 @@ __global__ __launch_bounds__(256) void k_build_phi_slots(const PhiEnt<P> *__rest
     if ((threadIdx.x & (kWave - 1)) == 0 && novf) atomicAdd(overflow, novf);
 }
 // ---- run-indexed layout built from run lists that are already on the device (the k-mer levels of k_compose.hip) -----------
-// dir[doff[t] + b] = # runs of table t that start below b << dshift[t] (rbg_dev.h DevRunTab): one thread per directory entry
+// dir[doff[t] + b] = # runs of table t that start below b << dshift[t] (rbg_dev.h DevRunTab2): one thread per directory entry
 template <typename P>
 __global__ __launch_bounds__(256) void k_run_dirs(const RunEnt<P> *__restrict__ ent, const uint64_t *__restrict__ first, const uint64_t *__restrict__ nruns,
                                                   const uint64_t *__restrict__ doff, const uint32_t *__restrict__ dshift, const uint32_t T,
@@ -303,12 +202,6 @@ __global__ __launch_bounds__(256) void k_run_dirs(const RunEnt<P> *__restrict__ 
         }
         dir[i] = static_cast<uint32_t>(lo);
     }
-}
-// out[j] = key of entry j * step (one sampled level of a depth's index: rbg_dev.h DevTree)
-template <typename P>
-__global__ __launch_bounds__(256) void k_sample_keys(const RunEnt<P> *__restrict__ ent, const uint64_t step, const uint64_t count, P *__restrict__ out) {
-    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
-    for (uint64_t j = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < count; j += stride) out[j] = ent[j * step].start;
 }
 // 8-byte samples -> the 6-byte form of the run-indexed layout (rbg_dev.h Samp48)
 __global__ __launch_bounds__(256) void k_pack_samp48(const uint64_t *__restrict__ in, const uint64_t n, uint16_t *__restrict__ out) {
@@ -576,50 +469,10 @@ int launch_run_dirs(uint32_t pos_bytes, const void *ent, const uint64_t *first, 
         hipLaunchKernelGGL((k_run_dirs<uint64_t>), dim3(grid), dim3(256), 0, st, static_cast<const RunEnt<uint64_t> *>(ent), first, nruns, doff, dshift, T, total, dir);
     return static_cast<int>(hipGetLastError());
 }
-int launch_sample_keys(uint32_t pos_bytes, const void *ent, uint64_t step, uint64_t count, void *out, void *stream) {
-    if (!count) return 0;
-    const int grid = static_cast<int>(std::min<uint64_t>((count + 255) / 256, 256ull * 64));
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    if (pos_bytes == 4)
-        hipLaunchKernelGGL((k_sample_keys<uint32_t>), dim3(grid), dim3(256), 0, st, static_cast<const RunEnt<uint32_t> *>(ent), step, count, static_cast<uint32_t *>(out));
-    else
-        hipLaunchKernelGGL((k_sample_keys<uint64_t>), dim3(grid), dim3(256), 0, st, static_cast<const RunEnt<uint64_t> *>(ent), step, count, static_cast<uint64_t *>(out));
-    return static_cast<int>(hipGetLastError());
-}
 int launch_pack_samp48(const uint64_t *in, uint64_t n, void *out, void *stream) {
     if (!n) return 0;
     const int grid = static_cast<int>(std::min<uint64_t>((n + 255) / 256, 256ull * 64));
     hipLaunchKernelGGL(k_pack_samp48, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), in, n, static_cast<uint16_t *>(out));
-    return static_cast<int>(hipGetLastError());
-}
-
-int launch_build_rank_slots64(uint32_t pos_bytes, const void *ent, const void *samp, uint64_t nruns, uint64_t n, uint32_t shift, void *slots,
-                              unsigned long long *overflow, unsigned long long *dense_cursor, void *stream) {
-    const uint32_t bshift = shift + kSlot64Extra;
-    const uint64_t nb = (n >> bshift) + 2;
-    const uint64_t groups = (nb + kBuildGroup - 1) / kBuildGroup;
-    const int grid = static_cast<int>(std::min<uint64_t>((groups + 255) / 256, 256ull * 64));
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    if (pos_bytes == 4)
-        hipLaunchKernelGGL((k_build_rank_slots64<uint32_t>), dim3(grid), dim3(256), 0, st, static_cast<const RunEnt<uint32_t> *>(ent),
-                           static_cast<const uint32_t *>(samp), nruns, n, bshift, static_cast<RankSlot64 *>(slots), overflow, dense_cursor);
-    else
-        hipLaunchKernelGGL((k_build_rank_slots64<uint64_t>), dim3(grid), dim3(256), 0, st, static_cast<const RunEnt<uint64_t> *>(ent),
-                           static_cast<const uint64_t *>(samp), nruns, n, bshift, static_cast<RankSlot64 *>(slots), overflow, dense_cursor);
-    return static_cast<int>(hipGetLastError());
-}
-
-int launch_fill_dense64(uint32_t pos_bytes, const void *ent, uint64_t n, uint32_t shift, const void *slots, uint8_t *dense, void *stream) {
-    const uint32_t bshift = shift + kSlot64Extra;
-    const uint64_t nb = (n >> bshift) + 2;
-    const int grid = static_cast<int>(std::min<uint64_t>((nb + 255) / 256, 256ull * 64));
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    if (pos_bytes == 4)
-        hipLaunchKernelGGL((k_fill_dense64<uint32_t>), dim3(grid), dim3(256), 0, st, static_cast<const RunEnt<uint32_t> *>(ent), n, bshift,
-                           static_cast<const RankSlot64 *>(slots), dense);
-    else
-        hipLaunchKernelGGL((k_fill_dense64<uint64_t>), dim3(grid), dim3(256), 0, st, static_cast<const RunEnt<uint64_t> *>(ent), n, bshift,
-                           static_cast<const RankSlot64 *>(slots), dense);
     return static_cast<int>(hipGetLastError());
 }
 

@@ -70,9 +70,7 @@ __global__ __launch_bounds__(256) void k_markers_fill(const DevIndex ix, const u
 // (:320,:333), so query q's markers land at  total - (c_0 + ... + c_q).
 // FILL=false: count pass (writes lo/hi and per-read totals to cnt_out[i+1]);
 // FILL=true : re-walks the read and writes the markers at mk_off[i].
-// S64: the index holds 64-byte slots (rbg_dev.h RankSlot64), read lane by lane here; the instantiations without it carry
-// none of that code (it cost the seeding kernels 50 registers and 700 bytes of scratch per lane when it was always there)
-template <typename P, bool FILL, bool S64 = false>
+template <typename P, bool FILL>
 __global__ __launch_bounds__(256) void k_find_range_markers(const DevIndex ix, const uint8_t *__restrict__ seqs,
                                                             const uint64_t *__restrict__ off, const uint64_t N,
                                                             const uint64_t wsize, const uint64_t max_range,
@@ -114,7 +112,7 @@ __global__ __launch_bounds__(256) void k_find_range_markers(const DevIndex ix, c
                     const DevSym S = slot < static_cast<uint32_t>(kLdsSyms) ? s_sym[slot] : ix.syms[slot];
                     RankAux q;
                     uint64_t c_before, c_upto, bh;
-                    rank_pair<P, S64>(S, ix.dense, lo, hi + 1, &c_before, &c_upto, &bh, &q);
+                    rank_pair<P>(S, ix.dense, lo, hi + 1, &c_before, &c_upto, &bh, &q);
                     const uint64_t c_inside = c_upto - c_before;
                     if (c_inside == 0) { alive = false; break; }
                     lo = S.F + c_before;
@@ -153,12 +151,12 @@ __global__ __launch_bounds__(256) void k_find_range_markers(const DevIndex ix, c
 // first seed of strictly greatest length.  Seeds are maximal exact matches found right to left;
 // the base that ends a seed is skipped.  A k-mer gather is attempted first; when it comes back
 // empty the symbol that actually ends the seed is found with single reference steps.
-template <typename P, bool S64 = false>
+template <typename P>
 __device__ __forceinline__ bool lf_w_loc(const DevSym &S, const uint8_t *__restrict__ dense, uint32_t adv, uint64_t &lo, uint64_t &hi,
                                          uint64_t &k) {
     RankAux q;
     uint64_t c_before, c_upto, bh;
-    rank_pair<P, S64>(S, dense, lo, hi + 1, &c_before, &c_upto, &bh, &q);
+    rank_pair<P>(S, dense, lo, hi + 1, &c_before, &c_upto, &bh, &q);
     const uint64_t c_inside = c_upto - c_before;
     if (c_inside == 0) return false;
     if (q.inside) k = k - adv;
@@ -168,7 +166,7 @@ __device__ __forceinline__ bool lf_w_loc(const DevSym &S, const uint8_t *__restr
     return true;
 }
 
-template <typename P, bool S64 = false>
+template <typename P>
 __global__ __launch_bounds__(1024) void k_greedy_seed(const DevIndex ix, const uint8_t *__restrict__ seqs,
                                                      const uint64_t *__restrict__ off, const uint64_t N,
                                                      const uint64_t min_length, uint64_t *__restrict__ lo_out,
@@ -195,8 +193,8 @@ __global__ __launch_bounds__(1024) void k_greedy_seed(const DevIndex ix, const u
         auto lf1 = [&](uint32_t c) -> bool {  // one reference step (rowbowt.hpp:235); an absent symbol is an empty range (:76)
             const uint32_t slot = s_lut[c];
             if (slot == 0xFFu) return false;
-            if (slot < static_cast<uint32_t>(kLdsSyms)) { const DevSym S = s_tab[slot]; return lf_w_loc<P, S64>(S, ix.dense, 1u, lo, hi, k); }
-            return lf_w_loc<P, S64>(ix.syms[slot], ix.dense, 1u, lo, hi, k);
+            if (slot < static_cast<uint32_t>(kLdsSyms)) { const DevSym S = s_tab[slot]; return lf_w_loc<P>(S, ix.dense, 1u, lo, hi, k); }
+            return lf_w_loc<P>(ix.syms[slot], ix.dense, 1u, lo, hi, k);
         };
         // the longest k-mer (2..min(cap, kmer_steps) symbols, all with k-mer tables) ending at byte p; success
         // is identical to *len nested LF_w_loc calls
@@ -227,7 +225,7 @@ __global__ __launch_bounds__(1024) void k_greedy_seed(const DevIndex ix, const u
             }
             *len = adv;
             const DevSym S = s_tab[idx];
-            return lf_w_loc<P, S64>(S, ix.dense, adv, lo, hi, k);
+            return lf_w_loc<P>(S, ix.dense, adv, lo, hi, k);
         };
         auto on_ok = [&](uint32_t adv) {
             j -= adv;
@@ -300,7 +298,7 @@ __global__ __launch_bounds__(1024) void k_greedy_seed(const DevIndex ix, const u
 // two more gathers so the failing base is the reference's.
 // LOG (count pass only): also leave the marker-seed log behind (rbg_dev.h SeedLog) so that the fill pass copies instead of
 // walking again; FILL with lg.base set: walk only the sequences the log lists as over quota.
-template <typename P, bool FILL, bool LOG = false, bool S64 = false>
+template <typename P, bool FILL, bool LOG = false>
 __global__ __launch_bounds__(1024) void k_marker_seeds(const DevIndex ix, const uint8_t *__restrict__ seqs,
                                                       const uint64_t *__restrict__ off, const uint64_t N,
                                                       const uint64_t wsize, const uint64_t max_range, const uint64_t ftab_k,
@@ -385,7 +383,7 @@ __global__ __launch_bounds__(1024) void k_marker_seeds(const DevIndex ix, const 
             const DevSym S = slot < static_cast<uint32_t>(kLdsSyms) ? s_tab[slot] : ix.syms[slot];
             RankAux q;
             uint64_t c_before, c_upto, bh;
-            rank_pair<P, S64>(S, ix.dense, lo, hi + 1, &c_before, &c_upto, &bh, &q);
+            rank_pair<P>(S, ix.dense, lo, hi + 1, &c_before, &c_upto, &bh, &q);
             if (c_upto <= c_before) return false;
             lo = S.F + c_before;
             hi = lo + (c_upto - c_before) - 1;
@@ -422,7 +420,7 @@ __global__ __launch_bounds__(1024) void k_marker_seeds(const DevIndex ix, const 
             const DevSym S = s_tab[idx];
             RankAux q;
             uint64_t c_before, c_upto, bh;
-            rank_pair<P, S64>(S, ix.dense, lo, hi + 1, &c_before, &c_upto, &bh, &q);
+            rank_pair<P>(S, ix.dense, lo, hi + 1, &c_before, &c_upto, &bh, &q);
             if (c_upto <= c_before) return false;
             lo = S.F + c_before;
             hi = lo + (c_upto - c_before) - 1;
@@ -594,7 +592,7 @@ __global__ __launch_bounds__(256) void k_marker_seeds_from_log(const DevIndex ix
 }
 
 // ---- single LF step for N (range, symbol) triples: RowBowt::LF(range_t, uint8_t), rowbowt.hpp:74-88
-template <typename P, bool S64 = false>
+template <typename P>
 __global__ __launch_bounds__(256) void k_lf(const DevIndex ix, const uint64_t *__restrict__ lo_in,
                                             const uint64_t *__restrict__ hi_in, const uint8_t *__restrict__ sym,
                                             const uint64_t N, uint64_t *__restrict__ lo_out, uint64_t *__restrict__ hi_out) {
@@ -608,7 +606,7 @@ __global__ __launch_bounds__(256) void k_lf(const DevIndex ix, const uint64_t *_
             const DevSym S = ix.syms[slot];
             RankAux q;
             uint64_t c_before, c_upto, bh;
-            rank_pair<P, S64>(S, ix.dense, lo, hi + 1, &c_before, &c_upto, &bh, &q);
+            rank_pair<P>(S, ix.dense, lo, hi + 1, &c_before, &c_upto, &bh, &q);
             if (c_upto > c_before) { nlo = S.F + c_before; nhi = nlo + (c_upto - c_before) - 1; }
         }
         lo_out[i] = nlo;
@@ -654,11 +652,9 @@ int launch_find_range_markers_plan(const DevIndex &ix, const LaunchCfg &cfg, con
     }
     const dim3 grid(grid_for(cfg, N)), block(cfg.block_threads);
     if (ix.pos_bytes == 4)
-        if (ix.slot_bytes == 64) hipLaunchKernelGGL((k_find_range_markers<uint32_t, false, true>), grid, block, 0, st, ix, seqs, off, N, wsize, max_range, lo, hi, mk_off, nullptr, nullptr);
-        else hipLaunchKernelGGL((k_find_range_markers<uint32_t, false>), grid, block, 0, st, ix, seqs, off, N, wsize, max_range, lo, hi, mk_off, nullptr, nullptr);
+        hipLaunchKernelGGL((k_find_range_markers<uint32_t, false>), grid, block, 0, st, ix, seqs, off, N, wsize, max_range, lo, hi, mk_off, nullptr, nullptr);
     else
-        if (ix.slot_bytes == 64) hipLaunchKernelGGL((k_find_range_markers<uint64_t, false, true>), grid, block, 0, st, ix, seqs, off, N, wsize, max_range, lo, hi, mk_off, nullptr, nullptr);
-        else hipLaunchKernelGGL((k_find_range_markers<uint64_t, false>), grid, block, 0, st, ix, seqs, off, N, wsize, max_range, lo, hi, mk_off, nullptr, nullptr);
+        hipLaunchKernelGGL((k_find_range_markers<uint64_t, false>), grid, block, 0, st, ix, seqs, off, N, wsize, max_range, lo, hi, mk_off, nullptr, nullptr);
     int rc = static_cast<int>(hipGetLastError());
     if (rc) return rc;
     return scan_in_place(mk_off + 1, N, tmp, tmp_bytes, st);
@@ -672,11 +668,9 @@ int launch_find_range_markers_fill(const DevIndex &ix, const LaunchCfg &cfg, con
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid(grid_for(cfg, N)), block(cfg.block_threads);
     if (ix.pos_bytes == 4)
-        if (ix.slot_bytes == 64) hipLaunchKernelGGL((k_find_range_markers<uint32_t, true, true>), grid, block, 0, st, ix, seqs, off, N, wsize, max_range, nullptr, nullptr, nullptr, mk_off, mk);
-        else hipLaunchKernelGGL((k_find_range_markers<uint32_t, true>), grid, block, 0, st, ix, seqs, off, N, wsize, max_range, nullptr, nullptr, nullptr, mk_off, mk);
+        hipLaunchKernelGGL((k_find_range_markers<uint32_t, true>), grid, block, 0, st, ix, seqs, off, N, wsize, max_range, nullptr, nullptr, nullptr, mk_off, mk);
     else
-        if (ix.slot_bytes == 64) hipLaunchKernelGGL((k_find_range_markers<uint64_t, true, true>), grid, block, 0, st, ix, seqs, off, N, wsize, max_range, nullptr, nullptr, nullptr, mk_off, mk);
-        else hipLaunchKernelGGL((k_find_range_markers<uint64_t, true>), grid, block, 0, st, ix, seqs, off, N, wsize, max_range, nullptr, nullptr, nullptr, mk_off, mk);
+        hipLaunchKernelGGL((k_find_range_markers<uint64_t, true>), grid, block, 0, st, ix, seqs, off, N, wsize, max_range, nullptr, nullptr, nullptr, mk_off, mk);
     return static_cast<int>(hipGetLastError());
 }
 
@@ -686,21 +680,19 @@ int launch_marker_seeds_plan(const DevIndex &ix, const LaunchCfg &cfg, const uin
     hipStream_t st = static_cast<hipStream_t>(stream);
     const SeedLog lg = make_seed_log(log, log_bytes, N, ix.pos_bytes);   // base == nullptr: no log (two walks)
     int rc;
-    if (ix.layout == 2 && (ftab_k == 0 || ix.run_fmt == 2)) {   // run-indexed layout: k_runs_seeds.hip (format 1 with an ftab: the per-lane search below)
+    if (ix.layout == 2) {   // run-indexed layout: k_runs_seeds.hip
         rc = launch_marker_seeds_runs(ix, cfg, seqs, off, N, wsize, max_range, seed_off, mk_off, nullptr, nullptr, nullptr, nullptr, false, stream, lg, ftab_k);
     } else {
-#define RBG_MSP1(PT, LG, SB)                                                                                                              \
+#define RBG_MSP(PT, LG)                                                                                                                  \
     do {                                                                                                                                  \
-        auto kern = k_marker_seeds<PT, false, LG, SB>;                                                                                    \
+        auto kern = k_marker_seeds<PT, false, LG>;                                                                                        \
         const KmerLaunch L = kmer_launch(ix, cfg, N, kern, 0, kSeedKmerLevel);                                                            \
         hipLaunchKernelGGL(kern, L.grid, L.block, L.lds, st, ix, seqs, off, N, wsize, max_range, ftab_k, seed_off, mk_off, nullptr, nullptr, nullptr, \
                            nullptr, kSeedKmerLevel, lg);                                                                                  \
     } while (0)
-#define RBG_MSP(PT, LG) do { if (ix.slot_bytes == 64) RBG_MSP1(PT, LG, true); else RBG_MSP1(PT, LG, false); } while (0)
         if (ix.pos_bytes == 4) { if (lg.base) RBG_MSP(uint32_t, true); else RBG_MSP(uint32_t, false); }
         else { if (lg.base) RBG_MSP(uint64_t, true); else RBG_MSP(uint64_t, false); }
 #undef RBG_MSP
-#undef RBG_MSP1
         rc = static_cast<int>(hipGetLastError());
     }
     if (rc) return rc;
@@ -727,19 +719,17 @@ int launch_marker_seeds_fill(const DevIndex &ix, const LaunchCfg &cfg, const uin
         rc = static_cast<int>(hipGetLastError());
         if (rc) return rc;
     }
-    if (ix.layout == 2 && (ftab_k == 0 || ix.run_fmt == 2))
+    if (ix.layout == 2)
         return launch_marker_seeds_runs(ix, cfg, seqs, off, N, wsize, max_range, nullptr, nullptr, seed_off, mk_off, seeds, mk, true, stream, lg, ftab_k);
-#define RBG_MSF1(PT, SB)                                                                                                                  \
+#define RBG_MSF(PT)                                                                                                                       \
     do {                                                                                                                                  \
-        auto kern = k_marker_seeds<PT, true, false, SB>;                                                                                  \
+        auto kern = k_marker_seeds<PT, true, false>;                                                                                      \
         const KmerLaunch L = kmer_launch(ix, cfg, N, kern, lg.base ? 256 : 0, kSeedKmerLevel);                                            \
         hipLaunchKernelGGL(kern, L.grid, L.block, L.lds, st, ix, seqs, off, N, wsize, max_range, ftab_k, nullptr, nullptr, seed_off, mk_off, seeds, mk, \
                            kSeedKmerLevel, lg);                                                                                           \
     } while (0)
-#define RBG_MSF(PT) do { if (ix.slot_bytes == 64) RBG_MSF1(PT, true); else RBG_MSF1(PT, false); } while (0)
     if (ix.pos_bytes == 4) RBG_MSF(uint32_t); else RBG_MSF(uint64_t);
 #undef RBG_MSF
-#undef RBG_MSF1
     return static_cast<int>(hipGetLastError());
 }
 
@@ -748,14 +738,13 @@ int launch_greedy_seed(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *
     if (N == 0) return 0;
     if (ix.layout == 2) return launch_greedy_seed_runs(ix, cfg, seqs, off, N, min_length, lo, hi, qs, qe, ss, stream);
     hipStream_t st = static_cast<hipStream_t>(stream);
-#define RBG_GS(PT, SB)                                                                                                    \
+#define RBG_GS(PT)                                                                                                        \
     do {                                                                                                                  \
-        auto kern = k_greedy_seed<PT, SB>;                                                                                \
+        auto kern = k_greedy_seed<PT>;                                                                                    \
         const KmerLaunch L = kmer_launch(ix, cfg, N, kern, 0, kSeedKmerLevel);                                            \
         hipLaunchKernelGGL(kern, L.grid, L.block, L.lds, st, ix, seqs, off, N, min_length, lo, hi, qs, qe, ss, kSeedKmerLevel); \
     } while (0)
-    if (ix.pos_bytes == 4) { if (ix.slot_bytes == 64) RBG_GS(uint32_t, true); else RBG_GS(uint32_t, false); }
-    else { if (ix.slot_bytes == 64) RBG_GS(uint64_t, true); else RBG_GS(uint64_t, false); }
+    if (ix.pos_bytes == 4) RBG_GS(uint32_t); else RBG_GS(uint64_t);
 #undef RBG_GS
     return static_cast<int>(hipGetLastError());
 }
@@ -766,13 +755,8 @@ int launch_lf(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t *lo, cons
     if (ix.layout == 2) return launch_lf_runs(ix, cfg, lo, hi, sym, N, lo_out, hi_out, stream);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid(grid_for(cfg, N)), block(cfg.block_threads);
-    if (ix.pos_bytes == 4) {
-        if (ix.slot_bytes == 64) hipLaunchKernelGGL((k_lf<uint32_t, true>), grid, block, 0, st, ix, lo, hi, sym, N, lo_out, hi_out);
-        else hipLaunchKernelGGL((k_lf<uint32_t>), grid, block, 0, st, ix, lo, hi, sym, N, lo_out, hi_out);
-    } else {
-        if (ix.slot_bytes == 64) hipLaunchKernelGGL((k_lf<uint64_t, true>), grid, block, 0, st, ix, lo, hi, sym, N, lo_out, hi_out);
-        else hipLaunchKernelGGL((k_lf<uint64_t>), grid, block, 0, st, ix, lo, hi, sym, N, lo_out, hi_out);
-    }
+    if (ix.pos_bytes == 4) hipLaunchKernelGGL((k_lf<uint32_t>), grid, block, 0, st, ix, lo, hi, sym, N, lo_out, hi_out);
+    else hipLaunchKernelGGL((k_lf<uint64_t>), grid, block, 0, st, ix, lo, hi, sym, N, lo_out, hi_out);
     return static_cast<int>(hipGetLastError());
 }
 

@@ -1,17 +1,8 @@
-// k_runs.hip -- the run-indexed layout (RBG_LAYOUT_RUNS, rbg_dev.h DevTree): K1/K2 and K3 with space proportional
-// to r.  rank and phi are predecessor searches over sorted run boundaries, as in the reference
-// (rle_string::rank rle_string.hpp:131-161, ToeholdSA::phi toehold_sa.hpp:56-72), done the way the hardware
-// likes them: the coarsest level of the 16-ary sampled index sits in LDS (per-lane binary search), every level
-// below it is probed by the WAVE -- each 16-lane row loads the 16-entry block of one of its lanes' queries with one
-// coalesced request (64 B of keys, 128 B of {key, value} pairs at 4-byte positions), compares, ballots and counts;
-// four queries per load instruction, all sixteen rounds of a level in flight together.  One lane still owns one
-// read (K1/K2) or one phi chain (K3); lanes whose own work is finished keep serving the others' probes.
-// With the directories (the default) a rank is one directory gather and ONE probe of the run list from the entry
-// the directory names; those probes are made by QUADS (four lanes per owner, four entries per lane, everything
-// cross-lane by DPP quad permutes), and the lane that holds the run computes the rank or phi's value itself: the
-// first version of these kernels (16-lane rows, every value by ds_bpermute) was bound by the LDS pipe, not by
-// memory (profiles/).  The 16-lane rows remain for the narrowing of crowded buckets, the descent of an
-// index built without directories, the unordered phi walk and the optional bucket records.
+// k_runs.hip -- the run-indexed layout (RBG_LAYOUT_RUNS): K1/K2 and K3 with space proportional to r.  rank and phi are
+// predecessor searches over sorted run boundaries, as in the reference (rle_string::rank rle_string.hpp:131-161,
+// ToeholdSA::phi toehold_sa.hpp:56-72): a directory (or a bucket record) has already cut the search down to the handful
+// of entries of one bucket, and the lane that owns the query fetches and scans exactly those (rbg_runs2_device.hpp).  One
+// lane owns one read (K1/K2) or one phi chain (K3); bucket records are fetched by quads of lanes.
 #include "rbg_runs2_device.hpp"
 
 namespace rbg {
@@ -48,9 +39,8 @@ struct PackedBits {   // per-lane reader of a packed read: peek / drop of up to 
     }
 };
 
-// V2: format 2 (rbg_runs2_device.hpp): every lane answers its own two ranks; the same steps in the same order
-template <typename P, bool TOEHOLD, bool PACKED = false, bool STATS = false, bool V2 = false>
-__global__ __launch_bounds__(512, STATS ? 2 : (V2 || sizeof(P) == 4) ? 4 : 3) void k_find_range_runs(const DevIndex ix, const void *__restrict__ src_a,
+template <typename P, bool TOEHOLD, bool PACKED = false, bool STATS = false>
+__global__ __launch_bounds__(512, STATS ? 2 : 4) void k_find_range_runs(const DevIndex ix, const void *__restrict__ src_a,
                                                         const void *__restrict__ src_b, const uint64_t N,
                                                         uint64_t *__restrict__ lo_out, uint64_t *__restrict__ hi_out,
                                                         uint64_t *__restrict__ ss_out, unsigned long long *__restrict__ stats,
@@ -69,20 +59,9 @@ __global__ __launch_bounds__(512, STATS ? 2 : (V2 || sizeof(P) == 4) ? 4 : 3) vo
         s_lut[t] = ix.lut[t];
         s_lut2[t] = ix.nmajor ? ix.lut2[t] : 0xFFu;
     }
-    RunSearch<P> S{};
-    RunSearch2<P> S2{};
-    const uint32_t *tab_first = nullptr;
-    const RunRec *const *rec_tabs = nullptr;
-    if constexpr (V2) {
-        RBG_RUN_SEARCH2_SHARED;
-        S2 = stage_run_search2<P>(ix, s_tab_first, s_ent2, s_dir2, s_rec2, s_dyn);
-        tab_first = s_tab_first;
-    } else {
-        RBG_RUN_SEARCH_SHARED(P, 8);   // 512-thread workgroups
-        S = stage_run_search<P, 8>(ix, s_tree, s_tab_first, s_rec, s_req, s_dyn);
-        tab_first = s_tab_first;
-        rec_tabs = s_rec;
-    }
+    RBG_RUN_SEARCH2_SHARED;
+    const RunSearch2<P> S2 = stage_run_search2<P>(ix, s_tab_first, s_ent2, s_dir2, s_rec2, s_dyn);
+    const uint32_t *tab_first = s_tab_first;
     if (PACKED) {
         for (int t = threadIdx.x; t < 256; t += blockDim.x)
             if (s_lut2[t] != 0xFFu) s_mslot[s_lut2[t] & 3u] = s_lut[t];   // major index -> symbol slot
@@ -115,7 +94,7 @@ __global__ __launch_bounds__(512, STATS ? 2 : (V2 || sizeof(P) == 4) ? 4 : 3) vo
         uint64_t k = TOEHOLD ? ix.last_run_sample : 0;
         bool alive = valid;
         bool pend = false;                                     // deferred toehold re-sample (k_search.hip): the last one is the only one used
-        uint32_t pend_d = 0, pend_run = 0, pend_c = 0;
+        uint32_t pend_d = 0;
         uint64_t pend_e = 0;
         ByteCursor rd{reinterpret_cast<const uint4 *>(seqs), ~uint64_t(0), make_uint4(0, 0, 0, 0)};
         if (valid && ix.ftab_k && p - beg >= ix.ftab_k) {      // rowbowt.hpp:124-125, :745-758 (k_search.hip)
@@ -192,8 +171,7 @@ __global__ __launch_bounds__(512, STATS ? 2 : (V2 || sizeof(P) == 4) ? 4 : 3) vo
             }
             RunStep r;
             // rank(lo, c), rank(hi + 1, c): rowbowt.hpp:79,83
-            if constexpr (V2) lane_lf2_quad<P, STATS>(S2, stepping, d, rec, lo, hi + 1, r, st);   // (every lane of the wave: the records are fetched by quads)
-            else coop_lf2<P, STATS>(ix, S, stepping, d, rec, lo, hi + 1, r, st);
+            lane_lf2_quad<P, STATS>(S2, stepping, d, rec, lo, hi + 1, r, st);   // (every lane of the wave: the records are fetched by quads)
             if (stepping) {
                 if (STATS) st[kStSymbols] += adv;
                 const uint64_t c_inside = r.c_upto - r.c_before;
@@ -202,7 +180,7 @@ __global__ __launch_bounds__(512, STATS ? 2 : (V2 || sizeof(P) == 4) ? 4 : 3) vo
                 } else {
                     if (TOEHOLD) {                              // LF_w_loc, rowbowt.hpp:559-566, `adv` times nested
                         if (r.inside) k = k - adv;
-                        else { pend = true; pend_d = d; pend_run = r.samp_run; pend_c = r.samp_c; pend_e = r.samp_e; k = 0; }
+                        else { pend = true; pend_d = d; pend_e = r.samp_e; k = 0; }
                     }
                     lo = r.F + r.c_before;                      // rowbowt.hpp:86
                     hi = lo + c_inside - 1;                     // rowbowt.hpp:87
@@ -211,13 +189,7 @@ __global__ __launch_bounds__(512, STATS ? 2 : (V2 || sizeof(P) == 4) ? 4 : 3) vo
             }
         }
         if (TOEHOLD && alive && pend) {
-            if constexpr (V2) {
-                k += run_step_sample2<P>(ix, pend_d, pend_e);
-            } else {
-                RunStep ps;
-                ps.samp_run = pend_run; ps.samp_c = pend_c;
-                k += run_step_sample<P>(ix, rec_tabs, pend_d, ps);
-            }
+            k += run_step_sample2<P>(ix, pend_d, pend_e);
             if (STATS) st[kStResample] += 1;
         }
         if (STATS && !PACKED && p_end > p_min) st[kStChunks] += ((p_end - 1) >> 4) - (p_min >> 4) + 1;
@@ -248,177 +220,11 @@ __global__ __launch_bounds__(512, STATS ? 2 : (V2 || sizeof(P) == 4) ? 4 : 3) vo
     }
 }
 
-// ---- K3 over the run-indexed layout -------------------------------------------------------------------------------
-// ToeholdSA::locate_range (toehold_sa.hpp:37-49): the phi chains as in k_locate_fill (LDS-staged values, chains in
-// toehold order), phi itself (toehold_sa.hpp:56-72) as a cooperative predecessor search over the sampled positions.
 template <typename P> struct ChunkR { static constexpr int v = sizeof(P) == 8 ? 8 : 16; };   // as in k_locate.hip
 
-// ORDERED: the chains come in toehold order (launch_locate_order): neighbouring lanes probe neighbouring entries
-// OUT: width a location is stored at (k_locate.hip); STATS: the instrumented instantiation -- [kLsPhiSteps] phi
-// evaluations (each: one 8-byte directory gather + one probe), [kLsPhiOvf] sampled positions those probes and the
-// narrowing rounds needed (2P bytes each), [kLsChains], [kLsLocs]
-template <typename P, bool ORDERED, typename OUT = uint64_t, bool STATS = false>
-__global__ __launch_bounds__(256, sizeof(P) == 4 ? 4 : 3) void k_locate_fill_runs(const DevIndex ix, const uint64_t *__restrict__ lo,
-                                                          const uint64_t *__restrict__ hi, const uint64_t *__restrict__ k,
-                                                          const uint64_t N, const uint64_t max_hits,
-                                                          const uint64_t *__restrict__ loc_off, OUT *__restrict__ locs,
-                                                          const uint64_t *__restrict__ sub, const uint32_t *__restrict__ order,
-                                                          const uint64_t *__restrict__ skeys, unsigned long long *__restrict__ stats) {
-    constexpr int kChunkR = ChunkR<P>::v;
-    __shared__ P s_val[4][kWave][kChunkR + 1];
-    __shared__ uint64_t s_dst[4][kWave];
-    __shared__ uint64_t s_occ[4][kWave];
-    __shared__ uint64_t s_minus[4][kWave];
-    __shared__ uint64_t s_first[4][kWave];
-    __shared__ DevTree s_tree[1];
-    __shared__ uint4 s_req[4][kWave * ReqSlots<P>::v];   // request slots, per wave (256-thread workgroups)
-    uint4 *req = s_req[threadIdx.x >> 6];
-    extern __shared__ __align__(16) unsigned char s_dyn[];
-    P *s_top = reinterpret_cast<P *>(s_dyn);
-    if (threadIdx.x == 0) s_tree[0] = ix.phi_tree;
-    for (uint32_t t = threadIdx.x; t < ix.phi_tree.top_n; t += blockDim.x) s_top[t] = static_cast<const P *>(ix.phi_top)[t];
-    __syncthreads();
-    const int nlvl = static_cast<int>(ix.phi_nlvl);
-    const uint32_t phi_hi = static_cast<uint32_t>(ix.r);
-    const uint32_t *__restrict__ pdir = ix.phi_dir;
-    const uint32_t pdir_shift = ix.phi_dir_shift;
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
-    const void *__restrict__ pent = ix.phi_ent;   // {sampled position, base} (rbg_dev.h PhiFmt)
-    unsigned long long c_locs = 0;
-    unsigned long long st_phi = 0, st_ent = 0, st_chains = 0;   // STATS only
-    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
-    for (uint64_t base = static_cast<uint64_t>(blockIdx.x) * blockDim.x + wv * kWave; base < N; base += stride) {
-        const uint64_t j = base + lane;
-        uint64_t i = j;
-        if (order && j < N) i = order[j];
-        uint64_t occ = 0, k1 = 0, dst = 0;
-        if (i < N && j < N) {
-            dst = loc_off[i];
-            if (skeys) {
-                k1 = skeys[j];
-                occ = loc_off[i + 1] - dst;
-            } else {
-                const uint64_t l = lo[i], h = hi[i];
-                occ = h >= l ? h - l + 1 : 0;                  // toehold_sa.hpp:38-39
-                if (occ > max_hits) occ = max_hits;
-                k1 = k[i];
-            }
-        }
-        const uint64_t minus = (sub && i < N && j < N) ? sub[i] : 0;
-        s_dst[wv][lane] = dst;
-        s_occ[wv][lane] = occ;
-        s_minus[wv][lane] = minus;
-        s_first[wv][lane] = k1;
-        c_locs += occ;
-        if (STATS && occ) st_chains += 1;
-        uint64_t wmax = occ;
-#pragma unroll
-        for (int o = kWave / 2; o > 0; o >>= 1) {
-            const uint64_t other = __shfl_xor(wmax, o, kWave);
-            wmax = other > wmax ? other : wmax;
-        }
-        for (uint64_t t0 = 0; t0 < wmax; t0 += kChunkR) {
-#pragma unroll 1
-            for (int e = 0; e < kChunkR; ++e) {
-                const uint64_t t = t0 + e;
-                const bool need = t < occ && t > 0;            // toehold_sa.hpp:44: k = phi(k)
-                const bool wrapped = need && k1 >= ix.n;        // a toehold below zero (k_locate.hip phi_step): outside phi's domain
-                const bool coop = need && !wrapped;
-                uint32_t tq = 0, unused_t = 0;
-                P pk = 0, pv = 0, nv = 0, u1 = 0, u2 = 0, u3 = 0, pval = 0;
-                bool by_dir = false;   // pval = prev_sample + delta already (the row computed it)
-                // the directory: # sampled positions below the bucket of k1 and below the next one; when the bucket (and
-                // the predecessor before it) fit one block, ONE row probe from there answers the query
-                bool descend = coop;
-                if (pdir) {
-                    uint32_t g0 = 0, g1 = 0;
-                    if (coop) {
-                        const uint64_t b = k1 >> pdir_shift;
-                        g0 = pdir[b];
-                        g1 = pdir[b + 1];
-                    }
-                    uint32_t start = g0 ? g0 - 1 : 0, z = g1 - start;
-                    if (STATS && coop) {   // (counted before the narrowing changes z: 16 pivots per round, then the candidates + 1)
-                        st_phi += 1;
-                        uint32_t zz = z;
-                        while (zz > static_cast<uint32_t>(kFan)) { st_ent += kFan; zz = (zz + kFan - 1) / kFan; }
-                        st_ent += zz + 1 > static_cast<uint32_t>(kFan) ? kFan : zz + 1;
-                    }
-                    // a crowded bucket is narrowed by pivot probes first (coop_narrow), as the ranks' are
-                    if (ORDERED) {
-                        while (__ballot(coop && z > static_cast<uint32_t>(kFan))) coop_narrow4<P, PhiList<P>>(s_tree, 0u, coop && z > static_cast<uint32_t>(kFan), start, z, static_cast<P>(k1));
-                        coop_probe_phi4<P>(s_tree[0], coop, start, static_cast<P>(k1), tq, pval);
-                        by_dir = coop;
-                    } else {
-                        while (__ballot(coop && z > static_cast<uint32_t>(kFan))) coop_narrow4<P, PhiList<P>>(s_tree, 0u, coop && z > static_cast<uint32_t>(kFan), start, z, static_cast<P>(k1));
-                        coop_probe_phi<P>(s_tree[0], req, coop, start, z, static_cast<P>(k1), tq, pval);
-                        by_dir = coop;
-                    }
-                    descend = false;
-                }
-                // the descent (one slice: all r sampled positions; entry r is the sentinel)
-                if (__ballot(descend)) {
-                    uint32_t td = 0;
-                    P dk = 0, dv = 0;
-                    if (descend) td = top_count<P>(s_top, 0, s_tree[0].top_n, k1);
-                    for (int l = nlvl - 1; l >= 0; --l) {
-                        const bool lv0 = descend && td > 0;
-                        coop_level<P>(s_tree, l, 0u, 0u, phi_hi, lv0, false, td, unused_t, static_cast<P>(k1), P(0));   // (k1 < n here)
-                    }
-                    {
-                        const bool lv0 = descend && td > 0;
-                        coop_leaf<P, PhiList<P>>(s_tree, 0u, 0u, phi_hi, lv0, false, td, unused_t, static_cast<P>(k1), P(0), dk, dv, nv, u1, u2, u3);
-                    }
-                    if (descend) { tq = td; pk = dk; pv = dv; }
-                }
-                if (need) {
-                    uint64_t s;
-                    if (wrapped) {
-                        const typename PhiList<P>::pair e2 = PhiList<P>::load(pent, ix.r - 1);
-                        s = (static_cast<uint64_t>(e2.y) + (k1 - static_cast<uint64_t>(e2.x))) % ix.n;
-                    } else if (tq == 0) {
-                        // no sampled position before k1: circular predecessor = the last one, delta = i + 1
-                        // (sparse_sd_vector.hpp:141-143, toehold_sa.hpp:59,65)
-                        s = static_cast<uint64_t>(PhiList<P>::val(pent, ix.r - 1)) + k1 + 1;
-                        if (s >= ix.n) s -= ix.n;
-                    } else {
-                        s = by_dir ? static_cast<uint64_t>(pval) : static_cast<uint64_t>(pv) + (k1 - pk);   // prev_sample + delta (toehold_sa.hpp:65-71)
-                        if (s >= ix.n) s -= ix.n;
-                    }
-                    k1 = s;
-                }
-                if (t < occ) s_val[wv][lane][e] = static_cast<P>(k1);
-            }
-            wave_lds_sync();
-#pragma unroll
-            for (int pass = 0; pass < kChunkR; ++pass) {
-                const int s = pass * (kWave / kChunkR) + lane / kChunkR;
-                const int e = lane & (kChunkR - 1);
-                const uint64_t t = t0 + e;
-                if (t < s_occ[wv][s]) locs[s_dst[wv][s] + t] = static_cast<OUT>((t ? static_cast<uint64_t>(s_val[wv][s][e]) : s_first[wv][s]) - s_minus[wv][s]);
-            }
-            wave_lds_sync();
-        }
-        wave_lds_sync();
-    }
-    c_locs = wave_sum(c_locs);
-    if (lane == 0 && c_locs) atomicAdd(&ix.counters[3], c_locs);
-    if (STATS) {
-        st_phi = wave_sum(st_phi);
-        st_ent = wave_sum(st_ent);
-        st_chains = wave_sum(st_chains);
-        if (lane == 0) {
-            if (st_phi) atomicAdd(&stats[kLsPhiSteps], st_phi);
-            if (st_ent) atomicAdd(&stats[kLsPhiOvf], st_ent);
-            if (st_chains) atomicAdd(&stats[kLsChains], st_chains);
-            if (c_locs) atomicAdd(&stats[kLsLocs], c_locs);
-        }
-    }
-}
-
-
-// ---- K3, format 2: every lane walks its own chain and answers its own phi (rbg_runs2_device.hpp lane_phi) -----------------
-// Same chains, same staging of the values in LDS and the same coalesced flush as above; a phi step is one directory
+// ---- K3 over the run-indexed layout: ToeholdSA::locate_range (toehold_sa.hpp:37-49) -- every lane walks its own chain and
+// answers its own phi (toehold_sa.hpp:56-72; rbg_runs2_device.hpp lane_phi).  The chains, the staging of the values in LDS and
+// the coalesced flush are k_locate_fill's (k_locate.hip; chains in toehold order); a phi step is one directory
 // gather (two neighbouring counts, plus the super count at 8-byte positions) and one scan of the bucket's few sampled
 // positions, no cross-lane traffic.  Works for ordered and unordered walks alike (the order only decides how well
 // neighbouring lanes share sectors).  STATS: [kLsPhiSteps] phi evaluations, [kLsPhiOvf] sampled positions the scans
@@ -530,22 +336,17 @@ int launch_find_range_runs_impl(const DevIndex &ix, const LaunchCfg &cfg, const 
                                 const uint32_t *sel = nullptr, const uint32_t *nsel = nullptr) {
     if (N == 0) return 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const bool v2 = ix.run_fmt == 2;
-    const size_t lds = v2 ? run_search2_lds(ix) : run_search_lds(ix);
+    const size_t lds = run_search2_lds(ix);
     LaunchCfg c = cfg;   // 512-thread workgroups: the staged tables and top level are shared by eight waves
     c.block_threads = 512;
     c.max_blocks = cfg.max_blocks > 0 ? std::max(1, cfg.max_blocks / 2) : 256 * 16;
     // sel mode: the number of reads is only known on the device; a fixed modest grid loops over it
     const dim3 grid(sel ? std::min(grid_for(c, N), 256) : grid_for(c, N)), block(512);
-#define RBG_LAUNCH_FRR1(PT, TOE, PK, STS, V)                                                           \
-    do {                                                                                               \
-        auto kern = k_find_range_runs<PT, TOE, PK, STS, V>;                                            \
-        raise_lds(kern, lds);                                                                          \
-        hipLaunchKernelGGL(kern, grid, block, lds, st, ix, src_a, src_b, N, lo, hi, ssamp, stats, sel, nsel);     \
-    } while (0)
 #define RBG_LAUNCH_FRR(PT, TOE, PK, STS)                                                               \
     do {                                                                                               \
-        if (v2) RBG_LAUNCH_FRR1(PT, TOE, PK, STS, true); else RBG_LAUNCH_FRR1(PT, TOE, PK, STS, false); \
+        auto kern = k_find_range_runs<PT, TOE, PK, STS>;                                               \
+        raise_lds(kern, lds);                                                                          \
+        hipLaunchKernelGGL(kern, grid, block, lds, st, ix, src_a, src_b, N, lo, hi, ssamp, stats, sel, nsel);     \
     } while (0)
 #define RBG_LAUNCH_FRR2(PT, TOE)                                                                       \
     do {                                                                                               \
@@ -560,7 +361,6 @@ int launch_find_range_runs_impl(const DevIndex &ix, const LaunchCfg &cfg, const 
     }
 #undef RBG_LAUNCH_FRR2
 #undef RBG_LAUNCH_FRR
-#undef RBG_LAUNCH_FRR1
     return static_cast<int>(hipGetLastError());
 }
 
@@ -586,41 +386,19 @@ int launch_locate_fill_runs(const DevIndex &ix, const LaunchCfg &cfg, const uint
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid(grid_for(cfg, N)), block(256);
     const uint32_t *perm = static_cast<const uint32_t *>(order);
-    if (ix.run_fmt == 2) {   // format 2: one kernel for ordered and unordered walks
 #define RBG_LAUNCH_LFR2(PT, OUT, STS, DST) \
     hipLaunchKernelGGL((k_locate_fill_runs2<PT, OUT, STS>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, DST, sub, perm, skeys, stats)
-        if (locs32) {
-            if (stats || ix.pos_bytes != 4) return static_cast<int>(hipErrorInvalidValue);
-            RBG_LAUNCH_LFR2(uint32_t, uint32_t, false, locs32);
-        } else if (stats) {
-            if (ix.pos_bytes == 4) RBG_LAUNCH_LFR2(uint32_t, uint64_t, true, locs); else RBG_LAUNCH_LFR2(uint64_t, uint64_t, true, locs);
-        } else if (ix.pos_bytes == 4) {
-            RBG_LAUNCH_LFR2(uint32_t, uint64_t, false, locs);
-        } else {
-            RBG_LAUNCH_LFR2(uint64_t, uint64_t, false, locs);
-        }
-#undef RBG_LAUNCH_LFR2
-        return static_cast<int>(hipGetLastError());
-    }
-    const size_t lds = static_cast<size_t>(ix.phi_tree.top_n) * ix.pos_bytes + 16;
-#define RBG_LAUNCH_LFR(PT, ORD, OUT, STS, DST)                                                                          \
-    do {                                                                                                               \
-        auto kern = k_locate_fill_runs<PT, ORD, OUT, STS>;                                                             \
-        raise_lds(kern, lds);                                                                                          \
-        hipLaunchKernelGGL(kern, grid, block, lds, st, ix, lo, hi, k, N, max_hits, loc_off, DST, sub, perm, skeys, stats);   \
-    } while (0)
     if (locs32) {
         if (stats || ix.pos_bytes != 4) return static_cast<int>(hipErrorInvalidValue);
-        if (perm) RBG_LAUNCH_LFR(uint32_t, true, uint32_t, false, locs32); else RBG_LAUNCH_LFR(uint32_t, false, uint32_t, false, locs32);
+        RBG_LAUNCH_LFR2(uint32_t, uint32_t, false, locs32);
     } else if (stats) {
-        if (!perm) return static_cast<int>(hipErrorNotSupported);   // the instrumented walk is the ordered one
-        if (ix.pos_bytes == 4) RBG_LAUNCH_LFR(uint32_t, true, uint64_t, true, locs); else RBG_LAUNCH_LFR(uint64_t, true, uint64_t, true, locs);
+        if (ix.pos_bytes == 4) RBG_LAUNCH_LFR2(uint32_t, uint64_t, true, locs); else RBG_LAUNCH_LFR2(uint64_t, uint64_t, true, locs);
     } else if (ix.pos_bytes == 4) {
-        if (perm) RBG_LAUNCH_LFR(uint32_t, true, uint64_t, false, locs); else RBG_LAUNCH_LFR(uint32_t, false, uint64_t, false, locs);
+        RBG_LAUNCH_LFR2(uint32_t, uint64_t, false, locs);
     } else {
-        if (perm) RBG_LAUNCH_LFR(uint64_t, true, uint64_t, false, locs); else RBG_LAUNCH_LFR(uint64_t, false, uint64_t, false, locs);
+        RBG_LAUNCH_LFR2(uint64_t, uint64_t, false, locs);
     }
-#undef RBG_LAUNCH_LFR
+#undef RBG_LAUNCH_LFR2
     return static_cast<int>(hipGetLastError());
 }
 

@@ -1,13 +1,12 @@
 // k_runs_seeds.hip -- the kernels beside the rb_align path on the run-indexed layout (RBG_LAYOUT_RUNS): single LF steps
 // (RowBowt::LF, rowbowt.hpp:74-88), find_range_w_markers (:292-339), greedy seeds (:222-256 reduced by :669-677) and
 // marker seeds (get_markers_greedy_seeding, :406-482).  Same outputs as their slot-table versions in k_markers.hip; what
-// differs is how a rank is answered: there one lane reads one slot, here the WAVE answers the two ranks of every lane's
-// step together (coop_lf2, rbg_runs_device.hpp: directory gather + one probe of the run list by a quad of lanes), and a
-// step may consume up to run_ksteps symbols through the k-mer depth's run list.  So each kernel is written as a state
-// machine: per round every lane that still has work names its next step (or does lane-local work that needs no rank:
-// ftab entries, absent symbols, marker queries), the wave answers all the steps, every lane applies its result.
-// (Round 2 answered these kernels' ranks lane by lane with a binary search from the symbol's directory, single symbols
-// only: 104 ms per 10 M reads for the greedy seeds on the bench index against 8 ms for K1.)
+// differs is how a rank is answered: there one lane reads one slot, here the lane reads its bucket's record (fetched by its
+// quad) or directory entry and scans the few run-list entries it names (rbg_runs2_device.hpp), and a step may consume up to
+// run_ksteps symbols through the k-mer depth's run list.  Each kernel is written as a state machine: per round every lane
+// that still has work names its next step (or does lane-local work that needs no rank: ftab entries, absent symbols,
+// marker queries), all lanes of the wave take their steps together (the quads fetch records for one another), every lane
+// applies its result.
 #include "rbg_runs2_device.hpp"
 
 namespace rbg {
@@ -91,60 +90,39 @@ __device__ __forceinline__ bool ftab_state(const DevIndex &ix, ByteCursor &rd, c
     return true;
 }
 
-// V2: format 2 of the layout (rbg_runs2_device.hpp): every lane answers its own ranks; the state machines stay as they are
-#define RBG_SEED_KERNEL_PROLOGUE(P, WAVES, V2)                                                    \
+#define RBG_SEED_KERNEL_PROLOGUE(P)                                                               \
     __shared__ uint8_t s_lut[256];                                                                \
     __shared__ uint8_t s_lut2[256];                                                               \
     for (int t = threadIdx.x; t < 256; t += blockDim.x) {                                         \
         s_lut[t] = ix.lut[t];                                                                     \
         s_lut2[t] = ix.nmajor ? ix.lut2[t] : 0xFFu;                                               \
     }                                                                                             \
-    RunSearch<P> S{};                                                                             \
-    RunSearch2<P> S2{};                                                                           \
-    const uint32_t *tab_first = nullptr;                                                          \
-    const RunRec *const *rec_tabs = nullptr;                                                      \
-    if constexpr (V2) {                                                                           \
-        RBG_RUN_SEARCH2_SHARED;                                                                   \
-        S2 = stage_run_search2<P>(ix, s_tab_first, s_ent2, s_dir2, s_rec2, s_dyn);                        \
-        tab_first = s_tab_first;                                                                  \
-    } else {                                                                                      \
-        RBG_RUN_SEARCH_SHARED(P, WAVES);                                                          \
-        S = stage_run_search<P, WAVES>(ix, s_tree, s_tab_first, s_rec, s_req, s_dyn);             \
-        tab_first = s_tab_first;                                                                  \
-        rec_tabs = s_rec;                                                                         \
-    }                                                                                             \
-    (void)S; (void)S2; (void)rec_tabs;                                                            \
+    RBG_RUN_SEARCH2_SHARED;                                                                       \
+    const RunSearch2<P> S2 = stage_run_search2<P>(ix, s_tab_first, s_ent2, s_dir2, s_rec2, s_dyn); \
+    const uint32_t *tab_first = s_tab_first;                                                      \
     const uint32_t D = ix.run_ksteps, DMASK = ix.run_depth_mask | 1u, M = ix.nmajor;              \
     const uint32_t lane = threadIdx.x & (kWave - 1);                                              \
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;                        \
     const uint64_t wave_first = static_cast<uint64_t>(blockIdx.x) * blockDim.x + (threadIdx.x & ~(kWave - 1))
 
-// both ranks of the step of every lane of the wave (format 1: cooperative, every lane must call; format 2: the lane's own)
+// both ranks of the step of every lane of the wave
 // LEAN: one record in registers at a time (rbg_runs2_device.hpp lane_lf2) -- for the instantiation whose state would otherwise cost
 // a workgroup per CU (512 threads: two or four waves per SIMD, nothing between: the greedy seeds at 8-byte positions); the others
 // fetch both records of a step, and both scans of crowded buckets, together
 // QUAD: the first record of a step fetched by the lane's quad (rbg_runs2_device.hpp lane_lf2_quad); not where its registers would cost the workgroup
-template <typename P, bool V2, bool LEAN = false, bool QUAD = true>
-__device__ __forceinline__ void seeds_lf2(const DevIndex &ix, const RunSearch<P> &S, const RunSearch2<P> &S2, const bool stepping, const uint32_t d,
-                                          const uint32_t rec, const uint64_t q0, const uint64_t q1, RunStep &r) {
-    if constexpr (V2) {
-        if constexpr (QUAD) lane_lf2_quad<P, false, LEAN>(S2, stepping, d, rec, q0, q1, r);   // (every lane calls)
-        else { if (stepping) lane_lf2<P, false, LEAN>(S2, d, rec, q0, q1, r); }
-    }
-    else coop_lf2<P>(ix, S, stepping, d, rec, q0, q1, r);
-}
-template <typename P, bool V2>
-__device__ __forceinline__ uint64_t seeds_sample(const DevIndex &ix, const RunRec *const *rec_tabs, const uint32_t d, const RunStep &r) {
-    if constexpr (V2) return run_step_sample2<P>(ix, d, r.samp_e);
-    else return run_step_sample<P>(ix, rec_tabs, d, r);
+template <typename P, bool LEAN = false, bool QUAD = true>
+__device__ __forceinline__ void seeds_lf2(const RunSearch2<P> &S2, const bool stepping, const uint32_t d, const uint32_t rec, const uint64_t q0, const uint64_t q1,
+                                          RunStep &r) {
+    if constexpr (QUAD) lane_lf2_quad<P, false, LEAN>(S2, stepping, d, rec, q0, q1, r);   // (every lane calls)
+    else { if (stepping) lane_lf2<P, false, LEAN>(S2, d, rec, q0, q1, r); }
 }
 
 // ---- single LF step for N (range, symbol) triples: RowBowt::LF(range_t, uint8_t), rowbowt.hpp:74-88 -------------------
-template <typename P, bool V2>
-__global__ __launch_bounds__(512, (V2 || sizeof(P) == 4) ? 4 : 3) void k_lf_runs(const DevIndex ix, const uint64_t *__restrict__ lo_in,
+template <typename P>
+__global__ __launch_bounds__(512, 4) void k_lf_runs(const DevIndex ix, const uint64_t *__restrict__ lo_in,
                                                                         const uint64_t *__restrict__ hi_in, const uint8_t *__restrict__ sym,
                                                                         const uint64_t N, uint64_t *__restrict__ lo_out, uint64_t *__restrict__ hi_out) {
-    RBG_SEED_KERNEL_PROLOGUE(P, 8, V2);
+    RBG_SEED_KERNEL_PROLOGUE(P);
     (void)D; (void)DMASK; (void)M; (void)s_lut2;
     for (uint64_t base = wave_first; base < N; base += stride) {
         const uint64_t i = base + lane;
@@ -160,7 +138,7 @@ __global__ __launch_bounds__(512, (V2 || sizeof(P) == 4) ? 4 : 3) void k_lf_runs
             if (stepping) rec = run_record(tab_first, 1u, slot);
         }
         RunStep r;
-        seeds_lf2<P, V2>(ix, S, S2, stepping, 0u, rec, lo, hi + 1, r);
+        seeds_lf2<P>(S2, stepping, 0u, rec, lo, hi + 1, r);
         if (valid) {
             uint64_t nlo = 1, nhi = 0;
             if (stepping && r.c_upto > r.c_before) { nlo = r.F + r.c_before; nhi = nlo + (r.c_upto - r.c_before) - 1; }
@@ -172,14 +150,14 @@ __global__ __launch_bounds__(512, (V2 || sizeof(P) == 4) ? 4 : 3) void k_lf_runs
 
 // ---- find_range_w_markers (rowbowt.hpp:292-339): single steps, a marker query at every window end ---------------------
 // (k_markers.hip k_find_range_markers; window results are PREPENDED in the reference, :320,:333)
-template <typename P, bool FILL, bool V2>
-__global__ __launch_bounds__(512, (V2 || sizeof(P) == 4) ? 4 : 3) void k_find_range_markers_runs(const DevIndex ix, const uint8_t *__restrict__ seqs,
+template <typename P, bool FILL>
+__global__ __launch_bounds__(512, 4) void k_find_range_markers_runs(const DevIndex ix, const uint8_t *__restrict__ seqs,
                                                             const uint64_t *__restrict__ off, const uint64_t N,
                                                             const uint64_t wsize, const uint64_t max_range,
                                                             uint64_t *__restrict__ lo_out, uint64_t *__restrict__ hi_out,
                                                             uint64_t *__restrict__ cnt_out,
                                                             const uint64_t *__restrict__ mk_off, uint64_t *__restrict__ mk) {
-    RBG_SEED_KERNEL_PROLOGUE(P, 8, V2);
+    RBG_SEED_KERNEL_PROLOGUE(P);
     (void)D; (void)DMASK; (void)M;
     if (!FILL && blockIdx.x == 0 && threadIdx.x == 0) cnt_out[0] = 0;
     for (uint64_t base = wave_first; base < N; base += stride) {
@@ -218,7 +196,7 @@ __global__ __launch_bounds__(512, (V2 || sizeof(P) == 4) ? 4 : 3) void k_find_ra
                 else rec = run_record(tab_first, 1u, slot);
             }
             RunStep r;
-            seeds_lf2<P, V2>(ix, S, S2, stepping, 0u, rec, lo, hi + 1, r);
+            seeds_lf2<P>(S2, stepping, 0u, rec, lo, hi + 1, r);
             if (stepping) {
                 const uint64_t c_inside = r.c_upto - r.c_before;
                 if (c_inside == 0) alive = false;
@@ -246,15 +224,15 @@ __global__ __launch_bounds__(512, (V2 || sizeof(P) == 4) ? 4 : 3) void k_find_ra
 // ---- greedy seeding: RowBowt::get_seeds_greedy_w_sample (rowbowt.hpp:222-256) reduced on the fly by
 // locate_from_longest_seed's choice (:669-677): per read the first seed of strictly greatest length (k_markers.hip
 // k_greedy_seed).  A k-mer step that comes back empty is narrowed by halving until the failing base is the reference's.
-// (format 2: three waves per SIMD -- at four the register limit of 128 sends a few of this kernel's values to scratch, and a format-2 kernel
+// (three waves per SIMD -- at four the register limit of 128 sends a few of this kernel's values to scratch, and a kernel of this layout
 //  that spilled faulted on the device in round 4, profiles/r04_fault_note.txt: none of them is allowed to)
-template <typename P, bool V2>
-__global__ __launch_bounds__(512, V2 ? 3 : sizeof(P) == 4 ? 4 : 3) void k_greedy_seed_runs(const DevIndex ix, const uint8_t *__restrict__ seqs,
+template <typename P>
+__global__ __launch_bounds__(512, 3) void k_greedy_seed_runs(const DevIndex ix, const uint8_t *__restrict__ seqs,
                                                      const uint64_t *__restrict__ off, const uint64_t N,
                                                      const uint64_t min_length, uint64_t *__restrict__ lo_out,
                                                      uint64_t *__restrict__ hi_out, uint64_t *__restrict__ qs_out,
                                                      uint64_t *__restrict__ qe_out, uint64_t *__restrict__ ss_out) {
-    RBG_SEED_KERNEL_PROLOGUE(P, 8, V2);
+    RBG_SEED_KERNEL_PROLOGUE(P);
     const uint64_t first_k = ix.last_run_sample;       // rowbowt.hpp:230
     const uint64_t fhi = ix.n - 1;
     for (uint64_t base = wave_first; base < N; base += stride) {
@@ -295,13 +273,13 @@ __global__ __launch_bounds__(512, V2 ? 3 : sizeof(P) == 4 ? 4 : 3) void k_greedy
                 stepping = true;
             }
             RunStep r;
-            seeds_lf2<P, V2, (sizeof(P) == 8), false>(ix, S, S2, stepping, pick.d, pick.rec, lo, hi + 1, r);
+            seeds_lf2<P, (sizeof(P) == 8), false>(S2, stepping, pick.d, pick.rec, lo, hi + 1, r);
             if (stepping) {
                 const uint64_t c_inside = r.c_upto - r.c_before;
                 const bool ok = c_inside != 0;
                 if (ok) {                               // LF_w_loc, rowbowt.hpp:555-573, pick.adv times nested
                     if (r.inside) k = k - pick.adv;
-                    else k = seeds_sample<P, V2>(ix, rec_tabs, pick.d, r);
+                    else k = run_step_sample2<P>(ix, pick.d, r.samp_e);
                     lo = r.F + r.c_before;
                     hi = lo + c_inside - 1;
                 }
@@ -331,14 +309,14 @@ __global__ __launch_bounds__(512, V2 ? 3 : sizeof(P) == 4 ? 4 : 3) void k_greedy
 // with that kernel (lane by lane).  One record per call of the reference's callback: {range lo, range hi, q.first,
 // seed_ei, first marker, one past last marker}.
 // LOG / lg: the marker-seed log (rbg_dev.h SeedLog), as in k_markers.hip k_marker_seeds
-template <typename P, bool FILL, bool LOG, bool V2>
-__global__ __launch_bounds__(512, V2 ? 3 : sizeof(P) == 4 ? 4 : 3) void k_marker_seeds_runs(const DevIndex ix, const uint8_t *__restrict__ seqs,
+template <typename P, bool FILL, bool LOG>
+__global__ __launch_bounds__(512, 3) void k_marker_seeds_runs(const DevIndex ix, const uint8_t *__restrict__ seqs,
                                                       const uint64_t *__restrict__ off, const uint64_t N,
                                                       const uint64_t wsize, const uint64_t max_range,
                                                       uint64_t *__restrict__ seed_cnt, uint64_t *__restrict__ mk_cnt,
                                                       const uint64_t *__restrict__ seed_off, const uint64_t *__restrict__ mk_off,
                                                       uint64_t *__restrict__ seeds, uint64_t *__restrict__ mk, const SeedLog lg) {
-    RBG_SEED_KERNEL_PROLOGUE(P, 8, V2);
+    RBG_SEED_KERNEL_PROLOGUE(P);
     if (!FILL && blockIdx.x == 0 && threadIdx.x == 0) { seed_cnt[0] = 0; mk_cnt[0] = 0; }
     const bool have_ma = ix.mk_nruns != 0;
     const uint64_t fhi = ix.n - 1;
@@ -431,7 +409,7 @@ __global__ __launch_bounds__(512, V2 ? 3 : sizeof(P) == 4 ? 4 : 3) void k_marker
                 stepping = true;
             }
             RunStep r;
-            seeds_lf2<P, V2, true>(ix, S, S2, stepping, pick.d, pick.rec, lo, hi + 1, r);
+            seeds_lf2<P, true>(S2, stepping, pick.d, pick.rec, lo, hi + 1, r);
             if (stepping) {
                 const uint64_t c_inside = r.c_upto - r.c_before;
                 const bool ok = c_inside != 0;
@@ -476,7 +454,7 @@ __global__ __launch_bounds__(512, 3) void k_marker_seeds_ftab_runs2(const DevInd
                                                                     uint64_t *__restrict__ seed_cnt, uint64_t *__restrict__ mk_cnt,
                                                                     const uint64_t *__restrict__ seed_off, const uint64_t *__restrict__ mk_off,
                                                                     uint64_t *__restrict__ seeds, uint64_t *__restrict__ mk, const SeedLog lg) {
-    RBG_SEED_KERNEL_PROLOGUE(P, 8, true);
+    RBG_SEED_KERNEL_PROLOGUE(P);
     (void)lane; (void)wave_first;
     if (!FILL && blockIdx.x == 0 && threadIdx.x == 0) { seed_cnt[0] = 0; mk_cnt[0] = 0; }
     const bool have_ma = ix.mk_nruns != 0;
@@ -608,7 +586,7 @@ SeedLaunch seed_launch(const DevIndex &ix, const LaunchCfg &cfg, uint64_t N) {
     LaunchCfg c = cfg;   // 512-thread workgroups: the staged tables are shared by eight waves
     c.block_threads = 512;
     c.max_blocks = cfg.max_blocks > 0 ? std::max(1, cfg.max_blocks / 2) : 256 * 16;
-    return SeedLaunch{dim3(grid_for(c, N)), dim3(512), ix.run_fmt == 2 ? run_search2_lds(ix) : run_search_lds(ix)};
+    return SeedLaunch{dim3(grid_for(c, N)), dim3(512), run_search2_lds(ix)};
 }
 
 }  // namespace
@@ -625,9 +603,8 @@ int launch_lf_runs(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t *lo,
     if (N == 0) return 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const SeedLaunch L = seed_launch(ix, cfg, N);
-    const bool v2 = ix.run_fmt == 2;
-    if (ix.pos_bytes == 4) { if (v2) RBG_LAUNCH_SEEDK((k_lf_runs<uint32_t, true>), lo, hi, sym, N, lo_out, hi_out); else RBG_LAUNCH_SEEDK((k_lf_runs<uint32_t, false>), lo, hi, sym, N, lo_out, hi_out); }
-    else { if (v2) RBG_LAUNCH_SEEDK((k_lf_runs<uint64_t, true>), lo, hi, sym, N, lo_out, hi_out); else RBG_LAUNCH_SEEDK((k_lf_runs<uint64_t, false>), lo, hi, sym, N, lo_out, hi_out); }
+    if (ix.pos_bytes == 4) RBG_LAUNCH_SEEDK((k_lf_runs<uint32_t>), lo, hi, sym, N, lo_out, hi_out);
+    else RBG_LAUNCH_SEEDK((k_lf_runs<uint64_t>), lo, hi, sym, N, lo_out, hi_out);
     return static_cast<int>(hipGetLastError());
 }
 
@@ -636,14 +613,12 @@ int launch_find_range_markers_runs(const DevIndex &ix, const LaunchCfg &cfg, con
                                    uint64_t *mk, bool fill, void *stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     const SeedLaunch L = seed_launch(ix, cfg, N);
-#define RBG_FRM(PT, V)                                                                                                                        \
+#define RBG_FRM(PT)                                                                                                                           \
     do {                                                                                                                                     \
-        if (fill) RBG_LAUNCH_SEEDK((k_find_range_markers_runs<PT, true, V>), seqs, off, N, wsize, max_range, lo, hi, cnt, mk_off, mk);        \
-        else RBG_LAUNCH_SEEDK((k_find_range_markers_runs<PT, false, V>), seqs, off, N, wsize, max_range, lo, hi, cnt, mk_off, mk);            \
+        if (fill) RBG_LAUNCH_SEEDK((k_find_range_markers_runs<PT, true>), seqs, off, N, wsize, max_range, lo, hi, cnt, mk_off, mk);           \
+        else RBG_LAUNCH_SEEDK((k_find_range_markers_runs<PT, false>), seqs, off, N, wsize, max_range, lo, hi, cnt, mk_off, mk);               \
     } while (0)
-    const bool v2 = ix.run_fmt == 2;
-    if (ix.pos_bytes == 4) { if (v2) RBG_FRM(uint32_t, true); else RBG_FRM(uint32_t, false); }
-    else { if (v2) RBG_FRM(uint64_t, true); else RBG_FRM(uint64_t, false); }
+    if (ix.pos_bytes == 4) RBG_FRM(uint32_t); else RBG_FRM(uint64_t);
 #undef RBG_FRM
     return static_cast<int>(hipGetLastError());
 }
@@ -653,9 +628,8 @@ int launch_greedy_seed_runs(const DevIndex &ix, const LaunchCfg &cfg, const uint
     if (N == 0) return 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const SeedLaunch L = seed_launch(ix, cfg, N);
-    const bool v2 = ix.run_fmt == 2;
-    if (ix.pos_bytes == 4) { if (v2) RBG_LAUNCH_SEEDK((k_greedy_seed_runs<uint32_t, true>), seqs, off, N, min_length, lo, hi, qs, qe, ss); else RBG_LAUNCH_SEEDK((k_greedy_seed_runs<uint32_t, false>), seqs, off, N, min_length, lo, hi, qs, qe, ss); }
-    else { if (v2) RBG_LAUNCH_SEEDK((k_greedy_seed_runs<uint64_t, true>), seqs, off, N, min_length, lo, hi, qs, qe, ss); else RBG_LAUNCH_SEEDK((k_greedy_seed_runs<uint64_t, false>), seqs, off, N, min_length, lo, hi, qs, qe, ss); }
+    if (ix.pos_bytes == 4) RBG_LAUNCH_SEEDK((k_greedy_seed_runs<uint32_t>), seqs, off, N, min_length, lo, hi, qs, qe, ss);
+    else RBG_LAUNCH_SEEDK((k_greedy_seed_runs<uint64_t>), seqs, off, N, min_length, lo, hi, qs, qe, ss);
     return static_cast<int>(hipGetLastError());
 }
 
@@ -665,8 +639,7 @@ int launch_marker_seeds_runs(const DevIndex &ix, const LaunchCfg &cfg, const uin
     hipStream_t st = static_cast<hipStream_t>(stream);
     SeedLaunch L = seed_launch(ix, cfg, N);
     if (fill && lg.base) L.grid = dim3(std::min<unsigned>(L.grid.x, 128u));   // the listed sequences only: their number is on the device
-    if (ftab_k) {   // rb_markers --ftab (format 2 only: launch_marker_seeds_plan / _fill keep format 1 on the per-lane slot kernel)
-        if (ix.run_fmt != 2) return static_cast<int>(hipErrorNotSupported);
+    if (ftab_k) {   // rb_markers --ftab
 #define RBG_MSF(PT)                                                                                                                          \
     do {                                                                                                                                     \
         if (fill) RBG_LAUNCH_SEEDK((k_marker_seeds_ftab_runs2<PT, true, false>), seqs, off, N, wsize, max_range, ftab_k, seed_cnt, mk_cnt, seed_off, mk_off, seeds, mk, lg); \
@@ -677,15 +650,13 @@ int launch_marker_seeds_runs(const DevIndex &ix, const LaunchCfg &cfg, const uin
 #undef RBG_MSF
         return static_cast<int>(hipGetLastError());
     }
-#define RBG_MSR(PT, V)                                                                                                                       \
+#define RBG_MSR(PT)                                                                                                                          \
     do {                                                                                                                                     \
-        if (fill) RBG_LAUNCH_SEEDK((k_marker_seeds_runs<PT, true, false, V>), seqs, off, N, wsize, max_range, seed_cnt, mk_cnt, seed_off, mk_off, seeds, mk, lg); \
-        else if (lg.base) RBG_LAUNCH_SEEDK((k_marker_seeds_runs<PT, false, true, V>), seqs, off, N, wsize, max_range, seed_cnt, mk_cnt, seed_off, mk_off, seeds, mk, lg); \
-        else RBG_LAUNCH_SEEDK((k_marker_seeds_runs<PT, false, false, V>), seqs, off, N, wsize, max_range, seed_cnt, mk_cnt, seed_off, mk_off, seeds, mk, lg); \
+        if (fill) RBG_LAUNCH_SEEDK((k_marker_seeds_runs<PT, true, false>), seqs, off, N, wsize, max_range, seed_cnt, mk_cnt, seed_off, mk_off, seeds, mk, lg); \
+        else if (lg.base) RBG_LAUNCH_SEEDK((k_marker_seeds_runs<PT, false, true>), seqs, off, N, wsize, max_range, seed_cnt, mk_cnt, seed_off, mk_off, seeds, mk, lg); \
+        else RBG_LAUNCH_SEEDK((k_marker_seeds_runs<PT, false, false>), seqs, off, N, wsize, max_range, seed_cnt, mk_cnt, seed_off, mk_off, seeds, mk, lg); \
     } while (0)
-    const bool v2 = ix.run_fmt == 2;
-    if (ix.pos_bytes == 4) { if (v2) RBG_MSR(uint32_t, true); else RBG_MSR(uint32_t, false); }
-    else { if (v2) RBG_MSR(uint64_t, true); else RBG_MSR(uint64_t, false); }
+    if (ix.pos_bytes == 4) RBG_MSR(uint32_t); else RBG_MSR(uint64_t);
 #undef RBG_MSR
     return static_cast<int>(hipGetLastError());
 }

@@ -108,14 +108,14 @@ __global__ __launch_bounds__(1024, 8) void k_find_range(const DevIndex ix, const
             if (STATS) {
                 RankAux pa;
                 const bool two = (lo >> S.shift) != ((hi + 1) >> S.shift);
-                rank_pair<P, false>(S, ix.dense, lo, hi + 1, &c_before, &c_upto, &bh, &q, &pa);
+                rank_pair<P>(S, ix.dense, lo, hi + 1, &c_before, &c_upto, &bh, &q, &pa);
                 st[kStSteps] += 1;
                 st[kStSlots] += two ? 2 : 1;
                 st[kStDense] += (pa.dense ? 1 : 0) + ((two || !pa.dense) && q.dense ? 1 : 0);
                 st[kStSearch] += (pa.ovf ? 1 : 0) + (q.ovf ? 1 : 0);
                 st[kStSymbols] += adv;
             } else {
-                rank_pair<P, false>(S, ix.dense, lo, hi + 1, &c_before, &c_upto, &bh, &q);  // rowbowt.hpp:79,83
+                rank_pair<P>(S, ix.dense, lo, hi + 1, &c_before, &c_upto, &bh, &q);  // rowbowt.hpp:79,83
             }
             const uint64_t c_inside = c_upto - c_before;
             if (c_inside == 0) return false;                               // rowbowt.hpp:85
@@ -308,7 +308,7 @@ struct BitStream {
 // k_find_range over packed reads: the same steps in the same order as the byte kernel takes for a
 // read made of major symbols only (ftab word, then min(kmer_steps, remaining) symbols per gather),
 // so ranges and toeholds are identical; flagged reads are left to the byte kernel (sel list).
-template <typename P, bool TOEHOLD, bool S64 = false>
+template <typename P, bool TOEHOLD>
 __global__ __launch_bounds__(1024, 8) void k_find_range_packed(const DevIndex ix, const uint2 *__restrict__ meta,
                                                            const uint4 *__restrict__ chunks, const uint64_t N,
                                                            uint64_t *__restrict__ lo_out, uint64_t *__restrict__ hi_out,
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(1024, 8) void k_find_range_packed(const DevIndex ix
         auto step = [&](const DevSym &S, uint32_t adv, uint32_t tab) -> bool {
             RankAux q;
             uint64_t c_before, c_upto, bh;
-            rank_pair<P, S64>(S, ix.dense, lo, hi + 1, &c_before, &c_upto, &bh, &q);      // rowbowt.hpp:79,83
+            rank_pair<P>(S, ix.dense, lo, hi + 1, &c_before, &c_upto, &bh, &q);      // rowbowt.hpp:79,83
             const uint64_t c_inside = c_upto - c_before;
             if (c_inside == 0) return false;                               // rowbowt.hpp:85
             if (TOEHOLD) {                                                 // LF_w_loc, rowbowt.hpp:559-566
@@ -442,7 +442,6 @@ int launch_find_range_impl(const DevIndex &ix, const LaunchCfg &cfg, const uint8
 int launch_find_range_stats(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
                             uint64_t *lo, uint64_t *hi, uint64_t *ssamp, unsigned long long *stats, void *stream) {
     if (ix.layout == 2) return launch_find_range_runs(ix, cfg, seqs, off, N, lo, hi, ssamp, stream, stats);  // (its sums mean other things: rbg.h)
-    if (ix.slot_bytes == 64) return launch_find_range64(ix, cfg, seqs, off, N, lo, hi, ssamp, nullptr, nullptr, stats, stream);
     return ix.ftab_k ? launch_find_range_impl<true, true>(ix, cfg, seqs, off, N, lo, hi, ssamp, nullptr, nullptr, stream, stats)
                      : launch_find_range_impl<false, true>(ix, cfg, seqs, off, N, lo, hi, ssamp, nullptr, nullptr, stream, stats);
 }
@@ -450,7 +449,6 @@ int launch_find_range_stats(const DevIndex &ix, const LaunchCfg &cfg, const uint
 int launch_find_range(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
                       uint64_t *lo, uint64_t *hi, uint64_t *ssamp, void *stream) {
     if (ix.layout == 2) return launch_find_range_runs(ix, cfg, seqs, off, N, lo, hi, ssamp, stream);  // run-indexed layout (k_runs.hip)
-    if (ix.slot_bytes == 64) return launch_find_range64(ix, cfg, seqs, off, N, lo, hi, ssamp, nullptr, nullptr, nullptr, stream);   // 64-byte slots (k_search64.hip)
     // without a table the table-free instantiation runs (it is also the one that BUILDS the table,
     // so profiles show that one-off launch under its own kernel name)
     return ix.ftab_k ? launch_find_range_impl<true>(ix, cfg, seqs, off, N, lo, hi, ssamp, nullptr, nullptr, stream)
@@ -514,15 +512,9 @@ int launch_find_range_packed_only(const DevIndex &ix, const LaunchCfg &cfg, cons
     hipStream_t st = static_cast<hipStream_t>(stream);
 #define RBG_LAUNCH_FRP(PT, TOE)                                                                       \
     do {                                                                                              \
-        if (ix.slot_bytes == 64) {                                                                    \
-            auto kern = k_find_range_packed<PT, TOE, true>;                                           \
-            const KmerLaunch L = kmer_launch(ix, cfg, N, kern);                                       \
-            hipLaunchKernelGGL(kern, L.grid, L.block, L.lds, st, ix, meta, chunks, N, lo, hi, ssamp); \
-        } else {                                                                                      \
-            auto kern = k_find_range_packed<PT, TOE, false>;                                          \
-            const KmerLaunch L = kmer_launch(ix, cfg, N, kern);                                       \
-            hipLaunchKernelGGL(kern, L.grid, L.block, L.lds, st, ix, meta, chunks, N, lo, hi, ssamp); \
-        }                                                                                             \
+        auto kern = k_find_range_packed<PT, TOE>;                                                     \
+        const KmerLaunch L = kmer_launch(ix, cfg, N, kern);                                           \
+        hipLaunchKernelGGL(kern, L.grid, L.block, L.lds, st, ix, meta, chunks, N, lo, hi, ssamp);     \
     } while (0)
     if (ix.pos_bytes == 4) {
         if (ssamp) RBG_LAUNCH_FRP(uint32_t, true); else RBG_LAUNCH_FRP(uint32_t, false);
@@ -551,15 +543,9 @@ int launch_find_range_packed(const DevIndex &ix, const LaunchCfg &cfg, const voi
     }
 #define RBG_LAUNCH_FRP(PT, TOE)                                                                       \
     do {                                                                                              \
-        if (ix.slot_bytes == 64) {                                                                    \
-            auto kern = k_find_range_packed<PT, TOE, true>;                                           \
-            const KmerLaunch L = kmer_launch(ix, cfg, N, kern);                                       \
-            hipLaunchKernelGGL(kern, L.grid, L.block, L.lds, st, ix, meta, chunks, N, lo, hi, ssamp); \
-        } else {                                                                                      \
-            auto kern = k_find_range_packed<PT, TOE, false>;                                          \
-            const KmerLaunch L = kmer_launch(ix, cfg, N, kern);                                       \
-            hipLaunchKernelGGL(kern, L.grid, L.block, L.lds, st, ix, meta, chunks, N, lo, hi, ssamp); \
-        }                                                                                             \
+        auto kern = k_find_range_packed<PT, TOE>;                                                     \
+        const KmerLaunch L = kmer_launch(ix, cfg, N, kern);                                           \
+        hipLaunchKernelGGL(kern, L.grid, L.block, L.lds, st, ix, meta, chunks, N, lo, hi, ssamp);     \
     } while (0)
     if (ix.pos_bytes == 4) {
         if (toe) RBG_LAUNCH_FRP(uint32_t, true); else RBG_LAUNCH_FRP(uint32_t, false);
@@ -571,7 +557,6 @@ int launch_find_range_packed(const DevIndex &ix, const LaunchCfg &cfg, const voi
     if (rc) return rc;
     // the reads the packed form cannot express (a symbol outside the major alphabet)
     const uint32_t *sel = reinterpret_cast<const uint32_t *>(b + L.sel), *nsel = reinterpret_cast<const uint32_t *>(b + L.nsel);
-    if (ix.slot_bytes == 64) return launch_find_range64(ix, cfg, seqs, off, N, lo, hi, ssamp, sel, nsel, nullptr, stream);
     return ix.ftab_k ? launch_find_range_impl<true>(ix, cfg, seqs, off, N, lo, hi, ssamp, sel, nsel, stream)
                      : launch_find_range_impl<false>(ix, cfg, seqs, off, N, lo, hi, ssamp, sel, nsel, stream);
 }

@@ -29,6 +29,7 @@
 #include "rbg_host.hpp"
 
 using namespace rbg;
+static_assert(kMaxRunDepth == kMaxKmerDepth && kLdsRunDepth == kMaxSlotKmerDepth, "rbg_dev.h and rbg_host.hpp name the same depths");
 
 #include "rbg_hostpath.hpp"
 
@@ -36,7 +37,7 @@ struct DevAlloc {
     void *p;
     size_t bytes;
 };
-// a device array of records that hold device pointers (DevSym / DevTree): what a peer copy has to re-point
+// a device array of records that hold device pointers (DevSym): what a peer copy has to re-point
 struct PtrTable {
     const void *d_ptr;
     size_t count, stride;
@@ -65,14 +66,12 @@ struct rbg_index {
     // what the load decided about the run-indexed layout (rbg_layout_info): nothing is left out without a line here
     struct RunsReport {
         uint32_t fmt = 0, depth_mask_asked = 0, depth_mask_kept = 0, depths_composed = 0;
-        uint64_t entries[kMaxRunDepth] = {0, 0, 0, 0, 0}, fillers[kMaxRunDepth] = {0, 0, 0, 0, 0}, dir_bytes[kMaxRunDepth] = {0, 0, 0, 0, 0};
+        uint64_t entries[kMaxRunDepth] = {}, fillers[kMaxRunDepth] = {}, dir_bytes[kMaxRunDepth] = {};
         uint64_t phi_entries = 0, phi_fillers = 0, phi_dir_bytes = 0, phi_dir_shift = 0;
         uint32_t rank_dirs = 0, phi_dir = 0;       // 1: present
         uint32_t depths_dropped_budget = 0;        // mask of depths the HBM budget left out
-        uint32_t depths_dropped_limit = 0;         // mask of depths a width limit left out (format 1: 2^32 entries)
-        uint32_t phi_dir_dropped = 0;              // 1: format 1 left the phi directory out (2 GiB / r >= 2^31)
         uint64_t phi_slots = 0, phi_slot_bytes = 0;   // format 2 with phi slots (RBG_OPT_RUN_PHI): their number and bytes (slots + ordinals)
-        uint64_t rec_bytes[kMaxRunDepth] = {0, 0, 0, 0, 0}, rec_overflow[kMaxRunDepth] = {0, 0, 0, 0, 0};   // format 2 with bucket records (RBG_OPT_RUN_REC)
+        uint64_t rec_bytes[kMaxRunDepth] = {}, rec_overflow[kMaxRunDepth] = {};   // bucket records (RBG_OPT_RUN_REC)
     } runs_report;
     // one-read host calls from concurrent threads are combined into one launch ("group commit", see Combiner below)
     struct Combiner {
@@ -127,7 +126,7 @@ std::atomic<int64_t> g_opt_block_threads{256};
 std::atomic<int64_t> g_opt_rank_shift{-1};
 std::atomic<int64_t> g_opt_phi_shift{-1};
 std::atomic<int64_t> g_opt_pos_bytes{0};
-std::atomic<int64_t> g_opt_kmer_steps{env_opt("RBG_KMER_STEPS", 5, 1, 5)};
+std::atomic<int64_t> g_opt_kmer_steps{env_opt("RBG_KMER_STEPS", kMaxKmerDepth, 1, kMaxKmerDepth)};   // (the slot layout stages at most kMaxSlotKmerDepth = 5)
 std::atomic<int64_t> g_opt_hbm_budget_mb{env_opt("RBG_HBM_BUDGET_MB", 0, 0, int64_t(1) << 40)};
 std::atomic<int64_t> g_opt_ftab_k{env_opt("RBG_FTAB_K", -1, -1, 16)};
 std::atomic<int64_t> g_opt_deep_shift{-1};
@@ -135,13 +134,18 @@ std::atomic<int64_t> g_opt_dense_overflow{1};
 std::atomic<int64_t> g_opt_rank_layout{env_opt("RBG_LAYOUT", RBG_LAYOUT_AUTO, RBG_LAYOUT_AUTO, RBG_LAYOUT_PREFER_SLOTS)};    // RBG_LAYOUT_AUTO / _SLOTS / _RUNS / _PREFER_SLOTS
 // the two automatic settings (include/rbg.h): both take the run-indexed layout when not even the single-symbol slot tables fit the budget;
 // RBG_LAYOUT_AUTO also when the slot tables would have to give up symbols per step for it (rbg_index::auto_runs, decided by options_for)
+// The k-mer depths that get run lists when RBG_OPT_RUN_DEPTHS names none: the deepest K, then K / 2, K / 4, ... and 1 (of eight: 1, 2, 4, 8).
+// A search step consumes the longest stretch a kept depth covers, so whole reads go by K symbols a step and the remainder of a
+// read (or of a seed) takes one step per set bit; every depth kept costs its run lists.
+inline uint32_t default_depth_mask(uint32_t K) {
+    uint32_t mask = 1u;
+    for (uint32_t d = K; d >= 1; d /= 2) mask |= 1u << (d - 1);
+    return mask;
+}
 inline bool layout_automatic() { const int64_t v = g_opt_rank_layout.load(); return v == RBG_LAYOUT_AUTO || v == RBG_LAYOUT_PREFER_SLOTS; }
-std::atomic<int64_t> g_opt_tree_top_kb{48};   // LDS the staged top levels of the run-indexed search may take per workgroup
-std::atomic<int64_t> g_opt_run_depths{env_opt("RBG_RUN_DEPTHS", 0, 0, (1 << kMaxRunDepth) - 1)};    // run-indexed layout: bit d - 1 = keep the k-mer depth d (0 = every other depth from the deepest down)
-std::atomic<int64_t> g_opt_run_fmt{env_opt("RBG_RUN_FMT", 2, 1, 2)};   // run-indexed layout: 1 = {P, P} pairs probed by quads of lanes (rounds 2-3), 2 = per-lane probes (rbg_dev.h DevRunTab2)
+std::atomic<int64_t> g_opt_run_depths{env_opt("RBG_RUN_DEPTHS", 0, 0, (1 << kMaxRunDepth) - 1)};    // run-indexed layout: bit d - 1 = keep the k-mer depth d (0 = default_depth_mask: the deepest, half of it, a quarter ..., 1)
 std::atomic<int64_t> g_opt_run_phi{env_opt("RBG_RUN_PHI", 0, 0, 2)};   // run-indexed layout, format 2: 0 = automatic, 1 = phi over the sampled-position list (12-16 bytes per run), 2 = phi SLOTS of about n/r rows (about 54 bytes per run at 8-byte positions; one sector per step instead of two)
 std::atomic<int64_t> g_opt_run_rec{env_opt("RBG_RUN_REC", 0, 0, 2)};   // run-indexed layout, format 2: bucket records (rbg_dev.h RunRec2) -- 0 = automatic (when the replica with them stays within half the budget), 1 = off, 2 = on
-std::atomic<int64_t> g_opt_slot_bytes{16};    // 16: RankSlot; 64: RankSlot64 (experiment: rbg_dev.h)
 std::atomic<int64_t> g_opt_packed_reads{1};  // host-pointer calls: 0 bytes over PCIe, 1 (default) 2-bit codes for batches >= 4096, 2 always
 
 // The replica's share of the free HBM when no budget is given (RBG_OPT_HBM_BUDGET_MB): A QUARTER.  Until round 3 a default
@@ -358,15 +362,12 @@ int dev_upload(rbg_index *ix, const void *src, size_t bytes, const void **dst) {
     return RBG_OK;
 }
 
-thread_local bool t_slot64 = false;   // the load in progress on this thread builds 64-byte slots (upload() decides)
-
 // bytes of one table in the replica; in_arena: what the arena has to hold of it (a table composed on the device keeps
 // its run list and samples in the level's own allocation)
 template <typename P>
 size_t table_bytes(const SymTable &t, bool with_samples, uint64_t n, bool in_arena = false) {
     const uint64_t nb = (n >> t.shift) + 2;
     const size_t lists = (in_arena && t.dev_ent) ? 0 : arena_round((t.nruns + 1) * sizeof(RunEnt<P>)) + (with_samples ? arena_round(t.nruns * sizeof(P)) : 0);
-    if (t_slot64) return lists + arena_round(((n >> (t.shift + kSlot64Extra)) + 2) * sizeof(RankSlot64));   // (the ordinal is in the slot)
     return lists + arena_round(nb * sizeof(RankSlot)) + arena_round(nb * sizeof(uint32_t));
 }
 
@@ -384,13 +385,11 @@ template <typename P>
 size_t replica_bytes(const HostIndex &h, bool in_arena = false) {
     size_t total = 0;
     for (const SymTable &t : h.sym) total += table_bytes<P>(t, h.has_tsa, h.n, in_arena);
-    for (const SymTable &t : h.pair) total += table_bytes<P>(t, h.has_tsa, h.n, in_arena);
-    for (const SymTable &t : h.triple) total += table_bytes<P>(t, h.has_tsa, h.n, in_arena);
-    for (const SymTable &t : h.quad) total += table_bytes<P>(t, h.has_tsa, h.n, in_arena);
-    for (const SymTable &t : h.quint) total += table_bytes<P>(t, h.has_tsa, h.n, in_arena);
-    total += arena_round(h.sym.size() * sizeof(DevSym)) + arena_round(h.pair.size() * sizeof(DevSym)) +
-             arena_round(h.triple.size() * sizeof(DevSym)) + arena_round(h.quad.size() * sizeof(DevSym)) +
-             arena_round(h.quint.size() * sizeof(DevSym)) + 3 * arena_round(256);
+    total += arena_round(h.sym.size() * sizeof(DevSym)) + 3 * arena_round(256);
+    for (uint32_t d = 2; d <= static_cast<uint32_t>(kMaxSlotKmerDepth); ++d) {
+        for (const SymTable &t : h.kmer(d)) total += table_bytes<P>(t, h.has_tsa, h.n, in_arena);
+        total += arena_round(h.kmer(d).size() * sizeof(DevSym));
+    }
     if (h.has_tsa) {
         const uint64_t nb = (h.n >> h.phi_shift) + 2;
         total += arena_round(h.r * sizeof(PhiEnt<P>)) + arena_round(nb * phi_slot_bytes<P>(h)) + arena_round(nb * sizeof(uint32_t));
@@ -434,20 +433,6 @@ int commit_sym(rbg_index *ix, const SymTable &t, bool with_samples, PreparedSym<
     } else {
         if ((rc = dev_upload(ix, p.ent.data(), p.ent.size() * sizeof(RunEnt<P>), &d.ent))) return rc;
         if (with_samples && (rc = dev_upload(ix, p.samp.data(), p.samp.size() * sizeof(P), &d.samp))) return rc;
-    }
-    if (t_slot64) {   // one 64-byte slot per 4 x 2^shift rows, built from the run list and its samples (rbg_dev.h RankSlot64)
-        const uint64_t nb64 = (ix->H().n >> (t.shift + kSlot64Extra)) + 2;
-        void *s64 = nullptr;
-        if ((rc = dev_reserve(ix, nb64 * sizeof(RankSlot64), &s64))) return rc;
-        if (launch_build_rank_slots64(sizeof(P), d.ent, d.samp, t.nruns, ix->H().n, t.shift, s64, d_overflow, d_overflow + 2, nullptr)) return RBG_ENODEV;
-        d.slots = s64;
-        d.ord = nullptr;
-        ix->rank_slots += nb64;
-        d.F = t.F;
-        d.shift = t.shift;
-        d.nruns = static_cast<uint32_t>(t.nruns);
-        ix->dense_todo.push_back(d);
-        return RBG_OK;
     }
     const uint64_t nb = (ix->H().n >> t.shift) + 2;
     void *slots = nullptr, *ord = nullptr;
@@ -510,7 +495,7 @@ int upload_tables(rbg_index *ix) {
     ix->ptr_tables.push_back({p, syms.size(), sizeof(DevSym), {offsetof(DevSym, ent), offsetof(DevSym, samp), offsetof(DevSym, slots), offsetof(DevSym, ord)}});
     ix->dev.nmajor = 0;
     ix->dev.kmer_steps = 1;
-    if (!h.pair.empty()) {
+    if (!h.kmer(2).empty()) {
         auto upload_set = [&](const std::vector<SymTable> &tabs, const DevSym **dst) -> int {
             VStage vs("one k-mer level: slot tables built");
             std::vector<DevSym> recs;
@@ -523,19 +508,10 @@ int upload_tables(rbg_index *ix) {
             *dst = static_cast<const DevSym *>(pp);
             return RBG_OK;
         };
-        if ((rc = upload_set(h.pair, &ix->dev.pairs))) return rc;
-        ix->dev.kmer_steps = 2;
-        if (!h.triple.empty()) {
-            if ((rc = upload_set(h.triple, &ix->dev.triples))) return rc;
-            ix->dev.kmer_steps = 3;
-        }
-        if (!h.quad.empty()) {
-            if ((rc = upload_set(h.quad, &ix->dev.quads))) return rc;
-            ix->dev.kmer_steps = 4;
-        }
-        if (!h.quint.empty()) {
-            if ((rc = upload_set(h.quint, &ix->dev.quints))) return rc;
-            ix->dev.kmer_steps = 5;
+        const DevSym **slot_tabs[kMaxSlotKmerDepth - 1] = {&ix->dev.pairs, &ix->dev.triples, &ix->dev.quads, &ix->dev.quints};
+        for (uint32_t d = 2; d <= static_cast<uint32_t>(kMaxSlotKmerDepth) && !h.kmer(d).empty(); ++d) {
+            if ((rc = upload_set(h.kmer(d), slot_tabs[d - 2]))) return rc;
+            ix->dev.kmer_steps = d;
         }
         rc = dev_upload(ix, h.major_of, 256, &p);
         if (rc) return rc;
@@ -574,19 +550,7 @@ int upload_tables(rbg_index *ix) {
     // second pass over the rank tables: now that the number of overflow buckets is known, give each its
     // dense table (rbg_dev.h).  The slots hold 32-bit offsets in 16-byte units: a pool beyond 64 GB (never seen:
     // 2.7 GB for the bench index) leaves the run-list search in place, as does an allocation failure.
-    if (t_slot64 && counts[2] > 0) {   // 4 KB per overflow bucket (one u32 per row)
-        VStage vs("dense tables of the overflow buckets (64-byte slots)");
-        if (counts[2] >= (1ull << 32)) return RBG_ENOMEM;
-        void *pool = nullptr;
-        const size_t bytes = static_cast<size_t>(counts[2]) * 4096 + 64;
-        HIP_TRY(hipMalloc(&pool, bytes));
-        ix->allocs.push_back({pool, bytes});
-        ix->hbm_bytes += bytes;
-        for (const DevSym &d : ix->dense_todo)
-            if (launch_fill_dense64(sizeof(P), d.ent, h.n, d.shift, d.slots, static_cast<uint8_t *>(pool), nullptr)) return RBG_ENODEV;
-        HIP_TRY(hipDeviceSynchronize());
-        ix->dev.dense = static_cast<const uint8_t *>(pool);
-    } else if (counts[2] > 0 && counts[2] < (1ull << 32)) {
+    if (counts[2] > 0 && counts[2] < (1ull << 32)) {
         VStage vs("dense tables of the overflow buckets");
         void *pool = nullptr;
         const size_t bytes = static_cast<size_t>(counts[2]) * 16 + 64;
@@ -606,55 +570,6 @@ int upload_tables(rbg_index *ix) {
     return RBG_OK;
 }
 
-// ---- run-indexed layout (rbg_dev.h DevTree): the run lists as they are plus a 16-ary sampled index over their keys
-// every 16th key, every 16th of those, ... until what is left of ALL trees of the kernel fits the LDS budget: that
-// coarsest level is staged in LDS, the ones below it live in HBM.  Space: (1 + 1/15) keys per run.
-template <typename P>
-struct TreeBuild {
-    std::vector<std::vector<P>> lvl;  // lvl[0] = every 16th key, ...
-};
-
-template <typename P, typename KeyAt>
-void sample_levels(uint64_t m, KeyAt key_at, uint32_t nlevels_total, TreeBuild<P> &tb) {
-    tb.lvl.clear();
-    uint64_t step = kTreeFan;
-    for (uint32_t l = 0; l < nlevels_total; ++l) {
-        std::vector<P> v((m + step - 1) / step);
-        for (uint64_t j = 0; j < v.size(); ++j) v[j] = static_cast<P>(key_at(j * step));
-        tb.lvl.push_back(std::move(v));
-        step *= kTreeFan;
-    }
-}
-
-// number of HBM-resident levels so that the coarsest level of every tree together takes at most `budget_keys`
-uint32_t tree_levels_for(const std::vector<uint64_t> &sizes, uint64_t budget_keys) {
-    for (uint32_t nl = 0; nl <= kMaxTreeLevels; ++nl) {
-        uint64_t total = 0, step = kTreeFan;
-        for (uint32_t t = 0; t < nl; ++t) step *= kTreeFan;
-        for (uint64_t m : sizes) total += (m + step - 1) / step;
-        if (total <= budget_keys) return nl;
-    }
-    return kMaxTreeLevels + 1;
-}
-
-template <typename P, typename KeyAt>
-int upload_tree(rbg_index *ix, const void *d_ent, uint64_t m, KeyAt key_at, uint32_t nlvl, std::vector<P> &top_all, DevTree &T) {
-    TreeBuild<P> tb;
-    sample_levels<P>(m, key_at, nlvl + 1, tb);
-    T = DevTree{};
-    T.ent = d_ent;
-    T.m = m;
-    for (uint32_t l = 0; l < nlvl; ++l) {
-        int rc = dev_upload(ix, tb.lvl[l].data(), tb.lvl[l].size() * sizeof(P), &T.lvl[l]);
-        if (rc) return rc;
-        T.lvl_n[l] = static_cast<uint32_t>(tb.lvl[l].size());
-    }
-    T.top_off = static_cast<uint32_t>(top_all.size());
-    T.top_n = static_cast<uint32_t>(tb.lvl[nlvl].size());
-    top_all.insert(top_all.end(), tb.lvl[nlvl].begin(), tb.lvl[nlvl].end());
-    return RBG_OK;
-}
-
 // give back one allocation the index tracks
 void free_tracked(rbg_index *ix, void *p) {
     if (!p) return;
@@ -663,465 +578,29 @@ void free_tracked(rbg_index *ix, void *p) {
     (void)hipFree(p);
 }
 
-// upload_tree for a run list that is already on the device (a k-mer level of k_compose.hip): the sampled levels are
-// gathered there, only the top one comes to the host (it is staged in LDS with the other depths')
-template <typename P>
-int upload_tree_dev(rbg_index *ix, const void *d_ent, uint64_t m, uint32_t nlvl, std::vector<P> &top_all, DevTree &T) {
-    T = DevTree{};
-    T.ent = d_ent;
-    T.m = m;
-    uint64_t step = kTreeFan;
-    for (uint32_t l = 0; l <= nlvl; ++l, step *= kTreeFan) {
-        const uint64_t count = (m + step - 1) / step;
-        void *lv = nullptr;
-        if (l < nlvl) {
-            int rc = dev_reserve(ix, count * sizeof(P), &lv);
-            if (rc) return rc;
-            HIP_TRY(static_cast<hipError_t>(launch_sample_keys(sizeof(P), d_ent, step, count, lv, nullptr)));
-            T.lvl[l] = lv;
-            T.lvl_n[l] = static_cast<uint32_t>(count);
-        } else {
-            HIP_TRY(hipMalloc(&lv, std::max<uint64_t>(count, 1) * sizeof(P)));
-            std::vector<P> top(count);
-            hipError_t e = static_cast<hipError_t>(launch_sample_keys(sizeof(P), d_ent, step, count, lv, nullptr));
-            if (e == hipSuccess && count) e = hipMemcpy(top.data(), lv, count * sizeof(P), hipMemcpyDeviceToHost);
-            (void)hipFree(lv);
-            HIP_TRY(e);
-            T.top_off = static_cast<uint32_t>(top_all.size());
-            T.top_n = static_cast<uint32_t>(count);
-            top_all.insert(top_all.end(), top.begin(), top.end());
-        }
-    }
-    return RBG_OK;
-}
-
-// RBG_RANK_REC=<t> (rbg_dev.h RunRec): build bucket records with at most t runs per bucket on average (t >= 1; fewer
-// runs per bucket = fewer overflowing buckets, more records).  Off by default: on the bench index they buy 5 % of
-// K1 for 3.7 times the space, the directories and run lists are the layout of choice.
-double rank_rec_target() {
-    const char *e_rdir = std::getenv("RBG_RANK_DIR"), *e_rec = std::getenv("RBG_RANK_REC");
-    if ((e_rdir && e_rdir[0] == '0') || !e_rec) return 0.0;
-    const double t = std::atof(e_rec);
-    return t >= 1.0 ? t : 0.0;
-}
-
 // bytes of the run-indexed replica with the k-mer depths of `mask` (bit d - 1) among those h holds (run lists, samples,
 // 1/15 of sampled keys, phi)
-bool runs_format1() {   // format 2 (per-lane probes) needs the directories; the options that build an index without them, or with bucket records, keep format 1
-    const char *e_rd = std::getenv("RBG_RANK_DIR"), *e_pd = std::getenv("RBG_PHI_DIR"), *e_hb = std::getenv("RBG_RUNS_HOST_BUILD");
-    return g_opt_run_fmt.load() == 1 || (e_rd && e_rd[0] == '0') || (e_pd && e_pd[0] == '0') || rank_rec_target() > 0 || (e_hb && e_hb[0] == '1');
-}
 template <typename P>
 size_t runs_replica_bytes(const HostIndex &h, uint32_t mask = ~0u) {
     size_t total = 0;
-    const double rec_target = rank_rec_target();
-    const bool f2 = !runs_format1();
-    // format 2: 8-byte entries at either width, directory entries of 4 / 8 bytes per (at most) half a run, no sampled levels
-    const size_t ent_bytes = f2 ? 8 : RunsFmt<P>::ent_bytes, dir_per_entry = f2 && sizeof(P) == 8 ? 4 : 2, lvl_per_entry = f2 ? 0 : sizeof(P);
-    uint32_t di = 0;
-    for (const std::vector<SymTable> *lv : {&h.sym, &h.pair, &h.triple, &h.quad, &h.quint}) {
-        if (!((mask | 1u) >> di++ & 1u)) continue;
+    // 8-byte entries at either width, directory entries of 4 / 8 bytes per (at most) half a run
+    const size_t ent_bytes = 8, dir_per_entry = sizeof(P) == 8 ? 4 : 2;
+    for (uint32_t di = 0; di < static_cast<uint32_t>(kMaxKmerDepth); ++di) {
+        const std::vector<SymTable> *lv = di == 0 ? &h.sym : &h.kmer(di + 1);
+        if (!((mask | 1u) >> di & 1u)) continue;
         size_t entries = 0;
         for (const SymTable &t : *lv) entries += t.nruns + 1;
-        total += entries * (ent_bytes + (h.has_tsa ? RunsFmt<P>::samp_bytes : 0)) + entries * lvl_per_entry / 15 + entries * dir_per_entry + lv->size() * 8 + 8 * kArenaAlign;
-        if (rec_target > 0) total += static_cast<size_t>(2.0 * static_cast<double>(entries) / rec_target + static_cast<double>(lv->size())) * sizeof(RunRec);   // (+ bucket records)
+        total += entries * (ent_bytes + (h.has_tsa ? RunsFmt<P>::samp_bytes : 0)) + entries * dir_per_entry + lv->size() * 8 + 8 * kArenaAlign;
     }
-    if (h.has_tsa) total += (h.r + 1) * PhiFmt<P>::ent_bytes + h.r * lvl_per_entry / 15 + (f2 ? h.r * 4 : std::min<size_t>(h.r, size_t(1) << 29) * 4);   // (+ the phi directory: at most r entries)
+    if (h.has_tsa) total += (h.r + 1) * PhiFmt<P>::ent_bytes + h.r * 4;   // (+ the phi directory: at most r entries)
     return total + 16 * kArenaAlign;
 }
 
-template <typename P> int materialize_kmer_levels(rbg_index *ix);
 void release_kmer_level(rbg_index *ix, uint32_t depth);
 std::vector<SymTable> &kmer_level_tables(HostIndex &h, uint32_t depth);
 
-template <typename P>
-int upload_tables_runs(rbg_index *ix) {
-    HostIndex &h = ix->H();
-    // k-mer levels composed on the device (k_compose.hip) are adopted where they lie: their run lists ARE this layout's
-    // entry arrays, and the directories, sampled levels and 6-byte samples are made from them by kernels (k_build.hip).
-    // Bucket records (RBG_RANK_REC) and RBG_RUNS_HOST_BUILD=1 (A/B, tests) bring them to the host first, as round 2 did:
-    // 43 s of the 53 s this layout took to load at n = 5e10.
-    const char *e_hb = std::getenv("RBG_RUNS_HOST_BUILD");
-    const bool host_build = rank_rec_target() > 0 || (e_hb && e_hb[0] == '1');
-    if (host_build) {
-        const int rcm = materialize_kmer_levels<P>(ix);
-        if (rcm) return rcm;
-    }
-    // (the depth-1 lists compose_on_device left on the device are the slot layout's; this layout packs the depth's tables
-    //  back to back from the host arrays)
-    for (SymTable &t : h.sym) {
-        free_tracked(ix, const_cast<void *>(t.dev_ent));
-        free_tracked(ix, const_cast<void *>(t.dev_samp));
-        t.dev_ent = t.dev_samp = nullptr;
-    }
-    const uint64_t budget_keys = g_opt_tree_top_kb.load() ? static_cast<uint64_t>(g_opt_tree_top_kb.load()) * 1024 / sizeof(P) : 16;
-    const std::vector<SymTable> *depth[kMaxRunDepth] = {&h.sym, &h.pair, &h.triple, &h.quad, &h.quint};
-    uint32_t D = 1;
-    while (D < static_cast<uint32_t>(kMaxRunDepth) && !depth[D]->empty()) ++D;
-    std::vector<uint64_t> sizes;
-    for (uint32_t d = 0; d < D; ++d) {
-        uint64_t entries = 0;
-        for (const SymTable &t : *depth[d]) entries += t.nruns + 1;
-        sizes.push_back(entries);
-    }
-    // entry indices are 32-bit in THIS format's kernels (format 2, the default, has 64-bit ones: upload_tables_runs2).  Until
-    // round 4 a depth with more entries was left out without a word -- and the depth forced in its place could have been
-    // released already; now it is an error that names the way out.  RBG_RUN1_MAX_ENTRIES lowers the limit for the test.
-    const uint64_t max_entries = static_cast<uint64_t>(env_opt("RBG_RUN1_MAX_ENTRIES", 0xFFFFFFF0ll, 16, 0xFFFFFFF0ll));
-    ix->runs_report.fmt = 1;
-    ix->runs_report.depths_composed = D;
-    for (uint32_t d = 0; d < D; ++d)
-        if (sizes[d] >= max_entries && ((ix->run_depth_mask ? ix->run_depth_mask : ~0u) >> d & 1u || d == 0 || d + 1 == D)) {
-            std::fprintf(stderr, "rbg: k-mer depth %u has %llu run-list entries: format 1 of the run-indexed layout holds fewer than %llu per depth; "
-                                 "use format 2 (RBG_OPT_RUN_FMT / RBG_RUN_FMT=2, the default), whose entry indices are 64-bit\n",
-                         d + 1, static_cast<unsigned long long>(sizes[d]), static_cast<unsigned long long>(max_entries));
-            ix->runs_report.depths_dropped_limit |= 1u << d;
-            return RBG_EARG;
-        }
-    // depths without run lists (rbg_index::run_depth_mask; the deepest is always kept: the kernels step by it)
-    uint32_t mask = (ix->run_depth_mask ? ix->run_depth_mask : ~0u) & ((1u << D) - 1u);
-    mask |= 1u | (1u << (D - 1));
-    std::vector<uint64_t> kept_sizes;
-    for (uint32_t d = 0; d < D; ++d)
-        if (mask >> d & 1u) kept_sizes.push_back(sizes[d]);
-    const char *e_rdir = std::getenv("RBG_RANK_DIR");   // "0": ranks by the descent only (A/B measurements, tests)
-    const bool use_dirs = !(e_rdir && e_rdir[0] == '0');
-    const double rec_target = rank_rec_target();   // bucket records (rbg_dev.h RunRec)
-    // RBG_RANK_DIR_RUNS: runs per directory bucket at most this on average (default 4; a directory entry is 4 bytes per bucket)
-    const char *e_dt = std::getenv("RBG_RANK_DIR_RUNS");
-    const double dir_target = e_dt && std::atof(e_dt) > 0 ? std::atof(e_dt) : 4.0;
-    const bool use_recs = rec_target > 0;
-    // with the directories the descent is the rare path: half the LDS for its top level leaves room for the table records
-    const uint32_t nlvl = tree_levels_for(kept_sizes, use_dirs && budget_keys > 64 ? std::max<uint64_t>(64, budget_keys / 2) : budget_keys);
-    if (nlvl > kMaxTreeLevels) return RBG_EARG;
-    std::vector<DevSym> syms(h.sym.size());
-    std::vector<DevTree> trees(D);
-    std::vector<DevRunTab> tabs;
-    std::vector<P> top_all;
-    int rc;
-    for (uint32_t d = 0; d < D; ++d) {
-        // the depth's tables back to back: entries {start, cum} (each table ends with its sentinel {n, total}), samples alongside
-        const std::vector<SymTable> &T = *depth[d];
-        const uint64_t entries = sizes[d];
-        if (!(mask >> d & 1u)) {   // no run lists at this depth: no records, nothing to step by
-            release_kmer_level(ix, d + 1);
-            for (SymTable &st : kmer_level_tables(h, d + 1)) st.dev_ent = st.dev_samp = nullptr;
-            ix->dev.run_samp[d] = nullptr;
-            ix->dev.run_dir[d] = nullptr;
-            ix->dev.run_rec[d] = nullptr;
-            ix->dev.run_tab_first[d] = static_cast<uint32_t>(tabs.size());
-            trees[d] = DevTree{};
-            continue;
-        }
-        ComposedLevel *L = (d >= 1 && d - 1 < ix->kmer_levels.size() && ix->kmer_levels[d - 1].ent) ? &ix->kmer_levels[d - 1] : nullptr;
-        if (L) {   // ---- the level is on the device already ----
-            if (L->entries != entries || L->first.size() != T.size()) return RBG_EARG;
-            typedef RunsFmt<P> Fmt;
-            const void *d_ent = L->ent, *d_samp = nullptr;
-            if (h.has_tsa) {
-                if (sizeof(P) == 4) {
-                    d_samp = L->samp;
-                } else {
-                    void *packed = nullptr;
-                    if ((rc = dev_reserve(ix, entries * Fmt::samp_bytes + 8, &packed))) return rc;
-                    HIP_TRY(static_cast<hipError_t>(launch_pack_samp48(static_cast<const uint64_t *>(L->samp), entries, packed, nullptr)));
-                    HIP_TRY(hipDeviceSynchronize());
-                    free_tracked(ix, L->samp);
-                    d_samp = packed;
-                }
-            }
-            L->ent = L->samp = nullptr;   // (adopted: the index's allocation list keeps them)
-            ix->dev.run_samp[d] = d_samp;
-            ix->dev.run_tab_first[d] = static_cast<uint32_t>(tabs.size());
-            ix->dev.run_rec[d] = nullptr;
-            std::vector<uint32_t> dshift(T.size(), 0);
-            std::vector<uint64_t> doff(T.size() + 1, 0), nr(T.size());
-            for (size_t t = 0; t < T.size(); ++t) {
-                uint32_t sh = 0;
-                const double runs = static_cast<double>(std::max<uint64_t>(1, T[t].nruns));
-                while (sh < 40 && runs * static_cast<double>(uint64_t(2) << sh) <= dir_target * static_cast<double>(h.n)) ++sh;
-                dshift[t] = sh;
-                doff[t + 1] = doff[t] + (h.n >> sh) + 2;
-                nr[t] = T[t].nruns;
-            }
-            const bool with_dir = use_dirs && doff[T.size()] < 0xFFFFFFF0ull;
-            ix->dev.run_dir[d] = nullptr;
-            if (with_dir) {
-                void *dp = nullptr, *tmp = nullptr;
-                if ((rc = dev_reserve(ix, doff[T.size()] * 4, &dp))) return rc;
-                const size_t nt = T.size(), bytes = (3 * nt + 1) * 8 + nt * 4;
-                HIP_TRY(hipMalloc(&tmp, bytes));
-                uint64_t *t_first = static_cast<uint64_t *>(tmp), *t_nr = t_first + nt, *t_doff = t_nr + nt;
-                uint32_t *t_sh = reinterpret_cast<uint32_t *>(t_doff + nt + 1);
-                hipError_t e = hipMemcpy(t_first, L->first.data(), nt * 8, hipMemcpyHostToDevice);
-                if (e == hipSuccess) e = hipMemcpy(t_nr, nr.data(), nt * 8, hipMemcpyHostToDevice);
-                if (e == hipSuccess) e = hipMemcpy(t_doff, doff.data(), (nt + 1) * 8, hipMemcpyHostToDevice);
-                if (e == hipSuccess) e = hipMemcpy(t_sh, dshift.data(), nt * 4, hipMemcpyHostToDevice);
-                if (e == hipSuccess) e = static_cast<hipError_t>(launch_run_dirs(sizeof(P), d_ent, t_first, t_nr, t_doff, t_sh, static_cast<uint32_t>(nt), doff[nt], static_cast<uint32_t *>(dp), nullptr));
-                if (e == hipSuccess) e = hipDeviceSynchronize();
-                (void)hipFree(tmp);
-                HIP_TRY(e);
-                ix->dev.run_dir[d] = static_cast<const uint32_t *>(dp);
-            }
-            for (size_t t = 0; t < T.size(); ++t)
-                tabs.push_back(DevRunTab{T[t].F, L->first[t], with_dir ? static_cast<uint32_t>(doff[t]) : 0u, with_dir ? dshift[t] : 0u});
-            tabs.push_back(DevRunTab{0, entries, 0u, 0u});   // closing record: the last table's slice ends here
-            if ((rc = upload_tree_dev<P>(ix, d_ent, entries - 1, nlvl, top_all, trees[d]))) return rc;
-            continue;
-        }
-        // (rbg_dev.h RunsFmt: 8-byte pairs + 4-byte samples, or 12-byte entries + 6-byte samples at 8-byte positions; spare
-        //  entries after the last sentinel: the kernels' two- and four-entry loads may touch them)
-        typedef RunsFmt<P> Fmt;
-        HostBuf<unsigned char> ent((entries + Fmt::spare) * Fmt::ent_bytes);   // (every byte is written below)
-        HostBuf<unsigned char> samp(h.has_tsa ? entries * Fmt::samp_bytes + 8 : 0);
-        if (samp.size()) std::memset(samp.data() + samp.size() - 8, 0, 8);
-        std::vector<uint64_t> first(T.size() + 1, 0);
-        for (size_t t = 0; t < T.size(); ++t) first[t + 1] = first[t] + T[t].nruns + 1;
-        {
-            const size_t W = std::max<size_t>(1, std::min<size_t>({16, std::thread::hardware_concurrency(), T.size()}));
-            std::vector<std::thread> workers;
-            for (size_t w = 0; w < W; ++w)
-                workers.emplace_back([&, w] {
-                    for (size_t t = w; t < T.size(); t += W) {
-                        const SymTable &tb = T[t];
-                        for (uint64_t k = 0; k <= tb.nruns; ++k) Fmt::put_ent(ent.data(), first[t] + k, tb.start[k], tb.cum[k]);
-                        if (t + 1 == T.size())
-                            for (size_t x = 1; x <= Fmt::spare; ++x) Fmt::put_ent(ent.data(), first[t] + tb.nruns + x, tb.start[tb.nruns], tb.cum[tb.nruns]);
-                        if (h.has_tsa) {
-                            for (uint64_t k = 0; k < tb.nruns; ++k) Fmt::put_samp(samp.data(), first[t] + k, tb.samp[k]);
-                            Fmt::put_samp(samp.data(), first[t] + tb.nruns, 0);
-                        }
-                    }
-                });
-            for (auto &w : workers) w.join();
-        }
-        const void *d_ent = nullptr, *d_samp = nullptr;
-        if ((rc = dev_upload(ix, ent.data(), ent.size(), &d_ent))) return rc;
-        if (h.has_tsa && (rc = dev_upload(ix, samp.data(), samp.size(), &d_samp))) return rc;
-        ix->dev.run_samp[d] = d_samp;
-        ix->dev.run_tab_first[d] = static_cast<uint32_t>(tabs.size());
-        // the tables' directories (rbg_dev.h DevRunTab): per table the widest bucket that still holds at most about
-        // four runs on average
-        std::vector<uint32_t> dshift(T.size(), 0);
-        std::vector<uint64_t> doff(T.size() + 1, 0);
-        for (size_t t = 0; t < T.size(); ++t) {
-            uint32_t sh = 0;
-            const double runs = static_cast<double>(std::max<uint64_t>(1, T[t].nruns));
-            while (sh < 40 && runs * static_cast<double>(uint64_t(2) << sh) <= dir_target * static_cast<double>(h.n)) ++sh;
-            dshift[t] = sh;
-            doff[t + 1] = doff[t] + (h.n >> sh) + 2;
-        }
-        // bucket records (rbg_dev.h RunRec): per table the widest bucket that holds at most rec_target runs on average
-        std::vector<uint32_t> rshift(T.size(), 0);
-        std::vector<uint64_t> roff(T.size() + 1, 0);
-        for (size_t t = 0; t < T.size(); ++t) {
-            uint32_t sh = 0;
-            const double runs = static_cast<double>(std::max<uint64_t>(1, T[t].nruns));
-            while (sh < kRecMaxShift && runs * static_cast<double>(uint64_t(2) << sh) <= rec_target * static_cast<double>(h.n)) ++sh;
-            rshift[t] = sh;
-            roff[t + 1] = roff[t] + (h.n >> sh) + 1;
-        }
-        const bool with_rec = use_recs && roff[T.size()] < 0xFFFFFFF0ull;
-        ix->dev.run_rec[d] = nullptr;
-        if (with_rec) {
-            std::vector<RunRec> recs(roff[T.size()]);
-            const size_t W = std::max<size_t>(1, std::min<size_t>({16, std::thread::hardware_concurrency(), T.size()}));
-            std::vector<std::thread> workers;
-            for (size_t w = 0; w < W; ++w)
-                workers.emplace_back([&, w] {
-                    for (size_t t = w; t < T.size(); t += W) {
-                        const SymTable &tb = T[t];
-                        RunRec *rt = recs.data() + roff[t];
-                        const uint64_t nb = roff[t + 1] - roff[t], width = uint64_t(1) << rshift[t];
-                        // entries 0 .. nruns of the table (the last is its sentinel {n, total}, a run of length 0)
-                        auto len_of = [&](uint64_t j) { return j < tb.nruns ? tb.cum[j + 1] - tb.cum[j] : uint64_t(0); };
-                        uint64_t g = 0;   // # entries that start below the bucket
-                        for (uint64_t b = 0; b < nb; ++b) {
-                            const uint64_t B = b << rshift[t];
-                            while (g <= tb.nruns && tb.start[g] < B) ++g;
-                            uint64_t e = g;   // entries that start inside the bucket: [g, e)
-                            while (e <= tb.nruns && tb.start[e] - B < width) ++e;
-                            const bool has_pred = g > 0;
-                            const uint64_t k = (has_pred ? 1 : 0) + (e - g);
-                            RunRec &r = rt[b];
-                            r.e0 = static_cast<uint32_t>(first[t] + (has_pred ? g - 1 : 0));
-                            r.base = 0;
-                            if (k > static_cast<uint64_t>(kRecRuns)) {
-                                r.flags = kRecOverflow | static_cast<uint32_t>(k);
-                                for (auto &pr : r.pair) pr = RunRecPair{kRecNoPair, 0};
-                                continue;
-                            }
-                            // cl: occurrences before the pair's run -- from `base` at 8-byte positions, absolute at 4-byte ones
-                            uint32_t np = 0;
-                            uint64_t cl = 0;   // relative to base
-                            uint64_t base = 0;
-                            if (has_pred) {
-                                const uint64_t gone = B - tb.start[g - 1], len = len_of(g - 1), used = std::min(gone, len);
-                                base = tb.cum[g - 1] + used;
-                                // the run continues into the bucket (or ends exactly at B): one position and one occurrence are
-                                // lent to the pair (off = -1); it ended earlier: an empty run
-                                const bool ended = gone > len;
-                                r.pair[np++] = RunRecPair{kRecPred, static_cast<uint32_t>((sizeof(P) == 4 ? base : 0) - (ended ? 0 : 1))};
-                                cl = std::min(len - used, width);
-                            }
-                            r.base = base;
-                            for (uint64_t j = g; j < e; ++j) {
-                                const uint64_t off = tb.start[j] - B;
-                                r.pair[np++] = RunRecPair{static_cast<uint32_t>(off), static_cast<uint32_t>((sizeof(P) == 4 ? base : 0) + cl)};
-                                cl += std::min(len_of(j), width - off);
-                            }
-                            for (; np <= static_cast<uint32_t>(kRecRuns); ++np) r.pair[np] = RunRecPair{kRecNoPair, static_cast<uint32_t>((sizeof(P) == 4 ? base : 0) + cl)};
-                            r.flags = static_cast<uint32_t>(k);
-                        }
-                    }
-                });
-            for (auto &w : workers) w.join();
-            const void *rp = nullptr;
-            if ((rc = dev_upload(ix, recs.data(), recs.size() * sizeof(RunRec), &rp))) return rc;
-            ix->dev.run_rec[d] = static_cast<const RunRec *>(rp);
-        }
-        // (with records the main kernels need no directory; the per-lane kernels use the first depth's)
-        const bool with_dir = use_dirs && (d == 0 || !with_rec) && doff[T.size()] < 0xFFFFFFF0ull;
-        ix->dev.run_dir[d] = nullptr;
-        if (with_dir) {
-            std::vector<uint32_t> dir(doff[T.size()]);
-            const size_t W = std::max<size_t>(1, std::min<size_t>({16, std::thread::hardware_concurrency(), T.size()}));
-            std::vector<std::thread> workers;
-            for (size_t w = 0; w < W; ++w)
-                workers.emplace_back([&, w] {
-                    for (size_t t = w; t < T.size(); t += W) {
-                        const SymTable &tb = T[t];
-                        uint32_t *dt = dir.data() + doff[t];
-                        const uint64_t nb = doff[t + 1] - doff[t];
-                        uint64_t g = 0;
-                        for (uint64_t b = 0; b < nb; ++b) {
-                            const uint64_t lim = b << dshift[t];
-                            while (g < tb.nruns && tb.start[g] < lim) ++g;
-                            dt[b] = static_cast<uint32_t>(g);
-                        }
-                    }
-                });
-            for (auto &w : workers) w.join();
-            const void *dp = nullptr;
-            if ((rc = dev_upload(ix, dir.data(), dir.size() * 4, &dp))) return rc;
-            ix->dev.run_dir[d] = static_cast<const uint32_t *>(dp);
-        }
-        for (size_t t = 0; t < T.size(); ++t)
-            tabs.push_back(with_rec ? DevRunTab{T[t].F, first[t], static_cast<uint32_t>(roff[t]), rshift[t]}
-                                    : DevRunTab{T[t].F, first[t], with_dir ? static_cast<uint32_t>(doff[t]) : 0u, with_dir ? dshift[t] : 0u});
-        tabs.push_back(DevRunTab{0, entries, 0u, 0u});   // closing record: the last table's slice ends here
-        {
-            // key of entry j of the depth's concatenated lists
-            auto key_at = [&](uint64_t j) {
-                const size_t t = static_cast<size_t>(std::upper_bound(first.begin(), first.end(), j) - first.begin()) - 1;
-                return T[t].start[j - first[t]];
-            };
-            if ((rc = upload_tree<P>(ix, d_ent, entries - 1, key_at, nlvl, top_all, trees[d]))) return rc;
-        }
-        if (d == 0)   // the per-lane kernels (seeding, windowed markers, single LF steps) search a symbol's own slice
-            for (size_t t = 0; t < T.size(); ++t) {
-                DevSym &r = syms[t];
-                r = DevSym{};
-                r.ent = static_cast<const char *>(d_ent) + first[t] * Fmt::ent_bytes;
-                r.samp = d_samp ? static_cast<const char *>(d_samp) + first[t] * Fmt::samp_bytes : nullptr;
-                r.F = T[t].F;
-                r.shift = with_dir ? dshift[t] : 0;    // with slots == nullptr: ord / shift are the symbol's directory (rank_runs_lane)
-                r.ord = with_dir ? ix->dev.run_dir[0] + doff[t] : nullptr;
-                r.nruns = static_cast<uint32_t>(T[t].nruns);
-            }
-    }
-    for (uint32_t d = 2; d <= 5; ++d) release_kmer_level(ix, d);   // (levels beyond D, or left over: nothing points at them)
-    ix->dev.run_tab_first[D] = static_cast<uint32_t>(tabs.size());
-    for (uint32_t d = D + 1; d <= static_cast<uint32_t>(kMaxRunDepth); ++d) ix->dev.run_tab_first[d] = static_cast<uint32_t>(tabs.size());
-    if (tabs.size() > static_cast<size_t>(kMaxRunTabs)) return RBG_EARG;
-    const void *p = nullptr;
-    if ((rc = dev_upload(ix, syms.data(), syms.size() * sizeof(DevSym), &p))) return rc;
-    ix->dev.syms = static_cast<const DevSym *>(p);
-    ix->ptr_tables.push_back({p, syms.size(), sizeof(DevSym), {offsetof(DevSym, ent), offsetof(DevSym, samp), offsetof(DevSym, slots), offsetof(DevSym, ord)}});
-    if ((rc = dev_upload(ix, trees.data(), trees.size() * sizeof(DevTree), &p))) return rc;
-    ix->dev.trees = static_cast<const DevTree *>(p);
-    {
-        std::vector<size_t> offs{offsetof(DevTree, ent)};
-        for (int l = 0; l < kMaxTreeLevels; ++l) offs.push_back(offsetof(DevTree, lvl) + 8 * static_cast<size_t>(l));
-        ix->ptr_tables.push_back({p, trees.size(), sizeof(DevTree), offs});
-    }
-    if ((rc = dev_upload(ix, tabs.data(), tabs.size() * sizeof(DevRunTab), &p))) return rc;
-    ix->dev.run_tabs = static_cast<const DevRunTab *>(p);
-    ix->dev.run_ntabs = static_cast<uint32_t>(tabs.size());
-    ix->dev.run_ksteps = D;
-    ix->dev.run_depth_mask = mask;
-    ix->run_depth_mask = mask;
-    ix->runs_report.depth_mask_kept = mask;
-    for (uint32_t d = 0; d < D; ++d)
-        if (mask >> d & 1u) { ix->runs_report.entries[d] = sizes[d]; ix->runs_report.rank_dirs |= ix->dev.run_dir[d] ? 1u : 0u; }
-    if ((rc = dev_upload(ix, top_all.data(), top_all.size() * sizeof(P), &ix->dev.tree_top))) return rc;
-    ix->dev.tree_top_n = static_cast<uint32_t>(top_all.size());
-    ix->dev.tree_nlvl = nlvl;
-    ix->dev.layout = RBG_LAYOUT_RUNS;
-    ix->dev.kmer_steps = 1;   // (the per-lane kernels take single steps in this layout)
-    ix->dev.nmajor = 0;
-    if (h.nmajor >= 2) {  // the ftab's word index and the k-mer table index need the major alphabet
-        if ((rc = dev_upload(ix, h.major_of, 256, &p))) return rc;
-        ix->dev.lut2 = static_cast<const uint8_t *>(p);
-        ix->dev.nmajor = h.nmajor;
-    }
-    if (h.has_tsa) {
-        typedef PhiFmt<P> Fmt;
-        HostBuf<unsigned char> pe((h.r + 1 + Fmt::spare) * Fmt::ent_bytes);   // (the sentinel and the spare entries after it)
-        parallel_for(h.r, [&](uint64_t a, uint64_t b, unsigned) {
-            for (uint64_t j = a; j < b; ++j) Fmt::put_ent(pe.data(), j, h.pred_pos[j], h.phi_base[j]);
-        });
-        for (size_t x = 0; x <= Fmt::spare; ++x) Fmt::put_ent(pe.data(), h.r + x, h.n, 0);  // sentinel: never below a query
-        if ((rc = dev_upload(ix, pe.data(), pe.size(), &ix->dev.phi_ent))) return rc;
-        // (k_locate_fill_runs stages 26-43 KB of values per workgroup besides the top level: 8 KB of it keeps four
-        //  workgroups per CU -- 32 ms per 10 M reads on the bench index against 44 ms with a 48 KB top level)
-        const uint32_t pl = tree_levels_for({h.r}, std::min<uint64_t>(budget_keys, 8192 / sizeof(P)));
-        if (pl > kMaxTreeLevels) return RBG_EARG;
-        std::vector<P> ptop;
-        if ((rc = upload_tree<P>(ix, ix->dev.phi_ent, h.r, [&](uint64_t j) { return h.pred_pos[j]; }, pl, ptop, ix->dev.phi_tree))) return rc;
-        if ((rc = dev_upload(ix, ptop.data(), ptop.size() * sizeof(P), &ix->dev.phi_top))) return rc;
-        ix->dev.phi_nlvl = pl;
-        ix->dev.phi_slots = nullptr;
-        ix->dev.phi_ord = nullptr;
-        // the directory (rbg_dev.h phi_dir): two to four sampled positions per bucket; n / 2^shift * 4 bytes, which is a
-        // few per cent of the run lists (61 MB beside 4.2 GB on the bench index); left out beyond 2 GiB
-        ix->dev.phi_dir = nullptr;
-        ix->dev.phi_dir_shift = 0;
-        uint32_t ds = 4;
-        while (ds < 24 && (static_cast<double>(h.r) * static_cast<double>(uint64_t(1) << ds)) / static_cast<double>(h.n) < 2.0) ++ds;
-        const uint64_t nd = (h.n >> ds) + 2;
-        const char *e_dir = std::getenv("RBG_PHI_DIR");   // "0": descent only (A/B measurements, tests)
-        const uint64_t dir_max = static_cast<uint64_t>(env_opt("RBG_PHI1_DIR_MAX_BYTES", int64_t(2) << 30, 16, int64_t(2) << 30));   // (lowered by the test of the line below)
-        if (nd * 4 <= dir_max && h.r < 0x7FFFFFF0ull && !(e_dir && e_dir[0] == '0')) {
-            std::vector<uint32_t> dir(nd);
-            uint64_t g = 0;
-            for (uint64_t b = 0; b < nd; ++b) {
-                const uint64_t lim = b << ds;
-                while (g < h.r && h.pred_pos[g] < lim) ++g;
-                dir[b] = static_cast<uint32_t>(g);
-            }
-            const void *dp = nullptr;
-            if ((rc = dev_upload(ix, dir.data(), dir.size() * 4, &dp))) return rc;
-            ix->dev.phi_dir = static_cast<const uint32_t *>(dp);
-            ix->dev.phi_dir_shift = ds;
-            ix->runs_report.phi_dir = 1;
-            ix->runs_report.phi_dir_bytes = nd * 4;
-            ix->runs_report.phi_dir_shift = ds;
-        } else if (!(e_dir && e_dir[0] == '0')) {
-            std::fprintf(stderr, "rbg: format 1 of the run-indexed layout leaves the phi directory out beyond 2 GiB or r >= 2^31 (%.2f GB, r = %llu): phi descends "
-                                 "the sampled levels, several times slower; format 2 (RBG_RUN_FMT=2, the default) has no such limit\n",
-                         nd * 4 / 1e9, static_cast<unsigned long long>(h.r));
-            ix->runs_report.phi_dir_dropped = 1;
-        }
-        ix->runs_report.phi_entries = h.r;
-    }
-    HIP_TRY(hipDeviceSynchronize());
-    return RBG_OK;
-}
-
-
-// ---- FORMAT 2 of the run-indexed layout (rbg_dev.h DevRunTab2; kernels: rbg_runs2_device.hpp) ----------------------------
-// Same inputs as upload_tables_runs: the depth-1 tables of the host index and the k-mer levels composed on the device.
+// ---- the run-indexed layout (rbg_dev.h DevRunTab2; kernels: rbg_runs2_device.hpp) ---------------------------------------
+// Inputs: the depth-1 tables of the host index and the k-mer levels composed on the device.
 // Everything but the conversion of the depth-1 lists happens in kernels (k_build.hip): fillers (8-byte positions, only
 // where a table has a gap of 2^30 rows or more), the low-word pairs, the directories, the phi list, its directory and
 // super counts.  Nothing is left out for its size: entry indices are 64-bit, a table may hold up to 2^32 - 16 entries
@@ -1212,7 +691,9 @@ int upload_tables_runs2(rbg_index *ix) {
         free_tracked(ix, const_cast<void *>(t.dev_samp));
         t.dev_ent = t.dev_samp = nullptr;
     }
-    const std::vector<SymTable> *depth[kMaxRunDepth] = {&h.sym, &h.pair, &h.triple, &h.quad, &h.quint};
+    const std::vector<SymTable> *depth[kMaxRunDepth];
+    depth[0] = &h.sym;
+    for (uint32_t d = 2; d <= static_cast<uint32_t>(kMaxRunDepth); ++d) depth[d - 1] = &h.kmer(d);
     uint32_t D = 1;
     while (D < static_cast<uint32_t>(kMaxRunDepth) && !depth[D]->empty()) ++D;
     rep.depths_composed = D;
@@ -1250,12 +731,11 @@ int upload_tables_runs2(rbg_index *ix) {
         use_recs = with_recs <= 0.5 * static_cast<double>(ix->hbm_budget) && nrec <= entries_kept;
     }
     std::vector<DevRunTab2> tabs;
-    std::vector<DevRunTab> tabs1;   // (format 1's records of the same tables: rbg_info and the peer copies expect the array)
     int rc;
     for (uint32_t d = 0; d < D; ++d) {
         const std::vector<SymTable> &T = *depth[d];
         ix->dev.run_tab_first[d] = static_cast<uint32_t>(tabs.size());
-        ix->dev.run_samp[d] = nullptr; ix->dev.run_dir[d] = nullptr; ix->dev.run_rec[d] = nullptr;
+        ix->dev.run_samp[d] = nullptr;
         ix->dev.run_ent2[d] = nullptr; ix->dev.run_dir2[d] = nullptr;
         if (!(mask >> d & 1u)) {   // no run lists at this depth: nothing steps by it
             release_kmer_level(ix, d + 1);
@@ -1399,7 +879,6 @@ int upload_tables_runs2(rbg_index *ix) {
         } else {
             ix->dev.run_ent2[d] = abs_ent;
             ix->dev.run_samp[d] = abs_samp;
-            ix->dev.run_dir[d] = use_recs ? nullptr : static_cast<const uint32_t *>(dirp);   // (format 1's kernels could read the same arrays)
         }
         if (std::getenv("RBG_VERBOSE")) {
             size_t f = 0, tt = 0;
@@ -1409,14 +888,12 @@ int upload_tables_runs2(rbg_index *ix) {
         }
         for (size_t t = 0; t < T.size(); ++t) {
             tabs.push_back(DevRunTab2{T[t].F, first[t], doff[t], dshift[t], 0u});
-            tabs1.push_back(DevRunTab{T[t].F, first[t], static_cast<uint32_t>(std::min<uint64_t>(doff[t], 0xFFFFFFFFull)), dshift[t]});
         }
         tabs.push_back(DevRunTab2{0, E2, 0, 0u, 0u});   // closing record
-        tabs1.push_back(DevRunTab{0, E2, 0u, 0u});
     }
-    for (uint32_t d = 2; d <= 5; ++d) release_kmer_level(ix, d);   // (levels beyond D, or left over: nothing points at them)
+    for (uint32_t d = 2; d <= static_cast<uint32_t>(kMaxKmerDepth); ++d) release_kmer_level(ix, d);   // (levels beyond D, or left over: nothing points at them)
     for (uint32_t d = D; d <= static_cast<uint32_t>(kMaxRunDepth); ++d) ix->dev.run_tab_first[d] = static_cast<uint32_t>(tabs.size());
-    if (tabs.size() > static_cast<size_t>(kMaxRunTabs)) return RBG_EARG;
+    if (ix->dev.run_tab_first[std::min<uint32_t>(D, kLdsRunDepth)] > static_cast<uint32_t>(kMaxLdsRunTabs)) return RBG_EARG;
     const void *p = nullptr;
     std::vector<DevSym> syms(h.sym.size());   // (no kernel reads a symbol record on this format: F only, for rbg_get_f-style readers)
     for (size_t t = 0; t < syms.size(); ++t) { syms[t] = DevSym{}; syms[t].F = h.sym[t].F; syms[t].nruns = static_cast<uint32_t>(std::min<uint64_t>(h.sym[t].nruns, 0xFFFFFFFFull)); }
@@ -1424,20 +901,13 @@ int upload_tables_runs2(rbg_index *ix) {
     ix->dev.syms = static_cast<const DevSym *>(p);
     if ((rc = dev_upload(ix, tabs.data(), tabs.size() * sizeof(DevRunTab2), &p))) return rc;
     ix->dev.run_tabs2 = static_cast<const DevRunTab2 *>(p);
-    if ((rc = dev_upload(ix, tabs1.data(), tabs1.size() * sizeof(DevRunTab), &p))) return rc;
-    ix->dev.run_tabs = static_cast<const DevRunTab *>(p);
     ix->dev.run_ntabs = static_cast<uint32_t>(tabs.size());
     ix->dev.run_ksteps = D;
     ix->dev.run_depth_mask = mask;
     ix->run_depth_mask = mask;
     rep.depth_mask_kept = mask;
     rep.rank_dirs = use_recs ? 0 : 1;
-    ix->dev.trees = nullptr;
-    ix->dev.tree_top = nullptr;
-    ix->dev.tree_top_n = 0;
-    ix->dev.tree_nlvl = 0;
     ix->dev.layout = RBG_LAYOUT_RUNS;
-    ix->dev.run_fmt = 2;
     ix->dev.kmer_steps = 1;
     ix->dev.nmajor = 0;
     if (h.nmajor >= 2) {  // the ftab's word index and the k-mer table index need the major alphabet
@@ -1445,9 +915,6 @@ int upload_tables_runs2(rbg_index *ix) {
         ix->dev.lut2 = static_cast<const uint8_t *>(p);
         ix->dev.nmajor = h.nmajor;
     }
-    ix->dev.phi_tree = DevTree{};
-    ix->dev.phi_top = nullptr;
-    ix->dev.phi_nlvl = 0;
     ix->dev.phi_slots = nullptr;
     ix->dev.phi_ord = nullptr;
     ix->dev.phi_dir = nullptr;
@@ -1612,8 +1079,8 @@ void release_kmer_level(rbg_index *ix, uint32_t depth) {
     }
     L = ComposedLevel();
 }
-std::vector<SymTable> &kmer_level_tables(HostIndex &h, uint32_t depth) { return depth == 2 ? h.pair : depth == 3 ? h.triple : depth == 4 ? h.quad : h.quint; }
-uint32_t depth_of_level(const HostIndex &h, const std::vector<SymTable> *lvl) { return lvl == &h.pair ? 2 : lvl == &h.triple ? 3 : lvl == &h.quad ? 4 : 5; }
+std::vector<SymTable> &kmer_level_tables(HostIndex &h, uint32_t depth) { return h.kmer(depth); }
+uint32_t depth_of_level(const HostIndex &h, const std::vector<SymTable> *lvl) { return static_cast<uint32_t>(lvl - h.kmer_lv) + 2u; }
 void drop_kmer_level(rbg_index *ix, std::vector<SymTable> &lvl) {
     release_kmer_level(ix, depth_of_level(ix->H(), &lvl));
     std::vector<SymTable>().swap(lvl);
@@ -1638,7 +1105,7 @@ int compose_on_device(rbg_index *ix) {
     for (uint32_t K = K0; K >= 2; --K) {
         // (a pass that failed partway -- the host fallback included -- must leave nothing of a deeper level behind: levels() and
         //  level_has_data() count what they find)
-        for (uint32_t d = 2; d <= 5; ++d) { release_kmer_level(ix, d); std::vector<SymTable>().swap(kmer_level_tables(h, d)); }
+        for (uint32_t d = 2; d <= static_cast<uint32_t>(kMaxKmerDepth); ++d) { release_kmer_level(ix, d); std::vector<SymTable>().swap(kmer_level_tables(h, d)); }
         ix->kmer_levels.clear();
         ix->runs_forced = false;
         const int rc = compose_on_device_k<P>(ix, K);
@@ -1715,9 +1182,7 @@ int compose_on_device_k(rbg_index *ix, const uint32_t K) {
             }
         }
         if (runs_certain && h.sigma <= static_cast<uint32_t>(kLdsSyms)) {
-            keep_mask = g_opt_run_depths.load() ? static_cast<uint32_t>(g_opt_run_depths.load()) | 1u : 1u;
-            if (!g_opt_run_depths.load())
-                for (int d = static_cast<int>(K); d >= 1; d -= 2) keep_mask |= 1u << (d - 1);
+            keep_mask = g_opt_run_depths.load() ? static_cast<uint32_t>(g_opt_run_depths.load()) | 1u : default_depth_mask(K);
             keep_mask |= 1u << (K - 1);
         }
     }
@@ -1804,48 +1269,17 @@ int compose_on_device_k(rbg_index *ix, const uint32_t K) {
     return RBG_OK;
 }
 
-// the run-indexed layout builds its directories and sampled levels on the host: bring the composed levels back as host
-// tables (and give their device arrays back; upload_tables_runs uploads its own)
-template <typename P>
-int materialize_kmer_levels(rbg_index *ix) {
-    HostIndex &h = ix->H();
-    for (uint32_t d = 2; d <= 5; ++d) {
-        if (d - 2 >= ix->kmer_levels.size() || !ix->kmer_levels[d - 2].ent) continue;
-        ComposedLevel &L = ix->kmer_levels[d - 2];
-        std::vector<SymTable> &tabs = kmer_level_tables(h, d);
-        if (tabs.empty() || (ix->run_depth_mask && !(ix->run_depth_mask >> (d - 1) & 1u))) { release_kmer_level(ix, d); continue; }
-        std::vector<RunEnt<P>> ent(L.entries);
-        std::vector<P> samp(L.samp ? L.entries : 0);
-        HIP_TRY(hipMemcpy(ent.data(), L.ent, L.entries * sizeof(RunEnt<P>), hipMemcpyDeviceToHost));
-        if (L.samp) HIP_TRY(hipMemcpy(samp.data(), L.samp, L.entries * sizeof(P), hipMemcpyDeviceToHost));
-        const size_t W = std::max<size_t>(1, std::min<size_t>({16, std::thread::hardware_concurrency(), tabs.size()}));
-        std::vector<std::thread> workers;
-        for (size_t w = 0; w < W; ++w)
-            workers.emplace_back([&, w] {
-                for (size_t t = w; t < tabs.size(); t += W) {
-                    SymTable &st = tabs[t];
-                    const uint64_t f = L.first[t];
-                    st.start.resize(st.nruns + 1); st.cum.resize(st.nruns + 1);
-                    for (uint64_t k = 0; k <= st.nruns; ++k) { st.start[k] = ent[f + k].start; st.cum[k] = ent[f + k].cum; }
-                    if (L.samp) { st.samp.resize(st.nruns); for (uint64_t k = 0; k < st.nruns; ++k) st.samp[k] = samp[f + k]; }
-                    st.dev_ent = st.dev_samp = nullptr;
-                }
-            });
-        for (auto &w : workers) w.join();
-        release_kmer_level(ix, d);
-    }
-    return RBG_OK;
-}
-
 // does k-mer depth d (2..5) still have its run lists -- on the host, or composed on the device and not given back?
 bool level_has_data(const rbg_index *ix, uint32_t d) {
-    const std::vector<SymTable> &T = d == 2 ? ix->H().pair : d == 3 ? ix->H().triple : d == 4 ? ix->H().quad : ix->H().quint;
+    const std::vector<SymTable> &T = ix->H().kmer(d);
     if (T.empty()) return false;
     if (d - 2 < ix->kmer_levels.size() && ix->kmer_levels[d - 2].ent) return true;
     for (const SymTable &t : T)
         if (t.start.size() == t.nruns + 1) return true;
     return false;
 }
+
+inline int levels_of(const HostIndex &h) { return static_cast<int>(h.kmer_levels()); }
 
 int upload(rbg_index *ix) {
     int ndev = 0;
@@ -1889,10 +1323,10 @@ int upload(rbg_index *ix) {
     if (!runs_layout && layout_automatic()) {
         size_t lvl1 = 0;  // the single-symbol level alone
         {
-            std::vector<SymTable> p2, p3, p4, p5;
-            p2.swap(h.pair); p3.swap(h.triple); p4.swap(h.quad); p5.swap(h.quint);
+            std::vector<SymTable> held[kMaxKmerDepth - 1];
+            for (uint32_t d = 2; d <= static_cast<uint32_t>(kMaxKmerDepth); ++d) held[d - 2].swap(h.kmer(d));
             lvl1 = need();
-            p2.swap(h.pair); p3.swap(h.triple); p4.swap(h.quad); p5.swap(h.quint);
+            for (uint32_t d = 2; d <= static_cast<uint32_t>(kMaxKmerDepth); ++d) held[d - 2].swap(h.kmer(d));
         }
         runs_layout = lvl1 > budget;
     }
@@ -1901,8 +1335,8 @@ int upload(rbg_index *ix) {
     // layout keeps every level at full speed instead, while it fits (about 110 bytes per run at its leanest).  Measured on the bench
     // index at the default budget: 1.13e9 reads/s from the 70 GB of five symbols in wide buckets, 1.14e9 from the 59 GB of four
     // symbols, 1.23e9 from the 8.7 GB of this layout (profiles/r04_bench.json space_speed / value_library_default).
-    if (!runs_layout && g_opt_rank_layout.load() == RBG_LAYOUT_AUTO && !h.pair.empty() && h.sigma <= static_cast<uint32_t>(kLdsSyms) &&
-        g_opt_slot_bytes.load() != 64 && need() > budget && 110.0 * static_cast<double>(h.r) <= static_cast<double>(budget)) {
+    if (!runs_layout && g_opt_rank_layout.load() == RBG_LAYOUT_AUTO && !h.kmer(2).empty() && h.sigma <= static_cast<uint32_t>(kLdsSyms) &&
+        need() > budget && 110.0 * static_cast<double>(h.r) <= static_cast<double>(budget)) {
         if (std::getenv("RBG_VERBOSE"))
             std::fprintf(stderr, "rbg: device %d: the slot tables of all k-mer levels (%.1f GB) exceed the %.1f GB replica budget: the run-indexed layout instead of "
                                  "wider buckets or fewer symbols per step (RBG_LAYOUT_PREFER_SLOTS keeps slot tables)\n", ix->device, need() / 1e9, budget / 1e9);
@@ -1915,16 +1349,11 @@ int upload(rbg_index *ix) {
         runs_layout = false;
     }
     ix->runs_layout = runs_layout;
-    // 64-byte slots (experiment): only the slot layout, only while every table sits at narrow buckets (the budget rule's
-    // wider buckets keep the 16-byte encoding) and with dense tables for the overflow buckets
-    bool want64 = g_opt_slot_bytes.load() == 64 && !runs_layout && g_opt_dense_overflow.load() != 0;
-    for (const std::vector<SymTable> *lv : {&h.sym, &h.pair, &h.triple, &h.quad, &h.quint})
-        for (const SymTable &t : *lv)
-            if (t.shift > kMaxNarrowShift) want64 = false;
-    struct Slot64Scope { bool prev; explicit Slot64Scope(bool v) : prev(t_slot64) { t_slot64 = v; } ~Slot64Scope() { t_slot64 = prev; } } slot64_scope(want64);
-    auto levels = [&] { return !h.quint.empty() ? 5 : !h.quad.empty() ? 4 : !h.triple.empty() ? 3 : !h.pair.empty() ? 2 : 1; };
+    if (!runs_layout)   // (the slot layout stages at most kMaxSlotKmerDepth symbols per gather)
+        while (levels_of(h) > kMaxSlotKmerDepth) drop_kmer_level(ix, h.kmer(h.kmer_levels()));
+    auto levels = [&] { return static_cast<int>(h.kmer_levels()); };
     if (runs_layout) {
-        // the k-mer depths stay (their run lists are O(r) too: DevRunTab, rbg_dev.h); the deepest goes while the replica
+        // the k-mer depths stay (their run lists are O(r) too: DevRunTab2, rbg_dev.h); the deepest goes while the replica
         // exceeds the budget
         if (ix->kmer_steps_requested == 0) ix->kmer_steps_requested = static_cast<uint64_t>(levels());
         // RBG_OPT_RUN_DEPTHS: a step needs no table of every depth below the deepest -- a stretch of 4 symbols is a depth-3
@@ -1935,10 +1364,8 @@ int upload(rbg_index *ix) {
         // rate on whole reads, a few per cent more steps where stretches are ragged (marker seeds); 0x1F keeps them all.
         ix->runs_report = rbg_index::RunsReport();
         ix->runs_report.depth_mask_asked = static_cast<uint32_t>(g_opt_run_depths.load());
-        uint32_t mask = g_opt_run_depths.load() ? static_cast<uint32_t>(g_opt_run_depths.load()) | 1u : 1u;
-        if (!g_opt_run_depths.load())
-            for (int d = levels(); d >= 1; d -= 2) mask |= 1u << (d - 1);
-        auto deepest_of = [&]() -> std::vector<SymTable> & { return !h.quint.empty() ? h.quint : !h.quad.empty() ? h.quad : !h.triple.empty() ? h.triple : h.pair; };
+        uint32_t mask = g_opt_run_depths.load() ? static_cast<uint32_t>(g_opt_run_depths.load()) | 1u : default_depth_mask(static_cast<uint32_t>(levels()));
+        auto deepest_of = [&]() -> std::vector<SymTable> & { return h.kmer(static_cast<uint32_t>(std::max(2, levels()))); };
         while (levels() > 1 && !(mask >> (levels() - 1) & 1u)) drop_kmer_level(ix, deepest_of());   // (nothing steps by a depth above the deepest kept)
         mask &= (1u << levels()) - 1u;
         auto need_runs = [&] { return h.pos_bytes == 4 ? runs_replica_bytes<uint32_t>(h, mask) : runs_replica_bytes<uint64_t>(h, mask); };
@@ -1976,7 +1403,6 @@ int upload(rbg_index *ix) {
     // and try again.  At pangenome scale this keeps a level more than dropping alone.
     auto widen = [&](std::vector<SymTable> &lvl) {
         if (h.n >> 40) return;  // wide slots carry 40-bit ranks
-        if (t_slot64) return;   // (64-byte slots have no wide form: levels are dropped instead)
         for (SymTable &t : lvl) {
             const double rows_per_run = static_cast<double>(h.n) / static_cast<double>(std::max<uint64_t>(1, t.nruns));
             uint32_t want = 0;
@@ -1985,10 +1411,11 @@ int upload(rbg_index *ix) {
         }
     };
     bool widened = false;
-    while (need() > budget && !h.pair.empty() && !runs_layout) {
+    while (need() > budget && !h.kmer(2).empty() && !runs_layout) {
         if (!widened && g_opt_deep_shift.load() < 0 && g_opt_rank_shift.load() < 0) {
             widened = true;
-            for (std::vector<SymTable> *lvl : {&h.quint, &h.quad, &h.triple, &h.pair})
+            for (uint32_t wd = static_cast<uint32_t>(kMaxSlotKmerDepth); wd >= 2; --wd) {
+                std::vector<SymTable> *lvl = &h.kmer(wd);
                 if (!lvl->empty() && need() > budget) {
                     const size_t before = need();
                     widen(*lvl);
@@ -1996,9 +1423,10 @@ int upload(rbg_index *ix) {
                         std::fprintf(stderr, "rbg: replica of %.1f GB exceeds the %.1f GB budget: wider buckets for the %zu-table k-mer level (%.1f GB)\n",
                                      before / 1e9, budget / 1e9, lvl->size(), need() / 1e9);
                 }
+            }
             continue;
         }
-        std::vector<SymTable> &deepest = !h.quint.empty() ? h.quint : !h.quad.empty() ? h.quad : !h.triple.empty() ? h.triple : h.pair;
+        std::vector<SymTable> &deepest = h.kmer(static_cast<uint32_t>(levels()));
         std::fprintf(stderr, "rbg: replica of %.1f GB exceeds the %.1f GB budget: dropping the %zu-table k-mer level\n",
                      need() / 1e9, budget / 1e9, deepest.size());
         drop_kmer_level(ix, deepest);
@@ -2010,13 +1438,9 @@ int upload(rbg_index *ix) {
     if (runs_layout && std::getenv("RBG_VERBOSE")) std::fprintf(stderr, "rbg: device %d: k-mer depths with run lists: mask 0x%x\n", ix->device, ix->run_depth_mask);
     int rc;
     d.layout = RBG_LAYOUT_SLOTS;
-    d.slot_bytes = t_slot64 ? 64 : 16;
     if (runs_layout) {
         if (std::getenv("RBG_VERBOSE")) std::fprintf(stderr, "rbg: device %d: run-indexed layout (space proportional to r)\n", ix->device);
-        const bool fmt1 = runs_format1();
-        d.run_fmt = fmt1 ? 1 : 2;
-        if (fmt1) rc = h.pos_bytes == 4 ? upload_tables_runs<uint32_t>(ix) : upload_tables_runs<uint64_t>(ix);
-        else rc = h.pos_bytes == 4 ? upload_tables_runs2<uint32_t>(ix) : upload_tables_runs2<uint64_t>(ix);
+        rc = h.pos_bytes == 4 ? upload_tables_runs2<uint32_t>(ix) : upload_tables_runs2<uint64_t>(ix);
         if (rc) return rc;
     } else {
         ix->arena_bytes = h.pos_bytes == 4 ? replica_bytes<uint32_t>(h, true) : replica_bytes<uint64_t>(h, true);   // (without the lists that are on the device already)
@@ -2135,34 +1559,44 @@ FlattenOptions options_for(int device, const RawRle &rle, uint64_t *requested, b
                             static_cast<double>((rle.n >> 6) + 2) * (4 * pos + 4);
         if (lvl1 > budget) return o;
     }
-    const double per_table = static_cast<double>((rle.n >> kMaxWideShift) + 2) * (sizeof(RankSlot) + sizeof(uint32_t));
-    double total = major * per_table, tables = major;
-    int keep = 1;
-    for (int k = 2; k <= o.kmer_steps; ++k) {
-        tables *= major;
-        total += tables * per_table;
-        if (total > budget) break;
-        keep = k;
-    }
-    if (keep < o.kmer_steps && g_opt_rank_layout.load() == RBG_LAYOUT_AUTO && sigma <= static_cast<unsigned>(kLdsSyms)) {
-        // RBG_LAYOUT_AUTO: rather than give up symbols per step, the run-indexed layout (all of them, in space proportional to r) -- on
-        // the bench index 1.26e9 reads/s from 8.7 GB against 1.18e9 from the 59 GB of four symbols per step (profiles/r04_bench.json
-        // space_speed); about 110 bytes per run at its leanest (depths 1, 3, 5; phi over the list of sampled positions)
+    // the slot layout stages the tables of at most kMaxSlotKmerDepth symbols per gather: more are asked of the run-indexed layout only
+    const int slot_steps = std::min(o.kmer_steps, kMaxSlotKmerDepth);
+    auto slot_levels_fitting = [&](uint32_t shift) {   // the deepest level whose slot tables (every table at this bucket shift) fit the budget with the levels above it
+        const double per_table = static_cast<double>((rle.n >> shift) + 2) * (sizeof(RankSlot) + sizeof(uint32_t));
+        double total = major * per_table, tables = major;
+        int keep = 1;
+        for (int k = 2; k <= slot_steps; ++k) {
+            tables *= major;
+            total += tables * per_table;
+            if (total > budget) break;
+            keep = k;
+        }
+        return keep;
+    };
+    const int keep = slot_levels_fitting(kMaxWideShift);   // conservative: a level upload() could keep is never excluded
+    if (g_opt_rank_layout.load() == RBG_LAYOUT_AUTO && sigma <= static_cast<unsigned>(kLdsSyms) && slot_levels_fitting(kMaxNarrowShift) < slot_steps) {
+        // RBG_LAYOUT_AUTO: slot tables only while those of every symbol per step fit the budget at their narrow buckets; rather than give up
+        // symbols per step -- or widen the buckets -- the run-indexed layout (all of them, in space proportional to r; deeper steps than the
+        // slot layout has: RBG_OPT_KMER_STEPS up to 8).  On the bench index 1.26e9 reads/s from 8.7 GB against 1.18e9 from the 59 GB of four
+        // symbols per step (profiles/r04_bench.json space_speed); about 110 bytes per run at its leanest.
         const double runs_least = 110.0 * static_cast<double>(rle.heads.size());
         if (runs_least <= budget) {
             if (std::getenv("RBG_VERBOSE"))
-                std::fprintf(stderr, "rbg: device %d: the slot tables of %d symbols per step exceed the %.1f GB replica budget (%d would fit): the run-indexed layout "
-                                     "instead (RBG_OPT_RANK_LAYOUT = RBG_LAYOUT_PREFER_SLOTS keeps slot tables with fewer symbols)\n", device, o.kmer_steps, budget / 1e9, keep);
+                std::fprintf(stderr, "rbg: device %d: the slot tables of %d symbols per step exceed the %.1f GB replica budget at narrow buckets: the run-indexed layout "
+                                     "instead, %d symbols per step (RBG_OPT_RANK_LAYOUT = RBG_LAYOUT_PREFER_SLOTS keeps slot tables with fewer symbols)\n", device, slot_steps,
+                             budget / 1e9, o.kmer_steps);
             *auto_runs = true;
             return o;
         }
     }
     if (keep < o.kmer_steps) {
-        if (std::getenv("RBG_VERBOSE"))
-            std::fprintf(stderr, "rbg: device %d: %.1f GB replica budget cannot hold k-mer levels beyond %d at n = %.3g: not composing them\n", device,
-                         budget / 1e9, keep, static_cast<double>(rle.n));
-        *requested = static_cast<uint64_t>(std::min(5, o.kmer_steps));
-        o.kmer_steps = keep;
+        if (keep < slot_steps) {
+            if (std::getenv("RBG_VERBOSE"))
+                std::fprintf(stderr, "rbg: device %d: %.1f GB replica budget cannot hold k-mer levels beyond %d at n = %.3g: not composing them\n", device,
+                             budget / 1e9, keep, static_cast<double>(rle.n));
+            *requested = static_cast<uint64_t>(slot_steps);   // (what the slot layout could have taken of the depth asked for)
+        }
+        o.kmer_steps = keep;   // (the slot layout: at most kMaxSlotKmerDepth symbols per gather)
     }
     return o;
 }
@@ -2579,7 +2013,7 @@ int rbg_set_default_option(int opt, int64_t value) {
             if (value < 0) return RBG_EARG;
             g_opt_hbm_budget_mb = value; return RBG_OK;
         case RBG_OPT_KMER_STEPS:
-            if (value < 1 || value > 5) return RBG_EARG;
+            if (value < 1 || value > kMaxKmerDepth) return RBG_EARG;
             g_opt_kmer_steps = value; return RBG_OK;
         case RBG_OPT_PACKED_READS:
             if (value < 0 || value > 2) return RBG_EARG;
@@ -2587,18 +2021,9 @@ int rbg_set_default_option(int opt, int64_t value) {
         case RBG_OPT_RANK_LAYOUT:
             if (value != RBG_LAYOUT_AUTO && value != RBG_LAYOUT_SLOTS && value != RBG_LAYOUT_RUNS && value != RBG_LAYOUT_PREFER_SLOTS) return RBG_EARG;
             g_opt_rank_layout = value; return RBG_OK;
-        case RBG_OPT_TREE_TOP_KB:
-            if (value < 0 || value > 96) return RBG_EARG;  // 0 = 16 keys in all: the deepest tree (tests)
-            g_opt_tree_top_kb = value; return RBG_OK;
-        case RBG_OPT_SLOT_BYTES:
-            if (value != 16 && value != 64) return RBG_EARG;
-            g_opt_slot_bytes = value; return RBG_OK;
         case RBG_OPT_RUN_DEPTHS:
             if (value < 0 || value >= (1 << kMaxRunDepth)) return RBG_EARG;
             g_opt_run_depths = value; return RBG_OK;
-        case RBG_OPT_RUN_FMT:
-            if (value != 1 && value != 2) return RBG_EARG;
-            g_opt_run_fmt = value; return RBG_OK;
         case RBG_OPT_RUN_PHI:
             if (value < 0 || value > 2) return RBG_EARG;
             g_opt_run_phi = value; return RBG_OK;
@@ -2625,10 +2050,7 @@ int rbg_get_default_option(int opt, int64_t *value) {
         case RBG_OPT_KMER_STEPS: *value = g_opt_kmer_steps.load(); return RBG_OK;
         case RBG_OPT_PACKED_READS: *value = g_opt_packed_reads.load(); return RBG_OK;
         case RBG_OPT_RANK_LAYOUT: *value = g_opt_rank_layout.load(); return RBG_OK;
-        case RBG_OPT_TREE_TOP_KB: *value = g_opt_tree_top_kb.load(); return RBG_OK;
-        case RBG_OPT_SLOT_BYTES: *value = g_opt_slot_bytes.load(); return RBG_OK;
         case RBG_OPT_RUN_DEPTHS: *value = g_opt_run_depths.load(); return RBG_OK;
-        case RBG_OPT_RUN_FMT: *value = g_opt_run_fmt.load(); return RBG_OK;
         case RBG_OPT_RUN_PHI: *value = g_opt_run_phi.load(); return RBG_OK;
         case RBG_OPT_RUN_REC: *value = g_opt_run_rec.load(); return RBG_OK;
         default: return RBG_EARG;
@@ -2980,27 +2402,23 @@ int rbg_info(const rbg_index *ix, rbg_info_t *out) {
     out->rank_slots_overflow = ix->rank_slots_overflow;
     out->phi_slots = ix->phi_slots;
     out->phi_slots_overflow = ix->phi_slots_overflow;
-    out->kmer_steps = !ix->H().quint.empty() ? 5 : !ix->H().quad.empty() ? 4 : !ix->H().triple.empty() ? 3 : !ix->H().pair.empty() ? 2 : 1;
+    out->kmer_steps = ix->H().kmer_levels();
     if (ix->device != RBG_DEVICE_NONE && ix->dev.layout == RBG_LAYOUT_RUNS) out->kmer_steps = ix->dev.run_ksteps;   // depths of the run-indexed search
-    out->kmer_symbols = ix->H().pair.empty() ? 0 : ix->H().nmajor;
-    out->slot_bytes = ix->device != RBG_DEVICE_NONE && ix->dev.layout == RBG_LAYOUT_SLOTS ? ix->dev.slot_bytes : 0;
+    out->kmer_symbols = ix->H().kmer(2).empty() ? 0 : ix->H().nmajor;
+    out->slot_bytes = ix->device != RBG_DEVICE_NONE && ix->dev.layout == RBG_LAYOUT_SLOTS ? 16 : 0;
     out->ftab_k = ix->dev.ftab_k;
     out->kmer_steps_requested = ix->kmer_steps_requested ? ix->kmer_steps_requested : out->kmer_steps;
     out->hbm_free_at_load = ix->hbm_free_at_load;
     out->hbm_budget = ix->hbm_budget;
     out->rank_layout = ix->runs_layout ? RBG_LAYOUT_RUNS : RBG_LAYOUT_SLOTS;
     out->replicas = ix->device == RBG_DEVICE_NONE ? 0 : 1;
-    for (const SymTable &t : ix->H().pair) out->pair_runs += t.nruns;
-    for (const SymTable &t : ix->H().triple) out->triple_runs += t.nruns;
-    for (const SymTable &t : ix->H().quad) out->quad_runs += t.nruns;
-    for (const SymTable &t : ix->H().quint) out->quint_runs += t.nruns;
-    if (ix->device != RBG_DEVICE_NONE && ix->dev.layout == RBG_LAYOUT_RUNS) {   // depths left without run lists (RBG_OPT_RUN_DEPTHS) report none
-        const uint32_t m = ix->dev.run_depth_mask;
-        if (!(m >> 1 & 1u)) out->pair_runs = 0;
-        if (!(m >> 2 & 1u)) out->triple_runs = 0;
-        if (!(m >> 3 & 1u)) out->quad_runs = 0;
-        if (!(m >> 4 & 1u)) out->quint_runs = 0;
+    out->depth_runs[0] = ix->H().r;
+    const bool runs_dev = ix->device != RBG_DEVICE_NONE && ix->dev.layout == RBG_LAYOUT_RUNS;
+    for (uint32_t d = 2; d <= static_cast<uint32_t>(kMaxKmerDepth); ++d) {
+        if (runs_dev && !(ix->dev.run_depth_mask >> (d - 1) & 1u)) continue;   // depths left without run lists (RBG_OPT_RUN_DEPTHS) report none
+        for (const SymTable &t : ix->H().kmer(d)) out->depth_runs[d - 1] += t.nruns;
     }
+    out->pair_runs = out->depth_runs[1]; out->triple_runs = out->depth_runs[2]; out->quad_runs = out->depth_runs[3]; out->quint_runs = out->depth_runs[4];
     return RBG_OK;
     });
 }
@@ -3017,10 +2435,8 @@ int rbg_layout_info(const rbg_index *ix, rbg_layout_info_t *out, uint64_t out_by
         v.depth_mask_asked = r.depth_mask_asked;
         v.depth_mask_kept = r.depth_mask_kept;
         v.depths_dropped_budget = r.depths_dropped_budget;
-        v.depths_dropped_limit = r.depths_dropped_limit;
         v.rank_directories = r.rank_dirs;
         v.phi_directory = r.phi_dir;
-        v.phi_directory_dropped = r.phi_dir_dropped;
         v.fill_shift = r.fmt == 2 && ix->H().pos_bytes == 8 ? ix->dev.run_fill_shift : 0;
         for (int d = 0; d < kMaxRunDepth; ++d) { v.entries[d] = r.entries[d]; v.fillers[d] = r.fillers[d]; v.dir_bytes[d] = r.dir_bytes[d]; }
         v.phi_entries = r.phi_entries; v.phi_fillers = r.phi_fillers; v.phi_dir_bytes = r.phi_dir_bytes; v.phi_dir_shift = r.phi_dir_shift;
@@ -4469,7 +3885,7 @@ int rbg_find_locs_greedy_seeding(rbg_index *ix, const uint8_t *seqs, const uint6
 
 // ---- more than one GPU in one process (index replicated, reads sharded, no data-path collective) ----
 // The replica is built ONCE (load / build on the primary's device) and copied to the other devices peer to peer
-// (xGMI); records that hold device pointers (DevSym / DevTree arrays, DevIndex) are re-pointed into the copy.
+// (xGMI); records that hold device pointers (DevSym arrays, DevIndex) are re-pointed into the copy.
 
 
 }  // extern "C"
@@ -4561,16 +3977,11 @@ int replicate_finish(rbg_index *src, ReplicaJob &job) {
     reloc.fix(d.syms); reloc.fix(d.phi_ent); reloc.fix(d.phi_slots); reloc.fix(d.phi_ord);
     reloc.fix(d.mk_start); reloc.fix(d.mk_end); reloc.fix(d.mk_off); reloc.fix(d.mk_vals); reloc.fix(d.mk_bucket);
     reloc.fix(d.counters); reloc.fix(d.lut); reloc.fix(d.pairs); reloc.fix(d.triples); reloc.fix(d.quads); reloc.fix(d.quints);
-    reloc.fix(d.lut2); reloc.fix(d.ftab); reloc.fix(d.dense); reloc.fix(d.trees); reloc.fix(d.tree_top); reloc.fix(d.phi_top);
-    reloc.fix(d.run_tabs);
+    reloc.fix(d.lut2); reloc.fix(d.ftab); reloc.fix(d.dense);
     reloc.fix(d.phi_dir);
-    for (int t = 0; t < kMaxRunDepth; ++t) reloc.fix(d.run_dir[t]);
     for (int t = 0; t < kMaxRunDepth; ++t) reloc.fix(d.run_samp[t]);
-    for (int t = 0; t < kMaxRunDepth; ++t) reloc.fix(d.run_rec[t]);
     reloc.fix(d.run_tabs2); reloc.fix(d.phi_super);
     for (int t = 0; t < kMaxRunDepth; ++t) { reloc.fix(d.run_ent2[t]); reloc.fix(d.run_dir2[t]); reloc.fix(d.run_rec2[t]); }
-    reloc.fix(d.phi_tree.ent);
-    for (int l = 0; l < kMaxTreeLevels; ++l) reloc.fix(d.phi_tree.lvl[l]);
     r->dev = d;
     if (hipMemset(d.counters, 0, 4 * sizeof(uint64_t)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return RBG_ENODEV;
     return RBG_OK;

@@ -99,27 +99,6 @@ template <> struct RunsFmt<uint64_t> {
 struct alignas(16) RankSlot {
     uint32_t r0, w1, w2, w3;
 };
-// 64-BYTE RANK SLOTS (RBG_OPT_SLOT_BYTES = 64; experiment of round 3).  A 16-byte slot costs a 64-byte
-// sector of fabric traffic anyway, and a quad of lanes fetching the four quarters of ONE aligned 64-byte record is served at
-// the rate of 16-byte gathers (tools/slot64_probe.hip: 47-48 G records/s against 49 G/s).  So the same bytes per BWT row can
-// be spent as one 64-byte slot per 4 x 2^shift rows (1024 at the usual shift 8): fewer steps whose two positions straddle
-// two buckets, fourteen inline runs instead of 4 x 4 that rarely fill, the run ordinal inline (no `ord` array: a fifth of
-// the replica) and the predecessor run's SAMPLE inline -- a toehold re-sample that lands before the bucket's first run
-// costs no gather at all, any other one gather instead of two.
-//   w0  = rank(B0, c) bits 0-31
-//   w1  = rank bits 32-47 | ext << 16 (11 bits: 0..1024 rows from B0 covered by a run that began before) | prev_is_c << 27
-//         | cnt << 28 (runs that START inside the bucket, 0..14; 15 = more: dense table)
-//   w2  = ord: # runs of the table starting before B0
-//   w3,w4 = samples_last of run ord - 1 (the sample a re-sample needs when no run starts between B0 and the row), 0 if none
-//   w5..w13 = the runs, 20 bits each from bit 0 of w5: off (10 bits) | (len - 1) << 10, len clipped to the bucket
-//   cnt == 15: w5 = index of the bucket's dense table in DevIndex::dense (4 KB each): one u32 per row o --
-//         rank(B0 + o) - r0 (bits 0-10) | # runs starting in [B0, B0 + o) << 11 (10 bits) | (row B0 + o - 1 holds c) << 31
-// Only for tables at narrow buckets (shift <= 8: bucket shift <= 10); an index with a wide-bucket table keeps 16-byte slots.
-struct alignas(64) RankSlot64 {
-    uint32_t w[16];
-};
-constexpr int kSlot64Runs = 14;
-constexpr uint32_t kSlot64Ovf = 15, kSlot64Extra = 2;   // bucket shift = table shift + kSlot64Extra
 constexpr int kSlotRuns = 4;
 constexpr int kSlotRunsWide = 2;
 constexpr uint32_t kMaxNarrowShift = 8, kMaxWideShift = 12;
@@ -156,73 +135,23 @@ struct DevSym {        // 48 bytes: 344 of them (symbols + 2/3/4-mers) are stage
 // ---- run-indexed layout (RBG_LAYOUT_RUNS): space proportional to r, nothing proportional to n ------------------
 // rank(i, c) = predecessor search over the symbol's sorted run starts (the reference's own structure is O(r) too:
 // rle_string::rank, rle_string.hpp:131-161 over sparse_sd_vector, :110-163), phi(i) = predecessor search over the
-// sampled text positions (toehold_sa.hpp:56-72).  The sorted keys carry a 16-ary sampled index: lvl[0] = every
-// 16th key, lvl[1] = every 16th of those, ...; the coarsest level ("top") is staged in LDS by every workgroup.
-// A probe of one level is ONE coalesced load of a 16-entry block by a 16-lane row of the wave (64 B of keys, 128 B of
-// {key, value} pairs at 4-byte positions: one or two sectors, where a 64-entry block cost four to eight), compared
-// 16-wide with a ballot; a wave-wide load instruction probes for four queries, and all sixteen rounds of a level
-// are in flight together (k_find_range_runs / k_locate_fill_runs).  Every tree of an index has the same number of levels.
-constexpr int kTreeFan = 16;
-constexpr int kMaxTreeLevels = 8;
-constexpr uint32_t kTreeTopBytes = 48 * 1024;  // LDS budget for the staged top levels of all trees of a kernel
-struct DevTree {
-    const void *ent;                    // {key, value} pairs of P each (RunEnt<P> / PhiEnt<P>): m entries + 1 sentinel
-    const void *lvl[kMaxTreeLevels];    // lvl[i][j] = key (16^(i+1)) * j; P each; levels [0, nlvl) live in HBM
-    uint64_t m;
-    uint32_t lvl_n[kMaxTreeLevels];
-    uint32_t top_off, top_n;            // this tree's slice of DevIndex::tree_top (level nlvl, staged in LDS)
-};
-
+// sampled text positions (toehold_sa.hpp:56-72).  The arrays are described below (DevRunTab2, RunRec2); the
+// wave-cooperative form of rounds 2-3 (16-ary sampled index, quads of lanes probing 16-entry blocks, 128-byte bucket
+// records) lost its A/Bs to the one-lane form and was retired in round 5 (profiles/r04_fmt_ab.txt, DESIGN_HISTORY.md).
 constexpr int kLdsSyms = 8;
 constexpr int kMaxMajor = 4;  // symbol tables staged in LDS per workgroup; rarer slots read from HBM
 
 // Run-indexed layout, K1/K2: every k-mer depth d = 1..run_ksteps (a depth-d table lists the rows whose d
-// preceding text characters spell the k-mer, as runs) has ONE tree (DevTree) over the run lists of all its tables, laid
-// back to back in table order -- each table's entries ascend and end with its sentinel {n, total}, so the concatenation
-// is sorted by (table, start).  A rank in table t is a predecessor search CLAMPED to the table's slice
-// [first_t, first_{t+1}): entries before the slice count as below the query, entries from the sentinel on as not below
-// it, which keeps the predicate monotone over the whole array -- one sampled index per depth instead of 1364 of them.
-// DevRunTab: what a step needs to know about its table; the records of a depth are followed by one closing record
-// (first = the depth's entry count) so that first_{t+1} is always the next record.
-// Each table also has a coarse DIRECTORY over its run starts -- dir[b] = # runs of the table starting below
-// b << dir_shift, the shift chosen per table so that a bucket holds about four runs (so the directories take about a
-// byte per run: still O(r)) -- which turns most ranks into one 8-byte gather plus ONE row probe of the run list; buckets
-// with more than 15 runs take the clamped descent.
-struct DevRunTab {
-    uint64_t F;          // first row of the k-mer's SA interval (RowBowt::f_ for a single symbol)
-    uint64_t first;      // index of the table's first entry in its depth's arrays
-    uint32_t dir_off;    // the table's directory starts at run_dir[depth][dir_off] ((n >> dir_shift) + 2 entries)
-    uint32_t dir_shift;
-};
-// BUCKET RECORDS (RBG_RANK_REC): the directory and the runs it points at, fused.  One aligned 128-byte record per
-// directory bucket [B, B + W), W = 1 << shift, read by a 16-lane row with ONE coalesced request (8 bytes per lane):
-// lane 0 the header, lane 1 `base` = the rank at B, lanes 2-15 up to 14 PAIRS (off, cl): the run before the bucket, then
-// the runs that start inside it, then a closing pair.  A pair says "a run starts at B + off, and cl occurrences of the
-// k-mer precede it" -- cl counts from `base` at 8-byte positions and is the rank itself at 4-byte positions (one value
-// less to fetch) -- so the lane that holds the last pair with off < o = i - B (signed compare) computes the rank at i
-// by itself: cl + min(o - off, cl_next - cl), its right neighbour's cl arriving by DPP.  The run before the bucket is
-// stored as off = -1 and cl one below the rank at B (the run continues into the bucket: the arithmetic then yields
-// base + min(o, what is left of it), and "i inside the run" stays o - off <= cl_next - cl), or cl = the rank at B
-// with an empty run when it ended earlier.  Unused pairs carry off = INT32_MAX, never below an offset.  A bucket with
-// more than kRecRuns runs is flagged: the header's (e0, count) then send the search through the run list.
-// DevRunTab::dir_off / dir_shift are the table's first record and bucket shift when its depth has records.
-constexpr int kRecRuns = 13;
-struct RunRecPair { uint32_t off, cl; };
-struct RunRec {
-    uint32_t e0;       // entry index (in the depth's arrays) of the first pair: the run before the bucket, or the table's first run
-    uint32_t flags;    // bits 0-7 pairs in use; bit 31: too many runs -- bits 0-30 = candidates from e0 on
-    uint64_t base;     // rank at B
-    RunRecPair pair[kRecRuns + 1];
-};
-static_assert(sizeof(RunRec) == 128, "one 128-byte line per bucket");
-constexpr uint32_t kRecOverflow = 0x80000000u, kRecPred = 0xFFFFFFFFu, kRecNoPair = 0x7FFFFFFFu;
-constexpr uint32_t kRecMaxShift = 30;   // offsets and occurrence counts within a bucket stay below 2^31
-
-// ---- run-indexed layout, FORMAT 2 (DevIndex::run_fmt == 2; the default since round 4) -------------------------------
-// Same arrays in spirit -- per kept k-mer depth the run lists of all its tables back to back, a directory per table, a
-// sample per entry -- but laid out for ONE LANE answering its own ranks (rbg_runs2_device.hpp): the directory names the
+// preceding text characters spell the k-mer, as runs) keeps the run lists of all its tables back to back in table order
+// -- each table's entries ascend and end with its sentinel {n, total} -- and one record per table (DevRunTab2).
+// Each table has a coarse DIRECTORY over its run starts -- dir[b] = # runs of the table starting below b << dir_shift,
+// the shift chosen per table so that a bucket holds about four runs (about a byte per run: still O(r)) -- or BUCKET
+// RECORDS (RunRec2) that fuse the directory entry with the entries it names.
+// ---- the arrays ("format 2" in profiles/ and DESIGN_HISTORY.md; the only format since round 5) ----------------------
+// Per kept k-mer depth the run lists of all its tables back to back, a directory per table, a sample per entry, laid
+// out for ONE LANE answering its own ranks (rbg_runs2_device.hpp): the directory names the
 // few entries that can hold the answer, the lane fetches them with independent 16-byte requests and scans them in
-// registers; no cross-lane traffic.  What changes at 8-byte positions (at 4-byte positions the arrays are format 1's):
+// registers; no cross-lane traffic.  At 4-byte positions the entries are {start, cum} pairs of u32; at 8-byte positions:
 //   entries  {start mod 2^32, cum mod 2^32}: 8 bytes instead of 16.  The directory bucket (shift <= 30) bounds the
 //            answer to the runs starting inside the bucket and the one before them, and FILLER entries (a continuation
 //            of the run, or an empty run, every 2^30 rows of a gap) keep every entry within 2^30 rows of the next one
@@ -277,8 +206,13 @@ struct PhiEnt12 { uint32_t pos_lo, base_lo, base_hi; };
 static_assert(sizeof(PhiEnt12) == 12, "three words per entry");
 constexpr uint32_t kPhiSuperShift = 16;    // phi_super[j] = # entries below bucket j << 16 (64-bit); phi_dir holds the low 32 bits of the counts
 
-constexpr int kMaxRunDepth = 5;
-constexpr int kMaxRunTabs = kLdsSyms + 16 + 64 + 256 + 1024 + kMaxRunDepth;  // records staged in LDS by k_find_range_runs
+// Symbols a search step may consume (RBG_OPT_KMER_STEPS; the reference's own multi-symbol shortcut is its ftab, rowbowt.hpp:121-131,
+// :726-758).  The table records {F, first, dir_off, dir_shift} of depths up to kLdsRunDepth are staged in LDS by every workgroup
+// (8 + 16 + 64 + 256 + 1024 of them at most: 44 KB); a deeper depth has 4^6 .. 4^8 tables -- 2 MB of records at depth 8 -- and its
+// record is read from the global array (two 16-byte loads of one line that stays in L2 / MALL: not an HBM sector).
+constexpr int kMaxRunDepth = 8;
+constexpr int kLdsRunDepth = 5;
+constexpr int kMaxLdsRunTabs = kLdsSyms + 16 + 64 + 256 + 1024 + kLdsRunDepth;  // records staged in LDS by k_find_range_runs
 
 struct DevIndex {
     uint64_t n, r;
@@ -299,7 +233,6 @@ struct DevIndex {
     // >= b << mk_shift (mk_nruns if none); (n >> mk_shift) + 2 entries; nullptr = binary search only
     const uint32_t *mk_bucket;
     uint32_t mk_shift;
-    uint32_t slot_bytes;   // 16 (RankSlot) or 64 (RankSlot64; DevSym::ord is nullptr then and `shift` stays the TABLE's shift)
     // {reads, matched, sum occ, sum locs}
     unsigned long long *counters;
     const uint8_t *lut;  // 256 bytes, device memory
@@ -321,34 +254,21 @@ struct DevIndex {
     uint32_t ftab_k;
     uint32_t phi_packed;    // 1: phi_slots holds PhiSlotPacked (8-byte positions only)
     const uint8_t *dense;   // dense tables of the overflow buckets of every narrow rank table (RankSlot); nullptr = none
-    // run-indexed layout (layout == 2): one tree per k-mer depth (DevRunTab above) and one over the phi samples
+    // run-indexed layout (layout == 2)
     uint32_t layout;        // 1 = slot tables (RBG_LAYOUT_SLOTS), 2 = run-indexed (RBG_LAYOUT_RUNS)
-    uint32_t tree_nlvl;     // HBM-resident sampled levels of every rank tree
-    const DevTree *trees;   // run_ksteps entries: depth 1 first
-    const void *tree_top;   // P keys: the top levels of all rank trees, back to back
-    uint32_t tree_top_n;
-    uint32_t phi_nlvl;
-    DevTree phi_tree;
-    const void *phi_top;    // P keys
-    uint32_t run_ksteps;    // symbols a step of k_find_range_runs may consume (1..5); kmer_steps stays 1 for the per-lane kernels
-    uint32_t run_ntabs;     // records in run_tabs
-    const DevRunTab *run_tabs;            // depth d's records start at run_tab_first[d - 1]
-    const void *run_samp[kMaxRunDepth];   // per depth: P per entry (run-end sample; SA - d for a depth-d run), nullptr without toehold SA
-    const uint32_t *run_dir[kMaxRunDepth];  // per depth: the tables' directories back to back (DevRunTab::dir_off); nullptr = descent only
-    uint32_t run_tab_first[kMaxRunDepth + 1];
+    uint32_t run_ksteps;    // symbols a step of k_find_range_runs may consume (1..kMaxRunDepth); kmer_steps stays 1 for the per-lane kernels
+    uint32_t run_ntabs;     // records in run_tabs2
+    const void *run_samp[kMaxRunDepth];   // per depth: one sample per entry (run-end sample; SA - d for a depth-d run: 4 bytes, 6 at 8-byte positions), nullptr without toehold SA
+    uint32_t run_tab_first[kMaxRunDepth + 1];   // depth d's records start at run_tab_first[d - 1]
     // run-indexed phi: a coarse directory over the sampled positions -- phi_dir[b] = # sampled positions below b << phi_dir_shift
     // ((n >> shift) + 2 entries; the shift keeps two to four sampled positions per bucket) -- so that a phi step is one
     // 8-byte gather (two neighbouring entries) and ONE row probe of the run list instead of a descent through the sampled
-    // levels; a bucket with more than 15 sampled positions is narrowed by pivot probes first.  nullptr: descent only.
+    // levels; a bucket with more than 8 sampled positions is narrowed by pivot probes first.  nullptr: phi slots answer phi.
     const uint32_t *phi_dir;
     uint32_t phi_dir_shift;
     uint32_t run_depth_mask;   // bit d - 1: the k-mer depth d has run lists (bit 0 always; RBG_OPT_RUN_DEPTHS / the budget rule may leave depths out)
-    const RunRec *run_rec[kMaxRunDepth];  // per depth: the tables' bucket records back to back; nullptr = directory / descent
-    // format 2 (see DevRunTab2 above): one lane answers its own ranks and phi steps
-    uint32_t run_fmt;                       // 1: {P, P} pairs probed by quads of lanes; 2: per-lane probes (low-word pairs at 8-byte positions)
     uint32_t phi_super_shift;               // 0 = no super counts (4-byte positions: r < 2^32)
     uint32_t run_fill_shift;                // 8-byte positions: entries of a table (and of the phi list) lie less than 2^this rows apart
-    uint32_t pad_fmt2;
     const void *run_ent2[kMaxRunDepth];     // uint2 {start, cum} (low words at 8-byte positions) + 2 spare entries
     const void *run_dir2[kMaxRunDepth];     // uint32_t counts (4-byte positions) or RunDir64 (8-byte positions)
     const DevRunTab2 *run_tabs2;            // run_ntabs records, depth d's from run_tab_first[d - 1]
@@ -474,9 +394,6 @@ struct LaunchCfg {
 // launchers (k_search.hip, k_locate.hip, k_markers.hip, k_build.hip).  All asynchronous on `stream`; return hipError_t as int.
 int launch_find_range(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
                       uint64_t *lo, uint64_t *hi, uint64_t *ssamp /*nullable*/, void *stream);
-// 64-byte slots (k_search64.hip); sel / nsel / stats as in launch_find_range's variants (nullable)
-int launch_find_range64(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N, uint64_t *lo, uint64_t *hi,
-                        uint64_t *ssamp /*nullable*/, const uint32_t *sel, const uint32_t *nsel, unsigned long long *stats, void *stream);
 // run-indexed layout (k_runs.hip)
 int launch_find_range_runs(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
                            uint64_t *lo, uint64_t *hi, uint64_t *ssamp /*nullable*/, void *stream,
@@ -489,7 +406,7 @@ int launch_locate_fill_runs(const DevIndex &ix, const LaunchCfg &cfg, const uint
                             uint64_t N, uint64_t max_hits, const uint64_t *loc_off, uint64_t *locs, const uint64_t *sub,
                             const void *order, const uint64_t *skeys, void *stream, unsigned long long *stats = nullptr /*kStatRunLocateN*/,
                             uint32_t *locs32 = nullptr);
-// the kernels beside the rb_align path on the run-indexed layout (k_runs_seeds.hip): wave-cooperative ranks, k-mer steps
+// the kernels beside the rb_align path on the run-indexed layout (k_runs_seeds.hip): k-mer steps through the depths' run lists
 int launch_lf_runs(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t *lo, const uint64_t *hi, const uint8_t *sym, uint64_t N,
                    uint64_t *lo_out, uint64_t *hi_out, void *stream);
 int launch_find_range_markers_runs(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
@@ -523,10 +440,6 @@ int launch_build_rank_slots(uint32_t pos_bytes, const void *ent, uint64_t nruns,
 // second pass, once the pool of dense_cursor * 16 bytes exists: fills the dense tables of one rank table
 int launch_fill_dense(uint32_t pos_bytes, const void *ent, uint64_t n, uint32_t shift, const void *slots, const uint32_t *ord,
                       uint8_t *dense, void *stream);
-// 64-byte slots (RankSlot64): samp = the table's samples (nullable); dense_cursor counts 4 KB dense tables handed out
-int launch_build_rank_slots64(uint32_t pos_bytes, const void *ent, const void *samp, uint64_t nruns, uint64_t n, uint32_t shift, void *slots,
-                              unsigned long long *overflow, unsigned long long *dense_cursor, void *stream);
-int launch_fill_dense64(uint32_t pos_bytes, const void *ent, uint64_t n, uint32_t shift, const void *slots, uint8_t *dense, void *stream);
 // the text of `rb_align -s` on the device (k_text.hip; rbg_align_text): phase 1 = element lengths and offsets in the workspace,
 // phase 2 = the bytes.  E = N + loc_off[N] elements (a head per read, then its locations), + N with a markers line per read
 size_t text_ws_bytes(uint64_t E);
@@ -538,11 +451,9 @@ void text_total_ptrs(void *ws, uint64_t E, const uint64_t **last_at, const uint3
 int launch_text_fill(const uint64_t *lo, const uint64_t *hi, const uint64_t *loc_off, const uint64_t *locs, uint64_t N, uint64_t E, const char *names,
                      const uint32_t *name_off, const uint64_t *doc_start, const char *doc_names, const uint32_t *doc_name_off, uint64_t ndocs,
                      uint64_t text_size, bool with_locs, const uint64_t *mk_off, const uint64_t *mk, void *ws, uint64_t total, char *text, void *stream);
-// run-indexed layout from run lists already on the device (k_build.hip): the tables' directories, one sampled level of a
-// depth's index, 8-byte samples packed to 6
+// run-indexed layout from run lists already on the device (k_build.hip): the tables' directories, 8-byte samples packed to 6
 int launch_run_dirs(uint32_t pos_bytes, const void *ent, const uint64_t *first, const uint64_t *nruns, const uint64_t *doff, const uint32_t *dshift,
                     uint32_t T, uint64_t total, uint32_t *dir, void *stream);
-int launch_sample_keys(uint32_t pos_bytes, const void *ent, uint64_t step, uint64_t count, void *out, void *stream);
 int launch_pack_samp48(const uint64_t *in, uint64_t n, void *out, void *stream);
 // format 2 of the run-indexed layout (k_build.hip): {key, value} u64 pairs on the device -> fillers, low-word pairs, directories
 int launch_fill_count(const void *ent, uint64_t m, uint64_t n, uint32_t fill_shift, uint64_t *arr /*m + 1, nullable*/, unsigned long long *total, void *stream);

@@ -165,179 +165,25 @@ __device__ __forceinline__ uint64_t rank_in_slot(const DevSym &S, const RankSlot
     return (static_cast<uint64_t>(sl.r0) | (static_cast<uint64_t>(w3 >> 16) << 32)) + add;
 }
 
-// ---- 64-byte slots (rbg_dev.h RankSlot64) ---------------------------------------------------------------------------
-struct Rank64Aux {
-    uint32_t nbefore;   // # runs of the table that start in [B0, i)
-    uint32_t ord;       // # runs starting before B0
-    uint64_t psamp;     // sample of run ord - 1
-    bool inside;        // position i - 1 holds the symbol / k-mer
-    bool dense;         // answered from a dense table (instrumented kernels)
-};
-// the T-th 20-bit run field (a template parameter: the word indices are constants before any optimisation runs, so the
-// sixteen words stay in registers -- indexed through a loop variable the array went to scratch)
-template <int T>
-__device__ __forceinline__ uint32_t slot64_run(const uint32_t (&w)[16]) {
-    constexpr int bit = 20 * T, k = 5 + (bit >> 5), sh = bit & 31;
-    if constexpr (sh <= 12) return (w[k] >> sh) & 0xFFFFFu;
-    else return static_cast<uint32_t>((static_cast<uint64_t>(w[k]) | (static_cast<uint64_t>(w[k + 1]) << 32)) >> sh) & 0xFFFFFu;
-}
-template <int T>
-__device__ __forceinline__ void slot64_runs(const uint32_t (&w)[16], const uint32_t cnt, const uint32_t max_runs, const uint32_t o, uint32_t &add, bool &in,
-                                            uint32_t &nb) {
-    if constexpr (T < kSlot64Runs) {
-        if (static_cast<uint32_t>(T) < max_runs) {   // (uniform over the wave: a scalar branch around the run)
-            const uint32_t run = slot64_run<T>(w);
-            const uint32_t off = run & 0x3FFu, len = (run >> 10) + 1u;
-            if (static_cast<uint32_t>(T) < cnt && o > off) {
-                const uint32_t d = o - off;
-                add += d < len ? d : len;
-                in = in || d <= len;
-                ++nb;
-            }
-            slot64_runs<T + 1>(w, cnt, max_runs, o, add, in, nb);   // (runs beyond the bound are not even looked at)
-        }
-    }
-}
-// rank(i) from the slot of i's bucket b (bucket shift = table shift + 2), already in registers
-// max_runs: a bound on the slot's inline runs that is uniform over the wave (k_search64.hip passes the wave's largest
-// count: the unrolled loop then ends with a scalar branch instead of fourteen predicated iterations); 14 = no bound
-__device__ __forceinline__ uint64_t rank_in_slot64(const uint32_t (&w)[16], uint32_t bshift, uint64_t b, uint64_t i,
-                                                   const uint8_t *__restrict__ dense, Rank64Aux *aux, const uint32_t max_runs = kSlot64Runs) {
-    const uint32_t o = static_cast<uint32_t>(i - (b << bshift));
-    const uint32_t w1 = w[1];
-    const uint64_t r0 = static_cast<uint64_t>(w[0]) | (static_cast<uint64_t>(w1 & 0xFFFFu) << 32);
-    const uint32_t cnt = w1 >> 28;
-    aux->ord = w[2];
-    aux->psamp = static_cast<uint64_t>(w[3]) | (static_cast<uint64_t>(w[4]) << 32);
-    aux->dense = false;
-    if (cnt == kSlot64Ovf) {
-        const uint32_t e = as_global<uint32_t>(dense + (static_cast<uint64_t>(w[5]) << 12))[o];
-        aux->dense = true;
-        aux->nbefore = (e >> 11) & 0x3FFu;
-        aux->inside = (e >> 31) != 0;
-        return r0 + (e & 0x7FFu);
-    }
-    const uint32_t ext = (w1 >> 16) & 0x7FFu;
-    uint32_t add = o < ext ? o : ext;
-    bool in = o ? (o <= ext) : ((w1 >> 27) & 1u);
-    uint32_t nb = 0;
-    slot64_runs<0>(w, cnt, max_runs, o, add, in, nb);
-    aux->nbefore = nb;
-    aux->inside = in;
-    return r0 + add;
-}
-// one lane fetching its own 64 bytes (four requests: the kernels beside the hot path; K1/K2 fetch by quads, k_search64.hip)
-__device__ __forceinline__ void load_slot64(const RankSlot64 *p, uint32_t (&w)[16]) {
-    const RBG_GLOBAL u32x4 *q = as_global<u32x4>(static_cast<const void *>(p));
-    const u32x4 a = q[0], b = q[1], c = q[2], d = q[3];
-    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
-    w[8] = c.x; w[9] = c.y; w[10] = c.z; w[11] = c.w; w[12] = d.x; w[13] = d.y; w[14] = d.z; w[15] = d.w;
-}
-// a RankAux that stands for a Rank64Aux: nbefore = the run ordinal itself (ord + nbefore), so that pred_run needs no ord[]
-__device__ __forceinline__ bool sym_is_slot64(const DevSym &S) { return S.slots != nullptr && S.ord == nullptr; }
-
-// The sorted lists of the run-indexed layout as the kernels read them (rbg_dev.h RunsFmt: {key, value} pairs of P; samples
-// of 4 bytes, or 6 bytes at 8-byte positions).
+// a sample of the run-indexed layout's run lists (rbg_dev.h RunsFmt: 4 bytes, or 6 bytes at 8-byte positions)
 template <typename P> struct RunList;
 template <> struct RunList<uint32_t> {
-    typedef unsigned int pair __attribute__((ext_vector_type(2)));
-    static __device__ __forceinline__ uint32_t key(const void *__restrict__ b, uint64_t i) { return as_global<RunEnt<uint32_t>>(b)[i].start; }
-    static __device__ __forceinline__ uint32_t val(const void *__restrict__ b, uint64_t i) { return as_global<RunEnt<uint32_t>>(b)[i].cum; }
-    static __device__ __forceinline__ pair load(const void *__restrict__ b, uint64_t i) { return as_global<pair>(b)[i]; }
     static __device__ __forceinline__ uint64_t samp(const void *__restrict__ b, uint64_t i) { return as_global<uint32_t>(b)[i]; }
 };
 template <> struct RunList<uint64_t> {
-    typedef unsigned long long pair __attribute__((ext_vector_type(2)));
-    static __device__ __forceinline__ uint64_t key(const void *__restrict__ b, uint64_t i) { return as_global<RunEnt<uint64_t>>(b)[i].start; }
-    static __device__ __forceinline__ uint64_t val(const void *__restrict__ b, uint64_t i) { return as_global<RunEnt<uint64_t>>(b)[i].cum; }
-    static __device__ __forceinline__ pair load(const void *__restrict__ b, uint64_t i) { return as_global<pair>(b)[i]; }
     static __device__ __forceinline__ uint64_t samp(const void *__restrict__ b, uint64_t i) {
         const RBG_GLOBAL uint16_t *h = as_global<uint16_t>(b) + 3 * i;
         return static_cast<uint64_t>(h[0]) | (static_cast<uint64_t>(h[1]) << 16) | (static_cast<uint64_t>(h[2]) << 32);
     }
 };
 
-// the phi list (rbg_dev.h PhiFmt): pairs of 32-bit words, or 12-byte entries at 8-byte positions -- one request per entry
-template <typename P> struct PhiList;
-template <> struct PhiList<uint32_t> : RunList<uint32_t> {};
-template <> struct PhiList<uint64_t> {
-    typedef unsigned long long pair __attribute__((ext_vector_type(2)));
-    typedef unsigned int vec3 __attribute__((ext_vector_type(3), aligned(4)));
-    static __device__ __forceinline__ pair unpack(uint32_t w0, uint32_t w1, uint32_t w2) {
-        return pair{static_cast<uint64_t>(w0) | (static_cast<uint64_t>(w2 & 0xFFFFu) << 32), static_cast<uint64_t>(w1) | (static_cast<uint64_t>(w2 >> 16) << 32)};
-    }
-    static __device__ __forceinline__ pair load(const void *__restrict__ b, uint64_t i) {
-        const vec3 w = *reinterpret_cast<const RBG_GLOBAL vec3 *>(as_global<uint32_t>(b) + 3 * i);
-        return unpack(w.x, w.y, w.z);
-    }
-    static __device__ __forceinline__ uint64_t key(const void *__restrict__ b, uint64_t i) { return load(b, i).x; }
-    static __device__ __forceinline__ uint64_t val(const void *__restrict__ b, uint64_t i) { return load(b, i).y; }
-};
-
-// Run-indexed layout, one lane on its own: binary search of the run list (the kernels that are not on the
-// rb_align path -- seeding, windowed markers, single LF steps -- answer their ranks this way there; K1/K2/K3 have
-// the wave-cooperative search of k_runs.hip).  aux->nbefore = # runs starting before i (pred_run needs no ord[]).
-template <typename P>
-__device__ __forceinline__ uint64_t rank_runs_lane(const DevSym &S, uint64_t i, RankAux *aux) {
-    typedef RunList<P> L;
-    const void *__restrict__ ent = S.ent;
-    uint64_t a = 0, z = S.nruns;
-    if (S.ord) {   // the symbol's directory (rbg_dev.h DevRunTab; upload_tables_runs puts it here): the runs of i's bucket and the one before
-        const uint64_t b = i >> S.shift;
-        const RBG_GLOBAL uint32_t *ord = as_global(S.ord);
-        a = ord[b];
-        z = ord[b + 1];
-        a = a ? a - 1 : 0;
-    }
-    while (z - a > 4) {
-        const uint64_t mid = a + ((z - a) >> 1);
-        if (static_cast<uint64_t>(L::key(ent, mid)) < i) a = mid + 1; else z = mid;
-    }
-    while (a < z && static_cast<uint64_t>(L::key(ent, a)) < i) ++a;
-    aux->ovf = false;
-    aux->dense = false;
-    aux->nbefore = static_cast<uint32_t>(a);
-    if (a == 0) { aux->inside = false; return 0; }
-    const typename L::pair e = L::load(ent, a - 1);
-    const uint64_t len = static_cast<uint64_t>(L::val(ent, a)) - static_cast<uint64_t>(e.y);
-    const uint64_t d = i - static_cast<uint64_t>(e.x);
-    aux->inside = d <= len;
-    return static_cast<uint64_t>(e.y) + (d < len ? d : len);
-}
-
 // both ranks of one LF step (rowbowt.hpp:79,83).  lo and hi+1 usually share a bucket late in the
 // search (the range has narrowed to a few dozen rows), so the step is ONE 4-word load.
-// SLOT64: also understand 64-byte slots, lane by lane (the kernels beside the hot path); K1/K2 over 16-byte slots are only
-// ever launched on an index that has none and instantiate without it -- the extra sixteen registers cost them spills
-template <typename P, bool SLOT64 = true>
+template <typename P>
 __device__ __forceinline__ void rank_pair(const DevSym &S, const uint8_t *__restrict__ dense, uint64_t lo, uint64_t hi1,
                                           uint64_t *c_before, uint64_t *c_upto, uint64_t *bh_out, RankAux *qaux,
                                           RankAux *paux_out = nullptr) {
     const RankSlot *__restrict__ slots = static_cast<const RankSlot *>(S.slots);
-    if (SLOT64 && sym_is_slot64(S)) {  // 64-byte slots, lane by lane
-        const RankSlot64 *__restrict__ s64 = static_cast<const RankSlot64 *>(S.slots);
-        const uint32_t bs = S.shift + kSlot64Extra;
-        const uint64_t bl = lo >> bs, bh = hi1 >> bs;
-        uint32_t w[16];
-        load_slot64(s64 + bl, w);
-        Rank64Aux a0, a1;
-        *c_before = rank_in_slot64(w, bs, bl, lo, dense, &a0);
-        if (bh != bl) load_slot64(s64 + bh, w);
-        *c_upto = rank_in_slot64(w, bs, bh, hi1, dense, &a1);
-        *bh_out = bh;
-        // (RankAux::nbefore carries the run ordinal ord + nbefore: pred_run / pred_sample read no ord[] in this format)
-        qaux->nbefore = a1.ord + a1.nbefore; qaux->inside = a1.inside; qaux->ovf = false; qaux->dense = a1.dense;
-        if (paux_out) { paux_out->nbefore = a0.ord + a0.nbefore; paux_out->inside = a0.inside; paux_out->ovf = false; paux_out->dense = a0.dense; }
-        return;
-    }
-    if (slots == nullptr) {  // run-indexed layout
-        RankAux pa;
-        *c_before = rank_runs_lane<P>(S, lo, &pa);
-        *c_upto = rank_runs_lane<P>(S, hi1, qaux);
-        *bh_out = 0;
-        if (paux_out) *paux_out = pa;
-        return;
-    }
     const uint64_t bl = lo >> S.shift, bh = hi1 >> S.shift;
     const RankSlot sl = load_slot(slots + bl);
     RankSlot sh = sl;
@@ -352,7 +198,6 @@ __device__ __forceinline__ void rank_pair(const DevSym &S, const uint8_t *__rest
 // ordinal of the last run of the symbol that starts before the position a RankAux describes
 template <typename P>
 __device__ __forceinline__ uint64_t pred_run(const DevSym &S, uint64_t b, bool ovf, uint32_t v) {
-    if (S.slots == nullptr || S.ord == nullptr) return static_cast<uint64_t>(v) - 1;  // run-indexed layout / 64-byte slots: v already counts from the first run
     return (ovf ? runs_before<P>(S, b, (b << S.shift) + v) : static_cast<uint64_t>(as_global(S.ord)[b]) + v) - 1;
 }
 
@@ -361,7 +206,6 @@ __device__ __forceinline__ uint64_t pred_run(const DevSym &S, uint64_t b, bool o
 template <typename P>
 __device__ __forceinline__ uint64_t pred_sample(const DevSym &S, uint64_t b, const RankAux &aux) {
     const uint64_t j = pred_run<P>(S, b, aux.ovf, aux.nbefore);
-    if (sizeof(P) == 8 && S.slots == nullptr) return RunList<P>::samp(S.samp, j);   // run-indexed layout: 6-byte samples (rbg_dev.h RunsFmt)
     return static_cast<uint64_t>(as_global<P>(S.samp)[j]);
 }
 

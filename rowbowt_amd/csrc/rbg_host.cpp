@@ -965,10 +965,7 @@ bool choose_major(HostIndex &out, const FlattenOptions &opt) {
     std::memset(out.major_of, 0xFF, sizeof(out.major_of));
     out.nmajor = 0;
     out.major_slot.clear();
-    out.pair.clear();
-    out.triple.clear();
-    out.quad.clear();
-    out.quint.clear();
+    out.clear_kmer();
     if (opt.kmer_steps < 2 || out.sigma < 2) return false;
     // the terminator: the smallest symbol, occurring once (rle_string.hpp:59,62 maps 0 -> 1).
     // Without one the wrap argument of DESIGN.md 2b does not hold: keep single steps only.
@@ -992,7 +989,7 @@ bool choose_major(HostIndex &out, const FlattenOptions &opt) {
 
 int build_kmer_tables(HostIndex &out, const RawTsa *tsa, const FlattenOptions &opt) {
     if (!choose_major(out, opt)) return RBG_OK;
-    if (opt.defer_kmer) { out.kmer_deferred = static_cast<uint32_t>(std::min(5, opt.kmer_steps)); return RBG_OK; }
+    if (opt.defer_kmer) { out.kmer_deferred = static_cast<uint32_t>(std::min(kMaxKmerDepth, opt.kmer_steps)); return RBG_OK; }
     return compose_kmer_tables_host(out, opt.kmer_steps, opt);
 }
 }  // namespace
@@ -1000,13 +997,13 @@ int build_kmer_tables(HostIndex &out, const RawTsa *tsa, const FlattenOptions &o
 int compose_kmer_tables_host(HostIndex &out, int kmer_steps, const FlattenOptions &opt_in) {
     FlattenOptions opt = opt_in;
     opt.kmer_steps = kmer_steps;
-    out.pair.clear(); out.triple.clear(); out.quad.clear(); out.quint.clear();
+    out.clear_kmer();
     out.kmer_deferred = 0;
     if (out.nmajor == 0 || kmer_steps < 2) return RBG_OK;
+    if (kmer_steps > kMaxKmerDepth) opt.kmer_steps = kmer_steps = kMaxKmerDepth;
     RawTsa tsa_view;   // compose() only needs samples_last
     const RawTsa *tsa = nullptr;
     if (out.has_tsa) { tsa_view.samples_last = out.samples_last; tsa = &tsa_view; }
-    {
     const std::vector<uint32_t> order = out.major_slot;
     const uint32_t M = out.nmajor;
     // depth 1: the BWT runs themselves, id = major index of the head, sample = samples_last_ (SA - 1)
@@ -1020,24 +1017,17 @@ int compose_kmer_tables_host(HostIndex &out, int kmer_steps, const FlattenOption
     if (tsa) G.samp = tsa->samples_last;
     std::vector<SymTable> depth1(M);
     for (uint32_t m = 0; m < M; ++m) depth1[m] = out.sym[order[m]];
-    Segmentation G2, G3, G4;
-    int rc = compose(out, order, G, 1, M, depth1, tsa != nullptr, opt, out.pair, opt.kmer_steps >= 3 ? &G2 : nullptr);
-    if (rc) return rc;
-    Segmentation().start.swap(G.start);
-    if (opt.kmer_steps >= 3) {
-        rc = compose(out, order, G2, 2, M * M, out.pair, tsa != nullptr, opt, out.triple, opt.kmer_steps >= 4 ? &G3 : nullptr);
+    // depth d + 1 from depth d's tables and segmentation, one sweep per depth
+    uint32_t n_ids = M;
+    for (int d = 1; d < kmer_steps; ++d, n_ids *= M) {
+        Segmentation Gn;
+        const bool more = d + 1 < kmer_steps;
+        const int rc = compose(out, order, G, static_cast<uint32_t>(d), n_ids, d == 1 ? depth1 : out.kmer(static_cast<uint32_t>(d)), tsa != nullptr, opt,
+                               out.kmer(static_cast<uint32_t>(d + 1)), more ? &Gn : nullptr);
         if (rc) return rc;
-    }
-    if (opt.kmer_steps >= 4) {
-        rc = compose(out, order, G3, 3, M * M * M, out.triple, tsa != nullptr, opt, out.quad, opt.kmer_steps >= 5 ? &G4 : nullptr);
-        if (rc) return rc;
-    }
-    if (opt.kmer_steps >= 5) {
-        rc = compose(out, order, G4, 4, M * M * M * M, out.quad, tsa != nullptr, opt, out.quint, nullptr);
-        if (rc) return rc;
+        G = std::move(Gn);
     }
     return RBG_OK;
-    }
 }
 
 namespace {

@@ -102,6 +102,11 @@ struct SymTable {
     const void *dev_ent = nullptr, *dev_samp = nullptr;
 };
 
+// symbols one search step may consume: the slot layout stages the tables of up to 5 symbols per gather in LDS, the run-indexed
+// layout reads the records of deeper tables from a global array (rbg_dev.h kMaxRunDepth is this constant)
+constexpr int kMaxKmerDepth = 8;
+constexpr int kMaxSlotKmerDepth = 5;
+
 struct HostIndex {
     uint64_t n = 0, r = 0;
     uint32_t sigma = 0;
@@ -113,16 +118,23 @@ struct HostIndex {
     std::vector<uint64_t> run_start;   // R + 1
     // toehold SA
     // multi-symbol steps: for the <= 4 most frequent non-terminator symbols ("major"),
-    // pair[m1 * nmajor + m0] / triple[(m2 * nmajor + m1) * nmajor + m0] are the tables of the rows
+    // kmer(2)[m1 * nmajor + m0] / kmer(3)[(m2 * nmajor + m1) * nmajor + m0] are the tables of the rows
     // whose preceding text characters are x1 x0 / x2 x1 x0 (x0 = bwt[p] adjacent to the suffix).
     // F is the first row of the SA interval of that k-mer; samp[] holds SA - k at each run end.
     uint32_t nmajor = 0;
     uint8_t major_byte[4] = {0, 0, 0, 0};
     uint8_t major_of[256];             // byte -> 0..nmajor-1, 0xFF otherwise
-    std::vector<SymTable> pair;        // nmajor^2, or empty (multi-symbol steps disabled)
-    std::vector<SymTable> triple;      // nmajor^3, or empty
-    std::vector<SymTable> quad;        // nmajor^4, or empty
-    std::vector<SymTable> quint;       // nmajor^5, or empty
+    std::vector<SymTable> kmer_lv[kMaxKmerDepth - 1];   // [d - 2]: the nmajor^d tables of depth d = 2 .. kMaxKmerDepth, or empty
+    std::vector<SymTable> &kmer(uint32_t d) { return kmer_lv[d - 2]; }
+    const std::vector<SymTable> &kmer(uint32_t d) const { return kmer_lv[d - 2]; }
+    // the deepest depth that has tables (1: single-symbol steps only)
+    uint32_t kmer_levels() const {
+        uint32_t k = 1;
+        for (uint32_t d = 2; d <= static_cast<uint32_t>(kMaxKmerDepth); ++d)
+            if (!kmer_lv[d - 2].empty()) k = d;
+        return k;
+    }
+    void clear_kmer() { for (auto &v : kmer_lv) std::vector<SymTable>().swap(v); }
     // > 0: flatten() only chose the k-mer alphabet and left the composition of depths 2 .. kmer_deferred to the device
     // (FlattenOptions::defer_kmer; rbg_capi.hip upload() runs k_compose.hip before it sizes the replica)
     uint32_t kmer_deferred = 0;
@@ -142,7 +154,7 @@ struct FlattenOptions {
     int deep_bucket_shift = -1;  // >= 0: bucket shift of the 4-mer and deeper levels (their runs are sparse)
     int phi_bucket_shift = -1;
     int force_pos_bytes = 0;     // 0: 4 when n fits, else 8
-    int kmer_steps = 5;          // symbols consumed per gather: 1 (reference shape) .. 5
+    int kmer_steps = 5;          // symbols consumed per step: 1 (reference shape) .. kMaxKmerDepth
     bool defer_kmer = false;     // choose the k-mer alphabet but leave the tables of depth >= 2 to the device (HostIndex::kmer_deferred)
 };
 

@@ -1,12 +1,12 @@
-// rbg_runs2_device.hpp -- FORMAT 2 of the run-indexed layout (rbg_dev.h DevRunTab2; DevIndex::run_fmt == 2): one lane
-// answers its own ranks and phi steps.  rle_string::rank (rle_string.hpp:131-161) and ToeholdSA::phi
-// (toehold_sa.hpp:56-72) stay predecessor searches over run boundaries / sampled positions in O(r) space, but the
-// directory has already cut the search down to the handful of entries of one bucket (and the one before them), so the
+// rbg_runs2_device.hpp -- the search of the run-indexed layout (rbg_dev.h DevRunTab2; "format 2" in profiles/ and
+// DESIGN_HISTORY.md): one lane answers its own ranks and phi steps.  rle_string::rank (rle_string.hpp:131-161) and
+// ToeholdSA::phi (toehold_sa.hpp:56-72) stay predecessor searches over run boundaries / sampled positions in O(r) space, but
+// the directory has already cut the search down to the handful of entries of one bucket (and the one before them), so the
 // lane that owns the query fetches exactly those -- independent 16-byte requests, all in flight together -- and scans
-// them in registers.  Round 2/3's probes spread the same entries over 16, 8 and finally 4 lanes (rbg_runs_device.hpp);
-// each halving of the group was faster because the work per step is cross-lane choreography, not memory: with one lane
-// per query there is none left.  At 8-byte positions the entries carry the low 32 bits of {start, cum}
-// only (rbg_dev.h: the bucket number is the high part, as in Elias-Fano): half the bytes per entry, 32-bit compares.
+// them in registers.  Rounds 2-3 spread the same entries over 16, 8 and finally 4 lanes; each halving of the group was
+// faster because the work per step is cross-lane choreography, not memory: with one lane per query there is none left
+// (DESIGN.md 2c).  At 8-byte positions the entries carry the low 32 bits of {start, cum} only (rbg_dev.h: the bucket number
+// is the high part, as in Elias-Fano): half the bytes per entry, 32-bit compares.
 #pragma once
 
 #include "rbg_runs_device.hpp"
@@ -19,7 +19,8 @@ constexpr uint32_t kLanePhiMaxZ = 8;   // sampled positions one phi scan covers 
 
 template <typename P>
 struct RunSearch2 {
-    const DevRunTab2 *tab;        // LDS: the tables' records (run_ntabs of them)
+    const DevRunTab2 *tab;        // LDS: the records of the tables of depths <= kLdsRunDepth
+    const DevRunTab2 *gtab;       // device memory: all run_ntabs records (the deeper depths' are read from here: rbg_dev.h kMaxRunDepth)
     const uint32_t *tab_first;    // LDS [kMaxRunDepth + 1]: first record of each depth
     const void *const *ent;       // LDS [kMaxRunDepth]: entry arrays per depth
     const void *const *dir;       // LDS [kMaxRunDepth]: directory arrays per depth
@@ -34,7 +35,7 @@ struct RunSearch2 {
     __shared__ const void *s_rec2[8];                                     \
     extern __shared__ __align__(16) unsigned char s_dyn[]
 
-inline size_t run_search2_lds(const DevIndex &ix) { return static_cast<size_t>(ix.run_ntabs) * sizeof(DevRunTab2) + 16; }
+inline size_t run_search2_lds(const DevIndex &ix) { return static_cast<size_t>(ix.run_tab_first[kLdsRunDepth]) * sizeof(DevRunTab2) + 16; }
 
 // fills the arrays of RBG_RUN_SEARCH2_SHARED and returns the view of them; ends with __syncthreads()
 template <typename P>
@@ -50,13 +51,28 @@ __device__ __forceinline__ RunSearch2<P> stage_run_search2(const DevIndex &ix, u
     {   // the records as 16-byte words (two per record)
         const uint4 *src = reinterpret_cast<const uint4 *>(ix.run_tabs2);
         uint4 *dst = reinterpret_cast<uint4 *>(s_tab);
-        for (uint32_t t = threadIdx.x; t < 2u * ix.run_ntabs; t += blockDim.x) dst[t] = src[t];
+        for (uint32_t t = threadIdx.x; t < 2u * ix.run_tab_first[kLdsRunDepth]; t += blockDim.x) dst[t] = src[t];
     }
     __syncthreads();
     RunSearch2<P> S;
-    S.tab = s_tab; S.tab_first = s_tab_first; S.ent = s_ent2; S.dir = s_dir2; S.rec = s_rec2;
+    S.tab = s_tab; S.gtab = ix.run_tabs2; S.tab_first = s_tab_first; S.ent = s_ent2; S.dir = s_dir2; S.rec = s_rec2;
     S.fill = ix.run_fill_shift;
     return S;
+}
+
+// the record of table `rec` of depth index d: from LDS up to kLdsRunDepth, else two 16-byte loads of one 32-byte record (L2 / MALL resident)
+template <typename P>
+__device__ __forceinline__ DevRunTab2 load_run_tab(const RunSearch2<P> &S, const uint32_t d, const uint32_t rec) {
+    if (d < static_cast<uint32_t>(kLdsRunDepth)) return S.tab[rec];
+    const RBG_GLOBAL u32x4 *p = as_global<u32x4>(static_cast<const void *>(S.gtab + rec));
+    const u32x4 a = p[0], b = p[1];
+    DevRunTab2 R;
+    R.F = static_cast<uint64_t>(a.x) | (static_cast<uint64_t>(a.y) << 32);
+    R.first = static_cast<uint64_t>(a.z) | (static_cast<uint64_t>(a.w) << 32);
+    R.dir_off = static_cast<uint64_t>(b.x) | (static_cast<uint64_t>(b.y) << 32);
+    R.dir_shift = b.z;
+    R.pad = 0;
+    return R;
 }
 
 typedef unsigned int u32x2a4 __attribute__((ext_vector_type(2), aligned(4)));
@@ -300,7 +316,7 @@ __device__ __forceinline__ void lane_finish(const char *__restrict__ tent, LaneR
 
 // What the instrumented instantiations count on this format (the eight sums of SearchStat): [kStSteps] search steps,
 // [kStSlots] directory gathers (two neighbouring entries: 8 or 16 bytes), [kStDense] run-list entries the scans needed
-// (8 bytes each), [kStSearch] narrowing rounds (seven 4-byte pivots each), the rest as in rbg_runs_device.hpp.
+// (8 bytes each), [kStSearch] narrowing rounds (seven 4-byte pivots each), the rest as rbg_runs_device.hpp lists them.
 
 // Both ranks of one LF step of ONE lane: rle_string::rank (rle_string.hpp:131-161) in the k-mer table `rec` of depth
 // index d at positions q0 = lo and q1 = hi + 1 (q0 <= q1).  out.samp_e = the entry whose sample a toehold re-sample needs.
@@ -308,7 +324,7 @@ template <typename P, bool STATS = false, bool LEAN = false>
 __device__ __forceinline__ void lane_lf2(const RunSearch2<P> &S, const uint32_t d, const uint32_t rec, const uint64_t q0, const uint64_t q1, RunStep &out,
                                          unsigned long long *st = nullptr) {
     constexpr bool W = sizeof(P) == 8;
-    const DevRunTab2 R = S.tab[rec];
+    const DevRunTab2 R = load_run_tab<P>(S, d, rec);
     out.F = R.F;
     const uint32_t sh = R.dir_shift;
     const uint64_t b0 = q0 >> sh, b1 = q1 >> sh;
@@ -454,7 +470,7 @@ __device__ __forceinline__ void lane_lf2_quad(const RunSearch2<P> &S, const bool
         return;
     }
     const uint32_t p = threadIdx.x & 3u;
-    DevRunTab2 R = S.tab[stepping ? rec : 0u];
+    const DevRunTab2 R = load_run_tab<P>(S, stepping ? d : 0u, stepping ? rec : 0u);
     const uint32_t sh = R.dir_shift;
     const uint64_t b0 = stepping ? q0 >> sh : 0u, b1 = stepping ? q1 >> sh : 0u;
     const char *recs = static_cast<const char *>(S.rec[stepping ? d : 0u]);

@@ -36,3 +36,35 @@ def _build_oracle():
     if not os.path.exists(lib) or not os.path.exists(cli) or not os.path.exists(cli2) or not os.path.exists(os.path.join(ROOT, "rowbowt_amd", "rb_build")) or os.path.getmtime(lib) < newest:
         subprocess.check_call(["make", "-C", csrc, "-j4"])
     yield
+
+
+# ---- fixtures of the GPU parity files (tests/test_gpu_*.py); nothing here touches a device until a test asks for one --------
+@pytest.fixture(scope="session")
+def small(data_dir):
+    """the reference's toy fixture through rbg_load on device 0, and the oracle on the same files"""
+    import orc
+    import rowbowt_amd as ra
+    rb = ra.load_rowbowt(os.path.join(data_dir, "small.fa"), ra.LoadRbwtFlag.SA | ra.LoadRbwtFlag.MA, device=0)
+    o = orc.Oracle.load(os.path.join(data_dir, "small.fa"), orc.SA | orc.MA)
+    yield rb, o
+    rb.close()
+    o.close()
+
+
+@pytest.fixture(scope="session")
+def simple_reads(data_dir):
+    import orc
+    return orc.read_fastx(os.path.join(data_dir, "simple_query.fq"))[1]
+
+
+@pytest.fixture(scope="session")
+def error_reads(data_dir):
+    import orc
+    return orc.read_fastx(os.path.join(data_dir, "error_query.fq"))[1]
+
+
+@pytest.fixture(scope="session")
+def synth():
+    """a synthetic pangenome small enough for the oracle and an explicit-text FM index (both position widths, ragged reads)"""
+    from synth import SynthIndex
+    return SynthIndex(L=4000, H=8, n_sites=60, seed=11)

@@ -25,7 +25,7 @@ def test_exports_match_header():
     L = ra.lib()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.rbg_abi_version() == 2
+    assert L.rbg_abi_version() == 3 == capi.ABI_VERSION
     assert b"CPU" in L.rbg_strerror(-3)
 
 
@@ -68,9 +68,12 @@ def test_loader_matches_oracle_reader(small_host, small_orc):
 
 def test_two_step_tables_built(small_host):
     i = small_host.info()
-    assert i.kmer_steps == 5 and i.kmer_symbols == 4
+    assert i.kmer_steps == 8 and i.kmer_symbols == 4   # (RBG_OPT_KMER_STEPS defaults to 8; a host-only index composes them all)
     assert 0 < i.pair_runs <= 2 * i.r and i.pair_runs <= i.triple_runs <= 3 * i.r and i.triple_runs <= i.quad_runs <= 4 * i.r
     assert i.quad_runs <= i.quint_runs <= 5 * i.r
+    runs = list(i.depth_runs)
+    assert runs[0] == i.r and runs[1:5] == [i.pair_runs, i.triple_runs, i.quad_runs, i.quint_runs]
+    assert all(runs[d - 1] <= runs[d] <= (d + 1) * i.r for d in range(1, 8))   # every depth cuts each run of the one before at most once more
 
 
 def test_greedy_seeding_fixture(data_dir):
@@ -150,21 +153,23 @@ def test_tuning_options_are_range_checked():
     (RBG_EARG) and leaves the previous value in force; the defaults are restored afterwards."""
     L = ra.lib()
     ok = {capi.OPT_BLOCK_THREADS: [64, 128, 256], capi.OPT_RANK_BUCKET_SHIFT: [0, 8, 12, -1], capi.OPT_PHI_BUCKET_SHIFT: [0, 8, -1],
-          capi.OPT_POS_BYTES: [4, 8, 0], capi.OPT_KMER_STEPS: [1, 3, 5], capi.OPT_HBM_BUDGET_MB: [1, 0], capi.OPT_FTAB_K: [0, 16, -1],
+          capi.OPT_POS_BYTES: [4, 8, 0], capi.OPT_KMER_STEPS: [1, 3, 5, 8], capi.OPT_HBM_BUDGET_MB: [1, 0], capi.OPT_FTAB_K: [0, 16, -1],
           capi.OPT_PACKED_READS: [0, 2, 1], capi.OPT_DEEP_BUCKET_SHIFT: [9, 12, -1], capi.OPT_DENSE_OVERFLOW: [0, 1],
-          capi.OPT_RANK_LAYOUT: [1, 2, 3, 0], capi.OPT_TREE_TOP_KB: [0, 96, 48], capi.OPT_SLOT_BYTES: [64, 16], capi.OPT_RUN_DEPTHS: [0x15, 31, 0],
-          capi.OPT_RUN_FMT: [1, 2], capi.OPT_RUN_PHI: [1, 2, 0], capi.OPT_RUN_REC: [1, 2, 0]}
+          capi.OPT_RANK_LAYOUT: [1, 2, 3, 0], capi.OPT_RUN_DEPTHS: [0x15, 31, 255, 0],
+          capi.OPT_RUN_PHI: [1, 2, 0], capi.OPT_RUN_REC: [1, 2, 0]}
     bad = {capi.OPT_BLOCK_THREADS: [0, 100, 512], capi.OPT_RANK_BUCKET_SHIFT: [-2, 13], capi.OPT_PHI_BUCKET_SHIFT: [-2, 9],
-           capi.OPT_POS_BYTES: [2, 16], capi.OPT_KMER_STEPS: [0, 6], capi.OPT_HBM_BUDGET_MB: [-1], capi.OPT_FTAB_K: [-2, 17],
+           capi.OPT_POS_BYTES: [2, 16], capi.OPT_KMER_STEPS: [0, 9], capi.OPT_HBM_BUDGET_MB: [-1], capi.OPT_FTAB_K: [-2, 17],
            capi.OPT_PACKED_READS: [-1, 3], capi.OPT_DEEP_BUCKET_SHIFT: [-2, 13], capi.OPT_DENSE_OVERFLOW: [-1, 2],
-           capi.OPT_RANK_LAYOUT: [-1, 4], capi.OPT_TREE_TOP_KB: [-1, 97], capi.OPT_SLOT_BYTES: [0, 32, 128], capi.OPT_RUN_DEPTHS: [-1, 32],
-           capi.OPT_RUN_FMT: [0, 3], capi.OPT_RUN_PHI: [-1, 3], capi.OPT_RUN_REC: [-1, 3]}
+           capi.OPT_RANK_LAYOUT: [-1, 4], capi.OPT_RUN_DEPTHS: [-1, 256],
+           capi.OPT_RUN_PHI: [-1, 3], capi.OPT_RUN_REC: [-1, 3]}
     for opt, vals in ok.items():
         for v in bad[opt]:
             assert L.rbg_set_default_option(opt, v) == -4, (opt, v)   # RBG_EARG
         for v in vals:                                                 # the last value of each list is the default
             assert L.rbg_set_default_option(opt, v) == 0, (opt, v)
     assert L.rbg_set_default_option(0, 1) == -4 and L.rbg_set_default_option(18, 1) == -4
+    for retired in (12, 13, 15):   # RBG_OPT_TREE_TOP_KB, _SLOT_BYTES, _RUN_FMT: gone with ABI 3, together with the kernels they selected
+        assert L.rbg_set_default_option(retired, 2) == -4 and L.rbg_get_default_option(retired, C.byref(C.c_int64())) == -4
     assert all(capi.get_default_option(o) == vals[-1] for o, vals in ok.items())
 
 
@@ -300,11 +305,11 @@ def test_load_time_knobs_from_the_environment():
         p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=120)
         assert p.returncode == 0, p.stderr[-2000:]
         return p.stdout.split(), p.stderr
-    assert run()[0] == ["0", "0", "5", "0", "-1", "1"]
+    assert run()[0] == ["0", "0", "8", "0", "-1", "1"]
     out, _ = run(RBG_LAYOUT="runs", RBG_RUN_DEPTHS="0x11", RBG_KMER_STEPS="4", RBG_HBM_BUDGET_MB="50000", RBG_FTAB_K="10")
     assert out == ["2", "17", "4", "50000", "10", "1"]
-    out, err = run(RBG_LAYOUT="sideways", RBG_RUN_DEPTHS="32", RBG_KMER_STEPS="6", RBG_FTAB_K="x")
-    assert out == ["0", "0", "5", "0", "-1", "1"]
+    out, err = run(RBG_LAYOUT="sideways", RBG_RUN_DEPTHS="256", RBG_KMER_STEPS="9", RBG_FTAB_K="x")
+    assert out == ["0", "0", "8", "0", "-1", "1"]
     assert all(("rbg: %s=" % k) in err and "ignored" in err for k in ("RBG_LAYOUT", "RBG_RUN_DEPTHS", "RBG_KMER_STEPS", "RBG_FTAB_K"))
     assert run(RBG_LAYOUT="2")[0][0] == "2"
 
@@ -484,8 +489,8 @@ def test_header_is_plain_c_and_links(tmp_path):
     assert _compile_c_example(tmp_path).exists()
 
 
-def test_no_format2_kernel_spills():
-    """No kernel of the run-indexed layout's format 2 may use scratch: the one instantiation that spilled (the instrumented search at
+def test_no_run_indexed_kernel_spills():
+    """No kernel of the run-indexed layout may use scratch: the one instantiation that spilled (the instrumented search at
     8-byte positions, after the bucket records had raised its register need) faulted on the device (profiles/r04_fault_note.txt).
     hipcc cross-compiles for gfx950 without a GPU and reports every kernel's ScratchSize."""
     import re
@@ -508,7 +513,7 @@ def test_no_format2_kernel_spills():
     with ThreadPoolExecutor(2) as ex:
         res = sum(ex.map(usage, ["k_runs.hip", "k_runs_seeds.hip"]), [])
     names = subprocess.run(["c++filt"], input="\n".join(n for n, _ in res), capture_output=True, text=True).stdout.splitlines()
-    v2 = [(n, s) for n, (_m, s) in zip(names, res) if re.search(r"(k_find_range_runs<.*, true>|_runs<.*true>|runs2<)", n)]
-    assert len(v2) >= 20, len(v2)
+    v2 = [(n, s) for n, (_m, s) in zip(names, res) if re.search(r"(k_find_range_runs<|_runs<|runs2<)", n)]
+    assert len(v2) >= 35, len(v2)   # (12 + 5 of k_runs.hip, 2 + 4 + 2 + 6 + 6 of k_runs_seeds.hip)
     spilled = [(n, s) for n, s in v2 if s > 0]
     assert not spilled, spilled

@@ -92,7 +92,7 @@ int main(int argc, char** argv) {
     int a = parse_rbwt(pre + ".rbwt", rle), b = parse_tsa(pre + ".tsa", tsa), c = parse_mab(pre + ".mab", ma);
     int d = 1;
     if (!a && !b) { HostIndex ix; FlattenOptions o; d = flatten(rle, &tsa, o, ix);
-        if (!d) std::printf("n=%llu r=%llu sigma=%u pairs=%zu triples=%zu\n", (unsigned long long)ix.n, (unsigned long long)ix.r, ix.sigma, ix.pair.size(), ix.triple.size()); }
+        if (!d) std::printf("n=%llu r=%llu sigma=%u pairs=%zu triples=%zu\n", (unsigned long long)ix.n, (unsigned long long)ix.r, ix.sigma, ix.kmer(2).size(), ix.kmer(3).size()); }
     std::printf("rc %d %d %d %d\n", a, b, c, d);
     if (argc == 2 && std::string(argv[1]) == "garbage") {
         // run-length BWTs and samples that satisfy what the C-ABI checks (non-empty maximal runs, samples
@@ -123,7 +123,7 @@ int main(int argc, char** argv) {
             }
             if (!ok) continue;
             RawTsa t; tsa_from_samples(g.n, g.R, ssa.data(), esa.data(), t);
-            HostIndex ix; FlattenOptions o; o.kmer_steps = 1 + static_cast<int>(rnd(5));
+            HostIndex ix; FlattenOptions o; o.kmer_steps = 1 + static_cast<int>(rnd(8));
             if (flatten(g, &t, o, ix) == 0) ++built;
         }
         std::printf("garbage built %d\n", built);

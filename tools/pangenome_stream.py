@@ -43,7 +43,7 @@ def main():
     ap.add_argument("--count-only", action="store_true")
     ap.add_argument("--layout", choices=("auto", "slots", "runs"), default="auto")
     ap.add_argument("--run-depths", type=lambda v: int(v, 0), default=0, help="RBG_OPT_RUN_DEPTHS: bit d - 1 = keep run lists of the k-mer depth d (run-indexed layout; 0 = all)")
-    ap.add_argument("--kmer-steps", type=int, default=0, choices=(0, 1, 2, 3, 4, 5), help="RBG_OPT_KMER_STEPS (0 = the library's default, 5)")
+    ap.add_argument("--kmer-steps", type=int, default=0, choices=range(0, 9), help="RBG_OPT_KMER_STEPS (0 = the library's default, 8)")
     ap.add_argument("--run-phi", type=int, default=0, choices=(0, 1, 2), help="RBG_OPT_RUN_PHI: 1 = phi over the list of sampled positions, 2 = phi slots, 0 = the library's choice")
     ap.add_argument("--run-rec", type=int, default=0, choices=(0, 1, 2), help="RBG_OPT_RUN_REC: 1 = directories over the run lists, 2 = bucket records, 0 = the library's choice")
     ap.add_argument("--replica-probe", action="store_true",
@@ -345,7 +345,7 @@ def main():
                        "index": {"L": args.L, "H": args.H, "n": int(n), "r": int(inp["r"]), "site_rate": args.site_rate, "true_bwt": True,
                                  "builder": "rowbowt_amd/tools/pangenome_bwt.py", "hbm_bytes": int(ix.hbm_bytes), "pos_bytes": int(ix.pos_bytes),
                                  "symbols_per_gather": int(ix.kmer_steps), "symbols_per_gather_requested": int(ix.kmer_steps_requested),
-                                 "kmer_depths_with_tables": [1] + [d for d, x in ((2, ix.pair_runs), (3, ix.triple_runs), (4, ix.quad_runs), (5, ix.quint_runs)) if int(x)],
+                                 "kmer_depths_with_tables": [d + 1 for d in range(8) if int(ix.depth_runs[d])],
                                  "hbm_free_at_load": int(ix.hbm_free_at_load), "hbm_budget": int(ix.hbm_budget),
                                  "rank_bucket_shift": int(ix.rank_bucket_shift), "phi_bucket_shift": int(ix.phi_bucket_shift),
                                  "rank_layout": int(ix.rank_layout), "ftab_k": int(ix.ftab_k),
@@ -433,8 +433,7 @@ def main():
     if rank == 0:
         li = rb.layout_info()
         out["config"]["index"]["layout_info"] = {"run_fmt": int(li.run_fmt), "depth_mask_kept": int(li.depth_mask_kept), "depths_dropped_budget": int(li.depths_dropped_budget),
-                                                 "depths_dropped_limit": int(li.depths_dropped_limit), "rank_directories": int(li.rank_directories),
-                                                 "phi_directory": int(li.phi_directory), "phi_directory_dropped": int(li.phi_directory_dropped),
+                                                 "rank_directories": int(li.rank_directories), "phi_directory": int(li.phi_directory),
                                                  "entries": [int(x) for x in li.entries], "fillers": [int(x) for x in li.fillers], "dir_bytes": [int(x) for x in li.dir_bytes],
                                                  "phi_entries": int(li.phi_entries), "phi_fillers": int(li.phi_fillers), "phi_dir_bytes": int(li.phi_dir_bytes),
                                                  "phi_dir_shift": int(li.phi_dir_shift), "phi_slots": int(li.phi_slots), "phi_slot_bytes": int(li.phi_slot_bytes),

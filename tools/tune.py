@@ -56,7 +56,6 @@ for cfg in args.configs.split(","):
         ra.set_default_option(capi.OPT_DENSE_OVERFLOW, int(os.environ["RBG_TUNE_DENSE"]))
     if os.environ.get("RBG_TUNE_LAYOUT"):   # "runs": the run-indexed layout (space proportional to r); optional sixth field of a config = LDS KB of its top level
         ra.set_default_option(capi.OPT_RANK_LAYOUT, capi.LAYOUT_RUNS if os.environ["RBG_TUNE_LAYOUT"] == "runs" else capi.LAYOUT_SLOTS)
-        ra.set_default_option(capi.OPT_TREE_TOP_KB, parts[5] if len(parts) > 5 else 48)
         if len(parts) > 6:   # seventh field: RBG_RANK_REC (runs per bucket record; 0 = directories and run lists only)
             os.environ["RBG_RANK_REC"] = str(parts[6])
         else:
@@ -94,7 +93,7 @@ for cfg in args.configs.split(","):
     ms_f = t(lambda: L.rbg_locate_fill_dev(rb.h, d_lo.data_ptr(), d_hi.data_ptr(), d_k.data_ptr(), N, MAXU, d_loc_off.data_ptr(), d_locs.data_ptr(), d_ws.data_ptr(), st))
     d_qs, d_qe = (torch.empty(N, dtype=torch.int64, device=dev) for _ in range(2))
     ms_g = t(lambda: L.rbg_greedy_longest_seed_dev(rb.h, d_seqs.data_ptr(), d_off.data_ptr(), N, 20, d_lo.data_ptr(), d_hi.data_ptr(), d_qs.data_ptr(), d_qe.data_ptr(), d_k.data_ptr(), st))
-    print(f"cfg pos_bytes={i.pos_bytes} kmer_steps={i.kmer_steps} pair_runs={i.pair_runs} triple_runs={i.triple_runs} quad_runs={i.quad_runs} quint_runs={i.quint_runs} ftab_k={i.ftab_k} rank_shift={i.rank_bucket_shift}({rs}) phi_shift={i.phi_bucket_shift}({ps}) block={bt}: hbm={i.hbm_bytes/1e9:.2f}GB "
+    print(f"cfg pos_bytes={i.pos_bytes} kmer_steps={i.kmer_steps} depth_runs={list(i.depth_runs)} ftab_k={i.ftab_k} rank_shift={i.rank_bucket_shift}({rs}) phi_shift={i.phi_bucket_shift}({ps}) block={bt}: hbm={i.hbm_bytes/1e9:.2f}GB "
           f"rank_ovf={i.rank_slots_overflow}/{i.rank_slots} phi_ovf={i.phi_slots_overflow}/{i.phi_slots}  "
           f"count={ms_c:.2f}ms toehold={ms_t:.2f}ms pack={ms_pk:.2f}ms packed_count={ms_pc:.2f}ms packed_toehold={ms_pt:.2f}ms fill(unordered)={ms_f0:.2f}ms order={ms_o:.2f}ms fill={ms_f:.2f}ms greedy_seed={ms_g:.2f}ms  build={time.time()-t0:.1f}s", flush=True)
     rb.close()
