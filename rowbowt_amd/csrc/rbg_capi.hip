@@ -1279,6 +1279,7 @@ bool level_has_data(const rbg_index *ix, uint32_t d) {
     return false;
 }
 
+bool compose_deferred(int device);
 inline int levels_of(const HostIndex &h) { return static_cast<int>(h.kmer_levels()); }
 
 int upload(rbg_index *ix) {
@@ -1342,6 +1343,20 @@ int upload(rbg_index *ix) {
                                  "wider buckets or fewer symbols per step (RBG_LAYOUT_PREFER_SLOTS keeps slot tables)\n", ix->device, need() / 1e9, budget / 1e9);
         runs_layout = true;
         ix->auto_runs = true;
+        // the levels at hand are the slot layout's (at most kMaxSlotKmerDepth, composed before this look could be taken); the run-indexed
+        // layout steps by as many symbols as were asked for: compose again, that deep (rare: options_for's estimate usually decides first)
+        const uint32_t asked = static_cast<uint32_t>(std::min<int64_t>(g_opt_kmer_steps.load(), kMaxKmerDepth));
+        if (asked > h.kmer_levels() && compose_deferred(ix->device) && h.nmajor >= 1) {
+            for (SymTable &t : h.sym) {
+                free_tracked(ix, const_cast<void *>(t.dev_ent));
+                free_tracked(ix, const_cast<void *>(t.dev_samp));
+                t.dev_ent = t.dev_samp = nullptr;
+            }
+            h.kmer_deferred = asked;
+            ix->kmer_steps_requested = asked;
+            const int rcc = h.pos_bytes == 4 ? compose_on_device<uint32_t>(ix) : compose_on_device<uint64_t>(ix);
+            if (rcc) return rcc;
+        }
     }
     if (ix->runs_forced) runs_layout = true;
     if (runs_layout && h.sigma > static_cast<uint32_t>(kLdsSyms)) {

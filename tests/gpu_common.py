@@ -12,6 +12,9 @@ import orc
 import rowbowt_amd as ra
 from rowbowt_amd import capi
 
+__all__ = ["ROOT", "DEFAULT_KMER_STEPS", "split", "_check_marker_seeds", "_run_cli", "_run_rb_markers", "_random_run_index", "_lf_walk_reads", "_with_layout",
+           "_run_indexed_checks"]
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 MAXU = G.MAXU
 ALL = ra.LoadRbwtFlag.SA | ra.LoadRbwtFlag.MA

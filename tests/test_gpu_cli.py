@@ -49,7 +49,7 @@ def test_cli_layout_from_the_environment(data_dir, tmp_path):
     for env in ({"RBG_LAYOUT": "runs"}, {"RBG_LAYOUT": "runs", "RBG_RUN_DEPTHS": "0x1F"}, {"RBG_LAYOUT": "runs", "RBG_RUN_DEPTHS": "9", "RBG_FTAB_K": "0"}):
         rc, out, err = _run_cli(args, env=dict(env, RBG_VERBOSE="1"))
         assert rc == 0 and out == out0 and "run-indexed layout" in err, err
-        mask = {None: "0x15", "0x1F": "0x1f", "9": "0x9"}[env.get("RBG_RUN_DEPTHS")]
+        mask = {None: "0x8b", "0x1F": "0x1f", "9": "0x9"}[env.get("RBG_RUN_DEPTHS")]
         assert f"k-mer depths with run lists: mask {mask}" in err, err
 
 

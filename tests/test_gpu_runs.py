@@ -97,14 +97,16 @@ def test_default_load_takes_eight_symbols_per_step_on_the_run_indexed_layout(syn
     assert all(info.depth_runs[d] > 0 for d in (0, 1, 3, 7)) and not any(info.depth_runs[d] for d in (2, 4, 5, 6))
     assert info.depth_runs[7] >= info.depth_runs[3] >= info.depth_runs[1] >= info.r
     _run_indexed_checks(S, rb)
-    with capi.default_option(capi.OPT_HBM_BUDGET_MB, 2):   # (the slot tables of this index: about 6 MB at five symbols per gather)
+    slots = _with_layout(capi.LAYOUT_SLOTS, lambda: ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0))
+    assert slots.info().rank_layout == capi.LAYOUT_SLOTS and slots.info().kmer_steps == 5
+    need_slots, need_runs = int(slots.info().hbm_bytes), int(info.hbm_bytes)
+    slots.close()
+    assert need_runs * 2 < need_slots
+    with capi.default_option(capi.OPT_HBM_BUDGET_MB, (need_runs * 2 >> 20) + 1):   # (room for the run lists of eight depths, not for the slot tables of five)
         auto = ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0)
     ai = auto.info()
     assert ai.rank_layout == capi.LAYOUT_RUNS and ai.kmer_steps == 8 and auto.layout_info().depth_mask_kept == 0x8B
     _run_indexed_checks(S, auto)
-    slots = _with_layout(capi.LAYOUT_SLOTS, lambda: ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0))
-    assert slots.info().rank_layout == capi.LAYOUT_SLOTS and slots.info().kmer_steps == 5
-    slots.close()
 
 
 @pytest.mark.parametrize("recs", [False, True])
@@ -173,7 +175,7 @@ def test_composition_spills_kept_depths_to_host_and_back(synth, depths, capfd):
     _run_indexed_checks(S, rb)
 
 
-@pytest.mark.parametrize("pos_bytes,rec,dir_runs", [(0, None, None), (8, None, "64"), (0, None, "64"), (0, "rec", None), (8, "rec", "64"), (8, "rec", "6")])
+@pytest.mark.parametrize("pos_bytes,rec,dir_runs", [(0, None, None), (8, None, "64"), (0, None, "64"), (0, "rec", None), (8, "rec", "64"), (0, "rec", "64")])
 def test_run_indexed_crowded_buckets(pos_bytes, rec, dir_runs):
     """Directory buckets with a hundred and more runs (k_runs.hip: narrowing rounds, one after the other when the
     directory is coarse -- dir_runs = RBG_RANK_DIR_RUNS, or RBG_RUN_REC_PER with bucket records; scans whose candidates all lie
@@ -267,7 +269,7 @@ def test_run_indexed_layout_goldens_and_budget_rule(small, simple_reads, error_r
     l2, h2, k2 = rb2.find_range_w_toehold(seqs, off)
     assert (l2 == wlo).all() and (h2 == whi).all() and (k2 == wk).all()
     rb2.close()
-    assert hbm_runs < 3_000_000   # (run lists, samples, sampled levels and directories of five depths, each array rounded to 64 KB)
+    assert hbm_runs < 8_000_000   # (run lists, samples and bucket records of four depths, each array rounded to 64 KB, and 2 MB of table records: 4^8 tables at depth 8)
 
 
 @pytest.mark.parametrize("pos_bytes,mask,kept,recs", [(0, 0, 0x8B, False), (0, 0x15, 0x15, False), (8, 0x11, 0x11, False), (0, 0x13, 0x13, True),

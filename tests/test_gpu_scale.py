@@ -163,7 +163,7 @@ def test_positions_beyond_32_bits():
             ra.set_default_option(capi.OPT_KMER_STEPS, DEFAULT_KMER_STEPS)
             ra.set_default_option(capi.OPT_RUN_PHI, 0)
         ir = rbr.info()
-        assert ir.rank_layout == capi.LAYOUT_RUNS and ir.pos_bytes == 8 and ir.kmer_steps == ks and ir.hbm_bytes < (4e9 if ks == 1 else 12e9) + (0 if top_kb else 3e9)
+        assert ir.rank_layout == capi.LAYOUT_RUNS and ir.pos_bytes == 8 and ir.kmer_steps == ks and ir.hbm_bytes < (4e9 if ks == 1 else 12e9 if ks <= 5 else 20e9) + (0 if top_kb else 3e9)
         lo, hi, k = rbr.find_range_w_toehold(seqs, off)
         lo2, hi2 = rbr.find_range(seqs, off)
         assert (lo == wlo).all() and (hi == whi).all() and (lo2 == wlo).all() and (hi2 == whi).all() and (ks > 1 or (k == wk).all())
@@ -224,7 +224,7 @@ def test_width_limits_2_38_and_2_40():
         with capi.default_option(capi.OPT_KMER_STEPS, ks):
             rbr = _with_layout(capi.LAYOUT_RUNS, lambda: ra.RowBowt.from_runs(*c[:4], device=0))
         ir = rbr.info()
-        assert ir.rank_layout == capi.LAYOUT_RUNS and ir.pos_bytes == 8 and ir.n == n and ir.hbm_bytes < 16e9
+        assert ir.rank_layout == capi.LAYOUT_RUNS and ir.pos_bytes == 8 and ir.n == n and ir.hbm_bytes < 24e9
         check(rbr, c, toeholds=ks == 1)
         rbr.close()
     # slot tables, single-symbol level, 256-row rank buckets and 256-position phi buckets: n/256 x (5 x 20 + 36) bytes
@@ -271,7 +271,7 @@ def test_width_limits_2_38_and_2_40():
         assert ei.value.code == -4                          # RBG_EARG: 40-bit ranks cannot hold this index
     rba = ra.RowBowt.from_runs(*c[:4], device=0)            # AUTO: the single-symbol slot level (n/256 x 100 B = 430 GB) does not fit
     ia = rba.info()
-    assert ia.rank_layout == capi.LAYOUT_RUNS and ia.pos_bytes == 8 and ia.hbm_bytes < 16e9
+    assert ia.rank_layout == capi.LAYOUT_RUNS and ia.pos_bytes == 8 and ia.hbm_bytes < 24e9
     check(rba, c, toeholds=False)                           # (k-mer depths: see above)
     rba.close()
     with capi.default_option(capi.OPT_KMER_STEPS, 1):

@@ -190,6 +190,11 @@ def _hbm_budget_drops_kmer_levels(S, layout):
     full = rb.info().hbm_bytes
     assert rb.info().kmer_steps == 5
     rb.close()
+    with capi.default_option(capi.OPT_RANK_LAYOUT, capi.LAYOUT_RUNS):
+        r8 = ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0)
+    need_runs8 = int(r8.info().hbm_bytes)   # (the run-indexed replica with eight symbols per step: a fraction of the slot tables of five)
+    assert r8.info().kmer_steps == 8 and need_runs8 * 4 < full
+    r8.close()
     seen = set()
     for frac in (4.0, 0.7, 0.3, 0.08, 0.02):   # (the budget rule prices the replica with the composition's own lists: about 2.7 x what stays)
         ra.set_default_option(capi.OPT_HBM_BUDGET_MB, max(1, int(full * frac) >> 20))
@@ -205,8 +210,8 @@ def _hbm_budget_drops_kmer_levels(S, layout):
         seen.add("runs" if runs and layout == capi.LAYOUT_AUTO else int(rb.info().kmer_steps))
         # levels that cannot fit are not even composed (options_for in rbg_capi.hip); what was asked for is still reported
         assert int(rb.info().kmer_steps_requested) == (8 if runs else 5) and int(rb.info().hbm_budget) == max(1, int(full * frac) >> 20) << 20   # (asked for: eight; the slot layout takes five of them at most)
-        if runs and layout == capi.LAYOUT_AUTO and 110 * len(S.heads) <= int(rb.info().hbm_budget):
-            assert int(rb.info().kmer_steps) >= 5        # the switch was made to keep the symbols per step (eight while the budget holds them)
+        if runs and layout == capi.LAYOUT_AUTO and int(rb.info().hbm_budget) >= 2 * need_runs8:
+            assert int(rb.info().kmer_steps) == 8        # the switch was made to keep the symbols per step: all eight while the budget holds them
         got = rb.find_range_w_toehold(seqs, off)
         assert all((g == w).all() for g, w in zip(got, want))
         rb.close()
