@@ -335,42 +335,38 @@ __global__ __launch_bounds__(256) void k_run_recs2(const RunEnt<P> *__restrict__
         r.e0 = static_cast<uint32_t>(e0);
         r.hi = (sizeof(P) == 8 && lo) ? static_cast<uint32_t>(static_cast<uint64_t>(e[lo - 1].cum) >> 31) : 0u;
 #pragma unroll
-        for (uint32_t k = 0; k < 2 * kRec2Ents; ++k) r.ent[k] = 0u;
-        bool compact = cnt >= 1 && cnt <= kRec2CompactIn + 1;
+        for (uint32_t k = 0; k < kRec2Pivots; ++k) r.ent[k] = 0u;
+        // COMPACT (rbg_dev.h): the first entry held in full, up to ten more as {offset into the bucket : sh bits, length : 32 - sh bits}
+        const uint64_t len_lim = sh < 32 ? (uint64_t(1) << (32 - sh)) : 0;
+        bool compact = sh < 32 && cnt <= kRec2CompactIn + 1;
         for (uint64_t j = 1; compact && j < cnt; ++j) {
-            const uint64_t off = static_cast<uint64_t>(e[e0 + j].start) - lim;     // (entries e0 + 1 .. start inside the bucket: lo <= e0 + 1)
             const uint64_t len = static_cast<uint64_t>(e[e0 + j + 1].cum) - static_cast<uint64_t>(e[e0 + j].cum);
-            compact = static_cast<uint64_t>(e[e0 + j].start) >= lim && off < 0x10000ull && len < 0x10000ull;
+            compact = static_cast<uint64_t>(e[e0 + j].start) >= lim && len < len_lim;   // (entries e0 + 1 .. start inside the bucket: lo <= e0 + 1)
         }
         if (compact) {
+            const uint32_t unused = static_cast<uint32_t>((uint64_t(1) << sh) - 1);                   // (offset = the bucket's last row, length 0: never below a position, adds nothing)
             r.meta = static_cast<uint32_t>(cnt) | kRec2Compact;
-            r.cum_end = static_cast<uint32_t>(static_cast<uint64_t>(e[e0].cum));                      // cum of the first entry held
-            r.ent[0] = static_cast<uint32_t>(static_cast<uint64_t>(e[e0].start));
-            r.ent[1] = static_cast<uint32_t>(static_cast<uint64_t>(e[e0 + 1].cum) - static_cast<uint64_t>(e[e0].cum));   // its length (< 2^32: fillers)
+            r.cum_end = cnt ? static_cast<uint32_t>(static_cast<uint64_t>(e[e0].cum)) : 0u;           // cum of the first entry held
+            r.ent[0] = cnt ? static_cast<uint32_t>(static_cast<uint64_t>(e[e0].start)) : 0u;
+            r.ent[1] = cnt ? static_cast<uint32_t>(static_cast<uint64_t>(e[e0 + 1].cum) - static_cast<uint64_t>(e[e0].cum)) : 0u;   // its length (< 2^32: fillers)
             for (uint64_t j = 1; j <= kRec2CompactIn; ++j) {
-                uint32_t v = 0x0000FFFFu;                                                              // (unused: offset 65535, length 0)
+                uint32_t v = unused;
                 if (j < cnt) {
                     const uint64_t off = static_cast<uint64_t>(e[e0 + j].start) - lim;
                     const uint64_t len = static_cast<uint64_t>(e[e0 + j + 1].cum) - static_cast<uint64_t>(e[e0 + j].cum);
-                    v = static_cast<uint32_t>(off) | (static_cast<uint32_t>(len) << 16);
+                    v = static_cast<uint32_t>(off) | static_cast<uint32_t>(len << sh);
                 }
                 r.ent[1 + j] = v;
             }
-        } else if (cnt > kRec2Ents) {
+        } else {
+            // more entries than a record holds, or a run too long for its length field: twelve PIVOTS a stride apart (rbg_runs2_device.hpp
+            // LaneRec: the starts of candidates stride, 2 x stride, ...), then one scan of the run list
             r.meta = kRec2Overflow;
             r.cum_end = static_cast<uint32_t>(cnt > 0xFFFFFFFFull ? 0xFFFFFFFFull : cnt);
-            // twelve pivots a stride apart (rbg_runs2_device.hpp LaneRec::rank): the starts of candidates stride, 2 x stride, ...
             const uint64_t z = r.cum_end, stride = (z + 12) / 13;
-            for (uint64_t j = 0; j < 2 * kRec2Ents; ++j)
+            for (uint64_t j = 0; j < kRec2Pivots; ++j)
                 r.ent[j] = (j + 1) * stride < z ? static_cast<uint32_t>(static_cast<uint64_t>(e[e0 + (j + 1) * stride].start)) : 0xFFFFFFFFu;
             ++novf;
-        } else {
-            r.meta = static_cast<uint32_t>(cnt);
-            for (uint64_t k = 0; k < cnt; ++k) {
-                r.ent[2 * k] = static_cast<uint32_t>(static_cast<uint64_t>(e[e0 + k].start));
-                r.ent[2 * k + 1] = static_cast<uint32_t>(static_cast<uint64_t>(e[e0 + k].cum));
-            }
-            r.cum_end = static_cast<uint32_t>(static_cast<uint64_t>(e[e0 + cnt].cum));   // (entry nr is the table's sentinel)
         }
         recs[i] = r;
     }

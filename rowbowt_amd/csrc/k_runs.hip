@@ -26,7 +26,10 @@ struct PackedBits {   // per-lane reader of a packed read: peek / drop of up to 
     uint64_t sr;
     __device__ __forceinline__ uint32_t next_word() {
         if (widx == 4) { w = *cp++; widx = 0; }
-        const uint32_t v = widx == 0 ? w.x : widx == 1 ? w.y : widx == 2 ? w.z : w.w;
+        // (the word in front, the others moved up: indexing the vector by widx becomes a dynamic index, and one into scratch once the
+        //  reader is captured by the step's lambda)
+        const uint32_t v = w.x;
+        w.x = w.y; w.y = w.z; w.z = w.w;
         ++widx;
         return v;
     }
@@ -39,7 +42,8 @@ struct PackedBits {   // per-lane reader of a packed read: peek / drop of up to 
     }
 };
 
-template <typename P, bool TOEHOLD, bool PACKED = false, bool STATS = false>
+// GLDS: the bucket records arrive by LDS-direct loads (rbg_runs2_device.hpp lane_lf2_quad) instead of quad permutes
+template <typename P, bool TOEHOLD, bool PACKED = false, bool STATS = false, bool GLDS = false>
 __global__ __launch_bounds__(512, STATS ? 2 : 4) void k_find_range_runs(const DevIndex ix, const void *__restrict__ src_a,
                                                         const void *__restrict__ src_b, const uint64_t N,
                                                         uint64_t *__restrict__ lo_out, uint64_t *__restrict__ hi_out,
@@ -55,6 +59,7 @@ __global__ __launch_bounds__(512, STATS ? 2 : 4) void k_find_range_runs(const De
     __shared__ uint8_t s_lut[256];
     __shared__ uint8_t s_lut2[256];
     __shared__ uint8_t s_mslot[4];
+    __shared__ __align__(16) unsigned char s_tile[GLDS ? 8 * kTileBytes : 16];   // (eight waves per workgroup)
     for (int t = threadIdx.x; t < 256; t += blockDim.x) {
         s_lut[t] = ix.lut[t];
         s_lut2[t] = ix.nmajor ? ix.lut2[t] : 0xFFu;
@@ -62,6 +67,7 @@ __global__ __launch_bounds__(512, STATS ? 2 : 4) void k_find_range_runs(const De
     RBG_RUN_SEARCH2_SHARED;
     const RunSearch2<P> S2 = stage_run_search2<P>(ix, s_tab_first, s_ent2, s_dir2, s_rec2, s_dyn);
     const uint32_t *tab_first = s_tab_first;
+    lds_byte *tile = (lds_byte *)s_tile + (GLDS ? (threadIdx.x >> 6) * kTileBytes : 0u);   // (C-style: a cast into the LDS address space)
     if (PACKED) {
         for (int t = threadIdx.x; t < 256; t += blockDim.x)
             if (s_lut2[t] != 0xFFu) s_mslot[s_lut2[t] & 3u] = s_lut[t];   // major index -> symbol slot
@@ -123,55 +129,77 @@ __global__ __launch_bounds__(512, STATS ? 2 : 4) void k_find_range_runs(const De
                 if (hi < lo) { alive = false; p = beg; }
             }
         }
-        while (__ballot(alive && p > beg)) {                   // right-to-left over the reads (rowbowt.hpp:127-129, :175-181)
-            bool stepping = alive && p > beg;
-            uint32_t d = 0, adv = 1, rec = 0;                  // depth index (adv - 1), symbols consumed, record in S.tab
-            if (stepping) {
-                if (PACKED) {
-                    adv = p < D ? static_cast<uint32_t>(p) : D;
-                    adv = 32u - static_cast<uint32_t>(__clz(DMASK & ((2u << (adv - 1)) - 1u)));   // the deepest depth kept that fits
-                    const uint32_t v = bs.take(2 * adv);
-                    rec = run_record(tab_first, adv, adv == 1 ? static_cast<uint32_t>(s_mslot[v]) : v);
-                    d = adv - 1;
-                    p -= 1;                                     // (the byte form's --p; the rest of adv is taken off after the step)
-                } else {
-                    --p;
-                    const uint32_t c = rd.at(p);
-                    if (STATS && p < p_min) p_min = p;
-                    const uint32_t m0 = s_lut2[c];
-                    uint32_t acc = m0;
-                    if (m0 != 0xFFu) {                          // the longest run of major symbols among the next D (k_search.hip)
-                        uint32_t pw = M, run_acc = m0;            // (of its prefixes, the longest whose depth has run lists)
+        // The steps of a read do not depend on the search: which table a step goes through is a matter of the read's symbols alone.  So the
+        // NEXT step is chosen, and its table's record fetched (from LDS, or for depths 6-8 from the global array: an L2 round trip), while
+        // the current step's bucket record is on its way -- the dependent chain of a step is its record (and, rarely, a scan), nothing else.
+        struct Pick { uint32_t d, adv, rec; bool ok; };
+        auto pick_at = [&](const uint64_t pp) __attribute__((always_inline)) -> Pick {        // the step that consumes the symbols ending at pp (exclusive: pp > beg)
+            Pick s{0u, 1u, 0u, true};
+            if (PACKED) {
+                s.adv = pp < D ? static_cast<uint32_t>(pp) : D;
+                s.adv = 32u - static_cast<uint32_t>(__clz(DMASK & ((2u << (s.adv - 1)) - 1u)));   // the deepest depth kept that fits
+                const uint32_t v = bs.take(2 * s.adv);
+                s.rec = run_record(tab_first, s.adv, s.adv == 1 ? static_cast<uint32_t>(s_mslot[v]) : v);
+                s.d = s.adv - 1;
+            } else {
+                const uint64_t q = pp - 1;
+                const uint32_t c = rd.at(q);
+                if (STATS && q < p_min) p_min = q;
+                const uint32_t m0 = s_lut2[c];
+                uint32_t acc = m0;
+                if (m0 != 0xFFu) {                              // the longest run of major symbols among the next D (k_search.hip)
+                    uint32_t pw = M, run_acc = m0;              // (of its prefixes, the longest whose depth has run lists)
 #pragma unroll 1
-                        for (uint32_t t = 1; t < static_cast<uint32_t>(kMaxRunDepth); ++t) {
-                            if (t >= D || p < beg + t) break;
-                            const uint32_t mm = s_lut2[rd.at(p - t)];
-                            if (STATS && p - t < p_min) p_min = p - t;
-                            if (mm == 0xFFu) break;
-                            run_acc += mm * pw;
-                            pw *= M;
-                            if ((DMASK >> t) & 1u) { adv = t + 1; acc = run_acc; }
-                        }
-                    }
-                    if (adv == 1) {
-                        const uint32_t slot = s_lut[c];
-                        if (slot == 0xFFu || slot >= static_cast<uint32_t>(kLdsSyms)) {
-                            // symbol absent (f_[c] >= f_[c+1], rowbowt.hpp:76).  (An index with more than kLdsSyms symbols is
-                            // never given this layout: upload() keeps the slot tables for it.)
-                            alive = false;
-                            stepping = false;
-                        } else {
-                            rec = run_record(tab_first, 1u, slot);
-                        }
-                    } else {
-                        d = adv - 1;
-                        rec = run_record(tab_first, adv, acc);
+                    for (uint32_t t = 1; t < static_cast<uint32_t>(kMaxRunDepth); ++t) {
+                        if (t >= D || q < beg + t) break;
+                        const uint32_t mm = s_lut2[rd.at(q - t)];
+                        if (STATS && q - t < p_min) p_min = q - t;
+                        if (mm == 0xFFu) break;
+                        run_acc += mm * pw;
+                        pw *= M;
+                        if ((DMASK >> t) & 1u) { s.adv = t + 1; acc = run_acc; }
                     }
                 }
+                if (s.adv == 1) {
+                    const uint32_t slot = s_lut[c];
+                    // symbol absent (f_[c] >= f_[c+1], rowbowt.hpp:76).  (An index with more than kLdsSyms symbols is
+                    // never given this layout: upload() keeps the slot tables for it.)
+                    if (slot == 0xFFu || slot >= static_cast<uint32_t>(kLdsSyms)) s.ok = false;
+                    else s.rec = run_record(tab_first, 1u, slot);
+                } else {
+                    s.d = s.adv - 1;
+                    s.rec = run_record(tab_first, s.adv, acc);
+                }
+            }
+            return s;
+        };
+        // (the packed form keeps the step's choice at the top of the loop: the extra state of looking ahead sent it to scratch, and no kernel
+        //  of this layout may spill -- tests/test_capi_host.py test_no_run_indexed_kernel_spills)
+        constexpr bool AHEAD = !PACKED;
+        Pick cur{0u, 1u, 0u, false};
+        DevRunTab2 Rcur = S2.tab[0];
+        if (AHEAD && alive && p > beg) {
+            cur = pick_at(p);
+            if (cur.ok) Rcur = load_run_tab<P>(S2, cur.d, cur.rec);
+        }
+        while (__ballot(alive && p > beg)) {                   // right-to-left over the reads (rowbowt.hpp:127-129, :175-181)
+            bool stepping = alive && p > beg;
+            if (!AHEAD && stepping) {
+                cur = pick_at(p);
+                if (cur.ok) Rcur = load_run_tab<P>(S2, cur.d, cur.rec);
+            }
+            if (stepping && !cur.ok) { alive = false; stepping = false; }
+            const uint32_t d = cur.d, adv = cur.adv;
+            const DevRunTab2 R = Rcur;
+            // the step after this one (taken only if this one leaves the range non-empty)
+            const uint64_t p_next = p - adv;
+            if (AHEAD && stepping && p_next > beg) {
+                cur = pick_at(p_next);
+                if (cur.ok) Rcur = load_run_tab<P>(S2, cur.d, cur.rec);
             }
             RunStep r;
             // rank(lo, c), rank(hi + 1, c): rowbowt.hpp:79,83
-            lane_lf2_quad<P, STATS>(S2, stepping, d, rec, lo, hi + 1, r, st);   // (every lane of the wave: the records are fetched by quads)
+            lane_lf2_quad<P, STATS, false, GLDS>(S2, stepping, d, R, lo, hi + 1, r, st, tile);   // (every lane of the wave: the records are fetched by quads)
             if (stepping) {
                 if (STATS) st[kStSymbols] += adv;
                 const uint64_t c_inside = r.c_upto - r.c_before;
@@ -184,7 +212,7 @@ __global__ __launch_bounds__(512, STATS ? 2 : 4) void k_find_range_runs(const De
                     }
                     lo = r.F + r.c_before;                      // rowbowt.hpp:86
                     hi = lo + c_inside - 1;                     // rowbowt.hpp:87
-                    p -= adv - 1;                               // the left neighbours are consumed too
+                    p = p_next;                                 // the left neighbours are consumed too
                 }
             }
         }
@@ -337,16 +365,22 @@ int launch_find_range_runs_impl(const DevIndex &ix, const LaunchCfg &cfg, const 
     if (N == 0) return 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const size_t lds = run_search2_lds(ix);
+    // how a quad's bucket records travel (rbg_runs2_device.hpp): LDS-direct loads (the default), or RBG_REC_FETCH=quad: registers + quad permutes
+    static const bool glds = [] { const char *e = std::getenv("RBG_REC_FETCH"); return !(e && std::strcmp(e, "quad") == 0); }();
     LaunchCfg c = cfg;   // 512-thread workgroups: the staged tables and top level are shared by eight waves
     c.block_threads = 512;
     c.max_blocks = cfg.max_blocks > 0 ? std::max(1, cfg.max_blocks / 2) : 256 * 16;
     // sel mode: the number of reads is only known on the device; a fixed modest grid loops over it
     const dim3 grid(sel ? std::min(grid_for(c, N), 256) : grid_for(c, N)), block(512);
+#define RBG_LAUNCH_FRR1(PT, TOE, PK, STS, GL)                                                          \
+    do {                                                                                               \
+        auto kern = k_find_range_runs<PT, TOE, PK, STS, GL>;                                           \
+        raise_lds(kern, lds + (GL ? 8 * kTileBytes : 0));                                              \
+        hipLaunchKernelGGL(kern, grid, block, lds, st, ix, src_a, src_b, N, lo, hi, ssamp, stats, sel, nsel);     \
+    } while (0)
 #define RBG_LAUNCH_FRR(PT, TOE, PK, STS)                                                               \
     do {                                                                                               \
-        auto kern = k_find_range_runs<PT, TOE, PK, STS>;                                               \
-        raise_lds(kern, lds);                                                                          \
-        hipLaunchKernelGGL(kern, grid, block, lds, st, ix, src_a, src_b, N, lo, hi, ssamp, stats, sel, nsel);     \
+        if (glds) RBG_LAUNCH_FRR1(PT, TOE, PK, STS, true); else RBG_LAUNCH_FRR1(PT, TOE, PK, STS, false); \
     } while (0)
 #define RBG_LAUNCH_FRR2(PT, TOE)                                                                       \
     do {                                                                                               \
@@ -361,6 +395,7 @@ int launch_find_range_runs_impl(const DevIndex &ix, const LaunchCfg &cfg, const 
     }
 #undef RBG_LAUNCH_FRR2
 #undef RBG_LAUNCH_FRR
+#undef RBG_LAUNCH_FRR1
     return static_cast<int>(hipGetLastError());
 }
 

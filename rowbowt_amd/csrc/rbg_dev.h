@@ -171,31 +171,31 @@ struct DevRunTab2 {
 };
 static_assert(sizeof(DevRunTab2) == 32, "two 16-byte LDS reads per record");
 struct RunDir64 { uint32_t count, hi; };   // directory entry at 8-byte positions (4-byte positions: the count alone)
-// BUCKET RECORDS of format 2 (RBG_OPT_RUN_REC; DevIndex::run_rec2): the directory entry and the entries it names, fused into ONE
-// aligned 64-byte record per bucket of a table, direct-addressed by (position >> shift) -- a rank is then one sector instead of a
-// directory sector plus the 1.6 sectors an unaligned stretch of the run list takes, and at every scale K1/K2 on this layout are bound
-// by exactly that sector count.  The record holds up to kRec2Ents entries {start, cum} (low words at 8-byte positions): the last
-// entry that starts before the bucket, then the ones that start inside it; `cum_end` is the cum of the entry after the last one
-// held (the length of its run).  A bucket with more candidates than that says so (e0, cum_end = their number) and holds twelve
-// PIVOTS where the entries would be -- the starts of candidates stride, 2 x stride, ... with stride = ceil(number / 13) -- so that the
-// lane narrows thirteen-fold from the record itself and reads the run list once.  About 64 / 2.5 bytes per entry: the price of the
-// speed, off when the budget is short.  (profiles/r04_rec_per_sweep.txt: 2.5 entries per bucket is the fastest on the bench index;
-// at n = 5e10 five per bucket run as fast from 31 GB less -- RBG_RUN_REC_PER.)
-constexpr uint32_t kRec2Ents = 6;
+// BUCKET RECORDS (RBG_OPT_RUN_REC; DevIndex::run_rec2): the directory entry and the entries it names, fused into ONE aligned 64-byte
+// record per bucket of a table, direct-addressed by (position >> shift) -- a rank is then one sector instead of a directory sector plus
+// the 1.6 sectors an unaligned stretch of the run list takes, and at every scale K1/K2 on this layout are bound by exactly that sector
+// count.  About 64 / 2.5 bytes per entry: the price of the speed, off when the budget is short.  (profiles/r04_rec_per_sweep.txt: 2.5
+// entries per bucket is the fastest on the bench index; at n = 5e10 five per bucket run as fast from 31 GB less -- RBG_RUN_REC_PER.)
+// COMPACT form (meta bit 5; nearly every bucket): the last entry that starts before the bucket (or the table's first) in full --
+// {cum (cum_end's place), start, length} -- and up to kRec2CompactIn entries that start inside it as {offset : sh, length : 32 - sh} bits,
+// sh = the table's bucket shift: dense tables (narrow buckets) get long length fields, the sparse tables of the deep k-mer depths
+// (buckets of 2^22 rows at depth 8 of the bench index) wide offsets.  Unused places hold {all ones, 0}.  The runs are disjoint and
+// ascending, so  rank = cum of the first + sum over ALL places of min(max(position - start, 0), length)  -- branch-free.
+// OVERFLOW form (meta bit 4): more candidates than that, or a run too long for its field: e0 / cum_end = their first / their number, and
+// twelve PIVOTS where the entries would be -- the starts of candidates stride, 2 x stride, ... with stride = ceil(number / 13) -- so
+// that the lane narrows thirteen-fold from the record itself and reads the run list once.
+// (Round 4 also had a form of six full {start, cum} pairs for short buckets with long runs; the variable split made it rare, and its
+//  compare-and-select scan was a third of the record code every wave executed: such buckets take the overflow form now.)
+constexpr uint32_t kRec2Pivots = 12;
 constexpr uint32_t kRec2Overflow = 16u;  // meta bit 4
-// COMPACT records (meta bit 5): where every run that starts inside the bucket is shorter than 2^16 rows and starts less than 2^16 rows
-// into it -- nearly every bucket of a pangenome's deep tables -- the record holds the entry before the bucket in full
-// {cum (cum_end's place), start, length} and up to kRec2CompactIn entries inside it as {offset:16, length:16}: eleven entries instead of
-// six in the same sector, so a bucket may be twice as wide (half the records) and still overflow far less often.  rank = cum of the
-// first + the sum over the entries below the position of min(position - start, length) (the runs are disjoint and ascending).
-constexpr uint32_t kRec2Compact = 32u;
+constexpr uint32_t kRec2Compact = 32u;   // meta bit 5
 constexpr uint32_t kRec2CompactIn = 10;
 struct alignas(64) RunRec2 {
     uint32_t e0;        // index (relative to the table's first entry) of the first entry held -- or of the first candidate of an overflowing bucket
     uint32_t hi;        // 8-byte positions: (cum of the entry before the bucket) >> 31 (RunDir64::hi); 0 otherwise
-    uint32_t meta;      // bits 0-3: entries held (0..6; 0..11 compact); bit 4: overflow (none held); bit 5: compact
-    uint32_t cum_end;   // cum of the entry after the last one held; overflow: the number of candidates from e0 on
-    uint32_t ent[2 * kRec2Ents];   // {start, cum} of the entries held; overflow: twelve pivot starts
+    uint32_t meta;      // bits 0-3: entries held (0..11); bit 4: overflow (none held); bit 5: compact
+    uint32_t cum_end;   // compact: cum of the first entry held; overflow: the number of candidates from e0 on
+    uint32_t ent[kRec2Pivots];   // compact: {start, length} of the first entry, then ten packed ones; overflow: twelve pivot starts
 };
 static_assert(sizeof(RunRec2) == 64, "one sector per bucket");
 constexpr uint32_t kRunFillShift = 30;     // fillers every 2^30 rows; directory shifts stay <= 30 at 8-byte positions (DevIndex::run_fill_shift;

@@ -25,6 +25,7 @@ struct RunSearch2 {
     const void *const *ent;       // LDS [kMaxRunDepth]: entry arrays per depth
     const void *const *dir;       // LDS [kMaxRunDepth]: directory arrays per depth
     const void *const *rec;       // LDS [kMaxRunDepth]: bucket records per depth (nullptr: directories)
+    const void *rec_any;          // the records of some depth that has them (what a lane without a record of its own fetches for its quad), or nullptr
     uint32_t fill;                // DevIndex::run_fill_shift
 };
 
@@ -57,6 +58,9 @@ __device__ __forceinline__ RunSearch2<P> stage_run_search2(const DevIndex &ix, u
     RunSearch2<P> S;
     S.tab = s_tab; S.gtab = ix.run_tabs2; S.tab_first = s_tab_first; S.ent = s_ent2; S.dir = s_dir2; S.rec = s_rec2;
     S.fill = ix.run_fill_shift;
+    S.rec_any = nullptr;
+    for (int t = kMaxRunDepth - 1; t >= 0; --t)
+        if (ix.run_rec2[t]) S.rec_any = ix.run_rec2[t];
     return S;
 }
 
@@ -204,19 +208,22 @@ __device__ __forceinline__ void lane_scan(const char *__restrict__ tent, const u
     }
 }
 
-// One bucket record in registers (rbg_dev.h RunRec2) and the rank of a position of its bucket: c = # entries of the table below the
-// position counted from the record's first (0: none below at all), lo32 = the rank's low word, inside = the position's left
-// neighbour lies in that run, e = the entry's index relative to the table's first.
-// An overflowing bucket (more candidates than a record holds) carries twelve pivots instead of entries: the lane narrows its
-// candidates thirteen-fold from the registers it already has, and what is left (eight entries or fewer up to 91 candidates; beyond
-// that lane_narrow's rounds first) is one scan of the run list -- pending(): the scan the caller still owes, so that the scans of
-// both positions of a step leave together.
+// One bucket record in registers (rbg_dev.h RunRec2) and the ranks of one or two positions of its bucket: c = # entries of the table below
+// the position counted from the record's first (0: none below at all), lo32 = the rank's low word, inside = the position's left
+// neighbour lies in that run, p = the first entry's index relative to the table's first.
+// COMPACT records answer by themselves, branch-free: the runs held are disjoint and ascending, so the rank is the first entry's cum plus
+// the sum over ALL places of min(max(position - start, 0), length) -- a saturating subtract, a min and an add per place; the places'
+// fields are unpacked once for both positions of a step (rank2).
+// An OVERFLOWING bucket carries twelve pivots instead of entries: the lane narrows its candidates thirteen-fold from the registers it
+// already has, and what is left (eight entries or fewer up to 91 candidates; beyond that lane_narrow's rounds first) is one scan of the
+// run list -- pending(): the scan the caller still owes, so that the scans of both positions of a step leave together.
 constexpr uint32_t kRecScanZ = 7u;   // candidates the scan after an overflowing record takes (+ the entry after them: four 16-byte loads)
 struct LaneRank {
     uint32_t c = 0, lo32 = 0, p = 0, z = 0;   // (p, z): candidates [p, p + z) of the pending scan
     bool inside = false, pending = false;
     uint32_t qa = 0, a_lo = 0;
 };
+__device__ __forceinline__ uint32_t sub_sat(const uint32_t a, const uint32_t b) { return __builtin_elementwise_sub_sat(a, b); }
 struct LaneRec {
     uint32_t w[16];
     __device__ __forceinline__ void load(const void *__restrict__ recs, const uint64_t at) {
@@ -225,57 +232,59 @@ struct LaneRec {
         w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
         w[8] = c.x; w[9] = c.y; w[10] = c.z; w[11] = c.w; w[12] = d.x; w[13] = d.y; w[14] = d.z; w[15] = d.w;
     }
-    // the part of a rank the record answers by itself
-    // o = the position's offset into its bucket (compact records)
-    __device__ __forceinline__ void rank(const uint32_t a_lo, const uint32_t qa, const uint32_t o, LaneRank &out) const {
+    __device__ __forceinline__ bool compact() const { return (w[2] & kRec2Compact) != 0; }
+    // the overflow form's part of a rank: thirteen-fold narrowing by the pivots; the scan stays pending
+    __device__ __forceinline__ void pivots(const uint32_t a_lo, const uint32_t qa, LaneRank &out) const {
         out.qa = qa; out.a_lo = a_lo;
-        out.p = w[0];
-        if (w[2] & kRec2Compact) {
-            const uint32_t n = w[2] & 15u;
-            const uint32_t s0 = w[4] - a_lo;
-            const bool b0 = n != 0u && s0 < qa;
-            uint32_t ld = qa - s0, ll = w[5];
-            uint32_t add = b0 ? (ld < ll ? ld : ll) : 0u, c = b0 ? 1u : 0u;
+        const uint32_t z = w[3], stride = (z + 12u) / 13u;
+        uint32_t m = 0;
 #pragma unroll
-            for (uint32_t k = 0; k < kRec2CompactIn; ++k) {
-                const uint32_t v = w[6 + k], off = v & 0xFFFFu, len = v >> 16;
-                const bool below = k + 1u < n && off < o;
-                const uint32_t d = o - off;
-                add += below ? (d < len ? d : len) : 0u;
-                c += below ? 1u : 0u;
-                ld = below ? d : ld;
-                ll = below ? len : ll;
-            }
-            out.c = c;
-            out.lo32 = w[3] + add;
-            out.inside = ld <= ll;
-            out.pending = false;
-            return;
+        for (uint32_t j = 0; j < kRec2Pivots; ++j) m += ((j + 1u) * stride < z && w[4 + j] - a_lo < qa) ? 1u : 0u;
+        const uint32_t adv = m * stride;
+        out.p = w[0] + adv;
+        out.z = (z - adv) < stride ? (z - adv) : stride;
+        out.pending = true;
+    }
+    // compact form, ONE position: qa = the position as a distance from the anchor, o = its offset into the bucket, sh = the table's bucket shift
+    template <bool NEED_C>
+    __device__ __forceinline__ void rank1(const uint32_t sh, const uint32_t a_lo, const uint32_t qa, const uint32_t o, LaneRank &out) const {
+        out.qa = qa; out.a_lo = a_lo; out.p = w[0]; out.pending = false;
+        const uint32_t mask = ~(~0u << (sh & 31u));
+        const uint32_t s0 = w[4] - a_lo, d0 = qa - s0, om1 = o - 1u;
+        const bool b0 = (w[2] & 15u) != 0u && s0 < qa;
+        uint32_t add = b0 ? (d0 < w[5] ? d0 : w[5]) : 0u, c = b0 ? 1u : 0u;
+        bool ins = b0 && d0 <= w[5];
+#pragma unroll
+        for (uint32_t k = 0; k < kRec2CompactIn; ++k) {
+            const uint32_t v = w[6 + k], off = v & mask, len = v >> (sh & 31u);
+            const uint32_t d = sub_sat(o, off);
+            add += d < len ? d : len;
+            if (NEED_C) { c += off < o ? 1u : 0u; ins = ins || (om1 - off) < len; }
         }
-        if (w[2] & kRec2Overflow) {
-            const uint32_t z = w[3], stride = (z + 12u) / 13u;
-            uint32_t m = 0;
+        out.c = NEED_C ? c : 1u; out.lo32 = w[3] + add; out.inside = ins;   // (without NEED_C only "a rank of zero" could hide behind c == 0, and the sum says that too)
+    }
+    // compact form, BOTH positions of a step (q0 <= q1 in the same bucket): the places are unpacked once
+    __device__ __forceinline__ void rank2(const uint32_t sh, const uint32_t a_lo, const uint32_t qa0, const uint32_t o0, const uint32_t qa1, const uint32_t o1,
+                                          LaneRank &A, LaneRank &B) const {
+        A.qa = qa0; A.a_lo = a_lo; A.p = w[0]; A.pending = false;
+        B.qa = qa1; B.a_lo = a_lo; B.p = w[0]; B.pending = false;
+        const uint32_t mask = ~(~0u << (sh & 31u));
+        const uint32_t s0 = w[4] - a_lo, l0 = w[5], da = qa0 - s0, db = qa1 - s0, om1 = o1 - 1u;
+        const bool have = (w[2] & 15u) != 0u, ba = have && s0 < qa0, bb = have && s0 < qa1;
+        uint32_t add_a = ba ? (da < l0 ? da : l0) : 0u, add_b = bb ? (db < l0 ? db : l0) : 0u, c = bb ? 1u : 0u;
+        bool ins = bb && db <= l0;
 #pragma unroll
-            for (uint32_t j = 0; j < 2 * kRec2Ents; ++j) m += ((j + 1u) * stride < z && w[4 + j] - a_lo < qa) ? 1u : 0u;
-            const uint32_t adv = m * stride;
-            out.p = w[0] + adv;
-            out.z = (z - adv) < stride ? (z - adv) : stride;
-            out.pending = true;
-            return;
+        for (uint32_t k = 0; k < kRec2CompactIn; ++k) {
+            const uint32_t v = w[6 + k], off = v & mask, len = v >> (sh & 31u);
+            const uint32_t ea = sub_sat(o0, off), eb = sub_sat(o1, off);
+            add_a += ea < len ? ea : len;
+            add_b += eb < len ? eb : len;
+            c += off < o1 ? 1u : 0u;
+            ins = ins || (om1 - off) < len;
         }
-        LaneQ Q;
-        Q.qa = qa;
-        const uint32_t n = w[2] & 15u;
-        Q.zlim = n;
-#pragma unroll
-        for (uint32_t k = 0; k < kRec2Ents; ++k) Q.feed(k, w[4 + 2 * k] - a_lo, w[5 + 2 * k]);
-        Q.feed(kRec2Ents, 0u, w[3]);                 // (never below: closes the last run held when all six are)
-        if (n < kRec2Ents && Q.c == n && n) Q.kn = w[3];   // the last entry held is the answer: its run ends at cum_end
-        out.c = Q.c;
-        const uint32_t dd = Q.qa - Q.ks, len = Q.kn - Q.kc;
-        out.lo32 = Q.kc + (dd < len ? dd : len);
-        out.inside = dd <= len;
-        out.pending = false;
+        A.c = 1u;   // (c == 0 means "no run below: rank 0" to the caller; the sum is 0 then anyway -- the first entry held is the table's first, cum 0)
+        A.lo32 = w[3] + add_a; A.inside = false;
+        B.c = c; B.lo32 = w[3] + add_b; B.inside = ins;
     }
 };
 
@@ -321,10 +330,9 @@ __device__ __forceinline__ void lane_finish(const char *__restrict__ tent, LaneR
 // Both ranks of one LF step of ONE lane: rle_string::rank (rle_string.hpp:131-161) in the k-mer table `rec` of depth
 // index d at positions q0 = lo and q1 = hi + 1 (q0 <= q1).  out.samp_e = the entry whose sample a toehold re-sample needs.
 template <typename P, bool STATS = false, bool LEAN = false>
-__device__ __forceinline__ void lane_lf2(const RunSearch2<P> &S, const uint32_t d, const uint32_t rec, const uint64_t q0, const uint64_t q1, RunStep &out,
-                                         unsigned long long *st = nullptr) {
+__device__ __forceinline__ void lane_lf2_tab(const RunSearch2<P> &S, const uint32_t d, const DevRunTab2 &R, const uint64_t q0, const uint64_t q1, RunStep &out,
+                                             unsigned long long *st = nullptr) {
     constexpr bool W = sizeof(P) == 8;
-    const DevRunTab2 R = load_run_tab<P>(S, d, rec);
     out.F = R.F;
     const uint32_t sh = R.dir_shift;
     const uint64_t b0 = q0 >> sh, b1 = q1 >> sh;
@@ -332,34 +340,35 @@ __device__ __forceinline__ void lane_lf2(const RunSearch2<P> &S, const uint32_t 
     if (const void *__restrict__ recs = S.rec[d]) {   // ---- bucket records: one aligned 64-byte record per position (rbg_dev.h RunRec2) ----
         const uint32_t al0 = W ? static_cast<uint32_t>(b0 << sh) - (1u << S.fill) : 0u;
         const uint32_t al1 = W ? static_cast<uint32_t>(b1 << sh) - (1u << S.fill) : 0u;
+        const uint32_t qa0 = static_cast<uint32_t>(q0) - al0, qa1 = static_cast<uint32_t>(q1) - al1;
+        const uint32_t o0 = static_cast<uint32_t>(q0 - (b0 << sh)), o1 = static_cast<uint32_t>(q1 - (b1 << sh));
         LaneRank A, B;
         uint32_t h0, h1;
         uint32_t rounds = 0, ents = 0;
-        if constexpr (LEAN) {
-            // (the seeding kernels: one record in registers at a time -- when hi + 1 falls into another bucket its record is fetched after
-            //  the first position is answered; holding both costs sixteen registers on every step and them a workgroup per CU)
-            LaneRec rr;
-            rr.load(recs, R.dir_off + b0);
-            rr.rank(al0, static_cast<uint32_t>(q0) - al0, static_cast<uint32_t>(q0 - (b0 << sh)), A);
-            h0 = rr.w[1];
-            if (b1 != b0) {
-                lane_finish(tent, A, nullptr, rounds, ents);
-                rr.load(recs, R.dir_off + b1);
-            }
-            rr.rank(al1, static_cast<uint32_t>(q1) - al1, static_cast<uint32_t>(q1 - (b1 << sh)), B);
-            h1 = rr.w[1];
-            if (b1 != b0) lane_finish(tent, B, nullptr, rounds, ents);
-            else lane_finish(tent, A, &B, rounds, ents);
+        LaneRec r0;
+        r0.load(recs, R.dir_off + b0);
+        h0 = h1 = r0.w[1];
+        if (b1 == b0) {
+            if (r0.compact()) r0.rank2(sh, al0, qa0, o0, qa1, o1, A, B);
+            else { r0.pivots(al0, qa0, A); r0.pivots(al1, qa1, B); }
+            lane_finish(tent, A, &B, rounds, ents);
+        } else if constexpr (LEAN) {
+            // (the seeding kernels: one record in registers at a time -- the second is fetched after the first position is answered;
+            //  holding both costs sixteen registers on every step and them a workgroup per CU)
+            if (r0.compact()) r0.template rank1<false>(sh, al0, qa0, o0, A); else r0.pivots(al0, qa0, A);
+            lane_finish(tent, A, nullptr, rounds, ents);
+            r0.load(recs, R.dir_off + b1);
+            h1 = r0.w[1];
+            if (r0.compact()) r0.template rank1<true>(sh, al1, qa1, o1, B); else r0.pivots(al1, qa1, B);
+            lane_finish(tent, B, nullptr, rounds, ents);
         } else {
             // both records leave together, then both scans of the run list (overflowing buckets): the dependent round trips of a step are
             // record -> scan [-> sample] whatever its two positions meet -- a wave waits for the longest chain among its 64 lanes
-            LaneRec r0, r1;
-            r0.load(recs, R.dir_off + b0);
-            if (b1 != b0) r1.load(recs, R.dir_off + b1);
-            r0.rank(al0, static_cast<uint32_t>(q0) - al0, static_cast<uint32_t>(q0 - (b0 << sh)), A);
-            h0 = r0.w[1];
-            if (b1 != b0) { r1.rank(al1, static_cast<uint32_t>(q1) - al1, static_cast<uint32_t>(q1 - (b1 << sh)), B); h1 = r1.w[1]; }
-            else { r0.rank(al1, static_cast<uint32_t>(q1) - al1, static_cast<uint32_t>(q1 - (b1 << sh)), B); h1 = h0; }
+            LaneRec r1;
+            r1.load(recs, R.dir_off + b1);
+            h1 = r1.w[1];
+            if (r0.compact()) r0.template rank1<false>(sh, al0, qa0, o0, A); else r0.pivots(al0, qa0, A);
+            if (r1.compact()) r1.template rank1<true>(sh, al1, qa1, o1, B); else r1.pivots(al1, qa1, B);
             lane_finish(tent, A, &B, rounds, ents);
         }
         if (STATS) { st[kStSlots] += b1 != b0 ? 2 : 1; st[kStSearch] += rounds; st[kStDense] += ents; st[kStSteps] += 1; }
@@ -427,6 +436,13 @@ __device__ __forceinline__ void lane_lf2(const RunSearch2<P> &S, const uint32_t 
     if (STATS) st[kStSteps] += 1;
 }
 
+template <typename P, bool STATS = false, bool LEAN = false>
+__device__ __forceinline__ void lane_lf2(const RunSearch2<P> &S, const uint32_t d, const uint32_t rec, const uint64_t q0, const uint64_t q1, RunStep &out,
+                                         unsigned long long *st = nullptr) {
+    const DevRunTab2 R = load_run_tab<P>(S, d, rec);
+    lane_lf2_tab<P, STATS, LEAN>(S, d, R, q0, q1, out, st);
+}
+
 // ---- the same step with the FIRST record of every lane fetched by its QUAD (k_find_range_runs) ----------------------------------------
 // A lane that reads its own 64-byte record issues four 16-byte requests to one line in four instructions: four address translations and four
 // L1 lookups where the data is one sector.  Here the four lanes of a quad read the record of each of them in turn -- lane p the p-th sixteen
@@ -460,56 +476,87 @@ __device__ __forceinline__ void quad_transpose16(uint32_t (&w)[16], const uint32
             w[4 * (b + 2) + k] = p1 ? hi : t;
         }
 }
+// GLDS: the same four rounds as LDS-DIRECT loads (global_load_lds_dwordx4: memory -> LDS, no VGPR in between, gfx950): in round r lane l
+// sends chunk (l & 3) of the record of quad lane r to  tile + r * kTileRound + 16 l  (the destination of such a load is the wave's base + 16
+// bytes per lane: exactly this image), so the record of owner lane L lies contiguous at  tile + (L & 3) * kTileRound + (L & ~3) * 16  and
+// the owner reads it back with four ds_read_b128 -- no transpose on the VALU (64 quad permutes and as many selects per record), sixteen
+// registers fewer while the loads fly.  kTileRound = 1 KiB + 16: the pad puts the four lanes of a quad on different banks.
+constexpr uint32_t kTileRound = 1024u + 16u;
+constexpr uint32_t kTileBytes = 4u * kTileRound;     // per wave
+typedef __attribute__((address_space(3))) unsigned char lds_byte;
+template <int r>
+__device__ __forceinline__ void glds_round(const uint32_t a_lo, const uint32_t a_hi, const uint32_t p, lds_byte *tile) {
+    const uint64_t an = (static_cast<uint64_t>(quad_bcast<r>(a_hi)) << 32) | quad_bcast<r>(a_lo);
+    __builtin_amdgcn_global_load_lds(reinterpret_cast<const RBG_GLOBAL void *>(an + 16u * p), reinterpret_cast<__attribute__((address_space(3))) void *>(tile + r * kTileRound), 16, 0, 0);
+}
 // LEAN: the second record (hi + 1 in another bucket) is fetched into the first one's registers once that is answered (the seeding kernels)
-template <typename P, bool STATS = false, bool LEAN = false>
-__device__ __forceinline__ void lane_lf2_quad(const RunSearch2<P> &S, const bool stepping, const uint32_t d, const uint32_t rec, const uint64_t q0, const uint64_t q1,
-                                              RunStep &out, unsigned long long *st = nullptr) {
+// R: the table's record (load_run_tab; the caller may have fetched it a step ahead); a lane that is not stepping passes the first record of depth 1
+template <typename P, bool STATS = false, bool LEAN = false, bool GLDS = false>
+__device__ __forceinline__ void lane_lf2_quad(const RunSearch2<P> &S, const bool stepping, const uint32_t d, const DevRunTab2 &R, const uint64_t q0, const uint64_t q1,
+                                              RunStep &out, unsigned long long *st = nullptr, lds_byte *tile = nullptr) {
     constexpr bool W = sizeof(P) == 8;
-    if (!S.rec[0]) {                       // (uniform: directories over the run lists)
-        if (stepping) lane_lf2<P, STATS>(S, d, rec, q0, q1, out, st);
-        return;
-    }
-    const uint32_t p = threadIdx.x & 3u;
-    const DevRunTab2 R = load_run_tab<P>(S, stepping ? d : 0u, stepping ? rec : 0u);
     const uint32_t sh = R.dir_shift;
-    const uint64_t b0 = stepping ? q0 >> sh : 0u, b1 = stepping ? q1 >> sh : 0u;
-    const char *recs = static_cast<const char *>(S.rec[stepping ? d : 0u]);
-    const uint64_t a0 = reinterpret_cast<uint64_t>(recs) + (R.dir_off + b0) * 64u;   // (a lane that is not stepping names the first record of depth 1)
+    const bool by_rec = stepping && S.rec[d] != nullptr;
+    if (stepping && !by_rec) lane_lf2_tab<P, STATS>(S, d, R, q0, q1, out, st);   // (a depth with directories over its run lists: the lane by itself)
+    if (__ballot(by_rec) == 0) return;                                            // (nobody's quad has a record to fetch in this step)
+    const uint32_t p = threadIdx.x & 3u;
+    const uint64_t b0 = by_rec ? q0 >> sh : 0u, b1 = by_rec ? q1 >> sh : 0u;
+    const char *recs = static_cast<const char *>(by_rec ? S.rec[d] : S.rec_any);
+    const uint64_t a0 = reinterpret_cast<uint64_t>(recs) + (by_rec ? (R.dir_off + b0) * 64u : 0u);   // (a lane without a record to fetch names the first record there is)
     const uint32_t a_lo = static_cast<uint32_t>(a0), a_hi = static_cast<uint32_t>(a0 >> 32);
     LaneRec r0, r1;
     uint32_t (&w0)[16] = r0.w;
+    const bool two = by_rec && b1 != b0;
+    if constexpr (GLDS) {
+        glds_round<0>(a_lo, a_hi, p, tile);
+        glds_round<1>(a_lo, a_hi, p, tile);
+        glds_round<2>(a_lo, a_hi, p, tile);
+        glds_round<3>(a_lo, a_hi, p, tile);
+        if constexpr (!LEAN) { if (two) r1.load(recs, R.dir_off + b1); }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the LDS-direct loads are this wave's own: no barrier, the counter is the wave's)
+        const lds_byte *own = tile + (threadIdx.x & 3u) * kTileRound + (threadIdx.x & 60u) * 16u;
+        typedef __attribute__((address_space(3))) const u32x4 lds_u32x4;
+        const u32x4 t0 = reinterpret_cast<lds_u32x4 *>(own)[0], t1 = reinterpret_cast<lds_u32x4 *>(own)[1], t2 = reinterpret_cast<lds_u32x4 *>(own)[2],
+                    t3 = reinterpret_cast<lds_u32x4 *>(own)[3];
+        w0[0] = t0.x; w0[1] = t0.y; w0[2] = t0.z; w0[3] = t0.w; w0[4] = t1.x; w0[5] = t1.y; w0[6] = t1.z; w0[7] = t1.w;
+        w0[8] = t2.x; w0[9] = t2.y; w0[10] = t2.z; w0[11] = t2.w; w0[12] = t3.x; w0[13] = t3.y; w0[14] = t3.z; w0[15] = t3.w;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the record is in registers before the next step's loads may land on the tile)
+    } else {
 #define RBG_QUAD_ROUND(r)                                                                                                             \
     {                                                                                                                                  \
         const uint64_t an = (static_cast<uint64_t>(quad_bcast<r>(a_hi)) << 32) | quad_bcast<r>(a_lo);                                  \
         const u32x4 t = *as_global<u32x4>(reinterpret_cast<const void *>(an + 16u * p));                                                \
         w0[4 * r] = t.x; w0[4 * r + 1] = t.y; w0[4 * r + 2] = t.z; w0[4 * r + 3] = t.w;                                                  \
     }
-    RBG_QUAD_ROUND(0) RBG_QUAD_ROUND(1) RBG_QUAD_ROUND(2) RBG_QUAD_ROUND(3)
+        RBG_QUAD_ROUND(0) RBG_QUAD_ROUND(1) RBG_QUAD_ROUND(2) RBG_QUAD_ROUND(3)
 #undef RBG_QUAD_ROUND
-    const bool two = stepping && b1 != b0;
-    if constexpr (!LEAN) { if (two) r1.load(recs, R.dir_off + b1); }
-    quad_transpose16(w0, p);
-    if (!stepping) return;
+        if constexpr (!LEAN) { if (two) r1.load(recs, R.dir_off + b1); }
+        quad_transpose16(w0, p);
+    }
+    if (!by_rec) return;
     out.F = R.F;
     const char *__restrict__ tent = static_cast<const char *>(S.ent[d]) + R.first * 8u;
     const uint32_t al0 = W ? static_cast<uint32_t>(b0 << sh) - (1u << S.fill) : 0u;
     const uint32_t al1 = W ? static_cast<uint32_t>(b1 << sh) - (1u << S.fill) : 0u;
+    const uint32_t qa0 = static_cast<uint32_t>(q0) - al0, qa1 = static_cast<uint32_t>(q1) - al1;
+    const uint32_t o0 = static_cast<uint32_t>(q0 - (b0 << sh)), o1 = static_cast<uint32_t>(q1 - (b1 << sh));
     LaneRank A, B;
-    uint32_t h0, h1, rounds = 0, ents = 0;
-    r0.rank(al0, static_cast<uint32_t>(q0) - al0, static_cast<uint32_t>(q0 - (b0 << sh)), A);
-    h0 = w0[1];
-    if constexpr (LEAN) {
-        if (two) {
-            lane_finish(tent, A, nullptr, rounds, ents);
-            r0.load(recs, R.dir_off + b1);
-        }
-        r0.rank(al1, static_cast<uint32_t>(q1) - al1, static_cast<uint32_t>(q1 - (b1 << sh)), B);
+    uint32_t h0 = w0[1], h1 = w0[1], rounds = 0, ents = 0;
+    if (!two) {
+        if (r0.compact()) r0.rank2(sh, al0, qa0, o0, qa1, o1, A, B);
+        else { r0.pivots(al0, qa0, A); r0.pivots(al1, qa1, B); }
+        lane_finish(tent, A, &B, rounds, ents);
+    } else if constexpr (LEAN) {
+        if (r0.compact()) r0.template rank1<false>(sh, al0, qa0, o0, A); else r0.pivots(al0, qa0, A);
+        lane_finish(tent, A, nullptr, rounds, ents);
+        r0.load(recs, R.dir_off + b1);
         h1 = w0[1];
-        if (two) lane_finish(tent, B, nullptr, rounds, ents);
-        else lane_finish(tent, A, &B, rounds, ents);
+        if (r0.compact()) r0.template rank1<true>(sh, al1, qa1, o1, B); else r0.pivots(al1, qa1, B);
+        lane_finish(tent, B, nullptr, rounds, ents);
     } else {
-        if (two) { r1.rank(al1, static_cast<uint32_t>(q1) - al1, static_cast<uint32_t>(q1 - (b1 << sh)), B); h1 = r1.w[1]; }
-        else { r0.rank(al1, static_cast<uint32_t>(q1) - al1, static_cast<uint32_t>(q1 - (b1 << sh)), B); h1 = h0; }
+        h1 = r1.w[1];
+        if (r0.compact()) r0.template rank1<false>(sh, al0, qa0, o0, A); else r0.pivots(al0, qa0, A);
+        if (r1.compact()) r1.template rank1<true>(sh, al1, qa1, o1, B); else r1.pivots(al1, qa1, B);
         lane_finish(tent, A, &B, rounds, ents);
     }
     if (STATS) { st[kStSlots] += two ? 2 : 1; st[kStSearch] += rounds; st[kStDense] += ents; st[kStSteps] += 1; }
@@ -518,6 +565,13 @@ __device__ __forceinline__ void lane_lf2_quad(const RunSearch2<P> &S, const bool
     out.c_upto = B.c ? (W ? y1 + static_cast<uint32_t>(B.lo32 - static_cast<uint32_t>(y1)) : B.lo32) : 0;
     out.inside = B.c != 0 && B.inside;
     out.samp_e = R.first + static_cast<uint64_t>(B.p) + B.c - 1u;
+}
+// the same with the table's record looked up here (the seeding kernels)
+template <typename P, bool STATS = false, bool LEAN = false>
+__device__ __forceinline__ void lane_lf2_quad(const RunSearch2<P> &S, const bool stepping, const uint32_t d, const uint32_t rec, const uint64_t q0, const uint64_t q1,
+                                              RunStep &out, unsigned long long *st = nullptr) {
+    const DevRunTab2 R = load_run_tab<P>(S, stepping ? d : 0u, stepping ? rec : 0u);
+    lane_lf2_quad<P, STATS, LEAN, false>(S, stepping, d, R, q0, q1, out, st, nullptr);
 }
 
 // the sample of the step's predecessor run (one gather)
