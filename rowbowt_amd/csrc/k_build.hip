@@ -300,7 +300,21 @@ __global__ __launch_bounds__(256) void k_run_dirs2(const u64pair *__restrict__ e
             const uint64_t mid = lo + ((hi - lo) >> 1);
             if (e[mid].x < lim) lo = mid + 1; else hi = mid;
         }
-        dir[i] = RunDir64{static_cast<uint32_t>(lo), lo ? static_cast<uint32_t>(e[lo - 1].y >> 31) : 0u};
+        dir[i] = RunDir64{static_cast<uint32_t>(lo), static_cast<uint32_t>(e[lo ? lo - 1 : 0].y >> 31)};   // (cums carry the table's F: below its first run the rank is F, the first entry's cum)
+    }
+}
+// cum += F of the entry's table (rbg_dev.h: the run lists hold rows of the F column, not counts)
+template <typename P>
+__global__ __launch_bounds__(256) void k_fold_F(RunEnt<P> *__restrict__ ent, const uint64_t *__restrict__ first, const uint64_t *__restrict__ F, const uint32_t T,
+                                               const uint64_t total) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += stride) {
+        uint32_t a = 0, z = T;                       // the table: last t with first[t] <= i
+        while (z - a > 1) {
+            const uint32_t mid = (a + z) >> 1;
+            if (first[mid] <= i) a = mid; else z = mid;
+        }
+        ent[i].cum = static_cast<P>(static_cast<uint64_t>(ent[i].cum) + F[a]);
     }
 }
 // bucket records of a depth's tables (rbg_dev.h RunRec2): record i belongs to bucket i - roff[t] of table t
@@ -333,7 +347,7 @@ __global__ __launch_bounds__(256) void k_run_recs2(const RunEnt<P> *__restrict__
         const uint64_t e0 = lo ? lo - 1 : 0, cnt = up - e0;
         RunRec2 r;
         r.e0 = static_cast<uint32_t>(e0);
-        r.hi = (sizeof(P) == 8 && lo) ? static_cast<uint32_t>(static_cast<uint64_t>(e[lo - 1].cum) >> 31) : 0u;
+        r.hi = sizeof(P) == 8 ? static_cast<uint32_t>(static_cast<uint64_t>(e[lo ? lo - 1 : 0].cum) >> 31) : 0u;   // (cums carry the table's F: entry 0's is F itself)
 #pragma unroll
         for (uint32_t k = 0; k < kRec2Pivots; ++k) r.ent[k] = 0u;
         // COMPACT (rbg_dev.h): the first entry held in full, up to ten more as {offset into the bucket : sh bits, length : 32 - sh bits}
@@ -346,7 +360,7 @@ __global__ __launch_bounds__(256) void k_run_recs2(const RunEnt<P> *__restrict__
         if (compact) {
             const uint32_t unused = static_cast<uint32_t>((uint64_t(1) << sh) - 1);                   // (offset = the bucket's last row, length 0: never below a position, adds nothing)
             r.meta = static_cast<uint32_t>(cnt) | kRec2Compact;
-            r.cum_end = cnt ? static_cast<uint32_t>(static_cast<uint64_t>(e[e0].cum)) : 0u;           // cum of the first entry held
+            r.cum_end = static_cast<uint32_t>(static_cast<uint64_t>(e[e0].cum));                      // cum of the first entry held (none held: the table's first, or its sentinel -- F)
             r.ent[0] = cnt ? static_cast<uint32_t>(static_cast<uint64_t>(e[e0].start)) : 0u;
             r.ent[1] = cnt ? static_cast<uint32_t>(static_cast<uint64_t>(e[e0 + 1].cum) - static_cast<uint64_t>(e[e0].cum)) : 0u;   // its length (< 2^32: fillers)
             for (uint64_t j = 1; j <= kRec2CompactIn; ++j) {
@@ -434,6 +448,13 @@ int launch_run_dirs2(const void *ent, const uint64_t *first, const uint64_t *nru
     if (!total) return 0;
     hipLaunchKernelGGL(k_run_dirs2, dim3(grid_of(total)), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const u64pair *>(ent), first, nruns, doff, dshift, T, total,
                        static_cast<RunDir64 *>(dir));
+    return static_cast<int>(hipGetLastError());
+}
+int launch_fold_F(uint32_t pos_bytes, void *ent, const uint64_t *first, const uint64_t *F, uint32_t T, uint64_t total, void *stream) {
+    if (total == 0 || T == 0) return 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (pos_bytes == 4) hipLaunchKernelGGL((k_fold_F<uint32_t>), dim3(grid_of(total)), dim3(256), 0, st, static_cast<RunEnt<uint32_t> *>(ent), first, F, T, total);
+    else hipLaunchKernelGGL((k_fold_F<uint64_t>), dim3(grid_of(total)), dim3(256), 0, st, static_cast<RunEnt<uint64_t> *>(ent), first, F, T, total);
     return static_cast<int>(hipGetLastError());
 }
 int launch_run_recs2(uint32_t pos_bytes, const void *ent, const uint64_t *first, const uint64_t *nruns, const uint64_t *roff, const uint32_t *rshift, uint32_t T, uint64_t total,

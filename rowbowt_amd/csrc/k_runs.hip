@@ -100,7 +100,7 @@ __global__ __launch_bounds__(512, STATS ? 2 : 4) void k_find_range_runs(const De
         uint64_t k = TOEHOLD ? ix.last_run_sample : 0;
         bool alive = valid;
         bool pend = false;                                     // deferred toehold re-sample (k_search.hip): the last one is the only one used
-        uint32_t pend_d = 0;
+        uint32_t pend_d = 0, pend_rec = 0;
         uint64_t pend_e = 0;
         ByteCursor rd{reinterpret_cast<const uint4 *>(seqs), ~uint64_t(0), make_uint4(0, 0, 0, 0)};
         if (valid && ix.ftab_k && p - beg >= ix.ftab_k) {      // rowbowt.hpp:124-125, :745-758 (k_search.hip)
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(512, STATS ? 2 : 4) void k_find_range_runs(const De
         //  of this layout may spill -- tests/test_capi_host.py test_no_run_indexed_kernel_spills)
         constexpr bool AHEAD = !PACKED;
         Pick cur{0u, 1u, 0u, false};
-        DevRunTab2 Rcur = S2.tab[0];
+        RunHot Rcur{0, 0};
         if (AHEAD && alive && p > beg) {
             cur = pick_at(p);
             if (cur.ok) Rcur = load_run_tab<P>(S2, cur.d, cur.rec);
@@ -189,8 +189,8 @@ __global__ __launch_bounds__(512, STATS ? 2 : 4) void k_find_range_runs(const De
                 if (cur.ok) Rcur = load_run_tab<P>(S2, cur.d, cur.rec);
             }
             if (stepping && !cur.ok) { alive = false; stepping = false; }
-            const uint32_t d = cur.d, adv = cur.adv;
-            const DevRunTab2 R = Rcur;
+            const uint32_t d = cur.d, adv = cur.adv, rec = cur.rec;
+            const RunHot R = Rcur;
             // the step after this one (taken only if this one leaves the range non-empty)
             const uint64_t p_next = p - adv;
             if (AHEAD && stepping && p_next > beg) {
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(512, STATS ? 2 : 4) void k_find_range_runs(const De
             }
             RunStep r;
             // rank(lo, c), rank(hi + 1, c): rowbowt.hpp:79,83
-            lane_lf2_quad<P, STATS, false, GLDS>(S2, stepping, d, R, lo, hi + 1, r, st, tile);   // (every lane of the wave: the records are fetched by quads)
+            lane_lf2_quad<P, STATS, false, GLDS>(S2, stepping, d, rec, R, lo, hi + 1, r, st, tile);   // (every lane of the wave: the records are fetched by quads)
             if (stepping) {
                 if (STATS) st[kStSymbols] += adv;
                 const uint64_t c_inside = r.c_upto - r.c_before;
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(512, STATS ? 2 : 4) void k_find_range_runs(const De
                 } else {
                     if (TOEHOLD) {                              // LF_w_loc, rowbowt.hpp:559-566, `adv` times nested
                         if (r.inside) k = k - adv;
-                        else { pend = true; pend_d = d; pend_e = r.samp_e; k = 0; }
+                        else { pend = true; pend_d = d; pend_rec = rec; pend_e = r.samp_e; k = 0; }
                     }
                     lo = r.F + r.c_before;                      // rowbowt.hpp:86
                     hi = lo + c_inside - 1;                     // rowbowt.hpp:87
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(512, STATS ? 2 : 4) void k_find_range_runs(const De
             }
         }
         if (TOEHOLD && alive && pend) {
-            k += run_step_sample2<P>(ix, pend_d, pend_e);
+            k += run_step_sample2<P>(ix, S2, pend_d, pend_rec, pend_e);
             if (STATS) st[kStResample] += 1;
         }
         if (STATS && !PACKED && p_end > p_min) st[kStChunks] += ((p_end - 1) >> 4) - (p_min >> 4) + 1;

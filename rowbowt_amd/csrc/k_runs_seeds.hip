@@ -279,7 +279,7 @@ __global__ __launch_bounds__(512, 3) void k_greedy_seed_runs(const DevIndex ix, 
                 const bool ok = c_inside != 0;
                 if (ok) {                               // LF_w_loc, rowbowt.hpp:555-573, pick.adv times nested
                     if (r.inside) k = k - pick.adv;
-                    else k = run_step_sample2<P>(ix, pick.d, r.samp_e);
+                    else k = run_step_sample2<P>(ix, S2, pick.d, pick.rec, r.samp_e);
                     lo = r.F + r.c_before;
                     hi = lo + c_inside - 1;
                 }

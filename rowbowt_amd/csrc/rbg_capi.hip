@@ -704,7 +704,7 @@ int upload_tables_runs2(rbg_index *ix) {
     // RBG_RUN_FILL_SHIFT / RBG_PHI_SUPER_SHIFT: test-only overrides so that small indexes meet fillers and several super blocks
     ix->dev.run_fill_shift = static_cast<uint32_t>(env_opt("RBG_RUN_FILL_SHIFT", kRunFillShift, 4, kRunFillShift));
     const uint32_t super_shift = static_cast<uint32_t>(env_opt("RBG_PHI_SUPER_SHIFT", kPhiSuperShift, 1, 24));
-    const uint32_t max_shift = W ? ix->dev.run_fill_shift : 40u;
+    const uint32_t max_shift = W ? ix->dev.run_fill_shift : 31u;   // (a per-lane shift of the low word: rbg_device.hpp pos_bucket)
     // BUCKET RECORDS (RBG_OPT_RUN_REC; rbg_dev.h RunRec2): one aligned 64-byte record per bucket of about three entries instead of
     // the directory -- a rank is one sector.  Automatic: when all kept depths with their records (about 64 / 3 bytes per entry) and
     // the rest of the replica stay within half the budget.  RBG_RUN_REC_PER: entries per bucket on average (default 2.5 inside the
@@ -731,6 +731,7 @@ int upload_tables_runs2(rbg_index *ix) {
         use_recs = with_recs <= 0.5 * static_cast<double>(ix->hbm_budget) && nrec <= entries_kept;
     }
     std::vector<DevRunTab2> tabs;
+    std::vector<uint64_t> hot;      // rbg_dev.h: dir_off | dir_shift << 56 per table
     int rc;
     for (uint32_t d = 0; d < D; ++d) {
         const std::vector<SymTable> &T = *depth[d];
@@ -803,6 +804,18 @@ int upload_tables_runs2(rbg_index *ix) {
             }
         rep.entries[d] = E2;
         rep.fillers[d] = fillers;
+        {   // every cum becomes a ROW of the F column: + the table's F (rbg_dev.h kRunHotShiftBit; k_build.hip k_fold_F)
+            TmpDev tf;
+            const size_t nt = T.size();
+            if ((rc = tf.alloc((2 * nt + 1) * 8))) return rc;
+            std::vector<uint64_t> Fv(nt);
+            for (size_t t = 0; t < nt; ++t) Fv[t] = T[t].F;
+            uint64_t *t_first = tf.as<uint64_t>(), *t_F = t_first + nt + 1;
+            HIP_TRY(hipMemcpy(t_first, first.data(), (nt + 1) * 8, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(t_F, Fv.data(), nt * 8, hipMemcpyHostToDevice));
+            HIP_TRY(static_cast<hipError_t>(launch_fold_F(sizeof(P), abs_ent, t_first, t_F, static_cast<uint32_t>(nt), E2 + (W ? 0 : 2), nullptr)));   // (4-byte positions: the two spare entries are final too)
+            HIP_TRY(hipDeviceSynchronize());
+        }
         // ---- directories: per table the widest bucket that still holds at most about dir_target entries on average ----
         std::vector<uint32_t> dshift(T.size(), 0);
         std::vector<uint64_t> doff(T.size() + 1, 0);
@@ -888,8 +901,11 @@ int upload_tables_runs2(rbg_index *ix) {
         }
         for (size_t t = 0; t < T.size(); ++t) {
             tabs.push_back(DevRunTab2{T[t].F, first[t], doff[t], dshift[t], 0u});
+            if (doff[t] >> kRunHotShiftBit) return RBG_EARG;   // (2^56 buckets: no index that fits a device comes near)
+            hot.push_back(doff[t] | static_cast<uint64_t>(dshift[t]) << kRunHotShiftBit);
         }
         tabs.push_back(DevRunTab2{0, E2, 0, 0u, 0u});   // closing record
+        hot.push_back(0);
     }
     for (uint32_t d = 2; d <= static_cast<uint32_t>(kMaxKmerDepth); ++d) release_kmer_level(ix, d);   // (levels beyond D, or left over: nothing points at them)
     for (uint32_t d = D; d <= static_cast<uint32_t>(kMaxRunDepth); ++d) ix->dev.run_tab_first[d] = static_cast<uint32_t>(tabs.size());
@@ -901,6 +917,8 @@ int upload_tables_runs2(rbg_index *ix) {
     ix->dev.syms = static_cast<const DevSym *>(p);
     if ((rc = dev_upload(ix, tabs.data(), tabs.size() * sizeof(DevRunTab2), &p))) return rc;
     ix->dev.run_tabs2 = static_cast<const DevRunTab2 *>(p);
+    if ((rc = dev_upload(ix, hot.data(), hot.size() * 8, &p))) return rc;
+    ix->dev.run_hot = static_cast<const uint64_t *>(p);
     ix->dev.run_ntabs = static_cast<uint32_t>(tabs.size());
     ix->dev.run_ksteps = D;
     ix->dev.run_depth_mask = mask;
@@ -3995,7 +4013,7 @@ int replicate_finish(rbg_index *src, ReplicaJob &job) {
     reloc.fix(d.lut2); reloc.fix(d.ftab); reloc.fix(d.dense);
     reloc.fix(d.phi_dir);
     for (int t = 0; t < kMaxRunDepth; ++t) reloc.fix(d.run_samp[t]);
-    reloc.fix(d.run_tabs2); reloc.fix(d.phi_super);
+    reloc.fix(d.run_tabs2); reloc.fix(d.run_hot); reloc.fix(d.phi_super);
     for (int t = 0; t < kMaxRunDepth; ++t) { reloc.fix(d.run_ent2[t]); reloc.fix(d.run_dir2[t]); reloc.fix(d.run_rec2[t]); }
     r->dev = d;
     if (hipMemset(d.counters, 0, 4 * sizeof(uint64_t)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return RBG_ENODEV;

@@ -169,7 +169,17 @@ struct DevRunTab2 {
     uint64_t dir_off;    // the table's directory starts at entry dir_off of its depth's directory array
     uint32_t dir_shift, pad;
 };
-static_assert(sizeof(DevRunTab2) == 32, "two 16-byte LDS reads per record");
+static_assert(sizeof(DevRunTab2) == 32, "two 16-byte reads per record");
+// What a search step needs of its table is where its directory / bucket records start and how wide a bucket is: ONE 8-byte word,
+//   hot = dir_off | dir_shift << 56,
+// staged in LDS for the depths up to kLdsRunDepth, read from a global array (512 KB at depth 8: L2-resident) for the deeper ones.  The
+// rest of DevRunTab2 is COLD: `first` is read when a step scans the run list (overflowing buckets, directories) or a toehold re-sample
+// is materialised, F never -- every cum of the run lists, records and directories is stored with the table's F already added
+// (k_build.hip k_fold_F): a rank comes out of the arithmetic as the ROW it maps to, F + rank, which is all LF wants of it
+// (rowbowt.hpp:86), and a position below a table's first run finds that table's F in the first entry's cum.
+// (Round 5, first form: the whole 32-byte record per step.  At depth 8 that was 2 MB of records read at random beside the index: 10
+//  L2 requests and 4.4 L2 misses per read of 23, profiles/r05_k2_pmc_tabs32.txt.)
+constexpr uint32_t kRunHotShiftBit = 56;
 struct RunDir64 { uint32_t count, hi; };   // directory entry at 8-byte positions (4-byte positions: the count alone)
 // BUCKET RECORDS (RBG_OPT_RUN_REC; DevIndex::run_rec2): the directory entry and the entries it names, fused into ONE aligned 64-byte
 // record per bucket of a table, direct-addressed by (position >> shift) -- a rank is then one sector instead of a directory sector plus
@@ -271,7 +281,8 @@ struct DevIndex {
     uint32_t run_fill_shift;                // 8-byte positions: entries of a table (and of the phi list) lie less than 2^this rows apart
     const void *run_ent2[kMaxRunDepth];     // uint2 {start, cum} (low words at 8-byte positions) + 2 spare entries
     const void *run_dir2[kMaxRunDepth];     // uint32_t counts (4-byte positions) or RunDir64 (8-byte positions)
-    const DevRunTab2 *run_tabs2;            // run_ntabs records, depth d's from run_tab_first[d - 1]
+    const DevRunTab2 *run_tabs2;            // run_ntabs records, depth d's from run_tab_first[d - 1] (cold: `first` for scans and re-samples)
+    const uint64_t *run_hot;                // run_ntabs words dir_off | dir_shift << 56: what a step reads of its table
     const RunRec2 *run_rec2[kMaxRunDepth];  // per depth: the tables' bucket records back to back (DevRunTab2::dir_off / dir_shift then address them); nullptr = directories
     const uint64_t *phi_super;              // 8-byte positions: full counts every 2^phi_super_shift buckets
     uint64_t phi_m;                         // entries of the phi list (fillers included); entry phi_m is the sentinel
@@ -464,6 +475,8 @@ int launch_pack_pairs32(const void *ent, uint64_t m, uint64_t spare, void *out, 
 int launch_pack_phi12(const void *ent, uint64_t m, uint64_t spare, void *out, void *stream);
 int launch_run_dirs2(const void *ent, const uint64_t *first, const uint64_t *nruns, const uint64_t *doff, const uint32_t *dshift, uint32_t T, uint64_t total,
                      void *dir, void *stream);
+// adds F[t] to the cum of every entry of table t (entries [first[t], first[t + 1]) of `ent`, RunEnt<P>; entries from first[T] on take the last table's)
+int launch_fold_F(uint32_t pos_bytes, void *ent, const uint64_t *first, const uint64_t *F, uint32_t T, uint64_t total, void *stream);
 int launch_run_recs2(uint32_t pos_bytes, const void *ent, const uint64_t *first, const uint64_t *nruns, const uint64_t *roff, const uint32_t *rshift, uint32_t T, uint64_t total,
                      void *recs, unsigned long long *overflow, void *stream);
 int launch_phi_dir(uint32_t pos_bytes, const void *ent, uint64_t m, uint32_t shift, uint64_t nb, uint32_t *dir, uint32_t ss, uint64_t *super, void *stream);

@@ -34,6 +34,22 @@ __device__ __forceinline__ const RBG_GLOBAL T *as_global(const T *p) { return (c
 template <typename T>
 __device__ __forceinline__ const RBG_GLOBAL T *as_global(const void *p) { return (const RBG_GLOBAL T *)p; }
 
+// The bucket of a position under a PER-LANE shift (the run-indexed layout: every table has its own bucket width, sh < 32): q >> sh in
+// 32-bit pieces.  Not the 64-bit shift -- on gfx950 a v_lshrrev_b64 / v_lshlrev_b64 whose AMOUNT sits in the last VGPR the kernel
+// allocates (and the allocation ends on a granule of eight) reads its amount from elsewhere: observed in k_lf_runs (72 VGPRs, amount in
+// v71: the result was shifted by the contents of v0), as a rank answered from another bucket's record or a memory fault, depending on what the
+// neighbouring wave had left in the register file (profiles/r05_shift64_last_vgpr.md).  A shift by a kernel argument is scalar and safe;
+// tests/test_capi_host.py scans the ISA of every kernel for the pattern.
+template <typename P>
+__device__ __forceinline__ uint64_t pos_bucket(const uint64_t q, const uint32_t sh) {
+    const uint32_t lo = static_cast<uint32_t>(q), hi = static_cast<uint32_t>(q >> 32);
+    if constexpr (sizeof(P) == 4) return lo >> sh;   // (4-byte positions: q <= n < 2^32)
+    else return (static_cast<uint64_t>(hi >> sh) << 32) | __builtin_amdgcn_alignbit(hi, lo, sh);
+}
+// low word of the bucket's first position, and the position's offset into its bucket
+__device__ __forceinline__ uint32_t pos_bucket_base32(const uint64_t q, const uint32_t sh) { return static_cast<uint32_t>(q) & (~0u << sh); }
+__device__ __forceinline__ uint32_t pos_bucket_offset(const uint64_t q, const uint32_t sh) { return static_cast<uint32_t>(q) & ~(~0u << sh); }
+
 template <typename SlotT>
 __device__ __forceinline__ SlotT load_slot(const SlotT *p) {
     SlotT s;

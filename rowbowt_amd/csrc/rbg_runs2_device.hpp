@@ -19,8 +19,9 @@ constexpr uint32_t kLanePhiMaxZ = 8;   // sampled positions one phi scan covers 
 
 template <typename P>
 struct RunSearch2 {
-    const DevRunTab2 *tab;        // LDS: the records of the tables of depths <= kLdsRunDepth
-    const DevRunTab2 *gtab;       // device memory: all run_ntabs records (the deeper depths' are read from here: rbg_dev.h kMaxRunDepth)
+    const uint64_t *hot;          // LDS: the hot words (rbg_dev.h: dir_off | dir_shift << 56) of the tables of depths <= kLdsRunDepth
+    const uint64_t *ghot;         // device memory: all run_ntabs hot words (the deeper depths' are read from here: rbg_dev.h kMaxRunDepth)
+    const DevRunTab2 *gtab;       // device memory: the cold records (`first`: scans of the run list, re-samples)
     const uint32_t *tab_first;    // LDS [kMaxRunDepth + 1]: first record of each depth
     const void *const *ent;       // LDS [kMaxRunDepth]: entry arrays per depth
     const void *const *dir;       // LDS [kMaxRunDepth]: directory arrays per depth
@@ -36,27 +37,23 @@ struct RunSearch2 {
     __shared__ const void *s_rec2[8];                                     \
     extern __shared__ __align__(16) unsigned char s_dyn[]
 
-inline size_t run_search2_lds(const DevIndex &ix) { return static_cast<size_t>(ix.run_tab_first[kLdsRunDepth]) * sizeof(DevRunTab2) + 16; }
+inline size_t run_search2_lds(const DevIndex &ix) { return static_cast<size_t>(ix.run_tab_first[kLdsRunDepth]) * sizeof(uint64_t) + 16; }
 
 // fills the arrays of RBG_RUN_SEARCH2_SHARED and returns the view of them; ends with __syncthreads()
 template <typename P>
 __device__ __forceinline__ RunSearch2<P> stage_run_search2(const DevIndex &ix, uint32_t *s_tab_first, const void **s_ent2, const void **s_dir2,
                                                            const void **s_rec2, unsigned char *s_dyn) {
-    DevRunTab2 *s_tab = reinterpret_cast<DevRunTab2 *>(s_dyn);
+    uint64_t *s_hot = reinterpret_cast<uint64_t *>(s_dyn);
     if (threadIdx.x < 8) {
         s_ent2[threadIdx.x] = threadIdx.x < static_cast<uint32_t>(kMaxRunDepth) ? ix.run_ent2[threadIdx.x] : nullptr;
         s_dir2[threadIdx.x] = threadIdx.x < static_cast<uint32_t>(kMaxRunDepth) ? ix.run_dir2[threadIdx.x] : nullptr;
         s_rec2[threadIdx.x] = threadIdx.x < static_cast<uint32_t>(kMaxRunDepth) ? static_cast<const void *>(ix.run_rec2[threadIdx.x]) : nullptr;
     }
     for (uint32_t t = threadIdx.x; t <= static_cast<uint32_t>(kMaxRunDepth); t += blockDim.x) s_tab_first[t] = ix.run_tab_first[t];
-    {   // the records as 16-byte words (two per record)
-        const uint4 *src = reinterpret_cast<const uint4 *>(ix.run_tabs2);
-        uint4 *dst = reinterpret_cast<uint4 *>(s_tab);
-        for (uint32_t t = threadIdx.x; t < 2u * ix.run_tab_first[kLdsRunDepth]; t += blockDim.x) dst[t] = src[t];
-    }
+    for (uint32_t t = threadIdx.x; t < ix.run_tab_first[kLdsRunDepth]; t += blockDim.x) s_hot[t] = ix.run_hot[t];
     __syncthreads();
     RunSearch2<P> S;
-    S.tab = s_tab; S.gtab = ix.run_tabs2; S.tab_first = s_tab_first; S.ent = s_ent2; S.dir = s_dir2; S.rec = s_rec2;
+    S.hot = s_hot; S.ghot = ix.run_hot; S.gtab = ix.run_tabs2; S.tab_first = s_tab_first; S.ent = s_ent2; S.dir = s_dir2; S.rec = s_rec2;
     S.fill = ix.run_fill_shift;
     S.rec_any = nullptr;
     for (int t = kMaxRunDepth - 1; t >= 0; --t)
@@ -64,20 +61,19 @@ __device__ __forceinline__ RunSearch2<P> stage_run_search2(const DevIndex &ix, u
     return S;
 }
 
-// the record of table `rec` of depth index d: from LDS up to kLdsRunDepth, else two 16-byte loads of one 32-byte record (L2 / MALL resident)
+// what a step reads of its table (rbg_dev.h kRunHotShiftBit): from LDS up to kLdsRunDepth, else one 8-byte load (L2 resident)
+struct RunHot {
+    uint64_t dir_off;     // the table's first directory entry / bucket record in its depth's array
+    uint32_t dir_shift;
+};
 template <typename P>
-__device__ __forceinline__ DevRunTab2 load_run_tab(const RunSearch2<P> &S, const uint32_t d, const uint32_t rec) {
-    if (d < static_cast<uint32_t>(kLdsRunDepth)) return S.tab[rec];
-    const RBG_GLOBAL u32x4 *p = as_global<u32x4>(static_cast<const void *>(S.gtab + rec));
-    const u32x4 a = p[0], b = p[1];
-    DevRunTab2 R;
-    R.F = static_cast<uint64_t>(a.x) | (static_cast<uint64_t>(a.y) << 32);
-    R.first = static_cast<uint64_t>(a.z) | (static_cast<uint64_t>(a.w) << 32);
-    R.dir_off = static_cast<uint64_t>(b.x) | (static_cast<uint64_t>(b.y) << 32);
-    R.dir_shift = b.z;
-    R.pad = 0;
-    return R;
+__device__ __forceinline__ RunHot load_run_tab(const RunSearch2<P> &S, const uint32_t d, const uint32_t rec) {
+    const uint64_t w = d < static_cast<uint32_t>(kLdsRunDepth) ? S.hot[rec] : as_global<uint64_t>(S.ghot)[rec];
+    return RunHot{w & ((uint64_t(1) << kRunHotShiftBit) - 1), static_cast<uint32_t>(w >> kRunHotShiftBit)};
 }
+// index of the table's first entry in its depth's arrays (cold: scans of the run list, re-samples)
+template <typename P>
+__device__ __forceinline__ uint64_t run_first(const RunSearch2<P> &S, const uint32_t rec) { return as_global<uint64_t>(static_cast<const void *>(S.gtab + rec))[1]; }
 
 typedef unsigned int u32x2a4 __attribute__((ext_vector_type(2), aligned(4)));
 typedef unsigned int u32x4a8 __attribute__((ext_vector_type(4), aligned(8)));
@@ -104,8 +100,10 @@ struct LaneQ {
     uint32_t c = 0;    // candidates below the position so far
     uint32_t ks = 0, kc = 0, kn = 0;   // the last entry below it {start, cum} and the cum of the entry after that one
     uint32_t ps = 0, pc = 0;
+    uint32_t fc = 0;   // cum of the window's first entry: the rank of a position with no entry below it (the table's first entry: cum = F)
     bool pb = false;
     __device__ __forceinline__ void feed(const uint32_t gi, const uint32_t sa, const uint32_t cu) {
+        if (gi == 0u) fc = cu;
         const bool nb = gi < zlim && sa < qa;
         const bool sel = pb && !nb;      // entry gi - 1 is the last one below the position
         ks = sel ? ps : ks;
@@ -288,12 +286,17 @@ struct LaneRec {
     }
 };
 
-// the pending scans of one or two ranks (LaneRank::pending): every request of both is issued before the first is waited for
-__device__ __forceinline__ void lane_finish(const char *__restrict__ tent, LaneRank &A, LaneRank *B, uint32_t &rounds, uint32_t &ents) {
-    if (A.pending && A.z > kRecScanZ) lane_narrow(tent, A.a_lo, A.qa, A.p, A.z, kRecScanZ, 8u, rounds);
-    if (B && B->pending && B->z > kRecScanZ) lane_narrow(tent, B->a_lo, B->qa, B->p, B->z, kRecScanZ, 8u, rounds);
-    u32x4a8 wa[4], wb[4];
+// the pending scans of one or two ranks (LaneRank::pending): every request of both is issued before the first is waited for.
+// The run list is the table's slice of its depth's entry array: ent_d + first * 8, `first` read from the table's cold record here, by
+// the lanes that have a scan to make (a dependent load, but only overflowing buckets pay it).
+template <typename P>
+__device__ __forceinline__ void lane_finish(const RunSearch2<P> &S, const uint32_t d, const uint32_t rec, LaneRank &A, LaneRank *B, uint32_t &rounds, uint32_t &ents) {
     const bool pb = B && B->pending;
+    if (!(A.pending || pb)) return;
+    const char *__restrict__ tent = static_cast<const char *>(S.ent[d]) + run_first<P>(S, rec) * 8u;
+    if (A.pending && A.z > kRecScanZ) lane_narrow(tent, A.a_lo, A.qa, A.p, A.z, kRecScanZ, 8u, rounds);
+    if (pb && B->z > kRecScanZ) lane_narrow(tent, B->a_lo, B->qa, B->p, B->z, kRecScanZ, 8u, rounds);
+    u32x4a8 wa[4], wb[4];
     if (A.pending) {
         const RBG_GLOBAL char *base = as_global<char>(static_cast<const void *>(tent)) + static_cast<uint64_t>(A.p) * 8u;
 #pragma unroll
@@ -315,8 +318,8 @@ __device__ __forceinline__ void lane_finish(const char *__restrict__ tent, LaneR
         }
         R.c = Q.c;
         const uint32_t dd = Q.qa - Q.ks, len = Q.kn - Q.kc;
-        R.lo32 = Q.kc + (dd < len ? dd : len);
-        R.inside = dd <= len;
+        R.lo32 = Q.c ? Q.kc + (dd < len ? dd : len) : Q.fc;   // (none below: the window starts at the table's first entry, whose cum is the table's F)
+        R.inside = Q.c != 0u && dd <= len;
         ents += R.z + 1u;
     };
     if (A.pending) take(A, wa);
@@ -324,24 +327,26 @@ __device__ __forceinline__ void lane_finish(const char *__restrict__ tent, LaneR
 }
 
 // What the instrumented instantiations count on this format (the eight sums of SearchStat): [kStSteps] search steps,
-// [kStSlots] directory gathers (two neighbouring entries: 8 or 16 bytes), [kStDense] run-list entries the scans needed
-// (8 bytes each), [kStSearch] narrowing rounds (seven 4-byte pivots each), the rest as rbg_runs_device.hpp lists them.
+// [kStSlots] bucket records fetched (64 bytes) or directory gathers (two neighbouring entries: 8 or 16 bytes), [kStDense] run-list
+// entries the scans needed (8 bytes each), [kStSearch] narrowing rounds (seven 4-byte pivots each), the rest as rbg_runs_device.hpp
+// lists them.
 
-// Both ranks of one LF step of ONE lane: rle_string::rank (rle_string.hpp:131-161) in the k-mer table `rec` of depth
-// index d at positions q0 = lo and q1 = hi + 1 (q0 <= q1).  out.samp_e = the entry whose sample a toehold re-sample needs.
+// Both ranks of one LF step of ONE lane: rle_string::rank (rle_string.hpp:131-161) in the k-mer table `rec` of depth index d (R: its
+// hot word) at positions q0 = lo and q1 = hi + 1 (q0 <= q1).  The cums of this layout carry the table's F (rbg_dev.h): out.c_before /
+// out.c_upto are the ROWS F + rank (out.F stays 0), so that LF is lo' = c_before, hi' = c_upto - 1 (rowbowt.hpp:86-87).
+// out.samp_e = the entry whose sample a toehold re-sample needs, relative to the table's first (run_step_sample2).
 template <typename P, bool STATS = false, bool LEAN = false>
-__device__ __forceinline__ void lane_lf2_tab(const RunSearch2<P> &S, const uint32_t d, const DevRunTab2 &R, const uint64_t q0, const uint64_t q1, RunStep &out,
+__device__ __forceinline__ void lane_lf2_tab(const RunSearch2<P> &S, const uint32_t d, const uint32_t rec, const RunHot &R, const uint64_t q0, const uint64_t q1, RunStep &out,
                                              unsigned long long *st = nullptr) {
     constexpr bool W = sizeof(P) == 8;
-    out.F = R.F;
+    out.F = 0;
     const uint32_t sh = R.dir_shift;
-    const uint64_t b0 = q0 >> sh, b1 = q1 >> sh;
-    const char *__restrict__ tent = static_cast<const char *>(S.ent[d]) + R.first * 8u;
+    const uint64_t b0 = pos_bucket<P>(q0, sh), b1 = pos_bucket<P>(q1, sh);   // (per-lane shifts: rbg_device.hpp pos_bucket)
     if (const void *__restrict__ recs = S.rec[d]) {   // ---- bucket records: one aligned 64-byte record per position (rbg_dev.h RunRec2) ----
-        const uint32_t al0 = W ? static_cast<uint32_t>(b0 << sh) - (1u << S.fill) : 0u;
-        const uint32_t al1 = W ? static_cast<uint32_t>(b1 << sh) - (1u << S.fill) : 0u;
+        const uint32_t al0 = W ? pos_bucket_base32(q0, sh) - (1u << S.fill) : 0u;
+        const uint32_t al1 = W ? pos_bucket_base32(q1, sh) - (1u << S.fill) : 0u;
         const uint32_t qa0 = static_cast<uint32_t>(q0) - al0, qa1 = static_cast<uint32_t>(q1) - al1;
-        const uint32_t o0 = static_cast<uint32_t>(q0 - (b0 << sh)), o1 = static_cast<uint32_t>(q1 - (b1 << sh));
+        const uint32_t o0 = pos_bucket_offset(q0, sh), o1 = pos_bucket_offset(q1, sh);
         LaneRank A, B;
         uint32_t h0, h1;
         uint32_t rounds = 0, ents = 0;
@@ -351,16 +356,16 @@ __device__ __forceinline__ void lane_lf2_tab(const RunSearch2<P> &S, const uint3
         if (b1 == b0) {
             if (r0.compact()) r0.rank2(sh, al0, qa0, o0, qa1, o1, A, B);
             else { r0.pivots(al0, qa0, A); r0.pivots(al1, qa1, B); }
-            lane_finish(tent, A, &B, rounds, ents);
+            lane_finish<P>(S, d, rec, A, &B, rounds, ents);
         } else if constexpr (LEAN) {
             // (the seeding kernels: one record in registers at a time -- the second is fetched after the first position is answered;
             //  holding both costs sixteen registers on every step and them a workgroup per CU)
             if (r0.compact()) r0.template rank1<false>(sh, al0, qa0, o0, A); else r0.pivots(al0, qa0, A);
-            lane_finish(tent, A, nullptr, rounds, ents);
+            lane_finish<P>(S, d, rec, A, nullptr, rounds, ents);
             r0.load(recs, R.dir_off + b1);
             h1 = r0.w[1];
             if (r0.compact()) r0.template rank1<true>(sh, al1, qa1, o1, B); else r0.pivots(al1, qa1, B);
-            lane_finish(tent, B, nullptr, rounds, ents);
+            lane_finish<P>(S, d, rec, B, nullptr, rounds, ents);
         } else {
             // both records leave together, then both scans of the run list (overflowing buckets): the dependent round trips of a step are
             // record -> scan [-> sample] whatever its two positions meet -- a wave waits for the longest chain among its 64 lanes
@@ -369,16 +374,17 @@ __device__ __forceinline__ void lane_lf2_tab(const RunSearch2<P> &S, const uint3
             h1 = r1.w[1];
             if (r0.compact()) r0.template rank1<false>(sh, al0, qa0, o0, A); else r0.pivots(al0, qa0, A);
             if (r1.compact()) r1.template rank1<true>(sh, al1, qa1, o1, B); else r1.pivots(al1, qa1, B);
-            lane_finish(tent, A, &B, rounds, ents);
+            lane_finish<P>(S, d, rec, A, &B, rounds, ents);
         }
         if (STATS) { st[kStSlots] += b1 != b0 ? 2 : 1; st[kStSearch] += rounds; st[kStDense] += ents; st[kStSteps] += 1; }
         const uint64_t y0 = static_cast<uint64_t>(h0) << 31, y1 = static_cast<uint64_t>(h1) << 31;
-        out.c_before = A.c ? (W ? y0 + static_cast<uint32_t>(A.lo32 - static_cast<uint32_t>(y0)) : A.lo32) : 0;
-        out.c_upto = B.c ? (W ? y1 + static_cast<uint32_t>(B.lo32 - static_cast<uint32_t>(y1)) : B.lo32) : 0;
+        out.c_before = W ? y0 + static_cast<uint32_t>(A.lo32 - static_cast<uint32_t>(y0)) : A.lo32;
+        out.c_upto = W ? y1 + static_cast<uint32_t>(B.lo32 - static_cast<uint32_t>(y1)) : B.lo32;
         out.inside = B.c != 0 && B.inside;
-        out.samp_e = R.first + static_cast<uint64_t>(B.p) + B.c - 1u;
+        out.samp_e = static_cast<uint64_t>(B.p) + B.c - 1u;
         return;
     }
+    const char *__restrict__ tent = static_cast<const char *>(S.ent[d]) + run_first<P>(S, rec) * 8u;
     const void *__restrict__ dir = S.dir[d];
     uint32_t a0, h0, e0, a1, h1, e1;
     load_dir2<P>(dir, R.dir_off + b0, a0, h0, e0);
@@ -388,8 +394,8 @@ __device__ __forceinline__ void lane_lf2_tab(const RunSearch2<P> &S, const uint3
     uint32_t p0 = a0 ? a0 - 1u : 0u, z0 = e0 - p0;     // candidates: the entries of the bucket and the one before them
     uint32_t p1 = a1 ? a1 - 1u : 0u, z1 = e1 - p1;
     // anchors (8-byte positions): every candidate of bucket b lies above (b << sh) - 2^fill (fillers, rbg_dev.h)
-    const uint32_t al0 = W ? static_cast<uint32_t>(b0 << sh) - (1u << S.fill) : 0u;
-    const uint32_t al1 = W ? static_cast<uint32_t>(b1 << sh) - (1u << S.fill) : 0u;
+    const uint32_t al0 = W ? pos_bucket_base32(q0, sh) - (1u << S.fill) : 0u;
+    const uint32_t al1 = W ? pos_bucket_base32(q1, sh) - (1u << S.fill) : 0u;
     const uint32_t qa0 = static_cast<uint32_t>(q0) - al0, qa1 = static_cast<uint32_t>(q1) - al1;
     uint32_t rounds = 0;
     if (z0 > kLaneMaxZ) lane_narrow(tent, al0, qa0, p0, z0, kLaneMaxZ, 8u, rounds);
@@ -413,34 +419,32 @@ __device__ __forceinline__ void lane_lf2_tab(const RunSearch2<P> &S, const uint3
         lane_scan<LEAN>(tent, p1, z1, al1, B, nullptr);
         if (STATS) st[kStDense] += z0 + z1 + 2u;
     }
-    // rank = cum + min(position - start, length of that run); its high part from the directory (rbg_dev.h RunDir64)
-    uint64_t c_before = 0, c_upto = 0;
+    // the row = cum + min(position - start, length of that run), or -- no entry below the position -- the cum of the table's first
+    // entry (its F); the high part from the directory (rbg_dev.h RunDir64)
     bool inside = false;
+    uint32_t lo32a = A.fc, lo32b = B.fc;
     if (A.c) {
         const uint32_t dd = A.qa - A.ks, len = A.kn - A.kc;
-        const uint32_t lo32 = A.kc + (dd < len ? dd : len);
-        const uint64_t y = static_cast<uint64_t>(h0) << 31;
-        c_before = W ? y + static_cast<uint32_t>(lo32 - static_cast<uint32_t>(y)) : lo32;
+        lo32a = A.kc + (dd < len ? dd : len);
     }
     if (B.c) {
         const uint32_t dd = B.qa - B.ks, len = B.kn - B.kc;
-        const uint32_t lo32 = B.kc + (dd < len ? dd : len);
-        const uint64_t y = static_cast<uint64_t>(h1) << 31;
-        c_upto = W ? y + static_cast<uint32_t>(lo32 - static_cast<uint32_t>(y)) : lo32;
+        lo32b = B.kc + (dd < len ? dd : len);
         inside = dd <= len;
     }
-    out.c_before = c_before;
-    out.c_upto = c_upto;
+    const uint64_t y0 = static_cast<uint64_t>(h0) << 31, y1 = static_cast<uint64_t>(h1) << 31;
+    out.c_before = W ? y0 + static_cast<uint32_t>(lo32a - static_cast<uint32_t>(y0)) : lo32a;
+    out.c_upto = W ? y1 + static_cast<uint32_t>(lo32b - static_cast<uint32_t>(y1)) : lo32b;
     out.inside = inside;
-    out.samp_e = R.first + p1 + B.c - 1u;   // (read only when B.c > 0 and the row is not inside the run)
+    out.samp_e = static_cast<uint64_t>(p1) + B.c - 1u;   // (read only when B.c > 0 and the row is not inside the run)
     if (STATS) st[kStSteps] += 1;
 }
 
 template <typename P, bool STATS = false, bool LEAN = false>
 __device__ __forceinline__ void lane_lf2(const RunSearch2<P> &S, const uint32_t d, const uint32_t rec, const uint64_t q0, const uint64_t q1, RunStep &out,
                                          unsigned long long *st = nullptr) {
-    const DevRunTab2 R = load_run_tab<P>(S, d, rec);
-    lane_lf2_tab<P, STATS, LEAN>(S, d, R, q0, q1, out, st);
+    const RunHot R = load_run_tab<P>(S, d, rec);
+    lane_lf2_tab<P, STATS, LEAN>(S, d, rec, R, q0, q1, out, st);
 }
 
 // ---- the same step with the FIRST record of every lane fetched by its QUAD (k_find_range_runs) ----------------------------------------
@@ -490,17 +494,17 @@ __device__ __forceinline__ void glds_round(const uint32_t a_lo, const uint32_t a
     __builtin_amdgcn_global_load_lds(reinterpret_cast<const RBG_GLOBAL void *>(an + 16u * p), reinterpret_cast<__attribute__((address_space(3))) void *>(tile + r * kTileRound), 16, 0, 0);
 }
 // LEAN: the second record (hi + 1 in another bucket) is fetched into the first one's registers once that is answered (the seeding kernels)
-// R: the table's record (load_run_tab; the caller may have fetched it a step ahead); a lane that is not stepping passes the first record of depth 1
+// R: the table's hot word (load_run_tab; the caller may have fetched it a step ahead)
 template <typename P, bool STATS = false, bool LEAN = false, bool GLDS = false>
-__device__ __forceinline__ void lane_lf2_quad(const RunSearch2<P> &S, const bool stepping, const uint32_t d, const DevRunTab2 &R, const uint64_t q0, const uint64_t q1,
-                                              RunStep &out, unsigned long long *st = nullptr, lds_byte *tile = nullptr) {
+__device__ __forceinline__ void lane_lf2_quad(const RunSearch2<P> &S, const bool stepping, const uint32_t d, const uint32_t rec, const RunHot &R, const uint64_t q0,
+                                              const uint64_t q1, RunStep &out, unsigned long long *st = nullptr, lds_byte *tile = nullptr) {
     constexpr bool W = sizeof(P) == 8;
     const uint32_t sh = R.dir_shift;
     const bool by_rec = stepping && S.rec[d] != nullptr;
-    if (stepping && !by_rec) lane_lf2_tab<P, STATS>(S, d, R, q0, q1, out, st);   // (a depth with directories over its run lists: the lane by itself)
+    if (stepping && !by_rec) lane_lf2_tab<P, STATS>(S, d, rec, R, q0, q1, out, st);   // (a depth with directories over its run lists: the lane by itself)
     if (__ballot(by_rec) == 0) return;                                            // (nobody's quad has a record to fetch in this step)
     const uint32_t p = threadIdx.x & 3u;
-    const uint64_t b0 = by_rec ? q0 >> sh : 0u, b1 = by_rec ? q1 >> sh : 0u;
+    const uint64_t b0 = by_rec ? pos_bucket<P>(q0, sh) : 0u, b1 = by_rec ? pos_bucket<P>(q1, sh) : 0u;
     const char *recs = static_cast<const char *>(by_rec ? S.rec[d] : S.rec_any);
     const uint64_t a0 = reinterpret_cast<uint64_t>(recs) + (by_rec ? (R.dir_off + b0) * 64u : 0u);   // (a lane without a record to fetch names the first record there is)
     const uint32_t a_lo = static_cast<uint32_t>(a0), a_hi = static_cast<uint32_t>(a0 >> 32);
@@ -534,50 +538,49 @@ __device__ __forceinline__ void lane_lf2_quad(const RunSearch2<P> &S, const bool
         quad_transpose16(w0, p);
     }
     if (!by_rec) return;
-    out.F = R.F;
-    const char *__restrict__ tent = static_cast<const char *>(S.ent[d]) + R.first * 8u;
-    const uint32_t al0 = W ? static_cast<uint32_t>(b0 << sh) - (1u << S.fill) : 0u;
-    const uint32_t al1 = W ? static_cast<uint32_t>(b1 << sh) - (1u << S.fill) : 0u;
+    out.F = 0;
+    const uint32_t al0 = W ? pos_bucket_base32(q0, sh) - (1u << S.fill) : 0u;
+    const uint32_t al1 = W ? pos_bucket_base32(q1, sh) - (1u << S.fill) : 0u;
     const uint32_t qa0 = static_cast<uint32_t>(q0) - al0, qa1 = static_cast<uint32_t>(q1) - al1;
-    const uint32_t o0 = static_cast<uint32_t>(q0 - (b0 << sh)), o1 = static_cast<uint32_t>(q1 - (b1 << sh));
+    const uint32_t o0 = pos_bucket_offset(q0, sh), o1 = pos_bucket_offset(q1, sh);
     LaneRank A, B;
     uint32_t h0 = w0[1], h1 = w0[1], rounds = 0, ents = 0;
     if (!two) {
         if (r0.compact()) r0.rank2(sh, al0, qa0, o0, qa1, o1, A, B);
         else { r0.pivots(al0, qa0, A); r0.pivots(al1, qa1, B); }
-        lane_finish(tent, A, &B, rounds, ents);
+        lane_finish<P>(S, d, rec, A, &B, rounds, ents);
     } else if constexpr (LEAN) {
         if (r0.compact()) r0.template rank1<false>(sh, al0, qa0, o0, A); else r0.pivots(al0, qa0, A);
-        lane_finish(tent, A, nullptr, rounds, ents);
+        lane_finish<P>(S, d, rec, A, nullptr, rounds, ents);
         r0.load(recs, R.dir_off + b1);
         h1 = w0[1];
         if (r0.compact()) r0.template rank1<true>(sh, al1, qa1, o1, B); else r0.pivots(al1, qa1, B);
-        lane_finish(tent, B, nullptr, rounds, ents);
+        lane_finish<P>(S, d, rec, B, nullptr, rounds, ents);
     } else {
         h1 = r1.w[1];
         if (r0.compact()) r0.template rank1<false>(sh, al0, qa0, o0, A); else r0.pivots(al0, qa0, A);
         if (r1.compact()) r1.template rank1<true>(sh, al1, qa1, o1, B); else r1.pivots(al1, qa1, B);
-        lane_finish(tent, A, &B, rounds, ents);
+        lane_finish<P>(S, d, rec, A, &B, rounds, ents);
     }
     if (STATS) { st[kStSlots] += two ? 2 : 1; st[kStSearch] += rounds; st[kStDense] += ents; st[kStSteps] += 1; }
     const uint64_t y0 = static_cast<uint64_t>(h0) << 31, y1 = static_cast<uint64_t>(h1) << 31;
-    out.c_before = A.c ? (W ? y0 + static_cast<uint32_t>(A.lo32 - static_cast<uint32_t>(y0)) : A.lo32) : 0;
-    out.c_upto = B.c ? (W ? y1 + static_cast<uint32_t>(B.lo32 - static_cast<uint32_t>(y1)) : B.lo32) : 0;
+    out.c_before = W ? y0 + static_cast<uint32_t>(A.lo32 - static_cast<uint32_t>(y0)) : A.lo32;
+    out.c_upto = W ? y1 + static_cast<uint32_t>(B.lo32 - static_cast<uint32_t>(y1)) : B.lo32;
     out.inside = B.c != 0 && B.inside;
-    out.samp_e = R.first + static_cast<uint64_t>(B.p) + B.c - 1u;
+    out.samp_e = static_cast<uint64_t>(B.p) + B.c - 1u;
 }
 // the same with the table's record looked up here (the seeding kernels)
 template <typename P, bool STATS = false, bool LEAN = false>
 __device__ __forceinline__ void lane_lf2_quad(const RunSearch2<P> &S, const bool stepping, const uint32_t d, const uint32_t rec, const uint64_t q0, const uint64_t q1,
                                               RunStep &out, unsigned long long *st = nullptr) {
-    const DevRunTab2 R = load_run_tab<P>(S, stepping ? d : 0u, stepping ? rec : 0u);
-    lane_lf2_quad<P, STATS, LEAN, false>(S, stepping, d, R, q0, q1, out, st, nullptr);
+    const RunHot R = load_run_tab<P>(S, stepping ? d : 0u, stepping ? rec : 0u);
+    lane_lf2_quad<P, STATS, LEAN, false>(S, stepping, d, rec, R, q0, q1, out, st, nullptr);
 }
 
-// the sample of the step's predecessor run (one gather)
+// the sample of the step's predecessor run: entry `rel` of table `rec` (the table's first entry from its cold record, then one gather)
 template <typename P>
-__device__ __forceinline__ uint64_t run_step_sample2(const DevIndex &ix, const uint32_t d, const uint64_t e) {
-    return RunList<P>::samp(ix.run_samp[d], e);
+__device__ __forceinline__ uint64_t run_step_sample2(const DevIndex &ix, const RunSearch2<P> &S, const uint32_t d, const uint32_t rec, const uint64_t rel) {
+    return RunList<P>::samp(ix.run_samp[d], run_first<P>(S, rec) + rel);
 }
 
 // ---- phi by one lane ------------------------------------------------------------------------------------------------------

@@ -34,9 +34,9 @@ __device__ __forceinline__ uint32_t run_record(const uint32_t *s_tab_first, uint
 
 // result of one lane's step
 struct RunStep {
-    uint64_t F = 0, c_before = 0, c_upto = 0;   // the table's first row; rank(lo, .), rank(hi + 1, .)
+    uint64_t F = 0, c_before = 0, c_upto = 0;   // F + rank(lo, .), F + rank(hi + 1, .) with F the table's first row: the run lists' cums carry it (F itself stays 0)
     bool inside = false;                        // row hi lies in a run of the table (LF_w_loc's fast branch, rowbowt.hpp:559-561)
-    uint64_t samp_e = 0;                        // else the predecessor run's sample: that entry's index in the depth's arrays
+    uint64_t samp_e = 0;                        // else the predecessor run's sample: that entry's index relative to the table's first entry
 };
 
 // What the instrumented instantiations count on this layout (the same eight sums as SearchStat, other meanings:

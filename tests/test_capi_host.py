@@ -489,31 +489,25 @@ def test_header_is_plain_c_and_links(tmp_path):
     assert _compile_c_example(tmp_path).exists()
 
 
-def test_no_run_indexed_kernel_spills():
-    """No kernel of the run-indexed layout may use scratch: the one instantiation that spilled (the instrumented search at
-    8-byte positions, after the bucket records had raised its register need) faulted on the device (profiles/r04_fault_note.txt).
-    hipcc cross-compiles for gfx950 without a GPU and reports every kernel's ScratchSize."""
+def test_no_run_indexed_kernel_spills_and_no_kernel_shifts_by_its_last_vgpr():
+    """(a) No kernel of the run-indexed layout may use scratch: the one instantiation that spilled (the instrumented search at 8-byte
+    positions, after the bucket records had raised its register need) faulted on the device (profiles/r04_fault_note.txt).
+    (b) No kernel at all may take the amount of a 64-bit shift from the last VGPR of its allocation: on gfx950 such a shift reads its
+    amount from elsewhere (profiles/r05_shift64_last_vgpr.md: k_lf_runs answered from other buckets' records, or faulted, depending on
+    what had run before).  tools/check_isa.py cross-compiles every kernel file to gfx950 assembly (no GPU needed) and reads both off it."""
     import re
-    from concurrent.futures import ThreadPoolExecutor
-    csrc = os.path.join(ROOT, "rowbowt_amd", "csrc")
-
-    def usage(f):
-        p = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-c", f, "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"],
-                           cwd=csrc, capture_output=True, text=True)
-        assert p.returncode == 0, p.stderr[-2000:]
-        out, cur = [], None
-        for line in p.stderr.splitlines():
-            m = re.search(r"remark: Function Name: (\S+)", line)
-            if m:
-                cur = m.group(1)
-            m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
-            if m and cur:
-                out.append((cur, int(m.group(1))))
-        return out
-    with ThreadPoolExecutor(2) as ex:
-        res = sum(ex.map(usage, ["k_runs.hip", "k_runs_seeds.hip"]), [])
-    names = subprocess.run(["c++filt"], input="\n".join(n for n, _ in res), capture_output=True, text=True).stdout.splitlines()
-    v2 = [(n, s) for n, (_m, s) in zip(names, res) if re.search(r"(k_find_range_runs<|_runs<|runs2<)", n)]
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_isa
+    per_file = check_isa.scan(workers=4)
+    assert set(per_file) >= {"k_runs.hip", "k_runs_seeds.hip", "k_search.hip", "k_locate.hip", "k_markers.hip", "k_build.hip", "k_compose.hip", "k_text.hip"}
+    bad = [(f,) + h for f, ks in per_file.items() for h in check_isa.hazards(ks)]
+    assert not bad, bad
+    res = per_file["k_runs.hip"] + per_file["k_runs_seeds.hip"]
+    names = subprocess.run(["c++filt"], input="\n".join(k[0] for k in res), capture_output=True, text=True).stdout.splitlines()
+    v2 = [(n, k[2]) for n, k in zip(names, res) if re.search(r"(k_find_range_runs<|_runs<|runs2<)", n)]
     assert len(v2) >= 35, len(v2)   # (12 + 5 of k_runs.hip, 2 + 4 + 2 + 6 + 6 of k_runs_seeds.hip)
-    spilled = [(n, s) for n, s in v2 if s > 0]
+    spilled = [(n, s) for n, s in v2 if s]
     assert not spilled, spilled
+    # the checker itself: a kernel of 72 VGPRs shifting by v71 is flagged, one shifting by v70 or with 73 VGPRs is not
+    assert check_isa.hazards([("k", 72, 0, [71, 3])]) == [("k", 72, 1)] and not check_isa.hazards([("k", 72, 0, [70]), ("k", 73, 0, [71])])
+    assert check_isa.hazards([("k", 70, 0, [71])]) == [("k", 70, 1)]   # (allocated in granules of eight: 70 -> 72)
