@@ -374,6 +374,38 @@ def test_pangenome_stream_true_bwt_beyond_32_bits(layout):
     print(f"n = {ix['n']:.3e}, {layout}: {d['value']:.3e} reads/s streamed, {ix['hbm_bytes'] / 1e9:.1f} GB replica")
 
 
+def test_pangenome_stream_one_process_three_replicas_on_device_0():
+    """BASELINE.json configs[3]'s several-GPU shape as ONE process (tools/pangenome_stream.py --replicas 3 --replica-devices 0,0,0): the
+    index is built once, rbg_replicate_many makes two peer copies, three host threads stream the three rbg_shard_bounds blocks of the
+    read indices on three HIP streams with their own generators, the counters are reduced at the end.  Checked: the primary against
+    the oracle and the properties, every copy against the primary on the same reads, the reduced counters against the stream
+    (reads == total, sum of range widths == locations written), and the shard arithmetic (blocks cover the stream, sizes differ by
+    at most one).  The reference's dispatcher is one process with one index too (rb_align.cpp:176-178)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    total = 3_000_001
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "pangenome_stream.py"), "--L", "2000000", "--H", "40", "--total-reads", str(total),
+                        "--reads", "400000", "--check-reads", "4000", "--property-reads", "50000", "--layout", "runs", "--implicit-text", "on",
+                        "--replicas", "3", "--replica-devices", "0,0,0", "--hbm-reserve-gb", "0"],
+                       capture_output=True, timeout=900, cwd=root)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    d = json.loads(p.stdout.decode().strip().splitlines()[-1])
+    rep = d["replicas"]
+    assert d["n_gpus"] == 3 and rep["formed"] == 3 and rep["devices"] == [0, 0, 0] and rep["identical_outputs_on_every_replica"] is True
+    per = rep["per_replica"]
+    assert sorted(x["reads"] for x in per) == [1_000_000, 1_000_000, 1_000_001] and all(x["batches"] == 3 and x["ms"] > 0 for x in per)
+    assert d["seconds"] * 1e3 >= max(x["ms"] for x in per) - 1e-6       # max over the replicas (first gate of any to last end of any)
+    c = d["counters"]
+    assert c["reads"] == total and c["sum_occ"] == c["sum_locs"] > 10 * total and "3 replicas" in c["reduced_over"]
+    assert d["parity"]["reads_checked"] == 4000 and d["parity"]["bit_exact_vs_oracle"] and d["parity"]["count_only_kernel_bit_exact"]
+    props = d["properties"]
+    assert all(props[k] for k in ("unmutated_reads_all_found", "empty_is_{1,0}", "every_location_is_an_occurrence", "locations_distinct",
+                                  "occ_equals_range_width", "own_position_reported"))
+    assert d["config"]["index"]["rank_layout"] == 2 and d["peaks"]["host_bytes"] > 0
+
+
 @pytest.mark.gpu
 def test_reads_sampled_from_the_structure_equal_reads_sampled_from_the_text():
     """rbg_sample_reads_pangenome_dev (reads from base sequence + sites + allele matrix) == rbg_sample_reads_dev (reads from the

@@ -12,6 +12,12 @@ locations of --check-reads reads against oracle/rb_oracle.c; size-independent pr
 
   python tools/pangenome_stream.py                      # n = 5.0e10 (L = 2.5e8, H = 200), 1e9 reads x 150 bp
   python tools/pangenome_stream.py --L 44000000 --H 100 --total-reads 100000000   # n = 4.4e9: just beyond 2^32
+  python tools/pangenome_stream.py --replicas 8         # ONE process, one index build: rbg_replicate_many copies the replica to devices 1..7
+                                                        # (peer copies over xGMI), one host thread + HIP stream + read generator per replica,
+                                                        # counters through rbg_counters_allreduce_local; host memory independent of the count
+  python tools/pangenome_stream.py --replicas 3 --replica-devices 0,0,0    # the same path on one GPU (tests, the builder's box)
+
+The reference's dispatcher for comparison: rb_align.cpp:176-178 (one process, one index, a loop over the reads).
 """
 import argparse
 import json
@@ -60,7 +66,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1,
                     help="GPUs of this node = ranks; N > 1 without RANK in the environment starts the N ranks itself (rowbowt_amd/launch.py)")
     ap.add_argument("--launch-check", action="store_true", help="start the ranks, print what each was given, touch no GPU")
+    ap.add_argument("--replicas", type=int, default=0,
+                    help="ONE process: the index is built once, rbg_replicate_many copies it to the other devices, one host thread per replica streams "
+                         "its rbg_shard_bounds block on its own stream with its own read generator; host memory does not depend on the count")
+    ap.add_argument("--replica-devices", default="", help="devices of --replicas, comma separated (default: 0, 1, ...; may repeat: tests put several on one GPU)")
     args = ap.parse_args()
+    if args.replicas and args.gpus > 1:
+        raise SystemExit("--replicas (one process) and --gpus N (one process per GPU) are two ways to use several GPUs: pick one")
     import importlib.util
     spec = importlib.util.spec_from_file_location("rbg_launch", os.path.join(ROOT, "rowbowt_amd", "launch.py"))
     launch = importlib.util.module_from_spec(spec)
@@ -202,67 +214,154 @@ def main():
         f"(asked {ix.kmer_steps_requested}; {ix.hbm_free_at_load / 1e9:.0f} GB free at load, budget {ix.hbm_budget / 1e9:.0f} GB), "
         f"ftab_k={ix.ftab_k}, flatten+upload {t_load:.1f}s")
 
-    # ---- the stream: this rank owns the contiguous block of global read indices shard_bounds() gives it
-    gb, ge = shard.shard_bounds(args.total_reads, rank, world)
-    N = min(args.reads, ge - gb)
-    nbatch = (ge - gb + N - 1) // N
-    d_seqs = torch.zeros(N * m + 32, dtype=torch.uint8, device=dev)
-    d_off = torch.empty(N + 1, dtype=torch.int64, device=dev)
-    d_lo, d_hi, d_k = (torch.empty(N, dtype=torch.int64, device=dev) for _ in range(3))
-    d_loc_off = torch.empty(N + 1, dtype=torch.int64, device=dev)
-    tmp_bytes = Lb.rbg_locate_plan_tmp_bytes(N)
-    d_tmp = torch.empty(tmp_bytes, dtype=torch.uint8, device=dev)
-    ws_bytes = Lb.rbg_locate_order_ws_bytes(N)
-    d_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    stream = torch.cuda.current_stream()
-    st = stream.cuda_stream
+    # ---- replicas of this process (--replicas G): G - 1 peer copies of the replica just built; the primary is replica 0
+    G = max(1, args.replicas)
+    rep_devices = [local_rank]
+    replicas = [rb]
+    t_replicate = 0.0
+    if args.replicas:
+        rep_devices = [int(x) for x in args.replica_devices.split(",")] if args.replica_devices else list(range(G))
+        if len(rep_devices) != G or rep_devices[0] != local_rank or any(d < 0 or d >= torch.cuda.device_count() for d in rep_devices):
+            raise SystemExit(f"--replica-devices must name {G} visible devices, the first of them {local_rank} (where the index was built): {rep_devices}")
+        t0 = time.time()
+        if G > 1:
+            replicas += rb.replicate_many(rep_devices[1:])
+        torch.cuda.synchronize()
+        t_replicate = time.time() - t0
+        mem_line(f"after {G - 1} peer cop{'y' if G == 2 else 'ies'} of the replica ({t_replicate:.2f} s)")
 
     def chk(rc, what):
         if rc != 0:
             raise RuntimeError(f"{what} failed: {Lb.rbg_strerror(rc).decode()}")
 
-    def gen(first, cnt, start_out=None):
-        so = start_out.data_ptr() if start_out is not None else None
-        if implicit:
-            chk(Lb.rbg_sample_reads_pangenome_dev(tv.base_b.data_ptr(), tv.sites.data_ptr(), tv.alt_b.data_ptr(), tv.G.data_ptr(), tv.S,
-                                                  tv.site_dir.data_ptr() if tv.site_dir is not None else None, tv.site_dir_shift, unit, H, L, m,
-                                                  args.seed + 2, first, cnt, args.sub_ppm, d_seqs.data_ptr(), d_off.data_ptr(), so, st), "sample_reads_pangenome")
-        else:
-            chk(Lb.rbg_sample_reads_dev(text.data_ptr(), unit, H, L, m, args.seed + 2, first, cnt, args.sub_ppm, d_seqs.data_ptr(),
-                                        d_off.data_ptr(), so, st), "sample_reads")
+    class Lane:
+        """one replica's stream: its block of the global read indices, its buffers, its read generator, its HIP stream"""
 
-    def search(cnt):
-        if args.count_only:
-            chk(Lb.rbg_find_range_dev(rb.h, d_seqs.data_ptr(), d_off.data_ptr(), cnt, d_lo.data_ptr(), d_hi.data_ptr(), st), "find_range")
-        else:
-            chk(Lb.rbg_find_range_w_toehold_dev(rb.h, d_seqs.data_ptr(), d_off.data_ptr(), cnt, d_lo.data_ptr(), d_hi.data_ptr(),
-                                                d_k.data_ptr(), st), "find_range_w_toehold")
+        def __init__(self, g, handle, device_index, lanes):
+            self.g, self.rb, self.dev = g, handle, torch.device("cuda", device_index)
+            self.gb, self.ge = shard.shard_bounds(args.total_reads, rank * lanes + g if lanes > 1 else rank, world * lanes if lanes > 1 else world)
+            self.N = min(args.reads, max(1, self.ge - self.gb))
+            self.nbatch = (self.ge - self.gb + self.N - 1) // self.N
+            dev_l, N = self.dev, self.N
+            with torch.cuda.device(dev_l):
+                # (the primary's lane runs on the stream the synthesis used; the others get their own)
+                self.stream = torch.cuda.current_stream(dev_l) if g == 0 else torch.cuda.Stream(dev_l)
+                self.st = self.stream.cuda_stream
+                self.d_seqs = torch.zeros(N * m + 32, dtype=torch.uint8, device=dev_l)
+                self.d_off = torch.empty(N + 1, dtype=torch.int64, device=dev_l)
+                self.d_lo, self.d_hi, self.d_k = (torch.empty(N, dtype=torch.int64, device=dev_l) for _ in range(3))
+                self.d_loc_off = torch.empty(N + 1, dtype=torch.int64, device=dev_l)
+                self.tmp_bytes = Lb.rbg_locate_plan_tmp_bytes(N)
+                self.d_tmp = torch.empty(self.tmp_bytes, dtype=torch.uint8, device=dev_l)
+                self.ws_bytes = Lb.rbg_locate_order_ws_bytes(N)
+                self.d_ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev_l)
+                self.d_locs = None
+                # the text (or the structure it is sampled from) on this lane's device: the same tensors where it is the primary's
+                if dev_l == dev:
+                    self.tv, self.text = tv, text
+                elif implicit:
+                    import copy
+                    self.tv, self.text = copy.copy(tv), None
+                    for name in ("base_b", "alt_b", "sites", "G", "site_dir"):
+                        t = getattr(tv, name)
+                        setattr(self.tv, name, None if t is None else t.to(dev_l))
+                else:
+                    self.tv, self.text = None, text.to(dev_l)
+            self.t_gen = 0.0
+            self.t_begin = self.t_end = 0.0
+            self.done = 0
 
-    # size the location buffer on the first batch (+25 %); a batch that needs more re-allocates (outside the timers)
-    gen(gb, N)
-    search(N)
-    d_locs = None
-    if not args.count_only:
-        chk(Lb.rbg_locate_plan_dev(rb.h, d_lo.data_ptr(), d_hi.data_ptr(), N, max_hits, d_loc_off.data_ptr(), d_tmp.data_ptr(), tmp_bytes, st), "plan")
-        cap = int(int(d_loc_off[-1].item()) * 1.25) + 1024
-        d_locs = torch.empty(cap, dtype=torch.int64, device=dev)
-        log(f"batch 0: {int(d_loc_off[-1].item())} locations for {N} reads; location buffer {cap * 8 / 1e9:.1f} GB")
+        def text_at(self, pos):
+            return self.tv.at(pos) if implicit else self.text[pos]
 
-    def locate(cnt):
-        nonlocal d_locs
-        chk(Lb.rbg_locate_plan_dev(rb.h, d_lo.data_ptr(), d_hi.data_ptr(), cnt, max_hits, d_loc_off.data_ptr(), d_tmp.data_ptr(), tmp_bytes, st), "plan")
-        total = int(d_loc_off[cnt].item())            # (the one host round trip of a batch: the ragged output has to be sized)
-        if total > d_locs.numel():
-            d_locs = torch.empty(int(total * 1.25), dtype=torch.int64, device=dev)
-        chk(Lb.rbg_locate_order_dev(rb.h, d_k.data_ptr(), cnt, d_ws.data_ptr(), ws_bytes, st), "order")
-        chk(Lb.rbg_locate_fill_dev(rb.h, d_lo.data_ptr(), d_hi.data_ptr(), d_k.data_ptr(), cnt, max_hits, d_loc_off.data_ptr(),
-                                   d_locs.data_ptr(), d_ws.data_ptr(), st), "fill")
-        return total
+        def gen(self, first, cnt, start_out=None):
+            so = start_out.data_ptr() if start_out is not None else None
+            t = self.tv
+            if implicit:
+                chk(Lb.rbg_sample_reads_pangenome_dev(t.base_b.data_ptr(), t.sites.data_ptr(), t.alt_b.data_ptr(), t.G.data_ptr(), t.S,
+                                                      t.site_dir.data_ptr() if t.site_dir is not None else None, t.site_dir_shift, unit, H, L, m,
+                                                      args.seed + 2, first, cnt, args.sub_ppm, self.d_seqs.data_ptr(), self.d_off.data_ptr(), so, self.st), "sample_reads_pangenome")
+            else:
+                chk(Lb.rbg_sample_reads_dev(self.text.data_ptr(), unit, H, L, m, args.seed + 2, first, cnt, args.sub_ppm, self.d_seqs.data_ptr(),
+                                            self.d_off.data_ptr(), so, self.st), "sample_reads")
+
+        def search(self, cnt):
+            if args.count_only:
+                chk(Lb.rbg_find_range_dev(self.rb.h, self.d_seqs.data_ptr(), self.d_off.data_ptr(), cnt, self.d_lo.data_ptr(), self.d_hi.data_ptr(), self.st), "find_range")
+            else:
+                chk(Lb.rbg_find_range_w_toehold_dev(self.rb.h, self.d_seqs.data_ptr(), self.d_off.data_ptr(), cnt, self.d_lo.data_ptr(), self.d_hi.data_ptr(),
+                                                    self.d_k.data_ptr(), self.st), "find_range_w_toehold")
+
+        def plan(self, cnt):
+            chk(Lb.rbg_locate_plan_dev(self.rb.h, self.d_lo.data_ptr(), self.d_hi.data_ptr(), cnt, max_hits, self.d_loc_off.data_ptr(), self.d_tmp.data_ptr(),
+                                       self.tmp_bytes, self.st), "plan")
+
+        def order(self, cnt):
+            chk(Lb.rbg_locate_order_dev(self.rb.h, self.d_k.data_ptr(), cnt, self.d_ws.data_ptr(), self.ws_bytes, self.st), "order")
+
+        def fill(self, cnt):
+            chk(Lb.rbg_locate_fill_dev(self.rb.h, self.d_lo.data_ptr(), self.d_hi.data_ptr(), self.d_k.data_ptr(), cnt, max_hits, self.d_loc_off.data_ptr(),
+                                       self.d_locs.data_ptr(), self.d_ws.data_ptr(), self.st), "fill")
+
+        def size_locs(self):
+            """the location buffer sized on the lane's first batch (+25 %); a batch that needs more re-allocates"""
+            with torch.cuda.device(self.dev), torch.cuda.stream(self.stream):
+                self.gen(self.gb, self.N)
+                self.search(self.N)
+                if not args.count_only:
+                    self.plan(self.N)
+                    total = int(self.d_loc_off[-1].item())
+                    self.d_locs = torch.empty(int(total * 1.25) + 1024, dtype=torch.int64, device=self.dev)
+                    return total
+            return 0
+
+        def locate(self, cnt):
+            self.plan(cnt)
+            total = int(self.d_loc_off[cnt].item())            # (the one host round trip of a batch: the ragged output has to be sized)
+            if total > self.d_locs.numel():
+                self.d_locs = torch.empty(int(total * 1.25), dtype=torch.int64, device=self.dev)
+            self.order(cnt)
+            self.fill(cnt)
+            return total
+
+        def run(self, gate):
+            """the timed stream of this lane (a host thread per lane when there are several): between the two gates"""
+            with torch.cuda.device(self.dev), torch.cuda.stream(self.stream):
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+                gate()
+                self.t_begin = time.perf_counter()
+                for b in range(self.nbatch):
+                    first = self.gb + b * self.N
+                    cnt = min(self.N, self.ge - first)
+                    ev[0].record(self.stream)
+                    self.gen(first, cnt)
+                    ev[1].record(self.stream)
+                    self.search(cnt)
+                    if not args.count_only:
+                        self.locate(cnt)
+                    self.stream.synchronize()
+                    self.t_gen += ev[0].elapsed_time(ev[1]) * 1e-3
+                    self.done += cnt
+                self.t_end = time.perf_counter()
+                gate()
+
+    lanes = [Lane(g, replicas[g], rep_devices[g], G) for g in range(G)]
+    ln0 = lanes[0]
+    gb, ge, N, nbatch = ln0.gb, ln0.ge, ln0.N, ln0.nbatch
+    stream, st = ln0.stream, ln0.st
+    d_seqs, d_off, d_lo, d_hi, d_k, d_loc_off = ln0.d_seqs, ln0.d_off, ln0.d_lo, ln0.d_hi, ln0.d_k, ln0.d_loc_off
+    text_at, gen, search, locate = ln0.text_at, ln0.gen, ln0.search, ln0.locate
+    for ln in lanes:
+        total0 = ln.size_locs()
+        if ln.g == 0 and not args.count_only:
+            log(f"batch 0: {total0} locations for {N} reads; location buffer {ln.d_locs.numel() * 8 / 1e9:.1f} GB")
+    mem_line(f"with the buffers of {G} lane(s)")
 
     def barrier():
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
+        for d in sorted(set(rep_devices)):
+            torch.cuda.synchronize(d)
 
     # per-kernel times of one batch (outside the timed region; HIP events on the launch stream)
     kernel_ms, touched = {}, None
@@ -278,11 +377,9 @@ def main():
         kernel_ms["sample_reads"] = timed(lambda: gen(gb, N))
         kernel_ms["find_range" if args.count_only else "find_range_w_toehold"] = timed(lambda: search(N))
         if not args.count_only:
-            kernel_ms["locate_plan"] = timed(lambda: chk(Lb.rbg_locate_plan_dev(rb.h, d_lo.data_ptr(), d_hi.data_ptr(), N, max_hits, d_loc_off.data_ptr(),
-                                                                                   d_tmp.data_ptr(), tmp_bytes, st), "plan"))
-            kernel_ms["locate_order"] = timed(lambda: chk(Lb.rbg_locate_order_dev(rb.h, d_k.data_ptr(), N, d_ws.data_ptr(), ws_bytes, st), "order"))
-            kernel_ms["locate_fill"] = timed(lambda: chk(Lb.rbg_locate_fill_dev(rb.h, d_lo.data_ptr(), d_hi.data_ptr(), d_k.data_ptr(), N, max_hits,
-                                                                                   d_loc_off.data_ptr(), d_locs.data_ptr(), d_ws.data_ptr(), st), "fill"))
+            kernel_ms["locate_plan"] = timed(lambda: ln0.plan(N))
+            kernel_ms["locate_order"] = timed(lambda: ln0.order(N))
+            kernel_ms["locate_fill"] = timed(lambda: ln0.fill(N))
         log("one batch, per kernel (ms): " + ", ".join(f"{k} {v:.2f}" for k, v in kernel_ms.items()))
         if args.replica_probe:
             rep = rb.replicate(local_rank)
@@ -301,47 +398,87 @@ def main():
         touched = dict(zip(("steps", "slots", "dense", "searched_ranks", "ftab", "resamples", "read_chunks", "symbols"), (d_stats.cpu().numpy()[:8] / N).round(3).tolist()))
         log("one batch, per read: " + ", ".join(f"{k} {v}" for k, v in touched.items()) +
             "   (run-indexed layout: slots = bucket records or directory gathers, dense = run-list entries scanned, searched_ranks = narrowing rounds)")
-        rb.counters_reset()
 
-    rb.counters_reset()
-    ev_g = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-    t_gen = t_search = 0.0
+    # ---- identical per-read outputs on every replica (outside the timed region): the primary's first reads through each copy
+    same_on_replicas = None
+    if G > 1:
+        ncmp = min(N, 100_000)
+        with torch.cuda.device(dev), torch.cuda.stream(ln0.stream):
+            gen(gb, ncmp)
+            search(ncmp)
+            tot = 0 if args.count_only else locate(ncmp)
+            ln0.stream.synchronize()
+            want = [t[:ncmp].cpu() for t in ((d_lo, d_hi) if args.count_only else (d_lo, d_hi, d_k))]
+            if not args.count_only:
+                want += [ln0.d_loc_off[:ncmp + 1].cpu(), ln0.d_locs[:tot].cpu()]
+        same_on_replicas = True
+        for ln in lanes[1:]:
+            with torch.cuda.device(ln.dev), torch.cuda.stream(ln.stream):
+                ln.gen(gb, ncmp)
+                ln.search(ncmp)
+                tot_g = 0 if args.count_only else ln.locate(ncmp)
+                ln.stream.synchronize()
+                got = [t[:ncmp].cpu() for t in ((ln.d_lo, ln.d_hi) if args.count_only else (ln.d_lo, ln.d_hi, ln.d_k))]
+                if not args.count_only:
+                    got += [ln.d_loc_off[:ncmp + 1].cpu(), ln.d_locs[:tot_g].cpu()]
+            same_on_replicas = same_on_replicas and len(got) == len(want) and all(a.shape == b.shape and bool((a == b).all()) for a, b in zip(got, want))
+        log(f"the first {ncmp} reads give identical ranges, toeholds and locations on all {G} replicas: {same_on_replicas}")
+
+    for r_ in replicas:
+        r_.counters_reset()
     barrier()
-    t_all = time.perf_counter()
-    done = 0
-    for b in range(nbatch):
-        first = gb + b * N
-        cnt = min(N, ge - first)
-        ev_g[0].record(stream)
-        gen(first, cnt)
-        ev_g[1].record(stream)
-        search(cnt)
-        if not args.count_only:
-            locate(cnt)
-        torch.cuda.synchronize()
-        t_gen += ev_g[0].elapsed_time(ev_g[1]) * 1e-3
-        done += cnt
-    barrier()
-    el = time.perf_counter() - t_all
-    counters = rb.counters().astype(np.int64)
+    if G == 1:
+        ln0.run(barrier)
+    else:
+        gate_obj = threading.Barrier(G)
+        errs = []
+
+        def lane_thread(ln):
+            try:
+                ln.run(gate_obj.wait)
+            except BaseException as e:   # noqa: BLE001  (a lane that fails must not leave the others at the gate)
+                errs.append(e)
+                gate_obj.abort()
+        ths = [threading.Thread(target=lane_thread, args=(ln,)) for ln in lanes]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        if errs:
+            raise errs[0]
+        barrier()
+    el = max(ln.t_end for ln in lanes) - min(ln.t_begin for ln in lanes)    # max over the replicas, between the gates
+    t_gen = max(ln.t_gen for ln in lanes)
+    done, ge_all = sum(ln.done for ln in lanes), sum(ln.ge - ln.gb for ln in lanes)
     t_el = torch.tensor([el, t_gen], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
     el, t_gen = float(t_el[0].item()), float(t_el[1].item())
-    g_counters = shard.reduce_counters(counters, device=dev)
+    if G > 1:
+        if len(set(rep_devices)) == G:
+            g_counters = [int(x) for x in capi.counters_allreduce_local(replicas)]
+            reduced_over = f"rbg_counters_allreduce_local: one grouped RCCL all-reduce over the {G} replicas of this process"
+        else:   # (several replicas on one device -- tests, the one-GPU box: RCCL wants distinct devices)
+            g_counters = [int(x) for x in np.sum([r_.counters().astype(np.int64) for r_ in replicas], axis=0)]
+            reduced_over = f"summed on the host over {G} replicas ({len(set(rep_devices))} device(s): RCCL needs one device per rank)"
+    else:
+        counters = rb.counters().astype(np.int64)
+        g_counters = shard.reduce_counters(counters, device=dev)
+        reduced_over = f"RCCL all_reduce over {world} rank(s)" if use_dist else "single GPU (no process group)"
 
     out = None
     if rank == 0:
         out = {
             "metric": f"reads/s ({m} bp, {'count' if args.count_only else 'count+locate'}), streamed",
-            "value": args.total_reads / el, "unit": "reads/s", "n_gpus": world, "higher_is_better": True, "scaling": "strong",
+            "value": args.total_reads / el, "unit": "reads/s", "n_gpus": world * G if args.replicas else world, "higher_is_better": True, "scaling": "strong",
             "value_excluding_read_generation": args.total_reads / max(el - t_gen, 1e-9),
             "seconds": el, "seconds_generating_reads": t_gen, "batches_per_gpu": nbatch, "reads_per_batch": N,
             "kernel_ms_one_batch": kernel_ms, "search_touched_per_read": touched,
             "dtype": "u64" if ix.pos_bytes == 8 else "u32/u64", "data": "synthetic",
             "config": {"workload": f"BASELINE.json configs[3] shape: {args.total_reads} synthetic {m} bp reads generated on the device per batch "
                                    f"(counter-based RNG), {'find_range' if args.count_only else 'find_range_w_toehold + locs_at'}, "
-                                   f"index replicated x{world}, reads sharded by contiguous global index, counters reduced over RCCL",
+                                   f"index replicated x{world * G}" + (f" in ONE process (built once, rbg_replicate_many to devices {rep_devices})" if args.replicas else "") +
+                                   ", reads sharded by contiguous global index (rbg_shard_bounds), no data-path collective, counters reduced at the end",
                        "index": {"L": args.L, "H": args.H, "n": int(n), "r": int(inp["r"]), "site_rate": args.site_rate, "true_bwt": True,
                                  "builder": "rowbowt_amd/tools/pangenome_bwt.py", "hbm_bytes": int(ix.hbm_bytes), "pos_bytes": int(ix.pos_bytes),
                                  "symbols_per_gather": int(ix.kmer_steps), "symbols_per_gather_requested": int(ix.kmer_steps_requested),
@@ -351,8 +488,19 @@ def main():
                                  "rank_layout": int(ix.rank_layout), "ftab_k": int(ix.ftab_k),
                                  "build_runs_s": t_build, "flatten_upload_s": t_load}},
             "counters": {"reads": g_counters[0], "matched": g_counters[1], "sum_occ": g_counters[2], "sum_locs": g_counters[3],
-                         "reduced_over": f"RCCL all_reduce over {world} rank(s)" if use_dist else "single GPU (no process group)"},
+                         "reduced_over": reduced_over},
         }
+        if args.replicas:
+            out["replicas"] = {"formed": G, "devices": rep_devices, "replicate_s": t_replicate, "identical_outputs_on_every_replica": same_on_replicas,
+                               "per_replica": [{"device": rep_devices[ln.g], "reads": ln.done, "batches": ln.nbatch, "ms": (ln.t_end - ln.t_begin) * 1e3,
+                                                "ms_generating_reads": ln.t_gen * 1e3} for ln in lanes],
+                               "timing": "max over the replicas between two gates (threading.Barrier; one host thread and one HIP stream per replica)"}
+            if same_on_replicas is False:
+                print(json.dumps(out))
+                raise SystemExit("REPLICA MISMATCH: a copy answers differently from the primary")
+        if done != ge_all:
+            print(json.dumps(out))
+            raise SystemExit(f"{done} reads streamed by this process, {ge_all} expected")
         if g_counters[0] != args.total_reads:
             print(json.dumps(out))
             raise SystemExit(f"counter mismatch: {g_counters[0]} reads counted, {args.total_reads} streamed")
@@ -377,7 +525,7 @@ def main():
             occ_t = offs[1:] - offs[:-1]
             ok_occ = bool((torch.where(hi_t >= lo_t, hi_t - lo_t + 1, torch.zeros_like(lo_t)).clamp(max=max_hits if max_hits < 2**63 else 2**63 - 1) == occ_t).all().item())
             ridx = torch.repeat_interleave(torch.arange(npr, device=dev), occ_t)
-            locs_t = d_locs[:total]
+            locs_t = ln0.d_locs[:total]
             bad = torch.zeros(total, dtype=torch.bool, device=dev)
             for j in range(m):
                 bad |= text_at(locs_t + j) != reads[ridx, j]
@@ -416,7 +564,7 @@ def main():
             else:
                 g_k = d_k[:nchk].cpu().numpy().view(np.uint64)
                 g_off = d_loc_off[:nchk + 1].cpu().numpy().view(np.uint64)
-                g_locs = d_locs[:int(g_off[-1])].cpu().numpy().view(np.uint64)
+                g_locs = ln0.d_locs[:int(g_off[-1])].cpu().numpy().view(np.uint64)
                 wlo, whi, wk = o.find_range_w_toehold_batch(h_seqs, h_off, nthreads=ncpu)
                 woff, wlocs = o.locs_at_batch(wlo, whi, wk, max_hits, nthreads=ncpu)
                 ok = bool((g_lo == wlo).all() and (g_hi == whi).all() and (g_k == wk).all() and (g_off == woff).all() and (g_locs == wlocs).all())
@@ -444,6 +592,8 @@ def main():
         if args.out_json:
             with open(args.out_json, "w") as f:
                 f.write(json.dumps(out) + "\n")
+    for r_ in replicas[1:]:
+        r_.close()
     rb.close()
     if use_dist:
         dist.barrier()
