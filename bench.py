@@ -91,6 +91,11 @@ def parse():
     ap.add_argument("--via-cache", action="store_true",
                     help="build the replica through the native cache file even on one GPU (with --gpus N > 1 every rank does: rank 0 "
                          "writes it to node-local shared memory once, all ranks load it)")
+    ap.add_argument("--replicas", type=int, default=0,
+                    help="ONE process with G replicas (rbg_replicate_many: the index is built once, peer-copied to the other devices), a host thread + HIP stream + "
+                         "read batch per replica; the line's value / n_gpus / ms_per_step then describe the G replicas (weak scaling: --reads per replica). "
+                         "The driver's N-GPU contract stays one process per GPU (--gpus N)")
+    ap.add_argument("--replica-devices", default="", help="devices of --replicas, comma separated (default 0, 1, ...; may repeat)")
     ap.add_argument("--property-reads", type=int, default=1_000_000,
                     help="reads whose every reported location is checked against the text on the GPU (size-independent property)")
     return ap.parse_args()
@@ -710,6 +715,7 @@ def main():
         if not (ok_match and ok_distinct and ok_occ and ok_empty):
             print(json.dumps(out))
             raise SystemExit("PROPERTY FAILURE at full size")
+    text_for_replicas = text if args.replicas else None   # (the --replicas leg samples each replica's batch from it)
     del text
     torch.cuda.empty_cache()
 
@@ -1074,6 +1080,131 @@ def main():
         out["space_speed"] = {"unit": "ms per launch of this run's batch (best of 3)", "rows": rows,
                               "note": "RBG_OPT_KMER_STEPS / the HBM budget rule pick the row; rbg_info reports which (symbols_per_gather, "
                                       "hbm_free_at_load, hbm_budget)"}
+
+    # ---- --replicas G: the same count+locate step on G replicas held by THIS process (SURVEY 8e's replication without a process
+    # per GPU: one build, rbg_replicate_many, no data-path collective; the reference is one process with one index, rb_align.cpp:176-178)
+    if rank == 0 and args.replicas and world == 1:
+        import threading
+        G = args.replicas
+        devs = [int(x) for x in args.replica_devices.split(",")] if args.replica_devices else list(range(G))
+        if len(devs) != G or devs[0] != local_rank or any(d < 0 or d >= torch.cuda.device_count() for d in devs):
+            raise SystemExit(f"--replica-devices must name {G} visible devices, the first of them {local_rank}: {devs}")
+        t0 = time.time()
+        reps = [rb] + (rb.replicate_many(devs[1:]) if G > 1 else [])
+        torch.cuda.synchronize()
+        t_rep = time.time() - t0
+        step()                       # the primary's results of its own batch: what every copy must reproduce
+        torch.cuda.synchronize()
+        want = [t.cpu() for t in (d_lo, d_hi, d_k, d_loc_off, d_locs[:total_locs])]
+
+        class Lane:
+            def __init__(self, g):
+                self.g, self.rb, self.dev = g, reps[g], torch.device("cuda", devs[g])
+                with torch.cuda.device(self.dev):
+                    self.stream = torch.cuda.Stream(self.dev)
+                    self.st = self.stream.cuda_stream
+                    text_g = text_for_replicas if self.dev == dev else text_for_replicas.to(self.dev)
+                    # replica g's block of the global batch of G x --reads reads (replica 0: the batch the headline ran)
+                    rd = reads if g == 0 else sp.sample_reads(text_g, info, N, m, seed=args.seed + 2 + g, sub_rate=0.1)[0]
+                    self.seqs = torch.cat([rd.reshape(-1), torch.zeros(32, dtype=torch.uint8, device=self.dev)])
+                    self.off = torch.arange(N + 1, device=self.dev, dtype=torch.int64) * m
+                    self.lo, self.hi, self.k = (torch.empty(N, dtype=torch.int64, device=self.dev) for _ in range(3))
+                    self.loc_off = torch.empty(N + 1, dtype=torch.int64, device=self.dev)
+                    self.tmp = torch.empty(tmp_bytes, dtype=torch.uint8, device=self.dev)
+                    self.ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.dev)
+                    self.locs = None
+                    self.same = None
+                    torch.cuda.synchronize(self.dev)   # (the buffers were made on the device's default stream; the lane works on its own)
+                    if g > 0:   # (the copy against the primary, on the primary's batch)
+                        keep, self.seqs = self.seqs, d_seqs.to(self.dev)
+                        torch.cuda.synchronize(self.dev)
+                        self.search()
+                        self.plan()
+                        self.stream.synchronize()
+                        self.locs = torch.empty(max(int(self.loc_off[-1].item()), 1), dtype=torch.int64, device=self.dev)
+                        self.order()
+                        self.fill()
+                        self.stream.synchronize()
+                        got = [t.cpu() for t in (self.lo, self.hi, self.k, self.loc_off, self.locs[:int(self.loc_off[-1].item())])]
+                        self.same = all(a.shape == b.shape and bool((a == b).all()) for a, b in zip(got, want))
+                        self.seqs = keep
+                    self.search()
+                    self.plan()
+                    self.stream.synchronize()
+                    self.total = int(self.loc_off[-1].item())
+                    self.locs = torch.empty(max(self.total, 1), dtype=torch.int64, device=self.dev)
+                self.t0 = self.t1 = 0.0
+
+            def search(self):
+                chk(L.rbg_find_range_w_toehold_dev(self.rb.h, self.seqs.data_ptr(), self.off.data_ptr(), N, self.lo.data_ptr(), self.hi.data_ptr(), self.k.data_ptr(), self.st), "find_range_w_toehold")
+
+            def plan(self):
+                chk(L.rbg_locate_plan_dev(self.rb.h, self.lo.data_ptr(), self.hi.data_ptr(), N, max_hits, self.loc_off.data_ptr(), self.tmp.data_ptr(), tmp_bytes, self.st), "locate_plan")
+
+            def order(self):
+                chk(L.rbg_locate_order_dev(self.rb.h, self.k.data_ptr(), N, self.ws.data_ptr(), ws_bytes, self.st), "locate_order")
+
+            def fill(self):
+                chk(L.rbg_locate_fill_dev(self.rb.h, self.lo.data_ptr(), self.hi.data_ptr(), self.k.data_ptr(), N, max_hits, self.loc_off.data_ptr(), self.locs.data_ptr(),
+                                          self.ws.data_ptr(), self.st), "locate_fill")
+
+            def run(self, gate):
+                with torch.cuda.device(self.dev):
+                    for _ in range(max(1, args.warmup)):
+                        self.search(); self.plan(); self.order(); self.fill()
+                    self.stream.synchronize()
+                    gate()
+                    self.t0 = time.perf_counter()
+                    for _ in range(K):
+                        self.search(); self.plan(); self.order(); self.fill()
+                    self.stream.synchronize()
+                    self.t1 = time.perf_counter()
+                    gate()
+
+        lanes = [Lane(g) for g in range(G)]
+        for r_ in reps:
+            r_.counters_reset()
+        gate_obj, errs = threading.Barrier(G), []
+
+        def lane_thread(ln):
+            try:
+                ln.run(gate_obj.wait)
+            except BaseException as e:   # noqa: BLE001
+                errs.append(e)
+                gate_obj.abort()
+        ths = [threading.Thread(target=lane_thread, args=(ln,)) for ln in lanes]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        if errs:
+            raise errs[0]
+        el_r = max(ln.t1 for ln in lanes) - min(ln.t0 for ln in lanes)
+        if len(set(devs)) == G and G > 1:
+            rc_ = [int(x) for x in _cb.counters_allreduce_local(reps)]
+            how = f"rbg_counters_allreduce_local over the {G} replicas (one grouped RCCL all-reduce)"
+        else:
+            rc_ = [int(x) for x in np.sum([r_.counters().astype(np.int64) for r_ in reps], axis=0)]
+            how = f"summed on the host ({len(set(devs))} device(s) for {G} replicas: RCCL needs one device per rank)"
+        same_all = all(ln.same for ln in lanes[1:])
+        steps_counted = K + max(1, args.warmup)
+        out["replicas_one_process"] = {
+            "formed": G, "devices": devs, "replicate_s": t_rep, "value": G * N * K / el_r, "unit": "reads/s", "ms_per_step": el_r / K * 1e3,
+            "per_replica_ms_per_step": [(ln.t1 - ln.t0) / K * 1e3 for ln in lanes], "locations_per_step": [ln.total for ln in lanes],
+            "every_copy_identical_to_the_primary_on_its_batch": same_all,
+            "counters": {"reads": rc_[0], "matched": rc_[1], "sum_occ": rc_[2], "sum_locs": rc_[3], "reduced_over": how,
+                         "as_streamed": rc_[0] == G * N * steps_counted and rc_[2] == rc_[3] == steps_counted * sum(ln.total for ln in lanes)},
+            "timing": "max over the replicas between two gates (one host thread and one HIP stream per replica)"}
+        if not same_all or not out["replicas_one_process"]["counters"]["as_streamed"]:
+            print(json.dumps(out))
+            raise SystemExit("REPLICA FAILURE: a copy answers differently from the primary, or the reduced counters are not the stream's")
+        # the line describes what ran: G replicas of one process
+        out["single_replica"] = {"value": out["value"], "ms_per_step": out["ms_per_step"]}
+        out.update({"value": G * N * K / el_r, "n_gpus": G, "ms_per_step": el_r / K * 1e3})
+        out["config"]["parallelism"] = (f"index replicated x{G} in ONE process (built once, rbg_replicate_many to devices {devs}), {N} reads per replica per step, "
+                                        "no data-path collective")
+        for r_ in reps[1:]:
+            r_.close()
 
     if rank == 0:
         print(json.dumps(out), flush=True)

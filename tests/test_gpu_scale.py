@@ -374,6 +374,25 @@ def test_pangenome_stream_true_bwt_beyond_32_bits(layout):
     print(f"n = {ix['n']:.3e}, {layout}: {d['value']:.3e} reads/s streamed, {ix['hbm_bytes'] / 1e9:.1f} GB replica")
 
 
+def test_bench_replicas_flag_three_replicas_on_device_0():
+    """`bench.py --replicas 3 --replica-devices 0,0,0`: the count+locate step on three replicas of ONE process (one build,
+    rbg_replicate_many, a host thread + stream + batch per replica).  Every copy reproduces the primary's ranges, toeholds and
+    locations on the primary's batch; the reduced counters are the stream's; the line's n_gpus is the replicas formed."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--replicas", "3", "--replica-devices", "0,0,0", "--L", "1500000", "--H", "8", "--reads", "150000",
+                        "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-space-speed", "--no-markers", "--check-reads", "2000", "--property-reads", "20000"],
+                       capture_output=True, timeout=600, cwd=root)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    d = json.loads(p.stdout.decode().strip().splitlines()[-1])
+    r = d["replicas_one_process"]
+    assert d["n_gpus"] == 3 and r["formed"] == 3 and r["every_copy_identical_to_the_primary_on_its_batch"] and r["counters"]["as_streamed"]
+    assert r["counters"]["reads"] == 3 * 150000 * 3 and d["value"] == r["value"] and d["single_replica"]["value"] > 0
+    assert "ONE process" in d["config"]["parallelism"] and d["parity"]["bit_exact_vs_oracle"]
+
+
 def test_pangenome_stream_one_process_three_replicas_on_device_0():
     """BASELINE.json configs[3]'s several-GPU shape as ONE process (tools/pangenome_stream.py --replicas 3 --replica-devices 0,0,0): the
     index is built once, rbg_replicate_many makes two peer copies, three host threads stream the three rbg_shard_bounds blocks of the

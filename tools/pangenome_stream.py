@@ -267,6 +267,7 @@ def main():
                         setattr(self.tv, name, None if t is None else t.to(dev_l))
                 else:
                     self.tv, self.text = None, text.to(dev_l)
+                torch.cuda.synchronize(dev_l)   # (made on the device's default stream; the lane works on its own)
             self.t_gen = 0.0
             self.t_begin = self.t_end = 0.0
             self.done = 0
