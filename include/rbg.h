@@ -542,8 +542,12 @@ enum { RBG_OPT_BLOCK_THREADS = 1, RBG_OPT_RANK_BUCKET_SHIFT = 2, RBG_OPT_PHI_BUC
                                   more holds twelve pivots into the run list instead: rbg_dev.h RunRec2), direct-addressed: a rank is ONE sector instead of a
                                   directory sector plus an unaligned stretch of the run list (K1/K2 on this layout are bound by that count); about
                                   21-26 bytes per entry on top of the run lists, which stay for crowded buckets and the samples; 1 = directories only;
-                                  0 (default) = records when the replica with them stays within half the HBM budget.  RBG_RUN_REC gives the initial
-                                  value, RBG_RUN_REC_PER the entries per bucket; rbg_layout_info().rec_bytes says what was built. */ };
+                                  0 (default) = decided PER DEPTH, deepest first (where a search spends its steps): a depth gets records -- at 2.5, else 4,
+                                  else 6 entries per bucket -- while the replica with them stays within half the HBM budget.  RBG_RUN_REC gives the initial
+                                  value, RBG_RUN_REC_PER the entries per bucket; rbg_layout_info().rec_bytes says what was built, per depth. */,
+       RBG_OPT_RUN_REC_DEPTHS = 18 /* with RBG_OPT_RUN_REC = 2: bit d - 1 = the k-mer depth d gets bucket records, the other kept depths keep their
+                                  directories (0, the default: every kept depth).  An index of r = 1e9 runs has room for the records of its deepest depth
+                                  but not of all (profiles/r05_pangenome_stream_r1e9.json).  RBG_RUN_REC_DEPTHS gives the initial value. */ };
 int rbg_set_default_option(int opt, int64_t value);
 /* the value a later load would use (so that a caller can change a knob for one load and put it back) */
 int rbg_get_default_option(int opt, int64_t *value);

@@ -21,7 +21,7 @@ MAXU = 2**64 - 1
 DEVICE_NONE = -1
 
 OPT_BLOCK_THREADS, OPT_RANK_BUCKET_SHIFT, OPT_PHI_BUCKET_SHIFT, OPT_POS_BYTES, OPT_KMER_STEPS, OPT_HBM_BUDGET_MB, OPT_FTAB_K, OPT_PACKED_READS, OPT_DEEP_BUCKET_SHIFT, OPT_DENSE_OVERFLOW, OPT_RANK_LAYOUT = range(1, 12)
-OPT_RUN_DEPTHS, OPT_RUN_PHI, OPT_RUN_REC = 14, 16, 17   # (12, 13, 15 were TREE_TOP_KB, SLOT_BYTES, RUN_FMT: retired with ABI 3)
+OPT_RUN_DEPTHS, OPT_RUN_PHI, OPT_RUN_REC, OPT_RUN_REC_DEPTHS = 14, 16, 17, 18   # (12, 13, 15 were TREE_TOP_KB, SLOT_BYTES, RUN_FMT: retired with ABI 3)
 ABI_VERSION = 3          # include/rbg.h RBG_ABI_VERSION this binding is written against
 MAX_KMER_DEPTH = 8       # RBG_OPT_KMER_STEPS / the depth arrays of Info and LayoutInfo
 LAYOUT_AUTO, LAYOUT_SLOTS, LAYOUT_RUNS, LAYOUT_PREFER_SLOTS = 0, 1, 2, 3

@@ -145,6 +145,7 @@ inline uint32_t default_depth_mask(uint32_t K) {
 inline bool layout_automatic() { const int64_t v = g_opt_rank_layout.load(); return v == RBG_LAYOUT_AUTO || v == RBG_LAYOUT_PREFER_SLOTS; }
 std::atomic<int64_t> g_opt_run_depths{env_opt("RBG_RUN_DEPTHS", 0, 0, (1 << kMaxRunDepth) - 1)};    // run-indexed layout: bit d - 1 = keep the k-mer depth d (0 = default_depth_mask: the deepest, half of it, a quarter ..., 1)
 std::atomic<int64_t> g_opt_run_phi{env_opt("RBG_RUN_PHI", 0, 0, 2)};   // run-indexed layout, format 2: 0 = automatic, 1 = phi over the sampled-position list (12-16 bytes per run), 2 = phi SLOTS of about n/r rows (about 54 bytes per run at 8-byte positions; one sector per step instead of two)
+std::atomic<int64_t> g_opt_run_rec_depths{env_opt("RBG_RUN_REC_DEPTHS", 0, 0, (1 << kMaxRunDepth) - 1)};   // with RBG_OPT_RUN_REC = 2: the depths (bit d - 1) that get bucket records; 0 = every kept depth
 std::atomic<int64_t> g_opt_run_rec{env_opt("RBG_RUN_REC", 0, 0, 2)};   // run-indexed layout, format 2: bucket records (rbg_dev.h RunRec2) -- 0 = automatic (when the replica with them stays within half the budget), 1 = off, 2 = on
 std::atomic<int64_t> g_opt_packed_reads{1};  // host-pointer calls: 0 bytes over PCIe, 1 (default) 2-bit codes for batches >= 4096, 2 always
 
@@ -710,26 +711,47 @@ int upload_tables_runs2(rbg_index *ix) {
     // the rest of the replica stay within half the budget.  RBG_RUN_REC_PER: entries per bucket on average (default 2.5 inside the
     // bucket; the one before them is held too).
     const char *e_rp = std::getenv("RBG_RUN_REC_PER");
-    const double rec_target = e_rp && std::atof(e_rp) > 0 ? std::atof(e_rp) : 2.5;
-    bool use_recs = g_opt_run_rec.load() == 2;
-    if (g_opt_run_rec.load() == 0 && ix->hbm_budget) {
-        double nrec = 0;   // records of all kept depths at the bucket widths they would get (a sparse table's shift stops at max_shift: n >> 30 buckets at least)
+    const double rec_asked = e_rp && std::atof(e_rp) > 0 ? std::atof(e_rp) : 0.0;
+    // PER DEPTH, deepest first (a search spends its steps at the deepest depth; the shallower ones take a read's ragged ends): rec_per[d] =
+    // entries per bucket on average of depth d's records, 0 = directories.  RBG_OPT_RUN_REC = 2: the depths of RBG_OPT_RUN_REC_DEPTHS
+    // (0 = all kept) at RBG_RUN_REC_PER (2.5).  Automatic: each depth in turn gets the narrowest buckets -- 2.5, 4 or 6 entries (a compact
+    // record holds eleven) -- with which the replica stays within half the budget and the records stay O(r) (at most one per entry).
+    std::vector<double> rec_per(D, 0.0);
+    auto records_of = [&](uint32_t d, double per) {   // records of depth d at `per` entries per bucket (a sparse table's shift stops at max_shift)
+        double nrec = 0;
+        for (const SymTable &t : *depth[d]) {
+            uint32_t sh = 0;
+            const double runs = static_cast<double>(std::max<uint64_t>(1, t.nruns));
+            while (sh < max_shift && runs * static_cast<double>(uint64_t(2) << sh) <= per * static_cast<double>(h.n)) ++sh;
+            nrec += static_cast<double>((h.n >> sh) + 2);
+        }
+        return nrec;
+    };
+    if (g_opt_run_rec.load() == 2) {
+        const uint32_t want = g_opt_run_rec_depths.load() ? static_cast<uint32_t>(g_opt_run_rec_depths.load()) : ~0u;
         for (uint32_t d = 0; d < D; ++d)
-            if (mask >> d & 1u)
-                for (const SymTable &t : *depth[d]) {
-                    uint32_t sh = 0;
-                    const double runs = static_cast<double>(std::max<uint64_t>(1, t.nruns));
-                    while (sh < max_shift && runs * static_cast<double>(uint64_t(2) << sh) <= rec_target * static_cast<double>(h.n)) ++sh;
-                    nrec += static_cast<double>((h.n >> sh) + 2);
+            if ((mask >> d & 1u) && (want >> d & 1u)) rec_per[d] = rec_asked > 0 ? rec_asked : 2.5;
+    } else if (g_opt_run_rec.load() == 0 && ix->hbm_budget) {
+        double total = static_cast<double>(W ? runs_replica_bytes<uint64_t>(h, mask) : runs_replica_bytes<uint32_t>(h, mask));
+        for (int d = static_cast<int>(D) - 1; d >= 0; --d) {
+            if (!(mask >> d & 1u)) continue;
+            double entries_d = 0;
+            for (const SymTable &t : *depth[d]) entries_d += static_cast<double>(t.nruns + 1);
+            const double pers[3] = {2.5, 4.0, 6.0};
+            for (const double per : pers) {
+                if (rec_asked > 0 && per != pers[0]) break;
+                const double nrec = records_of(static_cast<uint32_t>(d), rec_asked > 0 ? rec_asked : per);
+                if (nrec <= entries_d && total + nrec * 64.0 <= 0.5 * static_cast<double>(ix->hbm_budget)) {
+                    rec_per[d] = rec_asked > 0 ? rec_asked : per;
+                    total += nrec * 64.0;
+                    break;
                 }
-        const double with_recs = static_cast<double>(W ? runs_replica_bytes<uint64_t>(h, mask) : runs_replica_bytes<uint32_t>(h, mask)) + nrec * 64.0;
-        // (and only while the records are O(r): at most one per entry)
-        double entries_kept = 0;
-        for (uint32_t d = 0; d < D; ++d)
-            if (mask >> d & 1u)
-                for (const SymTable &t : *depth[d]) entries_kept += static_cast<double>(t.nruns + 1);
-        use_recs = with_recs <= 0.5 * static_cast<double>(ix->hbm_budget) && nrec <= entries_kept;
+            }
+        }
     }
+    bool any_recs = false, all_recs = true;
+    for (uint32_t d = 0; d < D; ++d)
+        if (mask >> d & 1u) { any_recs = any_recs || rec_per[d] > 0; all_recs = all_recs && rec_per[d] > 0; }
     std::vector<DevRunTab2> tabs;
     std::vector<uint64_t> hot;      // rbg_dev.h: dir_off | dir_shift << 56 per table
     int rc;
@@ -829,6 +851,8 @@ int upload_tables_runs2(rbg_index *ix) {
         void *dirp = nullptr;
         const size_t dir_ent = W ? sizeof(RunDir64) : 4;
         ix->dev.run_rec2[d] = nullptr;
+        const bool use_recs = rec_per[d] > 0;
+        const double rec_target = rec_per[d];
         if (use_recs) {
             // the records' buckets: the widest with at most rec_target entries starting inside on average
             for (size_t t = 0; t < T.size(); ++t) {
@@ -924,7 +948,8 @@ int upload_tables_runs2(rbg_index *ix) {
     ix->dev.run_depth_mask = mask;
     ix->run_depth_mask = mask;
     rep.depth_mask_kept = mask;
-    rep.rank_dirs = use_recs ? 0 : 1;
+    rep.rank_dirs = all_recs ? 0 : 1;   // (1: some kept depth answers its ranks through a directory)
+    (void)any_recs;
     ix->dev.layout = RBG_LAYOUT_RUNS;
     ix->dev.kmer_steps = 1;
     ix->dev.nmajor = 0;
@@ -1120,7 +1145,36 @@ int compose_on_device(rbg_index *ix) {
     h.kmer_deferred = 0;
     if (M < 1 || K0 < 2) return RBG_OK;
     if (ix->kmer_steps_requested == 0) ix->kmer_steps_requested = K0;
-    for (uint32_t K = K0; K >= 2; --K) {
+    // How deep is worth composing is decided BEFORE composing: a depth takes minutes and hundreds of GB of transient HBM at r = 1e9, and one the
+    // budget rule of upload() then drops -- or whose composition fails after the shallower ones were made -- was composed for nothing.  Estimate:
+    // a depth adds at most about 0.62 r runs to the one before it (measured 0.55-0.69 r per depth at r = 1.07e9, n / r = 282; less where n / r
+    // is smaller: 0.33 r on the bench index), pieces are indexed with 32 bits, the sweeps hold about 70 bytes per piece of the depth being made
+    // (profiles/r04_pangenome_stream_r1e9_k5.log), and -- run-indexed layout certain -- the kept depths at 18 bytes per entry plus phi must fit the
+    // budget (the single symbols and the depth itself: what upload()'s budget rule keeps last).  The fallback below still catches an estimate that was too kind.
+    uint32_t K_plan = K0;
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const int64_t opt_mb = g_opt_hbm_budget_mb.load();
+            const double budget = static_cast<double>(opt_mb > 0 ? static_cast<size_t>(opt_mb) << 20 : default_budget(free_b));
+            const bool runs_certain = g_opt_rank_layout.load() == RBG_LAYOUT_RUNS || ix->auto_runs;
+            const double r = static_cast<double>(h.r);
+            auto est = [&](uint32_t d) { return r * (1.0 + 0.62 * static_cast<double>(d - 1)); };
+            const double per_entry = 8.0 + (h.has_tsa ? 6.0 : 0.0) + 4.0;
+            while (K_plan > 1) {
+                bool ok = est(K_plan) < 0.9 * 4294967296.0 && 70.0 * est(K_plan) <= 0.95 * static_cast<double>(free_b);
+                if (ok && runs_certain)   // (the least upload()'s budget rule keeps of a depth K: the single symbols and K itself -- the depths between them go first)
+                    ok = (h.has_tsa ? 16.0 * r : 0.0) + (est(1) + est(K_plan)) * per_entry <= budget;
+                if (ok) break;
+                --K_plan;
+            }
+            if (K_plan < K0)
+                std::fprintf(stderr, "rbg: r = %.3g runs, %.1f GB free, %.1f GB replica budget: composing %u symbol(s) per step, not the %u asked for (estimated: depth %u would "
+                                     "hold about %.3g runs; RBG_OPT_HBM_BUDGET_MB / RBG_OPT_RUN_DEPTHS change what fits)\n", r, free_b / 1e9, budget / 1e9, K_plan, K0, K0, est(K0));
+        }
+    }
+    if (K_plan < 2) return RBG_OK;   // single-symbol steps: nothing to compose
+    for (uint32_t K = K_plan; K >= 2; --K) {
         // (a pass that failed partway -- the host fallback included -- must leave nothing of a deeper level behind: levels() and
         //  level_has_data() count what they find)
         for (uint32_t d = 2; d <= static_cast<uint32_t>(kMaxKmerDepth); ++d) { release_kmer_level(ix, d); std::vector<SymTable>().swap(kmer_level_tables(h, d)); }
@@ -2063,6 +2117,9 @@ int rbg_set_default_option(int opt, int64_t value) {
         case RBG_OPT_RUN_REC:
             if (value < 0 || value > 2) return RBG_EARG;
             g_opt_run_rec = value; return RBG_OK;
+        case RBG_OPT_RUN_REC_DEPTHS:
+            if (value < 0 || value >= (1 << kMaxRunDepth)) return RBG_EARG;
+            g_opt_run_rec_depths = value; return RBG_OK;
         default: return RBG_EARG;
     }
     });
@@ -2086,6 +2143,7 @@ int rbg_get_default_option(int opt, int64_t *value) {
         case RBG_OPT_RUN_DEPTHS: *value = g_opt_run_depths.load(); return RBG_OK;
         case RBG_OPT_RUN_PHI: *value = g_opt_run_phi.load(); return RBG_OK;
         case RBG_OPT_RUN_REC: *value = g_opt_run_rec.load(); return RBG_OK;
+        case RBG_OPT_RUN_REC_DEPTHS: *value = g_opt_run_rec_depths.load(); return RBG_OK;
         default: return RBG_EARG;
     }
     });

@@ -156,18 +156,18 @@ def test_tuning_options_are_range_checked():
           capi.OPT_POS_BYTES: [4, 8, 0], capi.OPT_KMER_STEPS: [1, 3, 5, 8], capi.OPT_HBM_BUDGET_MB: [1, 0], capi.OPT_FTAB_K: [0, 16, -1],
           capi.OPT_PACKED_READS: [0, 2, 1], capi.OPT_DEEP_BUCKET_SHIFT: [9, 12, -1], capi.OPT_DENSE_OVERFLOW: [0, 1],
           capi.OPT_RANK_LAYOUT: [1, 2, 3, 0], capi.OPT_RUN_DEPTHS: [0x15, 31, 255, 0],
-          capi.OPT_RUN_PHI: [1, 2, 0], capi.OPT_RUN_REC: [1, 2, 0]}
+          capi.OPT_RUN_PHI: [1, 2, 0], capi.OPT_RUN_REC: [1, 2, 0], capi.OPT_RUN_REC_DEPTHS: [0x80, 0x11, 0]}
     bad = {capi.OPT_BLOCK_THREADS: [0, 100, 512], capi.OPT_RANK_BUCKET_SHIFT: [-2, 13], capi.OPT_PHI_BUCKET_SHIFT: [-2, 9],
            capi.OPT_POS_BYTES: [2, 16], capi.OPT_KMER_STEPS: [0, 9], capi.OPT_HBM_BUDGET_MB: [-1], capi.OPT_FTAB_K: [-2, 17],
            capi.OPT_PACKED_READS: [-1, 3], capi.OPT_DEEP_BUCKET_SHIFT: [-2, 13], capi.OPT_DENSE_OVERFLOW: [-1, 2],
            capi.OPT_RANK_LAYOUT: [-1, 4], capi.OPT_RUN_DEPTHS: [-1, 256],
-           capi.OPT_RUN_PHI: [-1, 3], capi.OPT_RUN_REC: [-1, 3]}
+           capi.OPT_RUN_PHI: [-1, 3], capi.OPT_RUN_REC: [-1, 3], capi.OPT_RUN_REC_DEPTHS: [-1, 256]}
     for opt, vals in ok.items():
         for v in bad[opt]:
             assert L.rbg_set_default_option(opt, v) == -4, (opt, v)   # RBG_EARG
         for v in vals:                                                 # the last value of each list is the default
             assert L.rbg_set_default_option(opt, v) == 0, (opt, v)
-    assert L.rbg_set_default_option(0, 1) == -4 and L.rbg_set_default_option(18, 1) == -4
+    assert L.rbg_set_default_option(0, 1) == -4 and L.rbg_set_default_option(19, 1) == -4
     for retired in (12, 13, 15):   # RBG_OPT_TREE_TOP_KB, _SLOT_BYTES, _RUN_FMT: gone with ABI 3, together with the kernels they selected
         assert L.rbg_set_default_option(retired, 2) == -4 and L.rbg_get_default_option(retired, C.byref(C.c_int64())) == -4
     assert all(capi.get_default_option(o) == vals[-1] for o, vals in ok.items())

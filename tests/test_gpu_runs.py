@@ -37,7 +37,9 @@ def default_depth_mask(K):
                           # depths 6-8: the tables' records come from the global array (rbg_dev.h kLdsRunDepth), not from LDS
                           (0, -1, 8, "rec", False), (8, -1, 8, "rec", False), (0, -1, 8, "dir", False), (8, 0, 8, "dir", True), (0, 0, 8, "rec", True),
                           (0, -1, 6, "rec", False), (8, 3, 6, "dir", True), (0, -1, 7, "dir", False), (8, -1, 7, "rec+phislots", True), (0, 3, 8, "rec+phislots", False),
-                          (8, -1, 8, "phislots", False)])
+                          (8, -1, 8, "phislots", False),
+                          # records for the deepest depth only (RBG_OPT_RUN_REC_DEPTHS: what an r = 1e9 index has room for), directories below it
+                          (0, -1, 5, "rec@deepest", False), (8, -1, 8, "rec@deepest", False), (8, 0, 4, "rec@deepest+phislots", True), (0, 3, 7, "rec@deepest", False)])
 def test_run_indexed_layout(synth, pos_bytes, fk, ks, mode, all_depths):
     """RBG_LAYOUT_RUNS (k_runs.hip): space proportional to r, rank and phi as predecessor searches over the run lists
     (rle_string.hpp:131-161, toehold_sa.hpp:56-72) by the lane that owns the query, k-mer steps of up to ks symbols through the
@@ -46,9 +48,10 @@ def test_run_indexed_layout(synth, pos_bytes, fk, ks, mode, all_depths):
     (RBG_OPT_RUN_PHI = 2: the slot layout's direct-addressed phi records at buckets of about n / r rows); "rec" = BUCKET RECORDS
     instead of the rank directories (RBG_OPT_RUN_REC = 2: one aligned 64-byte record per bucket, fetched by quads of lanes)."""
     S = synth
-    phi_slots, recs = "phislots" in mode, "rec" in mode
+    phi_slots, recs, deepest_only = "phislots" in mode, "rec" in mode, "rec@deepest" in mode
     ra.set_default_option(capi.OPT_RUN_PHI, 2 if phi_slots else 1)
     ra.set_default_option(capi.OPT_RUN_REC, 2 if recs else 1)
+    ra.set_default_option(capi.OPT_RUN_REC_DEPTHS, 1 << (ks - 1) if deepest_only else 0)
     ra.set_default_option(capi.OPT_POS_BYTES, pos_bytes)
     ra.set_default_option(capi.OPT_FTAB_K, fk)
     ra.set_default_option(capi.OPT_KMER_STEPS, ks)
@@ -64,6 +67,7 @@ def test_run_indexed_layout(synth, pos_bytes, fk, ks, mode, all_depths):
     finally:
         ra.set_default_option(capi.OPT_RUN_PHI, 0)
         ra.set_default_option(capi.OPT_RUN_REC, 0)
+        ra.set_default_option(capi.OPT_RUN_REC_DEPTHS, 0)
         ra.set_default_option(capi.OPT_RUN_DEPTHS, 0)
         ra.set_default_option(capi.OPT_POS_BYTES, 0)
         ra.set_default_option(capi.OPT_FTAB_K, -1)
@@ -78,8 +82,10 @@ def test_run_indexed_layout(synth, pos_bytes, fk, ks, mode, all_depths):
     assert info.depth_runs[0] == info.r and list(info.depth_runs[1:5]) == [info.pair_runs, info.triple_runs, info.quad_runs, info.quint_runs]
     li = rb.layout_info()
     assert li.run_fmt == 2 and li.depths_dropped_budget == 0 and li.depth_mask_kept == want_mask and li.depths_composed == ks
-    assert li.rank_directories == (0 if recs else 1) and li.phi_entries == len(S.heads) and sum(li.fillers) == 0
-    assert all((li.rec_bytes[d] > 0) == (recs and bool(li.depth_mask_kept >> d & 1)) for d in range(D)) and (not rec_per or sum(li.rec_overflow) > 0)
+    with_dirs = not recs or (deepest_only and want_mask != 1 << (ks - 1))   # some kept depth answers its ranks through a directory
+    assert li.rank_directories == (1 if with_dirs else 0) and li.phi_entries == len(S.heads) and sum(li.fillers) == 0
+    rec_mask = 0 if not recs else (1 << (ks - 1)) if deepest_only else li.depth_mask_kept
+    assert all((li.rec_bytes[d] > 0) == bool(rec_mask >> d & 1) for d in range(D)) and (not rec_per or deepest_only or sum(li.rec_overflow) > 0)
     assert (li.phi_slots > 0 and li.phi_directory == 0 and rb.info().phi_slots == li.phi_slots) if phi_slots else (li.phi_slots == 0 and li.phi_directory == 1)
     assert all((li.entries[d] > 0) == bool(li.depth_mask_kept >> d & 1) for d in range(D))
     _run_indexed_checks(S, rb)

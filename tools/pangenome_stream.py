@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--kmer-steps", type=int, default=0, choices=range(0, 9), help="RBG_OPT_KMER_STEPS (0 = the library's default, 8)")
     ap.add_argument("--run-phi", type=int, default=0, choices=(0, 1, 2), help="RBG_OPT_RUN_PHI: 1 = phi over the list of sampled positions, 2 = phi slots, 0 = the library's choice")
     ap.add_argument("--run-rec", type=int, default=0, choices=(0, 1, 2), help="RBG_OPT_RUN_REC: 1 = directories over the run lists, 2 = bucket records, 0 = the library's choice")
+    ap.add_argument("--run-rec-depths", type=lambda v: int(v, 0), default=0, help="RBG_OPT_RUN_REC_DEPTHS: with --run-rec 2, the depths (bit d - 1) that get bucket records (0 = all kept)")
     ap.add_argument("--replica-probe", action="store_true",
                     help="after the per-kernel times: copy the device index once more onto the same device (rbg_replicate: fresh allocations, no composition "
                          "going on around them) and time the search kernel on the copy -- does the PLACEMENT of the arrays matter?")
@@ -200,6 +201,8 @@ def main():
         capi.set_default_option(capi.OPT_RUN_PHI, args.run_phi)
     if args.run_rec:
         capi.set_default_option(capi.OPT_RUN_REC, args.run_rec)
+    if args.run_rec_depths:
+        capi.set_default_option(capi.OPT_RUN_REC_DEPTHS, args.run_rec_depths)
     if args.kmer_steps:
         capi.set_default_option(capi.OPT_KMER_STEPS, args.kmer_steps)
     if args.hbm_reserve_gb > 0:
