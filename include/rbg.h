@@ -184,6 +184,8 @@ typedef struct rbg_layout_info_t {
                                          * bytes of slots + ordinals; 0 = phi goes through the list of sampled positions and its directory */
     uint64_t rec_bytes[8];            /* per depth: bytes of its tables' bucket records (RBG_OPT_RUN_REC; 0 = directories) */
     uint64_t rec_overflow[8];         /* per depth: buckets with more entries than a record holds (their ranks go through the run list) */
+    uint64_t budget_raised;           /* 1: RBG_LAYOUT_AUTO, no budget given, took three quarters of the free HBM instead of a quarter -- an index of so many runs
+                                       * that the quarter would have left it one or two symbols per step (rbg_info().hbm_budget is the budget applied) */
 } rbg_layout_info_t;
 int rbg_layout_info(const rbg_index *, rbg_layout_info_t *out, uint64_t out_bytes);
 
@@ -535,7 +537,7 @@ enum { RBG_OPT_BLOCK_THREADS = 1, RBG_OPT_RANK_BUCKET_SHIFT = 2, RBG_OPT_PHI_BUC
                                   through its directory (12-16 bytes per run: two dependent sectors per step); 2 = from direct-addressed phi SLOTS
                                   (the slot layout's PhiSlot records) whose buckets are about n / r rows wide, so that their number is proportional
                                   to r (about 54 bytes per run at 8-byte positions: one sector per step -- at pangenome scale K3 is bound by that
-                                  count); 0 (default) = slots when the whole replica then stays within half the HBM budget.  RBG_RUN_PHI gives the
+                                  count); 0 (default) = slots when the whole replica then stays within the HBM budget.  RBG_RUN_PHI gives the
                                   initial value; rbg_layout_info().phi_slots says what was built. */,
        RBG_OPT_RUN_REC = 17 /* run-indexed layout -- BUCKET RECORDS: 2 = every bucket of a table (about three entries wide) gets one aligned
                                   64-byte record holding its entries and the one before them (up to eleven in the compact form, six otherwise; a bucket with
@@ -543,7 +545,7 @@ enum { RBG_OPT_BLOCK_THREADS = 1, RBG_OPT_RANK_BUCKET_SHIFT = 2, RBG_OPT_PHI_BUC
                                   directory sector plus an unaligned stretch of the run list (K1/K2 on this layout are bound by that count); about
                                   21-26 bytes per entry on top of the run lists, which stay for crowded buckets and the samples; 1 = directories only;
                                   0 (default) = decided PER DEPTH, deepest first (where a search spends its steps): a depth gets records -- at 2.5, else 4,
-                                  else 6 entries per bucket -- while the replica with them stays within half the HBM budget.  RBG_RUN_REC gives the initial
+                                  else 6 entries per bucket -- while the replica with them (and with the phi slots, which come first) stays within the HBM budget.  RBG_RUN_REC gives the initial
                                   value, RBG_RUN_REC_PER the entries per bucket; rbg_layout_info().rec_bytes says what was built, per depth. */,
        RBG_OPT_RUN_REC_DEPTHS = 18 /* with RBG_OPT_RUN_REC = 2: bit d - 1 = the k-mer depth d gets bucket records, the other kept depths keep their
                                   directories (0, the default: every kept depth).  An index of r = 1e9 runs has room for the records of its deepest depth

@@ -61,7 +61,7 @@ class LayoutInfo(C.Structure):
                 ("depths_dropped_budget", C.c_uint32), ("rank_directories", C.c_uint32),
                 ("phi_directory", C.c_uint32), ("fill_shift", C.c_uint32),
                 ("entries", U64 * 8), ("fillers", U64 * 8), ("dir_bytes", U64 * 8),
-                ("phi_entries", U64), ("phi_fillers", U64), ("phi_dir_bytes", U64), ("phi_dir_shift", U64), ("phi_slots", U64), ("phi_slot_bytes", U64), ("rec_bytes", U64 * 8), ("rec_overflow", U64 * 8)]
+                ("phi_entries", U64), ("phi_fillers", U64), ("phi_dir_bytes", U64), ("phi_dir_shift", U64), ("phi_slots", U64), ("phi_slot_bytes", U64), ("rec_bytes", U64 * 8), ("rec_overflow", U64 * 8), ("budget_raised", U64)]
 
 
 # every symbol include/rbg.h declares: (name, restype, argtypes)

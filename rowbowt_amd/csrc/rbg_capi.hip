@@ -60,6 +60,8 @@ struct rbg_index {
     uint64_t rank_slots = 0, rank_slots_overflow = 0, phi_slots = 0, phi_slots_overflow = 0;
     uint64_t kmer_steps_requested = 0, hbm_free_at_load = 0, hbm_budget = 0;  // how the space/speed point was chosen (rbg_info)
     bool runs_layout = false;
+    uint64_t plan_free = 0, plan_budget = 0;   // free HBM and replica budget as options_for() saw them BEFORE anything of this load was on the device (0: not taken)
+    bool budget_raised = false;                // RBG_LAYOUT_AUTO raised the default budget from a quarter to three quarters of the free HBM (an index too large for the quarter)
     bool auto_runs = false;        // RBG_LAYOUT_AUTO chose the run-indexed layout because the slot tables of every requested symbol per step exceed the budget
     bool runs_forced = false;      // the composition already gave back the depths the run-indexed layout leaves out: no way back to slot tables
     uint32_t run_depth_mask = 0;   // run-indexed layout: the k-mer depths that have run lists (bit d - 1)
@@ -154,6 +156,22 @@ std::atomic<int64_t> g_opt_packed_reads{1};  // host-pointer calls: 0 bytes over
 // speed and left its caller 80 GB of a 288 GB device.  A drop-in library should leave the device to its caller unless told
 // otherwise: with a quarter the same load keeps the 4-symbol level (58 GB), and the budget option is one call away.
 inline size_t default_budget(size_t free_b) { return free_b / 4; }
+// How many symbols per step of the run-indexed layout are worth composing, estimated BEFORE composing: a depth adds at most about 0.62 r runs to
+// the one before it (measured 0.55-0.69 r per depth at r = 1.07e9, n / r = 282; 0.33 r on the bench index), pieces are indexed with 32 bits, the
+// sweeps hold about 70 bytes per piece of the depth being made (profiles/r04_pangenome_stream_r1e9_k5.log), and -- with_budget -- the least the budget
+// rule of upload() keeps of a depth K (the single symbols, K itself, phi) must fit the budget at 18 bytes per entry.
+inline double est_depth_runs(double r, uint32_t d) { return r * (1.0 + 0.62 * static_cast<double>(d - 1)); }
+inline uint32_t planned_depth(double r, bool samples, uint32_t K0, double free_b, double budget, bool with_budget) {
+    const double per_entry = 8.0 + (samples ? 6.0 : 0.0) + 4.0;
+    uint32_t K = K0;
+    while (K > 1) {
+        bool ok = est_depth_runs(r, K) < 0.9 * 4294967296.0 && 70.0 * est_depth_runs(r, K) <= 0.95 * free_b;
+        if (ok && with_budget) ok = (samples ? 16.0 * r : 0.0) + (est_depth_runs(r, 1) + est_depth_runs(r, K)) * per_entry <= budget;
+        if (ok) break;
+        --K;
+    }
+    return K;
+}
 
 #define HIP_TRY(expr)                                                                             \
     do {                                                                                          \
@@ -715,7 +733,7 @@ int upload_tables_runs2(rbg_index *ix) {
     // PER DEPTH, deepest first (a search spends its steps at the deepest depth; the shallower ones take a read's ragged ends): rec_per[d] =
     // entries per bucket on average of depth d's records, 0 = directories.  RBG_OPT_RUN_REC = 2: the depths of RBG_OPT_RUN_REC_DEPTHS
     // (0 = all kept) at RBG_RUN_REC_PER (2.5).  Automatic: each depth in turn gets the narrowest buckets -- 2.5, 4 or 6 entries (a compact
-    // record holds eleven) -- with which the replica stays within half the budget and the records stay O(r) (at most one per entry).
+    // record holds eleven) -- with which the replica (phi slots included) stays within the budget and the records stay O(r) (at most one per entry).
     std::vector<double> rec_per(D, 0.0);
     auto records_of = [&](uint32_t d, double per) {   // records of depth d at `per` entries per bucket (a sparse table's shift stops at max_shift)
         double nrec = 0;
@@ -733,6 +751,13 @@ int upload_tables_runs2(rbg_index *ix) {
             if ((mask >> d & 1u) && (want >> d & 1u)) rec_per[d] = rec_asked > 0 ? rec_asked : 2.5;
     } else if (g_opt_run_rec.load() == 0 && ix->hbm_budget) {
         double total = static_cast<double>(W ? runs_replica_bytes<uint64_t>(h, mask) : runs_replica_bytes<uint32_t>(h, mask));
+        if (h.has_tsa && g_opt_run_phi.load() != 1) {   // phi slots come first (decided after the rank tables, below: the same arithmetic): their room is not the records'
+            uint32_t ss = 0;
+            while (ss < 8 && static_cast<double>(uint64_t(2) << ss) <= static_cast<double>(h.n) / static_cast<double>(std::max<uint64_t>(1, h.r))) ++ss;
+            if (ss < h.phi_shift) ss = h.phi_shift;
+            const double nb = static_cast<double>((h.n >> ss) + 2);
+            if (nb <= 2.0 * static_cast<double>(h.r)) total += nb * (W ? 36.0 : 20.0);
+        }
         for (int d = static_cast<int>(D) - 1; d >= 0; --d) {
             if (!(mask >> d & 1u)) continue;
             double entries_d = 0;
@@ -741,7 +766,7 @@ int upload_tables_runs2(rbg_index *ix) {
             for (const double per : pers) {
                 if (rec_asked > 0 && per != pers[0]) break;
                 const double nrec = records_of(static_cast<uint32_t>(d), rec_asked > 0 ? rec_asked : per);
-                if (nrec <= entries_d && total + nrec * 64.0 <= 0.5 * static_cast<double>(ix->hbm_budget)) {
+                if (nrec <= entries_d && total + nrec * 64.0 <= static_cast<double>(ix->hbm_budget)) {
                     rec_per[d] = rec_asked > 0 ? rec_asked : per;
                     total += nrec * 64.0;
                     break;
@@ -963,7 +988,8 @@ int upload_tables_runs2(rbg_index *ix) {
     ix->dev.phi_dir = nullptr;
     ix->dev.phi_super = nullptr;
     ix->dev.phi_super_shift = 0;
-    // PHI SLOTS on this layout (RBG_OPT_RUN_PHI = 2; automatic when the whole replica then stays within half the budget): the slot
+    // PHI SLOTS on this layout (RBG_OPT_RUN_PHI = 2; automatic when the whole replica then stays within the budget -- the bucket records of the
+    // rank tables, decided before, have left room for them: K3 is the larger kernel at pangenome scale): the slot
     // layout's direct-addressed phi records (rbg_dev.h PhiSlot) with buckets of about n / r rows instead of 32-64 -- so their
     // number is proportional to r, not n -- answer a phi step from ONE sector where the list takes two (directory, entries); at
     // pangenome scale K3 is bound by exactly that sector count.  Cost: about 54 bytes per run at 8-byte positions against 16.
@@ -978,8 +1004,8 @@ int upload_tables_runs2(rbg_index *ix) {
         const size_t need = ((h.n >> slot_shift) + 2) * (slot_b + 4) + (h.r + 1) * sizeof(PhiEnt<P>);
         const int64_t mode = g_opt_run_phi.load();
         // automatic: only while the slots are O(r) -- at most two buckets per sampled position (the bucket shift stops at 8: an index with
-        // n / r far beyond 256 would get n / 256 of them) -- and the whole replica stays within half the budget
-        phi_by_slots = mode == 2 || (mode == 0 && ix->hbm_budget && ((h.n >> slot_shift) + 2) <= 2 * h.r && ix->hbm_bytes + need <= ix->hbm_budget / 2);
+        // n / r far beyond 256 would get n / 256 of them) -- and the whole replica stays within the budget
+        phi_by_slots = mode == 2 || (mode == 0 && ix->hbm_budget && ((h.n >> slot_shift) + 2) <= 2 * h.r && ix->hbm_bytes + need <= ix->hbm_budget);
         if (phi_by_slots) {
             VStage vs("phi slots of the run-indexed layout");
             HostBuf<PhiEnt<P>> pe(h.r + 1);
@@ -1145,32 +1171,21 @@ int compose_on_device(rbg_index *ix) {
     h.kmer_deferred = 0;
     if (M < 1 || K0 < 2) return RBG_OK;
     if (ix->kmer_steps_requested == 0) ix->kmer_steps_requested = K0;
-    // How deep is worth composing is decided BEFORE composing: a depth takes minutes and hundreds of GB of transient HBM at r = 1e9, and one the
-    // budget rule of upload() then drops -- or whose composition fails after the shallower ones were made -- was composed for nothing.  Estimate:
-    // a depth adds at most about 0.62 r runs to the one before it (measured 0.55-0.69 r per depth at r = 1.07e9, n / r = 282; less where n / r
-    // is smaller: 0.33 r on the bench index), pieces are indexed with 32 bits, the sweeps hold about 70 bytes per piece of the depth being made
-    // (profiles/r04_pangenome_stream_r1e9_k5.log), and -- run-indexed layout certain -- the kept depths at 18 bytes per entry plus phi must fit the
-    // budget (the single symbols and the depth itself: what upload()'s budget rule keeps last).  The fallback below still catches an estimate that was too kind.
+    // How deep is worth composing is decided BEFORE composing (planned_depth): a depth takes minutes and hundreds of GB of transient HBM at r = 1e9,
+    // and one the budget rule of upload() then drops -- or whose composition fails after the shallower ones were made -- was composed for nothing.
+    // The fallback below still catches an estimate that was too kind.
     uint32_t K_plan = K0;
     {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             const int64_t opt_mb = g_opt_hbm_budget_mb.load();
-            const double budget = static_cast<double>(opt_mb > 0 ? static_cast<size_t>(opt_mb) << 20 : default_budget(free_b));
+            const double budget = ix->plan_budget ? static_cast<double>(ix->plan_budget) : static_cast<double>(opt_mb > 0 ? static_cast<size_t>(opt_mb) << 20 : default_budget(free_b));
             const bool runs_certain = g_opt_rank_layout.load() == RBG_LAYOUT_RUNS || ix->auto_runs;
-            const double r = static_cast<double>(h.r);
-            auto est = [&](uint32_t d) { return r * (1.0 + 0.62 * static_cast<double>(d - 1)); };
-            const double per_entry = 8.0 + (h.has_tsa ? 6.0 : 0.0) + 4.0;
-            while (K_plan > 1) {
-                bool ok = est(K_plan) < 0.9 * 4294967296.0 && 70.0 * est(K_plan) <= 0.95 * static_cast<double>(free_b);
-                if (ok && runs_certain)   // (the least upload()'s budget rule keeps of a depth K: the single symbols and K itself -- the depths between them go first)
-                    ok = (h.has_tsa ? 16.0 * r : 0.0) + (est(1) + est(K_plan)) * per_entry <= budget;
-                if (ok) break;
-                --K_plan;
-            }
+            K_plan = planned_depth(static_cast<double>(h.r), h.has_tsa, K0, static_cast<double>(free_b), budget, runs_certain);
             if (K_plan < K0)
                 std::fprintf(stderr, "rbg: r = %.3g runs, %.1f GB free, %.1f GB replica budget: composing %u symbol(s) per step, not the %u asked for (estimated: depth %u would "
-                                     "hold about %.3g runs; RBG_OPT_HBM_BUDGET_MB / RBG_OPT_RUN_DEPTHS change what fits)\n", r, free_b / 1e9, budget / 1e9, K_plan, K0, K0, est(K0));
+                                     "hold about %.3g runs; RBG_OPT_HBM_BUDGET_MB / RBG_OPT_RUN_DEPTHS change what fits)\n", static_cast<double>(h.r), free_b / 1e9, budget / 1e9,
+                             K_plan, K0, K0, est_depth_runs(static_cast<double>(h.r), K0));
         }
     }
     if (K_plan < 2) return RBG_OK;   // single-symbol steps: nothing to compose
@@ -1387,7 +1402,9 @@ int upload(rbg_index *ix) {
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     const int64_t opt_mb = g_opt_hbm_budget_mb.load();
-    const size_t budget = opt_mb > 0 ? static_cast<size_t>(opt_mb) << 20 : default_budget(free_b);
+    // (the budget options_for() fixed before the composition put its levels on the device, where it was taken: VERDICT r4 item 8)
+    const size_t budget = ix->plan_budget ? static_cast<size_t>(ix->plan_budget) : opt_mb > 0 ? static_cast<size_t>(opt_mb) << 20 : default_budget(free_b);
+    if (ix->plan_free) free_b = static_cast<size_t>(ix->plan_free);
     auto need = [&] { return h.pos_bytes == 4 ? replica_bytes<uint32_t>(h) : replica_bytes<uint64_t>(h); };
     // Layout: the slot tables cost n/16 bytes per table + n/2 (n at 8-byte positions) for phi, whatever r is.  When
     // even the single-symbol level does not fit the budget -- or on request -- the run-indexed layout takes over
@@ -1618,7 +1635,7 @@ bool compose_deferred(int device) {
     return device != RBG_DEVICE_NONE && !(e && e[0] == '1');
 }
 
-FlattenOptions options_for(int device, const RawRle &rle, uint64_t *requested, bool *auto_runs) {
+FlattenOptions options_for(int device, const RawRle &rle, uint64_t *requested, bool *auto_runs, rbg_index *ix) {
     FlattenOptions o = current_options();
     *requested = 0;
     *auto_runs = false;
@@ -1630,7 +1647,11 @@ FlattenOptions options_for(int device, const RawRle &rle, uint64_t *requested, b
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return o;
     const int64_t opt_mb = g_opt_hbm_budget_mb.load();
-    const double budget = static_cast<double>(opt_mb > 0 ? static_cast<size_t>(opt_mb) << 20 : default_budget(free_b));
+    double budget = static_cast<double>(opt_mb > 0 ? static_cast<size_t>(opt_mb) << 20 : default_budget(free_b));
+    // (the budget of this load is fixed HERE, while nothing of it is on the device: upload() measures again after the composition has
+    //  taken its share, and a quarter of what is left then is not a quarter of the device)
+    ix->plan_free = free_b;
+    ix->plan_budget = static_cast<uint64_t>(budget);
     bool seen[256] = {};
     unsigned sigma = 0;
     for (uint8_t c : rle.heads)
@@ -1644,7 +1665,31 @@ FlattenOptions options_for(int device, const RawRle &rle, uint64_t *requested, b
         const double pos = (o.force_pos_bytes == 8 || rle.n >= 0xFFFFFFF0ull) ? 8 : 4;
         const double lvl1 = static_cast<double>(sigma) * static_cast<double>((rle.n >> kMaxNarrowShift) + 2) * (sizeof(RankSlot) + sizeof(uint32_t)) +
                             static_cast<double>((rle.n >> 6) + 2) * (4 * pos + 4);
-        if (lvl1 > budget) return o;
+        if (lvl1 > budget) {
+            // not even the single-symbol slot tables fit: the run-indexed layout, certainly (where the alphabet allows it)
+            if (sigma <= static_cast<unsigned>(kLdsSyms)) {
+                *auto_runs = true;
+                // An index that large may also be too large for the DEFAULT budget to step by more than a symbol or two (r = 1e9: 36 GB of run lists
+                // and phi before any k-mer depth; profiles/r05_pangenome_stream_r1e9_default.json: 5e7 reads/s from the quarter, 1.4e8 from the fast
+                // form).  RBG_LAYOUT_AUTO with no budget given then takes up to three quarters of the free HBM -- said on stderr, reported by
+                // rbg_info (hbm_budget) and rbg_layout_info (budget_raised); RBG_OPT_HBM_BUDGET_MB decides otherwise.
+                const double r = static_cast<double>(rle.heads.size());
+                const uint32_t want = static_cast<uint32_t>(std::min(o.kmer_steps, 4));
+                if (opt_mb == 0 && g_opt_rank_layout.load() == RBG_LAYOUT_AUTO &&
+                    planned_depth(r, true, static_cast<uint32_t>(o.kmer_steps), static_cast<double>(free_b), budget, true) < want) {
+                    const double raised = 0.75 * static_cast<double>(free_b);
+                    if (planned_depth(r, true, static_cast<uint32_t>(o.kmer_steps), static_cast<double>(free_b), raised, true) >
+                        planned_depth(r, true, static_cast<uint32_t>(o.kmer_steps), static_cast<double>(free_b), budget, true)) {
+                        std::fprintf(stderr, "rbg: device %d: r = %.3g runs: a quarter of the free HBM (%.1f GB) would leave fewer than %u symbols per step; RBG_LAYOUT_AUTO takes up to "
+                                             "three quarters (%.1f GB) for this index (RBG_OPT_HBM_BUDGET_MB sets the budget explicitly)\n", device, r, budget / 1e9, want, raised / 1e9);
+                        budget = raised;
+                        ix->plan_budget = static_cast<uint64_t>(budget);
+                        ix->budget_raised = true;
+                    }
+                }
+            }
+            return o;
+        }
     }
     // the slot layout stages the tables of at most kMaxSlotKmerDepth symbols per gather: more are asked of the run-indexed layout only
     const int slot_steps = std::min(o.kmer_steps, kMaxSlotKmerDepth);
@@ -2011,7 +2056,7 @@ int ftab_stream(rbg_index *ix, uint64_t k, Sink sink) {
 int index_from_bundle(FlatBundle &b, int device, rbg_index **out) {
     rbg_index *ix = new (std::nothrow) rbg_index();
     if (!ix) return RBG_ENOMEM;
-    FlattenOptions fo = options_for(device, b.rle, &ix->kmer_steps_requested, &ix->auto_runs);
+    FlattenOptions fo = options_for(device, b.rle, &ix->kmer_steps_requested, &ix->auto_runs, ix);
     fo.defer_kmer = compose_deferred(device);
     int rc = flatten(b.rle, b.has_tsa ? &b.tsa : nullptr, fo, ix->host);
     if (rc) { delete ix; return rc; }
@@ -2533,6 +2578,7 @@ int rbg_layout_info(const rbg_index *ix, rbg_layout_info_t *out, uint64_t out_by
         v.phi_entries = r.phi_entries; v.phi_fillers = r.phi_fillers; v.phi_dir_bytes = r.phi_dir_bytes; v.phi_dir_shift = r.phi_dir_shift;
         v.phi_slots = r.phi_slots; v.phi_slot_bytes = r.phi_slot_bytes;
         for (int d = 0; d < kMaxRunDepth; ++d) { v.rec_bytes[d] = r.rec_bytes[d]; v.rec_overflow[d] = r.rec_overflow[d]; }
+        v.budget_raised = ix->budget_raised ? 1 : 0;
     }
     std::memcpy(out, &v, static_cast<size_t>(std::min<uint64_t>(out_bytes, sizeof(v))));
     return RBG_OK;
