@@ -1,0 +1,112 @@
+"""The sdsl-format reader (rbg_load -> rbg_host.cpp parse_rbwt / parse_tsa) at realistic sizes, without the reference's toolchain
+(VERDICT r4 item 5): tests/sdsl_writer.py serialises a run-length BWT and its samples in the reference's on-disk layout
+(rle_string.hpp:248-275, toehold_sa.hpp:74-91, sparse_sd_vector.hpp:182-200, huff_string.hpp:54-63 over sdsl-lite's sd_vector,
+select_support_mcl, wt_huff, rank_support_v, int_vector<0>).  The writer is pinned by the fixtures the reference ships: re-serialising
+the decoded toy index reproduces them byte for byte.  Then an index of r = 2.1e6 runs and n = 4.4e9 > 2^32 (sample widths 33 and 22,
+sd_vectors of 500 superblocks) goes through rbg_load and must equal rbg_build_from_runs of the same arrays -- on the host arrays here,
+on 10^4 reads through HIP under -m gpu."""
+import os
+
+import numpy as np
+import pytest
+
+import rowbowt_amd as ra
+from rowbowt_amd import capi
+import sdsl_writer as W
+from gpu_common import _random_run_index
+
+ARRAYS = (0, 1, 2, 3, 4)   # include/rbg.h RBG_ARR_RUN_HEADS, RUN_START, SAMPLES_LAST, PRED_POS, PHI_BASE
+
+
+def test_writer_reproduces_the_shipped_fixtures_byte_for_byte(data_dir):
+    rbwt = open(os.path.join(data_dir, "small.fa.rbwt"), "rb").read()
+    tsa = open(os.path.join(data_dir, "small.fa.tsa"), "rb").read()
+    n, R, B, heads, lens = W.decode_rbwt(rbwt)
+    assert (n, R, B) == (30031, 7573, 2) and int(lens.sum()) == n
+    assert W.rbwt_bytes(heads, lens, B) == rbwt
+    r, n2, pred, last, p2r = W.decode_tsa(tsa)
+    assert (r, n2) == (R, n)
+    assert W.tsa_bytes(n2, pred, last, p2r) == tsa
+    # the decoder of this file and the library's reader agree on the fixture (so "decoded, re-serialised, identical" is about the same arrays)
+    rb = ra.load_rowbowt(os.path.join(data_dir, "small.fa"), ra.LoadRbwtFlag.SA, device=capi.DEVICE_NONE)
+    assert (rb.host_array(0) == heads).all() and (np.diff(rb.host_array(1).astype(np.int64)) == lens).all()
+    assert (rb.host_array(2).astype(np.int64) == last).all() and (rb.host_array(3).astype(np.int64) == pred).all()
+    rb.close()
+
+
+def test_writer_pieces_against_plain_arithmetic():
+    """the parts no fixture exercises at size: int_vector at widths up to 64 across word boundaries, sd_vector round trips through the decoder
+    for sparse / dense / tiny inputs, select supports over several superblocks (structure: counts and widths)"""
+    rng = np.random.default_rng(1)
+    for width in (1, 3, 13, 31, 33, 40, 63, 64):
+        vals = rng.integers(0, 1 << min(width, 62), 1000, dtype=np.uint64) | (np.uint64(1) << np.uint64(width - 1))
+        got, bits, w = W._Cur(W.int_vector_bytes(vals, width)).int_vector()
+        assert w == width and bits == 1000 * width and got == [int(v) for v in vals]
+    for u, m in ((1, 1), (2, 1), (100, 100), (1 << 20, 5), (1 << 20, 20000), (5_000_000_000, 30000)):
+        ones = np.sort(rng.choice(u, size=m, replace=False)) if u < (1 << 32) else np.unique(rng.integers(0, u, m))
+        cur = W._Cur(W.sparse_bytes(ones, u))
+        uu, back = cur.sparse()
+        assert uu == u and back == [int(x) for x in ones] and cur.p == len(cur.d)
+    # 20000 ones: 5 superblocks of the select support over `high`
+    cur = W._Cur(W.select_support_bytes(np.arange(0, 60000, 3), 60000))
+    assert cur.u64() == 20000
+    sb, _, w = cur.int_vector()
+    assert len(sb) == 5 and w == W.hi(60032) + 1 and sb == [0, 12288, 24576, 36864, 49152]
+
+
+@pytest.fixture(scope="module")
+def big_index(tmp_path_factory):
+    """r = 2.1e6 runs, n > 2^32: written in the reference's format"""
+    rng = np.random.default_rng(77)
+    heads, lens, ssa, esa, n = _random_run_index(rng, 2_100_000, 4200)
+    assert n > (1 << 32) and W.hi(n) + 1 >= 33
+    d = tmp_path_factory.mktemp("sdsl_big")
+    prefix = str(d / "big")
+    with open(prefix + ".rbwt", "wb") as f:
+        f.write(W.rbwt_bytes(heads, lens.astype(np.int64), 2))
+    pred, last, p2r = W.tsa_arrays_from_samples(n, ssa, esa)
+    with open(prefix + ".tsa", "wb") as f:
+        f.write(W.tsa_bytes(n, pred, last, p2r))
+    return prefix, heads, lens, ssa, esa, n
+
+
+def test_rbg_load_of_a_written_index_of_two_million_runs_beyond_32_bits_equals_from_runs(big_index):
+    prefix, heads, lens, ssa, esa, n = big_index
+    assert os.path.getsize(prefix + ".rbwt") > 5_000_000 and os.path.getsize(prefix + ".tsa") > 15_000_000
+    a = ra.load_rowbowt(prefix, ra.LoadRbwtFlag.SA, device=capi.DEVICE_NONE)
+    b = ra.RowBowt.from_runs(heads, lens, ssa, esa, device=capi.DEVICE_NONE)
+    ia, ib = a.info(), b.info()
+    assert (ia.n, ia.r, ia.sigma) == (ib.n, ib.r, ib.sigma) == (n, len(heads), 5) and ia.pos_bytes == ib.pos_bytes == 8
+    for which in ARRAYS:
+        x, y = a.host_array(which), b.host_array(which)
+        assert x.shape == y.shape and (x == y).all(), which
+    assert a.last_run_sample() == b.last_run_sample() and (a.get_f() == b.get_f()).all()
+    a.close()
+    b.close()
+    # a truncated or bit-flipped file is refused, not decoded into something else
+    data = open(prefix + ".rbwt", "rb").read()
+    for bad in (data[:len(data) // 2], data[:40] + bytes([data[40] ^ 0x10]) + data[41:]):
+        with open(prefix + "_bad.rbwt", "wb") as f:
+            f.write(bad)
+        with pytest.raises(Exception):
+            ra.load_rowbowt(prefix + "_bad", device=capi.DEVICE_NONE)
+
+
+@pytest.mark.gpu
+def test_queries_on_the_written_index_equal_from_runs_on_ten_thousand_reads(big_index):
+    prefix, heads, lens, ssa, esa, n = big_index
+    a = ra.load_rowbowt(prefix, ra.LoadRbwtFlag.SA, device=0)
+    b = ra.RowBowt.from_runs(heads, lens, ssa, esa, device=0)
+    rng = np.random.default_rng(5)
+    sym = np.frombuffer(b"ACGT", dtype=np.uint8)
+    reads = [sym[rng.integers(0, 4, int(m))].tobytes() for m in rng.integers(1, 14, 10_000)]
+    seqs, off = ra.pack_reads(reads)
+    la, ha, ka = a.find_range_w_toehold(seqs, off)
+    lb, hb, kb = b.find_range_w_toehold(seqs, off)
+    assert (la == lb).all() and (ha == hb).all() and (ka == kb).all() and int((ha >= la).sum()) > 5000
+    for max_hits in (3, 1):
+        oa, xa = a.locs_at(la, ha, ka, max_hits)
+        ob, xb = b.locs_at(lb, hb, kb, max_hits)
+        assert (oa == ob).all() and (xa == xb).all() and int((xa >= (1 << 32)).sum()) > 100
+    a.close()
+    b.close()
