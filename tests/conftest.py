@@ -31,7 +31,9 @@ def _build_oracle():
     csrc = os.path.join(ROOT, "rowbowt_amd", "csrc")
     lib = os.path.join(ROOT, "rowbowt_amd", "librbg.so")
     cli = os.path.join(ROOT, "rowbowt_amd", "rb_align")
-    newest = max(os.path.getmtime(os.path.join(csrc, f)) for f in os.listdir(csrc) if f.endswith((".hip", ".cpp", ".h", ".hpp")))
+    sources = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".cpp", ".h", ".hpp"))]
+    sources += [os.path.join(csrc, "capi", f) for f in os.listdir(os.path.join(csrc, "capi")) if f.endswith(".ipp")]   # the parts of rbg_capi.hip
+    newest = max(os.path.getmtime(f) for f in sources)
     cli2 = os.path.join(ROOT, "rowbowt_amd", "rb_markers")
     if not os.path.exists(lib) or not os.path.exists(cli) or not os.path.exists(cli2) or not os.path.exists(os.path.join(ROOT, "rowbowt_amd", "rb_build")) or os.path.getmtime(lib) < newest:
         subprocess.check_call(["make", "-C", csrc, "-j4"])
