@@ -226,7 +226,7 @@ __global__ __launch_bounds__(512, 4) void k_find_range_markers_runs(const DevInd
 // k_greedy_seed).  A k-mer step that comes back empty is narrowed by halving until the failing base is the reference's.
 // (three waves per SIMD -- at four the register limit of 128 sends a few of this kernel's values to scratch, and a kernel of this layout
 //  that spilled faulted on the device in round 4, profiles/r04_fault_note.txt: none of them is allowed to)
-template <typename P>
+template <typename P, bool QUAD>
 __global__ __launch_bounds__(512, 3) void k_greedy_seed_runs(const DevIndex ix, const uint8_t *__restrict__ seqs,
                                                      const uint64_t *__restrict__ off, const uint64_t N,
                                                      const uint64_t min_length, uint64_t *__restrict__ lo_out,
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(512, 3) void k_greedy_seed_runs(const DevIndex ix, 
                 stepping = true;
             }
             RunStep r;
-            seeds_lf2<P, (sizeof(P) == 8), false>(S2, stepping, pick.d, pick.rec, lo, hi + 1, r);
+            seeds_lf2<P, (QUAD || sizeof(P) == 8), QUAD>(S2, stepping, pick.d, pick.rec, lo, hi + 1, r);
             if (stepping) {
                 const uint64_t c_inside = r.c_upto - r.c_before;
                 const bool ok = c_inside != 0;
@@ -628,8 +628,17 @@ int launch_greedy_seed_runs(const DevIndex &ix, const LaunchCfg &cfg, const uint
     if (N == 0) return 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const SeedLaunch L = seed_launch(ix, cfg, N);
-    if (ix.pos_bytes == 4) RBG_LAUNCH_SEEDK((k_greedy_seed_runs<uint32_t>), seqs, off, N, min_length, lo, hi, qs, qe, ss);
-    else RBG_LAUNCH_SEEDK((k_greedy_seed_runs<uint64_t>), seqs, off, N, min_length, lo, hi, qs, qe, ss);
+    // every lane fetches its own record: the quad fetch of k_find_range_runs (rbg_runs2_device.hpp lane_lf2_quad) measured the same here (6.80 ms
+    // against 6.77 per 10 M reads on the bench index, profiles/r05_experiments.txt) and costs the 8-byte instantiation its fourth wave per SIMD
+    // (131 VGPRs).  RBG_GREEDY_FETCH=quad keeps the A/B runnable.
+    static const bool quad = [] { const char *e = std::getenv("RBG_GREEDY_FETCH"); return e && e[0] == 'q'; }();
+    if (quad) {
+        if (ix.pos_bytes == 4) RBG_LAUNCH_SEEDK((k_greedy_seed_runs<uint32_t, true>), seqs, off, N, min_length, lo, hi, qs, qe, ss);
+        else RBG_LAUNCH_SEEDK((k_greedy_seed_runs<uint64_t, true>), seqs, off, N, min_length, lo, hi, qs, qe, ss);
+    } else {
+        if (ix.pos_bytes == 4) RBG_LAUNCH_SEEDK((k_greedy_seed_runs<uint32_t, false>), seqs, off, N, min_length, lo, hi, qs, qe, ss);
+        else RBG_LAUNCH_SEEDK((k_greedy_seed_runs<uint64_t, false>), seqs, off, N, min_length, lo, hi, qs, qe, ss);
+    }
     return static_cast<int>(hipGetLastError());
 }
 
