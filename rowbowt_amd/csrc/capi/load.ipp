@@ -167,7 +167,9 @@ int upload(rbg_index *ix) {
                      need() / 1e9, budget / 1e9, deepest.size());
         drop_kmer_level(ix, deepest);
     }
-    if (std::getenv("RBG_VERBOSE") || static_cast<uint64_t>(levels()) != ix->kmer_steps_requested)
+    // (the slot layout stages at most kMaxSlotKmerDepth symbols per gather: a default request of eight that became five there is not news)
+    const uint64_t asked_here = runs_layout ? ix->kmer_steps_requested : std::min<uint64_t>(ix->kmer_steps_requested, static_cast<uint64_t>(kMaxSlotKmerDepth));
+    if (std::getenv("RBG_VERBOSE") || static_cast<uint64_t>(levels()) != asked_here)
         std::fprintf(stderr, "rbg: device %d: %.1f GB free, replica budget %.1f GB: keeping %d of %llu symbol(s) per %s (%.1f GB)\n", ix->device,
                      free_b / 1e9, budget / 1e9, levels(), static_cast<unsigned long long>(ix->kmer_steps_requested), runs_layout ? "search step" : "gather",
                      (runs_layout ? (h.pos_bytes == 4 ? runs_replica_bytes<uint32_t>(h, ix->run_depth_mask) : runs_replica_bytes<uint64_t>(h, ix->run_depth_mask)) : need()) / 1e9);

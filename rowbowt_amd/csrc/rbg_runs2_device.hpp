@@ -215,7 +215,8 @@ __device__ __forceinline__ void lane_scan(const char *__restrict__ tent, const u
 // An OVERFLOWING bucket carries twelve pivots instead of entries: the lane narrows its candidates thirteen-fold from the registers it
 // already has, and what is left (eight entries or fewer up to 91 candidates; beyond that lane_narrow's rounds first) is one scan of the
 // run list -- pending(): the scan the caller still owes, so that the scans of both positions of a step leave together.
-constexpr uint32_t kRecScanZ = 7u;   // candidates the scan after an overflowing record takes (+ the entry after them: four 16-byte loads)
+constexpr uint32_t kRecScanZ = 7u;   // candidates the FIRST pass of the scan after an overflowing record takes (+ the entry after them: four 16-byte loads)
+constexpr uint32_t kRecScanZ2 = 15u;  // ... and with a second pass of four loads, taken only when the eighth entry still lies below the position
 struct LaneRank {
     uint32_t c = 0, lo32 = 0, p = 0, z = 0;   // (p, z): candidates [p, p + z) of the pending scan
     bool inside = false, pending = false;
@@ -289,13 +290,19 @@ struct LaneRec {
 // the pending scans of one or two ranks (LaneRank::pending): every request of both is issued before the first is waited for.
 // The run list is the table's slice of its depth's entry array: ent_d + first * 8, `first` read from the table's cold record here, by
 // the lanes that have a scan to make (a dependent load, but only overflowing buckets pay it).
-template <typename P>
+// Up to fifteen candidates are scanned without narrowing: eight entries at once, and the next eight only for the lane whose eighth entry still
+// lies below its position (a second round trip for it alone -- the crowded buckets of a 520-haplotype pangenome hold about a hundred entries,
+// thirteen-fold pivots leave eight to ten: with a seven-candidate limit nearly every such rank paid a round of seven pivot gathers first,
+// 0.93 rounds per read at r = 1.07e9; profiles/r05_pangenome_stream_r1e9.json).
+// WIDE = false (the seeding kernels, LEAN: the second pass's registers would cost their logging instantiations a wave per SIMD): seven candidates, narrowed first.
+template <typename P, bool WIDE = true>
 __device__ __forceinline__ void lane_finish(const RunSearch2<P> &S, const uint32_t d, const uint32_t rec, LaneRank &A, LaneRank *B, uint32_t &rounds, uint32_t &ents) {
     const bool pb = B && B->pending;
     if (!(A.pending || pb)) return;
     const char *__restrict__ tent = static_cast<const char *>(S.ent[d]) + run_first<P>(S, rec) * 8u;
-    if (A.pending && A.z > kRecScanZ) lane_narrow(tent, A.a_lo, A.qa, A.p, A.z, kRecScanZ, 8u, rounds);
-    if (pb && B->z > kRecScanZ) lane_narrow(tent, B->a_lo, B->qa, B->p, B->z, kRecScanZ, 8u, rounds);
+    constexpr uint32_t kMaxZ = WIDE ? kRecScanZ2 : kRecScanZ;
+    if (A.pending && A.z > kMaxZ) lane_narrow(tent, A.a_lo, A.qa, A.p, A.z, kMaxZ, 8u, rounds);
+    if (pb && B->z > kMaxZ) lane_narrow(tent, B->a_lo, B->qa, B->p, B->z, kMaxZ, 8u, rounds);
     u32x4a8 wa[4], wb[4];
     if (A.pending) {
         const RBG_GLOBAL char *base = as_global<char>(static_cast<const void *>(tent)) + static_cast<uint64_t>(A.p) * 8u;
@@ -316,11 +323,23 @@ __device__ __forceinline__ void lane_finish(const RunSearch2<P> &S, const uint32
             Q.feed(2u * j, w[j].x - R.a_lo, w[j].y);
             Q.feed(2u * j + 1u, w[j].z - R.a_lo, w[j].w);
         }
+        if (WIDE && R.z > kRecScanZ && Q.pb) {   // the eighth entry is still below the position: entries 8 .. 15 (the scan's state carries over)
+            const RBG_GLOBAL char *base = as_global<char>(static_cast<const void *>(tent)) + static_cast<uint64_t>(R.p) * 8u;
+            u32x4a8 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const RBG_GLOBAL u32x4a8 *>(base + static_cast<uint64_t>(8u + 2u * j < R.z ? 8u + 2u * j : R.z) * 8u);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                Q.feed(8u + 2u * j, v[j].x - R.a_lo, v[j].y);
+                Q.feed(8u + 2u * j + 1u, v[j].z - R.a_lo, v[j].w);
+            }
+            ents += 8u;
+        }
         R.c = Q.c;
         const uint32_t dd = Q.qa - Q.ks, len = Q.kn - Q.kc;
         R.lo32 = Q.c ? Q.kc + (dd < len ? dd : len) : Q.fc;   // (none below: the window starts at the table's first entry, whose cum is the table's F)
         R.inside = Q.c != 0u && dd <= len;
-        ents += R.z + 1u;
+        ents += (R.z < 8u ? R.z + 1u : 8u);
     };
     if (A.pending) take(A, wa);
     if (pb) take(*B, wb);
@@ -356,16 +375,16 @@ __device__ __forceinline__ void lane_lf2_tab(const RunSearch2<P> &S, const uint3
         if (b1 == b0) {
             if (r0.compact()) r0.rank2(sh, al0, qa0, o0, qa1, o1, A, B);
             else { r0.pivots(al0, qa0, A); r0.pivots(al1, qa1, B); }
-            lane_finish<P>(S, d, rec, A, &B, rounds, ents);
+            lane_finish<P, !LEAN>(S, d, rec, A, &B, rounds, ents);
         } else if constexpr (LEAN) {
             // (the seeding kernels: one record in registers at a time -- the second is fetched after the first position is answered;
             //  holding both costs sixteen registers on every step and them a workgroup per CU)
             if (r0.compact()) r0.template rank1<false>(sh, al0, qa0, o0, A); else r0.pivots(al0, qa0, A);
-            lane_finish<P>(S, d, rec, A, nullptr, rounds, ents);
+            lane_finish<P, !LEAN>(S, d, rec, A, nullptr, rounds, ents);
             r0.load(recs, R.dir_off + b1);
             h1 = r0.w[1];
             if (r0.compact()) r0.template rank1<true>(sh, al1, qa1, o1, B); else r0.pivots(al1, qa1, B);
-            lane_finish<P>(S, d, rec, B, nullptr, rounds, ents);
+            lane_finish<P, !LEAN>(S, d, rec, B, nullptr, rounds, ents);
         } else {
             // both records leave together, then both scans of the run list (overflowing buckets): the dependent round trips of a step are
             // record -> scan [-> sample] whatever its two positions meet -- a wave waits for the longest chain among its 64 lanes
@@ -374,7 +393,7 @@ __device__ __forceinline__ void lane_lf2_tab(const RunSearch2<P> &S, const uint3
             h1 = r1.w[1];
             if (r0.compact()) r0.template rank1<false>(sh, al0, qa0, o0, A); else r0.pivots(al0, qa0, A);
             if (r1.compact()) r1.template rank1<true>(sh, al1, qa1, o1, B); else r1.pivots(al1, qa1, B);
-            lane_finish<P>(S, d, rec, A, &B, rounds, ents);
+            lane_finish<P, !LEAN>(S, d, rec, A, &B, rounds, ents);
         }
         if (STATS) { st[kStSlots] += b1 != b0 ? 2 : 1; st[kStSearch] += rounds; st[kStDense] += ents; st[kStSteps] += 1; }
         const uint64_t y0 = static_cast<uint64_t>(h0) << 31, y1 = static_cast<uint64_t>(h1) << 31;
@@ -501,7 +520,7 @@ __device__ __forceinline__ void lane_lf2_quad(const RunSearch2<P> &S, const bool
     constexpr bool W = sizeof(P) == 8;
     const uint32_t sh = R.dir_shift;
     const bool by_rec = stepping && S.rec[d] != nullptr;
-    if (stepping && !by_rec) lane_lf2_tab<P, STATS>(S, d, rec, R, q0, q1, out, st);   // (a depth with directories over its run lists: the lane by itself)
+    if (stepping && !by_rec) lane_lf2_tab<P, STATS, LEAN>(S, d, rec, R, q0, q1, out, st);   // (a depth with directories over its run lists: the lane by itself)
     if (__ballot(by_rec) == 0) return;                                            // (nobody's quad has a record to fetch in this step)
     const uint32_t p = threadIdx.x & 3u;
     const uint64_t b0 = by_rec ? pos_bucket<P>(q0, sh) : 0u, b1 = by_rec ? pos_bucket<P>(q1, sh) : 0u;
@@ -548,19 +567,19 @@ __device__ __forceinline__ void lane_lf2_quad(const RunSearch2<P> &S, const bool
     if (!two) {
         if (r0.compact()) r0.rank2(sh, al0, qa0, o0, qa1, o1, A, B);
         else { r0.pivots(al0, qa0, A); r0.pivots(al1, qa1, B); }
-        lane_finish<P>(S, d, rec, A, &B, rounds, ents);
+        lane_finish<P, !LEAN>(S, d, rec, A, &B, rounds, ents);
     } else if constexpr (LEAN) {
         if (r0.compact()) r0.template rank1<false>(sh, al0, qa0, o0, A); else r0.pivots(al0, qa0, A);
-        lane_finish<P>(S, d, rec, A, nullptr, rounds, ents);
+        lane_finish<P, !LEAN>(S, d, rec, A, nullptr, rounds, ents);
         r0.load(recs, R.dir_off + b1);
         h1 = w0[1];
         if (r0.compact()) r0.template rank1<true>(sh, al1, qa1, o1, B); else r0.pivots(al1, qa1, B);
-        lane_finish<P>(S, d, rec, B, nullptr, rounds, ents);
+        lane_finish<P, !LEAN>(S, d, rec, B, nullptr, rounds, ents);
     } else {
         h1 = r1.w[1];
         if (r0.compact()) r0.template rank1<false>(sh, al0, qa0, o0, A); else r0.pivots(al0, qa0, A);
         if (r1.compact()) r1.template rank1<true>(sh, al1, qa1, o1, B); else r1.pivots(al1, qa1, B);
-        lane_finish<P>(S, d, rec, A, &B, rounds, ents);
+        lane_finish<P, !LEAN>(S, d, rec, A, &B, rounds, ents);
     }
     if (STATS) { st[kStSlots] += two ? 2 : 1; st[kStSearch] += rounds; st[kStDense] += ents; st[kStSteps] += 1; }
     const uint64_t y0 = static_cast<uint64_t>(h0) << 31, y1 = static_cast<uint64_t>(h1) << 31;
