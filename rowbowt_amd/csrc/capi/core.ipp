@@ -132,6 +132,14 @@ inline size_t default_budget(size_t free_b) { return free_b / 4; }
 // the one before it (measured 0.55-0.69 r per depth at r = 1.07e9, n / r = 282; 0.33 r on the bench index), pieces are indexed with 32 bits, the
 // sweeps hold about 70 bytes per piece of the depth being made (profiles/r04_pangenome_stream_r1e9_k5.log), and -- with_budget -- the least the budget
 // rule of upload() keeps of a depth K (the single symbols, K itself, phi) must fit the budget at 18 bytes per entry.
+// RBG_ASSUME_FREE_HBM_MB (tests only): the free HBM the PLANNING of a load assumes (budget, composition depth), capped to this many MiB -- so that
+// the rules an index of r = 1e9 runs meets on a 288 GB device (budget raised, depth planned before composing) are exercised by a test-sized index.
+// Allocation itself is not limited by it.
+inline size_t assumed_free_hbm(size_t free_b) {
+    const char *e = std::getenv("RBG_ASSUME_FREE_HBM_MB");
+    if (!e || std::atoll(e) <= 0) return free_b;
+    return std::min<size_t>(free_b, static_cast<size_t>(std::atoll(e)) << 20);
+}
 inline double est_depth_runs(double r, uint32_t d) { return r * (1.0 + 0.62 * static_cast<double>(d - 1)); }
 inline uint32_t planned_depth(double r, bool samples, uint32_t K0, double free_b, double budget, bool with_budget) {
     const double per_entry = 8.0 + (samples ? 6.0 : 0.0) + 4.0;

@@ -280,6 +280,7 @@ FlattenOptions options_for(int device, const RawRle &rle, uint64_t *requested, b
     if (scope.rc) return o;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return o;
+    free_b = assumed_free_hbm(free_b);
     const int64_t opt_mb = g_opt_hbm_budget_mb.load();
     double budget = static_cast<double>(opt_mb > 0 ? static_cast<size_t>(opt_mb) << 20 : default_budget(free_b));
     // (the budget of this load is fixed HERE, while nothing of it is on the device: upload() measures again after the composition has

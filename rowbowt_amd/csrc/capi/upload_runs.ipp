@@ -561,6 +561,7 @@ int compose_on_device(rbg_index *ix) {
     {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            free_b = assumed_free_hbm(free_b);
             const int64_t opt_mb = g_opt_hbm_budget_mb.load();
             const double budget = ix->plan_budget ? static_cast<double>(ix->plan_budget) : static_cast<double>(opt_mb > 0 ? static_cast<size_t>(opt_mb) << 20 : default_budget(free_b));
             const bool runs_certain = g_opt_rank_layout.load() == RBG_LAYOUT_RUNS || ix->auto_runs;

@@ -60,7 +60,10 @@ def _run_rb_markers(args):
 def _random_run_index(rng, r, max_len, term_at=None):
     """A synthetic run list (random heads over ACGT with neighbouring runs different, random lengths, distinct random
     samples below n) with one terminator run: rank, LF, the toehold bookkeeping and phi are arithmetic on these arrays
-    alone, so they define the answers completely -- for the oracle and for the device alike (no text needed)."""
+    alone, so they define the answers completely -- for the oracle and for the device alike (no text needed).
+    One caveat: the samples of such a list are not LF-consistent as a BWT's are, so the toehold after a MULTI-symbol step is
+    defined by them only up to the choice between two run ends that coincide (the same SA value in a BWT): compare ranges at
+    any depth, toeholds and locations at single-symbol steps (or on a true BWT: synth.SynthIndex, the pangenome streams)."""
     sym = np.frombuffer(b"ACGT", dtype=np.uint8)
     step = rng.integers(1, 4, size=r, dtype=np.int64)
     step[0] = 0

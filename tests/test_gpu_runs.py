@@ -348,6 +348,57 @@ def test_run_indexed_layout_sparse_depths(synth, pos_bytes, mask, kept, recs):
     o.close()
 
 
+def test_default_load_of_an_index_too_large_for_a_quarter_of_the_device_plans_its_depth_and_raises_its_budget():
+    """What an index of r = 1e9 runs meets on a 288 GB device (profiles/r05_pangenome_stream_r1e9_default.json), on a test-sized index:
+    RBG_ASSUME_FREE_HBM_MB (tests only) caps the free HBM the PLANNING of a load assumes.  With 200 MB "free", a million runs over n = 1e8:
+    not even the single-symbol slot tables fit a quarter (50 MB), so the run-indexed layout is certain; the quarter would leave it one symbol per
+    step, so RBG_LAYOUT_AUTO takes three quarters (150 MB) and says so; the composition depth is planned BEFORE composing from the sweeps' 70
+    bytes per piece (3 of the 8 asked); the budget reported is the one fixed before anything was on the device.  Answers equal the oracle's."""
+    rng = np.random.default_rng(43)
+    heads, lens, ssa, esa, n = _random_run_index(rng, 1_000_000, 200)
+    o = orc.Oracle.from_runs(heads, lens, ssa, esa)
+    os.environ["RBG_ASSUME_FREE_HBM_MB"] = "200"
+    try:
+        # nothing set but the ftab: RBG_LAYOUT_AUTO, eight symbols asked for, no budget given.  (The 12-symbol device ftab is a constant 268 MB the
+        #  budget rule does not count -- half a per cent of a replica at the scale this is about, more than this whole index)
+        with capi.default_option(capi.OPT_FTAB_K, 0):
+            rb = ra.RowBowt.from_runs(heads, lens, ssa, esa, device=0)
+    finally:
+        del os.environ["RBG_ASSUME_FREE_HBM_MB"]
+    info, li = rb.info(), rb.layout_info()
+    assert info.rank_layout == capi.LAYOUT_RUNS and li.budget_raised == 1
+    assert int(info.hbm_free_at_load) == 200 << 20 and int(info.hbm_budget) == 150 << 20
+    assert info.kmer_steps_requested == 8 and 2 <= info.kmer_steps <= 4 and li.depths_composed == info.kmer_steps
+    assert int(info.hbm_bytes) <= int(info.hbm_budget) and li.depths_dropped_budget == 0
+    # the same index with the budget given explicitly is not second-guessed
+    os.environ["RBG_ASSUME_FREE_HBM_MB"] = "200"
+    try:
+        with capi.default_option(capi.OPT_HBM_BUDGET_MB, 60), capi.default_option(capi.OPT_FTAB_K, 0):
+            rb2 = ra.RowBowt.from_runs(heads, lens, ssa, esa, device=0)
+    finally:
+        del os.environ["RBG_ASSUME_FREE_HBM_MB"]
+    assert rb2.layout_info().budget_raised == 0 and int(rb2.info().hbm_budget) == 60 << 20 and int(rb2.info().hbm_bytes) <= 60 << 20
+    assert rb2.info().kmer_steps <= info.kmer_steps
+    reads = _lf_walk_reads(o, heads, lens, n, rng, 400, 40) + [b"ACGT", b"N", b""]
+    seqs, off = ra.pack_reads(reads)
+    want = o.find_range_w_toehold_batch(seqs, off)
+    # Ranges on both.  Toeholds and locations where the load kept single-symbol steps only: this index is a random run list, not a BWT -- its
+    # samples are not LF-consistent, and a k-mer step's stored sample may be taken from either of two run ends that coincide (equal in a BWT:
+    # both are SA - d of the same row; different here, for about one read in a few hundred, on either layout).  The k-mer toeholds are pinned
+    # on true BWTs (test_run_indexed_layout, the pangenome streams).
+    for x in (rb, rb2):
+        lo, hi = x.find_range(seqs, off)
+        assert (lo == want[0]).all() and (hi == want[1]).all()
+        if x.info().kmer_steps == 1:
+            got = x.find_range_w_toehold(seqs, off)
+            assert all((g == w).all() for g, w in zip(got, want))
+            loc_off, locs = x.locs_at(got[0], got[1], got[2], 5)
+            woff, wlocs = o.locs_at_batch(want[0], want[1], want[2], 5)
+            assert (loc_off == woff).all() and (locs == wlocs).all()
+        x.close()
+    o.close()
+
+
 def test_run_indexed_layout_budget_leaves_middle_depths_out():
     """Over budget the run-indexed layout gives up the depths between the first and the deepest before the deepest
     itself (rbg_capi.hip upload): the step length stays, the space goes down, the answers stay.  (A synthetic run list of
