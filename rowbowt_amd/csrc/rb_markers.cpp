@@ -414,9 +414,9 @@ int main(int argc, char **argv) {
     std::cerr << "(rle_string_sd) loading rowbowt + markers" << (args.ftab ? " and ftab" : "") << std::endl;  // rb_markers.cpp:553-557
     rbwt::LoadRbwtFlag flag = rbwt::LoadRbwtFlag::MA;  // :541-546
     if (args.ftab) flag = flag | rbwt::LoadRbwtFlag::FT;
-    // (the seeding kernels are faster on slot tables: keep them, with fewer symbols per step if the budget says so, where the library's
-    //  automatic layout would switch to the run-indexed one -- unless RBG_LAYOUT says otherwise)
-    if (!std::getenv("RBG_LAYOUT")) (void)rbg_set_default_option(RBG_OPT_RANK_LAYOUT, RBG_LAYOUT_PREFER_SLOTS);
+    // (the library's automatic layout: the run-indexed replica.  Until round 5 the tool asked for RBG_LAYOUT_PREFER_SLOTS because the seeding
+    //  kernels are a quarter faster on slot tables; that is 2 ms of a 190 ms query loop for two million reads, against a replica five times
+    //  the size and its load time -- profiles/r05_rb_markers_layout.txt.  RBG_LAYOUT=prefer-slots brings it back.)
     rbwt::RowBowt<> rb = rbwt::load_rowbowt<>(args.inpre, flag, args.device);
     if (rb.ftab_k() && rb.ftab_k() - 1 > args.wsize) {  // rowbowt.hpp:423-426
         std::cerr << "ERROR: wsize cannot be greater than or equal to ftab k size. please rebuild ftab with smaller k\n";

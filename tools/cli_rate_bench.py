@@ -115,6 +115,9 @@ def main():
     ap.add_argument("--threads", type=int, default=16)
     ap.add_argument("--dir", default="/tmp/cli_big")
     ap.add_argument("--only-s", action="store_true", help="only the rb_align -s rows on plain FASTQ (tuning runs)")
+    ap.add_argument("--only-markers", action="store_true",
+                    help="only the rb_markers rows, each under the layout the tool gets by default (RBG_LAYOUT_AUTO: the run-indexed replica) and under "
+                         "RBG_LAYOUT=prefer-slots (what the tool forced until round 5), three processes each (profiles/r05_rb_markers_layout.txt)")
     ap.add_argument("--only-sm", type=int, default=0, help="only the rb_align -s -m row on plain FASTQ, this many times (its spread)")
     ap.add_argument("--numa-probe", type=int, default=0,
                     help="the process-to-process spread of rb_align -s -m and its cause: this many fresh processes with the pinned result buffers left where "
@@ -178,6 +181,8 @@ def main():
     if args.numa_probe:
         numa_probe(exe, prefix, fq, args.reads, th, args.numa_probe)
         return
+    if args.only_markers:
+        rows = ()
     for flags, path, n, out in rows:
         t0 = time.perf_counter()
         env = dict(os.environ, RB_ALIGN_TRACE="1")
@@ -199,9 +204,13 @@ def main():
     if args.only_s or args.only_sm:
         return
     exe2 = os.path.join(ROOT, "rowbowt_amd", "rb_markers")
-    for flags in (th, ["--heuristic", "--best-strand-only", "--min-seed-length", "30"] + th):
+    variants = [("", {})]
+    if args.only_markers:
+        variants = [("[default layout] ", {}), ("[RBG_LAYOUT=prefer-slots] ", {"RBG_LAYOUT": "prefer-slots"})] * 3
+    for label, extra_env in variants:
+      for flags in (th, ["--heuristic", "--best-strand-only", "--min-seed-length", "30"] + th):
         t0 = time.perf_counter()
-        p = subprocess.run([exe2] + flags + [prefix, fqm], stdout=open(out_txt, "wb"), stderr=subprocess.PIPE, timeout=600, env=dict(os.environ, RB_ALIGN_TRACE="1"))
+        p = subprocess.run([exe2] + flags + [prefix, fqm], stdout=open(out_txt, "wb"), stderr=subprocess.PIPE, timeout=600, env=dict(os.environ, RB_ALIGN_TRACE="1", **extra_env))
         dt = time.perf_counter() - t0
         sz = os.path.getsize(out_txt)
         err = p.stderr.decode().strip().splitlines()
@@ -212,7 +221,7 @@ def main():
             loop = f"query loop {loop_s:.3f} s = {args.marker_reads / loop_s:.3e} reads/s"
         except Exception:  # noqa: BLE001
             loop = last
-        print(f"rb_markers {' '.join(flags)}: {args.marker_reads} x {m} bp (both strands) -> {sz / 1e6:.0f} MB of text; process {dt:.2f} s (exit {p.returncode}); {loop}" + (f"   [{tr[-1][17:]}]" if tr else ""), flush=True)
+        print(f"{label}rb_markers {' '.join(flags)}: {args.marker_reads} x {m} bp (both strands) -> {sz / 1e6:.0f} MB of text; process {dt:.2f} s (exit {p.returncode}); {loop}" + (f"   [{tr[-1][17:]}]" if tr else ""), flush=True)
 
 
 if __name__ == "__main__":
