@@ -54,6 +54,57 @@ def test_writer_pieces_against_plain_arithmetic():
     assert len(sb) == 5 and w == W.hi(60032) + 1 and sb == [0, 12288, 24576, 36864, 49152]
 
 
+def _small_random_index(rng, r, alphabet, max_len):
+    """a run list over `alphabet` (bytes) with neighbouring runs different, one terminator run, distinct samples.  (Samples stay above 32: a run list
+    is not a BWT, and a sample below the k-mer depth would mean a k-mer that spans the terminator -- the flattener refuses that as a malformed index)"""
+    sym = np.frombuffer(alphabet, dtype=np.uint8)
+    k = len(sym)
+    step = rng.integers(1, k, size=r) if k > 1 else np.zeros(r, dtype=np.int64)
+    step[0] = 0
+    heads = sym[np.cumsum(step) % k].copy()
+    lens = rng.integers(1, max_len + 1, size=r).astype(np.uint64)
+    if int(lens.sum()) < 2 * r + 64:
+        lens += np.uint64(2 + 64 // r)
+    t = int(rng.integers(0, r))
+    if (t == 0 or heads[t - 1] != 1) and (t == r - 1 or heads[t + 1] != 1):
+        heads[t], lens[t] = 1, 1
+    n = int(lens.sum())
+    if n < 2 * r + 40:                                  # (room for 2 r distinct samples above 32)
+        lens[0 if heads[0] != 1 else 1] += np.uint64(2 * r + 40 - n)
+        n = int(lens.sum())
+    vals = rng.permutation(n - 33)[:2 * r].astype(np.uint64) + np.uint64(33)     # y values of .ssa / .esa pairs (sample = y - 1)
+    return heads, lens, vals[:r].copy(), vals[r:].copy(), n
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_small_random_indexes_through_the_written_format(tmp_path, seed):
+    """shapes the fixtures do not have: two to a few thousand runs, letters with a single run (sd_vectors of one bit), alphabets with N
+    and lower case, run counts at and around the select supports' 4096-argument superblock, block sizes B other than 2"""
+    rng = np.random.default_rng(100 + seed)
+    r = [2, 3, 7, 64, 65, 4095, 4096, 4097, 8193, 2500, 300, 1000][seed]
+    alphabet = [b"AC", b"ACGT", b"ACGTN", b"ACGTNacgt", b"AT", b"ACGT", b"ACGT", b"ACGTN", b"ACGT", b"CG", b"ACGTRYKM", b"ACGT"][seed]
+    heads, lens, ssa, esa, n = _small_random_index(rng, r, alphabet, [1, 5, 40, 3, 1000, 2, 9, 30, 4, 100000, 6, 50][seed])
+    B = [2, 2, 3, 2, 5, 2, 2, 4, 2, 2, 7, 64][seed]
+    prefix = str(tmp_path / "idx")
+    with open(prefix + ".rbwt", "wb") as f:
+        f.write(W.rbwt_bytes(heads, lens.astype(np.int64), B))
+    pred, last, p2r = W.tsa_arrays_from_samples(n, ssa, esa)
+    with open(prefix + ".tsa", "wb") as f:
+        f.write(W.tsa_bytes(n, pred, last, p2r))
+    # the writer's own decoder reads it back ...
+    dn, dR, dB, dheads, dlens = W.decode_rbwt(open(prefix + ".rbwt", "rb").read()) if r <= 5000 else (n, r, B, heads, lens)
+    assert (dn, dR, dB) == (n, r, B) and (dheads == heads).all() and (dlens == lens.astype(np.int64)).all()
+    # ... and the library's reader gives what rbg_build_from_runs gives
+    a = ra.load_rowbowt(prefix, ra.LoadRbwtFlag.SA, device=capi.DEVICE_NONE)
+    b = ra.RowBowt.from_runs(heads, lens, ssa, esa, device=capi.DEVICE_NONE)
+    for which in ARRAYS:
+        x, y = a.host_array(which), b.host_array(which)
+        assert x.shape == y.shape and (x == y).all(), (which, seed)
+    assert a.info().sigma == b.info().sigma and (a.get_f() == b.get_f()).all() and a.last_run_sample() == b.last_run_sample()
+    a.close()
+    b.close()
+
+
 @pytest.fixture(scope="module")
 def big_index(tmp_path_factory):
     """r = 2.1e6 runs, n > 2^32: written in the reference's format"""
