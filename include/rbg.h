@@ -501,11 +501,11 @@ int rbg_sample_reads_pangenome_dev(const uint8_t *d_base, const uint64_t *d_site
  * as 2-bit codes.  (Packing a batch that is already in HBM is rbg_pack_reads_dev.)
  * RANK_LAYOUT: RBG_LAYOUT_AUTO (default): slot tables while those of every requested symbol per step (KMER_STEPS), at their
  * narrow buckets, fit the HBM budget; otherwise the run-indexed layout rather than slot tables with wider buckets or fewer
- * symbols per step (on the bench index at the default budget 1.23e9 count+locate reads/s from 8.7 GB, against 1.13e9 from
- * the 70 GB of five symbols in wide buckets and 1.14e9 from the 59 GB of four: profiles/r04_bench.json) -- unless that does
+ * symbols per step (on the bench index at the default budget 1.35-1.47e9 count+locate reads/s from 12 GB at eight symbols per step,
+ * against 1.26e9 from the 221 GB of five symbols per gather and 1.18e9 from the 59 GB of four: profiles/r05_bench.json) -- unless that does
  * not fit either (about 110 bytes per run).  RBG_LAYOUT_PREFER_SLOTS: slot tables with as many symbols per step as fit, the
- * run-indexed layout only when not even the single-symbol level does (the rule of rounds 2-3; rb_markers asks for it: its
- * seeding kernels are faster on slot tables).  rbg_info::rank_layout reports the outcome.
+ * run-indexed layout only when not even the single-symbol level does (the rule of rounds 2-3; the seeding kernels are a quarter faster
+ * on slot tables).  rbg_info::rank_layout reports the outcome.
  * RBG_LAYOUT_SLOTS, RBG_LAYOUT_RUNS = the run-indexed layout: the run lists of the k-mer depths RUN_DEPTHS names (by default the
  * deepest KMER_STEPS asks for and the budget holds, half of it, a quarter of it ... and 1) with a directory or bucket records per
  * table, space proportional to r and nothing proportional to n; rank and phi are predecessor searches over the few entries of
