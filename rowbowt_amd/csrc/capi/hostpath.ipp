@@ -549,4 +549,3 @@ int rbg_locs_at(rbg_index *ix, const uint64_t *lo, const uint64_t *hi, const uin
 }
 
 }  // extern "C"
-namespace {

@@ -4,7 +4,6 @@
 // (xGMI); records that hold device pointers (DevSym arrays, DevIndex) are re-pointed into the copy.
 
 
-}  // extern "C"
 
 namespace {
 

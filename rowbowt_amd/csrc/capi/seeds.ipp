@@ -332,3 +332,4 @@ int rbg_find_locs_greedy_seeding(rbg_index *ix, const uint8_t *seqs, const uint6
     });
 }
 
+}  // extern "C"

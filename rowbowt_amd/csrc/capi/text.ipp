@@ -1,4 +1,5 @@
 // capi/text.ipp -- rbg_align_text and its pinned text buffers (rb_align's output lines, written on the device).  Part of rbg_capi.hip.
+namespace {
 // the document table on the handle's device (rbg_align_text): sorted starts, names back to back
 int ensure_text_docs(rbg_index *ix) {
     std::lock_guard<std::mutex> g(ix->text_mu);
