@@ -112,3 +112,12 @@ def test_on_the_gpu_box_one_rank_more_than_devices_is_refused_and_launch_check_n
         assert p.returncode == 0
         ranks = sorted(json.loads(line.split("] ", 1)[-1])["RANK"] for line in (p.stdout + p.stderr).splitlines() if '"RANK"' in line)
         assert ranks == sorted(str(r) for r in range(ndev))
+
+
+def test_replicas_and_gpus_are_two_ways_and_exclude_each_other():
+    """tools/pangenome_stream.py: `--replicas G` (ONE process: one index build, peer copies, a thread per replica) and `--gpus N`
+    (one process per GPU) both shard the reads of rb_align.cpp:176-178 over replicas; asking for both is refused before anything is
+    imported or started."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pangenome_stream.py"), "--replicas", "2", "--gpus", "2", "--launch-check"],
+                       env=clean_env(), capture_output=True, text=True, timeout=60)
+    assert p.returncode != 0 and "--replicas" in p.stderr and "--gpus" in p.stderr and p.stdout.strip() == ""
