@@ -595,6 +595,28 @@ size_t runs_replica_bytes(const HostIndex &h, uint32_t mask = ~0u) {
     return total + 16 * kArenaAlign;
 }
 
+// bucket records of one k-mer depth at `per` entries per bucket on average: their number (a sparse table's bucket shift stops at max_shift)
+inline double runs_record_count(const HostIndex &h, uint32_t depth_index, double per, uint32_t max_shift) {
+    const std::vector<SymTable> &lv = depth_index == 0 ? h.sym : h.kmer(depth_index + 1);
+    double nrec = 0;
+    for (const SymTable &t : lv) {
+        uint32_t sh = 0;
+        const double runs = static_cast<double>(std::max<uint64_t>(1, t.nruns));
+        while (sh < max_shift && runs * static_cast<double>(uint64_t(2) << sh) <= per * static_cast<double>(h.n)) ++sh;
+        nrec += static_cast<double>((h.n >> sh) + 2);
+    }
+    return nrec;
+}
+// phi slots of about n / r rows on the run-indexed layout: their bytes, or 0 where the automatic rule would not build them (more than 2 r buckets)
+inline double runs_phi_slot_bytes(const HostIndex &h) {
+    if (!h.has_tsa) return 0;
+    uint32_t ss = 0;
+    while (ss < 8 && static_cast<double>(uint64_t(2) << ss) <= static_cast<double>(h.n) / static_cast<double>(std::max<uint64_t>(1, h.r))) ++ss;
+    if (ss < h.phi_shift) ss = h.phi_shift;
+    const double nb = static_cast<double>((h.n >> ss) + 2);
+    return nb <= 2.0 * static_cast<double>(h.r) ? nb * (h.pos_bytes == 8 ? 36.0 : 20.0) : 0.0;
+}
+
 void release_kmer_level(rbg_index *ix, uint32_t depth);
 std::vector<SymTable> &kmer_level_tables(HostIndex &h, uint32_t depth);
 

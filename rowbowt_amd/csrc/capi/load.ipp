@@ -123,6 +123,27 @@ int upload(rbg_index *ix) {
             while (levels() > 1 && !level_has_data(ix, static_cast<uint32_t>(levels()))) drop_kmer_level(ix, deepest_of());
             mask = (mask & ((1u << levels()) - 1u)) | (1u << (levels() - 1));   // (the new deepest level is stepped by again)
         }
+        // Records everywhere before depths in between: a depth whose ranks go through a directory pays narrowing rounds in crowded buckets (n = 5e10 under the
+        // default budget: 2.7 rounds and 78 scanned entries per read, K2 13.8 ms against 7 with records; profiles/r05_pangenome_stream_n5e10_default.json),
+        // the depths between the first and the deepest save a step per read.  So when the automatic rules decide (no RBG_OPT_RUN_DEPTHS, no RBG_OPT_RUN_REC) and
+        // bucket records for every kept depth do not fit the budget, but would with the first and the deepest depth alone, the depths between them go.
+        if (g_opt_run_depths.load() == 0 && g_opt_run_rec.load() == 0 && levels() > 2) {
+            const uint32_t ends = 1u | (1u << (levels() - 1));
+            const uint32_t max_shift = h.pos_bytes == 8 ? static_cast<uint32_t>(env_opt("RBG_RUN_FILL_SHIFT", kRunFillShift, 4, kRunFillShift)) : 31u;
+            auto with_records = [&](uint32_t m) {
+                double bytes = static_cast<double>(h.pos_bytes == 4 ? runs_replica_bytes<uint32_t>(h, m) : runs_replica_bytes<uint64_t>(h, m));
+                if (g_opt_run_phi.load() != 1) bytes += runs_phi_slot_bytes(h);
+                for (int d = 0; d < levels(); ++d)
+                    if (m >> d & 1u) bytes += runs_record_count(h, static_cast<uint32_t>(d), 6.0, max_shift) * 64.0;
+                return bytes;
+            };
+            if (mask != ends && with_records(mask) > static_cast<double>(budget) && with_records(ends) <= static_cast<double>(budget)) {
+                std::fprintf(stderr, "rbg: bucket records for every kept depth (%.1f GB with them) exceed the %.1f GB budget: leaving out the depths between 1 and %d "
+                                     "(%.1f GB with records for both)\n", with_records(mask) / 1e9, budget / 1e9, levels(), with_records(ends) / 1e9);
+                ix->runs_report.depths_dropped_budget |= mask & ~ends;
+                mask = ends;
+            }
+        }
         for (int d = 2; d < levels(); ++d)   // the depths left out give their device arrays back now
             if (!(mask >> (d - 1) & 1u)) {
                 release_kmer_level(ix, static_cast<uint32_t>(d));

@@ -118,40 +118,40 @@ int upload_tables_runs2(rbg_index *ix) {
     // (0 = all kept) at RBG_RUN_REC_PER (2.5).  Automatic: each depth in turn gets the narrowest buckets -- 2.5, 4 or 6 entries (a compact
     // record holds eleven) -- with which the replica (phi slots included) stays within the budget and the records stay O(r) (at most one per entry).
     std::vector<double> rec_per(D, 0.0);
-    auto records_of = [&](uint32_t d, double per) {   // records of depth d at `per` entries per bucket (a sparse table's shift stops at max_shift)
-        double nrec = 0;
-        for (const SymTable &t : *depth[d]) {
-            uint32_t sh = 0;
-            const double runs = static_cast<double>(std::max<uint64_t>(1, t.nruns));
-            while (sh < max_shift && runs * static_cast<double>(uint64_t(2) << sh) <= per * static_cast<double>(h.n)) ++sh;
-            nrec += static_cast<double>((h.n >> sh) + 2);
-        }
-        return nrec;
-    };
+    auto records_of = [&](uint32_t d, double per) { return runs_record_count(h, d, per, max_shift); };
     if (g_opt_run_rec.load() == 2) {
         const uint32_t want = g_opt_run_rec_depths.load() ? static_cast<uint32_t>(g_opt_run_rec_depths.load()) : ~0u;
         for (uint32_t d = 0; d < D; ++d)
             if ((mask >> d & 1u) && (want >> d & 1u)) rec_per[d] = rec_asked > 0 ? rec_asked : 2.5;
     } else if (g_opt_run_rec.load() == 0 && ix->hbm_budget) {
         double total = static_cast<double>(W ? runs_replica_bytes<uint64_t>(h, mask) : runs_replica_bytes<uint32_t>(h, mask));
-        if (h.has_tsa && g_opt_run_phi.load() != 1) {   // phi slots come first (decided after the rank tables, below: the same arithmetic): their room is not the records'
-            uint32_t ss = 0;
-            while (ss < 8 && static_cast<double>(uint64_t(2) << ss) <= static_cast<double>(h.n) / static_cast<double>(std::max<uint64_t>(1, h.r))) ++ss;
-            if (ss < h.phi_shift) ss = h.phi_shift;
-            const double nb = static_cast<double>((h.n >> ss) + 2);
-            if (nb <= 2.0 * static_cast<double>(h.r)) total += nb * (W ? 36.0 : 20.0);
+        if (g_opt_run_phi.load() != 1) total += runs_phi_slot_bytes(h);   // phi slots come first (decided after the rank tables, below: the same arithmetic): their room is not the records'
+        const double budget = static_cast<double>(ix->hbm_budget);
+        const double pers[3] = {2.5, 4.0, 6.0};
+        // room at the widest buckets (6 entries) for EVERY kept depth?  Then every depth gets records -- a depth left on directories pays narrowing rounds on
+        // its steps -- and a depth takes narrower buckets only with what the shallower ones do not need.  Otherwise: deepest first, while they fit.
+        std::vector<double> widest(D, 0.0), entries(D, 0.0);
+        double all_widest = 0;
+        bool every = true;
+        for (uint32_t d = 0; d < D; ++d) {
+            if (!(mask >> d & 1u)) continue;
+            for (const SymTable &t : *depth[d]) entries[d] += static_cast<double>(t.nruns + 1);
+            widest[d] = records_of(d, rec_asked > 0 ? rec_asked : pers[2]) * 64.0;
+            all_widest += widest[d];
+            every = every && widest[d] <= entries[d] * 64.0;
         }
+        every = every && total + all_widest <= budget;
+        double shallower_widest = all_widest;
         for (int d = static_cast<int>(D) - 1; d >= 0; --d) {
             if (!(mask >> d & 1u)) continue;
-            double entries_d = 0;
-            for (const SymTable &t : *depth[d]) entries_d += static_cast<double>(t.nruns + 1);
-            const double pers[3] = {2.5, 4.0, 6.0};
+            shallower_widest -= widest[d];
             for (const double per : pers) {
                 if (rec_asked > 0 && per != pers[0]) break;
-                const double nrec = records_of(static_cast<uint32_t>(d), rec_asked > 0 ? rec_asked : per);
-                if (nrec <= entries_d && total + nrec * 64.0 <= static_cast<double>(ix->hbm_budget)) {
-                    rec_per[d] = rec_asked > 0 ? rec_asked : per;
-                    total += nrec * 64.0;
+                const double use = rec_asked > 0 ? rec_asked : per;
+                const double bytes = records_of(static_cast<uint32_t>(d), use) * 64.0;
+                if (bytes <= entries[d] * 64.0 && total + bytes + (every ? shallower_widest : 0.0) <= budget) {
+                    rec_per[d] = use;
+                    total += bytes;
                     break;
                 }
             }

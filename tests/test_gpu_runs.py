@@ -399,6 +399,48 @@ def test_default_load_of_an_index_too_large_for_a_quarter_of_the_device_plans_it
     o.close()
 
 
+def test_records_for_every_kept_depth_come_before_the_depths_in_between():
+    """The automatic rules under a shrinking budget (capi/load.ipp, capi/upload_runs.ipp): while bucket records for all kept depths fit, every depth has
+    them (a depth takes narrower buckets only with what the others do not need); when they no longer fit but would for the first and the deepest depth
+    alone, the depths between go (a step per read) rather than the records (narrowing rounds on every step of a depth left on directories: K2 13.8 against
+    7 ms at n = 5e10, profiles/r05_pangenome_stream_n5e10_default.json).  A synthetic run list of a million runs (the budget option counts MB); ranges
+    equal the oracle's at the budget where that happens."""
+    rng = np.random.default_rng(47)
+    heads, lens, ssa, esa, n = _random_run_index(rng, 1_000_000, 200)
+    def build(budget_mb):
+        with capi.default_option(capi.OPT_FTAB_K, 0), capi.default_option(capi.OPT_HBM_BUDGET_MB, budget_mb), capi.default_option(capi.OPT_KMER_STEPS, 5):
+            return _with_layout(capi.LAYOUT_RUNS, lambda: ra.RowBowt.from_runs(heads, lens, ssa, esa, device=0))
+    full = build(1 << 16)
+    fi, fl = full.info(), full.layout_info()
+    assert fl.depth_mask_kept == 0x13 and all(fl.rec_bytes[d] > 0 for d in (0, 1, 4)) and fl.phi_slots > 0
+    top = int(fi.hbm_bytes)
+    full.close()
+    seen, picked = [], None
+    for frac in (0.95, 0.85, 0.75, 0.65, 0.55, 0.5, 0.45, 0.4, 0.35, 0.3):
+        budget_mb = max(1, int(top * frac) >> 20)
+        rb = build(budget_mb)
+        li, info = rb.layout_info(), rb.info()
+        kept = [d for d in range(8) if li.depth_mask_kept >> d & 1]
+        seen.append((frac, hex(li.depth_mask_kept), [d for d in kept if li.rec_bytes[d] > 0], int(info.hbm_bytes) >> 20, budget_mb))
+        assert int(info.hbm_bytes) <= (budget_mb + 2) << 20, seen
+        if li.depth_mask_kept == 0x11 and li.rec_bytes[0] > 0 and li.rec_bytes[4] > 0 and picked is None:
+            picked = rb
+            continue
+        rb.close()
+    assert picked is not None, seen     # the depth in between went while both ends kept their records
+    first = next(i for i, x in enumerate(seen) if x[1] == "0x11")
+    assert all(x[1] == "0x13" and x[2] == [0, 1, 4] for x in seen[:first]), seen   # until then: every depth kept, every depth with records
+    assert picked.info().kmer_steps == 5 and picked.layout_info().depths_dropped_budget == 0x02
+    o = orc.Oracle.from_runs(heads, lens, ssa, esa)
+    reads = _lf_walk_reads(o, heads, lens, n, rng, 400, 40) + [b"ACGT", b"N", b""]
+    seqs, off = ra.pack_reads(reads)
+    want = o.find_range_w_toehold_batch(seqs, off)
+    lo, hi = picked.find_range(seqs, off)
+    assert (lo == want[0]).all() and (hi == want[1]).all()
+    picked.close()
+    o.close()
+
+
 def test_run_indexed_layout_budget_leaves_middle_depths_out():
     """Over budget the run-indexed layout gives up the depths between the first and the deepest before the deepest
     itself (rbg_capi.hip upload): the step length stays, the space goes down, the answers stay.  (A synthetic run list of
