@@ -96,6 +96,10 @@ def parse():
                          "read batch per replica; the line's value / n_gpus / ms_per_step then describe the G replicas (weak scaling: --reads per replica). "
                          "The driver's N-GPU contract stays one process per GPU (--gpus N)")
     ap.add_argument("--replica-devices", default="", help="devices of --replicas, comma separated (default 0, 1, ...; may repeat)")
+    ap.add_argument("--no-pangenome-shape", action="store_true",
+                    help="skip the pangenome_shape block: BASELINE.json configs[3]'s index shape on one GPU (tools/pangenome_stream.py --preset driver in a "
+                         "child process once this process has given its HBM back: a true BWT of r = 1.2e8 runs, a default rbg_load, 150 bp device-generated "
+                         "reads, its own roofline and parity sample; about 50 s).  On by default on one GPU with the default workload, off under a launcher")
     ap.add_argument("--property-reads", type=int, default=1_000_000,
                     help="reads whose every reported location is checked against the text on the GPU (size-independent property)")
     return ap.parse_args()
@@ -104,6 +108,17 @@ def parse():
 def log(rank, *a):
     if rank == 0:
         print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+# What this rank is doing, for the post-mortem of a failed multi-GPU run: a rank that dies names its stage on stderr
+# (under rowbowt_amd/launch.py the parent then stops the others, which would otherwise wait in a collective for ever).
+STAGE = {"name": "start", "t0": time.time(), "rank": int(os.environ.get("RANK", "0")), "trace": os.environ.get("RBG_BENCH_TRACE", "") not in ("", "0")}
+
+
+def stage(name):
+    STAGE["name"] = name
+    if STAGE["trace"]:
+        print(f"[bench] rank {STAGE['rank']} +{time.time() - STAGE['t0']:.1f}s: {name}", file=sys.stderr, flush=True)
 
 
 def cpu_budget():
@@ -118,7 +133,7 @@ def cpu_budget():
     return max(1, n)
 
 
-def main():
+def run():
     args = parse()
     launch = load_launch()
     if not launch.under_launcher():
@@ -135,6 +150,14 @@ def main():
         return
     # the markers leg (BASELINE.json configs[4]) rides along on one GPU unless switched off
     args.markers = (args.markers or (world == 1 and "RANK" not in os.environ)) and not args.no_markers
+    if args.replicas and world > 1:
+        raise SystemExit("--replicas (one process, G replicas) and --gpus N (one process per GPU) are two ways to use several GPUs: pick one")
+    if args.replicas and not args.no_space_speed:
+        # (the space_speed block rebuilds the replica in other forms; the --replicas leg replicates and scales the HEADLINE replica)
+        args.no_space_speed = True
+        log(rank, "--replicas: skipping the space_speed block so that the replicated index is the headline replica")
+    STAGE["rank"] = rank
+    stage("import torch")
     import torch
     import torch.distributed as dist
 
@@ -152,6 +175,8 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
+        stage(f"init_process_group ({'gloo' if args.rehearse_ranks else 'nccl = RCCL'}, world {world}, device {local_rank}, "
+              f"{os.environ['MASTER_ADDR']}:{os.environ['MASTER_PORT']})")
         if args.rehearse_ranks:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -160,6 +185,7 @@ def main():
             raise SystemExit(f"RCCL group has {dist.get_world_size()} ranks, --gpus asked for {args.gpus}")
         world = dist.get_world_size()   # n_gpus of the line = the group that was actually formed
 
+    stage("load librbg.so")
     import rowbowt_amd as ra
     from rowbowt_amd import shard
     from rowbowt_amd.tools import synth_pangenome as sp
@@ -183,6 +209,7 @@ def main():
 
     # ---- synthesis (outside the timed region) --------------------------------------------------
     t0 = time.time()
+    stage("synthesise the text")
     text, info = sp.make_text(args.L, args.H, args.site_rate, args.seed, dev)   # (every rank: its reads are sampled from it)
     # The index is made ONCE per node: rank 0 builds the suffix array and the run-length BWT and writes the native cache
     # file (rbg_convert_runs) to node-local shared memory; every rank then loads its replica from it (rbg_load_cache).
@@ -190,8 +217,9 @@ def main():
     if world > 1 or args.via_cache:
         shm = "/dev/shm" if os.path.isdir("/dev/shm") else (os.environ.get("TMPDIR") or "/tmp")
         cache_path = os.path.join(shm, f"rbg_bench_{os.environ.get('MASTER_PORT', '0')}_{args.L}_{args.H}_{args.seed}.rbgpu")
-    inp, marker_arrays, t_sa = None, None, 0.0
+    inp, marker_arrays, t_sa, t_cache_write, cache_bytes = None, None, 0.0, 0.0, 0
     if rank == 0 or world == 1:
+        stage("suffix array + run-length BWT (rank 0)")
         sa = sp.suffix_array(text)
         torch.cuda.synchronize()
         t_sa = time.time() - t0
@@ -203,18 +231,30 @@ def main():
                   f"(suffix array {t_sa:.1f}s)")
         if cache_path:
             from rowbowt_amd import capi as _capi
+            stage(f"write the native cache file {cache_path} (rank 0)")
+            tc = time.time()
             _capi.convert_runs(inp["heads"], inp["lens"], inp["ssa"], inp["esa"], out_path=cache_path)
-    t0 = time.time()
+            t_cache_write, cache_bytes = time.time() - tc, os.path.getsize(cache_path)
+    t_wait = time.time()
     if cache_path:
         if use_dist:
+            stage("barrier: wait for rank 0's cache file")
             dist.barrier()   # the file is complete
+        t0 = time.time()
+        stage(f"rbg_load_cache({cache_path}) on device {local_rank}")
         rb = ra.RowBowt.from_cache(cache_path, ra.LoadRbwtFlag.SA, device=local_rank)
+        t_load = time.time() - t0
         if use_dist:
+            stage("barrier: every rank has read the cache file")
             dist.barrier()   # every rank has read it
         if rank == 0:
             os.unlink(cache_path)
     else:
+        t0 = time.time()
+        stage(f"rbg_build_from_runs on device {local_rank}")
         rb = ra.RowBowt.from_runs(inp["heads"], inp["lens"], inp["ssa"], inp["esa"], device=local_rank)
+        t_load = time.time() - t0
+    t_wait = t0 - t_wait   # (ranks > 0: the time spent waiting for rank 0's suffix array and cache file)
     ix = rb.info()
     if inp is None:   # (ranks > 0: what the line's config block and the checks need is on rank 0 only)
         inp = {"n": int(ix.n), "r": int(ix.r)}
@@ -225,6 +265,7 @@ def main():
     # shard_bounds() gives it and synthesises exactly those reads
     gb, ge = shard.shard_bounds(args.reads * world, rank, world)
     N = ge - gb
+    stage("sample this rank's reads")
     reads, _ = sp.sample_reads(text, info, N, m, seed=args.seed + 2 + rank, sub_rate=0.1)
     torch.cuda.empty_cache()
     d_seqs = reads.reshape(-1)
@@ -254,6 +295,7 @@ def main():
                                   d_tmp.data_ptr(), tmp_bytes, st), "locate_plan")
 
     # size the ragged output once (same reads every step => same total)
+    stage("first launch of the hot path (sizes the ragged output)")
     k_toehold()
     k_plan()
     total_locs = int(d_loc_off[-1].item())
@@ -292,6 +334,7 @@ def main():
         return time.perf_counter() - t
 
     # ---- count+locate (headline) ---------------------------------------------------------------
+    stage("warmup + the timed steps (barrier on both sides)")
     for _ in range(args.warmup):
         step()
     K = args.steps
@@ -317,6 +360,7 @@ def main():
     ms_fill = float(np.mean([ev[s][4].elapsed_time(ev[s][3]) for s in range(K)]))
 
     # ---- count-only (configs[1]) ---------------------------------------------------------------
+    stage("count-only steps")
     for _ in range(max(1, args.warmup)):
         k_count()
     evc = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(K)]
@@ -407,6 +451,7 @@ def main():
 
     # ---- markers path (BASELINE.json configs[4], rb_align -m: rb_align.cpp:133-143), optional ------
     mk_block = None
+    stage("capped / u32 / markers legs")
     if args.markers:
         rb.set_markers(*marker_arrays)
         d_mk_off = torch.empty(N + 1, dtype=torch.int64, device=dev)
@@ -528,11 +573,24 @@ def main():
     rb.counters_reset()
 
     # max over ranks, counters over RCCL
+    stage("all_reduce(MAX) of the times, all_reduce(SUM) of the counters")
+    el_own = el
     t_el = torch.tensor([el, el_count, el_pipe], dtype=torch.float64, device=cdev)
     if use_dist:
         dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
     el, el_count, el_pipe = float(t_el[0].item()), float(t_el[1].item()), float(t_el[2].item())
     g_counters = shard.reduce_counters(counters, device=cdev)  # the only collective of the run: 4 x u64 over RCCL
+    # what a post-mortem of a multi-GPU run needs, per rank (outside the timed region; an all_gather of eight doubles)
+    stage("all_gather of the per-rank diagnostics")
+    mine = torch.tensor([rank, local_rank, t_load, t_wait, el_own / K * 1e3, ms_toe, ms_fill, float(ix.hbm_bytes)], dtype=torch.float64, device=cdev)
+    if use_dist:
+        rows_t = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(rows_t, mine)
+    else:
+        rows_t = [mine]
+    per_rank = [{"rank": int(r_[0].item()), "device": int(r_[1].item()), "load_s": float(r_[2].item()), "wait_for_rank0_s": float(r_[3].item()),
+                 "ms_per_step": float(r_[4].item()), "k2_ms": float(r_[5].item()), "k3_ms": float(r_[6].item()), "hbm_bytes": int(r_[7].item())} for r_ in rows_t]
+    ranks_seen = len({r_["rank"] for r_ in per_rank})
 
     out = None
     if rank == 0:
@@ -655,6 +713,12 @@ def main():
                            "workload": "BASELINE.json configs[1]: find_range only"},
             "counters": {"reads": g_counters[0], "matched": g_counters[1], "sum_occ": g_counters[2], "sum_locs": g_counters[3],
                          "reduced_over": (f"{'gloo (rehearsal)' if args.rehearse_ranks else 'RCCL'} all_reduce over {world} rank(s)" if use_dist else "single GPU (no process group)")},
+            # the multi-GPU run's post-mortem block: who ran where, how long each rank loaded / waited / stepped, what the one-per-node cache cost
+            "per_rank": per_rank,
+            "rccl_ranks_seen": ranks_seen,
+            "collective_backend": ("gloo (rehearsal)" if args.rehearse_ranks else "nccl (RCCL)") if use_dist else None,
+            "cache_write_s": t_cache_write if cache_path else None, "cache_bytes": cache_bytes if cache_path else None,
+            "cache_path": cache_path, "suffix_array_s": t_sa,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "alg_bytes_per_launch": kernels[dom]["alg_bytes"], "kernel_ms": kernels[dom]["ms"],
@@ -691,6 +755,7 @@ def main():
     # first --property-reads reads really is an occurrence, locations of a read are distinct and
     # their number equals hi-lo+1; unmatched reads report {1,0}
     if rank == 0 and args.property_reads > 0:
+        stage("full-size properties (rank 0)")
         step()
         torch.cuda.synchronize()
         npr = min(args.property_reads, N)
@@ -715,12 +780,14 @@ def main():
         if not (ok_match and ok_distinct and ok_occ and ok_empty):
             print(json.dumps(out))
             raise SystemExit("PROPERTY FAILURE at full size")
-    text_for_replicas = text if args.replicas else None   # (the --replicas leg samples each replica's batch from it)
+    text_for_replicas = text if args.replicas else None   # (the --replicas leg samples each replica's batch from it; that leg skips the space_speed rebuilds, so the
+    #                                                          text is not resident beside a 221 GB replica)
     del text
     torch.cuda.empty_cache()
 
     # ---- parity sample + CPU baseline (rank 0, N=1 only; never part of the timed region) ------
     if rank == 0 and not (args.no_cpu_baseline and args.check_reads == 0):
+        stage("oracle parity sample + cpu_baseline (rank 0)")
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import orc  # oracle: checker + cpu_baseline only
 
@@ -854,6 +921,7 @@ def main():
     # per gather.  The headline ran at the deepest level that fitted; these rows say what the
     # same call costs on a device with less free HBM.
     if rank == 0 and world == 1 and not args.no_space_speed:
+        stage("space_speed block")
         from rowbowt_amd import capi
 
         def time_search():
@@ -1189,7 +1257,12 @@ def main():
         same_all = all(ln.same for ln in lanes[1:])
         steps_counted = K + max(1, args.warmup)
         out["replicas_one_process"] = {
-            "formed": G, "devices": devs, "replicate_s": t_rep, "value": G * N * K / el_r, "unit": "reads/s", "ms_per_step": el_r / K * 1e3,
+            "formed": G, "devices": devs, "replicate_s": t_rep,
+            # what was replicated (the headline replica: --replicas skips the space_speed rebuilds) and what each target's peer copies cost
+            "replicated": {"layout": "runs" if int(rb.info().rank_layout) == 2 else "slots", "hbm_bytes": int(rb.info().hbm_bytes), "is_the_headline_replica": True},
+            "peer_copies": [{"device": devs[g], **reps[g].replicate_stats()} for g in range(1, G)],
+            "fan_out_GBps": (sum(int(r_.info().hbm_bytes) for r_ in reps[1:]) / t_rep / 1e9) if G > 1 and t_rep > 0 else None,
+            "value": G * N * K / el_r, "unit": "reads/s", "ms_per_step": el_r / K * 1e3,
             "per_replica_ms_per_step": [(ln.t1 - ln.t0) / K * 1e3 for ln in lanes], "locations_per_step": [ln.total for ln in lanes],
             "every_copy_identical_to_the_primary_on_its_batch": same_all,
             "counters": {"reads": rc_[0], "matched": rc_[1], "sum_occ": rc_[2], "sum_locs": rc_[3], "reduced_over": how,
@@ -1206,13 +1279,66 @@ def main():
         for r_ in reps[1:]:
             r_.close()
 
+    rb.close()
+    return out, dict(rank=rank, world=world, use_dist=use_dist, args=args, dev=dev)
+
+
+def pangenome_shape_block(args, dev):
+    """BASELINE.json configs[3]'s index (r >= 1e8, positions beyond 32 bits, 150 bp reads made on the device) on this one GPU, through a DEFAULT
+    rbg_load in a fresh child process (tools/pangenome_stream.py --preset driver), started once run() has returned and with it every buffer and
+    the replica of the headline.  Not part of `value`: its own reads/s, kernel times, roofline, layout decisions and parity sample."""
+    import gc
+    import subprocess
+
+    import torch
+    gc.collect()
+    torch.cuda.empty_cache()
+    free_now, _t = torch.cuda.mem_get_info(dev)
+    env_pg = {k: v for k, v in os.environ.items() if not k.startswith("RBG_")}
+    t0 = time.time()
+    pg = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pangenome_stream.py"), "--preset", "driver"], capture_output=True, text=True, env=env_pg, cwd=ROOT)
+    blk = {"seconds_for_the_block": time.time() - t0, "hbm_free_when_started": int(free_now),
+           "command": "python tools/pangenome_stream.py --preset driver   (a child process: a default rbg_load in a fresh process)"}
+    try:
+        pj = json.loads(pg.stdout.strip().splitlines()[-1])
+        blk.update({"value": pj["value"], "unit": pj["unit"], "metric": pj["metric"], "value_excluding_read_generation": pj["value_excluding_read_generation"],
+                    "kernel_ms_one_batch": pj["kernel_ms_one_batch"], "search_touched_per_read": pj["search_touched_per_read"], "roofline": pj["roofline"],
+                    "index": pj["config"]["index"], "workload": pj["config"]["workload"], "reads_per_batch": pj["reads_per_batch"], "batches": pj["batches_per_gpu"],
+                    "counters": pj["counters"], "parity": pj.get("parity"), "properties": pj.get("properties"), "peaks": pj.get("peaks")})
+    except Exception as e:   # noqa: BLE001
+        blk["error"] = f"{type(e).__name__}: {e}; rc {pg.returncode}; stderr tail: {pg.stderr[-1500:]}"
+    if pg.returncode != 0 and "error" not in blk:
+        blk["error"] = f"rc {pg.returncode}; stderr tail: {pg.stderr[-1500:]}"
+    return blk
+
+
+def main():
+    res = run()
+    if res is None:
+        return
+    out, c = res
+    args, rank, world, use_dist = c["args"], c["rank"], c["world"], c["use_dist"]
+    default_workload = (args.L, args.H, args.reads, args.read_len, args.site_rate) == (40_000_000, 50, 10_000_000, 100, 0.01)
+    if rank == 0 and world == 1 and not use_dist and default_workload and not args.no_pangenome_shape and not args.replicas:
+        stage("pangenome_shape block (child process)")
+        out["pangenome_shape"] = pangenome_shape_block(args, c["dev"])
+        if "error" in out["pangenome_shape"]:
+            print(json.dumps(out))
+            raise SystemExit("pangenome_shape block failed: " + out["pangenome_shape"]["error"])
     if rank == 0:
         print(json.dumps(out), flush=True)
-    rb.close()
     if use_dist:
+        import torch.distributed as dist
+        stage("final barrier")
         dist.barrier()
         dist.destroy_process_group()
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except BaseException as e:   # noqa: BLE001
+        if not (isinstance(e, SystemExit) and e.code in (0, None)):
+            print(f"[bench] rank {STAGE['rank']} (pid {os.getpid()}, LOCAL_RANK {os.environ.get('LOCAL_RANK', '-')}) FAILED at stage "
+                  f"'{STAGE['name']}' after {time.time() - STAGE['t0']:.1f}s: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+        raise

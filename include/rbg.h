@@ -410,6 +410,10 @@ int rbg_replicate(rbg_index *primary, int device, rbg_index **replica_out);
  * transfers overlap -- each MI355X has its own xGMI link to the primary, the fan-out takes about one copy's time.
  * All or nothing: on failure no replica is left behind.  devices[] may repeat (tests put several on one device). */
 int rbg_replicate_many(rbg_index *primary, const int *devices, int G, rbg_index **replicas_out /* [G] */);
+/* What the fan-out cost one replica (measurement plumbing of the multi-GPU start, SURVEY 8e's "one-time distribution by parallel
+ * peer copies"; the reference has no counterpart): out = {milliseconds its copies took on its own stream (HIP events), bytes
+ * copied, peer access to the primary's device (1 = direct, 0 = staged through the host by the runtime, -1 = same device)}. */
+int rbg_replicate_stats(const rbg_index *replica, double out[3]);
 /* contiguous block [begin, end) of `rank` out of `world` (sizes differ by at most one; concatenating the ranks'
  * outputs restores the input order): read i of N goes to rank i * world / N */
 int rbg_shard_bounds(uint64_t n_items, int rank, int world, uint64_t *begin, uint64_t *end);

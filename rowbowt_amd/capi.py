@@ -131,6 +131,7 @@ _PROTOS = [
     ("rbg_sample_reads_pangenome_dev", C.c_int, [VP, VP, VP, VP, U64, VP, C.c_uint32, U64, U64, U64, U64, U64, U64, U64, C.c_uint32, VP, VP, VP, VP]),
     ("rbg_replicate", C.c_int, [VP, C.c_int, C.POINTER(VP)]),
     ("rbg_replicate_many", C.c_int, [VP, C.POINTER(C.c_int), C.c_int, C.POINTER(VP)]),
+    ("rbg_replicate_stats", C.c_int, [VP, C.POINTER(C.c_double)]),
     ("rbg_comm_cache_clear", C.c_int, []),
     ("rbg_shard_bounds", C.c_int, [U64, C.c_int, C.c_int, C.POINTER(U64), C.POINTER(U64)]),
     ("rbg_find_range_sharded", C.c_int, [VP, C.c_int, VP, VP, U64, VP, VP, VP]),
@@ -503,6 +504,14 @@ class RowBowt:
             r._primary = self
             out.append(r)
         return out
+
+    def replicate_stats(self):
+        """a replica's share of the fan-out: {ms of its peer copies, bytes, GB/s, peer access}"""
+        out = (C.c_double * 3)()
+        _check(self.L.rbg_replicate_stats(self.h, out), "rbg_replicate_stats")
+        ms, nbytes, peer = float(out[0]), int(out[1]), int(out[2])
+        return {"copy_ms": ms, "bytes": nbytes, "GBps": (nbytes / (ms * 1e-3) / 1e9) if ms > 0 else None,
+                "peer_access": {1: "direct", 0: "staged through the host", -1: "same device"}[peer]}
 
     def counters_reset(self):
         _check(self.L.rbg_counters_reset(self.h), "rbg_counters_reset")

@@ -32,6 +32,8 @@ struct rbg_index {
     uint64_t rank_slots = 0, rank_slots_overflow = 0, phi_slots = 0, phi_slots_overflow = 0;
     uint64_t kmer_steps_requested = 0, hbm_free_at_load = 0, hbm_budget = 0;  // how the space/speed point was chosen (rbg_info)
     bool runs_layout = false;
+    double replicate_ms = 0.0;     // replica handle: duration of its peer copies on its own stream (HIP events; rbg_replicate_stats)
+    int replicate_peer = -1;       // replica handle: 1 = peer access to the source's device was enabled, 0 = the runtime stages the copy, -1 = same device / primary
     uint64_t plan_free = 0, plan_budget = 0;   // free HBM and replica budget as options_for() saw them BEFORE anything of this load was on the device (0: not taken)
     bool budget_raised = false;                // RBG_LAYOUT_AUTO raised the default budget from a quarter to three quarters of the free HBM (an index too large for the quarter)
     bool auto_runs = false;        // RBG_LAYOUT_AUTO chose the run-indexed layout because the slot tables of every requested symbol per step exceed the budget

@@ -294,7 +294,15 @@ FlattenOptions options_for(int device, const RawRle &rle, uint64_t *requested, b
     FlattenOptions o = current_options();
     *requested = 0;
     *auto_runs = false;
-    if (device == RBG_DEVICE_NONE || o.kmer_steps < 2) return o;
+    // A host-only handle (conversion, cache writing, tests) answers no query -- the library has no CPU search path -- so nothing reads k-mer
+    // tables there: compose none (eight depths on the host cost 3 GB and a second per 3e6 runs, hundreds of GB at pangenome r: ADVICE r5).
+    // (RBG_HOST_COMPOSE=1 keeps the host composition -- the serial reference statement of k_compose.hip -- reachable without a device: tests)
+    if (device == RBG_DEVICE_NONE) {
+        const char *e = std::getenv("RBG_HOST_COMPOSE");
+        if (!(e && e[0] == '1')) o.kmer_steps = 1;
+        return o;
+    }
+    if (o.kmer_steps < 2) return o;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return o;
     DeviceScope scope(device);

@@ -11,6 +11,7 @@ namespace {
 struct ReplicaJob {
     rbg_index *r = nullptr;
     hipStream_t st = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;   // around the job's copies on its stream: the per-target duration (rbg_replicate_stats)
     Reloc reloc;
 };
 
@@ -46,8 +47,14 @@ int replicate_begin(rbg_index *src, int device, ReplicaJob &job) {
         (void)hipDeviceCanAccessPeer(&can, device, src->device);
         if (can) (void)hipDeviceEnablePeerAccess(src->device, 0);  // already enabled is fine
         (void)hipGetLastError();
+        r->replicate_peer = can ? 1 : 0;
+        if (!can)   // (still correct: hipMemcpyPeerAsync stages through the host; said so that a slow fan-out has its reason on stderr)
+            std::fprintf(stderr, "rbg: device %d has no peer access to device %d: the replica's %.1f GB are copied through the host\n", device, src->device, src->hbm_bytes / 1e9);
     }
     HIP_TRY(hipStreamCreateWithFlags(&job.st, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&job.ev0));
+    HIP_TRY(hipEventCreate(&job.ev1));
+    HIP_TRY(hipEventRecord(job.ev0, job.st));
     for (const DevAlloc &a : src->allocs) {
         void *p = nullptr;
         hipError_t e = hipMalloc(&p, a.bytes);
@@ -63,6 +70,7 @@ int replicate_begin(rbg_index *src, int device, ReplicaJob &job) {
         job.reloc.from.push_back(a);
         job.reloc.to.push_back({p, a.bytes});
     }
+    HIP_TRY(hipEventRecord(job.ev1, job.st));
     return RBG_OK;
 }
 
@@ -72,7 +80,12 @@ int replicate_finish(rbg_index *src, ReplicaJob &job) {
     const Reloc &reloc = job.reloc;
     DeviceScope scope(r->device);
     if (scope.rc) return scope.rc;
-    HIP_TRY(hipStreamSynchronize(job.st));
+    if (hipError_t e = hipStreamSynchronize(job.st); e != hipSuccess) {
+        std::fprintf(stderr, "rbg: the peer copies of the replica to device %d (from device %d) failed: %s\n", r->device, src->device, hipGetErrorString(e));
+        return RBG_ENODEV;
+    }
+    float ms = 0.f;
+    if (job.ev0 && job.ev1 && hipEventElapsedTime(&ms, job.ev0, job.ev1) == hipSuccess) r->replicate_ms = ms;
     for (const PtrTable &t : src->ptr_tables) {
         std::vector<char> buf(t.count * t.stride);
         void *dst = const_cast<void *>(reloc(t.d_ptr));
@@ -131,6 +144,8 @@ int rbg_replicate_many(rbg_index *src, const int *devices, int G, rbg_index **ou
         if (jobs[g].st) {
             DeviceScope scope(jobs[g].r->device);
             (void)hipStreamDestroy(jobs[g].st);
+            if (jobs[g].ev0) (void)hipEventDestroy(jobs[g].ev0);
+            if (jobs[g].ev1) (void)hipEventDestroy(jobs[g].ev1);
         }
     }
     if (rc) {
@@ -141,6 +156,16 @@ int rbg_replicate_many(rbg_index *src, const int *devices, int G, rbg_index **ou
     for (int g = 0; g < G; ++g) out[g] = jobs[g].r;
     return RBG_OK;
     });
+}
+
+// What the fan-out cost THIS replica: out = {milliseconds of its copies on its own stream, bytes copied, peer access (1 / 0; -1: same device)}.
+int rbg_replicate_stats(const rbg_index *replica, double out[3]) {
+    if (!replica || !out) return RBG_EARG;
+    if (!replica->primary) return RBG_EARG;   // a primary was built, not copied
+    out[0] = replica->replicate_ms;
+    out[1] = static_cast<double>(replica->hbm_bytes);
+    out[2] = replica->replicate_peer;
+    return RBG_OK;
 }
 
 int rbg_replicate(rbg_index *src, int device, rbg_index **out) {
@@ -321,7 +346,10 @@ int rbg_counters_allreduce_local(rbg_index *const *replicas, int G, uint64_t out
     auto it = cc.cliques.find(devs);
     if (it == cc.cliques.end()) {
         std::vector<ncclComm_t> fresh(G);
-        if (nc.CommInitAll(fresh.data(), G, devs.data()) != ncclSuccess) return RBG_ENODEV;
+        if (ncclResult_t e = nc.CommInitAll(fresh.data(), G, devs.data()); e != ncclSuccess) {
+            std::fprintf(stderr, "rbg: ncclCommInitAll over %d devices failed (ncclResult %d): no counters clique\n", G, static_cast<int>(e));
+            return RBG_ENODEV;
+        }
         it = cc.cliques.emplace(devs, std::move(fresh)).first;
     }
     const std::vector<ncclComm_t> &comms = it->second;
@@ -335,9 +363,15 @@ int rbg_counters_allreduce_local(rbg_index *const *replicas, int G, uint64_t out
         (void)nc.GroupStart();
         for (int g = 0; g < G; ++g) {
             DeviceScope scope(devs[g]);
-            if (nc.AllReduce(replicas[g]->dev.counters, sums[g], 4, ncclUint64, ncclSum, comms[g], nullptr) != ncclSuccess) rc = RBG_ENODEV;
+            if (ncclResult_t e = nc.AllReduce(replicas[g]->dev.counters, sums[g], 4, ncclUint64, ncclSum, comms[g], nullptr); e != ncclSuccess) {
+                std::fprintf(stderr, "rbg: ncclAllReduce of the counters on device %d failed (ncclResult %d)\n", devs[g], static_cast<int>(e));
+                rc = RBG_ENODEV;
+            }
         }
-        if (nc.GroupEnd() != ncclSuccess) rc = RBG_ENODEV;
+        if (ncclResult_t e = nc.GroupEnd(); e != ncclSuccess) {
+            std::fprintf(stderr, "rbg: ncclGroupEnd of the counters' all-reduce over %d devices failed (ncclResult %d)\n", G, static_cast<int>(e));
+            rc = RBG_ENODEV;
+        }
     }
     for (int g = 0; g < G; ++g) {
         DeviceScope scope(devs[g]);

@@ -375,7 +375,7 @@ int launch_find_range_runs_impl(const DevIndex &ix, const LaunchCfg &cfg, const 
 #define RBG_LAUNCH_FRR1(PT, TOE, PK, STS, GL)                                                          \
     do {                                                                                               \
         auto kern = k_find_range_runs<PT, TOE, PK, STS, GL>;                                           \
-        raise_lds(kern, lds + (GL ? 8 * kTileBytes : 0));                                              \
+        raise_lds(kern, lds, GL ? 8 * kTileBytes : 0);                                                \
         hipLaunchKernelGGL(kern, grid, block, lds, st, ix, src_a, src_b, N, lo, hi, ssamp, stats, sel, nsel);     \
     } while (0)
 #define RBG_LAUNCH_FRR(PT, TOE, PK, STS)                                                               \

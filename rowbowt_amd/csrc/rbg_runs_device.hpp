@@ -5,6 +5,8 @@
 // Everything lives in an anonymous namespace: each unit gets its own inlined copy.
 #pragma once
 
+#include <map>
+
 #include "rbg_device.hpp"
 
 namespace rbg {
@@ -16,16 +18,24 @@ __device__ __forceinline__ void wave_lds_sync() {  // as in k_locate.hip: orders
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// `bytes` = the launch's DYNAMIC LDS (what the attribute limits); `static_bytes` = the kernel's static __shared__ arrays, which count
+// towards the 48 KB a kernel gets without asking but are not part of the attribute's value
 template <typename Kernel>
-void raise_lds(Kernel kernel, size_t bytes) {
-    if (bytes <= 48 * 1024) return;
+void raise_lds(Kernel kernel, size_t bytes, size_t static_bytes = 0) {
+    if (bytes + static_bytes <= 48 * 1024) return;
     static std::mutex mu;
-    static std::set<std::pair<int, const void *>> raised;
+    static std::map<std::pair<int, const void *>, size_t> raised;   // the largest size raised so far per (device, kernel)
     int dev = 0;
     (void)hipGetDevice(&dev);
     const auto key = std::make_pair(dev, reinterpret_cast<const void *>(kernel));
     std::lock_guard<std::mutex> g(mu);
-    if (raised.insert(key).second) (void)hipFuncSetAttribute(key.second, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+    size_t &have = raised[key];
+    if (bytes <= have) return;
+    // (a later index on the same device may need more than the first one did: raise again, and say so when the runtime refuses --
+    //  the launch that follows would fail with an unrelated-looking error)
+    const hipError_t e = hipFuncSetAttribute(key.second, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+    if (e == hipSuccess) have = bytes;
+    else std::fprintf(stderr, "rbg: raising a kernel's dynamic LDS limit to %zu bytes failed: %s\n", bytes, hipGetErrorString(e));
 }
 
 // the record of the step that consumes the k-mer `acc` (read as a base-nmajor number, least significant digit = the

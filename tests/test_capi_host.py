@@ -66,9 +66,16 @@ def test_loader_matches_oracle_reader(small_host, small_orc):
     assert i.marker_runs == 190 and i.marker_vals == 190
 
 
-def test_two_step_tables_built(small_host):
+def test_two_step_tables_built(small_host, data_dir, monkeypatch):
+    # a host-only handle answers no query, so by default it composes no k-mer table (eight depths on the host cost
+    # hundreds of GB at pangenome r for tables nothing reads) ...
     i = small_host.info()
-    assert i.kmer_steps == 8 and i.kmer_symbols == 4   # (RBG_OPT_KMER_STEPS defaults to 8; a host-only index composes them all)
+    assert i.kmer_steps == 1 and list(i.depth_runs)[1:] == [0] * 7
+    # ... RBG_HOST_COMPOSE=1 keeps the host composition (the serial statement of k_compose.hip) reachable without a device
+    monkeypatch.setenv("RBG_HOST_COMPOSE", "1")
+    rb = ra.load_rowbowt(os.path.join(data_dir, "small.fa"), ra.LoadRbwtFlag.SA | ra.LoadRbwtFlag.MA, device=capi.DEVICE_NONE)
+    i = rb.info()
+    assert i.kmer_steps == 8 and i.kmer_symbols == 4   # (RBG_OPT_KMER_STEPS defaults to 8)
     assert 0 < i.pair_runs <= 2 * i.r and i.pair_runs <= i.triple_runs <= 3 * i.r and i.triple_runs <= i.quad_runs <= 4 * i.r
     assert i.quad_runs <= i.quint_runs <= 5 * i.r
     runs = list(i.depth_runs)

@@ -320,7 +320,7 @@ def test_full_size_properties_and_parity_sample():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
-                        "--check-reads", "5000", "--property-reads", "300000", "--markers"],
+                        "--check-reads", "5000", "--property-reads", "300000", "--markers", "--no-pangenome-shape"],   # (that block is the test below)
                        capture_output=True, timeout=1500, cwd=root)
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     d = json.loads(p.stdout.decode().strip().splitlines()[-1])
@@ -372,6 +372,44 @@ def test_pangenome_stream_true_bwt_beyond_32_bits(layout):
         assert (li["rank_directories"] == 1) != (sum(li["rec_bytes"]) > 0)   # ranks: directories over the run lists, or bucket records
         assert (li["phi_directory"] == 1) != (li["phi_slots"] > 0)      # phi: the list of sampled positions with its directory, or slots of about n / r rows
     print(f"n = {ix['n']:.3e}, {layout}: {d['value']:.3e} reads/s streamed, {ix['hbm_bytes'] / 1e9:.1f} GB replica")
+
+
+def test_pangenome_shape_r_above_1e8_default_load():
+    """BASELINE.json configs[3]'s INDEX at its named scale (r >= 1e8) under the driver's own test run: `tools/pangenome_stream.py --preset driver`
+    = a true BWT of n = 2.0e10 symbols (L = 1e8, H = 200; rle_string.hpp:131-161 / toehold_sa.hpp:56-72 are the structures being scaled),
+    a DEFAULT rbg_load -- no option, no budget, no RBG_* variable --, five batches of 10 M x 150 bp reads generated on the device.  Ranges,
+    toeholds (above 2^32 among them), locations and the count-only kernel bit-exact against the oracle on 2 000 reads; the size-independent
+    properties on 100 000; and what the load-time budget rules decided (rbg_layout_info), so that a rule edit shows here and not only in a
+    builder-side full-size run."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if not k.startswith("RBG_")}
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "pangenome_stream.py"), "--preset", "driver"], capture_output=True, timeout=1200, cwd=root, env=env)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    d = json.loads(p.stdout.decode().strip().splitlines()[-1])
+    ix = d["config"]["index"]
+    assert ix["default_load"] is True and ix["true_bwt"] and ix["r"] >= 100_000_000 and ix["n"] > 19_000_000_000 and ix["pos_bytes"] == 8
+    # the rules: beyond toy sizes a default load builds the run-indexed layout within a quarter of the free HBM (no raise at this r),
+    # eight symbols per step, depth 1 and the deepest kept with bucket records on every kept depth, phi slots
+    li = ix["layout_info"]
+    assert ix["rank_layout"] == 2 and li["run_fmt"] == 2 and li["budget_raised"] == 0
+    assert ix["hbm_bytes"] <= ix["hbm_budget"] <= ix["hbm_free_at_load"] // 4 + (1 << 20)
+    assert ix["symbols_per_gather"] == 8 and 1 in li["depths_kept"] and 8 in li["depths_kept"]
+    assert li["depths_with_records"] == li["depths_kept"] and li["rank_directories"] == 0 and li["phi_slots"] > 0 and li["phi_directory"] == 0
+    par = d["parity"]
+    assert par["reads_checked"] == 2000 and par["bit_exact_vs_oracle"] and par["count_only_kernel_bit_exact"]
+    assert par["toeholds_above_2^32"] > 100 and par["locs_checked"] > 100_000
+    props = d["properties"]
+    assert props["reads"] == 100000 and props["locations"] > 5_000_000
+    assert all(props[k] for k in ("unmutated_reads_all_found", "empty_is_{1,0}", "every_location_is_an_occurrence", "locations_distinct",
+                                  "occ_equals_range_width", "own_position_reported"))
+    c = d["counters"]
+    assert c["reads"] == 50_000_000 and c["sum_occ"] == c["sum_locs"] > 5_000_000_000
+    roof = d["roofline"]
+    assert roof["bound"] == "hbm" and 0 < roof["frac"] < 1 and set(roof["kernels"]) == {"find_range_w_toehold", "locate_fill"}
+    assert d["search_touched_per_read"]["searched_ranks"] < 0.5      # records: (almost) no narrowing rounds
+    print(f"n = {ix['n']:.3e}, r = {ix['r']:.3e}: {d['value']:.3e} reads/s streamed from a {ix['hbm_bytes'] / 1e9:.1f} GB default replica; "
+          f"K2 {d['kernel_ms_one_batch']['find_range_w_toehold']:.1f} ms, K3 {d['kernel_ms_one_batch']['locate_fill']:.1f} ms per 10 M reads")
 
 
 def test_bench_replicas_flag_three_replicas_on_device_0():

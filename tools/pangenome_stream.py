@@ -30,6 +30,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 MAXU = 2**64 - 1
+# --preset driver (explicit options of the same command line do not override it: one definition for bench.py and the test)
+PRESET_DRIVER = dict(L=100_000_000, H=200, site_rate=0.01, read_len=150, reads=10_000_000, total_reads=50_000_000, check_reads=2000,
+                     property_reads=100_000, hbm_reserve_gb=0.0, implicit_text="on", layout="auto", count_only=False)
 
 
 def main():
@@ -71,7 +74,14 @@ def main():
                     help="ONE process: the index is built once, rbg_replicate_many copies it to the other devices, one host thread per replica streams "
                          "its rbg_shard_bounds block on its own stream with its own read generator; host memory does not depend on the count")
     ap.add_argument("--replica-devices", default="", help="devices of --replicas, comma separated (default: 0, 1, ...; may repeat: tests put several on one GPU)")
+    ap.add_argument("--preset", choices=("driver",), default=None,
+                    help="driver: BASELINE.json configs[3]'s index shape at the size the driver's own runs carry (bench.py's pangenome_shape block and "
+                         "tests/test_gpu_scale.py): a true BWT of r >= 1e8 runs (L = 1e8, H = 200: n = 2.0e10), a DEFAULT rbg_load (no option, no budget), "
+                         "5 batches of 10 M x 150 bp device-generated reads, 2 000 reads against the oracle, the properties on 100 000")
     args = ap.parse_args()
+    if args.preset == "driver":
+        for k_, v_ in PRESET_DRIVER.items():
+            setattr(args, k_, v_)
     if args.replicas and args.gpus > 1:
         raise SystemExit("--replicas (one process) and --gpus N (one process per GPU) are two ways to use several GPUs: pick one")
     import importlib.util
@@ -205,6 +215,9 @@ def main():
         capi.set_default_option(capi.OPT_RUN_REC_DEPTHS, args.run_rec_depths)
     if args.kmer_steps:
         capi.set_default_option(capi.OPT_KMER_STEPS, args.kmer_steps)
+    # a DEFAULT load: no option of the library set by this tool and none through the environment (what a drop-in caller's rbg_load gets)
+    default_load = (args.hbm_reserve_gb <= 0 and args.ftab_k < 0 and args.layout == "auto" and not (args.run_depths or args.run_phi or args.run_rec or args.run_rec_depths or args.kmer_steps)
+                    and not any(k.startswith("RBG_") for k in os.environ))
     if args.hbm_reserve_gb > 0:
         free_b, _total = torch.cuda.mem_get_info(dev)
         capi.set_default_option(capi.OPT_HBM_BUDGET_MB, max(1024, int((free_b - args.hbm_reserve_gb * 1e9) / 2**20)))
@@ -368,7 +381,7 @@ def main():
             torch.cuda.synchronize(d)
 
     # per-kernel times of one batch (outside the timed region; HIP events on the launch stream)
-    kernel_ms, touched = {}, None
+    kernel_ms, touched, roof = {}, None, None
     if rank == 0:
         def timed(fn):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -402,6 +415,56 @@ def main():
         touched = dict(zip(("steps", "slots", "dense", "searched_ranks", "ftab", "resamples", "read_chunks", "symbols"), (d_stats.cpu().numpy()[:8] / N).round(3).tolist()))
         log("one batch, per read: " + ", ".join(f"{k} {v}" for k, v in touched.items()) +
             "   (run-indexed layout: slots = bucket records or directory gathers, dense = run-list entries scanned, searched_ranks = narrowing rounds)")
+        # ---- roofline of this index's own kernels (bench.py's byte model): bytes of the algorithm AS RUN, counted by the
+        # instrumented instantiations on this batch, over the HIP-event durations above, against the 8 TB/s HBM peak
+        sv = dict(zip(("steps", "slots", "dense", "searched_ranks", "ftab", "resamples", "read_chunks", "symbols"), d_stats.cpu().numpy().tolist()[:8]))
+        P_ = int(ix.pos_bytes)
+        li_ = rb.layout_info() if int(ix.rank_layout) == 2 else None
+        rec_on_ = bool(li_ and any(int(x) for x in li_.rec_bytes))
+        ftab_b = 16 if P_ == 4 else 32
+        if li_ is not None:
+            per_slot = 64 if rec_on_ else (16 if P_ == 8 else 8)
+            k2_bytes = (N * (16 + (16 if args.count_only else 24)) + 16 * sv["read_chunks"] + ftab_b * sv["ftab"] + per_slot * sv["slots"]
+                        + 8 * sv["dense"] + 28 * sv["searched_ranks"] + (4 if P_ == 4 else 6) * sv["resamples"])
+        else:
+            k2_bytes = (N * (16 + (16 if args.count_only else 24)) + 16 * sv["read_chunks"] + ftab_b * sv["ftab"] + 16 * sv["slots"]
+                        + 2 * sv["dense"] + (8 + 3 * 2 * P_) * sv["searched_ranks"] + (4 + P_) * sv["resamples"])
+        k2_name = "find_range" if args.count_only else "find_range_w_toehold"
+        roof = {"kernels": {k2_name: {"ms": kernel_ms[k2_name], "alg_bytes": int(k2_bytes)}}}
+        if not args.count_only:
+            d_stats.zero_()
+            chk(Lb.rbg_locate_fill_stats_dev(rb.h, d_lo.data_ptr(), d_hi.data_ptr(), d_k.data_ptr(), N, max_hits, d_loc_off.data_ptr(), ln0.d_locs.data_ptr(),
+                                             ln0.d_ws.data_ptr(), d_stats.data_ptr(), st), "locate_fill_stats")
+            torch.cuda.synchronize()
+            phi_slots_ = li_ is None or int(li_.phi_slots) > 0
+            lv = dict(zip(("phi_steps", "phi_searched" if phi_slots_ else "probe_entries", "chains", "locs"), d_stats.cpu().numpy().tolist()[:4]))
+            if phi_slots_:   # one PhiSlot per step (16 bytes packed while n < 2^38, else 4 x P), searched steps as on the slot layout
+                slot_b_ = 16 if (P_ == 4 or (int(ix.n) >> 38) == 0) else 32
+                k3_bytes = N * 28 + slot_b_ * lv["phi_steps"] + (8 + 3 * 2 * P_) * lv["phi_searched"] + 8 * lv["locs"]
+            else:
+                k3_bytes = N * 28 + (8 if P_ == 4 else 16) * lv["phi_steps"] + (8 if P_ == 4 else 12) * lv["probe_entries"] + 8 * lv["locs"]
+            roof["kernels"]["locate_fill"] = {"ms": kernel_ms["locate_fill"], "alg_bytes": int(k3_bytes), "touched": lv}
+        for kk, v in roof["kernels"].items():
+            v["alg_GBps"] = v["alg_bytes"] / (v["ms"] * 1e-3) / 1e9
+            v["frac_of_hbm_peak"] = v["alg_GBps"] / 8000.0
+        dom_ = max(roof["kernels"], key=lambda kk: roof["kernels"][kk]["ms"])
+        roof.update({"bound": "hbm", "kernel": dom_, "achieved": roof["kernels"][dom_]["alg_GBps"], "peak": 8000.0, "unit": "GB/s",
+                     "frac": roof["kernels"][dom_]["frac_of_hbm_peak"], "traffic": None,
+                     "note": "achieved = bytes of the algorithm as run (instrumented instantiation of the same kernel on one batch of this stream) / the "
+                             "kernel's duration by HIP events on the launch stream; traffic = counter bytes when profiles/pmc_traffic.json holds a pass of "
+                             "this workload taken with this librbg.so"})
+        try:   # counter traffic: only a committed pass of THIS library on THIS workload counts
+            import hashlib
+            so_hash = hashlib.sha256(open(os.path.join(ROOT, "rowbowt_amd", "librbg.so"), "rb").read()).hexdigest()
+            pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            ent = pj.get(f"pangenome_shape L={args.L} H={args.H} m={m}", {})
+            if pj.get("_librbg_sha256") == so_hash and dom_ in ent:
+                roof["traffic"] = ent[dom_].get("hbm_bytes_per_launch")
+                roof["tcc_miss_per_launch"] = ent[dom_].get("tcc_miss_per_launch")
+                roof["traffic_frac_of_hbm_peak"] = roof["traffic"] / (roof["kernels"][dom_]["ms"] * 1e-3) / 1e9 / 8000.0
+            roof["librbg_sha256"] = so_hash
+        except Exception:
+            pass
 
     # ---- identical per-read outputs on every replica (outside the timed region): the primary's first reads through each copy
     same_on_replicas = None
@@ -477,7 +540,7 @@ def main():
             "value": args.total_reads / el, "unit": "reads/s", "n_gpus": world * G if args.replicas else world, "higher_is_better": True, "scaling": "strong",
             "value_excluding_read_generation": args.total_reads / max(el - t_gen, 1e-9),
             "seconds": el, "seconds_generating_reads": t_gen, "batches_per_gpu": nbatch, "reads_per_batch": N,
-            "kernel_ms_one_batch": kernel_ms, "search_touched_per_read": touched,
+            "kernel_ms_one_batch": kernel_ms, "search_touched_per_read": touched, "roofline": roof,
             "dtype": "u64" if ix.pos_bytes == 8 else "u32/u64", "data": "synthetic",
             "config": {"workload": f"BASELINE.json configs[3] shape: {args.total_reads} synthetic {m} bp reads generated on the device per batch "
                                    f"(counter-based RNG), {'find_range' if args.count_only else 'find_range_w_toehold + locs_at'}, "
@@ -589,7 +652,10 @@ def main():
                                                  "entries": [int(x) for x in li.entries], "fillers": [int(x) for x in li.fillers], "dir_bytes": [int(x) for x in li.dir_bytes],
                                                  "phi_entries": int(li.phi_entries), "phi_fillers": int(li.phi_fillers), "phi_dir_bytes": int(li.phi_dir_bytes),
                                                  "phi_dir_shift": int(li.phi_dir_shift), "phi_slots": int(li.phi_slots), "phi_slot_bytes": int(li.phi_slot_bytes),
-                                                 "rec_bytes": [int(x) for x in li.rec_bytes], "rec_overflow": [int(x) for x in li.rec_overflow]}
+                                                 "rec_bytes": [int(x) for x in li.rec_bytes], "rec_overflow": [int(x) for x in li.rec_overflow],
+                                                 "budget_raised": int(li.budget_raised), "depths_kept": [d + 1 for d in range(8) if int(li.depth_mask_kept) >> d & 1],
+                                                 "depths_with_records": [d + 1 for d in range(8) if int(li.rec_bytes[d])]}
+        out["config"]["index"]["default_load"] = default_load
         out["config"]["index"]["text"] = "implicit (sampled from the pangenome's structure)" if implicit else "materialised in HBM"
         out["peaks"] = {"host_bytes": int(peaks["host_bytes"]), "host_limit_bytes": peaks["host_limit"], "hbm_bytes": int(peaks["hbm_bytes"])}
         print(json.dumps(out), flush=True)
