@@ -366,6 +366,30 @@ int upload_tables_runs2(rbg_index *ix) {
         ix->dev.lut2 = static_cast<const uint8_t *>(p);
         ix->dev.nmajor = h.nmajor;
     }
+    // the register tables of the in-kernel read staging (rbg_dev.h stage_*): a shift under which the four major bytes hash to four different
+    // three-bit values
+    ix->dev.stage_ok = 0;
+    if (h.nmajor == 4) {
+        for (uint32_t sh = 0; sh <= 5 && !ix->dev.stage_ok; ++sh) {
+            uint8_t code[8] = {0, 0, 0, 0, 0, 0, 0, 0}, byte[8];
+            bool used[8] = {false, false, false, false, false, false, false, false}, distinct = true;
+            for (uint32_t m = 0; m < 4; ++m) {
+                const uint32_t t = (h.major_byte[m] >> sh) & 7u;
+                if (used[t]) distinct = false;
+                used[t] = true;
+                code[t] = static_cast<uint8_t>(m);
+                byte[t] = h.major_byte[m];
+            }
+            if (!distinct) continue;
+            // an unused place must never equal the byte that hashes to it: a byte whose own hash is another place
+            for (uint32_t t = 0; t < 8; ++t)
+                if (!used[t]) byte[t] = static_cast<uint8_t>(((t ^ 1u) & 7u) << sh);
+            ix->dev.stage_ok = 1;
+            ix->dev.stage_shift = sh;
+            std::memcpy(ix->dev.stage_code, code, 8);
+            std::memcpy(ix->dev.stage_byte, byte, 8);
+        }
+    }
     ix->dev.phi_slots = nullptr;
     ix->dev.phi_ord = nullptr;
     ix->dev.phi_dir = nullptr;

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void k_locate_fill(const DevIndex ix, const ui
                                                      const uint64_t *__restrict__ loc_off, OUT *__restrict__ locs,
                                                      const uint64_t *__restrict__ sub, const uint32_t *__restrict__ order,
                                                      const uint64_t *__restrict__ skeys,
-                                                     unsigned long long *__restrict__ stats = nullptr) {
+                                                     unsigned long long *__restrict__ stats = nullptr, const uint32_t align_flush = 0) {
     // staged at the position width: text positions fit P, and at 4 bytes the workgroup's LDS drops from
     // 39 KB to 24 KB (6 instead of 4 waves per SIMD); the per-read offset is applied when flushing
     __shared__ P s_val[4][kWave][CH + 1];  // +1: keeps the per-lane rows off the same banks
@@ -119,6 +119,14 @@ __global__ __launch_bounds__(256) void k_locate_fill(const DevIndex ix, const ui
     __shared__ uint64_t s_occ[4][kWave];
     __shared__ uint64_t s_minus[4][kWave];
     __shared__ uint64_t s_first[4][kWave];  // the toehold itself is not a text position when it wrapped (2^64 - 1)
+    // LINE-ALIGNED FLUSHES (round 6): a read's segment of CH values used to start wherever its locations start, so a flush of CH x 8 bytes
+    // straddled two lines and wrote both partially (39 GB written for 28 GB of locations at r = 1.07e9: profiles/r05_pmc_stream_r1e9.txt).  Now the
+    // chain is cut at multiples of CH elements of the OUTPUT ARRAY: a = (address of the read's first location / 8) mod CH, round c holds the
+    // elements v = t + a in [c CH, (c + 1) CH), so every flush but a read's first and last writes one whole aligned segment.  The price: a lane
+    // waits a columns before its first step, so a wave's longest chain grows by up to CH - 1 steps -- 17 % of the bench index's 41, which lost
+    // there in round 3 (profiles/r03_k3_align_ab.txt) -- so `align_flush` is set for long chains only (launch_locate_fill: RBG_K3_ALIGN).
+    __shared__ uint32_t s_a[4][kWave];
+    const uint64_t out_elem0 = reinterpret_cast<uintptr_t>(locs) / sizeof(OUT);
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
     unsigned long long c_locs = 0;
     unsigned long long st_phi = 0, st_ovf = 0, st_chains = 0;  // STATS only
@@ -148,13 +156,15 @@ __global__ __launch_bounds__(256) void k_locate_fill(const DevIndex ix, const ui
             }
         }
         const uint64_t minus = (sub && i < N) ? sub[i] : 0;  // locate_from_longest_seed, rowbowt.hpp:681-683
-        s_dst[wv][lane] = dst;
+        const uint32_t a = (occ && align_flush) ? static_cast<uint32_t>((out_elem0 + dst) & static_cast<uint64_t>(CH - 1)) : 0u;
+        s_dst[wv][lane] = dst - a;   // (wraps for a read at the very start of a misaligned array; + v >= a brings it back)
         s_occ[wv][lane] = occ;
+        s_a[wv][lane] = a;
         s_minus[wv][lane] = minus;
         s_first[wv][lane] = k1;
         c_locs += occ;
         if (STATS && occ) st_chains += 1;
-        uint64_t wmax = occ;
+        uint64_t wmax = occ + a;
 #pragma unroll
         for (int o = kWave / 2; o > 0; o >>= 1) {
             const uint64_t other = __shfl_xor(wmax, o, kWave);
@@ -163,8 +173,8 @@ __global__ __launch_bounds__(256) void k_locate_fill(const DevIndex ix, const ui
         for (uint64_t t0 = 0; t0 < wmax; t0 += CH) {
 #pragma unroll
             for (int e = 0; e < CH; ++e) {
-                const uint64_t t = t0 + e;
-                if (t < occ) {
+                const uint64_t t = t0 + e - a;
+                if (t0 + e >= a && t < occ) {
                     if (STATS) {
                         if (t) {
                             bool searched = false;
@@ -183,8 +193,8 @@ __global__ __launch_bounds__(256) void k_locate_fill(const DevIndex ix, const ui
             for (int pass = 0; pass < CH; ++pass) {  // kWave/CH reads per pass, CH lanes each
                 const int s = pass * (kWave / CH) + lane / CH;
                 const int e = lane & (CH - 1);
-                const uint64_t t = t0 + e;
-                if (t < s_occ[wv][s]) locs[s_dst[wv][s] + t] = static_cast<OUT>((t ? static_cast<uint64_t>(s_val[wv][s][e]) : s_first[wv][s]) - s_minus[wv][s]);
+                const uint64_t v = t0 + e, as = s_a[wv][s], t = v - as;
+                if (v >= as && t < s_occ[wv][s]) locs[s_dst[wv][s] + v] = static_cast<OUT>((t ? static_cast<uint64_t>(s_val[wv][s][e]) : s_first[wv][s]) - s_minus[wv][s]);
             }
             wave_lds_sync();
         }
@@ -288,20 +298,24 @@ int launch_locate_fill(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t 
     // the order workspace also holds the toeholds in sorted order (launch_locate_order's key output)
     const uint64_t *skeys = order ? reinterpret_cast<const uint64_t *>(static_cast<const char *>(order) + order_layout(N).keys) : nullptr;
     const uint32_t *perm = static_cast<const uint32_t *>(order);
+    // line-aligned flushes (k_locate_fill): RBG_K3_ALIGN = 1 / 0 forces them on / off; by default on where a read has many locations on average
+    // (n / r rows per run = haplotypes per locus, about: the chains of a pangenome index are that long) -- profiles/r06_k3_align_ab.txt
+    static const int align_env = [] { const char *e = std::getenv("RBG_K3_ALIGN"); return e ? std::atoi(e) : -1; }();
+    const uint32_t align_flush = align_env >= 0 ? (align_env ? 1u : 0u) : (ix.pos_bytes == 8 && ix.n / (ix.r ? ix.r : 1) >= 100 ? 1u : 0u);
     if (ix.layout == 2 && !ix.phi_slots) {  // run-indexed layout (k_runs.hip); with phi slots (RBG_OPT_RUN_PHI) the slot kernels below answer its phi
-        return launch_locate_fill_runs(ix, cfg, lo, hi, k, N, max_hits, loc_off, locs, sub, order, skeys, stream, stats, locs32);
+        return launch_locate_fill_runs(ix, cfg, lo, hi, k, N, max_hits, loc_off, locs, sub, order, skeys, stream, stats, locs32, align_flush);
     }
     if (locs32) {   // 4-byte locations (4-byte positions only; the caller checked)
         if (stats || ix.pos_bytes != 4) return static_cast<int>(hipErrorInvalidValue);
-        hipLaunchKernelGGL((k_locate_fill<uint32_t, false, uint32_t>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, locs32, sub, perm, skeys, nullptr);
+        hipLaunchKernelGGL((k_locate_fill<uint32_t, false, uint32_t>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, locs32, sub, perm, skeys, nullptr, align_flush);
         return static_cast<int>(hipGetLastError());
     }
     if (stats) {
-        if (ix.pos_bytes == 4) hipLaunchKernelGGL((k_locate_fill<uint32_t, true>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, locs, sub, perm, skeys, stats);
-        else hipLaunchKernelGGL((k_locate_fill<uint64_t, true>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, locs, sub, perm, skeys, stats);
+        if (ix.pos_bytes == 4) hipLaunchKernelGGL((k_locate_fill<uint32_t, true>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, locs, sub, perm, skeys, stats, align_flush);
+        else hipLaunchKernelGGL((k_locate_fill<uint64_t, true>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, locs, sub, perm, skeys, stats, align_flush);
     } else {
-        if (ix.pos_bytes == 4) hipLaunchKernelGGL((k_locate_fill<uint32_t>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, locs, sub, perm, skeys, nullptr);
-        else hipLaunchKernelGGL((k_locate_fill<uint64_t>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, locs, sub, perm, skeys, nullptr);
+        if (ix.pos_bytes == 4) hipLaunchKernelGGL((k_locate_fill<uint32_t>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, locs, sub, perm, skeys, nullptr, align_flush);
+        else hipLaunchKernelGGL((k_locate_fill<uint64_t>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, locs, sub, perm, skeys, nullptr, align_flush);
     }
     return static_cast<int>(hipGetLastError());
 }

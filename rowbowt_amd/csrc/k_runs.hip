@@ -3,6 +3,8 @@
 // ToeholdSA::phi toehold_sa.hpp:56-72): a directory (or a bucket record) has already cut the search down to the handful
 // of entries of one bucket, and the lane that owns the query fetches and scans exactly those (rbg_runs2_device.hpp).  One
 // lane owns one read (K1/K2) or one phi chain (K3); bucket records are fetched by quads of lanes.
+#include <type_traits>
+
 #include "rbg_runs2_device.hpp"
 
 namespace rbg {
@@ -42,8 +44,80 @@ struct PackedBits {   // per-lane reader of a packed read: peek / drop of up to 
     }
 };
 
+// ---- STAGE: the wave's reads as 2-bit codes in LDS, made by the wave itself -----------------------------------------------------------
+// A lane that walks its read through a cursor of 16-byte chunks fetches a chunk every second step: by then the memory system has turned its
+// caches over (a step is a random sector per lane), so every chunk is an L2 miss of its own -- 6.8 per 100 bp read, a third of K2's misses
+// (profiles/r06_k2_sectors.md).  Here every lane fetches ALL chunks of its read back to back at the top of the wave's iteration -- neighbouring
+// lanes hold neighbouring reads, so a line is asked for by all its readers within a few hundred cycles and leaves HBM once -- and keeps them
+// as 2-bit codes of the k-mer alphabet in consumption order (the layout of k_pack_reads: symbol q[m - 1 - t] at bits [2t, 2t + 2)), word w of
+// lane l at codes[w * 64 + l]: a step's table index is then the next 2 * adv bits, two LDS words and a funnel shift, no per-symbol lookup.
+// Four symbols per instruction: a byte's code and the byte it has to be come out of two 8-byte register tables by v_perm_b32 (rbg_dev.h
+// stage_*).  A wave with a read longer than kStageCap symbols, or with a symbol outside the k-mer alphabet, walks its reads as bytes.
+constexpr uint32_t kStageCap = 256u;                         // symbols per read the staging holds
+constexpr uint32_t kStageWords = kStageCap / 16u + 1u;       // (+ 1: the word after the last one is read, never used)
+constexpr uint32_t kStageWaveBytes = kStageWords * 64u * 4u;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+
+struct StageTab { uint32_t code_lo, code_hi, byte_lo, byte_hi, shift; };
+// one aligned 16-byte chunk -> its sixteen codes in consumption order (byte 15 first) + the bytes that are not symbols of the alphabet (diff != 0)
+__device__ __forceinline__ uint32_t stage_chunk(const u32x4 w, const StageTab &T, uint32_t (&diff)[4]) {
+    const uint32_t x[4] = {w.x, w.y, w.z, w.w};
+    uint32_t c8[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const uint32_t idx = (x[t] >> T.shift) & 0x07070707u;
+        const uint32_t code = __builtin_amdgcn_perm(T.code_hi, T.code_lo, idx);
+        diff[t] = x[t] ^ __builtin_amdgcn_perm(T.byte_hi, T.byte_lo, idx);
+        c8[t] = (code * 0x40100401u) >> 24;                 // code(byte 3) | code(byte 2) << 2 | code(byte 1) << 4 | code(byte 0) << 6
+    }
+    return c8[3] | (c8[2] << 8) | (c8[1] << 16) | (c8[0] << 24);
+}
+// bytes of a 16-bit per-byte mask's nibble as a 32-bit byte mask
+__device__ __forceinline__ uint32_t nibble_bytes(const uint32_t nib) { return (((nib & 15u) * 0x00204081u) & 0x01010101u) * 0xFFu; }
+// the read [beg, end) of this lane -> codes column `col` (stride 64 words); returns true when a byte is no symbol of the k-mer alphabet.
+// m = end - beg <= kStageCap.  chunks_out: 16-byte chunks fetched (STATS).
+__device__ __forceinline__ bool stage_read(const uint4 *__restrict__ chunks16, const uint64_t beg, const uint64_t end, const StageTab &T, lds_u32 *col, uint32_t &chunks_out) {
+    chunks_out = 0;
+    if (end <= beg) return false;
+    uint64_t ci = (end - 1) >> 4;
+    const uint64_t ci_lo = beg >> 4;
+    const uint32_t hi_b = static_cast<uint32_t>(end - 1) & 15u, lo_b = static_cast<uint32_t>(beg) & 15u;
+    const uint32_t skip2 = 2u * (15u - hi_b);                   // the top chunk's first symbols lie beyond the read's end
+    uint32_t nwords = static_cast<uint32_t>((end - beg + 15) >> 4);
+    uint32_t bad = 0;
+    uint32_t d[4];
+    u32x4 w = as_global<u32x4>(static_cast<const void *>(chunks16))[ci];
+    uint32_t prev = stage_chunk(w, T, d);
+    {   // the top chunk: bytes above hi_b (and, for a read inside one chunk, below lo_b) are not the read's
+        uint32_t vm = (2u << hi_b) - 1u;
+        if (ci == ci_lo) vm &= ~((1u << lo_b) - 1u);
+        bad |= (d[0] & nibble_bytes(vm)) | (d[1] & nibble_bytes(vm >> 4)) | (d[2] & nibble_bytes(vm >> 8)) | (d[3] & nibble_bytes(vm >> 12));
+    }
+    chunks_out = static_cast<uint32_t>(ci - ci_lo) + 1u;
+    while (nwords) {
+        uint32_t next = 0;
+        if (ci > ci_lo) {
+            --ci;
+            w = as_global<u32x4>(static_cast<const void *>(chunks16))[ci];
+            next = stage_chunk(w, T, d);
+            if (ci == ci_lo) {                                  // the bottom chunk: bytes below lo_b are not the read's
+                const uint32_t vm = ~((1u << lo_b) - 1u);
+                bad |= (d[0] & nibble_bytes(vm)) | (d[1] & nibble_bytes(vm >> 4)) | (d[2] & nibble_bytes(vm >> 8)) | (d[3] & nibble_bytes(vm >> 12));
+            } else {
+                bad |= d[0] | d[1] | d[2] | d[3];
+            }
+        }
+        *col = __builtin_amdgcn_alignbit(next, prev, skip2);   // ({next, prev} >> skip2): skip2 <= 30
+        col += 64;
+        prev = next;
+        --nwords;
+    }
+    return bad != 0;
+}
+
 // GLDS: the bucket records arrive by LDS-direct loads (rbg_runs2_device.hpp lane_lf2_quad) instead of quad permutes
-template <typename P, bool TOEHOLD, bool PACKED = false, bool STATS = false, bool GLDS = false>
+// STAGE (byte form only): the wave stages its reads as 2-bit codes in LDS first (above)
+template <typename P, bool TOEHOLD, bool PACKED = false, bool STATS = false, bool GLDS = false, bool STAGE = false>
 __global__ __launch_bounds__(512, STATS ? 2 : 4) void k_find_range_runs(const DevIndex ix, const void *__restrict__ src_a,
                                                         const void *__restrict__ src_b, const uint64_t N,
                                                         uint64_t *__restrict__ lo_out, uint64_t *__restrict__ hi_out,
@@ -60,6 +134,7 @@ __global__ __launch_bounds__(512, STATS ? 2 : 4) void k_find_range_runs(const De
     __shared__ uint8_t s_lut2[256];
     __shared__ uint8_t s_mslot[4];
     __shared__ __align__(16) unsigned char s_tile[GLDS ? 8 * kTileBytes : 16];   // (eight waves per workgroup)
+    __shared__ uint32_t s_codes[STAGE ? 8 * kStageWords * 64 : 1];               // STAGE: the waves' reads as 2-bit codes
     for (int t = threadIdx.x; t < 256; t += blockDim.x) {
         s_lut[t] = ix.lut[t];
         s_lut2[t] = ix.nmajor ? ix.lut2[t] : 0xFFu;
@@ -68,7 +143,7 @@ __global__ __launch_bounds__(512, STATS ? 2 : 4) void k_find_range_runs(const De
     const RunSearch2<P> S2 = stage_run_search2<P>(ix, s_tab_first, s_ent2, s_dir2, s_rec2, s_dyn);
     const uint32_t *tab_first = s_tab_first;
     lds_byte *tile = (lds_byte *)s_tile + (GLDS ? (threadIdx.x >> 6) * kTileBytes : 0u);   // (C-style: a cast into the LDS address space)
-    if (PACKED) {
+    if (PACKED || STAGE) {
         for (int t = threadIdx.x; t < 256; t += blockDim.x)
             if (s_lut2[t] != 0xFFu) s_mslot[s_lut2[t] & 3u] = s_lut[t];   // major index -> symbol slot
         __syncthreads();
@@ -76,6 +151,9 @@ __global__ __launch_bounds__(512, STATS ? 2 : 4) void k_find_range_runs(const De
     const uint32_t D = ix.run_ksteps, DMASK = ix.run_depth_mask | 1u;
     const uint32_t M = ix.nmajor;
     const uint32_t lane = threadIdx.x & (kWave - 1);
+    lds_u32 *codes = (lds_u32 *)s_codes + (STAGE ? (threadIdx.x >> 6) * (kStageWords * 64u) + lane : 0u);   // this lane's column: word w at codes[64 w]
+    const StageTab stage_tab{ix.stage_code[0], ix.stage_code[1], ix.stage_byte[0], ix.stage_byte[1], ix.stage_shift};
+    const bool stage_on = STAGE && ix.stage_ok != 0 && M == 4;
 
     unsigned long long c_occ = 0, c_reads = 0;
     uint32_t c_matched = 0;
@@ -94,142 +172,171 @@ __global__ __launch_bounds__(512, STATS ? 2 : 4) void k_find_range_runs(const De
                 else { p = mt.y; bs.cp = chunks + mt.x; }        // p = symbols still to consume (beg = 0)
             }
         } else if (valid) { beg = off[i]; p = off[i + 1]; }
-        const uint64_t p_end = p;
-        uint64_t p_min = p;                                    // STATS: lowest read byte fetched
-        uint64_t lo = 0, hi = ix.n - 1;                       // full_range(), rowbowt.hpp:115-118
-        uint64_t k = TOEHOLD ? ix.last_run_sample : 0;
-        bool alive = valid;
-        bool pend = false;                                     // deferred toehold re-sample (k_search.hip): the last one is the only one used
-        uint32_t pend_d = 0, pend_rec = 0;
-        uint64_t pend_e = 0;
-        ByteCursor rd{reinterpret_cast<const uint4 *>(seqs), ~uint64_t(0), make_uint4(0, 0, 0, 0)};
-        if (valid && ix.ftab_k && p - beg >= ix.ftab_k) {      // rowbowt.hpp:124-125, :745-758 (k_search.hip)
-            uint64_t idx = 0;
-            bool all_major = true;
-            PackedBits probe = bs;                             // consumed only if the entry is usable
-            if (PACKED) {
-                idx = probe.take(2 * ix.ftab_k);               // the first ftab_k symbols are the low 2 * ftab_k bits
-            } else {
-                uint64_t pw = 1;
-                for (uint32_t t = 1; t <= ix.ftab_k; ++t) {
-                    const uint32_t mm = s_lut2[rd.at(p - t)];
-                    all_major = all_major && mm != 0xFFu;
-                    idx += (mm & 3u) * pw;
-                    pw *= M;
-                }
-            }
-            uint64_t flo, fhi2, fk;
-            if (STATS) { p_min = p - ix.ftab_k; if (all_major) st[kStFtab] += 1; }
-            if (all_major && ftab_lookup<P>(ix, idx, flo, fhi2, fk)) {
-                if (PACKED) bs = probe;
-                lo = flo; hi = fhi2;
-                if (TOEHOLD) k = fk;
-                p -= ix.ftab_k;
-                if (STATS) st[kStSymbols] += ix.ftab_k;
-                if (hi < lo) { alive = false; p = beg; }
+        // STAGE: the wave's reads become 2-bit codes in LDS (stage_read above) unless one of them is too long or holds a symbol outside the k-mer
+        // alphabet; the walk below is instantiated for both forms, the wave takes one
+        bool staged = false;
+        if constexpr (STAGE && !PACKED) {
+            if (stage_on && __ballot(valid && p - beg > kStageCap) == 0) {
+                uint32_t nch = 0;
+                const bool bad = valid && stage_read(reinterpret_cast<const uint4 *>(seqs), beg, p, stage_tab, codes, nch);
+                if (STATS) st[kStChunks] += nch;
+                staged = __ballot(bad) == 0;
+                if (staged) { p -= beg; beg = 0; }
+                else if (STATS) st[kStChunks] -= nch;          // (the byte walk counts its own)
             }
         }
-        // The steps of a read do not depend on the search: which table a step goes through is a matter of the read's symbols alone.  So the
-        // NEXT step is chosen, and its table's record fetched (from LDS, or for depths 6-8 from the global array: an L2 round trip), while
-        // the current step's bucket record is on its way -- the dependent chain of a step is its record (and, rarely, a scan), nothing else.
-        struct Pick { uint32_t d, adv, rec; bool ok; };
-        auto pick_at = [&](const uint64_t pp) __attribute__((always_inline)) -> Pick {        // the step that consumes the symbols ending at pp (exclusive: pp > beg)
-            Pick s{0u, 1u, 0u, true};
-            if (PACKED) {
-                s.adv = pp < D ? static_cast<uint32_t>(pp) : D;
-                s.adv = 32u - static_cast<uint32_t>(__clz(DMASK & ((2u << (s.adv - 1)) - 1u)));   // the deepest depth kept that fits
-                const uint32_t v = bs.take(2 * s.adv);
-                s.rec = run_record(tab_first, s.adv, s.adv == 1 ? static_cast<uint32_t>(s_mslot[v]) : v);
-                s.d = s.adv - 1;
-            } else {
-                const uint64_t q = pp - 1;
-                const uint32_t c = rd.at(q);
-                if (STATS && q < p_min) p_min = q;
-                const uint32_t m0 = s_lut2[c];
-                uint32_t acc = m0;
-                if (m0 != 0xFFu) {                              // the longest run of major symbols among the next D (k_search.hip)
-                    uint32_t pw = M, run_acc = m0;              // (of its prefixes, the longest whose depth has run lists)
-#pragma unroll 1
-                    for (uint32_t t = 1; t < static_cast<uint32_t>(kMaxRunDepth); ++t) {
-                        if (t >= D || q < beg + t) break;
-                        const uint32_t mm = s_lut2[rd.at(q - t)];
-                        if (STATS && q - t < p_min) p_min = q - t;
-                        if (mm == 0xFFu) break;
-                        run_acc += mm * pw;
+        auto walk = [&](auto staged_tag) __attribute__((always_inline)) {
+            constexpr bool STAGED = decltype(staged_tag)::value;
+            const uint64_t p_end = p;
+            uint64_t p_min = p;                                    // STATS: lowest read byte fetched
+            const uint32_t m32 = static_cast<uint32_t>(p);         // STAGED: the read's length (p counts the symbols still to consume, beg = 0)
+            uint64_t lo = 0, hi = ix.n - 1;                       // full_range(), rowbowt.hpp:115-118
+            uint64_t k = TOEHOLD ? ix.last_run_sample : 0;
+            bool alive = valid;
+            bool pend = false;                                     // deferred toehold re-sample (k_search.hip): the last one is the only one used
+            uint32_t pend_d = 0, pend_rec = 0;
+            uint64_t pend_e = 0;
+            ByteCursor rd{reinterpret_cast<const uint4 *>(seqs), ~uint64_t(0), make_uint4(0, 0, 0, 0)};
+            if (valid && ix.ftab_k && p - beg >= ix.ftab_k) {      // rowbowt.hpp:124-125, :745-758 (k_search.hip)
+                uint64_t idx = 0;
+                bool all_major = true;
+                PackedBits probe = bs;                             // consumed only if the entry is usable
+                if constexpr (STAGED) {
+                    const uint32_t w0 = codes[0];                  // the first ftab_k (<= 16) symbols are the low 2 * ftab_k bits of the first word
+                    idx = ix.ftab_k >= 16u ? w0 : (w0 & ((1u << (2u * ix.ftab_k)) - 1u));
+                } else if (PACKED) {
+                    idx = probe.take(2 * ix.ftab_k);               // the first ftab_k symbols are the low 2 * ftab_k bits
+                } else {
+                    uint64_t pw = 1;
+                    for (uint32_t t = 1; t <= ix.ftab_k; ++t) {
+                        const uint32_t mm = s_lut2[rd.at(p - t)];
+                        all_major = all_major && mm != 0xFFu;
+                        idx += (mm & 3u) * pw;
                         pw *= M;
-                        if ((DMASK >> t) & 1u) { s.adv = t + 1; acc = run_acc; }
                     }
                 }
-                if (s.adv == 1) {
-                    const uint32_t slot = s_lut[c];
-                    // symbol absent (f_[c] >= f_[c+1], rowbowt.hpp:76).  (An index with more than kLdsSyms symbols is
-                    // never given this layout: upload() keeps the slot tables for it.)
-                    if (slot == 0xFFu || slot >= static_cast<uint32_t>(kLdsSyms)) s.ok = false;
-                    else s.rec = run_record(tab_first, 1u, slot);
-                } else {
-                    s.d = s.adv - 1;
-                    s.rec = run_record(tab_first, s.adv, acc);
+                uint64_t flo, fhi2, fk;
+                if (STATS) { if (!STAGED) p_min = p - ix.ftab_k; if (all_major) st[kStFtab] += 1; }
+                if (all_major && ftab_lookup<P>(ix, idx, flo, fhi2, fk)) {
+                    if (PACKED) bs = probe;
+                    lo = flo; hi = fhi2;
+                    if (TOEHOLD) k = fk;
+                    p -= ix.ftab_k;
+                    if (STATS) st[kStSymbols] += ix.ftab_k;
+                    if (hi < lo) { alive = false; p = beg; }
                 }
             }
-            return s;
-        };
-        // (the packed form keeps the step's choice at the top of the loop: the extra state of looking ahead sent it to scratch, and no kernel
-        //  of this layout may spill -- tests/test_capi_host.py test_no_run_indexed_kernel_spills)
-        constexpr bool AHEAD = !PACKED;
-        Pick cur{0u, 1u, 0u, false};
-        RunHot Rcur{0, 0};
-        if (AHEAD && alive && p > beg) {
-            cur = pick_at(p);
-            if (cur.ok) Rcur = load_run_tab<P>(S2, cur.d, cur.rec);
-        }
-        while (__ballot(alive && p > beg)) {                   // right-to-left over the reads (rowbowt.hpp:127-129, :175-181)
-            bool stepping = alive && p > beg;
-            if (!AHEAD && stepping) {
+            // The steps of a read do not depend on the search: which table a step goes through is a matter of the read's symbols alone.  So the
+            // NEXT step is chosen, and its table's record fetched (from LDS, or for depths 6-8 from the global array: an L2 round trip), while
+            // the current step's bucket record is on its way -- the dependent chain of a step is its record (and, rarely, a scan), nothing else.
+            struct Pick { uint32_t d, adv, rec; bool ok; };
+            auto pick_at = [&](const uint64_t pp) __attribute__((always_inline)) -> Pick {        // the step that consumes the symbols ending at pp (exclusive: pp > beg)
+                Pick s{0u, 1u, 0u, true};
+                if constexpr (STAGED) {
+                    s.adv = pp < D ? static_cast<uint32_t>(pp) : D;
+                    s.adv = 32u - static_cast<uint32_t>(__clz(DMASK & ((2u << (s.adv - 1)) - 1u)));   // the deepest depth kept that fits
+                    const uint32_t t0 = m32 - static_cast<uint32_t>(pp);                               // symbols consumed so far
+                    const lds_u32 *cw = codes + (t0 >> 4) * 64u;
+                    const uint32_t v = __builtin_amdgcn_alignbit(cw[64], cw[0], (t0 & 15u) * 2u) & ((1u << (2u * s.adv)) - 1u);
+                    s.rec = run_record(tab_first, s.adv, s.adv == 1 ? static_cast<uint32_t>(s_mslot[v]) : v);
+                    s.d = s.adv - 1;
+                } else if (PACKED) {
+                    s.adv = pp < D ? static_cast<uint32_t>(pp) : D;
+                    s.adv = 32u - static_cast<uint32_t>(__clz(DMASK & ((2u << (s.adv - 1)) - 1u)));   // the deepest depth kept that fits
+                    const uint32_t v = bs.take(2 * s.adv);
+                    s.rec = run_record(tab_first, s.adv, s.adv == 1 ? static_cast<uint32_t>(s_mslot[v]) : v);
+                    s.d = s.adv - 1;
+                } else {
+                    const uint64_t q = pp - 1;
+                    const uint32_t c = rd.at(q);
+                    if (STATS && q < p_min) p_min = q;
+                    const uint32_t m0 = s_lut2[c];
+                    uint32_t acc = m0;
+                    if (m0 != 0xFFu) {                              // the longest run of major symbols among the next D (k_search.hip)
+                        uint32_t pw = M, run_acc = m0;              // (of its prefixes, the longest whose depth has run lists)
+    #pragma unroll 1
+                        for (uint32_t t = 1; t < static_cast<uint32_t>(kMaxRunDepth); ++t) {
+                            if (t >= D || q < beg + t) break;
+                            const uint32_t mm = s_lut2[rd.at(q - t)];
+                            if (STATS && q - t < p_min) p_min = q - t;
+                            if (mm == 0xFFu) break;
+                            run_acc += mm * pw;
+                            pw *= M;
+                            if ((DMASK >> t) & 1u) { s.adv = t + 1; acc = run_acc; }
+                        }
+                    }
+                    if (s.adv == 1) {
+                        const uint32_t slot = s_lut[c];
+                        // symbol absent (f_[c] >= f_[c+1], rowbowt.hpp:76).  (An index with more than kLdsSyms symbols is
+                        // never given this layout: upload() keeps the slot tables for it.)
+                        if (slot == 0xFFu || slot >= static_cast<uint32_t>(kLdsSyms)) s.ok = false;
+                        else s.rec = run_record(tab_first, 1u, slot);
+                    } else {
+                        s.d = s.adv - 1;
+                        s.rec = run_record(tab_first, s.adv, acc);
+                    }
+                }
+                return s;
+            };
+            // (the packed form keeps the step's choice at the top of the loop: the extra state of looking ahead sent it to scratch, and no kernel
+            //  of this layout may spill -- tests/test_capi_host.py test_no_run_indexed_kernel_spills)
+            constexpr bool AHEAD = !PACKED || STAGED;
+            Pick cur{0u, 1u, 0u, false};
+            RunHot Rcur{0, 0};
+            if (AHEAD && alive && p > beg) {
                 cur = pick_at(p);
                 if (cur.ok) Rcur = load_run_tab<P>(S2, cur.d, cur.rec);
             }
-            if (stepping && !cur.ok) { alive = false; stepping = false; }
-            const uint32_t d = cur.d, adv = cur.adv, rec = cur.rec;
-            const RunHot R = Rcur;
-            // the step after this one (taken only if this one leaves the range non-empty)
-            const uint64_t p_next = p - adv;
-            if (AHEAD && stepping && p_next > beg) {
-                cur = pick_at(p_next);
-                if (cur.ok) Rcur = load_run_tab<P>(S2, cur.d, cur.rec);
-            }
-            RunStep r;
-            // rank(lo, c), rank(hi + 1, c): rowbowt.hpp:79,83
-            lane_lf2_quad<P, STATS, false, GLDS>(S2, stepping, d, rec, R, lo, hi + 1, r, st, tile);   // (every lane of the wave: the records are fetched by quads)
-            if (stepping) {
-                if (STATS) st[kStSymbols] += adv;
-                const uint64_t c_inside = r.c_upto - r.c_before;
-                if (c_inside == 0) {                            // rowbowt.hpp:85 (whichever of the nested steps emptied the range)
-                    alive = false;
-                } else {
-                    if (TOEHOLD) {                              // LF_w_loc, rowbowt.hpp:559-566, `adv` times nested
-                        if (r.inside) k = k - adv;
-                        else { pend = true; pend_d = d; pend_rec = rec; pend_e = r.samp_e; k = 0; }
+            while (__ballot(alive && p > beg)) {                   // right-to-left over the reads (rowbowt.hpp:127-129, :175-181)
+                bool stepping = alive && p > beg;
+                if (!AHEAD && stepping) {
+                    cur = pick_at(p);
+                    if (cur.ok) Rcur = load_run_tab<P>(S2, cur.d, cur.rec);
+                }
+                if (stepping && !cur.ok) { alive = false; stepping = false; }
+                const uint32_t d = cur.d, adv = cur.adv, rec = cur.rec;
+                const RunHot R = Rcur;
+                // the step after this one (taken only if this one leaves the range non-empty)
+                const uint64_t p_next = p - adv;
+                if (AHEAD && stepping && p_next > beg) {
+                    cur = pick_at(p_next);
+                    if (cur.ok) Rcur = load_run_tab<P>(S2, cur.d, cur.rec);
+                }
+                RunStep r;
+                // rank(lo, c), rank(hi + 1, c): rowbowt.hpp:79,83
+                lane_lf2_quad<P, STATS, false, GLDS>(S2, stepping, d, rec, R, lo, hi + 1, r, st, tile);   // (every lane of the wave: the records are fetched by quads)
+                if (stepping) {
+                    if (STATS) st[kStSymbols] += adv;
+                    const uint64_t c_inside = r.c_upto - r.c_before;
+                    if (c_inside == 0) {                            // rowbowt.hpp:85 (whichever of the nested steps emptied the range)
+                        alive = false;
+                    } else {
+                        if (TOEHOLD) {                              // LF_w_loc, rowbowt.hpp:559-566, `adv` times nested
+                            if (r.inside) k = k - adv;
+                            else { pend = true; pend_d = d; pend_rec = rec; pend_e = r.samp_e; k = 0; }
+                        }
+                        lo = r.F + r.c_before;                      // rowbowt.hpp:86
+                        hi = lo + c_inside - 1;                     // rowbowt.hpp:87
+                        p = p_next;                                 // the left neighbours are consumed too
                     }
-                    lo = r.F + r.c_before;                      // rowbowt.hpp:86
-                    hi = lo + c_inside - 1;                     // rowbowt.hpp:87
-                    p = p_next;                                 // the left neighbours are consumed too
                 }
             }
-        }
-        if (TOEHOLD && alive && pend) {
-            k += run_step_sample2<P>(ix, S2, pend_d, pend_rec, pend_e);
-            if (STATS) st[kStResample] += 1;
-        }
-        if (STATS && !PACKED && p_end > p_min) st[kStChunks] += ((p_end - 1) >> 4) - (p_min >> 4) + 1;
-        if (STATS && PACKED && valid) st[kStChunks] += (p_end + 63) >> 6;
-        if (!alive) { lo = 1; hi = 0; k = 0; }                 // {1,0}; LFData::clear rowbowt.hpp:153-159
-        if (valid) {
-            lo_out[i] = lo;
-            hi_out[i] = hi;
-            if (TOEHOLD) ss_out[i] = k;
-            c_reads += 1;
-            if (alive) { c_matched += 1; c_occ += hi - lo + 1; }
-        }
+            if (TOEHOLD && alive && pend) {
+                k += run_step_sample2<P>(ix, S2, pend_d, pend_rec, pend_e);
+                if (STATS) st[kStResample] += 1;
+            }
+            if (STATS && !PACKED && !STAGED && p_end > p_min) st[kStChunks] += ((p_end - 1) >> 4) - (p_min >> 4) + 1;
+            if (STATS && PACKED && valid) st[kStChunks] += (p_end + 63) >> 6;
+            if (!alive) { lo = 1; hi = 0; k = 0; }                 // {1,0}; LFData::clear rowbowt.hpp:153-159
+            if (valid) {
+                lo_out[i] = lo;
+                hi_out[i] = hi;
+                if (TOEHOLD) ss_out[i] = k;
+                c_reads += 1;
+                if (alive) { c_matched += 1; c_occ += hi - lo + 1; }
+            }
+        };
+        if (STAGE && staged) walk(std::integral_constant<bool, STAGE>{}); else walk(std::false_type{});
     }
     c_reads = wave_sum(c_reads);
     const unsigned long long w_matched = wave_sum(static_cast<unsigned long long>(c_matched));
@@ -263,13 +370,16 @@ __global__ __launch_bounds__(256, 4) void k_locate_fill_runs2(const DevIndex ix,
                                                           const uint64_t N, const uint64_t max_hits,
                                                           const uint64_t *__restrict__ loc_off, OUT *__restrict__ locs,
                                                           const uint64_t *__restrict__ sub, const uint32_t *__restrict__ order,
-                                                          const uint64_t *__restrict__ skeys, unsigned long long *__restrict__ stats) {
+                                                          const uint64_t *__restrict__ skeys, unsigned long long *__restrict__ stats,
+                                                          const uint32_t align_flush) {
     constexpr int kChunkR = ChunkR<P>::v;
     __shared__ P s_val[4][kWave][kChunkR + 1];
     __shared__ uint64_t s_dst[4][kWave];
     __shared__ uint64_t s_occ[4][kWave];
     __shared__ uint64_t s_minus[4][kWave];
     __shared__ uint64_t s_first[4][kWave];
+    __shared__ uint32_t s_a[4][kWave];   // line-aligned flushes, as in k_locate_fill (k_locate.hip)
+    const uint64_t out_elem0 = reinterpret_cast<uintptr_t>(locs) / sizeof(OUT);
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
     unsigned long long c_locs = 0;
     unsigned long long st_phi = 0, st_ent = 0, st_chains = 0;   // STATS only
@@ -293,13 +403,15 @@ __global__ __launch_bounds__(256, 4) void k_locate_fill_runs2(const DevIndex ix,
             }
         }
         const uint64_t minus = (sub && i < N && j < N) ? sub[i] : 0;
-        s_dst[wv][lane] = dst;
+        const uint32_t a = (occ && align_flush) ? static_cast<uint32_t>((out_elem0 + dst) & static_cast<uint64_t>(kChunkR - 1)) : 0u;
+        s_dst[wv][lane] = dst - a;
         s_occ[wv][lane] = occ;
+        s_a[wv][lane] = a;
         s_minus[wv][lane] = minus;
         s_first[wv][lane] = k1;
         c_locs += occ;
         if (STATS && occ) st_chains += 1;
-        uint64_t wmax = occ;
+        uint64_t wmax = occ + a;
 #pragma unroll
         for (int o = kWave / 2; o > 0; o >>= 1) {
             const uint64_t other = __shfl_xor(wmax, o, kWave);
@@ -308,8 +420,9 @@ __global__ __launch_bounds__(256, 4) void k_locate_fill_runs2(const DevIndex ix,
         for (uint64_t t0 = 0; t0 < wmax; t0 += kChunkR) {
 #pragma unroll 1
             for (int e = 0; e < kChunkR; ++e) {
-                const uint64_t t = t0 + e;
-                if (t < occ && t > 0) {                        // toehold_sa.hpp:44: k = phi(k)
+                const uint64_t t = t0 + e - a;
+                const bool mine = t0 + e >= a && t < occ;
+                if (mine && t > 0) {                           // toehold_sa.hpp:44: k = phi(k)
                     uint64_t s;
                     if (k1 >= n) {
                         // a toehold below zero (k_locate.hip phi_step): outside phi's domain -- the last sample is its predecessor
@@ -327,15 +440,15 @@ __global__ __launch_bounds__(256, 4) void k_locate_fill_runs2(const DevIndex ix,
                     }
                     k1 = s;
                 }
-                if (t < occ) s_val[wv][lane][e] = static_cast<P>(k1);
+                if (mine) s_val[wv][lane][e] = static_cast<P>(k1);
             }
             wave_lds_sync();
 #pragma unroll
             for (int pass = 0; pass < kChunkR; ++pass) {
                 const int s = pass * (kWave / kChunkR) + lane / kChunkR;
                 const int e = lane & (kChunkR - 1);
-                const uint64_t t = t0 + e;
-                if (t < s_occ[wv][s]) locs[s_dst[wv][s] + t] = static_cast<OUT>((t ? static_cast<uint64_t>(s_val[wv][s][e]) : s_first[wv][s]) - s_minus[wv][s]);
+                const uint64_t v = t0 + e, as = s_a[wv][s], t = v - as;
+                if (v >= as && t < s_occ[wv][s]) locs[s_dst[wv][s] + v] = static_cast<OUT>((t ? static_cast<uint64_t>(s_val[wv][s][e]) : s_first[wv][s]) - s_minus[wv][s]);
             }
             wave_lds_sync();
         }
@@ -367,20 +480,25 @@ int launch_find_range_runs_impl(const DevIndex &ix, const LaunchCfg &cfg, const 
     const size_t lds = run_search2_lds(ix);
     // how a quad's bucket records travel (rbg_runs2_device.hpp): LDS-direct loads (the default), or RBG_REC_FETCH=quad: registers + quad permutes
     static const bool glds = [] { const char *e = std::getenv("RBG_REC_FETCH"); return !(e && std::strcmp(e, "quad") == 0); }();
+    // the byte form stages its reads as 2-bit codes in LDS (STAGE above; needs an alphabet the register tables express: DevIndex::stage_ok);
+    // RBG_STAGE_READS=0: every lane walks its read through a cursor of 16-byte chunks as before round 6 (A/B, profiles/r06_k2_sectors.md)
+    static const bool stage = [] { const char *e = std::getenv("RBG_STAGE_READS"); return !(e && e[0] == '0'); }();
     LaunchCfg c = cfg;   // 512-thread workgroups: the staged tables and top level are shared by eight waves
     c.block_threads = 512;
     c.max_blocks = cfg.max_blocks > 0 ? std::max(1, cfg.max_blocks / 2) : 256 * 16;
     // sel mode: the number of reads is only known on the device; a fixed modest grid loops over it
     const dim3 grid(sel ? std::min(grid_for(c, N), 256) : grid_for(c, N)), block(512);
-#define RBG_LAUNCH_FRR1(PT, TOE, PK, STS, GL)                                                          \
+#define RBG_LAUNCH_FRR1(PT, TOE, PK, STS, GL, SG)                                                      \
     do {                                                                                               \
-        auto kern = k_find_range_runs<PT, TOE, PK, STS, GL>;                                           \
-        raise_lds(kern, lds, GL ? 8 * kTileBytes : 0);                                                \
+        auto kern = k_find_range_runs<PT, TOE, PK, STS, GL, SG>;                                       \
+        raise_lds(kern, lds, (GL ? 8 * kTileBytes : 0) + (SG ? 8 * kStageWaveBytes : 0));             \
         hipLaunchKernelGGL(kern, grid, block, lds, st, ix, src_a, src_b, N, lo, hi, ssamp, stats, sel, nsel);     \
     } while (0)
 #define RBG_LAUNCH_FRR(PT, TOE, PK, STS)                                                               \
     do {                                                                                               \
-        if (glds) RBG_LAUNCH_FRR1(PT, TOE, PK, STS, true); else RBG_LAUNCH_FRR1(PT, TOE, PK, STS, false); \
+        if (glds && stage && !PK && !sel) RBG_LAUNCH_FRR1(PT, TOE, false, STS, true, true);            \
+        else if (glds) RBG_LAUNCH_FRR1(PT, TOE, PK, STS, true, false);                                 \
+        else RBG_LAUNCH_FRR1(PT, TOE, PK, STS, false, false);                                          \
     } while (0)
 #define RBG_LAUNCH_FRR2(PT, TOE)                                                                       \
     do {                                                                                               \
@@ -416,13 +534,13 @@ int launch_find_range_runs_packed(const DevIndex &ix, const LaunchCfg &cfg, cons
 
 int launch_locate_fill_runs(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t *lo, const uint64_t *hi, const uint64_t *k,
                             uint64_t N, uint64_t max_hits, const uint64_t *loc_off, uint64_t *locs, const uint64_t *sub,
-                            const void *order, const uint64_t *skeys, void *stream, unsigned long long *stats, uint32_t *locs32) {
+                            const void *order, const uint64_t *skeys, void *stream, unsigned long long *stats, uint32_t *locs32, uint32_t align_flush) {
     if (N == 0) return 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid(grid_for(cfg, N)), block(256);
     const uint32_t *perm = static_cast<const uint32_t *>(order);
 #define RBG_LAUNCH_LFR2(PT, OUT, STS, DST) \
-    hipLaunchKernelGGL((k_locate_fill_runs2<PT, OUT, STS>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, DST, sub, perm, skeys, stats)
+    hipLaunchKernelGGL((k_locate_fill_runs2<PT, OUT, STS>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, DST, sub, perm, skeys, stats, align_flush)
     if (locs32) {
         if (stats || ix.pos_bytes != 4) return static_cast<int>(hipErrorInvalidValue);
         RBG_LAUNCH_LFR2(uint32_t, uint32_t, false, locs32);

@@ -287,6 +287,12 @@ struct DevIndex {
     const uint64_t *phi_super;              // 8-byte positions: full counts every 2^phi_super_shift buckets
     uint64_t phi_m;                         // entries of the phi list (fillers included); entry phi_m is the sentinel
     uint64_t phi_last_pos, phi_last_base;   // the last sampled position and its base (circular predecessor, toehold_sa.hpp:59,65)
+    // In-kernel 2-bit staging of the reads (k_find_range_runs STAGE): with four major symbols whose bytes differ in the three bits
+    // from `stage_shift` up (ACGT and acgt: shift 0), a byte's code and the byte it must be come out of two 8-byte register tables by v_perm_b32 --
+    // four symbols per instruction, no per-symbol LDS lookup.  stage_ok == 0: the alphabet does not allow it; the kernel reads bytes as before.
+    uint32_t stage_ok, stage_shift;
+    uint32_t stage_code[2];    // byte t of {[0], [1]}: the major index of the symbol whose (byte >> shift) & 7 == t (0 where there is none)
+    uint32_t stage_byte[2];    // ... and that symbol's byte (a byte no symbol of the alphabet has where there is none)
 };
 
 // What the instrumented instantiations count (sums over the launch; include/rbg.h rbg_search_stats_t mirrors it).
@@ -416,7 +422,7 @@ int launch_find_range_runs_packed(const DevIndex &ix, const LaunchCfg &cfg, cons
 int launch_locate_fill_runs(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t *lo, const uint64_t *hi, const uint64_t *k,
                             uint64_t N, uint64_t max_hits, const uint64_t *loc_off, uint64_t *locs, const uint64_t *sub,
                             const void *order, const uint64_t *skeys, void *stream, unsigned long long *stats = nullptr /*kStatRunLocateN*/,
-                            uint32_t *locs32 = nullptr);
+                            uint32_t *locs32 = nullptr, uint32_t align_flush = 0 /* line-aligned flushes: k_locate.hip */);
 // the kernels beside the rb_align path on the run-indexed layout (k_runs_seeds.hip): k-mer steps through the depths' run lists
 int launch_lf_runs(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t *lo, const uint64_t *hi, const uint8_t *sym, uint64_t N,
                    uint64_t *lo_out, uint64_t *hi_out, void *stream);

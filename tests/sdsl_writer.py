@@ -1,4 +1,4 @@
-"""Test-side WRITER of the reference's on-disk index formats (.rbwt, .tsa), so that the sdsl-format reader of the library
+"""Test-side WRITER of the reference's on-disk index formats (.rbwt, .tsa, .mab), so that the sdsl-format reader of the library
 (rowbowt_amd/csrc/rbg_host.cpp parse_rbwt / parse_tsa) can be pinned at sizes the reference's toolchain -- sdsl-lite is an
 empty submodule in /root/reference, its build needs cmake and three more un-vendored libraries -- cannot produce here.
 
@@ -19,7 +19,8 @@ What is written (all little-endian):
          the tree: node count, 22-byte nodes {bv_pos, bv_pos_rank (leaves: bv size, the symbol), parent, child[2]}, c_to_leaf[256],
          path[256] (length in the top byte, branch bits below; an absent symbol: the largest present symbol below it)
 
-PINNED: re-serialising the decoded toy index reproduces tests/data/small.fa.rbwt and small.fa.tsa byte for byte
+  .mab   pfbwt-f MarkerArray (rowbowt_io.hpp:185 loads it): mab_bytes below
+PINNED: re-serialising the decoded toy index reproduces tests/data/small.fa.rbwt, small.fa.tsa and small.fa.mab byte for byte
 (tests/test_sdsl_writer.py).  NOT pinned by any fixture (none has them): long superblocks of a select support, Huffman ties between equal
 frequencies -- the reader skips the former and decodes any valid tree, so neither matters to what the writer is for.
 Everything is numpy: an index of r = 2e6 runs and n > 2^32 is written in seconds.
@@ -283,6 +284,36 @@ def tsa_arrays_from_samples(n, ssa_y, esa_y):
 
 
 # ---- decoders of the same structures (toy sizes: what the byte-for-byte test re-serialises) ----------------------------------------
+def mab_bytes(starts, ends, off, vals, wsize, universe=None):
+    """pfbwt-f's MarkerArray as rb_build writes it and load_rowbowt reads it (rowbowt_io.hpp:185; SURVEY 8b-format, inferred from the shipped
+    small.fa.mab and reproduced byte for byte below): three raw sdsl::sd_vector<> -- the first and the last BWT row of every marker run
+    (inclusive intervals, ascending, disjoint) over one universe, and a bit at the index of every run's first value over a universe of
+    `count` values -- then u64 count, count x u64 MarkerT, i32 window size.  `off`: nruns + 1 offsets into vals (off[-1] == len(vals)).
+    universe: the fixture's is its last run end + 2 (29 598 + 2; n = 30 031 there): taken as the default, the reader does not use it."""
+    starts, ends, off = (np.asarray(a, dtype=U64) for a in (starts, ends, off))
+    vals = np.ascontiguousarray(np.asarray(vals, dtype="<u8"))
+    assert len(starts) == len(ends) == len(off) - 1 and int(off[-1]) == len(vals)
+    if universe is None:
+        universe = int(ends[-1]) + 2 if len(ends) else 0
+    return (sd_vector_bytes(starts, universe) + sd_vector_bytes(ends, universe) + sd_vector_bytes(off[:-1], len(vals)) +
+            struct.pack("<Q", len(vals)) + vals.tobytes() + struct.pack("<i", int(wsize)))
+
+
+def decode_mab(data):
+    """-> universe, starts, ends, off (nruns + 1), vals (uint64 array), wsize"""
+    c = _Cur(data)
+    u0, s = c.sd_vector()
+    u1, e = c.sd_vector()
+    u2, f = c.sd_vector()
+    cnt = c.u64()
+    vals = np.frombuffer(c.d, dtype="<u8", count=cnt, offset=c.p).copy()
+    c.p += cnt * 8
+    wsize = struct.unpack_from("<i", c.d, c.p)[0]
+    c.p += 4
+    assert c.p == len(data) and u0 == u1 and u2 == cnt and len(s) == len(e) == len(f)
+    return u0, np.array(s, dtype=np.int64), np.array(e, dtype=np.int64), np.array(f + [cnt], dtype=np.int64), vals, wsize
+
+
 class _Cur:
     def __init__(self, data):
         self.d, self.p = data, 0

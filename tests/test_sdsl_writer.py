@@ -27,6 +27,11 @@ def test_writer_reproduces_the_shipped_fixtures_byte_for_byte(data_dir):
     r, n2, pred, last, p2r = W.decode_tsa(tsa)
     assert (r, n2) == (R, n)
     assert W.tsa_bytes(n2, pred, last, p2r) == tsa
+    # .mab (pfbwt-f MarkerArray; rowbowt_io.hpp:185): decoded and re-serialised, identical
+    mab = open(os.path.join(data_dir, "small.fa.mab"), "rb").read()
+    u, ms, me, moff, mvals, wsize = W.decode_mab(mab)
+    assert (u, len(ms), len(mvals), wsize) == (29600, 190, 190, 10)
+    assert W.mab_bytes(ms, me, moff, mvals, wsize, universe=u) == mab and W.mab_bytes(ms, me, moff, mvals, wsize) == mab
     # the decoder of this file and the library's reader agree on the fixture (so "decoded, re-serialised, identical" is about the same arrays)
     rb = ra.load_rowbowt(os.path.join(data_dir, "small.fa"), ra.LoadRbwtFlag.SA, device=capi.DEVICE_NONE)
     assert (rb.host_array(0) == heads).all() and (np.diff(rb.host_array(1).astype(np.int64)) == lens).all()
@@ -141,6 +146,102 @@ def test_rbg_load_of_a_written_index_of_two_million_runs_beyond_32_bits_equals_f
             f.write(bad)
         with pytest.raises(Exception):
             ra.load_rowbowt(prefix + "_bad", device=capi.DEVICE_NONE)
+
+
+def _random_marker_array(rng, n, nruns):
+    """disjoint ascending inclusive row intervals (1-3 rows wide, like small.fa.mab's), one to four values per run; MarkerT = allele in bits
+    60-63, position below"""
+    stride = n // nruns
+    assert stride >= 8
+    width = rng.integers(0, 3, size=nruns).astype(np.int64)
+    starts = np.arange(nruns, dtype=np.int64) * stride + rng.integers(0, stride - 3, size=nruns)   # (one run per stride of rows: disjoint, over the whole BWT)
+    ends = starts + width
+    assert int(ends[-1]) < n and (starts[1:] > ends[:-1]).all()
+    per = rng.integers(1, 5, size=nruns).astype(np.int64)
+    off = np.concatenate([[0], np.cumsum(per)])
+    vals = (rng.integers(0, 1 << 40, size=int(off[-1]), dtype=np.uint64) | (rng.integers(0, 3, size=int(off[-1])).astype(np.uint64) << np.uint64(60)))
+    return starts.astype(np.uint64), ends.astype(np.uint64), off.astype(np.uint64), vals
+
+
+@pytest.fixture(scope="module")
+def big_markers(big_index):
+    """a marker array of 1.2e6 runs / 3e6 values over the big index, written as <prefix>.mab (the reader had only ever seen
+    the 2.8 KB fixture)"""
+    prefix, _heads, _lens, _ssa, _esa, n = big_index
+    starts, ends, off, vals = _random_marker_array(np.random.default_rng(9), n, 1_200_000)
+    with open(prefix + ".mab", "wb") as f:
+        f.write(W.mab_bytes(starts, ends, off, vals, 10))
+    return starts, ends, off, vals
+
+
+def test_rbg_load_of_a_written_mab_of_a_million_marker_runs_equals_set_markers(big_index, big_markers):
+    prefix, heads, lens, ssa, esa, n = big_index
+    starts, ends, off, vals = big_markers
+    assert os.path.getsize(prefix + ".mab") > 25_000_000 and int(ends[-1]) > (1 << 32)    # (sd_vectors of 290 superblocks, rows beyond 32 bits)
+    a = ra.load_rowbowt(prefix, ra.LoadRbwtFlag.SA | ra.LoadRbwtFlag.MA, device=capi.DEVICE_NONE)
+    b = ra.RowBowt.from_runs(heads, lens, ssa, esa, device=capi.DEVICE_NONE)
+    b.set_markers(starts, ends, off, vals)
+    ia, ib = a.info(), b.info()
+    assert ia.has_markers == ib.has_markers == 1 and (ia.marker_runs, ia.marker_vals) == (ib.marker_runs, ib.marker_vals) == (1_200_000, len(vals))
+    for which, want in ((capi.ARR_MARKER_START, starts), (capi.ARR_MARKER_END, ends), (capi.ARR_MARKER_OFF, off), (capi.ARR_MARKER_VALS, vals)):
+        x, y = a.host_array(which), b.host_array(which)
+        assert x.shape == y.shape == want.shape and (x == y).all() and (x == want).all(), which
+    a.close()
+    b.close()
+    # the writer's own decoder on a slice-sized file (the pure-Python decoder is for small inputs): same arrays back
+    k = 5000
+    small = W.mab_bytes(starts[:k], ends[:k], off[:k + 1], vals[:int(off[k])], 10)
+    _u, ds, de, doff, dvals, dw = W.decode_mab(small)
+    assert (ds == starts[:k].astype(np.int64)).all() and (de == ends[:k].astype(np.int64)).all() and (doff == off[:k + 1].astype(np.int64)).all()
+    assert (dvals == vals[:int(off[k])]).all() and dw == 10
+    # a truncated .mab is refused
+    data = open(prefix + ".mab", "rb").read()
+    with open(prefix + "_cut.mab", "wb") as f:
+        f.write(data[:len(data) - 9])
+    for suf in (".rbwt", ".tsa"):
+        if not os.path.exists(prefix + "_cut" + suf):
+            os.symlink(prefix + suf, prefix + "_cut" + suf)
+    with pytest.raises(Exception):
+        ra.load_rowbowt(prefix + "_cut", ra.LoadRbwtFlag.MA, device=capi.DEVICE_NONE)
+
+
+@pytest.mark.gpu
+def test_rb_align_m_from_a_written_mab_equals_markers_attached_through_the_abi(big_index, big_markers, tmp_path):
+    """`rb_align -m` (rb_align.cpp:133-143: find_range + markers_at per read) from the index FILES in the reference's formats -- .rbwt, .tsa and
+    the 29 MB .mab -- against the same index built from arrays with the marker array attached through rbg_set_markers: identical stdout; and the
+    marker lists of 4 000 reads through rbg_load equal those through rbg_set_markers."""
+    from gpu_common import _run_cli
+    prefix, heads, lens, ssa, esa, n = big_index
+    starts, ends, off, vals = big_markers
+    a = ra.load_rowbowt(prefix, ra.LoadRbwtFlag.SA | ra.LoadRbwtFlag.MA, device=0)
+    b = ra.RowBowt.from_runs(heads, lens, ssa, esa, device=0)
+    b.set_markers(starts, ends, off, vals)
+    rng = np.random.default_rng(6)
+    sym = np.frombuffer(b"ACGT", dtype=np.uint8)
+    reads = [sym[rng.integers(0, 4, int(m))].tobytes() for m in rng.integers(8, 13, 4000)]
+    seqs, offs = ra.pack_reads(reads)
+    la, ha = a.find_range(seqs, offs)
+    lb, hb = b.find_range(seqs, offs)
+    assert (la == lb).all() and (ha == hb).all() and int((ha >= la).sum()) > 1000
+    ma_off, ma = a.markers_at(la, ha)
+    mb_off, mb = b.markers_at(lb, hb)
+    assert (ma_off == mb_off).all() and (ma == mb).all() and len(ma) > 1000
+    # the marker lists are what the arrays say: the values of every run that meets [lo, hi], in run order
+    for i in np.flatnonzero(ha >= la)[:300]:
+        f, l = np.searchsorted(ends, la[i], side="left"), np.searchsorted(starts, ha[i], side="right")
+        assert ma[int(ma_off[i]):int(ma_off[i + 1])].tolist() == vals[int(off[f]):int(off[l])].tolist() if l > f else ma_off[i] == ma_off[i + 1]
+    # the CLI from the files against the CLI from a native cache made of the arrays (rbg_convert_runs_markers)
+    fq = tmp_path / "r.fq"
+    fq.write_text("".join(f"@q{i}\n{r.decode()}\n+\n{'I' * len(r)}\n" for i, r in enumerate(reads[:1500])))
+    rc, out_files, err = _run_cli(["-m", prefix, str(fq)])
+    assert rc == 0, err
+    cache = str(tmp_path / "arr.rbgpu")
+    capi.convert_runs(heads, lens, ssa, esa, out_path=cache, markers=(starts, ends, off, vals))
+    rc, out_cache, err = _run_cli(["-m", cache[:-len(".rbgpu")], str(fq)])
+    assert rc == 0, err
+    assert out_files == out_cache and out_files.count("\n") >= 1500
+    a.close()
+    b.close()
 
 
 @pytest.mark.gpu
