@@ -96,6 +96,10 @@ def parse():
                          "read batch per replica; the line's value / n_gpus / ms_per_step then describe the G replicas (weak scaling: --reads per replica). "
                          "The driver's N-GPU contract stays one process per GPU (--gpus N)")
     ap.add_argument("--replica-devices", default="", help="devices of --replicas, comma separated (default 0, 1, ...; may repeat)")
+    ap.add_argument("--docs", choices=("on", "off"), default="off",
+                    help="attach the pangenome's document table (one document per haplotype: what the .docs file of a pangenome index lists, doclist.hpp:62-65) "
+                         "through rbg_set_docs before the timed steps: K3 then orders its chains by locus (offset inside the document, then document) instead "
+                         "of absolute text position -- result-neutral")
     ap.add_argument("--no-pangenome-shape", action="store_true",
                     help="skip the pangenome_shape block: BASELINE.json configs[3]'s index shape on one GPU (tools/pangenome_stream.py --preset driver in a "
                          "child process once this process has given its HBM back: a true BWT of r = 1.2e8 runs, a default rbg_load, 150 bp device-generated "
@@ -255,6 +259,8 @@ def run():
         rb = ra.RowBowt.from_runs(inp["heads"], inp["lens"], inp["ssa"], inp["esa"], device=local_rank)
         t_load = time.time() - t0
     t_wait = t0 - t_wait   # (ranks > 0: the time spent waiting for rank 0's suffix array and cache file)
+    if args.docs == "on":
+        rb.set_docs([f"hap{h_}" for h_ in range(info["H"])], [h_ * info["unit"] for h_ in range(info["H"])])
     ix = rb.info()
     if inp is None:   # (ranks > 0: what the line's config block and the checks need is on rank 0 only)
         inp = {"n": int(ix.n), "r": int(ix.r)}
@@ -474,7 +480,24 @@ def run():
             mstep()
         el_mk = timed(mstep, K)
         n_with = int(((d_mk_off[1:] - d_mk_off[:-1]) > 0).sum().item())
+        # the two marker kernels of the step apart (HIP events), and the step's bytes: K1's as run (kernels["k_find_range<count>"] below) + per read the
+        # range (16) and its offset (8 + 8), two directory entries (8) and about two run starts / ends (16) per matched read, 16 per marker copied
+        e_m = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        k_count()
+        e_m[0].record(stream)
+        k_mplan()
+        e_m[1].record(stream)
+        chk(L.rbg_markers_fill_dev(rb.h, d_lo.data_ptr(), d_hi.data_ptr(), N, d_mk_off.data_ptr(), d_mk.data_ptr(), st), "markers_fill")
+        e_m[2].record(stream)
+        torch.cuda.synchronize()
+        ms_mplan, ms_mfill = e_m[0].elapsed_time(e_m[1]), e_m[1].elapsed_time(e_m[2])
+        mk_bytes = 2 * (N * 32 + n_matched * 24) + 16 * total_mk
         mk_block = {"value": N * K / el_mk, "unit": "reads/s (this rank)", "ms_per_step": el_mk / K * 1e3,
+                    "kernels_ms": {"markers_plan(k_markers_count+scan)": ms_mplan, "markers_fill": ms_mfill},
+                    "roofline": {"bound": "hbm", "kernel": "k_find_range<count> (the step's dominant kernel: its roofline is kernels[k_find_range<count>] of this line); the two marker kernels:",
+                                 "marker_kernels_alg_bytes": mk_bytes, "marker_kernels_ms": ms_mplan + ms_mfill,
+                                 "achieved": mk_bytes / ((ms_mplan + ms_mfill) * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": mk_bytes / ((ms_mplan + ms_mfill) * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None},
                     "workload": "BASELINE.json configs[4] in rb_align -m form: find_range + markers_at(range), synthetic marker array "
                                 "(w=10 rows before every variant site, both alleles)",
                     "marker_runs": int(len(marker_arrays[0])), "marker_values": int(len(marker_arrays[3])),
@@ -536,6 +559,58 @@ def run():
 
         gstep()
         el_g = timed(gstep, K)
+        # ---- what the seeding kernels touched, and their rooflines (run-indexed layout: the instrumented instantiations, outside every timed region;
+        # DESIGN.md 3).  Bytes as run: per sequence and walk its offsets (16) and 16 per read chunk; the plan's two counts (16); 64 per bucket
+        # record, 8 per run-list entry scanned, 28 per narrowing round, the ftab entry, 4 / 6 per re-sample; per marker query 4 per directory entry,
+        # 8 per run start / end read, 8 per value offset; the fill's seed records (48 each) and marker values (8 read + 8 written each).
+        seed_roof = {}
+        if int(ix.rank_layout) == 2:
+            SD = ("steps", "slots", "dense", "searched_ranks", "ftab", "resamples", "read_chunks", "symbols", "marker_queries", "marker_dir", "marker_probes",
+                  "marker_off", "marker_vals", "seed_recs", "sequences")
+            Pm = int(ix.pos_bytes)
+            ftab_bm, samp_bm = (16 if Pm == 4 else 32), (4 if Pm == 4 else 6)
+            li_m = rb.layout_info()
+            rec_bm = 64 if any(int(x) for x in li_m.rec_bytes) else (8 if Pm == 4 else 16)
+            d_sst = torch.zeros(16, dtype=torch.int64, device=dev)
+
+            def seed_bytes(v, walks, counts_out):
+                return (v["sequences"] * 16 + 16 * v["read_chunks"] + counts_out + rec_bm * v["slots"] + 8 * v["dense"] + 28 * v["searched_ranks"] + ftab_bm * v["ftab"]
+                        + samp_bm * v["resamples"] + 4 * v["marker_dir"] + 8 * v["marker_probes"] + 8 * v["marker_off"] + 16 * v["marker_vals"] + 48 * v["seed_recs"])
+
+            chk(L.rbg_marker_seeds_stats_dev(rb.h, d_seqs2.data_ptr(), d_off2.data_ptr(), 2 * N, WS, MR, d_soff.data_ptr(), d_moff.data_ptr(), d_tmp2.data_ptr(), tmp2,
+                                             d_srec.data_ptr(), d_smk.data_ptr(), d_sst.data_ptr(), st), "marker_seeds_stats")
+            torch.cuda.synchronize()
+            same_inst = (int(d_soff[-1].item()), int(d_moff[-1].item())) == (n_seeds, n_smk)
+            v_ms = dict(zip(SD, d_sst.cpu().numpy().tolist()[:15]))
+            b_ms = seed_bytes(v_ms, 2, 2 * N * 16)
+            t_ms = el_sd / K
+            seed_roof["marker_seeds"] = {"bound": "hbm", "kernel": "k_marker_seeds_runs (count walk + fill walk)", "achieved": b_ms / t_ms / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                         "frac": b_ms / t_ms / 1e9 / HBM_PEAK_GBS, "alg_bytes_per_step": b_ms, "ms": t_ms * 1e3, "touched": v_ms,
+                                         "per_sequence_and_walk": {k_: v_ms[k_] / max(v_ms["sequences"], 1) for k_ in SD[:-1]},
+                                         "sectors_per_sequence_and_walk": (v_ms["slots"] + (v_ms["dense"] + 7) // 8 + v_ms["searched_ranks"] + v_ms["ftab"] + v_ms["marker_dir"]
+                                                                           + v_ms["marker_probes"] + v_ms["marker_off"]) / max(v_ms["sequences"], 1),
+                                         "same_outputs_as_the_timed_instantiation": same_inst, "traffic": None}
+            d_sst.zero_()
+            chk(L.rbg_greedy_longest_seed_stats_dev(rb.h, d_seqs.data_ptr(), d_off.data_ptr(), N, 20, *(t.data_ptr() for t in d_g), d_sst.data_ptr(), st), "greedy_seed_stats")
+            torch.cuda.synchronize()
+            v_g = dict(zip(SD, d_sst.cpu().numpy().tolist()[:15]))
+            b_g = seed_bytes(v_g, 1, N * 40)
+            t_g = el_g / K
+            seed_roof["greedy_seed"] = {"bound": "hbm", "kernel": "k_greedy_seed_runs", "achieved": b_g / t_g / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": b_g / t_g / 1e9 / HBM_PEAK_GBS, "alg_bytes_per_step": b_g, "ms": t_g * 1e3, "touched": v_g,
+                                        "per_sequence": {k_: v_g[k_] / max(v_g["sequences"], 1) for k_ in SD[:-1]}, "traffic": None}
+            # counter traffic where the stamped PMC file of this library holds the seeding kernels (tools/run_profiles_pmc.sh with --markers)
+            try:
+                import hashlib as _hl
+                pjm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+                if pjm.get("_librbg_sha256") == _hl.sha256(open(os.path.join(ROOT, "rowbowt_amd", "librbg.so"), "rb").read()).hexdigest():
+                    for key_, name_ in (("marker_seeds", "k_marker_seeds_runs (plan + fill)"), ("greedy_seed", "k_greedy_seed_runs")):
+                        e_ = pjm.get(name_)
+                        if isinstance(e_, dict) and e_.get("hbm_bytes_per_launch"):
+                            seed_roof[key_]["traffic"] = e_["hbm_bytes_per_launch"]
+                            seed_roof[key_]["tcc_miss_per_launch"] = e_.get("tcc_miss_per_launch")
+            except Exception:
+                pass
         slot_other = {"greedy_seed_ms": el_g / K * 1e3, "marker_seeds_ms": el_sd / K * 1e3, "marker_seeds_logged_ms": el_sl / K * 1e3}
         ref_g = [t.clone() for t in d_g]
         ref_seed_counts = (n_seeds, n_smk)
@@ -548,6 +623,9 @@ def run():
                                                "identical_to_the_two_walk_pair": same_log,
                                                "workload": "rbg_marker_seeds_plan_log_dev + _fill_log_dev: the count pass logs, the fill pass copies"},
                                     "workload": "rb_markers default mode: get_markers_greedy_seeding on read + reverse complement"}
+        if seed_roof:
+            mk_block["marker_seeds"]["roofline"] = seed_roof["marker_seeds"]
+            mk_block["greedy_seed"]["roofline"] = seed_roof["greedy_seed"]
 
     # ---- what the kernels touched: one pass of the INSTRUMENTED instantiations on the same batch (outside every
     # timed region; same outputs).  The bytes of the algorithm as run follow from these counts.
@@ -641,6 +719,7 @@ def run():
         import hashlib
         so_hash = hashlib.sha256(open(os.path.join(ROOT, "rowbowt_amd", "librbg.so"), "rb").read()).hexdigest()
         traffic = misses = None
+        pmc_by_kernel = {}   # kernels' counter traffic (HBM bytes, L2 misses per launch) where the stamped PMC file holds them
         pmc_note = "no PMC passes committed for this build"
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         default_workload = (args.L, args.H, args.reads, args.read_len, args.site_rate) == (40_000_000, 50, 10_000_000, 100, 0.01)
@@ -652,6 +731,11 @@ def run():
                     traffic = pj.get(pkey, {}).get("hbm_bytes_per_launch")
                     misses = pj.get(pkey, {}).get("tcc_miss_per_launch")
                     pmc_note = pj.get("_source")
+                    sfx = f" [runs, pos_bytes {P}]" if runs_layout else ""
+                    for kk_ in kernels:
+                        ent_ = pj.get(kk_ + sfx) if kk_.startswith("k_find_range") else pj.get(kk_)
+                        if isinstance(ent_, dict) and ent_.get("hbm_bytes_per_launch"):
+                            pmc_by_kernel[kk_] = ent_
                 else:
                     pmc_note = "profiles/pmc_traffic.json was taken with a different librbg.so build: dropped"
             except Exception:
@@ -696,6 +780,10 @@ def run():
                           "hbm_budget_source": ("bench.py --hbm-budget-gb -1: three quarters of the free HBM" if args.hbm_budget_gb < 0
                                                 else "the library's default (a quarter of the free HBM)" if args.hbm_budget_gb == 0 else f"--hbm-budget-gb {args.hbm_budget_gb}"), "ftab_k": int(ix.ftab_k), "depth_runs": [int(x) for x in ix.depth_runs]},
                 "reads_per_gpu": N, "read_len": m, "substituted_fraction": 0.1,
+                "documents": info["H"] if args.docs == "on" else 0,
+                "chain_order": ("by locus: offset inside the document, then document"
+                                if args.docs == "on" and os.environ.get("RBG_LOCATE_ORDER") != "abs" and (info["H"] >= 128 or os.environ.get("RBG_LOCATE_ORDER") == "locus")
+                                else "by absolute text position"),
                 "parallelism": f"index replicated x{world}, reads sharded, no data-path collective",
                 **({"rehearsal": f"NOT A MEASUREMENT: {world} ranks on {torch.cuda.device_count()} GPU(s), collectives over gloo (--rehearse-ranks)"}
                    if args.rehearse_ranks else {}),
@@ -743,8 +831,16 @@ def run():
                          "note": "achieved = bytes of the algorithm as run (counted by the instrumented instantiation of the same kernel on the "
                                  "same batch: executed steps x slots touched x 16 + read chunks + ftab entries + re-sample gathers + offsets + "
                                  "outputs) / mean kernel duration (HIP events on the launch stream)"},
+            # per kernel: `frac_of_hbm_peak` prices the bytes of the algorithm AS RUN (every executed step's bytes, whether a cache or HBM served them:
+            # where neighbouring chains share sectors -- K3 in toehold order -- it EXCEEDS what HBM moved); `traffic_*` are the counters' HBM bytes
+            # (FETCH_SIZE + WRITE_SIZE of the stamped PMC file) over the same duration: the HBM figure
             "kernels": {k: {"ms": v["ms"], "alg_bytes": v["alg_bytes"], "alg_GBps": v["alg_bytes"] / (v["ms"] * 1e-3) / 1e9,
-                            "frac_of_hbm_peak": v["alg_bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "touched": v.get("touched")}
+                            "frac_of_hbm_peak": v["alg_bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "frac_of_hbm_peak_is": "bytes of the algorithm as run, cache-served bytes included",
+                            **({"traffic_bytes": pmc_by_kernel[k]["hbm_bytes_per_launch"], "tcc_miss_per_launch": pmc_by_kernel[k].get("tcc_miss_per_launch"),
+                                "traffic_frac_of_hbm_peak": pmc_by_kernel[k]["hbm_bytes_per_launch"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "alg_bytes_over_traffic": v["alg_bytes"] / pmc_by_kernel[k]["hbm_bytes_per_launch"]} if k in pmc_by_kernel else {}),
+                            "touched": v.get("touched")}
                         for k, v in kernels.items()},
             "per_read": {"lf_gathers": st_toe["steps"] / N, "slots": st_toe["slots"] / N, "symbols_consumed": st_toe["symbols"] / N,
                          "read_chunks": st_toe["read_chunks"] / N, "resamples": st_toe["resamples"] / N,

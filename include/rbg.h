@@ -456,6 +456,23 @@ enum { RBG_LS_PHI_STEPS = 0,  /* phi evaluations (one phi slot each) */
        RBG_LS_CHAINS,         /* reads with at least one location */
        RBG_LS_LOCS,           /* locations stored */
        RBG_LOCATE_STATS };
+/* The seeding kernels' instrumented instantiations (run-indexed layout only; RBG_EARG elsewhere): RBG_SEED_STATS sums -- the eight of
+ * RBG_SEARCH_STATS with that layout's meanings, then the marker side.  rbg_marker_seeds_stats_dev = rbg_marker_seeds_plan_dev +
+ * rbg_marker_seeds_fill_dev (the two-walk pair, no log, no --ftab) with both walks instrumented: same offsets, records and markers. */
+enum { RBG_SD_MARKER_QUERIES = 8, /* window queries that went to the marker runs (rowbowt.hpp:437-441 with range <= max_range) */
+       RBG_SD_MARKER_DIR,         /* directory entries read for them (4 bytes each) */
+       RBG_SD_MARKER_PROBES,      /* run starts / ends read (8 bytes each) */
+       RBG_SD_MARKER_OFF,         /* value offsets read (8 bytes each) */
+       RBG_SD_MARKER_VALS,        /* marker values copied (8 read + 8 written each) */
+       RBG_SD_SEED_RECS,          /* seed records written (48 bytes each) */
+       RBG_SD_SEQUENCES,          /* sequences walked */
+       RBG_SEED_STATS };
+int rbg_greedy_longest_seed_stats_dev(rbg_index *, const uint8_t *d_seqs, const uint64_t *d_off, uint64_t N, uint64_t min_length,
+                                      uint64_t *d_lo, uint64_t *d_hi, uint64_t *d_qstart, uint64_t *d_qend, uint64_t *d_ssamp,
+                                      uint64_t *d_stats /* RBG_SEED_STATS */, void *stream);
+int rbg_marker_seeds_stats_dev(rbg_index *, const uint8_t *d_seqs, const uint64_t *d_off, uint64_t N, uint64_t wsize, uint64_t max_range,
+                               uint64_t *d_seed_off, uint64_t *d_mk_off, void *d_tmp, size_t tmp_bytes, rbg_marker_seed_t *d_seeds,
+                               uint64_t *d_mk, uint64_t *d_stats /* RBG_SEED_STATS */, void *stream);
 int rbg_find_range_stats_dev(rbg_index *, const uint8_t *d_seqs, const uint64_t *d_off, uint64_t N, uint64_t *d_lo,
                              uint64_t *d_hi, uint64_t *d_ssamp /* NULL = count-only kernel */,
                              uint64_t *d_stats /* RBG_SEARCH_STATS */, void *stream);

@@ -125,6 +125,8 @@ _PROTOS = [
     ("rbg_marker_seeds_plan_log_dev", C.c_int, [VP, VP, VP, U64, U64, U64, U64, VP, VP, VP, C.c_size_t, VP, C.c_size_t, VP]),
     ("rbg_marker_seeds_fill_log_dev", C.c_int, [VP, VP, VP, U64, U64, U64, U64, VP, VP, VP, VP, VP, C.c_size_t, VP]),
     ("rbg_locate_fill_dev32", C.c_int, [VP, VP, VP, VP, U64, U64, VP, VP, VP, VP]),
+    ("rbg_greedy_longest_seed_stats_dev", C.c_int, [VP, VP, VP, U64, U64, VP, VP, VP, VP, VP, VP, VP]),
+    ("rbg_marker_seeds_stats_dev", C.c_int, [VP, VP, VP, U64, U64, U64, VP, VP, VP, C.c_size_t, VP, VP, VP, VP]),
     ("rbg_find_range_stats_dev", C.c_int, [VP, VP, VP, U64, VP, VP, VP, VP, VP]),
     ("rbg_locate_fill_stats_dev", C.c_int, [VP, VP, VP, VP, U64, U64, VP, VP, VP, VP, VP]),
     ("rbg_sample_reads_dev", C.c_int, [VP, U64, U64, U64, U64, U64, U64, U64, C.c_uint32, VP, VP, VP, VP]),

@@ -397,11 +397,14 @@ FlattenOptions options_for(int device, const RawRle &rle, uint64_t *requested, b
     return o;
 }
 
+int upload_order_docs(rbg_index *ix);   // (below, beside rbg_set_docs)
+
 int finish(rbg_index *ix, int device, rbg_index **out) {
     ix->device = device;
     if (device != RBG_DEVICE_NONE) {
         const auto t0 = std::chrono::steady_clock::now();
         int rc = upload(ix);
+        if (!rc) rc = upload_order_docs(ix);   // (a document table loaded with the index: K3's chains in locus order)
         if (rc) { rbg_free(ix); return rc; }
         if (std::getenv("RBG_VERBOSE"))
             std::fprintf(stderr, "rbg: slot tables + upload %.2f s (%.2f GB)\n",
@@ -1120,6 +1123,45 @@ int rbg_set_markers(rbg_index *ix, const uint64_t *run_start, const uint64_t *ru
     });
 }
 
+}  // extern "C"
+namespace {
+// the document starts on the device for K3's locus order (rbg_dev.h order_docs).  RBG_LOCATE_ORDER=abs keeps the order by absolute position.
+int upload_order_docs(rbg_index *ix) {
+    DevIndex &d = ix->dev;
+    d.order_docs = nullptr;
+    d.order_ndocs = d.order_dbits = d.order_lowbits = d.order_obits = 0;
+    if (ix->device == RBG_DEVICE_NONE || ix->primary) return RBG_OK;
+    // RBG_LOCATE_ORDER = abs: never; locus: whenever there are two documents or more; unset: from 128 documents on -- measured (profiles/
+    // r06_locus_order_ab.txt): K3 53.7 -> 50.4 ms per 10 M x 150 bp reads at r = 1.07e9 / 520 haplotypes, equal at 200 haplotypes, and on the bench
+    // index (50 haplotypes) the key pass and the wider sort cost more (0.17 ms) than K3 gains (0.02 ms).
+    const char *e = std::getenv("RBG_LOCATE_ORDER");
+    if (e && std::strcmp(e, "abs") == 0) return RBG_OK;
+    const bool forced = e && std::strcmp(e, "locus") == 0;
+    const RawDocs &dl = ix->H().dl;
+    const uint64_t nd = dl.sorted.size();
+    if (!ix->H().has_dl || nd < (forced ? 2u : 128u) || nd > (uint64_t(1) << 20) || dl.sorted[0] != 0) return RBG_OK;   // (one document: the absolute order already is the locus order)
+    uint64_t longest = 0;
+    for (uint64_t j = 0; j < nd; ++j) longest = std::max(longest, (j + 1 < nd ? dl.sorted[j + 1] : ix->H().n) - dl.sorted[j]);
+    uint32_t obits = 1, dbits = 1;
+    while (obits < 64 && (longest >> obits)) ++obits;
+    while ((nd >> dbits)) ++dbits;
+    if (obits + dbits > 60) return RBG_OK;
+    DeviceScope scope(ix->device);
+    if (scope.rc) return scope.rc;
+    const void *p = nullptr;
+    int rc = dev_upload(ix, dl.sorted.data(), nd * 8, &p);
+    if (rc) return rc;
+    d.order_docs = static_cast<const uint64_t *>(p);
+    d.order_ndocs = static_cast<uint32_t>(nd);
+    d.order_dbits = dbits;
+    d.order_obits = obits;
+    // positions inside one line of phi slots need no sorting (as in the absolute order: launch_locate_order's begin_bit)
+    d.order_lowbits = std::min<uint32_t>(d.phi_shift + 2u, obits > 8 ? obits - 8 : 0u);
+    return RBG_OK;
+}
+}  // namespace
+extern "C" {
+
 int rbg_set_docs(rbg_index *ix, const char *names_joined, const uint64_t *starts, uint64_t ndocs) {
     return guarded([&]() -> int {
     if (!ix || !names_joined || !starts || ix->primary) return RBG_EARG;
@@ -1139,7 +1181,7 @@ int rbg_set_docs(rbg_index *ix, const char *names_joined, const uint64_t *starts
         std::lock_guard<std::mutex> g2(ix->text_mu);
         ix->text_docs = rbg_index::TextDocs();
     }
-    return RBG_OK;
+    return upload_order_docs(ix);   // (K3's chain order by locus: attach the documents BEFORE replicating, like the markers)
     });
 }
 

@@ -106,7 +106,7 @@ int replicate_finish(rbg_index *src, ReplicaJob &job) {
     reloc.fix(d.mk_start); reloc.fix(d.mk_end); reloc.fix(d.mk_off); reloc.fix(d.mk_vals); reloc.fix(d.mk_bucket);
     reloc.fix(d.counters); reloc.fix(d.lut); reloc.fix(d.pairs); reloc.fix(d.triples); reloc.fix(d.quads); reloc.fix(d.quints);
     reloc.fix(d.lut2); reloc.fix(d.ftab); reloc.fix(d.dense);
-    reloc.fix(d.phi_dir);
+    reloc.fix(d.phi_dir); reloc.fix(d.order_docs);
     for (int t = 0; t < kMaxRunDepth; ++t) reloc.fix(d.run_samp[t]);
     reloc.fix(d.run_tabs2); reloc.fix(d.run_hot); reloc.fix(d.phi_super);
     for (int t = 0; t < kMaxRunDepth; ++t) { reloc.fix(d.run_ent2[t]); reloc.fix(d.run_dir2[t]); reloc.fix(d.run_rec2[t]); }

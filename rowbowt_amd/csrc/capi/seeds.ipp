@@ -265,6 +265,39 @@ int rbg_greedy_longest_seed_dev(rbg_index *ix, const uint8_t *d_seqs, const uint
     });
 }
 
+// The instrumented instantiations of the seeding kernels (run-indexed layout; include/rbg.h RBG_SEED_STATS): the same walks and outputs, plus what
+// they touched.  bench.py prices the kernels' rooflines from these sums.
+int rbg_greedy_longest_seed_stats_dev(rbg_index *ix, const uint8_t *d_seqs, const uint64_t *d_off, uint64_t N, uint64_t min_length,
+                                      uint64_t *d_lo, uint64_t *d_hi, uint64_t *d_qstart, uint64_t *d_qend, uint64_t *d_ssamp, uint64_t *d_stats,
+                                      void *stream) {
+    return guarded([&]() -> int {
+    if (!queryable(ix)) return RBG_ENODEV;
+    if (!ix->H().has_tsa) return RBG_ENOTLOADED;
+    if (!d_stats || (N && (!d_seqs || !d_off || !d_lo || !d_hi || !d_qstart || !d_qend || !d_ssamp))) return RBG_EARG;
+    if (reinterpret_cast<uintptr_t>(d_seqs) & 15) return RBG_EARG;
+    if (ix->dev.layout != RBG_LAYOUT_RUNS) return RBG_EARG;
+    return launch_greedy_seed(ix->dev, ix->cfg, d_seqs, d_off, N, min_length, d_lo, d_hi, d_qstart, d_qend, d_ssamp, stream,
+                              reinterpret_cast<unsigned long long *>(d_stats)) ? RBG_ENODEV : RBG_OK;
+    });
+}
+
+// plan (count walk + scans) and fill (second walk) of the marker seeds in one call, both instrumented, sums added to d_stats
+int rbg_marker_seeds_stats_dev(rbg_index *ix, const uint8_t *d_seqs, const uint64_t *d_off, uint64_t N, uint64_t wsize, uint64_t max_range,
+                               uint64_t *d_seed_off, uint64_t *d_mk_off, void *d_tmp, size_t tmp_bytes, rbg_marker_seed_t *d_seeds, uint64_t *d_mk,
+                               uint64_t *d_stats, void *stream) {
+    return guarded([&]() -> int {
+    if (!queryable(ix)) return RBG_ENODEV;
+    if (!d_stats || !d_seed_off || !d_mk_off || (N && (!d_seqs || !d_off || !d_seeds))) return RBG_EARG;
+    if (reinterpret_cast<uintptr_t>(d_seqs) & 15) return RBG_EARG;
+    if (tmp_bytes < scan_tmp_bytes(N) || (N && !d_tmp)) return RBG_EARG;
+    if (ix->dev.layout != RBG_LAYOUT_RUNS) return RBG_EARG;
+    unsigned long long *st = reinterpret_cast<unsigned long long *>(d_stats);
+    if (launch_marker_seeds_plan(ix->dev, ix->cfg, d_seqs, d_off, N, wsize, max_range, 0, d_seed_off, d_mk_off, d_tmp, tmp_bytes, stream, nullptr, 0, st)) return RBG_ENODEV;
+    return launch_marker_seeds_fill(ix->dev, ix->cfg, d_seqs, d_off, N, wsize, max_range, 0, d_seed_off, d_mk_off, reinterpret_cast<uint64_t *>(d_seeds), d_mk,
+                                    stream, nullptr, 0, st) ? RBG_ENODEV : RBG_OK;
+    });
+}
+
 int rbg_locate_fill_offset_dev(rbg_index *ix, const uint64_t *d_lo, const uint64_t *d_hi, const uint64_t *d_k, uint64_t N,
                                uint64_t max_hits, const uint64_t *d_loc_off, uint64_t *d_locs, const uint64_t *d_sub,
                                const void *d_order, void *stream) {

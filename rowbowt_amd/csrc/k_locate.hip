@@ -18,6 +18,34 @@ __global__ __launch_bounds__(256) void k_occ(const uint64_t *__restrict__ lo, co
     if (blockIdx.x == 0 && threadIdx.x == 0) out[0] = 0;
 }
 
+// ---- the locus order's sort key (rbg_dev.h order_docs): k <-> {offset >> low, document, offset & (2^low - 1)} -----------------------------
+// A toehold outside the text (it wrapped below zero: k >= n) has no document: its key is all ones and K3 reads the toehold itself.
+__device__ __forceinline__ uint64_t locus_key(const DevIndex &ix, const uint64_t k) {
+    if (k >= ix.n) return ~uint64_t(0);
+    uint32_t a = 0, z = ix.order_ndocs;          // the last document that starts at or before k (doclist.hpp:46-50: a predecessor query)
+    while (z - a > 1u) {
+        const uint32_t m = (a + z) >> 1;
+        if (ix.order_docs[m] <= k) a = m; else z = m;
+    }
+    const uint64_t o = k - ix.order_docs[a];
+    const uint32_t low = ix.order_lowbits, db = ix.order_dbits;
+    return ((o >> low) << (db + low)) | (static_cast<uint64_t>(a) << low) | (o & ((uint64_t(1) << low) - 1u));
+}
+__device__ __forceinline__ uint64_t locus_toehold(const DevIndex &ix, const uint64_t key, const uint64_t *__restrict__ k, const uint64_t i) {
+    if (key == ~uint64_t(0)) return k[i];
+    const uint32_t low = ix.order_lowbits, db = ix.order_dbits;
+    const uint64_t doc = (key >> low) & ((uint64_t(1) << db) - 1u);
+    return ix.order_docs[doc] + (((key >> (db + low)) << low) | (key & ((uint64_t(1) << low) - 1u)));
+}
+__global__ __launch_bounds__(256) void k_locus_keys(const DevIndex ix, const uint64_t *__restrict__ k, const uint64_t N, uint64_t *__restrict__ keys,
+                                                    uint32_t *__restrict__ iota) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < N; i += stride) {
+        keys[i] = locus_key(ix, k[i]);
+        iota[i] = static_cast<uint32_t>(i);
+    }
+}
+
 template <typename P>
 __device__ __forceinline__ uint64_t phi_step(const DevIndex &ix, uint64_t i, bool *searched = nullptr) {
     const PhiSlot<P> *__restrict__ slots = static_cast<const PhiSlot<P> *>(ix.phi_slots);
@@ -124,7 +152,8 @@ __global__ __launch_bounds__(256) void k_locate_fill(const DevIndex ix, const ui
     // chain is cut at multiples of CH elements of the OUTPUT ARRAY: a = (address of the read's first location / 8) mod CH, round c holds the
     // elements v = t + a in [c CH, (c + 1) CH), so every flush but a read's first and last writes one whole aligned segment.  The price: a lane
     // waits a columns before its first step, so a wave's longest chain grows by up to CH - 1 steps -- 17 % of the bench index's 41, which lost
-    // there in round 3 (profiles/r03_k3_align_ab.txt) -- so `align_flush` is set for long chains only (launch_locate_fill: RBG_K3_ALIGN).
+    // there in round 3 (profiles/r03_k3_align_ab.txt), and at pangenome scale in round 6 it put the lanes of a wave out of phase (profiles/
+    // r06_k3_align_ab.txt: 11.1 -> 14.9 ms): `align_flush` is OFF unless RBG_K3_ALIGN=1 asks for the A/B (launch_locate_fill).
     __shared__ uint32_t s_a[4][kWave];
     const uint64_t out_elem0 = reinterpret_cast<uintptr_t>(locs) / sizeof(OUT);
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
@@ -146,7 +175,7 @@ __global__ __launch_bounds__(256) void k_locate_fill(const DevIndex ix, const ui
                 // ordered walk: the toehold travels with the sort (sequential read) and the count is the
                 // planned one, loc_off[i+1] - loc_off[i] = min(occ, max_hits): one random 64-byte sector
                 // per read instead of four (lo, hi, k, loc_off)
-                k1 = skeys[j];
+                k1 = ix.order_docs ? locus_toehold(ix, skeys[j], k, i) : skeys[j];
                 occ = loc_off[i + 1] - dst;
             } else {
                 const uint64_t l = lo[i], h = hi[i];
@@ -224,7 +253,7 @@ __global__ __launch_bounds__(256) void k_iota(uint32_t *__restrict__ v, const ui
     for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < N; i += stride) v[i] = static_cast<uint32_t>(i);
 }
 struct OrderWs {
-    size_t perm, iota, keys, sort, sort_bytes, total;
+    size_t perm, iota, keys, keys_in, sort, sort_bytes, total;   // keys_in: the locus keys the sort reads (the absolute order sorts the toeholds where they are)
 };
 OrderWs order_layout(uint64_t N) {
     auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
@@ -232,7 +261,8 @@ OrderWs order_layout(uint64_t N) {
     w.perm = 0;
     w.iota = up(w.perm + N * 4);
     w.keys = up(w.iota + N * 4);
-    w.sort = up(w.keys + N * 8);
+    w.keys_in = up(w.keys + N * 8);
+    w.sort = up(w.keys_in + N * 8);
     size_t bytes = 0;
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, static_cast<const uint64_t *>(nullptr), static_cast<uint64_t *>(nullptr),
                                              static_cast<const uint32_t *>(nullptr), static_cast<uint32_t *>(nullptr),
@@ -256,6 +286,16 @@ int launch_locate_order(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t
     uint32_t *perm = reinterpret_cast<uint32_t *>(base + w.perm);
     uint32_t *iota = reinterpret_cast<uint32_t *>(base + w.iota);
     uint64_t *keys = reinterpret_cast<uint64_t *>(base + w.keys);
+    if (ix.order_docs) {   // locus order: sort the keys {offset >> low, document, ...} on the bits above `low`
+        uint64_t *keys_in = reinterpret_cast<uint64_t *>(base + w.keys_in);
+        hipLaunchKernelGGL(k_locus_keys, dim3(grid_for(cfg, N)), dim3(256), 0, st, ix, k, N, keys_in, iota);
+        int rc0 = static_cast<int>(hipGetLastError());
+        if (rc0) return rc0;
+        size_t bytes0 = w.sort_bytes;
+        // (all 64 bits when a toehold may have wrapped: its all-ones key sorts last either way; the bits above obits + dbits are zero otherwise)
+        const int lo_bit = static_cast<int>(ix.order_lowbits), hi_bit = static_cast<int>(ix.order_obits + ix.order_dbits) + 1;
+        return static_cast<int>(hipcub::DeviceRadixSort::SortPairs(base + w.sort, bytes0, keys_in, keys, iota, perm, static_cast<int64_t>(N), lo_bit, hi_bit < 64 ? hi_bit : 64, st));
+    }
     hipLaunchKernelGGL(k_iota, dim3(grid_for(cfg, N)), dim3(256), 0, st, iota, N);
     int rc = static_cast<int>(hipGetLastError());
     if (rc) return rc;
@@ -298,16 +338,24 @@ int launch_locate_fill(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t 
     // the order workspace also holds the toeholds in sorted order (launch_locate_order's key output)
     const uint64_t *skeys = order ? reinterpret_cast<const uint64_t *>(static_cast<const char *>(order) + order_layout(N).keys) : nullptr;
     const uint32_t *perm = static_cast<const uint32_t *>(order);
-    // line-aligned flushes (k_locate_fill): RBG_K3_ALIGN = 1 / 0 forces them on / off; by default on where a read has many locations on average
-    // (n / r rows per run = haplotypes per locus, about: the chains of a pangenome index are that long) -- profiles/r06_k3_align_ab.txt
-    static const int align_env = [] { const char *e = std::getenv("RBG_K3_ALIGN"); return e ? std::atoi(e) : -1; }();
-    const uint32_t align_flush = align_env >= 0 ? (align_env ? 1u : 0u) : (ix.pos_bytes == 8 && ix.n / (ix.r ? ix.r : 1) >= 100 ? 1u : 0u);
+    // line-aligned flushes (k_locate_fill): OFF; RBG_K3_ALIGN=1 switches them on for the A/B of profiles/r06_k3_align_ab.txt.  They lost twice: on the
+    // bench index in round 3 (the longest chain of a wave grows by up to CH - 1 of 41 steps) and at r = 1.2e8 in round 6 (11.1 -> 14.9 ms per 10 M x
+    // 150 bp reads, 135 steps per chain): lanes that wait a different number of columns before their first step fall out of PHASE, and chains of one
+    // locus walking in phase -- neighbouring lanes asking for the same phi sector in the same instruction -- is what K3's speed rests on.
+    static const int align_env = [] { const char *e = std::getenv("RBG_K3_ALIGN"); return e ? std::atoi(e) : 0; }();
+    const uint32_t align_flush = align_env > 0 ? 1u : 0u;
     if (ix.layout == 2 && !ix.phi_slots) {  // run-indexed layout (k_runs.hip); with phi slots (RBG_OPT_RUN_PHI) the slot kernels below answer its phi
         return launch_locate_fill_runs(ix, cfg, lo, hi, k, N, max_hits, loc_off, locs, sub, order, skeys, stream, stats, locs32, align_flush);
     }
     if (locs32) {   // 4-byte locations (4-byte positions only; the caller checked)
         if (stats || ix.pos_bytes != 4) return static_cast<int>(hipErrorInvalidValue);
         hipLaunchKernelGGL((k_locate_fill<uint32_t, false, uint32_t>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, locs32, sub, perm, skeys, nullptr, align_flush);
+        return static_cast<int>(hipGetLastError());
+    }
+    // RBG_K3_CHUNK=16 (8-byte positions; A/B): sixteen steps staged per flush instead of RBG_K3_CHUNK_U64 -- with line-aligned flushes a whole 128-byte line per store
+    static const int chunk_env = [] { const char *e = std::getenv("RBG_K3_CHUNK"); return e ? std::atoi(e) : 0; }();
+    if (chunk_env == 16 && !stats && ix.pos_bytes == 8) {
+        hipLaunchKernelGGL((k_locate_fill<uint64_t, false, uint64_t, 16>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, locs, sub, perm, skeys, nullptr, align_flush);
         return static_cast<int>(hipGetLastError());
     }
     if (stats) {

@@ -676,9 +676,13 @@ int launch_find_range_markers_fill(const DevIndex &ix, const LaunchCfg &cfg, con
 
 int launch_marker_seeds_plan(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
                              uint64_t wsize, uint64_t max_range, uint64_t ftab_k, uint64_t *seed_off, uint64_t *mk_off, void *tmp,
-                             size_t tmp_bytes, void *stream, void *log, size_t log_bytes) {
+                             size_t tmp_bytes, void *stream, void *log, size_t log_bytes, unsigned long long *stats) {
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const SeedLog lg = make_seed_log(log, log_bytes, N, ix.pos_bytes);   // base == nullptr: no log (two walks)
+    SeedLog lg = make_seed_log(log, log_bytes, N, ix.pos_bytes);   // base == nullptr: no log (two walks)
+    if (stats) {
+        if (ix.layout != 2 || lg.base || ftab_k) return static_cast<int>(hipErrorNotSupported);   // the instrumented walks: run-indexed layout, no log, no --ftab
+        lg.stats = stats;
+    }
     int rc;
     if (ix.layout == 2) {   // run-indexed layout: k_runs_seeds.hip
         rc = launch_marker_seeds_runs(ix, cfg, seqs, off, N, wsize, max_range, seed_off, mk_off, nullptr, nullptr, nullptr, nullptr, false, stream, lg, ftab_k);
@@ -703,10 +707,14 @@ int launch_marker_seeds_plan(const DevIndex &ix, const LaunchCfg &cfg, const uin
 
 int launch_marker_seeds_fill(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
                              uint64_t wsize, uint64_t max_range, uint64_t ftab_k, const uint64_t *seed_off, const uint64_t *mk_off,
-                             uint64_t *seeds, uint64_t *mk, void *stream, void *log, size_t log_bytes) {
+                             uint64_t *seeds, uint64_t *mk, void *stream, void *log, size_t log_bytes, unsigned long long *stats) {
     if (N == 0) return 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     SeedLog lg = make_seed_log(log, log_bytes, N, ix.pos_bytes);
+    if (stats) {
+        if (ix.layout != 2 || lg.base || ftab_k) return static_cast<int>(hipErrorNotSupported);
+        lg.stats = stats;
+    }
     if (reinterpret_cast<uintptr_t>(seeds) & 15) lg.base = nullptr;   // (the copy stores records as 16-byte pieces)
     if (lg.base) {
         // copy what the count pass logged; the sequences over quota end up listed behind lg.nsel and are walked below
@@ -734,9 +742,10 @@ int launch_marker_seeds_fill(const DevIndex &ix, const LaunchCfg &cfg, const uin
 }
 
 int launch_greedy_seed(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
-                       uint64_t min_length, uint64_t *lo, uint64_t *hi, uint64_t *qs, uint64_t *qe, uint64_t *ss, void *stream) {
+                       uint64_t min_length, uint64_t *lo, uint64_t *hi, uint64_t *qs, uint64_t *qe, uint64_t *ss, void *stream, unsigned long long *stats) {
     if (N == 0) return 0;
-    if (ix.layout == 2) return launch_greedy_seed_runs(ix, cfg, seqs, off, N, min_length, lo, hi, qs, qe, ss, stream);
+    if (ix.layout == 2) return launch_greedy_seed_runs(ix, cfg, seqs, off, N, min_length, lo, hi, qs, qe, ss, stream, stats);
+    if (stats) return static_cast<int>(hipErrorNotSupported);   // (instrumented on the run-indexed layout only)
     hipStream_t st = static_cast<hipStream_t>(stream);
 #define RBG_GS(PT)                                                                                                        \
     do {                                                                                                                  \

@@ -356,6 +356,13 @@ __global__ __launch_bounds__(512, STATS ? 2 : 4) void k_find_range_runs(const De
 }
 
 template <typename P> struct ChunkR { static constexpr int v = sizeof(P) == 8 ? 8 : 16; };   // as in k_locate.hip
+// the toehold of a locus key (k_locate.hip locus_key / locus_toehold: the chains' order by locus)
+__device__ __forceinline__ uint64_t locus_toehold_r(const DevIndex &ix, const uint64_t key, const uint64_t *__restrict__ k, const uint64_t i) {
+    if (key == ~uint64_t(0)) return k[i];
+    const uint32_t low = ix.order_lowbits, db = ix.order_dbits;
+    const uint64_t doc = (key >> low) & ((uint64_t(1) << db) - 1u);
+    return ix.order_docs[doc] + (((key >> (db + low)) << low) | (key & ((uint64_t(1) << low) - 1u)));
+}
 
 // ---- K3 over the run-indexed layout: ToeholdSA::locate_range (toehold_sa.hpp:37-49) -- every lane walks its own chain and
 // answers its own phi (toehold_sa.hpp:56-72; rbg_runs2_device.hpp lane_phi).  The chains, the staging of the values in LDS and
@@ -393,7 +400,7 @@ __global__ __launch_bounds__(256, 4) void k_locate_fill_runs2(const DevIndex ix,
         if (i < N && j < N) {
             dst = loc_off[i];
             if (skeys) {
-                k1 = skeys[j];
+                k1 = ix.order_docs ? locus_toehold_r(ix, skeys[j], k, i) : skeys[j];
                 occ = loc_off[i + 1] - dst;
             } else {
                 const uint64_t l = lo[i], h = hi[i];

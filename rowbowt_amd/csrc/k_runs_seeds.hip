@@ -14,16 +14,18 @@ namespace {
 
 // runs are disjoint, ascending inclusive SA-index intervals; at_range(lo,hi) = values of all runs with start <= hi &&
 // end >= lo, in run order (k_markers.hip marker_span)
-__device__ __forceinline__ void marker_span_r(const DevIndex &ix, uint64_t lo, uint64_t hi, uint64_t *first, uint64_t *last) {
+// st (instrumented instantiations): [kSdMarkerDir] += directory entries read, [kSdMarkerProbes] += mk_end / mk_start entries read
+__device__ __forceinline__ void marker_span_r(const DevIndex &ix, uint64_t lo, uint64_t hi, uint64_t *first, uint64_t *last, unsigned long long *st = nullptr) {
     if (ix.mk_bucket) {
         if (lo >= ix.n) { *first = *last = ix.mk_nruns; return; }
         if (hi >= ix.n) hi = ix.n - 1;
         uint64_t a = ix.mk_bucket[lo >> ix.mk_shift];
-        while (a < ix.mk_nruns && ix.mk_end[a] < lo) ++a;
+        if (st) { st[kSdMarkerDir] += 2; st[kSdMarkerProbes] += 2; }
+        while (a < ix.mk_nruns && ix.mk_end[a] < lo) { ++a; if (st) st[kSdMarkerProbes] += 1; }
         *first = a;
         uint64_t z = ix.mk_bucket[hi >> ix.mk_shift];
         if (z < a) z = a;
-        while (z < ix.mk_nruns && ix.mk_start[z] <= hi) ++z;
+        while (z < ix.mk_nruns && ix.mk_start[z] <= hi) { ++z; if (st) st[kSdMarkerProbes] += 1; }
         *last = z;
         return;
     }
@@ -110,11 +112,20 @@ __device__ __forceinline__ bool ftab_state(const DevIndex &ix, ByteCursor &rd, c
 // a workgroup per CU (512 threads: two or four waves per SIMD, nothing between: the greedy seeds at 8-byte positions); the others
 // fetch both records of a step, and both scans of crowded buckets, together
 // QUAD: the first record of a step fetched by the lane's quad (rbg_runs2_device.hpp lane_lf2_quad); not where its registers would cost the workgroup
-template <typename P, bool LEAN = false, bool QUAD = true>
+template <typename P, bool LEAN = false, bool QUAD = true, bool STATS = false>
 __device__ __forceinline__ void seeds_lf2(const RunSearch2<P> &S2, const bool stepping, const uint32_t d, const uint32_t rec, const uint64_t q0, const uint64_t q1,
-                                          RunStep &r) {
-    if constexpr (QUAD) lane_lf2_quad<P, false, LEAN>(S2, stepping, d, rec, q0, q1, r);   // (every lane calls)
-    else { if (stepping) lane_lf2<P, false, LEAN>(S2, d, rec, q0, q1, r); }
+                                          RunStep &r, unsigned long long *st = nullptr) {
+    if constexpr (QUAD) lane_lf2_quad<P, STATS, LEAN>(S2, stepping, d, rec, q0, q1, r, st);   // (every lane calls)
+    else { if (stepping) lane_lf2<P, STATS, LEAN>(S2, d, rec, q0, q1, r, st); }
+}
+// the instrumented instantiations' sums, added to the launch's array at the end of the kernel
+template <int NS>
+__device__ __forceinline__ void seed_stats_flush(unsigned long long (&st)[NS], unsigned long long *__restrict__ stats, const uint32_t lane) {
+#pragma unroll
+    for (int t = 0; t < NS; ++t) {
+        const unsigned long long v = wave_sum(st[t]);
+        if (lane == 0 && v) atomicAdd(&stats[t], v);
+    }
 }
 
 // ---- single LF step for N (range, symbol) triples: RowBowt::LF(range_t, uint8_t), rowbowt.hpp:74-88 -------------------
@@ -226,13 +237,15 @@ __global__ __launch_bounds__(512, 4) void k_find_range_markers_runs(const DevInd
 // k_greedy_seed).  A k-mer step that comes back empty is narrowed by halving until the failing base is the reference's.
 // (three waves per SIMD -- at four the register limit of 128 sends a few of this kernel's values to scratch, and a kernel of this layout
 //  that spilled faulted on the device in round 4, profiles/r04_fault_note.txt: none of them is allowed to)
-template <typename P, bool QUAD>
-__global__ __launch_bounds__(512, 3) void k_greedy_seed_runs(const DevIndex ix, const uint8_t *__restrict__ seqs,
+template <typename P, bool QUAD, bool STATS = false>
+__global__ __launch_bounds__(512, STATS ? 2 : 3) void k_greedy_seed_runs(const DevIndex ix, const uint8_t *__restrict__ seqs,
                                                      const uint64_t *__restrict__ off, const uint64_t N,
                                                      const uint64_t min_length, uint64_t *__restrict__ lo_out,
                                                      uint64_t *__restrict__ hi_out, uint64_t *__restrict__ qs_out,
-                                                     uint64_t *__restrict__ qe_out, uint64_t *__restrict__ ss_out) {
+                                                     uint64_t *__restrict__ qe_out, uint64_t *__restrict__ ss_out,
+                                                     unsigned long long *__restrict__ stats = nullptr) {
     RBG_SEED_KERNEL_PROLOGUE(P);
+    unsigned long long st[kSeedStatN] = {};            // STATS only (dead code otherwise)
     const uint64_t first_k = ix.last_run_sample;       // rowbowt.hpp:230
     const uint64_t fhi = ix.n - 1;
     for (uint64_t base = wave_first; base < N; base += stride) {
@@ -246,8 +259,10 @@ __global__ __launch_bounds__(512, 3) void k_greedy_seed_runs(const DevIndex ix, 
         uint64_t j = m;                                 // next symbol to consume is q[j-1]
         uint32_t nlen = 0;                              // > 0: a k-mer step over q[j-nlen, j) came back empty and is being narrowed
         ByteCursor rd{reinterpret_cast<const uint4 *>(seqs), ~uint64_t(0), make_uint4(0, 0, 0, 0)};
+        if (STATS) { rd.fetched = &st[kStChunks]; if (valid) st[kSdSequences] += 1; }
         auto on_ok = [&](uint32_t adv) {
             j -= adv;
+            if (STATS) st[kStSymbols] += adv;
             plo = lo; phi = hi; pk = k;                 // rowbowt.hpp:248-249
         };
         auto on_fail = [&]() {                          // q[j-1] ends the seed q[j, ei)  (rowbowt.hpp:236-246; m-i == j here)
@@ -264,7 +279,10 @@ __global__ __launch_bounds__(512, 3) void k_greedy_seed_runs(const DevIndex ix, 
                 const uint64_t p = beg + j - 1;
                 if (nlen == 0) {
                     // a fresh seed: the state after its first ftab_k symbols is one gather in the device table
-                    if (j == ei && ix.ftab_k && j >= ix.ftab_k && ftab_state<P>(ix, rd, s_lut2, p, M, lo, hi, k)) { on_ok(ix.ftab_k); continue; }
+                    if (j == ei && ix.ftab_k && j >= ix.ftab_k) {
+                        if (STATS) st[kStFtab] += 1;
+                        if (ftab_state<P>(ix, rd, s_lut2, p, M, lo, hi, k)) { on_ok(ix.ftab_k); continue; }
+                    }
                     pick = pick_step(rd, s_lut, s_lut2, tab_first, p, j, D, DMASK, M);
                     if (!pick.ok) { on_fail(); continue; }
                 } else {
@@ -273,13 +291,13 @@ __global__ __launch_bounds__(512, 3) void k_greedy_seed_runs(const DevIndex ix, 
                 stepping = true;
             }
             RunStep r;
-            seeds_lf2<P, (QUAD || sizeof(P) == 8), QUAD>(S2, stepping, pick.d, pick.rec, lo, hi + 1, r);
+            seeds_lf2<P, (QUAD || sizeof(P) == 8), QUAD, STATS>(S2, stepping, pick.d, pick.rec, lo, hi + 1, r, st);
             if (stepping) {
                 const uint64_t c_inside = r.c_upto - r.c_before;
                 const bool ok = c_inside != 0;
                 if (ok) {                               // LF_w_loc, rowbowt.hpp:555-573, pick.adv times nested
                     if (r.inside) k = k - pick.adv;
-                    else k = run_step_sample2<P>(ix, S2, pick.d, pick.rec, r.samp_e);
+                    else { k = run_step_sample2<P>(ix, S2, pick.d, pick.rec, r.samp_e); if (STATS) st[kStResample] += 1; }
                     lo = r.F + r.c_before;
                     hi = lo + c_inside - 1;
                 }
@@ -302,6 +320,7 @@ __global__ __launch_bounds__(512, 3) void k_greedy_seed_runs(const DevIndex ix, 
             ss_out[i] = b_k;
         }
     }
+    if (STATS) seed_stats_flush(st, stats, lane);
 }
 
 // ---- marker seeds: RowBowt::get_markers_greedy_seeding without an ftab file (rowbowt.hpp:406-482; rb_markers' default
@@ -309,14 +328,15 @@ __global__ __launch_bounds__(512, 3) void k_greedy_seed_runs(const DevIndex ix, 
 // with that kernel (lane by lane).  One record per call of the reference's callback: {range lo, range hi, q.first,
 // seed_ei, first marker, one past last marker}.
 // LOG / lg: the marker-seed log (rbg_dev.h SeedLog), as in k_markers.hip k_marker_seeds
-template <typename P, bool FILL, bool LOG>
-__global__ __launch_bounds__(512, 3) void k_marker_seeds_runs(const DevIndex ix, const uint8_t *__restrict__ seqs,
+template <typename P, bool FILL, bool LOG, bool STATS = false>
+__global__ __launch_bounds__(512, STATS ? 2 : 3) void k_marker_seeds_runs(const DevIndex ix, const uint8_t *__restrict__ seqs,
                                                       const uint64_t *__restrict__ off, const uint64_t N,
                                                       const uint64_t wsize, const uint64_t max_range,
                                                       uint64_t *__restrict__ seed_cnt, uint64_t *__restrict__ mk_cnt,
                                                       const uint64_t *__restrict__ seed_off, const uint64_t *__restrict__ mk_off,
                                                       uint64_t *__restrict__ seeds, uint64_t *__restrict__ mk, const SeedLog lg) {
     RBG_SEED_KERNEL_PROLOGUE(P);
+    unsigned long long st[kSeedStatN] = {};               // STATS only (dead code otherwise)
     if (!FILL && blockIdx.x == 0 && threadIdx.x == 0) { seed_cnt[0] = 0; mk_cnt[0] = 0; }
     const bool have_ma = ix.mk_nruns != 0;
     const uint64_t fhi = ix.n - 1;
@@ -336,6 +356,7 @@ __global__ __launch_bounds__(512, 3) void k_marker_seeds_runs(const DevIndex ix,
         uint32_t nlen = 0;
         uint64_t unused_k = 0;
         ByteCursor rd{reinterpret_cast<const uint4 *>(seqs), ~uint64_t(0), make_uint4(0, 0, 0, 0)};
+        if (STATS) { rd.fetched = &st[kStChunks]; if (valid) st[kSdSequences] += 1; }
         unsigned char *lbase = (LOG && valid) ? lg.base + i * lg.stride : nullptr;
         // (the log's two arrays are addressed from lbase where they are written: two more pointers held over the whole walk cost the
         //  logging instantiation its fourth wave per SIMD)
@@ -346,9 +367,11 @@ __global__ __launch_bounds__(512, 3) void k_marker_seeds_runs(const DevIndex ix,
         auto update_mbuf = [&](uint64_t l, uint64_t h) {  // :437-441
             if (!have_ma || h - l + 1 > max_range) return;
             uint64_t f, e;
-            marker_span_r(ix, l, h, &f, &e);
+            if (STATS) st[kSdMarkerQueries] += 1;
+            marker_span_r(ix, l, h, &f, &e, STATS ? st : nullptr);
             if (e <= f) return;
             const uint64_t src = ix.mk_off[f], cnt = ix.mk_off[e] - src;
+            if (STATS) { st[kSdMarkerOff] += 2; if (FILL) st[kSdMarkerVals] += cnt; }
             if (FILL) {
                 uint64_t *d = mk + mbase + tot;
                 for (uint64_t t = 0; t < cnt; ++t) d[t] = ix.mk_vals[src + t];
@@ -361,6 +384,7 @@ __global__ __launch_bounds__(512, 3) void k_marker_seeds_runs(const DevIndex ix,
             tot += cnt;
         };
         auto emit = [&](uint64_t l, uint64_t h, uint64_t qs, uint64_t qe) {  // fn(range, (qs, qe-1), mbuf)
+            if (STATS && FILL) st[kSdSeedRecs] += 1;
             if (FILL) {
                 uint64_t *d = srec + 6 * ns;
                 d[0] = l; d[1] = h; d[2] = qs; d[3] = qe; d[4] = mbase + mb_begin; d[5] = mbase + tot;
@@ -375,6 +399,7 @@ __global__ __launch_bounds__(512, 3) void k_marker_seeds_runs(const DevIndex ix,
         };
         auto on_ok = [&](uint32_t adv) {              // adv symbols consumed, range still non-empty
             j -= adv;
+            if (STATS) st[kStSymbols] += adv;
             if (window_ei - j >= wsize) {             // :469-472 (m-i-1 == j after the step)
                 update_mbuf(lo, hi);
                 window_ei = j;
@@ -400,7 +425,10 @@ __global__ __launch_bounds__(512, 3) void k_marker_seeds_runs(const DevIndex ix,
                     uint64_t dist = j + wsize > window_ei ? j + wsize - window_ei : 1;
                     if (dist == 0) dist = 1;
                     const uint64_t cap = dist < j ? dist : j;
-                    if (j == seed_ei && ix.ftab_k && cap >= ix.ftab_k && ftab_state<P>(ix, rd, s_lut2, p, M, lo, hi, unused_k)) { on_ok(ix.ftab_k); continue; }
+                    if (j == seed_ei && ix.ftab_k && cap >= ix.ftab_k) {
+                        if (STATS) st[kStFtab] += 1;
+                        if (ftab_state<P>(ix, rd, s_lut2, p, M, lo, hi, unused_k)) { on_ok(ix.ftab_k); continue; }
+                    }
                     pick = pick_step(rd, s_lut, s_lut2, tab_first, p, cap, D, DMASK, M);
                     if (!pick.ok) { on_fail(); continue; }
                 } else {
@@ -409,7 +437,7 @@ __global__ __launch_bounds__(512, 3) void k_marker_seeds_runs(const DevIndex ix,
                 stepping = true;
             }
             RunStep r;
-            seeds_lf2<P, true>(S2, stepping, pick.d, pick.rec, lo, hi + 1, r);
+            seeds_lf2<P, true, true, STATS>(S2, stepping, pick.d, pick.rec, lo, hi + 1, r, st);
             if (stepping) {
                 const uint64_t c_inside = r.c_upto - r.c_before;
                 const bool ok = c_inside != 0;
@@ -441,6 +469,7 @@ __global__ __launch_bounds__(512, 3) void k_marker_seeds_runs(const DevIndex ix,
             }
         }
     }
+    if (STATS) seed_stats_flush(st, lg.stats, lane);
 }
 
 // ---- marker seeds with an ftab of k-mer size K (rb_markers --ftab; rowbowt.hpp:406-482 with :430-433, :454-464) on format 2:
@@ -624,20 +653,25 @@ int launch_find_range_markers_runs(const DevIndex &ix, const LaunchCfg &cfg, con
 }
 
 int launch_greedy_seed_runs(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
-                            uint64_t min_length, uint64_t *lo, uint64_t *hi, uint64_t *qs, uint64_t *qe, uint64_t *ss, void *stream) {
+                            uint64_t min_length, uint64_t *lo, uint64_t *hi, uint64_t *qs, uint64_t *qe, uint64_t *ss, void *stream, unsigned long long *stats) {
     if (N == 0) return 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const SeedLaunch L = seed_launch(ix, cfg, N);
+    if (stats) {   // the instrumented instantiation (rbg_greedy_longest_seed_stats_dev): same walk, same outputs
+        if (ix.pos_bytes == 4) RBG_LAUNCH_SEEDK((k_greedy_seed_runs<uint32_t, false, true>), seqs, off, N, min_length, lo, hi, qs, qe, ss, stats);
+        else RBG_LAUNCH_SEEDK((k_greedy_seed_runs<uint64_t, false, true>), seqs, off, N, min_length, lo, hi, qs, qe, ss, stats);
+        return static_cast<int>(hipGetLastError());
+    }
     // every lane fetches its own record: the quad fetch of k_find_range_runs (rbg_runs2_device.hpp lane_lf2_quad) measured the same here (6.80 ms
     // against 6.77 per 10 M reads on the bench index, profiles/r05_experiments.txt) and costs the 8-byte instantiation its fourth wave per SIMD
     // (131 VGPRs).  RBG_GREEDY_FETCH=quad keeps the A/B runnable.
     static const bool quad = [] { const char *e = std::getenv("RBG_GREEDY_FETCH"); return e && e[0] == 'q'; }();
     if (quad) {
-        if (ix.pos_bytes == 4) RBG_LAUNCH_SEEDK((k_greedy_seed_runs<uint32_t, true>), seqs, off, N, min_length, lo, hi, qs, qe, ss);
-        else RBG_LAUNCH_SEEDK((k_greedy_seed_runs<uint64_t, true>), seqs, off, N, min_length, lo, hi, qs, qe, ss);
+        if (ix.pos_bytes == 4) RBG_LAUNCH_SEEDK((k_greedy_seed_runs<uint32_t, true>), seqs, off, N, min_length, lo, hi, qs, qe, ss, nullptr);
+        else RBG_LAUNCH_SEEDK((k_greedy_seed_runs<uint64_t, true>), seqs, off, N, min_length, lo, hi, qs, qe, ss, nullptr);
     } else {
-        if (ix.pos_bytes == 4) RBG_LAUNCH_SEEDK((k_greedy_seed_runs<uint32_t, false>), seqs, off, N, min_length, lo, hi, qs, qe, ss);
-        else RBG_LAUNCH_SEEDK((k_greedy_seed_runs<uint64_t, false>), seqs, off, N, min_length, lo, hi, qs, qe, ss);
+        if (ix.pos_bytes == 4) RBG_LAUNCH_SEEDK((k_greedy_seed_runs<uint32_t, false>), seqs, off, N, min_length, lo, hi, qs, qe, ss, nullptr);
+        else RBG_LAUNCH_SEEDK((k_greedy_seed_runs<uint64_t, false>), seqs, off, N, min_length, lo, hi, qs, qe, ss, nullptr);
     }
     return static_cast<int>(hipGetLastError());
 }
@@ -657,6 +691,16 @@ int launch_marker_seeds_runs(const DevIndex &ix, const LaunchCfg &cfg, const uin
     } while (0)
         if (ix.pos_bytes == 4) RBG_MSF(uint32_t); else RBG_MSF(uint64_t);
 #undef RBG_MSF
+        return static_cast<int>(hipGetLastError());
+    }
+    if (lg.stats && !lg.base) {   // the instrumented instantiations (rbg_marker_seeds_stats_dev): same walks, same outputs
+#define RBG_MSS(PT)                                                                                                                          \
+    do {                                                                                                                                     \
+        if (fill) RBG_LAUNCH_SEEDK((k_marker_seeds_runs<PT, true, false, true>), seqs, off, N, wsize, max_range, seed_cnt, mk_cnt, seed_off, mk_off, seeds, mk, lg); \
+        else RBG_LAUNCH_SEEDK((k_marker_seeds_runs<PT, false, false, true>), seqs, off, N, wsize, max_range, seed_cnt, mk_cnt, seed_off, mk_off, seeds, mk, lg); \
+    } while (0)
+        if (ix.pos_bytes == 4) RBG_MSS(uint32_t); else RBG_MSS(uint64_t);
+#undef RBG_MSS
         return static_cast<int>(hipGetLastError());
     }
 #define RBG_MSR(PT)                                                                                                                          \

@@ -290,6 +290,12 @@ struct DevIndex {
     // In-kernel 2-bit staging of the reads (k_find_range_runs STAGE): with four major symbols whose bytes differ in the three bits
     // from `stage_shift` up (ACGT and acgt: shift 0), a byte's code and the byte it must be come out of two 8-byte register tables by v_perm_b32 --
     // four symbols per instruction, no per-symbol LDS lookup.  stage_ok == 0: the alphabet does not allow it; the kernel reads bytes as before.
+    // Chain order of K3 by LOCUS (launch_locate_order): with a document table attached (DocList, doclist.hpp:46-79: one document per
+    // haplotype sequence in a pangenome index) the chains are sorted by {offset inside the document (coarse), document, offset (fine)} instead of
+    // the absolute text position: reads of one locus whose toeholds lie in the same haplotype become neighbours whatever that haplotype is, and
+    // chains of one locus visit the haplotypes in the same order -- neighbouring lanes share phi sectors for the whole walk.  Result-neutral.
+    const uint64_t *order_docs;   // sorted document starts (order_ndocs of them), nullptr = order by absolute position
+    uint32_t order_ndocs, order_dbits, order_lowbits, order_obits;   // key = (offset >> lowbits) << (dbits + lowbits) | doc << lowbits | offset & (2^lowbits - 1)
     uint32_t stage_ok, stage_shift;
     uint32_t stage_code[2];    // byte t of {[0], [1]}: the major index of the symbol whose (byte >> shift) & 7 == t (0 where there is none)
     uint32_t stage_byte[2];    // ... and that symbol's byte (a byte no symbol of the alphabet has where there is none)
@@ -337,6 +343,19 @@ struct SeedLog {
     uint64_t stride;
     uint32_t qs, qw;
     uint32_t *nsel;            // nsel[0] = # sequences over quota, their indices from nsel + 4 on
+    unsigned long long *stats = nullptr;   // != nullptr (run-indexed layout, no log): the INSTRUMENTED instantiation adds what it touched (kSeedStatN sums)
+};
+// What the instrumented seeding kernels of the run-indexed layout count (rbg_marker_seeds_stats_dev / rbg_greedy_longest_seed_stats_dev): the
+// eight sums of SearchStat with that layout's meanings (rbg_runs2_device.hpp), then the marker side.
+enum SeedStat {
+    kSdMarkerQueries = kStatSearchN,   // window queries that went to the marker runs (range <= max_range)
+    kSdMarkerDir,                      // directory entries read for them (4 bytes each)
+    kSdMarkerProbes,                   // mk_end / mk_start entries read (8 bytes each)
+    kSdMarkerOff,                      // mk_off entries read (8 bytes each)
+    kSdMarkerVals,                     // marker values copied (8 read + 8 written)
+    kSdSeedRecs,                       // seed records written (48 bytes each)
+    kSdSequences,                      // sequences walked
+    kSeedStatN
 };
 constexpr uint32_t kSeedLogOverflow = 0xFFFFFFFFu;
 constexpr uint32_t kSeedLogWindows = 6, kSeedLogSeedsDefault = 12;
@@ -349,7 +368,7 @@ inline size_t seed_log_bytes(uint64_t N, uint32_t pos_bytes, uint32_t seeds_per_
 }
 // the log a scratch area of `bytes` can hold for N sequences (base == nullptr: too small for two seeds each)
 inline SeedLog make_seed_log(void *scratch, size_t bytes, uint64_t N, uint32_t pos_bytes) {
-    SeedLog lg{nullptr, 0, 0, kSeedLogWindows, nullptr};
+    SeedLog lg{nullptr, 0, 0, kSeedLogWindows, nullptr, nullptr};
     if (!scratch || N == 0 || (reinterpret_cast<uintptr_t>(scratch) & 15)) return lg;
     const size_t tail = 64 + (N + 4) * 4, fixed = 8 + kSeedLogWindows * sizeof(SeedLogWin), rec = seed_log_rec_bytes(pos_bytes);
     if (bytes < tail + N * (fixed + 2 * rec)) return lg;
@@ -430,7 +449,8 @@ int launch_find_range_markers_runs(const DevIndex &ix, const LaunchCfg &cfg, con
                                    uint64_t wsize, uint64_t max_range, uint64_t *lo, uint64_t *hi, uint64_t *cnt, const uint64_t *mk_off,
                                    uint64_t *mk, bool fill, void *stream);
 int launch_greedy_seed_runs(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
-                            uint64_t min_length, uint64_t *lo, uint64_t *hi, uint64_t *qs, uint64_t *qe, uint64_t *ss, void *stream);
+                            uint64_t min_length, uint64_t *lo, uint64_t *hi, uint64_t *qs, uint64_t *qe, uint64_t *ss, void *stream,
+                            unsigned long long *stats = nullptr /*kSeedStatN: the instrumented instantiation*/);
 // lg.base != nullptr: the count pass (fill == false) writes the log; the fill pass walks only the sequences listed behind lg.nsel
 int launch_marker_seeds_runs(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N, uint64_t wsize,
                              uint64_t max_range, uint64_t *seed_cnt, uint64_t *mk_cnt, const uint64_t *seed_off, const uint64_t *mk_off,
@@ -499,12 +519,12 @@ int launch_find_range_packed_only(const DevIndex &ix, const LaunchCfg &cfg, cons
 // log (nullable scratch): when it can hold a log (make_seed_log) the plan writes one and the fill copies from it
 int launch_marker_seeds_plan(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
                              uint64_t wsize, uint64_t max_range, uint64_t ftab_k, uint64_t *seed_off, uint64_t *mk_off, void *tmp,
-                             size_t tmp_bytes, void *stream, void *log = nullptr, size_t log_bytes = 0);
+                             size_t tmp_bytes, void *stream, void *log = nullptr, size_t log_bytes = 0, unsigned long long *stats = nullptr /*kSeedStatN; run-indexed layout, no log*/);
 int launch_marker_seeds_fill(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
                              uint64_t wsize, uint64_t max_range, uint64_t ftab_k, const uint64_t *seed_off, const uint64_t *mk_off,
-                             uint64_t *seeds, uint64_t *mk, void *stream, void *log = nullptr, size_t log_bytes = 0);
+                             uint64_t *seeds, uint64_t *mk, void *stream, void *log = nullptr, size_t log_bytes = 0, unsigned long long *stats = nullptr);
 int launch_greedy_seed(const DevIndex &ix, const LaunchCfg &cfg, const uint8_t *seqs, const uint64_t *off, uint64_t N,
-                       uint64_t min_length, uint64_t *lo, uint64_t *hi, uint64_t *qs, uint64_t *qe, uint64_t *ss, void *stream);
+                       uint64_t min_length, uint64_t *lo, uint64_t *hi, uint64_t *qs, uint64_t *qe, uint64_t *ss, void *stream, unsigned long long *stats = nullptr);
 int launch_markers_plan(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t *lo, const uint64_t *hi, uint64_t N,
                         uint64_t *mk_off, void *tmp, size_t tmp_bytes, void *stream);
 int launch_markers_fill(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t *lo, const uint64_t *hi, uint64_t N,

@@ -237,9 +237,10 @@ struct ByteCursor {
     const uint4 *__restrict__ chunks;
     uint64_t cur_ci;
     uint4 w;
+    unsigned long long *fetched = nullptr;   // instrumented instantiations: counts the chunks fetched (nullptr, never assigned, elsewhere: folded away)
     __device__ __forceinline__ uint32_t at(uint64_t p) {
         const uint64_t ci = p >> 4;
-        if (ci != cur_ci) { w = chunks[ci]; cur_ci = ci; }
+        if (ci != cur_ci) { w = chunks[ci]; cur_ci = ci; if (fetched) ++*fetched; }
         // select + shift (indexing the vector by a run-time lane value makes the compiler spill it)
         const uint32_t sel = static_cast<uint32_t>(p) & 15u;
         const uint64_t lo64 = (static_cast<uint64_t>(w.y) << 32) | w.x;

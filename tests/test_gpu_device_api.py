@@ -71,6 +71,72 @@ def test_device_resident_api(synth):
     o.close()
 
 
+@pytest.mark.parametrize("layout,phi", [(capi.LAYOUT_SLOTS, 0), (capi.LAYOUT_RUNS, 2), (capi.LAYOUT_RUNS, 1)])
+@pytest.mark.parametrize("pos_bytes", [4, 8])
+def test_locate_chains_in_locus_order(synth, layout, phi, pos_bytes, monkeypatch):
+    """K3's chain order by LOCUS (round 6): with a document table attached (rbg_set_docs: one document per haplotype, doclist.hpp:46-79) the chains
+    are sorted by {offset inside the document, document} instead of absolute text position.  Result-neutral: the locations -- ToeholdSA::locate_range,
+    toehold_sa.hpp:37-49 -- are the oracle's whatever the order, for every max_hits, on the slot layout and on the run-indexed one with phi slots and
+    with the phi list, at both position widths; a toehold that wrapped below zero (a match at text position 0) travels through the sort's all-ones
+    key; documents of different lengths; the order by absolute position (no documents) on the same handle before they are attached."""
+    import torch
+    S = synth
+    monkeypatch.setenv("RBG_LOCATE_ORDER", "locus")   # (by default the locus order starts at 128 documents: capi/load.ipp upload_order_docs)
+    with capi.default_option(capi.OPT_RANK_LAYOUT, layout), capi.default_option(capi.OPT_RUN_PHI, phi), capi.default_option(capi.OPT_POS_BYTES, pos_bytes):
+        rb = ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0)
+    o = orc.Oracle.from_runs(S.heads, S.lens, S.ssa, S.esa)
+    reads = S.sample_reads(3000, 60, seed=8, sub_rate=0.1) + [bytes(S.text[:40]), bytes(S.text[:25]), bytes(S.text[1:30])]   # (text position 0: the toehold wraps)
+    seqs, off = ra.pack_reads(reads)
+    N = len(reads)
+    dev = torch.device("cuda:0")
+    d_seqs = torch.from_numpy(np.concatenate([seqs, np.zeros((-len(seqs)) % 16 + 16, np.uint8)])).to(dev)
+    d_off = torch.from_numpy(off.view(np.int64)).to(dev)
+    d_lo, d_hi, d_k = (torch.empty(N, dtype=torch.int64, device=dev) for _ in range(3))
+    st = torch.cuda.current_stream().cuda_stream
+    L = ra.lib()
+    assert L.rbg_find_range_w_toehold_dev(rb.h, d_seqs.data_ptr(), d_off.data_ptr(), N, d_lo.data_ptr(), d_hi.data_ptr(), d_k.data_ptr(), st) == 0
+    wlo, whi, wk = o.find_range_w_toehold_batch(seqs, off, nthreads=4)
+    assert (d_k.cpu().numpy().view(np.uint64) == wk).all() and int((wk[whi >= wlo] >= S.n).sum()) >= 1   # (at least one wrapped toehold among the matches)
+    d_loc_off = torch.empty(N + 1, dtype=torch.int64, device=dev)
+    tmp_bytes, ws_bytes = L.rbg_locate_plan_tmp_bytes(N), L.rbg_locate_order_ws_bytes(N)
+    d_tmp = torch.empty(tmp_bytes, dtype=torch.uint8, device=dev)
+    d_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+
+    def located(max_hits):
+        assert L.rbg_locate_plan_dev(rb.h, d_lo.data_ptr(), d_hi.data_ptr(), N, max_hits, d_loc_off.data_ptr(), d_tmp.data_ptr(), tmp_bytes, st) == 0
+        total = int(d_loc_off[-1].item())
+        d_locs = torch.full((max(total, 1),), -1, dtype=torch.int64, device=dev)
+        assert L.rbg_locate_order_dev(rb.h, d_k.data_ptr(), N, d_ws.data_ptr(), ws_bytes, st) == 0
+        assert L.rbg_locate_fill_dev(rb.h, d_lo.data_ptr(), d_hi.data_ptr(), d_k.data_ptr(), N, max_hits, d_loc_off.data_ptr(), d_locs.data_ptr(), d_ws.data_ptr(), st) == 0
+        torch.cuda.synchronize()
+        perm = d_ws[:4 * N].view(torch.int32).cpu().numpy().astype(np.int64)
+        return d_loc_off.cpu().numpy().view(np.uint64).copy(), d_locs[:total].cpu().numpy().view(np.uint64).copy(), perm
+
+    want = {mh: o.locs_at_batch(wlo, whi, wk, mh, nthreads=4) for mh in (MAXU, 3, 1)}
+    abs_perm = None
+    for docs in (None, (S.doc_names, S.doc_starts), (["a", "b", "c"], [0, 7, S.n - 5])):   # (no documents; one per haplotype; three of very different lengths)
+        if docs:
+            rb.set_docs(*docs)
+        for mh in (MAXU, 3, 1):
+            g_off, g_locs, perm = located(mh)
+            assert (g_off == want[mh][0]).all() and (g_locs == want[mh][1]).all(), (docs and len(docs[0]), mh)
+            assert sorted(perm.tolist()) == list(range(N))          # the order is a permutation of the reads
+        if docs is None:
+            abs_perm = perm
+        elif len(docs[0]) == S.H:
+            # the locus order is another order: chains of DIFFERENT haplotypes at the same locus are neighbours in it, never in the absolute order
+            unit = S.doc_starts[1]
+
+            def cross(pm):
+                live = np.array([i for i in pm if whi[i] >= wlo[i] and wk[i] < S.n])
+                kk = wk[live].astype(np.int64)
+                doc, offs = kk // unit, kk % unit
+                return float(np.mean((doc[1:] != doc[:-1]) & (np.abs(np.diff(offs)) < 1024)))
+            assert (perm != abs_perm).any() and cross(perm) > 0.2 and cross(abs_perm) < 0.05, (cross(perm), cross(abs_perm))
+    rb.close()
+    o.close()
+
+
 @pytest.mark.parametrize("layout", [capi.LAYOUT_SLOTS, capi.LAYOUT_RUNS])
 def test_instrumented_kernels_and_32_bit_locations(synth, layout):
     """rbg_find_range_stats_dev / rbg_locate_fill_stats_dev (the instrumented instantiations bench.py prices the kernels

@@ -30,7 +30,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 MAXU = 2**64 - 1
-# --preset driver (explicit options of the same command line do not override it: one definition for bench.py and the test)
+# --preset driver: one definition for bench.py and the test (an option given explicitly on the same command line wins)
 PRESET_DRIVER = dict(L=100_000_000, H=200, site_rate=0.01, read_len=150, reads=10_000_000, total_reads=50_000_000, check_reads=2000,
                      property_reads=100_000, hbm_reserve_gb=0.0, implicit_text="on", layout="auto", count_only=False)
 
@@ -74,6 +74,10 @@ def main():
                     help="ONE process: the index is built once, rbg_replicate_many copies it to the other devices, one host thread per replica streams "
                          "its rbg_shard_bounds block on its own stream with its own read generator; host memory does not depend on the count")
     ap.add_argument("--replica-devices", default="", help="devices of --replicas, comma separated (default: 0, 1, ...; may repeat: tests put several on one GPU)")
+    ap.add_argument("--docs", choices=("on", "off"), default="on",
+                    help="attach the document table of the pangenome (one document per haplotype, like the .docs file a pangenome index ships with: "
+                         "doclist.hpp:62-65) through rbg_set_docs: K3 then orders its chains by LOCUS (offset inside the document, then document) instead of "
+                         "absolute text position -- result-neutral; off = no document table, the absolute order")
     ap.add_argument("--preset", choices=("driver",), default=None,
                     help="driver: BASELINE.json configs[3]'s index shape at the size the driver's own runs carry (bench.py's pangenome_shape block and "
                          "tests/test_gpu_scale.py): a true BWT of r >= 1e8 runs (L = 1e8, H = 200: n = 2.0e10), a DEFAULT rbg_load (no option, no budget), "
@@ -81,7 +85,8 @@ def main():
     args = ap.parse_args()
     if args.preset == "driver":
         for k_, v_ in PRESET_DRIVER.items():
-            setattr(args, k_, v_)
+            if getattr(args, k_) == ap.get_default(k_):   # (an option given explicitly beside the preset wins: A/B runs with fewer check reads)
+                setattr(args, k_, v_)
     if args.replicas and args.gpus > 1:
         raise SystemExit("--replicas (one process) and --gpus N (one process per GPU) are two ways to use several GPUs: pick one")
     import importlib.util
@@ -223,6 +228,8 @@ def main():
         capi.set_default_option(capi.OPT_HBM_BUDGET_MB, max(1024, int((free_b - args.hbm_reserve_gb * 1e9) / 2**20)))
     t0 = time.time()
     rb = ra.RowBowt.from_runs(inp["heads"], inp["lens"], inp["ssa"], inp["esa"], device=local_rank)
+    if args.docs == "on":
+        rb.set_docs([f"hap{h_}" for h_ in range(H)], [h_ * unit for h_ in range(H)])
     ix = rb.info()
     t_load = time.time() - t0
     mem_line("after the load")
@@ -656,6 +663,10 @@ def main():
                                                  "budget_raised": int(li.budget_raised), "depths_kept": [d + 1 for d in range(8) if int(li.depth_mask_kept) >> d & 1],
                                                  "depths_with_records": [d + 1 for d in range(8) if int(li.rec_bytes[d])]}
         out["config"]["index"]["default_load"] = default_load
+        out["config"]["index"]["documents"] = H if args.docs == "on" else 0
+        locus_on = args.docs == "on" and os.environ.get("RBG_LOCATE_ORDER") != "abs" and (H >= 128 or os.environ.get("RBG_LOCATE_ORDER") == "locus")
+        out["config"]["chain_order"] = ("by locus: offset inside the document, then document (rbg_set_docs: one document per haplotype; from 128 documents on)"
+                                        if locus_on else "by absolute text position")
         out["config"]["index"]["text"] = "implicit (sampled from the pangenome's structure)" if implicit else "materialised in HBM"
         out["peaks"] = {"host_bytes": int(peaks["host_bytes"]), "host_limit_bytes": peaks["host_limit"], "hbm_bytes": int(peaks["hbm_bytes"])}
         print(json.dumps(out), flush=True)
