@@ -319,14 +319,37 @@ size_t scan_tmp_bytes(uint64_t N) {
     return bytes + 256;
 }
 
+// occ(i) = min(hi - lo + 1, max_hits) or 0 (toehold_sa.hpp:38-39), computed where the scan reads it: the plan is ONE pass over (lo, hi) -- until
+// round 6 a kernel wrote the counts and the scan read them back (0.126 -> 0.09 ms per 10 M reads)
+struct OccOf {
+    const uint64_t *lo, *hi;
+    uint64_t max_hits;
+    __host__ __device__ __forceinline__ uint64_t operator()(const uint64_t i) const {
+        const uint64_t l = lo[i], h = hi[i];
+        uint64_t occ = h >= l ? h - l + 1 : 0;
+        return occ > max_hits ? max_hits : occ;
+    }
+};
+__global__ void k_zero_u64(uint64_t *p) { *p = 0; }
+
 int launch_locate_plan(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t *lo, const uint64_t *hi, uint64_t N,
                        uint64_t max_hits, uint64_t *loc_off, void *tmp, size_t tmp_bytes, void *stream) {
-    (void)ix;
+    (void)ix; (void)cfg;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(k_occ, dim3(grid_for(cfg, N)), dim3(cfg.block_threads), 0, st, lo, hi, N, max_hits, loc_off);
+    hipLaunchKernelGGL(k_zero_u64, dim3(1), dim3(1), 0, st, loc_off);
     int rc = static_cast<int>(hipGetLastError());
-    if (rc) return rc;
-    return scan_in_place(loc_off + 1, N, tmp, tmp_bytes, st);
+    if (rc || N == 0) return rc;
+    static const bool two_pass = [] { const char *e = std::getenv("RBG_PLAN_TWO_PASS"); return e && e[0] == '1'; }();   // (A/B: the round-5 form)
+    if (two_pass) {
+        hipLaunchKernelGGL(k_occ, dim3(grid_for(cfg, N)), dim3(cfg.block_threads), 0, st, lo, hi, N, max_hits, loc_off);
+        if ((rc = static_cast<int>(hipGetLastError()))) return rc;
+        return scan_in_place(loc_off + 1, N, tmp, tmp_bytes, st);
+    }
+    hipcub::TransformInputIterator<uint64_t, OccOf, hipcub::CountingInputIterator<uint64_t>> in(hipcub::CountingInputIterator<uint64_t>(0), OccOf{lo, hi, max_hits});
+    size_t need = 0;
+    (void)hipcub::DeviceScan::InclusiveSum(nullptr, need, in, loc_off + 1, static_cast<int64_t>(N));
+    if (need > tmp_bytes) return static_cast<int>(hipErrorInvalidValue);
+    return static_cast<int>(hipcub::DeviceScan::InclusiveSum(tmp, need, in, loc_off + 1, static_cast<int64_t>(N), st));
 }
 
 int launch_locate_fill(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t *lo, const uint64_t *hi,

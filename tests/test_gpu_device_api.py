@@ -85,7 +85,7 @@ def test_locate_chains_in_locus_order(synth, layout, phi, pos_bytes, monkeypatch
     with capi.default_option(capi.OPT_RANK_LAYOUT, layout), capi.default_option(capi.OPT_RUN_PHI, phi), capi.default_option(capi.OPT_POS_BYTES, pos_bytes):
         rb = ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0)
     o = orc.Oracle.from_runs(S.heads, S.lens, S.ssa, S.esa)
-    reads = S.sample_reads(3000, 60, seed=8, sub_rate=0.1) + [bytes(S.text[:40]), bytes(S.text[:25]), bytes(S.text[1:30])]   # (text position 0: the toehold wraps)
+    reads = S.sample_reads(3000, 60, seed=8, sub_rate=0.1) + [bytes(S.text[:40]), bytes(S.text[:25]), bytes(S.text[1:30])]
     seqs, off = ra.pack_reads(reads)
     N = len(reads)
     dev = torch.device("cuda:0")
@@ -96,7 +96,15 @@ def test_locate_chains_in_locus_order(synth, layout, phi, pos_bytes, monkeypatch
     L = ra.lib()
     assert L.rbg_find_range_w_toehold_dev(rb.h, d_seqs.data_ptr(), d_off.data_ptr(), N, d_lo.data_ptr(), d_hi.data_ptr(), d_k.data_ptr(), st) == 0
     wlo, whi, wk = o.find_range_w_toehold_batch(seqs, off, nthreads=4)
-    assert (d_k.cpu().numpy().view(np.uint64) == wk).all() and int((wk[whi >= wlo] >= S.n).sum()) >= 1   # (at least one wrapped toehold among the matches)
+    assert (d_k.cpu().numpy().view(np.uint64) == wk).all()
+    # a toehold that wrapped below zero (2^64 - 1: what LF_w_loc's k - 1 leaves of a toehold 0, rowbowt.hpp:561): planted on two reads with several
+    # locations -- outside phi's domain, the reference's arithmetic on the last sampled position is followed (k_locate.hip phi_step), and the sort's key has no
+    # document for it
+    wk = wk.copy()
+    multi = np.flatnonzero(whi - wlo + 1 >= 3)[:2]
+    assert len(multi) == 2
+    wk[multi] = np.uint64(MAXU)
+    d_k.copy_(torch.from_numpy(wk.view(np.int64)))
     d_loc_off = torch.empty(N + 1, dtype=torch.int64, device=dev)
     tmp_bytes, ws_bytes = L.rbg_locate_plan_tmp_bytes(N), L.rbg_locate_order_ws_bytes(N)
     d_tmp = torch.empty(tmp_bytes, dtype=torch.uint8, device=dev)
