@@ -44,77 +44,7 @@ struct PackedBits {   // per-lane reader of a packed read: peek / drop of up to 
     }
 };
 
-// ---- STAGE: the wave's reads as 2-bit codes in LDS, made by the wave itself -----------------------------------------------------------
-// A lane that walks its read through a cursor of 16-byte chunks fetches a chunk every second step: by then the memory system has turned its
-// caches over (a step is a random sector per lane), so every chunk is an L2 miss of its own -- 6.8 per 100 bp read, a third of K2's misses
-// (profiles/r06_k2_sectors.md).  Here every lane fetches ALL chunks of its read back to back at the top of the wave's iteration -- neighbouring
-// lanes hold neighbouring reads, so a line is asked for by all its readers within a few hundred cycles and leaves HBM once -- and keeps them
-// as 2-bit codes of the k-mer alphabet in consumption order (the layout of k_pack_reads: symbol q[m - 1 - t] at bits [2t, 2t + 2)), word w of
-// lane l at codes[w * 64 + l]: a step's table index is then the next 2 * adv bits, two LDS words and a funnel shift, no per-symbol lookup.
-// Four symbols per instruction: a byte's code and the byte it has to be come out of two 8-byte register tables by v_perm_b32 (rbg_dev.h
-// stage_*).  A wave with a read longer than kStageCap symbols, or with a symbol outside the k-mer alphabet, walks its reads as bytes.
-constexpr uint32_t kStageCap = 256u;                         // symbols per read the staging holds
-constexpr uint32_t kStageWords = kStageCap / 16u + 1u;       // (+ 1: the word after the last one is read, never used)
-constexpr uint32_t kStageWaveBytes = kStageWords * 64u * 4u;
-typedef __attribute__((address_space(3))) uint32_t lds_u32;
-
-struct StageTab { uint32_t code_lo, code_hi, byte_lo, byte_hi, shift; };
-// one aligned 16-byte chunk -> its sixteen codes in consumption order (byte 15 first) + the bytes that are not symbols of the alphabet (diff != 0)
-__device__ __forceinline__ uint32_t stage_chunk(const u32x4 w, const StageTab &T, uint32_t (&diff)[4]) {
-    const uint32_t x[4] = {w.x, w.y, w.z, w.w};
-    uint32_t c8[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const uint32_t idx = (x[t] >> T.shift) & 0x07070707u;
-        const uint32_t code = __builtin_amdgcn_perm(T.code_hi, T.code_lo, idx);
-        diff[t] = x[t] ^ __builtin_amdgcn_perm(T.byte_hi, T.byte_lo, idx);
-        c8[t] = (code * 0x40100401u) >> 24;                 // code(byte 3) | code(byte 2) << 2 | code(byte 1) << 4 | code(byte 0) << 6
-    }
-    return c8[3] | (c8[2] << 8) | (c8[1] << 16) | (c8[0] << 24);
-}
-// bytes of a 16-bit per-byte mask's nibble as a 32-bit byte mask
-__device__ __forceinline__ uint32_t nibble_bytes(const uint32_t nib) { return (((nib & 15u) * 0x00204081u) & 0x01010101u) * 0xFFu; }
-// the read [beg, end) of this lane -> codes column `col` (stride 64 words); returns true when a byte is no symbol of the k-mer alphabet.
-// m = end - beg <= kStageCap.  chunks_out: 16-byte chunks fetched (STATS).
-__device__ __forceinline__ bool stage_read(const uint4 *__restrict__ chunks16, const uint64_t beg, const uint64_t end, const StageTab &T, lds_u32 *col, uint32_t &chunks_out) {
-    chunks_out = 0;
-    if (end <= beg) return false;
-    uint64_t ci = (end - 1) >> 4;
-    const uint64_t ci_lo = beg >> 4;
-    const uint32_t hi_b = static_cast<uint32_t>(end - 1) & 15u, lo_b = static_cast<uint32_t>(beg) & 15u;
-    const uint32_t skip2 = 2u * (15u - hi_b);                   // the top chunk's first symbols lie beyond the read's end
-    uint32_t nwords = static_cast<uint32_t>((end - beg + 15) >> 4);
-    uint32_t bad = 0;
-    uint32_t d[4];
-    u32x4 w = as_global<u32x4>(static_cast<const void *>(chunks16))[ci];
-    uint32_t prev = stage_chunk(w, T, d);
-    {   // the top chunk: bytes above hi_b (and, for a read inside one chunk, below lo_b) are not the read's
-        uint32_t vm = (2u << hi_b) - 1u;
-        if (ci == ci_lo) vm &= ~((1u << lo_b) - 1u);
-        bad |= (d[0] & nibble_bytes(vm)) | (d[1] & nibble_bytes(vm >> 4)) | (d[2] & nibble_bytes(vm >> 8)) | (d[3] & nibble_bytes(vm >> 12));
-    }
-    chunks_out = static_cast<uint32_t>(ci - ci_lo) + 1u;
-    while (nwords) {
-        uint32_t next = 0;
-        if (ci > ci_lo) {
-            --ci;
-            w = as_global<u32x4>(static_cast<const void *>(chunks16))[ci];
-            next = stage_chunk(w, T, d);
-            if (ci == ci_lo) {                                  // the bottom chunk: bytes below lo_b are not the read's
-                const uint32_t vm = ~((1u << lo_b) - 1u);
-                bad |= (d[0] & nibble_bytes(vm)) | (d[1] & nibble_bytes(vm >> 4)) | (d[2] & nibble_bytes(vm >> 8)) | (d[3] & nibble_bytes(vm >> 12));
-            } else {
-                bad |= d[0] | d[1] | d[2] | d[3];
-            }
-        }
-        *col = __builtin_amdgcn_alignbit(next, prev, skip2);   // ({next, prev} >> skip2): skip2 <= 30
-        col += 64;
-        prev = next;
-        --nwords;
-    }
-    return bad != 0;
-}
-
+// (the staging of a wave's reads as 2-bit codes in LDS -- stage_read, StageTab, kStageCap -- lives in rbg_runs_device.hpp: the seeding kernels use it too)
 // GLDS: the bucket records arrive by LDS-direct loads (rbg_runs2_device.hpp lane_lf2_quad) instead of quad permutes
 // STAGE (byte form only): the wave stages its reads as 2-bit codes in LDS first (above)
 template <typename P, bool TOEHOLD, bool PACKED = false, bool STATS = false, bool GLDS = false, bool STAGE = false>

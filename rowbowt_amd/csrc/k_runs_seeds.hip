@@ -7,6 +7,8 @@
 // that still has work names its next step (or does lane-local work that needs no rank: ftab entries, absent symbols,
 // marker queries), all lanes of the wave take their steps together (the quads fetch records for one another), every lane
 // applies its result.
+#include <type_traits>
+
 #include "rbg_runs2_device.hpp"
 
 namespace rbg {
@@ -91,6 +93,38 @@ __device__ __forceinline__ bool ftab_state(const DevIndex &ix, ByteCursor &rd, c
     lo = flo; hi = fhi; k = fk;
     return true;
 }
+
+// ---- the same two on a read STAGED as 2-bit codes in LDS (rbg_runs_device.hpp stage_read: every symbol of the read is a k-mer symbol) -----------
+// t = consumption index of the symbol the step starts at (symbols between it and the read's end); cap >= 1 symbols may be consumed
+__device__ __forceinline__ StepPick pick_step_staged(const lds_u32 *codes, const uint8_t *s_mslot, const uint32_t *s_tab_first, const uint32_t t, const uint64_t cap,
+                                                     const uint32_t D, const uint32_t DMASK) {
+    StepPick s{1u, 0u, 0u, true};
+    const uint32_t lim = cap < D ? static_cast<uint32_t>(cap) : D;
+    s.adv = 32u - static_cast<uint32_t>(__clz(DMASK & ((2u << (lim - 1)) - 1u)));   // the deepest depth kept that fits
+    const uint32_t v = staged_bits(codes, t, s.adv);
+    s.rec = run_record(s_tab_first, s.adv, s.adv == 1 ? static_cast<uint32_t>(s_mslot[v]) : v);
+    s.d = s.adv - 1;
+    return s;
+}
+template <typename P>
+__device__ __forceinline__ bool ftab_state_staged(const DevIndex &ix, const lds_u32 *codes, const uint32_t t, uint64_t &lo, uint64_t &hi, uint64_t &k) {
+    uint64_t flo, fhi, fk;
+    if (!ftab_lookup<P>(ix, staged_bits(codes, t, ix.ftab_k), flo, fhi, fk) || flo > fhi) return false;
+    lo = flo; hi = fhi; k = fk;
+    return true;
+}
+
+// STAGES: the kernel stages its waves' reads (34.8 KB of LDS per workgroup: the two seed walks; the others read bytes)
+#define RBG_SEED_STAGE_SHARED                                                                     \
+    __shared__ uint32_t s_codes[8 * kStageWords * 64];                                            \
+    __shared__ uint8_t s_mslot[4];                                                                \
+    for (int t = threadIdx.x; t < 256; t += blockDim.x)                                           \
+        if (s_lut2[t] != 0xFFu) s_mslot[s_lut2[t] & 3u] = s_lut[t];                               \
+    __syncthreads();                                                                              \
+    lds_u32 *codes = (lds_u32 *)s_codes + (threadIdx.x >> 6) * (kStageWords * 64u) + lane;        \
+    const StageTab stage_tab{ix.stage_code[0], ix.stage_code[1], ix.stage_byte[0], ix.stage_byte[1], ix.stage_shift}; \
+    static_assert(kStageCap >= 16, "");                                                           \
+    const bool stage_on = ix.stage_ok != 0 && M == 4
 
 #define RBG_SEED_KERNEL_PROLOGUE(P)                                                               \
     __shared__ uint8_t s_lut[256];                                                                \
@@ -245,6 +279,7 @@ __global__ __launch_bounds__(512, STATS ? 2 : 3) void k_greedy_seed_runs(const D
                                                      uint64_t *__restrict__ qe_out, uint64_t *__restrict__ ss_out,
                                                      unsigned long long *__restrict__ stats = nullptr) {
     RBG_SEED_KERNEL_PROLOGUE(P);
+    RBG_SEED_STAGE_SHARED;
     unsigned long long st[kSeedStatN] = {};            // STATS only (dead code otherwise)
     const uint64_t first_k = ix.last_run_sample;       // rowbowt.hpp:230
     const uint64_t fhi = ix.n - 1;
@@ -253,6 +288,17 @@ __global__ __launch_bounds__(512, STATS ? 2 : 3) void k_greedy_seed_runs(const D
         const bool valid = i < N;
         uint64_t beg = 0, m = 0;
         if (valid) { beg = off[i]; m = off[i + 1] - beg; }
+        // the wave's reads as 2-bit codes in LDS (k_runs.hip STAGE: every chunk of a read fetched once, back to back) unless one is too long or
+        // holds a symbol outside the k-mer alphabet
+        bool staged = false;
+        if (stage_on && __ballot(valid && m > kStageCap) == 0) {
+            uint32_t nch = 0;
+            const bool bad = valid && stage_read(reinterpret_cast<const uint4 *>(seqs), beg, beg + m, stage_tab, codes, nch);
+            staged = __ballot(bad) == 0;
+            if (STATS && staged) st[kStChunks] += nch;
+        }
+        auto walk = [&](auto staged_tag) __attribute__((always_inline)) {
+        constexpr bool STAGED = decltype(staged_tag)::value;
         uint64_t lo = 0, hi = fhi, plo = 0, phi = fhi;
         uint64_t k = first_k, pk = ~uint64_t(0), ei = m;
         uint64_t b_lo = 1, b_hi = 0, b_qs = 0, b_qe = 0, b_k = 0, b_len = 0;
@@ -279,14 +325,17 @@ __global__ __launch_bounds__(512, STATS ? 2 : 3) void k_greedy_seed_runs(const D
                 const uint64_t p = beg + j - 1;
                 if (nlen == 0) {
                     // a fresh seed: the state after its first ftab_k symbols is one gather in the device table
+                    const uint32_t tc = static_cast<uint32_t>(m - j);   // STAGED: symbols between q[j-1] and the read's end
                     if (j == ei && ix.ftab_k && j >= ix.ftab_k) {
                         if (STATS) st[kStFtab] += 1;
-                        if (ftab_state<P>(ix, rd, s_lut2, p, M, lo, hi, k)) { on_ok(ix.ftab_k); continue; }
+                        if (STAGED ? ftab_state_staged<P>(ix, codes, tc, lo, hi, k) : ftab_state<P>(ix, rd, s_lut2, p, M, lo, hi, k)) { on_ok(ix.ftab_k); continue; }
                     }
-                    pick = pick_step(rd, s_lut, s_lut2, tab_first, p, j, D, DMASK, M);
+                    pick = STAGED ? pick_step_staged(codes, s_mslot, tab_first, tc, j, D, DMASK) : pick_step(rd, s_lut, s_lut2, tab_first, p, j, D, DMASK, M);
                     if (!pick.ok) { on_fail(); continue; }
                 } else {
-                    pick = pick_step(rd, s_lut, s_lut2, tab_first, p, nlen / 2, D, DMASK, M);   // == nlen / 2 symbols: the window holds k-mer symbols only
+                    // == nlen / 2 symbols: the window holds k-mer symbols only
+                    pick = STAGED ? pick_step_staged(codes, s_mslot, tab_first, static_cast<uint32_t>(m - j), nlen / 2, D, DMASK)
+                                  : pick_step(rd, s_lut, s_lut2, tab_first, p, nlen / 2, D, DMASK, M);
                 }
                 stepping = true;
             }
@@ -319,6 +368,8 @@ __global__ __launch_bounds__(512, STATS ? 2 : 3) void k_greedy_seed_runs(const D
             qe_out[i] = b_qe;
             ss_out[i] = b_k;
         }
+        };
+        if (staged) walk(std::true_type{}); else walk(std::false_type{});
     }
     if (STATS) seed_stats_flush(st, stats, lane);
 }
@@ -336,6 +387,7 @@ __global__ __launch_bounds__(512, STATS ? 2 : 3) void k_marker_seeds_runs(const 
                                                       const uint64_t *__restrict__ seed_off, const uint64_t *__restrict__ mk_off,
                                                       uint64_t *__restrict__ seeds, uint64_t *__restrict__ mk, const SeedLog lg) {
     RBG_SEED_KERNEL_PROLOGUE(P);
+    RBG_SEED_STAGE_SHARED;
     unsigned long long st[kSeedStatN] = {};               // STATS only (dead code otherwise)
     if (!FILL && blockIdx.x == 0 && threadIdx.x == 0) { seed_cnt[0] = 0; mk_cnt[0] = 0; }
     const bool have_ma = ix.mk_nruns != 0;
@@ -347,6 +399,15 @@ __global__ __launch_bounds__(512, STATS ? 2 : 3) void k_marker_seeds_runs(const 
         const uint64_t i = (listed && valid) ? static_cast<uint64_t>(lg.nsel[4 + base + lane]) : base + lane;
         uint64_t beg = 0, m = 0;
         if (valid) { beg = off[i]; m = off[i + 1] - beg; }
+        bool staged = false;                              // the wave's reads as 2-bit codes in LDS (as in k_greedy_seed_runs)
+        if (stage_on && __ballot(valid && m > kStageCap) == 0) {
+            uint32_t nch = 0;
+            const bool bad = valid && stage_read(reinterpret_cast<const uint4 *>(seqs), beg, beg + m, stage_tab, codes, nch);
+            staged = __ballot(bad) == 0;
+            if (STATS && staged) st[kStChunks] += nch;
+        }
+        auto walk = [&](auto staged_tag) __attribute__((always_inline)) {
+        constexpr bool STAGED = decltype(staged_tag)::value;
         uint64_t lo = 0, hi = fhi, plo = 0, phi = fhi;    // range, prev_range (:427-428)
         uint64_t window_ei = m, seed_ei = m;              // :434
         uint64_t ns = 0, tot = 0, mb_begin = 0;           // mbuf == markers [mb_begin, tot) of this read
@@ -425,14 +486,16 @@ __global__ __launch_bounds__(512, STATS ? 2 : 3) void k_marker_seeds_runs(const 
                     uint64_t dist = j + wsize > window_ei ? j + wsize - window_ei : 1;
                     if (dist == 0) dist = 1;
                     const uint64_t cap = dist < j ? dist : j;
+                    const uint32_t tc = static_cast<uint32_t>(m - j);   // STAGED: symbols between q[j-1] and the read's end
                     if (j == seed_ei && ix.ftab_k && cap >= ix.ftab_k) {
                         if (STATS) st[kStFtab] += 1;
-                        if (ftab_state<P>(ix, rd, s_lut2, p, M, lo, hi, unused_k)) { on_ok(ix.ftab_k); continue; }
+                        if (STAGED ? ftab_state_staged<P>(ix, codes, tc, lo, hi, unused_k) : ftab_state<P>(ix, rd, s_lut2, p, M, lo, hi, unused_k)) { on_ok(ix.ftab_k); continue; }
                     }
-                    pick = pick_step(rd, s_lut, s_lut2, tab_first, p, cap, D, DMASK, M);
+                    pick = STAGED ? pick_step_staged(codes, s_mslot, tab_first, tc, cap, D, DMASK) : pick_step(rd, s_lut, s_lut2, tab_first, p, cap, D, DMASK, M);
                     if (!pick.ok) { on_fail(); continue; }
                 } else {
-                    pick = pick_step(rd, s_lut, s_lut2, tab_first, p, nlen / 2, D, DMASK, M);
+                    pick = STAGED ? pick_step_staged(codes, s_mslot, tab_first, static_cast<uint32_t>(m - j), nlen / 2, D, DMASK)
+                                  : pick_step(rd, s_lut, s_lut2, tab_first, p, nlen / 2, D, DMASK, M);
                 }
                 stepping = true;
             }
@@ -468,6 +531,8 @@ __global__ __launch_bounds__(512, STATS ? 2 : 3) void k_marker_seeds_runs(const 
                 hdr[1] = nw;
             }
         }
+        };
+        if (staged) walk(std::true_type{}); else walk(std::false_type{});
     }
     if (STATS) seed_stats_flush(st, lg.stats, lane);
 }
@@ -623,7 +688,7 @@ SeedLaunch seed_launch(const DevIndex &ix, const LaunchCfg &cfg, uint64_t N) {
 #define RBG_LAUNCH_SEEDK(KERN, ...)                                                     \
     do {                                                                                \
         auto kern = KERN;                                                               \
-        raise_lds(kern, L.lds);                                                         \
+        raise_lds(kern, L.lds, 8 * kStageWaveBytes);   /* (the two seed walks hold the staged reads: static LDS) */ \
         hipLaunchKernelGGL(kern, L.grid, L.block, L.lds, st, ix, __VA_ARGS__);          \
     } while (0)
 

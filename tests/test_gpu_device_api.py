@@ -140,7 +140,8 @@ def test_locate_chains_in_locus_order(synth, layout, phi, pos_bytes, monkeypatch
                 kk = wk[live].astype(np.int64)
                 doc, offs = kk // unit, kk % unit
                 return float(np.mean((doc[1:] != doc[:-1]) & (np.abs(np.diff(offs)) < 1024)))
-            assert (perm != abs_perm).any() and cross(perm) > 0.2 and cross(abs_perm) < 0.05, (cross(perm), cross(abs_perm))
+            # (most toeholds of a locus share a haplotype -- SA[hi] is the haplotype sorted last there -- so a tenth of the neighbours crossing is a lot)
+            assert (perm != abs_perm).any() and cross(perm) > 0.05 and cross(abs_perm) < 0.01, (cross(perm), cross(abs_perm))
     rb.close()
     o.close()
 
