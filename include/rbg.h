@@ -161,7 +161,8 @@ typedef struct rbg_info_t {
                              * or no run lists on the run-indexed layout); pair_runs .. quint_runs above are [1] .. [4] */
 } rbg_info_t;
 enum { RBG_LAYOUT_AUTO = 0, RBG_LAYOUT_SLOTS = 1, RBG_LAYOUT_RUNS = 2, RBG_LAYOUT_PREFER_SLOTS = 3 };
-int rbg_info(const rbg_index *, rbg_info_t *out);
+int rbg_info(const rbg_index *, rbg_info_t *out);   /* writes sizeof(rbg_info_t) bytes of THIS header: a client built against another ABI uses ... */
+int rbg_info_sized(const rbg_index *, rbg_info_t *out, uint64_t out_bytes);   /* ... this: min(out_bytes, sizeof) bytes; fields are only added at the end from ABI 3 on */
 
 /* What the load decided about the run-indexed layout (RBG_LAYOUT_RUNS), so that no table is left out silently: the
  * reference's structures have no size limits (rle_string.hpp:131-161, toehold_sa.hpp:56-72 are plain uint64_t), and where
@@ -509,7 +510,10 @@ int rbg_sample_reads_pangenome_dev(const uint8_t *d_base, const uint64_t *d_site
  * tables of DESIGN.md 2b -- each level is four times the tables of the one before, 218 GB in all for a
  * 2-Gbase index; 1 keeps the reference's one-symbol steps only; the deepest levels are dropped
  * automatically when the replica would not fit), HBM_BUDGET_MB (0 = A QUARTER of the free HBM -- three quarters until round 3; a drop-in library leaves the device to its caller unless told otherwise:
- * upper bound for the replica, deciding how many k-mer levels are kept), FTAB_K (-1 = automatic (the longest word of at most 12 symbols with 4^k <= n/16),
+ * upper bound for the replica, deciding how many k-mer levels are kept.  ONE EXCEPTION, reported by rbg_layout_info().budget_raised and on stderr: under
+ * RBG_LAYOUT_AUTO with no budget given, an index of so many runs that the quarter would leave it fewer than four symbols per step (r about 1e9) takes up
+ * to three quarters -- and only on a device the load has to itself (at least nine tenths of it free: with the caller's own buffers, another replica or
+ * another process already there the quarter stays); any explicit HBM_BUDGET_MB switches the exception off), FTAB_K (-1 = automatic (the longest word of at most 12 symbols with 4^k <= n/16),
  * 0 = no ftab, else the word length of the ftab built on the GPU at load time: the state after the
  * last FTAB_K symbols of a read is one gather; result-neutral like the reference's ftab,
  * rowbowt.hpp:124-125,726-758).

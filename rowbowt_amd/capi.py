@@ -87,6 +87,7 @@ _PROTOS = [
     ("rbg_set_docs", C.c_int, [VP, C.c_char_p, VP, U64]),
     ("rbg_free", None, [VP]),
     ("rbg_info", C.c_int, [VP, C.POINTER(Info)]),
+    ("rbg_info_sized", C.c_int, [VP, C.POINTER(Info), U64]),
     ("rbg_layout_info", C.c_int, [VP, C.POINTER(LayoutInfo), U64]),
     ("rbg_get_f", C.c_int, [VP, VP]),
     ("rbg_last_run_sample", C.c_int, [VP, C.POINTER(U64)]),

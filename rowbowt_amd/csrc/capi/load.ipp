@@ -339,7 +339,11 @@ FlattenOptions options_for(int device, const RawRle &rle, uint64_t *requested, b
                 // rbg_info (hbm_budget) and rbg_layout_info (budget_raised); RBG_OPT_HBM_BUDGET_MB decides otherwise.
                 const double r = static_cast<double>(rle.heads.size());
                 const uint32_t want = static_cast<uint32_t>(std::min(o.kmer_steps, 4));
-                if (opt_mb == 0 && g_opt_rank_layout.load() == RBG_LAYOUT_AUTO &&
+                // ... and only on a device this load has (almost) to itself: with a tenth of it or more already taken -- the caller's own buffers,
+                // another replica, another process -- the quarter stays (a caller that sized its buffers around the quarter rule).
+                const size_t whole = std::getenv("RBG_ASSUME_FREE_HBM_MB") ? free_b : total_b;
+                const bool device_to_itself = static_cast<double>(free_b) >= 0.9 * static_cast<double>(whole);
+                if (opt_mb == 0 && g_opt_rank_layout.load() == RBG_LAYOUT_AUTO && device_to_itself &&
                     planned_depth(r, true, static_cast<uint32_t>(o.kmer_steps), static_cast<double>(free_b), budget, true) < want) {
                     const double raised = 0.75 * static_cast<double>(free_b);
                     if (planned_depth(r, true, static_cast<uint32_t>(o.kmer_steps), static_cast<double>(free_b), raised, true) >
@@ -1223,6 +1227,17 @@ void rbg_free_buffer(void *p) {
     std::free(p);
 }
 
+// rbg_info for a caller compiled against ANOTHER layout of rbg_info_t (the struct grew with ABI 3 and rbg_info cannot know what its caller
+// allocated): fills min(out_bytes, sizeof(rbg_info_t)) bytes -- fields are only ever added at the end from ABI 3 on.
+int rbg_info_sized(const rbg_index *ix, rbg_info_t *out, uint64_t out_bytes) {
+    if (!ix || !out || out_bytes < 8) return RBG_EARG;
+    rbg_info_t v;
+    const int rc = rbg_info(ix, &v);
+    if (rc) return rc;
+    std::memcpy(out, &v, static_cast<size_t>(std::min<uint64_t>(out_bytes, sizeof(v))));
+    return RBG_OK;
+}
+
 int rbg_info(const rbg_index *ix, rbg_info_t *out) {
     return guarded([&]() -> int {
     if (!ix || !out) return RBG_EARG;
@@ -1268,6 +1283,10 @@ int rbg_info(const rbg_index *ix, rbg_info_t *out) {
 int rbg_layout_info(const rbg_index *ix, rbg_layout_info_t *out, uint64_t out_bytes) {
     return guarded([&]() -> int {
     if (!ix || !out || out_bytes < 8) return RBG_EARG;
+    // (ABI 3 changed this struct in the middle -- five-entry arrays became eight -- so a size that is neither this layout's nor a prefix of it at
+    //  an 8-byte boundary beyond the ABI-3 head is a caller compiled against ABI 2: refused rather than filled with shifted fields)
+    if (out_bytes < offsetof(rbg_layout_info_t, budget_raised) && out_bytes != offsetof(rbg_layout_info_t, rec_bytes) && out_bytes != offsetof(rbg_layout_info_t, entries))
+        return RBG_EARG;
     rbg_layout_info_t v;
     std::memset(&v, 0, sizeof(v));
     if (ix->device != RBG_DEVICE_NONE && ix->dev.layout == RBG_LAYOUT_RUNS) {

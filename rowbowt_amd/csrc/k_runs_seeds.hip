@@ -301,6 +301,13 @@ __global__ __launch_bounds__(512, STATS ? 2 : 3) void k_greedy_seed_runs(const D
         constexpr bool STAGED = decltype(staged_tag)::value;
         uint64_t lo = 0, hi = fhi, plo = 0, phi = fhi;
         uint64_t k = first_k, pk = ~uint64_t(0), ei = m;
+        // DEFERRED re-samples (as in k_find_range_runs): a step whose row hi does not carry the symbol re-samples the toehold from the run list -- two
+        // dependent gathers behind the step's record -- but only the LAST re-sample before a seed's end is ever used: the step leaves {table, entry}
+        // behind and k = 0, later steps subtract from k, and the sample is fetched when a seed becomes the read's best (toehold = sample + k in
+        // wrapping arithmetic: exactly the reference's chain of k - 1, rowbowt.hpp:555-573).  pend_* / ppend_*: of k and of pk (the state before the step).
+        bool pend = false, ppend = false;
+        uint32_t pend_d = 0, pend_rec = 0, ppend_d = 0, ppend_rec = 0;
+        uint64_t pend_e = 0, ppend_e = 0;
         uint64_t b_lo = 1, b_hi = 0, b_qs = 0, b_qe = 0, b_k = 0, b_len = 0;
         uint64_t j = m;                                 // next symbol to consume is q[j-1]
         uint32_t nlen = 0;                              // > 0: a k-mer step over q[j-nlen, j) came back empty and is being narrowed
@@ -310,10 +317,16 @@ __global__ __launch_bounds__(512, STATS ? 2 : 3) void k_greedy_seed_runs(const D
             j -= adv;
             if (STATS) st[kStSymbols] += adv;
             plo = lo; phi = hi; pk = k;                 // rowbowt.hpp:248-249
+            ppend = pend; ppend_d = pend_d; ppend_rec = pend_rec; ppend_e = pend_e;
         };
+        bool b_pend = false;                            // ... and of the best seed's toehold: fetched once, when the read is done
+        uint32_t b_pd = 0, b_prec = 0;
+        uint64_t b_pe = 0;
+        auto take_best = [&]() { b_k = pk; b_pend = ppend; b_pd = ppend_d; b_prec = ppend_rec; b_pe = ppend_e; };
         auto on_fail = [&]() {                          // q[j-1] ends the seed q[j, ei)  (rowbowt.hpp:236-246; m-i == j here)
-            if (ei - j >= min_length && ei - j > b_len) { b_len = ei - j; b_lo = plo; b_hi = phi; b_qs = j; b_qe = ei; b_k = pk; }
+            if (ei - j >= min_length && ei - j > b_len) { b_len = ei - j; b_lo = plo; b_hi = phi; b_qs = j; b_qe = ei; take_best(); }
             k = first_k;
+            pend = false; ppend = false;
             lo = 0; hi = fhi; plo = 0; phi = fhi;
             j -= 1;                                     // skip the base that failed
             ei = j;
@@ -328,7 +341,7 @@ __global__ __launch_bounds__(512, STATS ? 2 : 3) void k_greedy_seed_runs(const D
                     const uint32_t tc = static_cast<uint32_t>(m - j);   // STAGED: symbols between q[j-1] and the read's end
                     if (j == ei && ix.ftab_k && j >= ix.ftab_k) {
                         if (STATS) st[kStFtab] += 1;
-                        if (STAGED ? ftab_state_staged<P>(ix, codes, tc, lo, hi, k) : ftab_state<P>(ix, rd, s_lut2, p, M, lo, hi, k)) { on_ok(ix.ftab_k); continue; }
+                        if (STAGED ? ftab_state_staged<P>(ix, codes, tc, lo, hi, k) : ftab_state<P>(ix, rd, s_lut2, p, M, lo, hi, k)) { pend = false; on_ok(ix.ftab_k); continue; }
                     }
                     pick = STAGED ? pick_step_staged(codes, s_mslot, tab_first, tc, j, D, DMASK) : pick_step(rd, s_lut, s_lut2, tab_first, p, j, D, DMASK, M);
                     if (!pick.ok) { on_fail(); continue; }
@@ -346,7 +359,7 @@ __global__ __launch_bounds__(512, STATS ? 2 : 3) void k_greedy_seed_runs(const D
                 const bool ok = c_inside != 0;
                 if (ok) {                               // LF_w_loc, rowbowt.hpp:555-573, pick.adv times nested
                     if (r.inside) k = k - pick.adv;
-                    else { k = run_step_sample2<P>(ix, S2, pick.d, pick.rec, r.samp_e); if (STATS) st[kStResample] += 1; }
+                    else { pend = true; pend_d = pick.d; pend_rec = pick.rec; pend_e = r.samp_e; k = 0; }
                     lo = r.F + r.c_before;
                     hi = lo + c_inside - 1;
                 }
@@ -361,7 +374,8 @@ __global__ __launch_bounds__(512, STATS ? 2 : 3) void k_greedy_seed_runs(const D
             }
         }
         if (valid) {
-            if (ei >= min_length && ei > b_len) { b_len = ei; b_lo = plo; b_hi = phi; b_qs = 0; b_qe = ei; b_k = pk; }  // :252-254
+            if (ei >= min_length && ei > b_len) { b_len = ei; b_lo = plo; b_hi = phi; b_qs = 0; b_qe = ei; take_best(); }  // :252-254
+            if (b_pend) { b_k += run_step_sample2<P>(ix, S2, b_pd, b_prec, b_pe); if (STATS) st[kStResample] += 1; }
             lo_out[i] = b_lo;
             hi_out[i] = b_hi;
             qs_out[i] = b_qs;

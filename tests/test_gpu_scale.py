@@ -309,6 +309,12 @@ def test_bench_two_ranks_rehearsal():
     assert d["n_gpus"] == 2 and d["value"] > 0 and "rehearsal" in d["config"] and d["vs_baseline"] is None
     assert d["config"]["reads_per_gpu"] == 150000
     assert d["parity"]["bit_exact_vs_oracle"] and d["counters"]["reads"] == 2 * 150000 * 2   # (two ranks x the two timed steps)
+    # the post-mortem block of a multi-GPU run: who ran where, how long each rank loaded / waited / stepped, what the per-node cache cost
+    per = d["per_rank"]
+    assert [x["rank"] for x in per] == [0, 1] and all(x["device"] == 0 and x["load_s"] > 0 and x["ms_per_step"] > 0 and x["k2_ms"] > 0 and x["hbm_bytes"] > 0 for x in per)
+    assert per[1]["wait_for_rank0_s"] >= 0 and d["rccl_ranks_seen"] == 2 and "gloo" in d["collective_backend"]
+    assert d["cache_write_s"] > 0 and d["cache_bytes"] > 100_000 and d["cache_path"].endswith(".rbgpu") and d["suffix_array_s"] > 0
+    assert abs(d["ms_per_step"] - max(x["ms_per_step"] for x in per)) < 1e-6      # the line's time is the max over the ranks
 
 
 def test_full_size_properties_and_parity_sample():

@@ -121,3 +121,24 @@ def test_replicas_and_gpus_are_two_ways_and_exclude_each_other():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pangenome_stream.py"), "--replicas", "2", "--gpus", "2", "--launch-check"],
                        env=clean_env(), capture_output=True, text=True, timeout=60)
     assert p.returncode != 0 and "--replicas" in p.stderr and "--gpus" in p.stderr and p.stdout.strip() == ""
+
+
+def test_a_rank_that_fails_names_its_stage_before_the_parent_stops_the_others():
+    """VERDICT r5 item 5 (the first 8-GPU run is the driver's): a rank of bench.py that dies says WHICH rank, WHERE in its run (bench.py `stage()`) and
+    why on stderr; the launching parent then reports the exit code and stops the other ranks.  Here: two rehearsal ranks on a box without a GPU --
+    both fail at the stage that asks for the device."""
+    if os.path.exists("/dev/kfd"):
+        pytest.skip("a GPU box: the ranks would run")
+    p = subprocess.run([sys.executable, SCRIPTS[0], "--gpus", "2", "--rehearse-ranks", "--L", "20000", "--H", "3", "--reads", "100"],
+                       capture_output=True, text=True, timeout=600, env=clean_env())
+    assert p.returncode != 0
+    assert "FAILED at stage 'import torch'" in p.stderr and "bench.py needs an MI355X" in p.stderr
+    assert "[bench] rank 0 (pid" in p.stderr or "[bench] rank 1 (pid" in p.stderr
+    assert "[launch] rank" in p.stderr and "stopping the other ranks" in p.stderr
+
+
+def test_replicas_flag_is_refused_under_a_multi_rank_world():
+    """bench.py --replicas G (one process, G replicas) with --gpus N > 1 used to be ignored silently: refused now, like pangenome_stream.py"""
+    env = clean_env(RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    p = subprocess.run([sys.executable, SCRIPTS[0], "--gpus", "2", "--replicas", "2"], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode != 0 and "pick one" in p.stderr
