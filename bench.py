@@ -778,7 +778,13 @@ def run():
                           "hbm_free_at_load": int(ix.hbm_free_at_load), "hbm_budget": int(ix.hbm_budget),
                           "rank_layout": "runs" if int(ix.rank_layout) == 2 else "slots",
                           "hbm_budget_source": ("bench.py --hbm-budget-gb -1: three quarters of the free HBM" if args.hbm_budget_gb < 0
-                                                else "the library's default (a quarter of the free HBM)" if args.hbm_budget_gb == 0 else f"--hbm-budget-gb {args.hbm_budget_gb}"), "ftab_k": int(ix.ftab_k), "depth_runs": [int(x) for x in ix.depth_runs]},
+                                                else "the library's default (a quarter of the free HBM)" if args.hbm_budget_gb == 0 else f"--hbm-budget-gb {args.hbm_budget_gb}"), "ftab_k": int(ix.ftab_k), "depth_runs": [int(x) for x in ix.depth_runs],
+                          # what the load's budget rules decided (rbg_layout_info; tools/layout_rules_table.py makes DESIGN.md 2c's table from these)
+                          **({"layout_info": {"budget_raised": int(li.budget_raised), "depths_kept": [d_ + 1 for d_ in range(8) if int(li.depth_mask_kept) >> d_ & 1],
+                                              "depths_with_records": [d_ + 1 for d_ in range(8) if int(li.rec_bytes[d_])], "depths_dropped_budget": int(li.depths_dropped_budget),
+                                              "entries": [int(x) for x in li.entries], "rec_bytes": [int(x) for x in li.rec_bytes],
+                                              "phi_slots": int(li.phi_slots), "phi_slot_bytes": int(li.phi_slot_bytes), "phi_entries": int(li.phi_entries),
+                                              "rank_directories": int(li.rank_directories), "phi_directory": int(li.phi_directory)}} if li else {})},
                 "reads_per_gpu": N, "read_len": m, "substituted_fraction": 0.1,
                 "documents": info["H"] if args.docs == "on" else 0,
                 "chain_order": ("by locus: offset inside the document, then document"

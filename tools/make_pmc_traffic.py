@@ -68,7 +68,8 @@ NAMES = {"FETCH_SIZE": ("fetch_bytes", 1024), "WRITE_SIZE": ("write_bytes", 1024
 
 def _targs(kernel):
     k = kernel.replace("rbg::(anonymous namespace)::", "")
-    return k.split("<", 1)[0].split("::")[-1], (k.split("<", 1)[1].rsplit(">", 1)[0].replace(" ", "").split(",") if "<" in k else [])
+    head = k.split("<", 1)[0].split("(", 1)[0].split("::")[-1].split(" ")[-1]   # ("void rbg::...::name<args>(params)" as rocprofv3 prints it)
+    return head, (k.split("<", 1)[1].split(">(", 1)[0].rsplit(">", 1)[0].replace(" ", "").split(",") if "<" in k else [])
 
 
 def collect(d, label_fn):
