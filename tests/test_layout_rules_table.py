@@ -18,7 +18,7 @@ def test_design_holds_the_generated_table():
 
 def test_every_row_obeys_the_rules():
     for p in T.DEFAULT:
-        d = json.loads(open(os.path.join(ROOT, p)).read().strip().splitlines()[-1])
+        d = T.load(p)
         ix = d["config"]["index"]
         li = ix["layout_info"]
         raised = li.get("budget_raised", 0)

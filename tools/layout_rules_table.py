@@ -12,12 +12,22 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DEFAULT = ["profiles/r06_bench.json", "profiles/r06_pangenome_driver.json", "profiles/r05_pangenome_stream_n5e10_default.json",
+DEFAULT = ["profiles/r06_bench.json", "profiles/r06_bench.json#pangenome_shape", "profiles/r06_pangenome_stream_n5e10_default.json",
            "profiles/r06_pangenome_stream_r1e9_default_locus.json"]
 
 
+def load(path):
+    """the JSON line of a file; 'file#pangenome_shape' = that block of a bench.py line (tools/pangenome_stream.py --preset driver run by bench.py)"""
+    f, _, block = path.partition("#")
+    d = json.loads(open(os.path.join(ROOT, f)).read().strip().splitlines()[-1])
+    if block:
+        b = d[block]
+        d = {"value": b["value"], "config": {"index": b["index"]}}
+    return d
+
+
 def row_of(path):
-    d = json.loads(open(os.path.join(ROOT, path)).read().strip().splitlines()[-1])
+    d = load(path)
     ix = d["config"]["index"]
     li = ix.get("layout_info") or {}
     kept = li.get("depths_kept") or [i + 1 for i in range(8) if li.get("depth_mask_kept", 0) >> i & 1]
@@ -34,7 +44,7 @@ def table(paths):
     out = ["| n | r | haplotypes | free HBM (GB) | budget (GB) | symbols per step | depths kept | depths with bucket records | phi | replica (GB) | reads/s from it | file |",
            "|---|---|---|---|---|---|---|---|---|---|---|---|"]
     for p in paths:
-        if os.path.exists(os.path.join(ROOT, p)):
+        if os.path.exists(os.path.join(ROOT, p.partition("#")[0])):
             out.append(row_of(p))
     return "\n".join(out)
 
