@@ -561,21 +561,22 @@ def run():
         el_g = timed(gstep, K)
         # ---- what the seeding kernels touched, and their rooflines (run-indexed layout: the instrumented instantiations, outside every timed region;
         # DESIGN.md 3).  Bytes as run: per sequence and walk its offsets (16) and 16 per read chunk; the plan's two counts (16); 64 per bucket
-        # record, 8 per run-list entry scanned, 28 per narrowing round, the ftab entry, 4 / 6 per re-sample; per marker query 4 per directory entry,
-        # 8 per run start / end read, 8 per value offset; the fill's seed records (48 each) and marker values (8 read + 8 written each).
+        # record, 8 per run-list entry scanned, 28 per narrowing round, the ftab entry, 4 / 6 per re-sample; per marker query 32 per bucket record (one or
+        # two), behind an overflowing record 8 per run start / end and value offset read; the fill's seed records (48 each) and marker values (8 + 8 each).
         seed_roof = {}
         if int(ix.rank_layout) == 2:
             SD = ("steps", "slots", "dense", "searched_ranks", "ftab", "resamples", "read_chunks", "symbols", "marker_queries", "marker_dir", "marker_probes",
                   "marker_off", "marker_vals", "seed_recs", "sequences")
             Pm = int(ix.pos_bytes)
             ftab_bm, samp_bm = (16 if Pm == 4 else 32), (4 if Pm == 4 else 6)
+            mkdir_bm = 4 if os.environ.get("RBG_MK_REC", "1")[:1] == "0" else 32     # a marker query reads 32-byte bucket records (round 6), or 4-byte directory entries
             li_m = rb.layout_info()
             rec_bm = 64 if any(int(x) for x in li_m.rec_bytes) else (8 if Pm == 4 else 16)
             d_sst = torch.zeros(16, dtype=torch.int64, device=dev)
 
             def seed_bytes(v, walks, counts_out):
                 return (v["sequences"] * 16 + 16 * v["read_chunks"] + counts_out + rec_bm * v["slots"] + 8 * v["dense"] + 28 * v["searched_ranks"] + ftab_bm * v["ftab"]
-                        + samp_bm * v["resamples"] + 4 * v["marker_dir"] + 8 * v["marker_probes"] + 8 * v["marker_off"] + 16 * v["marker_vals"] + 48 * v["seed_recs"])
+                        + samp_bm * v["resamples"] + mkdir_bm * v["marker_dir"] + 8 * v["marker_probes"] + 8 * v["marker_off"] + 16 * v["marker_vals"] + 48 * v["seed_recs"])
 
             chk(L.rbg_marker_seeds_stats_dev(rb.h, d_seqs2.data_ptr(), d_off2.data_ptr(), 2 * N, WS, MR, d_soff.data_ptr(), d_moff.data_ptr(), d_tmp2.data_ptr(), tmp2,
                                              d_srec.data_ptr(), d_smk.data_ptr(), d_sst.data_ptr(), st), "marker_seeds_stats")

@@ -461,9 +461,10 @@ enum { RBG_LS_PHI_STEPS = 0,  /* phi evaluations (one phi slot each) */
  * RBG_SEARCH_STATS with that layout's meanings, then the marker side.  rbg_marker_seeds_stats_dev = rbg_marker_seeds_plan_dev +
  * rbg_marker_seeds_fill_dev (the two-walk pair, no log, no --ftab) with both walks instrumented: same offsets, records and markers. */
 enum { RBG_SD_MARKER_QUERIES = 8, /* window queries that went to the marker runs (rowbowt.hpp:437-441 with range <= max_range) */
-       RBG_SD_MARKER_DIR,         /* directory entries read for them (4 bytes each) */
-       RBG_SD_MARKER_PROBES,      /* run starts / ends read (8 bytes each) */
-       RBG_SD_MARKER_OFF,         /* value offsets read (8 bytes each) */
+       RBG_SD_MARKER_DIR,         /* bucket records read for them (32 bytes each: one per end of the range, one when both ends share a bucket; with RBG_MK_REC=0
+                                     directory entries, 4 bytes each) */
+       RBG_SD_MARKER_PROBES,      /* run starts / ends read from the arrays (8 bytes each): only behind an overflowing bucket's record */
+       RBG_SD_MARKER_OFF,         /* value offsets read from the array (8 bytes each): likewise */
        RBG_SD_MARKER_VALS,        /* marker values copied (8 read + 8 written each) */
        RBG_SD_SEED_RECS,          /* seed records written (48 bytes each) */
        RBG_SD_SEQUENCES,          /* sequences walked */

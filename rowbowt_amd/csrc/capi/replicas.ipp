@@ -103,7 +103,7 @@ int replicate_finish(rbg_index *src, ReplicaJob &job) {
     }
     DevIndex d = src->dev;
     reloc.fix(d.syms); reloc.fix(d.phi_ent); reloc.fix(d.phi_slots); reloc.fix(d.phi_ord);
-    reloc.fix(d.mk_start); reloc.fix(d.mk_end); reloc.fix(d.mk_off); reloc.fix(d.mk_vals); reloc.fix(d.mk_bucket);
+    reloc.fix(d.mk_start); reloc.fix(d.mk_end); reloc.fix(d.mk_off); reloc.fix(d.mk_vals); reloc.fix(d.mk_bucket); reloc.fix(d.mk_rec);
     reloc.fix(d.counters); reloc.fix(d.lut); reloc.fix(d.pairs); reloc.fix(d.triples); reloc.fix(d.quads); reloc.fix(d.quints);
     reloc.fix(d.lut2); reloc.fix(d.ftab); reloc.fix(d.dense);
     reloc.fix(d.phi_dir); reloc.fix(d.order_docs);

@@ -519,6 +519,7 @@ int upload_markers(rbg_index *ix) {
     ix->dev.mk_nruns = m.start.size();
     ix->dev.mk_bucket = nullptr;
     ix->dev.mk_shift = 0;
+    ix->dev.mk_rec = nullptr;
     const uint64_t nruns = m.start.size(), n = ix->H().n;
     if (nruns && nruns < 0xFFFFFFFFull) {
         // about two buckets per run: at_range's two predecessor searches (2 x log2(nruns) dependent
@@ -536,6 +537,33 @@ int upload_markers(rbg_index *ix) {
         if ((rc = dev_upload(ix, bucket.data(), nb * 4, &p))) return rc;
         ix->dev.mk_bucket = static_cast<const uint32_t *>(p);
         ix->dev.mk_shift = shift;
+        // the bucket records (rbg_dev.h MkRec): 32 bytes per bucket, i.e. about 64 per run.  RBG_MK_REC=0: the arrays only (A/B, tests)
+        const char *e = std::getenv("RBG_MK_REC");
+        if (shift <= 16 && !(e && e[0] == '0') && (m.vals.size() >> 40) == 0) {
+            std::vector<MkRec> recs(nb);
+            for (uint64_t b = 0; b < nb; ++b) {
+                MkRec &R = recs[b];
+                std::memset(&R, 0, sizeof(R));
+                const uint64_t a = bucket[b], first_row = b << shift, end_row = first_row + (uint64_t(1) << shift);
+                R.a = static_cast<uint32_t>(a);
+                const uint64_t off_a = a < nruns ? m.off[a] : m.vals.size();
+                R.off_lo = static_cast<uint32_t>(off_a);
+                R.off_hi = static_cast<uint8_t>(off_a >> 32);
+                uint32_t k = 0;
+                bool over = false;
+                for (uint64_t j2 = a; j2 < nruns && m.start[j2] < end_row; ++j2) {
+                    const uint64_t c = m.off[j2 + 1] - m.off[j2];
+                    if (k == kMkRecRuns || c > 0xFFFF) { over = true; break; }
+                    R.s_off[k] = static_cast<uint16_t>(m.start[j2] > first_row ? m.start[j2] - first_row : 0);
+                    R.e_off[k] = static_cast<uint16_t>(std::min<uint64_t>(m.end[j2] - first_row, 0xFFFF));   // (end >= first_row: j2 >= a)
+                    R.cnt[k] = static_cast<uint16_t>(c);
+                    ++k;
+                }
+                R.nin = over ? static_cast<uint8_t>(kMkRecOverflow) : static_cast<uint8_t>(k);
+            }
+            if ((rc = dev_upload(ix, recs.data(), nb * sizeof(MkRec), &p))) return rc;
+            ix->dev.mk_rec = static_cast<const MkRec *>(p);
+        }
     }
     return RBG_OK;
 }

@@ -37,6 +37,16 @@ __device__ __forceinline__ uint64_t locus_toehold(const DevIndex &ix, const uint
     const uint64_t doc = (key >> low) & ((uint64_t(1) << db) - 1u);
     return ix.order_docs[doc] + (((key >> (db + low)) << low) | (key & ((uint64_t(1) << low) - 1u)));
 }
+// 4-byte positions, absolute order: the sort moves 32-bit keys (a third fewer bytes per radix pass than 64-bit ones).  A toehold outside the text
+// (it wrapped below zero) travels as 0xFFFFFFFF -- no position of an index with 4-byte positions -- and K3 reads the toehold itself.
+__global__ __launch_bounds__(256) void k_keys32(const DevIndex ix, const uint64_t *__restrict__ k, const uint64_t N, uint32_t *__restrict__ keys, uint32_t *__restrict__ iota) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < N; i += stride) {
+        const uint64_t v = k[i];
+        keys[i] = v >= ix.n ? 0xFFFFFFFFu : static_cast<uint32_t>(v);
+        iota[i] = static_cast<uint32_t>(i);
+    }
+}
 __global__ __launch_bounds__(256) void k_locus_keys(const DevIndex ix, const uint64_t *__restrict__ k, const uint64_t N, uint64_t *__restrict__ keys,
                                                     uint32_t *__restrict__ iota) {
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
@@ -175,7 +185,9 @@ __global__ __launch_bounds__(256) void k_locate_fill(const DevIndex ix, const ui
                 // ordered walk: the toehold travels with the sort (sequential read) and the count is the
                 // planned one, loc_off[i+1] - loc_off[i] = min(occ, max_hits): one random 64-byte sector
                 // per read instead of four (lo, hi, k, loc_off)
-                k1 = ix.order_docs ? locus_toehold(ix, skeys[j], k, i) : skeys[j];
+                if (ix.order_docs) k1 = locus_toehold(ix, skeys[j], k, i);
+                else if (sizeof(P) == 4) { const uint32_t k32 = reinterpret_cast<const uint32_t *>(skeys)[j]; k1 = k32 == 0xFFFFFFFFu ? k[i] : k32; }   // (k_keys32)
+                else k1 = skeys[j];
                 occ = loc_off[i + 1] - dst;
             } else {
                 const uint64_t l = lo[i], h = hi[i];
@@ -296,11 +308,21 @@ int launch_locate_order(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t
         const int lo_bit = static_cast<int>(ix.order_lowbits), hi_bit = static_cast<int>(ix.order_obits + ix.order_dbits) + 1;
         return static_cast<int>(hipcub::DeviceRadixSort::SortPairs(base + w.sort, bytes0, keys_in, keys, iota, perm, static_cast<int64_t>(N), lo_bit, hi_bit < 64 ? hi_bit : 64, st));
     }
+    int end_bit = 1;
+    while (end_bit < 64 && (ix.n >> end_bit)) ++end_bit;  // toeholds are text positions < n
+    if (ix.pos_bytes == 4) {   // 32-bit keys (k_keys32): the key pass also makes the identity permutation
+        uint32_t *k32_in = reinterpret_cast<uint32_t *>(base + w.keys_in), *k32_out = reinterpret_cast<uint32_t *>(base + w.keys);
+        hipLaunchKernelGGL(k_keys32, dim3(grid_for(cfg, N)), dim3(256), 0, st, ix, k, N, k32_in, iota);
+        int rc32 = static_cast<int>(hipGetLastError());
+        if (rc32) return rc32;
+        int b0 = static_cast<int>(ix.phi_shift) + 2;
+        if (end_bit - b0 < 8) b0 = 0;
+        size_t bytes32 = w.sort_bytes;   // (sized for 64-bit keys: enough for 32-bit ones)
+        return static_cast<int>(hipcub::DeviceRadixSort::SortPairs(base + w.sort, bytes32, k32_in, k32_out, iota, perm, static_cast<int64_t>(N), b0, end_bit < 32 ? end_bit : 32, st));
+    }
     hipLaunchKernelGGL(k_iota, dim3(grid_for(cfg, N)), dim3(256), 0, st, iota, N);
     int rc = static_cast<int>(hipGetLastError());
     if (rc) return rc;
-    int end_bit = 1;
-    while (end_bit < 64 && (ix.n >> end_bit)) ++end_bit;  // toeholds are text positions < n
     // the order only has to bring chains of nearby text positions together: the low bits (positions
     // inside one 64-byte line of phi slots) need no sorting, which saves a radix pass
     int begin_bit = static_cast<int>(ix.phi_shift) + 2;

@@ -4,34 +4,7 @@
 namespace rbg {
 namespace {
 
-// ---- K4: markers --------------------------------------------------------------------------------
-// runs are disjoint, ascending inclusive SA-index intervals; at_range(lo,hi) = values of all runs
-// with start <= hi && end >= lo, in run order.
-__device__ __forceinline__ void marker_span(const DevIndex &ix, uint64_t lo, uint64_t hi, uint64_t *first, uint64_t *last) {
-    if (ix.mk_bucket) {
-        if (lo >= ix.n) { *first = *last = ix.mk_nruns; return; }  // caller-supplied rows beyond the BWT: nothing
-        if (hi >= ix.n) hi = ix.n - 1;
-        // first run with end >= lo: the bucket table gives the first run ending at or after the start of
-        // lo's bucket; the answer is at most a bucket's worth of runs further on
-        uint64_t a = ix.mk_bucket[lo >> ix.mk_shift];
-        while (a < ix.mk_nruns && ix.mk_end[a] < lo) ++a;
-        *first = a;
-        // one past the last run with start <= hi: every run before the entry of hi's bucket ends, hence
-        // starts, before hi
-        uint64_t z = ix.mk_bucket[hi >> ix.mk_shift];
-        if (z < a) z = a;
-        while (z < ix.mk_nruns && ix.mk_start[z] <= hi) ++z;
-        *last = z;
-        return;
-    }
-    uint64_t a = 0, z = ix.mk_nruns;
-    while (a < z) { const uint64_t m = a + ((z - a) >> 1); if (ix.mk_end[m] < lo) a = m + 1; else z = m; }
-    *first = a;  // first run with end >= lo
-    a = 0; z = ix.mk_nruns;
-    while (a < z) { const uint64_t m = a + ((z - a) >> 1); if (ix.mk_start[m] <= hi) a = m + 1; else z = m; }
-    *last = a;   // one past the last run with start <= hi
-}
-
+// ---- K4: markers (rbg_device.hpp marker_query: at_range from the bucket records, or the directory + run arrays) ------------
 __global__ __launch_bounds__(256) void k_markers_count(const DevIndex ix, const uint64_t *__restrict__ lo,
                                                        const uint64_t *__restrict__ hi, const uint64_t N,
                                                        uint64_t *__restrict__ out) {
@@ -39,9 +12,8 @@ __global__ __launch_bounds__(256) void k_markers_count(const DevIndex ix, const 
     for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < N; i += stride) {
         uint64_t cnt = 0;
         if (hi[i] >= lo[i]) {
-            uint64_t f, l;
-            marker_span(ix, lo[i], hi[i], &f, &l);
-            if (l > f) cnt = ix.mk_off[l] - ix.mk_off[f];
+            uint64_t src, c;
+            if (marker_query(ix, lo[i], hi[i], &src, &c)) cnt = c;
         }
         out[i + 1] = cnt;
     }
@@ -54,10 +26,8 @@ __global__ __launch_bounds__(256) void k_markers_fill(const DevIndex ix, const u
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
     for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < N; i += stride) {
         if (hi[i] < lo[i]) continue;
-        uint64_t f, l;
-        marker_span(ix, lo[i], hi[i], &f, &l);
-        if (l <= f) continue;
-        const uint64_t src = ix.mk_off[f], cnt = ix.mk_off[l] - src;
+        uint64_t src, cnt;
+        if (!marker_query(ix, lo[i], hi[i], &src, &cnt)) continue;
         uint64_t *dst = mk + mk_off[i];
         for (uint64_t t = 0; t < cnt; ++t) dst[t] = ix.mk_vals[src + t];
     }
@@ -123,10 +93,8 @@ __global__ __launch_bounds__(256) void k_find_range_markers(const DevIndex ix, c
                     query = (m - 1) % wsize != 0;          // :328
                 }
                 if (query && hi - lo + 1 <= max_range) {   // :318,:331
-                    uint64_t f, l;
-                    marker_span(ix, lo, hi, &f, &l);
-                    if (l > f) {
-                        const uint64_t src = ix.mk_off[f], cnt = ix.mk_off[l] - src;
+                    uint64_t src, cnt;
+                    if (marker_query(ix, lo, hi, &src, &cnt)) {
                         acc += cnt;
                         if (FILL) {
                             uint64_t *d = dst + (want - acc);
@@ -336,10 +304,8 @@ __global__ __launch_bounds__(1024) void k_marker_seeds(const DevIndex ix, const 
         bool lover = LOG && (m >> 32) != 0;               // (positions in the read are logged as 32 bits)
         auto update_mbuf = [&](uint64_t l, uint64_t h) {  // :437-441
             if (!have_ma || h - l + 1 > max_range) return;
-            uint64_t f, e;
-            marker_span(ix, l, h, &f, &e);
-            if (e <= f) return;
-            const uint64_t src = ix.mk_off[f], cnt = ix.mk_off[e] - src;
+            uint64_t src, cnt;
+            if (!marker_query(ix, l, h, &src, &cnt)) return;
             if (FILL) {
                 uint64_t *d = mk + mbase + tot;
                 for (uint64_t t = 0; t < cnt; ++t) d[t] = ix.mk_vals[src + t];

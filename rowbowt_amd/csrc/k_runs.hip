@@ -330,7 +330,9 @@ __global__ __launch_bounds__(256, 4) void k_locate_fill_runs2(const DevIndex ix,
         if (i < N && j < N) {
             dst = loc_off[i];
             if (skeys) {
-                k1 = ix.order_docs ? locus_toehold_r(ix, skeys[j], k, i) : skeys[j];
+                if (ix.order_docs) k1 = locus_toehold_r(ix, skeys[j], k, i);
+                else if (sizeof(P) == 4) { const uint32_t k32 = reinterpret_cast<const uint32_t *>(skeys)[j]; k1 = k32 == 0xFFFFFFFFu ? k[i] : k32; }   // (k_locate.hip k_keys32)
+                else k1 = skeys[j];
                 occ = loc_off[i + 1] - dst;
             } else {
                 const uint64_t l = lo[i], h = hi[i];

@@ -14,30 +14,7 @@
 namespace rbg {
 namespace {
 
-// runs are disjoint, ascending inclusive SA-index intervals; at_range(lo,hi) = values of all runs with start <= hi &&
-// end >= lo, in run order (k_markers.hip marker_span)
-// st (instrumented instantiations): [kSdMarkerDir] += directory entries read, [kSdMarkerProbes] += mk_end / mk_start entries read
-__device__ __forceinline__ void marker_span_r(const DevIndex &ix, uint64_t lo, uint64_t hi, uint64_t *first, uint64_t *last, unsigned long long *st = nullptr) {
-    if (ix.mk_bucket) {
-        if (lo >= ix.n) { *first = *last = ix.mk_nruns; return; }
-        if (hi >= ix.n) hi = ix.n - 1;
-        uint64_t a = ix.mk_bucket[lo >> ix.mk_shift];
-        if (st) { st[kSdMarkerDir] += 2; st[kSdMarkerProbes] += 2; }
-        while (a < ix.mk_nruns && ix.mk_end[a] < lo) { ++a; if (st) st[kSdMarkerProbes] += 1; }
-        *first = a;
-        uint64_t z = ix.mk_bucket[hi >> ix.mk_shift];
-        if (z < a) z = a;
-        while (z < ix.mk_nruns && ix.mk_start[z] <= hi) { ++z; if (st) st[kSdMarkerProbes] += 1; }
-        *last = z;
-        return;
-    }
-    uint64_t a = 0, z = ix.mk_nruns;
-    while (a < z) { const uint64_t m = a + ((z - a) >> 1); if (ix.mk_end[m] < lo) a = m + 1; else z = m; }
-    *first = a;
-    a = 0; z = ix.mk_nruns;
-    while (a < z) { const uint64_t m = a + ((z - a) >> 1); if (ix.mk_start[m] <= hi) a = m + 1; else z = m; }
-    *last = a;
-}
+// (the marker query -- MarkerArray::at_range as {src, cnt} -- is rbg_device.hpp marker_query: bucket records, or the directory + run arrays)
 
 // the step that consumes the longest k-mer of at most `cap` symbols (all of them k-mer symbols) ending at byte p:
 // adv = its length, (d, rec) = depth index and record of its table.  adv == 1: the single symbol's table, or
@@ -222,10 +199,8 @@ __global__ __launch_bounds__(512, 4) void k_find_range_markers_runs(const DevInd
         ByteCursor rd{reinterpret_cast<const uint4 *>(seqs), ~uint64_t(0), make_uint4(0, 0, 0, 0)};
         auto query = [&]() {                           // :318,:331
             if (hi - lo + 1 > max_range) return;
-            uint64_t f, l;
-            marker_span_r(ix, lo, hi, &f, &l);
-            if (l <= f) return;
-            const uint64_t src = ix.mk_off[f], cnt = ix.mk_off[l] - src;
+            uint64_t src, cnt;
+            if (!marker_query(ix, lo, hi, &src, &cnt)) return;
             acc += cnt;
             if (FILL) {
                 uint64_t *d = dst + (want - acc);
@@ -441,12 +416,10 @@ __global__ __launch_bounds__(512, STATS ? 2 : 3) void k_marker_seeds_runs(const 
         bool lover = LOG && (m >> 32) != 0;
         auto update_mbuf = [&](uint64_t l, uint64_t h) {  // :437-441
             if (!have_ma || h - l + 1 > max_range) return;
-            uint64_t f, e;
+            uint64_t src, cnt;
             if (STATS) st[kSdMarkerQueries] += 1;
-            marker_span_r(ix, l, h, &f, &e, STATS ? st : nullptr);
-            if (e <= f) return;
-            const uint64_t src = ix.mk_off[f], cnt = ix.mk_off[e] - src;
-            if (STATS) { st[kSdMarkerOff] += 2; if (FILL) st[kSdMarkerVals] += cnt; }
+            if (!marker_query(ix, l, h, &src, &cnt, STATS ? st : nullptr)) return;
+            if (STATS && FILL) st[kSdMarkerVals] += cnt;
             if (FILL) {
                 uint64_t *d = mk + mbase + tot;
                 for (uint64_t t = 0; t < cnt; ++t) d[t] = ix.mk_vals[src + t];
@@ -587,10 +560,8 @@ __global__ __launch_bounds__(512, 3) void k_marker_seeds_ftab_runs2(const DevInd
         ByteCursor rd{reinterpret_cast<const uint4 *>(seqs), ~uint64_t(0), make_uint4(0, 0, 0, 0)};
         auto update_mbuf = [&](uint64_t l, uint64_t h) {  // :437-441
             if (!have_ma || h - l + 1 > max_range) return;
-            uint64_t f, e;
-            marker_span_r(ix, l, h, &f, &e);
-            if (e <= f) return;
-            const uint64_t src = ix.mk_off[f], cnt = ix.mk_off[e] - src;
+            uint64_t src, cnt;
+            if (!marker_query(ix, l, h, &src, &cnt)) return;
             if (FILL) {
                 uint64_t *d = mk + mbase + tot;
                 for (uint64_t t = 0; t < cnt; ++t) d[t] = ix.mk_vals[src + t];

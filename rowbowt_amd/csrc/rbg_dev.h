@@ -224,6 +224,23 @@ constexpr int kMaxRunDepth = 8;
 constexpr int kLdsRunDepth = 5;
 constexpr int kMaxLdsRunTabs = kLdsSyms + 16 + 64 + 256 + 1024 + kLdsRunDepth;  // records staged in LDS by k_find_range_runs
 
+// One 32-byte record per bucket of the marker directory (round 6): at_range(lo, hi) -- MarkerArray::at_range as rowbowt.hpp:272-290 / :437-441 call it -- from the
+// records of the buckets of lo and hi, ONE or two sectors, instead of a directory entry, the run ends, the run starts and the value offsets (4.9 sectors per query,
+// a third of the marker seeds' misses: profiles/r06_pmc_markers.txt).  `a` = the first run whose end is >= the bucket's first row (what mk_bucket holds), its value
+// offset, and EVERY run from `a` on that starts before the bucket's end, as {start, end} relative to the bucket's first row (start clamped to 0 from below, end to
+// 0xFFFF from above) and its number of values.  Runs are disjoint and ascending, so for lo in this bucket the first run with end >= lo is a + #{listed: end < lo},
+// and for hi in this bucket one past the last run with start <= hi is a + #{listed: start <= hi}; the value offsets follow from off_a and the listed counts.
+// nin == kMkRecOverflow: more than kMkRecRuns such runs, or a run with more than 65535 values: the arrays answer (from `a`, as before).
+constexpr uint32_t kMkRecRuns = 3, kMkRecOverflow = 0xFF;
+struct MkRec {
+    uint32_t a;
+    uint32_t off_lo;
+    uint8_t off_hi, nin;
+    uint16_t s_off[kMkRecRuns], e_off[kMkRecRuns], cnt[kMkRecRuns];
+    uint16_t pad[2];
+};
+static_assert(sizeof(MkRec) == 32, "two marker records per 64-byte sector");
+
 struct DevIndex {
     uint64_t n, r;
     uint64_t last_run_sample;
@@ -243,6 +260,7 @@ struct DevIndex {
     // >= b << mk_shift (mk_nruns if none); (n >> mk_shift) + 2 entries; nullptr = binary search only
     const uint32_t *mk_bucket;
     uint32_t mk_shift;
+    const MkRec *mk_rec;     // the same buckets as 32-byte records (nullptr: RBG_MK_REC=0, or buckets wider than 2^16 rows)
     // {reads, matched, sum occ, sum locs}
     unsigned long long *counters;
     const uint8_t *lut;  // 256 bytes, device memory
@@ -349,9 +367,9 @@ struct SeedLog {
 // eight sums of SearchStat with that layout's meanings (rbg_runs2_device.hpp), then the marker side.
 enum SeedStat {
     kSdMarkerQueries = kStatSearchN,   // window queries that went to the marker runs (range <= max_range)
-    kSdMarkerDir,                      // directory entries read for them (4 bytes each)
-    kSdMarkerProbes,                   // mk_end / mk_start entries read (8 bytes each)
-    kSdMarkerOff,                      // mk_off entries read (8 bytes each)
+    kSdMarkerDir,                      // bucket records read for them (32 bytes each; directory entries of 4 bytes with RBG_MK_REC=0)
+    kSdMarkerProbes,                   // mk_end / mk_start entries read (8 bytes each): behind an overflowing record only
+    kSdMarkerOff,                      // mk_off entries read (8 bytes each): likewise
     kSdMarkerVals,                     // marker values copied (8 read + 8 written)
     kSdSeedRecs,                       // seed records written (48 bytes each)
     kSdSequences,                      // sequences walked

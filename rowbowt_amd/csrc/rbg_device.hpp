@@ -231,6 +231,76 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
     return v;
 }
 
+// ---- the marker query: MarkerArray::at_range(lo, hi) (rowbowt.hpp:272-290, :318, :437-441) as {src, cnt}: the values mk_vals[src, src + cnt) of all runs with
+// start <= hi && end >= lo, in run order.  Runs are disjoint, ascending inclusive SA-index intervals.  From the bucket records (rbg_dev.h MkRec: one or two
+// sectors), else from the directory + the run arrays.  st (instrumented seed walks): [kStatSearchN + 1] += records / directory entries read, [+ 2] += run starts /
+// ends read, [+ 3] += value offsets read.
+__device__ __forceinline__ void marker_span_arrays(const DevIndex &ix, uint64_t lo, uint64_t hi, uint64_t a, uint64_t z, uint64_t *first, uint64_t *last, unsigned long long *st) {
+    while (a < ix.mk_nruns && ix.mk_end[a] < lo) { ++a; if (st) st[kStatSearchN + 2] += 1; }
+    *first = a;
+    if (z < a) z = a;
+    while (z < ix.mk_nruns && ix.mk_start[z] <= hi) { ++z; if (st) st[kStatSearchN + 2] += 1; }
+    *last = z;
+    if (st) st[kStatSearchN + 2] += 2;
+}
+__device__ __forceinline__ bool marker_query(const DevIndex &ix, uint64_t lo, uint64_t hi, uint64_t *src, uint64_t *cnt, unsigned long long *st = nullptr) {
+    if (lo >= ix.n) return false;          // caller-supplied rows beyond the BWT: nothing
+    if (hi >= ix.n) hi = ix.n - 1;
+    uint64_t f, l;
+    if (ix.mk_rec) {
+        const uint32_t sh = ix.mk_shift;
+        const uint64_t b0 = lo >> sh, b1 = hi >> sh;
+        const u32x4 *r0p = reinterpret_cast<const u32x4 *>(ix.mk_rec + b0), *r1p = reinterpret_cast<const u32x4 *>(ix.mk_rec + b1);
+        MkRec R0, R1;
+        const u32x4 x0 = as_global<u32x4>(static_cast<const void *>(r0p))[0], x1 = as_global<u32x4>(static_cast<const void *>(r0p))[1];
+        __builtin_memcpy(&R0, &x0, 16); __builtin_memcpy(reinterpret_cast<char *>(&R0) + 16, &x1, 16);
+        if (b1 != b0) {
+            const u32x4 y0 = as_global<u32x4>(static_cast<const void *>(r1p))[0], y1 = as_global<u32x4>(static_cast<const void *>(r1p))[1];
+            __builtin_memcpy(&R1, &y0, 16); __builtin_memcpy(reinterpret_cast<char *>(&R1) + 16, &y1, 16);
+        } else {
+            R1 = R0;
+        }
+        if (st) st[kStatSearchN + 1] += b1 != b0 ? 2 : 1;
+        if (R0.nin != kMkRecOverflow && R1.nin != kMkRecOverflow) {
+            const uint32_t lo_rel = static_cast<uint32_t>(lo - (b0 << sh)), hi_rel = static_cast<uint32_t>(hi - (b1 << sh));
+            uint64_t off_f = static_cast<uint64_t>(R0.off_lo) | (static_cast<uint64_t>(R0.off_hi) << 32);
+            uint64_t off_l = static_cast<uint64_t>(R1.off_lo) | (static_cast<uint64_t>(R1.off_hi) << 32);
+            uint32_t nf = 0, nl = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < kMkRecRuns; ++j) {
+                const bool bf = j < R0.nin && R0.e_off[j] < lo_rel;      // (ends ascend: a prefix of the listed runs)
+                const bool bl = j < R1.nin && R1.s_off[j] <= hi_rel;     // (starts ascend)
+                nf += bf ? 1u : 0u; off_f += bf ? R0.cnt[j] : 0u;
+                nl += bl ? 1u : 0u; off_l += bl ? R1.cnt[j] : 0u;
+            }
+            f = static_cast<uint64_t>(R0.a) + nf;
+            l = static_cast<uint64_t>(R1.a) + nl;
+            if (l <= f) return false;
+            *src = off_f;
+            *cnt = off_l - off_f;
+            return true;
+        }
+        marker_span_arrays(ix, lo, hi, R0.a, R1.a, &f, &l, st);   // an overflowing bucket: the arrays, from the records' first runs
+    } else if (ix.mk_bucket) {
+        // first run with end >= lo: the directory gives the first run ending at or after the start of lo's bucket, the answer is at most a bucket's worth of runs
+        // further on; one past the last run with start <= hi: every run before the entry of hi's bucket ends, hence starts, before hi
+        if (st) st[kStatSearchN + 1] += 2;
+        marker_span_arrays(ix, lo, hi, ix.mk_bucket[lo >> ix.mk_shift], ix.mk_bucket[hi >> ix.mk_shift], &f, &l, st);
+    } else {
+        uint64_t a = 0, z = ix.mk_nruns;
+        while (a < z) { const uint64_t m = a + ((z - a) >> 1); if (ix.mk_end[m] < lo) a = m + 1; else z = m; }
+        f = a;   // first run with end >= lo
+        a = 0; z = ix.mk_nruns;
+        while (a < z) { const uint64_t m = a + ((z - a) >> 1); if (ix.mk_start[m] <= hi) a = m + 1; else z = m; }
+        l = a;   // one past the last run with start <= hi
+    }
+    if (l <= f) return false;
+    if (st) st[kStatSearchN + 3] += 2;
+    *src = ix.mk_off[f];
+    *cnt = ix.mk_off[l] - *src;
+    return true;
+}
+
 // ---- K1 / K2 ------------------------------------------------------------------------------------
 // per-lane cursor over the read bytes, fetched as aligned 16-byte chunks while walking right to left
 struct ByteCursor {

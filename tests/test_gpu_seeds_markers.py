@@ -50,6 +50,62 @@ def test_synth_markers(synth):
     o.close()
 
 
+@pytest.mark.parametrize("shape", ["sparse", "crowded", "wide", "mixed"])
+def test_marker_bucket_records_against_the_arrays(synth, shape, monkeypatch):
+    """The marker directory's 32-byte bucket records (round 6; rbg_dev.h MkRec, rbg_device.hpp marker_query): MarkerArray::at_range(lo, hi) as rb_align -m and the
+    marker seeds ask it (rowbowt.hpp:272-290, :437-441) answered from the records of the buckets of lo and hi.  Against plain arithmetic on the arrays (the values of
+    every run with start <= hi && end >= lo, in run order) and against the library with RBG_MK_REC=0, on marker arrays the fixtures do not have: one-row runs packed so
+    that buckets overflow their three listed runs, runs wider than many buckets, runs of up to nine values, ranges that start or end beyond the BWT."""
+    S = synth
+    rng = np.random.default_rng({"sparse": 1, "crowded": 2, "wide": 3, "mixed": 4}[shape])
+    n = S.n
+    if shape == "sparse":
+        starts = np.sort(rng.choice(n - 4, size=300, replace=False))
+        starts = starts[np.concatenate([[True], np.diff(starts) > 3])]
+        ends = starts + rng.integers(0, 3, size=len(starts))
+    elif shape == "crowded":      # four of five rows start a one-row run: every bucket overflows
+        rows = np.arange(0, n - 1)
+        starts = rows[rows % 5 != 4]
+        ends = starts.copy()
+    elif shape == "wide":         # a few runs hundreds of rows wide
+        cuts = np.sort(rng.choice(n - 2, size=60, replace=False))
+        starts, ends = cuts[0::2][:29], cuts[1::2][:29] - 1
+        keep = ends >= starts
+        starts, ends = starts[keep], ends[keep]
+    else:
+        parts, pos = [], 0
+        while pos < n - 50:
+            w = int(rng.choice([0, 0, 1, 2, 40, 700]))
+            parts.append((pos, min(pos + w, n - 1)))
+            pos += w + int(rng.choice([1, 1, 2, 9, 300]))
+        starts, ends = np.array([a for a, _ in parts]), np.array([b for _, b in parts])
+    assert (starts[1:] > ends[:-1]).all() and int(ends[-1]) < n
+    per = rng.integers(1, 10 if shape != "crowded" else 3, size=len(starts))
+    off = np.concatenate([[0], np.cumsum(per)]).astype(np.uint64)
+    vals = (rng.integers(0, 1 << 40, size=int(off[-1]), dtype=np.uint64) | (rng.integers(0, 3, size=int(off[-1])).astype(np.uint64) << np.uint64(60)))
+    starts, ends = starts.astype(np.uint64), ends.astype(np.uint64)
+    lo = rng.integers(0, n, size=6000).astype(np.uint64)
+    width = rng.choice([0, 0, 1, 5, 60, 1500], size=6000).astype(np.uint64)
+    hi = np.minimum(lo + width, np.uint64(n + 40))           # (some ranges end beyond the BWT)
+    lo[:20] = n + 3                                           # (and some start there: nothing)
+    hi[:20] = n + 9
+    got = {}
+    for rec in ("1", "0"):
+        monkeypatch.setenv("RBG_MK_REC", rec)
+        with capi.default_option(capi.OPT_RANK_LAYOUT, capi.LAYOUT_RUNS):
+            rb = ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0)
+        rb.set_markers(starts, ends, off, vals)
+        got[rec] = rb.markers_at(lo, hi)
+        rb.close()
+    assert (got["1"][0] == got["0"][0]).all() and (got["1"][1] == got["0"][1]).all()
+    m_off, m = got["1"]
+    for i in range(len(lo)):
+        f, l = np.searchsorted(ends, lo[i], side="left"), np.searchsorted(starts, hi[i], side="right")
+        want = vals[int(off[f]):int(off[l])] if l > f else vals[:0]
+        assert (m[int(m_off[i]):int(m_off[i + 1])] == want).all(), (shape, i, int(lo[i]), int(hi[i]))
+    assert int(m_off[-1]) > 1000
+
+
 def test_marker_seeds_small(small, simple_reads, error_reads):
     """get_markers_greedy_seeding (rowbowt.hpp:406-482, no ftab) on the reference's fixture"""
     rb, o = small
