@@ -1399,7 +1399,11 @@ def pangenome_shape_block(args, dev):
     free_now, _t = torch.cuda.mem_get_info(dev)
     env_pg = {k: v for k, v in os.environ.items() if not k.startswith("RBG_")}
     t0 = time.time()
-    pg = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pangenome_stream.py"), "--preset", "driver"], capture_output=True, text=True, env=env_pg, cwd=ROOT)
+    try:
+        pg = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pangenome_stream.py"), "--preset", "driver"], capture_output=True, text=True, env=env_pg, cwd=ROOT,
+                            timeout=900)
+    except subprocess.TimeoutExpired as e:
+        return {"seconds_for_the_block": time.time() - t0, "hbm_free_when_started": int(free_now), "error": f"the child did not finish within 900 s: {e}", "fatal": False}
     blk = {"seconds_for_the_block": time.time() - t0, "hbm_free_when_started": int(free_now),
            "command": "python tools/pangenome_stream.py --preset driver   (a child process: a default rbg_load in a fresh process)"}
     try:
@@ -1412,6 +1416,12 @@ def pangenome_shape_block(args, dev):
         blk["error"] = f"{type(e).__name__}: {e}; rc {pg.returncode}; stderr tail: {pg.stderr[-1500:]}"
     if pg.returncode != 0 and "error" not in blk:
         blk["error"] = f"rc {pg.returncode}; stderr tail: {pg.stderr[-1500:]}"
+    # a WRONG answer of the child is fatal to the whole line (its own exit says PARITY / PROPERTY / REPLICA FAILURE or a counter mismatch); a child that could not run
+    # (no memory left on a shared device, a timeout) is reported in the block and on stderr and leaves the headline line standing
+    if "error" in blk:
+        wrong = any(w in (pg.stderr or "") for w in ("PARITY FAILURE", "PROPERTY FAILURE", "counter mismatch")) or \
+            (blk.get("parity") is not None and not blk["parity"].get("bit_exact_vs_oracle", True))
+        blk["fatal"] = bool(wrong)
     return blk
 
 
@@ -1426,8 +1436,10 @@ def main():
         stage("pangenome_shape block (child process)")
         out["pangenome_shape"] = pangenome_shape_block(args, c["dev"])
         if "error" in out["pangenome_shape"]:
-            print(json.dumps(out))
-            raise SystemExit("pangenome_shape block failed: " + out["pangenome_shape"]["error"])
+            print("[bench] pangenome_shape block failed: " + out["pangenome_shape"]["error"], file=sys.stderr, flush=True)
+            if out["pangenome_shape"].get("fatal"):
+                print(json.dumps(out))
+                raise SystemExit("pangenome_shape block: WRONG ANSWERS from the child (see stderr)")
     if rank == 0:
         print(json.dumps(out), flush=True)
     if use_dist:
