@@ -13,7 +13,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DEFAULT = ["profiles/r06_bench.json", "profiles/r06_bench.json#pangenome_shape", "profiles/r06_pangenome_stream_n5e10_default.json",
-           "profiles/r06_pangenome_stream_r1e9_default_locus.json"]
+           "profiles/r06_pangenome_stream_r1e9_default.json"]
 
 
 def load(path):
