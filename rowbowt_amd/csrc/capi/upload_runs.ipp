@@ -538,8 +538,13 @@ int upload_markers(rbg_index *ix) {
         ix->dev.mk_bucket = static_cast<const uint32_t *>(p);
         ix->dev.mk_shift = shift;
         // the bucket records (rbg_dev.h MkRec): 32 bytes per bucket, i.e. about 64 per run.  RBG_MK_REC=0: the arrays only (A/B, tests)
+        // (32 bytes per bucket = about 64 per marker run: only while that is a small part of the device -- at most an eighth of the free HBM and 16 GB; a marker array
+        //  of 1e9 runs keeps the 4-byte directory)
         const char *e = std::getenv("RBG_MK_REC");
-        if (shift <= 16 && !(e && e[0] == '0') && (m.vals.size() >> 40) == 0) {
+        size_t free_b = 0, total_b = 0;
+        (void)hipMemGetInfo(&free_b, &total_b);
+        const bool rec_fits = nb * sizeof(MkRec) <= std::min<size_t>(free_b / 8, size_t(16) << 30);
+        if (shift <= 16 && !(e && e[0] == '0') && (m.vals.size() >> 40) == 0 && rec_fits) {
             std::vector<MkRec> recs(nb);
             for (uint64_t b = 0; b < nb; ++b) {
                 MkRec &R = recs[b];
