@@ -307,6 +307,10 @@ int rbg_release_text(rbg_index *, const char *text);
 /* make `count` pinned text buffers of `bytes` now (pinning a few hundred MB takes tenths of a second: a tool does it before its clock starts) */
 int rbg_reserve_text(rbg_index *, uint64_t bytes, int count);
 /* ---- queries, device-resident buffers (HBM in, HBM out; asynchronous on `stream`) ---------- */
+/* d_seqs: the reads back to back as in the host calls, in device memory, 16-BYTE ALIGNED (RBG_EARG otherwise), and the allocation must reach the next
+ * multiple of 16 bytes at or past its last read's end: the kernels fetch reads as aligned 16-byte chunks (the bytes beyond a read's end are never used).
+ * d_off[N + 1]: byte offsets.  Same answers as the host calls (find_range rowbowt.hpp:121-131, find_range_w_toehold :169-184); nothing is allocated, nothing
+ * synchronised: graph-capturable. */
 
 int rbg_find_range_dev(rbg_index *, const uint8_t *d_seqs, const uint64_t *d_off, uint64_t N,
                        uint64_t *d_lo, uint64_t *d_hi, void *stream);
