@@ -125,6 +125,78 @@ def stage(name):
         print(f"[bench] rank {STAGE['rank']} +{time.time() - STAGE['t0']:.1f}s: {name}", file=sys.stderr, flush=True)
 
 
+class DeviceClocks:
+    """The GPU's clocks, power and temperature while the timed steps run, sampled from sysfs by a thread (the amdgpu driver's pp_dpm_* / hwmon files of the
+    card whose PCI address is the torch device's; a few reads every 5 ms, no GPU call) -- so that a bench line says under which clocks its kernel times were taken
+    (K3 differs by 0.2-0.5 ms between boxes on the same code).  Everything is best effort: where the files are missing the block is None."""
+
+    def __init__(self, torch, dev):
+        import glob
+        import threading
+        self.dir, self.hwmon, self.samples, self._stop, self._th = None, None, [], threading.Event(), None
+        try:
+            pr = torch.cuda.get_device_properties(dev)
+            want = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}"
+            for c in glob.glob("/sys/class/drm/card*/device"):
+                if want in os.path.realpath(c).lower() and os.path.exists(os.path.join(c, "pp_dpm_sclk")):
+                    self.dir = c
+                    hw = glob.glob(os.path.join(c, "hwmon", "hwmon*"))
+                    self.hwmon = hw[0] if hw else None
+                    break
+        except Exception:
+            self.dir = None
+
+    @staticmethod
+    def _cur_mhz(path):
+        try:
+            for ln in open(path):
+                if "*" in ln:
+                    return float(ln.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+        except Exception:
+            pass
+        return None
+
+    @staticmethod
+    def _num(path, scale):
+        try:
+            return float(open(path).read().strip()) * scale
+        except Exception:
+            return None
+
+    def _sample(self):
+        d = {k: self._cur_mhz(os.path.join(self.dir, f"pp_dpm_{k}")) for k in ("sclk", "mclk", "fclk")}
+        if self.hwmon:
+            d["power_w"] = self._num(os.path.join(self.hwmon, "power1_input"), 1e-6)
+            d["temp_c"] = self._num(os.path.join(self.hwmon, "temp2_input"), 1e-3)
+        return d
+
+    def start(self):
+        if not self.dir:
+            return
+        import threading
+
+        def loop():
+            while not self._stop.is_set():
+                self.samples.append(self._sample())
+                self._stop.wait(0.005)
+        self._th = threading.Thread(target=loop, daemon=True)
+        self._th.start()
+
+    def stop(self):
+        if not self._th:
+            return None
+        self._stop.set()
+        self._th.join(timeout=2)
+        out = {"samples": len(self.samples), "source": self.dir + "/pp_dpm_{sclk,mclk,fclk} (+ hwmon power1_input, temp2_input), every 5 ms over the timed steps"}
+        if self.hwmon:
+            out["power_cap_w"] = self._num(os.path.join(self.hwmon, "power1_cap"), 1e-6)
+        for k in ("sclk", "mclk", "fclk", "power_w", "temp_c"):
+            v = sorted(x[k] for x in self.samples if x.get(k) is not None)
+            if v:
+                out[k if k.endswith(("_w", "_c")) else k + "_mhz"] = {"min": v[0], "median": v[len(v) // 2], "max": v[-1]}
+        return out
+
+
 def cpu_budget():
     """CPUs this process may use: the smaller of the visible ones and the container's CPU quota (cgroup v2 cpu.max)"""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -358,7 +430,10 @@ def run():
         ev[s][3].record(stream)
 
     rb.counters_reset()
+    clocks = DeviceClocks(torch, dev)
+    clocks.start()
     el = timed(step_ev, K, events=True)
+    device_state = clocks.stop()
     counters = rb.counters().astype(np.int64)
     ms_toe = float(np.mean([ev[s][0].elapsed_time(ev[s][1]) for s in range(K)]))
     ms_plan = float(np.mean([ev[s][1].elapsed_time(ev[s][2]) for s in range(K)]))
@@ -809,6 +884,7 @@ def run():
             "counters": {"reads": g_counters[0], "matched": g_counters[1], "sum_occ": g_counters[2], "sum_locs": g_counters[3],
                          "reduced_over": (f"{'gloo (rehearsal)' if args.rehearse_ranks else 'RCCL'} all_reduce over {world} rank(s)" if use_dist else "single GPU (no process group)")},
             # the multi-GPU run's post-mortem block: who ran where, how long each rank loaded / waited / stepped, what the one-per-node cache cost
+            "device_state_during_the_timed_steps": device_state,
             "per_rank": per_rank,
             "rccl_ranks_seen": ranks_seen,
             "collective_backend": ("gloo (rehearsal)" if args.rehearse_ranks else "nccl (RCCL)") if use_dist else None,
