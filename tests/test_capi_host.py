@@ -518,3 +518,25 @@ def test_no_run_indexed_kernel_spills_and_no_kernel_shifts_by_its_last_vgpr():
     # the checker itself: a kernel of 72 VGPRs shifting by v71 is flagged, one shifting by v70 or with 73 VGPRs is not
     assert check_isa.hazards([("k", 72, 0, [71, 3])]) == [("k", 72, 1)] and not check_isa.hazards([("k", 72, 0, [70]), ("k", 73, 0, [71])])
     assert check_isa.hazards([("k", 70, 0, [71])]) == [("k", 70, 1)]   # (allocated in granules of eight: 70 -> 72)
+
+
+def test_info_sized_and_layout_info_sizes(small_host):
+    """rbg_info writes sizeof(rbg_info_t) of the header it was built with, so a caller built against another layout of the struct uses rbg_info_sized
+    (fills at most out_bytes); rbg_layout_info refuses a size that is neither this ABI's nor a documented prefix of it (an ABI-2 caller would get shifted fields)."""
+    import ctypes as C
+    L = ra.lib()
+    full = capi.Info()
+    assert L.rbg_info(small_host.h, C.byref(full)) == 0
+    # a smaller struct (an older client): only its bytes are written
+    buf = (C.c_uint8 * (C.sizeof(capi.Info) + 16))(*([0xAB] * (C.sizeof(capi.Info) + 16)))
+    part = 64
+    assert L.rbg_info_sized(small_host.h, C.cast(buf, C.POINTER(capi.Info)), part) == 0
+    assert bytes(buf[:part]) == bytes(C.string_at(C.byref(full), part)) and all(b == 0xAB for b in buf[part:part + 32])
+    assert L.rbg_info_sized(small_host.h, C.cast(buf, C.POINTER(capi.Info)), C.sizeof(capi.Info) + 16) == 0      # a larger one: sizeof(rbg_info_t) bytes, no more
+    assert bytes(buf[:C.sizeof(capi.Info)]) == bytes(C.string_at(C.byref(full), C.sizeof(capi.Info))) and all(b == 0xAB for b in buf[C.sizeof(capi.Info):])
+    assert L.rbg_info_sized(small_host.h, C.cast(buf, C.POINTER(capi.Info)), 4) != 0
+    li = capi.LayoutInfo()
+    assert L.rbg_layout_info(small_host.h, C.byref(li), C.sizeof(li)) == 0
+    assert L.rbg_layout_info(small_host.h, C.byref(li), C.sizeof(li) - 8) == 0            # the struct before its last field: a prefix at a field boundary
+    abi2 = 8 * 4 + 3 * 5 * 8 + 6 * 8 + 2 * 5 * 8      # ABI 2: five-entry arrays
+    assert L.rbg_layout_info(small_host.h, C.byref(li), abi2) != 0
