@@ -493,3 +493,67 @@ def test_run_indexed_layout_budget_leaves_middle_depths_out():
         assert (got[0] == want[0]).all() and (got[1] == want[1]).all()
         b.close()
     full.close()
+
+
+@pytest.mark.parametrize("pos_bytes", [4, 8])
+def test_staged_read_walk_at_its_boundaries(synth, pos_bytes):
+    """The run-indexed search stages a wave's reads as 2-bit codes in LDS (round 6: k_runs.hip STAGE, rbg_runs_device.hpp stage_read) -- unless a read of the wave is
+    longer than 256 symbols or holds a symbol outside the k-mer alphabet, then the wave walks bytes.  Both walks, and waves that mix them, against the oracle
+    (find_range / find_range_w_toehold, rowbowt.hpp:121-131, :169-184): read lengths around the 16-symbol code words and the 256-symbol cap, reads that start at every
+    byte alignment, an N / a lower-case base / a NUL at the first, a middle and the last position, whole batches of long reads, and one long read among 63 short ones."""
+    S = synth
+    rng = np.random.default_rng(17)
+    with capi.default_option(capi.OPT_RANK_LAYOUT, capi.LAYOUT_RUNS), capi.default_option(capi.OPT_POS_BYTES, pos_bytes):
+        rb = ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0)
+    o = orc.Oracle.from_runs(S.heads, S.lens, S.ssa, S.esa)
+    unit = S.L + S.pad
+
+    def piece(m):
+        h = int(rng.integers(S.H))
+        s0 = h * unit + int(rng.integers(0, S.L - m + 1))
+        return bytearray(S.text[s0:s0 + m].tobytes())
+    reads = []
+    for m in (1, 2, 11, 12, 13, 15, 16, 17, 31, 32, 33, 63, 64, 65, 100, 150, 254, 255, 256, 257, 258, 300, 513):
+        for _ in range(40):
+            reads.append(bytes(piece(m)))                       # (consecutive reads of odd lengths: every start alignment modulo 16)
+    for m in (20, 100, 256):                                    # symbols outside the alphabet at the ends and inside
+        for where in (0, m // 2, m - 1):
+            for bad in (ord("N"), ord("a"), 0, 0xC1):
+                r = piece(m)
+                r[where] = bad
+                reads.append(bytes(r))
+    for _ in range(3):                                          # a wave of 63 short reads and one long one; a wave with one non-ACGT read
+        reads += [bytes(piece(100)) for _ in range(63)] + [bytes(piece(400))]
+        w = [piece(100) for _ in range(64)]
+        w[int(rng.integers(64))][50] = ord("N")
+        reads += [bytes(x) for x in w]
+    reads += [bytes(piece(300)) for _ in range(128)]            # whole waves of long reads
+    reads += [b"", b"A", b"N"]
+    seqs, off = ra.pack_reads(reads)
+    wlo, whi, wk = o.find_range_w_toehold_batch(seqs, off, nthreads=4)
+    lo, hi, k = rb.find_range_w_toehold(seqs, off)
+    assert (lo == wlo).all() and (hi == whi).all() and (k == wk).all()
+    clo, chi = rb.find_range(seqs, off)
+    assert (clo == wlo).all() and (chi == whi).all()
+    # the device entry points on a resident batch (what bench.py times): the same, with the instrumented instantiation counting one chunk fetch per 16 bytes of a staged read
+    import torch
+    dev = torch.device("cuda:0")
+    d_seqs = torch.from_numpy(np.concatenate([seqs, np.zeros((-len(seqs)) % 16 + 16, np.uint8)])).to(dev)
+    d_off = torch.from_numpy(off.view(np.int64)).to(dev)
+    N = len(reads)
+    d_lo, d_hi, d_k = (torch.empty(N, dtype=torch.int64, device=dev) for _ in range(3))
+    d_stats = torch.zeros(16, dtype=torch.int64, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    L = ra.lib()
+    assert L.rbg_find_range_w_toehold_dev(rb.h, d_seqs.data_ptr(), d_off.data_ptr(), N, d_lo.data_ptr(), d_hi.data_ptr(), d_k.data_ptr(), st) == 0
+    torch.cuda.synchronize()
+    assert (d_lo.cpu().numpy().view(np.uint64) == wlo).all() and (d_hi.cpu().numpy().view(np.uint64) == whi).all() and (d_k.cpu().numpy().view(np.uint64) == wk).all()
+    assert L.rbg_find_range_stats_dev(rb.h, d_seqs.data_ptr(), d_off.data_ptr(), N, d_lo.data_ptr(), d_hi.data_ptr(), d_k.data_ptr(), d_stats.data_ptr(), st) == 0
+    torch.cuda.synchronize()
+    assert (d_lo.cpu().numpy().view(np.uint64) == wlo).all() and (d_k.cpu().numpy().view(np.uint64) == wk).all()
+    chunks = int(d_stats[6].item())
+    total = int(off[-1])
+    assert total // 16 <= chunks <= total // 16 + 2 * N            # every byte fetched about once (a chunk per 16 bytes + the ends), staged or not
+    assert int((whi >= wlo).sum()) > 800
+    rb.close()
+    o.close()
