@@ -276,3 +276,47 @@ def test_greedy_seeding_vs_oracle(synth, ksteps):
             assert nseeds > 3000
     rb.close()
     o.close()
+
+
+def test_seed_walks_with_staged_and_unstaged_reads(synth):
+    """The seeding kernels of the run-indexed layout stage their waves' reads as 2-bit codes in LDS like K2 (round 6); a wave with a read longer than 256 symbols or
+    with a symbol outside the k-mer alphabet walks bytes.  Greedy seeds (get_seeds_greedy_w_sample reduced by locate_from_longest_seed, rowbowt.hpp:222-256, :669-677)
+    and marker seeds (get_markers_greedy_seeding, :406-482) against the oracle on batches that mix both kinds wave by wave and inside a wave."""
+    S = synth
+    rng = np.random.default_rng(23)
+    with capi.default_option(capi.OPT_RANK_LAYOUT, capi.LAYOUT_RUNS):
+        rb = ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0)
+    rb.set_markers(*S.markers(10))
+    o = orc.Oracle.from_runs(S.heads, S.lens, S.ssa, S.esa)
+    o.set_markers(*S.markers(10))
+    unit = S.L + S.pad
+
+    def piece(m, nsub):
+        h = int(rng.integers(S.H))
+        s0 = h * unit + int(rng.integers(0, S.L - m + 1))
+        r = bytearray(S.text[s0:s0 + m].tobytes())
+        for _ in range(nsub):
+            q = int(rng.integers(m))
+            r[q] = int(rng.choice([c for c in b"ACGT" if c != r[q]]))
+        return r
+    reads = []
+    for _ in range(2):
+        reads += [bytes(piece(100, int(rng.integers(0, 3)))) for _ in range(64)]                 # a staged wave
+        reads += [bytes(piece(300, int(rng.integers(0, 4)))) for _ in range(64)]                 # a wave of long reads: bytes
+        w = [piece(int(rng.choice([40, 100, 256])), int(rng.integers(0, 3))) for _ in range(64)]   # a staged wave but for one N
+        w[int(rng.integers(64))][7] = ord("N")
+        reads += [bytes(x) for x in w]
+        w = [piece(100, 1) for _ in range(63)] + [piece(257, 2)]                                  # 63 short reads and one just over the cap
+        reads += [bytes(x) for x in w]
+    reads += [b"", b"A", b"N", bytes(piece(256, 0)), bytes(piece(19, 0)), bytes(piece(20, 1))]
+    nseed, nmk = _check_marker_seeds(rb, o, reads, 19, 1000)
+    assert nseed >= len(reads) and nmk > 100
+    nseed10, _ = _check_marker_seeds(rb, o, reads[:200], 10, 1000)
+    assert nseed10 >= 200
+    seqs, off = ra.pack_reads(reads)
+    loc_off, locs = rb.find_locs_greedy_seeding(seqs, off, 20)
+    got = split(loc_off, locs)
+    for i, q in enumerate(reads):
+        assert got[i] == o.greedy_locate(q, 20)[0], (i, len(q))
+    rb.close()
+    o.close()
