@@ -6,18 +6,7 @@
 namespace rbg {
 namespace {
 
-// ---- K3: locate ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_occ(const uint64_t *__restrict__ lo, const uint64_t *__restrict__ hi,
-                                             const uint64_t N, const uint64_t max_hits, uint64_t *__restrict__ out) {
-    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
-    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < N; i += stride) {
-        uint64_t occ = hi[i] >= lo[i] ? hi[i] - lo[i] + 1 : 0;  // toehold_sa.hpp:38-39
-        if (occ > max_hits) occ = max_hits;
-        out[i + 1] = occ;
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) out[0] = 0;
-}
-
+// ---- K3: locate (the counts of the plan are computed where its scan reads them: OccOf below) ---------
 // ---- the locus order's sort key (rbg_dev.h order_docs): k <-> {offset >> low, document, offset & (2^low - 1)} -----------------------------
 // A toehold outside the text (it wrapped below zero: k >= n) has no document: its key is all ones and K3 reads the toehold itself.
 __device__ __forceinline__ uint64_t locus_key(const DevIndex &ix, const uint64_t k) {
@@ -115,57 +104,29 @@ __device__ __forceinline__ uint64_t phi_step(const DevIndex &ix, uint64_t i, boo
     return s;
 }
 
-// One lane walks one read's phi chain (toehold_sa.hpp:37-49); the chain is serial, the reads are
-// not.  The locations of a read are contiguous in `locs`, but a lane storing its own values would
-// make every store instruction touch 64 different lines, and stores are gather-class requests just
-// like the slot loads (tools/gather_roof.hip).  So values are staged per wave in LDS, kChunk steps
-// at a time, and flushed with kChunk lanes writing one read's (8 * kChunk)-byte segment: a store
-// instruction then touches a handful of lines instead of 64.  Measured per 10M reads: unordered
-// chains 10.5 / 8.6 / 7.6 ms at kChunk 8 / 16 / 32 (7.3 at 32 in a later build); with the chains in
-// toehold order (the default) 3.5 / 3.1 / 3.5 ms, hence 16 (staged as uint64: 39 KB of LDS per workgroup;
-// staged at the position width since: 24 KB at 4-byte positions, 3.1 -> 3.0 ms).
+// One lane walks one read's phi chain (toehold_sa.hpp:37-49); the chain is serial, the reads are not.  The values are staged per wave in LDS,
+// kChunk steps at a time, and flushed with kChunk lanes writing one read's segment (rbg_device.hpp ChainStage: what is staged, why, and what it
+// costs in LDS).  Measured per 10M reads: unordered chains 10.5 / 8.6 / 7.6 ms at kChunk 8 / 16 / 32; with the chains in toehold order (the
+// default) 3.5 / 3.1 / 3.5 ms, hence 16 at 4-byte positions; at 8-byte positions 8 (RBG_K3_CHUNK_U64: 16 costs half the workgroups their LDS).
 constexpr int kChunk = 16;
 #ifndef RBG_K3_CHUNK_U64
-#define RBG_K3_CHUNK_U64 8    // steps staged per flush at 8-byte positions: 3.67 / 3.17-3.35 / 3.43 ms per 10 M reads at 16 / 8 / 4
-                              // (bench index forced to 8-byte positions; 16 costs a third of the workgroups their LDS)
+#define RBG_K3_CHUNK_U64 8
 #endif
-
-__device__ __forceinline__ void wave_lds_sync() {
-    // LDS operations of one wave execute in issue order; this only stops the compiler from moving
-    // the cross-lane reads above the writes (and vice versa)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 // STATS = the instrumented instantiation (rbg_locate_fill_stats_dev): the same walk plus the LocateStat sums.
 // OUT = the width a location is stored at: uint64_t (the API's, toehold_sa.hpp:37-49 fills a vector<uint64_t>) or, for
 // device pipelines on an index with 4-byte positions, uint32_t (rbg_locate_fill_dev32: half the write requests; the low
 // 32 bits of the same values, so a toehold that wrapped below zero reads 0xFFFFFFFF).
-template <typename P, bool STATS = false, typename OUT = uint64_t, int CH = (sizeof(P) == 8 ? RBG_K3_CHUNK_U64 : kChunk)>
-__global__ __launch_bounds__(256) void k_locate_fill(const DevIndex ix, const uint64_t *__restrict__ lo,
-                                                     const uint64_t *__restrict__ hi, const uint64_t *__restrict__ k,
-                                                     const uint64_t N, const uint64_t max_hits,
-                                                     const uint64_t *__restrict__ loc_off, OUT *__restrict__ locs,
-                                                     const uint64_t *__restrict__ sub, const uint32_t *__restrict__ order,
-                                                     const uint64_t *__restrict__ skeys,
-                                                     unsigned long long *__restrict__ stats = nullptr, const uint32_t align_flush = 0) {
-    // staged at the position width: text positions fit P, and at 4 bytes the workgroup's LDS drops from
-    // 39 KB to 24 KB (6 instead of 4 waves per SIMD); the per-read offset is applied when flushing
-    __shared__ P s_val[4][kWave][CH + 1];  // +1: keeps the per-lane rows off the same banks
-    __shared__ uint64_t s_dst[4][kWave];
-    __shared__ uint64_t s_occ[4][kWave];
-    __shared__ uint64_t s_minus[4][kWave];
-    __shared__ uint64_t s_first[4][kWave];  // the toehold itself is not a text position when it wrapped (2^64 - 1)
-    // LINE-ALIGNED FLUSHES (round 6): a read's segment of CH values used to start wherever its locations start, so a flush of CH x 8 bytes
-    // straddled two lines and wrote both partially (39 GB written for 28 GB of locations at r = 1.07e9: profiles/r05_pmc_stream_r1e9.txt).  Now the
-    // chain is cut at multiples of CH elements of the OUTPUT ARRAY: a = (address of the read's first location / 8) mod CH, round c holds the
-    // elements v = t + a in [c CH, (c + 1) CH), so every flush but a read's first and last writes one whole aligned segment.  The price: a lane
-    // waits a columns before its first step, so a wave's longest chain grows by up to CH - 1 steps -- 17 % of the bench index's 41, which lost
-    // there in round 3 (profiles/r03_k3_align_ab.txt), and at pangenome scale in round 6 it put the lanes of a wave out of phase (profiles/
-    // r06_k3_align_ab.txt: 11.1 -> 14.9 ms): `align_flush` is OFF unless RBG_K3_ALIGN=1 asks for the A/B (launch_locate_fill).
-    __shared__ uint32_t s_a[4][kWave];
-    const uint64_t out_elem0 = reinterpret_cast<uintptr_t>(locs) / sizeof(OUT);
+// SUB = `sub` is subtracted from every location (locate_from_longest_seed, rowbowt.hpp:681-683).
+template <typename P, bool STATS = false, typename OUT = uint64_t, bool SUB = false, int CH = (sizeof(P) == 8 ? RBG_K3_CHUNK_U64 : kChunk)>
+__global__ __launch_bounds__(256, SUB ? 7 : 8) void k_locate_fill(const DevIndex ix, const uint64_t *__restrict__ lo,
+                                                        const uint64_t *__restrict__ hi, const uint64_t *__restrict__ k,
+                                                        const uint64_t N, const uint64_t max_hits,
+                                                        const uint64_t *__restrict__ loc_off, OUT *__restrict__ locs,
+                                                        const uint64_t *__restrict__ sub, const uint32_t *__restrict__ order,
+                                                        const uint64_t *__restrict__ skeys,
+                                                        unsigned long long *__restrict__ stats = nullptr) {
+    __shared__ ChainStage<P, CH, SUB> S;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
     unsigned long long c_locs = 0;
     unsigned long long st_phi = 0, st_ovf = 0, st_chains = 0;  // STATS only
@@ -196,47 +157,41 @@ __global__ __launch_bounds__(256) void k_locate_fill(const DevIndex ix, const ui
                 k1 = k[i];
             }
         }
-        const uint64_t minus = (sub && i < N) ? sub[i] : 0;  // locate_from_longest_seed, rowbowt.hpp:681-683
-        const uint32_t a = (occ && align_flush) ? static_cast<uint32_t>((out_elem0 + dst) & static_cast<uint64_t>(CH - 1)) : 0u;
-        s_dst[wv][lane] = dst - a;   // (wraps for a read at the very start of a misaligned array; + v >= a brings it back)
-        s_occ[wv][lane] = occ;
-        s_a[wv][lane] = a;
-        s_minus[wv][lane] = minus;
-        s_first[wv][lane] = k1;
+        const uint64_t minus = (SUB && i < N) ? sub[i] : 0;
+        S.dst[wv][lane] = dst;
+        if (SUB) S.minus[wv][lane] = minus;
+        // the toehold itself is not a text position when it wrapped (2^64 - 1): at 4-byte positions its owner stores that location (ChainStage)
+        const bool off_text = sizeof(P) == 4 && k1 >= ix.n;
+        if (off_text && occ) locs[dst] = static_cast<OUT>(k1 - minus);
         c_locs += occ;
         if (STATS && occ) st_chains += 1;
-        uint64_t wmax = occ + a;
+        uint64_t wmax = occ;
 #pragma unroll
         for (int o = kWave / 2; o > 0; o >>= 1) {
             const uint64_t other = __shfl_xor(wmax, o, kWave);
             wmax = other > wmax ? other : wmax;
         }
         for (uint64_t t0 = 0; t0 < wmax; t0 += CH) {
+            const uint32_t cnt = chain_round_count<CH>(occ, t0);
+            S.cnt[wv][lane] = static_cast<uint8_t>(cnt);
 #pragma unroll
             for (int e = 0; e < CH; ++e) {
-                const uint64_t t = t0 + e - a;
-                if (t0 + e >= a && t < occ) {
-                    if (STATS) {
-                        if (t) {
+                if (static_cast<uint32_t>(e) < cnt) {
+                    if (e || t0) {   // every location but a read's first is phi of the one before (toehold_sa.hpp:44)
+                        if (STATS) {
                             bool searched = false;
                             k1 = phi_step<P>(ix, k1, &searched);
                             st_phi += 1;
                             st_ovf += searched ? 1 : 0;
+                        } else {
+                            k1 = phi_step<P>(ix, k1);
                         }
-                    } else if (t) {
-                        k1 = phi_step<P>(ix, k1);  // toehold_sa.hpp:44
                     }
-                    s_val[wv][lane][e] = static_cast<P>(k1);
+                    chain_put(S, wv, lane, e, k1, e == 0 && t0 == 0 && off_text);
                 }
             }
             wave_lds_sync();
-#pragma unroll
-            for (int pass = 0; pass < CH; ++pass) {  // kWave/CH reads per pass, CH lanes each
-                const int s = pass * (kWave / CH) + lane / CH;
-                const int e = lane & (CH - 1);
-                const uint64_t v = t0 + e, as = s_a[wv][s], t = v - as;
-                if (v >= as && t < s_occ[wv][s]) locs[s_dst[wv][s] + v] = static_cast<OUT>((t ? static_cast<uint64_t>(s_val[wv][s][e]) : s_first[wv][s]) - s_minus[wv][s]);
-            }
+            chain_flush(S, wv, lane, t0, locs);
             wave_lds_sync();
         }
         wave_lds_sync();
@@ -327,8 +282,7 @@ int launch_locate_order(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t
     // inside one 64-byte line of phi slots) need no sorting, which saves a radix pass
     int begin_bit = static_cast<int>(ix.phi_shift) + 2;
     if (end_bit - begin_bit < 8) begin_bit = 0;
-    static const int order_bits = [] { const char *e = std::getenv("RBG_LOCATE_ORDER_BITS"); return e ? std::atoi(e) : 0; }();   // (experiments: sort on the top bits only)
-    if (order_bits > 0 && end_bit - order_bits > begin_bit) begin_bit = end_bit - order_bits;
+    // (sorting on fewer, higher bits costs K3 what it saves the sort: profiles/r06_experiments.txt)
     size_t bytes = w.sort_bytes;
     return static_cast<int>(hipcub::DeviceRadixSort::SortPairs(base + w.sort, bytes, k, keys, iota, perm, static_cast<int64_t>(N),
                                                                begin_bit, end_bit, st));
@@ -361,12 +315,6 @@ int launch_locate_plan(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t 
     hipLaunchKernelGGL(k_zero_u64, dim3(1), dim3(1), 0, st, loc_off);
     int rc = static_cast<int>(hipGetLastError());
     if (rc || N == 0) return rc;
-    static const bool two_pass = [] { const char *e = std::getenv("RBG_PLAN_TWO_PASS"); return e && e[0] == '1'; }();   // (A/B: the round-5 form)
-    if (two_pass) {
-        hipLaunchKernelGGL(k_occ, dim3(grid_for(cfg, N)), dim3(cfg.block_threads), 0, st, lo, hi, N, max_hits, loc_off);
-        if ((rc = static_cast<int>(hipGetLastError()))) return rc;
-        return scan_in_place(loc_off + 1, N, tmp, tmp_bytes, st);
-    }
     hipcub::TransformInputIterator<uint64_t, OccOf, hipcub::CountingInputIterator<uint64_t>> in(hipcub::CountingInputIterator<uint64_t>(0), OccOf{lo, hi, max_hits});
     size_t need = 0;
     (void)hipcub::DeviceScan::InclusiveSum(nullptr, need, in, loc_off + 1, static_cast<int64_t>(N));
@@ -383,33 +331,27 @@ int launch_locate_fill(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t 
     // the order workspace also holds the toeholds in sorted order (launch_locate_order's key output)
     const uint64_t *skeys = order ? reinterpret_cast<const uint64_t *>(static_cast<const char *>(order) + order_layout(N).keys) : nullptr;
     const uint32_t *perm = static_cast<const uint32_t *>(order);
-    // line-aligned flushes (k_locate_fill): OFF; RBG_K3_ALIGN=1 switches them on for the A/B of profiles/r06_k3_align_ab.txt.  They lost twice: on the
-    // bench index in round 3 (the longest chain of a wave grows by up to CH - 1 of 41 steps) and at r = 1.2e8 in round 6 (11.1 -> 14.9 ms per 10 M x
-    // 150 bp reads, 135 steps per chain): lanes that wait a different number of columns before their first step fall out of PHASE, and chains of one
-    // locus walking in phase -- neighbouring lanes asking for the same phi sector in the same instruction -- is what K3's speed rests on.
-    static const int align_env = [] { const char *e = std::getenv("RBG_K3_ALIGN"); return e ? std::atoi(e) : 0; }();
-    const uint32_t align_flush = align_env > 0 ? 1u : 0u;
+    // (Line-aligned flush segments -- a lane waiting `dst mod CH` columns before its first step so that every flush writes whole lines -- lost twice
+    //  and were retired with the round-3 staging: on the bench index in round 3, and at r = 1.2e8 in round 6 (11.1 -> 14.9 ms, profiles/
+    //  r06_k3_align_ab.txt): lanes that wait a different number of columns fall out of PHASE, and chains of one locus walking in phase --
+    //  neighbouring lanes asking for the same phi sector in the same instruction -- is what K3's speed rests on.)
+    if ((stats || locs32) && sub) return static_cast<int>(hipErrorInvalidValue);
     if (ix.layout == 2 && !ix.phi_slots) {  // run-indexed layout (k_runs.hip); with phi slots (RBG_OPT_RUN_PHI) the slot kernels below answer its phi
-        return launch_locate_fill_runs(ix, cfg, lo, hi, k, N, max_hits, loc_off, locs, sub, order, skeys, stream, stats, locs32, align_flush);
+        return launch_locate_fill_runs(ix, cfg, lo, hi, k, N, max_hits, loc_off, locs, sub, order, skeys, stream, stats, locs32);
     }
+#define RBG_LAUNCH_K3(PT, STS, OUT, SB, DST) \
+    hipLaunchKernelGGL((k_locate_fill<PT, STS, OUT, SB>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, DST, sub, perm, skeys, stats)
     if (locs32) {   // 4-byte locations (4-byte positions only; the caller checked)
-        if (stats || ix.pos_bytes != 4) return static_cast<int>(hipErrorInvalidValue);
-        hipLaunchKernelGGL((k_locate_fill<uint32_t, false, uint32_t>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, locs32, sub, perm, skeys, nullptr, align_flush);
-        return static_cast<int>(hipGetLastError());
-    }
-    // RBG_K3_CHUNK=16 (8-byte positions; A/B): sixteen steps staged per flush instead of RBG_K3_CHUNK_U64 -- with line-aligned flushes a whole 128-byte line per store
-    static const int chunk_env = [] { const char *e = std::getenv("RBG_K3_CHUNK"); return e ? std::atoi(e) : 0; }();
-    if (chunk_env == 16 && !stats && ix.pos_bytes == 8) {
-        hipLaunchKernelGGL((k_locate_fill<uint64_t, false, uint64_t, 16>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, locs, sub, perm, skeys, nullptr, align_flush);
-        return static_cast<int>(hipGetLastError());
-    }
-    if (stats) {
-        if (ix.pos_bytes == 4) hipLaunchKernelGGL((k_locate_fill<uint32_t, true>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, locs, sub, perm, skeys, stats, align_flush);
-        else hipLaunchKernelGGL((k_locate_fill<uint64_t, true>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, locs, sub, perm, skeys, stats, align_flush);
+        if (ix.pos_bytes != 4) return static_cast<int>(hipErrorInvalidValue);
+        RBG_LAUNCH_K3(uint32_t, false, uint32_t, false, locs32);
+    } else if (stats) {
+        if (ix.pos_bytes == 4) RBG_LAUNCH_K3(uint32_t, true, uint64_t, false, locs); else RBG_LAUNCH_K3(uint64_t, true, uint64_t, false, locs);
+    } else if (sub) {
+        if (ix.pos_bytes == 4) RBG_LAUNCH_K3(uint32_t, false, uint64_t, true, locs); else RBG_LAUNCH_K3(uint64_t, false, uint64_t, true, locs);
     } else {
-        if (ix.pos_bytes == 4) hipLaunchKernelGGL((k_locate_fill<uint32_t>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, locs, sub, perm, skeys, nullptr, align_flush);
-        else hipLaunchKernelGGL((k_locate_fill<uint64_t>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, locs, sub, perm, skeys, nullptr, align_flush);
+        if (ix.pos_bytes == 4) RBG_LAUNCH_K3(uint32_t, false, uint64_t, false, locs); else RBG_LAUNCH_K3(uint64_t, false, uint64_t, false, locs);
     }
+#undef RBG_LAUNCH_K3
     return static_cast<int>(hipGetLastError());
 }
 

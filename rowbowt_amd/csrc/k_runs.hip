@@ -301,22 +301,15 @@ __device__ __forceinline__ uint64_t locus_toehold_r(const DevIndex &ix, const ui
 // positions, no cross-lane traffic.  Works for ordered and unordered walks alike (the order only decides how well
 // neighbouring lanes share sectors).  STATS: [kLsPhiSteps] phi evaluations, [kLsPhiOvf] sampled positions the scans
 // and the narrowing rounds needed (8 or 12 bytes each; 7 pivot keys per round), [kLsChains], [kLsLocs].
-template <typename P, typename OUT = uint64_t, bool STATS = false>
+template <typename P, typename OUT = uint64_t, bool STATS = false, bool SUB = false>
 __global__ __launch_bounds__(256, 4) void k_locate_fill_runs2(const DevIndex ix, const uint64_t *__restrict__ lo,
                                                           const uint64_t *__restrict__ hi, const uint64_t *__restrict__ k,
                                                           const uint64_t N, const uint64_t max_hits,
                                                           const uint64_t *__restrict__ loc_off, OUT *__restrict__ locs,
                                                           const uint64_t *__restrict__ sub, const uint32_t *__restrict__ order,
-                                                          const uint64_t *__restrict__ skeys, unsigned long long *__restrict__ stats,
-                                                          const uint32_t align_flush) {
+                                                          const uint64_t *__restrict__ skeys, unsigned long long *__restrict__ stats) {
     constexpr int kChunkR = ChunkR<P>::v;
-    __shared__ P s_val[4][kWave][kChunkR + 1];
-    __shared__ uint64_t s_dst[4][kWave];
-    __shared__ uint64_t s_occ[4][kWave];
-    __shared__ uint64_t s_minus[4][kWave];
-    __shared__ uint64_t s_first[4][kWave];
-    __shared__ uint32_t s_a[4][kWave];   // line-aligned flushes, as in k_locate_fill (k_locate.hip)
-    const uint64_t out_elem0 = reinterpret_cast<uintptr_t>(locs) / sizeof(OUT);
+    __shared__ ChainStage<P, kChunkR, SUB> S;   // (rbg_device.hpp: the staging and the flush are k_locate_fill's)
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
     unsigned long long c_locs = 0;
     unsigned long long st_phi = 0, st_ent = 0, st_chains = 0;   // STATS only
@@ -341,27 +334,26 @@ __global__ __launch_bounds__(256, 4) void k_locate_fill_runs2(const DevIndex ix,
                 k1 = k[i];
             }
         }
-        const uint64_t minus = (sub && i < N && j < N) ? sub[i] : 0;
-        const uint32_t a = (occ && align_flush) ? static_cast<uint32_t>((out_elem0 + dst) & static_cast<uint64_t>(kChunkR - 1)) : 0u;
-        s_dst[wv][lane] = dst - a;
-        s_occ[wv][lane] = occ;
-        s_a[wv][lane] = a;
-        s_minus[wv][lane] = minus;
-        s_first[wv][lane] = k1;
+        const uint64_t minus = (SUB && i < N && j < N) ? sub[i] : 0;
+        S.dst[wv][lane] = dst;
+        if (SUB) S.minus[wv][lane] = minus;
+        const bool off_text = sizeof(P) == 4 && k1 >= n;       // a toehold below zero: its owner stores that location (ChainStage)
+        if (off_text && occ) locs[dst] = static_cast<OUT>(k1 - minus);
         c_locs += occ;
         if (STATS && occ) st_chains += 1;
-        uint64_t wmax = occ + a;
+        uint64_t wmax = occ;
 #pragma unroll
         for (int o = kWave / 2; o > 0; o >>= 1) {
             const uint64_t other = __shfl_xor(wmax, o, kWave);
             wmax = other > wmax ? other : wmax;
         }
         for (uint64_t t0 = 0; t0 < wmax; t0 += kChunkR) {
+            const uint32_t cnt = chain_round_count<kChunkR>(occ, t0);
+            S.cnt[wv][lane] = static_cast<uint8_t>(cnt);
 #pragma unroll 1
             for (int e = 0; e < kChunkR; ++e) {
-                const uint64_t t = t0 + e - a;
-                const bool mine = t0 + e >= a && t < occ;
-                if (mine && t > 0) {                           // toehold_sa.hpp:44: k = phi(k)
+                const bool mine = static_cast<uint32_t>(e) < cnt;
+                if (mine && (e || t0)) {                       // toehold_sa.hpp:44: k = phi(k)
                     uint64_t s;
                     if (k1 >= n) {
                         // a toehold below zero (k_locate.hip phi_step): outside phi's domain -- the last sample is its predecessor
@@ -379,16 +371,10 @@ __global__ __launch_bounds__(256, 4) void k_locate_fill_runs2(const DevIndex ix,
                     }
                     k1 = s;
                 }
-                if (mine) s_val[wv][lane][e] = static_cast<P>(k1);
+                if (mine) chain_put(S, wv, lane, e, k1, e == 0 && t0 == 0 && off_text);
             }
             wave_lds_sync();
-#pragma unroll
-            for (int pass = 0; pass < kChunkR; ++pass) {
-                const int s = pass * (kWave / kChunkR) + lane / kChunkR;
-                const int e = lane & (kChunkR - 1);
-                const uint64_t v = t0 + e, as = s_a[wv][s], t = v - as;
-                if (v >= as && t < s_occ[wv][s]) locs[s_dst[wv][s] + v] = static_cast<OUT>((t ? static_cast<uint64_t>(s_val[wv][s][e]) : s_first[wv][s]) - s_minus[wv][s]);
-            }
+            chain_flush(S, wv, lane, t0, locs);
             wave_lds_sync();
         }
         wave_lds_sync();
@@ -473,22 +459,25 @@ int launch_find_range_runs_packed(const DevIndex &ix, const LaunchCfg &cfg, cons
 
 int launch_locate_fill_runs(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t *lo, const uint64_t *hi, const uint64_t *k,
                             uint64_t N, uint64_t max_hits, const uint64_t *loc_off, uint64_t *locs, const uint64_t *sub,
-                            const void *order, const uint64_t *skeys, void *stream, unsigned long long *stats, uint32_t *locs32, uint32_t align_flush) {
+                            const void *order, const uint64_t *skeys, void *stream, unsigned long long *stats, uint32_t *locs32) {
     if (N == 0) return 0;
+    if ((stats || locs32) && sub) return static_cast<int>(hipErrorInvalidValue);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid(grid_for(cfg, N)), block(256);
     const uint32_t *perm = static_cast<const uint32_t *>(order);
-#define RBG_LAUNCH_LFR2(PT, OUT, STS, DST) \
-    hipLaunchKernelGGL((k_locate_fill_runs2<PT, OUT, STS>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, DST, sub, perm, skeys, stats, align_flush)
+#define RBG_LAUNCH_LFR2(PT, OUT, STS, SB, DST) \
+    hipLaunchKernelGGL((k_locate_fill_runs2<PT, OUT, STS, SB>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, DST, sub, perm, skeys, stats)
     if (locs32) {
-        if (stats || ix.pos_bytes != 4) return static_cast<int>(hipErrorInvalidValue);
-        RBG_LAUNCH_LFR2(uint32_t, uint32_t, false, locs32);
+        if (ix.pos_bytes != 4) return static_cast<int>(hipErrorInvalidValue);
+        RBG_LAUNCH_LFR2(uint32_t, uint32_t, false, false, locs32);
     } else if (stats) {
-        if (ix.pos_bytes == 4) RBG_LAUNCH_LFR2(uint32_t, uint64_t, true, locs); else RBG_LAUNCH_LFR2(uint64_t, uint64_t, true, locs);
+        if (ix.pos_bytes == 4) RBG_LAUNCH_LFR2(uint32_t, uint64_t, true, false, locs); else RBG_LAUNCH_LFR2(uint64_t, uint64_t, true, false, locs);
+    } else if (sub) {
+        if (ix.pos_bytes == 4) RBG_LAUNCH_LFR2(uint32_t, uint64_t, false, true, locs); else RBG_LAUNCH_LFR2(uint64_t, uint64_t, false, true, locs);
     } else if (ix.pos_bytes == 4) {
-        RBG_LAUNCH_LFR2(uint32_t, uint64_t, false, locs);
+        RBG_LAUNCH_LFR2(uint32_t, uint64_t, false, false, locs);
     } else {
-        RBG_LAUNCH_LFR2(uint64_t, uint64_t, false, locs);
+        RBG_LAUNCH_LFR2(uint64_t, uint64_t, false, false, locs);
     }
 #undef RBG_LAUNCH_LFR2
     return static_cast<int>(hipGetLastError());

@@ -459,7 +459,7 @@ int launch_find_range_runs_packed(const DevIndex &ix, const LaunchCfg &cfg, cons
 int launch_locate_fill_runs(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t *lo, const uint64_t *hi, const uint64_t *k,
                             uint64_t N, uint64_t max_hits, const uint64_t *loc_off, uint64_t *locs, const uint64_t *sub,
                             const void *order, const uint64_t *skeys, void *stream, unsigned long long *stats = nullptr /*kStatRunLocateN*/,
-                            uint32_t *locs32 = nullptr, uint32_t align_flush = 0 /* line-aligned flushes: k_locate.hip */);
+                            uint32_t *locs32 = nullptr);
 // the kernels beside the rb_align path on the run-indexed layout (k_runs_seeds.hip): k-mer steps through the depths' run lists
 int launch_lf_runs(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t *lo, const uint64_t *hi, const uint8_t *sym, uint64_t N,
                    uint64_t *lo_out, uint64_t *hi_out, void *stream);

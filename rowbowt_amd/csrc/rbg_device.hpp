@@ -231,6 +231,77 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
     return v;
 }
 
+__device__ __forceinline__ void wave_lds_sync() {
+    // LDS operations of one wave execute in issue order; this only stops the compiler from moving
+    // the cross-lane reads above the writes (and vice versa)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---- K3's staging: the values of a wave's 64 phi chains, CH steps at a time, and their coalesced flush (k_locate.hip k_locate_fill, k_runs.hip
+// k_locate_fill_runs2).  One lane walks one read's chain (toehold_sa.hpp:37-49); the locations of a read are contiguous in `locs`, but a lane
+// storing its own values would make every store instruction touch 64 different lines, and stores are gather-class requests like the slot loads
+// (tools/gather_roof.hip).  So the values are staged per wave in LDS and flushed with CH lanes writing one read's (8 CH)-byte segment.
+//
+// What bounds the walk is the number of chains in flight (a phi step is a dependent gather), and what bounded THAT was this staging's LDS: 26.6 KB
+// per 256-thread workgroup until round 6 (values + per lane an 8-byte destination, count, subtrahend and first location, a 4-byte flush alignment)
+// = six waves per SIMD at 4-byte positions, five at 8-byte ones.  A workgroup now keeps per lane only what the FLUSHING lanes need:
+//   val    the values of the round as 32-bit words, a row of CH * (sizeof(P) / 4) + 1 per lane (the odd row length spreads the owners' column
+//          writes and the flush's row reads over the banks; an 8-byte position travels as two words so that the pad stays four bytes);
+//   dst    where the read's locations start (8 bytes: 3.5e9 locations per batch at pangenome scale);
+//   cnt    how many values of THIS round are the read's (one byte, rewritten per round) instead of the 8-byte count;
+//   minus  locate_from_longest_seed's subtrahend (rowbowt.hpp:681-683): in the SUB instantiation only.
+// = 19.3 KB: eight workgroups per CU, eight waves per SIMD (the kernels stay within 64 VGPRs).  profiles/r06_k3_lean_ab.txt: K3 at 8-byte positions
+// -4 to -8 % (r = 1.2e8: 11.2-11.6 -> 10.3-11.1 ms per 10 M x 150 bp), level at 4-byte positions (there the location buffer's placement decides).
+// The first location of a chain is the toehold itself, a text position except when it wrapped below zero (LF_w_loc, rowbowt.hpp:561: k - 1 at
+// text position 0): at 4-byte positions such a value is staged as the all-ones word -- no position of such an index --, the flush skips it and
+// the owner stores that one location itself (chain_first_off_text).
+template <typename P, int CH, bool SUB>
+struct ChainStage {
+    static_assert(CH == 8 || CH == 16, "a flush pass serves 64 / CH reads");
+    static constexpr int W = sizeof(P) / 4, ROW = CH * W + 1;
+    uint32_t val[4][kWave][ROW];
+    uint64_t dst[4][kWave];
+    uint64_t minus[SUB ? 4 : 1][SUB ? kWave : 1];
+    uint8_t cnt[4][kWave];
+};
+// the read's share of the round that starts at step t0 (the walk and the flushing lanes count in 32 bits)
+template <int CH>
+__device__ __forceinline__ uint32_t chain_round_count(const uint64_t occ, const uint64_t t0) {
+    return occ > t0 ? static_cast<uint32_t>(occ - t0 < static_cast<uint64_t>(CH) ? occ - t0 : CH) : 0u;
+}
+template <typename P, int CH, bool SUB>
+__device__ __forceinline__ void chain_put(ChainStage<P, CH, SUB> &S, const int wv, const int lane, const int e, const uint64_t v, const bool off_text) {
+    if (sizeof(P) == 4) {
+        S.val[wv][lane][e] = off_text ? 0xFFFFFFFFu : static_cast<uint32_t>(v);
+    } else {
+        S.val[wv][lane][2 * e] = static_cast<uint32_t>(v);
+        S.val[wv][lane][2 * e + 1] = static_cast<uint32_t>(v >> 32);
+    }
+}
+// after wave_lds_sync(): CH lanes per read, 64 / CH reads per pass; `locs[dst + t0 + e] = value - minus` for the values the round holds
+template <typename P, int CH, bool SUB, typename OUT>
+__device__ __forceinline__ void chain_flush(const ChainStage<P, CH, SUB> &S, const int wv, const int lane, const uint64_t t0, OUT *__restrict__ locs) {
+    constexpr int G = kWave / CH;
+#pragma unroll
+    for (int pass = 0; pass < CH; ++pass) {
+        const int s = pass * G + lane / CH;
+        const int e = lane & (CH - 1);
+        if (static_cast<uint32_t>(e) < S.cnt[wv][s]) {
+            uint64_t x;
+            if (sizeof(P) == 4) {
+                const uint32_t x32 = S.val[wv][s][e];
+                if (x32 == 0xFFFFFFFFu) continue;   // a first location outside the text: its owner stored it
+                x = x32;
+            } else {
+                x = static_cast<uint64_t>(S.val[wv][s][2 * e]) | (static_cast<uint64_t>(S.val[wv][s][2 * e + 1]) << 32);
+            }
+            locs[S.dst[wv][s] + t0 + e] = static_cast<OUT>(x - (SUB ? S.minus[wv][s] : uint64_t(0)));
+        }
+    }
+}
+
 // ---- the marker query: MarkerArray::at_range(lo, hi) (rowbowt.hpp:272-290, :318, :437-441) as {src, cnt}: the values mk_vals[src, src + cnt) of all runs with
 // start <= hi && end >= lo, in run order.  Runs are disjoint, ascending inclusive SA-index intervals.  From the bucket records (rbg_dev.h MkRec: one or two
 // sectors), else from the directory + the run arrays.  st (instrumented seed walks): [kStatSearchN + 1] += records / directory entries read, [+ 2] += run starts /

@@ -12,11 +12,7 @@
 namespace rbg {
 namespace {
 
-__device__ __forceinline__ void wave_lds_sync() {  // as in k_locate.hip: orders the wave's own LDS writes and cross-lane reads
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
+// (wave_lds_sync -- the wave-local LDS fence -- is rbg_device.hpp's)
 
 // `bytes` = the launch's DYNAMIC LDS (what the attribute limits); `static_bytes` = the kernel's static __shared__ arrays, which count
 // towards the 48 KB a kernel gets without asking but are not part of the attribute's value

@@ -146,6 +146,60 @@ def test_locate_chains_in_locus_order(synth, layout, phi, pos_bytes, monkeypatch
     o.close()
 
 
+@pytest.mark.parametrize("layout,phi", [(capi.LAYOUT_SLOTS, 0), (capi.LAYOUT_RUNS, 2), (capi.LAYOUT_RUNS, 1)])
+@pytest.mark.parametrize("pos_bytes", [4, 8])
+def test_k3_staging_at_its_edges(synth, layout, phi, pos_bytes):
+    """K3's staging (rbg_device.hpp ChainStage, round 6: values at the position width, a one-byte count per round, the first location of a chain
+    that is no text position stored by its owner): chains cut by max_hits at, just below and just above the flush rounds of 8 and 16 steps;
+    toeholds that wrapped below zero by one AND by two (LF_w_loc's k - 1, rowbowt.hpp:561, once or twice past text position 0 -- at 4-byte
+    positions the staged word for them is all ones, whatever the value) on chains of several locations; the ordered and the unordered walk;
+    64-bit locations against the oracle (toehold_sa.hpp:37-49), 32-bit ones = their low words, nothing written outside a read's segment."""
+    import torch
+    S = synth
+    with capi.default_option(capi.OPT_RANK_LAYOUT, layout), capi.default_option(capi.OPT_RUN_PHI, phi), capi.default_option(capi.OPT_POS_BYTES, pos_bytes):
+        rb = ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0)
+    o = orc.Oracle.from_runs(S.heads, S.lens, S.ssa, S.esa)
+    reads = S.sample_reads(1500, 24, seed=77, sub_rate=0.05) + [bytes(S.text[:30]), b"", b"ACGTN"]   # (short reads: long chains)
+    seqs, off = ra.pack_reads(reads)
+    N = len(reads)
+    wlo, whi, wk = o.find_range_w_toehold_batch(seqs, off, nthreads=4)
+    occ = np.where(whi >= wlo, whi - wlo + 1, 0).astype(np.int64)
+    assert occ.max() > 33                                          # (chains longer than two rounds of sixteen)
+    wk = wk.copy()
+    multi = np.flatnonzero(occ >= 3)
+    wk[multi[0]] = np.uint64(MAXU)
+    wk[multi[1]] = np.uint64(MAXU - 1)
+    wk[multi[2]] = np.uint64(S.n + 5)                               # (no toehold the search produces; the walk's arithmetic is the reference's all the same)
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    L = ra.lib()
+    d_lo, d_hi, d_k = (torch.from_numpy(a.view(np.int64).copy()).to(dev) for a in (wlo, whi, wk))
+    d_loc_off = torch.empty(N + 1, dtype=torch.int64, device=dev)
+    tmp_bytes, ws_bytes = L.rbg_locate_plan_tmp_bytes(N), L.rbg_locate_order_ws_bytes(N)
+    d_tmp = torch.empty(tmp_bytes, dtype=torch.uint8, device=dev)
+    d_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    assert L.rbg_locate_order_dev(rb.h, d_k.data_ptr(), N, d_ws.data_ptr(), ws_bytes, st) == 0
+    for mh in (1, 7, 8, 9, 15, 16, 17, 31, 32, 33, MAXU):
+        woff, wlocs = o.locs_at_batch(wlo, whi, wk, mh, nthreads=4)
+        assert L.rbg_locate_plan_dev(rb.h, d_lo.data_ptr(), d_hi.data_ptr(), N, mh, d_loc_off.data_ptr(), d_tmp.data_ptr(), tmp_bytes, st) == 0
+        total = int(d_loc_off[-1].item())
+        assert total == int(woff[-1])
+        for order in (d_ws.data_ptr(), None):
+            d_locs = torch.full((total + 2,), -7, dtype=torch.int64, device=dev)
+            assert L.rbg_locate_fill_dev(rb.h, d_lo.data_ptr(), d_hi.data_ptr(), d_k.data_ptr(), N, mh, d_loc_off.data_ptr(), d_locs.data_ptr(), order, st) == 0
+            torch.cuda.synchronize()
+            assert (d_locs[:total].cpu().numpy().view(np.uint64) == wlocs).all(), (mh, order is None)
+            assert d_locs[total:].tolist() == [-7, -7]
+            if pos_bytes == 4:
+                d_locs32 = torch.full((total + 2,), -7, dtype=torch.int32, device=dev)
+                assert L.rbg_locate_fill_dev32(rb.h, d_lo.data_ptr(), d_hi.data_ptr(), d_k.data_ptr(), N, mh, d_loc_off.data_ptr(), d_locs32.data_ptr(), order, st) == 0
+                torch.cuda.synchronize()
+                assert (d_locs32[:total].cpu().numpy().view(np.uint32) == (wlocs & np.uint64(0xFFFFFFFF)).astype(np.uint32)).all(), (mh, order is None)
+                assert d_locs32[total:].tolist() == [-7, -7]
+    rb.close()
+    o.close()
+
+
 @pytest.mark.parametrize("layout", [capi.LAYOUT_SLOTS, capi.LAYOUT_RUNS])
 def test_instrumented_kernels_and_32_bit_locations(synth, layout):
     """rbg_find_range_stats_dev / rbg_locate_fill_stats_dev (the instrumented instantiations bench.py prices the kernels
