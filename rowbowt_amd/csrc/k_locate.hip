@@ -267,6 +267,7 @@ int launch_locate_order(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t
     while (end_bit < 64 && (ix.n >> end_bit)) ++end_bit;  // toeholds are text positions < n
     if (ix.pos_bytes == 4) {   // 32-bit keys (k_keys32): the key pass also makes the identity permutation
         uint32_t *k32_in = reinterpret_cast<uint32_t *>(base + w.keys_in), *k32_out = reinterpret_cast<uint32_t *>(base + w.keys);
+        // (computing the keys where the sort reads them -- rocprim iterators, no key pass -- reads the 8-byte toeholds twice: 0.331 -> 0.337 ms, profiles/r06_experiments.txt)
         hipLaunchKernelGGL(k_keys32, dim3(grid_for(cfg, N)), dim3(256), 0, st, ix, k, N, k32_in, iota);
         int rc32 = static_cast<int>(hipGetLastError());
         if (rc32) return rc32;
@@ -327,6 +328,8 @@ int launch_locate_fill(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t 
                        const uint64_t *sub, const void *order, void *stream, unsigned long long *stats, uint32_t *locs32) {
     if (N == 0) return 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    // (the grid: up to 32 workgroups per CU looping over the chains; 8 / 16 / 64 per CU and one workgroup per 256 chains without a loop measured
+    //  level or worse within the processes' spread: profiles/r06_experiments.txt)
     const dim3 grid(grid_for(cfg, N)), block(cfg.block_threads);
     // the order workspace also holds the toeholds in sorted order (launch_locate_order's key output)
     const uint64_t *skeys = order ? reinterpret_cast<const uint64_t *>(static_cast<const char *>(order) + order_layout(N).keys) : nullptr;
