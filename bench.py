@@ -818,6 +818,19 @@ def run():
                 traffic = misses = None
         # request ceiling: tools/gather_ceiling.hip's sweep (committed result; measured on an MI355X of this pool)
         ceiling = None
+        # what an L2-served scattered request costs beside a miss (tools/gather_width.hip: one dependent miss + H gathers from a 512 KB table per step)
+        hit_cost_s = None
+        try:
+            gw = json.load(open(os.path.join(ROOT, "profiles", "r06_gather_width.json")))["rows"]
+            mix_rows = {}
+            for r_ in gw:
+                h_ = [v for k_, v in r_.items() if k_.startswith("bytes_per_access")][0]
+                if h_ <= 0 and r_["waves_per_simd"] == 4:
+                    mix_rows[-h_] = r_["G_accesses_per_s"] * 1e9
+            if 0 in mix_rows and 2 in mix_rows:
+                hit_cost_s = (1.0 / mix_rows[2] - 1.0 / mix_rows[0]) / 2.0
+        except Exception:
+            pass
         try:
             ceiling = json.load(open(os.path.join(ROOT, "profiles", "gather_ceiling.json")))["peak_G_gathers_per_s"]
         except Exception:
@@ -923,6 +936,14 @@ def run():
                             **({"traffic_bytes": pmc_by_kernel[k]["hbm_bytes_per_launch"], "tcc_miss_per_launch": pmc_by_kernel[k].get("tcc_miss_per_launch"),
                                 "traffic_frac_of_hbm_peak": pmc_by_kernel[k]["hbm_bytes_per_launch"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                 "alg_bytes_over_traffic": v["alg_bytes"] / pmc_by_kernel[k]["hbm_bytes_per_launch"]} if k in pmc_by_kernel else {}),
+                            # the request model: misses at the gather ceiling + L2-served requests at what tools/gather_width.hip measured for one
+                            **({"ceiling_model": {"miss_ms": pmc_by_kernel[k]["tcc_miss_per_launch"] / (ceiling * 1e9) * 1e3,
+                                                  "l2_hit_ms": pmc_by_kernel[k]["tcc_hit_per_launch"] * hit_cost_s * 1e3,
+                                                  "model_ms": (pmc_by_kernel[k]["tcc_miss_per_launch"] / (ceiling * 1e9) + pmc_by_kernel[k]["tcc_hit_per_launch"] * hit_cost_s) * 1e3,
+                                                  "measured_over_model": v["ms"] / ((pmc_by_kernel[k]["tcc_miss_per_launch"] / (ceiling * 1e9) + pmc_by_kernel[k]["tcc_hit_per_launch"] * hit_cost_s) * 1e3),
+                                                  "note": "L2 misses / the random-gather ceiling (profiles/gather_ceiling.json) + L2 hits x the cost of an L2-served scattered "
+                                                          "request beside a miss (profiles/r06_gather_width.json, H = 2 row): 1.0 = the kernel runs at what its requests cost"}}
+                               if k in pmc_by_kernel and ceiling and hit_cost_s and pmc_by_kernel[k].get("tcc_miss_per_launch") and pmc_by_kernel[k].get("tcc_hit_per_launch") else {}),
                             "touched": v.get("touched")}
                         for k, v in kernels.items()},
             "per_read": {"lf_gathers": st_toe["steps"] / N, "slots": st_toe["slots"] / N, "symbols_consumed": st_toe["symbols"] / N,
