@@ -108,7 +108,10 @@ __device__ __forceinline__ uint64_t phi_step(const DevIndex &ix, uint64_t i, boo
 // kChunk steps at a time, and flushed with kChunk lanes writing one read's segment (rbg_device.hpp ChainStage: what is staged, why, and what it
 // costs in LDS).  Measured per 10M reads: unordered chains 10.5 / 8.6 / 7.6 ms at kChunk 8 / 16 / 32; with the chains in toehold order (the
 // default) 3.5 / 3.1 / 3.5 ms, hence 16 at 4-byte positions; at 8-byte positions 8 (RBG_K3_CHUNK_U64: 16 costs half the workgroups their LDS).
-constexpr int kChunk = 16;
+#ifndef RBG_K3_CHUNK_U32
+#define RBG_K3_CHUNK_U32 8
+#endif
+constexpr int kChunk = RBG_K3_CHUNK_U32;
 #ifndef RBG_K3_CHUNK_U64
 #define RBG_K3_CHUNK_U64 8
 #endif
@@ -118,15 +121,17 @@ constexpr int kChunk = 16;
 // device pipelines on an index with 4-byte positions, uint32_t (rbg_locate_fill_dev32: half the write requests; the low
 // 32 bits of the same values, so a toehold that wrapped below zero reads 0xFFFFFFFF).
 // SUB = `sub` is subtracted from every location (locate_from_longest_seed, rowbowt.hpp:681-683).
-template <typename P, bool STATS = false, typename OUT = uint64_t, bool SUB = false, int CH = (sizeof(P) == 8 ? RBG_K3_CHUNK_U64 : kChunk)>
-__global__ __launch_bounds__(256, SUB ? 7 : 8) void k_locate_fill(const DevIndex ix, const uint64_t *__restrict__ lo,
+template <typename P, bool STATS = false, typename OUT = uint64_t, bool SUB = false, bool HI8 = false, int CH = (sizeof(P) == 8 ? RBG_K3_CHUNK_U64 : kChunk), bool RING = true>
+__global__ __launch_bounds__(256, (chain_stage_waves<ChainStage<P, CH, SUB, RING, HI8>>())) void k_locate_fill(const DevIndex ix, const uint64_t *__restrict__ lo,
                                                         const uint64_t *__restrict__ hi, const uint64_t *__restrict__ k,
                                                         const uint64_t N, const uint64_t max_hits,
                                                         const uint64_t *__restrict__ loc_off, OUT *__restrict__ locs,
                                                         const uint64_t *__restrict__ sub, const uint32_t *__restrict__ order,
                                                         const uint64_t *__restrict__ skeys,
                                                         unsigned long long *__restrict__ stats = nullptr) {
-    __shared__ ChainStage<P, CH, SUB> S;
+    using Stage = ChainStage<P, CH, SUB, RING, HI8>;
+    __shared__ Stage S;
+    const uint64_t out_elem0 = reinterpret_cast<uintptr_t>(locs) / sizeof(OUT);
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
     unsigned long long c_locs = 0;
     unsigned long long st_phi = 0, st_ovf = 0, st_chains = 0;  // STATS only
@@ -158,14 +163,16 @@ __global__ __launch_bounds__(256, SUB ? 7 : 8) void k_locate_fill(const DevIndex
             }
         }
         const uint64_t minus = (SUB && i < N) ? sub[i] : 0;
-        S.dst[wv][lane] = dst;
+        // the window grid of this read: its first location sits a elements past a CH-element boundary of the output array (RING; else a = 0)
+        const uint32_t a = (RING && occ) ? static_cast<uint32_t>((out_elem0 + dst) & static_cast<uint64_t>(CH - 1)) : 0u;
+        S.dst[wv][lane] = dst - a;   // (wraps for a read at the very start of a misaligned array; + v >= a brings it back)
         if (SUB) S.minus[wv][lane] = minus;
         // the toehold itself is not a text position when it wrapped (2^64 - 1): at 4-byte positions its owner stores that location (ChainStage)
-        const bool off_text = sizeof(P) == 4 && k1 >= ix.n;
+        const bool off_text = Stage::kSentinel && k1 >= ix.n;
         if (off_text && occ) locs[dst] = static_cast<OUT>(k1 - minus);
         c_locs += occ;
         if (STATS && occ) st_chains += 1;
-        uint64_t wmax = occ;
+        uint64_t wmax = occ + a;      // the chain's extent in virtual columns
 #pragma unroll
         for (int o = kWave / 2; o > 0; o >>= 1) {
             const uint64_t other = __shfl_xor(wmax, o, kWave);
@@ -173,7 +180,7 @@ __global__ __launch_bounds__(256, SUB ? 7 : 8) void k_locate_fill(const DevIndex
         }
         for (uint64_t t0 = 0; t0 < wmax; t0 += CH) {
             const uint32_t cnt = chain_round_count<CH>(occ, t0);
-            S.cnt[wv][lane] = static_cast<uint8_t>(cnt);
+            S.bounds[wv][lane] = chain_window_bounds<CH>(occ, a, t0);
 #pragma unroll
             for (int e = 0; e < CH; ++e) {
                 if (static_cast<uint32_t>(e) < cnt) {
@@ -187,7 +194,7 @@ __global__ __launch_bounds__(256, SUB ? 7 : 8) void k_locate_fill(const DevIndex
                             k1 = phi_step<P>(ix, k1);
                         }
                     }
-                    chain_put(S, wv, lane, e, k1, e == 0 && t0 == 0 && off_text);
+                    chain_put(S, wv, lane, a + static_cast<uint32_t>(t0) + e, k1, e == 0 && t0 == 0 && off_text);
                 }
             }
             wave_lds_sync();
@@ -342,8 +349,13 @@ int launch_locate_fill(const DevIndex &ix, const LaunchCfg &cfg, const uint64_t 
     if (ix.layout == 2 && !ix.phi_slots) {  // run-indexed layout (k_runs.hip); with phi slots (RBG_OPT_RUN_PHI) the slot kernels below answer its phi
         return launch_locate_fill_runs(ix, cfg, lo, hi, k, N, max_hits, loc_off, locs, sub, order, skeys, stream, stats, locs32);
     }
+    // (rbg_device.hpp ChainStage: a value as its low word + one high byte; RBG_K3_HI8=0 -- tests -- stages whole 8-byte values at any n)
+    const bool hi8 = ix.pos_bytes == 8 && ix.n < kChainHi8Limit && chain_hi8_enabled();
 #define RBG_LAUNCH_K3(PT, STS, OUT, SB, DST) \
-    hipLaunchKernelGGL((k_locate_fill<PT, STS, OUT, SB>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, DST, sub, perm, skeys, stats)
+    do { \
+        if (sizeof(PT) == 8 && hi8) hipLaunchKernelGGL((k_locate_fill<PT, STS, OUT, SB, sizeof(PT) == 8>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, DST, sub, perm, skeys, stats); \
+        else hipLaunchKernelGGL((k_locate_fill<PT, STS, OUT, SB, false>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, DST, sub, perm, skeys, stats); \
+    } while (0)
     if (locs32) {   // 4-byte locations (4-byte positions only; the caller checked)
         if (ix.pos_bytes != 4) return static_cast<int>(hipErrorInvalidValue);
         RBG_LAUNCH_K3(uint32_t, false, uint32_t, false, locs32);

@@ -285,7 +285,7 @@ __global__ __launch_bounds__(512, STATS ? 2 : 4) void k_find_range_runs(const De
     }
 }
 
-template <typename P> struct ChunkR { static constexpr int v = sizeof(P) == 8 ? 8 : 16; };   // as in k_locate.hip
+template <typename P> struct ChunkR { static constexpr int v = 8; };   // as in k_locate.hip (flush windows of eight locations: 64 bytes)
 // the toehold of a locus key (k_locate.hip locus_key / locus_toehold: the chains' order by locus)
 __device__ __forceinline__ uint64_t locus_toehold_r(const DevIndex &ix, const uint64_t key, const uint64_t *__restrict__ k, const uint64_t i) {
     if (key == ~uint64_t(0)) return k[i];
@@ -301,7 +301,7 @@ __device__ __forceinline__ uint64_t locus_toehold_r(const DevIndex &ix, const ui
 // positions, no cross-lane traffic.  Works for ordered and unordered walks alike (the order only decides how well
 // neighbouring lanes share sectors).  STATS: [kLsPhiSteps] phi evaluations, [kLsPhiOvf] sampled positions the scans
 // and the narrowing rounds needed (8 or 12 bytes each; 7 pivot keys per round), [kLsChains], [kLsLocs].
-template <typename P, typename OUT = uint64_t, bool STATS = false, bool SUB = false>
+template <typename P, typename OUT = uint64_t, bool STATS = false, bool SUB = false, bool HI8 = false>
 __global__ __launch_bounds__(256, 4) void k_locate_fill_runs2(const DevIndex ix, const uint64_t *__restrict__ lo,
                                                           const uint64_t *__restrict__ hi, const uint64_t *__restrict__ k,
                                                           const uint64_t N, const uint64_t max_hits,
@@ -309,7 +309,10 @@ __global__ __launch_bounds__(256, 4) void k_locate_fill_runs2(const DevIndex ix,
                                                           const uint64_t *__restrict__ sub, const uint32_t *__restrict__ order,
                                                           const uint64_t *__restrict__ skeys, unsigned long long *__restrict__ stats) {
     constexpr int kChunkR = ChunkR<P>::v;
-    __shared__ ChainStage<P, kChunkR, SUB> S;   // (rbg_device.hpp: the staging and the flush are k_locate_fill's)
+    constexpr bool RING = true;
+    using Stage = ChainStage<P, kChunkR, SUB, RING, HI8>;
+    __shared__ Stage S;   // (rbg_device.hpp: the staging and the flush are k_locate_fill's)
+    const uint64_t out_elem0 = reinterpret_cast<uintptr_t>(locs) / sizeof(OUT);
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
     unsigned long long c_locs = 0;
     unsigned long long st_phi = 0, st_ent = 0, st_chains = 0;   // STATS only
@@ -335,13 +338,15 @@ __global__ __launch_bounds__(256, 4) void k_locate_fill_runs2(const DevIndex ix,
             }
         }
         const uint64_t minus = (SUB && i < N && j < N) ? sub[i] : 0;
-        S.dst[wv][lane] = dst;
+        // the window grid of this read: its first location sits a elements past a CH-element boundary of the output array (RING; else a = 0)
+        const uint32_t a = (RING && occ) ? static_cast<uint32_t>((out_elem0 + dst) & static_cast<uint64_t>(kChunkR - 1)) : 0u;
+        S.dst[wv][lane] = dst - a;   // (wraps for a read at the very start of a misaligned array; + v >= a brings it back)
         if (SUB) S.minus[wv][lane] = minus;
-        const bool off_text = sizeof(P) == 4 && k1 >= n;       // a toehold below zero: its owner stores that location (ChainStage)
+        const bool off_text = Stage::kSentinel && k1 >= n;     // a toehold below zero: its owner stores that location (ChainStage)
         if (off_text && occ) locs[dst] = static_cast<OUT>(k1 - minus);
         c_locs += occ;
         if (STATS && occ) st_chains += 1;
-        uint64_t wmax = occ;
+        uint64_t wmax = occ + a;      // the chain's extent in virtual columns
 #pragma unroll
         for (int o = kWave / 2; o > 0; o >>= 1) {
             const uint64_t other = __shfl_xor(wmax, o, kWave);
@@ -349,7 +354,7 @@ __global__ __launch_bounds__(256, 4) void k_locate_fill_runs2(const DevIndex ix,
         }
         for (uint64_t t0 = 0; t0 < wmax; t0 += kChunkR) {
             const uint32_t cnt = chain_round_count<kChunkR>(occ, t0);
-            S.cnt[wv][lane] = static_cast<uint8_t>(cnt);
+            S.bounds[wv][lane] = chain_window_bounds<kChunkR>(occ, a, t0);
 #pragma unroll 1
             for (int e = 0; e < kChunkR; ++e) {
                 const bool mine = static_cast<uint32_t>(e) < cnt;
@@ -371,7 +376,7 @@ __global__ __launch_bounds__(256, 4) void k_locate_fill_runs2(const DevIndex ix,
                     }
                     k1 = s;
                 }
-                if (mine) chain_put(S, wv, lane, e, k1, e == 0 && t0 == 0 && off_text);
+                if (mine) chain_put(S, wv, lane, a + static_cast<uint32_t>(t0) + e, k1, e == 0 && t0 == 0 && off_text);
             }
             wave_lds_sync();
             chain_flush(S, wv, lane, t0, locs);
@@ -465,8 +470,12 @@ int launch_locate_fill_runs(const DevIndex &ix, const LaunchCfg &cfg, const uint
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid(grid_for(cfg, N)), block(256);
     const uint32_t *perm = static_cast<const uint32_t *>(order);
+    const bool hi8 = ix.pos_bytes == 8 && ix.n < kChainHi8Limit && chain_hi8_enabled();
 #define RBG_LAUNCH_LFR2(PT, OUT, STS, SB, DST) \
-    hipLaunchKernelGGL((k_locate_fill_runs2<PT, OUT, STS, SB>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, DST, sub, perm, skeys, stats)
+    do { \
+        if (sizeof(PT) == 8 && hi8) hipLaunchKernelGGL((k_locate_fill_runs2<PT, OUT, STS, SB, sizeof(PT) == 8>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, DST, sub, perm, skeys, stats); \
+        else hipLaunchKernelGGL((k_locate_fill_runs2<PT, OUT, STS, SB, false>), grid, block, 0, st, ix, lo, hi, k, N, max_hits, loc_off, DST, sub, perm, skeys, stats); \
+    } while (0)
     if (locs32) {
         if (ix.pos_bytes != 4) return static_cast<int>(hipErrorInvalidValue);
         RBG_LAUNCH_LFR2(uint32_t, uint32_t, false, false, locs32);

@@ -8,6 +8,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <cstdlib>
 #include <mutex>
 #include <set>
 #include <utility>
@@ -250,56 +251,99 @@ __device__ __forceinline__ void wave_lds_sync() {
 //   val    the values of the round as 32-bit words, a row of CH * (sizeof(P) / 4) + 1 per lane (the odd row length spreads the owners' column
 //          writes and the flush's row reads over the banks; an 8-byte position travels as two words so that the pad stays four bytes);
 //   dst    where the read's locations start (8 bytes: 3.5e9 locations per batch at pangenome scale);
-//   cnt    how many values of THIS round are the read's (one byte, rewritten per round) instead of the 8-byte count;
+//   bounds which columns of THIS round's window are the read's (two bytes, rewritten per round) instead of the 8-byte count;
 //   minus  locate_from_longest_seed's subtrahend (rowbowt.hpp:681-683): in the SUB instantiation only.
 // = 19.3 KB: eight workgroups per CU, eight waves per SIMD (the kernels stay within 64 VGPRs).  profiles/r06_k3_lean_ab.txt: K3 at 8-byte positions
 // -4 to -8 % (r = 1.2e8: 11.2-11.6 -> 10.3-11.1 ms per 10 M x 150 bp), level at 4-byte positions (there the location buffer's placement decides).
 // The first location of a chain is the toehold itself, a text position except when it wrapped below zero (LF_w_loc, rowbowt.hpp:561: k - 1 at
 // text position 0): at 4-byte positions such a value is staged as the all-ones word -- no position of such an index --, the flush skips it and
 // the owner stores that one location itself (chain_first_off_text).
-template <typename P, int CH, bool SUB>
+// FLUSH WINDOWS ON BOUNDARIES OF THE OUTPUT ARRAY (RING; round 6, second half).  A scattered store's cost depends on its alignment by a factor of
+// three (tools/scatter_width.hip, profiles/r06_scatter_width.txt: a 128-byte segment wherever a read's locations start 1.19 TB/s, on a 64-byte boundary
+// 2.9; a 64-byte segment 0.85 against 2.89).  Aligning by making a lane WAIT before its first step lost twice (it breaks the phase of the walk).  Here
+// nobody waits: step t of a chain is staged at VIRTUAL column v = a + t, a = (index of the read's first location in the output array) mod CH, in a ring of
+// 2 CH columns; after the round of steps [t0, t0 + CH) every lane has produced all v < t0 + CH, so the WINDOW v in [t0, t0 + CH) is flushed -- it lies on
+// a CH-element boundary of the output array for every read -- and the a values beyond it wait in the ring for the next flush.  Per lane and round the
+// flushing lanes need the window's bounds, two bytes, instead of a count.
+// 8-byte positions below 2^40 (HI8: every index built so far -- n = 3.0e11 at r = 1.07e9 is 2^38.1) stage a value as its low word + ONE high byte: 24 KB per
+// workgroup with the ring, six waves per SIMD, where whole 8-byte values take 36 KB (four waves).
+template <typename P, int CH, bool SUB, bool RING = true, bool HI8 = false>
 struct ChainStage {
     static_assert(CH == 8 || CH == 16, "a flush pass serves 64 / CH reads");
-    static constexpr int W = sizeof(P) / 4, ROW = CH * W + 1;
+    static_assert(!HI8 || sizeof(P) == 8, "the high byte belongs to 8-byte positions");
+    static constexpr int W = (sizeof(P) == 8 && !HI8) ? 2 : 1, COLS = RING ? 2 * CH : CH, ROW = COLS * W + 1;
+    static constexpr bool kSentinel = sizeof(P) == 4 || HI8;   // a first location outside the text travels as all ones (else it is staged whole)
     uint32_t val[4][kWave][ROW];
-    uint64_t dst[4][kWave];
+    uint64_t dst[4][kWave];                       // the read's first location, minus a: where virtual column 0 would land
     uint64_t minus[SUB ? 4 : 1][SUB ? kWave : 1];
-    uint8_t cnt[4][kWave];
+    uint16_t bounds[4][kWave];                    // lo | hi << 8: the window's columns [lo, hi) are the read's (rewritten per round)
+    uint8_t hi[HI8 ? 4 : 1][HI8 ? kWave : 1][HI8 ? COLS + 1 : 1];
 };
-// the read's share of the round that starts at step t0 (the walk and the flushing lanes count in 32 bits)
+// waves per SIMD the staging's LDS leaves room for (256-thread workgroups, 160 KB per CU): the kernels' launch bound
+template <typename ST>
+constexpr int chain_stage_waves() {
+    constexpr int fit = static_cast<int>(160 * 1024 / sizeof(ST));
+    return fit > 8 ? 8 : fit;
+}
+// the read's share of the round of steps [t0, t0 + CH) (the walk counts in 32 bits)
 template <int CH>
 __device__ __forceinline__ uint32_t chain_round_count(const uint64_t occ, const uint64_t t0) {
     return occ > t0 ? static_cast<uint32_t>(occ - t0 < static_cast<uint64_t>(CH) ? occ - t0 : CH) : 0u;
 }
-template <typename P, int CH, bool SUB>
-__device__ __forceinline__ void chain_put(ChainStage<P, CH, SUB> &S, const int wv, const int lane, const int e, const uint64_t v, const bool off_text) {
+// the read's share of the WINDOW [t0, t0 + CH) of virtual columns: [max(a, t0), min(a + occ, t0 + CH)) relative to t0, as lo | hi << 8
+template <int CH>
+__device__ __forceinline__ uint16_t chain_window_bounds(const uint64_t occ, const uint32_t a, const uint64_t t0) {
+    const uint64_t end = occ + a;                 // (occ == 0: a == 0, an empty window)
+    const uint32_t lo = a > t0 ? (a - t0 < static_cast<uint64_t>(CH) ? static_cast<uint32_t>(a - t0) : CH) : 0u;
+    const uint32_t hi = end > t0 ? (end - t0 < static_cast<uint64_t>(CH) ? static_cast<uint32_t>(end - t0) : CH) : 0u;
+    return static_cast<uint16_t>(lo | (hi << 8));
+}
+// stage the value of virtual column v (= a + t); off_text: the value is no text position (only a chain's first can be: ChainStage::kSentinel forms)
+template <typename P, int CH, bool SUB, bool RING, bool HI8>
+__device__ __forceinline__ void chain_put(ChainStage<P, CH, SUB, RING, HI8> &S, const int wv, const int lane, const uint32_t v, const uint64_t x, const bool off_text) {
+    const uint32_t c = v & (ChainStage<P, CH, SUB, RING, HI8>::COLS - 1);
     if (sizeof(P) == 4) {
-        S.val[wv][lane][e] = off_text ? 0xFFFFFFFFu : static_cast<uint32_t>(v);
+        S.val[wv][lane][c] = off_text ? 0xFFFFFFFFu : static_cast<uint32_t>(x);
+    } else if (HI8) {
+        S.val[wv][lane][c] = off_text ? 0xFFFFFFFFu : static_cast<uint32_t>(x);
+        S.hi[wv][lane][c] = off_text ? uint8_t(0xFF) : static_cast<uint8_t>(x >> 32);
     } else {
-        S.val[wv][lane][2 * e] = static_cast<uint32_t>(v);
-        S.val[wv][lane][2 * e + 1] = static_cast<uint32_t>(v >> 32);
+        S.val[wv][lane][2 * c] = static_cast<uint32_t>(x);
+        S.val[wv][lane][2 * c + 1] = static_cast<uint32_t>(x >> 32);
     }
 }
-// after wave_lds_sync(): CH lanes per read, 64 / CH reads per pass; `locs[dst + t0 + e] = value - minus` for the values the round holds
-template <typename P, int CH, bool SUB, typename OUT>
-__device__ __forceinline__ void chain_flush(const ChainStage<P, CH, SUB> &S, const int wv, const int lane, const uint64_t t0, OUT *__restrict__ locs) {
+// after wave_lds_sync(): CH lanes per read, 64 / CH reads per pass; `locs[dst + t0 + e] = value - minus` for the columns [lo, hi) of the window at t0
+template <typename P, int CH, bool SUB, bool RING, bool HI8, typename OUT>
+__device__ __forceinline__ void chain_flush(const ChainStage<P, CH, SUB, RING, HI8> &S, const int wv, const int lane, const uint64_t t0, OUT *__restrict__ locs) {
     constexpr int G = kWave / CH;
+    const uint32_t c0 = static_cast<uint32_t>(t0) & (ChainStage<P, CH, SUB, RING, HI8>::COLS - 1);   // (t0 is a multiple of CH: 0 or CH in the ring)
 #pragma unroll
     for (int pass = 0; pass < CH; ++pass) {
         const int s = pass * G + lane / CH;
-        const int e = lane & (CH - 1);
-        if (static_cast<uint32_t>(e) < S.cnt[wv][s]) {
+        const uint32_t e = lane & (CH - 1);
+        const uint32_t bd = S.bounds[wv][s];
+        if (e >= (bd & 0xFFu) && e < (bd >> 8)) {
             uint64_t x;
             if (sizeof(P) == 4) {
-                const uint32_t x32 = S.val[wv][s][e];
+                const uint32_t x32 = S.val[wv][s][c0 + e];
                 if (x32 == 0xFFFFFFFFu) continue;   // a first location outside the text: its owner stored it
                 x = x32;
+            } else if (HI8) {
+                const uint32_t x32 = S.val[wv][s][c0 + e], h = S.hi[wv][s][c0 + e];
+                if (x32 == 0xFFFFFFFFu && h == 0xFFu) continue;
+                x = static_cast<uint64_t>(x32) | (static_cast<uint64_t>(h) << 32);
             } else {
-                x = static_cast<uint64_t>(S.val[wv][s][2 * e]) | (static_cast<uint64_t>(S.val[wv][s][2 * e + 1]) << 32);
+                x = static_cast<uint64_t>(S.val[wv][s][2 * (c0 + e)]) | (static_cast<uint64_t>(S.val[wv][s][2 * (c0 + e) + 1]) << 32);
             }
             locs[S.dst[wv][s] + t0 + e] = static_cast<OUT>(x - (SUB ? S.minus[wv][s] : uint64_t(0)));
         }
     }
+}
+// positions below this fit the HI8 staging with the all-ones value to spare
+constexpr uint64_t kChainHi8Limit = (uint64_t(1) << 40) - 16;
+inline bool chain_hi8_enabled() {
+    static const bool on = [] { const char *e = std::getenv("RBG_K3_HI8"); return !(e && e[0] == '0'); }();
+    return on;
 }
 
 // ---- the marker query: MarkerArray::at_range(lo, hi) (rowbowt.hpp:272-290, :318, :437-441) as {src, cnt}: the values mk_vals[src, src + cnt) of all runs with

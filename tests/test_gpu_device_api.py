@@ -147,15 +147,27 @@ def test_locate_chains_in_locus_order(synth, layout, phi, pos_bytes, monkeypatch
 
 
 @pytest.mark.parametrize("layout,phi", [(capi.LAYOUT_SLOTS, 0), (capi.LAYOUT_RUNS, 2), (capi.LAYOUT_RUNS, 1)])
-@pytest.mark.parametrize("pos_bytes", [4, 8])
-def test_k3_staging_at_its_edges(synth, layout, phi, pos_bytes):
-    """K3's staging (rbg_device.hpp ChainStage, round 6: values at the position width, a one-byte count per round, the first location of a chain
-    that is no text position stored by its owner): chains cut by max_hits at, just below and just above the flush rounds of 8 and 16 steps;
+@pytest.mark.parametrize("pos_bytes", [4, 8, -8])
+def test_k3_staging_at_its_edges(synth, layout, phi, pos_bytes, monkeypatch):
+    """K3's staging (rbg_device.hpp ChainStage, round 6: values at the position width -- 8-byte positions below 2^40 as a low word + one high byte, or whole
+    (pos_bytes -8) --, flush WINDOWS on 64-byte boundaries of the output array taken from a ring, the first location of a chain that is no text position
+    stored by its owner): chains cut by max_hits at, just below and just above the rounds of 8 steps, at every alignment of a read's first location;
     toeholds that wrapped below zero by one AND by two (LF_w_loc's k - 1, rowbowt.hpp:561, once or twice past text position 0 -- at 4-byte
     positions the staged word for them is all ones, whatever the value) on chains of several locations; the ordered and the unordered walk;
     64-bit locations against the oracle (toehold_sa.hpp:37-49), 32-bit ones = their low words, nothing written outside a read's segment."""
+    import subprocess
     import torch
     S = synth
+    if pos_bytes < 0:
+        # 8-byte positions staged WHOLE (what an index of 2^40 positions or more gets; below that a value travels as its low word + one high byte): the switch is read
+        # once per process, so this case runs in a child
+        if os.environ.get("RBG_K3_HI8") != "0":
+            env = dict(os.environ, RBG_K3_HI8="0")
+            r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", f"{__file__}::test_k3_staging_at_its_edges[-8-{layout}-{phi}]"], env=env,
+                               capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+            return
+        pos_bytes = 8
     with capi.default_option(capi.OPT_RANK_LAYOUT, layout), capi.default_option(capi.OPT_RUN_PHI, phi), capi.default_option(capi.OPT_POS_BYTES, pos_bytes):
         rb = ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0)
     o = orc.Oracle.from_runs(S.heads, S.lens, S.ssa, S.esa)
