@@ -347,7 +347,8 @@ size_t rbg_locate_order_ws_bytes(uint64_t N);
 int rbg_locate_order_dev(rbg_index *, const uint64_t *d_k, uint64_t N, void *d_ws, size_t ws_bytes, void *stream);
 /* d_order: the workspace prepared by rbg_locate_order_dev for the same d_k, or NULL (input order).
  * With d_order the walk takes each read's toehold from the workspace (it travelled with the sort) and
- * its count from d_loc_off (rbg_locate_plan_dev with the same max_hits): d_lo/d_hi/d_k are then not read. */
+ * its count from d_loc_off (rbg_locate_plan_dev with the same max_hits): d_lo/d_hi/d_k are then not read.
+ * d_locs needs 8-byte alignment only: the walk stores whole 64-byte windows of the array wherever it starts. */
 int rbg_locate_fill_dev(rbg_index *, const uint64_t *d_lo, const uint64_t *d_hi, const uint64_t *d_k, uint64_t N,
                         uint64_t max_hits, const uint64_t *d_loc_off, uint64_t *d_locs, const void *d_order, void *stream);
 /* locate_fill with a per-read value subtracted from every location (d_sub nullable): the

@@ -105,9 +105,10 @@ __device__ __forceinline__ uint64_t phi_step(const DevIndex &ix, uint64_t i, boo
 }
 
 // One lane walks one read's phi chain (toehold_sa.hpp:37-49); the chain is serial, the reads are not.  The values are staged per wave in LDS,
-// kChunk steps at a time, and flushed with kChunk lanes writing one read's segment (rbg_device.hpp ChainStage: what is staged, why, and what it
-// costs in LDS).  Measured per 10M reads: unordered chains 10.5 / 8.6 / 7.6 ms at kChunk 8 / 16 / 32; with the chains in toehold order (the
-// default) 3.5 / 3.1 / 3.5 ms, hence 16 at 4-byte positions; at 8-byte positions 8 (RBG_K3_CHUNK_U64: 16 costs half the workgroups their LDS).
+// kChunk steps at a time, and flushed as WINDOWS of kChunk locations on boundaries of the output array, kChunk lanes per read (rbg_device.hpp
+// ChainStage: what is staged, why, and what it costs in LDS).  Eight steps = 64-byte windows at both position widths since the windows are
+// aligned (profiles/r06_k3_ring_ab.txt); with unaligned segments sixteen steps were better at 4-byte positions (3.5 / 3.1 / 3.5 ms per 10 M
+// reads at 8 / 16 / 32, round 3) -- a 64-byte store on a 64-byte boundary runs at 2.9 TB/s, a 128-byte one wherever it falls at 1.2.
 #ifndef RBG_K3_CHUNK_U32
 #define RBG_K3_CHUNK_U32 8
 #endif

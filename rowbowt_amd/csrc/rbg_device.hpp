@@ -253,11 +253,11 @@ __device__ __forceinline__ void wave_lds_sync() {
 //   dst    where the read's locations start (8 bytes: 3.5e9 locations per batch at pangenome scale);
 //   bounds which columns of THIS round's window are the read's (two bytes, rewritten per round) instead of the 8-byte count;
 //   minus  locate_from_longest_seed's subtrahend (rowbowt.hpp:681-683): in the SUB instantiation only.
-// = 19.3 KB: eight workgroups per CU, eight waves per SIMD (the kernels stay within 64 VGPRs).  profiles/r06_k3_lean_ab.txt: K3 at 8-byte positions
-// -4 to -8 % (r = 1.2e8: 11.2-11.6 -> 10.3-11.1 ms per 10 M x 150 bp), level at 4-byte positions (there the location buffer's placement decides).
+// = 19.3 KB (20.0 with the ring below): eight workgroups per CU, eight waves per SIMD (the kernels stay within 64 VGPRs).  profiles/r06_k3_lean_ab.txt:
+// K3 -10 % at r = 1.2e8 (9.9-10.3 -> 8.9-9.2 ms per 10 M x 150 bp), -2.4 % on the bench index.
 // The first location of a chain is the toehold itself, a text position except when it wrapped below zero (LF_w_loc, rowbowt.hpp:561: k - 1 at
 // text position 0): at 4-byte positions such a value is staged as the all-ones word -- no position of such an index --, the flush skips it and
-// the owner stores that one location itself (chain_first_off_text).
+// the owner stores that one location itself (ChainStage::kSentinel; the high-byte form of 8-byte positions does the same).
 // FLUSH WINDOWS ON BOUNDARIES OF THE OUTPUT ARRAY (RING; round 6, second half).  A scattered store's cost depends on its alignment by a factor of
 // three (tools/scatter_width.hip, profiles/r06_scatter_width.txt: a 128-byte segment wherever a read's locations start 1.19 TB/s, on a 64-byte boundary
 // 2.9; a 64-byte segment 0.85 against 2.89).  Aligning by making a lane WAIT before its first step lost twice (it breaks the phase of the walk).  Here
