@@ -871,7 +871,7 @@ def run():
                           # what the load's budget rules decided (rbg_layout_info; tools/layout_rules_table.py makes DESIGN.md 2c's table from these)
                           **({"layout_info": {"budget_raised": int(li.budget_raised), "depths_kept": [d_ + 1 for d_ in range(8) if int(li.depth_mask_kept) >> d_ & 1],
                                               "depths_with_records": [d_ + 1 for d_ in range(8) if int(li.rec_bytes[d_])], "depths_dropped_budget": int(li.depths_dropped_budget),
-                                              "entries": [int(x) for x in li.entries], "rec_bytes": [int(x) for x in li.rec_bytes],
+                                              "entries": [int(x) for x in li.entries], "rec_bytes": [int(x) for x in li.rec_bytes], "rec_overflow": [int(x) for x in li.rec_overflow],
                                               "phi_slots": int(li.phi_slots), "phi_slot_bytes": int(li.phi_slot_bytes), "phi_entries": int(li.phi_entries),
                                               "rank_directories": int(li.rank_directories), "phi_directory": int(li.phi_directory)}} if li else {})},
                 "reads_per_gpu": N, "read_len": m, "substituted_fraction": 0.1,

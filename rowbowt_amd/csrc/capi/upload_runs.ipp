@@ -261,30 +261,95 @@ int upload_tables_runs2(rbg_index *ix) {
         ix->dev.run_rec2[d] = nullptr;
         const bool use_recs = rec_per[d] > 0;
         const double rec_target = rec_per[d];
+        if (d == 0) { ix->dev.run_uni_depth = static_cast<uint32_t>(kMaxRunDepth); ix->dev.run_uni_stride = ix->dev.run_uni_shift = 0; }
         if (use_recs) {
             // the records' buckets: the widest with at most rec_target entries starting inside on average
-            for (size_t t = 0; t < T.size(); ++t) {
+            auto widest = [&](double runs) {
                 uint32_t sh = 0;
-                const double runs = static_cast<double>(std::max<uint64_t>(1, nr[t]));
+                runs = std::max(1.0, runs);
                 while (sh < max_shift && runs * static_cast<double>(uint64_t(2) << sh) <= rec_target * static_cast<double>(h.n)) ++sh;
-                dshift[t] = sh;
-                doff[t + 1] = doff[t] + (h.n >> sh) + 2;
+                return sh;
+            };
+            for (size_t t = 0; t < T.size(); ++t) {
+                dshift[t] = widest(static_cast<double>(nr[t]));
+                doff[t + 1] = doff[t] + (h.n >> dshift[t]) + 2;
+            }
+            // UNIFORM geometry (DevIndex::run_uni) for a depth whose hot words a step would read from global memory: one shift -- the widest for the
+            // depth's AVERAGE table -- and one record count for every table, so that a step computes its table's hot word.  Taken when it costs no more
+            // than a tenth more records than the tables' own shifts, and kept when the buckets that then overflow their record (more than eleven entries:
+            // pivots + a scan of the run list) stay rare -- a depth with a few very frequent k-mers keeps per-table shifts.  RBG_RUN_UNIFORM=0 / 1: never /
+            // whenever the depth is deep enough (tests, A/B).
+            const int uni_env = [] { const char *e = std::getenv("RBG_RUN_UNIFORM"); return e ? std::atoi(e) : -1; }();   // (read per load: tests switch it)
+            bool uniform = false;
+            std::vector<uint32_t> own_shift = dshift;
+            std::vector<uint64_t> own_off = doff;
+            bool deepest = true;   // (one uniform depth: the deepest kept one with records -- DevIndex::run_uni_*)
+            for (uint32_t d2 = d + 1; d2 < D; ++d2) deepest = deepest && !((mask >> d2 & 1u) && rec_per[d2] > 0);
+            if (deepest && d >= static_cast<uint32_t>(kLdsRunDepth) && uni_env != 0 && T.size() > 1) {
+                double total_runs = 0;
+                for (size_t t = 0; t < T.size(); ++t) total_runs += static_cast<double>(nr[t]);
+                const uint32_t su = widest(total_runs / static_cast<double>(T.size()));
+                const uint64_t stride = (h.n >> su) + 2;
+                if (!(stride >> 27) && su < 32 && tabs.size() + T.size() < (1u << 24) && (uni_env == 1 || static_cast<double>(stride) * static_cast<double>(T.size()) <= 1.1 * static_cast<double>(own_off[T.size()]))) {
+                    uniform = true;
+                    for (size_t t = 0; t < T.size(); ++t) { dshift[t] = su; doff[t + 1] = doff[t] + stride; }
+                }
             }
             void *recp = nullptr;
-            if ((rc = dev_reserve(ix, doff[T.size()] * sizeof(RunRec2) + 64, &recp))) return rc;
-            TmpDev tmp, ovf;
-            const size_t nt = T.size(), bytes = (3 * nt + 1) * 8 + nt * 4;
-            if ((rc = tmp.alloc(bytes)) || (rc = ovf.alloc(8))) return rc;
-            HIP_TRY(hipMemset(ovf.p, 0, 8));
-            uint64_t *t_first = tmp.as<uint64_t>(), *t_nr = t_first + nt, *t_doff = t_nr + nt;
-            uint32_t *t_sh = reinterpret_cast<uint32_t *>(t_doff + nt + 1);
-            HIP_TRY(hipMemcpy(t_first, first.data(), nt * 8, hipMemcpyHostToDevice));
-            HIP_TRY(hipMemcpy(t_nr, nr.data(), nt * 8, hipMemcpyHostToDevice));
-            HIP_TRY(hipMemcpy(t_doff, doff.data(), (nt + 1) * 8, hipMemcpyHostToDevice));
-            HIP_TRY(hipMemcpy(t_sh, dshift.data(), nt * 4, hipMemcpyHostToDevice));
-            HIP_TRY(static_cast<hipError_t>(launch_run_recs2(sizeof(P), abs_ent, t_first, t_nr, t_doff, t_sh, static_cast<uint32_t>(nt), doff[nt], recp, ovf.as<unsigned long long>(), nullptr)));
             unsigned long long novf = 0;
-            HIP_TRY(hipMemcpy(&novf, ovf.p, 8, hipMemcpyDeviceToHost));
+            // the depth's bucket records under the geometry (dshift, doff) as they stand: recp, novf
+            auto build_recs = [&]() -> int {
+                int rc2;
+                if ((rc2 = dev_reserve(ix, doff[T.size()] * sizeof(RunRec2) + 64, &recp))) return rc2;
+                TmpDev tmp, ovf;
+                const size_t nt = T.size(), bytes = (3 * nt + 1) * 8 + nt * 4;
+                if ((rc2 = tmp.alloc(bytes)) || (rc2 = ovf.alloc(8))) return rc2;
+                HIP_TRY(hipMemset(ovf.p, 0, 8));
+                uint64_t *t_first = tmp.as<uint64_t>(), *t_nr = t_first + nt, *t_doff = t_nr + nt;
+                uint32_t *t_sh = reinterpret_cast<uint32_t *>(t_doff + nt + 1);
+                HIP_TRY(hipMemcpy(t_first, first.data(), nt * 8, hipMemcpyHostToDevice));
+                HIP_TRY(hipMemcpy(t_nr, nr.data(), nt * 8, hipMemcpyHostToDevice));
+                HIP_TRY(hipMemcpy(t_doff, doff.data(), (nt + 1) * 8, hipMemcpyHostToDevice));
+                HIP_TRY(hipMemcpy(t_sh, dshift.data(), nt * 4, hipMemcpyHostToDevice));
+                HIP_TRY(static_cast<hipError_t>(launch_run_recs2(sizeof(P), abs_ent, t_first, t_nr, t_doff, t_sh, static_cast<uint32_t>(nt), doff[nt], recp, ovf.as<unsigned long long>(), nullptr)));
+                HIP_TRY(hipMemcpy(&novf, ovf.p, 8, hipMemcpyDeviceToHost));
+                return 0;
+            };
+            if ((rc = build_recs())) return rc;
+            // Overflowing records (more than eleven entries: pivots + a scan of the run list, two or three sectors instead of one) come from how a locus's runs
+            // cluster, whatever the geometry: on the bench index 4.9 % of the uniform depth-8 records against 4.7 % under the tables' own shifts.  So a uniform
+            // depth with MANY of them is measured against the tables' own shifts, not against zero: it stays when it overflows at most a quarter more often.
+            if (uniform && uni_env != 1 && static_cast<double>(novf) * 256.0 > static_cast<double>(doff[T.size()])) {
+                const std::vector<uint32_t> uni_shift = dshift;
+                const std::vector<uint64_t> uni_off = doff;
+                const unsigned long long novf_uni = novf;
+                free_tracked(ix, recp);
+                recp = nullptr;
+                dshift = own_shift;
+                doff = own_off;
+                if ((rc = build_recs())) return rc;
+                const unsigned long long novf_own = novf;
+                if (static_cast<double>(novf_uni) <= 1.25 * static_cast<double>(novf_own) + static_cast<double>(uni_off[T.size()]) / 256.0) {
+                    free_tracked(ix, recp);
+                    recp = nullptr;
+                    dshift = uni_shift;
+                    doff = uni_off;
+                    if ((rc = build_recs())) return rc;
+                } else {
+                    uniform = false;
+                    if (std::getenv("RBG_VERBOSE"))
+                        std::fprintf(stderr, "rbg:   depth %u: uniform directories would leave %llu records overflowing, the tables' own shifts %llu: the tables keep their own shifts\n",
+                                     d + 1, novf_uni, novf_own);
+                }
+            }
+            if (uniform) {
+                const uint64_t stride = doff[1] - doff[0];
+                if (stride >> 27) return RBG_EARG;   // (load_run_tab's packed constants: a 27-bit stride, a 5-bit shift, a 24-bit first record)
+                ix->dev.run_uni_depth = d; ix->dev.run_uni_stride = static_cast<uint32_t>(stride); ix->dev.run_uni_shift = dshift[0];
+                if (std::getenv("RBG_VERBOSE"))
+                    std::fprintf(stderr, "rbg:   depth %u: uniform directories (shift %u, %llu records per table, %llu of %llu overflowing): hot words computed\n", d + 1, dshift[0],
+                                 static_cast<unsigned long long>(stride), novf, static_cast<unsigned long long>(doff[T.size()]));
+            }
             ix->dev.run_rec2[d] = static_cast<const RunRec2 *>(recp);
             rep.rec_bytes[d] = doff[T.size()] * sizeof(RunRec2);
             rep.rec_overflow[d] = novf;

@@ -301,6 +301,14 @@ struct DevIndex {
     const void *run_dir2[kMaxRunDepth];     // uint32_t counts (4-byte positions) or RunDir64 (8-byte positions)
     const DevRunTab2 *run_tabs2;            // run_ntabs records, depth d's from run_tab_first[d - 1] (cold: `first` for scans and re-samples)
     const uint64_t *run_hot;                // run_ntabs words dir_off | dir_shift << 56: what a step reads of its table
+    // UNIFORM geometry of a depth beyond kLdsRunDepth (round 6, second half): every table of the depth has the same bucket shift and the same
+    // number of bucket records, so a step COMPUTES its table's hot word -- (table's ordinal in the depth) x stride | shift << 56 -- instead of reading it
+    // from the 512 KB global array: an L2-served scattered request costs a tenth of a miss (profiles/r06_gather_width.txt), and a search made one
+    // per step.  ONE depth can be uniform (the deepest kept one: where a search spends its steps), so that its three constants sit in scalar registers;
+    // run_uni_depth = kMaxRunDepth: none (every table has its own shift; the load decides: capi/upload_runs.ipp).
+    uint32_t run_uni_depth;                 // depth index d (k-mer depth d + 1) of the uniform depth
+    uint32_t run_uni_stride;                // bucket records per table there
+    uint32_t run_uni_shift;                 // the bucket shift of all its tables
     const RunRec2 *run_rec2[kMaxRunDepth];  // per depth: the tables' bucket records back to back (DevRunTab2::dir_off / dir_shift then address them); nullptr = directories
     const uint64_t *phi_super;              // 8-byte positions: full counts every 2^phi_super_shift buckets
     uint64_t phi_m;                         // entries of the phi list (fillers included); entry phi_m is the sentinel

@@ -14,6 +14,7 @@
 namespace rbg {
 namespace {
 
+constexpr int kRunUniAt = 12;          // s_tab_first[12..15]: the uniform depth's constants (kMaxRunDepth + 1 = 9 words of first records before them)
 constexpr uint32_t kLaneMaxZ = 15;     // candidates one scan covers (16 entries = two chunks of four 16-byte requests); more: narrowed first
 constexpr uint32_t kLanePhiMaxZ = 8;   // sampled positions one phi scan covers (two chunks of four entries)
 
@@ -31,7 +32,7 @@ struct RunSearch2 {
 };
 
 #define RBG_RUN_SEARCH2_SHARED                                            \
-    __shared__ uint32_t s_tab_first[kMaxRunDepth + 1];                    \
+    __shared__ __align__(16) uint32_t s_tab_first[kMaxRunDepth + 1 + 3 + 4];  \
     __shared__ const void *s_ent2[8];                                     \
     __shared__ const void *s_dir2[8];                                     \
     __shared__ const void *s_rec2[8];                                     \
@@ -50,10 +51,16 @@ __device__ __forceinline__ RunSearch2<P> stage_run_search2(const DevIndex &ix, u
         s_rec2[threadIdx.x] = threadIdx.x < static_cast<uint32_t>(kMaxRunDepth) ? static_cast<const void *>(ix.run_rec2[threadIdx.x]) : nullptr;
     }
     for (uint32_t t = threadIdx.x; t <= static_cast<uint32_t>(kMaxRunDepth); t += blockDim.x) s_tab_first[t] = ix.run_tab_first[t];
+    if (threadIdx.x == 0) {   // the uniform depth's constants (DevIndex::run_uni_*), one 8-byte LDS read per step: {first record | depth << 24, stride | shift << 27}
+        const bool on = ix.run_uni_depth < static_cast<uint32_t>(kMaxRunDepth);
+        s_tab_first[kRunUniAt] = (on ? ix.run_tab_first[ix.run_uni_depth] : 0u) | (on ? ix.run_uni_depth : 0xFFu) << 24;
+        s_tab_first[kRunUniAt + 1] = ix.run_uni_stride | ix.run_uni_shift << 27;
+    }
     for (uint32_t t = threadIdx.x; t < ix.run_tab_first[kLdsRunDepth]; t += blockDim.x) s_hot[t] = ix.run_hot[t];
     __syncthreads();
     RunSearch2<P> S;
-    S.hot = s_hot; S.ghot = ix.run_hot; S.gtab = ix.run_tabs2; S.tab_first = s_tab_first; S.ent = s_ent2; S.dir = s_dir2; S.rec = s_rec2;
+    S.hot = s_hot; S.ghot = ix.run_hot;
+ S.gtab = ix.run_tabs2; S.tab_first = s_tab_first; S.ent = s_ent2; S.dir = s_dir2; S.rec = s_rec2;
     S.fill = ix.run_fill_shift;
     S.rec_any = nullptr;
     for (int t = kMaxRunDepth - 1; t >= 0; --t)
@@ -68,7 +75,14 @@ struct RunHot {
 };
 template <typename P>
 __device__ __forceinline__ RunHot load_run_tab(const RunSearch2<P> &S, const uint32_t d, const uint32_t rec) {
-    const uint64_t w = d < static_cast<uint32_t>(kLdsRunDepth) ? S.hot[rec] : as_global<uint64_t>(S.ghot)[rec];
+    // uniform geometry (DevIndex::run_uni_*): the table's ordinal in its depth x the depth's stride, one 32 x 32 -> 64 bit multiply, no memory request
+    // uniform geometry (DevIndex::run_uni_*): the table's ordinal in its depth x the depth's stride, one 32 x 32 -> 64 bit multiply.  Branch-free: the lanes
+    // of the uniform depth all name the depth's FIRST hot word (one request for the wave instead of one per lane) and replace what it returns.
+    const uint2 u = *reinterpret_cast<const uint2 *>(S.tab_first + kRunUniAt);   // {first record | depth << 24, stride | shift << 27}
+    const bool uni = d == (u.x >> 24);
+    const uint32_t first = u.x & 0xFFFFFFu;
+    const uint64_t w0 = d < static_cast<uint32_t>(kLdsRunDepth) ? S.hot[rec] : as_global<uint64_t>(S.ghot)[uni ? first : rec];
+    const uint64_t w = uni ? (static_cast<uint64_t>(rec - first) * (u.y & 0x7FFFFFFu)) | (static_cast<uint64_t>(u.y >> 27) << kRunHotShiftBit) : w0;
     return RunHot{w & ((uint64_t(1) << kRunHotShiftBit) - 1), static_cast<uint32_t>(w >> kRunHotShiftBit)};
 }
 // index of the table's first entry in its depth's arrays (cold: scans of the run list, re-samples)

@@ -91,6 +91,26 @@ def test_run_indexed_layout(synth, pos_bytes, fk, ks, mode, all_depths):
     _run_indexed_checks(S, rb)
 
 
+@pytest.mark.parametrize("uniform", ["0", "1"])
+@pytest.mark.parametrize("pos_bytes,ks,all_depths,rec_per", [(0, 8, False, None), (8, 8, False, "9"), (0, 6, True, None), (8, 7, False, None), (0, 8, True, "9")])
+def test_uniform_directories_of_the_deepest_depth(synth, uniform, pos_bytes, ks, all_depths, rec_per, monkeypatch):
+    """The deepest kept depth beyond the LDS-staged ones may get UNIFORM geometry (rbg_dev.h DevIndex::run_uni_*: one bucket shift and one record count for all of
+    its tables, so that a step computes its table's hot word instead of reading it from the global array).  RBG_RUN_UNIFORM=1 forces it -- also where the tables'
+    sizes differ and buckets overflow their records (rec_per 9: pivots, then the run list) --, =0 forbids it; the answers are the oracle's either way, on every
+    read shape of test_synth_all_paths, at both position widths, with the default depth set and with every depth kept."""
+    S = synth
+    monkeypatch.setenv("RBG_RUN_UNIFORM", uniform)
+    if rec_per:
+        monkeypatch.setenv("RBG_RUN_REC_PER", rec_per)
+    with capi.default_option(capi.OPT_RUN_PHI, 2), capi.default_option(capi.OPT_RUN_REC, 2), capi.default_option(capi.OPT_POS_BYTES, pos_bytes), \
+            capi.default_option(capi.OPT_KMER_STEPS, ks), capi.default_option(capi.OPT_RUN_DEPTHS, (1 << ks) - 1 if all_depths else 0):
+        rb = _with_layout(capi.LAYOUT_RUNS, lambda: ra.RowBowt.from_runs(S.heads, S.lens, S.ssa, S.esa, device=0))
+    info, li = rb.info(), rb.layout_info()
+    assert info.rank_layout == capi.LAYOUT_RUNS and info.kmer_steps == ks and li.rec_bytes[ks - 1] > 0 and li.rank_directories == 0
+    assert not rec_per or sum(li.rec_overflow) > 0
+    _run_indexed_checks(S, rb)
+
+
 def test_default_load_takes_eight_symbols_per_step_on_the_run_indexed_layout(synth):
     """RBG_OPT_KMER_STEPS defaults to 8 and RBG_OPT_RUN_DEPTHS to the halving rule: with nothing set but the layout, the replica has run
     lists for depths 1, 2, 4 and 8, steps by eight symbols, and answers like the oracle; RBG_LAYOUT_AUTO under a budget the slot tables
