@@ -369,7 +369,7 @@ __global__ __launch_bounds__(512, STATS ? 2 : 3) void k_greedy_seed_runs(const D
 // seed_ei, first marker, one past last marker}.
 // LOG / lg: the marker-seed log (rbg_dev.h SeedLog), as in k_markers.hip k_marker_seeds
 template <typename P, bool FILL, bool LOG, bool STATS = false>
-__global__ __launch_bounds__(512, STATS ? 2 : 3) void k_marker_seeds_runs(const DevIndex ix, const uint8_t *__restrict__ seqs,
+__global__ __launch_bounds__(512, STATS ? 2 : 4) void k_marker_seeds_runs(const DevIndex ix, const uint8_t *__restrict__ seqs,
                                                       const uint64_t *__restrict__ off, const uint64_t N,
                                                       const uint64_t wsize, const uint64_t max_range,
                                                       uint64_t *__restrict__ seed_cnt, uint64_t *__restrict__ mk_cnt,
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(512, STATS ? 2 : 3) void k_marker_seeds_runs(const 
 // build_ftab(K) makes for this index is find_range of an ACGT-only k-mer: K symbols from the full range, taken as k-mer
 // steps through the depths' run lists; every other step of the loop is a single symbol, as in the reference.
 template <typename P, bool FILL, bool LOG>
-__global__ __launch_bounds__(512, 3) void k_marker_seeds_ftab_runs2(const DevIndex ix, const uint8_t *__restrict__ seqs, const uint64_t *__restrict__ off,
+__global__ __launch_bounds__(512, sizeof(P) == 8 ? 3 : 4) void k_marker_seeds_ftab_runs2(const DevIndex ix, const uint8_t *__restrict__ seqs, const uint64_t *__restrict__ off,
                                                                     const uint64_t N, const uint64_t wsize, const uint64_t max_range, const uint64_t K,
                                                                     uint64_t *__restrict__ seed_cnt, uint64_t *__restrict__ mk_cnt,
                                                                     const uint64_t *__restrict__ seed_off, const uint64_t *__restrict__ mk_off,
